@@ -1,0 +1,857 @@
+/*
+ * oracle/fundsp_oracle.c -- TEST INFRASTRUCTURE ONLY.  CPU restatement ("oracle") of the FunDSP hot path:
+ * AudioNode::tick / AudioNode::process of the leaf DSP nodes plus the minimal combinator / executor glue the
+ * BASELINE configs need.  It is the checker for the HIP engine; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product library (fundsp_amd/csrc) never includes or links it.
+ *
+ * Reference: SamiPerttu/fundsp 0.23.0 mounted at /root/reference.  Every function cites the reference
+ * file:line it restates.  The reference cannot be compiled in this image (no rustc/cargo), so parity is
+ * pinned through the reference's own test invariants re-run against this file (tests/test_oracle_*.py):
+ * closed-form frequency responses (tests/test_flow.rs:18-80), tick == process to 1e-4
+ * (tests/test_basic.rs:21-92), exact delay/constant identities (tests/test_basic.rs:365-378,520-529).
+ * Transcendentals from the un-vendored `libm`/`wide` crates: see o_math.h ("parity unpinned" at bit level).
+ *
+ * Numeric contract: prelude32 (F = f32); no FMA contraction, no reassociation (build: -ffp-contract=off).
+ * Buffers are planar [channel][64] f32 exactly like BufferRef/BufferMut (src/buffer.rs:8-12).
+ */
+#include "fundsp_oracle.h"
+#include "o_math.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#define DEFAULT_SR 44100.0 /* src/lib.rs:42 */
+#define MAXB 64            /* MAX_BUFFER_SIZE src/lib.rs:48 */
+#define SIMD_N 8
+#define O_MAX_FIR 16
+#define O_MAX_CH 64
+
+static const float F32_PI = 3.14159274101257324f;  /* core::f32::consts::PI */
+static const float F32_TAU = 6.28318548202514648f; /* core::f32::consts::TAU */
+static const float F32_SQRT_2 = 1.41421353816986084f;
+
+typedef struct { float a1, a2, a3, m0, m1, m2; } svf_coefs;
+typedef struct { float a1, a2, b0, b1, b2; } bq_coefs;
+
+struct onode {
+    int type, nin, nout;
+    uint64_t id;
+    onode *x, *y;
+    float *tmp; /* [x->nout][64] scratch for Pipe / Binop (BufferArray::uninitialized, audionode.rs:1446) */
+    int op;
+    float scalar;
+    /* leaf state (one struct for all leaves keeps the oracle small; each leaf uses its own fields) */
+    struct {
+        float value[O_MAX_CH]; /* Constant */
+        /* Sine (oscillator.rs:21-26) */
+        float phase, sample_duration;
+        uint64_t hash;
+        int has_initial_phase;
+        float initial_phase;
+        /* Noise (noise.rs:173-177) */
+        uint32_t nstate;
+        int has_seed;
+        uint64_t seed;
+        /* Svf / FixedSvf (svf.rs:748-759, 861-871) */
+        int mode;
+        float sr, cutoff, q, gain;
+        svf_coefs sc;
+        float ic1eq, ic2eq;
+        /* Biquad family (biquad.rs:136-143) ; BiquadBank uses the [8] arrays (biquad_bank.rs:14-24) */
+        bq_coefs bc;
+        float x1, x2, y1, y2;
+        double sr64;
+        float center;
+        bq_coefs bank_c[8];
+        float bx1[8], bx2[8], by1[8], by2[8];
+        /* Moog (moog.rs:17-33) */
+        float rez, p, k, s0, s1, s2, s3, px, ps0, ps1, ps2;
+        /* Fir (fir.rs:14-18) */
+        int fir_n;
+        float w[O_MAX_FIR], v[O_MAX_FIR];
+        /* Tick (delay.rs:19-22) */
+        float tickbuf[O_MAX_CH];
+        /* Delay (delay.rs:72-78) */
+        float *dbuf;
+        size_t dlen, di, time_in_samples;
+        double dtime, dsr;
+    } s;
+};
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* helpers                                                                                                */
+/* ------------------------------------------------------------------------------------------------------ */
+static onode *o_new(int type, int nin, int nout, uint64_t id) {
+    onode *n = (onode *)calloc(1, sizeof(onode));
+    n->type = type;
+    n->nin = nin;
+    n->nout = nout;
+    n->id = id;
+    return n;
+}
+
+int o_inputs(const onode *n) { return n->nin; }
+int o_outputs(const onode *n) { return n->nout; }
+
+void o_free(onode *n) {
+    if (!n) return;
+    o_free(n->x);
+    o_free(n->y);
+    free(n->tmp);
+    free(n->s.dbuf);
+    free(n);
+}
+
+/* exported scalar math for the math unit tests */
+float o_math_sinf(float x) { return o_sinf(x); }
+float o_math_cosf(float x) { return o_cosf(x); }
+float o_math_tanf(float x) { return o_tanf(x); }
+float o_math_tanhf(float x) { return o_tanhf(x); }
+float o_math_expf(float x) { return o_expf(x); }
+float o_math_expm1f(float x) { return o_expm1f(x); }
+float o_math_wide_sinf(float x) { return o_wide_sinf(x); }
+double o_math_rnd1(uint64_t x) { return o_rnd1(x); }
+uint64_t o_math_hash1(uint64_t x) { return o_hash1(x); }
+uint64_t o_math_atto(uint64_t state, uint64_t data) { return o_atto(state, data); }
+uint32_t o_math_hash32x(uint32_t x) { return o_hash32x(x); }
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* coefficient constructors                                                                               */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/* SvfCoefs::{lowpass..highshelf} src/svf.rs:28-221.  g = tan((PI*cutoff)/sample_rate) in f32. */
+static svf_coefs svf_make(int mode, float sr, float cutoff, float q, float gain) {
+    svf_coefs c;
+    float g, k, a;
+    switch (mode) {
+    case O_SVF_BELL: /* svf.rs:155-174 */
+        a = sqrtf(gain);
+        g = o_tanf(F32_PI * cutoff / sr);
+        k = 1.0f / (q * a);
+        break;
+    case O_SVF_LOWSHELF: /* svf.rs:178-197 */
+        a = sqrtf(gain);
+        g = o_tanf(F32_PI * cutoff / sr) / sqrtf(a);
+        k = 1.0f / q;
+        break;
+    case O_SVF_HIGHSHELF: /* svf.rs:201-220 */
+        a = sqrtf(gain);
+        g = o_tanf(F32_PI * cutoff / sr) * sqrtf(a);
+        k = 1.0f / q;
+        break;
+    default: /* svf.rs:28-151 */
+        a = 0.0f;
+        g = o_tanf(F32_PI * cutoff / sr);
+        k = 1.0f / q;
+        break;
+    }
+    c.a1 = 1.0f / (1.0f + g * (g + k));
+    c.a2 = g * c.a1;
+    c.a3 = g * c.a2;
+    switch (mode) {
+    case O_SVF_LOWPASS: c.m0 = 0.0f; c.m1 = 0.0f; c.m2 = 1.0f; break;
+    case O_SVF_HIGHPASS: c.m0 = 1.0f; c.m1 = -k; c.m2 = -1.0f; break;
+    case O_SVF_BANDPASS: c.m0 = 0.0f; c.m1 = 1.0f; c.m2 = 0.0f; break;
+    case O_SVF_NOTCH: c.m0 = 1.0f; c.m1 = -k; c.m2 = 0.0f; break;
+    case O_SVF_PEAK: c.m0 = 1.0f; c.m1 = -k; c.m2 = -2.0f; break;
+    case O_SVF_ALLPASS: c.m0 = 1.0f; c.m1 = -2.0f * k; c.m2 = 0.0f; break;
+    case O_SVF_BELL: c.m0 = 1.0f; c.m1 = k * (a * a - 1.0f); c.m2 = 0.0f; break;
+    case O_SVF_LOWSHELF: c.m0 = 1.0f; c.m1 = k * (a - 1.0f); c.m2 = a * a - 1.0f; break;
+    default: /* HIGHSHELF */ c.m0 = a * a; c.m1 = k * (1.0f - a) * a; c.m2 = 1.0f - a * a; break;
+    }
+    return c;
+}
+
+/* BiquadCoefs::butter_lowpass src/biquad.rs:30-41 */
+static bq_coefs bq_butter_lowpass(float sr, float cutoff) {
+    bq_coefs c;
+    float f = o_tanf(cutoff * F32_PI / sr);
+    float a0r = 1.0f / (1.0f + F32_SQRT_2 * f + f * f);
+    c.a1 = (2.0f * f * f - 2.0f) * a0r;
+    c.a2 = (1.0f - F32_SQRT_2 * f + f * f) * a0r;
+    c.b0 = f * f * a0r;
+    c.b1 = 2.0f * c.b0;
+    c.b2 = c.b0;
+    return c;
+}
+/* BiquadCoefs::resonator src/biquad.rs:45-54 */
+static bq_coefs bq_resonator(float sr, float center, float q) {
+    bq_coefs c;
+    float r = o_expf(-F32_PI * center / (q * sr));
+    c.a1 = -2.0f * r * o_cosf(F32_TAU * center / sr);
+    c.a2 = r * r;
+    c.b0 = sqrtf(1.0f - r * r) * 0.5f;
+    c.b1 = 0.0f;
+    c.b2 = -c.b0;
+    return c;
+}
+/* BiquadCoefs::lowpass src/biquad.rs:58-71 */
+static bq_coefs bq_lowpass(float sr, float cutoff, float q) {
+    bq_coefs c;
+    float omega = F32_TAU * cutoff / sr;
+    float alpha = o_sinf(omega) / (2.0f * q);
+    float beta = o_cosf(omega);
+    float a0r = 1.0f / (1.0f + alpha);
+    c.a1 = -2.0f * beta * a0r;
+    c.a2 = (1.0f - alpha) * a0r;
+    c.b1 = (1.0f - beta) * a0r;
+    c.b0 = c.b1 * 0.5f;
+    c.b2 = c.b0;
+    return c;
+}
+/* BiquadCoefs::highpass src/biquad.rs:75-88 */
+static bq_coefs bq_highpass(float sr, float cutoff, float q) {
+    bq_coefs c;
+    float omega = F32_TAU * cutoff / sr;
+    float alpha = o_sinf(omega) / (2.0f * q);
+    float beta = o_cosf(omega);
+    float a0r = 1.0f / (1.0f + alpha);
+    c.a1 = -2.0f * beta * a0r;
+    c.a2 = (1.0f - alpha) * a0r;
+    c.b0 = (1.0f + beta) * 0.5f * a0r;
+    c.b1 = (-1.0f - beta) * a0r;
+    c.b2 = c.b0;
+    return c;
+}
+/* BiquadCoefs::bell src/biquad.rs:92-106 */
+static bq_coefs bq_bell(float sr, float center, float q, float gain) {
+    bq_coefs c;
+    float omega = F32_TAU * center / sr;
+    float alpha = o_sinf(omega) / (2.0f * q);
+    float beta = o_cosf(omega);
+    float a = sqrtf(gain);
+    float a0r = 1.0f / (1.0f + alpha / a);
+    c.a1 = -2.0f * beta * a0r;
+    c.a2 = (1.0f - alpha / a) * a0r;
+    c.b0 = (1.0f + alpha * a) * a0r;
+    c.b1 = c.a1;
+    c.b2 = (1.0f - alpha * a) * a0r;
+    return c;
+}
+
+void o_biquad_coefs(int kind, float sr, float f, float q, float gain, float *out5) {
+    bq_coefs c;
+    switch (kind) {
+    case O_BQ_BUTTER: c = bq_butter_lowpass(sr, f); break;
+    case O_BQ_RESONATOR: c = bq_resonator(sr, f, q); break;
+    case O_BQ_LOWPASS: c = bq_lowpass(sr, f, q); break;
+    case O_BQ_HIGHPASS: c = bq_highpass(sr, f, q); break;
+    default: c = bq_bell(sr, f, q, gain); break;
+    }
+    out5[0] = c.a1; out5[1] = c.a2; out5[2] = c.b0; out5[3] = c.b1; out5[4] = c.b2;
+}
+
+void o_svf_coefs(int mode, float sr, float cutoff, float q, float gain, float *out6) {
+    svf_coefs c = svf_make(mode, sr, cutoff, q, gain);
+    out6[0] = c.a1; out6[1] = c.a2; out6[2] = c.a3; out6[3] = c.m0; out6[4] = c.m1; out6[5] = c.m2;
+}
+
+/* Moog::set_cutoff_q src/moog.rs:48-57 */
+static void moog_set_cutoff_q(onode *n, float cutoff, float q) {
+    n->s.cutoff = cutoff;
+    n->s.q = q;
+    float c = 2.0f * cutoff / n->s.sr;
+    n->s.p = c * (1.8f - 0.8f * c);
+    n->s.k = 2.0f * o_sinf(c * F32_PI * 0.5f) - 1.0f;
+    float t1 = (1.0f - n->s.p) * 1.386249f;
+    float t2 = 12.0f + t1 * t1;
+    n->s.rez = q * (t2 + 6.0f * t1) / (t2 - 6.0f * t1);
+}
+
+void o_moog_coefs(float sr, float cutoff, float q, float *out3) {
+    onode tmp;
+    memset(&tmp, 0, sizeof tmp);
+    tmp.s.sr = sr;
+    moog_set_cutoff_q(&tmp, cutoff, q);
+    out3[0] = tmp.s.rez; out3[1] = tmp.s.p; out3[2] = tmp.s.k;
+}
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* reset / set_sample_rate / set_hash / ping                                                              */
+/* ------------------------------------------------------------------------------------------------------ */
+
+static void leaf_reset(onode *n) {
+    switch (n->type) {
+    case O_SINE: /* oscillator.rs:55-60 */
+        n->s.phase = n->s.has_initial_phase ? n->s.initial_phase : (float)o_rnd1(n->s.hash);
+        break;
+    case O_NOISE: { /* noise.rs:192-195 */
+        uint64_t h = n->s.has_seed ? n->s.seed : n->s.hash;
+        n->s.nstate = (uint32_t)(h ^ (h >> 32));
+        break;
+    }
+    case O_SVF:
+    case O_FIXED_SVF: /* svf.rs:818-821, 984-987 */
+        n->s.ic1eq = 0.0f;
+        n->s.ic2eq = 0.0f;
+        break;
+    case O_BIQUAD:
+    case O_BUTTER_LOWPASS:
+    case O_RESONATOR: /* biquad.rs:172-177 */
+        n->s.x1 = n->s.x2 = n->s.y1 = n->s.y2 = 0.0f;
+        break;
+    case O_BIQUAD_BANK: /* biquad_bank.rs:61-66 */
+        for (int i = 0; i < 8; i++) n->s.bx1[i] = n->s.bx2[i] = n->s.by1[i] = n->s.by2[i] = 0.0f;
+        break;
+    case O_MOOG: /* moog.rs:65-74 */
+        n->s.s0 = n->s.s1 = n->s.s2 = n->s.s3 = n->s.px = n->s.ps0 = n->s.ps1 = n->s.ps2 = 0.0f;
+        break;
+    case O_FIR: /* fir.rs:48-50 */
+        for (int i = 0; i < O_MAX_FIR; i++) n->s.v[i] = 0.0f;
+        break;
+    case O_TICK: /* delay.rs:39-41 */
+        for (int i = 0; i < O_MAX_CH; i++) n->s.tickbuf[i] = 0.0f;
+        break;
+    case O_DELAY: /* delay.rs:100-103 */
+        n->s.di = 0;
+        for (size_t i = 0; i < n->s.dlen; i++) n->s.dbuf[i] = 0.0f;
+        break;
+    default: break;
+    }
+}
+
+void o_reset(onode *n) {
+    if (n->x) o_reset(n->x); /* Pipe/Stack/Binop/Unop::reset audionode.rs:1430-1433 etc. */
+    if (n->y) o_reset(n->y);
+    leaf_reset(n);
+}
+
+static void leaf_set_sample_rate(onode *n, double sr) {
+    switch (n->type) {
+    case O_SINE: /* oscillator.rs:62-64: convert(1.0 / sample_rate) -- f64 divide then cast */
+        n->s.sample_duration = (float)(1.0 / sr);
+        break;
+    case O_SVF:
+    case O_FIXED_SVF: /* svf.rs:823-826, 989-992 -> SvfMode::update_frequency -> update (svf.rs:236-239) */
+        n->s.sr = (float)sr;
+        n->s.sc = svf_make(n->s.mode, n->s.sr, n->s.cutoff, n->s.q, n->s.gain);
+        break;
+    case O_BIQUAD: /* biquad.rs:179-181: coefficients are NOT recomputed */
+    case O_BIQUAD_BANK:
+    case O_FIR:
+    case O_TICK:
+        n->s.sr64 = sr;
+        break;
+    case O_BUTTER_LOWPASS: /* biquad.rs:263-267 */
+        n->s.sr = (float)sr;
+        n->s.sr64 = sr;
+        n->s.bc = bq_butter_lowpass(n->s.sr, n->s.cutoff);
+        break;
+    case O_RESONATOR: /* biquad.rs:349-352 */
+        n->s.sr = (float)sr;
+        n->s.bc = bq_resonator(n->s.sr, n->s.center, n->s.q);
+        break;
+    case O_MOOG: /* moog.rs:76-79 */
+        n->s.sr = (float)sr;
+        moog_set_cutoff_q(n, n->s.cutoff, n->s.q);
+        break;
+    case O_DELAY: /* delay.rs:105-113 */
+        if (n->s.dsr != sr) {
+            n->s.dsr = sr;
+            n->s.time_in_samples = (size_t)round(n->s.dtime * sr);
+            size_t len = n->s.time_in_samples + 1;
+            n->s.dbuf = (float *)realloc(n->s.dbuf, len * sizeof(float));
+            n->s.dlen = len;
+            leaf_reset(n);
+        }
+        break;
+    default: break;
+    }
+}
+
+void o_set_sample_rate(onode *n, double sr) {
+    if (n->x) o_set_sample_rate(n->x, sr);
+    if (n->y) o_set_sample_rate(n->y, sr);
+    leaf_set_sample_rate(n, sr);
+}
+
+/* AudioNode::set_hash (oscillator.rs:94-97, noise.rs:226-229); default is a no-op (audionode.rs:136-139) */
+static void leaf_set_hash(onode *n, uint64_t hash) {
+    if (n->type == O_SINE || n->type == O_NOISE) {
+        n->s.hash = hash;
+        leaf_reset(n);
+    }
+}
+
+/* AudioNode::ping: leaf default audionode.rs:156-161; Pipe/Stack/Binop :1459-1461,:966-968; Unop :1286-1288 */
+static uint64_t o_ping(onode *n, int probe, uint64_t hash) {
+    switch (n->type) {
+    case O_PIPE:
+    case O_STACK:
+    case O_BINOP:
+        return o_ping(n->y, probe, o_ping(n->x, probe, o_atto(hash, n->id)));
+    case O_UNOP:
+        return o_ping(n->x, probe, o_atto(hash, n->id));
+    default:
+        if (!probe) leaf_set_hash(n, hash);
+        return o_atto(hash, n->id);
+    }
+}
+
+/* what every combinator constructor does (audionode.rs:871-876, 1242-1247, 1389-1394) */
+static void ctor_ping(onode *n) {
+    uint64_t h = o_ping(n, 1, n->id); /* AttoHash::new(Self::ID) */
+    o_ping(n, 0, h);
+}
+
+/* AudioNode::set_seed audionode.rs:366-368 */
+void o_set_seed(onode *n, uint64_t seed) { o_ping(n, 0, seed); }
+
+uint64_t o_sine_hash(const onode *n) { return n->s.hash; }
+float o_sine_phase(const onode *n) { return n->s.phase; }
+uint32_t o_noise_state(const onode *n) { return n->s.nstate; }
+/* Setting::phase (oscillator.rs:88-92): stores only; caller resets (combinator.rs:263-267 resets) */
+void o_sine_set_phase(onode *n, float phase) {
+    n->s.has_initial_phase = 1;
+    n->s.initial_phase = phase;
+    leaf_reset(n);
+}
+void o_noise_set_seed(onode *n, uint64_t seed) {
+    n->s.has_seed = 1;
+    n->s.seed = seed;
+    leaf_reset(n);
+}
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* constructors                                                                                           */
+/* ------------------------------------------------------------------------------------------------------ */
+
+onode *o_constant(int n, const float *v) { /* audionode.rs:465-475, ID 2 */
+    onode *c = o_new(O_CONSTANT, 0, n, 2);
+    for (int i = 0; i < n; i++) c->s.value[i] = v[i];
+    return c;
+}
+onode *o_pass(void) { return o_new(O_PASS, 1, 1, 48); } /* audionode.rs:408-436 */
+
+onode *o_sine(void) { /* Sine::new oscillator.rs:30-35, ID 21 */
+    onode *n = o_new(O_SINE, 1, 1, 21);
+    leaf_reset(n);
+    leaf_set_sample_rate(n, DEFAULT_SR);
+    return n;
+}
+onode *o_noise(void) { return o_new(O_NOISE, 0, 1, 20); } /* Noise::new = default, noise.rs:179-183 */
+
+/* FixedSvf::new svf.rs:879-892 with SvfParams{sample_rate: DEFAULT_SR,..} prelude.rs:2111-2121; ID 43 */
+onode *o_fixed_svf(int mode, float cutoff, float q, float gain) {
+    onode *n = o_new(O_FIXED_SVF, 1, 1, 43);
+    n->s.mode = mode;
+    n->s.sr = (float)DEFAULT_SR;
+    n->s.cutoff = cutoff;
+    n->s.q = q;
+    n->s.gain = gain;
+    n->s.sc = svf_make(mode, n->s.sr, cutoff, q, gain);
+    return n;
+}
+/* Svf::new svf.rs:767-779; inputs = 3 (audio,cutoff,q) or 4 (+gain) for bell/shelves; ID 36 */
+onode *o_svf(int mode, float cutoff, float q, float gain) {
+    int nin = (mode >= O_SVF_BELL) ? 4 : 3;
+    onode *n = o_new(O_SVF, nin, 1, 36);
+    n->s.mode = mode;
+    n->s.sr = (float)DEFAULT_SR;
+    n->s.cutoff = cutoff;
+    n->s.q = q;
+    n->s.gain = gain;
+    n->s.sc = svf_make(mode, n->s.sr, cutoff, q, gain);
+    return n;
+}
+onode *o_biquad(float a1, float a2, float b0, float b1, float b2) { /* biquad.rs:151-158, ID 15 */
+    onode *n = o_new(O_BIQUAD, 1, 1, 15);
+    n->s.bc.a1 = a1; n->s.bc.a2 = a2; n->s.bc.b0 = b0; n->s.bc.b1 = b1; n->s.bc.b2 = b2;
+    n->s.sr64 = DEFAULT_SR;
+    return n;
+}
+onode *o_butter_lowpass(int inputs, float cutoff) { /* biquad.rs:234-250, ID 16 */
+    onode *n = o_new(O_BUTTER_LOWPASS, inputs, 1, 16);
+    n->s.sr = (float)DEFAULT_SR;
+    n->s.sr64 = DEFAULT_SR;
+    n->s.bc = bq_butter_lowpass(n->s.sr, cutoff);
+    n->s.cutoff = cutoff;
+    return n;
+}
+onode *o_resonator(int inputs, float center, float q) { /* biquad.rs:318-337, ID 17 */
+    onode *n = o_new(O_RESONATOR, inputs, 1, 17);
+    n->s.sr = (float)DEFAULT_SR;
+    n->s.center = center;
+    n->s.q = q;
+    n->s.bc = bq_resonator(n->s.sr, center, q);
+    return n;
+}
+onode *o_biquad_bank(void) { /* BiquadBank::<f32x8>::new biquad_bank.rs:30-35, ID 98 */
+    onode *n = o_new(O_BIQUAD_BANK, 8, 8, 98);
+    n->s.sr64 = DEFAULT_SR;
+    return n;
+}
+/* Setting::biquad(..).index(i) -> biquad_bank.rs:86-96 */
+void o_biquad_bank_set(onode *n, int index, float a1, float a2, float b0, float b1, float b2) {
+    n->s.bank_c[index].a1 = a1; n->s.bank_c[index].a2 = a2;
+    n->s.bank_c[index].b0 = b0; n->s.bank_c[index].b1 = b1; n->s.bank_c[index].b2 = b2;
+}
+onode *o_moog(int inputs, float cutoff, float q) { /* Moog::new moog.rs:37-44, ID 60 */
+    onode *n = o_new(O_MOOG, inputs, 1, 60);
+    n->s.sr = (float)DEFAULT_SR;
+    moog_set_cutoff_q(n, cutoff, q);
+    return n;
+}
+onode *o_fir(int n_taps, const float *w) { /* Fir::new fir.rs:21-27, ID 52 */
+    onode *n = o_new(O_FIR, 1, 1, 52);
+    n->s.fir_n = n_taps;
+    for (int i = 0; i < n_taps; i++) n->s.w[i] = w[i];
+    n->s.sr64 = DEFAULT_SR;
+    return n;
+}
+onode *o_tick_node(int channels) { /* Tick::new delay.rs:24-31, ID 9 */
+    onode *n = o_new(O_TICK, channels, channels, 9);
+    n->s.sr64 = DEFAULT_SR;
+    return n;
+}
+onode *o_delay(double time) { /* Delay::new delay.rs:80-91, ID 13 */
+    onode *n = o_new(O_DELAY, 1, 1, 13);
+    n->s.dtime = time;
+    leaf_set_sample_rate(n, DEFAULT_SR);
+    return n;
+}
+
+onode *o_pipe(onode *x, onode *y) { /* Pipe::new audionode.rs:1388-1394, ID 6 */
+    if (x->nout != y->nin) return NULL;
+    onode *n = o_new(O_PIPE, x->nin, y->nout, 6);
+    n->x = x; n->y = y;
+    n->tmp = (float *)calloc((size_t)(x->nout ? x->nout : 1) * MAXB, sizeof(float));
+    ctor_ping(n);
+    return n;
+}
+onode *o_stack(onode *x, onode *y) { /* Stack::new audionode.rs:1511-1517, ID 7 */
+    onode *n = o_new(O_STACK, x->nin + y->nin, x->nout + y->nout, 7);
+    n->x = x; n->y = y;
+    ctor_ping(n);
+    return n;
+}
+onode *o_binop(int op, onode *x, onode *y) { /* Binop::new audionode.rs:870-876, ID 3 */
+    if (x->nout != y->nout) return NULL;
+    onode *n = o_new(O_BINOP, x->nin + y->nin, x->nout, 3);
+    n->x = x; n->y = y; n->op = op;
+    n->tmp = (float *)calloc((size_t)x->nout * MAXB, sizeof(float));
+    ctor_ping(n);
+    return n;
+}
+onode *o_unop(int op, onode *x, float scalar) { /* Unop::new audionode.rs:1241-1247, ID 4 */
+    onode *n = o_new(O_UNOP, x->nin, x->nout, 4);
+    n->x = x; n->op = op; n->scalar = scalar;
+    ctor_ping(n);
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* tick                                                                                                   */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/* Svf::update_inputs for 3-input modes svf.rs:299-313, 4-input modes svf.rs:588-...: recompute on change */
+static inline void svf_update_inputs(onode *n, const float *in) {
+    float cutoff = in[1], q = in[2];
+    if (n->nin == 4) {
+        float gain = in[3];
+        if (cutoff != n->s.cutoff || q != n->s.q || gain != n->s.gain) {
+            n->s.cutoff = cutoff; n->s.q = q; n->s.gain = gain;
+            n->s.sc = svf_make(n->s.mode, n->s.sr, cutoff, q, gain);
+        }
+    } else {
+        if (cutoff != n->s.cutoff || q != n->s.q) {
+            n->s.cutoff = cutoff; n->s.q = q;
+            n->s.sc = svf_make(n->s.mode, n->s.sr, cutoff, q, n->s.gain);
+        }
+    }
+}
+
+/* FixedSvf::tick svf.rs:995-1006 == Svf::tick svf.rs:829-843 after update_inputs */
+static inline float svf_tick(onode *n, float v0) {
+    const svf_coefs *c = &n->s.sc;
+    float v3 = v0 - n->s.ic2eq;
+    float v1 = c->a1 * n->s.ic1eq + c->a2 * v3;
+    float v2 = n->s.ic2eq + c->a2 * n->s.ic1eq + c->a3 * v3;
+    n->s.ic1eq = 2.0f * v1 - n->s.ic1eq;
+    n->s.ic2eq = 2.0f * v2 - n->s.ic2eq;
+    return c->m0 * v0 + c->m1 * v1 + c->m2 * v2;
+}
+
+/* Biquad::tick biquad.rs:184-194 (DF1, left-to-right) */
+static inline float biquad_tick(onode *n, float x0) {
+    const bq_coefs *c = &n->s.bc;
+    float y0 = c->b0 * x0 + c->b1 * n->s.x1 + c->b2 * n->s.x2 - c->a1 * n->s.y1 - c->a2 * n->s.y2;
+    n->s.x2 = n->s.x1;
+    n->s.x1 = x0;
+    n->s.y2 = n->s.y1;
+    n->s.y1 = y0;
+    return y0;
+}
+
+/* Moog::tick moog.rs:82-100 */
+static inline float moog_tick(onode *n, const float *in) {
+    if (n->nin > 1) moog_set_cutoff_q(n, in[1], in[2]); /* unconditional, every sample (moog.rs:83-85) */
+    float x = -n->s.rez * n->s.s3 + in[0];
+    n->s.s0 = (x + n->s.px) * n->s.p - n->s.k * n->s.s0;
+    n->s.s1 = (n->s.s0 + n->s.ps0) * n->s.p - n->s.k * n->s.s1;
+    n->s.s2 = (n->s.s1 + n->s.ps1) * n->s.p - n->s.k * n->s.s2;
+    n->s.s3 = o_tanhf((n->s.s2 + n->s.ps2) * n->s.p - n->s.k * n->s.s3);
+    n->s.px = x;
+    n->s.ps0 = n->s.s0;
+    n->s.ps1 = n->s.s1;
+    n->s.ps2 = n->s.s2;
+    return n->s.s3;
+}
+
+/* Fir::tick fir.rs:57-70 */
+static inline float fir_tick(onode *n, float x) {
+    int N = n->s.fir_n;
+    for (int i = 0; i + 1 < N; i++) n->s.v[i] = n->s.v[i + 1];
+    n->s.v[N - 1] = x;
+    float output = 0.0f;
+    for (int i = 0; i < N; i++) output += n->s.w[i] * n->s.v[i];
+    return output;
+}
+
+static inline float binop_apply(int op, float x, float y) { /* FrameAdd/Sub/Mul audionode.rs:725-847 */
+    switch (op) {
+    case O_ADD: return x + y;
+    case O_SUB: return x - y;
+    default: return x * y;
+    }
+}
+static inline float unop_apply(int op, float x, float s) { /* FrameNeg/Id/AddScalar/NegAddScalar/MulScalar :1030-1228 */
+    switch (op) {
+    case O_NEG: return -x;
+    case O_ID: return x;
+    case O_ADD_SCALAR: return x + s;
+    case O_NEG_ADD_SCALAR: return -x + s;
+    default: return x * s;
+    }
+}
+
+void o_tick(onode *n, const float *in, float *out) {
+    float t[O_MAX_CH];
+    switch (n->type) {
+    case O_CONSTANT: /* audionode.rs:496-499 */
+        for (int i = 0; i < n->nout; i++) out[i] = n->s.value[i];
+        break;
+    case O_PASS: out[0] = in[0]; break;
+    case O_SINE: { /* oscillator.rs:67-72 */
+        float phase = n->s.phase;
+        n->s.phase += in[0] * n->s.sample_duration;
+        n->s.phase -= floorf(n->s.phase);
+        out[0] = o_sinf(phase * F32_TAU);
+        break;
+    }
+    case O_NOISE: /* noise.rs:197-202 */
+        n->s.nstate += 1u;
+        out[0] = (float)(o_hash32x(n->s.nstate) >> 8) * (2.0f / (float)((1 << 24) - 1)) - 1.0f;
+        break;
+    case O_SVF:
+        svf_update_inputs(n, in);
+        out[0] = svf_tick(n, in[0]);
+        break;
+    case O_FIXED_SVF: out[0] = svf_tick(n, in[0]); break;
+    case O_BIQUAD: out[0] = biquad_tick(n, in[0]); break;
+    case O_BUTTER_LOWPASS: /* biquad.rs:269-277 */
+        if (n->nin > 1) {
+            float cutoff = in[1];
+            if (cutoff != n->s.cutoff) {
+                n->s.bc = bq_butter_lowpass(n->s.sr, cutoff);
+                n->s.cutoff = cutoff;
+            }
+        }
+        out[0] = biquad_tick(n, in[0]);
+        break;
+    case O_RESONATOR: /* biquad.rs:354-366 */
+        if (n->nin >= 3) {
+            float center = in[1], q = in[2];
+            if (center != n->s.center || q != n->s.q) {
+                n->s.bc = bq_resonator(n->s.sr, center, q);
+                n->s.center = center;
+                n->s.q = q;
+            }
+        }
+        out[0] = biquad_tick(n, in[0]);
+        break;
+    case O_BIQUAD_BANK: /* biquad_bank.rs:73-84, lane-wise f32x8 arithmetic == 8 scalar DF1s */
+        for (int l = 0; l < 8; l++) {
+            const bq_coefs *c = &n->s.bank_c[l];
+            float x0 = in[l];
+            float y0 = c->b0 * x0 + c->b1 * n->s.bx1[l] + c->b2 * n->s.bx2[l] - c->a1 * n->s.by1[l] -
+                       c->a2 * n->s.by2[l];
+            n->s.bx2[l] = n->s.bx1[l];
+            n->s.bx1[l] = x0;
+            n->s.by2[l] = n->s.by1[l];
+            n->s.by1[l] = y0;
+            out[l] = y0;
+        }
+        break;
+    case O_MOOG: out[0] = moog_tick(n, in); break;
+    case O_FIR: out[0] = fir_tick(n, in[0]); break;
+    case O_TICK: /* delay.rs:47-52 */
+        for (int i = 0; i < n->nout; i++) {
+            out[i] = n->s.tickbuf[i];
+            n->s.tickbuf[i] = in[i];
+        }
+        break;
+    case O_DELAY: /* delay.rs:116-124 */
+        n->s.dbuf[n->s.di] = in[0];
+        n->s.di += 1;
+        if (n->s.di >= n->s.dlen) n->s.di = 0;
+        out[0] = n->s.dbuf[n->s.di];
+        break;
+    case O_PIPE: /* audionode.rs:1441-1443 */
+        o_tick(n->x, in, t);
+        o_tick(n->y, t, out);
+        break;
+    case O_STACK: /* audionode.rs:1564-1577 */
+        o_tick(n->x, in, out);
+        o_tick(n->y, in + n->x->nin, out + n->x->nout);
+        break;
+    case O_BINOP: /* audionode.rs:926-931 */
+        o_tick(n->x, in, t);
+        o_tick(n->y, in + n->x->nin, out);
+        for (int i = 0; i < n->nout; i++) out[i] = binop_apply(n->op, t[i], out[i]);
+        break;
+    case O_UNOP: /* audionode.rs:1268-1270 */
+        o_tick(n->x, in, out);
+        for (int i = 0; i < n->nout; i++) out[i] = unop_apply(n->op, out[i], n->scalar);
+        break;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* process (block path).  in/out are planar [channel][64].                                                */
+/* ------------------------------------------------------------------------------------------------------ */
+
+static inline int simd_items(int samples) { return (samples + 7) >> 3; } /* lib.rs:77-79 */
+static inline int full_simd_items(int samples) { return samples >> 3; }  /* lib.rs:83-85 */
+
+/* AudioNode::process default fallback audionode.rs:85-105 */
+static void process_via_tick(onode *n, int size, const float *in, float *out) {
+    float fi[O_MAX_CH], fo[O_MAX_CH];
+    for (int i = 0; i < size; i++) {
+        for (int c = 0; c < n->nin; c++) fi[c] = in[c * MAXB + i];
+        o_tick(n, fi, fo);
+        for (int c = 0; c < n->nout; c++) out[c * MAXB + i] = fo[c];
+    }
+}
+/* AudioNode::process_remainder audionode.rs:110-126 */
+static void process_remainder(onode *n, int size, const float *in, float *out) {
+    float fi[O_MAX_CH], fo[O_MAX_CH];
+    for (int i = size & ~7; i < size; i++) {
+        for (int c = 0; c < n->nin; c++) fi[c] = in[c * MAXB + i];
+        o_tick(n, fi, fo);
+        for (int c = 0; c < n->nout; c++) out[c * MAXB + i] = fo[c];
+    }
+}
+
+void o_process(onode *n, int size, const float *in, float *out) {
+    switch (n->type) {
+    case O_CONSTANT: /* audionode.rs:501-508: splat over simd_items(size) */
+        for (int c = 0; c < n->nout; c++)
+            for (int j = 0; j < simd_items(size) * 8; j++) out[c * MAXB + j] = n->s.value[c];
+        break;
+    case O_SINE: { /* oscillator.rs:74-86: phase unwrapped across the block, wide sin, one wrap at the end */
+        float phase = n->s.phase;
+        for (int i = 0; i < full_simd_items(size); i++) {
+            float element[SIMD_N];
+            for (int j = 0; j < SIMD_N; j++) {
+                element[j] = phase;
+                phase += in[(i << 3) + j] * n->s.sample_duration;
+            }
+            for (int j = 0; j < SIMD_N; j++) out[(i << 3) + j] = o_wide_sinf(element[j] * F32_TAU);
+        }
+        n->s.phase = phase - floorf(phase);
+        process_remainder(n, size, in, out);
+        break;
+    }
+    case O_NOISE: { /* noise.rs:204-218: writes simd_items(size)*8 samples, advances state by size */
+        uint32_t state = n->s.nstate;
+        for (int i = 0; i < simd_items(size) * 8; i++)
+            out[i] = (float)(o_hash32x(state + (uint32_t)i + 1u) >> 8) * (2.0f / (float)((1 << 24) - 1)) - 1.0f;
+        n->s.nstate = state + (uint32_t)size;
+        break;
+    }
+    case O_PIPE: /* audionode.rs:1445-1449 */
+        o_process(n->x, size, in, n->tmp);
+        o_process(n->y, size, n->tmp, out);
+        break;
+    case O_STACK: /* audionode.rs:1580-1591 */
+        o_process(n->x, size, in, out);
+        o_process(n->y, size, in + n->x->nin * MAXB, out + n->x->nout * MAXB);
+        break;
+    case O_BINOP: /* audionode.rs:933-955 */
+        o_process(n->x, size, in, n->tmp);
+        o_process(n->y, size, in + n->x->nin * MAXB, out);
+        for (int c = 0; c < n->nout; c++)
+            for (int i = 0; i < simd_items(size) * 8; i++)
+                out[c * MAXB + i] = binop_apply(n->op, n->tmp[c * MAXB + i], out[c * MAXB + i]);
+        break;
+    case O_UNOP: /* audionode.rs:1273-1280 */
+        o_process(n->x, size, in, out);
+        for (int c = 0; c < n->nout; c++)
+            for (int i = 0; i < simd_items(size) * 8; i++)
+                out[c * MAXB + i] = unop_apply(n->op, out[c * MAXB + i], n->scalar);
+        break;
+    case O_FIXED_SVF: /* no override -> tick fallback; inlined here so the CPU baseline is not penalised */
+        for (int i = 0; i < size; i++) out[i] = svf_tick(n, in[i]);
+        break;
+    case O_BIQUAD:
+        for (int i = 0; i < size; i++) out[i] = biquad_tick(n, in[i]);
+        break;
+    default: /* every other leaf inherits the per-sample fallback */
+        process_via_tick(n, size, in, out);
+        break;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* executors                                                                                              */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/* Wave::render src/wave.rs:441-466 for a generator (0 inputs).  out is [channels][length]. Returns length. */
+size_t o_wave_render(onode *n, double sample_rate, double duration, float *out, size_t capacity) {
+    if (n->nin != 0 || n->nout <= 0 || duration < 0.0) return 0;
+    o_set_sample_rate(n, sample_rate);
+    size_t length = (size_t)round(duration * sample_rate);
+    if (length > capacity) return 0;
+    float *buffer = (float *)malloc((size_t)n->nout * MAXB * sizeof(float));
+    size_t i = 0;
+    while (i < length) {
+        int nn = (int)((length - i) < MAXB ? (length - i) : MAXB);
+        o_process(n, nn, NULL, buffer);
+        for (int c = 0; c < n->nout; c++)
+            for (int j = 0; j < nn; j++) out[(size_t)c * length + i + j] = buffer[c * MAXB + j];
+        i += (size_t)nn;
+    }
+    free(buffer);
+    return length;
+}
+
+/* Wave::filter-style executor (wave.rs:518-565 shape): chops [channels][length] input into <=64 blocks and
+ * calls process; `block` lets tests use other chunkings (the reference always uses 64). */
+void o_render_blocks(onode *n, size_t length, int block, const float *in, float *out) {
+    float *bi = (float *)calloc((size_t)(n->nin ? n->nin : 1) * MAXB, sizeof(float));
+    float *bo = (float *)calloc((size_t)n->nout * MAXB, sizeof(float));
+    size_t i = 0;
+    if (block <= 0 || block > MAXB) block = MAXB;
+    while (i < length) {
+        int nn = (int)((length - i) < (size_t)block ? (length - i) : (size_t)block);
+        for (int c = 0; c < n->nin; c++)
+            for (int j = 0; j < nn; j++) bi[c * MAXB + j] = in[(size_t)c * length + i + j];
+        o_process(n, nn, bi, bo);
+        for (int c = 0; c < n->nout; c++)
+            for (int j = 0; j < nn; j++) out[(size_t)c * length + i + j] = bo[c * MAXB + j];
+        i += (size_t)nn;
+    }
+    free(bi);
+    free(bo);
+}
+
+/* per-sample executor: length ticks; in [channels][length], out [channels][length] */
+void o_render_ticks(onode *n, size_t length, const float *in, float *out) {
+    float fi[O_MAX_CH], fo[O_MAX_CH];
+    for (size_t i = 0; i < length; i++) {
+        for (int c = 0; c < n->nin; c++) fi[c] = in[(size_t)c * length + i];
+        o_tick(n, fi, fo);
+        for (int c = 0; c < n->nout; c++) out[(size_t)c * length + i] = fo[c];
+    }
+}

@@ -1,0 +1,106 @@
+/*
+ * oracle/fundsp_oracle.h -- TEST INFRASTRUCTURE ONLY (CPU oracle for the FunDSP hot path).
+ * See fundsp_oracle.c for the reference citations.  Loaded with ctypes from tests/oracle.py.
+ */
+#ifndef FUNDSP_ORACLE_H
+#define FUNDSP_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct onode onode;
+
+enum {
+    O_CONSTANT = 0, O_PASS, O_SINE, O_NOISE, O_SVF, O_FIXED_SVF, O_BIQUAD, O_BUTTER_LOWPASS, O_RESONATOR,
+    O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP
+};
+/* SvfMode order follows src/svf.rs:281-742 */
+enum {
+    O_SVF_LOWPASS = 0, O_SVF_HIGHPASS, O_SVF_BANDPASS, O_SVF_NOTCH, O_SVF_PEAK, O_SVF_ALLPASS,
+    O_SVF_BELL, O_SVF_LOWSHELF, O_SVF_HIGHSHELF
+};
+enum { O_BQ_BUTTER = 0, O_BQ_RESONATOR, O_BQ_LOWPASS, O_BQ_HIGHPASS, O_BQ_BELL };
+enum { O_ADD = 0, O_SUB, O_MUL };
+enum { O_NEG = 0, O_ID, O_ADD_SCALAR, O_NEG_ADD_SCALAR, O_MUL_SCALAR };
+
+/* leaves */
+onode *o_constant(int n, const float *v);
+onode *o_pass(void);
+onode *o_sine(void);
+onode *o_noise(void);
+onode *o_fixed_svf(int mode, float cutoff, float q, float gain);
+onode *o_svf(int mode, float cutoff, float q, float gain);
+onode *o_biquad(float a1, float a2, float b0, float b1, float b2);
+onode *o_butter_lowpass(int inputs, float cutoff);
+onode *o_resonator(int inputs, float center, float q);
+onode *o_biquad_bank(void);
+void o_biquad_bank_set(onode *n, int index, float a1, float a2, float b0, float b1, float b2);
+onode *o_moog(int inputs, float cutoff, float q);
+onode *o_fir(int n_taps, const float *w);
+onode *o_tick_node(int channels);
+onode *o_delay(double time);
+/* combinators (take ownership of children) */
+onode *o_pipe(onode *x, onode *y);
+onode *o_stack(onode *x, onode *y);
+onode *o_binop(int op, onode *x, onode *y);
+onode *o_unop(int op, onode *x, float scalar);
+void o_free(onode *n);
+
+int o_inputs(const onode *n);
+int o_outputs(const onode *n);
+void o_reset(onode *n);
+void o_set_sample_rate(onode *n, double sr);
+void o_set_seed(onode *n, uint64_t seed);
+void o_sine_set_phase(onode *n, float phase);
+void o_noise_set_seed(onode *n, uint64_t seed);
+uint64_t o_sine_hash(const onode *n);
+float o_sine_phase(const onode *n);
+uint32_t o_noise_state(const onode *n);
+
+void o_tick(onode *n, const float *in, float *out);
+void o_process(onode *n, int size, const float *in, float *out);
+size_t o_wave_render(onode *n, double sample_rate, double duration, float *out, size_t capacity);
+void o_render_blocks(onode *n, size_t length, int block, const float *in, float *out);
+void o_render_ticks(onode *n, size_t length, const float *in, float *out);
+
+/* coefficient helpers + scalar math (unit tests) */
+void o_svf_coefs(int mode, float sr, float cutoff, float q, float gain, float *out6);
+void o_biquad_coefs(int kind, float sr, float f, float q, float gain, float *out5);
+void o_moog_coefs(float sr, float cutoff, float q, float *out3);
+float o_math_sinf(float x);
+float o_math_cosf(float x);
+float o_math_tanf(float x);
+float o_math_tanhf(float x);
+float o_math_expf(float x);
+float o_math_expm1f(float x);
+float o_math_wide_sinf(float x);
+double o_math_rnd1(uint64_t x);
+uint64_t o_math_hash1(uint64_t x);
+uint64_t o_math_atto(uint64_t state, uint64_t data);
+uint32_t o_math_hash32x(uint32_t x);
+
+/* voice-bank driver (oracle/o_bank.c): V independent voices of one BASELINE config, used as the parity
+ * checker at bank scale and as bench.py's cpu_baseline ("port").  Per-voice parameters are inputs (the same
+ * arrays are handed to the HIP engine), so nothing about the workload definition is duplicated here.
+ *   config 2: voice = noise().seed(seed[v]) >> biquad(BiquadCoefs::lowpass(sr, p0[v]=fc, p1[v]=q))   (one BiquadBank lane)
+ *   config 3: voice = sine_hz(p0=f) * f * (p1=m) + f >> sine() >> lowpass_hz(p2=fc, p3=q), then set_seed(seed[v]) */
+typedef struct {
+    int config;
+    int process_mode;   /* 1 = AudioNode::process in <=64-sample blocks (Wave::render chunking), 0 = per-sample tick */
+    int out_layout;     /* 0 = [voice][frame] (CPU-natural), 1 = [frame][voice] (device-native), 2 = no store */
+    int threads;
+    double sample_rate;
+    size_t voices, frames;
+    const float *p0, *p1, *p2, *p3;
+    const uint64_t *seed;
+} o_bank_job;
+double o_bank_render(const o_bank_job *job, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

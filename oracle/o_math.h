@@ -1,0 +1,422 @@
+/*
+ * oracle/o_math.h -- TEST INFRASTRUCTURE ONLY (CPU oracle). Never linked into the product library.
+ *
+ * Scalar restatement of the transcendental / hashing substrate FunDSP's hot path depends on.
+ *
+ * FunDSP (reference @ /root/reference, crate 0.23.0) maps its `Float`/`Real` traits to two third-party
+ * crates whose sources are NOT vendored under /root/reference (no Cargo.lock; semver minimums from
+ * Cargo.toml:15-28):
+ *   - `libm = 0.2.15`  : scalar f32 path  (src/lib.rs:180-222, 444-492, 773-798)  -> sinf cosf tanf tanhf expf floorf ...
+ *   - `wide = 1.1.1`   : f32x8 SIMD path  (src/lib.rs:296-335, 596-670)           -> f32x8::sin, round ...
+ *
+ * `libm` 0.2.x is a line-by-line port of musl libc's math (itself FreeBSD msun): sinf.c/cosf.c/tanf.c with
+ * the double-precision kernels __sindf/__cosdf/__tandf, __rem_pio2f, expm1f.c, tanhf.c, the pre-2019 expf.c.
+ * `wide`'s f32x8::sin_cos is a port of Agner Fog's vectorclass `sincos_f` (vectormath_trig.h): Cody-Waite
+ * 3-constant reduction + degree-2 polynomials in x^2 (Cephes single-precision coefficients).
+ * Those published algorithms are restated here.  PARITY UNPINNED at the bit level for these functions: the
+ * crate sources are absent and there is no Rust toolchain in the build image, so the constants below are
+ * validated only (a) against their own decimal comments, (b) to < 1 ulp against double-precision libm in
+ * tests/test_oracle_math.py, and (c) through the reference's 1e-4 / 2e-4 test tolerances.
+ *
+ * Everything is compiled with -ffp-contract=off: Rust never contracts a*b+c.
+ */
+#ifndef FUNDSP_ORACLE_MATH_H
+#define FUNDSP_ORACLE_MATH_H
+
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline uint32_t o_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float o_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* ---- musl __sindf / __cosdf / __tandf (k_sinf.c, k_cosf.c, k_tanf.c) -------------------------------- */
+static inline float o_k_sindf(double x) {
+    static const double S1 = -0x15555554cbac77.0p-55, /* -0.166666666416265235595 */
+        S2 = 0x111110896efbb2.0p-59,                  /*  0.0083333293858894631756 */
+        S3 = -0x1a00f9e2cae774.0p-65,                 /* -0.000198393348360966317347 */
+        S4 = 0x16cd878c3b46a7.0p-71;                  /*  0.0000027183114939898219064 */
+    double r, s, w, z;
+    z = x * x;
+    w = z * z;
+    r = S3 + z * S4;
+    s = z * x;
+    return (float)((x + s * (S1 + z * S2)) + s * w * r);
+}
+
+static inline float o_k_cosdf(double x) {
+    static const double C0 = -0x1ffffffd0c5e81.0p-54, /* -0.499999997251031003120 */
+        C1 = 0x155553e1053a42.0p-57,                  /*  0.0416666233237390631894 */
+        C2 = -0x16c087e80f1e27.0p-62,                 /* -0.00138867637746099294692 */
+        C3 = 0x199342e0ee5069.0p-68;                  /*  0.0000243904487962774090654 */
+    double r, w, z;
+    z = x * x;
+    w = z * z;
+    r = C2 + z * C3;
+    return (float)(((1.0 + z * C0) + w * C1) + (w * z) * r);
+}
+
+static inline float o_k_tandf(double x, int odd) {
+    static const double T[] = {
+        0x15554d3418c99f.0p-54, /* 0.333331395030791399758 */
+        0x1112fd38999f72.0p-55, /* 0.133392002712976742718 */
+        0x1b54c91d865afe.0p-57, /* 0.0533812378445670393523 */
+        0x191df3908c33ce.0p-58, /* 0.0245283181166547278873 */
+        0x185dadfcecf44e.0p-61, /* 0.00297435743359967304927 */
+        0x1362b9bf971bcd.0p-59, /* 0.00946564784943673166728 */
+    };
+    double z, r, w, s, t, u;
+    z = x * x;
+    r = T[4] + z * T[5];
+    t = T[2] + z * T[3];
+    w = z * z;
+    s = z * x;
+    u = T[0] + z * T[1];
+    r = (x + s * u) + (s * w) * (t + w * r);
+    return (float)(odd ? -1.0 / r : r);
+}
+
+/* musl __rem_pio2f, medium-size branch only (|x| < 2^28*pi/2). Larger arguments never occur on the
+ * hot path (phases are wrapped to [0,1), filter arguments are < pi); they return n=0,y=NaN here. */
+static inline int o_rem_pio2f(float x, double *y) {
+    static const double toint = 1.5 / DBL_EPSILON, invpio2 = 6.36619772367581382433e-01, /* 0x3FE45F30, 0x6DC9C883 */
+        pio2_1 = 1.57079631090164184570e+00,                                           /* 0x3FF921FB, 0x50000000 */
+        pio2_1t = 1.58932547735281966916e-08;                                          /* 0x3E5110b4, 0x611A6263 */
+    uint32_t ix = o_f2u(x) & 0x7fffffff;
+    if (ix < 0x4dc90fdb) { /* |x| ~< 2^28*(pi/2), medium size */
+        double fn = (double)x * invpio2 + toint - toint;
+        int n = (int32_t)fn;
+        *y = x - fn * pio2_1 - fn * pio2_1t;
+        return n;
+    }
+    *y = NAN;
+    return 0;
+}
+
+#define O_PIO2 1.570796326794896558e+00 /* M_PI_2 */
+
+/* musl sinf.c */
+static inline float o_sinf(float x) {
+    static const double s1pio2 = 1 * O_PIO2, s2pio2 = 2 * O_PIO2, s3pio2 = 3 * O_PIO2, s4pio2 = 4 * O_PIO2;
+    double y;
+    uint32_t ix = o_f2u(x);
+    int n, sign = ix >> 31;
+    ix &= 0x7fffffff;
+    if (ix <= 0x3f490fda) {    /* |x| ~<= pi/4 */
+        if (ix < 0x39800000) { /* |x| < 2**-12 */
+            return x;
+        }
+        return o_k_sindf(x);
+    }
+    if (ix <= 0x407b53d1) {     /* |x| ~<= 5*pi/4 */
+        if (ix <= 0x4016cbe3) { /* |x| ~<= 3pi/4 */
+            if (sign)
+                return -o_k_cosdf(x + s1pio2);
+            else
+                return o_k_cosdf(x - s1pio2);
+        }
+        return o_k_sindf(sign ? -(x + s2pio2) : -(x - s2pio2));
+    }
+    if (ix <= 0x40e231d5) {     /* |x| ~<= 9*pi/4 */
+        if (ix <= 0x40afeddf) { /* |x| ~<= 7*pi/4 */
+            if (sign)
+                return o_k_cosdf(x + s3pio2);
+            else
+                return -o_k_cosdf(x - s3pio2);
+        }
+        return o_k_sindf(sign ? x + s4pio2 : x - s4pio2);
+    }
+    if (ix >= 0x7f800000) return x - x;
+    n = o_rem_pio2f(x, &y);
+    switch (n & 3) {
+    case 0: return o_k_sindf(y);
+    case 1: return o_k_cosdf(y);
+    case 2: return o_k_sindf(-y);
+    default: return -o_k_cosdf(y);
+    }
+}
+
+/* musl cosf.c */
+static inline float o_cosf(float x) {
+    static const double c1pio2 = 1 * O_PIO2, c2pio2 = 2 * O_PIO2, c3pio2 = 3 * O_PIO2, c4pio2 = 4 * O_PIO2;
+    double y;
+    uint32_t ix = o_f2u(x);
+    unsigned n, sign = ix >> 31;
+    ix &= 0x7fffffff;
+    if (ix <= 0x3f490fda) {    /* |x| ~<= pi/4 */
+        if (ix < 0x39800000) { /* |x| < 2**-12 */
+            return 1.0f;
+        }
+        return o_k_cosdf(x);
+    }
+    if (ix <= 0x407b53d1) {    /* |x| ~<= 5*pi/4 */
+        if (ix > 0x4016cbe3)   /* |x|  ~> 3*pi/4 */
+            return -o_k_cosdf(sign ? x + c2pio2 : x - c2pio2);
+        else {
+            if (sign)
+                return o_k_sindf(x + c1pio2);
+            else
+                return o_k_sindf(c1pio2 - x);
+        }
+    }
+    if (ix <= 0x40e231d5) {  /* |x| ~<= 9*pi/4 */
+        if (ix > 0x40afeddf) /* |x| ~> 7*pi/4 */
+            return o_k_cosdf(sign ? x + c4pio2 : x - c4pio2);
+        else {
+            if (sign)
+                return o_k_sindf(-x - c3pio2);
+            else
+                return o_k_sindf(x - c3pio2);
+        }
+    }
+    if (ix >= 0x7f800000) return x - x;
+    n = (unsigned)o_rem_pio2f(x, &y);
+    switch (n & 3) {
+    case 0: return o_k_cosdf(y);
+    case 1: return o_k_sindf(-y);
+    case 2: return -o_k_cosdf(y);
+    default: return o_k_sindf(y);
+    }
+}
+
+/* musl tanf.c */
+static inline float o_tanf(float x) {
+    static const double t1pio2 = 1 * O_PIO2, t2pio2 = 2 * O_PIO2, t3pio2 = 3 * O_PIO2, t4pio2 = 4 * O_PIO2;
+    double y;
+    uint32_t ix = o_f2u(x);
+    unsigned n, sign = ix >> 31;
+    ix &= 0x7fffffff;
+    if (ix <= 0x3f490fda) {    /* |x| ~<= pi/4 */
+        if (ix < 0x39800000) { /* |x| < 2**-12 */
+            return x;
+        }
+        return o_k_tandf(x, 0);
+    }
+    if (ix <= 0x407b53d1) {    /* |x| ~<= 5*pi/4 */
+        if (ix <= 0x4016cbe3)  /* |x| ~<= 3pi/4 */
+            return o_k_tandf((sign ? x + t1pio2 : x - t1pio2), 1);
+        else
+            return o_k_tandf((sign ? x + t2pio2 : x - t2pio2), 0);
+    }
+    if (ix <= 0x40e231d5) {    /* |x| ~<= 9*pi/4 */
+        if (ix <= 0x40afeddf)  /* |x| ~<= 7*pi/4 */
+            return o_k_tandf((sign ? x + t3pio2 : x - t3pio2), 1);
+        else
+            return o_k_tandf((sign ? x + t4pio2 : x - t4pio2), 0);
+    }
+    if (ix >= 0x7f800000) return x - x;
+    n = (unsigned)o_rem_pio2f(x, &y);
+    return o_k_tandf(y, n & 1);
+}
+
+/* musl expm1f.c (FreeBSD s_expm1f.c) */
+static inline float o_expm1f(float x) {
+    static const float ln2_hi = 6.9313812256e-01f, /* 0x3f317180 */
+        ln2_lo = 9.0580006145e-06f,                /* 0x3717f7d1 */
+        invln2 = 1.4426950216e+00f,                /* 0x3fb8aa3b */
+        Q1 = -3.3333212137e-2f,                    /* -0x888868.0p-28 */
+        Q2 = 1.5807170421e-3f;                     /*  0xcf3010.0p-33 */
+    float y, hi, lo, c = 0.0f, t, e, hxs, hfx, r1, twopk;
+    uint32_t ui = o_f2u(x);
+    uint32_t hx = ui & 0x7fffffff;
+    int k, sign = ui >> 31;
+
+    if (hx >= 0x4195b844) { /* if |x|>=27*ln2 */
+        if (hx > 0x7f800000) return x;
+        if (sign) return -1.0f;
+        if (x > 8.8721679688e+01f) { /* o_threshold 0x42b17180 */
+            x *= 0x1p127f;
+            return x;
+        }
+    }
+    if (hx > 0x3eb17218) {     /* if  |x| > 0.5 ln2 */
+        if (hx < 0x3F851592) { /* and |x| < 1.5 ln2 */
+            if (!sign) {
+                hi = x - ln2_hi;
+                lo = ln2_lo;
+                k = 1;
+            } else {
+                hi = x + ln2_hi;
+                lo = -ln2_lo;
+                k = -1;
+            }
+        } else {
+            k = (int)(invln2 * x + (sign ? -0.5f : 0.5f));
+            t = (float)k;
+            hi = x - t * ln2_hi; /* t*ln2_hi is exact here */
+            lo = t * ln2_lo;
+        }
+        x = hi - lo;
+        c = (hi - x) - lo;
+    } else if (hx < 0x33000000) { /* when |x|<2**-25, return x */
+        return x;
+    } else
+        k = 0;
+
+    hfx = 0.5f * x;
+    hxs = x * hfx;
+    r1 = 1.0f + hxs * (Q1 + hxs * Q2);
+    t = 3.0f - r1 * hfx;
+    e = hxs * ((r1 - t) / (6.0f - x * t));
+    if (k == 0) /* c is 0 */
+        return x - (x * e - hxs);
+    e = x * (e - c) - c;
+    e -= hxs;
+    if (k == -1) return 0.5f * (x - e) - 0.5f;
+    if (k == 1) {
+        if (x < -0.25f) return -2.0f * (e - (x + 0.5f));
+        return 1.0f + 2.0f * (x - e);
+    }
+    twopk = o_u2f((uint32_t)(0x7f + k) << 23); /* 2^k */
+    if (k < 0 || k > 56) {                     /* suffice to return exp(x)-1 */
+        y = x - e + 1.0f;
+        if (k == 128)
+            y = y * 2.0f * 0x1p127f;
+        else
+            y = y * twopk;
+        return y - 1.0f;
+    }
+    float uf = o_u2f((uint32_t)(0x7f - k) << 23); /* 2^-k */
+    if (k < 23)
+        y = (x - e + (1 - uf)) * twopk;
+    else
+        y = (x - (e + uf) + 1) * twopk;
+    return y;
+}
+
+/* musl tanhf.c */
+static inline float o_tanhf(float x) {
+    uint32_t w = o_f2u(x);
+    int sign = w >> 31;
+    float t;
+    w &= 0x7fffffff;
+    x = o_u2f(w);
+    if (w > 0x3f0c9f54) {     /* |x| > log(3)/2 ~= 0.5493 or nan */
+        if (w > 0x41200000) { /* |x| > 10 */
+            t = 1 + 0 / x;
+        } else {
+            t = o_expm1f(2 * x);
+            t = 1 - 2 / (t + 2);
+        }
+    } else if (w > 0x3e82c578) { /* |x| > log(5/3)/2 ~= 0.2554 */
+        t = o_expm1f(2 * x);
+        t = t / (t + 2);
+    } else if (w >= 0x00800000) { /* |x| >= 0x1p-126 */
+        t = o_expm1f(-2 * x);
+        t = -t / (t + 2);
+    } else { /* |x| is subnormal */
+        t = x;
+    }
+    return sign ? -t : t;
+}
+
+/* musl expf.c as of the 2018 port (FreeBSD e_expf.c; libm 0.2 expf.rs) */
+static inline float o_expf(float x) {
+    static const float half[2] = {0.5f, -0.5f}, ln2hi = 6.9314575195e-1f, /* 0x3f317200 */
+        ln2lo = 1.4286067653e-6f,                                         /* 0x35bfbe8e */
+        invln2 = 1.4426950216e+0f,                                        /* 0x3fb8aa3b */
+        P1 = 1.6666625440e-1f,                                            /*  0xaaaa8f.0p-26 */
+        P2 = -2.7667332906e-3f;                                           /* -0xb55215.0p-32 */
+    float hi, lo, c, xx, y;
+    int k, sign;
+    uint32_t hx = o_f2u(x);
+    sign = hx >> 31;
+    hx &= 0x7fffffff;
+    if (hx >= 0x42aeac50) { /* if |x| >= -87.33655f or NaN */
+        if (hx > 0x7f800000) return x;
+        if (hx >= 0x42b17218 && !sign) { /* x >= 88.722839f */
+            x *= 0x1p127f;
+            return x;
+        }
+        if (sign) {
+            if (hx >= 0x42cff1b5) return 0; /* x <= -103.972084f */
+        }
+    }
+    if (hx > 0x3eb17218) { /* if |x| > 0.5 ln2 */
+        if (hx > 0x3f851592) /* if |x| > 1.5 ln2 */
+            k = (int)(invln2 * x + half[sign]);
+        else
+            k = 1 - sign - sign;
+        hi = x - k * ln2hi; /* k*ln2hi is exact here */
+        lo = k * ln2lo;
+        x = hi - lo;
+    } else if (hx > 0x39000000) { /* |x| > 2**-14 */
+        k = 0;
+        hi = x;
+        lo = 0;
+    } else {
+        return 1 + x;
+    }
+    xx = x * x;
+    c = x - xx * (P1 + xx * P2);
+    y = 1 + (x * c / (2 - c) - lo + hi);
+    if (k == 0) return y;
+    return scalbnf(y, k);
+}
+
+/* ---- wide 1.1.1 f32x8::sin, one lane (vectorclass sincos_f). mul_add / mul_neg_add are UNFUSED: that is
+ *      what `wide` compiles to for a default x86-64 `cargo build` (no `fma` target feature). ---------- */
+static inline float o_round_half_even(float x) { return nearbyintf(x); } /* default rounding mode */
+
+static inline float o_wide_sinf(float self) {
+    const float DP1F = 0.78515625f * 2.0f;
+    const float DP2F = 2.4187564849853515625E-4f * 2.0f;
+    const float DP3F = 3.77489497744594108E-8f * 2.0f;
+    const float P0sinf = -1.6666654611E-1f, P1sinf = 8.3321608736E-3f, P2sinf = -1.9515295891E-4f;
+    const float P0cosf = 4.166664568298827E-2f, P1cosf = -1.388731625493765E-3f, P2cosf = 2.443315711809948E-5f;
+    const float TWO_OVER_PI = 2.0f / 3.14159274101257324f; /* 2.0 / core::f32::consts::PI, evaluated in f32 */
+
+    float xa = fabsf(self);
+    float y = o_round_half_even(xa * TWO_OVER_PI);
+    int32_t q = (int32_t)y; /* round_int of an already-integral value */
+    float x = xa - y * DP1F;
+    x = x - y * DP2F;
+    x = x - y * DP3F;
+    float x2 = x * x;
+    /* polynomial_2!(x2, c0, c1, c2) = (x2*x2)*c2 + (x2*c1 + c0) */
+    float x4 = x2 * x2;
+    float s = (x4 * P2sinf + (x2 * P1sinf + P0sinf)) * (x * x2) + x;
+    float c = (x4 * P2cosf + (x2 * P1cosf + P0cosf)) * (x2 * x2) + (1.0f - 0.5f * x2);
+    int swap = (q & 1) != 0;
+    if (q > 0x2000000 && xa < INFINITY) { /* overflow: q unreliable */
+        s = 0.0f;
+        c = 1.0f;
+    }
+    float sin1 = swap ? c : s;
+    uint32_t sign_sin = ((uint32_t)q << 30) ^ o_f2u(self);
+    return o_u2f(o_f2u(sin1) ^ (sign_sin & 0x80000000u));
+}
+
+/* ---- integer hashing (bit-exact; src/math.rs:569-576, 592-599, 632-658; src/noise.rs:150-158) ------- */
+static inline double o_rnd1(uint64_t x) {
+    x = x ^ 0x5555555555555555ULL;
+    x = x * 0x9e3779b97f4a7c15ULL;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    x = x ^ (x >> 31);
+    return (double)(x >> 11) * (1.0 / (double)(1ULL << 53));
+}
+
+static inline uint64_t o_hash1(uint64_t x) {
+    x = x ^ 0x5555555555555555ULL;
+    x = x * 0x517cc1b727220a95ULL;
+    x = (x ^ (x >> 32)) * 0xd6e8feb86659fd93ULL;
+    x = (x ^ (x >> 32)) * 0xd6e8feb86659fd93ULL;
+    return x ^ (x >> 32);
+}
+
+/* AttoHash::hash (math.rs:649-658) */
+static inline uint64_t o_atto(uint64_t state, uint64_t data) {
+    uint64_t r = (state << 5) | (state >> 59);
+    return (r ^ data) * 0x517cc1b727220a95ULL;
+}
+
+static inline uint32_t o_hash32x(uint32_t x) {
+    const uint32_t MUL_X = 0x45d9f3b;
+    x = (x ^ (x >> 16)) * MUL_X;
+    x = (x ^ (x >> 16)) * MUL_X;
+    return (x ^ (x >> 16)) * MUL_X;
+}
+
+#endif

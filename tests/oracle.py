@@ -1,0 +1,253 @@
+"""ctypes front-end for the CPU oracle (oracle/libfundsp_oracle.so) in FunDSP graph notation.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The opcode names and operator overloads follow the reference's prelude32 (src/prelude32.rs) and
+combinator.rs (`>>` Pipe, `|` Stack, `*`/`+`/`-` with nodes = Binop, with floats = Unop) so that tests
+read like the reference's own tests.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_SO = os.path.join(_ORACLE_DIR, "libfundsp_oracle.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("fundsp_oracle.c", "o_bank.c", "fundsp_oracle.h", "o_math.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"])
+    return _SO
+
+
+_lib = None
+
+SVF_MODES = dict(lowpass=0, highpass=1, bandpass=2, notch=3, peak=4, allpass=5, bell=6, lowshelf=7, highshelf=8)
+BQ_KINDS = dict(butter=0, resonator=1, lowpass=2, highpass=3, bell=4)
+ADD, SUB, MUL = 0, 1, 2
+NEG, ID, ADD_SCALAR, NEG_ADD_SCALAR, MUL_SCALAR = range(5)
+DEFAULT_SR = 44100.0
+
+
+class BankJob(C.Structure):
+    _fields_ = [
+        ("config", C.c_int), ("process_mode", C.c_int), ("out_layout", C.c_int), ("threads", C.c_int),
+        ("sample_rate", C.c_double), ("voices", C.c_size_t), ("frames", C.c_size_t),
+        ("p0", C.POINTER(C.c_float)), ("p1", C.POINTER(C.c_float)), ("p2", C.POINTER(C.c_float)),
+        ("p3", C.POINTER(C.c_float)), ("seed", C.POINTER(C.c_uint64)),
+    ]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    P, f, i, d, u64 = C.c_void_p, C.c_float, C.c_int, C.c_double, C.c_uint64
+    fp = C.POINTER(C.c_float)
+    sig = {
+        "o_constant": (P, [i, fp]), "o_pass": (P, []), "o_sine": (P, []), "o_noise": (P, []),
+        "o_fixed_svf": (P, [i, f, f, f]), "o_svf": (P, [i, f, f, f]), "o_biquad": (P, [f, f, f, f, f]),
+        "o_butter_lowpass": (P, [i, f]), "o_resonator": (P, [i, f, f]), "o_biquad_bank": (P, []),
+        "o_biquad_bank_set": (None, [P, i, f, f, f, f, f]), "o_moog": (P, [i, f, f]), "o_fir": (P, [i, fp]),
+        "o_tick_node": (P, [i]), "o_delay": (P, [d]),
+        "o_pipe": (P, [P, P]), "o_stack": (P, [P, P]), "o_binop": (P, [i, P, P]), "o_unop": (P, [i, P, f]),
+        "o_free": (None, [P]), "o_inputs": (i, [P]), "o_outputs": (i, [P]), "o_reset": (None, [P]),
+        "o_set_sample_rate": (None, [P, d]), "o_set_seed": (None, [P, u64]),
+        "o_sine_set_phase": (None, [P, f]), "o_noise_set_seed": (None, [P, u64]),
+        "o_sine_hash": (u64, [P]), "o_sine_phase": (f, [P]), "o_noise_state": (C.c_uint32, [P]),
+        "o_tick": (None, [P, fp, fp]), "o_process": (None, [P, i, fp, fp]),
+        "o_wave_render": (C.c_size_t, [P, d, d, fp, C.c_size_t]),
+        "o_render_blocks": (None, [P, C.c_size_t, i, fp, fp]), "o_render_ticks": (None, [P, C.c_size_t, fp, fp]),
+        "o_svf_coefs": (None, [i, f, f, f, f, fp]), "o_biquad_coefs": (None, [i, f, f, f, f, fp]),
+        "o_moog_coefs": (None, [f, f, f, fp]),
+        "o_math_sinf": (f, [f]), "o_math_cosf": (f, [f]), "o_math_tanf": (f, [f]), "o_math_tanhf": (f, [f]),
+        "o_math_expf": (f, [f]), "o_math_expm1f": (f, [f]), "o_math_wide_sinf": (f, [f]),
+        "o_math_rnd1": (d, [u64]), "o_math_hash1": (u64, [u64]), "o_math_atto": (u64, [u64, u64]),
+        "o_math_hash32x": (C.c_uint32, [C.c_uint32]),
+        "o_bank_render": (d, [C.POINTER(BankJob), fp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+class Node:
+    """Owning handle of an oracle graph. Combining nodes transfers ownership to the new parent."""
+
+    def __init__(self, ptr, children=()):
+        if not ptr:
+            raise ValueError("oracle: arity mismatch while combining nodes")
+        self.ptr = ptr
+        self._owned = True
+        self.children = list(children)
+        for c in children:
+            c._owned = False
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and self.ptr and _lib is not None:
+            _lib.o_free(self.ptr)
+            self.ptr = None
+
+    # --- AudioNode / AudioUnit surface (audionode.rs:29-369, audiounit.rs:21-371)
+    def inputs(self): return lib().o_inputs(self.ptr)
+    def outputs(self): return lib().o_outputs(self.ptr)
+    def reset(self): lib().o_reset(self.ptr)
+    def set_sample_rate(self, sr): lib().o_set_sample_rate(self.ptr, float(sr))
+    def set_seed(self, seed): lib().o_set_seed(self.ptr, int(seed) & (2**64 - 1))
+
+    def tick(self, frame=()):
+        fin = np.asarray(frame, dtype=np.float32).reshape(-1)
+        assert fin.size == self.inputs()
+        out = np.zeros(max(self.outputs(), 1), dtype=np.float32)
+        lib().o_tick(self.ptr, _fptr(fin) if fin.size else None, _fptr(out))
+        return out[: self.outputs()]
+
+    def process(self, size, inp=None):
+        """inp: [inputs][64] planar block. Returns [outputs][64] (values past `size` undefined)."""
+        out = np.zeros((max(self.outputs(), 1), 64), dtype=np.float32)
+        if self.inputs():
+            inp = np.ascontiguousarray(inp, dtype=np.float32)
+            assert inp.shape == (self.inputs(), 64)
+        lib().o_process(self.ptr, int(size), _fptr(inp) if self.inputs() else None, _fptr(out))
+        return out[: self.outputs()]
+
+    def render_blocks(self, x=None, length=None, block=64):
+        """Feed [inputs][length] through process() in `block`-sized chunks -> [outputs][length]."""
+        if self.inputs():
+            x = np.ascontiguousarray(np.atleast_2d(np.asarray(x, dtype=np.float32)))
+            length = x.shape[1]
+        out = np.zeros((self.outputs(), length), dtype=np.float32)
+        lib().o_render_blocks(self.ptr, length, block, _fptr(x) if self.inputs() else None, _fptr(out))
+        return out
+
+    def render_ticks(self, x=None, length=None):
+        if self.inputs():
+            x = np.ascontiguousarray(np.atleast_2d(np.asarray(x, dtype=np.float32)))
+            length = x.shape[1]
+        out = np.zeros((self.outputs(), length), dtype=np.float32)
+        lib().o_render_ticks(self.ptr, length, _fptr(x) if self.inputs() else None, _fptr(out))
+        return out
+
+    # --- graph notation (combinator.rs:289-488)
+    def __rshift__(self, other): return Node(lib().o_pipe(self.ptr, other.ptr), (self, other))
+    def __or__(self, other): return Node(lib().o_stack(self.ptr, other.ptr), (self, other))
+
+    def _bin(self, other, op, uop, scalar=None):
+        if isinstance(other, Node):
+            return Node(lib().o_binop(op, self.ptr, other.ptr), (self, other))
+        return Node(lib().o_unop(uop, self.ptr, float(other if scalar is None else scalar)), (self,))
+
+    def __mul__(self, o): return self._bin(o, MUL, MUL_SCALAR)
+    def __rmul__(self, o): return self._bin(o, MUL, MUL_SCALAR)
+    def __add__(self, o): return self._bin(o, ADD, ADD_SCALAR)
+    def __radd__(self, o): return self._bin(o, ADD, ADD_SCALAR)
+    def __sub__(self, o):
+        if isinstance(o, Node):
+            return self._bin(o, SUB, None)
+        return self._bin(o, None, ADD_SCALAR, scalar=-float(o))  # combinator.rs: `x - f32` = AddScalar(-y)
+    def __rsub__(self, o): return self._bin(o, None, NEG_ADD_SCALAR)
+    def __neg__(self): return Node(lib().o_unop(NEG, self.ptr, 0.0), (self,))
+
+    # builders (combinator.rs:263-267 `.phase()`, `.seed()`)
+    def phase(self, p):
+        lib().o_sine_set_phase(self.ptr, float(p))
+        return self
+
+    def seed(self, s):
+        lib().o_noise_set_seed(self.ptr, int(s) & (2**64 - 1))
+        return self
+
+
+# --- prelude32 opcodes -------------------------------------------------------------------------------------
+def constant(*v):
+    a = np.asarray(v, dtype=np.float32).reshape(-1)
+    return Node(lib().o_constant(a.size, _fptr(a)))
+
+
+dc = constant
+def pass_(): return Node(lib().o_pass())
+def sine(): return Node(lib().o_sine())
+def sine_hz(f): return constant(f) >> sine()                       # prelude.rs:349
+def noise(): return Node(lib().o_noise())
+white = noise
+def _fsvf(mode, f, q, gain=1.0): return Node(lib().o_fixed_svf(SVF_MODES[mode], f, q, gain))
+def lowpass_hz(f, q): return _fsvf("lowpass", f, q)                # prelude.rs:2111
+def highpass_hz(f, q): return _fsvf("highpass", f, q)
+def bandpass_hz(f, q): return _fsvf("bandpass", f, q)
+def notch_hz(f, q): return _fsvf("notch", f, q)
+def peak_hz(f, q): return _fsvf("peak", f, q)
+def allpass_hz(f, q): return _fsvf("allpass", f, q)
+def bell_hz(f, q, gain): return _fsvf("bell", f, q, gain)
+def lowshelf_hz(f, q, gain): return _fsvf("lowshelf", f, q, gain)
+def highshelf_hz(f, q, gain): return _fsvf("highshelf", f, q, gain)
+def svf(mode, f=440.0, q=1.0, gain=1.0): return Node(lib().o_svf(SVF_MODES[mode], f, q, gain))
+def lowpass(): return svf("lowpass")                               # prelude.rs: Svf with (audio, cutoff, q) inputs
+def biquad(a1, a2, b0, b1, b2): return Node(lib().o_biquad(a1, a2, b0, b1, b2))
+def butterpass_hz(f): return Node(lib().o_butter_lowpass(1, f))
+def butterpass(): return Node(lib().o_butter_lowpass(2, 440.0))
+def resonator_hz(center, bandwidth): return Node(lib().o_resonator(1, center, center / bandwidth))
+def biquad_bank(): return Node(lib().o_biquad_bank())
+def moog_hz(f, q): return Node(lib().o_moog(1, f, q))
+def moog(): return Node(lib().o_moog(3, 1000.0, 0.1))             # prelude.rs:551-553
+def fir(*w):
+    a = np.asarray(w, dtype=np.float32).reshape(-1)
+    return Node(lib().o_fir(a.size, _fptr(a)))
+def tick(channels=1): return Node(lib().o_tick_node(channels))
+def delay(t): return Node(lib().o_delay(float(t)))
+
+
+def set_biquad_bank(node, index, coefs):
+    lib().o_biquad_bank_set(node.ptr, index, *[float(c) for c in coefs])
+
+
+def wave_render(sample_rate, duration, node):
+    """Wave::render (wave.rs:441-466) -> [channels][length] float32."""
+    length = int(round(duration * sample_rate))
+    out = np.zeros((node.outputs(), length), dtype=np.float32)
+    n = lib().o_wave_render(node.ptr, float(sample_rate), float(duration), _fptr(out), length)
+    assert n == length
+    return out
+
+
+def svf_coefs(mode, sr, cutoff, q, gain=1.0):
+    out = np.zeros(6, dtype=np.float32)
+    lib().o_svf_coefs(SVF_MODES[mode], sr, cutoff, q, gain, _fptr(out))
+    return out
+
+
+def biquad_coefs(kind, sr, f, q=1.0, gain=1.0):
+    out = np.zeros(5, dtype=np.float32)
+    lib().o_biquad_coefs(BQ_KINDS[kind], sr, f, q, gain, _fptr(out))
+    return out
+
+
+def moog_coefs(sr, cutoff, q):
+    out = np.zeros(3, dtype=np.float32)
+    lib().o_moog_coefs(sr, cutoff, q, _fptr(out))
+    return out
+
+
+def bank_render(config, params, seeds, frames, sample_rate=48000.0, process_mode=True, out_layout=1, threads=1,
+                store=True):
+    """Render V voices of BASELINE config 2 or 3. params: list of float32 [V] arrays. Returns (out, seconds)."""
+    V = len(seeds)
+    ps = [np.ascontiguousarray(p, dtype=np.float32) for p in params] + [None] * (4 - len(params))
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    job = BankJob(config, int(process_mode), out_layout if store else 2, threads, sample_rate, V, frames,
+                  *[_fptr(p) for p in ps], seeds.ctypes.data_as(C.POINTER(C.c_uint64)))
+    out = None
+    if store:
+        out = np.zeros((frames, V) if out_layout == 1 else (V, frames), dtype=np.float32)
+    secs = lib().o_bank_render(C.byref(job), _fptr(out))
+    return out, secs
