@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X voice-bank engine.
+
+Metric (BASELINE.json): Msamples/s (whole node) for the 65 536-voice SVF+FM graph
+    sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q)           (BASELINE config 3)
+One step = one pass of the hot path: render FRAMES samples of every voice of the rank's bank into an
+HBM-resident [frame][voice] f32 buffer (voice-out mode A, AudioNode::process semantics, 64-sample blocks).
+Multi-GPU: voices shard as contiguous ranges, one process per GPU, no data-path collective (weak scaling:
+65 536 voices per GPU); `--mix` adds the on-device stereo mix-down + one RCCL all-reduce per step.
+
+Prints ONE JSON line on rank 0 (contract in the round brief) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def cpu_baseline(voices_per_gpu, frames, sample_rate, target_seconds):
+    """Time the CPU oracle ("port" of the reference's process() path) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle as O
+    from fundsp_amd import workloads as W
+
+    cores = os.cpu_count() or 1
+    # calibrate on a small sample, then size the timed sample for ~target_seconds of wall time
+    p = W.fm_svf_params(2 * cores, sample_rate)
+    _, s = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], frames, sample_rate, True, 0, cores, store=False)
+    rate = 2 * cores * frames / max(s, 1e-6)
+    n = int(min(voices_per_gpu, max(cores, rate * target_seconds / frames)))
+    n = max(cores, n // cores * cores)
+    p = W.fm_svf_params(n, sample_rate)
+    out = np.zeros((n, frames), dtype=np.float32)
+    job_params = [p["f"], p["m"], p["fc"], p["q"]]
+    _, s = O.bank_render(3, job_params, p["seed"], frames, sample_rate, True, 0, cores, store=False)
+    del out
+    return {
+        "value": round(n * frames / s / 1e6, 3),
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n} of the {voices_per_gpu} config-3 voices x {frames} frames, oracle process() path "
+                  f"(C restatement, gcc -O2 -ffp-contract=off), {cores} threads, {s:.2f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--voices", type=int, default=65536, help="voices per GPU (weak scaling)")
+    ap.add_argument("--frames", type=int, default=48000, help="frames per step (1 s @ 48 kHz)")
+    ap.add_argument("--sample-rate", type=float, default=48000.0)
+    ap.add_argument("--layout", choices=["voice_minor", "planar"], default="voice_minor")
+    ap.add_argument("--mode", choices=["process", "tick"], default="process")
+    ap.add_argument("--mix", action="store_true", help="add on-device stereo mix-down + all-reduce per step")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+
+    import fundsp_amd as F
+    from fundsp_amd import dist as fdist
+    from fundsp_amd import workloads as W
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    V, T, sr = args.voices, args.frames, args.sample_rate
+    layout = F.LAYOUT_VOICE_MINOR if args.layout == "voice_minor" else F.LAYOUT_PLANAR
+    mode = F.MODE_PROCESS if args.mode == "process" else F.MODE_TICK
+    first = rank * V  # contiguous voice ranges of the N*V-voice whole-node bank
+    bank = W.make_fm_svf_bank(V, sr, voice0=first)
+    fs = T if layout == F.LAYOUT_PLANAR else 0
+    out = torch.empty((1, T, V) if layout == F.LAYOUT_VOICE_MINOR else (V, 1, fs), dtype=torch.float32, device="cuda")
+
+    def step():
+        bank.process(T, None, out, layout=layout, frame_stride=fs, mode=mode)
+        if args.mix:
+            mix = F.mix_stereo(out[0] if layout == F.LAYOUT_VOICE_MINOR else out[:, 0, :].t().contiguous())
+            fdist.allreduce_mix(mix)
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP events recorded by the C ABI on the launch stream around the render kernel (read after the loop
+        # would only see the last launch; reading here synchronises on that launch, which the next step's
+        # launch on the same stream is ordered behind anyway)
+        kernel_ms.append(bank.last_kernel_ms())
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_samples = float(world) * V * T * args.steps
+        value = total_samples / elapsed / 1e6
+        avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        algo_bytes = V * T * 4 + V * 64  # 4 B per voice-sample out + 64 B state/params per voice per launch
+        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("voices") == V and rec.get("frames") == T:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "Msamples/s (whole node) for 65536-voice SVF+FM graph",
+            "value": round(value, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE config 3: sine_hz(f)*f*m+f >> sine() >> lowpass_hz(fc,q), "
+                            f"{V} voices/GPU x {T} frames/step @ {sr:g} Hz, voice-out ([frame][voice] f32), "
+                            f"{args.mode} semantics, per-voice params from rnd1(4v+k), phases via set_seed(v)",
+                "voices_per_gpu": V,
+                "frames_per_step": T,
+                "layout": args.layout,
+                "mix_allreduce": bool(args.mix),
+                "parallelism": f"voice-shard x{world}",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "kernel": "fd::k_render<fm_svf, process, voice_minor>",
+                "kernel_ms_avg": round(avg_ms, 4),
+                "algorithmic_bytes_per_launch": algo_bytes,
+            },
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            res["cpu_baseline"] = cpu_baseline(V, T, sr, args.cpu_seconds)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

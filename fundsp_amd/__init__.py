@@ -1,0 +1,8 @@
+"""fundsp_amd -- MI355X (gfx950) voice-bank renderer behind FunDSP's AudioNode::process boundary.
+
+The compute path is hand-written HIP (fundsp_amd/csrc) behind the C ABI in include/fundsp_hip.h; this package is
+the thin host-side mirror of the reference's AudioNode surface used by tests and bench.py.
+"""
+from ._lib import (DEFAULT_SR, LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MAX_BUFFER_SIZE, MODE_PROCESS, MODE_TICK,  # noqa: F401
+                   FdspError, lib)
+from .bank import Bank, biquad_coefs, kind_slots, kinds, mix_stereo, svf_coefs  # noqa: F401

@@ -1,0 +1,86 @@
+"""ctypes binding of the C ABI declared in include/fundsp_hip.h (libfundsp_hip.so, built in-tree for gfx950).
+
+There is no CPU fallback: if the HIP library is missing the import of anything that needs it raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libfundsp_hip.so")
+
+OK, EINVAL, ENOMEM, EDEVICE = 0, -1, -2, -3
+LAYOUT_VOICE_MINOR, LAYOUT_PLANAR = 0, 1
+MODE_PROCESS, MODE_TICK = 0, 1
+MAX_BUFFER_SIZE = 64
+DEFAULT_SR = 44100.0
+
+# every symbol include/fundsp_hip.h declares: name -> (restype, argtypes)
+_P, _i, _f, _d, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_uint64
+_fp, _u64p, _cs = C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.c_char_p
+SYMBOLS = {
+    "fdsp_last_error": (_cs, []),
+    "fdsp_kind_count": (_i, []),
+    "fdsp_kind_name": (_cs, [_i]),
+    "fdsp_kind_by_name": (_i, [_cs]),
+    "fdsp_kind_inputs": (_i, [_i]),
+    "fdsp_kind_outputs": (_i, [_i]),
+    "fdsp_kind_slot_count": (_i, [_i]),
+    "fdsp_kind_slot_name": (_cs, [_i, _i]),
+    "fdsp_kind_slot_kind": (_i, [_i, _i]),
+    "fdsp_bank_create": (_i, [_cs, _sz, C.POINTER(_P)]),
+    "fdsp_bank_destroy": (None, [_P]),
+    "fdsp_bank_inputs": (_i, [_P]),
+    "fdsp_bank_outputs": (_i, [_P]),
+    "fdsp_bank_voices": (_sz, [_P]),
+    "fdsp_bank_set_sample_rate": (_i, [_P, _d]),
+    "fdsp_bank_reset": (_i, [_P]),
+    "fdsp_bank_set_seed": (_i, [_P, _u64p, _sz, _sz]),
+    "fdsp_bank_slot_count": (_i, [_P]),
+    "fdsp_bank_slot_name": (_cs, [_P, _i]),
+    "fdsp_bank_slot_kind": (_i, [_P, _i]),
+    "fdsp_bank_set_param": (_i, [_P, _cs, _fp, _sz, _sz]),
+    "fdsp_bank_set_param_all": (_i, [_P, _cs, _f]),
+    "fdsp_bank_set_param_u64": (_i, [_P, _cs, _u64p, _sz, _sz]),
+    "fdsp_bank_get_slot": (_i, [_P, _cs, _fp, _sz, _sz]),
+    "fdsp_bank_get_state": (_i, [_P, _fp]),
+    "fdsp_bank_set_state": (_i, [_P, _fp]),
+    "fdsp_bank_process": (_i, [_P, _sz, _P, _P, _i, _sz, _i, _P]),
+    "fdsp_bank_process_host": (_i, [_P, _sz, _fp, _fp, _i, _sz, _i]),
+    "fdsp_bank_synchronize": (_i, [_P]),
+    "fdsp_bank_last_kernel_ms": (_i, [_P, C.POINTER(C.c_float)]),
+    "fdsp_mix_stereo": (_i, [_P, _P, _P, _sz, _sz, _P]),
+    "fdsp_svf_coefs": (_i, [_i, _f, _f, _f, _f, _fp]),
+    "fdsp_biquad_coefs": (_i, [_i, _f, _f, _f, _f, _fp]),
+    "fdsp_rnd1": (_d, [_u64]),
+    "fdsp_hash1": (_u64, [_u64]),
+}
+
+_lib = None
+
+
+class FdspError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"fundsp_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                f"{SO_PATH} not found: build the HIP engine first (python -c 'import __graft_entry__ as g; g.build()' "
+                "or make -C fundsp_amd/csrc). There is no CPU fallback.")
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise FdspError(rc, lib().fdsp_last_error().decode())
+    return rc

@@ -1,0 +1,197 @@
+"""Host-side mirror of the reference's AudioNode surface for a voice bank (V lock-step instances of one graph).
+
+Method names and argument meaning follow `AudioNode` / `AudioUnit` (reference src/audionode.rs:29-369,
+src/audiounit.rs:21-371): inputs/outputs, reset, set_sample_rate, set_seed, process, tick, and `set(...)` via
+named per-voice parameters.  Everything calls the C ABI (include/fundsp_hip.h); torch is used only to own
+device memory and to pick the current HIP stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS, MODE_TICK, check, lib
+
+SVF_MODES = dict(lowpass=0, highpass=1, bandpass=2, notch=3, peak=4, allpass=5, bell=6, lowshelf=7, highshelf=8)
+BQ_KINDS = dict(butter=0, resonator=1, lowpass=2, highpass=3, bell=4)
+
+
+def kinds():
+    L = lib()
+    return [L.fdsp_kind_name(k).decode() for k in range(L.fdsp_kind_count())]
+
+
+def kind_slots(kind):
+    L = lib()
+    k = L.fdsp_kind_by_name(kind.encode())
+    if k < 0:
+        raise KeyError(kind)
+    return [(L.fdsp_kind_slot_name(k, i).decode(), L.fdsp_kind_slot_kind(k, i)) for i in range(L.fdsp_kind_slot_count(k))]
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Bank:
+    """V voices of one compiled voice graph on the current HIP device."""
+
+    def __init__(self, kind, voices):
+        self._h = C.c_void_p()
+        self.kind = kind
+        check(lib().fdsp_bank_create(kind.encode(), int(voices), C.byref(self._h)))
+        self.voices = int(voices)
+        self.sample_rate = _lib.DEFAULT_SR
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().fdsp_bank_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # --- AudioNode surface
+    def inputs(self):
+        return lib().fdsp_bank_inputs(self._h)
+
+    def outputs(self):
+        return lib().fdsp_bank_outputs(self._h)
+
+    def set_sample_rate(self, sample_rate):
+        check(lib().fdsp_bank_set_sample_rate(self._h, float(sample_rate)))
+        self.sample_rate = float(sample_rate)
+
+    def reset(self):
+        check(lib().fdsp_bank_reset(self._h))
+
+    def set_seed(self, seeds=None, first=0):
+        """AudioNode::set_seed per voice. seeds=None re-applies the construction-time hash."""
+        if seeds is None:
+            check(lib().fdsp_bank_set_seed(self._h, None, first, self.voices - first))
+            return
+        s = np.ascontiguousarray(seeds, dtype=np.uint64)
+        check(lib().fdsp_bank_set_seed(self._h, s.ctypes.data_as(C.POINTER(C.c_uint64)), first, s.size))
+
+    # --- parameters (Setting)
+    def slots(self):
+        L = lib()
+        return [(L.fdsp_bank_slot_name(self._h, i).decode(), L.fdsp_bank_slot_kind(self._h, i))
+                for i in range(L.fdsp_bank_slot_count(self._h))]
+
+    def set_param(self, name, values, first=0):
+        if np.isscalar(values):
+            check(lib().fdsp_bank_set_param_all(self._h, name.encode(), float(values)))
+            return
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        check(lib().fdsp_bank_set_param(self._h, name.encode(), _fptr(v), first, v.size))
+
+    def set_param_u64(self, name, values, first=0):
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        check(lib().fdsp_bank_set_param_u64(self._h, name.encode(), v.ctypes.data_as(C.POINTER(C.c_uint64)), first, v.size))
+
+    def get_slot(self, name, first=0, count=None):
+        count = self.voices - first if count is None else count
+        out = np.zeros(count, dtype=np.float32)
+        check(lib().fdsp_bank_get_slot(self._h, name.encode(), _fptr(out), first, count))
+        return out
+
+    def get_state(self):
+        out = np.zeros((len(self.slots()), self.voices), dtype=np.float32)
+        check(lib().fdsp_bank_get_state(self._h, _fptr(out)))
+        return out
+
+    def set_state(self, state):
+        s = np.ascontiguousarray(state, dtype=np.float32)
+        assert s.shape == (len(self.slots()), self.voices)
+        check(lib().fdsp_bank_set_state(self._h, _fptr(s)))
+
+    # --- hot path
+    def process(self, frames, inp=None, out=None, layout=LAYOUT_VOICE_MINOR, frame_stride=None, mode=MODE_PROCESS,
+                stream=None):
+        """Render `frames` samples per voice into a device tensor (torch, HBM-resident I/O).
+
+        voice-minor: inp [inputs, frames, V], out [outputs, frames, V]
+        planar:      inp [V, inputs, frame_stride], out [V, outputs, frame_stride]
+        """
+        import torch
+
+        frames = int(frames)
+        ni, no = self.inputs(), self.outputs()
+        if layout == LAYOUT_PLANAR and frame_stride is None:
+            frame_stride = max(frames, 1)
+        fs = int(frame_stride or 0)
+        if out is None:
+            shape = (no, frames, self.voices) if layout == LAYOUT_VOICE_MINOR else (self.voices, no, fs)
+            out = torch.empty(shape, dtype=torch.float32, device="cuda")
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+        d_in = None
+        if ni:
+            assert inp is not None and inp.is_cuda and inp.dtype == torch.float32 and inp.is_contiguous()
+            d_in = C.c_void_p(inp.data_ptr())
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        check(lib().fdsp_bank_process(self._h, frames, d_in, C.c_void_p(out.data_ptr()), layout, fs, mode,
+                                      C.c_void_p(stream) if stream else None))
+        return out
+
+    def process_host(self, frames, inp=None, layout=LAYOUT_PLANAR, frame_stride=None, mode=MODE_PROCESS):
+        """Same with numpy buffers (staged, synchronous). Planar default: [V][channels][frame_stride]."""
+        frames = int(frames)
+        ni, no = self.inputs(), self.outputs()
+        if layout == LAYOUT_PLANAR and frame_stride is None:
+            frame_stride = max(frames, 1)
+        fs = int(frame_stride or 0)
+        shape = (no, frames, self.voices) if layout == LAYOUT_VOICE_MINOR else (self.voices, no, fs)
+        out = np.zeros(shape, dtype=np.float32)
+        h_in = None
+        if ni:
+            inp = np.ascontiguousarray(inp, dtype=np.float32)
+            exp = (ni, frames, self.voices) if layout == LAYOUT_VOICE_MINOR else (self.voices, ni, fs)
+            assert inp.shape == exp, (inp.shape, exp)
+            h_in = _fptr(inp)
+        check(lib().fdsp_bank_process_host(self._h, frames, h_in, _fptr(out), layout, fs, mode))
+        return out
+
+    def tick(self, frame=None):
+        """AudioNode::tick for every voice: frame [V, inputs] -> [V, outputs]."""
+        ni = self.inputs()
+        inp = None
+        if ni:
+            inp = np.ascontiguousarray(frame, dtype=np.float32).reshape(self.voices, ni, 1)
+        out = self.process_host(1, inp, layout=LAYOUT_PLANAR, frame_stride=1, mode=MODE_TICK)
+        return out[:, :, 0]
+
+    def synchronize(self):
+        check(lib().fdsp_bank_synchronize(self._h))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        check(lib().fdsp_bank_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+
+def svf_coefs(mode, sample_rate, cutoff, q, gain=1.0):
+    out = np.zeros(6, dtype=np.float32)
+    check(lib().fdsp_svf_coefs(SVF_MODES[mode], sample_rate, cutoff, q, gain, _fptr(out)))
+    return out
+
+
+def biquad_coefs(kind, sample_rate, f, q=1.0, gain=1.0):
+    """BiquadCoefs::{butter_lowpass,resonator,lowpass,highpass,bell} (biquad.rs:27-116) -> (a1,a2,b0,b1,b2)."""
+    out = np.zeros(5, dtype=np.float32)
+    check(lib().fdsp_biquad_coefs(BQ_KINDS[kind], sample_rate, f, q, gain, _fptr(out)))
+    return out
+
+
+def mix_stereo(voices_out, pan=None, stream=None):
+    """On-device stereo mix-down of a voice-minor mono render [frames, V] -> [2, frames]."""
+    import torch
+
+    assert voices_out.is_cuda and voices_out.dim() == 2 and voices_out.is_contiguous()
+    frames, V = voices_out.shape
+    mix = torch.empty((2, frames), dtype=torch.float32, device=voices_out.device)
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    check(lib().fdsp_mix_stereo(C.c_void_p(voices_out.data_ptr()), C.c_void_p(pan.data_ptr()) if pan is not None else None,
+                                C.c_void_p(mix.data_ptr()), frames, V, C.c_void_p(stream) if stream else None))
+    return mix

@@ -1,0 +1,413 @@
+// fd_capi.hip -- C ABI (include/fundsp_hip.h) of the MI355X voice-bank engine.
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/fundsp_hip.h"
+#include "fd_engine.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? FDSP_ENOMEM : FDSP_EDEVICE,                        \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                            \
+    } while (0)
+
+std::vector<fd::KindOps>& registry() {
+    static std::vector<fd::KindOps> kinds;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        fd::register_leaf_kinds(kinds);
+        fd::register_graph_kinds(kinds);
+    });
+    return kinds;
+}
+
+}  // namespace
+
+struct fdsp_bank {
+    const fd::KindOps* ops;
+    size_t V, stride;
+    int nslots;
+    float* slots;
+    hipStream_t stream;
+    hipEvent_t e0, e1;
+    bool timed;
+    double sr;
+    std::unordered_map<std::string, int> index;
+};
+
+namespace {
+
+int find_slot(const fdsp_bank* b, const char* name) {
+    if (!name) return -1;
+    auto it = b->index.find(name);
+    return it == b->index.end() ? -1 : it->second;
+}
+
+int check_range(const fdsp_bank* b, size_t first, size_t count) {
+    if (first > b->V || count > b->V - first) return fail(FDSP_EINVAL, "voice range out of bounds");
+    return FDSP_OK;
+}
+
+// pan weights of Panner (pan.rs:13-17) for the mix-down
+__global__ void k_pan_weights(const float* pan, float* wl, float* wr, size_t V) {
+    size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float value = pan ? pan[v] : 0.0f;
+    float c = value < -1.0f ? -1.0f : (value > 1.0f ? 1.0f : value);  // clamp11
+    float angle = (c + 1.0f) * (fd::F32_PI * 0.25f);
+    wl[v] = fd::cosf_musl(angle);
+    wr[v] = fd::sinf_musl(angle);
+}
+
+// One 256-thread workgroup per frame: thread k accumulates voices k, k+256, ... in order, then a fixed LDS tree.
+__global__ __launch_bounds__(256) void k_mix(const float* __restrict__ x, const float* __restrict__ wl,
+                                             const float* __restrict__ wr, float* __restrict__ mix, size_t T,
+                                             size_t V) {
+    __shared__ float sl[256], sr[256];
+    const size_t t = blockIdx.x;
+    const float* row = x + t * V;
+    float l = 0.0f, r = 0.0f;
+    for (size_t v = threadIdx.x; v < V; v += 256) {
+        float s = row[v];
+        l += s * wl[v];
+        r += s * wr[v];
+    }
+    sl[threadIdx.x] = l;
+    sr[threadIdx.x] = r;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            sl[threadIdx.x] += sl[threadIdx.x + h];
+            sr[threadIdx.x] += sr[threadIdx.x + h];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        mix[t] = sl[0];
+        mix[T + t] = sr[0];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fdsp_last_error(void) { return g_err.c_str(); }
+
+int fdsp_kind_count(void) { return (int)registry().size(); }
+const char* fdsp_kind_name(int kind) {
+    auto& r = registry();
+    return (kind >= 0 && kind < (int)r.size()) ? r[kind].name : nullptr;
+}
+int fdsp_kind_by_name(const char* name) {
+    auto& r = registry();
+    if (!name) return -1;
+    for (size_t i = 0; i < r.size(); i++)
+        if (std::strcmp(r[i].name, name) == 0) return (int)i;
+    return -1;
+}
+
+int fdsp_kind_inputs(int kind) {
+    auto& r = registry();
+    return (kind >= 0 && kind < (int)r.size()) ? r[kind].nin : FDSP_EINVAL;
+}
+int fdsp_kind_outputs(int kind) {
+    auto& r = registry();
+    return (kind >= 0 && kind < (int)r.size()) ? r[kind].nout : FDSP_EINVAL;
+}
+int fdsp_kind_slot_count(int kind) {
+    auto& r = registry();
+    return (kind >= 0 && kind < (int)r.size()) ? (int)r[kind].slots.size() : FDSP_EINVAL;
+}
+const char* fdsp_kind_slot_name(int kind, int slot) {
+    auto& r = registry();
+    if (kind < 0 || kind >= (int)r.size() || slot < 0 || slot >= (int)r[kind].slots.size()) return nullptr;
+    return r[kind].slots[slot].name.c_str();
+}
+int fdsp_kind_slot_kind(int kind, int slot) {
+    auto& r = registry();
+    if (kind < 0 || kind >= (int)r.size() || slot < 0 || slot >= (int)r[kind].slots.size()) return FDSP_EINVAL;
+    return r[kind].slots[slot].kind;
+}
+
+int fdsp_bank_create(const char* kind, size_t voices, fdsp_bank** out) {
+    if (!out) return fail(FDSP_EINVAL, "out is NULL");
+    *out = nullptr;
+    int k = fdsp_kind_by_name(kind);
+    if (k < 0) return fail(FDSP_EINVAL, std::string("unknown voice-graph kind: ") + (kind ? kind : "(null)"));
+    if (voices == 0) return fail(FDSP_EINVAL, "voices must be > 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FDSP_EDEVICE, "no HIP device available: the fundsp_hip engine has no CPU fallback");
+    fdsp_bank* b = new fdsp_bank();
+    b->ops = &registry()[k];
+    b->V = voices;
+    b->stride = (voices + 63) / 64 * 64;
+    b->nslots = (int)b->ops->slots.size();
+    b->slots = nullptr;
+    b->stream = nullptr;
+    b->timed = false;
+    b->sr = FDSP_DEFAULT_SR;
+    for (int i = 0; i < b->nslots; i++) b->index[b->ops->slots[i].name] = i;
+    size_t bytes = (size_t)(b->nslots > 0 ? b->nslots : 1) * b->stride * sizeof(float);
+    hipError_t e = hipMalloc((void**)&b->slots, bytes);
+    if (e != hipSuccess) {
+        delete b;
+        return fail(FDSP_ENOMEM, std::string("hipMalloc(slots): ") + hipGetErrorString(e));
+    }
+    if (hipStreamCreate(&b->stream) != hipSuccess ||
+        hipEventCreate(&b->e0) != hipSuccess || hipEventCreate(&b->e1) != hipSuccess) {
+        hipFree(b->slots);
+        delete b;
+        return fail(FDSP_EDEVICE, "stream/event creation failed");
+    }
+    hipMemsetAsync(b->slots, 0, bytes, b->stream);
+    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 0, b->sr, nullptr, b->stream);
+    e = hipStreamSynchronize(b->stream);
+    if (e != hipSuccess) {
+        fdsp_bank_destroy(b);
+        return fail(FDSP_EDEVICE, std::string("bank construction kernel failed: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return FDSP_OK;
+}
+
+void fdsp_bank_destroy(fdsp_bank* b) {
+    if (!b) return;
+    if (b->stream) hipStreamSynchronize(b->stream);
+    if (b->slots) hipFree(b->slots);
+    hipEventDestroy(b->e0);
+    hipEventDestroy(b->e1);
+    if (b->stream) hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int fdsp_bank_inputs(const fdsp_bank* b) { return b ? b->ops->nin : FDSP_EINVAL; }
+int fdsp_bank_outputs(const fdsp_bank* b) { return b ? b->ops->nout : FDSP_EINVAL; }
+size_t fdsp_bank_voices(const fdsp_bank* b) { return b ? b->V : 0; }
+
+int fdsp_bank_set_sample_rate(fdsp_bank* b, double sr) {
+    if (!b || !(sr > 0.0)) return fail(FDSP_EINVAL, "bad bank or sample rate");
+    b->sr = sr;
+    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, sr, nullptr, b->stream);
+    HIPCHK(hipGetLastError());
+    return FDSP_OK;
+}
+
+int fdsp_bank_reset(fdsp_bank* b) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 2, b->sr, nullptr, b->stream);
+    HIPCHK(hipGetLastError());
+    return FDSP_OK;
+}
+
+int fdsp_bank_set_seed(fdsp_bank* b, const uint64_t* h_seeds, size_t first, size_t count) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    if (int rc = check_range(b, first, count)) return rc;
+    if (count == 0) return FDSP_OK;
+    uint64_t* d = nullptr;
+    if (h_seeds) {
+        HIPCHK(hipMalloc((void**)&d, count * sizeof(uint64_t)));
+        hipError_t e = hipMemcpyAsync(d, h_seeds, count * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream);
+        if (e != hipSuccess) {
+            hipFree(d);
+            return fail(FDSP_EDEVICE, hipGetErrorString(e));
+        }
+    }
+    b->ops->lifecycle(b->slots, b->stride, first, count, 3, b->sr, d, b->stream);
+    hipError_t e = hipStreamSynchronize(b->stream);
+    if (d) hipFree(d);
+    if (e != hipSuccess) return fail(FDSP_EDEVICE, hipGetErrorString(e));
+    return FDSP_OK;
+}
+
+int fdsp_bank_slot_count(const fdsp_bank* b) { return b ? b->nslots : FDSP_EINVAL; }
+const char* fdsp_bank_slot_name(const fdsp_bank* b, int slot) {
+    return (b && slot >= 0 && slot < b->nslots) ? b->ops->slots[slot].name.c_str() : nullptr;
+}
+int fdsp_bank_slot_kind(const fdsp_bank* b, int slot) {
+    return (b && slot >= 0 && slot < b->nslots) ? b->ops->slots[slot].kind : FDSP_EINVAL;
+}
+
+static int set_words(fdsp_bank* b, int slot, const void* h_words, size_t first, size_t count) {
+    HIPCHK(hipMemcpyAsync(b->slots + (size_t)slot * b->stride + first, h_words, count * sizeof(float),
+                          hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));  // h_words is borrowed for the call only
+    return FDSP_OK;
+}
+
+int fdsp_bank_set_param(fdsp_bank* b, const char* name, const float* h_values, size_t first, size_t count) {
+    if (!b || !h_values) return fail(FDSP_EINVAL, "bank or values NULL");
+    int s = find_slot(b, name);
+    if (s < 0) return fail(FDSP_EINVAL, std::string("unknown slot: ") + (name ? name : "(null)"));
+    if (int rc = check_range(b, first, count)) return rc;
+    if (count == 0) return FDSP_OK;
+    if (int rc = set_words(b, s, h_values, first, count)) return rc;
+    // re-derive coefficients like the reference setters do (idempotent for untouched voices)
+    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, b->stream);
+    HIPCHK(hipGetLastError());
+    return FDSP_OK;
+}
+
+int fdsp_bank_set_param_all(fdsp_bank* b, const char* name, float value) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    std::vector<float> tmp(b->V, value);
+    return fdsp_bank_set_param(b, name, tmp.data(), 0, b->V);
+}
+
+int fdsp_bank_set_param_u64(fdsp_bank* b, const char* name, const uint64_t* h_values, size_t first, size_t count) {
+    if (!b || !h_values || !name) return fail(FDSP_EINVAL, "bank, name or values NULL");
+    int lo = find_slot(b, (std::string(name) + ".lo").c_str());
+    int hi = find_slot(b, (std::string(name) + ".hi").c_str());
+    if (lo < 0 || hi < 0) return fail(FDSP_EINVAL, std::string("unknown u64 slot: ") + name);
+    if (int rc = check_range(b, first, count)) return rc;
+    if (count == 0) return FDSP_OK;
+    std::vector<uint32_t> wl(count), wh(count);
+    for (size_t i = 0; i < count; i++) {
+        wl[i] = (uint32_t)h_values[i];
+        wh[i] = (uint32_t)(h_values[i] >> 32);
+    }
+    if (int rc = set_words(b, lo, wl.data(), first, count)) return rc;
+    if (int rc = set_words(b, hi, wh.data(), first, count)) return rc;
+    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, b->stream);
+    HIPCHK(hipGetLastError());
+    return FDSP_OK;
+}
+
+int fdsp_bank_get_slot(fdsp_bank* b, const char* name, float* h_values, size_t first, size_t count) {
+    if (!b || !h_values) return fail(FDSP_EINVAL, "bank or values NULL");
+    int s = find_slot(b, name);
+    if (s < 0) return fail(FDSP_EINVAL, std::string("unknown slot: ") + (name ? name : "(null)"));
+    if (int rc = check_range(b, first, count)) return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(h_values, b->slots + (size_t)s * b->stride + first, count * sizeof(float), hipMemcpyDeviceToHost));
+    return FDSP_OK;
+}
+
+int fdsp_bank_get_state(fdsp_bank* b, float* h_slots) {
+    if (!b || !h_slots) return fail(FDSP_EINVAL, "bank or buffer NULL");
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->nslots == 0) return FDSP_OK;
+    HIPCHK(hipMemcpy2D(h_slots, b->V * sizeof(float), b->slots, b->stride * sizeof(float), b->V * sizeof(float),
+                       (size_t)b->nslots, hipMemcpyDeviceToHost));
+    return FDSP_OK;
+}
+
+int fdsp_bank_set_state(fdsp_bank* b, const float* h_slots) {
+    if (!b || !h_slots) return fail(FDSP_EINVAL, "bank or buffer NULL");
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->nslots == 0) return FDSP_OK;
+    HIPCHK(hipMemcpy2D(b->slots, b->stride * sizeof(float), h_slots, b->V * sizeof(float), b->V * sizeof(float),
+                       (size_t)b->nslots, hipMemcpyHostToDevice));
+    return FDSP_OK;
+}
+
+int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_out, int layout, size_t frame_stride,
+                      int mode, void* stream) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    if (frames == 0) return FDSP_OK;  // size == 0 is a legal no-op (audionode.rs:82)
+    if (!d_out) return fail(FDSP_EINVAL, "d_out is NULL");
+    if (b->ops->nin > 0 && !d_in) return fail(FDSP_EINVAL, "d_in is NULL but the graph has inputs");
+    if (layout != FDSP_LAYOUT_VOICE_MINOR && layout != FDSP_LAYOUT_PLANAR) return fail(FDSP_EINVAL, "bad layout");
+    if (mode != FDSP_MODE_PROCESS && mode != FDSP_MODE_TICK) return fail(FDSP_EINVAL, "bad mode");
+    if (layout == FDSP_LAYOUT_PLANAR && frame_stride < frames) return fail(FDSP_EINVAL, "frame_stride < frames");
+    hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+    if (s != b->stream) HIPCHK(hipStreamSynchronize(b->stream));  // order after pending parameter updates
+    HIPCHK(hipEventRecord(b->e0, s));
+    b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b->e1, s));
+    b->timed = true;
+    return FDSP_OK;
+}
+
+int fdsp_bank_process_host(fdsp_bank* b, size_t frames, const float* h_in, float* h_out, int layout,
+                           size_t frame_stride, int mode) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    if (frames == 0) return FDSP_OK;
+    if (!h_out) return fail(FDSP_EINVAL, "h_out is NULL");
+    const size_t row = layout == FDSP_LAYOUT_PLANAR ? frame_stride : frames;
+    if (layout == FDSP_LAYOUT_PLANAR && frame_stride < frames) return fail(FDSP_EINVAL, "frame_stride < frames");
+    const size_t n_in = (size_t)b->ops->nin * row * b->V, n_out = (size_t)b->ops->nout * row * b->V;
+    if (b->ops->nin > 0 && !h_in) return fail(FDSP_EINVAL, "h_in is NULL but the graph has inputs");
+    float *d_in = nullptr, *d_out = nullptr;
+    if (n_in) HIPCHK(hipMalloc((void**)&d_in, n_in * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&d_out, n_out * sizeof(float));
+    if (e != hipSuccess) {
+        if (d_in) hipFree(d_in);
+        return fail(FDSP_ENOMEM, hipGetErrorString(e));
+    }
+    int rc = FDSP_OK;
+    if (n_in) e = hipMemcpyAsync(d_in, h_in, n_in * sizeof(float), hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, n_out * sizeof(float), b->stream);
+    if (e == hipSuccess) rc = fdsp_bank_process(b, frames, d_in, d_out, layout, frame_stride, mode, nullptr);
+    if (e == hipSuccess && rc == FDSP_OK)
+        e = hipMemcpyAsync(h_out, d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    if (d_in) hipFree(d_in);
+    hipFree(d_out);
+    if (e != hipSuccess) return fail(FDSP_EDEVICE, hipGetErrorString(e));
+    return rc;
+}
+
+int fdsp_bank_synchronize(fdsp_bank* b) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return FDSP_OK;
+}
+
+int fdsp_bank_last_kernel_ms(fdsp_bank* b, float* ms) {
+    if (!b || !ms) return fail(FDSP_EINVAL, "bank or ms NULL");
+    if (!b->timed) return fail(FDSP_EINVAL, "no process call recorded yet");
+    HIPCHK(hipEventSynchronize(b->e1));
+    HIPCHK(hipEventElapsedTime(ms, b->e0, b->e1));
+    return FDSP_OK;
+}
+
+int fdsp_mix_stereo(const float* d_voices, const float* d_pan, float* d_mix, size_t frames, size_t voices,
+                    void* stream) {
+    if (!d_voices || !d_mix) return fail(FDSP_EINVAL, "NULL buffer");
+    if (frames == 0 || voices == 0) return FDSP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    float* w = nullptr;
+    HIPCHK(hipMallocAsync((void**)&w, 2 * voices * sizeof(float), s));
+    hipLaunchKernelGGL(k_pan_weights, dim3((unsigned)((voices + 255) / 256)), dim3(256), 0, s, d_pan, w, w + voices,
+                       voices);
+    hipLaunchKernelGGL(k_mix, dim3((unsigned)frames), dim3(256), 0, s, d_voices, w, w + voices, d_mix, frames, voices);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipFreeAsync(w, s));
+    return FDSP_OK;
+}
+
+int fdsp_svf_coefs(int mode, float sr, float cutoff, float q, float gain, float* out6) {
+    if (!out6 || mode < 0 || mode > FDSP_SVF_HIGHSHELF) return fail(FDSP_EINVAL, "bad svf mode or NULL out");
+    fd::SvfCoefs c = fd::svf_coefs(mode, sr, cutoff, q, gain);
+    out6[0] = c.a1; out6[1] = c.a2; out6[2] = c.a3; out6[3] = c.m0; out6[4] = c.m1; out6[5] = c.m2;
+    return FDSP_OK;
+}
+
+int fdsp_biquad_coefs(int kind, float sr, float f, float q, float gain, float* out5) {
+    if (!out5 || kind < 0 || kind > FDSP_BQ_BELL) return fail(FDSP_EINVAL, "bad biquad kind or NULL out");
+    fd::BiquadCoefs c = fd::biquad_coefs(kind, sr, f, q, gain);
+    out5[0] = c.a1; out5[1] = c.a2; out5[2] = c.b0; out5[3] = c.b1; out5[4] = c.b2;
+    return FDSP_OK;
+}
+
+double fdsp_rnd1(uint64_t x) { return fd::rnd1(x); }
+uint64_t fdsp_hash1(uint64_t x) { return fd::hash1(x); }
+
+}  // extern "C"

@@ -1,0 +1,343 @@
+// fd_engine.hpp -- bank kernels of the MI355X voice-bank engine, generic over a voice-graph type G.
+//
+// Launch geometry: one wave64 workgroup per 64 voices (lane == voice).  At BASELINE config 3 (65 536 voices)
+// that is 1024 single-wave workgroups = one wave per SIMD on a 256-CU MI355X; all of them are co-resident, so
+// at any instant the chip writes one contiguous [frame][voice] row segment per wave (256 B per store
+// instruction, 2 full 128-B lines) and rows advance in near lock-step -- HBM sees a streaming write.
+// No MFMA anywhere: every per-lane recurrence is a scalar IIR / phase accumulator, not a contraction.
+//
+// Per-voice registers are loaded once per launch from the SoA `slots[slot][voice]` (coalesced, 256 B per wave
+// per slot) and only STATE slots are written back at the end; output samples are the only per-frame HBM
+// traffic of a generator graph (4 B per voice-sample).
+//
+// FDSP_LAYOUT_PLANAR ([voice][channel][frame], the reference BufferArray layout) is served by transposing
+// 64 voices x 64 frames tiles through LDS: rows padded to 68 floats so that both the per-lane row access
+// (ds_read/write_b128 of 4 consecutive frames) and the global<->LDS staging (16 lanes x float4 = one 256-B
+// voice row) are bank-conflict free and every HBM access is a 256-B contiguous run.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "fd_nodes.hpp"
+
+namespace fd {
+
+constexpr int LAYOUT_VOICE_MINOR = 0, LAYOUT_PLANAR = 1;
+constexpr int MODE_PROCESS = 0, MODE_TICK = 1;
+constexpr int TILE_STRIDE = 68;  // floats per voice row in an LDS tile (64 + 4: keeps b128 alignment, breaks bank aliasing)
+
+// ---- visitors --------------------------------------------------------------------------------------------
+struct VLoad {
+    const float* p;
+    size_t stride;
+    int slot;
+    FD_D void f(float& x, FieldKind, const char*) { x = p[(size_t)slot++ * stride]; }
+    FD_D void fi(float& x, FieldKind, const char*, int) { x = p[(size_t)slot++ * stride]; }
+    FD_D void u32(uint32_t& x, FieldKind, const char*) { x = f2u(p[(size_t)slot++ * stride]); }
+    FD_D void u64(uint64_t& x, FieldKind, const char*) {
+        uint32_t lo = f2u(p[(size_t)slot * stride]);
+        uint32_t hi = f2u(p[(size_t)(slot + 1) * stride]);
+        slot += 2;
+        x = ((uint64_t)hi << 32) | lo;
+    }
+    FD_D void enter(int) {}
+    FD_D void leave() {}
+};
+
+template <bool ALL>
+struct VStore {
+    float* p;
+    size_t stride;
+    int slot;
+    FD_D void f(float& x, FieldKind k, const char*) {
+        if (ALL || k == STATE) p[(size_t)slot * stride] = x;
+        slot++;
+    }
+    FD_D void fi(float& x, FieldKind k, const char*, int) {
+        if (ALL || k == STATE) p[(size_t)slot * stride] = x;
+        slot++;
+    }
+    FD_D void u32(uint32_t& x, FieldKind k, const char*) {
+        if (ALL || k == STATE) p[(size_t)slot * stride] = u2f(x);
+        slot++;
+    }
+    FD_D void u64(uint64_t& x, FieldKind k, const char*) {
+        if (ALL || k == STATE) {
+            p[(size_t)slot * stride] = u2f((uint32_t)x);
+            p[(size_t)(slot + 1) * stride] = u2f((uint32_t)(x >> 32));
+        }
+        slot += 2;
+    }
+    FD_D void enter(int) {}
+    FD_D void leave() {}
+};
+
+struct SlotInfo {
+    std::string name;
+    int kind;
+};
+
+struct VDescribe {  // host only
+    std::vector<SlotInfo>* out;
+    std::vector<int> path;
+    std::string prefix() const {
+        std::string s;
+        for (size_t i = 0; i < path.size(); i++) {
+            if (i) s += ".";
+            s += std::to_string(path[i]);
+        }
+        return s;
+    }
+    void add(const std::string& field, int kind) { out->push_back({prefix() + ":" + field, kind}); }
+    void f(float&, FieldKind k, const char* name) { add(name, k); }
+    void fi(float&, FieldKind k, const char* name, int index) {
+        add(std::string(name) + "[" + std::to_string(index) + "]", k);
+    }
+    void u32(uint32_t&, FieldKind k, const char* name) { add(name, k); }
+    void u64(uint64_t&, FieldKind k, const char* name) {
+        add(std::string(name) + ".lo", k);
+        add(std::string(name) + ".hi", k);
+    }
+    void enter(int i) { path.push_back(i); }
+    void leave() { path.pop_back(); }
+};
+
+// ---- lifecycle kernels -------------------------------------------------------------------------------------
+// op: 0 = construct (defaults, DEFAULT_SR, constructor ping), 1 = update (set_sample_rate / parameter change),
+//     2 = reset, 3 = set_seed (seeds != null) or re-apply the construction hash (seeds == null)
+template <class G>
+__global__ __launch_bounds__(64) void k_lifecycle(float* slots, size_t stride, size_t first, size_t count, int op,
+                                                  double sr, const uint64_t* seeds) {
+    size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    size_t v = first + i;
+    G g;
+    {
+        VLoad ld{slots + v, stride, 0};
+        g.visit(ld);
+    }
+    if (op == 0) {
+        g.init();
+        g.update(sr);
+        uint64_t h = g.ping(true, G::ID);  // Pipe::new etc: ping(true, AttoHash::new(Self::ID)) then ping(false, h)
+        g.ping(false, h);
+    } else if (op == 1) {
+        g.update(sr);
+    } else if (op == 2) {
+        g.reset();
+    } else {
+        if (seeds) {
+            g.ping(false, seeds[i]);  // AudioNode::set_seed audionode.rs:366-368
+        } else {
+            uint64_t h = g.ping(true, G::ID);
+            g.ping(false, h);
+        }
+    }
+    VStore<true> st{slots + v, stride, 0};
+    g.visit(st);
+}
+
+// ---- the hot kernel ----------------------------------------------------------------------------------------
+template <class G, int MODE, int LAYOUT>
+__global__ __launch_bounds__(64) void k_render(float* __restrict__ slots, size_t stride, size_t V,
+                                               const float* __restrict__ in, float* __restrict__ out, size_t T,
+                                               size_t fstride) {
+    constexpr int NI = G::IN, NO = G::OUT;
+    const int lane = threadIdx.x;
+    const size_t v0 = (size_t)blockIdx.x * 64;
+    const size_t v = v0 + lane;
+    const bool active = v < V;
+
+    G g;
+    {
+        VLoad ld{slots + v, stride, 0};  // stride is padded to a multiple of 64: always in bounds
+        g.visit(ld);
+    }
+
+    if (LAYOUT == LAYOUT_VOICE_MINOR) {
+        if (!active) return;
+        const float* inv = in + v;
+        float* outv = out + v;
+        for (size_t t0 = 0; t0 < T; t0 += 64) {
+            const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+            const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
+            float fi[NI > 0 ? NI : 1], fo[NO];
+#pragma unroll 8
+            for (int i = 0; i < full; i++) {
+                const size_t t = t0 + i;
+#pragma unroll
+                for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
+                g.template step<true>(fi, fo);
+#pragma unroll
+                for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+            }
+            if (MODE == MODE_PROCESS) g.end_simd();
+            for (int i = full; i < size; i++) {
+                const size_t t = t0 + i;
+#pragma unroll
+                for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
+                g.template step<false>(fi, fo);
+#pragma unroll
+                for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+            }
+        }
+    } else {
+        __shared__ __attribute__((aligned(16))) float tin[(NI > 0 ? NI : 1) * 64 * TILE_STRIDE];
+        __shared__ __attribute__((aligned(16))) float tout[NO * 64 * TILE_STRIDE];
+        const int sub = lane >> 4;         // which of 4 voice rows this lane stages per pass
+        const int fr = (lane & 15) << 2;   // first of its 4 frames
+        const bool aligned = ((fstride & 3) == 0) && ((((uintptr_t)in) & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
+        for (size_t t0 = 0; t0 < T; t0 += 64) {
+            const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+            const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
+            const bool vec = aligned && (t0 + 64 <= fstride);
+            // stage inputs: global [voice][ch][frame] -> LDS [ch][voice][frame]
+            if (NI > 0) {
+#pragma unroll
+                for (int c = 0; c < NI; c++) {
+                    for (int r = 0; r < 16; r++) {
+                        const int vr = r * 4 + sub;
+                        const size_t gv = v0 + vr;
+                        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (gv < V) {
+                            const float* src = in + (gv * NI + c) * fstride + t0 + fr;
+                            if (vec) {
+                                x = *reinterpret_cast<const float4*>(src);
+                            } else {
+                                if (fr + 0 < size) x.x = src[0];
+                                if (fr + 1 < size) x.y = src[1];
+                                if (fr + 2 < size) x.z = src[2];
+                                if (fr + 3 < size) x.w = src[3];
+                            }
+                        }
+                        *reinterpret_cast<float4*>(&tin[(c * 64 + vr) * TILE_STRIDE + fr]) = x;
+                    }
+                }
+                __syncthreads();
+            }
+            // compute: each lane walks its own LDS row, 4 frames per ds_read_b128 / ds_write_b128
+            for (int i4 = 0; i4 < size; i4 += 4) {
+                float xi[NI > 0 ? NI : 1][4];
+                float xo[NO][4];
+#pragma unroll
+                for (int c = 0; c < NI; c++) {
+                    float4 q = *reinterpret_cast<const float4*>(&tin[(c * 64 + lane) * TILE_STRIDE + i4]);
+                    xi[c][0] = q.x; xi[c][1] = q.y; xi[c][2] = q.z; xi[c][3] = q.w;
+                }
+                if (i4 < full) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float fi[NI > 0 ? NI : 1], fo[NO];
+#pragma unroll
+                        for (int c = 0; c < NI; c++) fi[c] = xi[c][j];
+                        g.template step<true>(fi, fo);
+#pragma unroll
+                        for (int c = 0; c < NO; c++) xo[c][j] = fo[c];
+                    }
+                    if (MODE == MODE_PROCESS && i4 + 4 == full) g.end_simd();
+                } else {
+                    if (MODE == MODE_PROCESS && i4 == full && full == 0) g.end_simd();
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float fi[NI > 0 ? NI : 1], fo[NO];
+#pragma unroll
+                        for (int c = 0; c < NI; c++) fi[c] = xi[c][j];
+#pragma unroll
+                        for (int c = 0; c < NO; c++) fo[c] = 0.0f;
+                        if (i4 + j < size) g.template step<false>(fi, fo);
+#pragma unroll
+                        for (int c = 0; c < NO; c++) xo[c][j] = fo[c];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NO; c++)
+                    *reinterpret_cast<float4*>(&tout[(c * 64 + lane) * TILE_STRIDE + i4]) =
+                        make_float4(xo[c][0], xo[c][1], xo[c][2], xo[c][3]);
+            }
+            __syncthreads();
+            // stage outputs: LDS [ch][voice][frame] -> global [voice][ch][frame]
+#pragma unroll
+            for (int c = 0; c < NO; c++) {
+                for (int r = 0; r < 16; r++) {
+                    const int vr = r * 4 + sub;
+                    const size_t gv = v0 + vr;
+                    if (gv < V) {
+                        float4 x = *reinterpret_cast<const float4*>(&tout[(c * 64 + vr) * TILE_STRIDE + fr]);
+                        float* dst = out + (gv * NO + c) * fstride + t0 + fr;
+                        if (vec && fr + 4 <= ((size + 3) & ~3)) {
+                            *reinterpret_cast<float4*>(dst) = x;
+                        } else {
+                            if (fr + 0 < size) dst[0] = x.x;
+                            if (fr + 1 < size) dst[1] = x.y;
+                            if (fr + 2 < size) dst[2] = x.z;
+                            if (fr + 3 < size) dst[3] = x.w;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (!active) return;
+    }
+
+    VStore<false> st{slots + v, stride, 0};
+    g.visit(st);
+}
+
+// ---- per-kind dispatch table ---------------------------------------------------------------------------------
+struct KindOps {
+    const char* name;
+    int nin, nout;
+    std::vector<SlotInfo> slots;
+    void (*lifecycle)(float* slots, size_t stride, size_t first, size_t count, int op, double sr,
+                      const uint64_t* d_seeds, hipStream_t s);
+    void (*render)(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
+                   int layout, int mode, hipStream_t s);
+};
+
+template <class G>
+void launch_lifecycle(float* slots, size_t stride, size_t first, size_t count, int op, double sr,
+                      const uint64_t* d_seeds, hipStream_t s) {
+    if (count == 0) return;
+    unsigned grid = (unsigned)((count + 63) / 64);
+    hipLaunchKernelGGL((k_lifecycle<G>), dim3(grid), dim3(64), 0, s, slots, stride, first, count, op, sr, d_seeds);
+}
+
+template <class G>
+void launch_render(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
+                   int layout, int mode, hipStream_t s) {
+    if (V == 0 || T == 0) return;
+    unsigned grid = (unsigned)((V + 63) / 64);
+    dim3 g(grid), b(64);
+    if (layout == LAYOUT_VOICE_MINOR) {
+        if (mode == MODE_PROCESS)
+            hipLaunchKernelGGL((k_render<G, MODE_PROCESS, LAYOUT_VOICE_MINOR>), g, b, 0, s, slots, stride, V, in, out, T, fstride);
+        else
+            hipLaunchKernelGGL((k_render<G, MODE_TICK, LAYOUT_VOICE_MINOR>), g, b, 0, s, slots, stride, V, in, out, T, fstride);
+    } else {
+        if (mode == MODE_PROCESS)
+            hipLaunchKernelGGL((k_render<G, MODE_PROCESS, LAYOUT_PLANAR>), g, b, 0, s, slots, stride, V, in, out, T, fstride);
+        else
+            hipLaunchKernelGGL((k_render<G, MODE_TICK, LAYOUT_PLANAR>), g, b, 0, s, slots, stride, V, in, out, T, fstride);
+    }
+}
+
+template <class G>
+KindOps make_kind(const char* name) {
+    KindOps k;
+    k.name = name;
+    k.nin = G::IN;
+    k.nout = G::OUT;
+    G g{};
+    VDescribe d{&k.slots, {}};
+    g.visit(d);
+    k.lifecycle = &launch_lifecycle<G>;
+    k.render = &launch_render<G>;
+    return k;
+}
+
+void register_leaf_kinds(std::vector<KindOps>& out);
+void register_graph_kinds(std::vector<KindOps>& out);
+
+}  // namespace fd

@@ -1,0 +1,24 @@
+// fd_kinds_leaf.hip -- bank kernels for single leaf nodes (each replaces that node's AudioNode::process).
+#include "fd_engine.hpp"
+
+namespace fd {
+void register_leaf_kinds(std::vector<KindOps>& out) {
+    out.push_back(make_kind<Pass>("pass"));
+    out.push_back(make_kind<Sine>("sine"));
+    out.push_back(make_kind<Noise>("noise"));
+    out.push_back(make_kind<FixedSvf>("fixed_svf"));
+    out.push_back(make_kind<Svf<3>>("svf3"));
+    out.push_back(make_kind<Svf<4>>("svf4"));
+    out.push_back(make_kind<Biquad>("biquad"));
+    out.push_back(make_kind<BiquadT<98>>("biquad_bank"));
+    out.push_back(make_kind<ButterLowpass<1>>("butterpass_hz"));
+    out.push_back(make_kind<ButterLowpass<2>>("butterpass"));
+    out.push_back(make_kind<Resonator<1>>("resonator_hz"));
+    out.push_back(make_kind<Resonator<3>>("resonator"));
+    out.push_back(make_kind<Moog<1>>("moog_hz"));
+    out.push_back(make_kind<Moog<3>>("moog"));
+    out.push_back(make_kind<Fir<2>>("fir2"));
+    out.push_back(make_kind<Fir<3>>("fir3"));
+    out.push_back(make_kind<Tick<1>>("tick"));
+}
+}  // namespace fd

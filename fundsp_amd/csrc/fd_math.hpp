@@ -1,0 +1,358 @@
+// fd_math.hpp -- numeric substrate of the MI355X voice-bank engine (host + gfx950 device).
+//
+// FunDSP's scalar `Float`/`Real` traits dispatch f32 math to the `libm` crate and its SIMD block path to
+// `wide::f32x8` (reference src/lib.rs:180-222, 296-335, 444-492, 596-670, 773-798).  To be sample-compatible
+// with the reference's CPU `tick`/`process` the engine evaluates the SAME published algorithms instead of the
+// GPU's own approximations (`__sinf`, `v_sin_f32` ...):
+//   * libm 0.2 = musl/FreeBSD msun: sinf/cosf/tanf reduce by quadrant and evaluate the double-precision
+//     kernels __sindf/__cosdf/__tandf; tanhf is built on expm1f.
+//   * wide f32x8::sin = Agner Fog vectorclass sincos_f (Cody-Waite reduction + Cephes f32 polynomials),
+//     unfused mul/add (default x86-64 build has no `fma` target feature).
+// The f64 kernels cost 2x an f32 VALU op on CDNA4 (FP64 vector = half rate) and only run in `tick` mode and in
+// coefficient updates; the block (`process`) path of Sine uses the all-f32 wide polynomial.
+//
+// Every function is written branch-light for wave64 execution: lanes of one wave hold different voices, so
+// range selection is done with selects on a shared evaluation instead of divergent branches.
+// Build with -ffp-contract=off: Rust never contracts a*b+c and parity with the CPU path depends on it.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FD_HD __host__ __device__ __forceinline__
+
+namespace fd {
+
+constexpr float F32_PI = 3.14159274101257324f;   // core::f32::consts::PI
+constexpr float F32_TAU = 6.28318548202514648f;  // core::f32::consts::TAU
+constexpr float F32_SQRT_2 = 1.41421353816986084f;
+
+FD_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+FD_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// ---- musl k_sinf.c / k_cosf.c / k_tanf.c ---------------------------------------------------------------
+constexpr double S1 = -0x15555554cbac77.0p-55, S2 = 0x111110896efbb2.0p-59, S3 = -0x1a00f9e2cae774.0p-65,
+                 S4 = 0x16cd878c3b46a7.0p-71;
+constexpr double C0 = -0x1ffffffd0c5e81.0p-54, C1 = 0x155553e1053a42.0p-57, C2 = -0x16c087e80f1e27.0p-62,
+                 C3 = 0x199342e0ee5069.0p-68;
+
+FD_HD float k_sindf(double x) {
+    double z = x * x;
+    double w = z * z;
+    double r = S3 + z * S4;
+    double s = z * x;
+    return (float)((x + s * (S1 + z * S2)) + s * w * r);
+}
+FD_HD float k_cosdf(double x) {
+    double z = x * x;
+    double w = z * z;
+    double r = C2 + z * C3;
+    return (float)(((1.0 + z * C0) + w * C1) + (w * z) * r);
+}
+FD_HD float k_tandf(double x, bool odd) {
+    constexpr double T0 = 0x15554d3418c99f.0p-54, T1 = 0x1112fd38999f72.0p-55, T2 = 0x1b54c91d865afe.0p-57,
+                     T3 = 0x191df3908c33ce.0p-58, T4 = 0x185dadfcecf44e.0p-61, T5 = 0x1362b9bf971bcd.0p-59;
+    double z = x * x;
+    double r = T4 + z * T5;
+    double t = T2 + z * T3;
+    double w = z * z;
+    double s = z * x;
+    double u = T0 + z * T1;
+    r = (x + s * u) + (s * w) * (t + w * r);
+    return (float)(odd ? -1.0 / r : r);
+}
+
+constexpr double PIO2 = 1.570796326794896558e+00;  // M_PI_2
+
+// musl __rem_pio2f, medium branch (|x| < 2^28*pi/2).  Hot-path arguments never leave [0, 2*pi].
+FD_HD int rem_pio2f(float x, double* y) {
+    constexpr double toint = 1.5 / 2.22044604925031308085e-16, invpio2 = 6.36619772367581382433e-01,
+                     pio2_1 = 1.57079631090164184570e+00, pio2_1t = 1.58932547735281966916e-08;
+    double fn = (double)x * invpio2 + toint - toint;
+    int n = (int32_t)fn;
+    *y = x - fn * pio2_1 - fn * pio2_1t;
+    return n;
+}
+
+// Quadrant decode shared by sinf/cosf/tanf: k = number of pi/2 steps removed (0..4) for |x| <= 9pi/4,
+// y = reduced argument carrying the sign handling of musl's explicit cases.
+struct quad {
+    double y;
+    int k;
+    bool sign, small, big;
+};
+FD_HD quad quad_reduce(float x) {
+    quad q;
+    uint32_t ix = f2u(x);
+    q.sign = (ix >> 31) != 0;
+    ix &= 0x7fffffffu;
+    q.small = ix < 0x39800000u;  // |x| < 2**-12
+    q.big = ix > 0x40e231d5u;    // |x| > 9*pi/4 (or inf/nan)
+    int k = (ix > 0x3f490fdau) + (ix > 0x4016cbe3u) + (ix > 0x407b53d1u) + (ix > 0x40afeddfu);
+    double c = (double)k * PIO2;  // k*M_PI_2 rounded once, identical to musl's compile-time s{k}pio2 constants
+    q.k = k;
+    q.y = k == 0 ? (double)x : (q.sign ? (double)x + c : (double)x - c);
+    return q;
+}
+
+// musl sinf.c
+FD_HD float sinf_musl(float x) {
+    quad q = quad_reduce(x);
+    if (__builtin_expect(q.big, 0)) {
+        uint32_t ix = f2u(x) & 0x7fffffffu;
+        if (ix >= 0x7f800000u) return x - x;
+        double y;
+        int n = rem_pio2f(x, &y);
+        switch (n & 3) {
+        case 0: return k_sindf(y);
+        case 1: return k_cosdf(y);
+        case 2: return k_sindf(-y);
+        default: return -k_cosdf(y);
+        }
+    }
+    // k=0: sindf(x); k=1: sign ? -cosdf(y) : cosdf(y); k=2: sindf(-y); k=3: sign ? cosdf(y) : -cosdf(y); k=4: sindf(y)
+    double a = q.k == 2 ? -q.y : q.y;
+    float s = k_sindf(a);
+    float c = k_cosdf(a);
+    bool use_cos = (q.k & 1) != 0;
+    bool neg = use_cos && ((q.k == 1) == q.sign);
+    float r = use_cos ? c : s;
+    r = neg ? -r : r;
+    return q.small ? x : r;
+}
+
+// musl cosf.c
+FD_HD float cosf_musl(float x) {
+    quad q = quad_reduce(x);
+    if (__builtin_expect(q.big, 0)) {
+        uint32_t ix = f2u(x) & 0x7fffffffu;
+        if (ix >= 0x7f800000u) return x - x;
+        double y;
+        int n = rem_pio2f(x, &y);
+        switch (n & 3) {
+        case 0: return k_cosdf(y);
+        case 1: return k_sindf(-y);
+        case 2: return -k_cosdf(y);
+        default: return k_sindf(y);
+        }
+    }
+    // k=0: cosdf(x); k=1: sign ? sindf(x+c) : sindf(c-x); k=2: -cosdf(y); k=3: sign ? sindf(-x-c) : sindf(x-c); k=4: cosdf(y)
+    double a = q.y;
+    if (q.k == 1) a = q.sign ? q.y : -q.y;
+    if (q.k == 3) a = q.sign ? -q.y : q.y;
+    float s = k_sindf(a);
+    float c = k_cosdf(a);
+    bool use_sin = (q.k & 1) != 0;
+    float r = use_sin ? s : (q.k == 2 ? -c : c);
+    return q.small ? 1.0f : r;
+}
+
+// musl tanf.c
+FD_HD float tanf_musl(float x) {
+    quad q = quad_reduce(x);
+    if (__builtin_expect(q.big, 0)) {
+        uint32_t ix = f2u(x) & 0x7fffffffu;
+        if (ix >= 0x7f800000u) return x - x;
+        double y;
+        int n = rem_pio2f(x, &y);
+        return k_tandf(y, (n & 1) != 0);
+    }
+    float r = k_tandf(q.y, (q.k & 1) != 0);
+    return q.small ? x : r;
+}
+
+// musl expm1f.c
+FD_HD float expm1f_musl(float x) {
+    constexpr float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, invln2 = 1.4426950216e+00f,
+                    Q1 = -3.3333212137e-2f, Q2 = 1.5807170421e-3f;
+    float y, hi, lo, c = 0.0f, t, e, hxs, hfx, r1, twopk;
+    uint32_t ui = f2u(x);
+    uint32_t hx = ui & 0x7fffffffu;
+    int k;
+    bool sign = (ui >> 31) != 0;
+    if (hx >= 0x4195b844u) {  // |x| >= 27*ln2
+        if (hx > 0x7f800000u) return x;
+        if (sign) return -1.0f;
+        if (x > 8.8721679688e+01f) {
+            x *= 0x1p127f;
+            return x;
+        }
+    }
+    if (hx > 0x3eb17218u) {      // |x| > 0.5 ln2
+        if (hx < 0x3F851592u) {  // |x| < 1.5 ln2
+            if (!sign) {
+                hi = x - ln2_hi;
+                lo = ln2_lo;
+                k = 1;
+            } else {
+                hi = x + ln2_hi;
+                lo = -ln2_lo;
+                k = -1;
+            }
+        } else {
+            k = (int)(invln2 * x + (sign ? -0.5f : 0.5f));
+            t = (float)k;
+            hi = x - t * ln2_hi;
+            lo = t * ln2_lo;
+        }
+        x = hi - lo;
+        c = (hi - x) - lo;
+    } else if (hx < 0x33000000u) {
+        return x;
+    } else
+        k = 0;
+    hfx = 0.5f * x;
+    hxs = x * hfx;
+    r1 = 1.0f + hxs * (Q1 + hxs * Q2);
+    t = 3.0f - r1 * hfx;
+    e = hxs * ((r1 - t) / (6.0f - x * t));
+    if (k == 0) return x - (x * e - hxs);
+    e = x * (e - c) - c;
+    e -= hxs;
+    if (k == -1) return 0.5f * (x - e) - 0.5f;
+    if (k == 1) {
+        if (x < -0.25f) return -2.0f * (e - (x + 0.5f));
+        return 1.0f + 2.0f * (x - e);
+    }
+    twopk = u2f((uint32_t)(0x7f + k) << 23);
+    if (k < 0 || k > 56) {
+        y = x - e + 1.0f;
+        if (k == 128)
+            y = y * 2.0f * 0x1p127f;
+        else
+            y = y * twopk;
+        return y - 1.0f;
+    }
+    float uf = u2f((uint32_t)(0x7f - k) << 23);
+    if (k < 23)
+        y = (x - e + (1 - uf)) * twopk;
+    else
+        y = (x - (e + uf) + 1) * twopk;
+    return y;
+}
+
+// musl tanhf.c
+FD_HD float tanhf_musl(float x) {
+    uint32_t w = f2u(x);
+    bool sign = (w >> 31) != 0;
+    float t;
+    w &= 0x7fffffffu;
+    x = u2f(w);
+    if (w > 0x3f0c9f54u) {
+        if (w > 0x41200000u) {
+            t = 1 + 0 / x;
+        } else {
+            t = expm1f_musl(2 * x);
+            t = 1 - 2 / (t + 2);
+        }
+    } else if (w > 0x3e82c578u) {
+        t = expm1f_musl(2 * x);
+        t = t / (t + 2);
+    } else if (w >= 0x00800000u) {
+        t = expm1f_musl(-2 * x);
+        t = -t / (t + 2);
+    } else {
+        t = x;
+    }
+    return sign ? -t : t;
+}
+
+// libm 0.2 scalbnf for the normal range used by expf (|k| small)
+FD_HD float scalbnf_small(float y, int k) { return y * u2f((uint32_t)(0x7f + k) << 23); }
+
+// musl expf.c (2018, FreeBSD e_expf.c)
+FD_HD float expf_musl(float x) {
+    constexpr float ln2hi = 6.9314575195e-1f, ln2lo = 1.4286067653e-6f, invln2 = 1.4426950216e+0f,
+                    P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
+    float hi, lo, c, xx, y;
+    int k;
+    uint32_t hx = f2u(x);
+    int sign = (int)(hx >> 31);
+    hx &= 0x7fffffffu;
+    if (hx >= 0x42aeac50u) {
+        if (hx > 0x7f800000u) return x;
+        if (hx >= 0x42b17218u && !sign) {
+            x *= 0x1p127f;
+            return x;
+        }
+        if (sign && hx >= 0x42cff1b5u) return 0.0f;
+    }
+    if (hx > 0x3eb17218u) {
+        if (hx > 0x3f851592u)
+            k = (int)(invln2 * x + (sign ? -0.5f : 0.5f));
+        else
+            k = 1 - sign - sign;
+        hi = x - k * ln2hi;
+        lo = k * ln2lo;
+        x = hi - lo;
+    } else if (hx > 0x39000000u) {
+        k = 0;
+        hi = x;
+        lo = 0;
+    } else {
+        return 1 + x;
+    }
+    xx = x * x;
+    c = x - xx * (P1 + xx * P2);
+    y = 1 + (x * c / (2 - c) - lo + hi);
+    if (k == 0) return y;
+    if (k > -126 && k < 128) return scalbnf_small(y, k);
+    // subnormal / overflow tails: two-step scaling like scalbnf
+    float s1 = scalbnf_small(y, k / 2);
+    return scalbnf_small(s1, k - k / 2);
+}
+
+// ---- wide f32x8::sin, one lane (all f32, unfused) --------------------------------------------------------
+FD_HD float wide_sinf(float self) {
+    constexpr float DP1F = 0.78515625f * 2.0f;
+    constexpr float DP2F = 2.4187564849853515625E-4f * 2.0f;
+    constexpr float DP3F = 3.77489497744594108E-8f * 2.0f;
+    constexpr float P0sinf = -1.6666654611E-1f, P1sinf = 8.3321608736E-3f, P2sinf = -1.9515295891E-4f;
+    constexpr float P0cosf = 4.166664568298827E-2f, P1cosf = -1.388731625493765E-3f, P2cosf = 2.443315711809948E-5f;
+    constexpr float TWO_OVER_PI = 2.0f / 3.14159274101257324f;
+    float xa = __builtin_fabsf(self);
+    float y = __builtin_rintf(xa * TWO_OVER_PI);  // round half to even (v_rndne_f32)
+    int32_t q = (int32_t)y;
+    float x = xa - y * DP1F;
+    x = x - y * DP2F;
+    x = x - y * DP3F;
+    float x2 = x * x;
+    float x4 = x2 * x2;
+    float s = (x4 * P2sinf + (x2 * P1sinf + P0sinf)) * (x * x2) + x;
+    float c = (x4 * P2cosf + (x2 * P1cosf + P0cosf)) * (x2 * x2) + (1.0f - 0.5f * x2);
+    bool overflow = (q > 0x2000000) && (xa < __builtin_inff());
+    s = overflow ? 0.0f : s;
+    c = overflow ? 1.0f : c;
+    float sin1 = (q & 1) ? c : s;
+    uint32_t sign_sin = ((uint32_t)q << 30) ^ f2u(self);
+    return u2f(f2u(sin1) ^ (sign_sin & 0x80000000u));
+}
+
+// ---- integer hashing (bit-exact) -------------------------------------------------------------------------
+FD_HD double rnd1(uint64_t x) {  // math.rs:569-576
+    x = x ^ 0x5555555555555555ULL;
+    x = x * 0x9e3779b97f4a7c15ULL;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    x = x ^ (x >> 31);
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+FD_HD uint64_t hash1(uint64_t x) {  // math.rs:592-599
+    x = x ^ 0x5555555555555555ULL;
+    x = x * 0x517cc1b727220a95ULL;
+    x = (x ^ (x >> 32)) * 0xd6e8feb86659fd93ULL;
+    x = (x ^ (x >> 32)) * 0xd6e8feb86659fd93ULL;
+    return x ^ (x >> 32);
+}
+FD_HD uint64_t atto(uint64_t state, uint64_t data) {  // AttoHash::hash math.rs:649-658
+    uint64_t r = (state << 5) | (state >> 59);
+    return (r ^ data) * 0x517cc1b727220a95ULL;
+}
+FD_HD uint32_t hash32x(uint32_t x) {  // noise.rs:154-158
+    constexpr uint32_t MUL_X = 0x45d9f3b;
+    x = (x ^ (x >> 16)) * MUL_X;
+    x = (x ^ (x >> 16)) * MUL_X;
+    return (x ^ (x >> 16)) * MUL_X;
+}
+
+}  // namespace fd

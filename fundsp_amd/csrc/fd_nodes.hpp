@@ -1,0 +1,642 @@
+// fd_nodes.hpp -- device-side node library of the MI355X voice-bank engine.
+//
+// One wavefront lane evaluates one voice.  A voice graph is a C++ type built from the templates below, which
+// mirror FunDSP's statically typed combinator tree (reference src/audionode.rs: Pipe :1375, Stack :1496,
+// Binop :850, Unop :1232, Constant :465) and its leaf DSP nodes.  Because the whole tree is one type, the
+// compiler fuses a voice into straight-line VALU code with every per-voice coefficient and every piece of
+// IIR state held in VGPRs for the whole launch -- the block temporaries (`BufferArray`) the CPU combinators
+// pass through memory never exist here.
+//
+// Per-voice data lives in HBM as a structure of arrays `slots[slot][voice]`; every node enumerates its fields
+// through `visit(v)` in a fixed order, so one visitor pattern provides coalesced load / store of the lane's
+// registers, host-side introspection (slot names) and state snapshots (FunDSP nodes are `Clone`).
+//
+// Semantics per node follow the reference `tick` (scalar path) and, where the reference overrides it with a
+// different arithmetic, its `process` (block path): `step<true>` = sample inside a full 8-sample SIMD item of
+// a block, `step<false>` = per-sample `tick` (block remainder, or tick mode).  Citations are reference file:line.
+#pragma once
+
+#include "fd_math.hpp"
+
+#define FD_D __device__ __forceinline__
+
+namespace fd {
+
+enum FieldKind { PARAM = 0, COEF = 1, STATE = 2 };
+
+constexpr int SVF_LOWPASS = 0, SVF_HIGHPASS = 1, SVF_BANDPASS = 2, SVF_NOTCH = 3, SVF_PEAK = 4, SVF_ALLPASS = 5,
+              SVF_BELL = 6, SVF_LOWSHELF = 7, SVF_HIGHSHELF = 8;
+
+// ---------------------------------------------------------------------------------------------------------
+// shared coefficient math (host + device): the C ABI exposes the same constructors to host callers
+// ---------------------------------------------------------------------------------------------------------
+struct SvfCoefs { float a1, a2, a3, m0, m1, m2; };
+struct BiquadCoefs { float a1, a2, b0, b1, b2; };
+
+// SvfCoefs::{lowpass .. highshelf}  svf.rs:28-221
+FD_HD SvfCoefs svf_coefs(int mode, float sr, float cutoff, float q, float gain) {
+    SvfCoefs c;
+    float t = tanf_musl(F32_PI * cutoff / sr);
+    float a = 0.0f, g = t, k = 1.0f / q;
+    if (mode >= SVF_BELL) {
+        a = __builtin_sqrtf(gain);
+        if (mode == SVF_BELL) k = 1.0f / (q * a);
+        if (mode == SVF_LOWSHELF) g = t / __builtin_sqrtf(a);
+        if (mode == SVF_HIGHSHELF) g = t * __builtin_sqrtf(a);
+    }
+    c.a1 = 1.0f / (1.0f + g * (g + k));
+    c.a2 = g * c.a1;
+    c.a3 = g * c.a2;
+    switch (mode) {
+    case SVF_LOWPASS: c.m0 = 0.0f; c.m1 = 0.0f; c.m2 = 1.0f; break;
+    case SVF_HIGHPASS: c.m0 = 1.0f; c.m1 = -k; c.m2 = -1.0f; break;
+    case SVF_BANDPASS: c.m0 = 0.0f; c.m1 = 1.0f; c.m2 = 0.0f; break;
+    case SVF_NOTCH: c.m0 = 1.0f; c.m1 = -k; c.m2 = 0.0f; break;
+    case SVF_PEAK: c.m0 = 1.0f; c.m1 = -k; c.m2 = -2.0f; break;
+    case SVF_ALLPASS: c.m0 = 1.0f; c.m1 = -2.0f * k; c.m2 = 0.0f; break;
+    case SVF_BELL: c.m0 = 1.0f; c.m1 = k * (a * a - 1.0f); c.m2 = 0.0f; break;
+    case SVF_LOWSHELF: c.m0 = 1.0f; c.m1 = k * (a - 1.0f); c.m2 = a * a - 1.0f; break;
+    default: c.m0 = a * a; c.m1 = k * (1.0f - a) * a; c.m2 = 1.0f - a * a; break;
+    }
+    return c;
+}
+
+// BiquadCoefs::{butter_lowpass, resonator, lowpass, highpass, bell}  biquad.rs:27-116
+constexpr int BQ_BUTTER = 0, BQ_RESONATOR = 1, BQ_LOWPASS = 2, BQ_HIGHPASS = 3, BQ_BELL = 4;
+FD_HD BiquadCoefs biquad_coefs(int kind, float sr, float f0, float q, float gain) {
+    BiquadCoefs c;
+    if (kind == BQ_BUTTER) {
+        float f = tanf_musl(f0 * F32_PI / sr);
+        float a0r = 1.0f / (1.0f + F32_SQRT_2 * f + f * f);
+        c.a1 = (2.0f * f * f - 2.0f) * a0r;
+        c.a2 = (1.0f - F32_SQRT_2 * f + f * f) * a0r;
+        c.b0 = f * f * a0r;
+        c.b1 = 2.0f * c.b0;
+        c.b2 = c.b0;
+        return c;
+    }
+    if (kind == BQ_RESONATOR) {
+        float r = expf_musl(-F32_PI * f0 / (q * sr));
+        c.a1 = -2.0f * r * cosf_musl(F32_TAU * f0 / sr);
+        c.a2 = r * r;
+        c.b0 = __builtin_sqrtf(1.0f - r * r) * 0.5f;
+        c.b1 = 0.0f;
+        c.b2 = -c.b0;
+        return c;
+    }
+    float omega = F32_TAU * f0 / sr;
+    float alpha = sinf_musl(omega) / (2.0f * q);
+    float beta = cosf_musl(omega);
+    if (kind == BQ_LOWPASS) {
+        float a0r = 1.0f / (1.0f + alpha);
+        c.a1 = -2.0f * beta * a0r;
+        c.a2 = (1.0f - alpha) * a0r;
+        c.b1 = (1.0f - beta) * a0r;
+        c.b0 = c.b1 * 0.5f;
+        c.b2 = c.b0;
+    } else if (kind == BQ_HIGHPASS) {
+        float a0r = 1.0f / (1.0f + alpha);
+        c.a1 = -2.0f * beta * a0r;
+        c.a2 = (1.0f - alpha) * a0r;
+        c.b0 = (1.0f + beta) * 0.5f * a0r;
+        c.b1 = (-1.0f - beta) * a0r;
+        c.b2 = c.b0;
+    } else {
+        float a = __builtin_sqrtf(gain);
+        float a0r = 1.0f / (1.0f + alpha / a);
+        c.a1 = -2.0f * beta * a0r;
+        c.a2 = (1.0f - alpha / a) * a0r;
+        c.b0 = (1.0f + alpha * a) * a0r;
+        c.b1 = c.a1;
+        c.b2 = (1.0f - alpha * a) * a0r;
+    }
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// leaves
+// ---------------------------------------------------------------------------------------------------------
+
+// Constant<N>  audionode.rs:465-523 (ID 2).  The value is per voice.
+template <int N>
+struct Constant {
+    static constexpr int IN = 0, OUT = N;
+    static constexpr uint64_t ID = 2;
+    float value[N];
+    template <class V> FD_HD void visit(V& v) {
+        _Pragma("unroll") for (int i = 0; i < N; i++) v.fi(value[i], PARAM, "value", i);
+    }
+    FD_HD void init() {
+        for (int i = 0; i < N; i++) value[i] = 0.0f;
+    }
+    FD_HD void update(double) {}
+    FD_HD void reset() {}
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void end_simd() {}
+    template <bool SIMD> FD_HD void step(const float*, float* out) {
+        for (int i = 0; i < N; i++) out[i] = value[i];
+    }
+};
+
+// Pass  audionode.rs:408-436 (ID 48)
+struct Pass {
+    static constexpr int IN = 1, OUT = 1;
+    static constexpr uint64_t ID = 48;
+    template <class V> FD_HD void visit(V&) {}
+    FD_HD void init() {}
+    FD_HD void update(double) {}
+    FD_HD void reset() {}
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void end_simd() {}
+    template <bool SIMD> FD_HD void step(const float* in, float* out) { out[0] = in[0]; }
+};
+
+// Sine<f32>  oscillator.rs:21-102 (ID 21)
+struct Sine {
+    static constexpr int IN = 1, OUT = 1;
+    static constexpr uint64_t ID = 21;
+    float phase, sample_duration, has_phase, initial_phase;
+    uint64_t hash;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(phase, STATE, "phase");
+        v.f(sample_duration, COEF, "sample_duration");
+        v.f(has_phase, PARAM, "has_initial_phase");
+        v.f(initial_phase, PARAM, "initial_phase");
+        v.u64(hash, STATE, "hash");
+    }
+    FD_HD void init() {  // Sine::new :30-35 (Default -> hash 0, no initial phase; reset; sr = 44100 via update)
+        has_phase = 0.0f;
+        initial_phase = 0.0f;
+        hash = 0;
+        reset();
+    }
+    FD_HD void update(double sr) { sample_duration = (float)(1.0 / sr); }                   // :62-64
+    FD_HD void reset() { phase = has_phase != 0.0f ? initial_phase : (float)rnd1(hash); }  // :55-60
+    FD_HD uint64_t ping(bool probe, uint64_t h) {                                            // audionode.rs:156-161
+        if (!probe) {  // set_hash :94-97
+            hash = h;
+            reset();
+        }
+        return atto(h, ID);
+    }
+    FD_HD void end_simd() { phase = phase - __builtin_floorf(phase); }  // :85 (one wrap after the SIMD items)
+    template <bool SIMD> FD_HD void step(const float* in, float* out) {
+        if (SIMD) {  // process :74-86: phase runs unwrapped inside the block, f32x8 (wide) sin
+            float tmp = phase;
+            phase += in[0] * sample_duration;
+            out[0] = wide_sinf(tmp * F32_TAU);
+        } else {  // tick :67-72: wrapped phase, libm sinf
+            float p = phase;
+            phase += in[0] * sample_duration;
+            phase -= __builtin_floorf(phase);
+            out[0] = sinf_musl(p * F32_TAU);
+        }
+    }
+};
+
+// Noise  noise.rs:173-234 (ID 20).  Integer-exact; process == tick sample for sample.
+struct Noise {
+    static constexpr int IN = 0, OUT = 1;
+    static constexpr uint64_t ID = 20;
+    uint32_t state;
+    float has_seed;
+    uint64_t seed, hash;
+    template <class V> FD_HD void visit(V& v) {
+        v.u32(state, STATE, "state");
+        v.f(has_seed, PARAM, "has_seed");
+        v.u64(seed, PARAM, "seed");
+        v.u64(hash, STATE, "hash");
+    }
+    FD_HD void init() {  // Noise::new = Default :179-183 (state 0 until pinged or reset)
+        state = 0;
+        has_seed = 0.0f;
+        seed = 0;
+        hash = 0;
+    }
+    FD_HD void update(double) {}
+    FD_HD void reset() {  // :192-195
+        uint64_t h = has_seed != 0.0f ? seed : hash;
+        state = (uint32_t)(h ^ (h >> 32));
+    }
+    FD_HD uint64_t ping(bool probe, uint64_t h) {
+        if (!probe) {  // set_hash :226-229
+            hash = h;
+            reset();
+        }
+        return atto(h, ID);
+    }
+    FD_HD void end_simd() {}
+    template <bool SIMD> FD_HD void step(const float*, float* out) {  // :197-202
+        state += 1u;
+        out[0] = (float)(hash32x(state) >> 8) * (2.0f / (float)((1 << 24) - 1)) - 1.0f;
+    }
+};
+
+// SVF core shared by FixedSvf and Svf:  svf.rs:995-1006 / :829-843
+struct SvfCore {
+    float a1, a2, a3, m0, m1, m2, ic1eq, ic2eq;
+    FD_HD float tick(float v0) {
+        float v3 = v0 - ic2eq;
+        float v1 = a1 * ic1eq + a2 * v3;
+        float v2 = ic2eq + a2 * ic1eq + a3 * v3;
+        ic1eq = 2.0f * v1 - ic1eq;
+        ic2eq = 2.0f * v2 - ic2eq;
+        return m0 * v0 + m1 * v1 + m2 * v2;
+    }
+    FD_HD void set(const SvfCoefs& c) {
+        a1 = c.a1; a2 = c.a2; a3 = c.a3; m0 = c.m0; m1 = c.m1; m2 = c.m2;
+    }
+};
+
+// FixedSvf<f32, M>  svf.rs:861-1031 (ID 43).  The mode is a per-voice parameter: the recurrence is mode
+// independent (17 flops with generic m0..m2, exactly the reference arithmetic); only `update` branches on it.
+struct FixedSvf {
+    static constexpr int IN = 1, OUT = 1;
+    static constexpr uint64_t ID = 43;
+    float mode, cutoff, q, gain, sr;
+    SvfCore c;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(mode, PARAM, "mode");
+        v.f(cutoff, PARAM, "cutoff");
+        v.f(q, PARAM, "q");
+        v.f(gain, PARAM, "gain");
+        v.f(sr, COEF, "sample_rate");
+        v.f(c.a1, COEF, "a1"); v.f(c.a2, COEF, "a2"); v.f(c.a3, COEF, "a3");
+        v.f(c.m0, COEF, "m0"); v.f(c.m1, COEF, "m1"); v.f(c.m2, COEF, "m2");
+        v.f(c.ic1eq, STATE, "ic1eq");
+        v.f(c.ic2eq, STATE, "ic2eq");
+    }
+    FD_HD void init() {
+        mode = (float)SVF_LOWPASS; cutoff = 440.0f; q = 1.0f; gain = 1.0f;
+        c.ic1eq = 0.0f; c.ic2eq = 0.0f;
+    }
+    FD_HD void update(double sample_rate) {  // set_sample_rate :989-992 -> update_frequency -> update :236-239
+        sr = (float)sample_rate;
+        c.set(svf_coefs((int)mode, sr, cutoff, q, gain));
+    }
+    FD_HD void reset() { c.ic1eq = 0.0f; c.ic2eq = 0.0f; }  // :984-987
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void end_simd() {}
+    template <bool SIMD> FD_HD void step(const float* in, float* out) { out[0] = c.tick(in[0]); }
+};
+
+// Svf<f32, M> with parameter inputs  svf.rs:748-855 (ID 36).  NIN = 3 (audio, cutoff, q) or 4 (+ gain).
+template <int NIN>
+struct Svf {
+    static constexpr int IN = NIN, OUT = 1;
+    static constexpr uint64_t ID = 36;
+    float mode, cutoff, q, gain, sr;
+    SvfCore c;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(mode, PARAM, "mode");
+        v.f(cutoff, STATE, "cutoff");
+        v.f(q, STATE, "q");
+        v.f(gain, STATE, "gain");
+        v.f(sr, COEF, "sample_rate");
+        v.f(c.a1, STATE, "a1"); v.f(c.a2, STATE, "a2"); v.f(c.a3, STATE, "a3");
+        v.f(c.m0, STATE, "m0"); v.f(c.m1, STATE, "m1"); v.f(c.m2, STATE, "m2");
+        v.f(c.ic1eq, STATE, "ic1eq");
+        v.f(c.ic2eq, STATE, "ic2eq");
+    }
+    FD_HD void init() {
+        mode = (float)(NIN == 4 ? SVF_BELL : SVF_LOWPASS); cutoff = 440.0f; q = 1.0f; gain = 1.0f;
+        c.ic1eq = 0.0f; c.ic2eq = 0.0f;
+    }
+    FD_HD void update(double sample_rate) {  // :823-826
+        sr = (float)sample_rate;
+        c.set(svf_coefs((int)mode, sr, cutoff, q, gain));
+    }
+    FD_HD void reset() { c.ic1eq = 0.0f; c.ic2eq = 0.0f; }  // :818-821
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void end_simd() {}
+    template <bool SIMD> FD_HD void step(const float* in, float* out) {
+        // update_inputs :299-313 (3 inputs) / :588-606 (4 inputs): recompute only when an input changed
+        bool changed = in[1] != cutoff || in[2] != q;
+        if (NIN == 4) changed = changed || in[3] != gain;
+        if (changed) {
+            cutoff = in[1];
+            q = in[2];
+            if (NIN == 4) gain = in[3];
+            c.set(svf_coefs((int)mode, sr, cutoff, q, gain));
+        }
+        out[0] = c.tick(in[0]);
+    }
+};
+
+// Biquad<f32>  biquad.rs:136-218 (ID 15): DF1, coefficients are raw parameters (set_sample_rate keeps them).
+// One lane of BiquadBank<f32x8> (biquad_bank.rs:73-84, ID 98) performs exactly this arithmetic.
+template <uint64_t NODE_ID>
+struct BiquadT {
+    static constexpr int IN = 1, OUT = 1;
+    static constexpr uint64_t ID = NODE_ID;
+    float a1, a2, b0, b1, b2, x1, x2, y1, y2;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(a1, PARAM, "a1"); v.f(a2, PARAM, "a2");
+        v.f(b0, PARAM, "b0"); v.f(b1, PARAM, "b1"); v.f(b2, PARAM, "b2");
+        v.f(x1, STATE, "x1"); v.f(x2, STATE, "x2"); v.f(y1, STATE, "y1"); v.f(y2, STATE, "y2");
+    }
+    FD_HD void init() { a1 = a2 = b0 = b1 = b2 = 0.0f; reset(); }
+    FD_HD void update(double) {}                        // :179-181
+    FD_HD void reset() { x1 = x2 = y1 = y2 = 0.0f; }   // :172-177
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void end_simd() {}
+    FD_HD float tick(float x0) {  // :184-194
+        float y0 = b0 * x0 + b1 * x1 + b2 * x2 - a1 * y1 - a2 * y2;
+        x2 = x1;
+        x1 = x0;
+        y2 = y1;
+        y1 = y0;
+        return y0;
+    }
+    template <bool SIMD> FD_HD void step(const float* in, float* out) { out[0] = tick(in[0]); }
+};
+using Biquad = BiquadT<15>;
+
+// ButterLowpass<f32, N>  biquad.rs:227-300 (ID 16), N = 1 (fixed) or 2 (cutoff input)
+template <int NIN>
+struct ButterLowpass {
+    static constexpr int IN = NIN, OUT = 1;
+    static constexpr uint64_t ID = 16;
+    float cutoff, sr;
+    Biquad b;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(cutoff, NIN > 1 ? STATE : PARAM, "cutoff");
+        v.f(sr, COEF, "sample_rate");
+        v.f(b.a1, NIN > 1 ? STATE : COEF, "a1"); v.f(b.a2, NIN > 1 ? STATE : COEF, "a2");
+        v.f(b.b0, NIN > 1 ? STATE : COEF, "b0"); v.f(b.b1, NIN > 1 ? STATE : COEF, "b1");
+        v.f(b.b2, NIN > 1 ? STATE : COEF, "b2");
+        v.f(b.x1, STATE, "x1"); v.f(b.x2, STATE, "x2"); v.f(b.y1, STATE, "y1"); v.f(b.y2, STATE, "y2");
+    }
+    FD_HD void set_cutoff(float f) {  // :246-250
+        BiquadCoefs c = biquad_coefs(BQ_BUTTER, sr, f, 0.0f, 0.0f);
+        b.a1 = c.a1; b.a2 = c.a2; b.b0 = c.b0; b.b1 = c.b1; b.b2 = c.b2;
+        cutoff = f;
+    }
+    FD_HD void init() { cutoff = 440.0f; b.init(); }
+    FD_HD void update(double sample_rate) {  // :263-267
+        sr = (float)sample_rate;
+        set_cutoff(cutoff);
+    }
+    FD_HD void reset() { b.reset(); }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void end_simd() {}
+    template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :269-277
+        if (NIN > 1) {
+            if (in[1] != cutoff) set_cutoff(in[1]);
+        }
+        out[0] = b.tick(in[0]);
+    }
+};
+
+// Resonator<f32, N>  biquad.rs:310-380 (ID 17), N = 1 (fixed) or 3 (center, q inputs)
+template <int NIN>
+struct Resonator {
+    static constexpr int IN = NIN, OUT = 1;
+    static constexpr uint64_t ID = 17;
+    float center, q, sr;
+    Biquad b;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(center, NIN > 1 ? STATE : PARAM, "center");
+        v.f(q, NIN > 1 ? STATE : PARAM, "q");
+        v.f(sr, COEF, "sample_rate");
+        v.f(b.a1, NIN > 1 ? STATE : COEF, "a1"); v.f(b.a2, NIN > 1 ? STATE : COEF, "a2");
+        v.f(b.b0, NIN > 1 ? STATE : COEF, "b0"); v.f(b.b1, NIN > 1 ? STATE : COEF, "b1");
+        v.f(b.b2, NIN > 1 ? STATE : COEF, "b2");
+        v.f(b.x1, STATE, "x1"); v.f(b.x2, STATE, "x2"); v.f(b.y1, STATE, "y1"); v.f(b.y2, STATE, "y2");
+    }
+    FD_HD void set_center_q(float c0, float q0) {  // :330-335
+        BiquadCoefs c = biquad_coefs(BQ_RESONATOR, sr, c0, q0, 0.0f);
+        b.a1 = c.a1; b.a2 = c.a2; b.b0 = c.b0; b.b1 = c.b1; b.b2 = c.b2;
+        center = c0;
+        q = q0;
+    }
+    FD_HD void init() { center = 440.0f; q = 1.0f; b.init(); }
+    FD_HD void update(double sample_rate) {  // :349-352
+        sr = (float)sample_rate;
+        set_center_q(center, q);
+    }
+    FD_HD void reset() { b.reset(); }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void end_simd() {}
+    template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :354-366
+        if (NIN >= 3) {
+            if (in[1] != center || in[2] != q) set_center_q(in[1], in[2]);
+        }
+        out[0] = b.tick(in[0]);
+    }
+};
+
+// Moog<f32, N>  moog.rs:17-117 (ID 60).  N = 1 (fixed cutoff/q) or 3 (audio, cutoff Hz, Q inputs; the
+// coefficients including a sinf are then recomputed EVERY sample, unconditionally: moog.rs:83-85).
+template <int NIN>
+struct Moog {
+    static constexpr int IN = NIN, OUT = 1;
+    static constexpr uint64_t ID = 60;
+    float q, cutoff, sr, rez, p, k, s0, s1, s2, s3, px, ps0, ps1, ps2;
+    template <class V> FD_HD void visit(V& v) {
+        constexpr FieldKind PK = NIN > 1 ? STATE : PARAM, CK = NIN > 1 ? STATE : COEF;
+        v.f(cutoff, PK, "cutoff"); v.f(q, PK, "q");
+        v.f(sr, COEF, "sample_rate");
+        v.f(rez, CK, "rez"); v.f(p, CK, "p"); v.f(k, CK, "k");
+        v.f(s0, STATE, "s0"); v.f(s1, STATE, "s1"); v.f(s2, STATE, "s2"); v.f(s3, STATE, "s3");
+        v.f(px, STATE, "px"); v.f(ps0, STATE, "ps0"); v.f(ps1, STATE, "ps1"); v.f(ps2, STATE, "ps2");
+    }
+    FD_HD void set_cutoff_q(float cutoff_, float q_) {  // :48-57
+        cutoff = cutoff_;
+        q = q_;
+        float c = 2.0f * cutoff / sr;
+        p = c * (1.8f - 0.8f * c);
+        k = 2.0f * sinf_musl(c * F32_PI * 0.5f) - 1.0f;
+        float t1 = (1.0f - p) * 1.386249f;
+        float t2 = 12.0f + t1 * t1;
+        rez = q * (t2 + 6.0f * t1) / (t2 - 6.0f * t1);
+    }
+    FD_HD void init() {  // prelude.rs:551-553 moog() = Moog::new(1000.0, 0.1)
+        cutoff = 1000.0f;
+        q = 0.1f;
+        reset();
+    }
+    FD_HD void update(double sample_rate) {  // :76-79
+        sr = (float)sample_rate;
+        set_cutoff_q(cutoff, q);
+    }
+    FD_HD void reset() { s0 = s1 = s2 = s3 = px = ps0 = ps1 = ps2 = 0.0f; }  // :65-74
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void end_simd() {}
+    template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :82-100
+        if (NIN > 1) set_cutoff_q(in[1], in[2]);
+        float x = -rez * s3 + in[0];
+        s0 = (x + px) * p - k * s0;
+        s1 = (s0 + ps0) * p - k * s1;
+        s2 = (s1 + ps1) * p - k * s2;
+        s3 = tanhf_musl((s2 + ps2) * p - k * s3);
+        px = x;
+        ps0 = s0;
+        ps1 = s1;
+        ps2 = s2;
+        out[0] = s3;
+    }
+};
+
+// Fir<N>  fir.rs:14-89 (ID 52)
+template <int N>
+struct Fir {
+    static constexpr int IN = 1, OUT = 1;
+    static constexpr uint64_t ID = 52;
+    float w[N], v[N];
+    template <class V> FD_HD void visit(V& vis) {
+        _Pragma("unroll") for (int i = 0; i < N; i++) vis.fi(w[i], PARAM, "w", i);
+        _Pragma("unroll") for (int i = 0; i < N; i++) vis.fi(v[i], STATE, "v", i);
+    }
+    FD_HD void init() {
+        for (int i = 0; i < N; i++) w[i] = 0.0f;
+        reset();
+    }
+    FD_HD void update(double) {}
+    FD_HD void reset() {
+        for (int i = 0; i < N; i++) v[i] = 0.0f;
+    }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void end_simd() {}
+    template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :57-70
+        for (int i = 0; i + 1 < N; i++) v[i] = v[i + 1];
+        v[N - 1] = in[0];
+        float output = 0.0f;
+        for (int i = 0; i < N; i++) output += w[i] * v[i];
+        out[0] = output;
+    }
+};
+
+// Tick<N>  delay.rs:19-65 (ID 9): one-sample delay
+template <int N>
+struct Tick {
+    static constexpr int IN = N, OUT = N;
+    static constexpr uint64_t ID = 9;
+    float buffer[N];
+    template <class V> FD_HD void visit(V& v) {
+        _Pragma("unroll") for (int i = 0; i < N; i++) v.fi(buffer[i], STATE, "buffer", i);
+    }
+    FD_HD void init() { reset(); }
+    FD_HD void update(double) {}
+    FD_HD void reset() {
+        for (int i = 0; i < N; i++) buffer[i] = 0.0f;
+    }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void end_simd() {}
+    template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :47-52
+        for (int i = 0; i < N; i++) {
+            float o = buffer[i];
+            buffer[i] = in[i];
+            out[i] = o;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// combinators
+// ---------------------------------------------------------------------------------------------------------
+
+// Pipe<X, Y>  audionode.rs:1375-1492 (ID 6)
+template <class X, class Y>
+struct Pipe {
+    static_assert(X::OUT == Y::IN, "Pipe arity mismatch");
+    static constexpr int IN = X::IN, OUT = Y::OUT;
+    static constexpr uint64_t ID = 6;
+    X x;
+    Y y;
+    template <class V> FD_HD void visit(V& v) {
+        v.enter(0); x.visit(v); v.leave();
+        v.enter(1); y.visit(v); v.leave();
+    }
+    FD_HD void init() { x.init(); y.init(); }
+    FD_HD void update(double sr) { x.update(sr); y.update(sr); }
+    FD_HD void reset() { x.reset(); y.reset(); }
+    FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }  // :1459
+    FD_HD void end_simd() { x.end_simd(); y.end_simd(); }
+    template <bool SIMD> FD_HD void step(const float* in, float* out) {
+        float t[X::OUT > 0 ? X::OUT : 1];
+        x.template step<SIMD>(in, t);
+        y.template step<SIMD>(t, out);
+    }
+};
+
+// Stack<X, Y>  audionode.rs:1496-1650 (ID 7)
+template <class X, class Y>
+struct Stack {
+    static constexpr int IN = X::IN + Y::IN, OUT = X::OUT + Y::OUT;
+    static constexpr uint64_t ID = 7;
+    X x;
+    Y y;
+    template <class V> FD_HD void visit(V& v) {
+        v.enter(0); x.visit(v); v.leave();
+        v.enter(1); y.visit(v); v.leave();
+    }
+    FD_HD void init() { x.init(); y.init(); }
+    FD_HD void update(double sr) { x.update(sr); y.update(sr); }
+    FD_HD void reset() { x.reset(); y.reset(); }
+    FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }
+    FD_HD void end_simd() { x.end_simd(); y.end_simd(); }
+    template <bool SIMD> FD_HD void step(const float* in, float* out) {
+        x.template step<SIMD>(in, out);
+        y.template step<SIMD>(in + X::IN, out + X::OUT);
+    }
+};
+
+struct OpAdd { static FD_HD float f(float a, float b) { return a + b; } };
+struct OpSub { static FD_HD float f(float a, float b) { return a - b; } };
+struct OpMul { static FD_HD float f(float a, float b) { return a * b; } };
+
+// Binop<B, X, Y>  audionode.rs:850-1027 (ID 3)
+template <class OP, class X, class Y>
+struct Binop {
+    static_assert(X::OUT == Y::OUT, "Binop arity mismatch");
+    static constexpr int IN = X::IN + Y::IN, OUT = X::OUT;
+    static constexpr uint64_t ID = 3;
+    X x;
+    Y y;
+    template <class V> FD_HD void visit(V& v) {
+        v.enter(0); x.visit(v); v.leave();
+        v.enter(1); y.visit(v); v.leave();
+    }
+    FD_HD void init() { x.init(); y.init(); }
+    FD_HD void update(double sr) { x.update(sr); y.update(sr); }
+    FD_HD void reset() { x.reset(); y.reset(); }
+    FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }  // :966
+    FD_HD void end_simd() { x.end_simd(); y.end_simd(); }
+    template <bool SIMD> FD_HD void step(const float* in, float* out) {
+        float t[OUT];
+        x.template step<SIMD>(in, t);
+        y.template step<SIMD>(in + X::IN, out);
+        for (int i = 0; i < OUT; i++) out[i] = OP::f(t[i], out[i]);
+    }
+};
+
+// FrameUnop variants audionode.rs:1030-1228; the scalar is a per-voice parameter
+struct UNeg { static constexpr bool HAS_SCALAR = false; static FD_HD float f(float x, float) { return -x; } };
+struct UAddScalar { static constexpr bool HAS_SCALAR = true; static FD_HD float f(float x, float s) { return x + s; } };
+struct UNegAddScalar { static constexpr bool HAS_SCALAR = true; static FD_HD float f(float x, float s) { return -x + s; } };
+struct UMulScalar { static constexpr bool HAS_SCALAR = true; static FD_HD float f(float x, float s) { return x * s; } };
+
+// Unop<X, U>  audionode.rs:1232-1326 (ID 4)
+template <class X, class U>
+struct Unop {
+    static constexpr int IN = X::IN, OUT = X::OUT;
+    static constexpr uint64_t ID = 4;
+    X x;
+    float scalar;
+    template <class V> FD_HD void visit(V& v) {
+        v.enter(0); x.visit(v); v.leave();
+        if (U::HAS_SCALAR) v.f(scalar, PARAM, "scalar");
+    }
+    FD_HD void init() { x.init(); scalar = 0.0f; }
+    FD_HD void update(double sr) { x.update(sr); }
+    FD_HD void reset() { x.reset(); }
+    FD_HD uint64_t ping(bool probe, uint64_t h) { return x.ping(probe, atto(h, ID)); }  // :1286
+    FD_HD void end_simd() { x.end_simd(); }
+    template <bool SIMD> FD_HD void step(const float* in, float* out) {
+        x.template step<SIMD>(in, out);
+        for (int i = 0; i < OUT; i++) out[i] = U::f(out[i], scalar);
+    }
+};
+
+}  // namespace fd

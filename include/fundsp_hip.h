@@ -1,0 +1,150 @@
+/*
+ * fundsp_hip.h -- C ABI of the MI355X (gfx950) voice-bank engine for FunDSP leaf DSP nodes.
+ *
+ * Drop-in boundary.  FunDSP has no FFI of its own; the operator boundary this library replaces is the Rust
+ * trait method
+ *     fn process(&mut self, size: usize, input: &BufferRef, output: &mut BufferMut)   src/audionode.rs:85
+ * (dyn twin AudioUnit::process, src/audiounit.rs:45) together with the lifecycle methods a node honours:
+ *     reset :52, set_sample_rate :68, tick :79, set(Setting) :130, set_hash :136, ping :156, set_seed :366.
+ * A *bank* is V independent voice instances of one compiled voice graph evaluated in lock-step, one wavefront
+ * lane per voice.  INTEGRATION.md shows the `extern "C"` block + `impl AudioNode for HipBank` a FunDSP
+ * maintainer would add on the Rust side.
+ *
+ * Conventions
+ *  - All functions return 0 on success or a negative FDSP_E* code; fdsp_last_error() gives the message.
+ *    Nothing unwinds across the ABI (AudioNode::process itself is infallible, audionode.rs:85).
+ *  - Plain pointers and sizes only.  `d_*` pointers are device (HBM) pointers, `h_*` are host pointers.
+ *  - A bank handle is not thread-safe but is thread-movable (AudioNode: Send, `process(&mut self)`).
+ *  - Sample data is IEEE f32; internal state is f32 (prelude32, F = f32).
+ *
+ * Buffer layouts (`layout` argument)
+ *  - FDSP_LAYOUT_VOICE_MINOR: element (channel c, frame t, voice v) at  (c*frames + t)*voices + v.
+ *      Device-native: lane-consecutive addresses, no staging.
+ *  - FDSP_LAYOUT_PLANAR:      element (voice v, channel c, frame t) at  (v*channels + c)*frame_stride + t.
+ *      With frame_stride = 64 this is exactly an array of the reference's BufferArray/BufferRef blocks
+ *      ([channel][8 x f32x8], src/buffer.rs:8-12, 356-365), one per voice; the engine transposes 64x64 tiles
+ *      through LDS so HBM access stays coalesced.
+ *
+ * Render modes (`mode` argument)
+ *  - FDSP_MODE_PROCESS: AudioNode::process semantics.  `frames` is chopped into <=64-sample blocks exactly
+ *      like Wave::render (src/wave.rs:452-464); nodes that override `process` with different arithmetic
+ *      (Sine: unwrapped in-block phase + f32x8 sin, src/oscillator.rs:74-86) use it for the full 8-sample
+ *      SIMD items of each block and `tick` for the remainder.
+ *  - FDSP_MODE_TICK: every sample through AudioNode::tick (src/audionode.rs:79).
+ */
+#ifndef FUNDSP_HIP_H
+#define FUNDSP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDSP_OK 0
+#define FDSP_EINVAL (-1)   /* bad argument (unknown kind / parameter name / range / layout) */
+#define FDSP_ENOMEM (-2)   /* device allocation failed */
+#define FDSP_EDEVICE (-3)  /* HIP runtime error or no gfx950 device */
+
+#define FDSP_LAYOUT_VOICE_MINOR 0
+#define FDSP_LAYOUT_PLANAR 1
+
+#define FDSP_MODE_PROCESS 0
+#define FDSP_MODE_TICK 1
+
+#define FDSP_MAX_BUFFER_SIZE 64 /* MAX_BUFFER_SIZE, src/lib.rs:48 */
+#define FDSP_DEFAULT_SR 44100.0 /* DEFAULT_SR, src/lib.rs:42 */
+
+/* SvfMode values for the "mode" parameter of fixed_svf / svf3 / svf4 (src/svf.rs:281-742) */
+enum { FDSP_SVF_LOWPASS = 0, FDSP_SVF_HIGHPASS, FDSP_SVF_BANDPASS, FDSP_SVF_NOTCH, FDSP_SVF_PEAK,
+       FDSP_SVF_ALLPASS, FDSP_SVF_BELL, FDSP_SVF_LOWSHELF, FDSP_SVF_HIGHSHELF };
+/* BiquadCoefs constructors (src/biquad.rs:27-116) */
+enum { FDSP_BQ_BUTTER_LOWPASS = 0, FDSP_BQ_RESONATOR, FDSP_BQ_LOWPASS, FDSP_BQ_HIGHPASS, FDSP_BQ_BELL };
+
+typedef struct fdsp_bank fdsp_bank;
+
+const char* fdsp_last_error(void);
+
+/* ---- voice-graph kinds compiled into the library -------------------------------------------------------
+ * Leaves (each replaces that node's AudioNode::process):
+ *   "sine" oscillator.rs:21  "noise" noise.rs:173  "fixed_svf" svf.rs:861  "svf3"/"svf4" svf.rs:748
+ *   "biquad" biquad.rs:136  "biquad_bank" biquad_bank.rs:14 (voice = instance*8 + lane)
+ *   "butterpass_hz"/"butterpass" biquad.rs:227  "resonator_hz"/"resonator" biquad.rs:310
+ *   "moog_hz"/"moog" moog.rs:17  "fir2"/"fir3" fir.rs:14  "tick" delay.rs:19  "pass" audionode.rs:408
+ * Fused BASELINE graphs (combinator semantics of audionode.rs Pipe/Unop/Constant are fused in registers):
+ *   "sine_hz"            constant(f) >> sine()                                         prelude.rs:349
+ *   "sine_hz_lowpass_hz" sine_hz(f) >> lowpass_hz(fc, q)                    (BASELINE config 1)
+ *   "noise_biquad"       noise() >> biquad(..)        one BiquadBank lane  (BASELINE config 2)
+ *   "fm_svf"             sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q) (BASELINE config 3)
+ */
+int fdsp_kind_count(void);
+const char* fdsp_kind_name(int kind);
+int fdsp_kind_by_name(const char* name); /* -1 if unknown */
+/* Host-only introspection of a kind (no device needed): arity and the named per-voice slots. */
+int fdsp_kind_inputs(int kind);
+int fdsp_kind_outputs(int kind);
+int fdsp_kind_slot_count(int kind);
+const char* fdsp_kind_slot_name(int kind, int slot);
+int fdsp_kind_slot_kind(int kind, int slot);
+
+/* ---- lifecycle (mirrors constructors / AudioNode::{set_sample_rate,reset,set_seed}) --------------------- */
+/* Creates a bank of `voices` instances on the current HIP device.  State after creation equals the
+ * reference constructor: DEFAULT_SR, default parameters, combinator construction-time ping (audionode.rs:871-876). */
+int fdsp_bank_create(const char* kind, size_t voices, fdsp_bank** out);
+void fdsp_bank_destroy(fdsp_bank* bank);
+int fdsp_bank_inputs(const fdsp_bank* bank);   /* AudioNode::Inputs  */
+int fdsp_bank_outputs(const fdsp_bank* bank);  /* AudioNode::Outputs */
+size_t fdsp_bank_voices(const fdsp_bank* bank);
+int fdsp_bank_set_sample_rate(fdsp_bank* bank, double sample_rate); /* audionode.rs:68 */
+int fdsp_bank_reset(fdsp_bank* bank);                               /* audionode.rs:52 */
+/* AudioNode::set_seed (audionode.rs:366-368) per voice: ping(false, AttoHash::new(seed[i])) for voices
+ * first..first+count.  h_seeds == NULL re-applies the construction-time hash to that range. */
+int fdsp_bank_set_seed(fdsp_bank* bank, const uint64_t* h_seeds, size_t first, size_t count);
+
+/* ---- parameters (mirrors AudioNode::set(Setting), setting.rs:14-72) ------------------------------------
+ * Every per-voice field of the graph is a named slot "<path>:<field>[index]": <path> = child indices from the
+ * root joined by '.', e.g. in "fm_svf" the filter cutoff is "1:cutoff" and the modulator frequency constant
+ * is "0.0.0.0.0.0:value".  Setting a parameter re-derives dependent coefficients immediately, like the
+ * reference's setters (e.g. FixedSvf::set_cutoff_q svf.rs:944-948). */
+int fdsp_bank_slot_count(const fdsp_bank* bank);
+const char* fdsp_bank_slot_name(const fdsp_bank* bank, int slot);
+int fdsp_bank_slot_kind(const fdsp_bank* bank, int slot); /* 0 = parameter, 1 = derived coefficient, 2 = state */
+int fdsp_bank_set_param(fdsp_bank* bank, const char* name, const float* h_values, size_t first, size_t count);
+int fdsp_bank_set_param_all(fdsp_bank* bank, const char* name, float value);
+int fdsp_bank_set_param_u64(fdsp_bank* bank, const char* name, const uint64_t* h_values, size_t first, size_t count);
+int fdsp_bank_get_slot(fdsp_bank* bank, const char* name, float* h_values, size_t first, size_t count);
+/* Full per-voice snapshot, [slot_count][voices] f32 words (FunDSP nodes are Clone: audionode.rs:29). */
+int fdsp_bank_get_state(fdsp_bank* bank, float* h_slots);
+int fdsp_bank_set_state(fdsp_bank* bank, const float* h_slots);
+
+/* ---- the hot path --------------------------------------------------------------------------------------
+ * Render `frames` samples of every voice.  d_in may be NULL for generators.  `frame_stride` is only used by
+ * FDSP_LAYOUT_PLANAR (row length in samples, >= frames; 64 for BufferArray blocks).  `stream` is a
+ * hipStream_t (NULL = the bank's own stream); the call is asynchronous with respect to the host. */
+int fdsp_bank_process(fdsp_bank* bank, size_t frames, const float* d_in, float* d_out, int layout,
+                      size_t frame_stride, int mode, void* stream);
+/* Same with host buffers (staged through device memory; synchronous).  With voices = 1, layout PLANAR,
+ * frame_stride = 64 and frames = size <= 64 this is a literal AudioNode::process call on one node. */
+int fdsp_bank_process_host(fdsp_bank* bank, size_t frames, const float* h_in, float* h_out, int layout,
+                           size_t frame_stride, int mode);
+int fdsp_bank_synchronize(fdsp_bank* bank);
+/* Device time in milliseconds of the most recent fdsp_bank_process launch (HIP events on the launch stream). */
+int fdsp_bank_last_kernel_ms(fdsp_bank* bank, float* ms);
+
+/* ---- on-device stereo mix-down of voice-minor output (per-GPU partial of the multi-GPU mix) ----
+ * d_voices: [frames][voices] mono voice outputs; d_pan: [voices] pan position in -1..1 or NULL (centre);
+ * d_mix: [2][frames].  Equal-power pan weights follow Panner (src/pan.rs:13-17). Deterministic summation order. */
+int fdsp_mix_stereo(const float* d_voices, const float* d_pan, float* d_mix, size_t frames, size_t voices,
+                    void* stream);
+
+/* ---- host-side helpers that restate reference coefficient constructors with the engine's own math --------- */
+int fdsp_svf_coefs(int mode, float sample_rate, float cutoff, float q, float gain, float* out6);     /* svf.rs:28-221 */
+int fdsp_biquad_coefs(int kind, float sample_rate, float f, float q, float gain, float* out5);       /* biquad.rs:27-116 */
+double fdsp_rnd1(uint64_t x);  /* math.rs:569-576 */
+uint64_t fdsp_hash1(uint64_t x); /* math.rs:592-599 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

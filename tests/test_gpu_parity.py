@@ -1,0 +1,368 @@
+"""Parity of the HIP engine (through the C ABI) against the CPU oracle.  Run with `-m gpu` on an MI355X.
+
+Bar: BIT-EXACT.  Both sides evaluate the same published algorithms (musl-style libm for `tick`, vectorclass-style
+f32 polynomial for Sine::process) with FMA contraction off, so every comparison is np.array_equal on the f32
+bit patterns -- tighter than the reference's own 1e-4 self-consistency bar (tests/test_basic.rs:31).
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from fundsp_amd import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS, MODE_TICK
+from fundsp_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+SR = 48000.0
+MODES = [MODE_PROCESS, MODE_TICK]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bit_equal(got, want, what=""):
+    got = np.asarray(got, dtype=np.float32)
+    want = np.asarray(want, dtype=np.float32)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    if not np.array_equal(bits(got), bits(want)):
+        bad = np.argwhere(bits(got) != bits(want))
+        i = tuple(bad[0])
+        raise AssertionError(f"{what}: {len(bad)} / {got.size} samples differ; first at {i}: "
+                             f"got {got[i]!r} want {want[i]!r} (|diff| max {np.nanmax(np.abs(got - want))})")
+
+
+def oracle_render(node, x, frames, mode):
+    """[inputs][frames] -> [outputs][frames] with the executor matching `mode`."""
+    if mode == MODE_PROCESS:
+        return node.render_blocks(x, length=frames, block=64)
+    return node.render_ticks(x, length=frames)
+
+
+def run_bank(bank, x, frames, layout, mode):
+    """x: [V][inputs][frames] or None -> [V][outputs][frames] via the device-pointer entry point."""
+    import torch
+
+    V, ni, no = bank.voices, bank.inputs(), bank.outputs()
+    inp = None
+    if layout == LAYOUT_VOICE_MINOR:
+        if ni:
+            inp = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 2, 0))).cuda()
+        out = bank.process(frames, inp, layout=layout, mode=mode)
+        torch.cuda.synchronize()
+        return out.cpu().numpy().transpose(2, 0, 1)
+    fs = (frames + 63) // 64 * 64 + 64  # row stride larger than frames, 16-byte aligned rows
+    if ni:
+        buf = np.zeros((V, ni, fs), dtype=np.float32)
+        buf[:, :, :frames] = x
+        inp = torch.from_numpy(buf).cuda()
+    out = bank.process(frames, inp, layout=layout, frame_stride=fs, mode=mode)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()[:, :, :frames]
+
+
+def noise_input(V, ni, frames, seed=1):
+    rng = np.random.default_rng(seed)
+    return (rng.random((V, ni, frames), dtype=np.float32) * 2.0 - 1.0).astype(np.float32)
+
+
+@pytest.mark.parametrize("layout", [LAYOUT_VOICE_MINOR, LAYOUT_PLANAR])
+@pytest.mark.parametrize("mode", MODES)
+def test_fixed_svf_all_modes(gpu, layout, mode):
+    V, T = 9 * 16 + 3, 333  # ragged: not a multiple of 64 voices, not a multiple of 8 frames
+    rng = np.random.default_rng(7)
+    modes = np.arange(V) % 9
+    fc = (20.0 * 1000.0 ** rng.random(V)).astype(np.float32).clip(20, 0.45 * SR)
+    q = (0.3 + 5 * rng.random(V)).astype(np.float32)
+    gain = (0.25 + 3 * rng.random(V)).astype(np.float32)
+    b = gpu.Bank("fixed_svf", V)
+    b.set_param(":mode", modes.astype(np.float32))
+    b.set_param(":cutoff", fc)
+    b.set_param(":q", q)
+    b.set_param(":gain", gain)
+    b.set_sample_rate(SR)
+    x = noise_input(V, 1, T)
+    got = run_bank(b, x, T, layout, mode)
+    names = list(O.SVF_MODES)
+    for v in range(V):
+        n = O._fsvf(names[modes[v]], float(fc[v]), float(q[v]), float(gain[v]))
+        n.set_sample_rate(SR)
+        assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"fixed_svf voice {v} mode {names[modes[v]]}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_sine_leaf(gpu, mode):
+    V, T = 70, 200
+    b = gpu.Bank("sine", V)
+    b.set_sample_rate(SR)
+    b.set_seed(np.arange(V, dtype=np.uint64) * 977 + 5)
+    rng = np.random.default_rng(3)
+    x = (rng.random((V, 1, T), dtype=np.float32) * 20000.0).astype(np.float32)
+    x[0] = 440.0
+    x[1] = -440.0  # negative frequency: phase still wraps into [0,1)
+    got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, mode)
+    for v in range(V):
+        n = O.sine()
+        n.set_sample_rate(SR)
+        n.set_seed(v * 977 + 5)
+        assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"sine voice {v}")
+
+
+def test_sine_initial_phase_and_reset(gpu):
+    V, T = 64, 64
+    b = gpu.Bank("sine", V)
+    b.set_sample_rate(SR)
+    b.set_param(":has_initial_phase", 1.0)
+    b.set_param(":initial_phase", np.linspace(0, 0.99, V).astype(np.float32))
+    b.reset()
+    x = np.full((V, 1, T), 1000.0, dtype=np.float32)
+    a = run_bank(b, x, T, LAYOUT_PLANAR, MODE_TICK)
+    b.reset()  # reset determinism, audionode.rs:44-49
+    c = run_bank(b, x, T, LAYOUT_PLANAR, MODE_TICK)
+    assert_bit_equal(a, c, "reset determinism")
+    for v in (0, 17, 63):
+        n = O.sine().phase(float(np.linspace(0, 0.99, V).astype(np.float32)[v]))
+        n.set_sample_rate(SR)
+        assert_bit_equal(a[v], n.render_ticks(x[v]), f"sine.phase voice {v}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_noise_leaf(gpu, mode):
+    V, T = 66, 100
+    b = gpu.Bank("noise", V)
+    seeds = W.hash1(np.arange(V, dtype=np.uint64))
+    b.set_seed(seeds)
+    got = run_bank(b, None, T, LAYOUT_VOICE_MINOR, mode)
+    for v in (0, 1, 33, 65):
+        n = O.noise()
+        n.set_seed(int(seeds[v]))
+        assert_bit_equal(got[v], oracle_render(n, None, T, mode)[:, :T], f"noise voice {v}")
+
+
+@pytest.mark.parametrize("kind,node_id", [("biquad", 15), ("biquad_bank", 98)])
+def test_biquad_and_bank_lanes(gpu, kind, node_id):
+    V, T = 128, 257
+    p = W.noise_biquad_params(V, SR)
+    coefs = np.stack([gpu.biquad_coefs("lowpass", SR, float(f), float(q)) for f, q in zip(p["fc"], p["q"])])
+    b = gpu.Bank(kind, V)
+    for i, n in enumerate(("a1", "a2", "b0", "b1", "b2")):
+        b.set_param(f":{n}", coefs[:, i])
+    x = noise_input(V, 1, T, seed=11)
+    got = run_bank(b, x, T, LAYOUT_PLANAR, MODE_PROCESS)
+    if kind == "biquad":
+        for v in range(0, V, 7):
+            n = O.biquad(*coefs[v])
+            assert_bit_equal(got[v], n.render_blocks(x[v]), f"biquad voice {v}")
+    else:  # 16 instances of BiquadBank<f32x8>, voice = instance*8 + lane (biquad_bank.rs:73-96)
+        for inst in range(V // 8):
+            n = O.biquad_bank()
+            for lane in range(8):
+                O.set_biquad_bank(n, lane, coefs[inst * 8 + lane])
+            want = n.render_blocks(x[inst * 8:inst * 8 + 8, 0, :])
+            assert_bit_equal(got[inst * 8:inst * 8 + 8, 0, :], want, f"biquad_bank instance {inst}")
+
+
+def test_biquad_coefficient_constructors(gpu):
+    rng = np.random.default_rng(5)
+    for kind in ("butter", "resonator", "lowpass", "highpass", "bell"):
+        for _ in range(200):
+            f = float(np.float32(20.0 * 1000.0 ** rng.random()))
+            q = float(np.float32(0.3 + 9 * rng.random()))
+            g = float(np.float32(0.2 + 4 * rng.random()))
+            assert_bit_equal(gpu.biquad_coefs(kind, SR, f, q, g), O.biquad_coefs(kind, SR, f, q, g), kind)
+    for mode in O.SVF_MODES:
+        for _ in range(200):
+            f = float(np.float32(20.0 * 1000.0 ** rng.random()))
+            q = float(np.float32(0.3 + 9 * rng.random()))
+            g = float(np.float32(0.2 + 4 * rng.random()))
+            assert_bit_equal(gpu.svf_coefs(mode, SR, f, q, g), O.svf_coefs(mode, SR, f, q, g), mode)
+
+
+@pytest.mark.parametrize("kind,make", [
+    ("butterpass_hz", lambda p: O.butterpass_hz(p[0])),
+    ("resonator_hz", lambda p: O.Node(O.lib().o_resonator(1, p[0], p[1]))),
+    ("moog_hz", lambda p: O.moog_hz(p[0], p[1])),
+])
+def test_fixed_filters(gpu, kind, make):
+    V, T = 64, 300
+    rng = np.random.default_rng(9)
+    fc = (50.0 * 200.0 ** rng.random(V)).astype(np.float32)
+    q = (0.1 + 0.8 * rng.random(V)).astype(np.float32) if kind == "moog_hz" else (1 + 20 * rng.random(V)).astype(np.float32)
+    b = gpu.Bank(kind, V)
+    b.set_param(":cutoff" if kind != "resonator_hz" else ":center", fc)
+    if kind != "butterpass_hz":
+        b.set_param(":q", q)
+    b.set_sample_rate(SR)
+    x = noise_input(V, 1, T, seed=13)
+    got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    for v in range(0, V, 5):
+        n = make((float(fc[v]), float(q[v])))
+        n.set_sample_rate(SR)
+        assert_bit_equal(got[v], n.render_blocks(x[v]), f"{kind} voice {v}")
+
+
+@pytest.mark.parametrize("kind", ["svf3", "svf4", "moog", "butterpass", "resonator"])
+def test_modulated_filters(gpu, kind):
+    """Parameter inputs: piecewise-constant control signals trigger the recompute-on-change paths
+    (svf.rs:299-313, biquad.rs:271-276,356-365) and Moog's unconditional per-sample update (moog.rs:83-85)."""
+    V, T = 64, 192
+    rng = np.random.default_rng(21)
+    b = gpu.Bank(kind, V)
+    ni = b.inputs()
+    x = noise_input(V, ni, T, seed=17)
+    hold = 16 if kind != "moog" else 1
+    ctl = lambda lo, hi: np.repeat(lo + (hi - lo) * rng.random((V, T // hold)), hold, axis=1).astype(np.float32)
+    x[:, 1, :] = ctl(100.0, 8000.0)
+    if ni >= 3:
+        x[:, 2, :] = ctl(0.5, 4.0) if kind != "moog" else ctl(0.05, 0.7)
+    if ni >= 4:
+        x[:, 3, :] = ctl(0.5, 2.0)
+    modes = (np.arange(V) % 6) if kind == "svf3" else 6 + (np.arange(V) % 3)
+    if kind.startswith("svf"):
+        b.set_param(":mode", modes.astype(np.float32))
+    b.set_sample_rate(SR)
+    got = run_bank(b, x, T, LAYOUT_PLANAR, MODE_PROCESS)
+    names = list(O.SVF_MODES)
+    for v in range(0, V, 3):
+        if kind.startswith("svf"):
+            n = O.svf(names[modes[v]])
+        elif kind == "moog":
+            n = O.moog()
+        elif kind == "butterpass":
+            n = O.butterpass()
+        else:
+            n = O.Node(O.lib().o_resonator(3, 440.0, 1.0))
+        n.set_sample_rate(SR)
+        assert_bit_equal(got[v], n.render_blocks(x[v]), f"{kind} voice {v}")
+
+
+def test_fir_and_tick(gpu):
+    V, T = 64, 100
+    x = noise_input(V, 1, T, seed=23)
+    b = gpu.Bank("fir3", V)
+    w = np.array([0.25, 0.5, 0.25], dtype=np.float32)
+    for i in range(3):
+        b.set_param(f":w[{i}]", float(w[i]))
+    got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_TICK)
+    for v in (0, 31, 63):
+        assert_bit_equal(got[v], O.fir(*w).render_ticks(x[v]), "fir3")
+    t = gpu.Bank("tick", V)
+    got = run_bank(t, x, T, LAYOUT_PLANAR, MODE_PROCESS)
+    want = np.concatenate([np.zeros((V, 1, 1), np.float32), x[:, :, :-1]], axis=2)  # exact 1-sample delay
+    assert_bit_equal(got, want, "tick")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_config1_sine_hz_lowpass_hz(gpu, mode):
+    """BASELINE config 1: sine_hz(440) >> lowpass_hz(1000, 1), Wave::render 1 s @ 48 kHz (750 blocks)."""
+    b = gpu.Bank("sine_hz_lowpass_hz", 1)
+    b.set_param("0.0:value[0]", 440.0)
+    b.set_param("1:cutoff", 1000.0)
+    b.set_param("1:q", 1.0)
+    b.set_sample_rate(SR)
+    T = 48000
+    got = run_bank(b, None, T, LAYOUT_VOICE_MINOR, mode)[0]
+    g = O.sine_hz(440.0) >> O.lowpass_hz(1000.0, 1.0)
+    if mode == MODE_PROCESS:
+        want = O.wave_render(SR, 1.0, g)
+    else:
+        g.set_sample_rate(SR)
+        want = g.render_ticks(length=T)
+    assert_bit_equal(got, want, "config 1")
+    # construction-time ping must give the [derived] phase of SURVEY.md 8(a): 0.6899407
+    b2 = gpu.Bank("sine_hz_lowpass_hz", 1)
+    assert abs(float(b2.get_slot("0.1:phase")[0]) - 0.6899407) < 1e-7
+
+
+@pytest.mark.parametrize("layout", [LAYOUT_VOICE_MINOR, LAYOUT_PLANAR])
+@pytest.mark.parametrize("mode", MODES)
+def test_config2_noise_biquad(gpu, layout, mode):
+    V, T = 1024, 64 * 3 + 5
+    p = W.noise_biquad_params(V, SR)
+    b = W.make_noise_biquad_bank(V, SR, params=p)
+    got = run_bank(b, None, T, layout, mode)
+    want, _ = O.bank_render(2, [p["fc"], p["q"]], p["seed"], T, SR, process_mode=(mode == MODE_PROCESS), out_layout=0)
+    assert_bit_equal(got[:, 0, :], want, "config 2")
+
+
+@pytest.mark.parametrize("layout", [LAYOUT_VOICE_MINOR, LAYOUT_PLANAR])
+@pytest.mark.parametrize("mode", MODES)
+def test_config3_fm_svf(gpu, layout, mode):
+    V, T = 512 + 17, 64 * 4 + 13
+    p = W.fm_svf_params(V, SR)
+    b = W.make_fm_svf_bank(V, SR, params=p)
+    got = run_bank(b, None, T, layout, mode)
+    want, _ = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], T, SR,
+                            process_mode=(mode == MODE_PROCESS), out_layout=0, threads=8)
+    assert_bit_equal(got[:, 0, :], want, "config 3")
+
+
+def test_chunked_calls_and_state_snapshot(gpu):
+    """Two 128-frame calls == one 256-frame call (64-aligned chunks keep Wave::render's blocking); a state snapshot
+    restores the exact continuation (nodes are Clone, audionode.rs:29)."""
+    V = 200
+    p = W.fm_svf_params(V, SR)
+    one = run_bank(W.make_fm_svf_bank(V, SR, params=p), None, 256, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    b = W.make_fm_svf_bank(V, SR, params=p)
+    a1 = run_bank(b, None, 128, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    snap = b.get_state()
+    a2 = run_bank(b, None, 128, LAYOUT_PLANAR, MODE_PROCESS)
+    assert_bit_equal(np.concatenate([a1, a2], axis=2), one, "chunked")
+    b.set_state(snap)
+    a3 = run_bank(b, None, 128, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    assert_bit_equal(a3, a2, "snapshot restore")
+
+
+def test_single_voice_process_is_audionode_process(gpu):
+    """V=1, planar, frame_stride=64: a literal AudioNode::process(size, BufferRef, BufferMut) call, incl. size=0
+    and a ragged size (process_remainder, audionode.rs:110-126)."""
+    b = gpu.Bank("fixed_svf", 1)
+    b.set_param(":cutoff", 1234.0)
+    b.set_param(":q", 0.7)
+    b.set_sample_rate(SR)
+    n = O.lowpass_hz(1234.0, 0.7)
+    n.set_sample_rate(SR)
+    rng = np.random.default_rng(1)
+    for size in (64, 0, 13, 1, 64, 37):
+        blk = (rng.random((1, 1, 64), dtype=np.float32) - 0.5).astype(np.float32)
+        got = b.process_host(size, blk, layout=LAYOUT_PLANAR, frame_stride=64)
+        want = n.process(size, blk[0])
+        assert_bit_equal(got[0, :, :size], want[:, :size], f"process(size={size})")
+    # tick entry point
+    got = b.tick(np.array([[0.25]], dtype=np.float32))
+    assert_bit_equal(got[0], n.tick([0.25]), "tick")
+
+
+def test_error_behaviour(gpu):
+    with pytest.raises(gpu.FdspError):
+        gpu.Bank("no_such_kind", 4)
+    b = gpu.Bank("fixed_svf", 4)
+    with pytest.raises(gpu.FdspError):
+        b.set_param(":nope", 1.0)
+    with pytest.raises(gpu.FdspError):
+        b.set_param(":cutoff", np.ones(5, dtype=np.float32))  # range overflow
+
+
+def test_mix_stereo(gpu):
+    import torch
+
+    T, V = 97, 1000
+    rng = np.random.default_rng(2)
+    x = (rng.random((T, V), dtype=np.float32) - 0.5).astype(np.float32)
+    pan = (rng.random(V, dtype=np.float32) * 2.4 - 1.2).astype(np.float32)
+    mix = gpu.mix_stereo(torch.from_numpy(x).cuda(), torch.from_numpy(pan).cuda()).cpu().numpy()
+    ang = (np.clip(pan, -1, 1).astype(np.float32) + np.float32(1)) * (np.float32(np.pi) * np.float32(0.25))
+    wl = np.array([O.lib().o_math_cosf(float(a)) for a in ang], dtype=np.float32)
+    wr = np.array([O.lib().o_math_sinf(float(a)) for a in ang], dtype=np.float32)
+    # same fixed summation order as the kernel: 256 strided partial sums, then a binary tree
+    def tree(w):
+        part = np.zeros((T, 256), dtype=np.float32)
+        for v in range(V):
+            part[:, v % 256] = part[:, v % 256] + x[:, v] * w[v]
+        h = 128
+        while h > 0:
+            part[:, :h] = part[:, :h] + part[:, h:2 * h]
+            h //= 2
+        return part[:, 0]
+    assert_bit_equal(mix[0], tree(wl), "mix L")
+    assert_bit_equal(mix[1], tree(wr), "mix R")
