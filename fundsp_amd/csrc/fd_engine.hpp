@@ -138,16 +138,30 @@ __global__ __launch_bounds__(64) void k_lifecycle(float* slots, size_t stride, s
     g.visit(st);
 }
 
+// LDS hand-off inside ONE wave (each wave owns its tiles): order the wave's own DS operations and stop the
+// compiler from moving LDS accesses across the hand-off.  No s_barrier: waves of a workgroup stay decoupled.
+FD_D void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- the hot kernel ----------------------------------------------------------------------------------------
-template <class G, int MODE, int LAYOUT>
-__global__ __launch_bounds__(64) void k_render(float* __restrict__ slots, size_t stride, size_t V,
-                                               const float* __restrict__ in, float* __restrict__ out, size_t T,
-                                               size_t fstride) {
+// WPB = waves per workgroup.  Four-wave workgroups are used whenever LDS allows: the dispatcher places the four
+// waves of one workgroup on the four SIMDs of a CU, so a 65 536-voice bank (256 workgroups) lands exactly one wave
+// per SIMD.  Single-wave workgroups do NOT spread evenly (measured with tools/census.hip: 1024 x 64-thread
+// workgroups leave ~10 % of the SIMDs idle and double up as many), which stretches a VALU-bound launch.
+template <class G, int MODE, int LAYOUT, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, size_t stride, size_t V,
+                                                     const float* __restrict__ in, float* __restrict__ out,
+                                                     size_t T, size_t fstride) {
     constexpr int NI = G::IN, NO = G::OUT;
-    const int lane = threadIdx.x;
-    const size_t v0 = (size_t)blockIdx.x * 64;
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;  // wave in block
+    const size_t v0 = ((size_t)blockIdx.x * WPB + wib) * 64;
     const size_t v = v0 + lane;
     const bool active = v < V;
+    if (v0 >= stride) return;  // whole wave beyond the padded bank (last workgroup of a ragged bank)
 
     G g;
     {
@@ -183,8 +197,11 @@ __global__ __launch_bounds__(64) void k_render(float* __restrict__ slots, size_t
             }
         }
     } else {
-        __shared__ __attribute__((aligned(16))) float tin[(NI > 0 ? NI : 1) * 64 * TILE_STRIDE];
-        __shared__ __attribute__((aligned(16))) float tout[NO * 64 * TILE_STRIDE];
+        // one private tile set per wave: no cross-wave sharing, so only wave-level ordering is needed
+        __shared__ __attribute__((aligned(16))) float tin_all[WPB * (NI > 0 ? NI : 1) * 64 * TILE_STRIDE];
+        __shared__ __attribute__((aligned(16))) float tout_all[WPB * NO * 64 * TILE_STRIDE];
+        float* tin = tin_all + wib * (NI > 0 ? NI : 1) * 64 * TILE_STRIDE;
+        float* tout = tout_all + wib * NO * 64 * TILE_STRIDE;
         const int sub = lane >> 4;         // which of 4 voice rows this lane stages per pass
         const int fr = (lane & 15) << 2;   // first of its 4 frames
         const bool aligned = ((fstride & 3) == 0) && ((((uintptr_t)in) & 15) == 0) && ((((uintptr_t)out) & 15) == 0);
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(64) void k_render(float* __restrict__ slots, size_t
                         *reinterpret_cast<float4*>(&tin[(c * 64 + vr) * TILE_STRIDE + fr]) = x;
                     }
                 }
-                __syncthreads();
+                wave_sync();
             }
             // compute: each lane walks its own LDS row, 4 frames per ds_read_b128 / ds_write_b128
             for (int i4 = 0; i4 < size; i4 += 4) {
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(64) void k_render(float* __restrict__ slots, size_t
                     *reinterpret_cast<float4*>(&tout[(c * 64 + lane) * TILE_STRIDE + i4]) =
                         make_float4(xo[c][0], xo[c][1], xo[c][2], xo[c][3]);
             }
-            __syncthreads();
+            wave_sync();
             // stage outputs: LDS [ch][voice][frame] -> global [voice][ch][frame]
 #pragma unroll
             for (int c = 0; c < NO; c++) {
@@ -276,7 +293,7 @@ __global__ __launch_bounds__(64) void k_render(float* __restrict__ slots, size_t
                     }
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
         if (!active) return;
     }
@@ -304,22 +321,32 @@ void launch_lifecycle(float* slots, size_t stride, size_t first, size_t count, i
     hipLaunchKernelGGL((k_lifecycle<G>), dim3(grid), dim3(64), 0, s, slots, stride, first, count, op, sr, d_seeds);
 }
 
+template <class G, int MODE, int LAYOUT>
+void launch_render_cfg(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
+                       hipStream_t s) {
+    // 4-wave workgroups unless the per-wave LDS tiles of the planar path would not fit 4x in 64 KB of LDS
+    constexpr size_t lds_per_wave = LAYOUT == LAYOUT_PLANAR ? (size_t)(G::IN + G::OUT) * 64 * TILE_STRIDE * 4 : 0;
+    constexpr int WPB = (lds_per_wave * 4 <= 160 * 1024 - 1024) ? 4 : 1;
+    const size_t waves = (V + 63) / 64;
+    unsigned grid = (unsigned)((waves + WPB - 1) / WPB);
+    hipLaunchKernelGGL((k_render<G, MODE, LAYOUT, WPB>), dim3(grid), dim3(64 * WPB), 0, s, slots, stride, V, in, out, T,
+                       fstride);
+}
+
 template <class G>
 void launch_render(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
                    int layout, int mode, hipStream_t s) {
     if (V == 0 || T == 0) return;
-    unsigned grid = (unsigned)((V + 63) / 64);
-    dim3 g(grid), b(64);
     if (layout == LAYOUT_VOICE_MINOR) {
         if (mode == MODE_PROCESS)
-            hipLaunchKernelGGL((k_render<G, MODE_PROCESS, LAYOUT_VOICE_MINOR>), g, b, 0, s, slots, stride, V, in, out, T, fstride);
+            launch_render_cfg<G, MODE_PROCESS, LAYOUT_VOICE_MINOR>(slots, stride, V, in, out, T, fstride, s);
         else
-            hipLaunchKernelGGL((k_render<G, MODE_TICK, LAYOUT_VOICE_MINOR>), g, b, 0, s, slots, stride, V, in, out, T, fstride);
+            launch_render_cfg<G, MODE_TICK, LAYOUT_VOICE_MINOR>(slots, stride, V, in, out, T, fstride, s);
     } else {
         if (mode == MODE_PROCESS)
-            hipLaunchKernelGGL((k_render<G, MODE_PROCESS, LAYOUT_PLANAR>), g, b, 0, s, slots, stride, V, in, out, T, fstride);
+            launch_render_cfg<G, MODE_PROCESS, LAYOUT_PLANAR>(slots, stride, V, in, out, T, fstride, s);
         else
-            hipLaunchKernelGGL((k_render<G, MODE_TICK, LAYOUT_PLANAR>), g, b, 0, s, slots, stride, V, in, out, T, fstride);
+            launch_render_cfg<G, MODE_TICK, LAYOUT_PLANAR>(slots, stride, V, in, out, T, fstride, s);
     }
 }
 

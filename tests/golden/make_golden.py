@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the CPU oracle (NOT from the reference: /root/reference is Rust and there is
+no rustc/cargo in the build image, so it cannot be executed to produce vectors).
+
+The fixtures freeze the oracle's current behaviour so that (a) any later edit of the oracle that changes a bit is
+caught by the CPU suite and (b) the GPU suite has committed vectors to compare against besides the live oracle.
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle as O  # noqa: E402
+from fundsp_amd import workloads as W  # noqa: E402
+
+SR = 48000.0
+
+
+def main():
+    # config 1: Wave::render of sine_hz(440) >> lowpass_hz(1000, 1), first 2048 samples at 48 kHz
+    g = O.sine_hz(440.0) >> O.lowpass_hz(1000.0, 1.0)
+    c1 = O.wave_render(SR, 2048 / SR, g)[0]
+    # config 2: 64 noise>>biquad voices, 200 frames, process and tick path
+    p2 = W.noise_biquad_params(64, SR)
+    c2p, _ = O.bank_render(2, [p2["fc"], p2["q"]], p2["seed"], 200, SR, True, 0)
+    c2t, _ = O.bank_render(2, [p2["fc"], p2["q"]], p2["seed"], 200, SR, False, 0)
+    # config 3: 64 FM voices, 333 frames (ragged tail), process and tick path
+    p3 = W.fm_svf_params(64, SR)
+    c3p, _ = O.bank_render(3, [p3["f"], p3["m"], p3["fc"], p3["q"]], p3["seed"], 333, SR, True, 0)
+    c3t, _ = O.bank_render(3, [p3["f"], p3["m"], p3["fc"], p3["q"]], p3["seed"], 333, SR, False, 0)
+    np.savez_compressed(os.path.join(HERE, "configs_v1.npz"), config1=c1, config2_process=c2p, config2_tick=c2t,
+                        config3_process=c3p, config3_tick=c3t)
+    print("wrote", os.path.join(HERE, "configs_v1.npz"))
+
+
+if __name__ == "__main__":
+    main()

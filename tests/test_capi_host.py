@@ -1,0 +1,93 @@
+"""Host-side checks of the product library (no GPU needed): libfundsp_hip.so loads, exports every symbol
+include/fundsp_hip.h declares, introspects its voice-graph kinds, and its host-callable coefficient constructors
+agree bit-for-bit with the oracle.  No compute kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fundsp_amd
+
+    fundsp_amd.lib()
+    return fundsp_amd
+
+
+def test_exports_every_declared_symbol(F):
+    header = open(os.path.join(ROOT, "include", "fundsp_hip.h")).read()
+    declared = set(re.findall(r"\b(fdsp_[a-z0-9_]+)\s*\(", header))
+    declared -= {"fdsp_bank"}  # the opaque struct tag
+    assert len(declared) >= 30
+    raw = C.CDLL(F._lib.SO_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} is declared in include/fundsp_hip.h but not exported"
+    assert declared == set(F._lib.SYMBOLS), declared ^ set(F._lib.SYMBOLS)
+
+
+def test_kinds_and_slots(F):
+    kinds = F.kinds()
+    for k in ("sine", "noise", "fixed_svf", "svf3", "svf4", "biquad", "biquad_bank", "moog", "moog_hz", "fir3",
+              "sine_hz_lowpass_hz", "noise_biquad", "fm_svf"):
+        assert k in kinds
+    slots = dict(F.kind_slots("fm_svf"))
+    from fundsp_amd import workloads as W
+
+    for name in W.FM_SLOTS.values():
+        assert name in slots, name
+    assert slots["1:cutoff"] == 0 and slots["1:a1"] == 1 and slots["1:ic1eq"] == 2  # param / coef / state
+    assert F.lib().fdsp_kind_by_name(b"nope") == -1
+    L = F.lib()
+    k = L.fdsp_kind_by_name(b"svf4")
+    assert L.fdsp_kind_inputs(k) == 4 and L.fdsp_kind_outputs(k) == 1
+
+
+def test_host_coefficient_constructors_match_oracle(F):
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        f = float(np.float32(20.0 * 1000.0 ** rng.random()))
+        q = float(np.float32(0.3 + 9 * rng.random()))
+        g = float(np.float32(0.2 + 4 * rng.random()))
+        sr = float(rng.choice([44100.0, 48000.0, 96000.0]))
+        f = min(f, 0.49 * sr)
+        for kind in O.BQ_KINDS:
+            assert np.array_equal(F.biquad_coefs(kind, sr, f, q, g).view(np.uint32),
+                                  O.biquad_coefs(kind, sr, f, q, g).view(np.uint32)), kind
+        for mode in O.SVF_MODES:
+            assert np.array_equal(F.svf_coefs(mode, sr, f, q, g).view(np.uint32),
+                                  O.svf_coefs(mode, sr, f, q, g).view(np.uint32)), mode
+    L = F.lib()
+    for x in (0, 1, 77, 2**63 + 5):
+        assert L.fdsp_rnd1(x) == O.lib().o_math_rnd1(x)
+        assert L.fdsp_hash1(x) == O.lib().o_math_hash1(x)
+
+
+def test_no_cpu_fallback(F):
+    """Without a HIP device the product path must fail loudly, never compute on the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device error path cannot be exercised")
+    with pytest.raises(F.FdspError) as e:
+        F.Bank("fm_svf", 64)
+    assert e.value.code == F._lib.EDEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under fundsp_amd/ or include/ may import, include or link it."""
+    bad = []
+    for base in ("fundsp_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for fn in files:
+                if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"fundsp_oracle|o_math\.h|libfundsp_oracle|import oracle|from oracle", txt):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad

@@ -1,0 +1,138 @@
+"""Structural / self-consistency invariants of the oracle, re-expressed from the reference's tests -- CPU only.
+
+tests/test_basic.rs: check_wave :21-47 (Wave::render == tick path within 1e-4 after reset), exact delay identity
+:520-529 (tick >> tick >> tick == delay(3/44100)), constants :365-378, outputs_diverge :532-612 (identical
+generators in one graph get different pseudorandom phases), doc-test audionode.rs:44-49 (reset determinism).
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+
+
+def check_wave(make, frames=441, tol=1e-4):
+    """check_wave (test_basic.rs:21-47) for mono generators."""
+    g = make()
+    w = O.wave_render(44100.0, frames / 44100.0, g)
+    g.reset()
+    t = g.render_ticks(length=frames)
+    assert np.max(np.abs(w - t)) <= tol
+    g.reset()
+    assert np.array_equal(O.wave_render(44100.0, frames / 44100.0, g), w)  # reset restores the initial state
+
+
+def test_check_wave_hot_path_generators():
+    check_wave(lambda: O.sine_hz(440.0))
+    check_wave(lambda: O.noise())
+    check_wave(lambda: O.noise().seed(1) * O.noise())
+    check_wave(lambda: O.sine_hz(220.0) >> O.lowpass_hz(1000.0, 1.0))
+    check_wave(lambda: O.noise() >> O.moog_hz(1500.0, 0.5))                       # test_basic.rs:276-290 (moog_hz)
+    check_wave(lambda: O.noise() >> O.resonator_hz(440.0, 110.0))                 # :343-346
+    check_wave(lambda: (O.noise() | O.dc(1000.0, 2.0)) >> O.svf("lowpass"))       # :201-210 (lowpass_q etc.)
+    check_wave(lambda: (O.noise() | O.dc(1000.0, 2.0, 3.0)) >> O.svf("bell"))
+    check_wave(lambda: (O.sine_hz(110.0) * 110.0 * 2.0 + 110.0) >> O.sine() >> O.lowpass_hz(2000.0, 1.0))  # config 3
+
+
+def test_check_wave_filter_biquad_bank():
+    """check_wave_filter (test_basic.rs:72-92) + biquad_bank case :314-317: a bank equals 8 independent biquads
+    bit-for-bit in both the tick and the process path (lane arithmetic is element-wise f32x8)."""
+    rng = np.random.default_rng(0)
+    x = (rng.random((8, 2000), dtype=np.float32) * 2 - 1).astype(np.float32)
+    coefs = [O.biquad_coefs("lowpass", 44100.0, 200.0 * (i + 1), 0.7 + 0.3 * i) for i in range(8)]
+    bank = O.biquad_bank()
+    for i in range(8):
+        O.set_biquad_bank(bank, i, coefs[i])
+    yb = bank.render_blocks(x)
+    bank.reset()
+    assert np.array_equal(bank.render_ticks(x), yb)
+    for i in range(8):
+        assert np.array_equal(O.biquad(*coefs[i]).render_blocks(x[i]), yb[i:i + 1])
+
+
+def test_tick_chain_equals_delay():  # test_basic.rs:520-529
+    rng = np.random.default_rng(1)
+    x = rng.integers(-100, 100, size=(1, 500)).astype(np.float32)
+    a = (O.tick() >> O.tick() >> O.tick()).render_blocks(x)
+    b = O.delay(3.0 / 44100.0).render_blocks(x)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[0, 3:], x[0, :-3]) and not a[0, :3].any()
+
+
+def test_constants():  # test_basic.rs:365-378
+    g = O.dc(2.0) * 3.0 + 0.5
+    assert g.tick()[0] == 6.5
+    assert np.all(O.wave_render(44100.0, 100 / 44100.0, g) == 6.5)
+    s = O.dc(1.0, 2.0) | O.dc(3.0)
+    assert list(s.tick()) == [1.0, 2.0, 3.0]
+    assert (3.0 - O.dc(1.0)).tick()[0] == 2.0 and (O.dc(1.0) - 3.0).tick()[0] == -2.0 and (-O.dc(1.0)).tick()[0] == -1.0
+
+
+def test_outputs_diverge():  # test_basic.rs:532-612: identical generators in one graph get different phases
+    g = O.sine_hz(440.0) | O.sine_hz(440.0)
+    w = O.wave_render(44100.0, 0.01, g)
+    assert np.max(np.abs(w[0] - w[1])) > 0.1
+    g2 = O.noise() | O.noise()
+    w2 = O.wave_render(44100.0, 0.01, g2)
+    assert not np.array_equal(w2[0], w2[1])
+    # ... while two separately built identical graphs are identical (deterministic hashing)
+    assert np.array_equal(O.wave_render(44100.0, 0.01, O.sine_hz(440.0) | O.sine_hz(440.0)), w)
+
+
+def test_set_seed_gives_distinct_reproducible_voices():
+    def voice(seed):
+        g = (O.sine_hz(200.0) * 200.0 * 1.5 + 200.0) >> O.sine() >> O.lowpass_hz(3000.0, 1.0)
+        g.set_sample_rate(48000.0)
+        g.set_seed(seed)
+        return g.render_blocks(length=300)
+    assert np.array_equal(voice(5), voice(5))
+    assert not np.array_equal(voice(5), voice(6))
+
+
+def test_process_block_size_edge_cases():
+    """size = 0 is a no-op, ragged sizes go through process_remainder (audionode.rs:81-126)."""
+    g = O.sine_hz(440.0) >> O.lowpass_hz(1000.0, 1.0)
+    ref = O.sine_hz(440.0) >> O.lowpass_hz(1000.0, 1.0)
+    out = []
+    for size in (0, 1, 7, 8, 9, 63, 64, 0, 13):
+        blk = g.process(size)
+        out.append(blk[0, :size])
+    got = np.concatenate(out)
+    # same chunking through the generic executor
+    want = []
+    for size in (0, 1, 7, 8, 9, 63, 64, 0, 13):
+        want.append(ref.process(size)[0, :size])
+    assert np.array_equal(got, np.concatenate(want))
+    assert got.shape[0] == 165 and np.isfinite(got).all()
+
+
+def test_sample_rate_semantics():
+    """Biquad keeps raw coefficients across set_sample_rate (biquad.rs:179-181); SVF / Moog / Resonator /
+    ButterLowpass recompute (svf.rs:989-992, moog.rs:76-79, biquad.rs:263-267,349-352) -- SURVEY.md App. B.14."""
+    c44 = O.svf_coefs("lowpass", 44100.0, 1000.0, 1.0)
+    c48 = O.svf_coefs("lowpass", 48000.0, 1000.0, 1.0)
+    assert not np.array_equal(c44, c48)
+    rng = np.random.default_rng(3)
+    x = (rng.random((1, 256), dtype=np.float32) - 0.5).astype(np.float32)
+    n = O.lowpass_hz(1000.0, 1.0)
+    y44 = n.render_blocks(x)
+    n.reset()
+    n.set_sample_rate(48000.0)
+    y48 = n.render_blocks(x)
+    assert not np.array_equal(y44, y48)
+    b = O.biquad(*O.biquad_coefs("lowpass", 44100.0, 1000.0, 1.0))
+    y1 = b.render_blocks(x)
+    b.reset()
+    b.set_sample_rate(96000.0)
+    assert np.array_equal(b.render_blocks(x), y1)
+
+
+def test_moog_with_inputs_recomputes_every_sample():
+    """moog() (3 inputs) with constant control inputs equals moog_hz (moog.rs:83-85 vs Moog::new)."""
+    rng = np.random.default_rng(4)
+    x = (rng.random((1, 300), dtype=np.float32) - 0.5).astype(np.float32)
+    a = O.moog_hz(2000.0, 0.4)
+    a.set_sample_rate(48000.0)
+    ctl = np.concatenate([x, np.full((1, 300), 2000.0, np.float32), np.full((1, 300), 0.4, np.float32)])
+    b = O.moog()
+    b.set_sample_rate(48000.0)
+    assert np.array_equal(a.render_blocks(x), b.render_blocks(ctl))

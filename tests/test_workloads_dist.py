@@ -1,0 +1,103 @@
+"""Workload definitions and the multi-GPU (N > 1) path on CPU: contiguous voice sharding with no data-path
+collective, and the single exchange step -- the stereo mix-down all-reduce -- over `gloo`, world_size 2.
+The renderer stand-in on CPU is the oracle (tests may use it); on the GPU box the same code path runs over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle as O
+from fundsp_amd import dist as fdist
+from fundsp_amd import workloads as W
+
+
+def test_rnd1_hash1_vectorised_match_oracle():
+    xs = np.array([0, 1, 2, 3, 1000, 2**40 + 3, 2**64 - 1], dtype=np.uint64)
+    L = O.lib()
+    assert list(W.rnd1(xs)) == [L.o_math_rnd1(int(x)) for x in xs]
+    assert [int(h) for h in W.hash1(xs)] == [L.o_math_hash1(int(x)) for x in xs]
+
+
+def test_config3_parameter_ranges_and_sharding_consistency():
+    sr = 48000.0
+    p = W.fm_svf_params(4096, sr)
+    assert p["f"].min() >= 55.0 and p["f"].max() < 1760.0
+    assert p["m"].min() >= 0.5 and p["m"].max() < 8.0
+    assert p["q"].min() >= 0.5 and p["q"].max() < 4.0
+    assert np.all(p["fc"] >= p["f"] * 0.999) and p["fc"].max() <= 0.45 * sr + 1
+    # a shard's parameters are exactly the slice of the whole bank's parameters (voices are index-addressed)
+    first, count = fdist.shard_range(4096, 1, 3)
+    q = W.fm_svf_params(count, sr, voice0=first)
+    for k in ("f", "m", "fc", "q", "seed"):
+        assert np.array_equal(q[k], p[k][first:first + count])
+
+
+def test_config2_parameter_ranges():
+    p = W.noise_biquad_params(1024, 48000.0)
+    assert p["fc"].min() >= 20.0 and p["fc"].max() <= 0.49 * 48000 and p["q"].min() >= 0.5 and p["q"].max() <= 10.0
+    assert len(set(int(s) for s in p["seed"])) == 1024
+
+
+@pytest.mark.parametrize("total,world", [(65536, 8), (10, 3), (7, 8), (262144, 8), (1, 1)])
+def test_shard_range_partitions(total, world):
+    spans = [fdist.shard_range(total, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+    for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+        assert f0 + c0 == f1
+    assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, total, frames, ret):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sr = 48000.0
+        first, count = fdist.shard_range(total, rank, world)
+        p = W.fm_svf_params(count, sr, voice0=first)
+        out, _ = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], frames, sr, True, 1, 1)  # [frame][voice]
+        w = np.float32(np.cos(np.float32(np.pi) * np.float32(0.25)))
+        part = np.stack([(out * w).sum(axis=1, dtype=np.float32)] * 2)  # centre pan: L = R
+        mix = fdist.allreduce_mix(torch.from_numpy(part.copy()))
+        ret[rank] = mix.numpy().copy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mixdown_allreduce_gloo_world2():
+    import torch.multiprocessing as mp
+
+    total, frames, world = 48, 200, 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, total, frames, ret), nprocs=world, join=True)
+    # single-process reference: the whole bank, same per-voice weights
+    p = W.fm_svf_params(total, 48000.0)
+    out, _ = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], frames, 48000.0, True, 1, 1)
+    w = np.float32(np.cos(np.float32(np.pi) * np.float32(0.25)))
+    full = (out.astype(np.float64) * float(w)).sum(axis=1)
+    for r in range(world):
+        assert ret[r].shape == (2, frames)
+        # float summation order differs between 1 and 2 ranks: tolerance ~ sqrt(V) * eps * max|x|
+        assert np.max(np.abs(ret[r][0] - full)) < 1e-4
+        assert np.array_equal(ret[0], ret[r])  # every rank holds the same reduced mix
+
+
+def test_allreduce_mix_is_identity_without_process_group():
+    import torch
+
+    t = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    assert fdist.allreduce_mix(t.clone()).equal(t)

@@ -9,7 +9,7 @@
 typedef float float2_ __attribute__((ext_vector_type(2)));
 
 template <int KIND>
-__global__ __launch_bounds__(64) void k(float* out, int iters, float a, float b) {
+__global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b) {
     float x[16];
     float2_ y[16];
 #pragma unroll
@@ -29,17 +29,17 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float a, float b)
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) s += x[i] + y[i].x + y[i].y;
-    out[blockIdx.x * 64 + threadIdx.x] = s;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
 // dependent chain: one accumulator
-__global__ __launch_bounds__(64) void kdep(float* out, int iters, float a) {
+__global__ __launch_bounds__(256) void kdep(float* out, int iters, float a) {
     float x = threadIdx.x * 0.001f;
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int i = 0; i < 16; i++) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(a));
     }
-    out[blockIdx.x * 64 + threadIdx.x] = x;
+    out[blockIdx.x * 256 + threadIdx.x] = x;
 }
 
 int main() {
@@ -54,18 +54,18 @@ int main() {
     printf("clock %d kHz\n", clk_khz);
     for (int kind = 0; kind < 7; kind++) {
         for (int wps : {1, 2, 4, 8}) {
-            int grid = 1024 * wps;
+            int grid = 256 * wps;  // 256-thread workgroups: 4 waves land on the 4 SIMDs of a CU
             float ms = 0;
             for (int rep = 0; rep < 3; rep++) {
                 hipEventRecord(e0);
                 switch (kind) {
-                case 0: hipLaunchKernelGGL(k<0>, dim3(grid), dim3(64), 0, 0, out, iters, 1.0001f, 0.5f); break;
-                case 1: hipLaunchKernelGGL(k<1>, dim3(grid), dim3(64), 0, 0, out, iters, 0.9999f, 0.5f); break;
-                case 2: hipLaunchKernelGGL(k<2>, dim3(grid), dim3(64), 0, 0, out, iters, 1.0001f, 0.5f); break;
-                case 3: hipLaunchKernelGGL(k<3>, dim3(grid), dim3(64), 0, 0, out, iters, 0.9999f, 0.5f); break;
-                case 4: hipLaunchKernelGGL(k<4>, dim3(grid), dim3(64), 0, 0, out, iters, 1.0001f, 0.5f); break;
-                case 5: hipLaunchKernelGGL(k<5>, dim3(grid), dim3(64), 0, 0, out, iters, 1.0001f, 0.5f); break;
-                default: hipLaunchKernelGGL(kdep, dim3(grid), dim3(64), 0, 0, out, iters, 1.0001f); break;
+                case 0: hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f, 0.5f); break;
+                case 1: hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, out, iters, 0.9999f, 0.5f); break;
+                case 2: hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f, 0.5f); break;
+                case 3: hipLaunchKernelGGL(k<3>, dim3(grid), dim3(256), 0, 0, out, iters, 0.9999f, 0.5f); break;
+                case 4: hipLaunchKernelGGL(k<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f, 0.5f); break;
+                case 5: hipLaunchKernelGGL(k<5>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f, 0.5f); break;
+                default: hipLaunchKernelGGL(kdep, dim3(grid), dim3(256), 0, 0, out, iters, 1.0001f); break;
                 }
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
