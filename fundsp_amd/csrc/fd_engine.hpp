@@ -177,14 +177,32 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
             const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
             const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
             float fi[NI > 0 ? NI : 1], fo[NO];
-#pragma unroll 8
-            for (int i = 0; i < full; i++) {
+            g.begin_block();
+            const G snap = g;  // block-start registers, for the rollback below
+#pragma unroll 4
+            for (int i = 0; i < full; i += 2) {  // two frames per iteration (full is a multiple of 8)
                 const size_t t = t0 + i;
+                v2f pi[NI > 0 ? NI : 1], po[NO];
 #pragma unroll
-                for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
-                g.template step<true>(fi, fo);
+                for (int c = 0; c < NI; c++)
+                    pi[c] = v2f{inv[((size_t)c * T + t) * V], inv[((size_t)c * T + t + 1) * V]};
+                g.template step2<true>(pi, po);
 #pragma unroll
-                for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+                for (int c = 0; c < NO; c++) {
+                    outv[((size_t)c * T + t) * V] = po[c].x;
+                    outv[((size_t)c * T + t + 1) * V] = po[c].y;
+                }
+            }
+            if (__builtin_expect(g.tripped(), 0)) {  // a packed-path shortcut left its exact domain: redo the block
+                g = snap;
+                for (int i = 0; i < full; i++) {
+                    const size_t t = t0 + i;
+#pragma unroll
+                    for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
+                    g.template step<true>(fi, fo);
+#pragma unroll
+                    for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+                }
             }
             if (MODE == MODE_PROCESS) g.end_simd();
             for (int i = full; i < size; i++) {
@@ -233,44 +251,69 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
                 }
                 wave_sync();
             }
-            // compute: each lane walks its own LDS row, 4 frames per ds_read_b128 / ds_write_b128
-            for (int i4 = 0; i4 < size; i4 += 4) {
-                float xi[NI > 0 ? NI : 1][4];
-                float xo[NO][4];
-#pragma unroll
-                for (int c = 0; c < NI; c++) {
-                    float4 q = *reinterpret_cast<const float4*>(&tin[(c * 64 + lane) * TILE_STRIDE + i4]);
-                    xi[c][0] = q.x; xi[c][1] = q.y; xi[c][2] = q.z; xi[c][3] = q.w;
+            // compute: each lane walks its own LDS row, 4 frames per ds_read_b128 / ds_write_b128.
+            // pass 0 = packed two-frame path; pass 1 (rare) = rollback + scalar path if a packed shortcut tripped.
+            g.begin_block();
+            const G snap = g;
+            for (int pass = 0; pass < 2; pass++) {
+                if (pass == 1) {
+                    if (__builtin_expect(!g.tripped(), 1)) break;
+                    g = snap;
                 }
-                if (i4 < full) {
+                for (int i4 = 0; i4 < size; i4 += 4) {
+                    float xi[NI > 0 ? NI : 1][4];
+                    float xo[NO][4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        float fi[NI > 0 ? NI : 1], fo[NO];
-#pragma unroll
-                        for (int c = 0; c < NI; c++) fi[c] = xi[c][j];
-                        g.template step<true>(fi, fo);
-#pragma unroll
-                        for (int c = 0; c < NO; c++) xo[c][j] = fo[c];
+                    for (int c = 0; c < NI; c++) {
+                        float4 q = *reinterpret_cast<const float4*>(&tin[(c * 64 + lane) * TILE_STRIDE + i4]);
+                        xi[c][0] = q.x; xi[c][1] = q.y; xi[c][2] = q.z; xi[c][3] = q.w;
                     }
-                    if (MODE == MODE_PROCESS && i4 + 4 == full) g.end_simd();
-                } else {
-                    if (MODE == MODE_PROCESS && i4 == full && full == 0) g.end_simd();
+                    if (i4 < full) {
+                        if (pass == 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        float fi[NI > 0 ? NI : 1], fo[NO];
+                            for (int j = 0; j < 4; j += 2) {
+                                v2f pi[NI > 0 ? NI : 1], po[NO];
 #pragma unroll
-                        for (int c = 0; c < NI; c++) fi[c] = xi[c][j];
+                                for (int c = 0; c < NI; c++) pi[c] = v2f{xi[c][j], xi[c][j + 1]};
+                                g.template step2<true>(pi, po);
 #pragma unroll
-                        for (int c = 0; c < NO; c++) fo[c] = 0.0f;
-                        if (i4 + j < size) g.template step<false>(fi, fo);
+                                for (int c = 0; c < NO; c++) {
+                                    xo[c][j] = po[c].x;
+                                    xo[c][j + 1] = po[c].y;
+                                }
+                            }
+                        } else {
 #pragma unroll
-                        for (int c = 0; c < NO; c++) xo[c][j] = fo[c];
+                            for (int j = 0; j < 4; j++) {
+                                float fi[NI > 0 ? NI : 1], fo[NO];
+#pragma unroll
+                                for (int c = 0; c < NI; c++) fi[c] = xi[c][j];
+                                g.template step<true>(fi, fo);
+#pragma unroll
+                                for (int c = 0; c < NO; c++) xo[c][j] = fo[c];
+                            }
+                        }
+                        if (MODE == MODE_PROCESS && i4 + 4 == full && (pass == 1 || !g.tripped())) g.end_simd();
+                    } else {
+                        if (pass == 0 && g.tripped()) break;  // the remainder is rendered by the redo pass
+                        if (MODE == MODE_PROCESS && i4 == full && full == 0) g.end_simd();
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            float fi[NI > 0 ? NI : 1], fo[NO];
+#pragma unroll
+                            for (int c = 0; c < NI; c++) fi[c] = xi[c][j];
+#pragma unroll
+                            for (int c = 0; c < NO; c++) fo[c] = 0.0f;
+                            if (i4 + j < size) g.template step<false>(fi, fo);
+#pragma unroll
+                            for (int c = 0; c < NO; c++) xo[c][j] = fo[c];
+                        }
                     }
+#pragma unroll
+                    for (int c = 0; c < NO; c++)
+                        *reinterpret_cast<float4*>(&tout[(c * 64 + lane) * TILE_STRIDE + i4]) =
+                            make_float4(xo[c][0], xo[c][1], xo[c][2], xo[c][3]);
                 }
-#pragma unroll
-                for (int c = 0; c < NO; c++)
-                    *reinterpret_cast<float4*>(&tout[(c * 64 + lane) * TILE_STRIDE + i4]) =
-                        make_float4(xo[c][0], xo[c][1], xo[c][2], xo[c][3]);
             }
             wave_sync();
             // stage outputs: LDS [ch][voice][frame] -> global [voice][ch][frame]

@@ -328,6 +328,48 @@ FD_HD float wide_sinf(float self) {
     return u2f(f2u(sin1) ^ (sign_sin & 0x80000000u));
 }
 
+// ---- two-frame packed form of wide_sinf ------------------------------------------------------------------
+// A lone wave issues one instruction per ~4 cycles whatever its type (profiles/r01_pmc_sq_run4.txt), and gfx950's
+// packed-f32 VALU ops (v_pk_mul_f32 / v_pk_add_f32) do two lanes-ops per issue slot.  The feed-forward part of an
+// oscillator (the sine polynomial of frame n and n+1) is therefore evaluated as one <2 x float> computation.
+// Component-wise the arithmetic is IDENTICAL to wide_sinf (same operations, same order, no contraction).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+FD_HD v2f splat2(float x) { return v2f{x, x}; }
+
+// `tmax` accumulates the largest quadrant argument seen (one v_max3_f32): the shortcuts below are exact only while
+// it stays < 8192; the caller checks it once per 64-sample block and, if it tripped, re-renders that block with the
+// fully general scalar wide_sinf (optimistic execution + rollback keeps the hot loop branch-free).
+FD_HD v2f wide_sin2(v2f self, float& tmax) {
+    constexpr float DP1F = 0.78515625f * 2.0f;                 //  8 significant bits
+    constexpr float DP2F = 2.4187564849853515625E-4f * 2.0f;   // 11 significant bits
+    constexpr float DP3F = 3.77489497744594108E-8f * 2.0f;
+    constexpr float P0sinf = -1.6666654611E-1f, P1sinf = 8.3321608736E-3f, P2sinf = -1.9515295891E-4f;
+    constexpr float P0cosf = 4.166664568298827E-2f, P1cosf = -1.388731625493765E-3f, P2cosf = 2.443315711809948E-5f;
+    constexpr float TWO_OVER_PI = 2.0f / 3.14159274101257324f;
+    v2f xa = v2f{__builtin_fabsf(self.x), __builtin_fabsf(self.y)};
+    v2f t = xa * TWO_OVER_PI;
+    // Out-of-domain arguments (quadrant index >= 8192: more than ~2000 cycles of phase inside one 64-sample block,
+    // where the exact-FMA shortcuts and wide's q > 2^25 overflow rule would matter) only raise tmax here.
+    tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(t.x, t.y));
+    v2f y = v2f{__builtin_rintf(t.x), __builtin_rintf(t.y)};
+    int32_t q0 = (int32_t)y.x, q1 = (int32_t)y.y;
+    // y < 2^13 is an integer, so y*DP1F (13+8 bits) and y*DP2F (13+11 bits) are exact products: the fused and the
+    // unfused forms of `x - y*DPn` round the same real number once -> identical bits.  Likewise 0.5*x2 below.
+    v2f x = __builtin_elementwise_fma(y, splat2(-DP1F), xa);
+    x = __builtin_elementwise_fma(y, splat2(-DP2F), x);
+    x = x - y * DP3F;
+    v2f x2 = x * x;
+    v2f x4 = x2 * x2;
+    v2f s = (x4 * P2sinf + (x2 * P1sinf + P0sinf)) * (x * x2) + x;
+    v2f c = (x4 * P2cosf + (x2 * P1cosf + P0cosf)) * x4 + __builtin_elementwise_fma(x2, splat2(-0.5f), splat2(1.0f));
+    float r0 = (q0 & 1) ? c.x : s.x;
+    float r1 = (q1 & 1) ? c.y : s.y;
+    uint32_t g0 = (((uint32_t)q0 << 30) ^ f2u(self.x)) & 0x80000000u;
+    uint32_t g1 = (((uint32_t)q1 << 30) ^ f2u(self.y)) & 0x80000000u;
+    return v2f{u2f(f2u(r0) ^ g0), u2f(f2u(r1) ^ g1)};
+}
+
 // ---- integer hashing (bit-exact) -------------------------------------------------------------------------
 FD_HD double rnd1(uint64_t x) {  // math.rs:569-576
     x = x ^ 0x5555555555555555ULL;

@@ -24,6 +24,22 @@ namespace fd {
 
 enum FieldKind { PARAM = 0, COEF = 1, STATE = 2 };
 
+// step2<SIMD>(in, out): two consecutive frames at once, channel c of frames (n, n+1) packed in one <2 x float>.
+// Feed-forward nodes (Constant, Unop, Binop, the sine polynomial of Sine::process) implement it with packed f32
+// arithmetic, which halves their instruction count; nodes whose samples depend serially on each other use this
+// default, which is two `step` calls.  Either way each frame's arithmetic is identical to `step`.
+#define FD_STEP2_VIA_STEP                                                      \
+    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) {           \
+        float i0[IN > 0 ? IN : 1], i1[IN > 0 ? IN : 1], o0[OUT], o1[OUT];      \
+        _Pragma("unroll") for (int c = 0; c < IN; c++) {                       \
+            i0[c] = in[c].x;                                                   \
+            i1[c] = in[c].y;                                                   \
+        }                                                                      \
+        this->template step<SIMD>(i0, o0);                                     \
+        this->template step<SIMD>(i1, o1);                                     \
+        _Pragma("unroll") for (int c = 0; c < OUT; c++) out[c] = v2f{o0[c], o1[c]}; \
+    }
+
 constexpr int SVF_LOWPASS = 0, SVF_HIGHPASS = 1, SVF_BANDPASS = 2, SVF_NOTCH = 3, SVF_PEAK = 4, SVF_ALLPASS = 5,
               SVF_BELL = 6, SVF_LOWSHELF = 7, SVF_HIGHSHELF = 8;
 
@@ -133,8 +149,13 @@ struct Constant {
     FD_HD void reset() {}
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
+    FD_HD void begin_block() {}
+    FD_HD bool tripped() const { return false; }
     template <bool SIMD> FD_HD void step(const float*, float* out) {
         for (int i = 0; i < N; i++) out[i] = value[i];
+    }
+    template <bool SIMD> FD_HD void step2(const v2f*, v2f* out) {
+        for (int i = 0; i < N; i++) out[i] = splat2(value[i]);
     }
 };
 
@@ -148,7 +169,10 @@ struct Pass {
     FD_HD void reset() {}
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
+    FD_HD void begin_block() {}
+    FD_HD bool tripped() const { return false; }
     template <bool SIMD> FD_HD void step(const float* in, float* out) { out[0] = in[0]; }
+    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) { out[0] = in[0]; }
 };
 
 // Sine<f32>  oscillator.rs:21-102 (ID 21)
@@ -157,6 +181,9 @@ struct Sine {
     static constexpr uint64_t ID = 21;
     float phase, sample_duration, has_phase, initial_phase;
     uint64_t hash;
+    float tmax;  // transient guard of the packed sine path (not a slot)
+    FD_HD void begin_block() { tmax = 0.0f; }
+    FD_HD bool tripped() const { return !(tmax < 8192.0f); }
     template <class V> FD_HD void visit(V& v) {
         v.f(phase, STATE, "phase");
         v.f(sample_duration, COEF, "sample_duration");
@@ -190,6 +217,21 @@ struct Sine {
             phase += in[0] * sample_duration;
             phase -= __builtin_floorf(phase);
             out[0] = sinf_musl(p * F32_TAU);
+        }
+    }
+    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) {
+        if (SIMD) {  // serial f32 phase recurrence for the two frames, then ONE packed polynomial evaluation
+            v2f d = in[0] * sample_duration;
+            float t0 = phase;
+            phase += d.x;
+            float t1 = phase;
+            phase += d.y;
+            out[0] = wide_sin2(v2f{t0, t1} * F32_TAU, tmax);
+        } else {
+            float o0, o1, i0 = in[0].x, i1 = in[0].y;
+            this->template step<false>(&i0, &o0);
+            this->template step<false>(&i1, &o1);
+            out[0] = v2f{o0, o1};
         }
     }
 };
@@ -226,22 +268,34 @@ struct Noise {
         return atto(h, ID);
     }
     FD_HD void end_simd() {}
+    FD_HD void begin_block() {}
+    FD_HD bool tripped() const { return false; }
     template <bool SIMD> FD_HD void step(const float*, float* out) {  // :197-202
         state += 1u;
         out[0] = (float)(hash32x(state) >> 8) * (2.0f / (float)((1 << 24) - 1)) - 1.0f;
     }
+    FD_STEP2_VIA_STEP
 };
 
 // SVF core shared by FixedSvf and Svf:  svf.rs:995-1006 / :829-843
 struct SvfCore {
     float a1, a2, a3, m0, m1, m2, ic1eq, ic2eq;
+    // Same operations in the same order as the reference; independent pairs share one packed instruction:
+    //   (a1*ic1, a2*ic1), (a2*v3, a3*v3), (p.x + r.x, ic2 + p.y), (m0*v0, m1*v1).
+    // `2*v - ic` is evaluated as fma(2, v, -ic): 2*v is exact in binary floating point, so the fused and the
+    // unfused form round the same real number once -- identical bits for every non-overflowing value.
     FD_HD float tick(float v0) {
         float v3 = v0 - ic2eq;
-        float v1 = a1 * ic1eq + a2 * v3;
-        float v2 = ic2eq + a2 * ic1eq + a3 * v3;
-        ic1eq = 2.0f * v1 - ic1eq;
-        ic2eq = 2.0f * v2 - ic2eq;
-        return m0 * v0 + m1 * v1 + m2 * v2;
+        v2f p = v2f{a1, a2} * splat2(ic1eq);
+        v2f r = v2f{a2, a3} * splat2(v3);
+        v2f s = v2f{p.x, ic2eq} + v2f{r.x, p.y};
+        float v1 = s.x;
+        float v2 = s.y + r.y;
+        v2f ic = __builtin_elementwise_fma(splat2(2.0f), v2f{v1, v2}, -v2f{ic1eq, ic2eq});
+        ic1eq = ic.x;
+        ic2eq = ic.y;
+        v2f mm = v2f{m0, m1} * v2f{v0, v1};
+        return (mm.x + mm.y) + m2 * v2;
     }
     FD_HD void set(const SvfCoefs& c) {
         a1 = c.a1; a2 = c.a2; a3 = c.a3; m0 = c.m0; m1 = c.m1; m2 = c.m2;
@@ -277,7 +331,10 @@ struct FixedSvf {
     FD_HD void reset() { c.ic1eq = 0.0f; c.ic2eq = 0.0f; }  // :984-987
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
+    FD_HD void begin_block() {}
+    FD_HD bool tripped() const { return false; }
     template <bool SIMD> FD_HD void step(const float* in, float* out) { out[0] = c.tick(in[0]); }
+    FD_STEP2_VIA_STEP
 };
 
 // Svf<f32, M> with parameter inputs  svf.rs:748-855 (ID 36).  NIN = 3 (audio, cutoff, q) or 4 (+ gain).
@@ -309,6 +366,8 @@ struct Svf {
     FD_HD void reset() { c.ic1eq = 0.0f; c.ic2eq = 0.0f; }  // :818-821
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
+    FD_HD void begin_block() {}
+    FD_HD bool tripped() const { return false; }
     template <bool SIMD> FD_HD void step(const float* in, float* out) {
         // update_inputs :299-313 (3 inputs) / :588-606 (4 inputs): recompute only when an input changed
         bool changed = in[1] != cutoff || in[2] != q;
@@ -321,6 +380,7 @@ struct Svf {
         }
         out[0] = c.tick(in[0]);
     }
+    FD_STEP2_VIA_STEP
 };
 
 // Biquad<f32>  biquad.rs:136-218 (ID 15): DF1, coefficients are raw parameters (set_sample_rate keeps them).
@@ -340,6 +400,8 @@ struct BiquadT {
     FD_HD void reset() { x1 = x2 = y1 = y2 = 0.0f; }   // :172-177
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
+    FD_HD void begin_block() {}
+    FD_HD bool tripped() const { return false; }
     FD_HD float tick(float x0) {  // :184-194
         float y0 = b0 * x0 + b1 * x1 + b2 * x2 - a1 * y1 - a2 * y2;
         x2 = x1;
@@ -349,6 +411,7 @@ struct BiquadT {
         return y0;
     }
     template <bool SIMD> FD_HD void step(const float* in, float* out) { out[0] = tick(in[0]); }
+    FD_STEP2_VIA_STEP
 };
 using Biquad = BiquadT<15>;
 
@@ -380,12 +443,15 @@ struct ButterLowpass {
     FD_HD void reset() { b.reset(); }
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
+    FD_HD void begin_block() {}
+    FD_HD bool tripped() const { return false; }
     template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :269-277
         if (NIN > 1) {
             if (in[1] != cutoff) set_cutoff(in[1]);
         }
         out[0] = b.tick(in[0]);
     }
+    FD_STEP2_VIA_STEP
 };
 
 // Resonator<f32, N>  biquad.rs:310-380 (ID 17), N = 1 (fixed) or 3 (center, q inputs)
@@ -418,12 +484,15 @@ struct Resonator {
     FD_HD void reset() { b.reset(); }
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
+    FD_HD void begin_block() {}
+    FD_HD bool tripped() const { return false; }
     template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :354-366
         if (NIN >= 3) {
             if (in[1] != center || in[2] != q) set_center_q(in[1], in[2]);
         }
         out[0] = b.tick(in[0]);
     }
+    FD_STEP2_VIA_STEP
 };
 
 // Moog<f32, N>  moog.rs:17-117 (ID 60).  N = 1 (fixed cutoff/q) or 3 (audio, cutoff Hz, Q inputs; the
@@ -463,6 +532,8 @@ struct Moog {
     FD_HD void reset() { s0 = s1 = s2 = s3 = px = ps0 = ps1 = ps2 = 0.0f; }  // :65-74
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
+    FD_HD void begin_block() {}
+    FD_HD bool tripped() const { return false; }
     template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :82-100
         if (NIN > 1) set_cutoff_q(in[1], in[2]);
         float x = -rez * s3 + in[0];
@@ -476,6 +547,7 @@ struct Moog {
         ps2 = s2;
         out[0] = s3;
     }
+    FD_STEP2_VIA_STEP
 };
 
 // Fir<N>  fir.rs:14-89 (ID 52)
@@ -498,6 +570,8 @@ struct Fir {
     }
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
+    FD_HD void begin_block() {}
+    FD_HD bool tripped() const { return false; }
     template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :57-70
         for (int i = 0; i + 1 < N; i++) v[i] = v[i + 1];
         v[N - 1] = in[0];
@@ -505,6 +579,7 @@ struct Fir {
         for (int i = 0; i < N; i++) output += w[i] * v[i];
         out[0] = output;
     }
+    FD_STEP2_VIA_STEP
 };
 
 // Tick<N>  delay.rs:19-65 (ID 9): one-sample delay
@@ -523,6 +598,8 @@ struct Tick {
     }
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
+    FD_HD void begin_block() {}
+    FD_HD bool tripped() const { return false; }
     template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :47-52
         for (int i = 0; i < N; i++) {
             float o = buffer[i];
@@ -530,6 +607,7 @@ struct Tick {
             out[i] = o;
         }
     }
+    FD_STEP2_VIA_STEP
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -553,10 +631,17 @@ struct Pipe {
     FD_HD void reset() { x.reset(); y.reset(); }
     FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }  // :1459
     FD_HD void end_simd() { x.end_simd(); y.end_simd(); }
+    FD_HD void begin_block() { x.begin_block(); y.begin_block(); }
+    FD_HD bool tripped() const { return x.tripped() || y.tripped(); }
     template <bool SIMD> FD_HD void step(const float* in, float* out) {
         float t[X::OUT > 0 ? X::OUT : 1];
         x.template step<SIMD>(in, t);
         y.template step<SIMD>(t, out);
+    }
+    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) {
+        v2f t[X::OUT > 0 ? X::OUT : 1];
+        x.template step2<SIMD>(in, t);
+        y.template step2<SIMD>(t, out);
     }
 };
 
@@ -576,15 +661,21 @@ struct Stack {
     FD_HD void reset() { x.reset(); y.reset(); }
     FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }
     FD_HD void end_simd() { x.end_simd(); y.end_simd(); }
+    FD_HD void begin_block() { x.begin_block(); y.begin_block(); }
+    FD_HD bool tripped() const { return x.tripped() || y.tripped(); }
     template <bool SIMD> FD_HD void step(const float* in, float* out) {
         x.template step<SIMD>(in, out);
         y.template step<SIMD>(in + X::IN, out + X::OUT);
     }
+    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) {
+        x.template step2<SIMD>(in, out);
+        y.template step2<SIMD>(in + X::IN, out + X::OUT);
+    }
 };
 
-struct OpAdd { static FD_HD float f(float a, float b) { return a + b; } };
-struct OpSub { static FD_HD float f(float a, float b) { return a - b; } };
-struct OpMul { static FD_HD float f(float a, float b) { return a * b; } };
+struct OpAdd { template <class T> static FD_HD T f(T a, T b) { return a + b; } };
+struct OpSub { template <class T> static FD_HD T f(T a, T b) { return a - b; } };
+struct OpMul { template <class T> static FD_HD T f(T a, T b) { return a * b; } };
 
 // Binop<B, X, Y>  audionode.rs:850-1027 (ID 3)
 template <class OP, class X, class Y>
@@ -603,19 +694,27 @@ struct Binop {
     FD_HD void reset() { x.reset(); y.reset(); }
     FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }  // :966
     FD_HD void end_simd() { x.end_simd(); y.end_simd(); }
+    FD_HD void begin_block() { x.begin_block(); y.begin_block(); }
+    FD_HD bool tripped() const { return x.tripped() || y.tripped(); }
     template <bool SIMD> FD_HD void step(const float* in, float* out) {
         float t[OUT];
         x.template step<SIMD>(in, t);
         y.template step<SIMD>(in + X::IN, out);
         for (int i = 0; i < OUT; i++) out[i] = OP::f(t[i], out[i]);
     }
+    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) {
+        v2f t[OUT];
+        x.template step2<SIMD>(in, t);
+        y.template step2<SIMD>(in + X::IN, out);
+        for (int i = 0; i < OUT; i++) out[i] = OP::f(t[i], out[i]);
+    }
 };
 
 // FrameUnop variants audionode.rs:1030-1228; the scalar is a per-voice parameter
-struct UNeg { static constexpr bool HAS_SCALAR = false; static FD_HD float f(float x, float) { return -x; } };
-struct UAddScalar { static constexpr bool HAS_SCALAR = true; static FD_HD float f(float x, float s) { return x + s; } };
-struct UNegAddScalar { static constexpr bool HAS_SCALAR = true; static FD_HD float f(float x, float s) { return -x + s; } };
-struct UMulScalar { static constexpr bool HAS_SCALAR = true; static FD_HD float f(float x, float s) { return x * s; } };
+struct UNeg { static constexpr bool HAS_SCALAR = false; template <class T> static FD_HD T f(T x, float) { return -x; } };
+struct UAddScalar { static constexpr bool HAS_SCALAR = true; template <class T> static FD_HD T f(T x, float s) { return x + s; } };
+struct UNegAddScalar { static constexpr bool HAS_SCALAR = true; template <class T> static FD_HD T f(T x, float s) { return -x + s; } };
+struct UMulScalar { static constexpr bool HAS_SCALAR = true; template <class T> static FD_HD T f(T x, float s) { return x * s; } };
 
 // Unop<X, U>  audionode.rs:1232-1326 (ID 4)
 template <class X, class U>
@@ -633,8 +732,14 @@ struct Unop {
     FD_HD void reset() { x.reset(); }
     FD_HD uint64_t ping(bool probe, uint64_t h) { return x.ping(probe, atto(h, ID)); }  // :1286
     FD_HD void end_simd() { x.end_simd(); }
+    FD_HD void begin_block() { x.begin_block(); }
+    FD_HD bool tripped() const { return x.tripped(); }
     template <bool SIMD> FD_HD void step(const float* in, float* out) {
         x.template step<SIMD>(in, out);
+        for (int i = 0; i < OUT; i++) out[i] = U::f(out[i], scalar);
+    }
+    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) {
+        x.template step2<SIMD>(in, out);
         for (int i = 0; i < OUT; i++) out[i] = U::f(out[i], scalar);
     }
 };

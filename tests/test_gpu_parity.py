@@ -108,6 +108,29 @@ def test_sine_leaf(gpu, mode):
         assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"sine voice {v}")
 
 
+@pytest.mark.parametrize("layout", [LAYOUT_VOICE_MINOR, LAYOUT_PLANAR])
+def test_sine_process_out_of_domain_rollback(gpu, layout):
+    """The packed two-frame sine path is exact only while the in-block quadrant index stays < 8192; absurd
+    frequencies (1e9 / 1e10 Hz: ~1e6..1e7 cycles of phase inside one block, the second one beyond wide's
+    q > 2^25 overflow rule) must trip the per-block guard and be re-rendered bit-exactly, without disturbing the
+    ordinary voices that share the wave."""
+    V, T = 96, 64 * 3 + 20
+    b = gpu.Bank("sine", V)
+    b.set_sample_rate(SR)
+    b.set_seed(np.arange(V, dtype=np.uint64) + 100)
+    x = np.full((V, 1, T), 440.0, dtype=np.float32)
+    x[3] = 1.0e9
+    x[40] = 1.0e10
+    x[70, 0, 100:] = 3.0e9   # trips only from the second block on
+    x[71] = -2.0e9
+    got = run_bank(b, x, T, layout, MODE_PROCESS)
+    for v in (0, 3, 4, 40, 63, 64, 70, 71, 95):
+        n = O.sine()
+        n.set_sample_rate(SR)
+        n.set_seed(v + 100)
+        assert_bit_equal(got[v], n.render_blocks(x[v]), f"sine voice {v}")
+
+
 def test_sine_initial_phase_and_reset(gpu):
     V, T = 64, 64
     b = gpu.Bank("sine", V)
