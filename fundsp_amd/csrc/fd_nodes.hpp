@@ -280,22 +280,24 @@ struct Noise {
 // SVF core shared by FixedSvf and Svf:  svf.rs:995-1006 / :829-843
 struct SvfCore {
     float a1, a2, a3, m0, m1, m2, ic1eq, ic2eq;
-    // Same operations in the same order as the reference; independent pairs share one packed instruction:
-    //   (a1*ic1, a2*ic1), (a2*v3, a3*v3), (p.x + r.x, ic2 + p.y), (m0*v0, m1*v1).
+    // Same operations in the same order as the reference; independent products share one packed instruction:
+    //   (a1*ic1, a2*ic1), (a2*v3, a3*v3), (m0*v0, m1*v1); the three sums stay scalar (no register shuffles).
     // `2*v - ic` is evaluated as fma(2, v, -ic): 2*v is exact in binary floating point, so the fused and the
     // unfused form round the same real number once -- identical bits for every non-overflowing value.
     FD_HD float tick(float v0) {
         float v3 = v0 - ic2eq;
         v2f p = v2f{a1, a2} * splat2(ic1eq);
         v2f r = v2f{a2, a3} * splat2(v3);
-        v2f s = v2f{p.x, ic2eq} + v2f{r.x, p.y};
-        float v1 = s.x;
-        float v2 = s.y + r.y;
-        v2f ic = __builtin_elementwise_fma(splat2(2.0f), v2f{v1, v2}, -v2f{ic1eq, ic2eq});
+        v2f v01, v12;
+        v12.x = p.x + r.x;            // v1
+        float t = ic2eq + p.y;
+        v12.y = t + r.y;              // v2
+        v01 = v2f{v0, v12.x};
+        v2f ic = __builtin_elementwise_fma(splat2(2.0f), v12, -v2f{ic1eq, ic2eq});
         ic1eq = ic.x;
         ic2eq = ic.y;
-        v2f mm = v2f{m0, m1} * v2f{v0, v1};
-        return (mm.x + mm.y) + m2 * v2;
+        v2f mm = v2f{m0, m1} * v01;
+        return (mm.x + mm.y) + m2 * v12.y;
     }
     FD_HD void set(const SvfCoefs& c) {
         a1 = c.a1; a2 = c.a2; a3 = c.a3; m0 = c.m0; m1 = c.m1; m2 = c.m2;
