@@ -49,6 +49,10 @@ SYMBOLS = {
     "fdsp_bank_synchronize": (_i, [_P]),
     "fdsp_bank_last_kernel_ms": (_i, [_P, C.POINTER(C.c_float)]),
     "fdsp_mix_stereo": (_i, [_P, _P, _P, _sz, _sz, _P]),
+    "fdsp_sum_voices": (_i, [_P, _P, _sz, _sz, _sz, _P]),
+    "fdsp_wavetable_build": (_i, [_i]),
+    "fdsp_wavetable_upload": (_i, [_i, _i, _fp, C.POINTER(C.c_int), _fp]),
+    "fdsp_wavetable_get": (_i, [_i, C.POINTER(C.c_int), _fp, C.POINTER(C.c_int), _fp, _sz]),
     "fdsp_svf_coefs": (_i, [_i, _f, _f, _f, _f, _fp]),
     "fdsp_biquad_coefs": (_i, [_i, _f, _f, _f, _f, _fp]),
     "fdsp_rnd1": (_d, [_u64]),

@@ -183,6 +183,51 @@ def biquad_coefs(kind, sample_rate, f, q=1.0, gain=1.0):
     return out
 
 
+WT_SETS = dict(saw=0, square=1, triangle=2, user=3)
+
+
+def wavetable_build(kind):
+    """Generate and install a built-in shared wavetable set (saw_table / square_table / triangle_table)."""
+    check(lib().fdsp_wavetable_build(WT_SETS[kind]))
+
+
+def wavetable_upload(kind, pitches, waves):
+    """Install caller-provided tables: pitches [n] ascending, waves = list of power-of-two-length float32 arrays."""
+    p = np.ascontiguousarray(pitches, dtype=np.float32)
+    lengths = np.array([len(w) for w in waves], dtype=np.int32)
+    data = np.ascontiguousarray(np.concatenate(waves), dtype=np.float32)
+    check(lib().fdsp_wavetable_upload(WT_SETS[kind], len(waves), _fptr(p), lengths.ctypes.data_as(C.POINTER(C.c_int)),
+                                      _fptr(data)))
+
+
+def wavetable_get(kind):
+    n = C.c_int()
+    check(lib().fdsp_wavetable_get(WT_SETS[kind], C.byref(n), None, None, None, 0))
+    if n.value == 0:
+        return None, None
+    p = np.zeros(n.value, dtype=np.float32)
+    lengths = np.zeros(n.value, dtype=np.int32)
+    check(lib().fdsp_wavetable_get(WT_SETS[kind], C.byref(n), _fptr(p), lengths.ctypes.data_as(C.POINTER(C.c_int)), None, 0))
+    data = np.zeros(int(lengths.sum()), dtype=np.float32)
+    check(lib().fdsp_wavetable_get(WT_SETS[kind], C.byref(n), None, None, _fptr(data), data.size))
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    return p, [data[offs[i]:offs[i + 1]] for i in range(n.value)]
+
+
+def sum_voices(x, stream=None):
+    """[channels, frames, V] voice-minor device tensor -> [channels, frames] (deterministic order)."""
+    import torch
+
+    assert x.is_cuda and x.dim() == 3 and x.is_contiguous()
+    ch, frames, V = x.shape
+    out = torch.empty((ch, frames), dtype=torch.float32, device=x.device)
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    check(lib().fdsp_sum_voices(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), ch, frames, V,
+                                C.c_void_p(stream) if stream else None))
+    return out
+
+
 def mix_stereo(voices_out, pan=None, stream=None):
     """On-device stereo mix-down of a voice-minor mono render [frames, V] -> [2, frames]."""
     import torch

@@ -1,4 +1,5 @@
 // fd_capi.hip -- C ABI (include/fundsp_hip.h) of the MI355X voice-bank engine.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -33,6 +34,126 @@ std::vector<fd::KindOps>& registry() {
         fd::register_graph_kinds(kinds);
     });
     return kinds;
+}
+
+// ---- shared device data (wavetables): one fd::Aux per process, the counterpart of FunDSP's static table singletons ----
+fd::Aux g_host_aux;              // host mirror (data pointers are device pointers)
+fd::Aux* g_dev_aux = nullptr;
+std::mutex g_aux_mutex;
+
+const void* device_aux() {
+    std::lock_guard<std::mutex> lock(g_aux_mutex);
+    if (!g_dev_aux) {
+        std::memset(&g_host_aux, 0, sizeof g_host_aux);
+        if (hipMalloc((void**)&g_dev_aux, sizeof(fd::Aux)) != hipSuccess) return nullptr;
+        hipMemcpy(g_dev_aux, &g_host_aux, sizeof(fd::Aux), hipMemcpyHostToDevice);
+    }
+    return g_dev_aux;
+}
+
+int upload_table_set(int set, int n, const float* pitches, const int* lengths, const float* data) {
+    if (set < 0 || set >= fd::WT_SETS || n < 3 || n > fd::WT_MAX_TABLES) return fail(FDSP_EINVAL, "bad wavetable set or table count");
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+        if (lengths[i] <= 0 || (lengths[i] & (lengths[i] - 1))) return fail(FDSP_EINVAL, "table lengths must be powers of two");
+        total += (size_t)lengths[i];
+    }
+    if (!device_aux()) return fail(FDSP_EDEVICE, "no device memory for wavetables");
+    std::lock_guard<std::mutex> lock(g_aux_mutex);
+    float* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, total * sizeof(float)));
+    HIPCHK(hipMemcpy(d, data, total * sizeof(float), hipMemcpyHostToDevice));
+    fd::WtSet& w = g_host_aux.wt[set];
+    if (w.data) hipFree(const_cast<float*>(w.data));
+    w.n = n;
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+        w.pitch[i] = pitches[i];
+        w.off[i] = (int)off;
+        w.len[i] = lengths[i];
+        off += (size_t)lengths[i];
+    }
+    w.data = d;
+    HIPCHK(hipMemcpy(g_dev_aux, &g_host_aux, sizeof(fd::Aux), hipMemcpyHostToDevice));
+    return FDSP_OK;
+}
+
+// In-place radix-2 inverse FFT (unnormalised), f32 like the reference's microfft path (fft.rs:51-100).
+void ifft_inplace(std::vector<float>& re, std::vector<float>& im) {
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; i++) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            std::swap(re[i], re[j]);
+            std::swap(im[i], im[j]);
+        }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = 2.0 * 3.14159265358979323846 / (double)len;
+        for (size_t i = 0; i < n; i += len) {
+            for (size_t k = 0; k < len / 2; k++) {
+                const float wr = (float)std::cos(ang * (double)k), wi = (float)std::sin(ang * (double)k);
+                const size_t a = i + k, b = i + k + len / 2;
+                const float xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - xr;
+                im[b] = im[a] - xi;
+                re[a] = re[a] + xr;
+                im[a] = im[a] + xi;
+            }
+        }
+    }
+}
+
+// Wavetable::new + make_wave (wavetable.rs:44-123) for the built-in shapes (saw_table :493, square_table :510,
+// triangle_table :523).  Table bits are not pinned against the reference (its FFT lives in the microfft crate).
+int build_default_table_set(int set) {
+    auto phase = [set](unsigned i) -> double {
+        if (set == 0) return (i & 1) == 1 ? 0.0 : 0.5;
+        if (set == 1) return 0.0;
+        return (i & 3) == 3 ? 0.5 : 0.0;
+    };
+    auto amplitude = [set](unsigned i) -> double {
+        if (set == 0) return 1.0 / (double)i;
+        if (set == 1) return (i & 1) == 1 ? 1.0 / (double)i : 0.0;
+        return (i & 1) == 1 ? 1.0 / ((double)i * (double)i) : 0.0;
+    };
+    if (set < 0 || set > 2) return fail(FDSP_EINVAL, "built-in table sets: 0 saw, 1 square, 2 triangle");
+    std::vector<float> pitches, data;
+    std::vector<int> lengths;
+    const double p_factor = std::pow(2.0, 1.0 / 4.0);
+    float max_amplitude = 0.0f;
+    for (double pitch = 20.0; pitch <= 20000.0; pitch *= p_factor) {
+        const size_t harmonics = (size_t)std::floor(22000.0 / pitch);
+        size_t length = 1;
+        while (length < 4 * harmonics) length <<= 1;
+        length = length < 32 ? 32 : (length > 8192 ? 8192 : length);
+        std::vector<float> re(length, 0.0f), im(length, 0.0f);
+        for (size_t i = 1; i <= harmonics; i++) {
+            const double f = pitch * (double)i;
+            double x = (f - 22000.0) / (20000.0 - 22000.0);
+            x = x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x);
+            const double w = amplitude((unsigned)i) * (((x * 6 - 15) * x + 10) * x * x * x);  // smooth5
+            if (w > 0.0) {
+                const float r = (float)w, theta = (float)(6.283185307179586 * phase((unsigned)i));
+                re[i] = r * std::cos(theta);
+                im[i] = r * std::sin(theta);
+            }
+        }
+        ifft_inplace(re, im);  // microfft's ifft divides by N and make_wave multiplies by N again: net unnormalised
+        for (size_t k = 0; k < length; k++) {
+            max_amplitude = std::fmax(max_amplitude, std::fabs(im[k]));
+            data.push_back(im[k]);
+        }
+        pitches.push_back((float)pitch);
+        lengths.push_back((int)length);
+    }
+    if (max_amplitude > 0.0f) {
+        const float z = 1.0f / max_amplitude;
+        for (float& x : data) x *= z;
+    }
+    return upload_table_set(set, (int)pitches.size(), pitches.data(), lengths.data(), data.data());
 }
 
 }  // namespace
@@ -100,6 +221,22 @@ __global__ __launch_bounds__(256) void k_mix(const float* __restrict__ x, const 
         mix[t] = sl[0];
         mix[T + t] = sr[0];
     }
+}
+
+// Sum over voices of a voice-minor buffer [rows][voices] -> [rows]; same fixed order as k_mix (per-GPU partial of the
+// stereo mix-down for graphs that already end in a Panner, e.g. BASELINE config 4).
+__global__ __launch_bounds__(256) void k_sum_voices(const float* __restrict__ x, float* __restrict__ out, size_t V) {
+    __shared__ float sm[256];
+    const float* row = x + (size_t)blockIdx.x * V;
+    float a = 0.0f;
+    for (size_t v = threadIdx.x; v < V; v += 256) a += row[v];
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) sm[threadIdx.x] += sm[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
 }
 
 }  // namespace
@@ -176,7 +313,7 @@ int fdsp_bank_create(const char* kind, size_t voices, fdsp_bank** out) {
         return fail(FDSP_EDEVICE, "stream/event creation failed");
     }
     hipMemsetAsync(b->slots, 0, bytes, b->stream);
-    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 0, b->sr, nullptr, b->stream);
+    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 0, b->sr, nullptr, device_aux(), b->stream);
     e = hipStreamSynchronize(b->stream);
     if (e != hipSuccess) {
         fdsp_bank_destroy(b);
@@ -203,14 +340,14 @@ size_t fdsp_bank_voices(const fdsp_bank* b) { return b ? b->V : 0; }
 int fdsp_bank_set_sample_rate(fdsp_bank* b, double sr) {
     if (!b || !(sr > 0.0)) return fail(FDSP_EINVAL, "bad bank or sample rate");
     b->sr = sr;
-    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, sr, nullptr, b->stream);
+    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, sr, nullptr, device_aux(), b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
 }
 
 int fdsp_bank_reset(fdsp_bank* b) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
-    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 2, b->sr, nullptr, b->stream);
+    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 2, b->sr, nullptr, device_aux(), b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
 }
@@ -228,7 +365,7 @@ int fdsp_bank_set_seed(fdsp_bank* b, const uint64_t* h_seeds, size_t first, size
             return fail(FDSP_EDEVICE, hipGetErrorString(e));
         }
     }
-    b->ops->lifecycle(b->slots, b->stride, first, count, 3, b->sr, d, b->stream);
+    b->ops->lifecycle(b->slots, b->stride, first, count, 3, b->sr, d, device_aux(), b->stream);
     hipError_t e = hipStreamSynchronize(b->stream);
     if (d) hipFree(d);
     if (e != hipSuccess) return fail(FDSP_EDEVICE, hipGetErrorString(e));
@@ -258,7 +395,7 @@ int fdsp_bank_set_param(fdsp_bank* b, const char* name, const float* h_values, s
     if (count == 0) return FDSP_OK;
     if (int rc = set_words(b, s, h_values, first, count)) return rc;
     // re-derive coefficients like the reference setters do (idempotent for untouched voices)
-    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, b->stream);
+    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, device_aux(), b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
 }
@@ -283,7 +420,7 @@ int fdsp_bank_set_param_u64(fdsp_bank* b, const char* name, const uint64_t* h_va
     }
     if (int rc = set_words(b, lo, wl.data(), first, count)) return rc;
     if (int rc = set_words(b, hi, wh.data(), first, count)) return rc;
-    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, b->stream);
+    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, device_aux(), b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
 }
@@ -328,7 +465,7 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
     hipStream_t s = stream ? (hipStream_t)stream : b->stream;
     if (s != b->stream) HIPCHK(hipStreamSynchronize(b->stream));  // order after pending parameter updates
     HIPCHK(hipEventRecord(b->e0, s));
-    b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, s);
+    b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, device_aux(), s);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->e1, s));
     b->timed = true;
@@ -390,6 +527,39 @@ int fdsp_mix_stereo(const float* d_voices, const float* d_pan, float* d_mix, siz
     hipLaunchKernelGGL(k_mix, dim3((unsigned)frames), dim3(256), 0, s, d_voices, w, w + voices, d_mix, frames, voices);
     HIPCHK(hipGetLastError());
     HIPCHK(hipFreeAsync(w, s));
+    return FDSP_OK;
+}
+
+int fdsp_wavetable_upload(int set, int n_tables, const float* h_pitches, const int* h_lengths, const float* h_data) {
+    if (!h_pitches || !h_lengths || !h_data) return fail(FDSP_EINVAL, "NULL table data");
+    return upload_table_set(set, n_tables, h_pitches, h_lengths, h_data);
+}
+
+int fdsp_wavetable_build(int set) { return build_default_table_set(set); }
+
+int fdsp_wavetable_get(int set, int* n_tables, float* h_pitches, int* h_lengths, float* h_data, size_t capacity) {
+    if (set < 0 || set >= fd::WT_SETS || !n_tables) return fail(FDSP_EINVAL, "bad set");
+    std::lock_guard<std::mutex> lock(g_aux_mutex);
+    const fd::WtSet& w = g_host_aux.wt[set];
+    *n_tables = g_dev_aux ? w.n : 0;
+    if (!g_dev_aux || w.n == 0) return FDSP_OK;
+    size_t total = 0;
+    for (int i = 0; i < w.n; i++) total += (size_t)w.len[i];
+    if (h_pitches) std::memcpy(h_pitches, w.pitch, sizeof(float) * (size_t)w.n);
+    if (h_lengths) std::memcpy(h_lengths, w.len, sizeof(int) * (size_t)w.n);
+    if (h_data) {
+        if (capacity < total) return fail(FDSP_EINVAL, "capacity too small");
+        HIPCHK(hipMemcpy(h_data, w.data, total * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return FDSP_OK;
+}
+
+int fdsp_sum_voices(const float* d_in, float* d_out, size_t channels, size_t frames, size_t voices, void* stream) {
+    if (!d_in || !d_out) return fail(FDSP_EINVAL, "NULL buffer");
+    if (channels == 0 || frames == 0 || voices == 0) return FDSP_OK;
+    hipLaunchKernelGGL(k_sum_voices, dim3((unsigned)(channels * frames)), dim3(256), 0, (hipStream_t)stream, d_in, d_out,
+                       voices);
+    HIPCHK(hipGetLastError());
     return FDSP_OK;
 }
 

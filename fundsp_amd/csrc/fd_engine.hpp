@@ -108,11 +108,12 @@ struct VDescribe {  // host only
 //     2 = reset, 3 = set_seed (seeds != null) or re-apply the construction hash (seeds == null)
 template <class G>
 __global__ __launch_bounds__(64) void k_lifecycle(float* slots, size_t stride, size_t first, size_t count, int op,
-                                                  double sr, const uint64_t* seeds) {
+                                                  double sr, const uint64_t* seeds, const void* aux) {
     size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= count) return;
     size_t v = first + i;
     G g;
+    g.bind(aux);
     {
         VLoad ld{slots + v, stride, 0};
         g.visit(ld);
@@ -154,7 +155,7 @@ FD_D void wave_sync() {
 template <class G, int MODE, int LAYOUT, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, size_t stride, size_t V,
                                                      const float* __restrict__ in, float* __restrict__ out,
-                                                     size_t T, size_t fstride) {
+                                                     size_t T, size_t fstride, const void* aux) {
     constexpr int NI = G::IN, NO = G::OUT;
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;  // wave in block
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
     if (v0 >= stride) return;  // whole wave beyond the padded bank (last workgroup of a ragged bank)
 
     G g;
+    g.bind(aux);
     {
         VLoad ld{slots + v, stride, 0};  // stride is padded to a multiple of 64: always in bounds
         g.visit(ld);
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
             const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
             const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
             float fi[NI > 0 ? NI : 1], fo[NO];
-            g.begin_block();
+            g.begin_block(size);
             const G snap = g;  // block-start registers, for the rollback below
 #pragma unroll 4
             for (int i = 0; i < full; i += 2) {  // two frames per iteration (full is a multiple of 8)
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
 #pragma unroll
                 for (int c = 0; c < NI; c++)
                     pi[c] = v2f{inv[((size_t)c * T + t) * V], inv[((size_t)c * T + t + 1) * V]};
-                g.template step2<true>(pi, po);
+                g.template step2<PH_SIMD>(pi, po);
 #pragma unroll
                 for (int c = 0; c < NO; c++) {
                     outv[((size_t)c * T + t) * V] = po[c].x;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
                     const size_t t = t0 + i;
 #pragma unroll
                     for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
-                    g.template step<true>(fi, fo);
+                    g.template step<PH_SIMD>(fi, fo);
 #pragma unroll
                     for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
                 }
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
                 const size_t t = t0 + i;
 #pragma unroll
                 for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
-                g.template step<false>(fi, fo);
+                g.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(fi, fo);
 #pragma unroll
                 for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
             }
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
             }
             // compute: each lane walks its own LDS row, 4 frames per ds_read_b128 / ds_write_b128.
             // pass 0 = packed two-frame path; pass 1 (rare) = rollback + scalar path if a packed shortcut tripped.
-            g.begin_block();
+            g.begin_block(size);
             const G snap = g;
             for (int pass = 0; pass < 2; pass++) {
                 if (pass == 1) {
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
                                 v2f pi[NI > 0 ? NI : 1], po[NO];
 #pragma unroll
                                 for (int c = 0; c < NI; c++) pi[c] = v2f{xi[c][j], xi[c][j + 1]};
-                                g.template step2<true>(pi, po);
+                                g.template step2<PH_SIMD>(pi, po);
 #pragma unroll
                                 for (int c = 0; c < NO; c++) {
                                     xo[c][j] = po[c].x;
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
                                 float fi[NI > 0 ? NI : 1], fo[NO];
 #pragma unroll
                                 for (int c = 0; c < NI; c++) fi[c] = xi[c][j];
-                                g.template step<true>(fi, fo);
+                                g.template step<PH_SIMD>(fi, fo);
 #pragma unroll
                                 for (int c = 0; c < NO; c++) xo[c][j] = fo[c];
                             }
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
                             for (int c = 0; c < NI; c++) fi[c] = xi[c][j];
 #pragma unroll
                             for (int c = 0; c < NO; c++) fo[c] = 0.0f;
-                            if (i4 + j < size) g.template step<false>(fi, fo);
+                            if (i4 + j < size) g.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(fi, fo);
 #pragma unroll
                             for (int c = 0; c < NO; c++) xo[c][j] = fo[c];
                         }
@@ -351,45 +353,45 @@ struct KindOps {
     int nin, nout;
     std::vector<SlotInfo> slots;
     void (*lifecycle)(float* slots, size_t stride, size_t first, size_t count, int op, double sr,
-                      const uint64_t* d_seeds, hipStream_t s);
+                      const uint64_t* d_seeds, const void* aux, hipStream_t s);
     void (*render)(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
-                   int layout, int mode, hipStream_t s);
+                   int layout, int mode, const void* aux, hipStream_t s);
 };
 
 template <class G>
 void launch_lifecycle(float* slots, size_t stride, size_t first, size_t count, int op, double sr,
-                      const uint64_t* d_seeds, hipStream_t s) {
+                      const uint64_t* d_seeds, const void* aux, hipStream_t s) {
     if (count == 0) return;
     unsigned grid = (unsigned)((count + 63) / 64);
-    hipLaunchKernelGGL((k_lifecycle<G>), dim3(grid), dim3(64), 0, s, slots, stride, first, count, op, sr, d_seeds);
+    hipLaunchKernelGGL((k_lifecycle<G>), dim3(grid), dim3(64), 0, s, slots, stride, first, count, op, sr, d_seeds, aux);
 }
 
 template <class G, int MODE, int LAYOUT>
 void launch_render_cfg(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
-                       hipStream_t s) {
+                       const void* aux, hipStream_t s) {
     // 4-wave workgroups unless the per-wave LDS tiles of the planar path would not fit 4x in 64 KB of LDS
     constexpr size_t lds_per_wave = LAYOUT == LAYOUT_PLANAR ? (size_t)(G::IN + G::OUT) * 64 * TILE_STRIDE * 4 : 0;
     constexpr int WPB = (lds_per_wave * 4 <= 160 * 1024 - 1024) ? 4 : 1;
     const size_t waves = (V + 63) / 64;
     unsigned grid = (unsigned)((waves + WPB - 1) / WPB);
     hipLaunchKernelGGL((k_render<G, MODE, LAYOUT, WPB>), dim3(grid), dim3(64 * WPB), 0, s, slots, stride, V, in, out, T,
-                       fstride);
+                       fstride, aux);
 }
 
 template <class G>
 void launch_render(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
-                   int layout, int mode, hipStream_t s) {
+                   int layout, int mode, const void* aux, hipStream_t s) {
     if (V == 0 || T == 0) return;
     if (layout == LAYOUT_VOICE_MINOR) {
         if (mode == MODE_PROCESS)
-            launch_render_cfg<G, MODE_PROCESS, LAYOUT_VOICE_MINOR>(slots, stride, V, in, out, T, fstride, s);
+            launch_render_cfg<G, MODE_PROCESS, LAYOUT_VOICE_MINOR>(slots, stride, V, in, out, T, fstride, aux, s);
         else
-            launch_render_cfg<G, MODE_TICK, LAYOUT_VOICE_MINOR>(slots, stride, V, in, out, T, fstride, s);
+            launch_render_cfg<G, MODE_TICK, LAYOUT_VOICE_MINOR>(slots, stride, V, in, out, T, fstride, aux, s);
     } else {
         if (mode == MODE_PROCESS)
-            launch_render_cfg<G, MODE_PROCESS, LAYOUT_PLANAR>(slots, stride, V, in, out, T, fstride, s);
+            launch_render_cfg<G, MODE_PROCESS, LAYOUT_PLANAR>(slots, stride, V, in, out, T, fstride, aux, s);
         else
-            launch_render_cfg<G, MODE_TICK, LAYOUT_PLANAR>(slots, stride, V, in, out, T, fstride, s);
+            launch_render_cfg<G, MODE_TICK, LAYOUT_PLANAR>(slots, stride, V, in, out, T, fstride, aux, s);
     }
 }
 

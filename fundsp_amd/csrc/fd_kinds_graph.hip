@@ -13,10 +13,17 @@ using NoiseBiquad = Pipe<Noise, Biquad>;
 using FmMod = Unop<Unop<Unop<SineHz, UMulScalar>, UMulScalar>, UAddScalar>;
 using FmSvf = Pipe<Pipe<FmMod, Sine>, FixedSvf>;
 
+// config 4 voice: ((dc(f) >> saw() | dc(fc) | dc(q)) >> moog()) * adsr_live(a, d, s, r) >> pan(p)
+// (`|` binds loosest, `*` tightest: combinator.rs; moog() is the 3-input variant prelude.rs:551; the gate is the
+// graph's one input, feeding adsr_live -- Binop inputs = X inputs (0) + Y inputs (1), audionode.rs:912)
+using SawMoog = Pipe<Stack<Stack<Pipe<Constant<1>, WaveSynth<0>>, Constant<1>>, Constant<1>>, Moog<3>>;
+using SawMoogAdsrPan = Pipe<Binop<OpMul, SawMoog, AdsrLive>, Panner>;
+
 void register_graph_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<SineHz>("sine_hz"));
     out.push_back(make_kind<SineHzLowpass>("sine_hz_lowpass_hz"));
     out.push_back(make_kind<NoiseBiquad>("noise_biquad"));
     out.push_back(make_kind<FmSvf>("fm_svf"));
+    out.push_back(make_kind<SawMoogAdsrPan>("saw_moog_adsr_pan"));
 }
 }  // namespace fd

@@ -20,5 +20,10 @@ void register_leaf_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<Fir<2>>("fir2"));
     out.push_back(make_kind<Fir<3>>("fir3"));
     out.push_back(make_kind<Tick<1>>("tick"));
+    out.push_back(make_kind<WaveSynth<0>>("saw"));
+    out.push_back(make_kind<WaveSynth<1>>("square"));
+    out.push_back(make_kind<WaveSynth<2>>("triangle"));
+    out.push_back(make_kind<AdsrLive>("adsr_live"));
+    out.push_back(make_kind<Panner>("pan"));
 }
 }  // namespace fd

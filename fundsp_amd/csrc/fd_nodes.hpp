@@ -24,19 +24,27 @@ namespace fd {
 
 enum FieldKind { PARAM = 0, COEF = 1, STATE = 2 };
 
-// step2<SIMD>(in, out): two consecutive frames at once, channel c of frames (n, n+1) packed in one <2 x float>.
+// Which reference path a sample belongs to (template argument of step / step2):
+//   PH_SIMD  process mode, sample inside a full 8-sample SIMD item of the block  -> a node's `process` arithmetic
+//   PH_REM   process mode, one of the trailing `size & 7` samples: nodes that end their `process` with
+//            process_remainder (Sine, WaveSynth, Shaper) use `tick` here; nodes whose `process` walks the whole
+//            block themselves (EnvelopeIn, Noise, Constant, Panner) keep their `process` arithmetic
+//   PH_TICK  tick mode: AudioNode::tick for every sample
+constexpr int PH_SIMD = 0, PH_REM = 1, PH_TICK = 2;
+
+// step2<PH>(in, out): two consecutive frames at once, channel c of frames (n, n+1) packed in one <2 x float>.
 // Feed-forward nodes (Constant, Unop, Binop, the sine polynomial of Sine::process) implement it with packed f32
 // arithmetic, which halves their instruction count; nodes whose samples depend serially on each other use this
 // default, which is two `step` calls.  Either way each frame's arithmetic is identical to `step`.
 #define FD_STEP2_VIA_STEP                                                      \
-    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) {           \
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {           \
         float i0[IN > 0 ? IN : 1], i1[IN > 0 ? IN : 1], o0[OUT], o1[OUT];      \
         _Pragma("unroll") for (int c = 0; c < IN; c++) {                       \
             i0[c] = in[c].x;                                                   \
             i1[c] = in[c].y;                                                   \
         }                                                                      \
-        this->template step<SIMD>(i0, o0);                                     \
-        this->template step<SIMD>(i1, o1);                                     \
+        this->template step<PH>(i0, o0);                                     \
+        this->template step<PH>(i1, o1);                                     \
         _Pragma("unroll") for (int c = 0; c < OUT; c++) out[c] = v2f{o0[c], o1[c]}; \
     }
 
@@ -149,12 +157,13 @@ struct Constant {
     FD_HD void reset() {}
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
-    FD_HD void begin_block() {}
+    FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    template <bool SIMD> FD_HD void step(const float*, float* out) {
+    FD_HD void bind(const void*) {}
+    template <int PH> FD_HD void step(const float*, float* out) {
         for (int i = 0; i < N; i++) out[i] = value[i];
     }
-    template <bool SIMD> FD_HD void step2(const v2f*, v2f* out) {
+    template <int PH> FD_HD void step2(const v2f*, v2f* out) {
         for (int i = 0; i < N; i++) out[i] = splat2(value[i]);
     }
 };
@@ -169,10 +178,11 @@ struct Pass {
     FD_HD void reset() {}
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
-    FD_HD void begin_block() {}
+    FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    template <bool SIMD> FD_HD void step(const float* in, float* out) { out[0] = in[0]; }
-    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) { out[0] = in[0]; }
+    FD_HD void bind(const void*) {}
+    template <int PH> FD_HD void step(const float* in, float* out) { out[0] = in[0]; }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) { out[0] = in[0]; }
 };
 
 // Sine<f32>  oscillator.rs:21-102 (ID 21)
@@ -182,8 +192,9 @@ struct Sine {
     float phase, sample_duration, has_phase, initial_phase;
     uint64_t hash;
     float tmax;  // transient guard of the packed sine path (not a slot)
-    FD_HD void begin_block() { tmax = 0.0f; }
+    FD_HD void begin_block(int) { tmax = 0.0f; }
     FD_HD bool tripped() const { return !(tmax < 8192.0f); }
+    FD_HD void bind(const void*) {}
     template <class V> FD_HD void visit(V& v) {
         v.f(phase, STATE, "phase");
         v.f(sample_duration, COEF, "sample_duration");
@@ -207,8 +218,8 @@ struct Sine {
         return atto(h, ID);
     }
     FD_HD void end_simd() { phase = phase - __builtin_floorf(phase); }  // :85 (one wrap after the SIMD items)
-    template <bool SIMD> FD_HD void step(const float* in, float* out) {
-        if (SIMD) {  // process :74-86: phase runs unwrapped inside the block, f32x8 (wide) sin
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        if (PH == PH_SIMD) {  // process :74-86: phase runs unwrapped inside the block, f32x8 (wide) sin
             float tmp = phase;
             phase += in[0] * sample_duration;
             out[0] = wide_sinf(tmp * F32_TAU);
@@ -219,8 +230,8 @@ struct Sine {
             out[0] = sinf_musl(p * F32_TAU);
         }
     }
-    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) {
-        if (SIMD) {  // serial f32 phase recurrence for the two frames, then ONE packed polynomial evaluation
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        if (PH == PH_SIMD) {  // serial f32 phase recurrence for the two frames, then ONE packed polynomial evaluation
             v2f d = in[0] * sample_duration;
             float t0 = phase;
             phase += d.x;
@@ -229,8 +240,8 @@ struct Sine {
             out[0] = wide_sin2(v2f{t0, t1} * F32_TAU, tmax);
         } else {
             float o0, o1, i0 = in[0].x, i1 = in[0].y;
-            this->template step<false>(&i0, &o0);
-            this->template step<false>(&i1, &o1);
+            this->template step<PH>(&i0, &o0);
+            this->template step<PH>(&i1, &o1);
             out[0] = v2f{o0, o1};
         }
     }
@@ -268,9 +279,10 @@ struct Noise {
         return atto(h, ID);
     }
     FD_HD void end_simd() {}
-    FD_HD void begin_block() {}
+    FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    template <bool SIMD> FD_HD void step(const float*, float* out) {  // :197-202
+    FD_HD void bind(const void*) {}
+    template <int PH> FD_HD void step(const float*, float* out) {  // :197-202
         state += 1u;
         out[0] = (float)(hash32x(state) >> 8) * (2.0f / (float)((1 << 24) - 1)) - 1.0f;
     }
@@ -333,9 +345,10 @@ struct FixedSvf {
     FD_HD void reset() { c.ic1eq = 0.0f; c.ic2eq = 0.0f; }  // :984-987
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
-    FD_HD void begin_block() {}
+    FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    template <bool SIMD> FD_HD void step(const float* in, float* out) { out[0] = c.tick(in[0]); }
+    FD_HD void bind(const void*) {}
+    template <int PH> FD_HD void step(const float* in, float* out) { out[0] = c.tick(in[0]); }
     FD_STEP2_VIA_STEP
 };
 
@@ -368,9 +381,10 @@ struct Svf {
     FD_HD void reset() { c.ic1eq = 0.0f; c.ic2eq = 0.0f; }  // :818-821
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
-    FD_HD void begin_block() {}
+    FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    template <bool SIMD> FD_HD void step(const float* in, float* out) {
+    FD_HD void bind(const void*) {}
+    template <int PH> FD_HD void step(const float* in, float* out) {
         // update_inputs :299-313 (3 inputs) / :588-606 (4 inputs): recompute only when an input changed
         bool changed = in[1] != cutoff || in[2] != q;
         if (NIN == 4) changed = changed || in[3] != gain;
@@ -402,8 +416,9 @@ struct BiquadT {
     FD_HD void reset() { x1 = x2 = y1 = y2 = 0.0f; }   // :172-177
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
-    FD_HD void begin_block() {}
+    FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
+    FD_HD void bind(const void*) {}
     FD_HD float tick(float x0) {  // :184-194
         float y0 = b0 * x0 + b1 * x1 + b2 * x2 - a1 * y1 - a2 * y2;
         x2 = x1;
@@ -412,7 +427,7 @@ struct BiquadT {
         y1 = y0;
         return y0;
     }
-    template <bool SIMD> FD_HD void step(const float* in, float* out) { out[0] = tick(in[0]); }
+    template <int PH> FD_HD void step(const float* in, float* out) { out[0] = tick(in[0]); }
     FD_STEP2_VIA_STEP
 };
 using Biquad = BiquadT<15>;
@@ -445,9 +460,10 @@ struct ButterLowpass {
     FD_HD void reset() { b.reset(); }
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
-    FD_HD void begin_block() {}
+    FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :269-277
+    FD_HD void bind(const void*) {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // :269-277
         if (NIN > 1) {
             if (in[1] != cutoff) set_cutoff(in[1]);
         }
@@ -486,9 +502,10 @@ struct Resonator {
     FD_HD void reset() { b.reset(); }
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
-    FD_HD void begin_block() {}
+    FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :354-366
+    FD_HD void bind(const void*) {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // :354-366
         if (NIN >= 3) {
             if (in[1] != center || in[2] != q) set_center_q(in[1], in[2]);
         }
@@ -534,9 +551,10 @@ struct Moog {
     FD_HD void reset() { s0 = s1 = s2 = s3 = px = ps0 = ps1 = ps2 = 0.0f; }  // :65-74
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
-    FD_HD void begin_block() {}
+    FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :82-100
+    FD_HD void bind(const void*) {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // :82-100
         if (NIN > 1) set_cutoff_q(in[1], in[2]);
         float x = -rez * s3 + in[0];
         s0 = (x + px) * p - k * s0;
@@ -572,9 +590,10 @@ struct Fir {
     }
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
-    FD_HD void begin_block() {}
+    FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :57-70
+    FD_HD void bind(const void*) {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // :57-70
         for (int i = 0; i + 1 < N; i++) v[i] = v[i + 1];
         v[N - 1] = in[0];
         float output = 0.0f;
@@ -600,9 +619,10 @@ struct Tick {
     }
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
-    FD_HD void begin_block() {}
+    FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    template <bool SIMD> FD_HD void step(const float* in, float* out) {  // :47-52
+    FD_HD void bind(const void*) {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // :47-52
         for (int i = 0; i < N; i++) {
             float o = buffer[i];
             buffer[i] = in[i];
@@ -610,6 +630,288 @@ struct Tick {
         }
     }
     FD_STEP2_VIA_STEP
+};
+
+
+// ---------------------------------------------------------------------------------------------------------
+// wavetable oscillator, envelope, panner (BASELINE config 4)
+// ---------------------------------------------------------------------------------------------------------
+
+// Shared wavetable data (Arc<Wavetable> in the reference, wavetable.rs:82-84): one table set per waveform, in HBM
+// (saw: 40 tables, 41 024 floats = 160 KiB -- lives in L2; LDS cannot hold it next to anything else).
+constexpr int WT_MAX_TABLES = 48, WT_SETS = 4;
+struct WtSet {
+    int n;
+    float pitch[WT_MAX_TABLES];
+    int off[WT_MAX_TABLES];
+    int len[WT_MAX_TABLES];
+    const float* data;
+};
+struct Aux {
+    WtSet wt[WT_SETS];
+};
+
+FD_HD float optimal4x44(float a0, float a1, float a2, float a3, float x) {  // wavetable.rs:24-38
+    float z = x - (float)0.5;
+    float even1 = a2 + a1, odd1 = a2 - a1, even2 = a3 + a0, odd2 = a3 - a0;
+    float c0 = even1 * (float)0.4656725512077848 + even2 * (float)0.03432729708429672;
+    float c1 = odd1 * (float)0.5374383075356016 + odd2 * (float)0.1542946255730746;
+    float c2 = even1 * (float)-0.25194210134021744 + even2 * (float)0.2519474493593906;
+    float c3 = odd1 * (float)-0.46896069955075126 + odd2 * (float)0.15578800670302476;
+    float c4 = even1 * (float)0.00986988334359864 + even2 * (float)-0.00989340017126506;
+    return (((c4 * z + c3) * z + c2) * z + c1) * z + c0;
+}
+FD_HD float clamp01f(float x) {  // math.rs:136-138
+    x = x > 0.0f ? x : 0.0f;
+    return x < 1.0f ? x : 1.0f;
+}
+FD_HD float wt_at(const WtSet* t, int i, float phase) {  // Wavetable::at :154-166 (== one lane of at_simd)
+    const float* tab = t->data + t->off[i];
+    uint32_t len = (uint32_t)t->len[i];
+    float p = (float)len * phase;
+    uint32_t i1 = (uint32_t)p;
+    float w = p - (float)i1;
+    uint32_t mask = len - 1;
+    uint32_t i0 = (i1 - 1u) & mask;
+    i1 = i1 & mask;
+    uint32_t i2 = (i1 + 1u) & mask;
+    uint32_t i3 = (i1 + 2u) & mask;
+    return optimal4x44(tab[i0], tab[i1], tab[i2], tab[i3], w);
+}
+FD_HD int wt_table_index(const WtSet* t, int hint, float frequency) {  // :189-211
+    if (frequency >= t->pitch[hint] && frequency <= t->pitch[hint + 1]) return hint;
+    int i0 = 0, i1 = t->n - 3;
+    while (i0 < i1) {
+        int i = (i0 + i1) >> 1;
+        if (t->pitch[i] > frequency) {
+            i1 = i;
+        } else if (t->pitch[i + 1] > frequency) {
+            i0 = i;
+            break;
+        } else {
+            i0 = i + 1;
+        }
+    }
+    return i0;
+}
+
+// WaveSynth<U1>  wavetable.rs:249-359 (ID 34).  SET selects the shared table set (0 saw, 1 square, 2 triangle).
+template <int SET>
+struct WaveSynth {
+    static constexpr int IN = 1, OUT = 1;
+    static constexpr uint64_t ID = 34;
+    float phase, sample_duration, has_phase, initial_phase;
+    uint32_t hint;
+    uint64_t hash;
+    // transients
+    const WtSet* wt;
+    int item_pos, item_table;
+    float item_w;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(phase, STATE, "phase");
+        v.u32(hint, STATE, "table_hint");
+        v.f(sample_duration, COEF, "sample_duration");
+        v.f(has_phase, PARAM, "has_initial_phase");
+        v.f(initial_phase, PARAM, "initial_phase");
+        v.u64(hash, STATE, "hash");
+    }
+    FD_HD void bind(const void* a) { wt = &static_cast<const Aux*>(a)->wt[SET]; }
+    FD_HD void init() {  // WaveSynth::new :270-281: phase 0.0 WITHOUT reset
+        phase = 0.0f;
+        hint = 0;
+        has_phase = 0.0f;
+        initial_phase = 0.0f;
+        hash = 0;
+    }
+    FD_HD void update(double sr) { sample_duration = 1.0f / (float)sr; }                    // :299-302
+    FD_HD void reset() { phase = has_phase != 0.0f ? initial_phase : (float)rnd1(hash); }  // :292-297
+    FD_HD uint64_t ping(bool probe, uint64_t h) {
+        if (!probe) {  // set_hash :304-307
+            hash = h;
+            reset();
+        }
+        return atto(h, ID);
+    }
+    FD_HD void begin_block(int) { item_pos = 0; }
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() { phase = phase - __builtin_floorf(phase); }  // :345
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        if (PH == PH_SIMD) {  // process :327-348
+            if ((item_pos & 7) == 0) {  // table pair and crossfade from LANE 0's frequency for the whole 8-sample item
+                float f0 = __builtin_fabsf(in[0]);
+                item_table = wt_table_index(wt, (int)hint, f0);
+                item_w = clamp01f((f0 - wt->pitch[item_table]) / (wt->pitch[item_table + 1] - wt->pitch[item_table]));
+                hint = (uint32_t)item_table;
+            }
+            item_pos++;
+            phase += in[0] * sample_duration;
+            float ph = phase - __builtin_floorf(phase);  // wide's inherent f32x8::floor (true floor)
+            out[0] = (1.0f - item_w) * wt_at(wt, item_table + 1, ph) + item_w * wt_at(wt, item_table + 2, ph);
+        } else {  // tick :310-324: increment + wrap BEFORE reading
+            float frequency = in[0];
+            phase += frequency * sample_duration;
+            phase -= __builtin_floorf(phase);
+            float f0 = __builtin_fabsf(frequency);
+            int table = wt_table_index(wt, (int)hint, f0);
+            float w = clamp01f((f0 - wt->pitch[table]) / (wt->pitch[table + 1] - wt->pitch[table]));
+            hint = (uint32_t)table;
+            out[0] = (1.0f - w) * wt_at(wt, table + 1, phase) + w * wt_at(wt, table + 2, phase);
+        }
+    }
+    FD_STEP2_VIA_STEP
+};
+
+FD_HD float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; }  // math.rs:169-178
+
+// adsr_live(attack, decay, sustain, release) = EnvelopeIn<f32, closure, U1, f32>  (adsr.rs:21-70,
+// prelude.rs:626-639, envelope.rs:185-358; ID 53).  The Rust closure + its two atomics become plain per-voice state.
+struct AdsrLive {
+    static constexpr int IN = 1, OUT = 1;
+    static constexpr uint64_t ID = 53;
+    float attack, decay, sustain, release, interval;       // params
+    float sd;                                               // coef
+    float attacked, attack_start, release_start;            // closure state
+    float t, t0, t1, v0, v1, value, value_d;                // EnvelopeIn state
+    uint64_t t_hash, hash;
+    // block-walk transients (process path)
+    int blk_i, blk_size, remaining, loop_len;
+    bool full_seg;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(attack, PARAM, "attack"); v.f(decay, PARAM, "decay"); v.f(sustain, PARAM, "sustain");
+        v.f(release, PARAM, "release"); v.f(interval, PARAM, "interval");
+        v.f(sd, COEF, "sample_duration");
+        v.f(attacked, STATE, "attacked"); v.f(attack_start, STATE, "attack_start"); v.f(release_start, STATE, "release_start");
+        v.f(t, STATE, "t"); v.f(t0, STATE, "t_0"); v.f(t1, STATE, "t_1");
+        v.f(v0, STATE, "value_0"); v.f(v1, STATE, "value_1"); v.f(value, STATE, "value"); v.f(value_d, STATE, "value_d");
+        v.u64(t_hash, STATE, "t_hash");
+        v.u64(hash, STATE, "hash");
+    }
+    FD_HD void bind(const void*) {}
+    FD_HD void init() {
+        attack = 0.01f; decay = 0.1f; sustain = 0.6f; release = 0.2f;
+        interval = (float)0.002;  // envelope2: F::from_f64(0.002)
+        attacked = 0.0f; attack_start = 0.0f; release_start = -1.0f;
+        v0 = v1 = value = value_d = 0.0f;
+        hash = 0;
+        reset();
+    }
+    FD_HD void update(double sr) { sd = (float)(1.0 / sr); }  // envelope.rs:300-302
+    FD_HD void reset() {  // :293-298 (closure state is NOT reset)
+        t = 0.0f; t0 = 0.0f; t1 = 0.0f;
+        t_hash = hash;
+    }
+    FD_HD uint64_t ping(bool probe, uint64_t h) {
+        if (!probe) {  // set_hash :346-349: no reset
+            hash = h;
+            t_hash = h;
+        }
+        return atto(h, ID);
+    }
+    FD_HD float closure(float time, float control) {  // adsr.rs:36-56
+        if (release_start >= 0.0f && control > 0.0f) {
+            attacked = 1.0f;
+            attack_start = time;
+            release_start = -1.0f;
+        } else if (release_start < 0.0f && control <= 0.0f) {
+            release_start = time;
+        }
+        if (attacked == 0.0f) return 0.0f;
+        float tt = time - attack_start, ads;
+        if (tt < attack) {
+            ads = lerpf(0.0f, 1.0f, tt / attack);
+        } else {
+            float decay_time = tt - attack;
+            ads = decay_time < decay ? lerpf(1.0f, sustain, decay_time / decay) : sustain;
+        }
+        if (release_start < 0.0f) return ads;
+        float a = release_start + release, b = release_start;
+        return ads * clamp01f((time - a) / (b - a));
+    }
+    FD_HD void next_segment(float input) {  // envelope.rs:252-278
+        if (t0 == 0.0f && t1 == 0.0f) {
+            v0 = closure(t0, input);
+        } else {
+            t0 = t1;
+            v0 = v1;
+        }
+        float next_interval = lerpf(0.75f, 1.25f, (float)rnd1(t_hash)) * interval;
+        t1 = t0 + next_interval;
+        v1 = closure(t1, input);
+        t_hash = t_hash * 6364136223846793005ULL + 1ULL;
+        float u = (t - t0) / (t1 - t0);
+        value = lerpf(v0, v1, u);
+        float samples = next_interval / sd;
+        value_d = (v1 - v0) / samples;
+    }
+    FD_HD void begin_block(int size) { blk_i = 0; blk_size = size; remaining = 0; full_seg = false; loop_len = 0; }
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    FD_HD void start_chunk() {  // one iteration head of the `while i < size` loop, envelope.rs:323-326
+        float c = __builtin_ceilf((t1 - t) / sd);
+        long long left = (long long)c;
+        int room = blk_size - blk_i;
+        bool huge = left < 0 || left > (long long)room;  // `as usize` of a negative value is huge
+        loop_len = huge ? room : (int)left;
+        full_seg = !huge && loop_len == (int)left;
+        remaining = loop_len;
+    }
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        if (PH == PH_TICK) {  // tick :305-313
+            if (t >= t1) next_segment(in[0]);
+            out[0] = value;
+            value += value_d;
+            t += sd;
+        } else {  // process :315-340, walked sample by sample (the whole block, no remainder path)
+            if (blk_i == 0) {
+                if (t >= t1) next_segment(in[0]);
+                start_chunk();
+            }
+            for (int guard = 0; remaining == 0 && guard < 4; guard++) {  // chunk exhausted before this sample
+                if (full_seg) next_segment(in[0]);
+                start_chunk();
+            }
+            out[0] = value;
+            value += value_d;
+            remaining--;
+            blk_i++;
+            if (remaining == 0) t += (float)(long long)loop_len * sd;
+        }
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// Panner<U1>  pan.rs:26-93 (ID 49): fixed pan, mono -> stereo.
+struct Panner {
+    static constexpr int IN = 1, OUT = 2;
+    static constexpr uint64_t ID = 49;
+    float pan, lw, rw;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(pan, PARAM, "pan");
+        v.f(lw, COEF, "left_weight");
+        v.f(rw, COEF, "right_weight");
+    }
+    FD_HD void bind(const void*) {}
+    FD_HD void init() { pan = 0.0f; }
+    FD_HD void update(double) {  // pan_weights :13-17
+        float c = pan > -1.0f ? pan : -1.0f;
+        c = c < 1.0f ? c : 1.0f;
+        float angle = (c + 1.0f) * (F32_PI * 0.25f);
+        lw = cosf_musl(angle);
+        rw = sinf_musl(angle);
+    }
+    FD_HD void reset() {}
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // :55-62 / :63-69
+        out[0] = lw * in[0];
+        out[1] = rw * in[0];
+    }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        out[0] = in[0] * lw;
+        out[1] = in[0] * rw;
+    }
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -633,17 +935,18 @@ struct Pipe {
     FD_HD void reset() { x.reset(); y.reset(); }
     FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }  // :1459
     FD_HD void end_simd() { x.end_simd(); y.end_simd(); }
-    FD_HD void begin_block() { x.begin_block(); y.begin_block(); }
+    FD_HD void begin_block(int n) { x.begin_block(n); y.begin_block(n); }
+    FD_HD void bind(const void* a) { x.bind(a); y.bind(a); }
     FD_HD bool tripped() const { return x.tripped() || y.tripped(); }
-    template <bool SIMD> FD_HD void step(const float* in, float* out) {
+    template <int PH> FD_HD void step(const float* in, float* out) {
         float t[X::OUT > 0 ? X::OUT : 1];
-        x.template step<SIMD>(in, t);
-        y.template step<SIMD>(t, out);
+        x.template step<PH>(in, t);
+        y.template step<PH>(t, out);
     }
-    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) {
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
         v2f t[X::OUT > 0 ? X::OUT : 1];
-        x.template step2<SIMD>(in, t);
-        y.template step2<SIMD>(t, out);
+        x.template step2<PH>(in, t);
+        y.template step2<PH>(t, out);
     }
 };
 
@@ -663,15 +966,16 @@ struct Stack {
     FD_HD void reset() { x.reset(); y.reset(); }
     FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }
     FD_HD void end_simd() { x.end_simd(); y.end_simd(); }
-    FD_HD void begin_block() { x.begin_block(); y.begin_block(); }
+    FD_HD void begin_block(int n) { x.begin_block(n); y.begin_block(n); }
+    FD_HD void bind(const void* a) { x.bind(a); y.bind(a); }
     FD_HD bool tripped() const { return x.tripped() || y.tripped(); }
-    template <bool SIMD> FD_HD void step(const float* in, float* out) {
-        x.template step<SIMD>(in, out);
-        y.template step<SIMD>(in + X::IN, out + X::OUT);
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        x.template step<PH>(in, out);
+        y.template step<PH>(in + X::IN, out + X::OUT);
     }
-    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) {
-        x.template step2<SIMD>(in, out);
-        y.template step2<SIMD>(in + X::IN, out + X::OUT);
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        x.template step2<PH>(in, out);
+        y.template step2<PH>(in + X::IN, out + X::OUT);
     }
 };
 
@@ -696,18 +1000,19 @@ struct Binop {
     FD_HD void reset() { x.reset(); y.reset(); }
     FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }  // :966
     FD_HD void end_simd() { x.end_simd(); y.end_simd(); }
-    FD_HD void begin_block() { x.begin_block(); y.begin_block(); }
+    FD_HD void begin_block(int n) { x.begin_block(n); y.begin_block(n); }
+    FD_HD void bind(const void* a) { x.bind(a); y.bind(a); }
     FD_HD bool tripped() const { return x.tripped() || y.tripped(); }
-    template <bool SIMD> FD_HD void step(const float* in, float* out) {
+    template <int PH> FD_HD void step(const float* in, float* out) {
         float t[OUT];
-        x.template step<SIMD>(in, t);
-        y.template step<SIMD>(in + X::IN, out);
+        x.template step<PH>(in, t);
+        y.template step<PH>(in + X::IN, out);
         for (int i = 0; i < OUT; i++) out[i] = OP::f(t[i], out[i]);
     }
-    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) {
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
         v2f t[OUT];
-        x.template step2<SIMD>(in, t);
-        y.template step2<SIMD>(in + X::IN, out);
+        x.template step2<PH>(in, t);
+        y.template step2<PH>(in + X::IN, out);
         for (int i = 0; i < OUT; i++) out[i] = OP::f(t[i], out[i]);
     }
 };
@@ -734,14 +1039,15 @@ struct Unop {
     FD_HD void reset() { x.reset(); }
     FD_HD uint64_t ping(bool probe, uint64_t h) { return x.ping(probe, atto(h, ID)); }  // :1286
     FD_HD void end_simd() { x.end_simd(); }
-    FD_HD void begin_block() { x.begin_block(); }
+    FD_HD void begin_block(int n) { x.begin_block(n); }
+    FD_HD void bind(const void* a) { x.bind(a); }
     FD_HD bool tripped() const { return x.tripped(); }
-    template <bool SIMD> FD_HD void step(const float* in, float* out) {
-        x.template step<SIMD>(in, out);
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        x.template step<PH>(in, out);
         for (int i = 0; i < OUT; i++) out[i] = U::f(out[i], scalar);
     }
-    template <bool SIMD> FD_HD void step2(const v2f* in, v2f* out) {
-        x.template step2<SIMD>(in, out);
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        x.template step2<PH>(in, out);
         for (int i = 0; i < OUT; i++) out[i] = U::f(out[i], scalar);
     }
 };

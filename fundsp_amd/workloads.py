@@ -103,3 +103,45 @@ def make_noise_biquad_bank(voices, sample_rate=48000.0, voice0=0, params=None, k
     b.set_param_u64("0:seed", p["seed"])
     b.reset()  # Noise::reset picks the seed up (noise.rs:192-195); filter state is already zero
     return b
+
+
+def saw_moog_params(voices, sample_rate=48000.0, voice0=0):
+    """Config 4 voice: ((dc(f) >> saw() | dc(fc) | dc(q)) >> moog()) * adsr_live(0.01, 0.1, 0.6, 0.2) >> pan(p).
+
+    f in [55, 1760) Hz log-uniform, fc = f * 2^[1,5) clamped below 0.4*sr, q in [0.1, 0.7), pan in [-1, 1);
+    u_k = rnd1(4 v + k); oscillator phase from set_seed(v).
+    """
+    v = np.arange(voice0, voice0 + voices, dtype=np.uint64)
+    u = [rnd1(np.uint64(4) * v + np.uint64(k)) for k in range(4)]
+    f = 55.0 * np.exp2(5.0 * u[0])
+    fc = np.minimum(f * np.exp2(1.0 + 4.0 * u[1]), 0.4 * sample_rate)
+    q = 0.1 + 0.6 * u[2]
+    pan = -1.0 + 2.0 * u[3]
+    return dict(f=f.astype(np.float32), fc=fc.astype(np.float32), q=q.astype(np.float32), pan=pan.astype(np.float32),
+                seed=v.copy())
+
+
+def gate_signal(frames, sample_rate=48000.0, on_frame=1, off_seconds=0.5):
+    """adsr_live only attacks on a low->high gate transition (adsr.rs:37-43): low at frame 0, high until
+    `off_seconds`, then low (release)."""
+    g = np.zeros(frames, dtype=np.float32)
+    g[on_frame:min(frames, int(off_seconds * sample_rate))] = 1.0
+    return g
+
+
+C4_SLOTS = dict(f="0.0.0.0.0.0:value[0]", fc="0.0.0.0.1:value[0]", q="0.0.0.1:value[0]", pan="1:pan",
+                attack="0.1:attack", decay="0.1:decay", sustain="0.1:sustain", release="0.1:release")
+
+
+def make_saw_moog_bank(voices, sample_rate=48000.0, voice0=0, params=None, adsr=(0.01, 0.1, 0.6, 0.2)):
+    from .bank import Bank
+
+    p = params or saw_moog_params(voices, sample_rate, voice0)
+    b = Bank("saw_moog_adsr_pan", voices)
+    for k in ("f", "fc", "q", "pan"):
+        b.set_param(C4_SLOTS[k], p[k])
+    for k, val in zip(("attack", "decay", "sustain", "release"), adsr):
+        b.set_param(C4_SLOTS[k], float(val))
+    b.set_sample_rate(sample_rate)
+    b.set_seed(p["seed"])
+    return b

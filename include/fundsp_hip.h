@@ -77,6 +77,10 @@ const char* fdsp_last_error(void);
  *   "sine_hz_lowpass_hz" sine_hz(f) >> lowpass_hz(fc, q)                    (BASELINE config 1)
  *   "noise_biquad"       noise() >> biquad(..)        one BiquadBank lane  (BASELINE config 2)
  *   "fm_svf"             sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q) (BASELINE config 3)
+ *   "saw_moog_adsr_pan"  ((dc(f) >> saw() | dc(fc) | dc(q)) >> moog()) * adsr_live(a,d,s,r) >> pan(p)
+ *                        1 input (gate), 2 outputs                            (BASELINE config 4 voice)
+ * More leaves: "saw"/"square"/"triangle" wavetable.rs:249 (need fdsp_wavetable_build/upload first),
+ *   "adsr_live" adsr.rs:21 + envelope.rs:185, "pan" pan.rs:26
  */
 int fdsp_kind_count(void);
 const char* fdsp_kind_name(int kind);
@@ -137,6 +141,19 @@ int fdsp_bank_last_kernel_ms(fdsp_bank* bank, float* ms);
  * d_mix: [2][frames].  Equal-power pan weights follow Panner (src/pan.rs:13-17). Deterministic summation order. */
 int fdsp_mix_stereo(const float* d_voices, const float* d_pan, float* d_mix, size_t frames, size_t voices,
                     void* stream);
+
+/* Sum over voices of a voice-minor buffer d_in [channels][frames][voices] -> d_out [channels][frames] (per-GPU partial
+ * of the mix-down for graphs that already end in a Panner). Deterministic order, same as fdsp_mix_stereo. */
+int fdsp_sum_voices(const float* d_in, float* d_out, size_t channels, size_t frames, size_t voices, void* stream);
+
+/* ---- shared wavetables (Arc<Wavetable> singletons of the reference: saw_table/square_table/triangle_table,
+ * src/wavetable.rs:493-560).  `set`: 0 = saw, 1 = square, 2 = triangle, 3 = user.  Tables are a list of
+ * (pitch, power-of-two-length wave) pairs in ascending pitch, data concatenated.  fdsp_wavetable_build() generates the
+ * built-in shape with the engine's own make_wave (wavetable.rs:44-123); fdsp_wavetable_upload() installs caller data
+ * (e.g. tables produced by FunDSP itself).  Must be called before rendering a kind that uses the set. */
+int fdsp_wavetable_build(int set);
+int fdsp_wavetable_upload(int set, int n_tables, const float* h_pitches, const int* h_lengths, const float* h_data);
+int fdsp_wavetable_get(int set, int* n_tables, float* h_pitches, int* h_lengths, float* h_data, size_t capacity);
 
 /* ---- host-side helpers that restate reference coefficient constructors with the engine's own math --------- */
 int fdsp_svf_coefs(int mode, float sample_rate, float cutoff, float q, float gain, float* out6);     /* svf.rs:28-221 */

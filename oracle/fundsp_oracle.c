@@ -75,7 +75,25 @@ struct onode {
         float *dbuf;
         size_t dlen, di, time_in_samples;
         double dtime, dsr;
+        /* WaveSynth (wavetable.rs:249-264) */
+        const owavetable *wt;
+        size_t table_hint;
+        float ws_sr;
+        /* EnvelopeIn<f32, adsr_live closure, U1, f32> (envelope.rs:185-218, adsr.rs:21-57) */
+        float et, et0, et1, ev0, ev1, ev, evd, einterval, esd;
+        uint64_t et_hash;
+        int attacked;
+        float attack_start, release_start, adsr_a, adsr_d, adsr_s, adsr_r;
+        /* Panner (pan.rs:26-30) */
+        float left_weight, right_weight;
     } s;
+};
+
+struct owavetable {
+    int n;
+    float *pitch;
+    int *len;
+    float **tab;
 };
 
 /* ------------------------------------------------------------------------------------------------------ */
@@ -306,6 +324,15 @@ static void leaf_reset(onode *n) {
         n->s.di = 0;
         for (size_t i = 0; i < n->s.dlen; i++) n->s.dbuf[i] = 0.0f;
         break;
+    case O_WAVESYNTH: /* wavetable.rs:292-297 */
+        n->s.phase = n->s.has_initial_phase ? n->s.initial_phase : (float)o_rnd1(n->s.hash);
+        break;
+    case O_ADSR_LIVE: /* envelope.rs:293-298: the closure state (attacked, start times) is NOT reset */
+        n->s.et = 0.0f;
+        n->s.et0 = 0.0f;
+        n->s.et1 = 0.0f;
+        n->s.et_hash = n->s.hash;
+        break;
     default: break;
     }
 }
@@ -345,6 +372,13 @@ static void leaf_set_sample_rate(onode *n, double sr) {
         n->s.sr = (float)sr;
         moog_set_cutoff_q(n, n->s.cutoff, n->s.q);
         break;
+    case O_WAVESYNTH: /* wavetable.rs:299-302: f32 reciprocal of the f32-cast rate */
+        n->s.ws_sr = (float)sr;
+        n->s.sample_duration = 1.0f / (float)sr;
+        break;
+    case O_ADSR_LIVE: /* envelope.rs:300-302 */
+        n->s.esd = (float)(1.0 / sr);
+        break;
     case O_DELAY: /* delay.rs:105-113 */
         if (n->s.dsr != sr) {
             n->s.dsr = sr;
@@ -367,9 +401,12 @@ void o_set_sample_rate(onode *n, double sr) {
 
 /* AudioNode::set_hash (oscillator.rs:94-97, noise.rs:226-229); default is a no-op (audionode.rs:136-139) */
 static void leaf_set_hash(onode *n, uint64_t hash) {
-    if (n->type == O_SINE || n->type == O_NOISE) {
+    if (n->type == O_SINE || n->type == O_NOISE || n->type == O_WAVESYNTH) {
         n->s.hash = hash;
         leaf_reset(n);
+    } else if (n->type == O_ADSR_LIVE) { /* envelope.rs:346-349: no reset */
+        n->s.hash = hash;
+        n->s.et_hash = hash;
     }
 }
 
@@ -511,6 +548,78 @@ onode *o_delay(double time) { /* Delay::new delay.rs:80-91, ID 13 */
     return n;
 }
 
+/* ---- wavetable data (wavetable.rs:82-84: Vec<(f32, Vec<f32>)>) ---- */
+owavetable *o_wavetable_create(int n_tables, const float *pitches, const int *lengths, const float *data) {
+    owavetable *t = (owavetable *)calloc(1, sizeof(owavetable));
+    t->n = n_tables;
+    t->pitch = (float *)malloc(sizeof(float) * (size_t)n_tables);
+    t->len = (int *)malloc(sizeof(int) * (size_t)n_tables);
+    t->tab = (float **)malloc(sizeof(float *) * (size_t)n_tables);
+    size_t off = 0;
+    for (int i = 0; i < n_tables; i++) {
+        t->pitch[i] = pitches[i];
+        t->len[i] = lengths[i];
+        t->tab[i] = (float *)malloc(sizeof(float) * (size_t)lengths[i]);
+        memcpy(t->tab[i], data + off, sizeof(float) * (size_t)lengths[i]);
+        off += (size_t)lengths[i];
+    }
+    return t;
+}
+void o_wavetable_free(owavetable *t) {
+    if (!t) return;
+    for (int i = 0; i < t->n; i++) free(t->tab[i]);
+    free(t->tab);
+    free(t->len);
+    free(t->pitch);
+    free(t);
+}
+
+onode *o_wavesynth(const owavetable *table, int outputs) { /* WaveSynth::new wavetable.rs:270-281, ID 34 */
+    onode *n = o_new(O_WAVESYNTH, 1, outputs, 34);
+    n->s.wt = table;
+    n->s.phase = 0.0f; /* NOT reset in new() */
+    n->s.hash = 0;
+    n->s.has_initial_phase = 0;
+    n->s.table_hint = 0;
+    n->s.ws_sr = (float)DEFAULT_SR;
+    n->s.sample_duration = 1.0f / (float)DEFAULT_SR;
+    return n;
+}
+void o_wavesynth_set_phase(onode *n, float phase) { /* Setting::phase wavetable.rs:350-354 + reset */
+    n->s.has_initial_phase = 1;
+    n->s.initial_phase = phase;
+    n->s.phase = phase;
+}
+
+/* adsr_live(attack, decay, sustain, release) = envelope2(closure) = EnvelopeIn::new(0.002, ..)
+ * adsr.rs:21-57, prelude.rs:626-639, envelope.rs:228-250; ID 53 */
+onode *o_adsr_live(float attack, float decay, float sustain, float release) {
+    onode *n = o_new(O_ADSR_LIVE, 1, 1, 53);
+    n->s.adsr_a = attack; n->s.adsr_d = decay; n->s.adsr_s = sustain; n->s.adsr_r = release;
+    n->s.attacked = 0;
+    n->s.attack_start = 0.0f;
+    n->s.release_start = -1.0f;
+    n->s.einterval = (float)0.002;
+    n->s.hash = 0;
+    leaf_set_sample_rate(n, DEFAULT_SR);
+    leaf_reset(n);
+    return n;
+}
+
+static void pan_weights(float value, float *l, float *r) { /* pan.rs:13-17 */
+    float c = value;
+    c = c > -1.0f ? c : -1.0f; /* clamp11: x.max(-1).min(1) */
+    c = c < 1.0f ? c : 1.0f;
+    float angle = (c + 1.0f) * (F32_PI * 0.25f);
+    *l = o_cosf(angle);
+    *r = o_sinf(angle);
+}
+onode *o_panner(int inputs, float pan) { /* Panner::new pan.rs:33-40, ID 49 */
+    onode *n = o_new(O_PANNER, inputs, 2, 49);
+    pan_weights(pan, &n->s.left_weight, &n->s.right_weight);
+    return n;
+}
+
 onode *o_pipe(onode *x, onode *y) { /* Pipe::new audionode.rs:1388-1394, ID 6 */
     if (x->nout != y->nin) return NULL;
     onode *n = o_new(O_PIPE, x->nin, y->nout, 6);
@@ -625,6 +734,96 @@ static inline float unop_apply(int op, float x, float s) { /* FrameNeg/Id/AddSca
     }
 }
 
+/* ---- Wavetable (wavetable.rs:24-38, 154-241) ---- */
+static inline float optimal4x44(float a0, float a1, float a2, float a3, float x) {
+    float z = x - (float)0.5;
+    float even1 = a2 + a1, odd1 = a2 - a1, even2 = a3 + a0, odd2 = a3 - a0;
+    float c0 = even1 * (float)0.4656725512077848 + even2 * (float)0.03432729708429672;
+    float c1 = odd1 * (float)0.5374383075356016 + odd2 * (float)0.1542946255730746;
+    float c2 = even1 * (float)-0.25194210134021744 + even2 * (float)0.2519474493593906;
+    float c3 = odd1 * (float)-0.46896069955075126 + odd2 * (float)0.15578800670302476;
+    float c4 = even1 * (float)0.00986988334359864 + even2 * (float)-0.00989340017126506;
+    return (((c4 * z + c3) * z + c2) * z + c1) * z + c0;
+}
+static inline float wt_at(const owavetable *t, size_t i, float phase) { /* at() :154-166 == at_simd lane :169-186 */
+    const float *tab = t->tab[i];
+    size_t len = (size_t)t->len[i];
+    float p = (float)len * phase;
+    size_t i1 = (size_t)p; /* to_int_unchecked / fast_trunc_int: truncation, phase in 0...1 */
+    float w = p - (float)i1;
+    size_t mask = len - 1;
+    size_t i0 = (i1 - 1) & mask;
+    i1 = i1 & mask;
+    size_t i2 = (i1 + 1) & mask;
+    size_t i3 = (i1 + 2) & mask;
+    return optimal4x44(tab[i0], tab[i1], tab[i2], tab[i3], w);
+}
+static inline size_t wt_table_index(const owavetable *t, size_t hint, float frequency) { /* :189-211 */
+    if (frequency >= t->pitch[hint] && frequency <= t->pitch[hint + 1]) return hint;
+    size_t i0 = 0, i1 = (size_t)t->n - 3;
+    while (i0 < i1) {
+        size_t i = (i0 + i1) >> 1;
+        if (t->pitch[i] > frequency) {
+            i1 = i;
+        } else if (t->pitch[i + 1] > frequency) {
+            i0 = i;
+            break;
+        } else {
+            i0 = i + 1;
+        }
+    }
+    return i0;
+}
+static inline float clamp01f(float x) { /* math.rs:136-138: x.max(0).min(1) */
+    x = x > 0.0f ? x : 0.0f;
+    return x < 1.0f ? x : 1.0f;
+}
+static inline float wt_read(const owavetable *t, size_t *hint, float frequency, float phase) { /* read :214-226 */
+    size_t table = wt_table_index(t, *hint, frequency);
+    float w = clamp01f((frequency - t->pitch[table]) / (t->pitch[table + 1] - t->pitch[table]));
+    *hint = table;
+    return (1.0f - w) * wt_at(t, table + 1, phase) + w * wt_at(t, table + 2, phase);
+}
+
+/* ---- adsr_live closure (adsr.rs:21-70) and EnvelopeIn::next_segment (envelope.rs:252-278), F = f32 ---- */
+static inline float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; } /* math.rs:169-178 */
+static float adsr_closure(onode *n, float time, float control) {
+    if (n->s.release_start >= 0.0f && control > 0.0f) {
+        n->s.attacked = 1;
+        n->s.attack_start = time;
+        n->s.release_start = -1.0f;
+    } else if (n->s.release_start < 0.0f && control <= 0.0f) {
+        n->s.release_start = time;
+    }
+    if (!n->s.attacked) return 0.0f;
+    float tt = time - n->s.attack_start, ads;
+    if (tt < n->s.adsr_a) {
+        ads = lerpf(0.0f, 1.0f, tt / n->s.adsr_a);
+    } else {
+        float decay_time = tt - n->s.adsr_a;
+        ads = decay_time < n->s.adsr_d ? lerpf(1.0f, n->s.adsr_s, decay_time / n->s.adsr_d) : n->s.adsr_s;
+    }
+    if (n->s.release_start < 0.0f) return ads;
+    float a = n->s.release_start + n->s.adsr_r, b = n->s.release_start;
+    return ads * clamp01f((time - a) / (b - a));
+}
+static void env_next_segment(onode *n, float input) {
+    if (n->s.et0 == 0.0f && n->s.et1 == 0.0f) {
+        n->s.ev0 = adsr_closure(n, n->s.et0, input);
+    } else {
+        n->s.et0 = n->s.et1;
+        n->s.ev0 = n->s.ev1;
+    }
+    float next_interval = lerpf(0.75f, 1.25f, (float)o_rnd1(n->s.et_hash)) * n->s.einterval;
+    n->s.et1 = n->s.et0 + next_interval;
+    n->s.ev1 = adsr_closure(n, n->s.et1, input);
+    n->s.et_hash = n->s.et_hash * 6364136223846793005ULL + 1ULL;
+    float u = (n->s.et - n->s.et0) / (n->s.et1 - n->s.et0);
+    n->s.ev = lerpf(n->s.ev0, n->s.ev1, u);
+    float samples = next_interval / n->s.esd;
+    n->s.evd = (n->s.ev1 - n->s.ev0) / samples;
+}
+
 void o_tick(onode *n, const float *in, float *out) {
     float t[O_MAX_CH];
     switch (n->type) {
@@ -696,6 +895,26 @@ void o_tick(onode *n, const float *in, float *out) {
         n->s.di += 1;
         if (n->s.di >= n->s.dlen) n->s.di = 0;
         out[0] = n->s.dbuf[n->s.di];
+        break;
+    case O_WAVESYNTH: { /* wavetable.rs:310-324: increment + wrap BEFORE reading */
+        float frequency = in[0];
+        float delta = frequency * n->s.sample_duration;
+        n->s.phase += delta;
+        n->s.phase -= floorf(n->s.phase);
+        out[0] = wt_read(n->s.wt, &n->s.table_hint, fabsf(frequency), n->s.phase);
+        if (n->nout > 1) out[1] = n->s.phase;
+        break;
+    }
+    case O_ADSR_LIVE: /* envelope.rs:305-313 */
+        if (n->s.et >= n->s.et1) env_next_segment(n, in[0]);
+        out[0] = n->s.ev;
+        n->s.ev += n->s.evd;
+        n->s.et += n->s.esd;
+        break;
+    case O_PANNER: /* pan.rs:55-62 */
+        if (n->nin > 1) pan_weights(in[1], &n->s.left_weight, &n->s.right_weight);
+        out[0] = n->s.left_weight * in[0];
+        out[1] = n->s.right_weight * in[0];
         break;
     case O_PIPE: /* audionode.rs:1441-1443 */
         o_tick(n->x, in, t);
@@ -790,6 +1009,66 @@ void o_process(onode *n, int size, const float *in, float *out) {
         for (int c = 0; c < n->nout; c++)
             for (int i = 0; i < simd_items(size) * 8; i++)
                 out[c * MAXB + i] = unop_apply(n->op, out[c * MAXB + i], n->scalar);
+        break;
+    case O_WAVESYNTH: { /* wavetable.rs:327-348: 8 phases accumulated, vector floor wrap (wide's inherent
+                           f32x8::floor = true floor), table pair chosen from LANE 0's frequency for the item */
+        float phase = n->s.phase;
+        size_t hint = n->s.table_hint;
+        for (int i = 0; i < full_simd_items(size); i++) {
+            float frequency = in[i << 3];
+            float ph[SIMD_N];
+            for (int j = 0; j < SIMD_N; j++) {
+                phase += in[(i << 3) + j] * n->s.sample_duration;
+                ph[j] = phase;
+            }
+            for (int j = 0; j < SIMD_N; j++) ph[j] = ph[j] - floorf(ph[j]);
+            size_t table = wt_table_index(n->s.wt, hint, fabsf(frequency));
+            float w = clamp01f((fabsf(frequency) - n->s.wt->pitch[table]) /
+                               (n->s.wt->pitch[table + 1] - n->s.wt->pitch[table]));
+            for (int j = 0; j < SIMD_N; j++)
+                out[(i << 3) + j] = (1.0f - w) * wt_at(n->s.wt, table + 1, ph[j]) + w * wt_at(n->s.wt, table + 2, ph[j]);
+            hint = table;
+            if (n->nout > 1)
+                for (int j = 0; j < SIMD_N; j++) out[MAXB + (i << 3) + j] = ph[j];
+        }
+        n->s.phase = phase - floorf(phase);
+        n->s.table_hint = hint;
+        process_remainder(n, size, in, out);
+        break;
+    }
+    case O_ADSR_LIVE: { /* envelope.rs:315-340: whole-block segment walk (no remainder path) */
+        if (size == 0) break;
+        if (n->s.et >= n->s.et1) env_next_segment(n, in[0]);
+        int i = 0;
+        while (i < size) {
+            int64_t left = (int64_t)ceilf((n->s.et1 - n->s.et) / n->s.esd);
+            size_t segment_samples_left = (size_t)left;
+            size_t loop_samples = (size_t)(size - i) < segment_samples_left ? (size_t)(size - i) : segment_samples_left;
+            float value = n->s.ev, delta = n->s.evd;
+            for (size_t k = 0; k < loop_samples; k++) {
+                out[i + (int)k] = value;
+                value += delta;
+            }
+            n->s.ev = value;
+            i += (int)loop_samples;
+            n->s.et += (float)(int64_t)loop_samples * n->s.esd;
+            if (loop_samples == segment_samples_left && i < size) env_next_segment(n, in[i]);
+        }
+        break;
+    }
+    case O_PANNER: /* pan.rs:63-76 */
+        if (n->nin == 1) {
+            for (int i = 0; i < simd_items(size) * 8; i++) {
+                out[i] = in[i] * n->s.left_weight;
+                out[MAXB + i] = in[i] * n->s.right_weight;
+            }
+        } else {
+            for (int i = 0; i < size; i++) {
+                pan_weights(in[MAXB + i], &n->s.left_weight, &n->s.right_weight);
+                out[i] = in[i] * n->s.left_weight;
+                out[MAXB + i] = in[i] * n->s.right_weight;
+            }
+        }
         break;
     case O_FIXED_SVF: /* no override -> tick fallback; inlined here so the CPU baseline is not penalised */
         for (int i = 0; i < size; i++) out[i] = svf_tick(n, in[i]);

@@ -16,7 +16,8 @@ typedef struct onode onode;
 
 enum {
     O_CONSTANT = 0, O_PASS, O_SINE, O_NOISE, O_SVF, O_FIXED_SVF, O_BIQUAD, O_BUTTER_LOWPASS, O_RESONATOR,
-    O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP
+    O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP,
+    O_WAVESYNTH, O_ADSR_LIVE, O_PANNER
 };
 /* SvfMode order follows src/svf.rs:281-742 */
 enum {
@@ -43,6 +44,14 @@ onode *o_moog(int inputs, float cutoff, float q);
 onode *o_fir(int n_taps, const float *w);
 onode *o_tick_node(int channels);
 onode *o_delay(double time);
+/* wavetables are shared data (Arc<Wavetable> in the reference): created once, referenced by synth nodes */
+typedef struct owavetable owavetable;
+owavetable *o_wavetable_create(int n_tables, const float *pitches, const int *lengths, const float *data);
+void o_wavetable_free(owavetable *t);
+onode *o_wavesynth(const owavetable *table, int outputs);
+void o_wavesynth_set_phase(onode *n, float phase);
+onode *o_adsr_live(float attack, float decay, float sustain, float release);
+onode *o_panner(int inputs, float pan);
 /* combinators (take ownership of children) */
 onode *o_pipe(onode *x, onode *y);
 onode *o_stack(onode *x, onode *y);

@@ -69,6 +69,9 @@ def lib():
         "o_math_rnd1": (d, [u64]), "o_math_hash1": (u64, [u64]), "o_math_atto": (u64, [u64, u64]),
         "o_math_hash32x": (C.c_uint32, [C.c_uint32]),
         "o_bank_render": (d, [C.POINTER(BankJob), fp]),
+        "o_wavetable_create": (P, [i, fp, C.POINTER(C.c_int), fp]), "o_wavetable_free": (None, [P]),
+        "o_wavesynth": (P, [P, i]), "o_wavesynth_set_phase": (None, [P, f]),
+        "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -168,6 +171,10 @@ class Node:
         lib().o_noise_set_seed(self.ptr, int(s) & (2**64 - 1))
         return self
 
+    def wave_phase(self, p):
+        lib().o_wavesynth_set_phase(self.ptr, float(p))
+        return self
+
 
 # --- prelude32 opcodes -------------------------------------------------------------------------------------
 def constant(*v):
@@ -205,6 +212,80 @@ def fir(*w):
     return Node(lib().o_fir(a.size, _fptr(a)))
 def tick(channels=1): return Node(lib().o_tick_node(channels))
 def delay(t): return Node(lib().o_delay(float(t)))
+
+
+# --- wavetables (wavetable.rs:44-123, 493-623).  Tables are DATA shared by the oracle and the engine in parity
+# tests; this numpy builder follows make_wave / Wavetable::new (f64 spectrum set-up, f32 polar partials, inverse FFT,
+# global peak normalisation).  The reference's microfft f32 butterflies are not restated: table bits are unpinned.
+def _smooth5(x): return ((x * 6 - 15) * x + 10) * x * x * x
+
+
+def make_wavetable_arrays(kind="saw", min_pitch=20.0, max_pitch=20000.0, tables_per_octave=4.0):
+    def phase(i):
+        if kind == "saw": return 0.0 if (i & 1) == 1 else 0.5
+        if kind == "square": return 0.0
+        if kind == "triangle": return 0.5 if (i & 3) == 3 else 0.0
+        raise KeyError(kind)
+
+    def amplitude(i):
+        if kind == "saw": return 1.0 / i
+        if kind == "square": return 1.0 / i if (i & 1) == 1 else 0.0
+        if kind == "triangle": return 1.0 / (i * i) if (i & 1) == 1 else 0.0
+        raise KeyError(kind)
+
+    pitches, waves = [], []
+    pitch, p_factor = float(min_pitch), 2.0 ** (1.0 / tables_per_octave)
+    while pitch <= max_pitch:
+        harmonics = int(np.floor(22000.0 / pitch))
+        target = 4 * harmonics
+        length = int(min(8192, max(32, 1 << max(0, (target - 1).bit_length()))))
+        a = np.zeros(length, dtype=np.complex128)
+        for i in range(1, harmonics + 1):
+            f = pitch * i
+            w = amplitude(i) * _smooth5(min(1.0, max(0.0, (f - 22000.0) / (20000.0 - 22000.0))))
+            if w > 0.0:
+                ang = np.float32(2 * np.pi * phase(i))
+                a[i] = np.float32(w) * np.complex64(np.cos(ang) + 1j * np.sin(ang))
+        wave = (np.fft.ifft(a) * length).imag.astype(np.float32)
+        pitches.append(np.float32(pitch))
+        waves.append(wave)
+        pitch *= p_factor
+    peak = max(float(np.max(np.abs(w))) for w in waves)
+    z = np.float32(1.0 / peak)
+    waves = [(w * z).astype(np.float32) for w in waves]
+    return np.array(pitches, dtype=np.float32), waves
+
+
+class Wavetable:
+    _cache = {}
+
+    def __init__(self, pitches, waves):
+        self.pitches = np.ascontiguousarray(pitches, dtype=np.float32)
+        self.lengths = np.array([len(w) for w in waves], dtype=np.int32)
+        self.data = np.ascontiguousarray(np.concatenate(waves), dtype=np.float32)
+        self.ptr = lib().o_wavetable_create(len(waves), _fptr(self.pitches),
+                                            self.lengths.ctypes.data_as(C.POINTER(C.c_int)), _fptr(self.data))
+
+    @classmethod
+    def get(cls, kind):
+        if kind not in cls._cache:
+            cls._cache[kind] = cls(*make_wavetable_arrays(kind))
+        return cls._cache[kind]
+
+
+def wavesynth(kind="saw", outputs=1):
+    t = Wavetable.get(kind)
+    n = Node(lib().o_wavesynth(t.ptr, outputs))
+    n._table = t  # keep the shared table alive
+    return n
+
+
+def saw(): return wavesynth("saw")                                    # prelude.rs:2003
+def square(): return wavesynth("square")
+def triangle(): return wavesynth("triangle")
+def saw_hz(f): return constant(f) >> saw()
+def adsr_live(a, d, s, r): return Node(lib().o_adsr_live(a, d, s, r))  # adsr.rs:21
+def pan(p): return Node(lib().o_panner(1, p))                         # prelude.rs:1250
 
 
 def set_biquad_bank(node, index, coefs):

@@ -136,3 +136,48 @@ def test_moog_with_inputs_recomputes_every_sample():
     b = O.moog()
     b.set_sample_rate(48000.0)
     assert np.array_equal(a.render_blocks(x), b.render_blocks(ctl))
+
+
+def test_wavesynth_check_wave_and_tables():
+    """tests/test_basic.rs:188-216: saw/square/triangle via Wave::render equal the tick path within 1e-4;
+    table layout as derived in SURVEY.md section 7 (40 tables, 41 024 floats)."""
+    for kind in ("saw", "square", "triangle"):
+        check_wave(lambda k=kind: O.dc(110.0) >> O.wavesynth(k))
+        check_wave(lambda k=kind: O.dc(1760.0) >> O.wavesynth(k))
+    p, w = O.make_wavetable_arrays("saw")
+    assert len(p) == 40 and sum(len(x) for x in w) == 41024
+    assert len(w[0]) == 8192 and len(w[-1]) == 32 and abs(max(np.abs(x).max() for x in w) - 1.0) < 1e-6
+    # a saw at 100 Hz has the 1/n spectrum (bandlimited below 20 kHz)
+    g = O.dc(100.0) >> O.wavesynth("saw")
+    y = O.wave_render(48000.0, 1.0, g)[0].astype(np.float64)
+    spec = np.abs(np.fft.rfft(y * np.hanning(len(y))))
+    h1, h2, h3 = spec[100], spec[200], spec[300]
+    assert abs(h1 / h2 - 2.0) < 0.05 and abs(h1 / h3 - 3.0) < 0.05
+
+
+def test_adsr_live_shape():
+    """adsr.rs:21-70: nothing before the first low->high gate transition; attack to 1, decay to sustain, release to 0."""
+    sr = 48000.0
+    gate = np.zeros((1, 48000), dtype=np.float32)
+    gate[0, 100:24000] = 1.0
+    e = O.adsr_live(0.01, 0.1, 0.6, 0.2)
+    e.set_sample_rate(sr)
+    y = e.render_blocks(gate)[0]
+    assert np.all(y[:100] == 0.0)
+    assert abs(y[100 + 480 + 150] - 1.0) < 0.25 and y.max() <= 1.0 + 1e-6      # peak around the end of the attack
+    assert np.all(np.abs(y[12000:23000] - 0.6) < 1e-3)                         # sustain
+    assert y[24000 + 9600 + 400] == 0.0 or abs(y[24000 + 9600 + 400]) < 1e-6   # released after 0.2 s
+    # a gate that is high from the very first sample never attacks (release_start starts at -1, adsr.rs:30,37-43)
+    e2 = O.adsr_live(0.01, 0.1, 0.6, 0.2)
+    e2.set_sample_rate(sr)
+    assert not e2.render_blocks(np.ones((1, 4000), dtype=np.float32)).any()
+
+
+def test_pan_weights_exact():
+    """pan.rs:13-17: centre pan gives cos(pi/4) on both sides (libm cosf/sinf), hard left/right give (1, ~0)/(~0, 1)."""
+    x = np.ones((1, 8), dtype=np.float32)
+    c = O.pan(0.0).render_blocks(x)
+    assert abs(c[0, 0] - np.float32(np.sqrt(0.5))) < 1e-7 and abs(c[1, 0] - np.float32(np.sqrt(0.5))) < 1e-7
+    l = O.pan(-1.0).render_blocks(x)
+    assert l[0, 0] == 1.0 and abs(l[1, 0]) < 1e-7
+    assert np.array_equal(O.pan(5.0).render_blocks(x), O.pan(1.0).render_blocks(x))  # clamp11
