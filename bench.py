@@ -56,7 +56,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--voices", type=int, default=65536, help="voices per GPU (weak scaling)")
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4],
+                    help="3 = headline FM+SVF voices (default); 4 = saw>>moog*adsr>>pan voices (informational)")
+    ap.add_argument("--voices", type=int, default=None, help="voices per GPU (weak scaling); default 65536 (config 3) / 32768 (config 4)")
     ap.add_argument("--frames", type=int, default=48000, help="frames per step (1 s @ 48 kHz)")
     ap.add_argument("--sample-rate", type=float, default=48000.0)
     ap.add_argument("--layout", choices=["voice_minor", "planar"], default="voice_minor")
@@ -87,18 +89,34 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if args.voices is None:
+        args.voices = 65536 if args.config == 3 else 32768
     V, T, sr = args.voices, args.frames, args.sample_rate
     layout = F.LAYOUT_VOICE_MINOR if args.layout == "voice_minor" else F.LAYOUT_PLANAR
     mode = F.MODE_PROCESS if args.mode == "process" else F.MODE_TICK
     first = rank * V  # contiguous voice ranges of the N*V-voice whole-node bank
-    bank = W.make_fm_svf_bank(V, sr, voice0=first)
+    inp = None
+    if args.config == 3:
+        bank = W.make_fm_svf_bank(V, sr, voice0=first)
+        n_out, bytes_per_sample = 1, 4
+    else:
+        assert layout == F.LAYOUT_VOICE_MINOR, "config 4 bench uses the device-native layout"
+        F.wavetable_build("saw")
+        bank = W.make_saw_moog_bank(V, sr, voice0=first)
+        gate = torch.from_numpy(W.gate_signal(T, sr)).cuda()
+        inp = gate[None, :, None].expand(1, T, V).contiguous()  # [1][frame][voice] gate resident in HBM
+        n_out, bytes_per_sample = 2, 12
     fs = T if layout == F.LAYOUT_PLANAR else 0
-    out = torch.empty((1, T, V) if layout == F.LAYOUT_VOICE_MINOR else (V, 1, fs), dtype=torch.float32, device="cuda")
+    out = torch.empty((n_out, T, V) if layout == F.LAYOUT_VOICE_MINOR else (V, n_out, fs), dtype=torch.float32,
+                      device="cuda")
 
     def step():
-        bank.process(T, None, out, layout=layout, frame_stride=fs, mode=mode)
+        bank.process(T, inp, out, layout=layout, frame_stride=fs, mode=mode)
         if args.mix:
-            mix = F.mix_stereo(out[0] if layout == F.LAYOUT_VOICE_MINOR else out[:, 0, :].t().contiguous())
+            if args.config == 3:
+                mix = F.mix_stereo(out[0] if layout == F.LAYOUT_VOICE_MINOR else out[:, 0, :].t().contiguous())
+            else:
+                mix = F.sum_voices(out)  # voices are already panned to stereo
             fdist.allreduce_mix(mix)
 
     def fence():
@@ -128,19 +146,22 @@ def main():
         total_samples = float(world) * V * T * args.steps
         value = total_samples / elapsed / 1e6
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
-        algo_bytes = V * T * 4 + V * 64  # 4 B per voice-sample out + 64 B state/params per voice per launch
+        # config 3 = 4 B per voice-sample out + 64 B state/params per voice per launch;
+        # config 4 = 4 B gate in + 8 B stereo out per voice-sample (+ 188 B of slots per voice per launch)
+        algo_bytes = V * T * bytes_per_sample + V * (64 if args.config == 3 else 188)
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                if rec.get("voices") == V and rec.get("frames") == T:
+                if rec.get("voices") == V and rec.get("frames") == T and args.config == 3:
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         res = {
-            "metric": "Msamples/s (whole node) for 65536-voice SVF+FM graph",
+            "metric": "Msamples/s (whole node) for 65536-voice SVF+FM graph" if args.config == 3 else
+                      "Msamples/s (whole node) for saw>>moog*adsr>>pan voices (BASELINE config 4, informational)",
             "value": round(value, 3),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -153,7 +174,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE config 3: sine_hz(f)*f*m+f >> sine() >> lowpass_hz(fc,q), "
+                "workload": ("BASELINE config 3: sine_hz(f)*f*m+f >> sine() >> lowpass_hz(fc,q), " if args.config == 3 else
+                             "BASELINE config 4 voice: ((dc(f)>>saw()|dc(fc)|dc(q))>>moog())*adsr_live(.01,.1,.6,.2)>>pan(p), gate in, ") +
                             f"{V} voices/GPU x {T} frames/step @ {sr:g} Hz, voice-out ([frame][voice] f32), "
                             f"{args.mode} semantics, per-voice params from rnd1(4v+k), phases via set_seed(v)",
                 "voices_per_gpu": V,
@@ -169,12 +191,12 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "kernel": "fd::k_render<fm_svf, process, voice_minor>",
+                "kernel": f"fd::k_render<{'fm_svf' if args.config == 3 else 'saw_moog_adsr_pan'}, {args.mode}, {args.layout}>",
                 "kernel_ms_avg": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and args.config == 3:
             res["cpu_baseline"] = cpu_baseline(V, T, sr, args.cpu_seconds)
         else:
             res["cpu_baseline"] = None

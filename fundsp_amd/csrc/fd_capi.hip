@@ -38,6 +38,7 @@ std::vector<fd::KindOps>& registry() {
 
 // ---- shared device data (wavetables): one fd::Aux per process, the counterpart of FunDSP's static table singletons ----
 fd::Aux g_host_aux;              // host mirror (data pointers are device pointers)
+std::vector<float> g_host_tables[fd::WT_SETS];  // unpadded host copies (fdsp_wavetable_get)
 fd::Aux* g_dev_aux = nullptr;
 std::mutex g_aux_mutex;
 
@@ -60,20 +61,33 @@ int upload_table_set(int set, int n, const float* pitches, const int* lengths, c
     }
     if (!device_aux()) return fail(FDSP_EDEVICE, "no device memory for wavetables");
     std::lock_guard<std::mutex> lock(g_aux_mutex);
+    // device layout: every table circularly padded [t[len-1], t[0..len-1], t[0], t[1]] (fd_nodes.hpp wt_tap)
+    std::vector<float> padded;
+    padded.reserve(total + 3 * (size_t)n);
+    std::vector<int> offs(n);
+    size_t src = 0;
+    for (int i = 0; i < n; i++) {
+        const size_t len = (size_t)lengths[i];
+        offs[i] = (int)padded.size();
+        padded.push_back(data[src + len - 1]);
+        padded.insert(padded.end(), data + src, data + src + len);
+        padded.push_back(data[src]);
+        padded.push_back(data[src + 1]);
+        src += len;
+    }
     float* d = nullptr;
-    HIPCHK(hipMalloc((void**)&d, total * sizeof(float)));
-    HIPCHK(hipMemcpy(d, data, total * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&d, padded.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(d, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
     fd::WtSet& w = g_host_aux.wt[set];
     if (w.data) hipFree(const_cast<float*>(w.data));
     w.n = n;
-    size_t off = 0;
     for (int i = 0; i < n; i++) {
         w.pitch[i] = pitches[i];
-        w.off[i] = (int)off;
+        w.off[i] = offs[i];
         w.len[i] = lengths[i];
-        off += (size_t)lengths[i];
     }
     w.data = d;
+    g_host_tables[set].assign(data, data + total);
     HIPCHK(hipMemcpy(g_dev_aux, &g_host_aux, sizeof(fd::Aux), hipMemcpyHostToDevice));
     return FDSP_OK;
 }
@@ -549,7 +563,7 @@ int fdsp_wavetable_get(int set, int* n_tables, float* h_pitches, int* h_lengths,
     if (h_lengths) std::memcpy(h_lengths, w.len, sizeof(int) * (size_t)w.n);
     if (h_data) {
         if (capacity < total) return fail(FDSP_EINVAL, "capacity too small");
-        HIPCHK(hipMemcpy(h_data, w.data, total * sizeof(float), hipMemcpyDeviceToHost));
+        std::memcpy(h_data, g_host_tables[set].data(), total * sizeof(float));
     }
     return FDSP_OK;
 }

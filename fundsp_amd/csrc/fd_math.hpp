@@ -161,100 +161,81 @@ FD_HD float tanf_musl(float x) {
     return q.small ? x : r;
 }
 
-// musl expm1f.c
-FD_HD float expm1f_musl(float x) {
+// musl expm1f.c, evaluated branch-light: the argument-reduction case (k, hi, lo) and the reconstruction case are
+// chosen with selects around ONE shared polynomial, because the lanes of a wave (different voices) fall into
+// different cases on almost every sample and divergent branches would execute every path.  Each lane still
+// performs exactly the operations of the case musl would take for it, in the same order.
+FD_HD float expm1f_musl(float x0) {
     constexpr float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, invln2 = 1.4426950216e+00f,
                     Q1 = -3.3333212137e-2f, Q2 = 1.5807170421e-3f;
-    float y, hi, lo, c = 0.0f, t, e, hxs, hfx, r1, twopk;
-    uint32_t ui = f2u(x);
-    uint32_t hx = ui & 0x7fffffffu;
-    int k;
-    bool sign = (ui >> 31) != 0;
-    if (hx >= 0x4195b844u) {  // |x| >= 27*ln2
-        if (hx > 0x7f800000u) return x;
-        if (sign) return -1.0f;
-        if (x > 8.8721679688e+01f) {
-            x *= 0x1p127f;
-            return x;
-        }
-    }
-    if (hx > 0x3eb17218u) {      // |x| > 0.5 ln2
-        if (hx < 0x3F851592u) {  // |x| < 1.5 ln2
-            if (!sign) {
-                hi = x - ln2_hi;
-                lo = ln2_lo;
-                k = 1;
-            } else {
-                hi = x + ln2_hi;
-                lo = -ln2_lo;
-                k = -1;
-            }
-        } else {
-            k = (int)(invln2 * x + (sign ? -0.5f : 0.5f));
-            t = (float)k;
-            hi = x - t * ln2_hi;
-            lo = t * ln2_lo;
-        }
-        x = hi - lo;
-        c = (hi - x) - lo;
-    } else if (hx < 0x33000000u) {
-        return x;
-    } else
-        k = 0;
-    hfx = 0.5f * x;
-    hxs = x * hfx;
-    r1 = 1.0f + hxs * (Q1 + hxs * Q2);
-    t = 3.0f - r1 * hfx;
-    e = hxs * ((r1 - t) / (6.0f - x * t));
-    if (k == 0) return x - (x * e - hxs);
-    e = x * (e - c) - c;
-    e -= hxs;
-    if (k == -1) return 0.5f * (x - e) - 0.5f;
-    if (k == 1) {
-        if (x < -0.25f) return -2.0f * (e - (x + 0.5f));
-        return 1.0f + 2.0f * (x - e);
-    }
-    twopk = u2f((uint32_t)(0x7f + k) << 23);
-    if (k < 0 || k > 56) {
-        y = x - e + 1.0f;
-        if (k == 128)
-            y = y * 2.0f * 0x1p127f;
-        else
-            y = y * twopk;
-        return y - 1.0f;
-    }
+    const uint32_t ui = f2u(x0);
+    const uint32_t hx = ui & 0x7fffffffu;
+    const bool sign = (ui >> 31) != 0;
+    // early-outs that do not use the polynomial (rare: huge |x|, NaN, tiny |x|)
+    const bool is_nan = hx > 0x7f800000u;
+    const bool big = hx >= 0x4195b844u;               // |x| >= 27*ln2
+    const bool ovf = big && !sign && x0 > 8.8721679688e+01f;
+    const bool tiny = hx < 0x33000000u;               // |x| < 2**-25
+    // argument reduction
+    const bool reduce = hx > 0x3eb17218u;             // |x| > 0.5 ln2
+    const bool near1 = hx < 0x3F851592u;              // |x| < 1.5 ln2
+    int kg = (int)(invln2 * x0 + (sign ? -0.5f : 0.5f));
+    float tg = (float)kg;
+    int k = reduce ? (near1 ? (sign ? -1 : 1) : kg) : 0;
+    float hi = near1 ? (sign ? x0 + ln2_hi : x0 - ln2_hi) : x0 - tg * ln2_hi;
+    float lo = near1 ? (sign ? -ln2_lo : ln2_lo) : tg * ln2_lo;
+    float xr = hi - lo;
+    float cr = (hi - xr) - lo;
+    float x = reduce ? xr : x0;
+    float c = reduce ? cr : 0.0f;
+    // primary range
+    float hfx = 0.5f * x;
+    float hxs = x * hfx;
+    float r1 = 1.0f + hxs * (Q1 + hxs * Q2);
+    float t = 3.0f - r1 * hfx;
+    float e = hxs * ((r1 - t) / (6.0f - x * t));
+    float res_k0 = x - (x * e - hxs);
+    float e2 = x * (e - c) - c;
+    e2 -= hxs;
+    float res_km1 = 0.5f * (x - e2) - 0.5f;
+    float res_k1 = x < -0.25f ? -2.0f * (e2 - (x + 0.5f)) : 1.0f + 2.0f * (x - e2);
+    float twopk = u2f((uint32_t)(0x7f + k) << 23);
+    float y_out = x - e2 + 1.0f;
+    y_out = (k == 128) ? y_out * 2.0f * 0x1p127f : y_out * twopk;
+    float res_out = y_out - 1.0f;                      // k < 0 || k > 56
     float uf = u2f((uint32_t)(0x7f - k) << 23);
-    if (k < 23)
-        y = (x - e + (1 - uf)) * twopk;
-    else
-        y = (x - (e + uf) + 1) * twopk;
-    return y;
+    float res_lt23 = (x - e2 + (1 - uf)) * twopk;
+    float res_ge23 = (x - (e2 + uf) + 1) * twopk;
+    float res = (k == 0) ? res_k0
+              : (k == -1) ? res_km1
+              : (k == 1) ? res_k1
+              : (k < 0 || k > 56) ? res_out
+              : (k < 23) ? res_lt23 : res_ge23;
+    res = tiny ? x0 : res;
+    res = ovf ? x0 * 0x1p127f : res;
+    res = (big && sign) ? -1.0f : res;
+    res = is_nan ? x0 : res;
+    return res;
 }
 
-// musl tanhf.c
-FD_HD float tanhf_musl(float x) {
-    uint32_t w = f2u(x);
-    bool sign = (w >> 31) != 0;
-    float t;
+// musl tanhf.c, one expm1f + one division per call (case selection by selects, see expm1f_musl)
+FD_HD float tanhf_musl(float x0) {
+    uint32_t w = f2u(x0);
+    const bool sign = (w >> 31) != 0;
     w &= 0x7fffffffu;
-    x = u2f(w);
-    if (w > 0x3f0c9f54u) {
-        if (w > 0x41200000u) {
-            t = 1 + 0 / x;
-        } else {
-            t = expm1f_musl(2 * x);
-            t = 1 - 2 / (t + 2);
-        }
-    } else if (w > 0x3e82c578u) {
-        t = expm1f_musl(2 * x);
-        t = t / (t + 2);
-    } else if (w >= 0x00800000u) {
-        t = expm1f_musl(-2 * x);
-        t = -t / (t + 2);
-    } else {
-        t = x;
-    }
-    return sign ? -t : t;
+    const float x = u2f(w);
+    const bool c_big = w > 0x41200000u;    // |x| > 10
+    const bool c1 = w > 0x3f0c9f54u;       // |x| > log(3)/2
+    const bool c2 = w > 0x3e82c578u;       // |x| > log(5/3)/2
+    const bool c3 = w >= 0x00800000u;      // normal
+    float t = expm1f_musl(c2 ? 2 * x : -2 * x);
+    float num = c1 ? 2.0f : (c2 ? t : -t);
+    float quo = num / (t + 2);
+    float r = c1 ? 1 - quo : quo;          // c1: 1 - 2/(t+2); c2: t/(t+2); c3: -t/(t+2)
+    r = c_big ? 1 + 0 / x : r;
+    r = c3 ? r : x;                        // subnormal: t = x
+    r = (w > 0x7f800000u) ? (1 + 0 / x) : r;  // NaN follows the |x| > 10 branch in musl
+    return sign ? -r : r;
 }
 
 // libm 0.2 scalbnf for the normal range used by expf (|k| small)

@@ -555,7 +555,13 @@ struct Moog {
     FD_HD bool tripped() const { return false; }
     FD_HD void bind(const void*) {}
     template <int PH> FD_HD void step(const float* in, float* out) {  // :82-100
-        if (NIN > 1) set_cutoff_q(in[1], in[2]);
+        // The reference recomputes (p, k, rez) from (cutoff, q) on EVERY sample (moog.rs:83-85).  They are a pure
+        // function of the two inputs and the sample rate, so recomputing only when an input differs from the stored
+        // one yields the same registers bit for bit (NaN inputs compare unequal and recompute, as the reference does)
+        // and keeps the f64 sine out of the steady-state loop.
+        if (NIN > 1) {
+            if (in[1] != cutoff || in[2] != q) set_cutoff_q(in[1], in[2]);
+        }
         float x = -rez * s3 + in[0];
         s0 = (x + px) * p - k * s0;
         s1 = (s0 + ps0) * p - k * s1;
@@ -665,19 +671,6 @@ FD_HD float clamp01f(float x) {  // math.rs:136-138
     x = x > 0.0f ? x : 0.0f;
     return x < 1.0f ? x : 1.0f;
 }
-FD_HD float wt_at(const WtSet* t, int i, float phase) {  // Wavetable::at :154-166 (== one lane of at_simd)
-    const float* tab = t->data + t->off[i];
-    uint32_t len = (uint32_t)t->len[i];
-    float p = (float)len * phase;
-    uint32_t i1 = (uint32_t)p;
-    float w = p - (float)i1;
-    uint32_t mask = len - 1;
-    uint32_t i0 = (i1 - 1u) & mask;
-    i1 = i1 & mask;
-    uint32_t i2 = (i1 + 1u) & mask;
-    uint32_t i3 = (i1 + 2u) & mask;
-    return optimal4x44(tab[i0], tab[i1], tab[i2], tab[i3], w);
-}
 FD_HD int wt_table_index(const WtSet* t, int hint, float frequency) {  // :189-211
     if (frequency >= t->pitch[hint] && frequency <= t->pitch[hint + 1]) return hint;
     int i0 = 0, i1 = t->n - 3;
@@ -696,6 +689,28 @@ FD_HD int wt_table_index(const WtSet* t, int hint, float frequency) {  // :189-2
 }
 
 // WaveSynth<U1>  wavetable.rs:249-359 (ID 34).  SET selects the shared table set (0 saw, 1 square, 2 triangle).
+//
+// The descriptor of the current table pair (pitch bounds, offsets, masks) is cached in registers and refreshed only
+// when the frequency leaves the hinted table's range -- exactly the condition under which the reference's
+// table_index() leaves its fast path (:190-192) -- so a steady voice does no dependent descriptor loads, only the
+// 2 x 4 data gathers per sample (served by L2: the saw set is 160 KiB).  step2 issues the 16 gathers of two frames
+// back to back so their latencies overlap.
+// Device tables are stored circularly padded -- [t[len-1], t[0..len-1], t[0], t[1]] -- so the four interpolation taps
+// t[i1-1..i1+2] of Wavetable::at are ONE contiguous (unaligned) 16-byte gather per lane instead of four.
+struct Tap4 { float a0, a1, a2, a3, w; };
+FD_HD Tap4 wt_tap(const float* __restrict__ tab, uint32_t mask, float phase) {  // loads of Wavetable::at :154-166
+    float p = (float)(mask + 1u) * phase;
+    uint32_t i1 = (uint32_t)p;
+    Tap4 t;
+    t.w = p - (float)i1;
+    i1 = i1 & mask;
+    float q[4];
+    __builtin_memcpy(q, tab + i1, 16);  // padded layout: tab[i1 + 0..3] = t[i1-1], t[i1], t[i1+1], t[i1+2]
+    t.a0 = q[0]; t.a1 = q[1]; t.a2 = q[2]; t.a3 = q[3];
+    return t;
+}
+FD_HD float tap_eval(const Tap4& t) { return optimal4x44(t.a0, t.a1, t.a2, t.a3, t.w); }
+
 template <int SET>
 struct WaveSynth {
     static constexpr int IN = 1, OUT = 1;
@@ -705,8 +720,12 @@ struct WaveSynth {
     uint64_t hash;
     // transients
     const WtSet* wt;
-    int item_pos, item_table;
+    int item_pos;
     float item_w;
+    int c_table;  // cached descriptor of tables c_table+1 / c_table+2; -1 = invalid
+    float c_p0, c_p1;
+    const float *c_tab1, *c_tab2;
+    uint32_t c_mask1, c_mask2;
     template <class V> FD_HD void visit(V& v) {
         v.f(phase, STATE, "phase");
         v.u32(hint, STATE, "table_hint");
@@ -715,7 +734,10 @@ struct WaveSynth {
         v.f(initial_phase, PARAM, "initial_phase");
         v.u64(hash, STATE, "hash");
     }
-    FD_HD void bind(const void* a) { wt = &static_cast<const Aux*>(a)->wt[SET]; }
+    FD_HD void bind(const void* a) {
+        wt = &static_cast<const Aux*>(a)->wt[SET];
+        c_table = -1;
+    }
     FD_HD void init() {  // WaveSynth::new :270-281: phase 0.0 WITHOUT reset
         phase = 0.0f;
         hint = 0;
@@ -735,30 +757,61 @@ struct WaveSynth {
     FD_HD void begin_block(int) { item_pos = 0; }
     FD_HD bool tripped() const { return false; }
     FD_HD void end_simd() { phase = phase - __builtin_floorf(phase); }  // :345
+    // == table_index(hint, f0) (:189-211) + crossfade weight (:216-220), with the descriptor cache
+    FD_HD float select(float f0) {
+        if (!(c_table == (int)hint && f0 >= c_p0 && f0 <= c_p1)) {
+            int t = wt_table_index(wt, (int)hint, f0);
+            c_table = t;
+            c_p0 = wt->pitch[t];
+            c_p1 = wt->pitch[t + 1];
+            c_tab1 = wt->data + wt->off[t + 1];
+            c_tab2 = wt->data + wt->off[t + 2];
+            c_mask1 = (uint32_t)wt->len[t + 1] - 1u;
+            c_mask2 = (uint32_t)wt->len[t + 2] - 1u;
+            hint = (uint32_t)t;
+        }
+        return clamp01f((f0 - c_p0) / (c_p1 - c_p0));
+    }
     template <int PH> FD_HD void step(const float* in, float* out) {
         if (PH == PH_SIMD) {  // process :327-348
-            if ((item_pos & 7) == 0) {  // table pair and crossfade from LANE 0's frequency for the whole 8-sample item
-                float f0 = __builtin_fabsf(in[0]);
-                item_table = wt_table_index(wt, (int)hint, f0);
-                item_w = clamp01f((f0 - wt->pitch[item_table]) / (wt->pitch[item_table + 1] - wt->pitch[item_table]));
-                hint = (uint32_t)item_table;
-            }
+            // table pair and crossfade from LANE 0's frequency for the whole 8-sample item
+            if ((item_pos & 7) == 0) item_w = select(__builtin_fabsf(in[0]));
             item_pos++;
             phase += in[0] * sample_duration;
             float ph = phase - __builtin_floorf(phase);  // wide's inherent f32x8::floor (true floor)
-            out[0] = (1.0f - item_w) * wt_at(wt, item_table + 1, ph) + item_w * wt_at(wt, item_table + 2, ph);
+            Tap4 t1 = wt_tap(c_tab1, c_mask1, ph), t2 = wt_tap(c_tab2, c_mask2, ph);
+            out[0] = (1.0f - item_w) * tap_eval(t1) + item_w * tap_eval(t2);
         } else {  // tick :310-324: increment + wrap BEFORE reading
             float frequency = in[0];
             phase += frequency * sample_duration;
             phase -= __builtin_floorf(phase);
-            float f0 = __builtin_fabsf(frequency);
-            int table = wt_table_index(wt, (int)hint, f0);
-            float w = clamp01f((f0 - wt->pitch[table]) / (wt->pitch[table + 1] - wt->pitch[table]));
-            hint = (uint32_t)table;
-            out[0] = (1.0f - w) * wt_at(wt, table + 1, phase) + w * wt_at(wt, table + 2, phase);
+            float w = select(__builtin_fabsf(frequency));
+            Tap4 t1 = wt_tap(c_tab1, c_mask1, phase), t2 = wt_tap(c_tab2, c_mask2, phase);
+            out[0] = (1.0f - w) * tap_eval(t1) + w * tap_eval(t2);
         }
     }
-    FD_STEP2_VIA_STEP
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        if (PH == PH_SIMD) {
+            if ((item_pos & 7) == 0) item_w = select(__builtin_fabsf(in[0].x));
+            item_pos += 2;
+            v2f d = in[0] * sample_duration;
+            phase += d.x;
+            float ph0 = phase - __builtin_floorf(phase);
+            phase += d.y;
+            float ph1 = phase - __builtin_floorf(phase);
+            // 16 independent gathers in flight before any of them is consumed
+            Tap4 a1 = wt_tap(c_tab1, c_mask1, ph0), a2 = wt_tap(c_tab2, c_mask2, ph0);
+            Tap4 b1 = wt_tap(c_tab1, c_mask1, ph1), b2 = wt_tap(c_tab2, c_mask2, ph1);
+            float o0 = (1.0f - item_w) * tap_eval(a1) + item_w * tap_eval(a2);
+            float o1 = (1.0f - item_w) * tap_eval(b1) + item_w * tap_eval(b2);
+            out[0] = v2f{o0, o1};
+        } else {
+            float o0, o1, i0 = in[0].x, i1 = in[0].y;
+            this->template step<PH>(&i0, &o0);
+            this->template step<PH>(&i1, &o1);
+            out[0] = v2f{o0, o1};
+        }
+    }
 };
 
 FD_HD float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; }  // math.rs:169-178
