@@ -36,12 +36,22 @@ def _fptr(a):
 class Bank:
     """V voices of one compiled voice graph on the current HIP device."""
 
-    def __init__(self, kind, voices):
+    def __init__(self, kind, voices, _handle=None):
         self._h = C.c_void_p()
         self.kind = kind
-        check(lib().fdsp_bank_create(kind.encode(), int(voices), C.byref(self._h)))
+        if _handle is None:
+            check(lib().fdsp_bank_create(kind.encode(), int(voices), C.byref(self._h)))
+        else:
+            self._h = _handle
         self.voices = int(voices)
         self.sample_rate = _lib.DEFAULT_SR
+
+    @classmethod
+    def reverb_stereo(cls, instances, room_size, time, damping):
+        """Bank of `instances` x reverb_stereo(room_size, time, damping) (32-line FDN, prelude.rs:1732)."""
+        h = C.c_void_p()
+        check(lib().fdsp_reverb_stereo_create(int(instances), float(room_size), float(time), float(damping), C.byref(h)))
+        return cls("reverb_stereo", instances, _handle=h)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

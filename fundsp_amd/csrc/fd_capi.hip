@@ -9,6 +9,7 @@
 
 #include "../../include/fundsp_hip.h"
 #include "fd_engine.hpp"
+#include "fd_fdn.hpp"
 
 namespace {
 
@@ -172,7 +173,14 @@ int build_default_table_set(int set) {
 
 }  // namespace
 
+struct FdnBank {  // reverb_stereo banks (fd_fdn.hip): rings + per-line state instead of the slot SoA
+    double room, time, damping;
+    fd::FdnConst c;
+    fd::FdnState st;
+};
+
 struct fdsp_bank {
+    FdnBank* fdn = nullptr;
     const fd::KindOps* ops;
     size_t V, stride;
     int nslots;
@@ -337,9 +345,84 @@ int fdsp_bank_create(const char* kind, size_t voices, fdsp_bank** out) {
     return FDSP_OK;
 }
 
+static void fdn_free(FdnBank* f) {
+    if (!f) return;
+    if (f->st.rings) hipFree(f->st.rings);
+    if (f->st.idx) hipFree(f->st.idx);
+    if (f->st.v1) hipFree(f->st.v1);
+    if (f->st.v2) hipFree(f->st.v2);
+    if (f->st.fb) hipFree(f->st.fb);
+    f->st = fd::FdnState{};
+}
+
+// (re)allocate rings for the current sample rate and zero everything: Delay::set_sample_rate resizes + resets
+// when the rate changes (delay.rs:105-113)
+static int fdn_configure(fdsp_bank* b, double sr) {
+    FdnBank* f = b->fdn;
+    fd::fdn_make_const(f->room, f->time, f->damping, sr, &f->c);
+    for (int i = 0; i < 32; i++)
+        if (f->c.len[i] <= 64)
+            return fail(FDSP_EINVAL, "reverb_stereo: every delay must exceed 64 samples (room_size * sample_rate too small)");
+    fdn_free(f);
+    const size_t n = b->V;
+    HIPCHK(hipMalloc((void**)&f->st.rings, n * f->c.ring_stride * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&f->st.idx, n * 32 * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&f->st.v1, n * 32 * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&f->st.v2, n * 32 * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&f->st.fb, n * 32 * sizeof(float)));
+    fd::fdn_launch_reset(f->c, f->st, n, b->stream);
+    HIPCHK(hipGetLastError());
+    return FDSP_OK;
+}
+
+int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, double damping, fdsp_bank** out) {
+    if (!out) return fail(FDSP_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (instances == 0 || !(room_size > 0.0) || !(time > 0.0)) return fail(FDSP_EINVAL, "bad reverb_stereo arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FDSP_EDEVICE, "no HIP device available: the fundsp_hip engine has no CPU fallback");
+    fdsp_bank* b = new fdsp_bank();
+    b->fdn = new FdnBank();
+    b->fdn->room = room_size;
+    b->fdn->time = time;
+    b->fdn->damping = damping;
+    b->fdn->st = fd::FdnState{};
+    b->ops = nullptr;
+    b->V = instances;
+    b->stride = instances;
+    b->nslots = 0;
+    b->slots = nullptr;
+    b->timed = false;
+    b->sr = FDSP_DEFAULT_SR;
+    if (hipStreamCreate(&b->stream) != hipSuccess || hipEventCreate(&b->e0) != hipSuccess ||
+        hipEventCreate(&b->e1) != hipSuccess) {
+        delete b->fdn;
+        delete b;
+        return fail(FDSP_EDEVICE, "stream/event creation failed");
+    }
+    int rc = fdn_configure(b, b->sr);
+    if (rc != FDSP_OK) {
+        fdsp_bank_destroy(b);
+        return rc;
+    }
+    hipError_t e = hipStreamSynchronize(b->stream);
+    if (e != hipSuccess) {
+        fdsp_bank_destroy(b);
+        return fail(FDSP_EDEVICE, hipGetErrorString(e));
+    }
+    *out = b;
+    return FDSP_OK;
+}
+
 void fdsp_bank_destroy(fdsp_bank* b) {
     if (!b) return;
     if (b->stream) hipStreamSynchronize(b->stream);
+    if (b->fdn) {
+        fdn_free(b->fdn);
+        delete b->fdn;
+        b->fdn = nullptr;
+    }
     if (b->slots) hipFree(b->slots);
     hipEventDestroy(b->e0);
     hipEventDestroy(b->e1);
@@ -347,12 +430,18 @@ void fdsp_bank_destroy(fdsp_bank* b) {
     delete b;
 }
 
-int fdsp_bank_inputs(const fdsp_bank* b) { return b ? b->ops->nin : FDSP_EINVAL; }
-int fdsp_bank_outputs(const fdsp_bank* b) { return b ? b->ops->nout : FDSP_EINVAL; }
+int fdsp_bank_inputs(const fdsp_bank* b) { return b ? (b->fdn ? 2 : b->ops->nin) : FDSP_EINVAL; }
+int fdsp_bank_outputs(const fdsp_bank* b) { return b ? (b->fdn ? 2 : b->ops->nout) : FDSP_EINVAL; }
 size_t fdsp_bank_voices(const fdsp_bank* b) { return b ? b->V : 0; }
 
 int fdsp_bank_set_sample_rate(fdsp_bank* b, double sr) {
     if (!b || !(sr > 0.0)) return fail(FDSP_EINVAL, "bad bank or sample rate");
+    if (b->fdn) {
+        if (sr == b->sr) return FDSP_OK;  // Delay::set_sample_rate: nothing happens unless the rate changes
+        HIPCHK(hipStreamSynchronize(b->stream));
+        b->sr = sr;
+        return fdn_configure(b, sr);
+    }
     b->sr = sr;
     b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, sr, nullptr, device_aux(), b->stream);
     HIPCHK(hipGetLastError());
@@ -361,6 +450,11 @@ int fdsp_bank_set_sample_rate(fdsp_bank* b, double sr) {
 
 int fdsp_bank_reset(fdsp_bank* b) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    if (b->fdn) {
+        fd::fdn_launch_reset(b->fdn->c, b->fdn->st, b->V, b->stream);
+        HIPCHK(hipGetLastError());
+        return FDSP_OK;
+    }
     b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 2, b->sr, nullptr, device_aux(), b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
@@ -368,6 +462,7 @@ int fdsp_bank_reset(fdsp_bank* b) {
 
 int fdsp_bank_set_seed(fdsp_bank* b, const uint64_t* h_seeds, size_t first, size_t count) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    if (b->fdn) return FDSP_OK;  // no node of reverb_stereo uses its hash (Delay, Fir, Panner: default set_hash)
     if (int rc = check_range(b, first, count)) return rc;
     if (count == 0) return FDSP_OK;
     uint64_t* d = nullptr;
@@ -388,10 +483,10 @@ int fdsp_bank_set_seed(fdsp_bank* b, const uint64_t* h_seeds, size_t first, size
 
 int fdsp_bank_slot_count(const fdsp_bank* b) { return b ? b->nslots : FDSP_EINVAL; }
 const char* fdsp_bank_slot_name(const fdsp_bank* b, int slot) {
-    return (b && slot >= 0 && slot < b->nslots) ? b->ops->slots[slot].name.c_str() : nullptr;
+    return (b && b->ops && slot >= 0 && slot < b->nslots) ? b->ops->slots[slot].name.c_str() : nullptr;
 }
 int fdsp_bank_slot_kind(const fdsp_bank* b, int slot) {
-    return (b && slot >= 0 && slot < b->nslots) ? b->ops->slots[slot].kind : FDSP_EINVAL;
+    return (b && b->ops && slot >= 0 && slot < b->nslots) ? b->ops->slots[slot].kind : FDSP_EINVAL;
 }
 
 static int set_words(fdsp_bank* b, int slot, const void* h_words, size_t first, size_t count) {
@@ -402,6 +497,7 @@ static int set_words(fdsp_bank* b, int slot, const void* h_words, size_t first, 
 }
 
 int fdsp_bank_set_param(fdsp_bank* b, const char* name, const float* h_values, size_t first, size_t count) {
+    if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b || !h_values) return fail(FDSP_EINVAL, "bank or values NULL");
     int s = find_slot(b, name);
     if (s < 0) return fail(FDSP_EINVAL, std::string("unknown slot: ") + (name ? name : "(null)"));
@@ -415,12 +511,14 @@ int fdsp_bank_set_param(fdsp_bank* b, const char* name, const float* h_values, s
 }
 
 int fdsp_bank_set_param_all(fdsp_bank* b, const char* name, float value) {
+    if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
     std::vector<float> tmp(b->V, value);
     return fdsp_bank_set_param(b, name, tmp.data(), 0, b->V);
 }
 
 int fdsp_bank_set_param_u64(fdsp_bank* b, const char* name, const uint64_t* h_values, size_t first, size_t count) {
+    if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b || !h_values || !name) return fail(FDSP_EINVAL, "bank, name or values NULL");
     int lo = find_slot(b, (std::string(name) + ".lo").c_str());
     int hi = find_slot(b, (std::string(name) + ".hi").c_str());
@@ -440,6 +538,7 @@ int fdsp_bank_set_param_u64(fdsp_bank* b, const char* name, const uint64_t* h_va
 }
 
 int fdsp_bank_get_slot(fdsp_bank* b, const char* name, float* h_values, size_t first, size_t count) {
+    if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b || !h_values) return fail(FDSP_EINVAL, "bank or values NULL");
     int s = find_slot(b, name);
     if (s < 0) return fail(FDSP_EINVAL, std::string("unknown slot: ") + (name ? name : "(null)"));
@@ -450,6 +549,7 @@ int fdsp_bank_get_slot(fdsp_bank* b, const char* name, float* h_values, size_t f
 }
 
 int fdsp_bank_get_state(fdsp_bank* b, float* h_slots) {
+    if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b || !h_slots) return fail(FDSP_EINVAL, "bank or buffer NULL");
     HIPCHK(hipStreamSynchronize(b->stream));
     if (b->nslots == 0) return FDSP_OK;
@@ -459,6 +559,7 @@ int fdsp_bank_get_state(fdsp_bank* b, float* h_slots) {
 }
 
 int fdsp_bank_set_state(fdsp_bank* b, const float* h_slots) {
+    if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b || !h_slots) return fail(FDSP_EINVAL, "bank or buffer NULL");
     HIPCHK(hipStreamSynchronize(b->stream));
     if (b->nslots == 0) return FDSP_OK;
@@ -472,14 +573,17 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
     if (frames == 0) return FDSP_OK;  // size == 0 is a legal no-op (audionode.rs:82)
     if (!d_out) return fail(FDSP_EINVAL, "d_out is NULL");
-    if (b->ops->nin > 0 && !d_in) return fail(FDSP_EINVAL, "d_in is NULL but the graph has inputs");
+    if (fdsp_bank_inputs(b) > 0 && !d_in) return fail(FDSP_EINVAL, "d_in is NULL but the graph has inputs");
     if (layout != FDSP_LAYOUT_VOICE_MINOR && layout != FDSP_LAYOUT_PLANAR) return fail(FDSP_EINVAL, "bad layout");
     if (mode != FDSP_MODE_PROCESS && mode != FDSP_MODE_TICK) return fail(FDSP_EINVAL, "bad mode");
     if (layout == FDSP_LAYOUT_PLANAR && frame_stride < frames) return fail(FDSP_EINVAL, "frame_stride < frames");
     hipStream_t s = stream ? (hipStream_t)stream : b->stream;
     if (s != b->stream) HIPCHK(hipStreamSynchronize(b->stream));  // order after pending parameter updates
     HIPCHK(hipEventRecord(b->e0, s));
-    b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, device_aux(), s);
+    if (b->fdn)  // Feedback::process is the per-sample tick (feedback.rs:136-146): both modes are the same arithmetic
+        fd::fdn_launch_render(b->fdn->c, b->fdn->st, b->V, d_in, d_out, frames, frame_stride, layout, s);
+    else
+        b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, device_aux(), s);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->e1, s));
     b->timed = true;
@@ -493,8 +597,8 @@ int fdsp_bank_process_host(fdsp_bank* b, size_t frames, const float* h_in, float
     if (!h_out) return fail(FDSP_EINVAL, "h_out is NULL");
     const size_t row = layout == FDSP_LAYOUT_PLANAR ? frame_stride : frames;
     if (layout == FDSP_LAYOUT_PLANAR && frame_stride < frames) return fail(FDSP_EINVAL, "frame_stride < frames");
-    const size_t n_in = (size_t)b->ops->nin * row * b->V, n_out = (size_t)b->ops->nout * row * b->V;
-    if (b->ops->nin > 0 && !h_in) return fail(FDSP_EINVAL, "h_in is NULL but the graph has inputs");
+    const size_t n_in = (size_t)fdsp_bank_inputs(b) * row * b->V, n_out = (size_t)fdsp_bank_outputs(b) * row * b->V;
+    if (fdsp_bank_inputs(b) > 0 && !h_in) return fail(FDSP_EINVAL, "h_in is NULL but the graph has inputs");
     float *d_in = nullptr, *d_out = nullptr;
     if (n_in) HIPCHK(hipMalloc((void**)&d_in, n_in * sizeof(float)));
     hipError_t e = hipMalloc((void**)&d_out, n_out * sizeof(float));

@@ -1,0 +1,211 @@
+// fd_fdn.hip -- FDN reverb kernel (see fd_fdn.hpp).  Compiled with -fgpu-flush-denormals-to-zero: FunDSP's
+// Feedback::new calls prevent_denormals() (feedback.rs:96, denormal.rs:18: MXCSR FTZ+DAZ), so the reference renders
+// feedback graphs with flushed denormals; this translation unit matches that mode, the rest of the engine keeps IEEE
+// denormals.
+#include <cmath>
+
+#include "fd_fdn.hpp"
+#include "fd_math.hpp"
+
+namespace fd {
+
+static const double RV_DELAYS[32] = {  // prelude.rs:1739-1744
+    0.073904, 0.052918, 0.066238, 0.066387, 0.037783, 0.080073, 0.050961, 0.075900, 0.043646,
+    0.072095, 0.056194, 0.045961, 0.058934, 0.068016, 0.047529, 0.058156, 0.072972, 0.036084,
+    0.062715, 0.076377, 0.044339, 0.076725, 0.077884, 0.046126, 0.067741, 0.049800, 0.051709,
+    0.082923, 0.070121, 0.079315, 0.055039, 0.081859,
+};
+
+void fdn_make_const(double room_size, double time, double damping, double sample_rate, FdnConst* c) {
+    // a = pow(db_amp(-60.0), 0.03 * room_size / 10.0 / time) as f32, db_amp(x) = exp((x / 20) * LN_10)  (math.rs:76-78,294)
+    const double db_amp = std::exp((-60.0 / 20.0) * 2.302585092994046);
+    const float a = (float)std::pow(db_amp, 0.03 * room_size / 10.0 / time);
+    const float gain = 1.0f - (float)damping;  // fir3(1.0 - damping as f32)  prelude.rs:863-867
+    const float alpha = (gain + 1.0f) / 2.0f;
+    const float beta = (1.0f - alpha) / 2.0f;
+    c->w[0] = beta * a;
+    c->w[1] = alpha * a;
+    c->w[2] = beta * a;
+    size_t off = 0;
+    for (int i = 0; i < 32; i++) {
+        const int delay = (int)std::round(RV_DELAYS[i] * room_size / 10.0 * sample_rate);
+        c->len[i] = delay + 1;
+        c->off[i] = (int)off;
+        off += ((size_t)c->len[i] + 63) / 64 * 64;  // keep every ring 256-B aligned
+        const float x = (float)((double)i / 31.0);  // sumf: F::from_f64(i / (N-1))  prelude.rs:1613-1616
+        const float x2 = x * x;                     // smooth9  math.rs:431-437
+        const float t = ((((70.0f * x - 315.0f) * x + 540.0f) * x - 420.0f) * x + 126.0f) * x2 * x2 * x;
+        float p = -1.0f * (1.0f - t) + 1.0f * t;    // lerp(-1.0, 1.0, t)
+        p = p > -1.0f ? p : -1.0f;                  // pan_weights: clamp11  pan.rs:13-17
+        p = p < 1.0f ? p : 1.0f;
+        const float angle = (p + 1.0f) * (F32_PI * 0.25f);
+        c->wl[i] = cosf_musl(angle);
+        c->wr[i] = sinf_musl(angle);
+    }
+    c->ring_stride = off;
+}
+
+constexpr int TS = 65;  // LDS row stride (floats): lane-per-row access is bank-conflict free
+
+__global__ __launch_bounds__(256) void k_fdn_reset(FdnConst c, FdnState s, size_t instances) {
+    // zero the rings and the per-line state (Feedback::reset feedback.rs:123-126 -> Delay::reset, Fir::reset)
+    const size_t total = instances * c.ring_stride;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) s.rings[i] = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < instances * 32; i += (size_t)gridDim.x * 256) {
+        s.idx[i] = 0;
+        s.v1[i] = 0.0f;
+        s.v2[i] = 0.0f;
+        s.fb[i] = 0.0f;
+    }
+}
+
+__device__ __forceinline__ float xor_lane(float v, int h) {
+    int x = __builtin_bit_cast(int, v), r;
+    switch (h) {
+    case 1: r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); break;             // quad_perm [1,0,3,2]
+    case 2: r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); break;             // quad_perm [2,3,0,1]
+    case 4: r = __builtin_amdgcn_ds_swizzle(x, 0x1F | (4 << 10)); break;                     // bit-mode xor 4
+    case 8: r = __builtin_amdgcn_ds_swizzle(x, 0x1F | (8 << 10)); break;
+    default: r = __builtin_amdgcn_ds_swizzle(x, 0x1F | (16 << 10)); break;
+    }
+    return __builtin_bit_cast(float, r);
+}
+
+__device__ __forceinline__ void fdn_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// layout 0: voice-minor [ch][frame][instance]; layout 1: planar [instance][ch][fstride]
+__global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size_t V, const float* __restrict__ in,
+                                                    float* __restrict__ out, size_t T, size_t fstride, int layout) {
+    __shared__ float tile_all[4][64 * TS];   // ring samples in / new ring samples out, one row per (instance, line)
+    __shared__ float tileo_all[4][64 * TS];  // line outputs of the block, for the ordered pan sum
+    __shared__ float tin_all[4][4 * 64];     // [instance in wave][channel][frame]
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    float* tile = tile_all[wib];
+    float* tileo = tileo_all[wib];
+    float* tin = tin_all[wib];
+    const size_t inst0 = ((size_t)blockIdx.x * 4 + wib) * 2;
+    if (inst0 >= V) return;
+    const int j = lane >> 5, k = lane & 31;
+    const size_t inst = inst0 + j;
+    const bool valid = inst < V;
+    const size_t sidx = (valid ? inst : inst0) * 32 + k;
+    int idx = s.idx[sidx];
+    float v1 = s.v1[sidx], v2 = s.v2[sidx], fb = s.fb[sidx];
+    const int mylen = c.len[k];
+    const float w0 = c.w[0], w1 = c.w[1], w2 = c.w[2];
+    const float scale = (float)(1.0 / 5.656854249492381);  // (1.0 / sqrt(32 as f64)) as f32  feedback.rs:57
+    uint32_t negmask[5];
+#pragma unroll
+    for (int st = 0; st < 5; st++) negmask[st] = (k & (1 << st)) ? 0x80000000u : 0u;
+
+    for (size_t t0 = 0; t0 < T; t0 += 64) {
+        const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+        // ---- phase 1: stage this block's 64 ring reads per line (coalesced 256-B rows) and the stereo input
+        for (int r = 0; r < 64; r++) {
+            const int jj = r >> 5, kk = r & 31;
+            const size_t ri = inst0 + jj;
+            const int i0 = __builtin_amdgcn_readlane(idx, r);
+            const int len = c.len[kk];
+            float x = 0.0f;
+            if (ri < V && lane < size) {
+                int pos = i0 + 1 + lane;
+                while (pos >= len) pos -= len;
+                x = s.rings[ri * c.ring_stride + (size_t)c.off[kk] + (size_t)pos];
+            }
+            tile[r * TS + lane] = x;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {  // q = jj*2 + channel
+            const size_t ri = inst0 + (q >> 1);
+            const int ch = q & 1;
+            float x = 0.0f;
+            if (ri < V && lane < size)
+                x = layout == 0 ? in[((size_t)ch * T + t0 + lane) * V + ri] : in[(ri * 2 + ch) * fstride + t0 + lane];
+            tin[q * 64 + lane] = x;
+        }
+        fdn_wave_sync();
+        // ---- phase 2: 64 samples of the recirculating network, one lane per delay line
+        for (int n = 0; n < size; n++) {
+            const float x = tin[(j * 2 + (k & 1)) * 64 + n] + fb;  // MultiSplit<U2,U16> (audionode.rs:600) + Feedback::tick
+            const float d = tile[lane * TS + n];                   // Delay::tick: oldest sample of the ring ...
+            tile[lane * TS + n] = x;                               // ... and the new one takes the slot written this step
+            const float v0 = v1;                                   // Fir<U3>::tick fir.rs:57-70
+            v1 = v2;
+            v2 = d;
+            float o = 0.0f;
+            o += w0 * v0;
+            o += w1 * v1;
+            o += w2 * v2;
+            tileo[lane * TS + n] = o;
+            float h = o;                                           // FrameHadamard feedback.rs:35-57, stages h = 1..16
+#pragma unroll
+            for (int st = 0; st < 5; st++) {
+                const float p = xor_lane(h, 1 << st);
+                // lower lane of a pair: x + y (own + partner); upper lane: x - y (partner - own)
+                h = p + u2f(f2u(h) ^ negmask[st]);
+            }
+            fb = h * scale;
+        }
+        fdn_wave_sync();
+        // ---- phase 3: write the 64 new ring samples per line back (coalesced), ordered pan sum with lane = frame
+        for (int r = 0; r < 64; r++) {
+            const int jj = r >> 5, kk = r & 31;
+            const size_t ri = inst0 + jj;
+            const int i0 = __builtin_amdgcn_readlane(idx, r);
+            const int len = c.len[kk];
+            if (ri < V && lane < size) {
+                int pos = i0 + lane;
+                while (pos >= len) pos -= len;
+                s.rings[ri * c.ring_stride + (size_t)c.off[kk] + (size_t)pos] = tile[r * TS + lane];
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const size_t ri = inst0 + jj;
+            float l = 0.0f, rr = 0.0f;
+            for (int kk = 0; kk < 32; kk++) {  // Reduce::tick left fold (audionode.rs:2427-2439) of Panner outputs
+                const float o = tileo[(jj * 32 + kk) * TS + lane];
+                const float pl = c.wl[kk] * o, pr = c.wr[kk] * o;
+                l = kk == 0 ? pl : l + pl;
+                rr = kk == 0 ? pr : rr + pr;
+            }
+            l *= (float)(1.0 / 16.0);  // * dc((1/16, 1/16))
+            rr *= (float)(1.0 / 16.0);
+            if (ri < V && lane < size) {
+                if (layout == 0) {
+                    out[((size_t)0 * T + t0 + lane) * V + ri] = l;
+                    out[((size_t)1 * T + t0 + lane) * V + ri] = rr;
+                } else {
+                    out[(ri * 2 + 0) * fstride + t0 + lane] = l;
+                    out[(ri * 2 + 1) * fstride + t0 + lane] = rr;
+                }
+            }
+        }
+        idx += size;
+        while (idx >= mylen) idx -= mylen;
+        fdn_wave_sync();
+    }
+    if (valid) {
+        s.idx[sidx] = idx;
+        s.v1[sidx] = v1;
+        s.v2[sidx] = v2;
+        s.fb[sidx] = fb;
+    }
+}
+
+void fdn_launch_reset(const FdnConst& c, const FdnState& s, size_t instances, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fdn_reset, dim3(2048), dim3(256), 0, stream, c, s, instances);
+}
+
+void fdn_launch_render(const FdnConst& c, const FdnState& s, size_t instances, const float* in, float* out, size_t T,
+                       size_t fstride, int layout, hipStream_t stream) {
+    if (instances == 0 || T == 0) return;
+    const unsigned grid = (unsigned)((instances + 7) / 8);
+    hipLaunchKernelGGL(k_fdn_render, dim3(grid), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout);
+}
+
+}  // namespace fd

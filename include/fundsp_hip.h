@@ -96,6 +96,11 @@ int fdsp_kind_slot_kind(int kind, int slot);
 /* Creates a bank of `voices` instances on the current HIP device.  State after creation equals the
  * reference constructor: DEFAULT_SR, default parameters, combinator construction-time ping (audionode.rs:871-876). */
 int fdsp_bank_create(const char* kind, size_t voices, fdsp_bank** out);
+/* reverb_stereo(room_size, time, damping) (src/prelude.rs:1732-1762): bank of `instances` independent 32-line FDN
+ * reverbs, 2 inputs / 2 outputs each, all with the same parameters.  Mapped one lane per delay line (32 lanes per
+ * instance), delay rings in HBM; flushes f32 denormals like the reference does after Feedback::new
+ * (src/feedback.rs:96, src/denormal.rs:18).  The handle works with set_sample_rate / reset / process / destroy. */
+int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, double damping, fdsp_bank** out);
 void fdsp_bank_destroy(fdsp_bank* bank);
 int fdsp_bank_inputs(const fdsp_bank* bank);   /* AudioNode::Inputs  */
 int fdsp_bank_outputs(const fdsp_bank* bank);  /* AudioNode::Outputs */

@@ -19,6 +19,9 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#if defined(__x86_64__) || defined(__i386__)
+#include <xmmintrin.h>
+#endif
 
 #define DEFAULT_SR 44100.0 /* src/lib.rs:42 */
 #define MAXB 64            /* MAX_BUFFER_SIZE src/lib.rs:48 */
@@ -86,6 +89,11 @@ struct onode {
         float attack_start, release_start, adsr_a, adsr_d, adsr_s, adsr_r;
         /* Panner (pan.rs:26-30) */
         float left_weight, right_weight;
+        /* reverb_stereo: 32 x (Delay >> Fir<U3>) inside Feedback<U32,_,FrameHadamard> (prelude.rs:1732-1762) */
+        double rv_room, rv_time, rv_damping, rv_sr;
+        float *rv_buf[32];
+        size_t rv_len[32], rv_i[32];
+        float rv_v[32][3], rv_w[3], rv_value[32], rv_wl[32], rv_wr[32];
     } s;
 };
 
@@ -113,6 +121,8 @@ int o_outputs(const onode *n) { return n->nout; }
 
 void o_free(onode *n) {
     if (!n) return;
+    if (n->type == O_REVERB_STEREO)
+        for (int i = 0; i < 32; i++) free(n->s.rv_buf[i]);
     o_free(n->x);
     o_free(n->y);
     free(n->tmp);
@@ -324,6 +334,14 @@ static void leaf_reset(onode *n) {
         n->s.di = 0;
         for (size_t i = 0; i < n->s.dlen; i++) n->s.dbuf[i] = 0.0f;
         break;
+    case O_REVERB_STEREO: /* Feedback::reset feedback.rs:123-126 -> Delay / Fir reset */
+        for (int i = 0; i < 32; i++) {
+            n->s.rv_i[i] = 0;
+            for (size_t k = 0; k < n->s.rv_len[i]; k++) n->s.rv_buf[i][k] = 0.0f;
+            n->s.rv_v[i][0] = n->s.rv_v[i][1] = n->s.rv_v[i][2] = 0.0f;
+            n->s.rv_value[i] = 0.0f;
+        }
+        break;
     case O_WAVESYNTH: /* wavetable.rs:292-297 */
         n->s.phase = n->s.has_initial_phase ? n->s.initial_phase : (float)o_rnd1(n->s.hash);
         break;
@@ -371,6 +389,19 @@ static void leaf_set_sample_rate(onode *n, double sr) {
     case O_MOOG: /* moog.rs:76-79 */
         n->s.sr = (float)sr;
         moog_set_cutoff_q(n, n->s.cutoff, n->s.q);
+        break;
+    case O_REVERB_STEREO:
+        if (n->s.rv_sr != sr) { /* Delay::set_sample_rate delay.rs:105-113 (resize + reset only on change) */
+            int d[32];
+            n->s.rv_sr = sr;
+            o_reverb_stereo_params(n->s.rv_room, n->s.rv_time, n->s.rv_damping, sr, n->s.rv_w, d, n->s.rv_wl, n->s.rv_wr);
+            for (int i = 0; i < 32; i++) {
+                n->s.rv_len[i] = (size_t)d[i] + 1;
+                n->s.rv_buf[i] = (float *)realloc(n->s.rv_buf[i], n->s.rv_len[i] * sizeof(float));
+                n->s.rv_i[i] = 0;
+                for (size_t k = 0; k < n->s.rv_len[i]; k++) n->s.rv_buf[i][k] = 0.0f;
+            }
+        }
         break;
     case O_WAVESYNTH: /* wavetable.rs:299-302: f32 reciprocal of the f32-cast rate */
         n->s.ws_sr = (float)sr;
@@ -617,6 +648,45 @@ static void pan_weights(float value, float *l, float *r) { /* pan.rs:13-17 */
 onode *o_panner(int inputs, float pan) { /* Panner::new pan.rs:33-40, ID 49 */
     onode *n = o_new(O_PANNER, inputs, 2, 49);
     pan_weights(pan, &n->s.left_weight, &n->s.right_weight);
+    return n;
+}
+
+/* ---- reverb_stereo (prelude.rs:1732-1762) ---- */
+static const double RV_DELAYS[32] = {
+    0.073904, 0.052918, 0.066238, 0.066387, 0.037783, 0.080073, 0.050961, 0.075900, 0.043646,
+    0.072095, 0.056194, 0.045961, 0.058934, 0.068016, 0.047529, 0.058156, 0.072972, 0.036084,
+    0.062715, 0.076377, 0.044339, 0.076725, 0.077884, 0.046126, 0.067741, 0.049800, 0.051709,
+    0.082923, 0.070121, 0.079315, 0.055039, 0.081859,
+};
+static float smooth9f(float x) { /* math.rs:431-437 */
+    float x2 = x * x;
+    return ((((70.0f * x - 315.0f) * x + 540.0f) * x - 420.0f) * x + 126.0f) * x2 * x2 * x;
+}
+void o_reverb_stereo_params(double room_size, double time, double damping, double sample_rate, float *w3, int *delays32,
+                            float *wl32, float *wr32) {
+    /* a = pow(db_amp(-60.0), 0.03 * room_size / 10.0 / time) as f32; db_amp(x) = exp10(x/20) = exp((x/20)*LN_10)
+     * (math.rs:76-78,294-296) -- f64 libm; the host C library's exp/pow stand in for the `libm` crate here */
+    double db_amp = exp((-60.0 / 20.0) * 2.302585092994046);
+    float a = (float)pow(db_amp, 0.03 * room_size / 10.0 / time);
+    /* fir3(gain).weights() * a : prelude.rs:863-867 */
+    float gain = 1.0f - (float)damping;
+    float alpha = (gain + 1.0f) / 2.0f;
+    float beta = (1.0f - alpha) / 2.0f;
+    w3[0] = beta * a; w3[1] = alpha * a; w3[2] = beta * a;
+    for (int i = 0; i < 32; i++) {
+        delays32[i] = (int)round(RV_DELAYS[i] * room_size / 10.0 * sample_rate); /* Delay::set_sample_rate delay.rs:108 */
+        /* sumf::<U32>(|x| pan(lerp(-1.0, 1.0, smooth9(x)))), x = (i / 31) as f32  (prelude.rs:1603-1622,1759) */
+        float x = (float)((double)i / 31.0);
+        float t = smooth9f(x);
+        float p = -1.0f * (1.0f - t) + 1.0f * t;
+        pan_weights(p, &wl32[i], &wr32[i]);
+    }
+}
+onode *o_reverb_stereo(double room_size, double time, double damping) {
+    onode *n = o_new(O_REVERB_STEREO, 2, 2, 6);
+    n->s.rv_room = room_size; n->s.rv_time = time; n->s.rv_damping = damping;
+    n->s.rv_sr = 0.0;
+    leaf_set_sample_rate(n, DEFAULT_SR);
     return n;
 }
 
@@ -911,6 +981,49 @@ void o_tick(onode *n, const float *in, float *out) {
         n->s.ev += n->s.evd;
         n->s.et += n->s.esd;
         break;
+    case O_REVERB_STEREO: {
+        /* Feedback::new calls prevent_denormals() (feedback.rs:96; denormal.rs:18: MXCSR = 0x9fc0, FTZ + DAZ) on the
+         * constructing thread, so a graph rendered on that thread runs flushed: do the same for this node. */
+#if defined(__x86_64__) || defined(__i386__)
+        unsigned int csr = _mm_getcsr();
+        _mm_setcsr(0x9fc0);
+#endif
+        float o[32];
+        for (int i = 0; i < 32; i++) {
+            float x = in[i % 2] + n->s.rv_value[i];          /* MultiSplit<U2,U16> :600-602 ; Feedback::tick :131 */
+            n->s.rv_buf[i][n->s.rv_i[i]] = x;                 /* Delay::tick delay.rs:116-124 */
+            n->s.rv_i[i] += 1;
+            if (n->s.rv_i[i] >= n->s.rv_len[i]) n->s.rv_i[i] = 0;
+            float d = n->s.rv_buf[i][n->s.rv_i[i]];
+            float *v = n->s.rv_v[i];                          /* Fir<U3>::tick fir.rs:57-70 */
+            v[0] = v[1]; v[1] = v[2]; v[2] = d;
+            float acc = 0.0f;
+            for (int k = 0; k < 3; k++) acc += n->s.rv_w[k] * v[k];
+            o[i] = acc;
+        }
+        float h[32];                                          /* FrameHadamard::frame feedback.rs:35-57 */
+        for (int i = 0; i < 32; i++) h[i] = o[i];
+        for (int hh = 1; hh < 32; hh *= 2)
+            for (int i = 0; i < 32; i += hh * 2)
+                for (int j = i; j < i + hh; j++) {
+                    float x = h[j], y = h[j + hh];
+                    h[j] = x + y;
+                    h[j + hh] = x - y;
+                }
+        float scale = (float)(1.0 / sqrt(32.0));
+        for (int i = 0; i < 32; i++) n->s.rv_value[i] = h[i] * scale;
+        float l = 0.0f, r = 0.0f;                             /* Reduce::tick audionode.rs:2427-2439 (left fold) */
+        for (int i = 0; i < 32; i++) {
+            float pl = n->s.rv_wl[i] * o[i], pr = n->s.rv_wr[i] * o[i];
+            if (i > 0) { l = l + pl; r = r + pr; } else { l = pl; r = pr; }
+        }
+        out[0] = l * (float)(1.0 / 16.0);                     /* * dc((1/16, 1/16)) */
+        out[1] = r * (float)(1.0 / 16.0);
+#if defined(__x86_64__) || defined(__i386__)
+        _mm_setcsr(csr);
+#endif
+        break;
+    }
     case O_PANNER: /* pan.rs:55-62 */
         if (n->nin > 1) pan_weights(in[1], &n->s.left_weight, &n->s.right_weight);
         out[0] = n->s.left_weight * in[0];

@@ -17,7 +17,7 @@ typedef struct onode onode;
 enum {
     O_CONSTANT = 0, O_PASS, O_SINE, O_NOISE, O_SVF, O_FIXED_SVF, O_BIQUAD, O_BUTTER_LOWPASS, O_RESONATOR,
     O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP,
-    O_WAVESYNTH, O_ADSR_LIVE, O_PANNER
+    O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO
 };
 /* SvfMode order follows src/svf.rs:281-742 */
 enum {
@@ -52,6 +52,11 @@ onode *o_wavesynth(const owavetable *table, int outputs);
 void o_wavesynth_set_phase(onode *n, float phase);
 onode *o_adsr_live(float attack, float decay, float sustain, float release);
 onode *o_panner(int inputs, float pan);
+/* reverb_stereo(room_size, time, damping): 32-line FDN (prelude.rs:1732-1762). */
+onode *o_reverb_stereo(double room_size, double time, double damping);
+/* derived constants of reverb_stereo at `sample_rate`: FIR weights (3), delay lengths in samples (32), pan weights (32+32) */
+void o_reverb_stereo_params(double room_size, double time, double damping, double sample_rate, float *w3, int *delays32,
+                            float *wl32, float *wr32);
 /* combinators (take ownership of children) */
 onode *o_pipe(onode *x, onode *y);
 onode *o_stack(onode *x, onode *y);

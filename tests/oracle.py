@@ -72,6 +72,8 @@ def lib():
         "o_wavetable_create": (P, [i, fp, C.POINTER(C.c_int), fp]), "o_wavetable_free": (None, [P]),
         "o_wavesynth": (P, [P, i]), "o_wavesynth_set_phase": (None, [P, f]),
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
+        "o_reverb_stereo": (P, [d, d, d]),
+        "o_reverb_stereo_params": (None, [d, d, d, d, fp, C.POINTER(C.c_int), fp, fp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -286,6 +288,16 @@ def triangle(): return wavesynth("triangle")
 def saw_hz(f): return constant(f) >> saw()
 def adsr_live(a, d, s, r): return Node(lib().o_adsr_live(a, d, s, r))  # adsr.rs:21
 def pan(p): return Node(lib().o_panner(1, p))                         # prelude.rs:1250
+
+
+def reverb_stereo(room_size, time, damping): return Node(lib().o_reverb_stereo(room_size, time, damping))  # prelude.rs:1732
+
+
+def reverb_stereo_params(room_size, time, damping, sample_rate):
+    w = np.zeros(3, np.float32); d = np.zeros(32, np.int32); wl = np.zeros(32, np.float32); wr = np.zeros(32, np.float32)
+    lib().o_reverb_stereo_params(room_size, time, damping, sample_rate, _fptr(w), d.ctypes.data_as(C.POINTER(C.c_int)),
+                                 _fptr(wl), _fptr(wr))
+    return w, d, wl, wr
 
 
 def set_biquad_bank(node, index, coefs):

@@ -1,0 +1,66 @@
+"""GPU parity for BASELINE config 5: reverb_stereo (32-line FDN, prelude.rs:1732-1762) -- lane-per-delay-line kernel
+vs the oracle's per-sample restatement.  Bit-exact, including the ordered 32-term pan sum and the Hadamard stages."""
+import numpy as np
+import pytest
+
+import oracle as O
+from fundsp_amd import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS
+from test_gpu_parity import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+
+
+def render(bank, x, layout):
+    """x: [V][2][T] -> [V][2][T]"""
+    import torch
+
+    V, _, T = x.shape
+    if layout == LAYOUT_PLANAR:
+        out = bank.process(T, torch.from_numpy(x).cuda(), layout=LAYOUT_PLANAR, frame_stride=T)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+    inp = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 2, 0))).cuda()
+    out = bank.process(T, inp, layout=LAYOUT_VOICE_MINOR)
+    torch.cuda.synchronize()
+    return out.cpu().numpy().transpose(2, 0, 1)
+
+
+@pytest.mark.parametrize("layout", [LAYOUT_PLANAR, LAYOUT_VOICE_MINOR])
+def test_reverb_stereo_matches_oracle(gpu, layout):
+    V, T = 5, 64 * 150 + 17  # > 2 trips around the longest line (3980 samples); odd V: half-empty last wave
+    rng = np.random.default_rng(12)
+    x = (rng.random((V, 2, T), dtype=np.float32) * 2 - 1).astype(np.float32)
+    x[1, :, 200:] = 0.0      # an impulse-like burst that decays
+    x[2] = 0.0
+    x[2, 0, 0] = 1.0         # pure impulse on the left channel
+    b = gpu.Bank.reverb_stereo(V, 10.0, 2.0, 0.5)
+    b.set_sample_rate(SR)
+    assert b.inputs() == 2 and b.outputs() == 2
+    got = render(b, x, layout)
+    for v in range(V):
+        n = O.reverb_stereo(10.0, 2.0, 0.5)
+        n.set_sample_rate(SR)
+        assert_bit_equal(got[v], n.render_blocks(x[v]), f"reverb instance {v}")
+    assert np.abs(got[2, :, 4000:]).max() > 1e-4  # the impulse actually recirculated
+
+
+def test_reverb_chunked_calls_reset_and_other_rooms(gpu):
+    V, T = 3, 64 * 70
+    rng = np.random.default_rng(13)
+    x = (rng.random((V, 2, T), dtype=np.float32) * 2 - 1).astype(np.float32)
+    b = gpu.Bank.reverb_stereo(V, 20.0, 5.0, 0.2)
+    b.set_sample_rate(SR)
+    one = render(b, x, LAYOUT_PLANAR)
+    b.reset()
+    a1 = render(b, np.ascontiguousarray(x[:, :, :1000]), LAYOUT_PLANAR)      # ragged chunk: 1000 = 15*64 + 40
+    a2 = render(b, np.ascontiguousarray(x[:, :, 1000:]), LAYOUT_PLANAR)
+    assert_bit_equal(np.concatenate([a1, a2], axis=2), one, "chunked == whole")
+    n = O.reverb_stereo(20.0, 5.0, 0.2)
+    n.set_sample_rate(SR)
+    assert_bit_equal(one[1], n.render_blocks(x[1]), "room 20 m")
+
+
+def test_reverb_rejects_tiny_delays(gpu):
+    with pytest.raises(gpu.FdspError):
+        gpu.Bank.reverb_stereo(1, 0.1, 2.0, 0.5)  # 10 cm room: delays shorter than a 64-sample block
