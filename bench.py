@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=3, choices=[3, 4],
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5],
                     help="3 = headline FM+SVF voices (default); 4 = saw>>moog*adsr>>pan voices (informational)")
     ap.add_argument("--voices", type=int, default=None, help="voices per GPU (weak scaling); default 65536 (config 3) / 32768 (config 4)")
     ap.add_argument("--frames", type=int, default=48000, help="frames per step (1 s @ 48 kHz)")
@@ -90,7 +90,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     if args.voices is None:
-        args.voices = 65536 if args.config == 3 else 32768
+        args.voices = {3: 65536, 4: 32768, 5: 2048}[args.config]
     V, T, sr = args.voices, args.frames, args.sample_rate
     layout = F.LAYOUT_VOICE_MINOR if args.layout == "voice_minor" else F.LAYOUT_PLANAR
     mode = F.MODE_PROCESS if args.mode == "process" else F.MODE_TICK
@@ -99,6 +99,15 @@ def main():
     if args.config == 3:
         bank = W.make_fm_svf_bank(V, sr, voice0=first)
         n_out, bytes_per_sample = 1, 4
+    elif args.config == 5:
+        # 16 384 x reverb_stereo(10, 2, 0.5) over 8 GPUs = 2048 instances per GPU; stereo white noise resident in HBM;
+        # planar [instance][channel][frame] I/O (lane = frame in the kernel's staging phases)
+        layout = F.LAYOUT_PLANAR
+        bank = F.Bank.reverb_stereo(V, 10.0, 2.0, 0.5)
+        bank.set_sample_rate(sr)
+        g = torch.Generator(device="cuda").manual_seed(1234 + first)
+        inp = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
+        n_out, bytes_per_sample = 2, 272  # 32 ring reads + 32 ring writes + 2 in + 2 out, x 4 B
     else:
         assert layout == F.LAYOUT_VOICE_MINOR, "config 4 bench uses the device-native layout"
         F.wavetable_build("saw")
@@ -115,6 +124,8 @@ def main():
         if args.mix:
             if args.config == 3:
                 mix = F.mix_stereo(out[0] if layout == F.LAYOUT_VOICE_MINOR else out[:, 0, :].t().contiguous())
+            elif args.config == 5:
+                mix = out.sum(dim=0)     # [2][T] sum over instances (planar layout)
             else:
                 mix = F.sum_voices(out)  # voices are already panned to stereo
             fdist.allreduce_mix(mix)
@@ -148,7 +159,7 @@ def main():
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         # config 3 = 4 B per voice-sample out + 64 B state/params per voice per launch;
         # config 4 = 4 B gate in + 8 B stereo out per voice-sample (+ 188 B of slots per voice per launch)
-        algo_bytes = V * T * bytes_per_sample + V * (64 if args.config == 3 else 188)
+        algo_bytes = V * T * bytes_per_sample + V * {3: 64, 4: 188, 5: 512}[args.config]
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -160,8 +171,9 @@ def main():
             except Exception:
                 traffic = None
         res = {
-            "metric": "Msamples/s (whole node) for 65536-voice SVF+FM graph" if args.config == 3 else
-                      "Msamples/s (whole node) for saw>>moog*adsr>>pan voices (BASELINE config 4, informational)",
+            "metric": {3: "Msamples/s (whole node) for 65536-voice SVF+FM graph",
+                       4: "Msamples/s (whole node) for saw>>moog*adsr>>pan voices (BASELINE config 4, informational)",
+                       5: "M instance-frames/s (whole node) for reverb_stereo FDN instances (BASELINE config 5, informational)"}[args.config],
             "value": round(value, 3),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -174,8 +186,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": ("BASELINE config 3: sine_hz(f)*f*m+f >> sine() >> lowpass_hz(fc,q), " if args.config == 3 else
-                             "BASELINE config 4 voice: ((dc(f)>>saw()|dc(fc)|dc(q))>>moog())*adsr_live(.01,.1,.6,.2)>>pan(p), gate in, ") +
+                "workload": {3: "BASELINE config 3: sine_hz(f)*f*m+f >> sine() >> lowpass_hz(fc,q), ",
+                             4: "BASELINE config 4 voice: ((dc(f)>>saw()|dc(fc)|dc(q))>>moog())*adsr_live(.01,.1,.6,.2)>>pan(p), gate in, ",
+                             5: "BASELINE config 5: reverb_stereo(10.0, 2.0, 0.5) 32-line FDN, stereo noise in, planar I/O, "}[args.config] +
                             f"{V} voices/GPU x {T} frames/step @ {sr:g} Hz, voice-out ([frame][voice] f32), "
                             f"{args.mode} semantics, per-voice params from rnd1(4v+k), phases via set_seed(v)",
                 "voices_per_gpu": V,
@@ -191,7 +204,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "kernel": f"fd::k_render<{'fm_svf' if args.config == 3 else 'saw_moog_adsr_pan'}, {args.mode}, {args.layout}>",
+                "kernel": (f"fd::k_render<{'fm_svf' if args.config == 3 else 'saw_moog_adsr_pan'}, {args.mode}, {args.layout}>"
+                           if args.config != 5 else "fd::k_fdn_render"),
                 "kernel_ms_avg": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },

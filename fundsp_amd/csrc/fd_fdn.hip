@@ -59,14 +59,25 @@ __global__ __launch_bounds__(256) void k_fdn_reset(FdnConst c, FdnState s, size_
     }
 }
 
-__device__ __forceinline__ float xor_lane(float v, int h) {
+// Value of lane (l ^ h) inside each 32-lane instance.  Strides 1..8 are pure DPP register moves (no LDS round trip on
+// the per-sample critical path): xor 1/2 = quad_perm; xor 4 = quad reversal then row_half_mirror (i -> 7-i);
+// xor 8 = row_half_mirror then row_mirror (i -> 15-i).  Stride 16 crosses DPP rows: gfx950's v_permlane16_swap.
+template <int H>
+__device__ __forceinline__ float xor_lane(float v, bool upper16) {
     int x = __builtin_bit_cast(int, v), r;
-    switch (h) {
-    case 1: r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); break;             // quad_perm [1,0,3,2]
-    case 2: r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); break;             // quad_perm [2,3,0,1]
-    case 4: r = __builtin_amdgcn_ds_swizzle(x, 0x1F | (4 << 10)); break;                     // bit-mode xor 4
-    case 8: r = __builtin_amdgcn_ds_swizzle(x, 0x1F | (8 << 10)); break;
-    default: r = __builtin_amdgcn_ds_swizzle(x, 0x1F | (16 << 10)); break;
+    if (H == 1) r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);       // quad_perm [1,0,3,2]
+    else if (H == 2) r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    else if (H == 4) {
+        int t = __builtin_amdgcn_update_dpp(x, x, 0x1B, 0xF, 0xF, false);            // quad_perm [3,2,1,0]
+        r = __builtin_amdgcn_update_dpp(t, t, 0x141, 0xF, 0xF, false);               // row_half_mirror
+    } else if (H == 8) {
+        int t = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false);           // row_half_mirror
+        r = __builtin_amdgcn_update_dpp(t, t, 0x140, 0xF, 0xF, false);               // row_mirror
+    } else {
+        // permlane16_swap(a, b): a.row1 <-> b.row0 and a.row3 <-> b.row2.  With a = b = x: a's odd rows receive the
+        // even rows' values and b's even rows receive the odd rows' values.
+        auto sw = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+        r = upper16 ? (int)sw[0] : (int)sw[1];
     }
     return __builtin_bit_cast(float, r);
 }
@@ -105,18 +116,22 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
     for (size_t t0 = 0; t0 < T; t0 += 64) {
         const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
         // ---- phase 1: stage this block's 64 ring reads per line (coalesced 256-B rows) and the stereo input
-        for (int r = 0; r < 64; r++) {
-            const int jj = r >> 5, kk = r & 31;
-            const size_t ri = inst0 + jj;
-            const int i0 = __builtin_amdgcn_readlane(idx, r);
-            const int len = c.len[kk];
-            float x = 0.0f;
-            if (ri < V && lane < size) {
-                int pos = i0 + 1 + lane;
-                while (pos >= len) pos -= len;
-                x = s.rings[ri * c.ring_stride + (size_t)c.off[kk] + (size_t)pos];
+        // 32 independent 256-B row loads in flight per wave before the first LDS write (memory-level parallelism:
+        // a wave alone on its SIMD cannot hide HBM latency any other way)
+        for (int r0 = 0; r0 < 64; r0 += 32) {
+            float xr[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) {
+                const int r = r0 + u, kk = u;         // r0 is 0 or 32: jj = r0 >> 5, line = u
+                const size_t ri = inst0 + (r0 >> 5);
+                const int i0 = __builtin_amdgcn_readlane(idx, r);
+                const int len = c.len[kk];
+                int pos = i0 + 1 + lane;              // len > 64 (checked at creation): one conditional wrap suffices
+                pos = pos >= len ? pos - len : pos;
+                xr[u] = (ri < V && lane < size) ? s.rings[ri * c.ring_stride + (size_t)c.off[kk] + (size_t)pos] : 0.0f;
             }
-            tile[r * TS + lane] = x;
+#pragma unroll
+            for (int u = 0; u < 32; u++) tile[(r0 + u) * TS + lane] = xr[u];
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {  // q = jj*2 + channel
@@ -128,39 +143,63 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
             tin[q * 64 + lane] = x;
         }
         fdn_wave_sync();
-        // ---- phase 2: 64 samples of the recirculating network, one lane per delay line
-        for (int n = 0; n < size; n++) {
-            const float x = tin[(j * 2 + (k & 1)) * 64 + n] + fb;  // MultiSplit<U2,U16> (audionode.rs:600) + Feedback::tick
-            const float d = tile[lane * TS + n];                   // Delay::tick: oldest sample of the ring ...
-            tile[lane * TS + n] = x;                               // ... and the new one takes the slot written this step
-            const float v0 = v1;                                   // Fir<U3>::tick fir.rs:57-70
-            v1 = v2;
-            v2 = d;
-            float o = 0.0f;
-            o += w0 * v0;
-            o += w1 * v1;
-            o += w2 * v2;
-            tileo[lane * TS + n] = o;
-            float h = o;                                           // FrameHadamard feedback.rs:35-57, stages h = 1..16
+        // ---- phase 2: 64 samples of the recirculating network, one lane per delay line.  Ring reads and inputs of 8
+        // frames are fetched from LDS ahead of the serial recurrence (they do not depend on it); the only cross-lane
+        // traffic on the per-sample critical path is the 5-stage Hadamard.
+        const float* trow = tile + lane * TS;
+        const float* irow = tin + (j * 2 + (k & 1)) * 64;  // MultiSplit<U2,U16>: channel i takes input i % 2 (audionode.rs:600)
+        const bool upper16 = (k & 16) != 0;
+        for (int n0 = 0; n0 < size; n0 += 8) {
+            float dd[8], xi[8], xo[8], oo[8];
 #pragma unroll
-            for (int st = 0; st < 5; st++) {
-                const float p = xor_lane(h, 1 << st);
-                // lower lane of a pair: x + y (own + partner); upper lane: x - y (partner - own)
-                h = p + u2f(f2u(h) ^ negmask[st]);
+            for (int u = 0; u < 8; u++) {
+                dd[u] = trow[n0 + u];
+                xi[u] = irow[n0 + u];
             }
-            fb = h * scale;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const float x = xi[u] + fb;   // Feedback::tick: input + value
+                xo[u] = x;                    // Delay::tick: the new sample takes the slot read this step
+                const float v0 = v1;          // Fir<U3>::tick fir.rs:57-70
+                v1 = v2;
+                v2 = dd[u];
+                float o = 0.0f;
+                o += w0 * v0;
+                o += w1 * v1;
+                o += w2 * v2;
+                oo[u] = o;
+                float h = o;                  // FrameHadamard feedback.rs:35-57, stages h = 1, 2, 4, 8, 16
+                // lower lane of a pair: x + y (own + partner); upper lane: x - y (partner - own)
+                h = xor_lane<1>(h, upper16) + u2f(f2u(h) ^ negmask[0]);
+                h = xor_lane<2>(h, upper16) + u2f(f2u(h) ^ negmask[1]);
+                h = xor_lane<4>(h, upper16) + u2f(f2u(h) ^ negmask[2]);
+                h = xor_lane<8>(h, upper16) + u2f(f2u(h) ^ negmask[3]);
+                h = xor_lane<16>(h, upper16) + u2f(f2u(h) ^ negmask[4]);
+                const float fbn = h * scale;
+                fb = (n0 + u < size) ? fbn : fb;  // ragged tail of the last block: frames past `size` change nothing
+                if (n0 + u >= size) { v2 = v1; v1 = v0; }  // (undo the shift)
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                tile[lane * TS + n0 + u] = xo[u];
+                tileo[lane * TS + n0 + u] = oo[u];
+            }
         }
         fdn_wave_sync();
         // ---- phase 3: write the 64 new ring samples per line back (coalesced), ordered pan sum with lane = frame
-        for (int r = 0; r < 64; r++) {
-            const int jj = r >> 5, kk = r & 31;
-            const size_t ri = inst0 + jj;
-            const int i0 = __builtin_amdgcn_readlane(idx, r);
-            const int len = c.len[kk];
-            if (ri < V && lane < size) {
+        for (int r0 = 0; r0 < 64; r0 += 32) {
+            float xr[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) xr[u] = tile[(r0 + u) * TS + lane];
+#pragma unroll
+            for (int u = 0; u < 32; u++) {
+                const int r = r0 + u, kk = u;
+                const size_t ri = inst0 + (r0 >> 5);
+                const int i0 = __builtin_amdgcn_readlane(idx, r);
+                const int len = c.len[kk];
                 int pos = i0 + lane;
-                while (pos >= len) pos -= len;
-                s.rings[ri * c.ring_stride + (size_t)c.off[kk] + (size_t)pos] = tile[r * TS + lane];
+                pos = pos >= len ? pos - len : pos;
+                if (ri < V && lane < size) s.rings[ri * c.ring_stride + (size_t)c.off[kk] + (size_t)pos] = xr[u];
             }
         }
 #pragma unroll
