@@ -25,5 +25,18 @@ void register_leaf_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<WaveSynth<2>>("triangle"));
     out.push_back(make_kind<AdsrLive>("adsr_live"));
     out.push_back(make_kind<Panner>("pan"));
+    out.push_back(make_kind<Shaper>("shape"));
+    out.push_back(make_kind<PhaseOsc<OSC_RAMP>>("ramp"));
+    out.push_back(make_kind<PhaseOsc<OSC_POLYSAW>>("poly_saw"));
+    out.push_back(make_kind<PhaseOsc<OSC_POLYSQUARE>>("poly_square"));
+    out.push_back(make_kind<PhaseOsc<OSC_POLYPULSE>>("poly_pulse"));
+    out.push_back(make_kind<Chaos<false>>("rossler"));
+    out.push_back(make_kind<Chaos<true>>("lorenz"));
+    out.push_back(make_kind<NlBiquad<false, 1>>("fbiquad_hz"));
+    out.push_back(make_kind<NlBiquad<true, 1>>("dbiquad_hz"));
+    out.push_back(make_kind<NlBiquad<false, 3>>("fbiquad3"));
+    out.push_back(make_kind<NlBiquad<false, 4>>("fbiquad4"));
+    out.push_back(make_kind<NlBiquad<true, 3>>("dbiquad3"));
+    out.push_back(make_kind<NlBiquad<true, 4>>("dbiquad4"));
 }
 }  // namespace fd

@@ -238,6 +238,74 @@ FD_HD float tanhf_musl(float x0) {
     return sign ? -r : r;
 }
 
+// musl atanf.c (FreeBSD s_atanf.c), case selection by selects
+FD_HD float atanf_musl(float x0) {
+    constexpr float aT0 = 3.3333328366e-01f, aT1 = -1.9999158382e-01f, aT2 = 1.4253635705e-01f,
+                    aT3 = -1.0648017377e-01f, aT4 = 6.1687607318e-02f;
+    uint32_t ix = f2u(x0);
+    const bool sign = (ix >> 31) != 0;
+    ix &= 0x7fffffffu;
+    if (__builtin_expect(ix >= 0x4c800000u, 0)) {  // |x| >= 2**26
+        if (ix > 0x7f800000u) return x0;
+        float z = 1.5707962513e+00f + 0x1p-120f;
+        return sign ? -z : z;
+    }
+    const bool small = ix < 0x3ee00000u;  // |x| < 0.4375: no reduction
+    const bool tiny = ix < 0x39800000u;   // |x| < 2**-12
+    const float ax = __builtin_fabsf(x0);
+    int id;
+    float num, den;
+    if (ix < 0x3f980000u) {      // |x| < 1.1875
+        if (ix < 0x3f300000u) {  //  7/16 <= |x| < 11/16
+            id = 0; num = 2.0f * ax - 1.0f; den = 2.0f + ax;
+        } else {                 // 11/16 <= |x| < 19/16
+            id = 1; num = ax - 1.0f; den = ax + 1.0f;
+        }
+    } else {
+        if (ix < 0x401c0000u) {  // |x| < 2.4375
+            id = 2; num = ax - 1.5f; den = 1.0f + 1.5f * ax;
+        } else {                 // 2.4375 <= |x| < 2**26
+            id = 3; num = -1.0f; den = ax;
+        }
+    }
+    const float x = small ? x0 : num / den;
+    const float z = x * x, w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * aT4));
+    const float s2 = w * (aT1 + w * aT3);
+    const float hi = id == 0 ? 4.6364760399e-01f : id == 1 ? 7.8539812565e-01f : id == 2 ? 9.8279368877e-01f : 1.5707962513e+00f;
+    const float lo = id == 0 ? 5.0121582440e-09f : id == 1 ? 3.7748947079e-08f : id == 2 ? 3.4473217170e-08f : 7.5497894159e-08f;
+    const float r_small = x - x * (s1 + s2);
+    const float zz = hi - ((x * (s1 + s2) - lo) - x);
+    const float r_red = sign ? -zz : zz;
+    const float r = small ? r_small : r_red;
+    return tiny ? x0 : r;
+}
+
+// wide f32x8::atan, one lane (vectorclass atan_f): octant selection + degree-3 polynomial in z^2, unfused
+FD_HD float wide_atanf(float self) {
+    constexpr float P3 = 8.05374449538E-2f, P2 = -1.38776856032E-1f, P1 = 1.99777106478E-1f, P0 = -3.33329491539E-1f;
+    constexpr float SQRT2 = 1.41421356237309504880f, FRAC_PI_2 = 1.57079632679489661923f, FRAC_PI_4 = 0.785398163397448309616f;
+    float t = __builtin_fabsf(self);
+    bool notsmal = t >= SQRT2 - 1.0f;
+    bool notbig = t <= SQRT2 + 1.0f;
+    float s = notbig ? FRAC_PI_4 : FRAC_PI_2;
+    s = notsmal ? s : 0.0f;
+    float a = notbig ? t : 0.0f;
+    a = notsmal ? a - 1.0f : a;
+    float b = notbig ? 1.0f : 0.0f;
+    b = notsmal ? b + t : b;
+    float z = a / b;
+    float zz = z * z;
+    // polynomial_3!(zz, P0, P1, P2, P3) = (P2 + P3*zz)*zz^2 + (P1*zz + P0)
+    float z4 = zz * zz;
+    float re = (zz * P3 + P2) * z4 + (zz * P1 + P0);
+    re = re * (zz * z) + z + s;
+    return (f2u(self) >> 31) ? -re : re;
+}
+
+// libm roundf (half away from zero) -- musl roundf.c semantics
+FD_HD float roundf_musl(float x) { return __builtin_roundf(x); }
+
 // libm 0.2 scalbnf for the normal range used by expf (|k| small)
 FD_HD float scalbnf_small(float y, int k) { return y * u2f((uint32_t)(0x7f + k) << 23); }
 

@@ -968,6 +968,252 @@ struct Panner {
 };
 
 // ---------------------------------------------------------------------------------------------------------
+// waveshapers (shape.rs:11-201) -- the shape KIND is a per-voice parameter (one kernel for all shapes)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SH_CLIP = 0, SH_CLIPTO = 1, SH_TANH = 2, SH_ATAN = 3, SH_SOFTSIGN = 4, SH_CRUSH = 5, SH_SOFTCRUSH = 6,
+              SH_ADAPTIVE_TANH = 7;
+
+FD_HD float smooth9f(float x) {  // math.rs:431-437
+    float x2 = x * x;
+    return ((((70.0f * x - 315.0f) * x + 540.0f) * x - 420.0f) * x + 126.0f) * x2 * x2 * x;
+}
+FD_HD float rs_clamp(float lo, float hi, float x) {  // math.rs:130-132: x.max(lo).min(hi)
+    x = x > lo ? x : lo;  // f32::max / min (NaN-free inputs assumed equivalent)
+    return x < hi ? x : hi;
+}
+
+struct Shape {
+    float kind, p0, p1;        // params: Clip(p0) ClipTo(p0,p1) Tanh(p0) Atan(p0) Softsign(p0) Crush(p0) SoftCrush(p0) Adaptive(timescale=p1, Tanh(p0))
+    float smoothing, state;    // Adaptive only: smoothing is a host-computed coefficient (f64 pow, shape.rs:197-200)
+    template <class V> FD_HD void visit(V& v) {
+        v.f(kind, PARAM, "shape"); v.f(p0, PARAM, "shape_p0"); v.f(p1, PARAM, "shape_p1");
+        v.f(smoothing, PARAM, "shape_smoothing");
+        v.f(state, STATE, "shape_state");
+    }
+    FD_HD void init() { kind = (float)SH_TANH; p0 = 1.0f; p1 = 0.0f; smoothing = 0.0f; state = 0.0f; }  // Adaptive::new: state 0.0
+    FD_HD void reset() { if ((int)kind == SH_ADAPTIVE_TANH) state = 1.0e-3f; }                            // shape.rs:193-196
+    // Shape::shape (scalar path)
+    FD_HD float shape(float input) {
+        switch ((int)kind) {
+        case SH_CLIP: return rs_clamp(-1.0f, 1.0f, input * p0);                                  // :48-51
+        case SH_CLIPTO: return rs_clamp(p0, p1, input);                                           // :64-67
+        case SH_TANH: return tanhf_musl(input * p0);                                              // :82-85
+        case SH_ATAN: return atanf_musl(input * (p0 * F32_PI * 0.5f)) * (2.0f / F32_PI);          // :93-96
+        case SH_SOFTSIGN: { float x = input * p0; return x / (1.0f + __builtin_fabsf(x)); }      // :109-112, math.rs:386
+        case SH_CRUSH: return roundf_musl(input * p0) / p0;                                       // :125-128
+        case SH_SOFTCRUSH: { float x = input * p0; float y = __builtin_floorf(x); return (y + smooth9f(x - y)) / p0; }  // :141-146
+        default: {                                                                                // Adaptive<Tanh> :185-192
+            state = smoothing * state + (1.0f - smoothing) * (1.0e-6f + input * input);
+            return tanhf_musl((input / __builtin_sqrtf(state)) * p0);
+        }
+        }
+    }
+    // Shape::simd, one lane (the f32x8 path of Shaper::process)
+    FD_HD float simd(float input) {
+        switch ((int)kind) {
+        case SH_ATAN: return wide_atanf(input * (p0 * F32_PI * 0.5f)) * (2.0f / F32_PI);          // :98-100
+        case SH_SOFTSIGN: return input * p0 / (1.0f + __builtin_fabsf(input) * p0);               // :114-116
+        case SH_CRUSH: return __builtin_rintf(input * p0) / p0;                                   // :130-132 (wide round: half to even)
+        case SH_SOFTCRUSH: {                                                                      // :148-152, vector floor lib.rs:326-328
+            float x = input * p0;
+            float y = __builtin_rintf(x - 0.4999999f);
+            return (y + smooth9f(x - y)) / p0;
+        }
+        default: return shape(input);  // Clip / ClipTo: fast_max/fast_min == clamp for non-NaN; Tanh, Adaptive: per-lane shape()
+        }
+    }
+};
+
+// Shaper<S>  shape.rs:205-247 (ID 42)
+struct Shaper {
+    static constexpr int IN = 1, OUT = 1;
+    static constexpr uint64_t ID = 42;
+    Shape sh;
+    template <class V> FD_HD void visit(V& v) { sh.visit(v); }
+    FD_HD void bind(const void*) {}
+    FD_HD void init() { sh.init(); }
+    FD_HD void update(double) {}
+    FD_HD void reset() { sh.reset(); }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        out[0] = PH == PH_SIMD ? sh.simd(in[0]) : sh.shape(in[0]);
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// phase oscillators without a process override: Ramp, PolySaw, PolySquare, PolyPulse (oscillator.rs:441-760)
+// ---------------------------------------------------------------------------------------------------------
+FD_HD float polyblep(float t, float dt) {  // oscillator.rs:512-523
+    if (t < dt) {
+        float z = t / dt;
+        return z + z - z * z - 1.0f;
+    } else if (t > 1.0f - dt) {
+        float z = (t - 1.0f) / dt;
+        return z + z + z * z + 1.0f;
+    }
+    return 0.0f;
+}
+
+constexpr int OSC_RAMP = 0, OSC_POLYSAW = 1, OSC_POLYSQUARE = 2, OSC_POLYPULSE = 3;
+template <int KIND>
+struct PhaseOsc {
+    static constexpr int IN = KIND == OSC_POLYPULSE ? 2 : 1, OUT = 1;
+    static constexpr uint64_t ID = KIND == OSC_RAMP ? 94 : KIND == OSC_POLYSAW ? 95 : KIND == OSC_POLYSQUARE ? 96 : 97;
+    float phase, sample_duration, has_phase, initial_phase;
+    uint64_t hash;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(phase, STATE, "phase");
+        v.f(sample_duration, COEF, "sample_duration");
+        v.f(has_phase, PARAM, "has_initial_phase");
+        v.f(initial_phase, PARAM, "initial_phase");
+        v.u64(hash, STATE, "hash");
+    }
+    FD_HD void bind(const void*) {}
+    FD_HD void init() { has_phase = 0.0f; initial_phase = 0.0f; hash = 0; reset(); }
+    FD_HD void update(double sr) { sample_duration = (float)(1.0 / sr); }
+    FD_HD void reset() { phase = has_phase != 0.0f ? initial_phase : (float)rnd1(hash); }
+    FD_HD uint64_t ping(bool probe, uint64_t h) {
+        if (!probe) { hash = h; reset(); }
+        return atto(h, ID);
+    }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        const float ph = phase;
+        const float delta = in[0] * sample_duration;
+        phase += delta;
+        phase -= __builtin_floorf(phase);
+        if (KIND == OSC_RAMP) {  // :478-483
+            out[0] = ph;
+        } else if (KIND == OSC_POLYSAW) {  // :570-577
+            out[0] = 2.0f * ph - 1.0f - polyblep(ph, delta);
+        } else {  // PolySquare :646-659 (width 0.5) / PolyPulse :729-739 (width = input 1)
+            const float width = KIND == OSC_POLYPULSE ? in[IN - 1] : 0.5f;
+            const float square = ph < width ? 1.0f : -1.0f;
+            const float half = ph - width;
+            out[0] = square + polyblep(ph, delta) - polyblep(half - __builtin_floorf(half), delta);
+        }
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// Rossler (oscillator.rs:323-375, ID 73) and Lorenz (:382-435, ID 74) attractors, explicit Euler
+template <bool LORENZ>
+struct Chaos {
+    static constexpr int IN = 1, OUT = 1;
+    static constexpr uint64_t ID = LORENZ ? 74 : 73;
+    float x, y, z, sr;
+    uint64_t hash;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(x, STATE, "x"); v.f(y, STATE, "y"); v.f(z, STATE, "z");
+        v.f(sr, COEF, "sample_rate");
+        v.u64(hash, STATE, "hash");
+    }
+    FD_HD void bind(const void*) {}
+    FD_HD void init() { hash = 0; reset(); }
+    FD_HD void update(double sample_rate) { sr = (float)sample_rate; }
+    FD_HD void reset() {  // lerp(0.0, 1.0, rnd1(hash) as f32)
+        float t = (float)rnd1(hash);
+        x = 0.0f * (1.0f - t) + 1.0f * t;
+        y = 1.0f;
+        z = 1.0f;
+    }
+    FD_HD uint64_t ping(bool probe, uint64_t h) {
+        if (!probe) { hash = h; reset(); }
+        return atto(h, ID);
+    }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        if (LORENZ) {  // :407-417
+            float dx = 10.0f * (y - x);
+            float dy = x * (28.0f - z) - y;
+            float dz = x * y - (8.0f / 3.0f) * z;
+            float dt = in[0] / sr;
+            x += dx * dt; y += dy * dt; z += dz * dt;
+            out[0] = x * 0.05107f;
+        } else {  // :348-358
+            float dx = -y - z;
+            float dy = x + 0.15f * y;
+            float dz = 0.2f + z * (x - 10.0f);
+            float dt = 2.91f * in[0] / sr;
+            x += dx * dt; y += dy * dt; z += dz * dt;
+            out[0] = x * 0.05757f;
+        }
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// biquads with nonlinear feedback / state shaping (biquad.rs:494-920): FbBiquad (ID 88), FixedFbBiquad (ID 90),
+// DirtyBiquad (ID 89), FixedDirtyBiquad (ID 91).  Mode (resonator/lowpass/highpass/bell) and shape are per voice.
+// NIN = 1: fixed; NIN = 3: (audio, center, q); NIN = 4: (audio, center, q, gain).
+// ---------------------------------------------------------------------------------------------------------
+template <bool DIRTY, int NIN>
+struct NlBiquad {
+    static constexpr int IN = NIN, OUT = 1;
+    static constexpr uint64_t ID = DIRTY ? (NIN == 1 ? 91 : 89) : (NIN == 1 ? 90 : 88);
+    float mode, center, q, gain, sr;
+    float a1, a2, b0, b1, b2, s1, s2;
+    Shape sh1, sh2;
+    template <class V> FD_HD void visit(V& v) {
+        constexpr FieldKind PK = NIN > 1 ? STATE : PARAM, CK = NIN > 1 ? STATE : COEF;
+        v.f(mode, PARAM, "mode");
+        v.f(center, PK, "center"); v.f(q, PK, "q"); v.f(gain, PK, "gain");
+        v.f(sr, COEF, "sample_rate");
+        v.f(a1, CK, "a1"); v.f(a2, CK, "a2"); v.f(b0, CK, "b0"); v.f(b1, CK, "b1"); v.f(b2, CK, "b2");
+        v.f(s1, STATE, "s1"); v.f(s2, STATE, "s2");
+        v.enter(0); sh1.visit(v); v.leave();
+        if (DIRTY) { v.enter(1); sh2.visit(v); v.leave(); }
+    }
+    FD_HD void bind(const void*) {}
+    FD_HD void coefs() {  // BiquadMode::update :404-490 (kinds: BQ_RESONATOR/LOWPASS/HIGHPASS/BELL)
+        BiquadCoefs c = biquad_coefs((int)mode, sr, center, q, gain);
+        a1 = c.a1; a2 = c.a2; b0 = c.b0; b1 = c.b1; b2 = c.b2;
+    }
+    FD_HD void init() {  // ::new :505-521: center 440, q 1, gain 1
+        mode = (float)BQ_LOWPASS; center = 440.0f; q = 1.0f; gain = 1.0f; s1 = 0.0f; s2 = 0.0f;
+        sh1.init(); sh2.init();
+    }
+    FD_HD void update(double sample_rate) { sr = (float)sample_rate; coefs(); }
+    FD_HD void reset() { s1 = 0.0f; s2 = 0.0f; sh1.reset(); if (DIRTY) sh2.reset(); }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        if (NIN == 3) {  // :549-557: squared-difference change detection
+            float dc = in[1] - center, dq = in[2] - q;
+            if (dc * dc + dq * dq != 0.0f) { center = in[1]; q = in[2]; coefs(); }
+        }
+        if (NIN == 4) {  // :558-572
+            float dc = in[1] - center, dq = in[2] - q, dg = in[3] - gain;
+            if (dc * dc + dq * dq + dg * dg != 0.0f) { center = in[1]; q = in[2]; gain = in[3]; coefs(); }
+        }
+        const float x0 = in[0];
+        const float y0 = b0 * x0 + s1;
+        if (DIRTY) {  // :789-796
+            const float n1 = sh1.shape(s2 + b1 * x0 - y0 * a1);
+            const float n2 = sh2.shape(b2 * x0 - y0 * a2);
+            s1 = n1;
+            s2 = n2;
+        } else {  // :577-581
+            const float fb = sh1.shape(y0);
+            s1 = s2 + b1 * x0 - fb * a1;
+            s2 = b2 * x0 - fb * a2;
+        }
+        out[0] = y0;
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// ---------------------------------------------------------------------------------------------------------
 // combinators
 // ---------------------------------------------------------------------------------------------------------
 

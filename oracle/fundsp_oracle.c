@@ -89,6 +89,11 @@ struct onode {
         float attack_start, release_start, adsr_a, adsr_d, adsr_s, adsr_r;
         /* Panner (pan.rs:26-30) */
         float left_weight, right_weight;
+        /* Shape x2 (shape.rs), PhaseOsc kind, Chaos, nonlinear biquad (biquad.rs:494-920) */
+        struct { int kind; float p0, p1, smoothing, state; } sh[2];
+        int osc_kind, lorenz, nl_dirty, nl_mode;
+        float cx, cy, cz;
+        float ns1, ns2;
         /* reverb_stereo: 32 x (Delay >> Fir<U3>) inside Feedback<U32,_,FrameHadamard> (prelude.rs:1732-1762) */
         double rv_room, rv_time, rv_damping, rv_sr;
         float *rv_buf[32];
@@ -138,6 +143,10 @@ float o_math_tanhf(float x) { return o_tanhf(x); }
 float o_math_expf(float x) { return o_expf(x); }
 float o_math_expm1f(float x) { return o_expm1f(x); }
 float o_math_wide_sinf(float x) { return o_wide_sinf(x); }
+float o_math_atanf(float x) { return o_atanf(x); }
+float o_math_wide_atanf(float x) { return o_wide_atanf(x); }
+/* Adaptive::set_sample_rate shape.rs:197-200: pow(0.5, 1.0 / (timescale.to_f64() * sample_rate)).to_f32() as f64 value */
+double o_adaptive_smoothing(float timescale, double sample_rate) { return pow(0.5, 1.0 / ((double)timescale * sample_rate)); }
 double o_math_rnd1(uint64_t x) { return o_rnd1(x); }
 uint64_t o_math_hash1(uint64_t x) { return o_hash1(x); }
 uint64_t o_math_atto(uint64_t state, uint64_t data) { return o_atto(state, data); }
@@ -257,6 +266,15 @@ static bq_coefs bq_bell(float sr, float center, float q, float gain) {
     return c;
 }
 
+static bq_coefs bq_by_mode(int mode, float sr, float center, float q, float gain) { /* BiquadMode::update biquad.rs:404-490 */
+    switch (mode) {
+    case O_BQ_RESONATOR: return bq_resonator(sr, center, q);
+    case O_BQ_LOWPASS: return bq_lowpass(sr, center, q);
+    case O_BQ_HIGHPASS: return bq_highpass(sr, center, q);
+    default: return bq_bell(sr, center, q, gain);
+    }
+}
+
 void o_biquad_coefs(int kind, float sr, float f, float q, float gain, float *out5) {
     bq_coefs c;
     switch (kind) {
@@ -293,6 +311,55 @@ void o_moog_coefs(float sr, float cutoff, float q, float *out3) {
     moog_set_cutoff_q(&tmp, cutoff, q);
     out3[0] = tmp.s.rez; out3[1] = tmp.s.p; out3[2] = tmp.s.k;
 }
+
+/* ---- shapes (shape.rs:35-201) ---- */
+static float smooth9f(float x);
+static inline float rs_clampf(float lo, float hi, float x) { /* math.rs:130-132 */
+    x = x > lo ? x : lo;
+    return x < hi ? x : hi;
+}
+static float shape_scalar(onode *n, int which, float input) { /* Shape::shape */
+    float p0 = n->s.sh[which].p0, p1 = n->s.sh[which].p1;
+    switch (n->s.sh[which].kind) {
+    case O_SH_CLIP: return rs_clampf(-1.0f, 1.0f, input * p0);
+    case O_SH_CLIPTO: return rs_clampf(p0, p1, input);
+    case O_SH_TANH: return o_tanhf(input * p0);
+    case O_SH_ATAN: return o_atanf(input * (p0 * F32_PI * 0.5f)) * (2.0f / F32_PI);
+    case O_SH_SOFTSIGN: { float x = input * p0; return x / (1.0f + fabsf(x)); }
+    case O_SH_CRUSH: return roundf(input * p0) / p0;
+    case O_SH_SOFTCRUSH: { float x = input * p0; float y = floorf(x); return (y + smooth9f(x - y)) / p0; }
+    default: { /* Adaptive<Tanh> shape.rs:185-192 */
+        float sm = n->s.sh[which].smoothing;
+        n->s.sh[which].state = sm * n->s.sh[which].state + (1.0f - sm) * (1.0e-6f + input * input);
+        return o_tanhf((input / sqrtf(n->s.sh[which].state)) * p0);
+    }
+    }
+}
+static float shape_simd_lane(onode *n, int which, float input) { /* Shape::simd, one lane */
+    float p0 = n->s.sh[which].p0;
+    switch (n->s.sh[which].kind) {
+    case O_SH_ATAN: return o_wide_atanf(input * (p0 * F32_PI * 0.5f)) * (2.0f / F32_PI);
+    case O_SH_SOFTSIGN: return input * p0 / (1.0f + fabsf(input) * p0);
+    case O_SH_CRUSH: return nearbyintf(input * p0) / p0;            /* wide round: half to even */
+    case O_SH_SOFTCRUSH: {                                           /* Num::floor for f32x8: (x - 0.4999999).round() lib.rs:326 */
+        float x = input * p0;
+        float y = nearbyintf(x - 0.4999999f);
+        return (y + smooth9f(x - y)) / p0;
+    }
+    default: return shape_scalar(n, which, input);
+    }
+}
+static inline float polyblepf(float t, float dt) { /* oscillator.rs:512-523 */
+    if (t < dt) {
+        float z = t / dt;
+        return z + z - z * z - 1.0f;
+    } else if (t > 1.0f - dt) {
+        float z = (t - 1.0f) / dt;
+        return z + z + z * z + 1.0f;
+    }
+    return 0.0f;
+}
+static bq_coefs bq_by_mode(int mode, float sr, float center, float q, float gain);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* reset / set_sample_rate / set_hash / ping                                                              */
@@ -343,7 +410,23 @@ static void leaf_reset(onode *n) {
         }
         break;
     case O_WAVESYNTH: /* wavetable.rs:292-297 */
+    case O_PHASE_OSC: /* oscillator.rs:449-454 etc. */
         n->s.phase = n->s.has_initial_phase ? n->s.initial_phase : (float)o_rnd1(n->s.hash);
+        break;
+    case O_CHAOS: { /* oscillator.rs:337-341, 396-400: lerp(0.0, 1.0, rnd1(hash) as f32) */
+        float t = (float)o_rnd1(n->s.hash);
+        n->s.cx = 0.0f * (1.0f - t) + 1.0f * t;
+        n->s.cy = 1.0f;
+        n->s.cz = 1.0f;
+        break;
+    }
+    case O_SHAPER: /* Adaptive::reset shape.rs:193-196 */
+        if (n->s.sh[0].kind == O_SH_ADAPTIVE_TANH) n->s.sh[0].state = 1.0e-3f;
+        break;
+    case O_NLBIQUAD: /* biquad.rs:529-533, 750-755 */
+        n->s.ns1 = n->s.ns2 = 0.0f;
+        for (int i = 0; i < (n->s.nl_dirty ? 2 : 1); i++)
+            if (n->s.sh[i].kind == O_SH_ADAPTIVE_TANH) n->s.sh[i].state = 1.0e-3f;
         break;
     case O_ADSR_LIVE: /* envelope.rs:293-298: the closure state (attacked, start times) is NOT reset */
         n->s.et = 0.0f;
@@ -410,6 +493,21 @@ static void leaf_set_sample_rate(onode *n, double sr) {
     case O_ADSR_LIVE: /* envelope.rs:300-302 */
         n->s.esd = (float)(1.0 / sr);
         break;
+    case O_PHASE_OSC: /* oscillator.rs:456-458 */
+        n->s.sample_duration = (float)(1.0 / sr);
+        break;
+    case O_CHAOS:
+        n->s.sr = (float)sr;
+        break;
+    case O_SHAPER:
+        if (n->s.sh[0].kind == O_SH_ADAPTIVE_TANH) n->s.sh[0].smoothing = (float)o_adaptive_smoothing(n->s.sh[0].p1, sr);
+        break;
+    case O_NLBIQUAD: /* biquad.rs:535-538 */
+        n->s.sr = (float)sr;
+        n->s.bc = bq_by_mode(n->s.nl_mode, n->s.sr, n->s.center, n->s.q, n->s.gain);
+        for (int i = 0; i < 2; i++)
+            if (n->s.sh[i].kind == O_SH_ADAPTIVE_TANH) n->s.sh[i].smoothing = (float)o_adaptive_smoothing(n->s.sh[i].p1, sr);
+        break;
     case O_DELAY: /* delay.rs:105-113 */
         if (n->s.dsr != sr) {
             n->s.dsr = sr;
@@ -432,7 +530,7 @@ void o_set_sample_rate(onode *n, double sr) {
 
 /* AudioNode::set_hash (oscillator.rs:94-97, noise.rs:226-229); default is a no-op (audionode.rs:136-139) */
 static void leaf_set_hash(onode *n, uint64_t hash) {
-    if (n->type == O_SINE || n->type == O_NOISE || n->type == O_WAVESYNTH) {
+    if (n->type == O_SINE || n->type == O_NOISE || n->type == O_WAVESYNTH || n->type == O_PHASE_OSC || n->type == O_CHAOS) {
         n->s.hash = hash;
         leaf_reset(n);
     } else if (n->type == O_ADSR_LIVE) { /* envelope.rs:346-349: no reset */
@@ -648,6 +746,46 @@ static void pan_weights(float value, float *l, float *r) { /* pan.rs:13-17 */
 onode *o_panner(int inputs, float pan) { /* Panner::new pan.rs:33-40, ID 49 */
     onode *n = o_new(O_PANNER, inputs, 2, 49);
     pan_weights(pan, &n->s.left_weight, &n->s.right_weight);
+    return n;
+}
+
+onode *o_shaper(int shape, float p0, float p1) { /* Shaper::new shape.rs:209-215, ID 42 */
+    onode *n = o_new(O_SHAPER, 1, 1, 42);
+    n->s.sh[0].kind = shape; n->s.sh[0].p0 = p0; n->s.sh[0].p1 = p1; n->s.sh[0].state = 0.0f;
+    leaf_set_sample_rate(n, DEFAULT_SR);
+    return n;
+}
+onode *o_phase_osc(int kind) { /* Ramp::new :453 / PolySaw::new :537 / PolySquare::new :613 / PolyPulse::new :696 */
+    static const uint64_t ids[4] = {94, 95, 96, 97};
+    onode *n = o_new(O_PHASE_OSC, kind == O_OSC_POLYPULSE ? 2 : 1, 1, ids[kind]);
+    n->s.osc_kind = kind;
+    leaf_reset(n);
+    leaf_set_sample_rate(n, DEFAULT_SR);
+    return n;
+}
+void o_osc_set_phase(onode *n, float phase) {
+    n->s.has_initial_phase = 1;
+    n->s.initial_phase = phase;
+    leaf_reset(n);
+}
+onode *o_chaos(int lorenz) { /* Rossler::new :331 (ID 73) / Lorenz::new :390 (ID 74) */
+    onode *n = o_new(O_CHAOS, 1, 1, lorenz ? 74 : 73);
+    n->s.lorenz = lorenz;
+    leaf_reset(n);
+    leaf_set_sample_rate(n, DEFAULT_SR);
+    return n;
+}
+/* FbBiquad::new :505 (ID 88) / FixedFbBiquad::new :603 (ID 90) / DirtyBiquad::new :712 (ID 89) /
+ * FixedDirtyBiquad::new :819 (ID 91), then set_center_q(_gain) like the prelude constructors (prelude.rs:2912-3100) */
+onode *o_nlbiquad(int dirty, int inputs, int mode, int shape, float p0, float p1, float center, float q, float gain) {
+    uint64_t id = dirty ? (inputs == 1 ? 91 : 89) : (inputs == 1 ? 90 : 88);
+    onode *n = o_new(O_NLBIQUAD, inputs, 1, id);
+    n->s.nl_dirty = dirty;
+    n->s.nl_mode = mode;
+    for (int i = 0; i < 2; i++) { n->s.sh[i].kind = shape; n->s.sh[i].p0 = p0; n->s.sh[i].p1 = p1; n->s.sh[i].state = 0.0f; }
+    n->s.center = center; n->s.q = q; n->s.gain = gain;
+    n->s.ns1 = n->s.ns2 = 0.0f;
+    leaf_set_sample_rate(n, DEFAULT_SR);
     return n;
 }
 
@@ -981,6 +1119,71 @@ void o_tick(onode *n, const float *in, float *out) {
         n->s.ev += n->s.evd;
         n->s.et += n->s.esd;
         break;
+    case O_SHAPER: out[0] = shape_scalar(n, 0, in[0]); break; /* shape.rs:226-229 */
+    case O_PHASE_OSC: {
+        float phase = n->s.phase;
+        float delta = in[0] * n->s.sample_duration;
+        n->s.phase += delta;
+        n->s.phase -= floorf(n->s.phase);
+        if (n->s.osc_kind == O_OSC_RAMP) { /* :478-483 */
+            out[0] = phase;
+        } else if (n->s.osc_kind == O_OSC_POLYSAW) { /* :570-577 */
+            out[0] = 2.0f * phase - 1.0f - polyblepf(phase, delta);
+        } else { /* :646-659 / :729-739 */
+            float width = n->s.osc_kind == O_OSC_POLYPULSE ? in[1] : 0.5f;
+            float square = phase < width ? 1.0f : -1.0f;
+            float half = phase - width;
+            out[0] = square + polyblepf(phase, delta) - polyblepf(half - floorf(half), delta);
+        }
+        break;
+    }
+    case O_CHAOS:
+        if (n->s.lorenz) { /* oscillator.rs:407-417 */
+            float dx = 10.0f * (n->s.cy - n->s.cx);
+            float dy = n->s.cx * (28.0f - n->s.cz) - n->s.cy;
+            float dz = n->s.cx * n->s.cy - (8.0f / 3.0f) * n->s.cz;
+            float dt = in[0] / n->s.sr;
+            n->s.cx += dx * dt; n->s.cy += dy * dt; n->s.cz += dz * dt;
+            out[0] = n->s.cx * 0.05107f;
+        } else { /* oscillator.rs:348-358 */
+            float dx = -n->s.cy - n->s.cz;
+            float dy = n->s.cx + 0.15f * n->s.cy;
+            float dz = 0.2f + n->s.cz * (n->s.cx - 10.0f);
+            float dt = 2.91f * in[0] / n->s.sr;
+            n->s.cx += dx * dt; n->s.cy += dy * dt; n->s.cz += dz * dt;
+            out[0] = n->s.cx * 0.05757f;
+        }
+        break;
+    case O_NLBIQUAD: {
+        if (n->nin == 3) { /* biquad.rs:549-557 */
+            float dc = in[1] - n->s.center, dq = in[2] - n->s.q;
+            if (dc * dc + dq * dq != 0.0f) {
+                n->s.center = in[1]; n->s.q = in[2];
+                n->s.bc = bq_by_mode(n->s.nl_mode, n->s.sr, n->s.center, n->s.q, n->s.gain);
+            }
+        }
+        if (n->nin == 4) { /* biquad.rs:558-572 */
+            float dc = in[1] - n->s.center, dq = in[2] - n->s.q, dg = in[3] - n->s.gain;
+            if (dc * dc + dq * dq + dg * dg != 0.0f) {
+                n->s.center = in[1]; n->s.q = in[2]; n->s.gain = in[3];
+                n->s.bc = bq_by_mode(n->s.nl_mode, n->s.sr, n->s.center, n->s.q, n->s.gain);
+            }
+        }
+        float x0 = in[0];
+        float y0 = n->s.bc.b0 * x0 + n->s.ns1;
+        if (n->s.nl_dirty) { /* biquad.rs:789-796 */
+            float n1 = shape_scalar(n, 0, n->s.ns2 + n->s.bc.b1 * x0 - y0 * n->s.bc.a1);
+            float n2 = shape_scalar(n, 1, n->s.bc.b2 * x0 - y0 * n->s.bc.a2);
+            n->s.ns1 = n1;
+            n->s.ns2 = n2;
+        } else { /* biquad.rs:577-581 */
+            float fb = shape_scalar(n, 0, y0);
+            n->s.ns1 = n->s.ns2 + n->s.bc.b1 * x0 - fb * n->s.bc.a1;
+            n->s.ns2 = n->s.bc.b2 * x0 - fb * n->s.bc.a2;
+        }
+        out[0] = y0;
+        break;
+    }
     case O_REVERB_STEREO: {
         /* Feedback::new calls prevent_denormals() (feedback.rs:96; denormal.rs:18: MXCSR = 0x9fc0, FTZ + DAZ) on the
          * constructing thread, so a graph rendered on that thread runs flushed: do the same for this node. */
@@ -1149,6 +1352,10 @@ void o_process(onode *n, int size, const float *in, float *out) {
         process_remainder(n, size, in, out);
         break;
     }
+    case O_SHAPER: /* shape.rs:235-240: Shape::simd on full items, tick for the remainder */
+        for (int i = 0; i < full_simd_items(size) * 8; i++) out[i] = shape_simd_lane(n, 0, in[i]);
+        process_remainder(n, size, in, out);
+        break;
     case O_ADSR_LIVE: { /* envelope.rs:315-340: whole-block segment walk (no remainder path) */
         if (size == 0) break;
         if (n->s.et >= n->s.et1) env_next_segment(n, in[0]);

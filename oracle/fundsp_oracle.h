@@ -17,8 +17,10 @@ typedef struct onode onode;
 enum {
     O_CONSTANT = 0, O_PASS, O_SINE, O_NOISE, O_SVF, O_FIXED_SVF, O_BIQUAD, O_BUTTER_LOWPASS, O_RESONATOR,
     O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP,
-    O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO
+    O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO, O_SHAPER, O_PHASE_OSC, O_CHAOS, O_NLBIQUAD
 };
+enum { O_SH_CLIP = 0, O_SH_CLIPTO, O_SH_TANH, O_SH_ATAN, O_SH_SOFTSIGN, O_SH_CRUSH, O_SH_SOFTCRUSH, O_SH_ADAPTIVE_TANH };
+enum { O_OSC_RAMP = 0, O_OSC_POLYSAW, O_OSC_POLYSQUARE, O_OSC_POLYPULSE };
 /* SvfMode order follows src/svf.rs:281-742 */
 enum {
     O_SVF_LOWPASS = 0, O_SVF_HIGHPASS, O_SVF_BANDPASS, O_SVF_NOTCH, O_SVF_PEAK, O_SVF_ALLPASS,
@@ -52,6 +54,16 @@ onode *o_wavesynth(const owavetable *table, int outputs);
 void o_wavesynth_set_phase(onode *n, float phase);
 onode *o_adsr_live(float attack, float decay, float sustain, float release);
 onode *o_panner(int inputs, float pan);
+/* Shaper<S> (shape.rs:205); for O_SH_ADAPTIVE_TANH p0 = hardness, p1 = timescale */
+onode *o_shaper(int shape, float p0, float p1);
+onode *o_phase_osc(int kind);                       /* Ramp / PolySaw / PolySquare / PolyPulse (oscillator.rs:441-760) */
+void o_osc_set_phase(onode *n, float phase);
+onode *o_chaos(int lorenz);                         /* Rossler / Lorenz (oscillator.rs:323-435) */
+/* FbBiquad / DirtyBiquad and their Fixed variants (biquad.rs:494-920): mode = O_BQ_RESONATOR..O_BQ_BELL, inputs 1/3/4 */
+onode *o_nlbiquad(int dirty, int inputs, int mode, int shape, float p0, float p1, float center, float q, float gain);
+float o_math_atanf(float x);
+float o_math_wide_atanf(float x);
+double o_adaptive_smoothing(float timescale, double sample_rate);
 /* reverb_stereo(room_size, time, damping): 32-line FDN (prelude.rs:1732-1762). */
 onode *o_reverb_stereo(double room_size, double time, double damping);
 /* derived constants of reverb_stereo at `sample_rate`: FIR weights (3), delay lengths in samples (32), pan weights (32+32) */

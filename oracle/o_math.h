@@ -311,6 +311,75 @@ static inline float o_tanhf(float x) {
     return sign ? -t : t;
 }
 
+/* musl atanf.c (FreeBSD s_atanf.c) */
+static inline float o_atanf(float x) {
+    static const float atanhi[] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    static const float atanlo[] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    static const float aT[] = {3.3333328366e-01f, -1.9999158382e-01f, 1.4253635705e-01f, -1.0648017377e-01f, 6.1687607318e-02f};
+    float w, s1, s2, z;
+    uint32_t ix = o_f2u(x), sign = ix >> 31;
+    int id;
+    ix &= 0x7fffffff;
+    if (ix >= 0x4c800000) { /* if |x| >= 2**26 */
+        if (ix > 0x7f800000) return x;
+        z = atanhi[3] + 0x1p-120f;
+        return sign ? -z : z;
+    }
+    if (ix < 0x3ee00000) {     /* |x| < 0.4375 */
+        if (ix < 0x39800000) { /* |x| < 2**-12 */
+            return x;
+        }
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {     /* |x| < 1.1875 */
+            if (ix < 0x3f300000) { /*  7/16 <= |x| < 11/16 */
+                id = 0;
+                x = (2.0f * x - 1.0f) / (2.0f + x);
+            } else { /* 11/16 <= |x| < 19/16 */
+                id = 1;
+                x = (x - 1.0f) / (x + 1.0f);
+            }
+        } else {
+            if (ix < 0x401c0000) { /* |x| < 2.4375 */
+                id = 2;
+                x = (x - 1.5f) / (1.0f + 1.5f * x);
+            } else { /* 2.4375 <= |x| < 2**26 */
+                id = 3;
+                x = -1.0f / x;
+            }
+        }
+    }
+    z = x * x;
+    w = z * z;
+    s1 = z * (aT[0] + w * (aT[2] + w * aT[4]));
+    s2 = w * (aT[1] + w * aT[3]);
+    if (id < 0) return x - x * (s1 + s2);
+    z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return sign ? -z : z;
+}
+
+/* wide 1.1.1 f32x8::atan, one lane (vectorclass atan_f), unfused */
+static inline float o_wide_atanf(float self) {
+    const float P3 = 8.05374449538E-2f, P2 = -1.38776856032E-1f, P1 = 1.99777106478E-1f, P0 = -3.33329491539E-1f;
+    const float SQRT2 = 1.41421356237309504880f, FRAC_PI_2 = 1.57079632679489661923f, FRAC_PI_4 = 0.785398163397448309616f;
+    float t = fabsf(self);
+    int notsmal = t >= SQRT2 - 1.0f;
+    int notbig = t <= SQRT2 + 1.0f;
+    float s = notbig ? FRAC_PI_4 : FRAC_PI_2;
+    s = notsmal ? s : 0.0f;
+    float a = notbig ? t : 0.0f;
+    a = notsmal ? a - 1.0f : a;
+    float b = notbig ? 1.0f : 0.0f;
+    b = notsmal ? b + t : b;
+    float z = a / b;
+    float zz = z * z;
+    float z4 = zz * zz;
+    float re = (zz * P3 + P2) * z4 + (zz * P1 + P0); /* polynomial_3!(zz, P0, P1, P2, P3) */
+    re = re * (zz * z) + z + s;
+    return (o_f2u(self) >> 31) ? -re : re;
+}
+
 /* musl expf.c as of the 2018 port (FreeBSD e_expf.c; libm 0.2 expf.rs) */
 static inline float o_expf(float x) {
     static const float half[2] = {0.5f, -0.5f}, ln2hi = 6.9314575195e-1f, /* 0x3f317200 */

@@ -72,6 +72,9 @@ def lib():
         "o_wavetable_create": (P, [i, fp, C.POINTER(C.c_int), fp]), "o_wavetable_free": (None, [P]),
         "o_wavesynth": (P, [P, i]), "o_wavesynth_set_phase": (None, [P, f]),
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
+        "o_shaper": (P, [i, f, f]), "o_phase_osc": (P, [i]), "o_osc_set_phase": (None, [P, f]), "o_chaos": (P, [i]),
+        "o_nlbiquad": (P, [i, i, i, i, f, f, f, f, f]), "o_math_atanf": (f, [f]), "o_math_wide_atanf": (f, [f]),
+        "o_adaptive_smoothing": (d, [f, d]),
         "o_reverb_stereo": (P, [d, d, d]),
         "o_reverb_stereo_params": (None, [d, d, d, d, fp, C.POINTER(C.c_int), fp, fp]),
     }
@@ -288,6 +291,24 @@ def triangle(): return wavesynth("triangle")
 def saw_hz(f): return constant(f) >> saw()
 def adsr_live(a, d, s, r): return Node(lib().o_adsr_live(a, d, s, r))  # adsr.rs:21
 def pan(p): return Node(lib().o_panner(1, p))                         # prelude.rs:1250
+
+
+SHAPES = dict(clip=0, clip_to=1, tanh=2, atan=3, softsign=4, crush=5, soft_crush=6, adaptive_tanh=7)
+OSCS = dict(ramp=0, poly_saw=1, poly_square=2, poly_pulse=3)
+
+
+def shape(kind, p0=1.0, p1=0.0): return Node(lib().o_shaper(SHAPES[kind], p0, p1))          # prelude.rs:1194
+def ramp(): return Node(lib().o_phase_osc(0))
+def poly_saw(): return Node(lib().o_phase_osc(1))
+def poly_square(): return Node(lib().o_phase_osc(2))
+def poly_pulse(): return Node(lib().o_phase_osc(3))
+def rossler(): return Node(lib().o_chaos(0))
+def lorenz(): return Node(lib().o_chaos(1))
+
+
+def nlbiquad(dirty, inputs, mode, shape_kind, p0=1.0, p1=0.0, center=440.0, q=1.0, gain=1.0):
+    """dbell_hz(Tanh(1.0), 1000, 10, 2) == nlbiquad(True, 1, "bell", "tanh", 1.0, 0, 1000, 10, 2) etc. (prelude.rs:2912-3100)"""
+    return Node(lib().o_nlbiquad(int(dirty), inputs, BQ_KINDS[mode], SHAPES[shape_kind], p0, p1, center, q, gain))
 
 
 def reverb_stereo(room_size, time, damping): return Node(lib().o_reverb_stereo(room_size, time, damping))  # prelude.rs:1732

@@ -181,3 +181,43 @@ def test_pan_weights_exact():
     l = O.pan(-1.0).render_blocks(x)
     assert l[0, 0] == 1.0 and abs(l[1, 0]) < 1e-7
     assert np.array_equal(O.pan(5.0).render_blocks(x), O.pan(1.0).render_blocks(x))  # clamp11
+
+
+def test_nonlinear_biquads_and_polyblep_check_wave():
+    """tests/test_basic.rs:219-237: dbell_hz/dhighpass_hz/dresonator_hz/dlowpass_hz/fbell_hz/flowpass_hz/fresonator_hz/
+    fhighpass_hz with Tanh/Softsign/Atan/Clip shapes, ramp; :308-312 PolyBLEP oscillators."""
+    cases = [
+        lambda: O.noise() >> O.nlbiquad(True, 1, "bell", "tanh", 1.0, 0, 1000.0, 10.0, 2.0),
+        lambda: O.noise() >> O.nlbiquad(True, 1, "highpass", "softsign", 1.0, 0, 2000.0, 2.0),
+        lambda: O.noise() >> O.nlbiquad(True, 1, "resonator", "tanh", 0.5, 0, 1000.0, 10.0),
+        lambda: O.noise() >> O.nlbiquad(True, 1, "lowpass", "softsign", 0.5, 0, 2000.0, 2.0),
+        lambda: O.noise() >> O.nlbiquad(False, 1, "bell", "atan", 1.0, 0, 500.0, 50.0, 0.5),
+        lambda: O.noise() >> O.nlbiquad(False, 1, "lowpass", "clip", 1.0, 0, 2000.0, 2.0),
+        lambda: O.noise() >> O.nlbiquad(False, 1, "resonator", "atan", 0.5, 0, 500.0, 50.0),
+        lambda: O.noise() >> O.nlbiquad(False, 1, "highpass", "softsign", 0.2, 0, 2000.0, 2.0),
+        lambda: O.dc(440.0) >> O.ramp(),
+        lambda: O.dc(110.0) >> O.poly_saw(),
+        lambda: O.dc(220.0) >> O.poly_square(),
+        lambda: O.dc(220.0, 0.3) >> O.poly_pulse(),
+        lambda: O.noise() >> O.shape("tanh", 2.0),
+        lambda: O.noise() >> O.shape("atan", 1.0),      # Shaper::process uses wide atan, tick uses libm atanf
+        lambda: O.noise() >> O.shape("softsign", 3.0),
+        lambda: O.noise() >> O.shape("soft_crush", 4.0),
+    ]
+    for make in cases:
+        check_wave(make)
+
+
+def test_atan_restatements_and_polyblep_saw_shape():
+    L = O.lib()
+    xs = np.linspace(-40.0, 40.0, 20001).astype(np.float32)
+    ref = np.arctan(xs.astype(np.float64))
+    got = np.array([L.o_math_atanf(float(x)) for x in xs], dtype=np.float64)
+    ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+    assert np.max(np.abs(got - ref)[xs != 0] / ulp[xs != 0]) < 1.0          # musl atanf: < 1 ulp
+    gw = np.array([L.o_math_wide_atanf(float(x)) for x in xs], dtype=np.float64)
+    assert np.max(np.abs(gw - ref)) < 3e-7                                  # vectorclass atan_f
+    y = O.wave_render(48000.0, 0.1, O.dc(100.0) >> O.poly_saw())[0]
+    assert y.min() > -1.05 and y.max() < 1.05
+    d = np.diff(y)
+    assert np.sum(d < -1.0) in (9, 10, 11)                                  # ten downward resets in 0.1 s at 100 Hz
