@@ -28,6 +28,7 @@ SYMBOLS = {
     "fdsp_kind_slot_name": (_cs, [_i, _i]),
     "fdsp_kind_slot_kind": (_i, [_i, _i]),
     "fdsp_bank_create": (_i, [_cs, _sz, C.POINTER(_P)]),
+    "fdsp_bank_create_ring": (_i, [_cs, _sz, _sz, C.POINTER(_P)]),
     "fdsp_reverb_stereo_create": (_i, [_sz, _d, _d, _d, C.POINTER(_P)]),
     "fdsp_bank_destroy": (None, [_P]),
     "fdsp_bank_inputs": (_i, [_P]),

@@ -36,11 +36,11 @@ def _fptr(a):
 class Bank:
     """V voices of one compiled voice graph on the current HIP device."""
 
-    def __init__(self, kind, voices, _handle=None):
+    def __init__(self, kind, voices, _handle=None, ring_frames=0):
         self._h = C.c_void_p()
         self.kind = kind
         if _handle is None:
-            check(lib().fdsp_bank_create(kind.encode(), int(voices), C.byref(self._h)))
+            check(lib().fdsp_bank_create_ring(kind.encode(), int(voices), int(ring_frames), C.byref(self._h)))
         else:
             self._h = _handle
         self.voices = int(voices)

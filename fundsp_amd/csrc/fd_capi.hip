@@ -181,6 +181,8 @@ struct FdnBank {  // reverb_stereo banks (fd_fdn.hip): rings + per-line state in
 
 struct fdsp_bank {
     FdnBank* fdn = nullptr;
+    float* ring = nullptr;       // delay-ring memory [ring node][position][voice] for kinds with Delay / Tap nodes
+    uint32_t ring_cap = 0;       // positions per ring node
     const fd::KindOps* ops;
     size_t V, stride;
     int nslots;
@@ -304,6 +306,10 @@ int fdsp_kind_slot_kind(int kind, int slot) {
 }
 
 int fdsp_bank_create(const char* kind, size_t voices, fdsp_bank** out) {
+    return fdsp_bank_create_ring(kind, voices, 0, out);
+}
+
+int fdsp_bank_create_ring(const char* kind, size_t voices, size_t ring_frames, fdsp_bank** out) {
     if (!out) return fail(FDSP_EINVAL, "out is NULL");
     *out = nullptr;
     int k = fdsp_kind_by_name(kind);
@@ -334,8 +340,22 @@ int fdsp_bank_create(const char* kind, size_t voices, fdsp_bank** out) {
         delete b;
         return fail(FDSP_EDEVICE, "stream/event creation failed");
     }
+    if (b->ops->nrings > 0) {
+        if (ring_frames == 0 || ring_frames > 0x7fffffffu) {
+            fdsp_bank_destroy(b);
+            return fail(FDSP_EINVAL, "this kind contains delay lines: create it with fdsp_bank_create_ring(kind, voices, ring_frames)");
+        }
+        b->ring_cap = (uint32_t)ring_frames;
+        const size_t rbytes = (size_t)b->ops->nrings * ring_frames * b->stride * sizeof(float);
+        e = hipMalloc((void**)&b->ring, rbytes);
+        if (e != hipSuccess) {
+            fdsp_bank_destroy(b);
+            return fail(FDSP_ENOMEM, std::string("hipMalloc(ring): ") + hipGetErrorString(e));
+        }
+        hipMemsetAsync(b->ring, 0, rbytes, b->stream);
+    }
     hipMemsetAsync(b->slots, 0, bytes, b->stream);
-    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 0, b->sr, nullptr, device_aux(), b->stream);
+    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 0, b->sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
     e = hipStreamSynchronize(b->stream);
     if (e != hipSuccess) {
         fdsp_bank_destroy(b);
@@ -424,6 +444,7 @@ void fdsp_bank_destroy(fdsp_bank* b) {
         b->fdn = nullptr;
     }
     if (b->slots) hipFree(b->slots);
+    if (b->ring) hipFree(b->ring);
     hipEventDestroy(b->e0);
     hipEventDestroy(b->e1);
     if (b->stream) hipStreamDestroy(b->stream);
@@ -443,7 +464,7 @@ int fdsp_bank_set_sample_rate(fdsp_bank* b, double sr) {
         return fdn_configure(b, sr);
     }
     b->sr = sr;
-    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, sr, nullptr, device_aux(), b->stream);
+    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
 }
@@ -455,7 +476,7 @@ int fdsp_bank_reset(fdsp_bank* b) {
         HIPCHK(hipGetLastError());
         return FDSP_OK;
     }
-    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 2, b->sr, nullptr, device_aux(), b->stream);
+    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 2, b->sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
 }
@@ -474,7 +495,7 @@ int fdsp_bank_set_seed(fdsp_bank* b, const uint64_t* h_seeds, size_t first, size
             return fail(FDSP_EDEVICE, hipGetErrorString(e));
         }
     }
-    b->ops->lifecycle(b->slots, b->stride, first, count, 3, b->sr, d, device_aux(), b->stream);
+    b->ops->lifecycle(b->slots, b->stride, first, count, 3, b->sr, d, device_aux(), b->ring, b->ring_cap, b->stream);
     hipError_t e = hipStreamSynchronize(b->stream);
     if (d) hipFree(d);
     if (e != hipSuccess) return fail(FDSP_EDEVICE, hipGetErrorString(e));
@@ -505,7 +526,7 @@ int fdsp_bank_set_param(fdsp_bank* b, const char* name, const float* h_values, s
     if (count == 0) return FDSP_OK;
     if (int rc = set_words(b, s, h_values, first, count)) return rc;
     // re-derive coefficients like the reference setters do (idempotent for untouched voices)
-    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, device_aux(), b->stream);
+    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
 }
@@ -532,7 +553,7 @@ int fdsp_bank_set_param_u64(fdsp_bank* b, const char* name, const uint64_t* h_va
     }
     if (int rc = set_words(b, lo, wl.data(), first, count)) return rc;
     if (int rc = set_words(b, hi, wh.data(), first, count)) return rc;
-    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, device_aux(), b->stream);
+    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
 }
@@ -583,7 +604,7 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
     if (b->fdn)  // Feedback::process is the per-sample tick (feedback.rs:136-146): both modes are the same arithmetic
         fd::fdn_launch_render(b->fdn->c, b->fdn->st, b->V, d_in, d_out, frames, frame_stride, layout, s);
     else
-        b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, device_aux(), s);
+        b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, device_aux(), b->ring, b->ring_cap, s);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->e1, s));
     b->timed = true;

@@ -108,12 +108,14 @@ struct VDescribe {  // host only
 //     2 = reset, 3 = set_seed (seeds != null) or re-apply the construction hash (seeds == null)
 template <class G>
 __global__ __launch_bounds__(64) void k_lifecycle(float* slots, size_t stride, size_t first, size_t count, int op,
-                                                  double sr, const uint64_t* seeds, const void* aux) {
+                                                  double sr, const uint64_t* seeds, const void* aux, float* ring,
+                                                  uint32_t ring_cap) {
     size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= count) return;
     size_t v = first + i;
     G g;
-    g.bind(aux);
+    Ctx ctx{static_cast<const Aux*>(aux), ring + v, ring_cap, stride, 0};
+    g.bind(ctx);
     {
         VLoad ld{slots + v, stride, 0};
         g.visit(ld);
@@ -155,7 +157,8 @@ FD_D void wave_sync() {
 template <class G, int MODE, int LAYOUT, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, size_t stride, size_t V,
                                                      const float* __restrict__ in, float* __restrict__ out,
-                                                     size_t T, size_t fstride, const void* aux) {
+                                                     size_t T, size_t fstride, const void* aux, float* ring,
+                                                     uint32_t ring_cap) {
     constexpr int NI = G::IN, NO = G::OUT;
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;  // wave in block
@@ -165,7 +168,8 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
     if (v0 >= stride) return;  // whole wave beyond the padded bank (last workgroup of a ragged bank)
 
     G g;
-    g.bind(aux);
+    Ctx ctx{static_cast<const Aux*>(aux), ring + v, ring_cap, stride, 0};
+    g.bind(ctx);
     {
         VLoad ld{slots + v, stride, 0};  // stride is padded to a multiple of 64: always in bounds
         g.visit(ld);
@@ -350,48 +354,49 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
 // ---- per-kind dispatch table ---------------------------------------------------------------------------------
 struct KindOps {
     const char* name;
-    int nin, nout;
+    int nin, nout, nrings;
     std::vector<SlotInfo> slots;
     void (*lifecycle)(float* slots, size_t stride, size_t first, size_t count, int op, double sr,
-                      const uint64_t* d_seeds, const void* aux, hipStream_t s);
+                      const uint64_t* d_seeds, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s);
     void (*render)(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
-                   int layout, int mode, const void* aux, hipStream_t s);
+                   int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s);
 };
 
 template <class G>
 void launch_lifecycle(float* slots, size_t stride, size_t first, size_t count, int op, double sr,
-                      const uint64_t* d_seeds, const void* aux, hipStream_t s) {
+                      const uint64_t* d_seeds, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
     if (count == 0) return;
     unsigned grid = (unsigned)((count + 63) / 64);
-    hipLaunchKernelGGL((k_lifecycle<G>), dim3(grid), dim3(64), 0, s, slots, stride, first, count, op, sr, d_seeds, aux);
+    hipLaunchKernelGGL((k_lifecycle<G>), dim3(grid), dim3(64), 0, s, slots, stride, first, count, op, sr, d_seeds, aux,
+                       ring, ring_cap);
 }
 
 template <class G, int MODE, int LAYOUT>
 void launch_render_cfg(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
-                       const void* aux, hipStream_t s) {
+                       const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
     // 4-wave workgroups unless the per-wave LDS tiles of the planar path would not fit 4x in 64 KB of LDS
     constexpr size_t lds_per_wave = LAYOUT == LAYOUT_PLANAR ? (size_t)(G::IN + G::OUT) * 64 * TILE_STRIDE * 4 : 0;
     constexpr int WPB = (lds_per_wave * 4 <= 160 * 1024 - 1024) ? 4 : 1;
     const size_t waves = (V + 63) / 64;
     unsigned grid = (unsigned)((waves + WPB - 1) / WPB);
     hipLaunchKernelGGL((k_render<G, MODE, LAYOUT, WPB>), dim3(grid), dim3(64 * WPB), 0, s, slots, stride, V, in, out, T,
-                       fstride, aux);
+                       fstride, aux, ring, ring_cap);
 }
 
 template <class G>
 void launch_render(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
-                   int layout, int mode, const void* aux, hipStream_t s) {
+                   int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
     if (V == 0 || T == 0) return;
     if (layout == LAYOUT_VOICE_MINOR) {
         if (mode == MODE_PROCESS)
-            launch_render_cfg<G, MODE_PROCESS, LAYOUT_VOICE_MINOR>(slots, stride, V, in, out, T, fstride, aux, s);
+            launch_render_cfg<G, MODE_PROCESS, LAYOUT_VOICE_MINOR>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s);
         else
-            launch_render_cfg<G, MODE_TICK, LAYOUT_VOICE_MINOR>(slots, stride, V, in, out, T, fstride, aux, s);
+            launch_render_cfg<G, MODE_TICK, LAYOUT_VOICE_MINOR>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s);
     } else {
         if (mode == MODE_PROCESS)
-            launch_render_cfg<G, MODE_PROCESS, LAYOUT_PLANAR>(slots, stride, V, in, out, T, fstride, aux, s);
+            launch_render_cfg<G, MODE_PROCESS, LAYOUT_PLANAR>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s);
         else
-            launch_render_cfg<G, MODE_TICK, LAYOUT_PLANAR>(slots, stride, V, in, out, T, fstride, aux, s);
+            launch_render_cfg<G, MODE_TICK, LAYOUT_PLANAR>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s);
     }
 }
 
@@ -401,6 +406,7 @@ KindOps make_kind(const char* name) {
     k.name = name;
     k.nin = G::IN;
     k.nout = G::OUT;
+    k.nrings = G::RINGS;
     G g{};
     VDescribe d{&k.slots, {}};
     g.visit(d);

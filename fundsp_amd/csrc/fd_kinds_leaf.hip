@@ -25,6 +25,12 @@ void register_leaf_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<WaveSynth<2>>("triangle"));
     out.push_back(make_kind<AdsrLive>("adsr_live"));
     out.push_back(make_kind<Panner>("pan"));
+    out.push_back(make_kind<Delay>("delay"));
+    out.push_back(make_kind<TapT<false>>("tap"));
+    out.push_back(make_kind<TapT<true>>("tap_linear"));
+    out.push_back(make_kind<AllNest<Delay>>("allnest_delay"));
+    out.push_back(make_kind<AllNest<Tick<1>>>("allnest_tick"));
+    out.push_back(make_kind<AllNest<Pass>>("allnest_pass"));
     out.push_back(make_kind<Shaper>("shape"));
     out.push_back(make_kind<PhaseOsc<OSC_RAMP>>("ramp"));
     out.push_back(make_kind<PhaseOsc<OSC_POLYSAW>>("poly_saw"));

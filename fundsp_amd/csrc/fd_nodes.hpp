@@ -32,6 +32,19 @@ enum FieldKind { PARAM = 0, COEF = 1, STATE = 2 };
 //   PH_TICK  tick mode: AudioNode::tick for every sample
 constexpr int PH_SIMD = 0, PH_REM = 1, PH_TICK = 2;
 
+// Per-launch context handed to every node by bind(): shared wavetable data and this bank's delay-ring memory.
+// Ring memory is laid out [ring node][position][voice] (voice-minor, like the audio I/O): all lanes of a wave write the
+// same ring position in the same instruction, so ring writes are coalesced 256-B rows; reads at per-voice delays gather.
+struct Aux;
+struct Ctx {
+    const Aux* aux;
+    float* ring;         // base of this LANE's column: ring + voice
+    uint32_t ring_cap;   // positions per ring node
+    size_t vstride;      // floats between consecutive positions (= padded voice count)
+    int next_ring;       // running index handed out to ring nodes in visit order
+    FD_HD float* claim_ring() { return ring + (size_t)(next_ring++) * ring_cap * vstride; }
+};
+
 // step2<PH>(in, out): two consecutive frames at once, channel c of frames (n, n+1) packed in one <2 x float>.
 // Feed-forward nodes (Constant, Unop, Binop, the sine polynomial of Sine::process) implement it with packed f32
 // arithmetic, which halves their instruction count; nodes whose samples depend serially on each other use this
@@ -144,7 +157,7 @@ FD_HD BiquadCoefs biquad_coefs(int kind, float sr, float f0, float q, float gain
 // Constant<N>  audionode.rs:465-523 (ID 2).  The value is per voice.
 template <int N>
 struct Constant {
-    static constexpr int IN = 0, OUT = N;
+    static constexpr int IN = 0, OUT = N, RINGS = 0;
     static constexpr uint64_t ID = 2;
     float value[N];
     template <class V> FD_HD void visit(V& v) {
@@ -159,7 +172,7 @@ struct Constant {
     FD_HD void end_simd() {}
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     template <int PH> FD_HD void step(const float*, float* out) {
         for (int i = 0; i < N; i++) out[i] = value[i];
     }
@@ -170,7 +183,7 @@ struct Constant {
 
 // Pass  audionode.rs:408-436 (ID 48)
 struct Pass {
-    static constexpr int IN = 1, OUT = 1;
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = 48;
     template <class V> FD_HD void visit(V&) {}
     FD_HD void init() {}
@@ -180,21 +193,21 @@ struct Pass {
     FD_HD void end_simd() {}
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     template <int PH> FD_HD void step(const float* in, float* out) { out[0] = in[0]; }
     template <int PH> FD_HD void step2(const v2f* in, v2f* out) { out[0] = in[0]; }
 };
 
 // Sine<f32>  oscillator.rs:21-102 (ID 21)
 struct Sine {
-    static constexpr int IN = 1, OUT = 1;
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = 21;
     float phase, sample_duration, has_phase, initial_phase;
     uint64_t hash;
     float tmax;  // transient guard of the packed sine path (not a slot)
     FD_HD void begin_block(int) { tmax = 0.0f; }
     FD_HD bool tripped() const { return !(tmax < 8192.0f); }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     template <class V> FD_HD void visit(V& v) {
         v.f(phase, STATE, "phase");
         v.f(sample_duration, COEF, "sample_duration");
@@ -249,7 +262,7 @@ struct Sine {
 
 // Noise  noise.rs:173-234 (ID 20).  Integer-exact; process == tick sample for sample.
 struct Noise {
-    static constexpr int IN = 0, OUT = 1;
+    static constexpr int IN = 0, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = 20;
     uint32_t state;
     float has_seed;
@@ -281,7 +294,7 @@ struct Noise {
     FD_HD void end_simd() {}
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     template <int PH> FD_HD void step(const float*, float* out) {  // :197-202
         state += 1u;
         out[0] = (float)(hash32x(state) >> 8) * (2.0f / (float)((1 << 24) - 1)) - 1.0f;
@@ -319,7 +332,7 @@ struct SvfCore {
 // FixedSvf<f32, M>  svf.rs:861-1031 (ID 43).  The mode is a per-voice parameter: the recurrence is mode
 // independent (17 flops with generic m0..m2, exactly the reference arithmetic); only `update` branches on it.
 struct FixedSvf {
-    static constexpr int IN = 1, OUT = 1;
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = 43;
     float mode, cutoff, q, gain, sr;
     SvfCore c;
@@ -347,7 +360,7 @@ struct FixedSvf {
     FD_HD void end_simd() {}
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     template <int PH> FD_HD void step(const float* in, float* out) { out[0] = c.tick(in[0]); }
     FD_STEP2_VIA_STEP
 };
@@ -355,7 +368,7 @@ struct FixedSvf {
 // Svf<f32, M> with parameter inputs  svf.rs:748-855 (ID 36).  NIN = 3 (audio, cutoff, q) or 4 (+ gain).
 template <int NIN>
 struct Svf {
-    static constexpr int IN = NIN, OUT = 1;
+    static constexpr int IN = NIN, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = 36;
     float mode, cutoff, q, gain, sr;
     SvfCore c;
@@ -383,7 +396,7 @@ struct Svf {
     FD_HD void end_simd() {}
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     template <int PH> FD_HD void step(const float* in, float* out) {
         // update_inputs :299-313 (3 inputs) / :588-606 (4 inputs): recompute only when an input changed
         bool changed = in[1] != cutoff || in[2] != q;
@@ -403,7 +416,7 @@ struct Svf {
 // One lane of BiquadBank<f32x8> (biquad_bank.rs:73-84, ID 98) performs exactly this arithmetic.
 template <uint64_t NODE_ID>
 struct BiquadT {
-    static constexpr int IN = 1, OUT = 1;
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = NODE_ID;
     float a1, a2, b0, b1, b2, x1, x2, y1, y2;
     template <class V> FD_HD void visit(V& v) {
@@ -418,7 +431,7 @@ struct BiquadT {
     FD_HD void end_simd() {}
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     FD_HD float tick(float x0) {  // :184-194
         float y0 = b0 * x0 + b1 * x1 + b2 * x2 - a1 * y1 - a2 * y2;
         x2 = x1;
@@ -435,7 +448,7 @@ using Biquad = BiquadT<15>;
 // ButterLowpass<f32, N>  biquad.rs:227-300 (ID 16), N = 1 (fixed) or 2 (cutoff input)
 template <int NIN>
 struct ButterLowpass {
-    static constexpr int IN = NIN, OUT = 1;
+    static constexpr int IN = NIN, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = 16;
     float cutoff, sr;
     Biquad b;
@@ -462,7 +475,7 @@ struct ButterLowpass {
     FD_HD void end_simd() {}
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     template <int PH> FD_HD void step(const float* in, float* out) {  // :269-277
         if (NIN > 1) {
             if (in[1] != cutoff) set_cutoff(in[1]);
@@ -475,7 +488,7 @@ struct ButterLowpass {
 // Resonator<f32, N>  biquad.rs:310-380 (ID 17), N = 1 (fixed) or 3 (center, q inputs)
 template <int NIN>
 struct Resonator {
-    static constexpr int IN = NIN, OUT = 1;
+    static constexpr int IN = NIN, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = 17;
     float center, q, sr;
     Biquad b;
@@ -504,7 +517,7 @@ struct Resonator {
     FD_HD void end_simd() {}
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     template <int PH> FD_HD void step(const float* in, float* out) {  // :354-366
         if (NIN >= 3) {
             if (in[1] != center || in[2] != q) set_center_q(in[1], in[2]);
@@ -518,7 +531,7 @@ struct Resonator {
 // coefficients including a sinf are then recomputed EVERY sample, unconditionally: moog.rs:83-85).
 template <int NIN>
 struct Moog {
-    static constexpr int IN = NIN, OUT = 1;
+    static constexpr int IN = NIN, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = 60;
     float q, cutoff, sr, rez, p, k, s0, s1, s2, s3, px, ps0, ps1, ps2;
     template <class V> FD_HD void visit(V& v) {
@@ -553,7 +566,7 @@ struct Moog {
     FD_HD void end_simd() {}
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     template <int PH> FD_HD void step(const float* in, float* out) {  // :82-100
         // The reference recomputes (p, k, rez) from (cutoff, q) on EVERY sample (moog.rs:83-85).  They are a pure
         // function of the two inputs and the sample rate, so recomputing only when an input differs from the stored
@@ -579,7 +592,7 @@ struct Moog {
 // Fir<N>  fir.rs:14-89 (ID 52)
 template <int N>
 struct Fir {
-    static constexpr int IN = 1, OUT = 1;
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = 52;
     float w[N], v[N];
     template <class V> FD_HD void visit(V& vis) {
@@ -598,7 +611,7 @@ struct Fir {
     FD_HD void end_simd() {}
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     template <int PH> FD_HD void step(const float* in, float* out) {  // :57-70
         for (int i = 0; i + 1 < N; i++) v[i] = v[i + 1];
         v[N - 1] = in[0];
@@ -612,7 +625,7 @@ struct Fir {
 // Tick<N>  delay.rs:19-65 (ID 9): one-sample delay
 template <int N>
 struct Tick {
-    static constexpr int IN = N, OUT = N;
+    static constexpr int IN = N, OUT = N, RINGS = 0;
     static constexpr uint64_t ID = 9;
     float buffer[N];
     template <class V> FD_HD void visit(V& v) {
@@ -627,7 +640,7 @@ struct Tick {
     FD_HD void end_simd() {}
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     template <int PH> FD_HD void step(const float* in, float* out) {  // :47-52
         for (int i = 0; i < N; i++) {
             float o = buffer[i];
@@ -713,7 +726,7 @@ FD_HD float tap_eval(const Tap4& t) { return optimal4x44(t.a0, t.a1, t.a2, t.a3,
 
 template <int SET>
 struct WaveSynth {
-    static constexpr int IN = 1, OUT = 1;
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = 34;
     float phase, sample_duration, has_phase, initial_phase;
     uint32_t hint;
@@ -734,8 +747,8 @@ struct WaveSynth {
         v.f(initial_phase, PARAM, "initial_phase");
         v.u64(hash, STATE, "hash");
     }
-    FD_HD void bind(const void* a) {
-        wt = &static_cast<const Aux*>(a)->wt[SET];
+    FD_HD void bind(Ctx& a) {
+        wt = &a.aux->wt[SET];
         c_table = -1;
     }
     FD_HD void init() {  // WaveSynth::new :270-281: phase 0.0 WITHOUT reset
@@ -819,7 +832,7 @@ FD_HD float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; } 
 // adsr_live(attack, decay, sustain, release) = EnvelopeIn<f32, closure, U1, f32>  (adsr.rs:21-70,
 // prelude.rs:626-639, envelope.rs:185-358; ID 53).  The Rust closure + its two atomics become plain per-voice state.
 struct AdsrLive {
-    static constexpr int IN = 1, OUT = 1;
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = 53;
     float attack, decay, sustain, release, interval;       // params
     float sd;                                               // coef
@@ -839,7 +852,7 @@ struct AdsrLive {
         v.u64(t_hash, STATE, "t_hash");
         v.u64(hash, STATE, "hash");
     }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     FD_HD void init() {
         attack = 0.01f; decay = 0.1f; sustain = 0.6f; release = 0.2f;
         interval = (float)0.002;  // envelope2: F::from_f64(0.002)
@@ -935,7 +948,7 @@ struct AdsrLive {
 
 // Panner<U1>  pan.rs:26-93 (ID 49): fixed pan, mono -> stereo.
 struct Panner {
-    static constexpr int IN = 1, OUT = 2;
+    static constexpr int IN = 1, OUT = 2, RINGS = 0;
     static constexpr uint64_t ID = 49;
     float pan, lw, rw;
     template <class V> FD_HD void visit(V& v) {
@@ -943,7 +956,7 @@ struct Panner {
         v.f(lw, COEF, "left_weight");
         v.f(rw, COEF, "right_weight");
     }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     FD_HD void init() { pan = 0.0f; }
     FD_HD void update(double) {  // pan_weights :13-17
         float c = pan > -1.0f ? pan : -1.0f;
@@ -1026,11 +1039,11 @@ struct Shape {
 
 // Shaper<S>  shape.rs:205-247 (ID 42)
 struct Shaper {
-    static constexpr int IN = 1, OUT = 1;
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = 42;
     Shape sh;
     template <class V> FD_HD void visit(V& v) { sh.visit(v); }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     FD_HD void init() { sh.init(); }
     FD_HD void update(double) {}
     FD_HD void reset() { sh.reset(); }
@@ -1061,7 +1074,7 @@ FD_HD float polyblep(float t, float dt) {  // oscillator.rs:512-523
 constexpr int OSC_RAMP = 0, OSC_POLYSAW = 1, OSC_POLYSQUARE = 2, OSC_POLYPULSE = 3;
 template <int KIND>
 struct PhaseOsc {
-    static constexpr int IN = KIND == OSC_POLYPULSE ? 2 : 1, OUT = 1;
+    static constexpr int IN = KIND == OSC_POLYPULSE ? 2 : 1, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = KIND == OSC_RAMP ? 94 : KIND == OSC_POLYSAW ? 95 : KIND == OSC_POLYSQUARE ? 96 : 97;
     float phase, sample_duration, has_phase, initial_phase;
     uint64_t hash;
@@ -1072,7 +1085,7 @@ struct PhaseOsc {
         v.f(initial_phase, PARAM, "initial_phase");
         v.u64(hash, STATE, "hash");
     }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     FD_HD void init() { has_phase = 0.0f; initial_phase = 0.0f; hash = 0; reset(); }
     FD_HD void update(double sr) { sample_duration = (float)(1.0 / sr); }
     FD_HD void reset() { phase = has_phase != 0.0f ? initial_phase : (float)rnd1(hash); }
@@ -1105,7 +1118,7 @@ struct PhaseOsc {
 // Rossler (oscillator.rs:323-375, ID 73) and Lorenz (:382-435, ID 74) attractors, explicit Euler
 template <bool LORENZ>
 struct Chaos {
-    static constexpr int IN = 1, OUT = 1;
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = LORENZ ? 74 : 73;
     float x, y, z, sr;
     uint64_t hash;
@@ -1114,7 +1127,7 @@ struct Chaos {
         v.f(sr, COEF, "sample_rate");
         v.u64(hash, STATE, "hash");
     }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     FD_HD void init() { hash = 0; reset(); }
     FD_HD void update(double sample_rate) { sr = (float)sample_rate; }
     FD_HD void reset() {  // lerp(0.0, 1.0, rnd1(hash) as f32)
@@ -1157,7 +1170,7 @@ struct Chaos {
 // ---------------------------------------------------------------------------------------------------------
 template <bool DIRTY, int NIN>
 struct NlBiquad {
-    static constexpr int IN = NIN, OUT = 1;
+    static constexpr int IN = NIN, OUT = 1, RINGS = 0;
     static constexpr uint64_t ID = DIRTY ? (NIN == 1 ? 91 : 89) : (NIN == 1 ? 90 : 88);
     float mode, center, q, gain, sr;
     float a1, a2, b0, b1, b2, s1, s2;
@@ -1172,7 +1185,7 @@ struct NlBiquad {
         v.enter(0); sh1.visit(v); v.leave();
         if (DIRTY) { v.enter(1); sh2.visit(v); v.leave(); }
     }
-    FD_HD void bind(const void*) {}
+    FD_HD void bind(Ctx&) {}
     FD_HD void coefs() {  // BiquadMode::update :404-490 (kinds: BQ_RESONATOR/LOWPASS/HIGHPASS/BELL)
         BiquadCoefs c = biquad_coefs((int)mode, sr, center, q, gain);
         a1 = c.a1; a2 = c.a2; b0 = c.b0; b1 = c.b1; b2 = c.b2;
@@ -1214,6 +1227,159 @@ struct NlBiquad {
 };
 
 // ---------------------------------------------------------------------------------------------------------
+// delay lines (delay.rs): Delay, Tap<U1>, TapLinear<U1>, AllNest<U1, X>.  Ring memory: see Ctx.
+// ---------------------------------------------------------------------------------------------------------
+FD_HD float splinef(float y0, float y1, float y2, float y3, float x) {  // Catmull-Rom, math.rs:360-366
+    return y1 + x * 0.5f * (y2 - y0 + x * (2.0f * y0 - 5.0f * y1 + 4.0f * y2 - y3 + x * (3.0f * (y1 - y2) + y3 - y0)));
+}
+FD_HD uint32_t next_pow2_u32(uint32_t x) {  // usize::next_power_of_two
+    uint32_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// Delay  delay.rs:72-139 (ID 13): fixed delay of round(time * sr) samples; ring length = that + 1.
+struct Delay {
+    static constexpr int IN = 1, OUT = 1, RINGS = 1;
+    static constexpr uint64_t ID = 13;
+    float time;           // seconds (prelude delay(t: f32) -> Delay::new(t as f64))
+    float last_sr;        // the rate the ring was sized for: a CHANGE resizes and resets (delay.rs:105-113)
+    uint32_t len, i;
+    float* ring;
+    size_t vs;
+    uint32_t cap;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(time, PARAM, "time");
+        v.f(last_sr, COEF, "sized_for_sample_rate");
+        v.u32(len, COEF, "length");
+        v.u32(i, STATE, "i");
+    }
+    FD_HD void bind(Ctx& c) { ring = c.claim_ring(); vs = c.vstride; cap = c.ring_cap; }
+    FD_HD void clear() {
+        for (uint32_t k = 0; k < cap; k++) ring[(size_t)k * vs] = 0.0f;
+    }
+    FD_HD void init() { time = 0.0f; last_sr = 0.0f; len = 1; i = 0; }
+    FD_HD void update(double sr) {
+        uint32_t want = (uint32_t)__builtin_round((double)time * sr) + 1u;
+        want = want > cap ? cap : want;  // capacity is fixed at bank creation (fdsp_bank_create_ring)
+        if (last_sr != (float)sr || want != len) {
+            last_sr = (float)sr;
+            len = want;
+            reset();
+        }
+    }
+    FD_HD void reset() { i = 0; clear(); }  // :100-103
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // :116-124
+        ring[(size_t)i * vs] = in[0];
+        i += 1;
+        if (i >= len) i = 0;
+        out[0] = ring[(size_t)i * vs];
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// Tap<U1> (cubic, ID 50, delay.rs:148-286) and TapLinear<U1> (ID 54, :386-505): variable fractional delay in seconds
+// on input 1.  The f32x8 `process` writes 8 samples and then reads with per-lane offsets; because the clamped delay
+// is at least one sample (Tap) / the read never runs ahead of the write (TapLinear), each lane reads exactly what
+// `tick` reads, so one sample-serial implementation serves both paths.
+template <bool LINEAR>
+struct TapT {
+    static constexpr int IN = 2, OUT = 1, RINGS = 1;
+    static constexpr uint64_t ID = LINEAR ? 54 : 50;
+    float min_delay, max_delay;                    // params
+    float srf, min_c, max_c;                       // coefs
+    uint32_t mask, i;
+    float* ring;
+    size_t vs;
+    uint32_t cap;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(min_delay, PARAM, "min_delay"); v.f(max_delay, PARAM, "max_delay");
+        v.f(srf, COEF, "sample_rate"); v.f(min_c, COEF, "min_delay_clamped"); v.f(max_c, COEF, "max_delay_clamped");
+        v.u32(mask, COEF, "mask");
+        v.u32(i, STATE, "i");
+    }
+    FD_HD void bind(Ctx& c) { ring = c.claim_ring(); vs = c.vstride; cap = c.ring_cap; }
+    FD_HD void init() { min_delay = 0.0f; max_delay = 0.0f; srf = 0.0f; mask = 0; i = 0; min_c = max_c = 0.0f; }
+    FD_HD void update(double sample_rate) {  // :198-209 / :436-445
+        float sr = (float)sample_rate;
+        float blen = LINEAR ? __builtin_ceilf(max_delay * sr) + 2.0f : __builtin_ceilf(max_delay * sr) + 3.0f + 8.0f;
+        uint32_t n = next_pow2_u32((uint32_t)blen);
+        while (n > cap) n >>= 1;  // capacity fixed at bank creation
+        uint32_t m = n - 1u;
+        if (srf != sr || m != mask) {
+            srf = sr;
+            mask = m;
+            min_c = LINEAR ? min_delay : (min_delay > 1.00001f / sr ? min_delay : 1.00001f / sr);
+            max_c = LINEAR ? max_delay : (max_delay > 1.00001f / sr ? max_delay : 1.00001f / sr);
+            reset();
+        }
+    }
+    FD_HD void reset() {  // :193-196
+        i = 0;
+        for (uint32_t k = 0; k <= mask && k < cap; k++) ring[(size_t)k * vs] = 0.0f;
+    }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // tick :212-236 / :448-463
+        ring[(size_t)i * vs] = in[0];
+        float tap = rs_clamp(min_c, max_c, in[1]) * srf;
+        uint32_t tap_floor = (uint32_t)tap;
+        uint32_t i1 = (i - tap_floor) & mask;
+        float d = tap - (float)tap_floor;
+        float o = 0.0f;
+        if (LINEAR) {
+            uint32_t i2 = (i1 - 1u) & mask;
+            float a = ring[(size_t)i1 * vs], b = ring[(size_t)i2 * vs];
+            o += a * (1.0f - d) + b * d;  // lerp math.rs:169-178
+        } else {
+            uint32_t i0 = (i1 + 1u) & mask, i2 = (i1 - 1u) & mask, i3 = (i1 - 2u) & mask;
+            o += splinef(ring[(size_t)i0 * vs], ring[(size_t)i1 * vs], ring[(size_t)i2 * vs], ring[(size_t)i3 * vs], d);
+        }
+        i = (i + 1u) & mask;
+        out[0] = o;
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// AllNest<U1, X>  delay.rs:294-377 (ID 83): Schroeder allpass around the single-channel node X, fixed coefficient.
+template <class X>
+struct AllNest {
+    static_assert(X::IN == 1 && X::OUT == 1, "AllNest wraps a 1-in 1-out node");
+    static constexpr int IN = 1, OUT = 1, RINGS = X::RINGS;
+    static constexpr uint64_t ID = 83;
+    X x;
+    float eta, z;
+    template <class V> FD_HD void visit(V& v) {
+        v.enter(0); x.visit(v); v.leave();
+        v.f(eta, PARAM, "coefficient");
+        v.f(z, STATE, "z");
+    }
+    FD_HD void bind(Ctx& c) { x.bind(c); }
+    FD_HD void init() { x.init(); eta = 0.0f; z = 0.0f; }
+    FD_HD void update(double sr) { x.update(sr); }
+    FD_HD void reset() { z = 0.0f; x.reset(); }  // :316-319
+    FD_HD uint64_t ping(bool probe, uint64_t h) { return x.ping(probe, atto(h, ID)); }  // :337-339
+    FD_HD void begin_block(int n) { x.begin_block(n); }
+    FD_HD bool tripped() const { return x.tripped(); }
+    FD_HD void end_simd() { x.end_simd(); }
+    template <int PH> FD_HD void step(const float* in, float* out) {  // :322-330 (tick everywhere: no process override)
+        float v = in[0] - eta * z;
+        float y = eta * v + z;
+        float zi;
+        x.template step<PH_TICK>(&v, &zi);
+        z = zi;
+        out[0] = y;
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// ---------------------------------------------------------------------------------------------------------
 // combinators
 // ---------------------------------------------------------------------------------------------------------
 
@@ -1221,7 +1387,7 @@ struct NlBiquad {
 template <class X, class Y>
 struct Pipe {
     static_assert(X::OUT == Y::IN, "Pipe arity mismatch");
-    static constexpr int IN = X::IN, OUT = Y::OUT;
+    static constexpr int IN = X::IN, OUT = Y::OUT, RINGS = X::RINGS + Y::RINGS;
     static constexpr uint64_t ID = 6;
     X x;
     Y y;
@@ -1235,7 +1401,7 @@ struct Pipe {
     FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }  // :1459
     FD_HD void end_simd() { x.end_simd(); y.end_simd(); }
     FD_HD void begin_block(int n) { x.begin_block(n); y.begin_block(n); }
-    FD_HD void bind(const void* a) { x.bind(a); y.bind(a); }
+    FD_HD void bind(Ctx& a) { x.bind(a); y.bind(a); }
     FD_HD bool tripped() const { return x.tripped() || y.tripped(); }
     template <int PH> FD_HD void step(const float* in, float* out) {
         float t[X::OUT > 0 ? X::OUT : 1];
@@ -1252,7 +1418,7 @@ struct Pipe {
 // Stack<X, Y>  audionode.rs:1496-1650 (ID 7)
 template <class X, class Y>
 struct Stack {
-    static constexpr int IN = X::IN + Y::IN, OUT = X::OUT + Y::OUT;
+    static constexpr int IN = X::IN + Y::IN, OUT = X::OUT + Y::OUT, RINGS = X::RINGS + Y::RINGS;
     static constexpr uint64_t ID = 7;
     X x;
     Y y;
@@ -1266,7 +1432,7 @@ struct Stack {
     FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }
     FD_HD void end_simd() { x.end_simd(); y.end_simd(); }
     FD_HD void begin_block(int n) { x.begin_block(n); y.begin_block(n); }
-    FD_HD void bind(const void* a) { x.bind(a); y.bind(a); }
+    FD_HD void bind(Ctx& a) { x.bind(a); y.bind(a); }
     FD_HD bool tripped() const { return x.tripped() || y.tripped(); }
     template <int PH> FD_HD void step(const float* in, float* out) {
         x.template step<PH>(in, out);
@@ -1286,7 +1452,7 @@ struct OpMul { template <class T> static FD_HD T f(T a, T b) { return a * b; } }
 template <class OP, class X, class Y>
 struct Binop {
     static_assert(X::OUT == Y::OUT, "Binop arity mismatch");
-    static constexpr int IN = X::IN + Y::IN, OUT = X::OUT;
+    static constexpr int IN = X::IN + Y::IN, OUT = X::OUT, RINGS = X::RINGS + Y::RINGS;
     static constexpr uint64_t ID = 3;
     X x;
     Y y;
@@ -1300,7 +1466,7 @@ struct Binop {
     FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }  // :966
     FD_HD void end_simd() { x.end_simd(); y.end_simd(); }
     FD_HD void begin_block(int n) { x.begin_block(n); y.begin_block(n); }
-    FD_HD void bind(const void* a) { x.bind(a); y.bind(a); }
+    FD_HD void bind(Ctx& a) { x.bind(a); y.bind(a); }
     FD_HD bool tripped() const { return x.tripped() || y.tripped(); }
     template <int PH> FD_HD void step(const float* in, float* out) {
         float t[OUT];
@@ -1325,7 +1491,7 @@ struct UMulScalar { static constexpr bool HAS_SCALAR = true; template <class T> 
 // Unop<X, U>  audionode.rs:1232-1326 (ID 4)
 template <class X, class U>
 struct Unop {
-    static constexpr int IN = X::IN, OUT = X::OUT;
+    static constexpr int IN = X::IN, OUT = X::OUT, RINGS = X::RINGS;
     static constexpr uint64_t ID = 4;
     X x;
     float scalar;
@@ -1339,7 +1505,7 @@ struct Unop {
     FD_HD uint64_t ping(bool probe, uint64_t h) { return x.ping(probe, atto(h, ID)); }  // :1286
     FD_HD void end_simd() { x.end_simd(); }
     FD_HD void begin_block(int n) { x.begin_block(n); }
-    FD_HD void bind(const void* a) { x.bind(a); }
+    FD_HD void bind(Ctx& a) { x.bind(a); }
     FD_HD bool tripped() const { return x.tripped(); }
     template <int PH> FD_HD void step(const float* in, float* out) {
         x.template step<PH>(in, out);

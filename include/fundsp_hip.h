@@ -79,6 +79,11 @@ const char* fdsp_last_error(void);
  *   "fm_svf"             sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q) (BASELINE config 3)
  *   "saw_moog_adsr_pan"  ((dc(f) >> saw() | dc(fc) | dc(q)) >> moog()) * adsr_live(a,d,s,r) >> pan(p)
  *                        1 input (gate), 2 outputs                            (BASELINE config 4 voice)
+ * Delay lines (need fdsp_bank_create_ring): "delay" delay.rs:72, "tap" :148, "tap_linear" :386,
+ *   "allnest_delay"/"allnest_tick"/"allnest_pass" :294 (AllNest around Delay / Tick / Pass)
+ * Shapers and oscillators: "shape" shape.rs:205 (per-voice shape kind), "ramp"/"poly_saw"/"poly_square"/"poly_pulse"
+ *   oscillator.rs:441-760, "rossler"/"lorenz" :323-435; nonlinear biquads "fbiquad_hz"/"dbiquad_hz"/"fbiquad3"/
+ *   "fbiquad4"/"dbiquad3"/"dbiquad4" biquad.rs:494-920
  * More leaves: "saw"/"square"/"triangle" wavetable.rs:249 (need fdsp_wavetable_build/upload first),
  *   "adsr_live" adsr.rs:21 + envelope.rs:185, "pan" pan.rs:26
  */
@@ -96,6 +101,11 @@ int fdsp_kind_slot_kind(int kind, int slot);
 /* Creates a bank of `voices` instances on the current HIP device.  State after creation equals the
  * reference constructor: DEFAULT_SR, default parameters, combinator construction-time ping (audionode.rs:871-876). */
 int fdsp_bank_create(const char* kind, size_t voices, fdsp_bank** out);
+/* Kinds that contain delay lines ("delay", "tap", "tap_linear", "allnest_delay": src/delay.rs) keep their rings in HBM,
+ * laid out [ring node][position][voice].  `ring_frames` is the capacity (positions) of every ring of the graph and must
+ * cover the longest delay at the highest sample rate that will be set: Delay needs round(time*sr)+1, Tap
+ * next_pow2(ceil(max_delay*sr)+11), TapLinear next_pow2(ceil(max_delay*sr)+2) (delay.rs:108-110,204-206,440-442). */
+int fdsp_bank_create_ring(const char* kind, size_t voices, size_t ring_frames, fdsp_bank** out);
 /* reverb_stereo(room_size, time, damping) (src/prelude.rs:1732-1762): bank of `instances` independent 32-line FDN
  * reverbs, 2 inputs / 2 outputs each, all with the same parameters.  Mapped one lane per delay line (32 lanes per
  * instance), delay rings in HBM; flushes f32 denormals like the reference does after Feedback::new

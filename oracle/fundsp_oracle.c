@@ -89,6 +89,11 @@ struct onode {
         float attack_start, release_start, adsr_a, adsr_d, adsr_s, adsr_r;
         /* Panner (pan.rs:26-30) */
         float left_weight, right_weight;
+        /* Tap / TapLinear (delay.rs:148-161, 386-397), AllNest (delay.rs:294-303) */
+        int tap_linear;
+        float tap_min, tap_max, tap_min_c, tap_max_c, tap_sr, eta, zz;
+        float *tbuf;
+        size_t tlen, ti;
         /* Shape x2 (shape.rs), PhaseOsc kind, Chaos, nonlinear biquad (biquad.rs:494-920) */
         struct { int kind; float p0, p1, smoothing, state; } sh[2];
         int osc_kind, lorenz, nl_dirty, nl_mode;
@@ -132,6 +137,7 @@ void o_free(onode *n) {
     o_free(n->y);
     free(n->tmp);
     free(n->s.dbuf);
+    free(n->s.tbuf);
     free(n);
 }
 
@@ -413,6 +419,13 @@ static void leaf_reset(onode *n) {
     case O_PHASE_OSC: /* oscillator.rs:449-454 etc. */
         n->s.phase = n->s.has_initial_phase ? n->s.initial_phase : (float)o_rnd1(n->s.hash);
         break;
+    case O_TAP: /* delay.rs:193-196 */
+        n->s.ti = 0;
+        for (size_t i = 0; i < n->s.tlen; i++) n->s.tbuf[i] = 0.0f;
+        break;
+    case O_ALLNEST: /* delay.rs:316-319 (child reset by o_reset's recursion) */
+        n->s.zz = 0.0f;
+        break;
     case O_CHAOS: { /* oscillator.rs:337-341, 396-400: lerp(0.0, 1.0, rnd1(hash) as f32) */
         float t = (float)o_rnd1(n->s.hash);
         n->s.cx = 0.0f * (1.0f - t) + 1.0f * t;
@@ -496,6 +509,28 @@ static void leaf_set_sample_rate(onode *n, double sr) {
     case O_PHASE_OSC: /* oscillator.rs:456-458 */
         n->s.sample_duration = (float)(1.0 / sr);
         break;
+    case O_TAP: { /* delay.rs:198-209 / :436-445 */
+        float srf = (float)sr;
+        if (n->s.tap_sr != srf) {
+            n->s.tap_sr = srf;
+            float blen;
+            if (n->s.tap_linear) {
+                n->s.tap_min_c = n->s.tap_min;
+                n->s.tap_max_c = n->s.tap_max;
+                blen = ceilf(n->s.tap_max * srf) + 2.0f;
+            } else {
+                n->s.tap_min_c = n->s.tap_min > 1.00001f / srf ? n->s.tap_min : 1.00001f / srf;
+                n->s.tap_max_c = n->s.tap_max > 1.00001f / srf ? n->s.tap_max : 1.00001f / srf;
+                blen = ceilf(n->s.tap_max * srf) + 3.0f + (float)SIMD_N;
+            }
+            size_t len = 1;
+            while (len < (size_t)blen) len <<= 1;
+            n->s.tbuf = (float *)realloc(n->s.tbuf, len * sizeof(float));
+            n->s.tlen = len;
+            leaf_reset(n);
+        }
+        break;
+    }
     case O_CHAOS:
         n->s.sr = (float)sr;
         break;
@@ -547,6 +582,7 @@ static uint64_t o_ping(onode *n, int probe, uint64_t hash) {
     case O_BINOP:
         return o_ping(n->y, probe, o_ping(n->x, probe, o_atto(hash, n->id)));
     case O_UNOP:
+    case O_ALLNEST: /* delay.rs:337-339 */
         return o_ping(n->x, probe, o_atto(hash, n->id));
     default:
         if (!probe) leaf_set_hash(n, hash);
@@ -747,6 +783,26 @@ onode *o_panner(int inputs, float pan) { /* Panner::new pan.rs:33-40, ID 49 */
     onode *n = o_new(O_PANNER, inputs, 2, 49);
     pan_weights(pan, &n->s.left_weight, &n->s.right_weight);
     return n;
+}
+
+onode *o_tap(int linear, float min_delay, float max_delay) { /* Tap::new :164-176 (ID 50) / TapLinear::new :404-418 (ID 54) */
+    onode *n = o_new(O_TAP, 2, 1, linear ? 54 : 50);
+    n->s.tap_linear = linear;
+    n->s.tap_min = min_delay;
+    n->s.tap_max = max_delay;
+    n->s.tap_sr = 0.0f;
+    leaf_set_sample_rate(n, DEFAULT_SR);
+    return n;
+}
+onode *o_allnest(float coefficient, onode *x) { /* AllNest::new :313-326, ID 83 (no constructor ping) */
+    onode *n = o_new(O_ALLNEST, 1, 1, 83);
+    n->x = x;
+    n->s.eta = coefficient;
+    n->s.zz = 0.0f;
+    return n;
+}
+static inline float splinef(float y0, float y1, float y2, float y3, float x) { /* math.rs:360-366 */
+    return y1 + x * 0.5f * (y2 - y0 + x * (2.0f * y0 - 5.0f * y1 + 4.0f * y2 - y3 + x * (3.0f * (y1 - y2) + y3 - y0)));
 }
 
 onode *o_shaper(int shape, float p0, float p1) { /* Shaper::new shape.rs:209-215, ID 42 */
@@ -1119,6 +1175,34 @@ void o_tick(onode *n, const float *in, float *out) {
         n->s.ev += n->s.evd;
         n->s.et += n->s.esd;
         break;
+    case O_TAP: { /* Tap::tick delay.rs:212-236 / TapLinear::tick :448-463 (the f32x8 process path reads the same samples) */
+        size_t mask = n->s.tlen - 1;
+        n->s.tbuf[n->s.ti] = in[0];
+        float tap = rs_clampf(n->s.tap_min_c, n->s.tap_max_c, in[1]) * n->s.tap_sr;
+        size_t tap_floor = (size_t)tap;
+        size_t i1 = (n->s.ti - tap_floor) & mask;
+        float d = tap - (float)tap_floor;
+        float o = 0.0f;
+        if (n->s.tap_linear) {
+            size_t i2 = (i1 - 1) & mask;
+            o += n->s.tbuf[i1] * (1.0f - d) + n->s.tbuf[i2] * d;
+        } else {
+            size_t i0 = (i1 + 1) & mask, i2 = (i1 - 1) & mask, i3 = (i1 - 2) & mask;
+            o += splinef(n->s.tbuf[i0], n->s.tbuf[i1], n->s.tbuf[i2], n->s.tbuf[i3], d);
+        }
+        n->s.ti = (n->s.ti + 1) & mask;
+        out[0] = o;
+        break;
+    }
+    case O_ALLNEST: { /* delay.rs:322-330 */
+        float v = in[0] - n->s.eta * n->s.zz;
+        float y = n->s.eta * v + n->s.zz;
+        float z;
+        o_tick(n->x, &v, &z);
+        n->s.zz = z;
+        out[0] = y;
+        break;
+    }
     case O_SHAPER: out[0] = shape_scalar(n, 0, in[0]); break; /* shape.rs:226-229 */
     case O_PHASE_OSC: {
         float phase = n->s.phase;

@@ -72,6 +72,7 @@ def lib():
         "o_wavetable_create": (P, [i, fp, C.POINTER(C.c_int), fp]), "o_wavetable_free": (None, [P]),
         "o_wavesynth": (P, [P, i]), "o_wavesynth_set_phase": (None, [P, f]),
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
+        "o_tap": (P, [i, f, f]), "o_allnest": (P, [f, P]),
         "o_shaper": (P, [i, f, f]), "o_phase_osc": (P, [i]), "o_osc_set_phase": (None, [P, f]), "o_chaos": (P, [i]),
         "o_nlbiquad": (P, [i, i, i, i, f, f, f, f, f]), "o_math_atanf": (f, [f]), "o_math_wide_atanf": (f, [f]),
         "o_adaptive_smoothing": (d, [f, d]),
@@ -295,6 +296,11 @@ def pan(p): return Node(lib().o_panner(1, p))                         # prelude.
 
 SHAPES = dict(clip=0, clip_to=1, tanh=2, atan=3, softsign=4, crush=5, soft_crush=6, adaptive_tanh=7)
 OSCS = dict(ramp=0, poly_saw=1, poly_square=2, poly_pulse=3)
+
+
+def tap(min_delay, max_delay): return Node(lib().o_tap(0, min_delay, max_delay))                  # prelude.rs:910
+def tap_linear(min_delay, max_delay): return Node(lib().o_tap(1, min_delay, max_delay))           # prelude.rs:948
+def allnest_c(coefficient, x): return Node(lib().o_allnest(coefficient, x.ptr), (x,))             # prelude.rs allnest_c
 
 
 def shape(kind, p0=1.0, p1=0.0): return Node(lib().o_shaper(SHAPES[kind], p0, p1))          # prelude.rs:1194

@@ -221,3 +221,25 @@ def test_atan_restatements_and_polyblep_saw_shape():
     assert y.min() > -1.05 and y.max() < 1.05
     d = np.diff(y)
     assert np.sum(d < -1.0) in (9, 10, 11)                                  # ten downward resets in 0.1 s at 100 Hz
+
+
+def test_taps_check_wave_and_allnest_allpass():
+    """tests/test_basic.rs:347-352 (multitap / multitap_linear through check_wave) and test_flow.rs:251-283 (allnest)."""
+    check_wave(lambda: (O.noise() | O.dc(0.004)) >> O.tap(0.001, 0.01))
+    check_wave(lambda: (O.noise() | O.dc(0.004)) >> O.tap_linear(0.0, 0.01))
+    for make in (lambda: O.allnest_c(0.5, O.pass_()), lambda: O.allnest_c(0.6, O.tick()),
+                 lambda: O.allnest_c(-0.6, O.allpass_hz(3000.0, 3.0)), lambda: O.allnest_c(0.4, O.delay(0.001))):
+        n = make()
+        n.set_sample_rate(44100.0)
+        x = np.zeros((1, 0x8000), dtype=np.float32)
+        x[0, 0] = 1.0
+        mag = np.abs(np.fft.rfft(n.render_blocks(x)[0].astype(np.float64)))[1:]
+        assert np.all(np.abs(mag - 1.0) <= 1e-5)
+    # a tap at an integer delay reproduces the input exactly (Catmull-Rom passes through its knots)
+    sr = 48000.0
+    rng = np.random.default_rng(5)
+    x = (rng.random((1, 600), dtype=np.float32) - 0.5).astype(np.float32)
+    t = O.tap(0.0, 0.01)
+    t.set_sample_rate(sr)
+    y = t.render_ticks(np.concatenate([x, np.full((1, 600), 96.0 / sr, np.float32)]))
+    assert np.array_equal(y[0, 96:], x[0, :-96])
