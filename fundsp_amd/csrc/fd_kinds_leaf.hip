@@ -25,6 +25,15 @@ void register_leaf_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<WaveSynth<2>>("triangle"));
     out.push_back(make_kind<AdsrLive>("adsr_live"));
     out.push_back(make_kind<Panner>("pan"));
+    out.push_back(make_kind<OnePole<OP_LOWPOLE, 1>>("lowpole_hz"));
+    out.push_back(make_kind<OnePole<OP_LOWPOLE, 2>>("lowpole"));
+    out.push_back(make_kind<OnePole<OP_HIGHPOLE, 1>>("highpole_hz"));
+    out.push_back(make_kind<OnePole<OP_HIGHPOLE, 2>>("highpole"));
+    out.push_back(make_kind<OnePole<OP_DCBLOCK, 1>>("dcblock_hz"));
+    out.push_back(make_kind<OnePole<OP_ALLPOLE, 1>>("allpole_delay"));
+    out.push_back(make_kind<OnePole<OP_ALLPOLE, 2>>("allpole"));
+    out.push_back(make_kind<Pinkpass>("pinkpass"));
+    out.push_back(make_kind<Morph>("morph"));
     out.push_back(make_kind<Delay>("delay"));
     out.push_back(make_kind<TapT<false>>("tap"));
     out.push_back(make_kind<TapT<true>>("tap_linear"));

@@ -1380,6 +1380,126 @@ struct AllNest {
 };
 
 // ---------------------------------------------------------------------------------------------------------
+// one-pole family (filter.rs): Lowpole (ID 18), Highpole (ID 47), DCBlock (ID 22), Pinkpass (ID 26), Allpole (ID 46),
+// and Morph (svf.rs:1040-1111, ID 62).  SURVEY 8(f) row 1: same lane-per-voice skeleton as the biquads.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int OP_LOWPOLE = 0, OP_HIGHPOLE = 1, OP_DCBLOCK = 2, OP_ALLPOLE = 3;
+template <int KIND, int NIN>
+struct OnePole {
+    static constexpr int IN = NIN, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = KIND == OP_LOWPOLE ? 18 : KIND == OP_HIGHPOLE ? 47 : KIND == OP_DCBLOCK ? 22 : 46;
+    float cutoff, sr, coeff, x1, y1;  // Allpole: cutoff = delay (samples), coeff = eta; Lowpole: y1 = value
+    template <class V> FD_HD void visit(V& v) {
+        constexpr FieldKind PK = NIN > 1 ? STATE : PARAM, CK = NIN > 1 ? STATE : COEF;
+        v.f(cutoff, PK, KIND == OP_ALLPOLE ? "delay" : "cutoff");
+        v.f(sr, COEF, "sample_rate");
+        v.f(coeff, CK, "coeff");
+        v.f(x1, STATE, "x1");
+        v.f(y1, STATE, "y1");
+    }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void set_cutoff(float c) {
+        cutoff = c;
+        if (KIND == OP_LOWPOLE || KIND == OP_HIGHPOLE) coeff = expf_musl(-F32_TAU * c / sr);  // filter.rs:35-38, 371-374
+        if (KIND == OP_DCBLOCK) coeff = 1.0f - F32_TAU / sr * c;                               // :121-124
+        if (KIND == OP_ALLPOLE) coeff = (1.0f - c) / (1.0f + c);                               // :292-295
+    }
+    FD_HD void init() { cutoff = KIND == OP_ALLPOLE ? 1.0f : 440.0f; x1 = y1 = 0.0f; }
+    FD_HD void update(double sample_rate) { sr = (float)sample_rate; set_cutoff(cutoff); }
+    FD_HD void reset() { x1 = 0.0f; y1 = 0.0f; }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        if (NIN > 1) {
+            if (KIND == OP_ALLPOLE) set_cutoff(in[1]);            // :317-319 unconditional
+            else if (in[1] != cutoff) set_cutoff(in[1]);          // :57-62, :393-398
+        }
+        const float x = in[0];
+        if (KIND == OP_LOWPOLE) {                                 // :64-66
+            y1 = (1.0f - coeff) * x + coeff * y1;
+            out[0] = y1;
+        } else if (KIND == OP_HIGHPOLE) {                         // :399-403
+            float y0 = coeff * (y1 + x - x1);
+            x1 = x; y1 = y0;
+            out[0] = y0;
+        } else if (KIND == OP_DCBLOCK) {                          // :146-151
+            float y0 = x - x1 + coeff * y1;
+            x1 = x; y1 = y0;
+            out[0] = y0;
+        } else {                                                  // Allpole :320-324
+            float y0 = coeff * (x - y1) + x1;
+            x1 = x; y1 = y0;
+            out[0] = y0;
+        }
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// Pinkpass  filter.rs:178-262 (Paul Kellett's pinking filter)
+struct Pinkpass {
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 26;
+    float b[7];
+    template <class V> FD_HD void visit(V& v) {
+        _Pragma("unroll") for (int i = 0; i < 7; i++) v.fi(b[i], STATE, "b", i);
+    }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void init() { reset(); }
+    FD_HD void update(double) {}
+    FD_HD void reset() { for (int i = 0; i < 7; i++) b[i] = 0.0f; }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // :226-246
+        const float x = in[0];
+        b[0] = (float)0.99886 * b[0] + x * (float)0.0555179;
+        b[1] = (float)0.99332 * b[1] + x * (float)0.0750759;
+        b[2] = (float)0.96900 * b[2] + x * (float)0.1538520;
+        b[3] = (float)0.86650 * b[3] + x * (float)0.3104856;
+        b[4] = (float)0.55000 * b[4] + x * (float)0.5329522;
+        b[5] = (float)-0.7616 * b[5] - x * (float)0.0168980;
+        out[0] = (b[0] + b[1] + b[2] + b[3] + b[4] + b[5] + b[6] + x * (float)0.5362) * (float)0.115830421;
+        b[6] = x * (float)0.115926;
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// Morph<f32>  svf.rs:1040-1111 (ID 62): Svf<PeakMode> + dry mix; inputs (audio, cutoff, q, morph).
+struct Morph {
+    static constexpr int IN = 4, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 62;
+    Svf<3> filter;
+    float morph;
+    template <class V> FD_HD void visit(V& v) {
+        v.enter(0); filter.visit(v); v.leave();
+        v.f(morph, STATE, "morph");
+    }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void init() {  // Morph::new :1046-1061: gain = 0
+        filter.init();
+        filter.mode = (float)SVF_PEAK;
+        filter.gain = 0.0f;
+        morph = 0.0f;
+    }
+    FD_HD void update(double sr) { filter.update(sr); }
+    FD_HD void reset() { filter.reset(); }
+    FD_HD uint64_t ping(bool probe, uint64_t h) { return atto(filter.ping(probe, h), ID); }  // :1108-1110
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // tick :1076-1080 == process :1083-1095
+        morph = in[3];
+        float fo;
+        filter.template step<PH>(in, &fo);
+        out[0] = (fo + in[3] * in[0]) * 0.5f;
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// ---------------------------------------------------------------------------------------------------------
 // combinators
 // ---------------------------------------------------------------------------------------------------------
 

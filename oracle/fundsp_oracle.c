@@ -94,6 +94,9 @@ struct onode {
         float tap_min, tap_max, tap_min_c, tap_max_c, tap_sr, eta, zz;
         float *tbuf;
         size_t tlen, ti;
+        /* one-pole family (filter.rs:19-431), Pinkpass, Morph */
+        int op_kind;
+        float op_coeff, op_x1, op_y1, pink[7], morph;
         /* Shape x2 (shape.rs), PhaseOsc kind, Chaos, nonlinear biquad (biquad.rs:494-920) */
         struct { int kind; float p0, p1, smoothing, state; } sh[2];
         int osc_kind, lorenz, nl_dirty, nl_mode;
@@ -366,6 +369,7 @@ static inline float polyblepf(float t, float dt) { /* oscillator.rs:512-523 */
     return 0.0f;
 }
 static bq_coefs bq_by_mode(int mode, float sr, float center, float q, float gain);
+static void onepole_set(onode *n, float c);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* reset / set_sample_rate / set_hash / ping                                                              */
@@ -419,6 +423,9 @@ static void leaf_reset(onode *n) {
     case O_PHASE_OSC: /* oscillator.rs:449-454 etc. */
         n->s.phase = n->s.has_initial_phase ? n->s.initial_phase : (float)o_rnd1(n->s.hash);
         break;
+    case O_ONEPOLE: n->s.op_x1 = n->s.op_y1 = 0.0f; break;
+    case O_PINKPASS: for (int i = 0; i < 7; i++) n->s.pink[i] = 0.0f; break;
+    case O_MORPH: n->s.ic1eq = n->s.ic2eq = 0.0f; break;
     case O_TAP: /* delay.rs:193-196 */
         n->s.ti = 0;
         for (size_t i = 0; i < n->s.tlen; i++) n->s.tbuf[i] = 0.0f;
@@ -508,6 +515,14 @@ static void leaf_set_sample_rate(onode *n, double sr) {
         break;
     case O_PHASE_OSC: /* oscillator.rs:456-458 */
         n->s.sample_duration = (float)(1.0 / sr);
+        break;
+    case O_ONEPOLE: /* filter.rs:47-50 etc. */
+        n->s.sr = (float)sr;
+        onepole_set(n, n->s.cutoff);
+        break;
+    case O_MORPH: /* svf.rs:1072-1074 -> Svf::set_sample_rate */
+        n->s.sr = (float)sr;
+        n->s.sc = svf_make(O_SVF_PEAK, n->s.sr, n->s.cutoff, n->s.q, n->s.gain);
         break;
     case O_TAP: { /* delay.rs:198-209 / :436-445 */
         float srf = (float)sr;
@@ -803,6 +818,34 @@ onode *o_allnest(float coefficient, onode *x) { /* AllNest::new :313-326, ID 83 
 }
 static inline float splinef(float y0, float y1, float y2, float y3, float x) { /* math.rs:360-366 */
     return y1 + x * 0.5f * (y2 - y0 + x * (2.0f * y0 - 5.0f * y1 + 4.0f * y2 - y3 + x * (3.0f * (y1 - y2) + y3 - y0)));
+}
+
+static void onepole_set(onode *n, float c) {
+    n->s.cutoff = c;
+    switch (n->s.op_kind) {
+    case O_OP_LOWPOLE:
+    case O_OP_HIGHPOLE: n->s.op_coeff = o_expf(-F32_TAU * c / n->s.sr); break; /* filter.rs:35-38, 371-374 */
+    case O_OP_DCBLOCK: n->s.op_coeff = 1.0f - F32_TAU / n->s.sr * c; break;     /* :121-124 */
+    default: n->s.op_coeff = (1.0f - c) / (1.0f + c); break;                    /* Allpole :292-295 */
+    }
+}
+onode *o_onepole(int kind, int inputs, float cutoff_or_delay) { /* ::new filter.rs:28-38,110-119,281-290,364-374 */
+    static const uint64_t ids[4] = {18, 47, 22, 46};
+    onode *n = o_new(O_ONEPOLE, inputs, 1, ids[kind]);
+    n->s.op_kind = kind;
+    n->s.sr = (float)DEFAULT_SR;
+    onepole_set(n, cutoff_or_delay);
+    return n;
+}
+onode *o_pinkpass(void) { return o_new(O_PINKPASS, 1, 1, 26); } /* filter.rs:190-197 */
+onode *o_morph(float cutoff, float q, float morph) { /* Morph::new svf.rs:1046-1061, ID 62 */
+    onode *n = o_new(O_MORPH, 4, 1, 62);
+    n->s.mode = O_SVF_PEAK;
+    n->s.sr = (float)DEFAULT_SR;
+    n->s.cutoff = cutoff; n->s.q = q; n->s.gain = 0.0f;
+    n->s.sc = svf_make(O_SVF_PEAK, n->s.sr, cutoff, q, 0.0f);
+    n->s.morph = morph;
+    return n;
 }
 
 onode *o_shaper(int shape, float p0, float p1) { /* Shaper::new shape.rs:209-215, ID 42 */
@@ -1175,6 +1218,42 @@ void o_tick(onode *n, const float *in, float *out) {
         n->s.ev += n->s.evd;
         n->s.et += n->s.esd;
         break;
+    case O_ONEPOLE: {
+        if (n->nin > 1) {
+            if (n->s.op_kind == O_OP_ALLPOLE) onepole_set(n, in[1]);
+            else if (in[1] != n->s.cutoff) onepole_set(n, in[1]);
+        }
+        float x = in[0], c = n->s.op_coeff, y0;
+        switch (n->s.op_kind) {
+        case O_OP_LOWPOLE: n->s.op_y1 = (1.0f - c) * x + c * n->s.op_y1; out[0] = n->s.op_y1; break;        /* :64-66 */
+        case O_OP_HIGHPOLE: y0 = c * (n->s.op_y1 + x - n->s.op_x1); n->s.op_x1 = x; n->s.op_y1 = y0; out[0] = y0; break;
+        case O_OP_DCBLOCK: y0 = x - n->s.op_x1 + c * n->s.op_y1; n->s.op_x1 = x; n->s.op_y1 = y0; out[0] = y0; break;
+        default: y0 = c * (x - n->s.op_y1) + n->s.op_x1; n->s.op_x1 = x; n->s.op_y1 = y0; out[0] = y0; break;
+        }
+        break;
+    }
+    case O_PINKPASS: { /* filter.rs:226-246 */
+        float x = in[0], *b = n->s.pink;
+        b[0] = (float)0.99886 * b[0] + x * (float)0.0555179;
+        b[1] = (float)0.99332 * b[1] + x * (float)0.0750759;
+        b[2] = (float)0.96900 * b[2] + x * (float)0.1538520;
+        b[3] = (float)0.86650 * b[3] + x * (float)0.3104856;
+        b[4] = (float)0.55000 * b[4] + x * (float)0.5329522;
+        b[5] = (float)-0.7616 * b[5] - x * (float)0.0168980;
+        out[0] = (b[0] + b[1] + b[2] + b[3] + b[4] + b[5] + b[6] + x * (float)0.5362) * (float)0.115830421;
+        b[6] = x * (float)0.115926;
+        break;
+    }
+    case O_MORPH: { /* svf.rs:1076-1080: Svf<PeakMode>::tick on inputs 0..3, then dry mix */
+        n->s.morph = in[3];
+        if (in[1] != n->s.cutoff || in[2] != n->s.q) {
+            n->s.cutoff = in[1]; n->s.q = in[2];
+            n->s.sc = svf_make(O_SVF_PEAK, n->s.sr, in[1], in[2], n->s.gain);
+        }
+        float fo = svf_tick(n, in[0]);
+        out[0] = (fo + in[3] * in[0]) * 0.5f;
+        break;
+    }
     case O_TAP: { /* Tap::tick delay.rs:212-236 / TapLinear::tick :448-463 (the f32x8 process path reads the same samples) */
         size_t mask = n->s.tlen - 1;
         n->s.tbuf[n->s.ti] = in[0];

@@ -17,8 +17,10 @@ typedef struct onode onode;
 enum {
     O_CONSTANT = 0, O_PASS, O_SINE, O_NOISE, O_SVF, O_FIXED_SVF, O_BIQUAD, O_BUTTER_LOWPASS, O_RESONATOR,
     O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP,
-    O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO, O_SHAPER, O_PHASE_OSC, O_CHAOS, O_NLBIQUAD, O_TAP, O_ALLNEST
+    O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO, O_SHAPER, O_PHASE_OSC, O_CHAOS, O_NLBIQUAD, O_TAP, O_ALLNEST,
+    O_ONEPOLE, O_PINKPASS, O_MORPH
 };
+enum { O_OP_LOWPOLE = 0, O_OP_HIGHPOLE, O_OP_DCBLOCK, O_OP_ALLPOLE };
 enum { O_SH_CLIP = 0, O_SH_CLIPTO, O_SH_TANH, O_SH_ATAN, O_SH_SOFTSIGN, O_SH_CRUSH, O_SH_SOFTCRUSH, O_SH_ADAPTIVE_TANH };
 enum { O_OSC_RAMP = 0, O_OSC_POLYSAW, O_OSC_POLYSQUARE, O_OSC_POLYPULSE };
 /* SvfMode order follows src/svf.rs:281-742 */
@@ -57,6 +59,9 @@ onode *o_panner(int inputs, float pan);
 /* Shaper<S> (shape.rs:205); for O_SH_ADAPTIVE_TANH p0 = hardness, p1 = timescale */
 onode *o_tap(int linear, float min_delay, float max_delay);   /* Tap<U1> / TapLinear<U1> (delay.rs:148,386) */
 onode *o_allnest(float coefficient, onode *x);                /* AllNest<U1, X> (delay.rs:294), takes ownership of x */
+onode *o_onepole(int kind, int inputs, float cutoff_or_delay); /* Lowpole/Highpole/DCBlock/Allpole (filter.rs) */
+onode *o_pinkpass(void);
+onode *o_morph(float cutoff, float q, float morph);           /* Morph (svf.rs:1040) */
 onode *o_shaper(int shape, float p0, float p1);
 onode *o_phase_osc(int kind);                       /* Ramp / PolySaw / PolySquare / PolyPulse (oscillator.rs:441-760) */
 void o_osc_set_phase(onode *n, float phase);

@@ -72,6 +72,7 @@ def lib():
         "o_wavetable_create": (P, [i, fp, C.POINTER(C.c_int), fp]), "o_wavetable_free": (None, [P]),
         "o_wavesynth": (P, [P, i]), "o_wavesynth_set_phase": (None, [P, f]),
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
+        "o_onepole": (P, [i, i, f]), "o_pinkpass": (P, []), "o_morph": (P, [f, f, f]),
         "o_tap": (P, [i, f, f]), "o_allnest": (P, [f, P]),
         "o_shaper": (P, [i, f, f]), "o_phase_osc": (P, [i]), "o_osc_set_phase": (None, [P, f]), "o_chaos": (P, [i]),
         "o_nlbiquad": (P, [i, i, i, i, f, f, f, f, f]), "o_math_atanf": (f, [f]), "o_math_wide_atanf": (f, [f]),
@@ -296,6 +297,17 @@ def pan(p): return Node(lib().o_panner(1, p))                         # prelude.
 
 SHAPES = dict(clip=0, clip_to=1, tanh=2, atan=3, softsign=4, crush=5, soft_crush=6, adaptive_tanh=7)
 OSCS = dict(ramp=0, poly_saw=1, poly_square=2, poly_pulse=3)
+
+
+def lowpole_hz(f): return Node(lib().o_onepole(0, 1, f))
+def lowpole(): return Node(lib().o_onepole(0, 2, 440.0))
+def highpole_hz(f): return Node(lib().o_onepole(1, 1, f))
+def highpole(): return Node(lib().o_onepole(1, 2, 440.0))
+def dcblock_hz(f): return Node(lib().o_onepole(2, 1, f))
+def allpole_delay(d): return Node(lib().o_onepole(3, 1, d))
+def allpole(): return Node(lib().o_onepole(3, 2, 1.0))
+def pinkpass(): return Node(lib().o_pinkpass())
+def morph(): return Node(lib().o_morph(440.0, 1.0, 0.0))
 
 
 def tap(min_delay, max_delay): return Node(lib().o_tap(0, min_delay, max_delay))                  # prelude.rs:910

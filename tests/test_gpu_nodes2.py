@@ -134,3 +134,43 @@ def test_modulated_nonlinear_biquads(gpu, kind, dirty, ni):
         n = O.nlbiquad(dirty, ni, mode, "softsign", 0.5, 0.0)
         n.set_sample_rate(SR)
         assert_bit_equal(got[v], n.render_blocks(x[v]), f"{kind} voice {v}")
+
+
+@pytest.mark.parametrize("kind,make", [
+    ("lowpole_hz", lambda p: O.lowpole_hz(p)), ("highpole_hz", lambda p: O.highpole_hz(p)),
+    ("dcblock_hz", lambda p: O.dcblock_hz(p)), ("allpole_delay", lambda p: O.allpole_delay(p)),
+])
+def test_one_pole_filters(gpu, kind, make):
+    V, T = 64, 500
+    rng = np.random.default_rng(61)
+    p = (20.0 * 500.0 ** rng.random(V)).astype(np.float32) if kind != "allpole_delay" else (0.05 + 2 * rng.random(V)).astype(np.float32)
+    b = gpu.Bank(kind, V)
+    b.set_param(":delay" if kind == "allpole_delay" else ":cutoff", p)
+    b.set_sample_rate(SR)
+    x = noise_input(V, 1, T, seed=62)
+    got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    for v in range(0, V, 5):
+        n = make(float(p[v]))
+        n.set_sample_rate(SR)
+        assert_bit_equal(got[v], n.render_blocks(x[v]), f"{kind} voice {v}")
+
+
+@pytest.mark.parametrize("kind,make", [("lowpole", O.lowpole), ("highpole", O.highpole), ("allpole", O.allpole),
+                                       ("pinkpass", O.pinkpass), ("morph", O.morph)])
+def test_one_pole_modulated_pink_morph(gpu, kind, make):
+    V, T = 64, 320
+    rng = np.random.default_rng(63)
+    b = gpu.Bank(kind, V)
+    ni = b.inputs()
+    x = noise_input(V, ni, T, seed=64)
+    if ni >= 2:
+        x[:, 1, :] = np.repeat((0.2 + 3 * rng.random((V, T // 32))) if kind == "allpole" else (100 + 5000 * rng.random((V, T // 32))), 32, axis=1)
+    if ni == 4:
+        x[:, 2, :] = np.repeat(0.5 + 4 * rng.random((V, T // 32)), 32, axis=1)
+        x[:, 3, :] = np.repeat(-1 + 2 * rng.random((V, T // 32)), 32, axis=1)
+    b.set_sample_rate(SR)
+    got = run_bank(b, x, T, LAYOUT_PLANAR, MODE_PROCESS)
+    for v in range(0, V, 9):
+        n = make()
+        n.set_sample_rate(SR)
+        assert_bit_equal(got[v], n.render_blocks(x[v]), f"{kind} voice {v}")

@@ -168,3 +168,21 @@ def test_allpass_property(make):  # test_flow.rs:251-283
     y = node.render_blocks(x)[0]
     mag = np.abs(np.fft.rfft(y.astype(np.float64)))[1:]
     assert np.all(np.abs(mag - 1.0) <= 1e-5)
+
+
+def test_one_pole_family_responses():
+    """test_flow.rs:101-104,112-115: lowpole_hz, dcblock, highpole; closed forms from filter.rs:79-92 (Lowpole),
+    :162-175 (DCBlock), :417-431 (Highpole), :338-349 (Allpole); allpole is allpass (test_flow.rs:256-257)."""
+    for fc in (1000.0, 10000.0):
+        c = float(np.float32(np.exp(-2 * np.pi * fc / SR)))
+        check(O.lowpole_hz(fc), lambda f, c=c: (1 - c) / (1 - c * np.exp(-2j * np.pi * f / SR)), tol=3e-4)
+    c = float(np.float32(np.exp(-2 * np.pi * 5000.0 / SR)))
+    check(O.highpole_hz(5000.0), lambda f: c * (1 - np.exp(-2j * np.pi * f / SR)) / (1 - c * np.exp(-2j * np.pi * f / SR)), tol=3e-4)
+    cd = float(np.float32(1.0 - 2 * np.pi / SR * 100.0))
+    check(O.dcblock_hz(100.0), lambda f: (1 - np.exp(-2j * np.pi * f / SR)) / (1 - cd * np.exp(-2j * np.pi * f / SR)), tol=3e-4)
+    for d in (0.5, 0.8):
+        n = O.allpole_delay(d)
+        x = np.zeros((1, LENGTH), dtype=np.float32)
+        x[0, 0] = 1.0
+        mag = np.abs(np.fft.rfft(n.render_blocks(x)[0].astype(np.float64)))[1:]
+        assert np.all(np.abs(mag - 1.0) <= 1e-5)
