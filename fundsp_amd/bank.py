@@ -47,6 +47,32 @@ class Bank:
         self.sample_rate = _lib.DEFAULT_SR
 
     @classmethod
+    def from_graph(cls, graph, voices, ring_frames=0, sample_rate=None):
+        """Compile `graph` (fundsp_amd.graph notation) into a fused kernel set at run time and build a bank of `voices`
+        instances of it with the graph's parameters applied (scalars to every voice, arrays per voice)."""
+        from . import graph as G
+
+        name = graph.kind_name()
+        rc = lib().fdsp_graph_compile(name.encode(), graph.type.encode())
+        if rc < 0:
+            check(rc)
+        for kind in G.uses_wavetables(graph):
+            if wavetable_get(kind)[0] is None:
+                wavetable_build(kind)
+        b = cls(name, voices, ring_frames=ring_frames)
+        for slot, value, is_u64 in graph.slot_values():
+            if is_u64:
+                v = np.asarray(value, dtype=np.uint64)
+                b.set_param_u64(slot, np.full(voices, v, dtype=np.uint64) if v.ndim == 0 else v)
+            else:
+                v = np.asarray(value, dtype=np.float32)
+                b.set_param(slot, float(v) if v.ndim == 0 else v)
+        if sample_rate is not None:
+            b.set_sample_rate(sample_rate)
+        b.reset()  # builders such as .phase() / .seed() take effect on reset (combinator.rs:263-267)
+        return b
+
+    @classmethod
     def reverb_stereo(cls, instances, room_size, time, damping):
         """Bank of `instances` x reverb_stereo(room_size, time, damping) (32-line FDN, prelude.rs:1732)."""
         h = C.c_void_p()

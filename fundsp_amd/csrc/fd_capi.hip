@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -27,15 +28,20 @@ int fail(int code, const std::string& msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                            \
     } while (0)
 
-std::vector<fd::KindOps>& registry() {
-    static std::vector<fd::KindOps> kinds;
+// Kinds are never removed and banks keep pointers into the table, so entries live in a deque (stable addresses);
+// run-time compiled graphs (fd_jit.cpp) append to it.
+std::deque<fd::KindOps>& registry() {
+    static std::deque<fd::KindOps> kinds;
     static std::once_flag once;
     std::call_once(once, [] {
-        fd::register_leaf_kinds(kinds);
-        fd::register_graph_kinds(kinds);
+        std::vector<fd::KindOps> tmp;
+        fd::register_leaf_kinds(tmp);
+        fd::register_graph_kinds(tmp);
+        for (auto& k : tmp) kinds.push_back(std::move(k));
     });
     return kinds;
 }
+std::mutex g_registry_mutex;
 
 // ---- shared device data (wavetables): one fd::Aux per process, the counterpart of FunDSP's static table singletons ----
 fd::Aux g_host_aux;              // host mirror (data pointers are device pointers)
@@ -272,14 +278,37 @@ const char* fdsp_last_error(void) { return g_err.c_str(); }
 int fdsp_kind_count(void) { return (int)registry().size(); }
 const char* fdsp_kind_name(int kind) {
     auto& r = registry();
-    return (kind >= 0 && kind < (int)r.size()) ? r[kind].name : nullptr;
+    return (kind >= 0 && kind < (int)r.size()) ? r[kind].name.c_str() : nullptr;
 }
 int fdsp_kind_by_name(const char* name) {
     auto& r = registry();
     if (!name) return -1;
     for (size_t i = 0; i < r.size(); i++)
-        if (std::strcmp(r[i].name, name) == 0) return (int)i;
+        if (r[i].name == name) return (int)i;
     return -1;
+}
+
+int fdsp_graph_compile(const char* name, const char* type_expr) {
+    if (!name || !type_expr || !*name || !*type_expr) return fail(FDSP_EINVAL, "name or type expression missing");
+    int existing = fdsp_kind_by_name(name);
+    if (existing >= 0) return existing;  // kinds are immutable: a second compile of the same name is a lookup
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(FDSP_EDEVICE, "no HIP device available: compiled graphs are loaded onto the device");
+    fd::KindOps k;
+    std::string err;
+    if (fd::jit_make_kind(name, type_expr, &k, &err) != 0) return fail(FDSP_EINVAL, err);
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    registry().push_back(std::move(k));
+    return (int)registry().size() - 1;
+}
+
+int fdsp_graph_check(const char* type_expr) {
+    if (!type_expr) return fail(FDSP_EINVAL, "type expression missing");
+    std::vector<char> code;
+    std::string log;
+    if (fd::jit_compile_code(type_expr, &code, &log) != 0) return fail(FDSP_EINVAL, log);
+    return FDSP_OK;
 }
 
 int fdsp_kind_inputs(int kind) {

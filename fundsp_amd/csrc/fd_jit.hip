@@ -1,0 +1,186 @@
+// fd_jit.hip -- run-time compilation of arbitrary voice graphs (graph -> kernel compiler).
+//
+// FunDSP builds a graph as a statically typed combinator tree (An<Pipe<Pipe<Constant<U1>,Sine<f32>>,FixedSvf<..>>>);
+// fd_nodes.hpp mirrors those types as device templates.  The ahead-of-time "kinds" instantiate a fixed set of them;
+// this file instantiates ANY type expression over the same templates at run time: hiprtc compiles the very headers the
+// library was built from (fd_math.hpp, fd_nodes.hpp, fd_device.hpp, read from fundsp_amd/csrc next to the .so) with the
+// same flags (-O3, -ffp-contract=off), so a JIT kind is sample-identical to the same graph compiled ahead of time.
+// No tracing, no IR: the "compiler" is the C++ template instantiation itself.
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+
+#include "fd_engine.hpp"
+
+namespace fd {
+
+namespace {
+
+std::string lib_dir() {
+    Dl_info info;
+    if (dladdr((void*)&lib_dir, &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        size_t k = p.find_last_of('/');
+        return k == std::string::npos ? "." : p.substr(0, k);
+    }
+    return ".";
+}
+
+bool read_file(const std::string& path, std::string* out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    *out = ss.str();
+    return true;
+}
+
+struct JitModule {
+    hipModule_t mod = nullptr;
+    hipFunction_t lifecycle = nullptr, describe = nullptr;
+    hipFunction_t render[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [mode][layout]
+    int wpb[2] = {4, 4};                                                     // per layout
+    ~JitModule() {
+        if (mod) hipModuleUnload(mod);
+    }
+};
+
+}  // namespace
+
+std::string jit_source(const std::string& type_expr) {
+    std::string s;
+    s += "#include \"fd_device.hpp\"\n";
+    s += "namespace fd { using JitG = " + type_expr + "; }\n";
+    s += "using fd::JitG;\n";
+    s += "constexpr int JIT_WPB0 = fd::RenderGeom<JitG, 0>::WPB;\nconstexpr int JIT_WPB1 = fd::RenderGeom<JitG, 1>::WPB;\n";
+    s += "extern \"C\" __global__ __launch_bounds__(64) void jit_lifecycle(float* slots, size_t stride, size_t first, "
+         "size_t count, int op, double sr, const uint64_t* seeds, const void* aux, float* ring, uint32_t cap) {\n"
+         "  fd::lifecycle_body<JitG>(slots, stride, first, count, op, sr, seeds, aux, ring, cap); }\n";
+    for (int mode = 0; mode < 2; mode++)
+        for (int layout = 0; layout < 2; layout++) {
+            std::string m = std::to_string(mode), l = std::to_string(layout);
+            s += "extern \"C\" __global__ __launch_bounds__(64 * JIT_WPB" + l + ") void jit_render_" + m + l +
+                 "(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ out, "
+                 "size_t T, size_t fstride, const void* aux, float* ring, uint32_t cap) {\n"
+                 "  fd::render_body<JitG, " + m + ", " + l + ", JIT_WPB" + l +
+                 ">(slots, stride, V, in, out, T, fstride, aux, ring, cap); }\n";
+        }
+    s += "extern \"C\" __global__ void jit_describe(char* out, int cap, int* meta) { fd::describe_body<JitG>(out, cap, meta); }\n";
+    return s;
+}
+
+// Compile only (no device needed): returns the code object or an error log.
+int jit_compile_code(const std::string& type_expr, std::vector<char>* code, std::string* log) {
+    const std::string dir = lib_dir() + "/csrc/";
+    const char* names[3] = {"fd_math.hpp", "fd_nodes.hpp", "fd_device.hpp"};
+    std::string hdr[3];
+    for (int i = 0; i < 3; i++)
+        if (!read_file(dir + names[i], &hdr[i])) {
+            *log = "cannot read " + dir + names[i] + " (the JIT compiles the engine's own headers)";
+            return -1;
+        }
+    const char* hsrc[3] = {hdr[0].c_str(), hdr[1].c_str(), hdr[2].c_str()};
+    const std::string src = jit_source(type_expr);
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "fdsp_jit_graph.hip", 3, hsrc, names) != HIPRTC_SUCCESS) {
+        *log = "hiprtcCreateProgram failed";
+        return -1;
+    }
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+    hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    if (ls > 1) {
+        log->resize(ls);
+        hiprtcGetProgramLog(prog, &(*log)[0]);
+    }
+    if (r != HIPRTC_SUCCESS) {
+        *log = "hiprtc: " + std::string(hiprtcGetErrorString(r)) + " while compiling graph type `" + type_expr + "`:\n" + *log;
+        hiprtcDestroyProgram(&prog);
+        return -1;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    code->resize(cs);
+    hiprtcGetCode(prog, code->data());
+    hiprtcDestroyProgram(&prog);
+    return 0;
+}
+
+int jit_make_kind(const std::string& name, const std::string& type_expr, KindOps* out, std::string* err) {
+    std::vector<char> code;
+    if (jit_compile_code(type_expr, &code, err) != 0) return -1;
+    auto jm = std::make_shared<JitModule>();
+    if (hipModuleLoadData(&jm->mod, code.data()) != hipSuccess) {
+        *err = "hipModuleLoadData failed for the compiled graph";
+        return -1;
+    }
+    bool ok = hipModuleGetFunction(&jm->lifecycle, jm->mod, "jit_lifecycle") == hipSuccess &&
+              hipModuleGetFunction(&jm->describe, jm->mod, "jit_describe") == hipSuccess;
+    for (int m = 0; m < 2 && ok; m++)
+        for (int l = 0; l < 2 && ok; l++) {
+            std::string fn = "jit_render_" + std::to_string(m) + std::to_string(l);
+            ok = hipModuleGetFunction(&jm->render[m][l], jm->mod, fn.c_str()) == hipSuccess;
+        }
+    if (!ok) {
+        *err = "compiled graph is missing an entry point";
+        return -1;
+    }
+    // slot introspection on the device (the AOT kinds run the same visit() on the host)
+    const int cap = 1 << 16;
+    char* d_txt = nullptr;
+    int* d_meta = nullptr;
+    if (hipMalloc((void**)&d_txt, cap) != hipSuccess || hipMalloc((void**)&d_meta, 8 * sizeof(int)) != hipSuccess) {
+        *err = "hipMalloc failed";
+        return -1;
+    }
+    int cap_arg = cap;
+    void* dargs[] = {&d_txt, &cap_arg, &d_meta};
+    hipError_t e = hipModuleLaunchKernel(jm->describe, 1, 1, 1, 1, 1, 1, 0, nullptr, dargs, nullptr);
+    std::vector<char> txt(cap);
+    int meta[8] = {0};
+    if (e == hipSuccess) e = hipMemcpy(txt.data(), d_txt, cap, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(meta, d_meta, sizeof meta, hipMemcpyDeviceToHost);
+    hipFree(d_txt);
+    hipFree(d_meta);
+    if (e != hipSuccess) {
+        *err = std::string("describe kernel failed: ") + hipGetErrorString(e);
+        return -1;
+    }
+    out->name = name;
+    out->nin = meta[0];
+    out->nout = meta[1];
+    out->nrings = meta[2];
+    jm->wpb[LAYOUT_VOICE_MINOR] = 4;
+    jm->wpb[LAYOUT_PLANAR] = meta[4];
+    out->slots.clear();
+    std::istringstream lines(std::string(txt.data(), (size_t)meta[3]));
+    std::string line;
+    while (std::getline(lines, line)) {
+        size_t sp = line.find_last_of(' ');
+        if (sp == std::string::npos) continue;
+        out->slots.push_back({line.substr(0, sp), std::atoi(line.c_str() + sp + 1)});
+    }
+    out->lifecycle = [jm](float* slots, size_t stride, size_t first, size_t count, int op, double sr,
+                          const uint64_t* d_seeds, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
+        if (count == 0) return;
+        void* args[] = {&slots, &stride, &first, &count, &op, &sr, &d_seeds, &aux, &ring, &ring_cap};
+        hipModuleLaunchKernel(jm->lifecycle, (unsigned)((count + 63) / 64), 1, 1, 64, 1, 1, 0, s, args, nullptr);
+    };
+    out->render = [jm](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T, size_t fstride,
+                       int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
+        if (V == 0 || T == 0) return;
+        const int wpb = jm->wpb[layout];
+        const size_t waves = (V + 63) / 64;
+        void* args[] = {&slots, &stride, &V, &in, &outp, &T, &fstride, &aux, &ring, &ring_cap};
+        hipModuleLaunchKernel(jm->render[mode][layout], (unsigned)((waves + wpb - 1) / wpb), 1, 1, 64 * wpb, 1, 1, 0, s,
+                              args, nullptr);
+    };
+    return 0;
+}
+
+}  // namespace fd

@@ -16,8 +16,16 @@
 // Build with -ffp-contract=off: Rust never contracts a*b+c and parity with the CPU path depends on it.
 #pragma once
 
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else  // hiprtc (fd_jit.hip): no system headers; its built-in runtime header keeps the fixed-width types in a namespace
+using __hip_internal::int32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
+typedef unsigned long uintptr_t;
+#endif
 
 #define FD_HD __host__ __device__ __forceinline__
 

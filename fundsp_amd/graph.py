@@ -1,0 +1,165 @@
+"""FunDSP graph notation on the host, lowered to a run-time compiled voice-bank kernel.
+
+This mirrors the part of the reference's `prelude32` + `combinator.rs` surface that describes a *voice*: the same opcode
+names (`sine_hz`, `lowpass_hz`, `moog`, `saw`, `adsr_live`, `pan`, ...) and the same operators (`>>` Pipe, `|` Stack,
+`*`/`+`/`-` between nodes = Binop, with numbers = Unop; Python's precedence of these operators matches Rust's), so a
+graph reads like its Rust original:
+
+    g = sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q)          # README.md:98-103
+    bank = Bank.from_graph(g, voices=65536)
+
+Every numeric argument may be a scalar (all voices) or a length-`voices` array (one value per voice).  A graph object is
+only a description: `type` is the combinator type FunDSP would build, spelled with the device templates of
+fundsp_amd/csrc/fd_nodes.hpp, and `params` the per-node parameter values addressed the way the C ABI names slots
+("<path>:<field>").  The arithmetic runs on the GPU through the C ABI (fdsp_graph_compile + fdsp_bank_*).
+"""
+import hashlib
+
+import numpy as np
+
+from .bank import BQ_KINDS, SVF_MODES
+
+SHAPES = dict(clip=0, clip_to=1, tanh=2, atan=3, softsign=4, crush=5, soft_crush=6, adaptive_tanh=7)
+
+
+class Graph:
+    __array_ufunc__ = None  # let `ndarray * Graph` reach Graph.__rmul__
+
+    def __init__(self, type_str, nin, nout, params=(), rings=0):
+        self.type, self.nin, self.nout, self.rings = type_str, nin, nout, rings
+        self.params = list(params)  # (path tuple, field, value, is_u64)
+
+    # --- combinators (combinator.rs:289-488)
+    def _pair(self, other, tmpl, nin, nout):
+        ps = [((0,) + p, f, v, u) for p, f, v, u in self.params] + [((1,) + p, f, v, u) for p, f, v, u in other.params]
+        return Graph(f"{tmpl}<{self.type},{other.type}>", nin, nout, ps, self.rings + other.rings)
+
+    def __rshift__(self, other):
+        if self.nout != other.nin:
+            raise TypeError(f"Pipe arity mismatch: {self.nout} outputs >> {other.nin} inputs")
+        return self._pair(other, "Pipe", self.nin, other.nout)
+
+    def __or__(self, other):
+        return self._pair(other, "Stack", self.nin + other.nin, self.nout + other.nout)
+
+    def _binop(self, other, op):
+        if self.nout != other.nout:
+            raise TypeError("Binop arity mismatch")
+        ps = [((0,) + p, f, v, u) for p, f, v, u in self.params] + [((1,) + p, f, v, u) for p, f, v, u in other.params]
+        return Graph(f"Binop<{op},{self.type},{other.type}>", self.nin + other.nin, self.nout, ps, self.rings + other.rings)
+
+    def _unop(self, u, scalar=None):
+        ps = [((0,) + p, f, v, uu) for p, f, v, uu in self.params]
+        if scalar is not None:
+            ps.append(((), "scalar", scalar, False))
+        return Graph(f"Unop<{self.type},{u}>", self.nin, self.nout, ps, self.rings)
+
+    def __mul__(self, o): return self._binop(o, "OpMul") if isinstance(o, Graph) else self._unop("UMulScalar", o)
+    def __rmul__(self, o): return self._unop("UMulScalar", o)
+    def __add__(self, o): return self._binop(o, "OpAdd") if isinstance(o, Graph) else self._unop("UAddScalar", o)
+    def __radd__(self, o): return self._unop("UAddScalar", o)
+    def __sub__(self, o): return self._binop(o, "OpSub") if isinstance(o, Graph) else self._unop("UAddScalar", -np.asarray(o, dtype=np.float32))
+    def __rsub__(self, o): return self._unop("UNegAddScalar", o)
+    def __neg__(self): return self._unop("UNeg")
+
+    # --- builders (combinator.rs:263-267)
+    def _set(self, field, value, u64=False):
+        self.params.append(((), field, value, u64))
+        return self
+
+    def phase(self, p):
+        self._set("has_initial_phase", 1.0)
+        return self._set("initial_phase", p)
+
+    def seed(self, s):
+        self._set("has_seed", 1.0)
+        return self._set("seed", s, u64=True)
+
+    def kind_name(self):
+        return "jit_" + hashlib.sha1(self.type.encode()).hexdigest()[:16]
+
+    def slot_values(self):
+        """[(slot name, value, is_u64)] in assignment order."""
+        return [(".".join(str(i) for i in p) + ":" + f, v, u) for p, f, v, u in self.params]
+
+
+def _leaf(t, nin, nout, rings=0, **fields):
+    return Graph(t, nin, nout, [((), k, v, False) for k, v in fields.items()], rings)
+
+
+# --- prelude32 opcodes -------------------------------------------------------------------------------------------
+def constant(*v): return Graph(f"Constant<{len(v)}>", 0, len(v), [((), f"value[{i}]", x, False) for i, x in enumerate(v)])
+dc = constant
+def pass_(): return _leaf("Pass", 1, 1)
+def tick(): return _leaf("Tick<1>", 1, 1)
+def sine(): return _leaf("Sine", 1, 1)
+def sine_hz(f): return constant(f) >> sine()
+def noise(): return _leaf("Noise", 0, 1)
+white = noise
+def _fsvf(mode, f, q, gain=1.0): return _leaf("FixedSvf", 1, 1, mode=float(SVF_MODES[mode]), cutoff=f, q=q, gain=gain)
+def lowpass_hz(f, q): return _fsvf("lowpass", f, q)
+def highpass_hz(f, q): return _fsvf("highpass", f, q)
+def bandpass_hz(f, q): return _fsvf("bandpass", f, q)
+def notch_hz(f, q): return _fsvf("notch", f, q)
+def peak_hz(f, q): return _fsvf("peak", f, q)
+def allpass_hz(f, q): return _fsvf("allpass", f, q)
+def bell_hz(f, q, gain): return _fsvf("bell", f, q, gain)
+def lowshelf_hz(f, q, gain): return _fsvf("lowshelf", f, q, gain)
+def highshelf_hz(f, q, gain): return _fsvf("highshelf", f, q, gain)
+def _svf(mode): return _leaf("Svf<4>" if SVF_MODES[mode] >= 6 else "Svf<3>", 4 if SVF_MODES[mode] >= 6 else 3, 1, mode=float(SVF_MODES[mode]))
+def lowpass(): return _svf("lowpass")
+def highpass(): return _svf("highpass")
+def bandpass(): return _svf("bandpass")
+def notch(): return _svf("notch")
+def peak(): return _svf("peak")
+def allpass(): return _svf("allpass")
+def bell(): return _svf("bell")
+def lowshelf(): return _svf("lowshelf")
+def highshelf(): return _svf("highshelf")
+def morph(): return _leaf("Morph", 4, 1)
+def biquad(a1, a2, b0, b1, b2): return _leaf("Biquad", 1, 1, a1=a1, a2=a2, b0=b0, b1=b1, b2=b2)
+def butterpass_hz(f): return _leaf("ButterLowpass<1>", 1, 1, cutoff=f)
+def butterpass(): return _leaf("ButterLowpass<2>", 2, 1)
+def resonator_hz(center, bandwidth): return _leaf("Resonator<1>", 1, 1, center=center, q=bandwidth)
+def resonator(): return _leaf("Resonator<3>", 3, 1)
+def moog_hz(f, q): return _leaf("Moog<1>", 1, 1, cutoff=f, q=q)
+def moog(): return _leaf("Moog<3>", 3, 1)
+def fir(*w): return Graph(f"Fir<{len(w)}>", 1, 1, [((), f"w[{i}]", x, False) for i, x in enumerate(w)])
+def fir3(gain):  # prelude.rs:863-867 (f32 arithmetic)
+    g = np.asarray(gain, dtype=np.float32)
+    alpha = (g + np.float32(1.0)) / np.float32(2.0)
+    beta = (np.float32(1.0) - alpha) / np.float32(2.0)
+    return fir(beta, alpha, beta)
+def lowpole_hz(f): return _leaf("OnePole<OP_LOWPOLE,1>", 1, 1, cutoff=f)
+def lowpole(): return _leaf("OnePole<OP_LOWPOLE,2>", 2, 1)
+def highpole_hz(f): return _leaf("OnePole<OP_HIGHPOLE,1>", 1, 1, cutoff=f)
+def highpole(): return _leaf("OnePole<OP_HIGHPOLE,2>", 2, 1)
+def dcblock_hz(f): return _leaf("OnePole<OP_DCBLOCK,1>", 1, 1, cutoff=f)
+def allpole_delay(d): return _leaf("OnePole<OP_ALLPOLE,1>", 1, 1, delay=d)
+def allpole(): return _leaf("OnePole<OP_ALLPOLE,2>", 2, 1)
+def pinkpass(): return _leaf("Pinkpass", 1, 1)
+def delay(t): return _leaf("Delay", 1, 1, rings=1, time=t)
+def tap(min_delay, max_delay): return _leaf("TapT<false>", 2, 1, rings=1, min_delay=min_delay, max_delay=max_delay)
+def tap_linear(min_delay, max_delay): return _leaf("TapT<true>", 2, 1, rings=1, min_delay=min_delay, max_delay=max_delay)
+def allnest_c(coefficient, x):
+    return Graph(f"AllNest<{x.type}>", 1, 1, [((0,) + p, f, v, u) for p, f, v, u in x.params] + [((), "coefficient", coefficient, False)], x.rings)
+def saw(): return _leaf("WaveSynth<0>", 1, 1)
+def square(): return _leaf("WaveSynth<1>", 1, 1)
+def triangle(): return _leaf("WaveSynth<2>", 1, 1)
+def saw_hz(f): return constant(f) >> saw()
+def square_hz(f): return constant(f) >> square()
+def triangle_hz(f): return constant(f) >> triangle()
+def ramp(): return _leaf("PhaseOsc<OSC_RAMP>", 1, 1)
+def poly_saw(): return _leaf("PhaseOsc<OSC_POLYSAW>", 1, 1)
+def poly_square(): return _leaf("PhaseOsc<OSC_POLYSQUARE>", 1, 1)
+def poly_pulse(): return _leaf("PhaseOsc<OSC_POLYPULSE>", 2, 1)
+def rossler(): return _leaf("Chaos<false>", 1, 1)
+def lorenz(): return _leaf("Chaos<true>", 1, 1)
+def adsr_live(a, d, s, r): return _leaf("AdsrLive", 1, 1, attack=a, decay=d, sustain=s, release=r)
+def pan(p): return _leaf("Panner", 1, 2, pan=p)
+def shape(kind, p0=1.0, p1=0.0, smoothing=0.0):
+    return _leaf("Shaper", 1, 1, shape=float(SHAPES[kind]), shape_p0=p0, shape_p1=p1, shape_smoothing=smoothing)
+
+
+def uses_wavetables(g):
+    return [k for k, t in (("saw", "WaveSynth<0>"), ("square", "WaveSynth<1>"), ("triangle", "WaveSynth<2>")) if t in g.type]

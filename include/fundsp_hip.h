@@ -90,6 +90,17 @@ const char* fdsp_last_error(void);
 int fdsp_kind_count(void);
 const char* fdsp_kind_name(int kind);
 int fdsp_kind_by_name(const char* name); /* -1 if unknown */
+/* ---- run-time compiled voice graphs (graph -> kernel compiler) -------------------------------------------
+ * `type_expr` is the graph's combinator TYPE, exactly what FunDSP's operators build (src/combinator.rs:289-488),
+ * spelled with the engine's node templates (fundsp_amd/csrc/fd_nodes.hpp), e.g.
+ *     sine_hz(f) >> lowpass_hz(fc, q)   ==  "Pipe<Pipe<Constant<1>,Sine>,FixedSvf>"
+ *     (noise() | dc(fc) | dc(q)) >> moog()  ==  "Pipe<Stack<Stack<Noise,Constant<1>>,Constant<1>>,Moog<3>>"
+ * The graph is compiled with hiprtc from the library's own headers (same flags as the ahead-of-time kinds) into one
+ * fused kernel set and registered under `name`; fdsp_bank_create(name, ..) then works as for built-in kinds.
+ * Returns the kind index (>= 0) or a negative error (fdsp_last_error() holds the compiler log).
+ * fdsp_graph_check() only compiles (no device needed) -- a syntax / arity check of a type expression. */
+int fdsp_graph_compile(const char* name, const char* type_expr);
+int fdsp_graph_check(const char* type_expr);
 /* Host-only introspection of a kind (no device needed): arity and the named per-voice slots. */
 int fdsp_kind_inputs(int kind);
 int fdsp_kind_outputs(int kind);

@@ -210,7 +210,7 @@ def lowpass(): return svf("lowpass")                               # prelude.rs:
 def biquad(a1, a2, b0, b1, b2): return Node(lib().o_biquad(a1, a2, b0, b1, b2))
 def butterpass_hz(f): return Node(lib().o_butter_lowpass(1, f))
 def butterpass(): return Node(lib().o_butter_lowpass(2, 440.0))
-def resonator_hz(center, bandwidth): return Node(lib().o_resonator(1, center, center / bandwidth))
+def resonator_hz(center, bandwidth): return Node(lib().o_resonator(1, center, bandwidth))  # prelude32.rs:534: passed straight to Resonator::new
 def biquad_bank(): return Node(lib().o_biquad_bank())
 def moog_hz(f, q): return Node(lib().o_moog(1, f, q))
 def moog(): return Node(lib().o_moog(3, 1000.0, 0.1))             # prelude.rs:551-553

@@ -91,3 +91,26 @@ def test_product_does_not_reference_the_oracle():
                     if re.search(r"fundsp_oracle|o_math\.h|libfundsp_oracle|import oracle|from oracle", txt):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_graph_notation_lowers_to_reference_types_and_compiles(F):
+    """The host graph notation builds the combinator TYPE FunDSP's operators would build (combinator.rs:289-488, Rust
+    precedence `*` > `+` > `>>` > `|`), and hiprtc accepts it (compile only: no device needed)."""
+    from fundsp_amd import graph as G
+
+    g = G.sine_hz(440.0) * 440.0 * 2.0 + 440.0 >> G.sine() >> G.lowpass_hz(1000.0, 1.0)
+    assert g.type == "Pipe<Pipe<Unop<Unop<Unop<Pipe<Constant<1>,Sine>,UMulScalar>,UMulScalar>,UAddScalar>,Sine>,FixedSvf>"
+    assert (g.nin, g.nout) == (0, 1)
+    names = [n for n, _, _ in g.slot_values()]
+    assert names[:4] == ["0.0.0.0.0.0:value[0]", "0.0.0.0:scalar", "0.0.0:scalar", "0.0:scalar"]
+    aot = dict(F.kind_slots("fm_svf"))
+    assert all(n in aot for n in names)                      # same slot addressing as the ahead-of-time kind
+    c4 = ((G.dc(110.0) >> G.saw() | G.dc(800.0) | G.dc(0.3)) >> G.moog()) * G.adsr_live(.01, .1, .6, .2) >> G.pan(0.2)
+    assert c4.type == ("Pipe<Binop<OpMul,Pipe<Stack<Stack<Pipe<Constant<1>,WaveSynth<0>>,Constant<1>>,Constant<1>>,Moog<3>>,"
+                       "AdsrLive>,Panner>") and (c4.nin, c4.nout) == (1, 2)
+    L = F.lib()
+    assert L.fdsp_graph_check(g.type.encode()) == 0
+    assert L.fdsp_graph_check(b"Pipe<Noise,AllNest<Delay>>") == 0
+    assert L.fdsp_graph_check(b"Pipe<Sine,Stack<Sine,Sine>>") < 0 and b"arity mismatch" in L.fdsp_last_error()
+    with pytest.raises(TypeError):
+        G.sine() >> (G.sine() | G.sine())
