@@ -101,3 +101,25 @@ def test_allreduce_mix_is_identity_without_process_group():
 
     t = torch.arange(6, dtype=torch.float32).reshape(2, 3)
     assert fdist.allreduce_mix(t.clone()).equal(t)
+
+
+def test_wav_sink_layout(tmp_path):
+    """write.rs:26-116: header fields and interleaving; read back with an independent reader (scipy)."""
+    import struct
+
+    from scipy.io import wavfile
+
+    from fundsp_amd import wav
+
+    x = np.stack([np.linspace(-1, 1, 100, dtype=np.float32), np.linspace(1, -1, 100, dtype=np.float32) * 0.5])
+    b = wav.wav32_bytes(x, 48000.0)
+    assert b[:4] == b"RIFF" and b[8:16] == b"WAVEfmt " and b[36:40] == b"data" and len(b) == 44 + 800
+    assert struct.unpack("<I", b[4:8])[0] == 800 + 36 and struct.unpack("<HHI", b[20:28]) == (3, 2, 48000)
+    assert struct.unpack("<IHH", b[28:36]) == (48000 * 2 * 4, 8, 32)
+    p32, p16 = tmp_path / "a32.wav", tmp_path / "a16.wav"
+    wav.save_wav32(p32, x, 48000.0)
+    wav.save_wav16(p16, x, 48000.0)
+    sr, y = wavfile.read(p32)
+    assert sr == 48000 and np.array_equal(y.T, x)
+    sr, y16 = wavfile.read(p16)
+    assert y16.dtype == np.int16 and y16[0, 0] == -32767 and y16[-1, 0] == 32767 and abs(int(y16[0, 1]) - 16384) <= 1
