@@ -204,8 +204,10 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "kernel": (f"fd::k_render<{'fm_svf' if args.config == 3 else 'saw_moog_adsr_pan'}, {args.mode}, {args.layout}>"
-                           if args.config != 5 else "fd::k_fdn_render"),
+                "kernel": {3: f"fd::k_render_split<fm_svf, cut after stage 1, {args.mode}> (two-wave pipeline, voice_minor)"
+                              if args.layout == "voice_minor" else f"fd::k_render<fm_svf, {args.mode}, planar>",
+                           4: f"fd::k_render<saw_moog_adsr_pan, {args.mode}, {args.layout}>",
+                           5: "fd::k_fdn_render"}[args.config],
                 "kernel_ms_avg": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },

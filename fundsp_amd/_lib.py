@@ -22,6 +22,7 @@ SYMBOLS = {
     "fdsp_kind_count": (_i, []),
     "fdsp_kind_name": (_cs, [_i]),
     "fdsp_kind_by_name": (_i, [_cs]),
+    "fdsp_set_option": (_i, [_cs, _i]),
     "fdsp_graph_compile": (_i, [_cs, _cs]),
     "fdsp_graph_check": (_i, [_cs]),
     "fdsp_kind_inputs": (_i, [_i]),

@@ -15,6 +15,9 @@
 namespace {
 
 thread_local std::string g_err;
+}
+namespace fd { int g_pipe_split = 1; }
+namespace {
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -286,6 +289,14 @@ int fdsp_kind_by_name(const char* name) {
     for (size_t i = 0; i < r.size(); i++)
         if (r[i].name == name) return (int)i;
     return -1;
+}
+
+int fdsp_set_option(const char* name, int value) {
+    if (name && std::strcmp(name, "pipe_split") == 0) {
+        fd::g_pipe_split = value ? 1 : 0;
+        return FDSP_OK;
+    }
+    return fail(FDSP_EINVAL, "unknown option");
 }
 
 int fdsp_graph_compile(const char* name, const char* type_expr) {

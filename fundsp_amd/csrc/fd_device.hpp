@@ -332,6 +332,302 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
     render_body<G, MODE, LAYOUT, WPB>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
 }
 
+// ---- two-wave pipeline split of a Pipe chain --------------------------------------------------------------------
+// At one voice-wave per SIMD (65 536 voices on 1024 SIMDs) a lone wave issues one instruction per ~4.7 cycles while
+// the VALU could take one every ~3.3 (profiles/r01_voice_sweep_*).  For graphs that are a chain A >> B >> C ... the
+// chain is cut once: the PREFIX stages of 64 voices run in one wave, the SUFFIX stages of the same voices in a second
+// wave one 64-sample block behind, the cut's channels handed over through a double-buffered LDS tile.  Both waves
+// keep their own part of the voice state in registers; the per-sample arithmetic of every node is untouched, so the
+// output is bit-identical to the single-wave kernel -- only the issue slots of the SIMD are now fed by two waves.
+template <class T> struct Cost { static constexpr int v = 12; };  // rough VALU instructions per sample (cut placement only)
+template <int N> struct Cost<Constant<N>> { static constexpr int v = 0; };
+template <> struct Cost<Pass> { static constexpr int v = 0; };
+template <> struct Cost<Sine> { static constexpr int v = 28; };
+template <> struct Cost<Noise> { static constexpr int v = 10; };
+template <> struct Cost<FixedSvf> { static constexpr int v = 12; };
+template <int N> struct Cost<Moog<N>> { static constexpr int v = 130; };
+template <int S> struct Cost<WaveSynth<S>> { static constexpr int v = 100; };
+template <> struct Cost<AdsrLive> { static constexpr int v = 80; };
+template <> struct Cost<Shaper> { static constexpr int v = 60; };
+template <> struct Cost<Panner> { static constexpr int v = 2; };
+template <class X, class Y> struct Cost<Pipe<X, Y>> { static constexpr int v = Cost<X>::v + Cost<Y>::v; };
+template <class X, class Y> struct Cost<Stack<X, Y>> { static constexpr int v = Cost<X>::v + Cost<Y>::v; };
+template <class O, class X, class Y> struct Cost<Binop<O, X, Y>> { static constexpr int v = Cost<X>::v + Cost<Y>::v + 1; };
+template <class X, class U> struct Cost<Unop<X, U>> { static constexpr int v = Cost<X>::v + 1; };
+
+template <class G> struct Chain { static constexpr int N = 1; };  // cut points of a (nested) Pipe chain = N - 1
+template <class X, class Y> struct Chain<Pipe<X, Y>> { static constexpr int N = Chain<X>::N + Chain<Y>::N; };
+// (A cut INSIDE Sine -- phase recurrence | polynomial -- balances config 3 at 35 | 36 instructions but measured slower
+// (6.41 ms vs 5.93 ms): with both waves busy all the time the packed-f32 VALU pipe, not issue, is the limit.  The
+// Split<1, Sine> specialisation below is kept for experiments: enable it with Chain<Sine>::N = 2.)
+
+struct VGate {  // forwards to a slot visitor only while enabled; always advances the slot counter
+    template <class V> struct W {
+        V* v;
+        bool on;
+        FD_D void f(float& x, FieldKind k, const char* n) { if (on) v->f(x, k, n); else v->slot++; }
+        FD_D void fi(float& x, FieldKind k, const char* n, int i) { if (on) v->fi(x, k, n, i); else v->slot++; }
+        FD_D void u32(uint32_t& x, FieldKind k, const char* n) { if (on) v->u32(x, k, n); else v->slot++; }
+        FD_D void u64(uint64_t& x, FieldKind k, const char* n) { if (on) v->u64(x, k, n); else v->slot += 2; }
+        FD_D void enter(int) {}
+        FD_D void leave() {}
+    };
+};
+
+template <int K, class G> struct Split;  // K = number of chain stages in the prefix (1 .. N-1)
+
+// Sine cut in the middle: the prefix owns the serial phase recurrence (all of Sine's state) and hands over the angle
+// of the block path (or, on the tick path, the finished sample); the suffix owns the pure polynomial and its guard.
+template <>
+struct Split<1, Sine> {
+    static constexpr int mid() { return 1; }
+    static constexpr int pre_cost() { return 4; }
+    template <int PH> static FD_D void pre_step2(Sine& g, const v2f* in, v2f* out) {
+        if constexpr (PH == PH_SIMD) {
+            v2f d = in[0] * g.sample_duration;
+            float t0 = g.phase;
+            g.phase += d.x;
+            float t1 = g.phase;
+            g.phase += d.y;
+            out[0] = v2f{t0, t1} * F32_TAU;
+        } else {
+            g.template step2<PH>(in, out);
+        }
+    }
+    template <int PH> static FD_D void pre_step(Sine& g, const float* in, float* out) {
+        if constexpr (PH == PH_SIMD) {
+            float tmp = g.phase;
+            g.phase += in[0] * g.sample_duration;
+            out[0] = tmp * F32_TAU;
+        } else {
+            g.template step<PH>(in, out);
+        }
+    }
+    template <int PH> static FD_D void suf_step2(Sine& g, const v2f* in, v2f* out) {
+        if constexpr (PH == PH_SIMD) out[0] = wide_sin2(in[0], g.tmax); else out[0] = in[0];
+    }
+    template <int PH> static FD_D void suf_step(Sine&, const float* in, float* out) {
+        if constexpr (PH == PH_SIMD) out[0] = wide_sinf(in[0]); else out[0] = in[0];
+    }
+    static FD_D void pre_begin(Sine&, int) {}
+    static FD_D void suf_begin(Sine& g, int n) { g.begin_block(n); }
+    static FD_D void pre_end(Sine& g) { g.end_simd(); }
+    static FD_D void suf_end(Sine&) {}
+    static FD_D bool pre_tripped(const Sine&) { return false; }
+    static FD_D bool suf_tripped(const Sine& g) { return g.tripped(); }
+    template <bool PRE, class W> static FD_D void visit_part(Sine& g, W& w) { w.on = PRE; g.visit(w); }
+};
+
+template <int K, class X, class Y>
+struct Split<K, Pipe<X, Y>> {
+    using G = Pipe<X, Y>;
+    static constexpr int NX = Chain<X>::N;
+    static constexpr int WHERE = K == NX ? 0 : (K < NX ? -1 : 1);  // cut between x and y / inside x / inside y
+    static constexpr int KX = K < NX ? K : 1, KY = K > NX ? K - NX : 1;
+    static constexpr int mid() {
+        if constexpr (WHERE == 0) return X::OUT; else if constexpr (WHERE < 0) return Split<KX, X>::mid(); else return Split<KY, Y>::mid();
+    }
+    static constexpr int pre_cost() {
+        if constexpr (WHERE == 0) return Cost<X>::v;
+        else if constexpr (WHERE < 0) return Split<KX, X>::pre_cost();
+        else return Cost<X>::v + Split<KY, Y>::pre_cost();
+    }
+    template <int PH> static FD_D void pre_step2(G& g, const v2f* in, v2f* out) {
+        if constexpr (WHERE == 0) g.x.template step2<PH>(in, out);
+        else if constexpr (WHERE < 0) Split<KX, X>::template pre_step2<PH>(g.x, in, out);
+        else { v2f t[X::OUT > 0 ? X::OUT : 1]; g.x.template step2<PH>(in, t); Split<KY, Y>::template pre_step2<PH>(g.y, t, out); }
+    }
+    template <int PH> static FD_D void pre_step(G& g, const float* in, float* out) {
+        if constexpr (WHERE == 0) g.x.template step<PH>(in, out);
+        else if constexpr (WHERE < 0) Split<KX, X>::template pre_step<PH>(g.x, in, out);
+        else { float t[X::OUT > 0 ? X::OUT : 1]; g.x.template step<PH>(in, t); Split<KY, Y>::template pre_step<PH>(g.y, t, out); }
+    }
+    template <int PH> static FD_D void suf_step2(G& g, const v2f* in, v2f* out) {
+        if constexpr (WHERE == 0) g.y.template step2<PH>(in, out);
+        else if constexpr (WHERE < 0) { v2f t[X::OUT]; Split<KX, X>::template suf_step2<PH>(g.x, in, t); g.y.template step2<PH>(t, out); }
+        else Split<KY, Y>::template suf_step2<PH>(g.y, in, out);
+    }
+    template <int PH> static FD_D void suf_step(G& g, const float* in, float* out) {
+        if constexpr (WHERE == 0) g.y.template step<PH>(in, out);
+        else if constexpr (WHERE < 0) { float t[X::OUT]; Split<KX, X>::template suf_step<PH>(g.x, in, t); g.y.template step<PH>(t, out); }
+        else Split<KY, Y>::template suf_step<PH>(g.y, in, out);
+    }
+    static FD_D void pre_begin(G& g, int n) {
+        if constexpr (WHERE == 0) g.x.begin_block(n);
+        else if constexpr (WHERE < 0) Split<KX, X>::pre_begin(g.x, n);
+        else { g.x.begin_block(n); Split<KY, Y>::pre_begin(g.y, n); }
+    }
+    static FD_D void suf_begin(G& g, int n) {
+        if constexpr (WHERE == 0) g.y.begin_block(n);
+        else if constexpr (WHERE < 0) { Split<KX, X>::suf_begin(g.x, n); g.y.begin_block(n); }
+        else Split<KY, Y>::suf_begin(g.y, n);
+    }
+    static FD_D void pre_end(G& g) {
+        if constexpr (WHERE == 0) g.x.end_simd();
+        else if constexpr (WHERE < 0) Split<KX, X>::pre_end(g.x);
+        else { g.x.end_simd(); Split<KY, Y>::pre_end(g.y); }
+    }
+    static FD_D void suf_end(G& g) {
+        if constexpr (WHERE == 0) g.y.end_simd();
+        else if constexpr (WHERE < 0) { Split<KX, X>::suf_end(g.x); g.y.end_simd(); }
+        else Split<KY, Y>::suf_end(g.y);
+    }
+    static FD_D bool pre_tripped(const G& g) {
+        if constexpr (WHERE == 0) return g.x.tripped();
+        else if constexpr (WHERE < 0) return Split<KX, X>::pre_tripped(g.x);
+        else return g.x.tripped() || Split<KY, Y>::pre_tripped(g.y);
+    }
+    static FD_D bool suf_tripped(const G& g) {
+        if constexpr (WHERE == 0) return g.y.tripped();
+        else if constexpr (WHERE < 0) return Split<KX, X>::suf_tripped(g.x) || g.y.tripped();
+        else return Split<KY, Y>::suf_tripped(g.y);
+    }
+    // visit only the prefix (PRE) or only the suffix part of the slots; slot numbering stays that of G::visit
+    template <bool PRE, class W> static FD_D void visit_part(G& g, W& w) {
+        if constexpr (WHERE == 0) { w.on = PRE; g.x.visit(w); w.on = !PRE; g.y.visit(w); }
+        else if constexpr (WHERE < 0) { Split<KX, X>::template visit_part<PRE>(g.x, w); w.on = !PRE; g.y.visit(w); }
+        else { w.on = PRE; g.x.visit(w); Split<KY, Y>::template visit_part<PRE>(g.y, w); }
+    }
+};
+
+template <class G> struct BestCut { static constexpr int K = 0; static constexpr bool ok = false; };
+template <class X, class Y>
+struct BestCut<Pipe<X, Y>> {
+    using G = Pipe<X, Y>;
+    static constexpr int N = Chain<G>::N, total = Cost<G>::v;
+    template <int K> static constexpr int worst() { int p = Split<K, G>::pre_cost(); int s = total - p; return p > s ? p : s; }
+    template <int K> static constexpr int best_from() {
+        if constexpr (K >= N) return 0;
+        else { int rest = best_from<K + 1>(); if (rest == 0) return K; return worst<K>() <= pick_worst(rest) ? K : rest; }
+    }
+    static constexpr int pick_worst(int k) { return pick<1>(k); }
+    template <int K> static constexpr int pick(int k) { if constexpr (K >= N) return 1 << 30; else return k == K ? worst<K>() : pick<K + 1>(k); }
+    static constexpr int K = best_from<1>();
+    // worth it only if both halves carry real work and the graph has no delay rings / inputs on the suffix side
+    static constexpr bool ok = G::RINGS == 0 && Split<K, G>::pre_cost() >= 8 && total - Split<K, G>::pre_cost() >= 8 &&
+                               Split<K, G>::mid() == 1;  // one hand-over channel: 128 KiB of LDS for the double-buffered tiles of 4 groups
+};
+
+template <class G, int K, int MODE>
+FD_D void render_split_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
+                            float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap) {
+    using S = Split<K, G>;
+    constexpr int NI = G::IN, NO = G::OUT, NM = S::mid();
+    // 8 waves: waves 0-3 run the prefix of voice groups 0-3, waves 4-7 the suffix of the same groups.  The hardware
+    // places wave w and w+4 of a workgroup on the same SIMD, so every SIMD hosts one prefix and one suffix wave.
+    __shared__ v2f hand[4][2][NM][32][64];  // [group][buffer][channel][frame pair][lane]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int grp = w & 3;
+    const bool suffix = w >= 4;
+    const size_t v0 = ((size_t)blockIdx.x * 4 + grp) * 64;
+    const size_t v = v0 + lane;
+    const bool live = v0 < stride;             // whole group beyond the bank: still takes part in the barriers
+    const bool active = v < V;
+    G g;
+    Ctx ctx{static_cast<const Aux*>(aux), ring + (live ? v : 0), ring_cap, stride, 0};
+    g.bind(ctx);
+    if (live) {
+        VLoad ld{slots + v, stride, 0};
+        VGate::W<VLoad> gate{&ld, true};
+        if (suffix) S::template visit_part<false>(g, gate); else S::template visit_part<true>(g, gate);
+    }
+    const float* inv = in + v;
+    float* outv = out + v;
+    const size_t nblocks = (T + 63) / 64;
+    for (size_t it = 0; it <= nblocks; it++) {
+        const size_t b = suffix ? it - 1 : it;             // the block this wave works on in this round
+        if (live && active && (suffix ? it >= 1 : it < nblocks)) {
+            const size_t t0 = b * 64;
+            const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+            const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
+            v2f (*hb)[32][64] = hand[grp][b & 1];
+            if (!suffix) {
+                S::pre_begin(g, size);
+                const G snap = g;
+#pragma unroll 4
+                for (int i = 0; i < full; i += 2) {
+                    const size_t t = t0 + i;
+                    v2f pi[NI > 0 ? NI : 1], pm[NM];
+#pragma unroll
+                    for (int c = 0; c < NI; c++) pi[c] = v2f{inv[((size_t)c * T + t) * V], inv[((size_t)c * T + t + 1) * V]};
+                    S::template pre_step2<PH_SIMD>(g, pi, pm);
+#pragma unroll
+                    for (int c = 0; c < NM; c++) hb[c][i >> 1][lane] = pm[c];
+                }
+                if (__builtin_expect(S::pre_tripped(g), 0)) {
+                    g = snap;
+                    for (int i = 0; i < full; i++) {
+                        float fi[NI > 0 ? NI : 1], fm[NM];
+#pragma unroll
+                        for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t0 + i) * V];
+                        S::template pre_step<PH_SIMD>(g, fi, fm);
+#pragma unroll
+                        for (int c = 0; c < NM; c++) reinterpret_cast<float*>(&hb[c][i >> 1][lane])[i & 1] = fm[c];
+                    }
+                }
+                if (MODE == MODE_PROCESS) S::pre_end(g);
+                for (int i = full; i < size; i++) {
+                    float fi[NI > 0 ? NI : 1], fm[NM];
+#pragma unroll
+                    for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t0 + i) * V];
+                    S::template pre_step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(g, fi, fm);
+#pragma unroll
+                    for (int c = 0; c < NM; c++) reinterpret_cast<float*>(&hb[c][i >> 1][lane])[i & 1] = fm[c];
+                }
+            } else {
+                S::suf_begin(g, size);
+                const G snap = g;
+#pragma unroll 4
+                for (int i = 0; i < full; i += 2) {
+                    const size_t t = t0 + i;
+                    v2f pm[NM], po[NO];
+#pragma unroll
+                    for (int c = 0; c < NM; c++) pm[c] = hb[c][i >> 1][lane];
+                    S::template suf_step2<PH_SIMD>(g, pm, po);
+#pragma unroll
+                    for (int c = 0; c < NO; c++) {
+                        outv[((size_t)c * T + t) * V] = po[c].x;
+                        outv[((size_t)c * T + t + 1) * V] = po[c].y;
+                    }
+                }
+                if (__builtin_expect(S::suf_tripped(g), 0)) {
+                    g = snap;
+                    for (int i = 0; i < full; i++) {
+                        float fm[NM], fo[NO];
+#pragma unroll
+                        for (int c = 0; c < NM; c++) fm[c] = reinterpret_cast<const float*>(&hb[c][i >> 1][lane])[i & 1];
+                        S::template suf_step<PH_SIMD>(g, fm, fo);
+#pragma unroll
+                        for (int c = 0; c < NO; c++) outv[((size_t)c * T + t0 + i) * V] = fo[c];
+                    }
+                }
+                if (MODE == MODE_PROCESS) S::suf_end(g);
+                for (int i = full; i < size; i++) {
+                    float fm[NM], fo[NO];
+#pragma unroll
+                    for (int c = 0; c < NM; c++) fm[c] = reinterpret_cast<const float*>(&hb[c][i >> 1][lane])[i & 1];
+                    S::template suf_step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(g, fm, fo);
+#pragma unroll
+                    for (int c = 0; c < NO; c++) outv[((size_t)c * T + t0 + i) * V] = fo[c];
+                }
+            }
+        }
+        __syncthreads();  // hand-over point: prefix block `it` is complete, suffix has drained block `it - 1`
+    }
+    if (live && active) {
+        VStore<false> st{slots + v, stride, 0};
+        VGate::W<VStore<false>> gate{&st, true};
+        if (suffix) S::template visit_part<false>(g, gate); else S::template visit_part<true>(g, gate);
+    }
+}
+
+template <class G, int K, int MODE>
+__global__ __launch_bounds__(512) void k_render_split(float* __restrict__ slots, size_t stride, size_t V,
+                                                      const float* __restrict__ in, float* __restrict__ out, size_t T,
+                                                      const void* aux, float* ring, uint32_t ring_cap) {
+    render_split_body<G, K, MODE>(slots, stride, V, in, out, T, aux, ring, ring_cap);
+}
+
 // LDS the planar path needs per wave, and the workgroup width chosen from it (shared by the AOT and JIT launchers)
 template <class G, int LAYOUT>
 struct RenderGeom {

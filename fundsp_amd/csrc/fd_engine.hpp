@@ -72,10 +72,31 @@ void launch_render_cfg(float* slots, size_t stride, size_t V, const float* in, f
                        fstride, aux, ring, ring_cap);
 }
 
+extern int g_pipe_split;  // fdsp_set_option("pipe_split", 0/1): two-wave pipeline split of Pipe chains (fd_device.hpp)
+
+template <class G, int MODE>
+bool launch_render_split(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, const void* aux,
+                         float* ring, uint32_t ring_cap, hipStream_t s) {
+    if constexpr (BestCut<G>::ok) {
+        constexpr int K = BestCut<G>::K;
+        const size_t groups = (V + 63) / 64;
+        hipLaunchKernelGGL((k_render_split<G, K, MODE>), dim3((unsigned)((groups + 3) / 4)), dim3(512), 0, s, slots, stride, V,
+                           in, out, T, aux, ring, ring_cap);
+        return true;
+    } else {
+        return false;
+    }
+}
+
 template <class G>
 void launch_render(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
                    int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
     if (V == 0 || T == 0) return;
+    if (layout == LAYOUT_VOICE_MINOR && g_pipe_split) {
+        const bool done = mode == MODE_PROCESS ? launch_render_split<G, MODE_PROCESS>(slots, stride, V, in, out, T, aux, ring, ring_cap, s)
+                                               : launch_render_split<G, MODE_TICK>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
+        if (done) return;
+    }
     if (layout == LAYOUT_VOICE_MINOR) {
         if (mode == MODE_PROCESS)
             launch_render_cfg<G, MODE_PROCESS, LAYOUT_VOICE_MINOR>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s);

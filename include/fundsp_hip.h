@@ -90,6 +90,11 @@ const char* fdsp_last_error(void);
 int fdsp_kind_count(void);
 const char* fdsp_kind_name(int kind);
 int fdsp_kind_by_name(const char* name); /* -1 if unknown */
+/* Engine options.  "pipe_split" (default 1): render Pipe-chain graphs of the ahead-of-time kinds in the voice-minor
+ * layout with the two-wave pipeline split (prefix stages and suffix stages of each 64-voice group in two waves that
+ * share a SIMD; identical samples, better issue-slot utilisation at one voice-wave per SIMD).  0 = single-wave kernel. */
+int fdsp_set_option(const char* name, int value);
+
 /* ---- run-time compiled voice graphs (graph -> kernel compiler) -------------------------------------------
  * `type_expr` is the graph's combinator TYPE, exactly what FunDSP's operators build (src/combinator.rs:289-488),
  * spelled with the engine's node templates (fundsp_amd/csrc/fd_nodes.hpp), e.g.

@@ -392,3 +392,21 @@ def test_mix_stereo(gpu):
         return part[:, 0]
     assert_bit_equal(mix[0], tree(wl), "mix L")
     assert_bit_equal(mix[1], tree(wr), "mix R")
+
+
+def test_pipe_split_is_bit_identical_to_single_wave(gpu):
+    """The two-wave pipeline split (default for Pipe-chain kinds in the voice-minor layout) must not change a bit."""
+    V, T = 64 * 5 + 31, 64 * 7 + 29
+    p = W.fm_svf_params(V, SR)
+    outs = []
+    for flag in (1, 0):
+        assert gpu.lib().fdsp_set_option(b"pipe_split", flag) == 0
+        for mode in MODES:
+            b = W.make_fm_svf_bank(V, SR, params=p)
+            outs.append(run_bank(b, None, T, LAYOUT_VOICE_MINOR, mode))
+        b2 = W.make_noise_biquad_bank(V, SR)
+        outs.append(run_bank(b2, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS))
+    gpu.lib().fdsp_set_option(b"pipe_split", 1)
+    for a, b in zip(outs[:3], outs[3:]):
+        assert_bit_equal(a, b, "split vs single wave")
+    assert gpu.lib().fdsp_set_option(b"no_such_option", 1) < 0
