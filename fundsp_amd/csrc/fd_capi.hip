@@ -421,8 +421,8 @@ static int fdn_configure(fdsp_bank* b, double sr) {
     FdnBank* f = b->fdn;
     fd::fdn_make_const(f->room, f->time, f->damping, sr, &f->c);
     for (int i = 0; i < 32; i++)
-        if (f->c.len[i] <= 64)
-            return fail(FDSP_EINVAL, "reverb_stereo: every delay must exceed 64 samples (room_size * sample_rate too small)");
+        if (f->c.len[i] <= 128)
+            return fail(FDSP_EINVAL, "reverb_stereo: every delay must exceed 128 samples (room_size * sample_rate too small)");
     fdn_free(f);
     const size_t n = b->V;
     HIPCHK(hipMalloc((void**)&f->st.rings, n * f->c.ring_stride * sizeof(float)));

@@ -113,34 +113,46 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
 #pragma unroll
     for (int st = 0; st < 5; st++) negmask[st] = (k & (1 << st)) ? 0x80000000u : 0u;
 
-    for (size_t t0 = 0; t0 < T; t0 += 64) {
-        const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
-        // ---- phase 1: stage this block's 64 ring reads per line (coalesced 256-B rows) and the stereo input
-        // 32 independent 256-B row loads in flight per wave before the first LDS write (memory-level parallelism:
-        // a wave alone on its SIMD cannot hide HBM latency any other way)
-        for (int r0 = 0; r0 < 64; r0 += 32) {
-            float xr[32];
+    // Ring rows and inputs of a block are fetched one block AHEAD into registers (issued before the recurrence of the
+    // current block, consumed after it): every delay exceeds 128 samples, so the rows block b+1 reads are not touched
+    // by block b's writes, and the HBM latency hides behind phase 2.
+    float xr[64], xin[4];
+    auto fetch = [&](size_t t0n, int idx_now) {
+        const int sizen = (int)((T - t0n) < 64 ? (T - t0n) : 64);
 #pragma unroll
-            for (int u = 0; u < 32; u++) {
-                const int r = r0 + u, kk = u;         // r0 is 0 or 32: jj = r0 >> 5, line = u
-                const size_t ri = inst0 + (r0 >> 5);
-                const int i0 = __builtin_amdgcn_readlane(idx, r);
-                const int len = c.len[kk];
-                int pos = i0 + 1 + lane;              // len > 64 (checked at creation): one conditional wrap suffices
-                pos = pos >= len ? pos - len : pos;
-                xr[u] = (ri < V && lane < size) ? s.rings[ri * c.ring_stride + (size_t)c.off[kk] + (size_t)pos] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 32; u++) tile[(r0 + u) * TS + lane] = xr[u];
+        for (int r = 0; r < 64; r++) {
+            const int kk = r & 31;
+            const size_t ri = inst0 + (r >> 5);
+            const int i0 = __builtin_amdgcn_readlane(idx_now, r);
+            const int len = c.len[kk];
+            int pos = i0 + 1 + lane;  // len > 128 (checked at creation): one conditional wrap suffices
+            pos = pos >= len ? pos - len : pos;
+            xr[r] = (ri < V && lane < sizen) ? s.rings[ri * c.ring_stride + (size_t)c.off[kk] + (size_t)pos] : 0.0f;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {  // q = jj*2 + channel
+        for (int q = 0; q < 4; q++) {  // q = instance-in-wave * 2 + channel
             const size_t ri = inst0 + (q >> 1);
             const int ch = q & 1;
-            float x = 0.0f;
-            if (ri < V && lane < size)
-                x = layout == 0 ? in[((size_t)ch * T + t0 + lane) * V + ri] : in[(ri * 2 + ch) * fstride + t0 + lane];
-            tin[q * 64 + lane] = x;
+            xin[q] = (ri < V && lane < sizen)
+                         ? (layout == 0 ? in[((size_t)ch * T + t0n + lane) * V + ri] : in[(ri * 2 + ch) * fstride + t0n + lane])
+                         : 0.0f;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int r = 0; r < 64; r++) tile[r * TS + lane] = xr[r];
+#pragma unroll
+        for (int q = 0; q < 4; q++) tin[q * 64 + lane] = xin[q];
+    };
+    fetch(0, idx);
+    stage();
+    for (size_t t0 = 0; t0 < T; t0 += 64) {
+        const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+        const bool more = t0 + 64 < T;
+        if (more) {  // ---- phase 1 of the NEXT block: loads in flight during this block's recurrence
+            int idx_next = idx + 64;
+            idx_next = idx_next >= mylen ? idx_next - mylen : idx_next;
+            fetch(t0 + 64, idx_next);
         }
         fdn_wave_sync();
         // ---- phase 2: 64 samples of the recirculating network, one lane per delay line.  Ring reads and inputs of 8
@@ -227,6 +239,7 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
         idx += size;
         while (idx >= mylen) idx -= mylen;
         fdn_wave_sync();
+        if (more) stage();  // the tiles are free again: land the prefetched rows of the next block
     }
     if (valid) {
         s.idx[sidx] = idx;
