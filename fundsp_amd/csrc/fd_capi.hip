@@ -16,7 +16,18 @@ namespace {
 
 thread_local std::string g_err;
 }
-namespace fd { int g_pipe_split = 1; }
+namespace fd {
+int g_pipe_split = 1;
+int simd_count() {
+    static int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 1024;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 1024;
+        return cus * 4;
+    }();
+    return n;
+}
+}  // namespace fd
 namespace {
 
 int fail(int code, const std::string& msg) {

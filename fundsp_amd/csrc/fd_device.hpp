@@ -135,16 +135,23 @@ FD_D void render_body(float* __restrict__ slots, size_t stride, size_t V, const 
     constexpr int NI = G::IN, NO = G::OUT;
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;  // wave in block
-    const size_t v0 = ((size_t)blockIdx.x * WPB + wib) * 64;
+    // Voices per wave.  Small banks (fewer than one full wave per SIMD) are spread over more, partially filled waves so
+    // that every SIMD of the chip has a wave to run: in the voice-minor layout the otherwise unused `fstride` argument
+    // carries the number of voices per wave (16 / 32; 0 or 64 = full waves).
+    const int vpw = (LAYOUT == LAYOUT_VOICE_MINOR && fstride > 0 && fstride < 64) ? (int)fstride : 64;
+    const size_t v0 = ((size_t)blockIdx.x * WPB + wib) * vpw;
     const size_t v = v0 + lane;
-    const bool active = v < V;
+    const bool active = v < V && lane < vpw;
     if (v0 >= stride) return;  // whole wave beyond the padded bank (last workgroup of a ragged bank)
 
     G g;
-    Ctx ctx{static_cast<const Aux*>(aux), ring + v, ring_cap, stride, 0};
+    // Padding lanes (V <= v < stride) own a private, zero-initialised column of the padded slot / ring arrays, so the
+    // planar path may run them harmlessly; lanes past the padding (partial waves only) alias lane 0 and only read.
+    const size_t vc = v < stride ? v : v0;
+    Ctx ctx{static_cast<const Aux*>(aux), ring + vc, ring_cap, stride, 0};
     g.bind(ctx);
     {
-        VLoad ld{slots + v, stride, 0};  // stride is padded to a multiple of 64: always in bounds
+        VLoad ld{slots + vc, stride, 0};  // stride is padded to a multiple of 64: always in bounds
         g.visit(ld);
     }
 
@@ -626,6 +633,13 @@ __global__ __launch_bounds__(512) void k_render_split(float* __restrict__ slots,
                                                       const float* __restrict__ in, float* __restrict__ out, size_t T,
                                                       const void* aux, float* ring, uint32_t ring_cap) {
     render_split_body<G, K, MODE>(slots, stride, V, in, out, T, aux, ring, ring_cap);
+}
+
+// Launch policy for the voice-minor layout: voices per wave such that the grid has at least one wave per SIMD.
+inline int voices_per_wave(size_t V, int simds) {
+    int vpw = 64;
+    while (vpw > 16 && (V + vpw - 1) / vpw < (size_t)simds) vpw >>= 1;
+    return vpw;
 }
 
 // LDS the planar path needs per wave, and the workgroup width chosen from it (shared by the AOT and JIT launchers)

@@ -39,6 +39,8 @@ struct VDescribe {  // host only
     void leave() { path.pop_back(); }
 };
 
+int simd_count();  // SIMDs of the current device (CUs x 4), fd_capi.hip
+
 // ---- per-kind dispatch table ---------------------------------------------------------------------------------
 struct KindOps {
     std::string name;
@@ -66,7 +68,9 @@ void launch_render_cfg(float* slots, size_t stride, size_t V, const float* in, f
                        const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
     // 4-wave workgroups unless the per-wave LDS tiles of the planar path would not fit 4x in the CU's LDS
     constexpr int WPB = RenderGeom<G, LAYOUT>::WPB;
-    const size_t waves = (V + 63) / 64;
+    const int vpw = LAYOUT == LAYOUT_VOICE_MINOR ? voices_per_wave(V, simd_count()) : 64;
+    if (LAYOUT == LAYOUT_VOICE_MINOR) fstride = (size_t)vpw;  // see render_body: fstride carries voices-per-wave here
+    const size_t waves = (V + vpw - 1) / vpw;
     unsigned grid = (unsigned)((waves + WPB - 1) / WPB);
     hipLaunchKernelGGL((k_render<G, MODE, LAYOUT, WPB>), dim3(grid), dim3(64 * WPB), 0, s, slots, stride, V, in, out, T,
                        fstride, aux, ring, ring_cap);

@@ -175,7 +175,9 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, KindOps
                        int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
         if (V == 0 || T == 0) return;
         const int wpb = jm->wpb[layout];
-        const size_t waves = (V + 63) / 64;
+        const int vpw = layout == LAYOUT_VOICE_MINOR ? voices_per_wave(V, simd_count()) : 64;
+        if (layout == LAYOUT_VOICE_MINOR) fstride = (size_t)vpw;
+        const size_t waves = (V + vpw - 1) / vpw;
         void* args[] = {&slots, &stride, &V, &in, &outp, &T, &fstride, &aux, &ring, &ring_cap};
         hipModuleLaunchKernel(jm->render[mode][layout], (unsigned)((waves + wpb - 1) / wpb), 1, 1, 64 * wpb, 1, 1, 0, s,
                               args, nullptr);
