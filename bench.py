@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--layout", choices=["voice_minor", "planar"], default="voice_minor")
     ap.add_argument("--mode", choices=["process", "tick"], default="process")
     ap.add_argument("--mix", action="store_true", help="add on-device stereo mix-down + all-reduce per step")
+    ap.add_argument("--pipe-split", type=int, default=1, choices=[0, 1, 2, 3],
+                    help="pipeline split of Pipe-chain kinds: 0 off, 1 best plan (default), 2 / 3 = that many stages")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -89,6 +91,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if args.pipe_split != 1:
+        from fundsp_amd import _lib
+        assert _lib.lib().fdsp_set_option(b"pipe_split", args.pipe_split) == 0
     if args.voices is None:
         args.voices = {3: 65536, 4: 32768, 5: 2048}[args.config]
     V, T, sr = args.voices, args.frames, args.sample_rate

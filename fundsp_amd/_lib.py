@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libfundsp_hip.so")
+# FUNDSP_HIP_LIB overrides the in-tree library (A/B builds of the same C ABI, e.g. tools/build_variants.sh)
+SO_PATH = os.environ.get("FUNDSP_HIP_LIB") or os.path.join(_HERE, "libfundsp_hip.so")
 
 OK, EINVAL, ENOMEM, EDEVICE = 0, -1, -2, -3
 LAYOUT_VOICE_MINOR, LAYOUT_PLANAR = 0, 1

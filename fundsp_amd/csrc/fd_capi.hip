@@ -304,7 +304,8 @@ int fdsp_kind_by_name(const char* name) {
 
 int fdsp_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "pipe_split") == 0) {
-        fd::g_pipe_split = value ? 1 : 0;
+        if (value < 0 || value > 4) return fail(FDSP_EINVAL, "pipe_split takes 0 (off), 1 (auto), 2 or 3 (stages), 4 (loader only)");
+        fd::g_pipe_split = value;
         return FDSP_OK;
     }
     return fail(FDSP_EINVAL, "unknown option");

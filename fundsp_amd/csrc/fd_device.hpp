@@ -134,7 +134,7 @@ FD_D void render_body(float* __restrict__ slots, size_t stride, size_t V, const 
                       uint32_t ring_cap) {
     constexpr int NI = G::IN, NO = G::OUT;
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;  // wave in block
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in block (wave-uniform -> SGPR)
     // Voices per wave.  Small banks (fewer than one full wave per SIMD) are spread over more, partially filled waves so
     // that every SIMD of the chip has a wave to run: in the voice-minor layout the otherwise unused `fstride` argument
     // carries the number of voices per wave (16 / 32; 0 or 64 = full waves).
@@ -157,26 +157,50 @@ FD_D void render_body(float* __restrict__ slots, size_t stride, size_t V, const 
 
     if (LAYOUT == LAYOUT_VOICE_MINOR) {
         if (!active) return;
-        const float* inv = in + v;
-        float* outv = out + v;
+        // wave-uniform base + lane offset: the per-frame address arithmetic runs on the scalar unit
+        // (global_load/store saddr form), not in the VALU-bound instruction stream
+        const float* inw = in + v0;
+        float* outw = out + v0;
+#define inv(i) inw[(i) + lane]
+#define outv(i) outw[(i) + lane]
+        // Input streams are software-pipelined: the 8 frames after the ones being computed are already in flight
+        // (a lone wave per SIMD cannot hide a global-load round trip per frame any other way).
+        float nx[NI > 0 ? NI : 1][8];
+        auto fetch = [&](size_t tn) {  // branch-free: frames past the end re-read the last frame (never used)
+#pragma unroll
+            for (int c = 0; c < NI; c++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const size_t t = tn + k < T ? tn + k : T - 1;
+                    nx[c][k] = inv(((size_t)c * T + t) * V);
+                }
+        };
+        fetch(0);
         for (size_t t0 = 0; t0 < T; t0 += 64) {
             const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
             const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
             float fi[NI > 0 ? NI : 1], fo[NO];
             g.begin_block(size);
             const G snap = g;  // block-start registers, for the rollback below
-#pragma unroll 4
-            for (int i = 0; i < full; i += 2) {  // two frames per iteration (full is a multiple of 8)
-                const size_t t = t0 + i;
-                v2f pi[NI > 0 ? NI : 1], po[NO];
+            for (int i = 0; i < full; i += 8) {  // one SIMD item of the reference = 8 frames = 4 packed pairs
+                float cu[NI > 0 ? NI : 1][8];
 #pragma unroll
                 for (int c = 0; c < NI; c++)
-                    pi[c] = v2f{inv[((size_t)c * T + t) * V], inv[((size_t)c * T + t + 1) * V]};
-                g.template step2<PH_SIMD>(pi, po);
 #pragma unroll
-                for (int c = 0; c < NO; c++) {
-                    outv[((size_t)c * T + t) * V] = po[c].x;
-                    outv[((size_t)c * T + t + 1) * V] = po[c].y;
+                    for (int k = 0; k < 8; k++) cu[c][k] = nx[c][k];
+                fetch(t0 + i + 8);
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    const size_t t = t0 + i + k;
+                    v2f pi[NI > 0 ? NI : 1], po[NO];
+#pragma unroll
+                    for (int c = 0; c < NI; c++) pi[c] = v2f{cu[c][k], cu[c][k + 1]};
+                    g.template step2<PH_SIMD>(pi, po);
+#pragma unroll
+                    for (int c = 0; c < NO; c++) {
+                        outv(((size_t)c * T + t) * V) = po[c].x;
+                        outv(((size_t)c * T + t + 1) * V) = po[c].y;
+                    }
                 }
             }
             if (__builtin_expect(g.tripped(), 0)) {  // a packed-path shortcut left its exact domain: redo the block
@@ -184,22 +208,29 @@ FD_D void render_body(float* __restrict__ slots, size_t stride, size_t V, const 
                 for (int i = 0; i < full; i++) {
                     const size_t t = t0 + i;
 #pragma unroll
-                    for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
+                    for (int c = 0; c < NI; c++) fi[c] = inv(((size_t)c * T + t) * V);
                     g.template step<PH_SIMD>(fi, fo);
 #pragma unroll
-                    for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+                    for (int c = 0; c < NO; c++) outv(((size_t)c * T + t) * V) = fo[c];
                 }
             }
             if (MODE == MODE_PROCESS) g.end_simd();
+            // Scalar paths (the remainder of a process block, every sample in tick mode) read their inputs at the
+            // point of use.  (Feeding them from the prefetched registers in a nested loop miscompiled AdsrLive's tick
+            // on this toolchain -- ROCm 7.2 clang, gfx950: a conditionally updated state word was lost -- so the
+            // slow paths keep the simplest possible loop shape.)
             for (int i = full; i < size; i++) {
                 const size_t t = t0 + i;
 #pragma unroll
-                for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
+                for (int c = 0; c < NI; c++) fi[c] = inv(((size_t)c * T + t) * V);
                 g.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(fi, fo);
 #pragma unroll
-                for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+                for (int c = 0; c < NO; c++) outv(((size_t)c * T + t) * V) = fo[c];
             }
+            if (size > full) fetch(t0 + 64);  // the scalar frames were not consumed from nx: refill it for the next block
         }
+#undef inv
+#undef outv
     } else {
         // one private tile set per wave: no cross-wave sharing, so only wave-level ordering is needed
         __shared__ __attribute__((aligned(16))) float tin_all[WPB * (NI > 0 ? NI : 1) * 64 * TILE_STRIDE];
@@ -339,19 +370,20 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
     render_body<G, MODE, LAYOUT, WPB>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
 }
 
-// ---- two-wave pipeline split of a Pipe chain --------------------------------------------------------------------
+// ---- multi-wave pipeline split of a Pipe chain ------------------------------------------------------------------
 // At one voice-wave per SIMD (65 536 voices on 1024 SIMDs) a lone wave issues one instruction per ~4.7 cycles while
-// the VALU could take one every ~3.3 (profiles/r01_voice_sweep_*).  For graphs that are a chain A >> B >> C ... the
-// chain is cut once: the PREFIX stages of 64 voices run in one wave, the SUFFIX stages of the same voices in a second
-// wave one 64-sample block behind, the cut's channels handed over through a double-buffered LDS tile.  Both waves
-// keep their own part of the voice state in registers; the per-sample arithmetic of every node is untouched, so the
-// output is bit-identical to the single-wave kernel -- only the issue slots of the SIMD are now fed by two waves.
+// the VALU could take one every ~2.5-3.3 (profiles/r01_ubench_valu.txt, r01_voice_sweep_*).  For graphs that are a
+// chain A >> B >> C ... the chain is cut into S = 2 or 3 STAGES: each stage of the same 64 voices runs in its own
+// wave, stage s one hand-over tile behind stage s-1, the cut's channel handed over through double-buffered LDS tiles.
+// Every wave keeps its own part of the voice state in registers; the per-sample arithmetic of every node is
+// untouched, so the output is bit-identical to the single-wave kernel -- only the issue slots of the SIMD are now fed
+// by S waves whose dependent-instruction latencies overlap.
 template <class T> struct Cost { static constexpr int v = 12; };  // rough VALU instructions per sample (cut placement only)
 template <int N> struct Cost<Constant<N>> { static constexpr int v = 0; };
 template <> struct Cost<Pass> { static constexpr int v = 0; };
-template <> struct Cost<Sine> { static constexpr int v = 28; };
+template <> struct Cost<Sine> { static constexpr int v = 20; };
 template <> struct Cost<Noise> { static constexpr int v = 10; };
-template <> struct Cost<FixedSvf> { static constexpr int v = 12; };
+template <> struct Cost<FixedSvf> { static constexpr int v = 16; };
 template <int N> struct Cost<Moog<N>> { static constexpr int v = 130; };
 template <int S> struct Cost<WaveSynth<S>> { static constexpr int v = 100; };
 template <> struct Cost<AdsrLive> { static constexpr int v = 80; };
@@ -362,11 +394,8 @@ template <class X, class Y> struct Cost<Stack<X, Y>> { static constexpr int v = 
 template <class O, class X, class Y> struct Cost<Binop<O, X, Y>> { static constexpr int v = Cost<X>::v + Cost<Y>::v + 1; };
 template <class X, class U> struct Cost<Unop<X, U>> { static constexpr int v = Cost<X>::v + 1; };
 
-template <class G> struct Chain { static constexpr int N = 1; };  // cut points of a (nested) Pipe chain = N - 1
+template <class G> struct Chain { static constexpr int N = 1; };  // stages of a (nested) Pipe chain; cut points = N - 1
 template <class X, class Y> struct Chain<Pipe<X, Y>> { static constexpr int N = Chain<X>::N + Chain<Y>::N; };
-// (A cut INSIDE Sine -- phase recurrence | polynomial -- balances config 3 at 35 | 36 instructions but measured slower
-// (6.41 ms vs 5.93 ms): with both waves busy all the time the packed-f32 VALU pipe, not issue, is the limit.  The
-// Split<1, Sine> specialisation below is kept for experiments: enable it with Chain<Sine>::N = 2.)
 
 struct VGate {  // forwards to a slot visitor only while enabled; always advances the slot counter
     template <class V> struct W {
@@ -381,258 +410,287 @@ struct VGate {  // forwards to a slot visitor only while enabled; always advance
     };
 };
 
-template <int K, class G> struct Split;  // K = number of chain stages in the prefix (1 .. N-1)
+// Seg<G, A, B>: the chain stages [A, B) of G, run on G's own state object.  The primary template is a whole node.
+template <class G, int A, int B>
+struct Seg {
+    static_assert(A == 0 && B == 1, "a node that is not a Pipe is one chain stage");
+    static constexpr int IN = G::IN, OUT = G::OUT, cost = Cost<G>::v;
+    template <int PH> static FD_D void step2(G& g, const v2f* in, v2f* out) { g.template step2<PH>(in, out); }
+    template <int PH> static FD_D void step(G& g, const float* in, float* out) { g.template step<PH>(in, out); }
+    static FD_D void begin(G& g, int n) { g.begin_block(n); }
+    static FD_D void end(G& g) { g.end_simd(); }
+    static FD_D bool tripped(const G& g) { return g.tripped(); }
+    // visit ALL slots of g in G::visit order (slot numbering unchanged); only this segment's slots are enabled
+    template <class W> static FD_D void visit(G& g, W& w) { w.on = true; g.visit(w); }
+};
+template <class X, class Y, int A, int B>
+struct Seg<Pipe<X, Y>, A, B> {
+    using G = Pipe<X, Y>;
+    static constexpr int NX = Chain<X>::N, NY = Chain<Y>::N;
+    static_assert(0 <= A && A < B && B <= NX + NY, "empty or out-of-range chain segment");
+    static constexpr bool HX = A < NX, HY = B > NX;  // the segment has stages inside x / inside y
+    using SX = Seg<X, HX ? A : 0, HX ? (B < NX ? B : NX) : NX>;
+    using SY = Seg<Y, HY ? (A > NX ? A - NX : 0) : 0, HY ? B - NX : NY>;
+    static constexpr int IN = HX ? SX::IN : SY::IN, OUT = HY ? SY::OUT : SX::OUT;
+    static constexpr int cost = (HX ? SX::cost : 0) + (HY ? SY::cost : 0);
+    template <int PH> static FD_D void step2(G& g, const v2f* in, v2f* out) {
+        if constexpr (HX && HY) { v2f t[SX::OUT > 0 ? SX::OUT : 1]; SX::template step2<PH>(g.x, in, t); SY::template step2<PH>(g.y, t, out); }
+        else if constexpr (HX) SX::template step2<PH>(g.x, in, out);
+        else SY::template step2<PH>(g.y, in, out);
+    }
+    template <int PH> static FD_D void step(G& g, const float* in, float* out) {
+        if constexpr (HX && HY) { float t[SX::OUT > 0 ? SX::OUT : 1]; SX::template step<PH>(g.x, in, t); SY::template step<PH>(g.y, t, out); }
+        else if constexpr (HX) SX::template step<PH>(g.x, in, out);
+        else SY::template step<PH>(g.y, in, out);
+    }
+    static FD_D void begin(G& g, int n) {
+        if constexpr (HX) SX::begin(g.x, n);
+        if constexpr (HY) SY::begin(g.y, n);
+    }
+    static FD_D void end(G& g) {
+        if constexpr (HX) SX::end(g.x);
+        if constexpr (HY) SY::end(g.y);
+    }
+    static FD_D bool tripped(const G& g) {
+        bool t = false;
+        if constexpr (HX) t = t || SX::tripped(g.x);
+        if constexpr (HY) t = t || SY::tripped(g.y);
+        return t;
+    }
+    template <class W> static FD_D void visit(G& g, W& w) {
+        if constexpr (HX) SX::visit(g.x, w); else { w.on = false; g.x.visit(w); }
+        if constexpr (HY) SY::visit(g.y, w); else { w.on = false; g.y.visit(w); }
+    }
+};
 
-// Sine cut in the middle: the prefix owns the serial phase recurrence (all of Sine's state) and hands over the angle
-// of the block path (or, on the tick path, the finished sample); the suffix owns the pure polynomial and its guard.
-template <>
-struct Split<1, Sine> {
-    static constexpr int mid() { return 1; }
-    static constexpr int pre_cost() { return 4; }
-    template <int PH> static FD_D void pre_step2(Sine& g, const v2f* in, v2f* out) {
-        if constexpr (PH == PH_SIMD) {
-            v2f d = in[0] * g.sample_duration;
-            float t0 = g.phase;
-            g.phase += d.x;
-            float t1 = g.phase;
-            g.phase += d.y;
-            out[0] = v2f{t0, t1} * F32_TAU;
-        } else {
-            g.template step2<PH>(in, out);
+// Tile geometry.  A tile is SUB frames of 64 voices.  The workgroup serves 4 voice groups with double-buffered tiles:
+// NI input-feed channels (see the loader wave below) plus S - 1 hand-over channels, 2 KiB * SUB each, within 128 KiB.
+template <int NI, int S>
+struct PipeGeom {
+    static constexpr int CH = NI + S - 1;
+    static constexpr int SUB = CH <= 1 ? 64 : CH == 2 ? 32 : CH <= 4 ? 16 : CH <= 8 ? 8 : 0;  // 0 = does not fit
+    static constexpr int WAVES = 4 * (S + (NI > 0 ? 1 : 0));
+    static constexpr bool ok = SUB >= 8 && WAVES <= 16 && CH >= 1;
+};
+
+// Where to cut: S stages (2 or 3) with cut points K1 < K2 chosen to minimise the most expensive stage.  Every cut must
+// hand over exactly one channel (the LDS tiles are sized for it) and every stage must carry real work.
+struct PipePlan { int S, K1, K2; };
+template <class G, int I = 0>
+constexpr void pipe_plan_fill(int* cost, int* width) {
+    if constexpr (I < Chain<G>::N) {
+        cost[I] = Seg<G, I, I + 1>::cost;
+        width[I] = Seg<G, I, I + 1>::OUT;  // channels crossing the cut after stage I
+        pipe_plan_fill<G, I + 1>(cost, width);
+    }
+}
+template <class G>
+constexpr PipePlan pipe_plan(int want) {  // want: 0 = best plan, 1 / 2 / 3 = at most one / exactly two / three compute stages
+    constexpr int N = Chain<G>::N;
+    static_assert(N <= 32, "chain too long");
+    // a graph with inputs always gets the loader wave (S = 1 if it cannot or need not be cut)
+    const PipePlan fallback = G::IN > 0 && PipeGeom<G::IN, 1>::ok ? PipePlan{1, N, N} : PipePlan{0, 0, 0};
+    if (N < 2 || G::RINGS != 0 || want == 1) return fallback;
+    int cost[32] = {0}, width[32] = {0};
+    pipe_plan_fill<G>(cost, width);
+    auto sum = [&](int a, int b) { int t = 0; for (int i = a; i < b; i++) t += cost[i]; return t; };
+    constexpr int MIN_STAGE = 8;
+    PipePlan best = fallback;
+    int best_worst = 1 << 30;
+    if (want != 3 && PipeGeom<G::IN, 2>::ok)
+        for (int k = 1; k < N; k++) {
+            int p = sum(0, k), q = sum(k, N), w = p > q ? p : q;
+            if (width[k - 1] == 1 && p >= MIN_STAGE && q >= MIN_STAGE && w < best_worst) { best = PipePlan{2, k, N}; best_worst = w; }
+        }
+    if (want == 3 && PipeGeom<G::IN, 3>::ok)  // three stages only on request: measured slower than two on config 3
+        for (int k1 = 1; k1 < N; k1++)
+            for (int k2 = k1 + 1; k2 < N; k2++) {
+                int p = sum(0, k1), q = sum(k1, k2), r = sum(k2, N), w = p > q ? (p > r ? p : r) : (q > r ? q : r);
+                if (width[k1 - 1] == 1 && width[k2 - 1] == 1 && p >= MIN_STAGE && q >= MIN_STAGE && r >= MIN_STAGE && w < best_worst) {
+                    best = PipePlan{3, k1, k2};
+                    best_worst = w;
+                }
+            }
+    return best;
+}
+
+// One stage's work on one tile: frames [lo, hi) of the block that starts at t0 (size / full as in
+// AudioNode::process: `full` frames of packed SIMD items, end_simd, then the remainder path).
+// The packed path of the FIRST stage takes its inputs from the feed tile `fin` (written by the loader wave); the
+// scalar paths read HBM at the point of use (see render_body).
+template <class SG, class G, int MODE, int SUB, bool FIRST, bool LAST>
+FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_t V, int lane, const float* inw, float* outw,
+                     const float (*fin)[SUB][64], v2f (*hin)[64], v2f (*hout)[64]) {
+    constexpr int NI = SG::IN, NO = SG::OUT;
+    static_assert(FIRST || NI == 1, "one hand-over channel");
+    static_assert(LAST || NO == 1, "one hand-over channel");
+    const int lo = h * SUB;
+    const int hi = lo + SUB < size ? lo + SUB : size;
+    const int shi = hi < full ? hi : full;  // end of the packed part inside this tile
+    if (h == 0) SG::begin(g, size);
+    if (lo < shi) {
+        const G snap = g;  // tile-start registers, for the rollback below
+#pragma unroll 4
+        for (int i = lo; i < shi; i += 2) {  // two frames per iteration (lo, shi are multiples of 8)
+            const size_t t = t0 + i;
+            v2f pi[NI > 0 ? NI : 1], po[NO];
+            if constexpr (FIRST) {
+#pragma unroll
+                for (int c = 0; c < NI; c++) pi[c] = v2f{fin[c][i - lo][lane], fin[c][i - lo + 1][lane]};
+            } else {
+                pi[0] = hin[(i - lo) >> 1][lane];
+            }
+            SG::template step2<PH_SIMD>(g, pi, po);
+            if constexpr (LAST) {
+#pragma unroll
+                for (int c = 0; c < NO; c++) {
+                    outw[((size_t)c * T + t) * V + lane] = po[c].x;
+                    outw[((size_t)c * T + t + 1) * V + lane] = po[c].y;
+                }
+            } else {
+                hout[(i - lo) >> 1][lane] = po[0];
+            }
+        }
+        if (__builtin_expect(SG::tripped(g), 0)) {  // a packed-path shortcut left its exact domain: redo the tile
+            g = snap;
+            for (int i = lo; i < shi; i++) {
+                float fi[NI > 0 ? NI : 1], fo[NO];
+                if constexpr (FIRST) {
+#pragma unroll
+                    for (int c = 0; c < NI; c++) fi[c] = inw[((size_t)c * T + t0 + i) * V + lane];
+                } else {
+                    fi[0] = reinterpret_cast<const float*>(&hin[(i - lo) >> 1][lane])[i & 1];
+                }
+                SG::template step<PH_SIMD>(g, fi, fo);
+                if constexpr (LAST) {
+#pragma unroll
+                    for (int c = 0; c < NO; c++) outw[((size_t)c * T + t0 + i) * V + lane] = fo[c];
+                } else {
+                    reinterpret_cast<float*>(&hout[(i - lo) >> 1][lane])[i & 1] = fo[0];
+                }
+            }
         }
     }
-    template <int PH> static FD_D void pre_step(Sine& g, const float* in, float* out) {
-        if constexpr (PH == PH_SIMD) {
-            float tmp = g.phase;
-            g.phase += in[0] * g.sample_duration;
-            out[0] = tmp * F32_TAU;
+    // end_simd runs once per block, after its last packed item and before its remainder (also when full == 0)
+    if (MODE == MODE_PROCESS && h == (full == 0 ? 0 : (full - 1) / SUB)) SG::end(g);
+    for (int i = lo > full ? lo : full; i < hi; i++) {
+        float fi[NI > 0 ? NI : 1], fo[NO];
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int c = 0; c < NI; c++) fi[c] = inw[((size_t)c * T + t0 + i) * V + lane];
         } else {
-            g.template step<PH>(in, out);
+            fi[0] = reinterpret_cast<const float*>(&hin[(i - lo) >> 1][lane])[i & 1];
+        }
+        SG::template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(g, fi, fo);
+        if constexpr (LAST) {
+#pragma unroll
+            for (int c = 0; c < NO; c++) outw[((size_t)c * T + t0 + i) * V + lane] = fo[c];
+        } else {
+            reinterpret_cast<float*>(&hout[(i - lo) >> 1][lane])[i & 1] = fo[0];
         }
     }
-    template <int PH> static FD_D void suf_step2(Sine& g, const v2f* in, v2f* out) {
-        if constexpr (PH == PH_SIMD) out[0] = wide_sin2(in[0], g.tmax); else out[0] = in[0];
-    }
-    template <int PH> static FD_D void suf_step(Sine&, const float* in, float* out) {
-        if constexpr (PH == PH_SIMD) out[0] = wide_sinf(in[0]); else out[0] = in[0];
-    }
-    static FD_D void pre_begin(Sine&, int) {}
-    static FD_D void suf_begin(Sine& g, int n) { g.begin_block(n); }
-    static FD_D void pre_end(Sine& g) { g.end_simd(); }
-    static FD_D void suf_end(Sine&) {}
-    static FD_D bool pre_tripped(const Sine&) { return false; }
-    static FD_D bool suf_tripped(const Sine& g) { return g.tripped(); }
-    template <bool PRE, class W> static FD_D void visit_part(Sine& g, W& w) { w.on = PRE; g.visit(w); }
-};
+}
 
-template <int K, class X, class Y>
-struct Split<K, Pipe<X, Y>> {
-    using G = Pipe<X, Y>;
-    static constexpr int NX = Chain<X>::N;
-    static constexpr int WHERE = K == NX ? 0 : (K < NX ? -1 : 1);  // cut between x and y / inside x / inside y
-    static constexpr int KX = K < NX ? K : 1, KY = K > NX ? K - NX : 1;
-    static constexpr int mid() {
-        if constexpr (WHERE == 0) return X::OUT; else if constexpr (WHERE < 0) return Split<KX, X>::mid(); else return Split<KY, Y>::mid();
-    }
-    static constexpr int pre_cost() {
-        if constexpr (WHERE == 0) return Cost<X>::v;
-        else if constexpr (WHERE < 0) return Split<KX, X>::pre_cost();
-        else return Cost<X>::v + Split<KY, Y>::pre_cost();
-    }
-    template <int PH> static FD_D void pre_step2(G& g, const v2f* in, v2f* out) {
-        if constexpr (WHERE == 0) g.x.template step2<PH>(in, out);
-        else if constexpr (WHERE < 0) Split<KX, X>::template pre_step2<PH>(g.x, in, out);
-        else { v2f t[X::OUT > 0 ? X::OUT : 1]; g.x.template step2<PH>(in, t); Split<KY, Y>::template pre_step2<PH>(g.y, t, out); }
-    }
-    template <int PH> static FD_D void pre_step(G& g, const float* in, float* out) {
-        if constexpr (WHERE == 0) g.x.template step<PH>(in, out);
-        else if constexpr (WHERE < 0) Split<KX, X>::template pre_step<PH>(g.x, in, out);
-        else { float t[X::OUT > 0 ? X::OUT : 1]; g.x.template step<PH>(in, t); Split<KY, Y>::template pre_step<PH>(g.y, t, out); }
-    }
-    template <int PH> static FD_D void suf_step2(G& g, const v2f* in, v2f* out) {
-        if constexpr (WHERE == 0) g.y.template step2<PH>(in, out);
-        else if constexpr (WHERE < 0) { v2f t[X::OUT]; Split<KX, X>::template suf_step2<PH>(g.x, in, t); g.y.template step2<PH>(t, out); }
-        else Split<KY, Y>::template suf_step2<PH>(g.y, in, out);
-    }
-    template <int PH> static FD_D void suf_step(G& g, const float* in, float* out) {
-        if constexpr (WHERE == 0) g.y.template step<PH>(in, out);
-        else if constexpr (WHERE < 0) { float t[X::OUT]; Split<KX, X>::template suf_step<PH>(g.x, in, t); g.y.template step<PH>(t, out); }
-        else Split<KY, Y>::template suf_step<PH>(g.y, in, out);
-    }
-    static FD_D void pre_begin(G& g, int n) {
-        if constexpr (WHERE == 0) g.x.begin_block(n);
-        else if constexpr (WHERE < 0) Split<KX, X>::pre_begin(g.x, n);
-        else { g.x.begin_block(n); Split<KY, Y>::pre_begin(g.y, n); }
-    }
-    static FD_D void suf_begin(G& g, int n) {
-        if constexpr (WHERE == 0) g.y.begin_block(n);
-        else if constexpr (WHERE < 0) { Split<KX, X>::suf_begin(g.x, n); g.y.begin_block(n); }
-        else Split<KY, Y>::suf_begin(g.y, n);
-    }
-    static FD_D void pre_end(G& g) {
-        if constexpr (WHERE == 0) g.x.end_simd();
-        else if constexpr (WHERE < 0) Split<KX, X>::pre_end(g.x);
-        else { g.x.end_simd(); Split<KY, Y>::pre_end(g.y); }
-    }
-    static FD_D void suf_end(G& g) {
-        if constexpr (WHERE == 0) g.y.end_simd();
-        else if constexpr (WHERE < 0) { Split<KX, X>::suf_end(g.x); g.y.end_simd(); }
-        else Split<KY, Y>::suf_end(g.y);
-    }
-    static FD_D bool pre_tripped(const G& g) {
-        if constexpr (WHERE == 0) return g.x.tripped();
-        else if constexpr (WHERE < 0) return Split<KX, X>::pre_tripped(g.x);
-        else return g.x.tripped() || Split<KY, Y>::pre_tripped(g.y);
-    }
-    static FD_D bool suf_tripped(const G& g) {
-        if constexpr (WHERE == 0) return g.y.tripped();
-        else if constexpr (WHERE < 0) return Split<KX, X>::suf_tripped(g.x) || g.y.tripped();
-        else return Split<KY, Y>::suf_tripped(g.y);
-    }
-    // visit only the prefix (PRE) or only the suffix part of the slots; slot numbering stays that of G::visit
-    template <bool PRE, class W> static FD_D void visit_part(G& g, W& w) {
-        if constexpr (WHERE == 0) { w.on = PRE; g.x.visit(w); w.on = !PRE; g.y.visit(w); }
-        else if constexpr (WHERE < 0) { Split<KX, X>::template visit_part<PRE>(g.x, w); w.on = !PRE; g.y.visit(w); }
-        else { w.on = PRE; g.x.visit(w); Split<KY, Y>::template visit_part<PRE>(g.y, w); }
-    }
-};
-
-template <class G> struct BestCut { static constexpr int K = 0; static constexpr bool ok = false; };
-template <class X, class Y>
-struct BestCut<Pipe<X, Y>> {
-    using G = Pipe<X, Y>;
-    static constexpr int N = Chain<G>::N, total = Cost<G>::v;
-    template <int K> static constexpr int worst() { int p = Split<K, G>::pre_cost(); int s = total - p; return p > s ? p : s; }
-    template <int K> static constexpr int best_from() {
-        if constexpr (K >= N) return 0;
-        else { int rest = best_from<K + 1>(); if (rest == 0) return K; return worst<K>() <= pick_worst(rest) ? K : rest; }
-    }
-    static constexpr int pick_worst(int k) { return pick<1>(k); }
-    template <int K> static constexpr int pick(int k) { if constexpr (K >= N) return 1 << 30; else return k == K ? worst<K>() : pick<K + 1>(k); }
-    static constexpr int K = best_from<1>();
-    // worth it only if both halves carry real work and the graph has no delay rings / inputs on the suffix side
-    static constexpr bool ok = G::RINGS == 0 && Split<K, G>::pre_cost() >= 8 && total - Split<K, G>::pre_cost() >= 8 &&
-                               Split<K, G>::mid() == 1;  // one hand-over channel: 128 KiB of LDS for the double-buffered tiles of 4 groups
-};
-
-template <class G, int K, int MODE>
-FD_D void render_split_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
-                            float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap) {
-    using S = Split<K, G>;
-    constexpr int NI = G::IN, NO = G::OUT, NM = S::mid();
-    // 8 waves: waves 0-3 run the prefix of voice groups 0-3, waves 4-7 the suffix of the same groups.  The hardware
-    // places wave w and w+4 of a workgroup on the same SIMD, so every SIMD hosts one prefix and one suffix wave.
-    __shared__ v2f hand[4][2][NM][32][64];  // [group][buffer][channel][frame pair][lane]
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int grp = w & 3;
-    const bool suffix = w >= 4;
+// The pipeline kernel.  Waves of one workgroup, 4 voice groups (w & 3) times NW roles (w >> 2):
+//   role 0 (only if the graph has inputs): the LOADER wave.  It does nothing but stream the group's input channels
+//     from HBM into the double-buffered feed tile, one tile ahead.  gfx9-family waves have ONE counter for loads and
+//     stores (vmcnt) and mixed pending loads/stores force s_waitcnt vmcnt(0), so a wave that also stores samples
+//     stalls on its own stores whenever it waits for an input; the loader never stores, the compute waves never load.
+//   then S compute stages (S == 1: the whole graph), stage s one tile behind stage s - 1.
+// The hardware places waves w, w+4, w+8, ... of a workgroup on the same SIMD.
+template <class G, int MODE, int S, int K1, int K2>
+FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
+                           float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap) {
+    constexpr int N = Chain<G>::N, NI = G::IN;
+    constexpr bool FEED = NI > 0;
+    constexpr int SUB = PipeGeom<NI, S>::SUB, SPB = 64 / SUB;
+    static_assert(PipeGeom<NI, S>::ok, "tiles do not fit");
+    using S0 = Seg<G, 0, S == 1 ? N : K1>;
+    using S1 = Seg<G, S == 1 ? 0 : K1, S <= 2 ? N : K2>;   // unused when S == 1
+    using S2 = Seg<G, S <= 2 ? 0 : K2, N>;                 // unused when S <= 2
+    __shared__ float feed[FEED ? 4 : 1][2][FEED ? NI : 1][FEED ? SUB : 1][FEED ? 64 : 1];  // [group][buffer][channel][frame][lane]
+    __shared__ v2f hand[S > 1 ? S - 1 : 1][S > 1 ? 4 : 1][2][S > 1 ? SUB / 2 : 1][S > 1 ? 64 : 1];  // [cut][group][buffer][frame pair][lane]
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // w: wave-uniform
+    const int grp = w & 3, role = w >> 2;
     const size_t v0 = ((size_t)blockIdx.x * 4 + grp) * 64;
     const size_t v = v0 + lane;
-    const bool live = v0 < stride;             // whole group beyond the bank: still takes part in the barriers
+    const bool live = v0 < stride;  // a whole group beyond the bank still takes part in the barriers
     const bool active = v < V;
+    const size_t ntiles = ((T + 63) / 64) * SPB;
+    const size_t rounds = ntiles + (S - 1) + (FEED ? 1 : 0);
+    const float* inw = in + v0;  // wave-uniform bases + lane
+    float* outw = out + v0;
+
+    if (FEED && role == 0) {  // ---- loader wave ----
+        float rg[FEED ? NI : 1][SUB];
+        auto issue = [&](size_t j) {  // frames past the end re-read the last frame (never used): no branches
+            const size_t tj = (j / SPB) * 64 + (j % SPB) * SUB;
+#pragma unroll
+            for (int c = 0; c < NI; c++)
+#pragma unroll
+                for (int k = 0; k < SUB; k++) {
+                    const size_t t = tj + k < T ? tj + k : T - 1;
+                    rg[c][k] = inw[((size_t)c * T + t) * V + lane];
+                }
+        };
+        const bool on = live && active;
+        if (on) issue(0);
+        for (size_t it = 0; it < rounds; it++) {
+            if (on && it < ntiles) {
+#pragma unroll
+                for (int c = 0; c < NI; c++)
+#pragma unroll
+                    for (int k = 0; k < SUB; k++) feed[grp][it & 1][c][k][lane] = rg[c][k];
+                if (it + 1 < ntiles) issue(it + 1);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    const int stage = role - (FEED ? 1 : 0);
+    const size_t first = (size_t)stage + (FEED ? 1 : 0);  // the round in which this stage sees tile 0
     G g;
     Ctx ctx{static_cast<const Aux*>(aux), ring + (live ? v : 0), ring_cap, stride, 0};
     g.bind(ctx);
     if (live) {
         VLoad ld{slots + v, stride, 0};
         VGate::W<VLoad> gate{&ld, true};
-        if (suffix) S::template visit_part<false>(g, gate); else S::template visit_part<true>(g, gate);
+        if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
     }
-    const float* inv = in + v;
-    float* outv = out + v;
-    const size_t nblocks = (T + 63) / 64;
-    for (size_t it = 0; it <= nblocks; it++) {
-        const size_t b = suffix ? it - 1 : it;             // the block this wave works on in this round
-        if (live && active && (suffix ? it >= 1 : it < nblocks)) {
-            const size_t t0 = b * 64;
+    for (size_t it = 0; it < rounds; it++) {
+        if (live && active && it >= first && it - first < ntiles) {
+            const size_t j = it - first;          // the tile this stage works on in this round
+            const size_t t0 = (j / SPB) * 64;
+            const int h = (int)(j % SPB);
             const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
             const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
-            v2f (*hb)[32][64] = hand[grp][b & 1];
-            if (!suffix) {
-                S::pre_begin(g, size);
-                const G snap = g;
-#pragma unroll 4
-                for (int i = 0; i < full; i += 2) {
-                    const size_t t = t0 + i;
-                    v2f pi[NI > 0 ? NI : 1], pm[NM];
-#pragma unroll
-                    for (int c = 0; c < NI; c++) pi[c] = v2f{inv[((size_t)c * T + t) * V], inv[((size_t)c * T + t + 1) * V]};
-                    S::template pre_step2<PH_SIMD>(g, pi, pm);
-#pragma unroll
-                    for (int c = 0; c < NM; c++) hb[c][i >> 1][lane] = pm[c];
-                }
-                if (__builtin_expect(S::pre_tripped(g), 0)) {
-                    g = snap;
-                    for (int i = 0; i < full; i++) {
-                        float fi[NI > 0 ? NI : 1], fm[NM];
-#pragma unroll
-                        for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t0 + i) * V];
-                        S::template pre_step<PH_SIMD>(g, fi, fm);
-#pragma unroll
-                        for (int c = 0; c < NM; c++) reinterpret_cast<float*>(&hb[c][i >> 1][lane])[i & 1] = fm[c];
-                    }
-                }
-                if (MODE == MODE_PROCESS) S::pre_end(g);
-                for (int i = full; i < size; i++) {
-                    float fi[NI > 0 ? NI : 1], fm[NM];
-#pragma unroll
-                    for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t0 + i) * V];
-                    S::template pre_step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(g, fi, fm);
-#pragma unroll
-                    for (int c = 0; c < NM; c++) reinterpret_cast<float*>(&hb[c][i >> 1][lane])[i & 1] = fm[c];
-                }
+            const float (*fin)[SUB][64] = nullptr;
+            if constexpr (FEED) fin = feed[grp][j & 1];
+            if (stage == 0) {
+                if constexpr (S == 1) pipe_stage<S0, G, MODE, SUB, true, true>(g, h, t0, size, full, T, V, lane, inw, outw, fin, nullptr, nullptr);
+                else pipe_stage<S0, G, MODE, SUB, true, false>(g, h, t0, size, full, T, V, lane, inw, outw, fin, nullptr, hand[0][grp][j & 1]);
+            } else if (stage == 1) {
+                if constexpr (S == 2) pipe_stage<S1, G, MODE, SUB, false, true>(g, h, t0, size, full, T, V, lane, inw, outw, nullptr, hand[0][grp][j & 1], nullptr);
+                else if constexpr (S == 3) pipe_stage<S1, G, MODE, SUB, false, false>(g, h, t0, size, full, T, V, lane, inw, outw, nullptr, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
             } else {
-                S::suf_begin(g, size);
-                const G snap = g;
-#pragma unroll 4
-                for (int i = 0; i < full; i += 2) {
-                    const size_t t = t0 + i;
-                    v2f pm[NM], po[NO];
-#pragma unroll
-                    for (int c = 0; c < NM; c++) pm[c] = hb[c][i >> 1][lane];
-                    S::template suf_step2<PH_SIMD>(g, pm, po);
-#pragma unroll
-                    for (int c = 0; c < NO; c++) {
-                        outv[((size_t)c * T + t) * V] = po[c].x;
-                        outv[((size_t)c * T + t + 1) * V] = po[c].y;
-                    }
-                }
-                if (__builtin_expect(S::suf_tripped(g), 0)) {
-                    g = snap;
-                    for (int i = 0; i < full; i++) {
-                        float fm[NM], fo[NO];
-#pragma unroll
-                        for (int c = 0; c < NM; c++) fm[c] = reinterpret_cast<const float*>(&hb[c][i >> 1][lane])[i & 1];
-                        S::template suf_step<PH_SIMD>(g, fm, fo);
-#pragma unroll
-                        for (int c = 0; c < NO; c++) outv[((size_t)c * T + t0 + i) * V] = fo[c];
-                    }
-                }
-                if (MODE == MODE_PROCESS) S::suf_end(g);
-                for (int i = full; i < size; i++) {
-                    float fm[NM], fo[NO];
-#pragma unroll
-                    for (int c = 0; c < NM; c++) fm[c] = reinterpret_cast<const float*>(&hb[c][i >> 1][lane])[i & 1];
-                    S::template suf_step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(g, fm, fo);
-#pragma unroll
-                    for (int c = 0; c < NO; c++) outv[((size_t)c * T + t0 + i) * V] = fo[c];
-                }
+                if constexpr (S == 3) pipe_stage<S2, G, MODE, SUB, false, true>(g, h, t0, size, full, T, V, lane, inw, outw, nullptr, hand[S - 2][grp][j & 1], nullptr);
             }
         }
-        __syncthreads();  // hand-over point: prefix block `it` is complete, suffix has drained block `it - 1`
+        __syncthreads();  // hand-over point: every role has finished its tile of this round
     }
     if (live && active) {
         VStore<false> st{slots + v, stride, 0};
         VGate::W<VStore<false>> gate{&st, true};
-        if (suffix) S::template visit_part<false>(g, gate); else S::template visit_part<true>(g, gate);
+        if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
     }
 }
 
-template <class G, int K, int MODE>
-__global__ __launch_bounds__(512) void k_render_split(float* __restrict__ slots, size_t stride, size_t V,
-                                                      const float* __restrict__ in, float* __restrict__ out, size_t T,
-                                                      const void* aux, float* ring, uint32_t ring_cap) {
-    render_split_body<G, K, MODE>(slots, stride, V, in, out, T, aux, ring, ring_cap);
+template <class G, int MODE, int S, int K1, int K2>
+__global__ __launch_bounds__((64 * PipeGeom<G::IN, S>::WAVES)) void k_render_pipe(float* __restrict__ slots, size_t stride, size_t V,
+                                                                                const float* __restrict__ in, float* __restrict__ out,
+                                                                                size_t T, const void* aux, float* ring, uint32_t ring_cap) {
+    render_pipe_body<G, MODE, S, K1, K2>(slots, stride, V, in, out, T, aux, ring, ring_cap);
 }
 
 // Launch policy for the voice-minor layout: voices per wave such that the grid has at least one wave per SIMD.

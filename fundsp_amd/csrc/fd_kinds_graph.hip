@@ -19,11 +19,18 @@ using FmSvf = Pipe<Pipe<FmMod, Sine>, FixedSvf>;
 using SawMoog = Pipe<Stack<Stack<Pipe<Constant<1>, WaveSynth<0>>, Constant<1>>, Constant<1>>, Moog<3>>;
 using SawMoogAdsrPan = Pipe<Binop<OpMul, SawMoog, AdsrLive>, Panner>;
 
+// filter chains with an audio input (exercise the loader wave together with 2 / 3 compute stages):
+//   lowpass_hz(fc, q) >> shape(..)   and   lowpass_hz(fc, q) >> shape(..) >> highpass_hz(fc2, q2)
+using SvfShape = Pipe<FixedSvf, Shaper>;
+using SvfShapeSvf = Pipe<SvfShape, FixedSvf>;
+
 void register_graph_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<SineHz>("sine_hz"));
     out.push_back(make_kind<SineHzLowpass>("sine_hz_lowpass_hz"));
     out.push_back(make_kind<NoiseBiquad>("noise_biquad"));
     out.push_back(make_kind<FmSvf>("fm_svf"));
     out.push_back(make_kind<SawMoogAdsrPan>("saw_moog_adsr_pan"));
+    out.push_back(make_kind<SvfShape>("svf_shape"));
+    out.push_back(make_kind<SvfShapeSvf>("svf_shape_svf"));
 }
 }  // namespace fd

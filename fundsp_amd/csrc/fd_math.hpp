@@ -390,6 +390,12 @@ FD_HD float wide_sinf(float self) {
 // packed-f32 VALU ops (v_pk_mul_f32 / v_pk_add_f32) do two lanes-ops per issue slot.  The feed-forward part of an
 // oscillator (the sine polynomial of frame n and n+1) is therefore evaluated as one <2 x float> computation.
 // Component-wise the arithmetic is IDENTICAL to wide_sinf (same operations, same order, no contraction).
+#ifndef FD_SINE_PACKED
+#define FD_SINE_PACKED 1
+#endif
+#ifndef FD_SINE_UNIFIED
+#define FD_SINE_UNIFIED 0
+#endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 FD_HD v2f splat2(float x) { return v2f{x, x}; }
@@ -404,27 +410,71 @@ FD_HD v2f wide_sin2(v2f self, float& tmax) {
     constexpr float P0sinf = -1.6666654611E-1f, P1sinf = 8.3321608736E-3f, P2sinf = -1.9515295891E-4f;
     constexpr float P0cosf = 4.166664568298827E-2f, P1cosf = -1.388731625493765E-3f, P2cosf = 2.443315711809948E-5f;
     constexpr float TWO_OVER_PI = 2.0f / 3.14159274101257324f;
-    v2f xa = v2f{__builtin_fabsf(self.x), __builtin_fabsf(self.y)};
-    v2f t = xa * TWO_OVER_PI;
-    // Out-of-domain arguments (quadrant index >= 8192: more than ~2000 cycles of phase inside one 64-sample block,
+    constexpr float MAGIC = 12582912.0f;  // 1.5 * 2^23: adding it rounds |t| < 2^22 to the nearest-even integer
+    // wide's algorithm works on |self| and restores the sign at the end.  Every operation below is odd- or even-
+    // symmetric under round-to-nearest-even, so the SIGNED evaluation gives the same bits with fewer instructions:
+    //   t, y, x flip sign with self (products / RNE sums of negated operands are the negated results);
+    //   s(-x) = -s(x) and c(-x) = c(x) exactly;  the quadrant index becomes q' = -q (two's complement), whose low
+    //   bits satisfy q'&1 == q&1 and, for odd q, bit1(q') == !bit1(q) -- exactly the extra flip sign(self) needs
+    //   on the even cosine branch; for even q the odd sine branch carries sign(self) by itself.
+    // The single exception is self == -0.0, where the final `poly*(x*x2) + x` sums (+0) + (-0) = +0 while wide
+    // returns -0.0 (it flips the sign of sin(+0)): callers divert that argument (Sine::begin_block).
+    // Out-of-domain arguments (|quadrant index| >= 8192: more than ~2000 cycles of phase inside one 64-sample block,
     // where the exact-FMA shortcuts and wide's q > 2^25 overflow rule would matter) only raise tmax here.
-    tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(t.x, t.y));
-    v2f y = v2f{__builtin_rintf(t.x), __builtin_rintf(t.y)};
-    int32_t q0 = (int32_t)y.x, q1 = (int32_t)y.y;
-    // y < 2^13 is an integer, so y*DP1F (13+8 bits) and y*DP2F (13+11 bits) are exact products: the fused and the
+    v2f t = self * TWO_OVER_PI;
+    tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(__builtin_fabsf(t.x), __builtin_fabsf(t.y)));
+    // round(t) and its low integer bits from one add: for |t| < 2^13 the sum lies in [2^23, 2^24) where ulp = 1, so
+    // ym = RNE(t) + MAGIC exactly, y = ym - MAGIC is exact, and mantissa(ym) = 0x400000 + RNE(t) (two's complement).
+    v2f ym = t + MAGIC;
+    v2f y = ym - MAGIC;
+    uint32_t b0 = f2u(ym.x), b1 = f2u(ym.y);
+    // |y| < 2^13 is an integer, so y*DP1F (13+8 bits) and y*DP2F (13+11 bits) are exact products: the fused and the
     // unfused forms of `x - y*DPn` round the same real number once -> identical bits.  Likewise 0.5*x2 below.
-    v2f x = __builtin_elementwise_fma(y, splat2(-DP1F), xa);
+    v2f x = __builtin_elementwise_fma(y, splat2(-DP1F), self);
     x = __builtin_elementwise_fma(y, splat2(-DP2F), x);
     x = x - y * DP3F;
     v2f x2 = x * x;
     v2f x4 = x2 * x2;
     v2f s = (x4 * P2sinf + (x2 * P1sinf + P0sinf)) * (x * x2) + x;
     v2f c = (x4 * P2cosf + (x2 * P1cosf + P0cosf)) * x4 + __builtin_elementwise_fma(x2, splat2(-0.5f), splat2(1.0f));
-    float r0 = (q0 & 1) ? c.x : s.x;
-    float r1 = (q1 & 1) ? c.y : s.y;
-    uint32_t g0 = (((uint32_t)q0 << 30) ^ f2u(self.x)) & 0x80000000u;
-    uint32_t g1 = (((uint32_t)q1 << 30) ^ f2u(self.y)) & 0x80000000u;
-    return v2f{u2f(f2u(r0) ^ g0), u2f(f2u(r1) ^ g1)};
+    uint32_t m0 = (uint32_t)((int32_t)(b0 << 31) >> 31), m1 = (uint32_t)((int32_t)(b1 << 31) >> 31);  // odd quadrant
+    uint32_t r0 = (f2u(c.x) & m0) | (f2u(s.x) & ~m0);
+    uint32_t r1 = (f2u(c.y) & m1) | (f2u(s.y) & ~m1);
+    return v2f{u2f(r0 ^ ((b0 << 30) & 0x80000000u)), u2f(r1 ^ ((b1 << 30) & 0x80000000u))};
+}
+
+// Scalar twin of wide_sin2 (same signed evaluation, same guard): used where two plain VALU ops beat one packed op.
+FD_HD float wide_sin1(float self, float& tmax) {
+    constexpr float DP1F = 0.78515625f * 2.0f, DP2F = 2.4187564849853515625E-4f * 2.0f, DP3F = 3.77489497744594108E-8f * 2.0f;
+    constexpr float P0sinf = -1.6666654611E-1f, P1sinf = 8.3321608736E-3f, P2sinf = -1.9515295891E-4f;
+    constexpr float P0cosf = 4.166664568298827E-2f, P1cosf = -1.388731625493765E-3f, P2cosf = 2.443315711809948E-5f;
+    constexpr float TWO_OVER_PI = 2.0f / 3.14159274101257324f;
+    constexpr float MAGIC = 12582912.0f;
+    float t = self * TWO_OVER_PI;
+    tmax = __builtin_fmaxf(tmax, __builtin_fabsf(t));
+    float ym = t + MAGIC;
+    float y = ym - MAGIC;
+    uint32_t b = f2u(ym);
+    float x = __builtin_fmaf(y, -DP1F, self);
+    x = __builtin_fmaf(y, -DP2F, x);
+    x = x - y * DP3F;
+    float x2 = x * x;
+    float x4 = x2 * x2;
+#if FD_SINE_UNIFIED
+    // sin and cos share one polynomial skeleton  (x4*K2 + (x2*K1 + K0)) * m + base : select the operands per lane
+    bool odd = (b & 1u) != 0;
+    float k0 = odd ? P0cosf : P0sinf, k1 = odd ? P1cosf : P1sinf, k2 = odd ? P2cosf : P2sinf;
+    float m = odd ? x4 : x * x2;
+    float base = odd ? __builtin_fmaf(x2, -0.5f, 1.0f) : x;
+    float r = (x4 * k2 + (x2 * k1 + k0)) * m + base;
+    return u2f(f2u(r) ^ ((b << 30) & 0x80000000u));
+#else
+    float s = (x4 * P2sinf + (x2 * P1sinf + P0sinf)) * (x * x2) + x;
+    float c = (x4 * P2cosf + (x2 * P1cosf + P0cosf)) * x4 + __builtin_fmaf(x2, -0.5f, 1.0f);
+    uint32_t m = (uint32_t)((int32_t)(b << 31) >> 31);
+    uint32_t r = (f2u(c) & m) | (f2u(s) & ~m);
+    return u2f(r ^ ((b << 30) & 0x80000000u));
+#endif
 }
 
 // ---- integer hashing (bit-exact) -------------------------------------------------------------------------

@@ -205,7 +205,10 @@ struct Sine {
     float phase, sample_duration, has_phase, initial_phase;
     uint64_t hash;
     float tmax;  // transient guard of the packed sine path (not a slot)
-    FD_HD void begin_block(int) { tmax = 0.0f; }
+    // A phase of exactly -0.0 is the one argument wide_sin2 gets wrong (+0.0 instead of -0.0, see fd_math.hpp).  The
+    // unwrapped phase can only be -0.0 inside a block if it is -0.0 at the block start (-0 + d is -0 only for d = -0),
+    // so such a block is sent down the rollback path up front.
+    FD_HD void begin_block(int) { tmax = f2u(phase) == 0x80000000u ? __builtin_inff() : 0.0f; }
     FD_HD bool tripped() const { return !(tmax < 8192.0f); }
     FD_HD void bind(Ctx&) {}
     template <class V> FD_HD void visit(V& v) {
@@ -250,7 +253,11 @@ struct Sine {
             phase += d.x;
             float t1 = phase;
             phase += d.y;
+#if FD_SINE_PACKED
             out[0] = wide_sin2(v2f{t0, t1} * F32_TAU, tmax);
+#else
+            out[0] = v2f{wide_sin1(t0 * F32_TAU, tmax), wide_sin1(t1 * F32_TAU, tmax)};
+#endif
         } else {
             float o0, o1, i0 = in[0].x, i1 = in[0].y;
             this->template step<PH>(&i0, &o0);
@@ -303,6 +310,9 @@ struct Noise {
 };
 
 // SVF core shared by FixedSvf and Svf:  svf.rs:995-1006 / :829-843
+#ifndef FD_SVF_PACKED
+#define FD_SVF_PACKED 0
+#endif
 struct SvfCore {
     float a1, a2, a3, m0, m1, m2, ic1eq, ic2eq;
     // Same operations in the same order as the reference; independent products share one packed instruction:
@@ -310,6 +320,7 @@ struct SvfCore {
     // `2*v - ic` is evaluated as fma(2, v, -ic): 2*v is exact in binary floating point, so the fused and the
     // unfused form round the same real number once -- identical bits for every non-overflowing value.
     FD_HD float tick(float v0) {
+#if FD_SVF_PACKED
         float v3 = v0 - ic2eq;
         v2f p = v2f{a1, a2} * splat2(ic1eq);
         v2f r = v2f{a2, a3} * splat2(v3);
@@ -323,6 +334,14 @@ struct SvfCore {
         ic2eq = ic.y;
         v2f mm = v2f{m0, m1} * v01;
         return (mm.x + mm.y) + m2 * v12.y;
+#else
+        float v3 = v0 - ic2eq;
+        float v1 = a1 * ic1eq + a2 * v3;
+        float v2 = ic2eq + a2 * ic1eq + a3 * v3;
+        ic1eq = __builtin_fmaf(2.0f, v1, -ic1eq);
+        ic2eq = __builtin_fmaf(2.0f, v2, -ic2eq);
+        return m0 * v0 + m1 * v1 + m2 * v2;
+#endif
     }
     FD_HD void set(const SvfCoefs& c) {
         a1 = c.a1; a2 = c.a2; a3 = c.a3; m0 = c.m0; m1 = c.m1; m2 = c.m2;

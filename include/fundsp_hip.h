@@ -91,8 +91,9 @@ int fdsp_kind_count(void);
 const char* fdsp_kind_name(int kind);
 int fdsp_kind_by_name(const char* name); /* -1 if unknown */
 /* Engine options.  "pipe_split" (default 1): render Pipe-chain graphs of the ahead-of-time kinds in the voice-minor
- * layout with the two-wave pipeline split (prefix stages and suffix stages of each 64-voice group in two waves that
- * share a SIMD; identical samples, better issue-slot utilisation at one voice-wave per SIMD).  0 = single-wave kernel. */
+ * layout with the multi-wave pipeline split (the chain stages of each 64-voice group cut into 2 or 3 consecutive
+ * segments that run in 2 or 3 waves sharing a SIMD; identical samples, better issue-slot utilisation at one
+ * voice-wave per SIMD).  1 = best plan, 2 / 3 = exactly that many stages (if the graph allows), 0 = single-wave kernel. */
 int fdsp_set_option(const char* name, int value);
 
 /* ---- run-time compiled voice graphs (graph -> kernel compiler) -------------------------------------------

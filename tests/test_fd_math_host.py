@@ -1,0 +1,24 @@
+"""Host-side check of the device math header: the optimistic packed sine (wide_sin2) and its scalar twin (wide_sin1)
+must reproduce the general scalar restatement of wide::f32x8::sin bit for bit everywhere inside their guard domain
+(|quadrant index| < 8192), including quadrant ties, tiny and negative arguments.  Built with hipcc for the host."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_wide_sin2_matches_wide_sinf_on_host(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = tmp_path / "check_wide_sin2"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-std=c++17", "-Wno-unused-result",
+           "-I", os.path.join(ROOT, "fundsp_amd", "csrc"), "-o", str(exe),
+           os.path.join(ROOT, "tests", "host", "check_wide_sin2.hip")]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bad 0" in r.stdout

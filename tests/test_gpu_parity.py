@@ -395,11 +395,12 @@ def test_mix_stereo(gpu):
 
 
 def test_pipe_split_is_bit_identical_to_single_wave(gpu):
-    """The two-wave pipeline split (default for Pipe-chain kinds in the voice-minor layout) must not change a bit."""
-    V, T = 64 * 5 + 31, 64 * 7 + 29
+    """The multi-wave pipeline split (default for Pipe-chain kinds in the voice-minor layout) must not change a bit:
+    single wave (0), best plan (1), forced two stages (2), forced three stages (3, half-block hand-over tiles)."""
+    V, T = 64 * 5 + 31, 64 * 7 + 24  # whole SIMD items: ragged tails and tick mode always take the single-wave kernel
     p = W.fm_svf_params(V, SR)
     outs = []
-    for flag in (1, 0):
+    for flag in (0, 1, 2, 3):
         assert gpu.lib().fdsp_set_option(b"pipe_split", flag) == 0
         for mode in MODES:
             b = W.make_fm_svf_bank(V, SR, params=p)
@@ -407,6 +408,76 @@ def test_pipe_split_is_bit_identical_to_single_wave(gpu):
         b2 = W.make_noise_biquad_bank(V, SR)
         outs.append(run_bank(b2, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS))
     gpu.lib().fdsp_set_option(b"pipe_split", 1)
-    for a, b in zip(outs[:3], outs[3:]):
-        assert_bit_equal(a, b, "split vs single wave")
+    for k in range(1, 4):
+        for a, b in zip(outs[:3], outs[3 * k:3 * k + 3]):
+            assert_bit_equal(a, b, f"pipe_split={k} vs single wave")
     assert gpu.lib().fdsp_set_option(b"no_such_option", 1) < 0
+    assert gpu.lib().fdsp_set_option(b"pipe_split", 5) < 0
+
+
+@pytest.mark.parametrize("T", [5, 8, 16, 32, 40, 64, 64 * 2 + 32, 64 * 2 + 40, 64 * 3 + 56])
+def test_pipe_split_tile_edges(gpu, T):
+    """Hand-over tiles of the three-stage split are half blocks: every position of the packed / remainder boundary
+    (audionode.rs:85-105) relative to the tile boundary must give the single-wave samples, in both modes."""
+    V = 130
+    p = W.fm_svf_params(V, SR)
+    ref = {}
+    for flag in (0, 2, 3):
+        assert gpu.lib().fdsp_set_option(b"pipe_split", flag) == 0
+        for mode in MODES:
+            b = W.make_fm_svf_bank(V, SR, params=p)
+            got = np.concatenate([run_bank(b, None, T, LAYOUT_VOICE_MINOR, mode), run_bank(b, None, T, LAYOUT_VOICE_MINOR, mode)], axis=-1)
+            if flag == 0:
+                ref[mode] = got
+            else:
+                assert_bit_equal(got, ref[mode], f"pipe_split={flag} mode={mode} T={T}")
+    gpu.lib().fdsp_set_option(b"pipe_split", 1)
+
+
+FEED_T = [8, 16, 17, 24, 40, 64, 64 * 2 + 40, 64 * 3 + 56]
+
+
+@pytest.mark.parametrize("T", FEED_T)
+@pytest.mark.parametrize("kind", ["sine", "svf3", "svf4", "svf_shape", "svf_shape_svf", "saw_moog_adsr_pan"])
+def test_loader_wave_is_bit_identical_to_single_wave(gpu, kind, T):
+    """Graphs with inputs render through the pipeline kernel with a loader wave (feed tiles of 64 / 32 / 16 frames)
+    and, where the chain allows, 2 or 3 compute stages; every plan must give the single-wave kernel's samples."""
+    V = 64 * 4 + 9
+    if kind == "saw_moog_adsr_pan":
+        gpu.wavetable_build("saw")
+    rng = np.random.default_rng(77)
+    ref = {}
+    for flag in (0, 1, 2, 3, 4):
+        assert gpu.lib().fdsp_set_option(b"pipe_split", flag) == 0
+        for mode in MODES:
+            b = gpu.Bank(kind, V)
+            names = [n for n, k in b.slots() if k == 0]
+            rs = np.random.default_rng(5)
+            for n in names:  # per-voice random but valid parameters
+                if n.endswith("cutoff"):
+                    b.set_param(n, (200.0 + 5000.0 * rs.random(V)).astype(np.float32))
+                elif n.endswith(":q"):
+                    b.set_param(n, (0.5 + 3.0 * rs.random(V)).astype(np.float32))
+            if kind.startswith("svf_shape"):
+                b.set_param("1:shape" if kind == "svf_shape" else "0.1:shape", float(O.SHAPES["tanh"]))
+            b.set_sample_rate(SR)
+            ni = b.inputs()
+            x = (rng.random((V, ni, 2 * T), dtype=np.float32) * 2 - 1).astype(np.float32)
+            if kind == "sine":
+                x = x * 3000.0
+            elif kind in ("svf3", "svf4"):
+                x[:, 1] = 300.0 + 4000.0 * np.abs(x[:, 1])
+                x[:, 2] = 0.5 + 2.0 * np.abs(x[:, 2])
+                if ni == 4:
+                    x[:, 3] = 1.0 + np.abs(x[:, 3])
+            elif kind == "saw_moog_adsr_pan":
+                x[:] = 1.0
+                x[:, :, T:] = 0.0
+            got = np.concatenate([run_bank(b, x[:, :, :T], T, LAYOUT_VOICE_MINOR, mode),
+                                  run_bank(b, x[:, :, T:], T, LAYOUT_VOICE_MINOR, mode)], axis=-1)
+            if flag == 0:
+                ref[mode] = got
+            else:
+                assert_bit_equal(got, ref[mode], f"{kind} pipe_split={flag} mode={mode} T={T}")
+        rng = np.random.default_rng(77)
+    gpu.lib().fdsp_set_option(b"pipe_split", 1)
