@@ -33,6 +33,11 @@ void register_leaf_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<OnePole<OP_ALLPOLE, 1>>("allpole_delay"));
     out.push_back(make_kind<OnePole<OP_ALLPOLE, 2>>("allpole"));
     out.push_back(make_kind<Pinkpass>("pinkpass"));
+    out.push_back(make_kind<Rez<1>>("rez_hz"));
+    out.push_back(make_kind<Rez<3>>("rez"));
+    out.push_back(make_kind<Follow>("follow"));
+    out.push_back(make_kind<AFollow>("afollow"));
+    out.push_back(make_kind<Mls>("mls"));
     out.push_back(make_kind<Morph>("morph"));
     out.push_back(make_kind<Delay>("delay"));
     out.push_back(make_kind<TapT<false>>("tap"));

@@ -477,6 +477,32 @@ FD_HD float wide_sin1(float self, float& tmax) {
 #endif
 }
 
+// follow.rs:12-24 (f64).  log / exp are the device library's double routines; the reference's are libm 0.2.15's.  Both
+// are accurate to < 1 ulp of f64 and the result is rounded to f32, so the f32 coefficient agrees except when the f64
+// value lies within ~1e-16 relative of an f32 rounding boundary (same policy as the oracle: SURVEY 8c).
+extern "C" __device__ double __ocml_log_f64(double);
+extern "C" __device__ double __ocml_exp_f64(double);
+FD_HD double log_f64(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ocml_log_f64(x);
+#else
+    return __builtin_log(x);
+#endif
+}
+FD_HD double exp_f64(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ocml_exp_f64(x);
+#else
+    return __builtin_exp(x);
+#endif
+}
+FD_HD double halfway_coeff(double samples) {
+    double r0 = log_f64(samples > 1.0 ? samples : 1.0) - 0.861624594696583;
+    double r1 = 1.0 / (1.0 + exp_f64(0.0 - r0));
+    double r2 = r1 * 1.13228543863477 - 0.1322853859;
+    return 1.0 - (r2 < 0.9999999 ? r2 : 0.9999999);
+}
+
 // ---- integer hashing (bit-exact) -------------------------------------------------------------------------
 FD_HD double rnd1(uint64_t x) {  // math.rs:569-576
     x = x ^ 0x5555555555555555ULL;

@@ -1456,6 +1456,187 @@ struct OnePole {
     FD_STEP2_VIA_STEP
 };
 
+// Rez<f32, N>  rez.rs:11-105 (ID 75): Paul Kellett's resonant two-pole.  bandpass = 0 lowpass, 1 bandpass.
+// NIN = 1 (fixed cutoff / q) or 3 (audio, cutoff, q).
+template <int NIN>
+struct Rez {
+    static constexpr int IN = NIN, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 75;
+    float bandpass, cutoff, q, sr, f, fb, buf0, buf1;
+    template <class V> FD_HD void visit(V& v) {
+        constexpr FieldKind PK = NIN > 1 ? STATE : PARAM, CK = NIN > 1 ? STATE : COEF;
+        v.f(bandpass, PARAM, "bandpass");
+        v.f(cutoff, PK, "cutoff");
+        v.f(q, PK, "q");
+        v.f(sr, COEF, "sample_rate");
+        v.f(f, CK, "f");
+        v.f(fb, CK, "fb");
+        v.f(buf0, STATE, "buf0");
+        v.f(buf1, STATE, "buf1");
+    }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void set_cutoff_q(float c, float qq) {  // :41-46
+        cutoff = c;
+        f = 2.0f * sinf_musl(F32_PI * c / sr);
+        q = qq;
+        fb = qq + qq / (1.0f - f);
+    }
+    FD_HD void init() { bandpass = 0.0f; cutoff = 440.0f; q = 1.0f; buf0 = buf1 = 0.0f; f = fb = 1.0f; }
+    FD_HD void update(double sample_rate) { sr = (float)sample_rate; set_cutoff_q(cutoff, q); }  // :62-65
+    FD_HD void reset() { buf0 = 0.0f; buf1 = 0.0f; }                                              // :57-60
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // :67-82
+        if (NIN > 1) {
+            if (in[1] != cutoff || in[2] != q) set_cutoff_q(in[1], in[2]);
+        }
+        float hp = in[0] - buf0;
+        float bp = buf0 - buf1;
+        buf0 += f * (hp + fb * tanhf_musl(bp));
+        buf1 += f * (buf0 - buf1);
+        out[0] = buf1 - bandpass * buf0;
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// Follow<f32>  follow.rs:26-131 (ID 24): three one-poles in series; the first sample is taken over as is.
+struct Follow {
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 24;
+    float response_time, sr, coeff, coeff_now, v1, v2, v3;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(response_time, PARAM, "response_time");
+        v.f(sr, COEF, "sample_rate");
+        v.f(coeff, COEF, "coeff");
+        v.f(coeff_now, STATE, "coeff_now");
+        v.f(v1, STATE, "v1"); v.f(v2, STATE, "v2"); v.f(v3, STATE, "v3");
+    }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void init() { response_time = 0.1f; coeff = 0.0f; reset(); }  // Follow::new :48-56
+    FD_HD void update(double sample_rate) {                              // :96-99 -> set_response_time :61-67
+        sr = (float)sample_rate;
+        coeff = (float)halfway_coeff((double)(response_time * sr));
+        if (coeff_now < 1.0f) coeff_now = coeff;
+    }
+    FD_HD void reset() { v1 = v2 = v3 = 0.0f; coeff_now = 1.0f; }        // :89-94
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {     // :101-110
+        const float c = coeff_now, rc = 1.0f - c;
+        v1 = c * in[0] + rc * v1;
+        v2 = c * v1 + rc * v2;
+        v3 = c * v2 + rc * v3;
+        coeff_now = coeff;
+        out[0] = v3;
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// AFollow<f32>  follow.rs:132-273 (ID 29): attack / release coefficients, ScalarOrPair for (T, T) combinator.rs:164-173
+struct AFollow {
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 29;
+    float atime, rtime, sr, acoeff, rcoeff, acoeff_now, rcoeff_now, v1, v2, v3;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(atime, PARAM, "attack_time");
+        v.f(rtime, PARAM, "release_time");
+        v.f(sr, COEF, "sample_rate");
+        v.f(acoeff, COEF, "acoeff");
+        v.f(rcoeff, COEF, "rcoeff");
+        v.f(acoeff_now, STATE, "acoeff_now");
+        v.f(rcoeff_now, STATE, "rcoeff_now");
+        v.f(v1, STATE, "v1"); v.f(v2, STATE, "v2"); v.f(v3, STATE, "v3");
+    }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void init() { atime = 0.01f; rtime = 0.1f; acoeff = rcoeff = 0.0f; reset(); }
+    FD_HD void update(double sample_rate) {  // :217-221 -> set_time :178-192
+        sr = (float)sample_rate;
+        acoeff = (float)halfway_coeff((double)(atime * sr));
+        rcoeff = (float)halfway_coeff((double)(rtime * sr));
+        if (acoeff_now < 1.0f) { acoeff_now = acoeff; rcoeff_now = rcoeff; }
+    }
+    FD_HD void reset() { v1 = v2 = v3 = 0.0f; acoeff_now = 1.0f; rcoeff_now = 1.0f; }  // :209-215
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    FD_HD float pole(float input, float cur) const {
+        return cur + __builtin_fmaxf(0.0f, input - cur) * acoeff_now - __builtin_fmaxf(0.0f, cur - input) * rcoeff_now;
+    }
+    template <int PH> FD_HD void step(const float* in, float* out) {  // :223-246
+        v1 = pole(in[0], v1);
+        v2 = pole(v1, v2);
+        v3 = pole(v2, v3);
+        acoeff_now = acoeff;
+        rcoeff_now = rcoeff;
+        out[0] = v3;
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// Mls  noise.rs:14-151 (ID 19): maximum length sequence noise, integer-exact.  `bits` (1..31) is a parameter; a bank
+// starts in MlsState::new's all-ones state of the default 29-bit sequence until reset / set_seed re-derives it.
+FD_HD uint32_t mls_poly(uint32_t n) {  // MLS_POLY noise.rs:23-55
+    constexpr uint32_t P[31] = {0x1u, 0x3u, 0x6u, 0xCu, 0x14u, 0x30u, 0x48u, 0xB8u, 0x110u, 0x240u, 0x500u, 0xCA0u,
+                                0x1B00u, 0x3088u, 0x6000u, 0xD008u, 0x12000u, 0x20400u, 0x63000u, 0x90000u, 0x140000u,
+                                0x300000u, 0x420000u, 0xE10000u, 0x1200000u, 0x2000023u, 0x4000013u, 0x9000000u,
+                                0x14000000u, 0x20000029u, 0x48000000u};
+    uint32_t r = P[0];
+#pragma unroll
+    for (int i = 1; i < 31; i++) r = (n == (uint32_t)i + 1u) ? P[i] : r;  // select chain: no per-lane table in scratch
+    return r;
+}
+struct Mls {
+    static constexpr int IN = 0, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 19;
+    float bits, has_seed;
+    uint32_t state, poly;
+    uint64_t seed, hash;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(bits, PARAM, "bits");
+        v.u32(state, STATE, "state");
+        v.u32(poly, COEF, "poly");
+        v.f(has_seed, PARAM, "has_seed");
+        v.u64(seed, PARAM, "seed");
+        v.u64(hash, STATE, "hash");
+    }
+    FD_HD void bind(Ctx&) {}
+    FD_HD uint32_t n() const { return (uint32_t)bits; }
+    FD_HD void init() {  // mls() = mls_bits(29): Mls::new(MlsState::new(29)) :58-62,109-117
+        bits = 29.0f; has_seed = 0.0f; seed = 0; hash = 0;
+        state = (1u << 29) - 1u;
+        poly = mls_poly(29);
+    }
+    FD_HD void update(double) { poly = mls_poly(n()); }
+    FD_HD void reset() {  // :124-127 -> MlsState::new_with_seed :66-72
+        uint64_t h = has_seed != 0.0f ? seed : hash;
+        uint32_t s32 = (uint32_t)(h ^ (h >> 32));
+        state = 1u + s32 % ((1u << n()) - 1u);
+    }
+    FD_HD uint64_t ping(bool probe, uint64_t h) {
+        if (!probe) {  // set_hash :142-145
+            hash = h;
+            reset();
+        }
+        return atto(h, ID);
+    }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float*, float* out) {  // tick :129-134, MlsState::next / value :81-96
+        const uint32_t nn = n();
+        float value = (float)((state >> (nn - 1u)) & 1u);
+        uint32_t parity = (uint32_t)__builtin_popcount(poly & state) & 1u;
+        state = ((state << 1) | parity) & ((1u << nn) - 1u);
+        out[0] = value * 2.0f - 1.0f;
+    }
+    FD_STEP2_VIA_STEP
+};
+
 // Pinkpass  filter.rs:178-262 (Paul Kellett's pinking filter)
 struct Pinkpass {
     static constexpr int IN = 1, OUT = 1, RINGS = 0;

@@ -138,6 +138,14 @@ def dcblock_hz(f): return _leaf("OnePole<OP_DCBLOCK,1>", 1, 1, cutoff=f)
 def allpole_delay(d): return _leaf("OnePole<OP_ALLPOLE,1>", 1, 1, delay=d)
 def allpole(): return _leaf("OnePole<OP_ALLPOLE,2>", 2, 1)
 def pinkpass(): return _leaf("Pinkpass", 1, 1)
+def lowrez_hz(cutoff, q): return _leaf("Rez<1>", 1, 1, bandpass=0.0, cutoff=cutoff, q=q)
+def lowrez(): return _leaf("Rez<3>", 3, 1, bandpass=0.0)
+def bandrez_hz(center, q): return _leaf("Rez<1>", 1, 1, bandpass=1.0, cutoff=center, q=q)
+def bandrez(): return _leaf("Rez<3>", 3, 1, bandpass=1.0)
+def follow(t): return _leaf("Follow", 1, 1, response_time=t)
+def afollow(a, r): return _leaf("AFollow", 1, 1, attack_time=a, release_time=r)
+def mls_bits(n): return _leaf("Mls", 0, 1, bits=float(n))
+def mls(): return mls_bits(29)
 def delay(t): return _leaf("Delay", 1, 1, rings=1, time=t)
 def tap(min_delay, max_delay): return _leaf("TapT<false>", 2, 1, rings=1, min_delay=min_delay, max_delay=max_delay)
 def tap_linear(min_delay, max_delay): return _leaf("TapT<true>", 2, 1, rings=1, min_delay=min_delay, max_delay=max_delay)

@@ -102,6 +102,10 @@ struct onode {
         int osc_kind, lorenz, nl_dirty, nl_mode;
         float cx, cy, cz;
         float ns1, ns2;
+        /* Rez (rez.rs:11-21), Follow / AFollow (follow.rs:31-43,137-152), Mls (noise.rs:14-20,103-107) */
+        float rz_buf0, rz_buf1, rz_f, rz_fb, rz_bandpass;
+        float fo_v1, fo_v2, fo_v3, fo_coeff, fo_coeff_now, fo_rcoeff, fo_rcoeff_now, fo_time, fo_rtime;
+        uint32_t mls_n, mls_s;
         /* reverb_stereo: 32 x (Delay >> Fir<U3>) inside Feedback<U32,_,FrameHadamard> (prelude.rs:1732-1762) */
         double rv_room, rv_time, rv_damping, rv_sr;
         float *rv_buf[32];
@@ -370,6 +374,9 @@ static inline float polyblepf(float t, float dt) { /* oscillator.rs:512-523 */
 }
 static bq_coefs bq_by_mode(int mode, float sr, float center, float q, float gain);
 static void onepole_set(onode *n, float c);
+static void rez_set(onode *n, float cutoff, float q);
+static void follow_set(onode *n, float t);
+static void afollow_set(onode *n, float a, float r);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* reset / set_sample_rate / set_hash / ping                                                              */
@@ -424,6 +431,22 @@ static void leaf_reset(onode *n) {
         n->s.phase = n->s.has_initial_phase ? n->s.initial_phase : (float)o_rnd1(n->s.hash);
         break;
     case O_ONEPOLE: n->s.op_x1 = n->s.op_y1 = 0.0f; break;
+    case O_REZ: n->s.rz_buf0 = n->s.rz_buf1 = 0.0f; break; /* rez.rs:57-60 */
+    case O_FOLLOW: /* follow.rs:89-94 */
+        n->s.fo_v1 = n->s.fo_v2 = n->s.fo_v3 = 0.0f;
+        n->s.fo_coeff_now = 1.0f;
+        break;
+    case O_AFOLLOW: /* follow.rs:209-215 */
+        n->s.fo_v1 = n->s.fo_v2 = n->s.fo_v3 = 0.0f;
+        n->s.fo_coeff_now = 1.0f;
+        n->s.fo_rcoeff_now = 1.0f;
+        break;
+    case O_MLS: { /* noise.rs:124-127, MlsState::new_with_seed :66-72 */
+        uint64_t h = n->s.has_seed ? n->s.seed : n->s.hash;
+        uint32_t seed = (uint32_t)(h ^ (h >> 32));
+        n->s.mls_s = 1u + seed % ((1u << n->s.mls_n) - 1u);
+        break;
+    }
     case O_PINKPASS: for (int i = 0; i < 7; i++) n->s.pink[i] = 0.0f; break;
     case O_MORPH: n->s.ic1eq = n->s.ic2eq = 0.0f; break;
     case O_TAP: /* delay.rs:193-196 */
@@ -520,6 +543,18 @@ static void leaf_set_sample_rate(onode *n, double sr) {
         n->s.sr = (float)sr;
         onepole_set(n, n->s.cutoff);
         break;
+    case O_REZ: /* rez.rs:62-65 */
+        n->s.sr = (float)sr;
+        rez_set(n, n->s.cutoff, n->s.q);
+        break;
+    case O_FOLLOW: /* follow.rs:96-99 */
+        n->s.sr = (float)sr;
+        follow_set(n, n->s.fo_time);
+        break;
+    case O_AFOLLOW: /* follow.rs:217-221 */
+        n->s.sr = (float)sr;
+        afollow_set(n, n->s.fo_time, n->s.fo_rtime);
+        break;
     case O_MORPH: /* svf.rs:1072-1074 -> Svf::set_sample_rate */
         n->s.sr = (float)sr;
         n->s.sc = svf_make(O_SVF_PEAK, n->s.sr, n->s.cutoff, n->s.q, n->s.gain);
@@ -580,7 +615,8 @@ void o_set_sample_rate(onode *n, double sr) {
 
 /* AudioNode::set_hash (oscillator.rs:94-97, noise.rs:226-229); default is a no-op (audionode.rs:136-139) */
 static void leaf_set_hash(onode *n, uint64_t hash) {
-    if (n->type == O_SINE || n->type == O_NOISE || n->type == O_WAVESYNTH || n->type == O_PHASE_OSC || n->type == O_CHAOS) {
+    if (n->type == O_SINE || n->type == O_NOISE || n->type == O_WAVESYNTH || n->type == O_PHASE_OSC || n->type == O_CHAOS ||
+        n->type == O_MLS) { /* Mls::set_hash noise.rs:142-145 */
         n->s.hash = hash;
         leaf_reset(n);
     } else if (n->type == O_ADSR_LIVE) { /* envelope.rs:346-349: no reset */
@@ -838,6 +874,89 @@ onode *o_onepole(int kind, int inputs, float cutoff_or_delay) { /* ::new filter.
     return n;
 }
 onode *o_pinkpass(void) { return o_new(O_PINKPASS, 1, 1, 26); } /* filter.rs:190-197 */
+
+/* Rez<f32, N>  rez.rs:23-47 (ID 75): Paul Kellett's resonant two-pole; bandpass = 0 lowpass / 1 bandpass */
+static void rez_set(onode *n, float cutoff, float q) { /* set_cutoff_q :41-46 */
+    n->s.cutoff = cutoff;
+    n->s.rz_f = 2.0f * o_sinf(F32_PI * cutoff / n->s.sr);
+    n->s.q = q;
+    n->s.rz_fb = q + q / (1.0f - n->s.rz_f);
+}
+onode *o_rez(int inputs, float bandpass, float cutoff, float q) {
+    onode *n = o_new(O_REZ, inputs, 1, 75);
+    n->s.rz_buf0 = n->s.rz_buf1 = 0.0f;
+    n->s.rz_f = 1.0f; n->s.rz_fb = 1.0f;
+    n->s.sr = (float)DEFAULT_SR;
+    n->s.rz_bandpass = bandpass;
+    rez_set(n, cutoff, q);
+    return n;
+}
+/* follow.rs:12-24 in f64; `log`/`exp` here are the C library's, the reference's are libm 0.2.15's: both are
+ * accurate to < 1 ulp of f64 and the result is rounded to f32 (F::from_f64), so the f32 coefficient agrees except
+ * when the f64 value sits within ~1e-16 relative of an f32 rounding boundary (parity unpinned at that level). */
+static double halfway_coeff(double samples) {
+    double r0 = log(samples > 1.0 ? samples : 1.0) - 0.861624594696583;
+    double r1 = 1.0 / (1.0 + exp(0.0 - r0));
+    double r2 = r1 * 1.13228543863477 - 0.1322853859;
+    return 1.0 - (r2 < 0.9999999 ? r2 : 0.9999999);
+}
+static void follow_set(onode *n, float t) { /* set_response_time :61-67 */
+    n->s.fo_time = t;
+    n->s.fo_coeff = (float)halfway_coeff((double)(t * n->s.sr));
+    if (n->s.fo_coeff_now < 1.0f) n->s.fo_coeff_now = n->s.fo_coeff;
+}
+onode *o_follow(float response_time) { /* Follow::new :48-56 (ID 24) */
+    onode *n = o_new(O_FOLLOW, 1, 1, 24);
+    n->s.fo_time = response_time;
+    n->s.fo_coeff = 0.0f;
+    leaf_reset(n);
+    leaf_set_sample_rate(n, DEFAULT_SR);
+    return n;
+}
+static void afollow_set(onode *n, float a, float r) { /* set_time :178-192 */
+    n->s.fo_time = a;
+    n->s.fo_rtime = r;
+    n->s.fo_coeff = (float)halfway_coeff((double)(a * n->s.sr));
+    n->s.fo_rcoeff = (float)halfway_coeff((double)(r * n->s.sr));
+    if (n->s.fo_coeff_now < 1.0f) {
+        n->s.fo_coeff_now = n->s.fo_coeff;
+        n->s.fo_rcoeff_now = n->s.fo_rcoeff;
+    }
+}
+onode *o_afollow(float attack_time, float release_time) { /* AFollow::new :157-166 (ID 29) */
+    onode *n = o_new(O_AFOLLOW, 1, 1, 29);
+    n->s.fo_time = attack_time;
+    n->s.fo_rtime = release_time;
+    n->s.fo_coeff = n->s.fo_rcoeff = 0.0f;
+    leaf_reset(n);
+    leaf_set_sample_rate(n, DEFAULT_SR);
+    return n;
+}
+/* Mls::new(MlsState::new(n))  noise.rs:58-62,109-117 (ID 19): state (1 << n) - 1 until the first reset / ping */
+static const uint32_t MLS_POLY[31] = { /* noise.rs:23-55 */
+    0x1u, 0x3u, 0x6u, 0xCu, 0x14u, 0x30u, 0x48u, 0xB8u, 0x110u, 0x240u, 0x500u, 0xCA0u, 0x1B00u, 0x3088u, 0x6000u, 0xD008u,
+    0x12000u, 0x20400u, 0x63000u, 0x90000u, 0x140000u, 0x300000u, 0x420000u, 0xE10000u, 0x1200000u, 0x2000023u, 0x4000013u,
+    0x9000000u, 0x14000000u, 0x20000029u, 0x48000000u};
+onode *o_mls(unsigned bits) {
+    onode *n = o_new(O_MLS, 0, 1, 19);
+    n->s.mls_n = bits;
+    n->s.mls_s = (1u << bits) - 1u;
+    n->s.has_seed = 0; n->s.seed = 0; n->s.hash = 0;
+    return n;
+}
+/* test helper: length of the cycle of MlsState::next from the all-ones state (a maximum length sequence has 2^n - 1) */
+uint64_t o_mls_period(unsigned bits) {
+    const uint32_t mask = (1u << bits) - 1u, start = mask;
+    uint32_t s = start;
+    uint64_t k = 0;
+    do {
+        uint32_t parity = (uint32_t)__builtin_popcount(MLS_POLY[bits - 1] & s) & 1u;
+        s = ((s << 1) | parity) & mask;
+        k++;
+    } while (s != start && k <= (uint64_t)mask + 1u);
+    return k;
+}
+void o_mls_set_seed(onode *n, uint64_t seed) { n->s.has_seed = 1; n->s.seed = seed; } /* Setting::seed :136-140 */
 onode *o_morph(float cutoff, float q, float morph) { /* Morph::new svf.rs:1046-1061, ID 62 */
     onode *n = o_new(O_MORPH, 4, 1, 62);
     n->s.mode = O_SVF_PEAK;
@@ -1081,6 +1200,7 @@ static inline size_t wt_table_index(const owavetable *t, size_t hint, float freq
     }
     return i0;
 }
+static inline float fmaxf_rs(float a, float b) { return fmaxf(a, b); } /* f32::max (lib.rs:200-206): IEEE maxNum */
 static inline float clamp01f(float x) { /* math.rs:136-138: x.max(0).min(1) */
     x = x > 0.0f ? x : 0.0f;
     return x < 1.0f ? x : 1.0f;
@@ -1230,6 +1350,47 @@ void o_tick(onode *n, const float *in, float *out) {
         case O_OP_DCBLOCK: y0 = x - n->s.op_x1 + c * n->s.op_y1; n->s.op_x1 = x; n->s.op_y1 = y0; out[0] = y0; break;
         default: y0 = c * (x - n->s.op_y1) + n->s.op_x1; n->s.op_x1 = x; n->s.op_y1 = y0; out[0] = y0; break;
         }
+        break;
+    }
+    case O_REZ: { /* rez.rs:67-82 */
+        if (n->nin > 1) {
+            float cutoff = in[1], q = in[2];
+            if (cutoff != n->s.cutoff || q != n->s.q) rez_set(n, cutoff, q);
+        }
+        float hp = in[0] - n->s.rz_buf0;
+        float bp = n->s.rz_buf0 - n->s.rz_buf1;
+        n->s.rz_buf0 += n->s.rz_f * (hp + n->s.rz_fb * o_tanhf(bp));
+        n->s.rz_buf1 += n->s.rz_f * (n->s.rz_buf0 - n->s.rz_buf1);
+        out[0] = n->s.rz_buf1 - n->s.rz_bandpass * n->s.rz_buf0;
+        break;
+    }
+    case O_FOLLOW: { /* follow.rs:101-110 */
+        float c = n->s.fo_coeff_now, rc = 1.0f - c;
+        n->s.fo_v1 = c * in[0] + rc * n->s.fo_v1;
+        n->s.fo_v2 = c * n->s.fo_v1 + rc * n->s.fo_v2;
+        n->s.fo_v3 = c * n->s.fo_v2 + rc * n->s.fo_v3;
+        n->s.fo_coeff_now = n->s.fo_coeff;
+        out[0] = n->s.fo_v3;
+        break;
+    }
+    case O_AFOLLOW: { /* follow.rs:223-246 with ScalarOrPair for (T, T), combinator.rs:164-173 */
+        float a = n->s.fo_coeff_now, r = n->s.fo_rcoeff_now, x = in[0];
+#define FPOLE(input, cur) ((cur) + fmaxf_rs(0.0f, (input) - (cur)) * a - fmaxf_rs(0.0f, (cur) - (input)) * r)
+        n->s.fo_v1 = FPOLE(x, n->s.fo_v1);
+        n->s.fo_v2 = FPOLE(n->s.fo_v1, n->s.fo_v2);
+        n->s.fo_v3 = FPOLE(n->s.fo_v2, n->s.fo_v3);
+#undef FPOLE
+        n->s.fo_coeff_now = n->s.fo_coeff;
+        n->s.fo_rcoeff_now = n->s.fo_rcoeff;
+        out[0] = n->s.fo_v3;
+        break;
+    }
+    case O_MLS: { /* noise.rs:129-134, MlsState::next / value :81-96 */
+        float value = (float)((n->s.mls_s >> (n->s.mls_n - 1)) & 1u);
+        uint32_t feedback = MLS_POLY[n->s.mls_n - 1] & n->s.mls_s;
+        uint32_t parity = (uint32_t)__builtin_popcount(feedback) & 1u;
+        n->s.mls_s = ((n->s.mls_s << 1) | parity) & ((1u << n->s.mls_n) - 1u);
+        out[0] = value * 2.0f - 1.0f;
         break;
     }
     case O_PINKPASS: { /* filter.rs:226-246 */

@@ -73,6 +73,8 @@ def lib():
         "o_wavesynth": (P, [P, i]), "o_wavesynth_set_phase": (None, [P, f]),
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
         "o_onepole": (P, [i, i, f]), "o_pinkpass": (P, []), "o_morph": (P, [f, f, f]),
+        "o_rez": (P, [i, f, f, f]), "o_follow": (P, [f]), "o_afollow": (P, [f, f]), "o_mls": (P, [C.c_uint]),
+        "o_mls_set_seed": (None, [P, C.c_uint64]), "o_mls_period": (C.c_uint64, [C.c_uint]),
         "o_tap": (P, [i, f, f]), "o_allnest": (P, [f, P]),
         "o_shaper": (P, [i, f, f]), "o_phase_osc": (P, [i]), "o_osc_set_phase": (None, [P, f]), "o_chaos": (P, [i]),
         "o_nlbiquad": (P, [i, i, i, i, f, f, f, f, f]), "o_math_atanf": (f, [f]), "o_math_wide_atanf": (f, [f]),
@@ -307,6 +309,14 @@ def dcblock_hz(f): return Node(lib().o_onepole(2, 1, f))
 def allpole_delay(d): return Node(lib().o_onepole(3, 1, d))
 def allpole(): return Node(lib().o_onepole(3, 2, 1.0))
 def pinkpass(): return Node(lib().o_pinkpass())
+def lowrez_hz(cutoff, q): return Node(lib().o_rez(1, 0.0, cutoff, q))        # prelude.rs:2566
+def lowrez(): return Node(lib().o_rez(3, 0.0, 440.0, 1.0))                    # prelude.rs:2559 Rez::new(0, 440, 1)
+def bandrez_hz(center, q): return Node(lib().o_rez(1, 1.0, center, q))       # prelude.rs:2590
+def bandrez(): return Node(lib().o_rez(3, 1.0, 440.0, 1.0))                   # prelude.rs:2583
+def follow(t): return Node(lib().o_follow(t))                                # prelude32.rs:1251
+def afollow(a, r): return Node(lib().o_afollow(a, r))                        # prelude32.rs:1266
+def mls_bits(n): return Node(lib().o_mls(n))                                 # prelude32.rs:772
+def mls(): return mls_bits(29)                                               # prelude32.rs:784
 def morph(): return Node(lib().o_morph(440.0, 1.0, 0.0))
 
 

@@ -1,0 +1,93 @@
+"""Bit-exact GPU parity of the nodes added after the first round-1 sweep: Rez (rez.rs), Follow / AFollow (follow.rs),
+Mls (noise.rs) -- SURVEY.md 8(f) row 1 and 8(a) a16."""
+import numpy as np
+import pytest
+
+import oracle as O
+from fundsp_amd import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS, MODE_TICK
+from test_gpu_parity import assert_bit_equal, noise_input, oracle_render, run_bank
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+MODES = [MODE_PROCESS, MODE_TICK]
+
+
+@pytest.mark.parametrize("bandpass", [0.0, 1.0])
+@pytest.mark.parametrize("mode", MODES)
+def test_rez_fixed(gpu, bandpass, mode):
+    V, T = 96, 64 * 3 + 21
+    rng = np.random.default_rng(61)
+    fc = (100.0 + 6000.0 * rng.random(V)).astype(np.float32)
+    q = (0.05 + 0.9 * rng.random(V)).astype(np.float32)
+    b = gpu.Bank("rez_hz", V)
+    b.set_param(":bandpass", bandpass)
+    b.set_param(":cutoff", fc)
+    b.set_param(":q", q)
+    b.set_sample_rate(SR)
+    x = noise_input(V, 1, T, seed=62)
+    for layout in (LAYOUT_VOICE_MINOR, LAYOUT_PLANAR):
+        b.reset()
+        got = run_bank(b, x, T, layout, mode)
+        for v in (0, 1, 31, 64, 95):
+            n = O.bandrez_hz(float(fc[v]), float(q[v])) if bandpass else O.lowrez_hz(float(fc[v]), float(q[v]))
+            n.set_sample_rate(SR)
+            assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"rez_hz voice {v}")
+
+
+def test_rez_with_inputs(gpu):
+    V, T = 64, 64 * 2 + 40
+    x = noise_input(V, 3, T, seed=63)
+    x[:, 1] = 200.0 + 3000.0 * np.abs(x[:, 1])
+    x[:, 1, 50:90] = x[:, 1, 49:50]           # stretches of constant cutoff / q: coefficients must NOT be re-derived
+    x[:, 2] = 0.1 + 0.8 * np.abs(x[:, 2])
+    x[:, 2, 50:90] = x[:, 2, 49:50]
+    b = gpu.Bank("rez", V)
+    b.set_param(":bandpass", 1.0)
+    b.set_sample_rate(SR)
+    got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    for v in (0, 7, 63):
+        n = O.bandrez()
+        n.set_sample_rate(SR)
+        assert_bit_equal(got[v], oracle_render(n, x[v], T, MODE_PROCESS), f"rez voice {v}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_follow_and_afollow(gpu, mode):
+    V, T = 70, 64 * 5 + 9
+    rng = np.random.default_rng(64)
+    rt = (0.0005 + 0.05 * rng.random(V)).astype(np.float32)
+    rel = (0.0005 + 0.05 * rng.random(V)).astype(np.float32)
+    x = np.repeat(noise_input(V, 1, (T + 31) // 32, seed=65), 32, axis=2)[:, :, :T].copy()  # stepped control signal
+    b = gpu.Bank("follow", V)
+    b.set_param(":response_time", rt)
+    b.set_sample_rate(SR)
+    got = np.concatenate([run_bank(b, x, T, LAYOUT_VOICE_MINOR, mode), run_bank(b, x, T, LAYOUT_VOICE_MINOR, mode)], axis=-1)
+    a = gpu.Bank("afollow", V)
+    a.set_param(":attack_time", rt)
+    a.set_param(":release_time", rel)
+    a.set_sample_rate(SR)
+    gota = run_bank(a, x, T, LAYOUT_PLANAR, mode)
+    xx = np.concatenate([x, x], axis=-1)
+    for v in (0, 3, 64, 69):
+        n = O.follow(float(rt[v]))
+        n.set_sample_rate(SR)
+        assert_bit_equal(got[v], oracle_render(n, xx[v], 2 * T, mode), f"follow voice {v}")
+        m = O.afollow(float(rt[v]), float(rel[v]))
+        m.set_sample_rate(SR)
+        assert_bit_equal(gota[v], oracle_render(m, x[v], T, mode), f"afollow voice {v}")
+
+
+@pytest.mark.parametrize("bits", [5, 10, 29, 31])
+def test_mls(gpu, bits):
+    V, T = 64, 64 * 3 + 11
+    b = gpu.Bank("mls", V)
+    b.set_param(":bits", float(bits))
+    b.set_sample_rate(SR)                                   # refreshes the feedback polynomial for the new width
+    seeds = np.arange(V, dtype=np.uint64) * 977 + 5
+    b.set_seed(seeds)
+    got = run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    assert set(np.unique(got)) <= {-1.0, 1.0}
+    for v in (0, 1, 63):
+        n = O.mls_bits(bits)
+        n.set_seed(int(seeds[v]))
+        assert_bit_equal(got[v], oracle_render(n, None, T, MODE_PROCESS), f"mls({bits}) voice {v}")

@@ -244,3 +244,64 @@ def test_taps_check_wave_and_allnest_allpass():
     t.set_sample_rate(sr)
     y = t.render_ticks(np.concatenate([x, np.full((1, 600), 96.0 / sr, np.float32)]))
     assert np.max(np.abs(y[0, 96:] - x[0, :-96])) < 1e-5
+
+
+# ---- SURVEY 8(f) row 1, second half: Rez, Follow, AFollow; and Mls (8a row a16 sibling) -------------------------
+def test_mls_sequences_are_maximum_length():
+    """Pins the transcription of MLS_POLY (noise.rs:23-55): every table entry must generate a cycle of exactly
+    2^n - 1 states (that is what 'maximum length sequence' means), and one period holds 2^(n-1) ones."""
+    for n in range(1, 25):
+        assert O.lib().o_mls_period(n) == (1 << n) - 1, n
+    for n in (25, 28, 31):  # the long ones: a few seconds of C
+        assert O.lib().o_mls_period(n) == (1 << n) - 1, n
+    node = O.mls_bits(10)
+    node.set_seed(5)
+    y = node.render_ticks(length=1023)[0]
+    assert set(np.unique(y)) == {-1.0, 1.0}
+    assert int((y > 0).sum()) == 512          # balance property of an MLS
+    assert np.array_equal(node.render_ticks(length=1023)[0], y)  # period 1023
+
+
+def test_follow_halfway_response():
+    """follow(t) reaches halfway to a new value after t seconds (follow.rs:12-24: accurate to 0.5 %)."""
+    sr = 48000.0
+    for rt in (0.001, 0.01, 0.1):
+        n = O.follow(rt)
+        n.set_sample_rate(sr)
+        x = np.ones((1, int(rt * sr * 3)), dtype=np.float32)
+        x[0, 0] = 0.0                       # the first sample is taken over as is (coeff_now = 1, follow.rs:93,104-109)
+        y = n.render_ticks(x)[0]
+        assert y[0] == 0.0
+        assert abs(y[int(round(rt * sr))] - 0.5) < 0.02, (rt, y[int(round(rt * sr))])
+        assert np.all(np.diff(y) >= 0)      # three one-poles in series: monotone step response
+
+
+def test_afollow_attack_release_asymmetry():
+    sr = 48000.0
+    n = O.afollow(0.001, 0.05)
+    n.set_sample_rate(sr)
+    x = np.concatenate([np.zeros(1), np.ones(4800), np.zeros(4800)]).astype(np.float32)[None, :]
+    y = n.render_ticks(x)[0]
+    up = np.argmax(y[1:4801] >= 0.5)            # halfway up after ~ attack time
+    down = np.argmax(y[4801:] <= 0.5)           # halfway down after ~ release time
+    assert abs(up - 48) <= 3 and abs(down - 2400) <= 60, (up, down)
+    m = O.afollow(0.01, 0.01)                   # equal times behave like follow() after the first sample
+    f = O.follow(0.01)
+    m.set_sample_rate(sr); f.set_sample_rate(sr)
+    z = np.random.default_rng(3).random((1, 500), dtype=np.float32)
+    assert np.allclose(m.render_ticks(z), f.render_ticks(z), atol=2e-6)
+
+
+def test_rez_lowpass_bandpass_and_inputs_variant():
+    sr = 48000.0
+    lp, bp = O.lowrez_hz(1000.0, 0.5), O.bandrez_hz(1000.0, 0.5)
+    lp.set_sample_rate(sr); bp.set_sample_rate(sr)
+    dc = np.ones((1, 4000), dtype=np.float32) * 0.25
+    assert abs(lp.render_ticks(dc)[0, -1] - 0.25) < 1e-3       # lowpass passes DC
+    assert abs(bp.render_ticks(dc)[0, -1]) < 1e-3              # bandpass blocks it
+    # Rez<U3> with constant cutoff / q inputs == Rez<U1> (rez.rs:68-75 only re-derives on change)
+    fixed, var = O.lowrez_hz(700.0, 0.3), O.lowrez()
+    fixed.set_sample_rate(sr); var.set_sample_rate(sr)
+    x = (np.random.default_rng(4).random((1, 300), dtype=np.float32) * 2 - 1).astype(np.float32)
+    xin = np.concatenate([x, np.full_like(x, 700.0), np.full_like(x, 0.3)])
+    assert np.array_equal(fixed.render_ticks(x), var.render_ticks(xin))
