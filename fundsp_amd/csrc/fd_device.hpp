@@ -74,6 +74,16 @@ struct VStore {
 // ---- lifecycle kernels -------------------------------------------------------------------------------------
 // op: 0 = construct (defaults, DEFAULT_SR, constructor ping), 1 = update (set_sample_rate / parameter change),
 //     2 = reset, 3 = set_seed (seeds != null) or re-apply the construction hash (seeds == null)
+// What a node's constructor does about hashing.  Combinators ping themselves with AttoHash::new(Self::ID)
+// (audionode.rs:871-876, 1242-1247, 1389-1394); the engine does the same for a bank's top-level node.
+// Oversampler::new instead pings the ENCLOSED node with AttoHash::new(Self::ID) (oversample.rs:93-95).
+template <class G> struct CtorPing {
+    static FD_D void run(G& g) { uint64_t h = g.ping(true, G::ID); g.ping(false, h); }
+};
+template <class X> struct CtorPing<Oversampler<X>> {
+    static FD_D void run(Oversampler<X>& g) { uint64_t h = g.x.ping(true, Oversampler<X>::ID); g.x.ping(false, h); }
+};
+
 template <class G>
 FD_D void lifecycle_body(float* slots, size_t stride, size_t first, size_t count, int op, double sr,
                          const uint64_t* seeds, const void* aux, float* ring, uint32_t ring_cap) {
@@ -90,8 +100,7 @@ FD_D void lifecycle_body(float* slots, size_t stride, size_t first, size_t count
     if (op == 0) {
         g.init();
         g.update(sr);
-        uint64_t h = g.ping(true, G::ID);  // Pipe::new etc: ping(true, AttoHash::new(Self::ID)) then ping(false, h)
-        g.ping(false, h);
+        CtorPing<G>::run(g);
     } else if (op == 1) {
         g.update(sr);
     } else if (op == 2) {
@@ -100,8 +109,7 @@ FD_D void lifecycle_body(float* slots, size_t stride, size_t first, size_t count
         if (seeds) {
             g.ping(false, seeds[i]);  // AudioNode::set_seed audionode.rs:366-368
         } else {
-            uint64_t h = g.ping(true, G::ID);
-            g.ping(false, h);
+            CtorPing<G>::run(g);
         }
     }
     VStore<true> st{slots + v, stride, 0};

@@ -24,12 +24,19 @@ using SawMoogAdsrPan = Pipe<Binop<OpMul, SawMoog, AdsrLive>, Panner>;
 using SvfShape = Pipe<FixedSvf, Shaper>;
 using SvfShapeSvf = Pipe<SvfShape, FixedSvf>;
 
+// oversample(..) (prelude32.rs:983): the README's canonical FM patch  oversample(sine_hz(f) * f * m + f >> sine())
+// (README.md:1631), and an oversampled waveshaper  oversample(shape(..))  as the 1-in 1-out case
+using OversampleFm = Oversampler<Pipe<FmMod, Sine>>;
+using OversampleShape = Oversampler<Shaper>;
+
 void register_graph_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<SineHz>("sine_hz"));
     out.push_back(make_kind<SineHzLowpass>("sine_hz_lowpass_hz"));
     out.push_back(make_kind<NoiseBiquad>("noise_biquad"));
     out.push_back(make_kind<FmSvf>("fm_svf"));
     out.push_back(make_kind<SawMoogAdsrPan>("saw_moog_adsr_pan"));
+    out.push_back(make_kind<OversampleFm>("oversample_fm"));
+    out.push_back(make_kind<OversampleShape>("oversample_shape"));
     out.push_back(make_kind<SvfShape>("svf_shape"));
     out.push_back(make_kind<SvfShapeSvf>("svf_shape_svf"));
 }

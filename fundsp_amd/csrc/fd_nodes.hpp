@@ -1398,6 +1398,159 @@ struct AllNest {
     FD_STEP2_VIA_STEP
 };
 
+// Oversampler<X>  oversample.rs:66-249 (ID 51): X runs at twice the sample rate between a minimum-phase half-band
+// interpolator and decimator (HALFBAND_MIN :329-373).  The reference keeps 128-sample rings per channel; only the newest
+// 24 input and 48 inner-output samples ever reach a filter (START_SAMPLE_OFFSET_HALF / _FULL :523-524), so the device
+// state is those histories in age order (oldest first) -- the f32x8 lane a sample lands in depends only on its age.
+// wide's mul_add / reduce_add as in the oracle (unfused; low f32x4 sum + high f32x4 sum).
+// Process semantics (:178-212): each half of the outer block feeds ONE inner block of `size` samples through
+// X::process, so the inner node sees begin_block / SIMD items / end_simd / remainder per half; an odd `size` leaves the
+// last outer sample unwritten in the reference (0.0 here, state untouched).  The reference's decimation loop runs
+// over Inputs::USIZE channels (:200) -- a generator is never written at all; this node writes every output channel.
+FD_HD float halfband_min(int i) {
+    constexpr float H[43] = {
+        4.73552339e-02f, 1.81988040e-01f, 3.49148434e-01f, 3.92748135e-01f, 2.18230867e-01f, -5.31842843e-02f,
+        -1.79186566e-01f, -7.34488007e-02f, 8.94524103e-02f, 1.00868556e-01f, -2.08681451e-02f, -8.82510989e-02f,
+        -2.07640777e-02f, 6.22587555e-02f, 4.07776255e-02f, -3.52258090e-02f, -4.57407870e-02f, 1.27033444e-02f,
+        4.14376136e-02f, 3.30799834e-03f, -3.24608206e-02f, -1.27856355e-02f, 2.21659033e-02f, 1.67803711e-02f,
+        -1.27406974e-02f, -1.68177367e-02f, 5.35518220e-03f, 1.44761581e-02f, -3.70651781e-04f, -1.11140183e-02f,
+        -2.40622311e-03f, 7.71596027e-03f, 3.48227062e-03f, -4.86763558e-03f, -3.45536353e-03f, 2.79880054e-03f,
+        2.86736431e-03f, -1.48746153e-03f, -2.11827989e-03f, 7.72684113e-04f, 1.44384114e-03f, -4.49807048e-04f,
+        -9.41945265e-04f};
+    return H[i];
+}
+FD_HD float wide_reduce_add8(const float* a) {
+    float lo = 0.0f, hi = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) lo += a[j];
+#pragma unroll
+    for (int j = 4; j < 8; j++) hi += a[j];
+    return lo + hi;
+}
+template <class X>
+struct Oversampler {
+    static constexpr int IN = X::IN, OUT = X::OUT, RINGS = X::RINGS;
+    static constexpr uint64_t ID = 51;
+    X x;
+    float hin[IN > 0 ? IN : 1][24];  // newest input samples, oldest first
+    float hout[OUT][48];             // newest inner output samples, oldest first
+    int blk_size, blk_i;             // transients of the process walk
+    template <class V> FD_HD void visit(V& v) {
+        v.enter(0); x.visit(v); v.leave();
+#pragma unroll
+        for (int c = 0; c < IN; c++)
+#pragma unroll
+            for (int k = 0; k < 24; k++) v.fi(hin[c][k], STATE, "inv", c * 24 + k);
+#pragma unroll
+        for (int c = 0; c < OUT; c++)
+#pragma unroll
+            for (int k = 0; k < 48; k++) v.fi(hout[c][k], STATE, "outv", c * 48 + k);
+    }
+    FD_HD void bind(Ctx& c) { x.bind(c); }
+    FD_HD void clear() {
+#pragma unroll
+        for (int c = 0; c < IN; c++)
+#pragma unroll
+            for (int k = 0; k < 24; k++) hin[c][k] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < OUT; c++)
+#pragma unroll
+            for (int k = 0; k < 48; k++) hout[c][k] = 0.0f;
+    }
+    FD_HD void init() { x.init(); clear(); }
+    FD_HD void update(double sr) { x.update(sr * 2.0); }                                // :137-140
+    FD_HD void reset() { x.reset(); clear(); }                                          // :131-135
+    FD_HD uint64_t ping(bool probe, uint64_t h) { return x.ping(probe, atto(h, ID)); }  // :218-220
+    FD_HD void begin_block(int n) { blk_size = n; blk_i = 0; }
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    // push one input sample per channel, return the two inner input frames (interpolating_filter :11-41)
+    FD_HD void interpolate(const float* in, float* even, float* odd) {
+#pragma unroll
+        for (int c = 0; c < IN; c++) {
+#pragma unroll
+            for (int k = 0; k < 23; k++) hin[c][k] = hin[c][k + 1];
+            hin[c][23] = in[c];
+            float ae[8], ao[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { ae[j] = 0.0f; ao[j] = 0.0f; }
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = i * 8 + j;
+                    const float ce = k < 2 ? 0.0f : halfband_min(2 * (k - 2));      // INTERPOLATING_EVEN_COEFFS :453-484
+                    const float co = k < 3 ? 0.0f : halfband_min(2 * (k - 3) + 1);  // INTERPOLATING_ODD_COEFFS :488-519
+                    ae[j] = hin[c][k] * ce + ae[j];
+                    ao[j] = hin[c][k] * co + ao[j];
+                }
+            even[c] = wide_reduce_add8(ae) * 2.0f;
+            odd[c] = wide_reduce_add8(ao) * 2.0f;
+        }
+    }
+    FD_HD void push_out(const float* o) {
+#pragma unroll
+        for (int c = 0; c < OUT; c++) {
+#pragma unroll
+            for (int k = 0; k < 47; k++) hout[c][k] = hout[c][k + 1];
+            hout[c][47] = o[c];
+        }
+    }
+    FD_HD void decimate(float* out) const {  // decimating_filter :43-64
+#pragma unroll
+        for (int c = 0; c < OUT; c++) {
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = i * 8 + j;
+                    const float cd = k < 5 ? 0.0f : halfband_min(k - 5);  // DECIMATING_COEFFS :381-449
+                    acc[j] = hout[c][k] * cd + acc[j];
+                }
+            out[c] = wide_reduce_add8(acc);
+        }
+    }
+    FD_HD void inner_process_step(int kk, const float* i, float* o) {  // inner sample kk of an inner block of blk_size
+        const int ifull = blk_size & ~7;
+        if (kk == 0) {
+            x.begin_block(blk_size);
+            if (ifull == 0) x.end_simd();
+        }
+        if (kk < ifull) x.template step<PH_SIMD>(i, o); else x.template step<PH_REM>(i, o);
+        if (kk + 1 == ifull) x.end_simd();
+    }
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        float even[IN > 0 ? IN : 1], odd[IN > 0 ? IN : 1], o[OUT];
+        if (PH == PH_TICK) {  // tick :142-176
+            interpolate(in, even, odd);
+            x.template step<PH_TICK>(even, o);
+            push_out(o);
+            x.template step<PH_TICK>(odd, o);
+            push_out(o);
+            decimate(out);
+        } else {              // process :178-212, walked sample by sample
+            const int half = blk_size >> 1;
+            const int i = blk_i++;
+            if (i >= 2 * half) {  // odd tail: never processed by the reference
+#pragma unroll
+                for (int c = 0; c < OUT; c++) out[c] = 0.0f;
+                return;
+            }
+            const int k = (i >= half ? i - half : i) * 2;
+            interpolate(in, even, odd);
+            inner_process_step(k, even, o);
+            push_out(o);
+            inner_process_step(k + 1, odd, o);
+            push_out(o);
+            decimate(out);
+        }
+    }
+    FD_STEP2_VIA_STEP
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // one-pole family (filter.rs): Lowpole (ID 18), Highpole (ID 47), DCBlock (ID 22), Pinkpass (ID 26), Allpole (ID 46),
 // and Morph (svf.rs:1040-1111, ID 62).  SURVEY 8(f) row 1: same lane-per-voice skeleton as the biquads.

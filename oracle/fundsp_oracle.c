@@ -19,6 +19,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #if defined(__x86_64__) || defined(__i386__)
 #include <xmmintrin.h>
 #endif
@@ -102,6 +103,9 @@ struct onode {
         int osc_kind, lorenz, nl_dirty, nl_mode;
         float cx, cy, cz;
         float ns1, ns2;
+        /* Oversampler<X> (oversample.rs:66-80): 128-sample input / output rings per channel */
+        float *os_inv, *os_outv; /* [channel][128] */
+        size_t os_in_i, os_out_i;
         /* Rez (rez.rs:11-21), Follow / AFollow (follow.rs:31-43,137-152), Mls (noise.rs:14-20,103-107) */
         float rz_buf0, rz_buf1, rz_f, rz_fb, rz_bandpass;
         float fo_v1, fo_v2, fo_v3, fo_coeff, fo_coeff_now, fo_rcoeff, fo_rcoeff_now, fo_time, fo_rtime;
@@ -145,6 +149,8 @@ void o_free(onode *n) {
     free(n->tmp);
     free(n->s.dbuf);
     free(n->s.tbuf);
+    free(n->s.os_inv);
+    free(n->s.os_outv);
     free(n);
 }
 
@@ -432,6 +438,10 @@ static void leaf_reset(onode *n) {
         break;
     case O_ONEPOLE: n->s.op_x1 = n->s.op_y1 = 0.0f; break;
     case O_REZ: n->s.rz_buf0 = n->s.rz_buf1 = 0.0f; break; /* rez.rs:57-60 */
+    case O_OVERSAMPLE: /* oversample.rs:131-135: rings cleared, ring indices kept (child reset by o_reset) */
+        memset(n->s.os_inv, 0, (size_t)(n->nin ? n->nin : 1) * 128 * sizeof(float));
+        memset(n->s.os_outv, 0, (size_t)n->nout * 128 * sizeof(float));
+        break;
     case O_FOLLOW: /* follow.rs:89-94 */
         n->s.fo_v1 = n->s.fo_v2 = n->s.fo_v3 = 0.0f;
         n->s.fo_coeff_now = 1.0f;
@@ -608,6 +618,10 @@ static void leaf_set_sample_rate(onode *n, double sr) {
 }
 
 void o_set_sample_rate(onode *n, double sr) {
+    if (n->type == O_OVERSAMPLE) { /* oversample.rs:137-140 */
+        o_set_sample_rate(n->x, sr * 2.0);
+        return;
+    }
     if (n->x) o_set_sample_rate(n->x, sr);
     if (n->y) o_set_sample_rate(n->y, sr);
     leaf_set_sample_rate(n, sr);
@@ -633,6 +647,7 @@ static uint64_t o_ping(onode *n, int probe, uint64_t hash) {
     case O_BINOP:
         return o_ping(n->y, probe, o_ping(n->x, probe, o_atto(hash, n->id)));
     case O_UNOP:
+    case O_OVERSAMPLE: /* oversample.rs:218-220 */
     case O_ALLNEST: /* delay.rs:337-339 */
         return o_ping(n->x, probe, o_atto(hash, n->id));
     default:
@@ -1046,6 +1061,58 @@ onode *o_reverb_stereo(double room_size, double time, double damping) {
     return n;
 }
 
+/* ---- Oversampler<X>  oversample.rs (ID 51) --------------------------------------------------------------------
+ * HALFBAND_MIN :329-373, grouped into f32x8 slices :381-541.  wide's f32x8 mul_add / reduce_add are restated for the
+ * default x86-64 build (no `fma`, no `avx` target feature): mul_add = a * b + c unfused; reduce_add = sum of the low
+ * f32x4 (iter().sum(): ((0 + a0) + a1) + a2) + a3) plus the same sum of the high f32x4.  Parity unpinned (wide 1.1.1
+ * source is not under /root/reference). */
+static const float HALFBAND_MIN[43] = {
+    4.73552339e-02f, 1.81988040e-01f, 3.49148434e-01f, 3.92748135e-01f, 2.18230867e-01f, -5.31842843e-02f, -1.79186566e-01f,
+    -7.34488007e-02f, 8.94524103e-02f, 1.00868556e-01f, -2.08681451e-02f, -8.82510989e-02f, -2.07640777e-02f, 6.22587555e-02f,
+    4.07776255e-02f, -3.52258090e-02f, -4.57407870e-02f, 1.27033444e-02f, 4.14376136e-02f, 3.30799834e-03f, -3.24608206e-02f,
+    -1.27856355e-02f, 2.21659033e-02f, 1.67803711e-02f, -1.27406974e-02f, -1.68177367e-02f, 5.35518220e-03f, 1.44761581e-02f,
+    -3.70651781e-04f, -1.11140183e-02f, -2.40622311e-03f, 7.71596027e-03f, 3.48227062e-03f, -4.86763558e-03f, -3.45536353e-03f,
+    2.79880054e-03f, 2.86736431e-03f, -1.48746153e-03f, -2.11827989e-03f, 7.72684113e-04f, 1.44384114e-03f, -4.49807048e-04f,
+    -9.41945265e-04f};
+static inline float os_dec_coeff(int k) { return k < 5 ? 0.0f : HALFBAND_MIN[k - 5]; }            /* DECIMATING_COEFFS :381-449 */
+static inline float os_even_coeff(int k) { return k < 2 ? 0.0f : HALFBAND_MIN[2 * (k - 2)]; }     /* INTERPOLATING_EVEN :453-484 */
+static inline float os_odd_coeff(int k) { return k < 3 ? 0.0f : HALFBAND_MIN[2 * (k - 3) + 1]; }  /* INTERPOLATING_ODD :488-519 */
+static inline float wide_reduce_add8(const float *a) {
+    float lo = 0.0f, hi = 0.0f;
+    for (int j = 0; j < 4; j++) lo += a[j];
+    for (int j = 4; j < 8; j++) hi += a[j];
+    return lo + hi;
+}
+static void os_interpolate(const float *ring, size_t new_index, float *even, float *odd) { /* :11-41 */
+    size_t start = new_index + (129 - 3 * 8);
+    float ae[8] = {0}, ao[8] = {0};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 8; j++) {
+            float smp = ring[(start + (size_t)i * 8 + j) & 0x7f];
+            ae[j] = smp * os_even_coeff(i * 8 + j) + ae[j];
+            ao[j] = smp * os_odd_coeff(i * 8 + j) + ao[j];
+        }
+    *even = wide_reduce_add8(ae) * 2.0f;
+    *odd = wide_reduce_add8(ao) * 2.0f;
+}
+static float os_decimate(const float *ring, size_t last_index) { /* :43-64 */
+    size_t start = last_index + (129 - (43 / 8 + 1) * 8);
+    float acc[8] = {0};
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 8; j++) acc[j] = ring[(start + (size_t)i * 8 + j) & 0x7f] * os_dec_coeff(i * 8 + j) + acc[j];
+    return wide_reduce_add8(acc);
+}
+onode *o_oversample(onode *x) { /* Oversampler::new :90-104 */
+    onode *n = o_new(O_OVERSAMPLE, x->nin, x->nout, 51);
+    n->x = x;
+    n->s.os_inv = (float *)calloc((size_t)(x->nin ? x->nin : 1) * 128, sizeof(float));
+    n->s.os_outv = (float *)calloc((size_t)x->nout * 128, sizeof(float));
+    o_set_sample_rate(x, DEFAULT_SR * 2.0);
+    uint64_t h = o_ping(x, 1, 51); /* node.ping(true, AttoHash::new(Self::ID)) -- the inner node, not self */
+    o_ping(x, 0, h);
+    return n;
+}
+
 onode *o_pipe(onode *x, onode *y) { /* Pipe::new audionode.rs:1388-1394, ID 6 */
     if (x->nout != y->nin) return NULL;
     onode *n = o_new(O_PIPE, x->nin, y->nout, 6);
@@ -1434,6 +1501,22 @@ void o_tick(onode *n, const float *in, float *out) {
         out[0] = o;
         break;
     }
+    case O_OVERSAMPLE: { /* oversample.rs:142-176 */
+        float oi[O_MAX_CH], oi2[O_MAX_CH], oo[O_MAX_CH];
+        for (int c = 0; c < n->nin; c++) {
+            n->s.os_inv[c * 128 + n->s.os_in_i] = in[c];
+            os_interpolate(n->s.os_inv + c * 128, n->s.os_in_i, &oi[c], &oi2[c]);
+        }
+        n->s.os_in_i = (n->s.os_in_i + 1) & 0x7f;
+        o_tick(n->x, oi, oo);
+        for (int c = 0; c < n->nout; c++) n->s.os_outv[c * 128 + n->s.os_out_i] = oo[c];
+        n->s.os_out_i = (n->s.os_out_i + 1) & 0x7f;
+        o_tick(n->x, oi2, oo);
+        for (int c = 0; c < n->nout; c++) n->s.os_outv[c * 128 + n->s.os_out_i] = oo[c];
+        for (int c = 0; c < n->nout; c++) out[c] = os_decimate(n->s.os_outv + c * 128, n->s.os_out_i);
+        n->s.os_out_i = (n->s.os_out_i + 1) & 0x7f;
+        break;
+    }
     case O_ALLNEST: { /* delay.rs:322-330 */
         float v = in[0] - n->s.eta * n->s.zz;
         float y = n->s.eta * v + n->s.zz;
@@ -1604,6 +1687,36 @@ static void process_remainder(onode *n, int size, const float *in, float *out) {
 
 void o_process(onode *n, int size, const float *in, float *out) {
     switch (n->type) {
+    case O_OVERSAMPLE: { /* oversample.rs:178-212.  Two passes of size / 2 outer samples; the inner node processes `size`
+                          * inner samples per pass.  An odd `size` leaves the last outer sample untouched (the reference
+                          * never writes it).  Deviation, documented in DESIGN.md: the reference's decimation loop runs
+                          * over Inputs::USIZE channels (:200), so a generator (0 inputs) is never written at all and a
+                          * node with more inputs than outputs indexes out of range; the loop below runs over the
+                          * OUTPUT channels, which is identical whenever inputs == outputs. */
+        float ii[O_MAX_CH * MAXB], io[O_MAX_CH * MAXB];
+        const int offs[2] = {0, size / 2};
+        for (int pass = 0; pass < 2; pass++) {
+            int offset = offs[pass];
+            for (int i = 0; i < size / 2; i++) {
+                for (int c = 0; c < n->nin; c++) {
+                    n->s.os_inv[c * 128 + n->s.os_in_i] = in[c * MAXB + i + offset];
+                    os_interpolate(n->s.os_inv + c * 128, n->s.os_in_i, &ii[c * MAXB + i * 2], &ii[c * MAXB + i * 2 + 1]);
+                }
+                n->s.os_in_i = (n->s.os_in_i + 1) & 0x7f;
+            }
+            o_process(n->x, size, ii, io);
+            for (int i = 0; i < size / 2; i++) {
+                for (int c = 0; c < n->nout; c++) {
+                    n->s.os_outv[c * 128 + n->s.os_out_i] = io[c * MAXB + i * 2];
+                    size_t next = (n->s.os_out_i + 1) & 0x7f;
+                    n->s.os_outv[c * 128 + next] = io[c * MAXB + i * 2 + 1];
+                    out[c * MAXB + i + offset] = os_decimate(n->s.os_outv + c * 128, next);
+                }
+                n->s.os_out_i = (n->s.os_out_i + 2) & 0x7f;
+            }
+        }
+        break;
+    }
     case O_CONSTANT: /* audionode.rs:501-508: splat over simd_items(size) */
         for (int c = 0; c < n->nout; c++)
             for (int j = 0; j < simd_items(size) * 8; j++) out[c * MAXB + j] = n->s.value[c];
@@ -1760,6 +1873,7 @@ void o_render_blocks(onode *n, size_t length, int block, const float *in, float 
         int nn = (int)((length - i) < (size_t)block ? (length - i) : (size_t)block);
         for (int c = 0; c < n->nin; c++)
             for (int j = 0; j < nn; j++) bi[c * MAXB + j] = in[(size_t)c * length + i + j];
+        memset(bo, 0, (size_t)n->nout * MAXB * sizeof(float)); /* samples a node leaves unwritten (Oversampler, odd size) read 0 */
         o_process(n, nn, bi, bo);
         for (int c = 0; c < n->nout; c++)
             for (int j = 0; j < nn; j++) out[(size_t)c * length + i + j] = bo[c * MAXB + j];

@@ -74,7 +74,7 @@ def lib():
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
         "o_onepole": (P, [i, i, f]), "o_pinkpass": (P, []), "o_morph": (P, [f, f, f]),
         "o_rez": (P, [i, f, f, f]), "o_follow": (P, [f]), "o_afollow": (P, [f, f]), "o_mls": (P, [C.c_uint]),
-        "o_mls_set_seed": (None, [P, C.c_uint64]), "o_mls_period": (C.c_uint64, [C.c_uint]),
+        "o_mls_set_seed": (None, [P, C.c_uint64]), "o_oversample": (P, [P]), "o_mls_period": (C.c_uint64, [C.c_uint]),
         "o_tap": (P, [i, f, f]), "o_allnest": (P, [f, P]),
         "o_shaper": (P, [i, f, f]), "o_phase_osc": (P, [i]), "o_osc_set_phase": (None, [P, f]), "o_chaos": (P, [i]),
         "o_nlbiquad": (P, [i, i, i, i, f, f, f, f, f]), "o_math_atanf": (f, [f]), "o_math_wide_atanf": (f, [f]),
@@ -316,7 +316,8 @@ def bandrez(): return Node(lib().o_rez(3, 1.0, 440.0, 1.0))                   # 
 def follow(t): return Node(lib().o_follow(t))                                # prelude32.rs:1251
 def afollow(a, r): return Node(lib().o_afollow(a, r))                        # prelude32.rs:1266
 def mls_bits(n): return Node(lib().o_mls(n))                                 # prelude32.rs:772
-def mls(): return mls_bits(29)                                               # prelude32.rs:784
+def mls(): return mls_bits(29)
+def oversample(x): return Node(lib().o_oversample(x.ptr), [x])                # prelude32.rs:983                                               # prelude32.rs:784
 def morph(): return Node(lib().o_morph(440.0, 1.0, 0.0))
 
 

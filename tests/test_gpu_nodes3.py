@@ -91,3 +91,48 @@ def test_mls(gpu, bits):
         n = O.mls_bits(bits)
         n.set_seed(int(seeds[v]))
         assert_bit_equal(got[v], oracle_render(n, None, T, MODE_PROCESS), f"mls({bits}) voice {v}")
+
+
+# ---- Oversampler ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", [LAYOUT_VOICE_MINOR, LAYOUT_PLANAR])
+@pytest.mark.parametrize("mode", MODES)
+def test_oversample_fm(gpu, layout, mode):
+    """oversample(sine_hz(f) * f * m + f >> sine())  (README.md:1631): per-voice f, m; tick and process walks.
+    T is even per block (the reference leaves the last sample of an odd block unwritten; covered below)."""
+    from fundsp_amd import workloads as W
+
+    V, T = 70, 64 * 3 + 22
+    p = W.fm_svf_params(V, SR)
+    b = gpu.Bank("oversample_fm", V)
+    b.set_param("0.0.0.0.0.0:value[0]", p["f"])        # Constant inside sine_hz
+    b.set_param("0.0.0.0:scalar", p["f"])              # * f
+    b.set_param("0.0.0:scalar", p["m"])                # * m
+    b.set_param("0.0:scalar", p["f"])                  # + f
+    b.set_sample_rate(SR)
+    seeds = np.arange(V, dtype=np.uint64) + 11
+    b.set_seed(seeds)
+    got = np.concatenate([run_bank(b, None, T, layout, mode), run_bank(b, None, T, layout, mode)], axis=-1)
+    for v in (0, 5, 64, 69):
+        f, m = float(p["f"][v]), float(p["m"][v])
+        n = O.oversample(O.sine_hz(f) * f * m + f >> O.sine())
+        n.set_sample_rate(SR)
+        n.set_seed(int(seeds[v]))
+        want = np.concatenate([oracle_render(n, None, T, mode), oracle_render(n, None, T, mode)], axis=-1)
+        assert_bit_equal(got[v], want, f"oversample_fm voice {v}")
+
+
+@pytest.mark.parametrize("T", [64 * 2 + 40, 64 + 5, 7])
+@pytest.mark.parametrize("mode", MODES)
+def test_oversample_shape(gpu, mode, T):
+    """oversample(shape(Tanh(2))): 1 in, 1 out; odd block tails follow the reference's process (last sample unwritten -> 0)."""
+    V = 64
+    x = noise_input(V, 1, T, seed=71)
+    b = gpu.Bank("oversample_shape", V)
+    b.set_param("0:shape", float(O.SHAPES["tanh"]))
+    b.set_param("0:shape_p0", 2.0)
+    b.set_sample_rate(SR)
+    got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, mode)
+    for v in (0, 33, 63):
+        n = O.oversample(O.shape("tanh", 2.0))
+        n.set_sample_rate(SR)
+        assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"oversample_shape voice {v} T={T}")
