@@ -143,4 +143,16 @@ double o_bank_render(const o_bank_job *job, float *out);
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- Sequencer (sequencer.rs), oracle/o_sequencer.c: one event per voice, per-event inputs allowed --------------- */
+typedef struct oseq oseq;
+oseq *o_seq_new(int inputs, int outputs, double sample_rate);
+void o_seq_free(oseq *s);
+/* ease: 0 = Fade::Power, 1 = Fade::Smooth; takes ownership of unit; returns the event's index or -1 */
+int o_seq_push(oseq *s, double start, double end, int ease, double fade_in, double fade_out, onode *unit);
+void o_seq_process(oseq *s, int size, const float *in, float *mix, float *per_event);
+void o_seq_tick(oseq *s, const float *in, float *mix, float *per_event);
+void o_seq_render(oseq *s, size_t length, int process, const float *in, float *mix, float *per_event);
+double o_seq_time(const oseq *s);
+
 #endif

@@ -74,7 +74,9 @@ def lib():
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
         "o_onepole": (P, [i, i, f]), "o_pinkpass": (P, []), "o_morph": (P, [f, f, f]),
         "o_rez": (P, [i, f, f, f]), "o_follow": (P, [f]), "o_afollow": (P, [f, f]), "o_mls": (P, [C.c_uint]),
-        "o_mls_set_seed": (None, [P, C.c_uint64]), "o_oversample": (P, [P]), "o_mls_period": (C.c_uint64, [C.c_uint]),
+        "o_mls_set_seed": (None, [P, C.c_uint64]), "o_oversample": (P, [P]),
+        "o_seq_new": (P, [i, i, d]), "o_seq_free": (None, [P]), "o_seq_push": (i, [P, d, d, i, d, d, P]),
+        "o_seq_render": (None, [P, C.c_size_t, i, fp, fp, fp]), "o_seq_time": (d, [P]), "o_mls_period": (C.c_uint64, [C.c_uint]),
         "o_tap": (P, [i, f, f]), "o_allnest": (P, [f, P]),
         "o_shaper": (P, [i, f, f]), "o_phase_osc": (P, [i]), "o_osc_set_phase": (None, [P, f]), "o_chaos": (P, [i]),
         "o_nlbiquad": (P, [i, i, i, i, f, f, f, f, f]), "o_math_atanf": (f, [f]), "o_math_wide_atanf": (f, [f]),
@@ -394,3 +396,40 @@ def bank_render(config, params, seeds, frames, sample_rate=48000.0, process_mode
         out = np.zeros((frames, V) if out_layout == 1 else (V, frames), dtype=np.float32)
     secs = lib().o_bank_render(C.byref(job), _fptr(out))
     return out, secs
+
+
+FADE_POWER, FADE_SMOOTH = 0, 1
+
+
+class Sequencer:
+    """sequencer.rs Sequencer (ReplayMode::None): push events, render.  Every event may have its own input stream."""
+
+    def __init__(self, inputs, outputs, sample_rate):
+        self.ptr = lib().o_seq_new(inputs, outputs, float(sample_rate))
+        self.inputs, self.outputs, self.n = inputs, outputs, 0
+
+    def __del__(self):
+        if self.ptr and _lib is not None:
+            _lib.o_seq_free(self.ptr)
+            self.ptr = None
+
+    def push(self, start, end, fade, fade_in, fade_out, node):
+        idx = lib().o_seq_push(self.ptr, float(start), float(end), int(fade), float(fade_in), float(fade_out), node.ptr)
+        if idx < 0:
+            raise ValueError("sequencer: arity mismatch or fade longer than the event")
+        node._owned = False
+        self._keep = getattr(self, "_keep", []) + [node]
+        self.n += 1
+        return idx
+
+    def render(self, length, process=True, inputs=None):
+        """-> (mix [outputs][length], per_event [events][outputs][length]); inputs [events][inputs][length] or None"""
+        x = np.zeros((max(self.n, 1), max(self.inputs, 1), length), dtype=np.float32)
+        if inputs is not None and self.inputs:
+            x[:self.n, :self.inputs] = np.asarray(inputs, dtype=np.float32).reshape(self.n, self.inputs, length)
+        mix = np.zeros((self.outputs, length), dtype=np.float32)
+        per = np.zeros((max(self.n, 1), self.outputs, length), dtype=np.float32)
+        lib().o_seq_render(self.ptr, length, 1 if process else 0, _fptr(x), _fptr(mix), _fptr(per))
+        return mix, per[:self.n]
+
+    def time(self): return lib().o_seq_time(self.ptr)
