@@ -12,6 +12,7 @@ SO_PATH = os.environ.get("FUNDSP_HIP_LIB") or os.path.join(_HERE, "libfundsp_hip
 OK, EINVAL, ENOMEM, EDEVICE = 0, -1, -2, -3
 LAYOUT_VOICE_MINOR, LAYOUT_PLANAR = 0, 1
 MODE_PROCESS, MODE_TICK = 0, 1
+FADE_POWER, FADE_SMOOTH = 0, 1  # sequencer.rs Fade::Power / Fade::Smooth
 MAX_BUFFER_SIZE = 64
 DEFAULT_SR = 44100.0
 
@@ -52,6 +53,10 @@ SYMBOLS = {
     "fdsp_bank_set_state": (_i, [_P, _fp]),
     "fdsp_bank_process": (_i, [_P, _sz, _P, _P, _i, _sz, _i, _P]),
     "fdsp_bank_process_host": (_i, [_P, _sz, _fp, _fp, _i, _sz, _i]),
+    "fdsp_bank_set_events": (_i, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int), _sz, _sz]),
+    "fdsp_bank_process_events": (_i, [_P, _sz, _P, _P, _i, _P]),
+    "fdsp_bank_events_rewind": (_i, [_P, _d]),
+    "fdsp_bank_events_time": (_d, [_P]),
     "fdsp_bank_synchronize": (_i, [_P]),
     "fdsp_bank_last_kernel_ms": (_i, [_P, C.POINTER(C.c_float)]),
     "fdsp_mix_stereo": (_i, [_P, _P, _P, _sz, _sz, _P]),

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS, MODE_TICK, check, lib
+from ._lib import FADE_POWER, FADE_SMOOTH, LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS, MODE_TICK, check, lib
 
 SVF_MODES = dict(lowpass=0, highpass=1, bandpass=2, notch=3, peak=4, allpass=5, bell=6, lowshelf=7, highshelf=8)
 BQ_KINDS = dict(butter=0, resonator=1, lowpass=2, highpass=3, bell=4)
@@ -168,6 +168,45 @@ class Bank:
             stream = torch.cuda.current_stream().cuda_stream
         check(lib().fdsp_bank_process(self._h, frames, d_in, C.c_void_p(out.data_ptr()), layout, fs, mode,
                                       C.c_void_p(stream) if stream else None))
+        return out
+
+    # --- voice scheduler: Sequencer::push / process with one event per voice (sequencer.rs:355-398, 838-951)
+    def set_events(self, start, end, fade_in=0.0, fade_out=0.0, fade=FADE_SMOOTH, first=0):
+        """Per-voice events in seconds on the sequencer clock; scalars broadcast.  Resets nothing else."""
+        start = np.atleast_1d(np.asarray(start, dtype=np.float64))
+        n = start.size
+        ev = np.empty((n, 4), dtype=np.float64)
+        ev[:, 0] = start
+        ev[:, 1] = np.broadcast_to(np.asarray(end, dtype=np.float64), (n,))
+        ev[:, 2] = np.broadcast_to(np.asarray(fade_in, dtype=np.float64), (n,))
+        ev[:, 3] = np.broadcast_to(np.asarray(fade_out, dtype=np.float64), (n,))
+        fd = np.ascontiguousarray(np.broadcast_to(np.asarray(fade, dtype=np.int32), (n,)))
+        check(lib().fdsp_bank_set_events(self._h, ev.ctypes.data_as(C.POINTER(C.c_double)),
+                                         fd.ctypes.data_as(C.POINTER(C.c_int)), first, n))
+
+    def events_rewind(self, time=0.0):
+        check(lib().fdsp_bank_events_rewind(self._h, float(time)))
+
+    def events_time(self):
+        return lib().fdsp_bank_events_time(self._h)
+
+    def process_events(self, frames, inp=None, out=None, mode=MODE_PROCESS, stream=None):
+        """Sequencer rendering: out [outputs, frames, V] = every voice's faded contribution (0 outside its event)."""
+        import torch
+
+        frames = int(frames)
+        ni, no = self.inputs(), self.outputs()
+        if out is None:
+            out = torch.empty((no, frames, self.voices), dtype=torch.float32, device="cuda")
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+        d_in = None
+        if ni:
+            assert inp is not None and inp.is_cuda and inp.dtype == torch.float32 and inp.is_contiguous()
+            d_in = C.c_void_p(inp.data_ptr())
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        check(lib().fdsp_bank_process_events(self._h, frames, d_in, C.c_void_p(out.data_ptr()), mode,
+                                             C.c_void_p(stream) if stream else None))
         return out
 
     def process_host(self, frames, inp=None, layout=LAYOUT_PLANAR, frame_stride=None, mode=MODE_PROCESS):

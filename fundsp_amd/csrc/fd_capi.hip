@@ -6,6 +6,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <limits>
 #include <vector>
 
 #include "../../include/fundsp_hip.h"
@@ -212,6 +213,10 @@ struct fdsp_bank {
     bool timed;
     double sr;
     std::unordered_map<std::string, int> index;
+    // voice scheduler (fdsp_bank_set_events / fdsp_bank_process_events): device [4][stride] f64 + [stride] int, clock
+    double* ev = nullptr;
+    int* ev_fade = nullptr;
+    double seq_time = 0.0;
 };
 
 namespace {
@@ -497,6 +502,8 @@ void fdsp_bank_destroy(fdsp_bank* b) {
     }
     if (b->slots) hipFree(b->slots);
     if (b->ring) hipFree(b->ring);
+    if (b->ev) hipFree(b->ev);
+    if (b->ev_fade) hipFree(b->ev_fade);
     hipEventDestroy(b->e0);
     hipEventDestroy(b->e1);
     if (b->stream) hipStreamDestroy(b->stream);
@@ -660,6 +667,74 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->e1, s));
     b->timed = true;
+    return FDSP_OK;
+}
+
+int fdsp_bank_set_events(fdsp_bank* b, const double* events, const int* fade, size_t first, size_t count) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    if (b->fdn) return fail(FDSP_EINVAL, "reverb banks have no event scheduler");
+    if (!events) return fail(FDSP_EINVAL, "events is NULL");
+    if (int rc = check_range(b, first, count)) return rc;
+    for (size_t i = 0; i < count; i++) {  // Sequencer::push asserts (sequencer.rs:366-367)
+        const double* e = events + 4 * i;
+        const double duration = e[1] - e[0];
+        if (!(e[2] <= duration && e[3] <= duration) || e[2] < 0.0 || e[3] < 0.0)
+            return fail(FDSP_EINVAL, "event fade times must be >= 0 and may not exceed the event's duration");
+        if (fade && fade[i] != FDSP_FADE_POWER && fade[i] != FDSP_FADE_SMOOTH) return fail(FDSP_EINVAL, "bad fade curve");
+    }
+    if (!b->ev) {
+        HIPCHK(hipMalloc((void**)&b->ev, 4 * b->stride * sizeof(double)));
+        HIPCHK(hipMalloc((void**)&b->ev_fade, b->stride * sizeof(int)));
+        // voices without an event never play: start = end = +inf
+        std::vector<double> init(4 * b->stride, 0.0);
+        for (size_t v = 0; v < b->stride; v++) init[v] = init[b->stride + v] = std::numeric_limits<double>::infinity();
+        std::vector<int> fi(b->stride, FDSP_FADE_SMOOTH);
+        HIPCHK(hipMemcpyAsync(b->ev, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipMemcpyAsync(b->ev_fade, fi.data(), fi.size() * sizeof(int), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
+    std::vector<double> col(count);
+    for (int k = 0; k < 4; k++) {
+        for (size_t i = 0; i < count; i++) col[i] = events[4 * i + k];
+        HIPCHK(hipMemcpyAsync(b->ev + (size_t)k * b->stride + first, col.data(), count * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
+    std::vector<int> fv(count, FDSP_FADE_SMOOTH);
+    if (fade) fv.assign(fade, fade + count);
+    HIPCHK(hipMemcpyAsync(b->ev_fade + first, fv.data(), count * sizeof(int), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return FDSP_OK;
+}
+
+int fdsp_bank_events_rewind(fdsp_bank* b, double time) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    b->seq_time = time;
+    return FDSP_OK;
+}
+
+double fdsp_bank_events_time(const fdsp_bank* b) { return b ? b->seq_time : 0.0; }
+
+int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, float* d_out, int mode, void* stream) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    if (frames == 0) return FDSP_OK;
+    if (!b->ev) return fail(FDSP_EINVAL, "no events set (fdsp_bank_set_events)");
+    if (!d_out) return fail(FDSP_EINVAL, "d_out is NULL");
+    if (fdsp_bank_inputs(b) > 0 && !d_in) return fail(FDSP_EINVAL, "d_in is NULL but the graph has inputs");
+    if (mode != FDSP_MODE_PROCESS && mode != FDSP_MODE_TICK) return fail(FDSP_EINVAL, "bad mode");
+    hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+    if (s != b->stream) HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipEventRecord(b->e0, s));
+    b->ops->render_events(b->slots, b->stride, b->V, d_in, d_out, frames, b->ev, b->ev_fade, b->seq_time, b->sr, mode,
+                          device_aux(), b->ring, b->ring_cap, s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b->e1, s));
+    b->timed = true;
+    // advance the sequencer clock exactly as the reference does: one f64 addition per block / per sample
+    const double sd = 1.0 / b->sr;
+    if (mode == FDSP_MODE_PROCESS)
+        for (size_t t0 = 0; t0 < frames; t0 += 64) b->seq_time += sd * (double)(frames - t0 < 64 ? frames - t0 : 64);
+    else
+        for (size_t t = 0; t < frames; t++) b->seq_time += sd;
     return FDSP_OK;
 }
 

@@ -378,6 +378,176 @@ __global__ __launch_bounds__(64 * WPB) void k_render(float* __restrict__ slots, 
     render_body<G, MODE, LAYOUT, WPB>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
 }
 
+// ---- on-device voice scheduler: Sequencer semantics, one event per voice ---------------------------
+// Reference: src/sequencer.rs, ReplayMode::None, no loop point: push :355-398, ready_to_active :584-605, process
+// :838-951, tick :769-836, fade_in / fade_out :122-216, smooth5 / sine_ease math.rs:418-420,453-458.
+// Voice v plays from ev[0][v] = start_time to ev[1][v] = end_time (seconds on the sequencer clock, f64 like the
+// reference) with fade-in / fade-out times ev[2][v], ev[3][v] and curve fade[v] (0 = Fade::Power, 1 = Fade::Smooth).
+// The kernel writes every voice's own faded contribution to [channel][frame][voice] (0 outside the event); the sum
+// over voices is fdsp_sum_voices.  Exactly as in the reference, a unit is processed in the part of each 64-frame
+// sequencer block that its event overlaps -- a SHORTER process() block at its start and end -- and the fade factors
+// are re-derived per block from the f64 clock and accumulated in f32 inside the block.
+FD_HD float smooth5f(float x) { return ((x * 6.0f - 15.0f) * x + 10.0f) * x * x * x; }
+FD_HD float sine_easef(float x) {  // Bhaskara's approximation, math.rs:453-458
+    constexpr float PI_F = (float)3.14159265358979323846, HALF_PI_F = (float)(3.14159265358979323846 * 0.5);
+    constexpr float D = (float)(5.0 * 3.14159265358979323846 * 3.14159265358979323846);
+    x = x * HALF_PI_F;
+    return 16.0f * x * (PI_F - x) / (D - 4.0f * x * (PI_F - x));
+}
+FD_HD float fade_at(int ease, float x) { return ease == 0 ? sine_easef(x) : smooth5f(x); }
+FD_HD long long round_index(double x) {  // `round(x) as usize`: half away from zero, negative / NaN -> 0
+    double r = __builtin_round(x);
+    return r > 0.0 ? (r < 4.0e18 ? (long long)r : (long long)4.0e18) : 0;
+}
+
+template <class G, int MODE>
+FD_D void render_events_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
+                             float* __restrict__ out, size_t T, const double* __restrict__ ev,
+                             const int* __restrict__ fade, double time0, double sample_rate, const void* aux, float* ring,
+                             uint32_t ring_cap) {
+    constexpr int NI = G::IN, NO = G::OUT;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t v0 = ((size_t)blockIdx.x * 4 + wib) * 64;
+    const size_t v = v0 + lane;
+    if (v0 >= stride) return;
+    if (v >= V) return;
+    G g;
+    Ctx ctx{static_cast<const Aux*>(aux), ring + v, ring_cap, stride, 0};
+    g.bind(ctx);
+    {
+        VLoad ld{slots + v, stride, 0};
+        g.visit(ld);
+    }
+    const double e_start = ev[v], e_end = ev[stride + v], e_fin = ev[2 * stride + v], e_fout = ev[3 * stride + v];
+    const int ease = fade ? fade[v] : 1;
+    const double sd = 1.0 / sample_rate;  // Sequencer::set_sample_rate :752-753
+    double time = time0;
+    const float* inv = in + v;
+    float* outv = out + v;
+    if (MODE == MODE_PROCESS) {
+        for (size_t t0 = 0; t0 < T; t0 += 64) {
+            const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+            const double end_time = time + sd * (double)size;
+            const double threshold = end_time - sd * 0.5;                       // ready_to_active :586
+            bool act = e_start < threshold && !(e_end <= time + 0.5 * sd);      // :588, :861
+            long long start_index = e_start <= time ? 0 : round_index((e_start - time) * sample_rate);
+            long long end_index = size;
+            if (!(e_end >= end_time)) {
+                long long r = round_index((e_end - time) * sample_rate);
+                end_index = r < size ? r : size;
+            }
+            act = act && end_index > start_index;
+            const int n = act ? (int)(end_index - start_index) : 0;
+            const int full = n & ~7;
+            // fade_in :122-167
+            bool fin_on = false;
+            long long fin_end_i = 0;
+            float fin_cur = 0.0f, fin_d = 0.0f;
+            {
+                const double fade_end = e_start + e_fin;
+                if (act && e_fin > 0.0 && fade_end > time) {
+                    fin_on = true;
+                    fin_end_i = fade_end >= end_time ? end_index : round_index((fade_end - time) / sd);
+                    fin_cur = (float)(((time + (double)start_index * sd) - e_start) / (fade_end - e_start));
+                    fin_d = (float)(sd / e_fin);
+                }
+            }
+            // fade_out :169-216
+            bool fout_on = false;
+            long long fout_i = 0;
+            float fout_cur = 0.0f, fout_d = 0.0f;
+            {
+                const double fade_start = e_end - e_fout;
+                if (act && e_fout > 0.0 && fade_start < end_time) {
+                    fout_on = true;
+                    fout_i = fade_start <= time ? 0 : round_index((fade_start - time) / sd);
+                    fout_cur = (float)(((time + (double)fout_i * sd) - fade_start) / (e_end - fade_start));
+                    fout_d = (float)(sd / e_fout);
+                }
+            }
+            if (act) {
+                g.begin_block(n);
+                if (full == 0) g.end_simd();
+            }
+            for (int i = 0; i < size; i++) {
+                const size_t t = t0 + i;
+                float fo[NO];
+#pragma unroll
+                for (int c = 0; c < NO; c++) fo[c] = 0.0f;
+                if (act && i >= start_index && i < end_index) {
+                    const int k = i - (int)start_index;  // index in the event's own sub-block buffer
+                    float fi[NI > 0 ? NI : 1];
+#pragma unroll
+                    for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
+                    if (k < full) g.template step<PH_SIMD>(fi, fo); else g.template step<PH_REM>(fi, fo);
+                    if (k + 1 == full) g.end_simd();
+                    if (fin_on && k < fin_end_i) {
+                        const float e = fade_at(ease, fin_cur);
+#pragma unroll
+                        for (int c = 0; c < NO; c++) fo[c] *= e;
+                        fin_cur += fin_d;
+                    }
+                    if (fout_on && k >= fout_i && k < end_index) {
+                        const float e = fade_at(ease, 1.0f - fout_cur);
+#pragma unroll
+                        for (int c = 0; c < NO; c++) fo[c] *= e;
+                        fout_cur += fout_d;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+            }
+            time = end_time;
+        }
+    } else {
+        for (size_t t = 0; t < T; t++) {  // Sequencer::tick :769-836
+            const double end_time = time + sd;
+            const double threshold = end_time - sd * 0.5;
+            const bool act = e_start < threshold && !(e_end <= time + 0.5 * sd);
+            float fo[NO];
+#pragma unroll
+            for (int c = 0; c < NO; c++) fo[c] = 0.0f;
+            if (act) {
+                float fi[NI > 0 ? NI : 1];
+#pragma unroll
+                for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
+                g.template step<PH_TICK>(fi, fo);
+                if (e_fin > 0.0) {
+                    const float f = (float)((time - e_start) / ((e_start + e_fin) - e_start));
+                    if (f < 1.0f) {
+                        const float e = fade_at(ease, f);
+#pragma unroll
+                        for (int c = 0; c < NO; c++) fo[c] *= e;
+                    }
+                }
+                if (e_fout > 0.0) {
+                    const float f = (float)((time - (e_end - e_fout)) / (e_end - (e_end - e_fout)));
+                    if (f > 0.0f) {
+                        const float e = fade_at(ease, 1.0f - f);
+#pragma unroll
+                        for (int c = 0; c < NO; c++) fo[c] *= e;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+            time = end_time;
+        }
+    }
+    VStore<false> st{slots + v, stride, 0};
+    g.visit(st);
+}
+
+template <class G, int MODE>
+__global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots, size_t stride, size_t V,
+                                                      const float* __restrict__ in, float* __restrict__ out, size_t T,
+                                                      const double* __restrict__ ev, const int* __restrict__ fade,
+                                                      double time0, double sample_rate, const void* aux, float* ring,
+                                                      uint32_t ring_cap) {
+    render_events_body<G, MODE>(slots, stride, V, in, out, T, ev, fade, time0, sample_rate, aux, ring, ring_cap);
+}
+
 // ---- multi-wave pipeline split of a Pipe chain ------------------------------------------------------------------
 // At one voice-wave per SIMD (65 536 voices on 1024 SIMDs) a lone wave issues one instruction per ~4.7 cycles while
 // the VALU could take one every ~2.5-3.3 (profiles/r01_ubench_valu.txt, r01_voice_sweep_*).  For graphs that are a

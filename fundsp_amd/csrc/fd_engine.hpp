@@ -52,6 +52,11 @@ struct KindOps {
     std::function<void(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
                        int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s)>
         render;
+    // Sequencer-style rendering (fd_device.hpp render_events_body): ev = device [4][stride] f64, fade = device [V] or null
+    std::function<void(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, const double* ev,
+                       const int* fade, double time0, double sr, int mode, const void* aux, float* ring,
+                       uint32_t ring_cap, hipStream_t s)>
+        render_events;
 };
 
 template <class G>
@@ -129,6 +134,20 @@ void launch_render(float* slots, size_t stride, size_t V, const float* in, float
 }
 
 template <class G>
+void launch_render_events(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, const double* ev,
+                          const int* fade, double time0, double sr, int mode, const void* aux, float* ring,
+                          uint32_t ring_cap, hipStream_t s) {
+    if (V == 0 || T == 0) return;
+    const unsigned grid = (unsigned)(((V + 63) / 64 + 3) / 4);
+    if (mode == MODE_PROCESS)
+        hipLaunchKernelGGL((k_render_events<G, MODE_PROCESS>), dim3(grid), dim3(256), 0, s, slots, stride, V, in, out, T, ev,
+                           fade, time0, sr, aux, ring, ring_cap);
+    else
+        hipLaunchKernelGGL((k_render_events<G, MODE_TICK>), dim3(grid), dim3(256), 0, s, slots, stride, V, in, out, T, ev,
+                           fade, time0, sr, aux, ring, ring_cap);
+}
+
+template <class G>
 KindOps make_kind(const char* name) {
     KindOps k;
     k.name = name;
@@ -140,6 +159,7 @@ KindOps make_kind(const char* name) {
     g.visit(d);
     k.lifecycle = &launch_lifecycle<G>;
     k.render = &launch_render<G>;
+    k.render_events = &launch_render_events<G>;
     return k;
 }
 

@@ -43,6 +43,7 @@ struct JitModule {
     hipModule_t mod = nullptr;
     hipFunction_t lifecycle = nullptr, describe = nullptr;
     hipFunction_t render[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [mode][layout]
+    hipFunction_t events[2] = {nullptr, nullptr};                            // [mode]
     int wpb[2] = {4, 4};                                                     // per layout
     ~JitModule() {
         if (mod) hipModuleUnload(mod);
@@ -69,6 +70,14 @@ std::string jit_source(const std::string& type_expr) {
                  "  fd::render_body<JitG, " + m + ", " + l + ", JIT_WPB" + l +
                  ">(slots, stride, V, in, out, T, fstride, aux, ring, cap); }\n";
         }
+    for (int mode = 0; mode < 2; mode++) {
+        std::string m = std::to_string(mode);
+        s += "extern \"C\" __global__ __launch_bounds__(256) void jit_events_" + m +
+             "(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ out, "
+             "size_t T, const double* __restrict__ ev, const int* __restrict__ fade, double time0, double sr, const void* aux, "
+             "float* ring, uint32_t cap) {\n"
+             "  fd::render_events_body<JitG, " + m + ">(slots, stride, V, in, out, T, ev, fade, time0, sr, aux, ring, cap); }\n";
+    }
     s += "extern \"C\" __global__ void jit_describe(char* out, int cap, int* meta) { fd::describe_body<JitG>(out, cap, meta); }\n";
     return s;
 }
@@ -126,6 +135,10 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, KindOps
             std::string fn = "jit_render_" + std::to_string(m) + std::to_string(l);
             ok = hipModuleGetFunction(&jm->render[m][l], jm->mod, fn.c_str()) == hipSuccess;
         }
+    for (int m = 0; m < 2 && ok; m++) {
+        std::string fn = "jit_events_" + std::to_string(m);
+        ok = hipModuleGetFunction(&jm->events[m], jm->mod, fn.c_str()) == hipSuccess;
+    }
     if (!ok) {
         *err = "compiled graph is missing an entry point";
         return -1;
@@ -181,6 +194,13 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, KindOps
         void* args[] = {&slots, &stride, &V, &in, &outp, &T, &fstride, &aux, &ring, &ring_cap};
         hipModuleLaunchKernel(jm->render[mode][layout], (unsigned)((waves + wpb - 1) / wpb), 1, 1, 64 * wpb, 1, 1, 0, s,
                               args, nullptr);
+    };
+    out->render_events = [jm](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T,
+                              const double* ev, const int* fade, double time0, double sr, int mode, const void* aux,
+                              float* ring, uint32_t ring_cap, hipStream_t s) {
+        if (V == 0 || T == 0) return;
+        void* args[] = {&slots, &stride, &V, &in, &outp, &T, &ev, &fade, &time0, &sr, &aux, &ring, &ring_cap};
+        hipModuleLaunchKernel(jm->events[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, 256, 1, 1, 0, s, args, nullptr);
     };
     return 0;
 }

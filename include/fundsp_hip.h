@@ -168,6 +168,25 @@ int fdsp_bank_synchronize(fdsp_bank* bank);
 /* Device time in milliseconds of the most recent fdsp_bank_process launch (HIP events on the launch stream). */
 int fdsp_bank_last_kernel_ms(fdsp_bank* bank, float* ms);
 
+/* ---- on-device voice scheduler: the reference's Sequencer with one event per voice ---------------------------
+ * Replaces Sequencer::push + process / tick (src/sequencer.rs:355-398, 838-951, 769-836; ReplayMode::None, no loop
+ * point) for a bank whose voices are the events' units.  `events` holds 4 doubles per voice -- start_time, end_time,
+ * fade_in_time, fade_out_time, seconds on the sequencer clock -- and `fade` the curve per voice (NULL = Smooth).
+ * As in push(), fade times may not exceed the event's duration.  Voices without an event never play.
+ * fdsp_bank_process_events renders `frames` frames from the bank's sequencer clock (0 after set_events of a fresh
+ * bank; see fdsp_bank_events_rewind) into d_out [outputs][frames][voices]: each voice's own faded contribution, zeros
+ * outside its event.  Their sum over voices (fdsp_sum_voices) is the Sequencer's output.  Units are processed in
+ * sequencer blocks of 64 frames exactly like the reference (a unit's first and last process() block is the part of
+ * the sequencer block its event overlaps), so launches other than the last should be multiples of 64 frames.
+ * FDSP_MODE_TICK follows Sequencer::tick.  d_in: [inputs][frames][voices] per-voice inputs (the reference feeds
+ * every event the same input; give every voice the same stream to reproduce that). */
+#define FDSP_FADE_POWER 0  /* Fade::Power: equal-power crossfades (sine_ease) */
+#define FDSP_FADE_SMOOTH 1 /* Fade::Smooth: equal-amplitude crossfades (smooth5), the default */
+int fdsp_bank_set_events(fdsp_bank* bank, const double* events, const int* fade, size_t first_voice, size_t count);
+int fdsp_bank_process_events(fdsp_bank* bank, size_t frames, const float* d_in, float* d_out, int mode, void* stream);
+int fdsp_bank_events_rewind(fdsp_bank* bank, double time); /* set the sequencer clock (Sequencer::reset -> 0.0) */
+double fdsp_bank_events_time(const fdsp_bank* bank);       /* Sequencer::time() */
+
 /* ---- on-device stereo mix-down of voice-minor output (per-GPU partial of the multi-GPU mix) ----
  * d_voices: [frames][voices] mono voice outputs; d_pan: [voices] pan position in -1..1 or NULL (centre);
  * d_mix: [2][frames].  Equal-power pan weights follow Panner (src/pan.rs:13-17). Deterministic summation order. */

@@ -1,0 +1,97 @@
+"""On-device voice scheduler vs the oracle's Sequencer restatement (sequencer.rs): every voice's faded contribution must
+match its event's contribution bit for bit, in process and tick semantics; the mix is their sum."""
+import numpy as np
+import pytest
+
+import oracle as O
+from fundsp_amd import FADE_POWER, FADE_SMOOTH, MODE_PROCESS, MODE_TICK
+from fundsp_amd import workloads as W
+from test_gpu_config4 import tables  # noqa: F401  (fixture: the oracle's wavetables installed on the device)
+from test_gpu_parity import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+
+
+def random_events(V, T, rng):
+    start = rng.integers(0, T // 2, V).astype(np.float64)
+    dur = rng.integers(40, T // 2, V).astype(np.float64)
+    start[0], dur[0] = 0.0, float(T + 100)                 # plays through the whole launch
+    start[1], dur[1] = 37.0, 3.0                           # shorter than one SIMD item
+    start[2], dur[2] = 64.0, 64.0                          # exactly one sequencer block
+    start[3], dur[3] = float(T + 10), 50.0                 # never starts inside the launch
+    start += rng.random(V) * 0.4 - 0.2                     # off-grid times: rounding to the sample grid
+    fin = np.minimum(dur - 1, rng.integers(0, 300, V)) * (rng.random(V) < 0.8)    # push(): fades <= duration
+    fout = np.minimum(dur - 1, rng.integers(0, 300, V)) * (rng.random(V) < 0.8)
+    fade = rng.integers(0, 2, V).astype(np.int32)
+    return start / SR, (start + dur) / SR, fin / SR, fout / SR, fade
+
+
+@pytest.mark.parametrize("mode", [MODE_PROCESS, MODE_TICK])
+def test_fm_voices_with_events(gpu, mode):
+    import torch
+
+    V, T = 70, 64 * 9 + 21
+    rng = np.random.default_rng(91)
+    p = W.fm_svf_params(V, SR)
+    start, end, fin, fout, fade = random_events(V, T, rng)
+    b = W.make_fm_svf_bank(V, SR, params=p)
+    b.set_events(start, end, fin, fout, fade)
+    got = b.process_events(T, mode=mode)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy().transpose(2, 0, 1)             # [V][1][T]
+    seq = O.Sequencer(0, 1, SR)
+    for v in range(V):
+        f, m = float(p["f"][v]), float(p["m"][v])
+        n = O.sine_hz(f) * f * m + f >> O.sine() >> O.lowpass_hz(float(p["fc"][v]), float(p["q"][v]))
+        n.set_seed(int(p["seed"][v]))
+        seq.push(start[v], end[v], int(fade[v]), fin[v], fout[v], n)
+    mix, per = seq.render(T, process=(mode == MODE_PROCESS))
+    for v in range(V):
+        assert_bit_equal(got[v], per[v], f"event voice {v}")
+    assert np.any(got[0] != 0) and not np.any(got[3] != 0)
+    assert abs(b.events_time() - seq.time()) == 0.0
+    summed = gpu.sum_voices(torch.from_numpy(np.ascontiguousarray(got.transpose(1, 2, 0))).cuda()).cpu().numpy()
+    assert np.allclose(summed, mix, atol=1e-4)             # tree order vs the sequencer's serial order
+
+
+def test_gated_voices_with_inputs_and_two_launches(gpu, tables):
+    """A kind with an input (saw >> moog * adsr >> pan, gate in) scheduled per voice, rendered in two launches of whole
+    sequencer blocks: the clock and every voice's state carry over."""
+    import torch
+
+    V, T1, T2 = 64, 64 * 4, 64 * 3 + 17
+    T = T1 + T2
+    rng = np.random.default_rng(92)
+    p = W.saw_moog_params(V, SR)
+    adsr = (0.005, 0.01, 0.6, 0.01)
+    b = W.make_saw_moog_bank(V, SR, params=p, adsr=adsr)
+    start, end, fin, fout, fade = random_events(V, T, rng)
+    b.set_events(start, end, fin, fout, fade)
+    gate = np.zeros((V, 1, T), dtype=np.float32)
+    gate[:, 0, 5:T - 120] = 1.0
+    g = torch.from_numpy(np.ascontiguousarray(gate.transpose(1, 2, 0))).cuda()
+    o1 = b.process_events(T1, g[:, :T1].contiguous())
+    o2 = b.process_events(T2, g[:, T1:].contiguous())
+    torch.cuda.synchronize()
+    got = torch.cat([o1, o2], dim=1).cpu().numpy().transpose(2, 0, 1)
+    from test_gpu_config4 import config4_oracle_voice
+
+    seq = O.Sequencer(1, 2, SR)
+    for v in range(V):
+        seq.push(start[v], end[v], int(fade[v]), fin[v], fout[v], config4_oracle_voice(p, v, adsr))
+    _, per = seq.render(T, True, inputs=gate)
+    for v in range(0, V, 5):
+        assert_bit_equal(got[v], per[v], f"gated event voice {v}")
+
+
+def test_event_validation(gpu):
+    b = gpu.Bank("sine_hz", 8)
+    with pytest.raises(gpu.FdspError):
+        b.set_events(0.0, 0.01, fade_in=0.02)              # fade longer than the event (Sequencer::push asserts)
+    with pytest.raises(gpu.FdspError):
+        b.process_events(64)                               # no events set
+    b.set_events(np.zeros(8), np.full(8, 0.01), fade=FADE_POWER)
+    b.process_events(64)
+    b.events_rewind(0.0)
+    assert b.events_time() == 0.0
