@@ -19,6 +19,7 @@ thread_local std::string g_err;
 }
 namespace fd {
 int g_pipe_split = 1;
+int g_fdn_kernel = 0;
 int simd_count() {
     static int n = [] {
         int dev = 0, cus = 0;
@@ -311,6 +312,11 @@ int fdsp_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "pipe_split") == 0) {
         if (value < 0 || value > 4) return fail(FDSP_EINVAL, "pipe_split takes 0 (off), 1 (auto), 2 or 3 (stages), 4 (loader only)");
         fd::g_pipe_split = value;
+        return FDSP_OK;
+    }
+    if (name && std::strcmp(name, "fdn_kernel") == 0) {
+        if (value < 0 || value > 1) return fail(FDSP_EINVAL, "fdn_kernel takes 0 (lane per frame) or 1 (lane per delay line)");
+        fd::g_fdn_kernel = value;
         return FDSP_OK;
     }
     return fail(FDSP_EINVAL, "unknown option");

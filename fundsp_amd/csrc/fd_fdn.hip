@@ -8,6 +8,11 @@
 #include "fd_math.hpp"
 
 namespace fd {
+int simd_count();          // fd_capi.hip
+extern int g_fdn_kernel;   // fdsp_set_option("fdn_kernel", 0 = lane-per-frame (default), 1 = lane-per-delay-line)
+}
+
+namespace fd {
 
 static const double RV_DELAYS[32] = {  // prelude.rs:1739-1744
     0.073904, 0.052918, 0.066238, 0.066387, 0.037783, 0.080073, 0.050961, 0.075900, 0.043646,
@@ -89,20 +94,27 @@ __device__ __forceinline__ void fdn_wave_sync() {
 }
 
 // layout 0: voice-minor [ch][frame][instance]; layout 1: planar [instance][ch][fstride]
+// IPW = instances per wave.  2 fills all 64 lanes of the recurrence; 1 leaves lanes 32-63 idle there but halves the LDS
+// tiles (two workgroups per CU) and doubles the number of waves -- the per-sample recurrence is a chain of dependent
+// VALU / DPP operations (a lone wave issues one every ~9 cycles), so a second resident wave per SIMD is worth more than
+// full lanes whenever the bank has fewer than two 2-instance waves per SIMD (BASELINE config 5: 2048 per GPU).
+template <int IPW>
 __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size_t V, const float* __restrict__ in,
                                                     float* __restrict__ out, size_t T, size_t fstride, int layout) {
-    __shared__ float tile_all[4][64 * TS];   // ring samples in / new ring samples out, one row per (instance, line)
-    __shared__ float tileo_all[4][64 * TS];  // line outputs of the block, for the ordered pan sum
-    __shared__ float tin_all[4][4 * 64];     // [instance in wave][channel][frame]
+    constexpr int R = 32 * IPW;                // ring rows (delay lines) per wave
+    __shared__ float tile_all[4][R * TS];      // ring samples in / new ring samples out, one row per (instance, line)
+    __shared__ float tileo_all[4][R * TS];     // line outputs of the block, for the ordered pan sum
+    __shared__ float tin_all[4][2 * IPW * 64]; // [instance in wave][channel][frame]
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     float* tile = tile_all[wib];
     float* tileo = tileo_all[wib];
     float* tin = tin_all[wib];
-    const size_t inst0 = ((size_t)blockIdx.x * 4 + wib) * 2;
+    const size_t inst0 = ((size_t)blockIdx.x * 4 + wib) * IPW;
     if (inst0 >= V) return;
-    const int j = lane >> 5, k = lane & 31;
+    const int j = IPW == 2 ? lane >> 5 : 0, k = lane & 31;
+    const bool line = lane < R;                // this lane owns a delay line in the recurrence
     const size_t inst = inst0 + j;
-    const bool valid = inst < V;
+    const bool valid = line && inst < V;
     const size_t sidx = (valid ? inst : inst0) * 32 + k;
     int idx = s.idx[sidx];
     float v1 = s.v1[sidx], v2 = s.v2[sidx], fb = s.fb[sidx];
@@ -115,12 +127,12 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
 
     // Ring rows and inputs of a block are fetched one block AHEAD into registers (issued before the recurrence of the
     // current block, consumed after it): every delay exceeds 128 samples, so the rows block b+1 reads are not touched
-    // by block b's writes, and the HBM latency hides behind phase 2.
-    float xr[64], xin[4];
+    // by block b's writes, and the HBM latency hides behind phase 2.  In these phases lane = frame (all 64 lanes).
+    float xr[R], xin[2 * IPW];
     auto fetch = [&](size_t t0n, int idx_now) {
         const int sizen = (int)((T - t0n) < 64 ? (T - t0n) : 64);
 #pragma unroll
-        for (int r = 0; r < 64; r++) {
+        for (int r = 0; r < R; r++) {
             const int kk = r & 31;
             const size_t ri = inst0 + (r >> 5);
             const int i0 = __builtin_amdgcn_readlane(idx_now, r);
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
             xr[r] = (ri < V && lane < sizen) ? s.rings[ri * c.ring_stride + (size_t)c.off[kk] + (size_t)pos] : 0.0f;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {  // q = instance-in-wave * 2 + channel
+        for (int q = 0; q < 2 * IPW; q++) {  // q = instance-in-wave * 2 + channel
             const size_t ri = inst0 + (q >> 1);
             const int ch = q & 1;
             xin[q] = (ri < V && lane < sizen)
@@ -140,9 +152,9 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
     };
     auto stage = [&]() {
 #pragma unroll
-        for (int r = 0; r < 64; r++) tile[r * TS + lane] = xr[r];
+        for (int r = 0; r < R; r++) tile[r * TS + lane] = xr[r];
 #pragma unroll
-        for (int q = 0; q < 4; q++) tin[q * 64 + lane] = xin[q];
+        for (int q = 0; q < 2 * IPW; q++) tin[q * 64 + lane] = xin[q];
     };
     fetch(0, idx);
     stage();
@@ -158,51 +170,55 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
         // ---- phase 2: 64 samples of the recirculating network, one lane per delay line.  Ring reads and inputs of 8
         // frames are fetched from LDS ahead of the serial recurrence (they do not depend on it); the only cross-lane
         // traffic on the per-sample critical path is the 5-stage Hadamard.
-        const float* trow = tile + lane * TS;
-        const float* irow = tin + (j * 2 + (k & 1)) * 64;  // MultiSplit<U2,U16>: channel i takes input i % 2 (audionode.rs:600)
-        const bool upper16 = (k & 16) != 0;
-        for (int n0 = 0; n0 < size; n0 += 8) {
-            float dd[8], xi[8], xo[8], oo[8];
+#ifndef FD_FDN_SKIP_P2
+        if (line) {
+            const float* trow = tile + lane * TS;
+            const float* irow = tin + (j * 2 + (k & 1)) * 64;  // MultiSplit<U2,U16>: channel i takes input i % 2 (audionode.rs:600)
+            const bool upper16 = (k & 16) != 0;
+            for (int n0 = 0; n0 < size; n0 += 8) {
+                float dd[8], xi[8], xo[8], oo[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                dd[u] = trow[n0 + u];
-                xi[u] = irow[n0 + u];
-            }
+                for (int u = 0; u < 8; u++) {
+                    dd[u] = trow[n0 + u];
+                    xi[u] = irow[n0 + u];
+                }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const float x = xi[u] + fb;   // Feedback::tick: input + value
-                xo[u] = x;                    // Delay::tick: the new sample takes the slot read this step
-                const float v0 = v1;          // Fir<U3>::tick fir.rs:57-70
-                v1 = v2;
-                v2 = dd[u];
-                float o = 0.0f;
-                o += w0 * v0;
-                o += w1 * v1;
-                o += w2 * v2;
-                oo[u] = o;
-                float h = o;                  // FrameHadamard feedback.rs:35-57, stages h = 1, 2, 4, 8, 16
-                // lower lane of a pair: x + y (own + partner); upper lane: x - y (partner - own)
-                h = xor_lane<1>(h, upper16) + u2f(f2u(h) ^ negmask[0]);
-                h = xor_lane<2>(h, upper16) + u2f(f2u(h) ^ negmask[1]);
-                h = xor_lane<4>(h, upper16) + u2f(f2u(h) ^ negmask[2]);
-                h = xor_lane<8>(h, upper16) + u2f(f2u(h) ^ negmask[3]);
-                h = xor_lane<16>(h, upper16) + u2f(f2u(h) ^ negmask[4]);
-                const float fbn = h * scale;
-                fb = (n0 + u < size) ? fbn : fb;  // ragged tail of the last block: frames past `size` change nothing
-                if (n0 + u >= size) { v2 = v1; v1 = v0; }  // (undo the shift)
-            }
+                for (int u = 0; u < 8; u++) {
+                    const float x = xi[u] + fb;   // Feedback::tick: input + value
+                    xo[u] = x;                    // Delay::tick: the new sample takes the slot read this step
+                    const float v0 = v1;          // Fir<U3>::tick fir.rs:57-70
+                    v1 = v2;
+                    v2 = dd[u];
+                    float o = 0.0f;
+                    o += w0 * v0;
+                    o += w1 * v1;
+                    o += w2 * v2;
+                    oo[u] = o;
+                    float h = o;                  // FrameHadamard feedback.rs:35-57, stages h = 1, 2, 4, 8, 16
+                    // lower lane of a pair: x + y (own + partner); upper lane: x - y (partner - own)
+                    h = xor_lane<1>(h, upper16) + u2f(f2u(h) ^ negmask[0]);
+                    h = xor_lane<2>(h, upper16) + u2f(f2u(h) ^ negmask[1]);
+                    h = xor_lane<4>(h, upper16) + u2f(f2u(h) ^ negmask[2]);
+                    h = xor_lane<8>(h, upper16) + u2f(f2u(h) ^ negmask[3]);
+                    h = xor_lane<16>(h, upper16) + u2f(f2u(h) ^ negmask[4]);
+                    const float fbn = h * scale;
+                    fb = (n0 + u < size) ? fbn : fb;  // ragged tail of the last block: frames past `size` change nothing
+                    if (n0 + u >= size) { v2 = v1; v1 = v0; }  // (undo the shift)
+                }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                tile[lane * TS + n0 + u] = xo[u];
-                tileo[lane * TS + n0 + u] = oo[u];
+                for (int u = 0; u < 8; u++) {
+                    tile[lane * TS + n0 + u] = xo[u];
+                    tileo[lane * TS + n0 + u] = oo[u];
+                }
             }
         }
+#endif
         fdn_wave_sync();
         // ---- phase 3: write the 64 new ring samples per line back (coalesced), ordered pan sum with lane = frame
-        for (int r0 = 0; r0 < 64; r0 += 32) {
-            float xr[32];
+        for (int r0 = 0; r0 < R; r0 += 32) {
+            float xw[32];
 #pragma unroll
-            for (int u = 0; u < 32; u++) xr[u] = tile[(r0 + u) * TS + lane];
+            for (int u = 0; u < 32; u++) xw[u] = tile[(r0 + u) * TS + lane];
 #pragma unroll
             for (int u = 0; u < 32; u++) {
                 const int r = r0 + u, kk = u;
@@ -211,11 +227,13 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
                 const int len = c.len[kk];
                 int pos = i0 + lane;
                 pos = pos >= len ? pos - len : pos;
-                if (ri < V && lane < size) s.rings[ri * c.ring_stride + (size_t)c.off[kk] + (size_t)pos] = xr[u];
+#ifndef FD_FDN_SKIP_STORE
+                if (ri < V && lane < size) s.rings[ri * c.ring_stride + (size_t)c.off[kk] + (size_t)pos] = xw[u];
+#endif
             }
         }
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
+        for (int jj = 0; jj < IPW; jj++) {
             const size_t ri = inst0 + jj;
             float l = 0.0f, rr = 0.0f;
             for (int kk = 0; kk < 32; kk++) {  // Reduce::tick left fold (audionode.rs:2427-2439) of Panner outputs
@@ -249,6 +267,142 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
     }
 }
 
+// ---- lane = FRAME formulation ------------------------------------------------------------------------------------
+// Inside one 64-frame block nothing depends on the feedback: every delay is longer than 128 samples, so the 64 ring
+// reads of a line -- and with them the FIR outputs, the Hadamard and the new feedback values -- are known up front; the
+// only frame-to-frame coupling is `x[n] = in[n] + fb[n-1]` (the ring write) and the FIR's two-sample history.  So one
+// wave renders one instance with lane = frame: the 32 lines live in 32 registers, the Hadamard is 5 x 32 register
+// butterflies (no DPP, no permlane), ring rows are loaded and stored directly in the lane = frame order HBM wants
+// (no LDS transposes), the pan sum is a register fold, and the one-frame shifts go through two small LDS rows per line.
+// ~610 VALU + ~160 LDS instructions per instance-block instead of ~1660 + ~350; no LDS-bound occupancy limit.
+// (non-temporal ring loads / stores measured 10.2 ms vs 6.4-6.9 ms: the L2 write-combining matters)
+constexpr int HS = 68;  // floats per history row: [0..1] carry-in, [2..65] this block (also used with offset 1 for fb)
+
+__global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState s, size_t V, const float* __restrict__ in,
+                                                           float* __restrict__ out, size_t T, size_t fstride, int layout) {
+    __shared__ float hist_all[4][32 * HS];  // per line: delay outputs d[n-2], d[n-1] | d[0..63]
+    __shared__ float fbr_all[4][32 * HS];   // per line: fb[-1] | fb[0..63]
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* hist = hist_all[wib];
+    float* fbr = fbr_all[wib];
+    const size_t inst = (size_t)blockIdx.x * 4 + wib;
+    if (inst >= V) return;
+    const float w0 = c.w[0], w1 = c.w[1], w2 = c.w[2];
+    const float scale = (float)(1.0 / 5.656854249492381);  // (1.0 / sqrt(32 as f64)) as f32  feedback.rs:57
+    float* rings = s.rings + inst * c.ring_stride;
+    int idx[32];  // Delay::i of every line: wave-uniform
+#pragma unroll
+    for (int k = 0; k < 32; k++) idx[k] = __builtin_amdgcn_readfirstlane(s.idx[inst * 32 + k]);
+    if (lane < 32) {  // carry-in: Fir::v[1], v[2] and Feedback::value of every line
+        hist[lane * HS + 0] = s.v1[inst * 32 + lane];
+        hist[lane * HS + 1] = s.v2[inst * 32 + lane];
+        fbr[lane * HS + 0] = s.fb[inst * 32 + lane];
+    }
+    float dn[32], xin[2];  // prefetched ring reads / inputs of the NEXT block (lane = frame)
+    auto fetch = [&](size_t t0n, int adv) {
+        const int sizen = (int)((T - t0n) < 64 ? (T - t0n) : 64);
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            const int len = c.len[k];
+            int i0 = idx[k] + adv;
+            i0 = i0 >= len ? i0 - len : i0;
+            int pos = i0 + 1 + lane;  // Delay::tick reads the slot AFTER the write index (delay.rs:116-124); len > 128
+            pos = pos >= len ? pos - len : pos;
+            dn[k] = lane < sizen ? rings[(size_t)c.off[k] + (size_t)pos] : 0.0f;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+            xin[ch] = lane < sizen ? (layout == 0 ? in[((size_t)ch * T + t0n + lane) * V + inst] : in[(inst * 2 + ch) * fstride + t0n + lane]) : 0.0f;
+    };
+    fetch(0, 0);
+    for (size_t t0 = 0; t0 < T; t0 += 64) {
+        const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+        float d[32], xi0 = xin[0], xi1 = xin[1];
+#pragma unroll
+        for (int k = 0; k < 32; k++) d[k] = dn[k];
+        if (t0 + 64 < T) fetch(t0 + 64, 64);  // loads of the next block fly during this block's arithmetic
+        // delay outputs -> history rows (lane n writes slot n + 2), then the FIR reads slots n, n + 1 (fir.rs:57-70)
+#pragma unroll
+        for (int k = 0; k < 32; k++) hist[k * HS + 2 + lane] = d[k];
+        fdn_wave_sync();
+        float o[32], h[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            const float v0 = hist[k * HS + lane], v1 = hist[k * HS + lane + 1];
+            float acc = 0.0f;
+            acc += w0 * v0;
+            acc += w1 * v1;
+            acc += w2 * d[k];
+            o[k] = acc;
+            h[k] = acc;
+        }
+        // FrameHadamard feedback.rs:35-57: in-place butterflies h = 1, 2, 4, 8, 16; (x, y) -> (x + y, x - y)
+#pragma unroll
+        for (int st = 1; st < 32; st <<= 1)
+#pragma unroll
+            for (int i = 0; i < 32; i++)
+                if ((i & st) == 0) {
+                    const float x = h[i], y = h[i + st];
+                    h[i] = x + y;
+                    h[i + st] = x - y;
+                }
+        // feedback of frame n -> row slot n + 1; the ring write of frame n needs slot n (Feedback::tick: input + value)
+#pragma unroll
+        for (int k = 0; k < 32; k++) fbr[k * HS + 1 + lane] = h[k] * scale;
+        fdn_wave_sync();
+        if (lane < size) {
+#pragma unroll
+            for (int k = 0; k < 32; k++) {  // MultiSplit<U2,U16>: line k takes input channel k % 2 (audionode.rs:600)
+                const float x = ((k & 1) ? xi1 : xi0) + fbr[k * HS + lane];
+                const int len = c.len[k];
+                int pos = idx[k] + lane;  // Delay::tick: the new sample takes the slot at the write index
+                pos = pos >= len ? pos - len : pos;
+                rings[(size_t)c.off[k] + (size_t)pos] = x;
+            }
+            float l = 0.0f, rr = 0.0f;  // Reduce::tick left fold (audionode.rs:2427-2439) of the 32 Panner outputs
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const float pl = c.wl[k] * o[k], pr = c.wr[k] * o[k];
+                l = k == 0 ? pl : l + pl;
+                rr = k == 0 ? pr : rr + pr;
+            }
+            l *= (float)(1.0 / 16.0);  // * dc((1/16, 1/16))
+            rr *= (float)(1.0 / 16.0);
+            if (layout == 0) {
+                out[((size_t)0 * T + t0 + lane) * V + inst] = l;
+                out[((size_t)1 * T + t0 + lane) * V + inst] = rr;
+            } else {
+                out[(inst * 2 + 0) * fstride + t0 + lane] = l;
+                out[(inst * 2 + 1) * fstride + t0 + lane] = rr;
+            }
+        }
+        fdn_wave_sync();
+        // carry the last two delay outputs and the last feedback value of this block into slots 0, 1 / 0
+        if (lane < 32) {
+            const float a = hist[lane * HS + size], b = hist[lane * HS + size + 1], f = fbr[lane * HS + size];
+            hist[lane * HS + 0] = a;
+            hist[lane * HS + 1] = b;
+            fbr[lane * HS + 0] = f;
+        }
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            const int len = c.len[k];
+            idx[k] += size;
+            idx[k] = idx[k] >= len ? idx[k] - len : idx[k];
+        }
+        fdn_wave_sync();
+    }
+    if (lane < 32) {
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < 32; k++) mine = lane == k ? idx[k] : mine;
+        s.idx[inst * 32 + lane] = mine;
+        s.v1[inst * 32 + lane] = hist[lane * HS + 0];
+        s.v2[inst * 32 + lane] = hist[lane * HS + 1];
+        s.fb[inst * 32 + lane] = fbr[lane * HS + 0];
+    }
+}
+
 void fdn_launch_reset(const FdnConst& c, const FdnState& s, size_t instances, hipStream_t stream) {
     hipLaunchKernelGGL(k_fdn_reset, dim3(2048), dim3(256), 0, stream, c, s, instances);
 }
@@ -256,8 +410,17 @@ void fdn_launch_reset(const FdnConst& c, const FdnState& s, size_t instances, hi
 void fdn_launch_render(const FdnConst& c, const FdnState& s, size_t instances, const float* in, float* out, size_t T,
                        size_t fstride, int layout, hipStream_t stream) {
     if (instances == 0 || T == 0) return;
-    const unsigned grid = (unsigned)((instances + 7) / 8);
-    hipLaunchKernelGGL(k_fdn_render, dim3(grid), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout);
+    if (g_fdn_kernel == 0) {
+        hipLaunchKernelGGL(k_fdn_render_frames, dim3((unsigned)((instances + 3) / 4)), dim3(256), 0, stream, c, s, instances, in,
+                           out, T, fstride, layout);
+    } else if ((instances + 1) / 2 < 2 * (size_t)simd_count()) {
+        // lane = line kernel: one instance per wave while that is what it takes to have two waves per SIMD
+        const unsigned grid = (unsigned)((instances + 3) / 4);
+        hipLaunchKernelGGL(k_fdn_render<1>, dim3(grid), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout);
+    } else {
+        const unsigned grid = (unsigned)((instances + 7) / 8);
+        hipLaunchKernelGGL(k_fdn_render<2>, dim3(grid), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout);
+    }
 }
 
 }  // namespace fd

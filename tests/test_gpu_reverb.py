@@ -1,5 +1,6 @@
-"""GPU parity for BASELINE config 5: reverb_stereo (32-line FDN, prelude.rs:1732-1762) -- lane-per-delay-line kernel
-vs the oracle's per-sample restatement.  Bit-exact, including the ordered 32-term pan sum and the Hadamard stages."""
+"""GPU parity for BASELINE config 5: reverb_stereo (32-line FDN, prelude.rs:1732-1762) -- the lane-per-frame kernel
+(default) and the lane-per-delay-line kernel vs the oracle's per-sample restatement.  Bit-exact, including the ordered
+32-term pan sum and the Hadamard stages."""
 import numpy as np
 import pytest
 
@@ -26,8 +27,15 @@ def render(bank, x, layout):
     return out.cpu().numpy().transpose(2, 0, 1)
 
 
+@pytest.fixture(params=[0, 1], ids=["lane_per_frame", "lane_per_line"])
+def fdn_kernel(gpu, request):
+    assert gpu.lib().fdsp_set_option(b"fdn_kernel", request.param) == 0
+    yield request.param
+    gpu.lib().fdsp_set_option(b"fdn_kernel", 0)
+
+
 @pytest.mark.parametrize("layout", [LAYOUT_PLANAR, LAYOUT_VOICE_MINOR])
-def test_reverb_stereo_matches_oracle(gpu, layout):
+def test_reverb_stereo_matches_oracle(gpu, layout, fdn_kernel):
     V, T = 5, 64 * 150 + 17  # > 2 trips around the longest line (3980 samples); odd V: half-empty last wave
     rng = np.random.default_rng(12)
     x = (rng.random((V, 2, T), dtype=np.float32) * 2 - 1).astype(np.float32)
@@ -45,7 +53,7 @@ def test_reverb_stereo_matches_oracle(gpu, layout):
     assert np.abs(got[2, :, 4000:]).max() > 1e-4  # the impulse actually recirculated
 
 
-def test_reverb_chunked_calls_reset_and_other_rooms(gpu):
+def test_reverb_chunked_calls_reset_and_other_rooms(gpu, fdn_kernel):
     V, T = 3, 64 * 70
     rng = np.random.default_rng(13)
     x = (rng.random((V, 2, T), dtype=np.float32) * 2 - 1).astype(np.float32)
