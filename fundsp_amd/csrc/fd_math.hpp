@@ -477,6 +477,185 @@ FD_HD float wide_sin1(float self, float& tmax) {
 #endif
 }
 
+// musl scalbnf / powf as of the 2018 port (FreeBSD e_powf.c; libm 0.2.15 scalbnf.rs, powf.rs), used by Dsf.
+FD_HD float scalbnf_musl(float x, int n) {
+    float y = x; /* musl scalbnf.c (libm 0.2 scalbnf.rs): two-step scaling, no double rounding into the subnormals */
+    if (n > 127) {
+        y *= 0x1p127f;
+        n -= 127;
+        if (n > 127) {
+            y *= 0x1p127f;
+            n -= 127;
+            if (n > 127) n = 127;
+        }
+    } else if (n < -126) {
+        y *= 0x1p-126f * 0x1p24f;
+        n += 126 - 24;
+        if (n < -126) {
+            y *= 0x1p-126f * 0x1p24f;
+            n += 126 - 24;
+            if (n < -126) n = -126;
+        }
+    }
+    return y * u2f((uint32_t)(0x7f + n) << 23);
+}
+FD_HD float powf_musl(float x, float y) {
+    const float bp[2] = {1.0f, 1.5f}, dp_h[2] = {0.0f, 5.84960938e-01f}, dp_l[2] = {0.0f, 1.56322085e-06f};
+    const float two24 = 16777216.0f, huge = 1.0e30f, tiny = 1.0e-30f;
+    const float L1 = 6.0000002384e-01f, L2 = 4.2857143283e-01f, L3 = 3.3333334327e-01f, L4 = 2.7272811532e-01f,
+                L5 = 2.3066075146e-01f, L6 = 2.0697501302e-01f;
+    const float P1 = 1.6666667163e-01f, P2 = -2.7777778450e-03f, P3 = 6.6137559770e-05f, P4 = -1.6533901999e-06f,
+                P5 = 4.1381369442e-08f;
+    const float lg2 = 6.9314718246e-01f, lg2_h = 6.93145752e-01f, lg2_l = 1.42860654e-06f, ovt = 4.2995665694e-08f;
+    const float cp = 9.6179670095e-01f, cp_h = 9.6191406250e-01f, cp_l = -1.1736857402e-04f;
+    const float ivln2 = 1.4426950216e+00f, ivln2_h = 1.4426879883e+00f, ivln2_l = 7.0526075433e-06f;
+    float z, ax, z_h, z_l, p_h, p_l, y1, t1, t2, r, s, sn, t, u, v, w;
+    int32_t i, j, k, yisint, n, hx, hy, ix, iy, is;
+    hx = (int32_t)f2u(x);
+    hy = (int32_t)f2u(y);
+    ix = hx & 0x7fffffff;
+    iy = hy & 0x7fffffff;
+    if (iy == 0) return 1.0f;                              /* x**0 = 1, even if x is NaN */
+    if (hx == 0x3f800000) return 1.0f;                     /* 1**y = 1, even if y is NaN */
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;  /* NaN if either arg is NaN */
+    yisint = 0;                                            /* is y an odd / even integer (only matters for x < 0) */
+    if (hx < 0) {
+        if (iy >= 0x4b800000) yisint = 2;
+        else if (iy >= 0x3f800000) {
+            k = (iy >> 23) - 0x7f;
+            j = iy >> (23 - k);
+            if ((j << (23 - k)) == iy) yisint = 2 - (j & 1);
+        }
+    }
+    if (iy == 0x7f800000) { /* y is +-inf */
+        if (ix == 0x3f800000) return 1.0f;
+        else if (ix > 0x3f800000) return hy >= 0 ? y : 0.0f;
+        else return hy >= 0 ? 0.0f : -y;
+    }
+    if (iy == 0x3f800000) return hy >= 0 ? x : 1.0f / x; /* y is +-1 */
+    if (hy == 0x40000000) return x * x;                   /* y is 2 */
+    if (hy == 0x3f000000) {                               /* y is 0.5 */
+        if (hx >= 0) return __builtin_sqrtf(x);
+    }
+    ax = __builtin_fabsf(x);
+    if (ix == 0x7f800000 || ix == 0 || ix == 0x3f800000) { /* x is +-0, +-inf, +-1 */
+        z = ax;
+        if (hy < 0) z = 1.0f / z;
+        if (hx < 0) {
+            if (((ix - 0x3f800000) | yisint) == 0) z = (z - z) / (z - z);
+            else if (yisint == 1) z = -z;
+        }
+        return z;
+    }
+    sn = 1.0f; /* sign of the result */
+    if (hx < 0) {
+        if (yisint == 0) return (x - x) / (x - x);
+        if (yisint == 1) sn = -1.0f;
+    }
+    if (iy > 0x4d000000) { /* |y| > 2**27 */
+        if (ix < 0x3f7ffff8) return hy < 0 ? sn * huge * huge : sn * tiny * tiny;
+        if (ix > 0x3f800007) return hy > 0 ? sn * huge * huge : sn * tiny * tiny;
+        t = ax - 1;
+        w = (t * t) * (0.5f - t * (0.333333333333f - t * 0.25f));
+        u = ivln2_h * t;
+        v = t * ivln2_l - w * ivln2;
+        t1 = u + v;
+        is = (int32_t)f2u(t1);
+        t1 = u2f((uint32_t)is & 0xfffff000u);
+        t2 = v - (t1 - u);
+    } else {
+        float s2, s_h, s_l, t_h, t_l;
+        n = 0;
+        if (ix < 0x00800000) { /* subnormal x */
+            ax *= two24;
+            n -= 24;
+            ix = (int32_t)f2u(ax);
+        }
+        n += ((ix) >> 23) - 0x7f;
+        j = ix & 0x007fffff;
+        ix = j | 0x3f800000; /* normalize ix */
+        if (j <= 0x1cc471) k = 0;      /* |x| < sqrt(3/2) */
+        else if (j < 0x5db3d7) k = 1;  /* |x| < sqrt(3)   */
+        else {
+            k = 0;
+            n += 1;
+            ix -= 0x00800000;
+        }
+        ax = u2f((uint32_t)ix);
+        u = ax - bp[k]; /* s = s_h + s_l = (x-1)/(x+1) or (x-1.5)/(x+1.5) */
+        v = 1.0f / (ax + bp[k]);
+        s = u * v;
+        s_h = s;
+        is = (int32_t)f2u(s_h);
+        s_h = u2f((uint32_t)is & 0xfffff000u);
+        is = (int32_t)((((uint32_t)ix >> 1) & 0xfffff000u) | 0x20000000u); /* t_h = ax + bp[k], high part */
+        t_h = u2f((uint32_t)(is + 0x00400000 + (k << 21)));
+        t_l = ax - (t_h - bp[k]);
+        s_l = v * ((u - s_h * t_h) - s_h * t_l);
+        s2 = s * s; /* log(ax) */
+        r = s2 * s2 * (L1 + s2 * (L2 + s2 * (L3 + s2 * (L4 + s2 * (L5 + s2 * L6)))));
+        r += s_l * (s_h + s);
+        s2 = s_h * s_h;
+        t_h = 3.0f + s2 + r;
+        is = (int32_t)f2u(t_h);
+        t_h = u2f((uint32_t)is & 0xfffff000u);
+        t_l = r - ((t_h - 3.0f) - s2);
+        u = s_h * t_h; /* u + v = s * (1 + ...) */
+        v = s_l * t_h + t_l * s;
+        p_h = u + v; /* 2/(3 log2) * (s + ...) */
+        is = (int32_t)f2u(p_h);
+        p_h = u2f((uint32_t)is & 0xfffff000u);
+        p_l = v - (p_h - u);
+        z_h = cp_h * p_h; /* cp_h + cp_l = 2/(3 log2) */
+        z_l = cp_l * p_h + p_l * cp + dp_l[k];
+        t = (float)n; /* log2(ax) = (s + ..) * 2/(3 log2) = n + dp_h + z_h + z_l */
+        t1 = (((z_h + z_l) + dp_h[k]) + t);
+        is = (int32_t)f2u(t1);
+        t1 = u2f((uint32_t)is & 0xfffff000u);
+        t2 = z_l - (((t1 - t) - dp_h[k]) - z_h);
+    }
+    is = (int32_t)f2u(y); /* split y into y1 + y2 and compute (y1 + y2) * (t1 + t2) */
+    y1 = u2f((uint32_t)is & 0xfffff000u);
+    p_l = (y - y1) * t1 + y * t2;
+    p_h = y1 * t1;
+    z = p_l + p_h;
+    j = (int32_t)f2u(z);
+    if (j > 0x43000000) return sn * huge * huge; /* z > 128: overflow */
+    else if (j == 0x43000000) {                  /* z == 128 */
+        if (p_l + ovt > z - p_h) return sn * huge * huge;
+    } else if ((j & 0x7fffffff) > 0x43160000) return sn * tiny * tiny; /* z < -150: underflow */
+    else if ((uint32_t)j == 0xc3160000u) {                              /* z == -150 */
+        if (p_l <= z - p_h) return sn * tiny * tiny;
+    }
+    i = j & 0x7fffffff; /* 2**(p_h + p_l) */
+    k = (i >> 23) - 0x7f;
+    n = 0;
+    if (i > 0x3f000000) { /* |z| > 0.5: n = [z + 0.5] */
+        n = j + (0x00800000 >> (k + 1));
+        k = ((n & 0x7fffffff) >> 23) - 0x7f; /* new k for n */
+        t = u2f((uint32_t)(n & ~(0x007fffff >> k)));
+        n = ((n & 0x007fffff) | 0x00800000) >> (23 - k);
+        if (j < 0) n = -n;
+        p_h -= t;
+    }
+    t = p_l + p_h;
+    is = (int32_t)f2u(t);
+    t = u2f((uint32_t)is & 0xffff8000u);
+    u = t * lg2_h;
+    v = (p_l - (t - p_h)) * lg2 + t * lg2_l;
+    z = u + v;
+    w = v - (z - u);
+    t = z * z;
+    t1 = z - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    r = (z * t1) / (t1 - 2.0f) - (w + z * w);
+    z = 1.0f - (r - z);
+    j = (int32_t)f2u(z);
+    j += (int32_t)((uint32_t)n << 23);
+    if ((j >> 23) <= 0) z = scalbnf_musl(z, n); /* subnormal output */
+    else z = u2f((uint32_t)j);
+    return sn * z;
+}
+
 // follow.rs:12-24 (f64).  log / exp are the device library's double routines; the reference's are libm 0.2.15's.  Both
 // are accurate to < 1 ulp of f64 and the result is rounded to f32, so the f32 coefficient agrees except when the f64
 // value lies within ~1e-16 relative of an f32 rounding boundary (same policy as the oracle: SURVEY 8c).

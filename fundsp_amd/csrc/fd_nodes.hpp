@@ -267,6 +267,59 @@ struct Sine {
     }
 };
 
+// Dsf<N>  oscillator.rs:103-208 (ID 55): discrete summation formula oscillator (Moorer 1976), tick only.
+// NIN = 1 (frequency) or 2 (frequency, roughness).
+template <int NIN>
+struct Dsf {
+    static constexpr int IN = NIN, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 55;
+    float phase, roughness, harmonic_spacing, sample_duration, has_phase, initial_phase;
+    uint64_t hash;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(phase, STATE, "phase");
+        v.f(roughness, NIN > 1 ? STATE : PARAM, "roughness");
+        v.f(harmonic_spacing, PARAM, "harmonic_spacing");
+        v.f(sample_duration, COEF, "sample_duration");
+        v.f(has_phase, PARAM, "has_initial_phase");
+        v.f(initial_phase, PARAM, "initial_phase");
+        v.u64(hash, STATE, "hash");
+    }
+    FD_HD void bind(Ctx&) {}
+    FD_HD static float clamp_roughness(float r) {  // set_roughness :154-157: clamp(0.0001, 0.9999, r)
+        return __builtin_fminf(__builtin_fmaxf(r, 0.0001f), 0.9999f);
+    }
+    FD_HD void init() {  // dsf_saw_r(0.5) defaults; Dsf::new :132-146
+        harmonic_spacing = 1.0f; roughness = 0.5f; has_phase = 0.0f; initial_phase = 0.0f; hash = 0;
+        reset();
+    }
+    FD_HD void update(double sr) {  // :168-170; the host-set roughness is clamped like set_roughness does
+        sample_duration = (float)(1.0 / sr);
+        roughness = clamp_roughness(roughness);
+    }
+    FD_HD void reset() { phase = has_phase != 0.0f ? initial_phase : (float)rnd1(hash); }  // :161-166
+    FD_HD uint64_t ping(bool probe, uint64_t h) {
+        if (!probe) {  // set_hash :198-201
+            hash = h;
+            reset();
+        }
+        return atto(h, ID);
+    }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // tick :172-187, dsf :105-113
+        if (NIN > 1) roughness = clamp_roughness(in[1]);
+        phase += in[0] * sample_duration;
+        phase -= __builtin_floorf(phase);
+        const float n = __builtin_floorf(22050.0f / in[0] / harmonic_spacing);
+        const float f = phase * F32_TAU, d = phase * F32_TAU * harmonic_spacing, r = roughness;
+        out[0] = (sinf_musl(f) - r * sinf_musl(f - d) -
+                  powf_musl(r, n + 1.0f) * (sinf_musl(f + (n + 1.0f) * d) - r * sinf_musl(f + n * d))) /
+                 (1.0f + r * r - 2.0f * r * cosf_musl(d));
+    }
+    FD_STEP2_VIA_STEP
+};
+
 // Noise  noise.rs:173-234 (ID 20).  Integer-exact; process == tick sample for sample.
 struct Noise {
     static constexpr int IN = 0, OUT = 1, RINGS = 0;

@@ -146,6 +146,10 @@ def follow(t): return _leaf("Follow", 1, 1, response_time=t)
 def afollow(a, r): return _leaf("AFollow", 1, 1, attack_time=a, release_time=r)
 def mls_bits(n): return _leaf("Mls", 0, 1, bits=float(n))
 def mls(): return mls_bits(29)
+def dsf_saw(): return _leaf("Dsf<2>", 2, 1, harmonic_spacing=1.0, roughness=0.5)
+def dsf_saw_r(r): return _leaf("Dsf<1>", 1, 1, harmonic_spacing=1.0, roughness=r)
+def dsf_square(): return _leaf("Dsf<2>", 2, 1, harmonic_spacing=2.0, roughness=0.5)
+def dsf_square_r(r): return _leaf("Dsf<1>", 1, 1, harmonic_spacing=2.0, roughness=r)
 def delay(t): return _leaf("Delay", 1, 1, rings=1, time=t)
 def tap(min_delay, max_delay): return _leaf("TapT<false>", 2, 1, rings=1, min_delay=min_delay, max_delay=max_delay)
 def tap_linear(min_delay, max_delay): return _leaf("TapT<true>", 2, 1, rings=1, min_delay=min_delay, max_delay=max_delay)

@@ -106,6 +106,8 @@ struct onode {
         /* Oversampler<X> (oversample.rs:66-80): 128-sample input / output rings per channel */
         float *os_inv, *os_outv; /* [channel][128] */
         size_t os_in_i, os_out_i;
+        /* Dsf (oscillator.rs:121-129) */
+        float dsf_roughness, dsf_spacing;
         /* Rez (rez.rs:11-21), Follow / AFollow (follow.rs:31-43,137-152), Mls (noise.rs:14-20,103-107) */
         float rz_buf0, rz_buf1, rz_f, rz_fb, rz_bandpass;
         float fo_v1, fo_v2, fo_v3, fo_coeff, fo_coeff_now, fo_rcoeff, fo_rcoeff_now, fo_time, fo_rtime;
@@ -160,6 +162,7 @@ float o_math_cosf(float x) { return o_cosf(x); }
 float o_math_tanf(float x) { return o_tanf(x); }
 float o_math_tanhf(float x) { return o_tanhf(x); }
 float o_math_expf(float x) { return o_expf(x); }
+float o_math_powf(float x, float y) { return o_powf(x, y); }
 float o_math_expm1f(float x) { return o_expm1f(x); }
 float o_math_wide_sinf(float x) { return o_wide_sinf(x); }
 float o_math_atanf(float x) { return o_atanf(x); }
@@ -433,6 +436,7 @@ static void leaf_reset(onode *n) {
         }
         break;
     case O_WAVESYNTH: /* wavetable.rs:292-297 */
+    case O_DSF:       /* oscillator.rs:161-166 */
     case O_PHASE_OSC: /* oscillator.rs:449-454 etc. */
         n->s.phase = n->s.has_initial_phase ? n->s.initial_phase : (float)o_rnd1(n->s.hash);
         break;
@@ -547,6 +551,7 @@ static void leaf_set_sample_rate(onode *n, double sr) {
         n->s.esd = (float)(1.0 / sr);
         break;
     case O_PHASE_OSC: /* oscillator.rs:456-458 */
+    case O_DSF:       /* oscillator.rs:168-170 */
         n->s.sample_duration = (float)(1.0 / sr);
         break;
     case O_ONEPOLE: /* filter.rs:47-50 etc. */
@@ -630,7 +635,7 @@ void o_set_sample_rate(onode *n, double sr) {
 /* AudioNode::set_hash (oscillator.rs:94-97, noise.rs:226-229); default is a no-op (audionode.rs:136-139) */
 static void leaf_set_hash(onode *n, uint64_t hash) {
     if (n->type == O_SINE || n->type == O_NOISE || n->type == O_WAVESYNTH || n->type == O_PHASE_OSC || n->type == O_CHAOS ||
-        n->type == O_MLS) { /* Mls::set_hash noise.rs:142-145 */
+        n->type == O_MLS || n->type == O_DSF) { /* Mls::set_hash noise.rs:142-145 */
         n->s.hash = hash;
         leaf_reset(n);
     } else if (n->type == O_ADSR_LIVE) { /* envelope.rs:346-349: no reset */
@@ -1000,6 +1005,20 @@ void o_osc_set_phase(onode *n, float phase) {
     n->s.has_initial_phase = 1;
     n->s.initial_phase = phase;
     leaf_reset(n);
+}
+/* Dsf<U1/U2>  oscillator.rs:131-158 (ID 55) */
+static inline float dsf_clamp_roughness(float r) { /* set_roughness :154-157: clamp(0.0001, 0.9999, r) = r.max(lo).min(hi) */
+    r = fmaxf(r, 0.0001f);
+    return fminf(r, 0.9999f);
+}
+onode *o_dsf(int inputs, float harmonic_spacing, float roughness) {
+    onode *n = o_new(O_DSF, inputs, 1, 55);
+    n->s.dsf_spacing = harmonic_spacing;
+    n->s.dsf_roughness = roughness;
+    leaf_reset(n);
+    leaf_set_sample_rate(n, DEFAULT_SR);
+    n->s.dsf_roughness = dsf_clamp_roughness(roughness);
+    return n;
 }
 onode *o_chaos(int lorenz) { /* Rossler::new :331 (ID 73) / Lorenz::new :390 (ID 74) */
     onode *n = o_new(O_CHAOS, 1, 1, lorenz ? 74 : 73);
@@ -1524,6 +1543,16 @@ void o_tick(onode *n, const float *in, float *out) {
         o_tick(n->x, &v, &z);
         n->s.zz = z;
         out[0] = y;
+        break;
+    }
+    case O_DSF: { /* oscillator.rs:172-187, dsf :105-113 */
+        if (n->nin > 1) n->s.dsf_roughness = dsf_clamp_roughness(in[1]);
+        n->s.phase += in[0] * n->s.sample_duration;
+        n->s.phase -= floorf(n->s.phase);
+        float nn = floorf(22050.0f / in[0] / n->s.dsf_spacing);
+        float f = n->s.phase * F32_TAU, d = n->s.phase * F32_TAU * n->s.dsf_spacing, r = n->s.dsf_roughness;
+        out[0] = (o_sinf(f) - r * o_sinf(f - d) - o_powf(r, nn + 1.0f) * (o_sinf(f + (nn + 1.0f) * d) - r * o_sinf(f + nn * d))) /
+                 (1.0f + r * r - 2.0f * r * o_cosf(d));
         break;
     }
     case O_SHAPER: out[0] = shape_scalar(n, 0, in[0]); break; /* shape.rs:226-229 */

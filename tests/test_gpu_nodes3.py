@@ -136,3 +136,38 @@ def test_oversample_shape(gpu, mode, T):
         n = O.oversample(O.shape("tanh", 2.0))
         n.set_sample_rate(SR)
         assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"oversample_shape voice {v} T={T}")
+
+
+# ---- Dsf (oscillator.rs:103-208): needs libm powf, restated in fd_math.hpp / o_math.h ---------------------------------
+@pytest.mark.parametrize("spacing", [1.0, 2.0])
+@pytest.mark.parametrize("mode", MODES)
+def test_dsf(gpu, spacing, mode):
+    V, T = 96, 64 * 2 + 19
+    rng = np.random.default_rng(81)
+    rough = (0.05 + 0.9 * rng.random(V)).astype(np.float32)
+    rough[:3] = [0.0, 1.0, 0.5]                                  # clamped to 0.0001 / 0.9999 by set_roughness
+    x = np.zeros((V, 2, T), dtype=np.float32)
+    x[:, 0] = (30.0 + 8000.0 * rng.random((V, 1)) ** 2) * (1.0 + 0.2 * rng.random((V, T)))   # wandering frequency
+    x[5, 0, :] = 23000.0                                         # n = 0: pow(r, 1) special case
+    x[6, 0, :] = 11025.0                                         # n = 1 or 2: pow(r, 2) special case
+    x[:, 1] = np.clip(rough[:, None] + 0.3 * (rng.random((V, T)) - 0.5), -0.2, 1.2)
+    b1 = gpu.Bank("dsf_r", V)
+    b1.set_param(":harmonic_spacing", spacing)
+    b1.set_param(":roughness", rough)
+    b1.set_sample_rate(SR)
+    b1.set_seed(np.arange(V, dtype=np.uint64) + 3)
+    g1 = run_bank(b1, x[:, :1], T, LAYOUT_VOICE_MINOR, mode)
+    b2 = gpu.Bank("dsf", V)
+    b2.set_param(":harmonic_spacing", spacing)
+    b2.set_sample_rate(SR)
+    b2.set_seed(np.arange(V, dtype=np.uint64) + 3)
+    g2 = run_bank(b2, x, T, LAYOUT_PLANAR, mode)
+    for v in (0, 1, 2, 5, 6, 40, 95):
+        n1 = O.dsf_saw_r(float(rough[v])) if spacing == 1.0 else O.dsf_square_r(float(rough[v]))
+        n1.set_sample_rate(SR)
+        n1.set_seed(v + 3)
+        assert_bit_equal(g1[v], oracle_render(n1, x[v, :1], T, mode), f"dsf_r voice {v}")
+        n2 = O.dsf_saw() if spacing == 1.0 else O.dsf_square()
+        n2.set_sample_rate(SR)
+        n2.set_seed(v + 3)
+        assert_bit_equal(g2[v], oracle_render(n2, x[v], T, mode), f"dsf voice {v}")

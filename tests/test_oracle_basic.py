@@ -349,3 +349,24 @@ def test_oversampled_fm_generator():
     # tick vs process differ only by Sine's own tick / process arithmetic (unwrapped f32 phase inside a block), which at
     # the inner 96 kHz rate and modulated frequencies up to 1.3 kHz stays below 1e-3
     assert np.max(np.abs(y - z)) < 1e-3
+
+
+def test_dsf_is_the_partial_sum_it_claims_to_be():
+    """Dsf (oscillator.rs:105-187): closed form of sum_{i<=n} r^i sin(f + i d) (Moorer 1976), n = floor(22050 / f / spacing)."""
+    sr, f0 = 48000.0, 441.0
+    for node, spacing, r in ((O.dsf_saw_r(0.5), 1.0, 0.5), (O.dsf_square_r(0.7), 2.0, 0.7)):
+        node.set_sample_rate(sr)
+        node.phase(0.125)                                   # Setting::phase (oscillator.rs:192)
+        T = 300
+        y = node.render_ticks(np.full((1, T), f0, dtype=np.float32))[0]
+        n = np.floor(22050.0 / f0 / spacing)
+        k = np.arange(0, int(n) + 1)
+        ph = (0.125 + f0 / sr * np.arange(1, T + 1)) % 1.0  # tick advances the phase before evaluating (:176-178)
+        want = np.array([(r ** k * np.sin(p * 2 * np.pi + k * p * 2 * np.pi * spacing)).sum() for p in ph])
+        assert np.max(np.abs(want - y)) < 2e-3, (spacing, np.max(np.abs(want - y)))
+    two = O.dsf_saw()
+    two.set_sample_rate(sr); two.set_seed(9)
+    one = O.dsf_saw_r(0.3)
+    one.set_sample_rate(sr); one.set_seed(9)
+    x = np.stack([np.full(200, 300.0), np.full(200, 0.3)]).astype(np.float32)
+    assert np.array_equal(two.render_ticks(x), one.render_ticks(x[:1]))   # roughness input == fixed roughness

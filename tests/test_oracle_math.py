@@ -130,3 +130,26 @@ def test_noise_is_integer_exact_and_uniform():
     a = O.noise().seed(99).render_blocks(length=1000)
     b = O.noise().seed(99).render_ticks(length=1000)
     assert np.array_equal(a, b)
+
+
+def test_powf_restatement_accuracy():
+    """libm 0.2 powf (FreeBSD e_powf.c) restated in o_math.h: documented error < 1 ulp; special cases of pow()."""
+    rng = np.random.default_rng(17)
+    L = O.lib()
+    worst = 0.0
+    xs = np.concatenate([rng.uniform(1e-4, 0.9999, 20000), rng.uniform(0.5, 3.0, 5000), np.exp(rng.uniform(-30, 30, 5000))]).astype(np.float32)
+    ys = np.concatenate([np.floor(rng.uniform(1, 500, 20000)), rng.uniform(-20, 20, 5000), rng.uniform(-3, 3, 5000)]).astype(np.float32)
+    for x, y in zip(xs, ys):
+        got = L.o_math_powf(float(x), float(y))
+        want = np.float64(x) ** np.float64(y)
+        if want == 0.0 or not np.isfinite(want) or want < 1e-37 or want > 1e38:
+            continue
+        ulp = np.spacing(np.float32(want))
+        worst = max(worst, abs(np.float64(got) - want) / ulp)
+    assert worst < 1.0, worst
+    assert L.o_math_powf(2.0, 0.0) == 1.0 and L.o_math_powf(float("nan"), 0.0) == 1.0 and L.o_math_powf(1.0, float("nan")) == 1.0
+    assert L.o_math_powf(0.5, 1.0) == 0.5 and L.o_math_powf(3.0, 2.0) == 9.0 and L.o_math_powf(4.0, 0.5) == 2.0
+    assert L.o_math_powf(-2.0, 3.0) == -8.0 and L.o_math_powf(-2.0, 2.0) == 4.0 and np.isnan(L.o_math_powf(-2.0, 0.5))
+    assert L.o_math_powf(0.5, float("inf")) == 0.0 and L.o_math_powf(2.0, float("inf")) == float("inf")
+    assert L.o_math_powf(10.0, 50.0) == float("inf") and L.o_math_powf(10.0, -50.0) == 0.0
+    assert L.o_math_powf(0.5, 140.0) == np.float32(2.0 ** -140)        # subnormal result through scalbnf
