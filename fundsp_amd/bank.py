@@ -170,6 +170,12 @@ class Bank:
                                       C.c_void_p(stream) if stream else None))
         return out
 
+    def set_ring(self, ring_index, data, first=0):
+        """Upload ring contents [voices][frames] (e.g. Pluck's excitation stream into ring 0)."""
+        d = np.ascontiguousarray(data, dtype=np.float32)
+        assert d.ndim == 2
+        check(lib().fdsp_bank_set_ring(self._h, int(ring_index), _fptr(d), d.shape[1], first, d.shape[0]))
+
     # --- voice scheduler: Sequencer::push / process with one event per voice (sequencer.rs:355-398, 838-951)
     def set_events(self, start, end, fade_in=0.0, fade_out=0.0, fade=FADE_SMOOTH, first=0):
         """Per-voice events in seconds on the sequencer clock; scalars broadcast.  Resets nothing else."""

@@ -676,6 +676,25 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
     return FDSP_OK;
 }
 
+int fdsp_bank_set_ring(fdsp_bank* b, int ring_index, const float* data, size_t frames, size_t first, size_t count) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    if (b->fdn || !b->ring) return fail(FDSP_EINVAL, "this bank has no ring memory");
+    if (!data) return fail(FDSP_EINVAL, "data is NULL");
+    if (ring_index < 0 || ring_index >= b->ops->nrings) return fail(FDSP_EINVAL, "ring index out of range");
+    if (frames > b->ring_cap) return fail(FDSP_EINVAL, "more frames than the ring capacity given to fdsp_bank_create_ring");
+    if (int rc = check_range(b, first, count)) return rc;
+    if (frames == 0 || count == 0) return FDSP_OK;
+    // device layout [ring node][position][voice]: transpose the caller's [voice][frame] rows on the host
+    std::vector<float> t(frames * count);
+    for (size_t v = 0; v < count; v++)
+        for (size_t i = 0; i < frames; i++) t[i * count + v] = data[v * frames + i];
+    float* dst = b->ring + (size_t)ring_index * b->ring_cap * b->stride + first;
+    HIPCHK(hipMemcpy2DAsync(dst, b->stride * sizeof(float), t.data(), count * sizeof(float), count * sizeof(float), frames,
+                            hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return FDSP_OK;
+}
+
 int fdsp_bank_set_events(fdsp_bank* b, const double* events, const int* fade, size_t first, size_t count) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
     if (b->fdn) return fail(FDSP_EINVAL, "reverb banks have no event scheduler");

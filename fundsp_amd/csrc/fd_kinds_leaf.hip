@@ -38,6 +38,7 @@ void register_leaf_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<Follow>("follow"));
     out.push_back(make_kind<AFollow>("afollow"));
     out.push_back(make_kind<Mls>("mls"));
+    out.push_back(make_kind<Pluck>("pluck"));
     out.push_back(make_kind<Dsf<1>>("dsf_r"));
     out.push_back(make_kind<Dsf<2>>("dsf"));
     out.push_back(make_kind<Morph>("morph"));

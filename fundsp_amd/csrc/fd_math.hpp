@@ -661,6 +661,7 @@ FD_HD float powf_musl(float x, float y) {
 // value lies within ~1e-16 relative of an f32 rounding boundary (same policy as the oracle: SURVEY 8c).
 extern "C" __device__ double __ocml_log_f64(double);
 extern "C" __device__ double __ocml_exp_f64(double);
+extern "C" __device__ double __ocml_pow_f64(double, double);
 FD_HD double log_f64(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __ocml_log_f64(x);
@@ -673,6 +674,13 @@ FD_HD double exp_f64(double x) {
     return __ocml_exp_f64(x);
 #else
     return __builtin_exp(x);
+#endif
+}
+FD_HD double pow_f64(double x, double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ocml_pow_f64(x, y);
+#else
+    return __builtin_pow(x, y);
 #endif
 }
 FD_HD double halfway_coeff(double samples) {

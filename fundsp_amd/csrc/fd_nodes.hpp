@@ -1354,6 +1354,111 @@ struct Delay {
     FD_STEP2_VIA_STEP
 };
 
+// Pluck  oscillator.rs:210-317 (ID 58): Karplus-Strong string = delay line -> Fir<U3> damping -> Allpole tuning, fed back.
+// Two ring nodes: ring 0 holds the EXCITATION, i.e. the stream `Rnd::from_u64(hash).f32_in(-1.0, 1.0)` that
+// initialize_line draws (:257-261).  funutd's generator is a third-party crate whose source is not under
+// /root/reference, so the host uploads that stream (fdsp_bank_set_ring, ring 0) -- the Rust shim calls funutd itself;
+// everything after the draw (mean removal in f64, loop gain, damping, tuning, the loop) is reproduced here.  Ring 1
+// is the working line.  `gain` uses the device library's f64 pow (policy of halfway_coeff: f64 result rounded to f32).
+struct Pluck {
+    static constexpr int IN = 1, OUT = 1, RINGS = 2;
+    static constexpr uint64_t ID = 58;
+    float frequency, gain_per_second, damping;   // params (constructor arguments)
+    float gain, w[3], eta;                        // derived
+    float fv[3], ax1, ay1;                        // Fir / Allpole state
+    float initialized, last_freq;
+    uint32_t len, pos;
+    uint64_t sr_bits, hash;                       // sample_rate is f64 in the reference (:224)
+    float *raw, *line;
+    size_t vs;
+    uint32_t cap;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(frequency, PARAM, "frequency");
+        v.f(gain_per_second, PARAM, "gain_per_second");
+        v.f(damping, PARAM, "high_frequency_damping");
+        v.f(gain, COEF, "gain");
+        _Pragma("unroll") for (int i = 0; i < 3; i++) v.fi(w[i], COEF, "w", i);
+        v.f(eta, STATE, "eta");
+        _Pragma("unroll") for (int i = 0; i < 3; i++) v.fi(fv[i], STATE, "v", i);
+        v.f(ax1, STATE, "x1");
+        v.f(ay1, STATE, "y1");
+        v.f(initialized, STATE, "initialized");
+        v.f(last_freq, STATE, "initialized_for_frequency");
+        v.u32(len, STATE, "length");
+        v.u32(pos, STATE, "pos");
+        v.u64(sr_bits, COEF, "sample_rate");
+        v.u64(hash, STATE, "hash");
+    }
+    FD_HD void bind(Ctx& c) { raw = c.claim_ring(); line = c.claim_ring(); vs = c.vstride; cap = c.ring_cap; }
+    FD_HD static double bits2d(uint64_t b) { return __builtin_bit_cast(double, b); }
+    FD_HD void init() {
+        frequency = 440.0f; gain_per_second = 0.5f; damping = 0.5f;
+        fv[0] = fv[1] = fv[2] = 0.0f; ax1 = ay1 = 0.0f; eta = 0.0f;
+        initialized = 0.0f; last_freq = 0.0f; len = 1; pos = 0; hash = 0;
+        sr_bits = __builtin_bit_cast(uint64_t, 44100.0);
+    }
+    FD_HD void update(double sr) {  // Pluck::new :229-242 (parameter-derived parts) + set_sample_rate :279-285
+        const float g = 1.0f - damping;  // fir3(1.0 - high_frequency_damping)  prelude.rs:863-867
+        const float alpha = (g + 1.0f) / 2.0f, beta = (1.0f - alpha) / 2.0f;
+        w[0] = beta; w[1] = alpha; w[2] = beta;
+        gain = (float)pow_f64((double)gain_per_second, 1.0 / (double)frequency);
+        if (bits2d(sr_bits) != sr || last_freq != frequency) {
+            sr_bits = __builtin_bit_cast(uint64_t, sr);
+            initialized = 0.0f;
+        }
+    }
+    FD_HD void reset() { fv[0] = fv[1] = fv[2] = 0.0f; initialized = 0.0f; }  // :274-277
+    FD_HD uint64_t ping(bool probe, uint64_t h) {
+        if (!probe) {  // set_hash :307-310
+            hash = h;
+            initialized = 0.0f;
+        }
+        return atto(h, ID);
+    }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    FD_HD void initialize_line() {  // :244-268
+        const double total_delay = bits2d(sr_bits) / (double)frequency - 1.0;
+        const double loop_delay = __builtin_floor(total_delay - 0.2);
+        const double allpass_delay = total_delay - loop_delay;
+        ax1 = ay1 = 0.0f;                           // tuning.reset()
+        const float d = (float)allpass_delay;       // tuning.set_delay: eta = (1 - d) / (1 + d)  filter.rs:292-295
+        eta = (1.0f - d) / (1.0f + d);
+        uint32_t n = loop_delay > 0.0 ? (uint32_t)loop_delay : 0u;
+        n = n > cap ? cap : n;                      // ring capacity is fixed at bank creation
+        n = n < 1u ? 1u : n;
+        len = n;
+        double mean = 0.0;
+        for (uint32_t i = 0; i < n; i++) {
+            const float x = raw[(size_t)i * vs];
+            line[(size_t)i * vs] = x;
+            mean += (double)x;
+        }
+        mean /= (double)n;
+        for (uint32_t i = 0; i < n; i++) line[(size_t)i * vs] -= (float)mean;
+        pos = 0;
+        last_freq = frequency;
+        initialized = 1.0f;
+    }
+    template <int PH> FD_HD void step(const float* in, float* out) {  // tick :287-305
+        if (initialized == 0.0f) initialize_line();
+        float o = line[(size_t)pos * vs] * gain + in[0];
+        fv[0] = fv[1]; fv[1] = fv[2]; fv[2] = o;    // damping.filter_mono: Fir<U3>::tick fir.rs:57-70
+        float acc = 0.0f;
+        acc += w[0] * fv[0];
+        acc += w[1] * fv[1];
+        acc += w[2] * fv[2];
+        const float y0 = eta * (acc - ay1) + ax1;   // tuning.filter_mono: Allpole::tick filter.rs:320-324
+        ax1 = acc; ay1 = y0;
+        line[(size_t)pos * vs] = y0;
+        pos += 1;
+        if (pos == len) pos = 0;
+        out[0] = y0;
+    }
+    FD_STEP2_VIA_STEP
+};
+
 // Tap<U1> (cubic, ID 50, delay.rs:148-286) and TapLinear<U1> (ID 54, :386-505): variable fractional delay in seconds
 // on input 1.  The f32x8 `process` writes 8 samples and then reads with per-lane offsets; because the clamped delay
 // is at least one sample (Tap) / the read never runs ahead of the write (TapLinear), each lane reads exactly what

@@ -146,6 +146,8 @@ def follow(t): return _leaf("Follow", 1, 1, response_time=t)
 def afollow(a, r): return _leaf("AFollow", 1, 1, attack_time=a, release_time=r)
 def mls_bits(n): return _leaf("Mls", 0, 1, bits=float(n))
 def mls(): return mls_bits(29)
+def pluck(frequency, gain_per_second, damping):  # excitation: Bank.set_ring(0, rnd_stream)
+    return _leaf("Pluck", 1, 1, rings=2, frequency=frequency, gain_per_second=gain_per_second, high_frequency_damping=damping)
 def dsf_saw(): return _leaf("Dsf<2>", 2, 1, harmonic_spacing=1.0, roughness=0.5)
 def dsf_saw_r(r): return _leaf("Dsf<1>", 1, 1, harmonic_spacing=1.0, roughness=r)
 def dsf_square(): return _leaf("Dsf<2>", 2, 1, harmonic_spacing=2.0, roughness=0.5)

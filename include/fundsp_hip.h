@@ -170,6 +170,13 @@ int fdsp_bank_synchronize(fdsp_bank* bank);
 /* Device time in milliseconds of the most recent fdsp_bank_process launch (HIP events on the launch stream). */
 int fdsp_bank_last_kernel_ms(fdsp_bank* bank, float* ms);
 
+/* Upload the first `frames` positions of ring node `ring_index` (visit order) for `count` voices from `first_voice`:
+ * data is [count][frames] f32.  Used for state a Rust caller must provide because it comes from a crate outside the
+ * reference tree: Pluck's excitation, the stream `Rnd::from_u64(hash).f32_in(-1.0, 1.0)` of funutd that
+ * Pluck::initialize_line draws (src/oscillator.rs:257-261), goes into ring 0 of the "pluck" kind. */
+int fdsp_bank_set_ring(fdsp_bank* bank, int ring_index, const float* data, size_t frames, size_t first_voice,
+                       size_t count);
+
 /* ---- on-device voice scheduler: the reference's Sequencer with one event per voice ---------------------------
  * Replaces Sequencer::push + process / tick (src/sequencer.rs:355-398, 838-951, 769-836; ReplayMode::None, no loop
  * point) for a bank whose voices are the events' units.  `events` holds 4 doubles per voice -- start_time, end_time,

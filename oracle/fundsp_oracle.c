@@ -106,6 +106,13 @@ struct onode {
         /* Oversampler<X> (oversample.rs:66-80): 128-sample input / output rings per channel */
         float *os_inv, *os_outv; /* [channel][128] */
         size_t os_in_i, os_out_i;
+        /* Pluck (oscillator.rs:215-226): Fir<U3> damping = w/v above, Allpole tuning = op_* below; the excitation is the
+         * stream `Rnd::from_u64(hash).f32_in(-1, 1)` of funutd (crate source absent) and is supplied by the caller */
+        float pl_freq, pl_gain;
+        float *pl_raw, *pl_line;
+        size_t pl_raw_n, pl_len, pl_pos;
+        int pl_init;
+        double pl_sr;
         /* Dsf (oscillator.rs:121-129) */
         float dsf_roughness, dsf_spacing;
         /* Rez (rez.rs:11-21), Follow / AFollow (follow.rs:31-43,137-152), Mls (noise.rs:14-20,103-107) */
@@ -151,6 +158,8 @@ void o_free(onode *n) {
     free(n->tmp);
     free(n->s.dbuf);
     free(n->s.tbuf);
+    free(n->s.pl_raw);
+    free(n->s.pl_line);
     free(n->s.os_inv);
     free(n->s.os_outv);
     free(n);
@@ -442,6 +451,10 @@ static void leaf_reset(onode *n) {
         break;
     case O_ONEPOLE: n->s.op_x1 = n->s.op_y1 = 0.0f; break;
     case O_REZ: n->s.rz_buf0 = n->s.rz_buf1 = 0.0f; break; /* rez.rs:57-60 */
+    case O_PLUCK: /* oscillator.rs:274-277 */
+        for (int i = 0; i < O_MAX_FIR; i++) n->s.v[i] = 0.0f;
+        n->s.pl_init = 0;
+        break;
     case O_OVERSAMPLE: /* oversample.rs:131-135: rings cleared, ring indices kept (child reset by o_reset) */
         memset(n->s.os_inv, 0, (size_t)(n->nin ? n->nin : 1) * 128 * sizeof(float));
         memset(n->s.os_outv, 0, (size_t)n->nout * 128 * sizeof(float));
@@ -558,6 +571,12 @@ static void leaf_set_sample_rate(onode *n, double sr) {
         n->s.sr = (float)sr;
         onepole_set(n, n->s.cutoff);
         break;
+    case O_PLUCK: /* oscillator.rs:279-285 */
+        if (n->s.pl_sr != sr) {
+            n->s.pl_sr = sr;
+            n->s.pl_init = 0;
+        }
+        break;
     case O_REZ: /* rez.rs:62-65 */
         n->s.sr = (float)sr;
         rez_set(n, n->s.cutoff, n->s.q);
@@ -638,6 +657,9 @@ static void leaf_set_hash(onode *n, uint64_t hash) {
         n->type == O_MLS || n->type == O_DSF) { /* Mls::set_hash noise.rs:142-145 */
         n->s.hash = hash;
         leaf_reset(n);
+    } else if (n->type == O_PLUCK) { /* oscillator.rs:307-310 */
+        n->s.hash = hash;
+        n->s.pl_init = 0;
     } else if (n->type == O_ADSR_LIVE) { /* envelope.rs:346-349: no reset */
         n->s.hash = hash;
         n->s.et_hash = hash;
@@ -1005,6 +1027,46 @@ void o_osc_set_phase(onode *n, float phase) {
     n->s.has_initial_phase = 1;
     n->s.initial_phase = phase;
     leaf_reset(n);
+}
+/* Pluck::new oscillator.rs:229-242 (ID 58).  `excitation`: at least as many samples as the loop delay will need. */
+onode *o_pluck(float frequency, float gain_per_second, float high_frequency_damping, const float *excitation, size_t n_exc) {
+    onode *n = o_new(O_PLUCK, 1, 1, 58);
+    float g = 1.0f - high_frequency_damping; /* fir3(1.0 - damping) prelude.rs:863-867 */
+    float alpha = (g + 1.0f) / 2.0f, beta = (1.0f - alpha) / 2.0f;
+    n->s.fir_n = 3;
+    n->s.w[0] = beta; n->s.w[1] = alpha; n->s.w[2] = beta;
+    n->s.op_kind = O_OP_ALLPOLE; /* Allpole::new(1.0) */
+    n->s.sr = (float)DEFAULT_SR;
+    onepole_set(n, 1.0f);
+    n->s.pl_gain = (float)pow((double)gain_per_second, 1.0 / (double)frequency);
+    n->s.pl_freq = frequency;
+    n->s.pl_sr = DEFAULT_SR;
+    n->s.pl_raw = (float *)malloc((n_exc ? n_exc : 1) * sizeof(float));
+    memcpy(n->s.pl_raw, excitation, n_exc * sizeof(float));
+    n->s.pl_raw_n = n_exc;
+    return n;
+}
+static void pluck_initialize_line(onode *n) { /* oscillator.rs:244-268 */
+    const double epsilon = 0.2;
+    double total_delay = n->s.pl_sr / (double)n->s.pl_freq - 1.0;
+    double loop_delay = floor(total_delay - epsilon);
+    double allpass_delay = total_delay - loop_delay;
+    n->s.op_x1 = n->s.op_y1 = 0.0f;      /* tuning.reset() */
+    n->s.sr = (float)n->s.pl_sr;         /* tuning.set_sample_rate */
+    onepole_set(n, (float)allpass_delay); /* tuning.set_delay */
+    size_t len = loop_delay > 0.0 ? (size_t)loop_delay : 0;
+    if (len > n->s.pl_raw_n) len = n->s.pl_raw_n; /* the caller supplied too little excitation */
+    n->s.pl_line = (float *)realloc(n->s.pl_line, (len ? len : 1) * sizeof(float));
+    n->s.pl_len = len;
+    double mean = 0.0;
+    for (size_t i = 0; i < len; i++) {
+        n->s.pl_line[i] = n->s.pl_raw[i];
+        mean += (double)n->s.pl_line[i];
+    }
+    mean /= (double)len;
+    for (size_t i = 0; i < len; i++) n->s.pl_line[i] -= (float)mean;
+    n->s.pl_pos = 0;
+    n->s.pl_init = 1;
 }
 /* Dsf<U1/U2>  oscillator.rs:131-158 (ID 55) */
 static inline float dsf_clamp_roughness(float r) { /* set_roughness :154-157: clamp(0.0001, 0.9999, r) = r.max(lo).min(hi) */
@@ -1543,6 +1605,19 @@ void o_tick(onode *n, const float *in, float *out) {
         o_tick(n->x, &v, &z);
         n->s.zz = z;
         out[0] = y;
+        break;
+    }
+    case O_PLUCK: { /* oscillator.rs:287-305 */
+        if (!n->s.pl_init) pluck_initialize_line(n);
+        float o = n->s.pl_line[n->s.pl_pos] * n->s.pl_gain + in[0];
+        o = fir_tick(n, o);                                   /* damping.filter_mono */
+        float y0 = n->s.op_coeff * (o - n->s.op_y1) + n->s.op_x1; /* tuning.filter_mono (Allpole :320-324) */
+        n->s.op_x1 = o; n->s.op_y1 = y0;
+        o = y0;
+        n->s.pl_line[n->s.pl_pos] = o;
+        n->s.pl_pos += 1;
+        if (n->s.pl_pos == n->s.pl_len) n->s.pl_pos = 0;
+        out[0] = o;
         break;
     }
     case O_DSF: { /* oscillator.rs:172-187, dsf :105-113 */

@@ -74,7 +74,7 @@ def lib():
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
         "o_onepole": (P, [i, i, f]), "o_pinkpass": (P, []), "o_morph": (P, [f, f, f]),
         "o_rez": (P, [i, f, f, f]), "o_follow": (P, [f]), "o_afollow": (P, [f, f]), "o_mls": (P, [C.c_uint]),
-        "o_mls_set_seed": (None, [P, C.c_uint64]), "o_oversample": (P, [P]), "o_dsf": (P, [i, f, f]),
+        "o_mls_set_seed": (None, [P, C.c_uint64]), "o_oversample": (P, [P]), "o_dsf": (P, [i, f, f]), "o_pluck": (P, [f, f, f, fp, C.c_size_t]),
         "o_math_powf": (f, [f, f]),
         "o_seq_new": (P, [i, i, d]), "o_seq_free": (None, [P]), "o_seq_push": (i, [P, d, d, i, d, d, P]),
         "o_seq_render": (None, [P, C.c_size_t, i, fp, fp, fp]), "o_seq_time": (d, [P]), "o_mls_period": (C.c_uint64, [C.c_uint]),
@@ -320,6 +320,9 @@ def follow(t): return Node(lib().o_follow(t))                                # p
 def afollow(a, r): return Node(lib().o_afollow(a, r))                        # prelude32.rs:1266
 def mls_bits(n): return Node(lib().o_mls(n))                                 # prelude32.rs:772
 def mls(): return mls_bits(29)
+def pluck(frequency, gain_per_second, damping, excitation):                    # prelude32.rs:1812 (+ the Rnd stream)
+    e = np.ascontiguousarray(excitation, dtype=np.float32)
+    return Node(lib().o_pluck(frequency, gain_per_second, damping, _fptr(e), e.size))
 def dsf_saw(): return Node(lib().o_dsf(2, 1.0, 0.5))                         # prelude32.rs:1773
 def dsf_saw_r(r): return Node(lib().o_dsf(1, 1.0, r))                        # prelude32.rs:1781
 def dsf_square(): return Node(lib().o_dsf(2, 2.0, 0.5))                      # prelude32.rs:1789

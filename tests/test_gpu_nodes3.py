@@ -171,3 +171,32 @@ def test_dsf(gpu, spacing, mode):
         n2.set_sample_rate(SR)
         n2.set_seed(v + 3)
         assert_bit_equal(g2[v], oracle_render(n2, x[v], T, mode), f"dsf voice {v}")
+
+
+# ---- Pluck (oscillator.rs:210-317): the funutd excitation stream is uploaded, everything after it is on the device ----
+@pytest.mark.parametrize("mode", MODES)
+def test_pluck(gpu, mode):
+    V, T = 70, 64 * 12 + 5
+    rng = np.random.default_rng(83)
+    freq = (60.0 + 2000.0 * rng.random(V) ** 2).astype(np.float32)
+    gps = (0.1 + 0.85 * rng.random(V)).astype(np.float32)
+    damp = rng.random(V).astype(np.float32)
+    exc = rng.uniform(-1, 1, (V, 1024)).astype(np.float32)     # >= sample_rate / 60 Hz - 1 samples
+    x = np.zeros((V, 1, T), dtype=np.float32)
+    x[:, 0, 300:340] = (rng.random((V, 40)) - 0.5).astype(np.float32)   # "extra string excitation" on the input
+    b = gpu.Bank("pluck", V, ring_frames=1024)
+    b.set_param(":frequency", freq)
+    b.set_param(":gain_per_second", gps)
+    b.set_param(":high_frequency_damping", damp)
+    b.set_ring(0, exc)
+    b.set_sample_rate(SR)
+    got = np.concatenate([run_bank(b, x, T, LAYOUT_VOICE_MINOR, mode), run_bank(b, x, T, LAYOUT_PLANAR, mode)], axis=-1)
+    b.reset()                                                   # reset re-initialises the line from the same stream
+    again = run_bank(b, x, T, LAYOUT_VOICE_MINOR, mode)
+    assert_bit_equal(again, got[:, :, :T], "pluck after reset")
+    xx = np.concatenate([x, x], axis=-1)
+    for v in (0, 1, 33, 64, 69):
+        n = O.pluck(float(freq[v]), float(gps[v]), float(damp[v]), exc[v])
+        n.set_sample_rate(SR)
+        assert_bit_equal(got[v], oracle_render(n, xx[v], 2 * T, mode), f"pluck voice {v}")
+    assert np.abs(got).max() > 0.05

@@ -370,3 +370,25 @@ def test_dsf_is_the_partial_sum_it_claims_to_be():
     one.set_sample_rate(sr); one.set_seed(9)
     x = np.stack([np.full(200, 300.0), np.full(200, 0.3)]).astype(np.float32)
     assert np.array_equal(two.render_ticks(x), one.render_ticks(x[:1]))   # roughness input == fixed roughness
+
+
+def test_pluck_is_tuned_and_decays():
+    """Karplus-Strong (oscillator.rs:215-317): period = sample_rate / frequency (loop delay + 1 damping + allpass), and the
+    loop gain makes the level fall by gain_per_second per second."""
+    sr, f, gps = 48000.0, 220.0, 0.5
+    exc = np.random.default_rng(21).uniform(-1, 1, 4096).astype(np.float32)
+    n = O.pluck(f, gps, 0.1, exc)
+    n.set_sample_rate(sr)
+    y = n.render_ticks(np.zeros((1, 48000), dtype=np.float32))[0].astype(np.float64)
+    seg = y[2000:2000 + 8192]
+    ac = np.correlate(seg, seg, "full")[len(seg) - 1:]
+    lag = 100 + int(np.argmax(ac[100:400]))
+    assert abs(lag - sr / f) <= 1, lag
+    spec = np.abs(np.fft.rfft(y[:32768] * np.hanning(32768)))
+    peak = np.argmax(spec[50:]) + 50
+    h = peak * sr / 32768 / f                                 # the strongest partial is a harmonic of f:
+    assert abs(h - round(h)) < 0.02, h                        # the allpass does the fine tuning
+    e1, e2 = np.sqrt(np.mean(y[4800:9600] ** 2)), np.sqrt(np.mean(y[4800 + 24000:9600 + 24000] ** 2))
+    assert e2 < e1 * 0.8                                      # decays (gain 0.5/s plus high-frequency damping)
+    n.reset()                                                 # reset -> the line is re-initialised from the same excitation
+    assert np.array_equal(n.render_ticks(np.zeros((1, 500), dtype=np.float32))[0], y[:500].astype(np.float32))
