@@ -26,6 +26,7 @@ SYMBOLS = {
     "fdsp_kind_by_name": (_i, [_cs]),
     "fdsp_set_option": (_i, [_cs, _i]),
     "fdsp_graph_compile": (_i, [_cs, _cs]),
+    "fdsp_graph_compile_src": (_i, [_cs, _cs, _cs]),
     "fdsp_graph_check": (_i, [_cs]),
     "fdsp_kind_inputs": (_i, [_i]),
     "fdsp_kind_outputs": (_i, [_i]),
@@ -87,6 +88,15 @@ def lib():
             raise ImportError(
                 f"{SO_PATH} not found: build the HIP engine first (python -c 'import __graft_entry__ as g; g.build()' "
                 "or make -C fundsp_amd/csrc). There is no CPU fallback.")
+        # PyTorch-ROCm ships its own HIP runtime; if ours initialises first in the process, torch later reports
+        # "No HIP GPUs are available".  Device memory handed to the C ABI comes from torch, so let torch go first.
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch

@@ -53,7 +53,7 @@ class Bank:
         from . import graph as G
 
         name = graph.kind_name()
-        rc = lib().fdsp_graph_compile(name.encode(), graph.type.encode())
+        rc = lib().fdsp_graph_compile_src(name.encode(), graph.type.encode(), graph.source.encode() if graph.source else None)
         if rc < 0:
             check(rc)
         for kind in G.uses_wavetables(graph):

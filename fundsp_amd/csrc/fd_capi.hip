@@ -322,7 +322,9 @@ int fdsp_set_option(const char* name, int value) {
     return fail(FDSP_EINVAL, "unknown option");
 }
 
-int fdsp_graph_compile(const char* name, const char* type_expr) {
+int fdsp_graph_compile(const char* name, const char* type_expr) { return fdsp_graph_compile_src(name, type_expr, nullptr); }
+
+int fdsp_graph_compile_src(const char* name, const char* type_expr, const char* source) {
     if (!name || !type_expr || !*name || !*type_expr) return fail(FDSP_EINVAL, "name or type expression missing");
     int existing = fdsp_kind_by_name(name);
     if (existing >= 0) return existing;  // kinds are immutable: a second compile of the same name is a lookup
@@ -331,7 +333,7 @@ int fdsp_graph_compile(const char* name, const char* type_expr) {
         return fail(FDSP_EDEVICE, "no HIP device available: compiled graphs are loaded onto the device");
     fd::KindOps k;
     std::string err;
-    if (fd::jit_make_kind(name, type_expr, &k, &err) != 0) return fail(FDSP_EINVAL, err);
+    if (fd::jit_make_kind(name, type_expr, source ? source : "", &k, &err) != 0) return fail(FDSP_EINVAL, err);
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     registry().push_back(std::move(k));
     return (int)registry().size() - 1;
@@ -341,7 +343,7 @@ int fdsp_graph_check(const char* type_expr) {
     if (!type_expr) return fail(FDSP_EINVAL, "type expression missing");
     std::vector<char> code;
     std::string log;
-    if (fd::jit_compile_code(type_expr, &code, &log) != 0) return fail(FDSP_EINVAL, log);
+    if (fd::jit_compile_code(type_expr, "", &code, &log) != 0) return fail(FDSP_EINVAL, log);
     return FDSP_OK;
 }
 

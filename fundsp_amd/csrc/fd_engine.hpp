@@ -163,8 +163,9 @@ KindOps make_kind(const char* name) {
     return k;
 }
 
-int jit_compile_code(const std::string& type_expr, std::vector<char>* code, std::string* log);
-int jit_make_kind(const std::string& name, const std::string& type_expr, KindOps* out, std::string* err);
+int jit_compile_code(const std::string& type_expr, const std::string& prelude, std::vector<char>* code, std::string* log);
+int jit_make_kind(const std::string& name, const std::string& type_expr, const std::string& prelude, KindOps* out,
+                  std::string* err);
 void register_leaf_kinds(std::vector<KindOps>& out);
 void register_graph_kinds(std::vector<KindOps>& out);
 

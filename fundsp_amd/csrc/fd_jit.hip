@@ -52,9 +52,11 @@ struct JitModule {
 
 }  // namespace
 
-std::string jit_source(const std::string& type_expr) {
+std::string jit_source(const std::string& type_expr, const std::string& prelude) {
     std::string s;
     s += "#include \"fd_device.hpp\"\n";
+    // user-supplied node / functor definitions (e.g. the closure of an Envelope) live in namespace fd like the built-ins
+    if (!prelude.empty()) s += "namespace fd {\n" + prelude + "\n}\n";
     s += "namespace fd { using JitG = " + type_expr + "; }\n";
     s += "using fd::JitG;\n";
     s += "constexpr int JIT_WPB0 = fd::RenderGeom<JitG, 0>::WPB;\nconstexpr int JIT_WPB1 = fd::RenderGeom<JitG, 1>::WPB;\n";
@@ -83,7 +85,7 @@ std::string jit_source(const std::string& type_expr) {
 }
 
 // Compile only (no device needed): returns the code object or an error log.
-int jit_compile_code(const std::string& type_expr, std::vector<char>* code, std::string* log) {
+int jit_compile_code(const std::string& type_expr, const std::string& prelude, std::vector<char>* code, std::string* log) {
     const std::string dir = lib_dir() + "/csrc/";
     const char* names[3] = {"fd_math.hpp", "fd_nodes.hpp", "fd_device.hpp"};
     std::string hdr[3];
@@ -93,14 +95,15 @@ int jit_compile_code(const std::string& type_expr, std::vector<char>* code, std:
             return -1;
         }
     const char* hsrc[3] = {hdr[0].c_str(), hdr[1].c_str(), hdr[2].c_str()};
-    const std::string src = jit_source(type_expr);
+    const std::string src = jit_source(type_expr, prelude);
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "fdsp_jit_graph.hip", 3, hsrc, names) != HIPRTC_SUCCESS) {
         *log = "hiprtcCreateProgram failed";
         return -1;
     }
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
-    hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+    // same code-generation flags as the ahead-of-time kinds (see Makefile for -fno-slp-vectorize)
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"};
+    hiprtcResult r = hiprtcCompileProgram(prog, 6, opts);
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);
     if (ls > 1) {
@@ -120,9 +123,10 @@ int jit_compile_code(const std::string& type_expr, std::vector<char>* code, std:
     return 0;
 }
 
-int jit_make_kind(const std::string& name, const std::string& type_expr, KindOps* out, std::string* err) {
+int jit_make_kind(const std::string& name, const std::string& type_expr, const std::string& prelude, KindOps* out,
+                  std::string* err) {
     std::vector<char> code;
-    if (jit_compile_code(type_expr, &code, err) != 0) return -1;
+    if (jit_compile_code(type_expr, prelude, &code, err) != 0) return -1;
     auto jm = std::make_shared<JitModule>();
     if (hipModuleLoadData(&jm->mod, code.data()) != hipSuccess) {
         *err = "hipModuleLoadData failed for the compiled graph";

@@ -1018,6 +1018,134 @@ struct AdsrLive {
     FD_STEP2_VIA_STEP
 };
 
+// Envelope<f32, E, R>  envelope.rs:17-179 (ID 14): control-rate closure E(t) sampled at jittered ~2 ms intervals and
+// linearly interpolated (envelope / lfo, prelude32.rs:581-611).  A Rust closure has no device form, so E is a FUNCTOR
+// type FN: `static constexpr int OUT`, `visit(v)` for its own parameters (may be empty), `eval(float t, float* out)`.
+// Two ship with the engine (the closures of the reference's doc examples); run-time compiled graphs can bring their
+// own (fdsp_graph_compile_src: C++ source of the functor compiled with the graph).
+struct EnvExp {  // lfo(|t| a * exp(-t * k))   (prelude32.rs:602 with a = k = 1)
+    static constexpr int OUT = 1;
+    float a, k;
+    template <class V> FD_HD void visit(V& v) { v.f(a, PARAM, "a"); v.f(k, PARAM, "k"); }
+    FD_HD void init() { a = 1.0f; k = 1.0f; }
+    FD_HD void eval(float t, float* out) const { out[0] = a * expf_musl(-t * k); }
+};
+struct EnvSineHz {  // lfo(|t| lerp11(lo, hi, sin_hz(hz, t)))   (math.rs:204-206, 462-464)
+    static constexpr int OUT = 1;
+    float hz, lo, hi;
+    template <class V> FD_HD void visit(V& v) { v.f(hz, PARAM, "hz"); v.f(lo, PARAM, "lo"); v.f(hi, PARAM, "hi"); }
+    FD_HD void init() { hz = 1.0f; lo = -1.0f; hi = 1.0f; }
+    FD_HD void eval(float t, float* out) const {
+        const float u = sinf_musl(t * hz * F32_TAU) * 0.5f + 0.5f;
+        out[0] = lo * (1.0f - u) + hi * u;
+    }
+};
+template <class FN>
+struct Envelope {
+    static constexpr int IN = 0, OUT = FN::OUT, RINGS = 0;
+    static constexpr uint64_t ID = 14;
+    FN fn;
+    float interval, sd;
+    float t, t0, t1, v0[OUT], v1[OUT], value[OUT], value_d[OUT];
+    uint64_t t_hash, hash;
+    int blk_i, blk_size, remaining, loop_len;  // block-walk transients (process path)
+    bool full_seg;
+    template <class V> FD_HD void visit(V& v) {
+        v.enter(0); fn.visit(v); v.leave();
+        v.f(interval, PARAM, "interval");
+        v.f(sd, COEF, "sample_duration");
+        v.f(t, STATE, "t"); v.f(t0, STATE, "t_0"); v.f(t1, STATE, "t_1");
+        _Pragma("unroll") for (int i = 0; i < OUT; i++) v.fi(v0[i], STATE, "value_0", i);
+        _Pragma("unroll") for (int i = 0; i < OUT; i++) v.fi(v1[i], STATE, "value_1", i);
+        _Pragma("unroll") for (int i = 0; i < OUT; i++) v.fi(value[i], STATE, "value", i);
+        _Pragma("unroll") for (int i = 0; i < OUT; i++) v.fi(value_d[i], STATE, "value_d", i);
+        v.u64(t_hash, STATE, "t_hash");
+        v.u64(hash, STATE, "hash");
+    }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void init() {  // Envelope::new :58-76 with interval 0.002 (prelude32.rs:591)
+        fn.init();
+        interval = (float)0.002;
+        hash = 0;
+        for (int i = 0; i < OUT; i++) { v0[i] = v1[i] = value[i] = value_d[i] = 0.0f; }
+        t = t0 = t1 = 0.0f;
+        t_hash = 0;
+    }
+    // The reference constructs with the closure in place and calls reset() (which evaluates it) last; here the functor's
+    // parameters arrive after construction, so every update() that precedes the first sample re-runs that reset.
+    FD_HD void update(double sr) {  // :124-126
+        sd = (float)(1.0 / sr);
+        if (t == 0.0f && t1 == 0.0f) reset();
+    }
+    FD_HD void reset() {  // :114-122
+        t = 0.0f; t0 = 0.0f; t1 = 0.0f;
+        t_hash = hash;
+        fn.eval(t0, v0);
+        for (int i = 0; i < OUT; i++) v1[i] = v0[i];
+    }
+    FD_HD uint64_t ping(bool probe, uint64_t h) {
+        if (!probe) {  // set_hash :165-168: no reset
+            hash = h;
+            t_hash = h;
+        }
+        return atto(h, ID);
+    }
+    FD_HD void next_segment() {  // :79-98
+        t0 = t1;
+        for (int i = 0; i < OUT; i++) v0[i] = v1[i];
+        const float next_interval = lerpf(0.75f, 1.25f, (float)rnd1(t_hash)) * interval;
+        t1 = t0 + next_interval;
+        fn.eval(t1, v1);
+        t_hash = t_hash * 6364136223846793005ULL + 1ULL;
+        const float u = (t - t0) / (t1 - t0);
+        const float samples = next_interval / sd;
+        for (int i = 0; i < OUT; i++) {
+            value[i] = lerpf(v0[i], v1[i], u);
+            value_d[i] = (v1[i] - v0[i]) / samples;
+        }
+    }
+    FD_HD void begin_block(int size) { blk_i = 0; blk_size = size; remaining = 0; full_seg = false; loop_len = 0; }
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    FD_HD void start_chunk() {  // one iteration head of the `while i < size` loop :137-140
+        float c = __builtin_ceilf((t1 - t) / sd);
+        long long left = (long long)c;
+        int room = blk_size - blk_i;
+        bool huge = left < 0 || left > (long long)room;  // `as usize` of a negative value is huge
+        loop_len = huge ? room : (int)left;
+        full_seg = !huge && loop_len == (int)left;
+        remaining = loop_len;
+    }
+    template <int PH> FD_HD void step(const float*, float* out) {
+        if (PH == PH_TICK) {  // tick :128-136
+            if (t >= t1) next_segment();
+            for (int i = 0; i < OUT; i++) { out[i] = value[i]; value[i] += value_d[i]; }
+            t += sd;
+        } else {  // process :138-163, walked sample by sample (the whole block, no remainder path)
+            if (blk_i == 0) {
+                if (t >= t1) next_segment();
+                start_chunk();
+            }
+            for (int guard = 0; remaining == 0 && guard < 4; guard++) {  // chunk exhausted before this sample
+                if (full_seg) next_segment();
+                start_chunk();
+            }
+            for (int i = 0; i < OUT; i++) { out[i] = value[i]; value[i] += value_d[i]; }
+            remaining--;
+            blk_i++;
+            if (remaining == 0) {
+                t += (float)(long long)loop_len * sd;
+                if (full_seg) {  // :154-156: unconditional, also when the block ends here (EnvelopeIn differs: `i < size`)
+                    next_segment();
+                    full_seg = false;
+                }
+            }
+        }
+    }
+    FD_STEP2_VIA_STEP
+};
+
+
 // Panner<U1>  pan.rs:26-93 (ID 49): fixed pan, mono -> stereo.
 struct Panner {
     static constexpr int IN = 1, OUT = 2, RINGS = 0;

@@ -25,14 +25,15 @@ SHAPES = dict(clip=0, clip_to=1, tanh=2, atan=3, softsign=4, crush=5, soft_crush
 class Graph:
     __array_ufunc__ = None  # let `ndarray * Graph` reach Graph.__rmul__
 
-    def __init__(self, type_str, nin, nout, params=(), rings=0):
+    def __init__(self, type_str, nin, nout, params=(), rings=0, source=""):
         self.type, self.nin, self.nout, self.rings = type_str, nin, nout, rings
         self.params = list(params)  # (path tuple, field, value, is_u64)
+        self.source = source        # C++ definitions (closure functors) the type refers to
 
     # --- combinators (combinator.rs:289-488)
     def _pair(self, other, tmpl, nin, nout):
         ps = [((0,) + p, f, v, u) for p, f, v, u in self.params] + [((1,) + p, f, v, u) for p, f, v, u in other.params]
-        return Graph(f"{tmpl}<{self.type},{other.type}>", nin, nout, ps, self.rings + other.rings)
+        return Graph(f"{tmpl}<{self.type},{other.type}>", nin, nout, ps, self.rings + other.rings, _merge(self.source, other.source))
 
     def __rshift__(self, other):
         if self.nout != other.nin:
@@ -46,13 +47,14 @@ class Graph:
         if self.nout != other.nout:
             raise TypeError("Binop arity mismatch")
         ps = [((0,) + p, f, v, u) for p, f, v, u in self.params] + [((1,) + p, f, v, u) for p, f, v, u in other.params]
-        return Graph(f"Binop<{op},{self.type},{other.type}>", self.nin + other.nin, self.nout, ps, self.rings + other.rings)
+        return Graph(f"Binop<{op},{self.type},{other.type}>", self.nin + other.nin, self.nout, ps, self.rings + other.rings,
+                     _merge(self.source, other.source))
 
     def _unop(self, u, scalar=None):
         ps = [((0,) + p, f, v, uu) for p, f, v, uu in self.params]
         if scalar is not None:
             ps.append(((), "scalar", scalar, False))
-        return Graph(f"Unop<{self.type},{u}>", self.nin, self.nout, ps, self.rings)
+        return Graph(f"Unop<{self.type},{u}>", self.nin, self.nout, ps, self.rings, self.source)
 
     def __mul__(self, o): return self._binop(o, "OpMul") if isinstance(o, Graph) else self._unop("UMulScalar", o)
     def __rmul__(self, o): return self._unop("UMulScalar", o)
@@ -76,11 +78,15 @@ class Graph:
         return self._set("seed", s, u64=True)
 
     def kind_name(self):
-        return "jit_" + hashlib.sha1(self.type.encode()).hexdigest()[:16]
+        return "jit_" + hashlib.sha1((self.type + "\0" + self.source).encode()).hexdigest()[:16]
 
     def slot_values(self):
         """[(slot name, value, is_u64)] in assignment order."""
         return [(".".join(str(i) for i in p) + ":" + f, v, u) for p, f, v, u in self.params]
+
+
+def _merge(a, b):
+    return a if (not b or b in a) else (a + "\n" + b)
 
 
 def _leaf(t, nin, nout, rings=0, **fields):
@@ -146,6 +152,15 @@ def follow(t): return _leaf("Follow", 1, 1, response_time=t)
 def afollow(a, r): return _leaf("AFollow", 1, 1, attack_time=a, release_time=r)
 def mls_bits(n): return _leaf("Mls", 0, 1, bits=float(n))
 def mls(): return mls_bits(29)
+def lfo_exp(a=1.0, k=1.0):        # lfo(|t| a * exp(-t * k))   prelude32.rs:602
+    return Graph("Envelope<EnvExp>", 0, 1, [((0,), "a", a, False), ((0,), "k", k, False)])
+def lfo_sine_hz(hz, lo=-1.0, hi=1.0):  # lfo(|t| lerp11(lo, hi, sin_hz(hz, t)))
+    return Graph("Envelope<EnvSineHz>", 0, 1, [((0,), "hz", hz, False), ((0,), "lo", lo, False), ((0,), "hi", hi, False)])
+def envelope(functor, source, outputs=1, **params):
+    """envelope(|t| ...) / lfo(|t| ...) (prelude32.rs:581-611) with the closure given as a C++ functor: `functor` is
+    its type name, `source` its definition (contract: Envelope<FN> in fd_nodes.hpp), `params` its per-voice fields."""
+    return Graph(f"Envelope<{functor}>", 0, outputs, [((0,), k, v, False) for k, v in params.items()], 0, source)
+lfo = envelope
 def pluck(frequency, gain_per_second, damping):  # excitation: Bank.set_ring(0, rnd_stream)
     return _leaf("Pluck", 1, 1, rings=2, frequency=frequency, gain_per_second=gain_per_second, high_frequency_damping=damping)
 def dsf_saw(): return _leaf("Dsf<2>", 2, 1, harmonic_spacing=1.0, roughness=0.5)
@@ -156,9 +171,9 @@ def delay(t): return _leaf("Delay", 1, 1, rings=1, time=t)
 def tap(min_delay, max_delay): return _leaf("TapT<false>", 2, 1, rings=1, min_delay=min_delay, max_delay=max_delay)
 def tap_linear(min_delay, max_delay): return _leaf("TapT<true>", 2, 1, rings=1, min_delay=min_delay, max_delay=max_delay)
 def allnest_c(coefficient, x):
-    return Graph(f"AllNest<{x.type}>", 1, 1, [((0,) + p, f, v, u) for p, f, v, u in x.params] + [((), "coefficient", coefficient, False)], x.rings)
+    return Graph(f"AllNest<{x.type}>", 1, 1, [((0,) + p, f, v, u) for p, f, v, u in x.params] + [((), "coefficient", coefficient, False)], x.rings, x.source)
 def oversample(x):  # prelude32.rs:983
-    return Graph(f"Oversampler<{x.type}>", x.nin, x.nout, [((0,) + p, f, v, u) for p, f, v, u in x.params], x.rings)
+    return Graph(f"Oversampler<{x.type}>", x.nin, x.nout, [((0,) + p, f, v, u) for p, f, v, u in x.params], x.rings, x.source)
 def saw(): return _leaf("WaveSynth<0>", 1, 1)
 def square(): return _leaf("WaveSynth<1>", 1, 1)
 def triangle(): return _leaf("WaveSynth<2>", 1, 1)

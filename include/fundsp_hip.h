@@ -108,6 +108,10 @@ int fdsp_set_option(const char* name, int value);
  * Returns the kind index (>= 0) or a negative error (fdsp_last_error() holds the compiler log).
  * fdsp_graph_check() only compiles (no device needed) -- a syntax / arity check of a type expression. */
 int fdsp_graph_compile(const char* name, const char* type_expr);
+/* Same, with C++ source compiled in front of the graph type (inside namespace fd): definitions the type expression
+ * refers to -- typically the functor that stands in for the Rust closure of envelope(|t| ...) / lfo(|t| ...), see
+ * Envelope<FN> in fundsp_amd/csrc/fd_nodes.hpp for the functor contract (OUT, visit, init, eval). */
+int fdsp_graph_compile_src(const char* name, const char* type_expr, const char* source);
 int fdsp_graph_check(const char* type_expr);
 /* Host-only introspection of a kind (no device needed): arity and the named per-voice slots. */
 int fdsp_kind_inputs(int kind);

@@ -29,6 +29,7 @@
 #define SIMD_N 8
 #define O_MAX_FIR 16
 #define O_MAX_CH 64
+#define O_MAX_ENV 8
 
 static const float F32_PI = 3.14159274101257324f;  /* core::f32::consts::PI */
 static const float F32_TAU = 6.28318548202514648f; /* core::f32::consts::TAU */
@@ -113,6 +114,10 @@ struct onode {
         size_t pl_raw_n, pl_len, pl_pos;
         int pl_init;
         double pl_sr;
+        /* Envelope<f32, E, R> (envelope.rs:17-49): the closure is a C callback; time fields et/et0/et1/einterval/esd/et_hash shared with EnvelopeIn */
+        o_env_fn env_fn;
+        void *env_ctx;
+        float env_v0[O_MAX_ENV], env_v1[O_MAX_ENV], env_val[O_MAX_ENV], env_d[O_MAX_ENV];
         /* Dsf (oscillator.rs:121-129) */
         float dsf_roughness, dsf_spacing;
         /* Rez (rez.rs:11-21), Follow / AFollow (follow.rs:31-43,137-152), Mls (noise.rs:14-20,103-107) */
@@ -498,6 +503,13 @@ static void leaf_reset(onode *n) {
         for (int i = 0; i < (n->s.nl_dirty ? 2 : 1); i++)
             if (n->s.sh[i].kind == O_SH_ADAPTIVE_TANH) n->s.sh[i].state = 1.0e-3f;
         break;
+    case O_ENVELOPE: { /* envelope.rs:114-122 */
+        n->s.et = 0.0f; n->s.et0 = 0.0f; n->s.et1 = 0.0f;
+        n->s.et_hash = n->s.hash;
+        n->s.env_fn(n->s.et0, n->s.env_v0, n->s.env_ctx);
+        for (int i = 0; i < n->nout; i++) n->s.env_v1[i] = n->s.env_v0[i];
+        break;
+    }
     case O_ADSR_LIVE: /* envelope.rs:293-298: the closure state (attacked, start times) is NOT reset */
         n->s.et = 0.0f;
         n->s.et0 = 0.0f;
@@ -560,6 +572,7 @@ static void leaf_set_sample_rate(onode *n, double sr) {
         n->s.ws_sr = (float)sr;
         n->s.sample_duration = 1.0f / (float)sr;
         break;
+    case O_ENVELOPE:  /* envelope.rs:124-126 */
     case O_ADSR_LIVE: /* envelope.rs:300-302 */
         n->s.esd = (float)(1.0 / sr);
         break;
@@ -660,7 +673,7 @@ static void leaf_set_hash(onode *n, uint64_t hash) {
     } else if (n->type == O_PLUCK) { /* oscillator.rs:307-310 */
         n->s.hash = hash;
         n->s.pl_init = 0;
-    } else if (n->type == O_ADSR_LIVE) { /* envelope.rs:346-349: no reset */
+    } else if (n->type == O_ADSR_LIVE || n->type == O_ENVELOPE) { /* envelope.rs:346-349, 165-168: no reset */
         n->s.hash = hash;
         n->s.et_hash = hash;
     }
@@ -1382,6 +1395,30 @@ static float adsr_closure(onode *n, float time, float control) {
     float a = n->s.release_start + n->s.adsr_r, b = n->s.release_start;
     return ads * clamp01f((time - a) / (b - a));
 }
+static void envelope_next_segment(onode *n) { /* Envelope::next_segment envelope.rs:79-98 */
+    n->s.et0 = n->s.et1;
+    for (int i = 0; i < n->nout; i++) n->s.env_v0[i] = n->s.env_v1[i];
+    float next_interval = lerpf(0.75f, 1.25f, (float)o_rnd1(n->s.et_hash)) * n->s.einterval;
+    n->s.et1 = n->s.et0 + next_interval;
+    n->s.env_fn(n->s.et1, n->s.env_v1, n->s.env_ctx);
+    n->s.et_hash = n->s.et_hash * 6364136223846793005ULL + 1ULL;
+    float u = (n->s.et - n->s.et0) / (n->s.et1 - n->s.et0);
+    float samples = next_interval / n->s.esd;
+    for (int i = 0; i < n->nout; i++) {
+        n->s.env_val[i] = lerpf(n->s.env_v0[i], n->s.env_v1[i], u);
+        n->s.env_d[i] = (n->s.env_v1[i] - n->s.env_v0[i]) / samples;
+    }
+}
+onode *o_envelope(float interval, int outputs, o_env_fn fn, void *ctx) { /* Envelope::new :58-76 (ID 14) */
+    if (outputs < 1 || outputs > O_MAX_ENV) return NULL;
+    onode *n = o_new(O_ENVELOPE, 0, outputs, 14);
+    n->s.env_fn = fn;
+    n->s.env_ctx = ctx;
+    n->s.einterval = interval;
+    leaf_set_sample_rate(n, DEFAULT_SR);
+    leaf_reset(n);
+    return n;
+}
 static void env_next_segment(onode *n, float input) {
     if (n->s.et0 == 0.0f && n->s.et1 == 0.0f) {
         n->s.ev0 = adsr_closure(n, n->s.et0, input);
@@ -1480,6 +1517,14 @@ void o_tick(onode *n, const float *in, float *out) {
         if (n->nout > 1) out[1] = n->s.phase;
         break;
     }
+    case O_ENVELOPE: /* envelope.rs:128-136 */
+        if (n->s.et >= n->s.et1) envelope_next_segment(n);
+        for (int i = 0; i < n->nout; i++) {
+            out[i] = n->s.env_val[i];
+            n->s.env_val[i] += n->s.env_d[i];
+        }
+        n->s.et += n->s.esd;
+        break;
     case O_ADSR_LIVE: /* envelope.rs:305-313 */
         if (n->s.et >= n->s.et1) env_next_segment(n, in[0]);
         out[0] = n->s.ev;
@@ -1897,6 +1942,27 @@ void o_process(onode *n, int size, const float *in, float *out) {
         for (int i = 0; i < full_simd_items(size) * 8; i++) out[i] = shape_simd_lane(n, 0, in[i]);
         process_remainder(n, size, in, out);
         break;
+    case O_ENVELOPE: { /* envelope.rs:138-163 */
+        if (n->s.et >= n->s.et1) envelope_next_segment(n);
+        int i = 0;
+        while (i < size) {
+            int64_t left = (int64_t)ceilf((n->s.et1 - n->s.et) / n->s.esd);
+            size_t segment_samples_left = (size_t)left;
+            size_t loop_samples = (size_t)(size - i) < segment_samples_left ? (size_t)(size - i) : segment_samples_left;
+            for (int c = 0; c < n->nout; c++) {
+                float value = n->s.env_val[c], delta = n->s.env_d[c];
+                for (size_t k = 0; k < loop_samples; k++) {
+                    out[c * MAXB + i + (int)k] = value;
+                    value += delta;
+                }
+                n->s.env_val[c] = value;
+            }
+            i += (int)loop_samples;
+            n->s.et += (float)(int64_t)loop_samples * n->s.esd;
+            if (loop_samples == segment_samples_left) envelope_next_segment(n);
+        }
+        break;
+    }
     case O_ADSR_LIVE: { /* envelope.rs:315-340: whole-block segment walk (no remainder path) */
         if (size == 0) break;
         if (n->s.et >= n->s.et1) env_next_segment(n, in[0]);

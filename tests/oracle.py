@@ -74,7 +74,7 @@ def lib():
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
         "o_onepole": (P, [i, i, f]), "o_pinkpass": (P, []), "o_morph": (P, [f, f, f]),
         "o_rez": (P, [i, f, f, f]), "o_follow": (P, [f]), "o_afollow": (P, [f, f]), "o_mls": (P, [C.c_uint]),
-        "o_mls_set_seed": (None, [P, C.c_uint64]), "o_oversample": (P, [P]), "o_dsf": (P, [i, f, f]), "o_pluck": (P, [f, f, f, fp, C.c_size_t]),
+        "o_mls_set_seed": (None, [P, C.c_uint64]), "o_oversample": (P, [P]), "o_dsf": (P, [i, f, f]), "o_envelope": (P, [f, i, P, P]), "o_pluck": (P, [f, f, f, fp, C.c_size_t]),
         "o_math_powf": (f, [f, f]),
         "o_seq_new": (P, [i, i, d]), "o_seq_free": (None, [P]), "o_seq_push": (i, [P, d, d, i, d, d, P]),
         "o_seq_render": (None, [P, C.c_size_t, i, fp, fp, fp]), "o_seq_time": (d, [P]), "o_mls_period": (C.c_uint64, [C.c_uint]),
@@ -320,6 +320,29 @@ def follow(t): return Node(lib().o_follow(t))                                # p
 def afollow(a, r): return Node(lib().o_afollow(a, r))                        # prelude32.rs:1266
 def mls_bits(n): return Node(lib().o_mls(n))                                 # prelude32.rs:772
 def mls(): return mls_bits(29)
+ENV_FN = C.CFUNCTYPE(None, C.c_float, C.POINTER(C.c_float), C.c_void_p)
+
+
+def envelope(fn, outputs=1, interval=0.002):                                  # prelude32.rs:581 envelope / :604 lfo
+    """fn(t: np.float32) -> float or sequence of `outputs` floats plays the Rust closure.  Use np.float32 arithmetic and
+    the oracle's own libm (m_expf, m_sinf, ...) inside it so that it computes what the f32 closure computes."""
+    def cb(t, out, _ctx):
+        r = fn(np.float32(t))
+        r = [r] if np.isscalar(r) else list(r)
+        for k in range(outputs):
+            out[k] = float(np.float32(r[k]))
+    c = ENV_FN(cb)
+    n = Node(lib().o_envelope(np.float32(interval), outputs, C.cast(c, C.c_void_p), None))
+    n._callback = c  # keep the trampoline alive as long as the node
+    return n
+
+
+lfo = envelope
+def m_expf(x): return np.float32(lib().o_math_expf(float(x)))
+def m_sinf(x): return np.float32(lib().o_math_sinf(float(x)))
+def m_cosf(x): return np.float32(lib().o_math_cosf(float(x)))
+
+
 def pluck(frequency, gain_per_second, damping, excitation):                    # prelude32.rs:1812 (+ the Rnd stream)
     e = np.ascontiguousarray(excitation, dtype=np.float32)
     return Node(lib().o_pluck(frequency, gain_per_second, damping, _fptr(e), e.size))

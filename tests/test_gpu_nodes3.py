@@ -200,3 +200,74 @@ def test_pluck(gpu, mode):
         n.set_sample_rate(SR)
         assert_bit_equal(got[v], oracle_render(n, xx[v], 2 * T, mode), f"pluck voice {v}")
     assert np.abs(got).max() > 0.05
+
+
+# ---- Envelope / lfo (envelope.rs:17-179): closures as device functors ---------------------------------------------------
+@pytest.mark.parametrize("mode", MODES)
+def test_lfo_functors(gpu, mode):
+    V, T = 70, 64 * 20 + 9
+    rng = np.random.default_rng(85)
+    a = (0.2 + rng.random(V)).astype(np.float32)
+    k = (0.5 + 40.0 * rng.random(V)).astype(np.float32)
+    b = gpu.Bank("lfo_exp", V)
+    b.set_param("0:a", a)
+    b.set_param("0:k", k)
+    b.set_sample_rate(SR)
+    seeds = np.arange(V, dtype=np.uint64) * 5 + 1
+    b.set_seed(seeds)
+    got = np.concatenate([run_bank(b, None, T, LAYOUT_VOICE_MINOR, mode), run_bank(b, None, T, LAYOUT_PLANAR, mode)], axis=-1)
+    hz = (0.2 + 15.0 * rng.random(V)).astype(np.float32)
+    s = gpu.Bank("lfo_sine_hz", V)
+    s.set_param("0:hz", hz)
+    s.set_param("0:lo", 0.25)
+    s.set_param("0:hi", 2.0)
+    s.set_sample_rate(SR)
+    s.set_seed(seeds)
+    gots = run_bank(s, None, T, LAYOUT_VOICE_MINOR, mode)
+    TAU = np.float32(6.2831855)
+    for v in (0, 9, 64, 69):
+        av, kv, hv = a[v], k[v], hz[v]
+        n = O.lfo(lambda t: av * O.m_expf(-t * kv))
+        n.set_sample_rate(SR)
+        n.set_seed(int(seeds[v]))
+        want = np.concatenate([oracle_render(n, None, T, mode), oracle_render(n, None, T, mode)], axis=-1)  # same block partition
+        assert_bit_equal(got[v], want, f"lfo_exp voice {v}")
+
+        def sine(t):
+            u = O.m_sinf(t * hv * TAU) * np.float32(0.5) + np.float32(0.5)
+            return np.float32(0.25) * (np.float32(1.0) - u) + np.float32(2.0) * u
+        m = O.lfo(sine)
+        m.set_sample_rate(SR)
+        m.set_seed(int(seeds[v]))
+        assert_bit_equal(gots[v], oracle_render(m, None, T, mode), f"lfo_sine_hz voice {v}")
+
+
+def test_jit_envelope_with_user_functor(gpu):
+    """envelope(|t| (sin_hz(r, t), cos_hz(r, t))) * noise stack: the closure arrives as C++ source with the graph."""
+    from fundsp_amd import graph as G
+
+    src = """
+struct EnvCircle {  // |t| (sin_hz(rate, t), cos_hz(rate, t))
+    static constexpr int OUT = 2;
+    float rate;
+    template <class V> FD_HD void visit(V& v) { v.f(rate, PARAM, "rate"); }
+    FD_HD void init() { rate = 1.0f; }
+    FD_HD void eval(float t, float* out) const {
+        out[0] = sinf_musl(t * rate * F32_TAU);
+        out[1] = cosf_musl(t * rate * F32_TAU);
+    }
+};
+"""
+    V, T = 64, 64 * 9 + 30
+    rate = np.linspace(0.5, 20.0, V).astype(np.float32)
+    g = G.envelope("EnvCircle", src, outputs=2, rate=rate) * (G.noise() | G.noise())
+    b = gpu.Bank.from_graph(g, V, sample_rate=SR)
+    b.set_seed(np.arange(V, dtype=np.uint64) + 2)
+    got = run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    TAU = np.float32(6.2831855)
+    for v in (0, 31, 63):
+        r = rate[v]
+        n = O.envelope(lambda t: (O.m_sinf(t * r * TAU), O.m_cosf(t * r * TAU)), outputs=2) * (O.noise() | O.noise())
+        n.set_sample_rate(SR)
+        n.set_seed(v + 2)
+        assert_bit_equal(got[v], oracle_render(n, None, T, MODE_PROCESS), f"jit envelope voice {v}")

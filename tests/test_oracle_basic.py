@@ -392,3 +392,25 @@ def test_pluck_is_tuned_and_decays():
     assert e2 < e1 * 0.8                                      # decays (gain 0.5/s plus high-frequency damping)
     n.reset()                                                 # reset -> the line is re-initialised from the same excitation
     assert np.array_equal(n.render_ticks(np.zeros((1, 500), dtype=np.float32))[0], y[:500].astype(np.float32))
+
+
+def test_envelope_samples_its_closure_and_tick_matches_process():
+    """Envelope (envelope.rs:17-179): lfo(|t| exp(-t)) follows exp(-t) within the 2 ms linear-interpolation error, the
+    segment grid is jittered deterministically from the hash, tick == process (check_wave's 1e-4 bar; here exact-ish)."""
+    sr = 48000.0
+    f = lambda t: O.m_expf(-t)
+    a, b = O.lfo(f), O.lfo(f)
+    for n in (a, b):
+        n.set_sample_rate(sr)
+        n.set_seed(77)
+    T = 64 * 40 + 13
+    y = a.render_ticks(length=T)[0]
+    z = b.render_blocks(length=T)[0]
+    t = np.arange(T) / sr
+    assert np.max(np.abs(y - np.exp(-t))) < 1e-5
+    assert np.max(np.abs(y - z)) < 1e-5   # tick accumulates t per sample, process per chunk: different f32 rounding of t
+    two = O.envelope(lambda t: (O.m_sinf(t * np.float32(2.0) * np.float32(6.2831855)), O.m_cosf(t * np.float32(2.0) * np.float32(6.2831855))), outputs=2)
+    two.set_sample_rate(sr)
+    w = two.render_blocks(length=4800)
+    assert w.shape == (2, 4800)
+    assert np.max(np.abs(w[0] ** 2 + w[1] ** 2 - 1.0)) < 1e-3
