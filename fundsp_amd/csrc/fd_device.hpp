@@ -224,9 +224,7 @@ FD_D void render_body(float* __restrict__ slots, size_t stride, size_t V, const 
             }
             if (MODE == MODE_PROCESS) g.end_simd();
             // Scalar paths (the remainder of a process block, every sample in tick mode) read their inputs at the
-            // point of use.  (Feeding them from the prefetched registers in a nested loop miscompiled AdsrLive's tick
-            // on this toolchain -- ROCm 7.2 clang, gfx950: a conditionally updated state word was lost -- so the
-            // slow paths keep the simplest possible loop shape.)
+            // point of use: they are the slow paths, and this keeps the loop as simple as it can be.
             for (int i = full; i < size; i++) {
                 const size_t t = t0 + i;
 #pragma unroll
@@ -694,8 +692,7 @@ constexpr PipePlan pipe_plan(int want) {  // want: 0 = best plan, 1 / 2 / 3 = at
 
 // One stage's work on one tile: frames [lo, hi) of the block that starts at t0 (size / full as in
 // AudioNode::process: `full` frames of packed SIMD items, end_simd, then the remainder path).
-// The packed path of the FIRST stage takes its inputs from the feed tile `fin` (written by the loader wave); the
-// scalar paths read HBM at the point of use (see render_body).
+// Inputs of the FIRST stage come from the feed tile `fin` (written by the loader wave), never from HBM directly.
 template <class SG, class G, int MODE, int SUB, bool FIRST, bool LAST>
 FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_t V, int lane, const float* inw, float* outw,
                      const float (*fin)[SUB][64], v2f (*hin)[64], v2f (*hout)[64]) {
@@ -735,7 +732,7 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
                 float fi[NI > 0 ? NI : 1], fo[NO];
                 if constexpr (FIRST) {
 #pragma unroll
-                    for (int c = 0; c < NI; c++) fi[c] = inw[((size_t)c * T + t0 + i) * V + lane];
+                    for (int c = 0; c < NI; c++) fi[c] = fin[c][i - lo][lane];
                 } else {
                     fi[0] = reinterpret_cast<const float*>(&hin[(i - lo) >> 1][lane])[i & 1];
                 }
@@ -755,7 +752,7 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
         float fi[NI > 0 ? NI : 1], fo[NO];
         if constexpr (FIRST) {
 #pragma unroll
-            for (int c = 0; c < NI; c++) fi[c] = inw[((size_t)c * T + t0 + i) * V + lane];
+            for (int c = 0; c < NI; c++) fi[c] = fin[c][i - lo][lane];
         } else {
             fi[0] = reinterpret_cast<const float*>(&hin[(i - lo) >> 1][lane])[i & 1];
         }

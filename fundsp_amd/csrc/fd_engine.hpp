@@ -99,26 +99,23 @@ bool launch_render_pipe(float* slots, size_t stride, size_t V, const float* in, 
         return false;
     }
 }
-// The pipeline kernel serves AudioNode::process semantics on whole SIMD items only (frames % 8 == 0, i.e. every
-// real-time block size).  Tick semantics and ragged tails go to the single-wave kernel: their per-sample loop inside
-// the pipeline kernel's round structure miscompiled on this toolchain (ROCm 7.2 clang, gfx950: AdsrLive's tick lost a
-// conditionally updated state word; tests/test_gpu_config4.py caught it), so that shape is simply never launched.
-template <class G>
+template <class G, int MODE>
 bool launch_render_split(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, const void* aux,
                          float* ring, uint32_t ring_cap, hipStream_t s) {
-    if ((T & 7) != 0) return false;
-    if (g_pipe_split == 4) return launch_render_pipe<G, MODE_PROCESS, 1>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
-    if (g_pipe_split == 2) return launch_render_pipe<G, MODE_PROCESS, 2>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
-    if (g_pipe_split == 3) return launch_render_pipe<G, MODE_PROCESS, 3>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
-    return launch_render_pipe<G, MODE_PROCESS, 0>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
+    if (g_pipe_split == 4) return launch_render_pipe<G, MODE, 1>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
+    if (g_pipe_split == 2) return launch_render_pipe<G, MODE, 2>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
+    if (g_pipe_split == 3) return launch_render_pipe<G, MODE, 3>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
+    return launch_render_pipe<G, MODE, 0>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
 }
 
 template <class G>
 void launch_render(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
                    int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
     if (V == 0 || T == 0) return;
-    if (layout == LAYOUT_VOICE_MINOR && g_pipe_split && mode == MODE_PROCESS) {
-        if (launch_render_split<G>(slots, stride, V, in, out, T, aux, ring, ring_cap, s)) return;
+    if (layout == LAYOUT_VOICE_MINOR && g_pipe_split) {
+        const bool done = mode == MODE_PROCESS ? launch_render_split<G, MODE_PROCESS>(slots, stride, V, in, out, T, aux, ring, ring_cap, s)
+                                               : launch_render_split<G, MODE_TICK>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
+        if (done) return;
     }
     if (layout == LAYOUT_VOICE_MINOR) {
         if (mode == MODE_PROCESS)

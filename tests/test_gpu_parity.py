@@ -397,7 +397,7 @@ def test_mix_stereo(gpu):
 def test_pipe_split_is_bit_identical_to_single_wave(gpu):
     """The multi-wave pipeline split (default for Pipe-chain kinds in the voice-minor layout) must not change a bit:
     single wave (0), best plan (1), forced two stages (2), forced three stages (3, half-block hand-over tiles)."""
-    V, T = 64 * 5 + 31, 64 * 7 + 24  # whole SIMD items: ragged tails and tick mode always take the single-wave kernel
+    V, T = 64 * 5 + 31, 64 * 7 + 29
     p = W.fm_svf_params(V, SR)
     outs = []
     for flag in (0, 1, 2, 3):
@@ -415,7 +415,7 @@ def test_pipe_split_is_bit_identical_to_single_wave(gpu):
     assert gpu.lib().fdsp_set_option(b"pipe_split", 5) < 0
 
 
-@pytest.mark.parametrize("T", [5, 8, 16, 32, 40, 64, 64 * 2 + 32, 64 * 2 + 40, 64 * 3 + 56])
+@pytest.mark.parametrize("T", [5, 8, 16, 31, 32, 33, 40, 64, 64 * 2 + 32, 64 * 2 + 37, 64 * 2 + 45, 64 * 3 + 63])
 def test_pipe_split_tile_edges(gpu, T):
     """Hand-over tiles of the three-stage split are half blocks: every position of the packed / remainder boundary
     (audionode.rs:85-105) relative to the tile boundary must give the single-wave samples, in both modes."""
@@ -434,7 +434,7 @@ def test_pipe_split_tile_edges(gpu, T):
     gpu.lib().fdsp_set_option(b"pipe_split", 1)
 
 
-FEED_T = [8, 16, 17, 24, 40, 64, 64 * 2 + 40, 64 * 3 + 56]
+FEED_T = [5, 16, 17, 40, 64, 64 * 2 + 37, 64 * 2 + 40, 64 * 3 + 63]
 
 
 @pytest.mark.parametrize("T", FEED_T)
