@@ -1,0 +1,86 @@
+"""BASELINE.json's full sizes on the device, checked through size-independent properties: spot bit-parity of randomly
+chosen voices against the oracle, chunked == whole (state carry), voice independence (a voice's samples do not depend
+on which bank or launch geometry it sits in), finiteness.  Outputs stay in HBM; only the spot voices cross PCIe."""
+import numpy as np
+import pytest
+
+import oracle as O
+from fundsp_amd import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS
+from fundsp_amd import workloads as W
+from test_gpu_config4 import config4_oracle_voice, tables  # noqa: F401
+from test_gpu_parity import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+
+
+def test_config3_full_size(gpu):
+    import torch
+
+    V, T = 65536, 48000
+    p = W.fm_svf_params(V, SR)
+    bank = W.make_fm_svf_bank(V, SR, params=p)
+    out = bank.process(T)                                     # [1][T][V], 12.6 GB
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+    assert float(out.abs().max()) < 16.0                      # resonant lowpass of a unit sine: bounded by its peak gain
+    rng = np.random.default_rng(2026)
+    spots = np.concatenate([[0, 63, 64, V - 1], rng.integers(0, V, 12)])
+    got = out[0][:, torch.from_numpy(spots).cuda()].t().contiguous().cpu().numpy()
+    want, _ = O.bank_render(3, [p["f"][spots], p["m"][spots], p["fc"][spots], p["q"][spots]], p["seed"][spots], T, SR,
+                            process_mode=True, out_layout=0, threads=8)
+    assert_bit_equal(got, want, "config 3 full size, spot voices")
+    # chunked == whole: two launches of 375 blocks each
+    b2 = W.make_fm_svf_bank(V, SR, params=p)
+    a = b2.process(T // 2)
+    b = b2.process(T // 2)
+    assert torch.equal(out[:, :T // 2], a) and torch.equal(out[:, T // 2:], b)
+    del a, b, b2
+    # voice independence: the same voices in a small bank (different grid, partially filled waves)
+    small = W.make_fm_svf_bank(200, SR, voice0=30000)
+    s = small.process(T)
+    assert torch.equal(out[0][:, 30000:30200], s[0])
+
+
+def test_config4_full_size(gpu, tables):
+    import torch
+
+    V, T = 32768, 48000
+    adsr = (0.01, 0.1, 0.6, 0.2)
+    p = W.saw_moog_params(V, SR)
+    bank = W.make_saw_moog_bank(V, SR, params=p, adsr=adsr)
+    gate_np = W.gate_signal(T, SR)
+    gate = torch.from_numpy(gate_np).cuda()[None, :, None].expand(1, T, V).contiguous()
+    out = bank.process(T, gate)                               # [2][T][V]
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+    rng = np.random.default_rng(2027)
+    spots = np.concatenate([[0, V - 1], rng.integers(0, V, 4)])
+    got = out[:, :, torch.from_numpy(spots).cuda()].permute(2, 0, 1).contiguous().cpu().numpy()
+    for k, v in enumerate(spots):
+        want = config4_oracle_voice(p, int(v), adsr).render_blocks(gate_np[None, :])
+        assert_bit_equal(got[k], want, f"config 4 full size, voice {v}")
+    mix = gpu.sum_voices(out)                                 # the per-GPU partial of the stereo mix-down
+    assert mix.shape == (2, T) and bool(torch.isfinite(mix).all())
+
+
+def test_config5_full_size(gpu):
+    import torch
+
+    V, T = 2048, 48000
+    bank = gpu.Bank.reverb_stereo(V, 10.0, 2.0, 0.5)
+    bank.set_sample_rate(SR)
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
+    out = bank.process(T, x, layout=LAYOUT_PLANAR, frame_stride=T)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+    for v in (0, 1, 1027, V - 1):
+        n = O.reverb_stereo(10.0, 2.0, 0.5)
+        n.set_sample_rate(SR)
+        assert_bit_equal(out[v].cpu().numpy(), n.render_blocks(x[v].cpu().numpy()), f"config 5 full size, instance {v}")
+    b2 = gpu.Bank.reverb_stereo(V, 10.0, 2.0, 0.5)
+    b2.set_sample_rate(SR)
+    a = b2.process(1000, x[:, :, :1000].contiguous(), layout=LAYOUT_PLANAR, frame_stride=1000)   # ragged chunk
+    b = b2.process(T - 1000, x[:, :, 1000:].contiguous(), layout=LAYOUT_PLANAR, frame_stride=T - 1000)
+    assert torch.equal(out[:, :, :1000], a) and torch.equal(out[:, :, 1000:], b)
