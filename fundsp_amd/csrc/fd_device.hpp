@@ -930,6 +930,22 @@ FD_D void describe_body(char* out, int cap, int* meta) {
     meta[2] = G::RINGS;
     meta[3] = d.pos;
     meta[4] = RenderGeom<G, LAYOUT_PLANAR>::WPB;
+    constexpr PipePlan P = pipe_plan<G>(0);  // pipeline kernel plan of run-time compiled graphs (0 stages = not used)
+    meta[5] = P.S;
+    meta[6] = P.S >= 1 ? 64 * PipeGeom<G::IN, (P.S >= 1 ? P.S : 1)>::WAVES : 0;
 }
+
+// pipeline kernel entry for run-time compiled graphs: empty when the graph has no plan
+template <class G, int MODE>
+FD_D void jit_pipe_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
+                        float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap) {
+    constexpr PipePlan P = pipe_plan<G>(0);
+    if constexpr (P.S >= 1) render_pipe_body<G, MODE, P.S, P.K1, P.K2>(slots, stride, V, in, out, T, aux, ring, ring_cap);
+}
+template <class G>
+struct JitPipeThreads {
+    static constexpr PipePlan P = pipe_plan<G>(0);
+    static constexpr int v = P.S >= 1 ? 64 * PipeGeom<G::IN, (P.S >= 1 ? P.S : 1)>::WAVES : 64;
+};
 
 }  // namespace fd

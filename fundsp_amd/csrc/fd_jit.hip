@@ -44,6 +44,8 @@ struct JitModule {
     hipFunction_t lifecycle = nullptr, describe = nullptr;
     hipFunction_t render[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [mode][layout]
     hipFunction_t events[2] = {nullptr, nullptr};                            // [mode]
+    hipFunction_t pipe[2] = {nullptr, nullptr};                              // [mode], pipeline kernel
+    int pipe_stages = 0, pipe_threads = 0;
     int wpb[2] = {4, 4};                                                     // per layout
     ~JitModule() {
         if (mod) hipModuleUnload(mod);
@@ -72,6 +74,14 @@ std::string jit_source(const std::string& type_expr, const std::string& prelude)
                  "  fd::render_body<JitG, " + m + ", " + l + ", JIT_WPB" + l +
                  ">(slots, stride, V, in, out, T, fstride, aux, ring, cap); }\n";
         }
+    s += "constexpr int JIT_PIPE_THREADS = fd::JitPipeThreads<JitG>::v;\n";
+    for (int mode = 0; mode < 2; mode++) {
+        std::string m = std::to_string(mode);
+        s += "extern \"C\" __global__ __launch_bounds__(JIT_PIPE_THREADS) void jit_pipe_" + m +
+             "(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ out, "
+             "size_t T, const void* aux, float* ring, uint32_t cap) {\n"
+             "  fd::jit_pipe_body<JitG, " + m + ">(slots, stride, V, in, out, T, aux, ring, cap); }\n";
+    }
     for (int mode = 0; mode < 2; mode++) {
         std::string m = std::to_string(mode);
         s += "extern \"C\" __global__ __launch_bounds__(256) void jit_events_" + m +
@@ -142,6 +152,8 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     for (int m = 0; m < 2 && ok; m++) {
         std::string fn = "jit_events_" + std::to_string(m);
         ok = hipModuleGetFunction(&jm->events[m], jm->mod, fn.c_str()) == hipSuccess;
+        fn = "jit_pipe_" + std::to_string(m);
+        ok = ok && hipModuleGetFunction(&jm->pipe[m], jm->mod, fn.c_str()) == hipSuccess;
     }
     if (!ok) {
         *err = "compiled graph is missing an entry point";
@@ -174,6 +186,8 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     out->nrings = meta[2];
     jm->wpb[LAYOUT_VOICE_MINOR] = 4;
     jm->wpb[LAYOUT_PLANAR] = meta[4];
+    jm->pipe_stages = meta[5];
+    jm->pipe_threads = meta[6];
     out->slots.clear();
     std::istringstream lines(std::string(txt.data(), (size_t)meta[3]));
     std::string line;
@@ -191,6 +205,12 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     out->render = [jm](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T, size_t fstride,
                        int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
         if (V == 0 || T == 0) return;
+        if (layout == LAYOUT_VOICE_MINOR && g_pipe_split && jm->pipe_stages >= 1) {  // loader wave / stage split
+            void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &aux, &ring, &ring_cap};
+            hipModuleLaunchKernel(jm->pipe[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_threads, 1, 1, 0, s,
+                                  pargs, nullptr);
+            return;
+        }
         const int wpb = jm->wpb[layout];
         const int vpw = layout == LAYOUT_VOICE_MINOR ? voices_per_wave(V, simd_count()) : 64;
         if (layout == LAYOUT_VOICE_MINOR) fstride = (size_t)vpw;

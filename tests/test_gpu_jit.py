@@ -82,3 +82,21 @@ def test_jit_type_errors_are_reported(gpu):
     assert rc < 0 and "Pipe arity mismatch" in gpu.lib().fdsp_last_error().decode()
     with pytest.raises(TypeError):
         GR.sine() >> (GR.sine() | GR.sine())                                             # caught on the host as well
+
+
+def test_jit_pipeline_kernel_matches_single_wave(gpu):
+    """Run-time compiled graphs take the pipeline kernel too (loader wave for inputs, two compute stages where the chain
+    allows): same samples as their single-wave kernel."""
+    V, T = 200, 64 * 6 + 21
+    x = noise_input(V, 1, T, seed=5)
+    for build, ni in ((lambda m: m.lowpass_hz(1200.0, 2.0) >> m.shape("tanh", 3.0) >> m.highpole_hz(200.0), 1),
+                      (lambda m: m.noise() >> m.moog_hz(1500.0, 0.4), 0)):
+        outs = []
+        for flag in (0, 1):
+            assert gpu.lib().fdsp_set_option(b"pipe_split", flag) == 0
+            b = gpu.Bank.from_graph(build(GR), V, sample_rate=SR)
+            b.set_seed(np.arange(V, dtype=np.uint64))
+            outs.append([run_bank(b, x if ni else None, T, LAYOUT_VOICE_MINOR, mode) for mode in (MODE_PROCESS, MODE_TICK)])
+        gpu.lib().fdsp_set_option(b"pipe_split", 1)
+        for a, c in zip(*outs):
+            assert_bit_equal(a, c, "jit pipeline vs single wave")
