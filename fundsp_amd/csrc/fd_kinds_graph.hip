@@ -28,6 +28,8 @@ using SvfShapeSvf = Pipe<SvfShape, FixedSvf>;
 // (README.md:1631), and an oversampled waveshaper  oversample(shape(..))  as the 1-in 1-out case
 using OversampleFm = Oversampler<Pipe<FmMod, Sine>>;
 using OversampleShape = Oversampler<Shaper>;
+// resample(sine_hz(f) * f * m + f >> sine()) (prelude32.rs:1021): the FM pair played back at a per-sample speed
+using ResampleFm = Resample<Pipe<FmMod, Sine>>;
 
 void register_graph_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<SineHz>("sine_hz"));
@@ -37,6 +39,7 @@ void register_graph_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<SawMoogAdsrPan>("saw_moog_adsr_pan"));
     out.push_back(make_kind<OversampleFm>("oversample_fm"));
     out.push_back(make_kind<OversampleShape>("oversample_shape"));
+    out.push_back(make_kind<ResampleFm>("resample_fm"));
     out.push_back(make_kind<SvfShape>("svf_shape"));
     out.push_back(make_kind<SvfShapeSvf>("svf_shape_svf"));
 }

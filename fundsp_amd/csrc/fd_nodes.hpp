@@ -1837,6 +1837,67 @@ struct Oversampler {
     FD_STEP2_VIA_STEP
 };
 
+// Resample<X>  resample.rs:205-315 (ID 69): enclosed GENERATOR X read at a variable speed (input 0; 1 = original) with
+// cubic (Catmull-Rom) interpolation.  Only the four newest inner samples are ever read (consumer_i - 1 .. + 2 and the
+// producer stops at consumer_i + 3), so the 128-sample ring of the reference becomes a 4-deep history.  No process
+// override in the reference: both modes tick, and X is always ticked.
+template <class X>
+struct Resample {
+    static_assert(X::IN == 0, "Resample wraps a generator");
+    static constexpr int IN = 1, OUT = X::OUT, RINGS = X::RINGS;
+    static constexpr uint64_t ID = 69;
+    X x;
+    float h[OUT][4];       // newest four inner samples, oldest first
+    uint64_t consumer_bits;  // f64 (resample.rs:218)
+    uint64_t producer;
+    template <class V> FD_HD void visit(V& v) {
+        v.enter(0); x.visit(v); v.leave();
+#pragma unroll
+        for (int c = 0; c < OUT; c++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) v.fi(h[c][k], STATE, "buffer", c * 4 + k);
+        v.u64(consumer_bits, STATE, "consumer");
+        v.u64(producer, STATE, "producer");
+    }
+    FD_HD void bind(Ctx& c) { x.bind(c); }
+    FD_HD void init() {
+        x.init();
+        for (int c = 0; c < OUT; c++)
+            for (int k = 0; k < 4; k++) h[c][k] = 0.0f;
+        consumer_bits = __builtin_bit_cast(uint64_t, 1.0);
+        producer = 0;
+    }
+    FD_HD void update(double sr) { x.update(sr); }                                     // :277-279
+    FD_HD void reset() {                                                                // :270-275
+        x.reset();
+        consumer_bits = __builtin_bit_cast(uint64_t, 1.0);
+        producer = 0;
+    }
+    FD_HD uint64_t ping(bool probe, uint64_t hh) { return x.ping(probe, atto(hh, ID)); }  // :308-310
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // tick :281-303
+        double consumer = __builtin_bit_cast(double, consumer_bits);
+        consumer += (double)__builtin_fmaxf(0.0f, in[0]);
+        const double d = consumer - __builtin_floor(consumer);
+        const uint64_t ci = (uint64_t)(consumer - d);
+        while (ci + 2 >= producer) {
+            float inner[OUT];
+            x.template step<PH_TICK>(nullptr, inner);
+#pragma unroll
+            for (int c = 0; c < OUT; c++) {
+                h[c][0] = h[c][1]; h[c][1] = h[c][2]; h[c][2] = h[c][3]; h[c][3] = inner[c];
+            }
+            producer += 1;
+        }
+        consumer_bits = __builtin_bit_cast(uint64_t, consumer);
+#pragma unroll
+        for (int c = 0; c < OUT; c++) out[c] = splinef(h[c][0], h[c][1], h[c][2], h[c][3], (float)d);
+    }
+    FD_STEP2_VIA_STEP
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // one-pole family (filter.rs): Lowpole (ID 18), Highpole (ID 47), DCBlock (ID 22), Pinkpass (ID 26), Allpole (ID 46),
 // and Morph (svf.rs:1040-1111, ID 62).  SURVEY 8(f) row 1: same lane-per-voice skeleton as the biquads.

@@ -172,6 +172,9 @@ def tap(min_delay, max_delay): return _leaf("TapT<false>", 2, 1, rings=1, min_de
 def tap_linear(min_delay, max_delay): return _leaf("TapT<true>", 2, 1, rings=1, min_delay=min_delay, max_delay=max_delay)
 def allnest_c(coefficient, x):
     return Graph(f"AllNest<{x.type}>", 1, 1, [((0,) + p, f, v, u) for p, f, v, u in x.params] + [((), "coefficient", coefficient, False)], x.rings, x.source)
+def resample(x):  # prelude32.rs:1021: x is a generator, input 0 = speed
+    assert x.nin == 0
+    return Graph(f"Resample<{x.type}>", 1, x.nout, [((0,) + p, f, v, u) for p, f, v, u in x.params], x.rings, x.source)
 def oversample(x):  # prelude32.rs:983
     return Graph(f"Oversampler<{x.type}>", x.nin, x.nout, [((0,) + p, f, v, u) for p, f, v, u in x.params], x.rings, x.source)
 def saw(): return _leaf("WaveSynth<0>", 1, 1)

@@ -104,6 +104,10 @@ struct onode {
         int osc_kind, lorenz, nl_dirty, nl_mode;
         float cx, cy, cz;
         float ns1, ns2;
+        /* Resample<X> (resample.rs:210-220): 128-sample ring per output channel */
+        float *rs_buf;
+        double rs_consumer;
+        size_t rs_producer;
         /* Oversampler<X> (oversample.rs:66-80): 128-sample input / output rings per channel */
         float *os_inv, *os_outv; /* [channel][128] */
         size_t os_in_i, os_out_i;
@@ -165,6 +169,7 @@ void o_free(onode *n) {
     free(n->s.tbuf);
     free(n->s.pl_raw);
     free(n->s.pl_line);
+    free(n->s.rs_buf);
     free(n->s.os_inv);
     free(n->s.os_outv);
     free(n);
@@ -460,6 +465,10 @@ static void leaf_reset(onode *n) {
         for (int i = 0; i < O_MAX_FIR; i++) n->s.v[i] = 0.0f;
         n->s.pl_init = 0;
         break;
+    case O_RESAMPLE: /* resample.rs:270-275 (child reset by o_reset; the ring keeps its contents) */
+        n->s.rs_consumer = 1.0;
+        n->s.rs_producer = 0;
+        break;
     case O_OVERSAMPLE: /* oversample.rs:131-135: rings cleared, ring indices kept (child reset by o_reset) */
         memset(n->s.os_inv, 0, (size_t)(n->nin ? n->nin : 1) * 128 * sizeof(float));
         memset(n->s.os_outv, 0, (size_t)n->nout * 128 * sizeof(float));
@@ -687,6 +696,7 @@ static uint64_t o_ping(onode *n, int probe, uint64_t hash) {
     case O_BINOP:
         return o_ping(n->y, probe, o_ping(n->x, probe, o_atto(hash, n->id)));
     case O_UNOP:
+    case O_RESAMPLE:   /* resample.rs:308-310 */
     case O_OVERSAMPLE: /* oversample.rs:218-220 */
     case O_ALLNEST: /* delay.rs:337-339 */
         return o_ping(n->x, probe, o_atto(hash, n->id));
@@ -1196,6 +1206,18 @@ static float os_decimate(const float *ring, size_t last_index) { /* :43-64 */
         for (int j = 0; j < 8; j++) acc[j] = ring[(start + (size_t)i * 8 + j) & 0x7f] * os_dec_coeff(i * 8 + j) + acc[j];
     return wide_reduce_add8(acc);
 }
+onode *o_resample(onode *x) { /* Resample::new resample.rs:228-238 (ID 69): x is a generator */
+    if (x->nin != 0) return NULL;
+    onode *n = o_new(O_RESAMPLE, 1, x->nout, 69);
+    n->x = x;
+    n->s.rs_buf = (float *)calloc((size_t)x->nout * 128, sizeof(float));
+    n->s.rs_consumer = 1.0;
+    n->s.rs_producer = 0;
+    o_set_sample_rate(x, DEFAULT_SR);
+    uint64_t h = o_ping(x, 1, 69);
+    o_ping(x, 0, h);
+    return n;
+}
 onode *o_oversample(onode *x) { /* Oversampler::new :90-104 */
     onode *n = o_new(O_OVERSAMPLE, x->nin, x->nout, 51);
     n->x = x;
@@ -1625,6 +1647,23 @@ void o_tick(onode *n, const float *in, float *out) {
         }
         n->s.ti = (n->s.ti + 1) & mask;
         out[0] = o;
+        break;
+    }
+    case O_RESAMPLE: { /* resample.rs:281-303 */
+        float spd = in[0] > 0.0f ? in[0] : 0.0f; /* max(0.0, input[0]) */
+        n->s.rs_consumer += (double)spd;
+        double d = n->s.rs_consumer - floor(n->s.rs_consumer);
+        size_t ci = (size_t)(n->s.rs_consumer - d);
+        float inner[O_MAX_CH];
+        while (ci + 2 >= n->s.rs_producer) {
+            o_tick(n->x, NULL, inner);
+            for (int c = 0; c < n->nout; c++) n->s.rs_buf[c * 128 + (n->s.rs_producer & 0x7f)] = inner[c];
+            n->s.rs_producer += 1;
+        }
+        for (int c = 0; c < n->nout; c++) {
+            const float *b = n->s.rs_buf + c * 128;
+            out[c] = splinef(b[(ci + 0x7f) & 0x7f], b[ci & 0x7f], b[(ci + 1) & 0x7f], b[(ci + 2) & 0x7f], (float)d);
+        }
         break;
     }
     case O_OVERSAMPLE: { /* oversample.rs:142-176 */

@@ -18,7 +18,7 @@ enum {
     O_CONSTANT = 0, O_PASS, O_SINE, O_NOISE, O_SVF, O_FIXED_SVF, O_BIQUAD, O_BUTTER_LOWPASS, O_RESONATOR,
     O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP,
     O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO, O_SHAPER, O_PHASE_OSC, O_CHAOS, O_NLBIQUAD, O_TAP, O_ALLNEST,
-    O_ONEPOLE, O_PINKPASS, O_MORPH, O_REZ, O_FOLLOW, O_AFOLLOW, O_MLS, O_OVERSAMPLE, O_DSF, O_PLUCK, O_ENVELOPE
+    O_ONEPOLE, O_PINKPASS, O_MORPH, O_REZ, O_FOLLOW, O_AFOLLOW, O_MLS, O_OVERSAMPLE, O_DSF, O_PLUCK, O_ENVELOPE, O_RESAMPLE
 };
 enum { O_OP_LOWPOLE = 0, O_OP_HIGHPOLE, O_OP_DCBLOCK, O_OP_ALLPOLE };
 enum { O_SH_CLIP = 0, O_SH_CLIPTO, O_SH_TANH, O_SH_ATAN, O_SH_SOFTSIGN, O_SH_CRUSH, O_SH_SOFTCRUSH, O_SH_ADAPTIVE_TANH };
@@ -67,6 +67,7 @@ onode *o_envelope(float interval, int outputs, o_env_fn fn, void *ctx);
 /* Pluck (oscillator.rs:215); excitation = the funutd Rnd stream the reference draws in initialize_line, given by the caller */
 onode *o_pluck(float frequency, float gain_per_second, float high_frequency_damping, const float *excitation, size_t n_exc);
 onode *o_dsf(int inputs, float harmonic_spacing, float roughness); /* Dsf<U1/U2> (oscillator.rs:121) */
+onode *o_resample(onode *x);                                     /* Resample<X> (resample.rs:210): x a generator; input 0 = speed */
 onode *o_oversample(onode *x);                                   /* Oversampler<X> (oversample.rs:66), takes ownership of x */
 onode *o_rez(int inputs, float bandpass, float cutoff, float q); /* Rez<f32, U1/U3> (rez.rs): inputs 1 or 3 */
 onode *o_follow(float response_time);                           /* Follow<f32> (follow.rs:31) */

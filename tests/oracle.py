@@ -74,7 +74,7 @@ def lib():
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
         "o_onepole": (P, [i, i, f]), "o_pinkpass": (P, []), "o_morph": (P, [f, f, f]),
         "o_rez": (P, [i, f, f, f]), "o_follow": (P, [f]), "o_afollow": (P, [f, f]), "o_mls": (P, [C.c_uint]),
-        "o_mls_set_seed": (None, [P, C.c_uint64]), "o_oversample": (P, [P]), "o_dsf": (P, [i, f, f]), "o_envelope": (P, [f, i, P, P]), "o_pluck": (P, [f, f, f, fp, C.c_size_t]),
+        "o_mls_set_seed": (None, [P, C.c_uint64]), "o_oversample": (P, [P]), "o_resample": (P, [P]), "o_dsf": (P, [i, f, f]), "o_envelope": (P, [f, i, P, P]), "o_pluck": (P, [f, f, f, fp, C.c_size_t]),
         "o_math_powf": (f, [f, f]),
         "o_seq_new": (P, [i, i, d]), "o_seq_free": (None, [P]), "o_seq_push": (i, [P, d, d, i, d, d, P]),
         "o_seq_render": (None, [P, C.c_size_t, i, fp, fp, fp]), "o_seq_time": (d, [P]), "o_mls_period": (C.c_uint64, [C.c_uint]),
@@ -350,6 +350,7 @@ def dsf_saw(): return Node(lib().o_dsf(2, 1.0, 0.5))                         # p
 def dsf_saw_r(r): return Node(lib().o_dsf(1, 1.0, r))                        # prelude32.rs:1781
 def dsf_square(): return Node(lib().o_dsf(2, 2.0, 0.5))                      # prelude32.rs:1789
 def dsf_square_r(r): return Node(lib().o_dsf(1, 2.0, r))                     # prelude32.rs:1797
+def resample(x): return Node(lib().o_resample(x.ptr), [x])                    # prelude32.rs:1021
 def oversample(x): return Node(lib().o_oversample(x.ptr), [x])                # prelude32.rs:983                                               # prelude32.rs:784
 def morph(): return Node(lib().o_morph(440.0, 1.0, 0.0))
 

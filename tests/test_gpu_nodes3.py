@@ -271,3 +271,34 @@ struct EnvCircle {  // |t| (sin_hz(rate, t), cos_hz(rate, t))
         n.set_sample_rate(SR)
         n.set_seed(v + 2)
         assert_bit_equal(got[v], oracle_render(n, None, T, MODE_PROCESS), f"jit envelope voice {v}")
+
+
+# ---- Resample (resample.rs:205-315) ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", MODES)
+def test_resample_fm(gpu, mode):
+    from fundsp_amd import workloads as W
+
+    V, T = 70, 64 * 4 + 27
+    rng = np.random.default_rng(87)
+    p = W.fm_svf_params(V, SR)
+    speed = (0.25 + 2.5 * rng.random((V, 1, T))).astype(np.float32)
+    speed[0] = 1.0                                              # original speed
+    speed[1, 0, 50:90] = 0.0                                    # frozen: no inner samples consumed
+    speed[2, 0, :] = -1.0                                       # negative speeds clamp to 0 (max(0.0, input))
+    speed[3, 0, 100] = 37.5                                     # a jump: many inner ticks for one output sample
+    b = gpu.Bank("resample_fm", V)
+    b.set_param("0.0.0.0.0.0:value[0]", p["f"])
+    b.set_param("0.0.0.0:scalar", p["f"])
+    b.set_param("0.0.0:scalar", p["m"])
+    b.set_param("0.0:scalar", p["f"])
+    b.set_sample_rate(SR)
+    seeds = np.arange(V, dtype=np.uint64) + 21
+    b.set_seed(seeds)
+    got = np.concatenate([run_bank(b, speed, T, LAYOUT_VOICE_MINOR, mode), run_bank(b, speed, T, LAYOUT_PLANAR, mode)], axis=-1)
+    xx = np.concatenate([speed, speed], axis=-1)
+    for v in (0, 1, 2, 3, 40, 69):
+        f, m = float(p["f"][v]), float(p["m"][v])
+        n = O.resample(O.sine_hz(f) * f * m + f >> O.sine())
+        n.set_sample_rate(SR)
+        n.set_seed(int(seeds[v]))
+        assert_bit_equal(got[v], oracle_render(n, xx[v], 2 * T, mode), f"resample_fm voice {v}")

@@ -414,3 +414,25 @@ def test_envelope_samples_its_closure_and_tick_matches_process():
     w = two.render_blocks(length=4800)
     assert w.shape == (2, 4800)
     assert np.max(np.abs(w[0] ** 2 + w[1] ** 2 - 1.0)) < 1e-3
+
+
+def test_resample_speed_one_is_a_one_sample_delay_and_speed_two_skips():
+    """Resample (resample.rs:205-315): Catmull-Rom through the knots -- at speed 1 the output is the generator read from
+    its third sample on (consumer starts at 1.0 and is advanced before the read); at speed 2 every second sample; at
+    speed 0.5 every other output is a knot."""
+    sr = 48000.0
+    gen = lambda: O.constant(330.0) >> O.sine().phase(0.25)   # explicit phase: independent of the ping hash
+    inner = gen()
+    inner.set_sample_rate(sr)
+    ref = inner.render_ticks(length=600)[0]
+    for speed, idx in ((1.0, np.arange(2, 202)), (2.0, np.arange(3, 403, 2))):
+        r = O.resample(gen())
+        r.set_sample_rate(sr)
+        y = r.render_ticks(np.full((1, 200), speed, dtype=np.float32))[0]
+        assert np.array_equal(y, ref[idx]), speed
+    h = O.resample(gen())
+    h.set_sample_rate(sr)
+    y = h.render_ticks(np.full((1, 300), 0.5, dtype=np.float32))[0]
+    assert np.array_equal(y[1::2][:100], ref[2:102])            # consumer 2.0, 3.0, ...: knots
+    mid = 0.5 * (ref[1:101] + ref[2:102])                       # consumer 1.5, 2.5, ...: between two knots
+    assert np.max(np.abs(y[0::2][:100] - mid)) < 2e-3           # cubic vs linear midpoint of a 330 Hz sine
