@@ -41,6 +41,7 @@ void register_leaf_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<Pluck>("pluck"));
     out.push_back(make_kind<Envelope<EnvExp>>("lfo_exp"));
     out.push_back(make_kind<Envelope<EnvSineHz>>("lfo_sine_hz"));
+    out.push_back(make_kind<EnvelopeIn<EnvInExp>>("lfo2_exp"));
     out.push_back(make_kind<Dsf<1>>("dsf_r"));
     out.push_back(make_kind<Dsf<2>>("dsf"));
     out.push_back(make_kind<Morph>("morph"));

@@ -1040,6 +1040,108 @@ struct EnvSineHz {  // lfo(|t| lerp11(lo, hi, sin_hz(hz, t)))   (math.rs:204-206
         out[0] = lo * (1.0f - u) + hi * u;
     }
 };
+// EnvelopeIn<f32, E, I, R>  envelope.rs:185-358 (ID 53): like Envelope, but the closure also sees the node's inputs
+// E(t, &inputs) (envelope2 / lfo2 / envelope_in / lfo_in, prelude32.rs:625-745).  adsr_live above is the instance whose
+// closure carries state; this is the general form for stateless functors: FN::IN inputs, FN::OUT outputs,
+// `eval(float t, const float* in, float* out)`.
+struct EnvInExp {  // lfo2(|t, speed| exp(-t * speed))   (prelude32.rs:623)
+    static constexpr int IN = 1, OUT = 1;
+    template <class V> FD_HD void visit(V&) {}
+    FD_HD void init() {}
+    FD_HD void eval(float t, const float* in, float* out) const { out[0] = expf_musl(-t * in[0]); }
+};
+template <class FN>
+struct EnvelopeIn {
+    static constexpr int IN = FN::IN, OUT = FN::OUT, RINGS = 0;
+    static constexpr uint64_t ID = 53;
+    FN fn;
+    float interval, sd;
+    float t, t0, t1, v0[OUT], v1[OUT], value[OUT], value_d[OUT];
+    uint64_t t_hash, hash;
+    int blk_i, blk_size, remaining, loop_len;  // block-walk transients (process path)
+    bool full_seg;
+    template <class V> FD_HD void visit(V& v) {
+        v.enter(0); fn.visit(v); v.leave();
+        v.f(interval, PARAM, "interval");
+        v.f(sd, COEF, "sample_duration");
+        v.f(t, STATE, "t"); v.f(t0, STATE, "t_0"); v.f(t1, STATE, "t_1");
+        _Pragma("unroll") for (int i = 0; i < OUT; i++) v.fi(v0[i], STATE, "value_0", i);
+        _Pragma("unroll") for (int i = 0; i < OUT; i++) v.fi(v1[i], STATE, "value_1", i);
+        _Pragma("unroll") for (int i = 0; i < OUT; i++) v.fi(value[i], STATE, "value", i);
+        _Pragma("unroll") for (int i = 0; i < OUT; i++) v.fi(value_d[i], STATE, "value_d", i);
+        v.u64(t_hash, STATE, "t_hash");
+        v.u64(hash, STATE, "hash");
+    }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void init() {  // EnvelopeIn::new :221-241 with interval 0.002
+        fn.init();
+        interval = (float)0.002;
+        hash = 0;
+        for (int i = 0; i < OUT; i++) { v0[i] = v1[i] = value[i] = value_d[i] = 0.0f; }
+        reset();
+    }
+    FD_HD void update(double sr) { sd = (float)(1.0 / sr); }  // :300-302
+    FD_HD void reset() { t = 0.0f; t0 = 0.0f; t1 = 0.0f; t_hash = hash; }  // :293-298
+    FD_HD uint64_t ping(bool probe, uint64_t h) {
+        if (!probe) {  // set_hash :346-349: no reset
+            hash = h;
+            t_hash = h;
+        }
+        return atto(h, ID);
+    }
+    FD_HD void next_segment(const float* in) {  // :244-278
+        if (t0 == 0.0f && t1 == 0.0f) {
+            fn.eval(t0, in, v0);
+        } else {
+            t0 = t1;
+            for (int i = 0; i < OUT; i++) v0[i] = v1[i];
+        }
+        const float next_interval = lerpf(0.75f, 1.25f, (float)rnd1(t_hash)) * interval;
+        t1 = t0 + next_interval;
+        fn.eval(t1, in, v1);
+        t_hash = t_hash * 6364136223846793005ULL + 1ULL;
+        const float u = (t - t0) / (t1 - t0);
+        const float samples = next_interval / sd;
+        for (int i = 0; i < OUT; i++) {
+            value[i] = lerpf(v0[i], v1[i], u);
+            value_d[i] = (v1[i] - v0[i]) / samples;
+        }
+    }
+    FD_HD void begin_block(int size) { blk_i = 0; blk_size = size; remaining = 0; full_seg = false; loop_len = 0; }
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    FD_HD void start_chunk() {  // one iteration head of the `while i < size` loop :323-326
+        float c = __builtin_ceilf((t1 - t) / sd);
+        long long left = (long long)c;
+        int room = blk_size - blk_i;
+        bool huge = left < 0 || left > (long long)room;  // `as usize` of a negative value is huge
+        loop_len = huge ? room : (int)left;
+        full_seg = !huge && loop_len == (int)left;
+        remaining = loop_len;
+    }
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        if (PH == PH_TICK) {  // tick :305-313
+            if (t >= t1) next_segment(in);
+            for (int i = 0; i < OUT; i++) { out[i] = value[i]; value[i] += value_d[i]; }
+            t += sd;
+        } else {  // process :315-340, walked sample by sample (the whole block, no remainder path)
+            if (blk_i == 0) {
+                if (t >= t1) next_segment(in);
+                start_chunk();
+            }
+            for (int guard = 0; remaining == 0 && guard < 4; guard++) {  // chunk exhausted before this sample (`i < size`)
+                if (full_seg) next_segment(in);
+                start_chunk();
+            }
+            for (int i = 0; i < OUT; i++) { out[i] = value[i]; value[i] += value_d[i]; }
+            remaining--;
+            blk_i++;
+            if (remaining == 0) t += (float)(long long)loop_len * sd;
+        }
+    }
+    FD_STEP2_VIA_STEP
+};
+
 template <class FN>
 struct Envelope {
     static constexpr int IN = 0, OUT = FN::OUT, RINGS = 0;

@@ -161,6 +161,13 @@ def envelope(functor, source, outputs=1, **params):
     its type name, `source` its definition (contract: Envelope<FN> in fd_nodes.hpp), `params` its per-voice fields."""
     return Graph(f"Envelope<{functor}>", 0, outputs, [((0,), k, v, False) for k, v in params.items()], 0, source)
 lfo = envelope
+def lfo2_exp():  # lfo2(|t, speed| exp(-t * speed))   prelude32.rs:623
+    return Graph("EnvelopeIn<EnvInExp>", 1, 1)
+def envelope_in(functor, source, inputs, outputs=1, **params):
+    """envelope2 / lfo2 / envelope_in / lfo_in (prelude32.rs:625-745): closure(t, inputs) as a C++ functor
+    (contract: EnvelopeIn<FN> in fd_nodes.hpp)."""
+    return Graph(f"EnvelopeIn<{functor}>", inputs, outputs, [((0,), k, v, False) for k, v in params.items()], 0, source)
+lfo_in = envelope_in
 def pluck(frequency, gain_per_second, damping):  # excitation: Bank.set_ring(0, rnd_stream)
     return _leaf("Pluck", 1, 1, rings=2, frequency=frequency, gain_per_second=gain_per_second, high_frequency_damping=damping)
 def dsf_saw(): return _leaf("Dsf<2>", 2, 1, harmonic_spacing=1.0, roughness=0.5)

@@ -120,6 +120,7 @@ struct onode {
         double pl_sr;
         /* Envelope<f32, E, R> (envelope.rs:17-49): the closure is a C callback; time fields et/et0/et1/einterval/esd/et_hash shared with EnvelopeIn */
         o_env_fn env_fn;
+        o_envin_fn envin_fn;
         void *env_ctx;
         float env_v0[O_MAX_ENV], env_v1[O_MAX_ENV], env_val[O_MAX_ENV], env_d[O_MAX_ENV];
         /* Dsf (oscillator.rs:121-129) */
@@ -519,6 +520,10 @@ static void leaf_reset(onode *n) {
         for (int i = 0; i < n->nout; i++) n->s.env_v1[i] = n->s.env_v0[i];
         break;
     }
+    case O_ENVELOPE_IN: /* envelope.rs:293-298 */
+        n->s.et = 0.0f; n->s.et0 = 0.0f; n->s.et1 = 0.0f;
+        n->s.et_hash = n->s.hash;
+        break;
     case O_ADSR_LIVE: /* envelope.rs:293-298: the closure state (attacked, start times) is NOT reset */
         n->s.et = 0.0f;
         n->s.et0 = 0.0f;
@@ -582,6 +587,7 @@ static void leaf_set_sample_rate(onode *n, double sr) {
         n->s.sample_duration = 1.0f / (float)sr;
         break;
     case O_ENVELOPE:  /* envelope.rs:124-126 */
+    case O_ENVELOPE_IN:
     case O_ADSR_LIVE: /* envelope.rs:300-302 */
         n->s.esd = (float)(1.0 / sr);
         break;
@@ -682,7 +688,7 @@ static void leaf_set_hash(onode *n, uint64_t hash) {
     } else if (n->type == O_PLUCK) { /* oscillator.rs:307-310 */
         n->s.hash = hash;
         n->s.pl_init = 0;
-    } else if (n->type == O_ADSR_LIVE || n->type == O_ENVELOPE) { /* envelope.rs:346-349, 165-168: no reset */
+    } else if (n->type == O_ADSR_LIVE || n->type == O_ENVELOPE || n->type == O_ENVELOPE_IN) { /* envelope.rs:346-349, 165-168: no reset */
         n->s.hash = hash;
         n->s.et_hash = hash;
     }
@@ -1441,6 +1447,34 @@ onode *o_envelope(float interval, int outputs, o_env_fn fn, void *ctx) { /* Enve
     leaf_reset(n);
     return n;
 }
+static void envin_next_segment(onode *n, const float *input) { /* EnvelopeIn::next_segment envelope.rs:244-278 */
+    if (n->s.et0 == 0.0f && n->s.et1 == 0.0f) {
+        n->s.envin_fn(n->s.et0, input, n->s.env_v0, n->s.env_ctx);
+    } else {
+        n->s.et0 = n->s.et1;
+        for (int i = 0; i < n->nout; i++) n->s.env_v0[i] = n->s.env_v1[i];
+    }
+    float next_interval = lerpf(0.75f, 1.25f, (float)o_rnd1(n->s.et_hash)) * n->s.einterval;
+    n->s.et1 = n->s.et0 + next_interval;
+    n->s.envin_fn(n->s.et1, input, n->s.env_v1, n->s.env_ctx);
+    n->s.et_hash = n->s.et_hash * 6364136223846793005ULL + 1ULL;
+    float u = (n->s.et - n->s.et0) / (n->s.et1 - n->s.et0);
+    float samples = next_interval / n->s.esd;
+    for (int i = 0; i < n->nout; i++) {
+        n->s.env_val[i] = lerpf(n->s.env_v0[i], n->s.env_v1[i], u);
+        n->s.env_d[i] = (n->s.env_v1[i] - n->s.env_v0[i]) / samples;
+    }
+}
+onode *o_envelope_in(float interval, int inputs, int outputs, o_envin_fn fn, void *ctx) { /* EnvelopeIn::new :221-241 (ID 53) */
+    if (outputs < 1 || outputs > O_MAX_ENV || inputs < 0 || inputs > O_MAX_CH) return NULL;
+    onode *n = o_new(O_ENVELOPE_IN, inputs, outputs, 53);
+    n->s.envin_fn = fn;
+    n->s.env_ctx = ctx;
+    n->s.einterval = interval;
+    leaf_set_sample_rate(n, DEFAULT_SR);
+    leaf_reset(n);
+    return n;
+}
 static void env_next_segment(onode *n, float input) {
     if (n->s.et0 == 0.0f && n->s.et1 == 0.0f) {
         n->s.ev0 = adsr_closure(n, n->s.et0, input);
@@ -1539,6 +1573,14 @@ void o_tick(onode *n, const float *in, float *out) {
         if (n->nout > 1) out[1] = n->s.phase;
         break;
     }
+    case O_ENVELOPE_IN: /* envelope.rs:305-313 */
+        if (n->s.et >= n->s.et1) envin_next_segment(n, in);
+        for (int i = 0; i < n->nout; i++) {
+            out[i] = n->s.env_val[i];
+            n->s.env_val[i] += n->s.env_d[i];
+        }
+        n->s.et += n->s.esd;
+        break;
     case O_ENVELOPE: /* envelope.rs:128-136 */
         if (n->s.et >= n->s.et1) envelope_next_segment(n);
         for (int i = 0; i < n->nout; i++) {
@@ -1981,6 +2023,33 @@ void o_process(onode *n, int size, const float *in, float *out) {
         for (int i = 0; i < full_simd_items(size) * 8; i++) out[i] = shape_simd_lane(n, 0, in[i]);
         process_remainder(n, size, in, out);
         break;
+    case O_ENVELOPE_IN: { /* envelope.rs:315-340 */
+        if (size == 0) break;
+        float fr[O_MAX_CH];
+        for (int c = 0; c < n->nin; c++) fr[c] = in[c * MAXB];
+        if (n->s.et >= n->s.et1) envin_next_segment(n, fr);
+        int i = 0;
+        while (i < size) {
+            int64_t left = (int64_t)ceilf((n->s.et1 - n->s.et) / n->s.esd);
+            size_t segment_samples_left = (size_t)left;
+            size_t loop_samples = (size_t)(size - i) < segment_samples_left ? (size_t)(size - i) : segment_samples_left;
+            for (int c = 0; c < n->nout; c++) {
+                float value = n->s.env_val[c], delta = n->s.env_d[c];
+                for (size_t k = 0; k < loop_samples; k++) {
+                    out[c * MAXB + i + (int)k] = value;
+                    value += delta;
+                }
+                n->s.env_val[c] = value;
+            }
+            i += (int)loop_samples;
+            n->s.et += (float)(int64_t)loop_samples * n->s.esd;
+            if (loop_samples == segment_samples_left && i < size) {
+                for (int c = 0; c < n->nin; c++) fr[c] = in[c * MAXB + i];
+                envin_next_segment(n, fr);
+            }
+        }
+        break;
+    }
     case O_ENVELOPE: { /* envelope.rs:138-163 */
         if (n->s.et >= n->s.et1) envelope_next_segment(n);
         int i = 0;

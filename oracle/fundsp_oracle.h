@@ -18,7 +18,7 @@ enum {
     O_CONSTANT = 0, O_PASS, O_SINE, O_NOISE, O_SVF, O_FIXED_SVF, O_BIQUAD, O_BUTTER_LOWPASS, O_RESONATOR,
     O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP,
     O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO, O_SHAPER, O_PHASE_OSC, O_CHAOS, O_NLBIQUAD, O_TAP, O_ALLNEST,
-    O_ONEPOLE, O_PINKPASS, O_MORPH, O_REZ, O_FOLLOW, O_AFOLLOW, O_MLS, O_OVERSAMPLE, O_DSF, O_PLUCK, O_ENVELOPE, O_RESAMPLE
+    O_ONEPOLE, O_PINKPASS, O_MORPH, O_REZ, O_FOLLOW, O_AFOLLOW, O_MLS, O_OVERSAMPLE, O_DSF, O_PLUCK, O_ENVELOPE, O_RESAMPLE, O_ENVELOPE_IN
 };
 enum { O_OP_LOWPOLE = 0, O_OP_HIGHPOLE, O_OP_DCBLOCK, O_OP_ALLPOLE };
 enum { O_SH_CLIP = 0, O_SH_CLIPTO, O_SH_TANH, O_SH_ATAN, O_SH_SOFTSIGN, O_SH_CRUSH, O_SH_SOFTCRUSH, O_SH_ADAPTIVE_TANH };
@@ -64,6 +64,9 @@ onode *o_pinkpass(void);
 /* Envelope<f32, E, R> (envelope.rs:17): `fn` plays the Rust closure E(t) -> R, writing `outputs` (<= 8) values */
 typedef void (*o_env_fn)(float t, float *out, void *ctx);
 onode *o_envelope(float interval, int outputs, o_env_fn fn, void *ctx);
+/* EnvelopeIn<f32, E, I, R> (envelope.rs:185) with a stateless closure E(t, &inputs) -> R */
+typedef void (*o_envin_fn)(float t, const float *in, float *out, void *ctx);
+onode *o_envelope_in(float interval, int inputs, int outputs, o_envin_fn fn, void *ctx);
 /* Pluck (oscillator.rs:215); excitation = the funutd Rnd stream the reference draws in initialize_line, given by the caller */
 onode *o_pluck(float frequency, float gain_per_second, float high_frequency_damping, const float *excitation, size_t n_exc);
 onode *o_dsf(int inputs, float harmonic_spacing, float roughness); /* Dsf<U1/U2> (oscillator.rs:121) */

@@ -74,7 +74,7 @@ def lib():
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
         "o_onepole": (P, [i, i, f]), "o_pinkpass": (P, []), "o_morph": (P, [f, f, f]),
         "o_rez": (P, [i, f, f, f]), "o_follow": (P, [f]), "o_afollow": (P, [f, f]), "o_mls": (P, [C.c_uint]),
-        "o_mls_set_seed": (None, [P, C.c_uint64]), "o_oversample": (P, [P]), "o_resample": (P, [P]), "o_dsf": (P, [i, f, f]), "o_envelope": (P, [f, i, P, P]), "o_pluck": (P, [f, f, f, fp, C.c_size_t]),
+        "o_mls_set_seed": (None, [P, C.c_uint64]), "o_oversample": (P, [P]), "o_resample": (P, [P]), "o_dsf": (P, [i, f, f]), "o_envelope": (P, [f, i, P, P]), "o_envelope_in": (P, [f, i, i, P, P]), "o_pluck": (P, [f, f, f, fp, C.c_size_t]),
         "o_math_powf": (f, [f, f]),
         "o_seq_new": (P, [i, i, d]), "o_seq_free": (None, [P]), "o_seq_push": (i, [P, d, d, i, d, d, P]),
         "o_seq_render": (None, [P, C.c_size_t, i, fp, fp, fp]), "o_seq_time": (d, [P]), "o_mls_period": (C.c_uint64, [C.c_uint]),
@@ -338,6 +338,24 @@ def envelope(fn, outputs=1, interval=0.002):                                  # 
 
 
 lfo = envelope
+ENVIN_FN = C.CFUNCTYPE(None, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
+
+
+def envelope_in(fn, inputs, outputs=1, interval=0.002):                       # prelude32.rs:716 envelope_in / :732 lfo_in
+    """fn(t, [inputs...]) -> float or sequence; envelope2 / lfo2 are the 1-input case (prelude32.rs:625-661)."""
+    def cb(t, inp, out, _ctx):
+        r = fn(np.float32(t), [np.float32(inp[k]) for k in range(inputs)])
+        r = [r] if np.isscalar(r) else list(r)
+        for k in range(outputs):
+            out[k] = float(np.float32(r[k]))
+    c = ENVIN_FN(cb)
+    n = Node(lib().o_envelope_in(np.float32(interval), inputs, outputs, C.cast(c, C.c_void_p), None))
+    n._callback = c
+    return n
+
+
+lfo_in = envelope_in
+def lfo2(fn): return envelope_in(lambda t, i: fn(t, i[0]), 1)
 def m_expf(x): return np.float32(lib().o_math_expf(float(x)))
 def m_sinf(x): return np.float32(lib().o_math_sinf(float(x)))
 def m_cosf(x): return np.float32(lib().o_math_cosf(float(x)))

@@ -302,3 +302,22 @@ def test_resample_fm(gpu, mode):
         n.set_sample_rate(SR)
         n.set_seed(int(seeds[v]))
         assert_bit_equal(got[v], oracle_render(n, xx[v], 2 * T, mode), f"resample_fm voice {v}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_lfo2_envelope_in(gpu, mode):
+    """lfo2(|t, speed| exp(-t * speed)) (prelude32.rs:623): EnvelopeIn with a stateless closure of (t, input)."""
+    V, T = 70, 64 * 12 + 31
+    rng = np.random.default_rng(89)
+    x = np.repeat((1.0 + 30.0 * rng.random((V, 1, T // 50 + 1))).astype(np.float32), 50, axis=2)[:, :, :T].copy()
+    b = gpu.Bank("lfo2_exp", V)
+    b.set_sample_rate(SR)
+    seeds = np.arange(V, dtype=np.uint64) * 3 + 2
+    b.set_seed(seeds)
+    got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, mode)
+    gotp = None
+    for v in (0, 17, 64, 69):
+        n = O.lfo2(lambda t, s: O.m_expf(-t * s))
+        n.set_sample_rate(SR)
+        n.set_seed(int(seeds[v]))
+        assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"lfo2_exp voice {v}")
