@@ -437,6 +437,8 @@ FD_HD v2f wide_sin2(v2f self, float& tmax) {
     v2f x4 = x2 * x2;
     v2f s = (x4 * P2sinf + (x2 * P1sinf + P0sinf)) * (x * x2) + x;
     v2f c = (x4 * P2cosf + (x2 * P1cosf + P0cosf)) * x4 + __builtin_elementwise_fma(x2, splat2(-0.5f), splat2(1.0f));
+    // (forcing v_bfe_i32 + v_bfi_b32 through inline asm instead of the and + cmp + cndmask the optimiser prefers saved
+    // nothing: the asm also stopped the 4-pair unrolling of the caller's loop)
     uint32_t m0 = (uint32_t)((int32_t)(b0 << 31) >> 31), m1 = (uint32_t)((int32_t)(b1 << 31) >> 31);  // odd quadrant
     uint32_t r0 = (f2u(c.x) & m0) | (f2u(s.x) & ~m0);
     uint32_t r1 = (f2u(c.y) & m1) | (f2u(s.y) & ~m1);
