@@ -574,8 +574,18 @@ template <class X, class Y> struct Cost<Stack<X, Y>> { static constexpr int v = 
 template <class O, class X, class Y> struct Cost<Binop<O, X, Y>> { static constexpr int v = Cost<X>::v + Cost<Y>::v + 1; };
 template <class X, class U> struct Cost<Unop<X, U>> { static constexpr int v = Cost<X>::v + 1; };
 
-template <class G> struct Chain { static constexpr int N = 1; };  // stages of a (nested) Pipe chain; cut points = N - 1
-template <class X, class Y> struct Chain<Pipe<X, Y>> { static constexpr int N = Chain<X>::N + Chain<Y>::N; };
+// Chain<G, HEAD>: the stages a graph can be cut into.  A Pipe chains its two sides.  A Binop whose left operand is a
+// GENERATOR chain (no inputs) and which sits at the head of the graph -- so that its right operand reads the graph's own
+// inputs -- counts the left operand's stages plus one TAIL stage (right operand + the operator):
+//   ((dc(f) >> saw() | dc(fc) | dc(q)) >> moog()) * adsr_live(..) >> pan(p)  =  [saw stack] [moog] [* adsr] [pan]
+template <class G, bool HEAD = true> struct Chain { static constexpr int N = 1; };
+template <class X, class Y, bool HEAD> struct Chain<Pipe<X, Y>, HEAD> {
+    static constexpr int N = Chain<X, HEAD>::N + Chain<Y, false>::N;
+};
+template <class O, class X, class Y> struct Chain<Binop<O, X, Y>, true> {
+    static constexpr bool SPLIT = X::IN == 0 && X::OUT == Y::OUT;
+    static constexpr int N = SPLIT ? Chain<X, true>::N + 1 : 1;
+};
 
 struct VGate {  // forwards to a slot visitor only while enabled; always advances the slot counter
     template <class V> struct W {
@@ -590,38 +600,44 @@ struct VGate {  // forwards to a slot visitor only while enabled; always advance
     };
 };
 
-// Seg<G, A, B>: the chain stages [A, B) of G, run on G's own state object.  The primary template is a whole node.
-template <class G, int A, int B>
+// Seg<G, A, B, HEAD>: the chain stages [A, B) of G, run on G's own state object.
+//   in  = what the segment's first stage consumes: the node's own inputs when A == 0, else the hand-over channels;
+//   gin = the node's own inputs (the graph's inputs for head-position nodes), valid in EVERY stage: a Binop tail reads
+//         its right operand's inputs there.
+// The primary template is a whole node.
+template <class G, int A, int B, bool HEAD = true>
 struct Seg {
-    static_assert(A == 0 && B == 1, "a node that is not a Pipe is one chain stage");
+    static_assert(A == 0 && B == 1, "a node that is not a chain is one stage");
     static constexpr int IN = G::IN, OUT = G::OUT, cost = Cost<G>::v;
-    template <int PH> static FD_D void step2(G& g, const v2f* in, v2f* out) { g.template step2<PH>(in, out); }
-    template <int PH> static FD_D void step(G& g, const float* in, float* out) { g.template step<PH>(in, out); }
+    static constexpr bool USES_GIN = false;
+    template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f*, v2f* out) { g.template step2<PH>(in, out); }
+    template <int PH> static FD_D void step(G& g, const float* in, const float*, float* out) { g.template step<PH>(in, out); }
     static FD_D void begin(G& g, int n) { g.begin_block(n); }
     static FD_D void end(G& g) { g.end_simd(); }
     static FD_D bool tripped(const G& g) { return g.tripped(); }
     // visit ALL slots of g in G::visit order (slot numbering unchanged); only this segment's slots are enabled
     template <class W> static FD_D void visit(G& g, W& w) { w.on = true; g.visit(w); }
 };
-template <class X, class Y, int A, int B>
-struct Seg<Pipe<X, Y>, A, B> {
+template <class X, class Y, int A, int B, bool HEAD>
+struct Seg<Pipe<X, Y>, A, B, HEAD> {
     using G = Pipe<X, Y>;
-    static constexpr int NX = Chain<X>::N, NY = Chain<Y>::N;
+    static constexpr int NX = Chain<X, HEAD>::N, NY = Chain<Y, false>::N;
     static_assert(0 <= A && A < B && B <= NX + NY, "empty or out-of-range chain segment");
     static constexpr bool HX = A < NX, HY = B > NX;  // the segment has stages inside x / inside y
-    using SX = Seg<X, HX ? A : 0, HX ? (B < NX ? B : NX) : NX>;
-    using SY = Seg<Y, HY ? (A > NX ? A - NX : 0) : 0, HY ? B - NX : NY>;
+    using SX = Seg<X, HX ? A : 0, HX ? (B < NX ? B : NX) : NX, HEAD>;
+    using SY = Seg<Y, HY ? (A > NX ? A - NX : 0) : 0, HY ? B - NX : NY, false>;
     static constexpr int IN = HX ? SX::IN : SY::IN, OUT = HY ? SY::OUT : SX::OUT;
     static constexpr int cost = (HX ? SX::cost : 0) + (HY ? SY::cost : 0);
-    template <int PH> static FD_D void step2(G& g, const v2f* in, v2f* out) {
-        if constexpr (HX && HY) { v2f t[SX::OUT > 0 ? SX::OUT : 1]; SX::template step2<PH>(g.x, in, t); SY::template step2<PH>(g.y, t, out); }
-        else if constexpr (HX) SX::template step2<PH>(g.x, in, out);
-        else SY::template step2<PH>(g.y, in, out);
+    static constexpr bool USES_GIN = HX && SX::USES_GIN;
+    template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f* gin, v2f* out) {
+        if constexpr (HX && HY) { v2f t[SX::OUT > 0 ? SX::OUT : 1]; SX::template step2<PH>(g.x, in, gin, t); SY::template step2<PH>(g.y, t, nullptr, out); }
+        else if constexpr (HX) SX::template step2<PH>(g.x, in, gin, out);
+        else SY::template step2<PH>(g.y, in, nullptr, out);
     }
-    template <int PH> static FD_D void step(G& g, const float* in, float* out) {
-        if constexpr (HX && HY) { float t[SX::OUT > 0 ? SX::OUT : 1]; SX::template step<PH>(g.x, in, t); SY::template step<PH>(g.y, t, out); }
-        else if constexpr (HX) SX::template step<PH>(g.x, in, out);
-        else SY::template step<PH>(g.y, in, out);
+    template <int PH> static FD_D void step(G& g, const float* in, const float* gin, float* out) {
+        if constexpr (HX && HY) { float t[SX::OUT > 0 ? SX::OUT : 1]; SX::template step<PH>(g.x, in, gin, t); SY::template step<PH>(g.y, t, nullptr, out); }
+        else if constexpr (HX) SX::template step<PH>(g.x, in, gin, out);
+        else SY::template step<PH>(g.y, in, nullptr, out);
     }
     static FD_D void begin(G& g, int n) {
         if constexpr (HX) SX::begin(g.x, n);
@@ -642,26 +658,117 @@ struct Seg<Pipe<X, Y>, A, B> {
         if constexpr (HY) SY::visit(g.y, w); else { w.on = false; g.y.visit(w); }
     }
 };
-
-// Tile geometry.  A tile is SUB frames of 64 voices.  The workgroup serves 4 voice groups with double-buffered tiles:
-// NI input-feed channels (see the loader wave below) plus S - 1 hand-over channels, 2 KiB * SUB each, within 128 KiB.
-template <int NI, int S>
-struct PipeGeom {
-    static constexpr int CH = NI + S - 1;
-    static constexpr int SUB = CH <= 1 ? 64 : CH == 2 ? 32 : CH <= 4 ? 16 : CH <= 8 ? 8 : 0;  // 0 = does not fit
-    static constexpr int WAVES = 4 * (S + (NI > 0 ? 1 : 0));
-    static constexpr bool ok = SUB >= 8 && WAVES <= 16 && CH >= 1;
+// Binop at the head of the graph with a generator chain on the left: stages 0 .. NX-1 are X's, stage NX is the tail
+// (y and the operator).  Same arithmetic as Binop::step2 (x, then y, then O::f), whichever waves run the parts.
+template <class O, class X, class Y, int A, int B>
+struct Seg<Binop<O, X, Y>, A, B, true> {
+    using G = Binop<O, X, Y>;
+    static constexpr bool SPLIT = Chain<G, true>::SPLIT;
+    static constexpr int NX = SPLIT ? Chain<X, true>::N : 0;
+    static_assert(SPLIT ? (0 <= A && A < B && B <= NX + 1) : (A == 0 && B == 1), "empty or out-of-range chain segment");
+    static constexpr bool HX = SPLIT ? A < NX : true;     // has stages of x
+    static constexpr bool TAIL = SPLIT ? B == NX + 1 : true;  // has y and the operator
+    using SX = Seg<X, (SPLIT && HX) ? A : 0, SPLIT ? (HX ? (B < NX ? B : NX) : NX) : Chain<X, true>::N, true>;
+    static constexpr int IN = SPLIT ? (A == 0 ? G::IN : Seg<X, 0, (A > 0 ? A : 1), true>::OUT) : G::IN;
+    static constexpr int OUT = TAIL ? G::OUT : SX::OUT;
+    static constexpr int cost = (HX ? SX::cost : 0) + (TAIL ? Cost<Y>::v + 1 : 0);
+    static constexpr bool USES_GIN = SPLIT && TAIL && Y::IN > 0;
+    template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f* gin, v2f* out) {
+        if constexpr (!SPLIT) {
+            g.template step2<PH>(in, out);
+        } else if constexpr (!TAIL) {
+            SX::template step2<PH>(g.x, in, gin, out);
+        } else {
+            v2f tx[X::OUT], ty[Y::OUT];
+            if constexpr (HX) SX::template step2<PH>(g.x, in, gin, tx);
+            else { _Pragma("unroll") for (int c = 0; c < X::OUT; c++) tx[c] = in[c]; }
+            g.y.template step2<PH>(gin, ty);  // X::IN == 0: the binop's inputs are y's inputs
+#pragma unroll
+            for (int c = 0; c < Y::OUT; c++) out[c] = O::f(tx[c], ty[c]);
+        }
+    }
+    template <int PH> static FD_D void step(G& g, const float* in, const float* gin, float* out) {
+        if constexpr (!SPLIT) {
+            g.template step<PH>(in, out);
+        } else if constexpr (!TAIL) {
+            SX::template step<PH>(g.x, in, gin, out);
+        } else {
+            float tx[X::OUT], ty[Y::OUT];
+            if constexpr (HX) SX::template step<PH>(g.x, in, gin, tx);
+            else { _Pragma("unroll") for (int c = 0; c < X::OUT; c++) tx[c] = in[c]; }
+            g.y.template step<PH>(gin, ty);
+#pragma unroll
+            for (int c = 0; c < Y::OUT; c++) out[c] = O::f(tx[c], ty[c]);
+        }
+    }
+    static FD_D void begin(G& g, int n) {
+        if constexpr (HX) SX::begin(g.x, n);
+        if constexpr (TAIL) g.y.begin_block(n);
+    }
+    static FD_D void end(G& g) {
+        if constexpr (HX) SX::end(g.x);
+        if constexpr (TAIL) g.y.end_simd();
+    }
+    static FD_D bool tripped(const G& g) {
+        bool t = false;
+        if constexpr (HX) t = t || SX::tripped(g.x);
+        if constexpr (TAIL) t = t || g.y.tripped();
+        return t;
+    }
+    template <class W> static FD_D void visit(G& g, W& w) {  // Binop::visit order: x, then y
+        if constexpr (HX) SX::visit(g.x, w); else { w.on = false; g.x.visit(w); }
+        w.on = TAIL;
+        g.y.visit(w);
+    }
 };
 
-// Where to cut: S stages (2 or 3) with cut points K1 < K2 chosen to minimise the most expensive stage.  Every cut must
-// hand over exactly one channel (the LDS tiles are sized for it) and every stage must carry real work.
+// Waves of the pipeline kernel's workgroup: 4 voice groups x (loader + S compute stages)
+template <int NI, int S>
+struct PipeGeom {
+    static constexpr int WAVES = 4 * (S + (NI > 0 ? 1 : 0));
+    static constexpr bool ok = WAVES <= 16 && (NI > 0 || S >= 2);
+};
+
+// Tile geometry of a plan.  A tile is SUB frames of 64 voices.  LDS holds, for 4 voice groups: the feed ring (NI input
+// channels x D tiles; D = 2, or S + 1 when a later stage reads the graph's inputs -- a Binop tail -- so that the loader's
+// tile survives until that stage has used it) and the double-buffered hand-over tiles of the S - 1 cuts (W channels each,
+// W = the widest cut).  One channel-tile of the 4 groups is 1 KiB * SUB; the budget is 128 KiB.
+template <class G, int S, int K1, int K2>
+struct PipeTiles {
+    static constexpr int N = Chain<G>::N, NI = G::IN;
+    using S0 = Seg<G, 0, S == 1 ? N : K1>;
+    using S1 = Seg<G, S == 1 ? 0 : K1, S <= 2 ? N : K2>;   // unused when S == 1
+    using S2 = Seg<G, S <= 2 ? 0 : K2, N>;                 // unused when S <= 2
+    static constexpr int W1 = S >= 2 ? S0::OUT : 0, W2 = S >= 3 ? S1::OUT : 0;
+    static constexpr int W = W1 > W2 ? W1 : W2;                                   // hand-over channels per cut (widest)
+    static constexpr bool LATE_GIN = (S >= 2 && S1::USES_GIN) || (S >= 3 && S2::USES_GIN);
+    static constexpr int D = NI > 0 ? (LATE_GIN ? S + 1 : 2) : 0;                 // feed ring depth
+    static constexpr int UNITS = NI * D + 2 * W * (S - 1);                        // channel-tiles
+    static constexpr int SUB = UNITS <= 2 ? 64 : UNITS <= 4 ? 32 : UNITS <= 8 ? 16 : UNITS <= 16 ? 8 : 0;  // 0 = does not fit
+    static constexpr bool ok = SUB >= 8 && PipeGeom<NI, S>::ok;
+};
+
+// Where to cut: S stages (2 or 3) with cut points K1 < K2 chosen to minimise the most expensive stage; every stage must
+// carry real work and the tiles must fit.
 struct PipePlan { int S, K1, K2; };
 template <class G, int I = 0>
-constexpr void pipe_plan_fill(int* cost, int* width) {
+constexpr void pipe_plan_fill(int* cost) {
     if constexpr (I < Chain<G>::N) {
         cost[I] = Seg<G, I, I + 1>::cost;
-        width[I] = Seg<G, I, I + 1>::OUT;  // channels crossing the cut after stage I
-        pipe_plan_fill<G, I + 1>(cost, width);
+        pipe_plan_fill<G, I + 1>(cost);
+    }
+}
+template <class G, int K1 = 1, int K2 = 2>
+constexpr void pipe_plan_fits(bool (*fit2)[32], bool (*fit3)[32][32]) {  // which cut sets have tiles that fit
+    constexpr int N = Chain<G>::N;
+    if constexpr (K1 < N) {
+        if constexpr (K2 == K1 + 1) (*fit2)[K1] = PipeTiles<G, 2, K1, N>::ok;
+        if constexpr (K2 < N) {
+            (*fit3)[K1][K2] = PipeTiles<G, 3, K1, K2>::ok;
+            pipe_plan_fits<G, K1, K2 + 1>(fit2, fit3);
+        } else {
+            pipe_plan_fits<G, K1 + 1, K1 + 2>(fit2, fit3);
+        }
     }
 }
 template <class G>
@@ -669,24 +776,31 @@ constexpr PipePlan pipe_plan(int want) {  // want: 0 = best plan, 1 / 2 / 3 = at
     constexpr int N = Chain<G>::N;
     static_assert(N <= 32, "chain too long");
     // a graph with inputs always gets the loader wave (S = 1 if it cannot or need not be cut)
-    const PipePlan fallback = G::IN > 0 && PipeGeom<G::IN, 1>::ok ? PipePlan{1, N, N} : PipePlan{0, 0, 0};
+    const PipePlan fallback = G::IN > 0 && PipeTiles<G, 1, N, N>::ok ? PipePlan{1, N, N} : PipePlan{0, 0, 0};
     if (N < 2 || G::RINGS != 0 || want == 1) return fallback;
-    int cost[32] = {0}, width[32] = {0};
-    pipe_plan_fill<G>(cost, width);
+    int cost[32] = {0};
+    bool fit2[32] = {false}, fit3[32][32] = {{false}};
+    pipe_plan_fill<G>(cost);
+    pipe_plan_fits<G>(&fit2, &fit3);
     auto sum = [&](int a, int b) { int t = 0; for (int i = a; i < b; i++) t += cost[i]; return t; };
     constexpr int MIN_STAGE = 8;
     PipePlan best = fallback;
     int best_worst = 1 << 30;
-    if (want != 3 && PipeGeom<G::IN, 2>::ok)
+    if (want != 3)
         for (int k = 1; k < N; k++) {
             int p = sum(0, k), q = sum(k, N), w = p > q ? p : q;
-            if (width[k - 1] == 1 && p >= MIN_STAGE && q >= MIN_STAGE && w < best_worst) { best = PipePlan{2, k, N}; best_worst = w; }
+            if (fit2[k] && p >= MIN_STAGE && q >= MIN_STAGE && w < best_worst) { best = PipePlan{2, k, N}; best_worst = w; }
         }
-    if (want == 3 && PipeGeom<G::IN, 3>::ok)  // three stages only on request: measured slower than two on config 3
+    // three stages: on request, or for heavy graphs (>= 150 instructions per sample) when they cut the heaviest stage
+    // by a third or more.  (On config 3 -- 59 instructions, two stages leave 36 -- the third wave's hand-over traffic and
+    // barriers cost more than it hides: 5.8 vs 5.4 ms.)
+    const int two_worst = best_worst, total = sum(0, N);
+    if (want != 2)
         for (int k1 = 1; k1 < N; k1++)
             for (int k2 = k1 + 1; k2 < N; k2++) {
                 int p = sum(0, k1), q = sum(k1, k2), r = sum(k2, N), w = p > q ? (p > r ? p : r) : (q > r ? q : r);
-                if (width[k1 - 1] == 1 && width[k2 - 1] == 1 && p >= MIN_STAGE && q >= MIN_STAGE && r >= MIN_STAGE && w < best_worst) {
+                const bool worth = want == 3 || (total >= 150 && (two_worst == (1 << 30) || 3 * w <= 2 * two_worst));
+                if (fit3[k1][k2] && worth && p >= MIN_STAGE && q >= MIN_STAGE && r >= MIN_STAGE && w < best_worst) {
                     best = PipePlan{3, k1, k2};
                     best_worst = w;
                 }
@@ -696,13 +810,16 @@ constexpr PipePlan pipe_plan(int want) {  // want: 0 = best plan, 1 / 2 / 3 = at
 
 // One stage's work on one tile: frames [lo, hi) of the block that starts at t0 (size / full as in
 // AudioNode::process: `full` frames of packed SIMD items, end_simd, then the remainder path).
-// Inputs of the FIRST stage come from the feed tile `fin` (written by the loader wave), never from HBM directly.
-template <class SG, class G, int MODE, int SUB, bool FIRST, bool LAST>
-FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_t V, int lane, const float* inw, float* outw,
-                     const float (*fin)[SUB][64], v2f (*hin)[64], v2f (*hout)[64]) {
-    constexpr int NI = SG::IN, NO = SG::OUT;
-    static_assert(FIRST || NI == 1, "one hand-over channel");
-    static_assert(LAST || NO == 1, "one hand-over channel");
+// Graph inputs come from the feed tile `fin` (written by the loader wave), never from HBM directly: the FIRST stage
+// consumes them as its inputs, a later stage that holds a Binop tail reads them as `gin`.
+// Hand-over tiles: [channel][frame pair][lane] (v2f).
+template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST>
+FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_t V, int lane, float* outw,
+                     const float (*fin)[SUB][64], v2f (*hin)[SUB / 2][64], v2f (*hout)[SUB / 2][64]) {
+    constexpr int NI = SG::IN, NO = SG::OUT, NG = G::IN;
+    constexpr bool GIN = !FIRST && SG::USES_GIN;
+    static_assert(LAST || NO <= W, "hand-over tile too narrow");
+    static_assert(FIRST || NI <= W, "hand-over tile too narrow");
     const int lo = h * SUB;
     const int hi = lo + SUB < size ? lo + SUB : size;
     const int shi = hi < full ? hi : full;  // end of the packed part inside this tile
@@ -713,14 +830,19 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
 #pragma unroll 4
         for (int i = lo; i < shi; i += 2) {  // two frames per iteration (lo, shi are multiples of 8)
             const size_t t = t0 + i;
-            v2f pi[NI > 0 ? NI : 1], po[NO];
+            v2f pi[NI > 0 ? NI : 1], gi[NG > 0 ? NG : 1], po[NO];
             if constexpr (FIRST) {
 #pragma unroll
                 for (int c = 0; c < NI; c++) pi[c] = v2f{fin[c][i - lo][lane], fin[c][i - lo + 1][lane]};
             } else {
-                pi[0] = hin[(i - lo) >> 1][lane];
+#pragma unroll
+                for (int c = 0; c < NI; c++) pi[c] = hin[c][(i - lo) >> 1][lane];
             }
-            SG::template step2<PH_SIMD>(g, pi, po);
+            if constexpr (GIN) {
+#pragma unroll
+                for (int c = 0; c < NG; c++) gi[c] = v2f{fin[c][i - lo][lane], fin[c][i - lo + 1][lane]};
+            }
+            SG::template step2<PH_SIMD>(g, pi, FIRST ? pi : gi, po);
             if constexpr (LAST) {
 #pragma unroll
                 for (int c = 0; c < NO; c++) {
@@ -728,25 +850,32 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
                     outw[((size_t)c * T + t + 1) * V + lane] = po[c].y;
                 }
             } else {
-                hout[(i - lo) >> 1][lane] = po[0];
+#pragma unroll
+                for (int c = 0; c < NO; c++) hout[c][(i - lo) >> 1][lane] = po[c];
             }
         }
         if (__builtin_expect(SG::tripped(g), 0)) {  // a packed-path shortcut left its exact domain: redo the tile
             g = snap;
             for (int i = lo; i < shi; i++) {
-                float fi[NI > 0 ? NI : 1], fo[NO];
+                float fi[NI > 0 ? NI : 1], gf[NG > 0 ? NG : 1], fo[NO];
                 if constexpr (FIRST) {
 #pragma unroll
                     for (int c = 0; c < NI; c++) fi[c] = fin[c][i - lo][lane];
                 } else {
-                    fi[0] = reinterpret_cast<const float*>(&hin[(i - lo) >> 1][lane])[i & 1];
+#pragma unroll
+                    for (int c = 0; c < NI; c++) fi[c] = reinterpret_cast<const float*>(&hin[c][(i - lo) >> 1][lane])[i & 1];
                 }
-                SG::template step<PH_SIMD>(g, fi, fo);
+                if constexpr (GIN) {
+#pragma unroll
+                    for (int c = 0; c < NG; c++) gf[c] = fin[c][i - lo][lane];
+                }
+                SG::template step<PH_SIMD>(g, fi, FIRST ? fi : gf, fo);
                 if constexpr (LAST) {
 #pragma unroll
                     for (int c = 0; c < NO; c++) outw[((size_t)c * T + t0 + i) * V + lane] = fo[c];
                 } else {
-                    reinterpret_cast<float*>(&hout[(i - lo) >> 1][lane])[i & 1] = fo[0];
+#pragma unroll
+                    for (int c = 0; c < NO; c++) reinterpret_cast<float*>(&hout[c][(i - lo) >> 1][lane])[i & 1] = fo[c];
                 }
             }
         }
@@ -754,45 +883,54 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
     // end_simd runs once per block, after its last packed item and before its remainder (also when full == 0)
     if (MODE == MODE_PROCESS && h == (full == 0 ? 0 : (full - 1) / SUB)) SG::end(g);
     for (int i = lo > full ? lo : full; i < hi; i++) {
-        float fi[NI > 0 ? NI : 1], fo[NO];
+        float fi[NI > 0 ? NI : 1], gf[NG > 0 ? NG : 1], fo[NO];
         if constexpr (FIRST) {
 #pragma unroll
             for (int c = 0; c < NI; c++) fi[c] = fin[c][i - lo][lane];
         } else {
-            fi[0] = reinterpret_cast<const float*>(&hin[(i - lo) >> 1][lane])[i & 1];
+#pragma unroll
+            for (int c = 0; c < NI; c++) fi[c] = reinterpret_cast<const float*>(&hin[c][(i - lo) >> 1][lane])[i & 1];
         }
-        SG::template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(g, fi, fo);
+        if constexpr (GIN) {
+#pragma unroll
+            for (int c = 0; c < NG; c++) gf[c] = fin[c][i - lo][lane];
+        }
+        SG::template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(g, fi, FIRST ? fi : gf, fo);
         if constexpr (LAST) {
 #pragma unroll
             for (int c = 0; c < NO; c++) outw[((size_t)c * T + t0 + i) * V + lane] = fo[c];
         } else {
-            reinterpret_cast<float*>(&hout[(i - lo) >> 1][lane])[i & 1] = fo[0];
+#pragma unroll
+            for (int c = 0; c < NO; c++) reinterpret_cast<float*>(&hout[c][(i - lo) >> 1][lane])[i & 1] = fo[c];
         }
     }
 }
 
 // The pipeline kernel.  Waves of one workgroup, 4 voice groups (w & 3) times NW roles (w >> 2):
 //   role 0 (only if the graph has inputs): the LOADER wave.  It does nothing but stream the group's input channels
-//     from HBM into the double-buffered feed tile, one tile ahead.  gfx9-family waves have ONE counter for loads and
+//     from HBM into the feed ring, one tile ahead.  gfx9-family waves have ONE counter for loads and
 //     stores (vmcnt) and mixed pending loads/stores force s_waitcnt vmcnt(0), so a wave that also stores samples
 //     stalls on its own stores whenever it waits for an input; the loader never stores, the compute waves never load.
 //   then S compute stages (S == 1: the whole graph), stage s one tile behind stage s - 1.
 // The hardware places waves w, w+4, w+8, ... of a workgroup on the same SIMD.
-template <class G, int MODE, int S, int K1, int K2>
+template <class G, int MODE, int S, int K1, int K2, int GPW = 4>
 FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
                            float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap) {
-    constexpr int N = Chain<G>::N, NI = G::IN;
+    using TL = PipeTiles<G, S, K1, K2>;
+    constexpr int NI = G::IN;
     constexpr bool FEED = NI > 0;
-    constexpr int SUB = PipeGeom<NI, S>::SUB, SPB = 64 / SUB;
-    static_assert(PipeGeom<NI, S>::ok, "tiles do not fit");
-    using S0 = Seg<G, 0, S == 1 ? N : K1>;
-    using S1 = Seg<G, S == 1 ? 0 : K1, S <= 2 ? N : K2>;   // unused when S == 1
-    using S2 = Seg<G, S <= 2 ? 0 : K2, N>;                 // unused when S <= 2
-    __shared__ float feed[FEED ? 4 : 1][2][FEED ? NI : 1][FEED ? SUB : 1][FEED ? 64 : 1];  // [group][buffer][channel][frame][lane]
-    __shared__ v2f hand[S > 1 ? S - 1 : 1][S > 1 ? 4 : 1][2][S > 1 ? SUB / 2 : 1][S > 1 ? 64 : 1];  // [cut][group][buffer][frame pair][lane]
+    constexpr int SUB = TL::SUB, SPB = 64 / SUB, W = TL::W, D = FEED ? TL::D : 1;
+    static_assert(TL::ok, "tiles do not fit");
+    using S0 = typename TL::S0;
+    using S1 = typename TL::S1;
+    using S2 = typename TL::S2;
+    // GPW = voice groups per workgroup: 4 fills a CU's SIMDs with one workgroup; small banks use 2 or 1 so that every CU
+    // gets a workgroup (a heavy graph's waves are latency-bound: spreading them over idle CUs beats stacking them)
+    __shared__ float feed[FEED ? GPW : 1][D][FEED ? NI : 1][FEED ? SUB : 1][FEED ? 64 : 1];  // [group][ring slot][channel][frame][lane]
+    __shared__ v2f hand[S > 1 ? S - 1 : 1][S > 1 ? GPW : 1][2][S > 1 ? W : 1][S > 1 ? SUB / 2 : 1][S > 1 ? 64 : 1];  // [cut][group][buffer][channel][frame pair][lane]
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // w: wave-uniform
-    const int grp = w & 3, role = w >> 2;
-    const size_t v0 = ((size_t)blockIdx.x * 4 + grp) * 64;
+    const int grp = w % GPW, role = w / GPW;
+    const size_t v0 = ((size_t)blockIdx.x * GPW + grp) * 64;
     const size_t v = v0 + lane;
     const bool live = v0 < stride;  // a whole group beyond the bank still takes part in the barriers
     const bool active = v < V;
@@ -820,7 +958,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
 #pragma unroll
                 for (int c = 0; c < NI; c++)
 #pragma unroll
-                    for (int k = 0; k < SUB; k++) feed[grp][it & 1][c][k][lane] = rg[c][k];
+                    for (int k = 0; k < SUB; k++) feed[grp][it % D][c][k][lane] = rg[c][k];
                 if (it + 1 < ntiles) issue(it + 1);
             }
             __syncthreads();
@@ -846,15 +984,15 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
             const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
             const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
             const float (*fin)[SUB][64] = nullptr;
-            if constexpr (FEED) fin = feed[grp][j & 1];
+            if constexpr (FEED) fin = feed[grp][j % D];
             if (stage == 0) {
-                if constexpr (S == 1) pipe_stage<S0, G, MODE, SUB, true, true>(g, h, t0, size, full, T, V, lane, inw, outw, fin, nullptr, nullptr);
-                else pipe_stage<S0, G, MODE, SUB, true, false>(g, h, t0, size, full, T, V, lane, inw, outw, fin, nullptr, hand[0][grp][j & 1]);
+                if constexpr (S == 1) pipe_stage<S0, G, MODE, SUB, W, true, true>(g, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr);
+                else pipe_stage<S0, G, MODE, SUB, W, true, false>(g, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
             } else if (stage == 1) {
-                if constexpr (S == 2) pipe_stage<S1, G, MODE, SUB, false, true>(g, h, t0, size, full, T, V, lane, inw, outw, nullptr, hand[0][grp][j & 1], nullptr);
-                else if constexpr (S == 3) pipe_stage<S1, G, MODE, SUB, false, false>(g, h, t0, size, full, T, V, lane, inw, outw, nullptr, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
+                if constexpr (S == 2) pipe_stage<S1, G, MODE, SUB, W, false, true>(g, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr);
+                else if constexpr (S == 3) pipe_stage<S1, G, MODE, SUB, W, false, false>(g, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
             } else {
-                if constexpr (S == 3) pipe_stage<S2, G, MODE, SUB, false, true>(g, h, t0, size, full, T, V, lane, inw, outw, nullptr, hand[S - 2][grp][j & 1], nullptr);
+                if constexpr (S == 3) pipe_stage<S2, G, MODE, SUB, W, false, true>(g, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr);
             }
         }
         __syncthreads();  // hand-over point: every role has finished its tile of this round
@@ -866,11 +1004,11 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     }
 }
 
-template <class G, int MODE, int S, int K1, int K2>
-__global__ __launch_bounds__((64 * PipeGeom<G::IN, S>::WAVES)) void k_render_pipe(float* __restrict__ slots, size_t stride, size_t V,
-                                                                                const float* __restrict__ in, float* __restrict__ out,
-                                                                                size_t T, const void* aux, float* ring, uint32_t ring_cap) {
-    render_pipe_body<G, MODE, S, K1, K2>(slots, stride, V, in, out, T, aux, ring, ring_cap);
+template <class G, int MODE, int S, int K1, int K2, int GPW>
+__global__ __launch_bounds__((16 * GPW * PipeGeom<G::IN, S>::WAVES)) void k_render_pipe(float* __restrict__ slots, size_t stride, size_t V,
+                                                                                      const float* __restrict__ in, float* __restrict__ out,
+                                                                                      size_t T, const void* aux, float* ring, uint32_t ring_cap) {
+    render_pipe_body<G, MODE, S, K1, K2, GPW>(slots, stride, V, in, out, T, aux, ring, ring_cap);
 }
 
 // Launch policy for the voice-minor layout: voices per wave such that the grid has at least one wave per SIMD.

@@ -91,9 +91,24 @@ bool launch_render_pipe(float* slots, size_t stride, size_t V, const float* in, 
     constexpr PipePlan P = pipe_plan<G>(WANT);
     if constexpr (P.S >= 1) {
         const size_t groups = (V + 63) / 64;
-        hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2>), dim3((unsigned)((groups + 3) / 4)),
-                           dim3(64 * PipeGeom<G::IN, P.S>::WAVES), 0, s,
-                           slots, stride, V, in, out, T, aux, ring, ring_cap);
+        constexpr int WAVES = PipeGeom<G::IN, P.S>::WAVES;  // for 4 voice groups
+        const size_t cus = (size_t)simd_count() / 4;
+        // light graphs keep 4 groups per workgroup; heavy ones (latency-bound waves) are spread so that every CU gets one
+        bool done = false;
+        if constexpr (Cost<G>::v >= 150) {
+            if (groups < 2 * cus) {
+                hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 1>), dim3((unsigned)groups), dim3(16 * WAVES), 0, s, slots,
+                                   stride, V, in, out, T, aux, ring, ring_cap);
+                done = true;
+            } else if (groups < 4 * cus) {
+                hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 2>), dim3((unsigned)((groups + 1) / 2)), dim3(16 * 2 * WAVES), 0,
+                                   s, slots, stride, V, in, out, T, aux, ring, ring_cap);
+                done = true;
+            }
+        }
+        if (!done)
+            hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 4>), dim3((unsigned)((groups + 3) / 4)), dim3(16 * 4 * WAVES), 0, s,
+                               slots, stride, V, in, out, T, aux, ring, ring_cap);
         return true;
     } else {
         return false;
