@@ -5,12 +5,16 @@
 //                            >> sumf::<U32>(|x| pan(lerp(-1, 1, smooth9(x)))) * dc((1/16, 1/16))
 // with fdn = Feedback<U32, _, FrameHadamard> (feedback.rs:18-146), Delay (delay.rs:72-139), Fir<U3> (fir.rs:14-89).
 //
-// Mapping (differs from the lane-per-voice kernels on purpose): one lane per DELAY LINE, 32 lanes per reverb
-// instance, two instances per wave64.  The 32-point Hadamard of every sample is 5 cross-lane butterfly stages
-// (DPP quad_perm for strides 1, 2; ds_swizzle bit-mode for 4, 8, 16) in the reference's stage order.  Delay rings live
-// in HBM (372.6 KiB per instance at 48 kHz); because every delay is longer than a 64-sample block, a block's 64
-// ring reads per line do not depend on its writes, so each block stages 64 contiguous samples per line through LDS
-// with coalesced 256-B reads and writes -- 272 B of HBM traffic per instance-frame, the algorithmic minimum.
+// Two formulations, identical samples (fdsp_set_option("fdn_kernel", ..)):
+//  * lane = FRAME (default, k_fdn_render_frames): one wave renders one instance.  Every delay is longer than two blocks,
+//    so inside a 64-frame block the ring reads -- and with them the FIR outputs, the Hadamard and the feedback values --
+//    do not depend on the block's own writes: the 32 lines sit in 32 registers, the Hadamard is 5 x 32 register
+//    butterflies in the reference's stage order, ring rows are loaded (one block ahead) and stored in the lane = frame
+//    order HBM wants, the pan sum is a register fold; two 8.7-KB LDS rows per wave carry the one- and two-frame shifts.
+//  * lane = DELAY LINE (k_fdn_render<IPW>): 32 lanes per instance, cross-lane Hadamard (DPP quad_perm / row mirrors,
+//    v_permlane16_swap), ring rows staged through LDS tiles.
+// Delay rings live in HBM (372.6 KiB per instance at 48 kHz); both kernels move the algorithmic minimum of 272 B per
+// instance-frame (32 ring reads + 32 ring writes + 2 in + 2 out).
 #pragma once
 
 #include <hip/hip_runtime.h>
