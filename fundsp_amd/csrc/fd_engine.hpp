@@ -127,7 +127,9 @@ template <class G>
 void launch_render(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
                    int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
     if (V == 0 || T == 0) return;
-    if (layout == LAYOUT_VOICE_MINOR && g_pipe_split) {
+    // the pipeline needs a few tiles to overlap its stages: a launch of one or two 64-frame blocks (real-time use) is
+    // faster through the single-wave kernel (config 3, T = 64: 17.5 -> ~10 us)
+    if (layout == LAYOUT_VOICE_MINOR && g_pipe_split && (T >= 256 || g_pipe_split > 1)) {
         const bool done = mode == MODE_PROCESS ? launch_render_split<G, MODE_PROCESS>(slots, stride, V, in, out, T, aux, ring, ring_cap, s)
                                                : launch_render_split<G, MODE_TICK>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
         if (done) return;
