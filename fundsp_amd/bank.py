@@ -215,15 +215,18 @@ class Bank:
                                              C.c_void_p(stream) if stream else None))
         return out
 
-    def process_host(self, frames, inp=None, layout=LAYOUT_PLANAR, frame_stride=None, mode=MODE_PROCESS):
-        """Same with numpy buffers (staged, synchronous). Planar default: [V][channels][frame_stride]."""
+    def process_host(self, frames, inp=None, layout=LAYOUT_PLANAR, frame_stride=None, mode=MODE_PROCESS, out=None):
+        """Same with numpy buffers (staged, synchronous). Planar default: [V][channels][frame_stride].
+        `out` (optional, right shape, C-contiguous f32) is written in place; planar padding past `frames` is left alone."""
         frames = int(frames)
         ni, no = self.inputs(), self.outputs()
         if layout == LAYOUT_PLANAR and frame_stride is None:
             frame_stride = max(frames, 1)
         fs = int(frame_stride or 0)
         shape = (no, frames, self.voices) if layout == LAYOUT_VOICE_MINOR else (self.voices, no, fs)
-        out = np.zeros(shape, dtype=np.float32)
+        if out is None:
+            out = np.zeros(shape, dtype=np.float32)
+        assert out.shape == shape and out.dtype == np.float32 and out.flags.c_contiguous, (out.shape, shape)
         h_in = None
         if ni:
             inp = np.ascontiguousarray(inp, dtype=np.float32)

@@ -20,6 +20,7 @@ thread_local std::string g_err;
 namespace fd {
 int g_pipe_split = 1;
 int g_fdn_kernel = 0;
+long g_zero_copy_max = 1 << 18;  // floats; fdsp_bank_process_host reads/writes pinned host memory directly below this
 int simd_count() {
     static int n = [] {
         int dev = 0, cus = 0;
@@ -218,6 +219,10 @@ struct fdsp_bank {
     double* ev = nullptr;
     int* ev_fade = nullptr;
     double seq_time = 0.0;
+    // fdsp_bank_process_host staging, grown on demand and kept: a real-time host calls once per 64-frame block
+    float *st_in = nullptr, *st_out = nullptr;     // device
+    float *pin_in = nullptr, *pin_out = nullptr;   // pinned host (small transfers only)
+    size_t st_in_n = 0, st_out_n = 0, pin_in_n = 0, pin_out_n = 0;
 };
 
 namespace {
@@ -312,6 +317,11 @@ int fdsp_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "pipe_split") == 0) {
         if (value < 0 || value > 4) return fail(FDSP_EINVAL, "pipe_split takes 0 (off), 1 (auto), 2 or 3 (stages), 4 (loader only)");
         fd::g_pipe_split = value;
+        return FDSP_OK;
+    }
+    if (name && std::strcmp(name, "host_zero_copy_max") == 0) {
+        if (value < 0) return fail(FDSP_EINVAL, "host_zero_copy_max takes a float count >= 0");
+        fd::g_zero_copy_max = value;
         return FDSP_OK;
     }
     if (name && std::strcmp(name, "fdn_kernel") == 0) {
@@ -512,6 +522,10 @@ void fdsp_bank_destroy(fdsp_bank* b) {
     if (b->ring) hipFree(b->ring);
     if (b->ev) hipFree(b->ev);
     if (b->ev_fade) hipFree(b->ev_fade);
+    if (b->st_in) hipFree(b->st_in);
+    if (b->st_out) hipFree(b->st_out);
+    if (b->pin_in) hipHostFree(b->pin_in);
+    if (b->pin_out) hipHostFree(b->pin_out);
     hipEventDestroy(b->e0);
     hipEventDestroy(b->e1);
     if (b->stream) hipStreamDestroy(b->stream);
@@ -765,31 +779,82 @@ int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, flo
     return FDSP_OK;
 }
 
+namespace {
+
+// grow-only staging buffer; `pinned` picks hipHostMalloc over hipMalloc
+hipError_t stage_reserve(float** p, size_t* have, size_t want, bool pinned) {
+    if (want <= *have) return hipSuccess;
+    if (*p) {
+        hipError_t e = pinned ? hipHostFree(*p) : hipFree(*p);
+        *p = nullptr;
+        *have = 0;
+        if (e != hipSuccess) return e;
+    }
+    size_t n = want + want / 2;
+    hipError_t e = pinned ? hipHostMalloc((void**)p, n * sizeof(float), hipHostMallocDefault)
+                          : hipMalloc((void**)p, n * sizeof(float));
+    if (e != hipSuccess) {
+        n = want;
+        e = pinned ? hipHostMalloc((void**)p, n * sizeof(float), hipHostMallocDefault)
+                   : hipMalloc((void**)p, n * sizeof(float));
+    }
+    if (e == hipSuccess) *have = n;
+    return e;
+}
+
+}  // namespace
+
 int fdsp_bank_process_host(fdsp_bank* b, size_t frames, const float* h_in, float* h_out, int layout,
                            size_t frame_stride, int mode) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
     if (frames == 0) return FDSP_OK;
     if (!h_out) return fail(FDSP_EINVAL, "h_out is NULL");
-    const size_t row = layout == FDSP_LAYOUT_PLANAR ? frame_stride : frames;
-    if (layout == FDSP_LAYOUT_PLANAR && frame_stride < frames) return fail(FDSP_EINVAL, "frame_stride < frames");
-    const size_t n_in = (size_t)fdsp_bank_inputs(b) * row * b->V, n_out = (size_t)fdsp_bank_outputs(b) * row * b->V;
-    if (fdsp_bank_inputs(b) > 0 && !h_in) return fail(FDSP_EINVAL, "h_in is NULL but the graph has inputs");
-    float *d_in = nullptr, *d_out = nullptr;
-    if (n_in) HIPCHK(hipMalloc((void**)&d_in, n_in * sizeof(float)));
-    hipError_t e = hipMalloc((void**)&d_out, n_out * sizeof(float));
-    if (e != hipSuccess) {
-        if (d_in) hipFree(d_in);
-        return fail(FDSP_ENOMEM, hipGetErrorString(e));
-    }
+    const bool planar = layout == FDSP_LAYOUT_PLANAR;
+    const size_t row = planar ? frame_stride : frames;
+    if (planar && frame_stride < frames) return fail(FDSP_EINVAL, "frame_stride < frames");
+    const size_t ni = (size_t)fdsp_bank_inputs(b), no = (size_t)fdsp_bank_outputs(b);
+    const size_t n_in = ni * row * b->V, n_out = no * row * b->V;
+    if (ni > 0 && !h_in) return fail(FDSP_EINVAL, "h_in is NULL but the graph has inputs");
+    hipError_t e = hipSuccess;
+    // planar rows longer than `frames`: only the first `frames` samples of each row cross the bus, and the caller's
+    // padding is left untouched (AudioNode::process does not write past `size`, audionode.rs:85)
+    const bool strided = planar && frame_stride > frames;
+    // small transfers (a real-time host's 64-frame blocks): the kernel reads and writes pinned host memory over the
+    // bus itself — two copy-engine round trips less than staging through HBM (tools/host_sweep.py: 26-45 us against
+    // 44-54 us per call up to 1024 voices; above ~1 MB the pageable copy path wins)
+    const bool zc = !strided && n_in <= (size_t)fd::g_zero_copy_max && n_out <= (size_t)fd::g_zero_copy_max &&
+                    stage_reserve(&b->pin_in, &b->pin_in_n, n_in, true) == hipSuccess &&
+                    stage_reserve(&b->pin_out, &b->pin_out_n, n_out, true) == hipSuccess;
     int rc = FDSP_OK;
-    if (n_in) e = hipMemcpyAsync(d_in, h_in, n_in * sizeof(float), hipMemcpyHostToDevice, b->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, n_out * sizeof(float), b->stream);
-    if (e == hipSuccess) rc = fdsp_bank_process(b, frames, d_in, d_out, layout, frame_stride, mode, nullptr);
-    if (e == hipSuccess && rc == FDSP_OK)
-        e = hipMemcpyAsync(h_out, d_out, n_out * sizeof(float), hipMemcpyDeviceToHost, b->stream);
+    if (zc) {
+        if (n_in) memcpy(b->pin_in, h_in, n_in * sizeof(float));
+        rc = fdsp_bank_process(b, frames, n_in ? b->pin_in : nullptr, b->pin_out, layout, frame_stride, mode, nullptr);
+        if (rc != FDSP_OK) return rc;
+        e = hipStreamSynchronize(b->stream);
+        if (e != hipSuccess) return fail(FDSP_EDEVICE, hipGetErrorString(e));
+        memcpy(h_out, b->pin_out, n_out * sizeof(float));
+        return FDSP_OK;
+    }
+    e = stage_reserve(&b->st_in, &b->st_in_n, n_in, false);
+    if (e == hipSuccess) e = stage_reserve(&b->st_out, &b->st_out_n, n_out, false);
+    if (e != hipSuccess) return fail(FDSP_ENOMEM, hipGetErrorString(e));
+    if (n_in) {
+        if (strided)
+            e = hipMemcpy2DAsync(b->st_in, row * sizeof(float), h_in, row * sizeof(float), frames * sizeof(float),
+                                 ni * b->V, hipMemcpyHostToDevice, b->stream);
+        else
+            e = hipMemcpyAsync(b->st_in, h_in, n_in * sizeof(float), hipMemcpyHostToDevice, b->stream);
+    }
+    if (e == hipSuccess)
+        rc = fdsp_bank_process(b, frames, n_in ? b->st_in : nullptr, b->st_out, layout, frame_stride, mode, nullptr);
+    if (e == hipSuccess && rc == FDSP_OK) {
+        if (strided)
+            e = hipMemcpy2DAsync(h_out, row * sizeof(float), b->st_out, row * sizeof(float), frames * sizeof(float),
+                                 no * b->V, hipMemcpyDeviceToHost, b->stream);
+        else
+            e = hipMemcpyAsync(h_out, b->st_out, n_out * sizeof(float), hipMemcpyDeviceToHost, b->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-    if (d_in) hipFree(d_in);
-    hipFree(d_out);
     if (e != hipSuccess) return fail(FDSP_EDEVICE, hipGetErrorString(e));
     return rc;
 }

@@ -95,6 +95,8 @@ int fdsp_kind_by_name(const char* name); /* -1 if unknown */
  * segments that run in 2 or 3 waves sharing a SIMD; identical samples, better issue-slot utilisation at one
  * voice-wave per SIMD).  1 = best plan, 2 / 3 = exactly that many stages (if the graph allows), 0 = single-wave kernel. */
 int fdsp_set_option(const char* name, int value);
+/* "host_zero_copy_max" (default 262144): fdsp_bank_process_host calls moving at most this many floats per direction
+ * let the kernel read/write pinned host memory directly instead of staging through HBM (lower per-block latency). */
 /* "fdn_kernel" (default 0): reverb banks render with one lane per FRAME (0) or one lane per DELAY LINE (1); identical
  * samples, the former is the faster formulation. */
 

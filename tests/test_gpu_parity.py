@@ -359,6 +359,37 @@ def test_single_voice_process_is_audionode_process(gpu):
     assert_bit_equal(got[0], n.tick([0.25]), "tick")
 
 
+def test_process_host_paths(gpu):
+    """fdsp_bank_process_host: the host-buffer boundary gives the device path's samples through each staging branch
+    (pinned small transfers, pageable large ones, strided planar rows) and leaves the caller's row padding alone,
+    as AudioNode::process leaves samples past `size` (audionode.rs:85)."""
+    rng = np.random.default_rng(11)
+    for V, T in ((300, 128), (70000, 96)):          # 70000*96 floats > the pinned-staging limit
+        p = W.fm_svf_params(V, SR)
+        want = run_bank(W.make_fm_svf_bank(V, SR, params=p), None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+        got = W.make_fm_svf_bank(V, SR, params=p).process_host(T, layout=LAYOUT_VOICE_MINOR)
+        assert_bit_equal(got.transpose(2, 0, 1), want, f"host voice-minor V={V}")
+        got = W.make_fm_svf_bank(V, SR, params=p).process_host(T, layout=LAYOUT_PLANAR)
+        assert_bit_equal(got, want, f"host planar V={V}")
+    # strided rows with an input: padding of the caller's buffer must survive, repeated calls reuse the staging
+    V, T, FS = 257, 50, 64
+    b = gpu.Bank("fixed_svf", V)
+    b.set_param(":cutoff", 900.0)
+    b.set_param(":q", 1.1)
+    b.set_sample_rate(SR)
+    ref = gpu.Bank("fixed_svf", V)
+    ref.set_param(":cutoff", 900.0)
+    ref.set_param(":q", 1.1)
+    ref.set_sample_rate(SR)
+    for call in range(3):
+        x = (rng.random((V, 1, FS), dtype=np.float32) - 0.5).astype(np.float32)
+        out = np.full((V, 1, FS), 7.5, dtype=np.float32)
+        b.process_host(T, x, layout=LAYOUT_PLANAR, frame_stride=FS, out=out)
+        want = run_bank(ref, x[:, :, :T].copy(), T, LAYOUT_PLANAR, MODE_PROCESS)
+        assert_bit_equal(out[:, :, :T], want, f"strided call {call}")
+        assert (out[:, :, T:] == 7.5).all(), "row padding was overwritten"
+
+
 def test_error_behaviour(gpu):
     with pytest.raises(gpu.FdspError):
         gpu.Bank("no_such_kind", 4)
