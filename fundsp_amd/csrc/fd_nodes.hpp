@@ -2439,4 +2439,406 @@ struct Unop {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// routing leaves and the remaining combinators (audionode.rs).  All of them are arithmetic-free or a handful of
+// adds; they exist so that any graph the reference's operators can spell fuses into the one per-voice kernel.
+// ---------------------------------------------------------------------------------------------------------
+
+#define FD_STATELESS_LEAF                                            \
+    template <class V> FD_HD void visit(V&) {}                       \
+    FD_HD void init() {}                                             \
+    FD_HD void update(double) {}                                     \
+    FD_HD void reset() {}                                            \
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }    \
+    FD_HD void end_simd() {}                                         \
+    FD_HD void begin_block(int) {}                                   \
+    FD_HD bool tripped() const { return false; }                     \
+    FD_HD void bind(Ctx&) {}
+
+// MultiPass<N>  audionode.rs:373-403 (ID 0)
+template <int N>
+struct MultiPass {
+    static constexpr int IN = N, OUT = N, RINGS = 0;
+    static constexpr uint64_t ID = 0;
+    FD_STATELESS_LEAF
+    template <int PH> FD_HD void step(const float* in, float* out) { for (int i = 0; i < N; i++) out[i] = in[i]; }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) { for (int i = 0; i < N; i++) out[i] = in[i]; }
+};
+
+// Sink<N>  audionode.rs:437-462 (ID 1)
+template <int N>
+struct Sink {
+    static constexpr int IN = N, OUT = 0, RINGS = 0;
+    static constexpr uint64_t ID = 1;
+    FD_STATELESS_LEAF
+    template <int PH> FD_HD void step(const float*, float*) {}
+    template <int PH> FD_HD void step2(const v2f*, v2f*) {}
+};
+
+// MultiSplit<M, N>: M inputs copied to N branches, output j + i*M = input j  audionode.rs:571-613 (ID 38);
+// Split<N> = the M == 1 case with its own ID  audionode.rs:527-568 (ID 40)
+template <int M, int N>
+struct MultiSplit {
+    static constexpr int IN = M, OUT = M * N, RINGS = 0;
+    static constexpr uint64_t ID = 38;
+    FD_STATELESS_LEAF
+    template <int PH> FD_HD void step(const float* in, float* out) { for (int i = 0; i < M * N; i++) out[i] = in[i % M]; }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) { for (int i = 0; i < M * N; i++) out[i] = in[i % M]; }
+};
+template <int N>
+struct Split {
+    static constexpr int IN = 1, OUT = N, RINGS = 0;
+    static constexpr uint64_t ID = 40;
+    FD_STATELESS_LEAF
+    template <int PH> FD_HD void step(const float* in, float* out) { for (int i = 0; i < N; i++) out[i] = in[0]; }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) { for (int i = 0; i < N; i++) out[i] = in[0]; }
+};
+
+// MultiJoin<M, N>  audionode.rs:668-730 (ID 39) and Join<N> :617-660 (ID 41): average N branches.
+// tick sums then DIVIDES by N (:643-648, :700-708); process scales every term by z = 1/N and sums (:649-659, :710-724).
+template <int M, int N, uint64_t JID>
+struct JoinT {
+    static constexpr int IN = M * N, OUT = M, RINGS = 0;
+    static constexpr uint64_t ID = JID;
+    FD_STATELESS_LEAF
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        if (PH == PH_TICK) {
+            for (int j = 0; j < M; j++) {
+                float o = in[j];
+                for (int i = 1; i < N; i++) o += in[j + i * M];
+                out[j] = o / (float)N;
+            }
+        } else {
+            const float z = 1.0f / (float)N;
+            for (int j = 0; j < M; j++) {
+                float o = in[j] * z;
+                for (int i = 1; i < N; i++) o += in[j + i * M] * z;
+                out[j] = o;
+            }
+        }
+    }
+    FD_STEP2_VIA_STEP
+};
+template <int N> using Join = JoinT<1, N, 41>;
+template <int M, int N> using MultiJoin = JoinT<M, N, 39>;
+
+// Reverse<N>  audionode.rs:2808-2837 (ID 45)
+template <int N>
+struct Reverse {
+    static constexpr int IN = N, OUT = N, RINGS = 0;
+    static constexpr uint64_t ID = 45;
+    FD_STATELESS_LEAF
+    template <int PH> FD_HD void step(const float* in, float* out) { for (int i = 0; i < N; i++) out[i] = in[N - 1 - i]; }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) { for (int i = 0; i < N; i++) out[i] = in[N - 1 - i]; }
+};
+
+// Impulse<N>  audionode.rs:2841-2875 (ID 81): one on the first sample after reset, zero afterwards
+template <int N>
+struct Impulse {
+    static constexpr int IN = 0, OUT = N, RINGS = 0;
+    static constexpr uint64_t ID = 81;
+    float value;
+    template <class V> FD_HD void visit(V& v) { v.f(value, STATE, "value"); }
+    FD_HD void init() { value = 1.0f; }
+    FD_HD void update(double) {}
+    FD_HD void reset() { value = 1.0f; }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void end_simd() {}
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void bind(Ctx&) {}
+    template <int PH> FD_HD void step(const float*, float* out) {
+        for (int i = 0; i < N; i++) out[i] = value;
+        value = 0.0f;
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// Map<M, I, O>  audionode.rs:1330-1371 (ID 5): the closure is a functor type `FN` with
+//   static void f(const float* in, float* out)     (one frame: NI inputs -> NO outputs)
+// supplied as source to fdsp_graph_compile_src.  Map has no process override, so every phase is the tick arithmetic.
+template <class FN, int NI, int NO>
+struct Map {
+    static constexpr int IN = NI, OUT = NO, RINGS = 0;
+    static constexpr uint64_t ID = 5;
+    FD_STATELESS_LEAF
+    template <int PH> FD_HD void step(const float* in, float* out) { FN::f(in, out); }
+    FD_STEP2_VIA_STEP
+};
+
+// Shaper<ShapeFn<S>>  shape.rs:35-42, 205-247 (ID 42): shape_fn(|x| ..) with the closure as a functor type
+//   static float f(float x)
+// The Shape trait's default `simd` applies `shape` lane by lane (shape.rs:16-18), so every phase is the same arithmetic.
+template <class FN>
+struct ShaperFn {
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 42;
+    FD_STATELESS_LEAF
+    template <int PH> FD_HD void step(const float* in, float* out) { out[0] = FN::f(in[0]); }
+    FD_STEP2_VIA_STEP
+};
+
+// Declick<f32>  dynamics.rs:245-313 (ID 23): smooth5 fade-in over `duration` seconds from time zero.
+// tick re-derives the fade phase from t every sample (:278-287); process accumulates phase_d = sample_duration /
+// duration inside the block and advances t by size * sample_duration in one multiplication (:289-307).
+struct Declick {
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 23;
+    float t, duration, sd;
+    float phase, phase_d, end_time;  // block transients (process path)
+    int blk_i, blk_size, end_index;
+    bool fading;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(duration, PARAM, "duration");
+        v.f(sd, COEF, "sample_duration");
+        v.f(t, STATE, "t");
+    }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void init() { t = 0.0f; duration = 0.010f; sd = 0.0f; fading = false; blk_i = blk_size = end_index = 0; }
+    FD_HD void update(double sr) { sd = (float)(1.0 / sr); }
+    FD_HD void reset() { t = 0.0f; }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    static FD_HD float smooth5(float x) { return ((x * 6.0f - 15.0f) * x + 10.0f) * x * x * x; }  // math.rs:418-420
+    FD_HD void begin_block(int size) {
+        blk_i = 0;
+        blk_size = size;
+        fading = t < duration;
+        if (fading) {
+            phase = (t - 0.0f) / (duration - 0.0f);  // delerp math.rs:218-220
+            phase_d = sd / duration;
+            end_time = t + (float)(long long)size * sd;
+            end_index = duration < end_time ? (int)(long long)__builtin_ceilf((duration - t) / sd) : size;
+        }
+    }
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        if (PH == PH_TICK) {
+            if (t < duration) {
+                const float ph = (t - 0.0f) / (duration - 0.0f);
+                const float value = smooth5(ph);
+                t += sd;
+                out[0] = in[0] * value;
+            } else {
+                out[0] = in[0];
+            }
+        } else {
+            float x = in[0];
+            if (fading) {
+                if (blk_i < end_index) {
+                    x *= smooth5(phase);
+                    phase += phase_d;
+                }
+                blk_i++;
+                if (blk_i == blk_size) t = end_time;  // :305, once per block
+            }
+            out[0] = x;
+        }
+    }
+    FD_STEP2_VIA_STEP
+};
+
+#define FD_PAIR_COMBINATOR                                                                                  \
+    X x;                                                                                                    \
+    Y y;                                                                                                    \
+    template <class V> FD_HD void visit(V& v) {                                                             \
+        v.enter(0); x.visit(v); v.leave();                                                                  \
+        v.enter(1); y.visit(v); v.leave();                                                                  \
+    }                                                                                                       \
+    FD_HD void init() { x.init(); y.init(); }                                                               \
+    FD_HD void update(double sr) { x.update(sr); y.update(sr); }                                            \
+    FD_HD void reset() { x.reset(); y.reset(); }                                                            \
+    FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }       \
+    FD_HD void end_simd() { x.end_simd(); y.end_simd(); }                                                   \
+    FD_HD void begin_block(int n) { x.begin_block(n); y.begin_block(n); }                                   \
+    FD_HD void bind(Ctx& a) { x.bind(a); y.bind(a); }                                                       \
+    FD_HD bool tripped() const { return x.tripped() || y.tripped(); }
+
+// Branch<X, Y>  audionode.rs:1653-1792 (ID 8): both read the same input, outputs side by side
+template <class X, class Y>
+struct Branch {
+    static_assert(X::IN == Y::IN, "Branch arity mismatch");
+    static constexpr int IN = X::IN, OUT = X::OUT + Y::OUT, RINGS = X::RINGS + Y::RINGS;
+    static constexpr uint64_t ID = 8;
+    FD_PAIR_COMBINATOR
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        x.template step<PH>(in, out);
+        y.template step<PH>(in, out + X::OUT);
+    }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        x.template step2<PH>(in, out);
+        y.template step2<PH>(in, out + X::OUT);
+    }
+};
+
+// Bus<X, Y>  audionode.rs:1796-1947 (ID 10): both read the same input, outputs added (x + y in tick :1861-1865 and
+// in process :1867-1876)
+template <class X, class Y>
+struct Bus {
+    static_assert(X::IN == Y::IN && X::OUT == Y::OUT, "Bus arity mismatch");
+    static constexpr int IN = X::IN, OUT = X::OUT, RINGS = X::RINGS + Y::RINGS;
+    static constexpr uint64_t ID = 10;
+    FD_PAIR_COMBINATOR
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        float t[OUT > 0 ? OUT : 1];
+        x.template step<PH>(in, out);
+        y.template step<PH>(in, t);
+        for (int i = 0; i < OUT; i++) out[i] = out[i] + t[i];
+    }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        v2f t[OUT > 0 ? OUT : 1];
+        x.template step2<PH>(in, out);
+        y.template step2<PH>(in, t);
+        for (int i = 0; i < OUT; i++) out[i] = out[i] + t[i];
+    }
+};
+
+// Thru<X>  audionode.rs:1951-2060 (ID 12): X's outputs, then the inputs X has no output for; when X has MORE outputs
+// than inputs the surplus outputs are cut (:1990-1999)
+template <class X>
+struct Thru {
+    static constexpr int IN = X::IN, OUT = X::IN, RINGS = X::RINGS;
+    static constexpr uint64_t ID = 12;
+    X x;
+    template <class V> FD_HD void visit(V& v) { v.enter(0); x.visit(v); v.leave(); }
+    FD_HD void init() { x.init(); }
+    FD_HD void update(double sr) { x.update(sr); }
+    FD_HD void reset() { x.reset(); }
+    FD_HD uint64_t ping(bool probe, uint64_t h) { return x.ping(probe, atto(h, ID)); }  // :2026-2028
+    FD_HD void end_simd() { x.end_simd(); }
+    FD_HD void begin_block(int n) { x.begin_block(n); }
+    FD_HD void bind(Ctx& a) { x.bind(a); }
+    FD_HD bool tripped() const { return x.tripped(); }
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        float t[X::OUT > 0 ? X::OUT : 1];
+        x.template step<PH>(in, t);
+        for (int i = 0; i < OUT; i++) out[i] = i < X::OUT ? t[i] : in[i];
+    }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        v2f t[X::OUT > 0 ? X::OUT : 1];
+        x.template step2<PH>(in, t);
+        for (int i = 0; i < OUT; i++) out[i] = i < X::OUT ? t[i] : in[i];
+    }
+};
+
+// N-fold combinators over N nodes of ONE type (the closure forms busi/stacki/branchi/sumi/pipei of the prelude).
+#define FD_MULTI_COMBINATOR                                                                                 \
+    X x[N];                                                                                                 \
+    template <class V> FD_HD void visit(V& v) {                                                             \
+        for (int i = 0; i < N; i++) { v.enter(i); x[i].visit(v); v.leave(); }                               \
+    }                                                                                                       \
+    FD_HD void init() { for (int i = 0; i < N; i++) x[i].init(); }                                          \
+    FD_HD void update(double sr) { for (int i = 0; i < N; i++) x[i].update(sr); }                           \
+    FD_HD void reset() { for (int i = 0; i < N; i++) x[i].reset(); }                                        \
+    FD_HD uint64_t ping(bool probe, uint64_t h) {                                                           \
+        h = atto(h, ID);                                                                                    \
+        for (int i = 0; i < N; i++) h = x[i].ping(probe, h);                                                \
+        return h;                                                                                           \
+    }                                                                                                       \
+    FD_HD void end_simd() { for (int i = 0; i < N; i++) x[i].end_simd(); }                                  \
+    FD_HD void begin_block(int n) { for (int i = 0; i < N; i++) x[i].begin_block(n); }                      \
+    FD_HD void bind(Ctx& a) { for (int i = 0; i < N; i++) x[i].bind(a); }                                   \
+    FD_HD bool tripped() const {                                                                            \
+        bool t = false;                                                                                     \
+        for (int i = 0; i < N; i++) t = t || x[i].tripped();                                                \
+        return t;                                                                                           \
+    }
+
+// MultiBus<N, X>  audionode.rs:2065-2207 (ID 28).  tick folds from a zero frame, (0 + x0) + x1 .. (:2117-2121);
+// process starts from x0's output (:2123-2134) -- they differ only in the sign of a zero.
+template <int N, class X>
+struct MultiBus {
+    static constexpr int IN = X::IN, OUT = X::OUT, RINGS = N * X::RINGS;
+    static constexpr uint64_t ID = 28;
+    FD_MULTI_COMBINATOR
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        float t[OUT > 0 ? OUT : 1];
+        x[0].template step<PH>(in, out);
+        if (PH == PH_TICK)
+            for (int c = 0; c < OUT; c++) out[c] = 0.0f + out[c];
+        _Pragma("unroll") for (int i = 1; i < N; i++) {
+            x[i].template step<PH>(in, t);
+            for (int c = 0; c < OUT; c++) out[c] = out[c] + t[c];
+        }
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// MultiStack<N, X>  audionode.rs:2211-2362 (ID 30)
+template <int N, class X>
+struct MultiStack {
+    static constexpr int IN = N * X::IN, OUT = N * X::OUT, RINGS = N * X::RINGS;
+    static constexpr uint64_t ID = 30;
+    FD_MULTI_COMBINATOR
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        _Pragma("unroll") for (int i = 0; i < N; i++) x[i].template step<PH>(in + i * X::IN, out + i * X::OUT);
+    }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        _Pragma("unroll") for (int i = 0; i < N; i++) x[i].template step2<PH>(in + i * X::IN, out + i * X::OUT);
+    }
+};
+
+// MultiBranch<N, X>  audionode.rs:2532-2669 (ID 33)
+template <int N, class X>
+struct MultiBranch {
+    static constexpr int IN = X::IN, OUT = N * X::OUT, RINGS = N * X::RINGS;
+    static constexpr uint64_t ID = 33;
+    FD_MULTI_COMBINATOR
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        _Pragma("unroll") for (int i = 0; i < N; i++) x[i].template step<PH>(in, out + i * X::OUT);
+    }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        _Pragma("unroll") for (int i = 0; i < N; i++) x[i].template step2<PH>(in, out + i * X::OUT);
+    }
+};
+
+// Reduce<N, X, B>  audionode.rs:2366-2528 (ID 31): own inputs per node, outputs folded left with the binary op
+template <int N, class X, class OP>
+struct Reduce {
+    static constexpr int IN = N * X::IN, OUT = X::OUT, RINGS = N * X::RINGS;
+    static constexpr uint64_t ID = 31;
+    FD_MULTI_COMBINATOR
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        float t[OUT > 0 ? OUT : 1];
+        x[0].template step<PH>(in, out);
+        _Pragma("unroll") for (int i = 1; i < N; i++) {
+            x[i].template step<PH>(in + i * X::IN, t);
+            for (int c = 0; c < OUT; c++) out[c] = OP::f(out[c], t[c]);
+        }
+    }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        v2f t[OUT > 0 ? OUT : 1];
+        x[0].template step2<PH>(in, out);
+        _Pragma("unroll") for (int i = 1; i < N; i++) {
+            x[i].template step2<PH>(in + i * X::IN, t);
+            for (int c = 0; c < OUT; c++) out[c] = OP::f(out[c], t[c]);
+        }
+    }
+};
+
+// Chain<N, X> of the reference (audionode.rs:2673-2804, ID 32): N nodes of one type in series (pipei)
+template <int N, class X>
+struct PipeN {
+    static_assert(X::IN == X::OUT, "pipei needs as many outputs as inputs");
+    static constexpr int IN = X::IN, OUT = X::OUT, RINGS = N * X::RINGS;
+    static constexpr uint64_t ID = 32;
+    FD_MULTI_COMBINATOR
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        float t[OUT > 0 ? OUT : 1];
+        x[0].template step<PH>(in, out);
+        _Pragma("unroll") for (int i = 1; i < N; i++) {
+            for (int c = 0; c < OUT; c++) t[c] = out[c];
+            x[i].template step<PH>(t, out);
+        }
+    }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        v2f t[OUT > 0 ? OUT : 1];
+        x[0].template step2<PH>(in, out);
+        _Pragma("unroll") for (int i = 1; i < N; i++) {
+            for (int c = 0; c < OUT; c++) t[c] = out[c];
+            x[i].template step2<PH>(t, out);
+        }
+    }
+};
+
 }  // namespace fd

@@ -43,6 +43,20 @@ class Graph:
     def __or__(self, other):
         return self._pair(other, "Stack", self.nin + other.nin, self.nout + other.nout)
 
+    def __and__(self, other):  # Bus, combinator.rs `&`
+        if self.nin != other.nin or self.nout != other.nout:
+            raise TypeError("Bus arity mismatch")
+        return self._pair(other, "Bus", self.nin, self.nout)
+
+    def __xor__(self, other):  # Branch, combinator.rs `^`
+        if self.nin != other.nin:
+            raise TypeError("Branch arity mismatch")
+        return self._pair(other, "Branch", self.nin, self.nout + other.nout)
+
+    def __invert__(self):      # Thru, combinator.rs `!`
+        return Graph(f"Thru<{self.type}>", self.nin, self.nin, [((0,) + p, f, v, u) for p, f, v, u in self.params],
+                     self.rings, self.source)
+
     def _binop(self, other, op):
         if self.nout != other.nout:
             raise TypeError("Binop arity mismatch")
@@ -127,7 +141,7 @@ def biquad(a1, a2, b0, b1, b2): return _leaf("Biquad", 1, 1, a1=a1, a2=a2, b0=b0
 def butterpass_hz(f): return _leaf("ButterLowpass<1>", 1, 1, cutoff=f)
 def butterpass(): return _leaf("ButterLowpass<2>", 2, 1)
 def resonator_hz(center, bandwidth): return _leaf("Resonator<1>", 1, 1, center=center, q=bandwidth)
-def resonator(): return _leaf("Resonator<3>", 3, 1)
+def resonator(): return _leaf("Resonator<3>", 3, 1, center=440.0, q=110.0)   # prelude32.rs:521
 def moog_hz(f, q): return _leaf("Moog<1>", 1, 1, cutoff=f, q=q)
 def moog(): return _leaf("Moog<3>", 3, 1)
 def fir(*w): return Graph(f"Fir<{len(w)}>", 1, 1, [((), f"w[{i}]", x, False) for i, x in enumerate(w)])
@@ -200,6 +214,145 @@ def adsr_live(a, d, s, r): return _leaf("AdsrLive", 1, 1, attack=a, decay=d, sus
 def pan(p): return _leaf("Panner", 1, 2, pan=p)
 def shape(kind, p0=1.0, p1=0.0, smoothing=0.0):
     return _leaf("Shaper", 1, 1, shape=float(SHAPES[kind]), shape_p0=p0, shape_p1=p1, shape_smoothing=smoothing)
+
+
+
+# --- routing (prelude32.rs:129-222, 1103-1156) and the function forms of the operators (:1330-1470)
+def zero(): return constant(0.0)
+def multizero(n): return constant(*([0.0] * n))
+def multipass(n): return _leaf(f"MultiPass<{n}>", n, n)
+def sink(): return _leaf("Sink<1>", 1, 0)
+def multisink(n): return _leaf(f"Sink<{n}>", n, 0)
+def split(n): return _leaf(f"Split<{n}>", 1, n)
+def multisplit(m, n): return _leaf(f"MultiSplit<{m},{n}>", m, m * n)
+def join(n): return _leaf(f"Join<{n}>", n, 1)
+def multijoin(m, n): return _leaf(f"MultiJoin<{m},{n}>", m * n, m)
+def reverse(n): return _leaf(f"Reverse<{n}>", n, n)
+def impulse(n=1): return _leaf(f"Impulse<{n}>", 0, n)
+def thru(x): return ~x
+def bus(x, y): return x & y
+def branch(x, y): return x ^ y
+def stack(x, y): return x | y
+def pipe(x, y): return x >> y
+def sum_(x, y): return x + y
+def product(x, y): return x * y
+def add(*x): return multipass(len(x)) + dc(*x)                    # prelude32.rs:391: MultiPass + dc(x)
+def sub(*x): return multipass(len(x)) - dc(*x)                    # prelude32.rs:409
+def mul(*x): return multipass(len(x)) * dc(*x)                    # prelude32.rs:427
+def declick(): return _leaf("Declick", 1, 1, duration=0.010)
+def declick_s(t): return _leaf("Declick", 1, 1, duration=t)
+
+
+def map_(functor, source, inputs, outputs=1):
+    """map(|i: &Frame<f32, I>| ..) (prelude32.rs:332) with the closure as a C++ functor type `functor` whose definition
+    `source` provides `static __device__ void f(const float* in, float* out)` (contract: Map<FN,NI,NO> in fd_nodes.hpp)."""
+    return Graph(f"Map<{functor},{inputs},{outputs}>", inputs, outputs, [], 0, source)
+
+
+def shape_fn(functor, source):
+    """shape_fn(|x| ..) (prelude32.rs:1181): functor with `static __device__ float f(float x)` (ShaperFn<FN>)."""
+    return Graph(f"ShaperFn<{functor}>", 1, 1, [], 0, source)
+
+
+def _multi(tmpl, nodes, nin_mul, nout_mul, extra=""):
+    nodes = list(nodes)
+    t = nodes[0].type
+    if any(n.type != t for n in nodes):
+        raise TypeError("the N nodes of busi/stacki/branchi/sumi/pipei must have one type (as in Rust)")
+    ps, src = [], ""
+    for i, n in enumerate(nodes):
+        ps += [((i,) + p, f, v, u) for p, f, v, u in n.params]
+        src = _merge(src, n.source)
+    k = len(nodes)
+    return Graph(f"{tmpl}<{k},{t}{extra}>", nodes[0].nin * (k if nin_mul else 1), nodes[0].nout * (k if nout_mul else 1),
+                 ps, sum(n.rings for n in nodes), src)
+
+
+def busi(n, f): return _multi("MultiBus", [f(i) for i in range(n)], False, False)        # prelude.rs:1385
+def stacki(n, f): return _multi("MultiStack", [f(i) for i in range(n)], True, True)      # prelude.rs:1452
+def branchi(n, f): return _multi("MultiBranch", [f(i) for i in range(n)], False, True)   # prelude.rs:1342
+def sumi(n, f): return _multi("Reduce", [f(i) for i in range(n)], True, False, ",OpAdd")  # prelude.rs:1565
+def pipei(n, f):                                                                          # prelude.rs:1620
+    g = _multi("PipeN", [f(i) for i in range(n)], False, False)
+    if g.nin != g.nout:
+        raise TypeError("pipei needs as many outputs as inputs")
+    return g
+def _frac(n, i): return np.float32(i / (n - 1)) if n > 1 else np.float32(0.5)
+def busf(n, f): return busi(n, lambda i: f(_frac(n, i)))
+def stackf(n, f): return stacki(n, lambda i: f(_frac(n, i)))
+def branchf(n, f): return branchi(n, lambda i: f(_frac(n, i)))
+def sumf(n, f): return sumi(n, lambda i: f(_frac(n, i)))
+def pipef(n, f): return pipei(n, lambda i: f(_frac(n, i)))
+
+
+# --- opcodes the prelude composes from the ones above
+def _svf_q(mode, q):                                                                  # prelude.rs:2127-2140 etc.
+    f = _svf(mode)
+    f.params.append(((), "q", q, False))
+    return (multipass(2) | dc(q)) >> f
+def _svf_qg(mode, q, gain):                                                           # prelude.rs:2425-2446 etc.
+    f = _svf(mode)
+    f.params += [((), "q", q, False), ((), "gain", gain, False)]
+    return (multipass(2) | dc(q, gain)) >> f
+def lowpass_q(q): return _svf_q("lowpass", q)
+def highpass_q(q): return _svf_q("highpass", q)
+def bandpass_q(q): return _svf_q("bandpass", q)
+def notch_q(q): return _svf_q("notch", q)
+def peak_q(q): return _svf_q("peak", q)
+def allpass_q(q): return _svf_q("allpass", q)
+def bell_q(q, gain): return _svf_qg("bell", q, gain)
+def lowshelf_q(q, gain): return _svf_qg("lowshelf", q, gain)
+def highshelf_q(q, gain): return _svf_qg("highshelf", q, gain)
+def lowrez_q(q): return (multipass(2) | dc(q)) >> lowrez()
+def bandrez_q(q): return (multipass(2) | dc(q)) >> bandrez()
+def moog_q(q): return (multipass(2) | dc(q)) >> _leaf("Moog<3>", 3, 1, cutoff=1000.0, q=q)   # prelude32.rs:560
+def morph_hz(f, q, m): return (pass_() | dc(f, q, m)) >> morph()
+def pink(): return white() >> pinkpass()                                              # prelude32.rs:1299
+def brown(): return white() >> lowpole_hz(10.0) * dc(13.7)                            # prelude32.rs:1305
+def dcblock(): return dcblock_hz(10.0)
+def clip(): return shape("clip", 1.0)
+def clip_to(lo, hi): return shape("clip_to", lo, hi)
+def ramp_hz(f): return dc(f) >> ramp()
+def poly_saw_hz(f): return dc(f) >> poly_saw()
+def poly_square_hz(f): return dc(f) >> poly_square()
+def poly_pulse_hz(f, width): return dc(f, width) >> poly_pulse()
+
+
+# waveshapes for the nonlinear biquads: (kind, p0, p1) as in shape()
+def Clip(h=1.0): return ("clip", h, 0.0)
+def ClipTo(lo, hi): return ("clip_to", lo, hi)
+def Tanh(h=1.0): return ("tanh", h, 0.0)
+def Atan(h=1.0): return ("atan", h, 0.0)
+def Softsign(h=1.0): return ("softsign", h, 0.0)
+def Crush(levels): return ("crush", levels, 0.0)
+def SoftCrush(levels): return ("soft_crush", levels, 0.0)
+
+
+def _nlbiquad(dirty, nin, mode, shp, **fields):
+    kind, p0, p1 = shp
+    ps = [((), "mode", float(BQ_KINDS[mode]), False)] + [((), k, v, False) for k, v in fields.items()]
+    for path in ((0,), (1,)) if dirty else ((0,),):
+        ps += [(path, "shape", float(SHAPES[kind]), False), (path, "shape_p0", p0, False), (path, "shape_p1", p1, False)]
+    return Graph(f"NlBiquad<{'true' if dirty else 'false'},{nin}>", nin, 1, ps)
+
+
+# biquad with nonlinear feedback (f..) / nonlinear state shaping (d..)  prelude32.rs:2440-2660
+def fresonator_hz(shp, center, q): return _nlbiquad(False, 1, "resonator", shp, center=center, q=q)
+def flowpass_hz(shp, cutoff, q): return _nlbiquad(False, 1, "lowpass", shp, center=cutoff, q=q)
+def fhighpass_hz(shp, cutoff, q): return _nlbiquad(False, 1, "highpass", shp, center=cutoff, q=q)
+def fbell_hz(shp, center, q, gain): return _nlbiquad(False, 1, "bell", shp, center=center, q=q, gain=gain)
+def dresonator_hz(shp, center, q): return _nlbiquad(True, 1, "resonator", shp, center=center, q=q)
+def dlowpass_hz(shp, cutoff, q): return _nlbiquad(True, 1, "lowpass", shp, center=cutoff, q=q)
+def dhighpass_hz(shp, cutoff, q): return _nlbiquad(True, 1, "highpass", shp, center=cutoff, q=q)
+def dbell_hz(shp, center, q, gain): return _nlbiquad(True, 1, "bell", shp, center=center, q=q, gain=gain)
+def fresonator(shp): return _nlbiquad(False, 3, "resonator", shp)
+def flowpass(shp): return _nlbiquad(False, 3, "lowpass", shp)
+def fhighpass(shp): return _nlbiquad(False, 3, "highpass", shp)
+def fbell(shp): return _nlbiquad(False, 4, "bell", shp)
+def dresonator(shp): return _nlbiquad(True, 3, "resonator", shp)
+def dlowpass(shp): return _nlbiquad(True, 3, "lowpass", shp)
+def dhighpass(shp): return _nlbiquad(True, 3, "highpass", shp)
+def dbell(shp): return _nlbiquad(True, 4, "bell", shp)
 
 
 def uses_wavetables(g):

@@ -42,6 +42,12 @@ struct onode {
     int type, nin, nout;
     uint64_t id;
     onode *x, *y;
+    onode **kids; /* O_MULTI: the N nodes of MultiBus / MultiStack / MultiBranch / Reduce / Chain */
+    int nkids, multi;
+    int jm, jn;   /* Split / Join: M channels, N branches */
+    o_map_fn map_fn;
+    void *map_ctx;
+    float *tmp2;  /* second scratch of Chain::process (audionode.rs:2729) */
     float *tmp; /* [x->nout][64] scratch for Pipe / Binop (BufferArray::uninitialized, audionode.rs:1446) */
     int op;
     float scalar;
@@ -123,6 +129,8 @@ struct onode {
         o_envin_fn envin_fn;
         void *env_ctx;
         float env_v0[O_MAX_ENV], env_v1[O_MAX_ENV], env_val[O_MAX_ENV], env_d[O_MAX_ENV];
+        /* Declick (dynamics.rs:245-250) */
+        float dc_t, dc_duration, dc_sd;
         /* Dsf (oscillator.rs:121-129) */
         float dsf_roughness, dsf_spacing;
         /* Rez (rez.rs:11-21), Follow / AFollow (follow.rs:31-43,137-152), Mls (noise.rs:14-20,103-107) */
@@ -165,6 +173,9 @@ void o_free(onode *n) {
         for (int i = 0; i < 32; i++) free(n->s.rv_buf[i]);
     o_free(n->x);
     o_free(n->y);
+    for (int i = 0; i < n->nkids; i++) o_free(n->kids[i]);
+    free(n->kids);
+    free(n->tmp2);
     free(n->tmp);
     free(n->s.dbuf);
     free(n->s.tbuf);
@@ -537,6 +548,9 @@ static void leaf_reset(onode *n) {
 void o_reset(onode *n) {
     if (n->x) o_reset(n->x); /* Pipe/Stack/Binop/Unop::reset audionode.rs:1430-1433 etc. */
     if (n->y) o_reset(n->y);
+    for (int i = 0; i < n->nkids; i++) o_reset(n->kids[i]);
+    if (n->type == O_IMPULSE) n->s.value[0] = 1.0f; /* audionode.rs:2860-2862 */
+    if (n->type == O_DECLICK) n->s.dc_t = 0.0f;     /* dynamics.rs:268-270 */
     leaf_reset(n);
 }
 
@@ -676,6 +690,8 @@ void o_set_sample_rate(onode *n, double sr) {
     }
     if (n->x) o_set_sample_rate(n->x, sr);
     if (n->y) o_set_sample_rate(n->y, sr);
+    for (int i = 0; i < n->nkids; i++) o_set_sample_rate(n->kids[i], sr);
+    if (n->type == O_DECLICK) n->s.dc_sd = (float)(1.0 / sr); /* dynamics.rs:272-275 */
     leaf_set_sample_rate(n, sr);
 }
 
@@ -700,7 +716,15 @@ static uint64_t o_ping(onode *n, int probe, uint64_t hash) {
     case O_PIPE:
     case O_STACK:
     case O_BINOP:
+    case O_BRANCH: /* audionode.rs:1753-1755 */
+    case O_BUS:    /* audionode.rs:1888-1890 */
         return o_ping(n->y, probe, o_ping(n->x, probe, o_atto(hash, n->id)));
+    case O_MULTI: { /* audionode.rs:2142-2148 and its four siblings */
+        uint64_t h = o_atto(hash, n->id);
+        for (int i = 0; i < n->nkids; i++) h = o_ping(n->kids[i], probe, h);
+        return h;
+    }
+    case O_THRU: /* audionode.rs:2026-2028 */
     case O_UNOP:
     case O_RESAMPLE:   /* resample.rs:308-310 */
     case O_OVERSAMPLE: /* oversample.rs:218-220 */
@@ -1232,6 +1256,82 @@ onode *o_oversample(onode *x) { /* Oversampler::new :90-104 */
     o_set_sample_rate(x, DEFAULT_SR * 2.0);
     uint64_t h = o_ping(x, 1, 51); /* node.ping(true, AttoHash::new(Self::ID)) -- the inner node, not self */
     o_ping(x, 0, h);
+    return n;
+}
+
+onode *o_multipass(int n) { return o_new(O_MULTIPASS, n, n, 0); }
+onode *o_sink(int n) { return o_new(O_SINK, n, 0, 1); }
+onode *o_split(int m, int n) { /* IDs 40 / 38 */
+    onode *s = o_new(O_SPLIT, m, m * n, m == 1 ? 40 : 38);
+    s->jm = m; s->jn = n;
+    return s;
+}
+onode *o_join(int m, int n) { /* IDs 41 / 39 */
+    onode *s = o_new(O_JOIN, m * n, m, m == 1 ? 41 : 39);
+    s->jm = m; s->jn = n;
+    return s;
+}
+onode *o_reverse(int n) { return o_new(O_REVERSE, n, n, 45); }
+onode *o_impulse(int n) { /* Impulse::new audionode.rs:2847-2852 */
+    onode *s = o_new(O_IMPULSE, 0, n, 81);
+    s->s.value[0] = 1.0f;
+    return s;
+}
+onode *o_map(int inputs, int outputs, o_map_fn fn, void *ctx) {
+    onode *s = o_new(O_MAP, inputs, outputs, 5);
+    s->map_fn = fn; s->map_ctx = ctx;
+    return s;
+}
+onode *o_shape_fn(o_map_fn fn, void *ctx) { /* the trait's default simd() is shape() per lane (shape.rs:16-18) */
+    onode *s = o_new(O_MAP, 1, 1, 42);
+    s->map_fn = fn; s->map_ctx = ctx;
+    return s;
+}
+onode *o_declick(float duration) { /* Declick::new dynamics.rs:253-260 */
+    onode *s = o_new(O_DECLICK, 1, 1, 23);
+    s->s.dc_duration = duration;
+    s->s.dc_t = 0.0f;
+    s->s.dc_sd = (float)(1.0 / 44100.0);
+    return s;
+}
+onode *o_branch(onode *x, onode *y) { /* Branch::new audionode.rs:1668-1674, ID 8 */
+    if (x->nin != y->nin) return NULL;
+    onode *n = o_new(O_BRANCH, x->nin, x->nout + y->nout, 8);
+    n->x = x; n->y = y;
+    ctor_ping(n);
+    return n;
+}
+onode *o_bus(onode *x, onode *y) { /* Bus::new audionode.rs:1813-1819, ID 10 */
+    if (x->nin != y->nin || x->nout != y->nout) return NULL;
+    onode *n = o_new(O_BUS, x->nin, x->nout, 10);
+    n->x = x; n->y = y;
+    n->tmp = (float *)calloc((size_t)(x->nout ? x->nout : 1) * MAXB, sizeof(float));
+    ctor_ping(n);
+    return n;
+}
+onode *o_thru(onode *x) { /* Thru::new audionode.rs:1956-1961, ID 12 */
+    onode *n = o_new(O_THRU, x->nin, x->nin, 12);
+    n->x = x;
+    n->tmp = (float *)calloc((size_t)(x->nout ? x->nout : 1) * MAXB, sizeof(float));
+    ctor_ping(n);
+    return n;
+}
+onode *o_multi(int kind, int count, onode **nodes, int op) {
+    static const uint64_t ids[5] = {28, 30, 33, 31, 32};
+    if (count < 1 || kind < 0 || kind > O_MULTI_CHAIN) return NULL;
+    for (int i = 1; i < count; i++)
+        if (nodes[i]->nin != nodes[0]->nin || nodes[i]->nout != nodes[0]->nout) return NULL;
+    int xi = nodes[0]->nin, xo = nodes[0]->nout;
+    if (kind == O_MULTI_CHAIN && xi != xo) return NULL;
+    int nin = (kind == O_MULTI_STACK || kind == O_MULTI_REDUCE) ? xi * count : xi;
+    int nout = (kind == O_MULTI_STACK || kind == O_MULTI_BRANCH) ? xo * count : xo;
+    onode *n = o_new(O_MULTI, nin, nout, ids[kind]);
+    n->multi = kind; n->op = op; n->nkids = count;
+    n->kids = (onode **)calloc((size_t)count, sizeof(onode *));
+    for (int i = 0; i < count; i++) n->kids[i] = nodes[i];
+    n->tmp = (float *)calloc((size_t)(xo ? xo : 1) * MAXB, sizeof(float));
+    n->tmp2 = (float *)calloc((size_t)(xo ? xo : 1) * MAXB, sizeof(float));
+    ctor_ping(n);
     return n;
 }
 
@@ -1882,6 +1982,78 @@ void o_tick(onode *n, const float *in, float *out) {
         o_tick(n->y, in + n->x->nin, out);
         for (int i = 0; i < n->nout; i++) out[i] = binop_apply(n->op, t[i], out[i]);
         break;
+    case O_MULTIPASS: for (int i = 0; i < n->nout; i++) out[i] = in[i]; break; /* audionode.rs:388-390 */
+    case O_SINK: break;
+    case O_SPLIT: for (int i = 0; i < n->nout; i++) out[i] = in[i % n->jm]; break; /* :551-553, :597-599 */
+    case O_JOIN: /* :638-644, :700-708: sum, then divide */
+        for (int j = 0; j < n->jm; j++) {
+            float o = in[j];
+            for (int i = 1; i < n->jn; i++) o += in[j + i * n->jm];
+            out[j] = o / (float)n->jn;
+        }
+        break;
+    case O_REVERSE: for (int i = 0; i < n->nout; i++) out[i] = in[n->nout - 1 - i]; break; /* :2823-2825 */
+    case O_IMPULSE: /* :2864-2868 */
+        for (int i = 0; i < n->nout; i++) out[i] = n->s.value[0];
+        n->s.value[0] = 0.0f;
+        break;
+    case O_MAP: n->map_fn(in, out, n->map_ctx); break; /* :1363-1365 */
+    case O_DECLICK: /* dynamics.rs:278-287 */
+        if (n->s.dc_t < n->s.dc_duration) {
+            float phase = (n->s.dc_t - 0.0f) / (n->s.dc_duration - 0.0f);
+            float value = ((phase * 6.0f - 15.0f) * phase + 10.0f) * phase * phase * phase;
+            n->s.dc_t += n->s.dc_sd;
+            out[0] = in[0] * value;
+        } else {
+            out[0] = in[0];
+        }
+        break;
+    case O_BRANCH: /* :1716-1726 */
+        o_tick(n->x, in, out);
+        o_tick(n->y, in, out + n->x->nout);
+        break;
+    case O_BUS: /* :1861-1865 */
+        o_tick(n->x, in, out);
+        o_tick(n->y, in, t);
+        for (int i = 0; i < n->nout; i++) out[i] = out[i] + t[i];
+        break;
+    case O_THRU: /* :1977-1986 */
+        o_tick(n->x, in, t);
+        for (int i = 0; i < n->nout; i++) out[i] = i < n->x->nout ? t[i] : in[i];
+        break;
+    case O_MULTI: {
+        int xi = n->kids[0]->nin, xo = n->kids[0]->nout;
+        switch (n->multi) {
+        case O_MULTI_BUS: /* :2117-2121: fold from a zero frame */
+            for (int c = 0; c < xo; c++) out[c] = 0.0f;
+            for (int i = 0; i < n->nkids; i++) {
+                o_tick(n->kids[i], in, t);
+                for (int c = 0; c < xo; c++) out[c] = out[c] + t[c];
+            }
+            break;
+        case O_MULTI_STACK: /* :2282-2291 */
+            for (int i = 0; i < n->nkids; i++) o_tick(n->kids[i], in + i * xi, out + i * xo);
+            break;
+        case O_MULTI_BRANCH: /* :2590-2598 */
+            for (int i = 0; i < n->nkids; i++) o_tick(n->kids[i], in, out + i * xo);
+            break;
+        case O_MULTI_REDUCE: /* :2430-2442 */
+            o_tick(n->kids[0], in, out);
+            for (int i = 1; i < n->nkids; i++) {
+                o_tick(n->kids[i], in + i * xi, t);
+                for (int c = 0; c < xo; c++) out[c] = binop_apply(n->op, out[c], t[c]);
+            }
+            break;
+        case O_MULTI_CHAIN: /* :2728-2734 */
+            o_tick(n->kids[0], in, out);
+            for (int i = 1; i < n->nkids; i++) {
+                for (int c = 0; c < xo; c++) t[c] = out[c];
+                o_tick(n->kids[i], t, out);
+            }
+            break;
+        }
+        break;
+    }
     case O_UNOP: /* audionode.rs:1268-1270 */
         o_tick(n->x, in, out);
         for (int i = 0; i < n->nout; i++) out[i] = unop_apply(n->op, out[i], n->scalar);
@@ -1987,6 +2159,102 @@ void o_process(onode *n, int size, const float *in, float *out) {
             for (int i = 0; i < simd_items(size) * 8; i++)
                 out[c * MAXB + i] = binop_apply(n->op, n->tmp[c * MAXB + i], out[c * MAXB + i]);
         break;
+    case O_MULTIPASS: /* audionode.rs:391-397 */
+    case O_SPLIT:     /* :554-560, :600-606 */
+    case O_REVERSE:   /* :2826-2832 */
+        for (int c = 0; c < n->nout; c++) {
+            int src = n->type == O_MULTIPASS ? c : n->type == O_SPLIT ? c % n->jm : n->nout - 1 - c;
+            for (int i = 0; i < simd_items(size) * 8; i++) out[c * MAXB + i] = in[src * MAXB + i];
+        }
+        break;
+    case O_SINK: break; /* :454 */
+    case O_DECLICK: { /* dynamics.rs:289-307 */
+        for (int i = 0; i < simd_items(size) * 8; i++) out[i] = in[i];
+        if (n->s.dc_t < n->s.dc_duration) {
+            float phase = (n->s.dc_t - 0.0f) / (n->s.dc_duration - 0.0f);
+            float phase_d = n->s.dc_sd / n->s.dc_duration;
+            float end_time = n->s.dc_t + (float)(long long)size * n->s.dc_sd;
+            int end_index = n->s.dc_duration < end_time
+                                ? (int)(long long)ceilf((n->s.dc_duration - n->s.dc_t) / n->s.dc_sd) : size;
+            if (end_index > MAXB) end_index = MAXB; /* the reference would panic on the slice */
+            for (int i = 0; i < end_index; i++) {
+                out[i] *= ((phase * 6.0f - 15.0f) * phase + 10.0f) * phase * phase * phase;
+                phase += phase_d;
+            }
+            n->s.dc_t = end_time;
+        }
+        break;
+    }
+    case O_JOIN: { /* :649-659, :710-724: every term scaled by z = 1/N, then summed */
+        float z = 1.0f / (float)n->jn;
+        for (int c = 0; c < n->jm; c++)
+            for (int i = 0; i < simd_items(size) * 8; i++) out[c * MAXB + i] = in[c * MAXB + i] * z;
+        for (int c = n->jm; c < n->jm * n->jn; c++)
+            for (int i = 0; i < simd_items(size) * 8; i++) out[(c % n->jm) * MAXB + i] += in[c * MAXB + i] * z;
+        break;
+    }
+    case O_BRANCH: /* :1728-1736 */
+        o_process(n->x, size, in, out);
+        o_process(n->y, size, in, out + n->x->nout * MAXB);
+        break;
+    case O_BUS: /* :1867-1876 */
+        o_process(n->x, size, in, out);
+        o_process(n->y, size, in, n->tmp);
+        for (int c = 0; c < n->nout; c++)
+            for (int i = 0; i < simd_items(size) * 8; i++) out[c * MAXB + i] += n->tmp[c * MAXB + i];
+        break;
+    case O_THRU: /* :1988-2011 */
+        if (n->nin == 0) break;
+        if (n->x->nin < n->x->nout) {
+            o_process(n->x, size, in, n->tmp);
+            for (int c = 0; c < n->nin; c++)
+                for (int i = 0; i < simd_items(size) * 8; i++) out[c * MAXB + i] = n->tmp[c * MAXB + i];
+        } else {
+            o_process(n->x, size, in, out);
+            for (int c = n->x->nout; c < n->nin; c++)
+                for (int i = 0; i < simd_items(size) * 8; i++) out[c * MAXB + i] = in[c * MAXB + i];
+        }
+        break;
+    case O_MULTI: {
+        int xi = n->kids[0]->nin, xo = n->kids[0]->nout, items = simd_items(size) * 8;
+        switch (n->multi) {
+        case O_MULTI_BUS: /* :2123-2134 */
+            o_process(n->kids[0], size, in, out);
+            for (int k = 1; k < n->nkids; k++) {
+                o_process(n->kids[k], size, in, n->tmp);
+                for (int c = 0; c < xo; c++)
+                    for (int i = 0; i < items; i++) out[c * MAXB + i] += n->tmp[c * MAXB + i];
+            }
+            break;
+        case O_MULTI_STACK: /* :2293-2305 */
+            for (int k = 0; k < n->nkids; k++) o_process(n->kids[k], size, in + k * xi * MAXB, out + k * xo * MAXB);
+            break;
+        case O_MULTI_BRANCH: /* :2600-2610 */
+            for (int k = 0; k < n->nkids; k++) o_process(n->kids[k], size, in, out + k * xo * MAXB);
+            break;
+        case O_MULTI_REDUCE: /* :2443-2464 */
+            o_process(n->kids[0], size, in, out);
+            for (int k = 1; k < n->nkids; k++) {
+                o_process(n->kids[k], size, in + k * xi * MAXB, n->tmp);
+                for (int c = 0; c < xo; c++)
+                    for (int i = 0; i < items; i++)
+                        out[c * MAXB + i] = binop_apply(n->op, out[c * MAXB + i], n->tmp[c * MAXB + i]);
+            }
+            break;
+        case O_MULTI_CHAIN: { /* :2736-2750: ping-pong between the output and one scratch buffer */
+            float *a = n->tmp, *b = n->tmp2;
+            o_process(n->kids[0], size, in, a);
+            for (int k = 1; k < n->nkids; k++) {
+                o_process(n->kids[k], size, a, b);
+                float *sw = a; a = b; b = sw;
+            }
+            for (int c = 0; c < xo; c++)
+                for (int i = 0; i < items; i++) out[c * MAXB + i] = a[c * MAXB + i];
+            break;
+        }
+        }
+        break;
+    }
     case O_UNOP: /* audionode.rs:1273-1280 */
         o_process(n->x, size, in, out);
         for (int c = 0; c < n->nout; c++)

@@ -18,7 +18,8 @@ enum {
     O_CONSTANT = 0, O_PASS, O_SINE, O_NOISE, O_SVF, O_FIXED_SVF, O_BIQUAD, O_BUTTER_LOWPASS, O_RESONATOR,
     O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP,
     O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO, O_SHAPER, O_PHASE_OSC, O_CHAOS, O_NLBIQUAD, O_TAP, O_ALLNEST,
-    O_ONEPOLE, O_PINKPASS, O_MORPH, O_REZ, O_FOLLOW, O_AFOLLOW, O_MLS, O_OVERSAMPLE, O_DSF, O_PLUCK, O_ENVELOPE, O_RESAMPLE, O_ENVELOPE_IN
+    O_ONEPOLE, O_PINKPASS, O_MORPH, O_REZ, O_FOLLOW, O_AFOLLOW, O_MLS, O_OVERSAMPLE, O_DSF, O_PLUCK, O_ENVELOPE, O_RESAMPLE, O_ENVELOPE_IN,
+    O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK
 };
 enum { O_OP_LOWPOLE = 0, O_OP_HIGHPOLE, O_OP_DCBLOCK, O_OP_ALLPOLE };
 enum { O_SH_CLIP = 0, O_SH_CLIPTO, O_SH_TANH, O_SH_ATAN, O_SH_SOFTSIGN, O_SH_CRUSH, O_SH_SOFTCRUSH, O_SH_ADAPTIVE_TANH };
@@ -94,6 +95,24 @@ onode *o_reverb_stereo(double room_size, double time, double damping);
 void o_reverb_stereo_params(double room_size, double time, double damping, double sample_rate, float *w3, int *delays32,
                             float *wl32, float *wr32);
 /* combinators (take ownership of children) */
+/* routing leaves and the remaining combinators (audionode.rs) */
+onode *o_multipass(int n);                 /* MultiPass<N> :373 */
+onode *o_sink(int n);                      /* Sink<N> :437 */
+onode *o_split(int m, int n);              /* Split<N> (m == 1, :527) / MultiSplit<M, N> (:571) */
+onode *o_join(int m, int n);               /* Join<N> (m == 1, :617) / MultiJoin<M, N> (:668) */
+onode *o_reverse(int n);                   /* Reverse<N> :2808 */
+onode *o_impulse(int n);                   /* Impulse<N> :2841 */
+typedef void (*o_map_fn)(const float *in, float *out, void *ctx);
+onode *o_map(int inputs, int outputs, o_map_fn fn, void *ctx); /* Map<M, I, O> :1330 */
+onode *o_shape_fn(o_map_fn fn, void *ctx);  /* Shaper<ShapeFn<S>> shape.rs:35,205 (ID 42): fn maps in[0] -> out[0] */
+onode *o_declick(float duration);          /* Declick<f32> dynamics.rs:245 */
+onode *o_branch(onode *x, onode *y);       /* Branch :1653 */
+onode *o_bus(onode *x, onode *y);          /* Bus :1796 */
+onode *o_thru(onode *x);                   /* Thru :1951 */
+enum { O_MULTI_BUS = 0, O_MULTI_STACK, O_MULTI_BRANCH, O_MULTI_REDUCE, O_MULTI_CHAIN };
+/* MultiBus :2065 / MultiStack :2211 / MultiBranch :2532 / Reduce :2366 (op = O_ADD..O_MUL) / Chain :2673; takes
+ * ownership of the n nodes, which must have equal arities */
+onode *o_multi(int kind, int n, onode **nodes, int op);
 onode *o_pipe(onode *x, onode *y);
 onode *o_stack(onode *x, onode *y);
 onode *o_binop(int op, onode *x, onode *y);

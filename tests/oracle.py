@@ -82,6 +82,10 @@ def lib():
         "o_shaper": (P, [i, f, f]), "o_phase_osc": (P, [i]), "o_osc_set_phase": (None, [P, f]), "o_chaos": (P, [i]),
         "o_nlbiquad": (P, [i, i, i, i, f, f, f, f, f]), "o_math_atanf": (f, [f]), "o_math_wide_atanf": (f, [f]),
         "o_adaptive_smoothing": (d, [f, d]),
+        "o_multipass": (P, [i]), "o_sink": (P, [i]), "o_split": (P, [i, i]), "o_join": (P, [i, i]),
+        "o_reverse": (P, [i]), "o_impulse": (P, [i]), "o_map": (P, [i, i, P, P]),
+        "o_shape_fn": (P, [P, P]), "o_declick": (P, [f]),
+        "o_branch": (P, [P, P]), "o_bus": (P, [P, P]), "o_thru": (P, [P]), "o_multi": (P, [i, i, C.POINTER(P), i]),
         "o_reverb_stereo": (P, [d, d, d]),
         "o_reverb_stereo_params": (None, [d, d, d, d, fp, C.POINTER(C.c_int), fp, fp]),
     }
@@ -157,6 +161,9 @@ class Node:
     # --- graph notation (combinator.rs:289-488)
     def __rshift__(self, other): return Node(lib().o_pipe(self.ptr, other.ptr), (self, other))
     def __or__(self, other): return Node(lib().o_stack(self.ptr, other.ptr), (self, other))
+    def __and__(self, other): return Node(lib().o_bus(self.ptr, other.ptr), (self, other))      # `&` combinator.rs:447
+    def __xor__(self, other): return Node(lib().o_branch(self.ptr, other.ptr), (self, other))   # `^` combinator.rs:426
+    def __invert__(self): return Node(lib().o_thru(self.ptr), (self,))                          # `!` combinator.rs:404
 
     def _bin(self, other, op, uop, scalar=None):
         if isinstance(other, Node):
@@ -195,7 +202,76 @@ def constant(*v):
 
 
 dc = constant
+def zero(): return constant(0.0)                                   # prelude32.rs:129
 def pass_(): return Node(lib().o_pass())
+def multipass(n): return Node(lib().o_multipass(n))               # prelude32.rs:147
+def sink(): return Node(lib().o_sink(1))                           # prelude32.rs:170
+def multisink(n): return Node(lib().o_sink(n))
+def split(n): return Node(lib().o_split(1, n))                     # prelude32.rs:1103
+def multisplit(m, n): return Node(lib().o_split(m, n))
+def join(n): return Node(lib().o_join(1, n))                       # prelude32.rs:1130
+def multijoin(m, n): return Node(lib().o_join(m, n))
+def reverse(n): return Node(lib().o_reverse(n))                    # prelude32.rs:190
+def impulse(n=1): return Node(lib().o_impulse(n))                  # prelude32.rs:2480
+def thru(x): return ~x
+def bus(x, y): return x & y
+def branch(x, y): return x ^ y
+def stack(x, y): return x | y
+def pipe(x, y): return x >> y
+def sum_(x, y): return x + y
+def product(x, y): return x * y
+def add(*x): return multipass(len(x)) + dc(*x)                    # prelude32.rs:391: MultiPass + dc(x)
+def sub(*x): return multipass(len(x)) - dc(*x)                    # prelude32.rs:409
+def mul(*x): return multipass(len(x)) * dc(*x)                    # prelude32.rs:427
+
+
+MAP_FN = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
+
+
+def map_(fn, inputs, outputs=1):                                   # prelude32.rs:332 map / shape_fn :1322
+    """fn(frame: np.float32[inputs]) -> float or sequence of `outputs` floats plays the Rust closure (use np.float32
+    arithmetic and the oracle's own libm inside it)."""
+    def cb(inp, out, _ctx):
+        r = fn(np.array([inp[k] for k in range(inputs)], dtype=np.float32))
+        r = [r] if np.isscalar(r) else list(r)
+        for k in range(outputs):
+            out[k] = float(np.float32(r[k]))
+    c = MAP_FN(cb)
+    n = Node(lib().o_map(inputs, outputs, C.cast(c, C.c_void_p), None))
+    n._callback = c
+    return n
+
+
+def shape_fn(fn):                                                 # prelude32.rs:1181: Shaper<ShapeFn<S>>
+    def cb(inp, out, _ctx):
+        out[0] = float(np.float32(fn(np.float32(inp[0]))))
+    c = MAP_FN(cb)
+    n = Node(lib().o_shape_fn(C.cast(c, C.c_void_p), None))
+    n._callback = c
+    return n
+
+
+def declick(): return Node(lib().o_declick(0.010))                # prelude32.rs:1167
+def declick_s(t): return Node(lib().o_declick(t))                 # prelude32.rs:1174
+
+
+def _multi(kind, nodes, op=0):
+    nodes = list(nodes)
+    arr = (C.c_void_p * len(nodes))(*[n.ptr for n in nodes])
+    return Node(lib().o_multi(kind, len(nodes), arr, op), nodes)
+
+
+def busi(n, f): return _multi(0, [f(i) for i in range(n)])        # prelude32.rs busi/busf: MultiBus
+def stacki(n, f): return _multi(1, [f(i) for i in range(n)])      # MultiStack
+def branchi(n, f): return _multi(2, [f(i) for i in range(n)])     # MultiBranch
+def sumi(n, f): return _multi(3, [f(i) for i in range(n)], ADD)   # Reduce<.., FrameAdd>
+def pipei(n, f): return _multi(4, [f(i) for i in range(n)])       # Chain
+def _frac(n, i): return np.float32(i / (n - 1)) if n > 1 else np.float32(0.5)              # prelude.rs busf etc.: closure of i / (n - 1)
+def busf(n, f): return busi(n, lambda i: f(_frac(n, i)))
+def stackf(n, f): return stacki(n, lambda i: f(_frac(n, i)))
+def branchf(n, f): return branchi(n, lambda i: f(_frac(n, i)))
+def sumf(n, f): return sumi(n, lambda i: f(_frac(n, i)))
+def pipef(n, f): return pipei(n, lambda i: f(_frac(n, i)))
 def sine(): return Node(lib().o_sine())
 def sine_hz(f): return constant(f) >> sine()                       # prelude.rs:349
 def noise(): return Node(lib().o_noise())
@@ -216,6 +292,7 @@ def biquad(a1, a2, b0, b1, b2): return Node(lib().o_biquad(a1, a2, b0, b1, b2))
 def butterpass_hz(f): return Node(lib().o_butter_lowpass(1, f))
 def butterpass(): return Node(lib().o_butter_lowpass(2, 440.0))
 def resonator_hz(center, bandwidth): return Node(lib().o_resonator(1, center, bandwidth))  # prelude32.rs:534: passed straight to Resonator::new
+def resonator(): return Node(lib().o_resonator(3, 440.0, 110.0))   # prelude32.rs:521: Resonator::new(440, 110), 3 inputs
 def biquad_bank(): return Node(lib().o_biquad_bank())
 def moog_hz(f, q): return Node(lib().o_moog(1, f, q))
 def moog(): return Node(lib().o_moog(3, 1000.0, 0.1))             # prelude.rs:551-553
@@ -390,6 +467,47 @@ def lorenz(): return Node(lib().o_chaos(1))
 def nlbiquad(dirty, inputs, mode, shape_kind, p0=1.0, p1=0.0, center=440.0, q=1.0, gain=1.0):
     """dbell_hz(Tanh(1.0), 1000, 10, 2) == nlbiquad(True, 1, "bell", "tanh", 1.0, 0, 1000, 10, 2) etc. (prelude.rs:2912-3100)"""
     return Node(lib().o_nlbiquad(int(dirty), inputs, BQ_KINDS[mode], SHAPES[shape_kind], p0, p1, center, q, gain))
+
+
+# waveshapes, and the opcodes the prelude composes from others (same spelling as fundsp_amd.graph)
+def Clip(h=1.0): return ("clip", h, 0.0)
+def ClipTo(lo, hi): return ("clip_to", lo, hi)
+def Tanh(h=1.0): return ("tanh", h, 0.0)
+def Atan(h=1.0): return ("atan", h, 0.0)
+def Softsign(h=1.0): return ("softsign", h, 0.0)
+def Crush(levels): return ("crush", levels, 0.0)
+def SoftCrush(levels): return ("soft_crush", levels, 0.0)
+def fresonator_hz(s, center, q): return nlbiquad(False, 1, "resonator", s[0], s[1], s[2], center, q)     # prelude32.rs:2653
+def flowpass_hz(s, cutoff, q): return nlbiquad(False, 1, "lowpass", s[0], s[1], s[2], cutoff, q)         # :2593
+def fhighpass_hz(s, cutoff, q): return nlbiquad(False, 1, "highpass", s[0], s[1], s[2], cutoff, q)       # :2545
+def fbell_hz(s, center, q, gain): return nlbiquad(False, 1, "bell", s[0], s[1], s[2], center, q, gain)   # :2496
+def dresonator_hz(s, center, q): return nlbiquad(True, 1, "resonator", s[0], s[1], s[2], center, q)      # :2623
+def dlowpass_hz(s, cutoff, q): return nlbiquad(True, 1, "lowpass", s[0], s[1], s[2], cutoff, q)          # :2569
+def dhighpass_hz(s, cutoff, q): return nlbiquad(True, 1, "highpass", s[0], s[1], s[2], cutoff, q)        # :2521
+def dbell_hz(s, center, q, gain): return nlbiquad(True, 1, "bell", s[0], s[1], s[2], center, q, gain)    # :2469
+def _svf_q(mode, q): return (multipass(2) | dc(q)) >> svf(mode, 440.0, q)                                # prelude.rs:2127-2140
+def lowpass_q(q): return _svf_q("lowpass", q)
+def highpass_q(q): return _svf_q("highpass", q)
+def bandpass_q(q): return _svf_q("bandpass", q)
+def notch_q(q): return _svf_q("notch", q)
+def peak_q(q): return _svf_q("peak", q)
+def allpass_q(q): return _svf_q("allpass", q)
+def bell_q(q, gain): return (multipass(2) | dc(q, gain)) >> svf("bell", 440.0, q, gain)                  # prelude.rs:2425-2446
+def lowshelf_q(q, gain): return (multipass(2) | dc(q, gain)) >> svf("lowshelf", 440.0, q, gain)
+def highshelf_q(q, gain): return (multipass(2) | dc(q, gain)) >> svf("highshelf", 440.0, q, gain)
+def lowrez_q(q): return (multipass(2) | dc(q)) >> lowrez()                                               # prelude32.rs:2168
+def bandrez_q(q): return (multipass(2) | dc(q)) >> bandrez()
+def moog_q(q): return (multipass(2) | dc(q)) >> Node(lib().o_moog(3, 1000.0, q))                         # prelude32.rs:560
+def morph_hz(f, q, m): return (pass_() | dc(f, q, m)) >> morph()                                         # prelude32.rs:2218
+def pink(): return white() >> pinkpass()                                                                 # prelude32.rs:1299
+def brown(): return white() >> lowpole_hz(10.0) * dc(13.7)                                               # prelude32.rs:1305
+def dcblock(): return dcblock_hz(10.0)                                                                   # prelude32.rs:1160
+def clip(): return shape("clip", 1.0)                                                                    # prelude32.rs:1201
+def clip_to(lo, hi): return shape("clip_to", lo, hi)
+def ramp_hz(f): return dc(f) >> ramp()
+def poly_saw_hz(f): return dc(f) >> poly_saw()
+def poly_square_hz(f): return dc(f) >> poly_square()
+def poly_pulse_hz(f, width): return dc(f, width) >> poly_pulse()
 
 
 def reverb_stereo(room_size, time, damping): return Node(lib().o_reverb_stereo(room_size, time, damping))  # prelude.rs:1732

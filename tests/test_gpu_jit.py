@@ -45,6 +45,19 @@ GRAPHS = {
     "saw_filter_env": (lambda m: (m.saw_hz(82.4) >> m.lowpass_hz(900.0, 3.0)) * (m.pass_() >> m.adsr_live(0.002, 0.01, 0.5, 0.005)), 1, 0),
     "chorus_tap": (lambda m: (m.pass_() | m.sine_hz(1.3) * 0.001 + 0.003) >> m.tap(0.001, 0.005), 1, 512),
     "pulse_resonator": (lambda m: (m.dc(140.0, 0.3) >> m.poly_pulse()) >> m.resonator_hz(700.0, 40.0) >> m.pan(-0.4), 0, 0),
+    # Bus `&`, Branch `^`, Thru `!`, Sink, routing leaves, the N-fold closure forms, Declick, the composed opcodes
+    "bus_branch_thru": (lambda m: (m.sine_hz(440.0) & m.sine_hz(220.0)) >> (m.pass_() ^ m.lowpole_hz(100.0)) >> (~m.sink() | m.pass_()), 0, 0),
+    "split_join": (lambda m: (m.noise() | m.noise()) >> m.multisplit(2, 3) >> m.multijoin(2, 3) >> m.reverse(2) >> m.join(2) >> m.split(3) >> m.join(3), 0, 0),
+    "busi_sines": (lambda m: m.busi(4, lambda i: m.sine_hz(100.0 * (i + 1))) * 0.25, 0, 0),
+    "stacki_sumi": (lambda m: m.stacki(3, lambda i: m.sine_hz(100.0 * (i + 1))) >> m.sumi(3, lambda i: m.lowpole_hz(100.0 + i)), 0, 0),
+    "branchf_filters": (lambda m: m.branchf(3, lambda t: m.lowpass_hz(500.0 + 1500.0 * float(t), 1.0)) >> m.join(3), 1, 0),
+    "pipei_poles": (lambda m: m.noise() >> m.pipei(4, lambda i: m.lowpole_hz(1000.0 + 100.0 * i)), 0, 0),
+    "busf_resonators": (lambda m: m.busf(5, lambda t: (m.noise() | m.dc(200.0 + 900.0 * float(t), 20.0)) >> ~m.resonator() >> m.resonator()), 0, 0),
+    "impulse_declick": (lambda m: (m.impulse() + m.noise()) >> m.declick_s(0.004), 0, 0),
+    "svf_q_forms": (lambda m: (m.pass_() | m.sine_hz(2.0) * 300.0 + 1000.0) >> (m.lowpass_q(2.0) ^ m.bell_q(1.5, 2.0)) >> (m.pass_() - m.pass_()), 1, 0),
+    "brown_pink": (lambda m: m.brown() & m.pink(), 0, 0),
+    "nl_biquads": (lambda m: m.fresonator_hz(m.Tanh(1.0), 500.0, 2.0) >> m.dlowpass_hz(m.Softsign(0.9), 800.0, 1.0) >> m.clip_to(-0.5, 0.5), 1, 0),
+    "moog_q_thru_cut": (lambda m: (m.pass_() | m.dc(800.0)) >> m.moog_q(0.5) >> m.clip() >> m.split(2) >> ~(m.sink() | m.sink()) >> m.join(2), 1, 0),
 }
 
 
@@ -75,6 +88,34 @@ def test_jit_graph_matches_oracle(gpu, name):
             n.set_sample_rate(SR)
             n.set_seed(int(seeds[v]))
             assert_bit_equal(got[v], oracle_render(n, None if x is None else x[v], T, mode), f"{name} voice {v} mode {mode}")
+
+
+def test_jit_map_and_shape_fn_closures(gpu):
+    """map(|i| ..) (audionode.rs:1330, prelude32.rs:332) and shape_fn(|x| ..) (shape.rs:35): the Rust closure arrives as
+    a C++ functor with the graph; the oracle plays it through a callback with the same f32 arithmetic."""
+    src = """
+struct MidSide {  // map(|i: &Frame<f32, U2>| (i[0] + i[1], i[0] - i[1], i[0] * i[1]))
+    static FD_HD void f(const float* in, float* out) { out[0] = in[0] + in[1]; out[1] = in[0] - in[1]; out[2] = in[0] * in[1]; }
+};
+struct SoftFold {  // shape_fn(|x| x / (1.0 + x * x) + tanh(x))
+    static FD_HD float f(float x) { return x / (1.0f + x * x) + tanhf_musl(x); }
+};
+"""
+    f32 = np.float32
+    g = (GR.noise() | GR.sine_hz(330.0)) >> GR.map_("MidSide", src, 2, 3) >> (GR.shape_fn("SoftFold", src) | GR.pass_() | GR.lowpole_hz(900.0))
+    n0 = lambda: ((O.noise() | O.sine_hz(330.0)) >> O.map_(lambda i: (i[0] + i[1], i[0] - i[1], i[0] * i[1]), 2, 3)
+                  >> (O.shape_fn(lambda x: x / (f32(1.0) + x * x) + f32(O.lib().o_math_tanhf(float(x)))) | O.pass_() | O.lowpole_hz(900.0)))
+    V, T = 40, 64 * 3 + 13
+    seeds = np.arange(V, dtype=np.uint64) * 31 + 5
+    for mode in (MODE_PROCESS, MODE_TICK):
+        b = gpu.Bank.from_graph(g, V, sample_rate=SR)
+        b.set_seed(seeds)
+        got = run_bank(b, None, T, LAYOUT_VOICE_MINOR, mode)
+        for v in (0, 39):
+            n = n0()
+            n.set_sample_rate(SR)
+            n.set_seed(int(seeds[v]))
+            assert_bit_equal(got[v], oracle_render(n, None, T, mode), f"map/shape_fn voice {v} mode {mode}")
 
 
 def test_jit_type_errors_are_reported(gpu):
