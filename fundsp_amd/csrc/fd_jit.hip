@@ -112,8 +112,12 @@ int jit_compile_code(const std::string& type_expr, const std::string& prelude, s
         return -1;
     }
     // same code-generation flags as the ahead-of-time kinds (see Makefile for -fno-slp-vectorize)
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"};
-    hiprtcResult r = hiprtcCompileProgram(prog, 6, opts);
+    // a graph with a Feedback node renders with f32 denormals flushed, like the reference after Feedback::new's
+    // prevent_denormals() (feedback.rs:96, denormal.rs:18)
+    const bool ftz = type_expr.find("Feedback") != std::string::npos;
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+                          "-fgpu-flush-denormals-to-zero"};
+    hiprtcResult r = hiprtcCompileProgram(prog, ftz ? 7 : 6, opts);
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);
     if (ls > 1) {

@@ -2721,6 +2721,92 @@ struct Thru {
     }
 };
 
+// Feedback<N, X, U>  feedback.rs:71-190 (ID 11) and Feedback2<N, X, Y, U> :193-330 (ID 66): the enclosed node's output
+// (through Y for Feedback2), passed through the feedback operator U, is added to the next sample's input.
+// U = FrameId (feedback(), feedback2()) or FrameHadamard (fdn(), fdn2(); :35-57: in-place butterflies h = 1, 2, 4, ..
+// then a scale by (1 / sqrt(N)) as f32).  process is the tick loop (:136-146, :277-287): the enclosed nodes always run
+// their tick arithmetic.  Feedback::new calls prevent_denormals() (:96, denormal.rs:18), so a graph with a Feedback
+// node is compiled with f32 denormals flushed (fd_jit.hip), like the FDN reverb kernel.
+struct FbId {
+    template <int N> static FD_HD void f(float*) {}
+};
+struct FbHadamard {
+    template <int N> static FD_HD void f(float* o) {
+        static_assert((N & (N - 1)) == 0, "fdn: the channel count must be a power of two");
+        _Pragma("unroll") for (int h = 1; h < N; h *= 2)
+            _Pragma("unroll") for (int i = 0; i < N; i += h * 2)
+                _Pragma("unroll") for (int j = i; j < i + h; j++) {
+                    const float a = o[j], b = o[j + h];
+                    o[j] = a + b;
+                    o[j + h] = a - b;
+                }
+        const float z = (float)(1.0 / __builtin_sqrt((double)N));
+        _Pragma("unroll") for (int i = 0; i < N; i++) o[i] = o[i] * z;
+    }
+};
+
+template <class X, class U>
+struct Feedback {
+    static_assert(X::IN == X::OUT, "feedback: the enclosed node needs as many outputs as inputs");
+    static constexpr int IN = X::IN, OUT = X::OUT, RINGS = X::RINGS;
+    static constexpr uint64_t ID = 11;
+    static constexpr bool FLUSHES_DENORMALS = true;
+    X x;
+    float value[OUT];
+    template <class V> FD_HD void visit(V& v) {
+        v.enter(0); x.visit(v); v.leave();
+        _Pragma("unroll") for (int i = 0; i < OUT; i++) v.fi(value[i], STATE, "value", i);
+    }
+    FD_HD void init() { x.init(); for (int i = 0; i < OUT; i++) value[i] = 0.0f; }
+    FD_HD void update(double sr) { x.update(sr); }
+    FD_HD void reset() { x.reset(); for (int i = 0; i < OUT; i++) value[i] = 0.0f; }
+    FD_HD uint64_t ping(bool probe, uint64_t h) { return x.ping(probe, atto(h, ID)); }  // :152-154
+    FD_HD void end_simd() {}
+    FD_HD void begin_block(int) {}
+    FD_HD void bind(Ctx& a) { x.bind(a); }
+    FD_HD bool tripped() const { return false; }
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        float t[OUT];
+        for (int i = 0; i < OUT; i++) t[i] = in[i] + value[i];
+        x.template step<PH_TICK>(t, out);
+        for (int i = 0; i < OUT; i++) value[i] = out[i];
+        U::template f<OUT>(value);
+    }
+    FD_STEP2_VIA_STEP
+};
+
+template <class X, class Y, class U>
+struct Feedback2 {
+    static_assert(X::IN == X::OUT && Y::IN == X::OUT && Y::OUT == X::OUT, "feedback2: arity mismatch");
+    static constexpr int IN = X::IN, OUT = X::OUT, RINGS = X::RINGS + Y::RINGS;
+    static constexpr uint64_t ID = 66;
+    static constexpr bool FLUSHES_DENORMALS = true;
+    X x;
+    Y y;
+    float value[OUT];
+    template <class V> FD_HD void visit(V& v) {
+        v.enter(0); x.visit(v); v.leave();
+        v.enter(1); y.visit(v); v.leave();
+        _Pragma("unroll") for (int i = 0; i < OUT; i++) v.fi(value[i], STATE, "value", i);
+    }
+    FD_HD void init() { x.init(); y.init(); for (int i = 0; i < OUT; i++) value[i] = 0.0f; }
+    FD_HD void update(double sr) { x.update(sr); y.update(sr); }
+    FD_HD void reset() { x.reset(); y.reset(); for (int i = 0; i < OUT; i++) value[i] = 0.0f; }
+    FD_HD uint64_t ping(bool probe, uint64_t h) { return y.ping(probe, x.ping(probe, atto(h, ID))); }  // :293-295
+    FD_HD void end_simd() {}
+    FD_HD void begin_block(int) {}
+    FD_HD void bind(Ctx& a) { x.bind(a); y.bind(a); }
+    FD_HD bool tripped() const { return false; }
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        float t[OUT];
+        for (int i = 0; i < OUT; i++) t[i] = in[i] + value[i];
+        x.template step<PH_TICK>(t, out);
+        y.template step<PH_TICK>(out, value);
+        U::template f<OUT>(value);
+    }
+    FD_STEP2_VIA_STEP
+};
+
 // N-fold combinators over N nodes of ONE type (the closure forms busi/stacki/branchi/sumi/pipei of the prelude).
 #define FD_MULTI_COMBINATOR                                                                                 \
     X x[N];                                                                                                 \

@@ -229,6 +229,18 @@ def join(n): return _leaf(f"Join<{n}>", n, 1)
 def multijoin(m, n): return _leaf(f"MultiJoin<{m},{n}>", m * n, m)
 def reverse(n): return _leaf(f"Reverse<{n}>", n, n)
 def impulse(n=1): return _leaf(f"Impulse<{n}>", 0, n)
+def _feedback(x, y, op):
+    if x.nin != x.nout or (y is not None and (y.nin != x.nout or y.nout != x.nout)):
+        raise TypeError("feedback: the enclosed nodes need as many outputs as inputs")
+    ps = [((0,) + p, f, v, u) for p, f, v, u in x.params]
+    if y is None:
+        return Graph(f"Feedback<{x.type},{op}>", x.nin, x.nout, ps, x.rings, x.source)
+    ps += [((1,) + p, f, v, u) for p, f, v, u in y.params]
+    return Graph(f"Feedback2<{x.type},{y.type},{op}>", x.nin, x.nout, ps, x.rings + y.rings, _merge(x.source, y.source))
+def feedback(x): return _feedback(x, None, "FbId")                 # prelude32.rs:1040
+def feedback2(x, y): return _feedback(x, y, "FbId")                # prelude32.rs:1061
+def fdn(x): return _feedback(x, None, "FbHadamard")                # prelude32.rs:1323
+def fdn2(x, y): return _feedback(x, y, "FbHadamard")               # prelude32.rs:1340
 def thru(x): return ~x
 def bus(x, y): return x & y
 def branch(x, y): return x ^ y

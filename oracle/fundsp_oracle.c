@@ -45,6 +45,9 @@ struct onode {
     onode **kids; /* O_MULTI: the N nodes of MultiBus / MultiStack / MultiBranch / Reduce / Chain */
     int nkids, multi;
     int jm, jn;   /* Split / Join: M channels, N branches */
+    int ftz;      /* this graph contains a Feedback node: rendered with MXCSR FTZ + DAZ (see o_feedback) */
+    int hadamard; /* Feedback: U = FrameHadamard */
+    float fb_value[O_MAX_CH];
     o_map_fn map_fn;
     void *map_ctx;
     float *tmp2;  /* second scratch of Chain::process (audionode.rs:2729) */
@@ -551,6 +554,7 @@ void o_reset(onode *n) {
     for (int i = 0; i < n->nkids; i++) o_reset(n->kids[i]);
     if (n->type == O_IMPULSE) n->s.value[0] = 1.0f; /* audionode.rs:2860-2862 */
     if (n->type == O_DECLICK) n->s.dc_t = 0.0f;     /* dynamics.rs:268-270 */
+    if (n->type == O_FEEDBACK) memset(n->fb_value, 0, sizeof n->fb_value); /* feedback.rs:118-121 */
     leaf_reset(n);
 }
 
@@ -724,6 +728,9 @@ static uint64_t o_ping(onode *n, int probe, uint64_t hash) {
         for (int i = 0; i < n->nkids; i++) h = o_ping(n->kids[i], probe, h);
         return h;
     }
+    case O_FEEDBACK: /* feedback.rs:152-154, 293-295 */
+        if (n->y) return o_ping(n->y, probe, o_ping(n->x, probe, o_atto(hash, n->id)));
+        return o_ping(n->x, probe, o_atto(hash, n->id));
     case O_THRU: /* audionode.rs:2026-2028 */
     case O_UNOP:
     case O_RESAMPLE:   /* resample.rs:308-310 */
@@ -738,6 +745,9 @@ static uint64_t o_ping(onode *n, int probe, uint64_t hash) {
 
 /* what every combinator constructor does (audionode.rs:871-876, 1242-1247, 1389-1394) */
 static void ctor_ping(onode *n) {
+    if ((n->x && n->x->ftz) || (n->y && n->y->ftz)) n->ftz = 1;
+    for (int i = 0; i < n->nkids; i++)
+        if (n->kids[i]->ftz) n->ftz = 1;
     uint64_t h = o_ping(n, 1, n->id); /* AttoHash::new(Self::ID) */
     o_ping(n, 0, h);
 }
@@ -942,7 +952,7 @@ onode *o_tap(int linear, float min_delay, float max_delay) { /* Tap::new :164-17
 }
 onode *o_allnest(float coefficient, onode *x) { /* AllNest::new :313-326, ID 83 (no constructor ping) */
     onode *n = o_new(O_ALLNEST, 1, 1, 83);
-    n->x = x;
+    n->x = x; n->ftz = x->ftz;
     n->s.eta = coefficient;
     n->s.zz = 0.0f;
     return n;
@@ -1239,7 +1249,7 @@ static float os_decimate(const float *ring, size_t last_index) { /* :43-64 */
 onode *o_resample(onode *x) { /* Resample::new resample.rs:228-238 (ID 69): x is a generator */
     if (x->nin != 0) return NULL;
     onode *n = o_new(O_RESAMPLE, 1, x->nout, 69);
-    n->x = x;
+    n->x = x; n->ftz = x->ftz;
     n->s.rs_buf = (float *)calloc((size_t)x->nout * 128, sizeof(float));
     n->s.rs_consumer = 1.0;
     n->s.rs_producer = 0;
@@ -1250,7 +1260,7 @@ onode *o_resample(onode *x) { /* Resample::new resample.rs:228-238 (ID 69): x is
 }
 onode *o_oversample(onode *x) { /* Oversampler::new :90-104 */
     onode *n = o_new(O_OVERSAMPLE, x->nin, x->nout, 51);
-    n->x = x;
+    n->x = x; n->ftz = x->ftz;
     n->s.os_inv = (float *)calloc((size_t)(x->nin ? x->nin : 1) * 128, sizeof(float));
     n->s.os_outv = (float *)calloc((size_t)x->nout * 128, sizeof(float));
     o_set_sample_rate(x, DEFAULT_SR * 2.0);
@@ -1306,6 +1316,16 @@ onode *o_bus(onode *x, onode *y) { /* Bus::new audionode.rs:1813-1819, ID 10 */
     onode *n = o_new(O_BUS, x->nin, x->nout, 10);
     n->x = x; n->y = y;
     n->tmp = (float *)calloc((size_t)(x->nout ? x->nout : 1) * MAXB, sizeof(float));
+    ctor_ping(n);
+    return n;
+}
+onode *o_feedback(onode *x, onode *y, int hadamard) { /* Feedback::new feedback.rs:95-105 (ID 11), Feedback2::new :222-233 (ID 66) */
+    if (x->nin != x->nout || (y && (y->nin != x->nout || y->nout != x->nout))) return NULL;
+    if (hadamard && (x->nout & (x->nout - 1))) return NULL; /* FrameHadamard::new asserts a power of two (:27) */
+    onode *n = o_new(O_FEEDBACK, x->nin, x->nout, y ? 66 : 11);
+    n->x = x; n->y = y; n->hadamard = hadamard;
+    n->ftz = 1; /* prevent_denormals() :96: the reference sets MXCSR FTZ + DAZ on the constructing thread for good; the
+                   oracle applies that mode to every render of a graph that contains the node */
     ctor_ping(n);
     return n;
 }
@@ -1592,7 +1612,23 @@ static void env_next_segment(onode *n, float input) {
     n->s.evd = (n->s.ev1 - n->s.ev0) / samples;
 }
 
+/* A graph that contains a Feedback node renders under MXCSR = 0x9fc0 (FTZ + DAZ), see o_feedback. */
+static __thread int g_ftz_on;
+#if defined(__x86_64__) || defined(__i386__)
+#define FTZ_ENTER unsigned int ftz_csr = _mm_getcsr(); _mm_setcsr(0x9fc0); g_ftz_on = 1
+#define FTZ_LEAVE g_ftz_on = 0; _mm_setcsr(ftz_csr)
+#else
+#define FTZ_ENTER g_ftz_on = 1
+#define FTZ_LEAVE g_ftz_on = 0
+#endif
+
 void o_tick(onode *n, const float *in, float *out) {
+    if (n->ftz && !g_ftz_on) {
+        FTZ_ENTER;
+        o_tick(n, in, out);
+        FTZ_LEAVE;
+        return;
+    }
     float t[O_MAX_CH];
     switch (n->type) {
     case O_CONSTANT: /* audionode.rs:496-499 */
@@ -2017,6 +2053,26 @@ void o_tick(onode *n, const float *in, float *out) {
         o_tick(n->y, in, t);
         for (int i = 0; i < n->nout; i++) out[i] = out[i] + t[i];
         break;
+    case O_FEEDBACK: { /* feedback.rs:129-134, 270-275 */
+        float fi[O_MAX_CH];
+        for (int i = 0; i < n->nin; i++) fi[i] = in[i] + n->fb_value[i];
+        o_tick(n->x, fi, out);
+        if (n->y) o_tick(n->y, out, n->fb_value);
+        else for (int i = 0; i < n->nout; i++) n->fb_value[i] = out[i];
+        if (n->hadamard) { /* FrameHadamard::frame :35-57 */
+            float *o = n->fb_value;
+            for (int h = 1; h < n->nout; h *= 2)
+                for (int i = 0; i < n->nout; i += h * 2)
+                    for (int j = i; j < i + h; j++) {
+                        float a = o[j], b = o[j + h];
+                        o[j] = a + b;
+                        o[j + h] = a - b;
+                    }
+            float z = (float)(1.0 / sqrt((double)n->nout));
+            for (int i = 0; i < n->nout; i++) o[i] = o[i] * z;
+        }
+        break;
+    }
     case O_THRU: /* :1977-1986 */
         o_tick(n->x, in, t);
         for (int i = 0; i < n->nout; i++) out[i] = i < n->x->nout ? t[i] : in[i];
@@ -2088,6 +2144,12 @@ static void process_remainder(onode *n, int size, const float *in, float *out) {
 }
 
 void o_process(onode *n, int size, const float *in, float *out) {
+    if (n->ftz && !g_ftz_on) {
+        FTZ_ENTER;
+        o_process(n, size, in, out);
+        FTZ_LEAVE;
+        return;
+    }
     switch (n->type) {
     case O_OVERSAMPLE: { /* oversample.rs:178-212.  Two passes of size / 2 outer samples; the inner node processes `size`
                           * inner samples per pass.  An odd `size` leaves the last outer sample untouched (the reference

@@ -19,7 +19,7 @@ enum {
     O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP,
     O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO, O_SHAPER, O_PHASE_OSC, O_CHAOS, O_NLBIQUAD, O_TAP, O_ALLNEST,
     O_ONEPOLE, O_PINKPASS, O_MORPH, O_REZ, O_FOLLOW, O_AFOLLOW, O_MLS, O_OVERSAMPLE, O_DSF, O_PLUCK, O_ENVELOPE, O_RESAMPLE, O_ENVELOPE_IN,
-    O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK
+    O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK, O_FEEDBACK
 };
 enum { O_OP_LOWPOLE = 0, O_OP_HIGHPOLE, O_OP_DCBLOCK, O_OP_ALLPOLE };
 enum { O_SH_CLIP = 0, O_SH_CLIPTO, O_SH_TANH, O_SH_ATAN, O_SH_SOFTSIGN, O_SH_CRUSH, O_SH_SOFTCRUSH, O_SH_ADAPTIVE_TANH };
@@ -108,6 +108,9 @@ onode *o_shape_fn(o_map_fn fn, void *ctx);  /* Shaper<ShapeFn<S>> shape.rs:35,20
 onode *o_declick(float duration);          /* Declick<f32> dynamics.rs:245 */
 onode *o_branch(onode *x, onode *y);       /* Branch :1653 */
 onode *o_bus(onode *x, onode *y);          /* Bus :1796 */
+/* Feedback<N, X, U> (feedback.rs:71, y == NULL) / Feedback2<N, X, Y, U> (:193); hadamard: U = FrameHadamard (fdn,
+ * fdn2) instead of FrameId (feedback, feedback2).  Takes ownership. */
+onode *o_feedback(onode *x, onode *y, int hadamard);
 onode *o_thru(onode *x);                   /* Thru :1951 */
 enum { O_MULTI_BUS = 0, O_MULTI_STACK, O_MULTI_BRANCH, O_MULTI_REDUCE, O_MULTI_CHAIN };
 /* MultiBus :2065 / MultiStack :2211 / MultiBranch :2532 / Reduce :2366 (op = O_ADD..O_MUL) / Chain :2673; takes

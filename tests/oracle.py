@@ -85,6 +85,7 @@ def lib():
         "o_multipass": (P, [i]), "o_sink": (P, [i]), "o_split": (P, [i, i]), "o_join": (P, [i, i]),
         "o_reverse": (P, [i]), "o_impulse": (P, [i]), "o_map": (P, [i, i, P, P]),
         "o_shape_fn": (P, [P, P]), "o_declick": (P, [f]),
+        "o_feedback": (P, [P, P, i]),
         "o_branch": (P, [P, P]), "o_bus": (P, [P, P]), "o_thru": (P, [P]), "o_multi": (P, [i, i, C.POINTER(P), i]),
         "o_reverb_stereo": (P, [d, d, d]),
         "o_reverb_stereo_params": (None, [d, d, d, d, fp, C.POINTER(C.c_int), fp, fp]),
@@ -213,6 +214,10 @@ def join(n): return Node(lib().o_join(1, n))                       # prelude32.r
 def multijoin(m, n): return Node(lib().o_join(m, n))
 def reverse(n): return Node(lib().o_reverse(n))                    # prelude32.rs:190
 def impulse(n=1): return Node(lib().o_impulse(n))                  # prelude32.rs:2480
+def feedback(x): return Node(lib().o_feedback(x.ptr, None, 0), (x,))            # prelude32.rs:1040
+def feedback2(x, y): return Node(lib().o_feedback(x.ptr, y.ptr, 0), (x, y))     # prelude32.rs:1061
+def fdn(x): return Node(lib().o_feedback(x.ptr, None, 1), (x,))                 # prelude32.rs:1323
+def fdn2(x, y): return Node(lib().o_feedback(x.ptr, y.ptr, 1), (x, y))          # prelude32.rs:1340
 def thru(x): return ~x
 def bus(x, y): return x & y
 def branch(x, y): return x ^ y

@@ -57,6 +57,11 @@ GRAPHS = {
     "svf_q_forms": (lambda m: (m.pass_() | m.sine_hz(2.0) * 300.0 + 1000.0) >> (m.lowpass_q(2.0) ^ m.bell_q(1.5, 2.0)) >> (m.pass_() - m.pass_()), 1, 0),
     "brown_pink": (lambda m: m.brown() & m.pink(), 0, 0),
     "nl_biquads": (lambda m: m.fresonator_hz(m.Tanh(1.0), 500.0, 2.0) >> m.dlowpass_hz(m.Softsign(0.9), 800.0, 1.0) >> m.clip_to(-0.5, 0.5), 1, 0),
+    # Feedback / Feedback2 with FrameId and FrameHadamard (feedback.rs); the enclosed nodes run their tick arithmetic
+    "feedback_echo": (lambda m: m.feedback(m.delay(0.001) * 0.9) >> m.feedback2(m.delay(0.0007), m.lowpole_hz(1500.0) * 0.8), 1, 64),
+    "fdn4": (lambda m: m.split(4) >> m.fdn(m.stacki(4, lambda i: m.delay(0.0005 * (i + 1)) >> m.fir(0.3, 0.4, 0.2))) >> m.join(4), 1, 128),
+    "fdn2_loop_filters": (lambda m: (m.pass_() | m.noise() * 0.01) >> m.fdn2(m.stacki(2, lambda i: m.delay(0.0011 * (i + 1))), m.stacki(2, lambda i: m.lowpole_hz(3000.0) * 0.7)) >> m.join(2), 1, 128),
+    "feedback_denormal_decay": (lambda m: m.impulse() >> m.feedback(m.tick() * 0.5) >> m.lowpole_hz(5000.0), 0, 0),
     "moog_q_thru_cut": (lambda m: (m.pass_() | m.dc(800.0)) >> m.moog_q(0.5) >> m.clip() >> m.split(2) >> ~(m.sink() | m.sink()) >> m.join(2), 1, 0),
 }
 
