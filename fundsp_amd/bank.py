@@ -267,11 +267,12 @@ def biquad_coefs(kind, sample_rate, f, q=1.0, gain=1.0):
     return out
 
 
-WT_SETS = dict(saw=0, square=1, triangle=2, user=3)
+WT_SETS = dict(saw=0, square=1, triangle=2, user=3, organ=4, soft_saw=5, hammond=6, user2=7)
 
 
 def wavetable_build(kind):
-    """Generate and install a built-in shared wavetable set (saw_table / square_table / triangle_table)."""
+    """Generate and install a built-in shared wavetable set (saw_table / square_table / triangle_table / organ_table /
+    soft_saw_table / hammond_table, wavetable.rs:493-623)."""
     check(lib().fdsp_wavetable_build(WT_SETS[kind]))
 
 

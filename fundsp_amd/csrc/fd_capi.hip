@@ -145,19 +145,28 @@ void ifft_inplace(std::vector<float>& re, std::vector<float>& im) {
 }
 
 // Wavetable::new + make_wave (wavetable.rs:44-123) for the built-in shapes (saw_table :493, square_table :510,
-// triangle_table :523).  Table bits are not pinned against the reference (its FFT lives in the microfft crate).
+// triangle_table :523, organ_table :546, soft_saw_table :574, hammond_table :598).  Table bits are not pinned against the reference (its FFT lives in the microfft crate).
 int build_default_table_set(int set) {
     auto phase = [set](unsigned i) -> double {
         if (set == 0) return (i & 1) == 1 ? 0.0 : 0.5;
-        if (set == 1) return 0.0;
-        return (i & 3) == 3 ? 0.5 : 0.0;
+        if (set == 1 || set == 6) return 0.0;
+        if (set == 2) return (i & 3) == 3 ? 0.5 : 0.0;
+        return (i & 3) == 3 ? 0.5 : ((i & 1) == 1 ? 0.0 : 0.5);  // organ, soft saw
     };
     auto amplitude = [set](unsigned i) -> double {
         if (set == 0) return 1.0 / (double)i;
         if (set == 1) return (i & 1) == 1 ? 1.0 / (double)i : 0.0;
-        return (i & 1) == 1 ? 1.0 / ((double)i * (double)i) : 0.0;
+        if (set == 2) return (i & 1) == 1 ? 1.0 / ((double)i * (double)i) : 0.0;
+        if (set == 5) return 1.0 / ((double)i * (double)i);
+        unsigned z = (unsigned)__builtin_ctz(i), j = i >> z;
+        if (set == 4) return 1.0 / (double)((uint64_t)i + (uint64_t)j * j * j);
+        // hammond
+        const double f = 1.0 / (double)((z + 1) * (z + 1));
+        if (i <= 3) return 1.0;
+        return j == 1 || j == 3 ? f : (j == 9 ? 0.2 * f : 0.0);
     };
-    if (set < 0 || set > 2) return fail(FDSP_EINVAL, "built-in table sets: 0 saw, 1 square, 2 triangle");
+    if (!(set >= 0 && set <= 2) && !(set >= 4 && set <= 6))
+        return fail(FDSP_EINVAL, "built-in table sets: 0 saw, 1 square, 2 triangle, 4 organ, 5 soft saw, 6 hammond");
     std::vector<float> pitches, data;
     std::vector<int> lengths;
     const double p_factor = std::pow(2.0, 1.0 / 4.0);

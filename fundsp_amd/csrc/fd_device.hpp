@@ -88,6 +88,13 @@ template <class X> struct CtorPing<Resample<X>> {  // Resample::new resample.rs:
     static FD_D void run(Resample<X>& g) { uint64_t h = g.x.ping(true, Resample<X>::ID); g.x.ping(false, h); }
 };
 
+template <> struct CtorPing<PulseWave> {  // pulse() = An(PulseWave::new()): only the inner Pipe's constructor pinged
+    static FD_D void run(PulseWave& g) {
+        uint64_t h = g.pulse.ping(true, PulseWave::Inner::ID);
+        g.pulse.ping(false, h);
+    }
+};
+
 template <class G>
 FD_D void lifecycle_body(float* slots, size_t stride, size_t first, size_t count, int op, double sr,
                          const uint64_t* seeds, const void* aux, float* ring, uint32_t ring_cap) {
@@ -565,7 +572,9 @@ template <> struct Cost<Sine> { static constexpr int v = 20; };
 template <> struct Cost<Noise> { static constexpr int v = 10; };
 template <> struct Cost<FixedSvf> { static constexpr int v = 16; };
 template <int N> struct Cost<Moog<N>> { static constexpr int v = 130; };
-template <int S> struct Cost<WaveSynth<S>> { static constexpr int v = 100; };
+template <int S, int N> struct Cost<WaveSynth<S, N>> { static constexpr int v = 100; };
+template <int S> struct Cost<PhaseSynth<S>> { static constexpr int v = 100; };
+template <> struct Cost<PulseWave> { static constexpr int v = 210; };
 template <> struct Cost<AdsrLive> { static constexpr int v = 80; };
 template <> struct Cost<Shaper> { static constexpr int v = 60; };
 template <> struct Cost<Panner> { static constexpr int v = 2; };

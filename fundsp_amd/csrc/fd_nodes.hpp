@@ -730,7 +730,7 @@ struct Tick {
 
 // Shared wavetable data (Arc<Wavetable> in the reference, wavetable.rs:82-84): one table set per waveform, in HBM
 // (saw: 40 tables, 41 024 floats = 160 KiB -- lives in L2; LDS cannot hold it next to anything else).
-constexpr int WT_MAX_TABLES = 48, WT_SETS = 4;
+constexpr int WT_MAX_TABLES = 48, WT_SETS = 8;  // 0 saw, 1 square, 2 triangle, 3 user, 4 organ, 5 soft saw, 6 hammond, 7 user
 struct WtSet {
     int n;
     float pitch[WT_MAX_TABLES];
@@ -796,9 +796,9 @@ FD_HD Tap4 wt_tap(const float* __restrict__ tab, uint32_t mask, float phase) {  
 }
 FD_HD float tap_eval(const Tap4& t) { return optimal4x44(t.a0, t.a1, t.a2, t.a3, t.w); }
 
-template <int SET>
+template <int SET, int NOUT = 1>  // WaveSynth<U2> also outputs the wrapped phase (wavetable.rs:318-324, 343-345)
 struct WaveSynth {
-    static constexpr int IN = 1, OUT = 1, RINGS = 0;
+    static constexpr int IN = 1, OUT = NOUT, RINGS = 0;
     static constexpr uint64_t ID = 34;
     float phase, sample_duration, has_phase, initial_phase;
     uint32_t hint;
@@ -866,6 +866,7 @@ struct WaveSynth {
             float ph = phase - __builtin_floorf(phase);  // wide's inherent f32x8::floor (true floor)
             Tap4 t1 = wt_tap(c_tab1, c_mask1, ph), t2 = wt_tap(c_tab2, c_mask2, ph);
             out[0] = (1.0f - item_w) * tap_eval(t1) + item_w * tap_eval(t2);
+            if (NOUT > 1) out[1] = ph;
         } else {  // tick :310-324: increment + wrap BEFORE reading
             float frequency = in[0];
             phase += frequency * sample_duration;
@@ -873,10 +874,11 @@ struct WaveSynth {
             float w = select(__builtin_fabsf(frequency));
             Tap4 t1 = wt_tap(c_tab1, c_mask1, phase), t2 = wt_tap(c_tab2, c_mask2, phase);
             out[0] = (1.0f - w) * tap_eval(t1) + w * tap_eval(t2);
+            if (NOUT > 1) out[1] = phase;
         }
     }
     template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
-        if (PH == PH_SIMD) {
+        if (PH == PH_SIMD && NOUT == 1) {
             if ((item_pos & 7) == 0) item_w = select(__builtin_fabsf(in[0].x));
             item_pos += 2;
             v2f d = in[0] * sample_duration;
@@ -891,12 +893,58 @@ struct WaveSynth {
             float o1 = (1.0f - item_w) * tap_eval(b1) + item_w * tap_eval(b2);
             out[0] = v2f{o0, o1};
         } else {
-            float o0, o1, i0 = in[0].x, i1 = in[0].y;
-            this->template step<PH>(&i0, &o0);
-            this->template step<PH>(&i1, &o1);
-            out[0] = v2f{o0, o1};
+            float o0[NOUT], o1[NOUT], i0 = in[0].x, i1 = in[0].y;
+            this->template step<PH>(&i0, o0);
+            this->template step<PH>(&i1, o1);
+            for (int c = 0; c < NOUT; c++) out[c] = v2f{o0[c], o1[c]};
         }
     }
+};
+
+// PhaseSynth  wavetable.rs:358-430 (ID 35): table read driven by a PHASE input; the table pair follows the frequency
+// implied by the phase step (at most Nyquist), 0.5 cycles for the first sample after reset.  No process override.
+template <int SET>
+struct PhaseSynth {
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 35;
+    float phase, phase_ready, sample_rate;
+    uint32_t hint;
+    const WtSet* wt;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(phase, STATE, "phase");
+        v.f(phase_ready, STATE, "phase_ready");
+        v.u32(hint, STATE, "table_hint");
+        v.f(sample_rate, COEF, "sample_rate");
+    }
+    FD_HD void bind(Ctx& a) { wt = &a.aux->wt[SET]; }
+    FD_HD void init() { phase = 0.0f; phase_ready = 0.0f; hint = 0; sample_rate = 44100.0f; }
+    FD_HD void update(double sr) { sample_rate = (float)sr; }
+    FD_HD void reset() { phase_ready = 0.0f; }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        float ph = in[0];
+        ph = ph - __builtin_floorf(ph);
+        float delta;
+        if (phase_ready != 0.0f) {
+            delta = __builtin_fminf(__builtin_fabsf(ph - phase),
+                               __builtin_fminf(__builtin_fabsf(ph - 1.0f - phase), __builtin_fabsf(ph + 1.0f - phase)));
+        } else {
+            phase_ready = 1.0f;
+            delta = 0.5f;
+        }
+        const float f0 = delta * sample_rate;
+        const int t = wt_table_index(wt, (int)hint, f0);  // Wavetable::read :213-226
+        hint = (uint32_t)t;
+        const float w = clamp01f((f0 - wt->pitch[t]) / (wt->pitch[t + 1] - wt->pitch[t]));
+        Tap4 t1 = wt_tap(wt->data + wt->off[t + 1], (uint32_t)wt->len[t + 1] - 1u, ph);
+        Tap4 t2 = wt_tap(wt->data + wt->off[t + 2], (uint32_t)wt->len[t + 2] - 1u, ph);
+        out[0] = (1.0f - w) * tap_eval(t1) + w * tap_eval(t2);
+        phase = ph;
+    }
+    FD_STEP2_VIA_STEP
 };
 
 FD_HD float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; }  // math.rs:169-178
@@ -2564,6 +2612,29 @@ struct Map {
     FD_STATELESS_LEAF
     template <int PH> FD_HD void step(const float* in, float* out) { FN::f(in, out); }
     FD_STEP2_VIA_STEP
+};
+
+// PulseWave  wavetable.rs:437-491 (ID 44): a pulse wave as the difference of two saw waves half a pulse width apart,
+//   (WaveSynth<U2>(saw) | pass()) >> (pass() | (pass() + pass()) >> PhaseSynth(saw)) >> pass() - pass()
+// input 0 = frequency, input 1 = pulse width in 0...1.  ping() pings the inner graph FIRST and hashes its own ID last
+// (:484-486); PulseWave::new does not ping, the inner Pipe's constructor did (CtorPing<PulseWave> in fd_device.hpp).
+struct PulseWave {
+    using Inner = Pipe<Pipe<Stack<WaveSynth<0, 2>, Pass>, Stack<Pass, Pipe<Binop<OpAdd, Pass, Pass>, PhaseSynth<0>>>>,
+                       Binop<OpSub, Pass, Pass>>;
+    static constexpr int IN = 2, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 44;
+    Inner pulse;
+    template <class V> FD_HD void visit(V& v) { v.enter(0); pulse.visit(v); v.leave(); }
+    FD_HD void init() { pulse.init(); }
+    FD_HD void update(double sr) { pulse.update(sr); }
+    FD_HD void reset() { pulse.reset(); }
+    FD_HD uint64_t ping(bool probe, uint64_t h) { return atto(pulse.ping(probe, h), ID); }
+    FD_HD void end_simd() { pulse.end_simd(); }
+    FD_HD void begin_block(int n) { pulse.begin_block(n); }
+    FD_HD void bind(Ctx& a) { pulse.bind(a); }
+    FD_HD bool tripped() const { return pulse.tripped(); }
+    template <int PH> FD_HD void step(const float* in, float* out) { pulse.template step<PH>(in, out); }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) { pulse.template step2<PH>(in, out); }
 };
 
 // Shaper<ShapeFn<S>>  shape.rs:35-42, 205-247 (ID 42): shape_fn(|x| ..) with the closure as a functor type

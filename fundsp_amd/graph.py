@@ -204,6 +204,13 @@ def triangle(): return _leaf("WaveSynth<2>", 1, 1)
 def saw_hz(f): return constant(f) >> saw()
 def square_hz(f): return constant(f) >> square()
 def triangle_hz(f): return constant(f) >> triangle()
+def organ(): return _leaf("WaveSynth<4>", 1, 1)                    # prelude32.rs organ/soft_saw/hammond: WaveSynth over
+def soft_saw(): return _leaf("WaveSynth<5>", 1, 1)                 # organ_table / soft_saw_table / hammond_table
+def hammond(): return _leaf("WaveSynth<6>", 1, 1)
+def organ_hz(f): return constant(f) >> organ()
+def soft_saw_hz(f): return constant(f) >> soft_saw()
+def hammond_hz(f): return constant(f) >> hammond()
+def pulse(): return _leaf("PulseWave", 2, 1)                       # input 0 frequency, input 1 pulse width (wavetable.rs:437)
 def ramp(): return _leaf("PhaseOsc<OSC_RAMP>", 1, 1)
 def poly_saw(): return _leaf("PhaseOsc<OSC_POLYSAW>", 1, 1)
 def poly_square(): return _leaf("PhaseOsc<OSC_POLYSQUARE>", 1, 1)
@@ -368,4 +375,6 @@ def dbell(shp): return _nlbiquad(True, 4, "bell", shp)
 
 
 def uses_wavetables(g):
-    return [k for k, t in (("saw", "WaveSynth<0>"), ("square", "WaveSynth<1>"), ("triangle", "WaveSynth<2>")) if t in g.type]
+    sets = (("saw", "WaveSynth<0>"), ("square", "WaveSynth<1>"), ("triangle", "WaveSynth<2>"), ("organ", "WaveSynth<4>"),
+            ("soft_saw", "WaveSynth<5>"), ("hammond", "WaveSynth<6>"), ("saw", "PulseWave"))
+    return sorted({k for k, t in sets if t in g.type})

@@ -213,7 +213,8 @@ int fdsp_mix_stereo(const float* d_voices, const float* d_pan, float* d_mix, siz
 int fdsp_sum_voices(const float* d_in, float* d_out, size_t channels, size_t frames, size_t voices, void* stream);
 
 /* ---- shared wavetables (Arc<Wavetable> singletons of the reference: saw_table/square_table/triangle_table,
- * src/wavetable.rs:493-560).  `set`: 0 = saw, 1 = square, 2 = triangle, 3 = user.  Tables are a list of
+ * src/wavetable.rs:493-560).  `set`: 0 = saw, 1 = square, 2 = triangle, 4 = organ, 5 = soft saw,
+ * 6 = hammond (organ_table/soft_saw_table/hammond_table :546-623), 3 and 7 = user.  Tables are a list of
  * (pitch, power-of-two-length wave) pairs in ascending pitch, data concatenated.  fdsp_wavetable_build() generates the
  * built-in shape with the engine's own make_wave (wavetable.rs:44-123); fdsp_wavetable_upload() installs caller data
  * (e.g. tables produced by FunDSP itself).  Must be called before rendering a kind that uses the set. */

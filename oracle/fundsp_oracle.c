@@ -132,6 +132,7 @@ struct onode {
         o_envin_fn envin_fn;
         void *env_ctx;
         float env_v0[O_MAX_ENV], env_v1[O_MAX_ENV], env_val[O_MAX_ENV], env_d[O_MAX_ENV];
+        int ps_ready; /* PhaseSynth::phase_ready */
         /* Declick (dynamics.rs:245-250) */
         float dc_t, dc_duration, dc_sd;
         /* Dsf (oscillator.rs:121-129) */
@@ -554,6 +555,7 @@ void o_reset(onode *n) {
     for (int i = 0; i < n->nkids; i++) o_reset(n->kids[i]);
     if (n->type == O_IMPULSE) n->s.value[0] = 1.0f; /* audionode.rs:2860-2862 */
     if (n->type == O_DECLICK) n->s.dc_t = 0.0f;     /* dynamics.rs:268-270 */
+    if (n->type == O_PHASESYNTH) n->s.ps_ready = 0; /* wavetable.rs:387-389 */
     if (n->type == O_FEEDBACK) memset(n->fb_value, 0, sizeof n->fb_value); /* feedback.rs:118-121 */
     leaf_reset(n);
 }
@@ -696,6 +698,7 @@ void o_set_sample_rate(onode *n, double sr) {
     if (n->y) o_set_sample_rate(n->y, sr);
     for (int i = 0; i < n->nkids; i++) o_set_sample_rate(n->kids[i], sr);
     if (n->type == O_DECLICK) n->s.dc_sd = (float)(1.0 / sr); /* dynamics.rs:272-275 */
+    if (n->type == O_PHASESYNTH) n->s.ws_sr = (float)sr;      /* wavetable.rs:391-393 */
     leaf_set_sample_rate(n, sr);
 }
 
@@ -731,6 +734,8 @@ static uint64_t o_ping(onode *n, int probe, uint64_t hash) {
     case O_FEEDBACK: /* feedback.rs:152-154, 293-295 */
         if (n->y) return o_ping(n->y, probe, o_ping(n->x, probe, o_atto(hash, n->id)));
         return o_ping(n->x, probe, o_atto(hash, n->id));
+    case O_WRAP: /* PulseWave::ping wavetable.rs:484-486: inner first, own ID last */
+        return o_atto(o_ping(n->x, probe, hash), n->id);
     case O_THRU: /* audionode.rs:2026-2028 */
     case O_UNOP:
     case O_RESAMPLE:   /* resample.rs:308-310 */
@@ -904,6 +909,20 @@ onode *o_wavesynth(const owavetable *table, int outputs) { /* WaveSynth::new wav
     n->s.table_hint = 0;
     n->s.ws_sr = (float)DEFAULT_SR;
     n->s.sample_duration = 1.0f / (float)DEFAULT_SR;
+    return n;
+}
+onode *o_phasesynth(const owavetable *table) { /* PhaseSynth::new wavetable.rs:367-377 */
+    onode *n = o_new(O_PHASESYNTH, 1, 1, 35);
+    n->s.wt = table;
+    n->s.phase = 0.0f;
+    n->s.ps_ready = 0;
+    n->s.table_hint = 0;
+    n->s.ws_sr = (float)DEFAULT_SR;
+    return n;
+}
+onode *o_wrap(onode *x, uint64_t id) {
+    onode *n = o_new(O_WRAP, x->nin, x->nout, id);
+    n->x = x; n->ftz = x->ftz;
     return n;
 }
 void o_wavesynth_set_phase(onode *n, float phase) { /* Setting::phase wavetable.rs:350-354 + reset */
@@ -1709,6 +1728,23 @@ void o_tick(onode *n, const float *in, float *out) {
         if (n->nout > 1) out[1] = n->s.phase;
         break;
     }
+    case O_PHASESYNTH: { /* wavetable.rs:399-425 */
+        float phase = in[0];
+        phase = phase - floorf(phase);
+        float delta;
+        if (n->s.ps_ready) {
+            float a = fabsf(phase - n->s.phase), b = fabsf(phase - 1.0f - n->s.phase), c = fabsf(phase + 1.0f - n->s.phase);
+            float bc = b < c ? b : c;
+            delta = a < bc ? a : bc;
+        } else {
+            n->s.ps_ready = 1;
+            delta = 0.5f;
+        }
+        out[0] = wt_read(n->s.wt, &n->s.table_hint, delta * n->s.ws_sr, phase);
+        n->s.phase = phase;
+        break;
+    }
+    case O_WRAP: o_tick(n->x, in, out); break; /* wavetable.rs:472-474 */
     case O_ENVELOPE_IN: /* envelope.rs:305-313 */
         if (n->s.et >= n->s.et1) envin_next_segment(n, in);
         for (int i = 0; i < n->nout; i++) {
@@ -2230,6 +2266,7 @@ void o_process(onode *n, int size, const float *in, float *out) {
         }
         break;
     case O_SINK: break; /* :454 */
+    case O_WRAP: o_process(n->x, size, in, out); break; /* wavetable.rs:475-477 */
     case O_DECLICK: { /* dynamics.rs:289-307 */
         for (int i = 0; i < simd_items(size) * 8; i++) out[i] = in[i];
         if (n->s.dc_t < n->s.dc_duration) {

@@ -70,7 +70,7 @@ def lib():
         "o_math_hash32x": (C.c_uint32, [C.c_uint32]),
         "o_bank_render": (d, [C.POINTER(BankJob), fp]),
         "o_wavetable_create": (P, [i, fp, C.POINTER(C.c_int), fp]), "o_wavetable_free": (None, [P]),
-        "o_wavesynth": (P, [P, i]), "o_wavesynth_set_phase": (None, [P, f]),
+        "o_wavesynth": (P, [P, i]), "o_phasesynth": (P, [P]), "o_wrap": (P, [P, u64]), "o_wavesynth_set_phase": (None, [P, f]),
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
         "o_onepole": (P, [i, i, f]), "o_pinkpass": (P, []), "o_morph": (P, [f, f, f]),
         "o_rez": (P, [i, f, f, f]), "o_follow": (P, [f]), "o_afollow": (P, [f, f]), "o_mls": (P, [C.c_uint]),
@@ -317,14 +317,23 @@ def _smooth5(x): return ((x * 6 - 15) * x + 10) * x * x * x
 def make_wavetable_arrays(kind="saw", min_pitch=20.0, max_pitch=20000.0, tables_per_octave=4.0):
     def phase(i):
         if kind == "saw": return 0.0 if (i & 1) == 1 else 0.5
-        if kind == "square": return 0.0
+        if kind in ("square", "hammond"): return 0.0
         if kind == "triangle": return 0.5 if (i & 3) == 3 else 0.0
+        if kind in ("organ", "soft_saw"): return 0.5 if (i & 3) == 3 else (0.0 if (i & 1) == 1 else 0.5)  # wavetable.rs:555-563
         raise KeyError(kind)
 
     def amplitude(i):
         if kind == "saw": return 1.0 / i
         if kind == "square": return 1.0 / i if (i & 1) == 1 else 0.0
         if kind == "triangle": return 1.0 / (i * i) if (i & 1) == 1 else 0.0
+        if kind == "soft_saw": return 1.0 / (i * i)                                                       # :590
+        z = (i & -i).bit_length() - 1
+        j = i >> z
+        if kind == "organ": return 1.0 / (i + j * j * j)                                                  # :564-568
+        if kind == "hammond":                                                                             # :602-619
+            f = 1.0 / ((z + 1) * (z + 1))
+            if i <= 3: return 1.0
+            return f if j in (1, 3) else (0.2 * f if j == 9 else 0.0)
         raise KeyError(kind)
 
     pitches, waves = [], []
@@ -378,6 +387,26 @@ def saw(): return wavesynth("saw")                                    # prelude.
 def square(): return wavesynth("square")
 def triangle(): return wavesynth("triangle")
 def saw_hz(f): return constant(f) >> saw()
+def organ(): return wavesynth("organ")                                # prelude32.rs organ / soft_saw / hammond
+def soft_saw(): return wavesynth("soft_saw")
+def hammond(): return wavesynth("hammond")
+def organ_hz(f): return constant(f) >> organ()
+def soft_saw_hz(f): return constant(f) >> soft_saw()
+def hammond_hz(f): return constant(f) >> hammond()
+
+
+def phasesynth(kind="saw"):
+    t = Wavetable.get(kind)
+    n = Node(lib().o_phasesynth(t.ptr))
+    n._table = t
+    return n
+
+
+def pulse():
+    """PulseWave::new (wavetable.rs:452-459): built from the oracle's own combinators, wrapped under ID 44."""
+    inner = (wavesynth("saw", 2) | pass_()) >> (pass_() | (pass_() + pass_()) >> phasesynth("saw")) >> pass_() - pass_()
+    n = Node(lib().o_wrap(inner.ptr, 44), (inner,))
+    return n
 def adsr_live(a, d, s, r): return Node(lib().o_adsr_live(a, d, s, r))  # adsr.rs:21
 def pan(p): return Node(lib().o_panner(1, p))                         # prelude.rs:1250
 

@@ -27,7 +27,7 @@ def tables(gpu):
 def test_builtin_table_generator_matches_oracle_tables(gpu):
     """Engine-side make_wave / Wavetable::new (f32 radix-2 IFFT) vs the numpy builder (f64 FFT): same table layout
     (40 tables, 41 024 floats for saw: SURVEY.md section 7), values within 2e-6 of the normalised peak."""
-    for kind in ("saw", "square", "triangle"):
+    for kind in ("saw", "square", "triangle", "organ", "soft_saw", "hammond"):   # wavetable.rs:493-623
         gpu.wavetable_build(kind)
         p, waves = gpu.wavetable_get(kind)
         op, owaves = O.make_wavetable_arrays(kind)

@@ -62,6 +62,9 @@ GRAPHS = {
     "fdn4": (lambda m: m.split(4) >> m.fdn(m.stacki(4, lambda i: m.delay(0.0005 * (i + 1)) >> m.fir(0.3, 0.4, 0.2))) >> m.join(4), 1, 128),
     "fdn2_loop_filters": (lambda m: (m.pass_() | m.noise() * 0.01) >> m.fdn2(m.stacki(2, lambda i: m.delay(0.0011 * (i + 1))), m.stacki(2, lambda i: m.lowpole_hz(3000.0) * 0.7)) >> m.join(2), 1, 128),
     "feedback_denormal_decay": (lambda m: m.impulse() >> m.feedback(m.tick() * 0.5) >> m.lowpole_hz(5000.0), 0, 0),
+    # wavetable family: PulseWave (WaveSynth<U2> + PhaseSynth), organ / soft saw / hammond tables
+    "pulse_wave": (lambda m: (m.sine_hz(3.0) * 50.0 + 220.0 | m.sine_hz(0.7) * 0.3 + 0.5) >> m.pulse() * 0.2, 0, 0),
+    "organ_family": (lambda m: m.organ_hz(110.0) + m.soft_saw_hz(220.0) * 0.5 + (m.sine_hz(5.0) * 3.0 + 55.0 >> m.hammond()), 0, 0),
     "moog_q_thru_cut": (lambda m: (m.pass_() | m.dc(800.0)) >> m.moog_q(0.5) >> m.clip() >> m.split(2) >> ~(m.sink() | m.sink()) >> m.join(2), 1, 0),
 }
 
@@ -71,10 +74,10 @@ def test_jit_graph_matches_oracle(gpu, name):
     build, ni, ring = GRAPHS[name]
     g = build(GR)
     V, T = 70, 64 * 9 + 11
-    if "saw" in name:
-        t = O.Wavetable.get("saw")
+    for kind in GR.uses_wavetables(g):   # the oracle's numpy-built tables, so both sides read identical table bits
+        t = O.Wavetable.get(kind)
         offs = np.concatenate([[0], np.cumsum(t.lengths)])
-        gpu.wavetable_upload("saw", t.pitches, [t.data[offs[i]:offs[i + 1]] for i in range(len(t.lengths))])
+        gpu.wavetable_upload(kind, t.pitches, [t.data[offs[i]:offs[i + 1]] for i in range(len(t.lengths))])
     seeds = np.arange(V, dtype=np.uint64) * 7919 + 13
     x = None
     if ni:

@@ -48,6 +48,15 @@ def test_check_wave_combinator_cases():
     check_wave(lambda: (O.noise() >> O.split(16) >> O.join(16)) | (O.noise() >> O.split(11) >> O.join(11)))     # :218
 
 
+def test_check_wave_pulse_and_table_family():
+    check_wave(lambda: O.dc(110.0, 0.5) >> O.pulse() * 0.2 >> O.delay(0.1), frames=4410)   # test_basic.rs:237
+    check_wave(lambda: O.organ_hz(110.0) * 0.5)
+    check_wave(lambda: O.soft_saw_hz(220.0) | O.hammond_hz(55.0) * 0.5)
+    a, b = O.pulse() | O.pulse(), None                                                      # outputs_diverge :606
+    y = a.render_ticks(np.tile(np.array([[110.0], [0.5], [110.0], [0.5]], dtype=np.float32), (1, 64)))
+    assert not np.array_equal(y[0], y[1])
+
+
 def is_equal(x, y, trials=1000, seed=0):
     """is_equal (test_basic.rs:95-110): random frames from {-1, 0, 1}, exact tick outputs."""
     rng = np.random.default_rng(seed)
