@@ -1296,39 +1296,57 @@ struct Envelope {
 };
 
 
-// Panner<U1>  pan.rs:26-93 (ID 49): fixed pan, mono -> stereo.
-struct Panner {
-    static constexpr int IN = 1, OUT = 2, RINGS = 0;
+// Panner<N>  pan.rs:26-93 (ID 49): mono -> stereo, equal power.  N = 1: fixed pan; N = 2: pan on input 1, weights
+// recomputed every sample in tick and in process alike (:55-61, :70-76).
+template <int NIN>
+struct PannerT {
+    static constexpr int IN = NIN, OUT = 2, RINGS = 0;
     static constexpr uint64_t ID = 49;
     float pan, lw, rw;
     template <class V> FD_HD void visit(V& v) {
         v.f(pan, PARAM, "pan");
-        v.f(lw, COEF, "left_weight");
-        v.f(rw, COEF, "right_weight");
+        v.f(lw, NIN > 1 ? STATE : COEF, "left_weight");
+        v.f(rw, NIN > 1 ? STATE : COEF, "right_weight");
     }
     FD_HD void bind(Ctx&) {}
-    FD_HD void init() { pan = 0.0f; }
-    FD_HD void update(double) {  // pan_weights :13-17
-        float c = pan > -1.0f ? pan : -1.0f;
+    FD_HD void init() { pan = 0.0f; weights(0.0f); }
+    FD_HD void weights(float value) {  // pan_weights :13-17
+        float c = value > -1.0f ? value : -1.0f;
         c = c < 1.0f ? c : 1.0f;
         float angle = (c + 1.0f) * (F32_PI * 0.25f);
         lw = cosf_musl(angle);
         rw = sinf_musl(angle);
     }
+    FD_HD void update(double) { if (NIN == 1) weights(pan); }
     FD_HD void reset() {}
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
     FD_HD void end_simd() {}
-    template <int PH> FD_HD void step(const float* in, float* out) {  // :55-62 / :63-69
-        out[0] = lw * in[0];
-        out[1] = rw * in[0];
+    template <int PH> FD_HD void step(const float* in, float* out) {  // :55-62 / :63-77
+        if (NIN > 1) {
+            weights(in[1]);
+            out[0] = PH == PH_TICK ? lw * in[0] : in[0] * lw;
+            out[1] = PH == PH_TICK ? rw * in[0] : in[0] * rw;
+        } else {
+            out[0] = lw * in[0];
+            out[1] = rw * in[0];
+        }
     }
     template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
-        out[0] = in[0] * lw;
-        out[1] = in[0] * rw;
+        if (NIN > 1) {
+            float i0[2] = {in[0].x, in[1].x}, i1[2] = {in[0].y, in[1].y}, o0[2], o1[2];
+            this->template step<PH>(i0, o0);
+            this->template step<PH>(i1, o1);
+            out[0] = v2f{o0[0], o1[0]};
+            out[1] = v2f{o0[1], o1[1]};
+        } else {
+            out[0] = in[0] * lw;
+            out[1] = in[0] * rw;
+        }
     }
 };
+using Panner = PannerT<1>;
 
 // ---------------------------------------------------------------------------------------------------------
 // waveshapers (shape.rs:11-201) -- the shape KIND is a per-voice parameter (one kernel for all shapes)
@@ -1741,9 +1759,9 @@ struct Pluck {
 // on input 1.  The f32x8 `process` writes 8 samples and then reads with per-lane offsets; because the clamped delay
 // is at least one sample (Tap) / the read never runs ahead of the write (TapLinear), each lane reads exactly what
 // `tick` reads, so one sample-serial implementation serves both paths.
-template <bool LINEAR>
+template <bool LINEAR, int NT = 1>  // NT taps: multitap / multitap_linear (inputs 1..NT = delays, output = their sum)
 struct TapT {
-    static constexpr int IN = 2, OUT = 1, RINGS = 1;
+    static constexpr int IN = 1 + NT, OUT = 1, RINGS = 1;
     static constexpr uint64_t ID = LINEAR ? 54 : 50;
     float min_delay, max_delay;                    // params
     float srf, min_c, max_c;                       // coefs
@@ -1783,18 +1801,20 @@ struct TapT {
     FD_HD void end_simd() {}
     template <int PH> FD_HD void step(const float* in, float* out) {  // tick :212-236 / :448-463
         ring[(size_t)i * vs] = in[0];
-        float tap = rs_clamp(min_c, max_c, in[1]) * srf;
-        uint32_t tap_floor = (uint32_t)tap;
-        uint32_t i1 = (i - tap_floor) & mask;
-        float d = tap - (float)tap_floor;
         float o = 0.0f;
-        if (LINEAR) {
-            uint32_t i2 = (i1 - 1u) & mask;
-            float a = ring[(size_t)i1 * vs], b = ring[(size_t)i2 * vs];
-            o += a * (1.0f - d) + b * d;  // lerp math.rs:169-178
-        } else {
-            uint32_t i0 = (i1 + 1u) & mask, i2 = (i1 - 1u) & mask, i3 = (i1 - 2u) & mask;
-            o += splinef(ring[(size_t)i0 * vs], ring[(size_t)i1 * vs], ring[(size_t)i2 * vs], ring[(size_t)i3 * vs], d);
+        _Pragma("unroll") for (int k = 1; k <= NT; k++) {
+            float tap = rs_clamp(min_c, max_c, in[k]) * srf;
+            uint32_t tap_floor = (uint32_t)tap;
+            uint32_t i1 = (i - tap_floor) & mask;
+            float d = tap - (float)tap_floor;
+            if (LINEAR) {
+                uint32_t i2 = (i1 - 1u) & mask;
+                float a = ring[(size_t)i1 * vs], b = ring[(size_t)i2 * vs];
+                o += a * (1.0f - d) + b * d;  // lerp math.rs:169-178
+            } else {
+                uint32_t i0 = (i1 + 1u) & mask, i2 = (i1 - 1u) & mask, i3 = (i1 - 2u) & mask;
+                o += splinef(ring[(size_t)i0 * vs], ring[(size_t)i1 * vs], ring[(size_t)i2 * vs], ring[(size_t)i3 * vs], d);
+            }
         }
         i = (i + 1u) & mask;
         out[0] = o;
@@ -1802,17 +1822,18 @@ struct TapT {
     FD_STEP2_VIA_STEP
 };
 
-// AllNest<U1, X>  delay.rs:294-377 (ID 83): Schroeder allpass around the single-channel node X, fixed coefficient.
-template <class X>
+// AllNest<N, X>  delay.rs:294-377 (ID 83): Schroeder allpass around the single-channel node X; N = 1: fixed
+// coefficient (allnest_c), N = 2: coefficient on input 1 (allnest).
+template <class X, int NIN = 1>
 struct AllNest {
     static_assert(X::IN == 1 && X::OUT == 1, "AllNest wraps a 1-in 1-out node");
-    static constexpr int IN = 1, OUT = 1, RINGS = X::RINGS;
+    static constexpr int IN = NIN, OUT = 1, RINGS = X::RINGS;
     static constexpr uint64_t ID = 83;
     X x;
     float eta, z;
     template <class V> FD_HD void visit(V& v) {
         v.enter(0); x.visit(v); v.leave();
-        v.f(eta, PARAM, "coefficient");
+        v.f(eta, NIN > 1 ? STATE : PARAM, "coefficient");
         v.f(z, STATE, "z");
     }
     FD_HD void bind(Ctx& c) { x.bind(c); }
@@ -1824,6 +1845,7 @@ struct AllNest {
     FD_HD bool tripped() const { return x.tripped(); }
     FD_HD void end_simd() { x.end_simd(); }
     template <int PH> FD_HD void step(const float* in, float* out) {  // :322-330 (tick everywhere: no process override)
+        if (NIN > 1) eta = in[1];
         float v = in[0] - eta * z;
         float y = eta * v + z;
         float zi;
@@ -2224,6 +2246,174 @@ struct AFollow {
         acoeff_now = acoeff;
         rcoeff_now = rcoeff;
         out[0] = v3;
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// MeterState  dynamics.rs:336-394: Meter::Sample (MODE 0), Meter::Peak(timescale) (1), Meter::Rms(timescale) (2).  The
+// f64 timescale travels as its bit pattern in a u64 slot.
+template <int MODE>
+struct MeterCore {
+    float smoothing, state;
+    uint64_t ts_bits;
+    template <class V> FD_HD void visit(V& v) {
+        v.u64(ts_bits, PARAM, "timescale");
+        v.f(smoothing, COEF, "smoothing");
+        v.f(state, STATE, "state");
+    }
+    FD_HD void init() { smoothing = 0.0f; state = 0.0f; ts_bits = __builtin_bit_cast(uint64_t, 0.1); }
+    FD_HD void update(double sr) {  // :355-364
+        if (MODE != 0) smoothing = (float)pow_f64(0.5, 1.0 / (__builtin_bit_cast(double, ts_bits) * sr));
+    }
+    FD_HD void reset() { state = 0.0f; }
+    FD_HD void tick(float value) {  // :367-375
+        if (MODE == 0) state = value;
+        else if (MODE == 1) state = __builtin_fmaxf(state * smoothing, __builtin_fabsf(value));
+        else state = state * smoothing + value * value * (1.0f - smoothing);
+    }
+    FD_HD float level() const { return MODE == 2 ? __builtin_sqrtf(state) : state; }  // :378-384
+};
+
+// MeterNode  dynamics.rs:398-438 (ID 61): outputs the meter level; Monitor :441-508 (ID 56): passes the input through and
+// keeps the level in its `state` slot (the reference publishes it through a Shared atomic; here the host reads the slot
+// with fdsp_bank_get_slot).  Monitor::process ticks a Meter::Sample with the block's last sample only -- the same
+// final state as ticking every sample.
+template <int MODE, bool MONITOR>
+struct MeterT {
+    static constexpr int IN = 1, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = MONITOR ? 56 : 61;
+    MeterCore<MODE> m;
+    template <class V> FD_HD void visit(V& v) { m.visit(v); }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void init() { m.init(); }
+    FD_HD void update(double sr) { m.update(sr); }
+    FD_HD void reset() { m.reset(); }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        m.tick(in[0]);
+        out[0] = MONITOR ? in[0] : m.level();
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// Var  shared.rs:85-133 (ID 68): outputs a value the host may change at any time -- a per-voice parameter here
+// (fdsp_bank_set_param "..:value" plays Shared::set_value).
+struct Var {
+    static constexpr int IN = 0, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 68;
+    float value;
+    template <class V> FD_HD void visit(V& v) { v.f(value, PARAM, "value"); }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void init() { value = 0.0f; }
+    FD_HD void update(double) {}
+    FD_HD void reset() {}
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float*, float* out) { out[0] = value; }
+    template <int PH> FD_HD void step2(const v2f*, v2f* out) { out[0] = v2f{value, value}; }
+};
+
+// Limiter<N>  dynamics.rs:125-241 (ID 25): look-ahead limiter.  Per voice: N delay rings of `length` frames, a max
+// reduction tree over the window's amplitudes (ReduceBuffer :59-121, kept in one more ring: [1] = total, leaves from
+// leaf_offset), an AFollow over max(1, total * 1.10).  Every voice is at the same ring / tree index, so all accesses
+// coalesce across the wave.  No process override: tick arithmetic everywhere.
+// `length` = max(1, round(sample_rate * attack_time)) must fit the bank's ring capacity: leaf_offset + length + 1 slots.
+template <int N>
+struct Limiter {
+    static constexpr int IN = N, OUT = N, RINGS = N + 1;
+    static constexpr uint64_t ID = 25;
+    float attack, release;  // params (Limiter::new arguments)
+    AFollow follower;
+    uint32_t length, leaf, index, fill;
+    float last_sr;
+    float* buf[N];
+    float* tree;
+    size_t vs;
+    uint32_t cap;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(attack, PARAM, "attack_time");
+        v.f(release, PARAM, "release_time");
+        v.enter(0); follower.visit(v); v.leave();
+        v.u32(length, COEF, "length");
+        v.u32(leaf, COEF, "leaf_offset");
+        v.f(last_sr, COEF, "sample_rate");
+        v.u32(index, STATE, "index");
+        v.u32(fill, STATE, "fill");
+    }
+    FD_HD void bind(Ctx& c) {
+        for (int i = 0; i < N; i++) buf[i] = c.claim_ring();
+        tree = c.claim_ring();
+        vs = c.vstride;
+        cap = c.ring_cap;
+    }
+    FD_HD void init() {
+        attack = 0.005f; release = 0.05f;
+        follower.init();
+        length = 0; leaf = 1; index = 0; fill = 0; last_sr = 0.0f;
+    }
+    FD_HD void clear() {  // reducer.clear(), buffer.clear(), index = 0  (:190-199)
+        index = 0;
+        fill = 0;
+        for (uint32_t k = 0; k < cap; k++) tree[(size_t)k * vs] = 0.0f;
+    }
+    FD_HD void update(double sr) {  // Limiter::new :159-171 + set_sample_rate :188-199
+        follower.atime = attack * 0.4f;
+        follower.rtime = release * 0.4f;
+        follower.update(sr);
+        double want = __builtin_round(sr * (double)attack);
+        uint32_t len = want < 1.0 ? 1u : (uint32_t)want;
+        while (len > 1u && next_pow2_u32(len) + len + (len & 1u) > cap) len--;  // capacity fixed at bank creation
+        if (len != length || last_sr != (float)sr) {
+            length = len;
+            leaf = next_pow2_u32(len);
+            last_sr = (float)sr;
+            clear();
+        }
+    }
+    FD_HD void reset() { clear(); }  // :184-186 (the follower keeps its state, only its coefficients are refreshed)
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    FD_HD void tree_set(uint32_t idx, float value) {  // ReduceBuffer::set :104-112
+        uint32_t i = leaf + idx;
+        tree[(size_t)i * vs] = value;
+        float cur = value;
+        while (i > 1u) {
+            cur = __builtin_fmaxf(cur, tree[(size_t)(i ^ 1u) * vs]);
+            i >>= 1;
+            tree[(size_t)i * vs] = cur;
+        }
+    }
+    template <int PH> FD_HD void step(const float* in, float* out) {  // tick :202-226
+        float amplitude = 0.0f;
+        for (int c = 0; c < N; c++) amplitude = __builtin_fmaxf(amplitude, __builtin_fabsf(in[c]));
+        tree_set(index, amplitude);
+        const float total = tree[vs];  // [1]
+        if (fill < length) {
+            for (int c = 0; c < N; c++) buf[c][(size_t)index * vs] = in[c];
+            fill++;
+            if (fill == length) follower.v1 = follower.v2 = follower.v3 = total;  // set_value :196-200
+            for (int c = 0; c < N; c++) out[c] = 0.0f;
+        } else {
+            float o[N];
+            for (int c = 0; c < N; c++) {
+                o[c] = buf[c][(size_t)index * vs];
+                buf[c][(size_t)index * vs] = in[c];
+            }
+            float x = __builtin_fmaxf(1.0f, total * 1.10f), y;
+            follower.template step<PH_TICK>(&x, &y);
+            const float limit = follower.v3;
+            const float z = 1.0f / limit;
+            for (int c = 0; c < N; c++) out[c] = o[c] * z;
+        }
+        index++;
+        if (index >= length) index = 0;
     }
     FD_STEP2_VIA_STEP
 };

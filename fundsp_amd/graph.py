@@ -111,7 +111,7 @@ def _leaf(t, nin, nout, rings=0, **fields):
 def constant(*v): return Graph(f"Constant<{len(v)}>", 0, len(v), [((), f"value[{i}]", x, False) for i, x in enumerate(v)])
 dc = constant
 def pass_(): return _leaf("Pass", 1, 1)
-def tick(): return _leaf("Tick<1>", 1, 1)
+def tick(n=1): return _leaf(f"Tick<{n}>", n, n)
 def sine(): return _leaf("Sine", 1, 1)
 def sine_hz(f): return constant(f) >> sine()
 def noise(): return _leaf("Noise", 0, 1)
@@ -191,6 +191,12 @@ def dsf_square_r(r): return _leaf("Dsf<1>", 1, 1, harmonic_spacing=2.0, roughnes
 def delay(t): return _leaf("Delay", 1, 1, rings=1, time=t)
 def tap(min_delay, max_delay): return _leaf("TapT<false>", 2, 1, rings=1, min_delay=min_delay, max_delay=max_delay)
 def tap_linear(min_delay, max_delay): return _leaf("TapT<true>", 2, 1, rings=1, min_delay=min_delay, max_delay=max_delay)
+def multitap(n, min_delay, max_delay): return _leaf(f"TapT<false,{n}>", 1 + n, 1, rings=1, min_delay=min_delay, max_delay=max_delay)
+def multitap_linear(n, min_delay, max_delay): return _leaf(f"TapT<true,{n}>", 1 + n, 1, rings=1, min_delay=min_delay, max_delay=max_delay)
+def multitick(n): return _leaf(f"Tick<{n}>", n, n)
+def panner(): return _leaf("PannerT<2>", 2, 2)
+def allnest(x):  # prelude32.rs:1112: coefficient on input 1
+    return Graph(f"AllNest<{x.type},2>", 2, 1, [((0,) + p, f, v, u) for p, f, v, u in x.params], x.rings, x.source)
 def allnest_c(coefficient, x):
     return Graph(f"AllNest<{x.type}>", 1, 1, [((0,) + p, f, v, u) for p, f, v, u in x.params] + [((), "coefficient", coefficient, False)], x.rings, x.source)
 def resample(x):  # prelude32.rs:1021: x is a generator, input 0 = speed
@@ -248,6 +254,17 @@ def feedback(x): return _feedback(x, None, "FbId")                 # prelude32.r
 def feedback2(x, y): return _feedback(x, y, "FbId")                # prelude32.rs:1061
 def fdn(x): return _feedback(x, None, "FbHadamard")                # prelude32.rs:1323
 def fdn2(x, y): return _feedback(x, y, "FbHadamard")               # prelude32.rs:1340
+METER_MODES = dict(sample=0, peak=1, rms=2)
+def _meter(mode, timescale, monitor):
+    ts = np.asarray(timescale, dtype=np.float64).view(np.uint64)   # the f64 timescale travels as its bit pattern
+    return Graph(f"MeterT<{METER_MODES[mode]},{'true' if monitor else 'false'}>", 1, 1, [((), "timescale", ts, True)])
+def meter(mode, timescale=0.1): return _meter(mode, timescale, False)     # prelude32.rs:300: meter(Meter::Peak(t)) etc.
+def monitor(mode, timescale=0.1): return _meter(mode, timescale, True)    # level readable from the ":state" slot
+def var(value): return _leaf("Var", 0, 1, value=value)                    # a Shared value = a per-voice parameter
+def limiter(attack, release):                                             # prelude32.rs:1275; needs ring_frames
+    return _leaf("Limiter<1>", 1, 1, rings=2, attack_time=attack, release_time=release)
+def limiter_stereo(attack, release):                                      # prelude32.rs:1286
+    return _leaf("Limiter<2>", 2, 2, rings=3, attack_time=attack, release_time=release)
 def thru(x): return ~x
 def bus(x, y): return x & y
 def branch(x, y): return x ^ y

@@ -42,6 +42,7 @@ struct onode {
     int type, nin, nout;
     uint64_t id;
     onode *x, *y;
+    onode *aux;   /* Limiter: its AFollow (not part of the graph recursion) */
     onode **kids; /* O_MULTI: the N nodes of MultiBus / MultiStack / MultiBranch / Reduce / Chain */
     int nkids, multi;
     int jm, jn;   /* Split / Join: M channels, N branches */
@@ -133,6 +134,14 @@ struct onode {
         void *env_ctx;
         float env_v0[O_MAX_ENV], env_v1[O_MAX_ENV], env_val[O_MAX_ENV], env_d[O_MAX_ENV];
         int ps_ready; /* PhaseSynth::phase_ready */
+        /* MeterState (dynamics.rs:336-339) */
+        int mt_mode, mt_monitor;
+        double mt_timescale;
+        float mt_smoothing, mt_state;
+        /* Limiter (dynamics.rs:125-139) */
+        double lm_lookahead, lm_sr;
+        size_t lm_length, lm_leaf, lm_index, lm_fill;
+        float *lm_tree, *lm_buf;
         /* Declick (dynamics.rs:245-250) */
         float dc_t, dc_duration, dc_sd;
         /* Dsf (oscillator.rs:121-129) */
@@ -159,6 +168,8 @@ struct owavetable {
 /* ------------------------------------------------------------------------------------------------------ */
 /* helpers                                                                                                */
 /* ------------------------------------------------------------------------------------------------------ */
+static void meter_set_sr(onode *n, double sr);
+static void limiter_set_sr(onode *n, double sr);
 static onode *o_new(int type, int nin, int nout, uint64_t id) {
     onode *n = (onode *)calloc(1, sizeof(onode));
     n->type = type;
@@ -177,6 +188,9 @@ void o_free(onode *n) {
         for (int i = 0; i < 32; i++) free(n->s.rv_buf[i]);
     o_free(n->x);
     o_free(n->y);
+    o_free(n->aux);
+    free(n->s.lm_tree);
+    free(n->s.lm_buf);
     for (int i = 0; i < n->nkids; i++) o_free(n->kids[i]);
     free(n->kids);
     free(n->tmp2);
@@ -556,6 +570,8 @@ void o_reset(onode *n) {
     if (n->type == O_IMPULSE) n->s.value[0] = 1.0f; /* audionode.rs:2860-2862 */
     if (n->type == O_DECLICK) n->s.dc_t = 0.0f;     /* dynamics.rs:268-270 */
     if (n->type == O_PHASESYNTH) n->s.ps_ready = 0; /* wavetable.rs:387-389 */
+    if (n->type == O_METER) n->s.mt_state = 0.0f;   /* dynamics.rs:351-353 */
+    if (n->type == O_LIMITER) limiter_set_sr(n, n->s.lm_sr); /* dynamics.rs:184-186 */
     if (n->type == O_FEEDBACK) memset(n->fb_value, 0, sizeof n->fb_value); /* feedback.rs:118-121 */
     leaf_reset(n);
 }
@@ -699,6 +715,8 @@ void o_set_sample_rate(onode *n, double sr) {
     for (int i = 0; i < n->nkids; i++) o_set_sample_rate(n->kids[i], sr);
     if (n->type == O_DECLICK) n->s.dc_sd = (float)(1.0 / sr); /* dynamics.rs:272-275 */
     if (n->type == O_PHASESYNTH) n->s.ws_sr = (float)sr;      /* wavetable.rs:391-393 */
+    if (n->type == O_METER) meter_set_sr(n, sr);
+    if (n->type == O_LIMITER) limiter_set_sr(n, sr);
     leaf_set_sample_rate(n, sr);
 }
 
@@ -960,8 +978,15 @@ onode *o_panner(int inputs, float pan) { /* Panner::new pan.rs:33-40, ID 49 */
     return n;
 }
 
-onode *o_tap(int linear, float min_delay, float max_delay) { /* Tap::new :164-176 (ID 50) / TapLinear::new :404-418 (ID 54) */
-    onode *n = o_new(O_TAP, 2, 1, linear ? 54 : 50);
+onode *o_tap(int linear, float min_delay, float max_delay) { return o_multitap(linear, 1, min_delay, max_delay); }
+onode *o_allnest2(onode *x) { /* allnest(x) = AllNest::<U2, _>::new(0.0, x) prelude32.rs:1112: coefficient on input 1 */
+    onode *n = o_allnest(0.0f, x);
+    n->nin = 2;
+    return n;
+}
+onode *o_multitap(int linear, int taps, float min_delay, float max_delay) { /* Tap::<N>::new :164-176 (ID 50) / TapLinear::<N>::new :404-418 (ID 54) */
+    if (taps < 1 || taps + 1 > O_MAX_CH) return NULL;
+    onode *n = o_new(O_TAP, 1 + taps, 1, linear ? 54 : 50);
     n->s.tap_linear = linear;
     n->s.tap_min = min_delay;
     n->s.tap_max = max_delay;
@@ -1046,6 +1071,51 @@ static void afollow_set(onode *n, float a, float r) { /* set_time :178-192 */
         n->s.fo_coeff_now = n->s.fo_coeff;
         n->s.fo_rcoeff_now = n->s.fo_rcoeff;
     }
+}
+static void meter_set_sr(onode *n, double sr) { /* dynamics.rs:355-364 */
+    if (n->s.mt_mode != O_METER_SAMPLE) n->s.mt_smoothing = (float)pow(0.5, 1.0 / (n->s.mt_timescale * sr));
+}
+onode *o_meter(int mode, double timescale, int monitor) {
+    onode *n = o_new(O_METER, 1, 1, monitor ? 56 : 61);
+    n->s.mt_mode = mode; n->s.mt_monitor = monitor; n->s.mt_timescale = timescale;
+    n->s.mt_smoothing = 0.0f; n->s.mt_state = 0.0f;
+    meter_set_sr(n, DEFAULT_SR);
+    return n;
+}
+float o_meter_level(const onode *n) { return n->s.mt_mode == O_METER_RMS ? sqrtf(n->s.mt_state) : n->s.mt_state; }
+onode *o_var(float value) {
+    onode *n = o_new(O_VAR, 0, 1, 68);
+    n->s.value[0] = value;
+    return n;
+}
+void o_var_set(onode *n, float value) { n->s.value[0] = value; }
+
+static void limiter_set_sr(onode *n, double sr) { /* dynamics.rs:188-199 */
+    n->s.lm_index = 0;
+    n->s.lm_sr = sr;
+    double r = round(sr * n->s.lm_lookahead);
+    size_t length = r < 1.0 ? 1 : (size_t)r;
+    if (length != n->s.lm_length) { /* new_buffer :154-156, ReduceBuffer::new :75-88 */
+        size_t leaf = 1;
+        while (leaf < length) leaf <<= 1;
+        n->s.lm_length = length;
+        n->s.lm_leaf = leaf;
+        n->s.lm_tree = (float *)realloc(n->s.lm_tree, (leaf + length + (length & 1)) * sizeof(float));
+        n->s.lm_buf = (float *)realloc(n->s.lm_buf, length * (size_t)n->nin * sizeof(float));
+    }
+    o_set_sample_rate(n->aux, sr);
+    memset(n->s.lm_tree, 0, (n->s.lm_leaf + n->s.lm_length + (n->s.lm_length & 1)) * sizeof(float));
+    n->s.lm_fill = 0; /* buffer.clear() */
+}
+onode *o_afollow(float attack_time, float release_time);
+onode *o_limiter(int channels, float attack_time, float release_time) { /* Limiter::new :159-171 with DEFAULT_SR (prelude32.rs:1275) */
+    if (channels < 1 || channels > O_MAX_CH) return NULL;
+    onode *n = o_new(O_LIMITER, channels, channels, 25);
+    n->aux = o_afollow(attack_time * 0.4f, release_time * 0.4f);
+    n->s.lm_lookahead = (double)attack_time;
+    n->s.lm_length = 0;
+    limiter_set_sr(n, DEFAULT_SR);
+    return n;
 }
 onode *o_afollow(float attack_time, float release_time) { /* AFollow::new :157-166 (ID 29) */
     onode *n = o_new(O_AFOLLOW, 1, 1, 29);
@@ -1745,6 +1815,48 @@ void o_tick(onode *n, const float *in, float *out) {
         break;
     }
     case O_WRAP: o_tick(n->x, in, out); break; /* wavetable.rs:472-474 */
+    case O_METER: { /* MeterState::tick dynamics.rs:367-375; MeterNode::tick :427-430; Monitor::tick :482-486 */
+        float v = in[0];
+        if (n->s.mt_mode == O_METER_SAMPLE) n->s.mt_state = v;
+        else if (n->s.mt_mode == O_METER_PEAK) n->s.mt_state = fmaxf_rs(n->s.mt_state * n->s.mt_smoothing, fabsf(v));
+        else n->s.mt_state = n->s.mt_state * n->s.mt_smoothing + v * v * (1.0f - n->s.mt_smoothing);
+        out[0] = n->s.mt_monitor ? v : o_meter_level(n);
+        break;
+    }
+    case O_VAR: out[0] = n->s.value[0]; break; /* shared.rs:117-120 */
+    case O_LIMITER: { /* dynamics.rs:202-226 */
+        float amplitude = 0.0f;
+        for (int c = 0; c < n->nin; c++) amplitude = fmaxf_rs(amplitude, fabsf(in[c]));
+        { /* ReduceBuffer::set :104-112 */
+            size_t i = n->s.lm_leaf + n->s.lm_index;
+            n->s.lm_tree[i] = amplitude;
+            while (i > 1) {
+                float reduced = fmaxf_rs(n->s.lm_tree[i], n->s.lm_tree[i ^ 1]);
+                i >>= 1;
+                n->s.lm_tree[i] = reduced;
+            }
+        }
+        float total = n->s.lm_tree[1];
+        float *slot = n->s.lm_buf + n->s.lm_index * (size_t)n->nin;
+        if (n->s.lm_fill < n->s.lm_length) {
+            for (int c = 0; c < n->nin; c++) slot[c] = in[c];
+            n->s.lm_fill++;
+            if (n->s.lm_fill == n->s.lm_length) /* follower.set_value(total) follow.rs:196-200 */
+                n->aux->s.fo_v1 = n->aux->s.fo_v2 = n->aux->s.fo_v3 = total;
+            for (int c = 0; c < n->nout; c++) out[c] = 0.0f;
+        } else {
+            float o[O_MAX_CH];
+            for (int c = 0; c < n->nin; c++) { o[c] = slot[c]; slot[c] = in[c]; }
+            float x = fmaxf_rs(1.0f, total * 1.10f), y;
+            o_tick(n->aux, &x, &y); /* filter_mono */
+            float limit = n->aux->s.fo_v3;
+            float z = 1.0f / limit;
+            for (int c = 0; c < n->nout; c++) out[c] = o[c] * z;
+        }
+        n->s.lm_index++; /* advance :144-149 */
+        if (n->s.lm_index >= n->s.lm_length) n->s.lm_index = 0;
+        break;
+    }
     case O_ENVELOPE_IN: /* envelope.rs:305-313 */
         if (n->s.et >= n->s.et1) envin_next_segment(n, in);
         for (int i = 0; i < n->nout; i++) {
@@ -1847,17 +1959,19 @@ void o_tick(onode *n, const float *in, float *out) {
     case O_TAP: { /* Tap::tick delay.rs:212-236 / TapLinear::tick :448-463 (the f32x8 process path reads the same samples) */
         size_t mask = n->s.tlen - 1;
         n->s.tbuf[n->s.ti] = in[0];
-        float tap = rs_clampf(n->s.tap_min_c, n->s.tap_max_c, in[1]) * n->s.tap_sr;
-        size_t tap_floor = (size_t)tap;
-        size_t i1 = (n->s.ti - tap_floor) & mask;
-        float d = tap - (float)tap_floor;
         float o = 0.0f;
-        if (n->s.tap_linear) {
-            size_t i2 = (i1 - 1) & mask;
-            o += n->s.tbuf[i1] * (1.0f - d) + n->s.tbuf[i2] * d;
-        } else {
-            size_t i0 = (i1 + 1) & mask, i2 = (i1 - 1) & mask, i3 = (i1 - 2) & mask;
-            o += splinef(n->s.tbuf[i0], n->s.tbuf[i1], n->s.tbuf[i2], n->s.tbuf[i3], d);
+        for (int k = 1; k < n->nin; k++) {
+            float tap = rs_clampf(n->s.tap_min_c, n->s.tap_max_c, in[k]) * n->s.tap_sr;
+            size_t tap_floor = (size_t)tap;
+            size_t i1 = (n->s.ti - tap_floor) & mask;
+            float d = tap - (float)tap_floor;
+            if (n->s.tap_linear) {
+                size_t i2 = (i1 - 1) & mask;
+                o += n->s.tbuf[i1] * (1.0f - d) + n->s.tbuf[i2] * d;
+            } else {
+                size_t i0 = (i1 + 1) & mask, i2 = (i1 - 1) & mask, i3 = (i1 - 2) & mask;
+                o += splinef(n->s.tbuf[i0], n->s.tbuf[i1], n->s.tbuf[i2], n->s.tbuf[i3], d);
+            }
         }
         n->s.ti = (n->s.ti + 1) & mask;
         out[0] = o;
@@ -1896,7 +2010,8 @@ void o_tick(onode *n, const float *in, float *out) {
         n->s.os_out_i = (n->s.os_out_i + 1) & 0x7f;
         break;
     }
-    case O_ALLNEST: { /* delay.rs:322-330 */
+    case O_ALLNEST: { /* delay.rs:344-352 */
+        if (n->nin > 1) n->s.eta = in[1];
         float v = in[0] - n->s.eta * n->s.zz;
         float y = n->s.eta * v + n->s.zz;
         float z;

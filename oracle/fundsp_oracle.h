@@ -19,7 +19,7 @@ enum {
     O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP,
     O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO, O_SHAPER, O_PHASE_OSC, O_CHAOS, O_NLBIQUAD, O_TAP, O_ALLNEST,
     O_ONEPOLE, O_PINKPASS, O_MORPH, O_REZ, O_FOLLOW, O_AFOLLOW, O_MLS, O_OVERSAMPLE, O_DSF, O_PLUCK, O_ENVELOPE, O_RESAMPLE, O_ENVELOPE_IN,
-    O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK, O_FEEDBACK, O_PHASESYNTH, O_WRAP
+    O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK, O_FEEDBACK, O_PHASESYNTH, O_WRAP, O_METER, O_VAR, O_LIMITER
 };
 enum { O_OP_LOWPOLE = 0, O_OP_HIGHPOLE, O_OP_DCBLOCK, O_OP_ALLPOLE };
 enum { O_SH_CLIP = 0, O_SH_CLIPTO, O_SH_TANH, O_SH_ATAN, O_SH_SOFTSIGN, O_SH_CRUSH, O_SH_SOFTCRUSH, O_SH_ADAPTIVE_TANH };
@@ -63,6 +63,8 @@ onode *o_adsr_live(float attack, float decay, float sustain, float release);
 onode *o_panner(int inputs, float pan);
 /* Shaper<S> (shape.rs:205); for O_SH_ADAPTIVE_TANH p0 = hardness, p1 = timescale */
 onode *o_tap(int linear, float min_delay, float max_delay);   /* Tap<U1> / TapLinear<U1> (delay.rs:148,386) */
+onode *o_multitap(int linear, int taps, float min_delay, float max_delay); /* Tap<N> / TapLinear<N> */
+onode *o_allnest2(onode *x);                                  /* AllNest<U2, X>: coefficient on input 1 */
 onode *o_allnest(float coefficient, onode *x);                /* AllNest<U1, X> (delay.rs:294), takes ownership of x */
 onode *o_onepole(int kind, int inputs, float cutoff_or_delay); /* Lowpole/Highpole/DCBlock/Allpole (filter.rs) */
 onode *o_pinkpass(void);
@@ -78,6 +80,12 @@ onode *o_dsf(int inputs, float harmonic_spacing, float roughness); /* Dsf<U1/U2>
 onode *o_resample(onode *x);                                     /* Resample<X> (resample.rs:210): x a generator; input 0 = speed */
 onode *o_oversample(onode *x);                                   /* Oversampler<X> (oversample.rs:66), takes ownership of x */
 onode *o_rez(int inputs, float bandpass, float cutoff, float q); /* Rez<f32, U1/U3> (rez.rs): inputs 1 or 3 */
+enum { O_METER_SAMPLE = 0, O_METER_PEAK, O_METER_RMS };
+onode *o_meter(int mode, double timescale, int monitor);        /* MeterNode (dynamics.rs:398, ID 61) / Monitor (:441, ID 56) */
+float o_meter_level(const onode *n);                             /* what Monitor stores in its Shared */
+onode *o_var(float value);                                       /* Var (shared.rs:85, ID 68) */
+void o_var_set(onode *n, float value);
+onode *o_limiter(int channels, float attack_time, float release_time); /* Limiter<N> (dynamics.rs:125, ID 25) */
 onode *o_follow(float response_time);                           /* Follow<f32> (follow.rs:31) */
 onode *o_afollow(float attack_time, float release_time);         /* AFollow<f32> (follow.rs:137) */
 onode *o_mls(unsigned bits);                                     /* Mls (noise.rs:103), 1 <= bits <= 31 */

@@ -78,14 +78,15 @@ def lib():
         "o_math_powf": (f, [f, f]),
         "o_seq_new": (P, [i, i, d]), "o_seq_free": (None, [P]), "o_seq_push": (i, [P, d, d, i, d, d, P]),
         "o_seq_render": (None, [P, C.c_size_t, i, fp, fp, fp]), "o_seq_time": (d, [P]), "o_mls_period": (C.c_uint64, [C.c_uint]),
-        "o_tap": (P, [i, f, f]), "o_allnest": (P, [f, P]),
+        "o_tap": (P, [i, f, f]), "o_allnest": (P, [f, P]), "o_multitap": (P, [i, i, f, f]), "o_allnest2": (P, [P]),
         "o_shaper": (P, [i, f, f]), "o_phase_osc": (P, [i]), "o_osc_set_phase": (None, [P, f]), "o_chaos": (P, [i]),
         "o_nlbiquad": (P, [i, i, i, i, f, f, f, f, f]), "o_math_atanf": (f, [f]), "o_math_wide_atanf": (f, [f]),
         "o_adaptive_smoothing": (d, [f, d]),
         "o_multipass": (P, [i]), "o_sink": (P, [i]), "o_split": (P, [i, i]), "o_join": (P, [i, i]),
         "o_reverse": (P, [i]), "o_impulse": (P, [i]), "o_map": (P, [i, i, P, P]),
         "o_shape_fn": (P, [P, P]), "o_declick": (P, [f]),
-        "o_feedback": (P, [P, P, i]),
+        "o_feedback": (P, [P, P, i]), "o_meter": (P, [i, d, i]), "o_meter_level": (f, [P]), "o_var": (P, [f]),
+        "o_var_set": (None, [P, f]), "o_limiter": (P, [i, f, f]),
         "o_branch": (P, [P, P]), "o_bus": (P, [P, P]), "o_thru": (P, [P]), "o_multi": (P, [i, i, C.POINTER(P), i]),
         "o_reverb_stereo": (P, [d, d, d]),
         "o_reverb_stereo_params": (None, [d, d, d, d, fp, C.POINTER(C.c_int), fp, fp]),
@@ -218,6 +219,13 @@ def feedback(x): return Node(lib().o_feedback(x.ptr, None, 0), (x,))            
 def feedback2(x, y): return Node(lib().o_feedback(x.ptr, y.ptr, 0), (x, y))     # prelude32.rs:1061
 def fdn(x): return Node(lib().o_feedback(x.ptr, None, 1), (x,))                 # prelude32.rs:1323
 def fdn2(x, y): return Node(lib().o_feedback(x.ptr, y.ptr, 1), (x, y))          # prelude32.rs:1340
+METER_MODES = dict(sample=0, peak=1, rms=2)
+def meter(mode, timescale=0.1): return Node(lib().o_meter(METER_MODES[mode], timescale, 0))    # prelude32.rs:300 meter(Meter::Peak(t))
+def monitor(mode, timescale=0.1): return Node(lib().o_meter(METER_MODES[mode], timescale, 1))  # prelude32.rs monitor(&shared, meter)
+def meter_level(n): return np.float32(lib().o_meter_level(n.ptr))
+def var(value): return Node(lib().o_var(value))                                               # prelude32.rs var(&shared)
+def limiter(attack, release): return Node(lib().o_limiter(1, attack, release))                # prelude32.rs:1275
+def limiter_stereo(attack, release): return Node(lib().o_limiter(2, attack, release))         # prelude32.rs:1286
 def thru(x): return ~x
 def bus(x, y): return x & y
 def branch(x, y): return x ^ y
@@ -487,6 +495,11 @@ def morph(): return Node(lib().o_morph(440.0, 1.0, 0.0))
 def tap(min_delay, max_delay): return Node(lib().o_tap(0, min_delay, max_delay))                  # prelude.rs:910
 def tap_linear(min_delay, max_delay): return Node(lib().o_tap(1, min_delay, max_delay))           # prelude.rs:948
 def allnest_c(coefficient, x): return Node(lib().o_allnest(coefficient, x.ptr), (x,))             # prelude.rs allnest_c
+def allnest(x): return Node(lib().o_allnest2(x.ptr), (x,))                                        # prelude32.rs:1112
+def multitap(n, min_delay, max_delay): return Node(lib().o_multitap(0, n, min_delay, max_delay))  # prelude32.rs:928
+def multitap_linear(n, min_delay, max_delay): return Node(lib().o_multitap(1, n, min_delay, max_delay))  # :965
+def multitick(n): return tick(n)                                                                  # prelude32.rs:878
+def panner(): return Node(lib().o_panner(2, 0.0))                                                 # prelude32.rs:1223
 
 
 def shape(kind, p0=1.0, p1=0.0): return Node(lib().o_shaper(SHAPES[kind], p0, p1))          # prelude.rs:1194

@@ -65,6 +65,14 @@ GRAPHS = {
     # wavetable family: PulseWave (WaveSynth<U2> + PhaseSynth), organ / soft saw / hammond tables
     "pulse_wave": (lambda m: (m.sine_hz(3.0) * 50.0 + 220.0 | m.sine_hz(0.7) * 0.3 + 0.5) >> m.pulse() * 0.2, 0, 0),
     "organ_family": (lambda m: m.organ_hz(110.0) + m.soft_saw_hz(220.0) * 0.5 + (m.sine_hz(5.0) * 3.0 + 55.0 >> m.hammond()), 0, 0),
+    "multitap_allnest_panner": (lambda m: (m.pass_() | m.sine_hz(0.9) * 0.001 + 0.003 | m.sine_hz(1.7) * 0.0005 + 0.002) >> m.multitap(2, 0.001, 0.005)
+                                >> (m.pass_() | m.sine_hz(3.0) * 0.6) >> m.allnest(m.delay(0.0013)) >> m.multitick(1)
+                                >> (m.pass_() | m.sine_hz(0.5)) >> m.panner(), 1, 512),
+    "multitap_linear3": (lambda m: (m.pass_() | m.dc(0.001, 0.0021, 0.0034)) >> m.multitap_linear(3, 0.0005, 0.004) >> m.join(1), 1, 256),
+    # dynamics: look-ahead limiter (reduce tree + delay rings), meters, a Shared value as a parameter
+    "limiter_mono": (lambda m: m.pass_() * 3.0 >> m.limiter(0.002, 0.02), 1, 512),
+    "limiter_stereo": (lambda m: (m.pass_() * 2.0 | m.noise() * (m.sine_hz(3.0) + 1.0)) >> m.limiter_stereo(0.001, 0.01), 1, 256),
+    "meters": (lambda m: (m.pass_() * m.var(0.7)) >> (m.meter("peak", 0.01) ^ m.meter("rms", 0.02) ^ m.meter("sample") ^ m.monitor("rms", 0.005)), 1, 0),
     "moog_q_thru_cut": (lambda m: (m.pass_() | m.dc(800.0)) >> m.moog_q(0.5) >> m.clip() >> m.split(2) >> ~(m.sink() | m.sink()) >> m.join(2), 1, 0),
 }
 
