@@ -391,6 +391,26 @@ def dhighpass(shp): return _nlbiquad(True, 3, "highpass", shp)
 def dbell(shp): return _nlbiquad(True, 4, "bell", shp)
 
 
+
+# --- effects the prelude composes (prelude.rs:2719-2753).  The Rust closure delay_f / phase_f arrives as an Envelope
+# functor (see envelope()): `functor` type name, `source` its definition ("" for the built-in EnvSineHz / EnvExp).
+def flanger(feedback_amount, minimum_delay, maximum_delay, functor, source="", **params):
+    return pass_() & feedback2((pass_() | lfo(functor, source, **params)) >> tap(minimum_delay, maximum_delay),
+                               shape("tanh", feedback_amount))
+
+
+def phaser(feedback_amount, functor, source="", **params):
+    # lfo(move |t| lerp(2.0, 20.0, clamp01(phase_f(t)))): the wrapper is a functor around the caller's
+    wrap = f"PhaserLfo_{functor}"
+    wsrc = (f"struct {wrap} {{ static constexpr int OUT = 1; {functor} f; "
+            "template <class V> FD_HD void visit(V& v) { f.visit(v); } FD_HD void init() { f.init(); } "
+            "FD_HD void eval(float t, float* out) const { float p; f.eval(t, &p); out[0] = lerpf(2.0f, 20.0f, clamp01f(p)); } };")
+    inner = ((pass_() | lfo(wrap, _merge(source, wsrc), **params))
+             >> pipei(10, lambda _i: add(0.0, 0.1) >> ~allpole())
+             >> (mul(feedback_amount) | sink()))
+    return pass_() & feedback(inner)
+
+
 def uses_wavetables(g):
     sets = (("saw", "WaveSynth<0>"), ("square", "WaveSynth<1>"), ("triangle", "WaveSynth<2>"), ("organ", "WaveSynth<4>"),
             ("soft_saw", "WaveSynth<5>"), ("hammond", "WaveSynth<6>"), ("saw", "PulseWave"))

@@ -557,6 +557,18 @@ def poly_square_hz(f): return dc(f) >> poly_square()
 def poly_pulse_hz(f, width): return dc(f, width) >> poly_pulse()
 
 
+def flanger(feedback_amount, minimum_delay, maximum_delay, delay_f):                                    # prelude.rs:2719-2730
+    return pass_() & feedback2((pass_() | lfo(delay_f)) >> tap(minimum_delay, maximum_delay), shape("tanh", feedback_amount))
+def phaser(feedback_amount, phase_f):                                                                   # prelude.rs:2743-2753
+    f32 = np.float32
+    def wrapped(t):
+        p = f32(phase_f(t))
+        p = f32(min(max(p, f32(0.0)), f32(1.0)))
+        return f32(2.0) * (f32(1.0) - p) + f32(20.0) * p
+    return pass_() & feedback((pass_() | lfo(wrapped)) >> pipei(10, lambda _i: add(0.0, 0.1) >> ~allpole())
+                              >> (mul(feedback_amount) | sink()))
+
+
 def reverb_stereo(room_size, time, damping): return Node(lib().o_reverb_stereo(room_size, time, damping))  # prelude.rs:1732
 
 

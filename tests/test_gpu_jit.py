@@ -134,6 +134,34 @@ struct SoftFold {  // shape_fn(|x| x / (1.0 + x * x) + tanh(x))
             assert_bit_equal(got[v], oracle_render(n, None, T, mode), f"map/shape_fn voice {v} mode {mode}")
 
 
+def test_jit_flanger_and_phaser(gpu):
+    """flanger(..) / phaser(..) (prelude.rs:2719-2753): Bus + Feedback2 / Feedback around taps, a tanh shaper, ten
+    pass-through allpoles; the modulation closure is a functor on the engine side and a callback in the oracle."""
+    f32 = np.float32
+    TAU = f32(6.2831855)
+    hz = 0.7
+    sin01 = lambda t: O.m_sinf(t * f32(hz) * TAU) * f32(0.5) + f32(0.5)                        # EnvSineHz::eval
+    V, T = 33, 64 * 7 + 5
+    x = noise_input(V, 1, T, seed=9)
+    cases = {
+        "flanger": (GR.flanger(0.6, 0.002, 0.006, "EnvSineHz", hz=hz, lo=0.002, hi=0.006),
+                    lambda: O.flanger(0.6, 0.002, 0.006, lambda t: f32(0.002) * (f32(1.0) - sin01(t)) + f32(0.006) * sin01(t)), 256),
+        "phaser": (GR.phaser(0.5, "EnvSineHz", hz=hz, lo=0.0, hi=1.0),
+                   lambda: O.phaser(0.5, lambda t: f32(0.0) * (f32(1.0) - sin01(t)) + f32(1.0) * sin01(t)), 0),
+    }
+    seeds = np.arange(V, dtype=np.uint64) + 100
+    for name, (g, make, ring) in cases.items():
+        for mode in (MODE_PROCESS, MODE_TICK):
+            b = gpu.Bank.from_graph(g, V, ring_frames=ring, sample_rate=SR)
+            b.set_seed(seeds)
+            got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, mode)
+            for v in (0, 32):
+                n = make()
+                n.set_sample_rate(SR)
+                n.set_seed(int(seeds[v]))
+                assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"{name} voice {v} mode {mode}")
+
+
 def test_jit_type_errors_are_reported(gpu):
     rc = gpu.lib().fdsp_graph_compile(b"bad_graph", b"Pipe<Sine,Stack<Sine,Sine>>")   # 1 output into 2 inputs
     assert rc < 0 and "Pipe arity mismatch" in gpu.lib().fdsp_last_error().decode()
