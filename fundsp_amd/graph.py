@@ -411,6 +411,36 @@ def phaser(feedback_amount, functor, source="", **params):
     return pass_() & feedback(inner)
 
 
+REVERB4_DELAYS = [0.059326634, 0.04778291, 0.06995449, 0.0393001, 0.041604012, 0.06215825, 0.052269846, 0.043227978,
+                  0.06966107, 0.031615064, 0.068442, 0.037332155, 0.032944717, 0.034493037, 0.06787566, 0.038824916,
+                  0.068260126, 0.068044715, 0.0688076, 0.066724524, 0.051293883, 0.06023173, 0.040897705, 0.031507637,
+                  0.060309593, 0.049584292, 0.04532072, 0.056379095, 0.035180368, 0.041291796, 0.046129026, 0.05504605]
+
+
+def _smooth9(x):  # math.rs:431-437 in f32
+    f = np.float32
+    x = f(x)
+    x2 = x * x
+    return ((((f(70) * x - f(315)) * x + f(540)) * x - f(420)) * x + f(126)) * x2 * x2 * x
+
+
+def reverb4_stereo_delays(delays, time):  # prelude.rs:1917-1941: two 16-line Hadamard FDNs in series
+    f = np.float32
+    a = f((10.0 ** (-60.0 / 20.0)) ** (0.03 * 10.0 / 10.0 / time))
+    w = (-a / f(4.0), -a / f(2.0), -a / f(4.0))
+    line1 = stacki(16, lambda i: delay(float(f(delays[i]))) >> fir(*w))
+    line2 = stacki(16, lambda i: delay(float(f(delays[16 + i]))) >> fir(*w))
+    pans = sumf(16, lambda x: pan(f(-1.0) * (f(1.0) - _smooth9(x)) + f(1.0) * _smooth9(x)))
+    return (multisplit(2, 8) >> fdn(line1) >> multijoin(2, 8) >> multisplit(2, 8) >> fdn(line2)
+            >> pans * dc(1.0 / 4.0, 1.0 / 4.0))
+
+
+def reverb4_stereo(room_size, time):  # prelude.rs:1873-1914
+    f = np.float32
+    scale = max(f(room_size), f(15.0)) / f(10.0)
+    return reverb4_stereo_delays([f(d) * scale for d in REVERB4_DELAYS], time)
+
+
 def uses_wavetables(g):
     sets = (("saw", "WaveSynth<0>"), ("square", "WaveSynth<1>"), ("triangle", "WaveSynth<2>"), ("organ", "WaveSynth<4>"),
             ("soft_saw", "WaveSynth<5>"), ("hammond", "WaveSynth<6>"), ("saw", "PulseWave"))

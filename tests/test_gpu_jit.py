@@ -162,6 +162,25 @@ def test_jit_flanger_and_phaser(gpu):
                 assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"{name} voice {v} mode {mode}")
 
 
+def test_jit_reverb4_stereo(gpu):
+    """reverb4_stereo(room_size, time) (prelude.rs:1873-1941) as a run-time compiled graph: two 16-line Hadamard FDNs in
+    series (stacki of delay >> fir inside fdn), multisplit / multijoin, a sumf of 16 panners -- 32 delay rings per voice,
+    rendered long enough for both feedback loops to close several times."""
+    V, T = 6, 64 * 200 + 17
+    g = GR.reverb4_stereo(20.0, 2.0)
+    assert g.rings == 32 and (g.nin, g.nout) == (2, 2)
+    x = noise_input(V, 2, T, seed=21)
+    x[:, :, 2000:] = 0.0                                           # a burst, then the tail
+    b = gpu.Bank.from_graph(g, V, ring_frames=8192, sample_rate=SR)
+    got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    for v in (0, V - 1):
+        n = O.reverb4_stereo(20.0, 2.0)
+        n.set_sample_rate(SR)
+        want = oracle_render(n, x[v], T, MODE_PROCESS)
+        assert np.abs(want[:, 9000:]).max() > 1e-4                 # the tail is alive
+        assert_bit_equal(got[v], want, f"reverb4_stereo voice {v}")
+
+
 def test_jit_type_errors_are_reported(gpu):
     rc = gpu.lib().fdsp_graph_compile(b"bad_graph", b"Pipe<Sine,Stack<Sine,Sine>>")   # 1 output into 2 inputs
     assert rc < 0 and "Pipe arity mismatch" in gpu.lib().fdsp_last_error().decode()
