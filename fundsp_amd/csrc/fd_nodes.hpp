@@ -1856,6 +1856,155 @@ struct AllNest {
     FD_STEP2_VIA_STEP
 };
 
+// Reverb<F>  reverb.rs:152-279 (ID 85), reverb3_stereo(time, diffusion, filter): an allpass loop.  Per voice: 4 input
+// diffusers + 8 blocks of (Delay, 4 Schroeder allpasses, filter, 4 Schroeder allpasses, filter) = 76 delay rings
+// (+ the filters' own), all walked serially every sample; the loop's last value feeds the next sample's first block.
+// Quirks kept: `pre` is neither reset by reset() (:211-224) nor re-sized by set_sample_rate() (:226-238) -- its delays
+// stay at (n - 1) samples whatever the rate; no process override (tick arithmetic everywhere); the enclosed filters are
+// never pinged (default leaf ping :156-161).  `a` = pow(db_amp(-60), 0.035 / time) as f32 and `coefficient` =
+// lerp(0.5, 0.9, diffusion) as f32 are computed by the host in f64 like Reverb::new (:162-207) and arrive as parameters.
+template <class F>
+struct Reverb3 {
+    static_assert(F::IN == 1 && F::OUT == 1, "reverb3_stereo: the loop filter is a 1-in 1-out node");
+    static constexpr int IN = 2, OUT = 2, RINGS = 4 + 8 * 9 + 16 * F::RINGS;
+    static constexpr uint64_t ID = 85;
+    using Schroeder = AllNest<Delay>;
+    struct Block {
+        Schroeder ap0[4], ap1[4];
+        F f0, f1;
+        Delay delay;
+    };
+    Schroeder pre[4];
+    Block block[8];
+    float feedback, a, coeff;
+    static FD_HD int ldelay(int k) {
+        constexpr int T[32] = {401, 421, 443, 463, 487, 503, 523, 547, 563, 587, 607, 619, 643, 661, 683, 701,
+                               727, 743, 761, 787, 809, 823, 839, 863, 883, 907, 929, 947, 967, 983, 1009, 1021};
+        return T[k];
+    }
+    static FD_HD int rdelay(int k) {
+        constexpr int T[32] = {419, 433, 457, 479, 491, 509, 541, 557, 577, 593, 613, 631, 653, 673, 691, 719,
+                               733, 757, 773, 797, 811, 829, 853, 877, 887, 911, 937, 953, 977, 997, 1013, 1033};
+        return T[k];
+    }
+    static FD_HD int bdelay(int k) {
+        constexpr int T[8] = {1087, 1091, 1093, 1097, 1103, 1109, 1117, 1123};
+        return T[k];
+    }
+    static FD_HD int pdelay(int k) {
+        constexpr int T[4] = {245, 367, 263, 349};
+        return T[k];
+    }
+    template <class V> FD_HD void visit(V& v) {
+        v.f(a, PARAM, "a");
+        v.f(coeff, PARAM, "coefficient");
+        v.f(feedback, STATE, "feedback");
+        int k = 0;
+        for (int i = 0; i < 4; i++) { v.enter(k++); pre[i].visit(v); v.leave(); }
+        for (int b = 0; b < 8; b++) {
+            for (int j = 0; j < 4; j++) { v.enter(k++); block[b].ap0[j].visit(v); v.leave(); }
+            for (int j = 0; j < 4; j++) { v.enter(k++); block[b].ap1[j].visit(v); v.leave(); }
+            v.enter(k++); block[b].f0.visit(v); v.leave();
+            v.enter(k++); block[b].f1.visit(v); v.leave();
+            v.enter(k++); block[b].delay.visit(v); v.leave();
+        }
+    }
+    FD_HD void bind(Ctx& c) {
+        for (int i = 0; i < 4; i++) pre[i].bind(c);
+        for (int b = 0; b < 8; b++) {
+            for (int j = 0; j < 4; j++) block[b].ap0[j].bind(c);
+            for (int j = 0; j < 4; j++) block[b].ap1[j].bind(c);
+            block[b].f0.bind(c);
+            block[b].f1.bind(c);
+            block[b].delay.bind(c);
+        }
+    }
+    FD_HD void init() {
+        a = 0.0f; coeff = 0.5f; feedback = 0.0f;
+        for (int i = 0; i < 4; i++) pre[i].init();
+        for (int b = 0; b < 8; b++) {
+            for (int j = 0; j < 4; j++) { block[b].ap0[j].init(); block[b].ap1[j].init(); }
+            block[b].f0.init();
+            block[b].f1.init();
+            block[b].delay.init();
+        }
+    }
+    // Delay::new(time) + set_sample_rate(sr) with the f64 time of Reverb::new: length round(time * sr) + 1, a change
+    // of rate or length clears the line (delay.rs:105-113)
+    static FD_HD void size_delay(Delay& d, int samples_at_default_sr, double sr) {
+        const double time = (double)samples_at_default_sr / 44100.0;
+        uint32_t want = (uint32_t)__builtin_round(time * sr) + 1u;
+        want = want > d.cap ? d.cap : want;
+        if (d.last_sr != (float)sr || want != d.len) {
+            d.last_sr = (float)sr;
+            d.len = want;
+            d.reset();
+        }
+    }
+    FD_HD void update(double sr) {
+        for (int i = 0; i < 4; i++) {
+            pre[i].eta = coeff;
+            size_delay(pre[i].x, pdelay(i) - 1, 44100.0);  // never re-sized (:226-238)
+        }
+        for (int b = 0; b < 8; b++) {
+            for (int j = 0; j < 4; j++) {
+                block[b].ap0[j].eta = coeff;
+                block[b].ap1[j].eta = coeff;
+                size_delay(block[b].ap0[j].x, ldelay(b + j * 8) - 1, sr);
+                size_delay(block[b].ap1[j].x, rdelay(b + j * 8) - 1, sr);
+            }
+            block[b].f0.update(sr);
+            block[b].f1.update(sr);
+            size_delay(block[b].delay, bdelay(7 - b), sr);
+        }
+    }
+    FD_HD void reset() {  // :211-224: not `pre`
+        for (int b = 0; b < 8; b++) {
+            for (int j = 0; j < 4; j++) { block[b].ap0[j].reset(); block[b].ap1[j].reset(); }
+            block[b].f0.reset();
+            block[b].f1.reset();
+            block[b].delay.reset();
+        }
+        feedback = 0.0f;
+    }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <class N> static FD_HD float mono(N& n, float x) {  // filter_mono
+        float y;
+        n.template step<PH_TICK>(&x, &y);
+        return y;
+    }
+    template <int PH> FD_HD void step(const float* in, float* out) {  // tick :241-272
+        float v0 = feedback, o0 = 0.0f, o1 = 0.0f;
+        float input0 = mono(pre[0], in[0] * 0.5f);
+        input0 = mono(pre[1], input0);
+        float input1 = mono(pre[2], in[1] * 0.5f);
+        input1 = mono(pre[3], input1);
+        for (int b = 0; b < 8; b++) {
+            Block& k = block[b];
+            v0 = mono(k.delay, v0);
+            v0 = mono(k.ap0[0], a * v0 + input0);
+            v0 = mono(k.ap0[1], v0);
+            v0 = mono(k.ap0[2], v0);
+            v0 = mono(k.ap0[3], v0);
+            v0 = mono(k.f0, v0);
+            o0 = v0;
+            v0 = mono(k.ap1[0], a * v0 + input1);
+            v0 = mono(k.ap1[1], v0);
+            v0 = mono(k.ap1[2], v0);
+            v0 = mono(k.ap1[3], v0);
+            v0 = mono(k.f1, v0);
+            o1 = v0;
+        }
+        feedback = v0;
+        out[0] = o0;
+        out[1] = o1;
+    }
+    FD_STEP2_VIA_STEP
+};
+
 // Oversampler<X>  oversample.rs:66-249 (ID 51): X runs at twice the sample rate between a minimum-phase half-band
 // interpolator and decimator (HALFBAND_MIN :329-373).  The reference keeps 128-sample rings per channel; only the newest
 // 24 input and 48 inner-output samples ever reach a filter (START_SAMPLE_OFFSET_HALF / _FULL :523-524), so the device

@@ -417,6 +417,9 @@ REVERB4_DELAYS = [0.059326634, 0.04778291, 0.06995449, 0.0393001, 0.041604012, 0
                   0.060309593, 0.049584292, 0.04532072, 0.056379095, 0.035180368, 0.041291796, 0.046129026, 0.05504605]
 
 
+def _db_amp(db): return float(np.exp(np.float64(db) / 20.0 * np.float64(2.302585092994046)))  # exp10: math.rs:76-78, 294-296
+
+
 def _smooth9(x):  # math.rs:431-437 in f32
     f = np.float32
     x = f(x)
@@ -424,9 +427,25 @@ def _smooth9(x):  # math.rs:431-437 in f32
     return ((((f(70) * x - f(315)) * x + f(540)) * x - f(420)) * x + f(126)) * x2 * x2 * x
 
 
+def reverb3_stereo(time, diffusion, make_filter):
+    """reverb3_stereo(time, diffusion, filter) (prelude.rs:1858, reverb.rs:152-279): allpass loop reverb; make_filter()
+    builds the 1-in 1-out loop filter (cloned 16 times by the reference).  Needs 76 delay rings of >= 1200 frames."""
+    f = np.float32
+    fs = [make_filter() for _ in range(16)]
+    if any(x.type != fs[0].type or x.nin != 1 or x.nout != 1 for x in fs):
+        raise TypeError("reverb3_stereo: the loop filter is one 1-in 1-out node type")
+    coeff = f(0.5 * (1.0 - diffusion) + 0.9 * diffusion)
+    a = f(_db_amp(-60.0) ** (0.035 / time))
+    ps = [((), "a", a, False), ((), "coefficient", coeff, False)]
+    for b in range(8):                      # visit order of Reverb3: pre 0..3, then per block ap0 x4, ap1 x4, f0, f1, delay
+        for k, flt in ((4 + b * 11 + 8, fs[2 * b]), (4 + b * 11 + 9, fs[2 * b + 1])):
+            ps += [((k,) + p, fld, v, u) for p, fld, v, u in flt.params]
+    return Graph(f"Reverb3<{fs[0].type}>", 2, 2, ps, 76 + 16 * fs[0].rings, fs[0].source)
+
+
 def reverb4_stereo_delays(delays, time):  # prelude.rs:1917-1941: two 16-line Hadamard FDNs in series
     f = np.float32
-    a = f((10.0 ** (-60.0 / 20.0)) ** (0.03 * 10.0 / 10.0 / time))
+    a = f(_db_amp(-60.0) ** (0.03 * 10.0 / 10.0 / time))
     w = (-a / f(4.0), -a / f(2.0), -a / f(4.0))
     line1 = stacki(16, lambda i: delay(float(f(delays[i]))) >> fir(*w))
     line2 = stacki(16, lambda i: delay(float(f(delays[16 + i]))) >> fir(*w))

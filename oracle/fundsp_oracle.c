@@ -43,6 +43,8 @@ struct onode {
     uint64_t id;
     onode *x, *y;
     onode *aux;   /* Limiter: its AFollow (not part of the graph recursion) */
+    onode *pre[4]; /* Reverb: input diffusers, outside reset / set_sample_rate (reverb.rs:211-238) */
+    float rv3_feedback, rv3_a;
     onode **kids; /* O_MULTI: the N nodes of MultiBus / MultiStack / MultiBranch / Reduce / Chain */
     int nkids, multi;
     int jm, jn;   /* Split / Join: M channels, N branches */
@@ -189,6 +191,7 @@ void o_free(onode *n) {
     o_free(n->x);
     o_free(n->y);
     o_free(n->aux);
+    for (int i = 0; i < 4; i++) o_free(n->pre[i]);
     free(n->s.lm_tree);
     free(n->s.lm_buf);
     for (int i = 0; i < n->nkids; i++) o_free(n->kids[i]);
@@ -571,6 +574,7 @@ void o_reset(onode *n) {
     if (n->type == O_DECLICK) n->s.dc_t = 0.0f;     /* dynamics.rs:268-270 */
     if (n->type == O_PHASESYNTH) n->s.ps_ready = 0; /* wavetable.rs:387-389 */
     if (n->type == O_METER) n->s.mt_state = 0.0f;   /* dynamics.rs:351-353 */
+    if (n->type == O_REVERB3) n->rv3_feedback = 0.0f; /* reverb.rs:223 (the blocks are the kids: reset by the recursion) */
     if (n->type == O_LIMITER) limiter_set_sr(n, n->s.lm_sr); /* dynamics.rs:184-186 */
     if (n->type == O_FEEDBACK) memset(n->fb_value, 0, sizeof n->fb_value); /* feedback.rs:118-121 */
     leaf_reset(n);
@@ -1418,6 +1422,36 @@ onode *o_feedback(onode *x, onode *y, int hadamard) { /* Feedback::new feedback.
     ctor_ping(n);
     return n;
 }
+onode *o_reverb3(double time, double diffusion, onode **filters) { /* Reverb::new reverb.rs:162-207 */
+    static const int ldelays[32] = {401, 421, 443, 463, 487, 503, 523, 547, 563, 587, 607, 619, 643, 661, 683, 701,
+                                    727, 743, 761, 787, 809, 823, 839, 863, 883, 907, 929, 947, 967, 983, 1009, 1021};
+    static const int rdelays[32] = {419, 433, 457, 479, 491, 509, 541, 557, 577, 593, 613, 631, 653, 673, 691, 719,
+                                    733, 757, 773, 797, 811, 829, 853, 877, 887, 911, 937, 953, 977, 997, 1013, 1033};
+    static const int delays[8] = {1087, 1091, 1093, 1097, 1103, 1109, 1117, 1123};
+    static const int predelay[4] = {245, 367, 263, 349};
+    for (int i = 0; i < 16; i++)
+        if (filters[i]->nin != 1 || filters[i]->nout != 1) return NULL;
+    onode *n = o_new(O_REVERB3, 2, 2, 85);
+    float coeff = (float)(0.5 * (1.0 - diffusion) + 0.9 * diffusion); /* lerp(0.5, 0.9, diffusion) as f32, math.rs:169-178 */
+    /* kids per block: allpass0[0..3], allpass1[0..3], filter0, filter1, delay */
+    n->nkids = 8 * 11;
+    n->kids = (onode **)calloc((size_t)n->nkids, sizeof(onode *));
+    for (int i = 0; i < 8; i++) {
+        onode **k = n->kids + i * 11;
+        for (int j = 0; j < 4; j++) {
+            k[j] = o_allnest(coeff, o_delay((double)(ldelays[i + j * 8] - 1) / DEFAULT_SR));
+            k[4 + j] = o_allnest(coeff, o_delay((double)(rdelays[i + j * 8] - 1) / DEFAULT_SR));
+        }
+        k[8] = filters[2 * i];
+        k[9] = filters[2 * i + 1];
+        k[10] = o_delay((double)delays[7 - i] / DEFAULT_SR);
+        if (k[8]->ftz || k[9]->ftz) n->ftz = 1;
+    }
+    n->rv3_a = (float)pow(exp(-60.0 / 20.0 * 2.302585092994046), 0.035 / time); /* pow(db_amp(-60.0), 0.035 / time) as f32; db_amp = exp10 = exp(x * LN_10), math.rs:76-78,294-296 */
+    for (int i = 0; i < 4; i++) n->pre[i] = o_allnest(coeff, o_delay((double)(predelay[i] - 1) / DEFAULT_SR));
+    n->rv3_feedback = 0.0f;
+    return n;
+}
 onode *o_thru(onode *x) { /* Thru::new audionode.rs:1956-1961, ID 12 */
     onode *n = o_new(O_THRU, x->nin, x->nin, 12);
     n->x = x;
@@ -1824,6 +1858,36 @@ void o_tick(onode *n, const float *in, float *out) {
         break;
     }
     case O_VAR: out[0] = n->s.value[0]; break; /* shared.rs:117-120 */
+    case O_REVERB3: { /* reverb.rs:241-272 */
+#define MONO(node, xin) (mono_x = (xin), o_tick((node), &mono_x, &mono_y), mono_y)
+        float mono_x, mono_y;
+        float v0 = n->rv3_feedback, output0 = 0.0f, output1 = 0.0f;
+        float input0 = MONO(n->pre[0], in[0] * 0.5f);
+        input0 = MONO(n->pre[1], input0);
+        float input1 = MONO(n->pre[2], in[1] * 0.5f);
+        input1 = MONO(n->pre[3], input1);
+        for (int b = 0; b < 8; b++) {
+            onode **k = n->kids + b * 11;
+            v0 = MONO(k[10], v0);
+            v0 = MONO(k[0], n->rv3_a * v0 + input0);
+            v0 = MONO(k[1], v0);
+            v0 = MONO(k[2], v0);
+            v0 = MONO(k[3], v0);
+            v0 = MONO(k[8], v0);
+            output0 = v0;
+            v0 = MONO(k[4], n->rv3_a * v0 + input1);
+            v0 = MONO(k[5], v0);
+            v0 = MONO(k[6], v0);
+            v0 = MONO(k[7], v0);
+            v0 = MONO(k[9], v0);
+            output1 = v0;
+        }
+#undef MONO
+        n->rv3_feedback = v0;
+        out[0] = output0;
+        out[1] = output1;
+        break;
+    }
     case O_LIMITER: { /* dynamics.rs:202-226 */
         float amplitude = 0.0f;
         for (int c = 0; c < n->nin; c++) amplitude = fmaxf_rs(amplitude, fabsf(in[c]));

@@ -19,7 +19,7 @@ enum {
     O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP,
     O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO, O_SHAPER, O_PHASE_OSC, O_CHAOS, O_NLBIQUAD, O_TAP, O_ALLNEST,
     O_ONEPOLE, O_PINKPASS, O_MORPH, O_REZ, O_FOLLOW, O_AFOLLOW, O_MLS, O_OVERSAMPLE, O_DSF, O_PLUCK, O_ENVELOPE, O_RESAMPLE, O_ENVELOPE_IN,
-    O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK, O_FEEDBACK, O_PHASESYNTH, O_WRAP, O_METER, O_VAR, O_LIMITER
+    O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK, O_FEEDBACK, O_PHASESYNTH, O_WRAP, O_METER, O_VAR, O_LIMITER, O_REVERB3
 };
 enum { O_OP_LOWPOLE = 0, O_OP_HIGHPOLE, O_OP_DCBLOCK, O_OP_ALLPOLE };
 enum { O_SH_CLIP = 0, O_SH_CLIPTO, O_SH_TANH, O_SH_ATAN, O_SH_SOFTSIGN, O_SH_CRUSH, O_SH_SOFTCRUSH, O_SH_ADAPTIVE_TANH };
@@ -103,6 +103,9 @@ float o_math_wide_atanf(float x);
 double o_adaptive_smoothing(float timescale, double sample_rate);
 /* reverb_stereo(room_size, time, damping): 32-line FDN (prelude.rs:1732-1762). */
 onode *o_reverb_stereo(double room_size, double time, double damping);
+/* Reverb<F> (reverb.rs:152, ID 85) = reverb3_stereo(time, diffusion, filter): `filters` are the 16 clones of the loop
+ * filter in block order (filter0, filter1 of block 0, then block 1, ...); takes ownership */
+onode *o_reverb3(double time, double diffusion, onode **filters);
 /* derived constants of reverb_stereo at `sample_rate`: FIR weights (3), delay lengths in samples (32), pan weights (32+32) */
 void o_reverb_stereo_params(double room_size, double time, double damping, double sample_rate, float *w3, int *delays32,
                             float *wl32, float *wr32);

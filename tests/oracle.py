@@ -88,7 +88,7 @@ def lib():
         "o_feedback": (P, [P, P, i]), "o_meter": (P, [i, d, i]), "o_meter_level": (f, [P]), "o_var": (P, [f]),
         "o_var_set": (None, [P, f]), "o_limiter": (P, [i, f, f]),
         "o_branch": (P, [P, P]), "o_bus": (P, [P, P]), "o_thru": (P, [P]), "o_multi": (P, [i, i, C.POINTER(P), i]),
-        "o_reverb_stereo": (P, [d, d, d]),
+        "o_reverb_stereo": (P, [d, d, d]), "o_reverb3": (P, [d, d, C.POINTER(P)]),
         "o_reverb_stereo_params": (None, [d, d, d, d, fp, C.POINTER(C.c_int), fp, fp]),
     }
     for name, (res, args) in sig.items():
@@ -575,6 +575,9 @@ REVERB4_DELAYS = [0.059326634, 0.04778291, 0.06995449, 0.0393001, 0.041604012, 0
                   0.060309593, 0.049584292, 0.04532072, 0.056379095, 0.035180368, 0.041291796, 0.046129026, 0.05504605]
 
 
+def _db_amp(db): return float(np.exp(np.float64(db) / 20.0 * np.float64(2.302585092994046)))  # exp10: math.rs:76-78, 294-296
+
+
 def _smooth9(x):  # math.rs:431-437 in f32
     f = np.float32
     x = f(x)
@@ -584,7 +587,7 @@ def _smooth9(x):  # math.rs:431-437 in f32
 
 def reverb4_stereo_delays(delays, time):  # prelude.rs:1917-1941: two 16-line Hadamard FDNs in series
     f = np.float32
-    a = f((10.0 ** (-60.0 / 20.0)) ** (0.03 * 10.0 / 10.0 / time))
+    a = f(_db_amp(-60.0) ** (0.03 * 10.0 / 10.0 / time))
     w = (-a / f(4.0), -a / f(2.0), -a / f(4.0))
     line1 = stacki(16, lambda i: delay(float(f(delays[i]))) >> fir(*w))
     line2 = stacki(16, lambda i: delay(float(f(delays[16 + i]))) >> fir(*w))
@@ -597,6 +600,13 @@ def reverb4_stereo(room_size, time):  # prelude.rs:1873-1914
     f = np.float32
     scale = max(f(room_size), f(15.0)) / f(10.0)
     return reverb4_stereo_delays([f(d) * scale for d in REVERB4_DELAYS], time)
+
+
+def reverb3_stereo(time, diffusion, make_filter):                                                      # prelude.rs:1858
+    """make_filter() builds one fresh 1-in 1-out loop filter (the reference clones `filter` 16 times)."""
+    fs = [make_filter() for _ in range(16)]
+    arr = (C.c_void_p * 16)(*[f.ptr for f in fs])
+    return Node(lib().o_reverb3(time, diffusion, arr), fs)
 
 
 def reverb_stereo(room_size, time, damping): return Node(lib().o_reverb_stereo(room_size, time, damping))  # prelude.rs:1732

@@ -181,6 +181,30 @@ def test_jit_reverb4_stereo(gpu):
         assert_bit_equal(got[v], want, f"reverb4_stereo voice {v}")
 
 
+def test_jit_reverb3_stereo(gpu):
+    """reverb3_stereo(time, diffusion, filter) (reverb.rs:152-279): the allpass-loop reverb as one node -- 76 delay rings
+    per voice walked serially, the loop filter a template parameter with per-voice cutoff."""
+    V, T = 5, 64 * 300 + 9
+    cut = np.linspace(900.0, 4000.0, V).astype(np.float32)
+    g = GR.reverb3_stereo(2.0, 0.6, lambda: GR.lowpole_hz(cut))
+    assert g.rings == 76 and (g.nin, g.nout) == (2, 2)
+    x = noise_input(V, 2, T, seed=23)
+    x[:, :, 3000:] = 0.0
+    b = gpu.Bank.from_graph(g, V, ring_frames=2048, sample_rate=SR)
+    got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    for v in (0, V - 1):
+        n = O.reverb3_stereo(2.0, 0.6, lambda: O.lowpole_hz(float(cut[v])))
+        n.set_sample_rate(SR)
+        want = oracle_render(n, x[v], T, MODE_PROCESS)
+        assert np.abs(want[:, 15000:]).max() > 1e-4                # past the first trip through all eight blocks
+        assert_bit_equal(got[v], want, f"reverb3_stereo voice {v}")
+    # reset() leaves the input diffusers' lines alone (reverb.rs:211-224): second render after reset == the oracle's
+    b.reset()
+    got2 = run_bank(b, np.ascontiguousarray(x[:, :, :64 * 20]), 64 * 20, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    n.reset()
+    assert_bit_equal(got2[V - 1], oracle_render(n, x[V - 1][:, :64 * 20], 64 * 20, MODE_PROCESS), "reverb3 after reset")
+
+
 def test_jit_type_errors_are_reported(gpu):
     rc = gpu.lib().fdsp_graph_compile(b"bad_graph", b"Pipe<Sine,Stack<Sine,Sine>>")   # 1 output into 2 inputs
     assert rc < 0 and "Pipe arity mismatch" in gpu.lib().fdsp_last_error().decode()

@@ -48,6 +48,7 @@ def run_bank(bank, x, frames, layout, mode):
 
     V, ni, no = bank.voices, bank.inputs(), bank.outputs()
     inp = None
+    assert not ni or x.shape == (V, ni, frames), (x.shape, (V, ni, frames))
     if layout == LAYOUT_VOICE_MINOR:
         if ni:
             inp = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 2, 0))).cuda()
