@@ -69,6 +69,8 @@ SYMBOLS = {
     "fdsp_svf_coefs": (_i, [_i, _f, _f, _f, _f, _fp]),
     "fdsp_biquad_coefs": (_i, [_i, _f, _f, _f, _f, _fp]),
     "fdsp_rnd1": (_d, [_u64]),
+    "fdsp_libm_sinf": (_f, [_f]),
+    "fdsp_libm_cosf": (_f, [_f]),
     "fdsp_hash1": (_u64, [_u64]),
 }
 

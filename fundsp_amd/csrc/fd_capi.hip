@@ -945,6 +945,8 @@ int fdsp_biquad_coefs(int kind, float sr, float f, float q, float gain, float* o
 }
 
 double fdsp_rnd1(uint64_t x) { return fd::rnd1(x); }
+float fdsp_libm_sinf(float x) { return fd::sinf_musl(x); }
+float fdsp_libm_cosf(float x) { return fd::cosf_musl(x); }
 uint64_t fdsp_hash1(uint64_t x) { return fd::hash1(x); }
 
 }  // extern "C"

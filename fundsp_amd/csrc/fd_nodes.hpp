@@ -517,6 +517,27 @@ struct BiquadT {
 };
 using Biquad = BiquadT<15>;
 
+// BiquadBank<f32x8>  biquad_bank.rs:14-130 (ID 98) as ONE voice: 8 channels in, 8 out, each lane its own coefficients
+// (Setting::biquad(..).index(i)).  Config 2 instead spreads the lanes of many banks over voices.
+struct BiquadBank {
+    static constexpr int IN = 8, OUT = 8, RINGS = 0;
+    static constexpr uint64_t ID = 98;
+    BiquadT<98> lane[8];
+    template <class V> FD_HD void visit(V& v) { for (int i = 0; i < 8; i++) { v.enter(i); lane[i].visit(v); v.leave(); } }
+    FD_HD void init() { for (int i = 0; i < 8; i++) lane[i].init(); }
+    FD_HD void update(double) {}
+    FD_HD void reset() { for (int i = 0; i < 8; i++) lane[i].reset(); }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void end_simd() {}
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void bind(Ctx&) {}
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        _Pragma("unroll") for (int i = 0; i < 8; i++) out[i] = lane[i].tick(in[i]);
+    }
+    FD_STEP2_VIA_STEP
+};
+
 // ButterLowpass<f32, N>  biquad.rs:227-300 (ID 16), N = 1 (fixed) or 2 (cutoff input)
 template <int NIN>
 struct ButterLowpass {
@@ -2465,6 +2486,58 @@ struct Var {
     FD_HD void end_simd() {}
     template <int PH> FD_HD void step(const float*, float* out) { out[0] = value; }
     template <int PH> FD_HD void step2(const v2f*, v2f* out) { out[0] = v2f{value, value}; }
+};
+
+// Mixer<M, N>  pan.rs:95-150 (ID 84): N outputs, each the dot product of the M inputs with one row of a matrix,
+// accumulated from 0.0 in input order (:125-132).  rotate(angle, gain) is the 2 x 2 case (prelude32.rs:2432).
+template <int M, int N>
+struct Mixer {
+    static constexpr int IN = M, OUT = N, RINGS = 0;
+    static constexpr uint64_t ID = 84;
+    float m[N][M];
+    template <class V> FD_HD void visit(V& v) {
+        _Pragma("unroll") for (int i = 0; i < N; i++)
+            _Pragma("unroll") for (int j = 0; j < M; j++) v.fi(m[i][j], PARAM, "matrix", i * M + j);
+    }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void init() { for (int i = 0; i < N; i++) for (int j = 0; j < M; j++) m[i][j] = 0.0f; }
+    FD_HD void update(double) {}
+    FD_HD void reset() {}
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        float o[N];
+        for (int i = 0; i < N; i++) {
+            float value = 0.0f;
+            for (int j = 0; j < M; j++) value += in[j] * m[i][j];
+            o[i] = value;
+        }
+        for (int i = 0; i < N; i++) out[i] = o[i];
+    }
+    FD_STEP2_VIA_STEP
+};
+
+// VarFn<F, R>  shared.rs:136-184 (ID 70): f(shared value) -> NO channels; the closure is a functor
+//   static void f(float value, float* out)
+// and the shared value a per-voice parameter.
+template <class FN, int NO>
+struct VarFn {
+    static constexpr int IN = 0, OUT = NO, RINGS = 0;
+    static constexpr uint64_t ID = 70;
+    float value;
+    template <class V> FD_HD void visit(V& v) { v.f(value, PARAM, "value"); }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void init() { value = 0.0f; }
+    FD_HD void update(double) {}
+    FD_HD void reset() {}
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float*, float* out) { FN::f(value, out); }
+    FD_STEP2_VIA_STEP
 };
 
 // Limiter<N>  dynamics.rs:125-241 (ID 25): look-ahead limiter.  Per voice: N delay rings of `length` frames, a max

@@ -100,7 +100,13 @@ class Graph:
 
 
 def _merge(a, b):
-    return a if (not b or b in a) else (a + "\n" + b)
+    """Union of two source preludes (a definition must not appear twice in the compiled translation unit)."""
+    a, b = a.strip(), b.strip()
+    if not b or b in a:
+        return a
+    if not a or a in b:
+        return b
+    return a + "\n" + b
 
 
 def _leaf(t, nin, nout, rings=0, **fields):
@@ -261,6 +267,27 @@ def _meter(mode, timescale, monitor):
 def meter(mode, timescale=0.1): return _meter(mode, timescale, False)     # prelude32.rs:300: meter(Meter::Peak(t)) etc.
 def monitor(mode, timescale=0.1): return _meter(mode, timescale, True)    # level readable from the ":state" slot
 def var(value): return _leaf("Var", 0, 1, value=value)                    # a Shared value = a per-voice parameter
+def mixer(matrix):                                                        # Mixer::new pan.rs:108, matrix[out][in]
+    m = np.asarray(matrix, dtype=object)
+    n_out, n_in = len(matrix), len(matrix[0])
+    return Graph(f"Mixer<{n_in},{n_out}>", n_in, n_out,
+                 [((), f"matrix[{i * n_in + j}]", matrix[i][j], False) for i in range(n_out) for j in range(n_in)])
+def rotate(angle, gain):                                                  # prelude32.rs:2432; libm cos / sin on the host
+    from ._lib import lib
+    c, s_ = np.float32(lib().fdsp_libm_cosf(float(angle))), np.float32(lib().fdsp_libm_sinf(float(angle)))
+    g = np.float32(gain)
+    return mixer([[c * g, -s_ * g], [s_ * g, c * g]])
+def var_fn(value, functor, source, outputs=1):
+    """var_fn(&shared, |x| ..): functor with `static FD_HD void f(float value, float* out)`; the value is the ":value" slot."""
+    return Graph(f"VarFn<{functor},{outputs}>", 0, outputs, [((), "value", value, False)], 0, source)
+def envelope2(functor, source, outputs=1, **params): return envelope_in(functor, source, 1, outputs, **params)   # prelude32.rs:625
+def envelope3(functor, source, outputs=1, **params): return envelope_in(functor, source, 2, outputs, **params)   # prelude32.rs:669
+lfo2, lfo3 = envelope2, envelope3
+def biquad_bank(coefs):
+    """biquad_bank() (prelude32.rs:2711) with Setting::biquad(a1, a2, b0, b1, b2).index(i) applied: `coefs` = 8 rows of
+    (a1, a2, b0, b1, b2), each entry a scalar or a per-voice array."""
+    ps = [((i,), n, coefs[i][k], False) for i in range(8) for k, n in enumerate(("a1", "a2", "b0", "b1", "b2"))]
+    return Graph("BiquadBank", 8, 8, ps)
 def limiter(attack, release):                                             # prelude32.rs:1275; needs ring_frames
     return _leaf("Limiter<1>", 1, 1, rings=2, attack_time=attack, release_time=release)
 def limiter_stereo(attack, release):                                      # prelude32.rs:1286

@@ -226,6 +226,10 @@ int fdsp_wavetable_get(int set, int* n_tables, float* h_pitches, int* h_lengths,
 int fdsp_svf_coefs(int mode, float sample_rate, float cutoff, float q, float gain, float* out6);     /* svf.rs:28-221 */
 int fdsp_biquad_coefs(int kind, float sample_rate, float f, float q, float gain, float* out5);       /* biquad.rs:27-116 */
 double fdsp_rnd1(uint64_t x);  /* math.rs:569-576 */
+/* the engine's restatement of libm::sinf / cosf (lib.rs:470-492) for host-side parameter derivation, e.g. the matrix of
+ * rotate(angle, gain) (prelude32.rs:2432) or pan weights */
+float fdsp_libm_sinf(float x);
+float fdsp_libm_cosf(float x);
 uint64_t fdsp_hash1(uint64_t x); /* math.rs:592-599 */
 
 #ifdef __cplusplus

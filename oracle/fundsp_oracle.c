@@ -1087,6 +1087,18 @@ onode *o_meter(int mode, double timescale, int monitor) {
     return n;
 }
 float o_meter_level(const onode *n) { return n->s.mt_mode == O_METER_RMS ? sqrtf(n->s.mt_state) : n->s.mt_state; }
+onode *o_mixer(int inputs, int outputs, const float *matrix) {
+    if (inputs < 1 || outputs < 1 || inputs > 8 || outputs > 8) return NULL;
+    onode *n = o_new(O_MIXER, inputs, outputs, 84);
+    for (int i = 0; i < inputs * outputs; i++) n->s.value[i] = matrix[i];
+    return n;
+}
+onode *o_var_fn(float value, int outputs, o_map_fn fn, void *ctx) {
+    onode *n = o_new(O_VAR, 0, outputs, 70);
+    n->s.value[0] = value;
+    n->map_fn = fn; n->map_ctx = ctx;
+    return n;
+}
 onode *o_var(float value) {
     onode *n = o_new(O_VAR, 0, 1, 68);
     n->s.value[0] = value;
@@ -1857,7 +1869,18 @@ void o_tick(onode *n, const float *in, float *out) {
         out[0] = n->s.mt_monitor ? v : o_meter_level(n);
         break;
     }
-    case O_VAR: out[0] = n->s.value[0]; break; /* shared.rs:117-120 */
+    case O_VAR: /* shared.rs:117-120; VarFn :171-173 */
+        if (n->map_fn) n->map_fn(&n->s.value[0], out, n->map_ctx);
+        else out[0] = n->s.value[0];
+        break;
+    case O_MIXER: /* pan.rs:124-133 */
+        for (int i = 0; i < n->nout; i++) {
+            float value = 0.0f;
+            for (int j = 0; j < n->nin; j++) value += in[j] * n->s.value[i * n->nin + j];
+            t[i] = value;
+        }
+        for (int i = 0; i < n->nout; i++) out[i] = t[i];
+        break;
     case O_REVERB3: { /* reverb.rs:241-272 */
 #define MONO(node, xin) (mono_x = (xin), o_tick((node), &mono_x, &mono_y), mono_y)
         float mono_x, mono_y;

@@ -19,7 +19,7 @@ enum {
     O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP,
     O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO, O_SHAPER, O_PHASE_OSC, O_CHAOS, O_NLBIQUAD, O_TAP, O_ALLNEST,
     O_ONEPOLE, O_PINKPASS, O_MORPH, O_REZ, O_FOLLOW, O_AFOLLOW, O_MLS, O_OVERSAMPLE, O_DSF, O_PLUCK, O_ENVELOPE, O_RESAMPLE, O_ENVELOPE_IN,
-    O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK, O_FEEDBACK, O_PHASESYNTH, O_WRAP, O_METER, O_VAR, O_LIMITER, O_REVERB3
+    O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK, O_FEEDBACK, O_PHASESYNTH, O_WRAP, O_METER, O_VAR, O_LIMITER, O_REVERB3, O_MIXER
 };
 enum { O_OP_LOWPOLE = 0, O_OP_HIGHPOLE, O_OP_DCBLOCK, O_OP_ALLPOLE };
 enum { O_SH_CLIP = 0, O_SH_CLIPTO, O_SH_TANH, O_SH_ATAN, O_SH_SOFTSIGN, O_SH_CRUSH, O_SH_SOFTCRUSH, O_SH_ADAPTIVE_TANH };
@@ -34,6 +34,7 @@ enum { O_ADD = 0, O_SUB, O_MUL };
 enum { O_NEG = 0, O_ID, O_ADD_SCALAR, O_NEG_ADD_SCALAR, O_MUL_SCALAR };
 
 /* leaves */
+typedef void (*o_map_fn)(const float *in, float *out, void *ctx); /* closure callback of Map / ShapeFn / VarFn */
 onode *o_constant(int n, const float *v);
 onode *o_pass(void);
 onode *o_sine(void);
@@ -83,6 +84,8 @@ onode *o_rez(int inputs, float bandpass, float cutoff, float q); /* Rez<f32, U1/
 enum { O_METER_SAMPLE = 0, O_METER_PEAK, O_METER_RMS };
 onode *o_meter(int mode, double timescale, int monitor);        /* MeterNode (dynamics.rs:398, ID 61) / Monitor (:441, ID 56) */
 float o_meter_level(const onode *n);                             /* what Monitor stores in its Shared */
+onode *o_mixer(int inputs, int outputs, const float *matrix);   /* Mixer<M, N> (pan.rs:95, ID 84); matrix[out][in] */
+onode *o_var_fn(float value, int outputs, o_map_fn fn, void *ctx); /* VarFn (shared.rs:136, ID 70): fn(&value, out) */
 onode *o_var(float value);                                       /* Var (shared.rs:85, ID 68) */
 void o_var_set(onode *n, float value);
 onode *o_limiter(int channels, float attack_time, float release_time); /* Limiter<N> (dynamics.rs:125, ID 25) */
@@ -117,7 +120,6 @@ onode *o_split(int m, int n);              /* Split<N> (m == 1, :527) / MultiSpl
 onode *o_join(int m, int n);               /* Join<N> (m == 1, :617) / MultiJoin<M, N> (:668) */
 onode *o_reverse(int n);                   /* Reverse<N> :2808 */
 onode *o_impulse(int n);                   /* Impulse<N> :2841 */
-typedef void (*o_map_fn)(const float *in, float *out, void *ctx);
 onode *o_map(int inputs, int outputs, o_map_fn fn, void *ctx); /* Map<M, I, O> :1330 */
 onode *o_shape_fn(o_map_fn fn, void *ctx);  /* Shaper<ShapeFn<S>> shape.rs:35,205 (ID 42): fn maps in[0] -> out[0] */
 onode *o_declick(float duration);          /* Declick<f32> dynamics.rs:245 */

@@ -86,7 +86,7 @@ def lib():
         "o_reverse": (P, [i]), "o_impulse": (P, [i]), "o_map": (P, [i, i, P, P]),
         "o_shape_fn": (P, [P, P]), "o_declick": (P, [f]),
         "o_feedback": (P, [P, P, i]), "o_meter": (P, [i, d, i]), "o_meter_level": (f, [P]), "o_var": (P, [f]),
-        "o_var_set": (None, [P, f]), "o_limiter": (P, [i, f, f]),
+        "o_var_set": (None, [P, f]), "o_mixer": (P, [i, i, fp]), "o_var_fn": (P, [f, i, P, P]), "o_limiter": (P, [i, f, f]),
         "o_branch": (P, [P, P]), "o_bus": (P, [P, P]), "o_thru": (P, [P]), "o_multi": (P, [i, i, C.POINTER(P), i]),
         "o_reverb_stereo": (P, [d, d, d]), "o_reverb3": (P, [d, d, C.POINTER(P)]),
         "o_reverb_stereo_params": (None, [d, d, d, d, fp, C.POINTER(C.c_int), fp, fp]),
@@ -224,6 +224,31 @@ def meter(mode, timescale=0.1): return Node(lib().o_meter(METER_MODES[mode], tim
 def monitor(mode, timescale=0.1): return Node(lib().o_meter(METER_MODES[mode], timescale, 1))  # prelude32.rs monitor(&shared, meter)
 def meter_level(n): return np.float32(lib().o_meter_level(n.ptr))
 def var(value): return Node(lib().o_var(value))                                               # prelude32.rs var(&shared)
+def mixer(matrix):                                                                            # Mixer::new pan.rs:108
+    m = np.ascontiguousarray(matrix, dtype=np.float32)
+    return Node(lib().o_mixer(m.shape[1], m.shape[0], _fptr(m)))
+def rotate(angle, gain):                                                                      # prelude32.rs:2432
+    c, s_ = m_cosf(angle), m_sinf(angle)
+    g = np.float32(gain)
+    return mixer([[c * g, -s_ * g], [s_ * g, c * g]])
+def var_fn(value, fn, outputs=1):                                                             # prelude32.rs var_fn(&shared, f)
+    def cb(inp, out, _ctx):
+        r = fn(np.float32(inp[0]))
+        r = [r] if np.isscalar(r) else list(r)
+        for k in range(outputs):
+            out[k] = float(np.float32(r[k]))
+    c = MAP_FN(cb)
+    n = Node(lib().o_var_fn(value, outputs, C.cast(c, C.c_void_p), None))
+    n._callback = c
+    return n
+def biquad_bank_coefs(coefs):                                                                 # prelude32.rs:2711 + Setting::biquad
+    n = biquad_bank()
+    for i in range(8):
+        set_biquad_bank(n, i, coefs[i])
+    return n
+def envelope2(fn): return envelope_in(lambda t, i: fn(t, i[0]), 1)                           # prelude32.rs:625
+def envelope3(fn): return envelope_in(lambda t, i: fn(t, i[0], i[1]), 2)                     # prelude32.rs:669
+lfo3 = envelope3
 def limiter(attack, release): return Node(lib().o_limiter(1, attack, release))                # prelude32.rs:1275
 def limiter_stereo(attack, release): return Node(lib().o_limiter(2, attack, release))         # prelude32.rs:1286
 def thru(x): return ~x

@@ -134,6 +134,41 @@ struct SoftFold {  // shape_fn(|x| x / (1.0 + x * x) + tanh(x))
             assert_bit_equal(got[v], oracle_render(n, None, T, mode), f"map/shape_fn voice {v} mode {mode}")
 
 
+def test_jit_mixer_varfn_biquad_bank_envelope3(gpu):
+    """rotate(angle, gain) = Mixer<U2, U2> (pan.rs:95, prelude32.rs:2432), var_fn(&shared, f) (shared.rs:136),
+    biquad_bank() with per-lane coefficients (biquad_bank.rs), lfo3(|t, x, y| ..) (prelude32.rs:697)."""
+    f32 = np.float32
+    src = """
+struct Detune { static FD_HD void f(float v, float* out) { out[0] = v * 0.99f; out[1] = v * 1.01f; } };
+struct Env3 {  // |t, x, y| exp(-t * x) * y
+    static constexpr int IN = 2, OUT = 1;
+    template <class V> FD_HD void visit(V&) {}
+    FD_HD void init() {}
+    FD_HD void eval(float t, const float* in, float* out) const { out[0] = expf_musl(-t * in[0]) * in[1]; }
+};
+"""
+    coefs = [O.biquad_coefs("lowpass", SR, 300.0 * (i + 1), 0.7 + 0.2 * i) for i in range(8)]
+    V, T = 20, 64 * 4 + 31
+    base = np.linspace(110.0, 440.0, V).astype(np.float32)
+    g = (GR.var_fn(base, "Detune", src, 2) >> (GR.sine() | GR.sine()) >> GR.rotate(0.6, 0.8) >> GR.multisplit(2, 4)
+         >> GR.biquad_bank(coefs) >> GR.multijoin(2, 4)
+         >> (GR.pass_() * (GR.dc(3.0, 0.5) >> GR.lfo3("Env3", src)) | GR.pass_()))
+    def make(v):
+        return (O.var_fn(float(base[v]), lambda x: (x * f32(0.99), x * f32(1.01)), 2) >> (O.sine() | O.sine())
+                >> O.rotate(0.6, 0.8) >> O.multisplit(2, 4) >> O.biquad_bank_coefs(coefs) >> O.multijoin(2, 4)
+                >> (O.pass_() * (O.dc(3.0, 0.5) >> O.lfo3(lambda t, x, y: O.m_expf(-t * x) * y)) | O.pass_()))
+    seeds = np.arange(V, dtype=np.uint64) + 7
+    for mode in (MODE_PROCESS, MODE_TICK):
+        b = gpu.Bank.from_graph(g, V, sample_rate=SR)
+        b.set_seed(seeds)
+        got = run_bank(b, None, T, LAYOUT_VOICE_MINOR, mode)
+        for v in (0, V - 1):
+            n = make(v)
+            n.set_sample_rate(SR)
+            n.set_seed(int(seeds[v]))
+            assert_bit_equal(got[v], oracle_render(n, None, T, mode), f"mixer/var_fn/bank voice {v} mode {mode}")
+
+
 def test_jit_flanger_and_phaser(gpu):
     """flanger(..) / phaser(..) (prelude.rs:2719-2753): Bus + Feedback2 / Feedback around taps, a tanh shaper, ten
     pass-through allpoles; the modulation closure is a functor on the engine side and a callback in the oracle."""
