@@ -1,0 +1,500 @@
+// fundsp_hip.hpp -- header-only C++17 host side above the C ABI (fundsp_hip.h).
+//
+// FunDSP is compiled code (Rust); this image has no Rust toolchain, so the host-side mirror of the reference's operator
+// interface for the voice path is C++ (INTEGRATION.md shows the Rust binding a maintainer would add).  The names and
+// argument meanings follow the reference:
+//   * `An` + the graph operators of src/combinator.rs:289-488   ( >>  |  &  ^  !  *  +  - , unary - )
+//   * the prelude32 opcodes of src/prelude32.rs                    ( sine_hz, lowpass_hz, moog, saw, adsr_live, pan, ... )
+//   * the AudioNode surface of src/audionode.rs:29-369 on `Bank`   ( inputs, outputs, reset, set_sample_rate, tick,
+//     process, set_hash -> set_seed, Clone -> clone ), and Wave::render (src/wave.rs:441-466) as `render`.
+// A graph is the combinator TYPE FunDSP would build, spelled with the device templates of fundsp_amd/csrc/fd_nodes.hpp,
+// plus its per-node parameters; Bank::from_graph compiles it into one fused kernel (fdsp_graph_compile_src).
+//
+// Error behaviour: arity mismatches are compile-time errors in Rust; here they throw fundsp_hip::Error when the graph
+// is put together (host) or compiled (device).  Errors of the C ABI become fundsp_hip::Error with the code and message.
+// AudioNode::process itself is infallible in the reference; Bank::process throws only on misuse / device failure.
+//
+// Every numeric opcode argument is a `P`: one value for all voices, or one value per voice.
+#ifndef FUNDSP_HIP_HPP
+#define FUNDSP_HIP_HPP
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "fundsp_hip.h"
+
+namespace fundsp_hip {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error("fundsp_hip error " + std::to_string(c) + ": " + m), code(c) {}
+};
+inline void check(int rc) {
+    if (rc < 0) throw Error(rc, fdsp_last_error());
+}
+
+constexpr size_t MAX_BUFFER_SIZE = FDSP_MAX_BUFFER_SIZE;  // src/lib.rs:48
+constexpr double DEFAULT_SR = FDSP_DEFAULT_SR;            // src/lib.rs:42
+
+// one value for every voice, or one per voice
+struct P {
+    std::vector<float> v;
+    P(float x) : v{x} {}
+    P(double x) : v{(float)x} {}
+    P(int x) : v{(float)x} {}
+    P(std::vector<float> per_voice) : v(std::move(per_voice)) {}
+};
+
+struct Param {
+    std::vector<int> path;  // child indices from the root (0 = left / inner, 1 = right), as the C ABI names slots
+    std::string field;
+    std::vector<float> values;
+    bool is_u64 = false;
+    std::vector<uint64_t> u64s;
+    std::string slot() const {
+        std::string s;
+        for (size_t i = 0; i < path.size(); i++) s += (i ? "." : "") + std::to_string(path[i]);
+        return s + ":" + field;
+    }
+};
+
+// An<X> of the reference: a node expression.  `type` is X.
+class An {
+ public:
+    std::string type, source;
+    int inputs = 0, outputs = 0, rings = 0;
+    std::vector<Param> params;
+
+    An() = default;
+    An(std::string t, int nin, int nout, int nrings = 0) : type(std::move(t)), inputs(nin), outputs(nout), rings(nrings) {}
+    An& with(const std::string& field, const P& p) {
+        params.push_back(Param{{}, field, p.v});
+        return *this;
+    }
+    // combinator.rs:263-267 `.phase(x)` / `.seed(x)`
+    An phase(P p) const {
+        An a = *this;
+        a.with("has_initial_phase", 1.0f).with("initial_phase", p);
+        return a;
+    }
+    An seed(uint64_t s) const {
+        An a = *this;
+        a.with("has_seed", 1.0f);
+        Param q{{}, "seed", {}, true, {s}};
+        a.params.push_back(q);
+        return a;
+    }
+};
+
+namespace detail {
+inline std::string merge(const std::string& a, const std::string& b) {
+    if (b.empty() || a.find(b) != std::string::npos) return a;
+    if (a.empty() || b.find(a) != std::string::npos) return b;
+    return a + "\n" + b;
+}
+inline void adopt(An& dst, const An& child, int index) {
+    for (Param p : child.params) {
+        p.path.insert(p.path.begin(), index);
+        dst.params.push_back(std::move(p));
+    }
+    dst.rings += child.rings;
+    dst.source = merge(dst.source, child.source);
+}
+inline An pair(const char* tmpl, const An& x, const An& y, int nin, int nout, const std::string& extra = "") {
+    An a(std::string(tmpl) + "<" + extra + x.type + "," + y.type + ">", nin, nout);
+    adopt(a, x, 0);
+    adopt(a, y, 1);
+    return a;
+}
+inline An unop(const An& x, const char* u, const P* scalar) {
+    An a("Unop<" + x.type + "," + u + ">", x.inputs, x.outputs);
+    adopt(a, x, 0);
+    if (scalar) a.with("scalar", *scalar);
+    return a;
+}
+inline An leaf(const std::string& t, int nin, int nout, int rings = 0) { return An(t, nin, nout, rings); }
+[[noreturn]] inline void arity(const std::string& what) { throw Error(FDSP_EINVAL, what); }
+}  // namespace detail
+
+// ---- graph operators (combinator.rs:289-488) ---------------------------------------------------------------------
+inline An operator>>(const An& x, const An& y) {  // Pipe
+    if (x.outputs != y.inputs)
+        detail::arity("Pipe arity mismatch: " + std::to_string(x.outputs) + " outputs >> " + std::to_string(y.inputs) + " inputs");
+    return detail::pair("Pipe", x, y, x.inputs, y.outputs);
+}
+inline An operator|(const An& x, const An& y) { return detail::pair("Stack", x, y, x.inputs + y.inputs, x.outputs + y.outputs); }
+inline An operator&(const An& x, const An& y) {  // Bus
+    if (x.inputs != y.inputs || x.outputs != y.outputs) detail::arity("Bus arity mismatch");
+    return detail::pair("Bus", x, y, x.inputs, x.outputs);
+}
+inline An operator^(const An& x, const An& y) {  // Branch
+    if (x.inputs != y.inputs) detail::arity("Branch arity mismatch");
+    return detail::pair("Branch", x, y, x.inputs, x.outputs + y.outputs);
+}
+inline An operator!(const An& x) {  // Thru
+    An a("Thru<" + x.type + ">", x.inputs, x.inputs);
+    detail::adopt(a, x, 0);
+    return a;
+}
+inline An binop(const char* op, const An& x, const An& y) {
+    if (x.outputs != y.outputs) detail::arity("Binop arity mismatch");
+    return detail::pair("Binop", x, y, x.inputs + y.inputs, x.outputs, std::string(op) + ",");
+}
+inline An operator*(const An& x, const An& y) { return binop("OpMul", x, y); }
+inline An operator+(const An& x, const An& y) { return binop("OpAdd", x, y); }
+inline An operator-(const An& x, const An& y) { return binop("OpSub", x, y); }
+inline An operator*(const An& x, const P& s) { return detail::unop(x, "UMulScalar", &s); }
+inline An operator*(const P& s, const An& x) { return detail::unop(x, "UMulScalar", &s); }
+inline An operator+(const An& x, const P& s) { return detail::unop(x, "UAddScalar", &s); }
+inline An operator+(const P& s, const An& x) { return detail::unop(x, "UAddScalar", &s); }
+inline An operator-(const An& x, const P& s) {  // `x - f32` = FrameAddScalar(-y)
+    P neg = s;
+    for (float& f : neg.v) f = -f;
+    return detail::unop(x, "UAddScalar", &neg);
+}
+inline An operator-(const P& s, const An& x) { return detail::unop(x, "UNegAddScalar", &s); }
+inline An operator-(const An& x) { return detail::unop(x, "UNeg", nullptr); }
+
+// ---- prelude32 opcodes -------------------------------------------------------------------------------------------
+inline An constant(std::initializer_list<P> v) {
+    An a("Constant<" + std::to_string(v.size()) + ">", 0, (int)v.size());
+    int i = 0;
+    for (const P& p : v) a.with("value[" + std::to_string(i++) + "]", p);
+    return a;
+}
+inline An constant(P v) { return constant({std::move(v)}); }
+inline An dc(P v) { return constant({std::move(v)}); }
+inline An dc(std::initializer_list<P> v) { return constant(v); }
+inline An zero() { return constant(0.0f); }
+inline An pass() { return detail::leaf("Pass", 1, 1); }
+inline An multipass(int n) { return detail::leaf("MultiPass<" + std::to_string(n) + ">", n, n); }
+inline An sink() { return detail::leaf("Sink<1>", 1, 0); }
+inline An multisink(int n) { return detail::leaf("Sink<" + std::to_string(n) + ">", n, 0); }
+inline An split(int n) { return detail::leaf("Split<" + std::to_string(n) + ">", 1, n); }
+inline An join(int n) { return detail::leaf("Join<" + std::to_string(n) + ">", n, 1); }
+inline An multisplit(int m, int n) { return detail::leaf("MultiSplit<" + std::to_string(m) + "," + std::to_string(n) + ">", m, m * n); }
+inline An multijoin(int m, int n) { return detail::leaf("MultiJoin<" + std::to_string(m) + "," + std::to_string(n) + ">", m * n, m); }
+inline An reverse(int n) { return detail::leaf("Reverse<" + std::to_string(n) + ">", n, n); }
+inline An impulse(int n = 1) { return detail::leaf("Impulse<" + std::to_string(n) + ">", 0, n); }
+inline An tick() { return detail::leaf("Tick<1>", 1, 1); }
+inline An sine() { return detail::leaf("Sine", 1, 1); }
+inline An sine_hz(P f) { return constant(std::move(f)) >> sine(); }  // prelude.rs:349
+inline An noise() { return detail::leaf("Noise", 0, 1); }
+inline An white() { return noise(); }
+inline An mls_bits(int n) { return detail::leaf("Mls", 0, 1).with("bits", (float)n); }
+inline An mls() { return mls_bits(29); }
+
+inline An fixed_svf(int mode, P cutoff, P q, P gain = 1.0f) {
+    return detail::leaf("FixedSvf", 1, 1).with("mode", (float)mode).with("cutoff", cutoff).with("q", q).with("gain", gain);
+}
+inline An lowpass_hz(P f, P q) { return fixed_svf(FDSP_SVF_LOWPASS, f, q); }  // prelude.rs:2111
+inline An highpass_hz(P f, P q) { return fixed_svf(FDSP_SVF_HIGHPASS, f, q); }
+inline An bandpass_hz(P f, P q) { return fixed_svf(FDSP_SVF_BANDPASS, f, q); }
+inline An notch_hz(P f, P q) { return fixed_svf(FDSP_SVF_NOTCH, f, q); }
+inline An peak_hz(P f, P q) { return fixed_svf(FDSP_SVF_PEAK, f, q); }
+inline An allpass_hz(P f, P q) { return fixed_svf(FDSP_SVF_ALLPASS, f, q); }
+inline An bell_hz(P f, P q, P gain) { return fixed_svf(FDSP_SVF_BELL, f, q, gain); }
+inline An lowshelf_hz(P f, P q, P gain) { return fixed_svf(FDSP_SVF_LOWSHELF, f, q, gain); }
+inline An highshelf_hz(P f, P q, P gain) { return fixed_svf(FDSP_SVF_HIGHSHELF, f, q, gain); }
+inline An svf(int mode) {  // Svf with (audio, cutoff, q[, gain]) inputs
+    const int nin = mode >= FDSP_SVF_BELL ? 4 : 3;
+    return detail::leaf("Svf<" + std::to_string(nin) + ">", nin, 1).with("mode", (float)mode);
+}
+inline An lowpass() { return svf(FDSP_SVF_LOWPASS); }
+inline An highpass() { return svf(FDSP_SVF_HIGHPASS); }
+inline An bandpass() { return svf(FDSP_SVF_BANDPASS); }
+inline An notch() { return svf(FDSP_SVF_NOTCH); }
+inline An peak() { return svf(FDSP_SVF_PEAK); }
+inline An allpass() { return svf(FDSP_SVF_ALLPASS); }
+inline An bell() { return svf(FDSP_SVF_BELL); }
+inline An lowshelf() { return svf(FDSP_SVF_LOWSHELF); }
+inline An highshelf() { return svf(FDSP_SVF_HIGHSHELF); }
+inline An lowpass_q(P q) { return (multipass(2) | dc(q)) >> svf(FDSP_SVF_LOWPASS).with("q", q); }  // prelude.rs:2127
+inline An highpass_q(P q) { return (multipass(2) | dc(q)) >> svf(FDSP_SVF_HIGHPASS).with("q", q); }
+inline An bandpass_q(P q) { return (multipass(2) | dc(q)) >> svf(FDSP_SVF_BANDPASS).with("q", q); }
+inline An morph() { return detail::leaf("Morph", 4, 1); }
+inline An biquad(P a1, P a2, P b0, P b1, P b2) {
+    return detail::leaf("Biquad", 1, 1).with("a1", a1).with("a2", a2).with("b0", b0).with("b1", b1).with("b2", b2);
+}
+inline An butterpass_hz(P f) { return detail::leaf("ButterLowpass<1>", 1, 1).with("cutoff", f); }
+inline An butterpass() { return detail::leaf("ButterLowpass<2>", 2, 1); }
+inline An resonator_hz(P center, P bandwidth) { return detail::leaf("Resonator<1>", 1, 1).with("center", center).with("q", bandwidth); }
+inline An resonator() { return detail::leaf("Resonator<3>", 3, 1).with("center", 440.0f).with("q", 110.0f); }
+inline An moog_hz(P f, P q) { return detail::leaf("Moog<1>", 1, 1).with("cutoff", f).with("q", q); }
+inline An moog() { return detail::leaf("Moog<3>", 3, 1); }  // prelude.rs:551-553
+inline An moog_q(P q) { return (multipass(2) | dc(q)) >> detail::leaf("Moog<3>", 3, 1).with("cutoff", 1000.0f).with("q", q); }
+inline An fir(std::initializer_list<P> w) {
+    An a("Fir<" + std::to_string(w.size()) + ">", 1, 1);
+    int i = 0;
+    for (const P& p : w) a.with("w[" + std::to_string(i++) + "]", p);
+    return a;
+}
+inline An lowpole_hz(P f) { return detail::leaf("OnePole<OP_LOWPOLE,1>", 1, 1).with("cutoff", f); }
+inline An lowpole() { return detail::leaf("OnePole<OP_LOWPOLE,2>", 2, 1); }
+inline An highpole_hz(P f) { return detail::leaf("OnePole<OP_HIGHPOLE,1>", 1, 1).with("cutoff", f); }
+inline An highpole() { return detail::leaf("OnePole<OP_HIGHPOLE,2>", 2, 1); }
+inline An dcblock_hz(P f) { return detail::leaf("OnePole<OP_DCBLOCK,1>", 1, 1).with("cutoff", f); }
+inline An dcblock() { return dcblock_hz(10.0f); }
+inline An allpole_delay(P d) { return detail::leaf("OnePole<OP_ALLPOLE,1>", 1, 1).with("delay", d); }
+inline An allpole() { return detail::leaf("OnePole<OP_ALLPOLE,2>", 2, 1); }
+inline An pinkpass() { return detail::leaf("Pinkpass", 1, 1); }
+inline An pink() { return white() >> pinkpass(); }                       // prelude32.rs:1299
+inline An brown() { return white() >> lowpole_hz(10.0f) * dc(13.7f); }    // prelude32.rs:1305
+inline An lowrez_hz(P c, P q) { return detail::leaf("Rez<1>", 1, 1).with("bandpass", 0.0f).with("cutoff", c).with("q", q); }
+inline An bandrez_hz(P c, P q) { return detail::leaf("Rez<1>", 1, 1).with("bandpass", 1.0f).with("cutoff", c).with("q", q); }
+inline An lowrez() { return detail::leaf("Rez<3>", 3, 1).with("bandpass", 0.0f); }
+inline An bandrez() { return detail::leaf("Rez<3>", 3, 1).with("bandpass", 1.0f); }
+inline An follow(P t) { return detail::leaf("Follow", 1, 1).with("response_time", t); }
+inline An afollow(P a, P r) { return detail::leaf("AFollow", 1, 1).with("attack_time", a).with("release_time", r); }
+inline An declick() { return detail::leaf("Declick", 1, 1).with("duration", 0.010f); }
+inline An declick_s(P t) { return detail::leaf("Declick", 1, 1).with("duration", t); }
+inline An limiter(P attack, P release) { return detail::leaf("Limiter<1>", 1, 1, 2).with("attack_time", attack).with("release_time", release); }
+inline An limiter_stereo(P attack, P release) { return detail::leaf("Limiter<2>", 2, 2, 3).with("attack_time", attack).with("release_time", release); }
+inline An var(P value) { return detail::leaf("Var", 0, 1).with("value", value); }
+
+enum Shape { CLIP = 0, CLIP_TO, TANH, ATAN, SOFTSIGN, CRUSH, SOFT_CRUSH, ADAPTIVE_TANH };  // shape.rs:35-201
+inline An shape(Shape kind, P p0 = 1.0f, P p1 = 0.0f) {                                     // prelude.rs:1194
+    return detail::leaf("Shaper", 1, 1).with("shape", (float)kind).with("shape_p0", p0).with("shape_p1", p1);
+}
+inline An clip() { return shape(CLIP, 1.0f); }
+inline An clip_to(P lo, P hi) { return shape(CLIP_TO, lo, hi); }
+
+inline An delay(P t) { return detail::leaf("Delay", 1, 1, 1).with("time", t); }
+inline An tap(P lo, P hi) { return detail::leaf("TapT<false>", 2, 1, 1).with("min_delay", lo).with("max_delay", hi); }
+inline An tap_linear(P lo, P hi) { return detail::leaf("TapT<true>", 2, 1, 1).with("min_delay", lo).with("max_delay", hi); }
+inline An multitap(int n, P lo, P hi) { return detail::leaf("TapT<false," + std::to_string(n) + ">", 1 + n, 1, 1).with("min_delay", lo).with("max_delay", hi); }
+inline An allnest_c(P coefficient, const An& x) {
+    An a("AllNest<" + x.type + ">", 1, 1);
+    detail::adopt(a, x, 0);
+    a.with("coefficient", coefficient);
+    return a;
+}
+inline An allnest(const An& x) {
+    An a("AllNest<" + x.type + ",2>", 2, 1);
+    detail::adopt(a, x, 0);
+    return a;
+}
+
+inline An wavesynth(int set) { return detail::leaf("WaveSynth<" + std::to_string(set) + ">", 1, 1); }
+inline An saw() { return wavesynth(0); }
+inline An square() { return wavesynth(1); }
+inline An triangle() { return wavesynth(2); }
+inline An organ() { return wavesynth(4); }
+inline An soft_saw() { return wavesynth(5); }
+inline An hammond() { return wavesynth(6); }
+inline An saw_hz(P f) { return constant(std::move(f)) >> saw(); }
+inline An square_hz(P f) { return constant(std::move(f)) >> square(); }
+inline An triangle_hz(P f) { return constant(std::move(f)) >> triangle(); }
+inline An pulse() { return detail::leaf("PulseWave", 2, 1); }
+inline An ramp() { return detail::leaf("PhaseOsc<OSC_RAMP>", 1, 1); }
+inline An poly_saw() { return detail::leaf("PhaseOsc<OSC_POLYSAW>", 1, 1); }
+inline An poly_square() { return detail::leaf("PhaseOsc<OSC_POLYSQUARE>", 1, 1); }
+inline An poly_pulse() { return detail::leaf("PhaseOsc<OSC_POLYPULSE>", 2, 1); }
+inline An rossler() { return detail::leaf("Chaos<false>", 1, 1); }
+inline An lorenz() { return detail::leaf("Chaos<true>", 1, 1); }
+inline An dsf_saw_r(P r) { return detail::leaf("Dsf<1>", 1, 1).with("harmonic_spacing", 1.0f).with("roughness", r); }
+inline An dsf_square_r(P r) { return detail::leaf("Dsf<1>", 1, 1).with("harmonic_spacing", 2.0f).with("roughness", r); }
+inline An adsr_live(P a, P d, P s, P r) {  // adsr.rs:21
+    return detail::leaf("AdsrLive", 1, 1).with("attack", a).with("decay", d).with("sustain", s).with("release", r);
+}
+inline An pan(P p) { return detail::leaf("Panner", 1, 2).with("pan", p); }  // prelude.rs:1250
+inline An panner() { return detail::leaf("PannerT<2>", 2, 2); }
+inline An oversample(const An& x) {
+    An a("Oversampler<" + x.type + ">", x.inputs, x.outputs);
+    detail::adopt(a, x, 0);
+    return a;
+}
+inline An resample(const An& x) {
+    if (x.inputs != 0) detail::arity("resample: the enclosed node is a generator");
+    An a("Resample<" + x.type + ">", 1, x.outputs);
+    detail::adopt(a, x, 0);
+    return a;
+}
+
+// closures: the Rust closure is a C++ functor type whose definition travels as `source` (contracts in fd_nodes.hpp)
+inline An envelope(const std::string& functor, const std::string& source, int outputs = 1) {  // envelope / lfo, prelude32.rs:581-611
+    An a("Envelope<" + functor + ">", 0, outputs);
+    a.source = source;
+    return a;
+}
+inline An lfo(const std::string& functor, const std::string& source, int outputs = 1) { return envelope(functor, source, outputs); }
+inline An map(const std::string& functor, const std::string& source, int inputs, int outputs) {  // prelude32.rs:332
+    An a("Map<" + functor + "," + std::to_string(inputs) + "," + std::to_string(outputs) + ">", inputs, outputs);
+    a.source = source;
+    return a;
+}
+inline An shape_fn(const std::string& functor, const std::string& source) {  // prelude32.rs:1181
+    An a("ShaperFn<" + functor + ">", 1, 1);
+    a.source = source;
+    return a;
+}
+
+// feedback.rs: feedback / feedback2 (FrameId), fdn / fdn2 (FrameHadamard)
+inline An feedback_with(const char* op, const An& x, const An* y) {
+    if (x.inputs != x.outputs || (y && (y->inputs != x.outputs || y->outputs != x.outputs)))
+        detail::arity("feedback: the enclosed nodes need as many outputs as inputs");
+    An a;
+    if (y) {
+        a = An("Feedback2<" + x.type + "," + y->type + "," + op + ">", x.inputs, x.outputs);
+        detail::adopt(a, x, 0);
+        detail::adopt(a, *y, 1);
+    } else {
+        a = An("Feedback<" + x.type + "," + op + ">", x.inputs, x.outputs);
+        detail::adopt(a, x, 0);
+    }
+    return a;
+}
+inline An feedback(const An& x) { return feedback_with("FbId", x, nullptr); }
+inline An feedback2(const An& x, const An& y) { return feedback_with("FbId", x, &y); }
+inline An fdn(const An& x) { return feedback_with("FbHadamard", x, nullptr); }
+inline An fdn2(const An& x, const An& y) { return feedback_with("FbHadamard", x, &y); }
+
+// N-fold closure forms (busi / stacki / branchi / sumi / pipei and the ..f variants, prelude.rs:1342-1640)
+inline An multi(const char* tmpl, int n, const std::function<An(int)>& f, bool nin_mul, bool nout_mul, const char* extra = "") {
+    if (n < 1) detail::arity("N-fold combinator needs N > 0");
+    std::vector<An> nodes;
+    for (int i = 0; i < n; i++) nodes.push_back(f(i));
+    for (const An& x : nodes)
+        if (x.type != nodes[0].type) detail::arity("the N nodes of an N-fold combinator have one type");
+    An a(std::string(tmpl) + "<" + std::to_string(n) + "," + nodes[0].type + extra + ">", nodes[0].inputs * (nin_mul ? n : 1),
+         nodes[0].outputs * (nout_mul ? n : 1));
+    for (int i = 0; i < n; i++) detail::adopt(a, nodes[i], i);
+    return a;
+}
+inline An busi(int n, const std::function<An(int)>& f) { return multi("MultiBus", n, f, false, false); }
+inline An stacki(int n, const std::function<An(int)>& f) { return multi("MultiStack", n, f, true, true); }
+inline An branchi(int n, const std::function<An(int)>& f) { return multi("MultiBranch", n, f, false, true); }
+inline An sumi(int n, const std::function<An(int)>& f) { return multi("Reduce", n, f, true, false, ",OpAdd"); }
+inline An pipei(int n, const std::function<An(int)>& f) { return multi("PipeN", n, f, false, false); }
+inline float frac(int n, int i) { return n > 1 ? (float)((double)i / (double)(n - 1)) : 0.5f; }
+inline An busf(int n, const std::function<An(float)>& f) { return busi(n, [&](int i) { return f(frac(n, i)); }); }
+inline An stackf(int n, const std::function<An(float)>& f) { return stacki(n, [&](int i) { return f(frac(n, i)); }); }
+inline An branchf(int n, const std::function<An(float)>& f) { return branchi(n, [&](int i) { return f(frac(n, i)); }); }
+inline An sumf(int n, const std::function<An(float)>& f) { return sumi(n, [&](int i) { return f(frac(n, i)); }); }
+inline An pipef(int n, const std::function<An(float)>& f) { return pipei(n, [&](int i) { return f(frac(n, i)); }); }
+
+// ---- Bank: V voices of one graph behind the AudioNode surface ---------------------------------------------------
+class Bank {
+ public:
+    Bank() = default;
+    // a kind compiled into the library ("fm_svf", "fixed_svf", ...) or registered by fdsp_graph_compile
+    Bank(const std::string& kind, size_t voices, size_t ring_frames = 0) : kind_(kind), ring_frames_(ring_frames) {
+        check(ring_frames ? fdsp_bank_create_ring(kind.c_str(), voices, ring_frames, &h_) : fdsp_bank_create(kind.c_str(), voices, &h_));
+    }
+    // compile the graph (one fused kernel set, cached by type + source), create the bank, apply the graph's parameters
+    static Bank from_graph(const An& g, size_t voices, size_t ring_frames = 0, double sample_rate = DEFAULT_SR) {
+        if (g.rings > 0 && ring_frames == 0) throw Error(FDSP_EINVAL, "this graph has delay lines: pass ring_frames");
+        const std::string name = "cpp_" + std::to_string(std::hash<std::string>{}(g.type + '\0' + g.source));
+        if (fdsp_kind_by_name(name.c_str()) < 0) check(fdsp_graph_compile_src(name.c_str(), g.type.c_str(), g.source.c_str()));
+        Bank b(name, voices, ring_frames);
+        for (const Param& p : g.params) {
+            const std::string slot = p.slot();
+            if (p.is_u64) {
+                std::vector<uint64_t> u(voices, p.u64s.size() == 1 ? p.u64s[0] : 0);
+                if (p.u64s.size() == voices) u = p.u64s;
+                check(fdsp_bank_set_param_u64(b.h_, slot.c_str(), u.data(), 0, voices));
+            } else if (p.values.size() == 1) {
+                check(fdsp_bank_set_param_all(b.h_, slot.c_str(), p.values[0]));
+            } else if (p.values.size() == voices) {
+                check(fdsp_bank_set_param(b.h_, slot.c_str(), p.values.data(), 0, voices));
+            } else {
+                throw Error(FDSP_EINVAL, slot + ": a per-voice parameter needs one value per voice");
+            }
+        }
+        b.set_sample_rate(sample_rate);
+        b.reset();  // `.phase()` / `.seed()` store only, the constructor's reset applies them (combinator.rs:263-267)
+        return b;
+    }
+    Bank(Bank&& o) noexcept { *this = std::move(o); }
+    Bank& operator=(Bank&& o) noexcept {
+        if (this != &o) {
+            close();
+            h_ = o.h_;
+            kind_ = std::move(o.kind_);
+            ring_frames_ = o.ring_frames_;
+            o.h_ = nullptr;
+        }
+        return *this;
+    }
+    Bank(const Bank&) = delete;
+    Bank& operator=(const Bank&) = delete;
+    ~Bank() { close(); }
+    void close() {
+        if (h_) fdsp_bank_destroy(h_);
+        h_ = nullptr;
+    }
+    fdsp_bank* handle() const { return h_; }
+
+    // AudioNode surface (audionode.rs:29-369); channels are per voice
+    int inputs() const { return fdsp_bank_inputs(h_); }
+    int outputs() const { return fdsp_bank_outputs(h_); }
+    size_t voices() const { return fdsp_bank_voices(h_); }
+    void reset() { check(fdsp_bank_reset(h_)); }
+    void set_sample_rate(double sr) { check(fdsp_bank_set_sample_rate(h_, sr)); }
+    void set_seed(uint64_t seed) {  // AudioNode::set_seed :366-368, the same seed for every voice
+        std::vector<uint64_t> s(voices(), seed);
+        check(fdsp_bank_set_seed(h_, s.data(), 0, s.size()));
+    }
+    void set_seed(const std::vector<uint64_t>& per_voice) { check(fdsp_bank_set_seed(h_, per_voice.data(), 0, per_voice.size())); }
+    // AudioNode::set(Setting): slots are addressed "<path>:<field>"
+    void set(const std::string& slot, float value) { check(fdsp_bank_set_param_all(h_, slot.c_str(), value)); }
+    void set(const std::string& slot, const std::vector<float>& per_voice, size_t first = 0) {
+        check(fdsp_bank_set_param(h_, slot.c_str(), per_voice.data(), first, per_voice.size()));
+    }
+    // AudioNode::tick for every voice: input [V][inputs], output [V][outputs]
+    void tick(const float* input, float* output) {
+        check(fdsp_bank_process_host(h_, 1, input, output, FDSP_LAYOUT_PLANAR, 1, FDSP_MODE_TICK));
+    }
+    // AudioNode::process(size, &BufferRef, &mut BufferMut): planar blocks [V * channels][64] f32, size <= 64
+    void process(size_t size, const float* input, float* output) {
+        if (size > MAX_BUFFER_SIZE) throw Error(FDSP_EINVAL, "process: size exceeds MAX_BUFFER_SIZE");
+        check(fdsp_bank_process_host(h_, size, input, output, FDSP_LAYOUT_PLANAR, MAX_BUFFER_SIZE, FDSP_MODE_PROCESS));
+    }
+    // device-resident rendering of any length (the engine applies Wave::render's 64-sample blocking itself)
+    void process_device(size_t frames, const float* d_in, float* d_out, int layout = FDSP_LAYOUT_VOICE_MINOR, size_t frame_stride = 0,
+                        int mode = FDSP_MODE_PROCESS, void* stream = nullptr) {
+        check(fdsp_bank_process(h_, frames, d_in, d_out, layout, frame_stride, mode, stream));
+    }
+    void synchronize() { check(fdsp_bank_synchronize(h_)); }
+    // Clone (audionode.rs:29): same kind, same parameters and state
+    Bank clone() const {
+        Bank b(kind_, voices(), ring_frames_);
+        std::vector<float> st((size_t)fdsp_bank_slot_count(h_) * voices());
+        check(fdsp_bank_get_state(h_, st.data()));
+        check(fdsp_bank_set_state(b.h_, st.data()));
+        return b;
+    }
+
+ private:
+    fdsp_bank* h_ = nullptr;
+    std::string kind_;
+    size_t ring_frames_ = 0;
+};
+
+// Wave::render (wave.rs:441-466): set the sample rate, chop `duration` into <= 64-sample blocks, call process.
+// Returns [V * outputs][length] planar.
+inline std::vector<float> render(double sample_rate, double duration, Bank& bank) {
+    if (bank.inputs() != 0) throw Error(FDSP_EINVAL, "render: the node must be a generator");
+    bank.set_sample_rate(sample_rate);
+    const size_t length = (size_t)std::llround(duration * sample_rate);
+    const size_t rows = bank.voices() * (size_t)bank.outputs();
+    std::vector<float> wave(rows * length), block(rows * MAX_BUFFER_SIZE);
+    for (size_t i = 0; i < length;) {
+        const size_t n = std::min(length - i, MAX_BUFFER_SIZE);
+        bank.process(n, nullptr, block.data());
+        for (size_t r = 0; r < rows; r++) std::memcpy(&wave[r * length + i], &block[r * MAX_BUFFER_SIZE], n * sizeof(float));
+        i += n;
+    }
+    return wave;
+}
+
+}  // namespace fundsp_hip
+
+#endif  // FUNDSP_HIP_HPP

@@ -1,0 +1,184 @@
+// C++ host side (include/fundsp_hip.hpp) against the oracle -- written the way the reference's own tests read
+// (tests/test_basic.rs: check_wave :21-47, tick vs process, reset determinism; README.md:98-103 FM patch).
+//
+//   test_cpp_host --host   no device: graph notation, type strings, arity errors, hiprtc type check
+//   test_cpp_host --gpu    on an MI355X: renders through Bank / render() and compares with the oracle bit for bit
+//
+// Test infrastructure: links oracle/libfundsp_oracle.so (the checker) and fundsp_amd/libfundsp_hip.so (the product).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fundsp_hip.hpp"
+#include "fundsp_oracle.h"
+
+using namespace fundsp_hip;
+
+static int failures = 0;
+#define EXPECT(cond)                                                           \
+    do {                                                                       \
+        if (!(cond)) {                                                         \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);        \
+            failures++;                                                        \
+        }                                                                      \
+    } while (0)
+
+template <class F>
+static bool throws(F&& f) {
+    try {
+        f();
+    } catch (const Error&) {
+        return true;
+    }
+    return false;
+}
+
+static bool bit_equal(const float* a, const float* b, size_t n, const char* what) {
+    for (size_t i = 0; i < n; i++)
+        if (std::memcmp(&a[i], &b[i], 4) != 0) {
+            std::printf("FAIL %s: sample %zu got %.9g want %.9g\n", what, i, a[i], b[i]);
+            failures++;
+            return false;
+        }
+    return true;
+}
+
+static void host_checks() {
+    // README.md:98-103 of the reference: sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q)
+    const float f = 110.0f, m = 2.0f;
+    An fm = sine_hz(f) * f * m + f >> sine() >> lowpass_hz(1000.0f, 1.0f);
+    EXPECT(fm.type == "Pipe<Pipe<Unop<Unop<Unop<Pipe<Constant<1>,Sine>,UMulScalar>,UMulScalar>,UAddScalar>,Sine>,FixedSvf>");
+    EXPECT(fm.inputs == 0 && fm.outputs == 1);
+    EXPECT(fdsp_graph_check(fm.type.c_str()) == 0);
+    // operator table arities (tests/test_basic.rs:604-640)
+    EXPECT((pass() ^ pass()).outputs == 2);
+    EXPECT((sink() | zero()).inputs == 1 && (sink() | zero()).outputs == 1);
+    EXPECT((!butterpass() >> lowpole()).inputs == 2);
+    EXPECT((pass() & lowpole_hz(100.0f)).outputs == 1);
+    EXPECT(throws([] { sine() >> (sine() | sine()); }));   // a compile-time error in Rust
+    EXPECT(throws([] { pass() & sink(); }));
+    EXPECT(fdsp_graph_check(fdn(stacki(3, [](int) { return pass(); })).type.c_str()) < 0);   // FrameHadamard: power of two
+    // parameter addressing follows the C ABI's "<path>:<field>" slot names
+    An g = sine_hz(440.0f) >> lowpass_hz(1000.0f, 1.0f);
+    bool found = false;
+    for (const Param& p : g.params) found = found || p.slot() == "1:cutoff";
+    EXPECT(found);
+    An echo = feedback(delay(0.5f) * 0.5f);   // test_basic.rs:646
+    EXPECT(echo.inputs == 1 && echo.outputs == 1 && echo.rings == 1);
+    EXPECT(fdsp_graph_check(echo.type.c_str()) == 0);
+    EXPECT(fdsp_graph_check((busi(4, [](int i) { return sine_hz(100.0f * (i + 1)); }) >> split(2) >> join(2)).type.c_str()) == 0);
+    EXPECT(throws([] { Bank b("no_such_kind", 4); }));
+}
+
+static onode* oracle_fm(float f, float m, float fc, float q) {
+    float c = f;
+    onode* mod = o_pipe(o_constant(1, &c), o_sine());
+    onode* g = o_unop(O_ADD_SCALAR, o_unop(O_MUL_SCALAR, o_unop(O_MUL_SCALAR, mod, f), m), f);
+    return o_pipe(o_pipe(g, o_sine()), o_fixed_svf(O_SVF_LOWPASS, fc, q, 1.0f));
+}
+
+static void gpu_checks() {
+    const double SR = 48000.0;
+    // config 1: sine_hz(440) >> lowpass_hz(1000, 1), one voice, one second through Wave::render's blocking
+    {
+        Bank b = Bank::from_graph(sine_hz(440.0f) >> lowpass_hz(1000.0f, 1.0f), 1);
+        std::vector<float> got = render(SR, 1.0, b);
+        float c = 440.0f;
+        onode* n = o_pipe(o_pipe(o_constant(1, &c), o_sine()), o_fixed_svf(O_SVF_LOWPASS, 1000.0f, 1.0f, 1.0f));
+        std::vector<float> want(48000);
+        EXPECT(o_wave_render(n, SR, 1.0, want.data(), want.size()) == 48000);
+        EXPECT(got.size() == 48000);
+        bit_equal(got.data(), want.data(), 48000, "config 1 render");
+        // reset restores the initial state (doc-test audionode.rs:44-49)
+        b.reset();
+        std::vector<float> again = render(SR, 1.0, b);
+        bit_equal(again.data(), got.data(), 48000, "render after reset");
+        // the tick path: 100 samples, one per call, against the oracle's tick after reset
+        b.reset();
+        o_reset(n);
+        for (int i = 0; i < 100; i++) {
+            float y = 0.0f, w = 0.0f;
+            b.tick(nullptr, &y);
+            o_tick(n, nullptr, &w);
+            if (!bit_equal(&y, &w, 1, "tick")) break;
+        }
+        o_free(n);
+    }
+    // the FM patch with per-voice parameters, 70 voices, seeds per voice; blocks of 64, 13, 0 and 64 samples
+    {
+        const size_t V = 70;
+        std::vector<float> f(V), m(V), fc(V), q(V);
+        std::vector<uint64_t> seeds(V);
+        for (size_t v = 0; v < V; v++) {
+            f[v] = 55.0f + 20.0f * (float)v;
+            m[v] = 0.5f + 0.1f * (float)v;
+            fc[v] = 300.0f + 90.0f * (float)v;
+            q[v] = 0.5f + 0.04f * (float)v;
+            seeds[v] = 1000 + 17 * v;
+        }
+        An g = sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q);
+        Bank b = Bank::from_graph(g, V, 0, SR);
+        b.set_seed(seeds);
+        const size_t sizes[4] = {64, 13, 0, 64};
+        std::vector<std::vector<float>> blocks;
+        for (size_t s : sizes) {
+            std::vector<float> out(V * 64, -7.0f);
+            b.process(s, nullptr, out.data());
+            blocks.push_back(out);
+        }
+        for (size_t v : {(size_t)0, (size_t)33, V - 1}) {
+            onode* n = oracle_fm(f[v], m[v], fc[v], q[v]);
+            o_set_sample_rate(n, SR);
+            o_set_seed(n, seeds[v]);
+            for (int k = 0; k < 4; k++) {
+                float want[64] = {0};
+                o_process(n, (int)sizes[k], nullptr, want);
+                bit_equal(&blocks[k][v * 64], want, sizes[k], "fm process block");
+                for (size_t i = sizes[k]; i < 64; i++) EXPECT(blocks[k][v * 64 + i] == -7.0f);  // samples past `size` untouched
+            }
+            o_free(n);
+        }
+        // Clone: a clone continues exactly like the original
+        Bank c = b.clone();
+        std::vector<float> a1(V * 64), a2(V * 64);
+        b.process(64, nullptr, a1.data());
+        c.process(64, nullptr, a2.data());
+        bit_equal(a1.data(), a2.data(), V * 64, "clone continues identically");
+    }
+    // a filter with an input: noise through the C ABI, the same samples through the oracle
+    {
+        Bank b("fixed_svf", 1);
+        b.set(":cutoff", 1234.0f);
+        b.set(":q", 0.7f);
+        b.set_sample_rate(SR);
+        onode* n = o_fixed_svf(O_SVF_LOWPASS, 1234.0f, 0.7f, 1.0f);
+        o_set_sample_rate(n, SR);
+        float x[64], got[64], want[64];
+        uint32_t s = 12345;
+        for (int blk = 0; blk < 5; blk++) {
+            for (float& t : x) {
+                s = s * 1664525u + 1013904223u;
+                t = (float)(s >> 8) * (1.0f / 8388608.0f) - 1.0f;
+            }
+            b.process(64, x, got);
+            o_process(n, 64, x, want);
+            bit_equal(got, want, 64, "fixed_svf process");
+        }
+        o_free(n);
+    }
+}
+
+int main(int argc, char** argv) {
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "--gpu") == 0;
+    try {
+        host_checks();
+        if (gpu) gpu_checks();
+    } catch (const std::exception& e) {
+        std::printf("FAIL: exception %s\n", e.what());
+        return 2;
+    }
+    std::printf("%s: %d failure(s)\n", gpu ? "gpu" : "host", failures);
+    return failures ? 1 : 0;
+}
