@@ -158,6 +158,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # also relate the kernel to what this box's HBM delivers to plain streaming kernels (a 2 GiB
+    # device-to-device copy = read + write, and a fill = write only, the kernel's own traffic shape), outside the timed region
+    measured = None
+    if rank == 0 and world == 1:
+        n = 1 << 29
+        a = torch.empty(n, dtype=torch.float32, device="cuda")
+        b2 = torch.empty(n, dtype=torch.float32, device="cuda")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        def timed(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e-3
+        t_copy = timed(lambda: b2.copy_(a))
+        t_fill = timed(lambda: a.fill_(1.0))
+        measured = {"copy_gbs": round(2 * n * 4 / t_copy / 1e9, 1), "fill_gbs": round(n * 4 / t_fill / 1e9, 1)}
+        del a, b2
+
     if rank == 0:
         total_samples = float(world) * V * T * args.steps
         value = total_samples / elapsed / 1e6
@@ -216,6 +238,8 @@ def main():
                            5: "fd::k_fdn_render"}[args.config],
                 "kernel_ms_avg": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
+                "measured_streaming": measured,
+                "frac_of_measured_fill": round(achieved / measured["fill_gbs"], 4) if measured else None,
             },
         }
         if world == 1 and args.cpu_seconds > 0 and args.config == 3:

@@ -14,6 +14,8 @@ CASES = [
     ("flanger", lambda: G.noise() >> G.flanger(0.6, 0.002, 0.006, "EnvSineHz", hz=0.7, lo=0.002, hi=0.006), 32768, 12000, 512, 24),
     ("phaser", lambda: G.noise() >> G.phaser(0.5, "EnvSineHz", hz=0.7, lo=0.0, hi=1.0), 32768, 12000, 0, 0),
     ("limiter_stereo 2 ms", lambda: (G.noise() | G.noise()) >> G.limiter_stereo(0.002, 0.02), 32768, 12000, 256, 0),
+    ("allpass chain, 6 rings", lambda: G.noise() >> G.pipei(6, lambda i: G.allnest_c(0.6, G.delay(0.003 + 0.0007 * i))), 32768, 12000, 512, 48),
+    ("echo feedback(delay)", lambda: G.noise() >> G.feedback(G.delay(0.005) * 0.5), 32768, 12000, 512, 8),
     ("reverb4_stereo", lambda: (G.noise() | G.noise()) >> G.reverb4_stereo(20.0, 2.0), 2048, 12000, 8192, 256),
     ("reverb3_stereo", lambda: (G.noise() | G.noise()) >> G.reverb3_stereo(2.0, 0.6, lambda: G.lowpole_hz(1600.0)), 2048, 12000, 2048, 608),
 ]
