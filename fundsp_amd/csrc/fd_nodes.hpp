@@ -2640,6 +2640,65 @@ struct Limiter {
     FD_STEP2_VIA_STEP
 };
 
+// Hold  noise.rs:242-322 (ID 76): sample-and-hold of input 0 at the frequency on input 1 (Hz); each hold lasts
+// lerp(1 - variability, 1 + variability, rnd.f64()) / frequency seconds.  The draws come from funutd's
+// `Rnd::from_u64(hash)`, a third-party generator whose source is not under /root/reference, so -- as for Pluck's
+// excitation -- the host uploads that stream (fdsp_bank_set_ring, this node's ring: each f64 draw as two consecutive
+// f32 words, low word first) after reading the node's ":hash" slot; the ring wraps if a render outlasts it.  reset()
+// re-seeds the generator in the reference (:281-285): the stream restarts.  Time is f64; no process override.
+struct Hold {
+    static constexpr int IN = 2, OUT = 1, RINGS = 1;
+    static constexpr uint64_t ID = 76;
+    float variability, hold;
+    uint32_t pos;
+    uint64_t sd_bits, t_bits, next_bits, hash;
+    float* ring;
+    size_t vs;
+    uint32_t cap;
+    template <class V> FD_HD void visit(V& v) {
+        v.f(variability, PARAM, "variability");
+        v.u64(sd_bits, COEF, "sample_duration");
+        v.u64(t_bits, STATE, "t");
+        v.u64(next_bits, STATE, "next_t");
+        v.f(hold, STATE, "hold");
+        v.u32(pos, STATE, "draws");
+        v.u64(hash, STATE, "hash");
+    }
+    FD_HD void bind(Ctx& c) { ring = c.claim_ring(); vs = c.vstride; cap = c.ring_cap; }
+    FD_HD void init() { variability = 0.0f; hold = 0.0f; hash = 0; sd_bits = 0; reset(); }
+    FD_HD void update(double sr) { sd_bits = __builtin_bit_cast(uint64_t, 1.0 / sr); }  // :287-289
+    FD_HD void reset() { pos = 0; t_bits = 0; next_bits = 0; }                             // :281-285
+    FD_HD uint64_t ping(bool probe, uint64_t h) {
+        if (!probe) {  // set_hash :312-315
+            hash = h;
+            reset();
+        }
+        return atto(h, ID);
+    }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float* in, float* out) {  // tick :292-304
+        double t = __builtin_bit_cast(double, t_bits);
+        const double next_t = __builtin_bit_cast(double, next_bits);
+        if (t >= next_t) {
+            hold = in[0];
+            const uint32_t draws = cap / 2u;
+            const uint32_t k = draws ? pos % draws : 0u;
+            const uint64_t lo = __builtin_bit_cast(uint32_t, ring[(size_t)(2u * k) * vs]);
+            const uint64_t hi = __builtin_bit_cast(uint32_t, ring[(size_t)(2u * k + 1u) * vs]);
+            const double r = __builtin_bit_cast(double, lo | (hi << 32));
+            pos += 1u;
+            const double a = 1.0 - (double)variability, b = 1.0 + (double)variability;
+            next_bits = __builtin_bit_cast(uint64_t, t + (a * (1.0 - r) + b * r) / (double)in[1]);  // lerp math.rs:169-178
+        }
+        t += __builtin_bit_cast(double, sd_bits);
+        t_bits = __builtin_bit_cast(uint64_t, t);
+        out[0] = hold;
+    }
+    FD_STEP2_VIA_STEP
+};
+
 // Mls  noise.rs:14-151 (ID 19): maximum length sequence noise, integer-exact.  `bits` (1..31) is a parameter; a bank
 // starts in MlsState::new's all-ones state of the default 29-bit sequence until reset / set_seed re-derives it.
 FD_HD uint32_t mls_poly(uint32_t n) {  // MLS_POLY noise.rs:23-55

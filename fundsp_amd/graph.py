@@ -267,6 +267,13 @@ def _meter(mode, timescale, monitor):
 def meter(mode, timescale=0.1): return _meter(mode, timescale, False)     # prelude32.rs:300: meter(Meter::Peak(t)) etc.
 def monitor(mode, timescale=0.1): return _meter(mode, timescale, True)    # level readable from the ":state" slot
 def var(value): return _leaf("Var", 0, 1, value=value)                    # a Shared value = a per-voice parameter
+def hold(variability):  # prelude32.rs:830; the Rnd draws: Bank.set_ring(<this node's ring>, hold_stream(draws))
+    return _leaf("Hold", 2, 1, rings=1, variability=variability)
+def hold_hz(f, variability): return (pass_() | dc(f)) >> hold(variability)                    # prelude32.rs:843
+def hold_stream(draws):
+    """[voices][n] f64 draws of `Rnd::from_u64(hash).f64()` -> the [voices][2n] f32 words Hold's ring takes."""
+    d = np.ascontiguousarray(draws, dtype=np.float64)
+    return d.view(np.float32).reshape(d.shape[0], -1)
 def mixer(matrix):                                                        # Mixer::new pan.rs:108, matrix[out][in]
     m = np.asarray(matrix, dtype=object)
     n_out, n_in = len(matrix), len(matrix[0])

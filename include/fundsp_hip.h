@@ -179,7 +179,8 @@ int fdsp_bank_last_kernel_ms(fdsp_bank* bank, float* ms);
 /* Upload the first `frames` positions of ring node `ring_index` (visit order) for `count` voices from `first_voice`:
  * data is [count][frames] f32.  Used for state a Rust caller must provide because it comes from a crate outside the
  * reference tree: Pluck's excitation, the stream `Rnd::from_u64(hash).f32_in(-1.0, 1.0)` of funutd that
- * Pluck::initialize_line draws (src/oscillator.rs:257-261), goes into ring 0 of the "pluck" kind. */
+ * Pluck::initialize_line draws (src/oscillator.rs:257-261), goes into ring 0 of the "pluck" kind; Hold's draws
+ * `Rnd::from_u64(hash).f64()` (src/noise.rs:299) go into that node's ring, each f64 as two f32 words, low word first. */
 int fdsp_bank_set_ring(fdsp_bank* bank, int ring_index, const float* data, size_t frames, size_t first_voice,
                        size_t count);
 

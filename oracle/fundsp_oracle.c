@@ -136,6 +136,11 @@ struct onode {
         void *env_ctx;
         float env_v0[O_MAX_ENV], env_v1[O_MAX_ENV], env_val[O_MAX_ENV], env_d[O_MAX_ENV];
         int ps_ready; /* PhaseSynth::phase_ready */
+        /* Hold (noise.rs:242-250) */
+        double *hd_draws;
+        size_t hd_n, hd_pos;
+        double hd_sd, hd_t, hd_next;
+        float hd_var, hd_hold;
         /* MeterState (dynamics.rs:336-339) */
         int mt_mode, mt_monitor;
         double mt_timescale;
@@ -192,6 +197,7 @@ void o_free(onode *n) {
     o_free(n->y);
     o_free(n->aux);
     for (int i = 0; i < 4; i++) o_free(n->pre[i]);
+    free(n->s.hd_draws);
     free(n->s.lm_tree);
     free(n->s.lm_buf);
     for (int i = 0; i < n->nkids; i++) o_free(n->kids[i]);
@@ -574,6 +580,7 @@ void o_reset(onode *n) {
     if (n->type == O_DECLICK) n->s.dc_t = 0.0f;     /* dynamics.rs:268-270 */
     if (n->type == O_PHASESYNTH) n->s.ps_ready = 0; /* wavetable.rs:387-389 */
     if (n->type == O_METER) n->s.mt_state = 0.0f;   /* dynamics.rs:351-353 */
+    if (n->type == O_HOLD) { n->s.hd_pos = 0; n->s.hd_t = 0.0; n->s.hd_next = 0.0; } /* noise.rs:281-285: rnd re-seeded */
     if (n->type == O_REVERB3) n->rv3_feedback = 0.0f; /* reverb.rs:223 (the blocks are the kids: reset by the recursion) */
     if (n->type == O_LIMITER) limiter_set_sr(n, n->s.lm_sr); /* dynamics.rs:184-186 */
     if (n->type == O_FEEDBACK) memset(n->fb_value, 0, sizeof n->fb_value); /* feedback.rs:118-121 */
@@ -720,6 +727,7 @@ void o_set_sample_rate(onode *n, double sr) {
     if (n->type == O_DECLICK) n->s.dc_sd = (float)(1.0 / sr); /* dynamics.rs:272-275 */
     if (n->type == O_PHASESYNTH) n->s.ws_sr = (float)sr;      /* wavetable.rs:391-393 */
     if (n->type == O_METER) meter_set_sr(n, sr);
+    if (n->type == O_HOLD) n->s.hd_sd = 1.0 / sr; /* noise.rs:287-289 */
     if (n->type == O_LIMITER) limiter_set_sr(n, sr);
     leaf_set_sample_rate(n, sr);
 }
@@ -730,6 +738,9 @@ static void leaf_set_hash(onode *n, uint64_t hash) {
         n->type == O_MLS || n->type == O_DSF) { /* Mls::set_hash noise.rs:142-145 */
         n->s.hash = hash;
         leaf_reset(n);
+    } else if (n->type == O_HOLD) { /* noise.rs:312-315: set_hash resets (the stream restarts) */
+        n->s.hash = hash;
+        n->s.hd_pos = 0; n->s.hd_t = 0.0; n->s.hd_next = 0.0;
     } else if (n->type == O_PLUCK) { /* oscillator.rs:307-310 */
         n->s.hash = hash;
         n->s.pl_init = 0;
@@ -1087,6 +1098,17 @@ onode *o_meter(int mode, double timescale, int monitor) {
     return n;
 }
 float o_meter_level(const onode *n) { return n->s.mt_mode == O_METER_RMS ? sqrtf(n->s.mt_state) : n->s.mt_state; }
+onode *o_hold(float variability, const double *draws, size_t n_draws) { /* Hold::new noise.rs:255-263 */
+    if (!n_draws) return NULL;
+    onode *n = o_new(O_HOLD, 2, 1, 76);
+    n->s.hd_var = variability;
+    n->s.hd_draws = (double *)malloc(n_draws * sizeof(double));
+    memcpy(n->s.hd_draws, draws, n_draws * sizeof(double));
+    n->s.hd_n = n_draws;
+    n->s.hd_pos = 0; n->s.hd_t = 0.0; n->s.hd_next = 0.0; n->s.hd_hold = 0.0f;
+    n->s.hd_sd = 1.0 / DEFAULT_SR;
+    return n;
+}
 onode *o_mixer(int inputs, int outputs, const float *matrix) {
     if (inputs < 1 || outputs < 1 || inputs > 8 || outputs > 8) return NULL;
     onode *n = o_new(O_MIXER, inputs, outputs, 84);
@@ -1872,6 +1894,17 @@ void o_tick(onode *n, const float *in, float *out) {
     case O_VAR: /* shared.rs:117-120; VarFn :171-173 */
         if (n->map_fn) n->map_fn(&n->s.value[0], out, n->map_ctx);
         else out[0] = n->s.value[0];
+        break;
+    case O_HOLD: /* noise.rs:292-304 */
+        if (n->s.hd_t >= n->s.hd_next) {
+            n->s.hd_hold = in[0];
+            double r = n->s.hd_draws[n->s.hd_pos % n->s.hd_n];
+            n->s.hd_pos++;
+            double a = 1.0 - (double)n->s.hd_var, b = 1.0 + (double)n->s.hd_var;
+            n->s.hd_next = n->s.hd_t + (a * (1.0 - r) + b * r) / (double)in[1];
+        }
+        n->s.hd_t += n->s.hd_sd;
+        out[0] = n->s.hd_hold;
         break;
     case O_MIXER: /* pan.rs:124-133 */
         for (int i = 0; i < n->nout; i++) {

@@ -19,7 +19,7 @@ enum {
     O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP,
     O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO, O_SHAPER, O_PHASE_OSC, O_CHAOS, O_NLBIQUAD, O_TAP, O_ALLNEST,
     O_ONEPOLE, O_PINKPASS, O_MORPH, O_REZ, O_FOLLOW, O_AFOLLOW, O_MLS, O_OVERSAMPLE, O_DSF, O_PLUCK, O_ENVELOPE, O_RESAMPLE, O_ENVELOPE_IN,
-    O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK, O_FEEDBACK, O_PHASESYNTH, O_WRAP, O_METER, O_VAR, O_LIMITER, O_REVERB3, O_MIXER
+    O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK, O_FEEDBACK, O_PHASESYNTH, O_WRAP, O_METER, O_VAR, O_LIMITER, O_REVERB3, O_MIXER, O_HOLD
 };
 enum { O_OP_LOWPOLE = 0, O_OP_HIGHPOLE, O_OP_DCBLOCK, O_OP_ALLPOLE };
 enum { O_SH_CLIP = 0, O_SH_CLIPTO, O_SH_TANH, O_SH_ATAN, O_SH_SOFTSIGN, O_SH_CRUSH, O_SH_SOFTCRUSH, O_SH_ADAPTIVE_TANH };
@@ -91,6 +91,9 @@ void o_var_set(onode *n, float value);
 onode *o_limiter(int channels, float attack_time, float release_time); /* Limiter<N> (dynamics.rs:125, ID 25) */
 onode *o_follow(float response_time);                           /* Follow<f32> (follow.rs:31) */
 onode *o_afollow(float attack_time, float release_time);         /* AFollow<f32> (follow.rs:137) */
+/* Hold (noise.rs:242, ID 76): `draws` is the stream Rnd::from_u64(hash).f64() of funutd (crate source absent: supplied
+ * by the caller, as for o_pluck); reset restarts it */
+onode *o_hold(float variability, const double *draws, size_t n_draws);
 onode *o_mls(unsigned bits);                                     /* Mls (noise.rs:103), 1 <= bits <= 31 */
 void o_mls_set_seed(onode *n, uint64_t seed);
 uint64_t o_mls_period(unsigned bits);                            /* test helper: cycle length from the all-ones state */

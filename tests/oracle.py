@@ -86,7 +86,7 @@ def lib():
         "o_reverse": (P, [i]), "o_impulse": (P, [i]), "o_map": (P, [i, i, P, P]),
         "o_shape_fn": (P, [P, P]), "o_declick": (P, [f]),
         "o_feedback": (P, [P, P, i]), "o_meter": (P, [i, d, i]), "o_meter_level": (f, [P]), "o_var": (P, [f]),
-        "o_var_set": (None, [P, f]), "o_mixer": (P, [i, i, fp]), "o_var_fn": (P, [f, i, P, P]), "o_limiter": (P, [i, f, f]),
+        "o_var_set": (None, [P, f]), "o_mixer": (P, [i, i, fp]), "o_hold": (P, [f, C.POINTER(C.c_double), C.c_size_t]), "o_var_fn": (P, [f, i, P, P]), "o_limiter": (P, [i, f, f]),
         "o_branch": (P, [P, P]), "o_bus": (P, [P, P]), "o_thru": (P, [P]), "o_multi": (P, [i, i, C.POINTER(P), i]),
         "o_reverb_stereo": (P, [d, d, d]), "o_reverb3": (P, [d, d, C.POINTER(P)]),
         "o_reverb_stereo_params": (None, [d, d, d, d, fp, C.POINTER(C.c_int), fp, fp]),
@@ -224,6 +224,10 @@ def meter(mode, timescale=0.1): return Node(lib().o_meter(METER_MODES[mode], tim
 def monitor(mode, timescale=0.1): return Node(lib().o_meter(METER_MODES[mode], timescale, 1))  # prelude32.rs monitor(&shared, meter)
 def meter_level(n): return np.float32(lib().o_meter_level(n.ptr))
 def var(value): return Node(lib().o_var(value))                                               # prelude32.rs var(&shared)
+def hold(variability, draws):                                                                 # prelude32.rs:830 (+ the Rnd stream)
+    d = np.ascontiguousarray(draws, dtype=np.float64)
+    return Node(lib().o_hold(variability, d.ctypes.data_as(C.POINTER(C.c_double)), d.size))
+def hold_hz(f, variability, draws): return (pass_() | dc(f)) >> hold(variability, draws)     # prelude32.rs:843
 def mixer(matrix):                                                                            # Mixer::new pan.rs:108
     m = np.ascontiguousarray(matrix, dtype=np.float32)
     return Node(lib().o_mixer(m.shape[1], m.shape[0], _fptr(m)))

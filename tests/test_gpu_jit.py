@@ -169,6 +169,31 @@ struct Env3 {  // |t, x, y| exp(-t * x) * y
             assert_bit_equal(got[v], oracle_render(n, None, T, mode), f"mixer/var_fn/bank voice {v} mode {mode}")
 
 
+def test_jit_hold_with_uploaded_rnd_stream(gpu):
+    """hold_hz(f, variability) (noise.rs:242-322, prelude32.rs:831): sample-and-hold whose hold lengths come from
+    funutd's Rnd -- the draws are uploaded per voice (as for Pluck), everything else runs on the device in f64 time."""
+    V, T, ND = 40, 64 * 30 + 11, 64
+    rng = np.random.default_rng(31)
+    draws = rng.random((V, ND))                                   # stands in for Rnd::from_u64(hash).f64()
+    g = GR.noise() >> GR.hold_hz(700.0, 0.5)
+    seeds = np.arange(V, dtype=np.uint64) + 3
+    for mode in (MODE_PROCESS, MODE_TICK):
+        b = gpu.Bank.from_graph(g, V, ring_frames=2 * ND, sample_rate=SR)
+        b.set_seed(seeds)
+        b.set_ring(0, GR.hold_stream(draws))
+        got = run_bank(b, None, T, LAYOUT_VOICE_MINOR, mode)
+        for v in (0, 17, V - 1):
+            n = O.noise() >> O.hold_hz(700.0, 0.5, draws[v])
+            n.set_sample_rate(SR)
+            n.set_seed(int(seeds[v]))
+            want = oracle_render(n, None, T, mode)
+            assert len(np.unique(want)) > 20                      # it does hold and re-sample
+            assert_bit_equal(got[v], want, f"hold voice {v} mode {mode}")
+        b.reset()                                                  # the stream restarts with the generator (:281-285)
+        again = run_bank(b, None, 256, LAYOUT_VOICE_MINOR, mode)
+        assert_bit_equal(again, got[:, :, :256], "hold after reset")
+
+
 def test_jit_flanger_and_phaser(gpu):
     """flanger(..) / phaser(..) (prelude.rs:2719-2753): Bus + Feedback2 / Feedback around taps, a tanh shaper, ten
     pass-through allpoles; the modulation closure is a functor on the engine side and a callback in the oracle."""
