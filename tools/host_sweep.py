@@ -1,3 +1,5 @@
+"""fdsp_bank_process_host: per-call latency of a 64-frame block, staged through HBM vs zero-copy (the option
+"host_zero_copy_max" picks the cross-over).  Run on the GPU box: python tools/host_sweep.py"""
 import sys, os, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
@@ -20,7 +22,7 @@ for kind in ("fm", "svf"):
   for layout in (1, 0):
     for V in (1, 16, 64, 256, 1024, 4096, 16384):
         r = []
-        for zc, pm in ((0, 0), (0, 1 << 30), (1 << 30, 1 << 30)):
-            L.fdsp_set_option(b"host_zero_copy_max", zc); L.fdsp_set_option(b"host_pinned_max", pm)
+        for zc in (0, 1 << 30):   # staged through HBM (pageable copies) vs kernel reading / writing pinned host memory
+            assert L.fdsp_set_option(b"host_zero_copy_max", zc) == 0
             r.append(run(kind, V, 64, layout, 300 if V < 10000 else 100))
-        print(f"hb2 {kind} layout={layout} V={V:6d}: pageable {r[0]:8.1f}  pinned {r[1]:8.1f}  zerocopy {r[2]:8.1f} us")
+        print(f"hb2 {kind} layout={layout} V={V:6d}: staged {r[0]:8.1f}  zerocopy {r[1]:8.1f} us")
