@@ -2684,10 +2684,13 @@ struct Hold {
         if (t >= next_t) {
             hold = in[0];
             const uint32_t draws = cap / 2u;
-            const uint32_t k = draws ? pos % draws : 0u;
-            const uint64_t lo = __builtin_bit_cast(uint32_t, ring[(size_t)(2u * k) * vs]);
-            const uint64_t hi = __builtin_bit_cast(uint32_t, ring[(size_t)(2u * k + 1u) * vs]);
-            const double r = __builtin_bit_cast(double, lo | (hi << 32));
+            double r = 0.5;  // a ring too small to hold one draw: the mean hold length
+            if (draws) {
+                const uint32_t k = pos % draws;
+                const uint64_t lo = __builtin_bit_cast(uint32_t, ring[(size_t)(2u * k) * vs]);
+                const uint64_t hi = __builtin_bit_cast(uint32_t, ring[(size_t)(2u * k + 1u) * vs]);
+                r = __builtin_bit_cast(double, lo | (hi << 32));
+            }
             pos += 1u;
             const double a = 1.0 - (double)variability, b = 1.0 + (double)variability;
             next_bits = __builtin_bit_cast(uint64_t, t + (a * (1.0 - r) + b * r) / (double)in[1]);  // lerp math.rs:169-178

@@ -393,6 +393,15 @@ class Bank {
         if (g.rings > 0 && ring_frames == 0) throw Error(FDSP_EINVAL, "this graph has delay lines: pass ring_frames");
         const std::string name = "cpp_" + std::to_string(std::hash<std::string>{}(g.type + '\0' + g.source));
         if (fdsp_kind_by_name(name.c_str()) < 0) check(fdsp_graph_compile_src(name.c_str(), g.type.c_str(), g.source.c_str()));
+        // the shared wavetables of the reference (saw_table() etc., wavetable.rs:493-623) are built on first use
+        static const std::pair<const char*, int> tables[] = {{"WaveSynth<0", 0}, {"PulseWave", 0}, {"WaveSynth<1", 1}, {"WaveSynth<2", 2},
+                                                             {"WaveSynth<4", 4}, {"WaveSynth<5", 5}, {"WaveSynth<6", 6}};
+        for (const auto& t : tables)
+            if (g.type.find(t.first) != std::string::npos) {
+                int n = 0;
+                check(fdsp_wavetable_get(t.second, &n, nullptr, nullptr, nullptr, 0));
+                if (n == 0) check(fdsp_wavetable_build(t.second));
+            }
         Bank b(name, voices, ring_frames);
         for (const Param& p : g.params) {
             const std::string slot = p.slot();

@@ -5,6 +5,8 @@
 //   test_cpp_host --gpu    on an MI355X: renders through Bank / render() and compares with the oracle bit for bit
 //
 // Test infrastructure: links oracle/libfundsp_oracle.so (the checker) and fundsp_amd/libfundsp_hip.so (the product).
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -146,6 +148,25 @@ static void gpu_checks() {
         b.process(64, nullptr, a1.data());
         c.process(64, nullptr, a2.data());
         bit_equal(a1.data(), a2.data(), V * 64, "clone continues identically");
+    }
+    // a wavetable voice through the closure-form combinators: tables are built on first use; tick == process within 1e-4
+    // like check_wave (tests/test_basic.rs:21-47)
+    {
+        An g = busi(3, [](int i) { return saw_hz(110.0f * (float)(i + 1)) * 0.3f; }) >> (pass() ^ lowpole_hz(800.0f)) >> join(2);
+        Bank b = Bank::from_graph(g, 4, 0, SR);
+        std::vector<float> w = render(SR, 0.01, b);
+        b.reset();
+        const size_t length = w.size() / 4;
+        double worst = 0.0;
+        for (size_t i = 0; i < length; i++) {
+            std::vector<float> y(4);
+            b.tick(nullptr, y.data());
+            for (size_t v = 0; v < 4; v++) worst = std::max(worst, (double)std::fabs(y[v] - w[v * length + i]));
+        }
+        EXPECT(worst <= 1e-4);
+        float peak = 0.0f;
+        for (float x : w) peak = std::max(peak, std::fabs(x));
+        EXPECT(peak > 0.05f && peak < 2.0f);
     }
     // a filter with an input: noise through the C ABI, the same samples through the oracle
     {
