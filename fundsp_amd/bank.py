@@ -84,7 +84,11 @@ class Bank:
             lib().fdsp_bank_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        # at interpreter shutdown the module globals may already be gone; the process is about to release the device anyway
+        if _lib is None or getattr(_lib, "_lib", None) is None:
+            return
+        self.close()
 
     # --- AudioNode surface
     def inputs(self):
