@@ -822,9 +822,12 @@ constexpr PipePlan pipe_plan(int want) {  // want: 0 = best plan, 1 / 2 / 3 = at
 // Graph inputs come from the feed tile `fin` (written by the loader wave), never from HBM directly: the FIRST stage
 // consumes them as its inputs, a later stage that holds a Binop tail reads them as `gin`.
 // Hand-over tiles: [channel][frame pair][lane] (v2f).
-template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST>
+// FS = floats per frame row of the feed tile (64, or 65 when the loader fills it by transposing planar rows); OL = where
+// the LAST stage puts its samples: 0 = HBM, voice-minor; 1 = an LDS tile [channel][frame][FS] that the storer wave of the
+// planar pipeline transposes out.
+template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST, int FS = 64, int OL = 0>
 FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_t V, int lane, float* outw,
-                     const float (*fin)[SUB][64], v2f (*hin)[SUB / 2][64], v2f (*hout)[SUB / 2][64]) {
+                     const float* fin, v2f (*hin)[SUB / 2][64], v2f (*hout)[SUB / 2][64]) {
     constexpr int NI = SG::IN, NO = SG::OUT, NG = G::IN;
     constexpr bool GIN = !FIRST && SG::USES_GIN;
     static_assert(LAST || NO <= W, "hand-over tile too narrow");
@@ -832,31 +835,34 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
     const int lo = h * SUB;
     const int hi = lo + SUB < size ? lo + SUB : size;
     const int shi = hi < full ? hi : full;  // end of the packed part inside this tile
+    auto put = [&](int c, int i, float x) {  // i = frame index inside the block
+        if constexpr (OL == 0) outw[((size_t)c * T + t0 + i) * V + lane] = x;
+        else outw[(c * SUB + (i - lo)) * FS + lane] = x;
+    };
     if (h == 0) SG::begin(g, size);
     if (lo < shi) {
         const G snap = g;  // tile-start registers, for the rollback below
         // (rolling this loop for heavy stages -- 1 pair per trip instead of 4 -- measured no faster on config 4: 52.9 vs 51.5 ms)
 #pragma unroll 4
         for (int i = lo; i < shi; i += 2) {  // two frames per iteration (lo, shi are multiples of 8)
-            const size_t t = t0 + i;
             v2f pi[NI > 0 ? NI : 1], gi[NG > 0 ? NG : 1], po[NO];
             if constexpr (FIRST) {
 #pragma unroll
-                for (int c = 0; c < NI; c++) pi[c] = v2f{fin[c][i - lo][lane], fin[c][i - lo + 1][lane]};
+                for (int c = 0; c < NI; c++) pi[c] = v2f{fin[(c * SUB + (i - lo)) * FS + lane], fin[(c * SUB + (i - lo + 1)) * FS + lane]};
             } else {
 #pragma unroll
                 for (int c = 0; c < NI; c++) pi[c] = hin[c][(i - lo) >> 1][lane];
             }
             if constexpr (GIN) {
 #pragma unroll
-                for (int c = 0; c < NG; c++) gi[c] = v2f{fin[c][i - lo][lane], fin[c][i - lo + 1][lane]};
+                for (int c = 0; c < NG; c++) gi[c] = v2f{fin[(c * SUB + (i - lo)) * FS + lane], fin[(c * SUB + (i - lo + 1)) * FS + lane]};
             }
             SG::template step2<PH_SIMD>(g, pi, FIRST ? pi : gi, po);
             if constexpr (LAST) {
 #pragma unroll
                 for (int c = 0; c < NO; c++) {
-                    outw[((size_t)c * T + t) * V + lane] = po[c].x;
-                    outw[((size_t)c * T + t + 1) * V + lane] = po[c].y;
+                    put(c, i, po[c].x);
+                    put(c, i + 1, po[c].y);
                 }
             } else {
 #pragma unroll
@@ -869,19 +875,19 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
                 float fi[NI > 0 ? NI : 1], gf[NG > 0 ? NG : 1], fo[NO];
                 if constexpr (FIRST) {
 #pragma unroll
-                    for (int c = 0; c < NI; c++) fi[c] = fin[c][i - lo][lane];
+                    for (int c = 0; c < NI; c++) fi[c] = fin[(c * SUB + (i - lo)) * FS + lane];
                 } else {
 #pragma unroll
                     for (int c = 0; c < NI; c++) fi[c] = reinterpret_cast<const float*>(&hin[c][(i - lo) >> 1][lane])[i & 1];
                 }
                 if constexpr (GIN) {
 #pragma unroll
-                    for (int c = 0; c < NG; c++) gf[c] = fin[c][i - lo][lane];
+                    for (int c = 0; c < NG; c++) gf[c] = fin[(c * SUB + (i - lo)) * FS + lane];
                 }
                 SG::template step<PH_SIMD>(g, fi, FIRST ? fi : gf, fo);
                 if constexpr (LAST) {
 #pragma unroll
-                    for (int c = 0; c < NO; c++) outw[((size_t)c * T + t0 + i) * V + lane] = fo[c];
+                    for (int c = 0; c < NO; c++) put(c, i, fo[c]);
                 } else {
 #pragma unroll
                     for (int c = 0; c < NO; c++) reinterpret_cast<float*>(&hout[c][(i - lo) >> 1][lane])[i & 1] = fo[c];
@@ -895,19 +901,19 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
         float fi[NI > 0 ? NI : 1], gf[NG > 0 ? NG : 1], fo[NO];
         if constexpr (FIRST) {
 #pragma unroll
-            for (int c = 0; c < NI; c++) fi[c] = fin[c][i - lo][lane];
+            for (int c = 0; c < NI; c++) fi[c] = fin[(c * SUB + (i - lo)) * FS + lane];
         } else {
 #pragma unroll
             for (int c = 0; c < NI; c++) fi[c] = reinterpret_cast<const float*>(&hin[c][(i - lo) >> 1][lane])[i & 1];
         }
         if constexpr (GIN) {
 #pragma unroll
-            for (int c = 0; c < NG; c++) gf[c] = fin[c][i - lo][lane];
+            for (int c = 0; c < NG; c++) gf[c] = fin[(c * SUB + (i - lo)) * FS + lane];
         }
         SG::template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(g, fi, FIRST ? fi : gf, fo);
         if constexpr (LAST) {
 #pragma unroll
-            for (int c = 0; c < NO; c++) outw[((size_t)c * T + t0 + i) * V + lane] = fo[c];
+            for (int c = 0; c < NO; c++) put(c, i, fo[c]);
         } else {
 #pragma unroll
             for (int c = 0; c < NO; c++) reinterpret_cast<float*>(&hout[c][(i - lo) >> 1][lane])[i & 1] = fo[c];
@@ -992,8 +998,8 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
             const int h = (int)(j % SPB);
             const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
             const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
-            const float (*fin)[SUB][64] = nullptr;
-            if constexpr (FEED) fin = feed[grp][j % D];
+            const float* fin = nullptr;
+            if constexpr (FEED) fin = &feed[grp][j % D][0][0][0];
             if (stage == 0) {
                 if constexpr (S == 1) pipe_stage<S0, G, MODE, SUB, W, true, true>(g, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr);
                 else pipe_stage<S0, G, MODE, SUB, W, true, false>(g, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
@@ -1018,6 +1024,182 @@ __global__ __launch_bounds__((16 * GPW * PipeGeom<G::IN, S>::WAVES)) void k_rend
                                                                                       const float* __restrict__ in, float* __restrict__ out,
                                                                                       size_t T, const void* aux, float* ring, uint32_t ring_cap) {
     render_pipe_body<G, MODE, S, K1, K2, GPW>(slots, stride, V, in, out, T, aux, ring, ring_cap);
+}
+
+// ---- the pipeline kernel for the PLANAR layout ([voice][channel][frame_stride], the reference's BufferArray rows) ----
+// Same stages, same hand-over tiles; what changes is how samples enter and leave the workgroup:
+//   * the LOADER wave reads each voice's row in float4 runs (16 lanes x 16 B = one 256-B run per voice row) and writes
+//     them TRANSPOSED into the feed tile (rows padded to 65 floats: the 4-B transposed writes hit distinct banks);
+//   * the last compute stage writes its samples into an LDS out tile instead of HBM;
+//   * a STORER wave, one round behind, transposes that tile back and stores float4 runs into the voices' rows.
+// The compute waves touch no global memory at all.  Needs 16-byte aligned rows (frame_stride % 4 == 0).
+constexpr int PFS = 65;  // floats per frame row of the transposed tiles
+template <class G>
+struct PlanarPlan {
+    static constexpr PipePlan P2 = pipe_plan<G>(2);  // the best two-stage cut, if the graph has one
+    static constexpr int N = Chain<G>::N;
+    template <int S, int K1> struct Tiles {
+        using S0 = Seg<G, 0, S == 1 ? N : K1>;
+        using S1 = Seg<G, S == 1 ? 0 : K1, N>;
+        static constexpr int W = S >= 2 ? S0::OUT : 0;
+        static constexpr bool LATE_GIN = S >= 2 && S1::USES_GIN;
+        static constexpr int D = G::IN > 0 ? (LATE_GIN ? S + 1 : 2) : 0;
+        static constexpr int UNITS = G::IN * D + 2 * W * (S - 1) + 2 * G::OUT;
+        // one unit = SUB frames x 65 floats x 4 voice groups = SUB * 1040 B; gfx950 gives a workgroup up to 160 KB of LDS
+        static constexpr int SUB = UNITS <= 4 ? 32 : UNITS <= 9 ? 16 : UNITS <= 18 ? 8 : 0;
+        static constexpr int WAVES = S + 1 + (G::IN > 0 ? 1 : 0);  // per voice group
+        static constexpr bool ok = SUB >= 8 && WAVES <= 4 && G::OUT > 0;
+    };
+    static constexpr bool two_ok() {
+        if constexpr (P2.S == 2) return Tiles<2, P2.K1>::ok; else return false;
+    }
+    static constexpr bool two = two_ok();
+    static constexpr int S = two ? 2 : (Tiles<1, N>::ok ? 1 : 0);
+    static constexpr int K1 = two ? P2.K1 : N;
+    using T = Tiles<(S >= 1 ? S : 1), K1>;
+};
+
+template <class G, int MODE, int S, int K1>
+FD_D void render_pipe_planar_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
+                                  float* __restrict__ out, size_t T, size_t fstride, const void* aux, float* ring, uint32_t ring_cap) {
+    using TL = typename PlanarPlan<G>::template Tiles<S, K1>;
+    constexpr int NI = G::IN, NO = G::OUT, GPW = 4;
+    constexpr bool FEED = NI > 0;
+    constexpr int SUB = TL::SUB, SPB = 64 / SUB, W = TL::W, D = FEED ? TL::D : 1;
+    constexpr int LPR = SUB / 4;        // lanes per voice row (one float4 each)
+    constexpr int VPP = 64 / LPR;       // voice rows per pass
+    constexpr int PASSES = 64 / VPP;    // = SUB / 4
+    static_assert(TL::ok, "tiles do not fit");
+    using S0 = typename TL::S0;
+    using S1 = typename TL::S1;
+    __shared__ float feed[FEED ? GPW : 1][D][FEED ? NI : 1][FEED ? SUB : 1][FEED ? PFS : 1];
+    __shared__ v2f hand[S > 1 ? GPW : 1][2][S > 1 ? W : 1][S > 1 ? SUB / 2 : 1][S > 1 ? 64 : 1];
+    __shared__ float otile[GPW][2][NO][SUB][PFS];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = w % GPW, role = w / GPW;
+    const size_t v0 = ((size_t)blockIdx.x * GPW + grp) * 64;
+    const size_t v = v0 + lane;
+    const bool live = v0 < stride;
+    const bool active = v < V;
+    const size_t ntiles = ((T + 63) / 64) * SPB;
+    const size_t rounds = ntiles + (size_t)S + (FEED ? 1 : 0);  // ... + the storer's round
+    const int lr = lane / LPR, fq = (lane % LPR) * 4;            // this lane's row inside a pass, its first frame in the tile
+    auto tile_t = [&](size_t j) { return (j / SPB) * 64 + (j % SPB) * SUB; };
+
+    if (FEED && role == 0) {  // ---- loader wave ----
+        float4 rg[FEED ? NI : 1][PASSES];
+        auto issue = [&](size_t j) {
+            const size_t t = tile_t(j) + fq;
+#pragma unroll
+            for (int c = 0; c < NI; c++)
+#pragma unroll
+                for (int p = 0; p < PASSES; p++) {
+                    const size_t gv = v0 + p * VPP + lr;
+                    float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (gv < V && t < T) {
+                        const float* src = in + (gv * NI + c) * fstride + t;
+                        if (t + 3 < T) {
+                            x = *reinterpret_cast<const float4*>(src);
+                        } else {
+                            x.x = src[0];
+                            if (t + 1 < T) x.y = src[1];
+                            if (t + 2 < T) x.z = src[2];
+                        }
+                    }
+                    rg[c][p] = x;
+                }
+        };
+        if (live) issue(0);
+        for (size_t it = 0; it < rounds; it++) {
+            if (live && it < ntiles) {
+#pragma unroll
+                for (int c = 0; c < NI; c++)
+#pragma unroll
+                    for (int p = 0; p < PASSES; p++) {
+                        float* dst = &feed[grp][it % D][c][fq][p * VPP + lr];
+                        dst[0] = rg[c][p].x;
+                        dst[PFS] = rg[c][p].y;
+                        dst[2 * PFS] = rg[c][p].z;
+                        dst[3 * PFS] = rg[c][p].w;
+                    }
+                if (it + 1 < ntiles) issue(it + 1);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    const int stage = role - (FEED ? 1 : 0);  // S = the storer
+    if (stage == S) {  // ---- storer wave: tile j leaves one round after the last compute stage wrote it ----
+        const size_t first = (size_t)S + (FEED ? 1 : 0);
+        for (size_t it = 0; it < rounds; it++) {
+            if (live && it >= first && it - first < ntiles) {
+                const size_t j = it - first;
+                const size_t t = tile_t(j) + fq;
+#pragma unroll
+                for (int c = 0; c < NO; c++)
+#pragma unroll
+                    for (int p = 0; p < PASSES; p++) {
+                        const size_t gv = v0 + p * VPP + lr;
+                        const float* src = &otile[grp][j & 1][c][fq][p * VPP + lr];
+                        const float4 x = make_float4(src[0], src[PFS], src[2 * PFS], src[3 * PFS]);
+                        if (gv < V && t < T) {
+                            float* dst = out + (gv * NO + c) * fstride + t;
+                            if (t + 3 < T) {
+                                *reinterpret_cast<float4*>(dst) = x;
+                            } else {
+                                dst[0] = x.x;
+                                if (t + 1 < T) dst[1] = x.y;
+                                if (t + 2 < T) dst[2] = x.z;
+                            }
+                        }
+                    }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    const size_t first = (size_t)stage + (FEED ? 1 : 0);
+    G g;
+    Ctx ctx{static_cast<const Aux*>(aux), ring + (live ? v : 0), ring_cap, stride, 0};
+    g.bind(ctx);
+    if (live) {
+        VLoad ld{slots + v, stride, 0};
+        VGate::W<VLoad> gate{&ld, true};
+        if (stage == 0) S0::visit(g, gate); else S1::visit(g, gate);
+    }
+    for (size_t it = 0; it < rounds; it++) {
+        if (live && active && it >= first && it - first < ntiles) {
+            const size_t j = it - first;
+            const size_t t0 = (j / SPB) * 64;
+            const int h = (int)(j % SPB);
+            const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+            const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
+            const float* fin = nullptr;
+            if constexpr (FEED) fin = &feed[grp][j % D][0][0][0];
+            float* ot = &otile[grp][j & 1][0][0][0];
+            if (stage == 0) {
+                if constexpr (S == 1) pipe_stage<S0, G, MODE, SUB, W, true, true, PFS, 1>(g, h, t0, size, full, T, V, lane, ot, fin, nullptr, nullptr);
+                else pipe_stage<S0, G, MODE, SUB, W, true, false, PFS, 1>(g, h, t0, size, full, T, V, lane, ot, fin, nullptr, hand[grp][j & 1]);
+            } else {
+                if constexpr (S == 2) pipe_stage<S1, G, MODE, SUB, W, false, true, PFS, 1>(g, h, t0, size, full, T, V, lane, ot, fin, hand[grp][j & 1], nullptr);
+            }
+        }
+        __syncthreads();
+    }
+    if (live && active) {
+        VStore<false> st{slots + v, stride, 0};
+        VGate::W<VStore<false>> gate{&st, true};
+        if (stage == 0) S0::visit(g, gate); else S1::visit(g, gate);
+    }
+}
+
+template <class G, int MODE, int S, int K1>
+__global__ __launch_bounds__((256 * PlanarPlan<G>::template Tiles<S, K1>::WAVES)) void k_render_pipe_planar(
+    float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ out, size_t T, size_t fstride,
+    const void* aux, float* ring, uint32_t ring_cap) {
+    render_pipe_planar_body<G, MODE, S, K1>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
 }
 
 // Launch policy for the voice-minor layout: voices per wave such that the grid has at least one wave per SIMD.

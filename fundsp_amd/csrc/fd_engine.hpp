@@ -123,10 +123,33 @@ bool launch_render_split(float* slots, size_t stride, size_t V, const float* in,
     return launch_render_pipe<G, MODE, 0>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
 }
 
+// planar layout through the pipeline kernel (loader / compute stages / storer); false = not applicable
+template <class G, int MODE>
+bool launch_render_pipe_planar(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
+                               const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
+    using PP = PlanarPlan<G>;
+    if constexpr (PP::S >= 1) {
+        constexpr int WAVES = PP::T::WAVES;
+        const size_t groups = (V + 63) / 64;
+        hipLaunchKernelGGL((k_render_pipe_planar<G, MODE, PP::S, PP::K1>), dim3((unsigned)((groups + 3) / 4)), dim3(256 * WAVES), 0, s,
+                           slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
+        return true;
+    } else {
+        return false;
+    }
+}
+
 template <class G>
 void launch_render(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
                    int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
     if (V == 0 || T == 0) return;
+    // planar rows that allow 16-byte runs go through the planar pipeline (same launch-size rule as below)
+    if (layout == LAYOUT_PLANAR && g_pipe_split && (T >= 256 || g_pipe_split > 1) && fstride % 4 == 0 && ((uintptr_t)in & 15) == 0 &&
+        ((uintptr_t)out & 15) == 0) {
+        const bool done = mode == MODE_PROCESS ? launch_render_pipe_planar<G, MODE_PROCESS>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s)
+                                               : launch_render_pipe_planar<G, MODE_TICK>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s);
+        if (done) return;
+    }
     // the pipeline needs a few tiles to overlap its stages: a launch of one or two 64-frame blocks (real-time use) is
     // faster through the single-wave kernel (config 3, T = 64: 17.5 -> ~10 us)
     if (layout == LAYOUT_VOICE_MINOR && g_pipe_split && (T >= 256 || g_pipe_split > 1)) {

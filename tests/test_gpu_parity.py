@@ -469,6 +469,64 @@ def test_pipe_split_tile_edges(gpu, T):
 FEED_T = [5, 16, 17, 40, 64, 64 * 2 + 37, 64 * 2 + 40, 64 * 3 + 63]
 
 
+@pytest.mark.parametrize("T", [5, 17, 64, 64 * 2 + 37, 64 * 5 + 63, 64 * 9])
+@pytest.mark.parametrize("kind", ["sine", "svf3", "noise", "fm_svf", "svf_shape_svf", "saw_moog_adsr_pan", "delay"])
+def test_planar_pipeline_is_bit_identical_to_single_wave(gpu, kind, T):
+    """The reference-native planar layout ([voice][channel][frame_stride]) through the planar pipeline kernel (loader
+    wave transposing rows into LDS, compute stages, storer wave transposing out) against the single-wave planar kernel:
+    same samples for ragged voice counts, ragged frame counts, two launches in a row, both modes."""
+    import torch
+
+    V = 64 * 4 + 9
+    if kind == "saw_moog_adsr_pan":
+        gpu.wavetable_build("saw")
+    ref = {}
+    for flag in (0, 4):                       # 4 forces the pipeline also for short launches
+        assert gpu.lib().fdsp_set_option(b"pipe_split", flag) == 0
+        for mode in MODES:
+            b = gpu.Bank(kind, V, ring_frames=64) if kind == "delay" else gpu.Bank(kind, V)
+            rs = np.random.default_rng(5)
+            for n in [n for n, k in b.slots() if k == 0]:
+                if n.endswith("cutoff"):
+                    b.set_param(n, (200.0 + 5000.0 * rs.random(V)).astype(np.float32))
+                elif n.endswith(":q"):
+                    b.set_param(n, (0.5 + 3.0 * rs.random(V)).astype(np.float32))
+                elif n.endswith(":time"):
+                    b.set_param(n, 0.0005)
+                elif n.endswith("value[0]") or n.endswith(":scalar"):
+                    b.set_param(n, (50.0 + 400.0 * rs.random(V)).astype(np.float32))
+            b.set_sample_rate(SR)
+            b.set_seed(np.arange(V, dtype=np.uint64))
+            ni = b.inputs()
+            rng = np.random.default_rng(77)
+            x = (rng.random((V, max(ni, 1), 2 * T), dtype=np.float32) * 2 - 1).astype(np.float32)
+            if kind == "sine":
+                x = x * 3000.0
+            elif kind == "svf3":
+                x[:, 1] = 300.0 + 4000.0 * np.abs(x[:, 1])
+                x[:, 2] = 0.5 + 2.0 * np.abs(x[:, 2])
+            elif kind == "saw_moog_adsr_pan":
+                x[:] = 1.0
+                x[:, :, T:] = 0.0
+            xi = x[:, :ni] if ni else None
+            got = np.concatenate([run_bank(b, None if xi is None else np.ascontiguousarray(xi[:, :, :T]), T, LAYOUT_PLANAR, mode),
+                                  run_bank(b, None if xi is None else np.ascontiguousarray(xi[:, :, T:]), T, LAYOUT_PLANAR, mode)], axis=-1)
+            if flag == 0:
+                ref[mode] = got
+            else:
+                assert_bit_equal(got, ref[mode], f"{kind} planar pipeline mode={mode} T={T}")
+    gpu.lib().fdsp_set_option(b"pipe_split", 1)
+    # rows that are not 16-byte aligned take the single-wave kernel: still the same samples
+    b = gpu.Bank("fixed_svf", V)
+    b.set_sample_rate(SR)
+    x = torch.from_numpy((np.random.default_rng(3).random((V, 1, 301), dtype=np.float32) - 0.5).astype(np.float32)).cuda()
+    out = b.process(300, x, layout=LAYOUT_PLANAR, frame_stride=301).cpu().numpy()[:, :, :300]
+    b2 = gpu.Bank("fixed_svf", V)
+    b2.set_sample_rate(SR)
+    want = run_bank(b2, x.cpu().numpy()[:, :, :300].copy(), 300, LAYOUT_PLANAR, MODE_PROCESS)
+    assert_bit_equal(out, want, "unaligned planar rows")
+
+
 @pytest.mark.parametrize("T", FEED_T)
 @pytest.mark.parametrize("kind", ["sine", "svf3", "svf4", "svf_shape", "svf_shape_svf", "saw_moog_adsr_pan"])
 def test_loader_wave_is_bit_identical_to_single_wave(gpu, kind, T):
