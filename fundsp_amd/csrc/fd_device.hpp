@@ -1267,6 +1267,7 @@ FD_D void describe_body(char* out, int cap, int* meta) {
     constexpr PipePlan P = pipe_plan<G>(0);  // pipeline kernel plan of run-time compiled graphs (0 stages = not used)
     meta[5] = P.S;
     meta[6] = P.S >= 1 ? 64 * PipeGeom<G::IN, (P.S >= 1 ? P.S : 1)>::WAVES : 0;
+    meta[7] = PlanarPlan<G>::S >= 1 ? 256 * PlanarPlan<G>::T::WAVES : 0;  // threads of the planar pipeline kernel (0 = none)
 }
 
 // pipeline kernel entry for run-time compiled graphs: empty when the graph has no plan
@@ -1276,6 +1277,16 @@ FD_D void jit_pipe_body(float* __restrict__ slots, size_t stride, size_t V, cons
     constexpr PipePlan P = pipe_plan<G>(0);
     if constexpr (P.S >= 1) render_pipe_body<G, MODE, P.S, P.K1, P.K2>(slots, stride, V, in, out, T, aux, ring, ring_cap);
 }
+template <class G, int MODE>
+FD_D void jit_pipe_planar_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
+                               float* __restrict__ out, size_t T, size_t fstride, const void* aux, float* ring, uint32_t ring_cap) {
+    using PP = PlanarPlan<G>;
+    if constexpr (PP::S >= 1) render_pipe_planar_body<G, MODE, PP::S, PP::K1>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
+}
+template <class G>
+struct JitPipePlanarThreads {
+    static constexpr int v = PlanarPlan<G>::S >= 1 ? 256 * PlanarPlan<G>::T::WAVES : 64;
+};
 template <class G>
 struct JitPipeThreads {
     static constexpr PipePlan P = pipe_plan<G>(0);

@@ -45,7 +45,8 @@ struct JitModule {
     hipFunction_t render[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [mode][layout]
     hipFunction_t events[2] = {nullptr, nullptr};                            // [mode]
     hipFunction_t pipe[2] = {nullptr, nullptr};                              // [mode], pipeline kernel
-    int pipe_stages = 0, pipe_threads = 0;
+    hipFunction_t pipe_planar[2] = {nullptr, nullptr};                       // [mode], planar-layout pipeline kernel
+    int pipe_stages = 0, pipe_threads = 0, pipe_planar_threads = 0;
     int wpb[2] = {4, 4};                                                     // per layout
     ~JitModule() {
         if (mod) hipModuleUnload(mod);
@@ -81,6 +82,14 @@ std::string jit_source(const std::string& type_expr, const std::string& prelude)
              "(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ out, "
              "size_t T, const void* aux, float* ring, uint32_t cap) {\n"
              "  fd::jit_pipe_body<JitG, " + m + ">(slots, stride, V, in, out, T, aux, ring, cap); }\n";
+    }
+    s += "constexpr int JIT_PIPE_PLANAR_THREADS = fd::JitPipePlanarThreads<JitG>::v;\n";
+    for (int mode = 0; mode < 2; mode++) {
+        std::string m = std::to_string(mode);
+        s += "extern \"C\" __global__ __launch_bounds__(JIT_PIPE_PLANAR_THREADS) void jit_pipe_planar_" + m +
+             "(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ out, "
+             "size_t T, size_t fstride, const void* aux, float* ring, uint32_t cap) {\n"
+             "  fd::jit_pipe_planar_body<JitG, " + m + ">(slots, stride, V, in, out, T, fstride, aux, ring, cap); }\n";
     }
     for (int mode = 0; mode < 2; mode++) {
         std::string m = std::to_string(mode);
@@ -158,6 +167,8 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
         ok = hipModuleGetFunction(&jm->events[m], jm->mod, fn.c_str()) == hipSuccess;
         fn = "jit_pipe_" + std::to_string(m);
         ok = ok && hipModuleGetFunction(&jm->pipe[m], jm->mod, fn.c_str()) == hipSuccess;
+        fn = "jit_pipe_planar_" + std::to_string(m);
+        ok = ok && hipModuleGetFunction(&jm->pipe_planar[m], jm->mod, fn.c_str()) == hipSuccess;
     }
     if (!ok) {
         *err = "compiled graph is missing an entry point";
@@ -192,6 +203,7 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     jm->wpb[LAYOUT_PLANAR] = meta[4];
     jm->pipe_stages = meta[5];
     jm->pipe_threads = meta[6];
+    jm->pipe_planar_threads = meta[7];
     out->slots.clear();
     std::istringstream lines(std::string(txt.data(), (size_t)meta[3]));
     std::string line;
@@ -213,6 +225,13 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
             void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &aux, &ring, &ring_cap};
             hipModuleLaunchKernel(jm->pipe[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_threads, 1, 1, 0, s,
                                   pargs, nullptr);
+            return;
+        }
+        if (layout == LAYOUT_PLANAR && g_pipe_split && jm->pipe_planar_threads > 0 && (T >= 256 || g_pipe_split > 1) && fstride % 4 == 0 &&
+            ((uintptr_t)in & 15) == 0 && ((uintptr_t)outp & 15) == 0) {  // loader / stages / storer (see launch_render)
+            void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &fstride, &aux, &ring, &ring_cap};
+            hipModuleLaunchKernel(jm->pipe_planar[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_planar_threads, 1, 1,
+                                  0, s, pargs, nullptr);
             return;
         }
         const int wpb = jm->wpb[layout];
