@@ -233,6 +233,8 @@ def main():
                 "traffic": traffic,
                 "kernel": {3: (f"fd::k_render_pipe<fm_svf, {args.mode}, 2 compute stages cut after the modulator> (voice_minor)"
                                if args.layout == "voice_minor" and args.mode == "process" and args.pipe_split in (1, 2) and T % 8 == 0
+                               else f"fd::k_render_pipe_planar<fm_svf, {args.mode}, 2 compute stages + storer wave> (planar)"
+                               if args.layout == "planar" and args.pipe_split == 1 and T >= 256 and T % 4 == 0
                                else f"fd::k_render<fm_svf, {args.mode}, {args.layout}> / pipe_split={args.pipe_split}"),
                            4: f"fd::k_render_pipe<saw_moog_adsr_pan, {args.mode}, loader wave + 3 compute stages (saw | moog | *adsr >> pan)> ({args.layout})",
                            5: "fd::k_fdn_render"}[args.config],
