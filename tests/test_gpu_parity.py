@@ -365,7 +365,7 @@ def test_process_host_paths(gpu):
     (pinned small transfers, pageable large ones, strided planar rows) and leaves the caller's row padding alone,
     as AudioNode::process leaves samples past `size` (audionode.rs:85)."""
     rng = np.random.default_rng(11)
-    for V, T in ((300, 128), (70000, 96)):          # 70000*96 floats > the pinned-staging limit
+    for V, T in ((300, 128), (100, 512), (70000, 96)):   # (100, 512): zero-copy + the planar pipeline kernel; 70000*96 floats: staged
         p = W.fm_svf_params(V, SR)
         want = run_bank(W.make_fm_svf_bank(V, SR, params=p), None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
         got = W.make_fm_svf_bank(V, SR, params=p).process_host(T, layout=LAYOUT_VOICE_MINOR)
