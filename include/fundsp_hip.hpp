@@ -421,6 +421,14 @@ class Bank {
         b.reset();  // `.phase()` / `.seed()` store only, the constructor's reset applies them (combinator.rs:263-267)
         return b;
     }
+    // reverb_stereo(room_size, time, damping) (prelude.rs:1732-1762): `instances` 32-line FDN reverbs, stereo in / out,
+    // rendered by the dedicated lane-per-frame kernel
+    static Bank reverb_stereo(size_t instances, double room_size, double time, double damping) {
+        Bank b;
+        check(fdsp_reverb_stereo_create(instances, room_size, time, damping, &b.h_));
+        b.kind_ = "reverb_stereo";
+        return b;
+    }
     Bank(Bank&& o) noexcept { *this = std::move(o); }
     Bank& operator=(Bank&& o) noexcept {
         if (this != &o) {
@@ -456,6 +464,11 @@ class Bank {
     void set(const std::string& slot, float value) { check(fdsp_bank_set_param_all(h_, slot.c_str(), value)); }
     void set(const std::string& slot, const std::vector<float>& per_voice, size_t first = 0) {
         check(fdsp_bank_set_param(h_, slot.c_str(), per_voice.data(), first, per_voice.size()));
+    }
+    // state a Rust caller supplies because it comes from a crate outside the reference tree (Pluck's excitation, Hold's
+    // Rnd draws): data[count][frames] into ring node `ring_index` for voices first .. first + count
+    void set_ring(int ring_index, const float* data, size_t frames, size_t first, size_t count) {
+        check(fdsp_bank_set_ring(h_, ring_index, data, frames, first, count));
     }
     // AudioNode::tick for every voice: input [V][inputs], output [V][outputs]
     void tick(const float* input, float* output) {

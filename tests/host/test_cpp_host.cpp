@@ -168,6 +168,23 @@ static void gpu_checks() {
         for (float x : w) peak = std::max(peak, std::fabs(x));
         EXPECT(peak > 0.05f && peak < 2.0f);
     }
+    // reverb_stereo(10, 2, 0.5) through its dedicated kernel: an impulse against the oracle's Feedback graph restatement
+    {
+        Bank b = Bank::reverb_stereo(2, 10.0, 2.0, 0.5);
+        b.set_sample_rate(SR);
+        onode* n = o_reverb_stereo(10.0, 2.0, 0.5);
+        o_set_sample_rate(n, SR);
+        EXPECT(b.inputs() == 2 && b.outputs() == 2);
+        for (int blk = 0; blk < 40; blk++) {   // 2560 frames: past the shortest delay lines
+            std::vector<float> x(2 * 2 * 64, 0.0f), got(2 * 2 * 64), want(2 * 64);
+            if (blk == 0) x[0] = x[64] = x[128] = x[192] = 1.0f;
+            b.process(64, x.data(), got.data());
+            o_process(n, 64, x.data(), want.data());
+            if (!bit_equal(got.data(), want.data(), 128, "reverb_stereo instance 0")) break;
+            if (!bit_equal(got.data() + 128, want.data(), 128, "reverb_stereo instance 1")) break;
+        }
+        o_free(n);
+    }
     // a filter with an input: noise through the C ABI, the same samples through the oracle
     {
         Bank b("fixed_svf", 1);
