@@ -475,6 +475,49 @@ FD_D void render_events_body(float* __restrict__ slots, size_t stride, size_t V,
                     fout_d = (float)(sd / e_fout);
                 }
             }
+            // Steady state -- every voice of the wave inside its event for the whole block, no fade running: the block is a
+            // plain process(size) of the unit, so it takes the packed two-frame path of render_body (same arithmetic).
+            const bool steady = act && start_index == 0 && end_index == size && !fin_on && !fout_on;
+            if (__builtin_amdgcn_ballot_w64(steady) == __builtin_amdgcn_ballot_w64(true)) {
+                g.begin_block(size);
+                const G snap = g;
+                for (int i = 0; i < full; i += 2) {
+                    const size_t t = t0 + i;
+                    v2f pi[NI > 0 ? NI : 1], po[NO];
+#pragma unroll
+                    for (int c = 0; c < NI; c++) pi[c] = v2f{inv[((size_t)c * T + t) * V], inv[((size_t)c * T + t + 1) * V]};
+                    g.template step2<PH_SIMD>(pi, po);
+#pragma unroll
+                    for (int c = 0; c < NO; c++) {
+                        outv[((size_t)c * T + t) * V] = po[c].x;
+                        outv[((size_t)c * T + t + 1) * V] = po[c].y;
+                    }
+                }
+                if (__builtin_expect(g.tripped(), 0)) {  // a packed-path shortcut left its exact domain: redo the block
+                    g = snap;
+                    for (int i = 0; i < full; i++) {
+                        const size_t t = t0 + i;
+                        float fi[NI > 0 ? NI : 1], fo[NO];
+#pragma unroll
+                        for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
+                        g.template step<PH_SIMD>(fi, fo);
+#pragma unroll
+                        for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+                    }
+                }
+                g.end_simd();
+                for (int i = full; i < size; i++) {
+                    const size_t t = t0 + i;
+                    float fi[NI > 0 ? NI : 1], fo[NO];
+#pragma unroll
+                    for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
+                    g.template step<PH_REM>(fi, fo);
+#pragma unroll
+                    for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+                }
+                time = end_time;
+                continue;
+            }
             if (act) {
                 g.begin_block(n);
                 if (full == 0) g.end_simd();

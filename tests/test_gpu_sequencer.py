@@ -55,6 +55,40 @@ def test_fm_voices_with_events(gpu, mode):
     assert np.allclose(summed, mix, atol=1e-4)             # tree order vs the sequencer's serial order
 
 
+def test_sustained_voices_take_the_packed_path(gpu):
+    """Blocks in which every voice of a wave is inside its event and no fade is running render through the packed
+    two-frame path (a plain process(size) of the unit); waves enter and leave that state at different times here --
+    fades at the start, staggered ends, a ragged last block -- and every sample must still match the Sequencer oracle."""
+    import torch
+
+    V, T = 64 * 2 + 20, 64 * 12 + 29
+    rng = np.random.default_rng(93)
+    p = W.fm_svf_params(V, SR)
+    start = np.zeros(V)
+    start[64:128] = 100.3                                   # second wave starts later, off the block grid
+    dur = np.full(V, float(T + 50))
+    dur[128:] = rng.integers(300, 700, V - 128)             # third (partial) wave: staggered ends
+    fin = np.where(np.arange(V) % 3 == 0, 150.0, 0.0)       # some voices fade in over 2.3 blocks
+    fout = np.zeros(V)
+    fout[128:] = 90.0
+    fade = (np.arange(V) % 2).astype(np.int32)
+    start, end, fin, fout = start / SR, (start + dur) / SR, fin / SR, fout / SR
+    b = W.make_fm_svf_bank(V, SR, params=p)
+    b.set_events(start, end, fin, fout, fade)
+    got = b.process_events(T, mode=MODE_PROCESS)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy().transpose(2, 0, 1)
+    seq = O.Sequencer(0, 1, SR)
+    for v in range(V):
+        f, m = float(p["f"][v]), float(p["m"][v])
+        n = O.sine_hz(f) * f * m + f >> O.sine() >> O.lowpass_hz(float(p["fc"][v]), float(p["q"][v]))
+        n.set_seed(int(p["seed"][v]))
+        seq.push(start[v], end[v], int(fade[v]), fin[v], fout[v], n)
+    _, per = seq.render(T, process=True)
+    for v in range(V):
+        assert_bit_equal(got[v], per[v], f"sustained voice {v}")
+
+
 def test_gated_voices_with_inputs_and_two_launches(gpu, tables):
     """A kind with an input (saw >> moog * adsr >> pan, gate in) scheduled per voice, rendered in two launches of whole
     sequencer blocks: the clock and every voice's state carry over."""
