@@ -222,6 +222,7 @@ struct fdsp_bank {
     hipStream_t stream;
     hipEvent_t e0, e1;
     bool timed;
+    bool ext_pending = false;  // the last render ran on a caller's stream: bank-stream work must wait for its e1
     double sr;
     std::unordered_map<std::string, int> index;
     // voice scheduler (fdsp_bank_set_events / fdsp_bank_process_events): device [4][stride] f64 + [stride] int, clock
@@ -235,6 +236,24 @@ struct fdsp_bank {
 };
 
 namespace {
+
+// A render on a caller stream is ordered after whatever the bank's own stream still has pending (parameter uploads).
+// While the caller's stream is being CAPTURED into a HIP graph a host-side synchronize would invalidate the capture; the
+// bank's stream is idle by then (every setter synchronizes before it returns), so the wait is simply skipped.
+hipError_t order_after_bank_stream(const fdsp_bank* b, hipStream_t s) {
+    if (s == b->stream) return hipSuccess;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return hipSuccess;
+    return hipStreamSynchronize(b->stream);
+}
+
+// ... and the other way round: lifecycle / parameter work on the bank's stream waits for the last render that ran on a
+// caller's stream (its completion event e1), so that a reset or a parameter upload cannot overtake it.
+hipError_t await_last_render(fdsp_bank* b) {
+    if (!b->ext_pending) return hipSuccess;
+    b->ext_pending = false;
+    return hipStreamWaitEvent(b->stream, b->e1, 0);
+}
 
 int find_slot(const fdsp_bank* b, const char* name) {
     if (!name) return -1;
@@ -554,6 +573,7 @@ int fdsp_bank_set_sample_rate(fdsp_bank* b, double sr) {
         return fdn_configure(b, sr);
     }
     b->sr = sr;
+    HIPCHK(await_last_render(b));
     b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
@@ -562,10 +582,12 @@ int fdsp_bank_set_sample_rate(fdsp_bank* b, double sr) {
 int fdsp_bank_reset(fdsp_bank* b) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
     if (b->fdn) {
+        HIPCHK(await_last_render(b));
         fd::fdn_launch_reset(b->fdn->c, b->fdn->st, b->V, b->stream);
         HIPCHK(hipGetLastError());
         return FDSP_OK;
     }
+    HIPCHK(await_last_render(b));
     b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 2, b->sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
@@ -585,6 +607,7 @@ int fdsp_bank_set_seed(fdsp_bank* b, const uint64_t* h_seeds, size_t first, size
             return fail(FDSP_EDEVICE, hipGetErrorString(e));
         }
     }
+    HIPCHK(await_last_render(b));
     b->ops->lifecycle(b->slots, b->stride, first, count, 3, b->sr, d, device_aux(), b->ring, b->ring_cap, b->stream);
     hipError_t e = hipStreamSynchronize(b->stream);
     if (d) hipFree(d);
@@ -601,6 +624,7 @@ int fdsp_bank_slot_kind(const fdsp_bank* b, int slot) {
 }
 
 static int set_words(fdsp_bank* b, int slot, const void* h_words, size_t first, size_t count) {
+    HIPCHK(await_last_render(b));
     HIPCHK(hipMemcpyAsync(b->slots + (size_t)slot * b->stride + first, h_words, count * sizeof(float),
                           hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));  // h_words is borrowed for the call only
@@ -616,6 +640,7 @@ int fdsp_bank_set_param(fdsp_bank* b, const char* name, const float* h_values, s
     if (count == 0) return FDSP_OK;
     if (int rc = set_words(b, s, h_values, first, count)) return rc;
     // re-derive coefficients like the reference setters do (idempotent for untouched voices)
+    HIPCHK(await_last_render(b));
     b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
@@ -643,6 +668,7 @@ int fdsp_bank_set_param_u64(fdsp_bank* b, const char* name, const uint64_t* h_va
     }
     if (int rc = set_words(b, lo, wl.data(), first, count)) return rc;
     if (int rc = set_words(b, hi, wh.data(), first, count)) return rc;
+    HIPCHK(await_last_render(b));
     b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
@@ -654,6 +680,7 @@ int fdsp_bank_get_slot(fdsp_bank* b, const char* name, float* h_values, size_t f
     int s = find_slot(b, name);
     if (s < 0) return fail(FDSP_EINVAL, std::string("unknown slot: ") + (name ? name : "(null)"));
     if (int rc = check_range(b, first, count)) return rc;
+    HIPCHK(await_last_render(b));
     HIPCHK(hipStreamSynchronize(b->stream));
     HIPCHK(hipMemcpy(h_values, b->slots + (size_t)s * b->stride + first, count * sizeof(float), hipMemcpyDeviceToHost));
     return FDSP_OK;
@@ -662,6 +689,7 @@ int fdsp_bank_get_slot(fdsp_bank* b, const char* name, float* h_values, size_t f
 int fdsp_bank_get_state(fdsp_bank* b, float* h_slots) {
     if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b || !h_slots) return fail(FDSP_EINVAL, "bank or buffer NULL");
+    HIPCHK(await_last_render(b));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (b->nslots == 0) return FDSP_OK;
     HIPCHK(hipMemcpy2D(h_slots, b->V * sizeof(float), b->slots, b->stride * sizeof(float), b->V * sizeof(float),
@@ -672,6 +700,7 @@ int fdsp_bank_get_state(fdsp_bank* b, float* h_slots) {
 int fdsp_bank_set_state(fdsp_bank* b, const float* h_slots) {
     if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b || !h_slots) return fail(FDSP_EINVAL, "bank or buffer NULL");
+    HIPCHK(await_last_render(b));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (b->nslots == 0) return FDSP_OK;
     HIPCHK(hipMemcpy2D(b->slots, b->stride * sizeof(float), h_slots, b->V * sizeof(float), b->V * sizeof(float),
@@ -689,15 +718,21 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
     if (mode != FDSP_MODE_PROCESS && mode != FDSP_MODE_TICK) return fail(FDSP_EINVAL, "bad mode");
     if (layout == FDSP_LAYOUT_PLANAR && frame_stride < frames) return fail(FDSP_EINVAL, "frame_stride < frames");
     hipStream_t s = stream ? (hipStream_t)stream : b->stream;
-    if (s != b->stream) HIPCHK(hipStreamSynchronize(b->stream));  // order after pending parameter updates
-    HIPCHK(hipEventRecord(b->e0, s));
+    HIPCHK(order_after_bank_stream(b, s));  // order after pending parameter updates
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s != b->stream) hipStreamIsCapturing(s, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;  // a captured launch leaves the timing events alone
+    if (!capturing) HIPCHK(hipEventRecord(b->e0, s));
     if (b->fdn)  // Feedback::process is the per-sample tick (feedback.rs:136-146): both modes are the same arithmetic
         fd::fdn_launch_render(b->fdn->c, b->fdn->st, b->V, d_in, d_out, frames, frame_stride, layout, s);
     else
         b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, device_aux(), b->ring, b->ring_cap, s);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(b->e1, s));
-    b->timed = true;
+    if (!capturing) {
+        HIPCHK(hipEventRecord(b->e1, s));
+        b->timed = true;
+        b->ext_pending = s != b->stream;
+    }
     return FDSP_OK;
 }
 
@@ -713,6 +748,7 @@ int fdsp_bank_set_ring(fdsp_bank* b, int ring_index, const float* data, size_t f
     std::vector<float> t(frames * count);
     for (size_t v = 0; v < count; v++)
         for (size_t i = 0; i < frames; i++) t[i * count + v] = data[v * frames + i];
+    HIPCHK(await_last_render(b));
     float* dst = b->ring + (size_t)ring_index * b->ring_cap * b->stride + first;
     HIPCHK(hipMemcpy2DAsync(dst, b->stride * sizeof(float), t.data(), count * sizeof(float), count * sizeof(float), frames,
                             hipMemcpyHostToDevice, b->stream));
@@ -732,6 +768,7 @@ int fdsp_bank_set_events(fdsp_bank* b, const double* events, const int* fade, si
             return fail(FDSP_EINVAL, "event fade times must be >= 0 and may not exceed the event's duration");
         if (fade && fade[i] != FDSP_FADE_POWER && fade[i] != FDSP_FADE_SMOOTH) return fail(FDSP_EINVAL, "bad fade curve");
     }
+    HIPCHK(await_last_render(b));
     if (!b->ev) {
         HIPCHK(hipMalloc((void**)&b->ev, 4 * b->stride * sizeof(double)));
         HIPCHK(hipMalloc((void**)&b->ev_fade, b->stride * sizeof(int)));
@@ -772,13 +809,19 @@ int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, flo
     if (fdsp_bank_inputs(b) > 0 && !d_in) return fail(FDSP_EINVAL, "d_in is NULL but the graph has inputs");
     if (mode != FDSP_MODE_PROCESS && mode != FDSP_MODE_TICK) return fail(FDSP_EINVAL, "bad mode");
     hipStream_t s = stream ? (hipStream_t)stream : b->stream;
-    if (s != b->stream) HIPCHK(hipStreamSynchronize(b->stream));
-    HIPCHK(hipEventRecord(b->e0, s));
+    HIPCHK(order_after_bank_stream(b, s));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s != b->stream) hipStreamIsCapturing(s, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!capturing) HIPCHK(hipEventRecord(b->e0, s));
     b->ops->render_events(b->slots, b->stride, b->V, d_in, d_out, frames, b->ev, b->ev_fade, b->seq_time, b->sr, mode,
                           device_aux(), b->ring, b->ring_cap, s);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(b->e1, s));
-    b->timed = true;
+    if (!capturing) {
+        HIPCHK(hipEventRecord(b->e1, s));
+        b->timed = true;
+        b->ext_pending = s != b->stream;
+    }
     // advance the sequencer clock exactly as the reference does: one f64 addition per block / per sample
     const double sd = 1.0 / b->sr;
     if (mode == FDSP_MODE_PROCESS)
