@@ -40,6 +40,13 @@ def test_config3_full_size(gpu):
     small = W.make_fm_svf_bank(200, SR, voice0=30000)
     s = small.process(T)
     assert torch.equal(out[0][:, 30000:30200], s[0])
+    del s, small
+    # the reference-native planar layout at full size (planar pipeline kernel): the same samples, transposed
+    b3 = W.make_fm_svf_bank(V, SR, params=p)
+    planar = b3.process(T, layout=LAYOUT_PLANAR, frame_stride=T)   # [V][1][T]
+    torch.cuda.synchronize()
+    for v0 in range(0, V, 8192):                                  # compare in slabs: no 12.6 GB transpose temporary
+        assert torch.equal(planar[v0:v0 + 8192, 0, :], out[0][:, v0:v0 + 8192].t())
 
 
 def test_config4_full_size(gpu, tables):
