@@ -282,6 +282,18 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
                                                            float* __restrict__ out, size_t T, size_t fstride, int layout) {
     __shared__ float hist_all[4][32 * HS];  // per line: delay outputs d[n-2], d[n-1] | d[0..63]
     __shared__ float fbr_all[4][32 * HS];   // per line: fb[-1] | fb[0..63]
+    // per-line constants in LDS (same for the four instances of the workgroup): as kernel-argument scalars the 128 of them
+    // do not fit the SGPR file next to the 32 ring indices and get parked in VGPR lanes (v_writelane / v_readlane + hazard
+    // nops: a fifth of the loop's instructions); an LDS broadcast read per use is cheaper
+    __shared__ int sc_len[32], sc_off[32];
+    __shared__ float sc_wl[32], sc_wr[32];
+    if (threadIdx.x < 32) {
+        sc_len[threadIdx.x] = c.len[threadIdx.x];
+        sc_off[threadIdx.x] = (int)c.off[threadIdx.x];
+        sc_wl[threadIdx.x] = c.wl[threadIdx.x];
+        sc_wr[threadIdx.x] = c.wr[threadIdx.x];
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* hist = hist_all[wib];
     float* fbr = fbr_all[wib];
@@ -303,12 +315,12 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
         const int sizen = (int)((T - t0n) < 64 ? (T - t0n) : 64);
 #pragma unroll
         for (int k = 0; k < 32; k++) {
-            const int len = c.len[k];
+            const int len = sc_len[k];
             int i0 = idx[k] + adv;
             i0 = i0 >= len ? i0 - len : i0;
             int pos = i0 + 1 + lane;  // Delay::tick reads the slot AFTER the write index (delay.rs:116-124); len > 128
             pos = pos >= len ? pos - len : pos;
-            dn[k] = lane < sizen ? rings[(size_t)c.off[k] + (size_t)pos] : 0.0f;
+            dn[k] = lane < sizen ? rings[(size_t)sc_off[k] + (size_t)pos] : 0.0f;
         }
 #pragma unroll
         for (int ch = 0; ch < 2; ch++)
@@ -354,15 +366,15 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
 #pragma unroll
             for (int k = 0; k < 32; k++) {  // MultiSplit<U2,U16>: line k takes input channel k % 2 (audionode.rs:600)
                 const float x = ((k & 1) ? xi1 : xi0) + fbr[k * HS + lane];
-                const int len = c.len[k];
+                const int len = sc_len[k];
                 int pos = idx[k] + lane;  // Delay::tick: the new sample takes the slot at the write index
                 pos = pos >= len ? pos - len : pos;
-                rings[(size_t)c.off[k] + (size_t)pos] = x;
+                rings[(size_t)sc_off[k] + (size_t)pos] = x;
             }
             float l = 0.0f, rr = 0.0f;  // Reduce::tick left fold (audionode.rs:2427-2439) of the 32 Panner outputs
 #pragma unroll
             for (int k = 0; k < 32; k++) {
-                const float pl = c.wl[k] * o[k], pr = c.wr[k] * o[k];
+                const float pl = sc_wl[k] * o[k], pr = sc_wr[k] * o[k];
                 l = k == 0 ? pl : l + pl;
                 rr = k == 0 ? pr : rr + pr;
             }
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
         }
 #pragma unroll
         for (int k = 0; k < 32; k++) {
-            const int len = c.len[k];
+            const int len = sc_len[k];
             idx[k] += size;
             idx[k] = idx[k] >= len ? idx[k] - len : idx[k];
         }
