@@ -64,6 +64,7 @@ SYMBOLS = {
     "fdsp_mix_stereo": (_i, [_P, _P, _P, _sz, _sz, _P]),
     "fdsp_sum_voices": (_i, [_P, _P, _sz, _sz, _sz, _P]),
     "fdsp_wavetable_build": (_i, [_i]),
+    "fdsp_wave_upload": (_i, [_i, _i, _sz, _fp]),
     "fdsp_wavetable_upload": (_i, [_i, _i, _fp, C.POINTER(C.c_int), _fp]),
     "fdsp_wavetable_get": (_i, [_i, C.POINTER(C.c_int), _fp, C.POINTER(C.c_int), _fp, _sz]),
     "fdsp_svf_coefs": (_i, [_i, _f, _f, _f, _f, _fp]),

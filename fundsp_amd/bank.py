@@ -61,7 +61,10 @@ class Bank:
                 wavetable_build(kind)
         b = cls(name, voices, ring_frames=ring_frames)
         for slot, value, is_u64 in graph.slot_values():
-            if is_u64:
+            if is_u64 == 2:   # a u32 slot: one word per voice, uploaded as raw bits
+                v = np.asarray(value, dtype=np.uint32)
+                b.set_param(slot, (np.full(voices, v, dtype=np.uint32) if v.ndim == 0 else v).view(np.float32))
+            elif is_u64:
                 v = np.asarray(value, dtype=np.uint64)
                 b.set_param_u64(slot, np.full(voices, v, dtype=np.uint64) if v.ndim == 0 else v)
             else:
@@ -272,6 +275,12 @@ def biquad_coefs(kind, sample_rate, f, q=1.0, gain=1.0):
 
 
 WT_SETS = dict(saw=0, square=1, triangle=2, user=3, organ=4, soft_saw=5, hammond=6, user2=7)
+
+
+def wave_upload(slot, data):
+    """Install a shared sample buffer [channels][length] f32 (the Arc<Wave> of playwave(), wave.rs:739) in sample slot 0..7."""
+    d = np.ascontiguousarray(np.atleast_2d(data), dtype=np.float32)
+    check(lib().fdsp_wave_upload(int(slot), d.shape[0], d.shape[1], _fptr(d)))
 
 
 def wavetable_build(kind):

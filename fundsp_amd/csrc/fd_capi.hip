@@ -116,6 +116,25 @@ int upload_table_set(int set, int n, const float* pitches, const int* lengths, c
     return FDSP_OK;
 }
 
+int upload_wave(int slot, int channels, size_t length, const float* data) {
+    if (slot < 0 || slot >= fd::WAVE_SLOTS) return fail(FDSP_EINVAL, "wave slot out of range");
+    if (channels < 1 || length == 0 || length > 0xFFFFFFF0ull || !data) return fail(FDSP_EINVAL, "bad wave shape or NULL data");
+    if (!device_aux()) return fail(FDSP_EDEVICE, "no device memory for waves");
+    std::lock_guard<std::mutex> lock(g_aux_mutex);
+    float* d = nullptr;
+    const size_t n = (size_t)channels * length;
+    HIPCHK(hipMalloc((void**)&d, n * sizeof(float)));
+    HIPCHK(hipMemcpy(d, data, n * sizeof(float), hipMemcpyHostToDevice));
+    fd::WaveBuf& w = g_host_aux.wave[slot];
+    HIPCHK(hipDeviceSynchronize());  // no render may still read the buffer this replaces
+    if (w.data) hipFree(const_cast<float*>(w.data));
+    w.data = d;
+    w.channels = (uint32_t)channels;
+    w.length = (uint32_t)length;
+    HIPCHK(hipMemcpy(g_dev_aux, &g_host_aux, sizeof(fd::Aux), hipMemcpyHostToDevice));
+    return FDSP_OK;
+}
+
 // In-place radix-2 inverse FFT (unnormalised), f32 like the reference's microfft path (fft.rs:51-100).
 void ifft_inplace(std::vector<float>& re, std::vector<float>& im) {
     const size_t n = re.size();
@@ -946,6 +965,7 @@ int fdsp_wavetable_upload(int set, int n_tables, const float* h_pitches, const i
 }
 
 int fdsp_wavetable_build(int set) { return build_default_table_set(set); }
+int fdsp_wave_upload(int slot, int channels, size_t length, const float* h_data) { return upload_wave(slot, channels, length, h_data); }
 
 int fdsp_wavetable_get(int set, int* n_tables, float* h_pitches, int* h_lengths, float* h_data, size_t capacity) {
     if (set < 0 || set >= fd::WT_SETS || !n_tables) return fail(FDSP_EINVAL, "bad set");

@@ -759,8 +759,15 @@ struct WtSet {
     int len[WT_MAX_TABLES];
     const float* data;
 };
+// shared sample buffers (the reference's Arc<Wave>: wave.rs), [channel][length] f32 in HBM
+constexpr int WAVE_SLOTS = 8;
+struct WaveBuf {
+    const float* data;
+    uint32_t channels, length;
+};
 struct Aux {
     WtSet wt[WT_SETS];
+    WaveBuf wave[WAVE_SLOTS];
 };
 
 FD_HD float optimal4x44(float a0, float a1, float a2, float a3, float x) {  // wavetable.rs:24-38
@@ -3085,6 +3092,46 @@ struct Map {
     static constexpr uint64_t ID = 5;
     FD_STATELESS_LEAF
     template <int PH> FD_HD void step(const float* in, float* out) { FN::f(in, out); }
+    FD_STEP2_VIA_STEP
+};
+
+// WavePlayer  wave.rs:739-797 (ID 65): plays channel `channel` of a shared Wave from start_point to end_point, jumping to
+// loop_point when it reaches the end (0xFFFFFFFF = no loop: silence afterwards).  The Wave lives in one of the
+// process-wide sample slots (fdsp_wave_upload); positions are per voice, so a bank is a sampler with independent heads
+// (resample(playwave(..)) gives each voice its own playback speed).  No process override.
+template <int SLOT>
+struct WavePlayer {
+    static constexpr int IN = 0, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 65;
+    uint32_t channel, index, start_point, end_point, loop_point;
+    const WaveBuf* wb;
+    template <class V> FD_HD void visit(V& v) {
+        v.u32(channel, PARAM, "channel");
+        v.u32(start_point, PARAM, "start_point");
+        v.u32(end_point, PARAM, "end_point");
+        v.u32(loop_point, PARAM, "loop_point");
+        v.u32(index, STATE, "index");
+    }
+    FD_HD void bind(Ctx& a) { wb = &a.aux->wave[SLOT]; }
+    FD_HD void init() { channel = 0; start_point = 0; end_point = 0; loop_point = 0xFFFFFFFFu; index = 0; }
+    // WavePlayer::new starts at start_point (:761); parameters arrive after construction here, so a head that has not
+    // moved yet follows its start point
+    FD_HD void update(double) { if (index < start_point || index > end_point) index = start_point; }
+    FD_HD void reset() { index = start_point; }
+    FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float*, float* out) {  // tick :779-792
+        float value = 0.0f;
+        const uint32_t end = end_point < wb->length ? end_point : wb->length;  // new() asserts end_point <= length
+        if (index < end && channel < wb->channels) {
+            value = wb->data[(size_t)channel * wb->length + index];
+            index += 1;
+            if (index == end_point && loop_point != 0xFFFFFFFFu) index = loop_point;
+        }
+        out[0] = value;
+    }
     FD_STEP2_VIA_STEP
 };
 

@@ -222,6 +222,12 @@ def hammond(): return _leaf("WaveSynth<6>", 1, 1)
 def organ_hz(f): return constant(f) >> organ()
 def soft_saw_hz(f): return constant(f) >> soft_saw()
 def hammond_hz(f): return constant(f) >> hammond()
+def playwave_at(slot, channel, start_point, end_point, loop_point=None):   # prelude32.rs:2234; the Wave: wave_upload(slot, ..)
+    # the fourth field 2 marks u32 slots: Bank.from_graph uploads their words bit for bit
+    return Graph(f"WavePlayer<{slot}>", 0, 1, [((), "channel", channel, 2), ((), "start_point", start_point, 2),
+                                               ((), "end_point", end_point, 2),
+                                               ((), "loop_point", 0xFFFFFFFF if loop_point is None else loop_point, 2)])
+def playwave(slot, channel, length, loop_point=None): return playwave_at(slot, channel, 0, length, loop_point)   # prelude32.rs:2225
 def pulse(): return _leaf("PulseWave", 2, 1)                       # input 0 frequency, input 1 pulse width (wavetable.rs:437)
 def ramp(): return _leaf("PhaseOsc<OSC_RAMP>", 1, 1)
 def poly_saw(): return _leaf("PhaseOsc<OSC_POLYSAW>", 1, 1)

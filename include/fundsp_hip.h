@@ -226,6 +226,9 @@ int fdsp_sum_voices(const float* d_in, float* d_out, size_t channels, size_t fra
  * (e.g. tables produced by FunDSP itself).  Must be called before rendering a kind that uses the set. */
 int fdsp_wavetable_build(int set);
 int fdsp_wavetable_upload(int set, int n_tables, const float* h_pitches, const int* h_lengths, const float* h_data);
+/* Shared sample buffers = the reference's Arc<Wave> handed to playwave() / playwave_at() (src/wave.rs:739-797,
+ * prelude32.rs:2225-2248): `slot` 0..7, data [channels][length] f32.  The WavePlayer<slot> node of a graph reads it. */
+int fdsp_wave_upload(int slot, int channels, size_t length, const float* h_data);
 int fdsp_wavetable_get(int set, int* n_tables, float* h_pitches, int* h_lengths, float* h_data, size_t capacity);
 
 /* ---- host-side helpers that restate reference coefficient constructors with the engine's own math --------- */

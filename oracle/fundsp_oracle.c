@@ -136,6 +136,11 @@ struct onode {
         void *env_ctx;
         float env_v0[O_MAX_ENV], env_v1[O_MAX_ENV], env_val[O_MAX_ENV], env_d[O_MAX_ENV];
         int ps_ready; /* PhaseSynth::phase_ready */
+        /* WavePlayer (wave.rs:739-746) */
+        const float *wp_data;
+        size_t wp_length, wp_index, wp_start, wp_end;
+        long wp_loop;
+        int wp_channel;
         /* Hold (noise.rs:242-250) */
         double *hd_draws;
         size_t hd_n, hd_pos;
@@ -580,6 +585,7 @@ void o_reset(onode *n) {
     if (n->type == O_DECLICK) n->s.dc_t = 0.0f;     /* dynamics.rs:268-270 */
     if (n->type == O_PHASESYNTH) n->s.ps_ready = 0; /* wavetable.rs:387-389 */
     if (n->type == O_METER) n->s.mt_state = 0.0f;   /* dynamics.rs:351-353 */
+    if (n->type == O_WAVEPLAYER) n->s.wp_index = n->s.wp_start; /* wave.rs:774-776 */
     if (n->type == O_HOLD) { n->s.hd_pos = 0; n->s.hd_t = 0.0; n->s.hd_next = 0.0; } /* noise.rs:281-285: rnd re-seeded */
     if (n->type == O_REVERB3) n->rv3_feedback = 0.0f; /* reverb.rs:223 (the blocks are the kids: reset by the recursion) */
     if (n->type == O_LIMITER) limiter_set_sr(n, n->s.lm_sr); /* dynamics.rs:184-186 */
@@ -942,6 +948,14 @@ onode *o_wavesynth(const owavetable *table, int outputs) { /* WaveSynth::new wav
     n->s.table_hint = 0;
     n->s.ws_sr = (float)DEFAULT_SR;
     n->s.sample_duration = 1.0f / (float)DEFAULT_SR;
+    return n;
+}
+onode *o_waveplayer(const float *data, int channels, size_t length, int channel, size_t start_point, size_t end_point,
+                   long loop_point) { /* WavePlayer::new wave.rs:749-766 */
+    if (channel < 0 || channel >= channels || end_point > length) return NULL; /* the asserts :756-757 */
+    onode *n = o_new(O_WAVEPLAYER, 0, 1, 65);
+    n->s.wp_data = data; n->s.wp_length = length; n->s.wp_channel = channel;
+    n->s.wp_index = start_point; n->s.wp_start = start_point; n->s.wp_end = end_point; n->s.wp_loop = loop_point;
     return n;
 }
 onode *o_phasesynth(const owavetable *table) { /* PhaseSynth::new wavetable.rs:367-377 */
@@ -1905,6 +1919,15 @@ void o_tick(onode *n, const float *in, float *out) {
         }
         n->s.hd_t += n->s.hd_sd;
         out[0] = n->s.hd_hold;
+        break;
+    case O_WAVEPLAYER: /* wave.rs:779-792 */
+        if (n->s.wp_index < n->s.wp_end) {
+            out[0] = n->s.wp_data[(size_t)n->s.wp_channel * n->s.wp_length + n->s.wp_index];
+            n->s.wp_index += 1;
+            if (n->s.wp_index == n->s.wp_end && n->s.wp_loop >= 0) n->s.wp_index = (size_t)n->s.wp_loop;
+        } else {
+            out[0] = 0.0f;
+        }
         break;
     case O_MIXER: /* pan.rs:124-133 */
         for (int i = 0; i < n->nout; i++) {

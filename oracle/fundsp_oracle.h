@@ -19,7 +19,7 @@ enum {
     O_BIQUAD_BANK, O_MOOG, O_FIR, O_TICK, O_DELAY, O_PIPE, O_STACK, O_BINOP, O_UNOP,
     O_WAVESYNTH, O_ADSR_LIVE, O_PANNER, O_REVERB_STEREO, O_SHAPER, O_PHASE_OSC, O_CHAOS, O_NLBIQUAD, O_TAP, O_ALLNEST,
     O_ONEPOLE, O_PINKPASS, O_MORPH, O_REZ, O_FOLLOW, O_AFOLLOW, O_MLS, O_OVERSAMPLE, O_DSF, O_PLUCK, O_ENVELOPE, O_RESAMPLE, O_ENVELOPE_IN,
-    O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK, O_FEEDBACK, O_PHASESYNTH, O_WRAP, O_METER, O_VAR, O_LIMITER, O_REVERB3, O_MIXER, O_HOLD
+    O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK, O_FEEDBACK, O_PHASESYNTH, O_WRAP, O_METER, O_VAR, O_LIMITER, O_REVERB3, O_MIXER, O_HOLD, O_WAVEPLAYER
 };
 enum { O_OP_LOWPOLE = 0, O_OP_HIGHPOLE, O_OP_DCBLOCK, O_OP_ALLPOLE };
 enum { O_SH_CLIP = 0, O_SH_CLIPTO, O_SH_TANH, O_SH_ATAN, O_SH_SOFTSIGN, O_SH_CRUSH, O_SH_SOFTCRUSH, O_SH_ADAPTIVE_TANH };
@@ -55,6 +55,9 @@ typedef struct owavetable owavetable;
 owavetable *o_wavetable_create(int n_tables, const float *pitches, const int *lengths, const float *data);
 void o_wavetable_free(owavetable *t);
 onode *o_wavesynth(const owavetable *table, int outputs);
+/* WavePlayer (wave.rs:739, ID 65) over caller-owned wave data [channels][length]; loop_point < 0 = None */
+onode *o_waveplayer(const float *data, int channels, size_t length, int channel, size_t start_point, size_t end_point,
+                   long loop_point);
 onode *o_phasesynth(const owavetable *table);   /* PhaseSynth wavetable.rs:358 (ID 35): input 0 = phase */
 /* A node that IS a fixed inner graph under its own ID, pinging the inner graph first and hashing its ID last:
  * PulseWave (wavetable.rs:437-491, ID 44).  Takes ownership of x. */

@@ -70,7 +70,7 @@ def lib():
         "o_math_hash32x": (C.c_uint32, [C.c_uint32]),
         "o_bank_render": (d, [C.POINTER(BankJob), fp]),
         "o_wavetable_create": (P, [i, fp, C.POINTER(C.c_int), fp]), "o_wavetable_free": (None, [P]),
-        "o_wavesynth": (P, [P, i]), "o_phasesynth": (P, [P]), "o_wrap": (P, [P, u64]), "o_wavesynth_set_phase": (None, [P, f]),
+        "o_wavesynth": (P, [P, i]), "o_phasesynth": (P, [P]), "o_waveplayer": (P, [fp, i, C.c_size_t, i, C.c_size_t, C.c_size_t, C.c_long]), "o_wrap": (P, [P, u64]), "o_wavesynth_set_phase": (None, [P, f]),
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
         "o_onepole": (P, [i, i, f]), "o_pinkpass": (P, []), "o_morph": (P, [f, f, f]),
         "o_rez": (P, [i, f, f, f]), "o_follow": (P, [f]), "o_afollow": (P, [f, f]), "o_mls": (P, [C.c_uint]),
@@ -430,6 +430,18 @@ def hammond(): return wavesynth("hammond")
 def organ_hz(f): return constant(f) >> organ()
 def soft_saw_hz(f): return constant(f) >> soft_saw()
 def hammond_hz(f): return constant(f) >> hammond()
+
+
+def playwave_at(wave, channel, start_point, end_point, loop_point=None):       # prelude32.rs:2234
+    w = np.ascontiguousarray(np.atleast_2d(wave), dtype=np.float32)
+    n = Node(lib().o_waveplayer(_fptr(w), w.shape[0], w.shape[1], channel, start_point, end_point,
+                                -1 if loop_point is None else loop_point))
+    n._wave = w   # the node borrows the samples
+    return n
+
+
+def playwave(wave, channel, loop_point=None):                                    # prelude32.rs:2225
+    return playwave_at(wave, channel, 0, np.atleast_2d(wave).shape[1], loop_point)
 
 
 def phasesynth(kind="saw"):

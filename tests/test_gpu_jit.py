@@ -169,6 +169,35 @@ struct Env3 {  // |t, x, y| exp(-t * x) * y
             assert_bit_equal(got[v], oracle_render(n, None, T, mode), f"mixer/var_fn/bank voice {v} mode {mode}")
 
 
+def test_jit_sampler_voices(gpu):
+    """playwave_at(wave, channel, start, end, loop) (wave.rs:739-797) as a bank of sampler heads over one shared Wave
+    in HBM: per-voice start / end / loop points, and resample(playwave(..)) for a per-voice, per-sample playback speed
+    (resample.rs:205-315)."""
+    V, T, L = 48, 64 * 9 + 7, 700
+    rng = np.random.default_rng(41)
+    wave = (rng.random((2, L), dtype=np.float32) * 2 - 1).astype(np.float32)
+    gpu.wave_upload(3, wave)
+    start = rng.integers(0, 300, V).astype(np.uint32)
+    end = (start + rng.integers(1, 400, V)).astype(np.uint32)
+    loop = np.where(np.arange(V) % 3 == 0, 0xFFFFFFFF, start + (end - start) // 2).astype(np.uint32)   # a third plays once
+    chan = (np.arange(V) % 2).astype(np.uint32)
+    g = GR.playwave_at(3, chan, start, end, loop) * 0.5
+    for mode in (MODE_PROCESS, MODE_TICK):
+        b = gpu.Bank.from_graph(g, V, sample_rate=SR)
+        got = run_bank(b, None, T, LAYOUT_VOICE_MINOR, mode)
+        for v in (0, 1, 2, 17, V - 1):
+            n = O.playwave_at(wave, int(chan[v]), int(start[v]), int(end[v]), None if loop[v] == 0xFFFFFFFF else int(loop[v])) * 0.5
+            assert_bit_equal(got[v], oracle_render(n, None, T, mode), f"sampler voice {v} mode {mode}")
+    # variable speed: the speed input drives Resample's cubic read of the playing wave
+    speed = (0.3 + 1.7 * rng.random((V, 1, T))).astype(np.float32)
+    g2 = GR.resample(GR.playwave(3, 0, L, loop_point=10))
+    b = gpu.Bank.from_graph(g2, V, sample_rate=SR)
+    got = run_bank(b, speed, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    for v in (0, V - 1):
+        n = O.resample(O.playwave(wave, 0, loop_point=10))
+        assert_bit_equal(got[v], oracle_render(n, speed[v], T, MODE_PROCESS), f"resampled sampler voice {v}")
+
+
 def test_jit_hold_with_uploaded_rnd_stream(gpu):
     """hold_hz(f, variability) (noise.rs:242-322, prelude32.rs:831): sample-and-hold whose hold lengths come from
     funutd's Rnd -- the draws are uploaded per voice (as for Pluck), everything else runs on the device in f64 time."""
