@@ -221,7 +221,9 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     out->render = [jm](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T, size_t fstride,
                        int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
         if (V == 0 || T == 0) return;
-        if (layout == LAYOUT_VOICE_MINOR && g_pipe_split && jm->pipe_stages >= 1) {  // loader wave / stage split
+        // loader wave / stage split; short launches (real-time blocks) are faster through the single-wave kernel, as for
+        // the ahead-of-time kinds (launch_render)
+        if (layout == LAYOUT_VOICE_MINOR && g_pipe_split && jm->pipe_stages >= 1 && (T >= 256 || g_pipe_split > 1)) {
             void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &aux, &ring, &ring_cap};
             hipModuleLaunchKernel(jm->pipe[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_threads, 1, 1, 0, s,
                                   pargs, nullptr);
