@@ -1,0 +1,121 @@
+"""Randomly composed voice graphs: every combinator of the notation over a pool of leaves, built twice from one
+expression tree -- with the engine's notation (fundsp_amd.graph, compiled at run time) and with the oracle's -- and
+compared bit for bit in process and tick semantics.  What this pins beyond the hand-written cases is the interplay:
+arity bookkeeping, parameter paths and, above all, the ping order that gives every oscillator / noise source its hash
+(audionode.rs:156-161 and each combinator's ping), for shapes nobody wrote down by hand."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from fundsp_amd import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS, MODE_TICK
+from fundsp_amd import graph as GR
+from test_gpu_parity import assert_bit_equal, noise_input, oracle_render, run_bank
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+
+
+def leaf(rng, nin, nout):
+    r = lambda lo, hi: float(np.float32(rng.uniform(lo, hi)))
+    pool = {
+        (0, 1): [lambda: ("sine_hz", r(50, 3000)), lambda: ("noise",), lambda: ("dc", r(-1, 1)), lambda: ("impulse",),
+                 lambda: ("poly_saw_hz", r(50, 2000)), lambda: ("mls",)],
+        (1, 1): [lambda: ("lowpass_hz", r(200, 8000), r(0.5, 3)), lambda: ("highpole_hz", r(20, 2000)),
+                 lambda: ("lowpole_hz", r(100, 9000)), lambda: ("shape_tanh", r(0.5, 3)), lambda: ("pass_",),
+                 lambda: ("mul", r(-1.5, 1.5)), lambda: ("follow", r(0.001, 0.05)), lambda: ("tick",),
+                 lambda: ("declick_s", r(0.001, 0.01)), lambda: ("bell_hz", r(200, 5000), r(0.5, 2), r(0.5, 2)),
+                 lambda: ("moog_hz", r(300, 4000), r(0.0, 0.6)), lambda: ("meter_rms", r(0.005, 0.05))],
+        (1, 2): [lambda: ("pan", r(-1, 1)), lambda: ("split", 2)],
+        (2, 1): [lambda: ("join", 2)],
+        (2, 2): [lambda: ("reverse", 2), lambda: ("multipass", 2), lambda: ("rotate", r(0, 3), r(0.3, 1.0))],
+        (0, 2): [lambda: ("dc2", r(-1, 1), r(-1, 1))],
+        (1, 0): [lambda: ("sink",)],
+        (2, 0): [lambda: ("multisink", 2)],
+    }
+    opts = pool.get((nin, nout))
+    return None if not opts else opts[rng.integers(len(opts))]()
+
+
+def gen(rng, nin, nout, depth):
+    """Expression tree for a node with `nin` inputs and `nout` outputs (0 <= nin, nout <= 2)."""
+    choices = []
+    if depth > 0:
+        choices += ["pipe"] * 3
+        if nin + nout >= 2 and (nin > 0 or nout > 1):
+            choices.append("stack")
+        if nout >= 1:
+            choices += ["bus", "binop", "unop"]
+        if nout == 2:
+            choices.append("branch")
+        if nin == nout and nin > 0:
+            choices.append("thru")
+    lf = leaf(rng, nin, nout)
+    if lf is not None:
+        choices += ["leaf"] * (2 if depth > 0 else 50)
+    for _ in range(50):
+        c = choices[rng.integers(len(choices))]
+        if c == "leaf":
+            return lf
+        if c == "pipe":
+            k = int(rng.integers(1, 3))
+            return ("pipe", gen(rng, nin, k, depth - 1), gen(rng, k, nout, depth - 1))
+        if c == "stack":
+            a, b = int(rng.integers(0, nin + 1)), int(rng.integers(0, nout + 1))
+            if (a, b) in ((0, 0), (nin, nout)):
+                continue
+            return ("stack", gen(rng, a, b, depth - 1), gen(rng, nin - a, nout - b, depth - 1))
+        if c == "bus":
+            return ("bus", gen(rng, nin, nout, depth - 1), gen(rng, nin, nout, depth - 1))
+        if c == "branch":
+            return ("branch", gen(rng, nin, 1, depth - 1), gen(rng, nin, 1, depth - 1))
+        if c == "thru":
+            return ("thru", gen(rng, nin, int(rng.integers(0, nin + 1)), depth - 1))
+        if c == "binop":
+            a = int(rng.integers(0, nin + 1))
+            return ("binop", "+-*"[rng.integers(3)], gen(rng, a, nout, depth - 1), gen(rng, nin - a, nout, depth - 1))
+        if c == "unop":
+            return ("unop", ["mul", "add", "neg", "rsub"][rng.integers(4)], float(np.float32(rng.uniform(-1.5, 1.5))),
+                    gen(rng, nin, nout, depth - 1))
+    raise AssertionError("no production fits")
+
+
+def build(t, m):
+    k = t[0]
+    if k == "pipe": return build(t[1], m) >> build(t[2], m)
+    if k == "stack": return build(t[1], m) | build(t[2], m)
+    if k == "bus": return build(t[1], m) & build(t[2], m)
+    if k == "branch": return build(t[1], m) ^ build(t[2], m)
+    if k == "thru": return ~build(t[1], m)
+    if k == "binop":
+        a, b = build(t[2], m), build(t[3], m)
+        return a + b if t[1] == "+" else a - b if t[1] == "-" else a * b
+    if k == "unop":
+        x = build(t[3], m)
+        return x * t[2] if t[1] == "mul" else x + t[2] if t[1] == "add" else -x if t[1] == "neg" else t[2] - x
+    if k == "shape_tanh": return m.shape("tanh", t[1])
+    if k == "dc2": return m.dc(t[1], t[2])
+    if k == "meter_rms": return m.meter("rms", t[1])
+    return getattr(m, k)(*t[1:])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_GRAPHS", "16"))))   # more for a bug hunt
+def test_random_graph_matches_oracle(gpu, seed):
+    rng = np.random.default_rng(1000 + seed)
+    nin, nout = int(rng.integers(0, 3)), int(rng.integers(1, 3))
+    tree = gen(rng, nin, nout, depth=int(rng.integers(3, 6)))
+    g = build(tree, GR)
+    assert (g.nin, g.nout) == (nin, nout), tree
+    V, T = 5, 64 * 4 + 19
+    seeds = np.arange(V, dtype=np.uint64) * 977 + seed
+    x = noise_input(V, nin, T, seed=seed) if nin else None
+    for mode, layout in ((MODE_PROCESS, LAYOUT_VOICE_MINOR), (MODE_TICK, LAYOUT_PLANAR)):
+        b = gpu.Bank.from_graph(g, V, sample_rate=SR)
+        b.set_seed(seeds)
+        got = run_bank(b, x, T, layout, mode)
+        for v in (0, V - 1):
+            n = build(tree, O)
+            n.set_sample_rate(SR)
+            n.set_seed(int(seeds[v]))
+            assert_bit_equal(got[v], oracle_render(n, None if x is None else x[v], T, mode), f"seed {seed} voice {v} mode {mode}: {tree}")
