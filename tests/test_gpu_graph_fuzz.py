@@ -26,7 +26,10 @@ def leaf(rng, nin, nout):
                  lambda: ("lowpole_hz", r(100, 9000)), lambda: ("shape_tanh", r(0.5, 3)), lambda: ("pass_",),
                  lambda: ("mul", r(-1.5, 1.5)), lambda: ("follow", r(0.001, 0.05)), lambda: ("tick",),
                  lambda: ("declick_s", r(0.001, 0.01)), lambda: ("bell_hz", r(200, 5000), r(0.5, 2), r(0.5, 2)),
-                 lambda: ("moog_hz", r(300, 4000), r(0.0, 0.6)), lambda: ("meter_rms", r(0.005, 0.05))],
+                 lambda: ("moog_hz", r(300, 4000), r(0.0, 0.6)), lambda: ("meter_rms", r(0.005, 0.05)),
+                 # delay lines (ring memory per voice) and feedback loops (the whole graph then renders with flushed denormals)
+                 lambda: ("delay", r(0.0001, 0.004)), lambda: ("allnest_delay", r(-0.7, 0.7), r(0.0001, 0.003)),
+                 lambda: ("echo", r(0.0002, 0.003), r(-0.8, 0.8)), lambda: ("tap_dc", r(0.0005, 0.003))],
         (1, 2): [lambda: ("pan", r(-1, 1)), lambda: ("split", 2)],
         (2, 1): [lambda: ("join", 2)],
         (2, 2): [lambda: ("reverse", 2), lambda: ("multipass", 2), lambda: ("rotate", r(0, 3), r(0.3, 1.0))],
@@ -97,6 +100,9 @@ def build(t, m):
     if k == "shape_tanh": return m.shape("tanh", t[1])
     if k == "dc2": return m.dc(t[1], t[2])
     if k == "meter_rms": return m.meter("rms", t[1])
+    if k == "allnest_delay": return m.allnest_c(t[1], m.delay(t[2]))
+    if k == "echo": return m.feedback(m.delay(t[1]) * t[2])
+    if k == "tap_dc": return (m.pass_() | m.dc(t[1])) >> m.tap(0.0004, 0.004)
     return getattr(m, k)(*t[1:])
 
 
@@ -111,7 +117,7 @@ def test_random_graph_matches_oracle(gpu, seed):
     seeds = np.arange(V, dtype=np.uint64) * 977 + seed
     x = noise_input(V, nin, T, seed=seed) if nin else None
     for mode, layout in ((MODE_PROCESS, LAYOUT_VOICE_MINOR), (MODE_TICK, LAYOUT_PLANAR)):
-        b = gpu.Bank.from_graph(g, V, sample_rate=SR)
+        b = gpu.Bank.from_graph(g, V, ring_frames=256 if g.rings else 0, sample_rate=SR)
         b.set_seed(seeds)
         got = run_bank(b, x, T, layout, mode)
         for v in (0, V - 1):
