@@ -116,7 +116,7 @@ def test_random_graph_matches_oracle(gpu, seed):
     V, T = 5, 64 * 4 + 19
     seeds = np.arange(V, dtype=np.uint64) * 977 + seed
     x = noise_input(V, nin, T, seed=seed) if nin else None
-    for mode, layout in ((MODE_PROCESS, LAYOUT_VOICE_MINOR), (MODE_TICK, LAYOUT_PLANAR)):
+    for mode, layout in ((MODE_PROCESS, LAYOUT_VOICE_MINOR), (MODE_TICK, LAYOUT_PLANAR), (MODE_PROCESS, LAYOUT_PLANAR)):
         b = gpu.Bank.from_graph(g, V, ring_frames=256 if g.rings else 0, sample_rate=SR)
         b.set_seed(seeds)
         got = run_bank(b, x, T, layout, mode)
