@@ -35,6 +35,33 @@ def main():
     np.savez_compressed(os.path.join(HERE, "configs_v1.npz"), config1=c1, config2_process=c2p, config2_tick=c2t,
                         config3_process=c3p, config3_tick=c3t)
     print("wrote", os.path.join(HERE, "configs_v1.npz"))
+    np.savez_compressed(os.path.join(HERE, "graphs_v1.npz"), **graph_vectors())
+    print("wrote", os.path.join(HERE, "graphs_v1.npz"))
+
+
+GRAPH_FRAMES = 64 * 3 + 9
+
+
+def graph_vectors():
+    """One short oracle render (process and tick semantics) of every graph of tests/test_gpu_jit.py::GRAPHS -- the leaf,
+    combinator and composed-opcode inventory in one place -- with seed 12345 and a fixed noise input."""
+    from test_gpu_jit import GRAPHS
+
+    out = {}
+    rng = np.random.default_rng(2024)
+    for name, (build, ni, _ring) in GRAPHS.items():
+        x = (rng.random((max(ni, 1), GRAPH_FRAMES), dtype=np.float32) * 2 - 1).astype(np.float32)
+        if name == "saw_filter_env":
+            x[0] = 0.0
+            x[0, 3:150] = 1.0
+        out[name + "__in"] = x
+        for mode in ("process", "tick"):
+            n = build(O)
+            n.set_sample_rate(SR)
+            n.set_seed(12345)
+            xin = x[:ni] if ni else None
+            out[f"{name}__{mode}"] = n.render_blocks(xin, length=GRAPH_FRAMES) if mode == "process" else n.render_ticks(xin, length=GRAPH_FRAMES)
+    return out
 
 
 if __name__ == "__main__":
