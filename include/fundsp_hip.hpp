@@ -75,7 +75,7 @@ class An {
     An() = default;
     An(std::string t, int nin, int nout, int nrings = 0) : type(std::move(t)), inputs(nin), outputs(nout), rings(nrings) {}
     An& with(const std::string& field, const P& p) {
-        params.push_back(Param{{}, field, p.v});
+        params.push_back(Param{{}, field, p.v, false, {}});
         return *this;
     }
     // combinator.rs:263-267 `.phase(x)` / `.seed(x)`
