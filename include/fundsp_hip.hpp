@@ -78,6 +78,11 @@ class An {
         params.push_back(Param{{}, field, p.v, false, {}});
         return *this;
     }
+    // a parameter of an enclosed object, e.g. the fields of an Envelope's functor live under child 0: "0:<field>"
+    An& with_child(int child, const std::string& field, const P& p) {
+        params.push_back(Param{{child}, field, p.v, false, {}});
+        return *this;
+    }
     // combinator.rs:263-267 `.phase(x)` / `.seed(x)`
     An phase(P p) const {
         An a = *this;
@@ -319,6 +324,7 @@ inline An resample(const An& x) {
 }
 
 // closures: the Rust closure is a C++ functor type whose definition travels as `source` (contracts in fd_nodes.hpp)
+// (functor parameters: .with_child(0, "<field>", value))
 inline An envelope(const std::string& functor, const std::string& source, int outputs = 1) {  // envelope / lfo, prelude32.rs:581-611
     An a("Envelope<" + functor + ">", 0, outputs);
     a.source = source;
@@ -380,6 +386,86 @@ inline An branchf(int n, const std::function<An(float)>& f) { return branchi(n, 
 inline An sumf(int n, const std::function<An(float)>& f) { return sumi(n, [&](int i) { return f(frac(n, i)); }); }
 inline An pipef(int n, const std::function<An(float)>& f) { return pipei(n, [&](int i) { return f(frac(n, i)); }); }
 
+// ---- more of the prelude (same constructions as fundsp_amd/graph.py) ------------------------------------------------
+inline An add(std::initializer_list<P> v) { return multipass((int)v.size()) + constant(v); }   // prelude32.rs:391
+inline An sub(std::initializer_list<P> v) { return multipass((int)v.size()) - constant(v); }   // prelude32.rs:409
+inline An mul(std::initializer_list<P> v) { return multipass((int)v.size()) * constant(v); }   // prelude32.rs:427
+inline An add(P v) { return add({std::move(v)}); }
+inline An sub(P v) { return sub({std::move(v)}); }
+inline An mul(P v) { return mul({std::move(v)}); }
+inline An mixer(const std::vector<std::vector<P>>& matrix) {  // Mixer::new pan.rs:108, matrix[out][in]
+    const int n_out = (int)matrix.size(), n_in = (int)matrix[0].size();
+    An a("Mixer<" + std::to_string(n_in) + "," + std::to_string(n_out) + ">", n_in, n_out);
+    for (int i = 0; i < n_out; i++)
+        for (int j = 0; j < n_in; j++) a.with("matrix[" + std::to_string(i * n_in + j) + "]", matrix[i][j]);
+    return a;
+}
+inline An rotate(float angle, float gain) {  // prelude32.rs:2432, libm cos / sin as the engine restates them
+    const float c = fdsp_libm_cosf(angle), s = fdsp_libm_sinf(angle);
+    return mixer({{c * gain, -s * gain}, {s * gain, c * gain}});
+}
+enum MeterMode { METER_SAMPLE = 0, METER_PEAK = 1, METER_RMS = 2 };  // dynamics.rs:316-320
+inline An meter_node(MeterMode mode, double timescale, bool monitor) {
+    An a("MeterT<" + std::to_string((int)mode) + "," + (monitor ? "true" : "false") + ">", 1, 1);
+    uint64_t bits;
+    std::memcpy(&bits, &timescale, 8);
+    Param q{{}, "timescale", {}, true, {bits}};  // the f64 timescale travels as its bit pattern
+    a.params.push_back(q);
+    return a;
+}
+inline An meter(MeterMode mode, double timescale = 0.1) { return meter_node(mode, timescale, false); }    // prelude32.rs:300
+inline An monitor(MeterMode mode, double timescale = 0.1) { return meter_node(mode, timescale, true); }   // level: ":state" slot
+inline An hold(P variability) { return detail::leaf("Hold", 2, 1, 1).with("variability", variability); }  // draws: Bank::set_ring
+inline An hold_hz(P f, P variability) { return (pass() | dc(f)) >> hold(variability); }                   // prelude32.rs:831
+inline An envelope_in(const std::string& functor, const std::string& source, int inputs, int outputs = 1) {  // prelude32.rs:625-745
+    An a("EnvelopeIn<" + functor + ">", inputs, outputs);
+    a.source = source;
+    return a;
+}
+inline An flanger(P feedback_amount, P minimum_delay, P maximum_delay, const An& delay_lfo) {  // prelude.rs:2719-2730
+    return pass() & feedback2((pass() | delay_lfo) >> tap(minimum_delay, maximum_delay), shape(TANH, feedback_amount));
+}
+inline An reverb4_stereo_delays(const std::vector<float>& delays, double time) {  // prelude.rs:1917-1941
+    if (delays.size() != 32) detail::arity("reverb4_stereo_delays takes 32 delay times");
+    const float a = (float)std::pow(std::exp(-60.0 / 20.0 * 2.302585092994046), 0.03 * 10.0 / 10.0 / time);
+    auto line = [&](int first) {
+        return stacki(16, [&](int i) { return delay(delays[(size_t)(first + i)]) >> fir({-a / 4.0f, -a / 2.0f, -a / 4.0f}); });
+    };
+    auto smooth9 = [](float x) {
+        const float x2 = x * x;
+        return ((((70.0f * x - 315.0f) * x + 540.0f) * x - 420.0f) * x + 126.0f) * x2 * x2 * x;
+    };
+    An pans = sumf(16, [&](float x) { return pan(-1.0f * (1.0f - smooth9(x)) + 1.0f * smooth9(x)); });
+    return multisplit(2, 8) >> fdn(line(0)) >> multijoin(2, 8) >> multisplit(2, 8) >> fdn(line(16)) >> pans * dc({0.25f, 0.25f});
+}
+inline An reverb4_stereo(double room_size, double time) {  // prelude.rs:1873-1914
+    static const float d[32] = {0.059326634f, 0.04778291f, 0.06995449f, 0.0393001f, 0.041604012f, 0.06215825f, 0.052269846f,
+                                0.043227978f, 0.06966107f, 0.031615064f, 0.068442f, 0.037332155f, 0.032944717f, 0.034493037f,
+                                0.06787566f, 0.038824916f, 0.068260126f, 0.068044715f, 0.0688076f, 0.066724524f, 0.051293883f,
+                                0.06023173f, 0.040897705f, 0.031507637f, 0.060309593f, 0.049584292f, 0.04532072f, 0.056379095f,
+                                0.035180368f, 0.041291796f, 0.046129026f, 0.05504605f};
+    const float scale = std::max((float)room_size, 15.0f) / 10.0f;
+    std::vector<float> delays(32);
+    for (int i = 0; i < 32; i++) delays[(size_t)i] = d[i] * scale;
+    return reverb4_stereo_delays(delays, time);
+}
+// playwave_at(wave, channel, start, end, loop) (prelude32.rs:2234) over sample slot `slot` (fdsp_wave_upload); the
+// u32 parameters travel as raw words
+inline An playwave_at(int slot, uint32_t channel, uint32_t start_point, uint32_t end_point, int64_t loop_point = -1) {
+    An a("WavePlayer<" + std::to_string(slot) + ">", 0, 1);
+    auto word = [](uint32_t u) {
+        float f;
+        std::memcpy(&f, &u, 4);
+        return std::vector<float>{f};
+    };
+    a.params.push_back(Param{{}, "channel", word(channel), false, {}});
+    a.params.push_back(Param{{}, "start_point", word(start_point), false, {}});
+    a.params.push_back(Param{{}, "end_point", word(end_point), false, {}});
+    a.params.push_back(Param{{}, "loop_point", word(loop_point < 0 ? 0xFFFFFFFFu : (uint32_t)loop_point), false, {}});
+    return a;
+}
+inline An playwave(int slot, uint32_t channel, uint32_t length, int64_t loop_point = -1) { return playwave_at(slot, channel, 0, length, loop_point); }
+
 // ---- Bank: V voices of one graph behind the AudioNode surface ---------------------------------------------------
 class Bank {
  public:
@@ -410,7 +496,8 @@ class Bank {
                 if (p.u64s.size() == voices) u = p.u64s;
                 check(fdsp_bank_set_param_u64(b.h_, slot.c_str(), u.data(), 0, voices));
             } else if (p.values.size() == 1) {
-                check(fdsp_bank_set_param_all(b.h_, slot.c_str(), p.values[0]));
+                std::vector<float> all(voices, p.values[0]);  // copied as words: raw u32 parameters keep every bit
+                check(fdsp_bank_set_param(b.h_, slot.c_str(), all.data(), 0, voices));
             } else if (p.values.size() == voices) {
                 check(fdsp_bank_set_param(b.h_, slot.c_str(), p.values.data(), 0, voices));
             } else {

@@ -72,6 +72,18 @@ static void host_checks() {
     EXPECT(fdsp_graph_check(echo.type.c_str()) == 0);
     EXPECT(fdsp_graph_check((busi(4, [](int i) { return sine_hz(100.0f * (i + 1)); }) >> split(2) >> join(2)).type.c_str()) == 0);
     EXPECT(throws([] { Bank b("no_such_kind", 4); }));
+    // the composed opcodes build the same types as the reference's prelude would
+    An rv = reverb4_stereo(20.0, 2.0);
+    EXPECT(rv.inputs == 2 && rv.outputs == 2 && rv.rings == 32 && fdsp_graph_check(rv.type.c_str()) == 0);
+    An fl = noise() >> flanger(0.6f, 0.002f, 0.006f, lfo("EnvSineHz", "").with_child(0, "hz", 0.7f).with_child(0, "lo", 0.002f).with_child(0, "hi", 0.006f));
+    EXPECT(fl.type == "Pipe<Noise,Bus<Pass,Feedback2<Pipe<Stack<Pass,Envelope<EnvSineHz>>,TapT<false>>,Shaper,FbId>>>");
+    EXPECT(fdsp_graph_check(fl.type.c_str()) == 0);
+    bool lfo_slot = false;
+    for (const Param& p : fl.params) lfo_slot = lfo_slot || p.slot() == "1.1.0.0.1.0:hz";
+    EXPECT(lfo_slot);
+    An chain = (pass() | dc(1.0f)) >> rotate(0.5f, 1.0f) >> (pass() | sink()) >> meter(METER_PEAK, 0.1) >> mul(0.5f);   // test_flow.rs:176
+    EXPECT(chain.inputs == 1 && chain.outputs == 1 && fdsp_graph_check(chain.type.c_str()) == 0);
+    EXPECT(playwave_at(3, 1, 10, 200, 50).type == "WavePlayer<3>");
 }
 
 static onode* oracle_fm(float f, float m, float fc, float q) {
