@@ -1102,11 +1102,11 @@ struct PlanarPlan {
     using T = Tiles<(S >= 1 ? S : 1), K1>;
 };
 
-template <class G, int MODE, int S, int K1>
+template <class G, int MODE, int S, int K1, int GPW = 4>
 FD_D void render_pipe_planar_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
                                   float* __restrict__ out, size_t T, size_t fstride, const void* aux, float* ring, uint32_t ring_cap) {
     using TL = typename PlanarPlan<G>::template Tiles<S, K1>;
-    constexpr int NI = G::IN, NO = G::OUT, GPW = 4;
+    constexpr int NI = G::IN, NO = G::OUT;
     constexpr bool FEED = NI > 0;
     constexpr int SUB = TL::SUB, SPB = 64 / SUB, W = TL::W, D = FEED ? TL::D : 1;
     constexpr int LPR = SUB / 4;        // lanes per voice row (one float4 each)
@@ -1238,11 +1238,11 @@ FD_D void render_pipe_planar_body(float* __restrict__ slots, size_t stride, size
     }
 }
 
-template <class G, int MODE, int S, int K1>
-__global__ __launch_bounds__((256 * PlanarPlan<G>::template Tiles<S, K1>::WAVES)) void k_render_pipe_planar(
+template <class G, int MODE, int S, int K1, int GPW>
+__global__ __launch_bounds__((64 * GPW * PlanarPlan<G>::template Tiles<S, K1>::WAVES)) void k_render_pipe_planar(
     float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ out, size_t T, size_t fstride,
     const void* aux, float* ring, uint32_t ring_cap) {
-    render_pipe_planar_body<G, MODE, S, K1>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
+    render_pipe_planar_body<G, MODE, S, K1, GPW>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
 }
 
 // Launch policy for the voice-minor layout: voices per wave such that the grid has at least one wave per SIMD.

@@ -131,8 +131,23 @@ bool launch_render_pipe_planar(float* slots, size_t stride, size_t V, const floa
     if constexpr (PP::S >= 1) {
         constexpr int WAVES = PP::T::WAVES;
         const size_t groups = (V + 63) / 64;
-        hipLaunchKernelGGL((k_render_pipe_planar<G, MODE, PP::S, PP::K1>), dim3((unsigned)((groups + 3) / 4)), dim3(256 * WAVES), 0, s,
-                           slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
+        const size_t cus = (size_t)simd_count() / 4;
+        // heavy graphs (latency-bound waves) are spread so that every CU gets a workgroup, as in launch_render_pipe
+        bool done = false;
+        if constexpr (Cost<G>::v >= 150) {
+            if (groups < 2 * cus) {
+                hipLaunchKernelGGL((k_render_pipe_planar<G, MODE, PP::S, PP::K1, 1>), dim3((unsigned)groups), dim3(64 * WAVES), 0, s, slots,
+                                   stride, V, in, out, T, fstride, aux, ring, ring_cap);
+                done = true;
+            } else if (groups < 4 * cus) {
+                hipLaunchKernelGGL((k_render_pipe_planar<G, MODE, PP::S, PP::K1, 2>), dim3((unsigned)((groups + 1) / 2)), dim3(128 * WAVES), 0,
+                                   s, slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
+                done = true;
+            }
+        }
+        if (!done)
+            hipLaunchKernelGGL((k_render_pipe_planar<G, MODE, PP::S, PP::K1, 4>), dim3((unsigned)((groups + 3) / 4)), dim3(256 * WAVES), 0, s,
+                               slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
         return true;
     } else {
         return false;
