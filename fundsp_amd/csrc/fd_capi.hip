@@ -1,4 +1,5 @@
 // fd_capi.hip -- C ABI (include/fundsp_hip.h) of the MI355X voice-bank engine.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -248,6 +249,11 @@ struct fdsp_bank {
     double* ev = nullptr;
     int* ev_fade = nullptr;
     double seq_time = 0.0;
+    // host mirror of the events [V][4] and its aggregates: a launch that every voice sustains (inside its event, no fade
+    // running) is a plain render and takes the pipeline kernel
+    std::vector<double> ev_host;
+    bool ev_dirty = true;
+    double ev_max_start = 0.0, ev_min_end = 0.0, ev_max_fade_in_end = 0.0, ev_min_fade_out_start = 0.0;
     // fdsp_bank_process_host staging, grown on demand and kept: a real-time host calls once per 64-frame block
     float *st_in = nullptr, *st_out = nullptr;     // device
     float *pin_in = nullptr, *pin_out = nullptr;   // pinned host (small transfers only)
@@ -799,6 +805,12 @@ int fdsp_bank_set_events(fdsp_bank* b, const double* events, const int* fade, si
         HIPCHK(hipMemcpyAsync(b->ev_fade, fi.data(), fi.size() * sizeof(int), hipMemcpyHostToDevice, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
     }
+    if (b->ev_host.empty()) {
+        b->ev_host.assign(4 * b->V, 0.0);
+        for (size_t v = 0; v < b->V; v++) b->ev_host[4 * v] = b->ev_host[4 * v + 1] = std::numeric_limits<double>::infinity();
+    }
+    std::memcpy(b->ev_host.data() + 4 * first, events, 4 * count * sizeof(double));
+    b->ev_dirty = true;
     std::vector<double> col(count);
     for (int k = 0; k < 4; k++) {
         for (size_t i = 0; i < count; i++) col[i] = events[4 * i + k];
@@ -833,6 +845,34 @@ int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, flo
     if (s != b->stream) hipStreamIsCapturing(s, &cap);
     const bool capturing = cap != hipStreamCaptureStatusNone;
     if (!capturing) HIPCHK(hipEventRecord(b->e0, s));
+    // the clock after this launch, advanced exactly as the reference does: one f64 addition per block / per sample
+    const double sd = 1.0 / b->sr, t_begin = b->seq_time;
+    double t_end = t_begin;
+    if (mode == FDSP_MODE_PROCESS)
+        for (size_t t0 = 0; t0 < frames; t0 += 64) t_end += sd * (double)(frames - t0 < 64 ? frames - t0 : 64);
+    else
+        for (size_t t = 0; t < frames; t++) t_end += sd;
+    if (b->ev_dirty) {
+        const double inf = std::numeric_limits<double>::infinity();
+        b->ev_max_start = -inf; b->ev_min_end = inf; b->ev_max_fade_in_end = -inf; b->ev_min_fade_out_start = inf;
+        for (size_t v = 0; v < b->V; v++) {
+            const double* e = b->ev_host.data() + 4 * v;
+            b->ev_max_start = std::max(b->ev_max_start, e[0]);
+            b->ev_min_end = std::min(b->ev_min_end, e[1]);
+            if (e[2] > 0.0) b->ev_max_fade_in_end = std::max(b->ev_max_fade_in_end, e[0] + e[2]);
+            if (e[3] > 0.0) b->ev_min_fade_out_start = std::min(b->ev_min_fade_out_start, e[1] - e[3]);
+        }
+        b->ev_dirty = false;
+    }
+    // Every voice inside its event for the whole launch and no fade running in any of its blocks (the kernel's own
+    // per-block conditions, evaluated for the first and the last block): the scheduler's output is the units' plain
+    // process / tick -- same arithmetic -- so the launch takes the (pipeline) render kernel.
+    const bool sustained = !b->ev_host.empty() && b->ev_max_start <= t_begin && b->ev_min_end >= t_end &&
+                           b->ev_max_fade_in_end <= t_begin && b->ev_min_fade_out_start >= t_end;
+    if (sustained)
+        b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, 0, FDSP_LAYOUT_VOICE_MINOR, mode, device_aux(), b->ring,
+                       b->ring_cap, s);
+    else
     b->ops->render_events(b->slots, b->stride, b->V, d_in, d_out, frames, b->ev, b->ev_fade, b->seq_time, b->sr, mode,
                           device_aux(), b->ring, b->ring_cap, s);
     HIPCHK(hipGetLastError());
@@ -841,12 +881,7 @@ int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, flo
         b->timed = true;
         b->ext_pending = s != b->stream;
     }
-    // advance the sequencer clock exactly as the reference does: one f64 addition per block / per sample
-    const double sd = 1.0 / b->sr;
-    if (mode == FDSP_MODE_PROCESS)
-        for (size_t t0 = 0; t0 < frames; t0 += 64) b->seq_time += sd * (double)(frames - t0 < 64 ? frames - t0 : 64);
-    else
-        for (size_t t = 0; t < frames; t++) b->seq_time += sd;
+    b->seq_time = t_end;
     return FDSP_OK;
 }
 

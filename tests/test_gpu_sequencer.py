@@ -89,6 +89,41 @@ def test_sustained_voices_take_the_packed_path(gpu):
         assert_bit_equal(got[v], per[v], f"sustained voice {v}")
 
 
+@pytest.mark.parametrize("mode", [MODE_PROCESS, MODE_TICK])
+def test_fully_sustained_launch_is_a_plain_render(gpu, mode):
+    """A launch that every voice sustains (inside its event, no fade running) is dispatched to the render kernels instead
+    of the scheduler kernel; three launches -- fades, sustained, ends -- must still add up to the Sequencer oracle's
+    samples, and the clock must advance identically."""
+    import torch
+
+    V = 64 * 3 + 5
+    T1, T2, T3 = 64 * 5, 64 * 6, 64 * 4 + 11          # whole sequencer blocks for the first two launches
+    T = T1 + T2 + T3
+    rng = np.random.default_rng(94)
+    p = W.fm_svf_params(V, SR)
+    start = rng.integers(0, 40, V).astype(np.float64) + rng.random(V) * 0.3
+    fin = rng.integers(0, 200, V).astype(np.float64)                     # all fade-ins over before T1 = 320
+    end = (T1 + T2) + rng.integers(60, T3, V).astype(np.float64)         # all ends inside the third launch
+    fout = rng.integers(0, 50, V).astype(np.float64)                     # fade-outs start after T1 + T2
+    fade = rng.integers(0, 2, V).astype(np.int32)
+    start, end, fin, fout = start / SR, end / SR, fin / SR, fout / SR
+    b = W.make_fm_svf_bank(V, SR, params=p)
+    b.set_events(start, end, fin, fout, fade)
+    outs = [b.process_events(n, mode=mode) for n in (T1, T2, T3)]
+    torch.cuda.synchronize()
+    got = torch.cat(outs, dim=1).cpu().numpy().transpose(2, 0, 1)
+    seq = O.Sequencer(0, 1, SR)
+    for v in range(V):
+        f, m = float(p["f"][v]), float(p["m"][v])
+        n = O.sine_hz(f) * f * m + f >> O.sine() >> O.lowpass_hz(float(p["fc"][v]), float(p["q"][v]))
+        n.set_seed(int(p["seed"][v]))
+        seq.push(start[v], end[v], int(fade[v]), fin[v], fout[v], n)
+    _, per = seq.render(T, process=(mode == MODE_PROCESS))
+    for v in range(V):
+        assert_bit_equal(got[v], per[v], f"voice {v}")
+    assert abs(b.events_time() - seq.time()) == 0.0
+
+
 def test_gated_voices_with_inputs_and_two_launches(gpu, tables):
     """A kind with an input (saw >> moog * adsr >> pan, gate in) scheduled per voice, rendered in two launches of whole
     sequencer blocks: the clock and every voice's state carry over."""

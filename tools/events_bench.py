@@ -21,4 +21,9 @@ def ev():
     b.events_rewind(0.0)
     b.process_events(T, out=out)
 t_ev = best(ev)
-print(f"events plain render {t_plain:.3f} ms ({V*T/t_plain/1e3:.0f} Msamples/s)  scheduler {t_ev:.3f} ms ({V*T/t_ev/1e3:.0f} Msamples/s)")
+def ev_sustained():          # a launch after every fade has ended: every voice sustains it -> dispatched to the render kernels
+    b.events_rewind(0.2)
+    b.process_events(T, out=out)
+t_sus = best(ev_sustained)
+print(f"events plain render {t_plain:.3f} ms ({V*T/t_plain/1e3:.0f} Msamples/s)  scheduler with fades {t_ev:.3f} ms "
+      f"({V*T/t_ev/1e3:.0f} Msamples/s)  fully sustained launch {t_sus:.3f} ms ({V*T/t_sus/1e3:.0f} Msamples/s)")
