@@ -572,6 +572,16 @@ class Bank {
         check(fdsp_bank_process(h_, frames, d_in, d_out, layout, frame_stride, mode, stream));
     }
     void synchronize() { check(fdsp_bank_synchronize(h_)); }
+    // Sequencer with one event per voice (sequencer.rs:355-398, 838-951): push = set_events (rows of start, end, fade_in,
+    // fade_out in seconds; `fade` FDSP_FADE_POWER / FDSP_FADE_SMOOTH per voice or nullptr), process = process_events
+    void set_events(const std::vector<double>& events_x4, const int* fade = nullptr, size_t first = 0) {
+        check(fdsp_bank_set_events(h_, events_x4.data(), fade, first, events_x4.size() / 4));
+    }
+    void process_events(size_t frames, const float* d_in, float* d_out, int mode = FDSP_MODE_PROCESS, void* stream = nullptr) {
+        check(fdsp_bank_process_events(h_, frames, d_in, d_out, mode, stream));
+    }
+    void events_rewind(double time) { check(fdsp_bank_events_rewind(h_, time)); }
+    double events_time() const { return fdsp_bank_events_time(h_); }
     // Clone (audionode.rs:29): same kind, same parameters and state
     Bank clone() const {
         Bank b(kind_, voices(), ring_frames_);
@@ -586,6 +596,9 @@ class Bank {
     std::string kind_;
     size_t ring_frames_ = 0;
 };
+
+// the Arc<Wave> of playwave(): [channels][length] f32 into sample slot 0..7
+inline void wave_upload(int slot, int channels, size_t length, const float* data) { check(fdsp_wave_upload(slot, channels, length, data)); }
 
 // Wave::render (wave.rs:441-466): set the sample rate, chop `duration` into <= 64-sample blocks, call process.
 // Returns [V * outputs][length] planar.
