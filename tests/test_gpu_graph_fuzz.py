@@ -108,7 +108,7 @@ def build(t, m):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_GRAPHS", "16"))))   # more for a bug hunt
 def test_random_graph_matches_oracle(gpu, seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(int(os.environ.get("FUNDSP_FUZZ_SEED0", "1000")) + seed)
     nin, nout = int(rng.integers(0, 3)), int(rng.integers(1, 3))
     tree = gen(rng, nin, nout, depth=int(rng.integers(3, 6)))
     g = build(tree, GR)
