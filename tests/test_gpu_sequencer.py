@@ -1,5 +1,7 @@
 """On-device voice scheduler vs the oracle's Sequencer restatement (sequencer.rs): every voice's faded contribution must
 match its event's contribution bit for bit, in process and tick semantics; the mix is their sum."""
+import os
+
 import numpy as np
 import pytest
 
@@ -27,12 +29,13 @@ def random_events(V, T, rng):
     return start / SR, (start + dur) / SR, fin / SR, fout / SR, fade
 
 
+@pytest.mark.parametrize("seed", [91 + k for k in range(int(os.environ.get("FUNDSP_FUZZ_EVENTS", "1")))])   # more for a hunt
 @pytest.mark.parametrize("mode", [MODE_PROCESS, MODE_TICK])
-def test_fm_voices_with_events(gpu, mode):
+def test_fm_voices_with_events(gpu, mode, seed):
     import torch
 
     V, T = 70, 64 * 9 + 21
-    rng = np.random.default_rng(91)
+    rng = np.random.default_rng(seed)
     p = W.fm_svf_params(V, SR)
     start, end, fin, fout, fade = random_events(V, T, rng)
     b = W.make_fm_svf_bank(V, SR, params=p)
