@@ -72,10 +72,16 @@ FD_HD float k_tandf(double x, bool odd) {
 
 constexpr double PIO2 = 1.570796326794896558e+00;  // M_PI_2
 
-// musl __rem_pio2f, medium branch (|x| < 2^28*pi/2).  Hot-path arguments never leave [0, 2*pi].
+// musl __rem_pio2f, medium branch (|x| < 2^28*pi/2).  Hot-path arguments never leave [0, 2*pi].  The large-argument
+// branch (__rem_pio2_large, Payne-Hanek) is NOT restated, here or in the oracle: beyond the medium range -- phases past
+// 4e8 radians, cutoffs past 1e8 sample rates -- both sides return NaN by the same rule.
 FD_HD int rem_pio2f(float x, double* y) {
     constexpr double toint = 1.5 / 2.22044604925031308085e-16, invpio2 = 6.36619772367581382433e-01,
                      pio2_1 = 1.57079631090164184570e+00, pio2_1t = 1.58932547735281966916e-08;
+    if ((f2u(x) & 0x7fffffffu) >= 0x4dc90fdbu) {
+        *y = __builtin_nan("");
+        return 0;
+    }
     double fn = (double)x * invpio2 + toint - toint;
     int n = (int32_t)fn;
     *y = x - fn * pio2_1 - fn * pio2_1t;
@@ -103,21 +109,45 @@ FD_HD quad quad_reduce(float x) {
     return q;
 }
 
+// |x| > 9*pi/4, inf, NaN: musl's rem_pio2f branches.  Never taken by wrapped phases or filter arguments, so they live
+// out of line: inlined into every kernel they would only bloat the code around the hot loops.
+#define FD_COLD __host__ __device__ inline __attribute__((noinline))
+FD_COLD float sinf_big(float x) {
+    uint32_t ix = f2u(x) & 0x7fffffffu;
+    if (ix >= 0x7f800000u) return x - x;
+    double y;
+    int n = rem_pio2f(x, &y);
+    switch (n & 3) {
+    case 0: return k_sindf(y);
+    case 1: return k_cosdf(y);
+    case 2: return k_sindf(-y);
+    default: return -k_cosdf(y);
+    }
+}
+FD_COLD float cosf_big(float x) {
+    uint32_t ix = f2u(x) & 0x7fffffffu;
+    if (ix >= 0x7f800000u) return x - x;
+    double y;
+    int n = rem_pio2f(x, &y);
+    switch (n & 3) {
+    case 0: return k_cosdf(y);
+    case 1: return k_sindf(-y);
+    case 2: return -k_cosdf(y);
+    default: return k_sindf(y);
+    }
+}
+FD_COLD float tanf_big(float x) {
+    uint32_t ix = f2u(x) & 0x7fffffffu;
+    if (ix >= 0x7f800000u) return x - x;
+    double y;
+    int n = rem_pio2f(x, &y);
+    return k_tandf(y, (n & 1) != 0);
+}
+
 // musl sinf.c
 FD_HD float sinf_musl(float x) {
     quad q = quad_reduce(x);
-    if (__builtin_expect(q.big, 0)) {
-        uint32_t ix = f2u(x) & 0x7fffffffu;
-        if (ix >= 0x7f800000u) return x - x;
-        double y;
-        int n = rem_pio2f(x, &y);
-        switch (n & 3) {
-        case 0: return k_sindf(y);
-        case 1: return k_cosdf(y);
-        case 2: return k_sindf(-y);
-        default: return -k_cosdf(y);
-        }
-    }
+    if (__builtin_expect(q.big, 0)) return sinf_big(x);
     // k=0: sindf(x); k=1: sign ? -cosdf(y) : cosdf(y); k=2: sindf(-y); k=3: sign ? cosdf(y) : -cosdf(y); k=4: sindf(y)
     double a = q.k == 2 ? -q.y : q.y;
     float s = k_sindf(a);
@@ -132,18 +162,7 @@ FD_HD float sinf_musl(float x) {
 // musl cosf.c
 FD_HD float cosf_musl(float x) {
     quad q = quad_reduce(x);
-    if (__builtin_expect(q.big, 0)) {
-        uint32_t ix = f2u(x) & 0x7fffffffu;
-        if (ix >= 0x7f800000u) return x - x;
-        double y;
-        int n = rem_pio2f(x, &y);
-        switch (n & 3) {
-        case 0: return k_cosdf(y);
-        case 1: return k_sindf(-y);
-        case 2: return -k_cosdf(y);
-        default: return k_sindf(y);
-        }
-    }
+    if (__builtin_expect(q.big, 0)) return cosf_big(x);
     // k=0: cosdf(x); k=1: sign ? sindf(x+c) : sindf(c-x); k=2: -cosdf(y); k=3: sign ? sindf(-x-c) : sindf(x-c); k=4: cosdf(y)
     double a = q.y;
     if (q.k == 1) a = q.sign ? q.y : -q.y;
@@ -158,13 +177,7 @@ FD_HD float cosf_musl(float x) {
 // musl tanf.c
 FD_HD float tanf_musl(float x) {
     quad q = quad_reduce(x);
-    if (__builtin_expect(q.big, 0)) {
-        uint32_t ix = f2u(x) & 0x7fffffffu;
-        if (ix >= 0x7f800000u) return x - x;
-        double y;
-        int n = rem_pio2f(x, &y);
-        return k_tandf(y, (n & 1) != 0);
-    }
+    if (__builtin_expect(q.big, 0)) return tanf_big(x);
     float r = k_tandf(q.y, (q.k & 1) != 0);
     return q.small ? x : r;
 }
