@@ -235,13 +235,13 @@ struct fdsp_bank {
     FdnBank* fdn = nullptr;
     float* ring = nullptr;       // delay-ring memory [ring node][position][voice] for kinds with Delay / Tap nodes
     uint32_t ring_cap = 0;       // positions per ring node
-    const fd::KindOps* ops;
-    size_t V, stride;
-    int nslots;
-    float* slots;
-    hipStream_t stream;
-    hipEvent_t e0, e1;
-    bool timed;
+    const fd::KindOps* ops = nullptr;
+    size_t V = 0, stride = 0;
+    int nslots = 0;
+    float* slots = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool timed = false;
     bool ext_pending = false;  // the last render ran on a caller's stream: bank-stream work must wait for its e1
     double sr;
     std::unordered_map<std::string, int> index;
@@ -464,8 +464,7 @@ int fdsp_bank_create_ring(const char* kind, size_t voices, size_t ring_frames, f
     }
     if (hipStreamCreate(&b->stream) != hipSuccess ||
         hipEventCreate(&b->e0) != hipSuccess || hipEventCreate(&b->e1) != hipSuccess) {
-        hipFree(b->slots);
-        delete b;
+        fdsp_bank_destroy(b);  // frees whatever of {slots, stream, e0, e1} exists
         return fail(FDSP_EDEVICE, "stream/event creation failed");
     }
     if (b->ops->nrings > 0) {
@@ -545,8 +544,7 @@ int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, d
     b->sr = FDSP_DEFAULT_SR;
     if (hipStreamCreate(&b->stream) != hipSuccess || hipEventCreate(&b->e0) != hipSuccess ||
         hipEventCreate(&b->e1) != hipSuccess) {
-        delete b->fdn;
-        delete b;
+        fdsp_bank_destroy(b);
         return fail(FDSP_EDEVICE, "stream/event creation failed");
     }
     int rc = fdn_configure(b, b->sr);
@@ -565,6 +563,8 @@ int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, d
 
 void fdsp_bank_destroy(fdsp_bank* b) {
     if (!b) return;
+    // a render that ran on a caller's stream may still be reading the slots: wait for its completion event first
+    if (b->ext_pending && b->e1) hipEventSynchronize(b->e1);
     if (b->stream) hipStreamSynchronize(b->stream);
     if (b->fdn) {
         fdn_free(b->fdn);
@@ -579,8 +579,8 @@ void fdsp_bank_destroy(fdsp_bank* b) {
     if (b->st_out) hipFree(b->st_out);
     if (b->pin_in) hipHostFree(b->pin_in);
     if (b->pin_out) hipHostFree(b->pin_out);
-    hipEventDestroy(b->e0);
-    hipEventDestroy(b->e1);
+    if (b->e0) hipEventDestroy(b->e0);
+    if (b->e1) hipEventDestroy(b->e1);
     if (b->stream) hipStreamDestroy(b->stream);
     delete b;
 }
