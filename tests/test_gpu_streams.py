@@ -65,3 +65,24 @@ def test_block_launches_captured_into_a_hip_graph(gpu):
         torch.cuda.synchronize()
     got = torch.cat(chunks, dim=1)
     assert torch.equal(ints(got), ints(want))
+
+
+def test_destroying_a_bank_waits_for_its_render_on_a_caller_stream(gpu):
+    """fdsp_bank_destroy right after an asynchronous render on a caller's stream: the output is complete and correct
+    (the teardown waits for the render's completion event before freeing the slots the kernel is reading)."""
+    import torch
+
+    V = 16384
+    p = W.fm_svf_params(V, SR)
+    want = W.make_fm_svf_bank(V, SR, params=p).process(4096)
+    s = torch.cuda.Stream()
+    for _ in range(5):
+        b = W.make_fm_svf_bank(V, SR, params=p)
+        out = torch.empty((1, 4096, V), dtype=torch.float32, device="cuda")
+        with torch.cuda.stream(s):
+            b.process(4096, out=out)              # asynchronous on s
+        b.close()                                 # fdsp_bank_destroy while the kernel may still be running
+        junk = [W.make_fm_svf_bank(V, SR, params=p) for _ in range(2)]   # re-use the freed slot memory at once
+        s.synchronize()
+        assert torch.equal(ints(out), ints(want))
+        del junk
