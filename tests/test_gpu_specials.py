@@ -11,6 +11,7 @@ from fundsp_amd import graph as GR
 from test_gpu_parity import assert_bit_equal, oracle_render, run_bank
 
 pytestmark = pytest.mark.gpu
+SEED0 = int(__import__("os").environ.get("FUNDSP_SPECIALS_SEED0", "0"))   # other draws for a hunt
 SR = 48000.0
 
 GRAPHS = {
@@ -53,13 +54,19 @@ def special_input(V, T, rng):
     x[5, 0, 7] = f32(-0.0)
     x[6, 0, :] *= f32(1e-30)                    # a whole voice down in the tiny range: products underflow to denormals
     x[7, 0, :] *= f32(1e30)                     # and one up where squares overflow
+    if SEED0:                                   # hunt mode: the same specials at other block offsets, plus a few more
+        for v in range(V):
+            x[v, 0] = np.roll(x[v, 0], int(rng.integers(0, T)))
+        pool = np.array([np.inf, -np.inf, np.nan, 1e-41, -1e-41, 3e38, -3e38, 0.0, -0.0, 1e-20, 1e20], dtype=f32)
+        for _ in range(6):
+            x[int(rng.integers(0, V)), 0, int(rng.integers(0, T))] = pool[int(rng.integers(0, len(pool)))]
     return x
 
 
 @pytest.mark.parametrize("name", list(GRAPHS))
 def test_special_values(gpu, name):
     V, T = 9, 64 * 2 + 11
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(7 + SEED0)
     x = special_input(V, T, rng)
     if name == "sine_of_input":
         x = np.abs(x) * np.float32(2000.0)      # a frequency input: inf -> phase inf -> sin(inf)
@@ -84,7 +91,7 @@ def test_special_values(gpu, name):
 @pytest.mark.parametrize("name", list(FREQ_GRAPHS))
 def test_special_frequencies(gpu, name):
     V, T = 9, 64 * 2 + 11
-    rng = np.random.default_rng(8)
+    rng = np.random.default_rng(8 + SEED0)
     with np.errstate(all="ignore"):
         x = np.abs(special_input(V, T, rng)) * np.float32(2000.0)
     x[8, 0, :] = -x[8, 0, :]                    # a negative-frequency voice
