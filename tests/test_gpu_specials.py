@@ -24,7 +24,14 @@ GRAPHS = {
     "follow_meter": lambda m: m.follow(0.01) >> m.meter("peak", 0.01),
     "sine_of_input": lambda m: m.sine(),
     "nl_biquad": lambda m: m.fresonator_hz(m.Tanh(1.0), 700.0, 3.0),
+    # delay lines / feedback loops (denormals flushed inside Feedback graphs like the reference) / dynamics
+    "feedback_echo": lambda m: m.feedback(m.delay(0.001) * 0.9) >> m.lowpole_hz(2000.0),
+    "allnest_delay": lambda m: m.allnest_c(0.5, m.delay(0.002)) >> m.dcblock_hz(20.0),
+    "limiter": lambda m: m.pass_() * 3.0 >> m.limiter(0.002, 0.02),
+    "afollow_declick_pan": lambda m: m.afollow(0.005, 0.05) >> m.declick() >> m.pan(0.3),
+    "eq_chain": lambda m: m.bell_hz(900.0, 1.2, 2.0) >> m.lowshelf_hz(200.0, 0.7, 0.5) >> m.notch_hz(3000.0, 4.0) >> m.allpass_hz(500.0, 1.0),
 }
+RING = 512     # ring positions for the kinds with delay lines (>= the longest delay at SR, a power of two)
 
 
 # oscillators driven by a frequency input that goes huge / infinite / NaN / negative / denormal
@@ -77,7 +84,7 @@ def test_special_values(gpu, name):
         with np.errstate(all="ignore"):
             x = np.where(np.isfinite(x) & (x > np.float32(1e11)), np.float32(np.inf), x).astype(np.float32)
     for mode in (MODE_PROCESS, MODE_TICK):
-        b = gpu.Bank.from_graph(GRAPHS[name](GR), V, sample_rate=SR)
+        b = gpu.Bank.from_graph(GRAPHS[name](GR), V, ring_frames=RING, sample_rate=SR)
         b.set_seed(np.arange(V, dtype=np.uint64))
         with np.errstate(all="ignore"):
             got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, mode)
