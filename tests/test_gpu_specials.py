@@ -29,6 +29,9 @@ GRAPHS = {
     "allnest_delay": lambda m: m.allnest_c(0.5, m.delay(0.002)) >> m.dcblock_hz(20.0),
     "limiter": lambda m: m.pass_() * 3.0 >> m.limiter(0.002, 0.02),
     "afollow_declick_pan": lambda m: m.afollow(0.005, 0.05) >> m.declick() >> m.pan(0.3),
+    # a delay TIME input carrying the specials (clamped like the reference: NaN -> the minimum, inf -> the maximum)
+    "tap_time_in": lambda m: m.split(2) >> (m.pass_() | m.pass_() * 0.004 + 0.003) >> m.tap(0.001, 0.005),
+    "tap_linear_time_in": lambda m: m.split(2) >> (m.pass_() | m.pass_() * 0.004 + 0.003) >> m.tap_linear(0.001, 0.005),
     "eq_chain": lambda m: m.bell_hz(900.0, 1.2, 2.0) >> m.lowshelf_hz(200.0, 0.7, 0.5) >> m.notch_hz(3000.0, 4.0) >> m.allpass_hz(500.0, 1.0),
 }
 RING = 512     # ring positions for the kinds with delay lines (>= the longest delay at SR, a power of two)
