@@ -170,7 +170,11 @@ int fdsp_bank_set_state(fdsp_bank* bank, const float* h_slots);
  * setters, reset, set_seed, get/set_state wait for that render (its completion event) -- in either direction nothing
  * overtakes.  A caller's stream that is being CAPTURED into a HIP graph is supported: the launch is recorded without
  * any host-side synchronisation or event, so a real-time host can capture its block-by-block loop once and replay it
- * (tests/test_gpu_streams.py; 65 536 voices x 64 frames: 20.8 -> 13.3 us per block). */
+ * (tests/test_gpu_streams.py; 65 536 voices x 64 frames: 20.8 -> 13.3 us per block).
+ * Input values: every IEEE value is accepted and treated like the reference treats it (tests/test_gpu_specials.py).
+ * One input sets the COST of a sample rather than its value: the speed input of Resample<X> (resample.rs:281-303) ticks
+ * the enclosed generator `speed` times per output sample, on the device as in the reference -- a speed of 1e9 is a
+ * billion inner ticks in one lane, i.e. a kernel that does not return in useful time.  Bound it on the host. */
 int fdsp_bank_process(fdsp_bank* bank, size_t frames, const float* d_in, float* d_out, int layout,
                       size_t frame_stride, int mode, void* stream);
 /* Same with host buffers (staged through device memory; synchronous).  With voices = 1, layout PLANAR,
