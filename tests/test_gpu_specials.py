@@ -120,3 +120,39 @@ def test_special_frequencies(gpu, name):
                 n.set_sample_rate(SR)
                 n.set_seed(v)
                 assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"{name} voice {v} mode {mode}")
+
+
+# filter PARAMETERS at and past the edges: zero, denormal, at / above Nyquist, huge (tan's argument leaves the restated
+# range -> NaN coefficients on both sides), infinite, NaN, negative.  Coefficients are computed on the device by the
+# same f32 / f64 formulas as the reference's constructors; whatever they give (NaN, inf, an unstable filter), the
+# samples that follow must agree.
+EDGE_HZ = np.array([0.0, 1e-40, 1e-3, 10.0, 23999.0, 24000.0, 24001.0, 47999.0, 1e6, 1e9, 1e30, np.inf, np.nan, -100.0],
+                   dtype=np.float32)
+PARAM_GRAPHS = {
+    "lowpass_hz": lambda m, f: m.lowpass_hz(f, 1.0),
+    "bandpass_q_edge": lambda m, f: m.bandpass_hz(1000.0, f),               # the list / 1000 as Q values
+    "bell_hz": lambda m, f: m.bell_hz(f, 1.5, 2.0),
+    "moog_hz": lambda m, f: m.moog_hz(f, 0.5),
+    "resonator_hz": lambda m, f: m.resonator_hz(f, 50.0),
+    "butterpass_hz": lambda m, f: m.butterpass_hz(f),
+    "onepole_hz": lambda m, f: m.lowpole_hz(f) >> m.highpole_hz(f),
+    "follow": lambda m, f: m.follow(f),                                     # the list / 10000 as response times
+}
+PARAM_SCALE = {"bandpass_q_edge": 1e-3, "follow": 1e-4}   # applied in f32 once, the same values go to both sides
+
+
+@pytest.mark.parametrize("name", list(PARAM_GRAPHS))
+def test_special_parameters(gpu, name):
+    V, T = len(EDGE_HZ), 64 * 2 + 11
+    rng = np.random.default_rng(9 + SEED0)
+    x = (rng.standard_normal((V, 1, T)) * 0.5).astype(np.float32)
+    with np.errstate(all="ignore"):
+        vals = (EDGE_HZ * np.float32(PARAM_SCALE.get(name, 1.0))).astype(np.float32)
+    for mode in (MODE_PROCESS, MODE_TICK):
+        with np.errstate(all="ignore"):
+            b = gpu.Bank.from_graph(PARAM_GRAPHS[name](GR, vals), V, sample_rate=SR)
+            got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, mode)
+            for v in range(V):
+                n = PARAM_GRAPHS[name](O, float(vals[v]))
+                n.set_sample_rate(SR)
+                assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"{name} param {vals[v]} mode {mode}")
