@@ -6,4 +6,4 @@ the thin host-side mirror of the reference's AudioNode surface used by tests and
 from ._lib import (DEFAULT_SR, FADE_POWER, FADE_SMOOTH, LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MAX_BUFFER_SIZE, MODE_PROCESS, MODE_TICK,  # noqa: F401
                    FdspError, lib)
 from .bank import (Bank, biquad_coefs, kind_slots, kinds, mix_stereo, sum_voices, svf_coefs, wavetable_build,  # noqa: F401
-                   wave_upload, wavetable_get, wavetable_upload)
+                   wave_upload, wavetable_compute, wavetable_get, wavetable_upload)

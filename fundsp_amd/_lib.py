@@ -67,6 +67,7 @@ SYMBOLS = {
     "fdsp_wave_upload": (_i, [_i, _i, _sz, _fp]),
     "fdsp_wavetable_upload": (_i, [_i, _i, _fp, C.POINTER(C.c_int), _fp]),
     "fdsp_wavetable_get": (_i, [_i, C.POINTER(C.c_int), _fp, C.POINTER(C.c_int), _fp, _sz]),
+    "fdsp_wavetable_compute": (_i, [_i, C.POINTER(C.c_int), _fp, C.POINTER(C.c_int), _fp, _sz]),
     "fdsp_svf_coefs": (_i, [_i, _f, _f, _f, _f, _fp]),
     "fdsp_biquad_coefs": (_i, [_i, _f, _f, _f, _f, _fp]),
     "fdsp_rnd1": (_d, [_u64]),

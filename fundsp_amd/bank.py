@@ -312,6 +312,19 @@ def wavetable_get(kind):
     return p, [data[offs[i]:offs[i + 1]] for i in range(n.value)]
 
 
+def wavetable_compute(kind):
+    """The built-in table set as fdsp_wavetable_build would install it, computed on the host (no device needed)."""
+    n = C.c_int()
+    check(lib().fdsp_wavetable_compute(WT_SETS[kind], C.byref(n), None, None, None, 0))
+    p = np.zeros(n.value, dtype=np.float32)
+    lengths = np.zeros(n.value, dtype=np.int32)
+    check(lib().fdsp_wavetable_compute(WT_SETS[kind], C.byref(n), _fptr(p), lengths.ctypes.data_as(C.POINTER(C.c_int)), None, 0))
+    data = np.zeros(int(lengths.sum()), dtype=np.float32)
+    check(lib().fdsp_wavetable_compute(WT_SETS[kind], C.byref(n), None, None, _fptr(data), data.size))
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    return p, [data[offs[i]:offs[i + 1]] for i in range(n.value)]
+
+
 def sum_voices(x, stream=None):
     """[channels, frames, V] voice-minor device tensor -> [channels, frames] (deterministic order)."""
     import torch

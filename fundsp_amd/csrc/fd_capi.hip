@@ -81,7 +81,7 @@ int upload_table_set(int set, int n, const float* pitches, const int* lengths, c
     if (set < 0 || set >= fd::WT_SETS || n < 3 || n > fd::WT_MAX_TABLES) return fail(FDSP_EINVAL, "bad wavetable set or table count");
     size_t total = 0;
     for (int i = 0; i < n; i++) {
-        if (lengths[i] <= 0 || (lengths[i] & (lengths[i] - 1))) return fail(FDSP_EINVAL, "table lengths must be powers of two");
+        if (lengths[i] < 4 || (lengths[i] & (lengths[i] - 1))) return fail(FDSP_EINVAL, "table lengths must be powers of two >= 4");
         total += (size_t)lengths[i];
     }
     if (!device_aux()) return fail(FDSP_EDEVICE, "no device memory for wavetables");
@@ -104,6 +104,7 @@ int upload_table_set(int set, int n, const float* pitches, const int* lengths, c
     HIPCHK(hipMalloc((void**)&d, padded.size() * sizeof(float)));
     HIPCHK(hipMemcpy(d, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
     fd::WtSet& w = g_host_aux.wt[set];
+    HIPCHK(hipDeviceSynchronize());  // no render may still read the tables this replaces
     if (w.data) hipFree(const_cast<float*>(w.data));
     w.n = n;
     for (int i = 0; i < n; i++) {
@@ -136,59 +137,75 @@ int upload_wave(int slot, int channels, size_t length, const float* data) {
     return FDSP_OK;
 }
 
-// In-place radix-2 inverse FFT (unnormalised), f32 like the reference's microfft path (fft.rs:51-100).
-void ifft_inplace(std::vector<float>& re, std::vector<float>& im) {
-    const size_t n = re.size();
+// microfft 0.6.0's inverse FFT as the reference's make_wave calls it (fft.rs:51-100, wavetable.rs:75), restated
+// (the crate source is not in the reference tree): in-place f32 radix-2 decimation-in-time complex FFT -- bit-reversal
+// reorder, butterfly stages of span 2, 4, .. N, twiddles exp(-2 pi i k / span) as correctly rounded f32 cosine / sine --
+// with the inverse obtained by reversing elements 1..N, transforming forward and dividing by N.
+struct Cf { float re, im; };
+void cfft_inplace(std::vector<Cf>& x) {
+    const size_t n = x.size();
     for (size_t i = 1, j = 0; i < n; i++) {
         size_t bit = n >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
         j ^= bit;
-        if (i < j) {
-            std::swap(re[i], re[j]);
-            std::swap(im[i], im[j]);
-        }
+        if (i < j) std::swap(x[i], x[j]);
     }
-    for (size_t len = 2; len <= n; len <<= 1) {
-        const double ang = 2.0 * 3.14159265358979323846 / (double)len;
-        for (size_t i = 0; i < n; i += len) {
-            for (size_t k = 0; k < len / 2; k++) {
-                const float wr = (float)std::cos(ang * (double)k), wi = (float)std::sin(ang * (double)k);
-                const size_t a = i + k, b = i + k + len / 2;
-                const float xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
-                re[b] = re[a] - xr;
-                im[b] = im[a] - xi;
-                re[a] = re[a] + xr;
-                im[a] = im[a] + xi;
+    for (size_t span = 2; span <= n; span <<= 1) {
+        const size_t half = span / 2;
+        for (size_t k = 0; k < half; k++) {
+            const double ang = 6.283185307179586476925286766559 * (double)k / (double)span;
+            const float wr = (float)std::cos(ang), wi = (float)-std::sin(ang);
+            for (size_t i = k; i < n; i += span) {
+                Cf& p = x[i];
+                Cf& q = x[i + half];
+                const float yr = wr * q.re - wi * q.im, yi = wr * q.im + wi * q.re;  // Complex32 * Complex32
+                const float ur = p.re, ui = p.im;
+                q.re = ur - yr;
+                q.im = ui - yi;
+                p.re = ur + yr;
+                p.im = ui + yi;
             }
         }
     }
 }
+void ifft_inplace(std::vector<Cf>& x) {
+    std::reverse(x.begin() + 1, x.end());
+    cfft_inplace(x);
+    const float fn = (float)x.size();
+    for (Cf& c : x) {
+        c.re = c.re / fn;
+        c.im = c.im / fn;
+    }
+}
 
 // Wavetable::new + make_wave (wavetable.rs:44-123) for the built-in shapes (saw_table :493, square_table :510,
-// triangle_table :523, organ_table :546, soft_saw_table :574, hammond_table :598).  Table bits are not pinned against the reference (its FFT lives in the microfft crate).
-int build_default_table_set(int set) {
-    auto phase = [set](unsigned i) -> double {
+// triangle_table :523, organ_table :546, soft_saw_table :574, hammond_table :598).  Every step in the reference's
+// precision and order (f64 partial weights, f32 polar insert, f32 FFT, f32 peak normalisation): the tables come out
+// bit-identical to the CPU oracle's restatement (tests/test_gpu_config4.py builds them here and compares).
+int compute_default_table_set(int set, std::vector<float>& pitches, std::vector<int>& lengths, std::vector<float>& data) {
+    auto phase = [set](uint32_t i) -> double {
         if (set == 0) return (i & 1) == 1 ? 0.0 : 0.5;
         if (set == 1 || set == 6) return 0.0;
         if (set == 2) return (i & 3) == 3 ? 0.5 : 0.0;
         return (i & 3) == 3 ? 0.5 : ((i & 1) == 1 ? 0.0 : 0.5);  // organ, soft saw
     };
-    auto amplitude = [set](unsigned i) -> double {
+    auto amplitude = [set](uint32_t i) -> double {  // the closures compute in u32 before the cast to f64
         if (set == 0) return 1.0 / (double)i;
         if (set == 1) return (i & 1) == 1 ? 1.0 / (double)i : 0.0;
-        if (set == 2) return (i & 1) == 1 ? 1.0 / ((double)i * (double)i) : 0.0;
-        if (set == 5) return 1.0 / ((double)i * (double)i);
-        unsigned z = (unsigned)__builtin_ctz(i), j = i >> z;
-        if (set == 4) return 1.0 / (double)((uint64_t)i + (uint64_t)j * j * j);
+        if (set == 2) return (i & 1) == 1 ? 1.0 / (double)(uint32_t)(i * i) : 0.0;
+        if (set == 5) return 1.0 / (double)(uint32_t)(i * i);
+        const uint32_t z = (uint32_t)__builtin_ctz(i), j = i >> z;
+        if (set == 4) return 1.0 / (double)(uint32_t)(i + j * j * j);
         // hammond
-        const double f = 1.0 / (double)((z + 1) * (z + 1));
+        const double f = 1.0 / (double)(uint32_t)((z + 1) * (z + 1));
         if (i <= 3) return 1.0;
         return j == 1 || j == 3 ? f : (j == 9 ? 0.2 * f : 0.0);
     };
     if (!(set >= 0 && set <= 2) && !(set >= 4 && set <= 6))
         return fail(FDSP_EINVAL, "built-in table sets: 0 saw, 1 square, 2 triangle, 4 organ, 5 soft saw, 6 hammond");
-    std::vector<float> pitches, data;
-    std::vector<int> lengths;
+    pitches.clear();
+    lengths.clear();
+    data.clear();
     const double p_factor = std::pow(2.0, 1.0 / 4.0);
     float max_amplitude = 0.0f;
     for (double pitch = 20.0; pitch <= 20000.0; pitch *= p_factor) {
@@ -196,22 +213,23 @@ int build_default_table_set(int set) {
         size_t length = 1;
         while (length < 4 * harmonics) length <<= 1;
         length = length < 32 ? 32 : (length > 8192 ? 8192 : length);
-        std::vector<float> re(length, 0.0f), im(length, 0.0f);
+        std::vector<Cf> a(length, Cf{0.0f, 0.0f});
         for (size_t i = 1; i <= harmonics; i++) {
             const double f = pitch * (double)i;
-            double x = (f - 22000.0) / (20000.0 - 22000.0);
-            x = x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x);
-            const double w = amplitude((unsigned)i) * (((x * 6 - 15) * x + 10) * x * x * x);  // smooth5
-            if (w > 0.0) {
-                const float r = (float)w, theta = (float)(6.283185307179586 * phase((unsigned)i));
-                re[i] = r * std::cos(theta);
-                im[i] = r * std::sin(theta);
+            double x = (f - 22000.0) / (20000.0 - 22000.0);            // delerp(MAX_F, FADE_F, f)
+            x = std::fmin(std::fmax(x, 0.0), 1.0);                     // clamp01
+            const double w = amplitude((uint32_t)i) * (((x * 6.0 - 15.0) * x + 10.0) * x * x * x);  // smooth5
+            if (w > 0.0) {  // Complex32::from_polar(w as f32, (TAU * phase) as f32)
+                const float r = (float)w, theta = (float)(6.283185307179586476925286766559 * phase((uint32_t)i));
+                a[i] = Cf{r * fd::cosf_musl(theta), r * fd::sinf_musl(theta)};
             }
         }
-        ifft_inplace(re, im);  // microfft's ifft divides by N and make_wave multiplies by N again: net unnormalised
+        ifft_inplace(a);
+        const float z = (float)length;
         for (size_t k = 0; k < length; k++) {
-            max_amplitude = std::fmax(max_amplitude, std::fabs(im[k]));
-            data.push_back(im[k]);
+            const float v = a[k].im * z;
+            max_amplitude = std::fmax(max_amplitude, std::fabs(v));
+            data.push_back(v);
         }
         pitches.push_back((float)pitch);
         lengths.push_back((int)length);
@@ -220,6 +238,13 @@ int build_default_table_set(int set) {
         const float z = 1.0f / max_amplitude;
         for (float& x : data) x *= z;
     }
+    return FDSP_OK;
+}
+int build_default_table_set(int set) {
+    std::vector<float> pitches, data;
+    std::vector<int> lengths;
+    const int rc = compute_default_table_set(set, pitches, lengths, data);
+    if (rc != FDSP_OK) return rc;
     return upload_table_set(set, (int)pitches.size(), pitches.data(), lengths.data(), data.data());
 }
 
@@ -1000,6 +1025,21 @@ int fdsp_wavetable_upload(int set, int n_tables, const float* h_pitches, const i
 }
 
 int fdsp_wavetable_build(int set) { return build_default_table_set(set); }
+int fdsp_wavetable_compute(int set, int* n_tables, float* h_pitches, int* h_lengths, float* h_data, size_t capacity) {
+    if (!n_tables) return fail(FDSP_EINVAL, "NULL n_tables");
+    std::vector<float> pitches, data;
+    std::vector<int> lengths;
+    const int rc = compute_default_table_set(set, pitches, lengths, data);
+    if (rc != FDSP_OK) return rc;
+    *n_tables = (int)pitches.size();
+    if (h_pitches) std::memcpy(h_pitches, pitches.data(), sizeof(float) * pitches.size());
+    if (h_lengths) std::memcpy(h_lengths, lengths.data(), sizeof(int) * lengths.size());
+    if (h_data) {
+        if (capacity < data.size()) return fail(FDSP_EINVAL, "capacity too small");
+        std::memcpy(h_data, data.data(), sizeof(float) * data.size());
+    }
+    return FDSP_OK;
+}
 int fdsp_wave_upload(int slot, int channels, size_t length, const float* h_data) { return upload_wave(slot, channels, length, h_data); }
 
 int fdsp_wavetable_get(int set, int* n_tables, float* h_pitches, int* h_lengths, float* h_data, size_t capacity) {

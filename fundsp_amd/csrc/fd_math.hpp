@@ -72,15 +72,130 @@ FD_HD float k_tandf(double x, bool odd) {
 
 constexpr double PIO2 = 1.570796326794896558e+00;  // M_PI_2
 
-// musl __rem_pio2f, medium branch (|x| < 2^28*pi/2).  Hot-path arguments never leave [0, 2*pi].  The large-argument
-// branch (__rem_pio2_large, Payne-Hanek) is NOT restated, here or in the oracle: beyond the medium range -- phases past
-// 4e8 radians, cutoffs past 1e8 sample rates -- both sides return NaN by the same rule.
+#define FD_COLD __host__ __device__ inline __attribute__((noinline))
+
+// musl __rem_pio2_large.c (libm crate src/math/rem_pio2_large.rs), the Payne-Hanek reduction, for the f32 callers:
+// one 24-bit chunk x0 in [2^23, 2^24) (nx = 1, jx = 0), prec = 0 (jk = jp = 3).  Same loops, same order of operations
+// as the published routine; only reached for |x| >= 2^28*pi/2, so it lives out of line (its arrays are scratch memory).
+FD_COLD int rem_pio2_large1(double x0, int e0, double* y) {
+    // ipio2[]: the bits of 2/pi in 24-bit pieces; PIo2[]: pi/2 in 24-bit-mantissa pieces (musl tables)
+    static constexpr int32_t IPIO2[66] = {
+        0xA2F983, 0x6E4E44, 0x1529FC, 0x2757D1, 0xF534DD, 0xC0DB62, 0x95993C, 0x439041, 0xFE5163, 0xABDEBB, 0xC561B7,
+        0x246E3A, 0x424DD2, 0xE00649, 0x2EEA09, 0xD1921C, 0xFE1DEB, 0x1CB129, 0xA73EE8, 0x8235F5, 0x2EBB44, 0x84E99C,
+        0x7026B4, 0x5F7E41, 0x3991D6, 0x398353, 0x39F49C, 0x845F8B, 0xBDF928, 0x3B1FF8, 0x97FFDE, 0x05980F, 0xEF2F11,
+        0x8B5A0A, 0x6D1F6D, 0x367ECF, 0x27CB09, 0xB74F46, 0x3F669E, 0x5FEA2D, 0x7527BA, 0xC7EBE5, 0xF17B3D, 0x0739F7,
+        0x8A5292, 0xEA6BFB, 0x5FB11F, 0x8D5D08, 0x560330, 0x46FC7B, 0x6BABF0, 0xCFBC20, 0x9AF436, 0x1DA9E3, 0x91615E,
+        0xE61B08, 0x659985, 0x5F14A0, 0x68408D, 0xFFD880, 0x4D7327, 0x310606, 0x1556CA, 0x73A8C9, 0x60E27B, 0xC08C6B};
+    static constexpr double PIO2_CHUNKS[8] = {
+        1.57079625129699707031e+00, 7.54978941586159635335e-08, 5.39030252995776476554e-15, 3.28200341580791294123e-22,
+        1.27065575308067607349e-29, 1.22933308981111328932e-36, 2.73370053816464559624e-44, 2.16741683877804819444e-51,
+    };
+    constexpr int jk = 3, jp = 3;
+    int32_t jz, jv, carry, n, iq[20], i, j, k, q0, ih;
+    double z, fw, f[20], fq[20], q[20];
+    jv = (e0 - 3) / 24;
+    if (jv < 0) jv = 0;
+    q0 = e0 - 24 * (jv + 1);
+    for (i = 0, j = jv; i <= jk; i++, j++) f[i] = (double)IPIO2[j];
+    for (i = 0; i <= jk; i++) q[i] = 0.0 + x0 * f[i];
+    jz = jk;
+    for (;;) {
+        for (i = 0, j = jz, z = q[jz]; j > 0; i++, j--) {  // distill q[] into iq[] reversingly
+            fw = (double)(int32_t)(0x1p-24 * z);
+            iq[i] = (int32_t)(z - 0x1p24 * fw);
+            z = q[j - 1] + fw;
+        }
+        z = __builtin_scalbn(z, q0);
+        z -= 8.0 * __builtin_floor(z * 0.125);
+        n = (int32_t)z;
+        z -= (double)n;
+        ih = 0;
+        if (q0 > 0) {
+            i = iq[jz - 1] >> (24 - q0);
+            n += i;
+            iq[jz - 1] -= i << (24 - q0);
+            ih = iq[jz - 1] >> (23 - q0);
+        } else if (q0 == 0)
+            ih = iq[jz - 1] >> 23;
+        else if (z >= 0.5)
+            ih = 2;
+        if (ih > 0) {  // q > 0.5
+            n += 1;
+            carry = 0;
+            for (i = 0; i < jz; i++) {
+                j = iq[i];
+                if (carry == 0) {
+                    if (j != 0) {
+                        carry = 1;
+                        iq[i] = 0x1000000 - j;
+                    }
+                } else
+                    iq[i] = 0xffffff - j;
+            }
+            if (q0 == 1) iq[jz - 1] &= 0x7fffff;
+            if (q0 == 2) iq[jz - 1] &= 0x3fffff;
+            if (ih == 2) {
+                z = 1.0 - z;
+                if (carry != 0) z -= __builtin_scalbn(1.0, q0);
+            }
+        }
+        if (z != 0.0) break;
+        j = 0;
+        for (i = jz - 1; i >= jk; i--) j |= iq[i];
+        if (j != 0) break;
+        for (k = 1; iq[jk - k] == 0; k++) {}  // recomputation: k more terms
+        for (i = jz + 1; i <= jz + k; i++) {
+            f[i] = (double)IPIO2[jv + i];
+            q[i] = 0.0 + x0 * f[i];
+        }
+        jz += k;
+    }
+    if (z == 0.0) {  // chop off zero terms
+        jz -= 1;
+        q0 -= 24;
+        while (iq[jz] == 0) {
+            jz--;
+            q0 -= 24;
+        }
+    } else {  // break z into 24-bit if necessary
+        z = __builtin_scalbn(z, -q0);
+        if (z >= 0x1p24) {
+            fw = (double)(int32_t)(0x1p-24 * z);
+            iq[jz] = (int32_t)(z - 0x1p24 * fw);
+            jz += 1;
+            q0 += 24;
+            iq[jz] = (int32_t)fw;
+        } else
+            iq[jz] = (int32_t)z;
+    }
+    fw = __builtin_scalbn(1.0, q0);
+    for (i = jz; i >= 0; i--) {
+        q[i] = fw * (double)iq[i];
+        fw *= 0x1p-24;
+    }
+    for (i = jz; i >= 0; i--) {
+        for (fw = 0.0, k = 0; k <= jp && k <= jz - i; k++) fw += PIO2_CHUNKS[k] * q[i + k];
+        fq[jz - i] = fw;
+    }
+    fw = 0.0;
+    for (i = jz; i >= 0; i--) fw += fq[i];
+    *y = ih == 0 ? fw : -fw;
+    return n & 7;
+}
+
+// musl __rem_pio2f.c (libm crate src/math/rem_pio2f.rs): medium branch for |x| < 2^28*pi/2, the rest through
+// __rem_pio2_large on the mantissa scaled into [2^23, 2^24).  inf / NaN are handled by the callers.
 FD_HD int rem_pio2f(float x, double* y) {
     constexpr double toint = 1.5 / 2.22044604925031308085e-16, invpio2 = 6.36619772367581382433e-01,
                      pio2_1 = 1.57079631090164184570e+00, pio2_1t = 1.58932547735281966916e-08;
-    if ((f2u(x) & 0x7fffffffu) >= 0x4dc90fdbu) {
-        *y = __builtin_nan("");
-        return 0;
+    const uint32_t ix = f2u(x) & 0x7fffffffu;
+    if (ix >= 0x4dc90fdbu) {
+        const int e0 = (int)(ix >> 23) - (0x7f + 23);
+        double ty;
+        const int n = rem_pio2_large1((double)u2f(ix - ((uint32_t)e0 << 23)), e0, &ty);
+        const bool sign = (f2u(x) >> 31) != 0;
+        *y = sign ? -ty : ty;
+        return sign ? -n : n;
     }
     double fn = (double)x * invpio2 + toint - toint;
     int n = (int32_t)fn;
@@ -111,7 +226,6 @@ FD_HD quad quad_reduce(float x) {
 
 // |x| > 9*pi/4, inf, NaN: musl's rem_pio2f branches.  Never taken by wrapped phases or filter arguments, so they live
 // out of line: inlined into every kernel they would only bloat the code around the hot loops.
-#define FD_COLD __host__ __device__ inline __attribute__((noinline))
 FD_COLD float sinf_big(float x) {
     uint32_t ix = f2u(x) & 0x7fffffffu;
     if (ix >= 0x7f800000u) return x - x;
@@ -373,6 +487,15 @@ FD_HD float expf_musl(float x) {
 }
 
 // ---- wide f32x8::sin, one lane (all f32, unfused) --------------------------------------------------------
+// f32x8::round_int of an integral value: NaN -> 0, saturating at both ends on every platform wide supports (its x86
+// form masks NaNs and flips lanes >= 2^31 to i32::MAX around cvtps2dq).  On gfx950 this is what v_cvt_i32_f32 does.
+FD_HD int32_t round_int_sat(float y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int32_t)y;
+#else
+    return y != y ? 0 : y >= 2147483648.0f ? INT32_MAX : y <= -2147483648.0f ? INT32_MIN : (int32_t)y;
+#endif
+}
 FD_HD float wide_sinf(float self) {
     constexpr float DP1F = 0.78515625f * 2.0f;
     constexpr float DP2F = 2.4187564849853515625E-4f * 2.0f;
@@ -382,7 +505,7 @@ FD_HD float wide_sinf(float self) {
     constexpr float TWO_OVER_PI = 2.0f / 3.14159274101257324f;
     float xa = __builtin_fabsf(self);
     float y = __builtin_rintf(xa * TWO_OVER_PI);  // round half to even (v_rndne_f32)
-    int32_t q = (int32_t)y;
+    int32_t q = round_int_sat(y);
     float x = xa - y * DP1F;
     x = x - y * DP2F;
     x = x - y * DP3F;

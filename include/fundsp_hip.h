@@ -234,6 +234,11 @@ int fdsp_wavetable_upload(int set, int n_tables, const float* h_pitches, const i
  * prelude32.rs:2225-2248): `slot` 0..7, data [channels][length] f32.  The WavePlayer<slot> node of a graph reads it. */
 int fdsp_wave_upload(int slot, int channels, size_t length, const float* h_data);
 int fdsp_wavetable_get(int set, int* n_tables, float* h_pitches, int* h_lengths, float* h_data, size_t capacity);
+/* The tables fdsp_wavetable_build(set) would install, computed on the host and returned without touching a device
+ * (Wavetable::new + make_wave, wavetable.rs:44-123: f64 partial weights, f32 polar insert, f32 radix-2 inverse FFT,
+ * f32 peak normalisation).  Bit-identical to the oracle's restatement (tests/test_wavetable_build.py); versus a
+ * double-precision FFT of the same spectrum they differ by < 1e-6.  Pass NULL data to query n_tables / lengths. */
+int fdsp_wavetable_compute(int set, int* n_tables, float* h_pitches, int* h_lengths, float* h_data, size_t capacity);
 
 /* ---- host-side helpers that restate reference coefficient constructors with the engine's own math --------- */
 int fdsp_svf_coefs(int mode, float sample_rate, float cutoff, float q, float gain, float* out6);     /* svf.rs:28-221 */

@@ -166,6 +166,8 @@ void o_render_ticks(onode *n, size_t length, const float *in, float *out);
 void o_svf_coefs(int mode, float sr, float cutoff, float q, float gain, float *out6);
 void o_biquad_coefs(int kind, float sr, float f, float q, float gain, float *out5);
 void o_moog_coefs(float sr, float cutoff, float q, float *out3);
+/* Wavetable::new for a built-in table (o_wavetable.c): 0 saw, 1 square, 2 triangle, 4 organ, 5 soft saw, 6 hammond */
+int o_make_wavetable(int kind, int max_tables, float *pitches, int *lengths, size_t data_cap, float *data);
 float o_math_sinf(float x);
 float o_math_cosf(float x);
 float o_math_tanf(float x);

@@ -77,21 +77,186 @@ static inline float o_k_tandf(double x, int odd) {
     return (float)(odd ? -1.0 / r : r);
 }
 
-/* musl __rem_pio2f, medium-size branch only (|x| < 2^28*pi/2). Larger arguments never occur on the
- * hot path (phases are wrapped to [0,1), filter arguments are < pi); they return n=0,y=NaN here. */
+/* musl __rem_pio2_large.c (FreeBSD k_rem_pio2.c; libm crate: src/math/rem_pio2_large.rs), the Payne-Hanek reduction
+ * behind |x| >= 2^28*pi/2.  Restated with its general loops; the callers here are the f32 functions, which pass ONE
+ * 24-bit chunk (nx = 1) at prec = 0 (jk = 3).  ipio2[] = the bits of 2/pi in 24-bit pieces (regenerated from a
+ * big-integer pi, first entries 0xA2F983 0x6E4E44 ... as published); PIo2[] = pi/2 in 24-bit-mantissa pieces. */
+static const int32_t o_ipio2[66] = {
+    0xA2F983, 0x6E4E44, 0x1529FC, 0x2757D1, 0xF534DD, 0xC0DB62, 0x95993C, 0x439041, 0xFE5163, 0xABDEBB, 0xC561B7,
+    0x246E3A, 0x424DD2, 0xE00649, 0x2EEA09, 0xD1921C, 0xFE1DEB, 0x1CB129, 0xA73EE8, 0x8235F5, 0x2EBB44, 0x84E99C,
+    0x7026B4, 0x5F7E41, 0x3991D6, 0x398353, 0x39F49C, 0x845F8B, 0xBDF928, 0x3B1FF8, 0x97FFDE, 0x05980F, 0xEF2F11,
+    0x8B5A0A, 0x6D1F6D, 0x367ECF, 0x27CB09, 0xB74F46, 0x3F669E, 0x5FEA2D, 0x7527BA, 0xC7EBE5, 0xF17B3D, 0x0739F7,
+    0x8A5292, 0xEA6BFB, 0x5FB11F, 0x8D5D08, 0x560330, 0x46FC7B, 0x6BABF0, 0xCFBC20, 0x9AF436, 0x1DA9E3, 0x91615E,
+    0xE61B08, 0x659985, 0x5F14A0, 0x68408D, 0xFFD880, 0x4D7327, 0x310606, 0x1556CA, 0x73A8C9, 0x60E27B, 0xC08C6B};
+static const double o_PIo2[8] = {
+    1.57079625129699707031e+00, /* 0x3FF921FB, 0x40000000 */
+    7.54978941586159635335e-08, /* 0x3E74442D, 0x00000000 */
+    5.39030252995776476554e-15, /* 0x3CF84698, 0x80000000 */
+    3.28200341580791294123e-22, /* 0x3B78CC51, 0x60000000 */
+    1.27065575308067607349e-29, /* 0x39F01B83, 0x80000000 */
+    1.22933308981111328932e-36, /* 0x387A2520, 0x40000000 */
+    2.73370053816464559624e-44, /* 0x36E38222, 0x80000000 */
+    2.16741683877804819444e-51, /* 0x3569F31D, 0x00000000 */
+};
+
+static inline int o_rem_pio2_large(const double *x, double *y, int e0, int nx) {
+    const int jk = 3, jp = 3; /* init_jk[prec = 0] */
+    int32_t jz, jx, jv, carry, n, iq[20], i, j, k, m, q0, ih;
+    double z, fw, f[20], fq[20], q[20];
+
+    /* determine jx, jv, q0 (note that 3 > q0) */
+    jx = nx - 1;
+    jv = (e0 - 3) / 24;
+    if (jv < 0) jv = 0;
+    q0 = e0 - 24 * (jv + 1);
+
+    /* set up f[0] to f[jx+jk] where f[jx+jk] = ipio2[jv+jk] */
+    j = jv - jx;
+    m = jx + jk;
+    for (i = 0; i <= m; i++, j++) f[i] = j < 0 ? 0.0 : (double)o_ipio2[j];
+
+    /* compute q[0], q[1], ... q[jk] */
+    for (i = 0; i <= jk; i++) {
+        for (j = 0, fw = 0.0; j <= jx; j++) fw += x[j] * f[jx + i - j];
+        q[i] = fw;
+    }
+
+    jz = jk;
+recompute:
+    /* distill q[] into iq[] reversingly */
+    for (i = 0, j = jz, z = q[jz]; j > 0; i++, j--) {
+        fw = (double)(int32_t)(0x1p-24 * z);
+        iq[i] = (int32_t)(z - 0x1p24 * fw);
+        z = q[j - 1] + fw;
+    }
+
+    /* compute n */
+    z = scalbn(z, q0);           /* actual value of z */
+    z -= 8.0 * floor(z * 0.125); /* trim off integer >= 8 */
+    n = (int32_t)z;
+    z -= (double)n;
+    ih = 0;
+    if (q0 > 0) { /* need iq[jz-1] to determine n */
+        i = iq[jz - 1] >> (24 - q0);
+        n += i;
+        iq[jz - 1] -= i << (24 - q0);
+        ih = iq[jz - 1] >> (23 - q0);
+    } else if (q0 == 0)
+        ih = iq[jz - 1] >> 23;
+    else if (z >= 0.5)
+        ih = 2;
+
+    if (ih > 0) { /* q > 0.5 */
+        n += 1;
+        carry = 0;
+        for (i = 0; i < jz; i++) { /* compute 1-q */
+            j = iq[i];
+            if (carry == 0) {
+                if (j != 0) {
+                    carry = 1;
+                    iq[i] = 0x1000000 - j;
+                }
+            } else
+                iq[i] = 0xffffff - j;
+        }
+        if (q0 > 0) { /* rare case: chance is 1 in 12 */
+            switch (q0) {
+            case 1: iq[jz - 1] &= 0x7fffff; break;
+            case 2: iq[jz - 1] &= 0x3fffff; break;
+            }
+        }
+        if (ih == 2) {
+            z = 1.0 - z;
+            if (carry != 0) z -= scalbn(1.0, q0);
+        }
+    }
+
+    /* check if recomputation is needed */
+    if (z == 0.0) {
+        j = 0;
+        for (i = jz - 1; i >= jk; i--) j |= iq[i];
+        if (j == 0) { /* need recomputation */
+            for (k = 1; iq[jk - k] == 0; k++) {} /* k = no. of terms needed */
+            for (i = jz + 1; i <= jz + k; i++) { /* add q[jz+1] to q[jz+k] */
+                f[jx + i] = (double)o_ipio2[jv + i];
+                for (j = 0, fw = 0.0; j <= jx; j++) fw += x[j] * f[jx + i - j];
+                q[i] = fw;
+            }
+            jz += k;
+            goto recompute;
+        }
+    }
+
+    /* chop off zero terms */
+    if (z == 0.0) {
+        jz -= 1;
+        q0 -= 24;
+        while (iq[jz] == 0) {
+            jz--;
+            q0 -= 24;
+        }
+    } else { /* break z into 24-bit if necessary */
+        z = scalbn(z, -q0);
+        if (z >= 0x1p24) {
+            fw = (double)(int32_t)(0x1p-24 * z);
+            iq[jz] = (int32_t)(z - 0x1p24 * fw);
+            jz += 1;
+            q0 += 24;
+            iq[jz] = (int32_t)fw;
+        } else
+            iq[jz] = (int32_t)z;
+    }
+
+    /* convert integer "bit" chunk to floating-point value */
+    fw = scalbn(1.0, q0);
+    for (i = jz; i >= 0; i--) {
+        q[i] = fw * (double)iq[i];
+        fw *= 0x1p-24;
+    }
+
+    /* compute PIo2[0,...,jp]*q[jz,...,0] */
+    for (i = jz; i >= 0; i--) {
+        for (fw = 0.0, k = 0; k <= jp && k <= jz - i; k++) fw += o_PIo2[k] * q[i + k];
+        fq[jz - i] = fw;
+    }
+
+    /* compress fq[] into y[] (prec 0) */
+    fw = 0.0;
+    for (i = jz; i >= 0; i--) fw += fq[i];
+    y[0] = ih == 0 ? fw : -fw;
+    return n & 7;
+}
+
+/* musl __rem_pio2f.c (libm crate: src/math/rem_pio2f.rs): medium branch for |x| < 2^28*pi/2, inf/NaN -> NaN,
+ * everything else through __rem_pio2_large on the mantissa scaled into [2^23, 2^24). */
 static inline int o_rem_pio2f(float x, double *y) {
     static const double toint = 1.5 / DBL_EPSILON, invpio2 = 6.36619772367581382433e-01, /* 0x3FE45F30, 0x6DC9C883 */
         pio2_1 = 1.57079631090164184570e+00,                                           /* 0x3FF921FB, 0x50000000 */
         pio2_1t = 1.58932547735281966916e-08;                                          /* 0x3E5110b4, 0x611A6263 */
     uint32_t ix = o_f2u(x) & 0x7fffffff;
+    double tx[1], ty[1];
+    int n, sign, e0;
     if (ix < 0x4dc90fdb) { /* |x| ~< 2^28*(pi/2), medium size */
         double fn = (double)x * invpio2 + toint - toint;
-        int n = (int32_t)fn;
+        n = (int32_t)fn;
         *y = x - fn * pio2_1 - fn * pio2_1t;
         return n;
     }
-    *y = NAN;
-    return 0;
+    if (ix >= 0x7f800000) { /* x is inf or NaN */
+        *y = x - x;
+        return 0;
+    }
+    /* scale x into [2^23, 2^24-1] */
+    sign = (int)(o_f2u(x) >> 31);
+    e0 = (int)(ix >> 23) - (0x7f + 23); /* e0 = ilogb(|x|)-23, positive */
+    tx[0] = (double)o_u2f(ix - ((uint32_t)e0 << 23));
+    n = o_rem_pio2_large(tx, ty, e0, 1);
+    if (sign) {
+        *y = -ty[0];
+        return -n;
+    }
+    *y = ty[0];
+    return n;
 }
 
 #define O_PIO2 1.570796326794896558e+00 /* M_PI_2 */
@@ -609,6 +774,16 @@ static inline float o_powf(float x, float y) {
  *      what `wide` compiles to for a default x86-64 `cargo build` (no `fma` target feature). ---------- */
 static inline float o_round_half_even(float x) { return nearbyintf(x); } /* default rounding mode */
 
+/* wide's f32x8::round_int (NOT fast_round_int) is defined for every input: its x86 form masks NaN lanes to 0 and
+ * flips lanes >= 2^31 to i32::MAX around cvtps2dq (the sequence it cites from V8), its wasm / NEON / portable forms
+ * are saturating conversions -- so: NaN -> 0, >= 2^31 -> i32::MAX, <= -2^31 -> i32::MIN on every platform. */
+static inline int32_t o_round_int_sat(float y) {
+    if (y != y) return 0;
+    if (y >= 2147483648.0f) return INT32_MAX;
+    if (y <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)y;
+}
+
 static inline float o_wide_sinf(float self) {
     const float DP1F = 0.78515625f * 2.0f;
     const float DP2F = 2.4187564849853515625E-4f * 2.0f;
@@ -619,7 +794,7 @@ static inline float o_wide_sinf(float self) {
 
     float xa = fabsf(self);
     float y = o_round_half_even(xa * TWO_OVER_PI);
-    int32_t q = (int32_t)y; /* round_int of an already-integral value */
+    int32_t q = o_round_int_sat(y); /* f32x8::round_int of an already-integral value */
     float x = xa - y * DP1F;
     x = x - y * DP2F;
     x = x - y * DP3F;

@@ -69,6 +69,7 @@ def lib():
         "o_math_rnd1": (d, [u64]), "o_math_hash1": (u64, [u64]), "o_math_atto": (u64, [u64, u64]),
         "o_math_hash32x": (C.c_uint32, [C.c_uint32]),
         "o_bank_render": (d, [C.POINTER(BankJob), fp]),
+        "o_make_wavetable": (i, [i, i, fp, C.POINTER(C.c_int), C.c_size_t, fp]),
         "o_wavetable_create": (P, [i, fp, C.POINTER(C.c_int), fp]), "o_wavetable_free": (None, [P]),
         "o_wavesynth": (P, [P, i]), "o_phasesynth": (P, [P]), "o_waveplayer": (P, [fp, i, C.c_size_t, i, C.c_size_t, C.c_size_t, C.c_long]), "o_wrap": (P, [P, u64]), "o_wavesynth_set_phase": (None, [P, f]),
         "o_adsr_live": (P, [f, f, f, f]), "o_panner": (P, [i, f]),
@@ -351,7 +352,24 @@ def delay(t): return Node(lib().o_delay(float(t)))
 def _smooth5(x): return ((x * 6 - 15) * x + 10) * x * x * x
 
 
-def make_wavetable_arrays(kind="saw", min_pitch=20.0, max_pitch=20000.0, tables_per_octave=4.0):
+WT_KINDS = dict(saw=0, square=1, triangle=2, organ=4, soft_saw=5, hammond=6)
+
+
+def make_wavetable_arrays(kind="saw"):
+    """Wavetable::new(20, 20000, 4, ..) for a built-in table: the oracle's C restatement (oracle/o_wavetable.c: make_wave
+    with the f32 radix-2 inverse FFT restated from microfft, global normalisation in f32)."""
+    pitches = np.zeros(64, dtype=np.float32)
+    lengths = np.zeros(64, dtype=np.int32)
+    data = np.zeros(64 * 8192, dtype=np.float32)
+    n = lib().o_make_wavetable(WT_KINDS[kind], 64, _fptr(pitches), lengths.ctypes.data_as(C.POINTER(C.c_int)), data.size, _fptr(data))
+    assert n > 0
+    offs = np.concatenate([[0], np.cumsum(lengths[:n])])
+    return pitches[:n].copy(), [data[offs[k]:offs[k + 1]].copy() for k in range(n)]
+
+
+def make_wavetable_arrays_f64(kind="saw", min_pitch=20.0, max_pitch=20000.0, tables_per_octave=4.0):
+    """Independent double-precision construction of the same tables (numpy complex128 inverse FFT): the yardstick that
+    bounds the f32 FFT restatement's error in tests/test_wavetable_build.py -- not used by any parity test."""
     def phase(i):
         if kind == "saw": return 0.0 if (i & 1) == 1 else 0.5
         if kind in ("square", "hammond"): return 0.0

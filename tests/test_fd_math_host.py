@@ -22,3 +22,19 @@ def test_wide_sin2_matches_wide_sinf_on_host(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bad 0" in r.stdout
+
+
+def test_device_trig_header_matches_oracle_over_the_whole_f32_range(tmp_path):
+    """fd_math.hpp's sinf/cosf/tanf (host build) vs oracle/o_math.h, bit for bit, 20M arguments of every exponent incl.
+    the Payne-Hanek branch, inf and NaN."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = tmp_path / "check_trig_big"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-std=c++17", "-Wno-unused-result",
+           "-I", os.path.join(ROOT, "fundsp_amd", "csrc"), "-I", os.path.join(ROOT, "oracle"), "-o", str(exe),
+           os.path.join(ROOT, "tests", "host", "check_trig_big.hip")]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bad 0" in r.stdout

@@ -81,12 +81,9 @@ def test_special_values(gpu, name):
     if name == "sine_of_input":
         with np.errstate(all="ignore"):
             x = np.abs(x) * np.float32(2000.0)  # a frequency input: inf -> phase inf -> sin(inf)
-        # A FINITE phase past 2^31 quadrants inside one block (a frequency above ~3e11 Hz) is platform-defined in
-        # the reference itself: wide's f32x8::sin converts the quadrant index with cvtps2dq on x86 (0x80000000 on
-        # overflow), with a saturating cast in its portable/NEON forms.  The device saturates (v_cvt_i32_f32), the
-        # oracle restates the x86 form; that regime is left out here ("unrestated regimes").
-        with np.errstate(all="ignore"):
-            x = np.where(np.isfinite(x) & (x > np.float32(1e11)), np.float32(np.inf), x).astype(np.float32)
+        # A FINITE phase past 2^31 quadrants inside one block (a frequency above ~3e11 Hz, voice 7) takes wide's
+        # round_int saturation (NaN -> 0, >= 2^31 -> i32::MAX on every platform; o_math.h o_round_int_sat) and then
+        # its q > 2^25 overflow rule: both sides restate it, nothing is left out.
     for mode in (MODE_PROCESS, MODE_TICK):
         b = gpu.Bank.from_graph(GRAPHS[name](GR), V, ring_frames=RING, sample_rate=SR)
         b.set_seed(np.arange(V, dtype=np.uint64))
@@ -157,3 +154,34 @@ def test_special_parameters(gpu, name):
                 n = PARAM_GRAPHS[name](O, float(vals[v]))
                 n.set_sample_rate(SR)
                 assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"{name} param {vals[v]} mode {mode}")
+
+
+# Trig arguments past musl's medium range (|x| >= 2^28*pi/2): cutoffs / frequencies of 1e13 .. 3e37 Hz put
+# tan(pi*fc/sr), sin(c*pi/2), cos(tau*f/sr) into __rem_pio2_large (Payne-Hanek), restated on both sides
+# (oracle/o_math.h, fd_math.hpp) -- the reference's libm returns a real value there, so no NaN rule.
+BIG_GRAPHS = ("svf_cutoff_in", "moog_cutoff_in", "butter_resonator_in")
+
+
+@pytest.mark.parametrize("name", BIG_GRAPHS)
+def test_trig_arguments_past_the_medium_range(gpu, name):
+    V, T = 8, 64 * 2 + 11
+    rng = np.random.default_rng(31 + SEED0)
+    x = (10.0 ** rng.uniform(13.0, 37.4, size=(V, 1, T))).astype(np.float32)   # pi*x/sr = 6.5e8 .. 1.6e33 and beyond
+    x[1] = -x[1]
+    x[2, 0, ::3] = np.float32(1e9)                                              # in and out of the big branch
+    x[3] = (2.0 ** rng.integers(40, 127, size=(1, T))).astype(np.float32)       # powers of two: sparse mantissas
+    x[4] = (10.0 ** rng.uniform(8.5, 13.5, size=(1, T))).astype(np.float32)     # around the medium / large boundary
+    finite = 0
+    for mode in (MODE_PROCESS, MODE_TICK):
+        b = gpu.Bank.from_graph(FREQ_GRAPHS[name](GR), V, sample_rate=SR)
+        b.set_seed(np.arange(V, dtype=np.uint64))
+        with np.errstate(all="ignore"):
+            got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, mode)
+            for v in range(V):
+                n = FREQ_GRAPHS[name](O)
+                n.set_sample_rate(SR)
+                n.set_seed(v)
+                want = oracle_render(n, x[v], T, mode)
+                finite += int(np.isfinite(want).sum())
+                assert_bit_equal(got[v], want, f"{name} voice {v} mode {mode}")
+    assert finite > 0

@@ -34,6 +34,23 @@ def test_libm_restatement_accuracy():
     assert max_ulp(L.o_math_expm1f, np.expm1, xh) < 1.0
 
 
+def test_libm_payne_hanek_range():
+    """|x| >= 2^28*pi/2: musl's __rem_pio2_large (restated in o_math.h) keeps sinf/cosf/tanf inside their documented
+    error bounds over every exponent up to FLT_MAX -- the reference's libm returns real values there, not NaN."""
+    import math
+    L = O.lib()
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0x4DC90FDB, 0x7F800000, size=40000, dtype=np.uint32) | (rng.integers(0, 2, size=40000, dtype=np.uint32) << 31)
+    xs = bits.astype(np.uint32).view(np.float32)
+    for fn, ref, bound in ((L.o_math_sinf, math.sin, 0.51), (L.o_math_cosf, math.cos, 0.51), (L.o_math_tanf, math.tan, 0.81)):
+        got = np.array([fn(float(x)) for x in xs], dtype=np.float32).astype(np.float64)
+        r = np.array([ref(float(x)) for x in xs])       # glibc's double sin/cos/tan reduce huge arguments exactly
+        ulp = np.spacing(np.abs(r).astype(np.float32)).astype(np.float64)
+        assert float(np.max(np.abs(got - r) / ulp)) < bound
+    assert L.o_math_sinf(1e30) == np.float32(math.sin(float(np.float32(1e30))))
+    assert L.o_math_sinf(-1e30) == -L.o_math_sinf(1e30)
+
+
 def test_libm_special_cases():
     L = O.lib()
     assert L.o_math_sinf(0.0) == 0.0 and np.signbit(np.float32(L.o_math_sinf(-0.0)))
