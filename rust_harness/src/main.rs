@@ -1,0 +1,278 @@
+//! Golden-vector and timing harness over the real `fundsp` crate (see README.md).
+//! Output format: NumPy `.npy` v1.0, little-endian f32, C order -- written by hand, no extra crates.
+
+use fundsp::prelude32::*;
+use std::fs;
+use std::io::Write;
+use std::path::{Path, PathBuf};
+
+mod graphs;
+
+pub const SR: f64 = 48000.0;
+
+// ---------------------------------------------------------------------------------------------------------------
+// I/O helpers
+// ---------------------------------------------------------------------------------------------------------------
+
+/// Raw little-endian f32 file -> Vec<f32>.
+fn read_f32(path: &Path) -> Vec<f32> {
+    let bytes = fs::read(path).unwrap_or_else(|e| panic!("cannot read {}: {e}", path.display()));
+    assert!(bytes.len() % 4 == 0);
+    bytes
+        .chunks_exact(4)
+        .map(|b| f32::from_le_bytes([b[0], b[1], b[2], b[3]]))
+        .collect()
+}
+
+/// Raw little-endian u64 file -> Vec<u64>.
+fn read_u64(path: &Path) -> Vec<u64> {
+    let bytes = fs::read(path).unwrap_or_else(|e| panic!("cannot read {}: {e}", path.display()));
+    assert!(bytes.len() % 8 == 0);
+    bytes
+        .chunks_exact(8)
+        .map(|b| u64::from_le_bytes([b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7]]))
+        .collect()
+}
+
+/// Write a 2-D f32 array `[rows][cols]` as `.npy`.
+pub fn write_npy(path: &Path, rows: usize, cols: usize, data: &[f32]) {
+    assert_eq!(data.len(), rows * cols);
+    let mut header = format!("{{'descr': '<f4', 'fortran_order': False, 'shape': ({rows}, {cols}), }}");
+    // magic (6) + version (2) + header length (2) + header, padded with spaces to a multiple of 64, ending in '\n'
+    let unpadded = 10 + header.len() + 1;
+    let pad = (64 - unpadded % 64) % 64;
+    header.push_str(&" ".repeat(pad));
+    header.push('\n');
+    let mut f = fs::File::create(path).unwrap_or_else(|e| panic!("cannot create {}: {e}", path.display()));
+    f.write_all(b"\x93NUMPY\x01\x00").unwrap();
+    f.write_all(&(header.len() as u16).to_le_bytes()).unwrap();
+    f.write_all(header.as_bytes()).unwrap();
+    let mut bytes = Vec::with_capacity(data.len() * 4);
+    for x in data {
+        bytes.extend_from_slice(&x.to_le_bytes());
+    }
+    f.write_all(&bytes).unwrap();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rendering: exactly what the parity tests do with the oracle (tests/test_gpu_parity.py::oracle_render)
+// ---------------------------------------------------------------------------------------------------------------
+
+/// Render `frames` samples of `node`: `process` mode = AudioNode::process in blocks of MAX_BUFFER_SIZE (64) with a
+/// ragged tail (what Wave::render does, wave.rs:441-466); tick mode = one AudioNode::tick per sample.
+/// `input` is `[channel][frame]`; output is `[channel][frame]`.
+pub fn render(node: &mut dyn AudioUnit, input: &[Vec<f32>], frames: usize, process: bool) -> Vec<Vec<f32>> {
+    let ni = node.inputs();
+    let no = node.outputs();
+    assert_eq!(input.len(), ni);
+    let mut out: Vec<Vec<f32>> = (0..no).map(|_| Vec::with_capacity(frames)).collect();
+    if process {
+        let mut ibuf = BufferVec::new(ni);
+        let mut obuf = BufferVec::new(no);
+        let mut i = 0;
+        while i < frames {
+            let n = (frames - i).min(MAX_BUFFER_SIZE);
+            for c in 0..ni {
+                for j in 0..n {
+                    ibuf.set_f32(c, j, input[c][i + j]);
+                }
+            }
+            node.process(n, &ibuf.buffer_ref(), &mut obuf.buffer_mut());
+            for c in 0..no {
+                for j in 0..n {
+                    out[c].push(obuf.at_f32(c, j));
+                }
+            }
+            i += n;
+        }
+    } else {
+        let mut fi = vec![0.0f32; ni];
+        let mut fo = vec![0.0f32; no];
+        for i in 0..frames {
+            for c in 0..ni {
+                fi[c] = input[c][i];
+            }
+            node.tick(&fi, &mut fo);
+            for c in 0..no {
+                out[c].push(fo[c]);
+            }
+        }
+    }
+    out
+}
+
+fn flatten(x: &[Vec<f32>]) -> Vec<f32> {
+    x.iter().flat_map(|c| c.iter().copied()).collect()
+}
+
+/// BASELINE config 3 voice: `sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q)` (README.md:98-103 of the reference).
+#[allow(clippy::precedence)]
+fn fm_voice(f: f32, m: f32, fc: f32, q: f32) -> impl AudioUnit {
+    sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q)
+}
+
+/// BASELINE config 2 voice: white noise through one lowpass biquad (one BiquadBank lane per voice in the bank form).
+fn noise_biquad_voice(fc: f32, q: f32) -> (An<Noise>, An<Biquad<f32>>) {
+    let c = BiquadCoefs::<f32>::lowpass(SR as f32, fc, q);
+    (noise(), biquad(c.a1, c.a2, c.b0, c.b1, c.b2))
+}
+
+fn golden(out_dir: &Path) {
+    fs::create_dir_all(out_dir).unwrap();
+    let inputs: PathBuf = Path::new(env!("CARGO_MANIFEST_DIR")).join("inputs");
+
+    // ---- config 1: Wave::render of sine_hz(440) >> lowpass_hz(1000, 1), first 2048 samples at 48 kHz
+    {
+        let mut g = sine_hz(440.0) >> lowpass_hz(1000.0, 1.0);
+        let w = Wave::render(SR, 2048.0 / SR, &mut g);
+        write_npy(&out_dir.join("config1.npy"), 1, w.len(), w.channel(0));
+    }
+
+    // ---- config 3: 64 FM voices, 333 frames (ragged tail), process and tick path; set_sample_rate then set_seed(v)
+    {
+        let f = read_f32(&inputs.join("config3_f.f32"));
+        let m = read_f32(&inputs.join("config3_m.f32"));
+        let fc = read_f32(&inputs.join("config3_fc.f32"));
+        let q = read_f32(&inputs.join("config3_q.f32"));
+        let seed = read_u64(&inputs.join("config3_seed.u64"));
+        let (v_n, t_n) = (f.len(), 333usize);
+        for (name, process) in [("config3_process.npy", true), ("config3_tick.npy", false)] {
+            let mut all = Vec::with_capacity(v_n * t_n);
+            for v in 0..v_n {
+                let mut g = fm_voice(f[v], m[v], fc[v], q[v]);
+                g.set_sample_rate(SR);
+                g.set_seed(seed[v]);
+                all.extend_from_slice(&render(&mut g, &[], t_n, process)[0]);
+            }
+            write_npy(&out_dir.join(name), v_n, t_n, &all);
+        }
+    }
+
+    // ---- config 2: 64 noise >> biquad voices, 200 frames; Noise seeded with Setting::seed(hash1(v)) + reset
+    {
+        let fc = read_f32(&inputs.join("config2_fc.f32"));
+        let q = read_f32(&inputs.join("config2_q.f32"));
+        let seed = read_u64(&inputs.join("config2_seed.u64"));
+        let (v_n, t_n) = (fc.len(), 200usize);
+        for (name, process) in [("config2_process.npy", true), ("config2_tick.npy", false)] {
+            let mut all = Vec::with_capacity(v_n * t_n);
+            for v in 0..v_n {
+                let (nz, bq) = noise_biquad_voice(fc[v], q[v]);
+                let mut g = nz.seed(seed[v]) >> bq;
+                g.set_sample_rate(SR);
+                g.reset();
+                all.extend_from_slice(&render(&mut g, &[], t_n, process)[0]);
+            }
+            write_npy(&out_dir.join(name), v_n, t_n, &all);
+        }
+    }
+
+    // ---- inventory graphs (graphs.rs): seed 12345, the fixed noise input of make_golden.py
+    for (name, ni) in graphs::names() {
+        let x = if ni > 0 {
+            let flat = read_f32(&inputs.join(format!("graph_{name}_in.f32")));
+            let t = flat.len() / ni;
+            (0..ni).map(|c| flat[c * t..(c + 1) * t].to_vec()).collect::<Vec<_>>()
+        } else {
+            Vec::new()
+        };
+        for (mode, process) in [("process", true), ("tick", false)] {
+            let mut g = graphs::build(name);
+            g.set_sample_rate(SR);
+            g.set_seed(12345);
+            let y = render(g.as_mut(), &x, graphs::FRAMES, process);
+            write_npy(&out_dir.join(format!("graph_{name}__{mode}.npy")), y.len(), graphs::FRAMES, &flatten(&y));
+        }
+    }
+
+    // ---- known-answer tables for the third-party transcendentals the oracle restates
+    {
+        let args = read_f32(&inputs.join("kat_args.f32"));
+        let n = args.len();
+        let table = |f: &dyn Fn(f32) -> f32| args.iter().map(|&x| f(x)).collect::<Vec<f32>>();
+        write_npy(&out_dir.join("kat_libm_sinf.npy"), 1, n, &table(&|x| libm::sinf(x)));
+        write_npy(&out_dir.join("kat_libm_cosf.npy"), 1, n, &table(&|x| libm::cosf(x)));
+        write_npy(&out_dir.join("kat_libm_tanf.npy"), 1, n, &table(&|x| libm::tanf(x)));
+        write_npy(&out_dir.join("kat_libm_tanhf.npy"), 1, n, &table(&|x| libm::tanhf(x)));
+        write_npy(&out_dir.join("kat_libm_expf.npy"), 1, n, &table(&|x| libm::expf(x)));
+        write_npy(&out_dir.join("kat_libm_atanf.npy"), 1, n, &table(&|x| libm::atanf(x)));
+        // wide: 8 lanes at a time; the tail is padded with zeros and cut
+        let wide8 = |f: &dyn Fn(wide::f32x8) -> wide::f32x8| {
+            let mut out = Vec::with_capacity(n);
+            for chunk in args.chunks(8) {
+                let mut a = [0.0f32; 8];
+                a[..chunk.len()].copy_from_slice(chunk);
+                let r = f(wide::f32x8::new(a)).to_array();
+                out.extend_from_slice(&r[..chunk.len()]);
+            }
+            out
+        };
+        write_npy(&out_dir.join("kat_wide_sin.npy"), 1, n, &wide8(&|x| x.sin()));
+        write_npy(&out_dir.join("kat_wide_atan.npy"), 1, n, &wide8(&|x| x.atan()));
+        // the saw wavetable as the reference builds it (pins make_wave + microfft): lowest and highest table via the
+        // oscillator itself is indirect, so dump one second of saw_hz(110) instead (process path)
+        let mut saw = saw_hz(110.0);
+        saw.set_sample_rate(SR);
+        saw.set_seed(1);
+        write_npy(&out_dir.join("kat_saw_hz_110.npy"), 1, 4096, &render(&mut saw, &[], 4096, true)[0]);
+    }
+    println!("wrote golden vectors to {}", out_dir.display());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Timing: BASELINE config 3 on the host cores (the "reference Rust SIMD CPU path" of BASELINE.json)
+// ---------------------------------------------------------------------------------------------------------------
+
+fn rnd1_param(v: u64, k: u64) -> f64 {
+    rnd1(4 * v + k)
+}
+
+fn bench(voices: usize, frames: usize, threads: usize) {
+    let t0 = std::time::Instant::now();
+    let mut handles = Vec::new();
+    for t in 0..threads {
+        let (v0, v1) = (voices * t / threads, voices * (t + 1) / threads);
+        handles.push(std::thread::spawn(move || {
+            let mut checksum = 0.0f64;
+            let mut obuf = BufferVec::new(1);
+            for v in v0..v1 {
+                let v = v as u64;
+                // same parameter law as fundsp_amd/workloads.py::fm_svf_params (values may differ in the last f32 bit
+                // from numpy's exp2; irrelevant for a timing)
+                let f = (55.0 * exp2(5.0 * rnd1_param(v, 0))) as f32;
+                let m = (0.5 + 7.5 * rnd1_param(v, 1)) as f32;
+                let fc = (f as f64 * exp2(4.0 * rnd1_param(v, 2))).min(0.45 * SR) as f32;
+                let q = (0.5 + 3.5 * rnd1_param(v, 3)) as f32;
+                let mut g = fm_voice(f, m, fc, q);
+                g.set_sample_rate(SR);
+                g.set_seed(v);
+                let mut i = 0;
+                while i < frames {
+                    let n = (frames - i).min(MAX_BUFFER_SIZE);
+                    g.process(n, &BufferRef::empty(), &mut obuf.buffer_mut());
+                    checksum += obuf.at_f32(0, n - 1) as f64;
+                    i += n;
+                }
+            }
+            checksum
+        }));
+    }
+    let checksum: f64 = handles.into_iter().map(|h| h.join().unwrap()).sum();
+    let s = t0.elapsed().as_secs_f64();
+    println!(
+        "{{\"metric\": \"Msamples/s, reference fundsp 0.23 process() path, config 3\", \"value\": {:.3}, \"voices\": {voices}, \"frames\": {frames}, \"threads\": {threads}, \"seconds\": {s:.3}, \"checksum\": {checksum}}}",
+        voices as f64 * frames as f64 / s / 1e6
+    );
+}
+
+fn main() {
+    let args: Vec<String> = std::env::args().collect();
+    match args.get(1).map(|s| s.as_str()) {
+        Some("golden") => golden(Path::new(args.get(2).map(|s| s.as_str()).unwrap_or("../tests/golden/ref_v1"))),
+        Some("bench") => {
+            let p = |i: usize, d: usize| args.get(i).and_then(|s| s.parse().ok()).unwrap_or(d);
+            bench(p(2, 4096), p(3, 48000), p(4, 8));
+        }
+        _ => eprintln!("usage: fundsp_harness golden <out_dir> | bench <voices> <frames> <threads>"),
+    }
+}

@@ -35,8 +35,48 @@ def main():
     np.savez_compressed(os.path.join(HERE, "configs_v1.npz"), config1=c1, config2_process=c2p, config2_tick=c2t,
                         config3_process=c3p, config3_tick=c3t)
     print("wrote", os.path.join(HERE, "configs_v1.npz"))
-    np.savez_compressed(os.path.join(HERE, "graphs_v1.npz"), **graph_vectors())
+    gv = graph_vectors()
+    np.savez_compressed(os.path.join(HERE, "graphs_v1.npz"), **gv)
     print("wrote", os.path.join(HERE, "graphs_v1.npz"))
+    harness_inputs(p2, p3, gv)
+
+
+def kat_args():
+    """Argument list of the transcendental known-answer tables (rust_harness: libm::*f and wide::f32x8::*): every
+    quadrant case of musl's sinf/cosf/tanf, the medium and the Payne-Hanek range, tanhf/expf breakpoints, specials."""
+    rng = np.random.default_rng(777)
+    parts = [
+        np.linspace(-7.2, 7.2, 1441),                       # explicit quadrant cases up to 9pi/4
+        np.linspace(-200.0, 200.0, 801),                    # Sine::process unwrapped phases
+        rng.uniform(-3000.0, 3000.0, 512),                  # __rem_pio2f medium path
+        10.0 ** rng.uniform(3.5, 8.5, 256),                 # up to the medium / large boundary
+        10.0 ** rng.uniform(8.5, 38.4, 512),                # __rem_pio2_large
+        -(10.0 ** rng.uniform(8.5, 38.4, 128)),
+        2.0 ** np.arange(-30, 128, dtype=np.float64),       # powers of two
+        np.array([0.0, -0.0, 1e-45, -1e-45, 1e-41, 1e-38, 1.17549435e-38, 3.4028235e38, -3.4028235e38, np.inf, -np.inf,
+                  np.nan, 0.5493, -0.5493, 9.0, 10.0, 88.72, 88.73, -103.9, -104.0, 1e-5, 2.0 ** -12, 0.785398, 2.356194,
+                  3.926990, 5.497787, 7.068583]),
+    ]
+    return np.concatenate(parts).astype(np.float32)
+
+
+def harness_inputs(p2, p3, gv):
+    """The exact arrays rust_harness/ reads (raw little-endian): per-voice parameters of configs 2 / 3, graph inputs,
+    the KAT argument list -- so that the real reference renders from identical bits."""
+    d = os.path.join(os.path.dirname(os.path.dirname(HERE)), "rust_harness", "inputs")
+    os.makedirs(d, exist_ok=True)
+    for k in ("f", "m", "fc", "q"):
+        p3[k].astype("<f4").tofile(os.path.join(d, f"config3_{k}.f32"))
+    p3["seed"].astype("<u8").tofile(os.path.join(d, "config3_seed.u64"))
+    for k in ("fc", "q"):
+        p2[k].astype("<f4").tofile(os.path.join(d, f"config2_{k}.f32"))
+    p2["seed"].astype("<u8").tofile(os.path.join(d, "config2_seed.u64"))
+    kat_args().astype("<f4").tofile(os.path.join(d, "kat_args.f32"))
+    from test_gpu_jit import GRAPHS
+    for name, (_b, ni, _r) in GRAPHS.items():
+        if ni:
+            gv[name + "__in"][:ni].astype("<f4").tofile(os.path.join(d, f"graph_{name}_in.f32"))
+    print("wrote", d)
 
 
 GRAPH_FRAMES = 64 * 3 + 9

@@ -343,7 +343,7 @@ def fir(*w):
     a = np.asarray(w, dtype=np.float32).reshape(-1)
     return Node(lib().o_fir(a.size, _fptr(a)))
 def tick(channels=1): return Node(lib().o_tick_node(channels))
-def delay(t): return Node(lib().o_delay(float(t)))
+def delay(t): return Node(lib().o_delay(float(np.float32(t))))   # prelude32.rs:893 delay(t: f32) -> Delay::new(t as f64)
 
 
 # --- wavetables (wavetable.rs:44-123, 493-623).  Tables are DATA shared by the oracle and the engine in parity
