@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X voice-bank engine.
 
-Metric (BASELINE.json): Msamples/s (whole node) for the 65 536-voice SVF+FM graph
+Metric (BASELINE.json): Msamples/s (whole node) for the 65 536-voice SVF+FM graph at 1/2/4/8 MI355X
     sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q)           (BASELINE config 3)
-One step = one pass of the hot path: render FRAMES samples of every voice of the rank's bank into an
-HBM-resident [frame][voice] f32 buffer (voice-out mode A, AudioNode::process semantics, 64-sample blocks).
-Multi-GPU: voices shard as contiguous ranges, one process per GPU, no data-path collective (weak scaling:
-65 536 voices per GPU); `--mix` adds the on-device stereo mix-down + one RCCL all-reduce per step.
+One step = one pass of the hot path: render FRAMES samples of every voice of the rank's shard into an HBM-resident
+[frame][voice] f32 buffer (voice-out mode A, AudioNode::process semantics, 64-sample blocks), exact arithmetic
+(bit-identical to the CPU oracle).
 
-Prints ONE JSON line on rank 0 (contract in the round brief) with `roofline` and `cpu_baseline` objects.
+Multi-GPU (`--gpus N`, one process per GPU): the headline is STRONG scaling -- the metric's 65 536 voices in total,
+sharded as contiguous ranges of 65 536 / N voices per GPU, no data-path collective.  `--scaling weak` keeps 65 536 voices
+per GPU instead; at N > 1 the weak figure is also measured (outside the timed region) and reported as
+`config.scaling_alt`.  `--mix` adds the on-device stereo mix-down + one RCCL all-reduce of [2][frames] per step.
+
+Prints ONE JSON line on rank 0 (contract in the round brief) with `roofline`, `cpu_baseline` and -- at N = 1, measured
+after the timed region -- a `secondary` list: the tolerance mode of the same workload, and BASELINE configs 2, 4, 5.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -20,35 +27,162 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+TOTAL_VOICES = 65536   # BASELINE.json: "65536-voice SVF+FM graph"
 
 
-def cpu_baseline(voices_per_gpu, frames, sample_rate, target_seconds):
-    """Time the CPU oracle ("port" of the reference's process() path) on a bounded sample of the same workload."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (C port of the reference's process()/tick() path) built for THIS host
+# ---------------------------------------------------------------------------------------------------------------------
+NATIVE_FLAGS = "-O3 -march=native -ffp-contract=off -fno-fast-math"
+
+
+def cpu_baseline(voices, frames, sample_rate, target_seconds):
+    """Time the CPU oracle on a bounded sample of the same workload, in both shapes SURVEY.md 8(d) names: process-shaped
+    (what Wave::render executes: Sine::process 8 frames per f32x8 item, the IIR leaves per sample) = `value`, and
+    tick-shaped (AudioNode::tick per sample, libm sinf).  Built on this host with NATIVE_FLAGS (oracle/Makefile `native`)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
     import oracle as O
     from fundsp_amd import workloads as W
 
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"])
+    L = C.CDLL(os.path.join(ROOT, "oracle", "_native", "libfundsp_oracle_native.so"))
+    L.o_bank_render.restype = C.c_double
+    L.o_bank_render.argtypes = [C.POINTER(O.BankJob), C.POINTER(C.c_float)]
     cores = os.cpu_count() or 1
-    # calibrate on a small sample, then size the timed sample for ~target_seconds of wall time
-    p = W.fm_svf_params(2 * cores, sample_rate)
-    _, s = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], frames, sample_rate, True, 0, cores, store=False)
-    rate = 2 * cores * frames / max(s, 1e-6)
-    n = int(min(voices_per_gpu, max(cores, rate * target_seconds / frames)))
-    n = max(cores, n // cores * cores)
-    p = W.fm_svf_params(n, sample_rate)
-    out = np.zeros((n, frames), dtype=np.float32)
-    job_params = [p["f"], p["m"], p["fc"], p["q"]]
-    _, s = O.bank_render(3, job_params, p["seed"], frames, sample_rate, True, 0, cores, store=False)
-    del out
+
+    def timed(n, process):
+        p = W.fm_svf_params(n, sample_rate)
+        return O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], frames, sample_rate, process, 0, cores,
+                             store=False, lib=L)[1]
+
+    out = {}
+    for shape, process in (("process", True), ("tick", False)):
+        s = timed(2 * cores, process)  # calibrate on a small sample, then size the timed sample for ~target_seconds / 2
+        rate = 2 * cores * frames / max(s, 1e-6)
+        n = int(min(voices, max(cores, rate * 0.5 * target_seconds / frames)))
+        n = max(cores, n // cores * cores)
+        s = timed(n, process)
+        out[shape] = (n * frames / s / 1e6, n, s)
+    v, n, s = out["process"]
     return {
-        "value": round(n * frames / s / 1e6, 3),
+        "value": round(v, 3),
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{n} of the {voices_per_gpu} config-3 voices x {frames} frames, oracle process() path "
-                  f"(C restatement, gcc -O2 -ffp-contract=off), {cores} threads, {s:.2f} s",
+        "tick_shaped_value": round(out["tick"][0], 3),
+        "sample": f"{n} of the {voices} config-3 voices x {frames} frames, oracle process() path "
+                  f"(C restatement of the reference, gcc {NATIVE_FLAGS}), {cores} threads, {s:.2f} s; "
+                  f"tick-shaped: {out['tick'][1]} voices, {out['tick'][2]:.2f} s",
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------------
+def make_workload(F, W, torch, config, V, T, sr, first, layout, math):
+    """-> dict(bank, inp, out, layout, fs, n_out, bytes_per_sample, slot_bytes, kernel)"""
+    inp = None
+    if config == 3:
+        bank = W.make_fm_svf_bank(V, sr, voice0=first)
+        n_out, bps, slot_bytes = 1, 4, 64          # SURVEY 8(d): 4 B/voice-sample out + 64 B state/params per launch
+        kernel = ("fd::k_render_pipe<fm_svf, process, 2 compute stages (modulator | carrier + lowpass-specialised SVF)>"
+                  if layout == F.LAYOUT_VOICE_MINOR else "fd::k_render_pipe_planar<fm_svf, process, 2 compute stages + storer wave>")
+    elif config == 2:
+        bank = W.make_noise_biquad_bank(V, sr, voice0=first)
+        n_out, bps, slot_bytes = 1, 4, 48          # noise generated in-kernel: 4 B/voice-sample out
+        kernel = "fd::k_render_pipe<noise_biquad> / fd::k_render<noise_biquad> (launches under 256 frames)"
+    elif config == 5:
+        # 16 384 x reverb_stereo(10, 2, 0.5) over 8 GPUs = 2048 instances per GPU; stereo white noise resident in HBM;
+        # planar [instance][channel][frame] I/O (the kernel is lane = frame)
+        layout = F.LAYOUT_PLANAR
+        bank = F.Bank.reverb_stereo(V, 10.0, 2.0, 0.5)
+        bank.set_sample_rate(sr)
+        g = torch.Generator(device="cuda").manual_seed(1234 + first)
+        inp = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
+        n_out, bps, slot_bytes = 2, 272, 512       # 32 ring reads + 32 ring writes + 2 in + 2 out, x 4 B
+        kernel = "fd::k_fdn_render_frames (lane = frame, one wave per instance)"
+    else:
+        layout = F.LAYOUT_VOICE_MINOR
+        F.wavetable_build("saw")
+        bank = W.make_saw_moog_bank(V, sr, voice0=first)
+        gate = torch.from_numpy(W.gate_signal(T, sr)).cuda()
+        inp = gate[None, :, None].expand(1, T, V).contiguous()  # [1][frame][voice] gate resident in HBM
+        n_out, bps, slot_bytes = 2, 12, 188        # 4 B gate in + 8 B stereo out per voice-sample
+        kernel = "fd::k_render_pipe<saw_moog_adsr_pan, process, loader wave + 3 compute stages (saw | moog | *adsr >> pan)>"
+    if math == "fast":
+        bank.set_option("math", F.MATH_FAST)
+    fs = T if layout == F.LAYOUT_PLANAR else 0
+    out = torch.empty((n_out, T, V) if layout == F.LAYOUT_VOICE_MINOR else (V, n_out, fs), dtype=torch.float32, device="cuda")
+    return dict(bank=bank, inp=inp, out=out, layout=layout, fs=fs, n_out=n_out, bps=bps, slot_bytes=slot_bytes, kernel=kernel)
+
+
+def quick(F, torch, wl, T, mode, steps=6, warmup=2):
+    """Secondary measurements (outside the headline's timed region): wall ms per step and the kernel's own HIP-event ms."""
+    bank = wl["bank"]
+    for _ in range(warmup):
+        bank.process(T, wl["inp"], wl["out"], layout=wl["layout"], frame_stride=wl["fs"], mode=mode)
+    torch.cuda.synchronize()
+    k = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bank.process(T, wl["inp"], wl["out"], layout=wl["layout"], frame_stride=wl["fs"], mode=mode)
+        k.append(bank.last_kernel_ms())
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, sum(k) / len(k)
+
+
+def secondary(F, W, torch, sr, mode):
+    """Configs the headline does not time (N = 1 only; each entry says what it measured)."""
+    out = []
+    V, T = TOTAL_VOICES, 48000
+    wl = make_workload(F, W, torch, 3, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, "fast")
+    ms, kms = quick(F, torch, wl, T, mode)
+    algo = V * T * 4 + V * 64
+    out.append({"name": "config3_math_fast", "what": "the headline workload in tolerance mode (FDSP_MATH_FAST: FMA sine polynomial, "
+                "recurrences exact; <= 1e-4 from the oracle, tests/test_gpu_math_fast.py)", "ms_per_step": round(ms, 4),
+                "kernel_ms_avg": round(kms, 4), "value": round(V * T / ms / 1e3, 1), "unit": "Msamples/s",
+                "roofline_frac": round(algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+    del wl
+    # config 2: 1024-voice biquad bank on white noise, 64-sample blocks (the launch-latency config)
+    V = 1024
+    c2 = {"name": "config2_biquad_bank_1024", "what": "BASELINE config 2: 1024 voices noise >> lowpass biquad (one BiquadBank<f32x8> lane "
+          "per voice), noise generated in-kernel, voice-out; T = frames per launch", "unit": "Msamples/s"}
+    for T in (64, 4096, 48000):
+        wl = make_workload(F, W, torch, 2, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, "exact")
+        ms, kms = quick(F, torch, wl, T, mode, steps=50 if T == 64 else 10, warmup=5)
+        c2[f"T{T}"] = {"us_per_launch": round(ms * 1e3, 2), "kernel_us": round(kms * 1e3, 2), "value": round(V * T / ms / 1e3, 2)}
+        if T == 64:  # the real-time pattern: one 64-frame block per launch, call by call vs replayed from a HIP graph
+            NB = 32
+            outs = [torch.empty_like(wl["out"]) for _ in range(NB)]
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    for kk in range(NB):
+                        wl["bank"].process(64, None, outs[kk], layout=wl["layout"], mode=mode)
+                g.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    g.replay()
+                torch.cuda.synchronize()
+                us = (time.perf_counter() - t0) / 20 / NB * 1e6
+            c2["T64"]["hip_graph_replay_us_per_block"] = round(us, 2)
+            c2["T64"]["hip_graph_value"] = round(V * 64 / us, 2)
+            del g, outs
+        del wl
+    out.append(c2)
+    for cfg, V, name, unit in ((4, 32768, "config4_saw_moog_adsr_pan_32768", "Msamples/s"), (5, 2048, "config5_reverb_stereo_2048", "M instance-frames/s")):
+        T = 48000
+        wl = make_workload(F, W, torch, cfg, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, "exact")
+        ms, kms = quick(F, torch, wl, T, mode, steps=4, warmup=1)
+        algo = V * T * wl["bps"] + V * wl["slot_bytes"]
+        out.append({"name": name, "what": f"BASELINE config {cfg} per-GPU shard ({V} {'voices' if cfg == 4 else 'instances'} x {T} frames), exact arithmetic",
+                    "ms_per_step": round(ms, 4), "kernel_ms_avg": round(kms, 4), "value": round(V * T / ms / 1e3, 1), "unit": unit,
+                    "algorithmic_bytes_per_unit": wl["bps"], "roofline_frac": round(algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "kernel": wl["kernel"]})
+        del wl
+    return out
 
 
 def main():
@@ -56,9 +190,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5],
-                    help="3 = headline FM+SVF voices (default); 4 = saw>>moog*adsr>>pan voices (informational)")
-    ap.add_argument("--voices", type=int, default=None, help="voices per GPU (weak scaling); default 65536 (config 3) / 32768 (config 4)")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
+                    help="3 = headline FM+SVF voices (default); 2 / 4 / 5 = the other BASELINE configs as the timed workload (informational)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default, BASELINE metric): the config's voice count in total, split over the GPUs; weak: that many per GPU")
+    ap.add_argument("--voices", type=int, default=None, help="total voices (strong) / voices per GPU (weak); default = the config's own")
     ap.add_argument("--frames", type=int, default=48000, help="frames per step (1 s @ 48 kHz)")
     ap.add_argument("--sample-rate", type=float, default=48000.0)
     ap.add_argument("--layout", choices=["voice_minor", "planar"], default="voice_minor")
@@ -66,7 +202,10 @@ def main():
     ap.add_argument("--mix", action="store_true", help="add on-device stereo mix-down + all-reduce per step")
     ap.add_argument("--pipe-split", type=int, default=1, choices=[0, 1, 2, 3],
                     help="pipeline split of Pipe-chain kinds: 0 off, 1 best plan (default), 2 / 3 = that many stages")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--math", choices=["exact", "fast"], default="exact",
+                    help="exact = the reference's arithmetic, bit-identical to the oracle (headline); fast = tolerance mode (FDSP_MATH_FAST)")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall-time budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs 2 / 4 / 5, tolerance mode)")
     args = ap.parse_args()
 
     import torch
@@ -94,69 +233,70 @@ def main():
     if args.pipe_split != 1:
         from fundsp_amd import _lib
         assert _lib.lib().fdsp_set_option(b"pipe_split", args.pipe_split) == 0
-    if args.voices is None:
-        args.voices = {3: 65536, 4: 32768, 5: 2048}[args.config]
-    V, T, sr = args.voices, args.frames, args.sample_rate
+    base_voices = args.voices or {2: 1024, 3: TOTAL_VOICES, 4: 32768, 5: 2048}[args.config]
+    T, sr = args.frames, args.sample_rate
     layout = F.LAYOUT_VOICE_MINOR if args.layout == "voice_minor" else F.LAYOUT_PLANAR
     mode = F.MODE_PROCESS if args.mode == "process" else F.MODE_TICK
-    first = rank * V  # contiguous voice ranges of the N*V-voice whole-node bank
-    inp = None
-    if args.config == 3:
-        bank = W.make_fm_svf_bank(V, sr, voice0=first)
-        n_out, bytes_per_sample = 1, 4
-    elif args.config == 5:
-        # 16 384 x reverb_stereo(10, 2, 0.5) over 8 GPUs = 2048 instances per GPU; stereo white noise resident in HBM;
-        # planar [instance][channel][frame] I/O (lane = frame in the kernel's staging phases)
-        layout = F.LAYOUT_PLANAR
-        bank = F.Bank.reverb_stereo(V, 10.0, 2.0, 0.5)
-        bank.set_sample_rate(sr)
-        g = torch.Generator(device="cuda").manual_seed(1234 + first)
-        inp = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
-        n_out, bytes_per_sample = 2, 272  # 32 ring reads + 32 ring writes + 2 in + 2 out, x 4 B
-    else:
-        assert layout == F.LAYOUT_VOICE_MINOR, "config 4 bench uses the device-native layout"
-        F.wavetable_build("saw")
-        bank = W.make_saw_moog_bank(V, sr, voice0=first)
-        gate = torch.from_numpy(W.gate_signal(T, sr)).cuda()
-        inp = gate[None, :, None].expand(1, T, V).contiguous()  # [1][frame][voice] gate resident in HBM
-        n_out, bytes_per_sample = 2, 12
-    fs = T if layout == F.LAYOUT_PLANAR else 0
-    out = torch.empty((n_out, T, V) if layout == F.LAYOUT_VOICE_MINOR else (V, n_out, fs), dtype=torch.float32,
-                      device="cuda")
-
-    def step():
-        bank.process(T, inp, out, layout=layout, frame_stride=fs, mode=mode)
-        if args.mix:
-            if args.config == 3:
-                mix = F.mix_stereo(out[0] if layout == F.LAYOUT_VOICE_MINOR else out[:, 0, :].t().contiguous())
-            elif args.config == 5:
-                mix = out.sum(dim=0)     # [2][T] sum over instances (planar layout)
-            else:
-                mix = F.sum_voices(out)  # voices are already panned to stereo
-            fdist.allreduce_mix(mix)
 
     def fence():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # HIP events recorded by the C ABI on the launch stream around the render kernel (read after the loop
-        # would only see the last launch; reading here synchronises on that launch, which the next step's
-        # launch on the same stream is ordered behind anyway)
-        kernel_ms.append(bank.last_kernel_ms())
-    fence()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_run(scaling, steps, warmup):
+        """K steps of the rank's shard between two fences; returns (max-over-ranks seconds, kernel ms list, workload, V)."""
+        if scaling == "strong":
+            first, V = fdist.shard_range(base_voices, rank, world)   # contiguous ranges of the whole-node bank
+        else:
+            first, V = rank * base_voices, base_voices
+        wl = make_workload(F, W, torch, args.config, V, T, sr, first, layout, args.math)
+        bank = wl["bank"]
+
+        def step():
+            bank.process(T, wl["inp"], wl["out"], layout=wl["layout"], frame_stride=wl["fs"], mode=mode)
+            if args.mix:
+                if args.config in (2, 3):
+                    mix = F.mix_stereo(wl["out"][0] if wl["layout"] == F.LAYOUT_VOICE_MINOR else wl["out"][:, 0, :].t().contiguous())
+                elif args.config == 5:
+                    mix = wl["out"].sum(dim=0)     # [2][T] sum over instances (planar layout)
+                else:
+                    mix = F.sum_voices(wl["out"])  # voices are already panned to stereo
+                fdist.allreduce_mix(mix)
+
+        for _ in range(warmup):
+            step()
+        fence()
+        kernel_ms = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            # HIP events recorded by the C ABI on the launch stream around the render kernel (reading here synchronises
+            # on that launch, which the next step's launch on the same stream is ordered behind anyway)
+            kernel_ms.append(bank.last_kernel_ms())
+        fence()
+        elapsed = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, kernel_ms, wl, V
+
+    elapsed, kernel_ms, wl, V = timed_run(args.scaling, args.steps, args.warmup)
+    total_voices = base_voices if args.scaling == "strong" else base_voices * world
+    scaling_alt = None
+    if distributed and args.config == 3:   # the other scaling law, outside the timed region, a few steps
+        other = "weak" if args.scaling == "strong" else "strong"
+        kernel_label, shard_bps, shard_slots = wl["kernel"], wl["bps"], wl["slot_bytes"]
+        del wl
+        e2, _, wl2, V2 = timed_run(other, max(3, args.steps // 2), 1)
+        tv2 = base_voices if other == "strong" else base_voices * world
+        n2 = max(3, args.steps // 2)
+        scaling_alt = {"scaling": other, "total_voices": tv2, "voices_per_gpu": V2, "value": round(tv2 * T * n2 / e2 / 1e6, 3),
+                       "ms_per_step": round(e2 / n2 * 1e3, 4)}
+        del wl2
+    else:
+        kernel_label, shard_bps, shard_slots = wl["kernel"], wl["bps"], wl["slot_bytes"]
+        del wl
 
     # SURVEY.md 8(d): also relate the kernel to what this box's HBM delivers to plain streaming kernels (a 2 GiB
     # device-to-device copy = read + write, and a fill = write only, the kernel's own traffic shape), outside the timed region
@@ -166,6 +306,7 @@ def main():
         a = torch.empty(n, dtype=torch.float32, device="cuda")
         b2 = torch.empty(n, dtype=torch.float32, device="cuda")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
         def timed(fn, reps=5):
             fn()
             torch.cuda.synchronize()
@@ -181,24 +322,28 @@ def main():
         del a, b2
 
     if rank == 0:
-        total_samples = float(world) * V * T * args.steps
+        total_samples = float(total_voices) * T * args.steps
         value = total_samples / elapsed / 1e6
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
-        # config 3 = 4 B per voice-sample out + 64 B state/params per voice per launch;
-        # config 4 = 4 B gate in + 8 B stereo out per voice-sample (+ 188 B of slots per voice per launch)
-        algo_bytes = V * T * bytes_per_sample + V * {3: 64, 4: 188, 5: 512}[args.config]
+        # ALGORITHMIC bytes of one launch of this rank's shard: per-unit figure x units + slots
+        algo_bytes = V * T * shard_bps + V * shard_slots
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic comes from separate rocprofv3 --pmc passes of this same command (it cannot be collected inside this
+        # process): the committed summary is quoted, with its source, when it was taken on this very shard shape
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                if rec.get("voices") == V and rec.get("frames") == T and args.config == 3:
+                if rec.get("voices") == V and rec.get("frames") == T and rec.get("config", 3) == args.config and rec.get("math", "exact") == args.math:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = rec.get("source", "profiles/pmc_latest.json") + " (separate rocprofv3 --pmc passes, not this run)"
             except Exception:
                 traffic = None
+        unit_name = {2: "voices", 3: "voices", 4: "voices", 5: "instances"}[args.config]
         res = {
             "metric": {3: "Msamples/s (whole node) for 65536-voice SVF+FM graph",
+                       2: "Msamples/s (whole node) for the 1024-voice biquad_bank on white noise (BASELINE config 2, informational)",
                        4: "Msamples/s (whole node) for saw>>moog*adsr>>pan voices (BASELINE config 4, informational)",
                        5: "M instance-frames/s (whole node) for reverb_stereo FDN instances (BASELINE config 5, informational)"}[args.config],
             "value": round(value, 3),
@@ -208,21 +353,26 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": {3: "BASELINE config 3: sine_hz(f)*f*m+f >> sine() >> lowpass_hz(fc,q), ",
+                             2: "BASELINE config 2: noise() >> lowpass biquad (BiquadBank<f32x8> lane per voice), ",
                              4: "BASELINE config 4 voice: ((dc(f)>>saw()|dc(fc)|dc(q))>>moog())*adsr_live(.01,.1,.6,.2)>>pan(p), gate in, ",
                              5: "BASELINE config 5: reverb_stereo(10.0, 2.0, 0.5) 32-line FDN, stereo noise in, planar I/O, "}[args.config] +
-                            f"{V} voices/GPU x {T} frames/step @ {sr:g} Hz, voice-out ([frame][voice] f32), "
-                            f"{args.mode} semantics, per-voice params from rnd1(4v+k), phases via set_seed(v)",
+                            f"{total_voices} {unit_name} in total = {V} per GPU x {T} frames/step @ {sr:g} Hz, "
+                            f"{'planar ([' + unit_name[:-1] + '][channel][frame] f32)' if args.config == 5 or args.layout == 'planar' else 'voice-out ([frame][voice] f32)'}, "
+                            f"{args.mode} semantics, {args.math} arithmetic, per-voice params from rnd1(4v+k), phases via set_seed(v)",
+                "total_voices": total_voices,
                 "voices_per_gpu": V,
                 "frames_per_step": T,
-                "layout": args.layout,
+                "layout": "planar" if args.config == 5 else args.layout,
                 "mix_allreduce": bool(args.mix),
+                "math": args.math,
                 "parallelism": f"voice-shard x{world}",
+                "scaling_alt": scaling_alt,
             },
             "roofline": {
                 "bound": "hbm",
@@ -231,13 +381,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "kernel": {3: (f"fd::k_render_pipe<fm_svf, {args.mode}, 2 compute stages cut after the modulator> (voice_minor)"
-                               if args.layout == "voice_minor" and args.mode == "process" and args.pipe_split in (1, 2) and T % 8 == 0
-                               else f"fd::k_render_pipe_planar<fm_svf, {args.mode}, 2 compute stages + storer wave> (planar)"
-                               if args.layout == "planar" and args.pipe_split == 1 and T >= 256 and T % 4 == 0
-                               else f"fd::k_render<fm_svf, {args.mode}, {args.layout}> / pipe_split={args.pipe_split}"),
-                           4: f"fd::k_render_pipe<saw_moog_adsr_pan, {args.mode}, loader wave + 3 compute stages (saw | moog | *adsr >> pan)> ({args.layout})",
-                           5: "fd::k_fdn_render"}[args.config],
+                "traffic_source": traffic_source,
+                "kernel": kernel_label,
                 "kernel_ms_avg": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "measured_streaming": measured,
@@ -245,9 +390,14 @@ def main():
             },
         }
         if world == 1 and args.cpu_seconds > 0 and args.config == 3:
-            res["cpu_baseline"] = cpu_baseline(V, T, sr, args.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(total_voices, T, sr, args.cpu_seconds)
         else:
             res["cpu_baseline"] = None
+        if world == 1 and not args.no_secondary and args.config == 3 and args.math == "exact":
+            try:
+                res["secondary"] = secondary(F, W, torch, sr, mode)
+            except Exception as e:  # never lose the headline line to a secondary measurement
+                res["secondary"] = [{"error": repr(e)}]
         print(json.dumps(res), flush=True)
 
     if distributed:

@@ -12,6 +12,7 @@ SO_PATH = os.environ.get("FUNDSP_HIP_LIB") or os.path.join(_HERE, "libfundsp_hip
 OK, EINVAL, ENOMEM, EDEVICE = 0, -1, -2, -3
 LAYOUT_VOICE_MINOR, LAYOUT_PLANAR = 0, 1
 MODE_PROCESS, MODE_TICK = 0, 1
+MATH_EXACT, MATH_FAST = 0, 1
 FADE_POWER, FADE_SMOOTH = 0, 1  # sequencer.rs Fade::Power / Fade::Smooth
 MAX_BUFFER_SIZE = 64
 DEFAULT_SR = 44100.0
@@ -25,6 +26,8 @@ SYMBOLS = {
     "fdsp_kind_name": (_cs, [_i]),
     "fdsp_kind_by_name": (_i, [_cs]),
     "fdsp_set_option": (_i, [_cs, _i]),
+    "fdsp_bank_set_option": (_i, [_P, _cs, _i]),
+    "fdsp_bank_get_option": (_i, [_P, _cs]),
     "fdsp_graph_compile": (_i, [_cs, _cs]),
     "fdsp_graph_compile_src": (_i, [_cs, _cs, _cs]),
     "fdsp_graph_check": (_i, [_cs]),
@@ -36,6 +39,10 @@ SYMBOLS = {
     "fdsp_bank_create": (_i, [_cs, _sz, C.POINTER(_P)]),
     "fdsp_bank_create_ring": (_i, [_cs, _sz, _sz, C.POINTER(_P)]),
     "fdsp_reverb_stereo_create": (_i, [_sz, _d, _d, _d, C.POINTER(_P)]),
+    "fdsp_device_count": (_i, []),
+    "fdsp_bank_create_on": (_i, [_i, _cs, _sz, _sz, C.POINTER(_P)]),
+    "fdsp_reverb_stereo_create_on": (_i, [_i, _sz, _d, _d, _d, C.POINTER(_P)]),
+    "fdsp_bank_device": (_i, [_P]),
     "fdsp_bank_destroy": (None, [_P]),
     "fdsp_bank_inputs": (_i, [_P]),
     "fdsp_bank_outputs": (_i, [_P]),
@@ -63,6 +70,16 @@ SYMBOLS = {
     "fdsp_bank_last_kernel_ms": (_i, [_P, C.POINTER(C.c_float)]),
     "fdsp_mix_stereo": (_i, [_P, _P, _P, _sz, _sz, _P]),
     "fdsp_sum_voices": (_i, [_P, _P, _sz, _sz, _sz, _P]),
+    "fdsp_comm_create_local": (_i, [_i, C.POINTER(C.c_int), C.POINTER(_P)]),
+    "fdsp_comm_unique_id": (_i, [_P]),
+    "fdsp_comm_create_rank": (_i, [_P, _i, _i, _i, C.POINTER(_P)]),
+    "fdsp_comm_destroy": (None, [_P]),
+    "fdsp_comm_ranks": (_i, [_P]),
+    "fdsp_comm_local_slots": (_i, [_P]),
+    "fdsp_comm_device": (_i, [_P, _i]),
+    "fdsp_mix_allreduce": (_i, [_P, _i, _P, _sz, _P]),
+    "fdsp_mix_allreduce_all": (_i, [_P, C.POINTER(_P), _sz, C.POINTER(_P)]),
+    "fdsp_comm_wait": (_i, [_P, _i, _P]),
     "fdsp_wavetable_build": (_i, [_i]),
     "fdsp_wave_upload": (_i, [_i, _i, _sz, _fp]),
     "fdsp_wavetable_upload": (_i, [_i, _i, _fp, C.POINTER(C.c_int), _fp]),

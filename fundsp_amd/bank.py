@@ -36,11 +36,12 @@ def _fptr(a):
 class Bank:
     """V voices of one compiled voice graph on the current HIP device."""
 
-    def __init__(self, kind, voices, _handle=None, ring_frames=0):
+    def __init__(self, kind, voices, _handle=None, ring_frames=0, device=-1):
+        """`device`: HIP device index the bank lives on (-1 = the calling thread's current device)."""
         self._h = C.c_void_p()
         self.kind = kind
         if _handle is None:
-            check(lib().fdsp_bank_create_ring(kind.encode(), int(voices), int(ring_frames), C.byref(self._h)))
+            check(lib().fdsp_bank_create_on(int(device), kind.encode(), int(voices), int(ring_frames), C.byref(self._h)))
         else:
             self._h = _handle
         self.voices = int(voices)
@@ -59,6 +60,12 @@ class Bank:
         for kind in G.uses_wavetables(graph):
             if wavetable_get(kind)[0] is None:
                 wavetable_build(kind)
+        if graph.rings and not ring_frames:
+            # the bank is constructed at DEFAULT_SR and then moved to sample_rate: the rings must hold both
+            need = [graph.ring_frames(r) for r in {_lib.DEFAULT_SR, float(sample_rate or _lib.DEFAULT_SR)}]
+            if None in need:
+                raise ValueError("this graph has a node whose ring size the graph cannot derive (Pluck / Hold / Reverb3): pass ring_frames")
+            ring_frames = max(need)
         b = cls(name, voices, ring_frames=ring_frames)
         for slot, value, is_u64 in graph.slot_values():
             if is_u64 == 2:   # a u32 slot: one word per voice, uploaded as raw bits
@@ -81,6 +88,9 @@ class Bank:
         h = C.c_void_p()
         check(lib().fdsp_reverb_stereo_create(int(instances), float(room_size), float(time), float(damping), C.byref(h)))
         return cls("reverb_stereo", instances, _handle=h)
+
+    def device(self):
+        return lib().fdsp_bank_device(self._h)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -167,9 +177,16 @@ class Bank:
             shape = (no, frames, self.voices) if layout == LAYOUT_VOICE_MINOR else (self.voices, no, fs)
             out = torch.empty(shape, dtype=torch.float32, device="cuda")
         assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+        if layout == LAYOUT_PLANAR:
+            assert fs >= frames, f"frame_stride {fs} < frames {frames}"
+        # the kernel trusts the pointers: a buffer smaller than the layout implies would be read / written out of bounds
+        need_out = no * frames * self.voices if layout == LAYOUT_VOICE_MINOR else self.voices * no * fs
+        assert out.numel() >= need_out, f"out has {out.numel()} floats, the {'voice-minor' if layout == LAYOUT_VOICE_MINOR else 'planar'} layout needs {need_out}"
         d_in = None
         if ni:
             assert inp is not None and inp.is_cuda and inp.dtype == torch.float32 and inp.is_contiguous()
+            need_in = ni * frames * self.voices if layout == LAYOUT_VOICE_MINOR else self.voices * ni * fs
+            assert inp.numel() >= need_in, f"inp has {inp.numel()} floats, the layout needs {need_in}"
             d_in = C.c_void_p(inp.data_ptr())
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
@@ -212,9 +229,11 @@ class Bank:
         if out is None:
             out = torch.empty((no, frames, self.voices), dtype=torch.float32, device="cuda")
         assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+        assert out.numel() >= no * frames * self.voices, f"out has {out.numel()} floats, needs {no * frames * self.voices}"
         d_in = None
         if ni:
             assert inp is not None and inp.is_cuda and inp.dtype == torch.float32 and inp.is_contiguous()
+            assert inp.numel() >= ni * frames * self.voices, f"inp has {inp.numel()} floats, needs {ni * frames * self.voices}"
             d_in = C.c_void_p(inp.data_ptr())
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
@@ -254,6 +273,17 @@ class Bank:
 
     def synchronize(self):
         check(lib().fdsp_bank_synchronize(self._h))
+
+    def set_option(self, name, value):
+        """Per-bank engine option: "math" = MATH_EXACT (0, default: bit-identical to the reference arithmetic) or
+        MATH_FAST (1, tolerance mode, include/fundsp_hip.h)."""
+        check(lib().fdsp_bank_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        rc = lib().fdsp_bank_get_option(self._h, name.encode())
+        if rc < 0:
+            check(rc)
+        return rc
 
     def last_kernel_ms(self):
         ms = C.c_float()
@@ -323,6 +353,68 @@ def wavetable_compute(kind):
     check(lib().fdsp_wavetable_compute(WT_SETS[kind], C.byref(n), None, None, _fptr(data), data.size))
     offs = np.concatenate([[0], np.cumsum(lengths)])
     return p, [data[offs[i]:offs[i + 1]] for i in range(n.value)]
+
+
+class Comm:
+    """RCCL communicator for the stereo mix-down across GPUs (include/fundsp_hip.h, fdsp_comm_*).
+
+    Comm.local(devices)  one process, several GPUs;  Comm.rank(id, nranks, rank, device)  one process per GPU, with the
+    128-byte id from Comm.unique_id() on rank 0 shipped out of band (torch.distributed, MPI, a file)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def local(cls, devices):
+        d = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        check(lib().fdsp_comm_create_local(len(devices), d, C.byref(h)))
+        return cls(h)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().fdsp_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    @classmethod
+    def rank(cls, unique_id, nranks, rank, device=-1):
+        h = C.c_void_p()
+        check(lib().fdsp_comm_create_rank(C.create_string_buffer(unique_id, 128), nranks, rank, device, C.byref(h)))
+        return cls(h)
+
+    def ranks(self):
+        return lib().fdsp_comm_ranks(self._h)
+
+    def allreduce(self, mix, slot=0, after_stream=None):
+        """Sum the [2, frames] device tensor `mix` in place across the ranks, on the communicator's side stream, ordered
+        behind `after_stream` (default: torch's current stream).  Returns at once; wait() orders a consumer behind it."""
+        import torch
+
+        assert mix.is_cuda and mix.dtype == torch.float32 and mix.is_contiguous()
+        if after_stream is None:
+            after_stream = torch.cuda.current_stream(mix.device).cuda_stream
+        check(lib().fdsp_mix_allreduce(self._h, slot, C.c_void_p(mix.data_ptr()), mix.numel(),
+                                       C.c_void_p(after_stream) if after_stream else None))
+        return mix
+
+    def wait(self, slot=0, stream=None):
+        """stream=None blocks the host; otherwise the given raw stream handle waits (0 / "current": torch's current)."""
+        if stream == "current":
+            import torch
+
+            stream = torch.cuda.current_stream().cuda_stream
+        check(lib().fdsp_comm_wait(self._h, slot, C.c_void_p(stream) if stream else None))
+
+    def close(self):
+        if self._h:
+            lib().fdsp_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        if _lib is None or getattr(_lib, "_lib", None) is None:
+            return
+        self.close()
 
 
 def sum_voices(x, stream=None):

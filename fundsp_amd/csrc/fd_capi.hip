@@ -21,15 +21,17 @@ thread_local std::string g_err;
 namespace fd {
 int g_pipe_split = 1;
 int g_fdn_kernel = 0;
+int g_math = FDSP_MATH_EXACT;  // default arithmetic of banks created from now on (fdsp_set_option("math", ..))
 long g_zero_copy_max = 1 << 18;  // floats; fdsp_bank_process_host reads/writes pinned host memory directly below this
-int simd_count() {
-    static int n = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 1024;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 1024;
-        return cus * 4;
-    }();
-    return n;
+int simd_count() {  // SIMDs (CUs x 4) of the CURRENT device, cached per device
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+    if (cache[dev] == 0) {
+        int cus = 0;
+        cache[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus * 4 : 1024;
+    }
+    return cache[dev];
 }
 }  // namespace fd
 namespace {
@@ -38,6 +40,11 @@ int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+}  // namespace
+namespace fd {
+int api_fail(int code, const std::string& msg) { return fail(code, msg); }  // for the other translation units of the C ABI
+}
+namespace {
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
@@ -60,21 +67,144 @@ std::deque<fd::KindOps>& registry() {
     return kinds;
 }
 std::mutex g_registry_mutex;
+// element `kind` of the registry, or nullptr; entries never move (deque) and are never removed, so the pointer stays
+// valid after the lock is released
+const fd::KindOps* kind_at(int kind) {
+    auto& r = registry();
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    return (kind >= 0 && kind < (int)r.size()) ? &r[kind] : nullptr;
+}
 
-// ---- shared device data (wavetables): one fd::Aux per process, the counterpart of FunDSP's static table singletons ----
-fd::Aux g_host_aux;              // host mirror (data pointers are device pointers)
-std::vector<float> g_host_tables[fd::WT_SETS];  // unpadded host copies (fdsp_wavetable_get)
-fd::Aux* g_dev_aux = nullptr;
+// ---- shared data (wavetables, sample buffers): the counterpart of FunDSP's static Arc<Wavetable> / Arc<Wave> singletons.
+// The host keeps ONE copy per set / slot; every device that has banks gets its own fd::Aux block with device copies,
+// brought up to date when a bank is created on it and whenever a set / slot is (re)installed.  Nothing here is bound to
+// "the first device": one process drives any number of GPUs (fdsp_bank_create_on).
+constexpr int MAX_DEVICES = 64;
+struct HostTableSet { int n = 0; std::vector<float> pitch; std::vector<int> len; std::vector<float> data; uint64_t ver = 0; };
+struct HostWave { int channels = 0; size_t length = 0; std::vector<float> data; uint64_t ver = 0; };
+struct DeviceCtx {
+    bool init = false;
+    fd::Aux host_aux;            // host mirror of this device's Aux (data pointers are device pointers)
+    fd::Aux* dev_aux = nullptr;
+    uint64_t table_ver[fd::WT_SETS] = {0}, wave_ver[fd::WAVE_SLOTS] = {0};
+};
+HostTableSet g_tables[fd::WT_SETS];
+HostWave g_waves[fd::WAVE_SLOTS];
+DeviceCtx g_devctx[MAX_DEVICES];
 std::mutex g_aux_mutex;
 
-const void* device_aux() {
-    std::lock_guard<std::mutex> lock(g_aux_mutex);
-    if (!g_dev_aux) {
-        std::memset(&g_host_aux, 0, sizeof g_host_aux);
-        if (hipMalloc((void**)&g_dev_aux, sizeof(fd::Aux)) != hipSuccess) return nullptr;
-        hipMemcpy(g_dev_aux, &g_host_aux, sizeof(fd::Aux), hipMemcpyHostToDevice);
+struct DeviceGuard {  // make `dev` current for the scope (hipSetDevice is per host thread)
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
     }
-    return g_dev_aux;
+    ~DeviceGuard() {
+        if (switched) hipSetDevice(prev);
+    }
+};
+int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess ? dev : -1;
+}
+int device_of(const void* p) {  // the device a device pointer belongs to (-1: unknown, leave the current device alone)
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return a.device;
+}
+
+// bring device `dev`'s copies of the shared tables / waves up to date (g_aux_mutex held, `dev` current)
+hipError_t sync_shared_locked(int dev) {
+    DeviceCtx& c = g_devctx[dev];
+    bool dirty = false;
+    if (!c.init) {
+        std::memset(&c.host_aux, 0, sizeof c.host_aux);
+        hipError_t e = hipMalloc((void**)&c.dev_aux, sizeof(fd::Aux));
+        if (e != hipSuccess) return e;
+        c.init = true;
+        dirty = true;
+    }
+    for (int set = 0; set < fd::WT_SETS; set++) {
+        const HostTableSet& t = g_tables[set];
+        if (t.ver == c.table_ver[set]) continue;
+        // device layout: every table circularly padded [t[len-1], t[0..len-1], t[0], t[1]] (fd_nodes.hpp wt_tap)
+        std::vector<float> padded;
+        padded.reserve(t.data.size() + 3 * (size_t)t.n);
+        fd::WtSet& w = c.host_aux.wt[set];
+        size_t src = 0;
+        for (int i = 0; i < t.n; i++) {
+            const size_t len = (size_t)t.len[i];
+            w.pitch[i] = t.pitch[i];
+            w.off[i] = (int)padded.size();
+            w.len[i] = t.len[i];
+            padded.push_back(t.data[src + len - 1]);
+            padded.insert(padded.end(), t.data.begin() + src, t.data.begin() + src + len);
+            padded.push_back(t.data[src]);
+            padded.push_back(t.data[src + 1]);
+            src += len;
+        }
+        float* d = nullptr;
+        hipError_t e = hipMalloc((void**)&d, padded.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(d, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipDeviceSynchronize();  // no render may still read the tables this replaces
+        if (e != hipSuccess) {
+            if (d) hipFree(d);
+            return e;
+        }
+        if (w.data) hipFree(const_cast<float*>(w.data));
+        w.n = t.n;
+        w.data = d;
+        c.table_ver[set] = t.ver;
+        dirty = true;
+    }
+    for (int slot = 0; slot < fd::WAVE_SLOTS; slot++) {
+        const HostWave& hw = g_waves[slot];
+        if (hw.ver == c.wave_ver[slot]) continue;
+        float* d = nullptr;
+        hipError_t e = hipMalloc((void**)&d, hw.data.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(d, hw.data.data(), hw.data.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipDeviceSynchronize();  // no render may still read the buffer this replaces
+        if (e != hipSuccess) {
+            if (d) hipFree(d);
+            return e;
+        }
+        fd::WaveBuf& w = c.host_aux.wave[slot];
+        if (w.data) hipFree(const_cast<float*>(w.data));
+        w.data = d;
+        w.channels = (uint32_t)hw.channels;
+        w.length = (uint32_t)hw.length;
+        c.wave_ver[slot] = hw.ver;
+        dirty = true;
+    }
+    if (dirty) return hipMemcpy(c.dev_aux, &c.host_aux, sizeof(fd::Aux), hipMemcpyHostToDevice);
+    return hipSuccess;
+}
+
+// the Aux block of device `dev` (created and synchronised on first use); nullptr on failure
+const void* device_aux(int dev) {
+    if (dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_aux_mutex);
+    DeviceGuard g(dev);
+    if (sync_shared_locked(dev) != hipSuccess) return nullptr;
+    return g_devctx[dev].dev_aux;
+}
+
+// after a set / slot changed on the host: refresh every device that already has an Aux block, and the current one
+int sync_all_devices() {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(FDSP_EDEVICE, "no HIP device available for shared wavetable / wave data");
+    const int cur = current_device();
+    std::lock_guard<std::mutex> lock(g_aux_mutex);
+    for (int dev = 0; dev < ndev && dev < MAX_DEVICES; dev++) {
+        if (!g_devctx[dev].init && dev != cur) continue;
+        DeviceGuard g(dev);
+        hipError_t e = sync_shared_locked(dev);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? FDSP_ENOMEM : FDSP_EDEVICE, std::string("shared data upload: ") + hipGetErrorString(e));
+    }
+    return FDSP_OK;
 }
 
 int upload_table_set(int set, int n, const float* pitches, const int* lengths, const float* data) {
@@ -84,57 +214,34 @@ int upload_table_set(int set, int n, const float* pitches, const int* lengths, c
         if (lengths[i] < 4 || (lengths[i] & (lengths[i] - 1))) return fail(FDSP_EINVAL, "table lengths must be powers of two >= 4");
         total += (size_t)lengths[i];
     }
-    if (!device_aux()) return fail(FDSP_EDEVICE, "no device memory for wavetables");
-    std::lock_guard<std::mutex> lock(g_aux_mutex);
-    // device layout: every table circularly padded [t[len-1], t[0..len-1], t[0], t[1]] (fd_nodes.hpp wt_tap)
-    std::vector<float> padded;
-    padded.reserve(total + 3 * (size_t)n);
-    std::vector<int> offs(n);
-    size_t src = 0;
-    for (int i = 0; i < n; i++) {
-        const size_t len = (size_t)lengths[i];
-        offs[i] = (int)padded.size();
-        padded.push_back(data[src + len - 1]);
-        padded.insert(padded.end(), data + src, data + src + len);
-        padded.push_back(data[src]);
-        padded.push_back(data[src + 1]);
-        src += len;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(FDSP_EDEVICE, "no HIP device available for wavetables");
+    {
+        std::lock_guard<std::mutex> lock(g_aux_mutex);
+        HostTableSet& t = g_tables[set];
+        t.n = n;
+        t.pitch.assign(pitches, pitches + n);
+        t.len.assign(lengths, lengths + n);
+        t.data.assign(data, data + total);
+        t.ver++;
     }
-    float* d = nullptr;
-    HIPCHK(hipMalloc((void**)&d, padded.size() * sizeof(float)));
-    HIPCHK(hipMemcpy(d, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
-    fd::WtSet& w = g_host_aux.wt[set];
-    HIPCHK(hipDeviceSynchronize());  // no render may still read the tables this replaces
-    if (w.data) hipFree(const_cast<float*>(w.data));
-    w.n = n;
-    for (int i = 0; i < n; i++) {
-        w.pitch[i] = pitches[i];
-        w.off[i] = offs[i];
-        w.len[i] = lengths[i];
-    }
-    w.data = d;
-    g_host_tables[set].assign(data, data + total);
-    HIPCHK(hipMemcpy(g_dev_aux, &g_host_aux, sizeof(fd::Aux), hipMemcpyHostToDevice));
-    return FDSP_OK;
+    return sync_all_devices();
 }
 
 int upload_wave(int slot, int channels, size_t length, const float* data) {
     if (slot < 0 || slot >= fd::WAVE_SLOTS) return fail(FDSP_EINVAL, "wave slot out of range");
     if (channels < 1 || length == 0 || length > 0xFFFFFFF0ull || !data) return fail(FDSP_EINVAL, "bad wave shape or NULL data");
-    if (!device_aux()) return fail(FDSP_EDEVICE, "no device memory for waves");
-    std::lock_guard<std::mutex> lock(g_aux_mutex);
-    float* d = nullptr;
-    const size_t n = (size_t)channels * length;
-    HIPCHK(hipMalloc((void**)&d, n * sizeof(float)));
-    HIPCHK(hipMemcpy(d, data, n * sizeof(float), hipMemcpyHostToDevice));
-    fd::WaveBuf& w = g_host_aux.wave[slot];
-    HIPCHK(hipDeviceSynchronize());  // no render may still read the buffer this replaces
-    if (w.data) hipFree(const_cast<float*>(w.data));
-    w.data = d;
-    w.channels = (uint32_t)channels;
-    w.length = (uint32_t)length;
-    HIPCHK(hipMemcpy(g_dev_aux, &g_host_aux, sizeof(fd::Aux), hipMemcpyHostToDevice));
-    return FDSP_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(FDSP_EDEVICE, "no HIP device available for waves");
+    {
+        std::lock_guard<std::mutex> lock(g_aux_mutex);
+        HostWave& w = g_waves[slot];
+        w.channels = channels;
+        w.length = length;
+        w.data.assign(data, data + (size_t)channels * length);
+        w.ver++;
+    }
+    return sync_all_devices();
 }
 
 // microfft 0.6.0's inverse FFT as the reference's make_wave calls it (fft.rs:51-100, wavetable.rs:75), restated
@@ -268,6 +375,9 @@ struct fdsp_bank {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool timed = false;
     bool ext_pending = false;  // the last render ran on a caller's stream: bank-stream work must wait for its e1
+    int math = FDSP_MATH_EXACT;  // FDSP_MATH_FAST: renders take the kind's tolerance-mode variant when it has one
+    int device = 0;              // the HIP device the bank lives on; every entry point makes it current for its own duration
+    const void* aux = nullptr;   // that device's shared-data block (fd::Aux)
     double sr;
     std::unordered_map<std::string, int> index;
     // voice scheduler (fdsp_bank_set_events / fdsp_bank_process_events): device [4][stride] f64 + [stride] int, clock
@@ -303,6 +413,22 @@ hipError_t await_last_render(fdsp_bank* b) {
     if (!b->ext_pending) return hipSuccess;
     b->ext_pending = false;
     return hipStreamWaitEvent(b->stream, b->e1, 0);
+}
+
+// Kinds with delay lines: did a node just ask for more ring positions than the bank was created with?  (The reference
+// resizes its buffer there; the bank cannot, so the call that caused it fails -- the bank keeps rendering with the
+// longest delay that fits.)  Synchronises the bank's stream; only called after lifecycle launches of ring kinds.
+int check_ring_need(fdsp_bank* b) {
+    if (!b->ring || !b->ops || b->ops->nrings == 0) return FDSP_OK;
+    uint32_t* d_need = reinterpret_cast<uint32_t*>(b->ring + (size_t)b->ops->nrings * b->ring_cap * b->stride);
+    uint32_t need = 0;
+    HIPCHK(hipMemcpyAsync(&need, d_need, sizeof need, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (need <= b->ring_cap) return FDSP_OK;
+    HIPCHK(hipMemsetAsync(d_need, 0, sizeof need, b->stream));
+    return fail(FDSP_EINVAL, "ring capacity too small: a delay / tap / limiter node needs " + std::to_string(need) +
+                                 " positions at this sample rate, the bank was created with ring_frames = " +
+                                 std::to_string(b->ring_cap) + " (the node keeps the longest length that fits)");
 }
 
 int find_slot(const fdsp_bank* b, const char* name) {
@@ -378,14 +504,19 @@ extern "C" {
 
 const char* fdsp_last_error(void) { return g_err.c_str(); }
 
-int fdsp_kind_count(void) { return (int)registry().size(); }
-const char* fdsp_kind_name(int kind) {
+int fdsp_kind_count(void) {
     auto& r = registry();
-    return (kind >= 0 && kind < (int)r.size()) ? r[kind].name.c_str() : nullptr;
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    return (int)r.size();
+}
+const char* fdsp_kind_name(int kind) {
+    const fd::KindOps* k = kind_at(kind);
+    return k ? k->name.c_str() : nullptr;
 }
 int fdsp_kind_by_name(const char* name) {
     auto& r = registry();
     if (!name) return -1;
+    std::lock_guard<std::mutex> lock(g_registry_mutex);  // fdsp_graph_compile_src appends concurrently
     for (size_t i = 0; i < r.size(); i++)
         if (r[i].name == name) return (int)i;
     return -1;
@@ -407,7 +538,28 @@ int fdsp_set_option(const char* name, int value) {
         fd::g_fdn_kernel = value;
         return FDSP_OK;
     }
+    if (name && std::strcmp(name, "math") == 0) {
+        if (value != FDSP_MATH_EXACT && value != FDSP_MATH_FAST) return fail(FDSP_EINVAL, "math takes FDSP_MATH_EXACT (0) or FDSP_MATH_FAST (1)");
+        fd::g_math = value;
+        return FDSP_OK;
+    }
     return fail(FDSP_EINVAL, "unknown option");
+}
+
+int fdsp_bank_set_option(fdsp_bank* b, const char* name, int value) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    if (name && std::strcmp(name, "math") == 0) {
+        if (value != FDSP_MATH_EXACT && value != FDSP_MATH_FAST) return fail(FDSP_EINVAL, "math takes FDSP_MATH_EXACT (0) or FDSP_MATH_FAST (1)");
+        b->math = value;
+        return FDSP_OK;
+    }
+    return fail(FDSP_EINVAL, "unknown bank option");
+}
+int fdsp_bank_get_option(const fdsp_bank* b, const char* name) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    if (name && std::strcmp(name, "math") == 0) return b->math;
+    if (name && std::strcmp(name, "math_has_fast_variant") == 0) return (b->ops && b->ops->render_fast) ? 1 : 0;
+    return fail(FDSP_EINVAL, "unknown bank option");
 }
 
 int fdsp_graph_compile(const char* name, const char* type_expr) { return fdsp_graph_compile_src(name, type_expr, nullptr); }
@@ -423,6 +575,8 @@ int fdsp_graph_compile_src(const char* name, const char* type_expr, const char* 
     std::string err;
     if (fd::jit_make_kind(name, type_expr, source ? source : "", &k, &err) != 0) return fail(FDSP_EINVAL, err);
     std::lock_guard<std::mutex> lock(g_registry_mutex);
+    for (size_t i = 0; i < registry().size(); i++)  // another thread may have compiled the same name meanwhile
+        if (registry()[i].name == name) return (int)i;
     registry().push_back(std::move(k));
     return (int)registry().size() - 1;
 }
@@ -436,33 +590,44 @@ int fdsp_graph_check(const char* type_expr) {
 }
 
 int fdsp_kind_inputs(int kind) {
-    auto& r = registry();
-    return (kind >= 0 && kind < (int)r.size()) ? r[kind].nin : FDSP_EINVAL;
+    const fd::KindOps* k = kind_at(kind);
+    return k ? k->nin : FDSP_EINVAL;
 }
 int fdsp_kind_outputs(int kind) {
-    auto& r = registry();
-    return (kind >= 0 && kind < (int)r.size()) ? r[kind].nout : FDSP_EINVAL;
+    const fd::KindOps* k = kind_at(kind);
+    return k ? k->nout : FDSP_EINVAL;
 }
 int fdsp_kind_slot_count(int kind) {
-    auto& r = registry();
-    return (kind >= 0 && kind < (int)r.size()) ? (int)r[kind].slots.size() : FDSP_EINVAL;
+    const fd::KindOps* k = kind_at(kind);
+    return k ? (int)k->slots.size() : FDSP_EINVAL;
 }
 const char* fdsp_kind_slot_name(int kind, int slot) {
-    auto& r = registry();
-    if (kind < 0 || kind >= (int)r.size() || slot < 0 || slot >= (int)r[kind].slots.size()) return nullptr;
-    return r[kind].slots[slot].name.c_str();
+    const fd::KindOps* k = kind_at(kind);
+    if (!k || slot < 0 || slot >= (int)k->slots.size()) return nullptr;
+    return k->slots[slot].name.c_str();
 }
 int fdsp_kind_slot_kind(int kind, int slot) {
-    auto& r = registry();
-    if (kind < 0 || kind >= (int)r.size() || slot < 0 || slot >= (int)r[kind].slots.size()) return FDSP_EINVAL;
-    return r[kind].slots[slot].kind;
+    const fd::KindOps* k = kind_at(kind);
+    if (!k || slot < 0 || slot >= (int)k->slots.size()) return FDSP_EINVAL;
+    return k->slots[slot].kind;
 }
 
+int fdsp_device_count(void) {
+    int ndev = 0;
+    return hipGetDeviceCount(&ndev) == hipSuccess ? ndev : 0;
+}
+
+int fdsp_bank_device(const fdsp_bank* b) { return b ? b->device : FDSP_EINVAL; }
+
 int fdsp_bank_create(const char* kind, size_t voices, fdsp_bank** out) {
-    return fdsp_bank_create_ring(kind, voices, 0, out);
+    return fdsp_bank_create_on(-1, kind, voices, 0, out);
 }
 
 int fdsp_bank_create_ring(const char* kind, size_t voices, size_t ring_frames, fdsp_bank** out) {
+    return fdsp_bank_create_on(-1, kind, voices, ring_frames, out);
+}
+
+int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring_frames, fdsp_bank** out) {
     if (!out) return fail(FDSP_EINVAL, "out is NULL");
     *out = nullptr;
     int k = fdsp_kind_by_name(kind);
@@ -471,8 +636,15 @@ int fdsp_bank_create_ring(const char* kind, size_t voices, size_t ring_frames, f
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(FDSP_EDEVICE, "no HIP device available: the fundsp_hip engine has no CPU fallback");
+    if (device < 0) device = current_device();
+    if (device < 0 || device >= ndev || device >= MAX_DEVICES) return fail(FDSP_EINVAL, "device index out of range");
+    DeviceGuard guard(device);
+    const void* aux = device_aux(device);
+    if (!aux) return fail(FDSP_EDEVICE, "cannot set up the shared-data block on the device");
     fdsp_bank* b = new fdsp_bank();
-    b->ops = &registry()[k];
+    b->device = device;
+    b->aux = aux;
+    b->ops = kind_at(k);
     b->V = voices;
     b->stride = (voices + 63) / 64 * 64;
     b->nslots = (int)b->ops->slots.size();
@@ -480,6 +652,7 @@ int fdsp_bank_create_ring(const char* kind, size_t voices, size_t ring_frames, f
     b->stream = nullptr;
     b->timed = false;
     b->sr = FDSP_DEFAULT_SR;
+    b->math = fd::g_math;
     for (int i = 0; i < b->nslots; i++) b->index[b->ops->slots[i].name] = i;
     size_t bytes = (size_t)(b->nslots > 0 ? b->nslots : 1) * b->stride * sizeof(float);
     hipError_t e = hipMalloc((void**)&b->slots, bytes);
@@ -498,7 +671,8 @@ int fdsp_bank_create_ring(const char* kind, size_t voices, size_t ring_frames, f
             return fail(FDSP_EINVAL, "this kind contains delay lines: create it with fdsp_bank_create_ring(kind, voices, ring_frames)");
         }
         b->ring_cap = (uint32_t)ring_frames;
-        const size_t rbytes = (size_t)b->ops->nrings * ring_frames * b->stride * sizeof(float);
+        // + one 64-byte line behind the rings: the word in which a node reports that it wanted more positions
+        const size_t rbytes = (size_t)b->ops->nrings * ring_frames * b->stride * sizeof(float) + 64;
         e = hipMalloc((void**)&b->ring, rbytes);
         if (e != hipSuccess) {
             fdsp_bank_destroy(b);
@@ -507,12 +681,16 @@ int fdsp_bank_create_ring(const char* kind, size_t voices, size_t ring_frames, f
         hipMemsetAsync(b->ring, 0, rbytes, b->stream);
     }
     hipMemsetAsync(b->slots, 0, bytes, b->stream);
-    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 0, b->sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
+    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 0, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
     e = hipStreamSynchronize(b->stream);
     if (e != hipSuccess) {
         fdsp_bank_destroy(b);
         return fail(FDSP_EDEVICE, std::string("bank construction kernel failed: ") + hipGetErrorString(e));
     }
+    // Construction runs every node's update() with its DEFAULT parameters (e.g. the limiter's 5 ms attack), which the
+    // caller is about to replace: a capacity complaint raised by defaults is discarded here; the first set_sample_rate /
+    // set_param re-evaluates every length with the real parameters and fails if the rings are too small for them.
+    if (b->ring) hipMemsetAsync(b->ring + (size_t)b->ops->nrings * b->ring_cap * b->stride, 0, 64, b->stream);
     *out = b;
     return FDSP_OK;
 }
@@ -529,32 +707,53 @@ static void fdn_free(FdnBank* f) {
 
 // (re)allocate rings for the current sample rate and zero everything: Delay::set_sample_rate resizes + resets
 // when the rate changes (delay.rs:105-113)
+// Transactional: the new constants are validated and the new buffers allocated BEFORE anything of the bank changes; on
+// any failure the bank keeps its old constants, rings and rate.
 static int fdn_configure(fdsp_bank* b, double sr) {
     FdnBank* f = b->fdn;
-    fd::fdn_make_const(f->room, f->time, f->damping, sr, &f->c);
+    fd::FdnConst c;
+    fd::fdn_make_const(f->room, f->time, f->damping, sr, &c);
     for (int i = 0; i < 32; i++)
-        if (f->c.len[i] <= 128)
+        if (c.len[i] <= 128)
             return fail(FDSP_EINVAL, "reverb_stereo: every delay must exceed 128 samples (room_size * sample_rate too small)");
-    fdn_free(f);
     const size_t n = b->V;
-    HIPCHK(hipMalloc((void**)&f->st.rings, n * f->c.ring_stride * sizeof(float)));
-    HIPCHK(hipMalloc((void**)&f->st.idx, n * 32 * sizeof(int)));
-    HIPCHK(hipMalloc((void**)&f->st.v1, n * 32 * sizeof(float)));
-    HIPCHK(hipMalloc((void**)&f->st.v2, n * 32 * sizeof(float)));
-    HIPCHK(hipMalloc((void**)&f->st.fb, n * 32 * sizeof(float)));
+    fd::FdnState st{};
+    hipError_t e = hipMalloc((void**)&st.rings, n * c.ring_stride * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&st.idx, n * 32 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&st.v1, n * 32 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&st.v2, n * 32 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&st.fb, n * 32 * sizeof(float));
+    if (e != hipSuccess) {
+        FdnBank tmp;
+        tmp.st = st;
+        fdn_free(&tmp);
+        return fail(e == hipErrorOutOfMemory ? FDSP_ENOMEM : FDSP_EDEVICE, std::string("reverb_stereo buffers: ") + hipGetErrorString(e));
+    }
+    fdn_free(f);  // the old buffers (the caller has synchronised the bank's stream)
+    f->c = c;
+    f->st = st;
+    b->sr = sr;
     fd::fdn_launch_reset(f->c, f->st, n, b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
 }
 
 int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, double damping, fdsp_bank** out) {
+    return fdsp_reverb_stereo_create_on(-1, instances, room_size, time, damping, out);
+}
+
+int fdsp_reverb_stereo_create_on(int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out) {
     if (!out) return fail(FDSP_EINVAL, "out is NULL");
     *out = nullptr;
     if (instances == 0 || !(room_size > 0.0) || !(time > 0.0)) return fail(FDSP_EINVAL, "bad reverb_stereo arguments");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(FDSP_EDEVICE, "no HIP device available: the fundsp_hip engine has no CPU fallback");
+    if (device < 0) device = current_device();
+    if (device < 0 || device >= ndev || device >= MAX_DEVICES) return fail(FDSP_EINVAL, "device index out of range");
+    DeviceGuard guard(device);
     fdsp_bank* b = new fdsp_bank();
+    b->device = device;
     b->fdn = new FdnBank();
     b->fdn->room = room_size;
     b->fdn->time = time;
@@ -588,6 +787,7 @@ int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, d
 
 void fdsp_bank_destroy(fdsp_bank* b) {
     if (!b) return;
+    DeviceGuard guard(b->device);
     // a render that ran on a caller's stream may still be reading the slots: wait for its completion event first
     if (b->ext_pending && b->e1) hipEventSynchronize(b->e1);
     if (b->stream) hipStreamSynchronize(b->stream);
@@ -616,21 +816,23 @@ size_t fdsp_bank_voices(const fdsp_bank* b) { return b ? b->V : 0; }
 
 int fdsp_bank_set_sample_rate(fdsp_bank* b, double sr) {
     if (!b || !(sr > 0.0)) return fail(FDSP_EINVAL, "bad bank or sample rate");
+    DeviceGuard guard(b->device);
     if (b->fdn) {
         if (sr == b->sr) return FDSP_OK;  // Delay::set_sample_rate: nothing happens unless the rate changes
+        HIPCHK(await_last_render(b));
         HIPCHK(hipStreamSynchronize(b->stream));
-        b->sr = sr;
-        return fdn_configure(b, sr);
+        return fdn_configure(b, sr);  // sets b->sr on success only
     }
     b->sr = sr;
     HIPCHK(await_last_render(b));
-    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
+    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
-    return FDSP_OK;
+    return check_ring_need(b);
 }
 
 int fdsp_bank_reset(fdsp_bank* b) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    DeviceGuard guard(b->device);
     if (b->fdn) {
         HIPCHK(await_last_render(b));
         fd::fdn_launch_reset(b->fdn->c, b->fdn->st, b->V, b->stream);
@@ -638,13 +840,14 @@ int fdsp_bank_reset(fdsp_bank* b) {
         return FDSP_OK;
     }
     HIPCHK(await_last_render(b));
-    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 2, b->sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
+    b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 2, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
 }
 
 int fdsp_bank_set_seed(fdsp_bank* b, const uint64_t* h_seeds, size_t first, size_t count) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    DeviceGuard guard(b->device);
     if (b->fdn) return FDSP_OK;  // no node of reverb_stereo uses its hash (Delay, Fir, Panner: default set_hash)
     if (int rc = check_range(b, first, count)) return rc;
     if (count == 0) return FDSP_OK;
@@ -658,7 +861,7 @@ int fdsp_bank_set_seed(fdsp_bank* b, const uint64_t* h_seeds, size_t first, size
         }
     }
     HIPCHK(await_last_render(b));
-    b->ops->lifecycle(b->slots, b->stride, first, count, 3, b->sr, d, device_aux(), b->ring, b->ring_cap, b->stream);
+    b->ops->lifecycle(b->slots, b->stride, first, count, 3, b->sr, d, b->aux, b->ring, b->ring_cap, b->stream);
     hipError_t e = hipStreamSynchronize(b->stream);
     if (d) hipFree(d);
     if (e != hipSuccess) return fail(FDSP_EDEVICE, hipGetErrorString(e));
@@ -684,6 +887,7 @@ static int set_words(fdsp_bank* b, int slot, const void* h_words, size_t first, 
 int fdsp_bank_set_param(fdsp_bank* b, const char* name, const float* h_values, size_t first, size_t count) {
     if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b || !h_values) return fail(FDSP_EINVAL, "bank or values NULL");
+    DeviceGuard guard(b->device);
     int s = find_slot(b, name);
     if (s < 0) return fail(FDSP_EINVAL, std::string("unknown slot: ") + (name ? name : "(null)"));
     if (int rc = check_range(b, first, count)) return rc;
@@ -691,9 +895,9 @@ int fdsp_bank_set_param(fdsp_bank* b, const char* name, const float* h_values, s
     if (int rc = set_words(b, s, h_values, first, count)) return rc;
     // re-derive coefficients like the reference setters do (idempotent for untouched voices)
     HIPCHK(await_last_render(b));
-    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
+    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
-    return FDSP_OK;
+    return check_ring_need(b);
 }
 
 int fdsp_bank_set_param_all(fdsp_bank* b, const char* name, float value) {
@@ -706,6 +910,7 @@ int fdsp_bank_set_param_all(fdsp_bank* b, const char* name, float value) {
 int fdsp_bank_set_param_u64(fdsp_bank* b, const char* name, const uint64_t* h_values, size_t first, size_t count) {
     if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b || !h_values || !name) return fail(FDSP_EINVAL, "bank, name or values NULL");
+    DeviceGuard guard(b->device);
     int lo = find_slot(b, (std::string(name) + ".lo").c_str());
     int hi = find_slot(b, (std::string(name) + ".hi").c_str());
     if (lo < 0 || hi < 0) return fail(FDSP_EINVAL, std::string("unknown u64 slot: ") + name);
@@ -719,14 +924,15 @@ int fdsp_bank_set_param_u64(fdsp_bank* b, const char* name, const uint64_t* h_va
     if (int rc = set_words(b, lo, wl.data(), first, count)) return rc;
     if (int rc = set_words(b, hi, wh.data(), first, count)) return rc;
     HIPCHK(await_last_render(b));
-    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, device_aux(), b->ring, b->ring_cap, b->stream);
+    b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
-    return FDSP_OK;
+    return check_ring_need(b);
 }
 
 int fdsp_bank_get_slot(fdsp_bank* b, const char* name, float* h_values, size_t first, size_t count) {
     if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b || !h_values) return fail(FDSP_EINVAL, "bank or values NULL");
+    DeviceGuard guard(b->device);
     int s = find_slot(b, name);
     if (s < 0) return fail(FDSP_EINVAL, std::string("unknown slot: ") + (name ? name : "(null)"));
     if (int rc = check_range(b, first, count)) return rc;
@@ -739,6 +945,7 @@ int fdsp_bank_get_slot(fdsp_bank* b, const char* name, float* h_values, size_t f
 int fdsp_bank_get_state(fdsp_bank* b, float* h_slots) {
     if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b || !h_slots) return fail(FDSP_EINVAL, "bank or buffer NULL");
+    DeviceGuard guard(b->device);
     HIPCHK(await_last_render(b));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (b->nslots == 0) return FDSP_OK;
@@ -750,6 +957,7 @@ int fdsp_bank_get_state(fdsp_bank* b, float* h_slots) {
 int fdsp_bank_set_state(fdsp_bank* b, const float* h_slots) {
     if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b || !h_slots) return fail(FDSP_EINVAL, "bank or buffer NULL");
+    DeviceGuard guard(b->device);
     HIPCHK(await_last_render(b));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (b->nslots == 0) return FDSP_OK;
@@ -761,6 +969,7 @@ int fdsp_bank_set_state(fdsp_bank* b, const float* h_slots) {
 int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_out, int layout, size_t frame_stride,
                       int mode, void* stream) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    DeviceGuard guard(b->device);
     if (frames == 0) return FDSP_OK;  // size == 0 is a legal no-op (audionode.rs:82)
     if (!d_out) return fail(FDSP_EINVAL, "d_out is NULL");
     if (fdsp_bank_inputs(b) > 0 && !d_in) return fail(FDSP_EINVAL, "d_in is NULL but the graph has inputs");
@@ -772,11 +981,16 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (s != b->stream) hipStreamIsCapturing(s, &cap);
     const bool capturing = cap != hipStreamCaptureStatusNone;  // a captured launch leaves the timing events alone
+    // a previous render may still be running on ANOTHER stream (caller streams differ from call to call, or the last one
+    // ran on a caller stream and this one runs on the bank's): it reads and writes the same voice state, so order behind it
+    if (b->ext_pending && !capturing) HIPCHK(hipStreamWaitEvent(s, b->e1, 0));
     if (!capturing) HIPCHK(hipEventRecord(b->e0, s));
     if (b->fdn)  // Feedback::process is the per-sample tick (feedback.rs:136-146): both modes are the same arithmetic
         fd::fdn_launch_render(b->fdn->c, b->fdn->st, b->V, d_in, d_out, frames, frame_stride, layout, s);
+    else if (b->math == FDSP_MATH_FAST && b->ops->render_fast)
+        b->ops->render_fast(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, b->aux, b->ring, b->ring_cap, s);
     else
-        b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, device_aux(), b->ring, b->ring_cap, s);
+        b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, b->aux, b->ring, b->ring_cap, s);
     HIPCHK(hipGetLastError());
     if (!capturing) {
         HIPCHK(hipEventRecord(b->e1, s));
@@ -788,6 +1002,7 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
 
 int fdsp_bank_set_ring(fdsp_bank* b, int ring_index, const float* data, size_t frames, size_t first, size_t count) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    DeviceGuard guard(b->device);
     if (b->fdn || !b->ring) return fail(FDSP_EINVAL, "this bank has no ring memory");
     if (!data) return fail(FDSP_EINVAL, "data is NULL");
     if (ring_index < 0 || ring_index >= b->ops->nrings) return fail(FDSP_EINVAL, "ring index out of range");
@@ -808,6 +1023,7 @@ int fdsp_bank_set_ring(fdsp_bank* b, int ring_index, const float* data, size_t f
 
 int fdsp_bank_set_events(fdsp_bank* b, const double* events, const int* fade, size_t first, size_t count) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    DeviceGuard guard(b->device);
     if (b->fdn) return fail(FDSP_EINVAL, "reverb banks have no event scheduler");
     if (!events) return fail(FDSP_EINVAL, "events is NULL");
     if (int rc = check_range(b, first, count)) return rc;
@@ -859,6 +1075,7 @@ double fdsp_bank_events_time(const fdsp_bank* b) { return b ? b->seq_time : 0.0;
 
 int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, float* d_out, int mode, void* stream) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    DeviceGuard guard(b->device);
     if (frames == 0) return FDSP_OK;
     if (!b->ev) return fail(FDSP_EINVAL, "no events set (fdsp_bank_set_events)");
     if (!d_out) return fail(FDSP_EINVAL, "d_out is NULL");
@@ -869,6 +1086,7 @@ int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, flo
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (s != b->stream) hipStreamIsCapturing(s, &cap);
     const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (b->ext_pending && !capturing) HIPCHK(hipStreamWaitEvent(s, b->e1, 0));
     if (!capturing) HIPCHK(hipEventRecord(b->e0, s));
     // the clock after this launch, advanced exactly as the reference does: one f64 addition per block / per sample
     const double sd = 1.0 / b->sr, t_begin = b->seq_time;
@@ -895,11 +1113,11 @@ int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, flo
     const bool sustained = !b->ev_host.empty() && b->ev_max_start <= t_begin && b->ev_min_end >= t_end &&
                            b->ev_max_fade_in_end <= t_begin && b->ev_min_fade_out_start >= t_end;
     if (sustained)
-        b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, 0, FDSP_LAYOUT_VOICE_MINOR, mode, device_aux(), b->ring,
+        b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, 0, FDSP_LAYOUT_VOICE_MINOR, mode, b->aux, b->ring,
                        b->ring_cap, s);
     else
     b->ops->render_events(b->slots, b->stride, b->V, d_in, d_out, frames, b->ev, b->ev_fade, b->seq_time, b->sr, mode,
-                          device_aux(), b->ring, b->ring_cap, s);
+                          b->aux, b->ring, b->ring_cap, s);
     HIPCHK(hipGetLastError());
     if (!capturing) {
         HIPCHK(hipEventRecord(b->e1, s));
@@ -938,6 +1156,7 @@ hipError_t stage_reserve(float** p, size_t* have, size_t want, bool pinned) {
 int fdsp_bank_process_host(fdsp_bank* b, size_t frames, const float* h_in, float* h_out, int layout,
                            size_t frame_stride, int mode) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    DeviceGuard guard(b->device);
     if (frames == 0) return FDSP_OK;
     if (!h_out) return fail(FDSP_EINVAL, "h_out is NULL");
     const bool planar = layout == FDSP_LAYOUT_PLANAR;
@@ -992,12 +1211,14 @@ int fdsp_bank_process_host(fdsp_bank* b, size_t frames, const float* h_in, float
 
 int fdsp_bank_synchronize(fdsp_bank* b) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    DeviceGuard guard(b->device);
     HIPCHK(hipStreamSynchronize(b->stream));
     return FDSP_OK;
 }
 
 int fdsp_bank_last_kernel_ms(fdsp_bank* b, float* ms) {
     if (!b || !ms) return fail(FDSP_EINVAL, "bank or ms NULL");
+    DeviceGuard guard(b->device);
     if (!b->timed) return fail(FDSP_EINVAL, "no process call recorded yet");
     HIPCHK(hipEventSynchronize(b->e1));
     HIPCHK(hipEventElapsedTime(ms, b->e0, b->e1));
@@ -1008,6 +1229,7 @@ int fdsp_mix_stereo(const float* d_voices, const float* d_pan, float* d_mix, siz
                     void* stream) {
     if (!d_voices || !d_mix) return fail(FDSP_EINVAL, "NULL buffer");
     if (frames == 0 || voices == 0) return FDSP_OK;
+    DeviceGuard guard(device_of(d_voices));  // the kernels run where the voices live, whatever device is current
     hipStream_t s = (hipStream_t)stream;
     float* w = nullptr;
     HIPCHK(hipMallocAsync((void**)&w, 2 * voices * sizeof(float), s));
@@ -1045,16 +1267,14 @@ int fdsp_wave_upload(int slot, int channels, size_t length, const float* h_data)
 int fdsp_wavetable_get(int set, int* n_tables, float* h_pitches, int* h_lengths, float* h_data, size_t capacity) {
     if (set < 0 || set >= fd::WT_SETS || !n_tables) return fail(FDSP_EINVAL, "bad set");
     std::lock_guard<std::mutex> lock(g_aux_mutex);
-    const fd::WtSet& w = g_host_aux.wt[set];
-    *n_tables = g_dev_aux ? w.n : 0;
-    if (!g_dev_aux || w.n == 0) return FDSP_OK;
-    size_t total = 0;
-    for (int i = 0; i < w.n; i++) total += (size_t)w.len[i];
-    if (h_pitches) std::memcpy(h_pitches, w.pitch, sizeof(float) * (size_t)w.n);
-    if (h_lengths) std::memcpy(h_lengths, w.len, sizeof(int) * (size_t)w.n);
+    const HostTableSet& t = g_tables[set];
+    *n_tables = t.n;
+    if (t.n == 0) return FDSP_OK;
+    if (h_pitches) std::memcpy(h_pitches, t.pitch.data(), sizeof(float) * (size_t)t.n);
+    if (h_lengths) std::memcpy(h_lengths, t.len.data(), sizeof(int) * (size_t)t.n);
     if (h_data) {
-        if (capacity < total) return fail(FDSP_EINVAL, "capacity too small");
-        std::memcpy(h_data, g_host_tables[set].data(), total * sizeof(float));
+        if (capacity < t.data.size()) return fail(FDSP_EINVAL, "capacity too small");
+        std::memcpy(h_data, t.data.data(), t.data.size() * sizeof(float));
     }
     return FDSP_OK;
 }
@@ -1062,6 +1282,7 @@ int fdsp_wavetable_get(int set, int* n_tables, float* h_pitches, int* h_lengths,
 int fdsp_sum_voices(const float* d_in, float* d_out, size_t channels, size_t frames, size_t voices, void* stream) {
     if (!d_in || !d_out) return fail(FDSP_EINVAL, "NULL buffer");
     if (channels == 0 || frames == 0 || voices == 0) return FDSP_OK;
+    DeviceGuard guard(device_of(d_in));
     hipLaunchKernelGGL(k_sum_voices, dim3((unsigned)(channels * frames)), dim3(256), 0, (hipStream_t)stream, d_in, d_out,
                        voices);
     HIPCHK(hipGetLastError());

@@ -103,6 +103,8 @@ FD_D void lifecycle_body(float* slots, size_t stride, size_t first, size_t count
     size_t v = first + i;
     G g;
     Ctx ctx{static_cast<const Aux*>(aux), ring + v, ring_cap, stride, 0};
+    // the "capacity too small" word sits right behind the bank's ring memory (fd_capi.hip allocates it)
+    if (G::RINGS > 0 && ring) ctx.ring_need = reinterpret_cast<uint32_t*>(ring + (size_t)G::RINGS * ring_cap * stride);
     g.bind(ctx);
     {
         VLoad ld{slots + v, stride, 0};
@@ -612,6 +614,8 @@ template <class T> struct Cost { static constexpr int v = 12; };  // rough VALU 
 template <int N> struct Cost<Constant<N>> { static constexpr int v = 0; };
 template <> struct Cost<Pass> { static constexpr int v = 0; };
 template <> struct Cost<Sine> { static constexpr int v = 20; };
+template <> struct Cost<SineFast> { static constexpr int v = 12; };
+template <> struct Cost<FixedSvfLp> { static constexpr int v = 11; };
 template <> struct Cost<Noise> { static constexpr int v = 10; };
 template <> struct Cost<FixedSvf> { static constexpr int v = 16; };
 template <int N> struct Cost<Moog<N>> { static constexpr int v = 130; };
@@ -1026,7 +1030,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
 
     const int stage = role - (FEED ? 1 : 0);
     const size_t first = (size_t)stage + (FEED ? 1 : 0);  // the round in which this stage sees tile 0
-    G g;
+    G g{};
     Ctx ctx{static_cast<const Aux*>(aux), ring + (live ? v : 0), ring_cap, stride, 0};
     g.bind(ctx);
     if (live) {
@@ -1034,27 +1038,43 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
         VGate::W<VLoad> gate{&ld, true};
         if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
     }
-    for (size_t it = 0; it < rounds; it++) {
-        if (live && active && it >= first && it - first < ntiles) {
-            const size_t j = it - first;          // the tile this stage works on in this round
-            const size_t t0 = (j / SPB) * 64;
-            const int h = (int)(j % SPB);
-            const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
-            const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
-            const float* fin = nullptr;
-            if constexpr (FEED) fin = &feed[grp][j % D][0][0][0];
-            if (stage == 0) {
-                if constexpr (S == 1) pipe_stage<S0, G, MODE, SUB, W, true, true>(g, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr);
-                else pipe_stage<S0, G, MODE, SUB, W, true, false>(g, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
-            } else if (stage == 1) {
-                if constexpr (S == 2) pipe_stage<S1, G, MODE, SUB, W, false, true>(g, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr);
-                else if constexpr (S == 3) pipe_stage<S1, G, MODE, SUB, W, false, false>(g, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
-            } else {
-                if constexpr (S == 3) pipe_stage<S2, G, MODE, SUB, W, false, true>(g, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr);
+    // The rounds, for the graph type GG: G itself, or its lowpass-specialised twin LpOf<G> (same registers, the
+    // packed SVF path 5 operations shorter) when every lane of THIS wave qualifies.  A wave that does not hold the SVF
+    // segment sees zeroed coefficients, takes the generic type and runs the same arithmetic for its own segment.
+    auto rounds_of = [&](auto* tag) {
+        using GG = typename Pointee<decltype(tag)>::type;
+        using TG = PipeTiles<GG, S, K1, K2>;
+        using T0 = typename TG::S0;
+        using T1 = typename TG::S1;
+        using T2 = typename TG::S2;
+        GG& gg = reinterpret_cast<GG&>(g);
+        for (size_t it = 0; it < rounds; it++) {
+            if (live && active && it >= first && it - first < ntiles) {
+                const size_t j = it - first;          // the tile this stage works on in this round
+                const size_t t0 = (j / SPB) * 64;
+                const int h = (int)(j % SPB);
+                const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+                const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
+                const float* fin = nullptr;
+                if constexpr (FEED) fin = &feed[grp][j % D][0][0][0];
+                if (stage == 0) {
+                    if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr);
+                    else pipe_stage<T0, GG, MODE, SUB, W, true, false>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
+                } else if (stage == 1) {
+                    if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr);
+                    else if constexpr (S == 3) pipe_stage<T1, GG, MODE, SUB, W, false, false>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
+                } else {
+                    if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr);
+                }
             }
+            __syncthreads();  // hand-over point: every role has finished its tile of this round
         }
-        __syncthreads();  // hand-over point: every role has finished its tile of this round
-    }
+    };
+    using GL = typename LpOf<G>::type;
+    bool lp = false;
+    if constexpr (!SameType<GL, G>::v && MODE == MODE_PROCESS)
+        lp = __builtin_amdgcn_ballot_w64((live && active) && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(live && active) != 0ull;
+    if (lp) rounds_of((GL*)nullptr); else rounds_of((G*)nullptr);
     if (live && active) {
         VStore<false> st{slots + v, stride, 0};
         VGate::W<VStore<false>> gate{&st, true};
@@ -1311,6 +1331,7 @@ FD_D void describe_body(char* out, int cap, int* meta) {
     meta[5] = P.S;
     meta[6] = P.S >= 1 ? 64 * PipeGeom<G::IN, (P.S >= 1 ? P.S : 1)>::WAVES : 0;
     meta[7] = PlanarPlan<G>::S >= 1 ? 256 * PlanarPlan<G>::T::WAVES : 0;  // threads of the planar pipeline kernel (0 = none)
+    meta[8] = SameType<typename FastOf<G>::type, G>::v ? 0 : 1;            // the graph has a tolerance-mode variant
 }
 
 // pipeline kernel entry for run-time compiled graphs: empty when the graph has no plan

@@ -52,6 +52,11 @@ struct KindOps {
     std::function<void(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
                        int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s)>
         render;
+    // the same launch for the tolerance-mode variant FastOf<G> of the graph (fdsp_set_option("math", 1)); empty when the
+    // graph has no node with a tolerance-mode form (then `render` is used)
+    std::function<void(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
+                       int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s)>
+        render_fast;
     // Sequencer-style rendering (fd_device.hpp render_events_body): ev = device [4][stride] f64, fade = device [V] or null
     std::function<void(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, const double* ev,
                        const int* fade, double time0, double sr, int mode, const void* aux, float* ring,
@@ -211,6 +216,8 @@ KindOps make_kind(const char* name) {
     g.visit(d);
     k.lifecycle = &launch_lifecycle<G>;
     k.render = &launch_render<G>;
+    using GF = typename FastOf<G>::type;
+    if constexpr (!SameType<GF, G>::v) k.render_fast = &launch_render<GF>;
     k.render_events = &launch_render_events<G>;
     return k;
 }

@@ -12,6 +12,8 @@
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <mutex>
+#include <cstdio>
 #include <sstream>
 
 #include "fd_engine.hpp"
@@ -39,19 +41,104 @@ bool read_file(const std::string& path, std::string* out) {
     return true;
 }
 
-struct JitModule {
+// One compiled graph: the code object plus, per HIP device, the module loaded on it (hipModule_t belongs to a device;
+// a process may keep banks of the same kind on several GPUs, fdsp_bank_create_on).  Loaded lazily under a mutex.
+struct JitFuncs {
     hipModule_t mod = nullptr;
     hipFunction_t lifecycle = nullptr, describe = nullptr;
     hipFunction_t render[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [mode][layout]
     hipFunction_t events[2] = {nullptr, nullptr};                            // [mode]
     hipFunction_t pipe[2] = {nullptr, nullptr};                              // [mode], pipeline kernel
     hipFunction_t pipe_planar[2] = {nullptr, nullptr};                       // [mode], planar-layout pipeline kernel
+};
+struct JitModule {
+    static constexpr int MAXD = 64;
+    std::vector<char> code;
+    std::mutex mu;
+    JitFuncs dev[MAXD];
+    bool loaded[MAXD] = {false};
     int pipe_stages = 0, pipe_threads = 0, pipe_planar_threads = 0;
     int wpb[2] = {4, 4};                                                     // per layout
+    // the tolerance-mode twin of this graph (FastOf<G>), compiled on first use
+    std::string type_expr, prelude;
+    bool has_fast = false, fast_failed = false;
+    std::shared_ptr<JitModule> fast;
     ~JitModule() {
-        if (mod) hipModuleUnload(mod);
+        for (int d = 0; d < MAXD; d++)
+            if (loaded[d] && dev[d].mod) hipModuleUnload(dev[d].mod);
+    }
+    // functions of the CURRENT device (nullptr + *err on failure)
+    const JitFuncs* get(std::string* err = nullptr) {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAXD) {
+            if (err) *err = "no current HIP device";
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> lock(mu);
+        if (loaded[d]) return dev[d].mod ? &dev[d] : nullptr;
+        loaded[d] = true;
+        JitFuncs& f = dev[d];
+        if (hipModuleLoadData(&f.mod, code.data()) != hipSuccess) {
+            f.mod = nullptr;
+            if (err) *err = "hipModuleLoadData failed for the compiled graph";
+            return nullptr;
+        }
+        bool ok = hipModuleGetFunction(&f.lifecycle, f.mod, "jit_lifecycle") == hipSuccess &&
+                  hipModuleGetFunction(&f.describe, f.mod, "jit_describe") == hipSuccess;
+        for (int m = 0; m < 2 && ok; m++)
+            for (int l = 0; l < 2 && ok; l++) {
+                std::string fn = "jit_render_" + std::to_string(m) + std::to_string(l);
+                ok = hipModuleGetFunction(&f.render[m][l], f.mod, fn.c_str()) == hipSuccess;
+            }
+        for (int m = 0; m < 2 && ok; m++) {
+            std::string fn = "jit_events_" + std::to_string(m);
+            ok = hipModuleGetFunction(&f.events[m], f.mod, fn.c_str()) == hipSuccess;
+            fn = "jit_pipe_" + std::to_string(m);
+            ok = ok && hipModuleGetFunction(&f.pipe[m], f.mod, fn.c_str()) == hipSuccess;
+            fn = "jit_pipe_planar_" + std::to_string(m);
+            ok = ok && hipModuleGetFunction(&f.pipe_planar[m], f.mod, fn.c_str()) == hipSuccess;
+        }
+        if (!ok) {
+            hipModuleUnload(f.mod);
+            f.mod = nullptr;
+            if (err) *err = "compiled graph is missing an entry point";
+            return nullptr;
+        }
+        return &f;
     }
 };
+
+// a launch that cannot happen (module not loadable on this device) must not look like success to the caller's
+// hipGetLastError(): provoke an invalid-handle error
+void jit_launch_failed() { hipModuleLaunchKernel(nullptr, 1, 1, 1, 1, 1, 1, 0, nullptr, nullptr, nullptr); }
+
+void jit_render(JitModule* jm, float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T, size_t fstride,
+                int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
+    if (V == 0 || T == 0) return;
+    const JitFuncs* f = jm->get();
+    if (!f) return jit_launch_failed();
+    // loader wave / stage split; short launches (real-time blocks) are faster through the single-wave kernel, as for
+    // the ahead-of-time kinds (launch_render)
+    if (layout == LAYOUT_VOICE_MINOR && g_pipe_split && jm->pipe_stages >= 1 && (T >= 256 || g_pipe_split > 1)) {
+        void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &aux, &ring, &ring_cap};
+        hipModuleLaunchKernel(f->pipe[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_threads, 1, 1, 0, s,
+                              pargs, nullptr);
+        return;
+    }
+    if (layout == LAYOUT_PLANAR && g_pipe_split && jm->pipe_planar_threads > 0 && (T >= 256 || g_pipe_split > 1) && fstride % 4 == 0 &&
+        ((uintptr_t)in & 15) == 0 && ((uintptr_t)outp & 15) == 0) {  // loader / stages / storer (see launch_render)
+        void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &fstride, &aux, &ring, &ring_cap};
+        hipModuleLaunchKernel(f->pipe_planar[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_planar_threads, 1, 1,
+                              0, s, pargs, nullptr);
+        return;
+    }
+    const int wpb = jm->wpb[layout];
+    const int vpw = layout == LAYOUT_VOICE_MINOR ? voices_per_wave(V, simd_count()) : 64;
+    if (layout == LAYOUT_VOICE_MINOR) fstride = (size_t)vpw;
+    const size_t waves = (V + vpw - 1) / vpw;
+    void* args[] = {&slots, &stride, &V, &in, &outp, &T, &fstride, &aux, &ring, &ring_cap};
+    hipModuleLaunchKernel(f->render[mode][layout], (unsigned)((waves + wpb - 1) / wpb), 1, 1, 64 * wpb, 1, 1, 0, s, args, nullptr);
+}
 
 }  // namespace
 
@@ -151,42 +238,24 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     std::vector<char> code;
     if (jit_compile_code(type_expr, prelude, &code, err) != 0) return -1;
     auto jm = std::make_shared<JitModule>();
-    if (hipModuleLoadData(&jm->mod, code.data()) != hipSuccess) {
-        *err = "hipModuleLoadData failed for the compiled graph";
-        return -1;
-    }
-    bool ok = hipModuleGetFunction(&jm->lifecycle, jm->mod, "jit_lifecycle") == hipSuccess &&
-              hipModuleGetFunction(&jm->describe, jm->mod, "jit_describe") == hipSuccess;
-    for (int m = 0; m < 2 && ok; m++)
-        for (int l = 0; l < 2 && ok; l++) {
-            std::string fn = "jit_render_" + std::to_string(m) + std::to_string(l);
-            ok = hipModuleGetFunction(&jm->render[m][l], jm->mod, fn.c_str()) == hipSuccess;
-        }
-    for (int m = 0; m < 2 && ok; m++) {
-        std::string fn = "jit_events_" + std::to_string(m);
-        ok = hipModuleGetFunction(&jm->events[m], jm->mod, fn.c_str()) == hipSuccess;
-        fn = "jit_pipe_" + std::to_string(m);
-        ok = ok && hipModuleGetFunction(&jm->pipe[m], jm->mod, fn.c_str()) == hipSuccess;
-        fn = "jit_pipe_planar_" + std::to_string(m);
-        ok = ok && hipModuleGetFunction(&jm->pipe_planar[m], jm->mod, fn.c_str()) == hipSuccess;
-    }
-    if (!ok) {
-        *err = "compiled graph is missing an entry point";
-        return -1;
-    }
+    jm->code = std::move(code);
+    jm->type_expr = type_expr;
+    jm->prelude = prelude;
+    const JitFuncs* f0 = jm->get(err);
+    if (!f0) return -1;
     // slot introspection on the device (the AOT kinds run the same visit() on the host)
     const int cap = 1 << 16;
     char* d_txt = nullptr;
     int* d_meta = nullptr;
-    if (hipMalloc((void**)&d_txt, cap) != hipSuccess || hipMalloc((void**)&d_meta, 8 * sizeof(int)) != hipSuccess) {
+    if (hipMalloc((void**)&d_txt, cap) != hipSuccess || hipMalloc((void**)&d_meta, 16 * sizeof(int)) != hipSuccess) {
         *err = "hipMalloc failed";
         return -1;
     }
     int cap_arg = cap;
     void* dargs[] = {&d_txt, &cap_arg, &d_meta};
-    hipError_t e = hipModuleLaunchKernel(jm->describe, 1, 1, 1, 1, 1, 1, 0, nullptr, dargs, nullptr);
+    hipError_t e = hipModuleLaunchKernel(f0->describe, 1, 1, 1, 1, 1, 1, 0, nullptr, dargs, nullptr);
     std::vector<char> txt(cap);
-    int meta[8] = {0};
+    int meta[16] = {0};
     if (e == hipSuccess) e = hipMemcpy(txt.data(), d_txt, cap, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(meta, d_meta, sizeof meta, hipMemcpyDeviceToHost);
     hipFree(d_txt);
@@ -204,6 +273,7 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     jm->pipe_stages = meta[5];
     jm->pipe_threads = meta[6];
     jm->pipe_planar_threads = meta[7];
+    jm->has_fast = meta[8] != 0;
     out->slots.clear();
     std::istringstream lines(std::string(txt.data(), (size_t)meta[3]));
     std::string line;
@@ -215,41 +285,47 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     out->lifecycle = [jm](float* slots, size_t stride, size_t first, size_t count, int op, double sr,
                           const uint64_t* d_seeds, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
         if (count == 0) return;
+        const JitFuncs* f = jm->get();
+        if (!f) return jit_launch_failed();
         void* args[] = {&slots, &stride, &first, &count, &op, &sr, &d_seeds, &aux, &ring, &ring_cap};
-        hipModuleLaunchKernel(jm->lifecycle, (unsigned)((count + 63) / 64), 1, 1, 64, 1, 1, 0, s, args, nullptr);
+        hipModuleLaunchKernel(f->lifecycle, (unsigned)((count + 63) / 64), 1, 1, 64, 1, 1, 0, s, args, nullptr);
     };
     out->render = [jm](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T, size_t fstride,
                        int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
-        if (V == 0 || T == 0) return;
-        // loader wave / stage split; short launches (real-time blocks) are faster through the single-wave kernel, as for
-        // the ahead-of-time kinds (launch_render)
-        if (layout == LAYOUT_VOICE_MINOR && g_pipe_split && jm->pipe_stages >= 1 && (T >= 256 || g_pipe_split > 1)) {
-            void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &aux, &ring, &ring_cap};
-            hipModuleLaunchKernel(jm->pipe[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_threads, 1, 1, 0, s,
-                                  pargs, nullptr);
-            return;
-        }
-        if (layout == LAYOUT_PLANAR && g_pipe_split && jm->pipe_planar_threads > 0 && (T >= 256 || g_pipe_split > 1) && fstride % 4 == 0 &&
-            ((uintptr_t)in & 15) == 0 && ((uintptr_t)outp & 15) == 0) {  // loader / stages / storer (see launch_render)
-            void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &fstride, &aux, &ring, &ring_cap};
-            hipModuleLaunchKernel(jm->pipe_planar[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_planar_threads, 1, 1,
-                                  0, s, pargs, nullptr);
-            return;
-        }
-        const int wpb = jm->wpb[layout];
-        const int vpw = layout == LAYOUT_VOICE_MINOR ? voices_per_wave(V, simd_count()) : 64;
-        if (layout == LAYOUT_VOICE_MINOR) fstride = (size_t)vpw;
-        const size_t waves = (V + vpw - 1) / vpw;
-        void* args[] = {&slots, &stride, &V, &in, &outp, &T, &fstride, &aux, &ring, &ring_cap};
-        hipModuleLaunchKernel(jm->render[mode][layout], (unsigned)((waves + wpb - 1) / wpb), 1, 1, 64 * wpb, 1, 1, 0, s,
-                              args, nullptr);
+        jit_render(jm.get(), slots, stride, V, in, outp, T, fstride, layout, mode, aux, ring, ring_cap, s);
     };
+    if (jm->has_fast)  // tolerance mode: the same source with JitG = FastOf<G>, compiled the first time a FAST bank renders
+        out->render_fast = [jm](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T, size_t fstride,
+                                int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
+            {
+                std::lock_guard<std::mutex> lock(jm->mu);
+                if (!jm->fast && !jm->fast_failed) {
+                    auto fm = std::make_shared<JitModule>();
+                    std::string log;
+                    if (jit_compile_code("typename fd::FastOf<" + jm->type_expr + ">::type", jm->prelude, &fm->code, &log) == 0) {
+                        fm->pipe_stages = jm->pipe_stages;   // FastOf keeps arities, chain shape and tile plan
+                        fm->pipe_threads = jm->pipe_threads;
+                        fm->pipe_planar_threads = jm->pipe_planar_threads;
+                        fm->wpb[0] = jm->wpb[0];
+                        fm->wpb[1] = jm->wpb[1];
+                        jm->fast = fm;
+                    } else {
+                        jm->fast_failed = true;
+                        fprintf(stderr, "fundsp_hip: tolerance-mode variant failed to compile, rendering exactly: %s\n", log.c_str());
+                    }
+                }
+            }
+            JitModule* m = jm->fast ? jm->fast.get() : jm.get();
+            jit_render(m, slots, stride, V, in, outp, T, fstride, layout, mode, aux, ring, ring_cap, s);
+        };
     out->render_events = [jm](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T,
                               const double* ev, const int* fade, double time0, double sr, int mode, const void* aux,
                               float* ring, uint32_t ring_cap, hipStream_t s) {
         if (V == 0 || T == 0) return;
+        const JitFuncs* f = jm->get();
+        if (!f) return jit_launch_failed();
         void* args[] = {&slots, &stride, &V, &in, &outp, &T, &ev, &fade, &time0, &sr, &aux, &ring, &ring_cap};
-        hipModuleLaunchKernel(jm->events[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, 256, 1, 1, 0, s, args, nullptr);
+        hipModuleLaunchKernel(f->events[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, 256, 1, 1, 0, s, args, nullptr);
     };
     return 0;
 }

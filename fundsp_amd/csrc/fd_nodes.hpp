@@ -42,7 +42,21 @@ struct Ctx {
     uint32_t ring_cap;   // positions per ring node
     size_t vstride;      // floats between consecutive positions (= padded voice count)
     int next_ring;       // running index handed out to ring nodes in visit order
+    // Where a node reports that the capacity fixed at bank creation is too small for what it was asked to hold (the
+    // reference would resize its buffer): the largest number of positions any node wanted.  One word behind the bank's
+    // ring memory, set by the lifecycle kernels only (nullptr in the render kernels); the host checks it after every
+    // call that can change a length and fails that call (fd_capi.hip check_ring_need).
+    uint32_t* ring_need = nullptr;
     FD_HD float* claim_ring() { return ring + (size_t)(next_ring++) * ring_cap * vstride; }
+    FD_HD void want_positions(uint32_t want) const {
+        if (ring_need && want > ring_cap) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            atomicMax(ring_need, want);
+#else
+            if (*ring_need < want) *ring_need = want;
+#endif
+        }
+    }
 };
 
 // step2<PH>(in, out): two consecutive frames at once, channel c of frames (n, n+1) packed in one <2 x float>.
@@ -267,6 +281,34 @@ struct Sine {
     }
 };
 
+// Sine in tolerance mode (FDSP_MATH_FAST): the phase recurrence of Sine::process is kept operation for operation, the
+// f32x8 sine polynomial is replaced by fast_sin (fd_math.hpp; within 1.2e-7 of it).  tick / remainder samples unchanged.
+struct SineFast : Sine {
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        if (PH == PH_SIMD) {
+            float tmp = phase;
+            phase += in[0] * sample_duration;
+            out[0] = fast_sin1(tmp * F32_TAU);
+        } else {
+            Sine::template step<PH>(in, out);
+        }
+    }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        if (PH == PH_SIMD) {
+            v2f d = in[0] * sample_duration;
+            float t0 = phase;
+            phase += d.x;
+            float t1 = phase;
+            phase += d.y;
+            out[0] = fast_sin2(v2f{t0, t1} * F32_TAU);
+        } else {
+            Sine::template step2<PH>(in, out);
+        }
+    }
+};
+
 // Dsf<N>  oscillator.rs:103-208 (ID 55): discrete summation formula oscillator (Moorer 1976), tick only.
 // NIN = 1 (frequency) or 2 (frequency, roughness).
 template <int NIN>
@@ -363,38 +405,40 @@ struct Noise {
 };
 
 // SVF core shared by FixedSvf and Svf:  svf.rs:995-1006 / :829-843
-#ifndef FD_SVF_PACKED
-#define FD_SVF_PACKED 0
-#endif
 struct SvfCore {
     float a1, a2, a3, m0, m1, m2, ic1eq, ic2eq;
-    // Same operations in the same order as the reference; independent products share one packed instruction:
-    //   (a1*ic1, a2*ic1), (a2*v3, a3*v3), (m0*v0, m1*v1); the three sums stay scalar (no register shuffles).
-    // `2*v - ic` is evaluated as fma(2, v, -ic): 2*v is exact in binary floating point, so the fused and the
-    // unfused form round the same real number once -- identical bits for every non-overflowing value.
+    // The reference's operations in the reference's order (svf.rs:995-1006): every scalar path uses this form.
     FD_HD float tick(float v0) {
-#if FD_SVF_PACKED
-        float v3 = v0 - ic2eq;
-        v2f p = v2f{a1, a2} * splat2(ic1eq);
-        v2f r = v2f{a2, a3} * splat2(v3);
-        v2f v01, v12;
-        v12.x = p.x + r.x;            // v1
-        float t = ic2eq + p.y;
-        v12.y = t + r.y;              // v2
-        v01 = v2f{v0, v12.x};
-        v2f ic = __builtin_elementwise_fma(splat2(2.0f), v12, -v2f{ic1eq, ic2eq});
-        ic1eq = ic.x;
-        ic2eq = ic.y;
-        v2f mm = v2f{m0, m1} * v01;
-        return (mm.x + mm.y) + m2 * v12.y;
-#else
         float v3 = v0 - ic2eq;
         float v1 = a1 * ic1eq + a2 * v3;
         float v2 = ic2eq + a2 * ic1eq + a3 * v3;
+        ic1eq = 2.0f * v1 - ic1eq;
+        ic2eq = 2.0f * v2 - ic2eq;
+        return m0 * v0 + m1 * v1 + m2 * v2;
+    }
+    // Packed-path form: `2*v - ic` as fma(2, v, -ic).  2*v is exact in binary floating point, so the fused and the
+    // unfused form round the same real number once -- identical bits -- EXCEPT when 2*v overflows (|v| >= 2^127): the
+    // reference's product becomes inf there while the fused form stays finite.  `vmax` accumulates max(|v1|, |v2|)
+    // (one v_max3_f32); the caller checks it per tile and re-renders the tile with tick() if it reached 2^127.
+    FD_HD float tick_fused(float v0, float& vmax) {
+        float v3 = v0 - ic2eq;
+        float v1 = a1 * ic1eq + a2 * v3;
+        float v2 = ic2eq + a2 * ic1eq + a3 * v3;
+        vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(__builtin_fabsf(v1), __builtin_fabsf(v2)));
         ic1eq = __builtin_fmaf(2.0f, v1, -ic1eq);
         ic2eq = __builtin_fmaf(2.0f, v2, -ic2eq);
         return m0 * v0 + m1 * v1 + m2 * v2;
-#endif
+    }
+    // ... and when m0 = m1 = +0.0 and m2 = 1.0 (LowpassMode): `m0*v0 + m1*v1 + m2*v2` = (+-0 + +-0) + v2 is v2 itself,
+    // bit for bit, whenever v0, v1 are finite and v2 is not -0.0 -- FixedSvfLp guards both (see there).
+    FD_HD float tick_lp(float v0, float& vmax) {
+        float v3 = v0 - ic2eq;
+        float v1 = a1 * ic1eq + a2 * v3;
+        float v2 = ic2eq + a2 * ic1eq + a3 * v3;
+        vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(__builtin_fabsf(v1), __builtin_fabsf(v2)));
+        ic1eq = __builtin_fmaf(2.0f, v1, -ic1eq);
+        ic2eq = __builtin_fmaf(2.0f, v2, -ic2eq);
+        return v2;
     }
     FD_HD void set(const SvfCoefs& c) {
         a1 = c.a1; a2 = c.a2; a3 = c.a3; m0 = c.m0; m1 = c.m1; m2 = c.m2;
@@ -408,6 +452,7 @@ struct FixedSvf {
     static constexpr uint64_t ID = 43;
     float mode, cutoff, q, gain, sr;
     SvfCore c;
+    float vmax;  // transient guard of the packed path (not a slot): SvfCore::tick_fused
     template <class V> FD_HD void visit(V& v) {
         v.f(mode, PARAM, "mode");
         v.f(cutoff, PARAM, "cutoff");
@@ -430,12 +475,47 @@ struct FixedSvf {
     FD_HD void reset() { c.ic1eq = 0.0f; c.ic2eq = 0.0f; }  // :984-987
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
-    FD_HD void begin_block(int) {}
-    FD_HD bool tripped() const { return false; }
-    FD_HD void bind(Ctx&) {}
+    FD_HD void begin_block(int) { vmax = 0.0f; }
+    FD_HD bool tripped() const { return !(vmax < 0x1p127f); }
+    FD_HD void bind(Ctx&) { vmax = 0.0f; }
     template <int PH> FD_HD void step(const float* in, float* out) { out[0] = c.tick(in[0]); }
-    FD_STEP2_VIA_STEP
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        if (PH == PH_SIMD) {  // a caller of the packed path checks tripped() per tile and redoes the tile with step()
+            const float a = c.tick_fused(in[0].x, vmax);
+            const float b = c.tick_fused(in[0].y, vmax);
+            out[0] = v2f{a, b};
+        } else {
+            out[0] = v2f{c.tick(in[0].x), c.tick(in[0].y)};
+        }
+    }
 };
+
+// FixedSvf in a wave whose lanes are ALL lowpass filters (m0 = m1 = +0.0, m2 = 1.0) and none of which starts the
+// launch with ic2eq = -0.0: the packed path returns v2 directly (5 of the 17 flops are `0*v0 + 0*v1 + 1*v2`).
+// Exactness: with those coefficients the reference's sum is (+-0 + +-0) + v2, which is v2 bit for bit unless
+//   (a) v2 is -0.0 -- impossible here: v2 = (ic2 + a2*ic1) + a3*v3 is -0.0 only if ic2 is, and ic2' = fma(2, v2, -ic2)
+//       is -0.0 only if v2 is -0.0 while ic2 is +0.0, so a launch that starts with ic2 != -0.0 never produces one; or
+//   (b) v0 or v1 is infinite (0 * inf = NaN in the reference) -- then ic1eq / ic2eq become and stay non-finite, so a
+//       tile whose END state is finite had finite v0, v1, v2 throughout; tripped() checks exactly that and the caller
+//       re-renders the tile from its snapshot with the generic arithmetic (`step` below is the inherited generic one).
+// The render kernels pick this type per wave (lp_ok below), never the host.
+struct FixedSvfLp : FixedSvf {
+    FD_HD bool tripped() const {  // vmax < 2^127 also rules out infinite v1 / v2; the state test catches NaNs
+        return !(vmax < 0x1p127f && __builtin_fabsf(c.ic1eq) < __builtin_inff() && __builtin_fabsf(c.ic2eq) < __builtin_inff());
+    }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        if (PH == PH_SIMD) {
+            const float a = c.tick_lp(in[0].x, vmax);
+            const float b = c.tick_lp(in[0].y, vmax);
+            out[0] = v2f{a, b};
+        } else {
+            FixedSvf::template step2<PH>(in, out);
+        }
+    }
+};
+FD_HD bool svf_is_plain_lowpass(const FixedSvf& f) {
+    return f2u(f.c.m0) == 0u && f2u(f.c.m1) == 0u && f2u(f.c.m2) == 0x3f800000u && f2u(f.c.ic2eq) != 0x80000000u;
+}
 
 // Svf<f32, M> with parameter inputs  svf.rs:748-855 (ID 36).  NIN = 3 (audio, cutoff, q) or 4 (+ gain).
 template <int NIN>
@@ -1644,20 +1724,23 @@ struct Delay {
     float* ring;
     size_t vs;
     uint32_t cap;
+    Ctx owner;  // for want_positions()
     template <class V> FD_HD void visit(V& v) {
         v.f(time, PARAM, "time");
         v.f(last_sr, COEF, "sized_for_sample_rate");
         v.u32(len, COEF, "length");
         v.u32(i, STATE, "i");
     }
-    FD_HD void bind(Ctx& c) { ring = c.claim_ring(); vs = c.vstride; cap = c.ring_cap; }
+    FD_HD void bind(Ctx& c) { ring = c.claim_ring(); vs = c.vstride; cap = c.ring_cap; owner = c; }
     FD_HD void clear() {
         for (uint32_t k = 0; k < cap; k++) ring[(size_t)k * vs] = 0.0f;
     }
     FD_HD void init() { time = 0.0f; last_sr = 0.0f; len = 1; i = 0; }
     FD_HD void update(double sr) {
-        uint32_t want = (uint32_t)__builtin_round((double)time * sr) + 1u;
-        want = want > cap ? cap : want;  // capacity is fixed at bank creation (fdsp_bank_create_ring)
+        const double wd = __builtin_round((double)time * sr) + 1.0;
+        uint32_t want = wd < 4294967295.0 ? (wd > 1.0 ? (uint32_t)wd : 1u) : 0xFFFFFFFFu;
+        owner.want_positions(want);      // capacity is fixed at bank creation (fdsp_bank_create_ring): the host fails the
+        want = want > cap ? cap : want;  // call that asked for more; until then the delay is the longest that fits
         if (last_sr != (float)sr || want != len) {
             last_sr = (float)sr;
             len = want;
@@ -1797,19 +1880,21 @@ struct TapT {
     float* ring;
     size_t vs;
     uint32_t cap;
+    Ctx owner;
     template <class V> FD_HD void visit(V& v) {
         v.f(min_delay, PARAM, "min_delay"); v.f(max_delay, PARAM, "max_delay");
         v.f(srf, COEF, "sample_rate"); v.f(min_c, COEF, "min_delay_clamped"); v.f(max_c, COEF, "max_delay_clamped");
         v.u32(mask, COEF, "mask");
         v.u32(i, STATE, "i");
     }
-    FD_HD void bind(Ctx& c) { ring = c.claim_ring(); vs = c.vstride; cap = c.ring_cap; }
+    FD_HD void bind(Ctx& c) { ring = c.claim_ring(); vs = c.vstride; cap = c.ring_cap; owner = c; }
     FD_HD void init() { min_delay = 0.0f; max_delay = 0.0f; srf = 0.0f; mask = 0; i = 0; min_c = max_c = 0.0f; }
     FD_HD void update(double sample_rate) {  // :198-209 / :436-445
         float sr = (float)sample_rate;
         float blen = LINEAR ? __builtin_ceilf(max_delay * sr) + 2.0f : __builtin_ceilf(max_delay * sr) + 3.0f + 8.0f;
         uint32_t n = next_pow2_u32((uint32_t)blen);
-        while (n > cap) n >>= 1;  // capacity fixed at bank creation
+        owner.want_positions(n);  // capacity fixed at bank creation: the host fails the call that asked for more
+        while (n > cap) n >>= 1;
         uint32_t m = n - 1u;
         if (srf != sr || m != mask) {
             srf = sr;
@@ -2564,6 +2649,7 @@ struct Limiter {
     float* tree;
     size_t vs;
     uint32_t cap;
+    Ctx owner;
     template <class V> FD_HD void visit(V& v) {
         v.f(attack, PARAM, "attack_time");
         v.f(release, PARAM, "release_time");
@@ -2579,6 +2665,7 @@ struct Limiter {
         tree = c.claim_ring();
         vs = c.vstride;
         cap = c.ring_cap;
+        owner = c;
     }
     FD_HD void init() {
         attack = 0.005f; release = 0.05f;
@@ -2595,8 +2682,9 @@ struct Limiter {
         follower.rtime = release * 0.4f;
         follower.update(sr);
         double want = __builtin_round(sr * (double)attack);
-        uint32_t len = want < 1.0 ? 1u : (uint32_t)want;
-        while (len > 1u && next_pow2_u32(len) + len + (len & 1u) > cap) len--;  // capacity fixed at bank creation
+        uint32_t len = want < 1.0 ? 1u : (want < 1073741824.0 ? (uint32_t)want : 1073741824u);
+        owner.want_positions(next_pow2_u32(len) + len + (len & 1u));  // capacity fixed at bank creation: the host fails the call
+        while (len > 1u && next_pow2_u32(len) + len + (len & 1u) > cap) len--;
         if (len != length || last_sr != (float)sr) {
             length = len;
             leaf = next_pow2_u32(len);
@@ -2967,6 +3055,39 @@ struct Unop {
         for (int i = 0; i < OUT; i++) out[i] = U::f(out[i], scalar);
     }
 };
+
+// ---- type-level variants of a graph -------------------------------------------------------------------------------
+// A variant replaces leaf types by layout-identical derived types (same fields, same visit order, same ID) that differ
+// only in the arithmetic of the packed path; the combinators Pipe / Stack / Binop / Unop carry the replacement through.
+// LpOf<G>:   FixedSvf -> FixedSvfLp.  Chosen per WAVE on the device when lp_ok(g) holds in all lanes; exact.
+// FastOf<G>: Sine -> SineFast.       Chosen per LAUNCH by the host (fdsp_set_option("math", 1)); tolerance mode.
+template <class G> struct LpOf { using type = G; };
+template <> struct LpOf<FixedSvf> { using type = FixedSvfLp; };
+template <class G> struct FastOf { using type = G; };
+template <> struct FastOf<Sine> { using type = SineFast; };
+#define FD_VARIANT_THROUGH(TRAIT)                                                                                       \
+    template <class X, class Y> struct TRAIT<Pipe<X, Y>> { using type = Pipe<typename TRAIT<X>::type, typename TRAIT<Y>::type>; };    \
+    template <class X, class Y> struct TRAIT<Stack<X, Y>> { using type = Stack<typename TRAIT<X>::type, typename TRAIT<Y>::type>; };  \
+    template <class O, class X, class Y> struct TRAIT<Binop<O, X, Y>> { using type = Binop<O, typename TRAIT<X>::type, typename TRAIT<Y>::type>; }; \
+    template <class X, class U> struct TRAIT<Unop<X, U>> { using type = Unop<typename TRAIT<X>::type, U>; };
+FD_VARIANT_THROUGH(LpOf)
+FD_VARIANT_THROUGH(FastOf)
+template <class A, class B> struct SameType { static constexpr bool v = false; };
+template <class A> struct SameType<A, A> { static constexpr bool v = true; };
+template <class T> struct Pointee;
+template <class T> struct Pointee<T*> { using type = T; };
+
+// lp_ok(g): this lane's FixedSvf nodes (those LpOf reaches) all satisfy FixedSvfLp's preconditions
+template <class G> FD_HD bool lp_ok(const G&) { return true; }
+FD_HD bool lp_ok(const FixedSvf& f) { return svf_is_plain_lowpass(f); }
+template <class X, class Y> FD_HD bool lp_ok(const Pipe<X, Y>& g);
+template <class X, class Y> FD_HD bool lp_ok(const Stack<X, Y>& g);
+template <class O, class X, class Y> FD_HD bool lp_ok(const Binop<O, X, Y>& g);
+template <class X, class U> FD_HD bool lp_ok(const Unop<X, U>& g);
+template <class X, class Y> FD_HD bool lp_ok(const Pipe<X, Y>& g) { return lp_ok(g.x) && lp_ok(g.y); }
+template <class X, class Y> FD_HD bool lp_ok(const Stack<X, Y>& g) { return lp_ok(g.x) && lp_ok(g.y); }
+template <class O, class X, class Y> FD_HD bool lp_ok(const Binop<O, X, Y>& g) { return lp_ok(g.x) && lp_ok(g.y); }
+template <class X, class U> FD_HD bool lp_ok(const Unop<X, U>& g) { return lp_ok(g.x); }
 
 // ---------------------------------------------------------------------------------------------------------
 // routing leaves and the remaining combinators (audionode.rs).  All of them are arithmetic-free or a handful of

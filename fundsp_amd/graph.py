@@ -91,6 +91,33 @@ class Graph:
         self._set("has_seed", 1.0)
         return self._set("seed", s, u64=True)
 
+    def ring_frames(self, sample_rate):
+        """Ring capacity (positions per ring) this graph needs at `sample_rate`, from its delay / tap / limiter parameters
+        (delay.rs:108-110, 204-206, 440-442; dynamics.rs:159-171), or None when a node sizes its ring from data the graph
+        does not hold (Pluck, Hold, Reverb3: pass ring_frames yourself)."""
+        if self.rings == 0:
+            return 0
+        if any(k in self.type for k in ("Pluck", "Hold", "Reverb3")):
+            return None
+        sr = float(sample_rate)
+
+        def pow2(n):
+            return 1 << max(0, int(n) - 1).bit_length()
+
+        need = 1
+        cubic = "TapT<false" in self.type
+        for _p, field, value, _u in self.params:
+            v = float(np.max(np.asarray(value, dtype=np.float32)))
+            if field == "time" and "Delay" in self.type:
+                need = max(need, int(round(v * sr)) + 1)
+            elif field == "max_delay":
+                blen = np.ceil(np.float32(v) * np.float32(sr)) + (11 if cubic else 2)
+                need = max(need, pow2(int(blen)))
+            elif field == "attack_time" and "Limiter" in self.type:
+                ln = max(1, int(round(sr * v)))
+                need = max(need, pow2(ln) + ln + (ln & 1))
+        return need
+
     def kind_name(self):
         return "jit_" + hashlib.sha1((self.type + "\0" + self.source).encode()).hexdigest()[:16]
 

@@ -95,6 +95,21 @@ int fdsp_kind_by_name(const char* name); /* -1 if unknown */
  * segments that run in 2 or 3 waves sharing a SIMD; identical samples, better issue-slot utilisation at one
  * voice-wave per SIMD).  1 = best plan, 2 / 3 = exactly that many stages (if the graph allows), 0 = single-wave kernel. */
 int fdsp_set_option(const char* name, int value);
+/* "math" (default FDSP_MATH_EXACT): the arithmetic of banks created afterwards.
+ *   FDSP_MATH_EXACT  every node evaluates the reference's own algorithm operation for operation (no contraction, the
+ *                    restated libm / wide functions): bit-identical to the CPU oracle.  The headline mode.
+ *   FDSP_MATH_FAST   tolerance mode: state recurrences (phases, filter states, envelopes) stay operation for operation,
+ *                    but feed-forward transcendental evaluations may use the engine's own FMA polynomials -- today the
+ *                    f32x8 sine of Sine::process (13 instead of 28 operations, within 1.2e-7 of it).  Outputs stay within
+ *                    the reference's own tick-vs-process tolerance of the exact mode (1e-4 absolute,
+ *                    tests/test_basic.rs:31; measured in tests/test_gpu_math_fast.py).  Kinds without such a node render
+ *                    exactly as before.
+ * Per bank: fdsp_bank_set_option(bank, "math", v) / fdsp_bank_get_option(bank, "math");
+ * fdsp_bank_get_option(bank, "math_has_fast_variant") tells whether FAST changes anything for the bank's kind. */
+#define FDSP_MATH_EXACT 0
+#define FDSP_MATH_FAST 1
+int fdsp_bank_set_option(fdsp_bank* bank, const char* name, int value);
+int fdsp_bank_get_option(const fdsp_bank* bank, const char* name);
 /* "host_zero_copy_max" (default 262144): fdsp_bank_process_host calls moving at most this many floats per direction
  * let the kernel read/write pinned host memory directly instead of staging through HBM (lower per-block latency). */
 /* "fdn_kernel" (default 0): reverb banks render with one lane per FRAME (0) or one lane per DELAY LINE (1); identical
@@ -136,6 +151,16 @@ int fdsp_bank_create_ring(const char* kind, size_t voices, size_t ring_frames, f
  * instance), delay rings in HBM; flushes f32 denormals like the reference does after Feedback::new
  * (src/feedback.rs:96, src/denormal.rs:18).  The handle works with set_sample_rate / reset / process / destroy. */
 int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, double damping, fdsp_bank** out);
+/* Several GPUs from one process.  A bank lives on ONE device, fixed at creation: the `_on` constructors take the HIP
+ * device index (-1 = the calling thread's current device, which is what the constructors above use).  Every entry point
+ * that takes a bank makes the bank's device current for its own duration and restores the caller's, so a host thread
+ * may interleave banks of different GPUs freely; a bank is still single-threaded (AudioNode::process(&mut self)),
+ * different banks may be driven from different threads.  Shared wavetables / waves are kept per device and installed
+ * on every device that has banks.  `ring_frames` = 0 for kinds without delay lines. */
+int fdsp_device_count(void);
+int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring_frames, fdsp_bank** out);
+int fdsp_reverb_stereo_create_on(int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out);
+int fdsp_bank_device(const fdsp_bank* bank);
 void fdsp_bank_destroy(fdsp_bank* bank);
 int fdsp_bank_inputs(const fdsp_bank* bank);   /* AudioNode::Inputs  */
 int fdsp_bank_outputs(const fdsp_bank* bank);  /* AudioNode::Outputs */
@@ -221,6 +246,31 @@ int fdsp_mix_stereo(const float* d_voices, const float* d_pan, float* d_mix, siz
 /* Sum over voices of a voice-minor buffer d_in [channels][frames][voices] -> d_out [channels][frames] (per-GPU partial
  * of the mix-down for graphs that already end in a Panner). Deterministic order, same as fdsp_mix_stereo. */
 int fdsp_sum_voices(const float* d_in, float* d_out, size_t channels, size_t frames, size_t voices, void* stream);
+
+/* ---- the exchange step across GPUs: all-reduce(sum) of the per-GPU partial mixes over RCCL / xGMI ----
+ * The only collective of the path: `count` = 2 * frames floats per GPU, latency-bound, issued once per launch.  It runs
+ * on the communicator's own side stream, ordered behind the work already queued on `after_stream` (the mix kernel), so
+ * the render stream can start the next launch immediately; consumers order themselves behind it with fdsp_comm_wait.
+ *   one process, n GPUs:        fdsp_comm_create_local(n, devices, &comm) (devices NULL = 0..n-1); slot k <-> devices[k];
+ *                               one thread per GPU calls fdsp_mix_allreduce(comm, k, ..), or one thread calls
+ *                               fdsp_mix_allreduce_all(comm, mixes, count, streams) (the calls are grouped)
+ *   one process per GPU:        rank 0: fdsp_comm_unique_id(id); ship the 128 bytes to the other ranks (MPI, a file,
+ *                               torch.distributed ...); every rank: fdsp_comm_create_rank(id, nranks, rank, device, &comm);
+ *                               slot is always 0.
+ * The sum is in place in d_mix.  Summation order across GPUs is RCCL's (ring / tree): compare mixes with a tolerance,
+ * voices bit for bit (SURVEY 8e parity caveat). */
+#define FDSP_COMM_ID_BYTES 128
+typedef struct fdsp_comm fdsp_comm;
+int fdsp_comm_create_local(int n, const int* devices, fdsp_comm** out);
+int fdsp_comm_unique_id(void* id128);
+int fdsp_comm_create_rank(const void* id128, int nranks, int rank, int device, fdsp_comm** out);
+void fdsp_comm_destroy(fdsp_comm* comm);
+int fdsp_comm_ranks(const fdsp_comm* comm);        /* ranks of the whole communicator */
+int fdsp_comm_local_slots(const fdsp_comm* comm);  /* ranks owned by this process */
+int fdsp_comm_device(const fdsp_comm* comm, int slot);
+int fdsp_mix_allreduce(fdsp_comm* comm, int slot, float* d_mix, size_t count, void* after_stream);
+int fdsp_mix_allreduce_all(fdsp_comm* comm, float* const* d_mix, size_t count, void* const* after_streams);
+int fdsp_comm_wait(fdsp_comm* comm, int slot, void* stream); /* stream == NULL: block the host */
 
 /* ---- shared wavetables (Arc<Wavetable> singletons of the reference: saw_table/square_table/triangle_table,
  * src/wavetable.rs:493-560).  `set`: 0 = saw, 1 = square, 2 = triangle, 4 = organ, 5 = soft saw,

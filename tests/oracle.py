@@ -710,8 +710,9 @@ def moog_coefs(sr, cutoff, q):
 
 
 def bank_render(config, params, seeds, frames, sample_rate=48000.0, process_mode=True, out_layout=1, threads=1,
-                store=True):
-    """Render V voices of BASELINE config 2 or 3. params: list of float32 [V] arrays. Returns (out, seconds)."""
+                store=True, lib=None):
+    """Render V voices of BASELINE config 2 or 3. params: list of float32 [V] arrays. Returns (out, seconds).
+    `lib`: another build of the same oracle (bench.py's -march=native flavour) whose o_bank_render to call."""
     V = len(seeds)
     ps = [np.ascontiguousarray(p, dtype=np.float32) for p in params] + [None] * (4 - len(params))
     seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
@@ -720,7 +721,7 @@ def bank_render(config, params, seeds, frames, sample_rate=48000.0, process_mode
     out = None
     if store:
         out = np.zeros((frames, V) if out_layout == 1 else (V, frames), dtype=np.float32)
-    secs = lib().o_bank_render(C.byref(job), _fptr(out))
+    secs = (lib or globals()["lib"]()).o_bank_render(C.byref(job), _fptr(out))
     return out, secs
 
 

@@ -38,3 +38,36 @@ def test_device_trig_header_matches_oracle_over_the_whole_f32_range(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bad 0" in r.stdout
+
+
+def test_tolerance_mode_sine_bound(tmp_path):
+    """FDSP_MATH_FAST's sine (fast_sin1 / fast_sin2) vs the wide::f32x8::sin restatement and vs double sin."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = tmp_path / "check_fast_sin"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-std=c++17", "-Wno-unused-result",
+           "-I", os.path.join(ROOT, "fundsp_amd", "csrc"), "-o", str(exe),
+           os.path.join(ROOT, "tests", "host", "check_fast_sin.hip")]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_svf_packed_paths_match_the_oracle_on_overflow_bursts(tmp_path):
+    """SvfCore::tick_fused (2*v - ic as one FMA, guarded against the |v| >= 2^127 case where the reference's unfused
+    product overflows) and FixedSvfLp (lowpass output = v2), each with its per-tile rollback, vs the oracle's svf tick."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    import oracle as O
+    O.lib()   # make sure oracle/libfundsp_oracle.so is built
+    exe = tmp_path / "check_svf_paths"
+    odir = os.path.join(ROOT, "oracle")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-std=c++17", "-Wno-unused-result",
+           "-I", os.path.join(ROOT, "fundsp_amd", "csrc"), "-I", odir, "-o", str(exe),
+           os.path.join(ROOT, "tests", "host", "check_svf_paths.hip"), "-L" + odir, "-lfundsp_oracle", "-Wl,-rpath," + odir]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bad 0" in r.stdout
