@@ -31,6 +31,8 @@ SYMBOLS = {
     "fdsp_graph_compile": (_i, [_cs, _cs]),
     "fdsp_graph_compile_src": (_i, [_cs, _cs, _cs]),
     "fdsp_graph_check": (_i, [_cs]),
+    "fdsp_rust_type_to_expr": (_i, [_cs, _cs, C.c_char_p, _sz, C.c_char_p, _sz]),
+    "fdsp_graph_compile_rust": (_i, [_cs, _cs, _cs, _cs]),
     "fdsp_kind_inputs": (_i, [_i]),
     "fdsp_kind_outputs": (_i, [_i]),
     "fdsp_kind_slot_count": (_i, [_i]),

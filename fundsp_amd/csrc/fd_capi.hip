@@ -376,6 +376,8 @@ struct fdsp_bank {
     bool timed = false;
     bool ext_pending = false;  // the last render ran on a caller's stream: bank-stream work must wait for its e1
     int math = FDSP_MATH_EXACT;  // FDSP_MATH_FAST: renders take the kind's tolerance-mode variant when it has one
+    bool ring_check_pending = false;  // a lifecycle launch may have changed a delay length: verify capacity before rendering
+    uint32_t ring_short = 0;          // > 0: positions a node wanted and did not get (renders fail until a later update fits)
     int device = 0;              // the HIP device the bank lives on; every entry point makes it current for its own duration
     const void* aux = nullptr;   // that device's shared-data block (fd::Aux)
     double sr;
@@ -415,20 +417,33 @@ hipError_t await_last_render(fdsp_bank* b) {
     return hipStreamWaitEvent(b->stream, b->e1, 0);
 }
 
-// Kinds with delay lines: did a node just ask for more ring positions than the bank was created with?  (The reference
-// resizes its buffer there; the bank cannot, so the call that caused it fails -- the bank keeps rendering with the
-// longest delay that fits.)  Synchronises the bank's stream; only called after lifecycle launches of ring kinds.
-int check_ring_need(fdsp_bank* b) {
+// Kinds with delay lines keep their rings at the capacity fixed at bank creation.  A node whose length no longer fits
+// (the reference would resize its buffer) reports the positions it wanted in one word behind the ring memory
+// (Ctx::want_positions, written by the lifecycle kernels).  Parameters arrive one slot at a time, so a complaint is only
+// final once the host starts rendering: every lifecycle launch that re-derives ALL voices clears the word first, marks
+// the bank, and the next render call reads it back -- and fails, loudly, as long as the rings are too small.
+uint32_t* ring_need_word(const fdsp_bank* b) {
+    return reinterpret_cast<uint32_t*>(b->ring + (size_t)b->ops->nrings * b->ring_cap * b->stride);
+}
+void before_update_launch(fdsp_bank* b, size_t first, size_t count) {
+    if (!b->ring || !b->ops || b->ops->nrings == 0) return;
+    if (first == 0 && count >= b->V) hipMemsetAsync(ring_need_word(b), 0, sizeof(uint32_t), b->stream);
+    b->ring_check_pending = true;
+}
+int check_ring_need(fdsp_bank* b, bool capturing) {
     if (!b->ring || !b->ops || b->ops->nrings == 0) return FDSP_OK;
-    uint32_t* d_need = reinterpret_cast<uint32_t*>(b->ring + (size_t)b->ops->nrings * b->ring_cap * b->stride);
-    uint32_t need = 0;
-    HIPCHK(hipMemcpyAsync(&need, d_need, sizeof need, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
-    if (need <= b->ring_cap) return FDSP_OK;
-    HIPCHK(hipMemsetAsync(d_need, 0, sizeof need, b->stream));
-    return fail(FDSP_EINVAL, "ring capacity too small: a delay / tap / limiter node needs " + std::to_string(need) +
-                                 " positions at this sample rate, the bank was created with ring_frames = " +
-                                 std::to_string(b->ring_cap) + " (the node keeps the longest length that fits)");
+    if (b->ring_check_pending && !capturing) {
+        uint32_t need = 0;
+        HIPCHK(hipMemcpyAsync(&need, ring_need_word(b), sizeof need, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        b->ring_check_pending = false;
+        b->ring_short = need > b->ring_cap ? need : 0;
+    }
+    if (b->ring_short)
+        return fail(FDSP_EINVAL, "ring capacity too small: a delay / tap / limiter node needs " + std::to_string(b->ring_short) +
+                                     " positions with the current parameters and sample rate, the bank was created with ring_frames = " +
+                                     std::to_string(b->ring_cap));
+    return FDSP_OK;
 }
 
 int find_slot(const fdsp_bank* b, const char* name) {
@@ -581,6 +596,26 @@ int fdsp_graph_compile_src(const char* name, const char* type_expr, const char* 
     return (int)registry().size() - 1;
 }
 
+int fdsp_graph_compile_rust(const char* name, const char* rust_type_name, const char* hints, const char* source) {
+    if (!name || !*name) return fail(FDSP_EINVAL, "name missing");
+    std::string expr, presets;
+    if (int rc = fd::rust_translate(rust_type_name, hints, &expr, &presets)) return rc;
+    const int before = fdsp_kind_by_name(name);
+    const int k = fdsp_graph_compile_src(name, expr.c_str(), source);
+    if (k < 0 || before >= 0) return k;  // error, or the name was compiled before (its presets are already in place)
+    std::vector<std::pair<std::string, float>> ps;
+    size_t pos = 0;
+    while (pos < presets.size()) {
+        const size_t nl = presets.find('\n', pos), eq = presets.find('=', pos);
+        if (nl == std::string::npos || eq == std::string::npos || eq > nl) break;
+        ps.push_back({presets.substr(pos, eq - pos), std::strtof(presets.c_str() + eq + 1, nullptr)});
+        pos = nl + 1;
+    }
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    registry()[k].presets = std::move(ps);
+    return k;
+}
+
 int fdsp_graph_check(const char* type_expr) {
     if (!type_expr) return fail(FDSP_EINVAL, "type expression missing");
     std::vector<char> code;
@@ -687,10 +722,31 @@ int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring
         fdsp_bank_destroy(b);
         return fail(FDSP_EDEVICE, std::string("bank construction kernel failed: ") + hipGetErrorString(e));
     }
+    if (!b->ops->presets.empty()) {  // parameters carried by the Rust type of the graph (fdsp_graph_compile_rust)
+        std::vector<float> col(b->stride);
+        for (const auto& kv : b->ops->presets) {
+            auto it = b->index.find(kv.first);
+            if (it == b->index.end()) {
+                fdsp_bank_destroy(b);
+                return fail(FDSP_EINVAL, "preset names an unknown slot: " + kv.first);
+            }
+            std::fill(col.begin(), col.end(), kv.second);
+            hipMemcpyAsync(b->slots + (size_t)it->second * b->stride, col.data(), b->stride * sizeof(float), hipMemcpyHostToDevice, b->stream);
+            hipStreamSynchronize(b->stream);
+        }
+        b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
+        if (hipStreamSynchronize(b->stream) != hipSuccess) {
+            fdsp_bank_destroy(b);
+            return fail(FDSP_EDEVICE, "applying the kind's presets failed");
+        }
+    }
     // Construction runs every node's update() with its DEFAULT parameters (e.g. the limiter's 5 ms attack), which the
-    // caller is about to replace: a capacity complaint raised by defaults is discarded here; the first set_sample_rate /
-    // set_param re-evaluates every length with the real parameters and fails if the rings are too small for them.
-    if (b->ring) hipMemsetAsync(b->ring + (size_t)b->ops->nrings * b->ring_cap * b->stride, 0, 64, b->stream);
+    // caller is about to replace: a capacity complaint raised by defaults is discarded.
+    if (b->ring) {
+        const uint32_t line[2] = {0u, (uint32_t)(b->V > 0xFFFFFFFFull ? 0xFFFFFFFFull : b->V)};  // [need, real voices]
+        hipMemcpyAsync(ring_need_word(b), line, sizeof line, hipMemcpyHostToDevice, b->stream);
+        hipStreamSynchronize(b->stream);
+    }
     *out = b;
     return FDSP_OK;
 }
@@ -825,9 +881,10 @@ int fdsp_bank_set_sample_rate(fdsp_bank* b, double sr) {
     }
     b->sr = sr;
     HIPCHK(await_last_render(b));
+    before_update_launch(b, 0, b->V);
     b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
-    return check_ring_need(b);
+    return FDSP_OK;
 }
 
 int fdsp_bank_reset(fdsp_bank* b) {
@@ -895,9 +952,10 @@ int fdsp_bank_set_param(fdsp_bank* b, const char* name, const float* h_values, s
     if (int rc = set_words(b, s, h_values, first, count)) return rc;
     // re-derive coefficients like the reference setters do (idempotent for untouched voices)
     HIPCHK(await_last_render(b));
+    before_update_launch(b, first, count);
     b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
-    return check_ring_need(b);
+    return FDSP_OK;
 }
 
 int fdsp_bank_set_param_all(fdsp_bank* b, const char* name, float value) {
@@ -924,9 +982,10 @@ int fdsp_bank_set_param_u64(fdsp_bank* b, const char* name, const uint64_t* h_va
     if (int rc = set_words(b, lo, wl.data(), first, count)) return rc;
     if (int rc = set_words(b, hi, wh.data(), first, count)) return rc;
     HIPCHK(await_last_render(b));
+    before_update_launch(b, first, count);
     b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
-    return check_ring_need(b);
+    return FDSP_OK;
 }
 
 int fdsp_bank_get_slot(fdsp_bank* b, const char* name, float* h_values, size_t first, size_t count) {
@@ -983,6 +1042,7 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
     const bool capturing = cap != hipStreamCaptureStatusNone;  // a captured launch leaves the timing events alone
     // a previous render may still be running on ANOTHER stream (caller streams differ from call to call, or the last one
     // ran on a caller stream and this one runs on the bank's): it reads and writes the same voice state, so order behind it
+    if (int rc = check_ring_need(b, capturing)) return rc;
     if (b->ext_pending && !capturing) HIPCHK(hipStreamWaitEvent(s, b->e1, 0));
     if (!capturing) HIPCHK(hipEventRecord(b->e0, s));
     if (b->fdn)  // Feedback::process is the per-sample tick (feedback.rs:136-146): both modes are the same arithmetic
@@ -1086,6 +1146,7 @@ int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, flo
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (s != b->stream) hipStreamIsCapturing(s, &cap);
     const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (int rc = check_ring_need(b, capturing)) return rc;
     if (b->ext_pending && !capturing) HIPCHK(hipStreamWaitEvent(s, b->e1, 0));
     if (!capturing) HIPCHK(hipEventRecord(b->e0, s));
     // the clock after this launch, advanced exactly as the reference does: one f64 addition per block / per sample

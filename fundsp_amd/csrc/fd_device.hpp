@@ -104,7 +104,11 @@ FD_D void lifecycle_body(float* slots, size_t stride, size_t first, size_t count
     G g;
     Ctx ctx{static_cast<const Aux*>(aux), ring + v, ring_cap, stride, 0};
     // the "capacity too small" word sits right behind the bank's ring memory (fd_capi.hip allocates it)
-    if (G::RINGS > 0 && ring) ctx.ring_need = reinterpret_cast<uint32_t*>(ring + (size_t)G::RINGS * ring_cap * stride);
+    // (word 1 of that line holds the number of REAL voices: padding lanes keep default parameters and must not complain)
+    if (G::RINGS > 0 && ring) {
+        uint32_t* line = reinterpret_cast<uint32_t*>(ring + (size_t)G::RINGS * ring_cap * stride);
+        if (v < line[1]) ctx.ring_need = line;
+    }
     g.bind(ctx);
     {
         VLoad ld{slots + v, stride, 0};
@@ -1072,7 +1076,10 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     };
     using GL = typename LpOf<G>::type;
     bool lp = false;
-    if constexpr (!SameType<GL, G>::v && MODE == MODE_PROCESS)
+#ifndef FD_LP_ENABLE
+#define FD_LP_ENABLE 1  // A/B switch (tools/build_variants.sh): 0 = always the generic SVF arithmetic
+#endif
+    if constexpr (!SameType<GL, G>::v && MODE == MODE_PROCESS && FD_LP_ENABLE)
         lp = __builtin_amdgcn_ballot_w64((live && active) && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(live && active) != 0ull;
     if (lp) rounds_of((GL*)nullptr); else rounds_of((G*)nullptr);
     if (live && active) {

@@ -46,6 +46,9 @@ struct KindOps {
     std::string name;
     int nin, nout, nrings;
     std::vector<SlotInfo> slots;
+    // parameters the graph's Rust TYPE carries (filter modes, shape kinds ...: fdsp_graph_compile_rust): applied to every
+    // voice of a new bank right after construction
+    std::vector<std::pair<std::string, float>> presets;
     std::function<void(float* slots, size_t stride, size_t first, size_t count, int op, double sr,
                        const uint64_t* d_seeds, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s)>
         lifecycle;
@@ -225,6 +228,7 @@ KindOps make_kind(const char* name) {
 int jit_compile_code(const std::string& type_expr, const std::string& prelude, std::vector<char>* code, std::string* log);
 int jit_make_kind(const std::string& name, const std::string& type_expr, const std::string& prelude, KindOps* out,
                   std::string* err);
+int rust_translate(const char* rust_type_name, const char* hints, std::string* expr, std::string* presets);  // fd_rust.hip
 void register_leaf_kinds(std::vector<KindOps>& out);
 void register_graph_kinds(std::vector<KindOps>& out);
 

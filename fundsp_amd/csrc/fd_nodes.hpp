@@ -283,6 +283,9 @@ struct Sine {
 
 // Sine in tolerance mode (FDSP_MATH_FAST): the phase recurrence of Sine::process is kept operation for operation, the
 // f32x8 sine polynomial is replaced by fast_sin (fd_math.hpp; within 1.2e-7 of it).  tick / remainder samples unchanged.
+#ifndef FD_FAST_PACKED
+#define FD_FAST_PACKED 0  // measured (profiles/r02_ab_variants.txt): two plain evaluations 3.47 ms, one packed 3.50 ms
+#endif
 struct SineFast : Sine {
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
@@ -302,7 +305,11 @@ struct SineFast : Sine {
             phase += d.x;
             float t1 = phase;
             phase += d.y;
+#if FD_FAST_PACKED
             out[0] = fast_sin2(v2f{t0, t1} * F32_TAU);
+#else
+            out[0] = v2f{fast_sin1(t0 * F32_TAU), fast_sin1(t1 * F32_TAU)};
+#endif
         } else {
             Sine::template step2<PH>(in, out);
         }
@@ -405,6 +412,14 @@ struct Noise {
 };
 
 // SVF core shared by FixedSvf and Svf:  svf.rs:995-1006 / :829-843
+#ifndef FD_SVF_GUARD
+#define FD_SVF_GUARD 1  // A/B switch only (0 = measure what the overflow guard costs; NOT exact)
+#endif
+#if FD_SVF_GUARD
+#define FD_SVF_TRACK(vmax, v1, v2) vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(__builtin_fabsf(v1), __builtin_fabsf(v2)))
+#else
+#define FD_SVF_TRACK(vmax, v1, v2) (void)0
+#endif
 struct SvfCore {
     float a1, a2, a3, m0, m1, m2, ic1eq, ic2eq;
     // The reference's operations in the reference's order (svf.rs:995-1006): every scalar path uses this form.
@@ -424,7 +439,7 @@ struct SvfCore {
         float v3 = v0 - ic2eq;
         float v1 = a1 * ic1eq + a2 * v3;
         float v2 = ic2eq + a2 * ic1eq + a3 * v3;
-        vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(__builtin_fabsf(v1), __builtin_fabsf(v2)));
+        FD_SVF_TRACK(vmax, v1, v2);
         ic1eq = __builtin_fmaf(2.0f, v1, -ic1eq);
         ic2eq = __builtin_fmaf(2.0f, v2, -ic2eq);
         return m0 * v0 + m1 * v1 + m2 * v2;
@@ -435,7 +450,7 @@ struct SvfCore {
         float v3 = v0 - ic2eq;
         float v1 = a1 * ic1eq + a2 * v3;
         float v2 = ic2eq + a2 * ic1eq + a3 * v3;
-        vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(__builtin_fabsf(v1), __builtin_fabsf(v2)));
+        FD_SVF_TRACK(vmax, v1, v2);
         ic1eq = __builtin_fmaf(2.0f, v1, -ic1eq);
         ic2eq = __builtin_fmaf(2.0f, v2, -ic2eq);
         return v2;

@@ -130,6 +130,21 @@ int fdsp_graph_compile(const char* name, const char* type_expr);
  * Envelope<FN> in fundsp_amd/csrc/fd_nodes.hpp for the functor contract (OUT, visit, init, eval). */
 int fdsp_graph_compile_src(const char* name, const char* type_expr, const char* source);
 int fdsp_graph_check(const char* type_expr);
+/* The Rust side of the compiler: hand over `core::any::type_name::<X>()` of the graph `An<X>` as it is, e.g.
+ *   fundsp::combinator::An<fundsp::audionode::Pipe<fundsp::audionode::Pipe<fundsp::audionode::Constant<typenum::uint::
+ *   UInt<typenum::uint::UTerm, typenum::bit::B1>>, fundsp::oscillator::Sine<f32>>, fundsp::svf::FixedSvf<f32,
+ *   fundsp::svf::LowpassMode<f32>>>>
+ * fdsp_rust_type_to_expr rewrites it with the engine's templates ("Pipe<Pipe<Constant<1>,Sine>,FixedSvf>") and lists
+ * the parameters the Rust TYPE carries as "slot=value" lines ("1:mode=0": filter modes, shape kinds, biquad modes;
+ * combinator.rs:178-488, audionode.rs:850,1232,1375,1496).  fdsp_graph_compile_rust compiles the result under `name`
+ * (like fdsp_graph_compile_src; `source` = functor definitions for closures, or NULL) and remembers those presets:
+ * every bank created from the kind gets them applied.  Field VALUES (frequencies, Q ..) are not in a type: set them with
+ * fdsp_bank_set_param as for any kind.  `hints` (or NULL) supplies what neither the type nor a slot carries, consumed
+ * in the order the nodes appear in the type:
+ *   "wavesynth=saw,square;meter=peak,rms;envelope=EnvExp;envelope_in=MyFn;map=MidSide;shape_fn=SoftFold" */
+int fdsp_rust_type_to_expr(const char* rust_type_name, const char* hints, char* out_expr, size_t expr_cap,
+                           char* out_presets, size_t presets_cap);
+int fdsp_graph_compile_rust(const char* name, const char* rust_type_name, const char* hints, const char* source);
 /* Host-only introspection of a kind (no device needed): arity and the named per-voice slots. */
 int fdsp_kind_inputs(int kind);
 int fdsp_kind_outputs(int kind);

@@ -1,0 +1,245 @@
+//! `HipBank`: V voices of one FunDSP graph rendered by the MI355X engine, behind the reference's own `AudioNode` trait.
+//!
+//! The trait surface, the combinators, `Net` and `Wave::render` stay in Rust (BASELINE.json north_star); what moves is
+//! `AudioNode::process` of the voices.  A bank of `V` voices with `I` inputs and `O` outputs per voice is an `AudioNode`
+//! with `V * I` inputs and `V * O` outputs: `BufferRef` / `BufferMut` are planar `[channel][64] f32`
+//! (src/buffer.rs:8-12), which is exactly `FDSP_LAYOUT_PLANAR` with `frame_stride = 64` when the channels are ordered
+//! voice-major -- the slices are handed over without repacking.
+//!
+//! ```ignore
+//! use fundsp::prelude32::*;
+//! use fundsp_hip::HipBank;
+//! // 512 voices of the README's FM patch; the graph TYPE is compiled for the device from its own type name
+//! let voice = sine_hz(110.0) * 110.0 * 2.0 + 110.0 >> sine() >> lowpass_hz(900.0, 1.0);
+//! let mut bank: HipBank<U0, U512> = HipBank::from_graph(&voice, 512).unwrap();
+//! bank.set_param("0.0.0.0.0.0:value[0]", &freqs).unwrap();          // per-voice field values, by slot
+//! let wave = Wave::render(48000.0, 1.0, &mut An(bank));              // unchanged executor: 64-sample process() blocks
+//! ```
+
+use core::ffi::{c_char, c_int, c_void};
+use core::marker::PhantomData;
+use fundsp::prelude32::*;
+use std::ffi::{CStr, CString};
+
+pub mod ffi {
+    //! `extern "C"` mirror of include/fundsp_hip.h (the subset the shim uses; same names, same argument order).
+    use super::*;
+
+    #[repr(C)]
+    pub struct FdspBank {
+        _private: [u8; 0],
+    }
+    #[repr(C)]
+    pub struct FdspComm {
+        _private: [u8; 0],
+    }
+    pub const FDSP_OK: c_int = 0;
+    pub const FDSP_LAYOUT_VOICE_MINOR: c_int = 0;
+    pub const FDSP_LAYOUT_PLANAR: c_int = 1;
+    pub const FDSP_MODE_PROCESS: c_int = 0;
+    pub const FDSP_MODE_TICK: c_int = 1;
+    pub const FDSP_MATH_EXACT: c_int = 0;
+    pub const FDSP_MATH_FAST: c_int = 1;
+
+    #[link(name = "fundsp_hip")]
+    unsafe extern "C" {
+        pub fn fdsp_last_error() -> *const c_char;
+        pub fn fdsp_device_count() -> c_int;
+        pub fn fdsp_kind_by_name(name: *const c_char) -> c_int;
+        pub fn fdsp_graph_compile_rust(name: *const c_char, rust_type_name: *const c_char, hints: *const c_char, source: *const c_char) -> c_int;
+        pub fn fdsp_bank_create_on(device: c_int, kind: *const c_char, voices: usize, ring_frames: usize, out: *mut *mut FdspBank) -> c_int;
+        pub fn fdsp_bank_destroy(bank: *mut FdspBank);
+        pub fn fdsp_bank_inputs(bank: *const FdspBank) -> c_int;
+        pub fn fdsp_bank_outputs(bank: *const FdspBank) -> c_int;
+        pub fn fdsp_bank_voices(bank: *const FdspBank) -> usize;
+        pub fn fdsp_bank_device(bank: *const FdspBank) -> c_int;
+        pub fn fdsp_bank_set_sample_rate(bank: *mut FdspBank, sample_rate: f64) -> c_int; // AudioNode::set_sample_rate
+        pub fn fdsp_bank_reset(bank: *mut FdspBank) -> c_int; // AudioNode::reset
+        pub fn fdsp_bank_set_seed(bank: *mut FdspBank, seeds: *const u64, first: usize, count: usize) -> c_int; // set_seed / ping
+        pub fn fdsp_bank_set_param(bank: *mut FdspBank, name: *const c_char, values: *const f32, first: usize, count: usize) -> c_int;
+        pub fn fdsp_bank_set_param_all(bank: *mut FdspBank, name: *const c_char, value: f32) -> c_int;
+        pub fn fdsp_bank_set_option(bank: *mut FdspBank, name: *const c_char, value: c_int) -> c_int;
+        pub fn fdsp_bank_slot_count(bank: *const FdspBank) -> c_int;
+        pub fn fdsp_bank_get_state(bank: *mut FdspBank, slots: *mut f32) -> c_int; // Clone
+        pub fn fdsp_bank_set_state(bank: *mut FdspBank, slots: *const f32) -> c_int;
+        pub fn fdsp_bank_process_host(bank: *mut FdspBank, frames: usize, input: *const f32, output: *mut f32, layout: c_int,
+                                      frame_stride: usize, mode: c_int) -> c_int; // AudioNode::process on host buffers
+        pub fn fdsp_bank_process(bank: *mut FdspBank, frames: usize, d_in: *const f32, d_out: *mut f32, layout: c_int,
+                                 frame_stride: usize, mode: c_int, stream: *mut c_void) -> c_int; // device-resident I/O
+        pub fn fdsp_mix_stereo(d_voices: *const f32, d_pan: *const f32, d_mix: *mut f32, frames: usize, voices: usize, stream: *mut c_void) -> c_int;
+        pub fn fdsp_comm_create_local(n: c_int, devices: *const c_int, out: *mut *mut FdspComm) -> c_int;
+        pub fn fdsp_comm_unique_id(id128: *mut c_void) -> c_int;
+        pub fn fdsp_comm_create_rank(id128: *const c_void, nranks: c_int, rank: c_int, device: c_int, out: *mut *mut FdspComm) -> c_int;
+        pub fn fdsp_comm_destroy(comm: *mut FdspComm);
+        pub fn fdsp_mix_allreduce(comm: *mut FdspComm, slot: c_int, d_mix: *mut f32, count: usize, after_stream: *mut c_void) -> c_int;
+        pub fn fdsp_comm_wait(comm: *mut FdspComm, slot: c_int, stream: *mut c_void) -> c_int;
+    }
+}
+use ffi::*;
+
+/// The engine's last error message for this thread.
+pub fn last_error() -> String {
+    unsafe { CStr::from_ptr(fdsp_last_error()).to_string_lossy().into_owned() }
+}
+
+fn check(rc: c_int) -> Result<(), String> {
+    if rc == FDSP_OK { Ok(()) } else { Err(last_error()) }
+}
+
+/// A bank of voices on one GPU.  `NI` = voices x inputs per voice, `NO` = voices x outputs per voice (typenum sizes, as
+/// every `AudioNode` declares them).
+pub struct HipBank<NI: Size<f32>, NO: Size<f32>> {
+    bank: *mut FdspBank,
+    kind: CString,
+    voices: usize,
+    ring_frames: usize,
+    device: c_int,
+    _marker: PhantomData<(NI, NO)>,
+}
+
+// The handle may move between threads and is used by one thread at a time (`process(&mut self)`); `&self` methods do
+// not touch the device.
+unsafe impl<NI: Size<f32>, NO: Size<f32>> Send for HipBank<NI, NO> {}
+unsafe impl<NI: Size<f32>, NO: Size<f32>> Sync for HipBank<NI, NO> {}
+
+impl<NI: Size<f32>, NO: Size<f32>> HipBank<NI, NO> {
+    /// `voices` instances of an ahead-of-time kind ("fm_svf", "fixed_svf", "biquad_bank" ...) on `device` (-1 = current).
+    pub fn new(kind: &str, voices: usize, ring_frames: usize, device: i32) -> Result<Self, String> {
+        let kind = CString::new(kind).map_err(|e| e.to_string())?;
+        let mut bank: *mut FdspBank = core::ptr::null_mut();
+        check(unsafe { fdsp_bank_create_on(device as c_int, kind.as_ptr(), voices, ring_frames, &mut bank) })?;
+        let (i, o) = unsafe { (fdsp_bank_inputs(bank) as usize, fdsp_bank_outputs(bank) as usize) };
+        if i * voices != NI::USIZE || o * voices != NO::USIZE {
+            unsafe { fdsp_bank_destroy(bank) };
+            return Err(format!("arity mismatch: the bank has {}x{} inputs and {}x{} outputs", voices, i, voices, o));
+        }
+        let device = unsafe { fdsp_bank_device(bank) };
+        Ok(Self { bank, kind, voices, ring_frames, device, _marker: PhantomData })
+    }
+
+    /// `voices` instances of the graph TYPE `X`: `core::any::type_name::<X>()` goes to the engine's front door
+    /// (fdsp_graph_compile_rust), which builds the fused device kernel and remembers the parameters the type carries
+    /// (filter modes, shape kinds).  Field values of `_voice` are NOT read: set them per voice with [`Self::set_param`].
+    pub fn from_graph<X: AudioNode>(_voice: &An<X>, voices: usize) -> Result<Self, String> {
+        Self::from_graph_with::<X>(voices, 0, -1, None, None)
+    }
+
+    pub fn from_graph_with<X: AudioNode>(voices: usize, ring_frames: usize, device: i32, hints: Option<&str>,
+                                         functor_source: Option<&str>) -> Result<Self, String> {
+        let type_name = core::any::type_name::<An<X>>();
+        // a stable kind name per graph type
+        let mut h = AttoHash::new(0x4849_5042);
+        for b in type_name.bytes() {
+            h = h.hash(b as u64);
+        }
+        let name = format!("rust_{:016x}", h.state());
+        let cname = CString::new(name.clone()).unwrap();
+        let ctype = CString::new(type_name).map_err(|e| e.to_string())?;
+        let chints = hints.map(|s| CString::new(s).unwrap());
+        let csrc = functor_source.map(|s| CString::new(s).unwrap());
+        let rc = unsafe {
+            fdsp_graph_compile_rust(cname.as_ptr(), ctype.as_ptr(), chints.as_ref().map_or(core::ptr::null(), |c| c.as_ptr()),
+                                    csrc.as_ref().map_or(core::ptr::null(), |c| c.as_ptr()))
+        };
+        if rc < 0 {
+            return Err(last_error());
+        }
+        Self::new(&name, voices, ring_frames, device)
+    }
+
+    pub fn voices(&self) -> usize { self.voices }
+    pub fn device(&self) -> i32 { self.device }
+
+    /// One value per voice for the named slot (`"<path>:<field>"`, listed by `fdsp_kind_slot_name`): what
+    /// `Setting::center(..)`, `.q(..)`, `Constant` values etc. are on a single node.
+    pub fn set_param(&mut self, slot: &str, values: &[f32]) -> Result<(), String> {
+        let c = CString::new(slot).map_err(|e| e.to_string())?;
+        check(unsafe { fdsp_bank_set_param(self.bank, c.as_ptr(), values.as_ptr(), 0, values.len()) })
+    }
+
+    pub fn set_param_all(&mut self, slot: &str, value: f32) -> Result<(), String> {
+        let c = CString::new(slot).map_err(|e| e.to_string())?;
+        check(unsafe { fdsp_bank_set_param_all(self.bank, c.as_ptr(), value) })
+    }
+
+    /// `AudioNode::set_seed` per voice (`ping(false, AttoHash::new(seed))`).
+    pub fn set_seeds(&mut self, seeds: &[u64]) -> Result<(), String> {
+        check(unsafe { fdsp_bank_set_seed(self.bank, seeds.as_ptr(), 0, seeds.len()) })
+    }
+
+    /// Tolerance mode (FDSP_MATH_FAST): FMA polynomials for feed-forward transcendentals, recurrences exact.
+    pub fn set_fast_math(&mut self, on: bool) -> Result<(), String> {
+        let c = CString::new("math").unwrap();
+        check(unsafe { fdsp_bank_set_option(self.bank, c.as_ptr(), if on { FDSP_MATH_FAST } else { FDSP_MATH_EXACT }) })
+    }
+
+    /// Raw handle for device-resident rendering (`fdsp_bank_process`, `fdsp_mix_stereo`, `fdsp_mix_allreduce`).
+    pub fn raw(&mut self) -> *mut FdspBank { self.bank }
+}
+
+impl<NI: Size<f32>, NO: Size<f32>> AudioNode for HipBank<NI, NO> {
+    const ID: u64 = 0x4849_5042; // "HIPB"
+    type Inputs = NI;
+    type Outputs = NO;
+
+    fn reset(&mut self) {
+        unsafe { fdsp_bank_reset(self.bank) };
+    }
+
+    fn set_sample_rate(&mut self, sample_rate: f64) {
+        let rc = unsafe { fdsp_bank_set_sample_rate(self.bank, sample_rate) };
+        debug_assert!(rc == FDSP_OK, "{}", last_error());
+    }
+
+    #[inline]
+    fn tick(&mut self, input: &Frame<f32, Self::Inputs>) -> Frame<f32, Self::Outputs> {
+        // one sample of every voice: planar rows of length 1 are [voice][channel] = the Frame's own order
+        let mut out: Frame<f32, Self::Outputs> = Frame::default();
+        let inp = if NI::USIZE > 0 { input.as_slice().as_ptr() } else { core::ptr::null() };
+        let rc = unsafe { fdsp_bank_process_host(self.bank, 1, inp, out.as_mut_slice().as_mut_ptr(), FDSP_LAYOUT_PLANAR, 1, FDSP_MODE_TICK) };
+        debug_assert!(rc == FDSP_OK, "{}", last_error());
+        out
+    }
+
+    fn process(&mut self, size: usize, input: &BufferRef, output: &mut BufferMut) {
+        // BufferRef(&[F32x]) / BufferMut(&mut [F32x]): contiguous [channel][64] f32, 32-byte aligned, channel = voice-major
+        let inp = if NI::USIZE > 0 { input.channel_f32(0).as_ptr() } else { core::ptr::null() };
+        let out = output.channel_f32_mut(0).as_mut_ptr();
+        let rc = unsafe { fdsp_bank_process_host(self.bank, size, inp, out, FDSP_LAYOUT_PLANAR, MAX_BUFFER_SIZE, FDSP_MODE_PROCESS) };
+        // process() is infallible in FunDSP: an error here is a programming error (wrong arity, lost device)
+        debug_assert!(rc == FDSP_OK, "{}", last_error());
+    }
+
+    fn set_hash(&mut self, hash: u64) {
+        // ping() reaches a leaf with ONE hash; a bank is V leaves: every voice gets it (a bank that should de-correlate
+        // its voices calls set_seeds with one seed per voice instead, as the parity tests do)
+        let seeds = vec![hash; self.voices];
+        unsafe { fdsp_bank_set_seed(self.bank, seeds.as_ptr(), 0, self.voices) };
+    }
+
+    fn route(&mut self, input: &SignalFrame, _frequency: f64) -> SignalFrame {
+        Routing::Arbitrary(0.0).route(input, self.outputs())
+    }
+}
+
+impl<NI: Size<f32>, NO: Size<f32>> Clone for HipBank<NI, NO> {
+    /// FunDSP nodes are `Clone`: a second bank of the same kind with the first one's parameters and state.
+    fn clone(&self) -> Self {
+        let mut bank: *mut FdspBank = core::ptr::null_mut();
+        let rc = unsafe { fdsp_bank_create_on(self.device, self.kind.as_ptr(), self.voices, self.ring_frames, &mut bank) };
+        assert!(rc == FDSP_OK, "{}", last_error());
+        let n = unsafe { fdsp_bank_slot_count(self.bank) } as usize * self.voices;
+        let mut state = vec![0.0f32; n];
+        unsafe {
+            fdsp_bank_get_state(self.bank, state.as_mut_ptr());
+            fdsp_bank_set_state(bank, state.as_ptr());
+        }
+        Self { bank, kind: self.kind.clone(), voices: self.voices, ring_frames: self.ring_frames, device: self.device, _marker: PhantomData }
+    }
+}
+
+impl<NI: Size<f32>, NO: Size<f32>> Drop for HipBank<NI, NO> {
+    fn drop(&mut self) {
+        unsafe { fdsp_bank_destroy(self.bank) }
+    }
+}

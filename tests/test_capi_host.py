@@ -114,3 +114,21 @@ def test_graph_notation_lowers_to_reference_types_and_compiles(F):
     assert L.fdsp_graph_check(b"Pipe<Sine,Stack<Sine,Sine>>") < 0 and b"arity mismatch" in L.fdsp_last_error()
     with pytest.raises(TypeError):
         G.sine() >> (G.sine() | G.sine())
+
+
+def test_rust_shim_declares_the_c_abi():
+    """rust_shim/src/lib.rs (the reference-side binding, source only) stays in sync with include/fundsp_hip.h: every
+    `pub fn fdsp_*` of its extern block exists in the header with the same number of parameters."""
+    header = open(os.path.join(ROOT, "include", "fundsp_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    shim = open(os.path.join(ROOT, "rust_shim", "src", "lib.rs")).read()
+    shim = re.sub(r"//[^\n]*", "", shim)
+    decls = re.findall(r"pub fn (fdsp_[a-z0-9_]+)\s*\(([^)]*)\)", shim, flags=re.S)
+    assert len(decls) >= 25
+    for name, args in decls:
+        m = re.search(r"\b" + name + r"\s*\(([^)]*)\)", header, flags=re.S)
+        assert m, f"{name} is bound by rust_shim but not declared in include/fundsp_hip.h"
+        n_rust = len([a for a in args.split(",") if a.strip()])
+        c_args = m.group(1).strip()
+        n_c = 0 if c_args in ("", "void") else len([a for a in c_args.split(",") if a.strip()])
+        assert n_rust == n_c, f"{name}: {n_rust} parameters in rust_shim, {n_c} in the header"

@@ -83,3 +83,45 @@ def test_allnest(gpu, inner):
 def test_ring_kind_needs_capacity(gpu):
     with pytest.raises(gpu.FdspError):
         gpu.Bank("delay", 8)
+
+
+def test_ring_capacity_too_small_is_an_error_not_a_shorter_delay(gpu):
+    """The reference resizes a Delay / Tap / Limiter buffer when time * sample_rate grows (delay.rs:105-113); a bank's
+    rings are fixed at creation, so asking for more than `ring_frames` must FAIL the next render loudly -- and stop
+    failing once the parameters fit again."""
+    V, T = 64, 64
+    b = gpu.Bank("delay", V, ring_frames=256)
+    b.set_param(":time", 0.004)          # 192 + 1 positions at 48 kHz: fits
+    b.set_sample_rate(SR)
+    x = noise_input(V, 1, T, seed=5)
+    run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    b.set_sample_rate(96000.0)           # 384 + 1 positions: does not fit in 256
+    with pytest.raises(gpu.FdspError, match="ring capacity too small.*385"):
+        run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    with pytest.raises(gpu.FdspError, match="ring capacity too small"):      # stays an error until fixed
+        run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    b.set_sample_rate(SR)
+    run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    one = np.full(V, 0.004, dtype=np.float32)
+    one[17] = 0.02                       # a single voice asks for 961 positions
+    b.set_param(":time", one)
+    with pytest.raises(gpu.FdspError, match="961"):
+        run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+
+
+def test_from_graph_sizes_the_rings_itself(gpu):
+    """Bank.from_graph without ring_frames: Graph.ring_frames derives the capacity from the delay / tap / limiter
+    parameters at the construction rate and the target rate; the render equals the oracle."""
+    from fundsp_amd import graph as GR
+
+    build = lambda m: m.delay(0.0105) >> m.allnest_c(0.4, m.delay(0.003)) >> (m.pass_() * 2.0 >> m.limiter(0.004, 0.03))
+    g = build(GR)
+    assert g.ring_frames(48000.0) == max(505, 256 + 192 + 0)   # delay 0.0105 s -> 504 + 1; limiter 0.004 s -> 256 + 192
+    assert g.ring_frames(96000.0) == 1009
+    V, T = 66, 64 * 4 + 7
+    b = gpu.Bank.from_graph(g, V, sample_rate=SR)
+    x = noise_input(V, 1, T, seed=8)
+    got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    n = build(O)
+    n.set_sample_rate(SR)
+    assert_bit_equal(got[3], oracle_render(n, x[3], T, MODE_PROCESS), "auto-sized rings")

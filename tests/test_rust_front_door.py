@@ -1,0 +1,121 @@
+"""The Rust-side front door of the graph compiler (fdsp_rust_type_to_expr / fdsp_graph_compile_rust, fd_rust.hip): the
+string `core::any::type_name::<X>()` of a FunDSP graph in, the engine's template expression + the parameters the Rust type
+carries out.  Table test over the whole graph inventory (tests/test_gpu_jit.py::GRAPHS + the BASELINE configs): every
+graph is built three times with the same builder -- as Rust type names (tests/rust_types.py), as the engine notation
+(fundsp_amd/graph.py) -- and the translation of the first must equal the second.  CPU only (no kernel is compiled here;
+`-m gpu` adds one end-to-end compile + render through the front door)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+import rust_types as RT
+from fundsp_amd import graph as GR
+from test_gpu_jit import GRAPHS
+
+
+def translate(F, type_name, hints=""):
+    expr = C.create_string_buffer(1 << 16)
+    pre = C.create_string_buffer(1 << 16)
+    rc = F.lib().fdsp_rust_type_to_expr(type_name.encode(), hints.encode() if hints else None, expr, len(expr), pre, len(pre))
+    if rc != 0:
+        raise ValueError(F.lib().fdsp_last_error().decode())
+    presets = {}
+    for line in pre.value.decode().splitlines():
+        k, v = line.split("=")
+        presets[k] = float(v)
+    return expr.value.decode(), presets
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fundsp_amd
+
+    fundsp_amd.lib()
+    return fundsp_amd
+
+
+EXTRA = {
+    "config1": lambda m: m.sine_hz(440.0) >> m.lowpass_hz(1000.0, 1.0),
+    "config3_fm": lambda m: m.sine_hz(110.0) * 110.0 * 2.0 + 110.0 >> m.sine() >> m.lowpass_hz(900.0, 1.0),
+    "config4_voice": lambda m: ((m.dc(110.0) >> m.saw() | m.dc(900.0) | m.dc(0.3)) >> m.moog()) * m.adsr_live(0.01, 0.1, 0.6, 0.2) >> m.pan(0.2),
+    "eq_chain": lambda m: m.bell_hz(900.0, 1.2, 2.0) >> m.lowshelf_hz(200.0, 0.7, 0.5) >> m.notch_hz(3000.0, 4.0) >> m.allpass_hz(500.0, 1.0),
+    "negations": lambda m: -(m.pass_() * 0.5) + (1.0 - m.pass_()),
+}
+ALL = dict({k: v[0] for k, v in GRAPHS.items()}, **EXTRA)
+
+
+@pytest.mark.parametrize("name", list(ALL))
+def test_rust_type_name_translates_to_the_engine_expression(F, name):
+    build = ALL[name]
+    rust = build(RT)
+    want = build(GR)
+    expr, presets = translate(F, rust.type_name(), rust.hint_string())
+    assert expr == want.type, f"{name}:\n rust   {rust.type_name()}\n got    {expr}\n want   {want.type}"
+    # the parameters a Rust TYPE carries: svf / biquad modes and shape kinds -- exactly those, with graph.py's values
+    carried = {}
+    for slot, value, _u in want.slot_values():
+        field = slot.split(":")[1]
+        if field in ("mode", "shape"):
+            carried[slot] = float(np.asarray(value, dtype=np.float32))
+    assert presets == carried, f"{name}: presets {presets} != {carried}"
+
+
+def test_config1_type_name_verbatim(F):
+    """The exact spelling rustc prints for `sine_hz(440.0) >> lowpass_hz(1000.0, 1.0)` (combinator.rs:178, prelude32.rs:350,1924)."""
+    tn = ("fundsp::combinator::An<fundsp::audionode::Pipe<fundsp::audionode::Pipe<fundsp::audionode::Constant<typenum::uint::UInt<"
+          "typenum::uint::UTerm, typenum::bit::B1>>, fundsp::oscillator::Sine<f32>>, fundsp::svf::FixedSvf<f32, fundsp::svf::LowpassMode<f32>>>>")
+    assert EXTRA["config1"](RT).type_name() == tn
+    assert translate(F, tn) == ("Pipe<Pipe<Constant<1>,Sine>,FixedSvf>", {"1:mode": 0.0})
+
+
+def test_typenum_closures_and_errors(F):
+    u = RT.U
+    assert translate(F, f"fundsp::audionode::Constant<{u(5)}>")[0] == "Constant<5>"
+    assert translate(F, f"fundsp::audionode::MultiSplit<{u(2)}, {u(12)}>")[0] == "MultiSplit<2,12>"
+    assert translate(F, "fundsp::audionode::Constant<typenum::U3>")[0] == "Constant<3>"          # alias form
+    # a user closure needs its stand-in functor; adsr_live's is recognised by path
+    env = f"fundsp::envelope::EnvelopeIn<f32, my_crate::patch::{{{{closure}}}}, {u(1)}, f32>"
+    with pytest.raises(ValueError, match="closure"):
+        translate(F, env)
+    assert translate(F, env, "envelope_in=MyFn")[0] == "EnvelopeIn<MyFn>"
+    m = f"fundsp::audionode::Map<my_crate::{{{{closure}}}}, {u(2)}, {u(3)}>"
+    assert translate(F, m, "map=MidSide")[0] == "Map<MidSide,2,3>"
+    with pytest.raises(ValueError, match="no device template"):
+        translate(F, "fundsp::resynth::Resynth<typenum::U1, typenum::U1, my::{{closure}}>")
+    with pytest.raises(ValueError, match="parse|trailing|expected"):
+        translate(F, "fundsp::audionode::Pipe<fundsp::audionode::Pass")
+    # wavetable hints in node order; default saw
+    two = (RT.saw() | RT.square()).type_name()
+    assert translate(F, two, "wavesynth=saw,square")[0] == "Stack<WaveSynth<0>,WaveSynth<1>>"
+    assert translate(F, two)[0] == "Stack<WaveSynth<0>,WaveSynth<0>>"
+
+
+@pytest.mark.gpu
+def test_compile_and_render_through_the_front_door(gpu):
+    """fdsp_graph_compile_rust end to end: the Rust type name of a graph with type-carried parameters (highpass + bell
+    modes, a Tanh shaper) is compiled, the presets are applied at bank creation, field values are set by slot, and the
+    render equals the oracle bit for bit."""
+    from test_gpu_parity import assert_bit_equal, noise_input, oracle_render, run_bank
+    from fundsp_amd import LAYOUT_VOICE_MINOR, MODE_PROCESS
+
+    build = lambda m: m.highpass_hz(300.0, 0.8) >> m.shape("tanh", 1.5) >> m.bell_hz(1200.0, 2.0, 3.0)
+    rust, g = build(RT), build(GR)
+    L = gpu.lib()
+    k = L.fdsp_graph_compile_rust(b"rust_front_door_demo", rust.type_name().encode(), None, None)
+    assert k >= 0, L.fdsp_last_error().decode()
+    V, T = 70, 64 * 5 + 9
+    b = gpu.Bank("rust_front_door_demo", V)
+    for slot, value, _u in g.slot_values():
+        if slot.split(":")[1] not in ("mode", "shape"):      # modes / shape kinds came with the type
+            b.set_param(slot, float(value))
+    b.set_sample_rate(48000.0)
+    x = noise_input(V, 1, T, seed=3)
+    got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    n = build(O)
+    n.set_sample_rate(48000.0)
+    for v in (0, 69):
+        n2 = build(O)
+        n2.set_sample_rate(48000.0)
+        assert_bit_equal(got[v], oracle_render(n2, x[v], T, MODE_PROCESS), f"voice {v}")
