@@ -754,7 +754,7 @@ int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring
 static void fdn_free(FdnBank* f) {
     if (!f) return;
     if (f->st.rings) hipFree(f->st.rings);
-    if (f->st.idx) hipFree(f->st.idx);
+    if (f->st.wpos) hipFree(f->st.wpos);
     if (f->st.v1) hipFree(f->st.v1);
     if (f->st.v2) hipFree(f->st.v2);
     if (f->st.fb) hipFree(f->st.fb);
@@ -775,7 +775,7 @@ static int fdn_configure(fdsp_bank* b, double sr) {
     const size_t n = b->V;
     fd::FdnState st{};
     hipError_t e = hipMalloc((void**)&st.rings, n * c.ring_stride * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&st.idx, n * 32 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&st.wpos, n * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&st.v1, n * 32 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&st.v2, n * 32 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&st.fb, n * 32 * sizeof(float));

@@ -31,12 +31,11 @@ void fdn_make_const(double room_size, double time, double damping, double sample
     c->w[0] = beta * a;
     c->w[1] = alpha * a;
     c->w[2] = beta * a;
-    size_t off = 0;
+    int maxlen = 0;
     for (int i = 0; i < 32; i++) {
         const int delay = (int)std::round(RV_DELAYS[i] * room_size / 10.0 * sample_rate);
         c->len[i] = delay + 1;
-        c->off[i] = (int)off;
-        off += ((size_t)c->len[i] + 63) / 64 * 64;  // keep every ring 256-B aligned
+        maxlen = c->len[i] > maxlen ? c->len[i] : maxlen;
         const float x = (float)((double)i / 31.0);  // sumf: F::from_f64(i / (N-1))  prelude.rs:1613-1616
         const float x2 = x * x;                     // smooth9  math.rs:431-437
         const float t = ((((70.0f * x - 315.0f) * x + 540.0f) * x - 420.0f) * x + 126.0f) * x2 * x2 * x;
@@ -47,7 +46,10 @@ void fdn_make_const(double room_size, double time, double damping, double sample
         c->wl[i] = cosf_musl(angle);
         c->wr[i] = sinf_musl(angle);
     }
-    c->ring_stride = off;
+    int cap = 256;
+    while (cap < maxlen) cap <<= 1;
+    c->cap = cap;
+    c->ring_stride = (size_t)32 * ((size_t)cap + 64);
 }
 
 constexpr int TS = 65;  // LDS row stride (floats): lane-per-row access is bank-conflict free
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void k_fdn_reset(FdnConst c, FdnState s, size_
     const size_t total = instances * c.ring_stride;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) s.rings[i] = 0.0f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < instances * 32; i += (size_t)gridDim.x * 256) {
-        s.idx[i] = 0;
+        if (i < instances) s.wpos[i] = 0;
         s.v1[i] = 0.0f;
         s.v2[i] = 0.0f;
         s.fb[i] = 0.0f;
@@ -116,9 +118,10 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
     const size_t inst = inst0 + j;
     const bool valid = line && inst < V;
     const size_t sidx = (valid ? inst : inst0) * 32 + k;
-    int idx = s.idx[sidx];
+    int wp = s.wpos[valid ? inst : inst0];  // the instance's write position (same value in its 32 lanes)
     float v1 = s.v1[sidx], v2 = s.v2[sidx], fb = s.fb[sidx];
-    const int mylen = c.len[k];
+    const int cmask = c.cap - 1;
+    const size_t cp = (size_t)c.cap + 64;
     const float w0 = c.w[0], w1 = c.w[1], w2 = c.w[2];
     const float scale = (float)(1.0 / 5.656854249492381);  // (1.0 / sqrt(32 as f64)) as f32  feedback.rs:57
     uint32_t negmask[5];
@@ -129,17 +132,15 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
     // current block, consumed after it): every delay exceeds 128 samples, so the rows block b+1 reads are not touched
     // by block b's writes, and the HBM latency hides behind phase 2.  In these phases lane = frame (all 64 lanes).
     float xr[R], xin[2 * IPW];
-    auto fetch = [&](size_t t0n, int idx_now) {
+    auto fetch = [&](size_t t0n, int wp_now) {
         const int sizen = (int)((T - t0n) < 64 ? (T - t0n) : 64);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int kk = r & 31;
             const size_t ri = inst0 + (r >> 5);
-            const int i0 = __builtin_amdgcn_readlane(idx_now, r);
-            const int len = c.len[kk];
-            int pos = i0 + 1 + lane;  // len > 128 (checked at creation): one conditional wrap suffices
-            pos = pos >= len ? pos - len : pos;
-            xr[r] = (ri < V && lane < sizen) ? s.rings[ri * c.ring_stride + (size_t)c.off[kk] + (size_t)pos] : 0.0f;
+            const int w0 = __builtin_amdgcn_readlane(wp_now, r);
+            const int pos = (w0 + lane - (c.len[kk] - 1)) & cmask;  // frame `lane` reads the slot written len - 1 frames earlier
+            xr[r] = (ri < V && lane < sizen) ? s.rings[ri * c.ring_stride + (size_t)kk * cp + (size_t)pos] : 0.0f;
         }
 #pragma unroll
         for (int q = 0; q < 2 * IPW; q++) {  // q = instance-in-wave * 2 + channel
@@ -156,15 +157,13 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
 #pragma unroll
         for (int q = 0; q < 2 * IPW; q++) tin[q * 64 + lane] = xin[q];
     };
-    fetch(0, idx);
+    fetch(0, wp);
     stage();
     for (size_t t0 = 0; t0 < T; t0 += 64) {
         const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
         const bool more = t0 + 64 < T;
         if (more) {  // ---- phase 1 of the NEXT block: loads in flight during this block's recurrence
-            int idx_next = idx + 64;
-            idx_next = idx_next >= mylen ? idx_next - mylen : idx_next;
-            fetch(t0 + 64, idx_next);
+            fetch(t0 + 64, (wp + 64) & cmask);
         }
         fdn_wave_sync();
         // ---- phase 2: 64 samples of the recirculating network, one lane per delay line.  Ring reads and inputs of 8
@@ -223,12 +222,14 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
             for (int u = 0; u < 32; u++) {
                 const int r = r0 + u, kk = u;
                 const size_t ri = inst0 + (r0 >> 5);
-                const int i0 = __builtin_amdgcn_readlane(idx, r);
-                const int len = c.len[kk];
-                int pos = i0 + lane;
-                pos = pos >= len ? pos - len : pos;
+                const int w0 = __builtin_amdgcn_readlane(wp, r);
+                const int pos = (w0 + lane) & cmask;
 #ifndef FD_FDN_SKIP_STORE
-                if (ri < V && lane < size) s.rings[ri * c.ring_stride + (size_t)c.off[kk] + (size_t)pos] = xw[u];
+                if (ri < V && lane < size) {
+                    float* ring = s.rings + ri * c.ring_stride + (size_t)kk * cp;
+                    ring[pos] = xw[u];
+                    if (pos < 64) ring[c.cap + pos] = xw[u];  // the mirror of the first 64 slots
+                }
 #endif
             }
         }
@@ -254,13 +255,12 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
                 }
             }
         }
-        idx += size;
-        while (idx >= mylen) idx -= mylen;
+        wp = (wp + size) & cmask;
         fdn_wave_sync();
         if (more) stage();  // the tiles are free again: land the prefetched rows of the next block
     }
     if (valid) {
-        s.idx[sidx] = idx;
+        if (k == 0) s.wpos[inst] = wp;
         s.v1[sidx] = v1;
         s.v2[sidx] = v2;
         s.fb[sidx] = fb;
@@ -278,18 +278,20 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
 // (non-temporal ring loads / stores measured 10.2 ms vs 6.4-6.9 ms: the L2 write-combining matters)
 constexpr int HS = 68;  // floats per history row: [0..1] carry-in, [2..65] this block (also used with offset 1 for fb)
 
+// CAP_LOG2: the ring capacity C = 1 << CAP_LOG2 is a compile-time constant here, so the 32 ring bases inside an instance
+// are immediates and a block's ring addresses come out of a handful of scalar instructions:
+//   read  of line k, frames 0..63:  rings[k * (C + 64) + ((w - D_k) & (C - 1)) + lane]      (the mirror zone: never wraps)
+//   write of line k, frames 0..63:  rings[k * (C + 64) + w + lane]                           (when w + 64 <= C)
+// Blocks whose write window wraps (one in C / 64), or touches the first 64 slots (mirror copy), or is ragged (the last
+// block of a launch that is not a multiple of 64 frames) take the general per-lane path.
+template <int CAP_LOG2>
 __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState s, size_t V, const float* __restrict__ in,
                                                            float* __restrict__ out, size_t T, size_t fstride, int layout) {
+    constexpr int C = 1 << CAP_LOG2, CMASK = C - 1, CP = C + 64;
     __shared__ float hist_all[4][32 * HS];  // per line: delay outputs d[n-2], d[n-1] | d[0..63]
     __shared__ float fbr_all[4][32 * HS];   // per line: fb[-1] | fb[0..63]
-    // per-line constants in LDS (same for the four instances of the workgroup): as kernel-argument scalars the 128 of them
-    // do not fit the SGPR file next to the 32 ring indices and get parked in VGPR lanes (v_writelane / v_readlane + hazard
-    // nops: a fifth of the loop's instructions); an LDS broadcast read per use is cheaper
-    __shared__ int sc_len[32], sc_off[32];
-    __shared__ float sc_wl[32], sc_wr[32];
-    if (threadIdx.x < 32) {
-        sc_len[threadIdx.x] = c.len[threadIdx.x];
-        sc_off[threadIdx.x] = (int)c.off[threadIdx.x];
+    __shared__ float sc_wl[32], sc_wr[32];  // pan weights: an LDS broadcast read per use (128 kernel-argument scalars
+    if (threadIdx.x < 32) {                 // next to the 32 delays do not fit the SGPR file)
         sc_wl[threadIdx.x] = c.wl[threadIdx.x];
         sc_wr[threadIdx.x] = c.wr[threadIdx.x];
     }
@@ -301,38 +303,43 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
     if (inst >= V) return;
     const float w0 = c.w[0], w1 = c.w[1], w2 = c.w[2];
     const float scale = (float)(1.0 / 5.656854249492381);  // (1.0 / sqrt(32 as f64)) as f32  feedback.rs:57
-    float* rings = s.rings + inst * c.ring_stride;
-    int idx[32];  // Delay::i of every line: wave-uniform
-#pragma unroll
-    for (int k = 0; k < 32; k++) idx[k] = __builtin_amdgcn_readfirstlane(s.idx[inst * 32 + k]);
+    // The instance's rings as a buffer resource: buffer_load / buffer_store take a VGPR offset (lane * 4, the same for
+    // every access), an SGPR offset (the line's base + the block's slot, scalar arithmetic) and no 64-bit VALU address math.
+    const __amdgpu_buffer_rsrc_t rings = __builtin_amdgcn_make_buffer_rsrc(s.rings + inst * c.ring_stride, 0, (int)(c.ring_stride * sizeof(float)), 0x00020000);
+    const int lane4 = lane * 4;
+    int wp = __builtin_amdgcn_readfirstlane(s.wpos[inst]);  // write position of the block's first frame: wave-uniform
     if (lane < 32) {  // carry-in: Fir::v[1], v[2] and Feedback::value of every line
         hist[lane * HS + 0] = s.v1[inst * 32 + lane];
         hist[lane * HS + 1] = s.v2[inst * 32 + lane];
         fbr[lane * HS + 0] = s.fb[inst * 32 + lane];
     }
     float dn[32], xin[2];  // prefetched ring reads / inputs of the NEXT block (lane = frame)
-    auto fetch = [&](size_t t0n, int adv) {
+    auto fetch = [&](size_t t0n, int wpn) {
         const int sizen = (int)((T - t0n) < 64 ? (T - t0n) : 64);
+        // frame 0 of the block reads the slot written len - 1 frames ago; the 64 slots from there on are contiguous (mirror
+        // zone), in bounds for every lane, and lanes past a ragged end read values nobody uses
 #pragma unroll
         for (int k = 0; k < 32; k++) {
-            const int len = sc_len[k];
-            int i0 = idx[k] + adv;
-            i0 = i0 >= len ? i0 - len : i0;
-            int pos = i0 + 1 + lane;  // Delay::tick reads the slot AFTER the write index (delay.rs:116-124); len > 128
-            pos = pos >= len ? pos - len : pos;
-            dn[k] = lane < sizen ? rings[(size_t)sc_off[k] + (size_t)pos] : 0.0f;
+            const int r = (wpn - (c.len[k] - 1)) & CMASK;
+            dn[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rings, lane4, (k * CP + r) * 4, 0));
         }
+        if (sizen == 64) {
 #pragma unroll
-        for (int ch = 0; ch < 2; ch++)
-            xin[ch] = lane < sizen ? (layout == 0 ? in[((size_t)ch * T + t0n + lane) * V + inst] : in[(inst * 2 + ch) * fstride + t0n + lane]) : 0.0f;
+            for (int ch = 0; ch < 2; ch++)
+                xin[ch] = layout == 0 ? in[((size_t)ch * T + t0n + lane) * V + inst] : (in + (inst * 2 + ch) * fstride + t0n)[lane];
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++)
+                xin[ch] = lane < sizen ? (layout == 0 ? in[((size_t)ch * T + t0n + lane) * V + inst] : in[(inst * 2 + ch) * fstride + t0n + lane]) : 0.0f;
+        }
     };
-    fetch(0, 0);
+    fetch(0, wp);
     for (size_t t0 = 0; t0 < T; t0 += 64) {
         const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
         float d[32], xi0 = xin[0], xi1 = xin[1];
 #pragma unroll
         for (int k = 0; k < 32; k++) d[k] = dn[k];
-        if (t0 + 64 < T) fetch(t0 + 64, 64);  // loads of the next block fly during this block's arithmetic
+        if (t0 + 64 < T) fetch(t0 + 64, (wp + 64) & CMASK);  // loads of the next block fly during this block's arithmetic
         // delay outputs -> history rows (lane n writes slot n + 2), then the FIR reads slots n, n + 1 (fir.rs:57-70)
 #pragma unroll
         for (int k = 0; k < 32; k++) hist[k * HS + 2 + lane] = d[k];
@@ -362,30 +369,38 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
 #pragma unroll
         for (int k = 0; k < 32; k++) fbr[k * HS + 1 + lane] = h[k] * scale;
         fdn_wave_sync();
-        if (lane < size) {
+        float xw[32];  // MultiSplit<U2,U16>: line k takes input channel k % 2 (audionode.rs:600); Feedback::tick: input + value
 #pragma unroll
-            for (int k = 0; k < 32; k++) {  // MultiSplit<U2,U16>: line k takes input channel k % 2 (audionode.rs:600)
-                const float x = ((k & 1) ? xi1 : xi0) + fbr[k * HS + lane];
-                const int len = sc_len[k];
-                int pos = idx[k] + lane;  // Delay::tick: the new sample takes the slot at the write index
-                pos = pos >= len ? pos - len : pos;
-                rings[(size_t)sc_off[k] + (size_t)pos] = x;
-            }
-            float l = 0.0f, rr = 0.0f;  // Reduce::tick left fold (audionode.rs:2427-2439) of the 32 Panner outputs
+        for (int k = 0; k < 32; k++) xw[k] = ((k & 1) ? xi1 : xi0) + fbr[k * HS + lane];
+        if (size == 64 && wp >= 64 && wp + 64 <= C) {  // the common block: one scalar offset per line
+#pragma unroll
+            for (int k = 0; k < 32; k++)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xw[k]), rings, lane4, (k * CP + wp) * 4, 0);
+        } else if (lane < size) {  // wrap, mirror zone or ragged tail: per-lane slots, Delay::tick slot by slot
+            const int pos = (wp + lane) & CMASK;
 #pragma unroll
             for (int k = 0; k < 32; k++) {
-                const float pl = sc_wl[k] * o[k], pr = sc_wr[k] * o[k];
-                l = k == 0 ? pl : l + pl;
-                rr = k == 0 ? pr : rr + pr;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xw[k]), rings, pos * 4, k * CP * 4, 0);
+                if (pos < 64)  // keep the mirror of the first 64 slots
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xw[k]), rings, (C + pos) * 4, k * CP * 4, 0);
             }
-            l *= (float)(1.0 / 16.0);  // * dc((1/16, 1/16))
-            rr *= (float)(1.0 / 16.0);
+        }
+        float l = 0.0f, rr = 0.0f;  // Reduce::tick left fold (audionode.rs:2427-2439) of the 32 Panner outputs
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            const float pl = sc_wl[k] * o[k], pr = sc_wr[k] * o[k];
+            l = k == 0 ? pl : l + pl;
+            rr = k == 0 ? pr : rr + pr;
+        }
+        l *= (float)(1.0 / 16.0);  // * dc((1/16, 1/16))
+        rr *= (float)(1.0 / 16.0);
+        if (lane < size) {
             if (layout == 0) {
                 out[((size_t)0 * T + t0 + lane) * V + inst] = l;
                 out[((size_t)1 * T + t0 + lane) * V + inst] = rr;
             } else {
-                out[(inst * 2 + 0) * fstride + t0 + lane] = l;
-                out[(inst * 2 + 1) * fstride + t0 + lane] = rr;
+                (out + (inst * 2 + 0) * fstride + t0)[lane] = l;
+                (out + (inst * 2 + 1) * fstride + t0)[lane] = rr;
             }
         }
         fdn_wave_sync();
@@ -396,19 +411,11 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
             hist[lane * HS + 1] = b;
             fbr[lane * HS + 0] = f;
         }
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            const int len = sc_len[k];
-            idx[k] += size;
-            idx[k] = idx[k] >= len ? idx[k] - len : idx[k];
-        }
+        wp = (wp + size) & CMASK;
         fdn_wave_sync();
     }
+    if (lane == 0) s.wpos[inst] = wp;
     if (lane < 32) {
-        int mine = 0;
-#pragma unroll
-        for (int k = 0; k < 32; k++) mine = lane == k ? idx[k] : mine;
-        s.idx[inst * 32 + lane] = mine;
         s.v1[inst * 32 + lane] = hist[lane * HS + 0];
         s.v2[inst * 32 + lane] = hist[lane * HS + 1];
         s.fb[inst * 32 + lane] = fbr[lane * HS + 0];
@@ -423,8 +430,15 @@ void fdn_launch_render(const FdnConst& c, const FdnState& s, size_t instances, c
                        size_t fstride, int layout, hipStream_t stream) {
     if (instances == 0 || T == 0) return;
     if (g_fdn_kernel == 0) {
-        hipLaunchKernelGGL(k_fdn_render_frames, dim3((unsigned)((instances + 3) / 4)), dim3(256), 0, stream, c, s, instances, in,
-                           out, T, fstride, layout);
+        const dim3 grid((unsigned)((instances + 3) / 4)), block(256);
+        switch (c.cap) {  // the ring capacity is a template parameter of the lane = frame kernel
+#define FD_FDN_CASE(L) case 1 << L: hipLaunchKernelGGL(k_fdn_render_frames<L>, grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout); break;
+            FD_FDN_CASE(8) FD_FDN_CASE(9) FD_FDN_CASE(10) FD_FDN_CASE(11) FD_FDN_CASE(12) FD_FDN_CASE(13) FD_FDN_CASE(14)
+            FD_FDN_CASE(15) FD_FDN_CASE(16) FD_FDN_CASE(17) FD_FDN_CASE(18)
+#undef FD_FDN_CASE
+        default:  // longer than 2^18 slots (5.4 s at 48 kHz): the lane = line kernel takes any capacity
+            hipLaunchKernelGGL(k_fdn_render<1>, grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout);
+        }
     } else if ((instances + 1) / 2 < 2 * (size_t)simd_count()) {
         // lane = line kernel: one instance per wave while that is what it takes to have two waves per SIMD
         const unsigned grid = (unsigned)((instances + 3) / 4);

@@ -13,8 +13,8 @@
 //    order HBM wants, the pan sum is a register fold; two 8.7-KB LDS rows per wave carry the one- and two-frame shifts.
 //  * lane = DELAY LINE (k_fdn_render<IPW>): 32 lanes per instance, cross-lane Hadamard (DPP quad_perm / row mirrors,
 //    v_permlane16_swap), ring rows staged through LDS tiles.
-// Delay rings live in HBM (372.6 KiB per instance at 48 kHz); both kernels move the algorithmic minimum of 272 B per
-// instance-frame (32 ring reads + 32 ring writes + 2 in + 2 out).
+// Delay rings live in HBM (32 x (4096 + 64) floats = 520 KiB per instance at 48 kHz, room size 10); both kernels move
+// the algorithmic minimum of 272 B per instance-frame (32 ring reads + 32 ring writes + 2 in + 2 out).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -23,17 +23,24 @@
 
 namespace fd {
 
+// Ring memory of one instance: 32 rings of CP = C + 64 floats, C a power of two >= the longest delay + 1 (and >= 256).
+// ALL lines share one write position w in [0, C): the sample of frame n goes to slot n mod C of every ring, and line k
+// reads slot (w - D_k) mod C, D_k = len_k - 1 -- the same delay as the reference's Delay (write at i, advance, read at the
+// new i: the sample written len - 1 ticks ago, delay.rs:116-124; slots never written read as the zeros of reset()).
+// The last 64 floats of a ring MIRROR its first 64 (every store to a slot p < 64 also goes to C + p), so a block's 64
+// consecutive reads starting anywhere in [0, C) never wrap; a block's 64 consecutive writes wrap once in C / 64 blocks.
+// That makes the ring addresses of a block SCALAR (base + one wave-uniform offset + lane): no per-lane index arithmetic.
 struct FdnConst {            // uniform over the bank (all instances share room / time / damping)
-    int off[32];             // ring offset of each line inside an instance's ring block (floats)
-    int len[32];             // ring length = delay in samples + 1  (delay.rs:108-110)
+    int len[32];             // Delay ring length of the reference = delay in samples + 1  (delay.rs:108-110)
+    int cap;                 // C: slots per ring (power of two); rings are cap + 64 floats apart
     float w[3];              // FIR weights: fir3(1 - damping).weights() * a  (prelude.rs:1746-1747)
     float wl[32], wr[32];    // pan weights of the 32 output panners (prelude.rs:1759, pan.rs:13-17)
-    size_t ring_stride;      // floats per instance
+    size_t ring_stride;      // floats per instance = 32 * (cap + 64)
 };
 
 struct FdnState {
-    float* rings;            // [instances][ring_stride]
-    int* idx;                // [instances][32]   Delay::i
+    float* rings;            // [instances][32][cap + 64]
+    int* wpos;               // [instances]       shared write position (the reference's 32 Delay::i are all w mod len_k)
     float* v1;               // [instances][32]   Fir::v[1]
     float* v2;               // [instances][32]   Fir::v[2]
     float* fb;               // [instances][32]   Feedback::value

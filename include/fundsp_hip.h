@@ -100,10 +100,12 @@ int fdsp_set_option(const char* name, int value);
  *                    restated libm / wide functions): bit-identical to the CPU oracle.  The headline mode.
  *   FDSP_MATH_FAST   tolerance mode: state recurrences (phases, filter states, envelopes) stay operation for operation,
  *                    but feed-forward transcendental evaluations may use the engine's own FMA polynomials -- today the
- *                    f32x8 sine of Sine::process (13 instead of 28 operations, within 1.2e-7 of it).  Outputs stay within
- *                    the reference's own tick-vs-process tolerance of the exact mode (1e-4 absolute,
- *                    tests/test_basic.rs:31; measured in tests/test_gpu_math_fast.py).  Kinds without such a node render
- *                    exactly as before.
+ *                    f32x8 sine of Sine::process (13 instead of 28 operations, within 1.2e-7 of it).  Stated tolerance,
+ *                    measured in tests/test_gpu_math_fast.py on the BASELINE config-3 FM voices against the exact mode:
+ *                    <= 1e-4 absolute over the reference's own check window (441 samples, tests/test_basic.rs:21-47);
+ *                    <= 1e-3 max, <= 5e-5 rms over a full second (measured 2.6e-4 / 1.2e-5) -- an FM patch integrates
+ *                    every last-bit difference of the modulator into the carrier phase: the reference's own tick and
+ *                    process paths drift ~0.2 apart over the same second.  Kinds without such a node render exactly.
  * Per bank: fdsp_bank_set_option(bank, "math", v) / fdsp_bank_get_option(bank, "math");
  * fdsp_bank_get_option(bank, "math_has_fast_variant") tells whether FAST changes anything for the bank's kind. */
 #define FDSP_MATH_EXACT 0

@@ -234,7 +234,7 @@ def test_jit_flanger_and_phaser(gpu):
     x = noise_input(V, 1, T, seed=9)
     cases = {
         "flanger": (GR.flanger(0.6, 0.002, 0.006, "EnvSineHz", hz=hz, lo=0.002, hi=0.006),
-                    lambda: O.flanger(0.6, 0.002, 0.006, lambda t: f32(0.002) * (f32(1.0) - sin01(t)) + f32(0.006) * sin01(t)), 256),
+                    lambda: O.flanger(0.6, 0.002, 0.006, lambda t: f32(0.002) * (f32(1.0) - sin01(t)) + f32(0.006) * sin01(t)), 512),
         "phaser": (GR.phaser(0.5, "EnvSineHz", hz=hz, lo=0.0, hi=1.0),
                    lambda: O.phaser(0.5, lambda t: f32(0.0) * (f32(1.0) - sin01(t)) + f32(1.0) * sin01(t)), 0),
     }
