@@ -143,6 +143,19 @@ def secondary(F, W, torch, sr, mode):
                 "kernel_ms_avg": round(kms, 4), "value": round(V * T / ms / 1e3, 1), "unit": "Msamples/s",
                 "roofline_frac": round(algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     del wl
+    # the strong-scaling shards of the headline on ONE GPU: what each of N GPUs renders when the 65 536 voices are split N
+    # ways (no collective on the data path, so the N-GPU step time is the shard's time): small banks take the time-split kernel
+    shards = {"name": "config3_strong_scaling_shards", "what": "the per-GPU shard of the 65 536-voice headline at N = 2 / 4 / 8 GPUs, "
+              "rendered on this one GPU (exact arithmetic; banks of <= 32 768 voices take the time-split kernel k_render_ts); "
+              "implied_value = 65536 voices x frames / shard time", "unit": "Msamples/s"}
+    for n in (2, 4, 8):
+        Vs = TOTAL_VOICES // n
+        wl = make_workload(F, W, torch, 3, Vs, T, sr, 0, F.LAYOUT_VOICE_MINOR, "exact")
+        ms, kms = quick(F, torch, wl, T, mode)
+        shards[f"N{n}"] = {"voices_per_gpu": Vs, "ms_per_step": round(ms, 4), "kernel_ms_avg": round(kms, 4),
+                           "implied_value": round(TOTAL_VOICES * T / ms / 1e3, 1)}
+        del wl
+    out.append(shards)
     # config 2: 1024-voice biquad bank on white noise, 64-sample blocks (the launch-latency config)
     V = 1024
     c2 = {"name": "config2_biquad_bank_1024", "what": "BASELINE config 2: 1024 voices noise >> lowpass biquad (one BiquadBank<f32x8> lane "

@@ -21,6 +21,7 @@ thread_local std::string g_err;
 namespace fd {
 int g_pipe_split = 1;
 int g_fdn_kernel = 0;
+int g_time_split = 1;
 int g_math = FDSP_MATH_EXACT;  // default arithmetic of banks created from now on (fdsp_set_option("math", ..))
 long g_zero_copy_max = 1 << 18;  // floats; fdsp_bank_process_host reads/writes pinned host memory directly below this
 int simd_count() {  // SIMDs (CUs x 4) of the CURRENT device, cached per device
@@ -556,6 +557,11 @@ int fdsp_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "math") == 0) {
         if (value != FDSP_MATH_EXACT && value != FDSP_MATH_FAST) return fail(FDSP_EINVAL, "math takes FDSP_MATH_EXACT (0) or FDSP_MATH_FAST (1)");
         fd::g_math = value;
+        return FDSP_OK;
+    }
+    if (name && std::strcmp(name, "time_split") == 0) {
+        if (value < 0 || value > 1) return fail(FDSP_EINVAL, "time_split takes 0 (off) or 1 (small banks of eligible graphs)");
+        fd::g_time_split = value;
         return FDSP_OK;
     }
     return fail(FDSP_EINVAL, "unknown option");

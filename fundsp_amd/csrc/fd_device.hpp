@@ -606,6 +606,9 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
     render_events_body<G, MODE>(slots, stride, V, in, out, T, ev, fade, time0, sample_rate, aux, ring, ring_cap);
 }
 
+#ifndef FD_LP_ENABLE
+#define FD_LP_ENABLE 1  // A/B switch (tools/build_variants.sh): 0 = always the generic SVF arithmetic
+#endif
 // ---- multi-wave pipeline split of a Pipe chain ------------------------------------------------------------------
 // At one voice-wave per SIMD (65 536 voices on 1024 SIMDs) a lone wave issues one instruction per ~4.7 cycles while
 // the VALU could take one every ~2.5-3.3 (profiles/r01_ubench_valu.txt, r01_voice_sweep_*).  For graphs that are a
@@ -672,6 +675,8 @@ struct Seg {
     static constexpr bool USES_GIN = false;
     template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f*, v2f* out) { g.template step2<PH>(in, out); }
     template <int PH> static FD_D void step(G& g, const float* in, const float*, float* out) { g.template step<PH>(in, out); }
+    template <int PH> static FD_D void skip2(G& g, const v2f* in) { g.template skip2<PH>(in); }  // time-split stages only
+    template <int PH> static FD_D void skip(G& g, const float* in) { g.template skip<PH>(in); }
     static FD_D void begin(G& g, int n) { g.begin_block(n); }
     static FD_D void end(G& g) { g.end_simd(); }
     static FD_D bool tripped(const G& g) { return g.tripped(); }
@@ -698,6 +703,14 @@ struct Seg<Pipe<X, Y>, A, B, HEAD> {
         if constexpr (HX && HY) { float t[SX::OUT > 0 ? SX::OUT : 1]; SX::template step<PH>(g.x, in, gin, t); SY::template step<PH>(g.y, t, nullptr, out); }
         else if constexpr (HX) SX::template step<PH>(g.x, in, gin, out);
         else SY::template step<PH>(g.y, in, nullptr, out);
+    }
+    template <int PH> static FD_D void skip2(G& g, const v2f* in) {
+        static_assert(!(HX && HY), "skip is defined for one-stage segments");
+        if constexpr (HX) SX::template skip2<PH>(g.x, in); else SY::template skip2<PH>(g.y, in);
+    }
+    template <int PH> static FD_D void skip(G& g, const float* in) {
+        static_assert(!(HX && HY), "skip is defined for one-stage segments");
+        if constexpr (HX) SX::template skip<PH>(g.x, in); else SY::template skip<PH>(g.y, in);
     }
     static FD_D void begin(G& g, int n) {
         if constexpr (HX) SX::begin(g.x, n);
@@ -981,7 +994,7 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
 // The hardware places waves w, w+4, w+8, ... of a workgroup on the same SIMD.
 template <class G, int MODE, int S, int K1, int K2, int GPW = 4>
 FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
-                           float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap) {
+                           float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap, int vpw = 64) {
     using TL = PipeTiles<G, S, K1, K2>;
     constexpr int NI = G::IN;
     constexpr bool FEED = NI > 0;
@@ -996,10 +1009,13 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     __shared__ v2f hand[S > 1 ? S - 1 : 1][S > 1 ? GPW : 1][2][S > 1 ? W : 1][S > 1 ? SUB / 2 : 1][S > 1 ? 64 : 1];  // [cut][group][buffer][channel][frame pair][lane]
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // w: wave-uniform
     const int grp = w % GPW, role = w / GPW;
-    const size_t v0 = ((size_t)blockIdx.x * GPW + grp) * 64;
+    // vpw = voices per wave: 64, or 32 / 16 for heavy graphs on banks too small to give every SIMD several waves -- the
+    // waves of such graphs are latency-bound (dependent chains, gathers, divergent branches), so twice the waves at half
+    // the lanes render the bank sooner (launch_render_pipe picks it)
+    const size_t v0 = ((size_t)blockIdx.x * GPW + grp) * (size_t)vpw;
     const size_t v = v0 + lane;
     const bool live = v0 < stride;  // a whole group beyond the bank still takes part in the barriers
-    const bool active = v < V;
+    const bool active = v < V && lane < vpw;
     const size_t ntiles = ((T + 63) / 64) * SPB;
     const size_t rounds = ntiles + (S - 1) + (FEED ? 1 : 0);
     const float* inw = in + v0;  // wave-uniform bases + lane
@@ -1037,7 +1053,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     G g{};
     Ctx ctx{static_cast<const Aux*>(aux), ring + (live ? v : 0), ring_cap, stride, 0};
     g.bind(ctx);
-    if (live) {
+    if (live && v < stride) {  // (lanes past a partial wave's voices may also lie past the padded bank)
         VLoad ld{slots + v, stride, 0};
         VGate::W<VLoad> gate{&ld, true};
         if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
@@ -1076,9 +1092,6 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     };
     using GL = typename LpOf<G>::type;
     bool lp = false;
-#ifndef FD_LP_ENABLE
-#define FD_LP_ENABLE 1  // A/B switch (tools/build_variants.sh): 0 = always the generic SVF arithmetic
-#endif
     if constexpr (!SameType<GL, G>::v && MODE == MODE_PROCESS && FD_LP_ENABLE)
         lp = __builtin_amdgcn_ballot_w64((live && active) && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(live && active) != 0ull;
     if (lp) rounds_of((GL*)nullptr); else rounds_of((G*)nullptr);
@@ -1092,8 +1105,133 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
 template <class G, int MODE, int S, int K1, int K2, int GPW>
 __global__ __launch_bounds__((16 * GPW * PipeGeom<G::IN, S>::WAVES)) void k_render_pipe(float* __restrict__ slots, size_t stride, size_t V,
                                                                                       const float* __restrict__ in, float* __restrict__ out,
-                                                                                      size_t T, const void* aux, float* ring, uint32_t ring_cap) {
-    render_pipe_body<G, MODE, S, K1, K2, GPW>(slots, stride, V, in, out, T, aux, ring, ring_cap);
+                                                                                      size_t T, const void* aux, float* ring, uint32_t ring_cap, int vpw) {
+    render_pipe_body<G, MODE, S, K1, K2, GPW>(slots, stride, V, in, out, T, aux, ring, ring_cap, vpw);
+}
+
+// ---- time-split pipeline for banks that leave most of the chip idle (strong-scaling shards) ------------------------
+// The pipeline above gives a voice group as many waves as its chain has stages, and every wave walks all 64 frames of a
+// block: the time per frame is the longest stage's instruction count, whatever the number of idle SIMDs around it.  A
+// bank of <= 2 voice groups per CU (32 768 voices on an MI355X: the 2-, 4-, 8-GPU shards of the 65 536-voice metric) has
+// SIMDs to spare, so here the FEED-FORWARD work of a stage is also split over TIME: a stage whose state advance is cheap
+// next to its output (an oscillator: one or two operations of phase recurrence against a ~25-operation sine polynomial)
+// runs in NP waves; each wave advances the state through all 64 frames of the block (skip2) but evaluates the output
+// only for its own 64 / NP frames.  Stages [0, N-1) of a three-stage chain are split like that, the last stage (the
+// serial filter) is one wave running pipe_stage as before.  Same arithmetic per frame as every other kernel: bit-exact.
+//   waves of a workgroup (ONE voice group): NP x stage 0 | NP x stage 1 | 1 x stage 2, stage s one block behind stage s-1;
+//   hand-over tiles [frame pair][lane] v2f, double-buffered: 2 cuts x 2 x 16 KiB = 64 KiB -> two workgroups per CU.
+// Needs: process mode, voice-minor layout, no graph inputs, a 3-stage chain whose first two stages define skip2,
+// T a multiple of 64 (launch_render falls back to the pipeline kernel otherwise).
+template <class SG, class G, bool FIRST, int W>
+FD_D void ts_stage(G& g, int part, int nparts, int lane, v2f (*hin)[32][64], v2f (*hout)[32][64]) {
+    constexpr int NI = SG::IN, NO = SG::OUT;
+    static_assert(NO <= W && (FIRST || NI <= W), "hand-over tile too narrow");
+    const int lo = 64 / nparts * part, hi = lo + 64 / nparts;  // this wave's frames of the block (multiples of 8)
+    SG::begin(g, 64);
+    const G snap = g;
+    auto feed = [&](int i, v2f* pi) {
+        if constexpr (!FIRST) {
+#pragma unroll
+            for (int c = 0; c < NI; c++) pi[c] = hin[c][i >> 1][lane];
+        }
+    };
+    for (int i = 0; i < lo; i += 2) {
+        v2f pi[NI > 0 ? NI : 1];
+        feed(i, pi);
+        SG::template skip2<PH_SIMD>(g, pi);
+    }
+#pragma unroll 4
+    for (int i = lo; i < hi; i += 2) {
+        v2f pi[NI > 0 ? NI : 1], po[NO];
+        feed(i, pi);
+        SG::template step2<PH_SIMD>(g, pi, pi, po);
+#pragma unroll
+        for (int c = 0; c < NO; c++) hout[c][i >> 1][lane] = po[c];
+    }
+    for (int i = hi; i < 64; i += 2) {
+        v2f pi[NI > 0 ? NI : 1];
+        feed(i, pi);
+        SG::template skip2<PH_SIMD>(g, pi);
+    }
+    if (__builtin_expect(SG::tripped(g), 0)) {  // a packed-path shortcut left its exact domain: redo the block, frame by frame
+        g = snap;
+        for (int i = 0; i < 64; i++) {
+            float fi[NI > 0 ? NI : 1], fo[NO];
+            if constexpr (!FIRST) {
+#pragma unroll
+                for (int c = 0; c < NI; c++) fi[c] = reinterpret_cast<const float*>(&hin[c][i >> 1][lane])[i & 1];
+            }
+            if (i >= lo && i < hi) {
+                SG::template step<PH_SIMD>(g, fi, fi, fo);
+#pragma unroll
+                for (int c = 0; c < NO; c++) reinterpret_cast<float*>(&hout[c][i >> 1][lane])[i & 1] = fo[c];
+            } else {
+                SG::template skip<PH_SIMD>(g, fi);
+            }
+        }
+    }
+    SG::end(g);  // end_simd: once per block, after its last packed item
+}
+
+template <class G> struct TsPlan {  // which graphs the time-split kernel takes
+    static constexpr bool ok = Chain<G>::N == 3 && G::IN == 0 && G::RINGS == 0;
+};
+
+template <class G, int NP>
+FD_D void render_ts_body(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T,
+                         const void* aux) {
+    using S0 = Seg<G, 0, 1>;
+    using S1 = Seg<G, 1, 2>;
+    using S2 = Seg<G, 2, 3>;
+    constexpr int W = S0::OUT > S1::OUT ? S0::OUT : S1::OUT;
+    static_assert(W * 2 * 2 * 16 <= 64, "hand-over tiles must fit 64 KiB");
+    __shared__ v2f hand[2][2][W][32][64];  // [cut][buffer][channel][frame pair][lane]
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int stage = w < NP ? 0 : (w < 2 * NP ? 1 : 2), part = w < NP ? w : w - NP;
+    const size_t v0 = (size_t)blockIdx.x * 64, v = v0 + lane;
+    const bool active = v < V;
+    const size_t nblocks = T / 64, rounds = nblocks + 2;
+    float* outw = out + v0;
+    G g{};
+    Ctx ctx{static_cast<const Aux*>(aux), nullptr, 0, stride, 0};
+    g.bind(ctx);
+    {
+        VLoad ld{slots + v, stride, 0};
+        VGate::W<VLoad> gate{&ld, true};
+        if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
+    }
+    auto rounds_of = [&](auto* tag) {
+        using GG = typename Pointee<decltype(tag)>::type;
+        using T0 = Seg<GG, 0, 1>;
+        using T1 = Seg<GG, 1, 2>;
+        using T2 = Seg<GG, 2, 3>;
+        GG& gg = reinterpret_cast<GG&>(g);
+        for (size_t it = 0; it < rounds; it++) {
+            if (active && it >= (size_t)stage && it - stage < nblocks) {
+                const size_t j = it - stage;  // the block this stage works on in this round
+                if (stage == 0) ts_stage<T0, GG, true, W>(gg, part, NP, lane, nullptr, hand[0][j & 1]);
+                else if (stage == 1) ts_stage<T1, GG, false, W>(gg, part, NP, lane, hand[0][j & 1], hand[1][j & 1]);
+                else pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[1][j & 1], nullptr);
+            }
+            __syncthreads();
+        }
+    };
+    using GL = typename LpOf<G>::type;
+    bool lp = false;
+    if constexpr (!SameType<GL, G>::v && FD_LP_ENABLE)
+        lp = __builtin_amdgcn_ballot_w64(active && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(active) != 0ull;
+    if (lp) rounds_of((GL*)nullptr); else rounds_of((G*)nullptr);
+    if (active && part == 0) {  // the NP waves of a split stage end with identical state: one of them stores it
+        VStore<false> st{slots + v, stride, 0};
+        VGate::W<VStore<false>> gate{&st, true};
+        if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
+    }
+}
+
+template <class G, int NP>
+__global__ __launch_bounds__(64 * (2 * NP + 1)) void k_render_ts(float* __restrict__ slots, size_t stride, size_t V,
+                                                                 float* __restrict__ out, size_t T, const void* aux) {
+    if constexpr (TsPlan<G>::ok) render_ts_body<G, NP>(slots, stride, V, out, T, aux);
 }
 
 // ---- the pipeline kernel for the PLANAR layout ([voice][channel][frame_stride], the reference's BufferArray rows) ----

@@ -98,25 +98,31 @@ bool launch_render_pipe(float* slots, size_t stride, size_t V, const float* in, 
                         float* ring, uint32_t ring_cap, hipStream_t s) {
     constexpr PipePlan P = pipe_plan<G>(WANT);
     if constexpr (P.S >= 1) {
-        const size_t groups = (V + 63) / 64;
         constexpr int WAVES = PipeGeom<G::IN, P.S>::WAVES;  // for 4 voice groups
         const size_t cus = (size_t)simd_count() / 4;
-        // light graphs keep 4 groups per workgroup; heavy ones (latency-bound waves) are spread so that every CU gets one
+        // Light graphs: 64 voices per wave, 4 voice groups per workgroup.  Heavy graphs (latency-bound waves: gathers,
+        // divergent branches, long dependent chains) want MORE waves rather than full ones: while the bank has fewer than
+        // four groups per CU, halve the voices per wave (32, 16) -- same instructions per wave, twice the waves in flight
+        // per SIMD -- and only then thin the workgroups out (2 / 1 groups) so that every CU gets one.
+        int vpw = 64;
+        if constexpr (Cost<G>::v >= 150)
+            while (vpw > 16 && (V + vpw - 1) / vpw < 4 * cus) vpw >>= 1;
+        const size_t groups = (V + vpw - 1) / vpw;
         bool done = false;
         if constexpr (Cost<G>::v >= 150) {
             if (groups < 2 * cus) {
                 hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 1>), dim3((unsigned)groups), dim3(16 * WAVES), 0, s, slots,
-                                   stride, V, in, out, T, aux, ring, ring_cap);
+                                   stride, V, in, out, T, aux, ring, ring_cap, vpw);
                 done = true;
             } else if (groups < 4 * cus) {
                 hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 2>), dim3((unsigned)((groups + 1) / 2)), dim3(16 * 2 * WAVES), 0,
-                                   s, slots, stride, V, in, out, T, aux, ring, ring_cap);
+                                   s, slots, stride, V, in, out, T, aux, ring, ring_cap, vpw);
                 done = true;
             }
         }
         if (!done)
             hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 4>), dim3((unsigned)((groups + 3) / 4)), dim3(16 * 4 * WAVES), 0, s,
-                               slots, stride, V, in, out, T, aux, ring, ring_cap);
+                               slots, stride, V, in, out, T, aux, ring, ring_cap, vpw);
         return true;
     } else {
         return false;
@@ -162,10 +168,22 @@ bool launch_render_pipe_planar(float* slots, size_t stride, size_t V, const floa
     }
 }
 
+// fdsp_set_option("time_split", v): 1 (default) = small banks of eligible graphs take the time-split kernel, 0 = never
+extern int g_time_split;
+
 template <class G>
 void launch_render(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
                    int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
     if (V == 0 || T == 0) return;
+    // banks that leave most SIMDs idle (<= 2 voice groups per CU): split the oscillator stages over time as well
+    if constexpr (TsPlan<G>::ok) {
+        const size_t groups = (V + 63) / 64, cus = (size_t)simd_count() / 4;
+        if (g_time_split && g_pipe_split == 1 && layout == LAYOUT_VOICE_MINOR && mode == MODE_PROCESS && T % 64 == 0 && T >= 256 &&
+            groups <= 2 * cus) {
+            hipLaunchKernelGGL((k_render_ts<G, 2>), dim3((unsigned)groups), dim3(64 * 5), 0, s, slots, stride, V, out, T, aux);
+            return;
+        }
+    }
     // planar rows that allow 16-byte runs go through the planar pipeline (same launch-size rule as below)
     if (layout == LAYOUT_PLANAR && g_pipe_split && (T >= 256 || g_pipe_split > 1) && fstride % 4 == 0 && ((uintptr_t)in & 15) == 0 &&
         ((uintptr_t)out & 15) == 0) {

@@ -193,6 +193,10 @@ struct Constant {
     template <int PH> FD_HD void step2(const v2f*, v2f* out) {
         for (int i = 0; i < N; i++) out[i] = splat2(value[i]);
     }
+    // skip / skip2: advance the node's STATE over one / two frames without producing their output (time-split stages,
+    // fd_device.hpp ts_stage).  Only nodes whose state advance is cheap next to their output define them.
+    template <int PH> FD_HD void skip(const float*) {}
+    template <int PH> FD_HD void skip2(const v2f*) {}
 };
 
 // Pass  audionode.rs:408-436 (ID 48)
@@ -278,6 +282,13 @@ struct Sine {
             this->template step<PH>(&i1, &o1);
             out[0] = v2f{o0, o1};
         }
+    }
+    // the phase recurrence alone (the same operations step / step2 perform on `phase`); PH_SIMD only
+    template <int PH> FD_HD void skip(const float* in) { phase += in[0] * sample_duration; }
+    template <int PH> FD_HD void skip2(const v2f* in) {
+        v2f d = in[0] * sample_duration;
+        phase += d.x;
+        phase += d.y;
     }
 };
 
@@ -2967,6 +2978,17 @@ struct Pipe {
         x.template step2<PH>(in, t);
         y.template step2<PH>(t, out);
     }
+    // x in full (y's state advance needs its input), y skipped
+    template <int PH> FD_HD void skip(const float* in) {
+        float t[X::OUT > 0 ? X::OUT : 1];
+        x.template step<PH>(in, t);
+        y.template skip<PH>(t);
+    }
+    template <int PH> FD_HD void skip2(const v2f* in) {
+        v2f t[X::OUT > 0 ? X::OUT : 1];
+        x.template step2<PH>(in, t);
+        y.template skip2<PH>(t);
+    }
 };
 
 // Stack<X, Y>  audionode.rs:1496-1650 (ID 7)
@@ -3069,6 +3091,8 @@ struct Unop {
         x.template step2<PH>(in, out);
         for (int i = 0; i < OUT; i++) out[i] = U::f(out[i], scalar);
     }
+    template <int PH> FD_HD void skip(const float* in) { x.template skip<PH>(in); }
+    template <int PH> FD_HD void skip2(const v2f* in) { x.template skip2<PH>(in); }
 };
 
 // ---- type-level variants of a graph -------------------------------------------------------------------------------

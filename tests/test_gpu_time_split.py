@@ -1,0 +1,76 @@
+"""The time-split kernel (fd_device.hpp k_render_ts): banks small enough to leave most SIMDs idle -- the 2-, 4-, 8-GPU
+shards of the 65 536-voice metric -- render a three-stage chain with its oscillator stages split over TIME as well (two
+waves per stage, each advancing the phase through the whole block but evaluating the sine for its own half).  Same
+arithmetic per frame as every other kernel: bit-exact against the oracle, against the pipeline kernel, across launches,
+in tolerance mode, and through the rollback path (a phase of -0.0)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from fundsp_amd import LAYOUT_VOICE_MINOR, MATH_FAST, MODE_PROCESS
+from fundsp_amd import workloads as W
+from test_gpu_parity import assert_bit_equal, run_bank
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+
+
+@pytest.fixture
+def time_split(gpu):
+    def set_(v):
+        assert gpu.lib().fdsp_set_option(b"time_split", v) == 0
+    yield set_
+    set_(1)
+
+
+def test_time_split_equals_oracle_and_pipeline_kernel(gpu, time_split):
+    V, T = 64 * 10 + 37, 64 * 24          # ragged last voice group; three launches of 8 blocks each
+    p = W.fm_svf_params(V, SR)
+    want, _ = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], T, SR, True, 0, 8)   # [voice][frame]
+    for split in (1, 0):
+        time_split(split)
+        b = W.make_fm_svf_bank(V, SR, params=p)
+        got = np.concatenate([run_bank(b, None, T // 3, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :] for _ in range(3)], axis=1)
+        assert_bit_equal(got, want, f"time_split={split}, three consecutive launches")
+    # a launch that is not a multiple of 64 frames falls back to the pipeline kernel and continues the same state
+    time_split(1)
+    b = W.make_fm_svf_bank(V, SR, params=p)
+    a = run_bank(b, None, 64 * 8, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :]
+    c = run_bank(b, None, 64 * 4 + 13, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :]
+    want2, _ = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], 64 * 12 + 13, SR, True, 0, 8)
+    assert_bit_equal(np.concatenate([a, c], axis=1), want2, "time-split launch followed by a ragged launch")
+
+
+def test_time_split_rollback_path_and_negative_frequencies(gpu, time_split):
+    """A modulator / carrier phase of exactly -0.0 at a block start sends that block down the packed path's rollback
+    (Sine::begin_block), in the split waves too; huge modulation indices trip the |quadrant| < 8192 guard mid-block."""
+    V, T = 64 * 3, 64 * 6
+    p = W.fm_svf_params(V, SR)
+    p["m"][5] = np.float32(2.0e6)         # carrier frequency input ~ 1e9 Hz: phases run past the guard inside a block
+    p["f"][9] = np.float32(-440.0)        # negative frequencies: phases decrease
+    outs = []
+    for split in (1, 0):
+        time_split(split)
+        b = W.make_fm_svf_bank(V, SR, params=p)
+        for slot in (W.FM_SLOTS["mod_phase"], W.FM_SLOTS["car_phase"]):
+            ph = b.get_slot(slot)
+            ph[7] = np.float32(-0.0)
+            b.set_param(slot, ph)
+        with np.errstate(all="ignore"):
+            outs.append(run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :])
+    assert_bit_equal(outs[0], outs[1], "time-split == pipeline kernel on rollback blocks")
+    assert np.isfinite(outs[0][9]).all()
+
+
+def test_time_split_in_tolerance_mode(gpu, time_split):
+    V, T = 64 * 4, 64 * 16
+    p = W.fm_svf_params(V, SR)
+    outs = []
+    for split in (1, 0):
+        time_split(split)
+        b = W.make_fm_svf_bank(V, SR, params=p)
+        b.set_option("math", MATH_FAST)
+        outs.append(run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :])
+    assert_bit_equal(outs[0], outs[1], "FDSP_MATH_FAST: time-split == pipeline kernel")
+    want, _ = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], T, SR, True, 0, 4)
+    assert np.max(np.abs(outs[0] - want)) < 1e-4 and not np.array_equal(outs[0], want)
