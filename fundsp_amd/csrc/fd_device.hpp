@@ -994,7 +994,7 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
 // The hardware places waves w, w+4, w+8, ... of a workgroup on the same SIMD.
 template <class G, int MODE, int S, int K1, int K2, int GPW = 4>
 FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
-                           float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap, int vpw = 64) {
+                           float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap) {
     using TL = PipeTiles<G, S, K1, K2>;
     constexpr int NI = G::IN;
     constexpr bool FEED = NI > 0;
@@ -1009,13 +1009,12 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     __shared__ v2f hand[S > 1 ? S - 1 : 1][S > 1 ? GPW : 1][2][S > 1 ? W : 1][S > 1 ? SUB / 2 : 1][S > 1 ? 64 : 1];  // [cut][group][buffer][channel][frame pair][lane]
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // w: wave-uniform
     const int grp = w % GPW, role = w / GPW;
-    // vpw = voices per wave: 64, or 32 / 16 for heavy graphs on banks too small to give every SIMD several waves -- the
-    // waves of such graphs are latency-bound (dependent chains, gathers, divergent branches), so twice the waves at half
-    // the lanes render the bank sooner (launch_render_pipe picks it)
-    const size_t v0 = ((size_t)blockIdx.x * GPW + grp) * (size_t)vpw;
+    // (Half-filled waves -- 32 voices per wave, twice the waves -- were measured for the heavy config-4 voice: 33.7 ms
+    // against 31.0 ms.  Its SIMDs are issue-bound on expensive instructions, not latency-bound; profiles/r02_c4_vpw.txt.)
+    const size_t v0 = ((size_t)blockIdx.x * GPW + grp) * 64;
     const size_t v = v0 + lane;
     const bool live = v0 < stride;  // a whole group beyond the bank still takes part in the barriers
-    const bool active = v < V && lane < vpw;
+    const bool active = v < V;
     const size_t ntiles = ((T + 63) / 64) * SPB;
     const size_t rounds = ntiles + (S - 1) + (FEED ? 1 : 0);
     const float* inw = in + v0;  // wave-uniform bases + lane
@@ -1053,7 +1052,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     G g{};
     Ctx ctx{static_cast<const Aux*>(aux), ring + (live ? v : 0), ring_cap, stride, 0};
     g.bind(ctx);
-    if (live && v < stride) {  // (lanes past a partial wave's voices may also lie past the padded bank)
+    if (live) {
         VLoad ld{slots + v, stride, 0};
         VGate::W<VLoad> gate{&ld, true};
         if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
@@ -1105,8 +1104,8 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
 template <class G, int MODE, int S, int K1, int K2, int GPW>
 __global__ __launch_bounds__((16 * GPW * PipeGeom<G::IN, S>::WAVES)) void k_render_pipe(float* __restrict__ slots, size_t stride, size_t V,
                                                                                       const float* __restrict__ in, float* __restrict__ out,
-                                                                                      size_t T, const void* aux, float* ring, uint32_t ring_cap, int vpw) {
-    render_pipe_body<G, MODE, S, K1, K2, GPW>(slots, stride, V, in, out, T, aux, ring, ring_cap, vpw);
+                                                                                      size_t T, const void* aux, float* ring, uint32_t ring_cap) {
+    render_pipe_body<G, MODE, S, K1, K2, GPW>(slots, stride, V, in, out, T, aux, ring, ring_cap);
 }
 
 // ---- time-split pipeline for banks that leave most of the chip idle (strong-scaling shards) ------------------------
@@ -1115,10 +1114,11 @@ __global__ __launch_bounds__((16 * GPW * PipeGeom<G::IN, S>::WAVES)) void k_rend
 // bank of <= 2 voice groups per CU (32 768 voices on an MI355X: the 2-, 4-, 8-GPU shards of the 65 536-voice metric) has
 // SIMDs to spare, so here the FEED-FORWARD work of a stage is also split over TIME: a stage whose state advance is cheap
 // next to its output (an oscillator: one or two operations of phase recurrence against a ~25-operation sine polynomial)
-// runs in NP waves; each wave advances the state through all 64 frames of the block (skip2) but evaluates the output
-// only for its own 64 / NP frames.  Stages [0, N-1) of a three-stage chain are split like that, the last stage (the
-// serial filter) is one wave running pipe_stage as before.  Same arithmetic per frame as every other kernel: bit-exact.
-//   waves of a workgroup (ONE voice group): NP x stage 0 | NP x stage 1 | 1 x stage 2, stage s one block behind stage s-1;
+// runs in several waves; each wave advances the state through all 64 frames of the block (skip2) but evaluates the
+// output only for its own share of the frames.  Stages 0 and 1 of a three-stage chain are split like that (NA and NB
+// waves), the last stage (the serial filter) is one wave running pipe_stage as before.  Same arithmetic per frame as
+// every other kernel: bit-exact.
+//   waves of a workgroup (ONE voice group): NA x stage 0 | NB x stage 1 | 1 x stage 2, stage s one block behind stage s-1;
 //   hand-over tiles [frame pair][lane] v2f, double-buffered: 2 cuts x 2 x 16 KiB = 64 KiB -> two workgroups per CU.
 // Needs: process mode, voice-minor layout, no graph inputs, a 3-stage chain whose first two stages define skip2,
 // T a multiple of 64 (launch_render falls back to the pipeline kernel otherwise).
@@ -1177,7 +1177,7 @@ template <class G> struct TsPlan {  // which graphs the time-split kernel takes
     static constexpr bool ok = Chain<G>::N == 3 && G::IN == 0 && G::RINGS == 0;
 };
 
-template <class G, int NP>
+template <class G, int NA, int NB>
 FD_D void render_ts_body(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T,
                          const void* aux) {
     using S0 = Seg<G, 0, 1>;
@@ -1187,7 +1187,21 @@ FD_D void render_ts_body(float* __restrict__ slots, size_t stride, size_t V, flo
     static_assert(W * 2 * 2 * 16 <= 64, "hand-over tiles must fit 64 KiB");
     __shared__ v2f hand[2][2][W][32][64];  // [cut][buffer][channel][frame pair][lane]
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int stage = w < NP ? 0 : (w < 2 * NP ? 1 : 2), part = w < NP ? w : w - NP;
+    // Role of wave w: NA waves of stage 0, NB of stage 1, one filter wave; rank r in [A0 .. A(NA-1), B0 .. B(NB-1), C].
+    // The hardware places wave w of a workgroup on SIMD w % 4, and two workgroups share a CU when the bank has more than
+    // one voice group per CU, so the order of the roles decides how evenly the four SIMDs are loaded:
+    //   <2, 2> (one group per CU, 5 waves; SIMD 0 carries two): the filter -- the heavy wave, ~18 instructions per frame
+    //           against ~11 of an oscillator half -- stays off SIMD 0:                 [A0, C, A1, B0, B1]
+    //   <2, 1> (two groups per CU, 4 waves each): neighbouring workgroups are rotated by two, so every SIMD gets one
+    //           oscillator half and one whole-block wave:       even [A0, A1, B, C]     odd [B, C, A0, A1]
+    constexpr int NW = NA + NB + 1;
+    int r;
+    if (NA == 2 && NB == 2) r = w == 1 ? 4 : (w > 1 ? w - 1 : w);
+    else if (NA == 2 && NB == 1) r = (blockIdx.x & 1) ? (w + 2) % NW : w;
+    else r = w;
+    const int stage = r < NA ? 0 : (r < NA + NB ? 1 : 2);
+    const int part = r < NA ? r : (r < NA + NB ? r - NA : 0);
+    const int nparts = stage == 0 ? NA : NB;
     const size_t v0 = (size_t)blockIdx.x * 64, v = v0 + lane;
     const bool active = v < V;
     const size_t nblocks = T / 64, rounds = nblocks + 2;
@@ -1209,8 +1223,8 @@ FD_D void render_ts_body(float* __restrict__ slots, size_t stride, size_t V, flo
         for (size_t it = 0; it < rounds; it++) {
             if (active && it >= (size_t)stage && it - stage < nblocks) {
                 const size_t j = it - stage;  // the block this stage works on in this round
-                if (stage == 0) ts_stage<T0, GG, true, W>(gg, part, NP, lane, nullptr, hand[0][j & 1]);
-                else if (stage == 1) ts_stage<T1, GG, false, W>(gg, part, NP, lane, hand[0][j & 1], hand[1][j & 1]);
+                if (stage == 0) ts_stage<T0, GG, true, W>(gg, part, nparts, lane, nullptr, hand[0][j & 1]);
+                else if (stage == 1) ts_stage<T1, GG, false, W>(gg, part, nparts, lane, hand[0][j & 1], hand[1][j & 1]);
                 else pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[1][j & 1], nullptr);
             }
             __syncthreads();
@@ -1221,17 +1235,17 @@ FD_D void render_ts_body(float* __restrict__ slots, size_t stride, size_t V, flo
     if constexpr (!SameType<GL, G>::v && FD_LP_ENABLE)
         lp = __builtin_amdgcn_ballot_w64(active && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(active) != 0ull;
     if (lp) rounds_of((GL*)nullptr); else rounds_of((G*)nullptr);
-    if (active && part == 0) {  // the NP waves of a split stage end with identical state: one of them stores it
+    if (active && part == 0) {  // the waves of a split stage end with identical state: one of them stores it
         VStore<false> st{slots + v, stride, 0};
         VGate::W<VStore<false>> gate{&st, true};
         if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
     }
 }
 
-template <class G, int NP>
-__global__ __launch_bounds__(64 * (2 * NP + 1)) void k_render_ts(float* __restrict__ slots, size_t stride, size_t V,
-                                                                 float* __restrict__ out, size_t T, const void* aux) {
-    if constexpr (TsPlan<G>::ok) render_ts_body<G, NP>(slots, stride, V, out, T, aux);
+template <class G, int NA, int NB>
+__global__ __launch_bounds__(64 * (NA + NB + 1)) void k_render_ts(float* __restrict__ slots, size_t stride, size_t V,
+                                                                  float* __restrict__ out, size_t T, const void* aux) {
+    if constexpr (TsPlan<G>::ok) render_ts_body<G, NA, NB>(slots, stride, V, out, T, aux);
 }
 
 // ---- the pipeline kernel for the PLANAR layout ([voice][channel][frame_stride], the reference's BufferArray rows) ----

@@ -100,29 +100,23 @@ bool launch_render_pipe(float* slots, size_t stride, size_t V, const float* in, 
     if constexpr (P.S >= 1) {
         constexpr int WAVES = PipeGeom<G::IN, P.S>::WAVES;  // for 4 voice groups
         const size_t cus = (size_t)simd_count() / 4;
-        // Light graphs: 64 voices per wave, 4 voice groups per workgroup.  Heavy graphs (latency-bound waves: gathers,
-        // divergent branches, long dependent chains) want MORE waves rather than full ones: while the bank has fewer than
-        // four groups per CU, halve the voices per wave (32, 16) -- same instructions per wave, twice the waves in flight
-        // per SIMD -- and only then thin the workgroups out (2 / 1 groups) so that every CU gets one.
-        int vpw = 64;
-        if constexpr (Cost<G>::v >= 150)
-            while (vpw > 16 && (V + vpw - 1) / vpw < 4 * cus) vpw >>= 1;
-        const size_t groups = (V + vpw - 1) / vpw;
+        // light graphs keep 4 groups per workgroup; heavy ones (latency-bound waves) are spread so that every CU gets one
+        const size_t groups = (V + 63) / 64;
         bool done = false;
         if constexpr (Cost<G>::v >= 150) {
             if (groups < 2 * cus) {
                 hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 1>), dim3((unsigned)groups), dim3(16 * WAVES), 0, s, slots,
-                                   stride, V, in, out, T, aux, ring, ring_cap, vpw);
+                                   stride, V, in, out, T, aux, ring, ring_cap);
                 done = true;
             } else if (groups < 4 * cus) {
                 hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 2>), dim3((unsigned)((groups + 1) / 2)), dim3(16 * 2 * WAVES), 0,
-                                   s, slots, stride, V, in, out, T, aux, ring, ring_cap, vpw);
+                                   s, slots, stride, V, in, out, T, aux, ring, ring_cap);
                 done = true;
             }
         }
         if (!done)
             hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 4>), dim3((unsigned)((groups + 3) / 4)), dim3(16 * 4 * WAVES), 0, s,
-                               slots, stride, V, in, out, T, aux, ring, ring_cap, vpw);
+                               slots, stride, V, in, out, T, aux, ring, ring_cap);
         return true;
     } else {
         return false;
@@ -180,7 +174,10 @@ void launch_render(float* slots, size_t stride, size_t V, const float* in, float
         const size_t groups = (V + 63) / 64, cus = (size_t)simd_count() / 4;
         if (g_time_split && g_pipe_split == 1 && layout == LAYOUT_VOICE_MINOR && mode == MODE_PROCESS && T % 64 == 0 && T >= 256 &&
             groups <= 2 * cus) {
-            hipLaunchKernelGGL((k_render_ts<G, 2>), dim3((unsigned)groups), dim3(64 * 5), 0, s, slots, stride, V, out, T, aux);
+            if (groups <= cus)  // one workgroup per CU: 2 + 2 + 1 waves
+                hipLaunchKernelGGL((k_render_ts<G, 2, 2>), dim3((unsigned)groups), dim3(64 * 5), 0, s, slots, stride, V, out, T, aux);
+            else                // two workgroups per CU: 2 + 1 + 1 waves each, roles rotated between neighbours
+                hipLaunchKernelGGL((k_render_ts<G, 2, 1>), dim3((unsigned)groups), dim3(64 * 4), 0, s, slots, stride, V, out, T, aux);
             return;
         }
     }
