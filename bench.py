@@ -185,12 +185,16 @@ def secondary(F, W, torch, sr, mode):
             del g, outs
         del wl
     out.append(c2)
-    for cfg, V, name, unit in ((4, 32768, "config4_saw_moog_adsr_pan_32768", "Msamples/s"), (5, 2048, "config5_reverb_stereo_2048", "M instance-frames/s")):
+    for cfg, V, name, unit, math in ((4, 32768, "config4_saw_moog_adsr_pan_32768", "Msamples/s", "exact"),
+                                     (4, 32768, "config4_math_fast", "Msamples/s", "fast"),
+                                     (5, 2048, "config5_reverb_stereo_2048", "M instance-frames/s", "exact")):
         T = 48000
-        wl = make_workload(F, W, torch, cfg, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, "exact")
+        wl = make_workload(F, W, torch, cfg, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, math)
         ms, kms = quick(F, torch, wl, T, mode, steps=4, warmup=1)
         algo = V * T * wl["bps"] + V * wl["slot_bytes"]
-        out.append({"name": name, "what": f"BASELINE config {cfg} per-GPU shard ({V} {'voices' if cfg == 4 else 'instances'} x {T} frames), exact arithmetic",
+        arith = "exact arithmetic" if math == "exact" else ("tolerance mode (FDSP_MATH_FAST: the ladder's tanh on the hardware exp2 / reciprocal, "
+                                                            "recurrence exact; within 1e-4 of the exact mode: tests/test_gpu_math_fast.py)")
+        out.append({"name": name, "what": f"BASELINE config {cfg} per-GPU shard ({V} {'voices' if cfg == 4 else 'instances'} x {T} frames), {arith}",
                     "ms_per_step": round(ms, 4), "kernel_ms_avg": round(kms, 4), "value": round(V * T / ms / 1e3, 1), "unit": unit,
                     "algorithmic_bytes_per_unit": wl["bps"], "roofline_frac": round(algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "kernel": wl["kernel"]})

@@ -626,6 +626,7 @@ template <> struct Cost<FixedSvfLp> { static constexpr int v = 11; };
 template <> struct Cost<Noise> { static constexpr int v = 10; };
 template <> struct Cost<FixedSvf> { static constexpr int v = 16; };
 template <int N> struct Cost<Moog<N>> { static constexpr int v = 130; };
+template <int N> struct Cost<MoogFast<N>> { static constexpr int v = 130; };  // = Moog: FastOf keeps the stage plan (fd_jit.hip relies on it)
 template <int S, int N> struct Cost<WaveSynth<S, N>> { static constexpr int v = 100; };
 template <int S> struct Cost<PhaseSynth<S>> { static constexpr int v = 100; };
 template <> struct Cost<PulseWave> { static constexpr int v = 210; };
@@ -663,6 +664,15 @@ struct VGate {  // forwards to a slot visitor only while enabled; always advance
     };
 };
 
+// Weight<T>: the same estimate where a tolerance-mode twin is much cheaper than its exact type.  Cost places the cuts
+// and must agree between G and FastOf<G> (one stage plan for both); Weight only decides which ROLES share a SIMD.
+template <class T> struct Weight { static constexpr int v = Cost<T>::v; };
+template <int N> struct Weight<MoogFast<N>> { static constexpr int v = 30; };
+template <class X, class Y> struct Weight<Pipe<X, Y>> { static constexpr int v = Weight<X>::v + Weight<Y>::v; };
+template <class X, class Y> struct Weight<Stack<X, Y>> { static constexpr int v = Weight<X>::v + Weight<Y>::v; };
+template <class O, class X, class Y> struct Weight<Binop<O, X, Y>> { static constexpr int v = Weight<X>::v + Weight<Y>::v + 1; };
+template <class X, class U> struct Weight<Unop<X, U>> { static constexpr int v = Weight<X>::v + 1; };
+
 // Seg<G, A, B, HEAD>: the chain stages [A, B) of G, run on G's own state object.
 //   in  = what the segment's first stage consumes: the node's own inputs when A == 0, else the hand-over channels;
 //   gin = the node's own inputs (the graph's inputs for head-position nodes), valid in EVERY stage: a Binop tail reads
@@ -671,7 +681,7 @@ struct VGate {  // forwards to a slot visitor only while enabled; always advance
 template <class G, int A, int B, bool HEAD = true>
 struct Seg {
     static_assert(A == 0 && B == 1, "a node that is not a chain is one stage");
-    static constexpr int IN = G::IN, OUT = G::OUT, cost = Cost<G>::v;
+    static constexpr int IN = G::IN, OUT = G::OUT, cost = Cost<G>::v, weight = Weight<G>::v;
     static constexpr bool USES_GIN = false;
     template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f*, v2f* out) { g.template step2<PH>(in, out); }
     template <int PH> static FD_D void step(G& g, const float* in, const float*, float* out) { g.template step<PH>(in, out); }
@@ -693,6 +703,7 @@ struct Seg<Pipe<X, Y>, A, B, HEAD> {
     using SY = Seg<Y, HY ? (A > NX ? A - NX : 0) : 0, HY ? B - NX : NY, false>;
     static constexpr int IN = HX ? SX::IN : SY::IN, OUT = HY ? SY::OUT : SX::OUT;
     static constexpr int cost = (HX ? SX::cost : 0) + (HY ? SY::cost : 0);
+    static constexpr int weight = (HX ? SX::weight : 0) + (HY ? SY::weight : 0);
     static constexpr bool USES_GIN = HX && SX::USES_GIN;
     template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f* gin, v2f* out) {
         if constexpr (HX && HY) { v2f t[SX::OUT > 0 ? SX::OUT : 1]; SX::template step2<PH>(g.x, in, gin, t); SY::template step2<PH>(g.y, t, nullptr, out); }
@@ -745,6 +756,7 @@ struct Seg<Binop<O, X, Y>, A, B, true> {
     static constexpr int IN = SPLIT ? (A == 0 ? G::IN : Seg<X, 0, (A > 0 ? A : 1), true>::OUT) : G::IN;
     static constexpr int OUT = TAIL ? G::OUT : SX::OUT;
     static constexpr int cost = (HX ? SX::cost : 0) + (TAIL ? Cost<Y>::v + 1 : 0);
+    static constexpr int weight = (HX ? SX::weight : 0) + (TAIL ? Weight<Y>::v + 1 : 0);
     static constexpr bool USES_GIN = SPLIT && TAIL && Y::IN > 0;
     template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f* gin, v2f* out) {
         if constexpr (!SPLIT) {
@@ -985,6 +997,35 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
     }
 }
 
+struct RoleOrder { int role[4]; };
+template <bool FEED, int S, int W0, int W1, int W2, int GPW>
+constexpr RoleOrder role_order() {
+    RoleOrder o{{0, 1, 2, 3}};
+    constexpr int NW = S + (FEED ? 1 : 0);
+    if (GPW != 2 || NW < 3) return o;
+    int wt[4] = {0, 0, 0, 0};
+    int n = 0;
+    if (FEED) wt[n++] = 4;
+    wt[n++] = W0;
+    if (S >= 2) wt[n++] = W1;
+    if (S >= 3) wt[n++] = W2;
+    if (NW == 3) {  // slots 0 and 2 share a SIMD, slot 1 has one to itself: the heaviest role goes there
+        int h = 0;
+        for (int i = 1; i < 3; i++) if (wt[i] > wt[h]) h = i;
+        if (h != 1) { o.role[1] = h; o.role[h] = 1; }
+        return o;
+    }
+    // four roles: the pairing {a, b | c, d} with the lightest heavier pair; slots (0, 2) take the first pair
+    const int pairs[3][4] = {{0, 2, 1, 3}, {0, 1, 2, 3}, {0, 3, 1, 2}};  // identity first: ties keep the plain order
+    int best = 0, best_w = 1 << 30;
+    for (int p = 0; p < 3; p++) {
+        int a = wt[pairs[p][0]] + wt[pairs[p][1]], b = wt[pairs[p][2]] + wt[pairs[p][3]], m = a > b ? a : b;
+        if (m < best_w) { best_w = m; best = p; }
+    }
+    o.role[0] = pairs[best][0]; o.role[2] = pairs[best][1]; o.role[1] = pairs[best][2]; o.role[3] = pairs[best][3];
+    return o;
+}
+
 // The pipeline kernel.  Waves of one workgroup, 4 voice groups (w & 3) times NW roles (w >> 2):
 //   role 0 (only if the graph has inputs): the LOADER wave.  It does nothing but stream the group's input channels
 //     from HBM into the feed ring, one tile ahead.  gfx9-family waves have ONE counter for loads and
@@ -1008,7 +1049,11 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     __shared__ float feed[FEED ? GPW : 1][D][FEED ? NI : 1][FEED ? SUB : 1][FEED ? 64 : 1];  // [group][ring slot][channel][frame][lane]
     __shared__ v2f hand[S > 1 ? S - 1 : 1][S > 1 ? GPW : 1][2][S > 1 ? W : 1][S > 1 ? SUB / 2 : 1][S > 1 ? 64 : 1];  // [cut][group][buffer][channel][frame pair][lane]
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // w: wave-uniform
-    const int grp = w % GPW, role = w / GPW;
+    // Two voice groups per workgroup: waves w and w + 4 share a SIMD, i.e. role slots (0, 2) and (1, 3) of a group with
+    // four roles, slots 0 and 2 of one with three.  The roles are dealt to the slots so that the heaviest SIMD is as
+    // light as possible (config 4, exact: loader + moog | saw + tail; tolerance mode: loader + saw | moog + tail).
+    constexpr RoleOrder RO = role_order<FEED, S, S0::weight, S1::weight, S2::weight, GPW>();
+    const int grp = w % GPW, role = RO.role[w / GPW];
     // (Half-filled waves -- 32 voices per wave, twice the waves -- were measured for the heavy config-4 voice: 33.7 ms
     // against 31.0 ms.  Its SIMDs are issue-bound on expensive instructions, not latency-bound; profiles/r02_c4_vpw.txt.)
     const size_t v0 = ((size_t)blockIdx.x * GPW + grp) * 64;

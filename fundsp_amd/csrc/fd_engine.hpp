@@ -103,12 +103,26 @@ bool launch_render_pipe(float* slots, size_t stride, size_t V, const float* in, 
         // light graphs keep 4 groups per workgroup; heavy ones (latency-bound waves) are spread so that every CU gets one
         const size_t groups = (V + 63) / 64;
         bool done = false;
+#if defined(FD_PIPE_GPW) || defined(FD_PIPE_GPW_HEAVY)  // A/B switches (tools/build_variants.sh): force the voice groups per
+#ifndef FD_PIPE_GPW                                      // workgroup of the light / the heavy graphs (profiles/r02_ab_gpw_*.txt)
+#define FD_PIPE_GPW 0
+#endif
+#ifndef FD_PIPE_GPW_HEAVY
+#define FD_PIPE_GPW_HEAVY 0
+#endif
+        constexpr int FORCE = Cost<G>::v < 150 ? FD_PIPE_GPW : FD_PIPE_GPW_HEAVY;
+        if constexpr (FORCE > 0) {
+            hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, FORCE>), dim3((unsigned)((groups + FORCE - 1) / FORCE)),
+                               dim3(16 * FORCE * WAVES), 0, s, slots, stride, V, in, out, T, aux, ring, ring_cap);
+            done = true;
+        }
+#endif
         if constexpr (Cost<G>::v >= 150) {
-            if (groups < 2 * cus) {
+            if (!done && groups < 2 * cus) {
                 hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 1>), dim3((unsigned)groups), dim3(16 * WAVES), 0, s, slots,
                                    stride, V, in, out, T, aux, ring, ring_cap);
                 done = true;
-            } else if (groups < 4 * cus) {
+            } else if (!done && groups < 4 * cus) {
                 hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 2>), dim3((unsigned)((groups + 1) / 2)), dim3(16 * 2 * WAVES), 0,
                                    s, slots, stride, V, in, out, T, aux, ring, ring_cap);
                 done = true;

@@ -314,11 +314,18 @@ FD_HD float expm1f_musl(float x0) {
     // argument reduction
     const bool reduce = hx > 0x3eb17218u;             // |x| > 0.5 ln2
     const bool near1 = hx < 0x3F851592u;              // |x| < 1.5 ln2
-    int kg = (int)(invln2 * x0 + (sign ? -0.5f : 0.5f));
+    // (every arm of a case is evaluated into a named value first and then selected: an arithmetic expression inside
+    // `?:` comes out of the compiler as a divergent branch, and the one wave that runs a ladder filter pays for each)
+    const float half = sign ? -0.5f : 0.5f;
+    int kg = (int)(invln2 * x0 + half);
     float tg = (float)kg;
-    int k = reduce ? (near1 ? (sign ? -1 : 1) : kg) : 0;
-    float hi = near1 ? (sign ? x0 + ln2_hi : x0 - ln2_hi) : x0 - tg * ln2_hi;
-    float lo = near1 ? (sign ? -ln2_lo : ln2_lo) : tg * ln2_lo;
+    const int k1 = sign ? -1 : 1;
+    int k = reduce ? (near1 ? k1 : kg) : 0;
+    const float ln2_hi_s = sign ? -ln2_hi : ln2_hi;   // x0 + ln2_hi == x0 - (-ln2_hi): one subtraction either way
+    const float hi_near = x0 - ln2_hi_s, hi_far = x0 - tg * ln2_hi;
+    const float lo_near = sign ? -ln2_lo : ln2_lo, lo_far = tg * ln2_lo;
+    float hi = near1 ? hi_near : hi_far;
+    float lo = near1 ? lo_near : lo_far;
     float xr = hi - lo;
     float cr = (hi - xr) - lo;
     float x = reduce ? xr : x0;
@@ -333,19 +340,21 @@ FD_HD float expm1f_musl(float x0) {
     float e2 = x * (e - c) - c;
     e2 -= hxs;
     float res_km1 = 0.5f * (x - e2) - 0.5f;
-    float res_k1 = x < -0.25f ? -2.0f * (e2 - (x + 0.5f)) : 1.0f + 2.0f * (x - e2);
+    const float res_k1a = -2.0f * (e2 - (x + 0.5f)), res_k1b = 1.0f + 2.0f * (x - e2);
+    float res_k1 = x < -0.25f ? res_k1a : res_k1b;
     float twopk = u2f((uint32_t)(0x7f + k) << 23);
     float y_out = x - e2 + 1.0f;
-    y_out = (k == 128) ? y_out * 2.0f * 0x1p127f : y_out * twopk;
+    const float y_out128 = y_out * 2.0f * 0x1p127f, y_outk = y_out * twopk;
+    y_out = (k == 128) ? y_out128 : y_outk;
     float res_out = y_out - 1.0f;                      // k < 0 || k > 56
     float uf = u2f((uint32_t)(0x7f - k) << 23);
     float res_lt23 = (x - e2 + (1 - uf)) * twopk;
     float res_ge23 = (x - (e2 + uf) + 1) * twopk;
-    float res = (k == 0) ? res_k0
-              : (k == -1) ? res_km1
-              : (k == 1) ? res_k1
-              : (k < 0 || k > 56) ? res_out
-              : (k < 23) ? res_lt23 : res_ge23;
+    float res = (k < 23) ? res_lt23 : res_ge23;
+    res = (k < 0 || k > 56) ? res_out : res;
+    res = (k == 1) ? res_k1 : res;
+    res = (k == -1) ? res_km1 : res;
+    res = (k == 0) ? res_k0 : res;
     res = tiny ? x0 : res;
     res = ovf ? x0 * 0x1p127f : res;
     res = (big && sign) ? -1.0f : res;
@@ -367,9 +376,14 @@ FD_HD float tanhf_musl(float x0) {
     float num = c1 ? 2.0f : (c2 ? t : -t);
     float quo = num / (t + 2);
     float r = c1 ? 1 - quo : quo;          // c1: 1 - 2/(t+2); c2: t/(t+2); c3: -t/(t+2)
-    r = c_big ? 1 + 0 / x : r;
+    // |x| > 10 and NaN: musl's 1 + 0/x, without the division (a division inside `?:` becomes a divergent branch):
+    // 0/x is +0 for every finite or infinite x > 10 and the quieted x for a NaN, so the sum is 1, or x + 1 for a NaN
+    const bool is_nan = w > 0x7f800000u;
+    const float x_plus_1 = x + 1.0f;
+    const float r_big = is_nan ? x_plus_1 : 1.0f;
+    r = c_big ? r_big : r;
     r = c3 ? r : x;                        // subnormal: t = x
-    r = (w > 0x7f800000u) ? (1 + 0 / x) : r;  // NaN follows the |x| > 10 branch in musl
+    r = is_nan ? r_big : r;                // NaN follows the |x| > 10 branch in musl
     return sign ? -r : r;
 }
 
@@ -652,6 +666,29 @@ FD_HD float fast_sin1(float x) {
     q = __builtin_fmaf(q, z, C1);
     q = __builtin_fmaf(q, z, C0);
     return __builtin_fmaf(q, r * z, r);
+}
+
+// Tolerance-mode tanh (FDSP_MATH_FAST, Moog): 1 - 2 / (e^(2x) + 1) on the hardware exp2 / reciprocal (v_exp_f32,
+// v_rcp_f32; 1 ulp each) for |x| >= 0.25, the odd Taylor polynomial to x^9 below (the exponential form cancels there:
+// its ABSOLUTE error of ~1e-7 is a relative 1e-4 at |x| = 1e-3, and a resonating ladder carries a relative error of its
+// quiet start into the phase of its loud steady state).  |error| <= 2e-7 absolute and <= 6e-7 relative over the whole
+// line; +-1 at the infinities, NaN stays NaN.  Both forms are evaluated and one selected: ~8 dependent instructions
+// where musl's tanhf is ~150, which is what the one-sample feedback loop of the ladder waits for.
+FD_HD float fast_tanh1(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float e = __builtin_amdgcn_exp2f(x * 2.88539008177792681f);  // 2 log2(e)
+    float r = __builtin_amdgcn_rcpf(e + 1.0f);
+#else
+    float e = __builtin_exp2f(x * 2.88539008177792681f);
+    float r = 1.0f / (e + 1.0f);
+#endif
+    const float big = __builtin_fmaf(-2.0f, r, 1.0f);
+    const float z = x * x;
+    float q = __builtin_fmaf(0.0218694885361552f, z, -0.053968253968254f);  // 62/2835, -17/315
+    q = __builtin_fmaf(q, z, 0.133333333333333f);                            // 2/15
+    q = __builtin_fmaf(q, z, -0.333333333333333f);                           // -1/3
+    const float small = __builtin_fmaf(x * z, q, x);
+    return __builtin_fabsf(x) < 0.25f ? small : big;
 }
 
 // musl scalbnf / powf as of the 2018 port (FreeBSD e_powf.c; libm 0.2.15 scalbnf.rs, powf.rs), used by Dsf.

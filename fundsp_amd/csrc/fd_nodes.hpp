@@ -788,6 +788,35 @@ struct Moog {
     FD_STEP2_VIA_STEP
 };
 
+// Moog in tolerance mode (FDSP_MATH_FAST): the ladder recurrence is kept operation for operation (unfused), only the
+// saturating tanh of the last stage is fast_tanh1.  The coefficient formulas run when (cutoff, q) change, not per
+// sample, and stay exact.  tick / remainder samples unchanged.
+template <int NIN>
+struct MoogFast : Moog<NIN> {
+    using B = Moog<NIN>;
+    static constexpr int IN = B::IN, OUT = B::OUT;
+    template <int PH> FD_HD void step(const float* in, float* out) {
+        if (PH == PH_SIMD) {
+            if (NIN > 1) {
+                if (in[1] != this->cutoff || in[2] != this->q) this->set_cutoff_q(in[1], in[2]);
+            }
+            float x = -this->rez * this->s3 + in[0];
+            this->s0 = (x + this->px) * this->p - this->k * this->s0;
+            this->s1 = (this->s0 + this->ps0) * this->p - this->k * this->s1;
+            this->s2 = (this->s1 + this->ps1) * this->p - this->k * this->s2;
+            this->s3 = fast_tanh1((this->s2 + this->ps2) * this->p - this->k * this->s3);
+            this->px = x;
+            this->ps0 = this->s0;
+            this->ps1 = this->s1;
+            this->ps2 = this->s2;
+            out[0] = this->s3;
+        } else {
+            B::template step<PH>(in, out);
+        }
+    }
+    FD_STEP2_VIA_STEP
+};
+
 // Fir<N>  fir.rs:14-89 (ID 52)
 template <int N>
 struct Fir {
@@ -1096,6 +1125,11 @@ struct AdsrLive {
     // block-walk transients (process path)
     int blk_i, blk_size, remaining, loop_len;
     bool full_seg;
+    // the next segment, prepared at the head of the block (speculate)
+    bool s_valid, s_full;
+    int s_loop_len;
+    float s_t1, s_v1, s_value, s_value_d;
+    uint64_t s_hash;
     template <class V> FD_HD void visit(V& v) {
         v.f(attack, PARAM, "attack"); v.f(decay, PARAM, "decay"); v.f(sustain, PARAM, "sustain");
         v.f(release, PARAM, "release"); v.f(interval, PARAM, "interval");
@@ -1127,14 +1161,12 @@ struct AdsrLive {
         }
         return atto(h, ID);
     }
-    FD_HD float closure(float time, float control) {  // adsr.rs:36-56
-        if (release_start >= 0.0f && control > 0.0f) {
-            attacked = 1.0f;
-            attack_start = time;
-            release_start = -1.0f;
-        } else if (release_start < 0.0f && control <= 0.0f) {
-            release_start = time;
-        }
+    // the closure, adsr.rs:36-56, in two parts: the trigger logic (the only place its state changes) ...
+    FD_HD bool closure_triggers(float control) const {
+        return (release_start >= 0.0f && control > 0.0f) || (release_start < 0.0f && control <= 0.0f);
+    }
+    // ... and its arithmetic for the CURRENT trigger state
+    FD_HD float closure_value(float time) const {
         if (attacked == 0.0f) return 0.0f;
         float tt = time - attack_start, ads;
         if (tt < attack) {
@@ -1146,6 +1178,16 @@ struct AdsrLive {
         if (release_start < 0.0f) return ads;
         float a = release_start + release, b = release_start;
         return ads * clamp01f((time - a) / (b - a));
+    }
+    FD_HD float closure(float time, float control) {
+        if (release_start >= 0.0f && control > 0.0f) {
+            attacked = 1.0f;
+            attack_start = time;
+            release_start = -1.0f;
+        } else if (release_start < 0.0f && control <= 0.0f) {
+            release_start = time;
+        }
+        return closure_value(time);
     }
     FD_HD void next_segment(float input) {  // envelope.rs:252-278
         if (t0 == 0.0f && t1 == 0.0f) {
@@ -1163,9 +1205,37 @@ struct AdsrLive {
         float samples = next_interval / sd;
         value_d = (v1 - v0) / samples;
     }
-    FD_HD void begin_block(int size) { blk_i = 0; blk_size = size; remaining = 0; full_seg = false; loop_len = 0; }
+    FD_HD void begin_block(int size) { blk_i = 0; blk_size = size; remaining = 0; full_seg = false; loop_len = 0; s_valid = false; }
     FD_HD bool tripped() const { return false; }
     FD_HD void end_simd() {}
+    // Voices reach the ends of their ~2 ms segments at different samples, so in a wave of 64 some lane needs
+    // next_segment -- two closure evaluations, seven divisions, a 64-bit hash -- at almost every sample, and the wave
+    // pays for it every time.  Everything about a voice's next segment except the trigger logic is known at the head
+    // of the block: where the current chunk ends (start_chunk), t there, the jittered interval (t_hash), and the
+    // closure's VALUE at the new t_1 as long as the gate does not trigger at that sample.  So all lanes prepare their
+    // next segment together, once per block, with the very operations next_segment / start_chunk would perform; at the
+    // boundary a lane whose gate sample does not trigger takes the prepared registers, any other lane (gate edge,
+    // first segment, a second boundary in the same block at low sample rates) runs next_segment as before.
+    FD_HD void speculate() {
+        s_valid = false;
+        if (!(full_seg && loop_len < blk_size - blk_i) || (t0 == 0.0f && t1 == 0.0f)) return;
+        const float nt = t + (float)(long long)loop_len * sd;  // t at the boundary (the update at the end of step)
+        const float next_interval = lerpf(0.75f, 1.25f, (float)rnd1(t_hash)) * interval;
+        s_t1 = t1 + next_interval;
+        s_v1 = closure_value(s_t1);
+        s_hash = t_hash * 6364136223846793005ULL + 1ULL;
+        const float u = (nt - t1) / (s_t1 - t1);
+        s_value = lerpf(v1, s_v1, u);
+        const float samples = next_interval / sd;
+        s_value_d = (s_v1 - v1) / samples;
+        const float c = __builtin_ceilf((s_t1 - nt) / sd);  // start_chunk at the boundary sample
+        const long long left = (long long)c;
+        const int room = blk_size - (blk_i + loop_len);
+        const bool huge = left < 0 || left > (long long)room;
+        s_loop_len = huge ? room : (int)left;
+        s_full = !huge && s_loop_len == (int)left;
+        s_valid = true;
+    }
     FD_HD void start_chunk() {  // one iteration head of the `while i < size` loop, envelope.rs:323-326
         float c = __builtin_ceilf((t1 - t) / sd);
         long long left = (long long)c;
@@ -1185,10 +1255,19 @@ struct AdsrLive {
             if (blk_i == 0) {
                 if (t >= t1) next_segment(in[0]);
                 start_chunk();
+                speculate();
             }
             for (int guard = 0; remaining == 0 && guard < 4; guard++) {  // chunk exhausted before this sample
-                if (full_seg) next_segment(in[0]);
-                start_chunk();
+                if (full_seg && s_valid && !closure_triggers(in[0])) {  // the segment prepared at the head of the block
+                    t0 = t1; v0 = v1;
+                    t1 = s_t1; v1 = s_v1; t_hash = s_hash;
+                    value = s_value; value_d = s_value_d;
+                    loop_len = s_loop_len; full_seg = s_full; remaining = loop_len;
+                } else {
+                    if (full_seg) next_segment(in[0]);
+                    start_chunk();
+                }
+                s_valid = false;
             }
             out[0] = value;
             value += value_d;
@@ -3099,11 +3178,12 @@ struct Unop {
 // A variant replaces leaf types by layout-identical derived types (same fields, same visit order, same ID) that differ
 // only in the arithmetic of the packed path; the combinators Pipe / Stack / Binop / Unop carry the replacement through.
 // LpOf<G>:   FixedSvf -> FixedSvfLp.  Chosen per WAVE on the device when lp_ok(g) holds in all lanes; exact.
-// FastOf<G>: Sine -> SineFast.       Chosen per LAUNCH by the host (fdsp_set_option("math", 1)); tolerance mode.
+// FastOf<G>: Sine -> SineFast, Moog<N> -> MoogFast<N>.  Chosen per LAUNCH by the host (fdsp_set_option("math", 1)); tolerance mode.
 template <class G> struct LpOf { using type = G; };
 template <> struct LpOf<FixedSvf> { using type = FixedSvfLp; };
 template <class G> struct FastOf { using type = G; };
 template <> struct FastOf<Sine> { using type = SineFast; };
+template <int N> struct FastOf<Moog<N>> { using type = MoogFast<N>; };
 #define FD_VARIANT_THROUGH(TRAIT)                                                                                       \
     template <class X, class Y> struct TRAIT<Pipe<X, Y>> { using type = Pipe<typename TRAIT<X>::type, typename TRAIT<Y>::type>; };    \
     template <class X, class Y> struct TRAIT<Stack<X, Y>> { using type = Stack<typename TRAIT<X>::type, typename TRAIT<Y>::type>; };  \

@@ -71,3 +71,21 @@ def test_svf_packed_paths_match_the_oracle_on_overflow_bursts(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bad 0" in r.stdout
+
+
+def test_select_form_tanh_expm1_match_the_oracle(tmp_path):
+    """fd_math.hpp's expm1f_musl / tanhf_musl (all cases evaluated, one selected -- the form the one-wave ladder filter
+    needs) vs the oracle's branch-form restatements, bit for bit over 2^23 evenly spaced f32, the case boundaries and
+    40 M random patterns."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = tmp_path / "check_tanh_expm1"
+    odir = os.path.join(ROOT, "oracle")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-std=c++17", "-Wno-unused-result",
+           "-I", os.path.join(ROOT, "fundsp_amd", "csrc"), "-o", str(exe),
+           os.path.join(ROOT, "tests", "host", "check_tanh_expm1.hip"), "-L" + odir, "-lfundsp_oracle", "-Wl,-rpath," + odir]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bad 0" in r.stdout

@@ -7,8 +7,9 @@
   the engine's own FMA sine (within 1.2e-7 of wide's).  Bound against the oracle on the BASELINE config-3 graph: the
   reference's own tick-vs-process tolerance, 1e-4 absolute, over the reference's own window (441 samples,
   tests/test_basic.rs:21-47); 1e-3 max / 5e-5 rms over a full second -- the FM patch integrates last-bit differences of the
-  modulator into the carrier phase, the reference's own two paths drift ~0.2 apart over that second.  Exact mode stays
-  bit-exact next to it."""
+  modulator into the carrier phase, the reference's own two paths drift ~0.2 apart over that second.  `Moog` (config 4)
+  evaluates its saturating tanh on the hardware exp2 / reciprocal; bounded at 1e-4 absolute on the config-4 voice.  Exact
+  mode stays bit-exact next to it."""
 import numpy as np
 import pytest
 
@@ -129,3 +130,82 @@ def test_fast_mode_is_a_noop_for_kinds_without_a_variant(gpu):
     b2.set_option("math", MATH_FAST)
     want, _ = O.bank_render(2, [p["fc"], p["q"]], p["seed"], 300, SR, True, 0)
     assert_bit_equal(run_bank(b2, None, 300, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :], want, "noise_biquad under FAST")
+
+
+def test_moog_fast_mode_within_tolerance(gpu):
+    """Tolerance mode of the ladder: only the saturating tanh changes (hardware exp2 / reciprocal, |error| <= 2.5e-7), the
+    recurrence stays unfused.  Leaf `moog` (audio, cutoff, Q inputs) driven from whisper-quiet to hard saturation; the
+    error of a voice is bounded against ITS OWN peak so that the quiet voices count too.  Exact mode bit-exact next to it."""
+    V, T = 128, 64 * 40 + 9
+    rng = np.random.default_rng(21)
+    amp = (1e-3 * 3e4 ** (np.arange(V) / (V - 1))).astype(np.float32)          # 1e-3 .. 30
+    x = np.zeros((V, 3, T), dtype=np.float32)
+    x[:, 0, :] = (rng.standard_normal((V, T)) * amp[:, None]).astype(np.float32)
+    x[:, 1, :] = (200.0 * 40.0 ** rng.random(V)).astype(np.float32)[:, None]   # cutoff Hz
+    x[:, 2, :] = (0.1 + 0.8 * rng.random(V)).astype(np.float32)[:, None]       # Q
+    x[7, 0, 100] = np.inf                                                      # saturates to 1, recovers
+    want = np.zeros((V, 1, T), dtype=np.float32)
+    for v in range(V):
+        n = O.moog()
+        n.set_sample_rate(SR)
+        want[v] = oracle_render(n, x[v], T, MODE_PROCESS)
+    exact = gpu.Bank("moog", V)
+    exact.set_sample_rate(SR)
+    assert exact.get_option("math_has_fast_variant") == 1
+    with np.errstate(all="ignore"):
+        assert_bit_equal(run_bank(exact, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS), want, "moog exact")
+        fast = gpu.Bank("moog", V)
+        fast.set_sample_rate(SR)
+        fast.set_option("math", MATH_FAST)
+        got = run_bank(fast, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    err = np.abs(np.where(fin, got.astype(np.float64) - want.astype(np.float64), 0.0))
+    peak = np.abs(np.where(fin, want, 0.0)).max(axis=(1, 2))
+    rel = err.max(axis=(1, 2)) / np.maximum(peak, 1e-30)
+    print(f"\nFDSP_MATH_FAST moog vs oracle: max |diff| {err.max():.3e}; worst voice relative to its own peak {rel.max():.3e} "
+          f"(peaks {peak.min():.2e} .. {peak.max():.2e})")
+    assert err.max() <= 2e-5                 # absolute: 1e-4 is the reference's own bar (tests/test_basic.rs:21-47)
+    assert not np.array_equal(got, want)
+    # tick mode of a FAST bank keeps the exact tanh
+    ft = gpu.Bank("moog", V)
+    ft.set_sample_rate(SR)
+    ft.set_option("math", MATH_FAST)
+    with np.errstate(all="ignore"):
+        wt = np.stack([oracle_render(_moog(), x[v][:, :333], 333, MODE_TICK) for v in range(8)])
+        assert_bit_equal(run_bank(ft, x[:, :, :333].copy(), 333, LAYOUT_PLANAR, MODE_TICK)[:8], wt, "moog tick under FAST")
+
+
+def _moog():
+    n = O.moog()
+    n.set_sample_rate(SR)
+    return n
+
+
+def test_config4_fast_mode_within_tolerance(gpu):
+    """BASELINE config 4 voice in tolerance mode (Moog tanh; the saw, the envelope and the pan stay exact) against the
+    oracle: max |diff| <= 1e-4 (the reference's own tolerance) with a wide margin; prints the measured deviation."""
+    from test_gpu_config4 import config4_oracle_voice
+
+    for kind in ("saw",):
+        gpu.wavetable_build(kind)
+    V, T = 256, 64 * 150 + 5
+    adsr = (0.005, 0.01, 0.6, 0.01)
+    p = W.saw_moog_params(V, SR)
+    gate = np.broadcast_to(W.gate_signal(T, SR, on_frame=1, off_seconds=8000 / SR), (V, 1, T)).copy()
+    fast = W.make_saw_moog_bank(V, SR, params=p, adsr=adsr)
+    assert fast.get_option("math_has_fast_variant") == 1
+    fast.set_option("math", MATH_FAST)
+    got = run_bank(fast, gate, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    exact = W.make_saw_moog_bank(V, SR, params=p, adsr=adsr)
+    ge = run_bank(exact, gate, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    worst = 0.0
+    for v in range(0, V, 5):
+        want = oracle_render(config4_oracle_voice(p, v, adsr), gate[v], T, MODE_PROCESS)
+        assert_bit_equal(ge[v], want, f"config 4 exact voice {v}")
+        worst = max(worst, float(np.abs(got[v].astype(np.float64) - want.astype(np.float64)).max()))
+    d = np.abs(got.astype(np.float64) - ge.astype(np.float64))
+    print(f"\nFDSP_MATH_FAST config 4 vs oracle: max |diff| {worst:.3e} (sampled voices), vs the exact bank over all {V} voices "
+          f"{d.max():.3e}, rms {np.sqrt((d ** 2).mean()):.3e}; output peak {np.abs(ge).max():.3f}")
+    assert d.max() <= 1e-4 and worst <= 1e-4
+    assert not np.array_equal(got, ge)
