@@ -1,17 +1,19 @@
 #!/bin/bash
 # tools/profile_round.sh TAG -- the rocprofv3 passes behind profiles/<TAG>_*: kernel-trace stats of the three bench
 # configs, then separate PMC passes (HBM FETCH/WRITE with calibration kernels, SQ counters).  Run on the GPU box.
+# CFGS="4 4fast" limits the kernel-trace passes, PMC=0 skips the counter passes.
 TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-for cfg in 3 3fast 2 4 5; do
+for cfg in ${CFGS:-3 3fast 2 4 4fast 5}; do
   ARGS="--config ${cfg%fast} --steps 10 --warmup 3 --cpu-seconds 0 --no-secondary"
-  if [ "$cfg" = "3fast" ]; then ARGS="$ARGS --math fast"; fi
+  if [ "$cfg" != "${cfg%fast}" ]; then ARGS="$ARGS --math fast"; fi
   rocprofv3 --kernel-trace --stats -d $OUT/kt$cfg -o kt -- python bench.py $ARGS > $OUT/bench_c$cfg.json 2> $OUT/kt$cfg.log
   DB=$(find $OUT/kt$cfg -name "*.db" | head -1)
   python tools/rocprof_summary.py $DB "$TAG: rocprofv3 --kernel-trace --stats -- python bench.py $ARGS" > $OUT/kernel_stats_c$cfg.txt
 done
+if [ "${PMC:-1}" = "0" ]; then ls $OUT; exit 0; fi
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$ctr -o pmc -- python tools/traffic_workload.py > $OUT/pmc_$ctr.log 2>&1
   CSV=$(find $OUT/pmc_$ctr -name "*counter_collection.csv" | head -1)
