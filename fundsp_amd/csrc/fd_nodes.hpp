@@ -1413,6 +1413,11 @@ struct Envelope {
     uint64_t t_hash, hash;
     int blk_i, blk_size, remaining, loop_len;  // block-walk transients (process path)
     bool full_seg;
+    // the next segment and the chunk after it, prepared at the head of the block (speculate; see AdsrLive)
+    bool s_valid, s_cvalid, s_full;
+    int s_loop_len;
+    float s_t1, s_v1[OUT], s_value[OUT], s_value_d[OUT];
+    uint64_t s_hash;
     template <class V> FD_HD void visit(V& v) {
         v.enter(0); fn.visit(v); v.leave();
         v.f(interval, PARAM, "interval");
@@ -1454,6 +1459,7 @@ struct Envelope {
         return atto(h, ID);
     }
     FD_HD void next_segment() {  // :79-98
+        s_valid = false;  // whatever was prepared refers to the segment that ends here
         t0 = t1;
         for (int i = 0; i < OUT; i++) v0[i] = v1[i];
         const float next_interval = lerpf(0.75f, 1.25f, (float)rnd1(t_hash)) * interval;
@@ -1467,7 +1473,32 @@ struct Envelope {
             value_d[i] = (v1[i] - v0[i]) / samples;
         }
     }
-    FD_HD void begin_block(int size) { blk_i = 0; blk_size = size; remaining = 0; full_seg = false; loop_len = 0; }
+    FD_HD void begin_block(int size) { blk_i = 0; blk_size = size; remaining = 0; full_seg = false; loop_len = 0; s_valid = s_cvalid = false; }
+    // The closure of an Envelope sees nothing but time, so a voice's next segment is fully known at the head of the block:
+    // all lanes evaluate theirs together (one closure call per voice per block instead of one divergent call per lane per
+    // boundary sample), with the operations next_segment / start_chunk perform, and take the registers at the boundary.
+    FD_HD void speculate() {
+        s_valid = s_cvalid = false;
+        if (!full_seg) return;
+        const float nt = t + (float)(long long)loop_len * sd;  // t at the boundary (the update at the end of step)
+        const float next_interval = lerpf(0.75f, 1.25f, (float)rnd1(t_hash)) * interval;
+        s_t1 = t1 + next_interval;
+        fn.eval(s_t1, s_v1);
+        s_hash = t_hash * 6364136223846793005ULL + 1ULL;
+        const float u = (nt - t1) / (s_t1 - t1);
+        const float samples = next_interval / sd;
+        for (int i = 0; i < OUT; i++) {
+            s_value[i] = lerpf(v1[i], s_v1[i], u);
+            s_value_d[i] = (s_v1[i] - v1[i]) / samples;
+        }
+        const float c = __builtin_ceilf((s_t1 - nt) / sd);  // start_chunk at the sample after the boundary
+        const long long left = (long long)c;
+        const int room = blk_size - (blk_i + loop_len);
+        const bool huge = left < 0 || left > (long long)room;
+        s_loop_len = huge ? room : (int)left;
+        s_full = !huge && s_loop_len == (int)left;
+        s_valid = true;
+    }
     FD_HD bool tripped() const { return false; }
     FD_HD void end_simd() {}
     FD_HD void start_chunk() {  // one iteration head of the `while i < size` loop :137-140
@@ -1488,10 +1519,16 @@ struct Envelope {
             if (blk_i == 0) {
                 if (t >= t1) next_segment();
                 start_chunk();
+                speculate();
             }
             for (int guard = 0; remaining == 0 && guard < 4; guard++) {  // chunk exhausted before this sample
                 if (full_seg) next_segment();
-                start_chunk();
+                if (s_cvalid) {  // the chunk prepared with the segment that was just taken
+                    loop_len = s_loop_len; full_seg = s_full; remaining = loop_len;
+                } else {
+                    start_chunk();
+                }
+                s_cvalid = false;
             }
             for (int i = 0; i < OUT; i++) { out[i] = value[i]; value[i] += value_d[i]; }
             remaining--;
@@ -1499,7 +1536,14 @@ struct Envelope {
             if (remaining == 0) {
                 t += (float)(long long)loop_len * sd;
                 if (full_seg) {  // :154-156: unconditional, also when the block ends here (EnvelopeIn differs: `i < size`)
-                    next_segment();
+                    if (s_valid) {  // the segment prepared at the head of the block
+                        t0 = t1; t1 = s_t1; t_hash = s_hash;
+                        for (int i = 0; i < OUT; i++) { v0[i] = v1[i]; v1[i] = s_v1[i]; value[i] = s_value[i]; value_d[i] = s_value_d[i]; }
+                        s_valid = false;
+                        s_cvalid = true;
+                    } else {
+                        next_segment();
+                    }
                     full_seg = false;
                 }
             }

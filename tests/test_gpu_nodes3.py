@@ -203,8 +203,10 @@ def test_pluck(gpu, mode):
 
 
 # ---- Envelope / lfo (envelope.rs:17-179): closures as device functors ---------------------------------------------------
+@pytest.mark.parametrize("sr", [48000.0, 5000.0])  # 5 kHz: several ~2 ms segments end inside one 64-sample block
 @pytest.mark.parametrize("mode", MODES)
-def test_lfo_functors(gpu, mode):
+def test_lfo_functors(gpu, mode, sr):
+    SR = sr
     V, T = 70, 64 * 20 + 9
     rng = np.random.default_rng(85)
     a = (0.2 + rng.random(V)).astype(np.float32)
