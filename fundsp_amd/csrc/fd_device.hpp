@@ -818,7 +818,7 @@ struct PipeGeom {
 // channels x D tiles; D = 2, or S + 1 when a later stage reads the graph's inputs -- a Binop tail -- so that the loader's
 // tile survives until that stage has used it) and the double-buffered hand-over tiles of the S - 1 cuts (W channels each,
 // W = the widest cut).  One channel-tile of the 4 groups is 1 KiB * SUB; the budget is 128 KiB.
-template <class G, int S, int K1, int K2>
+template <class G, int S, int K1, int K2, int GPW = 4>
 struct PipeTiles {
     static constexpr int N = Chain<G>::N, NI = G::IN;
     using S0 = Seg<G, 0, S == 1 ? N : K1>;
@@ -828,7 +828,10 @@ struct PipeTiles {
     static constexpr int W = W1 > W2 ? W1 : W2;                                   // hand-over channels per cut (widest)
     static constexpr bool LATE_GIN = (S >= 2 && S1::USES_GIN) || (S >= 3 && S2::USES_GIN);
     static constexpr int D = NI > 0 ? (LATE_GIN ? S + 1 : 2) : 0;                 // feed ring depth
-    static constexpr int UNITS = NI * D + 2 * W * (S - 1);                        // channel-tiles
+    static constexpr int UNITS4 = NI * D + 2 * W * (S - 1);                       // channel-tiles (of 4 voice groups)
+    // a workgroup of 2 or 1 voice groups (heavy graphs on small banks) spends the same LDS on tiles 2 / 4 times as long:
+    // half / a quarter of the hand-over rounds and barriers
+    static constexpr int UNITS = UNITS4 <= 16 ? (UNITS4 * GPW + 3) / 4 : UNITS4;
     static constexpr int SUB = UNITS <= 2 ? 64 : UNITS <= 4 ? 32 : UNITS <= 8 ? 16 : UNITS <= 16 ? 8 : 0;  // 0 = does not fit
     static constexpr bool ok = SUB >= 8 && PipeGeom<NI, S>::ok;
 };
@@ -1036,7 +1039,7 @@ constexpr RoleOrder role_order() {
 template <class G, int MODE, int S, int K1, int K2, int GPW = 4>
 FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
                            float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap) {
-    using TL = PipeTiles<G, S, K1, K2>;
+    using TL = PipeTiles<G, S, K1, K2, GPW>;
     constexpr int NI = G::IN;
     constexpr bool FEED = NI > 0;
     constexpr int SUB = TL::SUB, SPB = 64 / SUB, W = TL::W, D = FEED ? TL::D : 1;

@@ -117,12 +117,13 @@ bool launch_render_pipe(float* slots, size_t stride, size_t V, const float* in, 
             done = true;
         }
 #endif
+        // (a workgroup of 1 or 2 groups spends the LDS of 4 on longer tiles -- PipeTiles -- so it must be alone on its CU)
         if constexpr (Cost<G>::v >= 150) {
-            if (!done && groups < 2 * cus) {
+            if (!done && groups <= cus) {
                 hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 1>), dim3((unsigned)groups), dim3(16 * WAVES), 0, s, slots,
                                    stride, V, in, out, T, aux, ring, ring_cap);
                 done = true;
-            } else if (!done && groups < 4 * cus) {
+            } else if (!done && groups <= 2 * cus) {
                 hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 2>), dim3((unsigned)((groups + 1) / 2)), dim3(16 * 2 * WAVES), 0,
                                    s, slots, stride, V, in, out, T, aux, ring, ring_cap);
                 done = true;
