@@ -362,8 +362,19 @@ FD_HD float expm1f_musl(float x0) {
     return res;
 }
 
-// musl tanhf.c, one expm1f + one division per call (case selection by selects, see expm1f_musl)
+// musl tanhf.c: t = expm1f(+-2|x|), then one division.  expm1f is restated here for the arguments tanhf can hand it,
+// a = 2|x| for |x| > log(5/3)/2 and a = -2|x| below -- that removes the cases a ladder filter's one wave would otherwise
+// evaluate and discard on every sample:
+//   a < 0:  |a| <= 0.5108 < 1.5 ln2, so k = 0 (|a| <= 0.5 ln2, no reduction) or k = -1;
+//   a > 0:  a > 0.5108 > 0.5 ln2, so k = 1 (a < 1.5 ln2) or k = (int)(invln2 a + 0.5) = 2 .. 29 (a <= 20; beyond that
+//           tanhf's own |x| > 10 case overrides); for k = 1 the reduced argument is > -0.19, never the x < -0.25 form;
+//   never:  k < -1, k > 56, the |a| >= 27 ln2 early-outs (only with |x| > 10 or NaN, both overridden).
+// hi = a - k ln2_hi, lo = k ln2_lo also cover musl's k = +-1 special forms: a product with +-1 is exact.
+// Each lane performs exactly the operations musl performs for its case (tests/host/check_tanh_expm1.hip: bit-identical
+// to the branch-form oracle).
 FD_HD float tanhf_musl(float x0) {
+    constexpr float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, invln2 = 1.4426950216e+00f,
+                    Q1 = -3.3333212137e-2f, Q2 = 1.5807170421e-3f;
     uint32_t w = f2u(x0);
     const bool sign = (w >> 31) != 0;
     w &= 0x7fffffffu;
@@ -372,13 +383,54 @@ FD_HD float tanhf_musl(float x0) {
     const bool c1 = w > 0x3f0c9f54u;       // |x| > log(3)/2
     const bool c2 = w > 0x3e82c578u;       // |x| > log(5/3)/2
     const bool c3 = w >= 0x00800000u;      // normal
-    float t = expm1f_musl(c2 ? 2 * x : -2 * x);
-    float num = c1 ? 2.0f : (c2 ? t : -t);
-    float quo = num / (t + 2);
-    float r = c1 ? 1 - quo : quo;          // c1: 1 - 2/(t+2); c2: t/(t+2); c3: -t/(t+2)
+    const bool is_nan = w > 0x7f800000u;
+    // ---- t = expm1f(a) ----
+    const float two_x = 2 * x;
+    const float a = c2 ? two_x : -two_x;
+    const uint32_t ha = f2u(two_x);               // |a|
+    const bool tiny = ha < 0x33000000u;           // |a| < 2**-25: expm1f returns a
+    const bool reduce = ha > 0x3eb17218u;         // |a| > 0.5 ln2
+    const bool near1 = ha < 0x3F851592u;          // |a| < 1.5 ln2
+    const int kg = (int)(invln2 * a + 0.5f);
+    const float tg = (float)kg;
+    const float tpos = near1 ? 1.0f : tg;
+    const int kpos = near1 ? 1 : kg;
+    const float tk = c2 ? tpos : -1.0f;
+    const int k = c2 ? kpos : -1;                 // (used only where reduce holds)
+    const float hi = a - tk * ln2_hi;
+    const float lo = tk * ln2_lo;
+    const float xr = hi - lo;
+    const float cr = (hi - xr) - lo;
+    const float xx = reduce ? xr : a;
+    const float c = reduce ? cr : 0.0f;
+    const float hfx = 0.5f * xx;
+    const float hxs = xx * hfx;
+    const float r1 = 1.0f + hxs * (Q1 + hxs * Q2);
+    const float tt = 3.0f - r1 * hfx;
+    const float e = hxs * ((r1 - tt) / (6.0f - xx * tt));
+    const float res_k0 = xx - (xx * e - hxs);
+    float e2 = xx * (e - c) - c;
+    e2 -= hxs;
+    const float res_km1 = 0.5f * (xx - e2) - 0.5f;
+    const float res_k1 = 1.0f + 2.0f * (xx - e2);
+    const float twopk = u2f(((uint32_t)0x7f + (uint32_t)k) << 23);
+    const float uf = u2f(((uint32_t)0x7f - (uint32_t)k) << 23);
+    const float res_lt23 = (xx - e2 + (1 - uf)) * twopk;
+    const float res_ge23 = (xx - (e2 + uf) + 1) * twopk;
+    const float res_far = (k < 23) ? res_lt23 : res_ge23;
+    const float res_pos = near1 ? res_k1 : res_far;
+    const float res_neg = reduce ? res_km1 : res_k0;
+    float t = c2 ? res_pos : res_neg;
+    t = tiny ? a : t;
+    // ---- tanhf ----
+    const float mt = -t;
+    const float num_small = c2 ? t : mt;
+    const float num = c1 ? 2.0f : num_small;
+    const float quo = num / (t + 2);
+    const float one_minus = 1 - quo;
+    float r = c1 ? one_minus : quo;        // c1: 1 - 2/(t+2); c2: t/(t+2); c3: -t/(t+2)
     // |x| > 10 and NaN: musl's 1 + 0/x, without the division (a division inside `?:` becomes a divergent branch):
     // 0/x is +0 for every finite or infinite x > 10 and the quieted x for a NaN, so the sum is 1, or x + 1 for a NaN
-    const bool is_nan = w > 0x7f800000u;
     const float x_plus_1 = x + 1.0f;
     const float r_big = is_nan ? x_plus_1 : 1.0f;
     r = c_big ? r_big : r;

@@ -1,16 +1,19 @@
 // tests/host/check_tanh_expm1.hip -- host-side parity (hipcc, host only): the engine's select-form restatements of musl
 // expm1f / tanhf (fd_math.hpp: every case evaluated, one selected) against the oracle's branch-form ones
 // (oracle/o_math.h), bit for bit: every f32 whose low 9 mantissa bits are zero (all exponents, both signs, 2^23
-// values), the neighbourhoods of every case boundary, and 40 M random bit patterns.
+// values), the neighbourhoods of every case boundary, and 40 M random bit patterns.  `--all`: all 2^32 bit patterns.
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <cmath>
+#include <atomic>
+#include <thread>
+#include <vector>
 #define FD_HOST_ONLY 1
 #include "fd_math.hpp"
 extern "C" float o_math_tanhf(float);
 extern "C" float o_math_expm1f(float);
-static unsigned long long bad = 0, seen = 0;
+static std::atomic<unsigned long long> bad{0}, seen{0};
 static void check(uint32_t u) {
     using namespace fd;
     const float x = u2f(u);
@@ -24,7 +27,16 @@ static void check(uint32_t u) {
         bad++;
     }
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "--all")) {  // every one of the 2^32 bit patterns (one-off; ~1 min on 8 threads)
+        const unsigned nt = std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 8;
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < nt; k++)
+            th.emplace_back([k, nt] { for (uint64_t u = k; u < (1ull << 32); u += nt) check((uint32_t)u); });
+        for (auto& t : th) t.join();
+        printf("%llu values (all f32 bit patterns), bad %llu\n", (unsigned long long)seen, (unsigned long long)bad);
+        return bad ? 1 : 0;
+    }
     for (uint64_t u = 0; u < (1ull << 32); u += 512) check((uint32_t)u);
     const uint32_t edges[] = {0x41200000u, 0x3f0c9f54u, 0x3e82c578u, 0x00800000u, 0x4195b844u, 0x33000000u, 0x3eb17218u,
                               0x3F851592u, 0x42b17180u, 0x7f800000u, 0x3e800000u /* 0.25 */, 0x3f800000u, 0x40000000u};
@@ -37,6 +49,6 @@ int main() {
         if (i & 1) u = (u & 0x807fffffu) | ((0x70u + (u >> 28)) << 23);  // half of them with exponents around 1
         check(u);
     }
-    printf("%llu values, bad %llu\n", seen, bad);
+    printf("%llu values, bad %llu\n", (unsigned long long)seen, (unsigned long long)bad);
     return bad ? 1 : 0;
 }
