@@ -1522,6 +1522,13 @@ struct VDescribeDev {
     FD_D void enter(int i) { if (depth < 32) path[depth] = i; depth++; }
     FD_D void leave() { depth--; }
 };
+// heavy run-time compiled graphs also get the pipeline kernel for workgroups of 1 / 2 voice groups (small banks)
+template <class G>
+struct JitPipeSmall {
+    static constexpr PipePlan P = pipe_plan<G>(0);
+    static constexpr bool on = P.S >= 1 && Cost<G>::v >= 150;
+    template <int GPW> static constexpr int threads() { return on ? 16 * GPW * PipeGeom<G::IN, (P.S >= 1 ? P.S : 1)>::WAVES : 64; }
+};
 template <class G>
 FD_D void describe_body(char* out, int cap, int* meta) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1539,6 +1546,7 @@ FD_D void describe_body(char* out, int cap, int* meta) {
     meta[6] = P.S >= 1 ? 64 * PipeGeom<G::IN, (P.S >= 1 ? P.S : 1)>::WAVES : 0;
     meta[7] = PlanarPlan<G>::S >= 1 ? 256 * PlanarPlan<G>::T::WAVES : 0;  // threads of the planar pipeline kernel (0 = none)
     meta[8] = SameType<typename FastOf<G>::type, G>::v ? 0 : 1;            // the graph has a tolerance-mode variant
+    meta[9] = JitPipeSmall<G>::on ? 1 : 0;                                 // heavy: jit_pipe_g1 / _g2 exist for small banks
 }
 
 // pipeline kernel entry for run-time compiled graphs: empty when the graph has no plan
@@ -1547,6 +1555,13 @@ FD_D void jit_pipe_body(float* __restrict__ slots, size_t stride, size_t V, cons
                         float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap) {
     constexpr PipePlan P = pipe_plan<G>(0);
     if constexpr (P.S >= 1) render_pipe_body<G, MODE, P.S, P.K1, P.K2>(slots, stride, V, in, out, T, aux, ring, ring_cap);
+}
+// the same for workgroups of GPW = 1 / 2 voice groups: heavy graphs on small banks (see launch_render_pipe); empty otherwise
+template <class G, int MODE, int GPW>
+FD_D void jit_pipe_small_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
+                              float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap) {
+    constexpr PipePlan P = pipe_plan<G>(0);
+    if constexpr (JitPipeSmall<G>::on) render_pipe_body<G, MODE, P.S, P.K1, P.K2, GPW>(slots, stride, V, in, out, T, aux, ring, ring_cap);
 }
 template <class G, int MODE>
 FD_D void jit_pipe_planar_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,

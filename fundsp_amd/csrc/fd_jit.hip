@@ -49,6 +49,7 @@ struct JitFuncs {
     hipFunction_t render[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [mode][layout]
     hipFunction_t events[2] = {nullptr, nullptr};                            // [mode]
     hipFunction_t pipe[2] = {nullptr, nullptr};                              // [mode], pipeline kernel
+    hipFunction_t pipe_small[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [groups per workgroup - 1][mode], heavy graphs only
     hipFunction_t pipe_planar[2] = {nullptr, nullptr};                       // [mode], planar-layout pipeline kernel
 };
 struct JitModule {
@@ -58,6 +59,7 @@ struct JitModule {
     JitFuncs dev[MAXD];
     bool loaded[MAXD] = {false};
     int pipe_stages = 0, pipe_threads = 0, pipe_planar_threads = 0;
+    bool pipe_small = false;                                                 // heavy graph: workgroups of 1 / 2 voice groups for small banks
     int wpb[2] = {4, 4};                                                     // per layout
     // the tolerance-mode twin of this graph (FastOf<G>), compiled on first use
     std::string type_expr, prelude;
@@ -97,6 +99,10 @@ struct JitModule {
             ok = ok && hipModuleGetFunction(&f.pipe[m], f.mod, fn.c_str()) == hipSuccess;
             fn = "jit_pipe_planar_" + std::to_string(m);
             ok = ok && hipModuleGetFunction(&f.pipe_planar[m], f.mod, fn.c_str()) == hipSuccess;
+            for (int g = 0; g < 2 && ok; g++) {
+                fn = "jit_pipe_g" + std::to_string(g + 1) + "_" + std::to_string(m);
+                ok = hipModuleGetFunction(&f.pipe_small[g][m], f.mod, fn.c_str()) == hipSuccess;
+            }
         }
         if (!ok) {
             hipModuleUnload(f.mod);
@@ -121,7 +127,14 @@ void jit_render(JitModule* jm, float* slots, size_t stride, size_t V, const floa
     // the ahead-of-time kinds (launch_render)
     if (layout == LAYOUT_VOICE_MINOR && g_pipe_split && jm->pipe_stages >= 1 && (T >= 256 || g_pipe_split > 1)) {
         void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &aux, &ring, &ring_cap};
-        hipModuleLaunchKernel(f->pipe[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_threads, 1, 1, 0, s,
+        const size_t groups = (V + 63) / 64, cus = (size_t)simd_count() / 4;
+        if (jm->pipe_small && groups <= 2 * cus) {  // heavy graph, small bank: as launch_render_pipe
+            const unsigned gpw = groups <= cus ? 1 : 2;
+            hipModuleLaunchKernel(f->pipe_small[gpw - 1][mode], (unsigned)((groups + gpw - 1) / gpw), 1, 1,
+                                  (unsigned)jm->pipe_threads / 4 * gpw, 1, 1, 0, s, pargs, nullptr);
+            return;
+        }
+        hipModuleLaunchKernel(f->pipe[mode], (unsigned)((groups + 3) / 4), 1, 1, (unsigned)jm->pipe_threads, 1, 1, 0, s,
                               pargs, nullptr);
         return;
     }
@@ -170,6 +183,14 @@ std::string jit_source(const std::string& type_expr, const std::string& prelude)
              "size_t T, const void* aux, float* ring, uint32_t cap) {\n"
              "  fd::jit_pipe_body<JitG, " + m + ">(slots, stride, V, in, out, T, aux, ring, cap); }\n";
     }
+    for (int g = 1; g <= 2; g++)
+        for (int mode = 0; mode < 2; mode++) {
+            std::string m = std::to_string(mode), gs = std::to_string(g);
+            s += "extern \"C\" __global__ __launch_bounds__(fd::JitPipeSmall<JitG>::threads<" + gs + ">()) void jit_pipe_g" + gs + "_" + m +
+                 "(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ out, "
+                 "size_t T, const void* aux, float* ring, uint32_t cap) {\n"
+                 "  fd::jit_pipe_small_body<JitG, " + m + ", " + gs + ">(slots, stride, V, in, out, T, aux, ring, cap); }\n";
+        }
     s += "constexpr int JIT_PIPE_PLANAR_THREADS = fd::JitPipePlanarThreads<JitG>::v;\n";
     for (int mode = 0; mode < 2; mode++) {
         std::string m = std::to_string(mode);
@@ -274,6 +295,7 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     jm->pipe_threads = meta[6];
     jm->pipe_planar_threads = meta[7];
     jm->has_fast = meta[8] != 0;
+    jm->pipe_small = meta[9] != 0;
     out->slots.clear();
     std::istringstream lines(std::string(txt.data(), (size_t)meta[3]));
     std::string line;
@@ -306,6 +328,7 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
                         fm->pipe_stages = jm->pipe_stages;   // FastOf keeps arities, chain shape and tile plan
                         fm->pipe_threads = jm->pipe_threads;
                         fm->pipe_planar_threads = jm->pipe_planar_threads;
+                        fm->pipe_small = jm->pipe_small;
                         fm->wpb[0] = jm->wpb[0];
                         fm->wpb[1] = jm->wpb[1];
                         jm->fast = fm;
