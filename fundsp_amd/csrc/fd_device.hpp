@@ -606,6 +606,14 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
     render_events_body<G, MODE>(slots, stride, V, in, out, T, ev, fade, time0, sample_rate, aux, ring, ring_cap);
 }
 
+#ifndef FD_PAIR_UNROLL
+#define FD_PAIR_UNROLL 4  // A/B switch: frame pairs per trip of the packed loop of a pipeline stage
+#endif
+#ifdef FD_PIPE_WPE        // A/B switch: tell the compiler how many waves per SIMD the pipeline kernel runs with
+#define FD_PIPE_ATTR __attribute__((amdgpu_waves_per_eu(FD_PIPE_WPE, FD_PIPE_WPE)))
+#else
+#define FD_PIPE_ATTR
+#endif
 #ifndef FD_LP_ENABLE
 #define FD_LP_ENABLE 1  // A/B switch (tools/build_variants.sh): 0 = always the generic SVF arithmetic
 #endif
@@ -922,7 +930,7 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
     if (lo < shi) {
         const G snap = g;  // tile-start registers, for the rollback below
         // (rolling this loop for heavy stages -- 1 pair per trip instead of 4 -- measured no faster on config 4: 52.9 vs 51.5 ms)
-#pragma unroll 4
+#pragma unroll FD_PAIR_UNROLL
         for (int i = lo; i < shi; i += 2) {  // two frames per iteration (lo, shi are multiples of 8)
             v2f pi[NI > 0 ? NI : 1], gi[NG > 0 ? NG : 1], po[NO];
             if constexpr (FIRST) {
@@ -1150,7 +1158,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
 }
 
 template <class G, int MODE, int S, int K1, int K2, int GPW>
-__global__ __launch_bounds__((16 * GPW * PipeGeom<G::IN, S>::WAVES)) void k_render_pipe(float* __restrict__ slots, size_t stride, size_t V,
+__global__ __launch_bounds__((16 * GPW * PipeGeom<G::IN, S>::WAVES)) FD_PIPE_ATTR void k_render_pipe(float* __restrict__ slots, size_t stride, size_t V,
                                                                                       const float* __restrict__ in, float* __restrict__ out,
                                                                                       size_t T, const void* aux, float* ring, uint32_t ring_cap) {
     render_pipe_body<G, MODE, S, K1, K2, GPW>(slots, stride, V, in, out, T, aux, ring, ring_cap);
