@@ -1609,7 +1609,8 @@ using Panner = PannerT<1>;
 // waveshapers (shape.rs:11-201) -- the shape KIND is a per-voice parameter (one kernel for all shapes)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int SH_CLIP = 0, SH_CLIPTO = 1, SH_TANH = 2, SH_ATAN = 3, SH_SOFTSIGN = 4, SH_CRUSH = 5, SH_SOFTCRUSH = 6,
-              SH_ADAPTIVE_TANH = 7;
+              SH_ADAPTIVE_TANH = 7,  // Adaptive<Tanh>, the form the reference's own graphs use
+              SH_ADAPTIVE = 8;       // + inner kind: Adaptive<S> for any of the seven shapes (shape.rs:162-201)
 
 FD_HD float smooth9f(float x) {  // math.rs:431-437
     float x2 = x * x;
@@ -1621,7 +1622,7 @@ FD_HD float rs_clamp(float lo, float hi, float x) {  // math.rs:130-132: x.max(l
 }
 
 struct Shape {
-    float kind, p0, p1;        // params: Clip(p0) ClipTo(p0,p1) Tanh(p0) Atan(p0) Softsign(p0) Crush(p0) SoftCrush(p0) Adaptive(timescale=p1, Tanh(p0))
+    float kind, p0, p1;        // params: Clip(p0) ClipTo(p0,p1) Tanh(p0) Atan(p0) Softsign(p0) Crush(p0) SoftCrush(p0); Adaptive<S>: S's own
     float smoothing, state;    // Adaptive only: smoothing is a host-computed coefficient (f64 pow, shape.rs:197-200)
     template <class V> FD_HD void visit(V& v) {
         v.f(kind, PARAM, "shape"); v.f(p0, PARAM, "shape_p0"); v.f(p1, PARAM, "shape_p1");
@@ -1629,21 +1630,23 @@ struct Shape {
         v.f(state, STATE, "shape_state");
     }
     FD_HD void init() { kind = (float)SH_TANH; p0 = 1.0f; p1 = 0.0f; smoothing = 0.0f; state = 0.0f; }  // Adaptive::new: state 0.0
-    FD_HD void reset() { if ((int)kind == SH_ADAPTIVE_TANH) state = 1.0e-3f; }                            // shape.rs:193-196
+    FD_HD void reset() { if ((int)kind >= SH_ADAPTIVE_TANH) state = 1.0e-3f; }                            // shape.rs:193-196
     // Shape::shape (scalar path)
     FD_HD float shape(float input) {
-        switch ((int)kind) {
+        int k = (int)kind;
+        if (k >= SH_ADAPTIVE_TANH) {  // Adaptive<S> :185-192: level estimate, then the inner shape on input / sqrt(level)
+            state = smoothing * state + (1.0f - smoothing) * (1.0e-6f + input * input);
+            input = input / __builtin_sqrtf(state);
+            k = k == SH_ADAPTIVE_TANH ? SH_TANH : k - SH_ADAPTIVE;
+        }
+        switch (k) {
         case SH_CLIP: return rs_clamp(-1.0f, 1.0f, input * p0);                                  // :48-51
         case SH_CLIPTO: return rs_clamp(p0, p1, input);                                           // :64-67
         case SH_TANH: return tanhf_musl(input * p0);                                              // :82-85
         case SH_ATAN: return atanf_musl(input * (p0 * F32_PI * 0.5f)) * (2.0f / F32_PI);          // :93-96
         case SH_SOFTSIGN: { float x = input * p0; return x / (1.0f + __builtin_fabsf(x)); }      // :109-112, math.rs:386
         case SH_CRUSH: return roundf_musl(input * p0) / p0;                                       // :125-128
-        case SH_SOFTCRUSH: { float x = input * p0; float y = __builtin_floorf(x); return (y + smooth9f(x - y)) / p0; }  // :141-146
-        default: {                                                                                // Adaptive<Tanh> :185-192
-            state = smoothing * state + (1.0f - smoothing) * (1.0e-6f + input * input);
-            return tanhf_musl((input / __builtin_sqrtf(state)) * p0);
-        }
+        default: { float x = input * p0; float y = __builtin_floorf(x); return (y + smooth9f(x - y)) / p0; }  // SoftCrush :141-146
         }
     }
     // Shape::simd, one lane (the f32x8 path of Shaper::process)
@@ -1657,7 +1660,7 @@ struct Shape {
             float y = __builtin_rintf(x - 0.4999999f);
             return (y + smooth9f(x - y)) / p0;
         }
-        default: return shape(input);  // Clip / ClipTo: fast_max/fast_min == clamp for non-NaN; Tanh, Adaptive: per-lane shape()
+        default: return shape(input);  // Clip / ClipTo: fast_max/fast_min == clamp for non-NaN; Tanh, Adaptive<S>: per-lane shape()
         }
     }
 };

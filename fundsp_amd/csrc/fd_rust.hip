@@ -205,7 +205,12 @@ struct Translator {
         static const char* const names[] = {"Clip", "ClipTo", "Tanh", "Atan", "Softsign", "Crush", "SoftCrush", "Adaptive"};
         *kind = index_of(names, 8, n.last);
         if (*kind < 0) return fail("unknown Shape type " + n.full);
-        if (*kind == 7 && !(n.args.size() == 1 && n.args[0].last == "Tanh")) return fail("Adaptive<S> is built for S = Tanh only");
+        if (*kind == 7) {  // Adaptive<S>: 7 for S = Tanh (the reference's own spelling), 8 + S otherwise (fd_nodes.hpp SH_ADAPTIVE)
+            if (n.args.size() != 1) return fail(n.full + ": expected Adaptive<S>");
+            const int inner = index_of(names, 7, n.args[0].last);
+            if (inner < 0) return fail("Adaptive<S>: S must be one of the seven plain shapes, got " + n.args[0].full);
+            if (inner != 2) *kind = 8 + inner;
+        }
         return true;
     }
 

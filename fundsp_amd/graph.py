@@ -20,6 +20,7 @@ import numpy as np
 from .bank import BQ_KINDS, SVF_MODES
 
 SHAPES = dict(clip=0, clip_to=1, tanh=2, atan=3, softsign=4, crush=5, soft_crush=6, adaptive_tanh=7)
+SHAPES.update({f"adaptive_{k}": 8 + v for k, v in list(SHAPES.items())[:7] if k != "tanh"})  # Adaptive<S>, shape.rs:162-201
 
 
 class Graph:

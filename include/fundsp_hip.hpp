@@ -264,7 +264,8 @@ inline An limiter(P attack, P release) { return detail::leaf("Limiter<1>", 1, 1,
 inline An limiter_stereo(P attack, P release) { return detail::leaf("Limiter<2>", 2, 2, 3).with("attack_time", attack).with("release_time", release); }
 inline An var(P value) { return detail::leaf("Var", 0, 1).with("value", value); }
 
-enum Shape { CLIP = 0, CLIP_TO, TANH, ATAN, SOFTSIGN, CRUSH, SOFT_CRUSH, ADAPTIVE_TANH };  // shape.rs:35-201
+enum Shape { CLIP = 0, CLIP_TO, TANH, ATAN, SOFTSIGN, CRUSH, SOFT_CRUSH, ADAPTIVE_TANH,  // shape.rs:35-201
+             ADAPTIVE /* + inner shape: Adaptive<S>, e.g. ADAPTIVE + ATAN */ };
 inline An shape(Shape kind, P p0 = 1.0f, P p1 = 0.0f) {                                     // prelude.rs:1194
     return detail::leaf("Shaper", 1, 1).with("shape", (float)kind).with("shape_p0", p0).with("shape_p1", p1);
 }

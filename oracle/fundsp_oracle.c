@@ -112,7 +112,7 @@ struct onode {
         int op_kind;
         float op_coeff, op_x1, op_y1, pink[7], morph;
         /* Shape x2 (shape.rs), PhaseOsc kind, Chaos, nonlinear biquad (biquad.rs:494-920) */
-        struct { int kind; float p0, p1, smoothing, state; } sh[2];
+        struct { int kind; float p0, p1, smoothing, state, ts; } sh[2];  /* ts: Adaptive's timescale */
         int osc_kind, lorenz, nl_dirty, nl_mode;
         float cx, cy, cz;
         float ns1, ns2;
@@ -405,19 +405,21 @@ static inline float rs_clampf(float lo, float hi, float x) { /* math.rs:130-132 
 }
 static float shape_scalar(onode *n, int which, float input) { /* Shape::shape */
     float p0 = n->s.sh[which].p0, p1 = n->s.sh[which].p1;
-    switch (n->s.sh[which].kind) {
+    int kind = n->s.sh[which].kind;
+    if (kind >= O_SH_ADAPTIVE_TANH) { /* Adaptive<S> shape.rs:185-192: level estimate, then the inner shape on input / sqrt(level) */
+        float sm = n->s.sh[which].smoothing;
+        n->s.sh[which].state = sm * n->s.sh[which].state + (1.0f - sm) * (1.0e-6f + input * input);
+        input = input / sqrtf(n->s.sh[which].state);
+        kind = kind == O_SH_ADAPTIVE_TANH ? O_SH_TANH : kind - O_SH_ADAPTIVE;
+    }
+    switch (kind) {
     case O_SH_CLIP: return rs_clampf(-1.0f, 1.0f, input * p0);
     case O_SH_CLIPTO: return rs_clampf(p0, p1, input);
     case O_SH_TANH: return o_tanhf(input * p0);
     case O_SH_ATAN: return o_atanf(input * (p0 * F32_PI * 0.5f)) * (2.0f / F32_PI);
     case O_SH_SOFTSIGN: { float x = input * p0; return x / (1.0f + fabsf(x)); }
     case O_SH_CRUSH: return roundf(input * p0) / p0;
-    case O_SH_SOFTCRUSH: { float x = input * p0; float y = floorf(x); return (y + smooth9f(x - y)) / p0; }
-    default: { /* Adaptive<Tanh> shape.rs:185-192 */
-        float sm = n->s.sh[which].smoothing;
-        n->s.sh[which].state = sm * n->s.sh[which].state + (1.0f - sm) * (1.0e-6f + input * input);
-        return o_tanhf((input / sqrtf(n->s.sh[which].state)) * p0);
-    }
+    default: { float x = input * p0; float y = floorf(x); return (y + smooth9f(x - y)) / p0; } /* O_SH_SOFTCRUSH */
     }
 }
 static float shape_simd_lane(onode *n, int which, float input) { /* Shape::simd, one lane */
@@ -549,12 +551,12 @@ static void leaf_reset(onode *n) {
         break;
     }
     case O_SHAPER: /* Adaptive::reset shape.rs:193-196 */
-        if (n->s.sh[0].kind == O_SH_ADAPTIVE_TANH) n->s.sh[0].state = 1.0e-3f;
+        if (n->s.sh[0].kind >= O_SH_ADAPTIVE_TANH) n->s.sh[0].state = 1.0e-3f;
         break;
     case O_NLBIQUAD: /* biquad.rs:529-533, 750-755 */
         n->s.ns1 = n->s.ns2 = 0.0f;
         for (int i = 0; i < (n->s.nl_dirty ? 2 : 1); i++)
-            if (n->s.sh[i].kind == O_SH_ADAPTIVE_TANH) n->s.sh[i].state = 1.0e-3f;
+            if (n->s.sh[i].kind >= O_SH_ADAPTIVE_TANH) n->s.sh[i].state = 1.0e-3f;
         break;
     case O_ENVELOPE: { /* envelope.rs:114-122 */
         n->s.et = 0.0f; n->s.et0 = 0.0f; n->s.et1 = 0.0f;
@@ -700,13 +702,13 @@ static void leaf_set_sample_rate(onode *n, double sr) {
         n->s.sr = (float)sr;
         break;
     case O_SHAPER:
-        if (n->s.sh[0].kind == O_SH_ADAPTIVE_TANH) n->s.sh[0].smoothing = (float)o_adaptive_smoothing(n->s.sh[0].p1, sr);
+        if (n->s.sh[0].kind >= O_SH_ADAPTIVE_TANH) n->s.sh[0].smoothing = (float)o_adaptive_smoothing(n->s.sh[0].ts, sr);
         break;
     case O_NLBIQUAD: /* biquad.rs:535-538 */
         n->s.sr = (float)sr;
         n->s.bc = bq_by_mode(n->s.nl_mode, n->s.sr, n->s.center, n->s.q, n->s.gain);
         for (int i = 0; i < 2; i++)
-            if (n->s.sh[i].kind == O_SH_ADAPTIVE_TANH) n->s.sh[i].smoothing = (float)o_adaptive_smoothing(n->s.sh[i].p1, sr);
+            if (n->s.sh[i].kind >= O_SH_ADAPTIVE_TANH) n->s.sh[i].smoothing = (float)o_adaptive_smoothing(n->s.sh[i].ts, sr);
         break;
     case O_DELAY: /* delay.rs:105-113 */
         if (n->s.dsr != sr) {
@@ -1216,6 +1218,14 @@ onode *o_morph(float cutoff, float q, float morph) { /* Morph::new svf.rs:1046-1
 onode *o_shaper(int shape, float p0, float p1) { /* Shaper::new shape.rs:209-215, ID 42 */
     onode *n = o_new(O_SHAPER, 1, 1, 42);
     n->s.sh[0].kind = shape; n->s.sh[0].p0 = p0; n->s.sh[0].p1 = p1; n->s.sh[0].state = 0.0f;
+    n->s.sh[0].ts = p1;  /* O_SH_ADAPTIVE_TANH: p1 = timescale */
+    leaf_set_sample_rate(n, DEFAULT_SR);
+    return n;
+}
+onode *o_shaper_adaptive(int inner, float p0, float p1, float timescale) { /* Shaper::new(Adaptive::new(timescale, S)) shape.rs:173-183 */
+    onode *n = o_new(O_SHAPER, 1, 1, 42);
+    n->s.sh[0].kind = O_SH_ADAPTIVE + inner; n->s.sh[0].p0 = p0; n->s.sh[0].p1 = p1; n->s.sh[0].state = 0.0f;
+    n->s.sh[0].ts = timescale;
     leaf_set_sample_rate(n, DEFAULT_SR);
     return n;
 }
@@ -1300,7 +1310,7 @@ onode *o_nlbiquad(int dirty, int inputs, int mode, int shape, float p0, float p1
     onode *n = o_new(O_NLBIQUAD, inputs, 1, id);
     n->s.nl_dirty = dirty;
     n->s.nl_mode = mode;
-    for (int i = 0; i < 2; i++) { n->s.sh[i].kind = shape; n->s.sh[i].p0 = p0; n->s.sh[i].p1 = p1; n->s.sh[i].state = 0.0f; }
+    for (int i = 0; i < 2; i++) { n->s.sh[i].kind = shape; n->s.sh[i].p0 = p0; n->s.sh[i].p1 = p1; n->s.sh[i].state = 0.0f; n->s.sh[i].ts = p1; }
     n->s.center = center; n->s.q = q; n->s.gain = gain;
     n->s.ns1 = n->s.ns2 = 0.0f;
     leaf_set_sample_rate(n, DEFAULT_SR);

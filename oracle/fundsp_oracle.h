@@ -22,7 +22,8 @@ enum {
     O_MULTIPASS, O_SINK, O_SPLIT, O_JOIN, O_REVERSE, O_IMPULSE, O_MAP, O_BRANCH, O_BUS, O_THRU, O_MULTI, O_DECLICK, O_FEEDBACK, O_PHASESYNTH, O_WRAP, O_METER, O_VAR, O_LIMITER, O_REVERB3, O_MIXER, O_HOLD, O_WAVEPLAYER
 };
 enum { O_OP_LOWPOLE = 0, O_OP_HIGHPOLE, O_OP_DCBLOCK, O_OP_ALLPOLE };
-enum { O_SH_CLIP = 0, O_SH_CLIPTO, O_SH_TANH, O_SH_ATAN, O_SH_SOFTSIGN, O_SH_CRUSH, O_SH_SOFTCRUSH, O_SH_ADAPTIVE_TANH };
+enum { O_SH_CLIP = 0, O_SH_CLIPTO, O_SH_TANH, O_SH_ATAN, O_SH_SOFTSIGN, O_SH_CRUSH, O_SH_SOFTCRUSH, O_SH_ADAPTIVE_TANH,
+       O_SH_ADAPTIVE /* + inner shape: Adaptive<S> for any S (shape.rs:162-201) */ };
 enum { O_OSC_RAMP = 0, O_OSC_POLYSAW, O_OSC_POLYSQUARE, O_OSC_POLYPULSE };
 /* SvfMode order follows src/svf.rs:281-742 */
 enum {
@@ -66,6 +67,7 @@ void o_wavesynth_set_phase(onode *n, float phase);
 onode *o_adsr_live(float attack, float decay, float sustain, float release);
 onode *o_panner(int inputs, float pan);
 /* Shaper<S> (shape.rs:205); for O_SH_ADAPTIVE_TANH p0 = hardness, p1 = timescale */
+onode *o_shaper_adaptive(int inner, float p0, float p1, float timescale);  /* Shaper<Adaptive<S>>, S = O_SH_CLIP .. O_SH_SOFTCRUSH */
 onode *o_tap(int linear, float min_delay, float max_delay);   /* Tap<U1> / TapLinear<U1> (delay.rs:148,386) */
 onode *o_multitap(int linear, int taps, float min_delay, float max_delay); /* Tap<N> / TapLinear<N> */
 onode *o_allnest2(onode *x);                                  /* AllNest<U2, X>: coefficient on input 1 */

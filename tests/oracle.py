@@ -80,7 +80,7 @@ def lib():
         "o_seq_new": (P, [i, i, d]), "o_seq_free": (None, [P]), "o_seq_push": (i, [P, d, d, i, d, d, P]),
         "o_seq_render": (None, [P, C.c_size_t, i, fp, fp, fp]), "o_seq_time": (d, [P]), "o_mls_period": (C.c_uint64, [C.c_uint]),
         "o_tap": (P, [i, f, f]), "o_allnest": (P, [f, P]), "o_multitap": (P, [i, i, f, f]), "o_allnest2": (P, [P]),
-        "o_shaper": (P, [i, f, f]), "o_phase_osc": (P, [i]), "o_osc_set_phase": (None, [P, f]), "o_chaos": (P, [i]),
+        "o_shaper": (P, [i, f, f]), "o_shaper_adaptive": (P, [i, f, f, f]), "o_phase_osc": (P, [i]), "o_osc_set_phase": (None, [P, f]), "o_chaos": (P, [i]),
         "o_nlbiquad": (P, [i, i, i, i, f, f, f, f, f]), "o_math_atanf": (f, [f]), "o_math_wide_atanf": (f, [f]),
         "o_adaptive_smoothing": (d, [f, d]),
         "o_multipass": (P, [i]), "o_sink": (P, [i]), "o_split": (P, [i, i]), "o_join": (P, [i, i]),
@@ -479,6 +479,7 @@ def pan(p): return Node(lib().o_panner(1, p))                         # prelude.
 
 
 SHAPES = dict(clip=0, clip_to=1, tanh=2, atan=3, softsign=4, crush=5, soft_crush=6, adaptive_tanh=7)
+SHAPES.update({f"adaptive_{k}": 8 + v for k, v in list(SHAPES.items())[:7] if k != "tanh"})
 OSCS = dict(ramp=0, poly_saw=1, poly_square=2, poly_pulse=3)
 
 
@@ -562,6 +563,8 @@ def panner(): return Node(lib().o_panner(2, 0.0))                               
 
 
 def shape(kind, p0=1.0, p1=0.0): return Node(lib().o_shaper(SHAPES[kind], p0, p1))          # prelude.rs:1194
+def shape_adaptive(inner, p0, p1, timescale):  # shape(Adaptive::new(timescale, S)) shape.rs:173-183
+    return Node(lib().o_shaper_adaptive(SHAPES[inner], p0, p1, timescale))
 def ramp(): return Node(lib().o_phase_osc(0))
 def poly_saw(): return Node(lib().o_phase_osc(1))
 def poly_square(): return Node(lib().o_phase_osc(2))

@@ -43,6 +43,33 @@ def test_shaper(gpu, case, mode):
         assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"shape {kind} voice {v}")
 
 
+@pytest.mark.parametrize("case", [c for c in SHAPE_CASES if c[0] not in ("tanh", "adaptive_tanh")], ids=lambda c: "adaptive_" + c[0])
+@pytest.mark.parametrize("mode", MODES)
+def test_shaper_adaptive_any_inner(gpu, case, mode):
+    """Shaper<Adaptive<S>> for every plain shape S (shape.rs:162-201): level follower, then S::shape on input / sqrt(level);
+    Adaptive has no simd form of its own, so the process path applies S's SCALAR shape lane by lane (Crush rounds half
+    away from zero there, not half to even as Shaper<Crush>::process does)."""
+    inner, p0, p1 = case
+    timescale = 0.03
+    V, T = 64, 64 * 3 + 5
+    x = noise_input(V, 1, T, seed=32) * 2.0
+    x[2] *= np.float32(1e-3)
+    x[3, 0, 40:] = 0.0                     # level decays towards the 1e-6 floor
+    b = gpu.Bank("shape", V)
+    b.set_param(":shape", float(O.SHAPES["adaptive_" + inner]))
+    b.set_param(":shape_p0", p0)
+    b.set_param(":shape_p1", p1)
+    b.set_param(":shape_smoothing", float(np.float32(O.lib().o_adaptive_smoothing(timescale, SR))))
+    b.set_sample_rate(SR)
+    b.reset()
+    got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, mode)
+    for v in (0, 2, 3, 63):
+        n = O.shape_adaptive(inner, p0, p1, timescale)
+        n.set_sample_rate(SR)
+        n.reset()
+        assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"adaptive<{inner}> voice {v}")
+
+
 @pytest.mark.parametrize("kind", ["ramp", "poly_saw", "poly_square", "poly_pulse"])
 def test_phase_oscillators(gpu, kind):
     V, T = 64, 300

@@ -86,6 +86,12 @@ def test_typenum_closures_and_errors(F):
         translate(F, "fundsp::resynth::Resynth<typenum::U1, typenum::U1, my::{{closure}}>")
     with pytest.raises(ValueError, match="parse|trailing|expected"):
         translate(F, "fundsp::audionode::Pipe<fundsp::audionode::Pass")
+    # Adaptive<S>: 7 for the reference's own Adaptive<Tanh>, 8 + S for any other plain shape (fd_nodes.hpp SH_ADAPTIVE)
+    ad = lambda inner: translate(F, f"fundsp::shape::Shaper<fundsp::shape::Adaptive<fundsp::shape::{inner}>>")
+    assert ad("Tanh") == ("Shaper", {":shape": 7.0}) and ad("Atan") == ("Shaper", {":shape": 11.0})
+    assert ad("Clip")[1] == {":shape": 8.0} and ad("SoftCrush")[1] == {":shape": 14.0}
+    with pytest.raises(ValueError, match="plain shapes"):
+        translate(F, "fundsp::shape::Shaper<fundsp::shape::Adaptive<fundsp::shape::Adaptive<fundsp::shape::Tanh>>>")
     # wavetable hints in node order; default saw
     two = (RT.saw() | RT.square()).type_name()
     assert translate(F, two, "wavesynth=saw,square")[0] == "Stack<WaveSynth<0>,WaveSynth<1>>"
