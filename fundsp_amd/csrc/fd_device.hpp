@@ -606,8 +606,8 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
     render_events_body<G, MODE>(slots, stride, V, in, out, T, ev, fade, time0, sample_rate, aux, ring, ring_cap);
 }
 
-#ifndef FD_PAIR_UNROLL
-#define FD_PAIR_UNROLL 4  // A/B switch: frame pairs per trip of the packed loop of a pipeline stage
+#ifndef FD_ITEM_LOOP
+#define FD_ITEM_LOOP 1    // A/B switch: 0 = the packed loop as one flat loop of frame pairs, without the item_begin hint
 #endif
 #ifdef FD_PIPE_WPE        // A/B switch: tell the compiler how many waves per SIMD the pipeline kernel runs with
 #define FD_PIPE_ATTR __attribute__((amdgpu_waves_per_eu(FD_PIPE_WPE, FD_PIPE_WPE)))
@@ -930,8 +930,16 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
     if (lo < shi) {
         const G snap = g;  // tile-start registers, for the rollback below
         // (rolling this loop for heavy stages -- 1 pair per trip instead of 4 -- measured no faster on config 4: 52.9 vs 51.5 ms)
-#pragma unroll FD_PAIR_UNROLL
-        for (int i = lo; i < shi; i += 2) {  // two frames per iteration (lo, shi are multiples of 8)
+#if FD_ITEM_LOOP
+        for (int i8 = lo; i8 < shi; i8 += 8) {  // one 8-sample SIMD item per trip (lo, shi are multiples of 8) ...
+        item_begin(g);
+#pragma unroll
+        for (int i = i8; i < i8 + 8; i += 2) {  // ... two frames per inner iteration
+#else
+        {
+#pragma unroll 4
+        for (int i = lo; i < shi; i += 2) {
+#endif
             v2f pi[NI > 0 ? NI : 1], gi[NG > 0 ? NG : 1], po[NO];
             if constexpr (FIRST) {
 #pragma unroll
@@ -955,6 +963,7 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
 #pragma unroll
                 for (int c = 0; c < NO; c++) hout[c][(i - lo) >> 1][lane] = po[c];
             }
+        }
         }
         if (__builtin_expect(SG::tripped(g), 0)) {  // a packed-path shortcut left its exact domain: redo the tile
             g = snap;

@@ -952,9 +952,18 @@ FD_HD Tap4 wt_tap(const float* __restrict__ tab, uint32_t mask, float phase) {  
     Tap4 t;
     t.w = p - (float)i1;
     i1 = i1 & mask;
+    // padded layout: tab[i1 + 0..3] = t[i1-1], t[i1], t[i1+1], t[i1+2]
+#if defined(__HIP_DEVICE_COMPILE__)
+    // through an explicit global-address-space pointer: on a generic pointer (the table address comes out of a struct
+    // in memory) the 4-byte-aligned 16-byte load is split into four dword gathers before the address space is inferred
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const f4u q = *(const __attribute__((address_space(1))) f4u*)(tab + i1);
+    t.a0 = q.x; t.a1 = q.y; t.a2 = q.z; t.a3 = q.w;
+#else
     float q[4];
-    __builtin_memcpy(q, tab + i1, 16);  // padded layout: tab[i1 + 0..3] = t[i1-1], t[i1], t[i1+1], t[i1+2]
+    __builtin_memcpy(q, tab + i1, 16);
     t.a0 = q[0]; t.a1 = q[1]; t.a2 = q[2]; t.a3 = q[3];
+#endif
     return t;
 }
 FD_HD float tap_eval(const Tap4& t) { return optimal4x44(t.a0, t.a1, t.a2, t.a3, t.w); }
@@ -3254,6 +3263,22 @@ template <class X, class Y> FD_HD bool lp_ok(const Pipe<X, Y>& g) { return lp_ok
 template <class X, class Y> FD_HD bool lp_ok(const Stack<X, Y>& g) { return lp_ok(g.x) && lp_ok(g.y); }
 template <class O, class X, class Y> FD_HD bool lp_ok(const Binop<O, X, Y>& g) { return lp_ok(g.x) && lp_ok(g.y); }
 template <class X, class U> FD_HD bool lp_ok(const Unop<X, U>& g) { return lp_ok(g.x); }
+
+// item_begin(g): told by the packed loops that an 8-sample SIMD item starts with the next frame.  Nodes that do something
+// once per item (WaveSynth picks its table pair from the item's first frequency) keep a counter for that; at an item
+// start the counter is 0 mod 8 anyway, so writing the constant is no change of state -- but it lets the compiler fold
+// the `counter & 7` tests of the item's four frame pairs, and with the branches gone the table gathers of all four
+// pairs are issued back to back instead of one L2 round trip per pair.  Reaches through the plain combinators only.
+template <class G> FD_HD void item_begin(G&) {}
+template <int SET, int NOUT> FD_HD void item_begin(WaveSynth<SET, NOUT>& w) { w.item_pos = 0; }
+template <class X, class Y> FD_HD void item_begin(Pipe<X, Y>& g);
+template <class X, class Y> FD_HD void item_begin(Stack<X, Y>& g);
+template <class O, class X, class Y> FD_HD void item_begin(Binop<O, X, Y>& g);
+template <class X, class U> FD_HD void item_begin(Unop<X, U>& g);
+template <class X, class Y> FD_HD void item_begin(Pipe<X, Y>& g) { item_begin(g.x); item_begin(g.y); }
+template <class X, class Y> FD_HD void item_begin(Stack<X, Y>& g) { item_begin(g.x); item_begin(g.y); }
+template <class O, class X, class Y> FD_HD void item_begin(Binop<O, X, Y>& g) { item_begin(g.x); item_begin(g.y); }
+template <class X, class U> FD_HD void item_begin(Unop<X, U>& g) { item_begin(g.x); }
 
 // ---------------------------------------------------------------------------------------------------------
 // routing leaves and the remaining combinators (audionode.rs).  All of them are arithmetic-free or a handful of
