@@ -905,6 +905,15 @@ struct Aux {
     WaveBuf wave[WAVE_SLOTS];
 };
 
+// A load through a pointer that itself came out of a struct in memory (table / sample-buffer descriptors): say that it
+// points to HBM, or the compiler emits flat loads, which count on the LDS counter too and fence the hand-over stores.
+FD_HD float gload(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(1))) float*)p;
+#else
+    return *p;
+#endif
+}
 FD_HD float optimal4x44(float a0, float a1, float a2, float a3, float x) {  // wavetable.rs:24-38
     float z = x - (float)0.5;
     float even1 = a2 + a1, odd1 = a2 - a1, even2 = a3 + a0, odd2 = a3 - a0;
@@ -3438,7 +3447,7 @@ struct WavePlayer {
         float value = 0.0f;
         const uint32_t end = end_point < wb->length ? end_point : wb->length;  // new() asserts end_point <= length
         if (index < end && channel < wb->channels) {
-            value = wb->data[(size_t)channel * wb->length + index];
+            value = gload(wb->data + ((size_t)channel * wb->length + index));
             index += 1;
             if (index == end_point && loop_point != 0xFFFFFFFFu) index = loop_point;
         }
