@@ -606,6 +606,9 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
     render_events_body<G, MODE>(slots, stride, V, in, out, T, ev, fade, time0, sample_rate, aux, ring, ring_cap);
 }
 
+#ifndef FD_PIPE_FLAGSYNC
+#define FD_PIPE_FLAGSYNC 0
+#endif
 #ifndef FD_ITEM_LOOP
 #define FD_ITEM_LOOP 1    // A/B switch: 0 = the packed loop as one flat loop of frame pairs, without the item_begin hint
 #endif
@@ -1154,6 +1157,50 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
             __syncthreads();  // hand-over point: every role has finished its tile of this round
         }
     };
+#if FD_PIPE_FLAGSYNC
+    // A/B (tools/build_variants.sh -DFD_PIPE_FLAGSYNC=1): two-stage chains without inputs hand tiles over through per-group
+    // LDS counters instead of a workgroup barrier per round, so that the four voice groups of a workgroup do not wait for
+    // each other and a stage may run up to one tile ahead of its partner.
+    if constexpr (S == 2 && !FEED) {
+        __shared__ int flag_prod[GPW], flag_cons[GPW];
+        if (threadIdx.x < GPW) { flag_prod[threadIdx.x] = 0; flag_cons[threadIdx.x] = 0; }
+        __syncthreads();
+        auto rounds_flags = [&](auto* tag) {
+            using GG = typename Pointee<decltype(tag)>::type;
+            using TG = PipeTiles<GG, S, K1, K2>;
+            using T0 = typename TG::S0;
+            using T1 = typename TG::S1;
+            GG& gg = reinterpret_cast<GG&>(g);
+            for (size_t j = 0; j < ntiles; j++) {
+                const size_t t0 = (j / SPB) * 64;
+                const int h = (int)(j % SPB);
+                const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+                const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
+                if (stage == 0) {
+                    if (j >= 2)
+                        while (__hip_atomic_load(&flag_cons[grp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(j - 1)) __builtin_amdgcn_s_sleep(1);
+                    if (live && active) pipe_stage<T0, GG, MODE, SUB, W, true, false>(gg, h, t0, size, full, T, V, lane, outw, nullptr, nullptr, hand[0][grp][j & 1]);
+                    __hip_atomic_store(&flag_prod[grp], (int)(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    while (__hip_atomic_load(&flag_prod[grp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(j + 1)) __builtin_amdgcn_s_sleep(1);
+                    if (live && active) pipe_stage<T1, GG, MODE, SUB, W, false, true>(gg, h, t0, size, full, T, V, lane, outw, nullptr, hand[0][grp][j & 1], nullptr);
+                    __hip_atomic_store(&flag_cons[grp], (int)(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        };
+        using GLf = typename LpOf<G>::type;
+        bool lpf = false;
+        if constexpr (!SameType<GLf, G>::v && MODE == MODE_PROCESS && FD_LP_ENABLE)
+            lpf = __builtin_amdgcn_ballot_w64((live && active) && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(live && active) != 0ull;
+        if (lpf) rounds_flags((GLf*)nullptr); else rounds_flags((G*)nullptr);
+        if (live && active) {
+            VStore<false> st{slots + v, stride, 0};
+            VGate::W<VStore<false>> gate{&st, true};
+            if (stage == 0) S0::visit(g, gate); else S1::visit(g, gate);
+        }
+        return;
+    }
+#endif
     using GL = typename LpOf<G>::type;
     bool lp = false;
     if constexpr (!SameType<GL, G>::v && MODE == MODE_PROCESS && FD_LP_ENABLE)
