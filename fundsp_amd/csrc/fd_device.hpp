@@ -1049,6 +1049,12 @@ constexpr RoleOrder role_order() {
     return o;
 }
 
+constexpr bool role_order_is(RoleOrder o, int a, int b, int c, int d) { return o.role[0] == a && o.role[1] == b && o.role[2] == c && o.role[3] == d; }
+static_assert(role_order_is(role_order<true, 3, 100, 130, 83, 2>(), 0, 1, 2, 3), "config 4, exact: loader + moog | saw + tail");
+static_assert(role_order_is(role_order<true, 3, 100, 30, 83, 2>(), 0, 2, 1, 3), "config 4, tolerance mode: loader + saw | moog + tail");
+static_assert(role_order_is(role_order<false, 3, 30, 10, 20, 2>(), 1, 0, 2, 3), "three roles: the heaviest gets the SIMD of its own");
+static_assert(role_order_is(role_order<true, 3, 100, 30, 83, 4>(), 0, 1, 2, 3), "four groups per workgroup: every SIMD holds one group's roles");
+
 // The pipeline kernel.  Waves of one workgroup, 4 voice groups (w & 3) times NW roles (w >> 2):
 //   role 0 (only if the graph has inputs): the LOADER wave.  It does nothing but stream the group's input channels
 //     from HBM into the feed ring, one tile ahead.  gfx9-family waves have ONE counter for loads and
