@@ -1295,6 +1295,8 @@ template <class G> struct TsPlan {  // which graphs the time-split kernel takes
     static constexpr bool ok = Chain<G>::N == 3 && G::IN == 0 && G::RINGS == 0;
 };
 
+static __device__ unsigned int g_ts_arrivals[4096];  // workgroups of k_render_ts<.., 2, 1> seen per CU (role draw; never reset)
+
 template <class G, int NA, int NB>
 FD_D void render_ts_body(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T,
                          const void* aux) {
@@ -1306,17 +1308,33 @@ FD_D void render_ts_body(float* __restrict__ slots, size_t stride, size_t V, flo
     __shared__ v2f hand[2][2][W][32][64];  // [cut][buffer][channel][frame pair][lane]
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Role of wave w: NA waves of stage 0, NB of stage 1, one filter wave; rank r in [A0 .. A(NA-1), B0 .. B(NB-1), C].
-    // The hardware places wave w of a workgroup on SIMD w % 4, and two workgroups share a CU when the bank has more than
-    // one voice group per CU, so the order of the roles decides how evenly the four SIMDs are loaded:
-    //   <2, 2> (one group per CU, 5 waves; SIMD 0 carries two): the filter -- the heavy wave, ~18 instructions per frame
-    //           against ~11 of an oscillator half -- stays off SIMD 0:                 [A0, C, A1, B0, B1]
-    //   <2, 1> (two groups per CU, 4 waves each): neighbouring workgroups are rotated by two, so every SIMD gets one
-    //           oscillator half and one whole-block wave:       even [A0, A1, B, C]     odd [B, C, A0, A1]
-    constexpr int NW = NA + NB + 1;
+    // Waves w and w + 4 of a workgroup share a SIMD, and two workgroups share a CU when the bank has more than one voice
+    // group per CU, so the order of the roles decides how evenly the four SIMDs are loaded:
+    //   <2, 2> (one group per CU, 5 waves; waves 0 and 4 share a SIMD): the filter -- the heavy wave, ~18 instructions
+    //           per frame against ~11 of an oscillator half -- is not one of the two:       [A0, C, A1, B0, B1]
+    //   <2, 1> (two groups per CU, 4 waves each): roles by SIMD id, see below.
     int r;
     if (NA == 2 && NB == 2) r = w == 1 ? 4 : (w > 1 ? w - 1 : w);
-    else if (NA == 2 && NB == 1) r = (blockIdx.x & 1) ? (w + 2) % NW : w;
-    else r = w;
+    else if (NA == 2 && NB == 1) {
+        // Which SIMD wave w of a workgroup gets differs from workgroup to workgroup (the placement walks 0,2,1,3 from
+        // wherever the CU's pointer stands), and the two workgroups of a CU are not neighbours in the grid
+        // (profiles/r02_census_wave_placement.txt).  So the roles go by what the waves find: every wave reads its SIMD
+        // id, the workgroup draws 0 or 1 from a per-CU arrival counter, and SIMD s takes role ts_role[draw][s] -- two
+        // workgroups with different draws put an oscillator half next to a whole-block wave on every SIMD.  Any
+        // permutation is CORRECT; if the four waves do not sit on four SIMDs the plain order is used.
+        __shared__ int s_simd[4], s_draw;
+        const uint32_t hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+        if (lane == 0) s_simd[w] = (int)((hw >> 4) & 3);
+        if (threadIdx.x == 0) {
+            const uint32_t xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0xf;  // HW_REG_XCC_ID
+            const uint32_t key = (xcc << 8) | ((hw >> 8) & 0xff);                               // XCC, SE, SH, CU
+            s_draw = (int)(atomicAdd(&g_ts_arrivals[key & 4095], 1u) & 1u);
+        }
+        __syncthreads();
+        const int mask = (1 << s_simd[0]) | (1 << s_simd[1]) | (1 << s_simd[2]) | (1 << s_simd[3]);
+        constexpr int ts_role[2][4] = {{0, 1, 2, 3}, {2, 3, 0, 1}};  // draw 0: A0 A1 B C on SIMD 0..3; draw 1: B C A0 A1
+        r = mask == 15 ? ts_role[s_draw][(hw >> 4) & 3] : w;
+    } else r = w;
     const int stage = r < NA ? 0 : (r < NA + NB ? 1 : 2);
     const int part = r < NA ? r : (r < NA + NB ? r - NA : 0);
     const int nparts = stage == 0 ? NA : NB;
