@@ -102,7 +102,7 @@ int fdsp_set_option(const char* name, int value);
  *                    but feed-forward transcendental evaluations may use the engine's own forms -- today the f32x8
  *                    sine of Sine::process (FMA polynomial, 13 instead of 28 operations, within 1.2e-7 of it) and the
  *                    saturating tanh of Moog::process (hardware exp2 / reciprocal, odd polynomial below |x| = 0.25;
- *                    within 2e-7 absolute / 6e-7 relative; the BASELINE config-4 voice within 1e-4 of the exact mode,
+ *                    within 2.3e-7 absolute / 6.3e-7 relative over all f32; the BASELINE config-4 voice within 1e-4 of the exact mode,
  *                    measured 4e-7).  Stated tolerance of the sine,
  *                    measured in tests/test_gpu_math_fast.py on the BASELINE config-3 FM voices against the exact mode:
  *                    <= 1e-4 absolute over the reference's own check window (441 samples, tests/test_basic.rs:21-47);
