@@ -362,6 +362,26 @@ FD_HD float expm1f_musl(float x0) {
     return res;
 }
 
+// n / d for operands that need none of the IEEE division's range handling (no denormal, no overflow, quotient far from
+// both): the device's f32 division is v_div_scale x2, v_rcp, four fma / one mul of Newton-Raphson and residual
+// correction, v_div_fmas, v_div_fixup; with nothing to scale, v_div_scale passes its operand through, v_div_fmas is an
+// fma and v_div_fixup returns the quotient -- the same eight arithmetic instructions remain, three fewer in all.
+// (tanhf_musl with it is bit-identical to the oracle on all 2^32 inputs: tests/host/check_math_device.hip.)
+FD_HD float div_inrange(float n, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e0, r, r);
+    float q = n * r;
+    const float e1 = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e1, r, q);
+    const float e2 = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e2, r, q);
+#else
+    return n / d;
+#endif
+}
+
 // musl tanhf.c: t = expm1f(+-2|x|), then one division.  expm1f is restated here for the arguments tanhf can hand it,
 // a = 2|x| for |x| > log(5/3)/2 and a = -2|x| below -- that removes the cases a ladder filter's one wave would otherwise
 // evaluate and discard on every sample:
@@ -407,7 +427,7 @@ FD_HD float tanhf_musl(float x0) {
     const float hxs = xx * hfx;
     const float r1 = 1.0f + hxs * (Q1 + hxs * Q2);
     const float tt = 3.0f - r1 * hfx;
-    const float e = hxs * ((r1 - tt) / (6.0f - xx * tt));
+    const float e = hxs * div_inrange(r1 - tt, 6.0f - xx * tt);  // numerator ~ -2, denominator in [4.9, 7.1]
     const float res_k0 = xx - (xx * e - hxs);
     float e2 = xx * (e - c) - c;
     e2 -= hxs;
