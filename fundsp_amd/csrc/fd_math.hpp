@@ -409,7 +409,6 @@ FD_HD float tanhf_musl(float x0) {
     const float two_x = 2 * x;
     const float a = c2 ? two_x : -two_x;
     const uint32_t ha = f2u(two_x);               // |a|
-    const bool tiny = ha < 0x33000000u;           // |a| < 2**-25: expm1f returns a
     const bool reduce = ha > 0x3eb17218u;         // |a| > 0.5 ln2
     const bool near1 = ha < 0x3F851592u;          // |a| < 1.5 ln2
     const int kg = (int)(invln2 * a + 0.5f);
@@ -441,8 +440,9 @@ FD_HD float tanhf_musl(float x0) {
     const float res_far = (k < 23) ? res_lt23 : res_ge23;
     const float res_pos = near1 ? res_k1 : res_far;
     const float res_neg = reduce ? res_km1 : res_k0;
-    float t = c2 ? res_pos : res_neg;
-    t = tiny ? a : t;
+    const float t = c2 ? res_pos : res_neg;
+    // (musl returns a itself for |a| < 2**-25; the k = 0 form gives the same bits there -- a + a*a/2 rounds to a --,
+    // which the exhaustive device check confirms, so the case needs no select)
     // ---- tanhf ----
     const float mt = -t;
     const float num_small = c2 ? t : mt;
@@ -454,9 +454,8 @@ FD_HD float tanhf_musl(float x0) {
     // 0/x is +0 for every finite or infinite x > 10 and the quieted x for a NaN, so the sum is 1, or x + 1 for a NaN
     const float x_plus_1 = x + 1.0f;
     const float r_big = is_nan ? x_plus_1 : 1.0f;
-    r = c_big ? r_big : r;
+    r = c_big ? r_big : r;                 // (a NaN is > 10 as a bit pattern: it takes this arm, as in musl)
     r = c3 ? r : x;                        // subnormal: t = x
-    r = is_nan ? r_big : r;                // NaN follows the |x| > 10 branch in musl
     return sign ? -r : r;
 }
 
