@@ -89,3 +89,21 @@ def test_select_form_tanh_expm1_match_the_oracle(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bad 0" in r.stdout
+
+
+def test_envelope_block_preparation_matches_the_oracle(tmp_path):
+    """AdsrLive / Envelope process paths with the once-per-block preparation of the next segment (host build of
+    fd_nodes.hpp) vs the oracle's envelope.rs restatement: 6000 random ADSR settings, sample rates 2 .. 192 kHz, seeds,
+    block partitions with remainders, gate edges anywhere (incl. NaN / negative levels), two calls in a row."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    exe = tmp_path / "check_envelope_spec"
+    odir = os.path.join(ROOT, "oracle")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-std=c++17", "-Wno-unused-result",
+           "-I", os.path.join(ROOT, "fundsp_amd", "csrc"), "-I", odir, "-o", str(exe),
+           os.path.join(ROOT, "tests", "host", "check_envelope_spec.hip"), "-L" + odir, "-lfundsp_oracle", "-Wl,-rpath," + odir]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bad 0" in r.stdout
