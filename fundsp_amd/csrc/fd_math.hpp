@@ -432,13 +432,13 @@ FD_HD float tanhf_musl(float x0) {
     float e2 = xx * (e - c) - c;
     e2 -= hxs;
     const float res_km1 = 0.5f * (xx - e2) - 0.5f;
-    const float res_k1 = 1.0f + 2.0f * (xx - e2);
+    // (k = 1: musl's 1 + 2 (x - e) and the k < 23 form ((x - e) + 0.5) * 2 are the same bits -- a scaling by two commutes
+    // with the rounding of the sum --, so k = 1 takes the general form; the exhaustive device check covers it)
     const float twopk = u2f(((uint32_t)0x7f + (uint32_t)k) << 23);
     const float uf = u2f(((uint32_t)0x7f - (uint32_t)k) << 23);
     const float res_lt23 = (xx - e2 + (1 - uf)) * twopk;
     const float res_ge23 = (xx - (e2 + uf) + 1) * twopk;
-    const float res_far = (k < 23) ? res_lt23 : res_ge23;
-    const float res_pos = near1 ? res_k1 : res_far;
+    const float res_pos = (k < 23) ? res_lt23 : res_ge23;
     const float res_neg = reduce ? res_km1 : res_k0;
     const float t = c2 ? res_pos : res_neg;
     // (musl returns a itself for |a| < 2**-25; the k = 0 form gives the same bits there -- a + a*a/2 rounds to a --,
