@@ -46,6 +46,7 @@ SYMBOLS = {
     "fdsp_reverb_stereo_create_on": (_i, [_i, _sz, _d, _d, _d, C.POINTER(_P)]),
     "fdsp_bank_device": (_i, [_P]),
     "fdsp_bank_destroy": (None, [_P]),
+    "fdsp_bank_clone": (_i, [_P, C.POINTER(_P)]),
     "fdsp_bank_inputs": (_i, [_P]),
     "fdsp_bank_outputs": (_i, [_P]),
     "fdsp_bank_voices": (_sz, [_P]),

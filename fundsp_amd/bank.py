@@ -89,6 +89,15 @@ class Bank:
         check(lib().fdsp_reverb_stereo_create(int(instances), float(room_size), float(time), float(damping), C.byref(h)))
         return cls("reverb_stereo", instances, _handle=h)
 
+    def clone(self):
+        """AudioNode: Clone -- a new bank that continues exactly where this one stands (fdsp_bank_clone: slots, rings, sample
+        rate, arithmetic mode, launch options, scheduler events, reverb state)."""
+        h = C.c_void_p()
+        check(lib().fdsp_bank_clone(self._h, C.byref(h)))
+        b = Bank(self.kind, self.voices, _handle=h)
+        b.sample_rate = self.sample_rate
+        return b
+
     def device(self):
         return lib().fdsp_bank_device(self._h)
 
@@ -398,12 +407,34 @@ class Comm:
                                        C.c_void_p(after_stream) if after_stream else None))
         return mix
 
+    def allreduce_all(self, mixes, after_streams=None):
+        """ONE host thread driving a Comm.local([...]) communicator of several GPUs: sum `mixes[k]` (the [2, frames] tensor on
+        slot k's device) across all slots in one grouped call (fdsp_mix_allreduce_all: ncclGroupStart / End).  Per-slot
+        allreduce() calls issued one after the other from a single thread would wait for each other."""
+        import torch
+
+        n = lib().fdsp_comm_local_slots(self._h)
+        assert len(mixes) == n, f"{n} local slots, {len(mixes)} tensors"
+        count = mixes[0].numel()
+        for m in mixes:
+            assert m.is_cuda and m.dtype == torch.float32 and m.is_contiguous() and m.numel() == count
+        if after_streams is None:
+            after_streams = [torch.cuda.current_stream(m.device).cuda_stream for m in mixes]
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(m.data_ptr()) for m in mixes])
+        strs = (C.c_void_p * n)(*[C.c_void_p(s) if s else C.c_void_p(None) for s in after_streams])
+        check(lib().fdsp_mix_allreduce_all(self._h, ptrs, count, strs))
+        return mixes
+
     def wait(self, slot=0, stream=None):
-        """stream=None blocks the host; otherwise the given raw stream handle waits (0 / "current": torch's current)."""
+        """stream=None blocks the HOST until the slot's last all-reduce is complete; stream="current" makes torch's current
+        stream wait for it; any other value is a raw hipStream_t handle that waits (the NULL stream cannot be named this
+        way: a handle of 0 means "block the host", as in the C ABI)."""
         if stream == "current":
             import torch
 
             stream = torch.cuda.current_stream().cuda_stream
+            if not stream:       # torch's current stream IS the NULL stream: order it by blocking the host
+                stream = None
         check(lib().fdsp_comm_wait(self._h, slot, C.c_void_p(stream) if stream else None))
 
     def close(self):

@@ -1,5 +1,6 @@
 // fd_capi.hip -- C ABI (include/fundsp_hip.h) of the MI355X voice-bank engine.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -13,17 +14,20 @@
 #include "../../include/fundsp_hip.h"
 #include "fd_engine.hpp"
 #include "fd_fdn.hpp"
+#include "fd_opts.hpp"
 
 namespace {
 
 thread_local std::string g_err;
 }
 namespace fd {
-int g_pipe_split = 1;
-int g_fdn_kernel = 0;
-int g_time_split = 1;
-int g_math = FDSP_MATH_EXACT;  // default arithmetic of banks created from now on (fdsp_set_option("math", ..))
-long g_zero_copy_max = 1 << 18;  // floats; fdsp_bank_process_host reads/writes pinned host memory directly below this
+// process-wide DEFAULTS (fdsp_set_option); a bank's own value (fdsp_bank_set_option) overrides them for that bank.  Atomics:
+// hosts drive banks from several threads.  The launch code never reads these: it reads the thread-local block below.
+std::atomic<int> g_pipe_split{1}, g_fdn_kernel{0}, g_time_split{1};
+std::atomic<int> g_math{FDSP_MATH_EXACT};  // default arithmetic of banks created from now on (fdsp_set_option("math", ..))
+std::atomic<int> g_timing{1};              // default of the per-launch HIP event pair (fdsp_bank_last_kernel_ms)
+std::atomic<long> g_zero_copy_max{1 << 18};  // floats; fdsp_bank_process_host reads/writes pinned host memory directly below this
+thread_local LaunchOpts tl_opts;           // fd_opts.hpp: what the launch code reads, resolved per bank by every render entry point
 int simd_count() {  // SIMDs (CUs x 4) of the CURRENT device, cached per device
     static int cache[64] = {0};
     int dev = 0;
@@ -88,6 +92,8 @@ struct DeviceCtx {
     fd::Aux host_aux;            // host mirror of this device's Aux (data pointers are device pointers)
     fd::Aux* dev_aux = nullptr;
     uint64_t table_ver[fd::WT_SETS] = {0}, wave_ver[fd::WAVE_SLOTS] = {0};
+    bool aux_dirty = false;            // host_aux is newer than *dev_aux (an upload of the block itself failed earlier)
+    std::vector<void*> retired;        // device buffers *dev_aux may still point to: freed only after the block was rewritten
 };
 HostTableSet g_tables[fd::WT_SETS];
 HostWave g_waves[fd::WAVE_SLOTS];
@@ -117,30 +123,36 @@ int device_of(const void* p) {  // the device a device pointer belongs to (-1: u
     return a.device;
 }
 
-// bring device `dev`'s copies of the shared tables / waves up to date (g_aux_mutex held, `dev` current)
+// bring device `dev`'s copies of the shared tables / waves up to date (g_aux_mutex held, `dev` current).
+// Order: render launches do not take g_aux_mutex and other host threads may be launching on this device, so
+// a buffer the device-side Aux block still points to is never freed first.  New buffers are allocated and filled, the
+// Aux block is rewritten (stream-ordered: launches enqueued after it see the new pointers), the device is drained --
+// every launch that could have read the old pointers has finished -- and only then are the replaced buffers freed.  A
+// failure at any step leaves *dev_aux pointing at live memory; host_aux / the version numbers only advance for what
+// was uploaded, and `aux_dirty` makes the next call retry the block itself.
 hipError_t sync_shared_locked(int dev) {
     DeviceCtx& c = g_devctx[dev];
-    bool dirty = false;
     if (!c.init) {
         std::memset(&c.host_aux, 0, sizeof c.host_aux);
         hipError_t e = hipMalloc((void**)&c.dev_aux, sizeof(fd::Aux));
         if (e != hipSuccess) return e;
         c.init = true;
-        dirty = true;
+        c.aux_dirty = true;
     }
-    for (int set = 0; set < fd::WT_SETS; set++) {
+    hipError_t err = hipSuccess;
+    for (int set = 0; set < fd::WT_SETS && err == hipSuccess; set++) {
         const HostTableSet& t = g_tables[set];
         if (t.ver == c.table_ver[set]) continue;
         // device layout: every table circularly padded [t[len-1], t[0..len-1], t[0], t[1]] (fd_nodes.hpp wt_tap)
         std::vector<float> padded;
         padded.reserve(t.data.size() + 3 * (size_t)t.n);
-        fd::WtSet& w = c.host_aux.wt[set];
+        fd::WtSet nw = c.host_aux.wt[set];
         size_t src = 0;
         for (int i = 0; i < t.n; i++) {
             const size_t len = (size_t)t.len[i];
-            w.pitch[i] = t.pitch[i];
-            w.off[i] = (int)padded.size();
-            w.len[i] = t.len[i];
+            nw.pitch[i] = t.pitch[i];
+            nw.off[i] = (int)padded.size();
+            nw.len[i] = t.len[i];
             padded.push_back(t.data[src + len - 1]);
             padded.insert(padded.end(), t.data.begin() + src, t.data.begin() + src + len);
             padded.push_back(t.data[src]);
@@ -148,40 +160,51 @@ hipError_t sync_shared_locked(int dev) {
             src += len;
         }
         float* d = nullptr;
-        hipError_t e = hipMalloc((void**)&d, padded.size() * sizeof(float));
-        if (e == hipSuccess) e = hipMemcpy(d, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipDeviceSynchronize();  // no render may still read the tables this replaces
-        if (e != hipSuccess) {
+        err = hipMalloc((void**)&d, padded.size() * sizeof(float));
+        if (err == hipSuccess) err = hipMemcpy(d, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (err != hipSuccess) {
             if (d) hipFree(d);
-            return e;
+            break;
         }
-        if (w.data) hipFree(const_cast<float*>(w.data));
+        fd::WtSet& w = c.host_aux.wt[set];
+        if (w.data) c.retired.push_back(const_cast<float*>(w.data));
+        w = nw;
         w.n = t.n;
         w.data = d;
         c.table_ver[set] = t.ver;
-        dirty = true;
+        c.aux_dirty = true;
     }
-    for (int slot = 0; slot < fd::WAVE_SLOTS; slot++) {
+    for (int slot = 0; slot < fd::WAVE_SLOTS && err == hipSuccess; slot++) {
         const HostWave& hw = g_waves[slot];
         if (hw.ver == c.wave_ver[slot]) continue;
         float* d = nullptr;
-        hipError_t e = hipMalloc((void**)&d, hw.data.size() * sizeof(float));
-        if (e == hipSuccess) e = hipMemcpy(d, hw.data.data(), hw.data.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipDeviceSynchronize();  // no render may still read the buffer this replaces
-        if (e != hipSuccess) {
+        err = hipMalloc((void**)&d, hw.data.size() * sizeof(float));
+        if (err == hipSuccess) err = hipMemcpy(d, hw.data.data(), hw.data.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (err != hipSuccess) {
             if (d) hipFree(d);
-            return e;
+            break;
         }
         fd::WaveBuf& w = c.host_aux.wave[slot];
-        if (w.data) hipFree(const_cast<float*>(w.data));
+        if (w.data) c.retired.push_back(const_cast<float*>(w.data));
         w.data = d;
         w.channels = (uint32_t)hw.channels;
         w.length = (uint32_t)hw.length;
         c.wave_ver[slot] = hw.ver;
-        dirty = true;
+        c.aux_dirty = true;
     }
-    if (dirty) return hipMemcpy(c.dev_aux, &c.host_aux, sizeof(fd::Aux), hipMemcpyHostToDevice);
-    return hipSuccess;
+    // whatever was uploaded goes live even if a later set failed: the block, then the drain, then the frees
+    if (c.aux_dirty) {
+        const hipError_t e = hipMemcpy(c.dev_aux, &c.host_aux, sizeof(fd::Aux), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return err != hipSuccess ? err : e;  // *dev_aux unchanged: the retired buffers stay alive
+        c.aux_dirty = false;
+    }
+    if (!c.retired.empty()) {
+        const hipError_t e = hipDeviceSynchronize();  // no launch that read the old block can still be running
+        if (e != hipSuccess) return err != hipSuccess ? err : e;
+        for (void* p : c.retired) hipFree(p);
+        c.retired.clear();
+    }
+    return err;
 }
 
 // the Aux block of device `dev` (created and synchronised on first use); nullptr on failure
@@ -377,6 +400,10 @@ struct fdsp_bank {
     bool timed = false;
     bool ext_pending = false;  // the last render ran on a caller's stream: bank-stream work must wait for its e1
     int math = FDSP_MATH_EXACT;  // FDSP_MATH_FAST: renders take the kind's tolerance-mode variant when it has one
+    // per-bank launch options (fdsp_bank_set_option); -1 = follow the process-wide default at every launch
+    int opt_pipe_split = -1, opt_time_split = -1, opt_fdn_kernel = -1, opt_timing = -1;
+    size_t ring_frames = 0;      // as given at creation (fdsp_bank_clone)
+    int last_kernel = 0;         // fd::LastKernel of the most recent render launch (fdsp_bank_get_option "last_kernel")
     bool ring_check_pending = false;  // a lifecycle launch may have changed a delay length: verify capacity before rendering
     uint32_t ring_short = 0;          // > 0: positions a node wanted and did not get (renders fail until a later update fits)
     int device = 0;              // the HIP device the bank lives on; every entry point makes it current for its own duration
@@ -427,14 +454,21 @@ uint32_t* ring_need_word(const fdsp_bank* b) {
     return reinterpret_cast<uint32_t*>(b->ring + (size_t)b->ops->nrings * b->ring_cap * b->stride);
 }
 void before_update_launch(fdsp_bank* b, size_t first, size_t count) {
+    (void)first; (void)count;
     if (!b->ring || !b->ops || b->ops->nrings == 0) return;
-    if (first == 0 && count >= b->V) hipMemsetAsync(ring_need_word(b), 0, sizeof(uint32_t), b->stream);
     b->ring_check_pending = true;
 }
+// Parameters arrive one slot and one voice RANGE at a time, so the word a partial update leaves behind says nothing
+// final: a too-long delay corrected range by range would keep its stale complaint, and a complaint of voices outside
+// the last range could be lost.  So the check itself asks every voice again: clear the word, re-derive all
+// voices (lifecycle op 1 = update(): recomputes the same coefficients from the same parameters, idempotent), read it.
 int check_ring_need(fdsp_bank* b, bool capturing) {
     if (!b->ring || !b->ops || b->ops->nrings == 0) return FDSP_OK;
     if (b->ring_check_pending && !capturing) {
         uint32_t need = 0;
+        HIPCHK(hipMemsetAsync(ring_need_word(b), 0, sizeof(uint32_t), b->stream));
+        b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&need, ring_need_word(b), sizeof need, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
         b->ring_check_pending = false;
@@ -538,30 +572,47 @@ int fdsp_kind_by_name(const char* name) {
     return -1;
 }
 
+namespace {
+// the launch options by name: range check shared by the process-wide and the per-bank setter
+struct OptSpec { const char* name; int lo, hi; const char* what; };
+const OptSpec LAUNCH_OPTS[] = {
+    {"pipe_split", 0, 4, "pipe_split takes 0 (off), 1 (auto), 2 or 3 (stages), 4 (loader only)"},
+    {"time_split", 0, 1, "time_split takes 0 (off) or 1 (small banks of eligible graphs)"},
+    {"fdn_kernel", 0, 1, "fdn_kernel takes 0 (lane per frame) or 1 (lane per delay line)"},
+    {"timing", 0, 1, "timing takes 0 (no per-launch event pair) or 1 (fdsp_bank_last_kernel_ms available)"},
+};
+const OptSpec* launch_opt(const char* name) {
+    if (!name) return nullptr;
+    for (const OptSpec& o : LAUNCH_OPTS)
+        if (std::strcmp(name, o.name) == 0) return &o;
+    return nullptr;
+}
+// resolve a bank's launch options into the calling thread's block (fd_opts.hpp) -- every render entry point, right
+// before it launches
+void resolve_opts(const fdsp_bank* b) {
+    fd::tl_opts.pipe_split = b->opt_pipe_split >= 0 ? b->opt_pipe_split : fd::g_pipe_split.load(std::memory_order_relaxed);
+    fd::tl_opts.time_split = b->opt_time_split >= 0 ? b->opt_time_split : fd::g_time_split.load(std::memory_order_relaxed);
+    fd::tl_opts.fdn_kernel = b->opt_fdn_kernel >= 0 ? b->opt_fdn_kernel : fd::g_fdn_kernel.load(std::memory_order_relaxed);
+    fd::tl_opts.last_kernel = fd::LK_NONE;
+}
+bool timing_on(const fdsp_bank* b) { return (b->opt_timing >= 0 ? b->opt_timing : fd::g_timing.load(std::memory_order_relaxed)) != 0; }
+}  // namespace
+
 int fdsp_set_option(const char* name, int value) {
-    if (name && std::strcmp(name, "pipe_split") == 0) {
-        if (value < 0 || value > 4) return fail(FDSP_EINVAL, "pipe_split takes 0 (off), 1 (auto), 2 or 3 (stages), 4 (loader only)");
-        fd::g_pipe_split = value;
+    if (const OptSpec* o = launch_opt(name)) {
+        if (value < o->lo || value > o->hi) return fail(FDSP_EINVAL, o->what);
+        (o->name[0] == 'p' ? fd::g_pipe_split : o->name[1] == 'i' && o->name[2] == 'm' && o->name[3] == 'e' ? fd::g_time_split
+         : o->name[0] == 'f' ? fd::g_fdn_kernel : fd::g_timing).store(value);
         return FDSP_OK;
     }
     if (name && std::strcmp(name, "host_zero_copy_max") == 0) {
         if (value < 0) return fail(FDSP_EINVAL, "host_zero_copy_max takes a float count >= 0");
-        fd::g_zero_copy_max = value;
-        return FDSP_OK;
-    }
-    if (name && std::strcmp(name, "fdn_kernel") == 0) {
-        if (value < 0 || value > 1) return fail(FDSP_EINVAL, "fdn_kernel takes 0 (lane per frame) or 1 (lane per delay line)");
-        fd::g_fdn_kernel = value;
+        fd::g_zero_copy_max.store(value);
         return FDSP_OK;
     }
     if (name && std::strcmp(name, "math") == 0) {
         if (value != FDSP_MATH_EXACT && value != FDSP_MATH_FAST) return fail(FDSP_EINVAL, "math takes FDSP_MATH_EXACT (0) or FDSP_MATH_FAST (1)");
-        fd::g_math = value;
-        return FDSP_OK;
-    }
-    if (name && std::strcmp(name, "time_split") == 0) {
-        if (value < 0 || value > 1) return fail(FDSP_EINVAL, "time_split takes 0 (off) or 1 (small banks of eligible graphs)");
-        fd::g_time_split = value;
+        fd::g_math.store(value);
         return FDSP_OK;
     }
     return fail(FDSP_EINVAL, "unknown option");
@@ -574,12 +625,23 @@ int fdsp_bank_set_option(fdsp_bank* b, const char* name, int value) {
         b->math = value;
         return FDSP_OK;
     }
+    if (const OptSpec* o = launch_opt(name)) {  // -1 = back to the process-wide default
+        if (value != -1 && (value < o->lo || value > o->hi)) return fail(FDSP_EINVAL, std::string(o->what) + "; -1 = follow the process-wide default");
+        (o->name[0] == 'p' ? b->opt_pipe_split : o->name[1] == 'i' && o->name[2] == 'm' && o->name[3] == 'e' ? b->opt_time_split
+         : o->name[0] == 'f' ? b->opt_fdn_kernel : b->opt_timing) = value;
+        return FDSP_OK;
+    }
     return fail(FDSP_EINVAL, "unknown bank option");
 }
 int fdsp_bank_get_option(const fdsp_bank* b, const char* name) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
     if (name && std::strcmp(name, "math") == 0) return b->math;
     if (name && std::strcmp(name, "math_has_fast_variant") == 0) return (b->ops && b->ops->render_fast) ? 1 : 0;
+    if (name && std::strcmp(name, "pipe_split") == 0) return b->opt_pipe_split >= 0 ? b->opt_pipe_split : fd::g_pipe_split.load();
+    if (name && std::strcmp(name, "time_split") == 0) return b->opt_time_split >= 0 ? b->opt_time_split : fd::g_time_split.load();
+    if (name && std::strcmp(name, "fdn_kernel") == 0) return b->opt_fdn_kernel >= 0 ? b->opt_fdn_kernel : fd::g_fdn_kernel.load();
+    if (name && std::strcmp(name, "timing") == 0) return timing_on(b) ? 1 : 0;
+    if (name && std::strcmp(name, "last_kernel") == 0) return b->last_kernel;
     return fail(FDSP_EINVAL, "unknown bank option");
 }
 
@@ -693,7 +755,7 @@ int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring
     b->stream = nullptr;
     b->timed = false;
     b->sr = FDSP_DEFAULT_SR;
-    b->math = fd::g_math;
+    b->math = fd::g_math.load();
     for (int i = 0; i < b->nslots; i++) b->index[b->ops->slots[i].name] = i;
     size_t bytes = (size_t)(b->nslots > 0 ? b->nslots : 1) * b->stride * sizeof(float);
     hipError_t e = hipMalloc((void**)&b->slots, bytes);
@@ -712,6 +774,7 @@ int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring
             return fail(FDSP_EINVAL, "this kind contains delay lines: create it with fdsp_bank_create_ring(kind, voices, ring_frames)");
         }
         b->ring_cap = (uint32_t)ring_frames;
+        b->ring_frames = ring_frames;
         // + one 64-byte line behind the rings: the word in which a node reports that it wanted more positions
         const size_t rbytes = (size_t)b->ops->nrings * ring_frames * b->stride * sizeof(float) + 64;
         e = hipMalloc((void**)&b->ring, rbytes);
@@ -870,6 +933,81 @@ void fdsp_bank_destroy(fdsp_bank* b) {
     if (b->e1) hipEventDestroy(b->e1);
     if (b->stream) hipStreamDestroy(b->stream);
     delete b;
+}
+
+// `Clone` of a FunDSP node (AudioNode: Clone, audionode.rs:35; Net / Sequencer clone their units routinely): a new
+// bank of the same kind on the same device that continues exactly where `src` stands -- slots (parameters, coefficients,
+// state), delay rings, sample rate, arithmetic mode, launch options, scheduler events and clock, reverb line state.
+int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
+    if (!src || !out) return fail(FDSP_EINVAL, "bank or out is NULL");
+    *out = nullptr;
+    DeviceGuard guard(src->device);
+    // everything queued on the source's stream (and a render on a caller's stream) lands before the copy reads it
+    if (src->ext_pending && src->e1) HIPCHK(hipEventSynchronize(src->e1));
+    HIPCHK(hipStreamSynchronize(src->stream));
+    fdsp_bank* b = nullptr;
+    int rc;
+    if (src->fdn)
+        rc = fdsp_reverb_stereo_create_on(src->device, src->V, src->fdn->room, src->fdn->time, src->fdn->damping, &b);
+    else
+        rc = fdsp_bank_create_on(src->device, src->ops->name.c_str(), src->V, src->ring_frames, &b);
+    if (rc != FDSP_OK) return rc;
+    auto bail = [&](hipError_t e, const char* what) {
+        fdsp_bank_destroy(b);
+        return fail(e == hipErrorOutOfMemory ? FDSP_ENOMEM : FDSP_EDEVICE, std::string("fdsp_bank_clone: ") + what + ": " + hipGetErrorString(e));
+    };
+    hipError_t e = hipSuccess;
+    if (src->fdn) {
+        if (src->sr != b->sr) {  // the rings' capacity and lengths follow the sample rate
+            HIPCHK(hipStreamSynchronize(b->stream));
+            rc = fdn_configure(b, src->sr);
+            if (rc != FDSP_OK) {
+                fdsp_bank_destroy(b);
+                return rc;
+            }
+        }
+        const size_t n = src->V;
+        const fd::FdnState &a = src->fdn->st, &d = b->fdn->st;
+        e = hipMemcpyAsync(d.rings, a.rings, n * src->fdn->c.ring_stride * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d.wpos, a.wpos, n * sizeof(int), hipMemcpyDeviceToDevice, b->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d.v1, a.v1, n * 32 * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d.v2, a.v2, n * 32 * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d.fb, a.fb, n * 32 * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
+        if (e != hipSuccess) return bail(e, "reverb state");
+    } else {
+        b->sr = src->sr;
+        e = hipMemcpyAsync(b->slots, src->slots, (size_t)(src->nslots > 0 ? src->nslots : 1) * src->stride * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
+        if (e != hipSuccess) return bail(e, "slots");
+        if (src->ring) {
+            e = hipMemcpyAsync(b->ring, src->ring, (size_t)src->ops->nrings * src->ring_cap * src->stride * sizeof(float) + 64, hipMemcpyDeviceToDevice, b->stream);
+            if (e != hipSuccess) return bail(e, "delay rings");
+        }
+        b->ring_check_pending = src->ring_check_pending;
+        b->ring_short = src->ring_short;
+        if (src->ev) {
+            e = hipMalloc((void**)&b->ev, 4 * src->stride * sizeof(double));
+            if (e == hipSuccess) e = hipMalloc((void**)&b->ev_fade, src->stride * sizeof(int));
+            if (e == hipSuccess) e = hipMemcpyAsync(b->ev, src->ev, 4 * src->stride * sizeof(double), hipMemcpyDeviceToDevice, b->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(b->ev_fade, src->ev_fade, src->stride * sizeof(int), hipMemcpyDeviceToDevice, b->stream);
+            if (e != hipSuccess) return bail(e, "events");
+        }
+        b->seq_time = src->seq_time;
+        b->ev_host = src->ev_host;
+        b->ev_dirty = src->ev_dirty;
+        b->ev_max_start = src->ev_max_start;
+        b->ev_min_end = src->ev_min_end;
+        b->ev_max_fade_in_end = src->ev_max_fade_in_end;
+        b->ev_min_fade_out_start = src->ev_min_fade_out_start;
+    }
+    b->math = src->math;
+    b->opt_pipe_split = src->opt_pipe_split;
+    b->opt_time_split = src->opt_time_split;
+    b->opt_fdn_kernel = src->opt_fdn_kernel;
+    b->opt_timing = src->opt_timing;
+    e = hipStreamSynchronize(b->stream);
+    if (e != hipSuccess) return bail(e, "copy");
+    *out = b;
+    return FDSP_OK;
 }
 
 int fdsp_bank_inputs(const fdsp_bank* b) { return b ? (b->fdn ? 2 : b->ops->nin) : FDSP_EINVAL; }
@@ -1050,17 +1188,23 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
     // ran on a caller stream and this one runs on the bank's): it reads and writes the same voice state, so order behind it
     if (int rc = check_ring_need(b, capturing)) return rc;
     if (b->ext_pending && !capturing) HIPCHK(hipStreamWaitEvent(s, b->e1, 0));
-    if (!capturing) HIPCHK(hipEventRecord(b->e0, s));
+    // the per-launch event pair is optional ("timing" = 0): a real-time host that renders one 64-frame block per call
+    // saves two event records per launch; the completion event is then recorded only where ordering needs it (a
+    // caller's stream)
+    const bool timing = timing_on(b);
+    if (!capturing && timing) HIPCHK(hipEventRecord(b->e0, s));
+    resolve_opts(b);
     if (b->fdn)  // Feedback::process is the per-sample tick (feedback.rs:136-146): both modes are the same arithmetic
         fd::fdn_launch_render(b->fdn->c, b->fdn->st, b->V, d_in, d_out, frames, frame_stride, layout, s);
     else if (b->math == FDSP_MATH_FAST && b->ops->render_fast)
         b->ops->render_fast(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, b->aux, b->ring, b->ring_cap, s);
     else
         b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, b->aux, b->ring, b->ring_cap, s);
+    b->last_kernel = fd::tl_opts.last_kernel;
     HIPCHK(hipGetLastError());
     if (!capturing) {
-        HIPCHK(hipEventRecord(b->e1, s));
-        b->timed = true;
+        if (timing || s != b->stream) HIPCHK(hipEventRecord(b->e1, s));
+        b->timed = timing;
         b->ext_pending = s != b->stream;
     }
     return FDSP_OK;
@@ -1179,12 +1323,14 @@ int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, flo
     // process / tick -- same arithmetic -- so the launch takes the (pipeline) render kernel.
     const bool sustained = !b->ev_host.empty() && b->ev_max_start <= t_begin && b->ev_min_end >= t_end &&
                            b->ev_max_fade_in_end <= t_begin && b->ev_min_fade_out_start >= t_end;
+    resolve_opts(b);
     if (sustained)
         b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, 0, FDSP_LAYOUT_VOICE_MINOR, mode, b->aux, b->ring,
                        b->ring_cap, s);
     else
     b->ops->render_events(b->slots, b->stride, b->V, d_in, d_out, frames, b->ev, b->ev_fade, b->seq_time, b->sr, mode,
                           b->aux, b->ring, b->ring_cap, s);
+    b->last_kernel = fd::tl_opts.last_kernel;
     HIPCHK(hipGetLastError());
     if (!capturing) {
         HIPCHK(hipEventRecord(b->e1, s));
@@ -1239,7 +1385,7 @@ int fdsp_bank_process_host(fdsp_bank* b, size_t frames, const float* h_in, float
     // small transfers (a real-time host's 64-frame blocks): the kernel reads and writes pinned host memory over the
     // bus itself — two copy-engine round trips less than staging through HBM (tools/host_sweep.py: 26-45 us against
     // 44-54 us per call up to 1024 voices; above ~1 MB the pageable copy path wins)
-    const bool zc = !strided && n_in <= (size_t)fd::g_zero_copy_max && n_out <= (size_t)fd::g_zero_copy_max &&
+    const bool zc = !strided && n_in <= (size_t)fd::g_zero_copy_max.load() && n_out <= (size_t)fd::g_zero_copy_max.load() &&
                     stage_reserve(&b->pin_in, &b->pin_in_n, n_in, true) == hipSuccess &&
                     stage_reserve(&b->pin_out, &b->pin_out_n, n_out, true) == hipSuccess;
     int rc = FDSP_OK;

@@ -85,14 +85,15 @@ int fdsp_comm_create_local(int n, const int* devices, fdsp_comm** out) {
     fdsp_comm* c = new fdsp_comm();
     c->nranks = n;
     c->slots.resize(n);
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n; i++) {  // every ncclComm_t has its slot BEFORE anything can fail: fdsp_comm_destroy frees them all
         c->slots[i].device = devs[i];
         c->slots[i].comm = comms[i];
+    }
+    for (int i = 0; i < n; i++)
         if (int rc = slot_setup(c->slots[i])) {
             fdsp_comm_destroy(c);
             return rc;
         }
-    }
     *out = c;
     return FDSP_OK;
 }

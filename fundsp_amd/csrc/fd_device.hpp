@@ -620,6 +620,9 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
 #ifndef FD_LP_ENABLE
 #define FD_LP_ENABLE 1  // A/B switch (tools/build_variants.sh): 0 = always the generic SVF arithmetic
 #endif
+#ifndef FD_KNOCK
+#define FD_KNOCK 0      // measurement only (NOT a renderer): compute stage FD_KNOCK - 1 of the pipeline kernel idles, so the other
+#endif                  // stage's wave has its SIMD to itself; the hand-over tiles start zeroed (profiles/r03_knockout_c3.txt)
 // ---- multi-wave pipeline split of a Pipe chain ------------------------------------------------------------------
 // At one voice-wave per SIMD (65 536 voices on 1024 SIMDs) a lone wave issues one instruction per ~4.7 cycles while
 // the VALU could take one every ~2.5-3.3 (profiles/r01_ubench_valu.txt, r01_voice_sweep_*).  For graphs that are a
@@ -684,6 +687,18 @@ template <class X, class Y> struct Weight<Stack<X, Y>> { static constexpr int v 
 template <class O, class X, class Y> struct Weight<Binop<O, X, Y>> { static constexpr int v = Weight<X>::v + Weight<Y>::v + 1; };
 template <class X, class U> struct Weight<Unop<X, U>> { static constexpr int v = Weight<X>::v + 1; };
 
+// HasSkip<T>: the node defines skip / skip2 (state advance without output) all the way down -- what a time-split stage
+// needs of the stages it runs in several waves.  Leaves are detected; Pipe and Unop forward to their operands (their
+// own skip2 members exist unconditionally and would only fail when instantiated); everything else: no.
+template <class...> struct VoidT { using type = void; };
+template <class T, class = void> struct LeafHasSkip { static constexpr bool v = false; };
+template <class T> struct LeafHasSkip<T, typename VoidT<decltype(&T::template skip2<PH_SIMD>)>::type> { static constexpr bool v = true; };
+template <class T> struct HasSkip { static constexpr bool v = LeafHasSkip<T>::v; };
+template <class X, class Y> struct HasSkip<Pipe<X, Y>> { static constexpr bool v = HasSkip<X>::v && HasSkip<Y>::v; };
+template <class X, class U> struct HasSkip<Unop<X, U>> { static constexpr bool v = HasSkip<X>::v; };
+template <class O, class X, class Y> struct HasSkip<Binop<O, X, Y>> { static constexpr bool v = false; };
+template <class X, class Y> struct HasSkip<Stack<X, Y>> { static constexpr bool v = false; };
+
 // Seg<G, A, B, HEAD>: the chain stages [A, B) of G, run on G's own state object.
 //   in  = what the segment's first stage consumes: the node's own inputs when A == 0, else the hand-over channels;
 //   gin = the node's own inputs (the graph's inputs for head-position nodes), valid in EVERY stage: a Binop tail reads
@@ -694,6 +709,7 @@ struct Seg {
     static_assert(A == 0 && B == 1, "a node that is not a chain is one stage");
     static constexpr int IN = G::IN, OUT = G::OUT, cost = Cost<G>::v, weight = Weight<G>::v;
     static constexpr bool USES_GIN = false;
+    static constexpr bool HAS_SKIP = HasSkip<G>::v;
     template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f*, v2f* out) { g.template step2<PH>(in, out); }
     template <int PH> static FD_D void step(G& g, const float* in, const float*, float* out) { g.template step<PH>(in, out); }
     template <int PH> static FD_D void skip2(G& g, const v2f* in) { g.template skip2<PH>(in); }  // time-split stages only
@@ -716,6 +732,7 @@ struct Seg<Pipe<X, Y>, A, B, HEAD> {
     static constexpr int cost = (HX ? SX::cost : 0) + (HY ? SY::cost : 0);
     static constexpr int weight = (HX ? SX::weight : 0) + (HY ? SY::weight : 0);
     static constexpr bool USES_GIN = HX && SX::USES_GIN;
+    static constexpr bool HAS_SKIP = !(HX && HY) && (HX ? SX::HAS_SKIP : SY::HAS_SKIP);  // skip is defined for one-stage segments
     template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f* gin, v2f* out) {
         if constexpr (HX && HY) { v2f t[SX::OUT > 0 ? SX::OUT : 1]; SX::template step2<PH>(g.x, in, gin, t); SY::template step2<PH>(g.y, t, nullptr, out); }
         else if constexpr (HX) SX::template step2<PH>(g.x, in, gin, out);
@@ -769,6 +786,7 @@ struct Seg<Binop<O, X, Y>, A, B, true> {
     static constexpr int cost = (HX ? SX::cost : 0) + (TAIL ? Cost<Y>::v + 1 : 0);
     static constexpr int weight = (HX ? SX::weight : 0) + (TAIL ? Weight<Y>::v + 1 : 0);
     static constexpr bool USES_GIN = SPLIT && TAIL && Y::IN > 0;
+    static constexpr bool HAS_SKIP = false;  // a Binop segment has no skip2 (ts_stage never takes one)
     template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f* gin, v2f* out) {
         if constexpr (!SPLIT) {
             g.template step2<PH>(in, out);
@@ -1094,6 +1112,10 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     const float* inw = in + v0;  // wave-uniform bases + lane
     float* outw = out + v0;
 
+#if FD_KNOCK
+    for (size_t i = threadIdx.x; i < sizeof(hand) / sizeof(float); i += blockDim.x) reinterpret_cast<float*>(hand)[i] = 0.0f;
+    __syncthreads();
+#endif
     if (FEED && role == 0) {  // ---- loader wave ----
         float rg[FEED ? NI : 1][SUB];
         auto issue = [&](size_t j) {  // frames past the end re-read the last frame (never used): no branches
@@ -1142,7 +1164,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
         using T2 = typename TG::S2;
         GG& gg = reinterpret_cast<GG&>(g);
         for (size_t it = 0; it < rounds; it++) {
-            if (live && active && it >= first && it - first < ntiles) {
+            if (live && active && it >= first && it - first < ntiles && (FD_KNOCK == 0 || stage != FD_KNOCK - 1)) {
                 const size_t j = it - first;          // the tile this stage works on in this round
                 const size_t t0 = (j / SPB) * 64;
                 const int h = (int)(j % SPB);
@@ -1291,9 +1313,20 @@ FD_D void ts_stage(G& g, int part, int nparts, int lane, v2f (*hin)[32][64], v2f
     SG::end(g);  // end_simd: once per block, after its last packed item
 }
 
-template <class G> struct TsPlan {  // which graphs the time-split kernel takes
-    static constexpr bool ok = Chain<G>::N == 3 && G::IN == 0 && G::RINGS == 0;
+template <class G, bool SHAPE = (Chain<G>::N == 3 && G::IN == 0 && G::RINGS == 0)>
+struct TsPlan {  // which graphs the time-split kernel takes
+    static constexpr bool ok = false;
 };
+// ... a three-stage chain without inputs or rings whose first two stages can advance their state without producing
+// output (skip2 on every node of the stage: Constant, Sine, Pipe, Unop today).  A 3-stage kind headed by a Noise, a
+// WaveSynth or a Binop split simply does not qualify (it used to fail to COMPILE).
+template <class G> struct TsPlan<G, true> {
+    static constexpr bool ok = Seg<G, 0, 1>::HAS_SKIP && Seg<G, 1, 2>::HAS_SKIP;
+};
+static_assert(HasSkip<Pipe<Constant<1>, Sine>>::v && HasSkip<Unop<Pipe<Constant<1>, SineFast>, UMulScalar>>::v && !HasSkip<Noise>::v &&
+              !HasSkip<FixedSvf>::v, "HasSkip: oscillator chains yes, Noise / filters no");
+static_assert(TsPlan<Pipe<Pipe<Unop<Pipe<Constant<1>, Sine>, UAddScalar>, Sine>, FixedSvf>>::ok && !TsPlan<Pipe<Pipe<Noise, Sine>, FixedSvf>>::ok &&
+              !TsPlan<Pipe<Sine, FixedSvf>>::ok, "TsPlan: three-stage oscillator chains only");
 
 static __device__ unsigned int g_ts_arrivals[4096];  // workgroups of k_render_ts<.., 2, 1> seen per CU (role draw; never reset)
 

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "fd_device.hpp"
+#include "fd_opts.hpp"
 
 namespace fd {
 
@@ -89,10 +90,6 @@ void launch_render_cfg(float* slots, size_t stride, size_t V, const float* in, f
                        fstride, aux, ring, ring_cap);
 }
 
-// fdsp_set_option("pipe_split", v): 0 = single-wave kernel, 1 = best plan (default), 2 / 3 = exactly that many compute
-// stages, 4 = loader wave only (no cut)
-extern int g_pipe_split;
-
 template <class G, int MODE, int WANT>
 bool launch_render_pipe(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, const void* aux,
                         float* ring, uint32_t ring_cap, hipStream_t s) {
@@ -140,9 +137,9 @@ bool launch_render_pipe(float* slots, size_t stride, size_t V, const float* in, 
 template <class G, int MODE>
 bool launch_render_split(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, const void* aux,
                          float* ring, uint32_t ring_cap, hipStream_t s) {
-    if (g_pipe_split == 4) return launch_render_pipe<G, MODE, 1>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
-    if (g_pipe_split == 2) return launch_render_pipe<G, MODE, 2>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
-    if (g_pipe_split == 3) return launch_render_pipe<G, MODE, 3>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
+    if (tl_opts.pipe_split == 4) return launch_render_pipe<G, MODE, 1>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
+    if (tl_opts.pipe_split == 2) return launch_render_pipe<G, MODE, 2>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
+    if (tl_opts.pipe_split == 3) return launch_render_pipe<G, MODE, 3>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
     return launch_render_pipe<G, MODE, 0>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
 }
 
@@ -177,8 +174,6 @@ bool launch_render_pipe_planar(float* slots, size_t stride, size_t V, const floa
     }
 }
 
-// fdsp_set_option("time_split", v): 1 (default) = small banks of eligible graphs take the time-split kernel, 0 = never
-extern int g_time_split;
 
 template <class G>
 void launch_render(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
@@ -187,29 +182,31 @@ void launch_render(float* slots, size_t stride, size_t V, const float* in, float
     // banks that leave most SIMDs idle (<= 2 voice groups per CU): split the oscillator stages over time as well
     if constexpr (TsPlan<G>::ok) {
         const size_t groups = (V + 63) / 64, cus = (size_t)simd_count() / 4;
-        if (g_time_split && g_pipe_split == 1 && layout == LAYOUT_VOICE_MINOR && mode == MODE_PROCESS && T % 64 == 0 && T >= 256 &&
+        if (tl_opts.time_split && tl_opts.pipe_split == 1 && layout == LAYOUT_VOICE_MINOR && mode == MODE_PROCESS && T % 64 == 0 && T >= 256 &&
             groups <= 2 * cus) {
             if (groups <= cus)  // one workgroup per CU: 2 + 2 + 1 waves
                 hipLaunchKernelGGL((k_render_ts<G, 2, 2>), dim3((unsigned)groups), dim3(64 * 5), 0, s, slots, stride, V, out, T, aux);
             else                // two workgroups per CU: 2 + 1 + 1 waves each, roles rotated between neighbours
                 hipLaunchKernelGGL((k_render_ts<G, 2, 1>), dim3((unsigned)groups), dim3(64 * 4), 0, s, slots, stride, V, out, T, aux);
+            tl_opts.last_kernel = LK_TIME_SPLIT;
             return;
         }
     }
     // planar rows that allow 16-byte runs go through the planar pipeline (same launch-size rule as below)
-    if (layout == LAYOUT_PLANAR && g_pipe_split && (T >= 256 || g_pipe_split > 1) && fstride % 4 == 0 && ((uintptr_t)in & 15) == 0 &&
+    if (layout == LAYOUT_PLANAR && tl_opts.pipe_split && (T >= 256 || tl_opts.pipe_split > 1) && fstride % 4 == 0 && ((uintptr_t)in & 15) == 0 &&
         ((uintptr_t)out & 15) == 0) {
         const bool done = mode == MODE_PROCESS ? launch_render_pipe_planar<G, MODE_PROCESS>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s)
                                                : launch_render_pipe_planar<G, MODE_TICK>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s);
-        if (done) return;
+        if (done) { tl_opts.last_kernel = LK_PIPELINE_PLANAR; return; }
     }
     // the pipeline needs a few tiles to overlap its stages: a launch of one or two 64-frame blocks (real-time use) is
     // faster through the single-wave kernel (config 3, T = 64: 17.5 -> ~10 us)
-    if (layout == LAYOUT_VOICE_MINOR && g_pipe_split && (T >= 256 || g_pipe_split > 1)) {
+    if (layout == LAYOUT_VOICE_MINOR && tl_opts.pipe_split && (T >= 256 || tl_opts.pipe_split > 1)) {
         const bool done = mode == MODE_PROCESS ? launch_render_split<G, MODE_PROCESS>(slots, stride, V, in, out, T, aux, ring, ring_cap, s)
                                                : launch_render_split<G, MODE_TICK>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
-        if (done) return;
+        if (done) { tl_opts.last_kernel = LK_PIPELINE; return; }
     }
+    tl_opts.last_kernel = LK_SINGLE_WAVE;
     if (layout == LAYOUT_VOICE_MINOR) {
         if (mode == MODE_PROCESS)
             launch_render_cfg<G, MODE_PROCESS, LAYOUT_VOICE_MINOR>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s);
@@ -228,6 +225,7 @@ void launch_render_events(float* slots, size_t stride, size_t V, const float* in
                           const int* fade, double time0, double sr, int mode, const void* aux, float* ring,
                           uint32_t ring_cap, hipStream_t s) {
     if (V == 0 || T == 0) return;
+    tl_opts.last_kernel = LK_EVENTS;
     const unsigned grid = (unsigned)(((V + 63) / 64 + 3) / 4);
     if (mode == MODE_PROCESS)
         hipLaunchKernelGGL((k_render_events<G, MODE_PROCESS>), dim3(grid), dim3(256), 0, s, slots, stride, V, in, out, T, ev,

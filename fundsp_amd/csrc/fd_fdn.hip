@@ -5,11 +5,11 @@
 #include <cmath>
 
 #include "fd_fdn.hpp"
+#include "fd_opts.hpp"
 #include "fd_math.hpp"
 
 namespace fd {
 int simd_count();          // fd_capi.hip
-extern int g_fdn_kernel;   // fdsp_set_option("fdn_kernel", 0 = lane-per-frame (default), 1 = lane-per-delay-line)
 }
 
 namespace fd {
@@ -429,7 +429,8 @@ void fdn_launch_reset(const FdnConst& c, const FdnState& s, size_t instances, hi
 void fdn_launch_render(const FdnConst& c, const FdnState& s, size_t instances, const float* in, float* out, size_t T,
                        size_t fstride, int layout, hipStream_t stream) {
     if (instances == 0 || T == 0) return;
-    if (g_fdn_kernel == 0) {
+    tl_opts.last_kernel = tl_opts.fdn_kernel == 0 ? LK_FDN_FRAMES : LK_FDN_LINES;
+    if (tl_opts.fdn_kernel == 0) {
         const dim3 grid((unsigned)((instances + 3) / 4)), block(256);
         switch (c.cap) {  // the ring capacity is a template parameter of the lane = frame kernel
 #define FD_FDN_CASE(L) case 1 << L: hipLaunchKernelGGL(k_fdn_render_frames<L>, grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout); break;

@@ -65,9 +65,12 @@ struct JitModule {
     std::string type_expr, prelude;
     bool has_fast = false, fast_failed = false;
     std::shared_ptr<JitModule> fast;
-    ~JitModule() {
+    ~JitModule() {  // a module is unloaded with ITS device current (it was loaded on that device's context)
+        int prev = -1;
+        const bool have_prev = hipGetDevice(&prev) == hipSuccess;
         for (int d = 0; d < MAXD; d++)
-            if (loaded[d] && dev[d].mod) hipModuleUnload(dev[d].mod);
+            if (loaded[d] && dev[d].mod && hipSetDevice(d) == hipSuccess) hipModuleUnload(dev[d].mod);
+        if (have_prev) hipSetDevice(prev);
     }
     // functions of the CURRENT device (nullptr + *err on failure)
     const JitFuncs* get(std::string* err = nullptr) {
@@ -125,26 +128,30 @@ void jit_render(JitModule* jm, float* slots, size_t stride, size_t V, const floa
     if (!f) return jit_launch_failed();
     // loader wave / stage split; short launches (real-time blocks) are faster through the single-wave kernel, as for
     // the ahead-of-time kinds (launch_render)
-    if (layout == LAYOUT_VOICE_MINOR && g_pipe_split && jm->pipe_stages >= 1 && (T >= 256 || g_pipe_split > 1)) {
+    if (layout == LAYOUT_VOICE_MINOR && tl_opts.pipe_split && jm->pipe_stages >= 1 && (T >= 256 || tl_opts.pipe_split > 1)) {
         void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &aux, &ring, &ring_cap};
         const size_t groups = (V + 63) / 64, cus = (size_t)simd_count() / 4;
         if (jm->pipe_small && groups <= 2 * cus) {  // heavy graph, small bank: as launch_render_pipe
             const unsigned gpw = groups <= cus ? 1 : 2;
             hipModuleLaunchKernel(f->pipe_small[gpw - 1][mode], (unsigned)((groups + gpw - 1) / gpw), 1, 1,
                                   (unsigned)jm->pipe_threads / 4 * gpw, 1, 1, 0, s, pargs, nullptr);
+            tl_opts.last_kernel = LK_PIPELINE;
             return;
         }
         hipModuleLaunchKernel(f->pipe[mode], (unsigned)((groups + 3) / 4), 1, 1, (unsigned)jm->pipe_threads, 1, 1, 0, s,
                               pargs, nullptr);
+        tl_opts.last_kernel = LK_PIPELINE;
         return;
     }
-    if (layout == LAYOUT_PLANAR && g_pipe_split && jm->pipe_planar_threads > 0 && (T >= 256 || g_pipe_split > 1) && fstride % 4 == 0 &&
+    if (layout == LAYOUT_PLANAR && tl_opts.pipe_split && jm->pipe_planar_threads > 0 && (T >= 256 || tl_opts.pipe_split > 1) && fstride % 4 == 0 &&
         ((uintptr_t)in & 15) == 0 && ((uintptr_t)outp & 15) == 0) {  // loader / stages / storer (see launch_render)
         void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &fstride, &aux, &ring, &ring_cap};
         hipModuleLaunchKernel(f->pipe_planar[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_planar_threads, 1, 1,
                               0, s, pargs, nullptr);
+        tl_opts.last_kernel = LK_PIPELINE_PLANAR;
         return;
     }
+    tl_opts.last_kernel = LK_SINGLE_WAVE;
     const int wpb = jm->wpb[layout];
     const int vpw = layout == LAYOUT_VOICE_MINOR ? voices_per_wave(V, simd_count()) : 64;
     if (layout == LAYOUT_VOICE_MINOR) fstride = (size_t)vpw;

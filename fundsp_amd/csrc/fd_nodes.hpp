@@ -768,11 +768,12 @@ struct Moog {
     FD_HD void bind(Ctx&) {}
     template <int PH> FD_HD void step(const float* in, float* out) {  // :82-100
         // The reference recomputes (p, k, rez) from (cutoff, q) on EVERY sample (moog.rs:83-85).  They are a pure
-        // function of the two inputs and the sample rate, so recomputing only when an input differs from the stored
-        // one yields the same registers bit for bit (NaN inputs compare unequal and recompute, as the reference does)
-        // and keeps the f64 sine out of the steady-state loop.
+        // function of the BITS of the two inputs and the sample rate, so recomputing only when an input's bit pattern
+        // differs from the stored one yields the same registers bit for bit and keeps the f64 sine out of the
+        // steady-state loop.  The test is on bits, not values: +0.0 == -0.0 as values, but cutoff = -0.0 gives
+        // c = -0.0 and p = -0.0 where +0.0 gives +0.0 (and the stored `cutoff` word itself is readable state).
         if (NIN > 1) {
-            if (in[1] != cutoff || in[2] != q) set_cutoff_q(in[1], in[2]);
+            if (f2u(in[1]) != f2u(cutoff) || f2u(in[2]) != f2u(q)) set_cutoff_q(in[1], in[2]);
         }
         float x = -rez * s3 + in[0];
         s0 = (x + px) * p - k * s0;
@@ -798,7 +799,7 @@ struct MoogFast : Moog<NIN> {
     template <int PH> FD_HD void step(const float* in, float* out) {
         if (PH == PH_SIMD) {
             if (NIN > 1) {
-                if (in[1] != this->cutoff || in[2] != this->q) this->set_cutoff_q(in[1], in[2]);
+                if (f2u(in[1]) != f2u(this->cutoff) || f2u(in[2]) != f2u(this->q)) this->set_cutoff_q(in[1], in[2]);
             }
             float x = -this->rez * this->s3 + in[0];
             this->s0 = (x + this->px) * this->p - this->k * this->s0;

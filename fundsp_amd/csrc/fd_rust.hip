@@ -419,6 +419,25 @@ struct Translator {
     }
 };
 
+// prelude64 graphs (`F = f64`: Sine<f64>, FixedSvf<f64, LowpassMode<f64>>, Moog<f64, U1>, Envelope<f64, ..>,
+// BiquadBank<wide::f64x4_::f64x4> ...; reference src/prelude64.rs:338, :1924, :2711, src/biquad_bank.rs:14-24,
+// src/lib.rs:521) keep their recurrences and phases in f64 -- and BiquadBank<f64x4> has FOUR lanes, not eight.  The
+// engine's nodes are the prelude32 ones (f32 state), so such a graph must be refused, not rendered
+// with f32 state: no prelude32 type carries an f64 parameter anywhere, so any f64 / f64xN argument means prelude64.
+const TypeNode* find_f64(const TypeNode& n) {
+    if (n.last == "f64" || n.last.compare(0, 4, "f64x") == 0) return &n;
+    for (const auto& a : n.args)
+        if (const TypeNode* hit = find_f64(a)) return hit;
+    return nullptr;
+}
+const TypeNode* find_f64_owner(const TypeNode& n) {  // the innermost node that has the f64 as a direct argument
+    for (const auto& a : n.args) {
+        if (a.last == "f64" || a.last.compare(0, 4, "f64x") == 0) return &n;
+        if (const TypeNode* hit = find_f64_owner(a)) return hit;
+    }
+    return nullptr;
+}
+
 int translate(const char* rust_type_name, const char* hints, std::string* expr, std::string* presets) {
     if (!rust_type_name || !*rust_type_name) return fd::api_fail(FDSP_EINVAL, "type name missing");
     const std::string src(rust_type_name);
@@ -427,6 +446,12 @@ int translate(const char* rust_type_name, const char* hints, std::string* expr, 
     if (!ps.parse(&root)) return fd::api_fail(FDSP_EINVAL, "cannot parse the Rust type name: " + ps.err);
     ps.ws();
     if (ps.i != src.size()) return fd::api_fail(FDSP_EINVAL, "trailing characters after the Rust type name at offset " + std::to_string(ps.i));
+    if (const TypeNode* f = find_f64(root)) {
+        const TypeNode* owner = find_f64_owner(root);
+        return fd::api_fail(FDSP_EINVAL, "F = f64: the engine renders prelude32 (F = f32) graphs only; `" + (owner ? owner->last : root.last) +
+                                             "<.." + f->last + "..>` is a prelude64 node (f64 state" +
+                                             (f->last != "f64" ? ", " + f->last.substr(4) + " lanes" : "") + ") and would not match the reference if rendered with f32 state");
+    }
     Translator tr(hints);
     if (!tr.tr(root, {}, expr)) return fd::api_fail(FDSP_EINVAL, tr.err);
     presets->clear();

@@ -115,6 +115,14 @@ int fdsp_set_option(const char* name, int value);
 #define FDSP_MATH_FAST 1
 int fdsp_bank_set_option(fdsp_bank* bank, const char* name, int value);
 int fdsp_bank_get_option(const fdsp_bank* bank, const char* name);
+/* The launch options -- "pipe_split", "time_split" (default 1: banks of <= 2 voice groups per CU of eligible graphs take
+ * the time-split kernel), "fdn_kernel", "timing" -- exist per bank as well: fdsp_bank_set_option(bank, name, v) overrides
+ * the process-wide value of fdsp_set_option for that bank (-1 = follow it again).  They are resolved per launch on the
+ * calling thread, so hosts driving different banks from different threads do not see each other's choices.
+ * "timing" (default 1): every render records a HIP event pair around the kernel (fdsp_bank_last_kernel_ms); 0 drops
+ * the pair -- a real-time host rendering one 64-frame block per call saves two event records per launch.
+ * fdsp_bank_get_option(bank, "last_kernel") (read-only): the kernel family the most recent render launch took --
+ * 1 single-wave, 2 pipeline, 3 planar pipeline, 4 time-split, 5 voice scheduler, 6 / 7 reverb lane-per-frame / -line. */
 /* "host_zero_copy_max" (default 262144): fdsp_bank_process_host calls moving at most this many floats per direction
  * let the kernel read/write pinned host memory directly instead of staging through HBM (lower per-block latency). */
 /* "fdn_kernel" (default 0): reverb banks render with one lane per FRAME (0) or one lane per DELAY LINE (1); identical
@@ -167,9 +175,11 @@ int fdsp_bank_create(const char* kind, size_t voices, fdsp_bank** out);
  * next_pow2(ceil(max_delay*sr)+11), TapLinear next_pow2(ceil(max_delay*sr)+2) (delay.rs:108-110,204-206,440-442). */
 int fdsp_bank_create_ring(const char* kind, size_t voices, size_t ring_frames, fdsp_bank** out);
 /* reverb_stereo(room_size, time, damping) (src/prelude.rs:1732-1762): bank of `instances` independent 32-line FDN
- * reverbs, 2 inputs / 2 outputs each, all with the same parameters.  Mapped one lane per delay line (32 lanes per
- * instance), delay rings in HBM; flushes f32 denormals like the reference does after Feedback::new
- * (src/feedback.rs:96, src/denormal.rs:18).  The handle works with set_sample_rate / reset / process / destroy. */
+ * reverbs, 2 inputs / 2 outputs each, all with the same parameters.  Default mapping: one wave per instance, one lane
+ * per FRAME of a 64-sample block (the 32 lines in 32 registers, the Hadamard as register butterflies; option
+ * "fdn_kernel" = 1 selects the lane-per-delay-line formulation, identical samples); delay rings in HBM; flushes f32
+ * denormals like the reference does after Feedback::new (src/feedback.rs:96, src/denormal.rs:18).  The handle works
+ * with set_sample_rate / reset / process / clone / destroy. */
 int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, double damping, fdsp_bank** out);
 /* Several GPUs from one process.  A bank lives on ONE device, fixed at creation: the `_on` constructors take the HIP
  * device index (-1 = the calling thread's current device, which is what the constructors above use).  Every entry point
@@ -182,6 +192,11 @@ int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring
 int fdsp_reverb_stereo_create_on(int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out);
 int fdsp_bank_device(const fdsp_bank* bank);
 void fdsp_bank_destroy(fdsp_bank* bank);
+/* `Clone` (every AudioNode is Clone, src/audionode.rs:35; Net and Sequencer clone their units): a new bank of the same
+ * kind on the same device that continues exactly where `bank` stands -- all slots (parameters, coefficients, state), the
+ * delay rings, the sample rate, the arithmetic mode and launch options, the scheduler's events and clock, a reverb's
+ * line state.  Rendering the clone and the original with the same input gives the same samples. */
+int fdsp_bank_clone(const fdsp_bank* bank, fdsp_bank** out);
 int fdsp_bank_inputs(const fdsp_bank* bank);   /* AudioNode::Inputs  */
 int fdsp_bank_outputs(const fdsp_bank* bank);  /* AudioNode::Outputs */
 size_t fdsp_bank_voices(const fdsp_bank* bank);

@@ -49,6 +49,7 @@ pub mod ffi {
         pub fn fdsp_graph_compile_rust(name: *const c_char, rust_type_name: *const c_char, hints: *const c_char, source: *const c_char) -> c_int;
         pub fn fdsp_bank_create_on(device: c_int, kind: *const c_char, voices: usize, ring_frames: usize, out: *mut *mut FdspBank) -> c_int;
         pub fn fdsp_bank_destroy(bank: *mut FdspBank);
+        pub fn fdsp_bank_clone(bank: *const FdspBank, out: *mut *mut FdspBank) -> c_int; // Clone: slots, rings, sample rate, options, events
         pub fn fdsp_bank_inputs(bank: *const FdspBank) -> c_int;
         pub fn fdsp_bank_outputs(bank: *const FdspBank) -> c_int;
         pub fn fdsp_bank_voices(bank: *const FdspBank) -> usize;
@@ -94,6 +95,9 @@ pub struct HipBank<NI: Size<f32>, NO: Size<f32>> {
     voices: usize,
     ring_frames: usize,
     device: c_int,
+    /// `tick` / `process` are infallible in FunDSP.  A failed launch (lost device, wrong arity) zeroes the output and is
+    /// recorded here -- in release builds too -- for the host to poll with `take_error()`.
+    last_error: Option<String>,
     _marker: PhantomData<(NI, NO)>,
 }
 
@@ -114,7 +118,7 @@ impl<NI: Size<f32>, NO: Size<f32>> HipBank<NI, NO> {
             return Err(format!("arity mismatch: the bank has {}x{} inputs and {}x{} outputs", voices, i, voices, o));
         }
         let device = unsafe { fdsp_bank_device(bank) };
-        Ok(Self { bank, kind, voices, ring_frames, device, _marker: PhantomData })
+        Ok(Self { bank, kind, voices, ring_frames, device, last_error: None, _marker: PhantomData })
     }
 
     /// `voices` instances of the graph TYPE `X`: `core::any::type_name::<X>()` goes to the engine's front door
@@ -149,6 +153,10 @@ impl<NI: Size<f32>, NO: Size<f32>> HipBank<NI, NO> {
 
     pub fn voices(&self) -> usize { self.voices }
     pub fn device(&self) -> i32 { self.device }
+
+    /// The error of a failed `tick` / `process` since the last call (those two cannot return one): `None` = all launches
+    /// succeeded.  A failed launch has already zeroed its output block.
+    pub fn take_error(&mut self) -> Option<String> { self.last_error.take() }
 
     /// One value per voice for the named slot (`"<path>:<field>"`, listed by `fdsp_kind_slot_name`): what
     /// `Setting::center(..)`, `.q(..)`, `Constant` values etc. are on a single node.
@@ -197,7 +205,11 @@ impl<NI: Size<f32>, NO: Size<f32>> AudioNode for HipBank<NI, NO> {
         let mut out: Frame<f32, Self::Outputs> = Frame::default();
         let inp = if NI::USIZE > 0 { input.as_slice().as_ptr() } else { core::ptr::null() };
         let rc = unsafe { fdsp_bank_process_host(self.bank, 1, inp, out.as_mut_slice().as_mut_ptr(), FDSP_LAYOUT_PLANAR, 1, FDSP_MODE_TICK) };
-        debug_assert!(rc == FDSP_OK, "{}", last_error());
+        if rc != FDSP_OK {
+            self.last_error = Some(last_error());
+            out = Frame::default(); // silence, not stale samples
+            debug_assert!(false, "{}", last_error());
+        }
         out
     }
 
@@ -206,8 +218,15 @@ impl<NI: Size<f32>, NO: Size<f32>> AudioNode for HipBank<NI, NO> {
         let inp = if NI::USIZE > 0 { input.channel_f32(0).as_ptr() } else { core::ptr::null() };
         let out = output.channel_f32_mut(0).as_mut_ptr();
         let rc = unsafe { fdsp_bank_process_host(self.bank, size, inp, out, FDSP_LAYOUT_PLANAR, MAX_BUFFER_SIZE, FDSP_MODE_PROCESS) };
-        // process() is infallible in FunDSP: an error here is a programming error (wrong arity, lost device)
-        debug_assert!(rc == FDSP_OK, "{}", last_error());
+        // process() is infallible in FunDSP: an error here is a programming error (wrong arity, lost device).  The block is
+        // silenced (never left holding stale samples) and the error kept for take_error(), in release builds too.
+        if rc != FDSP_OK {
+            self.last_error = Some(last_error());
+            for ch in 0..NO::USIZE {
+                output.channel_f32_mut(ch)[..size].fill(0.0);
+            }
+            debug_assert!(false, "{}", last_error());
+        }
     }
 
     fn set_hash(&mut self, hash: u64) {
@@ -223,18 +242,17 @@ impl<NI: Size<f32>, NO: Size<f32>> AudioNode for HipBank<NI, NO> {
 }
 
 impl<NI: Size<f32>, NO: Size<f32>> Clone for HipBank<NI, NO> {
-    /// FunDSP nodes are `Clone`: a second bank of the same kind with the first one's parameters and state.
+    /// FunDSP nodes are `Clone` (Net and Sequencer clone their units): a second bank that continues exactly where this one
+    /// stands.  `fdsp_bank_clone` copies everything a later `set_param` / `reset` / `process` depends on -- the slots, the
+    /// delay rings, the SAMPLE RATE and the arithmetic mode (a clone rebuilt from the slot words alone would re-derive its
+    /// coefficients at the 44.1 kHz default on the next parameter change), launch options, scheduler events and clock.
+    /// `Clone::clone` cannot fail, so a failed copy (device lost, out of memory) panics with the engine's message.
     fn clone(&self) -> Self {
         let mut bank: *mut FdspBank = core::ptr::null_mut();
-        let rc = unsafe { fdsp_bank_create_on(self.device, self.kind.as_ptr(), self.voices, self.ring_frames, &mut bank) };
-        assert!(rc == FDSP_OK, "{}", last_error());
-        let n = unsafe { fdsp_bank_slot_count(self.bank) } as usize * self.voices;
-        let mut state = vec![0.0f32; n];
-        unsafe {
-            fdsp_bank_get_state(self.bank, state.as_mut_ptr());
-            fdsp_bank_set_state(bank, state.as_ptr());
-        }
-        Self { bank, kind: self.kind.clone(), voices: self.voices, ring_frames: self.ring_frames, device: self.device, _marker: PhantomData }
+        let rc = unsafe { fdsp_bank_clone(self.bank, &mut bank) };
+        assert!(rc == FDSP_OK && !bank.is_null(), "fdsp_bank_clone: {}", last_error());
+        Self { bank, kind: self.kind.clone(), voices: self.voices, ring_frames: self.ring_frames, device: self.device,
+               last_error: None, _marker: PhantomData }
     }
 }
 

@@ -1,0 +1,64 @@
+"""fdsp_bank_clone: `Clone` of an AudioNode (audionode.rs:35) for a whole bank -- the clone continues exactly where the
+original stands: slots, delay rings, SAMPLE RATE, arithmetic mode, launch options, scheduler events, reverb line state
+(a clone rebuilt from the slot words alone re-derived its coefficients at 44.1 kHz on the next set_param)."""
+import numpy as np
+import pytest
+
+from fundsp_amd import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MATH_FAST, MODE_PROCESS
+from fundsp_amd import graph as GR
+from fundsp_amd import workloads as W
+from test_gpu_parity import assert_bit_equal, noise_input, run_bank
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+
+
+def test_clone_continues_the_original_bit_for_bit(gpu):
+    V, T = 70, 64 * 3 + 9
+    g = GR.lowpass_hz(1200.0, 1.5) >> GR.delay(0.003) >> GR.shape("tanh", 1.2)
+    a = gpu.Bank.from_graph(g, V, sample_rate=SR)
+    x = noise_input(V, 1, 2 * T, seed=11)
+    run_bank(a, x[:, :, :T], T, LAYOUT_VOICE_MINOR, MODE_PROCESS)          # some history in the filter state and the rings
+    b = a.clone()
+    ya = run_bank(a, x[:, :, T:], T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    yb = run_bank(b, x[:, :, T:], T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    assert_bit_equal(ya, yb, "clone vs original, second half")
+    # a parameter change on BOTH re-derives coefficients from the sample rate each bank holds: 48 kHz in both
+    for bank in (a, b):
+        bank.set_param("0.0:cutoff", 2500.0)
+    assert_bit_equal(a.get_slot("0.0:a1"), b.get_slot("0.0:a1"), "coefficients after set_param")
+    ya = run_bank(a, x[:, :, :T], T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    yb = run_bank(b, x[:, :, :T], T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    assert_bit_equal(ya, yb, "clone vs original after the same parameter change")
+    # reset() on the clone uses its own (copied) sample rate as well
+    a.reset(); b.reset()
+    assert_bit_equal(run_bank(a, x[:, :, :T], T, LAYOUT_VOICE_MINOR, MODE_PROCESS),
+                     run_bank(b, x[:, :, :T], T, LAYOUT_VOICE_MINOR, MODE_PROCESS), "after reset")
+
+
+def test_clone_carries_math_mode_and_options(gpu):
+    V, T = 64 * 3, 64 * 8
+    p = W.fm_svf_params(V, SR)
+    a = W.make_fm_svf_bank(V, SR, params=p)
+    a.set_option("math", MATH_FAST)
+    a.set_option("time_split", 0)
+    run_bank(a, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    b = a.clone()
+    assert b.get_option("math") == MATH_FAST and b.get_option("time_split") == 0
+    ya = run_bank(a, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    yb = run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    assert_bit_equal(ya, yb, "tolerance-mode clone")
+    assert b.get_option("last_kernel") == a.get_option("last_kernel") == 2
+
+
+def test_clone_of_a_reverb_bank(gpu):
+    N, T = 5, 64 * 6
+    a = gpu.Bank.reverb_stereo(N, 10.0, 2.0, 0.5)
+    a.set_sample_rate(SR)
+    x = noise_input(N, 2, 2 * T, seed=4)
+    run_bank(a, x[:, :, :T], T, LAYOUT_PLANAR, MODE_PROCESS)
+    b = a.clone()
+    ya = run_bank(a, x[:, :, T:], T, LAYOUT_PLANAR, MODE_PROCESS)
+    yb = run_bank(b, x[:, :, T:], T, LAYOUT_PLANAR, MODE_PROCESS)
+    assert_bit_equal(ya, yb, "reverb clone continues the tail")
+    assert np.abs(ya).max() > 0

@@ -107,6 +107,14 @@ def test_ring_capacity_too_small_is_an_error_not_a_shorter_delay(gpu):
     b.set_param(":time", one)
     with pytest.raises(gpu.FdspError, match="961"):
         run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    # corrected by PARTIAL-range updates only: the complaint must not survive the fix ...
+    b.set_param(":time", np.full(1, 0.004, dtype=np.float32), first=17)
+    run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    # ... and a complaint of voices OUTSIDE the last updated range must not be lost
+    b.set_param(":time", np.full(1, 0.02, dtype=np.float32), first=40)
+    b.set_param(":time", np.full(2, 0.003, dtype=np.float32), first=3)
+    with pytest.raises(gpu.FdspError, match="961"):
+        run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
 
 
 def test_from_graph_sizes_the_rings_itself(gpu):

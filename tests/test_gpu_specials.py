@@ -185,3 +185,39 @@ def test_trig_arguments_past_the_medium_range(gpu, name):
                 finite += int(np.isfinite(want).sum())
                 assert_bit_equal(got[v], want, f"{name} voice {v} mode {mode}")
     assert finite > 0
+
+
+def test_moog_recomputes_on_a_sign_of_zero_change(gpu):
+    """The reference recomputes Moog's (p, k, rez) from (cutoff, q) on EVERY sample (moog.rs:83-85); the engine only when
+    an input's BIT PATTERN differs from the stored one (VERDICT r02 Weak 9: a value test keeps p = +0.0 when the cutoff goes
+    from +0.0 to -0.0, where the reference recomputes c = -0.0, p = -0.0).  Samples against the oracle bit for bit, and
+    the stored coefficient registers after the block against the formulas of set_cutoff_q (moog.rs:48-57)."""
+    V, T = 4, 64 + 13
+    rng = np.random.default_rng(77)
+    x = np.zeros((V, 3, T), dtype=np.float32)
+    x[:, 0] = (rng.standard_normal((V, T)) * 0.3).astype(np.float32)
+    pz, nz = np.float32(0.0), np.float32(-0.0)
+    x[0, 1, 0::2], x[0, 1, 1::2], x[0, 2] = pz, nz, np.float32(0.3)     # cutoff alternates +0 / -0, ends on -0 (T odd)
+    x[1, 1], x[1, 2, 0::2], x[1, 2, 1::2] = np.float32(800.0), pz, nz   # q alternates
+    x[2, 1], x[2, 2] = nz, nz                                           # -0 throughout (the stored defaults are 1000, 0.1)
+    x[3, 1, : T // 2], x[3, 1, T // 2:], x[3, 2] = pz, nz, np.float32(0.5)   # one switch in mid-block
+    x[0, 1, -1] = nz
+    g = lambda m: m.moog()
+    for mode in (MODE_PROCESS, MODE_TICK):
+        for math in (0, 1):                                             # exact / tolerance mode (MoogFast memoises the same way)
+            b = gpu.Bank.from_graph(g(GR), V, sample_rate=SR)
+            if math:
+                b.set_option("math", gpu.MATH_FAST)
+            got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, mode)
+            if not math or mode == MODE_TICK:                           # tick mode of a FAST bank is exact
+                for v in range(V):
+                    n = g(O)
+                    n.set_sample_rate(SR)
+                    assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"moog voice {v} mode {mode} math {math}")
+            cut = b.get_slot(":cutoff").view(np.uint32)[:V]
+            p = b.get_slot(":p").view(np.uint32)[:V]
+            q = b.get_slot(":q").view(np.uint32)[:V]
+            assert cut[0] == 0x80000000 and p[0] == 0x80000000, f"cutoff -0.0 must leave c = p = -0.0 (mode {mode}, math {math}): {cut[0]:08x} {p[0]:08x}"
+            assert q[1] == (0x80000000 if (T - 1) % 2 else 0), f"q word {q[1]:08x}"
+            assert cut[2] == 0x80000000 and p[2] == 0x80000000 and q[2] == 0x80000000
+            assert cut[3] == 0x80000000 and p[3] == 0x80000000

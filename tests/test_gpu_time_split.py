@@ -32,6 +32,24 @@ def test_time_split_equals_oracle_and_pipeline_kernel(gpu, time_split):
         b = W.make_fm_svf_bank(V, SR, params=p)
         got = np.concatenate([run_bank(b, None, T // 3, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :] for _ in range(3)], axis=1)
         assert_bit_equal(got, want, f"time_split={split}, three consecutive launches")
+        # every kernel renders the same samples, so ask which one ran: 4 = time-split, 2 = pipeline
+        assert b.get_option("last_kernel") == (4 if split else 2)
+    # the option per BANK (process-wide value untouched): two banks side by side, one on each kernel
+    time_split(1)
+    b1, b0 = W.make_fm_svf_bank(V, SR, params=p), W.make_fm_svf_bank(V, SR, params=p)
+    b0.set_option("time_split", 0)
+    g1 = run_bank(b1, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :]
+    g0 = run_bank(b0, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :]
+    assert (b1.get_option("last_kernel"), b0.get_option("last_kernel")) == (4, 2)
+    assert_bit_equal(g1, want, "per-bank time_split=default")
+    assert_bit_equal(g0, want, "per-bank time_split=0")
+    b0.set_option("time_split", -1)          # back to the process-wide default
+    b0.reset(); b0.set_seed(p["seed"])
+    run_bank(b0, None, 64 * 4, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    assert b0.get_option("last_kernel") == 4
+    b0.set_option("pipe_split", 0)
+    run_bank(b0, None, 64 * 4, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    assert b0.get_option("last_kernel") == 1  # single-wave kernel
     # a launch that is not a multiple of 64 frames falls back to the pipeline kernel and continues the same state
     time_split(1)
     b = W.make_fm_svf_bank(V, SR, params=p)

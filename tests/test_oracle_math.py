@@ -170,3 +170,26 @@ def test_powf_restatement_accuracy():
     assert L.o_math_powf(0.5, float("inf")) == 0.0 and L.o_math_powf(2.0, float("inf")) == float("inf")
     assert L.o_math_powf(10.0, 50.0) == float("inf") and L.o_math_powf(10.0, -50.0) == 0.0
     assert L.o_math_powf(0.5, 140.0) == np.float32(2.0 ** -140)        # subnormal result through scalbnf
+
+
+def test_exhaustive_ulp_sweep_program_and_its_committed_result():
+    """tests/host/ulp_sweep.c bounds EVERY restated libm / wide function over all 2^32 f32 inputs against double precision
+    (VERDICT r02 Next 1b: the sampled ranges above left tanf beyond +-1.55, expf / tanhf beyond +-12 and both atan forms
+    unbounded).  The full pass takes ~6 minutes on 8 cores and is committed as profiles/r03_math_ulp_exhaustive.txt; the
+    suite re-runs the same program on every 1021st bit pattern (all binades, ~1 s) and checks the committed full pass."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "host", "_build", "ulp_sweep")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-I", os.path.join(root, "oracle"),
+                           "-o", exe, os.path.join(root, "tests", "host", "ulp_sweep.c"), "-lm"])
+    r = subprocess.run([exe, "4", "1021"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "all 14 functions inside their bounds" in r.stdout
+    full = open(os.path.join(root, "profiles", "r03_math_ulp_exhaustive.txt")).read()
+    assert "ALL 2^32 f32 bit patterns (stride 1)" in full and "all 14 functions inside their bounds" in full
+    for name in ("sinf", "cosf", "tanf", "expf", "expm1f", "tanhf", "atanf", "powf(x,x)", "wide_sin", "wide_atan"):
+        line = next(l for l in full.splitlines() if l.startswith(name + " "))
+        assert line.endswith(": OK") and "class mismatches 0" in line, line
