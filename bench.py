@@ -36,44 +36,123 @@ TOTAL_VOICES = 65536   # BASELINE.json: "65536-voice SVF+FM graph"
 NATIVE_FLAGS = "-O3 -march=native -ffp-contract=off -fno-fast-math"
 
 
-def cpu_baseline(voices, frames, sample_rate, target_seconds):
-    """Time the CPU oracle on a bounded sample of the same workload, in both shapes SURVEY.md 8(d) names: process-shaped
-    (what Wave::render executes: Sine::process 8 frames per f32x8 item, the IIR leaves per sample) = `value`, and
-    tick-shaped (AudioNode::tick per sample, libm sinf).  Built on this host with NATIVE_FLAGS (oracle/Makefile `native`)."""
+def _native_oracle():
+    """(oracle module, ctypes handle of the -O3 -march=native build of oracle/ made on THIS host)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as O
-    from fundsp_amd import workloads as W
 
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"])
     L = C.CDLL(os.path.join(ROOT, "oracle", "_native", "libfundsp_oracle_native.so"))
     L.o_bank_render.restype = C.c_double
     L.o_bank_render.argtypes = [C.POINTER(O.BankJob), C.POINTER(C.c_float)]
+    L.o_fast_simd_flavour.restype = C.c_char_p
+    return O, L
+
+
+def cpu_baseline(voices, frames, sample_rate, target_seconds):
+    """Time the CPU restatement of the reference path on a bounded sample of the same workload, on this host's cores.
+    `value` = the MONOMORPHISED process() path (oracle/o_fast.c: what rustc makes of the statically typed graph -- no node
+    tree, both sines one 8-lane `wide` operation per 8 frames on the host's SIMD unit, the SVF per sample; bit-identical
+    to the generic oracle, tests/test_oracle_fast.py).  Also reported: the generic tree-walking oracle in the same shape
+    (`tree_walk_value`, round 1-2's figure) and tick-shaped (`tick_shaped_value`: AudioNode::tick per sample, libm sinf).
+    Built on this host with NATIVE_FLAGS (oracle/Makefile `native`)."""
+    from fundsp_amd import workloads as W
+
+    O, L = _native_oracle()
     cores = os.cpu_count() or 1
 
-    def timed(n, process):
+    def timed(n, process, fast):
         p = W.fm_svf_params(n, sample_rate)
         return O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], frames, sample_rate, process, 0, cores,
-                             store=False, lib=L)[1]
+                             store=False, lib=L, fast=fast)[1]
 
     out = {}
-    for shape, process in (("process", True), ("tick", False)):
-        s = timed(2 * cores, process)  # calibrate on a small sample, then size the timed sample for ~target_seconds / 2
+    shapes = (("fast", True, True, 0.5), ("tree", True, False, 0.25), ("tick", False, False, 0.25))
+    for shape, process, fast, share in shapes:
+        s = timed(2 * cores, process, fast)  # calibrate on a small sample, then size the timed sample for its share of the budget
         rate = 2 * cores * frames / max(s, 1e-6)
-        n = int(min(voices, max(cores, rate * 0.5 * target_seconds / frames)))
+        n = int(min(voices, max(cores, rate * share * target_seconds / frames)))
         n = max(cores, n // cores * cores)
-        s = timed(n, process)
+        s = timed(n, process, fast)
         out[shape] = (n * frames / s / 1e6, n, s)
-    v, n, s = out["process"]
+    v, n, s = out["fast"]
     return {
         "value": round(v, 3),
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
+        "simd": L.o_fast_simd_flavour().decode(),
+        "tree_walk_value": round(out["tree"][0], 3),
         "tick_shaped_value": round(out["tick"][0], 3),
-        "sample": f"{n} of the {voices} config-3 voices x {frames} frames, oracle process() path "
-                  f"(C restatement of the reference, gcc {NATIVE_FLAGS}), {cores} threads, {s:.2f} s; "
+        "sample": f"{n} of the {voices} config-3 voices x {frames} frames, monomorphised process() path of the reference restated in C "
+                  f"(oracle/o_fast.c: f32x8 sines as 8-lane vector code, SVF per sample; gcc {NATIVE_FLAGS}), {cores} threads, {s:.2f} s; "
+                  f"generic tree-walking oracle, same shape: {out['tree'][1]} voices, {out['tree'][2]:.2f} s; "
                   f"tick-shaped: {out['tick'][1]} voices, {out['tick'][2]:.2f} s",
     }
+
+
+def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
+    """cpu_baseline of a secondary entry (configs 2 / 4 / 5): the generic oracle (C restatement of the reference's process()
+    path) on a bounded sample.  Config 2 through the threaded bank driver (native build); configs 4 / 5 render one voice /
+    instance per host thread through the oracle's node API (the -O2 build the tests use)."""
+    import threading
+
+    import numpy as np
+
+    from fundsp_amd import workloads as W
+
+    O, L = _native_oracle()
+    cores = os.cpu_count() or 1
+    if config == 2:
+        n = 4 * cores
+        for _ in range(2):   # calibrate on a small sample, then size the timed one for ~target_seconds
+            p = W.noise_biquad_params(n, sample_rate)
+            s = O.bank_render(2, [p["fc"], p["q"]], p["seed"], frames, sample_rate, True, 0, cores, store=False, lib=L)[1]
+            if s > 0.3 * target_seconds:
+                break
+            n = max(cores, int(n * target_seconds / max(s, 1e-4)) // cores * cores)
+        return {"value": round(n * frames / s / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                "sample": f"{n} config-2 voices x {frames} frames, oracle process() path, {cores} threads, {s:.2f} s"}
+    nt = min(cores, 32)
+    fr = min(frames, 12000)
+    if config == 4:
+        p = W.saw_moog_params(nt, sample_rate)
+        gate = W.gate_signal(fr, sample_rate)[None, :]
+
+        def make(v):
+            g = (((O.dc(float(p["f"][v])) >> O.saw()) | O.dc(float(p["fc"][v])) | O.dc(float(p["q"][v]))) >> O.moog()) \
+                * O.adsr_live(0.01, 0.1, 0.6, 0.2) >> O.pan(float(p["pan"][v]))
+            g.set_sample_rate(sample_rate)
+            g.set_seed(int(p["seed"][v]))
+            return g, gate
+        unit, what = "Msamples/s", "config-4 voices"
+    else:
+        rng = np.random.default_rng(5)
+        x = (rng.random((2, fr), dtype=np.float32) * 2 - 1).astype(np.float32)
+
+        def make(v):
+            g = O.reverb_stereo(10.0, 2.0, 0.5)
+            g.set_sample_rate(sample_rate)
+            return g, x
+        unit, what = "M instance-frames/s", "reverb_stereo instances"
+    nodes = [make(v) for v in range(nt)]
+    t0 = time.perf_counter()
+    nodes[0][0].render_blocks(nodes[0][1])            # calibration (and page-in): one voice, one pass
+    reps = max(1, int(target_seconds / max(time.perf_counter() - t0, 1e-4)))
+
+    def work(gx):
+        for _ in range(reps):
+            gx[0].render_blocks(gx[1])
+    ths = [threading.Thread(target=work, args=(gx,)) for gx in nodes]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    s = time.perf_counter() - t0
+    return {"value": round(nt * fr * reps / s / 1e6, 3), "unit": unit, "cores": nt, "kind": "port",
+            "sample": f"{nt} {what} x {fr * reps} frames ({reps} passes of {fr}), one per host thread, oracle process() path "
+                      f"(generic node tree, gcc -O2), {s:.2f} s"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -164,6 +243,11 @@ def secondary(F, W, torch, sr, mode):
         wl = make_workload(F, W, torch, 2, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, "exact")
         ms, kms = quick(F, torch, wl, T, mode, steps=50 if T == 64 else 10, warmup=5)
         c2[f"T{T}"] = {"us_per_launch": round(ms * 1e3, 2), "kernel_us": round(kms * 1e3, 2), "value": round(V * T / ms / 1e3, 2)}
+        if T == 48000:
+            try:
+                c2["cpu_baseline"] = cpu_baseline_config(2, sr, 48000)
+            except Exception as e:
+                c2["cpu_baseline"] = {"error": repr(e)}
         if T == 64:  # the real-time pattern: one 64-frame block per launch, call by call vs replayed from a HIP graph
             NB = 32
             outs = [torch.empty_like(wl["out"]) for _ in range(NB)]
@@ -198,11 +282,93 @@ def secondary(F, W, torch, sr, mode):
                     "ms_per_step": round(ms, 4), "kernel_ms_avg": round(kms, 4), "value": round(V * T / ms / 1e3, 1), "unit": unit,
                     "algorithmic_bytes_per_unit": wl["bps"], "roofline_frac": round(algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "kernel": wl["kernel"]})
+        if math == "exact":
+            try:
+                out[-1]["cpu_baseline"] = cpu_baseline_config(cfg, sr, T)
+            except Exception as e:
+                out[-1]["cpu_baseline"] = {"error": repr(e)}
         del wl
+    # The path's one exchange step, on one GPU (VERDICT r02 Weak 6: it had no timing at all): config 4's stereo mix-down
+    # (fdsp_sum_voices: [2][frame][voice] -> [2][frame], fixed-order tree) on the render stream, then ONE all-reduce(sum)
+    # of [2][frames] through the product's collective (fdsp_mix_allreduce: RCCL inside libfundsp_hip.so, on the
+    # communicator's side stream, 1 rank here), overlapped with the next render.
+    try:
+        V, T = 32768, 48000
+        wl = make_workload(F, W, torch, 4, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, "exact")
+        comm = F.Comm.local([0])
+        bank = wl["bank"]
+        ms_render, kms = quick(F, torch, wl, T, mode, steps=3, warmup=1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        mix = F.sum_voices(wl["out"])
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            mix = F.sum_voices(wl["out"])
+        e1.record()
+        torch.cuda.synchronize()
+        mix_ms = e0.elapsed_time(e1) / 5
+        t0 = time.perf_counter()
+        for _ in range(20):
+            comm.allreduce(mix, slot=0)
+            comm.wait(0)
+        ar_us = (time.perf_counter() - t0) / 20 * 1e6
+        keep = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            bank.process(T, wl["inp"], wl["out"], layout=wl["layout"], frame_stride=wl["fs"], mode=mode)
+            keep.append(F.sum_voices(wl["out"]))
+            comm.allreduce(keep[-1], slot=0)
+        comm.wait(0)
+        torch.cuda.synchronize()
+        ms_all = (time.perf_counter() - t0) / 4 * 1e3
+        out.append({"name": "config4_mix_single_rank", "what": "BASELINE config 4 per-GPU shard (32768 voices x 48000 frames) with the path's exchange "
+                    "step: fdsp_sum_voices on the render stream + one fdsp_mix_allreduce of [2][48000] f32 (RCCL inside the library, side stream, "
+                    "1-rank communicator), overlapped with the next render", "ms_per_step_render_only": round(ms_render, 4),
+                    "ms_per_step_with_mix_and_allreduce": round(ms_all, 4), "mix_kernel_ms": round(mix_ms, 4),
+                    "mix_read_gbs": round(V * T * 8 / (mix_ms * 1e-3) / 1e9, 1), "allreduce_blocking_us_1rank": round(ar_us, 1),
+                    "value": round(V * T / ms_all / 1e3, 1), "unit": "Msamples/s"})
+        comm.close()
+        del wl, keep, mix
+    except Exception as e:
+        out.append({"name": "config4_mix_single_rank", "error": repr(e)})
     return out
 
 
-def main():
+class Peers:
+    """How the ranks of one bench run meet: barrier, max-over-ranks, and the mix-down communicator.
+
+    * world == 1: nothing to meet.
+    * one process per GPU (the driver's `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`): torch.distributed
+      carries the barrier, the max and -- once -- the 128-byte RCCL id; the mix-down itself goes through the product's own
+      collective, fdsp_mix_allreduce (RCCL inside libfundsp_hip.so), NOT through torch.distributed.
+    * one process driving N GPUs (`python bench.py --gpus N` as typed, no RANK in the environment): N host threads, a
+      threading.Barrier, one local communicator (fdsp_comm_create_local = ncclCommInitAll), slot k = device k."""
+
+    def __init__(self, world, rank=0, dist=None, thread_barrier=None, shared=None, comm=None, slot=0):
+        self.world, self.rank, self.dist, self.tb, self.shared, self.comm, self.slot = world, rank, dist, thread_barrier, shared, comm, slot
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        elif self.tb is not None:
+            self.tb.wait()
+
+    def max(self, x, torch):
+        if self.dist is not None:
+            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return float(t.item())
+        if self.tb is not None:
+            self.shared[self.rank] = x
+            self.tb.wait()
+            m = max(self.shared)
+            self.tb.wait()
+            return m
+        return x
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -217,48 +383,129 @@ def main():
     ap.add_argument("--sample-rate", type=float, default=48000.0)
     ap.add_argument("--layout", choices=["voice_minor", "planar"], default="voice_minor")
     ap.add_argument("--mode", choices=["process", "tick"], default="process")
-    ap.add_argument("--mix", action="store_true", help="add on-device stereo mix-down + all-reduce per step")
+    ap.add_argument("--mix", action="store_true", help="add the on-device stereo mix-down + fdsp_mix_allreduce (RCCL inside the library, side stream) per step")
     ap.add_argument("--pipe-split", type=int, default=1, choices=[0, 1, 2, 3],
                     help="pipeline split of Pipe-chain kinds: 0 off, 1 best plan (default), 2 / 3 = that many stages")
     ap.add_argument("--math", choices=["exact", "fast"], default="exact",
                     help="exact = the reference's arithmetic, bit-identical to the oracle (headline); fast = tolerance mode (FDSP_MATH_FAST)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall-time budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs 2 / 4 / 5, tolerance mode)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_plan(args, env, device_count):
+    """How `bench.py --gpus N` runs.  -> ("single", None) | ("torchrun-rank", (rank, world, local_rank)) | ("threads", N).
+    Raises SystemExit with a message about DEVICES (never about launchers) when the box has too few."""
+    world = int(env.get("WORLD_SIZE", "1"))
+    if "RANK" in env and world > 1:
+        if world != args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus} was started under a launcher with WORLD_SIZE={world}: the two must agree")
+        return "torchrun-rank", (int(env["RANK"]), world, int(env.get("LOCAL_RANK", "0")))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    n = device_count()
+    if n < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: {args.gpus} HIP device{'s' if args.gpus > 1 else ''} needed, {n} present "
+                         f"(the product path has no CPU fallback)")
+    return ("single", None) if args.gpus == 1 else ("threads", args.gpus)
+
+
+def main(argv=None):
+    args = parse_args(argv)
 
     import torch
 
+    plan, info = launch_plan(args, os.environ, lambda: torch.cuda.device_count() if torch.cuda.is_available() else 0)
+
     import fundsp_amd as F
+    from fundsp_amd import _lib
+
+    if args.pipe_split != 1:
+        assert _lib.lib().fdsp_set_option(b"pipe_split", args.pipe_split) == 0
+    if plan == "threads":   # one process, N GPUs, N host threads: `python bench.py --gpus N` as typed
+        import threading
+
+        n = info
+        comm = F.Comm.local(list(range(n))) if args.mix else None
+        tb, shared, results, errors = threading.Barrier(n), [0.0] * n, [None] * n, []
+
+        def body(k):
+            try:
+                torch.cuda.set_device(k)
+                results[k] = run_rank(args, torch, F, Peers(n, k, thread_barrier=tb, shared=shared, comm=comm, slot=k), k)
+            except BaseException as e:   # a dead thread must not leave the others waiting at the barrier
+                errors.append(e)
+                tb.abort()
+        threads = [threading.Thread(target=body, args=(k,)) for k in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        if comm is not None:
+            comm.close()
+        print(json.dumps(results[0]), flush=True)
+        return
+    if plan == "torchrun-rank":
+        import torch.distributed as dist
+
+        rank, world, local_rank = info
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        comm = None
+        if args.mix:   # the RCCL id travels over torch.distributed ONCE; every all-reduce of the run is the library's own
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(F.Comm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            comm = F.Comm.rank(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+        res = run_rank(args, torch, F, Peers(world, rank, dist=dist, comm=comm), local_rank)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        dist.barrier()
+        if comm is not None:
+            comm.close()
+        dist.destroy_process_group()
+        return
+    torch.cuda.set_device(0)
+    comm = F.Comm.local([0]) if args.mix else None
+    print(json.dumps(run_rank(args, torch, F, Peers(1, 0, comm=comm), 0)), flush=True)
+    if comm is not None:
+        comm.close()
+
+
+def mix_step(F, torch, args, wl, peers):
+    """The path's one exchange step: per-GPU stereo mix-down on the render stream, then ONE all-reduce(sum) of [2][frames] f32
+    through fdsp_mix_allreduce on the communicator's side stream -- the next render does not wait for it."""
+    if args.config in (2, 3):
+        mix = F.mix_stereo(wl["out"][0] if wl["layout"] == F.LAYOUT_VOICE_MINOR else wl["out"][:, 0, :].t().contiguous())
+    elif args.config == 5:
+        mix = wl["out"].sum(dim=0)     # [2][T] sum over instances (planar layout)
+    else:
+        mix = F.sum_voices(wl["out"])  # voices are already panned to stereo
+    peers.comm.allreduce(mix, slot=peers.slot)
+    return mix
+
+
+def run_rank(args, torch, F, peers, device):
+    """One rank's share of the run (a process under torch.distributed.run, or a host thread of a one-process run).
+    Returns the result record on rank 0, None elsewhere."""
     from fundsp_amd import dist as fdist
     from fundsp_amd import workloads as W
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the product path)"
-    torch.cuda.set_device(local_rank)
+    rank, world = peers.rank, peers.world
     distributed = world > 1
-    if distributed:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    if args.pipe_split != 1:
-        from fundsp_amd import _lib
-        assert _lib.lib().fdsp_set_option(b"pipe_split", args.pipe_split) == 0
     base_voices = args.voices or {2: 1024, 3: TOTAL_VOICES, 4: 32768, 5: 2048}[args.config]
     T, sr = args.frames, args.sample_rate
     layout = F.LAYOUT_VOICE_MINOR if args.layout == "voice_minor" else F.LAYOUT_PLANAR
     mode = F.MODE_PROCESS if args.mode == "process" else F.MODE_TICK
 
     def fence():
-        if distributed:
-            dist.barrier()
+        torch.cuda.synchronize()
+        peers.barrier()
         torch.cuda.synchronize()
 
     def timed_run(scaling, steps, warmup):
@@ -269,17 +516,13 @@ def main():
             first, V = rank * base_voices, base_voices
         wl = make_workload(F, W, torch, args.config, V, T, sr, first, layout, args.math)
         bank = wl["bank"]
+        mixes = []
 
         def step():
             bank.process(T, wl["inp"], wl["out"], layout=wl["layout"], frame_stride=wl["fs"], mode=mode)
             if args.mix:
-                if args.config in (2, 3):
-                    mix = F.mix_stereo(wl["out"][0] if wl["layout"] == F.LAYOUT_VOICE_MINOR else wl["out"][:, 0, :].t().contiguous())
-                elif args.config == 5:
-                    mix = wl["out"].sum(dim=0)     # [2][T] sum over instances (planar layout)
-                else:
-                    mix = F.sum_voices(wl["out"])  # voices are already panned to stereo
-                fdist.allreduce_mix(mix)
+                mixes.append(mix_step(F, torch, args, wl, peers))
+                del mixes[:-2]   # the side stream may still be summing the previous one
 
         # untimed spin-up before the W warm-up steps: an idle MI355X sits at a 600 MHz shader clock and needs a few
         # hundred ms of work to reach its operating point (W = 2 steps are 10 ms; measured 5.27 vs 5.18 ms/step)
@@ -297,12 +540,10 @@ def main():
             # HIP events recorded by the C ABI on the launch stream around the render kernel (reading here synchronises
             # on that launch, which the next step's launch on the same stream is ordered behind anyway)
             kernel_ms.append(bank.last_kernel_ms())
+        if args.mix:
+            peers.comm.wait(peers.slot)   # the last all-reduce belongs to the timed region
         fence()
-        elapsed = time.perf_counter() - t0
-        if distributed:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        elapsed = peers.max(time.perf_counter() - t0, torch)
         return elapsed, kernel_ms, wl, V
 
     elapsed, kernel_ms, wl, V = timed_run(args.scaling, args.steps, args.warmup)
@@ -321,6 +562,8 @@ def main():
     else:
         kernel_label, shard_bps, shard_slots = wl["kernel"], wl["bps"], wl["slot_bytes"]
         del wl
+    if rank != 0:
+        return None
 
     # also relate the kernel to what this box's HBM delivers to plain streaming kernels (a 2 GiB
     # device-to-device copy = read + write, and a fill = write only, the kernel's own traffic shape), outside the timed region
@@ -395,6 +638,9 @@ def main():
                 "frames_per_step": T,
                 "layout": "planar" if args.config == 5 else args.layout,
                 "mix_allreduce": bool(args.mix),
+                "mix_collective": ("fdsp_mix_allreduce (RCCL inside libfundsp_hip.so, communicator side stream)" if args.mix else None),
+                "launch": ("one process per GPU (torch.distributed.run)" if peers.dist is not None else
+                           "one process, one host thread per GPU" if world > 1 else "one process, one GPU"),
                 "math": args.math,
                 "parallelism": f"voice-shard x{world}",
                 "scaling_alt": scaling_alt,
@@ -423,11 +669,7 @@ def main():
                 res["secondary"] = secondary(F, W, torch, sr, mode)
             except Exception as e:  # never lose the headline line to a secondary measurement
                 res["secondary"] = [{"error": repr(e)}]
-        print(json.dumps(res), flush=True)
-
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+        return res
 
 
 if __name__ == "__main__":

@@ -620,6 +620,12 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
 #ifndef FD_LP_ENABLE
 #define FD_LP_ENABLE 1  // A/B switch (tools/build_variants.sh): 0 = always the generic SVF arithmetic
 #endif
+#ifndef FD_PIPE_BUFFER_STORE
+#define FD_PIPE_BUFFER_STORE 1  // A/B switch: 0 = plain global stores (per-frame 64-bit vector address arithmetic)
+#endif
+#ifndef FD_PIPE_PRIO
+#define FD_PIPE_PRIO 0          // A/B switch: 1 = the LAST compute stage's waves run at s_setprio 1, 2 = the first stage's
+#endif
 #ifndef FD_KNOCK
 #define FD_KNOCK 0      // measurement only (NOT a renderer): compute stage FD_KNOCK - 1 of the pipeline kernel idles, so the other
 #endif                  // stage's wave has its SIMD to itself; the hand-over tiles start zeroed (profiles/r03_knockout_c3.txt)
@@ -943,9 +949,27 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
     const int lo = h * SUB;
     const int hi = lo + SUB < size ? lo + SUB : size;
     const int shi = hi < full ? hi : full;  // end of the packed part inside this tile
+    // Voice-minor output rows leave through buffer stores: the resource's base is this tile's first row (wave-uniform,
+    // SALU arithmetic once per tile), the frame's row offset travels in the instruction's SCALAR offset and lane * 4 is
+    // the only VGPR -- no per-frame 64-bit vector address arithmetic in a VALU-bound loop (it was one v_lshl_add_u64
+    // per frame).  Rows of a tile span at most SUB * V * 4 bytes < 2^32 (V < 2^24 voices per bank).
+#if FD_PIPE_BUFFER_STORE
+    __amdgpu_buffer_rsrc_t orow[OL == 0 ? NO : 1];
+    if constexpr (OL == 0) {
+#pragma unroll
+        for (int c = 0; c < NO; c++)
+            orow[c] = __builtin_amdgcn_make_buffer_rsrc(outw + ((size_t)c * T + t0 + lo) * V, 0, (int)0xffffffffu, 0x00020000);
+    }
+    const int vrow = (int)(V * sizeof(float));
+#endif
     auto put = [&](int c, int i, float x) {  // i = frame index inside the block
-        if constexpr (OL == 0) outw[((size_t)c * T + t0 + i) * V + lane] = x;
-        else outw[(c * SUB + (i - lo)) * FS + lane] = x;
+        if constexpr (OL == 0) {
+#if FD_PIPE_BUFFER_STORE
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(x), orow[c], lane * 4, (i - lo) * vrow, 0);
+#else
+            outw[((size_t)c * T + t0 + i) * V + lane] = x;
+#endif
+        } else outw[(c * SUB + (i - lo)) * FS + lane] = x;
     };
     if (h == 0) SG::begin(g, size);
     if (lo < shi) {
@@ -1233,6 +1257,11 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     bool lp = false;
     if constexpr (!SameType<GL, G>::v && MODE == MODE_PROCESS && FD_LP_ENABLE)
         lp = __builtin_amdgcn_ballot_w64((live && active) && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(live && active) != 0ull;
+#if FD_PIPE_PRIO == 1
+    if (stage == S - 1) __builtin_amdgcn_s_setprio(1);
+#elif FD_PIPE_PRIO == 2
+    if (stage == 0) __builtin_amdgcn_s_setprio(1);
+#endif
     if (lp) rounds_of((GL*)nullptr); else rounds_of((G*)nullptr);
     if (live && active) {
         VStore<false> st{slots + v, stride, 0};

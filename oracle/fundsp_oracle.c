@@ -2805,3 +2805,31 @@ void o_render_ticks(onode *n, size_t length, const float *in, float *out) {
         for (int c = 0; c < n->nout; c++) out[(size_t)c * length + i] = fo[c];
     }
 }
+
+
+/* ---- state of a config-3 voice, for the monomorphic CPU baseline (o_fast.c) -------------------------------------
+ * g = Pipe(Pipe(Unop(+f, Unop(*m, Unop(*f, Pipe(Constant, Sine)))), Sine), FixedSvf), as o_bank.c builds it.
+ * Returns 0 and fills the registers a hand-monomorphised process() keeps, or -1 if the tree has another shape. */
+int o_fm_svf_state(const onode *g, o_fm_svf_regs *r) {
+    if (!g || g->type != O_PIPE || !g->x || g->x->type != O_PIPE || !g->y || g->y->type != O_FIXED_SVF) return -1;
+    const onode *svf = g->y, *car = g->x->y, *e = g->x->x;
+    if (!car || car->type != O_SINE || !e || e->type != O_UNOP || e->op != O_ADD_SCALAR) return -1;
+    const onode *e1 = e->x;
+    if (!e1 || e1->type != O_UNOP || e1->op != O_MUL_SCALAR) return -1;
+    const onode *e2 = e1->x;
+    if (!e2 || e2->type != O_UNOP || e2->op != O_MUL_SCALAR) return -1;
+    const onode *mod = e2->x;
+    if (!mod || mod->type != O_PIPE || !mod->x || mod->x->type != O_CONSTANT || !mod->y || mod->y->type != O_SINE) return -1;
+    r->f_const = mod->x->s.value[0];
+    r->mul_f = e2->scalar;
+    r->mul_m = e1->scalar;
+    r->add_f = e->scalar;
+    r->mod_phase = mod->y->s.phase;
+    r->mod_sd = mod->y->s.sample_duration;
+    r->car_phase = car->s.phase;
+    r->car_sd = car->s.sample_duration;
+    r->a1 = svf->s.sc.a1; r->a2 = svf->s.sc.a2; r->a3 = svf->s.sc.a3;
+    r->m0 = svf->s.sc.m0; r->m1 = svf->s.sc.m1; r->m2 = svf->s.sc.m2;
+    r->ic1eq = svf->s.ic1eq; r->ic2eq = svf->s.ic2eq;
+    return 0;
+}

@@ -198,6 +198,17 @@ typedef struct {
     const uint64_t *seed;
 } o_bank_job;
 double o_bank_render(const o_bank_job *job, float *out);
+/* The same config-3 render through a MONOMORPHISED process() (oracle/o_fast.c): what rustc makes of the reference's
+ * statically typed graph -- no node tree, no switch per node per block, both sines 8 frames per vector exactly as
+ * Sine::process (oscillator.rs:74-86) with `wide`'s f32x8 arithmetic on the host's SIMD unit, the SVF per sample.
+ * Bit-identical to o_bank_render (tests/test_oracle_fast.py); bench.py's cpu_baseline.value.  config 3, process mode. */
+typedef struct {
+    float f_const, mul_f, mul_m, add_f, mod_phase, mod_sd, car_phase, car_sd, a1, a2, a3, m0, m1, m2, ic1eq, ic2eq;
+} o_fm_svf_regs;
+int o_fm_svf_state(const onode *g, o_fm_svf_regs *r);
+onode *o_bank_build_voice(const o_bank_job *job, size_t v);
+double o_bank_render_fast(const o_bank_job *job, float *out);
+const char *o_fast_simd_flavour(void);
 
 #ifdef __cplusplus
 }

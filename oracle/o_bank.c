@@ -40,6 +40,8 @@ typedef struct {
     size_t v0, v1;
 } slice;
 
+onode *o_bank_build_voice(const o_bank_job *job, size_t v) { return build_voice(job, v); }
+
 static void *run_slice(void *arg) {
     slice *s = (slice *)arg;
     const o_bank_job *job = s->job;

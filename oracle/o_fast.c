@@ -1,0 +1,192 @@
+/*
+ * oracle/o_fast.c -- TEST INFRASTRUCTURE ONLY (bench.py's cpu_baseline leg; never linked into the product).
+ *
+ * BASELINE config 3, `sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q)`, rendered the way the compiled Rust
+ * reference renders it: FunDSP graphs are statically typed, so rustc monomorphises Pipe<Pipe<Unop<..>, Sine>, FixedSvf>::
+ * process into one straight function per block -- no node tree, no dispatch -- and Sine::process evaluates its sine as ONE
+ * `wide::f32x8` operation per 8 frames (AVX on x86-64).  o_bank.c walks a heap tree with a switch per node per block
+ * and loops over the 8 "SIMD" lanes in scalar code (VERDICT r02 Weak 7: "likely several times slower than the Rust
+ * path it stands for").  This file is that monomorphised form:
+ *   Constant::process            audionode.rs:491-497   splat per SIMD item
+ *   Sine::process                oscillator.rs:74-86    8 serial phase steps, then (F32x::new(element) * TAU).sin()
+ *   Unop::process                audionode.rs:1292-1303 one vector op per item (same arithmetic per lane as the scalar form)
+ *   FixedSvf (default process)   audionode.rs:85-105 -> tick svf.rs:995-1006, per sample
+ *   remainders                   process_remainder audionode.rs:110-126 -> tick (libm sinf, wrapped phase)
+ * The 8-lane sine is `wide`'s algorithm (o_math.h o_wide_sinf, lane for lane) on GCC vector types: with -march=native it
+ * compiles to the host's 256-bit unit, exactly the operations of the scalar restatement -> bit-identical to o_bank_render
+ * (asserted in tests/test_oracle_fast.py), only faster.
+ */
+#include "fundsp_oracle.h"
+#include "o_math.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+typedef float v8f __attribute__((vector_size(32)));
+typedef int32_t v8i __attribute__((vector_size(32)));
+typedef uint32_t v8u __attribute__((vector_size(32)));
+
+#if defined(__AVX2__)
+#include <immintrin.h>
+const char *o_fast_simd_flavour(void) { return "AVX2 (256-bit, GCC vector types + vroundps / vcvtps2dq)"; }
+static inline v8f v8_rint(v8f x) { return (v8f)_mm256_round_ps((__m256)x, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+/* wide f32x8::round_int, x86 form: cvtps2dq, NaN lanes masked to 0, lanes >= 2^31 flipped to i32::MAX */
+static inline v8i v8_round_int_sat(v8f y) {
+    v8i q = (v8i)_mm256_cvtps_epi32((__m256)y);
+    const v8f big = {2147483648.0f, 2147483648.0f, 2147483648.0f, 2147483648.0f, 2147483648.0f, 2147483648.0f, 2147483648.0f, 2147483648.0f};
+    v8i is_big = (v8i)(y >= big), is_nan = (v8i)(y != y);
+    const v8i imax = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX};
+    q = (q & ~is_big) | (imax & is_big);
+    return q & ~is_nan;
+}
+#else
+const char *o_fast_simd_flavour(void) { return "portable GCC vector types (no AVX2 on the build host)"; }
+static inline v8f v8_rint(v8f x) {
+    v8f r;
+    for (int i = 0; i < 8; i++) r[i] = o_round_half_even(x[i]);
+    return r;
+}
+static inline v8i v8_round_int_sat(v8f y) {
+    v8i q;
+    for (int i = 0; i < 8; i++) q[i] = o_round_int_sat(y[i]);
+    return q;
+}
+#endif
+
+static inline v8f v8_splat(float x) { return (v8f){x, x, x, x, x, x, x, x}; }
+static inline v8i v8_splati(int32_t x) { return (v8i){x, x, x, x, x, x, x, x}; }
+
+/* o_wide_sinf (o_math.h), eight lanes at once: the same operations in the same order, unfused */
+static inline v8f wide_sin8(v8f self) {
+    const v8f DP1F = v8_splat(0.78515625f * 2.0f), DP2F = v8_splat(2.4187564849853515625E-4f * 2.0f),
+              DP3F = v8_splat(3.77489497744594108E-8f * 2.0f);
+    const v8f P0s = v8_splat(-1.6666654611E-1f), P1s = v8_splat(8.3321608736E-3f), P2s = v8_splat(-1.9515295891E-4f);
+    const v8f P0c = v8_splat(4.166664568298827E-2f), P1c = v8_splat(-1.388731625493765E-3f), P2c = v8_splat(2.443315711809948E-5f);
+    const v8f TWO_OVER_PI = v8_splat(2.0f / 3.14159274101257324f);
+    const v8u ABS = (v8u)v8_splati(0x7fffffff);
+    v8f xa = (v8f)((v8u)self & ABS);
+    v8f y = v8_rint(xa * TWO_OVER_PI);
+    v8i q = v8_round_int_sat(y);
+    v8f x = xa - y * DP1F;
+    x = x - y * DP2F;
+    x = x - y * DP3F;
+    v8f x2 = x * x;
+    v8f x4 = x2 * x2;
+    v8f s = (x4 * P2s + (x2 * P1s + P0s)) * (x * x2) + x;
+    v8f c = (x4 * P2c + (x2 * P1c + P0c)) * (x2 * x2) + (v8_splat(1.0f) - v8_splat(0.5f) * x2);
+    v8i swap = (q & v8_splati(1)) != v8_splati(0);
+    const v8f INF = v8_splat(__builtin_inff());
+    v8i overflow = (q > v8_splati(0x2000000)) & (v8i)(xa < INF);
+    s = (v8f)(((v8i)s & ~overflow));                                         /* overflow ? 0.0 : s */
+    c = (v8f)(((v8i)c & ~overflow) | ((v8i)v8_splat(1.0f) & overflow));      /* overflow ? 1.0 : c */
+    v8i sin1 = ((v8i)c & swap) | ((v8i)s & ~swap);
+    v8u sign_sin = ((v8u)q << 30) ^ (v8u)self;
+    return (v8f)((v8u)sin1 ^ (sign_sin & (v8u)v8_splati((int32_t)0x80000000u)));
+}
+
+/* one block (size <= 64) of one voice; out[64] */
+static inline void fm_svf_block(o_fm_svf_regs *r, int size, float *out) {
+    const float TAU = 6.28318548202514648f;
+    const int full = size & ~7;
+    v8f car[8]; /* carrier samples of the full items, then filtered per sample */
+    float mp = r->mod_phase, cp = r->car_phase;
+    const v8f vf = v8_splat(r->mul_f), vm = v8_splat(r->mul_m), va = v8_splat(r->add_f), vtau = v8_splat(TAU);
+    for (int i = 0; i < full; i += 8) {
+        v8f el;
+        for (int j = 0; j < 8; j++) { /* modulator Sine::process: the Constant's splat is its input */
+            el[j] = mp;
+            mp += r->f_const * r->mod_sd;
+        }
+        v8f mod = wide_sin8(el * vtau);
+        v8f fr = mod * vf * vm + va; /* Unop chain: ((x * f) * m) + f, each a separate rounding (-ffp-contract=off) */
+        for (int j = 0; j < 8; j++) { /* carrier Sine::process */
+            el[j] = cp;
+            cp += fr[j] * r->car_sd;
+        }
+        car[i >> 3] = wide_sin8(el * vtau);
+    }
+    mp = mp - floorf(mp); /* oscillator.rs:85: one wrap after the SIMD items */
+    cp = cp - floorf(cp);
+    float tail[8];
+    for (int i = full; i < size; i++) { /* process_remainder -> tick: wrapped phase, libm sinf */
+        float p = mp;
+        mp += r->f_const * r->mod_sd;
+        mp -= floorf(mp);
+        float fr = o_sinf(p * TAU) * r->mul_f * r->mul_m + r->add_f;
+        p = cp;
+        cp += fr * r->car_sd;
+        cp -= floorf(cp);
+        tail[i - full] = o_sinf(p * TAU);
+    }
+    r->mod_phase = mp;
+    r->car_phase = cp;
+    float ic1 = r->ic1eq, ic2 = r->ic2eq;
+    const float a1 = r->a1, a2 = r->a2, a3 = r->a3, m0 = r->m0, m1 = r->m1, m2 = r->m2;
+    for (int i = 0; i < size; i++) { /* FixedSvf::tick svf.rs:995-1006 */
+        const float v0 = i < full ? car[i >> 3][i & 7] : tail[i - full];
+        const float v3 = v0 - ic2;
+        const float v1 = a1 * ic1 + a2 * v3;
+        const float v2 = ic2 + a2 * ic1 + a3 * v3;
+        ic1 = 2.0f * v1 - ic1;
+        ic2 = 2.0f * v2 - ic2;
+        out[i] = m0 * v0 + m1 * v1 + m2 * v2;
+    }
+    r->ic1eq = ic1;
+    r->ic2eq = ic2;
+}
+
+typedef struct {
+    const o_bank_job *job;
+    float *out;
+    size_t v0, v1;
+} fslice;
+
+static void *run_fast_slice(void *arg) {
+    fslice *s = (fslice *)arg;
+    const o_bank_job *job = s->job;
+    const size_t T = job->frames, V = job->voices;
+    float blk[64];
+    for (size_t v = s->v0; v < s->v1; v++) {
+        /* construction, set_sample_rate and set_seed through the generic oracle nodes (once per voice, not timed work of
+         * the block path): the registers a monomorphised process() would hold */
+        onode *g = o_bank_build_voice(job, v);
+        o_fm_svf_regs r;
+        const int ok = g && o_fm_svf_state(g, &r) == 0;
+        o_free(g);
+        if (!ok) abort();
+        for (size_t i = 0; i < T; i += 64) {
+            const int n = (int)(T - i < 64 ? T - i : 64);
+            fm_svf_block(&r, n, blk);
+            if (job->out_layout == 0 && s->out)
+                memcpy(&s->out[v * T + i], blk, (size_t)n * sizeof(float));
+            else if (job->out_layout == 1 && s->out)
+                for (int j = 0; j < n; j++) s->out[(i + (size_t)j) * V + v] = blk[j];
+        }
+    }
+    return NULL;
+}
+
+double o_bank_render_fast(const o_bank_job *job, float *out) {
+    if (job->config != 3 || !job->process_mode) return -1.0;
+    int nt = job->threads > 0 ? job->threads : 1;
+    if ((size_t)nt > job->voices) nt = (int)job->voices;
+    if (nt < 1) nt = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nt);
+    fslice *sl = (fslice *)malloc(sizeof(fslice) * (size_t)nt);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < nt; t++) {
+        sl[t].job = job;
+        sl[t].out = out;
+        sl[t].v0 = job->voices * (size_t)t / (size_t)nt;
+        sl[t].v1 = job->voices * (size_t)(t + 1) / (size_t)nt;
+        pthread_create(&th[t], NULL, run_fast_slice, &sl[t]);
+    }
+    for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(th);
+    free(sl);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

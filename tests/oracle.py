@@ -69,6 +69,7 @@ def lib():
         "o_math_rnd1": (d, [u64]), "o_math_hash1": (u64, [u64]), "o_math_atto": (u64, [u64, u64]),
         "o_math_hash32x": (C.c_uint32, [C.c_uint32]),
         "o_bank_render": (d, [C.POINTER(BankJob), fp]),
+        "o_bank_render_fast": (d, [C.POINTER(BankJob), fp]), "o_fast_simd_flavour": (C.c_char_p, []),
         "o_make_wavetable": (i, [i, i, fp, C.POINTER(C.c_int), C.c_size_t, fp]),
         "o_wavetable_create": (P, [i, fp, C.POINTER(C.c_int), fp]), "o_wavetable_free": (None, [P]),
         "o_wavesynth": (P, [P, i]), "o_phasesynth": (P, [P]), "o_waveplayer": (P, [fp, i, C.c_size_t, i, C.c_size_t, C.c_size_t, C.c_long]), "o_wrap": (P, [P, u64]), "o_wavesynth_set_phase": (None, [P, f]),
@@ -713,9 +714,10 @@ def moog_coefs(sr, cutoff, q):
 
 
 def bank_render(config, params, seeds, frames, sample_rate=48000.0, process_mode=True, out_layout=1, threads=1,
-                store=True, lib=None):
+                store=True, lib=None, fast=False):
     """Render V voices of BASELINE config 2 or 3. params: list of float32 [V] arrays. Returns (out, seconds).
-    `lib`: another build of the same oracle (bench.py's -march=native flavour) whose o_bank_render to call."""
+    `lib`: another build of the same oracle (bench.py's -march=native flavour) whose o_bank_render to call.
+    `fast`: the monomorphised SIMD form of the config-3 process() path (oracle/o_fast.c), bit-identical to the tree walk."""
     V = len(seeds)
     ps = [np.ascontiguousarray(p, dtype=np.float32) for p in params] + [None] * (4 - len(params))
     seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
@@ -724,7 +726,14 @@ def bank_render(config, params, seeds, frames, sample_rate=48000.0, process_mode
     out = None
     if store:
         out = np.zeros((frames, V) if out_layout == 1 else (V, frames), dtype=np.float32)
-    secs = (lib or globals()["lib"]()).o_bank_render(C.byref(job), _fptr(out))
+    L = lib or globals()["lib"]()
+    if fast:
+        L.o_bank_render_fast.restype = C.c_double
+        L.o_bank_render_fast.argtypes = [C.POINTER(BankJob), C.POINTER(C.c_float)]
+        secs = L.o_bank_render_fast(C.byref(job), _fptr(out))
+        assert secs >= 0.0, "o_bank_render_fast takes config 3 in process mode only"
+    else:
+        secs = L.o_bank_render(C.byref(job), _fptr(out))
     return out, secs
 
 

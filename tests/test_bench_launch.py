@@ -1,0 +1,59 @@
+"""`python bench.py --gpus N` must run as typed (VERDICT r02 Missing 2): without RANK in the environment one process drives N
+devices from N host threads; under torch.distributed.run it is one rank; a box with too few devices is told so in terms
+of DEVICES, not launchers.  CPU only: the plan and the thread rendezvous, no device work."""
+import os
+import subprocess
+import sys
+import threading
+from types import SimpleNamespace
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def plan(gpus, env, devices):
+    return bench.launch_plan(SimpleNamespace(gpus=gpus), env, lambda: devices)
+
+
+def test_launch_plan():
+    assert plan(1, {}, 1) == ("single", None)
+    assert plan(1, {}, 8) == ("single", None)
+    assert plan(8, {}, 8) == ("threads", 8)                    # as typed on an 8-GPU node: one process, 8 host threads
+    assert plan(2, {"RANK": "1", "WORLD_SIZE": "2", "LOCAL_RANK": "1"}, 0) == ("torchrun-rank", (1, 2, 1))
+    assert plan(1, {"RANK": "0", "WORLD_SIZE": "1"}, 1) == ("single", None)   # torchrun --nproc-per-node 1
+    with pytest.raises(SystemExit, match="2 HIP devices needed, 1 present"):
+        plan(2, {}, 1)
+    with pytest.raises(SystemExit, match="1 HIP device needed, 0 present"):
+        plan(1, {}, 0)
+    with pytest.raises(SystemExit, match="WORLD_SIZE=4"):
+        plan(8, {"RANK": "0", "WORLD_SIZE": "4"}, 8)
+
+
+def test_bench_gpus_2_as_typed_reports_devices_not_launchers():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present: the run itself is the driver's business")
+    assert r.returncode != 0
+    msg = r.stderr.strip().splitlines()[-1]
+    assert "2 HIP devices needed" in msg and "present" in msg and "torch.distributed.run" not in msg and "launch" not in msg
+
+
+def test_thread_peers_barrier_and_max():
+    n = 4
+    tb, shared, got = threading.Barrier(n), [0.0] * n, [None] * n
+
+    def body(k):
+        p = bench.Peers(n, k, thread_barrier=tb, shared=shared)
+        p.barrier()
+        got[k] = (p.max(float(k + 1), None), p.max(float(10 - k), None))   # two rounds: the slots are reused safely
+    ts = [threading.Thread(target=body, args=(k,)) for k in range(n)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert got == [(4.0, 10.0)] * n
+    assert bench.Peers(1).max(3.5, None) == 3.5
