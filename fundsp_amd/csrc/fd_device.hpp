@@ -623,8 +623,14 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
 #ifndef FD_PIPE_BUFFER_STORE
 #define FD_PIPE_BUFFER_STORE 1  // A/B switch: 0 = plain global stores (per-frame 64-bit vector address arithmetic)
 #endif
+#ifndef FD_PIPE_PRODUCER_PLAIN
+#define FD_PIPE_PRODUCER_PLAIN 0  // A/B switch: 1 = stage 0 of a multi-stage pipeline evaluates its sines with plain ops
+#endif
+#ifndef FD_PIPE_PREFETCH
+#define FD_PIPE_PREFETCH 1      // A/B switch: 0 = hand-over pairs read where they are used
+#endif
 #ifndef FD_PIPE_PRIO
-#define FD_PIPE_PRIO 0          // A/B switch: 1 = the LAST compute stage's waves run at s_setprio 1, 2 = the first stage's
+#define FD_PIPE_PRIO 1          // 1 = the heaviest compute stage's waves run at s_setprio 1 (default); A/B: 0 none, 2 first stage, 3 by stage index
 #endif
 #ifndef FD_KNOCK
 #define FD_KNOCK 0      // measurement only (NOT a renderer): compute stage FD_KNOCK - 1 of the pipeline kernel idles, so the other
@@ -976,8 +982,20 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
         const G snap = g;  // tile-start registers, for the rollback below
         // (rolling this loop for heavy stages -- 1 pair per trip instead of 4 -- measured no faster on config 4: 52.9 vs 51.5 ms)
 #if FD_ITEM_LOOP
+        // The hand-over pairs of an item are read ONE ITEM AHEAD: issued at the top of the previous item, they have ~1000
+        // cycles to arrive.  Read where they are used (the compiler hoists them to the item's top, no further), a lone
+        // consumer wave sat out the LDS round trip at the start of every item (s_waitcnt lgkmcnt(0) two instructions
+        // after the ds_read: ~15 % of the filter stage's time at one wave per SIMD, profiles/r03_ab*.txt).
+        v2f ahead[(!FIRST && NI > 0) ? NI : 1][4];
+        if constexpr (!FIRST && FD_PIPE_PREFETCH) {
+#pragma unroll
+            for (int c = 0; c < NI; c++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) ahead[c][k] = hin[c][k][lane];
+        }
         for (int i8 = lo; i8 < shi; i8 += 8) {  // one 8-sample SIMD item per trip (lo, shi are multiples of 8) ...
         item_begin(g);
+        const int nx = i8 + 8 < shi ? i8 + 8 : i8;  // the tile's last item re-reads itself (never used)
 #pragma unroll
         for (int i = i8; i < i8 + 8; i += 2) {  // ... two frames per inner iteration
 #else
@@ -990,8 +1008,19 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
 #pragma unroll
                 for (int c = 0; c < NI; c++) pi[c] = v2f{fin[(c * SUB + (i - lo)) * FS + lane], fin[(c * SUB + (i - lo + 1)) * FS + lane]};
             } else {
+#if FD_ITEM_LOOP
+                if constexpr (FD_PIPE_PREFETCH) {  // consume the pair read during the previous item; re-arm its registers at once
+#pragma unroll
+                    for (int c = 0; c < NI; c++) {
+                        pi[c] = ahead[c][(i - i8) >> 1];
+                        ahead[c][(i - i8) >> 1] = hin[c][((nx - lo) >> 1) + ((i - i8) >> 1)][lane];
+                    }
+                } else
+#endif
+                {
 #pragma unroll
                 for (int c = 0; c < NI; c++) pi[c] = hin[c][(i - lo) >> 1][lane];
+                }
             }
             if constexpr (GIN) {
 #pragma unroll
@@ -1198,7 +1227,15 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                 if constexpr (FEED) fin = &feed[grp][j % D][0][0][0];
                 if (stage == 0) {
                     if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr);
+#if FD_PIPE_PRODUCER_PLAIN
+                    else {  // the producer stage's sines as plain (2-cycle) ops: see SinePlain
+                        using GP = typename PlainOf<GG>::type;
+                        using TP0 = typename PipeTiles<GP, S, K1, K2>::S0;
+                        pipe_stage<TP0, GP, MODE, SUB, W, true, false>(reinterpret_cast<GP&>(gg), h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
+                    }
+#else
                     else pipe_stage<T0, GG, MODE, SUB, W, true, false>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
+#endif
                 } else if (stage == 1) {
                     if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr);
                     else if constexpr (S == 3) pipe_stage<T1, GG, MODE, SUB, W, false, false>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
@@ -1258,9 +1295,21 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     if constexpr (!SameType<GL, G>::v && MODE == MODE_PROCESS && FD_LP_ENABLE)
         lp = __builtin_amdgcn_ballot_w64((live && active) && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(live && active) != 0ull;
 #if FD_PIPE_PRIO == 1
-    if (stage == S - 1) __builtin_amdgcn_s_setprio(1);
+    // The HEAVIEST stage's wave is the critical path of a voice group: its instruction stream is one dependent chain, so every
+    // cycle it waits for the VALU behind a sibling's instruction is a cycle added to the round.  VALU arbitration on a SIMD
+    // is oldest-first (profiles/r03_ubench_issue_v2.txt: the older of two waves runs unimpeded, the younger gets the
+    // leftovers), and wave age follows the role order, not the weight -- so the heaviest stage asks for priority
+    // (s_setprio 1: config 3 exact 5.20 -> 4.95 ms before the other changes of the round; the lighter waves fill its gaps).
+    {
+        constexpr int w0 = S0::weight, w1 = S >= 2 ? S1::weight : 0, w2 = S >= 3 ? S2::weight : 0;
+        constexpr int heavy = (w0 >= w1 && w0 >= w2) ? 0 : (w1 >= w2 ? 1 : 2);
+        if (S > 1 && stage == heavy) __builtin_amdgcn_s_setprio(1);
+    }
 #elif FD_PIPE_PRIO == 2
     if (stage == 0) __builtin_amdgcn_s_setprio(1);
+#elif FD_PIPE_PRIO == 3   // later stages first: the consumer of a hand-over never waits for issue slots behind its producer
+    if (stage == 1) __builtin_amdgcn_s_setprio(1);
+    if (stage == 2) __builtin_amdgcn_s_setprio(2);
 #endif
     if (lp) rounds_of((GL*)nullptr); else rounds_of((G*)nullptr);
     if (live && active) {
@@ -1309,13 +1358,15 @@ FD_D void ts_stage(G& g, int part, int nparts, int lane, v2f (*hin)[32][64], v2f
         feed(i, pi);
         SG::template skip2<PH_SIMD>(g, pi);
     }
-#pragma unroll 4
-    for (int i = lo; i < hi; i += 2) {
-        v2f pi[NI > 0 ? NI : 1], po[NO];
-        feed(i, pi);
-        SG::template step2<PH_SIMD>(g, pi, pi, po);
+    for (int i8 = lo; i8 < hi; i8 += 8) {  // one 8-sample SIMD item per trip (lo, hi are multiples of 8), fully unrolled inside
 #pragma unroll
-        for (int c = 0; c < NO; c++) hout[c][i >> 1][lane] = po[c];
+        for (int i = i8; i < i8 + 8; i += 2) {
+            v2f pi[NI > 0 ? NI : 1], po[NO];
+            feed(i, pi);
+            SG::template step2<PH_SIMD>(g, pi, pi, po);
+#pragma unroll
+            for (int c = 0; c < NO; c++) hout[c][i >> 1][lane] = po[c];
+        }
     }
     for (int i = hi; i < 64; i += 2) {
         v2f pi[NI > 0 ? NI : 1];
@@ -1432,6 +1483,9 @@ FD_D void render_ts_body(float* __restrict__ slots, size_t stride, size_t V, flo
     bool lp = false;
     if constexpr (!SameType<GL, G>::v && FD_LP_ENABLE)
         lp = __builtin_amdgcn_ballot_w64(active && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(active) != 0ull;
+#if FD_PIPE_PRIO
+    if (stage == 2) __builtin_amdgcn_s_setprio(1);  // the serial filter wave is the round's critical path (see render_pipe_body)
+#endif
     if (lp) rounds_of((GL*)nullptr); else rounds_of((G*)nullptr);
     if (active && part == 0) {  // the waves of a split stage end with identical state: one of them stores it
         VStore<false> st{slots + v, stride, 0};

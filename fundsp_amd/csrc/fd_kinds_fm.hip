@@ -1,0 +1,27 @@
+// fd_kinds_fm.hip -- the oscillator -> filter chains of BASELINE configs 1 and 3 (the headline kernel lives here).
+// The types spell out exactly what the reference's operator overloads build (combinator.rs:289-488; Rust precedence
+// `*` > `+` > `>>`).
+//
+// A translation unit of its own because it is built with `-mllvm -amdgpu-sched-strategy=iterative-ilp` (Makefile): the
+// stage that holds the carrier sine AND the serial SVF recurrence is one ~230-instruction basic block per SIMD item, and
+// the default scheduler flips -- on unrelated edits -- between interleaving the four frame pairs' packed sine work and
+// emitting it pair by pair with an `s_nop` after every dependent packed op (38-44 per item, 6-14 % slower; profiles/
+// r03_ab1_knockout_prio.txt, r03_isa_fm_svf.txt).  The ILP strategy produces the interleaved form every time.  It cannot
+// be a whole-library flag: ROCm 7.2's clang crashes with it in the register allocator on other kinds (Oversampler).
+#include "fd_engine.hpp"
+
+namespace fd {
+// sine_hz(f) = constant(f) >> sine()                       prelude.rs:349
+using SineHz = Pipe<Constant<1>, Sine>;
+// config 1: sine_hz(440) >> lowpass_hz(1000, 1)
+using SineHzLowpass = Pipe<SineHz, FixedSvf>;
+// config 3: sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q)     (README.md:98-103)
+using FmMod = Unop<Unop<Unop<SineHz, UMulScalar>, UMulScalar>, UAddScalar>;
+using FmSvf = Pipe<Pipe<FmMod, Sine>, FixedSvf>;
+
+void register_fm_kinds(std::vector<KindOps>& out) {
+    out.push_back(make_kind<SineHz>("sine_hz"));
+    out.push_back(make_kind<SineHzLowpass>("sine_hz_lowpass_hz"));
+    out.push_back(make_kind<FmSvf>("fm_svf"));
+}
+}  // namespace fd

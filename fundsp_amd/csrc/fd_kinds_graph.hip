@@ -1,17 +1,15 @@
 // fd_kinds_graph.hip -- fused voice graphs of the BASELINE configs.  The types spell out exactly what the
 // reference's operator overloads build (combinator.rs:289-488; Rust precedence `*` > `+` > `>>`).
+// (sine_hz, sine_hz_lowpass_hz and fm_svf -- configs 1 and 3 -- are in fd_kinds_fm.hip.)
 #include "fd_engine.hpp"
 
 namespace fd {
 // sine_hz(f) = constant(f) >> sine()                       prelude.rs:349
 using SineHz = Pipe<Constant<1>, Sine>;
-// config 1: sine_hz(440) >> lowpass_hz(1000, 1)
-using SineHzLowpass = Pipe<SineHz, FixedSvf>;
 // config 2 voice: noise() >> biquad(..) -- arithmetic of one BiquadBank<f32x8> lane fed by white noise
 using NoiseBiquad = Pipe<Noise, Biquad>;
-// config 3: sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q)     (README.md:98-103)
+// the FM pair of config 3 (README.md:98-103), here for the oversample / resample kinds below
 using FmMod = Unop<Unop<Unop<SineHz, UMulScalar>, UMulScalar>, UAddScalar>;
-using FmSvf = Pipe<Pipe<FmMod, Sine>, FixedSvf>;
 
 // config 4 voice: ((dc(f) >> saw() | dc(fc) | dc(q)) >> moog()) * adsr_live(a, d, s, r) >> pan(p)
 // (`|` binds loosest, `*` tightest: combinator.rs; moog() is the 3-input variant prelude.rs:551; the gate is the
@@ -31,11 +29,11 @@ using OversampleShape = Oversampler<Shaper>;
 // resample(sine_hz(f) * f * m + f >> sine()) (prelude32.rs:1021): the FM pair played back at a per-sample speed
 using ResampleFm = Resample<Pipe<FmMod, Sine>>;
 
+void register_fm_kinds(std::vector<KindOps>& out);  // fd_kinds_fm.hip
+
 void register_graph_kinds(std::vector<KindOps>& out) {
-    out.push_back(make_kind<SineHz>("sine_hz"));
-    out.push_back(make_kind<SineHzLowpass>("sine_hz_lowpass_hz"));
+    register_fm_kinds(out);
     out.push_back(make_kind<NoiseBiquad>("noise_biquad"));
-    out.push_back(make_kind<FmSvf>("fm_svf"));
     out.push_back(make_kind<SawMoogAdsrPan>("saw_moog_adsr_pan"));
     out.push_back(make_kind<OversampleFm>("oversample_fm"));
     out.push_back(make_kind<OversampleShape>("oversample_shape"));

@@ -618,6 +618,9 @@ FD_HD float wide_sinf(float self) {
 #ifndef FD_SINE_UNIFIED
 #define FD_SINE_UNIFIED 0
 #endif
+#ifndef FD_SINE_BFE
+#define FD_SINE_BFE 1    // the odd-quadrant select of wide_sin2 as v_bfe_i32 + v_bfi_b32 (one issue slot less per frame than v_and + v_cmp + v_cndmask); A/B switch: 0
+#endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 FD_HD v2f splat2(float x) { return v2f{x, x}; }
@@ -644,7 +647,7 @@ FD_HD v2f wide_sin2(v2f self, float& tmax) {
     // Out-of-domain arguments (|quadrant index| >= 8192: more than ~2000 cycles of phase inside one 64-sample block,
     // where the exact-FMA shortcuts and wide's q > 2^25 overflow rule would matter) only raise tmax here.
     v2f t = self * TWO_OVER_PI;
-    tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(__builtin_fabsf(t.x), __builtin_fabsf(t.y)));
+    tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, __builtin_fabsf(t.x)), __builtin_fabsf(t.y));  // one v_max3_f32 per pair
     // round(t) and its low integer bits from one add: for |t| < 2^13 the sum lies in [2^23, 2^24) where ulp = 1, so
     // ym = RNE(t) + MAGIC exactly, y = ym - MAGIC is exact, and mantissa(ym) = 0x400000 + RNE(t) (two's complement).
     v2f ym = t + MAGIC;
@@ -661,9 +664,21 @@ FD_HD v2f wide_sin2(v2f self, float& tmax) {
     v2f c = (x4 * P2cosf + (x2 * P1cosf + P0cosf)) * x4 + __builtin_elementwise_fma(x2, splat2(-0.5f), splat2(1.0f));
     // (forcing v_bfe_i32 + v_bfi_b32 through inline asm instead of the and + cmp + cndmask the optimiser prefers saved
     // nothing: the asm also stopped the 4-pair unrolling of the caller's loop)
+#if FD_SINE_BFE && defined(__HIP_DEVICE_COMPILE__)
+    // Odd-quadrant select as v_bfe_i32 (mask = bit 0 sign-extended) + v_bfi_b32 (mask ? c : s), through asm that the
+    // optimiser cannot rewrite: left alone it turns the mask select below into v_and + v_cmp + v_cndmask, and a VALU
+    // instruction that takes its lane mask from VCC / an SGPR pair costs several issue slots on gfx950
+    // (profiles/r03_ubench_issue.txt).  Plain (non-volatile) asm: pure functions of their inputs, free to schedule.
+    uint32_t m0, m1, r0, r1;
+    asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m0) : "v"(b0));
+    asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m1) : "v"(b1));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r0) : "v"(m0), "v"(f2u(c.x)), "v"(f2u(s.x)));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r1) : "v"(m1), "v"(f2u(c.y)), "v"(f2u(s.y)));
+#else
     uint32_t m0 = (uint32_t)((int32_t)(b0 << 31) >> 31), m1 = (uint32_t)((int32_t)(b1 << 31) >> 31);  // odd quadrant
     uint32_t r0 = (f2u(c.x) & m0) | (f2u(s.x) & ~m0);
     uint32_t r1 = (f2u(c.y) & m1) | (f2u(s.y) & ~m1);
+#endif
     return v2f{u2f(r0 ^ ((b0 << 30) & 0x80000000u)), u2f(r1 ^ ((b1 << 30) & 0x80000000u))};
 }
 

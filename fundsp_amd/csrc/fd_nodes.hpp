@@ -327,6 +327,24 @@ struct SineFast : Sine {
     }
 };
 
+// Sine with its packed path evaluated as two PLAIN wide_sin1 calls (same operations per frame, bit-identical): for a
+// producer stage that shares a SIMD with a prioritised consumer wave -- a 2-cycle plain op holds the VALU half as long as a
+// 4-cycle packed one, so it stands in the consumer's way half as long (fd_device.hpp FD_PIPE_PRODUCER_PLAIN).
+struct SinePlain : Sine {
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        if (PH == PH_SIMD) {
+            v2f d = in[0] * sample_duration;
+            float t0 = phase;
+            phase += d.x;
+            float t1 = phase;
+            phase += d.y;
+            out[0] = v2f{wide_sin1(t0 * F32_TAU, tmax), wide_sin1(t1 * F32_TAU, tmax)};
+        } else {
+            Sine::template step2<PH>(in, out);
+        }
+    }
+};
+
 // Dsf<N>  oscillator.rs:103-208 (ID 55): discrete summation formula oscillator (Moorer 1976), tick only.
 // NIN = 1 (frequency) or 2 (frequency, roughness).
 template <int NIN>
@@ -423,11 +441,16 @@ struct Noise {
 };
 
 // SVF core shared by FixedSvf and Svf:  svf.rs:995-1006 / :829-843
+#ifndef FD_SVF_PK
+#define FD_SVF_PK 1     // the lowpass SVF's two state equations as one packed computation (FixedSvfLp); A/B switch: 0 = plain
+#endif
 #ifndef FD_SVF_GUARD
 #define FD_SVF_GUARD 1  // A/B switch only (0 = measure what the overflow guard costs; NOT exact)
 #endif
 #if FD_SVF_GUARD
-#define FD_SVF_TRACK(vmax, v1, v2) vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(__builtin_fabsf(v1), __builtin_fabsf(v2)))
+// one v_max3_f32 vmax, |v1|, |v2| per frame (written as max(max(vmax, |v1|), |v2|): the other association made the
+// compiler pair frames up -- a v_max_f32 per frame plus a v_max3 per two)
+#define FD_SVF_TRACK(vmax, v1, v2) vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(v1)), __builtin_fabsf(v2))
 #else
 #define FD_SVF_TRACK(vmax, v1, v2) (void)0
 #endif
@@ -458,6 +481,22 @@ struct SvfCore {
     // ... and when m0 = m1 = +0.0 and m2 = 1.0 (LowpassMode): `m0*v0 + m1*v1 + m2*v2` = (+-0 + +-0) + v2 is v2 itself,
     // bit for bit, whenever v0, v1 are finite and v2 is not -0.0 -- FixedSvfLp guards both (see there).
     FD_HD float tick_lp(float v0, float& vmax) {
+#if FD_SVF_PK
+        // The two state equations as ONE <2 x float> computation (same operations, same order, per component): a lone
+        // wave issues one VALU instruction per ~4-5 cycles whatever its width (profiles/r03_ubench_issue.txt), and this
+        // recurrence is what the filter wave's issue slots go to -- 8 slots per frame instead of 11.
+        //   lane 0: v1 = a1*ic1 + a2*v3          lane 1: v2 = (ic2 + a2*ic1) + a3*v3
+        const float v3 = v0 - ic2eq;
+        const float u = a1 * ic1eq;
+        const float s = ic2eq + a2 * ic1eq;
+        const v2f q = v2f{v3, v3} * v2f{a2, a3};
+        const v2f v = v2f{u, s} + q;
+        FD_SVF_TRACK(vmax, v.x, v.y);
+        const v2f ic = __builtin_elementwise_fma(splat2(2.0f), v, -v2f{ic1eq, ic2eq});
+        ic1eq = ic.x;
+        ic2eq = ic.y;
+        return v.y;
+#else
         float v3 = v0 - ic2eq;
         float v1 = a1 * ic1eq + a2 * v3;
         float v2 = ic2eq + a2 * ic1eq + a3 * v3;
@@ -465,6 +504,7 @@ struct SvfCore {
         ic1eq = __builtin_fmaf(2.0f, v1, -ic1eq);
         ic2eq = __builtin_fmaf(2.0f, v2, -ic2eq);
         return v2;
+#endif
     }
     FD_HD void set(const SvfCoefs& c) {
         a1 = c.a1; a2 = c.a2; a3 = c.a3; m0 = c.m0; m1 = c.m1; m2 = c.m2;
@@ -3247,6 +3287,8 @@ struct Unop {
 // FastOf<G>: Sine -> SineFast, Moog<N> -> MoogFast<N>.  Chosen per LAUNCH by the host (fdsp_set_option("math", 1)); tolerance mode.
 template <class G> struct LpOf { using type = G; };
 template <> struct LpOf<FixedSvf> { using type = FixedSvfLp; };
+template <class G> struct PlainOf { using type = G; };     // Sine -> SinePlain (layout-identical; producer stages only)
+template <> struct PlainOf<Sine> { using type = SinePlain; };
 template <class G> struct FastOf { using type = G; };
 template <> struct FastOf<Sine> { using type = SineFast; };
 template <int N> struct FastOf<Moog<N>> { using type = MoogFast<N>; };
@@ -3257,6 +3299,7 @@ template <int N> struct FastOf<Moog<N>> { using type = MoogFast<N>; };
     template <class X, class U> struct TRAIT<Unop<X, U>> { using type = Unop<typename TRAIT<X>::type, U>; };
 FD_VARIANT_THROUGH(LpOf)
 FD_VARIANT_THROUGH(FastOf)
+FD_VARIANT_THROUGH(PlainOf)
 template <class A, class B> struct SameType { static constexpr bool v = false; };
 template <class A> struct SameType<A, A> { static constexpr bool v = true; };
 template <class T> struct Pointee;
