@@ -335,6 +335,27 @@ def secondary(F, W, torch, sr, mode):
     return out
 
 
+class quiet_stdout:
+    """RCCL prints a version banner to the C-level stdout when a communicator is created; the contract of this script is ONE
+    JSON line on stdout.  Inside this context fd 1 points at stderr; C stdio is flushed before fd 1 is restored."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 class Peers:
     """How the ranks of one bench run meet: barrier, max-over-ranks, and the mix-down communicator.
 
@@ -426,7 +447,8 @@ def main(argv=None):
         import threading
 
         n = info
-        comm = F.Comm.local(list(range(n))) if args.mix else None
+        with quiet_stdout():
+            comm = F.Comm.local(list(range(n))) if args.mix else None
         tb, shared, results, errors = threading.Barrier(n), [0.0] * n, [None] * n, []
 
         def body(k):
@@ -443,8 +465,9 @@ def main(argv=None):
             t.join()
         if errors:
             raise errors[0]
-        if comm is not None:
-            comm.close()
+        with quiet_stdout():
+            if comm is not None:
+                comm.close()
         print(json.dumps(results[0]), flush=True)
         return
     if plan == "torchrun-rank":
@@ -454,15 +477,18 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        with quiet_stdout():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         comm = None
         if args.mix:   # the RCCL id travels over torch.distributed ONCE; every all-reduce of the run is the library's own
             idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(F.Comm.unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, src=0)
-            comm = F.Comm.rank(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
-        res = run_rank(args, torch, F, Peers(world, rank, dist=dist, comm=comm), local_rank)
+            with quiet_stdout():
+                comm = F.Comm.rank(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+        with quiet_stdout():
+            res = run_rank(args, torch, F, Peers(world, rank, dist=dist, comm=comm), local_rank)
         if rank == 0:
             print(json.dumps(res), flush=True)
         dist.barrier()
@@ -471,10 +497,12 @@ def main(argv=None):
         dist.destroy_process_group()
         return
     torch.cuda.set_device(0)
-    comm = F.Comm.local([0]) if args.mix else None
-    print(json.dumps(run_rank(args, torch, F, Peers(1, 0, comm=comm), 0)), flush=True)
-    if comm is not None:
-        comm.close()
+    with quiet_stdout():   # everything C-level that talks (RCCL's banner) goes to stderr; the JSON line is printed last
+        comm = F.Comm.local([0]) if args.mix else None
+        res = run_rank(args, torch, F, Peers(1, 0, comm=comm), 0)
+        if comm is not None:
+            comm.close()
+    print(json.dumps(res), flush=True)
 
 
 def mix_step(F, torch, args, wl, peers):
