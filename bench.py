@@ -635,6 +635,22 @@ def run_rank(args, torch, F, peers, device):
                     traffic_source = rec.get("source", "profiles/pmc_latest.json") + " (separate rocprofv3 --pmc passes, not this run)"
             except Exception:
                 traffic = None
+        # the VALU view (the kernel is issue-bound, so the HBM fraction alone says little): instruction counts
+        # and cycles from the committed SQ pass + ISA listing (tools/valu_view.py), the flop rate from THIS run's kernel time
+        valu = None
+        vpath = os.path.join(ROOT, "profiles", "valu_latest.json")
+        if os.path.exists(vpath):
+            try:
+                rec = json.load(open(vpath))
+                if rec.get("voices") == V and rec.get("frames") == T and rec.get("config", 3) == args.config and rec.get("math", "exact") == args.math:
+                    flops = rec["flops_per_voice_frame_isa"] * V * T / (avg_ms * 1e-3)
+                    valu = {k: rec[k] for k in ("insts_per_voice_group_frame", "packed_fraction_isa", "plain_op_equivalents_per_voice_group_frame",
+                                                "issue_cycles_per_inst", "frac_of_issue_peak", "issue_peak", "wait_inst_any_frac_of_wave_cycles",
+                                                "wait_any_frac_of_wave_cycles", "source")}
+                    valu["tflops_this_run"] = round(flops / 1e12, 2)
+                    valu["flops_frac_of_157TF"] = round(flops / 157.3e12, 4)
+            except Exception:
+                valu = None
         unit_name = {2: "voices", 3: "voices", 4: "voices", 5: "instances"}[args.config]
         res = {
             "metric": {3: "Msamples/s (whole node) for 65536-voice SVF+FM graph",
@@ -686,6 +702,7 @@ def run_rank(args, torch, F, peers, device):
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "measured_streaming": measured,
                 "frac_of_measured_fill": round(achieved / measured["fill_gbs"], 4) if measured else None,
+                "valu": valu,
             },
         }
         if world == 1 and args.cpu_seconds > 0 and args.config == 3:

@@ -577,7 +577,7 @@ namespace {
 struct OptSpec { const char* name; int lo, hi; const char* what; };
 const OptSpec LAUNCH_OPTS[] = {
     {"pipe_split", 0, 4, "pipe_split takes 0 (off), 1 (auto), 2 or 3 (stages), 4 (loader only)"},
-    {"time_split", 0, 1, "time_split takes 0 (off) or 1 (small banks of eligible graphs)"},
+    {"time_split", 0, 2, "time_split takes 0 (off), 1 (small banks of eligible graphs: 3 + 3 + 1 waves per group) or 2 (round 2's 2 + 2 + 1 / 2 + 1 + 1 layouts)"},
     {"fdn_kernel", 0, 1, "fdn_kernel takes 0 (lane per frame) or 1 (lane per delay line)"},
     {"timing", 0, 1, "timing takes 0 (no per-launch event pair) or 1 (fdsp_bank_last_kernel_ms available)"},
 };

@@ -629,8 +629,14 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
 #ifndef FD_PIPE_PREFETCH
 #define FD_PIPE_PREFETCH 1      // A/B switch: 0 = hand-over pairs read where they are used
 #endif
+#ifndef FD_PIPE_PREFETCH_GPW
+#define FD_PIPE_PREFETCH_GPW 4  // the pipeline kernel prefetches in workgroups of fewer voice groups than this (A/B: 5 = always)
+#endif
 #ifndef FD_PIPE_PRIO
 #define FD_PIPE_PRIO 1          // 1 = the heaviest compute stage's waves run at s_setprio 1 (default); A/B: 0 none, 2 first stage, 3 by stage index
+#endif
+#ifndef FD_KNOCK_TS
+#define FD_KNOCK_TS 0   // measurement only: k_render_ts3 with 1 = the filter wave idle, 2 = only the filter wave, 3 = only stage 0, 4 = only stage 1
 #endif
 #ifndef FD_KNOCK
 #define FD_KNOCK 0      // measurement only (NOT a renderer): compute stage FD_KNOCK - 1 of the pipeline kernel idles, so the other
@@ -945,7 +951,7 @@ constexpr PipePlan pipe_plan(int want) {  // want: 0 = best plan, 1 / 2 / 3 = at
 // FS = floats per frame row of the feed tile (64, or 65 when the loader fills it by transposing planar rows); OL = where
 // the LAST stage puts its samples: 0 = HBM, voice-minor; 1 = an LDS tile [channel][frame][FS] that the storer wave of the
 // planar pipeline transposes out.
-template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST, int FS = 64, int OL = 0>
+template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST, int FS = 64, int OL = 0, bool PF = (FD_PIPE_PREFETCH != 0)>
 FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_t V, int lane, float* outw,
                      const float* fin, v2f (*hin)[SUB / 2][64], v2f (*hout)[SUB / 2][64]) {
     constexpr int NI = SG::IN, NO = SG::OUT, NG = G::IN;
@@ -982,12 +988,14 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
         const G snap = g;  // tile-start registers, for the rollback below
         // (rolling this loop for heavy stages -- 1 pair per trip instead of 4 -- measured no faster on config 4: 52.9 vs 51.5 ms)
 #if FD_ITEM_LOOP
-        // The hand-over pairs of an item are read ONE ITEM AHEAD: issued at the top of the previous item, they have ~1000
-        // cycles to arrive.  Read where they are used (the compiler hoists them to the item's top, no further), a lone
-        // consumer wave sat out the LDS round trip at the start of every item (s_waitcnt lgkmcnt(0) two instructions
-        // after the ds_read: ~15 % of the filter stage's time at one wave per SIMD, profiles/r03_ab*.txt).
+        // PF: the hand-over pairs of an item are read ONE ITEM AHEAD -- each pair's registers are re-armed right after the pair is
+        // consumed, ~150-1000 cycles before the next item wants them.  Read where they are used (the compiler hoists them to
+        // the item's top, no further) a consumer wave that has its SIMD to itself sits out the LDS round trip at the start of
+        // every item (~140 cycles, profiles/r03_ubench_issue_v3.txt "ds_read2st64_b64 + wait"): stage 1 alone 3.55 -> 3.38 ms.
+        // With a producer wave on the same SIMD the wait is filled anyway and the longer live ranges cost more than they save
+        // (config 3, 65 536 voices: 4.72 vs 4.60 ms), so the four-group pipeline kernel leaves it off.
         v2f ahead[(!FIRST && NI > 0) ? NI : 1][4];
-        if constexpr (!FIRST && FD_PIPE_PREFETCH) {
+        if constexpr (!FIRST && PF) {
 #pragma unroll
             for (int c = 0; c < NI; c++)
 #pragma unroll
@@ -1009,7 +1017,7 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
                 for (int c = 0; c < NI; c++) pi[c] = v2f{fin[(c * SUB + (i - lo)) * FS + lane], fin[(c * SUB + (i - lo + 1)) * FS + lane]};
             } else {
 #if FD_ITEM_LOOP
-                if constexpr (FD_PIPE_PREFETCH) {  // consume the pair read during the previous item; re-arm its registers at once
+                if constexpr (PF) {  // consume the pair read during the previous item; re-arm its registers at once
 #pragma unroll
                     for (int c = 0; c < NI; c++) {
                         pi[c] = ahead[c][(i - i8) >> 1];
@@ -1209,6 +1217,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     // The rounds, for the graph type GG: G itself, or its lowpass-specialised twin LpOf<G> (same registers, the
     // packed SVF path 5 operations shorter) when every lane of THIS wave qualifies.  A wave that does not hold the SVF
     // segment sees zeroed coefficients, takes the generic type and runs the same arithmetic for its own segment.
+    constexpr bool PFK = FD_PIPE_PREFETCH != 0 && GPW < FD_PIPE_PREFETCH_GPW;  // see pipe_stage: prefetch pays when the consumer wave is (nearly) alone on its SIMD
     auto rounds_of = [&](auto* tag) {
         using GG = typename Pointee<decltype(tag)>::type;
         using TG = PipeTiles<GG, S, K1, K2>;
@@ -1237,10 +1246,10 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                     else pipe_stage<T0, GG, MODE, SUB, W, true, false>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
 #endif
                 } else if (stage == 1) {
-                    if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr);
-                    else if constexpr (S == 3) pipe_stage<T1, GG, MODE, SUB, W, false, false>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
+                    if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr);
+                    else if constexpr (S == 3) pipe_stage<T1, GG, MODE, SUB, W, false, false, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
                 } else {
-                    if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr);
+                    if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr);
                 }
             }
             __syncthreads();  // hand-over point: every role has finished its tile of this round
@@ -1344,34 +1353,53 @@ template <class SG, class G, bool FIRST, int W>
 FD_D void ts_stage(G& g, int part, int nparts, int lane, v2f (*hin)[32][64], v2f (*hout)[32][64]) {
     constexpr int NI = SG::IN, NO = SG::OUT;
     static_assert(NO <= W && (FIRST || NI <= W), "hand-over tile too narrow");
-    const int lo = 64 / nparts * part, hi = lo + 64 / nparts;  // this wave's frames of the block (multiples of 8)
+    // this wave's frames of the block (multiples of 8): halves, or thirds as 24 + 24 + 16
+    const int lo = nparts == 3 ? 24 * part : 64 / nparts * part, hi = nparts == 3 ? (part == 2 ? 64 : lo + 24) : lo + 64 / nparts;
     SG::begin(g, 64);
     const G snap = g;
-    auto feed = [&](int i, v2f* pi) {
-        if constexpr (!FIRST) {
+    // The block in 8-frame items; a consumer stage reads every item's four hand-over pairs ONE ITEM AHEAD (each pair's
+    // registers re-armed as soon as the pair is consumed).  Read pair by pair at the point of use -- as rounds 1-2 had it --
+    // every pair of a SKIPPED item cost a whole LDS round trip (~140 cycles for three VALU instructions): the carrier
+    // waves, which skip through two thirds of the block, were the slowest waves of the kernel for that reason alone.
+    v2f ahead[(!FIRST && NI > 0) ? NI : 1][4];
+    if constexpr (!FIRST) {
 #pragma unroll
-            for (int c = 0; c < NI; c++) pi[c] = hin[c][i >> 1][lane];
-        }
-    };
-    for (int i = 0; i < lo; i += 2) {
-        v2f pi[NI > 0 ? NI : 1];
-        feed(i, pi);
-        SG::template skip2<PH_SIMD>(g, pi);
+        for (int c = 0; c < NI; c++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) ahead[c][k] = hin[c][k][lane];
     }
-    for (int i8 = lo; i8 < hi; i8 += 8) {  // one 8-sample SIMD item per trip (lo, hi are multiples of 8), fully unrolled inside
+    for (int i8 = 0; i8 < 64; i8 += 8) {
+        const int nx = i8 + 8 < 64 ? i8 + 8 : i8;  // the last item re-reads itself (never used)
+        const bool mine = i8 >= lo && i8 < hi;     // wave-uniform
+        if (mine) {
 #pragma unroll
-        for (int i = i8; i < i8 + 8; i += 2) {
-            v2f pi[NI > 0 ? NI : 1], po[NO];
-            feed(i, pi);
-            SG::template step2<PH_SIMD>(g, pi, pi, po);
+            for (int k = 0; k < 4; k++) {
+                v2f pi[NI > 0 ? NI : 1], po[NO];
+                if constexpr (!FIRST) {
 #pragma unroll
-            for (int c = 0; c < NO; c++) hout[c][i >> 1][lane] = po[c];
+                    for (int c = 0; c < NI; c++) {
+                        pi[c] = ahead[c][k];
+                        ahead[c][k] = hin[c][(nx >> 1) + k][lane];
+                    }
+                }
+                SG::template step2<PH_SIMD>(g, pi, pi, po);
+#pragma unroll
+                for (int c = 0; c < NO; c++) hout[c][(i8 >> 1) + k][lane] = po[c];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v2f pi[NI > 0 ? NI : 1];
+                if constexpr (!FIRST) {
+#pragma unroll
+                    for (int c = 0; c < NI; c++) {
+                        pi[c] = ahead[c][k];
+                        ahead[c][k] = hin[c][(nx >> 1) + k][lane];
+                    }
+                }
+                SG::template skip2<PH_SIMD>(g, pi);
+            }
         }
-    }
-    for (int i = hi; i < 64; i += 2) {
-        v2f pi[NI > 0 ? NI : 1];
-        feed(i, pi);
-        SG::template skip2<PH_SIMD>(g, pi);
     }
     if (__builtin_expect(SG::tripped(g), 0)) {  // a packed-path shortcut left its exact domain: redo the block, frame by frame
         g = snap;
@@ -1474,7 +1502,7 @@ FD_D void render_ts_body(float* __restrict__ slots, size_t stride, size_t V, flo
                 const size_t j = it - stage;  // the block this stage works on in this round
                 if (stage == 0) ts_stage<T0, GG, true, W>(gg, part, nparts, lane, nullptr, hand[0][j & 1]);
                 else if (stage == 1) ts_stage<T1, GG, false, W>(gg, part, nparts, lane, hand[0][j & 1], hand[1][j & 1]);
-                else pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[1][j & 1], nullptr);
+                else pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, 0, FD_PIPE_PREFETCH != 0>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[1][j & 1], nullptr);
             }
             __syncthreads();
         }
@@ -1498,6 +1526,100 @@ template <class G, int NA, int NB>
 __global__ __launch_bounds__(64 * (NA + NB + 1)) void k_render_ts(float* __restrict__ slots, size_t stride, size_t V,
                                                                   float* __restrict__ out, size_t T, const void* aux) {
     if constexpr (TsPlan<G>::ok) render_ts_body<G, NA, NB>(slots, stride, V, out, T, aux);
+}
+
+// ---- time-split, three ways (round 3) ----------------------------------------------------------------------------------
+// What the instruction-issue measurements of round 3 say about the kernel above (profiles/r03_ubench_issue_v*.txt): a
+// wave issues one VALU instruction per 4.1-5.1 cycles whatever its neighbours do, and two waves that share a SIMD get in
+// each other's way instruction by instruction.  In the 2 + 2 + 1 layout FIVE waves sit on four SIMDs, so one SIMD runs
+// two oscillator halves back to back and sets the round time (2.27 ms per 48 000 frames where the filter wave alone
+// needs ~1.2).  Here both oscillator stages are split THREE ways (24 + 24 + 16 frames of a block) and the roles are
+// placed so that the serial filter wave has a SIMD to itself (one group per CU) or shares it with one oscillator pair:
+//   GPW = 1 (<= one voice group per CU), 7 waves:  w: 0  1  2  3  4  5  6      (waves w and w + 4 share a SIMD)
+//                                              role: A0 A1 A2 C  B0 B1 B2
+//   GPW = 2 (<= two groups per CU), 14 waves = two such groups; the filter waves of the two groups land on the two SIMDs
+//           that hold three waves (w % 4 = 2, 3), the four-wave SIMDs hold oscillator thirds only.
+// The thirds of a stage each advance the state through the whole block (skip2) and evaluate their own frames; per frame
+// the arithmetic is that of every other kernel -- bit-exact (tests/test_gpu_time_split.py).
+template <int GPW> struct Ts3Roles;
+template <> struct Ts3Roles<1> {  // wave -> (group, stage, part)
+    static constexpr int WAVES = 7;
+    static constexpr int grp[7] = {0, 0, 0, 0, 0, 0, 0};
+    static constexpr int stg[7] = {0, 0, 0, 2, 1, 1, 1};
+    static constexpr int prt[7] = {0, 1, 2, 0, 0, 1, 2};
+};
+template <> struct Ts3Roles<2> {
+    // SIMD = w % 4:   SIMD 0: w 0 4 8 12   SIMD 1: w 1 5 9 13   SIMD 2: w 2 6 10   SIMD 3: w 3 7 11
+    static constexpr int WAVES = 14;
+    static constexpr int grp[14] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 1, 0};
+    static constexpr int stg[14] = {0, 0, 2, 2, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1};
+    static constexpr int prt[14] = {0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 1, 1, 2, 2};
+    // SIMD 0: g0 A0, g0 B0, g0 A2, g1 B2   SIMD 1: g1 A0, g1 B0, g1 A2, g0 B2   SIMD 2: g0 C, g0 A1, g0 B1   SIMD 3: g1 C, g1 A1, g1 B1
+};
+
+template <class G, int GPW>
+FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T, const void* aux) {
+    using S0 = Seg<G, 0, 1>;
+    using S1 = Seg<G, 1, 2>;
+    using S2 = Seg<G, 2, 3>;
+    using R = Ts3Roles<GPW>;
+    constexpr int W = S0::OUT > S1::OUT ? S0::OUT : S1::OUT;
+    static_assert(W * 2 * 2 * 16 * GPW <= 128, "hand-over tiles must fit 128 KiB");
+    __shared__ v2f hand[GPW][2][2][W][32][64];  // [group][cut][buffer][channel][frame pair][lane]
+#if FD_KNOCK_TS
+    for (size_t i = threadIdx.x; i < sizeof(hand) / sizeof(float); i += blockDim.x) reinterpret_cast<float*>(hand)[i] = 0.0f;
+    __syncthreads();
+#endif
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = R::grp[w], stage = R::stg[w], part = R::prt[w];
+    const size_t v0 = ((size_t)blockIdx.x * GPW + grp) * 64, v = v0 + lane;
+    const bool live = v0 < stride, active = v < V;   // a whole group past the bank still takes part in the barriers
+    const size_t nblocks = T / 64, rounds = nblocks + 2;
+    float* outw = out + v0;
+    G g{};
+    Ctx ctx{static_cast<const Aux*>(aux), nullptr, 0, stride, 0};
+    g.bind(ctx);
+    if (live) {
+        VLoad ld{slots + v, stride, 0};
+        VGate::W<VLoad> gate{&ld, true};
+        if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
+    }
+    auto rounds_of = [&](auto* tag) {
+        using GG = typename Pointee<decltype(tag)>::type;
+        using T0 = Seg<GG, 0, 1>;
+        using T1 = Seg<GG, 1, 2>;
+        using T2 = Seg<GG, 2, 3>;
+        GG& gg = reinterpret_cast<GG&>(g);
+        for (size_t it = 0; it < rounds; it++) {
+            if (live && active && it >= (size_t)stage && it - stage < nblocks && !(FD_KNOCK_TS == 1 && stage == 2) && !(FD_KNOCK_TS == 2 && stage < 2) &&
+                !(FD_KNOCK_TS == 3 && stage != 0) && !(FD_KNOCK_TS == 4 && stage != 1)) {
+                const size_t j = it - stage;  // the block this stage works on in this round
+                if (stage == 0) ts_stage<T0, GG, true, W>(gg, part, 3, lane, nullptr, hand[grp][0][j & 1]);
+                else if (stage == 1) ts_stage<T1, GG, false, W>(gg, part, 3, lane, hand[grp][0][j & 1], hand[grp][1][j & 1]);
+                else pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, 0, FD_PIPE_PREFETCH != 0>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr);
+            }
+            __syncthreads();
+        }
+    };
+    using GL = typename LpOf<G>::type;
+    bool lp = false;
+    if constexpr (!SameType<GL, G>::v && FD_LP_ENABLE)
+        lp = __builtin_amdgcn_ballot_w64((live && active) && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(live && active) != 0ull;
+#if FD_PIPE_PRIO
+    if (stage == 2) __builtin_amdgcn_s_setprio(1);  // the serial filter wave is the round's critical path
+#endif
+    if (lp) rounds_of((GL*)nullptr); else rounds_of((G*)nullptr);
+    if (live && active && part == 0) {  // the waves of a split stage end with identical state: one of them stores it
+        VStore<false> st{slots + v, stride, 0};
+        VGate::W<VStore<false>> gate{&st, true};
+        if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
+    }
+}
+
+template <class G, int GPW>
+__global__ __launch_bounds__(64 * Ts3Roles<GPW>::WAVES) void k_render_ts3(float* __restrict__ slots, size_t stride, size_t V,
+                                                                          float* __restrict__ out, size_t T, const void* aux) {
+    if constexpr (TsPlan<G>::ok) render_ts3_body<G, GPW>(slots, stride, V, out, T, aux);
 }
 
 // ---- the pipeline kernel for the PLANAR layout ([voice][channel][frame_stride], the reference's BufferArray rows) ----

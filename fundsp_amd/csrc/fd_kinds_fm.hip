@@ -8,16 +8,13 @@
 // emitting it pair by pair with an `s_nop` after every dependent packed op (38-44 per item, 6-14 % slower; profiles/
 // r03_ab1_knockout_prio.txt, r03_isa_fm_svf.txt).  The ILP strategy produces the interleaved form every time.  It cannot
 // be a whole-library flag: ROCm 7.2's clang crashes with it in the register allocator on other kinds (Oversampler).
-#include "fd_engine.hpp"
+#include "fd_kinds_fm.hpp"
 
 namespace fd {
-// sine_hz(f) = constant(f) >> sine()                       prelude.rs:349
-using SineHz = Pipe<Constant<1>, Sine>;
-// config 1: sine_hz(440) >> lowpass_hz(1000, 1)
-using SineHzLowpass = Pipe<SineHz, FixedSvf>;
-// config 3: sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q)     (README.md:98-103)
-using FmMod = Unop<Unop<Unop<SineHz, UMulScalar>, UMulScalar>, UAddScalar>;
-using FmSvf = Pipe<Pipe<FmMod, Sine>, FixedSvf>;
+// the three-way time-split kernels of these types are compiled in fd_kinds_fm_ts.hip (default scheduling strategy)
+#define FD_X(G, GPW) extern template __global__ void k_render_ts3<G, GPW>(float* __restrict__, size_t, size_t, float* __restrict__, size_t, const void*);
+FD_FM_TS3_KERNELS(FD_X)
+#undef FD_X
 
 void register_fm_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<SineHz>("sine_hz"));

@@ -59,6 +59,26 @@ def test_time_split_equals_oracle_and_pipeline_kernel(gpu, time_split):
     assert_bit_equal(np.concatenate([a, c], axis=1), want2, "time-split launch followed by a ragged launch")
 
 
+def test_time_split_two_groups_per_cu_layout(gpu, time_split):
+    """Banks of more than one voice group per CU (the 2-GPU shard of the headline) take the 14-wave workgroup of the
+    three-way time split (two groups per workgroup; ragged last workgroup: an odd number of groups plus a ragged group).
+    Against the pipeline kernel over the whole bank and against the oracle on voices of the first, a middle and the last
+    workgroup; round 2's 2 + 1 + 1 layout (time_split = 2) must agree as well."""
+    V, T = 64 * 301 + 5, 64 * 6
+    p = W.fm_svf_params(V, SR)
+    outs = {}
+    for split in (1, 2, 0):
+        time_split(split)
+        b = W.make_fm_svf_bank(V, SR, params=p)
+        outs[split] = run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :]
+        assert b.get_option("last_kernel") == (4 if split else 2)
+    assert_bit_equal(outs[1], outs[0], "3 + 3 + 1 time split == pipeline kernel, 302 voice groups")
+    assert_bit_equal(outs[2], outs[0], "2 + 1 + 1 time split == pipeline kernel")
+    pick = np.array([0, 63, 64, 127, 64 * 150 + 17, 64 * 300, V - 6, V - 1])
+    want, _ = O.bank_render(3, [p["f"][pick], p["m"][pick], p["fc"][pick], p["q"][pick]], p["seed"][pick], T, SR, True, 0, 4)
+    assert_bit_equal(outs[1][pick], want, "time split vs oracle")
+
+
 def test_time_split_rollback_path_and_negative_frequencies(gpu, time_split):
     """A modulator / carrier phase of exactly -0.0 at a block start sends that block down the packed path's rollback
     (Sine::begin_block), in the split waves too; huge modulation indices trip the |quadrant| < 8192 guard mid-block."""
