@@ -459,6 +459,66 @@ FD_HD float tanhf_musl(float x0) {
     return sign ? -r : r;
 }
 
+// tanhf_musl for the arguments a ladder filter sees on (nearly) every sample: |x| <= 7.5, not NaN.  Outside that range --
+// musl's |x| > 10 and NaN arms, and the k >= 23 form of the reconstruction (|x| >= 7.97) -- `wmax`, the running maximum
+// of the argument's magnitude BITS (one v_max_u32; a NaN's bits exceed every finite value's), makes the caller re-render
+// the tile with tanhf_musl (Moog::tripped, the rollback every packed-path shortcut of the engine uses).  Inside the range
+// each lane performs exactly tanhf_musl's operations for its case: the dropped arms are never selected there (|x| <= 7.5
+// gives a <= 15, k <= 22).  Ten instructions fewer on the one-sample feedback loop of the ladder.  Bit-identical to
+// tanhf_musl on all 2^31 x 2 bit patterns with |x| <= 7.5, zero and subnormals included (tests/host/check_tanh_expm1.hip).
+constexpr uint32_t TANH_COMMON_MAX_BITS = 0x40f00000u;  // 7.5f
+FD_HD float tanhf_common(float x0, uint32_t& wmax) {
+    constexpr float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, invln2 = 1.4426950216e+00f,
+                    Q1 = -3.3333212137e-2f, Q2 = 1.5807170421e-3f;
+    uint32_t w = f2u(x0);
+    const bool sign = (w >> 31) != 0;
+    w &= 0x7fffffffu;
+    wmax = wmax > w ? wmax : w;
+    const float x = u2f(w);
+    const bool c1 = w > 0x3f0c9f54u;       // |x| > log(3)/2
+    const bool c2 = w > 0x3e82c578u;       // |x| > log(5/3)/2
+    const bool c3 = w >= 0x00800000u;      // normal
+    const float two_x = 2 * x;
+    const float a = c2 ? two_x : -two_x;
+    const uint32_t ha = f2u(two_x);
+    const bool reduce = ha > 0x3eb17218u;
+    const bool near1 = ha < 0x3F851592u;
+    const int kg = (int)(invln2 * a + 0.5f);
+    const float tg = (float)kg;
+    const float tpos = near1 ? 1.0f : tg;
+    const int kpos = near1 ? 1 : kg;
+    const float tk = c2 ? tpos : -1.0f;
+    const int k = c2 ? kpos : -1;
+    const float hi = a - tk * ln2_hi;
+    const float lo = tk * ln2_lo;
+    const float xr = hi - lo;
+    const float cr = (hi - xr) - lo;
+    const float xx = reduce ? xr : a;
+    const float c = reduce ? cr : 0.0f;
+    const float hfx = 0.5f * xx;
+    const float hxs = xx * hfx;
+    const float r1 = 1.0f + hxs * (Q1 + hxs * Q2);
+    const float tt = 3.0f - r1 * hfx;
+    const float e = hxs * div_inrange(r1 - tt, 6.0f - xx * tt);
+    const float res_k0 = xx - (xx * e - hxs);
+    float e2 = xx * (e - c) - c;
+    e2 -= hxs;
+    const float res_km1 = 0.5f * (xx - e2) - 0.5f;
+    const float twopk = u2f(((uint32_t)0x7f + (uint32_t)k) << 23);
+    const float uf = u2f(((uint32_t)0x7f - (uint32_t)k) << 23);
+    const float res_pos = (xx - e2 + (1 - uf)) * twopk;   // k < 23 throughout the range
+    const float res_neg = reduce ? res_km1 : res_k0;
+    const float t = c2 ? res_pos : res_neg;
+    const float mt = -t;
+    const float num_small = c2 ? t : mt;
+    const float num = c1 ? 2.0f : num_small;
+    const float quo = div_inrange(num, t + 2);
+    const float one_minus = 1 - quo;
+    float r = c1 ? one_minus : quo;
+    r = c3 ? r : x;                        // zero / subnormal: t = x
+    return sign ? -r : r;
+}
+
 // musl atanf.c (FreeBSD s_atanf.c), case selection by selects
 FD_HD float atanf_musl(float x0) {
     constexpr float aT0 = 3.3333328366e-01f, aT1 = -1.9999158382e-01f, aT2 = 1.4253635705e-01f,

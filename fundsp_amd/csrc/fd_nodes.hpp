@@ -441,6 +441,9 @@ struct Noise {
 };
 
 // SVF core shared by FixedSvf and Svf:  svf.rs:995-1006 / :829-843
+#ifndef FD_MOOG_COMMON
+#define FD_MOOG_COMMON 1  // the ladder's packed path evaluates its tanh with tanhf_common (guarded, rollback); A/B switch: 0
+#endif
 #ifndef FD_SVF_PK
 #define FD_SVF_PK 1     // the lowpass SVF's two state equations as one packed computation (FixedSvfLp); A/B switch: 0 = plain
 #endif
@@ -803,9 +806,48 @@ struct Moog {
     FD_HD void reset() { s0 = s1 = s2 = s3 = px = ps0 = ps1 = ps2 = 0.0f; }  // :65-74
     FD_HD uint64_t ping(bool, uint64_t h) { return atto(h, ID); }
     FD_HD void end_simd() {}
-    FD_HD void begin_block(int) {}
-    FD_HD bool tripped() const { return false; }
-    FD_HD void bind(Ctx&) {}
+    uint32_t wmax;  // transient guard of the packed path (not a slot): largest |tanh argument| bits seen, see tanhf_common
+    FD_HD void begin_block(int) { wmax = 0u; }
+    FD_HD bool tripped() const { return wmax > TANH_COMMON_MAX_BITS; }
+    FD_HD void bind(Ctx&) { wmax = 0u; }
+    // Packed path (full SIMD items of a process block): the same recurrence with the saturator evaluated by tanhf_common --
+    // exact for |argument| <= 7.5; beyond (or NaN) the tile is re-rendered through step() from the caller's snapshot.
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+#if FD_MOOG_COMMON
+        if (PH == PH_SIMD) {
+            float o[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const float i0 = j ? in[0].y : in[0].x;
+                if (NIN > 1) {
+                    const float i1 = j ? in[1].y : in[1].x, i2 = j ? in[2].y : in[2].x;
+                    if (f2u(i1) != f2u(cutoff) || f2u(i2) != f2u(q)) set_cutoff_q(i1, i2);
+                }
+                float x = -rez * s3 + i0;
+                s0 = (x + px) * p - k * s0;
+                s1 = (s0 + ps0) * p - k * s1;
+                s2 = (s1 + ps1) * p - k * s2;
+                s3 = tanhf_common((s2 + ps2) * p - k * s3, wmax);
+                px = x;
+                ps0 = s0;
+                ps1 = s1;
+                ps2 = s2;
+                o[j] = s3;
+            }
+            out[0] = v2f{o[0], o[1]};
+            return;
+        }
+#endif
+        float i0[NIN], i1[NIN], o0, o1;
+#pragma unroll
+        for (int c = 0; c < NIN; c++) {
+            i0[c] = in[c].x;
+            i1[c] = in[c].y;
+        }
+        this->template step<PH>(i0, &o0);
+        this->template step<PH>(i1, &o1);
+        out[0] = v2f{o0, o1};
+    }
     template <int PH> FD_HD void step(const float* in, float* out) {  // :82-100
         // The reference recomputes (p, k, rez) from (cutoff, q) on EVERY sample (moog.rs:83-85).  They are a pure
         // function of the BITS of the two inputs and the sample rate, so recomputing only when an input's bit pattern
@@ -826,7 +868,6 @@ struct Moog {
         ps2 = s2;
         out[0] = s3;
     }
-    FD_STEP2_VIA_STEP
 };
 
 // Moog in tolerance mode (FDSP_MATH_FAST): the ladder recurrence is kept operation for operation (unfused), only the

@@ -27,7 +27,37 @@ static void check(uint32_t u) {
         bad++;
     }
 }
+// tanhf_common (the ladder's packed path) == tanhf_musl wherever its guard does not trip; the guard trips exactly above 7.5 / on NaN
+static void check_common(uint32_t u) {
+    using namespace fd;
+    const float x = u2f(u);
+    uint32_t wm = 0;
+    const uint32_t a = f2u(tanhf_common(x, wm));
+    const bool trip = wm > TANH_COMMON_MAX_BITS;
+    const bool should = (u & 0x7fffffffu) > TANH_COMMON_MAX_BITS;
+    seen++;
+    if (trip != should || (!trip && a != f2u(tanhf_musl(x)))) {
+        if (bad < 10) printf("tanhf_common: x = %a (%08x): %08x vs %08x, guard %d (expected %d)\n", x, u, a, f2u(tanhf_musl(x)), (int)trip, (int)should);
+        bad++;
+    }
+}
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "--common")) {  // all bit patterns up to 7.5 in magnitude (both signs) + a band above the guard
+        const unsigned nt = std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 8;
+        const uint64_t stride = argc > 2 ? strtoull(argv[2], nullptr, 0) : 1;
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < nt; k++)
+            th.emplace_back([k, nt, stride] {
+                for (uint64_t m = (uint64_t)k * stride; m <= (uint64_t)fd::TANH_COMMON_MAX_BITS + 70000; m += (uint64_t)nt * stride) {
+                    check_common((uint32_t)m);
+                    check_common((uint32_t)m | 0x80000000u);
+                }
+            });
+        for (auto& t : th) t.join();
+        for (uint32_t u : {0x7f800000u, 0xff800000u, 0x7fc00000u, 0xffc00001u, 0x7f800001u, 0x41200001u, 0x7f7fffffu}) check_common(u);
+        printf("tanhf_common: %llu values (stride %llu), bad %llu\n", (unsigned long long)seen, (unsigned long long)stride, (unsigned long long)bad);
+        return bad ? 1 : 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "--all")) {  // every one of the 2^32 bit patterns (one-off; ~1 min on 8 threads)
         const unsigned nt = std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 8;
         std::vector<std::thread> th;

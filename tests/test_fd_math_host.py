@@ -22,6 +22,12 @@ def test_wide_sin2_matches_wide_sinf_on_host(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bad 0" in r.stdout
+    # tanhf_common (the ladder's packed-path saturator, guarded): every 257th bit pattern of its whole domain here; all
+    # 2.18e9 of them were run once on this host (0 differences, 21 CPU-minutes) and all 2^32 on the device
+    # (tests/host/check_tanh_common_device.hip, profiles/r03_tanh_common_device_exhaustive.txt)
+    r = subprocess.run([str(exe), "--common", "257"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bad 0" in r.stdout
 
 
 def test_device_trig_header_matches_oracle_over_the_whole_f32_range(tmp_path):

@@ -1,0 +1,62 @@
+// tools/launch_overhead.cpp -- what a 64-frame launch costs a COMPILED host (VERDICT r02 Weak 9 / Next 8: round 2 only had the
+// Python-side figure, 18 of 26 us per launch outside the kernel).  BASELINE config 2: 1024 voices, noise >> lowpass biquad,
+// T = 64 frames per fdsp_bank_process call, device-resident output, straight through the C ABI.
+//   (a) back-to-back launches on the bank's stream, one sync at the end  -> host cost per launch when the GPU keeps up
+//   (b) launch + fdsp_bank_synchronize per block                          -> round-trip latency of one block
+// each with the per-launch HIP event pair on ("timing" = 1, default) and off ("timing" = 0).
+// build: g++ -O2 -std=c++17 -I include tools/launch_overhead.cpp -o tools/_launch_overhead -L fundsp_amd -lfundsp_hip -Wl,-rpath,$PWD/fundsp_amd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "fundsp_hip.h"
+
+#define CK(x)                                                                 \
+    do {                                                                      \
+        int rc_ = (x);                                                        \
+        if (rc_ != 0) {                                                       \
+            std::printf("%s -> %d: %s\n", #x, rc_, fdsp_last_error());        \
+            return 1;                                                         \
+        }                                                                     \
+    } while (0)
+
+int main() {
+    const size_t V = 1024, T = 64;
+    fdsp_bank* b = nullptr;
+    CK(fdsp_bank_create("noise_biquad", V, &b));
+    CK(fdsp_bank_set_sample_rate(b, 48000.0));
+    float* out = nullptr;
+    if (hipMalloc((void**)&out, V * T * sizeof(float)) != hipSuccess) return 2;
+    using clk = std::chrono::steady_clock;
+    for (int timing = 1; timing >= 0; timing--) {
+        CK(fdsp_bank_set_option(b, "timing", timing));
+        for (int i = 0; i < 200; i++) CK(fdsp_bank_process(b, T, nullptr, out, FDSP_LAYOUT_VOICE_MINOR, 0, FDSP_MODE_PROCESS, nullptr));
+        CK(fdsp_bank_synchronize(b));
+        const int N = 5000;
+        auto t0 = clk::now();
+        for (int i = 0; i < N; i++) CK(fdsp_bank_process(b, T, nullptr, out, FDSP_LAYOUT_VOICE_MINOR, 0, FDSP_MODE_PROCESS, nullptr));
+        auto t1 = clk::now();
+        CK(fdsp_bank_synchronize(b));
+        auto t2 = clk::now();
+        const double host_us = std::chrono::duration<double, std::micro>(t1 - t0).count() / N;
+        const double thru_us = std::chrono::duration<double, std::micro>(t2 - t0).count() / N;
+        auto t3 = clk::now();
+        for (int i = 0; i < 1000; i++) {
+            CK(fdsp_bank_process(b, T, nullptr, out, FDSP_LAYOUT_VOICE_MINOR, 0, FDSP_MODE_PROCESS, nullptr));
+            CK(fdsp_bank_synchronize(b));
+        }
+        auto t4 = clk::now();
+        const double rt_us = std::chrono::duration<double, std::micro>(t4 - t3).count() / 1000;
+        float kms = 0.f;
+        if (timing) fdsp_bank_last_kernel_ms(b, &kms);
+        std::printf("config 2, 1024 voices x 64 frames per launch, timing=%d: host time in fdsp_bank_process %.2f us/launch, %d back-to-back launches "
+                    "%.2f us/launch, launch + synchronize %.2f us/block%s\n", timing, host_us, N, thru_us, rt_us, timing ? "" : " (no event pair)");
+        if (timing) std::printf("  kernel alone (HIP events of the last launch): %.2f us\n", kms * 1e3);
+    }
+    hipFree(out);
+    fdsp_bank_destroy(b);
+    return 0;
+}
