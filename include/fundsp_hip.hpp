@@ -530,6 +530,22 @@ class Bank {
     }
     Bank(const Bank&) = delete;
     Bank& operator=(const Bank&) = delete;
+    // `Clone` (audionode.rs:35): a new bank that continues exactly where this one stands (fdsp_bank_clone: slots, delay
+    // rings, sample rate, arithmetic mode, launch options, scheduler events, reverb line state)
+    Bank clone() const {
+        Bank b;
+        check(fdsp_bank_clone(h_, &b.h_));
+        b.kind_ = kind_;
+        b.ring_frames_ = ring_frames_;
+        return b;
+    }
+    // launch options of this bank ("pipe_split", "time_split", "fdn_kernel", "timing", "math"; -1 = process-wide default)
+    void set_option(const std::string& name, int value) { check(fdsp_bank_set_option(h_, name.c_str(), value)); }
+    int get_option(const std::string& name) const {
+        const int v = fdsp_bank_get_option(h_, name.c_str());
+        if (v < 0) check(v);
+        return v;
+    }
     ~Bank() { close(); }
     void close() {
         if (h_) fdsp_bank_destroy(h_);
@@ -583,14 +599,6 @@ class Bank {
     }
     void events_rewind(double time) { check(fdsp_bank_events_rewind(h_, time)); }
     double events_time() const { return fdsp_bank_events_time(h_); }
-    // Clone (audionode.rs:29): same kind, same parameters and state
-    Bank clone() const {
-        Bank b(kind_, voices(), ring_frames_);
-        std::vector<float> st((size_t)fdsp_bank_slot_count(h_) * voices());
-        check(fdsp_bank_get_state(h_, st.data()));
-        check(fdsp_bank_set_state(b.h_, st.data()));
-        return b;
-    }
 
  private:
     fdsp_bank* h_ = nullptr;
