@@ -639,8 +639,8 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
 #define FD_KNOCK_TS 0   // measurement only: k_render_ts3 with 1 = the filter wave idle, 2 = only the filter wave, 3 = only stage 0, 4 = only stage 1
 #endif
 #ifndef FD_KNOCK
-#define FD_KNOCK 0      // measurement only (NOT a renderer): compute stage FD_KNOCK - 1 of the pipeline kernel idles, so the other
-#endif                  // stage's wave has its SIMD to itself; the hand-over tiles start zeroed (profiles/r03_knockout_c3.txt)
+#define FD_KNOCK 0      // measurement only (NOT a renderer): bit s set = compute stage s of the pipeline kernel idles, so the others
+#endif                  // run without it; the hand-over tiles start zeroed (profiles/r03_ab1_knockout_prio.txt, r03_knockout_c4.txt)
 // ---- multi-wave pipeline split of a Pipe chain ------------------------------------------------------------------
 // At one voice-wave per SIMD (65 536 voices on 1024 SIMDs) a lone wave issues one instruction per ~4.7 cycles while
 // the VALU could take one every ~2.5-3.3 (profiles/r01_ubench_valu.txt, r01_voice_sweep_*).  For graphs that are a
@@ -1226,7 +1226,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
         using T2 = typename TG::S2;
         GG& gg = reinterpret_cast<GG&>(g);
         for (size_t it = 0; it < rounds; it++) {
-            if (live && active && it >= first && it - first < ntiles && (FD_KNOCK == 0 || stage != FD_KNOCK - 1)) {
+            if (live && active && it >= first && it - first < ntiles && ((FD_KNOCK >> stage) & 1) == 0) {
                 const size_t j = it - first;          // the tile this stage works on in this round
                 const size_t t0 = (j / SPB) * 64;
                 const int h = (int)(j % SPB);

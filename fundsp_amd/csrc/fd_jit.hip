@@ -240,8 +240,8 @@ int jit_compile_code(const std::string& type_expr, const std::string& prelude, s
     // prevent_denormals() (feedback.rs:96, denormal.rs:18)
     const bool ftz = type_expr.find("Feedback") != std::string::npos;
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
-                          "-fgpu-flush-denormals-to-zero"};
-    hiprtcResult r = hiprtcCompileProgram(prog, ftz ? 7 : 6, opts);
+                          "-fgpu-flush-denormals-to-zero", "-DFD_FTZ=1"};  // FD_FTZ: fd_math.hpp's flush-only selects
+    hiprtcResult r = hiprtcCompileProgram(prog, ftz ? 8 : 6, opts);
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);
     if (ls > 1) {

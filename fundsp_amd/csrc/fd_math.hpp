@@ -362,6 +362,10 @@ FD_HD float expm1f_musl(float x0) {
     return res;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));  // one v_pk_*_f32 operand: two f32 in a VGPR pair
+
+FD_HD v2f splat2(float x) { return v2f{x, x}; }
+
 // n / d for operands that need none of the IEEE division's range handling (no denormal, no overflow, quotient far from
 // both): the device's f32 division is v_div_scale x2, v_rcp, four fma / one mul of Newton-Raphson and residual
 // correction, v_div_fmas, v_div_fixup; with nothing to scale, v_div_scale passes its operand through, v_div_fmas is an
@@ -460,63 +464,98 @@ FD_HD float tanhf_musl(float x0) {
 }
 
 // tanhf_musl for the arguments a ladder filter sees on (nearly) every sample: |x| <= 7.5, not NaN.  Outside that range --
-// musl's |x| > 10 and NaN arms, and the k >= 23 form of the reconstruction (|x| >= 7.97) -- `wmax`, the running maximum
+// musl's |x| > 10 and NaN arms, and the k >= 23 form of expm1f's reconstruction (|x| >= 7.97) -- `wmax`, the running maximum
 // of the argument's magnitude BITS (one v_max_u32; a NaN's bits exceed every finite value's), makes the caller re-render
-// the tile with tanhf_musl (Moog::tripped, the rollback every packed-path shortcut of the engine uses).  Inside the range
-// each lane performs exactly tanhf_musl's operations for its case: the dropped arms are never selected there (|x| <= 7.5
-// gives a <= 15, k <= 22).  Ten instructions fewer on the one-sample feedback loop of the ladder.  Bit-identical to
-// tanhf_musl on all 2^31 x 2 bit patterns with |x| <= 7.5, zero and subnormals included (tests/host/check_tanh_expm1.hip).
+// the tile with tanhf_musl (Moog::tripped, the rollback every packed-path shortcut of the engine uses).
+//
+// The ladder evaluates this once per sample on its one-sample feedback loop, where every instruction is an issue slot of the
+// stage's single wave (~4.4 cycles) whatever its data dependencies: the instruction COUNT is the cost (config 4: 99 slots per
+// sample for ladder + tanhf_musl-by-selects in round 2, 69 now).  Inside the guarded range the function is a function of ONE
+// f32, so every shortening is proven by enumeration, not argued: tests/host/check_tanh_common_device.hip compares it with the
+// device build of tanhf_musl on all 2^32 bit patterns, with denormals kept and flushed (profiles/r03_tanh_common_device_
+// exhaustive.txt; its control -- FD_TANH_DIV_B=3, a quotient without any correction -- differs on 153 M patterns).  What the
+// enumeration licenses:
+//   * ONE form for every case.  musl's expm1f has special forms for k = 0, k = -1 and k = 1; each is the k-general form
+//     (x - e + (1 - 2^-k)) 2^k with exact steps added or removed (c = 0, 2^-k = 1, 2^k = 1 for k = 0; a scaling by two
+//     commutes with a rounding for k = +-1), so every lane runs the general form with its own k and the only selects left are
+//     the sign of a = +-2|x| and tanhf's own |x| > log(3)/2.
+//   * k = rint(invln2 a) instead of (int)(invln2 a +- 0.5) and the k = +-1 shortcuts: the same k on every reachable a.
+//   * the two divisions as rcp, q = n r, one residual correction (4 instructions, div_common<2>): the textbook sequence with a
+//     Newton step on r and two corrections is what rounds correctly for EVERY operand pair; on the 2^31 pairs that occur
+//     here the short one gives the same bits.
+//   * the numerator of tanhf's quotient as |t| (t > 0 for a > 0, t <= 0 for a < 0), and the sign put back with one v_bfi
+//     (the magnitude is tanh |x| >= 0).
+//   * two packed instructions for the two pairs of independent like operations (k {ln2_hi, ln2_lo}; {r1, 6} - {tt, x tt}).
+// Host builds divide with `/` (tests/host/check_tanh_expm1.hip --common: all bit patterns against the branch-form oracle).
 constexpr uint32_t TANH_COMMON_MAX_BITS = 0x40f00000u;  // 7.5f
+#ifndef FD_TANH_DIV_A
+#define FD_TANH_DIV_A 2      // div_common level of tanhf_common's first division (0 = div_inrange; 3 = the check's control)
+#endif
+#ifndef FD_TANH_DIV_B
+#define FD_TANH_DIV_B 2      // ... and of its second one
+#endif
+#ifndef FD_FTZ
+#define FD_FTZ 0             // 1 in translation units built with -fgpu-flush-denormals-to-zero (fd_fdn.hip, fd_jit.hip's Feedback graphs)
+#endif
+template <int LEVEL>
+FD_HD float div_common(float n, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (LEVEL == 0) return div_inrange(n, d);
+    float r = __builtin_amdgcn_rcpf(d);
+    if (LEVEL == 1) {
+        const float e0 = __builtin_fmaf(-d, r, 1.0f);
+        r = __builtin_fmaf(e0, r, r);
+    }
+    const float q = n * r;
+    if (LEVEL == 3) return q;  // (NOT exact: the sensitivity control of the exhaustive check)
+    const float e1 = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e1, r, q);
+#else
+    return n / d;
+#endif
+}
 FD_HD float tanhf_common(float x0, uint32_t& wmax) {
     constexpr float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, invln2 = 1.4426950216e+00f,
                     Q1 = -3.3333212137e-2f, Q2 = 1.5807170421e-3f;
-    uint32_t w = f2u(x0);
-    const bool sign = (w >> 31) != 0;
-    w &= 0x7fffffffu;
+    const uint32_t w0 = f2u(x0);
+    const uint32_t w = w0 & 0x7fffffffu;
     wmax = wmax > w ? wmax : w;
     const float x = u2f(w);
-    const bool c1 = w > 0x3f0c9f54u;       // |x| > log(3)/2
-    const bool c2 = w > 0x3e82c578u;       // |x| > log(5/3)/2
-    const bool c3 = w >= 0x00800000u;      // normal
+    const bool c1 = w > 0x3f0c9f54u;       // |x| > log(3)/2:   tanh = 1 - 2 / (expm1(2|x|) + 2)
+    const bool c2 = w > 0x3e82c578u;       // |x| > log(5/3)/2: tanh = t / (t + 2), t = expm1(2|x|); below: -t / (t + 2), t = expm1(-2|x|)
     const float two_x = 2 * x;
     const float a = c2 ? two_x : -two_x;
-    const uint32_t ha = f2u(two_x);
-    const bool reduce = ha > 0x3eb17218u;
-    const bool near1 = ha < 0x3F851592u;
-    const int kg = (int)(invln2 * a + 0.5f);
-    const float tg = (float)kg;
-    const float tpos = near1 ? 1.0f : tg;
-    const int kpos = near1 ? 1 : kg;
-    const float tk = c2 ? tpos : -1.0f;
-    const int k = c2 ? kpos : -1;
-    const float hi = a - tk * ln2_hi;
-    const float lo = tk * ln2_lo;
-    const float xr = hi - lo;
-    const float cr = (hi - xr) - lo;
-    const float xx = reduce ? xr : a;
-    const float c = reduce ? cr : 0.0f;
+    // ---- expm1f(a), k-general form ----
+    const float tk = __builtin_rintf(invln2 * a);
+    const int k = (int)tk;
+    const v2f hl = splat2(tk) * v2f{ln2_hi, ln2_lo};
+    const float hi = a - hl.x;
+    const float lo = hl.y;
+    const float xx = hi - lo;
+    const float c = (hi - xx) - lo;
     const float hfx = 0.5f * xx;
     const float hxs = xx * hfx;
     const float r1 = 1.0f + hxs * (Q1 + hxs * Q2);
     const float tt = 3.0f - r1 * hfx;
-    const float e = hxs * div_inrange(r1 - tt, 6.0f - xx * tt);
-    const float res_k0 = xx - (xx * e - hxs);
+    const v2f nd = v2f{r1, 6.0f} - v2f{tt, xx * tt};
+    const float e = hxs * div_common<FD_TANH_DIV_A>(nd.x, nd.y);
     float e2 = xx * (e - c) - c;
     e2 -= hxs;
-    const float res_km1 = 0.5f * (xx - e2) - 0.5f;
-    const float twopk = u2f(((uint32_t)0x7f + (uint32_t)k) << 23);
-    const float uf = u2f(((uint32_t)0x7f - (uint32_t)k) << 23);
-    const float res_pos = (xx - e2 + (1 - uf)) * twopk;   // k < 23 throughout the range
-    const float res_neg = reduce ? res_km1 : res_k0;
-    const float t = c2 ? res_pos : res_neg;
-    const float mt = -t;
-    const float num_small = c2 ? t : mt;
-    const float num = c1 ? 2.0f : num_small;
-    const float quo = div_inrange(num, t + 2);
+    const uint32_t kb = (uint32_t)k << 23;
+    const float twopk = u2f(0x3f800000u + kb);
+    const float uf = u2f(0x3f800000u - kb);
+    const float t = (xx - e2 + (1 - uf)) * twopk;          // k < 23 throughout the range
+    // ---- tanhf ----
+    const float num = c1 ? 2.0f : __builtin_fabsf(t);
+    const float quo = div_common<FD_TANH_DIV_B>(num, t + 2);
     const float one_minus = 1 - quo;
     float r = c1 ? one_minus : quo;
-    r = c3 ? r : x;                        // zero / subnormal: t = x
-    return sign ? -r : r;
+#if FD_FTZ
+    // musl returns a zero or subnormal x itself.  With denormals kept the arithmetic above does too (t = -2x exactly,
+    // 2x / (2 - 2x) = x); a flush-to-zero build (graphs with a Feedback node) needs the select
+    r = (w >= 0x00800000u) ? r : x;
+#endif
+    return u2f((f2u(r) & 0x7fffffffu) | (w0 & 0x80000000u));
 }
 
 // musl atanf.c (FreeBSD s_atanf.c), case selection by selects
@@ -681,10 +720,6 @@ FD_HD float wide_sinf(float self) {
 #ifndef FD_SINE_BFE
 #define FD_SINE_BFE 1    // the odd-quadrant select of wide_sin2 as v_bfe_i32 + v_bfi_b32 (one issue slot less per frame than v_and + v_cmp + v_cndmask); A/B switch: 0
 #endif
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-FD_HD v2f splat2(float x) { return v2f{x, x}; }
-
 // `tmax` accumulates the largest quadrant argument seen (one v_max3_f32): the shortcuts below are exact only while
 // it stays < 8192; the caller checks it once per 64-sample block and, if it tripped, re-renders that block with the
 // fully general scalar wide_sinf (optimistic execution + rollback keeps the hot loop branch-free).

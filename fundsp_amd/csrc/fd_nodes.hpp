@@ -816,6 +816,33 @@ struct Moog {
 #if FD_MOOG_COMMON
         if (PH == PH_SIMD) {
             float o[2];
+            bool same = NIN == 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (NIN > 1) {
+                // (cutoff, q) of BOTH samples against the stored pair in one wave-uniform test: four xor/or instructions,
+                // one compare and a scalar branch per PAIR, where the per-sample form below costs a compare pair, an
+                // exec-mask save, a branch and a restore per SAMPLE on the stage's single wave
+                const uint32_t chg = (f2u(in[1].x) ^ f2u(cutoff)) | (f2u(in[2].x) ^ f2u(q)) | (f2u(in[1].y) ^ f2u(cutoff)) | (f2u(in[2].y) ^ f2u(q));
+                same = __builtin_amdgcn_ballot_w64(chg != 0u) == 0ull;
+            }
+#endif
+            if (__builtin_expect(same, 1)) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    float x = -rez * s3 + (j ? in[0].y : in[0].x);
+                    s0 = (x + px) * p - k * s0;
+                    s1 = (s0 + ps0) * p - k * s1;
+                    s2 = (s1 + ps1) * p - k * s2;
+                    s3 = tanhf_common((s2 + ps2) * p - k * s3, wmax);
+                    px = x;
+                    ps0 = s0;
+                    ps1 = s1;
+                    ps2 = s2;
+                    o[j] = s3;
+                }
+                out[0] = v2f{o[0], o[1]};
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const float i0 = j ? in[0].y : in[0].x;
@@ -823,6 +850,8 @@ struct Moog {
                     const float i1 = j ? in[1].y : in[1].x, i2 = j ? in[2].y : in[2].x;
                     if (f2u(i1) != f2u(cutoff) || f2u(i2) != f2u(q)) set_cutoff_q(i1, i2);
                 }
+                // (the five products with the previous sample's state as packed multiplies were tried: every packed result feeds
+                // the next instruction of this serial chain and costs a wait state -- 101 issue slots per sample against 99)
                 float x = -rez * s3 + i0;
                 s0 = (x + px) * p - k * s0;
                 s1 = (s0 + ps0) * p - k * s1;
@@ -1058,6 +1087,9 @@ FD_HD Tap4 wt_tap(const float* __restrict__ tab, uint32_t mask, float phase) {  
     return t;
 }
 FD_HD float tap_eval(const Tap4& t) { return optimal4x44(t.a0, t.a1, t.a2, t.a3, t.w); }
+#ifndef FD_WT_PREFETCH
+#define FD_WT_PREFETCH 1  // WaveSynth's packed path gathers the taps of the NEXT frame pair while it evaluates this one; A/B switch: 0
+#endif
 
 template <int SET, int NOUT = 1>  // WaveSynth<U2> also outputs the wrapped phase (wavetable.rs:318-324, 343-345)
 struct WaveSynth {
@@ -1074,6 +1106,10 @@ struct WaveSynth {
     float c_p0, c_p1;
     const float *c_tab1, *c_tab2;
     uint32_t c_mask1, c_mask2;
+    // the taps gathered ahead for the next frame pair (packed path), valid for exactly the wrapped phases pf_p0 / pf_p1
+    bool pf_ok;
+    uint32_t pf_p0, pf_p1;
+    Tap4 pf_a1, pf_a2, pf_b1, pf_b2;
     template <class V> FD_HD void visit(V& v) {
         v.f(phase, STATE, "phase");
         v.u32(hint, STATE, "table_hint");
@@ -1085,6 +1121,7 @@ struct WaveSynth {
     FD_HD void bind(Ctx& a) {
         wt = &a.aux->wt[SET];
         c_table = -1;
+        pf_ok = false;
     }
     FD_HD void init() {  // WaveSynth::new :270-281: phase 0.0 WITHOUT reset
         phase = 0.0f;
@@ -1117,6 +1154,7 @@ struct WaveSynth {
             c_mask1 = (uint32_t)wt->len[t + 1] - 1u;
             c_mask2 = (uint32_t)wt->len[t + 2] - 1u;
             hint = (uint32_t)t;
+            pf_ok = false;  // taps gathered ahead came from the previous table pair
         }
         return clamp01f((f0 - c_p0) / (c_p1 - c_p0));
     }
@@ -1149,9 +1187,38 @@ struct WaveSynth {
             float ph0 = phase - __builtin_floorf(phase);
             phase += d.y;
             float ph1 = phase - __builtin_floorf(phase);
+#if FD_WT_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
+            // The gathers are served by L2 (a saw set is 160 KiB) and the stage has ~35 instructions per frame: issued
+            // where they are used, their round trip (~600 cycles per pair) is 2/3 of the stage's time (config 4: stage 0
+            // alone 10.4 ms, 33 issue slots per frame).  The next pair's phases are this pair's plus the same two
+            // increments whenever the frequency input repeats, so its taps are gathered NOW, before this pair's are
+            // evaluated, and the next call takes them if its phases have exactly the predicted bits (wave-uniform test;
+            // any other case -- a moving frequency, a new table pair, a rollback -- gathers in place as before).  The
+            // values are the table's for those phases either way.
+            Tap4 a1, a2, b1, b2;
+            const bool hit = pf_ok && f2u(ph0) == pf_p0 && f2u(ph1) == pf_p1;
+            if (__builtin_amdgcn_ballot_w64(!hit) == 0ull) {
+                a1 = pf_a1; a2 = pf_a2; b1 = pf_b1; b2 = pf_b2;
+            } else {
+                a1 = wt_tap(c_tab1, c_mask1, ph0); a2 = wt_tap(c_tab2, c_mask2, ph0);
+                b1 = wt_tap(c_tab1, c_mask1, ph1); b2 = wt_tap(c_tab2, c_mask2, ph1);
+            }
+            {
+                float np = phase + d.x;
+                const float q0 = np - __builtin_floorf(np);
+                np += d.y;
+                const float q1 = np - __builtin_floorf(np);
+                pf_a1 = wt_tap(c_tab1, c_mask1, q0); pf_a2 = wt_tap(c_tab2, c_mask2, q0);
+                pf_b1 = wt_tap(c_tab1, c_mask1, q1); pf_b2 = wt_tap(c_tab2, c_mask2, q1);
+                pf_p0 = f2u(q0);
+                pf_p1 = f2u(q1);
+                pf_ok = true;
+            }
+#else
             // 16 independent gathers in flight before any of them is consumed
             Tap4 a1 = wt_tap(c_tab1, c_mask1, ph0), a2 = wt_tap(c_tab2, c_mask2, ph0);
             Tap4 b1 = wt_tap(c_tab1, c_mask1, ph1), b2 = wt_tap(c_tab2, c_mask2, ph1);
+#endif
             float o0 = (1.0f - item_w) * tap_eval(a1) + item_w * tap_eval(a2);
             float o1 = (1.0f - item_w) * tap_eval(b1) + item_w * tap_eval(b2);
             out[0] = v2f{o0, o1};
@@ -1230,6 +1297,10 @@ struct AdsrLive {
     int s_loop_len;
     float s_t1, s_v1, s_value, s_value_d;
     uint64_t s_hash;
+    // the planned block (step2's packed path, see plan_block)
+    bool fast, f_trip;
+    int fb;      // sample of the block at which the prepared segment takes over; -1: the current chunk covers the block
+    float f_cb;  // the gate at that sample
     template <class V> FD_HD void visit(V& v) {
         v.f(attack, PARAM, "attack"); v.f(decay, PARAM, "decay"); v.f(sustain, PARAM, "sustain");
         v.f(release, PARAM, "release"); v.f(interval, PARAM, "interval");
@@ -1305,9 +1376,23 @@ struct AdsrLive {
         float samples = next_interval / sd;
         value_d = (v1 - v0) / samples;
     }
-    FD_HD void begin_block(int size) { blk_i = 0; blk_size = size; remaining = 0; full_seg = false; loop_len = 0; s_valid = false; }
-    FD_HD bool tripped() const { return false; }
-    FD_HD void end_simd() {}
+    FD_HD void begin_block(int size) { blk_i = 0; blk_size = size; remaining = 0; full_seg = false; loop_len = 0; s_valid = false; fast = false; }
+    // A planned block is exact unless the gate triggers at the take-over sample (or the plan could not be made): then the
+    // caller re-renders from its snapshot through step(), which walks the block the reference's way
+    FD_HD bool tripped() const { return fast && (f_trip || (fb >= 0 && blk_i > fb && closure_triggers(f_cb))); }
+    FD_HD void end_simd() {
+        if (fast) {  // the bookkeeping the sample-by-sample walk does at its two chunk ends, once
+            t += (float)(long long)loop_len * sd;
+            if (fb >= 0) {
+                t0 = t1; v0 = v1;
+                t1 = s_t1; v1 = s_v1; t_hash = s_hash;
+                t += (float)(long long)s_loop_len * sd;
+            }
+            remaining = 0;
+            s_valid = false;
+            fast = false;
+        }
+    }
     // Voices reach the ends of their ~2 ms segments at different samples, so in a wave of 64 some lane needs
     // next_segment -- two closure evaluations, seven divisions, a 64-bit hash -- at almost every sample, and the wave
     // pays for it every time.  Everything about a voice's next segment except the trigger logic is known at the head
@@ -1353,9 +1438,12 @@ struct AdsrLive {
             t += sd;
         } else {  // process :315-340, walked sample by sample (the whole block, no remainder path)
             if (blk_i == 0) {
+                fast = false;
                 if (t >= t1) next_segment(in[0]);
                 start_chunk();
                 speculate();
+            } else {
+                leave_fast();
             }
             for (int guard = 0; remaining == 0 && guard < 4; guard++) {  // chunk exhausted before this sample
                 if (full_seg && s_valid && !closure_triggers(in[0])) {  // the segment prepared at the head of the block
@@ -1376,7 +1464,63 @@ struct AdsrLive {
             if (remaining == 0) t += (float)(long long)loop_len * sd;
         }
     }
-    FD_STEP2_VIA_STEP
+    // The packed path.  With the next segment prepared at the head of the block (speculate) the walk above still costs the
+    // whole wave a masked trip through the take-over code at every sample where ANY of its 64 voices ends a segment --
+    // every second sample at 48 kHz (64 voices, ~96-sample segments).  But once the head of the block has run, the block's
+    // outputs are decided but for one thing, the gate at the take-over sample: a voice plays its current line up to sample
+    // fb and the prepared one from there (segments are longer than a block, so there is at most one take-over; a second
+    // one, or a first segment, is left to the walk).  So the packed path runs the two-line form without branches -- a
+    // compare and three selects per sample --, remembers the gate at fb, and commits the segment registers once, in
+    // end_simd.  tripped() reports a triggering gate (the first segment end after every gate edge) and the caller
+    // re-renders through step(); leave_fast() hands a half-planned block over to the walk (rollback of a later tile).
+    FD_HD void plan_block(float input) {
+        if (t >= t1) next_segment(input);
+        start_chunk();
+        speculate();
+        fast = true;
+        fb = loop_len < blk_size ? loop_len : -1;
+        f_trip = fb >= 0 && !(s_valid && s_loop_len == blk_size - loop_len);
+        f_cb = 0.0f;
+    }
+    FD_HD void leave_fast() {
+        if (!fast) return;
+        fast = false;
+        if (fb >= 0 && blk_i >= fb) t += (float)(long long)loop_len * sd;  // the first chunk ended at sample fb - 1
+        if (fb >= 0 && blk_i > fb) {  // ... and the prepared segment took over at fb (no trigger: tripped() was false then)
+            t0 = t1; v0 = v1;
+            t1 = s_t1; v1 = s_v1; t_hash = s_hash;
+            loop_len = s_loop_len; full_seg = s_full; remaining = s_loop_len - (blk_i - fb);
+            s_valid = false;
+        } else {
+            remaining = loop_len - blk_i;
+        }
+    }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        if (PH == PH_SIMD) {
+            if (blk_i == 0 && (blk_size & 7) == 0) plan_block(in[0].x);  // (blocks with remainder samples are walked)
+            if (__builtin_expect(fast, 1)) {
+                const int rel = fb - blk_i;
+                const bool at0 = rel == 0, at1 = rel == 1;
+                value = at0 ? s_value : value;
+                value_d = at0 ? s_value_d : value_d;
+                f_cb = at0 ? in[0].x : f_cb;
+                const float o0 = value;
+                value += value_d;
+                value = at1 ? s_value : value;
+                value_d = at1 ? s_value_d : value_d;
+                f_cb = at1 ? in[0].y : f_cb;
+                const float o1 = value;
+                value += value_d;
+                blk_i += 2;
+                out[0] = v2f{o0, o1};
+                return;
+            }
+        }
+        float i0 = in[0].x, i1 = in[0].y, o0, o1;
+        this->template step<PH>(&i0, &o0);
+        this->template step<PH>(&i1, &o1);
+        out[0] = v2f{o0, o1};
+    }
 };
 
 // Envelope<f32, E, R>  envelope.rs:17-179 (ID 14): control-rate closure E(t) sampled at jittered ~2 ms intervals and

@@ -13,6 +13,9 @@ struct Rec { uint64_t cycles; uint32_t hw, role; };
 #ifndef LAB_TILE
 #define LAB_TILE 8  // trips between barriers in TILE mode (8 = 64-frame tiles)
 #endif
+#ifndef LAB_A_SPLIT
+#define LAB_A_SPLIT 1  // 2: role A is time-split over two waves per SIMD (12-wave workgroups: A, B, A), each doing half of the trips
+#endif
 #ifndef LAB_MERGED
 #define LAB_MERGED 0  // 1: every wave runs body A then body B each trip (the unsplit voice), no roles
 #endif
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(LAB_WAVES * 64) void lab(Rec* rec, int reps, int mo
             if (role == 0) {
                 if (mode & 1) {
 #pragma unroll 1
-                    for (int it = 0; it < LAB_TILE; it++) asm volatile("; LAB_BODY_A" ::: CLOB_V, CLOB_S);
+                    for (int it = 0; it < LAB_TILE / LAB_A_SPLIT; it++) asm volatile("; LAB_BODY_A" ::: CLOB_V, CLOB_S);
                 }
             } else if (mode & 2) {
 #pragma unroll 1

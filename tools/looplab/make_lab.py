@@ -52,7 +52,7 @@ A = min((L for L in loops if not any("buffer_store" in x for x in L)), key=len) 
 def sizes(ins):
     txt = "\n".join(ins) + "\n"
     out = subprocess.run([LLVM + "/llvm-mc", "-arch=amdgcn", "-mcpu=gfx950", "-show-encoding"], input=txt, capture_output=True, text=True).stdout
-    sz = [l.count("0x") for l in out.split("\n") if "encoding:" in l]
+    sz = [len(l.split("encoding: [", 1)[1].split("]")[0].split(",")) for l in out.split("\n") if "encoding: [" in l]
     assert len(sz) == len(ins), (len(sz), len(ins))
     return sz
 
@@ -103,6 +103,10 @@ VARIANTS = {
     "align_a2": (pad_align(A, 2), B),
     "align_a1": (pad_align(A, 1), B),
     "align_a2_nostore": (pad_align(A, 2), [x for x in B if "buffer_store" not in x]),
+    "align_a6": (pad_align(A, 6), B),
+    "align_a12": (pad_align(A, 12), B),
+    "align_ab6": (pad_align(A, 6), pad_align(B, 6)),
+    "align_ab12": (pad_align(A, 12), pad_align(B, 12)),
     "align_b": (A, pad_align(B)),
     "align_b2": (A, pad_align(B, 2)),
     "vconst": (vconst(A), vconst(B)),
@@ -113,7 +117,7 @@ tmpl = template()
 # carriers of other shapes: four waves per SIMD (16-wave workgroups, 32-frame tiles: the same LDS), and the unsplit voice
 # (every wave runs A then B) at two and four waves per SIMD
 SHAPES = {"": tmpl, "_w16": template("-DLAB_WAVES=16", "-DLAB_TILE=4"), "_merged": template("-DLAB_MERGED=1"),
-          "_merged_w16": template("-DLAB_MERGED=1", "-DLAB_WAVES=16")}
+          "_merged_w16": template("-DLAB_MERGED=1", "-DLAB_WAVES=16"), "_aab": template("-DLAB_WAVES=12", "-DLAB_A_SPLIT=2")}
 va, sa = used(A); vb, sb = used(B)
 init = ["\tv_mov_b32 v%d, 0.5" % r for r in sorted(va | vb | set(range(100, 120)))]
 # LDS addresses (the registers the ds_ instructions use) inside the allocation; null buffer resource
@@ -128,7 +132,7 @@ for l in A + B:
 init += ["\ts_mov_b32 s%d, 0" % r for r in sorted(sa | sb) if r < 100]
 # (a null resource -- all words zero -- drops every store; scalar offsets are then irrelevant)
 JOBS = [(name, "", ra, rb) for name, (ra, rb) in VARIANTS.items()]
-for shape in ("_w16", "_merged", "_merged_w16"):
+for shape in ("_w16", "_merged", "_merged_w16", "_aab"):
     JOBS += [("base", shape, A, B), ("align_a", shape, pad_align(A), B)]
 for name, shape, ra, rb in JOBS:
     name += shape
