@@ -635,6 +635,12 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
 #ifndef FD_PIPE_PRIO
 #define FD_PIPE_PRIO 1          // 1 = the heaviest compute stage's waves run at s_setprio 1 (default); A/B: 0 none, 2 first stage, 3 by stage index
 #endif
+#ifndef FD_BAL_MARGIN
+#define FD_BAL_MARGIN 0         // FD_PIPE_PRIO == 4: the consumer yields while the producer's items + margin < its own
+#endif
+#ifndef FD_BAL_SIDE
+#define FD_BAL_SIDE 1           // ... which wave steers: 0 = the consumer (yields), 1 = the producer (overtakes)
+#endif
 #ifndef FD_KNOCK_TS
 #define FD_KNOCK_TS 0   // measurement only: k_render_ts3 with 1 = the filter wave idle, 2 = only the filter wave, 3 = only stage 0, 4 = only stage 1
 #endif
@@ -951,9 +957,13 @@ constexpr PipePlan pipe_plan(int want) {  // want: 0 = best plan, 1 / 2 / 3 = at
 // FS = floats per frame row of the feed tile (64, or 65 when the loader fills it by transposing planar rows); OL = where
 // the LAST stage puts its samples: 0 = HBM, voice-minor; 1 = an LDS tile [channel][frame][FS] that the storer wave of the
 // planar pipeline transposes out.
-template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST, int FS = 64, int OL = 0, bool PF = (FD_PIPE_PREFETCH != 0)>
+// BAL (FD_PIPE_PRIO == 4, two-stage chains): the two waves of a voice group balance their SIMD between themselves.  `bal` points at
+// the group's two progress words in LDS (SIMD items of the current tile behind the producer / the consumer); BAL == 1: this
+// stage is the producer, 2: the consumer.  Both publish their count at every item; ONE of them (FD_BAL_SIDE) compares and sets
+// its own priority for the item -- see render_pipe_body.
+template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST, int FS = 64, int OL = 0, bool PF = (FD_PIPE_PREFETCH != 0), int BAL = 0>
 FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_t V, int lane, float* outw,
-                     const float* fin, v2f (*hin)[SUB / 2][64], v2f (*hout)[SUB / 2][64]) {
+                     const float* fin, v2f (*hin)[SUB / 2][64], v2f (*hout)[SUB / 2][64], int* bal = nullptr) {
     constexpr int NI = SG::IN, NO = SG::OUT, NG = G::IN;
     constexpr bool GIN = !FIRST && SG::USES_GIN;
     static_assert(LAST || NO <= W, "hand-over tile too narrow");
@@ -1001,7 +1011,29 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
 #pragma unroll
                 for (int k = 0; k < 4; k++) ahead[c][k] = hin[c][k][lane];
         }
+        int peer = 0;
+        bool slow = false;
+        if constexpr (BAL != 0) peer = __hip_atomic_load(bal + (BAL == 1 ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         for (int i8 = lo; i8 < shi; i8 += 8) {  // one 8-sample SIMD item per trip (lo, shi are multiples of 8) ...
+        if constexpr (BAL != 0) {
+            const int k = (i8 - lo) >> 3;  // items of this tile behind this wave
+            __hip_atomic_store(bal + (BAL == 1 ? 0 : 1), k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr ((BAL == 1) == (FD_BAL_SIDE == 1)) {  // this wave is the one that steers
+                const int cur = __hip_atomic_load(bal + (BAL == 1 ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // the partner's count: read one item ago (no wait) -- or, when that item ran in the partner's shadow and the
+                // count is several items old, read now (one exposed LDS round trip after an item of ~3000 cycles)
+                int seen;
+                if (slow) seen = __builtin_amdgcn_readfirstlane(cur); else seen = __builtin_amdgcn_readfirstlane(peer);
+                peer = cur;
+                if constexpr (BAL == 2) {  // the consumer steers: it yields while the producer is behind
+                    slow = seen + FD_BAL_MARGIN < k;
+                    if (slow) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
+                } else {                   // the producer steers: it overtakes the consumer's s_setprio 1 while it is behind
+                    slow = !(k < seen + FD_BAL_MARGIN);
+                    if (slow) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
+                }
+            }
+        }
         item_begin(g);
         const int nx = i8 + 8 < shi ? i8 + 8 : i8;  // the tile's last item re-reads itself (never used)
 #pragma unroll
@@ -1218,6 +1250,11 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     // packed SVF path 5 operations shorter) when every lane of THIS wave qualifies.  A wave that does not hold the SVF
     // segment sees zeroed coefficients, takes the generic type and runs the same arithmetic for its own segment.
     constexpr bool PFK = FD_PIPE_PREFETCH != 0 && GPW < FD_PIPE_PREFETCH_GPW;  // see pipe_stage: prefetch pays when the consumer wave is (nearly) alone on its SIMD
+    // the two waves of a voice group share a SIMD exactly when the workgroup holds four groups of a two-stage chain without a
+    // loader (waves w and w + 4): that is where they balance the SIMD between themselves (see pipe_stage, BAL)
+    constexpr bool BALK = FD_PIPE_PRIO == 4 && S == 2 && !FEED && GPW == 4 && MODE == MODE_PROCESS;
+    __shared__ int bal_word[BALK ? GPW : 1][2];  // [group][producer's, consumer's item count]
+    if (BALK && threadIdx.x < GPW) bal_word[threadIdx.x][0] = bal_word[threadIdx.x][1] = 0;
     auto rounds_of = [&](auto* tag) {
         using GG = typename Pointee<decltype(tag)>::type;
         using TG = PipeTiles<GG, S, K1, K2>;
@@ -1243,10 +1280,10 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                         pipe_stage<TP0, GP, MODE, SUB, W, true, false>(reinterpret_cast<GP&>(gg), h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
                     }
 #else
-                    else pipe_stage<T0, GG, MODE, SUB, W, true, false>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
+                    else pipe_stage<T0, GG, MODE, SUB, W, true, false, 64, 0, (FD_PIPE_PREFETCH != 0), BALK ? 1 : 0>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1], bal_word[grp]);
 #endif
                 } else if (stage == 1) {
-                    if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr);
+                    if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, 0, PFK, BALK ? 2 : 0>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp]);
                     else if constexpr (S == 3) pipe_stage<T1, GG, MODE, SUB, W, false, false, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
                 } else {
                     if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr);
@@ -1303,7 +1340,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     bool lp = false;
     if constexpr (!SameType<GL, G>::v && MODE == MODE_PROCESS && FD_LP_ENABLE)
         lp = __builtin_amdgcn_ballot_w64((live && active) && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(live && active) != 0ull;
-#if FD_PIPE_PRIO == 1
+#if FD_PIPE_PRIO == 1 || FD_PIPE_PRIO == 4
     // The HEAVIEST stage's wave is the critical path of a voice group: its instruction stream is one dependent chain, so every
     // cycle it waits for the VALU behind a sibling's instruction is a cycle added to the round.  VALU arbitration on a SIMD
     // is oldest-first (profiles/r03_ubench_issue_v2.txt: the older of two waves runs unimpeded, the younger gets the

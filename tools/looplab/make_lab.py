@@ -111,6 +111,17 @@ VARIANTS = {
     "align_b2": (A, pad_align(B, 2)),
     "vconst": (vconst(A), vconst(B)),
 }
+def prio_tail(ins, frac, hi=1, lo=0):
+    """priority mix: the body runs at s_setprio hi for its first frac instructions, at lo for the rest (each s_setprio with an
+    s_nop 0 so that the parity of every 8-byte run behind it is unchanged)"""
+    k = int(len(ins) * frac)
+    return [f"\ts_setprio {hi}", "\ts_nop 0"] + ins[:k] + [f"\ts_setprio {lo}", "\ts_nop 0"] + ins[k:]
+for f in (95, 90, 85, 80, 70, 60, 50):
+    VARIANTS[f"bmix{f}"] = (A, prio_tail(B, f / 100))           # role B: priority 1 for the first f %, 0 (A is older: A wins) after
+    VARIANTS[f"bmix{f}_al"] = (pad_align(A), prio_tail(B, f / 100))
+for f in (35, 50, 65, 80):
+    VARIANTS[f"amix{f}"] = (prio_tail(A, f / 100, 2, 0), B)      # role A: priority 2 (above B's 1) for its first f %
+    VARIANTS[f"bhead{f}"] = (A, prio_tail(B, 1 - f / 100, 0, 1))  # role B: priority 0 first, 1 for the last f %
 def template(*defs):
     return sh(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", "-", *defs, os.path.join(ROOT, "tools", "looplab", "lab_template.hip")])
 tmpl = template()
