@@ -16,11 +16,13 @@ Prints ONE JSON line on rank 0 (contract in the round brief) with `roofline`, `c
 after the timed region -- a `secondary` list: the tolerance mode of the same workload, and BASELINE configs 2, 4, 5.
 """
 import argparse
+import ctypes
 import ctypes as C
 import json
 import os
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -518,6 +520,74 @@ def mix_step(F, torch, args, wl, peers):
     return mix
 
 
+class PowerMeter:
+    """Socket energy / power / shader clock over the timed region, straight from librocm_smi64 (ctypes; measurement only).
+    Why it is in the line: the headline kernel runs the socket AT ITS POWER CAP (profiles/r03_power_bound.txt) -- the shader
+    clock during the run is what the power manager leaves, so joules per step bound the step time, not cycles.  Everything
+    here degrades to None when the library or a counter is missing."""
+
+    class _Freq(ctypes.Structure):
+        _fields_ = [("has_deep_sleep", ctypes.c_bool), ("num_supported", ctypes.c_uint32), ("current", ctypes.c_uint32),
+                    ("frequency", ctypes.c_uint64 * 33)]
+
+    def __init__(self, device=0):
+        self.dev, self.lib, self.samples = int(device), None, []
+        try:
+            lib = ctypes.CDLL("librocm_smi64.so")
+            if lib.rsmi_init(ctypes.c_uint64(0)) == 0:
+                self.lib = lib
+        except OSError:
+            self.lib = None
+
+    def energy_j(self):
+        if self.lib is None:
+            return None
+        c, res, ts = ctypes.c_uint64(0), ctypes.c_float(0), ctypes.c_uint64(0)
+        if self.lib.rsmi_dev_energy_count_get(ctypes.c_uint32(self.dev), ctypes.byref(c), ctypes.byref(res), ctypes.byref(ts)) != 0:
+            return None
+        return c.value * float(res.value) * 1e-6
+
+    def cap_w(self):
+        if self.lib is None:
+            return None
+        cap = ctypes.c_uint64(0)
+        if self.lib.rsmi_dev_power_cap_get(ctypes.c_uint32(self.dev), ctypes.c_uint32(0), ctypes.byref(cap)) != 0:
+            return None
+        return cap.value * 1e-6
+
+    def sclk_mhz(self):
+        if self.lib is None:
+            return None
+        f = PowerMeter._Freq()
+        if self.lib.rsmi_dev_gpu_clk_freq_get(ctypes.c_uint32(self.dev), ctypes.c_uint32(0), ctypes.byref(f)) != 0 or f.current >= 33:
+            return None
+        return f.frequency[f.current] * 1e-6
+
+    def start(self):
+        """begin of the window (the spin-up: the same launches as the timed steps, back to back)"""
+        self.samples = []
+        self.e0, self.t0 = self.energy_j(), time.perf_counter()
+
+    def sample_clock(self):
+        """one shader-clock reading while the GPU is still working through the queued steps"""
+        v = self.sclk_mhz()
+        if v:
+            self.samples.append(v)
+
+    def stop(self, steps_in_window):
+        e1, t1 = self.energy_j(), time.perf_counter()
+        if self.e0 is None or e1 is None or e1 <= self.e0:
+            return None
+        watts, cap = (e1 - self.e0) / (t1 - self.t0), self.cap_w()
+        return {"socket_watts": round(watts, 1), "cap_watts": cap, "frac_of_cap": round(watts / cap, 4) if cap else None,
+                "joules_per_step": round((e1 - self.e0) / steps_in_window, 4), "window_s": round(t1 - self.t0, 3),
+                "sclk_mhz": round(sum(self.samples) / len(self.samples), 0) if self.samples else None, "sclk_mhz_peak": 2400,
+                "source": "librocm_smi64: the socket's energy accumulator from the start of the spin-up to the end of the timed region "
+                          "(three library calls in all: a 100 Hz sampler thread cost the run 1-2 %), sclk read once while the last steps were queued",
+                "reading": "power-bound when socket_watts is within a few per cent of cap_watts and sclk is below its peak: "
+                           "profiles/r03_power_bound.txt (energy per instruction class and per HBM byte, the step's energy budget)"}
+
+
 def run_rank(args, torch, F, peers, device):
     """One rank's share of the run (a process under torch.distributed.run, or a host thread of a one-process run).
     Returns the result record on rank 0, None elsewhere."""
@@ -554,17 +624,24 @@ def run_rank(args, torch, F, peers, device):
 
         # untimed spin-up before the W warm-up steps: an idle MI355X sits at a 600 MHz shader clock and needs a few
         # hundred ms of work to reach its operating point (W = 2 steps are 10 ms; measured 5.27 vs 5.18 ms/step)
+        meter = PowerMeter(device) if rank == 0 else None
+        if meter is not None:
+            meter.start()
+        window_steps = 0
         t_spin = time.perf_counter() + args.spin_up
         while time.perf_counter() < t_spin:
             step()
             torch.cuda.synchronize()
+            window_steps += 1
         for _ in range(warmup):
             step()
         fence()
         kernel_ms = []
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
             step()
+            if meter is not None and i == steps // 2:
+                meter.sample_clock()   # while this step's kernel runs (the launch is asynchronous, the read below waits for it)
             # HIP events recorded by the C ABI on the launch stream around the render kernel (reading here synchronises
             # on that launch, which the next step's launch on the same stream is ordered behind anyway)
             kernel_ms.append(bank.last_kernel_ms())
@@ -572,6 +649,7 @@ def run_rank(args, torch, F, peers, device):
             peers.comm.wait(peers.slot)   # the last all-reduce belongs to the timed region
         fence()
         elapsed = peers.max(time.perf_counter() - t0, torch)
+        wl["power"] = meter.stop(window_steps + warmup + steps) if meter is not None else None
         return elapsed, kernel_ms, wl, V
 
     elapsed, kernel_ms, wl, V = timed_run(args.scaling, args.steps, args.warmup)
@@ -579,7 +657,7 @@ def run_rank(args, torch, F, peers, device):
     scaling_alt = None
     if distributed and args.config == 3:   # the other scaling law, outside the timed region, a few steps
         other = "weak" if args.scaling == "strong" else "strong"
-        kernel_label, shard_bps, shard_slots = wl["kernel"], wl["bps"], wl["slot_bytes"]
+        kernel_label, shard_bps, shard_slots, power = wl["kernel"], wl["bps"], wl["slot_bytes"], wl.get("power")
         del wl
         e2, _, wl2, V2 = timed_run(other, max(3, args.steps // 2), 1)
         tv2 = base_voices if other == "strong" else base_voices * world
@@ -588,7 +666,7 @@ def run_rank(args, torch, F, peers, device):
                        "ms_per_step": round(e2 / n2 * 1e3, 4)}
         del wl2
     else:
-        kernel_label, shard_bps, shard_slots = wl["kernel"], wl["bps"], wl["slot_bytes"]
+        kernel_label, shard_bps, shard_slots, power = wl["kernel"], wl["bps"], wl["slot_bytes"], wl.get("power")
         del wl
     if rank != 0:
         return None
@@ -703,6 +781,7 @@ def run_rank(args, torch, F, peers, device):
                 "measured_streaming": measured,
                 "frac_of_measured_fill": round(achieved / measured["fill_gbs"], 4) if measured else None,
                 "valu": valu,
+                "power": power,
             },
         }
         if world == 1 and args.cpu_seconds > 0 and args.config == 3:

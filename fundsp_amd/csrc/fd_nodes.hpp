@@ -1035,6 +1035,19 @@ FD_HD float optimal4x44(float a0, float a1, float a2, float a3, float x) {  // w
     float c4 = even1 * (float)0.00986988334359864 + even2 * (float)-0.00989340017126506;
     return (((c4 * z + c3) * z + c2) * z + c1) * z + c0;
 }
+// The same interpolator for TWO frames at once (component-wise the identical operations in the identical order, no contraction):
+// the oscillator stage of config 4 is VALU-issue bound and 448 of its 714 VALU instructions per 8-frame item were these
+// multiplies and adds, one frame at a time (profiles/r03_c4_stage0.txt).
+FD_HD v2f optimal4x44_2(v2f a0, v2f a1, v2f a2, v2f a3, v2f x) {
+    v2f z = x - (float)0.5;
+    v2f even1 = a2 + a1, odd1 = a2 - a1, even2 = a3 + a0, odd2 = a3 - a0;
+    v2f c0 = even1 * (float)0.4656725512077848 + even2 * (float)0.03432729708429672;
+    v2f c1 = odd1 * (float)0.5374383075356016 + odd2 * (float)0.1542946255730746;
+    v2f c2 = even1 * (float)-0.25194210134021744 + even2 * (float)0.2519474493593906;
+    v2f c3 = odd1 * (float)-0.46896069955075126 + odd2 * (float)0.15578800670302476;
+    v2f c4 = even1 * (float)0.00986988334359864 + even2 * (float)-0.00989340017126506;
+    return (((c4 * z + c3) * z + c2) * z + c1) * z + c0;
+}
 FD_HD float clamp01f(float x) {  // math.rs:136-138
     x = x > 0.0f ? x : 0.0f;
     return x < 1.0f ? x : 1.0f;
@@ -1066,6 +1079,27 @@ FD_HD int wt_table_index(const WtSet* t, int hint, float frequency) {  // :189-2
 // Device tables are stored circularly padded -- [t[len-1], t[0..len-1], t[0], t[1]] -- so the four interpolation taps
 // t[i1-1..i1+2] of Wavetable::at are ONE contiguous (unaligned) 16-byte gather per lane instead of four.
 struct Tap4 { float a0, a1, a2, a3, w; };
+// the pieces of wt_tap: index + interpolation weight, then the four floats from HBM / from the kernel's LDS copy
+FD_HD float wt_tap_index(uint32_t mask, float phase, uint32_t& i1) {
+    float p = (float)(mask + 1u) * phase;
+    uint32_t i = (uint32_t)p;
+    i1 = i & mask;
+    return p - (float)i;
+}
+FD_HD Tap4 wt_tap_mem(const float* __restrict__ at, float w) {  // (by value: a Tap4 passed by reference ended up as a memory object)
+    Tap4 t;
+    t.w = w;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const f4u q = *(const __attribute__((address_space(1))) f4u*)at;
+    t.a0 = q.x; t.a1 = q.y; t.a2 = q.z; t.a3 = q.w;
+#else
+    float q[4];
+    __builtin_memcpy(q, at, 16);
+    t.a0 = q[0]; t.a1 = q[1]; t.a2 = q[2]; t.a3 = q[3];
+#endif
+    return t;
+}
 FD_HD Tap4 wt_tap(const float* __restrict__ tab, uint32_t mask, float phase) {  // loads of Wavetable::at :154-166
     float p = (float)(mask + 1u) * phase;
     uint32_t i1 = (uint32_t)p;
@@ -1087,6 +1121,12 @@ FD_HD Tap4 wt_tap(const float* __restrict__ tab, uint32_t mask, float phase) {  
     return t;
 }
 FD_HD float tap_eval(const Tap4& t) { return optimal4x44(t.a0, t.a1, t.a2, t.a3, t.w); }
+FD_HD v2f tap_eval2(const Tap4 a, const Tap4 b) {  // frames n and n + 1 of one table
+    return optimal4x44_2(v2f{a.a0, b.a0}, v2f{a.a1, b.a1}, v2f{a.a2, b.a2}, v2f{a.a3, b.a3}, v2f{a.w, b.w});
+}
+#ifndef FD_WT_PACKED
+#define FD_WT_PACKED 1    // WaveSynth's packed path interpolates the two frames of a pair as one <2 x float> computation; A/B switch: 0
+#endif
 #ifndef FD_WT_PREFETCH
 #define FD_WT_PREFETCH 1  // WaveSynth's packed path gathers the taps of the NEXT frame pair while it evaluates this one; A/B switch: 0
 #endif
@@ -1208,8 +1248,11 @@ struct WaveSynth {
                 const float q0 = np - __builtin_floorf(np);
                 np += d.y;
                 const float q1 = np - __builtin_floorf(np);
-                pf_a1 = wt_tap(c_tab1, c_mask1, q0); pf_a2 = wt_tap(c_tab2, c_mask2, q0);
-                pf_b1 = wt_tap(c_tab1, c_mask1, q1); pf_b2 = wt_tap(c_tab2, c_mask2, q1);
+                uint32_t ia1, ia2, ib1, ib2;
+                const float wa1 = wt_tap_index(c_mask1, q0, ia1), wa2 = wt_tap_index(c_mask2, q0, ia2);
+                const float wb1 = wt_tap_index(c_mask1, q1, ib1), wb2 = wt_tap_index(c_mask2, q1, ib2);
+                pf_a1 = wt_tap_mem(c_tab1 + ia1, wa1); pf_a2 = wt_tap_mem(c_tab2 + ia2, wa2);
+                pf_b1 = wt_tap_mem(c_tab1 + ib1, wb1); pf_b2 = wt_tap_mem(c_tab2 + ib2, wb2);
                 pf_p0 = f2u(q0);
                 pf_p1 = f2u(q1);
                 pf_ok = true;
@@ -1219,9 +1262,13 @@ struct WaveSynth {
             Tap4 a1 = wt_tap(c_tab1, c_mask1, ph0), a2 = wt_tap(c_tab2, c_mask2, ph0);
             Tap4 b1 = wt_tap(c_tab1, c_mask1, ph1), b2 = wt_tap(c_tab2, c_mask2, ph1);
 #endif
+#if FD_WT_PACKED
+            out[0] = (1.0f - item_w) * tap_eval2(a1, b1) + item_w * tap_eval2(a2, b2);
+#else
             float o0 = (1.0f - item_w) * tap_eval(a1) + item_w * tap_eval(a2);
             float o1 = (1.0f - item_w) * tap_eval(b1) + item_w * tap_eval(b2);
             out[0] = v2f{o0, o1};
+#endif
         } else {
             float o0[NOUT], o1[NOUT], i0 = in[0].x, i1 = in[0].y;
             this->template step<PH>(&i0, o0);

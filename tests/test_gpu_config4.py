@@ -139,3 +139,32 @@ def test_sum_voices(gpu):
         part[:, :, :h] = part[:, :, :h] + part[:, :, h:2 * h]
         h //= 2
     assert_bit_equal(got, part[:, :, 0], "sum_voices")
+
+
+@pytest.mark.parametrize("kind", ["saw", "triangle"])
+def test_wavesynth_pipeline_kernel_table_crossings(gpu, tables, kind):
+    """WaveSynth through the PIPELINE kernel (long launch: loader wave, packed two-frame interpolation with the taps
+    gathered one pair ahead): voices across the whole pitch range, voices that cross table boundaries in both directions
+    inside one launch (the gather-ahead's prediction must miss and re-gather), voices exactly on table pitches, negative
+    frequencies -- bit-exact against the oracle."""
+    V, T = 96, 64 * 12 + 5
+    rng = np.random.default_rng(11)
+    x = np.zeros((V, 1, T), dtype=np.float32)
+    f = (40.0 * 60.0 ** rng.random(V)).astype(np.float32)          # 40 .. 2400 Hz
+    x[:, 0, :] = f[:, None]
+    x[0, 0, :] = np.linspace(60.0, 200.0, T)                       # crosses table boundaries upwards
+    x[1, 0, :] = np.linspace(300.0, 50.0, T)                       # ... and downwards
+    x[2, 0, :] = 100.0 + 30.0 * np.sin(np.arange(T) / 11.0)        # wobbles across a boundary
+    for k, pitch in enumerate(20.0 * 2.0 ** (np.arange(7, 13) / 4.0)):   # exactly on the pitches 67 .. 160 Hz
+        x[3 + k] = np.float32(pitch)
+    x[10] = -x[0]                                                  # negative frequencies, same crossings
+    b = gpu.Bank(kind, V)
+    b.set_sample_rate(SR)
+    b.set_seed(np.arange(V, dtype=np.uint64) + 3)
+    got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    assert b.get_option("last_kernel") == 2, "the launch must take the pipeline kernel"
+    for v in list(range(12)) + list(range(12, V, 7)):
+        n = O.wavesynth(kind)
+        n.set_sample_rate(SR)
+        n.set_seed(v + 3)
+        assert_bit_equal(got[v], oracle_render(n, x[v], T, MODE_PROCESS), f"{kind} voice {v}")
