@@ -25,6 +25,7 @@ import sys
 LLVM = "/opt/rocm/lib/llvm/bin"
 NOP_COST = 4.0      # issue cycles of one s_nop 0 (loop lab: six of them cost stage 1 ~22 cycles per trip)
 WIDEN_COST = 0.01   # prefer doing nothing where it is a tie
+LOOP_W = 8          # an instruction inside d nested loops weighs LOOP_W ^ d (d capped at 4)
 INSN = re.compile(r"^\s+([a-z][a-z0-9_]+)(\s|$)")
 # VOP1 / VOP2 operations whose _e64 form is the same operation (no carry-in / carry-out, no implicit vcc, no DPP/SDWA)
 WIDENABLE = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_max_f32", "v_min_f32", "v_and_b32", "v_or_b32", "v_xor_b32",
@@ -77,6 +78,25 @@ def main(src, dst):
             seg_start.append(k)
     seg_start.append(len(idx))
     action = [0] * len(idx)  # 0 keep, 1 widen, 2 nop in front, 3 nop in front + widen
+    # Dynamic weight of an instruction: LOOP_W ^ (number of loops around it), a loop = the span from a label to a branch back to it.
+    # (Without it the pass spent its padding where the static count was, and a hot loop could come out worse than it went in:
+    # config 4 ran 9.7 ms aligned against 9.45 ms plain once its tiles had doubled, profiles/r03_ab17_stage_loops.txt.)
+    import bisect
+    label_ix = {}
+    for n, l in enumerate(lines):
+        m = re.match(r"^(\.L[A-Za-z0-9_$.]+):", l)
+        if m:
+            label_ix[m.group(1)] = bisect.bisect_left(idx, n)
+    diff = [0] * (len(idx) + 1)
+    for k, n in enumerate(idx):
+        op = lines[n].split()
+        if op and (op[0].startswith("s_cbranch") or op[0] == "s_branch") and len(op) > 1 and op[1] in label_ix and label_ix[op[1]] <= k:
+            diff[label_ix[op[1]]] += 1
+            diff[k + 1] -= 1
+    weight, d = [1.0] * len(idx), 0
+    for k in range(len(idx)):
+        d += diff[k]
+        weight[k] = float(LOOP_W ** min(d, 4))
     before = after = 0.0
     INF = float("inf")
     for a, b in zip(seg_start[:-1], seg_start[1:]):
@@ -97,13 +117,13 @@ def main(src, dst):
                     c = 0.0
                     q = p
                     if act & 2:
-                        c += NOP_COST
+                        c += NOP_COST * weight[k]
                         q ^= 1
                     ww = 2 if (act & 1) else w
                     if act & 1:
-                        c += WIDEN_COST
+                        c += WIDEN_COST * weight[k]
                     if ww == 2 and q == 1:
-                        c += 1.0
+                        c += 1.0 * weight[k]
                     c += cost[i + 1][q ^ (ww & 1)]
                     if c < best:
                         best, bc = c, act
@@ -129,7 +149,6 @@ def main(src, dst):
             p ^= (w & 1)
     # Branches are SIMM16 dword offsets and the compiler has already relaxed the ones that did not fit: a function whose
     # longest branch would leave the range once padded keeps its original layout
-    import bisect
     label_at = {}
     for n, l in enumerate(lines):
         m = re.match(r"^(\.L[A-Za-z0-9_$.]+):", l)

@@ -641,6 +641,12 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
 #ifndef FD_BAL_SIDE
 #define FD_BAL_SIDE 1           // ... which wave steers: 0 = the consumer (yields), 1 = the producer (overtakes)
 #endif
+#ifndef FD_PIPE_STAGE_LOOPS
+#define FD_PIPE_STAGE_LOOPS 2   // every role of the pipeline kernel runs its own round loop: 1 always, 0 never, 2 = kernels of three or more roles
+#endif
+#ifndef FD_TS_STAGE_LOOPS
+#define FD_TS_STAGE_LOOPS 1     // ... the same for the three-way time-split kernel (shards 3.26 / 2.16 / 2.02 -> 3.17 / 2.15 / 1.98 ms); A/B switch: 0
+#endif
 #ifndef FD_KNOCK_TS
 #define FD_KNOCK_TS 0   // measurement only: k_render_ts3 with 1 = the filter wave idle, 2 = only the filter wave, 3 = only stage 0, 4 = only stage 1
 #endif
@@ -723,6 +729,38 @@ template <class X, class U> struct HasSkip<Unop<X, U>> { static constexpr bool v
 template <class O, class X, class Y> struct HasSkip<Binop<O, X, Y>> { static constexpr bool v = false; };
 template <class X, class Y> struct HasSkip<Stack<X, Y>> { static constexpr bool v = false; };
 
+// ConstTail<X>: the trailing output channels of a Stack that are plain Constant nodes -- `(x | dc(a) | dc(b))` ends in two.
+// Where a stage cut falls right behind such a Stack, those channels do not travel through the LDS hand-over tiles: the
+// CONSUMER stage loads the Constants' slots itself and appends their values to the channels it reads (the identity
+// `(x | c) >> y == x >> ((pass | c) >> y)`, values untouched).  Config 4's first cut shrinks from three channels to one, so
+// its tiles are twice as long for the same LDS (half the rounds, barriers and per-tile bookkeeping) and the producer /
+// consumer drop two LDS writes / reads per frame pair.
+#ifndef FD_PIPE_ELIDE
+#define FD_PIPE_ELIDE 1   // A/B switch: 0 = every channel of a cut travels through LDS
+#endif
+template <class X> struct ConstTail {
+    static constexpr int K = 0;
+    template <class W> static FD_D void visit(X& x, W& w) { w.on = false; x.visit(w); }
+    static FD_D void fill2(const X&, v2f*) {}
+    static FD_D void fill(const X&, float*) {}
+};
+template <class XL, int M> struct ConstTail<Stack<XL, Constant<M>>> {
+    using S = Stack<XL, Constant<M>>;
+    static constexpr int KL = ConstTail<XL>::K, K = KL + M;
+    template <class W> static FD_D void visit(S& s, W& w) {  // Stack::visit order and slot numbering; only the tail's Constants enabled
+        w.enter(0); ConstTail<XL>::visit(s.x, w); w.leave();
+        w.enter(1); w.on = true; s.y.visit(w); w.on = false; w.leave();
+    }
+    static FD_D void fill2(const S& s, v2f* tail) {  // tail[0 .. K): XL's trailing constants, then these M
+        ConstTail<XL>::fill2(s.x, tail);
+        _Pragma("unroll") for (int i = 0; i < M; i++) tail[KL + i] = splat2(s.y.value[i]);
+    }
+    static FD_D void fill(const S& s, float* tail) {
+        ConstTail<XL>::fill(s.x, tail);
+        _Pragma("unroll") for (int i = 0; i < M; i++) tail[KL + i] = s.y.value[i];
+    }
+};
+
 // Seg<G, A, B, HEAD>: the chain stages [A, B) of G, run on G's own state object.
 //   in  = what the segment's first stage consumes: the node's own inputs when A == 0, else the hand-over channels;
 //   gin = the node's own inputs (the graph's inputs for head-position nodes), valid in EVERY stage: a Binop tail reads
@@ -752,18 +790,43 @@ struct Seg<Pipe<X, Y>, A, B, HEAD> {
     static constexpr bool HX = A < NX, HY = B > NX;  // the segment has stages inside x / inside y
     using SX = Seg<X, HX ? A : 0, HX ? (B < NX ? B : NX) : NX, HEAD>;
     using SY = Seg<Y, HY ? (A > NX ? A - NX : 0) : 0, HY ? B - NX : NY, false>;
-    static constexpr int IN = HX ? SX::IN : SY::IN, OUT = HY ? SY::OUT : SX::OUT;
+    // a cut right behind x = a Stack with trailing Constants: they stay out of the hand-over (ConstTail)
+    static constexpr int KX = ConstTail<X>::K;
+    static constexpr bool ELIDE = FD_PIPE_ELIDE != 0 && KX > 0 && KX < X::OUT && NX == 1;
+    static constexpr bool ELIDE_OUT = ELIDE && HX && !HY && B == NX;  // this segment ends with x: its trailing constants are not handed over
+    static constexpr bool ELIDE_IN = ELIDE && !HX && A == NX;          // this segment starts with y: it supplies x's trailing constants itself
+    static constexpr int IN = HX ? SX::IN : (ELIDE_IN ? X::OUT - KX : SY::IN), OUT = HY ? SY::OUT : (ELIDE_OUT ? X::OUT - KX : SX::OUT);
     static constexpr int cost = (HX ? SX::cost : 0) + (HY ? SY::cost : 0);
     static constexpr int weight = (HX ? SX::weight : 0) + (HY ? SY::weight : 0);
     static constexpr bool USES_GIN = HX && SX::USES_GIN;
     static constexpr bool HAS_SKIP = !(HX && HY) && (HX ? SX::HAS_SKIP : SY::HAS_SKIP);  // skip is defined for one-stage segments
     template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f* gin, v2f* out) {
         if constexpr (HX && HY) { v2f t[SX::OUT > 0 ? SX::OUT : 1]; SX::template step2<PH>(g.x, in, gin, t); SY::template step2<PH>(g.y, t, nullptr, out); }
+        else if constexpr (ELIDE_OUT) {
+            v2f t[X::OUT];
+            SX::template step2<PH>(g.x, in, gin, t);
+            _Pragma("unroll") for (int c = 0; c < OUT; c++) out[c] = t[c];
+        } else if constexpr (ELIDE_IN) {
+            v2f t[X::OUT];
+            _Pragma("unroll") for (int c = 0; c < IN; c++) t[c] = in[c];
+            ConstTail<X>::fill2(g.x, t + IN);
+            SY::template step2<PH>(g.y, t, nullptr, out);
+        }
         else if constexpr (HX) SX::template step2<PH>(g.x, in, gin, out);
         else SY::template step2<PH>(g.y, in, nullptr, out);
     }
     template <int PH> static FD_D void step(G& g, const float* in, const float* gin, float* out) {
         if constexpr (HX && HY) { float t[SX::OUT > 0 ? SX::OUT : 1]; SX::template step<PH>(g.x, in, gin, t); SY::template step<PH>(g.y, t, nullptr, out); }
+        else if constexpr (ELIDE_OUT) {
+            float t[X::OUT];
+            SX::template step<PH>(g.x, in, gin, t);
+            _Pragma("unroll") for (int c = 0; c < OUT; c++) out[c] = t[c];
+        } else if constexpr (ELIDE_IN) {
+            float t[X::OUT];
+            _Pragma("unroll") for (int c = 0; c < IN; c++) t[c] = in[c];
+            ConstTail<X>::fill(g.x, t + IN);
+            SY::template step<PH>(g.y, t, nullptr, out);
+        }
         else if constexpr (HX) SX::template step<PH>(g.x, in, gin, out);
         else SY::template step<PH>(g.y, in, nullptr, out);
     }
@@ -790,7 +853,7 @@ struct Seg<Pipe<X, Y>, A, B, HEAD> {
         return t;
     }
     template <class W> static FD_D void visit(G& g, W& w) {
-        if constexpr (HX) SX::visit(g.x, w); else { w.on = false; g.x.visit(w); }
+        if constexpr (HX) SX::visit(g.x, w); else if constexpr (ELIDE_IN) ConstTail<X>::visit(g.x, w); else { w.on = false; g.x.visit(w); }
         if constexpr (HY) SY::visit(g.y, w); else { w.on = false; g.y.visit(w); }
     }
 };
@@ -1262,16 +1325,29 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
         using T1 = typename TG::S1;
         using T2 = typename TG::S2;
         GG& gg = reinterpret_cast<GG&>(g);
-        for (size_t it = 0; it < rounds; it++) {
-            if (live && active && it >= first && it - first < ntiles && ((FD_KNOCK >> stage) & 1) == 0) {
-                const size_t j = it - first;          // the tile this stage works on in this round
-                const size_t t0 = (j / SPB) * 64;
-                const int h = (int)(j % SPB);
-                const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
-                const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
-                const float* fin = nullptr;
-                if constexpr (FEED) fin = &feed[grp][j % D][0][0][0];
-                if (stage == 0) {
+        if constexpr (FD_PIPE_STAGE_LOOPS == 1 || (FD_PIPE_STAGE_LOOPS == 2 && S + (FEED ? 1 : 0) >= 3)) {
+            // One round loop PER ROLE for kernels of three or more roles (the stage is wave-uniform and fixed for the launch): with the
+            // stage dispatch inside a common loop the register allocator sees the live ranges of all roles at once -- the config-4 kernel
+            // spilled ~40 SGPRs to VGPR lanes in every round's preamble -- and every round pays the dispatch branches: config 4
+            // 9.45 -> 9.0 ms.  Two-role kernels keep the common loop (config 3: 4.63 vs 4.74 ms with per-role loops,
+            // profiles/r03_ab17_stage_loops.txt).  Every wave executes `rounds` barriers either way.
+            auto loop = [&](auto&& tile) {
+                for (size_t it = 0; it < rounds; it++) {
+                    if (live && active && it >= first && it - first < ntiles && ((FD_KNOCK >> stage) & 1) == 0) {
+                        const size_t j = it - first;          // the tile this stage works on in this round
+                        const size_t t0 = (j / SPB) * 64;
+                        const int h = (int)(j % SPB);
+                        const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+                        const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
+                        const float* fin = nullptr;
+                        if constexpr (FEED) fin = &feed[grp][j % D][0][0][0];
+                        tile(j, t0, h, size, full, fin);
+                    }
+                    __syncthreads();  // hand-over point: every role has finished its tile of this round
+                }
+            };
+            if (stage == 0) {
+                loop([&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
                     if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr);
 #if FD_PIPE_PRODUCER_PLAIN
                     else {  // the producer stage's sines as plain (2-cycle) ops: see SinePlain
@@ -1282,14 +1358,47 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
 #else
                     else pipe_stage<T0, GG, MODE, SUB, W, true, false, 64, 0, (FD_PIPE_PREFETCH != 0), BALK ? 1 : 0>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1], bal_word[grp]);
 #endif
-                } else if (stage == 1) {
+                });
+            } else if (stage == 1) {
+                loop([&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
                     if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, 0, PFK, BALK ? 2 : 0>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp]);
                     else if constexpr (S == 3) pipe_stage<T1, GG, MODE, SUB, W, false, false, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
-                } else {
+                });
+            } else {
+                loop([&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
                     if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr);
-                }
+                });
             }
-            __syncthreads();  // hand-over point: every role has finished its tile of this round
+        } else {
+            for (size_t it = 0; it < rounds; it++) {
+                if (live && active && it >= first && it - first < ntiles && ((FD_KNOCK >> stage) & 1) == 0) {
+                    const size_t j = it - first;          // the tile this stage works on in this round
+                    const size_t t0 = (j / SPB) * 64;
+                    const int h = (int)(j % SPB);
+                    const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+                    const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
+                    const float* fin = nullptr;
+                    if constexpr (FEED) fin = &feed[grp][j % D][0][0][0];
+                    if (stage == 0) {
+                        if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr);
+#if FD_PIPE_PRODUCER_PLAIN
+                        else {  // the producer stage's sines as plain (2-cycle) ops: see SinePlain
+                            using GP = typename PlainOf<GG>::type;
+                            using TP0 = typename PipeTiles<GP, S, K1, K2>::S0;
+                            pipe_stage<TP0, GP, MODE, SUB, W, true, false>(reinterpret_cast<GP&>(gg), h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
+                        }
+#else
+                        else pipe_stage<T0, GG, MODE, SUB, W, true, false, 64, 0, (FD_PIPE_PREFETCH != 0), BALK ? 1 : 0>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1], bal_word[grp]);
+#endif
+                    } else if (stage == 1) {
+                        if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, 0, PFK, BALK ? 2 : 0>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp]);
+                        else if constexpr (S == 3) pipe_stage<T1, GG, MODE, SUB, W, false, false, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
+                    } else {
+                        if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr);
+                    }
+                }
+                __syncthreads();  // hand-over point: every role has finished its tile of this round
+            }
         }
     };
 #if FD_PIPE_FLAGSYNC
@@ -1627,6 +1736,19 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
         using T1 = Seg<GG, 1, 2>;
         using T2 = Seg<GG, 2, 3>;
         GG& gg = reinterpret_cast<GG&>(g);
+#if FD_TS_STAGE_LOOPS   // a round loop per role (see render_pipe_body)
+        auto loop = [&](auto&& block) {
+            for (size_t it = 0; it < rounds; it++) {
+                if (live && active && it >= (size_t)stage && it - stage < nblocks && !(FD_KNOCK_TS == 1 && stage == 2) && !(FD_KNOCK_TS == 2 && stage < 2) &&
+                    !(FD_KNOCK_TS == 3 && stage != 0) && !(FD_KNOCK_TS == 4 && stage != 1))
+                    block(it - stage);  // the block this stage works on in this round
+                __syncthreads();
+            }
+        };
+        if (stage == 0) loop([&](size_t j) { ts_stage<T0, GG, true, W>(gg, part, 3, lane, nullptr, hand[grp][0][j & 1]); });
+        else if (stage == 1) loop([&](size_t j) { ts_stage<T1, GG, false, W>(gg, part, 3, lane, hand[grp][0][j & 1], hand[grp][1][j & 1]); });
+        else loop([&](size_t j) { pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, 0, FD_PIPE_PREFETCH != 0>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr); });
+#else
         for (size_t it = 0; it < rounds; it++) {
             if (live && active && it >= (size_t)stage && it - stage < nblocks && !(FD_KNOCK_TS == 1 && stage == 2) && !(FD_KNOCK_TS == 2 && stage < 2) &&
                 !(FD_KNOCK_TS == 3 && stage != 0) && !(FD_KNOCK_TS == 4 && stage != 1)) {
@@ -1637,6 +1759,7 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
             }
             __syncthreads();
         }
+#endif
     };
     using GL = typename LpOf<G>::type;
     bool lp = false;
