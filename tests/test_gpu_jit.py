@@ -90,7 +90,7 @@ def test_jit_graph_matches_oracle(gpu, name):
     x = None
     if ni:
         x = noise_input(V, ni, T, seed=77)
-        if name == "saw_filter_env":
+        if name in ("saw_filter_env", "saw_dc2_moog_env"):
             x[:, 0, :] = 0.0
             x[:, 0, 3:400] = 1.0  # gate
     for mode in (MODE_PROCESS, MODE_TICK):
@@ -104,6 +104,24 @@ def test_jit_graph_matches_oracle(gpu, name):
             n.set_sample_rate(SR)
             n.set_seed(int(seeds[v]))
             assert_bit_equal(got[v], oracle_render(n, None if x is None else x[v], T, mode), f"{name} voice {v} mode {mode}")
+
+
+# A stage cut right behind a Stack that ends in Constants: those channels do not travel through the hand-over tiles, the consumer
+# stage loads the Constant slots itself (fd_device.hpp ConstTail) -- here a Constant<2> tail in front of a ladder, under a Binop tail that reads
+# the graph's input (the nested one-by-one tail is config 4's own kind, tests/test_gpu_config4.py).  One graph only: a heavy kind
+# takes hiprtc ~100 s to compile.  (Kept apart from GRAPHS: that table is also the inventory of the golden fixtures and of the Rust front door.)
+CUT_GRAPHS = {
+    "saw_dc2_moog_env": (lambda m: ((m.saw_hz(61.7) | m.dc(1200.0, 0.3)) >> m.moog()) * (m.pass_() >> m.adsr_live(0.003, 0.02, 0.6, 0.01)), 1, 0),
+}
+
+
+@pytest.mark.parametrize("name", list(CUT_GRAPHS))
+def test_jit_constants_behind_a_cut(gpu, name):
+    GRAPHS[name] = CUT_GRAPHS[name]
+    try:
+        test_jit_graph_matches_oracle(gpu, name)
+    finally:
+        del GRAPHS[name]
 
 
 def test_jit_map_and_shape_fn_closures(gpu):
