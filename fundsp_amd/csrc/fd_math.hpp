@@ -717,6 +717,9 @@ FD_HD float wide_sinf(float self) {
 #ifndef FD_SINE_UNIFIED
 #define FD_SINE_UNIFIED 0
 #endif
+#ifndef FD_SINE_VV_PLAIN
+#define FD_SINE_VV_PLAIN 0   // A/B switch, see wide_sin2
+#endif
 #ifndef FD_SINE_BFE
 #define FD_SINE_BFE 1    // the odd-quadrant select of wide_sin2 as v_bfe_i32 + v_bfi_b32 (one issue slot less per frame than v_and + v_cmp + v_cndmask); A/B switch: 0
 #endif
@@ -752,11 +755,26 @@ FD_HD v2f wide_sin2(v2f self, float& tmax) {
     // unfused forms of `x - y*DPn` round the same real number once -> identical bits.  Likewise 0.5*x2 below.
     v2f x = __builtin_elementwise_fma(y, splat2(-DP1F), self);
     x = __builtin_elementwise_fma(y, splat2(-DP2F), x);
+#if FD_SINE_VV_PLAIN
+    // A/B (power): the operations whose BOTH operands are register pairs as two plain instructions each -- 2 x 0.7 nJ
+    // against 1.75 nJ for the packed form (profiles/r03_power_bound.txt); the ones with a constant operand stay packed (1.08 nJ).
+    // (an empty asm on each half keeps the back end from pairing the two scalar operations again)
+    auto keep = [](float t) { asm("" : "+v"(t)); return t; };
+    auto vmul = [&](v2f a, v2f b) { return v2f{keep(a.x * b.x), keep(a.y * b.y)}; };
+    auto vadd = [&](v2f a, v2f b) { return v2f{keep(a.x + b.x), keep(a.y + b.y)}; };
+    auto vsub = [&](v2f a, v2f b) { return v2f{keep(a.x - b.x), keep(a.y - b.y)}; };
+    x = vsub(x, y * DP3F);
+    v2f x2 = vmul(x, x);
+    v2f x4 = vmul(x2, x2);
+    v2f s = vadd(vmul(vadd(x4 * P2sinf, x2 * P1sinf + P0sinf), vmul(x, x2)), x);
+    v2f c = vadd(vmul(vadd(x4 * P2cosf, x2 * P1cosf + P0cosf), x4), __builtin_elementwise_fma(x2, splat2(-0.5f), splat2(1.0f)));
+#else
     x = x - y * DP3F;
     v2f x2 = x * x;
     v2f x4 = x2 * x2;
     v2f s = (x4 * P2sinf + (x2 * P1sinf + P0sinf)) * (x * x2) + x;
     v2f c = (x4 * P2cosf + (x2 * P1cosf + P0cosf)) * x4 + __builtin_elementwise_fma(x2, splat2(-0.5f), splat2(1.0f));
+#endif
     // (forcing v_bfe_i32 + v_bfi_b32 through inline asm instead of the and + cmp + cndmask the optimiser prefers saved
     // nothing: the asm also stopped the 4-pair unrolling of the caller's loop)
 #if FD_SINE_BFE && defined(__HIP_DEVICE_COMPILE__)
