@@ -623,6 +623,9 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
 #ifndef FD_PIPE_BUFFER_STORE
 #define FD_PIPE_BUFFER_STORE 1  // A/B switch: 0 = plain global stores (per-frame 64-bit vector address arithmetic)
 #endif
+#ifndef FD_PIPE_STORE_AUX
+#define FD_PIPE_STORE_AUX 0     // cache-policy bits of the pipeline kernel's output stores (A/B: 2 = nt, 19 = sc0 sc1 nt)
+#endif
 #ifndef FD_PIPE_PRODUCER_PLAIN
 #define FD_PIPE_PRODUCER_PLAIN 0  // A/B switch: 1 = stage 0 of a multi-stage pipeline evaluates its sines with plain ops
 #endif
@@ -1050,7 +1053,7 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
     auto put = [&](int c, int i, float x) {  // i = frame index inside the block
         if constexpr (OL == 0) {
 #if FD_PIPE_BUFFER_STORE
-            __builtin_amdgcn_raw_buffer_store_b32(f2u(x), orow[c], lane * 4, (i - lo) * vrow, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(f2u(x), orow[c], lane * 4, (i - lo) * vrow, FD_PIPE_STORE_AUX);
 #else
             outw[((size_t)c * T + t0 + i) * V + lane] = x;
 #endif
