@@ -1222,15 +1222,20 @@ constexpr RoleOrder role_order() {
         int a = wt[pairs[p][0]] + wt[pairs[p][1]], b = wt[pairs[p][2]] + wt[pairs[p][3]], m = a > b ? a : b;
         if (m < best_w) { best_w = m; best = p; }
     }
+#ifdef FD_ROLE_PAIR   // A/B switch: force the pairing (0 = loader + stage 1 | stage 0 + stage 2, 1 = loader + stage 0 | stage 1 + stage 2, 2 = loader + stage 2 | stage 0 + stage 1)
+    best = FD_ROLE_PAIR;
+#endif
     o.role[0] = pairs[best][0]; o.role[2] = pairs[best][1]; o.role[1] = pairs[best][2]; o.role[3] = pairs[best][3];
     return o;
 }
 
 constexpr bool role_order_is(RoleOrder o, int a, int b, int c, int d) { return o.role[0] == a && o.role[1] == b && o.role[2] == c && o.role[3] == d; }
+#ifndef FD_ROLE_PAIR
 static_assert(role_order_is(role_order<true, 3, 100, 130, 83, 2>(), 0, 1, 2, 3), "config 4, exact: loader + moog | saw + tail");
 static_assert(role_order_is(role_order<true, 3, 100, 30, 83, 2>(), 0, 2, 1, 3), "config 4, tolerance mode: loader + saw | moog + tail");
 static_assert(role_order_is(role_order<false, 3, 30, 10, 20, 2>(), 1, 0, 2, 3), "three roles: the heaviest gets the SIMD of its own");
 static_assert(role_order_is(role_order<true, 3, 100, 30, 83, 4>(), 0, 1, 2, 3), "four groups per workgroup: every SIMD holds one group's roles");
+#endif
 
 // The pipeline kernel.  Waves of one workgroup, 4 voice groups (w & 3) times NW roles (w >> 2):
 //   role 0 (only if the graph has inputs): the LOADER wave.  It does nothing but stream the group's input channels
