@@ -64,6 +64,9 @@ __global__ __launch_bounds__(1024) void k_stream(Rec* rec, int reps, float a, fl
         :: "v"(a), "v"(bl)
         : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "s20", "s21", "s22", "s23");
     __syncthreads();
+    // lane masks: 1 = the low 32 lanes execute the stream, 2 = the low 16 (what does an instruction cost when half / three quarters of its lanes are off?)
+    if (waves == 1) asm volatile("s_mov_b64 exec, 0xffffffff");
+    if (waves == 2) asm volatile("s_mov_b64 exec, 0xffff");
     uint64_t t0, t1, r0, r1;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0)::"memory");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(1024) void k_stream(Rec* rec, int reps, float a, fl
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
+    asm volatile("s_mov_b64 exec, -1");
     float acc;
     asm volatile("v_add_f32 %0, v0, v1\n v_add_f32 %0, %0, v2\n v_add_f32 %0, %0, v3\n v_add_f32 %0, %0, v15" : "=v"(acc));
     if (acc == 123.456f) lds[threadIdx.x] = acc;  // keep the registers alive
@@ -113,14 +117,14 @@ struct Sampler {  // socket power / sclk at ~10 Hz from a side thread (the launc
 };
 
 template <int K>
-double run_stream(Rec* d_rec, int waves_per_simd, double seconds, double base_w) {
+double run_stream(Rec* d_rec, int waves_per_simd, double seconds, double base_w, int lane_mask = 0) {
     const int threads = 256 * waves_per_simd, grid = 256, reps = 4000;  // 256 instructions x 4000 = 1.02 M instructions per wave per launch
     const size_t lds = 100 * 1024;                                      // one workgroup per CU
     hipFuncSetAttribute((const void*)k_stream<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1, ev[4];
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (auto& e : ev) hipEventCreate(&e);
-    auto launch = [&]() { k_stream<K><<<grid, threads, lds>>>(d_rec, reps, -1.0f, 0.7321f, waves_per_simd); };
+    auto launch = [&]() { k_stream<K><<<grid, threads, lds>>>(d_rec, reps, -1.0f, 0.7321f, lane_mask); };
     long launches = 0;
     auto pump = [&](double secs) {  // keep four launches queued at all times
         const double T = now_s();
@@ -152,6 +156,7 @@ double run_stream(Rec* d_rec, int waves_per_simd, double seconds, double base_w)
     const double watts = (double)(E1 - E0) * 1e-6 / (T1 - T0);
     const double ghz = cyc / (rt * 10.0);                                 // shader cycles per 10 ns tick of s_memrealtime, inside the loop
     const double busy = rtmax * 10e-9 * launches / (ms * 1e-3);           // fraction of the wall time a kernel was running
+    if (lane_mask) printf("[%d of 64 lanes] ", lane_mask == 1 ? 32 : 16);
     printf("%-56s %d/SIMD | %7.1f W | clock %5.3f GHz (smi avg %4.0f min %4.0f) | %5.2f cyc/inst per wave, %5.2f per SIMD | %5.2f T wave-inst/s | busy %4.2f", stream_name[K],
            waves_per_simd, watts, ghz, sm.fsum / sm.n, sm.fmin, cyc / nw / insts_per_wave, cyc / nw / insts_per_wave / waves_per_simd, rate * 1e-12, busy);
     if (base_w > 0 && K != S_SNOP) printf(" | %5.2f nJ/wave-inst | %5.1f TF", (watts - base_w) / rate * 1e9, rate * 64 * stream_flops[K] * 1e-12);
@@ -203,6 +208,17 @@ int main(int argc, char** argv) {
         const uint64_t E1 = energy_uj(); const double T1 = now_s();
         idle_w = (double)(E1 - E0) * 1e-6 / (T1 - T0);
         printf("%-58s         | %7.1f W | sclk smi %6.0f MHz\n", "idle (no kernel)", idle_w, sclk_mhz());
+    }
+    if (argc > 2 && atoi(argv[2]) == 1) {  // lane-mask mode: the same streams with 64 / 32 / 16 active lanes, two waves per SIMD
+        const double b2 = run_stream<S_SNOP>(d_rec, 2, seconds, 0);
+        for (int m : {0, 1, 2}) {
+            run_stream<S_FMA>(d_rec, 2, seconds, b2, m);
+            run_stream<S_MULADD>(d_rec, 2, seconds, b2, m);
+            run_stream<S_PKFMA_S>(d_rec, 2, seconds, b2, m);
+            run_stream<S_PKMULADD>(d_rec, 2, seconds, b2, m);
+            run_stream<S_PKMULADD_S>(d_rec, 2, seconds, b2, m);
+        }
+        return 0;
     }
     double base[5] = {0, 0, 0, 0, 0};
     for (int n : {1, 2, 4}) {
