@@ -57,3 +57,18 @@ def test_thread_peers_barrier_and_max():
     [t.join() for t in ts]
     assert got == [(4.0, 10.0)] * n
     assert bench.Peers(1).max(3.5, None) == 3.5
+
+
+def test_power_meter_degrades_to_none_without_a_device():
+    """bench.py's roofline.power comes from librocm_smi64; without the library or a device every reading is None and the
+    bench line simply carries `"power": null` (this container has no GPU: the CPU suite sees exactly that path)."""
+    import bench
+
+    m = bench.PowerMeter(0)
+    m.start()
+    m.sample_clock()
+    if m.lib is None or m.energy_j() is None:
+        assert m.stop(3) is None
+    else:   # a box with a GPU: a well-formed record
+        rec = m.stop(3)
+        assert rec is None or {"socket_watts", "cap_watts", "joules_per_step", "sclk_mhz"} <= set(rec)
