@@ -1504,11 +1504,10 @@ __global__ __launch_bounds__((16 * GPW * PipeGeom<G::IN, S>::WAVES)) FD_PIPE_ATT
 // Needs: process mode, voice-minor layout, no graph inputs, a 3-stage chain whose first two stages define skip2,
 // T a multiple of 64 (launch_render falls back to the pipeline kernel otherwise).
 template <class SG, class G, bool FIRST, int W>
-FD_D void ts_stage(G& g, int part, int nparts, int lane, v2f (*hin)[32][64], v2f (*hout)[32][64]) {
+FD_D void ts_stage(G& g, int lo, int hi, int lane, v2f (*hin)[32][64], v2f (*hout)[32][64]) {
     constexpr int NI = SG::IN, NO = SG::OUT;
     static_assert(NO <= W && (FIRST || NI <= W), "hand-over tile too narrow");
-    // this wave's frames of the block (multiples of 8): halves, or thirds as 24 + 24 + 16
-    const int lo = nparts == 3 ? 24 * part : 64 / nparts * part, hi = nparts == 3 ? (part == 2 ? 64 : lo + 24) : lo + 64 / nparts;
+    // [lo, hi): this wave's frames of the block (multiples of 8; ts_part / Ts3Roles::cut)
     SG::begin(g, 64);
     const G snap = g;
     // The block in 8-frame items; a consumer stage reads every item's four hand-over pairs ONE ITEM AHEAD (each pair's
@@ -1654,8 +1653,8 @@ FD_D void render_ts_body(float* __restrict__ slots, size_t stride, size_t V, flo
         for (size_t it = 0; it < rounds; it++) {
             if (active && it >= (size_t)stage && it - stage < nblocks) {
                 const size_t j = it - stage;  // the block this stage works on in this round
-                if (stage == 0) ts_stage<T0, GG, true, W>(gg, part, nparts, lane, nullptr, hand[0][j & 1]);
-                else if (stage == 1) ts_stage<T1, GG, false, W>(gg, part, nparts, lane, hand[0][j & 1], hand[1][j & 1]);
+                if (stage == 0) ts_stage<T0, GG, true, W>(gg, 64 / nparts * part, 64 / nparts * (part + 1), lane, nullptr, hand[0][j & 1]);
+                else if (stage == 1) ts_stage<T1, GG, false, W>(gg, 64 / nparts * part, 64 / nparts * (part + 1), lane, hand[0][j & 1], hand[1][j & 1]);
                 else pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, 0, FD_PIPE_PREFETCH != 0>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[1][j & 1], nullptr);
             }
             __syncthreads();
@@ -1696,18 +1695,46 @@ __global__ __launch_bounds__(64 * (NA + NB + 1)) void k_render_ts(float* __restr
 // The thirds of a stage each advance the state through the whole block (skip2) and evaluate their own frames; per frame
 // the arithmetic is that of every other kernel -- bit-exact (tests/test_gpu_time_split.py).
 template <int GPW> struct Ts3Roles;
-template <> struct Ts3Roles<1> {  // wave -> (group, stage, part)
+#ifndef FD_TS3_BCUT
+#define FD_TS3_BCUT 0   // A/B: where the parts of the two oscillator stages are cut (Ts3Roles<1>::cut)
+#endif
+#ifndef FD_TS3_B4
+#define FD_TS3_B4 1   // one group per CU: the SECOND oscillator stage in four quarters, the fourth next to the filter wave; A/B switch: 0 = thirds, 7 waves
+#endif
+#if FD_TS3_B4
+// Seven waves left the four SIMDs of a CU loaded 48 | 48 | 32 oscillator frames per block | the filter alone, and the two 48s set the round time
+// (profiles/r03_strong_scaling_shards.txt: the filter wave alone 1.21 ms, the kernel 1.98).  With the second oscillator stage in QUARTERS
+// the eighth wave sits next to the filter:  w: 0  1  2  3  4  5  6  7   ->   40 | 40 | 32 | filter + 16.
+//                                        role: A0 A1 A2 C  B0 B1 B2 B3
+template <> struct Ts3Roles<1> {  // wave -> (group, stage, part); parts per stage
+    static constexpr int WAVES = 8;
+    static constexpr int grp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static constexpr int stg[8] = {0, 0, 0, 2, 1, 1, 1, 1};
+    static constexpr int prt[8] = {0, 1, 2, 0, 0, 1, 2, 3};
+#if FD_TS3_BCUT == 1
+    static constexpr int cut[2][5] = {{0, 24, 48, 64, 64}, {0, 16, 32, 56, 64}};   // the quarter next to the filter wave is the short one
+#elif FD_TS3_BCUT == 2
+    static constexpr int cut[2][5] = {{0, 24, 40, 64, 64}, {0, 16, 40, 56, 64}};
+#else
+    static constexpr int cut[2][5] = {{0, 24, 48, 64, 64}, {0, 16, 32, 48, 64}};   // frames of a block per part: [cut[stage][part], cut[stage][part + 1])
+#endif
+};
+#else
+template <> struct Ts3Roles<1> {  // wave -> (group, stage, part); parts per stage
     static constexpr int WAVES = 7;
     static constexpr int grp[7] = {0, 0, 0, 0, 0, 0, 0};
     static constexpr int stg[7] = {0, 0, 0, 2, 1, 1, 1};
     static constexpr int prt[7] = {0, 1, 2, 0, 0, 1, 2};
+    static constexpr int cut[2][5] = {{0, 24, 48, 64, 64}, {0, 24, 48, 64, 64}};
 };
+#endif
 template <> struct Ts3Roles<2> {
     // SIMD = w % 4:   SIMD 0: w 0 4 8 12   SIMD 1: w 1 5 9 13   SIMD 2: w 2 6 10   SIMD 3: w 3 7 11
     static constexpr int WAVES = 14;
     static constexpr int grp[14] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 1, 0};
     static constexpr int stg[14] = {0, 0, 2, 2, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1};
     static constexpr int prt[14] = {0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 1, 1, 2, 2};
+    static constexpr int cut[2][5] = {{0, 24, 48, 64, 64}, {0, 24, 48, 64, 64}};
     // SIMD 0: g0 A0, g0 B0, g0 A2, g1 B2   SIMD 1: g1 A0, g1 B0, g1 A2, g0 B2   SIMD 2: g0 C, g0 A1, g0 B1   SIMD 3: g1 C, g1 A1, g1 B1
 };
 
@@ -1753,16 +1780,16 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
                 __syncthreads();
             }
         };
-        if (stage == 0) loop([&](size_t j) { ts_stage<T0, GG, true, W>(gg, part, 3, lane, nullptr, hand[grp][0][j & 1]); });
-        else if (stage == 1) loop([&](size_t j) { ts_stage<T1, GG, false, W>(gg, part, 3, lane, hand[grp][0][j & 1], hand[grp][1][j & 1]); });
+        if (stage == 0) loop([&](size_t j) { ts_stage<T0, GG, true, W>(gg, R::cut[0][part], R::cut[0][part + 1], lane, nullptr, hand[grp][0][j & 1]); });
+        else if (stage == 1) loop([&](size_t j) { ts_stage<T1, GG, false, W>(gg, R::cut[1][part], R::cut[1][part + 1], lane, hand[grp][0][j & 1], hand[grp][1][j & 1]); });
         else loop([&](size_t j) { pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, 0, FD_PIPE_PREFETCH != 0>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr); });
 #else
         for (size_t it = 0; it < rounds; it++) {
             if (live && active && it >= (size_t)stage && it - stage < nblocks && !(FD_KNOCK_TS == 1 && stage == 2) && !(FD_KNOCK_TS == 2 && stage < 2) &&
                 !(FD_KNOCK_TS == 3 && stage != 0) && !(FD_KNOCK_TS == 4 && stage != 1)) {
                 const size_t j = it - stage;  // the block this stage works on in this round
-                if (stage == 0) ts_stage<T0, GG, true, W>(gg, part, 3, lane, nullptr, hand[grp][0][j & 1]);
-                else if (stage == 1) ts_stage<T1, GG, false, W>(gg, part, 3, lane, hand[grp][0][j & 1], hand[grp][1][j & 1]);
+                if (stage == 0) ts_stage<T0, GG, true, W>(gg, R::cut[0][part], R::cut[0][part + 1], lane, nullptr, hand[grp][0][j & 1]);
+                else if (stage == 1) ts_stage<T1, GG, false, W>(gg, R::cut[1][part], R::cut[1][part + 1], lane, hand[grp][0][j & 1], hand[grp][1][j & 1]);
                 else pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, 0, FD_PIPE_PREFETCH != 0>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr);
             }
             __syncthreads();

@@ -186,9 +186,9 @@ void launch_render(float* slots, size_t stride, size_t V, const float* in, float
             groups <= 2 * cus) {
             if (tl_opts.time_split == 1) {  // round 3: both oscillator stages split three ways, the filter wave (nearly) alone on a SIMD
                 if (groups <= cus)
-                    hipLaunchKernelGGL((k_render_ts3<G, 1>), dim3((unsigned)groups), dim3(64 * 7), 0, s, slots, stride, V, out, T, aux);
+                    hipLaunchKernelGGL((k_render_ts3<G, 1>), dim3((unsigned)groups), dim3(64 * Ts3Roles<1>::WAVES), 0, s, slots, stride, V, out, T, aux);
                 else
-                    hipLaunchKernelGGL((k_render_ts3<G, 2>), dim3((unsigned)((groups + 1) / 2)), dim3(64 * 14), 0, s, slots, stride, V, out, T, aux);
+                    hipLaunchKernelGGL((k_render_ts3<G, 2>), dim3((unsigned)((groups + 1) / 2)), dim3(64 * Ts3Roles<2>::WAVES), 0, s, slots, stride, V, out, T, aux);
             } else if (groups <= cus)  // time_split = 2: round 2's layouts.  One workgroup per CU: 2 + 2 + 1 waves
                 hipLaunchKernelGGL((k_render_ts<G, 2, 2>), dim3((unsigned)groups), dim3(64 * 5), 0, s, slots, stride, V, out, T, aux);
             else                // two workgroups per CU: 2 + 1 + 1 waves each, roles rotated between neighbours
