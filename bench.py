@@ -160,8 +160,9 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
 # ---------------------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------------------
-def make_workload(F, W, torch, config, V, T, sr, first, layout, math):
-    """-> dict(bank, inp, out, layout, fs, n_out, bytes_per_sample, slot_bytes, kernel)"""
+def make_workload(F, W, torch, config, V, T, sr, first, layout, math, voice_out=True):
+    """-> dict(bank, inp, out, layout, fs, n_out, bytes_per_sample, slot_bytes, kernel); voice_out=False: no per-voice output
+    buffer (a run that only ever takes the fused mix-down, fdsp_bank_process_mix)"""
     inp = None
     if config == 3:
         bank = W.make_fm_svf_bank(V, sr, voice0=first)
@@ -193,7 +194,9 @@ def make_workload(F, W, torch, config, V, T, sr, first, layout, math):
     if math == "fast":
         bank.set_option("math", F.MATH_FAST)
     fs = T if layout == F.LAYOUT_PLANAR else 0
-    out = torch.empty((n_out, T, V) if layout == F.LAYOUT_VOICE_MINOR else (V, n_out, fs), dtype=torch.float32, device="cuda")
+    out = None
+    if voice_out:
+        out = torch.empty((n_out, T, V) if layout == F.LAYOUT_VOICE_MINOR else (V, n_out, fs), dtype=torch.float32, device="cuda")
     return dict(bank=bank, inp=inp, out=out, layout=layout, fs=fs, n_out=n_out, bps=bps, slot_bytes=slot_bytes, kernel=kernel)
 
 
@@ -290,50 +293,88 @@ def secondary(F, W, torch, sr, mode):
             except Exception as e:
                 out[-1]["cpu_baseline"] = {"error": repr(e)}
         del wl
-    # The path's one exchange step, on one GPU (VERDICT r02 Weak 6: it had no timing at all): config 4's stereo mix-down
-    # (fdsp_sum_voices: [2][frame][voice] -> [2][frame], fixed-order tree) on the render stream, then ONE all-reduce(sum)
-    # of [2][frames] through the product's collective (fdsp_mix_allreduce: RCCL inside libfundsp_hip.so, on the
-    # communicator's side stream, 1 rank here), overlapped with the next render.
+    # The path's one exchange step, on one GPU: config 4's stereo mix-down + ONE all-reduce(sum) of [2][frames] through the product's
+    # collective (fdsp_mix_allreduce: RCCL inside libfundsp_hip.so, on the communicator's side stream, 1 rank here), overlapped with
+    # the next render.  Round 4: the mix-down is FUSED into the render kernel (fdsp_bank_process_mix: the last stage of a voice group
+    # reduces its 64 voices through LDS, one float per channel and frame leaves for HBM) -- the voice-out buffer
+    # (12.6 GB) is neither written nor re-read.  The unfused pair (voice-out render + fdsp_sum_voices, same summation order) beside it.
     try:
         V, T = 32768, 48000
         wl = make_workload(F, W, torch, 4, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, "exact")
         comm = F.Comm.local([0])
         bank = wl["bank"]
+        bank.mix_reserve(T)
         ms_render, kms = quick(F, torch, wl, T, mode, steps=3, warmup=1)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        mix = F.sum_voices(wl["out"])
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(5):
-            mix = F.sum_voices(wl["out"])
-        e1.record()
-        torch.cuda.synchronize()
-        mix_ms = e0.elapsed_time(e1) / 5
+
+        def wall(fn, n):
+            fn()
+            comm.wait(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            comm.wait(0)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        keep = []
+
+        def fused_step():
+            keep.append(bank.process_mix(T, wl["inp"], mix=F.MIX_SUM, mode=mode))
+            comm.allreduce(keep[-1], slot=0)
+            del keep[:-2]
+
+        def unfused_step():
+            bank.process(T, wl["inp"], wl["out"], layout=wl["layout"], frame_stride=wl["fs"], mode=mode)
+            keep.append(F.sum_voices(wl["out"]))
+            comm.allreduce(keep[-1], slot=0)
+            del keep[:-2]
+        ms_fused = wall(fused_step, 4)
+        fused_kernel_ms = bank.last_kernel_ms()
+        ms_unfused = wall(unfused_step, 3)
+        mix = keep[-1]
         t0 = time.perf_counter()
         for _ in range(20):
             comm.allreduce(mix, slot=0)
             comm.wait(0)
         ar_us = (time.perf_counter() - t0) / 20 * 1e6
-        keep = []
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(4):
-            bank.process(T, wl["inp"], wl["out"], layout=wl["layout"], frame_stride=wl["fs"], mode=mode)
-            keep.append(F.sum_voices(wl["out"]))
-            comm.allreduce(keep[-1], slot=0)
-        comm.wait(0)
-        torch.cuda.synchronize()
-        ms_all = (time.perf_counter() - t0) / 4 * 1e3
+        groups = (V + 63) // 64
         out.append({"name": "config4_mix_single_rank", "what": "BASELINE config 4 per-GPU shard (32768 voices x 48000 frames) with the path's exchange "
-                    "step: fdsp_sum_voices on the render stream + one fdsp_mix_allreduce of [2][48000] f32 (RCCL inside the library, side stream, "
-                    "1-rank communicator), overlapped with the next render", "ms_per_step_render_only": round(ms_render, 4),
-                    "ms_per_step_with_mix_and_allreduce": round(ms_all, 4), "mix_kernel_ms": round(mix_ms, 4),
-                    "mix_read_gbs": round(V * T * 8 / (mix_ms * 1e-3) / 1e9, 1), "allreduce_blocking_us_1rank": round(ar_us, 1),
-                    "value": round(V * T / ms_all / 1e3, 1), "unit": "Msamples/s"})
+                    "step: the stereo mix-down FUSED into the render kernel (fdsp_bank_process_mix, FDSP_MIX_SUM: group partials [512][2][48000] f32 "
+                    "+ fd k_mix_tree) + one fdsp_mix_allreduce of [2][48000] f32 (RCCL inside the library, side stream, 1-rank communicator), "
+                    "overlapped with the next render; the unfused pair (voice-out render + fdsp_sum_voices, same order) beside it",
+                    "ms_per_step_render_only": round(ms_render, 4), "ms_per_step_with_mix_and_allreduce": round(ms_fused, 4),
+                    "fused_render_plus_tree_kernel_ms": round(fused_kernel_ms, 4),
+                    "ms_per_step_unfused_mix_and_allreduce": round(ms_unfused, 4),
+                    "partial_mix_bytes_per_step": groups * 2 * T * 4, "voice_out_bytes_not_written": V * T * 8,
+                    "allreduce_blocking_us_1rank": round(ar_us, 1),
+                    "value": round(V * T / ms_fused / 1e3, 1), "unit": "Msamples/s"})
         comm.close()
         del wl, keep, mix
     except Exception as e:
         out.append({"name": "config4_mix_single_rank", "error": repr(e)})
+    # ... and the headline's voices in mode B: every voice panned (FDSP_MIX_PAN) and summed in the render launch
+    try:
+        V, T = TOTAL_VOICES, 48000
+        wl = make_workload(F, W, torch, 3, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, "exact", voice_out=False)
+        bank = wl["bank"]
+        bank.mix_reserve(T)
+        mixbuf = torch.empty((2, T), dtype=torch.float32, device="cuda")
+        for _ in range(2):
+            bank.process_mix(T, mix=F.MIX_PAN, out=mixbuf, mode=mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = []
+        for _ in range(6):
+            bank.process_mix(T, mix=F.MIX_PAN, out=mixbuf, mode=mode)
+            k.append(bank.last_kernel_ms())
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 6 * 1e3
+        out.append({"name": "config3_mix_pan_fused", "what": "the headline's 65536 voices x 48000 frames in mode B (SURVEY 8(d)): per-voice equal-power pan + "
+                    "sum over the voices inside the render launch (fdsp_bank_process_mix, FDSP_MIX_PAN), [2][48000] f32 out; not a bandwidth test",
+                    "ms_per_step": round(ms, 4), "kernel_ms_avg_incl_tree": round(sum(k) / len(k), 4), "value": round(V * T / ms / 1e3, 1), "unit": "Msamples/s"})
+        del wl, mixbuf
+    except Exception as e:
+        out.append({"name": "config3_mix_pan_fused", "error": repr(e)})
     return out
 
 
@@ -406,6 +447,7 @@ def parse_args(argv=None):
     ap.add_argument("--sample-rate", type=float, default=48000.0)
     ap.add_argument("--layout", choices=["voice_minor", "planar"], default="voice_minor")
     ap.add_argument("--mode", choices=["process", "tick"], default="process")
+    ap.add_argument("--mix-mode", choices=["fused", "unfused"], default="fused", help="--mix: fused = the render kernel reduces over the voices itself (fdsp_bank_process_mix, no voice-out buffer); unfused = voice-out render + a second kernel")
     ap.add_argument("--mix", action="store_true", help="add the on-device stereo mix-down + fdsp_mix_allreduce (RCCL inside the library, side stream) per step")
     ap.add_argument("--pipe-split", type=int, default=1, choices=[0, 1, 2, 3],
                     help="pipeline split of Pipe-chain kinds: 0 off, 1 best plan (default), 2 / 3 = that many stages")
@@ -507,10 +549,20 @@ def main(argv=None):
     print(json.dumps(res), flush=True)
 
 
-def mix_step(F, torch, args, wl, peers):
-    """The path's one exchange step: per-GPU stereo mix-down on the render stream, then ONE all-reduce(sum) of [2][frames] f32
-    through fdsp_mix_allreduce on the communicator's side stream -- the next render does not wait for it."""
-    if args.config in (2, 3):
+def fused_mix(args, F, layout):
+    """--mix takes the fused mix-down (the render kernel reduces over the voices itself) wherever the bank has it: the voice-minor
+    configs 2 / 3 / 4.  --mix-mode unfused keeps round 3's shape (voice-out render, then a second kernel over it)."""
+    return bool(args.mix) and args.mix_mode == "fused" and args.config in (2, 3, 4) and layout == F.LAYOUT_VOICE_MINOR
+
+
+def mix_step(F, torch, args, wl, peers, mode):
+    """The path's one exchange step: the per-GPU stereo mix-down, then ONE all-reduce(sum) of [2][frames] f32 through
+    fdsp_mix_allreduce on the communicator's side stream -- the next render does not wait for it.  Fused (default): the mix-down
+    IS the render launch (fdsp_bank_process_mix; config 4's voices end in a Panner -> FDSP_MIX_SUM, the mono configs are panned
+    per voice -> FDSP_MIX_PAN).  Unfused: a second kernel over the voice-out buffer, same summation order."""
+    if wl["out"] is None:
+        mix = wl["bank"].process_mix(args.frames, wl["inp"], mix=F.MIX_SUM if args.config == 4 else F.MIX_PAN, mode=mode)
+    elif args.config in (2, 3):
         mix = F.mix_stereo(wl["out"][0] if wl["layout"] == F.LAYOUT_VOICE_MINOR else wl["out"][:, 0, :].t().contiguous())
     elif args.config == 5:
         mix = wl["out"].sum(dim=0)     # [2][T] sum over instances (planar layout)
@@ -612,14 +664,21 @@ def run_rank(args, torch, F, peers, device):
             first, V = fdist.shard_range(base_voices, rank, world)   # contiguous ranges of the whole-node bank
         else:
             first, V = rank * base_voices, base_voices
-        wl = make_workload(F, W, torch, args.config, V, T, sr, first, layout, args.math)
+        fused = fused_mix(args, F, layout)
+        wl = make_workload(F, W, torch, args.config, V, T, sr, first, layout, args.math, voice_out=not fused)
         bank = wl["bank"]
         mixes = []
+        if fused:
+            bank.mix_reserve(T)
+            # mode B of SURVEY 8(d): the algorithmic bytes are the inputs and the [2][T] mix -- "not a bandwidth test"
+            wl["bps"] = 4 if args.config == 4 else 0
+            wl["kernel"] = wl["kernel"].replace("fd::k_render_pipe<", "fd::k_render_pipe_mix<") + " + fd::k_mix_tree (fused mix-down: no voice-out buffer)"
 
         def step():
-            bank.process(T, wl["inp"], wl["out"], layout=wl["layout"], frame_stride=wl["fs"], mode=mode)
+            if not fused:
+                bank.process(T, wl["inp"], wl["out"], layout=wl["layout"], frame_stride=wl["fs"], mode=mode)
             if args.mix:
-                mixes.append(mix_step(F, torch, args, wl, peers))
+                mixes.append(mix_step(F, torch, args, wl, peers, mode))
                 del mixes[:-2]   # the side stream may still be summing the previous one
 
         # untimed spin-up before the W warm-up steps: an idle MI355X sits at a 600 MHz shader clock and needs a few
@@ -753,13 +812,14 @@ def run_rank(args, torch, F, peers, device):
                              4: "BASELINE config 4 voice: ((dc(f)>>saw()|dc(fc)|dc(q))>>moog())*adsr_live(.01,.1,.6,.2)>>pan(p), gate in, ",
                              5: "BASELINE config 5: reverb_stereo(10.0, 2.0, 0.5) 32-line FDN, stereo noise in, planar I/O, "}[args.config] +
                             f"{total_voices} {unit_name} in total = {V} per GPU x {T} frames/step @ {sr:g} Hz, "
-                            f"{'planar ([' + unit_name[:-1] + '][channel][frame] f32)' if args.config == 5 or args.layout == 'planar' else 'voice-out ([frame][voice] f32)'}, "
+                            f"{'planar ([' + unit_name[:-1] + '][channel][frame] f32)' if args.config == 5 or args.layout == 'planar' else ('mix-out ([2][frame] f32, fused stereo mix-down: mode B)' if fused_mix(args, F, layout) else 'voice-out ([frame][voice] f32)')}, "
                             f"{args.mode} semantics, {args.math} arithmetic, per-voice params from rnd1(4v+k), phases via set_seed(v)",
                 "total_voices": total_voices,
                 "voices_per_gpu": V,
                 "frames_per_step": T,
                 "layout": "planar" if args.config == 5 else args.layout,
                 "mix_allreduce": bool(args.mix),
+                "mix_mode": (("fused (fdsp_bank_process_mix)" if fused_mix(args, F, layout) else "unfused (voice-out render + a second kernel)") if args.mix else None),
                 "mix_collective": ("fdsp_mix_allreduce (RCCL inside libfundsp_hip.so, communicator side stream)" if args.mix else None),
                 "launch": ("one process per GPU (torch.distributed.run)" if peers.dist is not None else
                            "one process, one host thread per GPU" if world > 1 else "one process, one GPU"),

@@ -9,10 +9,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FUNDSP_HIP_LIB overrides the in-tree library (A/B builds of the same C ABI, e.g. tools/build_variants.sh)
 SO_PATH = os.environ.get("FUNDSP_HIP_LIB") or os.path.join(_HERE, "libfundsp_hip.so")
 
-OK, EINVAL, ENOMEM, EDEVICE = 0, -1, -2, -3
+OK, EINVAL, ENOMEM, EDEVICE, ENOTSUP = 0, -1, -2, -3, -4
 LAYOUT_VOICE_MINOR, LAYOUT_PLANAR = 0, 1
 MODE_PROCESS, MODE_TICK = 0, 1
 MATH_EXACT, MATH_FAST = 0, 1
+MIX_SUM, MIX_PAN = 1, 2  # fdsp_bank_process_mix: sum the output channels over the voices | pan a mono graph per voice, then sum
 FADE_POWER, FADE_SMOOTH = 0, 1  # sequencer.rs Fade::Power / Fade::Smooth
 MAX_BUFFER_SIZE = 64
 DEFAULT_SR = 44100.0
@@ -71,6 +72,9 @@ SYMBOLS = {
     "fdsp_bank_events_time": (_d, [_P]),
     "fdsp_bank_synchronize": (_i, [_P]),
     "fdsp_bank_last_kernel_ms": (_i, [_P, C.POINTER(C.c_float)]),
+    "fdsp_bank_process_mix": (_i, [_P, _sz, _P, _P, _i, _i, _P]),
+    "fdsp_bank_set_pan": (_i, [_P, _fp, _sz, _sz]),
+    "fdsp_bank_mix_reserve": (_i, [_P, _sz]),
     "fdsp_mix_stereo": (_i, [_P, _P, _P, _sz, _sz, _P]),
     "fdsp_sum_voices": (_i, [_P, _P, _sz, _sz, _sz, _P]),
     "fdsp_comm_create_local": (_i, [_i, C.POINTER(C.c_int), C.POINTER(_P)]),

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import FADE_POWER, FADE_SMOOTH, LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS, MODE_TICK, check, lib
+from ._lib import FADE_POWER, FADE_SMOOTH, LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MIX_PAN, MIX_SUM, MODE_PROCESS, MODE_TICK, check, lib
 
 SVF_MODES = dict(lowpass=0, highpass=1, bandpass=2, notch=3, peak=4, allpass=5, bell=6, lowshelf=7, highshelf=8)
 BQ_KINDS = dict(butter=0, resonator=1, lowpass=2, highpass=3, bell=4)
@@ -202,6 +202,37 @@ class Bank:
         check(lib().fdsp_bank_process(self._h, frames, d_in, C.c_void_p(out.data_ptr()), layout, fs, mode,
                                       C.c_void_p(stream) if stream else None))
         return out
+
+    def process_mix(self, frames, inp=None, mix=MIX_SUM, out=None, mode=MODE_PROCESS, stream=None):
+        """Render `frames` samples per voice and reduce them over the voices in the same launch (fdsp_bank_process_mix): the
+        per-voice output never exists in HBM.  mix = MIX_SUM -> [outputs, frames]; MIX_PAN (mono graphs, positions from
+        set_pan) -> [2, frames].  inp: voice-minor [inputs, frames, V].  Same summation order as sum_voices / mix_stereo."""
+        import torch
+
+        frames = int(frames)
+        ni, nm = self.inputs(), (2 if mix == MIX_PAN else self.outputs())
+        if out is None:
+            out = torch.empty((nm, frames), dtype=torch.float32, device="cuda")
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= nm * frames
+        d_in = None
+        if ni:
+            assert inp is not None and inp.is_cuda and inp.dtype == torch.float32 and inp.is_contiguous()
+            assert inp.numel() >= ni * frames * self.voices, f"inp has {inp.numel()} floats, needs {ni * frames * self.voices}"
+            d_in = C.c_void_p(inp.data_ptr())
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        check(lib().fdsp_bank_process_mix(self._h, frames, d_in, C.c_void_p(out.data_ptr()), int(mix), mode,
+                                          C.c_void_p(stream) if stream else None))
+        return out
+
+    def set_pan(self, pan, first=0):
+        """Pan position (-1 .. 1) per voice for MIX_PAN (Panner, pan.rs:13-17); every voice starts in the centre."""
+        p = np.ascontiguousarray(pan, dtype=np.float32).reshape(-1)
+        check(lib().fdsp_bank_set_pan(self._h, _fptr(p), first, p.size))
+
+    def mix_reserve(self, frames):
+        """Size the bank's partial-mix buffer for launches of up to `frames` frames (AudioNode::allocate semantics)."""
+        check(lib().fdsp_bank_mix_reserve(self._h, int(frames)))
 
     def set_ring(self, ring_index, data, first=0):
         """Upload ring contents [voices][frames] (e.g. Pluck's excitation stream into ring 0)."""
@@ -446,6 +477,28 @@ class Comm:
         if _lib is None or getattr(_lib, "_lib", None) is None:
             return
         self.close()
+
+
+def mix_order_reference(x):
+    """The mix-down's summation order (include/fundsp_hip.h) in numpy f32: x [..., voices] -> [...].
+    partial(group of 64) = (S0 + S1) + (S2 + S3), Sq = its 16 voices added one after the other (voices past the end = +0.0);
+    the partials in an aligned binary tree, a node without a right sibling passes through.  Host-side statement of the order
+    for tests and documentation -- the product path never calls it."""
+    x = np.asarray(x, dtype=np.float32)
+    V = x.shape[-1]
+    G = (V + 63) // 64
+    pad = np.zeros(x.shape[:-1] + (G * 64,), dtype=np.float32)
+    pad[..., :V] = x
+    q = pad.reshape(x.shape[:-1] + (G, 4, 16))
+    s = q[..., 0].copy()
+    for j in range(1, 16):
+        s = s + q[..., j]
+    level = (s[..., 0] + s[..., 1]) + (s[..., 2] + s[..., 3])  # [..., G]
+    while level.shape[-1] > 1:
+        n = level.shape[-1]
+        pairs = level[..., 0:n - (n & 1):2] + level[..., 1:n:2]
+        level = np.concatenate([pairs, level[..., n - 1:n]], axis=-1) if n & 1 else pairs
+    return level[..., 0]
 
 
 def sum_voices(x, stream=None):

@@ -423,6 +423,11 @@ struct fdsp_bank {
     float *st_in = nullptr, *st_out = nullptr;     // device
     float *pin_in = nullptr, *pin_out = nullptr;   // pinned host (small transfers only)
     size_t st_in_n = 0, st_out_n = 0, pin_in_n = 0, pin_out_n = 0;
+    // fused mix-down (fdsp_bank_process_mix): the voice groups' partial mixes [groups][channels][frames], grown on demand and
+    // kept (fdsp_bank_mix_reserve sizes it ahead of a real-time loop or a graph capture); pan weights [2][stride] (FDSP_MIX_PAN)
+    float* mix_part = nullptr;
+    size_t mix_part_n = 0;
+    float* panw = nullptr;
 };
 
 namespace {
@@ -503,49 +508,110 @@ __global__ void k_pan_weights(const float* pan, float* wl, float* wr, size_t V) 
     wr[v] = fd::sinf_musl(angle);
 }
 
-// One 256-thread workgroup per frame: thread k accumulates voices k, k+256, ... in order, then a fixed LDS tree.
-__global__ __launch_bounds__(256) void k_mix(const float* __restrict__ x, const float* __restrict__ wl,
-                                             const float* __restrict__ wr, float* __restrict__ mix, size_t T,
-                                             size_t V) {
-    __shared__ float sl[256], sr[256];
-    const size_t t = blockIdx.x;
-    const float* row = x + t * V;
-    float l = 0.0f, r = 0.0f;
-    for (size_t v = threadIdx.x; v < V; v += 256) {
-        float s = row[v];
-        l += s * wl[v];
-        r += s * wr[v];
-    }
-    sl[threadIdx.x] = l;
-    sr[threadIdx.x] = r;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
-        if ((int)threadIdx.x < h) {
-            sl[threadIdx.x] += sl[threadIdx.x + h];
-            sr[threadIdx.x] += sr[threadIdx.x + h];
+// ---- the mix-down's summation order (fd_device.hpp "fused mix-down"), for voice-out buffers --------------------------
+// partial(group of 64 voices) = (S0 + S1) + (S2 + S3), Sq = the quarter's 16 voices added one after the other (voices past the
+// end count as +0.0); then the groups' partials in an aligned binary tree.  The render kernels with the fused mix-down produce
+// the same partials without the voice-out buffer ever existing.
+FD_D float quad_swap(float x, int ctrl) {
+    return fd::u2f((uint32_t)(ctrl == 0 ? __builtin_amdgcn_update_dpp((int)fd::f2u(x), (int)fd::f2u(x), 0xB1, 0xF, 0xF, false)
+                                        : __builtin_amdgcn_update_dpp((int)fd::f2u(x), (int)fd::f2u(x), 0x4E, 0xF, 0xF, false)));
+}
+// x: [rows][V] voice-minor.  PAN = false: part[group][row] = partial sum of the row.  PAN = true (rows = frames of a mono render):
+// part[group][c][row], c = left / right, every sample weighted by its voice's pan weights first.
+// One workgroup = one voice group x 256 rows: thread (row, quarter) reads its quarter's 16 consecutive floats.
+template <bool PAN>
+__global__ __launch_bounds__(256) void k_group_partials(const float* __restrict__ x, const float* __restrict__ wl,
+                                                        const float* __restrict__ wr, float* __restrict__ part, size_t rows, size_t V) {
+    const size_t g = blockIdx.x, r0 = (size_t)blockIdx.y * 256;
+    const int q = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    const size_t vq = g * 64 + (size_t)q * 16;
+    float a[PAN ? 16 : 1], b[PAN ? 16 : 1];
+    if constexpr (PAN) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            a[j] = vq + j < V ? wl[vq + j] : 0.0f;
+            b[j] = vq + j < V ? wr[vq + j] : 0.0f;
         }
-        __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        mix[t] = sl[0];
-        mix[T + t] = sr[0];
+#pragma unroll 1
+    for (int p = 0; p < 4; p++) {
+        const size_t r = r0 + (size_t)p * 64 + rl;
+        const bool on = r < rows;
+        const float* src = x + (on ? r : 0) * V + vq;
+        float xs[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) xs[j] = (on && vq + j < V) ? src[j] : 0.0f;
+        float sl, sr = 0.0f;
+        if constexpr (PAN) {
+            sl = vq < V ? xs[0] * a[0] : 0.0f;
+            sr = vq < V ? xs[0] * b[0] : 0.0f;
+#pragma unroll
+            for (int j = 1; j < 16; j++) {
+                sl += vq + j < V ? xs[j] * a[j] : 0.0f;
+                sr += vq + j < V ? xs[j] * b[j] : 0.0f;
+            }
+        } else {
+            sl = xs[0];
+#pragma unroll
+            for (int j = 1; j < 16; j++) sl += xs[j];
+        }
+        const float tl = sl + quad_swap(sl, 0), ul = tl + quad_swap(tl, 1);
+        if constexpr (PAN) {
+            const float tr = sr + quad_swap(sr, 0), ur = tr + quad_swap(tr, 1);
+            if (on && q == 0) {
+                part[(g * 2 + 0) * rows + r] = ul;
+                part[(g * 2 + 1) * rows + r] = ur;
+            }
+        } else if (on && q == 0) part[g * rows + r] = ul;
     }
 }
 
-// Sum over voices of a voice-minor buffer [rows][voices] -> [rows]; same fixed order as k_mix (per-GPU partial of the
-// stereo mix-down for graphs that already end in a Panner, e.g. BASELINE config 4).
-__global__ __launch_bounds__(256) void k_sum_voices(const float* __restrict__ x, float* __restrict__ out, size_t V) {
-    __shared__ float sm[256];
-    const float* row = x + (size_t)blockIdx.x * V;
-    float a = 0.0f;
-    for (size_t v = threadIdx.x; v < V; v += 256) a += row[v];
-    sm[threadIdx.x] = a;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
-        if ((int)threadIdx.x < h) sm[threadIdx.x] += sm[threadIdx.x + h];
-        __syncthreads();
+// part: [G][R] -> mix[R]: the aligned binary tree over the G groups (a node without a right sibling passes through), one thread
+// per row.  Sixteen groups are loaded at a time (independent loads) and reduced in registers; the blocks of sixteen are merged by
+// a binary counter -- `stack[k]` holds the sum of an aligned run of 16 * 2^k groups.
+__global__ __launch_bounds__(256) void k_mix_tree(const float* __restrict__ part, float* __restrict__ mix, size_t R, size_t G) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float stack[28];
+    const size_t nb = (G + 15) / 16;
+    for (size_t b = 0; b < nb; b++) {
+        const int m = (int)(G - b * 16 < 16 ? G - b * 16 : 16);  // groups of this block (uniform)
+        float x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = j < m ? part[(b * 16 + j) * R + r] : 0.0f;
+#pragma unroll
+        for (int span = 1; span < 16; span <<= 1)
+#pragma unroll
+            for (int j = 0; j + span < 16; j += 2 * span)
+                if (j + span < m) x[j] = x[j] + x[j + span];
+        float carry = x[0];
+        bool placed = false;
+#pragma unroll
+        for (int k = 0; k < 28; k++) {
+            if (!placed) {
+                if (((b >> k) & 1) == 0) { stack[k] = carry; placed = true; }
+                else carry = stack[k] + carry;
+            }
+        }
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
+    float acc = 0.0f;
+    bool have = false;
+#pragma unroll
+    for (int k = 0; k < 28; k++)
+        if ((nb >> k) & 1) {
+            acc = have ? stack[k] + acc : stack[k];
+            have = true;
+        }
+    mix[r] = acc;
+}
+
+// the launch pair behind fdsp_sum_voices / fdsp_mix_stereo: group partials of a voice-out buffer, then the tree
+template <bool PAN>
+hipError_t launch_mix_rows(const float* x, const float* wl, const float* wr, float* part, float* mix, size_t rows, size_t V, hipStream_t s) {
+    const size_t G = (V + 63) / 64, R = PAN ? 2 * rows : rows;
+    hipLaunchKernelGGL((k_group_partials<PAN>), dim3((unsigned)G, (unsigned)((rows + 255) / 256)), dim3(256), 0, s, x, wl, wr, part, rows, V);
+    hipLaunchKernelGGL(k_mix_tree, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, part, mix, R, G);
+    return hipGetLastError();
 }
 
 }  // namespace
@@ -925,6 +991,8 @@ void fdsp_bank_destroy(fdsp_bank* b) {
     if (b->ring) hipFree(b->ring);
     if (b->ev) hipFree(b->ev);
     if (b->ev_fade) hipFree(b->ev_fade);
+    if (b->mix_part) hipFree(b->mix_part);
+    if (b->panw) hipFree(b->panw);
     if (b->st_in) hipFree(b->st_in);
     if (b->st_out) hipFree(b->st_out);
     if (b->pin_in) hipHostFree(b->pin_in);
@@ -959,7 +1027,8 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
     hipError_t e = hipSuccess;
     if (src->fdn) {
         if (src->sr != b->sr) {  // the rings' capacity and lengths follow the sample rate
-            HIPCHK(hipStreamSynchronize(b->stream));
+            e = hipStreamSynchronize(b->stream);
+            if (e != hipSuccess) return bail(e, "sync");
             rc = fdn_configure(b, src->sr);
             if (rc != FDSP_OK) {
                 fdsp_bank_destroy(b);
@@ -998,6 +1067,11 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
         b->ev_min_end = src->ev_min_end;
         b->ev_max_fade_in_end = src->ev_max_fade_in_end;
         b->ev_min_fade_out_start = src->ev_min_fade_out_start;
+    }
+    if (src->panw) {
+        e = hipMalloc((void**)&b->panw, 2 * src->stride * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpyAsync(b->panw, src->panw, 2 * src->stride * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
+        if (e != hipSuccess) return bail(e, "pan weights");
     }
     b->math = src->math;
     b->opt_pipe_split = src->opt_pipe_split;
@@ -1201,6 +1275,105 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
     else
         b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, b->aux, b->ring, b->ring_cap, s);
     b->last_kernel = fd::tl_opts.last_kernel;
+    HIPCHK(hipGetLastError());
+    if (!capturing) {
+        if (timing || s != b->stream) HIPCHK(hipEventRecord(b->e1, s));
+        b->timed = timing;
+        b->ext_pending = s != b->stream;
+    }
+    return FDSP_OK;
+}
+
+// ---- render + mix-down in one launch -------------------------------------------------------------------------------
+namespace {
+int mix_channels(const fdsp_bank* b, int mix) { return mix == FDSP_MIX_PAN ? 2 : fdsp_bank_outputs(b); }
+// the pan weights exist from the first use on; every voice starts in the centre (pan = 0: Panner::new, pan.rs:41-45)
+int ensure_panw(fdsp_bank* b) {
+    if (b->panw) return FDSP_OK;
+    hipError_t e = hipMalloc((void**)&b->panw, 2 * b->stride * sizeof(float));
+    if (e != hipSuccess) return fail(FDSP_ENOMEM, std::string("hipMalloc(pan weights): ") + hipGetErrorString(e));
+    hipLaunchKernelGGL(k_pan_weights, dim3((unsigned)((b->stride + 255) / 256)), dim3(256), 0, b->stream, (const float*)nullptr, b->panw,
+                       b->panw + b->stride, b->stride);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return FDSP_OK;
+}
+int mix_reserve(fdsp_bank* b, size_t floats) {
+    if (floats <= b->mix_part_n) return FDSP_OK;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->ext_pending) HIPCHK(hipEventSynchronize(b->e1));  // a render on a caller's stream may still write the old buffer
+    if (b->mix_part) hipFree(b->mix_part);
+    b->mix_part = nullptr;
+    b->mix_part_n = 0;
+    hipError_t e = hipMalloc((void**)&b->mix_part, floats * sizeof(float));
+    if (e != hipSuccess) return fail(FDSP_ENOMEM, std::string("hipMalloc(partial mixes): ") + hipGetErrorString(e));
+    b->mix_part_n = floats;
+    return FDSP_OK;
+}
+}  // namespace
+
+int fdsp_bank_set_pan(fdsp_bank* b, const float* h_pan, size_t first, size_t count) {
+    if (!b || !h_pan) return fail(FDSP_EINVAL, "bank or h_pan NULL");
+    DeviceGuard guard(b->device);
+    if (int rc = check_range(b, first, count)) return rc;
+    if (count == 0) return FDSP_OK;
+    if (int rc = ensure_panw(b)) return rc;
+    HIPCHK(await_last_render(b));
+    float* d = nullptr;
+    HIPCHK(hipMallocAsync((void**)&d, count * sizeof(float), b->stream));
+    hipError_t e = hipMemcpyAsync(d, h_pan, count * sizeof(float), hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_pan_weights, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, b->stream, (const float*)d, b->panw + first,
+                           b->panw + b->stride + first, count);
+        e = hipGetLastError();
+    }
+    hipFreeAsync(d, b->stream);
+    HIPCHK(e);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return FDSP_OK;
+}
+
+int fdsp_bank_mix_reserve(fdsp_bank* b, size_t frames) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    DeviceGuard guard(b->device);
+    const size_t nm = (size_t)(fdsp_bank_outputs(b) > 2 ? fdsp_bank_outputs(b) : 2);
+    return mix_reserve(b, (b->stride / 64) * nm * frames);
+}
+
+int fdsp_bank_process_mix(fdsp_bank* b, size_t frames, const float* d_in, float* d_mix, int mix, int mode, void* stream) {
+    if (!b) return fail(FDSP_EINVAL, "bank is NULL");
+    DeviceGuard guard(b->device);
+    if (frames == 0) return FDSP_OK;
+    if (!d_mix) return fail(FDSP_EINVAL, "d_mix is NULL");
+    if (fdsp_bank_inputs(b) > 0 && !d_in) return fail(FDSP_EINVAL, "d_in is NULL but the graph has inputs");
+    if (mode != FDSP_MODE_PROCESS && mode != FDSP_MODE_TICK) return fail(FDSP_EINVAL, "bad mode");
+    if (mix != FDSP_MIX_SUM && mix != FDSP_MIX_PAN) return fail(FDSP_EINVAL, "mix takes FDSP_MIX_SUM or FDSP_MIX_PAN");
+    if (mix == FDSP_MIX_PAN && fdsp_bank_outputs(b) != 1) return fail(FDSP_EINVAL, "FDSP_MIX_PAN pans a mono graph; this one has " + std::to_string(fdsp_bank_outputs(b)) + " outputs (use FDSP_MIX_SUM)");
+    if (b->fdn) return fail(FDSP_ENOTSUP, "reverb_stereo banks have no fused mix-down: render the instances and call fdsp_sum_voices");
+    const bool fast = b->math == FDSP_MATH_FAST && b->ops->render_mix_fast;
+    const auto& launch = fast ? b->ops->render_mix_fast : b->ops->render_mix;
+    if (!launch) return fail(FDSP_ENOTSUP, "kind '" + b->ops->name + "' was built without a fused mix-down kernel: render voice-out and call fdsp_sum_voices / fdsp_mix_stereo");
+    hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s != b->stream) hipStreamIsCapturing(s, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    const size_t nm = (size_t)mix_channels(b, mix), groups = b->stride / 64, R = nm * frames;
+    if (groups * R > b->mix_part_n || (mix == FDSP_MIX_PAN && !b->panw)) {
+        if (capturing) return fail(FDSP_EINVAL, "fdsp_bank_process_mix during a stream capture: call fdsp_bank_mix_reserve (and fdsp_bank_set_pan) before capturing");
+        if (int rc = mix_reserve(b, groups * R)) return rc;
+        if (mix == FDSP_MIX_PAN) if (int rc = ensure_panw(b)) return rc;
+    }
+    HIPCHK(order_after_bank_stream(b, s));
+    if (int rc = check_ring_need(b, capturing)) return rc;
+    if (b->ext_pending && !capturing) HIPCHK(hipStreamWaitEvent(s, b->e1, 0));
+    const bool timing = timing_on(b);
+    if (!capturing && timing) HIPCHK(hipEventRecord(b->e0, s));
+    resolve_opts(b);
+    const bool done = launch(b->slots, b->stride, b->V, d_in, b->mix_part, frames, mix, mode, b->aux, b->ring, b->ring_cap, b->panw, s);
+    if (!done) return fail(FDSP_ENOTSUP, "kind '" + b->ops->name + "': no fused mix-down kernel for this graph shape (single-stage graphs without inputs, 3+ outputs with FDSP_MIX_PAN)");
+    b->last_kernel = fd::tl_opts.last_kernel;
+    // the groups' partials -> d_mix, aligned binary tree (k_mix_tree); the time it takes is part of the render's event pair
+    hipLaunchKernelGGL(k_mix_tree, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, (const float*)b->mix_part, d_mix, R, (b->V + 63) / 64);
     HIPCHK(hipGetLastError());
     if (!capturing) {
         if (timing || s != b->stream) HIPCHK(hipEventRecord(b->e1, s));
@@ -1442,15 +1615,17 @@ int fdsp_mix_stereo(const float* d_voices, const float* d_pan, float* d_mix, siz
                     void* stream) {
     if (!d_voices || !d_mix) return fail(FDSP_EINVAL, "NULL buffer");
     if (frames == 0 || voices == 0) return FDSP_OK;
+    if (frames > 65535u * 256u) return fail(FDSP_EINVAL, "fdsp_mix_stereo: at most 16 776 960 frames per call");
     DeviceGuard guard(device_of(d_voices));  // the kernels run where the voices live, whatever device is current
     hipStream_t s = (hipStream_t)stream;
-    float* w = nullptr;
-    HIPCHK(hipMallocAsync((void**)&w, 2 * voices * sizeof(float), s));
+    const size_t G = (voices + 63) / 64;
+    float* w = nullptr;  // [2][voices] weights, then [G][2][frames] partial mixes
+    HIPCHK(hipMallocAsync((void**)&w, (2 * voices + G * 2 * frames) * sizeof(float), s));
     hipLaunchKernelGGL(k_pan_weights, dim3((unsigned)((voices + 255) / 256)), dim3(256), 0, s, d_pan, w, w + voices,
                        voices);
-    hipLaunchKernelGGL(k_mix, dim3((unsigned)frames), dim3(256), 0, s, d_voices, w, w + voices, d_mix, frames, voices);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipFreeAsync(w, s));
+    hipError_t e = launch_mix_rows<true>(d_voices, w, w + voices, w + 2 * voices, d_mix, frames, voices, s);
+    hipFreeAsync(w, s);
+    HIPCHK(e);
     return FDSP_OK;
 }
 
@@ -1495,10 +1670,15 @@ int fdsp_wavetable_get(int set, int* n_tables, float* h_pitches, int* h_lengths,
 int fdsp_sum_voices(const float* d_in, float* d_out, size_t channels, size_t frames, size_t voices, void* stream) {
     if (!d_in || !d_out) return fail(FDSP_EINVAL, "NULL buffer");
     if (channels == 0 || frames == 0 || voices == 0) return FDSP_OK;
+    const size_t rows = channels * frames, G = (voices + 63) / 64;
+    if (rows > 65535u * 256u) return fail(FDSP_EINVAL, "fdsp_sum_voices: at most 16 776 960 rows (channels x frames) per call");
     DeviceGuard guard(device_of(d_in));
-    hipLaunchKernelGGL(k_sum_voices, dim3((unsigned)(channels * frames)), dim3(256), 0, (hipStream_t)stream, d_in, d_out,
-                       voices);
-    HIPCHK(hipGetLastError());
+    hipStream_t s = (hipStream_t)stream;
+    float* part = nullptr;  // [G][rows] partial sums
+    HIPCHK(hipMallocAsync((void**)&part, G * rows * sizeof(float), s));
+    hipError_t e = launch_mix_rows<false>(d_in, nullptr, nullptr, part, d_out, rows, voices, s);
+    hipFreeAsync(part, s);
+    HIPCHK(e);
     return FDSP_OK;
 }
 

@@ -1015,6 +1015,60 @@ constexpr PipePlan pipe_plan(int want) {  // want: 0 = best plan, 1 / 2 / 3 = at
     return best;
 }
 
+// ---- fused mix-down ("mode B" of SURVEY.md 8(d): on-device reduction of the voices to [channels][frames]) ------------
+// The LAST stage of a voice group does not store its samples to HBM; it parks them in a small LDS tile
+// [mix channel][frame of the chunk][voice] and, every MC frames, reads the tile back TRANSPOSED -- lane = (channel, frame,
+// quarter of the group's voices) -- adds the 16 voices of its quarter one after the other, combines the four quarters
+// through DPP and writes ONE float per (channel, frame): the group's partial mix.  The order is fixed and does not depend on
+// the launch geometry:
+//     partial(group) = (S0 + S1) + (S2 + S3),   Sq = ((x[16q] + x[16q+1]) + x[16q+2]) + ... + x[16q+15]
+// (voices past the end of the bank count as +0.0).  k_mix_tree then adds the groups' partials in an aligned binary tree
+// (an odd node at the end of a level passes through).  fdsp_sum_voices / fdsp_mix_stereo of a voice-out render use the same
+// order, so the fused mix equals them bit for bit (tests/test_gpu_mix.py).
+// Reference shape: the Panner / Reduce arithmetic of src/pan.rs:50-76, src/audionode.rs:2406-2462 over a bank of voices.
+constexpr int MIX_NONE = 0, MIX_SUM = 1, MIX_PAN = 2;  // sum every output channel over the voices | pan a mono graph to stereo, then sum
+constexpr int MIX_ROW = 68;  // floats per (channel, frame) row of a mix tile: 64 voices + 4 (16-byte runs stay aligned, lane-per-row b128 reads spread over the banks)
+template <int NM, int GPW, int SUB>
+struct MixGeom {  // frames per chunk: what fits the 32 KiB the pipeline's own tiles leave of a CU's 160 KiB of LDS
+    static constexpr int fit = (31 * 1024) / GPW / (NM * MIX_ROW * 4);
+    static constexpr int MC0 = fit >= 64 ? 64 : fit >= 32 ? 32 : fit >= 16 ? 16 : fit >= 8 ? 8 : 0;
+    static constexpr int MC = MC0 > SUB ? SUB : MC0;
+    static constexpr int FLOATS = NM * (MC > 0 ? MC : 1) * MIX_ROW;
+    static constexpr bool ok = MC >= 8;
+};
+struct MixLane {   // what the last stage's wave knows about its mix tile
+    float* tile;   // LDS: [NM][MC][MIX_ROW]
+    int col;       // this lane's column: its voice's, or the padding column 64 for lanes past the end of the bank
+    float wl, wr;  // MIX_PAN: equal-power weights of this lane's voice (pan.rs:13-17)
+};
+FD_D float mix_quad(float x, int ctrl) {
+    return u2f((uint32_t)(ctrl == 0 ? __builtin_amdgcn_update_dpp((int)f2u(x), (int)f2u(x), 0xB1, 0xF, 0xF, false)     // quad_perm [1,0,3,2]
+                                    : __builtin_amdgcn_update_dpp((int)f2u(x), (int)f2u(x), 0x4E, 0xF, 0xF, false)));  // quad_perm [2,3,0,1]
+}
+// the chunk's first `nf` frames -> dst[channel * T + frame]; every lane of the wave takes part
+template <int NM, int MC>
+FD_D void mix_flush(const float* tile, float* dst, size_t T, int nf, int lane) {
+    constexpr int E = NM * MC;  // (channel, frame) entries of the tile
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the tile was written by other lanes of this wave (LDS operations of a wave execute in order)
+#pragma unroll
+    for (int p = 0; p < (E * 4 + 63) / 64; p++) {
+        const int idx = p * 64 + lane, e = idx >> 2, q = idx & 3;
+        const bool on = (E * 4) % 64 == 0 || e < E;
+        const float4* row = reinterpret_cast<const float4*>(tile + (on ? e : 0) * MIX_ROW + q * 16);
+        const float4 a = row[0], b = row[1], c = row[2], d = row[3];
+        float s = a.x;
+        s += a.y; s += a.z; s += a.w;
+        s += b.x; s += b.y; s += b.z; s += b.w;
+        s += c.x; s += c.y; s += c.z; s += c.w;
+        s += d.x; s += d.y; s += d.z; s += d.w;
+        const float t = s + mix_quad(s, 0);
+        const float u = t + mix_quad(t, 1);
+        const int ch = e / MC, f = e % MC;
+        if (on && q == 0 && f < nf) dst[(size_t)ch * T + f] = u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // ... and the next chunk's samples must not overtake these reads
+}
+
 // One stage's work on one tile: frames [lo, hi) of the block that starts at t0 (size / full as in
 // AudioNode::process: `full` frames of packed SIMD items, end_simd, then the remainder path).
 // Graph inputs come from the feed tile `fin` (written by the loader wave), never from HBM directly: the FIRST stage
@@ -1027,11 +1081,17 @@ constexpr PipePlan pipe_plan(int want) {  // want: 0 = best plan, 1 / 2 / 3 = at
 // the group's two progress words in LDS (SIMD items of the current tile behind the producer / the consumer); BAL == 1: this
 // stage is the producer, 2: the consumer.  Both publish their count at every item; ONE of them (FD_BAL_SIDE) compares and sets
 // its own priority for the item -- see render_pipe_body.
-template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST, int FS = 64, int OL = 0, bool PF = (FD_PIPE_PREFETCH != 0), int BAL = 0>
+// OL = 2 / 3 (fused mix-down, MIX_SUM / MIX_PAN): the samples go to the wave's mix tile `mx` and leave as the group's partial mix,
+// MC frames at a time (mix_flush); `outw` is then the group's partial row [channel][T] and EVERY lane of the wave runs the stage.
+template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST, int FS = 64, int OL = 0, bool PF = (FD_PIPE_PREFETCH != 0), int BAL = 0, int MC = 0>
 FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_t V, int lane, float* outw,
-                     const float* fin, v2f (*hin)[SUB / 2][64], v2f (*hout)[SUB / 2][64], int* bal = nullptr) {
+                     const float* fin, v2f (*hin)[SUB / 2][64], v2f (*hout)[SUB / 2][64], int* bal = nullptr, const MixLane* mx = nullptr) {
     constexpr int NI = SG::IN, NO = SG::OUT, NG = G::IN;
     constexpr bool GIN = !FIRST && SG::USES_GIN;
+    constexpr bool MIXO = OL >= 2;
+    constexpr int NM = OL == 3 ? 2 : NO;  // mix channels
+    static_assert(!MIXO || (LAST && MC >= 8 && (MC & (MC - 1)) == 0 && FD_ITEM_LOOP), "mix-down: last stage, chunks of 8 .. 64 frames");
+    static_assert(OL != 3 || NO == 1, "the pan mix-down takes a mono graph");
     static_assert(LAST || NO <= W, "hand-over tile too narrow");
     static_assert(FIRST || NI <= W, "hand-over tile too narrow");
     const int lo = h * SUB;
@@ -1057,7 +1117,20 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
 #else
             outw[((size_t)c * T + t0 + i) * V + lane] = x;
 #endif
-        } else outw[(c * SUB + (i - lo)) * FS + lane] = x;
+        } else if constexpr (OL == 1) outw[(c * SUB + (i - lo)) * FS + lane] = x;
+        else {
+            float* cell = mx->tile + ((i - lo) & (MC - 1)) * MIX_ROW + mx->col;
+            if constexpr (OL == 3) {
+                cell[0] = x * mx->wl;
+                cell[MC * MIX_ROW] = x * mx->wr;
+            } else cell[c * MC * MIX_ROW] = x;
+        }
+    };
+    auto flush_at = [&](int iend) {  // mix-down: the chunk that ends with frame iend - 1 of the block leaves for HBM
+        if constexpr (MIXO) {
+            const int nf = ((iend - lo - 1) & (MC - 1)) + 1;
+            mix_flush<NM, MC>(mx->tile, outw + (t0 + iend - nf), T, nf, lane);
+        }
     };
     if (h == 0) SG::begin(g, size);
     if (lo < shi) {
@@ -1144,8 +1217,15 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
                 for (int c = 0; c < NO; c++) hout[c][(i - lo) >> 1][lane] = po[c];
             }
         }
+#if FD_ITEM_LOOP
+        if constexpr (MIXO) { if (((i8 + 8 - lo) & (MC - 1)) == 0) flush_at(i8 + 8); }
+#endif
         }
-        if (__builtin_expect(SG::tripped(g), 0)) {  // a packed-path shortcut left its exact domain: redo the tile
+        // (mix-down: the tile holds one chunk, so when ANY lane tripped every lane redoes the tile frame by frame -- step() and
+        // step2() agree bit for bit where step2 is exact -- and the chunks already flushed are flushed again)
+        bool trip = SG::tripped(g);
+        if constexpr (MIXO) trip = __builtin_amdgcn_ballot_w64(trip) != 0ull;
+        if (__builtin_expect(trip, 0)) {  // a packed-path shortcut left its exact domain: redo the tile
             g = snap;
             for (int i = lo; i < shi; i++) {
                 float fi[NI > 0 ? NI : 1], gf[NG > 0 ? NG : 1], fo[NO];
@@ -1164,6 +1244,7 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
                 if constexpr (LAST) {
 #pragma unroll
                     for (int c = 0; c < NO; c++) put(c, i, fo[c]);
+                    if constexpr (MIXO) { if (((i + 1 - lo) & (MC - 1)) == 0) flush_at(i + 1); }
                 } else {
 #pragma unroll
                     for (int c = 0; c < NO; c++) reinterpret_cast<float*>(&hout[c][(i - lo) >> 1][lane])[i & 1] = fo[c];
@@ -1190,11 +1271,13 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
         if constexpr (LAST) {
 #pragma unroll
             for (int c = 0; c < NO; c++) put(c, i, fo[c]);
+            if constexpr (MIXO) { if (((i + 1 - lo) & (MC - 1)) == 0) flush_at(i + 1); }
         } else {
 #pragma unroll
             for (int c = 0; c < NO; c++) reinterpret_cast<float*>(&hout[c][(i - lo) >> 1][lane])[i & 1] = fo[c];
         }
     }
+    if constexpr (MIXO) { if (hi > lo && ((hi - lo) & (MC - 1)) != 0) flush_at(hi); }  // the tile's last, short chunk
 }
 
 struct RoleOrder { int role[4]; };
@@ -1244,9 +1327,12 @@ static_assert(role_order_is(role_order<true, 3, 100, 30, 83, 4>(), 0, 1, 2, 3), 
 //     stalls on its own stores whenever it waits for an input; the loader never stores, the compute waves never load.
 //   then S compute stages (S == 1: the whole graph), stage s one tile behind stage s - 1.
 // The hardware places waves w, w+4, w+8, ... of a workgroup on the same SIMD.
-template <class G, int MODE, int S, int K1, int K2, int GPW = 4>
+// MIX != MIX_NONE (k_render_pipe_mix): `out` is the bank's partial-mix buffer [voice group][mix channel][T] and `panw` the pan
+// weights [2][stride] (MIX_PAN); every lane of a live voice group runs (the padded voices of the last group are constructed
+// voices with default parameters; their samples land in the tile's padding column).
+template <class G, int MODE, int S, int K1, int K2, int GPW = 4, int MIX = MIX_NONE>
 FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
-                           float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap) {
+                           float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap, const float* __restrict__ panw = nullptr) {
     using TL = PipeTiles<G, S, K1, K2, GPW>;
     constexpr int NI = G::IN;
     constexpr bool FEED = NI > 0;
@@ -1274,7 +1360,14 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     const size_t ntiles = ((T + 63) / 64) * SPB;
     const size_t rounds = ntiles + (S - 1) + (FEED ? 1 : 0);
     const float* inw = in + v0;  // wave-uniform bases + lane
-    float* outw = out + v0;
+    constexpr int NM = MIX == MIX_PAN ? 2 : G::OUT;  // mix channels
+    using MG = MixGeom<NM, GPW, SUB>;
+    constexpr int OLM = MIX == MIX_NONE ? 0 : (MIX == MIX_PAN ? 3 : 2), MCM = MIX == MIX_NONE ? 0 : MG::MC;
+    static_assert(MIX == MIX_NONE || MG::ok, "mix tile does not fit");
+    float* outw = MIX == MIX_NONE ? out + v0 : out + (v0 / 64) * (size_t)NM * T;  // voice-out rows | this group's partial mix
+    __shared__ __attribute__((aligned(16))) float mixt[MIX == MIX_NONE ? 1 : GPW][MIX == MIX_NONE ? 4 : MG::FLOATS];
+    MixLane mxl{&mixt[MIX == MIX_NONE ? 0 : grp][0], active ? lane : 64, 0.0f, 0.0f};
+    const bool run = live && (MIX != MIX_NONE || active);  // (wave-uniform in a mix-down launch)
 
 #if FD_KNOCK
     for (size_t i = threadIdx.x; i < sizeof(hand) / sizeof(float); i += blockDim.x) reinterpret_cast<float*>(hand)[i] = 0.0f;
@@ -1289,10 +1382,11 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
 #pragma unroll
                 for (int k = 0; k < SUB; k++) {
                     const size_t t = tj + k < T ? tj + k : T - 1;
-                    rg[c][k] = inw[((size_t)c * T + t) * V + lane];
+                    if (MIX != MIX_NONE && !active) rg[c][k] = 0.0f;  // a padded voice of a mix-down launch hears silence
+                    else rg[c][k] = inw[((size_t)c * T + t) * V + lane];
                 }
         };
-        const bool on = live && active;
+        const bool on = run;
         if (on) issue(0);
         for (size_t it = 0; it < rounds; it++) {
             if (on && it < ntiles) {
@@ -1316,6 +1410,15 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
         VLoad ld{slots + v, stride, 0};
         VGate::W<VLoad> gate{&ld, true};
         if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
+    }
+    if constexpr (MIX != MIX_NONE) {
+        if (stage == S - 1) {  // the wave that owns the group's mix tile: silence in the columns no lane will write
+            if (!active) {
+#pragma unroll 1
+                for (int r = 0; r < NM * MCM; r++) mxl.tile[r * MIX_ROW + lane] = 0.0f;
+            }
+            if (MIX == MIX_PAN && live && active) { mxl.wl = panw[v]; mxl.wr = panw[stride + v]; }
+        }
     }
     // The rounds, for the graph type GG: G itself, or its lowpass-specialised twin LpOf<G> (same registers, the
     // packed SVF path 5 operations shorter) when every lane of THIS wave qualifies.  A wave that does not hold the SVF
@@ -1341,7 +1444,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
             // profiles/r03_ab17_stage_loops.txt).  Every wave executes `rounds` barriers either way.
             auto loop = [&](auto&& tile) {
                 for (size_t it = 0; it < rounds; it++) {
-                    if (live && active && it >= first && it - first < ntiles && ((FD_KNOCK >> stage) & 1) == 0) {
+                    if (run && it >= first && it - first < ntiles && ((FD_KNOCK >> stage) & 1) == 0) {
                         const size_t j = it - first;          // the tile this stage works on in this round
                         const size_t t0 = (j / SPB) * 64;
                         const int h = (int)(j % SPB);
@@ -1356,7 +1459,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
             };
             if (stage == 0) {
                 loop([&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
-                    if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr);
+                    if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true, 64, OLM, (FD_PIPE_PREFETCH != 0), 0, MCM>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr, nullptr, &mxl);
 #if FD_PIPE_PRODUCER_PLAIN
                     else {  // the producer stage's sines as plain (2-cycle) ops: see SinePlain
                         using GP = typename PlainOf<GG>::type;
@@ -1369,17 +1472,17 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                 });
             } else if (stage == 1) {
                 loop([&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
-                    if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, 0, PFK, BALK ? 2 : 0>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp]);
+                    if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, OLM, PFK, BALK ? 2 : 0, MCM>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp], &mxl);
                     else if constexpr (S == 3) pipe_stage<T1, GG, MODE, SUB, W, false, false, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
                 });
             } else {
                 loop([&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
-                    if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr);
+                    if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, OLM, PFK, 0, MCM>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr, nullptr, &mxl);
                 });
             }
         } else {
             for (size_t it = 0; it < rounds; it++) {
-                if (live && active && it >= first && it - first < ntiles && ((FD_KNOCK >> stage) & 1) == 0) {
+                if (run && it >= first && it - first < ntiles && ((FD_KNOCK >> stage) & 1) == 0) {
                     const size_t j = it - first;          // the tile this stage works on in this round
                     const size_t t0 = (j / SPB) * 64;
                     const int h = (int)(j % SPB);
@@ -1388,7 +1491,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                     const float* fin = nullptr;
                     if constexpr (FEED) fin = &feed[grp][j % D][0][0][0];
                     if (stage == 0) {
-                        if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr);
+                        if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true, 64, OLM, (FD_PIPE_PREFETCH != 0), 0, MCM>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr, nullptr, &mxl);
 #if FD_PIPE_PRODUCER_PLAIN
                         else {  // the producer stage's sines as plain (2-cycle) ops: see SinePlain
                             using GP = typename PlainOf<GG>::type;
@@ -1399,10 +1502,10 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                         else pipe_stage<T0, GG, MODE, SUB, W, true, false, 64, 0, (FD_PIPE_PREFETCH != 0), BALK ? 1 : 0>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1], bal_word[grp]);
 #endif
                     } else if (stage == 1) {
-                        if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, 0, PFK, BALK ? 2 : 0>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp]);
+                        if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, OLM, PFK, BALK ? 2 : 0, MCM>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp], &mxl);
                         else if constexpr (S == 3) pipe_stage<T1, GG, MODE, SUB, W, false, false, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
                     } else {
-                        if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr);
+                        if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, OLM, PFK, 0, MCM>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr, nullptr, &mxl);
                     }
                 }
                 __syncthreads();  // hand-over point: every role has finished its tile of this round
@@ -1410,6 +1513,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
         }
     };
 #if FD_PIPE_FLAGSYNC
+    static_assert(MIX == MIX_NONE, "the flag-synchronised A/B variant has no mix-down");
     // A/B (tools/build_variants.sh -DFD_PIPE_FLAGSYNC=1): two-stage chains without inputs hand tiles over through per-group
     // LDS counters instead of a workgroup barrier per round, so that the four voice groups of a workgroup do not wait for
     // each other and a stage may run up to one tile ahead of its partner.
@@ -1456,7 +1560,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     using GL = typename LpOf<G>::type;
     bool lp = false;
     if constexpr (!SameType<GL, G>::v && MODE == MODE_PROCESS && FD_LP_ENABLE)
-        lp = __builtin_amdgcn_ballot_w64((live && active) && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(live && active) != 0ull;
+        lp = __builtin_amdgcn_ballot_w64(run && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(run) != 0ull;
 #if FD_PIPE_PRIO == 1 || FD_PIPE_PRIO == 4
     // The HEAVIEST stage's wave is the critical path of a voice group: its instruction stream is one dependent chain, so every
     // cycle it waits for the VALU behind a sibling's instruction is a cycle added to the round.  VALU arbitration on a SIMD
@@ -1480,6 +1584,16 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
         VGate::W<VStore<false>> gate{&st, true};
         if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
     }
+}
+
+// the pipeline kernel with the fused mix-down: part = [voice groups][mix channels][T] partial mixes, panw = [2][stride] (MIX_PAN)
+template <class G, int MODE, int S, int K1, int K2, int GPW, int MIX>
+__global__ __launch_bounds__((16 * GPW * PipeGeom<G::IN, S>::WAVES)) FD_PIPE_ATTR void k_render_pipe_mix(float* __restrict__ slots, size_t stride, size_t V,
+                                                                                          const float* __restrict__ in, float* __restrict__ part,
+                                                                                          size_t T, const void* aux, float* ring, uint32_t ring_cap,
+                                                                                          const float* __restrict__ panw) {
+    static_assert(MIX == MIX_SUM || (MIX == MIX_PAN && G::OUT == 1), "mix-down: sum of the outputs, or pan of a mono graph");
+    render_pipe_body<G, MODE, S, K1, K2, GPW, MIX>(slots, stride, V, in, part, T, aux, ring, ring_cap, panw);
 }
 
 template <class G, int MODE, int S, int K1, int K2, int GPW>
@@ -1738,8 +1852,8 @@ template <> struct Ts3Roles<2> {
     // SIMD 0: g0 A0, g0 B0, g0 A2, g1 B2   SIMD 1: g1 A0, g1 B0, g1 A2, g0 B2   SIMD 2: g0 C, g0 A1, g0 B1   SIMD 3: g1 C, g1 A1, g1 B1
 };
 
-template <class G, int GPW>
-FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T, const void* aux) {
+template <class G, int GPW, int MIX = MIX_NONE>
+FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T, const void* aux, const float* __restrict__ panw = nullptr) {
     using S0 = Seg<G, 0, 1>;
     using S1 = Seg<G, 1, 2>;
     using S2 = Seg<G, 2, 3>;
@@ -1756,7 +1870,15 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
     const size_t v0 = ((size_t)blockIdx.x * GPW + grp) * 64, v = v0 + lane;
     const bool live = v0 < stride, active = v < V;   // a whole group past the bank still takes part in the barriers
     const size_t nblocks = T / 64, rounds = nblocks + 2;
-    float* outw = out + v0;
+    // fused mix-down (see render_pipe_body): the filter wave parks its samples in the group's mix tile, `out` holds the partial mixes
+    constexpr int NM = MIX == MIX_PAN ? 2 : G::OUT;
+    using MG = MixGeom<NM, GPW, 64>;
+    constexpr int OLM = MIX == MIX_NONE ? 0 : (MIX == MIX_PAN ? 3 : 2), MCM = MIX == MIX_NONE ? 0 : MG::MC;
+    static_assert(MIX == MIX_NONE || MG::ok, "mix tile does not fit");
+    float* outw = MIX == MIX_NONE ? out + v0 : out + (v0 / 64) * (size_t)NM * T;
+    __shared__ __attribute__((aligned(16))) float mixt[MIX == MIX_NONE ? 1 : GPW][MIX == MIX_NONE ? 4 : MG::FLOATS];
+    MixLane mxl{&mixt[MIX == MIX_NONE ? 0 : grp][0], active ? lane : 64, 0.0f, 0.0f};
+    const bool run = live && (MIX != MIX_NONE || active);
     G g{};
     Ctx ctx{static_cast<const Aux*>(aux), nullptr, 0, stride, 0};
     g.bind(ctx);
@@ -1764,6 +1886,15 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
         VLoad ld{slots + v, stride, 0};
         VGate::W<VLoad> gate{&ld, true};
         if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
+    }
+    if constexpr (MIX != MIX_NONE) {
+        if (stage == 2) {
+            if (!active) {
+#pragma unroll 1
+                for (int r = 0; r < NM * MCM; r++) mxl.tile[r * MIX_ROW + lane] = 0.0f;
+            }
+            if (MIX == MIX_PAN && live && active) { mxl.wl = panw[v]; mxl.wr = panw[stride + v]; }
+        }
     }
     auto rounds_of = [&](auto* tag) {
         using GG = typename Pointee<decltype(tag)>::type;
@@ -1774,7 +1905,7 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
 #if FD_TS_STAGE_LOOPS   // a round loop per role (see render_pipe_body)
         auto loop = [&](auto&& block) {
             for (size_t it = 0; it < rounds; it++) {
-                if (live && active && it >= (size_t)stage && it - stage < nblocks && !(FD_KNOCK_TS == 1 && stage == 2) && !(FD_KNOCK_TS == 2 && stage < 2) &&
+                if (run && it >= (size_t)stage && it - stage < nblocks && !(FD_KNOCK_TS == 1 && stage == 2) && !(FD_KNOCK_TS == 2 && stage < 2) &&
                     !(FD_KNOCK_TS == 3 && stage != 0) && !(FD_KNOCK_TS == 4 && stage != 1))
                     block(it - stage);  // the block this stage works on in this round
                 __syncthreads();
@@ -1782,15 +1913,15 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
         };
         if (stage == 0) loop([&](size_t j) { ts_stage<T0, GG, true, W>(gg, R::cut[0][part], R::cut[0][part + 1], lane, nullptr, hand[grp][0][j & 1]); });
         else if (stage == 1) loop([&](size_t j) { ts_stage<T1, GG, false, W>(gg, R::cut[1][part], R::cut[1][part + 1], lane, hand[grp][0][j & 1], hand[grp][1][j & 1]); });
-        else loop([&](size_t j) { pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, 0, FD_PIPE_PREFETCH != 0>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr); });
+        else loop([&](size_t j) { pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, OLM, FD_PIPE_PREFETCH != 0, 0, MCM>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr, nullptr, &mxl); });
 #else
         for (size_t it = 0; it < rounds; it++) {
-            if (live && active && it >= (size_t)stage && it - stage < nblocks && !(FD_KNOCK_TS == 1 && stage == 2) && !(FD_KNOCK_TS == 2 && stage < 2) &&
+            if (run && it >= (size_t)stage && it - stage < nblocks && !(FD_KNOCK_TS == 1 && stage == 2) && !(FD_KNOCK_TS == 2 && stage < 2) &&
                 !(FD_KNOCK_TS == 3 && stage != 0) && !(FD_KNOCK_TS == 4 && stage != 1)) {
                 const size_t j = it - stage;  // the block this stage works on in this round
                 if (stage == 0) ts_stage<T0, GG, true, W>(gg, R::cut[0][part], R::cut[0][part + 1], lane, nullptr, hand[grp][0][j & 1]);
                 else if (stage == 1) ts_stage<T1, GG, false, W>(gg, R::cut[1][part], R::cut[1][part + 1], lane, hand[grp][0][j & 1], hand[grp][1][j & 1]);
-                else pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, 0, FD_PIPE_PREFETCH != 0>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr);
+                else pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, OLM, FD_PIPE_PREFETCH != 0, 0, MCM>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr, nullptr, &mxl);
             }
             __syncthreads();
         }
@@ -1799,7 +1930,7 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
     using GL = typename LpOf<G>::type;
     bool lp = false;
     if constexpr (!SameType<GL, G>::v && FD_LP_ENABLE)
-        lp = __builtin_amdgcn_ballot_w64((live && active) && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(live && active) != 0ull;
+        lp = __builtin_amdgcn_ballot_w64(run && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(run) != 0ull;
 #if FD_PIPE_PRIO
     if (stage == 2) __builtin_amdgcn_s_setprio(1);  // the serial filter wave is the round's critical path
 #endif
@@ -1815,6 +1946,13 @@ template <class G, int GPW>
 __global__ __launch_bounds__(64 * Ts3Roles<GPW>::WAVES) void k_render_ts3(float* __restrict__ slots, size_t stride, size_t V,
                                                                           float* __restrict__ out, size_t T, const void* aux) {
     if constexpr (TsPlan<G>::ok) render_ts3_body<G, GPW>(slots, stride, V, out, T, aux);
+}
+// ... with the fused mix-down (see k_render_pipe_mix)
+template <class G, int GPW, int MIX>
+__global__ __launch_bounds__(64 * Ts3Roles<GPW>::WAVES) void k_render_ts3_mix(float* __restrict__ slots, size_t stride, size_t V,
+                                                                              float* __restrict__ part, size_t T, const void* aux,
+                                                                              const float* __restrict__ panw) {
+    if constexpr (TsPlan<G>::ok) render_ts3_body<G, GPW, MIX>(slots, stride, V, part, T, aux, panw);
 }
 
 // ---- the pipeline kernel for the PLANAR layout ([voice][channel][frame_stride], the reference's BufferArray rows) ----

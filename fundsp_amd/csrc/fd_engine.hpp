@@ -61,6 +61,12 @@ struct KindOps {
     std::function<void(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
                        int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s)>
         render_fast;
+    // Render + mix-down in one launch (fd_device.hpp "fused mix-down"): part = device [voice groups][mix channels][T] partial
+    // mixes, mix = MIX_SUM / MIX_PAN, panw = device [2][stride] pan weights (MIX_PAN).  Voice-minor inputs.  false = this graph /
+    // launch has no fused kernel.  Empty for kinds built without one (attach_mix<G>).
+    std::function<bool(float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, int mix, int mode,
+                       const void* aux, float* ring, uint32_t ring_cap, const float* panw, hipStream_t s)>
+        render_mix, render_mix_fast;
     // Sequencer-style rendering (fd_device.hpp render_events_body): ev = device [4][stride] f64, fade = device [V] or null
     std::function<void(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, const double* ev,
                        const int* fade, double time0, double sr, int mode, const void* aux, float* ring,
@@ -223,6 +229,74 @@ void launch_render(float* slots, size_t stride, size_t V, const float* in, float
         else
             launch_render_cfg<G, MODE_TICK, LAYOUT_PLANAR>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s);
     }
+}
+
+// ---- render + mix-down in one launch ------------------------------------------------------------------------------
+template <class G, int MODE, int MIX>
+bool launch_render_pipe_mix(float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, const void* aux,
+                            float* ring, uint32_t ring_cap, const float* panw, hipStream_t s) {
+    constexpr PipePlan P = pipe_plan<G>(0);
+    if constexpr (P.S >= 1) {
+        constexpr int WAVES = PipeGeom<G::IN, P.S>::WAVES;  // for 4 voice groups
+        const size_t cus = (size_t)simd_count() / 4, groups = (V + 63) / 64;
+        // the same workgroup widths as launch_render_pipe: heavy graphs on small banks are spread over the CUs
+        if constexpr (Cost<G>::v >= 150) {
+            if (groups <= cus) {
+                hipLaunchKernelGGL((k_render_pipe_mix<G, MODE, P.S, P.K1, P.K2, 1, MIX>), dim3((unsigned)groups), dim3(16 * WAVES), 0, s, slots,
+                                   stride, V, in, part, T, aux, ring, ring_cap, panw);
+                return true;
+            }
+            if (groups <= 2 * cus) {
+                hipLaunchKernelGGL((k_render_pipe_mix<G, MODE, P.S, P.K1, P.K2, 2, MIX>), dim3((unsigned)((groups + 1) / 2)), dim3(16 * 2 * WAVES), 0,
+                                   s, slots, stride, V, in, part, T, aux, ring, ring_cap, panw);
+                return true;
+            }
+        }
+        hipLaunchKernelGGL((k_render_pipe_mix<G, MODE, P.S, P.K1, P.K2, 4, MIX>), dim3((unsigned)((groups + 3) / 4)), dim3(16 * 4 * WAVES), 0, s,
+                           slots, stride, V, in, part, T, aux, ring, ring_cap, panw);
+        return true;
+    } else {
+        return false;
+    }
+}
+template <class G, int MIX>
+bool launch_render_mix_m(float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, int mode, const void* aux,
+                         float* ring, uint32_t ring_cap, const float* panw, hipStream_t s) {
+    if constexpr (TsPlan<G>::ok) {  // small banks of oscillator chains: the three-way time split, as in launch_render
+        const size_t groups = (V + 63) / 64, cus = (size_t)simd_count() / 4;
+        if (tl_opts.time_split == 1 && tl_opts.pipe_split == 1 && mode == MODE_PROCESS && T % 64 == 0 && T >= 256 && groups <= 2 * cus) {
+            if (groups <= cus)
+                hipLaunchKernelGGL((k_render_ts3_mix<G, 1, MIX>), dim3((unsigned)groups), dim3(64 * Ts3Roles<1>::WAVES), 0, s, slots, stride, V, part, T, aux, panw);
+            else
+                hipLaunchKernelGGL((k_render_ts3_mix<G, 2, MIX>), dim3((unsigned)((groups + 1) / 2)), dim3(64 * Ts3Roles<2>::WAVES), 0, s, slots, stride, V, part, T, aux, panw);
+            tl_opts.last_kernel = LK_TIME_SPLIT;
+            return true;
+        }
+    }
+    const bool done = mode == MODE_PROCESS ? launch_render_pipe_mix<G, MODE_PROCESS, MIX>(slots, stride, V, in, part, T, aux, ring, ring_cap, panw, s)
+                                           : launch_render_pipe_mix<G, MODE_TICK, MIX>(slots, stride, V, in, part, T, aux, ring, ring_cap, panw, s);
+    if (done) tl_opts.last_kernel = LK_PIPELINE;
+    return done;
+}
+template <class G>
+bool launch_render_mix(float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, int mix, int mode,
+                       const void* aux, float* ring, uint32_t ring_cap, const float* panw, hipStream_t s) {
+    if (V == 0 || T == 0) return true;
+    if (mix == MIX_PAN) {
+        if constexpr (G::OUT == 1) return launch_render_mix_m<G, MIX_PAN>(slots, stride, V, in, part, T, mode, aux, ring, ring_cap, panw, s);
+        else return false;
+    }
+    return launch_render_mix_m<G, MIX_SUM>(slots, stride, V, in, part, T, mode, aux, ring, ring_cap, panw, s);
+}
+// gives a kind its fused mix-down kernels (opt-in per kind: every instantiation is compile time and code size)
+template <class G>
+void attach_mix(std::vector<KindOps>& kinds, const char* name) {
+    for (KindOps& k : kinds)
+        if (k.name == name) {
+            k.render_mix = &launch_render_mix<G>;
+            using GF = typename FastOf<G>::type;
+            if constexpr (!SameType<GF, G>::v) k.render_mix_fast = &launch_render_mix<GF>;
+        }
 }
 
 template <class G>

@@ -1,28 +1,9 @@
 // fd_kinds_graph.hip -- fused voice graphs of the BASELINE configs.  The types spell out exactly what the
 // reference's operator overloads build (combinator.rs:289-488; Rust precedence `*` > `+` > `>>`).
 // (sine_hz, sine_hz_lowpass_hz and fm_svf -- configs 1 and 3 -- are in fd_kinds_fm.hip.)
-#include "fd_engine.hpp"
+#include "fd_kinds_graph.hpp"
 
 namespace fd {
-// sine_hz(f) = constant(f) >> sine()                       prelude.rs:349
-using SineHz = Pipe<Constant<1>, Sine>;
-// config 2 voice: noise() >> biquad(..) -- arithmetic of one BiquadBank<f32x8> lane fed by white noise
-using NoiseBiquad = Pipe<Noise, Biquad>;
-// the FM pair of config 3 (README.md:98-103), here for the oversample / resample kinds below
-using FmMod = Unop<Unop<Unop<SineHz, UMulScalar>, UMulScalar>, UAddScalar>;
-
-// config 4 voice: ((dc(f) >> saw() | dc(fc) | dc(q)) >> moog()) * adsr_live(a, d, s, r) >> pan(p)
-// (`|` binds loosest, `*` tightest: combinator.rs; moog() is the 3-input variant prelude.rs:551; the gate is the
-// graph's one input, feeding adsr_live -- Binop inputs = X inputs (0) + Y inputs (1), audionode.rs:912)
-using SawMoog = Pipe<Stack<Stack<Pipe<Constant<1>, WaveSynth<0>>, Constant<1>>, Constant<1>>, Moog<3>>;
-using SawMoogAdsrPan = Pipe<Binop<OpMul, SawMoog, AdsrLive>, Panner>;
-// Build-time pins of the config-4 stage plan (fd_device.hpp): three compute stages cut behind the oscillator stack and behind the ladder;
-// the stack's two trailing Constants stay out of the first hand-over (ConstTail), which leaves ONE channel per cut and, for two voice
-// groups per workgroup, 32-frame tiles; with a gate input that makes four roles, i.e. a round loop per role.
-static_assert(pipe_plan<SawMoogAdsrPan>(0).S == 3 && pipe_plan<SawMoogAdsrPan>(0).K1 == 1 && pipe_plan<SawMoogAdsrPan>(0).K2 == 2, "config 4: [saw stack] [moog] [* adsr >> pan]");
-static_assert(PipeTiles<SawMoogAdsrPan, 3, 1, 2, 2>::S0::OUT == (FD_PIPE_ELIDE ? 1 : 3) && PipeTiles<SawMoogAdsrPan, 3, 1, 2, 2>::S1::IN == (FD_PIPE_ELIDE ? 1 : 3), "config 4: the first cut carries the oscillator only");
-static_assert(PipeTiles<SawMoogAdsrPan, 3, 1, 2, 2>::SUB == (FD_PIPE_ELIDE ? 32 : 16) && PipeTiles<SawMoogAdsrPan, 3, 1, 2, 4>::SUB == (FD_PIPE_ELIDE ? 16 : 8), "config 4: tile lengths");
-
 // filter chains with an audio input (exercise the loader wave together with 2 / 3 compute stages):
 //   lowpass_hz(fc, q) >> shape(..)   and   lowpass_hz(fc, q) >> shape(..) >> highpass_hz(fc2, q2)
 using SvfShape = Pipe<FixedSvf, Shaper>;
@@ -36,6 +17,8 @@ using OversampleShape = Oversampler<Shaper>;
 using ResampleFm = Resample<Pipe<FmMod, Sine>>;
 
 void register_fm_kinds(std::vector<KindOps>& out);  // fd_kinds_fm.hip
+void attach_fm_mix(std::vector<KindOps>& out);      // fd_kinds_fm_mix.hip
+void attach_graph_mix(std::vector<KindOps>& out);   // fd_kinds_graph_mix.hip
 
 void register_graph_kinds(std::vector<KindOps>& out) {
     register_fm_kinds(out);
@@ -46,5 +29,8 @@ void register_graph_kinds(std::vector<KindOps>& out) {
     out.push_back(make_kind<ResampleFm>("resample_fm"));
     out.push_back(make_kind<SvfShape>("svf_shape"));
     out.push_back(make_kind<SvfShapeSvf>("svf_shape_svf"));
+    // render + mix-down in one launch for the kinds of the BASELINE configs
+    attach_fm_mix(out);
+    attach_graph_mix(out);
 }
 }  // namespace fd

@@ -46,6 +46,7 @@ extern "C" {
 #define FDSP_EINVAL (-1)   /* bad argument (unknown kind / parameter name / range / layout) */
 #define FDSP_ENOMEM (-2)   /* device allocation failed */
 #define FDSP_EDEVICE (-3)  /* HIP runtime error or no gfx950 device */
+#define FDSP_ENOTSUP (-4)  /* the request is valid but this kind / bank has no kernel for it (the message says what to call instead) */
 
 #define FDSP_LAYOUT_VOICE_MINOR 0
 #define FDSP_LAYOUT_PLANAR 1
@@ -272,14 +273,43 @@ int fdsp_bank_process_events(fdsp_bank* bank, size_t frames, const float* d_in, 
 int fdsp_bank_events_rewind(fdsp_bank* bank, double time); /* set the sequencer clock (Sequencer::reset -> 0.0) */
 double fdsp_bank_events_time(const fdsp_bank* bank);       /* Sequencer::time() */
 
-/* ---- on-device stereo mix-down of voice-minor output (per-GPU partial of the multi-GPU mix) ----
+/* ---- the stereo mix-down, per GPU (SURVEY 8d "mode B", 8e "per-GPU on-device tree-sum") ------------------------------
+ * What the reference computes for a bank of voices feeding one output: `voice >> pan(p)` per voice (Panner::process,
+ * src/pan.rs:50-76, weights src/pan.rs:13-17), then the sum over the voices (Reduce / Net mixing, src/audionode.rs:2406-2462).
+ * SUMMATION ORDER -- fixed, independent of the launch geometry, the same for every function of this section:
+ *     partial(group of 64 consecutive voices) = (S0 + S1) + (S2 + S3),
+ *         Sq = ((x[16q] + x[16q+1]) + x[16q+2]) + ... + x[16q+15]     (voices past the end of the bank count as +0.0)
+ *     mix = the groups' partials added in an aligned binary tree: level by level node(2k) + node(2k+1), a node without a
+ *         right sibling passes through unchanged.
+ * So a fused mix equals fdsp_sum_voices / fdsp_mix_stereo of the voice-out render bit for bit, and both are within
+ * sqrt(voices) * 6e-8 * max|x| of a serial mix (tests/test_gpu_mix.py).
+ *
+ * fdsp_bank_process_mix: render `frames` samples of every voice AND reduce them over the voices in the same launch -- the
+ * per-voice output never exists in HBM (a voice group's last stage parks MC frames in LDS, transposes and writes one float per
+ * channel and frame; a second, tiny launch adds the groups' partials).  d_in: voice-minor [inputs][frames][voices] or NULL.
+ *   mix = FDSP_MIX_SUM: d_mix [outputs][frames] = sum over the voices of every output channel (graphs that end in a Panner:
+ *         BASELINE config 4; the Sequencer's mix of its events);
+ *   mix = FDSP_MIX_PAN: mono graphs; every voice is panned with its own position (fdsp_bank_set_pan, -1 .. 1, default 0 =
+ *         centre) exactly like Panner::tick does (`weight * sample`), d_mix = [2][frames].
+ * The bank owns the partial-mix buffer ([voice groups][channels][frames] f32, 1/64 of a voice-out render); it grows on demand,
+ * fdsp_bank_mix_reserve(bank, frames) sizes it ahead of a real-time loop or a stream capture (AudioNode::allocate semantics).
+ * Stream, ordering, timing and capture rules are those of fdsp_bank_process.  FDSP_ENOTSUP: the kind was built without the
+ * fused kernels (the BASELINE kinds fm_svf, sine_hz_lowpass_hz, saw_moog_adsr_pan, noise_biquad have them) -- render
+ * voice-out and call the functions below, which use the same order. */
+#define FDSP_MIX_SUM 1
+#define FDSP_MIX_PAN 2
+int fdsp_bank_process_mix(fdsp_bank* bank, size_t frames, const float* d_in, float* d_mix, int mix, int mode, void* stream);
+int fdsp_bank_set_pan(fdsp_bank* bank, const float* h_pan, size_t first, size_t count);
+int fdsp_bank_mix_reserve(fdsp_bank* bank, size_t frames);
+
+/* The same mix-down of a voice-out render that already sits in HBM.
  * d_voices: [frames][voices] mono voice outputs; d_pan: [voices] pan position in -1..1 or NULL (centre);
- * d_mix: [2][frames].  Equal-power pan weights follow Panner (src/pan.rs:13-17). Deterministic summation order. */
+ * d_mix: [2][frames].  Equal-power pan weights follow Panner (src/pan.rs:13-17). */
 int fdsp_mix_stereo(const float* d_voices, const float* d_pan, float* d_mix, size_t frames, size_t voices,
                     void* stream);
 
 /* Sum over voices of a voice-minor buffer d_in [channels][frames][voices] -> d_out [channels][frames] (per-GPU partial
- * of the mix-down for graphs that already end in a Panner). Deterministic order, same as fdsp_mix_stereo. */
+ * of the mix-down for graphs that already end in a Panner). */
 int fdsp_sum_voices(const float* d_in, float* d_out, size_t channels, size_t frames, size_t voices, void* stream);
 
 /* ---- the exchange step across GPUs: all-reduce(sum) of the per-GPU partial mixes over RCCL / xGMI ----

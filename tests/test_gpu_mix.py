@@ -1,0 +1,180 @@
+"""The fused mix-down (fdsp_bank_process_mix, SURVEY.md 8(d) "mode B" / 8(e) "per-GPU on-device tree-sum"): the render kernels
+reduce over the voices themselves -- the per-voice output never exists in HBM.  Reference shape: `voice >> pan(p)` per voice
+(src/pan.rs:50-76) and the sum over voices (src/audionode.rs:2406-2462).
+
+Bar: the fused mix equals fdsp_sum_voices / fdsp_mix_stereo of the VOICE-OUT render BIT FOR BIT (same fixed order), equals the
+order's numpy statement applied to the oracle-checked voice-out samples, and is within sqrt(V) * 6e-8 * max|x| (+ 2 ulp of the mix) of
+a serial f64 mix of the oracle's voices (the tolerance SURVEY 8(e) states for a re-ordered f32 sum)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from fundsp_amd import LAYOUT_VOICE_MINOR, MIX_PAN, MIX_SUM, MODE_PROCESS, MODE_TICK
+from fundsp_amd import workloads as W
+from test_gpu_parity import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+
+
+@pytest.fixture(scope="module")
+def tables(gpu):
+    gpu.wavetable_build("saw")
+    return True
+
+
+def serial_tolerance(voices_out, mix):
+    """a re-ordered f32 sum of V terms against the serial mix: sqrt(V) * 6e-8 * max|x| -- plus two ulp of the largest
+    mix value: the f32 RESULT cannot sit closer than half an ulp to the f64 mix, whatever the order (the first GPU run measured
+    2.79e-6 against sqrt(200) * 6e-8 * 3.23 = 2.74e-6 on sums of magnitude 12, whose ulp is 9.5e-7)."""
+    return np.sqrt(voices_out.shape[-1]) * 6e-8 * np.abs(voices_out).max() + 2.0 ** -22 * np.abs(mix).max()
+
+
+def fm_bank(gpu, V, voice0=0):
+    p = W.fm_svf_params(V, SR, voice0)
+    b = W.make_fm_svf_bank(V, SR, params=p)
+    pan = (-1.0 + 2.0 * W.rnd1(np.arange(voice0, voice0 + V, dtype=np.uint64) + np.uint64(777))).astype(np.float32)
+    b.set_pan(pan)
+    return b, p, pan
+
+
+def test_summation_order_statement():
+    """mix_order_reference against a literal, loop-by-loop reading of include/fundsp_hip.h on a small ragged case."""
+    from fundsp_amd import mix_order_reference
+    rng = np.random.default_rng(1)
+    for V in (1, 15, 64, 65, 200, 64 * 5, 64 * 6 + 3):
+        x = (rng.random(V, dtype=np.float32) - 0.5).astype(np.float32)
+        G = (V + 63) // 64
+        xp = np.zeros(G * 64, dtype=np.float32)
+        xp[:V] = x
+        parts = []
+        for g in range(G):
+            S = []
+            for q in range(4):
+                s = xp[g * 64 + q * 16]
+                for j in range(1, 16):
+                    s = np.float32(s + xp[g * 64 + q * 16 + j])
+                S.append(s)
+            parts.append(np.float32(np.float32(S[0] + S[1]) + np.float32(S[2] + S[3])))
+        while len(parts) > 1:
+            nxt = [np.float32(parts[i] + parts[i + 1]) for i in range(0, len(parts) - 1, 2)]
+            if len(parts) & 1:
+                nxt.append(parts[-1])
+            parts = nxt
+        assert np.float32(mix_order_reference(x)).view(np.uint32) == np.float32(parts[0]).view(np.uint32), V
+
+
+@pytest.mark.parametrize("V,T", [(200, 64 * 5 + 13), (64 * 7, 64 * 4), (8192, 64 * 6), (32768, 64 * 4 + 9)])
+@pytest.mark.parametrize("mode", [MODE_PROCESS, MODE_TICK])
+def test_fm_pan_mix_equals_mix_of_voice_out(gpu, V, T, mode):
+    """Config-3 voices, MIX_PAN: fused == fdsp_mix_stereo(voice-out) == the order's numpy statement, bit for bit; a ragged last
+    voice group (200), the time-split kernels (8 192: one group per CU, T % 64 == 0; 32 768 with a ragged T: the pipeline)."""
+    import torch
+
+    if mode == MODE_TICK and V > 8192:
+        pytest.skip("tick mode: the small cases cover it")
+    b, p, pan = fm_bank(gpu, V)
+    ref = b.clone()
+    mix = b.process_mix(T, mix=MIX_PAN, mode=mode).cpu().numpy()
+    out = ref.process(T, layout=LAYOUT_VOICE_MINOR, mode=mode)            # [1][T][V]
+    unfused = gpu.mix_stereo(out[0], torch.from_numpy(pan).cuda()).cpu().numpy()
+    assert_bit_equal(mix, unfused, f"fused vs mix_stereo(voice-out), V={V}")
+    x = out[0].cpu().numpy()
+    ang = (np.clip(pan, -1, 1).astype(np.float32) + np.float32(1)) * (np.float32(np.pi) * np.float32(0.25))
+    wl = np.array([O.lib().o_math_cosf(float(a)) for a in ang], dtype=np.float32)
+    wr = np.array([O.lib().o_math_sinf(float(a)) for a in ang], dtype=np.float32)
+    assert_bit_equal(mix[0], gpu.mix_order_reference(x * wl[None, :]), "left vs the order's statement")
+    assert_bit_equal(mix[1], gpu.mix_order_reference(x * wr[None, :]), "right vs the order's statement")
+    # the voices' state after a fused launch is the state after a voice-out launch
+    assert_bit_equal(b.get_state(), ref.get_state(), "state after the launch")
+    assert np.abs(mix).max() > 0.1
+
+
+def test_fm_mix_against_the_oracles_serial_mix(gpu):
+    """Voices from the CPU oracle, panned and added one after the other in f64: the fused f32 mix is within the stated bound."""
+    V, T = 200, 64 * 3 + 5
+    b, p, pan = fm_bank(gpu, V)
+    mix = b.process_mix(T, mix=MIX_PAN).cpu().numpy()
+    want, _ = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], T, SR, True, 1, 4)   # [T][V]
+    ang = (np.clip(pan, -1, 1).astype(np.float32) + np.float32(1)) * (np.float32(np.pi) * np.float32(0.25))
+    wl = np.array([O.lib().o_math_cosf(float(a)) for a in ang], dtype=np.float32)
+    wr = np.array([O.lib().o_math_sinf(float(a)) for a in ang], dtype=np.float32)
+    serial = np.stack([(want * wl[None, :]).astype(np.float64).sum(axis=1), (want * wr[None, :]).astype(np.float64).sum(axis=1)])
+    assert np.abs(mix - serial).max() <= serial_tolerance(want, serial)
+    # ... and exactly the order's statement applied to the oracle's own samples (the voices are bit-exact)
+    assert_bit_equal(mix[0], gpu.mix_order_reference(want * wl[None, :]), "left vs oracle voices in the stated order")
+
+
+def test_fm_sum_mix_mono(gpu):
+    """MIX_SUM of a mono graph: [1][T] = fdsp_sum_voices of the voice-out render (the Sequencer's mix of its events)."""
+    V, T = 64 * 9 + 11, 64 * 5
+    b, p, _ = fm_bank(gpu, V)
+    ref = b.clone()
+    mix = b.process_mix(T, mix=MIX_SUM)
+    out = ref.process(T)
+    assert mix.shape == (1, T)
+    assert_bit_equal(mix.cpu().numpy(), gpu.sum_voices(out).cpu().numpy(), "sum mix vs sum_voices(voice-out)")
+
+
+@pytest.mark.parametrize("V,T", [(130, 64 * 30 + 7), (64 * 300 + 5, 64 * 6), (32768, 64 * 5)])
+def test_config4_mix_equals_sum_of_voice_out(gpu, tables, V, T):
+    """BASELINE config 4 (`... >> pan(p)` per voice, "RCCL stereo mix-down"): MIX_SUM of the two output channels.  One group per
+    workgroup (130 voices), two (19 205: ragged, odd group count), and the per-GPU shard of the config (32 768: two per workgroup)."""
+    import torch
+
+    adsr = (0.005, 0.01, 0.6, 0.01)
+    p = W.saw_moog_params(V, SR)
+    b = W.make_saw_moog_bank(V, SR, params=p, adsr=adsr)
+    ref = b.clone()
+    gate = torch.from_numpy(np.broadcast_to(W.gate_signal(T, SR, on_frame=1, off_seconds=1200 / SR)[None, :, None], (1, T, V)).copy()).cuda()
+    mix = b.process_mix(T, gate, mix=MIX_SUM)
+    out = ref.process(T, gate)                                             # [2][T][V]
+    assert mix.shape == (2, T)
+    assert_bit_equal(mix.cpu().numpy(), gpu.sum_voices(out).cpu().numpy(), f"fused vs sum_voices(voice-out), V={V}")
+    assert_bit_equal(mix.cpu().numpy(), gpu.mix_order_reference(out.cpu().numpy()), "vs the order's statement")
+    assert_bit_equal(b.get_state(), ref.get_state(), "state after the launch")
+    assert np.abs(mix.cpu().numpy()).max() > 0.05
+    with pytest.raises(gpu.FdspError):
+        b.process_mix(T, gate, mix=MIX_PAN)                                # a stereo graph is not panned again
+
+
+def test_config4_mix_small_against_oracle_voices(gpu, tables):
+    from test_gpu_config4 import config4_oracle_voice
+    from test_gpu_parity import oracle_render
+
+    V, T = 70, 64 * 20 + 3
+    adsr = (0.005, 0.01, 0.6, 0.01)
+    p = W.saw_moog_params(V, SR)
+    b = W.make_saw_moog_bank(V, SR, params=p, adsr=adsr)
+    import torch
+    g1 = W.gate_signal(T, SR, on_frame=1, off_seconds=900 / SR)
+    gate = torch.from_numpy(np.broadcast_to(g1[None, :, None], (1, T, V)).copy()).cuda()
+    mix = b.process_mix(T, gate, mix=MIX_SUM).cpu().numpy()
+    voices = np.stack([oracle_render(config4_oracle_voice(p, v, adsr), g1[None, :], T, MODE_PROCESS) for v in range(V)], axis=-1)  # [2][T][V]
+    assert_bit_equal(mix, gpu.mix_order_reference(voices), "fused mix vs the oracle's voices in the stated order")
+    assert np.abs(mix - voices.astype(np.float64).sum(axis=-1)).max() <= serial_tolerance(voices, mix)
+
+
+def test_chunked_mix_equals_whole_and_reserve(gpu):
+    """A launch of 64 * 6 frames == six launches of 64 (T < 256 goes through the pipeline kernel in a mix launch as well);
+    fdsp_bank_mix_reserve sizes the partial buffer ahead; kinds without the fused kernels say so."""
+    V = 64 * 3 + 7
+    b, p, _ = fm_bank(gpu, V)
+    c = b.clone()
+    c.mix_reserve(64)
+    whole = b.process_mix(64 * 6, mix=MIX_PAN).cpu().numpy()
+    parts = [c.process_mix(64, mix=MIX_PAN).cpu().numpy() for _ in range(6)]
+    assert_bit_equal(whole, np.concatenate(parts, axis=1), "chunked == whole")
+    lone = gpu.Bank("sine", 64)
+    with pytest.raises(gpu.FdspError) as e:
+        lone.process_mix(64, mix=MIX_SUM)
+    assert e.value.code == -4 and "fdsp_sum_voices" in str(e.value)
+
+
+def test_noise_biquad_sum_mix(gpu):
+    V, T = 1024, 64 * 8 + 3
+    b = W.make_noise_biquad_bank(V, SR)
+    ref = b.clone()
+    mix = b.process_mix(T, mix=MIX_SUM).cpu().numpy()
+    out = ref.process(T)
+    assert_bit_equal(mix, gpu.sum_voices(out).cpu().numpy(), "config-2 voices: fused sum vs sum_voices(voice-out)")

@@ -412,16 +412,9 @@ def test_mix_stereo(gpu):
     ang = (np.clip(pan, -1, 1).astype(np.float32) + np.float32(1)) * (np.float32(np.pi) * np.float32(0.25))
     wl = np.array([O.lib().o_math_cosf(float(a)) for a in ang], dtype=np.float32)
     wr = np.array([O.lib().o_math_sinf(float(a)) for a in ang], dtype=np.float32)
-    # same fixed summation order as the kernel: 256 strided partial sums, then a binary tree
+    # the mix-down's fixed summation order (include/fundsp_hip.h): weights first, like Panner::tick
     def tree(w):
-        part = np.zeros((T, 256), dtype=np.float32)
-        for v in range(V):
-            part[:, v % 256] = part[:, v % 256] + x[:, v] * w[v]
-        h = 128
-        while h > 0:
-            part[:, :h] = part[:, :h] + part[:, h:2 * h]
-            h //= 2
-        return part[:, 0]
+        return gpu.mix_order_reference(x * w[None, :])
     assert_bit_equal(mix[0], tree(wl), "mix L")
     assert_bit_equal(mix[1], tree(wr), "mix R")
 
