@@ -640,12 +640,13 @@ int fdsp_kind_by_name(const char* name) {
 
 namespace {
 // the launch options by name: range check shared by the process-wide and the per-bank setter
-struct OptSpec { const char* name; int lo, hi; const char* what; };
+// ... each entry names its process-wide default and its per-bank override itself: the setters and the getter index by the table
+struct OptSpec { const char* name; int lo, hi; const char* what; std::atomic<int>* global; int fdsp_bank::* field; };
 const OptSpec LAUNCH_OPTS[] = {
-    {"pipe_split", 0, 4, "pipe_split takes 0 (off), 1 (auto), 2 or 3 (stages), 4 (loader only)"},
-    {"time_split", 0, 2, "time_split takes 0 (off), 1 (small banks of eligible graphs: 3 + 3 + 1 waves per group) or 2 (round 2's 2 + 2 + 1 / 2 + 1 + 1 layouts)"},
-    {"fdn_kernel", 0, 1, "fdn_kernel takes 0 (lane per frame) or 1 (lane per delay line)"},
-    {"timing", 0, 1, "timing takes 0 (no per-launch event pair) or 1 (fdsp_bank_last_kernel_ms available)"},
+    {"pipe_split", 0, 4, "pipe_split takes 0 (off), 1 (auto), 2 or 3 (stages), 4 (loader only)", &fd::g_pipe_split, &fdsp_bank::opt_pipe_split},
+    {"time_split", 0, 2, "time_split takes 0 (off), 1 (small banks of eligible graphs: 3 + 3 + 1 waves per group) or 2 (round 2's 2 + 2 + 1 / 2 + 1 + 1 layouts)", &fd::g_time_split, &fdsp_bank::opt_time_split},
+    {"fdn_kernel", 0, 1, "fdn_kernel takes 0 (lane per frame) or 1 (lane per delay line)", &fd::g_fdn_kernel, &fdsp_bank::opt_fdn_kernel},
+    {"timing", 0, 1, "timing takes 0 (no per-launch event pair) or 1 (fdsp_bank_last_kernel_ms available)", &fd::g_timing, &fdsp_bank::opt_timing},
 };
 const OptSpec* launch_opt(const char* name) {
     if (!name) return nullptr;
@@ -667,8 +668,7 @@ bool timing_on(const fdsp_bank* b) { return (b->opt_timing >= 0 ? b->opt_timing 
 int fdsp_set_option(const char* name, int value) {
     if (const OptSpec* o = launch_opt(name)) {
         if (value < o->lo || value > o->hi) return fail(FDSP_EINVAL, o->what);
-        (o->name[0] == 'p' ? fd::g_pipe_split : o->name[1] == 'i' && o->name[2] == 'm' && o->name[3] == 'e' ? fd::g_time_split
-         : o->name[0] == 'f' ? fd::g_fdn_kernel : fd::g_timing).store(value);
+        o->global->store(value);
         return FDSP_OK;
     }
     if (name && std::strcmp(name, "host_zero_copy_max") == 0) {
@@ -693,8 +693,7 @@ int fdsp_bank_set_option(fdsp_bank* b, const char* name, int value) {
     }
     if (const OptSpec* o = launch_opt(name)) {  // -1 = back to the process-wide default
         if (value != -1 && (value < o->lo || value > o->hi)) return fail(FDSP_EINVAL, std::string(o->what) + "; -1 = follow the process-wide default");
-        (o->name[0] == 'p' ? b->opt_pipe_split : o->name[1] == 'i' && o->name[2] == 'm' && o->name[3] == 'e' ? b->opt_time_split
-         : o->name[0] == 'f' ? b->opt_fdn_kernel : b->opt_timing) = value;
+        b->*(o->field) = value;
         return FDSP_OK;
     }
     return fail(FDSP_EINVAL, "unknown bank option");
@@ -703,10 +702,8 @@ int fdsp_bank_get_option(const fdsp_bank* b, const char* name) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
     if (name && std::strcmp(name, "math") == 0) return b->math;
     if (name && std::strcmp(name, "math_has_fast_variant") == 0) return (b->ops && b->ops->render_fast) ? 1 : 0;
-    if (name && std::strcmp(name, "pipe_split") == 0) return b->opt_pipe_split >= 0 ? b->opt_pipe_split : fd::g_pipe_split.load();
-    if (name && std::strcmp(name, "time_split") == 0) return b->opt_time_split >= 0 ? b->opt_time_split : fd::g_time_split.load();
-    if (name && std::strcmp(name, "fdn_kernel") == 0) return b->opt_fdn_kernel >= 0 ? b->opt_fdn_kernel : fd::g_fdn_kernel.load();
-    if (name && std::strcmp(name, "timing") == 0) return timing_on(b) ? 1 : 0;
+    if (const OptSpec* o = launch_opt(name)) return b->*(o->field) >= 0 ? b->*(o->field) : o->global->load();
+    if (name && std::strcmp(name, "has_fused_mix") == 0) return (b->ops && b->ops->render_mix) ? 1 : 0;
     if (name && std::strcmp(name, "last_kernel") == 0) return b->last_kernel;
     return fail(FDSP_EINVAL, "unknown bank option");
 }
@@ -1471,7 +1468,8 @@ int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, flo
     const bool capturing = cap != hipStreamCaptureStatusNone;
     if (int rc = check_ring_need(b, capturing)) return rc;
     if (b->ext_pending && !capturing) HIPCHK(hipStreamWaitEvent(s, b->e1, 0));
-    if (!capturing) HIPCHK(hipEventRecord(b->e0, s));
+    const bool timing = timing_on(b);  // the per-launch event pair is optional, as in fdsp_bank_process
+    if (!capturing && timing) HIPCHK(hipEventRecord(b->e0, s));
     // the clock after this launch, advanced exactly as the reference does: one f64 addition per block / per sample
     const double sd = 1.0 / b->sr, t_begin = b->seq_time;
     double t_end = t_begin;
@@ -1506,8 +1504,8 @@ int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, flo
     b->last_kernel = fd::tl_opts.last_kernel;
     HIPCHK(hipGetLastError());
     if (!capturing) {
-        HIPCHK(hipEventRecord(b->e1, s));
-        b->timed = true;
+        if (timing || s != b->stream) HIPCHK(hipEventRecord(b->e1, s));
+        b->timed = timing;
         b->ext_pending = s != b->stream;
     }
     b->seq_time = t_end;

@@ -11,7 +11,7 @@
 #include "fd_kinds_fm.hpp"
 
 namespace fd {
-// the three-way time-split kernels of these types are compiled in fd_kinds_fm_ts.hip (default scheduling strategy)
+// the three-way time-split kernels of these types are compiled in fd_kinds_fm_ts.hip (-amdgpu-sched-strategy=max-ilp, see the Makefile)
 #define FD_X(G, GPW) extern template __global__ void k_render_ts3<G, GPW>(float* __restrict__, size_t, size_t, float* __restrict__, size_t, const void*);
 FD_FM_TS3_KERNELS(FD_X)
 #undef FD_X

@@ -1,5 +1,5 @@
 // fd_kinds_fm.hpp -- the graph types of BASELINE configs 1 and 3, shared by fd_kinds_fm.hip (their kinds, built with the ILP
-// scheduling strategy) and fd_kinds_fm_ts.hip (their three-way time-split kernels, built with the default strategy: ROCm
+// scheduling strategy) and fd_kinds_fm_ts.hip (their three-way time-split kernels, built with -amdgpu-sched-strategy=max-ilp: ROCm
 // 7.2's clang crashes in the register allocator when it compiles k_render_ts3 under -amdgpu-sched-strategy=iterative-ilp).
 // The types spell out exactly what the reference's operator overloads build (combinator.rs:289-488; Rust precedence
 // `*` > `+` > `>>`).

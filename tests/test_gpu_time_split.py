@@ -79,6 +79,24 @@ def test_time_split_two_groups_per_cu_layout(gpu, time_split):
     assert_bit_equal(outs[1][pick], want, "time split vs oracle")
 
 
+def test_time_split_odd_group_count_leaves_a_dead_second_group(gpu, time_split):
+    """64 * 300 + 5 voices = 301 voice groups (> one per CU): the last 14-wave workgroup holds ONE live group; the waves of its second
+    group (v0 == stride: `live` false in render_ts3_body<G, 2>) load and store nothing and only take part in the barriers
+    (the 302-group case above never reached that branch)."""
+    V, T = 64 * 300 + 5, 64 * 5
+    p = W.fm_svf_params(V, SR)
+    outs = {}
+    for split in (1, 0):
+        time_split(split)
+        b = W.make_fm_svf_bank(V, SR, params=p)
+        outs[split] = run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :]
+        assert b.get_option("last_kernel") == (4 if split else 2)
+    assert_bit_equal(outs[1], outs[0], "3 + 3 + 1 time split == pipeline kernel, 301 voice groups")
+    pick = np.array([0, 64 * 299 + 63, 64 * 300, V - 1])
+    want, _ = O.bank_render(3, [p["f"][pick], p["m"][pick], p["fc"][pick], p["q"][pick]], p["seed"][pick], T, SR, True, 0, 4)
+    assert_bit_equal(outs[1][pick], want, "time split vs oracle, last workgroup")
+
+
 def test_time_split_rollback_path_and_negative_frequencies(gpu, time_split):
     """A modulator / carrier phase of exactly -0.0 at a block start sends that block down the packed path's rollback
     (Sine::begin_block), in the split waves too; huge modulation indices trip the |quadrant| < 8192 guard mid-block."""
