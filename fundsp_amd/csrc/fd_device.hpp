@@ -653,6 +653,15 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
 #ifndef FD_KNOCK_TS
 #define FD_KNOCK_TS 0   // measurement only: k_render_ts3 with 1 = the filter wave idle, 2 = only the filter wave, 3 = only stage 0, 4 = only stage 1
 #endif
+#ifndef FD_SPLIT_PAIR
+#define FD_SPLIT_PAIR 0   // A/B switch: which roles of a split-stage kernel share a SIMD (split_roles)
+#endif
+#ifndef FD_SPLIT_PRIO
+#define FD_SPLIT_PRIO 0   // A/B switch: 1 = in a split-stage kernel the last stage runs at s_setprio 2 and the second part of stage 0 at 1
+#endif
+#ifndef FD_STORE_WRAP
+#define FD_STORE_WRAP 0   // measurement only (NOT a renderer): 1 = voice-minor rows wrap into the first 64 frames of the output (L2-resident stores)
+#endif
 #ifndef FD_KNOCK
 #define FD_KNOCK 0      // measurement only (NOT a renderer): bit s set = compute stage s of the pipeline kernel idles, so the others
 #endif                  // run without it; the hand-over tiles start zeroed (profiles/r03_ab1_knockout_prio.txt, r03_knockout_c4.txt)
@@ -730,7 +739,7 @@ template <class T> struct HasSkip { static constexpr bool v = LeafHasSkip<T>::v;
 template <class X, class Y> struct HasSkip<Pipe<X, Y>> { static constexpr bool v = HasSkip<X>::v && HasSkip<Y>::v; };
 template <class X, class U> struct HasSkip<Unop<X, U>> { static constexpr bool v = HasSkip<X>::v; };
 template <class O, class X, class Y> struct HasSkip<Binop<O, X, Y>> { static constexpr bool v = false; };
-template <class X, class Y> struct HasSkip<Stack<X, Y>> { static constexpr bool v = false; };
+template <class X, class Y> struct HasSkip<Stack<X, Y>> { static constexpr bool v = HasSkip<X>::v && HasSkip<Y>::v; };
 
 // ConstTail<X>: the trailing output channels of a Stack that are plain Constant nodes -- `(x | dc(a) | dc(b))` ends in two.
 // Where a stage cut falls right behind such a Stack, those channels do not travel through the LDS hand-over tiles: the
@@ -876,7 +885,15 @@ struct Seg<Binop<O, X, Y>, A, B, true> {
     static constexpr int cost = (HX ? SX::cost : 0) + (TAIL ? Cost<Y>::v + 1 : 0);
     static constexpr int weight = (HX ? SX::weight : 0) + (TAIL ? Weight<Y>::v + 1 : 0);
     static constexpr bool USES_GIN = SPLIT && TAIL && Y::IN > 0;
-    static constexpr bool HAS_SKIP = false;  // a Binop segment has no skip2 (ts_stage never takes one)
+    static constexpr bool HAS_SKIP = SPLIT && !TAIL && SX::HAS_SKIP;  // stages of the generator operand forward; the tail stage has none
+    template <int PH> static FD_D void skip2(G& g, const v2f* in) {
+        static_assert(SPLIT && !TAIL, "skip is defined for the generator operand's stages");
+        SX::template skip2<PH>(g.x, in);
+    }
+    template <int PH> static FD_D void skip(G& g, const float* in) {
+        static_assert(SPLIT && !TAIL, "skip is defined for the generator operand's stages");
+        SX::template skip<PH>(g.x, in);
+    }
     template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f* gin, v2f* out) {
         if constexpr (!SPLIT) {
             g.template step2<PH>(in, out);
@@ -1083,9 +1100,13 @@ FD_D void mix_flush(const float* tile, float* dst, size_t T, int nf, int lane) {
 // its own priority for the item -- see render_pipe_body.
 // OL = 2 / 3 (fused mix-down, MIX_SUM / MIX_PAN): the samples go to the wave's mix tile `mx` and leave as the group's partial mix,
 // MC frames at a time (mix_flush); `outw` is then the group's partial row [channel][T] and EVERY lane of the wave runs the stage.
-template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST, int FS = 64, int OL = 0, bool PF = (FD_PIPE_PREFETCH != 0), int BAL = 0, int MC = 0>
+// NP > 1 (a FIRST stage run in NP waves, render_pipe_body NA): every wave walks the whole tile, wave `part` EVALUATES the SIMD
+// items of its NP-th of the tile and advances the state through the others (SG::skip2) -- as ts_stage does for 64-frame blocks;
+// the remainder samples of a ragged block are computed by every part (same values, same hand-over cells).
+template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST, int FS = 64, int OL = 0, bool PF = (FD_PIPE_PREFETCH != 0), int BAL = 0, int MC = 0, int NP = 1>
 FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_t V, int lane, float* outw,
-                     const float* fin, v2f (*hin)[SUB / 2][64], v2f (*hout)[SUB / 2][64], int* bal = nullptr, const MixLane* mx = nullptr) {
+                     const float* fin, v2f (*hin)[SUB / 2][64], v2f (*hout)[SUB / 2][64], int* bal = nullptr, const MixLane* mx = nullptr, int part = 0) {
+    static_assert(NP == 1 || (FIRST && !LAST && FD_ITEM_LOOP && BAL == 0 && (SUB / 8) % NP == 0), "split stages: the first of several, whole items per part");
     constexpr int NI = SG::IN, NO = SG::OUT, NG = G::IN;
     constexpr bool GIN = !FIRST && SG::USES_GIN;
     constexpr bool MIXO = OL >= 2;
@@ -1106,7 +1127,7 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
     if constexpr (OL == 0) {
 #pragma unroll
         for (int c = 0; c < NO; c++)
-            orow[c] = __builtin_amdgcn_make_buffer_rsrc(outw + ((size_t)c * T + t0 + lo) * V, 0, (int)0xffffffffu, 0x00020000);
+            orow[c] = __builtin_amdgcn_make_buffer_rsrc(outw + ((size_t)c * T + (FD_STORE_WRAP ? ((t0 + lo) & 63) : (t0 + lo))) * V, 0, (int)0xffffffffu, 0x00020000);
     }
     const int vrow = (int)(V * sizeof(float));
 #endif
@@ -1174,6 +1195,18 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
             }
         }
         item_begin(g);
+        if constexpr (NP > 1) {
+            if ((i8 - lo) / (SUB / NP) != part) {  // another wave's item (wave-uniform): the state advance alone
+#pragma unroll
+                for (int i = i8; i < i8 + 8; i += 2) {
+                    v2f pi[NI > 0 ? NI : 1];
+#pragma unroll
+                    for (int c = 0; c < NI; c++) pi[c] = v2f{fin[(c * SUB + (i - lo)) * FS + lane], fin[(c * SUB + (i - lo + 1)) * FS + lane]};
+                    SG::template skip2<PH_SIMD>(g, pi);
+                }
+                continue;
+            }
+        }
         const int nx = i8 + 8 < shi ? i8 + 8 : i8;  // the tile's last item re-reads itself (never used)
 #pragma unroll
         for (int i = i8; i < i8 + 8; i += 2) {  // ... two frames per inner iteration
@@ -1239,6 +1272,9 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
                 if constexpr (GIN) {
 #pragma unroll
                     for (int c = 0; c < NG; c++) gf[c] = fin[(c * SUB + (i - lo)) * FS + lane];
+                }
+                if constexpr (NP > 1) {
+                    if ((i - lo) / (SUB / NP) != part) { SG::template skip<PH_SIMD>(g, fi); continue; }
                 }
                 SG::template step<PH_SIMD>(g, fi, FIRST ? fi : gf, fo);
                 if constexpr (LAST) {
@@ -1330,7 +1366,40 @@ static_assert(role_order_is(role_order<true, 3, 100, 30, 83, 4>(), 0, 1, 2, 3), 
 // MIX != MIX_NONE (k_render_pipe_mix): `out` is the bank's partial-mix buffer [voice group][mix channel][T] and `panw` the pan
 // weights [2][stride] (MIX_PAN); every lane of a live voice group runs (the padded voices of the last group are constructed
 // voices with default parameters; their samples land in the tile's padding column).
-template <class G, int MODE, int S, int K1, int K2, int GPW = 4, int MIX = MIX_NONE>
+// NA > 1 (k_render_pipe_split): compute stage 0 runs in NA waves per voice group (pipe_stage NP): config 4's wavetable oscillator
+// -- a cheap phase recurrence under an expensive interpolation -- in two, so that the SIMD it shares with the envelope-and-pan stage
+// holds three half-busy waves instead of two busy ones (a wave issues at most one VALU instruction per ~4 cycles; the SIMD takes
+// one every 2-4), while the ladder keeps the other SIMD to itself.  Waves w, w + 4, w + 8 of a workgroup share a SIMD:
+struct SplitRoles { int grp[16], role[16]; };  // role: 0 = loader (graphs with inputs), then the NA parts of stage 0, then stages 1 ..
+template <bool FEED, int S, int NA, int GPW>
+constexpr SplitRoles split_roles() {
+    SplitRoles r{};
+    for (int w = 0; w < 16; w++) { r.grp[w] = w % GPW; r.role[w] = w / GPW; }
+    if (FEED && S == 3 && NA == 2 && GPW == 2) {
+#if FD_SPLIT_PAIR == 1   // A/B: SIMD 0 / 1: a group's ladder + second oscillator half + loader; SIMD 2 / 3: its first oscillator half + tail
+        const int g[10] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1}, ro[10] = {3, 3, 1, 1, 2, 2, 4, 4, 0, 0};
+#else
+        //   SIMD 0: group 0's oscillator halves + tail   SIMD 1: group 1's   SIMD 2: group 0's ladder + loader   SIMD 3: group 1's
+        const int g[10] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1}, ro[10] = {1, 1, 3, 3, 2, 2, 0, 0, 4, 4};
+#endif
+        for (int w = 0; w < 10; w++) { r.grp[w] = g[w]; r.role[w] = ro[w]; }
+    }
+    return r;
+}
+// which graphs / workgroup widths take the split (launch_render_pipe): measured on config 4's shape only.
+// MEASURED AND NOT KEPT (profiles/r04_ab_a_split.txt): bit-identical, but slower -- config 4, 32 768 voices: 9.42 ms unsplit, 10.34 split
+// with the two halves next to the tail on one SIMD, 10.17 with priorities for the tail and the second half, 9.70 with the halves on
+// different SIMDs; the oscillator stage ALONE takes 7.69 ms in one wave and 7.50 in two: whatever bounds it, it is not the issue rate
+// of its wave.  The build leaves the split kernels out (FD_STAGE_SPLIT=1 compiles them; "stage_split" then selects at run time).
+#ifndef FD_STAGE_SPLIT
+#define FD_STAGE_SPLIT 0
+#endif
+template <class G, int S, int K1, int K2, int GPW>
+struct SplitPlan {
+    static constexpr int NA = (FD_STAGE_SPLIT != 0 && S == 3 && G::IN > 0 && GPW == 2 && PipeTiles<G, S, K1, K2, GPW>::ok && PipeTiles<G, S, K1, K2, GPW>::S0::HAS_SKIP &&
+                               (PipeTiles<G, S, K1, K2, GPW>::SUB / 8) % 2 == 0 && PipeTiles<G, S, K1, K2, GPW>::S0::weight >= 60) ? 2 : 1;
+};
+template <class G, int MODE, int S, int K1, int K2, int GPW = 4, int MIX = MIX_NONE, int NA = 1>
 FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
                            float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap, const float* __restrict__ panw = nullptr) {
     using TL = PipeTiles<G, S, K1, K2, GPW>;
@@ -1350,7 +1419,13 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     // four roles, slots 0 and 2 of one with three.  The roles are dealt to the slots so that the heaviest SIMD is as
     // light as possible (config 4, exact: loader + moog | saw + tail; tolerance mode: loader + saw | moog + tail).
     constexpr RoleOrder RO = role_order<FEED, S, S0::weight, S1::weight, S2::weight, GPW>();
-    const int grp = w % GPW, role = RO.role[w / GPW];
+    constexpr SplitRoles SR = split_roles<FEED, S, NA, GPW>();
+    static_assert(NA == 1 || (S0::HAS_SKIP && S >= 2 && MODE == MODE_PROCESS && GPW * ((FEED ? 1 : 0) + NA + S - 1) <= 16), "split stage 0: needs skip2, a later stage, process mode");
+    // role: 0 = loader (graphs with inputs), then compute stage 0 (NA parts), then the later stages
+    const int grp = NA == 1 ? w % GPW : SR.grp[w];
+    const int crole = NA == 1 ? RO.role[w / GPW] : SR.role[w];                       // canonical role index
+    const int part = (NA > 1 && crole >= (FEED ? 1 : 0) && crole < (FEED ? 1 : 0) + NA) ? crole - (FEED ? 1 : 0) : 0;
+    const int role = NA == 1 ? crole : (crole < (FEED ? 1 : 0) + NA ? (crole < (FEED ? 1 : 0) ? 0 : (FEED ? 1 : 0)) : crole - (NA - 1));  // ... with the parts folded
     // (Half-filled waves -- 32 voices per wave, twice the waves -- were measured for the heavy config-4 voice: 33.7 ms
     // against 31.0 ms.  Its SIMDs are issue-bound on expensive instructions, not latency-bound; profiles/r02_c4_vpw.txt.)
     const size_t v0 = ((size_t)blockIdx.x * GPW + grp) * 64;
@@ -1467,7 +1542,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                         pipe_stage<TP0, GP, MODE, SUB, W, true, false>(reinterpret_cast<GP&>(gg), h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
                     }
 #else
-                    else pipe_stage<T0, GG, MODE, SUB, W, true, false, 64, 0, (FD_PIPE_PREFETCH != 0), BALK ? 1 : 0>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1], bal_word[grp]);
+                    else pipe_stage<T0, GG, MODE, SUB, W, true, false, 64, 0, (FD_PIPE_PREFETCH != 0), BALK ? 1 : 0, 0, NA>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1], bal_word[grp], nullptr, part);
 #endif
                 });
             } else if (stage == 1) {
@@ -1499,7 +1574,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                             pipe_stage<TP0, GP, MODE, SUB, W, true, false>(reinterpret_cast<GP&>(gg), h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
                         }
 #else
-                        else pipe_stage<T0, GG, MODE, SUB, W, true, false, 64, 0, (FD_PIPE_PREFETCH != 0), BALK ? 1 : 0>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1], bal_word[grp]);
+                        else pipe_stage<T0, GG, MODE, SUB, W, true, false, 64, 0, (FD_PIPE_PREFETCH != 0), BALK ? 1 : 0, 0, NA>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1], bal_word[grp], nullptr, part);
 #endif
                     } else if (stage == 1) {
                         if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, OLM, PFK, BALK ? 2 : 0, MCM>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp], &mxl);
@@ -1561,6 +1636,10 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     bool lp = false;
     if constexpr (!SameType<GL, G>::v && MODE == MODE_PROCESS && FD_LP_ENABLE)
         lp = __builtin_amdgcn_ballot_w64(run && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(run) != 0ull;
+#if FD_SPLIT_PRIO
+    if (NA > 1 && stage == S - 1) __builtin_amdgcn_s_setprio(2);
+    if (NA > 1 && stage == 0 && part == 1) __builtin_amdgcn_s_setprio(1);
+#endif
 #if FD_PIPE_PRIO == 1 || FD_PIPE_PRIO == 4
     // The HEAVIEST stage's wave is the critical path of a voice group: its instruction stream is one dependent chain, so every
     // cycle it waits for the VALU behind a sibling's instruction is a cycle added to the round.  VALU arbitration on a SIMD
@@ -1579,11 +1658,20 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     if (stage == 2) __builtin_amdgcn_s_setprio(2);
 #endif
     if (lp) rounds_of((GL*)nullptr); else rounds_of((G*)nullptr);
-    if (live && active) {
+    if (live && active && part == 0) {  // (the parts of a split stage end with identical state: one of them stores it)
         VStore<false> st{slots + v, stride, 0};
         VGate::W<VStore<false>> gate{&st, true};
         if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
     }
+}
+
+// the pipeline kernel with compute stage 0 in NA waves per voice group (SplitPlan), voice-out or with the fused mix-down
+template <class G, int MODE, int S, int K1, int K2, int GPW, int MIX, int NA>
+__global__ __launch_bounds__((64 * GPW * ((G::IN > 0 ? 1 : 0) + NA + S - 1))) FD_PIPE_ATTR void k_render_pipe_split(float* __restrict__ slots, size_t stride, size_t V,
+                                                                                          const float* __restrict__ in, float* __restrict__ out,
+                                                                                          size_t T, const void* aux, float* ring, uint32_t ring_cap,
+                                                                                          const float* __restrict__ panw) {
+    render_pipe_body<G, MODE, S, K1, K2, GPW, MIX, NA>(slots, stride, V, in, out, T, aux, ring, ring_cap, panw);
 }
 
 // the pipeline kernel with the fused mix-down: part = [voice groups][mix channels][T] partial mixes, panw = [2][stride] (MIX_PAN)

@@ -127,8 +127,18 @@ bool launch_render_pipe(float* slots, size_t stride, size_t V, const float* in, 
                                    stride, V, in, out, T, aux, ring, ring_cap);
                 done = true;
             } else if (!done && groups <= 2 * cus) {
-                hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 2>), dim3((unsigned)((groups + 1) / 2)), dim3(16 * 2 * WAVES), 0,
-                                   s, slots, stride, V, in, out, T, aux, ring, ring_cap);
+                constexpr int NA = SplitPlan<G, P.S, P.K1, P.K2, 2>::NA;  // compute stage 0 in NA waves (config 4: the oscillator in two)
+                bool split = false;
+                if constexpr (NA > 1 && MODE == MODE_PROCESS) {
+                    if (tl_opts.stage_split) {
+                        hipLaunchKernelGGL((k_render_pipe_split<G, MODE, P.S, P.K1, P.K2, 2, MIX_NONE, NA>), dim3((unsigned)((groups + 1) / 2)),
+                                           dim3(64 * 2 * (WAVES / 4 + NA - 1)), 0, s, slots, stride, V, in, out, T, aux, ring, ring_cap, (const float*)nullptr);
+                        split = true;
+                    }
+                }
+                if (!split)
+                    hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 2>), dim3((unsigned)((groups + 1) / 2)), dim3(16 * 2 * WAVES), 0,
+                                       s, slots, stride, V, in, out, T, aux, ring, ring_cap);
                 done = true;
             }
         }
@@ -247,6 +257,14 @@ bool launch_render_pipe_mix(float* slots, size_t stride, size_t V, const float* 
                 return true;
             }
             if (groups <= 2 * cus) {
+                constexpr int NA = SplitPlan<G, P.S, P.K1, P.K2, 2>::NA;
+                if constexpr (NA > 1 && MODE == MODE_PROCESS) {
+                    if (tl_opts.stage_split) {
+                        hipLaunchKernelGGL((k_render_pipe_split<G, MODE, P.S, P.K1, P.K2, 2, MIX, NA>), dim3((unsigned)((groups + 1) / 2)),
+                                           dim3(64 * 2 * (WAVES / 4 + NA - 1)), 0, s, slots, stride, V, in, part, T, aux, ring, ring_cap, panw);
+                        return true;
+                    }
+                }
                 hipLaunchKernelGGL((k_render_pipe_mix<G, MODE, P.S, P.K1, P.K2, 2, MIX>), dim3((unsigned)((groups + 1) / 2)), dim3(16 * 2 * WAVES), 0,
                                    s, slots, stride, V, in, part, T, aux, ring, ring_cap, panw);
                 return true;

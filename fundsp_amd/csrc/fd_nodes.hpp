@@ -1276,6 +1276,25 @@ struct WaveSynth {
             for (int c = 0; c < NOUT; c++) out[c] = v2f{o0[c], o1[c]};
         }
     }
+    // skip / skip2 (stages run in several waves, fd_device.hpp): everything step / step2 do to the STATE -- the table choice at the
+    // head of an item (it moves `hint`), the unwrapped phase accumulation of the process path -- without the table reads.  The taps
+    // gathered ahead belong to the pair after the last EVALUATED one: stale after a skip.
+    template <int PH> FD_HD void skip(const float* in) {
+        static_assert(PH == PH_SIMD, "WaveSynth::skip: packed part of a process block only");
+        if ((item_pos & 7) == 0) item_w = select(__builtin_fabsf(in[0]));
+        item_pos++;
+        phase += in[0] * sample_duration;
+        pf_ok = false;
+    }
+    template <int PH> FD_HD void skip2(const v2f* in) {
+        static_assert(PH == PH_SIMD, "WaveSynth::skip2: packed part of a process block only");
+        if ((item_pos & 7) == 0) item_w = select(__builtin_fabsf(in[0].x));
+        item_pos += 2;
+        const v2f d = in[0] * sample_duration;
+        phase += d.x;
+        phase += d.y;
+        pf_ok = false;
+    }
 };
 
 // PhaseSynth  wavetable.rs:358-430 (ID 35): table read driven by a PHASE input; the table pair follows the frequency
@@ -3435,6 +3454,8 @@ struct Stack {
         x.template step2<PH>(in, out);
         y.template step2<PH>(in + X::IN, out + X::OUT);
     }
+    template <int PH> FD_HD void skip(const float* in) { x.template skip<PH>(in); y.template skip<PH>(in + X::IN); }
+    template <int PH> FD_HD void skip2(const v2f* in) { x.template skip2<PH>(in); y.template skip2<PH>(in + X::IN); }
 };
 
 struct OpAdd { template <class T> static FD_HD T f(T a, T b) { return a + b; } };

@@ -165,7 +165,7 @@ def test_chunked_mix_equals_whole_and_reserve(gpu):
     whole = b.process_mix(64 * 6, mix=MIX_PAN).cpu().numpy()
     parts = [c.process_mix(64, mix=MIX_PAN).cpu().numpy() for _ in range(6)]
     assert_bit_equal(whole, np.concatenate(parts, axis=1), "chunked == whole")
-    lone = gpu.Bank("sine", 64)
+    lone = gpu.Bank("noise", 64)
     with pytest.raises(gpu.FdspError) as e:
         lone.process_mix(64, mix=MIX_SUM)
     assert e.value.code == -4 and "fdsp_sum_voices" in str(e.value)

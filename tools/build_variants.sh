@@ -10,11 +10,11 @@ NAME=$1; shift
 FILE=${FILE:-fd_kinds_fm}
 mkdir -p ../../variants
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function -Wno-unused-value"
-if [ "$FILE" = "fd_kinds_fm" ] && [ "${ILP:-1}" = "1" ]; then FLAGS="$FLAGS -mllvm -amdgpu-sched-strategy=iterative-ilp"; fi
+if { [ "$FILE" = "fd_kinds_fm" ] || [ "$FILE" = "fd_kinds_fm_mix" ]; } && [ "${ILP:-1}" = "1" ]; then FLAGS="$FLAGS -mllvm -amdgpu-sched-strategy=iterative-ilp"; fi
 if [ "$FILE" = "fd_kinds_fm_ts" ] && [ "${ILP:-1}" = "1" ]; then FLAGS="$FLAGS -mllvm -amdgpu-sched-strategy=max-ilp"; fi
 /opt/rocm/bin/hipcc $FLAGS $@ -c $FILE.hip -o /tmp/${FILE}_$NAME.o
 OBJS=""
-for o in fd_capi fd_kinds_leaf fd_kinds_graph fd_kinds_fm fd_kinds_fm_ts fd_fdn fd_jit fd_comm fd_rust; do
+for o in fd_capi fd_kinds_leaf fd_kinds_graph fd_kinds_graph_mix fd_kinds_fm fd_kinds_fm_mix fd_kinds_fm_ts fd_fdn fd_jit fd_comm fd_rust; do
   if [ "$o" = "$FILE" ]; then OBJS="$OBJS /tmp/${FILE}_$NAME.o"; else OBJS="$OBJS $o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libfundsp_hip_$NAME.so $OBJS -lhiprtc -lrccl -ldl
