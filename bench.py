@@ -51,43 +51,95 @@ def _native_oracle():
     return O, L
 
 
+def host_cpu_budget():
+    """What this process may actually use of the host: logical CPUs, the affinity mask, and the cgroup CPU quota (v2 cpu.max /
+    v1 cpu.cfs_quota_us).  `effective` = min(affinity, ceil(quota)): the thread count the cpu_baseline legs run with and report
+    as `cores` (os.cpu_count() said 256 on a box whose run behaved like ~20)."""
+    logical = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = logical
+    quota = None
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt and txt[0] != "max":
+            quota = float(txt[0]) / float(txt[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            quota = None
+    effective = affinity if quota is None else max(1, min(affinity, int(quota + 0.999)))
+    load = None
+    try:
+        load = os.getloadavg()[0]
+    except OSError:
+        pass
+    return {"logical_cpus": logical, "affinity_cpus": affinity, "cgroup_quota_cpus": None if quota is None else round(quota, 2),
+            "effective_cpus": effective, "loadavg_1min_before": None if load is None else round(load, 1)}
+
+
 def cpu_baseline(voices, frames, sample_rate, target_seconds):
     """Time the CPU restatement of the reference path on a bounded sample of the same workload, on this host's cores.
     `value` = the MONOMORPHISED process() path (oracle/o_fast.c: what rustc makes of the statically typed graph -- no node
     tree, both sines one 8-lane `wide` operation per 8 frames on the host's SIMD unit, the SVF per sample; bit-identical
     to the generic oracle, tests/test_oracle_fast.py).  Also reported: the generic tree-walking oracle in the same shape
     (`tree_walk_value`, round 1-2's figure) and tick-shaped (`tick_shaped_value`: AudioNode::tick per sample, libm sinf).
-    Built on this host with NATIVE_FLAGS (oracle/Makefile `native`)."""
+    Built on this host with NATIVE_FLAGS (oracle/Makefile `native`).
+    `cores` = the threads used = what the process may use (host_cpu_budget: affinity mask and cgroup quota, not os.cpu_count()),
+    each pinned to its own CPU of the mask; `one_thread_value` = the same binary on ONE pinned thread for >= 1 s, and
+    `scaling_efficiency` = value / (cores x one_thread_value) -- well below 1 means the threads did not get a core each
+    (SMT siblings, an oversubscribed or throttled host), whatever the count says.  Every leg runs >= 3 s."""
     from fundsp_amd import workloads as W
 
     O, L = _native_oracle()
-    cores = os.cpu_count() or 1
+    budget = host_cpu_budget()
+    cores = budget["effective_cpus"]
+    L.o_bank_pin_threads.argtypes = [C.c_int]
+    L.o_bank_pin_threads(1)
 
-    def timed(n, process, fast):
+    def timed(n, process, fast, threads):
         p = W.fm_svf_params(n, sample_rate)
-        return O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], frames, sample_rate, process, 0, cores,
+        return O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], frames, sample_rate, process, 0, threads,
                              store=False, lib=L, fast=fast)[1]
 
-    out = {}
-    shapes = (("fast", True, True, 0.5), ("tree", True, False, 0.25), ("tick", False, False, 0.25))
-    for shape, process, fast, share in shapes:
-        s = timed(2 * cores, process, fast)  # calibrate on a small sample, then size the timed sample for its share of the budget
-        rate = 2 * cores * frames / max(s, 1e-6)
-        n = int(min(voices, max(cores, rate * share * target_seconds / frames)))
-        n = max(cores, n // cores * cores)
-        s = timed(n, process, fast)
-        out[shape] = (n * frames / s / 1e6, n, s)
+    def leg(process, fast, threads, seconds):
+        n = 2 * threads
+        s = timed(n, process, fast, threads)  # calibrate on a small sample, then size the timed sample for its share of the budget
+        for _ in range(3):                    # (a short calibration run under-estimates a loaded host: re-size until the leg is long enough)
+            rate = n * frames / max(s, 1e-6)
+            n = int(min(voices, max(threads, rate * seconds * 1.15 / frames)))
+            n = max(threads, n // threads * threads)
+            s = timed(n, process, fast, threads)
+            if s >= seconds or n >= voices // threads * threads:
+                break
+        return (n * frames / s / 1e6, n, s)
+
+    per_leg = max(3.0, target_seconds / 4.0)
+    out = {"fast": leg(True, True, cores, per_leg), "tree": leg(True, False, cores, per_leg), "tick": leg(False, False, cores, per_leg)}
+    one = leg(True, True, 1, max(1.0, target_seconds / 12.0))
+    L.o_bank_pin_threads(0)
     v, n, s = out["fast"]
+    eff = v / (cores * one[0]) if one[0] > 0 else None
     return {
         "value": round(v, 3),
         "unit": "Msamples/s",
         "cores": cores,
+        "host": budget,
+        "threads_pinned": True,
+        "one_thread_value": round(one[0], 3),
+        "scaling_efficiency": None if eff is None else round(eff, 3),
         "kind": "port",
         "simd": L.o_fast_simd_flavour().decode(),
         "tree_walk_value": round(out["tree"][0], 3),
         "tick_shaped_value": round(out["tick"][0], 3),
         "sample": f"{n} of the {voices} config-3 voices x {frames} frames, monomorphised process() path of the reference restated in C "
-                  f"(oracle/o_fast.c: f32x8 sines as 8-lane vector code, SVF per sample; gcc {NATIVE_FLAGS}), {cores} threads, {s:.2f} s; "
+                  f"(oracle/o_fast.c: f32x8 sines as 8-lane vector code, SVF per sample; gcc {NATIVE_FLAGS}), {cores} pinned threads, {s:.2f} s; "
+                  f"one thread: {one[1]} voices, {one[2]:.2f} s; "
                   f"generic tree-walking oracle, same shape: {out['tree'][1]} voices, {out['tree'][2]:.2f} s; "
                   f"tick-shaped: {out['tick'][1]} voices, {out['tick'][2]:.2f} s",
     }
@@ -104,8 +156,11 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
     from fundsp_amd import workloads as W
 
     O, L = _native_oracle()
-    cores = os.cpu_count() or 1
+    cores = host_cpu_budget()["effective_cpus"]
+    L.o_bank_pin_threads.argtypes = [C.c_int]
+    L.o_bank_pin_self.argtypes = [C.c_int]
     if config == 2:
+        L.o_bank_pin_threads(1)
         n = 4 * cores
         for _ in range(2):   # calibrate on a small sample, then size the timed one for ~target_seconds
             p = W.noise_biquad_params(n, sample_rate)
@@ -113,6 +168,7 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
             if s > 0.3 * target_seconds:
                 break
             n = max(cores, int(n * target_seconds / max(s, 1e-4)) // cores * cores)
+        L.o_bank_pin_threads(0)
         return {"value": round(n * frames / s / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
                 "sample": f"{n} config-2 voices x {frames} frames, oracle process() path, {cores} threads, {s:.2f} s"}
     nt = min(cores, 32)
@@ -142,16 +198,19 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
     nodes[0][0].render_blocks(nodes[0][1])            # calibration (and page-in): one voice, one pass
     reps = max(1, int(target_seconds / max(time.perf_counter() - t0, 1e-4)))
 
-    def work(gx):
+    def work(k, gx):
+        L.o_bank_pin_threads(1)
+        L.o_bank_pin_self(k)   # one CPU of the affinity mask per host thread
         for _ in range(reps):
             gx[0].render_blocks(gx[1])
-    ths = [threading.Thread(target=work, args=(gx,)) for gx in nodes]
+    ths = [threading.Thread(target=work, args=(k, gx)) for k, gx in enumerate(nodes)]
     t0 = time.perf_counter()
     for t in ths:
         t.start()
     for t in ths:
         t.join()
     s = time.perf_counter() - t0
+    L.o_bank_pin_threads(0)
     return {"value": round(nt * fr * reps / s / 1e6, 3), "unit": unit, "cores": nt, "kind": "port",
             "sample": f"{nt} {what} x {fr * reps} frames ({reps} passes of {fr}), one per host thread, oracle process() path "
                       f"(generic node tree, gcc -O2), {s:.2f} s"}
@@ -230,7 +289,7 @@ def secondary(F, W, torch, sr, mode):
     # the strong-scaling shards of the headline on ONE GPU: what each of N GPUs renders when the 65 536 voices are split N
     # ways (no collective on the data path, so the N-GPU step time is the shard's time): small banks take the time-split kernel
     shards = {"name": "config3_strong_scaling_shards", "what": "the per-GPU shard of the 65 536-voice headline at N = 2 / 4 / 8 GPUs, "
-              "rendered on this one GPU (exact arithmetic; banks of <= 32 768 voices take the time-split kernel k_render_ts); "
+              "rendered on this one GPU (exact arithmetic; banks of <= 32 768 voices take the three-way time-split kernel k_render_ts3); "
               "implied_value = 65536 voices x frames / shard time", "unit": "Msamples/s"}
     for n in (2, 4, 8):
         Vs = TOTAL_VOICES // n
@@ -274,6 +333,55 @@ def secondary(F, W, torch, sr, mode):
             del g, outs
         del wl
     out.append(c2)
+    # ... the same launch pattern from a COMPILED host, straight through the C ABI (tools/launch_overhead.cpp, built here with g++):
+    # what the Python binding adds per 64-frame block is the difference to T64.us_per_launch above
+    try:
+        exe = os.path.join(ROOT, "tools", "_launch_overhead")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "launch_overhead.cpp"), "-o", exe,
+                               "-L", os.path.join(ROOT, "fundsp_amd"), "-lfundsp_hip", "-Wl,-rpath," + os.path.join(ROOT, "fundsp_amd"),
+                               "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        txt = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+        rows = [json.loads(l[5:]) for l in txt.splitlines() if l.startswith("JSON ")]
+        c2["T64"]["compiled_host_cpp"] = {("timing_on" if r["timing"] else "timing_off"): {k: v for k, v in r.items() if k != "timing"} for r in rows}
+        c2["T64"]["compiled_host_cpp"]["what"] = ("tools/launch_overhead.cpp: fdsp_bank_process call by call from C++ (us): host time inside the call, 5000 back-to-back "
+                                                  "launches per launch, launch + fdsp_bank_synchronize per block; with / without the per-launch HIP event pair")
+    except Exception as e:
+        c2["T64"]["compiled_host_cpp"] = {"error": repr(e)}
+    # config 3 is quoted at T in {64, 4096, 48000}; the headline is T = 48000, here the other two (exact, voice-out).
+    # Algorithmic bytes V*T*4 + V*64: 5 B per voice-sample at T = 64.  T = 64 also replayed from a HIP graph (the real-time pattern).
+    c3 = {"name": "config3_frames_per_launch", "what": "BASELINE config 3 (65536 voices, exact, voice-out) at the other launch lengths of SURVEY 8(d): "
+          "T = 64 (one AudioNode::process block per launch: the single-wave kernel) and T = 4096; algorithmic bytes V*T*4 + V*64 per launch", "unit": "Msamples/s"}
+    V = TOTAL_VOICES
+    for T in (64, 4096):
+        wl = make_workload(F, W, torch, 3, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, "exact")
+        ms, kms = quick(F, torch, wl, T, mode, steps=50 if T == 64 else 20, warmup=5)
+        algo = V * T * 4 + V * 64
+        c3[f"T{T}"] = {"us_per_launch": round(ms * 1e3, 2), "kernel_us": round(kms * 1e3, 2), "value": round(V * T / ms / 1e3, 1),
+                       "algorithmic_bytes_per_voice_sample": round(algo / (V * T), 3),
+                       "roofline_frac": round(algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "last_kernel": wl["bank"].get_option("last_kernel")}
+        if T == 64:
+            NB = 16
+            outs = [torch.empty_like(wl["out"]) for _ in range(NB)]
+            s_ = torch.cuda.Stream()
+            with torch.cuda.stream(s_):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s_):
+                    for kk in range(NB):
+                        wl["bank"].process(64, None, outs[kk], layout=wl["layout"], mode=mode)
+                g.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    g.replay()
+                torch.cuda.synchronize()
+                us = (time.perf_counter() - t0) / 20 / NB * 1e6
+            c3["T64"]["hip_graph_replay_us_per_block"] = round(us, 2)
+            c3["T64"]["hip_graph_value"] = round(V * 64 / us, 1)
+            c3["T64"]["hip_graph_roofline_frac"] = round(algo / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            del g, outs
+        del wl
+    out.append(c3)
     for cfg, V, name, unit, math in ((4, 32768, "config4_saw_moog_adsr_pan_32768", "Msamples/s", "exact"),
                                      (4, 32768, "config4_math_fast", "Msamples/s", "fast"),
                                      (5, 2048, "config5_reverb_stereo_2048", "M instance-frames/s", "exact")):

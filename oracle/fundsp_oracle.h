@@ -207,6 +207,11 @@ typedef struct {
 } o_fm_svf_regs;
 int o_fm_svf_state(const onode *g, o_fm_svf_regs *r);
 onode *o_bank_build_voice(const o_bank_job *job, size_t v);
+/* timing hygiene of the cpu_baseline legs: pin worker t of a bank job to the t-th CPU of the process's affinity mask; how many
+ * CPUs that mask holds; pin the calling thread likewise (threads that bench.py starts itself). */
+void o_bank_pin_threads(int on);
+int o_bank_allowed_cpus(void);
+void o_bank_pin_self(int t);
 double o_bank_render_fast(const o_bank_job *job, float *out);
 const char *o_fast_simd_flavour(void);
 

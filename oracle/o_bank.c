@@ -7,11 +7,40 @@
  * sine_hz prelude.rs:349, lowpass_hz prelude.rs:2111, noise prelude.rs (Noise::new noise.rs:179),
  * biquad prelude.rs (Biquad::with_coefs biquad.rs:151), operators combinator.rs:344-475.
  */
+#define _GNU_SOURCE /* pthread_setaffinity_np, CPU_SET: pinned timing threads (o_bank_pin_threads) */
 #include "fundsp_oracle.h"
 
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <time.h>
+
+/* cpu_baseline honesty (bench.py): with pinning on, worker t of a bank job runs on the t-th CPU of the PROCESS'S affinity mask
+ * (wrapping around when there are more workers than CPUs), so "N threads" means N distinct CPUs whenever the mask has them. */
+static int g_pin_threads = 0;
+void o_bank_pin_threads(int on) { g_pin_threads = on; }
+int o_bank_allowed_cpus(void) {
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) != 0) return -1;
+    return CPU_COUNT(&set);
+}
+void o_bank_pin_self(int t) {
+    if (!g_pin_threads) return;
+    cpu_set_t set, one;
+    if (sched_getaffinity(0, sizeof set, &set) != 0) return;
+    int n = CPU_COUNT(&set);
+    if (n <= 0) return;
+    int want = t % n, seen = 0;
+    for (int c = 0; c < CPU_SETSIZE; c++) {
+        if (!CPU_ISSET(c, &set)) continue;
+        if (seen++ == want) {
+            CPU_ZERO(&one);
+            CPU_SET(c, &one);
+            pthread_setaffinity_np(pthread_self(), sizeof one, &one);
+            return;
+        }
+    }
+}
 
 static onode *build_voice(const o_bank_job *job, size_t v) {
     onode *g = NULL;
@@ -38,6 +67,7 @@ typedef struct {
     const o_bank_job *job;
     float *out;
     size_t v0, v1;
+    int t;
 } slice;
 
 onode *o_bank_build_voice(const o_bank_job *job, size_t v) { return build_voice(job, v); }
@@ -45,6 +75,7 @@ onode *o_bank_build_voice(const o_bank_job *job, size_t v) { return build_voice(
 static void *run_slice(void *arg) {
     slice *s = (slice *)arg;
     const o_bank_job *job = s->job;
+    o_bank_pin_self(s->t);
     size_t T = job->frames, V = job->voices;
     float blk[64];
     for (size_t v = s->v0; v < s->v1; v++) {
@@ -79,6 +110,7 @@ double o_bank_render(const o_bank_job *job, float *out) {
         sl[t].out = out;
         sl[t].v0 = job->voices * (size_t)t / (size_t)nt;
         sl[t].v1 = job->voices * (size_t)(t + 1) / (size_t)nt;
+        sl[t].t = t;
         pthread_create(&th[t], NULL, run_slice, &sl[t]);
     }
     for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);

@@ -141,11 +141,13 @@ typedef struct {
     const o_bank_job *job;
     float *out;
     size_t v0, v1;
+    int t;
 } fslice;
 
 static void *run_fast_slice(void *arg) {
     fslice *s = (fslice *)arg;
     const o_bank_job *job = s->job;
+    o_bank_pin_self(s->t);
     const size_t T = job->frames, V = job->voices;
     float blk[64];
     for (size_t v = s->v0; v < s->v1; v++) {
@@ -182,6 +184,7 @@ double o_bank_render_fast(const o_bank_job *job, float *out) {
         sl[t].out = out;
         sl[t].v0 = job->voices * (size_t)t / (size_t)nt;
         sl[t].v1 = job->voices * (size_t)(t + 1) / (size_t)nt;
+        sl[t].t = t;
         pthread_create(&th[t], NULL, run_fast_slice, &sl[t]);
     }
     for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);

@@ -40,6 +40,8 @@ pub mod ffi {
     pub const FDSP_MODE_TICK: c_int = 1;
     pub const FDSP_MATH_EXACT: c_int = 0;
     pub const FDSP_MATH_FAST: c_int = 1;
+    pub const FDSP_MIX_SUM: c_int = 1;
+    pub const FDSP_MIX_PAN: c_int = 2;
 
     #[link(name = "fundsp_hip")]
     unsafe extern "C" {
@@ -67,6 +69,12 @@ pub mod ffi {
                                       frame_stride: usize, mode: c_int) -> c_int; // AudioNode::process on host buffers
         pub fn fdsp_bank_process(bank: *mut FdspBank, frames: usize, d_in: *const f32, d_out: *mut f32, layout: c_int,
                                  frame_stride: usize, mode: c_int, stream: *mut c_void) -> c_int; // device-resident I/O
+        pub fn fdsp_bank_process_mix(bank: *mut FdspBank, frames: usize, d_in: *const f32, d_mix: *mut f32, mix: c_int, mode: c_int,
+                                     stream: *mut c_void) -> c_int; // render + reduce over the voices in one launch
+        pub fn fdsp_bank_set_pan(bank: *mut FdspBank, pan: *const f32, first: usize, count: usize) -> c_int;
+        pub fn fdsp_bank_mix_reserve(bank: *mut FdspBank, frames: usize) -> c_int; // AudioNode::allocate for the mix path
+        pub fn fdsp_bank_synchronize(bank: *mut FdspBank) -> c_int;
+        pub fn fdsp_sum_voices(d_in: *const f32, d_out: *mut f32, channels: usize, frames: usize, voices: usize, stream: *mut c_void) -> c_int;
         pub fn fdsp_mix_stereo(d_voices: *const f32, d_pan: *const f32, d_mix: *mut f32, frames: usize, voices: usize, stream: *mut c_void) -> c_int;
         pub fn fdsp_comm_create_local(n: c_int, devices: *const c_int, out: *mut *mut FdspComm) -> c_int;
         pub fn fdsp_comm_unique_id(id128: *mut c_void) -> c_int;
@@ -89,6 +97,12 @@ fn check(rc: c_int) -> Result<(), String> {
 
 /// A bank of voices on one GPU.  `NI` = voices x inputs per voice, `NO` = voices x outputs per voice (typenum sizes, as
 /// every `AudioNode` declares them).
+///
+/// The `AudioNode` face has a practical ceiling: `tick()` builds `Frame<f32, NO>` on the stack (a `GenericArray`: 4 B per
+/// channel -- 256 KB at `U65536`) and every combinator above the bank instantiates typenum arithmetic over `NI` / `NO`.  The
+/// reference uses `Size` at channel counts of tens (`U32` in its FDN reverbs, src/prelude.rs:1732-1762); use the trait face at
+/// bank sizes of that order (a few hundred voices at most) and [`HipBank::render_device`] / [`HipBank::render_mix`] for the
+/// BASELINE-sized banks, where `NI` / `NO` are only the arity check of `new` (pass `U0` and skip it with `new_unchecked_arity`).
 pub struct HipBank<NI: Size<f32>, NO: Size<f32>> {
     bank: *mut FdspBank,
     kind: CString,
@@ -119,6 +133,21 @@ impl<NI: Size<f32>, NO: Size<f32>> HipBank<NI, NO> {
         }
         let device = unsafe { fdsp_bank_device(bank) };
         Ok(Self { bank, kind, voices, ring_frames, device, last_error: None, _marker: PhantomData })
+    }
+
+    /// The same without the typenum arity check: for banks far beyond the channel counts `Size` is meant for (65 536 voices),
+    /// which are driven through `render_device` / `render_mix` only.  `tick` / `process` of such a bank report an arity error.
+    pub fn new_unchecked_arity(kind: &str, voices: usize, ring_frames: usize, device: i32) -> Result<Self, String> {
+        let kind = CString::new(kind).map_err(|e| e.to_string())?;
+        let mut bank: *mut FdspBank = core::ptr::null_mut();
+        check(unsafe { fdsp_bank_create_on(device as c_int, kind.as_ptr(), voices, ring_frames, &mut bank) })?;
+        let device = unsafe { fdsp_bank_device(bank) };
+        Ok(Self { bank, kind, voices, ring_frames, device, last_error: None, _marker: PhantomData })
+    }
+
+    fn arity_ok(&self) -> bool {
+        let (i, o) = unsafe { (fdsp_bank_inputs(self.bank) as usize, fdsp_bank_outputs(self.bank) as usize) };
+        i * self.voices == NI::USIZE && o * self.voices == NO::USIZE
     }
 
     /// `voices` instances of the graph TYPE `X`: `core::any::type_name::<X>()` goes to the engine's front door
@@ -183,6 +212,64 @@ impl<NI: Size<f32>, NO: Size<f32>> HipBank<NI, NO> {
 
     /// Raw handle for device-resident rendering (`fdsp_bank_process`, `fdsp_mix_stereo`, `fdsp_mix_allreduce`).
     pub fn raw(&mut self) -> *mut FdspBank { self.bank }
+
+    /// The big-block entry (the reference's `BigBlockAdapter::process_big`, src/audiounit.rs:510-528, without the 64-sample
+    /// chopping: the kernel blocks internally exactly like `Wave::render`).  Device-resident I/O, voice-minor:
+    /// `input` = `[inputs][frames][voices]`, `output` = `[outputs][frames][voices]` f32 in HBM; `stream` = a `hipStream_t` or null
+    /// (the bank's own stream).  Asynchronous: [`Self::synchronize`] or the caller's stream order the read-back.
+    /// This -- not `process()` -- is the throughput path: `process()` follows `AudioNode`'s contract on HOST buffers and moves
+    /// `voices x (inputs + outputs) x 256 B` over PCIe per 64-frame block (16.7 MB per block at 65 536 mono voices).
+    pub fn render_device(&mut self, frames: usize, input: DevicePtr<'_>, output: DevicePtrMut<'_>, stream: *mut c_void) -> Result<(), String> {
+        let (i, o) = unsafe { (fdsp_bank_inputs(self.bank) as usize, fdsp_bank_outputs(self.bank) as usize) };
+        if input.len < i * frames * self.voices || output.len < o * frames * self.voices {
+            return Err(format!("render_device: buffers of {} / {} floats, the launch needs {} / {}", input.len, output.len,
+                               i * frames * self.voices, o * frames * self.voices));
+        }
+        check(unsafe { fdsp_bank_process(self.bank, frames, input.ptr, output.ptr, FDSP_LAYOUT_VOICE_MINOR, 0, FDSP_MODE_PROCESS, stream) })
+    }
+
+    /// Render AND mix down in one launch (`fdsp_bank_process_mix`): what `voice >> pan(p)` per voice followed by the sum over
+    /// the voices computes (src/pan.rs:50-76, src/audionode.rs:2406-2462), without the per-voice output ever existing in HBM.
+    /// `pan = true`: mono graphs, every voice panned with its own position ([`Self::set_pan`]); `mix` = `[2][frames]`.
+    /// `pan = false`: the sum of every output channel over the voices; `mix` = `[outputs][frames]`.
+    /// Fixed summation order (include/fundsp_hip.h): bit-identical from launch to launch and across launch geometries.
+    pub fn render_mix(&mut self, frames: usize, input: DevicePtr<'_>, mix: DevicePtrMut<'_>, pan: bool, stream: *mut c_void) -> Result<(), String> {
+        let (i, o) = unsafe { (fdsp_bank_inputs(self.bank) as usize, fdsp_bank_outputs(self.bank) as usize) };
+        let nm = if pan { 2 } else { o };
+        if input.len < i * frames * self.voices || mix.len < nm * frames {
+            return Err(format!("render_mix: buffers of {} / {} floats, the launch needs {} / {}", input.len, mix.len, i * frames * self.voices, nm * frames));
+        }
+        check(unsafe { fdsp_bank_process_mix(self.bank, frames, input.ptr, mix.ptr, if pan { FDSP_MIX_PAN } else { FDSP_MIX_SUM }, FDSP_MODE_PROCESS, stream) })
+    }
+
+    /// Pan position (-1 .. 1) per voice for `render_mix(.., pan = true, ..)`; every voice starts in the centre (`pan(0.0)`).
+    pub fn set_pan(&mut self, pan: &[f32]) -> Result<(), String> {
+        check(unsafe { fdsp_bank_set_pan(self.bank, pan.as_ptr(), 0, pan.len()) })
+    }
+
+    /// `AudioNode::allocate` for the mix path: size the bank's partial-mix buffer for launches of up to `frames` frames, so that
+    /// `render_mix` never allocates (real-time loops, HIP graph capture).
+    pub fn allocate_mix(&mut self, frames: usize) -> Result<(), String> { check(unsafe { fdsp_bank_mix_reserve(self.bank, frames) }) }
+
+    /// Wait for the bank's own stream (renders launched with a null `stream`).
+    pub fn synchronize(&mut self) -> Result<(), String> { check(unsafe { fdsp_bank_synchronize(self.bank) }) }
+}
+
+/// A borrowed run of f32 in DEVICE memory (hipMalloc'd by the host application): pointer + length in floats.  The shim never
+/// dereferences it on the host; the length is what the launch-size check needs.  A generator's input is `DevicePtr::null()`.
+#[derive(Clone, Copy)]
+pub struct DevicePtr<'a> { ptr: *const f32, len: usize, _life: PhantomData<&'a f32> }
+pub struct DevicePtrMut<'a> { ptr: *mut f32, len: usize, _life: PhantomData<&'a mut f32> }
+impl<'a> DevicePtr<'a> {
+    /// # Safety
+    /// `ptr` must be device memory of at least `len` floats on the bank's device, alive for `'a` and not written while a launch reads it.
+    pub unsafe fn new(ptr: *const f32, len: usize) -> Self { Self { ptr, len, _life: PhantomData } }
+    pub fn null() -> Self { Self { ptr: core::ptr::null(), len: 0, _life: PhantomData } }
+}
+impl<'a> DevicePtrMut<'a> {
+    /// # Safety
+    /// `ptr` must be device memory of at least `len` floats on the bank's device, alive for `'a`, with no other reader or writer while a launch runs.
+    pub unsafe fn new(ptr: *mut f32, len: usize) -> Self { Self { ptr, len, _life: PhantomData } }
 }
 
 impl<NI: Size<f32>, NO: Size<f32>> AudioNode for HipBank<NI, NO> {
@@ -191,7 +278,10 @@ impl<NI: Size<f32>, NO: Size<f32>> AudioNode for HipBank<NI, NO> {
     type Outputs = NO;
 
     fn reset(&mut self) {
-        unsafe { fdsp_bank_reset(self.bank) };
+        // infallible in FunDSP (src/audionode.rs:52); a failed device call is kept for take_error()
+        if unsafe { fdsp_bank_reset(self.bank) } != FDSP_OK {
+            self.last_error = Some(last_error());
+        }
     }
 
     fn set_sample_rate(&mut self, sample_rate: f64) {
@@ -203,6 +293,10 @@ impl<NI: Size<f32>, NO: Size<f32>> AudioNode for HipBank<NI, NO> {
     fn tick(&mut self, input: &Frame<f32, Self::Inputs>) -> Frame<f32, Self::Outputs> {
         // one sample of every voice: planar rows of length 1 are [voice][channel] = the Frame's own order
         let mut out: Frame<f32, Self::Outputs> = Frame::default();
+        if !self.arity_ok() {
+            self.last_error = Some("tick: the bank was created with new_unchecked_arity; drive it through render_device / render_mix".into());
+            return out;
+        }
         let inp = if NI::USIZE > 0 { input.as_slice().as_ptr() } else { core::ptr::null() };
         let rc = unsafe { fdsp_bank_process_host(self.bank, 1, inp, out.as_mut_slice().as_mut_ptr(), FDSP_LAYOUT_PLANAR, 1, FDSP_MODE_TICK) };
         if rc != FDSP_OK {
@@ -215,6 +309,13 @@ impl<NI: Size<f32>, NO: Size<f32>> AudioNode for HipBank<NI, NO> {
 
     fn process(&mut self, size: usize, input: &BufferRef, output: &mut BufferMut) {
         // BufferRef(&[F32x]) / BufferMut(&mut [F32x]): contiguous [channel][64] f32, 32-byte aligned, channel = voice-major
+        if !self.arity_ok() {
+            self.last_error = Some("process: the bank was created with new_unchecked_arity; drive it through render_device / render_mix".into());
+            for ch in 0..NO::USIZE {
+                output.channel_f32_mut(ch)[..size].fill(0.0);
+            }
+            return;
+        }
         let inp = if NI::USIZE > 0 { input.channel_f32(0).as_ptr() } else { core::ptr::null() };
         let out = output.channel_f32_mut(0).as_mut_ptr();
         let rc = unsafe { fdsp_bank_process_host(self.bank, size, inp, out, FDSP_LAYOUT_PLANAR, MAX_BUFFER_SIZE, FDSP_MODE_PROCESS) };
@@ -233,7 +334,9 @@ impl<NI: Size<f32>, NO: Size<f32>> AudioNode for HipBank<NI, NO> {
         // ping() reaches a leaf with ONE hash; a bank is V leaves: every voice gets it (a bank that should de-correlate
         // its voices calls set_seeds with one seed per voice instead, as the parity tests do)
         let seeds = vec![hash; self.voices];
-        unsafe { fdsp_bank_set_seed(self.bank, seeds.as_ptr(), 0, self.voices) };
+        if unsafe { fdsp_bank_set_seed(self.bank, seeds.as_ptr(), 0, self.voices) } != FDSP_OK {
+            self.last_error = Some(last_error()); // set_hash is infallible (src/audionode.rs:136): kept for take_error()
+        }
     }
 
     fn route(&mut self, input: &SignalFrame, _frequency: f64) -> SignalFrame {

@@ -132,3 +132,11 @@ def test_rust_shim_declares_the_c_abi():
         c_args = m.group(1).strip()
         n_c = 0 if c_args in ("", "void") else len([a for a in c_args.split(",") if a.strip()])
         assert n_rust == n_c, f"{name}: {n_rust} parameters in rust_shim, {n_c} in the header"
+    bound = {name for name, _ in decls}
+    # the device-resident entries behind HipBank::render_device / render_mix / set_pan / allocate_mix
+    for name in ("fdsp_bank_process", "fdsp_bank_process_mix", "fdsp_bank_set_pan", "fdsp_bank_mix_reserve", "fdsp_bank_synchronize", "fdsp_sum_voices"):
+        assert name in bound, f"{name} is not bound by rust_shim"
+    for method in ("pub fn render_device", "pub fn render_mix", "pub fn set_pan", "pub fn allocate_mix", "pub fn take_error"):
+        assert method in shim, f"HipBank lacks `{method}`"
+    # the infallible trait methods keep the engine's return code instead of dropping it
+    assert shim.count("self.last_error = Some(last_error())") >= 4

@@ -55,6 +55,9 @@ int main() {
         std::printf("config 2, 1024 voices x 64 frames per launch, timing=%d: host time in fdsp_bank_process %.2f us/launch, %d back-to-back launches "
                     "%.2f us/launch, launch + synchronize %.2f us/block%s\n", timing, host_us, N, thru_us, rt_us, timing ? "" : " (no event pair)");
         if (timing) std::printf("  kernel alone (HIP events of the last launch): %.2f us\n", kms * 1e3);
+        // one machine-readable line per mode (bench.py quotes it beside its own Python-side figure)
+        std::printf("JSON {\"timing\": %d, \"host_us_per_launch\": %.2f, \"back_to_back_us_per_launch\": %.2f, \"launch_plus_sync_us\": %.2f, \"kernel_us\": %.2f}\n",
+                    timing, host_us, thru_us, rt_us, kms * 1e3);
     }
     hipFree(out);
     fdsp_bank_destroy(b);
