@@ -112,10 +112,10 @@ def cpu_baseline(voices, frames, sample_rate, target_seconds):
         s = timed(n, process, fast, threads)  # calibrate on a small sample, then size the timed sample for its share of the budget
         for _ in range(3):                    # (a short calibration run under-estimates a loaded host: re-size until the leg is long enough)
             rate = n * frames / max(s, 1e-6)
-            n = int(min(voices, max(threads, rate * seconds * 1.15 / frames)))
+            n = int(max(threads, rate * seconds * 1.15 / frames))   # (beyond the bank's 65 536 voices the family simply continues: voice index -> parameters)
             n = max(threads, n // threads * threads)
             s = timed(n, process, fast, threads)
-            if s >= seconds or n >= voices // threads * threads:
+            if s >= seconds:
                 break
         return (n * frames / s / 1e6, n, s)
 
@@ -137,7 +137,7 @@ def cpu_baseline(voices, frames, sample_rate, target_seconds):
         "simd": L.o_fast_simd_flavour().decode(),
         "tree_walk_value": round(out["tree"][0], 3),
         "tick_shaped_value": round(out["tick"][0], 3),
-        "sample": f"{n} of the {voices} config-3 voices x {frames} frames, monomorphised process() path of the reference restated in C "
+        "sample": f"{n} voices of the config-3 family (the bank has {voices}) x {frames} frames, monomorphised process() path of the reference restated in C "
                   f"(oracle/o_fast.c: f32x8 sines as 8-lane vector code, SVF per sample; gcc {NATIVE_FLAGS}), {cores} pinned threads, {s:.2f} s; "
                   f"one thread: {one[1]} voices, {one[2]:.2f} s; "
                   f"generic tree-walking oracle, same shape: {out['tree'][1]} voices, {out['tree'][2]:.2f} s; "
