@@ -519,7 +519,7 @@ FD_D float quad_swap(float x, int ctrl) {
 // x: [rows][V] voice-minor.  PAN = false: part[group][row] = partial sum of the row.  PAN = true (rows = frames of a mono render):
 // part[group][c][row], c = left / right, every sample weighted by its voice's pan weights first.
 // One workgroup = one voice group x 256 rows: thread (row, quarter) reads its quarter's 16 consecutive floats.
-template <bool PAN>
+template <bool PAN, bool VEC4>
 __global__ __launch_bounds__(256) void k_group_partials(const float* __restrict__ x, const float* __restrict__ wl,
                                                         const float* __restrict__ wr, float* __restrict__ part, size_t rows, size_t V) {
     const size_t g = blockIdx.x, r0 = (size_t)blockIdx.y * 256;
@@ -539,8 +539,17 @@ __global__ __launch_bounds__(256) void k_group_partials(const float* __restrict_
         const bool on = r < rows;
         const float* src = x + (on ? r : 0) * V + vq;
         float xs[16];
+        if (VEC4 && on && vq + 16 <= V) {  // aligned rows: four 16-byte loads per thread instead of sixteen dwords
+            const float4* s4 = reinterpret_cast<const float4*>(src);
 #pragma unroll
-        for (int j = 0; j < 16; j++) xs[j] = (on && vq + j < V) ? src[j] : 0.0f;
+            for (int j = 0; j < 4; j++) {
+                const float4 q4 = s4[j];
+                xs[4 * j] = q4.x; xs[4 * j + 1] = q4.y; xs[4 * j + 2] = q4.z; xs[4 * j + 3] = q4.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) xs[j] = (on && vq + j < V) ? src[j] : 0.0f;
+        }
         float sl, sr = 0.0f;
         if constexpr (PAN) {
             sl = vq < V ? xs[0] * a[0] : 0.0f;
@@ -609,7 +618,10 @@ __global__ __launch_bounds__(256) void k_mix_tree(const float* __restrict__ part
 template <bool PAN>
 hipError_t launch_mix_rows(const float* x, const float* wl, const float* wr, float* part, float* mix, size_t rows, size_t V, hipStream_t s) {
     const size_t G = (V + 63) / 64, R = PAN ? 2 * rows : rows;
-    hipLaunchKernelGGL((k_group_partials<PAN>), dim3((unsigned)G, (unsigned)((rows + 255) / 256)), dim3(256), 0, s, x, wl, wr, part, rows, V);
+    if (V % 4 == 0 && ((uintptr_t)x & 15) == 0)
+        hipLaunchKernelGGL((k_group_partials<PAN, true>), dim3((unsigned)G, (unsigned)((rows + 255) / 256)), dim3(256), 0, s, x, wl, wr, part, rows, V);
+    else
+        hipLaunchKernelGGL((k_group_partials<PAN, false>), dim3((unsigned)G, (unsigned)((rows + 255) / 256)), dim3(256), 0, s, x, wl, wr, part, rows, V);
     hipLaunchKernelGGL(k_mix_tree, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, part, mix, R, G);
     return hipGetLastError();
 }

@@ -1078,6 +1078,9 @@ FD_HD int wt_table_index(const WtSet* t, int hint, float frequency) {  // :189-2
 // back to back so their latencies overlap.
 // Device tables are stored circularly padded -- [t[len-1], t[0..len-1], t[0], t[1]] -- so the four interpolation taps
 // t[i1-1..i1+2] of Wavetable::at are ONE contiguous (unaligned) 16-byte gather per lane instead of four.
+#ifndef FD_WT_NT
+#define FD_WT_NT 0
+#endif
 struct Tap4 { float a0, a1, a2, a3, w; };
 // the pieces of wt_tap: index + interpolation weight, then the four floats from HBM / from the kernel's LDS copy
 FD_HD float wt_tap_index(uint32_t mask, float phase, uint32_t& i1) {
@@ -1091,7 +1094,11 @@ FD_HD Tap4 wt_tap_mem(const float* __restrict__ at, float w) {  // (by value: a 
     t.w = w;
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+#if FD_WT_NT   // A/B: the table gathers as non-temporal loads (served by L2, no L1 allocation)
+    const f4u q = __builtin_nontemporal_load((const __attribute__((address_space(1))) f4u*)at);
+#else
     const f4u q = *(const __attribute__((address_space(1))) f4u*)at;
+#endif
     t.a0 = q.x; t.a1 = q.y; t.a2 = q.z; t.a3 = q.w;
 #else
     float q[4];
@@ -1111,7 +1118,11 @@ FD_HD Tap4 wt_tap(const float* __restrict__ tab, uint32_t mask, float phase) {  
     // through an explicit global-address-space pointer: on a generic pointer (the table address comes out of a struct
     // in memory) the 4-byte-aligned 16-byte load is split into four dword gathers before the address space is inferred
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+#if FD_WT_NT
+    const f4u q = __builtin_nontemporal_load((const __attribute__((address_space(1))) f4u*)(tab + i1));
+#else
     const f4u q = *(const __attribute__((address_space(1))) f4u*)(tab + i1);
+#endif
     t.a0 = q.x; t.a1 = q.y; t.a2 = q.z; t.a3 = q.w;
 #else
     float q[4];

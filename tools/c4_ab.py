@@ -13,6 +13,8 @@ ap.add_argument("--maths", default="0")
 ap.add_argument("--reps", type=int, default=1)
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--mix", action="store_true")
+ap.add_argument("--uniform", action="store_true", help="every voice the same frequency and seed: all lanes of a wave gather from the same cache lines")
+ap.add_argument("--fmin", type=float, default=0.0, help="raise every voice's frequency to at least this (short tables only)")
 ap.add_argument("--label", default=os.path.basename(os.environ.get("FUNDSP_HIP_LIB", "default")))
 a = ap.parse_args()
 SR, T, V = 48000.0, 48000, 32768
@@ -24,7 +26,13 @@ ref = None
 for rep in range(a.reps):
     for math in [int(x) for x in a.maths.split(",")]:
         for split in [int(x) for x in a.splits.split(",")]:
-            b = W.make_saw_moog_bank(V, SR)
+            p = W.saw_moog_params(V, SR)
+            if a.uniform:
+                p["f"][:] = 220.0
+                p["seed"][:] = 7
+            if a.fmin > 0:
+                p["f"] = np.maximum(p["f"], np.float32(a.fmin))
+            b = W.make_saw_moog_bank(V, SR, params=p)
             b.set_option("math", math)
             b.set_option("stage_split", split)
             b.mix_reserve(T)
