@@ -1081,6 +1081,9 @@ FD_HD int wt_table_index(const WtSet* t, int hint, float frequency) {  // :189-2
 #ifndef FD_WT_NT
 #define FD_WT_NT 0
 #endif
+#ifndef FD_WT_SAME
+#define FD_WT_SAME 0
+#endif
 struct Tap4 { float a0, a1, a2, a3, w; };
 // the pieces of wt_tap: index + interpolation weight, then the four floats from HBM / from the kernel's LDS copy
 FD_HD float wt_tap_index(uint32_t mask, float phase, uint32_t& i1) {
@@ -1204,6 +1207,10 @@ struct WaveSynth {
             c_tab2 = wt->data + wt->off[t + 2];
             c_mask1 = (uint32_t)wt->len[t + 1] - 1u;
             c_mask2 = (uint32_t)wt->len[t + 2] - 1u;
+#if FD_WT_SAME   // measurement only (NOT a renderer): both taps from ONE table -- the second gather hits the first one's lines
+            c_tab2 = c_tab1;
+            c_mask2 = c_mask1;
+#endif
             hint = (uint32_t)t;
             pf_ok = false;  // taps gathered ahead came from the previous table pair
         }
