@@ -673,7 +673,7 @@ def mix_step(F, torch, args, wl, peers, mode):
     elif args.config in (2, 3):
         mix = F.mix_stereo(wl["out"][0] if wl["layout"] == F.LAYOUT_VOICE_MINOR else wl["out"][:, 0, :].t().contiguous())
     elif args.config == 5:
-        mix = wl["out"].sum(dim=0)     # [2][T] sum over instances (planar layout)
+        mix = F.sum_instances(wl["out"])   # [2][T] sum over the instances (planar layout), the mix-down's tree order
     else:
         mix = F.sum_voices(wl["out"])  # voices are already panned to stereo
     peers.comm.allreduce(mix, slot=peers.slot)

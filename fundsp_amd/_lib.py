@@ -77,6 +77,7 @@ SYMBOLS = {
     "fdsp_bank_mix_reserve": (_i, [_P, _sz]),
     "fdsp_mix_stereo": (_i, [_P, _P, _P, _sz, _sz, _P]),
     "fdsp_sum_voices": (_i, [_P, _P, _sz, _sz, _sz, _P]),
+    "fdsp_sum_instances": (_i, [_P, _P, _sz, _sz, _P]),
     "fdsp_comm_create_local": (_i, [_i, C.POINTER(C.c_int), C.POINTER(_P)]),
     "fdsp_comm_unique_id": (_i, [_P]),
     "fdsp_comm_create_rank": (_i, [_P, _i, _i, _i, C.POINTER(_P)]),

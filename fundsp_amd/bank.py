@@ -515,6 +515,20 @@ def sum_voices(x, stream=None):
     return out
 
 
+def sum_instances(x, stream=None):
+    """Sum over the instances of a planar render [instances, channels, frame_stride] -> [channels, frame_stride]
+    (fdsp_sum_instances: the aligned binary tree of the mix-down's order, over the instances)."""
+    import torch
+
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+    n, ch, fs = x.shape
+    out = torch.empty((ch, fs), dtype=torch.float32, device=x.device)
+    if stream is None:
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+    check(lib().fdsp_sum_instances(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), ch * fs, n, C.c_void_p(stream) if stream else None))
+    return out
+
+
 def mix_stereo(voices_out, pan=None, stream=None):
     """On-device stereo mix-down of a voice-minor mono render [frames, V] -> [2, frames]."""
     import torch

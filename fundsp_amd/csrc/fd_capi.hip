@@ -1695,6 +1695,16 @@ int fdsp_sum_voices(const float* d_in, float* d_out, size_t channels, size_t fra
     return FDSP_OK;
 }
 
+int fdsp_sum_instances(const float* d_in, float* d_out, size_t rows, size_t instances, void* stream) {
+    if (!d_in || !d_out) return fail(FDSP_EINVAL, "NULL buffer");
+    if (rows == 0 || instances == 0) return FDSP_OK;
+    DeviceGuard guard(device_of(d_in));
+    // planar output [instance][rows] IS the tree kernel's [groups][rows] shape: the aligned binary tree over the instances
+    hipLaunchKernelGGL(k_mix_tree, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, rows, instances);
+    HIPCHK(hipGetLastError());
+    return FDSP_OK;
+}
+
 int fdsp_svf_coefs(int mode, float sr, float cutoff, float q, float gain, float* out6) {
     if (!out6 || mode < 0 || mode > FDSP_SVF_HIGHSHELF) return fail(FDSP_EINVAL, "bad svf mode or NULL out");
     fd::SvfCoefs c = fd::svf_coefs(mode, sr, cutoff, q, gain);

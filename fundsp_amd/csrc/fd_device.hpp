@@ -2310,6 +2310,14 @@ FD_D void jit_pipe_small_body(float* __restrict__ slots, size_t stride, size_t V
     constexpr PipePlan P = pipe_plan<G>(0);
     if constexpr (JitPipeSmall<G>::on) render_pipe_body<G, MODE, P.S, P.K1, P.K2, GPW>(slots, stride, V, in, out, T, aux, ring, ring_cap);
 }
+// ... with the fused mix-down (fdsp_bank_process_mix on run-time compiled graphs; compiled on first use, four voice groups per workgroup --
+// the partial mixes do not depend on the launch geometry); empty when the graph has no plan / MIX_PAN on a graph that is not mono
+template <class G, int MODE, int MIX>
+FD_D void jit_pipe_mix_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
+                            float* __restrict__ part, size_t T, const void* aux, float* ring, uint32_t ring_cap, const float* __restrict__ panw) {
+    constexpr PipePlan P = pipe_plan<G>(0);
+    if constexpr (P.S >= 1 && (MIX == MIX_SUM || G::OUT == 1)) render_pipe_body<G, MODE, P.S, P.K1, P.K2, 4, MIX>(slots, stride, V, in, part, T, aux, ring, ring_cap, panw);
+}
 template <class G, int MODE>
 FD_D void jit_pipe_planar_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
                                float* __restrict__ out, size_t T, size_t fstride, const void* aux, float* ring, uint32_t ring_cap) {

@@ -20,6 +20,9 @@
 
 namespace fd {
 
+int jit_compile_src(const std::string& src, const std::string& type_expr, std::vector<char>* code, std::string* log);
+std::string jit_source_mix(const std::string& type_expr, const std::string& prelude);
+
 namespace {
 
 std::string lib_dir() {
@@ -40,6 +43,8 @@ bool read_file(const std::string& path, std::string* out) {
     *out = ss.str();
     return true;
 }
+
+struct JitMix;
 
 // One compiled graph: the code object plus, per HIP device, the module loaded on it (hipModule_t belongs to a device;
 // a process may keep banks of the same kind on several GPUs, fdsp_bank_create_on).  Loaded lazily under a mutex.
@@ -65,6 +70,10 @@ struct JitModule {
     std::string type_expr, prelude;
     bool has_fast = false, fast_failed = false;
     std::shared_ptr<JitModule> fast;
+    // the fused mix-down kernels (of G, and of FastOf<G>), compiled on first use
+    std::shared_ptr<JitMix> mix[2];
+    bool mix_failed[2] = {false, false};
+    int nout = 0;
     ~JitModule() {  // a module is unloaded with ITS device current (it was loaded on that device's context)
         int prev = -1;
         const bool have_prev = hipGetDevice(&prev) == hipSuccess;
@@ -113,6 +122,37 @@ struct JitModule {
             if (err) *err = "compiled graph is missing an entry point";
             return nullptr;
         }
+        return &f;
+    }
+};
+
+// The mix-down kernels of a compiled graph: code object + per-device module, like JitModule; fn[mix - 1][mode]
+struct JitMix {
+    std::vector<char> code;
+    std::mutex mu;
+    struct Dev { hipModule_t mod = nullptr; hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; bool loaded = false; } dev[JitModule::MAXD];
+    ~JitMix() {
+        int prev = -1;
+        const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+        for (int d = 0; d < JitModule::MAXD; d++)
+            if (dev[d].loaded && dev[d].mod && hipSetDevice(d) == hipSuccess) hipModuleUnload(dev[d].mod);
+        if (have_prev) hipSetDevice(prev);
+    }
+    const Dev* get() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= JitModule::MAXD) return nullptr;
+        std::lock_guard<std::mutex> lock(mu);
+        Dev& f = dev[d];
+        if (f.loaded) return f.mod ? &f : nullptr;
+        f.loaded = true;
+        if (hipModuleLoadData(&f.mod, code.data()) != hipSuccess) { f.mod = nullptr; return nullptr; }
+        bool ok = true;
+        for (int x = 0; x < 2 && ok; x++)
+            for (int m = 0; m < 2 && ok; m++) {
+                const std::string fn = "jit_pipe_mix_" + std::to_string(x + 1) + "_" + std::to_string(m);
+                ok = hipModuleGetFunction(&f.fn[x][m], f.mod, fn.c_str()) == hipSuccess;
+            }
+        if (!ok) { hipModuleUnload(f.mod); f.mod = nullptr; return nullptr; }
         return &f;
     }
 };
@@ -218,8 +258,30 @@ std::string jit_source(const std::string& type_expr, const std::string& prelude)
     return s;
 }
 
+// the fused mix-down kernels of a graph (fdsp_bank_process_mix): a module of their own, compiled the first time a bank of the kind mixes
+std::string jit_source_mix(const std::string& type_expr, const std::string& prelude) {
+    std::string s;
+    s += "#include \"fd_device.hpp\"\n";
+    if (!prelude.empty()) s += "namespace fd {\n" + prelude + "\n}\n";
+    s += "namespace fd { using JitG = " + type_expr + "; }\nusing fd::JitG;\n";
+    s += "constexpr int JIT_PIPE_THREADS = fd::JitPipeThreads<JitG>::v;\n";
+    for (int mix = 1; mix <= 2; mix++)
+        for (int mode = 0; mode < 2; mode++) {
+            std::string m = std::to_string(mode), x = std::to_string(mix);
+            s += "extern \"C\" __global__ __launch_bounds__(JIT_PIPE_THREADS) void jit_pipe_mix_" + x + "_" + m +
+                 "(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ part, "
+                 "size_t T, const void* aux, float* ring, uint32_t cap, const float* __restrict__ panw) {\n"
+                 "  fd::jit_pipe_mix_body<JitG, " + m + ", " + x + ">(slots, stride, V, in, part, T, aux, ring, cap, panw); }\n";
+        }
+    return s;
+}
+
 // Compile only (no device needed): returns the code object or an error log.
 int jit_compile_code(const std::string& type_expr, const std::string& prelude, std::vector<char>* code, std::string* log) {
+    return jit_compile_src(jit_source(type_expr, prelude), type_expr, code, log);
+}
+
+int jit_compile_src(const std::string& src, const std::string& type_expr, std::vector<char>* code, std::string* log) {
     const std::string dir = lib_dir() + "/csrc/";
     const char* names[3] = {"fd_math.hpp", "fd_nodes.hpp", "fd_device.hpp"};
     std::string hdr[3];
@@ -229,7 +291,6 @@ int jit_compile_code(const std::string& type_expr, const std::string& prelude, s
             return -1;
         }
     const char* hsrc[3] = {hdr[0].c_str(), hdr[1].c_str(), hdr[2].c_str()};
-    const std::string src = jit_source(type_expr, prelude);
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "fdsp_jit_graph.hip", 3, hsrc, names) != HIPRTC_SUCCESS) {
         *log = "hiprtcCreateProgram failed";
@@ -348,6 +409,45 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
             JitModule* m = jm->fast ? jm->fast.get() : jm.get();
             jit_render(m, slots, stride, V, in, outp, T, fstride, layout, mode, aux, ring, ring_cap, s);
         };
+    // render + mix-down in one launch (fdsp_bank_process_mix): graphs with a pipeline plan; the kernels are compiled on first use
+    jm->nout = meta[1];
+    auto mix_launch = [jm](int which, float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, int mix, int mode,
+                           const void* aux, float* ring, uint32_t ring_cap, const float* panw, hipStream_t s) -> bool {
+        if (V == 0 || T == 0) return true;
+        if (jm->pipe_stages < 1 || (mix == MIX_PAN && jm->nout != 1)) return false;
+        {
+            std::lock_guard<std::mutex> lock(jm->mu);
+            if (!jm->mix[which] && !jm->mix_failed[which]) {
+                auto mm = std::make_shared<JitMix>();
+                std::string log;
+                const std::string type = which ? "typename fd::FastOf<" + jm->type_expr + ">::type" : jm->type_expr;
+                if (jit_compile_src(jit_source_mix(type, jm->prelude), jm->type_expr, &mm->code, &log) == 0) jm->mix[which] = mm;
+                else {
+                    jm->mix_failed[which] = true;
+                    fprintf(stderr, "fundsp_hip: the fused mix-down kernels of this graph failed to compile: %s\n", log.c_str());
+                }
+            }
+        }
+        JitMix* mm = jm->mix[which].get();
+        if (!mm) return false;
+        const JitMix::Dev* f = mm->get();
+        if (!f) { jit_launch_failed(); return true; }
+        void* pargs[] = {&slots, &stride, &V, &in, &part, &T, &aux, &ring, &ring_cap, &panw};
+        hipModuleLaunchKernel(f->fn[mix - 1][mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_threads, 1, 1, 0, s, pargs, nullptr);
+        tl_opts.last_kernel = LK_PIPELINE;
+        return true;
+    };
+    if (jm->pipe_stages >= 1) {
+        out->render_mix = [mix_launch](float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, int mix, int mode,
+                                       const void* aux, float* ring, uint32_t ring_cap, const float* panw, hipStream_t s) {
+            return mix_launch(0, slots, stride, V, in, part, T, mix, mode, aux, ring, ring_cap, panw, s);
+        };
+        if (jm->has_fast)
+            out->render_mix_fast = [mix_launch](float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, int mix, int mode,
+                                                const void* aux, float* ring, uint32_t ring_cap, const float* panw, hipStream_t s) {
+                return mix_launch(1, slots, stride, V, in, part, T, mix, mode, aux, ring, ring_cap, panw, s);
+            };
+    }
     out->render_events = [jm](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T,
                               const double* ev, const int* fade, double time0, double sr, int mode, const void* aux,
                               float* ring, uint32_t ring_cap, hipStream_t s) {

@@ -317,6 +317,10 @@ int fdsp_mix_stereo(const float* d_voices, const float* d_pan, float* d_mix, siz
  * of the mix-down for graphs that already end in a Panner). */
 int fdsp_sum_voices(const float* d_in, float* d_out, size_t channels, size_t frames, size_t voices, void* stream);
 
+/* Sum over the instances of a PLANAR render d_in [instances][rows] (rows = channels x frame_stride: reverb_stereo banks, planar
+ * voice banks) -> d_out [rows]: the aligned binary tree of the summation order above, taken over the instances. */
+int fdsp_sum_instances(const float* d_in, float* d_out, size_t rows, size_t instances, void* stream);
+
 /* ---- the exchange step across GPUs: all-reduce(sum) of the per-GPU partial mixes over RCCL / xGMI ----
  * The only collective of the path: `count` = 2 * frames floats per GPU, latency-bound, issued once per launch.  It runs
  * on the communicator's own side stream, ordered behind the work already queued on `after_stream` (the mix kernel), so

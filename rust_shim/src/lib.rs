@@ -75,6 +75,7 @@ pub mod ffi {
         pub fn fdsp_bank_mix_reserve(bank: *mut FdspBank, frames: usize) -> c_int; // AudioNode::allocate for the mix path
         pub fn fdsp_bank_synchronize(bank: *mut FdspBank) -> c_int;
         pub fn fdsp_sum_voices(d_in: *const f32, d_out: *mut f32, channels: usize, frames: usize, voices: usize, stream: *mut c_void) -> c_int;
+        pub fn fdsp_sum_instances(d_in: *const f32, d_out: *mut f32, rows: usize, instances: usize, stream: *mut c_void) -> c_int;
         pub fn fdsp_mix_stereo(d_voices: *const f32, d_pan: *const f32, d_mix: *mut f32, frames: usize, voices: usize, stream: *mut c_void) -> c_int;
         pub fn fdsp_comm_create_local(n: c_int, devices: *const c_int, out: *mut *mut FdspComm) -> c_int;
         pub fn fdsp_comm_unique_id(id128: *mut c_void) -> c_int;

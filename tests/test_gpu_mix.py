@@ -178,3 +178,90 @@ def test_noise_biquad_sum_mix(gpu):
     mix = b.process_mix(T, mix=MIX_SUM).cpu().numpy()
     out = ref.process(T)
     assert_bit_equal(mix, gpu.sum_voices(out).cpu().numpy(), "config-2 voices: fused sum vs sum_voices(voice-out)")
+
+
+def test_shards_add_up_to_the_whole_bank_exactly_at_aligned_splits(gpu):
+    """contiguous voice shards, one all-reduce of the partial mixes.  The groups' partials are added in an ALIGNED
+    binary tree, so a bank split at a power-of-two group boundary reproduces the whole bank's mix with ONE addition per sample:
+    mix(whole) == mix(first half) + mix(second half) bit for bit (what a 2-GPU all-reduce computes); an unaligned split agrees
+    within the re-ordering tolerance."""
+    V, T = 64 * 16, 64 * 5
+    whole, p, pan = fm_bank(gpu, V)
+    want = whole.process_mix(T, mix=MIX_PAN).cpu().numpy()
+    halves = []
+    for first in (0, V // 2):
+        b, _, _ = fm_bank(gpu, V // 2, voice0=first)
+        halves.append(b.process_mix(T, mix=MIX_PAN).cpu().numpy())
+    assert_bit_equal(want, halves[0] + halves[1], "whole == half + half at an aligned split")
+    parts = []
+    for first, n in ((0, 64 * 5 + 3), (64 * 5 + 3, V - (64 * 5 + 3))):
+        b, _, _ = fm_bank(gpu, n, voice0=first)
+        parts.append(b.process_mix(T, mix=MIX_PAN).cpu().numpy())
+    assert np.abs(want - (parts[0] + parts[1])).max() <= np.sqrt(V) * 6e-8 * 4.0 + 2.0 ** -22 * np.abs(want).max()
+
+
+def test_run_time_compiled_graph_mixes(gpu):
+    """fdsp_bank_process_mix on a run-time compiled graph (the Rust front door's path): the mix kernels are compiled on first use."""
+    import torch
+    from fundsp_amd import graph as G
+
+    V, T = 64 * 5 + 9, 64 * 6 + 5
+    f = (110.0 * 2.0 ** (3.0 * W.rnd1(np.arange(V, dtype=np.uint64)))).astype(np.float32)
+    g = (G.dc(f) >> G.sine()) * 0.5 >> G.lowpass_hz(1200.0, 0.8)
+    b = gpu.Bank.from_graph(g, V, sample_rate=SR)
+    b.set_seed(np.arange(V, dtype=np.uint64) + 11)
+    assert b.get_option("has_fused_mix") == 1
+    ref = b.clone()
+    pan = np.linspace(-1, 1, V).astype(np.float32)
+    b.set_pan(pan)
+    mix = b.process_mix(T, mix=MIX_PAN).cpu().numpy()
+    out = ref.process(T)
+    assert_bit_equal(mix, gpu.mix_stereo(out[0], torch.from_numpy(pan).cuda()).cpu().numpy(), "run-time compiled graph: fused vs mix_stereo(voice-out)")
+    summed = b.clone()
+    s1 = summed.process_mix(T, mix=MIX_SUM).cpu().numpy()
+    o2 = b.process(T)
+    assert_bit_equal(s1, gpu.sum_voices(o2).cpu().numpy(), "the next block, MIX_SUM")
+
+
+def test_mix_on_a_caller_stream_and_in_a_hip_graph(gpu):
+    """Stream rules of fdsp_bank_process: a caller's stream, and a stream capture after fdsp_bank_mix_reserve / set_pan (no allocation
+    inside the capture); an unreserved bank refuses to mix during a capture."""
+    import torch
+
+    V, T = 64 * 4, 64
+    b, p, pan = fm_bank(gpu, V)
+    ref = b.clone()
+    want = np.concatenate([ref.process_mix(T, mix=MIX_PAN).cpu().numpy() for _ in range(3)], axis=1)
+    b.mix_reserve(T)
+    outs = [torch.empty((2, T), dtype=torch.float32, device="cuda") for _ in range(3)]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for k in range(3):
+                b.process_mix(T, mix=MIX_PAN, out=outs[k])
+        g.replay()
+    torch.cuda.synchronize()
+    assert_bit_equal(np.concatenate([o.cpu().numpy() for o in outs], axis=1), want, "three captured mix launches == three plain ones")
+    fresh, _, _ = fm_bank(gpu, V)
+    with torch.cuda.stream(s):
+        g2 = torch.cuda.CUDAGraph()
+        with pytest.raises(gpu.FdspError):
+            with torch.cuda.graph(g2, stream=s):
+                fresh.process_mix(T, mix=MIX_SUM, out=outs[0])
+
+
+def test_sum_instances_planar(gpu):
+    import torch
+
+    n, ch, fs = 37, 2, 96
+    rng = np.random.default_rng(9)
+    x = (rng.random((n, ch, fs), dtype=np.float32) - 0.5).astype(np.float32)
+    got = gpu.sum_instances(torch.from_numpy(x).cuda()).cpu().numpy()
+    level = [x[i] for i in range(n)]
+    while len(level) > 1:
+        nxt = [level[i] + level[i + 1] for i in range(0, len(level) - 1, 2)]
+        if len(level) & 1:
+            nxt.append(level[-1])
+        level = nxt
+    assert_bit_equal(got, level[0], "sum over instances: aligned binary tree")
