@@ -1084,12 +1084,18 @@ FD_HD int wt_table_index(const WtSet* t, int hint, float frequency) {  // :189-2
 #ifndef FD_WT_SAME
 #define FD_WT_SAME 0
 #endif
+#ifndef FD_WT_FIXED
+#define FD_WT_FIXED 0
+#endif
 struct Tap4 { float a0, a1, a2, a3, w; };
 // the pieces of wt_tap: index + interpolation weight, then the four floats from HBM / from the kernel's LDS copy
 FD_HD float wt_tap_index(uint32_t mask, float phase, uint32_t& i1) {
     float p = (float)(mask + 1u) * phase;
     uint32_t i = (uint32_t)p;
     i1 = i & mask;
+#if FD_WT_FIXED   // measurement only (NOT a renderer): every lane reads the same four floats of its table at every frame (perfect temporal reuse)
+    i1 = (i & mask) & 3u;
+#endif
     return p - (float)i;
 }
 FD_HD Tap4 wt_tap_mem(const float* __restrict__ at, float w) {  // (by value: a Tap4 passed by reference ended up as a memory object)
@@ -1116,6 +1122,9 @@ FD_HD Tap4 wt_tap(const float* __restrict__ tab, uint32_t mask, float phase) {  
     Tap4 t;
     t.w = p - (float)i1;
     i1 = i1 & mask;
+#if FD_WT_FIXED
+    i1 = i1 & 3u;
+#endif
     // padded layout: tab[i1 + 0..3] = t[i1-1], t[i1], t[i1+1], t[i1+2]
 #if defined(__HIP_DEVICE_COMPILE__)
     // through an explicit global-address-space pointer: on a generic pointer (the table address comes out of a struct
