@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import oracle as O
+from mix_order import mix_order_reference
 from fundsp_amd import LAYOUT_VOICE_MINOR, MIX_PAN, MIX_SUM, MODE_PROCESS, MODE_TICK
 from fundsp_amd import workloads as W
 from test_gpu_parity import assert_bit_equal
@@ -38,32 +39,6 @@ def fm_bank(gpu, V, voice0=0):
     return b, p, pan
 
 
-def test_summation_order_statement():
-    """mix_order_reference against a literal, loop-by-loop reading of include/fundsp_hip.h on a small ragged case."""
-    from fundsp_amd import mix_order_reference
-    rng = np.random.default_rng(1)
-    for V in (1, 15, 64, 65, 200, 64 * 5, 64 * 6 + 3):
-        x = (rng.random(V, dtype=np.float32) - 0.5).astype(np.float32)
-        G = (V + 63) // 64
-        xp = np.zeros(G * 64, dtype=np.float32)
-        xp[:V] = x
-        parts = []
-        for g in range(G):
-            S = []
-            for q in range(4):
-                s = xp[g * 64 + q * 16]
-                for j in range(1, 16):
-                    s = np.float32(s + xp[g * 64 + q * 16 + j])
-                S.append(s)
-            parts.append(np.float32(np.float32(S[0] + S[1]) + np.float32(S[2] + S[3])))
-        while len(parts) > 1:
-            nxt = [np.float32(parts[i] + parts[i + 1]) for i in range(0, len(parts) - 1, 2)]
-            if len(parts) & 1:
-                nxt.append(parts[-1])
-            parts = nxt
-        assert np.float32(mix_order_reference(x)).view(np.uint32) == np.float32(parts[0]).view(np.uint32), V
-
-
 @pytest.mark.parametrize("V,T", [(200, 64 * 5 + 13), (64 * 7, 64 * 4), (8192, 64 * 6), (32768, 64 * 4 + 9)])
 @pytest.mark.parametrize("mode", [MODE_PROCESS, MODE_TICK])
 def test_fm_pan_mix_equals_mix_of_voice_out(gpu, V, T, mode):
@@ -83,8 +58,8 @@ def test_fm_pan_mix_equals_mix_of_voice_out(gpu, V, T, mode):
     ang = (np.clip(pan, -1, 1).astype(np.float32) + np.float32(1)) * (np.float32(np.pi) * np.float32(0.25))
     wl = np.array([O.lib().o_math_cosf(float(a)) for a in ang], dtype=np.float32)
     wr = np.array([O.lib().o_math_sinf(float(a)) for a in ang], dtype=np.float32)
-    assert_bit_equal(mix[0], gpu.mix_order_reference(x * wl[None, :]), "left vs the order's statement")
-    assert_bit_equal(mix[1], gpu.mix_order_reference(x * wr[None, :]), "right vs the order's statement")
+    assert_bit_equal(mix[0], mix_order_reference(x * wl[None, :]), "left vs the order's statement")
+    assert_bit_equal(mix[1], mix_order_reference(x * wr[None, :]), "right vs the order's statement")
     # the voices' state after a fused launch is the state after a voice-out launch
     assert_bit_equal(b.get_state(), ref.get_state(), "state after the launch")
     assert np.abs(mix).max() > 0.1
@@ -102,7 +77,7 @@ def test_fm_mix_against_the_oracles_serial_mix(gpu):
     serial = np.stack([(want * wl[None, :]).astype(np.float64).sum(axis=1), (want * wr[None, :]).astype(np.float64).sum(axis=1)])
     assert np.abs(mix - serial).max() <= serial_tolerance(want, serial)
     # ... and exactly the order's statement applied to the oracle's own samples (the voices are bit-exact)
-    assert_bit_equal(mix[0], gpu.mix_order_reference(want * wl[None, :]), "left vs oracle voices in the stated order")
+    assert_bit_equal(mix[0], mix_order_reference(want * wl[None, :]), "left vs oracle voices in the stated order")
 
 
 def test_fm_sum_mix_mono(gpu):
@@ -131,7 +106,7 @@ def test_config4_mix_equals_sum_of_voice_out(gpu, tables, V, T):
     out = ref.process(T, gate)                                             # [2][T][V]
     assert mix.shape == (2, T)
     assert_bit_equal(mix.cpu().numpy(), gpu.sum_voices(out).cpu().numpy(), f"fused vs sum_voices(voice-out), V={V}")
-    assert_bit_equal(mix.cpu().numpy(), gpu.mix_order_reference(out.cpu().numpy()), "vs the order's statement")
+    assert_bit_equal(mix.cpu().numpy(), mix_order_reference(out.cpu().numpy()), "vs the order's statement")
     assert_bit_equal(b.get_state(), ref.get_state(), "state after the launch")
     assert np.abs(mix.cpu().numpy()).max() > 0.05
     with pytest.raises(gpu.FdspError):
@@ -151,7 +126,7 @@ def test_config4_mix_small_against_oracle_voices(gpu, tables):
     gate = torch.from_numpy(np.broadcast_to(g1[None, :, None], (1, T, V)).copy()).cuda()
     mix = b.process_mix(T, gate, mix=MIX_SUM).cpu().numpy()
     voices = np.stack([oracle_render(config4_oracle_voice(p, v, adsr), g1[None, :], T, MODE_PROCESS) for v in range(V)], axis=-1)  # [2][T][V]
-    assert_bit_equal(mix, gpu.mix_order_reference(voices), "fused mix vs the oracle's voices in the stated order")
+    assert_bit_equal(mix, mix_order_reference(voices), "fused mix vs the oracle's voices in the stated order")
     assert np.abs(mix - voices.astype(np.float64).sum(axis=-1)).max() <= serial_tolerance(voices, mix)
 
 

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import oracle as O
+from mix_order import mix_order_reference
 from fundsp_amd import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS, MODE_TICK
 from fundsp_amd import workloads as W
 
@@ -414,7 +415,7 @@ def test_mix_stereo(gpu):
     wr = np.array([O.lib().o_math_sinf(float(a)) for a in ang], dtype=np.float32)
     # the mix-down's fixed summation order (include/fundsp_hip.h): weights first, like Panner::tick
     def tree(w):
-        return gpu.mix_order_reference(x * w[None, :])
+        return mix_order_reference(x * w[None, :])
     assert_bit_equal(mix[0], tree(wl), "mix L")
     assert_bit_equal(mix[1], tree(wr), "mix R")
 
