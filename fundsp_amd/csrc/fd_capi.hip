@@ -498,9 +498,14 @@ int check_range(const fdsp_bank* b, size_t first, size_t count) {
 }
 
 // pan weights of Panner (pan.rs:13-17) for the mix-down
-__global__ void k_pan_weights(const float* pan, float* wl, float* wr, size_t V) {
+__global__ void k_pan_weights(const float* pan, float* wl, float* wr, size_t V, size_t live = ~(size_t)0) {
     size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
+    if (v >= live) {  // padding behind a bank's last voice: weight 0, 0 (a padded voice contributes +0.0 to the mix)
+        wl[v] = 0.0f;
+        wr[v] = 0.0f;
+        return;
+    }
     float value = pan ? pan[v] : 0.0f;
     float c = value < -1.0f ? -1.0f : (value > 1.0f ? 1.0f : value);  // clamp11
     float angle = (c + 1.0f) * (fd::F32_PI * 0.25f);
@@ -1305,7 +1310,7 @@ int ensure_panw(fdsp_bank* b) {
     hipError_t e = hipMalloc((void**)&b->panw, 2 * b->stride * sizeof(float));
     if (e != hipSuccess) return fail(FDSP_ENOMEM, std::string("hipMalloc(pan weights): ") + hipGetErrorString(e));
     hipLaunchKernelGGL(k_pan_weights, dim3((unsigned)((b->stride + 255) / 256)), dim3(256), 0, b->stream, (const float*)nullptr, b->panw,
-                       b->panw + b->stride, b->stride);
+                       b->panw + b->stride, b->stride, b->V);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(b->stream));
     return FDSP_OK;
@@ -1336,7 +1341,7 @@ int fdsp_bank_set_pan(fdsp_bank* b, const float* h_pan, size_t first, size_t cou
     hipError_t e = hipMemcpyAsync(d, h_pan, count * sizeof(float), hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_pan_weights, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, b->stream, (const float*)d, b->panw + first,
-                           b->panw + b->stride + first, count);
+                           b->panw + b->stride + first, count, ~(size_t)0);
         e = hipGetLastError();
     }
     hipFreeAsync(d, b->stream);
@@ -1635,7 +1640,7 @@ int fdsp_mix_stereo(const float* d_voices, const float* d_pan, float* d_mix, siz
     float* w = nullptr;  // [2][voices] weights, then [G][2][frames] partial mixes
     HIPCHK(hipMallocAsync((void**)&w, (2 * voices + G * 2 * frames) * sizeof(float), s));
     hipLaunchKernelGGL(k_pan_weights, dim3((unsigned)((voices + 255) / 256)), dim3(256), 0, s, d_pan, w, w + voices,
-                       voices);
+                       voices, ~(size_t)0);
     hipError_t e = launch_mix_rows<true>(d_voices, w, w + voices, w + 2 * voices, d_mix, frames, voices, s);
     hipFreeAsync(w, s);
     HIPCHK(e);

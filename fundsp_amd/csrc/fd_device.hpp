@@ -1054,20 +1054,27 @@ struct MixGeom {  // frames per chunk: what fits the 32 KiB the pipeline's own t
     static constexpr bool ok = MC >= 8;
 };
 struct MixLane {   // what the last stage's wave knows about its mix tile
-    float* tile;   // LDS: [NM][MC][MIX_ROW]
+    float* tile;   // LDS: [tile channels][MC][MIX_ROW]; MIX_PAN keeps ONE channel (the mono samples) and pans when it flushes
     int col;       // this lane's column: its voice's, or the padding column 64 for lanes past the end of the bank
-    float wl, wr;  // MIX_PAN: equal-power weights of this lane's voice (pan.rs:13-17)
+    // MIX_PAN: the equal-power weights (left, right; pan.rs:13-17) of the 16 voices of the quarter this lane adds up when it
+    // flushes -- quarter = lane & 3 in every pass, so they are loaded once per launch (voices past the end of the bank: 0, 0) --
+    // in registers (OL == 3), or, where 32 more registers would spill (the 14-wave time-split workgroup), in LDS: wlds[voice] (OL == 4)
+    v2f w[16];
+    const v2f* wlds;
 };
 FD_D float mix_quad(float x, int ctrl) {
     return u2f((uint32_t)(ctrl == 0 ? __builtin_amdgcn_update_dpp((int)f2u(x), (int)f2u(x), 0xB1, 0xF, 0xF, false)     // quad_perm [1,0,3,2]
                                     : __builtin_amdgcn_update_dpp((int)f2u(x), (int)f2u(x), 0x4E, 0xF, 0xF, false)));  // quad_perm [2,3,0,1]
 }
 // the chunk's first `nf` frames -> dst[channel * T + frame]; every lane of the wave takes part
-template <int NM, int MC>
+template <int NM, int MC, bool ROLL = false>
 FD_D void mix_flush(const float* tile, float* dst, size_t T, int nf, int lane) {
     constexpr int E = NM * MC;  // (channel, frame) entries of the tile
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the tile was written by other lanes of this wave (LDS operations of a wave execute in order)
-#pragma unroll
+    // ROLL: the passes stay a loop.  Unrolled, the ILP scheduling strategies the time-split kernels are built with hoist every pass's tile
+    // reads to the top (214 VGPRs in the one-group kernel: fine at 8 waves per CU and 0.24 ms faster than the loop; 137 SPILLS in the
+    // two-group one, whose 14 waves leave 128 registers each: there the loop is the faster form, profiles/r04_mix_bench_d.txt)
+#pragma unroll(ROLL ? 1 : 4)
     for (int p = 0; p < (E * 4 + 63) / 64; p++) {
         const int idx = p * 64 + lane, e = idx >> 2, q = idx & 3;
         const bool on = (E * 4) % 64 == 0 || e < E;
@@ -1084,6 +1091,40 @@ FD_D void mix_flush(const float* tile, float* dst, size_t T, int nf, int lane) {
         if (on && q == 0 && f < nf) dst[(size_t)ch * T + f] = u;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // ... and the next chunk's samples must not overtake these reads
+}
+
+// MIX_PAN: the tile holds the mono samples of MC frames; lane (frame, quarter) multiplies its quarter's 16 samples by their voices'
+// weights -- left and right as one <2 x float> product, rounded like Panner::tick's `weight * sample` -- and adds them up one after the
+// other (the same order per channel as mix_flush), the quarters through DPP; dst[frame] = left, dst[T + frame] = right.
+template <int MC, bool WREG, bool ROLL = false>
+FD_D void mix_flush_pan(const float* tile, float* dst, size_t T, int nf, int lane, const v2f* w, const v2f* wlds) {
+    constexpr int E = MC;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll(ROLL ? 1 : 4)
+    for (int p = 0; p < (E * 4 + 63) / 64; p++) {
+        const int idx = p * 64 + lane, e = idx >> 2, q = idx & 3;
+        const bool on = (E * 4) % 64 == 0 || e < E;
+        const float4* row = reinterpret_cast<const float4*>(tile + (on ? e : 0) * MIX_ROW + q * 16);
+        v2f s = v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // four samples at a time: the running sums are the only long-lived registers
+            const float4 xq = row[k];
+            const float x[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const v2f wj = WREG ? w[4 * k + j] : wlds[q * 16 + 4 * k + j];
+                const v2f t = splat2(x[j]) * wj;
+                s = (k == 0 && j == 0) ? t : s + t;
+            }
+        }
+        const float tl = s.x + mix_quad(s.x, 0), tr = s.y + mix_quad(s.y, 0);
+        const float ul = tl + mix_quad(tl, 1), ur = tr + mix_quad(tr, 1);
+        if (on && q == 0 && e < nf) {
+            dst[e] = ul;
+            dst[T + e] = ur;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
 // One stage's work on one tile: frames [lo, hi) of the block that starts at t0 (size / full as in
@@ -1103,16 +1144,16 @@ FD_D void mix_flush(const float* tile, float* dst, size_t T, int nf, int lane) {
 // NP > 1 (a FIRST stage run in NP waves, render_pipe_body NA): every wave walks the whole tile, wave `part` EVALUATES the SIMD
 // items of its NP-th of the tile and advances the state through the others (SG::skip2) -- as ts_stage does for 64-frame blocks;
 // the remainder samples of a ragged block are computed by every part (same values, same hand-over cells).
-template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST, int FS = 64, int OL = 0, bool PF = (FD_PIPE_PREFETCH != 0), int BAL = 0, int MC = 0, int NP = 1>
+template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST, int FS = 64, int OL = 0, bool PF = (FD_PIPE_PREFETCH != 0), int BAL = 0, int MC = 0, int NP = 1, bool MROLL = false>
 FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_t V, int lane, float* outw,
                      const float* fin, v2f (*hin)[SUB / 2][64], v2f (*hout)[SUB / 2][64], int* bal = nullptr, const MixLane* mx = nullptr, int part = 0) {
     static_assert(NP == 1 || (FIRST && !LAST && FD_ITEM_LOOP && BAL == 0 && (SUB / 8) % NP == 0), "split stages: the first of several, whole items per part");
     constexpr int NI = SG::IN, NO = SG::OUT, NG = G::IN;
     constexpr bool GIN = !FIRST && SG::USES_GIN;
     constexpr bool MIXO = OL >= 2;
-    constexpr int NM = OL == 3 ? 2 : NO;  // mix channels
+    constexpr int NM = OL >= 3 ? 2 : NO;  // mix channels
     static_assert(!MIXO || (LAST && MC >= 8 && (MC & (MC - 1)) == 0 && FD_ITEM_LOOP), "mix-down: last stage, chunks of 8 .. 64 frames");
-    static_assert(OL != 3 || NO == 1, "the pan mix-down takes a mono graph");
+    static_assert(OL < 3 || NO == 1, "the pan mix-down takes a mono graph");
     static_assert(LAST || NO <= W, "hand-over tile too narrow");
     static_assert(FIRST || NI <= W, "hand-over tile too narrow");
     const int lo = h * SUB;
@@ -1141,16 +1182,14 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
         } else if constexpr (OL == 1) outw[(c * SUB + (i - lo)) * FS + lane] = x;
         else {
             float* cell = mx->tile + ((i - lo) & (MC - 1)) * MIX_ROW + mx->col;
-            if constexpr (OL == 3) {
-                cell[0] = x * mx->wl;
-                cell[MC * MIX_ROW] = x * mx->wr;
-            } else cell[c * MC * MIX_ROW] = x;
+            cell[c * MC * MIX_ROW] = x;  // (MIX_PAN: NO == 1, the mono sample; the weights come in when the chunk is flushed)
         }
     };
     auto flush_at = [&](int iend) {  // mix-down: the chunk that ends with frame iend - 1 of the block leaves for HBM
         if constexpr (MIXO) {
             const int nf = ((iend - lo - 1) & (MC - 1)) + 1;
-            mix_flush<NM, MC>(mx->tile, outw + (t0 + iend - nf), T, nf, lane);
+            if constexpr (OL >= 3) mix_flush_pan<MC, OL == 3, MROLL>(mx->tile, outw + (t0 + iend - nf), T, nf, lane, mx->w, mx->wlds);
+            else mix_flush<NM, MC, MROLL>(mx->tile, outw + (t0 + iend - nf), T, nf, lane);
         }
     };
     if (h == 0) SG::begin(g, size);
@@ -1436,12 +1475,13 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     const size_t rounds = ntiles + (S - 1) + (FEED ? 1 : 0);
     const float* inw = in + v0;  // wave-uniform bases + lane
     constexpr int NM = MIX == MIX_PAN ? 2 : G::OUT;  // mix channels
-    using MG = MixGeom<NM, GPW, SUB>;
+    constexpr int NTC = MIX == MIX_PAN ? 1 : G::OUT;  // channels of the LDS tile (MIX_PAN parks the mono samples)
+    using MG = MixGeom<NTC, GPW, SUB>;
     constexpr int OLM = MIX == MIX_NONE ? 0 : (MIX == MIX_PAN ? 3 : 2), MCM = MIX == MIX_NONE ? 0 : MG::MC;
     static_assert(MIX == MIX_NONE || MG::ok, "mix tile does not fit");
     float* outw = MIX == MIX_NONE ? out + v0 : out + (v0 / 64) * (size_t)NM * T;  // voice-out rows | this group's partial mix
     __shared__ __attribute__((aligned(16))) float mixt[MIX == MIX_NONE ? 1 : GPW][MIX == MIX_NONE ? 4 : MG::FLOATS];
-    MixLane mxl{&mixt[MIX == MIX_NONE ? 0 : grp][0], active ? lane : 64, 0.0f, 0.0f};
+    MixLane mxl{&mixt[MIX == MIX_NONE ? 0 : grp][0], active ? lane : 64, {}, nullptr};
     const bool run = live && (MIX != MIX_NONE || active);  // (wave-uniform in a mix-down launch)
 
 #if FD_KNOCK
@@ -1490,9 +1530,14 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
         if (stage == S - 1) {  // the wave that owns the group's mix tile: silence in the columns no lane will write
             if (!active) {
 #pragma unroll 1
-                for (int r = 0; r < NM * MCM; r++) mxl.tile[r * MIX_ROW + lane] = 0.0f;
+                for (int r = 0; r < NTC * MCM; r++) mxl.tile[r * MIX_ROW + lane] = 0.0f;
             }
-            if (MIX == MIX_PAN && live && active) { mxl.wl = panw[v]; mxl.wr = panw[stride + v]; }
+            if constexpr (MIX == MIX_PAN) {  // the weights of the quarter this lane adds up (panw is padded to `stride` with zeros)
+                if (live) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) mxl.w[j] = v2f{panw[v0 + (lane & 3) * 16 + j], panw[stride + v0 + (lane & 3) * 16 + j]};
+                }
+            }
         }
     }
     // The rounds, for the graph type GG: G itself, or its lowpass-specialised twin LpOf<G> (same registers, the
@@ -1960,12 +2005,15 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
     const size_t nblocks = T / 64, rounds = nblocks + 2;
     // fused mix-down (see render_pipe_body): the filter wave parks its samples in the group's mix tile, `out` holds the partial mixes
     constexpr int NM = MIX == MIX_PAN ? 2 : G::OUT;
-    using MG = MixGeom<NM, GPW, 64>;
-    constexpr int OLM = MIX == MIX_NONE ? 0 : (MIX == MIX_PAN ? 3 : 2), MCM = MIX == MIX_NONE ? 0 : MG::MC;
+    constexpr int NTC = MIX == MIX_PAN ? 1 : G::OUT;
+    using MG = MixGeom<NTC, GPW, 64>;
+    constexpr bool WLDS = MIX == MIX_PAN && GPW == 2;  // 14 waves per workgroup: 128 registers per wave, the weights live in LDS
+    constexpr int OLM = MIX == MIX_NONE ? 0 : (MIX == MIX_PAN ? (WLDS ? 4 : 3) : 2), MCM = MIX == MIX_NONE ? 0 : MG::MC;
     static_assert(MIX == MIX_NONE || MG::ok, "mix tile does not fit");
     float* outw = MIX == MIX_NONE ? out + v0 : out + (v0 / 64) * (size_t)NM * T;
     __shared__ __attribute__((aligned(16))) float mixt[MIX == MIX_NONE ? 1 : GPW][MIX == MIX_NONE ? 4 : MG::FLOATS];
-    MixLane mxl{&mixt[MIX == MIX_NONE ? 0 : grp][0], active ? lane : 64, 0.0f, 0.0f};
+    __shared__ __attribute__((aligned(16))) v2f mixw[WLDS ? GPW : 1][WLDS ? 64 : 1];
+    MixLane mxl{&mixt[MIX == MIX_NONE ? 0 : grp][0], active ? lane : 64, {}, nullptr};
     const bool run = live && (MIX != MIX_NONE || active);
     G g{};
     Ctx ctx{static_cast<const Aux*>(aux), nullptr, 0, stride, 0};
@@ -1979,9 +2027,17 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
         if (stage == 2) {
             if (!active) {
 #pragma unroll 1
-                for (int r = 0; r < NM * MCM; r++) mxl.tile[r * MIX_ROW + lane] = 0.0f;
+                for (int r = 0; r < NTC * MCM; r++) mxl.tile[r * MIX_ROW + lane] = 0.0f;
             }
-            if (MIX == MIX_PAN && live && active) { mxl.wl = panw[v]; mxl.wr = panw[stride + v]; }
+            if constexpr (MIX == MIX_PAN) {  // the weights of the quarter this lane adds up (panw is padded to `stride` with zeros)
+                if constexpr (WLDS) {
+                    if (live) mixw[grp][lane] = v2f{panw[v0 + lane], panw[stride + v0 + lane]};
+                    mxl.wlds = &mixw[grp][0];
+                } else if (live) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) mxl.w[j] = v2f{panw[v0 + (lane & 3) * 16 + j], panw[stride + v0 + (lane & 3) * 16 + j]};
+                }
+            }
         }
     }
     auto rounds_of = [&](auto* tag) {
@@ -2001,7 +2057,7 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
         };
         if (stage == 0) loop([&](size_t j) { ts_stage<T0, GG, true, W>(gg, R::cut[0][part], R::cut[0][part + 1], lane, nullptr, hand[grp][0][j & 1]); });
         else if (stage == 1) loop([&](size_t j) { ts_stage<T1, GG, false, W>(gg, R::cut[1][part], R::cut[1][part + 1], lane, hand[grp][0][j & 1], hand[grp][1][j & 1]); });
-        else loop([&](size_t j) { pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, OLM, FD_PIPE_PREFETCH != 0, 0, MCM>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr, nullptr, &mxl); });
+        else loop([&](size_t j) { pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, OLM, FD_PIPE_PREFETCH != 0, 0, MCM, 1, (GPW == 2)>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr, nullptr, &mxl); });
 #else
         for (size_t it = 0; it < rounds; it++) {
             if (run && it >= (size_t)stage && it - stage < nblocks && !(FD_KNOCK_TS == 1 && stage == 2) && !(FD_KNOCK_TS == 2 && stage < 2) &&
@@ -2009,7 +2065,7 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
                 const size_t j = it - stage;  // the block this stage works on in this round
                 if (stage == 0) ts_stage<T0, GG, true, W>(gg, R::cut[0][part], R::cut[0][part + 1], lane, nullptr, hand[grp][0][j & 1]);
                 else if (stage == 1) ts_stage<T1, GG, false, W>(gg, R::cut[1][part], R::cut[1][part + 1], lane, hand[grp][0][j & 1], hand[grp][1][j & 1]);
-                else pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, OLM, FD_PIPE_PREFETCH != 0, 0, MCM>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr, nullptr, &mxl);
+                else pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, OLM, FD_PIPE_PREFETCH != 0, 0, MCM, 1, (GPW == 2)>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr, nullptr, &mxl);
             }
             __syncthreads();
         }
