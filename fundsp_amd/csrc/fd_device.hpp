@@ -1477,10 +1477,15 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     constexpr int NM = MIX == MIX_PAN ? 2 : G::OUT;  // mix channels
     constexpr int NTC = MIX == MIX_PAN ? 1 : G::OUT;  // channels of the LDS tile (MIX_PAN parks the mono samples)
     using MG = MixGeom<NTC, GPW, SUB>;
-    constexpr int OLM = MIX == MIX_NONE ? 0 : (MIX == MIX_PAN ? 3 : 2), MCM = MIX == MIX_NONE ? 0 : MG::MC;
+    // more than two waves per SIMD (workgroups of more than 8 waves) leave a wave 128 registers or fewer: the pan weights then live in LDS
+    // and the flush's passes stay a loop (as in the 14-wave time-split kernel)
+    constexpr bool TIGHT = GPW * ((FEED ? 1 : 0) + NA + S - 1) > 8;
+    constexpr bool WLDS = MIX == MIX_PAN && TIGHT;
+    constexpr int OLM = MIX == MIX_NONE ? 0 : (MIX == MIX_PAN ? (WLDS ? 4 : 3) : 2), MCM = MIX == MIX_NONE ? 0 : MG::MC;
     static_assert(MIX == MIX_NONE || MG::ok, "mix tile does not fit");
     float* outw = MIX == MIX_NONE ? out + v0 : out + (v0 / 64) * (size_t)NM * T;  // voice-out rows | this group's partial mix
     __shared__ __attribute__((aligned(16))) float mixt[MIX == MIX_NONE ? 1 : GPW][MIX == MIX_NONE ? 4 : MG::FLOATS];
+    __shared__ __attribute__((aligned(16))) v2f mixw[WLDS ? GPW : 1][WLDS ? 64 : 1];
     MixLane mxl{&mixt[MIX == MIX_NONE ? 0 : grp][0], active ? lane : 64, {}, nullptr};
     const bool run = live && (MIX != MIX_NONE || active);  // (wave-uniform in a mix-down launch)
 
@@ -1533,7 +1538,10 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                 for (int r = 0; r < NTC * MCM; r++) mxl.tile[r * MIX_ROW + lane] = 0.0f;
             }
             if constexpr (MIX == MIX_PAN) {  // the weights of the quarter this lane adds up (panw is padded to `stride` with zeros)
-                if (live) {
+                if constexpr (WLDS) {
+                    if (live) mixw[grp][lane] = v2f{panw[v0 + lane], panw[stride + v0 + lane]};
+                    mxl.wlds = &mixw[grp][0];
+                } else if (live) {
 #pragma unroll
                     for (int j = 0; j < 16; j++) mxl.w[j] = v2f{panw[v0 + (lane & 3) * 16 + j], panw[stride + v0 + (lane & 3) * 16 + j]};
                 }
@@ -1579,7 +1587,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
             };
             if (stage == 0) {
                 loop([&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
-                    if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true, 64, OLM, (FD_PIPE_PREFETCH != 0), 0, MCM>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr, nullptr, &mxl);
+                    if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true, 64, OLM, (FD_PIPE_PREFETCH != 0), 0, MCM, 1, TIGHT>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr, nullptr, &mxl);
 #if FD_PIPE_PRODUCER_PLAIN
                     else {  // the producer stage's sines as plain (2-cycle) ops: see SinePlain
                         using GP = typename PlainOf<GG>::type;
@@ -1592,12 +1600,12 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                 });
             } else if (stage == 1) {
                 loop([&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
-                    if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, OLM, PFK, BALK ? 2 : 0, MCM>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp], &mxl);
+                    if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, OLM, PFK, BALK ? 2 : 0, MCM, 1, TIGHT>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp], &mxl);
                     else if constexpr (S == 3) pipe_stage<T1, GG, MODE, SUB, W, false, false, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
                 });
             } else {
                 loop([&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
-                    if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, OLM, PFK, 0, MCM>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr, nullptr, &mxl);
+                    if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, OLM, PFK, 0, MCM, 1, TIGHT>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr, nullptr, &mxl);
                 });
             }
         } else {
@@ -1611,7 +1619,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                     const float* fin = nullptr;
                     if constexpr (FEED) fin = &feed[grp][j % D][0][0][0];
                     if (stage == 0) {
-                        if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true, 64, OLM, (FD_PIPE_PREFETCH != 0), 0, MCM>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr, nullptr, &mxl);
+                        if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true, 64, OLM, (FD_PIPE_PREFETCH != 0), 0, MCM, 1, TIGHT>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr, nullptr, &mxl);
 #if FD_PIPE_PRODUCER_PLAIN
                         else {  // the producer stage's sines as plain (2-cycle) ops: see SinePlain
                             using GP = typename PlainOf<GG>::type;
@@ -1622,10 +1630,10 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                         else pipe_stage<T0, GG, MODE, SUB, W, true, false, 64, 0, (FD_PIPE_PREFETCH != 0), BALK ? 1 : 0, 0, NA>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1], bal_word[grp], nullptr, part);
 #endif
                     } else if (stage == 1) {
-                        if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, OLM, PFK, BALK ? 2 : 0, MCM>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp], &mxl);
+                        if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, OLM, PFK, BALK ? 2 : 0, MCM, 1, TIGHT>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp], &mxl);
                         else if constexpr (S == 3) pipe_stage<T1, GG, MODE, SUB, W, false, false, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
                     } else {
-                        if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, OLM, PFK, 0, MCM>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr, nullptr, &mxl);
+                        if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, OLM, PFK, 0, MCM, 1, TIGHT>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr, nullptr, &mxl);
                     }
                 }
                 __syncthreads();  // hand-over point: every role has finished its tile of this round
