@@ -198,6 +198,28 @@ def test_run_time_compiled_graph_mixes(gpu):
     assert_bit_equal(s1, gpu.sum_voices(o2).cpu().numpy(), "the next block, MIX_SUM")
 
 
+def test_run_time_compiled_filter_chain_mixes_with_lds_weights(gpu):
+    """A graph with an audio input and two compute stages -- 12 waves per workgroup of four voice groups: the pan weights of the
+    fused mix-down live in LDS and the flush is a loop there (render_pipe_body TIGHT); a moog in the chain makes it `heavy`, so the
+    voice-out render of the small bank takes narrower workgroups than the mix launch: the partial mixes do not depend on that."""
+    import torch
+    from fundsp_amd import graph as G
+
+    V, T = 64 * 6 + 17, 64 * 7 + 3
+    g = G.lowpass_hz(900.0, 0.7) >> G.moog_hz(1500.0, 0.4) >> G.highpass_hz(120.0, 0.7)
+    b = gpu.Bank.from_graph(g, V, sample_rate=SR)
+    rng = np.random.default_rng(21)
+    x = torch.from_numpy((rng.random((1, T, V), dtype=np.float32) - 0.5).astype(np.float32)).cuda()
+    ref = b.clone()
+    pan = (rng.random(V, dtype=np.float32) * 2 - 1).astype(np.float32)
+    b.set_pan(pan)
+    mix = b.process_mix(T, x, mix=MIX_PAN).cpu().numpy()
+    out = ref.process(T, x)
+    assert_bit_equal(mix, gpu.mix_stereo(out[0], torch.from_numpy(pan).cuda()).cpu().numpy(), "filter chain with an input: fused PAN vs mix_stereo(voice-out)")
+    s1 = ref.clone().process_mix(T, x, mix=MIX_SUM).cpu().numpy()
+    assert_bit_equal(s1, gpu.sum_voices(ref.process(T, x)).cpu().numpy(), "the next block, MIX_SUM")
+
+
 def test_mix_on_a_caller_stream_and_in_a_hip_graph(gpu):
     """Stream rules of fdsp_bank_process: a caller's stream, and a stream capture after fdsp_bank_mix_reserve / set_pan (no allocation
     inside the capture); an unreserved bank refuses to mix during a capture."""
