@@ -51,7 +51,7 @@ def _native_oracle():
     return O, L
 
 
-def host_cpu_budget():
+def host_cpu_budget(cgroup_root="/sys/fs/cgroup"):
     """What this process may actually use of the host: logical CPUs, the affinity mask, and the cgroup CPU quota (v2 cpu.max /
     v1 cpu.cfs_quota_us).  `effective` = min(affinity, ceil(quota)): the thread count the cpu_baseline legs run with and report
     as `cores` (os.cpu_count() said 256 on a box whose run behaved like ~20)."""
@@ -62,13 +62,13 @@ def host_cpu_budget():
         affinity = logical
     quota = None
     try:
-        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        txt = open(os.path.join(cgroup_root, "cpu.max")).read().split()
         if txt and txt[0] != "max":
             quota = float(txt[0]) / float(txt[1])
     except (OSError, ValueError, IndexError):
         try:
-            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            q = float(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_quota_us")).read())
+            p = float(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_period_us")).read())
             if q > 0 and p > 0:
                 quota = q / p
         except (OSError, ValueError):

@@ -588,6 +588,14 @@ class Bank {
                         int mode = FDSP_MODE_PROCESS, void* stream = nullptr) {
         check(fdsp_bank_process(h_, frames, d_in, d_out, layout, frame_stride, mode, stream));
     }
+    // render + mix-down in one launch (fdsp_bank_process_mix): `voice >> pan(p)` per voice and the sum over the voices
+    // (pan.rs:50-76, Reduce audionode.rs:2406-2462) without the per-voice output ever existing in HBM.  d_mix: [2][frames] for
+    // FDSP_MIX_PAN (mono graphs, positions from set_pan, default centre), [outputs][frames] for FDSP_MIX_SUM.  d_in voice-minor.
+    void process_mix(size_t frames, const float* d_in, float* d_mix, int mix = FDSP_MIX_SUM, int mode = FDSP_MODE_PROCESS, void* stream = nullptr) {
+        check(fdsp_bank_process_mix(h_, frames, d_in, d_mix, mix, mode, stream));
+    }
+    void set_pan(const std::vector<float>& per_voice, size_t first = 0) { check(fdsp_bank_set_pan(h_, per_voice.data(), first, per_voice.size())); }
+    void mix_reserve(size_t frames) { check(fdsp_bank_mix_reserve(h_, frames)); }  // AudioNode::allocate for the mix path
     void synchronize() { check(fdsp_bank_synchronize(h_)); }
     // Sequencer with one event per voice (sequencer.rs:355-398, 838-951): push = set_events (rows of start, end, fade_in,
     // fade_out in seconds; `fade` FDSP_FADE_POWER / FDSP_FADE_SMOOTH per voice or nullptr), process = process_events

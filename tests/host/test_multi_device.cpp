@@ -131,9 +131,23 @@ static int gpu_mode() {
             EXPECT(hipMalloc((void**)&d_out, per * T * sizeof(float)) == hipSuccess);
             EXPECT(hipMalloc((void**)&d_mix, 2 * T * sizeof(float)) == hipSuccess);
             EXPECT(hipStreamCreate(&s) == hipSuccess);
+            // (a clone renders the same shard with the mix-down FUSED into the launch: fdsp_bank_process_mix, no voice-out buffer)
+            fdsp_bank* bf = nullptr;
+            EXPECT(fdsp_bank_clone(b, &bf) == FDSP_OK);
+            float* d_fused = nullptr;
+            EXPECT(hipMalloc((void**)&d_fused, 2 * T * sizeof(float)) == hipSuccess);
+            std::vector<float> fused(2 * T);
+            if (bf) {
+                EXPECT(fdsp_bank_process_mix(bf, T, nullptr, d_fused, FDSP_MIX_PAN, FDSP_MODE_PROCESS, s) == FDSP_OK);
+                EXPECT(hipMemcpyAsync(fused.data(), d_fused, 2 * T * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess);
+            }
             EXPECT(fdsp_bank_process(b, T, nullptr, d_out, FDSP_LAYOUT_VOICE_MINOR, 0, FDSP_MODE_PROCESS, s) == FDSP_OK);
             EXPECT(fdsp_mix_stereo(d_out, nullptr, d_mix, T, per, s) == FDSP_OK);
             EXPECT(hipMemcpyAsync(partial[t].data(), d_mix, 2 * T * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess);
+            EXPECT(hipStreamSynchronize(s) == hipSuccess);
+            EXPECT(std::memcmp(fused.data(), partial[t].data(), 2 * T * sizeof(float)) == 0);  // one summation order: bit for bit
+            if (bf) fdsp_bank_destroy(bf);
+            hipFree(d_fused);
             const bool joins = t < nranks;
             if (joins) {
                 EXPECT(fdsp_mix_allreduce(comm, t, d_mix, 2 * T, s) == FDSP_OK);
@@ -168,7 +182,7 @@ static int gpu_mode() {
             }
         }
     fdsp_comm_destroy(comm);
-    std::printf("%d thread(s) on %d device(s), %d rank(s): shards bit-exact, all-reduce checked\n", nthreads, ndev, nranks);
+    std::printf("%d thread(s) on %d device(s), %d rank(s): shards bit-exact, fused mix-down == mix of the voice-out render, all-reduce checked\n", nthreads, ndev, nranks);
     return failures;
 }
 

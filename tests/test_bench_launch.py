@@ -72,3 +72,28 @@ def test_power_meter_degrades_to_none_without_a_device():
     else:   # a box with a GPU: a well-formed record
         rec = m.stop(3)
         assert rec is None or {"socket_watts", "cap_watts", "joules_per_step", "sclk_mhz"} <= set(rec)
+
+
+def test_cpu_baseline_counts_the_cpus_the_process_may_use(tmp_path):
+    """cpu_baseline.cores = min(affinity, cgroup quota), not os.cpu_count() (a 256-thread host under a 16-CPU quota)."""
+    import bench
+
+    aff = len(os.sched_getaffinity(0))
+    v2 = tmp_path / "v2"
+    v2.mkdir()
+    (v2 / "cpu.max").write_text("200000 100000\n")
+    b = bench.host_cpu_budget(str(v2))
+    assert b["cgroup_quota_cpus"] == 2.0 and b["effective_cpus"] == min(aff, 2) and b["affinity_cpus"] == aff
+    (v2 / "cpu.max").write_text("max 100000\n")
+    b = bench.host_cpu_budget(str(v2))
+    assert b["cgroup_quota_cpus"] is None and b["effective_cpus"] == aff
+    (v2 / "cpu.max").write_text("150000 100000\n")          # 1.5 CPUs: two threads can run
+    assert bench.host_cpu_budget(str(v2))["effective_cpus"] == min(aff, 2)
+    v1 = tmp_path / "v1" / "cpu"
+    v1.mkdir(parents=True)
+    (v1 / "cpu.cfs_quota_us").write_text("300000\n")
+    (v1 / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.host_cpu_budget(str(tmp_path / "v1"))["effective_cpus"] == min(aff, 3)
+    (v1 / "cpu.cfs_quota_us").write_text("-1\n")
+    assert bench.host_cpu_budget(str(tmp_path / "v1"))["effective_cpus"] == aff
+    assert bench.host_cpu_budget(str(tmp_path / "nothing_here"))["effective_cpus"] == aff
