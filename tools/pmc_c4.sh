@@ -13,7 +13,7 @@ G[ic]="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_IFETCH_LEVE
 for grp in sq vmem tcp ic; do
   for cond in normal fmin400 uniform; do
     case $cond in normal) A="";; fmin400) A="--fmin 400";; uniform) A="--uniform";; esac
-    rocprofv3 --pmc ${G[$grp]} --output-format csv -d $OUT/${grp}_$cond -o pmc -- python tools/c4_ab.py --splits 0 $A > $OUT/${grp}_$cond.log 2>&1
+    timeout 180 rocprofv3 --pmc ${G[$grp]} --output-format csv -d $OUT/${grp}_$cond -o pmc -- python tools/c4_ab.py --splits 0 $A > $OUT/${grp}_$cond.log 2>&1
     CSV=$(find $OUT/${grp}_$cond -name "*counter_collection.csv" | head -1)
     python tools/pmc_summary.py $CSV "r04 config 4 ($cond voices): $grp counters" | grep -A12 "k_render_pipe<" > $OUT/${grp}_$cond.txt
   done
