@@ -298,7 +298,8 @@ double fdsp_bank_events_time(const fdsp_bank* bank);       /* Sequencer::time() 
  *         centre) exactly like Panner::tick does (`weight * sample`), d_mix = [2][frames].
  * The bank owns the partial-mix buffer ([voice groups][channels][frames] f32, 1/64 of a voice-out render); it grows on demand,
  * fdsp_bank_mix_reserve(bank, frames) sizes it ahead of a real-time loop or a stream capture (AudioNode::allocate semantics).
- * Stream, ordering, timing and capture rules are those of fdsp_bank_process.  FDSP_ENOTSUP: the kind was built without the
+ * Stream, ordering, timing and capture rules are those of fdsp_bank_process; a CAPTURED launch holds the partial-mix buffer of
+ * capture time, so reserve for the longest launch before capturing and do not grow the reservation while such a graph is alive.  FDSP_ENOTSUP: the kind was built without the
  * fused kernels (the BASELINE kinds fm_svf, sine_hz_lowpass_hz, saw_moog_adsr_pan, noise_biquad have them) -- render
  * voice-out and call the functions below, which use the same order. */
 #define FDSP_MIX_SUM 1
