@@ -376,6 +376,21 @@ def secondary(F, W, torch, sr, mode):
                     g.replay()
                 torch.cuda.synchronize()
                 us = (time.perf_counter() - t0) / 20 / NB * 1e6
+            # ... and the block a real-time callback actually wants: 64 frames of the stereo MIX (fdsp_bank_process_mix: the pipeline
+            # kernel with the fused mix-down + the tree pass; [2][64] f32 = 512 bytes leave the launch instead of 16.8 MB of voices)
+            wl["bank"].mix_reserve(64)
+            mixo = torch.empty((2, 64), dtype=torch.float32, device="cuda")
+            for _ in range(5):
+                wl["bank"].process_mix(64, mix=F.MIX_PAN, out=mixo, mode=mode)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            km = []
+            for _ in range(50):
+                wl["bank"].process_mix(64, mix=F.MIX_PAN, out=mixo, mode=mode)
+                km.append(wl["bank"].last_kernel_ms())
+            torch.cuda.synchronize()
+            c3["T64"]["fused_mix_us_per_launch"] = round((time.perf_counter() - t0) / 50 * 1e6, 2)
+            c3["T64"]["fused_mix_kernels_us"] = round(sum(km) / len(km) * 1e3, 2)
             c3["T64"]["hip_graph_replay_us_per_block"] = round(us, 2)
             c3["T64"]["hip_graph_value"] = round(V * 64 / us, 1)
             c3["T64"]["hip_graph_roofline_frac"] = round(algo / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
