@@ -580,43 +580,76 @@ __global__ __launch_bounds__(256) void k_group_partials(const float* __restrict_
     }
 }
 
-// part: [G][R] -> mix[R]: the aligned binary tree over the G groups (a node without a right sibling passes through), one thread
-// per row.  Sixteen groups are loaded at a time (independent loads) and reduced in registers; the blocks of sixteen are merged by
-// a binary counter -- `stack[k]` holds the sum of an aligned run of 16 * 2^k groups.
-__global__ __launch_bounds__(256) void k_mix_tree(const float* __restrict__ part, float* __restrict__ mix, size_t R, size_t G) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= R) return;
-    float stack[28];
-    const size_t nb = (G + 15) / 16;
-    for (size_t b = 0; b < nb; b++) {
-        const int m = (int)(G - b * 16 < 16 ? G - b * 16 : 16);  // groups of this block (uniform)
-        float x[16];
+// part: [G][R] -> mix[R]: the aligned binary tree over the G groups (a node without a right sibling passes through).
+// A workgroup takes RB rows; its 256 / RB thread slices each reduce an ALIGNED run of C groups (C a power of two >= 16: a subtree of
+// the same tree) -- sixteen groups loaded at a time (independent loads), reduced in registers, the blocks of sixteen merged by a binary
+// counter (`stack[k]` holds the sum of an aligned run of 16 * 2^k groups) -- and the slices' sums meet in LDS, again in tree order.
+// RB = 64 for long launches (coalesced 256-byte rows); RB = 16 for short ones (a 64-frame block has 128 rows: sixteen slices per row
+// keep the chain of dependent loads short -- one thread per row took 60 us for 1 024 groups).
+template <int RB>
+__global__ __launch_bounds__(256) void k_mix_tree(const float* __restrict__ part, float* __restrict__ mix, size_t R, size_t G, size_t C) {
+    constexpr int GS = 256 / RB;
+    __shared__ float red[GS][RB];
+    const int rl = threadIdx.x % RB, sl = threadIdx.x / RB;
+    const size_t r = (size_t)blockIdx.x * RB + rl;
+    const size_t g0 = (size_t)sl * C, g1 = g0 + C < G ? g0 + C : G;
+    float acc = 0.0f;
+    if (r < R && g0 < G) {
+        float stack[28];
+        const size_t nb = (g1 - g0 + 15) / 16;
+        for (size_t b = 0; b < nb; b++) {
+            const size_t gb = g0 + b * 16;
+            const int m = (int)(g1 - gb < 16 ? g1 - gb : 16);  // groups of this block (uniform over the slice)
+            float x[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = j < m ? part[(b * 16 + j) * R + r] : 0.0f;
+            for (int j = 0; j < 16; j++) x[j] = j < m ? part[(gb + j) * R + r] : 0.0f;
 #pragma unroll
-        for (int span = 1; span < 16; span <<= 1)
+            for (int span = 1; span < 16; span <<= 1)
 #pragma unroll
-            for (int j = 0; j + span < 16; j += 2 * span)
-                if (j + span < m) x[j] = x[j] + x[j + span];
-        float carry = x[0];
-        bool placed = false;
+                for (int j = 0; j + span < 16; j += 2 * span)
+                    if (j + span < m) x[j] = x[j] + x[j + span];
+            float carry = x[0];
+            bool placed = false;
 #pragma unroll
-        for (int k = 0; k < 28; k++) {
-            if (!placed) {
-                if (((b >> k) & 1) == 0) { stack[k] = carry; placed = true; }
-                else carry = stack[k] + carry;
+            for (int k = 0; k < 28; k++) {
+                if (!placed) {
+                    if (((b >> k) & 1) == 0) { stack[k] = carry; placed = true; }
+                    else carry = stack[k] + carry;
+                }
             }
         }
-    }
-    float acc = 0.0f;
-    bool have = false;
+        bool have = false;
 #pragma unroll
-    for (int k = 0; k < 28; k++)
-        if ((nb >> k) & 1) {
-            acc = have ? stack[k] + acc : stack[k];
-            have = true;
-        }
-    mix[r] = acc;
+        for (int k = 0; k < 28; k++)
+            if ((nb >> k) & 1) {
+                acc = have ? stack[k] + acc : stack[k];
+                have = true;
+            }
+    }
+    red[sl][rl] = acc;
+    __syncthreads();
+    if (sl == 0 && r < R) {
+        const int nvalid = (int)((G + C - 1) / C);  // slices that hold groups (<= GS)
+        float x[GS];
+#pragma unroll
+        for (int j = 0; j < GS; j++) x[j] = j < nvalid ? red[j][rl] : 0.0f;
+#pragma unroll
+        for (int span = 1; span < GS; span <<= 1)
+#pragma unroll
+            for (int j = 0; j + span < GS; j += 2 * span)
+                if (j + span < nvalid) x[j] = x[j] + x[j + span];
+        mix[r] = x[0];
+    }
+}
+// rows-per-workgroup policy and the slice width (a power of two >= 16 that covers the groups with the slices at hand)
+void launch_mix_tree(const float* part, float* mix, size_t R, size_t G, hipStream_t s) {
+    auto slice = [&](size_t slices) {
+        size_t c = 16;
+        while (c * slices < G) c <<= 1;
+        return c;
+    };
+    if (R >= 2048) hipLaunchKernelGGL((k_mix_tree<64>), dim3((unsigned)((R + 63) / 64)), dim3(256), 0, s, part, mix, R, G, slice(4));
+    else hipLaunchKernelGGL((k_mix_tree<16>), dim3((unsigned)((R + 15) / 16)), dim3(256), 0, s, part, mix, R, G, slice(16));
 }
 
 // the launch pair behind fdsp_sum_voices / fdsp_mix_stereo: group partials of a voice-out buffer, then the tree
@@ -627,7 +660,7 @@ hipError_t launch_mix_rows(const float* x, const float* wl, const float* wr, flo
         hipLaunchKernelGGL((k_group_partials<PAN, true>), dim3((unsigned)G, (unsigned)((rows + 255) / 256)), dim3(256), 0, s, x, wl, wr, part, rows, V);
     else
         hipLaunchKernelGGL((k_group_partials<PAN, false>), dim3((unsigned)G, (unsigned)((rows + 255) / 256)), dim3(256), 0, s, x, wl, wr, part, rows, V);
-    hipLaunchKernelGGL(k_mix_tree, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, part, mix, R, G);
+    launch_mix_tree(part, mix, R, G, s);
     return hipGetLastError();
 }
 
@@ -1390,7 +1423,7 @@ int fdsp_bank_process_mix(fdsp_bank* b, size_t frames, const float* d_in, float*
     if (!done) return fail(FDSP_ENOTSUP, "kind '" + b->ops->name + "': no fused mix-down kernel for this graph shape (single-stage graphs without inputs, 3+ outputs with FDSP_MIX_PAN)");
     b->last_kernel = fd::tl_opts.last_kernel;
     // the groups' partials -> d_mix, aligned binary tree (k_mix_tree); the time it takes is part of the render's event pair
-    hipLaunchKernelGGL(k_mix_tree, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, (const float*)b->mix_part, d_mix, R, (b->V + 63) / 64);
+    launch_mix_tree(b->mix_part, d_mix, R, (b->V + 63) / 64, s);
     HIPCHK(hipGetLastError());
     if (!capturing) {
         if (timing || s != b->stream) HIPCHK(hipEventRecord(b->e1, s));
@@ -1705,7 +1738,7 @@ int fdsp_sum_instances(const float* d_in, float* d_out, size_t rows, size_t inst
     if (rows == 0 || instances == 0) return FDSP_OK;
     DeviceGuard guard(device_of(d_in));
     // planar output [instance][rows] IS the tree kernel's [groups][rows] shape: the aligned binary tree over the instances
-    hipLaunchKernelGGL(k_mix_tree, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, rows, instances);
+    launch_mix_tree(d_in, d_out, rows, instances, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
 }

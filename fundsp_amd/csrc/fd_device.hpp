@@ -1070,11 +1070,12 @@ FD_D float mix_quad(float x, int ctrl) {
 template <int NM, int MC, bool ROLL = false>
 FD_D void mix_flush(const float* tile, float* dst, size_t T, int nf, int lane) {
     constexpr int E = NM * MC;  // (channel, frame) entries of the tile
+    constexpr int UF = ROLL ? 1 : 4;  // unroll factor of the pass loop
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the tile was written by other lanes of this wave (LDS operations of a wave execute in order)
     // ROLL: the passes stay a loop.  Unrolled, the ILP scheduling strategies the time-split kernels are built with hoist every pass's tile
     // reads to the top (214 VGPRs in the one-group kernel: fine at 8 waves per CU and 0.24 ms faster than the loop; 137 SPILLS in the
     // two-group one, whose 14 waves leave 128 registers each: there the loop is the faster form, profiles/r04_mix_bench_d.txt)
-#pragma unroll(ROLL ? 1 : 4)
+#pragma unroll UF
     for (int p = 0; p < (E * 4 + 63) / 64; p++) {
         const int idx = p * 64 + lane, e = idx >> 2, q = idx & 3;
         const bool on = (E * 4) % 64 == 0 || e < E;
@@ -1099,8 +1100,9 @@ FD_D void mix_flush(const float* tile, float* dst, size_t T, int nf, int lane) {
 template <int MC, bool WREG, bool ROLL = false>
 FD_D void mix_flush_pan(const float* tile, float* dst, size_t T, int nf, int lane, const v2f* w, const v2f* wlds) {
     constexpr int E = MC;
+    constexpr int UF = ROLL ? 1 : 4;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll(ROLL ? 1 : 4)
+#pragma unroll UF
     for (int p = 0; p < (E * 4 + 63) / 64; p++) {
         const int idx = p * 64 + lane, e = idx >> 2, q = idx & 3;
         const bool on = (E * 4) % 64 == 0 || e < E;
