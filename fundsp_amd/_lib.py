@@ -68,6 +68,7 @@ SYMBOLS = {
     "fdsp_bank_set_ring": (_i, [_P, _i, _fp, _sz, _sz, _sz]),
     "fdsp_bank_set_events": (_i, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int), _sz, _sz]),
     "fdsp_bank_process_events": (_i, [_P, _sz, _P, _P, _i, _P]),
+    "fdsp_bank_process_events_mix": (_i, [_P, _sz, _P, _P, _i, _P]),
     "fdsp_bank_events_rewind": (_i, [_P, _d]),
     "fdsp_bank_events_time": (_d, [_P]),
     "fdsp_bank_synchronize": (_i, [_P]),

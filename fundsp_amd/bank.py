@@ -281,6 +281,27 @@ class Bank:
                                              C.c_void_p(stream) if stream else None))
         return out
 
+    def process_events_mix(self, frames, inp=None, out=None, mode=MODE_PROCESS, stream=None):
+        """Sequencer rendering, mixed: out [outputs, frames] = the sum of the events' faded contributions (fdsp_bank_process_events_mix:
+        one launch, the mix-down's fixed order; equals sum_voices(process_events(..)) bit for bit)."""
+        import torch
+
+        frames = int(frames)
+        ni, no = self.inputs(), self.outputs()
+        if out is None:
+            out = torch.empty((no, frames), dtype=torch.float32, device="cuda")
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= no * frames
+        d_in = None
+        if ni:
+            assert inp is not None and inp.is_cuda and inp.dtype == torch.float32 and inp.is_contiguous()
+            assert inp.numel() >= ni * frames * self.voices, f"inp has {inp.numel()} floats, needs {ni * frames * self.voices}"
+            d_in = C.c_void_p(inp.data_ptr())
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        check(lib().fdsp_bank_process_events_mix(self._h, frames, d_in, C.c_void_p(out.data_ptr()), mode,
+                                                 C.c_void_p(stream) if stream else None))
+        return out
+
     def process_host(self, frames, inp=None, layout=LAYOUT_PLANAR, frame_stride=None, mode=MODE_PROCESS, out=None):
         """Same with numpy buffers (staged, synchronous). Planar default: [V][channels][frame_stride].
         `out` (optional, right shape, C-contiguous f32) is written in place; planar padding past `frames` is left alone."""

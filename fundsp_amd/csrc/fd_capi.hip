@@ -1506,19 +1506,30 @@ int fdsp_bank_events_rewind(fdsp_bank* b, double time) {
 
 double fdsp_bank_events_time(const fdsp_bank* b) { return b ? b->seq_time : 0.0; }
 
-int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, float* d_out, int mode, void* stream) {
+namespace {
+// fdsp_bank_process_events (d_mix == nullptr: every event's faded samples to d_out) and fdsp_bank_process_events_mix (d_out == nullptr: the
+// Sequencer's output, the sum of the events, to d_mix [outputs][frames]) share everything but the launch
+int events_render(fdsp_bank* b, size_t frames, const float* d_in, float* d_out, float* d_mix, int mode, void* stream) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
     DeviceGuard guard(b->device);
     if (frames == 0) return FDSP_OK;
+    const bool mixing = d_out == nullptr;
     if (!b->ev) return fail(FDSP_EINVAL, "no events set (fdsp_bank_set_events)");
-    if (!d_out) return fail(FDSP_EINVAL, "d_out is NULL");
+    if (!d_out && !d_mix) return fail(FDSP_EINVAL, mixing ? "d_mix is NULL" : "d_out is NULL");
     if (fdsp_bank_inputs(b) > 0 && !d_in) return fail(FDSP_EINVAL, "d_in is NULL but the graph has inputs");
     if (mode != FDSP_MODE_PROCESS && mode != FDSP_MODE_TICK) return fail(FDSP_EINVAL, "bad mode");
+    if (mixing && !b->ops->render_events_mix)
+        return fail(FDSP_ENOTSUP, "kind '" + b->ops->name + "' has no fused Sequencer mix: call fdsp_bank_process_events and fdsp_sum_voices");
     hipStream_t s = stream ? (hipStream_t)stream : b->stream;
-    HIPCHK(order_after_bank_stream(b, s));
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (s != b->stream) hipStreamIsCapturing(s, &cap);
-    const bool capturing = cap != hipStreamCaptureStatusNone;
+    const bool capturing = cap != hipStreamCaptureStatusNone;  // a captured launch leaves the timing events alone
+    const size_t nm = (size_t)fdsp_bank_outputs(b), groups = b->stride / 64, R = nm * frames;
+    if (mixing && groups * R > b->mix_part_n) {
+        if (capturing) return fail(FDSP_EINVAL, "fdsp_bank_process_events_mix during a stream capture: call fdsp_bank_mix_reserve before capturing");
+        if (int rc = mix_reserve(b, groups * R)) return rc;
+    }
+    HIPCHK(order_after_bank_stream(b, s));
     if (int rc = check_ring_need(b, capturing)) return rc;
     if (b->ext_pending && !capturing) HIPCHK(hipStreamWaitEvent(s, b->e1, 0));
     const bool timing = timing_on(b);  // the per-launch event pair is optional, as in fdsp_bank_process
@@ -1548,12 +1559,21 @@ int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, flo
     const bool sustained = !b->ev_host.empty() && b->ev_max_start <= t_begin && b->ev_min_end >= t_end &&
                            b->ev_max_fade_in_end <= t_begin && b->ev_min_fade_out_start >= t_end;
     resolve_opts(b);
-    if (sustained)
+    if (mixing) {
+        bool done = false;
+        if (sustained && b->ops->render_mix)  // (the exact type: the voice scheduler renders exactly, like fdsp_bank_process_events)
+            done = b->ops->render_mix(b->slots, b->stride, b->V, d_in, b->mix_part, frames, FDSP_MIX_SUM, mode, b->aux, b->ring, b->ring_cap, b->panw, s);
+        if (!done)
+            done = b->ops->render_events_mix(b->slots, b->stride, b->V, d_in, b->mix_part, frames, b->ev, b->ev_fade, b->seq_time, b->sr, mode,
+                                             b->aux, b->ring, b->ring_cap, s);
+        if (!done) return fail(FDSP_ENOTSUP, "kind '" + b->ops->name + "': more than two outputs -- no fused Sequencer mix; call fdsp_bank_process_events and fdsp_sum_voices");
+        launch_mix_tree(b->mix_part, d_mix, R, (b->V + 63) / 64, s);
+    } else if (sustained)
         b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, 0, FDSP_LAYOUT_VOICE_MINOR, mode, b->aux, b->ring,
                        b->ring_cap, s);
     else
-    b->ops->render_events(b->slots, b->stride, b->V, d_in, d_out, frames, b->ev, b->ev_fade, b->seq_time, b->sr, mode,
-                          b->aux, b->ring, b->ring_cap, s);
+        b->ops->render_events(b->slots, b->stride, b->V, d_in, d_out, frames, b->ev, b->ev_fade, b->seq_time, b->sr, mode,
+                              b->aux, b->ring, b->ring_cap, s);
     b->last_kernel = fd::tl_opts.last_kernel;
     HIPCHK(hipGetLastError());
     if (!capturing) {
@@ -1564,6 +1584,18 @@ int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, flo
     b->seq_time = t_end;
     return FDSP_OK;
 }
+}  // namespace
+
+int fdsp_bank_process_events(fdsp_bank* b, size_t frames, const float* d_in, float* d_out, int mode, void* stream) {
+    if (b && frames > 0 && !d_out) return fail(FDSP_EINVAL, "d_out is NULL");
+    return events_render(b, frames, d_in, d_out, nullptr, mode, stream);
+}
+
+int fdsp_bank_process_events_mix(fdsp_bank* b, size_t frames, const float* d_in, float* d_mix, int mode, void* stream) {
+    if (b && frames > 0 && !d_mix) return fail(FDSP_EINVAL, "d_mix is NULL");
+    return events_render(b, frames, d_in, nullptr, d_mix, mode, stream);
+}
+
 
 namespace {
 

@@ -415,7 +415,108 @@ FD_HD long long round_index(double x) {  // `round(x) as usize`: half away from 
     return r > 0.0 ? (r < 4.0e18 ? (long long)r : (long long)4.0e18) : 0;
 }
 
-template <class G, int MODE>
+// ---- fused mix-down ("mode B" of SURVEY.md 8(d): on-device reduction of the voices to [channels][frames]) ------------
+// The LAST stage of a voice group does not store its samples to HBM; it parks them in a small LDS tile
+// [mix channel][frame of the chunk][voice] and, every MC frames, reads the tile back TRANSPOSED -- lane = (channel, frame,
+// quarter of the group's voices) -- adds the 16 voices of its quarter one after the other, combines the four quarters
+// through DPP and writes ONE float per (channel, frame): the group's partial mix.  The order is fixed and does not depend on
+// the launch geometry:
+//     partial(group) = (S0 + S1) + (S2 + S3),   Sq = ((x[16q] + x[16q+1]) + x[16q+2]) + ... + x[16q+15]
+// (voices past the end of the bank count as +0.0).  k_mix_tree then adds the groups' partials in an aligned binary tree
+// (an odd node at the end of a level passes through).  fdsp_sum_voices / fdsp_mix_stereo of a voice-out render use the same
+// order, so the fused mix equals them bit for bit (tests/test_gpu_mix.py).
+// Reference shape: the Panner / Reduce arithmetic of src/pan.rs:50-76, src/audionode.rs:2406-2462 over a bank of voices.
+constexpr int MIX_NONE = 0, MIX_SUM = 1, MIX_PAN = 2;  // sum every output channel over the voices | pan a mono graph to stereo, then sum
+constexpr int MIX_ROW = 68;  // floats per (channel, frame) row of a mix tile: 64 voices + 4 (16-byte runs stay aligned, lane-per-row b128 reads spread over the banks)
+template <int NM, int GPW, int SUB>
+struct MixGeom {  // frames per chunk: what fits the 32 KiB the pipeline's own tiles leave of a CU's 160 KiB of LDS
+    static constexpr int fit = (31 * 1024) / GPW / (NM * MIX_ROW * 4);
+    static constexpr int MC0 = fit >= 64 ? 64 : fit >= 32 ? 32 : fit >= 16 ? 16 : fit >= 8 ? 8 : 0;
+    static constexpr int MC = MC0 > SUB ? SUB : MC0;
+    static constexpr int FLOATS = NM * (MC > 0 ? MC : 1) * MIX_ROW;
+    static constexpr bool ok = MC >= 8;
+};
+struct MixLane {   // what the last stage's wave knows about its mix tile
+    float* tile;   // LDS: [tile channels][MC][MIX_ROW]; MIX_PAN keeps ONE channel (the mono samples) and pans when it flushes
+    int col;       // this lane's column: its voice's, or the padding column 64 for lanes past the end of the bank
+    // MIX_PAN: the equal-power weights (left, right; pan.rs:13-17) of the 16 voices of the quarter this lane adds up when it
+    // flushes -- quarter = lane & 3 in every pass, so they are loaded once per launch (voices past the end of the bank: 0, 0) --
+    // in registers (OL == 3), or, where 32 more registers would spill (the 14-wave time-split workgroup), in LDS: wlds[voice] (OL == 4)
+    v2f w[16];
+    const v2f* wlds;
+};
+FD_D float mix_quad(float x, int ctrl) {
+    return u2f((uint32_t)(ctrl == 0 ? __builtin_amdgcn_update_dpp((int)f2u(x), (int)f2u(x), 0xB1, 0xF, 0xF, false)     // quad_perm [1,0,3,2]
+                                    : __builtin_amdgcn_update_dpp((int)f2u(x), (int)f2u(x), 0x4E, 0xF, 0xF, false)));  // quad_perm [2,3,0,1]
+}
+// the chunk's first `nf` frames -> dst[channel * T + frame]; every lane of the wave takes part
+template <int NM, int MC, bool ROLL = false>
+FD_D void mix_flush(const float* tile, float* dst, size_t T, int nf, int lane) {
+    constexpr int E = NM * MC;  // (channel, frame) entries of the tile
+    constexpr int UF = ROLL ? 1 : 4;  // unroll factor of the pass loop
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the tile was written by other lanes of this wave (LDS operations of a wave execute in order)
+    // ROLL: the passes stay a loop.  Unrolled, the ILP scheduling strategies the time-split kernels are built with hoist every pass's tile
+    // reads to the top (214 VGPRs in the one-group kernel: fine at 8 waves per CU and 0.24 ms faster than the loop; 137 SPILLS in the
+    // two-group one, whose 14 waves leave 128 registers each: there the loop is the faster form, profiles/r04_mix_bench_d.txt)
+#pragma unroll UF
+    for (int p = 0; p < (E * 4 + 63) / 64; p++) {
+        const int idx = p * 64 + lane, e = idx >> 2, q = idx & 3;
+        const bool on = (E * 4) % 64 == 0 || e < E;
+        const float4* row = reinterpret_cast<const float4*>(tile + (on ? e : 0) * MIX_ROW + q * 16);
+        const float4 a = row[0], b = row[1], c = row[2], d = row[3];
+        float s = a.x;
+        s += a.y; s += a.z; s += a.w;
+        s += b.x; s += b.y; s += b.z; s += b.w;
+        s += c.x; s += c.y; s += c.z; s += c.w;
+        s += d.x; s += d.y; s += d.z; s += d.w;
+        const float t = s + mix_quad(s, 0);
+        const float u = t + mix_quad(t, 1);
+        const int ch = e / MC, f = e % MC;
+        if (on && q == 0 && f < nf) dst[(size_t)ch * T + f] = u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // ... and the next chunk's samples must not overtake these reads
+}
+
+// MIX_PAN: the tile holds the mono samples of MC frames; lane (frame, quarter) multiplies its quarter's 16 samples by their voices'
+// weights -- left and right as one <2 x float> product, rounded like Panner::tick's `weight * sample` -- and adds them up one after the
+// other (the same order per channel as mix_flush), the quarters through DPP; dst[frame] = left, dst[T + frame] = right.
+template <int MC, bool WREG, bool ROLL = false>
+FD_D void mix_flush_pan(const float* tile, float* dst, size_t T, int nf, int lane, const v2f* w, const v2f* wlds) {
+    constexpr int E = MC;
+    constexpr int UF = ROLL ? 1 : 4;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll UF
+    for (int p = 0; p < (E * 4 + 63) / 64; p++) {
+        const int idx = p * 64 + lane, e = idx >> 2, q = idx & 3;
+        const bool on = (E * 4) % 64 == 0 || e < E;
+        const float4* row = reinterpret_cast<const float4*>(tile + (on ? e : 0) * MIX_ROW + q * 16);
+        v2f s = v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // four samples at a time: the running sums are the only long-lived registers
+            const float4 xq = row[k];
+            const float x[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const v2f wj = WREG ? w[4 * k + j] : wlds[q * 16 + 4 * k + j];
+                const v2f t = splat2(x[j]) * wj;
+                s = (k == 0 && j == 0) ? t : s + t;
+            }
+        }
+        const float tl = s.x + mix_quad(s.x, 0), tr = s.y + mix_quad(s.y, 0);
+        const float ul = tl + mix_quad(tl, 1), ur = tr + mix_quad(tr, 1);
+        if (on && q == 0 && e < nf) {
+            dst[e] = ul;
+            dst[T + e] = ur;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// MIXE (k_render_events_mix, fdsp_bank_process_events_mix): the Sequencer's OUTPUT -- the sum of its events (sequencer.rs:838-951) -- leaves the
+// launch instead of every event's own samples: a wave parks its block in an LDS tile [channel][64 frames][64 voices + 4] and flushes it as
+// the voice group's partial mix (mix_flush, the mix-down's fixed order); `out` is then the partial buffer [groups][channels][T].  Every lane
+// of a live group takes part in the flush; a padded voice of the last group is an event that never plays.
+template <class G, int MODE, bool MIXE = false>
 FD_D void render_events_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
                              float* __restrict__ out, size_t T, const double* __restrict__ ev,
                              const int* __restrict__ fade, double time0, double sample_rate, const void* aux, float* ring,
@@ -426,7 +527,11 @@ FD_D void render_events_body(float* __restrict__ slots, size_t stride, size_t V,
     const size_t v0 = ((size_t)blockIdx.x * 4 + wib) * 64;
     const size_t v = v0 + lane;
     if (v0 >= stride) return;
-    if (v >= V) return;
+    const bool voice = v < V;
+    if (!MIXE && !voice) return;
+    __shared__ __attribute__((aligned(16))) float etile[MIXE ? 4 : 1][MIXE ? NO * 64 * MIX_ROW : 4];
+    float* tile = &etile[MIXE ? wib : 0][0];
+    float* part = MIXE ? out + (v0 / 64) * (size_t)NO * T : nullptr;  // this group's partial mix [channel][T]
     G g;
     Ctx ctx{static_cast<const Aux*>(aux), ring + v, ring_cap, stride, 0};
     g.bind(ctx);
@@ -434,12 +539,18 @@ FD_D void render_events_body(float* __restrict__ slots, size_t stride, size_t V,
         VLoad ld{slots + v, stride, 0};
         g.visit(ld);
     }
-    const double e_start = ev[v], e_end = ev[stride + v], e_fin = ev[2 * stride + v], e_fout = ev[3 * stride + v];
-    const int ease = fade ? fade[v] : 1;
+    const double inf_ = __builtin_huge_val();
+    const double e_start = voice ? ev[v] : inf_, e_end = voice ? ev[stride + v] : -inf_, e_fin = voice ? ev[2 * stride + v] : 0.0,
+                 e_fout = voice ? ev[3 * stride + v] : 0.0;
+    const int ease = (fade && voice) ? fade[v] : 1;
     const double sd = 1.0 / sample_rate;  // Sequencer::set_sample_rate :752-753
     double time = time0;
     const float* inv = in + v;
     float* outv = out + v;
+    auto put = [&](int c, size_t t, float x) {  // frame t of the launch, channel c
+        if constexpr (MIXE) tile[(c * 64 + (int)(t & 63)) * MIX_ROW + lane] = x;
+        else outv[((size_t)c * T + t) * V] = x;
+    };
     if (MODE == MODE_PROCESS) {
         for (size_t t0 = 0; t0 < T; t0 += 64) {
             const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
@@ -495,8 +606,8 @@ FD_D void render_events_body(float* __restrict__ slots, size_t stride, size_t V,
                     g.template step2<PH_SIMD>(pi, po);
 #pragma unroll
                     for (int c = 0; c < NO; c++) {
-                        outv[((size_t)c * T + t) * V] = po[c].x;
-                        outv[((size_t)c * T + t + 1) * V] = po[c].y;
+                        put(c, t, po[c].x);
+                        put(c, t + 1, po[c].y);
                     }
                 }
                 if (__builtin_expect(g.tripped(), 0)) {  // a packed-path shortcut left its exact domain: redo the block
@@ -508,7 +619,7 @@ FD_D void render_events_body(float* __restrict__ slots, size_t stride, size_t V,
                         for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
                         g.template step<PH_SIMD>(fi, fo);
 #pragma unroll
-                        for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+                        for (int c = 0; c < NO; c++) put(c, t, fo[c]);
                     }
                 }
                 g.end_simd();
@@ -519,8 +630,9 @@ FD_D void render_events_body(float* __restrict__ slots, size_t stride, size_t V,
                     for (int c = 0; c < NI; c++) fi[c] = inv[((size_t)c * T + t) * V];
                     g.template step<PH_REM>(fi, fo);
 #pragma unroll
-                    for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+                    for (int c = 0; c < NO; c++) put(c, t, fo[c]);
                 }
+                if constexpr (MIXE) mix_flush<NO, 64>(tile, part + t0, T, size, lane);
                 time = end_time;
                 continue;
             }
@@ -554,8 +666,9 @@ FD_D void render_events_body(float* __restrict__ slots, size_t stride, size_t V,
                     }
                 }
 #pragma unroll
-                for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+                for (int c = 0; c < NO; c++) put(c, t, fo[c]);
             }
+            if constexpr (MIXE) mix_flush<NO, 64>(tile, part + t0, T, size, lane);
             time = end_time;
         }
     } else {
@@ -589,14 +702,28 @@ FD_D void render_events_body(float* __restrict__ slots, size_t stride, size_t V,
                 }
             }
 #pragma unroll
-            for (int c = 0; c < NO; c++) outv[((size_t)c * T + t) * V] = fo[c];
+            for (int c = 0; c < NO; c++) put(c, t, fo[c]);
+            if constexpr (MIXE) {
+                if ((t & 63) == 63 || t + 1 == T) mix_flush<NO, 64>(tile, part + (t & ~(size_t)63), T, (int)(t & 63) + 1, lane);
+            }
             time = end_time;
         }
     }
-    VStore<false> st{slots + v, stride, 0};
-    g.visit(st);
+    if (voice) {
+        VStore<false> st{slots + v, stride, 0};
+        g.visit(st);
+    }
 }
 
+template <class G, int MODE>
+__global__ __launch_bounds__(256) void k_render_events_mix(float* __restrict__ slots, size_t stride, size_t V,
+                                                          const float* __restrict__ in, float* __restrict__ part, size_t T,
+                                                          const double* __restrict__ ev, const int* __restrict__ fade,
+                                                          double time0, double sample_rate, const void* aux, float* ring,
+                                                          uint32_t ring_cap) {
+    static_assert(G::OUT * 64 * MIX_ROW * 4 * 4 <= 160 * 1024, "the block tiles of four waves must fit the CU's LDS");
+    render_events_body<G, MODE, true>(slots, stride, V, in, part, T, ev, fade, time0, sample_rate, aux, ring, ring_cap);
+}
 template <class G, int MODE>
 __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots, size_t stride, size_t V,
                                                       const float* __restrict__ in, float* __restrict__ out, size_t T,
@@ -1030,103 +1157,6 @@ constexpr PipePlan pipe_plan(int want) {  // want: 0 = best plan, 1 / 2 / 3 = at
                 }
             }
     return best;
-}
-
-// ---- fused mix-down ("mode B" of SURVEY.md 8(d): on-device reduction of the voices to [channels][frames]) ------------
-// The LAST stage of a voice group does not store its samples to HBM; it parks them in a small LDS tile
-// [mix channel][frame of the chunk][voice] and, every MC frames, reads the tile back TRANSPOSED -- lane = (channel, frame,
-// quarter of the group's voices) -- adds the 16 voices of its quarter one after the other, combines the four quarters
-// through DPP and writes ONE float per (channel, frame): the group's partial mix.  The order is fixed and does not depend on
-// the launch geometry:
-//     partial(group) = (S0 + S1) + (S2 + S3),   Sq = ((x[16q] + x[16q+1]) + x[16q+2]) + ... + x[16q+15]
-// (voices past the end of the bank count as +0.0).  k_mix_tree then adds the groups' partials in an aligned binary tree
-// (an odd node at the end of a level passes through).  fdsp_sum_voices / fdsp_mix_stereo of a voice-out render use the same
-// order, so the fused mix equals them bit for bit (tests/test_gpu_mix.py).
-// Reference shape: the Panner / Reduce arithmetic of src/pan.rs:50-76, src/audionode.rs:2406-2462 over a bank of voices.
-constexpr int MIX_NONE = 0, MIX_SUM = 1, MIX_PAN = 2;  // sum every output channel over the voices | pan a mono graph to stereo, then sum
-constexpr int MIX_ROW = 68;  // floats per (channel, frame) row of a mix tile: 64 voices + 4 (16-byte runs stay aligned, lane-per-row b128 reads spread over the banks)
-template <int NM, int GPW, int SUB>
-struct MixGeom {  // frames per chunk: what fits the 32 KiB the pipeline's own tiles leave of a CU's 160 KiB of LDS
-    static constexpr int fit = (31 * 1024) / GPW / (NM * MIX_ROW * 4);
-    static constexpr int MC0 = fit >= 64 ? 64 : fit >= 32 ? 32 : fit >= 16 ? 16 : fit >= 8 ? 8 : 0;
-    static constexpr int MC = MC0 > SUB ? SUB : MC0;
-    static constexpr int FLOATS = NM * (MC > 0 ? MC : 1) * MIX_ROW;
-    static constexpr bool ok = MC >= 8;
-};
-struct MixLane {   // what the last stage's wave knows about its mix tile
-    float* tile;   // LDS: [tile channels][MC][MIX_ROW]; MIX_PAN keeps ONE channel (the mono samples) and pans when it flushes
-    int col;       // this lane's column: its voice's, or the padding column 64 for lanes past the end of the bank
-    // MIX_PAN: the equal-power weights (left, right; pan.rs:13-17) of the 16 voices of the quarter this lane adds up when it
-    // flushes -- quarter = lane & 3 in every pass, so they are loaded once per launch (voices past the end of the bank: 0, 0) --
-    // in registers (OL == 3), or, where 32 more registers would spill (the 14-wave time-split workgroup), in LDS: wlds[voice] (OL == 4)
-    v2f w[16];
-    const v2f* wlds;
-};
-FD_D float mix_quad(float x, int ctrl) {
-    return u2f((uint32_t)(ctrl == 0 ? __builtin_amdgcn_update_dpp((int)f2u(x), (int)f2u(x), 0xB1, 0xF, 0xF, false)     // quad_perm [1,0,3,2]
-                                    : __builtin_amdgcn_update_dpp((int)f2u(x), (int)f2u(x), 0x4E, 0xF, 0xF, false)));  // quad_perm [2,3,0,1]
-}
-// the chunk's first `nf` frames -> dst[channel * T + frame]; every lane of the wave takes part
-template <int NM, int MC, bool ROLL = false>
-FD_D void mix_flush(const float* tile, float* dst, size_t T, int nf, int lane) {
-    constexpr int E = NM * MC;  // (channel, frame) entries of the tile
-    constexpr int UF = ROLL ? 1 : 4;  // unroll factor of the pass loop
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the tile was written by other lanes of this wave (LDS operations of a wave execute in order)
-    // ROLL: the passes stay a loop.  Unrolled, the ILP scheduling strategies the time-split kernels are built with hoist every pass's tile
-    // reads to the top (214 VGPRs in the one-group kernel: fine at 8 waves per CU and 0.24 ms faster than the loop; 137 SPILLS in the
-    // two-group one, whose 14 waves leave 128 registers each: there the loop is the faster form, profiles/r04_mix_bench_d.txt)
-#pragma unroll UF
-    for (int p = 0; p < (E * 4 + 63) / 64; p++) {
-        const int idx = p * 64 + lane, e = idx >> 2, q = idx & 3;
-        const bool on = (E * 4) % 64 == 0 || e < E;
-        const float4* row = reinterpret_cast<const float4*>(tile + (on ? e : 0) * MIX_ROW + q * 16);
-        const float4 a = row[0], b = row[1], c = row[2], d = row[3];
-        float s = a.x;
-        s += a.y; s += a.z; s += a.w;
-        s += b.x; s += b.y; s += b.z; s += b.w;
-        s += c.x; s += c.y; s += c.z; s += c.w;
-        s += d.x; s += d.y; s += d.z; s += d.w;
-        const float t = s + mix_quad(s, 0);
-        const float u = t + mix_quad(t, 1);
-        const int ch = e / MC, f = e % MC;
-        if (on && q == 0 && f < nf) dst[(size_t)ch * T + f] = u;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // ... and the next chunk's samples must not overtake these reads
-}
-
-// MIX_PAN: the tile holds the mono samples of MC frames; lane (frame, quarter) multiplies its quarter's 16 samples by their voices'
-// weights -- left and right as one <2 x float> product, rounded like Panner::tick's `weight * sample` -- and adds them up one after the
-// other (the same order per channel as mix_flush), the quarters through DPP; dst[frame] = left, dst[T + frame] = right.
-template <int MC, bool WREG, bool ROLL = false>
-FD_D void mix_flush_pan(const float* tile, float* dst, size_t T, int nf, int lane, const v2f* w, const v2f* wlds) {
-    constexpr int E = MC;
-    constexpr int UF = ROLL ? 1 : 4;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll UF
-    for (int p = 0; p < (E * 4 + 63) / 64; p++) {
-        const int idx = p * 64 + lane, e = idx >> 2, q = idx & 3;
-        const bool on = (E * 4) % 64 == 0 || e < E;
-        const float4* row = reinterpret_cast<const float4*>(tile + (on ? e : 0) * MIX_ROW + q * 16);
-        v2f s = v2f{0.0f, 0.0f};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {  // four samples at a time: the running sums are the only long-lived registers
-            const float4 xq = row[k];
-            const float x[4] = {xq.x, xq.y, xq.z, xq.w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const v2f wj = WREG ? w[4 * k + j] : wlds[q * 16 + 4 * k + j];
-                const v2f t = splat2(x[j]) * wj;
-                s = (k == 0 && j == 0) ? t : s + t;
-            }
-        }
-        const float tl = s.x + mix_quad(s.x, 0), tr = s.y + mix_quad(s.y, 0);
-        const float ul = tl + mix_quad(tl, 1), ur = tr + mix_quad(tr, 1);
-        if (on && q == 0 && e < nf) {
-            dst[e] = ul;
-            dst[T + e] = ur;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
 // One stage's work on one tile: frames [lo, hi) of the block that starts at t0 (size / full as in
@@ -2383,6 +2413,12 @@ FD_D void jit_pipe_mix_body(float* __restrict__ slots, size_t stride, size_t V, 
                             float* __restrict__ part, size_t T, const void* aux, float* ring, uint32_t ring_cap, const float* __restrict__ panw) {
     constexpr PipePlan P = pipe_plan<G>(0);
     if constexpr (P.S >= 1 && (MIX == MIX_SUM || G::OUT == 1)) render_pipe_body<G, MODE, P.S, P.K1, P.K2, 4, MIX>(slots, stride, V, in, part, T, aux, ring, ring_cap, panw);
+}
+template <class G, int MODE>
+FD_D void jit_events_mix_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ part, size_t T,
+                              const double* __restrict__ ev, const int* __restrict__ fade, double time0, double sr, const void* aux, float* ring,
+                              uint32_t ring_cap) {
+    if constexpr (G::OUT <= 2) render_events_body<G, MODE, true>(slots, stride, V, in, part, T, ev, fade, time0, sr, aux, ring, ring_cap);
 }
 template <class G, int MODE>
 FD_D void jit_pipe_planar_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,

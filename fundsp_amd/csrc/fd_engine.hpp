@@ -67,6 +67,11 @@ struct KindOps {
     std::function<bool(float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, int mix, int mode,
                        const void* aux, float* ring, uint32_t ring_cap, const float* panw, hipStream_t s)>
         render_mix, render_mix_fast;
+    // ... and the Sequencer's mixed output in one launch (render_events_body MIXE): part as above, [groups][outputs][T]; graphs of
+    // at most two outputs (the block tiles of four waves must fit the CU's LDS)
+    std::function<bool(float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, const double* ev,
+                       const int* fade, double time0, double sr, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s)>
+        render_events_mix;
     // Sequencer-style rendering (fd_device.hpp render_events_body): ev = device [4][stride] f64, fade = device [V] or null
     std::function<void(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, const double* ev,
                        const int* fade, double time0, double sr, int mode, const void* aux, float* ring,
@@ -306,12 +311,32 @@ bool launch_render_mix(float* slots, size_t stride, size_t V, const float* in, f
     }
     return launch_render_mix_m<G, MIX_SUM>(slots, stride, V, in, part, T, mode, aux, ring, ring_cap, panw, s);
 }
+template <class G>
+bool launch_render_events_mix(float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, const double* ev,
+                              const int* fade, double time0, double sr, int mode, const void* aux, float* ring,
+                              uint32_t ring_cap, hipStream_t s) {
+    if (V == 0 || T == 0) return true;
+    if constexpr (G::OUT <= 2) {
+        tl_opts.last_kernel = LK_EVENTS;
+        const unsigned grid = (unsigned)(((V + 63) / 64 + 3) / 4);
+        if (mode == MODE_PROCESS)
+            hipLaunchKernelGGL((k_render_events_mix<G, MODE_PROCESS>), dim3(grid), dim3(256), 0, s, slots, stride, V, in, part, T, ev,
+                               fade, time0, sr, aux, ring, ring_cap);
+        else
+            hipLaunchKernelGGL((k_render_events_mix<G, MODE_TICK>), dim3(grid), dim3(256), 0, s, slots, stride, V, in, part, T, ev,
+                               fade, time0, sr, aux, ring, ring_cap);
+        return true;
+    } else {
+        return false;
+    }
+}
 // gives a kind its fused mix-down kernels (opt-in per kind: every instantiation is compile time and code size)
 template <class G>
 void attach_mix(std::vector<KindOps>& kinds, const char* name) {
     for (KindOps& k : kinds)
         if (k.name == name) {
             k.render_mix = &launch_render_mix<G>;
+            k.render_events_mix = &launch_render_events_mix<G>;
             using GF = typename FastOf<G>::type;
             if constexpr (!SameType<GF, G>::v) k.render_mix_fast = &launch_render_mix<GF>;
         }

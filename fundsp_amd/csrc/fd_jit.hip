@@ -130,7 +130,7 @@ struct JitModule {
 struct JitMix {
     std::vector<char> code;
     std::mutex mu;
-    struct Dev { hipModule_t mod = nullptr; hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; bool loaded = false; } dev[JitModule::MAXD];
+    struct Dev { hipModule_t mod = nullptr; hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; hipFunction_t ev[2] = {nullptr, nullptr}; bool loaded = false; } dev[JitModule::MAXD];
     ~JitMix() {
         int prev = -1;
         const bool have_prev = hipGetDevice(&prev) == hipSuccess;
@@ -152,6 +152,10 @@ struct JitMix {
                 const std::string fn = "jit_pipe_mix_" + std::to_string(x + 1) + "_" + std::to_string(m);
                 ok = hipModuleGetFunction(&f.fn[x][m], f.mod, fn.c_str()) == hipSuccess;
             }
+        for (int m = 0; m < 2 && ok; m++) {
+            const std::string fn = "jit_events_mix_" + std::to_string(m);
+            ok = hipModuleGetFunction(&f.ev[m], f.mod, fn.c_str()) == hipSuccess;
+        }
         if (!ok) { hipModuleUnload(f.mod); f.mod = nullptr; return nullptr; }
         return &f;
     }
@@ -273,6 +277,14 @@ std::string jit_source_mix(const std::string& type_expr, const std::string& prel
                  "size_t T, const void* aux, float* ring, uint32_t cap, const float* __restrict__ panw) {\n"
                  "  fd::jit_pipe_mix_body<JitG, " + m + ", " + x + ">(slots, stride, V, in, part, T, aux, ring, cap, panw); }\n";
         }
+    for (int mode = 0; mode < 2; mode++) {
+        std::string m = std::to_string(mode);
+        s += "extern \"C\" __global__ __launch_bounds__(256) void jit_events_mix_" + m +
+             "(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ part, "
+             "size_t T, const double* __restrict__ ev, const int* __restrict__ fade, double time0, double sr, const void* aux, "
+             "float* ring, uint32_t cap) {\n"
+             "  fd::jit_events_mix_body<JitG, " + m + ">(slots, stride, V, in, part, T, ev, fade, time0, sr, aux, ring, cap); }\n";
+    }
     return s;
 }
 
@@ -411,24 +423,25 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
         };
     // render + mix-down in one launch (fdsp_bank_process_mix): graphs with a pipeline plan; the kernels are compiled on first use
     jm->nout = meta[1];
-    auto mix_launch = [jm](int which, float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, int mix, int mode,
+    auto mix_module = [jm](int which) -> JitMix* {  // the mix-down kernels of G (0) / FastOf<G> (1), compiled on first use
+        std::lock_guard<std::mutex> lock(jm->mu);
+        if (!jm->mix[which] && !jm->mix_failed[which]) {
+            auto mm = std::make_shared<JitMix>();
+            std::string log;
+            const std::string type = which ? "typename fd::FastOf<" + jm->type_expr + ">::type" : jm->type_expr;
+            if (jit_compile_src(jit_source_mix(type, jm->prelude), jm->type_expr, &mm->code, &log) == 0) jm->mix[which] = mm;
+            else {
+                jm->mix_failed[which] = true;
+                fprintf(stderr, "fundsp_hip: the fused mix-down kernels of this graph failed to compile: %s\n", log.c_str());
+            }
+        }
+        return jm->mix[which].get();
+    };
+    auto mix_launch = [jm, mix_module](int which, float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, int mix, int mode,
                            const void* aux, float* ring, uint32_t ring_cap, const float* panw, hipStream_t s) -> bool {
         if (V == 0 || T == 0) return true;
         if (jm->pipe_stages < 1 || (mix == MIX_PAN && jm->nout != 1)) return false;
-        {
-            std::lock_guard<std::mutex> lock(jm->mu);
-            if (!jm->mix[which] && !jm->mix_failed[which]) {
-                auto mm = std::make_shared<JitMix>();
-                std::string log;
-                const std::string type = which ? "typename fd::FastOf<" + jm->type_expr + ">::type" : jm->type_expr;
-                if (jit_compile_src(jit_source_mix(type, jm->prelude), jm->type_expr, &mm->code, &log) == 0) jm->mix[which] = mm;
-                else {
-                    jm->mix_failed[which] = true;
-                    fprintf(stderr, "fundsp_hip: the fused mix-down kernels of this graph failed to compile: %s\n", log.c_str());
-                }
-            }
-        }
-        JitMix* mm = jm->mix[which].get();
+        JitMix* mm = mix_module(which);
         if (!mm) return false;
         const JitMix::Dev* f = mm->get();
         if (!f) { jit_launch_failed(); return true; }
@@ -448,6 +461,20 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
                 return mix_launch(1, slots, stride, V, in, part, T, mix, mode, aux, ring, ring_cap, panw, s);
             };
     }
+    if (jm->nout <= 2)  // the Sequencer's mixed output in one launch (fdsp_bank_process_events_mix)
+        out->render_events_mix = [mix_module](float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, const double* ev,
+                                              const int* fade, double time0, double sr, int mode, const void* aux, float* ring,
+                                              uint32_t ring_cap, hipStream_t s) -> bool {
+            if (V == 0 || T == 0) return true;
+            JitMix* mm = mix_module(0);
+            if (!mm) return false;
+            const JitMix::Dev* f = mm->get();
+            if (!f) { jit_launch_failed(); return true; }
+            void* args[] = {&slots, &stride, &V, &in, &part, &T, &ev, &fade, &time0, &sr, &aux, &ring, &ring_cap};
+            hipModuleLaunchKernel(f->ev[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, 256, 1, 1, 0, s, args, nullptr);
+            tl_opts.last_kernel = LK_EVENTS;
+            return true;
+        };
     out->render_events = [jm](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T,
                               const double* ev, const int* fade, double time0, double sr, int mode, const void* aux,
                               float* ring, uint32_t ring_cap, hipStream_t s) {

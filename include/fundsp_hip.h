@@ -275,6 +275,11 @@ int fdsp_bank_set_ring(fdsp_bank* bank, int ring_index, const float* data, size_
 #define FDSP_FADE_SMOOTH 1 /* Fade::Smooth: equal-amplitude crossfades (smooth5), the default */
 int fdsp_bank_set_events(fdsp_bank* bank, const double* events, const int* fade, size_t first_voice, size_t count);
 int fdsp_bank_process_events(fdsp_bank* bank, size_t frames, const float* d_in, float* d_out, int mode, void* stream);
+/* The Sequencer's OUTPUT -- the sum of its events (sequencer.rs:838-951: every active event's faded block added into the output
+ * buffer) -- in one launch: d_mix [outputs][frames], the mix-down's fixed summation order (below), so it equals fdsp_sum_voices of
+ * fdsp_bank_process_events' output bit for bit; the per-event samples never exist in HBM.  Graphs of at most two outputs whose kind
+ * has the fused kernels (FDSP_ENOTSUP otherwise); the clock advances as in fdsp_bank_process_events. */
+int fdsp_bank_process_events_mix(fdsp_bank* bank, size_t frames, const float* d_in, float* d_mix, int mode, void* stream);
 int fdsp_bank_events_rewind(fdsp_bank* bank, double time); /* set the sequencer clock (Sequencer::reset -> 0.0) */
 double fdsp_bank_events_time(const fdsp_bank* bank);       /* Sequencer::time() */
 

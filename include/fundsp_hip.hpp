@@ -605,6 +605,10 @@ class Bank {
     void process_events(size_t frames, const float* d_in, float* d_out, int mode = FDSP_MODE_PROCESS, void* stream = nullptr) {
         check(fdsp_bank_process_events(h_, frames, d_in, d_out, mode, stream));
     }
+    // ... the Sequencer's mixed output in the same launch: d_mix [outputs][frames]
+    void process_events_mix(size_t frames, const float* d_in, float* d_mix, int mode = FDSP_MODE_PROCESS, void* stream = nullptr) {
+        check(fdsp_bank_process_events_mix(h_, frames, d_in, d_mix, mode, stream));
+    }
     void events_rewind(double time) { check(fdsp_bank_events_rewind(h_, time)); }
     double events_time() const { return fdsp_bank_events_time(h_); }
 

@@ -71,6 +71,7 @@ pub mod ffi {
                                  frame_stride: usize, mode: c_int, stream: *mut c_void) -> c_int; // device-resident I/O
         pub fn fdsp_bank_process_mix(bank: *mut FdspBank, frames: usize, d_in: *const f32, d_mix: *mut f32, mix: c_int, mode: c_int,
                                      stream: *mut c_void) -> c_int; // render + reduce over the voices in one launch
+        pub fn fdsp_bank_process_events_mix(bank: *mut FdspBank, frames: usize, d_in: *const f32, d_mix: *mut f32, mode: c_int, stream: *mut c_void) -> c_int; // Sequencer output
         pub fn fdsp_bank_set_pan(bank: *mut FdspBank, pan: *const f32, first: usize, count: usize) -> c_int;
         pub fn fdsp_bank_mix_reserve(bank: *mut FdspBank, frames: usize) -> c_int; // AudioNode::allocate for the mix path
         pub fn fdsp_bank_synchronize(bank: *mut FdspBank) -> c_int;

@@ -56,6 +56,14 @@ def test_fm_voices_with_events(gpu, mode, seed):
     assert abs(b.events_time() - seq.time()) == 0.0
     summed = gpu.sum_voices(torch.from_numpy(np.ascontiguousarray(got.transpose(1, 2, 0))).cuda()).cpu().numpy()
     assert np.allclose(summed, mix, atol=1e-4)             # tree order vs the sequencer's serial order
+    # the Sequencer's OUTPUT in one launch (fdsp_bank_process_events_mix): bit-equal to the sum of the per-event render above, the same
+    # clock afterwards, and the same voice state
+    b2 = W.make_fm_svf_bank(V, SR, params=p)
+    b2.set_events(start, end, fin, fout, fade)
+    fused = b2.process_events_mix(T, mode=mode).cpu().numpy()
+    assert_bit_equal(fused, summed, "Sequencer output fused vs sum_voices(process_events)")
+    assert b2.events_time() == b.events_time()
+    assert_bit_equal(b2.get_state(), b.get_state(), "voice state after the fused launch")
 
 
 def test_sustained_voices_take_the_packed_path(gpu):
@@ -125,6 +133,18 @@ def test_fully_sustained_launch_is_a_plain_render(gpu, mode):
     for v in range(V):
         assert_bit_equal(got[v], per[v], f"voice {v}")
     assert abs(b.events_time() - seq.time()) == 0.0
+    # the same three launches mixed in the launch (the sustained one takes the pipeline kernel with the fused mix-down): the Sequencer's
+    # output, bit-equal to the sum of the per-event samples
+    b2 = W.make_fm_svf_bank(V, SR, params=p)
+    b2.set_events(start, end, fin, fout, fade)
+    mixes, kernels = [], []
+    for n in (T1, T2, T3):
+        mixes.append(b2.process_events_mix(n, mode=mode))
+        kernels.append(b2.get_option("last_kernel"))
+    fused = torch.cat(mixes, dim=1).cpu().numpy()
+    assert kernels[0] == 5 and kernels[2] == 5 and kernels[1] in (1, 2, 4), kernels   # scheduler kernel | render kernel | scheduler kernel
+    assert_bit_equal(fused, gpu.sum_voices(torch.cat(outs, dim=1)).cpu().numpy(), "three mixed launches vs sum_voices of the per-event render")
+    assert b2.events_time() == b.events_time()
 
 
 def test_gated_voices_with_inputs_and_two_launches(gpu, tables):
