@@ -391,6 +391,21 @@ def secondary(F, W, torch, sr, mode):
             torch.cuda.synchronize()
             c3["T64"]["fused_mix_us_per_launch"] = round((time.perf_counter() - t0) / 50 * 1e6, 2)
             c3["T64"]["fused_mix_kernels_us"] = round(sum(km) / len(km) * 1e3, 2)
+            mixes = [torch.empty_like(mixo) for _ in range(16)]
+            sm = torch.cuda.Stream()
+            with torch.cuda.stream(sm):
+                gm = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gm, stream=sm):
+                    for kk in range(16):
+                        wl["bank"].process_mix(64, mix=F.MIX_PAN, out=mixes[kk], mode=mode)
+                gm.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    gm.replay()
+                torch.cuda.synchronize()
+                c3["T64"]["fused_mix_hip_graph_replay_us_per_block"] = round((time.perf_counter() - t0) / 20 / 16 * 1e6, 2)
+            del gm, mixes
             c3["T64"]["hip_graph_replay_us_per_block"] = round(us, 2)
             c3["T64"]["hip_graph_value"] = round(V * 64 / us, 1)
             c3["T64"]["hip_graph_roofline_frac"] = round(algo / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
