@@ -96,6 +96,49 @@ def test_mixdown_allreduce_gloo_world2():
         assert np.array_equal(ret[0], ret[r])  # every rank holds the same reduced mix
 
 
+def _worker_order(rank, world, port, total, frames, ret):
+    import torch
+    import torch.distributed as dist
+
+    from mix_order import mix_order_reference
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sr = 48000.0
+        first, count = fdist.shard_range(total, rank, world)
+        p = W.fm_svf_params(count, sr, voice0=first)
+        out, _ = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], frames, sr, True, 1, 1)  # [frame][voice]
+        w = np.float32(np.cos(np.float32(np.pi) * np.float32(0.25)))
+        part = np.stack([mix_order_reference(out * w)] * 2)   # what fdsp_bank_process_mix hands the collective: the shard's partial mix
+        ret[rank] = fdist.allreduce_mix(torch.from_numpy(part.copy())).numpy().copy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_reproduce_the_one_rank_mix_bit_for_bit():
+    """Round 4: the per-GPU partial mix is produced in the mix-down's fixed order (an aligned binary tree over the voice groups), so
+    with the bank split at an aligned power-of-two group boundary the 2-rank all-reduce -- ONE addition per sample -- returns exactly
+    the 1-rank mix: multi-GPU runs of the mix-down are bit-reproducible against a single GPU at N = 2 (N = 4 / 8: up to the
+    collective's own order over the shards)."""
+    import torch.multiprocessing as mp
+
+    from mix_order import mix_order_reference
+
+    total, frames, world = 64 * 8, 96, 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_order, args=(world, port, total, frames, ret), nprocs=world, join=True)
+    p = W.fm_svf_params(total, 48000.0)
+    out, _ = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], frames, 48000.0, True, 1, 1)
+    w = np.float32(np.cos(np.float32(np.pi) * np.float32(0.25)))
+    whole = mix_order_reference(out * w)
+    for r in range(world):
+        assert np.array_equal(ret[r][0].view(np.uint32), whole.view(np.uint32)), f"rank {r}: all-reduced mix != the one-rank mix"
+
+
 def test_allreduce_mix_is_identity_without_process_group():
     import torch
 
