@@ -65,6 +65,21 @@ def test_fm_pan_mix_equals_mix_of_voice_out(gpu, V, T, mode):
     assert np.abs(mix).max() > 0.1
 
 
+@pytest.mark.parametrize("V,T", [(1, 1), (5, 3), (63, 8), (64, 65), (65, 129)])
+def test_tiny_banks_and_launches(gpu, V, T):
+    """One voice, one frame; fewer voices than a quarter; launches shorter than a chunk and one frame past a block: fused == unfused,
+    both mix kinds, both modes."""
+    import torch
+
+    for mode in (MODE_PROCESS, MODE_TICK):
+        b, p, pan = fm_bank(gpu, V)
+        ref = b.clone()
+        ref2 = b.clone()
+        out = ref.process(T, layout=LAYOUT_VOICE_MINOR, mode=mode)
+        assert_bit_equal(b.process_mix(T, mix=MIX_PAN, mode=mode).cpu().numpy(), gpu.mix_stereo(out[0], torch.from_numpy(pan).cuda()).cpu().numpy(), f"PAN V={V} T={T}")
+        assert_bit_equal(ref2.process_mix(T, mix=MIX_SUM, mode=mode).cpu().numpy(), gpu.sum_voices(out).cpu().numpy(), f"SUM V={V} T={T}")
+
+
 def test_fm_mix_against_the_oracles_serial_mix(gpu):
     """Voices from the CPU oracle, panned and added one after the other in f64: the fused f32 mix is within the stated bound."""
     V, T = 200, 64 * 3 + 5
