@@ -159,6 +159,20 @@ hipError_t sync_shared_locked(int dev) {
             padded.push_back(t.data[src + 1]);
             src += len;
         }
+        // ... and an interleaved copy of every pair of adjacent tables of equal length (WtSet::pair_off): WaveSynth reads both
+        // tables of its pair at the same index there, 32 contiguous bytes
+        for (int i = 0; i < fd::WT_MAX_TABLES; i++) nw.pair_off[i] = -1;
+        for (int i = 0; i + 1 < t.n; i++) {
+            if (t.len[i] != t.len[i + 1]) continue;
+            while (padded.size() % 4) padded.push_back(0.0f);  // 16-byte aligned runs
+            nw.pair_off[i] = (int)padded.size();
+            const size_t n_pad = (size_t)t.len[i] + 3, oa = (size_t)nw.off[i], ob = (size_t)nw.off[i + 1];
+            for (size_t k = 0; k < n_pad; k++) {
+                const float a = padded[oa + k], bb = padded[ob + k];
+                padded.push_back(a);
+                padded.push_back(bb);
+            }
+        }
         float* d = nullptr;
         err = hipMalloc((void**)&d, padded.size() * sizeof(float));
         if (err == hipSuccess) err = hipMemcpy(d, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice);

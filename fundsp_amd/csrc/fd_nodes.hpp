@@ -1003,6 +1003,10 @@ struct WtSet {
     float pitch[WT_MAX_TABLES];
     int off[WT_MAX_TABLES];
     int len[WT_MAX_TABLES];
+    // pair_off[i] >= 0: tables i and i + 1 have the same length and a second, INTERLEAVED copy of the two padded tables starts there:
+    // [a[0], b[0], a[1], b[1], ...] -- the eight taps WaveSynth reads from its table pair at one phase are then 32 contiguous bytes
+    // (one cache line, mostly) instead of 16 bytes in each of two tables.  -1: different lengths (one pair in four), the plain tables.
+    int pair_off[WT_MAX_TABLES];
     const float* data;
 };
 // shared sample buffers (the reference's Arc<Wave>: wave.rs), [channel][length] f32 in HBM
@@ -1087,6 +1091,14 @@ FD_HD int wt_table_index(const WtSet* t, int hint, float frequency) {  // :189-2
 #ifndef FD_WT_FIXED
 #define FD_WT_FIXED 0
 #endif
+#ifndef FD_WT_PAIRS
+// A/B switch, OFF: 1 = WaveSynth reads adjacent tables of equal length from their interleaved copy (WtSet::pair_off): one cache line per
+// lane and frame instead of two.  Measured (profiles/r04_ab_h_wt_pairs.txt): bit-identical and SLOWER -- config 4 voice-out 9.33 -> 10.05 ms,
+// with the fused mix-down 8.04 -> 8.96: three pairs in four are interleaved, the lanes of a wave differ, so every frame pays six selects
+// and two variable shifts to put the taps where the plain layout has them, and that costs more than the lines saved (both taps from ONE
+// table, without any extra instruction, bought 0.73 ms: profiles/r04_ab_d_c4_one_table.txt).
+#define FD_WT_PAIRS 0
+#endif
 struct Tap4 { float a0, a1, a2, a3, w; };
 // the pieces of wt_tap: index + interpolation weight, then the four floats from HBM / from the kernel's LDS copy
 FD_HD float wt_tap_index(uint32_t mask, float phase, uint32_t& i1) {
@@ -1169,6 +1181,7 @@ struct WaveSynth {
     float c_p0, c_p1;
     const float *c_tab1, *c_tab2;
     uint32_t c_mask1, c_mask2;
+    uint32_t c_sh;  // index -> float offset: 0 = plain tables, 1 = the interleaved copy of the pair (c_tab2 = c_tab1 + 4 there)
     // the taps gathered ahead for the next frame pair (packed path), valid for exactly the wrapped phases pf_p0 / pf_p1
     bool pf_ok;
     uint32_t pf_p0, pf_p1;
@@ -1216,6 +1229,14 @@ struct WaveSynth {
             c_tab2 = wt->data + wt->off[t + 2];
             c_mask1 = (uint32_t)wt->len[t + 1] - 1u;
             c_mask2 = (uint32_t)wt->len[t + 2] - 1u;
+            c_sh = 0;
+#if FD_WT_PAIRS
+            if (wt->pair_off[t + 1] >= 0) {  // equal lengths: both tables' taps from one 32-byte run of the interleaved copy
+                c_tab1 = wt->data + wt->pair_off[t + 1];
+                c_tab2 = c_tab1 + 4;
+                c_sh = 1;
+            }
+#endif
 #if FD_WT_SAME   // measurement only (NOT a renderer): both taps from ONE table -- the second gather hits the first one's lines
             c_tab2 = c_tab1;
             c_mask2 = c_mask1;
@@ -1225,6 +1246,24 @@ struct WaveSynth {
         }
         return clamp01f((f0 - c_p0) / (c_p1 - c_p0));
     }
+    // the two gathers at table indices i1 / i2 have landed in t1 / t2: in the interleaved copy they hold {a0 b0 a1 b1} {a2 b2 a3 b3}
+    // (a = table 1, b = table 2) -- put the taps where the plain layout has them (six selects; the lanes of a wave differ)
+    FD_HD void untangle(Tap4& t1, Tap4& t2) const {
+#if FD_WT_PAIRS
+        const bool pr = c_sh != 0;
+        const float a1 = pr ? t1.a2 : t1.a1, a2 = pr ? t2.a0 : t1.a2, a3 = pr ? t2.a2 : t1.a3;
+        const float b0 = pr ? t1.a1 : t2.a0, b1 = pr ? t1.a3 : t2.a1, b2 = pr ? t2.a1 : t2.a2;
+        t1.a1 = a1; t1.a2 = a2; t1.a3 = a3;
+        t2.a0 = b0; t2.a1 = b1; t2.a2 = b2;
+#endif
+    }
+    FD_HD void taps(float ph, Tap4& t1, Tap4& t2) const {  // Wavetable::at of both tables at one phase (:154-166)
+        uint32_t i1, i2;
+        const float w1 = wt_tap_index(c_mask1, ph, i1), w2 = wt_tap_index(c_mask2, ph, i2);
+        t1 = wt_tap_mem(c_tab1 + (i1 << c_sh), w1);
+        t2 = wt_tap_mem(c_tab2 + (i2 << c_sh), w2);
+        untangle(t1, t2);
+    }
     template <int PH> FD_HD void step(const float* in, float* out) {
         if (PH == PH_SIMD) {  // process :327-348
             // table pair and crossfade from LANE 0's frequency for the whole 8-sample item
@@ -1232,7 +1271,8 @@ struct WaveSynth {
             item_pos++;
             phase += in[0] * sample_duration;
             float ph = phase - __builtin_floorf(phase);  // wide's inherent f32x8::floor (true floor)
-            Tap4 t1 = wt_tap(c_tab1, c_mask1, ph), t2 = wt_tap(c_tab2, c_mask2, ph);
+            Tap4 t1, t2;
+            taps(ph, t1, t2);
             out[0] = (1.0f - item_w) * tap_eval(t1) + item_w * tap_eval(t2);
             if (NOUT > 1) out[1] = ph;
         } else {  // tick :310-324: increment + wrap BEFORE reading
@@ -1240,7 +1280,8 @@ struct WaveSynth {
             phase += frequency * sample_duration;
             phase -= __builtin_floorf(phase);
             float w = select(__builtin_fabsf(frequency));
-            Tap4 t1 = wt_tap(c_tab1, c_mask1, phase), t2 = wt_tap(c_tab2, c_mask2, phase);
+            Tap4 t1, t2;
+            taps(phase, t1, t2);
             out[0] = (1.0f - w) * tap_eval(t1) + w * tap_eval(t2);
             if (NOUT > 1) out[1] = phase;
         }
@@ -1267,8 +1308,8 @@ struct WaveSynth {
             if (__builtin_amdgcn_ballot_w64(!hit) == 0ull) {
                 a1 = pf_a1; a2 = pf_a2; b1 = pf_b1; b2 = pf_b2;
             } else {
-                a1 = wt_tap(c_tab1, c_mask1, ph0); a2 = wt_tap(c_tab2, c_mask2, ph0);
-                b1 = wt_tap(c_tab1, c_mask1, ph1); b2 = wt_tap(c_tab2, c_mask2, ph1);
+                taps(ph0, a1, a2);
+                taps(ph1, b1, b2);
             }
             {
                 float np = phase + d.x;
@@ -1278,16 +1319,19 @@ struct WaveSynth {
                 uint32_t ia1, ia2, ib1, ib2;
                 const float wa1 = wt_tap_index(c_mask1, q0, ia1), wa2 = wt_tap_index(c_mask2, q0, ia2);
                 const float wb1 = wt_tap_index(c_mask1, q1, ib1), wb2 = wt_tap_index(c_mask2, q1, ib2);
-                pf_a1 = wt_tap_mem(c_tab1 + ia1, wa1); pf_a2 = wt_tap_mem(c_tab2 + ia2, wa2);
-                pf_b1 = wt_tap_mem(c_tab1 + ib1, wb1); pf_b2 = wt_tap_mem(c_tab2 + ib2, wb2);
+                pf_a1 = wt_tap_mem(c_tab1 + (ia1 << c_sh), wa1); pf_a2 = wt_tap_mem(c_tab2 + (ia2 << c_sh), wa2);
+                pf_b1 = wt_tap_mem(c_tab1 + (ib1 << c_sh), wb1); pf_b2 = wt_tap_mem(c_tab2 + (ib2 << c_sh), wb2);
+                untangle(pf_a1, pf_a2);
+                untangle(pf_b1, pf_b2);
                 pf_p0 = f2u(q0);
                 pf_p1 = f2u(q1);
                 pf_ok = true;
             }
 #else
             // 16 independent gathers in flight before any of them is consumed
-            Tap4 a1 = wt_tap(c_tab1, c_mask1, ph0), a2 = wt_tap(c_tab2, c_mask2, ph0);
-            Tap4 b1 = wt_tap(c_tab1, c_mask1, ph1), b2 = wt_tap(c_tab2, c_mask2, ph1);
+            Tap4 a1, a2, b1, b2;
+            taps(ph0, a1, a2);
+            taps(ph1, b1, b2);
 #endif
 #if FD_WT_PACKED
             out[0] = (1.0f - item_w) * tap_eval2(a1, b1) + item_w * tap_eval2(a2, b2);

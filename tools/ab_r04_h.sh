@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+run() { if [ "$1" != "default" ]; then export FUNDSP_HIP_LIB=$PWD/variants/libfundsp_hip_$1.so; else unset FUNDSP_HIP_LIB; fi; shift; timeout 120 python tools/c4_ab.py "$@" 2>&1 | grep -v amdgpu.ids; }
+for pass in 1 2; do
+run nopairs --splits 0 --mix --check --label "plain tables (FD_WT_PAIRS=0)"
+run default --splits 0 --mix --check --label "interleaved copies of equal-length table pairs"
+done
