@@ -33,7 +33,7 @@ for m in re.finditer(r"^(_ZN2fd13k_render_pipeI\S+):", asm, re.M):
         start = m.start()
         break
 assert start is not None, "headline kernel not found in the ISA"
-body = asm[start:asm.find("s_endpgm", start)].split("\n")
+body = asm[start:asm.find(".Lfunc_end", start)].split("\n")  # (the whole function: a kernel may hold more than one s_endpgm)
 labels = {}
 for n, l in enumerate(body):
     mm = re.match(r"^(\.LBB\d+_\d+):", l)
