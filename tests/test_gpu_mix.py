@@ -95,6 +95,21 @@ def test_fm_mix_against_the_oracles_serial_mix(gpu):
     assert_bit_equal(mix[0], mix_order_reference(want * wl[None, :]), "left vs oracle voices in the stated order")
 
 
+def test_pan_mix_is_the_oracles_panner_per_voice(gpu):
+    """FDSP_MIX_PAN against the reference's own shape: every voice as `voice >> pan(p)` through the ORACLE's Panner node (pan.rs:50-76),
+    the stereo voices added in the mix-down's order -- bit for bit, pan positions beyond +-1 included (clamp11)."""
+    V, T = 70, 64 * 2 + 11
+    p = W.fm_svf_params(V, SR)
+    b = W.make_fm_svf_bank(V, SR, params=p)
+    pan = np.linspace(-1.2, 1.2, V).astype(np.float32)
+    b.set_pan(pan)
+    mix = b.process_mix(T, mix=MIX_PAN).cpu().numpy()
+    want, _ = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], T, SR, True, 0, 4)      # the oracle's voices, [V][T]
+    voices = [O.pan(float(pan[v])).render_blocks(want[v][None, :]) for v in range(V)]                # each through the oracle's Panner: [2][T]
+    stereo = np.stack(voices, axis=-1)                                  # [2][T][V]
+    assert_bit_equal(mix, mix_order_reference(stereo), "fused PAN mix vs the oracle's `voice >> pan(p)` voices in the stated order")
+
+
 def test_fm_sum_mix_mono(gpu):
     """MIX_SUM of a mono graph: [1][T] = fdsp_sum_voices of the voice-out render (the Sequencer's mix of its events)."""
     V, T = 64 * 9 + 11, 64 * 5
