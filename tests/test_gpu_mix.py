@@ -292,3 +292,51 @@ def test_sum_instances_planar(gpu):
             nxt.append(level[-1])
         level = nxt
     assert_bit_equal(got, level[0], "sum over instances: aligned binary tree")
+
+
+INVENTORY_MIX = ["noise_moog", "stack_binop_sub", "comb_allpass_chain", "saw_filter_env", "chorus_tap", "pulse_resonator",
+                 "bus_branch_thru", "busf_resonators", "svf_q_forms", "pulse_wave", "multitap_allnest_panner", "limiter_stereo"]
+
+
+@pytest.mark.parametrize("name", INVENTORY_MIX)
+def test_inventory_graphs_mix_or_refuse(gpu, name):
+    """A sweep of the run-time compiled inventory (tests/test_gpu_jit.py GRAPHS: rings, wavetables, inputs, two outputs, stages of
+    every weight) through fdsp_bank_process_mix: a graph either mixes bit-equal to sum_voices / mix_stereo of its voice-out render
+    -- padded lanes of the last voice group included, V is not a multiple of 64 -- or refuses with FDSP_ENOTSUP and leaves the
+    bank where it was (the voice-out render that follows equals the one of an untouched clone)."""
+    import torch
+    from fundsp_amd import FdspError
+    from fundsp_amd._lib import ENOTSUP
+    from fundsp_amd import graph as G
+    from test_gpu_jit import GRAPHS, noise_input
+
+    build, ni, ring = GRAPHS[name]
+    g = build(G)
+    V, T = 64 * 3 + 21, 64 * 5 + 9
+    for kind in G.uses_wavetables(g):
+        t = O.Wavetable.get(kind)
+        offs = np.concatenate([[0], np.cumsum(t.lengths)])
+        gpu.wavetable_upload(kind, t.pitches, [t.data[offs[i]:offs[i + 1]] for i in range(len(t.lengths))])
+    b = gpu.Bank.from_graph(g, V, ring_frames=ring, sample_rate=SR)
+    b.set_seed(np.arange(V, dtype=np.uint64) * 977 + 3)
+    x = None
+    if ni:
+        xs = noise_input(V, ni, T, seed=5)                       # [voice][channel][frame]
+        x = torch.from_numpy(np.ascontiguousarray(xs.transpose(1, 2, 0))).cuda()   # voice-minor
+    ref = b.clone()
+    modes = [MIX_SUM] + ([MIX_PAN] if b.outputs() == 1 else [])
+    pan = np.cos(np.arange(V, dtype=np.float32)).astype(np.float32)
+    for mix in modes:
+        fused, plain = ref.clone(), ref.clone()
+        if mix == MIX_PAN:
+            fused.set_pan(pan)
+        try:
+            got = fused.process_mix(T, x, mix=mix).cpu().numpy()
+        except FdspError as e:
+            assert e.code == ENOTSUP, e
+            assert_bit_equal(fused.process(T, x).cpu().numpy(), plain.process(T, x).cpu().numpy(), f"{name}: a refused mix leaves the bank alone")
+            continue
+        out = plain.process(T, x)
+        want = gpu.sum_voices(out) if mix == MIX_SUM else gpu.mix_stereo(out[0], torch.from_numpy(pan).cuda())
+        assert_bit_equal(got, want.cpu().numpy(), f"{name}: fused mix {mix} vs the mix of the voice-out render")
+        assert_bit_equal(fused.process(T, x).cpu().numpy(), plain.process(T, x).cpu().numpy(), f"{name}: state after the fused mix")
