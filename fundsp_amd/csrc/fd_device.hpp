@@ -750,8 +750,15 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
 #ifndef FD_PIPE_BUFFER_STORE
 #define FD_PIPE_BUFFER_STORE 1  // A/B switch: 0 = plain global stores (per-frame 64-bit vector address arithmetic)
 #endif
+// Streams pass the caches by: every input line is read once and every output line written once, while a wavetable voice's table
+// lines are re-read for 7-14 frames each (two groups of 64 voices x two tables = the 256 lines of a CU's L1).  Non-temporal feed loads
+// and sample stores: config 4 9.14 -> 8.89 ms (either one alone 9.07-9.10; profiles/r04_ab_j_stream_policy.txt), the headline -- no
+// tables -- within the noise (profiles/r03_ab20_21_small.txt).  A/B: 0 / 0 = the plain policy; 19 = sc0 sc1 nt stores.
+#ifndef FD_FEED_NT
+#define FD_FEED_NT 1
+#endif
 #ifndef FD_PIPE_STORE_AUX
-#define FD_PIPE_STORE_AUX 0     // cache-policy bits of the pipeline kernel's output stores (A/B: 2 = nt, 19 = sc0 sc1 nt)
+#define FD_PIPE_STORE_AUX 2     // cache-policy bits of the pipeline kernel's output stores (0 = none, 2 = nt, 19 = sc0 sc1 nt)
 #endif
 #ifndef FD_PIPE_PRODUCER_PLAIN
 #define FD_PIPE_PRODUCER_PLAIN 0  // A/B switch: 1 = stage 0 of a multi-stage pipeline evaluates its sines with plain ops
@@ -1441,6 +1448,16 @@ static_assert(role_order_is(role_order<true, 3, 100, 30, 83, 4>(), 0, 1, 2, 3), 
 // -- a cheap phase recurrence under an expensive interpolation -- in two, so that the SIMD it shares with the envelope-and-pan stage
 // holds three half-busy waves instead of two busy ones (a wave issues at most one VALU instruction per ~4 cycles; the SIMD takes
 // one every 2-4), while the ladder keeps the other SIMD to itself.  Waves w, w + 4, w + 8 of a workgroup share a SIMD:
+// FD_ROLE_CROSS (two voice groups of loader + three stages, the middle stage the heaviest): SIMDs by ROLE instead of by group --
+//   SIMD 0: both groups' middle stages   SIMD 1: group 0's first stage + loader   SIMD 2: group 1's   SIMD 3: both groups' last stages
+// A one-sample-deep recurrence (config 4's ladder: 85 dependent plain instructions per sample) issues one instruction per ~4.4 cycles
+// whatever else happens; two of them fill the SIMD's 2-cycle slots between themselves, and the packed oscillator stage -- which
+// keeps a SIMD busy on its own -- no longer shares one with the envelope stage.
+#ifndef FD_ROLE_CROSS
+#define FD_ROLE_CROSS 0
+#endif
+struct CrossRoles { int grp[8], role[8]; };
+constexpr CrossRoles cross_roles() { return CrossRoles{{0, 0, 1, 0, 1, 0, 1, 1}, {2, 1, 1, 3, 2, 0, 0, 3}}; }
 struct SplitRoles { int grp[16], role[16]; };  // role: 0 = loader (graphs with inputs), then the NA parts of stage 0, then stages 1 ..
 template <bool FEED, int S, int NA, int GPW>
 constexpr SplitRoles split_roles() {
@@ -1493,8 +1510,10 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     constexpr SplitRoles SR = split_roles<FEED, S, NA, GPW>();
     static_assert(NA == 1 || (S0::HAS_SKIP && S >= 2 && MODE == MODE_PROCESS && GPW * ((FEED ? 1 : 0) + NA + S - 1) <= 16), "split stage 0: needs skip2, a later stage, process mode");
     // role: 0 = loader (graphs with inputs), then compute stage 0 (NA parts), then the later stages
-    const int grp = NA == 1 ? w % GPW : SR.grp[w];
-    const int crole = NA == 1 ? RO.role[w / GPW] : SR.role[w];                       // canonical role index
+    constexpr CrossRoles CR = cross_roles();
+    constexpr bool CROSS = FD_ROLE_CROSS != 0 && FEED && S == 3 && NA == 1 && GPW == 2 && S1::weight >= S0::weight;
+    const int grp = CROSS ? CR.grp[w] : (NA == 1 ? w % GPW : SR.grp[w]);
+    const int crole = CROSS ? CR.role[w] : (NA == 1 ? RO.role[w / GPW] : SR.role[w]);  // canonical role index
     const int part = (NA > 1 && crole >= (FEED ? 1 : 0) && crole < (FEED ? 1 : 0) + NA) ? crole - (FEED ? 1 : 0) : 0;
     const int role = NA == 1 ? crole : (crole < (FEED ? 1 : 0) + NA ? (crole < (FEED ? 1 : 0) ? 0 : (FEED ? 1 : 0)) : crole - (NA - 1));  // ... with the parts folded
     // (Half-filled waves -- 32 voices per wave, twice the waves -- were measured for the heavy config-4 voice: 33.7 ms
@@ -1535,7 +1554,11 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                 for (int k = 0; k < SUB; k++) {
                     const size_t t = tj + k < T ? tj + k : T - 1;
                     if (MIX != MIX_NONE && !active) rg[c][k] = 0.0f;  // a padded voice of a mix-down launch hears silence
+#if FD_FEED_NT   // A/B: the feed as non-temporal loads -- every line is read once, it need not displace table lines in L1
+                    else rg[c][k] = __builtin_nontemporal_load(&inw[((size_t)c * T + t) * V + lane]);
+#else
                     else rg[c][k] = inw[((size_t)c * T + t) * V + lane];
+#endif
                 }
         };
         const bool on = run;

@@ -1186,6 +1186,11 @@ struct WaveSynth {
     bool pf_ok;
     uint32_t pf_p0, pf_p1;
     Tap4 pf_a1, pf_a2, pf_b1, pf_b2;
+#if FD_WT_PREFETCH >= 2
+    // FD_WT_PREFETCH = D (2 or 4): D sets of taps in flight, the set of frame pair k + D is gathered while pair k is evaluated
+    struct PfSlot { bool ok; uint32_t p0, p1; Tap4 a1, a2, b1, b2; };
+    PfSlot pfs[FD_WT_PREFETCH];
+#endif
     template <class V> FD_HD void visit(V& v) {
         v.f(phase, STATE, "phase");
         v.u32(hint, STATE, "table_hint");
@@ -1197,7 +1202,14 @@ struct WaveSynth {
     FD_HD void bind(Ctx& a) {
         wt = &a.aux->wt[SET];
         c_table = -1;
+        pf_drop();
+    }
+    FD_HD void pf_drop() {  // nothing gathered ahead is valid any more
         pf_ok = false;
+#if FD_WT_PREFETCH >= 2
+#pragma unroll
+        for (int k = 0; k < FD_WT_PREFETCH; k++) pfs[k].ok = false;
+#endif
     }
     FD_HD void init() {  // WaveSynth::new :270-281: phase 0.0 WITHOUT reset
         phase = 0.0f;
@@ -1242,7 +1254,7 @@ struct WaveSynth {
             c_mask2 = c_mask1;
 #endif
             hint = (uint32_t)t;
-            pf_ok = false;  // taps gathered ahead came from the previous table pair
+            pf_drop();  // taps gathered ahead came from the previous table pair
         }
         return clamp01f((f0 - c_p0) / (c_p1 - c_p0));
     }
@@ -1295,7 +1307,46 @@ struct WaveSynth {
             float ph0 = phase - __builtin_floorf(phase);
             phase += d.y;
             float ph1 = phase - __builtin_floorf(phase);
-#if FD_WT_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
+#if FD_WT_PREFETCH >= 2 && defined(__HIP_DEVICE_COMPILE__)
+            // D sets of taps in flight (A/B of the gather latency under L1 misses): pair k takes set k mod D if its phases have the
+            // bits predicted D pairs ago, then the set is re-armed with the gathers of pair k + D.  The packed loops call this
+            // four times per SIMD item with item_pos known at compile time (item_begin), so the set is a fixed group of registers in
+            // each of the unrolled calls; anywhere else the switch below is a wave-uniform branch.  Whatever the order of calls,
+            // a set is only ever used for exactly the phases it was gathered for.
+            Tap4 a1, a2, b1, b2;
+            auto turn = [&](PfSlot& s) {
+                const bool hit = s.ok && f2u(ph0) == s.p0 && f2u(ph1) == s.p1;
+                if (__builtin_amdgcn_ballot_w64(!hit) == 0ull) {
+                    a1 = s.a1; a2 = s.a2; b1 = s.b1; b2 = s.b2;
+                } else {
+                    taps(ph0, a1, a2);
+                    taps(ph1, b1, b2);
+                }
+                float np = phase;
+#pragma unroll
+                for (int k = 1; k < FD_WT_PREFETCH; k++) { np += d.x; np += d.y; }
+                np += d.x;
+                const float q0 = np - __builtin_floorf(np);
+                np += d.y;
+                const float q1 = np - __builtin_floorf(np);
+                uint32_t ia1, ia2, ib1, ib2;
+                const float wa1 = wt_tap_index(c_mask1, q0, ia1), wa2 = wt_tap_index(c_mask2, q0, ia2);
+                const float wb1 = wt_tap_index(c_mask1, q1, ib1), wb2 = wt_tap_index(c_mask2, q1, ib2);
+                s.a1 = wt_tap_mem(c_tab1 + (ia1 << c_sh), wa1); s.a2 = wt_tap_mem(c_tab2 + (ia2 << c_sh), wa2);
+                s.b1 = wt_tap_mem(c_tab1 + (ib1 << c_sh), wb1); s.b2 = wt_tap_mem(c_tab2 + (ib2 << c_sh), wb2);
+                untangle(s.a1, s.a2);
+                untangle(s.b1, s.b2);
+                s.p0 = f2u(q0);
+                s.p1 = f2u(q1);
+                s.ok = true;
+            };
+            const int set = (item_pos >> 1) & (FD_WT_PREFETCH - 1);
+#if FD_WT_PREFETCH == 4
+            if (set == 0) turn(pfs[0]); else if (set == 1) turn(pfs[1]); else if (set == 2) turn(pfs[2]); else turn(pfs[3]);
+#else
+            if (set == 0) turn(pfs[0]); else turn(pfs[1]);
+#endif
+#elif FD_WT_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
             // The gathers are served by L2 (a saw set is 160 KiB) and the stage has ~35 instructions per frame: issued
             // where they are used, their round trip (~600 cycles per pair) is 2/3 of the stage's time (config 4: stage 0
             // alone 10.4 ms, 33 issue slots per frame).  The next pair's phases are this pair's plus the same two
@@ -1355,7 +1406,7 @@ struct WaveSynth {
         if ((item_pos & 7) == 0) item_w = select(__builtin_fabsf(in[0]));
         item_pos++;
         phase += in[0] * sample_duration;
-        pf_ok = false;
+        pf_drop();
     }
     template <int PH> FD_HD void skip2(const v2f* in) {
         static_assert(PH == PH_SIMD, "WaveSynth::skip2: packed part of a process block only");
@@ -1364,7 +1415,7 @@ struct WaveSynth {
         const v2f d = in[0] * sample_duration;
         phase += d.x;
         phase += d.y;
-        pf_ok = false;
+        pf_drop();
     }
 };
 

@@ -4,18 +4,24 @@
 #   FILE=fd_kinds_fm (default: the oscillator -> filter chains incl. the headline kernel, ~15 s) | fd_kinds_fm_ts (their
 #   three-way time-split kernels) | fd_kinds_graph (~90 s)
 #   ILP=0 drops the fm unit's -mllvm -amdgpu-sched-strategy=iterative-ilp
+#   FILE2=fd_kinds_graph_mix: a second unit built with the same macros (plain flags) into the same library
 set -e
 cd "$(dirname "$0")/../fundsp_amd/csrc"
 NAME=$1; shift
 FILE=${FILE:-fd_kinds_fm}
 mkdir -p ../../variants
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function -Wno-unused-value"
-if { [ "$FILE" = "fd_kinds_fm" ] || [ "$FILE" = "fd_kinds_fm_mix" ]; } && [ "${ILP:-1}" = "1" ]; then FLAGS="$FLAGS -mllvm -amdgpu-sched-strategy=iterative-ilp"; fi
-if [ "$FILE" = "fd_kinds_fm_ts" ] && [ "${ILP:-1}" = "1" ]; then FLAGS="$FLAGS -mllvm -amdgpu-sched-strategy=max-ilp"; fi
-/opt/rocm/bin/hipcc $FLAGS $@ -c $FILE.hip -o /tmp/${FILE}_$NAME.o
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function -Wno-unused-value"
+flags_of() {  # the Makefile's scheduling strategy per unit
+  local f="$BASE"
+  if { [ "$1" = "fd_kinds_fm" ] || [ "$1" = "fd_kinds_fm_mix" ]; } && [ "${ILP:-1}" = "1" ]; then f="$f -mllvm -amdgpu-sched-strategy=iterative-ilp"; fi
+  if [ "$1" = "fd_kinds_fm_ts" ] && [ "${ILP:-1}" = "1" ]; then f="$f -mllvm -amdgpu-sched-strategy=max-ilp"; fi
+  echo "$f"
+}
+/opt/rocm/bin/hipcc $(flags_of $FILE) $@ -c $FILE.hip -o /tmp/${FILE}_$NAME.o
+if [ -n "$FILE2" ]; then /opt/rocm/bin/hipcc $(flags_of $FILE2) $@ -c $FILE2.hip -o /tmp/${FILE2}_$NAME.o; fi
 OBJS=""
 for o in fd_capi fd_kinds_leaf fd_kinds_graph fd_kinds_graph_mix fd_kinds_fm fd_kinds_fm_mix fd_kinds_fm_ts fd_fdn fd_jit fd_comm fd_rust; do
-  if [ "$o" = "$FILE" ]; then OBJS="$OBJS /tmp/${FILE}_$NAME.o"; else OBJS="$OBJS $o.o"; fi
+  if [ "$o" = "$FILE" ]; then OBJS="$OBJS /tmp/${FILE}_$NAME.o"; elif [ "$o" = "$FILE2" ]; then OBJS="$OBJS /tmp/${FILE2}_$NAME.o"; else OBJS="$OBJS $o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libfundsp_hip_$NAME.so $OBJS -lhiprtc -lrccl -ldl
 echo built variants/libfundsp_hip_$NAME.so

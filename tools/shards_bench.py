@@ -9,10 +9,11 @@ import fundsp_amd as F
 from fundsp_amd import workloads as W
 
 T, sr = 48000, 48000.0
+TS = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 0]   # shards_bench.py 1 = the default kernels only
 for V in (32768, 16384, 8192):
     ref = None
     row = []
-    for ts in (1, 2, 0):
+    for ts in TS:
         b = W.make_fm_svf_bank(V, sr)
         b.set_option("time_split", ts)
         out = torch.empty((1, T, V), dtype=torch.float32, device="cuda")
