@@ -1434,7 +1434,10 @@ int fdsp_bank_process_mix(fdsp_bank* b, size_t frames, const float* d_in, float*
     if (!capturing && timing) HIPCHK(hipEventRecord(b->e0, s));
     resolve_opts(b);
     const bool done = launch(b->slots, b->stride, b->V, d_in, b->mix_part, frames, mix, mode, b->aux, b->ring, b->ring_cap, b->panw, s);
-    if (!done) return fail(FDSP_ENOTSUP, "kind '" + b->ops->name + "': no fused mix-down kernel for this graph shape (single-stage graphs without inputs, 3+ outputs with FDSP_MIX_PAN)");
+    if (!done) {
+        b->timed = false;  // e0 was re-recorded for a launch that did not happen: no event pair to read
+        return fail(FDSP_ENOTSUP, "kind '" + b->ops->name + "': no fused mix-down kernel for this graph shape (single-stage graphs without inputs, 3+ outputs with FDSP_MIX_PAN)");
+    }
     b->last_kernel = fd::tl_opts.last_kernel;
     // the groups' partials -> d_mix, aligned binary tree (k_mix_tree); the time it takes is part of the render's event pair
     launch_mix_tree(b->mix_part, d_mix, R, (b->V + 63) / 64, s);
@@ -1580,7 +1583,10 @@ int events_render(fdsp_bank* b, size_t frames, const float* d_in, float* d_out, 
         if (!done)
             done = b->ops->render_events_mix(b->slots, b->stride, b->V, d_in, b->mix_part, frames, b->ev, b->ev_fade, b->seq_time, b->sr, mode,
                                              b->aux, b->ring, b->ring_cap, s);
-        if (!done) return fail(FDSP_ENOTSUP, "kind '" + b->ops->name + "': more than two outputs -- no fused Sequencer mix; call fdsp_bank_process_events and fdsp_sum_voices");
+        if (!done) {
+            b->timed = false;
+            return fail(FDSP_ENOTSUP, "kind '" + b->ops->name + "': more than two outputs -- no fused Sequencer mix; call fdsp_bank_process_events and fdsp_sum_voices");
+        }
         launch_mix_tree(b->mix_part, d_mix, R, (b->V + 63) / 64, s);
     } else if (sustained)
         b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, 0, FDSP_LAYOUT_VOICE_MINOR, mode, b->aux, b->ring,
