@@ -351,7 +351,7 @@ def secondary(F, W, torch, sr, mode):
     # config 3 is quoted at T in {64, 4096, 48000}; the headline is T = 48000, here the other two (exact, voice-out).
     # Algorithmic bytes V*T*4 + V*64: 5 B per voice-sample at T = 64.  T = 64 also replayed from a HIP graph (the real-time pattern).
     c3 = {"name": "config3_frames_per_launch", "what": "BASELINE config 3 (65536 voices, exact, voice-out) at the other launch lengths of SURVEY 8(d): "
-          "T = 64 (one AudioNode::process block per launch: the single-wave kernel) and T = 4096; algorithmic bytes V*T*4 + V*64 per launch", "unit": "Msamples/s"}
+          "T = 64 (one AudioNode::process block per launch; `last_kernel` says which family ran: 2 = the stage pipeline) and T = 4096; algorithmic bytes V*T*4 + V*64 per launch", "unit": "Msamples/s"}
     V = TOTAL_VOICES
     for T in (64, 4096):
         wl = make_workload(F, W, torch, 3, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, "exact")

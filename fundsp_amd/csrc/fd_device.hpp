@@ -828,6 +828,20 @@ template <class X, class Y> struct Cost<Stack<X, Y>> { static constexpr int v = 
 template <class O, class X, class Y> struct Cost<Binop<O, X, Y>> { static constexpr int v = Cost<X>::v + Cost<Y>::v + 1; };
 template <class X, class U> struct Cost<Unop<X, U>> { static constexpr int v = Cost<X>::v + 1; };
 
+// Launch length (frames) from which a voice-minor launch takes the stage pipeline instead of the single-wave kernel.  Measured per
+// kernel family at T = 16 ... 512 (tools/small_t_kernels.py, profiles/r04_small_t_kernels.txt): with a chain worth cutting (config 3: 59
+// instructions per sample, config 4: 313) the pipeline wins from ONE 64-frame block on -- config 3, 65 536 voices: 13.5 vs 15.8 us at
+// T = 64, 19.5 vs 24.8 at 128, 24.7 vs 32.4 at 192; config 4: 30.6 vs 33.8, 47.7 vs 58.4, 63.6 vs 82.6 -- while a light graph (config 2's
+// noise >> biquad: 22) only gets its hand-over rounds paid back from four blocks on (7.1 vs 8.2 us at 64, 15.7 vs 15.2 at 256), and below a
+// block the single wave is as fast or faster everywhere.  A/B: -DFD_PIPE_MIN_T=n overrides both.
+template <class G> struct PipeMinT {
+#ifdef FD_PIPE_MIN_T
+    static constexpr int v = FD_PIPE_MIN_T;
+#else
+    static constexpr int v = Cost<G>::v >= 40 ? 64 : 256;
+#endif
+};
+
 // Chain<G, HEAD>: the stages a graph can be cut into.  A Pipe chains its two sides.  A Binop whose left operand is a
 // GENERATOR chain (no inputs) and which sits at the head of the graph -- so that its right operand reads the graph's own
 // inputs -- counts the left operand's stages plus one TAIL stage (right operand + the operator):
@@ -2413,6 +2427,7 @@ FD_D void describe_body(char* out, int cap, int* meta) {
     meta[7] = PlanarPlan<G>::S >= 1 ? 256 * PlanarPlan<G>::T::WAVES : 0;  // threads of the planar pipeline kernel (0 = none)
     meta[8] = SameType<typename FastOf<G>::type, G>::v ? 0 : 1;            // the graph has a tolerance-mode variant
     meta[9] = JitPipeSmall<G>::on ? 1 : 0;                                 // heavy: jit_pipe_g1 / _g2 exist for small banks
+    meta[10] = PipeMinT<G>::v;                                             // launch length from which the pipeline kernel is taken
 }
 
 // pipeline kernel entry for run-time compiled graphs: empty when the graph has no plan

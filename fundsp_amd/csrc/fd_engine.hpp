@@ -196,6 +196,13 @@ bool launch_render_pipe_planar(float* slots, size_t stride, size_t V, const floa
 }
 
 
+// Launch lengths from which a launch leaves the single-wave kernel: PipeMinT<G> (fd_device.hpp) for the stage pipeline, and one whole
+// 64-frame block for the time-split kernels of small banks (config 3's shards: 9.2-9.8 us against 13.5-13.9 at T = 64, 12.5-13.4 against
+// 22 at 128, 15-16 against 30 at 192; profiles/r04_small_t_kernels.txt).  "pipe_split" 2 / 3 force the pipeline at any length, 0 the
+// single-wave kernel.
+#ifndef FD_TS_MIN_T
+#define FD_TS_MIN_T 64
+#endif
 template <class G>
 void launch_render(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
                    int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
@@ -203,7 +210,7 @@ void launch_render(float* slots, size_t stride, size_t V, const float* in, float
     // banks that leave most SIMDs idle (<= 2 voice groups per CU): split the oscillator stages over time as well
     if constexpr (TsPlan<G>::ok) {
         const size_t groups = (V + 63) / 64, cus = (size_t)simd_count() / 4;
-        if (tl_opts.time_split && tl_opts.pipe_split == 1 && layout == LAYOUT_VOICE_MINOR && mode == MODE_PROCESS && T % 64 == 0 && T >= 256 &&
+        if (tl_opts.time_split && tl_opts.pipe_split == 1 && layout == LAYOUT_VOICE_MINOR && mode == MODE_PROCESS && T % 64 == 0 && T >= FD_TS_MIN_T &&
             groups <= 2 * cus) {
             if (tl_opts.time_split == 1) {  // round 3: both oscillator stages split three ways, the filter wave (nearly) alone on a SIMD
                 if (groups <= cus)
@@ -225,9 +232,8 @@ void launch_render(float* slots, size_t stride, size_t V, const float* in, float
                                                : launch_render_pipe_planar<G, MODE_TICK>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s);
         if (done) { tl_opts.last_kernel = LK_PIPELINE_PLANAR; return; }
     }
-    // the pipeline needs a few tiles to overlap its stages: a launch of one or two 64-frame blocks (real-time use) is
-    // faster through the single-wave kernel (config 3, T = 64: 17.5 -> ~10 us)
-    if (layout == LAYOUT_VOICE_MINOR && tl_opts.pipe_split && (T >= 256 || tl_opts.pipe_split > 1)) {
+    // the stage pipeline from PipeMinT<G> frames on (one 64-frame block for chains worth cutting, four for light graphs)
+    if (layout == LAYOUT_VOICE_MINOR && tl_opts.pipe_split && (T >= (size_t)PipeMinT<G>::v || tl_opts.pipe_split > 1)) {
         const bool done = mode == MODE_PROCESS ? launch_render_split<G, MODE_PROCESS>(slots, stride, V, in, out, T, aux, ring, ring_cap, s)
                                                : launch_render_split<G, MODE_TICK>(slots, stride, V, in, out, T, aux, ring, ring_cap, s);
         if (done) { tl_opts.last_kernel = LK_PIPELINE; return; }
@@ -287,7 +293,7 @@ bool launch_render_mix_m(float* slots, size_t stride, size_t V, const float* in,
                          float* ring, uint32_t ring_cap, const float* panw, hipStream_t s) {
     if constexpr (TsPlan<G>::ok) {  // small banks of oscillator chains: the three-way time split, as in launch_render
         const size_t groups = (V + 63) / 64, cus = (size_t)simd_count() / 4;
-        if (tl_opts.time_split == 1 && tl_opts.pipe_split == 1 && mode == MODE_PROCESS && T % 64 == 0 && T >= 256 && groups <= 2 * cus) {
+        if (tl_opts.time_split == 1 && tl_opts.pipe_split == 1 && mode == MODE_PROCESS && T % 64 == 0 && T >= FD_TS_MIN_T && groups <= 2 * cus) {
             if (groups <= cus)
                 hipLaunchKernelGGL((k_render_ts3_mix<G, 1, MIX>), dim3((unsigned)groups), dim3(64 * Ts3Roles<1>::WAVES), 0, s, slots, stride, V, part, T, aux, panw);
             else

@@ -63,7 +63,7 @@ struct JitModule {
     std::mutex mu;
     JitFuncs dev[MAXD];
     bool loaded[MAXD] = {false};
-    int pipe_stages = 0, pipe_threads = 0, pipe_planar_threads = 0;
+    int pipe_stages = 0, pipe_threads = 0, pipe_planar_threads = 0, pipe_min_t = 256;
     bool pipe_small = false;                                                 // heavy graph: workgroups of 1 / 2 voice groups for small banks
     int wpb[2] = {4, 4};                                                     // per layout
     // the tolerance-mode twin of this graph (FastOf<G>), compiled on first use
@@ -172,7 +172,7 @@ void jit_render(JitModule* jm, float* slots, size_t stride, size_t V, const floa
     if (!f) return jit_launch_failed();
     // loader wave / stage split; short launches (real-time blocks) are faster through the single-wave kernel, as for
     // the ahead-of-time kinds (launch_render)
-    if (layout == LAYOUT_VOICE_MINOR && tl_opts.pipe_split && jm->pipe_stages >= 1 && (T >= 256 || tl_opts.pipe_split > 1)) {
+    if (layout == LAYOUT_VOICE_MINOR && tl_opts.pipe_split && jm->pipe_stages >= 1 && (T >= (size_t)jm->pipe_min_t || tl_opts.pipe_split > 1)) {
         void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &aux, &ring, &ring_cap};
         const size_t groups = (V + 63) / 64, cus = (size_t)simd_count() / 4;
         if (jm->pipe_small && groups <= 2 * cus) {  // heavy graph, small bank: as launch_render_pipe
@@ -376,6 +376,7 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     jm->pipe_planar_threads = meta[7];
     jm->has_fast = meta[8] != 0;
     jm->pipe_small = meta[9] != 0;
+    jm->pipe_min_t = meta[10] > 0 ? meta[10] : 256;
     out->slots.clear();
     std::istringstream lines(std::string(txt.data(), (size_t)meta[3]));
     std::string line;
@@ -406,6 +407,7 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
                     std::string log;
                     if (jit_compile_code("typename fd::FastOf<" + jm->type_expr + ">::type", jm->prelude, &fm->code, &log) == 0) {
                         fm->pipe_stages = jm->pipe_stages;   // FastOf keeps arities, chain shape and tile plan
+                        fm->pipe_min_t = jm->pipe_min_t;
                         fm->pipe_threads = jm->pipe_threads;
                         fm->pipe_planar_threads = jm->pipe_planar_threads;
                         fm->pipe_small = jm->pipe_small;

@@ -130,3 +130,36 @@ def test_time_split_in_tolerance_mode(gpu, time_split):
     assert_bit_equal(outs[0], outs[1], "FDSP_MATH_FAST: time-split == pipeline kernel")
     want, _ = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], T, SR, True, 0, 4)
     assert np.max(np.abs(outs[0] - want)) < 1e-4 and not np.array_equal(outs[0], want)
+
+
+@pytest.mark.parametrize("V", [64 * 10 + 37, 64 * 300 + 5])
+def test_real_time_blocks_take_the_time_split_and_pipeline_kernels(gpu, time_split, V):
+    """Launches of ONE to three 64-frame blocks (a real-time host's AudioNode::process calls): small banks of oscillator chains take the
+    time-split kernels from one block on, every other launch of a chain worth cutting the stage pipeline (fd_engine.hpp FD_TS_MIN_T,
+    fd_device.hpp PipeMinT), shorter launches the single-wave kernel -- one state, one stream of samples whichever kernel ran: a run of
+    mixed launch lengths equals the oracle's continuous render bit for bit (one group per CU and the 14-wave two-group layout)."""
+    time_split(1)
+    p = W.fm_svf_params(V, SR)
+    lengths = [64, 64, 128, 192, 64, 256, 128, 16, 37]   # (process semantics: a launch is cut into blocks of 64 from ITS first frame, so only
+    aligned = sum(lengths[:-1])                            #  launches that start on a multiple of 64 continue the oracle's one long render)
+    want, _ = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], aligned, SR, True, 0, 8)
+    sel = [0, 1, 63, 64, V // 2, V - 38, V - 1]
+    b = W.make_fm_svf_bank(V, SR, params=p)
+    ref = W.make_fm_svf_bank(V, SR, params=p)
+    ref.set_option("pipe_split", 0)  # the single-wave kernel at every length
+    got, families = [], []
+    for T in lengths:
+        got.append(run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :])
+        families.append(b.get_option("last_kernel"))
+        assert_bit_equal(got[-1], run_bank(ref, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :], f"T = {T}: family {families[-1]} vs the single-wave kernel")
+    assert families == [4, 4, 4, 4, 4, 4, 4, 1, 1], families
+    assert_bit_equal(np.concatenate(got[:-1], axis=1)[sel], want[sel], "mixed launch lengths vs the oracle's continuous render")
+    # a bank too large for the time split: the stage pipeline from one block on, the single wave below
+    time_split(0)
+    b = W.make_fm_svf_bank(V, SR, params=p)
+    got, families = [], []
+    for T in lengths:
+        got.append(run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :])
+        families.append(b.get_option("last_kernel"))
+    assert families == [2, 2, 2, 2, 2, 2, 2, 1, 1], families
+    assert_bit_equal(np.concatenate(got[:-1], axis=1)[sel], want[sel], "pipeline kernel from one block on vs the oracle")
