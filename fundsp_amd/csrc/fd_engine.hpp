@@ -203,6 +203,12 @@ bool launch_render_pipe_planar(float* slots, size_t stride, size_t V, const floa
 #ifndef FD_TS_MIN_T
 #define FD_TS_MIN_T 64
 #endif
+// The planar pipeline (loader waves transpose 16-byte runs of the per-voice rows through LDS, a storer wave transposes back) beats the
+// single-wave kernel's strided row accesses at every measured length and for every graph -- config 3: 9.8 vs 10.9 us at T = 16, 16.2 vs
+// 19.1 at 64; config 4: 18.8 vs 28.0, 30.8 vs 51.9; config 2: 6.5 vs 6.9, 8.5 vs 9.0 (profiles/r04_small_t_kernels.txt, planar table).
+#ifndef FD_PLANAR_PIPE_MIN_T
+#define FD_PLANAR_PIPE_MIN_T 16
+#endif
 template <class G>
 void launch_render(float* slots, size_t stride, size_t V, const float* in, float* out, size_t T, size_t fstride,
                    int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
@@ -226,7 +232,7 @@ void launch_render(float* slots, size_t stride, size_t V, const float* in, float
         }
     }
     // planar rows that allow 16-byte runs go through the planar pipeline (same launch-size rule as below)
-    if (layout == LAYOUT_PLANAR && tl_opts.pipe_split && (T >= 256 || tl_opts.pipe_split > 1) && fstride % 4 == 0 && ((uintptr_t)in & 15) == 0 &&
+    if (layout == LAYOUT_PLANAR && tl_opts.pipe_split && (T >= FD_PLANAR_PIPE_MIN_T || tl_opts.pipe_split > 1) && fstride % 4 == 0 && ((uintptr_t)in & 15) == 0 &&
         ((uintptr_t)out & 15) == 0) {
         const bool done = mode == MODE_PROCESS ? launch_render_pipe_planar<G, MODE_PROCESS>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s)
                                                : launch_render_pipe_planar<G, MODE_TICK>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap, s);

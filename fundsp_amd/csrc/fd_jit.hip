@@ -187,7 +187,7 @@ void jit_render(JitModule* jm, float* slots, size_t stride, size_t V, const floa
         tl_opts.last_kernel = LK_PIPELINE;
         return;
     }
-    if (layout == LAYOUT_PLANAR && tl_opts.pipe_split && jm->pipe_planar_threads > 0 && (T >= 256 || tl_opts.pipe_split > 1) && fstride % 4 == 0 &&
+    if (layout == LAYOUT_PLANAR && tl_opts.pipe_split && jm->pipe_planar_threads > 0 && (T >= FD_PLANAR_PIPE_MIN_T || tl_opts.pipe_split > 1) && fstride % 4 == 0 &&
         ((uintptr_t)in & 15) == 0 && ((uintptr_t)outp & 15) == 0) {  // loader / stages / storer (see launch_render)
         void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &fstride, &aux, &ring, &ring_cap};
         hipModuleLaunchKernel(f->pipe_planar[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_planar_threads, 1, 1,

@@ -163,3 +163,31 @@ def test_real_time_blocks_take_the_time_split_and_pipeline_kernels(gpu, time_spl
         families.append(b.get_option("last_kernel"))
     assert families == [2, 2, 2, 2, 2, 2, 2, 1, 1], families
     assert_bit_equal(np.concatenate(got[:-1], axis=1)[sel], want[sel], "pipeline kernel from one block on vs the oracle")
+
+
+def test_planar_real_time_blocks_take_the_planar_pipeline(gpu):
+    """The reference's own buffer shape ([voice][channel][frames], planar) at real-time launch lengths: from 16 frames on a launch takes
+    the planar pipeline (loader / stages / storer waves, family 3), below that the single-wave kernel -- same samples either way, with and
+    without a graph input (config 3's voices, config 4's gated voices), process and tick semantics."""
+    from fundsp_amd import LAYOUT_PLANAR, MODE_TICK
+    import fundsp_amd as F
+
+    F.wavetable_build("saw")
+    V = 64 * 5 + 9
+    lengths = [64, 16, 128, 8, 192, 40, 64]
+    for make, ni in ((W.make_fm_svf_bank, 0), (W.make_saw_moog_bank, 1)):
+        for mode in (MODE_PROCESS, MODE_TICK):
+            b, ref = make(V, SR), make(V, SR)
+            ref.set_option("pipe_split", 0)  # the single-wave kernel at every length
+            families = []
+            for k, T in enumerate(lengths):
+                x = None
+                if ni:
+                    x = np.zeros((V, ni, T), dtype=np.float32)
+                    x[:, 0, :] = 1.0 if k % 3 else 0.0   # gate edges between the launches
+                    x[:, 0, T // 2:] = 1.0
+                got = run_bank(b, x, T, LAYOUT_PLANAR, mode)
+                families.append(b.get_option("last_kernel"))
+                assert_bit_equal(got, run_bank(ref, x, T, LAYOUT_PLANAR, mode), f"{make.__name__} mode {mode} T = {T}: family {families[-1]} vs the single-wave kernel")
+                assert ref.get_option("last_kernel") == 1
+            assert families == [3, 3, 3, 1, 3, 3, 3], families
