@@ -39,7 +39,7 @@ def fm_bank(gpu, V, voice0=0):
     return b, p, pan
 
 
-@pytest.mark.parametrize("V,T", [(200, 64 * 5 + 13), (64 * 7, 64 * 4), (8192, 64 * 6), (32768, 64 * 4 + 9)])
+@pytest.mark.parametrize("V,T", [(200, 64 * 5 + 13), (64 * 7, 64 * 4), (8192, 64 * 6), (32768, 64 * 4 + 9), (64 * 7, 64), (64 * 9 + 5, 128), (64 * 300, 192), (65536, 64)])
 @pytest.mark.parametrize("mode", [MODE_PROCESS, MODE_TICK])
 def test_fm_pan_mix_equals_mix_of_voice_out(gpu, V, T, mode):
     """Config-3 voices, MIX_PAN: fused == fdsp_mix_stereo(voice-out) == the order's numpy statement, bit for bit; a ragged last

@@ -191,3 +191,35 @@ def test_planar_real_time_blocks_take_the_planar_pipeline(gpu):
                 assert_bit_equal(got, run_bank(ref, x, T, LAYOUT_PLANAR, mode), f"{make.__name__} mode {mode} T = {T}: family {families[-1]} vs the single-wave kernel")
                 assert ref.get_option("last_kernel") == 1
             assert families == [3, 3, 3, 1, 3, 3, 3], families
+
+
+@pytest.mark.parametrize("name", ["modulated_svf", "saw_filter_env"])
+def test_run_time_compiled_graphs_at_real_time_launch_lengths(gpu, name):
+    """Run-time compiled graphs carry their own launch-length threshold (the meta block's PipeMinT): short launches in both layouts equal
+    the single-wave kernel's samples bit for bit, and the families are the ahead-of-time kinds' (2 / 3 = voice-minor / planar pipeline)."""
+    from fundsp_amd import LAYOUT_PLANAR
+    from fundsp_amd import graph as G
+    from test_gpu_jit import GRAPHS
+    from test_gpu_parity import noise_input
+
+    build, ni, ring = GRAPHS[name]
+    g = build(G)
+    V = 64 * 4 + 11
+    for kind in G.uses_wavetables(g):
+        t = O.Wavetable.get(kind)
+        offs = np.concatenate([[0], np.cumsum(t.lengths)])
+        gpu.wavetable_upload(kind, t.pitches, [t.data[offs[i]:offs[i + 1]] for i in range(len(t.lengths))])
+    lengths = [64, 16, 128, 8, 200]
+    for layout, fam in ((LAYOUT_VOICE_MINOR, 2), (LAYOUT_PLANAR, 3)):
+        b = gpu.Bank.from_graph(g, V, ring_frames=ring, sample_rate=SR)
+        b.set_seed(np.arange(V, dtype=np.uint64) * 31 + 7)
+        ref = b.clone()
+        ref.set_option("pipe_split", 0)
+        families = []
+        for k, T in enumerate(lengths):
+            x = noise_input(V, ni, T, seed=100 + k) if ni else None
+            got = run_bank(b, x, T, layout, MODE_PROCESS)
+            families.append(b.get_option("last_kernel"))
+            assert_bit_equal(got, run_bank(ref, x, T, layout, MODE_PROCESS), f"{name} layout {layout} T = {T}: family {families[-1]} vs the single-wave kernel")
+        want = [fam, fam if layout == LAYOUT_PLANAR else 1, fam, 1, fam]
+        assert families == want or all(f == 1 for f in families), (families, want)   # (a graph without a stage plan stays on the single wave)
