@@ -94,7 +94,10 @@ int fdsp_kind_by_name(const char* name); /* -1 if unknown */
 /* Engine options.  "pipe_split" (default 1): render Pipe-chain graphs of the ahead-of-time kinds in the voice-minor
  * layout with the multi-wave pipeline split (the chain stages of each 64-voice group cut into 2 or 3 consecutive
  * segments that run in 2 or 3 waves sharing a SIMD; identical samples, better issue-slot utilisation at one
- * voice-wave per SIMD).  1 = best plan, 2 / 3 = exactly that many stages (if the graph allows), 0 = single-wave kernel. */
+ * voice-wave per SIMD).  1 = best plan, 2 / 3 = exactly that many stages (if the graph allows), 0 = single-wave kernel.
+ * With 1 the launch length decides as well: a chain worth cutting takes the pipeline from ONE 64-frame block on (a light graph such
+ * as noise >> biquad from four blocks on, planar launches from 16 frames on), small banks of oscillator chains the time-split kernels
+ * from one whole block on, anything shorter the single-wave kernel; 2 / 3 force the pipeline at any length.  Same samples always. */
 int fdsp_set_option(const char* name, int value);
 /* "math" (default FDSP_MATH_EXACT): the arithmetic of banks created afterwards.
  *   FDSP_MATH_EXACT  every node evaluates the reference's own algorithm operation for operation (no contraction, the
