@@ -15,6 +15,9 @@ using SineHzLowpass = Pipe<SineHz, FixedSvf>;
 // config 3: sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q)     (README.md:98-103)
 using FmMod = Unop<Unop<Unop<SineHz, UMulScalar>, UMulScalar>, UAddScalar>;
 using FmSvf = Pipe<Pipe<FmMod, Sine>, FixedSvf>;
+#ifndef FD_PIPE_MIN_T
+static_assert(PipeMinT<FmSvf>::v == 64 && PipeMinT<SineHzLowpass>::v == 256, "launch lengths that leave the single-wave kernel: config 3 from one block on (measured)");
+#endif
 
 #define FD_FM_TS3_KERNELS(X)                                   \
     X(SineHzLowpass, 1) X(SineHzLowpass, 2)                    \

@@ -24,5 +24,9 @@ using SawMoogAdsrPan = Pipe<Binop<OpMul, SawMoog, AdsrLive>, Panner>;
 static_assert(pipe_plan<SawMoogAdsrPan>(0).S == 3 && pipe_plan<SawMoogAdsrPan>(0).K1 == 1 && pipe_plan<SawMoogAdsrPan>(0).K2 == 2, "config 4: [saw stack] [moog] [* adsr >> pan]");
 static_assert(PipeTiles<SawMoogAdsrPan, 3, 1, 2, 2>::S0::OUT == (FD_PIPE_ELIDE ? 1 : 3) && PipeTiles<SawMoogAdsrPan, 3, 1, 2, 2>::S1::IN == (FD_PIPE_ELIDE ? 1 : 3), "config 4: the first cut carries the oscillator only");
 static_assert(PipeTiles<SawMoogAdsrPan, 3, 1, 2, 2>::SUB == (FD_PIPE_ELIDE ? 32 : 16) && PipeTiles<SawMoogAdsrPan, 3, 1, 2, 4>::SUB == (FD_PIPE_ELIDE ? 16 : 8), "config 4: tile lengths");
+// ... and of the launch lengths from which the two kinds leave the single-wave kernel (PipeMinT: measured, profiles/r04_small_t_kernels.txt)
+#ifndef FD_PIPE_MIN_T
+static_assert(PipeMinT<NoiseBiquad>::v == 256 && PipeMinT<SawMoogAdsrPan>::v == 64, "config 2: the pipeline from four blocks on; config 4: from one");
+#endif
 
 }  // namespace fd
