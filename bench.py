@@ -173,16 +173,17 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
                 "sample": f"{n} config-2 voices x {frames} frames, oracle process() path, {cores} threads, {s:.2f} s"}
     nt = min(cores, 32)
     fr = min(frames, 12000)
-    if config == 4:
+    if config in (4, "4v"):
         p = W.saw_moog_params(nt, sample_rate)
         gate = W.gate_signal(fr, sample_rate)[None, :]
 
         def make(v):
+            env = O.adsr_live(0.01, 0.1, 0.6, 0.2) if config == 4 else (O.var(1.0) >> O.adsr_live(0.01, 0.1, 0.6, 0.2))
             g = (((O.dc(float(p["f"][v])) >> O.saw()) | O.dc(float(p["fc"][v])) | O.dc(float(p["q"][v]))) >> O.moog()) \
-                * O.adsr_live(0.01, 0.1, 0.6, 0.2) >> O.pan(float(p["pan"][v]))
+                * env >> O.pan(float(p["pan"][v]))
             g.set_sample_rate(sample_rate)
             g.set_seed(int(p["seed"][v]))
-            return g, gate
+            return g, (gate if config == 4 else np.zeros((0, fr), dtype=np.float32))
         unit, what = "Msamples/s", "config-4 voices"
     else:
         rng = np.random.default_rng(5)
@@ -195,14 +196,14 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
         unit, what = "M instance-frames/s", "reverb_stereo instances"
     nodes = [make(v) for v in range(nt)]
     t0 = time.perf_counter()
-    nodes[0][0].render_blocks(nodes[0][1])            # calibration (and page-in): one voice, one pass
+    nodes[0][0].render_blocks(nodes[0][1], length=fr)            # calibration (and page-in): one voice, one pass
     reps = max(1, int(target_seconds / max(time.perf_counter() - t0, 1e-4)))
 
     def work(k, gx):
         L.o_bank_pin_threads(1)
         L.o_bank_pin_self(k)   # one CPU of the affinity mask per host thread
         for _ in range(reps):
-            gx[0].render_blocks(gx[1])
+            gx[0].render_blocks(gx[1], length=fr)
     ths = [threading.Thread(target=work, args=(k, gx)) for k, gx in enumerate(nodes)]
     t0 = time.perf_counter()
     for t in ths:
@@ -242,6 +243,21 @@ def make_workload(F, W, torch, config, V, T, sr, first, layout, math, voice_out=
         inp = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
         n_out, bps, slot_bytes = 2, 272, 512       # 32 ring reads + 32 ring writes + 2 in + 2 out, x 4 B
         kernel = "fd::k_fdn_render_frames (lane = frame, one wave per instance)"
+    elif config == "4v":
+        # config 4 in the reference's own gate shape: `var(gate) >> adsr_live` (examples/live_adsr.rs:72; SURVEY 8(d) `dc(gate)`): the gate is a
+        # per-voice Var slot, read once per block like Var::process (shared.rs:122-125) -- the graph has NO input.  One step = one note per
+        # second = the launches of W.gate_plan (gate high for 0.5 s, then low), the slot set on the device between them.
+        layout = F.LAYOUT_VOICE_MINOR
+        F.wavetable_build("saw")
+        bank = W.make_saw_moog_var_bank(V, sr, voice0=first)
+        plan = W.gate_plan(T, sr)
+        n_out, bps, slot_bytes = 2, 8, 192         # 8 B stereo out per voice-sample, nothing in
+        kernel = "fd::k_render_pipe<saw_moog_var_adsr_pan, process, 3 compute stages (saw | moog | *(var >> adsr) >> pan), no loader wave>"
+        if math == "fast":
+            bank.set_option("math", F.MATH_FAST)
+        outs = [torch.empty((n_out, n, V), dtype=torch.float32, device="cuda") for _, n in plan] if voice_out else None
+        return dict(bank=bank, inp=None, out=None, outs=outs, plan=plan, gate_slot=W.C4V_SLOTS["gate"], layout=layout, fs=0, n_out=n_out, bps=bps,
+                    slot_bytes=slot_bytes, kernel=kernel)
     else:
         layout = F.LAYOUT_VOICE_MINOR
         F.wavetable_build("saw")
@@ -259,9 +275,35 @@ def make_workload(F, W, torch, config, V, T, sr, first, layout, math, voice_out=
     return dict(bank=bank, inp=inp, out=out, layout=layout, fs=fs, n_out=n_out, bps=bps, slot_bytes=slot_bytes, kernel=kernel)
 
 
+def run_plan(wl, mode, mix=None, mixbufs=None, kernel_ms=False):
+    """One step of a workload whose step is a PLAN of launches with a shared variable set in between (config "4v"); kernel_ms: wait for
+    every launch and return the sum of their HIP-event times (otherwise nothing waits: the step is enqueued back to back)"""
+    bank, kms = wl["bank"], 0.0
+    for k, (value, n) in enumerate(wl["plan"]):
+        bank.set_param(wl["gate_slot"], float(value))     # fdsp_bank_set_param_all: filled on the device, in stream order, no host wait
+        if mix is None:
+            bank.process(n, None, wl["outs"][k], layout=wl["layout"], mode=mode)
+        else:
+            bank.process_mix(n, None, mix=mix, out=mixbufs[k], mode=mode)
+        if kernel_ms:
+            kms += bank.last_kernel_ms()
+    return kms
+
+
 def quick(F, torch, wl, T, mode, steps=6, warmup=2):
     """Secondary measurements (outside the headline's timed region): wall ms per step and the kernel's own HIP-event ms."""
     bank = wl["bank"]
+    if "plan" in wl:
+        for _ in range(warmup):
+            run_plan(wl, mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run_plan(wl, mode)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        k = [run_plan(wl, mode, kernel_ms=True) for _ in range(max(2, steps // 2))]
+        return ms, sum(k) / len(k)
     for _ in range(warmup):
         bank.process(T, wl["inp"], wl["out"], layout=wl["layout"], frame_stride=wl["fs"], mode=mode)
     torch.cuda.synchronize()
@@ -412,7 +454,9 @@ def secondary(F, W, torch, sr, mode):
             del g, outs
         del wl
     out.append(c3)
-    for cfg, V, name, unit, math in ((4, 32768, "config4_saw_moog_adsr_pan_32768", "Msamples/s", "exact"),
+    for cfg, V, name, unit, math in (("4v", 32768, "config4_var_gate_32768", "Msamples/s", "exact"),
+                                     ("4v", 32768, "config4_var_gate_math_fast", "Msamples/s", "fast"),
+                                     (4, 32768, "config4_saw_moog_adsr_pan_32768", "Msamples/s", "exact"),
                                      (4, 32768, "config4_math_fast", "Msamples/s", "fast"),
                                      (5, 2048, "config5_reverb_stereo_2048", "M instance-frames/s", "exact")):
         T = 48000
@@ -421,10 +465,35 @@ def secondary(F, W, torch, sr, mode):
         algo = V * T * wl["bps"] + V * wl["slot_bytes"]
         arith = "exact arithmetic" if math == "exact" else ("tolerance mode (FDSP_MATH_FAST: the ladder's tanh on the hardware exp2 / reciprocal, "
                                                             "recurrence exact; within 1e-4 of the exact mode: tests/test_gpu_math_fast.py)")
-        out.append({"name": name, "what": f"BASELINE config {cfg} per-GPU shard ({V} {'voices' if cfg == 4 else 'instances'} x {T} frames), {arith}",
+        shape = {"4v": " -- the reference's gate shape `var(gate) >> adsr_live` (examples/live_adsr.rs:72): no graph input, the step = two launches "
+                       "(gate high 24000 frames, low 24000) with the Var slot set on the device in between; 8 B per voice-sample (stereo out)",
+                 4: " -- the gate as an audio-rate HBM input stream [frames][voices] (hosts that modulate the gate per sample): 4 B in + 8 B out per voice-sample"}.get(cfg, "")
+        out.append({"name": name, "what": f"BASELINE config {str(cfg)[0]} per-GPU shard ({V} {'voices' if cfg != 5 else 'instances'} x {T} frames), {arith}{shape}",
                     "ms_per_step": round(ms, 4), "kernel_ms_avg": round(kms, 4), "value": round(V * T / ms / 1e3, 1), "unit": unit,
                     "algorithmic_bytes_per_unit": wl["bps"], "roofline_frac": round(algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "kernel": wl["kernel"]})
+        if cfg == 4:   # both accountings of the stream-gate kind: with its own 4 B/voice-sample input stream, and at the stereo output alone
+            out[-1]["roofline_frac_at_8B_stereo_out_only"] = round((V * T * 8 + V * wl["slot_bytes"]) / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if cfg == "4v" and math == "exact":   # mode B of the same step: the stereo mix of the shard leaves the launches, [2][T] f32
+            try:
+                wl["outs"] = None
+                torch.cuda.empty_cache()
+                wl["bank"].mix_reserve(max(n for _, n in wl["plan"]))
+                mixbufs = [torch.empty((2, n), dtype=torch.float32, device="cuda") for _, n in wl["plan"]]
+                run_plan(wl, mode, F.MIX_SUM, mixbufs)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    run_plan(wl, mode, F.MIX_SUM, mixbufs)
+                torch.cuda.synchronize()
+                ms_b = (time.perf_counter() - t0) / 4 * 1e3
+                kb = [run_plan(wl, mode, F.MIX_SUM, mixbufs, kernel_ms=True) for _ in range(2)]
+                out[-1]["mode_b_fused_mix"] = {"what": "the same step through fdsp_bank_process_mix (FDSP_MIX_SUM): the shard's stereo mix [2][frames] leaves "
+                                               "the launches, no voice-out buffer; not a bandwidth test", "ms_per_step": round(ms_b, 4),
+                                               "kernel_ms_incl_tree": round(sum(kb) / len(kb), 4), "value": round(V * T / ms_b / 1e3, 1)}
+                del mixbufs
+            except Exception as e:
+                out[-1]["mode_b_fused_mix"] = {"error": repr(e)}
         if math == "exact":
             try:
                 out[-1]["cpu_baseline"] = cpu_baseline_config(cfg, sr, T)

@@ -1215,6 +1215,11 @@ int fdsp_bank_slot_kind(const fdsp_bank* b, int slot) {
     return (b && b->ops && slot >= 0 && slot < b->nslots) ? b->ops->slots[slot].kind : FDSP_EINVAL;
 }
 
+__global__ void k_fill_slot(float* __restrict__ row, float value, size_t V) {
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < V) row[v] = value;
+}
+
 static int set_words(fdsp_bank* b, int slot, const void* h_words, size_t first, size_t count) {
     HIPCHK(await_last_render(b));
     HIPCHK(hipMemcpyAsync(b->slots + (size_t)slot * b->stride + first, h_words, count * sizeof(float),
@@ -1243,8 +1248,19 @@ int fdsp_bank_set_param(fdsp_bank* b, const char* name, const float* h_values, s
 int fdsp_bank_set_param_all(fdsp_bank* b, const char* name, float value) {
     if (b && b->fdn) return fail(FDSP_EINVAL, "reverb_stereo banks have no named slots (parameters are fixed at creation)");
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
-    std::vector<float> tmp(b->V, value);
-    return fdsp_bank_set_param(b, name, tmp.data(), 0, b->V);
+    // One value for every voice -- Shared::set_value of a control all voices watch (shared.rs:98-101), e.g. the gate of config 4's
+    // `var(gate) >> adsr_live` between two launches: filled on the device, in stream order behind the last render, no host copy and
+    // no host wait (the per-voice form above borrows a host array and has to wait for its copy).
+    DeviceGuard guard(b->device);
+    int s = find_slot(b, name);
+    if (s < 0) return fail(FDSP_EINVAL, std::string("unknown slot: ") + (name ? name : "(null)"));
+    if (b->V == 0) return FDSP_OK;
+    HIPCHK(await_last_render(b));
+    hipLaunchKernelGGL(k_fill_slot, dim3((unsigned)((b->V + 255) / 256)), dim3(256), 0, b->stream, b->slots + (size_t)s * b->stride, value, b->V);
+    before_update_launch(b, 0, b->V);
+    b->ops->lifecycle(b->slots, b->stride, 0, b->V, 1, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
+    HIPCHK(hipGetLastError());
+    return FDSP_OK;
 }
 
 int fdsp_bank_set_param_u64(fdsp_bank* b, const char* name, const uint64_t* h_values, size_t first, size_t count) {

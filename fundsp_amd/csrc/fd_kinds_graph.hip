@@ -24,6 +24,7 @@ void register_graph_kinds(std::vector<KindOps>& out) {
     register_fm_kinds(out);
     out.push_back(make_kind<NoiseBiquad>("noise_biquad"));
     out.push_back(make_kind<SawMoogAdsrPan>("saw_moog_adsr_pan"));
+    out.push_back(make_kind<SawMoogVarAdsrPan>("saw_moog_var_adsr_pan"));
     out.push_back(make_kind<OversampleFm>("oversample_fm"));
     out.push_back(make_kind<OversampleShape>("oversample_shape"));
     out.push_back(make_kind<ResampleFm>("resample_fm"));

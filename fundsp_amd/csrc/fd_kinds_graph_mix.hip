@@ -8,5 +8,6 @@ namespace fd {
 void attach_graph_mix(std::vector<KindOps>& out) {
     attach_mix<NoiseBiquad>(out, "noise_biquad");
     attach_mix<SawMoogAdsrPan>(out, "saw_moog_adsr_pan");
+    attach_mix<SawMoogVarAdsrPan>(out, "saw_moog_var_adsr_pan");
 }
 }  // namespace fd

@@ -145,3 +145,38 @@ def make_saw_moog_bank(voices, sample_rate=48000.0, voice0=0, params=None, adsr=
     b.set_sample_rate(sample_rate)
     b.set_seed(p["seed"])
     return b
+
+
+# ---- config 4 in the reference's own gate shape: var(gate) >> adsr_live (examples/live_adsr.rs:72) ----------------------------------
+C4V_SLOTS = dict(f="0.0.0.0.0.0:value[0]", fc="0.0.0.0.1:value[0]", q="0.0.0.1:value[0]", pan="1:pan", gate="0.1.0:value",
+                 attack="0.1.1:attack", decay="0.1.1:decay", sustain="0.1.1:sustain", release="0.1.1:release")
+
+
+def gate_plan(frames, sample_rate=48000.0, off_seconds=0.5, block=64):
+    """One note per `frames`: [(gate, frames), ...] -- the gate high for `off_seconds` (rounded down to whole blocks), then low.
+    The value of a `var(..)` is read once per 64-sample block (Var::process, shared.rs:122-125), so a host that changes it does so
+    BETWEEN blocks: a plan is a list of launches with the variable set before each."""
+    on = min(frames, int(off_seconds * sample_rate) // block * block)
+    return [(g, n) for g, n in ((1.0, on), (0.0, frames - on)) if n > 0]
+
+
+def make_saw_moog_var_bank(voices, sample_rate=48000.0, voice0=0, params=None, adsr=(0.01, 0.1, 0.6, 0.2), prime=True):
+    """Config 4 voice with the gate as a shared variable, the shape of the reference's live_adsr example:
+    ((dc(f) >> saw() | dc(fc) | dc(q)) >> moog()) * (var(gate) >> adsr_live(a, d, s, r)) >> pan(p); same parameters as
+    saw_moog_params.  The graph has NO input: the gate lives in the per-voice slot C4V_SLOTS["gate"] (fdsp_bank_set_param* plays
+    Shared::set_value).  `prime`: render one block with the gate low, as in the reference example where the control starts at 0.0 while
+    audio already runs -- adsr_live attacks on a low -> high change only (adsr.rs:37-43)."""
+    from .bank import Bank
+
+    p = params or saw_moog_params(voices, sample_rate, voice0)
+    b = Bank("saw_moog_var_adsr_pan", voices)
+    for k in ("f", "fc", "q", "pan"):
+        b.set_param(C4V_SLOTS[k], p[k])
+    for k, val in zip(("attack", "decay", "sustain", "release"), adsr):
+        b.set_param(C4V_SLOTS[k], float(val))
+    b.set_param(C4V_SLOTS["gate"], 0.0)
+    b.set_sample_rate(sample_rate)
+    b.set_seed(p["seed"])
+    if prime:
+        b.process(64)
+    return b

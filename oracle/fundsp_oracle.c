@@ -2485,6 +2485,11 @@ void o_process(onode *n, int size, const float *in, float *out) {
         }
         break;
     }
+    case O_VAR: /* Var::process shared.rs:122-125: ONE read of the shared value per block, splat over simd_items(size)
+                 * (VarFn has no process override: shared.rs:136-184 -> the default per-sample walk below) */
+        if (n->map_fn) { process_via_tick(n, size, in, out); break; }
+        for (int j = 0; j < simd_items(size) * 8; j++) out[j] = n->s.value[0];
+        break;
     case O_CONSTANT: /* audionode.rs:501-508: splat over simd_items(size) */
         for (int c = 0; c < n->nout; c++)
             for (int j = 0; j < simd_items(size) * 8; j++) out[c * MAXB + j] = n->s.value[c];

@@ -194,6 +194,11 @@ class Node:
         lib().o_noise_set_seed(self.ptr, int(s) & (2**64 - 1))
         return self
 
+    def set_value(self, value):
+        """Shared::set_value (shared.rs:98-101) of the variable a `var(..)` node reads."""
+        lib().o_var_set(self.ptr, float(value))
+        return self
+
     def wave_phase(self, p):
         lib().o_wavesynth_set_phase(self.ptr, float(p))
         return self
