@@ -855,6 +855,11 @@ template <class O, class X, class Y> struct Chain<Binop<O, X, Y>, true> {
     static constexpr int N = SPLIT ? Chain<X, true>::N + 1 : 1;
 };
 
+// A DF1 biquad is a chain of TWO stages cut at the seam of its own expression (fd_nodes.hpp BiquadT: feed-forward half | recurrence):
+// behind a generator that can be split over time (Noise: a counter) the chain has three stages and small banks take the time-split
+// kernel -- BASELINE config 2: the serial wave carries the recurrence alone.
+template <uint64_t NODE_ID, bool HEAD> struct Chain<BiquadT<NODE_ID>, HEAD> { static constexpr int N = 2; };
+
 struct VGate {  // forwards to a slot visitor only while enabled; always advances the slot counter
     template <class V> struct W {
         V* v;
@@ -941,6 +946,45 @@ struct Seg {
     static FD_D bool tripped(const G& g) { return g.tripped(); }
     // visit ALL slots of g in G::visit order (slot numbering unchanged); only this segment's slots are enabled
     template <class W> static FD_D void visit(G& g, W& w) { w.on = true; g.visit(w); }
+};
+// BiquadT<ID>: stage 0 = the feed-forward half (state x1 x2, coefficients b0 b1 b2; packed, and skippable: the x history of a frame does
+// not depend on evaluating the frames before it), stage 1 = the recurrence (y1 y2, a1 a2).  [0, 2) is the whole node.
+template <uint64_t NODE_ID, int A, int B, bool HEAD>
+struct Seg<BiquadT<NODE_ID>, A, B, HEAD> {
+    using G = BiquadT<NODE_ID>;
+    static_assert(0 <= A && A < B && B <= 2, "empty or out-of-range chain segment");
+    static constexpr bool FF = A == 0, FB = B == 2;
+    static constexpr int IN = 1, OUT = 1;
+    static constexpr int cost = (FF ? 4 : 0) + (FB ? 10 : 0), weight = cost;   // (instructions per sample of the serial wave: fb's four count double)
+    static constexpr bool USES_GIN = false;
+    static constexpr bool HAS_SKIP = FF && !FB;
+    template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f*, v2f* out) {
+        if constexpr (FF && FB) g.template step2<PH>(in, out);
+        else if constexpr (FF) out[0] = g.ff2(in[0]);
+        else { const float ya = g.fb(in[0].x); out[0] = v2f{ya, g.fb(in[0].y)}; }
+    }
+    template <int PH> static FD_D void step(G& g, const float* in, const float*, float* out) {
+        if constexpr (FF && FB) g.template step<PH>(in, out);
+        else if constexpr (FF) out[0] = g.ff(in[0]);
+        else out[0] = g.fb(in[0]);
+    }
+    template <int PH> static FD_D void skip2(G& g, const v2f* in) {
+        static_assert(HAS_SKIP, "only the feed-forward half can be skipped");
+        g.ff_skip2(in[0]);
+    }
+    template <int PH> static FD_D void skip(G& g, const float* in) {
+        static_assert(HAS_SKIP, "only the feed-forward half can be skipped");
+        g.ff_skip(in[0]);
+    }
+    static FD_D void begin(G&, int) {}
+    static FD_D void end(G&) {}
+    static FD_D bool tripped(const G&) { return false; }
+    template <class W> static FD_D void visit(G& g, W& w) {  // BiquadT::visit order; each half sees its own slots
+        w.on = FB; w.f(g.a1, PARAM, "a1"); w.f(g.a2, PARAM, "a2");
+        w.on = FF; w.f(g.b0, PARAM, "b0"); w.f(g.b1, PARAM, "b1"); w.f(g.b2, PARAM, "b2");
+        w.f(g.x1, STATE, "x1"); w.f(g.x2, STATE, "x2");
+        w.on = FB; w.f(g.y1, STATE, "y1"); w.f(g.y2, STATE, "y2");
+    }
 };
 template <class X, class Y, int A, int B, bool HEAD>
 struct Seg<Pipe<X, Y>, A, B, HEAD> {
@@ -1908,10 +1952,12 @@ struct TsPlan {  // which graphs the time-split kernel takes
 template <class G> struct TsPlan<G, true> {
     static constexpr bool ok = Seg<G, 0, 1>::HAS_SKIP && Seg<G, 1, 2>::HAS_SKIP;
 };
-static_assert(HasSkip<Pipe<Constant<1>, Sine>>::v && HasSkip<Unop<Pipe<Constant<1>, SineFast>, UMulScalar>>::v && !HasSkip<Noise>::v &&
-              !HasSkip<FixedSvf>::v, "HasSkip: oscillator chains yes, Noise / filters no");
-static_assert(TsPlan<Pipe<Pipe<Unop<Pipe<Constant<1>, Sine>, UAddScalar>, Sine>, FixedSvf>>::ok && !TsPlan<Pipe<Pipe<Noise, Sine>, FixedSvf>>::ok &&
-              !TsPlan<Pipe<Sine, FixedSvf>>::ok, "TsPlan: three-stage oscillator chains only");
+static_assert(HasSkip<Pipe<Constant<1>, Sine>>::v && HasSkip<Unop<Pipe<Constant<1>, SineFast>, UMulScalar>>::v && HasSkip<Noise>::v &&
+              !HasSkip<FixedSvf>::v && !HasSkip<Biquad>::v, "HasSkip: oscillator chains and the counter-based Noise yes, filters no");
+static_assert(TsPlan<Pipe<Pipe<Unop<Pipe<Constant<1>, Sine>, UAddScalar>, Sine>, FixedSvf>>::ok && !TsPlan<Pipe<Pipe<Pass, Sine>, FixedSvf>>::ok &&
+              !TsPlan<Pipe<Sine, FixedSvf>>::ok, "TsPlan: three-stage generator chains only");
+static_assert(Chain<Pipe<Noise, Biquad>>::N == 3 && TsPlan<Pipe<Noise, Biquad>>::ok && Seg<Pipe<Noise, Biquad>, 1, 2>::HAS_SKIP && !Seg<Pipe<Noise, Biquad>, 2, 3>::HAS_SKIP,
+              "config 2: noise | the biquad's feed-forward half | its recurrence");
 
 static __device__ unsigned int g_ts_arrivals[4096];  // workgroups of k_render_ts<.., 2, 1> seen per CU (role draw; never reset)
 

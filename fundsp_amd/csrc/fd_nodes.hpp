@@ -438,6 +438,9 @@ struct Noise {
         out[0] = (float)(hash32x(state) >> 8) * (2.0f / (float)((1 << 24) - 1)) - 1.0f;
     }
     FD_STEP2_VIA_STEP
+    // the state is a sample counter: frames another wave evaluates are skipped by counting (time-split stages, fd_device.hpp)
+    template <int PH> FD_HD void skip(const float*) { state += 1u; }
+    template <int PH> FD_HD void skip2(const v2f*) { state += 2u; }
 };
 
 // SVF core shared by FixedSvf and Svf:  svf.rs:995-1006 / :829-843
@@ -662,7 +665,38 @@ struct BiquadT {
         return y0;
     }
     template <int PH> FD_HD void step(const float* in, float* out) { out[0] = tick(in[0]); }
-    FD_STEP2_VIA_STEP
+    // The DF1 expression at its own seam (biquad.rs:186-188: `b0*x0 + b1*x1 + b2*x2 - a1*y1 - a2*y2`, evaluated left to right):
+    //   p  = (b0*x0 + b1*x1) + b2*x2      feed-forward: no y in it, so two frames are one packed computation (ff2) and the x history of
+    //                                      any later frame is known without evaluating the frames before it (ff_skip2)
+    //   y0 = (p - a1*y1) - a2*y2          the recurrence: four dependent-issue operations per sample (fb)
+    // The same operations in the same order as tick(), so every split below is bit-identical to it.  A serial wave issues one VALU
+    // instruction per ~4.4 cycles whatever it depends on: tick() twice is 18 of them per frame pair, ff2 + 2 x fb is 13;
+    // and as a CHAIN OF TWO STAGES (fd_device.hpp Seg<BiquadT>) the recurrence wave carries 8.
+    FD_HD v2f ff2(v2f x) {
+        const v2f p = (x * b0 + v2f{x1, x.x} * b1) + v2f{x2, x1} * b2;
+        x2 = x.x;
+        x1 = x.y;
+        return p;
+    }
+    FD_HD float ff(float x0) {
+        const float p = (b0 * x0 + b1 * x1) + b2 * x2;
+        x2 = x1;
+        x1 = x0;
+        return p;
+    }
+    FD_HD void ff_skip2(v2f x) { x2 = x.x; x1 = x.y; }
+    FD_HD void ff_skip(float x0) { x2 = x1; x1 = x0; }
+    FD_HD float fb(float p) {
+        const float y0 = (p - a1 * y1) - a2 * y2;
+        y2 = y1;
+        y1 = y0;
+        return y0;
+    }
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        const v2f p = ff2(in[0]);
+        const float ya = fb(p.x);
+        out[0] = v2f{ya, fb(p.y)};
+    }
 };
 using Biquad = BiquadT<15>;
 

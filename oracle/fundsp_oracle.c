@@ -2447,6 +2447,55 @@ static void process_remainder(onode *n, int size, const float *in, float *out) {
     }
 }
 
+/* WaveSynth::process wavetable.rs:327-348: 8 phases accumulated, vector floor wrap (wide's inherent f32x8::floor = true floor), table
+ * pair chosen from LANE 0's frequency for the item.  A function of its own: the tree walk (o_process) and the monomorphised config-4
+ * voice (o_c4_block, the cpu_baseline leg) run the same code. */
+static void process_remainder(onode *n, int size, const float *in, float *out);
+static inline void wavesynth_process(onode *n, int size, const float *in, float *out) {
+    float phase = n->s.phase;
+    size_t hint = n->s.table_hint;
+    for (int i = 0; i < full_simd_items(size); i++) {
+        float frequency = in[i << 3];
+        float ph[SIMD_N];
+        for (int j = 0; j < SIMD_N; j++) {
+            phase += in[(i << 3) + j] * n->s.sample_duration;
+            ph[j] = phase;
+        }
+        for (int j = 0; j < SIMD_N; j++) ph[j] = ph[j] - floorf(ph[j]);
+        size_t table = wt_table_index(n->s.wt, hint, fabsf(frequency));
+        float w = clamp01f((fabsf(frequency) - n->s.wt->pitch[table]) /
+                           (n->s.wt->pitch[table + 1] - n->s.wt->pitch[table]));
+        for (int j = 0; j < SIMD_N; j++)
+            out[(i << 3) + j] = (1.0f - w) * wt_at(n->s.wt, table + 1, ph[j]) + w * wt_at(n->s.wt, table + 2, ph[j]);
+        hint = table;
+        if (n->nout > 1)
+            for (int j = 0; j < SIMD_N; j++) out[MAXB + (i << 3) + j] = ph[j];
+    }
+    n->s.phase = phase - floorf(phase);
+    n->s.table_hint = hint;
+    process_remainder(n, size, in, out);
+}
+/* EnvelopeIn::process envelope.rs:315-340 for adsr_live: whole-block segment walk (no remainder path) */
+static inline void adsr_live_process(onode *n, int size, const float *in, float *out) {
+    if (size == 0) return;
+    if (n->s.et >= n->s.et1) env_next_segment(n, in[0]);
+    int i = 0;
+    while (i < size) {
+        int64_t left = (int64_t)ceilf((n->s.et1 - n->s.et) / n->s.esd);
+        size_t segment_samples_left = (size_t)left;
+        size_t loop_samples = (size_t)(size - i) < segment_samples_left ? (size_t)(size - i) : segment_samples_left;
+        float value = n->s.ev, delta = n->s.evd;
+        for (size_t k = 0; k < loop_samples; k++) {
+            out[i + (int)k] = value;
+            value += delta;
+        }
+        n->s.ev = value;
+        i += (int)loop_samples;
+        n->s.et += (float)(int64_t)loop_samples * n->s.esd;
+        if (loop_samples == segment_samples_left && i < size) env_next_segment(n, in[i]);
+    }
+}
+
 void o_process(onode *n, int size, const float *in, float *out) {
     if (n->ftz && !g_ftz_on) {
         FTZ_ENTER;
@@ -2633,32 +2682,7 @@ void o_process(onode *n, int size, const float *in, float *out) {
             for (int i = 0; i < simd_items(size) * 8; i++)
                 out[c * MAXB + i] = unop_apply(n->op, out[c * MAXB + i], n->scalar);
         break;
-    case O_WAVESYNTH: { /* wavetable.rs:327-348: 8 phases accumulated, vector floor wrap (wide's inherent
-                           f32x8::floor = true floor), table pair chosen from LANE 0's frequency for the item */
-        float phase = n->s.phase;
-        size_t hint = n->s.table_hint;
-        for (int i = 0; i < full_simd_items(size); i++) {
-            float frequency = in[i << 3];
-            float ph[SIMD_N];
-            for (int j = 0; j < SIMD_N; j++) {
-                phase += in[(i << 3) + j] * n->s.sample_duration;
-                ph[j] = phase;
-            }
-            for (int j = 0; j < SIMD_N; j++) ph[j] = ph[j] - floorf(ph[j]);
-            size_t table = wt_table_index(n->s.wt, hint, fabsf(frequency));
-            float w = clamp01f((fabsf(frequency) - n->s.wt->pitch[table]) /
-                               (n->s.wt->pitch[table + 1] - n->s.wt->pitch[table]));
-            for (int j = 0; j < SIMD_N; j++)
-                out[(i << 3) + j] = (1.0f - w) * wt_at(n->s.wt, table + 1, ph[j]) + w * wt_at(n->s.wt, table + 2, ph[j]);
-            hint = table;
-            if (n->nout > 1)
-                for (int j = 0; j < SIMD_N; j++) out[MAXB + (i << 3) + j] = ph[j];
-        }
-        n->s.phase = phase - floorf(phase);
-        n->s.table_hint = hint;
-        process_remainder(n, size, in, out);
-        break;
-    }
+    case O_WAVESYNTH: wavesynth_process(n, size, in, out); break;
     case O_SHAPER: /* shape.rs:235-240: Shape::simd on full items, tick for the remainder */
         for (int i = 0; i < full_simd_items(size) * 8; i++) out[i] = shape_simd_lane(n, 0, in[i]);
         process_remainder(n, size, in, out);
@@ -2711,26 +2735,7 @@ void o_process(onode *n, int size, const float *in, float *out) {
         }
         break;
     }
-    case O_ADSR_LIVE: { /* envelope.rs:315-340: whole-block segment walk (no remainder path) */
-        if (size == 0) break;
-        if (n->s.et >= n->s.et1) env_next_segment(n, in[0]);
-        int i = 0;
-        while (i < size) {
-            int64_t left = (int64_t)ceilf((n->s.et1 - n->s.et) / n->s.esd);
-            size_t segment_samples_left = (size_t)left;
-            size_t loop_samples = (size_t)(size - i) < segment_samples_left ? (size_t)(size - i) : segment_samples_left;
-            float value = n->s.ev, delta = n->s.evd;
-            for (size_t k = 0; k < loop_samples; k++) {
-                out[i + (int)k] = value;
-                value += delta;
-            }
-            n->s.ev = value;
-            i += (int)loop_samples;
-            n->s.et += (float)(int64_t)loop_samples * n->s.esd;
-            if (loop_samples == segment_samples_left && i < size) env_next_segment(n, in[i]);
-        }
-        break;
-    }
+    case O_ADSR_LIVE: adsr_live_process(n, size, in, out); break;
     case O_PANNER: /* pan.rs:63-76 */
         if (n->nin == 1) {
             for (int i = 0; i < simd_items(size) * 8; i++) {
@@ -2838,3 +2843,121 @@ int o_fm_svf_state(const onode *g, o_fm_svf_regs *r) {
     r->ic1eq = svf->s.ic1eq; r->ic2eq = svf->s.ic2eq;
     return 0;
 }
+
+/* ---- monomorphised voices of BASELINE configs 4 and 5, for the cpu_baseline legs (o_fast.c) -------------------------------------
+ * FunDSP graphs are statically typed: rustc compiles `((dc(f) >> saw() | dc(fc) | dc(q)) >> moog()) * ENV >> pan(p)` into ONE process()
+ * per block -- every node's process / tick inlined, buffers on the stack, no tree, no dispatch.  These functions are that form, made
+ * of the SAME node functions the tree walk above calls (wavesynth_process, moog_tick, adsr_live_process, pan weights), so they are
+ * bit-identical to o_process on the same graph by construction (asserted in tests/test_oracle_fast.py); built -O3 -march=native by
+ * `make native`.  ENV = adsr_live(..) fed by the graph's input (the stream-gate shape) or var(gate) >> adsr_live(..) (the reference's
+ * own shape, examples/live_adsr.rs:72). */
+int o_c4_open(onode *g, o_c4_voice *v) {
+    memset(v, 0, sizeof *v);
+    if (!g || g->type != O_PIPE || !g->x || g->x->type != O_BINOP || g->x->op != O_MUL || !g->y || g->y->type != O_PANNER || g->y->nin != 1) return -1;
+    onode *sm = g->x->x, *env = g->x->y;
+    if (!sm || sm->type != O_PIPE || !sm->y || sm->y->type != O_MOOG || sm->y->nin != 3 || !sm->x || sm->x->type != O_STACK) return -1;
+    onode *st = sm->x; /* Stack(Stack(Pipe(Constant, WaveSynth), Constant), Constant) */
+    if (!st->x || st->x->type != O_STACK || !st->y || st->y->type != O_CONSTANT || st->y->nout != 1) return -1;
+    onode *st2 = st->x;
+    if (!st2->x || st2->x->type != O_PIPE || !st2->y || st2->y->type != O_CONSTANT || st2->y->nout != 1) return -1;
+    onode *osc = st2->x;
+    if (!osc->x || osc->x->type != O_CONSTANT || osc->x->nout != 1 || !osc->y || osc->y->type != O_WAVESYNTH || osc->y->nout != 1) return -1;
+    if (env && env->type == O_PIPE) { /* var(gate) >> adsr_live */
+        if (!env->x || env->x->type != O_VAR || env->x->map_fn || !env->y || env->y->type != O_ADSR_LIVE) return -1;
+        v->var = env->x;
+        v->env = env->y;
+    } else if (env && env->type == O_ADSR_LIVE) {
+        v->env = env;
+    } else {
+        return -1;
+    }
+    v->g = g; v->saw = osc->y; v->moog = sm->y; v->pan = g->y;
+    v->f = osc->x->s.value[0]; v->fc = st2->y->s.value[0]; v->q = st->y->s.value[0];
+    return 0;
+}
+/* one block (size <= 64): gate = the graph's input block (stream-gate shape; ignored when the voice has a Var); out = [2][64] */
+void o_c4_block(o_c4_voice *v, int size, const float *gate, float *out) {
+    float fr[MAXB], osc[MAXB], lad[MAXB], gt[MAXB], env[MAXB];
+    const int items8 = simd_items(size) * 8;
+    for (int i = 0; i < items8; i++) fr[i] = v->f;                      /* Constant::process audionode.rs:501-508 */
+    wavesynth_process(v->saw, size, fr, osc);                             /* WaveSynth::process wavetable.rs:327-348 */
+    for (int i = 0; i < size; i++) {                                      /* Stack -> Moog: default process = tick per sample (audionode.rs:85-105) */
+        const float in3[3] = {osc[i], v->fc, v->q};
+        lad[i] = moog_tick(v->moog, in3);
+    }
+    for (int i = size; i < items8; i++) lad[i] = 0.0f;
+    if (v->var) {
+        const float value = v->var->s.value[0];                           /* Var::process shared.rs:122-125: one read, splat */
+        for (int i = 0; i < items8; i++) gt[i] = value;
+        gate = gt;
+    }
+    adsr_live_process(v->env, size, gate, env);                           /* EnvelopeIn::process envelope.rs:315-340 */
+    for (int i = size; i < items8; i++) env[i] = 0.0f;
+    const float wl = v->pan->s.left_weight, wr = v->pan->s.right_weight;  /* Binop::process audionode.rs:933-955, Panner::process pan.rs:63-76 */
+    for (int i = 0; i < items8; i++) {
+        const float x = lad[i] * env[i];
+        out[i] = x * wl;
+        out[MAXB + i] = x * wr;
+    }
+}
+
+/* reverb_stereo (prelude.rs:1739-1775: Feedback<U32, 32 x (delay >> fir3), FrameHadamard> + pan fold), one BLOCK per call: the arithmetic
+ * of the O_REVERB_STEREO tick above, frame by frame, with the MXCSR switch (Feedback::new -> prevent_denormals, denormal.rs:18) once per
+ * block instead of twice per sample and the 32 lines as plain arrays the compiler can keep in vector registers.  in / out = [2][64]. */
+void o_reverb_stereo_block(onode *n, int size, const float *in, float *out) {
+#if defined(__x86_64__) || defined(__i386__)
+    const unsigned int csr = _mm_getcsr();
+    _mm_setcsr(0x9fc0);
+#endif
+    const float scale = (float)(1.0 / sqrt(32.0)), w0 = n->s.rv_w[0], w1 = n->s.rv_w[1], w2 = n->s.rv_w[2];
+    float value[32], v0[32], v1[32], v2[32];
+    size_t pos[32];
+    for (int i = 0; i < 32; i++) {
+        value[i] = n->s.rv_value[i];
+        v0[i] = n->s.rv_v[i][0]; v1[i] = n->s.rv_v[i][1]; v2[i] = n->s.rv_v[i][2];
+        pos[i] = n->s.rv_i[i];
+    }
+    for (int t = 0; t < size; t++) {
+        float o[32], h[32];
+        const float x0 = in[t], x1 = in[MAXB + t];
+        for (int i = 0; i < 32; i++) {
+            const float x = ((i & 1) ? x1 : x0) + value[i];
+            n->s.rv_buf[i][pos[i]] = x;
+            pos[i] += 1;
+            if (pos[i] >= n->s.rv_len[i]) pos[i] = 0;
+            v0[i] = v1[i]; v1[i] = v2[i]; v2[i] = n->s.rv_buf[i][pos[i]];
+        }
+        for (int i = 0; i < 32; i++) {
+            float acc = 0.0f;
+            acc += w0 * v0[i];
+            acc += w1 * v1[i];
+            acc += w2 * v2[i];
+            o[i] = acc;
+            h[i] = acc;
+        }
+        for (int hh = 1; hh < 32; hh *= 2)
+            for (int i = 0; i < 32; i += hh * 2)
+                for (int j = i; j < i + hh; j++) {
+                    const float x = h[j], y = h[j + hh];
+                    h[j] = x + y;
+                    h[j + hh] = x - y;
+                }
+        for (int i = 0; i < 32; i++) value[i] = h[i] * scale;
+        float l = n->s.rv_wl[0] * o[0], r = n->s.rv_wr[0] * o[0];
+        for (int i = 1; i < 32; i++) {
+            l = l + n->s.rv_wl[i] * o[i];
+            r = r + n->s.rv_wr[i] * o[i];
+        }
+        out[t] = l * (float)(1.0 / 16.0);
+        out[MAXB + t] = r * (float)(1.0 / 16.0);
+    }
+    for (int i = 0; i < 32; i++) {
+        n->s.rv_value[i] = value[i];
+        n->s.rv_v[i][0] = v0[i]; n->s.rv_v[i][1] = v1[i]; n->s.rv_v[i][2] = v2[i];
+        n->s.rv_i[i] = pos[i];
+    }
+#if defined(__x86_64__) || defined(__i386__)
+    _mm_setcsr(csr);
+#endif
+}
+int o_is_reverb_stereo(const onode *n) { return n && n->type == O_REVERB_STEREO; }

@@ -213,6 +213,36 @@ void o_bank_pin_threads(int on);
 int o_bank_allowed_cpus(void);
 void o_bank_pin_self(int t);
 double o_bank_render_fast(const o_bank_job *job, float *out);
+/* Configs 4 and 5 the same way (fundsp_oracle.c, bottom): the statically dispatched, inlined process() of the voice graph, made of the
+ * tree walk's own node functions -> bit-identical to o_process by construction.  o_c4_open matches
+ * `((dc(f) >> saw() | dc(fc) | dc(q)) >> moog()) * ENV >> pan(p)`, ENV = adsr_live (gate = the graph's input) or var(g) >> adsr_live. */
+typedef struct {
+    onode *g, *saw, *moog, *env, *var, *pan;
+    float f, fc, q;
+} o_c4_voice;
+int o_c4_open(onode *g, o_c4_voice *v);                                       /* 0, or -1 if the tree has another shape */
+void o_c4_block(o_c4_voice *v, int size, const float *gate, float *out);     /* gate [64] or NULL (Var shape); out [2][64] */
+void o_reverb_stereo_block(onode *n, int size, const float *in, float *out); /* in, out [2][64] */
+int o_is_reverb_stereo(const onode *n);
+/* Threaded drivers of the cpu_baseline legs of configs 4 / 5 (o_fast.c): voices [v0, v1) of a thread's slice rendered one after the other,
+ * many per thread, `frames` frames each in 64-sample blocks; returns seconds.  Config 4: p0..p3 = f, fc, q, pan; adsr = a, d, s, r;
+ * gate_var != 0: the Var shape, the variable follows plan[] = (value, frames) pairs; else the stream shape, gate[] = [frames].
+ * `fast` = 0 renders through the generic tree walk instead (the same job, for the bit-equality test and the tree-walk figure);
+ * out (or NULL) = [voice][2][frames]. */
+typedef struct {
+    int threads, fast, gate_var, n_plan;
+    double sample_rate;
+    size_t voices, frames;
+    const float *p0, *p1, *p2, *p3;
+    const uint64_t *seed;
+    float adsr[4];
+    const float *gate;      /* [frames] (stream shape) */
+    const float *plan;      /* n_plan x (value, frames) (Var shape) */
+} o_c4_job;
+double o_c4_bank_render(const o_c4_job *job, float *out);
+/* Config 5: `instances` x reverb_stereo(room, time, damping) on the SAME stereo input x [2][frames]; out (or NULL) = [instance][2][frames] */
+double o_reverb_bank_render(int threads, int fast, double sample_rate, size_t instances, size_t frames, double room, double time, double damping,
+                            const float *x, float *out);
 const char *o_fast_simd_flavour(void);
 
 #ifdef __cplusplus

@@ -193,3 +193,164 @@ double o_bank_render_fast(const o_bank_job *job, float *out) {
     free(sl);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---- cpu_baseline legs of BASELINE configs 4 and 5 ------------------------------------------------------------------------------
+ * Threaded like o_bank_render_fast: every thread renders its slice of the voices one after the other (MANY per thread, each for the whole
+ * duration in 64-sample blocks), through the monomorphised block functions of fundsp_oracle.c (fast = 1) or the generic tree walk (fast = 0). */
+static const owavetable *saw_table(void) { /* Wavetable::new for saw(): built once (o_wavetable.c), shared like the reference's Arc<Wavetable> */
+    static const owavetable *t;
+    static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_mutex_lock(&mu);
+    if (!t) {
+        float *pitches = (float *)malloc(64 * sizeof(float)), *data = (float *)malloc((size_t)64 * 8192 * sizeof(float));
+        int *lengths = (int *)malloc(64 * sizeof(int));
+        const int n = o_make_wavetable(0, 64, pitches, lengths, (size_t)64 * 8192, data);
+        if (n > 0) t = o_wavetable_create(n, pitches, lengths, data);
+        free(pitches); free(lengths); free(data);
+    }
+    pthread_mutex_unlock(&mu);
+    return t;
+}
+
+/* ((dc(f) >> saw() | dc(fc) | dc(q)) >> moog()) * ENV >> pan(p), set_sample_rate, set_seed(v): what tests/ and bench.py build through the
+ * Python notation, here through the C constructors; *var = the Var node (Var shape) or NULL */
+static onode *c4_build(const o_c4_job *job, size_t v, onode **var) {
+    const owavetable *t = saw_table();
+    if (!t) return NULL;
+    float f = job->p0[v], fc = job->p1[v], q = job->p2[v];
+    onode *osc = o_pipe(o_constant(1, &f), o_wavesynth(t, 1));
+    onode *sm = o_pipe(o_stack(o_stack(osc, o_constant(1, &fc)), o_constant(1, &q)), o_moog(3, 1000.0f, 0.1f));
+    onode *env = o_adsr_live(job->adsr[0], job->adsr[1], job->adsr[2], job->adsr[3]);
+    *var = NULL;
+    if (job->gate_var) {
+        *var = o_var(0.0f);
+        env = o_pipe(*var, env);
+    }
+    onode *g = o_pipe(o_binop(O_MUL, sm, env), o_panner(1, job->p3[v]));
+    o_set_sample_rate(g, job->sample_rate);
+    o_set_seed(g, job->seed[v]);
+    return g;
+}
+
+typedef struct {
+    const o_c4_job *job;
+    float *out;
+    size_t v0, v1;
+    int t;
+} c4slice;
+
+static void *run_c4_slice(void *arg) {
+    c4slice *s = (c4slice *)arg;
+    const o_c4_job *job = s->job;
+    o_bank_pin_self(s->t);
+    const size_t T = job->frames;
+    float in[64], blk[2 * 64];
+    memset(blk, 0, sizeof blk);
+    for (size_t v = s->v0; v < s->v1; v++) {
+        onode *var = NULL, *g = c4_build(job, v, &var);
+        o_c4_voice cv;
+        if (!g || (job->fast && o_c4_open(g, &cv) != 0)) abort();
+        size_t i = 0;
+        /* the Var shape walks its plan: one launch per entry, a new block starts with every entry (as separate process() calls would);
+         * the stream shape is one entry of T frames */
+        const int np = job->gate_var ? job->n_plan : 1;
+        for (int k = 0; k < np && i < T; k++) {
+            size_t n_entry = T;
+            if (job->gate_var) {
+                o_var_set(var, job->plan[2 * k]);
+                n_entry = (size_t)job->plan[2 * k + 1];
+            }
+            for (size_t j = 0; j < n_entry && i < T; j += 64) {
+                size_t left = n_entry - j < T - i ? n_entry - j : T - i;
+                const int n = (int)(left < 64 ? left : 64);
+                if (!job->gate_var) memcpy(in, job->gate + i, (size_t)n * sizeof(float));
+                if (job->fast) o_c4_block(&cv, n, in, blk);
+                else o_process(g, n, in, blk);
+                if (s->out) {
+                    memcpy(&s->out[(v * 2 + 0) * T + i], blk, (size_t)n * sizeof(float));
+                    memcpy(&s->out[(v * 2 + 1) * T + i], blk + 64, (size_t)n * sizeof(float));
+                }
+                i += (size_t)n;
+            }
+        }
+        o_free(g);
+    }
+    return NULL;
+}
+
+static double run_threads(int nt, size_t units, void *(*fn)(void *), void *slices, size_t slice_size, void (*fill)(void *, size_t, size_t, int)) {
+    if ((size_t)nt > units) nt = (int)units;
+    if (nt < 1) nt = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nt);
+    struct timespec t0, t1;
+    for (int t = 0; t < nt; t++) fill((char *)slices + (size_t)t * slice_size, units * (size_t)t / (size_t)nt, units * (size_t)(t + 1) / (size_t)nt, t);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < nt; t++) pthread_create(&th[t], NULL, fn, (char *)slices + (size_t)t * slice_size);
+    for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(th);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+static const o_c4_job *g_c4_job;
+static float *g_c4_out;
+static void c4_fill(void *p, size_t v0, size_t v1, int t) {
+    c4slice *s = (c4slice *)p;
+    s->job = g_c4_job; s->out = g_c4_out; s->v0 = v0; s->v1 = v1; s->t = t;
+}
+double o_c4_bank_render(const o_c4_job *job, float *out) {
+    if (!saw_table() || (job->gate_var ? (job->n_plan < 1 || !job->plan) : !job->gate)) return -1.0;
+    int nt = job->threads > 0 ? job->threads : 1;
+    c4slice *sl = (c4slice *)calloc((size_t)nt, sizeof(c4slice));
+    g_c4_job = job; g_c4_out = out;
+    const double s = run_threads(nt, job->voices, run_c4_slice, sl, sizeof(c4slice), c4_fill);
+    free(sl);
+    return s;
+}
+
+typedef struct {
+    int fast, t;
+    double sr, room, time, damping;
+    size_t i0, i1, frames;
+    const float *x;
+    float *out;
+} rvslice;
+static rvslice g_rv;
+static void rv_fill(void *p, size_t i0, size_t i1, int t) {
+    rvslice *s = (rvslice *)p;
+    *s = g_rv;
+    s->i0 = i0; s->i1 = i1; s->t = t;
+}
+static void *run_rv_slice(void *arg) {
+    rvslice *s = (rvslice *)arg;
+    o_bank_pin_self(s->t);
+    const size_t T = s->frames;
+    float in[2 * 64], blk[2 * 64];
+    for (size_t k = s->i0; k < s->i1; k++) {
+        onode *g = o_reverb_stereo(s->room, s->time, s->damping);
+        o_set_sample_rate(g, s->sr);
+        for (size_t i = 0; i < T; i += 64) {
+            const int n = (int)(T - i < 64 ? T - i : 64);
+            memcpy(in, s->x + i, (size_t)n * sizeof(float));
+            memcpy(in + 64, s->x + T + i, (size_t)n * sizeof(float));
+            if (s->fast) o_reverb_stereo_block(g, n, in, blk);
+            else o_process(g, n, in, blk);
+            if (s->out) {
+                memcpy(&s->out[(k * 2 + 0) * T + i], blk, (size_t)n * sizeof(float));
+                memcpy(&s->out[(k * 2 + 1) * T + i], blk + 64, (size_t)n * sizeof(float));
+            }
+        }
+        o_free(g);
+    }
+    return NULL;
+}
+double o_reverb_bank_render(int threads, int fast, double sample_rate, size_t instances, size_t frames, double room, double time, double damping,
+                            const float *x, float *out) {
+    int nt = threads > 0 ? threads : 1;
+    rvslice *sl = (rvslice *)calloc((size_t)nt, sizeof(rvslice));
+    memset(&g_rv, 0, sizeof g_rv);
+    g_rv.fast = fast; g_rv.sr = sample_rate; g_rv.room = room; g_rv.time = time; g_rv.damping = damping; g_rv.frames = frames; g_rv.x = x; g_rv.out = out;
+    const double s = run_threads(nt, instances, run_rv_slice, sl, sizeof(rvslice), rv_fill);
+    free(sl);
+    return s;
+}

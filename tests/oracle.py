@@ -742,6 +742,50 @@ def bank_render(config, params, seeds, frames, sample_rate=48000.0, process_mode
     return out, secs
 
 
+class C4Job(C.Structure):
+    _fields_ = [
+        ("threads", C.c_int), ("fast", C.c_int), ("gate_var", C.c_int), ("n_plan", C.c_int),
+        ("sample_rate", C.c_double), ("voices", C.c_size_t), ("frames", C.c_size_t),
+        ("p0", C.POINTER(C.c_float)), ("p1", C.POINTER(C.c_float)), ("p2", C.POINTER(C.c_float)), ("p3", C.POINTER(C.c_float)),
+        ("seed", C.POINTER(C.c_uint64)), ("adsr", C.c_float * 4), ("gate", C.POINTER(C.c_float)), ("plan", C.POINTER(C.c_float)),
+    ]
+
+
+def c4_bank_render(p, adsr, frames, sample_rate=48000.0, gate=None, plan=None, threads=1, fast=True, store=True, lib=None):
+    """V voices of BASELINE config 4 through the C bank driver (oracle/o_fast.c): `gate` [frames] = the stream-gate shape
+    (`... * adsr_live(..)`, the gate is the graph's input), `plan` [(value, frames), ..] = the reference's shape `var(g) >> adsr_live(..)`
+    with the variable set before every entry.  fast: the monomorphised process() (fundsp_oracle.c o_c4_block), else the tree walk.
+    -> (out [V][2][frames] or None, seconds)"""
+    V = len(p["seed"])
+    arrs = [np.ascontiguousarray(p[k], dtype=np.float32) for k in ("f", "fc", "q", "pan")]
+    seeds = np.ascontiguousarray(p["seed"], dtype=np.uint64)
+    g = None if gate is None else np.ascontiguousarray(gate, dtype=np.float32).reshape(-1)
+    pl = None if plan is None else np.ascontiguousarray([[v, n] for v, n in plan], dtype=np.float32).reshape(-1)
+    assert (g is None) != (pl is None) and (g is None or g.size >= frames)
+    job = C4Job(threads, int(fast), int(pl is not None), 0 if pl is None else len(plan), sample_rate, V, frames,
+                *[_fptr(a) for a in arrs], seeds.ctypes.data_as(C.POINTER(C.c_uint64)), (C.c_float * 4)(*[float(a) for a in adsr]), _fptr(g), _fptr(pl))
+    out = np.zeros((V, 2, frames), dtype=np.float32) if store else None
+    L = lib or globals()["lib"]()
+    L.o_c4_bank_render.restype = C.c_double
+    L.o_c4_bank_render.argtypes = [C.POINTER(C4Job), C.POINTER(C.c_float)]
+    secs = L.o_c4_bank_render(C.byref(job), _fptr(out))
+    assert secs >= 0.0
+    return out, secs
+
+
+def reverb_bank_render(instances, x, sample_rate=48000.0, room=10.0, time=2.0, damping=0.5, threads=1, fast=True, store=True, lib=None):
+    """`instances` x reverb_stereo(room, time, damping) on the stereo input x [2][frames] -> (out [instances][2][frames] or None, seconds)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    assert x.ndim == 2 and x.shape[0] == 2
+    frames = x.shape[1]
+    out = np.zeros((instances, 2, frames), dtype=np.float32) if store else None
+    L = lib or globals()["lib"]()
+    L.o_reverb_bank_render.restype = C.c_double
+    L.o_reverb_bank_render.argtypes = [C.c_int, C.c_int, C.c_double, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    secs = L.o_reverb_bank_render(threads, int(fast), sample_rate, instances, frames, room, time, damping, _fptr(x), _fptr(out))
+    return out, secs
+
+
 FADE_POWER, FADE_SMOOTH = 0, 1
 
 

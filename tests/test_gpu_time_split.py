@@ -223,3 +223,28 @@ def test_run_time_compiled_graphs_at_real_time_launch_lengths(gpu, name):
             assert_bit_equal(got, run_bank(ref, x, T, layout, MODE_PROCESS), f"{name} layout {layout} T = {T}: family {families[-1]} vs the single-wave kernel")
         want = [fam, fam if layout == LAYOUT_PLANAR else 1, fam, 1, fam]
         assert families == want or all(f == 1 for f in families), (families, want)   # (a graph without a stage plan stays on the single wave)
+
+
+@pytest.mark.parametrize("V,T", [(1024, 64 * 12), (64 * 5 + 9, 64), (64 * 301 + 5, 64 * 3)])
+def test_config2_biquad_split_at_its_seam(gpu, time_split, V, T):
+    """BASELINE config 2 (`noise() >> biquad`, 1024 voices): the DF1 biquad is a chain of two stages cut at the seam of its own
+    expression (biquad.rs:186-188: `(b0*x0 + b1*x1) + b2*x2` | `(p - a1*y1) - a2*y2`), so behind the counter-based Noise the chain has
+    three stages and a small bank takes the three-way time-split kernel: noise and the feed-forward half in three waves each, the
+    serial wave carries the recurrence alone.  Every kernel family renders the oracle's samples: time split (4), stage pipeline (2:
+    noise | whole biquad with the packed feed-forward half), single wave (1); one group per CU, a ragged lone block, two per workgroup."""
+    p = W.noise_biquad_params(V, SR)
+    pick = np.unique(np.concatenate([[0, 63, 64 % V, V - 1], np.random.default_rng(V).integers(0, V, 12)]))
+    want, _ = O.bank_render(2, [p["fc"][pick], p["q"][pick]], p["seed"][pick], 2 * T + 13, SR, True, 0, 4)      # [voice][frame]
+    outs = {}
+    for name, opts, family in (("time split", {}, 4), ("pipeline", {"time_split": 0, "pipe_split": 2}, 2), ("single wave", {"pipe_split": 0}, 1)):
+        b = W.make_noise_biquad_bank(V, SR, params=p)
+        for k, v in opts.items():
+            b.set_option(k, v)
+        a = run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :]
+        assert b.get_option("last_kernel") == family, name
+        c = run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :]      # the state carried into a second launch
+        d = run_bank(b, None, 13, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :]     # ... and into a ragged one (pipeline / single wave)
+        outs[name] = np.concatenate([a, c, d], axis=1)
+        assert_bit_equal(outs[name][pick], want, f"config 2, {name} vs oracle")
+    assert_bit_equal(outs["time split"], outs["single wave"], "time split == single wave, every voice")
+    assert_bit_equal(outs["pipeline"], outs["single wave"], "pipeline == single wave, every voice")

@@ -58,3 +58,71 @@ def test_native_build_is_bit_identical_too():
     want, _ = O.bank_render(*args, 1, 1)
     got, _ = O.bank_render(*args, 1, 4, lib=L, fast=True)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), L.o_fast_simd_flavour().decode()
+
+
+# ---- configs 4 and 5: the monomorphised process() of the cpu_baseline legs == the tree walk == the graph the tests build ------------
+ADSR = (0.005, 0.01, 0.6, 0.01)
+
+
+def _c4_python_voice(p, v, adsr, var):
+    gate = O.var(0.0) if var else None
+    env = (gate >> O.adsr_live(*adsr)) if var else O.adsr_live(*adsr)
+    g = (((O.dc(float(p["f"][v])) >> O.saw()) | O.dc(float(p["fc"][v])) | O.dc(float(p["q"][v]))) >> O.moog()) * env >> O.pan(float(p["pan"][v]))
+    g.set_sample_rate(SR)
+    g.set_seed(int(p["seed"][v]))
+    return g, gate
+
+
+@pytest.mark.parametrize("frames", [64 * 20 + 7, 64, 5])
+def test_config4_stream_gate_fast_equals_tree_walk_and_the_python_graph(frames):
+    V = 12
+    p = W.saw_moog_params(V, SR)
+    gate = W.gate_signal(frames, SR, on_frame=1, off_seconds=700 / SR)
+    want, _ = O.c4_bank_render(p, ADSR, frames, SR, gate=gate, fast=False)
+    got, _ = O.c4_bank_render(p, ADSR, frames, SR, gate=gate, threads=3, fast=True)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for v in (0, 5, V - 1):
+        g, _ = _c4_python_voice(p, v, ADSR, False)
+        assert np.array_equal(g.render_blocks(gate[None, :]).view(np.uint32), want[v].view(np.uint32)), f"voice {v}"
+    assert frames <= 64 or np.abs(want).max() > 0.05      # (the envelope's first ~2 ms segment is silent: the closure saw the gate low at t = 0)
+
+
+def test_config4_var_gate_fast_equals_tree_walk_and_the_python_graph():
+    V = 10
+    plan = [(0.0, 64), (1.0, 64 * 9), (0.0, 64 * 3 + 7), (0.5, 64 * 5), (0.0, 64 * 6 + 3)]
+    frames = sum(n for _, n in plan)
+    p = W.saw_moog_params(V, SR)
+    want, _ = O.c4_bank_render(p, ADSR, frames, SR, plan=plan, fast=False)
+    got, _ = O.c4_bank_render(p, ADSR, frames, SR, plan=plan, threads=2, fast=True)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for v in (0, 4, V - 1):
+        g, gate = _c4_python_voice(p, v, ADSR, True)
+        parts = []
+        for value, n in plan:
+            gate.set_value(value)
+            parts.append(g.render_blocks(length=n))
+        assert np.array_equal(np.concatenate(parts, axis=1).view(np.uint32), want[v].view(np.uint32)), f"voice {v}"
+    assert np.abs(want).max() > 0.05
+
+
+def test_var_process_is_a_block_constant_splat():
+    """Var::process (shared.rs:122-125) reads the variable once per block; Var::tick per sample: same values while nobody writes"""
+    n = O.var(0.25)
+    a = n.render_blocks(length=77)
+    n.set_value(-3.0)
+    b = n.render_ticks(length=9)
+    assert np.all(a == np.float32(0.25)) and np.all(b == np.float32(-3.0))
+
+
+@pytest.mark.parametrize("frames", [64 * 30 + 11, 64])
+def test_config5_block_form_equals_tree_walk(frames):
+    rng = np.random.default_rng(5)
+    x = (rng.random((2, frames), dtype=np.float32) * 2 - 1).astype(np.float32)
+    x[:, frames // 2:] = 0.0            # a silent tail: the feedback decays into the flush-to-zero range
+    want, _ = O.reverb_bank_render(3, x, SR, fast=False)
+    got, _ = O.reverb_bank_render(3, x, SR, threads=2, fast=True)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    n = O.reverb_stereo(10.0, 2.0, 0.5)
+    n.set_sample_rate(SR)
+    assert np.array_equal(n.render_blocks(x).view(np.uint32), want[0].view(np.uint32))
+    assert frames <= 64 or np.abs(want).max() > 0.01       # (the shortest delay line is longer than one block)

@@ -14,8 +14,13 @@ from fundsp_amd import workloads as W
 
 V, T, sr = int(os.environ.get("V", 32768)), 48000, 48000.0
 mode = F.MODE_PROCESS
+only = os.environ.get("ONLY")
 for math in ("exact", "fast"):
+    if only and math != "exact":
+        continue
     for cfg in ("4v", 4):
+        if only and str(cfg) != only:
+            continue
         wl = B.make_workload(F, W, torch, cfg, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, math)
         ms, kms = B.quick(F, torch, wl, T, mode, steps=4, warmup=1)
         row = {"cfg": cfg, "math": math, "V": V, "voice_out_ms": round(ms, 4), "kernel_ms": round(kms, 4)}
