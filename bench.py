@@ -146,11 +146,12 @@ def cpu_baseline(voices, frames, sample_rate, target_seconds):
 
 
 def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
-    """cpu_baseline of a secondary entry (configs 2 / 4 / 5): the generic oracle (C restatement of the reference's process()
-    path) on a bounded sample.  Config 2 through the threaded bank driver (native build); configs 4 / 5 render one voice /
-    instance per host thread through the oracle's node API (the -O2 build the tests use)."""
-    import threading
-
+    """cpu_baseline of a secondary entry (configs 2 / 4 / "4v" / 5): the C restatement of the reference's process() path on a bounded sample
+    of the same workload, built on this host with NATIVE_FLAGS, `cores` pinned threads with MANY voices per thread (the C bank drivers of
+    oracle/o_bank.c / o_fast.c split the voices over the threads), every leg >= 3 s.  Configs 4 / 5: the MONOMORPHISED process() -- the
+    statically dispatched, inlined form rustc makes of the typed graph (fundsp_oracle.c o_c4_block / o_reverb_stereo_block: the tree walk's
+    own node functions without the tree; bit-equal to it, tests/test_oracle_fast.py) -- with the generic tree walk beside it
+    (`tree_walk_value`).  Config 2 through the threaded bank driver (its Biquad / Noise process() are already inlined loops)."""
     import numpy as np
 
     from fundsp_amd import workloads as W
@@ -158,63 +159,49 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
     O, L = _native_oracle()
     cores = host_cpu_budget()["effective_cpus"]
     L.o_bank_pin_threads.argtypes = [C.c_int]
-    L.o_bank_pin_self.argtypes = [C.c_int]
-    if config == 2:
-        L.o_bank_pin_threads(1)
-        n = 4 * cores
-        for _ in range(2):   # calibrate on a small sample, then size the timed one for ~target_seconds
-            p = W.noise_biquad_params(n, sample_rate)
-            s = O.bank_render(2, [p["fc"], p["q"]], p["seed"], frames, sample_rate, True, 0, cores, store=False, lib=L)[1]
-            if s > 0.3 * target_seconds:
-                break
-            n = max(cores, int(n * target_seconds / max(s, 1e-4)) // cores * cores)
+    L.o_bank_pin_threads(1)
+    try:
+        if config == 2:
+            def timed(n, fast):
+                p = W.noise_biquad_params(n, sample_rate)
+                return O.bank_render(2, [p["fc"], p["q"]], p["seed"], frames, sample_rate, True, 0, cores, store=False, lib=L)[1]
+            unit, what, legs = "Msamples/s", "config-2 voices (noise >> lowpass biquad)", (("value", True),)
+        elif config in (4, "4v"):
+            adsr = (0.01, 0.1, 0.6, 0.2)
+            gate = W.gate_signal(frames, sample_rate) if config == 4 else None
+            plan = W.gate_plan(frames, sample_rate) if config == "4v" else None
+
+            def timed(n, fast):
+                p = W.saw_moog_params(n, sample_rate)
+                return O.c4_bank_render(p, adsr, frames, sample_rate, gate=gate, plan=plan, threads=cores, fast=fast, store=False, lib=L)[1]
+            unit = "Msamples/s"
+            what = ("config-4 voices, gate = " + ("an audio-rate input stream" if config == 4 else "var(gate) >> adsr_live, the variable set between the two halves of the note"))
+            legs = (("value", True), ("tree_walk_value", False))
+        else:
+            rng = np.random.default_rng(5)
+            x = (rng.random((2, frames), dtype=np.float32) * 2 - 1).astype(np.float32)
+
+            def timed(n, fast):
+                return O.reverb_bank_render(n, x, sample_rate, 10.0, 2.0, 0.5, threads=cores, fast=fast, store=False, lib=L)[1]
+            unit, what, legs = "M instance-frames/s", "reverb_stereo(10, 2, 0.5) instances on one stereo noise input", (("value", True), ("tree_walk_value", False))
+        out = {"unit": unit, "cores": cores, "threads_pinned": True,
+               "kind": "port (monomorphised)" if config != 2 else "port", "flags": f"gcc {NATIVE_FLAGS}"}
+        notes = []
+        for key, fast in legs:
+            n = cores
+            s = timed(n, fast)
+            for _ in range(3):   # size the sample for >= target_seconds (many voices per thread), re-size while the estimate was short
+                n = max(cores, int(n * target_seconds * 1.15 / max(s, 1e-4)) // cores * cores)
+                s = timed(n, fast)
+                if s >= target_seconds:
+                    break
+            out[key] = round(n * frames / s / 1e6, 3)
+            notes.append(f"{'monomorphised process()' if fast and config != 2 else ('oracle process() path' if config == 2 else 'generic tree walk')}: {n} {what} x {frames} frames "
+                         f"= {n // cores} per thread, {s:.2f} s")
+        out["sample"] = "; ".join(notes) + f"; {cores} pinned threads"
+        return out
+    finally:
         L.o_bank_pin_threads(0)
-        return {"value": round(n * frames / s / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                "sample": f"{n} config-2 voices x {frames} frames, oracle process() path, {cores} threads, {s:.2f} s"}
-    nt = min(cores, 32)
-    fr = min(frames, 12000)
-    if config in (4, "4v"):
-        p = W.saw_moog_params(nt, sample_rate)
-        gate = W.gate_signal(fr, sample_rate)[None, :]
-
-        def make(v):
-            env = O.adsr_live(0.01, 0.1, 0.6, 0.2) if config == 4 else (O.var(1.0) >> O.adsr_live(0.01, 0.1, 0.6, 0.2))
-            g = (((O.dc(float(p["f"][v])) >> O.saw()) | O.dc(float(p["fc"][v])) | O.dc(float(p["q"][v]))) >> O.moog()) \
-                * env >> O.pan(float(p["pan"][v]))
-            g.set_sample_rate(sample_rate)
-            g.set_seed(int(p["seed"][v]))
-            return g, (gate if config == 4 else np.zeros((0, fr), dtype=np.float32))
-        unit, what = "Msamples/s", "config-4 voices"
-    else:
-        rng = np.random.default_rng(5)
-        x = (rng.random((2, fr), dtype=np.float32) * 2 - 1).astype(np.float32)
-
-        def make(v):
-            g = O.reverb_stereo(10.0, 2.0, 0.5)
-            g.set_sample_rate(sample_rate)
-            return g, x
-        unit, what = "M instance-frames/s", "reverb_stereo instances"
-    nodes = [make(v) for v in range(nt)]
-    t0 = time.perf_counter()
-    nodes[0][0].render_blocks(nodes[0][1], length=fr)            # calibration (and page-in): one voice, one pass
-    reps = max(1, int(target_seconds / max(time.perf_counter() - t0, 1e-4)))
-
-    def work(k, gx):
-        L.o_bank_pin_threads(1)
-        L.o_bank_pin_self(k)   # one CPU of the affinity mask per host thread
-        for _ in range(reps):
-            gx[0].render_blocks(gx[1], length=fr)
-    ths = [threading.Thread(target=work, args=(k, gx)) for k, gx in enumerate(nodes)]
-    t0 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    s = time.perf_counter() - t0
-    L.o_bank_pin_threads(0)
-    return {"value": round(nt * fr * reps / s / 1e6, 3), "unit": unit, "cores": nt, "kind": "port",
-            "sample": f"{nt} {what} x {fr * reps} frames ({reps} passes of {fr}), one per host thread, oracle process() path "
-                      f"(generic node tree, gcc -O2), {s:.2f} s"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -232,7 +219,7 @@ def make_workload(F, W, torch, config, V, T, sr, first, layout, math, voice_out=
     elif config == 2:
         bank = W.make_noise_biquad_bank(V, sr, voice0=first)
         n_out, bps, slot_bytes = 1, 4, 48          # noise generated in-kernel: 4 B/voice-sample out
-        kernel = "fd::k_render_pipe<noise_biquad> / fd::k_render<noise_biquad> (launches under 256 frames)"
+        kernel = "fd::k_render_ts3<noise_biquad> (whole blocks, small banks: noise | biquad feed-forward half | recurrence) / fd::k_render_pipe / fd::k_render (ragged launches)"
     elif config == 5:
         # 16 384 x reverb_stereo(10, 2, 0.5) over 8 GPUs = 2048 instances per GPU; stereo white noise resident in HBM;
         # planar [instance][channel][frame] I/O (the kernel is lane = frame)
@@ -344,17 +331,20 @@ def secondary(F, W, torch, sr, mode):
     # config 2: 1024-voice biquad bank on white noise, 64-sample blocks (the launch-latency config)
     V = 1024
     c2 = {"name": "config2_biquad_bank_1024", "what": "BASELINE config 2: 1024 voices noise >> lowpass biquad (one BiquadBank<f32x8> lane "
-          "per voice), noise generated in-kernel, voice-out; T = frames per launch", "unit": "Msamples/s"}
-    for T in (64, 4096, 48000):
+          "per voice), noise generated in-kernel, voice-out; T = frames per launch.  The DF1 biquad is a chain of two stages cut at the seam of its expression "
+          "(feed-forward half | recurrence, biquad.rs:186-188), so launches of whole blocks take the three-way time-split kernel (last_kernel 4): noise and the "
+          "feed-forward half in three waves each, the serial wave carries the recurrence alone", "unit": "Msamples/s"}
+    for T in (64, 128, 256, 4096, 48000):
         wl = make_workload(F, W, torch, 2, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, "exact")
-        ms, kms = quick(F, torch, wl, T, mode, steps=50 if T == 64 else 10, warmup=5)
-        c2[f"T{T}"] = {"us_per_launch": round(ms * 1e3, 2), "kernel_us": round(kms * 1e3, 2), "value": round(V * T / ms / 1e3, 2)}
+        ms, kms = quick(F, torch, wl, T, mode, steps=50 if T <= 256 else 10, warmup=5)
+        c2[f"T{T}"] = {"us_per_launch": round(ms * 1e3, 2), "kernel_us": round(kms * 1e3, 2), "value": round(V * T / ms / 1e3, 2),
+                       "last_kernel": wl["bank"].get_option("last_kernel")}
         if T == 48000:
             try:
                 c2["cpu_baseline"] = cpu_baseline_config(2, sr, 48000)
             except Exception as e:
                 c2["cpu_baseline"] = {"error": repr(e)}
-        if T == 64:  # the real-time pattern: one 64-frame block per launch, call by call vs replayed from a HIP graph
+        if T <= 256:  # the real-time pattern: one launch per callback, call by call vs replayed from a HIP graph
             NB = 32
             outs = [torch.empty_like(wl["out"]) for _ in range(NB)]
             s = torch.cuda.Stream()
@@ -362,7 +352,7 @@ def secondary(F, W, torch, sr, mode):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=s):
                     for kk in range(NB):
-                        wl["bank"].process(64, None, outs[kk], layout=wl["layout"], mode=mode)
+                        wl["bank"].process(T, None, outs[kk], layout=wl["layout"], mode=mode)
                 g.replay()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -370,10 +360,23 @@ def secondary(F, W, torch, sr, mode):
                     g.replay()
                 torch.cuda.synchronize()
                 us = (time.perf_counter() - t0) / 20 / NB * 1e6
-            c2["T64"]["hip_graph_replay_us_per_block"] = round(us, 2)
-            c2["T64"]["hip_graph_value"] = round(V * 64 / us, 2)
+            c2[f"T{T}"]["hip_graph_replay_us_per_launch"] = round(us, 2)
+            c2[f"T{T}"]["hip_graph_value"] = round(V * T / us, 2)
             del g, outs
         del wl
+    # who wins at the block size the config names (64 frames per launch), and from which launch length the GPU does: the CPU's process()
+    # path works in 64-sample blocks whatever the caller's buffer, so its figure does not depend on T
+    cpu = c2.get("cpu_baseline", {}).get("value")
+    if cpu:
+        c2["cpu_vs_gpu"] = {"cpu_value": cpu, "cpu_cores": c2["cpu_baseline"].get("cores")}
+        for T in (64, 128, 256):
+            gv = c2[f"T{T}"]["hip_graph_value"]
+            c2["cpu_vs_gpu"][f"T{T}"] = {"gpu_hip_graph_value": gv, "winner": "gpu" if gv > cpu else "cpu", "gpu_over_cpu": round(gv / cpu, 3)}
+        c2["cpu_vs_gpu"]["T48000"] = {"gpu_value": c2["T48000"]["value"], "winner": "gpu" if c2["T48000"]["value"] > cpu else "cpu",
+                                      "gpu_over_cpu": round(c2["T48000"]["value"] / cpu, 3)}
+        c2["cpu_vs_gpu"]["note"] = ("a dependent chain of EMPTY kernels replays at ~1.6 us per node on this platform and an event pair around an empty kernel reads ~6 us "
+                                    "(tools/ubench_launch.hip, profiles/r05_ubench_launch_*.txt): 65 536 samples per 64-frame block leave the GPU ~3 us per launch to beat "
+                                    "the host's cores")
     out.append(c2)
     # ... the same launch pattern from a COMPILED host, straight through the C ABI (tools/launch_overhead.cpp, built here with g++):
     # what the Python binding adds per 64-frame block is the difference to T64.us_per_launch above
@@ -756,6 +759,11 @@ def main(argv=None):
     print(json.dumps(res), flush=True)
 
 
+def cpu_baseline_wanted(args, rank, world):
+    """The headline's cpu_baseline leg runs on rank 0 of EVERY run of the headline config, whatever the number of GPUs."""
+    return rank == 0 and world >= 1 and args.cpu_seconds > 0 and args.config == 3
+
+
 def fused_mix(args, F, layout):
     """--mix takes the fused mix-down (the render kernel reduces over the voices itself) wherever the bank has it: the voice-minor
     configs 2 / 3 / 4.  --mix-mode unfused keeps round 3's shape (voice-out render, then a second kernel over it)."""
@@ -1051,7 +1059,9 @@ def run_rank(args, torch, F, peers, device):
                 "power": power,
             },
         }
-        if world == 1 and args.cpu_seconds > 0 and args.config == 3:
+        # the CPU path "in the same run" (north_star): on rank 0, after the timed region -- at N > 1 too (the other ranks wait at the
+        # run's last barrier)
+        if cpu_baseline_wanted(args, peers.rank, world):
             res["cpu_baseline"] = cpu_baseline(total_voices, T, sr, args.cpu_seconds)
         else:
             res["cpu_baseline"] = None

@@ -97,3 +97,22 @@ def test_cpu_baseline_counts_the_cpus_the_process_may_use(tmp_path):
     (v1 / "cpu.cfs_quota_us").write_text("-1\n")
     assert bench.host_cpu_budget(str(tmp_path / "v1"))["effective_cpus"] == aff
     assert bench.host_cpu_budget(str(tmp_path / "nothing_here"))["effective_cpus"] == aff
+
+
+def test_cpu_baseline_runs_on_rank_0_of_multi_gpu_runs_too():
+    """north_star: the CPU path is timed "in the same run" next to the 1/2/4/8-GPU numbers (it used to be null at N > 1)."""
+    a = bench.parse_args(["--gpus", "2"])
+    assert bench.cpu_baseline_wanted(a, 0, 2) and bench.cpu_baseline_wanted(a, 0, 8) and bench.cpu_baseline_wanted(a, 0, 1)
+    assert not bench.cpu_baseline_wanted(a, 1, 2)
+    assert not bench.cpu_baseline_wanted(bench.parse_args(["--gpus", "2", "--cpu-seconds", "0"]), 0, 2)
+
+
+def test_secondary_cpu_baselines_are_the_native_monomorphised_legs():
+    """Every cpu_baseline of the bench line comes from the -O3 -march=native build, many voices per pinned thread; configs 4 / 5 through
+    the monomorphised process() (bit-equal to the tree walk: tests/test_oracle_fast.py)."""
+    for cfg, kind in ((2, "port"), ("4v", "port (monomorphised)"), (5, "port (monomorphised)")):
+        r = bench.cpu_baseline_config(cfg, 48000.0, 640, target_seconds=0.05)
+        assert r["kind"] == kind and "-O3 -march=native" in r["flags"] and r["value"] > 0 and r["threads_pinned"]
+        assert r["cores"] == bench.host_cpu_budget()["effective_cpus"]
+        if cfg != 2:
+            assert r["tree_walk_value"] > 0

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from fundsp_amd import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS
+from fundsp_amd import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MIX_PAN, MIX_SUM, MODE_PROCESS
 from fundsp_amd import workloads as W
 from test_gpu_config4 import config4_oracle_voice, tables  # noqa: F401
 from test_gpu_parity import assert_bit_equal
@@ -41,6 +41,15 @@ def test_config3_full_size(gpu):
     s = small.process(T)
     assert torch.equal(out[0][:, 30000:30200], s[0])
     del s, small
+    # mode B at full size (the bench's config3_mix_pan_fused launch shape: 750 blocks, 1 024 voice groups): every voice panned and summed
+    # inside the render launch == fdsp_mix_stereo of the voice-out render above, bit for bit
+    pan = (-1.0 + 2.0 * W.rnd1(np.arange(V, dtype=np.uint64) + np.uint64(777))).astype(np.float32)
+    bm = W.make_fm_svf_bank(V, SR, params=p)
+    bm.set_pan(pan)
+    fused = bm.process_mix(T, mix=MIX_PAN)
+    unfused = gpu.mix_stereo(out[0], torch.from_numpy(pan).cuda())
+    assert fused.shape == (2, T) and torch.equal(fused, unfused), "config 3 full size: fused mix-down vs mix_stereo(voice-out)"
+    del bm, fused, unfused
     # the reference-native planar layout at full size (planar pipeline kernel): the same samples, transposed
     b3 = W.make_fm_svf_bank(V, SR, params=p)
     planar = b3.process(T, layout=LAYOUT_PLANAR, frame_stride=T)   # [V][1][T]
@@ -69,6 +78,54 @@ def test_config4_full_size(gpu, tables):
         assert_bit_equal(got[k], want, f"config 4 full size, voice {v}")
     mix = gpu.sum_voices(out)                                 # the per-GPU partial of the stereo mix-down
     assert mix.shape == (2, T) and bool(torch.isfinite(mix).all())
+    # mode B at full size (the bench's config4_mix_single_rank launch shape): the fused mix-down == sum_voices of the voice-out render
+    bm = W.make_saw_moog_bank(V, SR, params=p, adsr=adsr)
+    fused = bm.process_mix(T, gate, mix=MIX_SUM)
+    assert torch.equal(fused, mix), "config 4 full size: fused mix-down vs sum_voices(voice-out)"
+    assert float(mix.abs().max()) > 1.0
+
+
+def test_config4_var_gate_full_size(gpu, tables):
+    """Config 4 in the reference's gate shape (`var(gate) >> adsr_live`, tests/test_gpu_config4_var.py) at the bench's sizes: one note per
+    second = two launches of 24 000 frames with the Var slot set in between; spot voices vs the oracle, chunked == whole, mode B == the
+    mix of the voice-out render."""
+    import torch
+    from test_gpu_config4_var import device_plan, oracle_plan  # noqa: F401
+
+    V, T = 32768, 48000
+    adsr = (0.01, 0.1, 0.6, 0.2)
+    p = W.saw_moog_params(V, SR)
+    plan = W.gate_plan(T, SR)
+    assert plan == [(1.0, 24000), (0.0, 24000)]
+    bank = W.make_saw_moog_var_bank(V, SR, params=p, adsr=adsr)      # primed with one low block
+    bm = bank.clone()
+    bc = bank.clone()
+    outs = []
+    for value, n in plan:
+        bank.set_param(W.C4V_SLOTS["gate"], value)
+        outs.append(bank.process(n))                                 # [2][n][V]
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(o).all()) for o in outs)
+    rng = np.random.default_rng(2028)
+    spots = np.concatenate([[0, V - 1], rng.integers(0, V, 4)])
+    idx = torch.from_numpy(spots).cuda()
+    got = torch.cat([o[:, :, idx] for o in outs], dim=1).permute(2, 0, 1).contiguous().cpu().numpy()
+    for k, v in enumerate(spots):
+        want = oracle_plan(p, int(v), adsr, [(0.0, 64)] + plan, MODE_PROCESS)[:, 64:]
+        assert_bit_equal(got[k], want, f"config 4 (var gate) full size, voice {v}")
+    mixes = []
+    for value, n in plan:
+        bm.set_param(W.C4V_SLOTS["gate"], value)
+        mixes.append(bm.process_mix(n, mix=MIX_SUM))
+    for o, m in zip(outs, mixes):
+        assert torch.equal(m, gpu.sum_voices(o)), "config 4 (var gate) full size: fused mix-down vs sum_voices(voice-out)"
+    assert float(mixes[0].abs().max()) > 1.0
+    # chunked == whole: the first half in two launches of 12 000 frames (187.5 blocks: a ragged launch starts a new block, so compare the
+    # block-aligned form 11 968 + 12 032)
+    bc.set_param(W.C4V_SLOTS["gate"], 1.0)
+    a = bc.process(11968)
+    b = bc.process(12032)
+    assert torch.equal(outs[0][:, :11968], a) and torch.equal(outs[0][:, 11968:], b)
 
 
 def test_config5_full_size(gpu):
