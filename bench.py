@@ -151,7 +151,8 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
     oracle/o_bank.c / o_fast.c split the voices over the threads), every leg >= 3 s.  Configs 4 / 5: the MONOMORPHISED process() -- the
     statically dispatched, inlined form rustc makes of the typed graph (fundsp_oracle.c o_c4_block / o_reverb_stereo_block: the tree walk's
     own node functions without the tree; bit-equal to it, tests/test_oracle_fast.py) -- with the generic tree walk beside it
-    (`tree_walk_value`).  Config 2 through the threaded bank driver (its Biquad / Noise process() are already inlined loops)."""
+    (`tree_walk_value`).  Config 2: the reference's own SIMD form, BiquadBank<f32x8> -- EIGHT voices per vector instruction (o_fast.c
+    o_biquad_bank8_render; bit-equal to the scalar voices) -- with one scalar Biquad per voice beside it (`scalar_voice_value`)."""
     import numpy as np
 
     from fundsp_amd import workloads as W
@@ -162,10 +163,10 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
     L.o_bank_pin_threads(1)
     try:
         if config == 2:
-            def timed(n, fast):
+            def timed(n, fast):   # fast: BiquadBank<f32x8>, eight voices per SIMD instruction -- the reference's own form of this config
                 p = W.noise_biquad_params(n, sample_rate)
-                return O.bank_render(2, [p["fc"], p["q"]], p["seed"], frames, sample_rate, True, 0, cores, store=False, lib=L)[1]
-            unit, what, legs = "Msamples/s", "config-2 voices (noise >> lowpass biquad)", (("value", True),)
+                return O.bank_render(2, [p["fc"], p["q"]], p["seed"], frames, sample_rate, True, 0, cores, store=False, lib=L, fast=fast)[1]
+            unit, what, legs = "Msamples/s", "config-2 voices (8 x noise >> BiquadBank<f32x8> lanes)", (("value", True), ("scalar_voice_value", False))
         elif config in (4, "4v"):
             adsr = (0.01, 0.1, 0.6, 0.2)
             gate = W.gate_signal(frames, sample_rate) if config == 4 else None
@@ -185,7 +186,7 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
                 return O.reverb_bank_render(n, x, sample_rate, 10.0, 2.0, 0.5, threads=cores, fast=fast, store=False, lib=L)[1]
             unit, what, legs = "M instance-frames/s", "reverb_stereo(10, 2, 0.5) instances on one stereo noise input", (("value", True), ("tree_walk_value", False))
         out = {"unit": unit, "cores": cores, "threads_pinned": True,
-               "kind": "port (monomorphised)" if config != 2 else "port", "flags": f"gcc {NATIVE_FLAGS}"}
+               "kind": "port (monomorphised)", "flags": f"gcc {NATIVE_FLAGS}"}
         notes = []
         for key, fast in legs:
             n = cores
@@ -196,7 +197,7 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
                 if s >= target_seconds:
                     break
             out[key] = round(n * frames / s / 1e6, 3)
-            notes.append(f"{'monomorphised process()' if fast and config != 2 else ('oracle process() path' if config == 2 else 'generic tree walk')}: {n} {what} x {frames} frames "
+            notes.append(f"{('BiquadBank<f32x8> (biquad_bank.rs:73-84), 8 voices per vector' if config == 2 else 'monomorphised process()') if fast else ('one scalar Biquad per voice, tree walk' if config == 2 else 'generic tree walk')}: {n} {what} x {frames} frames "
                          f"= {n // cores} per thread, {s:.2f} s")
         out["sample"] = "; ".join(notes) + f"; {cores} pinned threads"
         return out

@@ -23,7 +23,7 @@ thread_local std::string g_err;
 namespace fd {
 // process-wide DEFAULTS (fdsp_set_option); a bank's own value (fdsp_bank_set_option) overrides them for that bank.  Atomics:
 // hosts drive banks from several threads.  The launch code never reads these: it reads the thread-local block below.
-std::atomic<int> g_pipe_split{1}, g_fdn_kernel{0}, g_time_split{1}, g_stage_split{1};
+std::atomic<int> g_pipe_split{1}, g_fdn_kernel{0}, g_time_split{1};
 std::atomic<int> g_math{FDSP_MATH_EXACT};  // default arithmetic of banks created from now on (fdsp_set_option("math", ..))
 std::atomic<int> g_timing{1};              // default of the per-launch HIP event pair (fdsp_bank_last_kernel_ms)
 std::atomic<long> g_zero_copy_max{1 << 18};  // floats; fdsp_bank_process_host reads/writes pinned host memory directly below this
@@ -158,20 +158,6 @@ hipError_t sync_shared_locked(int dev) {
             padded.push_back(t.data[src]);
             padded.push_back(t.data[src + 1]);
             src += len;
-        }
-        // ... and an interleaved copy of every pair of adjacent tables of equal length (WtSet::pair_off): WaveSynth reads both
-        // tables of its pair at the same index there, 32 contiguous bytes
-        for (int i = 0; i < fd::WT_MAX_TABLES; i++) nw.pair_off[i] = -1;
-        for (int i = 0; i + 1 < t.n; i++) {
-            if (t.len[i] != t.len[i + 1]) continue;
-            while (padded.size() % 4) padded.push_back(0.0f);  // 16-byte aligned runs
-            nw.pair_off[i] = (int)padded.size();
-            const size_t n_pad = (size_t)t.len[i] + 3, oa = (size_t)nw.off[i], ob = (size_t)nw.off[i + 1];
-            for (size_t k = 0; k < n_pad; k++) {
-                const float a = padded[oa + k], bb = padded[ob + k];
-                padded.push_back(a);
-                padded.push_back(bb);
-            }
         }
         float* d = nullptr;
         err = hipMalloc((void**)&d, padded.size() * sizeof(float));
@@ -415,7 +401,7 @@ struct fdsp_bank {
     bool ext_pending = false;  // the last render ran on a caller's stream: bank-stream work must wait for its e1
     int math = FDSP_MATH_EXACT;  // FDSP_MATH_FAST: renders take the kind's tolerance-mode variant when it has one
     // per-bank launch options (fdsp_bank_set_option); -1 = follow the process-wide default at every launch
-    int opt_pipe_split = -1, opt_time_split = -1, opt_fdn_kernel = -1, opt_timing = -1, opt_stage_split = -1;
+    int opt_pipe_split = -1, opt_time_split = -1, opt_fdn_kernel = -1, opt_timing = -1;
     size_t ring_frames = 0;      // as given at creation (fdsp_bank_clone)
     int last_kernel = 0;         // fd::LastKernel of the most recent render launch (fdsp_bank_get_option "last_kernel")
     bool ring_check_pending = false;  // a lifecycle launch may have changed a delay length: verify capacity before rendering
@@ -711,7 +697,6 @@ const OptSpec LAUNCH_OPTS[] = {
     {"time_split", 0, 2, "time_split takes 0 (off), 1 (small banks of eligible graphs: 3 + 3 + 1 waves per group) or 2 (round 2's 2 + 2 + 1 / 2 + 1 + 1 layouts)", &fd::g_time_split, &fdsp_bank::opt_time_split},
     {"fdn_kernel", 0, 1, "fdn_kernel takes 0 (lane per frame) or 1 (lane per delay line)", &fd::g_fdn_kernel, &fdsp_bank::opt_fdn_kernel},
     {"timing", 0, 1, "timing takes 0 (no per-launch event pair) or 1 (fdsp_bank_last_kernel_ms available)", &fd::g_timing, &fdsp_bank::opt_timing},
-    {"stage_split", 0, 1, "stage_split takes 0 (every compute stage in one wave) or 1 (heavy graphs at two voice groups per CU: the oscillator stage in two waves)", &fd::g_stage_split, &fdsp_bank::opt_stage_split},
 };
 const OptSpec* launch_opt(const char* name) {
     if (!name) return nullptr;
@@ -725,7 +710,6 @@ void resolve_opts(const fdsp_bank* b) {
     fd::tl_opts.pipe_split = b->opt_pipe_split >= 0 ? b->opt_pipe_split : fd::g_pipe_split.load(std::memory_order_relaxed);
     fd::tl_opts.time_split = b->opt_time_split >= 0 ? b->opt_time_split : fd::g_time_split.load(std::memory_order_relaxed);
     fd::tl_opts.fdn_kernel = b->opt_fdn_kernel >= 0 ? b->opt_fdn_kernel : fd::g_fdn_kernel.load(std::memory_order_relaxed);
-    fd::tl_opts.stage_split = b->opt_stage_split >= 0 ? b->opt_stage_split : fd::g_stage_split.load(std::memory_order_relaxed);
     fd::tl_opts.last_kernel = fd::LK_NONE;
 }
 bool timing_on(const fdsp_bank* b) { return (b->opt_timing >= 0 ? b->opt_timing : fd::g_timing.load(std::memory_order_relaxed)) != 0; }
@@ -1141,7 +1125,6 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
     b->opt_time_split = src->opt_time_split;
     b->opt_fdn_kernel = src->opt_fdn_kernel;
     b->opt_timing = src->opt_timing;
-    b->opt_stage_split = src->opt_stage_split;
     e = hipStreamSynchronize(b->stream);
     if (e != hipSuccess) return bail(e, "copy");
     *out = b;
@@ -1417,6 +1400,7 @@ int fdsp_bank_mix_reserve(fdsp_bank* b, size_t frames) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
     DeviceGuard guard(b->device);
     const size_t nm = (size_t)(fdsp_bank_outputs(b) > 2 ? fdsp_bank_outputs(b) : 2);
+    if (b->ops && b->ops->prepare_mix) b->ops->prepare_mix(b->math == FDSP_MATH_FAST && (bool)b->ops->render_mix_fast);  // run-time compiled graphs: build the mix kernels NOW
     return mix_reserve(b, (b->stride / 64) * nm * frames);
 }
 

@@ -733,12 +733,6 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
     render_events_body<G, MODE>(slots, stride, V, in, out, T, ev, fade, time0, sample_rate, aux, ring, ring_cap);
 }
 
-#ifndef FD_PIPE_FLAGSYNC
-#define FD_PIPE_FLAGSYNC 0
-#endif
-#ifndef FD_ITEM_LOOP
-#define FD_ITEM_LOOP 1    // A/B switch: 0 = the packed loop as one flat loop of frame pairs, without the item_begin hint
-#endif
 #ifdef FD_PIPE_WPE        // A/B switch: tell the compiler how many waves per SIMD the pipeline kernel runs with
 #define FD_PIPE_ATTR __attribute__((amdgpu_waves_per_eu(FD_PIPE_WPE, FD_PIPE_WPE)))
 #else
@@ -747,58 +741,16 @@ __global__ __launch_bounds__(256) void k_render_events(float* __restrict__ slots
 #ifndef FD_LP_ENABLE
 #define FD_LP_ENABLE 1  // A/B switch (tools/build_variants.sh): 0 = always the generic SVF arithmetic
 #endif
-#ifndef FD_PIPE_BUFFER_STORE
-#define FD_PIPE_BUFFER_STORE 1  // A/B switch: 0 = plain global stores (per-frame 64-bit vector address arithmetic)
-#endif
 // Streams pass the caches by: every input line is read once and every output line written once, while a wavetable voice's table
 // lines are re-read for 7-14 frames each (two groups of 64 voices x two tables = the 256 lines of a CU's L1).  Non-temporal feed loads
 // and sample stores: config 4 9.14 -> 8.89 ms (either one alone 9.07-9.10; profiles/r04_ab_j_stream_policy.txt), the headline -- no
 // tables -- within the noise (profiles/r03_ab20_21_small.txt).  A/B: 0 / 0 = the plain policy; 19 = sc0 sc1 nt stores.
-#ifndef FD_FEED_NT
-#define FD_FEED_NT 1
-#endif
 #ifndef FD_PIPE_STORE_AUX
 #define FD_PIPE_STORE_AUX 2     // cache-policy bits of the pipeline kernel's output stores (0 = none, 2 = nt, 19 = sc0 sc1 nt)
-#endif
-#ifndef FD_PIPE_PRODUCER_PLAIN
-#define FD_PIPE_PRODUCER_PLAIN 0  // A/B switch: 1 = stage 0 of a multi-stage pipeline evaluates its sines with plain ops
 #endif
 #ifndef FD_PIPE_PREFETCH
 #define FD_PIPE_PREFETCH 1      // A/B switch: 0 = hand-over pairs read where they are used
 #endif
-#ifndef FD_PIPE_PREFETCH_GPW
-#define FD_PIPE_PREFETCH_GPW 4  // the pipeline kernel prefetches in workgroups of fewer voice groups than this (A/B: 5 = always)
-#endif
-#ifndef FD_PIPE_PRIO
-#define FD_PIPE_PRIO 1          // 1 = the heaviest compute stage's waves run at s_setprio 1 (default); A/B: 0 none, 2 first stage, 3 by stage index
-#endif
-#ifndef FD_BAL_MARGIN
-#define FD_BAL_MARGIN 0         // FD_PIPE_PRIO == 4: the consumer yields while the producer's items + margin < its own
-#endif
-#ifndef FD_BAL_SIDE
-#define FD_BAL_SIDE 1           // ... which wave steers: 0 = the consumer (yields), 1 = the producer (overtakes)
-#endif
-#ifndef FD_PIPE_STAGE_LOOPS
-#define FD_PIPE_STAGE_LOOPS 2   // every role of the pipeline kernel runs its own round loop: 1 always, 0 never, 2 = kernels of three or more roles
-#endif
-#ifndef FD_TS_STAGE_LOOPS
-#define FD_TS_STAGE_LOOPS 1     // ... the same for the three-way time-split kernel (shards 3.26 / 2.16 / 2.02 -> 3.17 / 2.15 / 1.98 ms); A/B switch: 0
-#endif
-#ifndef FD_KNOCK_TS
-#define FD_KNOCK_TS 0   // measurement only: k_render_ts3 with 1 = the filter wave idle, 2 = only the filter wave, 3 = only stage 0, 4 = only stage 1
-#endif
-#ifndef FD_SPLIT_PAIR
-#define FD_SPLIT_PAIR 0   // A/B switch: which roles of a split-stage kernel share a SIMD (split_roles)
-#endif
-#ifndef FD_SPLIT_PRIO
-#define FD_SPLIT_PRIO 0   // A/B switch: 1 = in a split-stage kernel the last stage runs at s_setprio 2 and the second part of stage 0 at 1
-#endif
-#ifndef FD_STORE_WRAP
-#define FD_STORE_WRAP 0   // measurement only (NOT a renderer): 1 = voice-minor rows wrap into the first 64 frames of the output (L2-resident stores)
-#endif
-#ifndef FD_KNOCK
-#define FD_KNOCK 0      // measurement only (NOT a renderer): bit s set = compute stage s of the pipeline kernel idles, so the others
-#endif                  // run without it; the hand-over tiles start zeroed (profiles/r03_ab1_knockout_prio.txt, r03_knockout_c4.txt)
 // ---- multi-wave pipeline split of a Pipe chain ------------------------------------------------------------------
 // At one voice-wave per SIMD (65 536 voices on 1024 SIMDs) a lone wave issues one instruction per ~4.7 cycles while
 // the VALU could take one every ~2.5-3.3 (profiles/r01_ubench_valu.txt, r01_voice_sweep_*).  For graphs that are a
@@ -1232,24 +1184,24 @@ constexpr PipePlan pipe_plan(int want) {  // want: 0 = best plan, 1 / 2 / 3 = at
 // FS = floats per frame row of the feed tile (64, or 65 when the loader fills it by transposing planar rows); OL = where
 // the LAST stage puts its samples: 0 = HBM, voice-minor; 1 = an LDS tile [channel][frame][FS] that the storer wave of the
 // planar pipeline transposes out.
-// BAL (FD_PIPE_PRIO == 4, two-stage chains): the two waves of a voice group balance their SIMD between themselves.  `bal` points at
-// the group's two progress words in LDS (SIMD items of the current tile behind the producer / the consumer); BAL == 1: this
-// stage is the producer, 2: the consumer.  Both publish their count at every item; ONE of them (FD_BAL_SIDE) compares and sets
-// its own priority for the item -- see render_pipe_body.
 // OL = 2 / 3 (fused mix-down, MIX_SUM / MIX_PAN): the samples go to the wave's mix tile `mx` and leave as the group's partial mix,
 // MC frames at a time (mix_flush); `outw` is then the group's partial row [channel][T] and EVERY lane of the wave runs the stage.
-// NP > 1 (a FIRST stage run in NP waves, render_pipe_body NA): every wave walks the whole tile, wave `part` EVALUATES the SIMD
-// items of its NP-th of the tile and advances the state through the others (SG::skip2) -- as ts_stage does for 64-frame blocks;
-// the remainder samples of a ragged block are computed by every part (same values, same hand-over cells).
-template <class SG, class G, int MODE, int SUB, int W, bool FIRST, bool LAST, int FS = 64, int OL = 0, bool PF = (FD_PIPE_PREFETCH != 0), int BAL = 0, int MC = 0, int NP = 1, bool MROLL = false>
+// StageCfg: the compile-time shape of one pipe_stage call -- tile length, hand-over width, position in the chain, where the samples go.
+template <int SUB_, int W_, bool FIRST_, bool LAST_, int FS_ = 64, int OL_ = 0, bool PF_ = (FD_PIPE_PREFETCH != 0), int MC_ = 0, bool MROLL_ = false>
+struct StageCfg {
+    static constexpr int SUB = SUB_, W = W_, FS = FS_, OL = OL_, MC = MC_;
+    static constexpr bool FIRST = FIRST_, LAST = LAST_, PF = PF_, MROLL = MROLL_;
+};
+template <class SG, class G, int MODE, class CFG>
 FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_t V, int lane, float* outw,
-                     const float* fin, v2f (*hin)[SUB / 2][64], v2f (*hout)[SUB / 2][64], int* bal = nullptr, const MixLane* mx = nullptr, int part = 0) {
-    static_assert(NP == 1 || (FIRST && !LAST && FD_ITEM_LOOP && BAL == 0 && (SUB / 8) % NP == 0), "split stages: the first of several, whole items per part");
+                     const float* fin, v2f (*hin)[CFG::SUB / 2][64], v2f (*hout)[CFG::SUB / 2][64], const MixLane* mx = nullptr) {
+    constexpr int SUB = CFG::SUB, W = CFG::W, FS = CFG::FS, OL = CFG::OL, MC = CFG::MC;
+    constexpr bool FIRST = CFG::FIRST, LAST = CFG::LAST, PF = CFG::PF, MROLL = CFG::MROLL;
     constexpr int NI = SG::IN, NO = SG::OUT, NG = G::IN;
     constexpr bool GIN = !FIRST && SG::USES_GIN;
     constexpr bool MIXO = OL >= 2;
     constexpr int NM = OL >= 3 ? 2 : NO;  // mix channels
-    static_assert(!MIXO || (LAST && MC >= 8 && (MC & (MC - 1)) == 0 && FD_ITEM_LOOP), "mix-down: last stage, chunks of 8 .. 64 frames");
+    static_assert(!MIXO || (LAST && MC >= 8 && (MC & (MC - 1)) == 0), "mix-down: last stage, chunks of 8 .. 64 frames");
     static_assert(OL < 3 || NO == 1, "the pan mix-down takes a mono graph");
     static_assert(LAST || NO <= W, "hand-over tile too narrow");
     static_assert(FIRST || NI <= W, "hand-over tile too narrow");
@@ -1260,22 +1212,16 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
     // SALU arithmetic once per tile), the frame's row offset travels in the instruction's SCALAR offset and lane * 4 is
     // the only VGPR -- no per-frame 64-bit vector address arithmetic in a VALU-bound loop (it was one v_lshl_add_u64
     // per frame).  Rows of a tile span at most SUB * V * 4 bytes < 2^32 (V < 2^24 voices per bank).
-#if FD_PIPE_BUFFER_STORE
     __amdgpu_buffer_rsrc_t orow[OL == 0 ? NO : 1];
     if constexpr (OL == 0) {
 #pragma unroll
         for (int c = 0; c < NO; c++)
-            orow[c] = __builtin_amdgcn_make_buffer_rsrc(outw + ((size_t)c * T + (FD_STORE_WRAP ? ((t0 + lo) & 63) : (t0 + lo))) * V, 0, (int)0xffffffffu, 0x00020000);
+            orow[c] = __builtin_amdgcn_make_buffer_rsrc(outw + ((size_t)c * T + (t0 + lo)) * V, 0, (int)0xffffffffu, 0x00020000);
     }
     const int vrow = (int)(V * sizeof(float));
-#endif
     auto put = [&](int c, int i, float x) {  // i = frame index inside the block
         if constexpr (OL == 0) {
-#if FD_PIPE_BUFFER_STORE
             __builtin_amdgcn_raw_buffer_store_b32(f2u(x), orow[c], lane * 4, (i - lo) * vrow, FD_PIPE_STORE_AUX);
-#else
-            outw[((size_t)c * T + t0 + i) * V + lane] = x;
-#endif
         } else if constexpr (OL == 1) outw[(c * SUB + (i - lo)) * FS + lane] = x;
         else {
             float* cell = mx->tile + ((i - lo) & (MC - 1)) * MIX_ROW + mx->col;
@@ -1293,7 +1239,6 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
     if (lo < shi) {
         const G snap = g;  // tile-start registers, for the rollback below
         // (rolling this loop for heavy stages -- 1 pair per trip instead of 4 -- measured no faster on config 4: 52.9 vs 51.5 ms)
-#if FD_ITEM_LOOP
         // PF: the hand-over pairs of an item are read ONE ITEM AHEAD -- each pair's registers are re-armed right after the pair is
         // consumed, ~150-1000 cycles before the next item wants them.  Read where they are used (the compiler hoists them to
         // the item's top, no further) a consumer wave that has its SIMD to itself sits out the LDS round trip at the start of
@@ -1307,56 +1252,16 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
 #pragma unroll
                 for (int k = 0; k < 4; k++) ahead[c][k] = hin[c][k][lane];
         }
-        int peer = 0;
-        bool slow = false;
-        if constexpr (BAL != 0) peer = __hip_atomic_load(bal + (BAL == 1 ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         for (int i8 = lo; i8 < shi; i8 += 8) {  // one 8-sample SIMD item per trip (lo, shi are multiples of 8) ...
-        if constexpr (BAL != 0) {
-            const int k = (i8 - lo) >> 3;  // items of this tile behind this wave
-            __hip_atomic_store(bal + (BAL == 1 ? 0 : 1), k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if constexpr ((BAL == 1) == (FD_BAL_SIDE == 1)) {  // this wave is the one that steers
-                const int cur = __hip_atomic_load(bal + (BAL == 1 ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                // the partner's count: read one item ago (no wait) -- or, when that item ran in the partner's shadow and the
-                // count is several items old, read now (one exposed LDS round trip after an item of ~3000 cycles)
-                int seen;
-                if (slow) seen = __builtin_amdgcn_readfirstlane(cur); else seen = __builtin_amdgcn_readfirstlane(peer);
-                peer = cur;
-                if constexpr (BAL == 2) {  // the consumer steers: it yields while the producer is behind
-                    slow = seen + FD_BAL_MARGIN < k;
-                    if (slow) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
-                } else {                   // the producer steers: it overtakes the consumer's s_setprio 1 while it is behind
-                    slow = !(k < seen + FD_BAL_MARGIN);
-                    if (slow) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
-                }
-            }
-        }
         item_begin(g);
-        if constexpr (NP > 1) {
-            if ((i8 - lo) / (SUB / NP) != part) {  // another wave's item (wave-uniform): the state advance alone
-#pragma unroll
-                for (int i = i8; i < i8 + 8; i += 2) {
-                    v2f pi[NI > 0 ? NI : 1];
-#pragma unroll
-                    for (int c = 0; c < NI; c++) pi[c] = v2f{fin[(c * SUB + (i - lo)) * FS + lane], fin[(c * SUB + (i - lo + 1)) * FS + lane]};
-                    SG::template skip2<PH_SIMD>(g, pi);
-                }
-                continue;
-            }
-        }
         const int nx = i8 + 8 < shi ? i8 + 8 : i8;  // the tile's last item re-reads itself (never used)
 #pragma unroll
         for (int i = i8; i < i8 + 8; i += 2) {  // ... two frames per inner iteration
-#else
-        {
-#pragma unroll 4
-        for (int i = lo; i < shi; i += 2) {
-#endif
             v2f pi[NI > 0 ? NI : 1], gi[NG > 0 ? NG : 1], po[NO];
             if constexpr (FIRST) {
 #pragma unroll
                 for (int c = 0; c < NI; c++) pi[c] = v2f{fin[(c * SUB + (i - lo)) * FS + lane], fin[(c * SUB + (i - lo + 1)) * FS + lane]};
             } else {
-#if FD_ITEM_LOOP
                 if constexpr (PF) {  // consume the pair read during the previous item; re-arm its registers at once
 #pragma unroll
                     for (int c = 0; c < NI; c++) {
@@ -1364,7 +1269,6 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
                         ahead[c][(i - i8) >> 1] = hin[c][((nx - lo) >> 1) + ((i - i8) >> 1)][lane];
                     }
                 } else
-#endif
                 {
 #pragma unroll
                 for (int c = 0; c < NI; c++) pi[c] = hin[c][(i - lo) >> 1][lane];
@@ -1386,14 +1290,13 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
                 for (int c = 0; c < NO; c++) hout[c][(i - lo) >> 1][lane] = po[c];
             }
         }
-#if FD_ITEM_LOOP
         if constexpr (MIXO) { if (((i8 + 8 - lo) & (MC - 1)) == 0) flush_at(i8 + 8); }
-#endif
         }
         // (mix-down: the tile holds one chunk, so when ANY lane tripped every lane redoes the tile frame by frame -- step() and
         // step2() agree bit for bit where step2 is exact -- and the chunks already flushed are flushed again)
         bool trip = SG::tripped(g);
-        if constexpr (MIXO) trip = __builtin_amdgcn_ballot_w64(trip) != 0ull;
+        // (... lanes past the end of the bank do not vote: their default-constructed voices land in the padding column whatever they compute)
+        if constexpr (MIXO) trip = __builtin_amdgcn_ballot_w64(trip && mx->col < 64) != 0ull;
         if (__builtin_expect(trip, 0)) {  // a packed-path shortcut left its exact domain: redo the tile
             g = snap;
             for (int i = lo; i < shi; i++) {
@@ -1408,9 +1311,6 @@ FD_D void pipe_stage(G& g, int h, size_t t0, int size, int full, size_t T, size_
                 if constexpr (GIN) {
 #pragma unroll
                     for (int c = 0; c < NG; c++) gf[c] = fin[(c * SUB + (i - lo)) * FS + lane];
-                }
-                if constexpr (NP > 1) {
-                    if ((i - lo) / (SUB / NP) != part) { SG::template skip<PH_SIMD>(g, fi); continue; }
                 }
                 SG::template step<PH_SIMD>(g, fi, FIRST ? fi : gf, fo);
                 if constexpr (LAST) {
@@ -1477,20 +1377,15 @@ constexpr RoleOrder role_order() {
         int a = wt[pairs[p][0]] + wt[pairs[p][1]], b = wt[pairs[p][2]] + wt[pairs[p][3]], m = a > b ? a : b;
         if (m < best_w) { best_w = m; best = p; }
     }
-#ifdef FD_ROLE_PAIR   // A/B switch: force the pairing (0 = loader + stage 1 | stage 0 + stage 2, 1 = loader + stage 0 | stage 1 + stage 2, 2 = loader + stage 2 | stage 0 + stage 1)
-    best = FD_ROLE_PAIR;
-#endif
     o.role[0] = pairs[best][0]; o.role[2] = pairs[best][1]; o.role[1] = pairs[best][2]; o.role[3] = pairs[best][3];
     return o;
 }
 
 constexpr bool role_order_is(RoleOrder o, int a, int b, int c, int d) { return o.role[0] == a && o.role[1] == b && o.role[2] == c && o.role[3] == d; }
-#ifndef FD_ROLE_PAIR
 static_assert(role_order_is(role_order<true, 3, 100, 130, 83, 2>(), 0, 1, 2, 3), "config 4, exact: loader + moog | saw + tail");
 static_assert(role_order_is(role_order<true, 3, 100, 30, 83, 2>(), 0, 2, 1, 3), "config 4, tolerance mode: loader + saw | moog + tail");
 static_assert(role_order_is(role_order<false, 3, 30, 10, 20, 2>(), 1, 0, 2, 3), "three roles: the heaviest gets the SIMD of its own");
 static_assert(role_order_is(role_order<true, 3, 100, 30, 83, 4>(), 0, 1, 2, 3), "four groups per workgroup: every SIMD holds one group's roles");
-#endif
 
 // The pipeline kernel.  Waves of one workgroup, 4 voice groups (w & 3) times NW roles (w >> 2):
 //   role 0 (only if the graph has inputs): the LOADER wave.  It does nothing but stream the group's input channels
@@ -1502,50 +1397,7 @@ static_assert(role_order_is(role_order<true, 3, 100, 30, 83, 4>(), 0, 1, 2, 3), 
 // MIX != MIX_NONE (k_render_pipe_mix): `out` is the bank's partial-mix buffer [voice group][mix channel][T] and `panw` the pan
 // weights [2][stride] (MIX_PAN); every lane of a live voice group runs (the padded voices of the last group are constructed
 // voices with default parameters; their samples land in the tile's padding column).
-// NA > 1 (k_render_pipe_split): compute stage 0 runs in NA waves per voice group (pipe_stage NP): config 4's wavetable oscillator
-// -- a cheap phase recurrence under an expensive interpolation -- in two, so that the SIMD it shares with the envelope-and-pan stage
-// holds three half-busy waves instead of two busy ones (a wave issues at most one VALU instruction per ~4 cycles; the SIMD takes
-// one every 2-4), while the ladder keeps the other SIMD to itself.  Waves w, w + 4, w + 8 of a workgroup share a SIMD:
-// FD_ROLE_CROSS (two voice groups of loader + three stages, the middle stage the heaviest): SIMDs by ROLE instead of by group --
-//   SIMD 0: both groups' middle stages   SIMD 1: group 0's first stage + loader   SIMD 2: group 1's   SIMD 3: both groups' last stages
-// A one-sample-deep recurrence (config 4's ladder: 85 dependent plain instructions per sample) issues one instruction per ~4.4 cycles
-// whatever else happens; two of them fill the SIMD's 2-cycle slots between themselves, and the packed oscillator stage -- which
-// keeps a SIMD busy on its own -- no longer shares one with the envelope stage.
-#ifndef FD_ROLE_CROSS
-#define FD_ROLE_CROSS 0
-#endif
-struct CrossRoles { int grp[8], role[8]; };
-constexpr CrossRoles cross_roles() { return CrossRoles{{0, 0, 1, 0, 1, 0, 1, 1}, {2, 1, 1, 3, 2, 0, 0, 3}}; }
-struct SplitRoles { int grp[16], role[16]; };  // role: 0 = loader (graphs with inputs), then the NA parts of stage 0, then stages 1 ..
-template <bool FEED, int S, int NA, int GPW>
-constexpr SplitRoles split_roles() {
-    SplitRoles r{};
-    for (int w = 0; w < 16; w++) { r.grp[w] = w % GPW; r.role[w] = w / GPW; }
-    if (FEED && S == 3 && NA == 2 && GPW == 2) {
-#if FD_SPLIT_PAIR == 1   // A/B: SIMD 0 / 1: a group's ladder + second oscillator half + loader; SIMD 2 / 3: its first oscillator half + tail
-        const int g[10] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1}, ro[10] = {3, 3, 1, 1, 2, 2, 4, 4, 0, 0};
-#else
-        //   SIMD 0: group 0's oscillator halves + tail   SIMD 1: group 1's   SIMD 2: group 0's ladder + loader   SIMD 3: group 1's
-        const int g[10] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1}, ro[10] = {1, 1, 3, 3, 2, 2, 0, 0, 4, 4};
-#endif
-        for (int w = 0; w < 10; w++) { r.grp[w] = g[w]; r.role[w] = ro[w]; }
-    }
-    return r;
-}
-// which graphs / workgroup widths take the split (launch_render_pipe): measured on config 4's shape only.
-// MEASURED AND NOT KEPT (profiles/r04_ab_a_split.txt): bit-identical, but slower -- config 4, 32 768 voices: 9.42 ms unsplit, 10.34 split
-// with the two halves next to the tail on one SIMD, 10.17 with priorities for the tail and the second half, 9.70 with the halves on
-// different SIMDs; the oscillator stage ALONE takes 7.69 ms in one wave and 7.50 in two: whatever bounds it, it is not the issue rate
-// of its wave.  The build leaves the split kernels out (FD_STAGE_SPLIT=1 compiles them; "stage_split" then selects at run time).
-#ifndef FD_STAGE_SPLIT
-#define FD_STAGE_SPLIT 0
-#endif
-template <class G, int S, int K1, int K2, int GPW>
-struct SplitPlan {
-    static constexpr int NA = (FD_STAGE_SPLIT != 0 && S == 3 && G::IN > 0 && GPW == 2 && PipeTiles<G, S, K1, K2, GPW>::ok && PipeTiles<G, S, K1, K2, GPW>::S0::HAS_SKIP &&
-                               (PipeTiles<G, S, K1, K2, GPW>::SUB / 8) % 2 == 0 && PipeTiles<G, S, K1, K2, GPW>::S0::weight >= 60) ? 2 : 1;
-};
-template <class G, int MODE, int S, int K1, int K2, int GPW = 4, int MIX = MIX_NONE, int NA = 1>
+template <class G, int MODE, int S, int K1, int K2, int GPW = 4, int MIX = MIX_NONE>
 FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
                            float* __restrict__ out, size_t T, const void* aux, float* ring, uint32_t ring_cap, const float* __restrict__ panw = nullptr) {
     using TL = PipeTiles<G, S, K1, K2, GPW>;
@@ -1565,15 +1417,8 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     // four roles, slots 0 and 2 of one with three.  The roles are dealt to the slots so that the heaviest SIMD is as
     // light as possible (config 4, exact: loader + moog | saw + tail; tolerance mode: loader + saw | moog + tail).
     constexpr RoleOrder RO = role_order<FEED, S, S0::weight, S1::weight, S2::weight, GPW>();
-    constexpr SplitRoles SR = split_roles<FEED, S, NA, GPW>();
-    static_assert(NA == 1 || (S0::HAS_SKIP && S >= 2 && MODE == MODE_PROCESS && GPW * ((FEED ? 1 : 0) + NA + S - 1) <= 16), "split stage 0: needs skip2, a later stage, process mode");
-    // role: 0 = loader (graphs with inputs), then compute stage 0 (NA parts), then the later stages
-    constexpr CrossRoles CR = cross_roles();
-    constexpr bool CROSS = FD_ROLE_CROSS != 0 && FEED && S == 3 && NA == 1 && GPW == 2 && S1::weight >= S0::weight;
-    const int grp = CROSS ? CR.grp[w] : (NA == 1 ? w % GPW : SR.grp[w]);
-    const int crole = CROSS ? CR.role[w] : (NA == 1 ? RO.role[w / GPW] : SR.role[w]);  // canonical role index
-    const int part = (NA > 1 && crole >= (FEED ? 1 : 0) && crole < (FEED ? 1 : 0) + NA) ? crole - (FEED ? 1 : 0) : 0;
-    const int role = NA == 1 ? crole : (crole < (FEED ? 1 : 0) + NA ? (crole < (FEED ? 1 : 0) ? 0 : (FEED ? 1 : 0)) : crole - (NA - 1));  // ... with the parts folded
+    const int grp = w % GPW;
+    const int role = RO.role[w / GPW];  // 0 = loader (graphs with inputs), then the compute stages
     // (Half-filled waves -- 32 voices per wave, twice the waves -- were measured for the heavy config-4 voice: 33.7 ms
     // against 31.0 ms.  Its SIMDs are issue-bound on expensive instructions, not latency-bound; profiles/r02_c4_vpw.txt.)
     const size_t v0 = ((size_t)blockIdx.x * GPW + grp) * 64;
@@ -1588,7 +1433,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     using MG = MixGeom<NTC, GPW, SUB>;
     // more than two waves per SIMD (workgroups of more than 8 waves) leave a wave 128 registers or fewer: the pan weights then live in LDS
     // and the flush's passes stay a loop (as in the 14-wave time-split kernel)
-    constexpr bool TIGHT = GPW * ((FEED ? 1 : 0) + NA + S - 1) > 8;
+    constexpr bool TIGHT = GPW * ((FEED ? 1 : 0) + S) > 8;
     constexpr bool WLDS = MIX == MIX_PAN && TIGHT;
     constexpr int OLM = MIX == MIX_NONE ? 0 : (MIX == MIX_PAN ? (WLDS ? 4 : 3) : 2), MCM = MIX == MIX_NONE ? 0 : MG::MC;
     static_assert(MIX == MIX_NONE || MG::ok, "mix tile does not fit");
@@ -1598,10 +1443,6 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     MixLane mxl{&mixt[MIX == MIX_NONE ? 0 : grp][0], active ? lane : 64, {}, nullptr};
     const bool run = live && (MIX != MIX_NONE || active);  // (wave-uniform in a mix-down launch)
 
-#if FD_KNOCK
-    for (size_t i = threadIdx.x; i < sizeof(hand) / sizeof(float); i += blockDim.x) reinterpret_cast<float*>(hand)[i] = 0.0f;
-    __syncthreads();
-#endif
     if (FEED && role == 0) {  // ---- loader wave ----
         float rg[FEED ? NI : 1][SUB];
         auto issue = [&](size_t j) {  // frames past the end re-read the last frame (never used): no branches
@@ -1612,11 +1453,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                 for (int k = 0; k < SUB; k++) {
                     const size_t t = tj + k < T ? tj + k : T - 1;
                     if (MIX != MIX_NONE && !active) rg[c][k] = 0.0f;  // a padded voice of a mix-down launch hears silence
-#if FD_FEED_NT   // A/B: the feed as non-temporal loads -- every line is read once, it need not displace table lines in L1
                     else rg[c][k] = __builtin_nontemporal_load(&inw[((size_t)c * T + t) * V + lane]);
-#else
-                    else rg[c][k] = inw[((size_t)c * T + t) * V + lane];
-#endif
                 }
         };
         const bool on = run;
@@ -1664,12 +1501,11 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
     // The rounds, for the graph type GG: G itself, or its lowpass-specialised twin LpOf<G> (same registers, the
     // packed SVF path 5 operations shorter) when every lane of THIS wave qualifies.  A wave that does not hold the SVF
     // segment sees zeroed coefficients, takes the generic type and runs the same arithmetic for its own segment.
-    constexpr bool PFK = FD_PIPE_PREFETCH != 0 && GPW < FD_PIPE_PREFETCH_GPW;  // see pipe_stage: prefetch pays when the consumer wave is (nearly) alone on its SIMD
-    // the two waves of a voice group share a SIMD exactly when the workgroup holds four groups of a two-stage chain without a
-    // loader (waves w and w + 4): that is where they balance the SIMD between themselves (see pipe_stage, BAL)
-    constexpr bool BALK = FD_PIPE_PRIO == 4 && S == 2 && !FEED && GPW == 4 && MODE == MODE_PROCESS;
-    __shared__ int bal_word[BALK ? GPW : 1][2];  // [group][producer's, consumer's item count]
-    if (BALK && threadIdx.x < GPW) bal_word[threadIdx.x][0] = bal_word[threadIdx.x][1] = 0;
+    constexpr bool PFK = FD_PIPE_PREFETCH != 0 && GPW < 4;  // see pipe_stage: prefetch pays when the consumer wave is (nearly) alone on its SIMD
+    // the stages' shapes: the LAST one owns the output (HBM rows, or the mix tile of a fused mix-down)
+    using C0 = StageCfg<SUB, W, true, S == 1, 64, S == 1 ? OLM : 0, (FD_PIPE_PREFETCH != 0), S == 1 ? MCM : 0, S == 1 && TIGHT>;
+    using C1 = StageCfg<SUB, W, false, S == 2, 64, S == 2 ? OLM : 0, PFK, S == 2 ? MCM : 0, S == 2 && TIGHT>;
+    using C2 = StageCfg<SUB, W, false, true, 64, OLM, PFK, MCM, TIGHT>;
     auto rounds_of = [&](auto* tag) {
         using GG = typename Pointee<decltype(tag)>::type;
         using TG = PipeTiles<GG, S, K1, K2>;
@@ -1677,7 +1513,18 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
         using T1 = typename TG::S1;
         using T2 = typename TG::S2;
         GG& gg = reinterpret_cast<GG&>(g);
-        if constexpr (FD_PIPE_STAGE_LOOPS == 1 || (FD_PIPE_STAGE_LOOPS == 2 && S + (FEED ? 1 : 0) >= 3)) {
+        auto tile0 = [&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
+            if constexpr (S == 1) pipe_stage<T0, GG, MODE, C0>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr, &mxl);
+            else pipe_stage<T0, GG, MODE, C0>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
+        };
+        auto tile1 = [&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
+            if constexpr (S == 2) pipe_stage<T1, GG, MODE, C1>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, &mxl);
+            else if constexpr (S == 3) pipe_stage<T1, GG, MODE, C1>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
+        };
+        auto tile2 = [&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
+            if constexpr (S == 3) pipe_stage<T2, GG, MODE, C2>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr, &mxl);
+        };
+        if constexpr (S + (FEED ? 1 : 0) >= 3) {
             // One round loop PER ROLE for kernels of three or more roles (the stage is wave-uniform and fixed for the launch): with the
             // stage dispatch inside a common loop the register allocator sees the live ranges of all roles at once -- the config-4 kernel
             // spilled ~40 SGPRs to VGPR lanes in every round's preamble -- and every round pays the dispatch branches: config 4
@@ -1685,7 +1532,7 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
             // profiles/r03_ab17_stage_loops.txt).  Every wave executes `rounds` barriers either way.
             auto loop = [&](auto&& tile) {
                 for (size_t it = 0; it < rounds; it++) {
-                    if (run && it >= first && it - first < ntiles && ((FD_KNOCK >> stage) & 1) == 0) {
+                    if (run && it >= first && it - first < ntiles) {
                         const size_t j = it - first;          // the tile this stage works on in this round
                         const size_t t0 = (j / SPB) * 64;
                         const int h = (int)(j % SPB);
@@ -1698,32 +1545,10 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                     __syncthreads();  // hand-over point: every role has finished its tile of this round
                 }
             };
-            if (stage == 0) {
-                loop([&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
-                    if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true, 64, OLM, (FD_PIPE_PREFETCH != 0), 0, MCM, 1, TIGHT>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr, nullptr, &mxl);
-#if FD_PIPE_PRODUCER_PLAIN
-                    else {  // the producer stage's sines as plain (2-cycle) ops: see SinePlain
-                        using GP = typename PlainOf<GG>::type;
-                        using TP0 = typename PipeTiles<GP, S, K1, K2>::S0;
-                        pipe_stage<TP0, GP, MODE, SUB, W, true, false>(reinterpret_cast<GP&>(gg), h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
-                    }
-#else
-                    else pipe_stage<T0, GG, MODE, SUB, W, true, false, 64, 0, (FD_PIPE_PREFETCH != 0), BALK ? 1 : 0, 0, NA>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1], bal_word[grp], nullptr, part);
-#endif
-                });
-            } else if (stage == 1) {
-                loop([&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
-                    if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, OLM, PFK, BALK ? 2 : 0, MCM, 1, TIGHT>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp], &mxl);
-                    else if constexpr (S == 3) pipe_stage<T1, GG, MODE, SUB, W, false, false, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
-                });
-            } else {
-                loop([&](size_t j, size_t t0, int h, int size, int full, const float* fin) {
-                    if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, OLM, PFK, 0, MCM, 1, TIGHT>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr, nullptr, &mxl);
-                });
-            }
+            if (stage == 0) loop(tile0); else if (stage == 1) loop(tile1); else loop(tile2);
         } else {
             for (size_t it = 0; it < rounds; it++) {
-                if (run && it >= first && it - first < ntiles && ((FD_KNOCK >> stage) & 1) == 0) {
+                if (run && it >= first && it - first < ntiles) {
                     const size_t j = it - first;          // the tile this stage works on in this round
                     const size_t t0 = (j / SPB) * 64;
                     const int h = (int)(j % SPB);
@@ -1731,82 +1556,18 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
                     const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
                     const float* fin = nullptr;
                     if constexpr (FEED) fin = &feed[grp][j % D][0][0][0];
-                    if (stage == 0) {
-                        if constexpr (S == 1) pipe_stage<T0, GG, MODE, SUB, W, true, true, 64, OLM, (FD_PIPE_PREFETCH != 0), 0, MCM, 1, TIGHT>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, nullptr, nullptr, &mxl);
-#if FD_PIPE_PRODUCER_PLAIN
-                        else {  // the producer stage's sines as plain (2-cycle) ops: see SinePlain
-                            using GP = typename PlainOf<GG>::type;
-                            using TP0 = typename PipeTiles<GP, S, K1, K2>::S0;
-                            pipe_stage<TP0, GP, MODE, SUB, W, true, false>(reinterpret_cast<GP&>(gg), h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1]);
-                        }
-#else
-                        else pipe_stage<T0, GG, MODE, SUB, W, true, false, 64, 0, (FD_PIPE_PREFETCH != 0), BALK ? 1 : 0, 0, NA>(gg, h, t0, size, full, T, V, lane, outw, fin, nullptr, hand[0][grp][j & 1], bal_word[grp], nullptr, part);
-#endif
-                    } else if (stage == 1) {
-                        if constexpr (S == 2) pipe_stage<T1, GG, MODE, SUB, W, false, true, 64, OLM, PFK, BALK ? 2 : 0, MCM, 1, TIGHT>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], nullptr, bal_word[grp], &mxl);
-                        else if constexpr (S == 3) pipe_stage<T1, GG, MODE, SUB, W, false, false, 64, 0, PFK>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[0][grp][j & 1], hand[S - 2][grp][j & 1]);
-                    } else {
-                        if constexpr (S == 3) pipe_stage<T2, GG, MODE, SUB, W, false, true, 64, OLM, PFK, 0, MCM, 1, TIGHT>(gg, h, t0, size, full, T, V, lane, outw, fin, hand[S - 2][grp][j & 1], nullptr, nullptr, &mxl);
-                    }
+                    if (stage == 0) tile0(j, t0, h, size, full, fin);
+                    else if (stage == 1) tile1(j, t0, h, size, full, fin);
+                    else tile2(j, t0, h, size, full, fin);
                 }
                 __syncthreads();  // hand-over point: every role has finished its tile of this round
             }
         }
     };
-#if FD_PIPE_FLAGSYNC
-    static_assert(MIX == MIX_NONE, "the flag-synchronised A/B variant has no mix-down");
-    // A/B (tools/build_variants.sh -DFD_PIPE_FLAGSYNC=1): two-stage chains without inputs hand tiles over through per-group
-    // LDS counters instead of a workgroup barrier per round, so that the four voice groups of a workgroup do not wait for
-    // each other and a stage may run up to one tile ahead of its partner.
-    if constexpr (S == 2 && !FEED) {
-        __shared__ int flag_prod[GPW], flag_cons[GPW];
-        if (threadIdx.x < GPW) { flag_prod[threadIdx.x] = 0; flag_cons[threadIdx.x] = 0; }
-        __syncthreads();
-        auto rounds_flags = [&](auto* tag) {
-            using GG = typename Pointee<decltype(tag)>::type;
-            using TG = PipeTiles<GG, S, K1, K2>;
-            using T0 = typename TG::S0;
-            using T1 = typename TG::S1;
-            GG& gg = reinterpret_cast<GG&>(g);
-            for (size_t j = 0; j < ntiles; j++) {
-                const size_t t0 = (j / SPB) * 64;
-                const int h = (int)(j % SPB);
-                const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
-                const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
-                if (stage == 0) {
-                    if (j >= 2)
-                        while (__hip_atomic_load(&flag_cons[grp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(j - 1)) __builtin_amdgcn_s_sleep(1);
-                    if (live && active) pipe_stage<T0, GG, MODE, SUB, W, true, false>(gg, h, t0, size, full, T, V, lane, outw, nullptr, nullptr, hand[0][grp][j & 1]);
-                    __hip_atomic_store(&flag_prod[grp], (int)(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
-                    while (__hip_atomic_load(&flag_prod[grp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (int)(j + 1)) __builtin_amdgcn_s_sleep(1);
-                    if (live && active) pipe_stage<T1, GG, MODE, SUB, W, false, true>(gg, h, t0, size, full, T, V, lane, outw, nullptr, hand[0][grp][j & 1], nullptr);
-                    __hip_atomic_store(&flag_cons[grp], (int)(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        };
-        using GLf = typename LpOf<G>::type;
-        bool lpf = false;
-        if constexpr (!SameType<GLf, G>::v && MODE == MODE_PROCESS && FD_LP_ENABLE)
-            lpf = __builtin_amdgcn_ballot_w64((live && active) && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(live && active) != 0ull;
-        if (lpf) rounds_flags((GLf*)nullptr); else rounds_flags((G*)nullptr);
-        if (live && active) {
-            VStore<false> st{slots + v, stride, 0};
-            VGate::W<VStore<false>> gate{&st, true};
-            if (stage == 0) S0::visit(g, gate); else S1::visit(g, gate);
-        }
-        return;
-    }
-#endif
     using GL = typename LpOf<G>::type;
     bool lp = false;
     if constexpr (!SameType<GL, G>::v && MODE == MODE_PROCESS && FD_LP_ENABLE)
         lp = __builtin_amdgcn_ballot_w64(run && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(run) != 0ull;
-#if FD_SPLIT_PRIO
-    if (NA > 1 && stage == S - 1) __builtin_amdgcn_s_setprio(2);
-    if (NA > 1 && stage == 0 && part == 1) __builtin_amdgcn_s_setprio(1);
-#endif
-#if FD_PIPE_PRIO == 1 || FD_PIPE_PRIO == 4
     // The HEAVIEST stage's wave is the critical path of a voice group: its instruction stream is one dependent chain, so every
     // cycle it waits for the VALU behind a sibling's instruction is a cycle added to the round.  VALU arbitration on a SIMD
     // is oldest-first (profiles/r03_ubench_issue_v2.txt: the older of two waves runs unimpeded, the younger gets the
@@ -1817,27 +1578,12 @@ FD_D void render_pipe_body(float* __restrict__ slots, size_t stride, size_t V, c
         constexpr int heavy = (w0 >= w1 && w0 >= w2) ? 0 : (w1 >= w2 ? 1 : 2);
         if (S > 1 && stage == heavy) __builtin_amdgcn_s_setprio(1);
     }
-#elif FD_PIPE_PRIO == 2
-    if (stage == 0) __builtin_amdgcn_s_setprio(1);
-#elif FD_PIPE_PRIO == 3   // later stages first: the consumer of a hand-over never waits for issue slots behind its producer
-    if (stage == 1) __builtin_amdgcn_s_setprio(1);
-    if (stage == 2) __builtin_amdgcn_s_setprio(2);
-#endif
     if (lp) rounds_of((GL*)nullptr); else rounds_of((G*)nullptr);
-    if (live && active && part == 0) {  // (the parts of a split stage end with identical state: one of them stores it)
+    if (live && active) {
         VStore<false> st{slots + v, stride, 0};
         VGate::W<VStore<false>> gate{&st, true};
         if (stage == 0) S0::visit(g, gate); else if (stage == 1) S1::visit(g, gate); else S2::visit(g, gate);
     }
-}
-
-// the pipeline kernel with compute stage 0 in NA waves per voice group (SplitPlan), voice-out or with the fused mix-down
-template <class G, int MODE, int S, int K1, int K2, int GPW, int MIX, int NA>
-__global__ __launch_bounds__((64 * GPW * ((G::IN > 0 ? 1 : 0) + NA + S - 1))) FD_PIPE_ATTR void k_render_pipe_split(float* __restrict__ slots, size_t stride, size_t V,
-                                                                                          const float* __restrict__ in, float* __restrict__ out,
-                                                                                          size_t T, const void* aux, float* ring, uint32_t ring_cap,
-                                                                                          const float* __restrict__ panw) {
-    render_pipe_body<G, MODE, S, K1, K2, GPW, MIX, NA>(slots, stride, V, in, out, T, aux, ring, ring_cap, panw);
 }
 
 // the pipeline kernel with the fused mix-down: part = [voice groups][mix channels][T] partial mixes, panw = [2][stride] (MIX_PAN)
@@ -2025,7 +1771,7 @@ FD_D void render_ts_body(float* __restrict__ slots, size_t stride, size_t V, flo
                 const size_t j = it - stage;  // the block this stage works on in this round
                 if (stage == 0) ts_stage<T0, GG, true, W>(gg, 64 / nparts * part, 64 / nparts * (part + 1), lane, nullptr, hand[0][j & 1]);
                 else if (stage == 1) ts_stage<T1, GG, false, W>(gg, 64 / nparts * part, 64 / nparts * (part + 1), lane, hand[0][j & 1], hand[1][j & 1]);
-                else pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, 0, FD_PIPE_PREFETCH != 0>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[1][j & 1], nullptr);
+                else pipe_stage<T2, GG, MODE_PROCESS, StageCfg<64, W, false, true>>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[1][j & 1], nullptr);
             }
             __syncthreads();
         }
@@ -2034,9 +1780,7 @@ FD_D void render_ts_body(float* __restrict__ slots, size_t stride, size_t V, flo
     bool lp = false;
     if constexpr (!SameType<GL, G>::v && FD_LP_ENABLE)
         lp = __builtin_amdgcn_ballot_w64(active && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(active) != 0ull;
-#if FD_PIPE_PRIO
     if (stage == 2) __builtin_amdgcn_s_setprio(1);  // the serial filter wave is the round's critical path (see render_pipe_body)
-#endif
     if (lp) rounds_of((GL*)nullptr); else rounds_of((G*)nullptr);
     if (active && part == 0) {  // the waves of a split stage end with identical state: one of them stores it
         VStore<false> st{slots + v, stride, 0};
@@ -2065,13 +1809,6 @@ __global__ __launch_bounds__(64 * (NA + NB + 1)) void k_render_ts(float* __restr
 // The thirds of a stage each advance the state through the whole block (skip2) and evaluate their own frames; per frame
 // the arithmetic is that of every other kernel -- bit-exact (tests/test_gpu_time_split.py).
 template <int GPW> struct Ts3Roles;
-#ifndef FD_TS3_BCUT
-#define FD_TS3_BCUT 0   // A/B: where the parts of the two oscillator stages are cut (Ts3Roles<1>::cut)
-#endif
-#ifndef FD_TS3_B4
-#define FD_TS3_B4 1   // one group per CU: the SECOND oscillator stage in four quarters, the fourth next to the filter wave; A/B switch: 0 = thirds, 7 waves
-#endif
-#if FD_TS3_B4
 // Seven waves left the four SIMDs of a CU loaded 48 | 48 | 32 oscillator frames per block | the filter alone, and the two 48s set the round time
 // (profiles/r03_strong_scaling_shards.txt: the filter wave alone 1.21 ms, the kernel 1.98).  With the second oscillator stage in QUARTERS
 // the eighth wave sits next to the filter:  w: 0  1  2  3  4  5  6  7   ->   40 | 40 | 32 | filter + 16.
@@ -2081,23 +1818,8 @@ template <> struct Ts3Roles<1> {  // wave -> (group, stage, part); parts per sta
     static constexpr int grp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     static constexpr int stg[8] = {0, 0, 0, 2, 1, 1, 1, 1};
     static constexpr int prt[8] = {0, 1, 2, 0, 0, 1, 2, 3};
-#if FD_TS3_BCUT == 1
-    static constexpr int cut[2][5] = {{0, 24, 48, 64, 64}, {0, 16, 32, 56, 64}};   // the quarter next to the filter wave is the short one
-#elif FD_TS3_BCUT == 2
-    static constexpr int cut[2][5] = {{0, 24, 40, 64, 64}, {0, 16, 40, 56, 64}};
-#else
     static constexpr int cut[2][5] = {{0, 24, 48, 64, 64}, {0, 16, 32, 48, 64}};   // frames of a block per part: [cut[stage][part], cut[stage][part + 1])
-#endif
 };
-#else
-template <> struct Ts3Roles<1> {  // wave -> (group, stage, part); parts per stage
-    static constexpr int WAVES = 7;
-    static constexpr int grp[7] = {0, 0, 0, 0, 0, 0, 0};
-    static constexpr int stg[7] = {0, 0, 0, 2, 1, 1, 1};
-    static constexpr int prt[7] = {0, 1, 2, 0, 0, 1, 2};
-    static constexpr int cut[2][5] = {{0, 24, 48, 64, 64}, {0, 24, 48, 64, 64}};
-};
-#endif
 template <> struct Ts3Roles<2> {
     // SIMD = w % 4:   SIMD 0: w 0 4 8 12   SIMD 1: w 1 5 9 13   SIMD 2: w 2 6 10   SIMD 3: w 3 7 11
     static constexpr int WAVES = 14;
@@ -2117,10 +1839,6 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
     constexpr int W = S0::OUT > S1::OUT ? S0::OUT : S1::OUT;
     static_assert(W * 2 * 2 * 16 * GPW <= 128, "hand-over tiles must fit 128 KiB");
     __shared__ v2f hand[GPW][2][2][W][32][64];  // [group][cut][buffer][channel][frame pair][lane]
-#if FD_KNOCK_TS
-    for (size_t i = threadIdx.x; i < sizeof(hand) / sizeof(float); i += blockDim.x) reinterpret_cast<float*>(hand)[i] = 0.0f;
-    __syncthreads();
-#endif
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = R::grp[w], stage = R::stg[w], part = R::prt[w];
     const size_t v0 = ((size_t)blockIdx.x * GPW + grp) * 64, v = v0 + lane;
@@ -2169,38 +1887,22 @@ FD_D void render_ts3_body(float* __restrict__ slots, size_t stride, size_t V, fl
         using T1 = Seg<GG, 1, 2>;
         using T2 = Seg<GG, 2, 3>;
         GG& gg = reinterpret_cast<GG&>(g);
-#if FD_TS_STAGE_LOOPS   // a round loop per role (see render_pipe_body)
         auto loop = [&](auto&& block) {
             for (size_t it = 0; it < rounds; it++) {
-                if (run && it >= (size_t)stage && it - stage < nblocks && !(FD_KNOCK_TS == 1 && stage == 2) && !(FD_KNOCK_TS == 2 && stage < 2) &&
-                    !(FD_KNOCK_TS == 3 && stage != 0) && !(FD_KNOCK_TS == 4 && stage != 1))
+                if (run && it >= (size_t)stage && it - stage < nblocks)
                     block(it - stage);  // the block this stage works on in this round
                 __syncthreads();
             }
         };
         if (stage == 0) loop([&](size_t j) { ts_stage<T0, GG, true, W>(gg, R::cut[0][part], R::cut[0][part + 1], lane, nullptr, hand[grp][0][j & 1]); });
         else if (stage == 1) loop([&](size_t j) { ts_stage<T1, GG, false, W>(gg, R::cut[1][part], R::cut[1][part + 1], lane, hand[grp][0][j & 1], hand[grp][1][j & 1]); });
-        else loop([&](size_t j) { pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, OLM, FD_PIPE_PREFETCH != 0, 0, MCM, 1, (GPW == 2)>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr, nullptr, &mxl); });
-#else
-        for (size_t it = 0; it < rounds; it++) {
-            if (run && it >= (size_t)stage && it - stage < nblocks && !(FD_KNOCK_TS == 1 && stage == 2) && !(FD_KNOCK_TS == 2 && stage < 2) &&
-                !(FD_KNOCK_TS == 3 && stage != 0) && !(FD_KNOCK_TS == 4 && stage != 1)) {
-                const size_t j = it - stage;  // the block this stage works on in this round
-                if (stage == 0) ts_stage<T0, GG, true, W>(gg, R::cut[0][part], R::cut[0][part + 1], lane, nullptr, hand[grp][0][j & 1]);
-                else if (stage == 1) ts_stage<T1, GG, false, W>(gg, R::cut[1][part], R::cut[1][part + 1], lane, hand[grp][0][j & 1], hand[grp][1][j & 1]);
-                else pipe_stage<T2, GG, MODE_PROCESS, 64, W, false, true, 64, OLM, FD_PIPE_PREFETCH != 0, 0, MCM, 1, (GPW == 2)>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr, nullptr, &mxl);
-            }
-            __syncthreads();
-        }
-#endif
+        else loop([&](size_t j) { pipe_stage<T2, GG, MODE_PROCESS, StageCfg<64, W, false, true, 64, OLM, FD_PIPE_PREFETCH != 0, MCM, (GPW == 2)>>(gg, 0, j * 64, 64, 64, T, V, lane, outw, nullptr, hand[grp][1][j & 1], nullptr, &mxl); });
     };
     using GL = typename LpOf<G>::type;
     bool lp = false;
     if constexpr (!SameType<GL, G>::v && FD_LP_ENABLE)
         lp = __builtin_amdgcn_ballot_w64(run && !lp_ok(g)) == 0ull && __builtin_amdgcn_ballot_w64(run) != 0ull;
-#if FD_PIPE_PRIO
     if (stage == 2) __builtin_amdgcn_s_setprio(1);  // the serial filter wave is the round's critical path
-#endif
     if (lp) rounds_of((GL*)nullptr); else rounds_of((G*)nullptr);
     if (live && active && part == 0) {  // the waves of a split stage end with identical state: one of them stores it
         VStore<false> st{slots + v, stride, 0};
@@ -2376,10 +2078,10 @@ FD_D void render_pipe_planar_body(float* __restrict__ slots, size_t stride, size
             if constexpr (FEED) fin = &feed[grp][j % D][0][0][0];
             float* ot = &otile[grp][j & 1][0][0][0];
             if (stage == 0) {
-                if constexpr (S == 1) pipe_stage<S0, G, MODE, SUB, W, true, true, PFS, 1>(g, h, t0, size, full, T, V, lane, ot, fin, nullptr, nullptr);
-                else pipe_stage<S0, G, MODE, SUB, W, true, false, PFS, 1>(g, h, t0, size, full, T, V, lane, ot, fin, nullptr, hand[grp][j & 1]);
+                if constexpr (S == 1) pipe_stage<S0, G, MODE, StageCfg<SUB, W, true, true, PFS, 1>>(g, h, t0, size, full, T, V, lane, ot, fin, nullptr, nullptr);
+                else pipe_stage<S0, G, MODE, StageCfg<SUB, W, true, false, PFS, 1>>(g, h, t0, size, full, T, V, lane, ot, fin, nullptr, hand[grp][j & 1]);
             } else {
-                if constexpr (S == 2) pipe_stage<S1, G, MODE, SUB, W, false, true, PFS, 1>(g, h, t0, size, full, T, V, lane, ot, fin, hand[grp][j & 1], nullptr);
+                if constexpr (S == 2) pipe_stage<S1, G, MODE, StageCfg<SUB, W, false, true, PFS, 1>>(g, h, t0, size, full, T, V, lane, ot, fin, hand[grp][j & 1], nullptr);
             }
         }
         __syncthreads();
@@ -2496,8 +2198,15 @@ template <class G, int MODE, int MIX>
 FD_D void jit_pipe_mix_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
                             float* __restrict__ part, size_t T, const void* aux, float* ring, uint32_t ring_cap, const float* __restrict__ panw) {
     constexpr PipePlan P = pipe_plan<G>(0);
-    if constexpr (P.S >= 1 && (MIX == MIX_SUM || G::OUT == 1)) render_pipe_body<G, MODE, P.S, P.K1, P.K2, 4, MIX>(slots, stride, V, in, part, T, aux, ring, ring_cap, panw);
+    if constexpr (P.S >= 1 && (MIX == MIX_SUM || G::OUT == 1)) {
+        // (graphs of four or more outputs: a mix tile of 8 frames does not fit beside the pipeline's tiles -- the host refuses such a
+        // launch up front, fd_jit.hip jit_mix_channels_ok, and this body stays empty so that the module still builds)
+        if constexpr (MixGeom<(MIX == MIX_PAN ? 1 : G::OUT), 4, PipeTiles<G, P.S, P.K1, P.K2, 4>::SUB>::ok)
+            render_pipe_body<G, MODE, P.S, P.K1, P.K2, 4, MIX>(slots, stride, V, in, part, T, aux, ring, ring_cap, panw);
+    }
 }
+constexpr bool jit_mix_channels_ok(int channels) { return (31 * 1024) / 4 / (channels * MIX_ROW * 4) >= 8; }  // MixGeom<channels, 4, .>::ok, for the host
+static_assert(jit_mix_channels_ok(3) && !jit_mix_channels_ok(4) && MixGeom<3, 4, 64>::ok && !MixGeom<4, 4, 64>::ok, "fused mix-down: at most three output channels at four voice groups per workgroup");
 template <class G, int MODE>
 FD_D void jit_events_mix_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ part, size_t T,
                               const double* __restrict__ ev, const int* __restrict__ fade, double time0, double sr, const void* aux, float* ring,

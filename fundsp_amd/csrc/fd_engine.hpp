@@ -67,6 +67,10 @@ struct KindOps {
     std::function<bool(float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, int mix, int mode,
                        const void* aux, float* ring, uint32_t ring_cap, const float* panw, hipStream_t s)>
         render_mix, render_mix_fast;
+    // Whatever the fused mix-down of this kind still has to do before its first launch (run-time compiled graphs: compile and load the
+    // mix kernels) -- called by fdsp_bank_mix_reserve / fdsp_bank_set_pan, the calls a host makes BEFORE its real-time loop or stream
+    // capture; `fast`: the tolerance-mode variant.  Empty for ahead-of-time kinds.
+    std::function<void(bool fast)> prepare_mix;
     // ... and the Sequencer's mixed output in one launch (render_events_body MIXE): part as above, [groups][outputs][T]; graphs of
     // at most two outputs (the block tiles of four waves must fit the CU's LDS)
     std::function<bool(float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, const double* ev,
@@ -111,20 +115,6 @@ bool launch_render_pipe(float* slots, size_t stride, size_t V, const float* in, 
         // light graphs keep 4 groups per workgroup; heavy ones (latency-bound waves) are spread so that every CU gets one
         const size_t groups = (V + 63) / 64;
         bool done = false;
-#if defined(FD_PIPE_GPW) || defined(FD_PIPE_GPW_HEAVY)  // A/B switches (tools/build_variants.sh): force the voice groups per
-#ifndef FD_PIPE_GPW                                      // workgroup of the light / the heavy graphs (profiles/r02_ab_gpw_*.txt)
-#define FD_PIPE_GPW 0
-#endif
-#ifndef FD_PIPE_GPW_HEAVY
-#define FD_PIPE_GPW_HEAVY 0
-#endif
-        constexpr int FORCE = Cost<G>::v < 150 ? FD_PIPE_GPW : FD_PIPE_GPW_HEAVY;
-        if constexpr (FORCE > 0) {
-            hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, FORCE>), dim3((unsigned)((groups + FORCE - 1) / FORCE)),
-                               dim3(16 * FORCE * WAVES), 0, s, slots, stride, V, in, out, T, aux, ring, ring_cap);
-            done = true;
-        }
-#endif
         // (a workgroup of 1 or 2 groups spends the LDS of 4 on longer tiles -- PipeTiles -- so it must be alone on its CU)
         if constexpr (Cost<G>::v >= 150) {
             if (!done && groups <= cus) {
@@ -132,18 +122,8 @@ bool launch_render_pipe(float* slots, size_t stride, size_t V, const float* in, 
                                    stride, V, in, out, T, aux, ring, ring_cap);
                 done = true;
             } else if (!done && groups <= 2 * cus) {
-                constexpr int NA = SplitPlan<G, P.S, P.K1, P.K2, 2>::NA;  // compute stage 0 in NA waves (config 4: the oscillator in two)
-                bool split = false;
-                if constexpr (NA > 1 && MODE == MODE_PROCESS) {
-                    if (tl_opts.stage_split) {
-                        hipLaunchKernelGGL((k_render_pipe_split<G, MODE, P.S, P.K1, P.K2, 2, MIX_NONE, NA>), dim3((unsigned)((groups + 1) / 2)),
-                                           dim3(64 * 2 * (WAVES / 4 + NA - 1)), 0, s, slots, stride, V, in, out, T, aux, ring, ring_cap, (const float*)nullptr);
-                        split = true;
-                    }
-                }
-                if (!split)
-                    hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 2>), dim3((unsigned)((groups + 1) / 2)), dim3(16 * 2 * WAVES), 0,
-                                       s, slots, stride, V, in, out, T, aux, ring, ring_cap);
+                hipLaunchKernelGGL((k_render_pipe<G, MODE, P.S, P.K1, P.K2, 2>), dim3((unsigned)((groups + 1) / 2)), dim3(16 * 2 * WAVES), 0,
+                                   s, slots, stride, V, in, out, T, aux, ring, ring_cap);
                 done = true;
             }
         }
@@ -274,14 +254,6 @@ bool launch_render_pipe_mix(float* slots, size_t stride, size_t V, const float* 
                 return true;
             }
             if (groups <= 2 * cus) {
-                constexpr int NA = SplitPlan<G, P.S, P.K1, P.K2, 2>::NA;
-                if constexpr (NA > 1 && MODE == MODE_PROCESS) {
-                    if (tl_opts.stage_split) {
-                        hipLaunchKernelGGL((k_render_pipe_split<G, MODE, P.S, P.K1, P.K2, 2, MIX, NA>), dim3((unsigned)((groups + 1) / 2)),
-                                           dim3(64 * 2 * (WAVES / 4 + NA - 1)), 0, s, slots, stride, V, in, part, T, aux, ring, ring_cap, panw);
-                        return true;
-                    }
-                }
                 hipLaunchKernelGGL((k_render_pipe_mix<G, MODE, P.S, P.K1, P.K2, 2, MIX>), dim3((unsigned)((groups + 1) / 2)), dim3(16 * 2 * WAVES), 0,
                                    s, slots, stride, V, in, part, T, aux, ring, ring_cap, panw);
                 return true;

@@ -73,6 +73,7 @@ struct JitModule {
     // the fused mix-down kernels (of G, and of FastOf<G>), compiled on first use
     std::shared_ptr<JitMix> mix[2];
     bool mix_failed[2] = {false, false};
+    std::mutex mix_mu;
     int nout = 0;
     ~JitModule() {  // a module is unloaded with ITS device current (it was loaded on that device's context)
         int prev = -1;
@@ -426,7 +427,7 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     // render + mix-down in one launch (fdsp_bank_process_mix): graphs with a pipeline plan; the kernels are compiled on first use
     jm->nout = meta[1];
     auto mix_module = [jm](int which) -> JitMix* {  // the mix-down kernels of G (0) / FastOf<G> (1), compiled on first use
-        std::lock_guard<std::mutex> lock(jm->mu);
+        std::lock_guard<std::mutex> lock(jm->mix_mu);   // (a mutex of its own: a render of this kind on another thread does not wait for the compile)
         if (!jm->mix[which] && !jm->mix_failed[which]) {
             auto mm = std::make_shared<JitMix>();
             std::string log;
@@ -442,7 +443,7 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     auto mix_launch = [jm, mix_module](int which, float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, int mix, int mode,
                            const void* aux, float* ring, uint32_t ring_cap, const float* panw, hipStream_t s) -> bool {
         if (V == 0 || T == 0) return true;
-        if (jm->pipe_stages < 1 || (mix == MIX_PAN && jm->nout != 1)) return false;
+        if (jm->pipe_stages < 1 || (mix == MIX_PAN && jm->nout != 1) || (mix == MIX_SUM && !jit_mix_channels_ok(jm->nout))) return false;
         JitMix* mm = mix_module(which);
         if (!mm) return false;
         const JitMix::Dev* f = mm->get();
@@ -452,7 +453,10 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
         tl_opts.last_kernel = LK_PIPELINE;
         return true;
     };
-    if (jm->pipe_stages >= 1) {
+    if (jm->pipe_stages >= 1 && (jm->nout == 1 || jit_mix_channels_ok(jm->nout))) {   // ("has_fused_mix" follows: no kernels, no entry)
+        out->prepare_mix = [mix_module](bool fast) {   // compile + load ahead of the real-time loop / stream capture
+            if (JitMix* mm = mix_module(fast ? 1 : 0)) mm->get();
+        };
         out->render_mix = [mix_launch](float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, int mix, int mode,
                                        const void* aux, float* ring, uint32_t ring_cap, const float* panw, hipStream_t s) {
             return mix_launch(0, slots, stride, V, in, part, T, mix, mode, aux, ring, ring_cap, panw, s);

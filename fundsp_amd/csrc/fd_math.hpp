@@ -488,12 +488,6 @@ FD_HD float tanhf_musl(float x0) {
 //   * two packed instructions for the two pairs of independent like operations (k {ln2_hi, ln2_lo}; {r1, 6} - {tt, x tt}).
 // Host builds divide with `/` (tests/host/check_tanh_expm1.hip --common: all bit patterns against the branch-form oracle).
 constexpr uint32_t TANH_COMMON_MAX_BITS = 0x40f00000u;  // 7.5f
-#ifndef FD_TANH_DIV_A
-#define FD_TANH_DIV_A 2      // div_common level of tanhf_common's first division (0 = div_inrange; 3 = the check's control)
-#endif
-#ifndef FD_TANH_DIV_B
-#define FD_TANH_DIV_B 2      // ... and of its second one
-#endif
 #ifndef FD_FTZ
 #define FD_FTZ 0             // 1 in translation units built with -fgpu-flush-denormals-to-zero (fd_fdn.hip, fd_jit.hip's Feedback graphs)
 #endif
@@ -538,7 +532,7 @@ FD_HD float tanhf_common(float x0, uint32_t& wmax) {
     const float r1 = 1.0f + hxs * (Q1 + hxs * Q2);
     const float tt = 3.0f - r1 * hfx;
     const v2f nd = v2f{r1, 6.0f} - v2f{tt, xx * tt};
-    const float e = hxs * div_common<FD_TANH_DIV_A>(nd.x, nd.y);
+    const float e = hxs * div_common<2>(nd.x, nd.y);
     float e2 = xx * (e - c) - c;
     e2 -= hxs;
     const uint32_t kb = (uint32_t)k << 23;
@@ -547,7 +541,7 @@ FD_HD float tanhf_common(float x0, uint32_t& wmax) {
     const float t = (xx - e2 + (1 - uf)) * twopk;          // k < 23 throughout the range
     // ---- tanhf ----
     const float num = c1 ? 2.0f : __builtin_fabsf(t);
-    const float quo = div_common<FD_TANH_DIV_B>(num, t + 2);
+    const float quo = div_common<2>(num, t + 2);
     const float one_minus = 1 - quo;
     float r = c1 ? one_minus : quo;
 #if FD_FTZ
@@ -711,18 +705,6 @@ FD_HD float wide_sinf(float self) {
 // packed-f32 VALU ops (v_pk_mul_f32 / v_pk_add_f32) do two lanes-ops per issue slot.  The feed-forward part of an
 // oscillator (the sine polynomial of frame n and n+1) is therefore evaluated as one <2 x float> computation.
 // Component-wise the arithmetic is IDENTICAL to wide_sinf (same operations, same order, no contraction).
-#ifndef FD_SINE_PACKED
-#define FD_SINE_PACKED 1
-#endif
-#ifndef FD_SINE_UNIFIED
-#define FD_SINE_UNIFIED 0
-#endif
-#ifndef FD_SINE_VV_PLAIN
-#define FD_SINE_VV_PLAIN 0   // A/B switch, see wide_sin2
-#endif
-#ifndef FD_SINE_BFE
-#define FD_SINE_BFE 1    // the odd-quadrant select of wide_sin2 as v_bfe_i32 + v_bfi_b32 (one issue slot less per frame than v_and + v_cmp + v_cndmask); A/B switch: 0
-#endif
 // `tmax` accumulates the largest quadrant argument seen (one v_max3_f32): the shortcuts below are exact only while
 // it stays < 8192; the caller checks it once per 64-sample block and, if it tripped, re-renders that block with the
 // fully general scalar wide_sinf (optimistic execution + rollback keeps the hot loop branch-free).
@@ -755,29 +737,14 @@ FD_HD v2f wide_sin2(v2f self, float& tmax) {
     // unfused forms of `x - y*DPn` round the same real number once -> identical bits.  Likewise 0.5*x2 below.
     v2f x = __builtin_elementwise_fma(y, splat2(-DP1F), self);
     x = __builtin_elementwise_fma(y, splat2(-DP2F), x);
-#if FD_SINE_VV_PLAIN
-    // A/B (power): the operations whose BOTH operands are register pairs as two plain instructions each -- 2 x 0.7 nJ
-    // against 1.75 nJ for the packed form (profiles/r03_power_bound.txt); the ones with a constant operand stay packed (1.08 nJ).
-    // (an empty asm on each half keeps the back end from pairing the two scalar operations again)
-    auto keep = [](float t) { asm("" : "+v"(t)); return t; };
-    auto vmul = [&](v2f a, v2f b) { return v2f{keep(a.x * b.x), keep(a.y * b.y)}; };
-    auto vadd = [&](v2f a, v2f b) { return v2f{keep(a.x + b.x), keep(a.y + b.y)}; };
-    auto vsub = [&](v2f a, v2f b) { return v2f{keep(a.x - b.x), keep(a.y - b.y)}; };
-    x = vsub(x, y * DP3F);
-    v2f x2 = vmul(x, x);
-    v2f x4 = vmul(x2, x2);
-    v2f s = vadd(vmul(vadd(x4 * P2sinf, x2 * P1sinf + P0sinf), vmul(x, x2)), x);
-    v2f c = vadd(vmul(vadd(x4 * P2cosf, x2 * P1cosf + P0cosf), x4), __builtin_elementwise_fma(x2, splat2(-0.5f), splat2(1.0f)));
-#else
     x = x - y * DP3F;
     v2f x2 = x * x;
     v2f x4 = x2 * x2;
     v2f s = (x4 * P2sinf + (x2 * P1sinf + P0sinf)) * (x * x2) + x;
     v2f c = (x4 * P2cosf + (x2 * P1cosf + P0cosf)) * x4 + __builtin_elementwise_fma(x2, splat2(-0.5f), splat2(1.0f));
-#endif
     // (forcing v_bfe_i32 + v_bfi_b32 through inline asm instead of the and + cmp + cndmask the optimiser prefers saved
     // nothing: the asm also stopped the 4-pair unrolling of the caller's loop)
-#if FD_SINE_BFE && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
     // Odd-quadrant select as v_bfe_i32 (mask = bit 0 sign-extended) + v_bfi_b32 (mask ? c : s), through asm that the
     // optimiser cannot rewrite: left alone it turns the mask select below into v_and + v_cmp + v_cndmask, and a VALU
     // instruction that takes its lane mask from VCC / an SGPR pair costs several issue slots on gfx950
@@ -812,21 +779,11 @@ FD_HD float wide_sin1(float self, float& tmax) {
     x = x - y * DP3F;
     float x2 = x * x;
     float x4 = x2 * x2;
-#if FD_SINE_UNIFIED
-    // sin and cos share one polynomial skeleton  (x4*K2 + (x2*K1 + K0)) * m + base : select the operands per lane
-    bool odd = (b & 1u) != 0;
-    float k0 = odd ? P0cosf : P0sinf, k1 = odd ? P1cosf : P1sinf, k2 = odd ? P2cosf : P2sinf;
-    float m = odd ? x4 : x * x2;
-    float base = odd ? __builtin_fmaf(x2, -0.5f, 1.0f) : x;
-    float r = (x4 * k2 + (x2 * k1 + k0)) * m + base;
-    return u2f(f2u(r) ^ ((b << 30) & 0x80000000u));
-#else
     float s = (x4 * P2sinf + (x2 * P1sinf + P0sinf)) * (x * x2) + x;
     float c = (x4 * P2cosf + (x2 * P1cosf + P0cosf)) * x4 + __builtin_fmaf(x2, -0.5f, 1.0f);
     uint32_t m = (uint32_t)((int32_t)(b << 31) >> 31);
     uint32_t r = (f2u(c) & m) | (f2u(s) & ~m);
     return u2f(r ^ ((b << 30) & 0x80000000u));
-#endif
 }
 
 // ---- tolerance mode (fdsp_set_option("math", FDSP_MATH_FAST)): a sine for Sine::process that is NOT wide's algorithm --

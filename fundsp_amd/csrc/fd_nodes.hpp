@@ -271,11 +271,7 @@ struct Sine {
             phase += d.x;
             float t1 = phase;
             phase += d.y;
-#if FD_SINE_PACKED
             out[0] = wide_sin2(v2f{t0, t1} * F32_TAU, tmax);
-#else
-            out[0] = v2f{wide_sin1(t0 * F32_TAU, tmax), wide_sin1(t1 * F32_TAU, tmax)};
-#endif
         } else {
             float o0, o1, i0 = in[0].x, i1 = in[0].y;
             this->template step<PH>(&i0, &o0);
@@ -294,9 +290,6 @@ struct Sine {
 
 // Sine in tolerance mode (FDSP_MATH_FAST): the phase recurrence of Sine::process is kept operation for operation, the
 // f32x8 sine polynomial is replaced by fast_sin (fd_math.hpp; within 1.2e-7 of it).  tick / remainder samples unchanged.
-#ifndef FD_FAST_PACKED
-#define FD_FAST_PACKED 0  // measured (profiles/r02_ab_variants.txt): two plain evaluations 3.47 ms, one packed 3.50 ms
-#endif
 struct SineFast : Sine {
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
@@ -316,11 +309,7 @@ struct SineFast : Sine {
             phase += d.x;
             float t1 = phase;
             phase += d.y;
-#if FD_FAST_PACKED
-            out[0] = fast_sin2(v2f{t0, t1} * F32_TAU);
-#else
             out[0] = v2f{fast_sin1(t0 * F32_TAU), fast_sin1(t1 * F32_TAU)};
-#endif
         } else {
             Sine::template step2<PH>(in, out);
         }
@@ -444,22 +433,9 @@ struct Noise {
 };
 
 // SVF core shared by FixedSvf and Svf:  svf.rs:995-1006 / :829-843
-#ifndef FD_MOOG_COMMON
-#define FD_MOOG_COMMON 1  // the ladder's packed path evaluates its tanh with tanhf_common (guarded, rollback); A/B switch: 0
-#endif
-#ifndef FD_SVF_PK
-#define FD_SVF_PK 1     // the lowpass SVF's two state equations as one packed computation (FixedSvfLp); A/B switch: 0 = plain
-#endif
-#ifndef FD_SVF_GUARD
-#define FD_SVF_GUARD 1  // A/B switch only (0 = measure what the overflow guard costs; NOT exact)
-#endif
-#if FD_SVF_GUARD
 // one v_max3_f32 vmax, |v1|, |v2| per frame (written as max(max(vmax, |v1|), |v2|): the other association made the
 // compiler pair frames up -- a v_max_f32 per frame plus a v_max3 per two)
 #define FD_SVF_TRACK(vmax, v1, v2) vmax = __builtin_fmaxf(__builtin_fmaxf(vmax, __builtin_fabsf(v1)), __builtin_fabsf(v2))
-#else
-#define FD_SVF_TRACK(vmax, v1, v2) (void)0
-#endif
 struct SvfCore {
     float a1, a2, a3, m0, m1, m2, ic1eq, ic2eq;
     // The reference's operations in the reference's order (svf.rs:995-1006): every scalar path uses this form.
@@ -487,7 +463,6 @@ struct SvfCore {
     // ... and when m0 = m1 = +0.0 and m2 = 1.0 (LowpassMode): `m0*v0 + m1*v1 + m2*v2` = (+-0 + +-0) + v2 is v2 itself,
     // bit for bit, whenever v0, v1 are finite and v2 is not -0.0 -- FixedSvfLp guards both (see there).
     FD_HD float tick_lp(float v0, float& vmax) {
-#if FD_SVF_PK
         // The two state equations as ONE <2 x float> computation (same operations, same order, per component): a lone
         // wave issues one VALU instruction per ~4-5 cycles whatever its width (profiles/r03_ubench_issue.txt), and this
         // recurrence is what the filter wave's issue slots go to -- 8 slots per frame instead of 11.
@@ -502,15 +477,6 @@ struct SvfCore {
         ic1eq = ic.x;
         ic2eq = ic.y;
         return v.y;
-#else
-        float v3 = v0 - ic2eq;
-        float v1 = a1 * ic1eq + a2 * v3;
-        float v2 = ic2eq + a2 * ic1eq + a3 * v3;
-        FD_SVF_TRACK(vmax, v1, v2);
-        ic1eq = __builtin_fmaf(2.0f, v1, -ic1eq);
-        ic2eq = __builtin_fmaf(2.0f, v2, -ic2eq);
-        return v2;
-#endif
     }
     FD_HD void set(const SvfCoefs& c) {
         a1 = c.a1; a2 = c.a2; a3 = c.a3; m0 = c.m0; m1 = c.m1; m2 = c.m2;
@@ -847,7 +813,6 @@ struct Moog {
     // Packed path (full SIMD items of a process block): the same recurrence with the saturator evaluated by tanhf_common --
     // exact for |argument| <= 7.5; beyond (or NaN) the tile is re-rendered through step() from the caller's snapshot.
     template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
-#if FD_MOOG_COMMON
         if (PH == PH_SIMD) {
             float o[2];
             bool same = NIN == 1;
@@ -900,7 +865,6 @@ struct Moog {
             out[0] = v2f{o[0], o[1]};
             return;
         }
-#endif
         float i0[NIN], i1[NIN], o0, o1;
 #pragma unroll
         for (int c = 0; c < NIN; c++) {
@@ -1037,10 +1001,6 @@ struct WtSet {
     float pitch[WT_MAX_TABLES];
     int off[WT_MAX_TABLES];
     int len[WT_MAX_TABLES];
-    // pair_off[i] >= 0: tables i and i + 1 have the same length and a second, INTERLEAVED copy of the two padded tables starts there:
-    // [a[0], b[0], a[1], b[1], ...] -- the eight taps WaveSynth reads from its table pair at one phase are then 32 contiguous bytes
-    // (one cache line, mostly) instead of 16 bytes in each of two tables.  -1: different lengths (one pair in four), the plain tables.
-    int pair_off[WT_MAX_TABLES];
     const float* data;
 };
 // shared sample buffers (the reference's Arc<Wave>: wave.rs), [channel][length] f32 in HBM
@@ -1116,32 +1076,12 @@ FD_HD int wt_table_index(const WtSet* t, int hint, float frequency) {  // :189-2
 // back to back so their latencies overlap.
 // Device tables are stored circularly padded -- [t[len-1], t[0..len-1], t[0], t[1]] -- so the four interpolation taps
 // t[i1-1..i1+2] of Wavetable::at are ONE contiguous (unaligned) 16-byte gather per lane instead of four.
-#ifndef FD_WT_NT
-#define FD_WT_NT 0
-#endif
-#ifndef FD_WT_SAME
-#define FD_WT_SAME 0
-#endif
-#ifndef FD_WT_FIXED
-#define FD_WT_FIXED 0
-#endif
-#ifndef FD_WT_PAIRS
-// A/B switch, OFF: 1 = WaveSynth reads adjacent tables of equal length from their interleaved copy (WtSet::pair_off): one cache line per
-// lane and frame instead of two.  Measured (profiles/r04_ab_h_wt_pairs.txt): bit-identical and SLOWER -- config 4 voice-out 9.33 -> 10.05 ms,
-// with the fused mix-down 8.04 -> 8.96: three pairs in four are interleaved, the lanes of a wave differ, so every frame pays six selects
-// and two variable shifts to put the taps where the plain layout has them, and that costs more than the lines saved (both taps from ONE
-// table, without any extra instruction, bought 0.73 ms: profiles/r04_ab_d_c4_one_table.txt).
-#define FD_WT_PAIRS 0
-#endif
 struct Tap4 { float a0, a1, a2, a3, w; };
 // the pieces of wt_tap: index + interpolation weight, then the four floats from HBM / from the kernel's LDS copy
 FD_HD float wt_tap_index(uint32_t mask, float phase, uint32_t& i1) {
     float p = (float)(mask + 1u) * phase;
     uint32_t i = (uint32_t)p;
     i1 = i & mask;
-#if FD_WT_FIXED   // measurement only (NOT a renderer): every lane reads the same four floats of its table at every frame (perfect temporal reuse)
-    i1 = (i & mask) & 3u;
-#endif
     return p - (float)i;
 }
 FD_HD Tap4 wt_tap_mem(const float* __restrict__ at, float w) {  // (by value: a Tap4 passed by reference ended up as a memory object)
@@ -1149,11 +1089,7 @@ FD_HD Tap4 wt_tap_mem(const float* __restrict__ at, float w) {  // (by value: a 
     t.w = w;
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-#if FD_WT_NT   // A/B: the table gathers as non-temporal loads (served by L2, no L1 allocation)
-    const f4u q = __builtin_nontemporal_load((const __attribute__((address_space(1))) f4u*)at);
-#else
     const f4u q = *(const __attribute__((address_space(1))) f4u*)at;
-#endif
     t.a0 = q.x; t.a1 = q.y; t.a2 = q.z; t.a3 = q.w;
 #else
     float q[4];
@@ -1168,19 +1104,12 @@ FD_HD Tap4 wt_tap(const float* __restrict__ tab, uint32_t mask, float phase) {  
     Tap4 t;
     t.w = p - (float)i1;
     i1 = i1 & mask;
-#if FD_WT_FIXED
-    i1 = i1 & 3u;
-#endif
     // padded layout: tab[i1 + 0..3] = t[i1-1], t[i1], t[i1+1], t[i1+2]
 #if defined(__HIP_DEVICE_COMPILE__)
     // through an explicit global-address-space pointer: on a generic pointer (the table address comes out of a struct
     // in memory) the 4-byte-aligned 16-byte load is split into four dword gathers before the address space is inferred
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-#if FD_WT_NT
-    const f4u q = __builtin_nontemporal_load((const __attribute__((address_space(1))) f4u*)(tab + i1));
-#else
     const f4u q = *(const __attribute__((address_space(1))) f4u*)(tab + i1);
-#endif
     t.a0 = q.x; t.a1 = q.y; t.a2 = q.z; t.a3 = q.w;
 #else
     float q[4];
@@ -1193,12 +1122,6 @@ FD_HD float tap_eval(const Tap4& t) { return optimal4x44(t.a0, t.a1, t.a2, t.a3,
 FD_HD v2f tap_eval2(const Tap4 a, const Tap4 b) {  // frames n and n + 1 of one table
     return optimal4x44_2(v2f{a.a0, b.a0}, v2f{a.a1, b.a1}, v2f{a.a2, b.a2}, v2f{a.a3, b.a3}, v2f{a.w, b.w});
 }
-#ifndef FD_WT_PACKED
-#define FD_WT_PACKED 1    // WaveSynth's packed path interpolates the two frames of a pair as one <2 x float> computation; A/B switch: 0
-#endif
-#ifndef FD_WT_PREFETCH
-#define FD_WT_PREFETCH 1  // WaveSynth's packed path gathers the taps of the NEXT frame pair while it evaluates this one; A/B switch: 0
-#endif
 
 template <int SET, int NOUT = 1>  // WaveSynth<U2> also outputs the wrapped phase (wavetable.rs:318-324, 343-345)
 struct WaveSynth {
@@ -1215,16 +1138,10 @@ struct WaveSynth {
     float c_p0, c_p1;
     const float *c_tab1, *c_tab2;
     uint32_t c_mask1, c_mask2;
-    uint32_t c_sh;  // index -> float offset: 0 = plain tables, 1 = the interleaved copy of the pair (c_tab2 = c_tab1 + 4 there)
     // the taps gathered ahead for the next frame pair (packed path), valid for exactly the wrapped phases pf_p0 / pf_p1
     bool pf_ok;
     uint32_t pf_p0, pf_p1;
     Tap4 pf_a1, pf_a2, pf_b1, pf_b2;
-#if FD_WT_PREFETCH >= 2
-    // FD_WT_PREFETCH = D (2 or 4): D sets of taps in flight, the set of frame pair k + D is gathered while pair k is evaluated
-    struct PfSlot { bool ok; uint32_t p0, p1; Tap4 a1, a2, b1, b2; };
-    PfSlot pfs[FD_WT_PREFETCH];
-#endif
     template <class V> FD_HD void visit(V& v) {
         v.f(phase, STATE, "phase");
         v.u32(hint, STATE, "table_hint");
@@ -1240,10 +1157,6 @@ struct WaveSynth {
     }
     FD_HD void pf_drop() {  // nothing gathered ahead is valid any more
         pf_ok = false;
-#if FD_WT_PREFETCH >= 2
-#pragma unroll
-        for (int k = 0; k < FD_WT_PREFETCH; k++) pfs[k].ok = false;
-#endif
     }
     FD_HD void init() {  // WaveSynth::new :270-281: phase 0.0 WITHOUT reset
         phase = 0.0f;
@@ -1275,40 +1188,16 @@ struct WaveSynth {
             c_tab2 = wt->data + wt->off[t + 2];
             c_mask1 = (uint32_t)wt->len[t + 1] - 1u;
             c_mask2 = (uint32_t)wt->len[t + 2] - 1u;
-            c_sh = 0;
-#if FD_WT_PAIRS
-            if (wt->pair_off[t + 1] >= 0) {  // equal lengths: both tables' taps from one 32-byte run of the interleaved copy
-                c_tab1 = wt->data + wt->pair_off[t + 1];
-                c_tab2 = c_tab1 + 4;
-                c_sh = 1;
-            }
-#endif
-#if FD_WT_SAME   // measurement only (NOT a renderer): both taps from ONE table -- the second gather hits the first one's lines
-            c_tab2 = c_tab1;
-            c_mask2 = c_mask1;
-#endif
             hint = (uint32_t)t;
             pf_drop();  // taps gathered ahead came from the previous table pair
         }
         return clamp01f((f0 - c_p0) / (c_p1 - c_p0));
     }
-    // the two gathers at table indices i1 / i2 have landed in t1 / t2: in the interleaved copy they hold {a0 b0 a1 b1} {a2 b2 a3 b3}
-    // (a = table 1, b = table 2) -- put the taps where the plain layout has them (six selects; the lanes of a wave differ)
-    FD_HD void untangle(Tap4& t1, Tap4& t2) const {
-#if FD_WT_PAIRS
-        const bool pr = c_sh != 0;
-        const float a1 = pr ? t1.a2 : t1.a1, a2 = pr ? t2.a0 : t1.a2, a3 = pr ? t2.a2 : t1.a3;
-        const float b0 = pr ? t1.a1 : t2.a0, b1 = pr ? t1.a3 : t2.a1, b2 = pr ? t2.a1 : t2.a2;
-        t1.a1 = a1; t1.a2 = a2; t1.a3 = a3;
-        t2.a0 = b0; t2.a1 = b1; t2.a2 = b2;
-#endif
-    }
     FD_HD void taps(float ph, Tap4& t1, Tap4& t2) const {  // Wavetable::at of both tables at one phase (:154-166)
         uint32_t i1, i2;
         const float w1 = wt_tap_index(c_mask1, ph, i1), w2 = wt_tap_index(c_mask2, ph, i2);
-        t1 = wt_tap_mem(c_tab1 + (i1 << c_sh), w1);
-        t2 = wt_tap_mem(c_tab2 + (i2 << c_sh), w2);
-        untangle(t1, t2);
+        t1 = wt_tap_mem(c_tab1 + i1, w1);
+        t2 = wt_tap_mem(c_tab2 + i2, w2);
     }
     template <int PH> FD_HD void step(const float* in, float* out) {
         if (PH == PH_SIMD) {  // process :327-348
@@ -1341,46 +1230,7 @@ struct WaveSynth {
             float ph0 = phase - __builtin_floorf(phase);
             phase += d.y;
             float ph1 = phase - __builtin_floorf(phase);
-#if FD_WT_PREFETCH >= 2 && defined(__HIP_DEVICE_COMPILE__)
-            // D sets of taps in flight (A/B of the gather latency under L1 misses): pair k takes set k mod D if its phases have the
-            // bits predicted D pairs ago, then the set is re-armed with the gathers of pair k + D.  The packed loops call this
-            // four times per SIMD item with item_pos known at compile time (item_begin), so the set is a fixed group of registers in
-            // each of the unrolled calls; anywhere else the switch below is a wave-uniform branch.  Whatever the order of calls,
-            // a set is only ever used for exactly the phases it was gathered for.
-            Tap4 a1, a2, b1, b2;
-            auto turn = [&](PfSlot& s) {
-                const bool hit = s.ok && f2u(ph0) == s.p0 && f2u(ph1) == s.p1;
-                if (__builtin_amdgcn_ballot_w64(!hit) == 0ull) {
-                    a1 = s.a1; a2 = s.a2; b1 = s.b1; b2 = s.b2;
-                } else {
-                    taps(ph0, a1, a2);
-                    taps(ph1, b1, b2);
-                }
-                float np = phase;
-#pragma unroll
-                for (int k = 1; k < FD_WT_PREFETCH; k++) { np += d.x; np += d.y; }
-                np += d.x;
-                const float q0 = np - __builtin_floorf(np);
-                np += d.y;
-                const float q1 = np - __builtin_floorf(np);
-                uint32_t ia1, ia2, ib1, ib2;
-                const float wa1 = wt_tap_index(c_mask1, q0, ia1), wa2 = wt_tap_index(c_mask2, q0, ia2);
-                const float wb1 = wt_tap_index(c_mask1, q1, ib1), wb2 = wt_tap_index(c_mask2, q1, ib2);
-                s.a1 = wt_tap_mem(c_tab1 + (ia1 << c_sh), wa1); s.a2 = wt_tap_mem(c_tab2 + (ia2 << c_sh), wa2);
-                s.b1 = wt_tap_mem(c_tab1 + (ib1 << c_sh), wb1); s.b2 = wt_tap_mem(c_tab2 + (ib2 << c_sh), wb2);
-                untangle(s.a1, s.a2);
-                untangle(s.b1, s.b2);
-                s.p0 = f2u(q0);
-                s.p1 = f2u(q1);
-                s.ok = true;
-            };
-            const int set = (item_pos >> 1) & (FD_WT_PREFETCH - 1);
-#if FD_WT_PREFETCH == 4
-            if (set == 0) turn(pfs[0]); else if (set == 1) turn(pfs[1]); else if (set == 2) turn(pfs[2]); else turn(pfs[3]);
-#else
-            if (set == 0) turn(pfs[0]); else turn(pfs[1]);
-#endif
-#elif FD_WT_PREFETCH && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
             // The gathers are served by L2 (a saw set is 160 KiB) and the stage has ~35 instructions per frame: issued
             // where they are used, their round trip (~600 cycles per pair) is 2/3 of the stage's time (config 4: stage 0
             // alone 10.4 ms, 33 issue slots per frame).  The next pair's phases are this pair's plus the same two
@@ -1404,10 +1254,8 @@ struct WaveSynth {
                 uint32_t ia1, ia2, ib1, ib2;
                 const float wa1 = wt_tap_index(c_mask1, q0, ia1), wa2 = wt_tap_index(c_mask2, q0, ia2);
                 const float wb1 = wt_tap_index(c_mask1, q1, ib1), wb2 = wt_tap_index(c_mask2, q1, ib2);
-                pf_a1 = wt_tap_mem(c_tab1 + (ia1 << c_sh), wa1); pf_a2 = wt_tap_mem(c_tab2 + (ia2 << c_sh), wa2);
-                pf_b1 = wt_tap_mem(c_tab1 + (ib1 << c_sh), wb1); pf_b2 = wt_tap_mem(c_tab2 + (ib2 << c_sh), wb2);
-                untangle(pf_a1, pf_a2);
-                untangle(pf_b1, pf_b2);
+                pf_a1 = wt_tap_mem(c_tab1 + ia1, wa1); pf_a2 = wt_tap_mem(c_tab2 + ia2, wa2);
+                pf_b1 = wt_tap_mem(c_tab1 + ib1, wb1); pf_b2 = wt_tap_mem(c_tab2 + ib2, wb2);
                 pf_p0 = f2u(q0);
                 pf_p1 = f2u(q1);
                 pf_ok = true;
@@ -1418,38 +1266,13 @@ struct WaveSynth {
             taps(ph0, a1, a2);
             taps(ph1, b1, b2);
 #endif
-#if FD_WT_PACKED
             out[0] = (1.0f - item_w) * tap_eval2(a1, b1) + item_w * tap_eval2(a2, b2);
-#else
-            float o0 = (1.0f - item_w) * tap_eval(a1) + item_w * tap_eval(a2);
-            float o1 = (1.0f - item_w) * tap_eval(b1) + item_w * tap_eval(b2);
-            out[0] = v2f{o0, o1};
-#endif
         } else {
             float o0[NOUT], o1[NOUT], i0 = in[0].x, i1 = in[0].y;
             this->template step<PH>(&i0, o0);
             this->template step<PH>(&i1, o1);
             for (int c = 0; c < NOUT; c++) out[c] = v2f{o0[c], o1[c]};
         }
-    }
-    // skip / skip2 (stages run in several waves, fd_device.hpp): everything step / step2 do to the STATE -- the table choice at the
-    // head of an item (it moves `hint`), the unwrapped phase accumulation of the process path -- without the table reads.  The taps
-    // gathered ahead belong to the pair after the last EVALUATED one: stale after a skip.
-    template <int PH> FD_HD void skip(const float* in) {
-        static_assert(PH == PH_SIMD, "WaveSynth::skip: packed part of a process block only");
-        if ((item_pos & 7) == 0) item_w = select(__builtin_fabsf(in[0]));
-        item_pos++;
-        phase += in[0] * sample_duration;
-        pf_drop();
-    }
-    template <int PH> FD_HD void skip2(const v2f* in) {
-        static_assert(PH == PH_SIMD, "WaveSynth::skip2: packed part of a process block only");
-        if ((item_pos & 7) == 0) item_w = select(__builtin_fabsf(in[0].x));
-        item_pos += 2;
-        const v2f d = in[0] * sample_duration;
-        phase += d.x;
-        phase += d.y;
-        pf_drop();
     }
 };
 

@@ -11,7 +11,6 @@ struct LaunchOpts {
     int pipe_split = 1;  // 0 = single-wave kernel, 1 = best plan (default), 2 / 3 = exactly that many compute stages, 4 = loader wave only
     int time_split = 1;  // 1 (default) = small banks of eligible graphs take the time-split kernel (3 + 3 + 1 waves), 2 = round 2's layouts, 0 = never
     int fdn_kernel = 0;  // reverb banks: 0 = lane-per-frame (default), 1 = lane-per-delay-line
-    int stage_split = 1; // 1 (default) = heavy graphs on banks of two voice groups per CU run their oscillator stage in two waves (SplitPlan), 0 = never
     // OUT: which kernel family the launch code chose (fdsp_bank_get_option(bank, "last_kernel")) -- lets a test assert that
     // the path it means to exercise is the one that ran, since every path produces the same samples
     int last_kernel = 0;

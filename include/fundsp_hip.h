@@ -120,18 +120,14 @@ int fdsp_set_option(const char* name, int value);
 int fdsp_bank_set_option(fdsp_bank* bank, const char* name, int value);
 int fdsp_bank_get_option(const fdsp_bank* bank, const char* name);
 /* The launch options -- "pipe_split", "time_split" (default 1: banks of <= 2 voice groups per CU of eligible graphs take
- * the time-split kernel), "stage_split", "fdn_kernel", "timing" -- exist per bank as well: fdsp_bank_set_option(bank, name, v) overrides
+ * the time-split kernel), "fdn_kernel", "timing" -- exist per bank as well: fdsp_bank_set_option(bank, name, v) overrides
  * the process-wide value of fdsp_set_option for that bank (-1 = follow it again).  They are resolved per launch on the
  * calling thread, so hosts driving different banks from different threads do not see each other's choices.
  * "timing" (default 1): every render records a HIP event pair around the kernel (fdsp_bank_last_kernel_ms); 0 drops
  * the pair -- a real-time host rendering one 64-frame block per call saves two event records per launch.
  * fdsp_bank_get_option(bank, "last_kernel") (read-only): the kernel family the most recent render launch took --
  * 1 single-wave, 2 pipeline, 3 planar pipeline, 4 time-split, 5 voice scheduler, 6 / 7 reverb lane-per-frame / -line. */
-/* "stage_split" (default 1; also per bank): A/B switch of builds with -DFD_STAGE_SPLIT=1 only (the default build has no such
- * kernels and ignores it): heavy graphs whose first compute stage is a skippable generator (the config-4 wavetable oscillator)
- * render banks of two voice groups per CU with that stage in TWO waves per voice group -- bit-identical samples, measured slower
- * (profiles/r04_ab_a_split.txt).
- * fdsp_bank_get_option(bank, "has_fused_mix") (read-only): 1 if fdsp_bank_process_mix has kernels for the bank's kind. */
+/* fdsp_bank_get_option(bank, "has_fused_mix") (read-only): 1 if fdsp_bank_process_mix has kernels for the bank's kind. */
 /* "host_zero_copy_max" (default 262144): fdsp_bank_process_host calls moving at most this many floats per direction
  * let the kernel read/write pinned host memory directly instead of staging through HBM (lower per-block latency). */
 /* "fdn_kernel" (default 0): reverb banks render with one lane per FRAME (0) or one lane per DELAY LINE (1); identical
@@ -306,6 +302,8 @@ double fdsp_bank_events_time(const fdsp_bank* bank);       /* Sequencer::time() 
  *         centre) exactly like Panner::tick does (`weight * sample`), d_mix = [2][frames].
  * The bank owns the partial-mix buffer ([voice groups][channels][frames] f32, 1/64 of a voice-out render); it grows on demand,
  * fdsp_bank_mix_reserve(bank, frames) sizes it ahead of a real-time loop or a stream capture (AudioNode::allocate semantics).
+ * A mix launch always takes the stage pipeline (or, for small banks of eligible graphs, the time-split kernel): "pipe_split" = 0 and the
+ * launch-length thresholds of fdsp_bank_process do not apply to it, and a kind whose graph has no pipeline plan answers FDSP_ENOTSUP.
  * Stream, ordering, timing and capture rules are those of fdsp_bank_process; a CAPTURED launch holds the partial-mix buffer of
  * capture time, so reserve for the longest launch before capturing and do not grow the reservation while such a graph is alive.  FDSP_ENOTSUP: the kind was built without the
  * fused kernels (the BASELINE kinds fm_svf, sine_hz_lowpass_hz, saw_moog_adsr_pan, noise_biquad have them) -- render

@@ -240,6 +240,9 @@ typedef struct {
     const float *plan;      /* n_plan x (value, frames) (Var shape) */
 } o_c4_job;
 double o_c4_bank_render(const o_c4_job *job, float *out);
+/* Config 2 as the reference runs it: BiquadBank<f32x8> (biquad_bank.rs:73-84), eight voices per SIMD instruction, fed by 8 Noise nodes;
+ * lane k of bank j = voice 8 j + k of o_bank_render's config 2, bit for bit.  Seconds, or < 0 for another config / tick mode. */
+double o_biquad_bank8_render(const o_bank_job *job, float *out);
 /* Config 5: `instances` x reverb_stereo(room, time, damping) on the SAME stereo input x [2][frames]; out (or NULL) = [instance][2][frames] */
 double o_reverb_bank_render(int threads, int fast, double sample_rate, size_t instances, size_t frames, double room, double time, double damping,
                             const float *x, float *out);

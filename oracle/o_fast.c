@@ -354,3 +354,76 @@ double o_reverb_bank_render(int threads, int fast, double sample_rate, size_t in
     free(sl);
     return s;
 }
+
+/* ---- BASELINE config 2 the way the reference runs it: BiquadBank<f32x8> (biquad_bank.rs:14-130) -- EIGHT voices per SIMD instruction ----
+ * `(noise() | .. | noise()) >> biquad_bank()`: 8 Noise generators (Noise::process noise.rs:204-218: 8 frames per item, time-vectorised
+ * integer hash) feed one bank whose tick (biquad_bank.rs:73-84) is the DF1 expression on f32x8 -- lane k of bank j is voice 8 j + k of
+ * o_bank_render's config 2 (same coefficients, same seeds), the same IEEE operations per lane in the same order -> bit-identical to the scalar
+ * restatement (tests/test_oracle_fast.py), one eighth of the arithmetic instructions.  Voices in groups of 8 (a ragged tail runs with
+ * silent lanes). */
+typedef struct {
+    const o_bank_job *job;
+    float *out;
+    size_t b0, b1;
+    int t;
+} bbslice;
+static const o_bank_job *g_bb_job;
+static float *g_bb_out;
+static void bb_fill(void *p, size_t b0, size_t b1, int t) {
+    bbslice *s = (bbslice *)p;
+    s->job = g_bb_job; s->out = g_bb_out; s->b0 = b0; s->b1 = b1; s->t = t;
+}
+static void *run_bb_slice(void *arg) {
+    bbslice *s = (bbslice *)arg;
+    const o_bank_job *job = s->job;
+    o_bank_pin_self(s->t);
+    const size_t T = job->frames, V = job->voices;
+    for (size_t bank = s->b0; bank < s->b1; bank++) {
+        v8f a1, a2, b0, b1, b2, x1 = v8_splat(0.0f), x2 = x1, y1 = x1, y2 = x1;
+        uint32_t nstate[8];
+        for (int k = 0; k < 8; k++) {
+            const size_t v = bank * 8 + (size_t)k;
+            float c[5] = {0, 0, 0, 0, 0};
+            uint64_t h = 0;
+            if (v < V) {
+                o_biquad_coefs(O_BQ_LOWPASS, (float)job->sample_rate, job->p0[v], job->p1[v], 1.0f, c);   /* Setting::biquad(..).index(k) */
+                h = job->seed[v];
+            }
+            a1[k] = c[0]; a2[k] = c[1]; b0[k] = c[2]; b1[k] = c[3]; b2[k] = c[4];
+            nstate[k] = (uint32_t)(h ^ (h >> 32));                                                        /* Noise::reset noise.rs:192-195 */
+        }
+        float nz[8][64], blk[8][64];
+        for (size_t i = 0; i < T; i += 64) {
+            const int n = (int)(T - i < 64 ? T - i : 64), items8 = ((n + 7) >> 3) * 8;
+            for (int k = 0; k < 8; k++) {                                                                 /* Noise::process noise.rs:204-218 */
+                const uint32_t st = nstate[k];
+                for (int j = 0; j < items8; j++) nz[k][j] = (float)(o_hash32x(st + (uint32_t)j + 1u) >> 8) * (2.0f / (float)((1 << 24) - 1)) - 1.0f;
+                nstate[k] = st + (uint32_t)n;
+            }
+            for (int j = 0; j < n; j++) {                                                                 /* default process -> BiquadBank::tick :73-84 */
+                const v8f x0 = {nz[0][j], nz[1][j], nz[2][j], nz[3][j], nz[4][j], nz[5][j], nz[6][j], nz[7][j]};   /* F::from_frame */
+                const v8f y0 = b0 * x0 + b1 * x1 + b2 * x2 - a1 * y1 - a2 * y2;
+                x2 = x1; x1 = x0; y2 = y1; y1 = y0;
+                for (int k = 0; k < 8; k++) blk[k][j] = y0[k];                                            /* to_frame */
+            }
+            if (s->out)
+                for (int k = 0; k < 8; k++) {
+                    const size_t v = bank * 8 + (size_t)k;
+                    if (v >= V) break;
+                    if (job->out_layout == 0) memcpy(&s->out[v * T + i], blk[k], (size_t)n * sizeof(float));
+                    else if (job->out_layout == 1) for (int j = 0; j < n; j++) s->out[(i + (size_t)j) * V + v] = blk[k][j];
+                }
+        }
+    }
+    return NULL;
+}
+/* config 2 of an o_bank_job through 8-lane banks; returns seconds, < 0 if the job is not config 2 in process mode */
+double o_biquad_bank8_render(const o_bank_job *job, float *out) {
+    if (job->config != 2 || !job->process_mode) return -1.0;
+    int nt = job->threads > 0 ? job->threads : 1;
+    bbslice *sl = (bbslice *)calloc((size_t)nt, sizeof(bbslice));
+    g_bb_job = job; g_bb_out = out;
+    const double s = run_threads(nt, (job->voices + 7) / 8, run_bb_slice, sl, sizeof(bbslice), bb_fill);
+    free(sl);
+    return s;
+}

@@ -732,6 +732,12 @@ def bank_render(config, params, seeds, frames, sample_rate=48000.0, process_mode
     if store:
         out = np.zeros((frames, V) if out_layout == 1 else (V, frames), dtype=np.float32)
     L = lib or globals()["lib"]()
+    if fast and config == 2:     # BiquadBank<f32x8>: eight voices per SIMD instruction (oracle/o_fast.c)
+        L.o_biquad_bank8_render.restype = C.c_double
+        L.o_biquad_bank8_render.argtypes = [C.POINTER(BankJob), C.POINTER(C.c_float)]
+        secs = L.o_biquad_bank8_render(C.byref(job), _fptr(out))
+        assert secs >= 0.0, "o_biquad_bank8_render takes config 2 in process mode only"
+        return out, secs
     if fast:
         L.o_bank_render_fast.restype = C.c_double
         L.o_bank_render_fast.argtypes = [C.POINTER(BankJob), C.POINTER(C.c_float)]

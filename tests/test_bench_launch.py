@@ -110,9 +110,8 @@ def test_cpu_baseline_runs_on_rank_0_of_multi_gpu_runs_too():
 def test_secondary_cpu_baselines_are_the_native_monomorphised_legs():
     """Every cpu_baseline of the bench line comes from the -O3 -march=native build, many voices per pinned thread; configs 4 / 5 through
     the monomorphised process() (bit-equal to the tree walk: tests/test_oracle_fast.py)."""
-    for cfg, kind in ((2, "port"), ("4v", "port (monomorphised)"), (5, "port (monomorphised)")):
+    for cfg, kind in ((2, "port (monomorphised)"), ("4v", "port (monomorphised)"), (5, "port (monomorphised)")):
         r = bench.cpu_baseline_config(cfg, 48000.0, 640, target_seconds=0.05)
         assert r["kind"] == kind and "-O3 -march=native" in r["flags"] and r["value"] > 0 and r["threads_pinned"]
         assert r["cores"] == bench.host_cpu_budget()["effective_cpus"]
-        if cfg != 2:
-            assert r["tree_walk_value"] > 0
+        assert r["scalar_voice_value" if cfg == 2 else "tree_walk_value"] > 0

@@ -228,6 +228,28 @@ def test_run_time_compiled_graph_mixes(gpu):
     assert_bit_equal(s1, gpu.sum_voices(o2).cpu().numpy(), "the next block, MIX_SUM")
 
 
+def test_run_time_compiled_wide_graph_has_no_fused_mix_and_says_so(gpu):
+    """A run-time compiled graph of four outputs: a mix tile of eight frames does not fit beside the pipeline's tiles at four voice groups
+    per workgroup (MixGeom), so the kind has no fused mix-down -- "has_fused_mix" says 0 and fdsp_bank_process_mix answers FDSP_ENOTSUP
+    at once (it used to spend a hiprtc compile on a module that could not build).  Three outputs fit."""
+    from fundsp_amd import graph as G
+
+    V, T = 64 * 3, 64 * 2
+    f = (110.0 * 2.0 ** (3.0 * W.rnd1(np.arange(V, dtype=np.uint64)))).astype(np.float32)
+    osc = lambda k: (G.dc(f * (k + 1)) >> G.sine()) * 0.5 >> G.lowpass_hz(1200.0, 0.8)   # noqa: E731
+    wide = gpu.Bank.from_graph(osc(0) | osc(1) | osc(2) | osc(3), V, sample_rate=SR)
+    assert wide.outputs() == 4 and wide.get_option("has_fused_mix") == 0
+    with pytest.raises(gpu.FdspError):
+        wide.process_mix(T, mix=MIX_SUM)
+    three = gpu.Bank.from_graph(osc(0) | osc(1) | osc(2), V, sample_rate=SR)
+    three.set_seed(np.arange(V, dtype=np.uint64))
+    if three.get_option("has_fused_mix") == 1:      # (a graph without a pipeline plan has none either)
+        three.mix_reserve(T)                          # compiles and loads the mix kernels ahead of the first launch
+        ref = three.clone()
+        mix = three.process_mix(T, mix=MIX_SUM).cpu().numpy()
+        assert_bit_equal(mix, gpu.sum_voices(ref.process(T)).cpu().numpy(), "three-output run-time compiled graph: fused vs sum_voices")
+
+
 def test_run_time_compiled_filter_chain_mixes_with_lds_weights(gpu):
     """A graph with an audio input and two compute stages -- 12 waves per workgroup of four voice groups: the pan weights of the
     fused mix-down live in LDS and the flush is a loop there (render_pipe_body TIGHT); a moog in the chain makes it `heavy`, so the

@@ -126,3 +126,15 @@ def test_config5_block_form_equals_tree_walk(frames):
     n.set_sample_rate(SR)
     assert np.array_equal(n.render_blocks(x).view(np.uint32), want[0].view(np.uint32))
     assert frames <= 64 or np.abs(want).max() > 0.01       # (the shortest delay line is longer than one block)
+
+
+@pytest.mark.parametrize("V,frames", [(24, 64 * 5 + 13), (13, 64), (8, 7)])
+def test_config2_biquad_bank_f32x8_equals_the_scalar_voices(V, frames):
+    """The cpu_baseline leg of config 2 is the reference's own SIMD form, BiquadBank<f32x8> (eight voices per instruction,
+    biquad_bank.rs:73-84): lane k of bank j == voice 8 j + k of the scalar restatement, bit for bit; ragged last bank, both layouts."""
+    p = W.noise_biquad_params(V, SR)
+    args = (2, [p["fc"], p["q"]], p["seed"], frames, SR, True)
+    for layout in (0, 1):
+        want, _ = O.bank_render(*args, layout, 1)
+        got, _ = O.bank_render(*args, layout, 3, fast=True)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"V={V} frames={frames} layout={layout}"

@@ -29,14 +29,15 @@ def evaluate(expr, known):
     work = re.sub(r"defined\s*(?:\(\s*([A-Za-z_]\w*)\s*\)|([A-Za-z_]\w*))", sub_defined, expr)
     shown = re.sub(r"defined\s*(?:\(\s*([A-Za-z_]\w*)\s*\)|([A-Za-z_]\w*))",
                    lambda m: ("0" if known[m.group(1) or m.group(2)] == "undef" else "1") if (m.group(1) or m.group(2)) in known else m.group(0), expr)
-    shown = IDENT.sub(lambda m: str(known[m.group(0)]) if m.group(0) in known else m.group(0), shown)
+    value_of = lambda n: "0" if known[n] == "undef" else str(known[n])   # an undefined name is 0 in #if arithmetic
+    shown = IDENT.sub(lambda m: value_of(m.group(0)) if m.group(0) in known else m.group(0), shown)
 
     def sub_ident(m):
         t = m.group(0)
         if t.startswith("__a"):
             return t
         if t in known:
-            return str(known[t])
+            return value_of(t)
         return atom(t)
     work = IDENT.sub(sub_ident, work)
     py = work.replace("&&", " and ").replace("||", " or ")
