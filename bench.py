@@ -375,9 +375,22 @@ def secondary(F, W, torch, sr, mode):
             c2["cpu_vs_gpu"][f"T{T}"] = {"gpu_hip_graph_value": gv, "winner": "gpu" if gv > cpu else "cpu", "gpu_over_cpu": round(gv / cpu, 3)}
         c2["cpu_vs_gpu"]["T48000"] = {"gpu_value": c2["T48000"]["value"], "winner": "gpu" if c2["T48000"]["value"] > cpu else "cpu",
                                       "gpu_over_cpu": round(c2["T48000"]["value"] / cpu, 3)}
-        c2["cpu_vs_gpu"]["note"] = ("a dependent chain of EMPTY kernels replays at ~1.6 us per node on this platform and an event pair around an empty kernel reads ~6 us "
-                                    "(tools/ubench_launch.hip, profiles/r05_ubench_launch_*.txt): 65 536 samples per 64-frame block leave the GPU ~3 us per launch to beat "
-                                    "the host's cores")
+        c2["cpu_vs_gpu"]["note"] = (f"the host renders one 64-frame block of the 1024 voices in {1024 * 64 / cpu:.2f} us (BiquadBank<f32x8>: eight voices per vector instruction, "
+                                    f"{c2['cpu_baseline'].get('cores')} cores); a dependent chain of EMPTY kernels replays at ~1.6 us per node on this platform, a kernel of "
+                                    "d us of work at d + 0.9, and an event pair around an empty kernel reads ~6 us (tools/ubench_launch.hip, profiles/r05_ubench_launch_*.txt): "
+                                    "a 1024-voice bank is 16 wavefronts on a chip of 1024 SIMDs -- at one block per launch the launch is the cost, the GPU wins from launches "
+                                    "of a few blocks on and by the bank size (voices_65536 below: the same kernel family on a bank that fills the chip)")
+    # ... the same graph on a bank that fills the machine (64 x the voices): what the engine does with config 2's arithmetic when it has the lanes
+    try:
+        Vb, Tb = 65536, 4096
+        wl = make_workload(F, W, torch, 2, Vb, Tb, sr, 0, F.LAYOUT_VOICE_MINOR, "exact")
+        ms, kms = quick(F, torch, wl, Tb, mode, steps=10, warmup=3)
+        c2["voices_65536"] = {"voices": Vb, "T": Tb, "us_per_launch": round(ms * 1e3, 2), "kernel_us": round(kms * 1e3, 2), "value": round(Vb * Tb / ms / 1e3, 1),
+                              "last_kernel": wl["bank"].get_option("last_kernel"),
+                              "roofline_frac": round((Vb * Tb * 4 + Vb * 48) / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del wl
+    except Exception as e:
+        c2["voices_65536"] = {"error": repr(e)}
     out.append(c2)
     # ... the same launch pattern from a COMPILED host, straight through the C ABI (tools/launch_overhead.cpp, built here with g++):
     # what the Python binding adds per 64-frame block is the difference to T64.us_per_launch above
@@ -760,6 +773,21 @@ def main(argv=None):
     print(json.dumps(res), flush=True)
 
 
+HEADLINE_KERNEL_SOURCES = ("fd_math.hpp", "fd_nodes.hpp", "fd_device.hpp", "fd_engine.hpp", "fd_opts.hpp", "fd_kinds_fm.hpp", "fd_kinds_fm.hip", "Makefile")
+
+
+def headline_kernel_source_hash():
+    """sha256 over the files the headline kernel (fd::k_render_pipe<fm_svf ..>, fd_kinds_fm.hip) is compiled from, in a fixed order:
+    what profiles/pmc_latest.json must carry for its HBM traffic to be quoted as this kernel's (tools/pmc_latest.py writes it)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in HEADLINE_KERNEL_SOURCES:
+        h.update(name.encode() + b"\0")
+        h.update(open(os.path.join(ROOT, "fundsp_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
 def cpu_baseline_wanted(args, rank, world):
     """The headline's cpu_baseline leg runs on rank 0 of EVERY run of the headline config, whatever the number of GPUs."""
     return rank == 0 and world >= 1 and args.cpu_seconds > 0 and args.config == 3
@@ -984,8 +1012,14 @@ def run_rank(args, torch, F, peers, device):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("voices") == V and rec.get("frames") == T and rec.get("config", 3) == args.config and rec.get("math", "exact") == args.math:
-                    traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_source = rec.get("source", "profiles/pmc_latest.json") + " (separate rocprofv3 --pmc passes, not this run)"
+                    # ... and on THIS kernel: the record names the kernel it counted and carries the hash of the sources that kernel is
+                    # compiled from; a record taken on another build of the headline kernel is not quoted
+                    if rec.get("kernel_source_sha256") == headline_kernel_source_hash() and "k_render_pipe" in rec.get("kernel", ""):
+                        traffic = rec.get("hbm_bytes_per_launch")
+                        traffic_source = rec.get("source", "profiles/pmc_latest.json") + " (separate rocprofv3 --pmc passes, not this run; same kernel sources: sha256 " + rec["kernel_source_sha256"][:12] + ")"
+                    else:
+                        traffic_source = ("profiles/pmc_latest.json was counted on another build of the kernel (its kernel_source_sha256 differs from this tree's): "
+                                          "not quoted -- rerun tools/pmc_hbm_pass.sh + tools/pmc_latest.py")
             except Exception:
                 traffic = None
         # the VALU view (the kernel is issue-bound, so the HBM fraction alone says little): instruction counts

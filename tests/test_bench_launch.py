@@ -115,3 +115,13 @@ def test_secondary_cpu_baselines_are_the_native_monomorphised_legs():
         assert r["kind"] == kind and "-O3 -march=native" in r["flags"] and r["value"] > 0 and r["threads_pinned"]
         assert r["cores"] == bench.host_cpu_budget()["effective_cpus"]
         assert r["scalar_voice_value" if cfg == 2 else "tree_walk_value"] > 0
+
+
+def test_pmc_latest_is_quoted_only_for_the_kernel_it_was_counted_on():
+    """bench.py quotes profiles/pmc_latest.json as roofline.traffic only when the record carries the hash of the sources the headline
+    kernel is compiled from in THIS tree (the file silently went stale whenever the kernel changed)."""
+    import json
+
+    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    assert len(bench.headline_kernel_source_hash()) == 64
+    assert "k_render_pipe" in rec["kernel"] and len(rec.get("kernel_source_sha256", "")) == 64

@@ -4,8 +4,12 @@ per-launch HBM bytes of the headline kernel with the corrections MI355X_MICROARC
 tallies 128-B requests at 64 B -> x2; both counters in KB), calibrated on the 12.58 GB copy of the same pass.
 usage: tools/pmc_latest.py <tag> (reads profiles/<tag>_pmc_FETCH_SIZE.txt / _WRITE_SIZE.txt)"""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (headline_kernel_source_hash: the tree these counters were taken on)
 
 tag = sys.argv[1]
 
@@ -33,6 +37,7 @@ total = f[rk] * 1024 * round(fetch_scale) + w[rk] * 1024 * round(write_scale)
 rec = {
     "config": 3, "math": "exact", "voices": 65536, "frames": 48000,
     "kernel": rk[:160],
+    "kernel_source_sha256": bench.headline_kernel_source_hash(),
     "FETCH_SIZE_KB": f[rk], "WRITE_SIZE_KB": w[rk],
     "calibration": {"copy_bytes_per_dispatch": known, "copy_dispatches": f[ck + "#n"], "FETCH_SIZE_KB_copy": f[ck], "WRITE_SIZE_KB_copy": w[ck],
                     "fetch_scale_measured": round(fetch_scale, 4), "write_scale_measured": round(write_scale, 4)},
