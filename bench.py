@@ -221,16 +221,17 @@ def make_workload(F, W, torch, config, V, T, sr, first, layout, math, voice_out=
         bank = W.make_noise_biquad_bank(V, sr, voice0=first)
         n_out, bps, slot_bytes = 1, 4, 48          # noise generated in-kernel: 4 B/voice-sample out
         kernel = "fd::k_render_ts3<noise_biquad> (whole blocks, small banks: noise | biquad feed-forward half | recurrence) / fd::k_render_pipe / fd::k_render (ragged launches)"
-    elif config == 5:
+    elif config in (5, "5r4"):
         # 16 384 x reverb_stereo(10, 2, 0.5) over 8 GPUs = 2048 instances per GPU; stereo white noise resident in HBM;
-        # planar [instance][channel][frame] I/O (the kernel is lane = frame)
+        # planar [instance][channel][frame] I/O (the kernel is lane = frame).  "5r4": reverb4_stereo(20, 2) -- two 16-line networks in
+        # series (prelude.rs:1873-1941) -- through the same kernel family
         layout = F.LAYOUT_PLANAR
-        bank = F.Bank.reverb_stereo(V, 10.0, 2.0, 0.5)
+        bank = F.Bank.reverb_stereo(V, 10.0, 2.0, 0.5) if config == 5 else F.Bank.reverb4_stereo(V, 20.0, 2.0)
         bank.set_sample_rate(sr)
         g = torch.Generator(device="cuda").manual_seed(1234 + first)
         inp = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
         n_out, bps, slot_bytes = 2, 272, 512       # 32 ring reads + 32 ring writes + 2 in + 2 out, x 4 B
-        kernel = "fd::k_fdn_render_frames (lane = frame, one wave per instance)"
+        kernel = "fd::k_fdn_render_frames (lane = frame, one wave per instance)" + ("" if config == 5 else ", two 16-line networks in series")
     elif config == "4v":
         # config 4 in the reference's own gate shape: `var(gate) >> adsr_live` (examples/live_adsr.rs:72; SURVEY 8(d) `dc(gate)`): the gate is a
         # per-voice Var slot, read once per block like Var::process (shared.rs:122-125) -- the graph has NO input.  One step = one note per
@@ -475,7 +476,8 @@ def secondary(F, W, torch, sr, mode):
                                      ("4v", 32768, "config4_var_gate_math_fast", "Msamples/s", "fast"),
                                      (4, 32768, "config4_saw_moog_adsr_pan_32768", "Msamples/s", "exact"),
                                      (4, 32768, "config4_math_fast", "Msamples/s", "fast"),
-                                     (5, 2048, "config5_reverb_stereo_2048", "M instance-frames/s", "exact")):
+                                     (5, 2048, "config5_reverb_stereo_2048", "M instance-frames/s", "exact"),
+                                     ("5r4", 2048, "reverb4_stereo_2048", "M instance-frames/s", "exact")):
         T = 48000
         wl = make_workload(F, W, torch, cfg, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, math)
         ms, kms = quick(F, torch, wl, T, mode, steps=4, warmup=1)
@@ -485,7 +487,10 @@ def secondary(F, W, torch, sr, mode):
         shape = {"4v": " -- the reference's gate shape `var(gate) >> adsr_live` (examples/live_adsr.rs:72): no graph input, the step = two launches "
                        "(gate high 24000 frames, low 24000) with the Var slot set on the device in between; 8 B per voice-sample (stereo out)",
                  4: " -- the gate as an audio-rate HBM input stream [frames][voices] (hosts that modulate the gate per sample): 4 B in + 8 B out per voice-sample"}.get(cfg, "")
-        out.append({"name": name, "what": f"BASELINE config {str(cfg)[0]} per-GPU shard ({V} {'voices' if cfg != 5 else 'instances'} x {T} frames), {arith}{shape}",
+        what = (f"BASELINE config {str(cfg)[0]} per-GPU shard ({V} {'voices' if cfg != 5 else 'instances'} x {T} frames), {arith}{shape}" if cfg != "5r4" else
+                f"the other Hadamard FDN reverb of the reference, reverb4_stereo(20, 2) (prelude.rs:1873-1941: two fdn::<U16> in series), {V} instances x {T} frames "
+                "through the lane-per-frame FDN kernel generalised to networks in series; same 272 B per instance-frame (32 ring reads + 32 ring writes + 2 in + 2 out)")
+        out.append({"name": name, "what": what,
                     "ms_per_step": round(ms, 4), "kernel_ms_avg": round(kms, 4), "value": round(V * T / ms / 1e3, 1), "unit": unit,
                     "algorithmic_bytes_per_unit": wl["bps"], "roofline_frac": round(algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "kernel": wl["kernel"]})
@@ -511,7 +516,7 @@ def secondary(F, W, torch, sr, mode):
                 del mixbufs
             except Exception as e:
                 out[-1]["mode_b_fused_mix"] = {"error": repr(e)}
-        if math == "exact":
+        if math == "exact" and cfg != "5r4":
             try:
                 out[-1]["cpu_baseline"] = cpu_baseline_config(cfg, sr, T)
             except Exception as e:

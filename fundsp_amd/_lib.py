@@ -42,6 +42,8 @@ SYMBOLS = {
     "fdsp_bank_create": (_i, [_cs, _sz, C.POINTER(_P)]),
     "fdsp_bank_create_ring": (_i, [_cs, _sz, _sz, C.POINTER(_P)]),
     "fdsp_reverb_stereo_create": (_i, [_sz, _d, _d, _d, C.POINTER(_P)]),
+    "fdsp_reverb4_stereo_create": (_i, [_sz, _d, _d, C.POINTER(_P)]),
+    "fdsp_reverb4_stereo_create_on": (_i, [_i, _sz, _d, _d, C.POINTER(_P)]),
     "fdsp_device_count": (_i, []),
     "fdsp_bank_create_on": (_i, [_i, _cs, _sz, _sz, C.POINTER(_P)]),
     "fdsp_reverb_stereo_create_on": (_i, [_i, _sz, _d, _d, _d, C.POINTER(_P)]),

@@ -89,6 +89,13 @@ class Bank:
         check(lib().fdsp_reverb_stereo_create(int(instances), float(room_size), float(time), float(damping), C.byref(h)))
         return cls("reverb_stereo", instances, _handle=h)
 
+    @classmethod
+    def reverb4_stereo(cls, instances, room_size, time):
+        """Bank of `instances` x reverb4_stereo(room_size, time) (two 16-line FDNs in series, prelude.rs:1873-1941)."""
+        h = C.c_void_p()
+        check(lib().fdsp_reverb4_stereo_create(int(instances), float(room_size), float(time), C.byref(h)))
+        return cls("reverb4_stereo", instances, _handle=h)
+
     def clone(self):
         """AudioNode: Clone -- a new bank that continues exactly where this one stands (fdsp_bank_clone: slots, rings, sample
         rate, arithmetic mode, launch options, scheduler events, reverb state)."""

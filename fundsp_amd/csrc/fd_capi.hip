@@ -381,7 +381,8 @@ int build_default_table_set(int set) {
 
 }  // namespace
 
-struct FdnBank {  // reverb_stereo banks (fd_fdn.hip): rings + per-line state instead of the slot SoA
+struct FdnBank {  // reverb_stereo / reverb4_stereo banks (fd_fdn.hip): rings + per-line state instead of the slot SoA
+    int kind = 0;  // 0 = reverb_stereo(room, time, damping), 1 = reverb4_stereo(room, time)
     double room, time, damping;
     fd::FdnConst c;
     fd::FdnState st;
@@ -950,10 +951,13 @@ static void fdn_free(FdnBank* f) {
 static int fdn_configure(fdsp_bank* b, double sr) {
     FdnBank* f = b->fdn;
     fd::FdnConst c;
-    fd::fdn_make_const(f->room, f->time, f->damping, sr, &c);
+    if (f->kind == 1) fd::fdn_make_const_reverb4(f->room, f->time, sr, &c);
+    else fd::fdn_make_const(f->room, f->time, f->damping, sr, &c);
     for (int i = 0; i < 32; i++)
         if (c.len[i] <= 128)
-            return fail(FDSP_EINVAL, "reverb_stereo: every delay must exceed 128 samples (room_size * sample_rate too small)");
+            return fail(FDSP_EINVAL, "reverb_stereo / reverb4_stereo: every delay must exceed 128 samples (room_size * sample_rate too small)");
+    if (f->kind == 1 && c.cap > (1 << 18))
+        return fail(FDSP_EINVAL, "reverb4_stereo: delays of more than 2^18 samples (room_size * sample_rate too large for the lane-per-frame kernel)");
     const size_t n = b->V;
     fd::FdnState st{};
     hipError_t e = hipMalloc((void**)&st.rings, n * c.ring_stride * sizeof(float));
@@ -980,10 +984,21 @@ int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, d
     return fdsp_reverb_stereo_create_on(-1, instances, room_size, time, damping, out);
 }
 
+static int fdn_bank_create_on(int kind, int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out);
 int fdsp_reverb_stereo_create_on(int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out) {
+    return fdn_bank_create_on(0, device, instances, room_size, time, damping, out);
+}
+int fdsp_reverb4_stereo_create(size_t instances, double room_size, double time, fdsp_bank** out) {
+    return fdn_bank_create_on(1, -1, instances, room_size, time, 0.0, out);
+}
+int fdsp_reverb4_stereo_create_on(int device, size_t instances, double room_size, double time, fdsp_bank** out) {
+    return fdn_bank_create_on(1, device, instances, room_size, time, 0.0, out);
+}
+
+static int fdn_bank_create_on(int kind, int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out) {
     if (!out) return fail(FDSP_EINVAL, "out is NULL");
     *out = nullptr;
-    if (instances == 0 || !(room_size > 0.0) || !(time > 0.0)) return fail(FDSP_EINVAL, "bad reverb_stereo arguments");
+    if (instances == 0 || !(room_size > 0.0) || !(time > 0.0)) return fail(FDSP_EINVAL, "bad reverb_stereo / reverb4_stereo arguments");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(FDSP_EDEVICE, "no HIP device available: the fundsp_hip engine has no CPU fallback");
@@ -993,6 +1008,7 @@ int fdsp_reverb_stereo_create_on(int device, size_t instances, double room_size,
     fdsp_bank* b = new fdsp_bank();
     b->device = device;
     b->fdn = new FdnBank();
+    b->fdn->kind = kind;
     b->fdn->room = room_size;
     b->fdn->time = time;
     b->fdn->damping = damping;
@@ -1063,7 +1079,7 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
     fdsp_bank* b = nullptr;
     int rc;
     if (src->fdn)
-        rc = fdsp_reverb_stereo_create_on(src->device, src->V, src->fdn->room, src->fdn->time, src->fdn->damping, &b);
+        rc = fdn_bank_create_on(src->fdn->kind, src->device, src->V, src->fdn->room, src->fdn->time, src->fdn->damping, &b);
     else
         rc = fdsp_bank_create_on(src->device, src->ops->name.c_str(), src->V, src->ring_frames, &b);
     if (rc != FDSP_OK) return rc;
@@ -1331,8 +1347,8 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
     const bool timing = timing_on(b);
     if (!capturing && timing) HIPCHK(hipEventRecord(b->e0, s));
     resolve_opts(b);
-    if (b->fdn)  // Feedback::process is the per-sample tick (feedback.rs:136-146): both modes are the same arithmetic
-        fd::fdn_launch_render(b->fdn->c, b->fdn->st, b->V, d_in, d_out, frames, frame_stride, layout, s);
+    if (b->fdn)  // Feedback::process is the per-sample tick (feedback.rs:136-146): both modes are the same arithmetic but for reverb4_stereo's MultiJoin
+        fd::fdn_launch_render(b->fdn->c, b->fdn->st, b->V, d_in, d_out, frames, frame_stride, layout, mode == FDSP_MODE_TICK ? 1 : 0, s);
     else if (b->math == FDSP_MATH_FAST && b->ops->render_fast)
         b->ops->render_fast(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, b->aux, b->ring, b->ring_cap, s);
     else

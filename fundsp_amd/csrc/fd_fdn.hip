@@ -50,6 +50,52 @@ void fdn_make_const(double room_size, double time, double damping, double sample
     while (cap < maxlen) cap <<= 1;
     c->cap = cap;
     c->ring_stride = (size_t)32 * ((size_t)cap + 64);
+    c->sections = 1;
+    c->had_scale = (float)(1.0 / std::sqrt(32.0));
+    c->out_scale = (float)(1.0 / 16.0);
+}
+
+static const float RV4_DELAYS[32] = {  // prelude.rs:1875-1908 ("Optimized delay times from `optimize.rs` example. Fitness -4546.")
+    0.059326634f, 0.04778291f, 0.06995449f, 0.0393001f, 0.041604012f, 0.06215825f, 0.052269846f, 0.043227978f, 0.06966107f, 0.031615064f, 0.068442f,
+    0.037332155f, 0.032944717f, 0.034493037f, 0.06787566f, 0.038824916f, 0.068260126f, 0.068044715f, 0.0688076f, 0.066724524f, 0.051293883f, 0.06023173f,
+    0.040897705f, 0.031507637f, 0.060309593f, 0.049584292f, 0.04532072f, 0.056379095f, 0.035180368f, 0.041291796f, 0.046129026f, 0.05504605f,
+};
+
+void fdn_make_const_reverb4(double room_size, double time, double sample_rate, FdnConst* c) {
+    // reverb4_stereo :1909-1913: every delay (f32) *= max(room_size as f32, 15.0) / 10.0; reverb4_stereo_delays :1921-1922: room_size = 10.0,
+    // a = pow(db_amp(-60.0), 0.03 * room_size / 10.0 / time) as f32; lines delay(d as f64) >> fir((-a / 4, -a / 2, -a / 4)) :1924-1930
+    const double db_amp = std::exp((-60.0 / 20.0) * 2.302585092994046);
+    const float a = (float)std::pow(db_amp, 0.03 * 10.0 / 10.0 / time);
+    c->w[0] = -a / 4.0f;
+    c->w[1] = -a / 2.0f;
+    c->w[2] = -a / 4.0f;
+    const float rs = (float)room_size, scale = (rs > 15.0f ? rs : 15.0f) / 10.0f;
+    int maxlen = 0;
+    for (int i = 0; i < 32; i++) {
+        const float d = RV4_DELAYS[i] * scale;
+        const int delay = (int)std::round((double)d * sample_rate);  // Delay::new(d as f64), set_sample_rate delay.rs:108
+        c->len[i] = delay + 1;
+        maxlen = c->len[i] > maxlen ? c->len[i] : maxlen;
+        c->wl[i] = c->wr[i] = 0.0f;
+    }
+    for (int i = 0; i < 16; i++) {  // sumf::<U16>(|x| pan(lerp(-1.0, 1.0, smooth9(x)))) over the SECOND network's lines: x = i / 15
+        const float x = (float)((double)i / 15.0);
+        const float x2 = x * x;
+        const float t = ((((70.0f * x - 315.0f) * x + 540.0f) * x - 420.0f) * x + 126.0f) * x2 * x2 * x;
+        float p = -1.0f * (1.0f - t) + 1.0f * t;
+        p = p > -1.0f ? p : -1.0f;
+        p = p < 1.0f ? p : 1.0f;
+        const float angle = (p + 1.0f) * (F32_PI * 0.25f);
+        c->wl[16 + i] = cosf_musl(angle);
+        c->wr[16 + i] = sinf_musl(angle);
+    }
+    int cap = 256;
+    while (cap < maxlen) cap <<= 1;
+    c->cap = cap;
+    c->ring_stride = (size_t)32 * ((size_t)cap + 64);
+    c->sections = 2;
+    c->had_scale = (float)(1.0 / std::sqrt(16.0));
+    c->out_scale = (float)(1.0 / 4.0);
 }
 
 constexpr int TS = 65;  // LDS row stride (floats): lane-per-row access is bank-conflict free
@@ -123,7 +169,7 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
     const int cmask = c.cap - 1;
     const size_t cp = (size_t)c.cap + 64;
     const float w0 = c.w[0], w1 = c.w[1], w2 = c.w[2];
-    const float scale = (float)(1.0 / 5.656854249492381);  // (1.0 / sqrt(32 as f64)) as f32  feedback.rs:57
+    const float scale = c.had_scale;  // (1.0 / sqrt(N as f64)) as f32  feedback.rs:57
     uint32_t negmask[5];
 #pragma unroll
     for (int st = 0; st < 5; st++) negmask[st] = (k & (1 << st)) ? 0x80000000u : 0u;
@@ -284,10 +330,16 @@ constexpr int HS = 68;  // floats per history row: [0..1] carry-in, [2..65] this
 //   write of line k, frames 0..63:  rings[k * (C + 64) + w + lane]                           (when w + 64 <= C)
 // Blocks whose write window wraps (one in C / 64), or touches the first 64 slots (mirror copy), or is ragged (the last
 // block of a launch that is not a multiple of 64 frames) take the general per-lane path.
-template <int CAP_LOG2>
+// NSEC = 2 (reverb4_stereo): the 32 lines are TWO 16-line networks in series -- lines 0-15 take the input, their FIR outputs are averaged to
+// two channels (MultiJoin<U2, U8>) and split again (MultiSplit<U2, U8>) into lines 16-31, whose outputs are panned.  Nothing else changes: the
+// ring reads, FIR outputs and Hadamard feedback of BOTH networks are known at the head of the block (every delay is longer than 128
+// samples), the butterflies simply stop at stride 8, and the second network's ring write of frame n adds the join of the first one's FIR
+// outputs of the same frame.
+template <int CAP_LOG2, int NSEC>
 __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState s, size_t V, const float* __restrict__ in,
-                                                           float* __restrict__ out, size_t T, size_t fstride, int layout) {
+                                                           float* __restrict__ out, size_t T, size_t fstride, int layout, int tick_mode) {
     constexpr int C = 1 << CAP_LOG2, CMASK = C - 1, CP = C + 64;
+    constexpr int NL = 32 / NSEC;  // lines per network
     __shared__ float hist_all[4][32 * HS];  // per line: delay outputs d[n-2], d[n-1] | d[0..63]
     __shared__ float fbr_all[4][32 * HS];   // per line: fb[-1] | fb[0..63]
     __shared__ float sc_wl[32], sc_wr[32];  // pan weights: an LDS broadcast read per use (128 kernel-argument scalars
@@ -302,7 +354,7 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
     const size_t inst = (size_t)blockIdx.x * 4 + wib;
     if (inst >= V) return;
     const float w0 = c.w[0], w1 = c.w[1], w2 = c.w[2];
-    const float scale = (float)(1.0 / 5.656854249492381);  // (1.0 / sqrt(32 as f64)) as f32  feedback.rs:57
+    const float scale = c.had_scale;  // (1.0 / sqrt(N as f64)) as f32  feedback.rs:57
     // The instance's rings as a buffer resource: buffer_load / buffer_store take a VGPR offset (lane * 4, the same for
     // every access), an SGPR offset (the line's base + the block's slot, scalar arithmetic) and no 64-bit VALU address math.
     const __amdgpu_buffer_rsrc_t rings = __builtin_amdgcn_make_buffer_rsrc(s.rings + inst * c.ring_stride, 0, (int)(c.ring_stride * sizeof(float)), 0x00020000);
@@ -355,9 +407,9 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
             o[k] = acc;
             h[k] = acc;
         }
-        // FrameHadamard feedback.rs:35-57: in-place butterflies h = 1, 2, 4, 8, 16; (x, y) -> (x + y, x - y)
+        // FrameHadamard feedback.rs:35-57: in-place butterflies h = 1, 2, 4, 8 (, 16); (x, y) -> (x + y, x - y), within each network
 #pragma unroll
-        for (int st = 1; st < 32; st <<= 1)
+        for (int st = 1; st < NL; st <<= 1)
 #pragma unroll
             for (int i = 0; i < 32; i++)
                 if ((i & st) == 0) {
@@ -369,9 +421,27 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
 #pragma unroll
         for (int k = 0; k < 32; k++) fbr[k * HS + 1 + lane] = h[k] * scale;
         fdn_wave_sync();
-        float xw[32];  // MultiSplit<U2,U16>: line k takes input channel k % 2 (audionode.rs:600); Feedback::tick: input + value
+        float xw[32];  // MultiSplit<U2, N/2>: line k takes input channel k % 2 (audionode.rs:600); Feedback::tick: input + value
 #pragma unroll
-        for (int k = 0; k < 32; k++) xw[k] = ((k & 1) ? xi1 : xi0) + fbr[k * HS + lane];
+        for (int k = 0; k < NL; k++) xw[k] = ((k & 1) ? xi1 : xi0) + fbr[k * HS + lane];
+        if constexpr (NSEC == 2) {
+            // MultiJoin<U2, U8> of the first network's 16 outputs -> 2 channels -> MultiSplit<U2, U8> into the second network.
+            // process(): every term scaled by z = 1/8, then added (audionode.rs:706-720); tick(): the sum, divided by 8 (:697-705)
+            float j0, j1;
+            if (tick_mode) {
+                j0 = o[0]; j1 = o[1];
+#pragma unroll
+                for (int i = 1; i < 8; i++) { j0 += o[2 * i]; j1 += o[2 * i + 1]; }
+                j0 = j0 / 8.0f; j1 = j1 / 8.0f;
+            } else {
+                const float z = 1.0f / 8.0f;
+                j0 = o[0] * z; j1 = o[1] * z;
+#pragma unroll
+                for (int i = 1; i < 8; i++) { j0 += o[2 * i] * z; j1 += o[2 * i + 1] * z; }
+            }
+#pragma unroll
+            for (int k = NL; k < 32; k++) xw[k] = ((k & 1) ? j1 : j0) + fbr[k * HS + lane];
+        }
         if (size == 64 && wp >= 64 && wp + 64 <= C) {  // the common block: one scalar offset per line
 #pragma unroll
             for (int k = 0; k < 32; k++)
@@ -385,15 +455,15 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xw[k]), rings, (C + pos) * 4, k * CP * 4, 0);
             }
         }
-        float l = 0.0f, rr = 0.0f;  // Reduce::tick left fold (audionode.rs:2427-2439) of the 32 Panner outputs
+        float l = 0.0f, rr = 0.0f;  // Reduce::tick left fold (audionode.rs:2427-2439) of the Panner outputs of the LAST network's lines
 #pragma unroll
-        for (int k = 0; k < 32; k++) {
+        for (int k = 32 - NL; k < 32; k++) {
             const float pl = sc_wl[k] * o[k], pr = sc_wr[k] * o[k];
-            l = k == 0 ? pl : l + pl;
-            rr = k == 0 ? pr : rr + pr;
+            l = k == 32 - NL ? pl : l + pl;
+            rr = k == 32 - NL ? pr : rr + pr;
         }
-        l *= (float)(1.0 / 16.0);  // * dc((1/16, 1/16))
-        rr *= (float)(1.0 / 16.0);
+        l *= c.out_scale;  // * dc((1/16, 1/16)) | * dc((1/4, 1/4))
+        rr *= c.out_scale;
         if (lane < size) {
             if (layout == 0) {
                 out[((size_t)0 * T + t0 + lane) * V + inst] = l;
@@ -427,17 +497,23 @@ void fdn_launch_reset(const FdnConst& c, const FdnState& s, size_t instances, hi
 }
 
 void fdn_launch_render(const FdnConst& c, const FdnState& s, size_t instances, const float* in, float* out, size_t T,
-                       size_t fstride, int layout, hipStream_t stream) {
+                       size_t fstride, int layout, int tick_mode, hipStream_t stream) {
     if (instances == 0 || T == 0) return;
-    tl_opts.last_kernel = tl_opts.fdn_kernel == 0 ? LK_FDN_FRAMES : LK_FDN_LINES;
-    if (tl_opts.fdn_kernel == 0) {
+    const bool frames = tl_opts.fdn_kernel == 0 || c.sections == 2;  // (two networks in series: the lane = frame formulation only)
+    tl_opts.last_kernel = frames ? LK_FDN_FRAMES : LK_FDN_LINES;
+    if (frames) {
         const dim3 grid((unsigned)((instances + 3) / 4)), block(256);
         switch (c.cap) {  // the ring capacity is a template parameter of the lane = frame kernel
-#define FD_FDN_CASE(L) case 1 << L: hipLaunchKernelGGL(k_fdn_render_frames<L>, grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout); break;
+#define FD_FDN_CASE(L)                                                                                                                                     \
+    case 1 << L:                                                                                                                                           \
+        if (c.sections == 2) hipLaunchKernelGGL((k_fdn_render_frames<L, 2>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode); \
+        else hipLaunchKernelGGL((k_fdn_render_frames<L, 1>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode);                 \
+        break;
             FD_FDN_CASE(8) FD_FDN_CASE(9) FD_FDN_CASE(10) FD_FDN_CASE(11) FD_FDN_CASE(12) FD_FDN_CASE(13) FD_FDN_CASE(14)
             FD_FDN_CASE(15) FD_FDN_CASE(16) FD_FDN_CASE(17) FD_FDN_CASE(18)
 #undef FD_FDN_CASE
-        default:  // longer than 2^18 slots (5.4 s at 48 kHz): the lane = line kernel takes any capacity
+        default:  // longer than 2^18 slots (5.4 s at 48 kHz): the lane = line kernel takes any capacity (reverb_stereo; fdn_configure
+                  // refuses such a reverb4_stereo)
             hipLaunchKernelGGL(k_fdn_render<1>, grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout);
         }
     } else if ((instances + 1) / 2 < 2 * (size_t)simd_count()) {

@@ -1,4 +1,5 @@
-// fd_fdn.hpp -- the 32-line feedback delay network of FunDSP's reverb_stereo (BASELINE config 5).
+// fd_fdn.hpp -- the Hadamard feedback delay networks of FunDSP's reverbs: reverb_stereo (BASELINE config 5: one 32-line network) and
+// reverb4_stereo (two 16-line networks in series), both `fdn::<N>(stacki(|i| delay(d_i) >> fir(w)))` shapes (prelude.rs:1336).
 //
 // Reference: prelude.rs:1732-1762 builds
 //     multisplit::<U2,U16>() >> fdn::<U32>(stacki(|i| delay(DELAYS[i]*room/10) >> fir(weights)))
@@ -31,10 +32,14 @@ namespace fd {
 // consecutive reads starting anywhere in [0, C) never wrap; a block's 64 consecutive writes wrap once in C / 64 blocks.
 // That makes the ring addresses of a block SCALAR (base + one wave-uniform offset + lane): no per-lane index arithmetic.
 struct FdnConst {            // uniform over the bank (all instances share room / time / damping)
+    int sections;            // 1: reverb_stereo (one 32-line FDN); 2: reverb4_stereo (two 16-line FDNs in series, lines 0-15 | 16-31)
+    float had_scale;         // (1.0 / sqrt(lines per section as f64)) as f32   feedback.rs:57
+    float out_scale;         // the `* dc((s, s))` behind the pan fold: 1/16 (reverb_stereo), 1/4 (reverb4_stereo)
     int len[32];             // Delay ring length of the reference = delay in samples + 1  (delay.rs:108-110)
     int cap;                 // C: slots per ring (power of two); rings are cap + 64 floats apart
     float w[3];              // FIR weights: fir3(1 - damping).weights() * a  (prelude.rs:1746-1747)
-    float wl[32], wr[32];    // pan weights of the 32 output panners (prelude.rs:1759, pan.rs:13-17)
+    float wl[32], wr[32];    // pan weights of the output panners (prelude.rs:1759, pan.rs:13-17), indexed by the LINE they pan: all 32
+                             // (reverb_stereo) or lines 16-31, the second network's (reverb4_stereo: sumf::<U16>)
     size_t ring_stride;      // floats per instance = 32 * (cap + 64)
 };
 
@@ -49,7 +54,12 @@ struct FdnState {
 // host: constants of reverb_stereo(room_size, time, damping) at `sample_rate` (prelude.rs:1739-1759)
 void fdn_make_const(double room_size, double time, double damping, double sample_rate, FdnConst* c);
 void fdn_launch_reset(const FdnConst& c, const FdnState& s, size_t instances, hipStream_t stream);
+// host: constants of reverb4_stereo(room_size, time) at `sample_rate` (prelude.rs:1873-1941): two fdn::<U16> of delay >> fir3 lines in
+// series, `multijoin::<U2, U8>() >> multisplit::<U2, U8>()` between them, sumf::<U16>(pan) * dc((1/4, 1/4)) behind the second
+void fdn_make_const_reverb4(double room_size, double time, double sample_rate, FdnConst* c);
+// tick_mode: MultiJoin::tick sums and divides, MultiJoin::process scales every term first (audionode.rs:697-720) -- the only place where
+// the two executors of these graphs differ in arithmetic (reverb4_stereo; reverb_stereo has no join)
 void fdn_launch_render(const FdnConst& c, const FdnState& s, size_t instances, const float* in, float* out, size_t T,
-                       size_t fstride, int layout, hipStream_t stream);
+                       size_t fstride, int layout, int tick_mode, hipStream_t stream);
 
 }  // namespace fd

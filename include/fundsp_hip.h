@@ -186,6 +186,12 @@ int fdsp_bank_create_ring(const char* kind, size_t voices, size_t ring_frames, f
  * denormals like the reference does after Feedback::new (src/feedback.rs:96, src/denormal.rs:18).  The handle works
  * with set_sample_rate / reset / process / clone / destroy. */
 int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, double damping, fdsp_bank** out);
+/* reverb4_stereo(room_size, time) (src/prelude.rs:1873-1941): TWO 16-line Hadamard networks in series --
+ * multisplit::<U2,U8>() >> fdn(16 x delay >> fir3) >> multijoin::<U2,U8>() >> multisplit::<U2,U8>() >> fdn(16 x delay >> fir3)
+ * >> sumf::<U16>(pan) * dc((1/4, 1/4)) -- through the same lane-per-frame kernel (both networks' ring reads, FIR outputs and feedback
+ * are known at the head of a block; 272 B per instance-frame as well).  FDSP_MODE_PROCESS / FDSP_MODE_TICK differ in MultiJoin's
+ * arithmetic exactly like the reference (src/audionode.rs:697-720).  Same handle semantics as reverb_stereo banks; "fdn_kernel" is ignored. */
+int fdsp_reverb4_stereo_create(size_t instances, double room_size, double time, fdsp_bank** out);
 /* Several GPUs from one process.  A bank lives on ONE device, fixed at creation: the `_on` constructors take the HIP
  * device index (-1 = the calling thread's current device, which is what the constructors above use).  Every entry point
  * that takes a bank makes the bank's device current for its own duration and restores the caller's, so a host thread
@@ -195,6 +201,7 @@ int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, d
 int fdsp_device_count(void);
 int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring_frames, fdsp_bank** out);
 int fdsp_reverb_stereo_create_on(int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out);
+int fdsp_reverb4_stereo_create_on(int device, size_t instances, double room_size, double time, fdsp_bank** out);
 int fdsp_bank_device(const fdsp_bank* bank);
 void fdsp_bank_destroy(fdsp_bank* bank);
 /* `Clone` (every AudioNode is Clone, src/audionode.rs:35; Net and Sequencer clone their units): a new bank of the same

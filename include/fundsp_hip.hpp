@@ -517,6 +517,13 @@ class Bank {
         b.kind_ = "reverb_stereo";
         return b;
     }
+    // reverb4_stereo(room_size, time) (prelude.rs:1873-1941): two 16-line FDNs in series, the same kernel family
+    static Bank reverb4_stereo(size_t instances, double room_size, double time) {
+        Bank b;
+        check(fdsp_reverb4_stereo_create(instances, room_size, time, &b.h_));
+        b.kind_ = "reverb4_stereo";
+        return b;
+    }
     Bank(Bank&& o) noexcept { *this = std::move(o); }
     Bank& operator=(Bank&& o) noexcept {
         if (this != &o) {

@@ -148,3 +148,27 @@ def test_config5_full_size(gpu):
     a = b2.process(1000, x[:, :, :1000].contiguous(), layout=LAYOUT_PLANAR, frame_stride=1000)   # ragged chunk
     b = b2.process(T - 1000, x[:, :, 1000:].contiguous(), layout=LAYOUT_PLANAR, frame_stride=T - 1000)
     assert torch.equal(out[:, :, :1000], a) and torch.equal(out[:, :, 1000:], b)
+
+
+def test_reverb4_stereo_full_size(gpu):
+    """reverb4_stereo(20, 2) at config 5's sizes (2048 instances x 48 000 frames) through the lane-per-frame FDN kernel (two 16-line
+    networks in series): spot instances vs the oracle's generic Feedback graph, chunked == whole."""
+    import torch
+
+    V, T = 2048, 48000
+    bank = gpu.Bank.reverb4_stereo(V, 20.0, 2.0)
+    bank.set_sample_rate(SR)
+    g = torch.Generator(device="cuda").manual_seed(199)
+    x = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
+    out = bank.process(T, x, layout=LAYOUT_PLANAR, frame_stride=T)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all()) and float(out.abs().max()) > 0.1
+    for v in (0, 1, 1027, V - 1):
+        n = O.reverb4_stereo(20.0, 2.0)
+        n.set_sample_rate(SR)
+        assert_bit_equal(out[v].cpu().numpy(), n.render_blocks(x[v].cpu().numpy()), f"reverb4_stereo full size, instance {v}")
+    b2 = gpu.Bank.reverb4_stereo(V, 20.0, 2.0)
+    b2.set_sample_rate(SR)
+    a = b2.process(64 * 100, x[:, :, :6400].contiguous(), layout=LAYOUT_PLANAR, frame_stride=6400)
+    b = b2.process(T - 6400, x[:, :, 6400:].contiguous(), layout=LAYOUT_PLANAR, frame_stride=T - 6400)
+    assert torch.equal(out[:, :, :6400], a) and torch.equal(out[:, :, 6400:], b)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from fundsp_amd import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS
+from fundsp_amd import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS, MODE_TICK
 from test_gpu_parity import assert_bit_equal
 
 pytestmark = pytest.mark.gpu
@@ -72,3 +72,49 @@ def test_reverb_chunked_calls_reset_and_other_rooms(gpu, fdn_kernel):
 def test_reverb_rejects_tiny_delays(gpu):
     with pytest.raises(gpu.FdspError):
         gpu.Bank.reverb_stereo(1, 0.1, 2.0, 0.5)  # 10 cm room: delays shorter than a 64-sample block
+
+
+@pytest.mark.parametrize("mode", [MODE_PROCESS, MODE_TICK])
+@pytest.mark.parametrize("layout", [LAYOUT_PLANAR, LAYOUT_VOICE_MINOR])
+def test_reverb4_stereo_bank_matches_oracle(gpu, layout, mode):
+    """reverb4_stereo(room_size, time) (prelude.rs:1873-1941) -- two 16-line Hadamard FDNs in series with a MultiJoin / MultiSplit between
+    them -- through the lane-per-frame FDN kernel (fdsp_reverb4_stereo_create): bit-exact against the oracle's generic Feedback graph in
+    both executors (MultiJoin::process scales every term, ::tick divides the sum: audionode.rs:697-720), ragged launch lengths, a silent
+    tail (the feedback decays into the flush-to-zero range), state carried across launches, clone."""
+    import torch
+
+    V, T = 6, 64 * 200 + 13                                       # (the first sound leaves the second network after >= 94 ms = 4 500 frames)
+    rng = np.random.default_rng(17)
+    x = (rng.random((V, 2, T), dtype=np.float32) * 2 - 1).astype(np.float32)
+    x[:, :, 2 * T // 3:] = 0.0
+    x[1] *= 1e-30                                                   # an instance that lives in the denormal range from the start
+    b = gpu.Bank.reverb4_stereo(V, 20.0, 2.0)
+    b.set_sample_rate(SR)
+    assert b.inputs() == 2 and b.outputs() == 2
+    cuts = [0, 64 * 20, 64 * 20 + 7, 64 * 150 + 7, T]              # a ragged launch in the middle: the next one starts a new block
+    parts = []
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        n = e - a
+        if layout == LAYOUT_PLANAR:
+            xi = torch.from_numpy(np.ascontiguousarray(x[:, :, a:e])).cuda()
+            parts.append(b.process(n, xi, layout=layout, frame_stride=n, mode=mode).cpu().numpy())
+        else:
+            xi = torch.from_numpy(np.ascontiguousarray(x[:, :, a:e].transpose(1, 2, 0))).cuda()
+            parts.append(b.process(n, xi, layout=layout, mode=mode).cpu().numpy().transpose(2, 0, 1))
+        if a == 0:
+            c = b.clone()
+    got = np.concatenate(parts, axis=2)
+    assert b.get_option("last_kernel") == 6
+    for v in range(V):
+        n = O.reverb4_stereo(20.0, 2.0)
+        n.set_sample_rate(SR)
+        want = []
+        for a, e in zip(cuts[:-1], cuts[1:]):
+            want.append(n.render_blocks(x[v][:, a:e]) if mode == MODE_PROCESS else n.render_ticks(x[v][:, a:e]))
+        assert_bit_equal(got[v], np.concatenate(want, axis=1), f"reverb4_stereo instance {v}")
+    assert np.abs(got[0]).max() > 0.01 and np.abs(got[:, :, :4000]).max() == 0.0
+    # the clone taken after the first launch continues exactly like the original
+    a, e = cuts[1], cuts[2]
+    xi = torch.from_numpy(np.ascontiguousarray(x[:, :, a:e])).cuda()
+    cc = c.process(e - a, xi, layout=LAYOUT_PLANAR, frame_stride=e - a, mode=mode).cpu().numpy()
+    assert_bit_equal(cc, got[:, :, a:e], "clone")
