@@ -313,7 +313,7 @@ def secondary(F, W, torch, sr, mode):
     ms, kms = quick(F, torch, wl, T, mode)
     algo = V * T * 4 + V * 64
     out.append({"name": "config3_math_fast", "what": "the headline workload in tolerance mode (FDSP_MATH_FAST: FMA sine polynomial, "
-                "recurrences exact; within 1e-4 of the exact mode over 441 samples, 1e-3 max / 5e-5 rms over the full second: tests/test_gpu_math_fast.py)", "ms_per_step": round(ms, 4),
+                "recurrences exact; within 1e-4 of the exact mode over 441 samples; over the full second asserted <= 1e-3 max / 5e-5 rms, measured 2.6e-4 / 1.2e-5: tests/test_gpu_math_fast.py)", "ms_per_step": round(ms, 4),
                 "kernel_ms_avg": round(kms, 4), "value": round(V * T / ms / 1e3, 1), "unit": "Msamples/s",
                 "roofline_frac": round(algo / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
     del wl
@@ -389,7 +389,28 @@ def secondary(F, W, torch, sr, mode):
         c2["voices_65536"] = {"voices": Vb, "T": Tb, "us_per_launch": round(ms * 1e3, 2), "kernel_us": round(kms * 1e3, 2), "value": round(Vb * Tb / ms / 1e3, 1),
                               "last_kernel": wl["bank"].get_option("last_kernel"),
                               "roofline_frac": round((Vb * Tb * 4 + Vb * 48) / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        del wl
+        # ... and that bank at the config's own block size, one 64-frame block per launch replayed from a HIP graph: the launch that costs the
+        # 1024-voice bank the comparison carries 64 x the voices here
+        NB = 16
+        outs = [torch.empty((1, 64, Vb), dtype=torch.float32, device="cuda") for _ in range(NB)]
+        s_ = torch.cuda.Stream()
+        with torch.cuda.stream(s_):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s_):
+                for kk in range(NB):
+                    wl["bank"].process(64, None, outs[kk], layout=wl["layout"], mode=mode)
+            g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                g.replay()
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) / 20 / NB * 1e6
+        c2["voices_65536"]["T64_hip_graph_replay_us_per_launch"] = round(us, 2)
+        c2["voices_65536"]["T64_hip_graph_value"] = round(Vb * 64 / us, 1)
+        if cpu:
+            c2["voices_65536"]["T64_gpu_over_cpu"] = round(Vb * 64 / us / cpu, 2)
+        del g, outs, wl
     except Exception as e:
         c2["voices_65536"] = {"error": repr(e)}
     out.append(c2)
