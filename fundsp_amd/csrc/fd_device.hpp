@@ -938,6 +938,48 @@ struct Seg<BiquadT<NODE_ID>, A, B, HEAD> {
         w.on = FB; w.f(g.y1, STATE, "y1"); w.f(g.y2, STATE, "y2");
     }
 };
+// The FIXED forms of the filters that hold a Biquad (butterpass_hz(f), resonator_hz(f, q): coefficients derived once, biquad.rs:227-380) cut
+// the same way -- the holder's own parameters travel with the recurrence half.  (The forms with a cutoff / centre input stay one stage: an input
+// may move the coefficients at any sample.)
+template <class G, int A, int B>
+struct HeldBiquadSeg {
+    using BS = Seg<Biquad, A, B, false>;
+    static constexpr bool FF = BS::FF, FB = BS::FB;
+    static constexpr int IN = 1, OUT = 1, cost = BS::cost, weight = BS::weight;
+    static constexpr bool USES_GIN = false, HAS_SKIP = BS::HAS_SKIP;
+    template <int PH> static FD_D void step2(G& g, const v2f* in, const v2f* gin, v2f* out) {
+        if constexpr (FF && FB) g.template step2<PH>(in, out); else BS::template step2<PH>(g.b, in, gin, out);
+    }
+    template <int PH> static FD_D void step(G& g, const float* in, const float* gin, float* out) {
+        if constexpr (FF && FB) g.template step<PH>(in, out); else BS::template step<PH>(g.b, in, gin, out);
+    }
+    template <int PH> static FD_D void skip2(G& g, const v2f* in) { BS::template skip2<PH>(g.b, in); }
+    template <int PH> static FD_D void skip(G& g, const float* in) { BS::template skip<PH>(g.b, in); }
+    static FD_D void begin(G&, int) {}
+    static FD_D void end(G&) {}
+    static FD_D bool tripped(const G&) { return false; }
+};
+template <bool HEAD> struct Chain<ButterLowpass<1>, HEAD> { static constexpr int N = 2; };
+template <bool HEAD> struct Chain<Resonator<1>, HEAD> { static constexpr int N = 2; };
+template <int A, int B, bool HEAD>
+struct Seg<ButterLowpass<1>, A, B, HEAD> : HeldBiquadSeg<ButterLowpass<1>, A, B> {
+    using H = HeldBiquadSeg<ButterLowpass<1>, A, B>;
+    template <class W> static FD_D void visit(ButterLowpass<1>& g, W& w) {  // ButterLowpass::visit order
+        w.on = H::FB; w.f(g.cutoff, PARAM, "cutoff"); w.f(g.sr, COEF, "sample_rate"); w.f(g.b.a1, COEF, "a1"); w.f(g.b.a2, COEF, "a2");
+        w.on = H::FF; w.f(g.b.b0, COEF, "b0"); w.f(g.b.b1, COEF, "b1"); w.f(g.b.b2, COEF, "b2"); w.f(g.b.x1, STATE, "x1"); w.f(g.b.x2, STATE, "x2");
+        w.on = H::FB; w.f(g.b.y1, STATE, "y1"); w.f(g.b.y2, STATE, "y2");
+    }
+};
+template <int A, int B, bool HEAD>
+struct Seg<Resonator<1>, A, B, HEAD> : HeldBiquadSeg<Resonator<1>, A, B> {
+    using H = HeldBiquadSeg<Resonator<1>, A, B>;
+    template <class W> static FD_D void visit(Resonator<1>& g, W& w) {  // Resonator::visit order
+        w.on = H::FB; w.f(g.center, PARAM, "center"); w.f(g.q, PARAM, "q"); w.f(g.sr, COEF, "sample_rate"); w.f(g.b.a1, COEF, "a1"); w.f(g.b.a2, COEF, "a2");
+        w.on = H::FF; w.f(g.b.b0, COEF, "b0"); w.f(g.b.b1, COEF, "b1"); w.f(g.b.b2, COEF, "b2"); w.f(g.b.x1, STATE, "x1"); w.f(g.b.x2, STATE, "x2");
+        w.on = H::FB; w.f(g.b.y1, STATE, "y1"); w.f(g.b.y2, STATE, "y2");
+    }
+};
+static_assert(Chain<Pipe<Noise, ButterLowpass<1>>>::N == 3 && Chain<Pipe<Noise, Resonator<1>>>::N == 3 && Chain<ButterLowpass<2>>::N == 1, "the fixed biquad holders cut like the biquad");
 template <class X, class Y, int A, int B, bool HEAD>
 struct Seg<Pipe<X, Y>, A, B, HEAD> {
     using G = Pipe<X, Y>;

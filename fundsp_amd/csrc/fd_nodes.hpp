@@ -684,7 +684,9 @@ struct BiquadBank {
     template <int PH> FD_HD void step(const float* in, float* out) {
         _Pragma("unroll") for (int i = 0; i < 8; i++) out[i] = lane[i].tick(in[i]);
     }
-    FD_STEP2_VIA_STEP
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {  // every lane: packed feed-forward half, then its two recurrence steps
+        _Pragma("unroll") for (int i = 0; i < 8; i++) lane[i].template step2<PH>(in + i, out + i);
+    }
 };
 
 // ButterLowpass<f32, N>  biquad.rs:227-300 (ID 16), N = 1 (fixed) or 2 (cutoff input)
@@ -724,7 +726,17 @@ struct ButterLowpass {
         }
         out[0] = b.tick(in[0]);
     }
-    FD_STEP2_VIA_STEP
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        if constexpr (NIN == 1) {  // fixed coefficients: the biquad's own packed form (feed-forward half as one <2 x float> computation)
+            b.template step2<PH>(in, out);
+        } else {                   // a cutoff input may move the coefficients between the two frames
+            float i0[NIN], i1[NIN], o0, o1;
+            _Pragma("unroll") for (int c = 0; c < NIN; c++) { i0[c] = in[c].x; i1[c] = in[c].y; }
+            this->template step<PH>(i0, &o0);
+            this->template step<PH>(i1, &o1);
+            out[0] = v2f{o0, o1};
+        }
+    }
 };
 
 // Resonator<f32, N>  biquad.rs:310-380 (ID 17), N = 1 (fixed) or 3 (center, q inputs)
@@ -766,7 +778,17 @@ struct Resonator {
         }
         out[0] = b.tick(in[0]);
     }
-    FD_STEP2_VIA_STEP
+    template <int PH> FD_HD void step2(const v2f* in, v2f* out) {
+        if constexpr (NIN == 1) {  // fixed coefficients: the biquad's own packed form
+            b.template step2<PH>(in, out);
+        } else {
+            float i0[NIN], i1[NIN], o0, o1;
+            _Pragma("unroll") for (int c = 0; c < NIN; c++) { i0[c] = in[c].x; i1[c] = in[c].y; }
+            this->template step<PH>(i0, &o0);
+            this->template step<PH>(i1, &o1);
+            out[0] = v2f{o0, o1};
+        }
+    }
 };
 
 // Moog<f32, N>  moog.rs:17-117 (ID 60).  N = 1 (fixed cutoff/q) or 3 (audio, cutoff Hz, Q inputs; the

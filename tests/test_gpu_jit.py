@@ -335,3 +335,37 @@ def test_jit_pipeline_kernel_matches_single_wave(gpu):
         gpu.lib().fdsp_set_option(b"pipe_split", 1)
         for a, c in zip(*outs):
             assert_bit_equal(a, c, "jit pipeline vs single wave")
+
+
+@pytest.mark.parametrize("name", ["butterpass_hz", "resonator_hz", "biquad"])
+def test_jit_fixed_biquad_holders_cut_at_the_seam(gpu, name):
+    """butterpass_hz(f) / resonator_hz(c, q) / biquad(..) behind a generator: the held DF1 biquad is a chain of two stages (feed-forward half |
+    recurrence, fd_device.hpp HeldBiquadSeg), so `noise() >> filter` has three chain stages.  Every plan renders the oracle's samples: the
+    best plan, exactly two stages, exactly three (noise | feed-forward half | recurrence), the single-wave kernel; ragged launch, state carry."""
+    V, T = 64 * 3 + 11, 64 * 7 + 5
+    build = {"butterpass_hz": lambda m: m.noise() >> m.butterpass_hz(900.0),
+             "resonator_hz": lambda m: m.noise() >> m.resonator_hz(700.0, 120.0),
+             "biquad": lambda m: m.noise() >> m.biquad(-1.2, 0.5, 0.2, 0.3, 0.1)}[name]
+    want = []
+    for v in range(0, V, 13):
+        n = build(O)
+        n.set_sample_rate(SR)
+        n.set_seed(v)
+        want.append(np.concatenate([n.render_blocks(length=T), n.render_blocks(length=64)], axis=1))
+    outs = []
+    for flag in (1, 2, 3, 0):
+        assert gpu.lib().fdsp_set_option(b"pipe_split", flag) == 0
+        try:
+            b = gpu.Bank.from_graph(build(GR), V, sample_rate=SR)
+            b.set_seed(np.arange(V, dtype=np.uint64))
+            a = run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+            c = run_bank(b, None, 64, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+            outs.append(np.concatenate([a, c], axis=2))
+            if flag in (0, 2, 3):
+                assert b.get_option("last_kernel") == (1 if flag == 0 else 2), (name, flag)
+        finally:
+            gpu.lib().fdsp_set_option(b"pipe_split", 1)
+    for k, v in enumerate(range(0, V, 13)):
+        assert_bit_equal(outs[0][v], want[k], f"{name} voice {v} vs oracle")
+    for o in outs[1:]:
+        assert_bit_equal(o, outs[0], f"{name}: every stage plan renders the same samples")
