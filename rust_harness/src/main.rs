@@ -167,6 +167,63 @@ fn golden(out_dir: &Path) {
         }
     }
 
+    // ---- config 4: 16 subtractive voices `((dc(f) >> saw() | dc(fc) | dc(q)) >> moog()) * ENV >> pan(p)`, adsr_live(0.005, 0.01, 0.6, 0.01),
+    //      in both gate shapes: ENV = adsr_live(..) fed by the graph's input (a gate stream), and the reference's own
+    //      ENV = var(&gate) >> adsr_live(..) (examples/live_adsr.rs:72) with the shared variable set between the entries of a plan
+    //      (value, frames) -- every entry starts a new block, exactly like separate process() calls
+    {
+        let f = read_f32(&inputs.join("config4_f.f32"));
+        let fc = read_f32(&inputs.join("config4_fc.f32"));
+        let q = read_f32(&inputs.join("config4_q.f32"));
+        let pan_p = read_f32(&inputs.join("config4_pan.f32"));
+        let seed = read_u64(&inputs.join("config4_seed.u64"));
+        let gate = read_f32(&inputs.join("config4_gate.f32"));
+        let plan = read_f32(&inputs.join("config4_plan.f32")); // value, frames, value, frames, ..
+        let (v_n, t_n) = (f.len(), gate.len());
+        for (tag, process) in [("process", true), ("tick", false)] {
+            let mut all = Vec::with_capacity(v_n * 2 * t_n);
+            for v in 0..v_n {
+                let mut g = ((dc(f[v]) >> saw() | dc(fc[v]) | dc(q[v])) >> moog()) * adsr_live(0.005, 0.01, 0.6, 0.01) >> pan(pan_p[v]);
+                g.set_sample_rate(SR);
+                g.set_seed(seed[v]);
+                all.extend_from_slice(&flatten(&render(&mut g, &[gate.clone()], t_n, process)));
+            }
+            write_npy(&out_dir.join(format!("config4_stream_{tag}.npy")), v_n * 2, t_n, &all);
+            let t_plan: usize = plan.chunks(2).map(|e| e[1] as usize).sum();
+            let mut all = Vec::with_capacity(v_n * 2 * t_plan);
+            for v in 0..v_n {
+                let control = shared(0.0);
+                let mut g = ((dc(f[v]) >> saw() | dc(fc[v]) | dc(q[v])) >> moog()) * (var(&control) >> adsr_live(0.005, 0.01, 0.6, 0.01)) >> pan(pan_p[v]);
+                g.set_sample_rate(SR);
+                g.set_seed(seed[v]);
+                let mut ch: Vec<Vec<f32>> = vec![Vec::new(), Vec::new()];
+                for e in plan.chunks(2) {
+                    control.set_value(e[0]);
+                    let y = render(&mut g, &[], e[1] as usize, process);
+                    ch[0].extend_from_slice(&y[0]);
+                    ch[1].extend_from_slice(&y[1]);
+                }
+                all.extend_from_slice(&flatten(&ch));
+            }
+            write_npy(&out_dir.join(format!("config4_var_{tag}.npy")), v_n * 2, t_plan, &all);
+        }
+    }
+
+    // ---- config 5 and its sibling: reverb_stereo(10, 2, 0.5) and reverb4_stereo(20, 2) on a fixed stereo noise input
+    {
+        let flat = read_f32(&inputs.join("config5_in.f32"));
+        let t_n = flat.len() / 2;
+        let x = vec![flat[..t_n].to_vec(), flat[t_n..].to_vec()];
+        for (tag, process) in [("process", true), ("tick", false)] {
+            let mut g = reverb_stereo(10.0, 2.0, 0.5);
+            g.set_sample_rate(SR);
+            write_npy(&out_dir.join(format!("config5_reverb_stereo_{tag}.npy")), 2, t_n, &flatten(&render(&mut g, &x, t_n, process)));
+            let mut g4 = reverb4_stereo(20.0, 2.0);
+            g4.set_sample_rate(SR);
+            write_npy(&out_dir.join(format!("reverb4_stereo_{tag}.npy")), 2, t_n, &flatten(&render(&mut g4, &x, t_n, process)));
+        }
+    }
+
     // ---- inventory graphs (graphs.rs): seed 12345, the fixed noise input of make_golden.py
     for (name, ni) in graphs::names() {
         let x = if ni > 0 {

@@ -60,6 +60,23 @@ def kat_args():
     return np.concatenate(parts).astype(np.float32)
 
 
+C4_V, C4_ADSR = 16, (0.005, 0.01, 0.6, 0.01)
+C4_PLAN = [(0.0, 64), (1.0, 64 * 9), (0.0, 64 * 3 + 7), (0.5, 64 * 5), (0.0, 64 * 6 + 3)]
+C4_FRAMES = sum(n for _, n in C4_PLAN)
+C5_FRAMES = 64 * 200 + 13
+
+
+def config45_inputs():
+    """What rust_harness reads for configs 4 / 5 (and what tests/test_golden.py renders through the oracle): config-4 voice parameters,
+    the gate stream of the stream-gate shape, the (value, frames) plan of the Var shape, one stereo noise input for the reverbs."""
+    p4 = W.saw_moog_params(C4_V, SR)
+    gate = W.gate_signal(C4_FRAMES, SR, on_frame=1, off_seconds=700 / SR)
+    rng = np.random.default_rng(4242)
+    x5 = (rng.random((2, C5_FRAMES), dtype=np.float32) * 2 - 1).astype(np.float32)
+    x5[:, 2 * C5_FRAMES // 3:] = 0.0
+    return p4, gate, x5
+
+
 def harness_inputs(p2, p3, gv):
     """The exact arrays rust_harness/ reads (raw little-endian): per-voice parameters of configs 2 / 3, graph inputs,
     the KAT argument list -- so that the real reference renders from identical bits."""
@@ -72,6 +89,13 @@ def harness_inputs(p2, p3, gv):
         p2[k].astype("<f4").tofile(os.path.join(d, f"config2_{k}.f32"))
     p2["seed"].astype("<u8").tofile(os.path.join(d, "config2_seed.u64"))
     kat_args().astype("<f4").tofile(os.path.join(d, "kat_args.f32"))
+    p4, gate, x5 = config45_inputs()
+    for k in ("f", "fc", "q", "pan"):
+        p4[k].astype("<f4").tofile(os.path.join(d, f"config4_{k}.f32"))
+    p4["seed"].astype("<u8").tofile(os.path.join(d, "config4_seed.u64"))
+    gate.astype("<f4").tofile(os.path.join(d, "config4_gate.f32"))
+    np.array([[v, n] for v, n in C4_PLAN], dtype="<f4").tofile(os.path.join(d, "config4_plan.f32"))
+    x5.astype("<f4").tofile(os.path.join(d, "config5_in.f32"))
     from test_gpu_jit import GRAPHS
     for name, (_b, ni, _r) in GRAPHS.items():
         if ni:
