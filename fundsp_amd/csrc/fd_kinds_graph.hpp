@@ -32,6 +32,8 @@ static_assert(PipeTiles<SawMoogAdsrPan, 3, 1, 2, 2>::S0::OUT == (FD_PIPE_ELIDE ?
 static_assert(PipeTiles<SawMoogAdsrPan, 3, 1, 2, 2>::SUB == (FD_PIPE_ELIDE ? 32 : 16) && PipeTiles<SawMoogAdsrPan, 3, 1, 2, 4>::SUB == (FD_PIPE_ELIDE ? 16 : 8), "config 4: tile lengths");
 static_assert(SawMoogVarAdsrPan::IN == 0 && pipe_plan<SawMoogVarAdsrPan>(0).S == 3 && pipe_plan<SawMoogVarAdsrPan>(0).K1 == 1 && pipe_plan<SawMoogVarAdsrPan>(0).K2 == 2, "config 4, Var gate: the same three stages, no loader");
 static_assert(PipeTiles<SawMoogVarAdsrPan, 3, 1, 2, 2>::SUB == (FD_PIPE_ELIDE ? 64 : 16) && PipeTiles<SawMoogVarAdsrPan, 3, 1, 2, 4>::SUB == (FD_PIPE_ELIDE ? 32 : 8), "config 4, Var gate: no feed ring, the tiles are twice as long");
+static_assert(!TsPlan<SawMoogVarAdsrPan>::ok && TsPlan<NoiseBiquad>::ok, "time-split kernels: config 2's generator chain yes (a counter, a feed-forward half, the recurrence); "
+                                                                        "config 4's no -- a wavetable oscillator and a ladder cannot skip frames");
 // ... and of the launch lengths from which the two kinds leave the single-wave kernel (PipeMinT: measured, profiles/r04_small_t_kernels.txt)
 #ifndef FD_PIPE_MIN_T
 static_assert(PipeMinT<NoiseBiquad>::v == 256 && PipeMinT<SawMoogAdsrPan>::v == 64, "config 2: the pipeline from four blocks on; config 4: from one");
