@@ -166,3 +166,20 @@ def test_wav_sink_layout(tmp_path):
     assert sr == 48000 and np.array_equal(y.T, x)
     sr, y16 = wavfile.read(p16)
     assert y16.dtype == np.int16 and y16[0, 0] == -32767 and y16[-1, 0] == 32767 and abs(int(y16[0, 1]) - 16384) <= 1
+
+
+def test_gate_plan_and_var_gate_slots():
+    """Config 4 in the reference's gate shape (`var(gate) >> adsr_live`): the plan of launches mirrors the stream workload's gate at block
+    granularity, and the slot names the workload sets exist in the kind (CPU: the slot table of the library needs no device)."""
+    from fundsp_amd import bank
+
+    assert W.gate_plan(48000, 48000.0) == [(1.0, 24000), (0.0, 24000)]
+    assert W.gate_plan(1000, 48000.0) == [(1.0, 1000)]                       # shorter than the note: all high
+    assert W.gate_plan(48000, 44100.0) == [(1.0, 22016), (0.0, 25984)]       # 0.5 s rounded DOWN to whole 64-frame blocks
+    assert sum(n for _, n in W.gate_plan(12345, 48000.0, off_seconds=0.1)) == 12345
+    slots = dict(bank.kind_slots("saw_moog_var_adsr_pan"))
+    for name in W.C4V_SLOTS.values():
+        assert name in slots, name
+    assert slots[W.C4V_SLOTS["gate"]] == 0                                    # a parameter (kind 0), like Shared::set_value's target
+    stream = dict(bank.kind_slots("saw_moog_adsr_pan"))
+    assert len(slots) == len(stream) + 1                                      # the Var's value is the one slot more
