@@ -400,6 +400,7 @@ struct fdsp_bank {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool timed = false;
     bool ext_pending = false;  // the last render ran on a caller's stream: bank-stream work must wait for its e1
+    mutable bool async_param_pending = false;  // fdsp_bank_set_param_all queued device-side work on the bank's stream and did not wait for it
     int math = FDSP_MATH_EXACT;  // FDSP_MATH_FAST: renders take the kind's tolerance-mode variant when it has one
     // per-bank launch options (fdsp_bank_set_option); -1 = follow the process-wide default at every launch
     int opt_pipe_split = -1, opt_time_split = -1, opt_fdn_kernel = -1, opt_timing = -1;
@@ -436,10 +437,14 @@ namespace {
 // A render on a caller stream is ordered after whatever the bank's own stream still has pending (parameter uploads).
 // While the caller's stream is being CAPTURED into a HIP graph a host-side synchronize would invalidate the capture; the
 // bank's stream is idle by then (every setter synchronizes before it returns), so the wait is simply skipped.
+// (The one setter that does NOT wait -- fdsp_bank_set_param_all, the device-side fill -- marks the bank; a capture that would start
+// behind such work is refused instead of racing with it: the host calls fdsp_bank_synchronize first.)
 hipError_t order_after_bank_stream(const fdsp_bank* b, hipStream_t s) {
     if (s == b->stream) return hipSuccess;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return hipSuccess;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return b->async_param_pending ? hipErrorStreamCaptureUnsupported : hipSuccess;
+    b->async_param_pending = false;
     return hipStreamSynchronize(b->stream);
 }
 
@@ -1256,6 +1261,7 @@ int fdsp_bank_set_param_all(fdsp_bank* b, const char* name, float value) {
     if (b->V == 0) return FDSP_OK;
     HIPCHK(await_last_render(b));
     hipLaunchKernelGGL(k_fill_slot, dim3((unsigned)((b->V + 255) / 256)), dim3(256), 0, b->stream, b->slots + (size_t)s * b->stride, value, b->V);
+    b->async_param_pending = true;
     before_update_launch(b, 0, b->V);
     b->ops->lifecycle(b->slots, b->stride, 0, b->V, 1, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
@@ -1718,6 +1724,7 @@ int fdsp_bank_synchronize(fdsp_bank* b) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
     DeviceGuard guard(b->device);
     HIPCHK(hipStreamSynchronize(b->stream));
+    b->async_param_pending = false;
     return FDSP_OK;
 }
 

@@ -227,6 +227,10 @@ int fdsp_bank_slot_count(const fdsp_bank* bank);
 const char* fdsp_bank_slot_name(const fdsp_bank* bank, int slot);
 int fdsp_bank_slot_kind(const fdsp_bank* bank, int slot); /* 0 = parameter, 1 = derived coefficient, 2 = state */
 int fdsp_bank_set_param(fdsp_bank* bank, const char* name, const float* h_values, size_t first, size_t count);
+/* One value for every voice (Shared::set_value of a variable all voices watch, src/shared.rs:98-101): filled ON THE DEVICE in stream order behind
+ * the last render -- no host copy, no host wait.  A render on the bank's own stream simply follows it; a render on a caller's stream waits for
+ * it on the host as for every setter; a caller's stream that is being CAPTURED cannot wait, so a capture started while such a fill is still
+ * queued is refused (FDSP_EDEVICE): call fdsp_bank_synchronize(bank) before capturing. */
 int fdsp_bank_set_param_all(fdsp_bank* bank, const char* name, float value);
 int fdsp_bank_set_param_u64(fdsp_bank* bank, const char* name, const uint64_t* h_values, size_t first, size_t count);
 int fdsp_bank_get_slot(fdsp_bank* bank, const char* name, float* h_values, size_t first, size_t count);

@@ -86,3 +86,42 @@ def test_destroying_a_bank_waits_for_its_render_on_a_caller_stream(gpu):
         s.synchronize()
         assert torch.equal(ints(out), ints(want))
         del junk
+
+
+def test_device_side_fill_and_stream_capture(gpu):
+    """fdsp_bank_set_param_all fills on the device and does not wait; a capture of renders on a caller's stream cannot wait either, so it is
+    refused while such a fill is still queued (the captured graph could otherwise replay before the fill lands) and accepted after
+    fdsp_bank_synchronize -- and then replays the variable's value of capture time block after block."""
+    import torch
+
+    gpu.wavetable_build("saw")
+    V, NB = 64 * 20, 4
+    p = W.saw_moog_params(V, SR)
+    adsr = (0.005, 0.01, 0.6, 0.01)
+    ref = W.make_saw_moog_var_bank(V, SR, params=p, adsr=adsr)
+    ref.set_param(W.C4V_SLOTS["gate"], 1.0)
+    want = ref.process(64 * NB * 2)
+    b = W.make_saw_moog_var_bank(V, SR, params=p, adsr=adsr)
+    outs = [torch.empty((2, 64, V), dtype=torch.float32, device="cuda") for _ in range(NB)]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        c = b.clone()
+        c.process(64, out=outs[0])                # load the kernels outside the capture (on a clone: b's state stays)
+        torch.cuda.synchronize()
+        b.set_param(W.C4V_SLOTS["gate"], 1.0)    # queued on the bank's stream, not waited for
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            with pytest.raises(gpu.FdspError):
+                b.process(64, out=outs[0])
+        del g
+        b.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for k in range(NB):
+                b.process(64, out=outs[k])
+        chunks = []
+        for _ in range(2):
+            g.replay()
+            chunks.append(torch.cat(outs, dim=1).clone())
+        torch.cuda.synchronize()
+    assert torch.equal(ints(torch.cat(chunks, dim=1)), ints(want))
