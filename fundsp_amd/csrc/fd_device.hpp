@@ -2218,6 +2218,13 @@ FD_D void describe_body(char* out, int cap, int* meta) {
     meta[8] = SameType<typename FastOf<G>::type, G>::v ? 0 : 1;            // the graph has a tolerance-mode variant
     meta[9] = JitPipeSmall<G>::on ? 1 : 0;                                 // heavy: jit_pipe_g1 / _g2 exist for small banks
     meta[10] = PipeMinT<G>::v;                                             // launch length from which the pipeline kernel is taken
+    meta[11] = TsPlan<G>::ok ? 1 : 0;                                      // a three-stage generator chain: small banks take the time-split kernels (jit_ts3_g1 / _g2)
+}
+// the three-way time-split kernels for run-time compiled graphs (small banks of three-stage generator chains; a module of their own with the
+// mix-down kernels, compiled on first use): empty when the graph does not qualify
+template <class G, int GPW>
+FD_D void jit_ts3_body(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T, const void* aux) {
+    if constexpr (TsPlan<G>::ok) render_ts3_body<G, GPW>(slots, stride, V, out, T, aux);
 }
 
 // pipeline kernel entry for run-time compiled graphs: empty when the graph has no plan

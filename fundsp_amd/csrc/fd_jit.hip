@@ -65,6 +65,7 @@ struct JitModule {
     bool loaded[MAXD] = {false};
     int pipe_stages = 0, pipe_threads = 0, pipe_planar_threads = 0, pipe_min_t = 256;
     bool pipe_small = false;                                                 // heavy graph: workgroups of 1 / 2 voice groups for small banks
+    bool ts_ok = false;                                                      // three-stage generator chain: small banks take the time-split kernels
     int wpb[2] = {4, 4};                                                     // per layout
     // the tolerance-mode twin of this graph (FastOf<G>), compiled on first use
     std::string type_expr, prelude;
@@ -131,7 +132,7 @@ struct JitModule {
 struct JitMix {
     std::vector<char> code;
     std::mutex mu;
-    struct Dev { hipModule_t mod = nullptr; hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; hipFunction_t ev[2] = {nullptr, nullptr}; bool loaded = false; } dev[JitModule::MAXD];
+    struct Dev { hipModule_t mod = nullptr; hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; hipFunction_t ev[2] = {nullptr, nullptr}; hipFunction_t ts[2] = {nullptr, nullptr}; bool loaded = false; } dev[JitModule::MAXD];
     ~JitMix() {
         int prev = -1;
         const bool have_prev = hipGetDevice(&prev) == hipSuccess;
@@ -157,6 +158,10 @@ struct JitMix {
             const std::string fn = "jit_events_mix_" + std::to_string(m);
             ok = hipModuleGetFunction(&f.ev[m], f.mod, fn.c_str()) == hipSuccess;
         }
+        for (int g = 0; g < 2 && ok; g++) {
+            const std::string fn = "jit_ts3_g" + std::to_string(g + 1);
+            ok = hipModuleGetFunction(&f.ts[g], f.mod, fn.c_str()) == hipSuccess;
+        }
         if (!ok) { hipModuleUnload(f.mod); f.mod = nullptr; return nullptr; }
         return &f;
     }
@@ -166,11 +171,48 @@ struct JitMix {
 // hipGetLastError(): provoke an invalid-handle error
 void jit_launch_failed() { hipModuleLaunchKernel(nullptr, 1, 1, 1, 1, 1, 1, 0, nullptr, nullptr, nullptr); }
 
+// The second module of a compiled graph -- the fused mix-down kernels and the time-split kernels of G (which = 0) / FastOf<G> (1) --,
+// compiled the first time a bank of the kind needs one of them.  Under a mutex of its own: a render of the kind on another thread does
+// not wait for the compile.
+JitMix* jit_extra_module(JitModule* jm, int which) {
+    std::lock_guard<std::mutex> lock(jm->mix_mu);
+    if (!jm->mix[which] && !jm->mix_failed[which]) {
+        auto mm = std::make_shared<JitMix>();
+        std::string log;
+        const std::string type = which ? "typename fd::FastOf<" + jm->type_expr + ">::type" : jm->type_expr;
+        if (jit_compile_src(jit_source_mix(type, jm->prelude), jm->type_expr, &mm->code, &log) == 0) jm->mix[which] = mm;
+        else {
+            jm->mix_failed[which] = true;
+            fprintf(stderr, "fundsp_hip: the mix-down / time-split kernels of this graph failed to compile: %s\n", log.c_str());
+        }
+    }
+    return jm->mix[which].get();
+}
+
+// `base` / `which`: the kind's module and which of its variants `jm` is (0 = G itself, 1 = its tolerance-mode twin) -- where the second module lives
 void jit_render(JitModule* jm, float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T, size_t fstride,
-                int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
+                int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s, JitModule* base = nullptr, int which = 0) {
     if (V == 0 || T == 0) return;
     const JitFuncs* f = jm->get();
     if (!f) return jit_launch_failed();
+    // banks that leave most SIMDs idle (<= 2 voice groups per CU) of three-stage generator chains: the three-way time split, as launch_render
+    // does for the ahead-of-time kinds (its kernels are compiled the first time such a launch happens; no such kernels -> the pipeline below)
+    if (base && base->ts_ok && tl_opts.time_split == 1 && tl_opts.pipe_split == 1 && layout == LAYOUT_VOICE_MINOR && mode == MODE_PROCESS &&
+        T % 64 == 0 && T >= FD_TS_MIN_T) {
+        const size_t groups = (V + 63) / 64, cus = (size_t)simd_count() / 4;
+        if (groups <= 2 * cus) {
+            JitMix* mm = jit_extra_module(base, which);
+            const JitMix::Dev* tf = mm ? mm->get() : nullptr;
+            if (tf) {
+                const int gpw = groups <= cus ? 1 : 2;
+                void* targs[] = {&slots, &stride, &V, &outp, &T, &aux};
+                hipModuleLaunchKernel(tf->ts[gpw - 1], (unsigned)((groups + gpw - 1) / gpw), 1, 1, 64u * (gpw == 1 ? Ts3Roles<1>::WAVES : Ts3Roles<2>::WAVES), 1, 1, 0, s,
+                                      targs, nullptr);
+                tl_opts.last_kernel = LK_TIME_SPLIT;
+                return;
+            }
+        }
+    }
     // loader wave / stage split; short launches (real-time blocks) are faster through the single-wave kernel, as for
     // the ahead-of-time kinds (launch_render)
     if (layout == LAYOUT_VOICE_MINOR && tl_opts.pipe_split && jm->pipe_stages >= 1 && (T >= (size_t)jm->pipe_min_t || tl_opts.pipe_split > 1)) {
@@ -278,6 +320,12 @@ std::string jit_source_mix(const std::string& type_expr, const std::string& prel
                  "size_t T, const void* aux, float* ring, uint32_t cap, const float* __restrict__ panw) {\n"
                  "  fd::jit_pipe_mix_body<JitG, " + m + ", " + x + ">(slots, stride, V, in, part, T, aux, ring, cap, panw); }\n";
         }
+    for (int g = 1; g <= 2; g++) {  // the three-way time-split kernels (voice-out, process mode): small banks of three-stage generator chains
+        std::string gs = std::to_string(g);
+        s += "extern \"C\" __global__ __launch_bounds__(64 * fd::Ts3Roles<" + gs + ">::WAVES) void jit_ts3_g" + gs +
+             "(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T, const void* aux) {\n"
+             "  fd::jit_ts3_body<JitG, " + gs + ">(slots, stride, V, out, T, aux); }\n";
+    }
     for (int mode = 0; mode < 2; mode++) {
         std::string m = std::to_string(mode);
         s += "extern \"C\" __global__ __launch_bounds__(256) void jit_events_mix_" + m +
@@ -378,6 +426,7 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     jm->has_fast = meta[8] != 0;
     jm->pipe_small = meta[9] != 0;
     jm->pipe_min_t = meta[10] > 0 ? meta[10] : 256;
+    jm->ts_ok = meta[11] != 0;
     out->slots.clear();
     std::istringstream lines(std::string(txt.data(), (size_t)meta[3]));
     std::string line;
@@ -396,7 +445,7 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     };
     out->render = [jm](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T, size_t fstride,
                        int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
-        jit_render(jm.get(), slots, stride, V, in, outp, T, fstride, layout, mode, aux, ring, ring_cap, s);
+        jit_render(jm.get(), slots, stride, V, in, outp, T, fstride, layout, mode, aux, ring, ring_cap, s, jm.get(), 0);
     };
     if (jm->has_fast)  // tolerance mode: the same source with JitG = FastOf<G>, compiled the first time a FAST bank renders
         out->render_fast = [jm](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T, size_t fstride,
@@ -422,24 +471,11 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
                 }
             }
             JitModule* m = jm->fast ? jm->fast.get() : jm.get();
-            jit_render(m, slots, stride, V, in, outp, T, fstride, layout, mode, aux, ring, ring_cap, s);
+            jit_render(m, slots, stride, V, in, outp, T, fstride, layout, mode, aux, ring, ring_cap, s, jm.get(), jm->fast ? 1 : 0);
         };
     // render + mix-down in one launch (fdsp_bank_process_mix): graphs with a pipeline plan; the kernels are compiled on first use
     jm->nout = meta[1];
-    auto mix_module = [jm](int which) -> JitMix* {  // the mix-down kernels of G (0) / FastOf<G> (1), compiled on first use
-        std::lock_guard<std::mutex> lock(jm->mix_mu);   // (a mutex of its own: a render of this kind on another thread does not wait for the compile)
-        if (!jm->mix[which] && !jm->mix_failed[which]) {
-            auto mm = std::make_shared<JitMix>();
-            std::string log;
-            const std::string type = which ? "typename fd::FastOf<" + jm->type_expr + ">::type" : jm->type_expr;
-            if (jit_compile_src(jit_source_mix(type, jm->prelude), jm->type_expr, &mm->code, &log) == 0) jm->mix[which] = mm;
-            else {
-                jm->mix_failed[which] = true;
-                fprintf(stderr, "fundsp_hip: the fused mix-down kernels of this graph failed to compile: %s\n", log.c_str());
-            }
-        }
-        return jm->mix[which].get();
-    };
+    auto mix_module = [jm](int which) -> JitMix* { return jit_extra_module(jm.get(), which); };
     auto mix_launch = [jm, mix_module](int which, float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, int mix, int mode,
                            const void* aux, float* ring, uint32_t ring_cap, const float* panw, hipStream_t s) -> bool {
         if (V == 0 || T == 0) return true;

@@ -369,3 +369,42 @@ def test_jit_fixed_biquad_holders_cut_at_the_seam(gpu, name):
         assert_bit_equal(outs[0][v], want[k], f"{name} voice {v} vs oracle")
     for o in outs[1:]:
         assert_bit_equal(o, outs[0], f"{name}: every stage plan renders the same samples")
+
+
+def test_jit_small_banks_take_the_time_split_kernels(gpu):
+    """Run-time compiled three-stage generator chains on banks that leave most SIMDs idle (<= 2 voice groups per CU) take the three-way
+    time-split kernels like the ahead-of-time kinds do (their module is compiled on the first such launch): the FM voice of BASELINE
+    config 3 and `noise() >> biquad` (config 2's shape), one group per CU and two; bit-equal to the stage pipeline, to the ahead-of-time
+    kind and to the oracle; a ragged launch falls back to the pipeline and continues the same state."""
+    V, T = 64 * 10 + 37, 64 * 6
+    p = W.fm_svf_params(V, SR)
+    g = GR.sine_hz(p["f"]) * p["f"] * p["m"] + p["f"] >> GR.sine() >> GR.lowpass_hz(p["fc"], p["q"])
+    want, _ = O.bank_render(3, [p["f"], p["m"], p["fc"], p["q"]], p["seed"], 2 * T + 13, SR, True, 0, 8)
+    outs = {}
+    for split in (1, 0):
+        b = gpu.Bank.from_graph(g, V, sample_rate=SR)
+        b.set_seed(p["seed"])
+        b.set_option("time_split", split)
+        a = run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :]
+        assert b.get_option("last_kernel") == (4 if split else 2)
+        c = run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :]
+        d = run_bank(b, None, 13, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :]
+        assert b.get_option("last_kernel") in (1, 2)
+        outs[split] = np.concatenate([a, c, d], axis=1)
+    assert_bit_equal(outs[1], want, "run-time compiled FM voice, time split vs oracle")
+    assert_bit_equal(outs[0], want, "run-time compiled FM voice, pipeline vs oracle")
+    # two voice groups per CU (302 groups on 256 CUs) and the noise >> biquad shape
+    V2 = 64 * 301 + 5
+    nb = GR.noise() >> GR.biquad(-1.2, 0.5, 0.2, 0.3, 0.1)
+    res = []
+    for split in (1, 0):
+        b = gpu.Bank.from_graph(nb, V2, sample_rate=SR)
+        b.set_seed(np.arange(V2, dtype=np.uint64))
+        b.set_option("time_split", split)
+        res.append(run_bank(b, None, 64 * 3, LAYOUT_VOICE_MINOR, MODE_PROCESS)[:, 0, :])
+        assert b.get_option("last_kernel") == 4 if split else b.get_option("last_kernel") in (1, 2)   # (a light graph: single wave below four blocks)
+    assert_bit_equal(res[0], res[1], "noise >> biquad, 302 voice groups: time split == the other kernel families")
+    n = O.noise() >> O.biquad(-1.2, 0.5, 0.2, 0.3, 0.1)
+    n.set_sample_rate(SR)
+    n.set_seed(V2 - 1)
+    assert_bit_equal(res[0][V2 - 1], n.render_blocks(length=64 * 3)[0], "noise >> biquad last voice vs oracle")
