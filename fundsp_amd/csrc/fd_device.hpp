@@ -2226,6 +2226,11 @@ template <class G, int GPW>
 FD_D void jit_ts3_body(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T, const void* aux) {
     if constexpr (TsPlan<G>::ok) render_ts3_body<G, GPW>(slots, stride, V, out, T, aux);
 }
+// ... and with the fused mix-down (k_render_ts3_mix): MIX_SUM for graphs of one or two outputs, MIX_PAN for mono graphs
+template <class G, int GPW, int MIX>
+FD_D void jit_ts3_mix_body(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ part, size_t T, const void* aux, const float* __restrict__ panw) {
+    if constexpr (TsPlan<G>::ok && (MIX == MIX_SUM ? G::OUT <= 2 : G::OUT == 1)) render_ts3_body<G, GPW, MIX>(slots, stride, V, part, T, aux, panw);
+}
 
 // pipeline kernel entry for run-time compiled graphs: empty when the graph has no plan
 template <class G, int MODE>

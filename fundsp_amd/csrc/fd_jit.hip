@@ -132,7 +132,7 @@ struct JitModule {
 struct JitMix {
     std::vector<char> code;
     std::mutex mu;
-    struct Dev { hipModule_t mod = nullptr; hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; hipFunction_t ev[2] = {nullptr, nullptr}; hipFunction_t ts[2] = {nullptr, nullptr}; bool loaded = false; } dev[JitModule::MAXD];
+    struct Dev { hipModule_t mod = nullptr; hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; hipFunction_t ev[2] = {nullptr, nullptr}; hipFunction_t ts[2] = {nullptr, nullptr}; hipFunction_t tsm[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; bool loaded = false; } dev[JitModule::MAXD];
     ~JitMix() {
         int prev = -1;
         const bool have_prev = hipGetDevice(&prev) == hipSuccess;
@@ -161,6 +161,10 @@ struct JitMix {
         for (int g = 0; g < 2 && ok; g++) {
             const std::string fn = "jit_ts3_g" + std::to_string(g + 1);
             ok = hipModuleGetFunction(&f.ts[g], f.mod, fn.c_str()) == hipSuccess;
+            for (int x = 0; x < 2 && ok; x++) {
+                const std::string fm = "jit_ts3_mix_g" + std::to_string(g + 1) + "_" + std::to_string(x + 1);
+                ok = hipModuleGetFunction(&f.tsm[g][x], f.mod, fm.c_str()) == hipSuccess;
+            }
         }
         if (!ok) { hipModuleUnload(f.mod); f.mod = nullptr; return nullptr; }
         return &f;
@@ -325,6 +329,12 @@ std::string jit_source_mix(const std::string& type_expr, const std::string& prel
         s += "extern \"C\" __global__ __launch_bounds__(64 * fd::Ts3Roles<" + gs + ">::WAVES) void jit_ts3_g" + gs +
              "(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T, const void* aux) {\n"
              "  fd::jit_ts3_body<JitG, " + gs + ">(slots, stride, V, out, T, aux); }\n";
+        for (int mix = 1; mix <= 2; mix++) {
+            std::string x = std::to_string(mix);
+            s += "extern \"C\" __global__ __launch_bounds__(64 * fd::Ts3Roles<" + gs + ">::WAVES) void jit_ts3_mix_g" + gs + "_" + x +
+                 "(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ part, size_t T, const void* aux, const float* __restrict__ panw) {\n"
+                 "  fd::jit_ts3_mix_body<JitG, " + gs + ", " + x + ">(slots, stride, V, part, T, aux, panw); }\n";
+        }
     }
     for (int mode = 0; mode < 2; mode++) {
         std::string m = std::to_string(mode);
@@ -484,6 +494,18 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
         if (!mm) return false;
         const JitMix::Dev* f = mm->get();
         if (!f) { jit_launch_failed(); return true; }
+        // small banks of three-stage generator chains: the time-split kernels with the fused mix-down, as launch_render_mix_m
+        if (jm->ts_ok && jm->nout <= 2 && tl_opts.time_split == 1 && tl_opts.pipe_split == 1 && mode == MODE_PROCESS && T % 64 == 0 && T >= FD_TS_MIN_T) {
+            const size_t groups = (V + 63) / 64, cus = (size_t)simd_count() / 4;
+            if (groups <= 2 * cus) {
+                const int gpw = groups <= cus ? 1 : 2;
+                void* targs[] = {&slots, &stride, &V, &part, &T, &aux, &panw};
+                hipModuleLaunchKernel(f->tsm[gpw - 1][mix - 1], (unsigned)((groups + gpw - 1) / gpw), 1, 1, 64u * (gpw == 1 ? Ts3Roles<1>::WAVES : Ts3Roles<2>::WAVES), 1, 1, 0, s,
+                                      targs, nullptr);
+                tl_opts.last_kernel = LK_TIME_SPLIT;
+                return true;
+            }
+        }
         void* pargs[] = {&slots, &stride, &V, &in, &part, &T, &aux, &ring, &ring_cap, &panw};
         hipModuleLaunchKernel(f->fn[mix - 1][mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_threads, 1, 1, 0, s, pargs, nullptr);
         tl_opts.last_kernel = LK_PIPELINE;

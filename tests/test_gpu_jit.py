@@ -393,6 +393,18 @@ def test_jit_small_banks_take_the_time_split_kernels(gpu):
         outs[split] = np.concatenate([a, c, d], axis=1)
     assert_bit_equal(outs[1], want, "run-time compiled FM voice, time split vs oracle")
     assert_bit_equal(outs[0], want, "run-time compiled FM voice, pipeline vs oracle")
+    # ... and the fused mix-down of the same small bank takes the time-split kernels too (MIX_PAN: every voice panned and summed in the launch)
+    import torch
+    from fundsp_amd import MIX_PAN
+
+    pan = np.linspace(-1, 1, V).astype(np.float32)
+    bm = gpu.Bank.from_graph(g, V, sample_rate=SR)
+    bm.set_seed(p["seed"])
+    bm.set_pan(pan)
+    mix = bm.process_mix(T, mix=MIX_PAN)
+    assert bm.get_option("last_kernel") == 4
+    vo = torch.from_numpy(np.ascontiguousarray(outs[1][:, :T].T)).cuda()                  # [T][V] voice-out of the first launch
+    assert_bit_equal(mix.cpu().numpy(), gpu.mix_stereo(vo, torch.from_numpy(pan).cuda()).cpu().numpy(), "run-time compiled FM voice: time-split fused mix vs mix_stereo(voice-out)")
     # two voice groups per CU (302 groups on 256 CUs) and the noise >> biquad shape
     V2 = 64 * 301 + 5
     nb = GR.noise() >> GR.biquad(-1.2, 0.5, 0.2, 0.3, 0.1)
