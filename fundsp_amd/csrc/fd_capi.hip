@@ -439,13 +439,18 @@ namespace {
 // bank's stream is idle by then (every setter synchronizes before it returns), so the wait is simply skipped.
 // (The one setter that does NOT wait -- fdsp_bank_set_param_all, the device-side fill -- marks the bank; a capture that would start
 // behind such work is refused instead of racing with it: the host calls fdsp_bank_synchronize first.)
+// every host-side wait for the bank's stream goes through here: whatever fdsp_bank_set_param_all queued has landed afterwards
+hipError_t sync_bank_stream(const fdsp_bank* b) {
+    const hipError_t e = hipStreamSynchronize(b->stream);
+    if (e == hipSuccess) b->async_param_pending = false;
+    return e;
+}
 hipError_t order_after_bank_stream(const fdsp_bank* b, hipStream_t s) {
     if (s == b->stream) return hipSuccess;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
         return b->async_param_pending ? hipErrorStreamCaptureUnsupported : hipSuccess;
-    b->async_param_pending = false;
-    return hipStreamSynchronize(b->stream);
+    return sync_bank_stream(b);
 }
 
 // ... and the other way round: lifecycle / parameter work on the bank's stream waits for the last render that ran on a
@@ -481,7 +486,7 @@ int check_ring_need(fdsp_bank* b, bool capturing) {
         b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&need, ring_need_word(b), sizeof need, hipMemcpyDeviceToHost, b->stream));
-        HIPCHK(hipStreamSynchronize(b->stream));
+        HIPCHK(sync_bank_stream(b));
         b->ring_check_pending = false;
         b->ring_short = need > b->ring_cap ? need : 0;
     }
@@ -887,6 +892,7 @@ int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring
         fdsp_bank_destroy(b);  // frees whatever of {slots, stream, e0, e1} exists
         return fail(FDSP_EDEVICE, "stream/event creation failed");
     }
+    if (b->ops->prepare_render) b->ops->prepare_render(voices);  // (run-time compiled kinds: whatever this bank size still has to compile)
     if (b->ops->nrings > 0) {
         if (ring_frames == 0 || ring_frames > 0x7fffffffu) {
             fdsp_bank_destroy(b);
@@ -905,7 +911,7 @@ int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring
     }
     hipMemsetAsync(b->slots, 0, bytes, b->stream);
     b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 0, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
-    e = hipStreamSynchronize(b->stream);
+    e = sync_bank_stream(b);
     if (e != hipSuccess) {
         fdsp_bank_destroy(b);
         return fail(FDSP_EDEVICE, std::string("bank construction kernel failed: ") + hipGetErrorString(e));
@@ -920,10 +926,10 @@ int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring
             }
             std::fill(col.begin(), col.end(), kv.second);
             hipMemcpyAsync(b->slots + (size_t)it->second * b->stride, col.data(), b->stride * sizeof(float), hipMemcpyHostToDevice, b->stream);
-            hipStreamSynchronize(b->stream);
+            sync_bank_stream(b);
         }
         b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
-        if (hipStreamSynchronize(b->stream) != hipSuccess) {
+        if (sync_bank_stream(b) != hipSuccess) {
             fdsp_bank_destroy(b);
             return fail(FDSP_EDEVICE, "applying the kind's presets failed");
         }
@@ -933,7 +939,7 @@ int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring
     if (b->ring) {
         const uint32_t line[2] = {0u, (uint32_t)(b->V > 0xFFFFFFFFull ? 0xFFFFFFFFull : b->V)};  // [need, real voices]
         hipMemcpyAsync(ring_need_word(b), line, sizeof line, hipMemcpyHostToDevice, b->stream);
-        hipStreamSynchronize(b->stream);
+        sync_bank_stream(b);
     }
     *out = b;
     return FDSP_OK;
@@ -1035,7 +1041,7 @@ static int fdn_bank_create_on(int kind, int device, size_t instances, double roo
         fdsp_bank_destroy(b);
         return rc;
     }
-    hipError_t e = hipStreamSynchronize(b->stream);
+    hipError_t e = sync_bank_stream(b);
     if (e != hipSuccess) {
         fdsp_bank_destroy(b);
         return fail(FDSP_EDEVICE, hipGetErrorString(e));
@@ -1049,7 +1055,7 @@ void fdsp_bank_destroy(fdsp_bank* b) {
     DeviceGuard guard(b->device);
     // a render that ran on a caller's stream may still be reading the slots: wait for its completion event first
     if (b->ext_pending && b->e1) hipEventSynchronize(b->e1);
-    if (b->stream) hipStreamSynchronize(b->stream);
+    if (b->stream) sync_bank_stream(b);
     if (b->fdn) {
         fdn_free(b->fdn);
         delete b->fdn;
@@ -1095,7 +1101,7 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
     hipError_t e = hipSuccess;
     if (src->fdn) {
         if (src->sr != b->sr) {  // the rings' capacity and lengths follow the sample rate
-            e = hipStreamSynchronize(b->stream);
+            e = sync_bank_stream(b);
             if (e != hipSuccess) return bail(e, "sync");
             rc = fdn_configure(b, src->sr);
             if (rc != FDSP_OK) {
@@ -1146,7 +1152,7 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
     b->opt_time_split = src->opt_time_split;
     b->opt_fdn_kernel = src->opt_fdn_kernel;
     b->opt_timing = src->opt_timing;
-    e = hipStreamSynchronize(b->stream);
+    e = sync_bank_stream(b);
     if (e != hipSuccess) return bail(e, "copy");
     *out = b;
     return FDSP_OK;
@@ -1162,7 +1168,7 @@ int fdsp_bank_set_sample_rate(fdsp_bank* b, double sr) {
     if (b->fdn) {
         if (sr == b->sr) return FDSP_OK;  // Delay::set_sample_rate: nothing happens unless the rate changes
         HIPCHK(await_last_render(b));
-        HIPCHK(hipStreamSynchronize(b->stream));
+        HIPCHK(sync_bank_stream(b));
         return fdn_configure(b, sr);  // sets b->sr on success only
     }
     b->sr = sr;
@@ -1205,7 +1211,7 @@ int fdsp_bank_set_seed(fdsp_bank* b, const uint64_t* h_seeds, size_t first, size
     }
     HIPCHK(await_last_render(b));
     b->ops->lifecycle(b->slots, b->stride, first, count, 3, b->sr, d, b->aux, b->ring, b->ring_cap, b->stream);
-    hipError_t e = hipStreamSynchronize(b->stream);
+    hipError_t e = sync_bank_stream(b);
     if (d) hipFree(d);
     if (e != hipSuccess) return fail(FDSP_EDEVICE, hipGetErrorString(e));
     return FDSP_OK;
@@ -1228,7 +1234,7 @@ static int set_words(fdsp_bank* b, int slot, const void* h_words, size_t first, 
     HIPCHK(await_last_render(b));
     HIPCHK(hipMemcpyAsync(b->slots + (size_t)slot * b->stride + first, h_words, count * sizeof(float),
                           hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));  // h_words is borrowed for the call only
+    HIPCHK(sync_bank_stream(b));  // h_words is borrowed for the call only
     return FDSP_OK;
 }
 
@@ -1299,7 +1305,7 @@ int fdsp_bank_get_slot(fdsp_bank* b, const char* name, float* h_values, size_t f
     if (s < 0) return fail(FDSP_EINVAL, std::string("unknown slot: ") + (name ? name : "(null)"));
     if (int rc = check_range(b, first, count)) return rc;
     HIPCHK(await_last_render(b));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(sync_bank_stream(b));
     HIPCHK(hipMemcpy(h_values, b->slots + (size_t)s * b->stride + first, count * sizeof(float), hipMemcpyDeviceToHost));
     return FDSP_OK;
 }
@@ -1309,7 +1315,7 @@ int fdsp_bank_get_state(fdsp_bank* b, float* h_slots) {
     if (!b || !h_slots) return fail(FDSP_EINVAL, "bank or buffer NULL");
     DeviceGuard guard(b->device);
     HIPCHK(await_last_render(b));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(sync_bank_stream(b));
     if (b->nslots == 0) return FDSP_OK;
     HIPCHK(hipMemcpy2D(h_slots, b->V * sizeof(float), b->slots, b->stride * sizeof(float), b->V * sizeof(float),
                        (size_t)b->nslots, hipMemcpyDeviceToHost));
@@ -1321,7 +1327,7 @@ int fdsp_bank_set_state(fdsp_bank* b, const float* h_slots) {
     if (!b || !h_slots) return fail(FDSP_EINVAL, "bank or buffer NULL");
     DeviceGuard guard(b->device);
     HIPCHK(await_last_render(b));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(sync_bank_stream(b));
     if (b->nslots == 0) return FDSP_OK;
     HIPCHK(hipMemcpy2D(b->slots, b->stride * sizeof(float), h_slots, b->V * sizeof(float), b->V * sizeof(float),
                        (size_t)b->nslots, hipMemcpyHostToDevice));
@@ -1380,12 +1386,12 @@ int ensure_panw(fdsp_bank* b) {
     hipLaunchKernelGGL(k_pan_weights, dim3((unsigned)((b->stride + 255) / 256)), dim3(256), 0, b->stream, (const float*)nullptr, b->panw,
                        b->panw + b->stride, b->stride, b->V);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(sync_bank_stream(b));
     return FDSP_OK;
 }
 int mix_reserve(fdsp_bank* b, size_t floats) {
     if (floats <= b->mix_part_n) return FDSP_OK;
-    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(sync_bank_stream(b));
     if (b->ext_pending) HIPCHK(hipEventSynchronize(b->e1));  // a render on a caller's stream may still write the old buffer
     if (b->mix_part) hipFree(b->mix_part);
     b->mix_part = nullptr;
@@ -1414,7 +1420,7 @@ int fdsp_bank_set_pan(fdsp_bank* b, const float* h_pan, size_t first, size_t cou
     }
     hipFreeAsync(d, b->stream);
     HIPCHK(e);
-    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(sync_bank_stream(b));
     return FDSP_OK;
 }
 
@@ -1489,7 +1495,7 @@ int fdsp_bank_set_ring(fdsp_bank* b, int ring_index, const float* data, size_t f
     float* dst = b->ring + (size_t)ring_index * b->ring_cap * b->stride + first;
     HIPCHK(hipMemcpy2DAsync(dst, b->stride * sizeof(float), t.data(), count * sizeof(float), count * sizeof(float), frames,
                             hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(sync_bank_stream(b));
     return FDSP_OK;
 }
 
@@ -1516,7 +1522,7 @@ int fdsp_bank_set_events(fdsp_bank* b, const double* events, const int* fade, si
         std::vector<int> fi(b->stride, FDSP_FADE_SMOOTH);
         HIPCHK(hipMemcpyAsync(b->ev, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
         HIPCHK(hipMemcpyAsync(b->ev_fade, fi.data(), fi.size() * sizeof(int), hipMemcpyHostToDevice, b->stream));
-        HIPCHK(hipStreamSynchronize(b->stream));
+        HIPCHK(sync_bank_stream(b));
     }
     if (b->ev_host.empty()) {
         b->ev_host.assign(4 * b->V, 0.0);
@@ -1528,12 +1534,12 @@ int fdsp_bank_set_events(fdsp_bank* b, const double* events, const int* fade, si
     for (int k = 0; k < 4; k++) {
         for (size_t i = 0; i < count; i++) col[i] = events[4 * i + k];
         HIPCHK(hipMemcpyAsync(b->ev + (size_t)k * b->stride + first, col.data(), count * sizeof(double), hipMemcpyHostToDevice, b->stream));
-        HIPCHK(hipStreamSynchronize(b->stream));
+        HIPCHK(sync_bank_stream(b));
     }
     std::vector<int> fv(count, FDSP_FADE_SMOOTH);
     if (fade) fv.assign(fade, fade + count);
     HIPCHK(hipMemcpyAsync(b->ev_fade + first, fv.data(), count * sizeof(int), hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(sync_bank_stream(b));
     return FDSP_OK;
 }
 
@@ -1691,7 +1697,7 @@ int fdsp_bank_process_host(fdsp_bank* b, size_t frames, const float* h_in, float
         if (n_in) memcpy(b->pin_in, h_in, n_in * sizeof(float));
         rc = fdsp_bank_process(b, frames, n_in ? b->pin_in : nullptr, b->pin_out, layout, frame_stride, mode, nullptr);
         if (rc != FDSP_OK) return rc;
-        e = hipStreamSynchronize(b->stream);
+        e = sync_bank_stream(b);
         if (e != hipSuccess) return fail(FDSP_EDEVICE, hipGetErrorString(e));
         memcpy(h_out, b->pin_out, n_out * sizeof(float));
         return FDSP_OK;
@@ -1715,7 +1721,7 @@ int fdsp_bank_process_host(fdsp_bank* b, size_t frames, const float* h_in, float
         else
             e = hipMemcpyAsync(h_out, b->st_out, n_out * sizeof(float), hipMemcpyDeviceToHost, b->stream);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    if (e == hipSuccess) e = sync_bank_stream(b);
     if (e != hipSuccess) return fail(FDSP_EDEVICE, hipGetErrorString(e));
     return rc;
 }
@@ -1723,7 +1729,7 @@ int fdsp_bank_process_host(fdsp_bank* b, size_t frames, const float* h_in, float
 int fdsp_bank_synchronize(fdsp_bank* b) {
     if (!b) return fail(FDSP_EINVAL, "bank is NULL");
     DeviceGuard guard(b->device);
-    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(sync_bank_stream(b));
     b->async_param_pending = false;
     return FDSP_OK;
 }

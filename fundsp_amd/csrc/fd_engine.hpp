@@ -71,6 +71,9 @@ struct KindOps {
     // mix kernels) -- called by fdsp_bank_mix_reserve / fdsp_bank_set_pan, the calls a host makes BEFORE its real-time loop or stream
     // capture; `fast`: the tolerance-mode variant.  Empty for ahead-of-time kinds.
     std::function<void(bool fast)> prepare_mix;
+    // ... and the render path of a bank of `voices` voices (run-time compiled three-stage generator chains: the time-split kernels that
+    // small banks take live in the kind's second module) -- called when a bank is created, so that no render compiles anything.
+    std::function<void(size_t voices)> prepare_render;
     // ... and the Sequencer's mixed output in one launch (render_events_body MIXE): part as above, [groups][outputs][T]; graphs of
     // at most two outputs (the block tiles of four waves must fit the CU's LDS)
     std::function<bool(float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, const double* ev,

@@ -457,6 +457,11 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
                        int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
         jit_render(jm.get(), slots, stride, V, in, outp, T, fstride, layout, mode, aux, ring, ring_cap, s, jm.get(), 0);
     };
+    if (jm->ts_ok)  // small banks of this kind take the time-split kernels: build their module when such a bank is created, not in its first render
+        out->prepare_render = [jm](size_t voices) {
+            if ((voices + 63) / 64 <= 2 * (size_t)simd_count() / 4)
+                if (JitMix* mm = jit_extra_module(jm.get(), 0)) mm->get();
+        };
     if (jm->has_fast)  // tolerance mode: the same source with JitG = FastOf<G>, compiled the first time a FAST bank renders
         out->render_fast = [jm](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T, size_t fstride,
                                 int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {

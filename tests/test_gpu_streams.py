@@ -125,3 +125,29 @@ def test_device_side_fill_and_stream_capture(gpu):
             chunks.append(torch.cat(outs, dim=1).clone())
         torch.cuda.synchronize()
     assert torch.equal(ints(torch.cat(chunks, dim=1)), ints(want))
+
+
+def test_run_time_compiled_small_bank_captures_its_first_launch(gpu):
+    """A run-time compiled generator chain on a small bank takes the time-split kernels, which live in the kind's second module: that module is
+    built when the BANK is created (KindOps::prepare_render), so even the bank's very first launches can be recorded into a HIP graph."""
+    import torch
+    from fundsp_amd import graph as GR
+
+    V, NB = 64 * 6, 4
+    p = W.fm_svf_params(V, SR)
+    g = GR.sine_hz(p["f"]) * p["f"] * p["m"] + p["f"] >> GR.sine() >> GR.lowpass_hz(p["fc"], p["q"])
+    want = W.make_fm_svf_bank(V, SR, params=p).process(64 * NB)
+    b = gpu.Bank.from_graph(g, V, sample_rate=SR)
+    b.set_seed(p["seed"])
+    outs = [torch.empty((1, 64, V), dtype=torch.float32, device="cuda") for _ in range(NB)]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            for k in range(NB):
+                b.process(64, out=outs[k])        # the first launches this bank ever sees
+        assert b.get_option("last_kernel") == 4
+        gr.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(ints(torch.cat(outs, dim=1)), ints(want))
