@@ -21,6 +21,10 @@ namespace {
 thread_local std::string g_err;
 }
 namespace fd {
+std::string jit_source_mix(const std::string& type_expr, const std::string& prelude);  // fd_jit.hip: the second module of a run-time compiled graph
+int jit_compile_src(const std::string& src, const std::string& type_expr, std::vector<char>* code, std::string* log);
+}  // namespace fd
+namespace fd {
 // process-wide DEFAULTS (fdsp_set_option); a bank's own value (fdsp_bank_set_option) overrides them for that bank.  Atomics:
 // hosts drive banks from several threads.  The launch code never reads these: it reads the thread-local block below.
 std::atomic<int> g_pipe_split{1}, g_fdn_kernel{0}, g_time_split{1};
@@ -813,6 +817,10 @@ int fdsp_graph_check(const char* type_expr) {
     std::vector<char> code;
     std::string log;
     if (fd::jit_compile_code(type_expr, "", &code, &log) != 0) return fail(FDSP_EINVAL, log);
+    // ... and the kind's second module (fused mix-down and time-split kernels, compiled lazily at run time): a graph whose main module builds
+    // must not fail there either
+    code.clear();
+    if (fd::jit_compile_src(fd::jit_source_mix(type_expr, ""), type_expr, &code, &log) != 0) return fail(FDSP_EINVAL, "second module (mix-down / time-split kernels): " + log);
     return FDSP_OK;
 }
 

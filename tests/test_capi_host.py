@@ -140,3 +140,19 @@ def test_rust_shim_declares_the_c_abi():
         assert method in shim, f"HipBank lacks `{method}`"
     # the infallible trait methods keep the engine's return code instead of dropping it
     assert shim.count("self.last_error = Some(last_error())") >= 4
+
+
+def test_second_module_of_run_time_compiled_graphs_builds():
+    """fdsp_graph_check compiles BOTH modules of a run-time compiled graph with hiprtc (no device needed): the main one and the lazily built
+    second one (fused mix-down, time-split kernels).  Shapes that exercise its guards: a three-stage generator chain (time-split kernels
+    instantiated), one with three outputs behind it (time-split mix-down refused by its guard, pipeline mix-down fits), four outputs (no mix
+    tile fits: empty bodies), a graph with an input and rings (no pipeline plan for the mix), a feedback graph (flush-to-zero flags)."""
+    import fundsp_amd
+
+    L = fundsp_amd.lib()
+    fm = "Pipe<Pipe<Unop<Pipe<Constant<1>,Sine>,UAddScalar>,Sine>,FixedSvf>"
+    for expr in (fm, "Pipe<Noise,Biquad>", "Pipe<Noise,ButterLowpass<1>>",
+                 f"Stack<Stack<{fm},{fm}>,{fm}>", f"Stack<Stack<{fm},{fm}>,Stack<{fm},{fm}>>",
+                 "Pipe<Pass,FixedSvf>",
+                 "Pipe<Pipe<Unop<Pipe<Constant<1>,Sine>,UAddScalar>,Sine>,Panner>"):      # a stereo generator chain: the time-split MIX_SUM kernels
+        assert L.fdsp_graph_check(expr.encode()) == 0, (expr, L.fdsp_last_error())
