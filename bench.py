@@ -548,60 +548,75 @@ def secondary(F, W, torch, sr, mode):
     # the next render.  Round 4: the mix-down is FUSED into the render kernel (fdsp_bank_process_mix: the last stage of a voice group
     # reduces its 64 voices through LDS, one float per channel and frame leaves for HBM) -- the voice-out buffer
     # (12.6 GB) is neither written nor re-read.  The unfused pair (voice-out render + fdsp_sum_voices, same summation order) beside it.
-    try:
-        V, T = 32768, 48000
-        wl = make_workload(F, W, torch, 4, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, "exact")
-        comm = F.Comm.local([0])
-        bank = wl["bank"]
-        bank.mix_reserve(T)
-        ms_render, kms = quick(F, torch, wl, T, mode, steps=3, warmup=1)
+    for cfg4, name4 in (("4v", "config4_var_gate_mix_single_rank"), (4, "config4_mix_single_rank")):
+        try:
+            V, T = 32768, 48000
+            wl = make_workload(F, W, torch, cfg4, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, "exact")
+            plan = wl.get("plan")
+            comm = F.Comm.local([0])
+            bank = wl["bank"]
+            bank.mix_reserve(T)
+            ms_render, kms = quick(F, torch, wl, T, mode, steps=3, warmup=1)
 
-        def wall(fn, n):
-            fn()
-            comm.wait(0)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
+            def wall(fn, n):
                 fn()
-            comm.wait(0)
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / n * 1e3
-        keep = []
+                comm.wait(0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                comm.wait(0)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e3
+            keep = []
 
-        def fused_step():
-            keep.append(bank.process_mix(T, wl["inp"], mix=F.MIX_SUM, mode=mode))
-            comm.allreduce(keep[-1], slot=0)
-            del keep[:-2]
+            fused_k = [0.0]
 
-        def unfused_step():
-            bank.process(T, wl["inp"], wl["out"], layout=wl["layout"], frame_stride=wl["fs"], mode=mode)
-            keep.append(F.sum_voices(wl["out"]))
-            comm.allreduce(keep[-1], slot=0)
-            del keep[:-2]
-        ms_fused = wall(fused_step, 4)
-        fused_kernel_ms = bank.last_kernel_ms()
-        ms_unfused = wall(unfused_step, 3)
-        mix = keep[-1]
-        t0 = time.perf_counter()
-        for _ in range(20):
-            comm.allreduce(mix, slot=0)
-            comm.wait(0)
-        ar_us = (time.perf_counter() - t0) / 20 * 1e6
-        groups = (V + 63) // 64
-        out.append({"name": "config4_mix_single_rank", "what": "BASELINE config 4 per-GPU shard (32768 voices x 48000 frames) with the path's exchange "
-                    "step: the stereo mix-down FUSED into the render kernel (fdsp_bank_process_mix, FDSP_MIX_SUM: group partials [512][2][48000] f32 "
-                    "+ fd k_mix_tree) + one fdsp_mix_allreduce of [2][48000] f32 (RCCL inside the library, side stream, 1-rank communicator), "
-                    "overlapped with the next render; the unfused pair (voice-out render + fdsp_sum_voices, same order) beside it",
-                    "ms_per_step_render_only": round(ms_render, 4), "ms_per_step_with_mix_and_allreduce": round(ms_fused, 4),
-                    "fused_render_plus_tree_kernel_ms": round(fused_kernel_ms, 4),
-                    "ms_per_step_unfused_mix_and_allreduce": round(ms_unfused, 4),
-                    "partial_mix_bytes_per_step": groups * 2 * T * 4, "voice_out_bytes_not_written": V * T * 8,
-                    "allreduce_blocking_us_1rank": round(ar_us, 1),
-                    "value": round(V * T / ms_fused / 1e3, 1), "unit": "Msamples/s"})
-        comm.close()
-        del wl, keep, mix
-    except Exception as e:
-        out.append({"name": "config4_mix_single_rank", "error": repr(e)})
+            def fused_step():
+                if plan is not None:   # the Var-gate shape: the note's launches, their [2][n] pieces joined, ONE all-reduce per step
+                    pieces = [torch.empty((2, n), dtype=torch.float32, device="cuda") for _, n in plan]
+                    run_plan(wl, mode, F.MIX_SUM, pieces)          # (enqueued back to back: nothing waits inside the step)
+                    keep.append(torch.cat(pieces, dim=1))
+                else:
+                    keep.append(bank.process_mix(T, wl["inp"], mix=F.MIX_SUM, mode=mode))
+                comm.allreduce(keep[-1], slot=0)
+                del keep[:-2]
+
+            def unfused_step():
+                if plan is not None:
+                    run_plan(wl, mode)
+                    keep.append(torch.cat([F.sum_voices(o) for o in wl["outs"]], dim=1))
+                else:
+                    bank.process(T, wl["inp"], wl["out"], layout=wl["layout"], frame_stride=wl["fs"], mode=mode)
+                    keep.append(F.sum_voices(wl["out"]))
+                comm.allreduce(keep[-1], slot=0)
+                del keep[:-2]
+            ms_fused = wall(fused_step, 4)
+            if plan is not None:
+                fused_k[0] = run_plan(wl, mode, F.MIX_SUM, [torch.empty((2, n), dtype=torch.float32, device="cuda") for _, n in plan], kernel_ms=True)
+            fused_kernel_ms = fused_k[0] if plan is not None else bank.last_kernel_ms()
+            ms_unfused = wall(unfused_step, 3)
+            mix = keep[-1]
+            t0 = time.perf_counter()
+            for _ in range(20):
+                comm.allreduce(mix, slot=0)
+                comm.wait(0)
+            ar_us = (time.perf_counter() - t0) / 20 * 1e6
+            groups = (V + 63) // 64
+            out.append({"name": name4, "what": ("BASELINE config 4 in the reference's gate shape (var(gate) >> adsr_live: two launches per step, the Var slot set in between), " if plan is not None else "BASELINE config 4, gate as an HBM input stream, ") + "per-GPU shard (32768 voices x 48000 frames) with the path's exchange "
+                        "step: the stereo mix-down FUSED into the render kernel (fdsp_bank_process_mix, FDSP_MIX_SUM: group partials [512][2][48000] f32 "
+                        "+ fd k_mix_tree) + one fdsp_mix_allreduce of [2][48000] f32 (RCCL inside the library, side stream, 1-rank communicator), "
+                        "overlapped with the next render; the unfused pair (voice-out render + fdsp_sum_voices, same order) beside it",
+                        "ms_per_step_render_only": round(ms_render, 4), "ms_per_step_with_mix_and_allreduce": round(ms_fused, 4),
+                        "fused_render_plus_tree_kernel_ms": round(fused_kernel_ms, 4),
+                        "ms_per_step_unfused_mix_and_allreduce": round(ms_unfused, 4),
+                        "partial_mix_bytes_per_step": groups * 2 * T * 4, "voice_out_bytes_not_written": V * T * 8,
+                        "allreduce_blocking_us_1rank": round(ar_us, 1),
+                        "value": round(V * T / ms_fused / 1e3, 1), "unit": "Msamples/s"})
+            comm.close()
+            del wl, keep, mix
+        except Exception as e:
+            out.append({"name": name4, "error": repr(e)})
     # ... and the headline's voices in mode B: every voice panned (FDSP_MIX_PAN) and summed in the render launch
     try:
         V, T = TOTAL_VOICES, 48000
@@ -703,6 +718,9 @@ def parse_args(argv=None):
                     help="pipeline split of Pipe-chain kinds: 0 off, 1 best plan (default), 2 / 3 = that many stages")
     ap.add_argument("--math", choices=["exact", "fast"], default="exact",
                     help="exact = the reference's arithmetic, bit-identical to the oracle (headline); fast = tolerance mode (FDSP_MATH_FAST)")
+    ap.add_argument("--gate", choices=["var", "stream"], default="var",
+                    help="--config 4: var = the reference's own gate shape `var(gate) >> adsr_live` (examples/live_adsr.rs:72): no graph input, one step = the "
+                         "launches of one note with the Var slot set on the device in between (default); stream = the gate as an audio-rate HBM input [frames][voices]")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall-time budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs 2 / 4 / 5, tolerance mode)")
     return ap.parse_args(argv)
@@ -935,16 +953,36 @@ def run_rank(args, torch, F, peers, device):
         else:
             first, V = rank * base_voices, base_voices
         fused = fused_mix(args, F, layout)
-        wl = make_workload(F, W, torch, args.config, V, T, sr, first, layout, args.math, voice_out=not fused)
+        cfg = "4v" if args.config == 4 and args.gate == "var" else args.config
+        wl = make_workload(F, W, torch, cfg, V, T, sr, first, layout, args.math, voice_out=not fused)
         bank = wl["bank"]
         mixes = []
+        plan = wl.get("plan")
         if fused:
             bank.mix_reserve(T)
             # mode B of SURVEY 8(d): the algorithmic bytes are the inputs and the [2][T] mix -- "not a bandwidth test"
-            wl["bps"] = 4 if args.config == 4 else 0
+            wl["bps"] = 4 if cfg == 4 else 0
             wl["kernel"] = wl["kernel"].replace("fd::k_render_pipe<", "fd::k_render_pipe_mix<") + " + fd::k_mix_tree (fused mix-down: no voice-out buffer)"
+        step_kernel_ms = [0.0]
 
         def step():
+            if plan is not None:
+                # the Var-gate shape: one note = the plan's launches with the shared variable set before each; the step's mix (mode B) is
+                # assembled from the launches' [2][n] pieces before its ONE all-reduce
+                if fused:
+                    pieces = [torch.empty((2, n), dtype=torch.float32, device="cuda") for _, n in plan]
+                    step_kernel_ms[0] = run_plan(wl, mode, F.MIX_SUM, pieces, kernel_ms=True)
+                    mix = torch.cat(pieces, dim=1)
+                else:
+                    step_kernel_ms[0] = run_plan(wl, mode, kernel_ms=True)
+                    mix = None
+                if args.mix:
+                    if mix is None:
+                        mix = torch.cat([F.sum_voices(o) for o in wl["outs"]], dim=1)
+                    peers.comm.allreduce(mix, slot=peers.slot)
+                    mixes.append(mix)
+                    del mixes[:-2]
+                return
             if not fused:
                 bank.process(T, wl["inp"], wl["out"], layout=wl["layout"], frame_stride=wl["fs"], mode=mode)
             if args.mix:
@@ -973,7 +1011,7 @@ def run_rank(args, torch, F, peers, device):
                 meter.sample_clock()   # while this step's kernel runs (the launch is asynchronous, the read below waits for it)
             # HIP events recorded by the C ABI on the launch stream around the render kernel (reading here synchronises
             # on that launch, which the next step's launch on the same stream is ordered behind anyway)
-            kernel_ms.append(bank.last_kernel_ms())
+            kernel_ms.append(step_kernel_ms[0] if plan is not None else bank.last_kernel_ms())
         if args.mix:
             peers.comm.wait(peers.slot)   # the last all-reduce belongs to the timed region
         fence()
@@ -1085,7 +1123,9 @@ def run_rank(args, torch, F, peers, device):
             "config": {
                 "workload": {3: "BASELINE config 3: sine_hz(f)*f*m+f >> sine() >> lowpass_hz(fc,q), ",
                              2: "BASELINE config 2: noise() >> lowpass biquad (BiquadBank<f32x8> lane per voice), ",
-                             4: "BASELINE config 4 voice: ((dc(f)>>saw()|dc(fc)|dc(q))>>moog())*adsr_live(.01,.1,.6,.2)>>pan(p), gate in, ",
+                             4: ("BASELINE config 4 voice: ((dc(f)>>saw()|dc(fc)|dc(q))>>moog())*(var(gate)>>adsr_live(.01,.1,.6,.2))>>pan(p), the gate a shared variable "
+                                 "set between the launches of one note (high 0.5 s, low 0.5 s), " if args.gate == "var" else
+                                 "BASELINE config 4 voice: ((dc(f)>>saw()|dc(fc)|dc(q))>>moog())*adsr_live(.01,.1,.6,.2)>>pan(p), gate in as an audio-rate stream, "),
                              5: "BASELINE config 5: reverb_stereo(10.0, 2.0, 0.5) 32-line FDN, stereo noise in, planar I/O, "}[args.config] +
                             f"{total_voices} {unit_name} in total = {V} per GPU x {T} frames/step @ {sr:g} Hz, "
                             f"{'planar ([' + unit_name[:-1] + '][channel][frame] f32)' if args.config == 5 or args.layout == 'planar' else ('mix-out ([2][frame] f32, fused stereo mix-down: mode B)' if fused_mix(args, F, layout) else 'voice-out ([frame][voice] f32)')}, "
