@@ -501,7 +501,7 @@ def secondary(F, W, torch, sr, mode):
                                      ("5r4", 2048, "reverb4_stereo_2048", "M instance-frames/s", "exact")):
         T = 48000
         wl = make_workload(F, W, torch, cfg, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, math)
-        ms, kms = quick(F, torch, wl, T, mode, steps=4, warmup=1)
+        ms, kms = quick(F, torch, wl, T, mode, steps=6 if cfg == "4v" else 4, warmup=3 if cfg == "4v" else 1)
         algo = V * T * wl["bps"] + V * wl["slot_bytes"]
         arith = "exact arithmetic" if math == "exact" else ("tolerance mode (FDSP_MATH_FAST: the ladder's tanh on the hardware exp2 / reciprocal, "
                                                             "recurrence exact; within 1e-4 of the exact mode: tests/test_gpu_math_fast.py)")
@@ -964,6 +964,7 @@ def run_rank(args, torch, F, peers, device):
             wl["bps"] = 4 if cfg == 4 else 0
             wl["kernel"] = wl["kernel"].replace("fd::k_render_pipe<", "fd::k_render_pipe_mix<") + " + fd::k_mix_tree (fused mix-down: no voice-out buffer)"
         step_kernel_ms = [0.0]
+        plan_kernel_ms = [False]   # inside the timed region the plan's launches are enqueued back to back; their HIP-event times are read in extra steps after it
 
         def step():
             if plan is not None:
@@ -971,10 +972,10 @@ def run_rank(args, torch, F, peers, device):
                 # assembled from the launches' [2][n] pieces before its ONE all-reduce
                 if fused:
                     pieces = [torch.empty((2, n), dtype=torch.float32, device="cuda") for _, n in plan]
-                    step_kernel_ms[0] = run_plan(wl, mode, F.MIX_SUM, pieces, kernel_ms=True)
+                    step_kernel_ms[0] = run_plan(wl, mode, F.MIX_SUM, pieces, kernel_ms=plan_kernel_ms[0])
                     mix = torch.cat(pieces, dim=1)
                 else:
-                    step_kernel_ms[0] = run_plan(wl, mode, kernel_ms=True)
+                    step_kernel_ms[0] = run_plan(wl, mode, kernel_ms=plan_kernel_ms[0])
                     mix = None
                 if args.mix:
                     if mix is None:
@@ -1011,11 +1012,20 @@ def run_rank(args, torch, F, peers, device):
                 meter.sample_clock()   # while this step's kernel runs (the launch is asynchronous, the read below waits for it)
             # HIP events recorded by the C ABI on the launch stream around the render kernel (reading here synchronises
             # on that launch, which the next step's launch on the same stream is ordered behind anyway)
-            kernel_ms.append(step_kernel_ms[0] if plan is not None else bank.last_kernel_ms())
+            if plan is None:
+                kernel_ms.append(bank.last_kernel_ms())
         if args.mix:
             peers.comm.wait(peers.slot)   # the last all-reduce belongs to the timed region
         fence()
         elapsed = peers.max(time.perf_counter() - t0, torch)
+        if plan is not None:   # the kernels' own HIP-event times: three more steps of the same work, waiting for every launch
+            plan_kernel_ms[0] = True
+            for _ in range(3):
+                step()
+                kernel_ms.append(step_kernel_ms[0])
+            if args.mix:
+                peers.comm.wait(peers.slot)
+            fence()
         wl["power"] = meter.stop(window_steps + warmup + steps) if meter is not None else None
         return elapsed, kernel_ms, wl, V
 
