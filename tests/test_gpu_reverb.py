@@ -138,3 +138,30 @@ def test_reverb4_dedicated_kernel_equals_the_run_time_compiled_graph(gpu):
     torch.cuda.synchronize()
     assert float(ya.abs().max()) > 0.05
     assert torch.equal(ya.view(torch.int32), yb.view(torch.int32))
+
+
+def test_reverb4_stereo_sample_rate_change_and_reset(gpu):
+    """Delay::set_sample_rate resizes and resets the lines when the rate changes (delay.rs:105-113): a reverb4_stereo bank moved from 48 kHz to
+    44.1 kHz renders what a fresh oracle graph at 44.1 kHz renders; reset() after some audio gives the same again; a too small room * rate is refused."""
+    import torch
+
+    V, T = 3, 64 * 150 + 5
+    rng = np.random.default_rng(23)
+    x = (rng.random((V, 2, T), dtype=np.float32) * 2 - 1).astype(np.float32)
+    b = gpu.Bank.reverb4_stereo(V, 25.0, 1.5)
+    b.set_sample_rate(SR)
+    b.process(64 * 10, torch.from_numpy(np.ascontiguousarray(x[:, :, :640])).cuda(), layout=LAYOUT_PLANAR, frame_stride=640)
+    b.set_sample_rate(44100.0)
+    got = b.process(T, torch.from_numpy(x).cuda(), layout=LAYOUT_PLANAR, frame_stride=T).cpu().numpy()
+    b.reset()
+    again = b.process(T, torch.from_numpy(x).cuda(), layout=LAYOUT_PLANAR, frame_stride=T).cpu().numpy()
+    for v in range(V):
+        n = O.reverb4_stereo(25.0, 1.5)
+        n.set_sample_rate(44100.0)
+        assert_bit_equal(got[v], n.render_blocks(x[v]), f"reverb4_stereo at 44.1 kHz, instance {v}")
+    assert_bit_equal(again, got, "after reset()")
+    assert np.abs(got).max() > 0.01
+    tiny = gpu.Bank.reverb4_stereo(2, 15.0, 2.0)
+    with pytest.raises(gpu.FdspError):
+        tiny.set_sample_rate(2000.0)          # the shortest line would be 95 samples: not longer than two blocks
+    tiny.set_sample_rate(SR)                  # the bank keeps working at a rate that fits
