@@ -133,7 +133,8 @@ def cpu_baseline(voices, frames, sample_rate, target_seconds):
         "threads_pinned": True,
         "one_thread_value": round(one[0], 3),
         "scaling_efficiency": None if eff is None else round(eff, 3),
-        "kind": "port",
+        "kind": "port (monomorphised)",
+        "flags": f"gcc {NATIVE_FLAGS}",
         "simd": L.o_fast_simd_flavour().decode(),
         "tree_walk_value": round(out["tree"][0], 3),
         "tick_shaped_value": round(out["tick"][0], 3),
