@@ -440,7 +440,8 @@ namespace {
 
 // A render on a caller stream is ordered after whatever the bank's own stream still has pending (parameter uploads).
 // While the caller's stream is being CAPTURED into a HIP graph a host-side synchronize would invalidate the capture; the
-// bank's stream is idle by then (every setter synchronizes before it returns), so the wait is simply skipped.
+// bank's stream is idle by then (every setter waits for the copies AND the coefficient-update launch it queued before it returns), so
+// the wait is simply skipped.
 // (The one setter that does NOT wait -- fdsp_bank_set_param_all, the device-side fill -- marks the bank; a capture that would start
 // behind such work is refused instead of racing with it: the host calls fdsp_bank_synchronize first.)
 // every host-side wait for the bank's stream goes through here: whatever fdsp_bank_set_param_all queued has landed afterwards
@@ -1184,6 +1185,7 @@ int fdsp_bank_set_sample_rate(fdsp_bank* b, double sr) {
     before_update_launch(b, 0, b->V);
     b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 1, sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
+    HIPCHK(sync_bank_stream(b));
     return FDSP_OK;
 }
 
@@ -1194,11 +1196,13 @@ int fdsp_bank_reset(fdsp_bank* b) {
         HIPCHK(await_last_render(b));
         fd::fdn_launch_reset(b->fdn->c, b->fdn->st, b->V, b->stream);
         HIPCHK(hipGetLastError());
+        HIPCHK(sync_bank_stream(b));
         return FDSP_OK;
     }
     HIPCHK(await_last_render(b));
     b->ops->lifecycle(b->slots, b->stride, 0, b->stride, 2, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
+    HIPCHK(sync_bank_stream(b));
     return FDSP_OK;
 }
 
@@ -1260,6 +1264,7 @@ int fdsp_bank_set_param(fdsp_bank* b, const char* name, const float* h_values, s
     before_update_launch(b, first, count);
     b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
+    HIPCHK(sync_bank_stream(b));  // (the bank's stream is idle when a setter returns: order_after_bank_stream relies on it under capture)
     return FDSP_OK;
 }
 
@@ -1302,6 +1307,7 @@ int fdsp_bank_set_param_u64(fdsp_bank* b, const char* name, const uint64_t* h_va
     before_update_launch(b, first, count);
     b->ops->lifecycle(b->slots, b->stride, first, count, 1, b->sr, nullptr, b->aux, b->ring, b->ring_cap, b->stream);
     HIPCHK(hipGetLastError());
+    HIPCHK(sync_bank_stream(b));
     return FDSP_OK;
 }
 
