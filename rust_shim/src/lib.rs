@@ -50,6 +50,8 @@ pub mod ffi {
         pub fn fdsp_kind_by_name(name: *const c_char) -> c_int;
         pub fn fdsp_graph_compile_rust(name: *const c_char, rust_type_name: *const c_char, hints: *const c_char, source: *const c_char) -> c_int;
         pub fn fdsp_bank_create_on(device: c_int, kind: *const c_char, voices: usize, ring_frames: usize, out: *mut *mut FdspBank) -> c_int;
+        pub fn fdsp_reverb_stereo_create_on(device: c_int, instances: usize, room_size: f64, time: f64, damping: f64, out: *mut *mut FdspBank) -> c_int;
+        pub fn fdsp_reverb4_stereo_create_on(device: c_int, instances: usize, room_size: f64, time: f64, out: *mut *mut FdspBank) -> c_int;
         pub fn fdsp_bank_destroy(bank: *mut FdspBank);
         pub fn fdsp_bank_clone(bank: *const FdspBank, out: *mut *mut FdspBank) -> c_int; // Clone: slots, rings, sample rate, options, events
         pub fn fdsp_bank_inputs(bank: *const FdspBank) -> c_int;
@@ -145,6 +147,27 @@ impl<NI: Size<f32>, NO: Size<f32>> HipBank<NI, NO> {
         check(unsafe { fdsp_bank_create_on(device as c_int, kind.as_ptr(), voices, ring_frames, &mut bank) })?;
         let device = unsafe { fdsp_bank_device(bank) };
         Ok(Self { bank, kind, voices, ring_frames, device, last_error: None, _marker: PhantomData })
+    }
+
+    /// `instances` x `reverb_stereo(room_size, time, damping)` (src/prelude.rs:1732-1762) through the dedicated lane-per-frame FDN kernel
+    /// (one wave per instance, the 32 delay lines in registers) instead of the generic lane-per-voice `Feedback` kernel `from_graph` builds
+    /// for the same type: bit-identical output, an order of magnitude faster.  Each instance has two inputs and two outputs.
+    pub fn reverb_stereo(instances: usize, room_size: f64, time: f64, damping: f64, device: i32) -> Result<Self, String> {
+        let mut bank: *mut FdspBank = core::ptr::null_mut();
+        check(unsafe { fdsp_reverb_stereo_create_on(device as c_int, instances, room_size, time, damping, &mut bank) })?;
+        Self::adopt(bank, "reverb_stereo", instances)
+    }
+
+    /// `instances` x `reverb4_stereo(room_size, time)` (src/prelude.rs:1873-1941: two 16-line Hadamard networks in series), same kernel family.
+    pub fn reverb4_stereo(instances: usize, room_size: f64, time: f64, device: i32) -> Result<Self, String> {
+        let mut bank: *mut FdspBank = core::ptr::null_mut();
+        check(unsafe { fdsp_reverb4_stereo_create_on(device as c_int, instances, room_size, time, &mut bank) })?;
+        Self::adopt(bank, "reverb4_stereo", instances)
+    }
+
+    fn adopt(bank: *mut FdspBank, kind: &str, voices: usize) -> Result<Self, String> {
+        let device = unsafe { fdsp_bank_device(bank) };
+        Ok(Self { bank, kind: CString::new(kind).unwrap(), voices, ring_frames: 0, device, last_error: None, _marker: PhantomData })
     }
 
     fn arity_ok(&self) -> bool {
