@@ -13,12 +13,41 @@ import torch
 import fundsp_amd as F
 from fundsp_amd import workloads as W
 
-V, T = 65536, 48000
-bank = W.make_fm_svf_bank(V, 48000.0)
-out = torch.empty((1, T, V), dtype=torch.float32, device="cuda")
-for _ in range(3):
-    bank.process(T, None, out)
+WHICH = os.environ.get("TRAFFIC_WORKLOAD", "c3")   # c3 (default: the headline kernel) | c2 | c4v | c5 | c5r4: the other HBM-side kernels
+T = 48000
+if WHICH == "c3":
+    V = 65536
+    bank = W.make_fm_svf_bank(V, 48000.0)
+    out = torch.empty((1, T, V), dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        bank.process(T, None, out)
+elif WHICH == "c2":        # noise >> biquad on a bank that fills the chip: 4 B per voice-sample out
+    V = 65536
+    bank = W.make_noise_biquad_bank(V, 48000.0)
+    out = torch.empty((1, T, V), dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        bank.process(T, None, out)
+elif WHICH == "c4v":       # config 4, the gate a Var slot: 8 B per voice-sample out, nothing in; one launch per gate value
+    V = 32768
+    F.wavetable_build("saw")
+    bank = W.make_saw_moog_var_bank(V, 48000.0)
+    out = torch.empty((2, T // 2, V), dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        for gate in (1.0, 0.0):
+            bank.set_param(W.C4V_SLOTS["gate"], gate)
+            bank.process(T // 2, None, out)
+else:                      # c5: reverb_stereo(10, 2, 0.5); c5r4: reverb4_stereo(20, 2): 272 B per instance-frame (rings + I/O)
+    V = 2048
+    bank = F.Bank.reverb_stereo(V, 10.0, 2.0, 0.5) if WHICH == "c5" else F.Bank.reverb4_stereo(V, 20.0, 2.0)
+    bank.set_sample_rate(48000.0)
+    inp = torch.rand((V, 2, T), dtype=torch.float32, device="cuda") * 2 - 1
+    outp = torch.empty((V, 2, T), dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        bank.process(T, inp, outp, layout=F.LAYOUT_PLANAR, frame_stride=T)
 torch.cuda.synchronize()
+if WHICH != "c3":          # the calibration kernels below keep their 12.58 GB buffer whatever was rendered
+    V = 65536
+    out = torch.empty((1, T, V), dtype=torch.float32, device="cuda")
 out.fill_(1.0)          # known: V*T*4 bytes written
 torch.cuda.synchronize()
 dst = torch.empty_like(out)
