@@ -1183,6 +1183,10 @@ def run_rank(args, torch, F, peers, device):
         if world == 1 and not args.no_secondary and args.config == 3 and args.math == "exact":
             try:
                 res["secondary"] = secondary(F, W, torch, sr, mode)
+                if measured:  # the HBM-side entries next to what this box's memory system streams (the fill / copy kernels timed above)
+                    for e in res["secondary"]:
+                        if isinstance(e, dict) and "roofline_frac" in e:
+                            e["frac_of_measured_fill"] = round(e["roofline_frac"] * HBM_PEAK_GBS / measured["fill_gbs"], 4)
             except Exception as e:  # never lose the headline line to a secondary measurement
                 res["secondary"] = [{"error": repr(e)}]
         return res
