@@ -1186,7 +1186,8 @@ def run_rank(args, torch, F, peers, device):
                 if measured:  # the HBM-side entries next to what this box's memory system streams (the fill / copy kernels timed above)
                     for e in res["secondary"]:
                         if isinstance(e, dict) and "roofline_frac" in e:
-                            e["frac_of_measured_fill"] = round(e["roofline_frac"] * HBM_PEAK_GBS / measured["fill_gbs"], 4)
+                            e["frac_of_measured_fill"] = round(e["roofline_frac"] * HBM_PEAK_GBS / measured["fill_gbs"], 4)   # write-only kernels
+                            e["frac_of_measured_copy"] = round(e["roofline_frac"] * HBM_PEAK_GBS / measured["copy_gbs"], 4)   # 1:1 read/write (the reverbs' rings)
             except Exception as e:  # never lose the headline line to a secondary measurement
                 res["secondary"] = [{"error": repr(e)}]
         return res
