@@ -404,7 +404,10 @@ struct fdsp_bank {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool timed = false;
     bool ext_pending = false;  // the last render ran on a caller's stream: bank-stream work must wait for its e1
-    mutable bool async_param_pending = false;  // fdsp_bank_set_param_all queued device-side work on the bank's stream and did not wait for it
+    // fdsp_bank_set_param_all queued device-side work on the bank's stream and did not wait for it.  A plain flag, also cleared from const
+    // paths (sync_bank_stream): safe under the handle's threading rule -- ONE host thread at a time per bank (fundsp_hip.h "Threading"), the
+    // rule `process(&mut self)` gives the reference's nodes; it is not an atomic and must not be read from a second thread.
+    mutable bool async_param_pending = false;
     int math = FDSP_MATH_EXACT;  // FDSP_MATH_FAST: renders take the kind's tolerance-mode variant when it has one
     // per-bank launch options (fdsp_bank_set_option); -1 = follow the process-wide default at every launch
     int opt_pipe_split = -1, opt_time_split = -1, opt_fdn_kernel = -1, opt_timing = -1;
@@ -450,12 +453,17 @@ hipError_t sync_bank_stream(const fdsp_bank* b) {
     if (e == hipSuccess) b->async_param_pending = false;
     return e;
 }
-hipError_t order_after_bank_stream(const fdsp_bank* b, hipStream_t s) {
-    if (s == b->stream) return hipSuccess;
+int order_after_bank_stream(const fdsp_bank* b, hipStream_t s) {
+    if (s == b->stream) return FDSP_OK;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-        return b->async_param_pending ? hipErrorStreamCaptureUnsupported : hipSuccess;
-    return sync_bank_stream(b);
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        if (b->async_param_pending)
+            return fail(FDSP_EDEVICE, "a device-side fdsp_bank_set_param_all is still queued on the bank's stream: call fdsp_bank_synchronize before capturing "
+                                      "(the capture is refused rather than left to race with the fill)");
+        return FDSP_OK;
+    }
+    HIPCHK(sync_bank_stream(b));
+    return FDSP_OK;
 }
 
 // ... and the other way round: lifecycle / parameter work on the bank's stream waits for the last render that ran on a
@@ -755,6 +763,12 @@ int fdsp_bank_set_option(fdsp_bank* b, const char* name, int value) {
     if (name && std::strcmp(name, "math") == 0) {
         if (value != FDSP_MATH_EXACT && value != FDSP_MATH_FAST) return fail(FDSP_EINVAL, "math takes FDSP_MATH_EXACT (0) or FDSP_MATH_FAST (1)");
         b->math = value;
+        // run-time compiled kinds: the tolerance-mode modules are built HERE, not inside the bank's next render (which may be captured)
+        if (value == FDSP_MATH_FAST && b->ops) {
+            DeviceGuard guard(b->device);
+            if (b->ops->prepare_render) b->ops->prepare_render(b->V, true);
+            if (b->ops->prepare_mix && b->ops->render_mix_fast && (b->mix_part || b->panw)) b->ops->prepare_mix(true);
+        }
         return FDSP_OK;
     }
     if (const OptSpec* o = launch_opt(name)) {  // -1 = back to the process-wide default
@@ -901,7 +915,7 @@ int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring
         fdsp_bank_destroy(b);  // frees whatever of {slots, stream, e0, e1} exists
         return fail(FDSP_EDEVICE, "stream/event creation failed");
     }
-    if (b->ops->prepare_render) b->ops->prepare_render(voices);  // (run-time compiled kinds: whatever this bank size still has to compile)
+    if (b->ops->prepare_render) b->ops->prepare_render(voices, b->math == FDSP_MATH_FAST);  // (run-time compiled kinds: whatever a bank of this size and arithmetic still has to compile)
     if (b->ops->nrings > 0) {
         if (ring_frames == 0 || ring_frames > 0x7fffffffu) {
             fdsp_bank_destroy(b);
@@ -1359,7 +1373,7 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
     if (mode != FDSP_MODE_PROCESS && mode != FDSP_MODE_TICK) return fail(FDSP_EINVAL, "bad mode");
     if (layout == FDSP_LAYOUT_PLANAR && frame_stride < frames) return fail(FDSP_EINVAL, "frame_stride < frames");
     hipStream_t s = stream ? (hipStream_t)stream : b->stream;
-    HIPCHK(order_after_bank_stream(b, s));  // order after pending parameter updates
+    if (int rc = order_after_bank_stream(b, s)) return rc;  // order after pending parameter updates
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (s != b->stream) hipStreamIsCapturing(s, &cap);
     const bool capturing = cap != hipStreamCaptureStatusNone;  // a captured launch leaves the timing events alone
@@ -1423,6 +1437,9 @@ int fdsp_bank_set_pan(fdsp_bank* b, const float* h_pan, size_t first, size_t cou
     if (int rc = check_range(b, first, count)) return rc;
     if (count == 0) return FDSP_OK;
     if (int rc = ensure_panw(b)) return rc;
+    // a host that pans and then mixes (the FDSP_MIX_PAN flow) may never call fdsp_bank_mix_reserve: run-time compiled graphs build their
+    // mix kernels here as well, so that the first fdsp_bank_process_mix compiles nothing
+    if (b->ops && b->ops->prepare_mix) b->ops->prepare_mix(b->math == FDSP_MATH_FAST && (bool)b->ops->render_mix_fast);
     HIPCHK(await_last_render(b));
     float* d = nullptr;
     HIPCHK(hipMallocAsync((void**)&d, count * sizeof(float), b->stream));
@@ -1469,7 +1486,7 @@ int fdsp_bank_process_mix(fdsp_bank* b, size_t frames, const float* d_in, float*
         if (int rc = mix_reserve(b, groups * R)) return rc;
         if (mix == FDSP_MIX_PAN) if (int rc = ensure_panw(b)) return rc;
     }
-    HIPCHK(order_after_bank_stream(b, s));
+    if (int rc = order_after_bank_stream(b, s)) return rc;
     if (int rc = check_ring_need(b, capturing)) return rc;
     if (b->ext_pending && !capturing) HIPCHK(hipStreamWaitEvent(s, b->e1, 0));
     const bool timing = timing_on(b);
@@ -1588,7 +1605,7 @@ int events_render(fdsp_bank* b, size_t frames, const float* d_in, float* d_out, 
         if (capturing) return fail(FDSP_EINVAL, "fdsp_bank_process_events_mix during a stream capture: call fdsp_bank_mix_reserve before capturing");
         if (int rc = mix_reserve(b, groups * R)) return rc;
     }
-    HIPCHK(order_after_bank_stream(b, s));
+    if (int rc = order_after_bank_stream(b, s)) return rc;
     if (int rc = check_ring_need(b, capturing)) return rc;
     if (b->ext_pending && !capturing) HIPCHK(hipStreamWaitEvent(s, b->e1, 0));
     const bool timing = timing_on(b);  // the per-launch event pair is optional, as in fdsp_bank_process

@@ -68,12 +68,13 @@ struct KindOps {
                        const void* aux, float* ring, uint32_t ring_cap, const float* panw, hipStream_t s)>
         render_mix, render_mix_fast;
     // Whatever the fused mix-down of this kind still has to do before its first launch (run-time compiled graphs: compile and load the
-    // mix kernels) -- called by fdsp_bank_mix_reserve / fdsp_bank_set_pan, the calls a host makes BEFORE its real-time loop or stream
-    // capture; `fast`: the tolerance-mode variant.  Empty for ahead-of-time kinds.
+    // mix kernels) -- called by fdsp_bank_mix_reserve AND fdsp_bank_set_pan (either may be the last call a host makes BEFORE its real-time
+    // loop or stream capture), and by fdsp_bank_set_option("math") for a bank that already holds a partial-mix buffer; `fast`: the tolerance-mode variant.  Empty for ahead-of-time kinds.
     std::function<void(bool fast)> prepare_mix;
     // ... and the render path of a bank of `voices` voices (run-time compiled three-stage generator chains: the time-split kernels that
-    // small banks take live in the kind's second module) -- called when a bank is created, so that no render compiles anything.
-    std::function<void(size_t voices)> prepare_render;
+    // small banks take live in the kind's second module; `fast`: the tolerance-mode twin FastOf<G>, a module of its own) -- called when a
+    // bank is created and when fdsp_bank_set_option switches its arithmetic, so that no render compiles anything.
+    std::function<void(size_t voices, bool fast)> prepare_render;
     // ... and the Sequencer's mixed output in one launch (render_events_body MIXE): part as above, [groups][outputs][T]; graphs of
     // at most two outputs (the block tiles of four waves must fit the CU's LDS)
     std::function<bool(float* slots, size_t stride, size_t V, const float* in, float* part, size_t T, const double* ev,

@@ -457,36 +457,44 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
                        int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
         jit_render(jm.get(), slots, stride, V, in, outp, T, fstride, layout, mode, aux, ring, ring_cap, s, jm.get(), 0);
     };
-    if (jm->ts_ok)  // small banks of this kind take the time-split kernels: build their module when such a bank is created, not in its first render
-        out->prepare_render = [jm](size_t voices) {
-            if ((voices + 63) / 64 <= 2 * (size_t)simd_count() / 4)
-                if (JitMix* mm = jit_extra_module(jm.get(), 0)) mm->get();
-        };
-    if (jm->has_fast)  // tolerance mode: the same source with JitG = FastOf<G>, compiled the first time a FAST bank renders
-        out->render_fast = [jm](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T, size_t fstride,
-                                int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
-            {
-                std::lock_guard<std::mutex> lock(jm->mu);
-                if (!jm->fast && !jm->fast_failed) {
-                    auto fm = std::make_shared<JitModule>();
-                    std::string log;
-                    if (jit_compile_code("typename fd::FastOf<" + jm->type_expr + ">::type", jm->prelude, &fm->code, &log) == 0) {
-                        fm->pipe_stages = jm->pipe_stages;   // FastOf keeps arities, chain shape and tile plan
-                        fm->pipe_min_t = jm->pipe_min_t;
-                        fm->pipe_threads = jm->pipe_threads;
-                        fm->pipe_planar_threads = jm->pipe_planar_threads;
-                        fm->pipe_small = jm->pipe_small;
-                        fm->wpb[0] = jm->wpb[0];
-                        fm->wpb[1] = jm->wpb[1];
-                        jm->fast = fm;
-                    } else {
-                        jm->fast_failed = true;
-                        fprintf(stderr, "fundsp_hip: tolerance-mode variant failed to compile, rendering exactly: %s\n", log.c_str());
-                    }
-                }
+    // tolerance mode: the same source with JitG = FastOf<G>, a module of its own -- compiled when a FAST bank of the kind is created or a
+    // bank is switched to FAST (prepare_render), at the latest the first time a FAST bank renders
+    auto fast_module = [jm]() -> JitModule* {
+        std::lock_guard<std::mutex> lock(jm->mu);
+        if (!jm->fast && !jm->fast_failed) {
+            auto fm = std::make_shared<JitModule>();
+            std::string log;
+            if (jit_compile_code("typename fd::FastOf<" + jm->type_expr + ">::type", jm->prelude, &fm->code, &log) == 0) {
+                fm->pipe_stages = jm->pipe_stages;   // FastOf keeps arities, chain shape and tile plan
+                fm->pipe_min_t = jm->pipe_min_t;
+                fm->pipe_threads = jm->pipe_threads;
+                fm->pipe_planar_threads = jm->pipe_planar_threads;
+                fm->pipe_small = jm->pipe_small;
+                fm->wpb[0] = jm->wpb[0];
+                fm->wpb[1] = jm->wpb[1];
+                jm->fast = fm;
+            } else {
+                jm->fast_failed = true;
+                fprintf(stderr, "fundsp_hip: tolerance-mode variant failed to compile, rendering exactly: %s\n", log.c_str());
             }
-            JitModule* m = jm->fast ? jm->fast.get() : jm.get();
-            jit_render(m, slots, stride, V, in, outp, T, fstride, layout, mode, aux, ring, ring_cap, s, jm.get(), jm->fast ? 1 : 0);
+        }
+        return jm->fast.get();
+    };
+    // Whatever a bank of `voices` voices still has to compile and load before its first render: the tolerance-mode module of a FAST bank, and
+    // for small banks of a three-stage generator chain the second module with the time-split kernels (of G, or of FastOf<G> when that twin
+    // exists -- the `which` jit_render will ask for).  Called when the bank is created / switched, not in its first render.
+    if (jm->ts_ok || jm->has_fast)
+        out->prepare_render = [jm, fast_module](size_t voices, bool fast) {
+            JitModule* fm = (fast && jm->has_fast) ? fast_module() : nullptr;
+            if (fm) fm->get();
+            if (jm->ts_ok && (voices + 63) / 64 <= 2 * (size_t)simd_count() / 4)
+                if (JitMix* mm = jit_extra_module(jm.get(), fm ? 1 : 0)) mm->get();
+        };
+    if (jm->has_fast)
+        out->render_fast = [jm, fast_module](float* slots, size_t stride, size_t V, const float* in, float* outp, size_t T, size_t fstride,
+                                             int layout, int mode, const void* aux, float* ring, uint32_t ring_cap, hipStream_t s) {
+            JitModule* fm = fast_module();
+            jit_render(fm ? fm : jm.get(), slots, stride, V, in, outp, T, fstride, layout, mode, aux, ring, ring_cap, s, jm.get(), fm ? 1 : 0);
         };
     // render + mix-down in one launch (fdsp_bank_process_mix): graphs with a pipeline plan; the kernels are compiled on first use
     jm->nout = meta[1];

@@ -246,7 +246,10 @@ int fdsp_bank_set_state(fdsp_bank* bank, const float* h_slots);
  * setters, reset, set_seed, get/set_state wait for that render (its completion event) -- in either direction nothing
  * overtakes.  A caller's stream that is being CAPTURED into a HIP graph is supported: the launch is recorded without
  * any host-side synchronisation or event, so a real-time host can capture its block-by-block loop once and replay it
- * (tests/test_gpu_streams.py; 65 536 voices x 64 frames: 20.8 -> 13.3 us per block).
+ * (tests/test_gpu_streams.py; 65 536 voices x 64 frames: 20.8 -> 13.3 us per block).  One refusal: a capture that would start behind a
+ * still-queued fdsp_bank_set_param_all (the one setter that does not wait, see its comment) returns FDSP_EDEVICE and fdsp_last_error()
+ * names the remedy -- fdsp_bank_synchronize(bank) before capturing.  Nothing compiles inside a render: run-time compiled kinds build
+ * what a bank needs when it is created and when fdsp_bank_set_option(bank, "math", ..) switches its arithmetic.
  * Input values: every IEEE value is accepted and treated like the reference treats it (tests/test_gpu_specials.py).
  * One input sets the COST of a sample rather than its value: the speed input of Resample<X> (resample.rs:281-303) ticks
  * the enclosed generator `speed` times per output sample, on the device as in the reference -- a speed of 1e9 is a
@@ -315,7 +318,9 @@ double fdsp_bank_events_time(const fdsp_bank* bank);       /* Sequencer::time() 
  * fdsp_bank_mix_reserve(bank, frames) sizes it ahead of a real-time loop or a stream capture (AudioNode::allocate semantics).
  * A mix launch always takes the stage pipeline (or, for small banks of eligible graphs, the time-split kernel): "pipe_split" = 0 and the
  * launch-length thresholds of fdsp_bank_process do not apply to it, and a kind whose graph has no pipeline plan answers FDSP_ENOTSUP.
- * Stream, ordering, timing and capture rules are those of fdsp_bank_process; a CAPTURED launch holds the partial-mix buffer of
+ * Stream, ordering, timing and capture rules are those of fdsp_bank_process (including the refusal of a capture behind a queued
+ * fdsp_bank_set_param_all; run-time compiled graphs build their mix kernels in fdsp_bank_mix_reserve AND in fdsp_bank_set_pan, whichever
+ * the host calls before its loop); a CAPTURED launch holds the partial-mix buffer of
  * capture time, so reserve for the longest launch before capturing and do not grow the reservation while such a graph is alive.  FDSP_ENOTSUP: the kind was built without the
  * fused kernels (the BASELINE kinds fm_svf, sine_hz_lowpass_hz, saw_moog_adsr_pan, noise_biquad have them) -- render
  * voice-out and call the functions below, which use the same order. */

@@ -111,7 +111,7 @@ def test_device_side_fill_and_stream_capture(gpu):
         b.set_param(W.C4V_SLOTS["gate"], 1.0)    # queued on the bank's stream, not waited for
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
-            with pytest.raises(gpu.FdspError):
+            with pytest.raises(gpu.FdspError, match="fdsp_bank_synchronize"):   # the refusal names its remedy
                 b.process(64, out=outs[0])
         del g
         b.synchronize()
@@ -151,3 +151,46 @@ def test_run_time_compiled_small_bank_captures_its_first_launch(gpu):
         gr.replay()
         torch.cuda.synchronize()
     assert torch.equal(ints(torch.cat(outs, dim=1)), ints(want))
+
+
+@pytest.mark.parametrize("how", ["switched", "default"])
+def test_run_time_compiled_fast_small_bank_captures_its_first_launch(gpu, how):
+    """The same for the tolerance mode: FastOf<G> is a module of its own (and its time-split kernels another), built when a FAST bank of the kind
+    is created (process-wide default) or when fdsp_bank_set_option switches a bank to FAST -- not inside the bank's first render, which
+    a host may be capturing.  A graph nobody has compiled before, so that a lazy compile could not hide in a cache."""
+    import torch
+    import fundsp_amd as F
+    from fundsp_amd import graph as GR
+
+    V, NB = 64 * 7, 3
+    p = W.fm_svf_params(V, SR)
+    mk = lambda: GR.sine_hz(p["f"]) * p["f"] * (p["m"] + (0.25 if how == "switched" else 0.5)) + p["f"] >> GR.sine() >> GR.lowpass_hz(p["fc"], p["q"])
+    if how == "default":
+        assert gpu.lib().fdsp_set_option(b"math", F.MATH_FAST) == 0
+    try:
+        b = gpu.Bank.from_graph(mk(), V, sample_rate=SR)
+        r = gpu.Bank.from_graph(mk(), V, sample_rate=SR)
+    finally:
+        gpu.lib().fdsp_set_option(b"math", F.MATH_EXACT)
+    if how == "switched":
+        b.set_option("math", F.MATH_FAST)
+        r.set_option("math", F.MATH_FAST)
+    assert b.get_option("math") == F.MATH_FAST and b.get_option("math_has_fast_variant") == 1
+    b.set_seed(p["seed"])
+    r.set_seed(p["seed"])
+    outs = [torch.empty((1, 64, V), dtype=torch.float32, device="cuda") for _ in range(NB)]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            for k in range(NB):
+                b.process(64, out=outs[k])        # the first launches this bank ever sees
+        assert b.get_option("last_kernel") == 4
+        gr.replay()
+        torch.cuda.synchronize()
+    want = r.process(64 * NB)
+    assert torch.equal(ints(torch.cat(outs, dim=1)), ints(want))
+    exact = gpu.Bank.from_graph(mk(), V, sample_rate=SR)
+    exact.set_seed(p["seed"])
+    assert not torch.equal(ints(exact.process(64 * NB)), ints(want)), "the FAST bank must not have rendered exactly"
