@@ -48,11 +48,23 @@ class Bank:
         self.sample_rate = _lib.DEFAULT_SR
 
     @classmethod
-    def from_graph(cls, graph, voices, ring_frames=0, sample_rate=None):
+    def from_graph(cls, graph, voices, ring_frames=0, sample_rate=None, fdn_kernel=True):
         """Compile `graph` (fundsp_amd.graph notation) into a fused kernel set at run time and build a bank of `voices`
-        instances of it with the graph's parameters applied (scalars to every voice, arrays per voice)."""
+        instances of it with the graph's parameters applied (scalars to every voice, arrays per voice).
+        A graph that IS a Hadamard feedback delay network (graph.fdn_plan: split >> fdn(stacki(delay >> fir)) >> join, uniform parameters,
+        every delay longer than two blocks) becomes a bank of the lane-per-frame FDN kernel instead (fdsp_fdn_create) -- the same samples,
+        two orders of magnitude faster than one lane per voice; `fdn_kernel=False` keeps the run-time compiled form."""
         from . import graph as G
 
+        plan = G.fdn_plan(graph) if fdn_kernel else None
+        if plan is not None:
+            rates = {_lib.DEFAULT_SR, float(sample_rate or _lib.DEFAULT_SR)}   # the bank is constructed at DEFAULT_SR and then moved
+            if all(int(np.floor(t * r + 0.5)) >= 128 for t in plan["delays"] for r in rates):
+                b = cls.fdn(voices, **plan)
+                if sample_rate is not None:
+                    b.set_sample_rate(sample_rate)
+                b.reset()
+                return b
         name = graph.kind_name()
         rc = lib().fdsp_graph_compile_src(name.encode(), graph.type.encode(), graph.source.encode() if graph.source else None)
         if rc < 0:
@@ -95,6 +107,16 @@ class Bank:
         h = C.c_void_p()
         check(lib().fdsp_reverb4_stereo_create(int(instances), float(room_size), float(time), C.byref(h)))
         return cls("reverb4_stereo", instances, _handle=h)
+
+    @classmethod
+    def fdn(cls, instances, lines, delays, taps, weights, inputs=1, outputs=1, device=-1):
+        """Bank of `instances` x `split / multisplit >> fdn(stacki(lines, |i| delay(delays[i]) >> fir(weights))) >> join / multijoin`
+        (prelude.rs:1323-1345) through the lane-per-frame FDN kernel (fdsp_fdn_create)."""
+        h = C.c_void_p()
+        d = (C.c_double * int(lines))(*[float(x) for x in delays])
+        w = (C.c_float * int(taps))(*[float(x) for x in weights])
+        check(lib().fdsp_fdn_create_on(int(device), int(instances), int(lines), d, int(taps), w, int(inputs), int(outputs), C.byref(h)))
+        return cls("fdn", instances, _handle=h)
 
     def clone(self):
         """AudioNode: Clone -- a new bank that continues exactly where this one stands (fdsp_bank_clone: slots, rings, sample

@@ -386,8 +386,9 @@ int build_default_table_set(int set) {
 }  // namespace
 
 struct FdnBank {  // reverb_stereo / reverb4_stereo banks (fd_fdn.hip): rings + per-line state instead of the slot SoA
-    int kind = 0;  // 0 = reverb_stereo(room, time, damping), 1 = reverb4_stereo(room, time)
-    double room, time, damping;
+    int kind = 0;  // 0 = reverb_stereo(room, time, damping), 1 = reverb4_stereo(room, time), 2 = the generic network (fdsp_fdn_create: desc)
+    double room = 0.0, time = 0.0, damping = 0.0;
+    fd::FdnDesc desc;
     fd::FdnConst c;
     fd::FdnState st;
 };
@@ -985,13 +986,15 @@ static void fdn_free(FdnBank* f) {
 static int fdn_configure(fdsp_bank* b, double sr) {
     FdnBank* f = b->fdn;
     fd::FdnConst c;
-    if (f->kind == 1) fd::fdn_make_const_reverb4(f->room, f->time, sr, &c);
+    if (f->kind == 2) fd::fdn_make_const_generic(f->desc, sr, &c);
+    else if (f->kind == 1) fd::fdn_make_const_reverb4(f->room, f->time, sr, &c);
     else fd::fdn_make_const(f->room, f->time, f->damping, sr, &c);
-    for (int i = 0; i < 32; i++)
+    for (int i = 0; i < c.lines; i++)
         if (c.len[i] <= 128)
-            return fail(FDSP_EINVAL, "reverb_stereo / reverb4_stereo: every delay must exceed 128 samples (room_size * sample_rate too small)");
-    if (f->kind == 1 && c.cap > (1 << 18))
-        return fail(FDSP_EINVAL, "reverb4_stereo: delays of more than 2^18 samples (room_size * sample_rate too large for the lane-per-frame kernel)");
+            return fail(FDSP_EINVAL, f->kind == 2 ? "fdsp_fdn_create: every delay must exceed 128 samples at the bank's sample rate (two blocks: the lane-per-frame kernel's rule)"
+                                                  : "reverb_stereo / reverb4_stereo: every delay must exceed 128 samples (room_size * sample_rate too small)");
+    if (f->kind != 0 && c.cap > (1 << 18))
+        return fail(FDSP_EINVAL, "reverb4_stereo / fdsp_fdn_create: delays of more than 2^18 samples (too long for the lane-per-frame kernel at this sample rate)");
     const size_t n = b->V;
     fd::FdnState st{};
     hipError_t e = hipMalloc((void**)&st.rings, n * c.ring_stride * sizeof(float));
@@ -1018,7 +1021,7 @@ int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, d
     return fdsp_reverb_stereo_create_on(-1, instances, room_size, time, damping, out);
 }
 
-static int fdn_bank_create_on(int kind, int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out);
+static int fdn_bank_create_on(int kind, int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out, const fd::FdnDesc* desc = nullptr);
 int fdsp_reverb_stereo_create_on(int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out) {
     return fdn_bank_create_on(0, device, instances, room_size, time, damping, out);
 }
@@ -1029,7 +1032,29 @@ int fdsp_reverb4_stereo_create_on(int device, size_t instances, double room_size
     return fdn_bank_create_on(1, device, instances, room_size, time, 0.0, out);
 }
 
-static int fdn_bank_create_on(int kind, int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out) {
+int fdsp_fdn_create_on(int device, size_t instances, int lines, const double* delays, int taps, const float* weights, int inputs, int outputs, fdsp_bank** out) {
+    if (out) *out = nullptr;
+    if (lines != 4 && lines != 8 && lines != 16 && lines != 32) return fail(FDSP_EINVAL, "fdsp_fdn_create: lines takes 4, 8, 16 or 32 (FrameHadamard needs a power of two; the kernel holds at most 32 lines in registers)");
+    if (taps < 1 || taps > 3) return fail(FDSP_EINVAL, "fdsp_fdn_create: taps takes 1..3 (Fir<U1> .. Fir<U3>)");
+    if ((inputs != 1 && inputs != 2) || (outputs != 1 && outputs != 2)) return fail(FDSP_EINVAL, "fdsp_fdn_create: inputs / outputs take 1 (split / join) or 2 (multisplit::<U2, _> / multijoin::<U2, _>)");
+    if (!delays || !weights) return fail(FDSP_EINVAL, "fdsp_fdn_create: delays or weights NULL");
+    fd::FdnDesc d;
+    d.lines = lines;
+    d.taps = taps;
+    d.nin = inputs;
+    d.nout = outputs;
+    for (int i = 0; i < lines; i++) {
+        if (!(delays[i] >= 0.0) || !(delays[i] < 1e6)) return fail(FDSP_EINVAL, "fdsp_fdn_create: a delay is negative or not a number (Delay::new asserts time >= 0)");
+        d.delay[i] = delays[i];
+    }
+    for (int j = 0; j < taps; j++) d.w[j] = weights[j];
+    return fdn_bank_create_on(2, device, instances, 1.0, 1.0, 0.0, out, &d);
+}
+int fdsp_fdn_create(size_t instances, int lines, const double* delays, int taps, const float* weights, int inputs, int outputs, fdsp_bank** out) {
+    return fdsp_fdn_create_on(-1, instances, lines, delays, taps, weights, inputs, outputs, out);
+}
+
+static int fdn_bank_create_on(int kind, int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out, const fd::FdnDesc* desc) {
     if (!out) return fail(FDSP_EINVAL, "out is NULL");
     *out = nullptr;
     if (instances == 0 || !(room_size > 0.0) || !(time > 0.0)) return fail(FDSP_EINVAL, "bad reverb_stereo / reverb4_stereo arguments");
@@ -1046,6 +1071,7 @@ static int fdn_bank_create_on(int kind, int device, size_t instances, double roo
     b->fdn->room = room_size;
     b->fdn->time = time;
     b->fdn->damping = damping;
+    if (desc) b->fdn->desc = *desc;
     b->fdn->st = fd::FdnState{};
     b->ops = nullptr;
     b->V = instances;
@@ -1113,7 +1139,7 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
     fdsp_bank* b = nullptr;
     int rc;
     if (src->fdn)
-        rc = fdn_bank_create_on(src->fdn->kind, src->device, src->V, src->fdn->room, src->fdn->time, src->fdn->damping, &b);
+        rc = fdn_bank_create_on(src->fdn->kind, src->device, src->V, src->fdn->room, src->fdn->time, src->fdn->damping, &b, &src->fdn->desc);
     else
         rc = fdsp_bank_create_on(src->device, src->ops->name.c_str(), src->V, src->ring_frames, &b);
     if (rc != FDSP_OK) return rc;
@@ -1181,8 +1207,8 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
     return FDSP_OK;
 }
 
-int fdsp_bank_inputs(const fdsp_bank* b) { return b ? (b->fdn ? 2 : b->ops->nin) : FDSP_EINVAL; }
-int fdsp_bank_outputs(const fdsp_bank* b) { return b ? (b->fdn ? 2 : b->ops->nout) : FDSP_EINVAL; }
+int fdsp_bank_inputs(const fdsp_bank* b) { return b ? (b->fdn ? b->fdn->c.nin : b->ops->nin) : FDSP_EINVAL; }
+int fdsp_bank_outputs(const fdsp_bank* b) { return b ? (b->fdn ? b->fdn->c.nout : b->ops->nout) : FDSP_EINVAL; }
 size_t fdsp_bank_voices(const fdsp_bank* b) { return b ? b->V : 0; }
 
 int fdsp_bank_set_sample_rate(fdsp_bank* b, double sr) {

@@ -51,6 +51,10 @@ void fdn_make_const(double room_size, double time, double damping, double sample
     c->cap = cap;
     c->ring_stride = (size_t)32 * ((size_t)cap + 64);
     c->sections = 1;
+    c->generic = 0;
+    c->lines = 32;
+    c->taps = 3;
+    c->nin = c->nout = 2;
     c->had_scale = (float)(1.0 / std::sqrt(32.0));
     c->out_scale = (float)(1.0 / 16.0);
 }
@@ -94,8 +98,35 @@ void fdn_make_const_reverb4(double room_size, double time, double sample_rate, F
     c->cap = cap;
     c->ring_stride = (size_t)32 * ((size_t)cap + 64);
     c->sections = 2;
+    c->generic = 0;
+    c->lines = 32;
+    c->taps = 3;
+    c->nin = c->nout = 2;
     c->had_scale = (float)(1.0 / std::sqrt(16.0));
     c->out_scale = (float)(1.0 / 4.0);
+}
+
+void fdn_make_const_generic(const FdnDesc& d, double sample_rate, FdnConst* c) {
+    *c = FdnConst{};
+    int maxlen = 0;
+    for (int i = 0; i < 32; i++) {
+        // Delay::new(t): length = round(t * sample_rate) samples, ring of length + 1 (delay.rs:104-112); lines past the network: unused
+        c->len[i] = i < d.lines ? (int)std::round(d.delay[i] * sample_rate) + 1 : 0;
+        maxlen = c->len[i] > maxlen ? c->len[i] : maxlen;
+    }
+    for (int j = 0; j < 3; j++) c->w[j] = j < d.taps ? d.w[j] : 0.0f;
+    int cap = 256;
+    while (cap < maxlen) cap <<= 1;
+    c->cap = cap;
+    c->sections = 1;
+    c->generic = 1;
+    c->lines = d.lines;
+    c->taps = d.taps;
+    c->nin = d.nin;
+    c->nout = d.nout;
+    c->ring_stride = (size_t)d.lines * ((size_t)cap + 64);
+    c->had_scale = (float)(1.0 / std::sqrt((double)d.lines));  // (1.0 / sqrt(N as f64)) as f32  feedback.rs:57
+    c->out_scale = 1.0f;
 }
 
 constexpr int TS = 65;  // LDS row stride (floats): lane-per-row access is bank-conflict free
@@ -492,6 +523,177 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
     }
 }
 
+
+// ---- the generic network, lane = FRAME -----------------------------------------------------------------------------------------------
+// `split::<N>() / multisplit::<M, N/M>() >> fdn::<N, _>(stacki(|i| delay(t_i) >> fir(w))) >> join::<N>() / multijoin::<M, N/M>()`: the Hadamard
+// feedback delay network as the prelude documents it (prelude.rs:1323-1345, the "Mono Reverb" example :1334), N = NL lines of any delays
+// longer than two blocks, FIR order K.  The same formulation as k_fdn_render_frames -- one wave per instance, lane = frame, the lines in
+// registers, ring rows loaded one block ahead and stored as 256-byte runs -- with the ring capacity a run-time value (a handful of scalar
+// instructions per line and block instead of immediates), no pan fold, and the splitter / joiner the graph names:
+//   in : line k takes input channel k % nin   (Split :559-562, MultiSplit :600-606: output i = input i % M)
+//   out: channel j = average of lines j, j + nout, ..  (Join / MultiJoin: process scales every term by 1 / n and adds :649-659, :710-724;
+//        tick adds and divides :643-648, :700-708)
+// Run-time compiled graphs of this shape render lane-per-voice at ~25 GB/s (every lane walks its N lines one after the other, 32 waves on
+// the chip for 2 048 instances); this kernel is what Bank.from_graph / fdsp_fdn_create give them instead.
+template <int NL, int K>
+__global__ __launch_bounds__(256) void k_fdn_frames_generic(FdnConst c, FdnState s, size_t V, const float* __restrict__ in,
+                                                            float* __restrict__ out, size_t T, size_t fstride, int layout, int tick_mode) {
+    static_assert(K >= 1 && K <= 3 && NL >= 2 && NL <= 32 && (NL & (NL - 1)) == 0, "generic FDN: 2..32 lines (a power of two), FIR order 1..3");
+    constexpr int H0 = K - 1;               // carried delay outputs per line: Fir::v[1 .. K-1]
+    __shared__ float hist_all[4][NL * HS];  // per line: the H0 carried delay outputs | d[0..63]
+    __shared__ float fbr_all[4][NL * HS];   // per line: fb[-1] | fb[0..63]
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* hist = hist_all[wib];
+    float* fbr = fbr_all[wib];
+    const size_t inst = (size_t)blockIdx.x * 4 + wib;
+    if (inst >= V) return;
+    const float w0 = c.w[0], w1 = c.w[1], w2 = c.w[2];
+    const float scale = c.had_scale;
+    const int nin = c.nin, nout = c.nout;   // 1 or 2
+    const int CMASK = c.cap - 1, CP = c.cap + 64;
+    const __amdgpu_buffer_rsrc_t rings = __builtin_amdgcn_make_buffer_rsrc(s.rings + inst * c.ring_stride, 0, (int)(c.ring_stride * sizeof(float)), 0x00020000);
+    const int lane4 = lane * 4;
+    int wp = __builtin_amdgcn_readfirstlane(s.wpos[inst]);
+    if (lane < NL) {  // carry-in: Fir::v[1..K-1] (v1 = the older, v2 = the newer of a Fir<U3>; a Fir<U2> keeps its one sample in v2), Feedback::value
+        if (K == 3) hist[lane * HS + 0] = s.v1[inst * 32 + lane];
+        if (K >= 2) hist[lane * HS + H0 - 1] = s.v2[inst * 32 + lane];
+        fbr[lane * HS + 0] = s.fb[inst * 32 + lane];
+    }
+    float dn[NL], xin[2];
+    auto fetch = [&](size_t t0n, int wpn) {
+        const int sizen = (int)((T - t0n) < 64 ? (T - t0n) : 64);
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int r = (wpn - (c.len[k] - 1)) & CMASK;   // frame 0 reads the slot written len - 1 frames ago; 64 contiguous slots from there (mirror zone)
+            dn[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rings, lane4, (k * CP + r) * 4, 0));
+        }
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+            xin[ch] = (ch < nin && lane < sizen) ? (layout == 0 ? in[((size_t)ch * T + t0n + lane) * V + inst] : in[(inst * nin + ch) * fstride + t0n + lane]) : 0.0f;
+    };
+    fetch(0, wp);
+    for (size_t t0 = 0; t0 < T; t0 += 64) {
+        const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+        float d[NL];
+        const float xi0 = xin[0], xi1 = nin == 2 ? xin[1] : xin[0];
+#pragma unroll
+        for (int k = 0; k < NL; k++) d[k] = dn[k];
+        if (t0 + 64 < T) fetch(t0 + 64, (wp + 64) & CMASK);
+        if (K > 1) {
+#pragma unroll
+            for (int k = 0; k < NL; k++) hist[k * HS + H0 + lane] = d[k];
+            fdn_wave_sync();
+        }
+        float o[NL], h[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {  // Fir::tick fir.rs:57-70: the sum starts at 0.0 and takes the taps oldest first
+            float acc = 0.0f;
+            if (K == 3) {
+                acc += w0 * hist[k * HS + lane];
+                acc += w1 * hist[k * HS + lane + 1];
+                acc += w2 * d[k];
+            } else if (K == 2) {
+                acc += w0 * hist[k * HS + lane];
+                acc += w1 * d[k];
+            } else {
+                acc += w0 * d[k];
+            }
+            o[k] = acc;
+            h[k] = acc;
+        }
+#pragma unroll
+        for (int st = 1; st < NL; st <<= 1)  // FrameHadamard feedback.rs:35-57
+#pragma unroll
+            for (int i = 0; i < NL; i++)
+                if ((i & st) == 0) {
+                    const float x = h[i], y = h[i + st];
+                    h[i] = x + y;
+                    h[i + st] = x - y;
+                }
+#pragma unroll
+        for (int k = 0; k < NL; k++) fbr[k * HS + 1 + lane] = h[k] * scale;
+        fdn_wave_sync();
+        float xw[NL];  // Feedback::tick: input + value (feedback.rs:130-134)
+#pragma unroll
+        for (int k = 0; k < NL; k++) xw[k] = ((k & 1) ? xi1 : xi0) + fbr[k * HS + lane];
+        if (size == 64 && wp >= 64 && wp + 64 <= c.cap) {
+#pragma unroll
+            for (int k = 0; k < NL; k++)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xw[k]), rings, lane4, (k * CP + wp) * 4, 0);
+        } else if (lane < size) {  // wrap, mirror zone or ragged tail
+            const int pos = (wp + lane) & CMASK;
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xw[k]), rings, pos * 4, k * CP * 4, 0);
+                if (pos < 64) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xw[k]), rings, (c.cap + pos) * 4, k * CP * 4, 0);
+            }
+        }
+        // Join<N> / MultiJoin<M, N/M>: channel j over lines j, j + nout, ..
+        float y0, y1 = 0.0f;
+        if (nout == 1) {
+            if (tick_mode) {
+                y0 = o[0];
+#pragma unroll
+                for (int i = 1; i < NL; i++) y0 += o[i];
+                y0 = y0 / (float)NL;
+            } else {
+                const float z = 1.0f / (float)NL;
+                y0 = o[0] * z;
+#pragma unroll
+                for (int i = 1; i < NL; i++) y0 += o[i] * z;
+            }
+        } else {
+            if (tick_mode) {
+                y0 = o[0]; y1 = o[1];
+#pragma unroll
+                for (int i = 1; i < NL / 2; i++) { y0 += o[2 * i]; y1 += o[2 * i + 1]; }
+                y0 = y0 / (float)(NL / 2); y1 = y1 / (float)(NL / 2);
+            } else {
+                const float z = 1.0f / (float)(NL / 2);
+                y0 = o[0] * z; y1 = o[1] * z;
+#pragma unroll
+                for (int i = 1; i < NL / 2; i++) { y0 += o[2 * i] * z; y1 += o[2 * i + 1] * z; }
+            }
+        }
+        if (lane < size) {
+            if (layout == 0) {
+                out[((size_t)0 * T + t0 + lane) * V + inst] = y0;
+                if (nout == 2) out[((size_t)1 * T + t0 + lane) * V + inst] = y1;
+            } else {
+                out[(inst * nout + 0) * fstride + t0 + lane] = y0;
+                if (nout == 2) out[(inst * nout + 1) * fstride + t0 + lane] = y1;
+            }
+        }
+        fdn_wave_sync();
+        if (lane < NL) {  // the block's last delay outputs and feedback value become the next block's carry-in
+            float a = 0.0f, b = 0.0f;
+            if (K == 3) { a = hist[lane * HS + size]; b = hist[lane * HS + size + 1]; }
+            if (K == 2) b = hist[lane * HS + size];
+            const float f = fbr[lane * HS + size];
+            if (K == 3) hist[lane * HS + 0] = a;
+            if (K >= 2) hist[lane * HS + H0 - 1] = b;
+            fbr[lane * HS + 0] = f;
+        }
+        wp = (wp + size) & CMASK;
+        fdn_wave_sync();
+    }
+    if (lane == 0) s.wpos[inst] = wp;
+    if (lane < NL) {
+        if (K == 3) s.v1[inst * 32 + lane] = hist[lane * HS + 0];
+        if (K >= 2) s.v2[inst * 32 + lane] = hist[lane * HS + H0 - 1];
+        s.fb[inst * 32 + lane] = fbr[lane * HS + 0];
+    }
+}
+
+template <int NL>
+static void fdn_launch_generic(const FdnConst& c, const FdnState& s, size_t instances, const float* in, float* out, size_t T, size_t fstride, int layout,
+                               int tick_mode, hipStream_t stream) {
+    const dim3 grid((unsigned)((instances + 3) / 4)), block(256);
+    if (c.taps == 3) hipLaunchKernelGGL((k_fdn_frames_generic<NL, 3>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode);
+    else if (c.taps == 2) hipLaunchKernelGGL((k_fdn_frames_generic<NL, 2>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode);
+    else hipLaunchKernelGGL((k_fdn_frames_generic<NL, 1>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode);
+}
+
 void fdn_launch_reset(const FdnConst& c, const FdnState& s, size_t instances, hipStream_t stream) {
     hipLaunchKernelGGL(k_fdn_reset, dim3(2048), dim3(256), 0, stream, c, s, instances);
 }
@@ -499,6 +701,15 @@ void fdn_launch_reset(const FdnConst& c, const FdnState& s, size_t instances, hi
 void fdn_launch_render(const FdnConst& c, const FdnState& s, size_t instances, const float* in, float* out, size_t T,
                        size_t fstride, int layout, int tick_mode, hipStream_t stream) {
     if (instances == 0 || T == 0) return;
+    if (c.generic) {
+        tl_opts.last_kernel = LK_FDN_FRAMES;
+        switch (c.lines) {
+        case 4: return fdn_launch_generic<4>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream);
+        case 8: return fdn_launch_generic<8>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream);
+        case 16: return fdn_launch_generic<16>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream);
+        default: return fdn_launch_generic<32>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream);
+        }
+    }
     const bool frames = tl_opts.fdn_kernel == 0 || c.sections == 2;  // (two networks in series: the lane = frame formulation only)
     tl_opts.last_kernel = frames ? LK_FDN_FRAMES : LK_FDN_LINES;
     if (frames) {

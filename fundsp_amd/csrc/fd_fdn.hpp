@@ -33,6 +33,11 @@ namespace fd {
 // That makes the ring addresses of a block SCALAR (base + one wave-uniform offset + lane): no per-lane index arithmetic.
 struct FdnConst {            // uniform over the bank (all instances share room / time / damping)
     int sections;            // 1: reverb_stereo (one 32-line FDN); 2: reverb4_stereo (two 16-line FDNs in series, lines 0-15 | 16-31)
+    // the generic network `split / multisplit >> fdn::<N>(stacki(|i| delay(t_i) >> fir(w))) >> join / multijoin` (prelude.rs:1323-1345 and its
+    // doc example :1334): generic != 0, `lines` = N (4, 8, 16, 32), `taps` = the FIR's order (1..3), line k takes input channel k % nin
+    // (Split<N> :527-568, MultiSplit<M, N/M> :571-613), output channel j averages lines j, j + nout, .. (Join<N> :617-660, MultiJoin<M, N/M>
+    // :668-730).  The reverbs: generic = 0, lines = 32 (all of them, both sections), taps = 3, nin = nout = 2.
+    int generic, lines, taps, nin, nout;
     float had_scale;         // (1.0 / sqrt(lines per section as f64)) as f32   feedback.rs:57
     float out_scale;         // the `* dc((s, s))` behind the pan fold: 1/16 (reverb_stereo), 1/4 (reverb4_stereo)
     int len[32];             // Delay ring length of the reference = delay in samples + 1  (delay.rs:108-110)
@@ -40,7 +45,14 @@ struct FdnConst {            // uniform over the bank (all instances share room 
     float w[3];              // FIR weights: fir3(1 - damping).weights() * a  (prelude.rs:1746-1747)
     float wl[32], wr[32];    // pan weights of the output panners (prelude.rs:1759, pan.rs:13-17), indexed by the LINE they pan: all 32
                              // (reverb_stereo) or lines 16-31, the second network's (reverb4_stereo: sumf::<U16>)
-    size_t ring_stride;      // floats per instance = 32 * (cap + 64)
+    size_t ring_stride;      // floats per instance = lines * (cap + 64)
+};
+
+// what a generic network is made of (host side; uniform over the bank like the reverbs' room / time / damping)
+struct FdnDesc {
+    int lines = 0, taps = 0, nin = 0, nout = 0;
+    double delay[32] = {};   // seconds, Delay::new(t) per line (delay.rs:93-113)
+    float w[3] = {};         // Fir::new(weights), the same for every line
 };
 
 struct FdnState {
@@ -59,6 +71,8 @@ void fdn_launch_reset(const FdnConst& c, const FdnState& s, size_t instances, hi
 void fdn_make_const_reverb4(double room_size, double time, double sample_rate, FdnConst* c);
 // tick_mode: MultiJoin::tick sums and divides, MultiJoin::process scales every term first (audionode.rs:697-720) -- the only place where
 // the two executors of these graphs differ in arithmetic (reverb4_stereo; reverb_stereo has no join)
+// host: constants of the generic network at `sample_rate`
+void fdn_make_const_generic(const FdnDesc& d, double sample_rate, FdnConst* c);
 void fdn_launch_render(const FdnConst& c, const FdnState& s, size_t instances, const float* in, float* out, size_t T,
                        size_t fstride, int layout, int tick_mode, hipStream_t stream);
 

@@ -528,6 +528,97 @@ def reverb4_stereo(room_size, time):  # prelude.rs:1873-1914
     return reverb4_stereo_delays([f(d) * scale for d in REVERB4_DELAYS], time)
 
 
+def _parse_type(t):
+    """`Name<arg, ..>` -> (name, [children]) with every argument parsed the same way (numbers and names become leaves)."""
+    pos = 0
+
+    def node():
+        nonlocal pos
+        a = pos
+        while pos < len(t) and t[pos] not in "<>,":
+            pos += 1
+        name, kids = t[a:pos].strip(), []
+        if pos < len(t) and t[pos] == "<":
+            pos += 1
+            while True:
+                kids.append(node())
+                if t[pos] == ",":
+                    pos += 1
+                    continue
+                pos += 1  # '>'
+                break
+        return name, kids
+
+    return node()
+
+
+def fdn_plan(g):
+    """The arguments of fdsp_fdn_create when `g` is the Hadamard feedback delay network the prelude documents (prelude.rs:1323-1345,
+    the "Mono Reverb" example :1334) --
+
+        split(N) | multisplit(2, N/2)  >>  fdn(stacki(N, lambda i: delay(t_i) >> fir(w..)))  >>  join(N) | multijoin(2, N/2)
+
+    with N in 4, 8, 16, 32, one to three FIR weights shared by all lines, and every parameter a scalar (the same network in every
+    instance) -- else None.  Such a graph renders through the lane-per-frame FDN kernel (one wave per instance, the lines in registers,
+    coalesced ring rows) instead of lane-per-voice; Bank.from_graph takes that route when every delay exceeds two blocks."""
+    name, kids = _parse_type(g.type)
+    chain = []
+
+    def flat(n, path):  # the Pipe chain, left to right, with the parameter path of every element
+        if n[0] == "Pipe" and len(n[1]) == 2:
+            flat(n[1][0], path + (0,))
+            flat(n[1][1], path + (1,))
+        else:
+            chain.append((n, path))
+
+    flat((name, kids), ())
+    if len(chain) != 3:
+        return None
+    (sp, _), (fb, fpath), (jn, _) = chain
+    try:
+        if sp[0] == "Split":
+            nin, n_in = 1, int(sp[1][0][0])
+        elif sp[0] == "MultiSplit" and int(sp[1][0][0]) == 2:
+            nin, n_in = 2, 2 * int(sp[1][1][0])
+        else:
+            return None
+        if jn[0] == "Join":
+            nout, n_out = 1, int(jn[1][0][0])
+        elif jn[0] == "MultiJoin" and int(jn[1][0][0]) == 2:
+            nout, n_out = 2, 2 * int(jn[1][1][0])
+        else:
+            return None
+        if fb[0] != "Feedback" or fb[1][1][0] != "FbHadamard":
+            return None
+        st = fb[1][0]
+        if st[0] != "MultiStack":
+            return None
+        n, line = int(st[1][0][0]), st[1][1]
+        if line[0] != "Pipe" or line[1][0][0] != "Delay" or line[1][1][0] != "Fir":
+            return None
+        taps = int(line[1][1][1][0][0])
+    except (IndexError, ValueError):
+        return None
+    if n not in (4, 8, 16, 32) or n_in != n or n_out != n or not 1 <= taps <= 3:
+        return None
+    vals = {}
+    for path, field, value, _u in g.params:
+        v = np.asarray(value)
+        if v.ndim != 0:
+            return None       # per-voice parameters: the generic kernels
+        vals[(tuple(path), field)] = v
+    try:
+        delays = [float(np.float32(vals[(fpath + (0, i, 0), "time")])) for i in range(n)]   # delay(t: f32) -> Delay::new(t as f64)
+        ws = [[np.float32(vals[(fpath + (0, i, 1), f"w[{j}]")]) for j in range(taps)] for i in range(n)]
+    except KeyError:
+        return None
+    if any(w != ws[0] for w in ws[1:]):
+        return None           # the kernel keeps one set of weights for all lines
+    if len(vals) != n * (1 + taps):
+        return None           # something else carries parameters (builders on the nodes): not this shape
+    return dict(lines=n, delays=delays, taps=taps, weights=[float(x) for x in ws[0]], inputs=nin, outputs=nout)
+
+
 def uses_wavetables(g):
     sets = (("saw", "WaveSynth<0>"), ("square", "WaveSynth<1>"), ("triangle", "WaveSynth<2>"), ("organ", "WaveSynth<4>"),
             ("soft_saw", "WaveSynth<5>"), ("hammond", "WaveSynth<6>"), ("saw", "PulseWave"))

@@ -192,6 +192,18 @@ int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, d
  * are known at the head of a block; 272 B per instance-frame as well).  FDSP_MODE_PROCESS / FDSP_MODE_TICK differ in MultiJoin's
  * arithmetic exactly like the reference (src/audionode.rs:697-720).  Same handle semantics as reverb_stereo banks; "fdn_kernel" is ignored. */
 int fdsp_reverb4_stereo_create(size_t instances, double room_size, double time, fdsp_bank** out);
+/* The generic Hadamard feedback delay network as the prelude documents it (src/prelude.rs:1323-1345, "Mono Reverb" :1334):
+ *     split::<N>() >> fdn::<N, _>(stacki::<N, _, _>(|i| delay(delays[i]) >> fir(weights))) >> join::<N>()
+ * `instances` independent networks of `lines` = N delay lines (4, 8, 16 or 32), Delay::new(delays[i]) seconds each
+ * (src/delay.rs:82-113), every line followed by the same Fir of `taps` = 1..3 weights (src/fir.rs:14-70), Feedback with FrameHadamard
+ * around them (src/feedback.rs:35-57,108-146).  `inputs` = 1 puts split::<N>() in front (src/audionode.rs:527-568), 2
+ * multisplit::<U2, N/2>() (:571-613: line k takes channel k % 2); `outputs` = 1 puts join::<N>() behind (:617-660), 2
+ * multijoin::<U2, N/2>() (:668-730; FDSP_MODE_PROCESS scales every term by 1/n and adds, FDSP_MODE_TICK adds and divides, like the
+ * reference's two executors).  Rendered by the lane-per-frame kernel of the reverbs (one wave per instance, the lines in registers, ring
+ * rows as 256-byte runs: 8 * lines + 4 * (inputs + outputs) bytes per instance-frame), which needs every delay to exceed two blocks
+ * (128 samples) at the bank's sample rate -- FDSP_EINVAL otherwise; such a graph still renders lane-per-voice through
+ * fdsp_graph_compile.  Flushes f32 denormals like every graph with a Feedback node.  Handle semantics of the reverb banks. */
+int fdsp_fdn_create(size_t instances, int lines, const double* delays, int taps, const float* weights, int inputs, int outputs, fdsp_bank** out);
 /* Several GPUs from one process.  A bank lives on ONE device, fixed at creation: the `_on` constructors take the HIP
  * device index (-1 = the calling thread's current device, which is what the constructors above use).  Every entry point
  * that takes a bank makes the bank's device current for its own duration and restores the caller's, so a host thread
@@ -202,6 +214,7 @@ int fdsp_device_count(void);
 int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring_frames, fdsp_bank** out);
 int fdsp_reverb_stereo_create_on(int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out);
 int fdsp_reverb4_stereo_create_on(int device, size_t instances, double room_size, double time, fdsp_bank** out);
+int fdsp_fdn_create_on(int device, size_t instances, int lines, const double* delays, int taps, const float* weights, int inputs, int outputs, fdsp_bank** out);
 int fdsp_bank_device(const fdsp_bank* bank);
 void fdsp_bank_destroy(fdsp_bank* bank);
 /* `Clone` (every AudioNode is Clone, src/audionode.rs:35; Net and Sequencer clone their units): a new bank of the same

@@ -164,3 +164,28 @@ def test_compile_and_render_through_the_front_door(gpu):
         n2 = build(O)
         n2.set_sample_rate(48000.0)
         assert_bit_equal(got[v], oracle_render(n2, x[v], T, MODE_PROCESS), f"voice {v}")
+
+
+def test_fdn_plan_recognises_the_documented_network_and_nothing_else():
+    """graph.fdn_plan: `split >> fdn(stacki(delay >> fir)) >> join` with uniform parameters becomes the argument list of fdsp_fdn_create
+    (the lane-per-frame kernel); anything else stays with the run-time compiler."""
+    import numpy as np
+    from fundsp_amd import graph as G
+
+    def net(n, head, tail, w=(0.2, 0.4, 0.2), delays=None, per_voice=False):
+        d = delays or [0.01 + 0.001 * i for i in range(n)]
+        line = G.stacki(n, lambda i: G.delay(np.full(3, d[i], np.float32) if per_voice and i == 1 else d[i]) >> G.fir(*w))
+        return head >> G.fdn(line) >> tail
+
+    p = G.fdn_plan(net(16, G.split(16), G.join(16)))                      # prelude.rs:1334
+    assert p["lines"] == 16 and p["taps"] == 3 and p["inputs"] == 1 and p["outputs"] == 1 and len(p["delays"]) == 16
+    assert p["delays"][3] == float(np.float32(0.013)) and p["weights"] == [float(np.float32(x)) for x in (0.2, 0.4, 0.2)]
+    g = G.multisplit(2, 4) >> (G.fdn(G.stacki(8, lambda i: G.delay(0.02) >> G.fir(0.5, 0.5))) >> G.multijoin(2, 4))   # right-nested pipes
+    p = G.fdn_plan(g)
+    assert p["lines"] == 8 and p["taps"] == 2 and p["inputs"] == 2 and p["outputs"] == 2
+    assert G.fdn_plan(net(16, G.split(16), G.join(16), per_voice=True)) is None            # a per-voice delay: the generic kernels
+    assert G.fdn_plan(net(2, G.split(2), G.join(2))) is None                                # fewer than four lines
+    assert G.fdn_plan(G.split(4) >> G.feedback(G.stacki(4, lambda i: G.delay(0.01) >> G.fir(0.5))) >> G.join(4)) is None   # no Hadamard
+    assert G.fdn_plan(G.split(4) >> G.fdn(G.stacki(4, lambda i: G.delay(0.01) >> G.lowpole_hz(1000.0))) >> G.join(4)) is None  # a recursive line filter
+    assert G.fdn_plan(G.split(4) >> G.fdn(G.stacki(4, lambda i: G.delay(0.01) >> G.fir(0.1 * (i + 1)))) >> G.join(4)) is None  # per-line weights
+    assert G.fdn_plan(G.reverb4_stereo(20.0, 2.0)) is None and G.fdn_plan(G.sine_hz(440.0)) is None
