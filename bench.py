@@ -233,6 +233,22 @@ def make_workload(F, W, torch, config, V, T, sr, first, layout, math, voice_out=
         inp = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
         n_out, bps, slot_bytes = 2, 272, 512       # 32 ring reads + 32 ring writes + 2 in + 2 out, x 4 B
         kernel = "fd::k_fdn_render_frames (lane = frame, one wave per instance)" + ("" if config == 5 else ", two 16-line networks in series")
+    elif config == "fdn16":
+        # the Hadamard network the prelude documents (prelude.rs:1334 "Mono Reverb"): split >> fdn::<U16>(stacki(delay(lerp(0.01, 0.03, rnd1(i)))
+        # >> fir((0.2, 0.4, 0.2)))) >> join, built from the GRAPH: Bank.from_graph recognises the shape (graph.fdn_plan) and takes the
+        # lane-per-frame FDN kernel (fdsp_fdn_create) instead of compiling a lane-per-voice Feedback graph; planar I/O, mono noise in
+        import numpy as np
+        from fundsp_amd import graph as G
+
+        layout = F.LAYOUT_PLANAR
+        r = W.rnd1(np.arange(16, dtype=np.uint64))
+        d = [float(np.float32(np.float32(0.01) * (np.float32(1) - np.float32(x)) + np.float32(0.03) * np.float32(x))) for x in r]
+        bank = F.Bank.from_graph(G.split(16) >> G.fdn(G.stacki(16, lambda i: G.delay(d[i]) >> G.fir(0.2, 0.4, 0.2))) >> G.join(16), V, sample_rate=sr)
+        assert bank.kind == "fdn", "Bank.from_graph did not take the lane-per-frame FDN kernel for the documented fdn graph"
+        g = torch.Generator(device="cuda").manual_seed(4321 + first)
+        inp = torch.rand((V, 1, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
+        n_out, bps, slot_bytes = 1, 136, 256       # 16 ring reads + 16 ring writes + 1 in + 1 out, x 4 B
+        kernel = "fd::k_fdn_frames_generic<16, 3> (lane = frame, one wave per instance, ring capacity at run time)"
     elif config == "4v":
         # config 4 in the reference's own gate shape: `var(gate) >> adsr_live` (examples/live_adsr.rs:72; SURVEY 8(d) `dc(gate)`): the gate is a
         # per-voice Var slot, read once per block like Var::process (shared.rs:122-125) -- the graph has NO input.  One step = one note per
@@ -499,7 +515,8 @@ def secondary(F, W, torch, sr, mode):
                                      (4, 32768, "config4_saw_moog_adsr_pan_32768", "Msamples/s", "exact"),
                                      (4, 32768, "config4_math_fast", "Msamples/s", "fast"),
                                      (5, 2048, "config5_reverb_stereo_2048", "M instance-frames/s", "exact"),
-                                     ("5r4", 2048, "reverb4_stereo_2048", "M instance-frames/s", "exact")):
+                                     ("5r4", 2048, "reverb4_stereo_2048", "M instance-frames/s", "exact"),
+                                     ("fdn16", 4096, "fdn16_mono_reverb_from_graph_4096", "M instance-frames/s", "exact")):
         T = 48000
         wl = make_workload(F, W, torch, cfg, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, math)
         ms, kms = quick(F, torch, wl, T, mode, steps=6 if cfg == "4v" else 4, warmup=3 if cfg == "4v" else 1)
@@ -509,7 +526,11 @@ def secondary(F, W, torch, sr, mode):
         shape = {"4v": " -- the reference's gate shape `var(gate) >> adsr_live` (examples/live_adsr.rs:72): no graph input, the step = two launches "
                        "(gate high 24000 frames, low 24000) with the Var slot set on the device in between; 8 B per voice-sample (stereo out)",
                  4: " -- the gate as an audio-rate HBM input stream [frames][voices] (hosts that modulate the gate per sample): 4 B in + 8 B out per voice-sample"}.get(cfg, "")
-        what = (f"BASELINE config {str(cfg)[0]} per-GPU shard ({V} {'voices' if cfg != 5 else 'instances'} x {T} frames), {arith}{shape}" if cfg != "5r4" else
+        what = (f"the generic Hadamard network of the prelude's own example (prelude.rs:1334: split >> fdn::<U16>(stacki(delay >> fir)) >> join), {V} instances x {T} frames, built "
+                "with Bank.from_graph: the graph's shape is recognised and rendered by the lane-per-frame FDN kernel (fdsp_fdn_create) -- the run-time compiled lane-per-voice "
+                "form of the same graph renders the same samples ~130 x slower (profiles/r06_fdn_generic_probe.txt); 136 B per instance-frame (16 ring reads + 16 ring writes + 1 in + 1 out)"
+                if cfg == "fdn16" else
+                f"BASELINE config {str(cfg)[0]} per-GPU shard ({V} {'voices' if cfg != 5 else 'instances'} x {T} frames), {arith}{shape}" if cfg != "5r4" else
                 f"the other Hadamard FDN reverb of the reference, reverb4_stereo(20, 2) (prelude.rs:1873-1941: two fdn::<U16> in series), {V} instances x {T} frames "
                 "through the lane-per-frame FDN kernel generalised to networks in series; same 272 B per instance-frame (32 ring reads + 32 ring writes + 2 in + 2 out)")
         out.append({"name": name, "what": what,

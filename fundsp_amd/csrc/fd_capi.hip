@@ -391,6 +391,8 @@ struct FdnBank {  // reverb_stereo / reverb4_stereo banks (fd_fdn.hip): rings + 
     fd::FdnDesc desc;
     fd::FdnConst c;
     fd::FdnState st;
+    float* stage = nullptr;   // planar staging of voice-minor launches: [V][inputs][frames] | [V][outputs][frames] (fd_fdn.hip "voice-minor I/O")
+    size_t stage_n = 0;
 };
 
 struct fdsp_bank {
@@ -978,6 +980,10 @@ static void fdn_free(FdnBank* f) {
     if (f->st.fb) hipFree(f->st.fb);
     f->st = fd::FdnState{};
 }
+static void fdn_free_stage(FdnBank* f) {
+    if (f && f->stage) hipFree(f->stage);
+    if (f) { f->stage = nullptr; f->stage_n = 0; }
+}
 
 // (re)allocate rings for the current sample rate and zero everything: Delay::set_sample_rate resizes + resets
 // when the rate changes (delay.rs:105-113)
@@ -1107,6 +1113,7 @@ void fdsp_bank_destroy(fdsp_bank* b) {
     if (b->stream) sync_bank_stream(b);
     if (b->fdn) {
         fdn_free(b->fdn);
+        fdn_free_stage(b->fdn);
         delete b->fdn;
         b->fdn = nullptr;
     }
@@ -1413,9 +1420,31 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
     const bool timing = timing_on(b);
     if (!capturing && timing) HIPCHK(hipEventRecord(b->e0, s));
     resolve_opts(b);
-    if (b->fdn)  // Feedback::process is the per-sample tick (feedback.rs:136-146): both modes are the same arithmetic but for reverb4_stereo's MultiJoin
-        fd::fdn_launch_render(b->fdn->c, b->fdn->st, b->V, d_in, d_out, frames, frame_stride, layout, mode == FDSP_MODE_TICK ? 1 : 0, s);
-    else if (b->math == FDSP_MATH_FAST && b->ops->render_fast)
+    if (b->fdn) {  // Feedback::process is the per-sample tick (feedback.rs:136-146): both modes are the same arithmetic but for the joins (MultiJoin / Join)
+        FdnBank* f = b->fdn;
+        const int tick = mode == FDSP_MODE_TICK ? 1 : 0, nin = f->c.nin, nout = f->c.nout;
+        // voice-minor buffers of banks with at least a tile of instances go through the planar staging copy (the lane = frame kernels read
+        // 256-byte runs of it instead of gathering a line per frame); the staging buffer grows outside captures only, like the partial mixes
+        bool staged = layout == FDSP_LAYOUT_VOICE_MINOR && b->V >= 64 && (f->c.generic || fd::tl_opts.fdn_kernel == 0 || f->c.sections == 2);
+        const size_t need = b->V * (size_t)(nin + nout) * frames;
+        if (staged && need > f->stage_n) {
+            if (capturing) staged = false;
+            else {
+                fdn_free_stage(f);  // (hipFree waits for launches that still use the old buffer)
+                if (hipMalloc((void**)&f->stage, need * sizeof(float)) == hipSuccess) f->stage_n = need;
+                else { (void)hipGetLastError(); f->stage = nullptr; staged = false; }   // no room: the kernels' own voice-minor path
+            }
+        }
+        if (staged) {
+            float* pin = f->stage;
+            float* pout = f->stage + b->V * (size_t)nin * frames;
+            fd::fdn_launch_transpose(d_in, pin, b->V, frames, nin, true, s);
+            fd::fdn_launch_render(f->c, f->st, b->V, pin, pout, frames, frames, FDSP_LAYOUT_PLANAR, tick, s);
+            fd::fdn_launch_transpose(pout, d_out, b->V, frames, nout, false, s);
+        } else {
+            fd::fdn_launch_render(f->c, f->st, b->V, d_in, d_out, frames, frame_stride, layout, tick, s);
+        }
+    } else if (b->math == FDSP_MATH_FAST && b->ops->render_fast)
         b->ops->render_fast(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, b->aux, b->ring, b->ring_cap, s);
     else
         b->ops->render(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, b->aux, b->ring, b->ring_cap, s);

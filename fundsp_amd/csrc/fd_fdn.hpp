@@ -76,4 +76,7 @@ void fdn_make_const_generic(const FdnDesc& d, double sample_rate, FdnConst* c);
 void fdn_launch_render(const FdnConst& c, const FdnState& s, size_t instances, const float* in, float* out, size_t T,
                        size_t fstride, int layout, int tick_mode, hipStream_t stream);
 
+// [channels][T][V] (voice-minor) <-> [V][channels][T] (planar, frame stride T): the staging copies of voice-minor launches (fd_fdn.hip)
+void fdn_launch_transpose(const float* src, float* dst, size_t V, size_t T, int channels, bool to_planar, hipStream_t stream);
+
 }  // namespace fd

@@ -184,7 +184,11 @@ int fdsp_bank_create_ring(const char* kind, size_t voices, size_t ring_frames, f
  * per FRAME of a 64-sample block (the 32 lines in 32 registers, the Hadamard as register butterflies; option
  * "fdn_kernel" = 1 selects the lane-per-delay-line formulation, identical samples); delay rings in HBM; flushes f32
  * denormals like the reference does after Feedback::new (src/feedback.rs:96, src/denormal.rs:18).  The handle works
- * with set_sample_rate / reset / process / clone / destroy. */
+ * with set_sample_rate / reset / process / clone / destroy.  Layouts: FDSP_LAYOUT_PLANAR ([instance][channel][frame_stride]) is what a
+ * lane-per-frame kernel reads and writes in 256-byte runs; FDSP_LAYOUT_VOICE_MINOR buffers of banks with 64 instances or more go
+ * through a planar staging copy owned by the bank (one tiled transpose in, one out: + 8 bytes per channel and instance-frame; it grows
+ * with the longest launch, outside stream captures only -- a captured launch that finds it too small gathers directly), smaller banks
+ * gather them directly. */
 int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, double damping, fdsp_bank** out);
 /* reverb4_stereo(room_size, time) (src/prelude.rs:1873-1941): TWO 16-line Hadamard networks in series --
  * multisplit::<U2,U8>() >> fdn(16 x delay >> fir3) >> multijoin::<U2,U8>() >> multisplit::<U2,U8>() >> fdn(16 x delay >> fir3)

@@ -52,6 +52,7 @@ pub mod ffi {
         pub fn fdsp_bank_create_on(device: c_int, kind: *const c_char, voices: usize, ring_frames: usize, out: *mut *mut FdspBank) -> c_int;
         pub fn fdsp_reverb_stereo_create_on(device: c_int, instances: usize, room_size: f64, time: f64, damping: f64, out: *mut *mut FdspBank) -> c_int;
         pub fn fdsp_reverb4_stereo_create_on(device: c_int, instances: usize, room_size: f64, time: f64, out: *mut *mut FdspBank) -> c_int;
+        pub fn fdsp_fdn_create_on(device: c_int, instances: usize, lines: c_int, delays: *const f64, taps: c_int, weights: *const f32, inputs: c_int, outputs: c_int, out: *mut *mut FdspBank) -> c_int;
         pub fn fdsp_bank_destroy(bank: *mut FdspBank);
         pub fn fdsp_bank_clone(bank: *const FdspBank, out: *mut *mut FdspBank) -> c_int; // Clone: slots, rings, sample rate, options, events
         pub fn fdsp_bank_inputs(bank: *const FdspBank) -> c_int;
@@ -163,6 +164,19 @@ impl<NI: Size<f32>, NO: Size<f32>> HipBank<NI, NO> {
         let mut bank: *mut FdspBank = core::ptr::null_mut();
         check(unsafe { fdsp_reverb4_stereo_create_on(device as c_int, instances, room_size, time, &mut bank) })?;
         Self::adopt(bank, "reverb4_stereo", instances)
+    }
+
+    /// `instances` x the Hadamard feedback delay network of the prelude's own example (src/prelude.rs:1323-1345):
+    /// `split::<N>() >> fdn::<N, _>(stacki::<N, _, _>(|i| delay(delays[i]) >> fir(weights))) >> join::<N>()` with `inputs = outputs = 1`,
+    /// `multisplit::<U2, _>` / `multijoin::<U2, _>` around it with 2.  `delays.len()` = N in 4, 8, 16, 32; one to three FIR weights; every
+    /// delay longer than 128 samples at the bank's sample rate.  Same kernel family as the reverbs: bit-identical to the `Feedback` graph
+    /// `from_graph` would build for the type, two orders of magnitude faster.
+    pub fn fdn(instances: usize, delays: &[f64], weights: &[f32], inputs: usize, outputs: usize, device: i32) -> Result<Self, String> {
+        let mut bank: *mut FdspBank = core::ptr::null_mut();
+        check(unsafe {
+            fdsp_fdn_create_on(device as c_int, instances, delays.len() as c_int, delays.as_ptr(), weights.len() as c_int, weights.as_ptr(), inputs as c_int, outputs as c_int, &mut bank)
+        })?;
+        Self::adopt(bank, "fdn", instances)
     }
 
     fn adopt(bank: *mut FdspBank, kind: &str, voices: usize) -> Result<Self, String> {

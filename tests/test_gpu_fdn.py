@@ -155,3 +155,34 @@ def test_short_delays_and_bad_arguments(gpu):
     with pytest.raises(gpu.FdspError, match="128 samples"):
         f.set_sample_rate(16000.0)
     assert f.inputs() == 1
+
+
+@pytest.mark.parametrize("kind", ["fdn8", "reverb_stereo", "reverb4_stereo"])
+def test_voice_minor_launches_of_larger_banks_take_the_staging_copy(gpu, kind):
+    """Banks of 64 instances or more take voice-minor buffers through a planar staging copy (fd_fdn.hip "voice-minor I/O"): the same samples
+    as the planar render of a twin bank and as the oracle, over ragged launches (the staging buffer grows with the longest launch)."""
+    V, T = 70, 64 * 12 + 9
+    rng = np.random.default_rng(5)
+    if kind == "fdn8":
+        delays, w = delays_of(8), (0.55, 0.4)
+        mk = lambda: gpu.Bank.fdn(V, 8, delays, 2, w, 2, 1)
+        net = lambda: oracle_net(8, delays, w, 2, 1)
+    elif kind == "reverb_stereo":
+        mk = lambda: gpu.Bank.reverb_stereo(V, 10.0, 2.0, 0.5)
+        net = lambda: O.reverb_stereo(10.0, 2.0, 0.5)
+    else:
+        mk = lambda: gpu.Bank.reverb4_stereo(V, 20.0, 2.0)
+        net = lambda: O.reverb4_stereo(20.0, 2.0)
+    a, b = mk(), mk()
+    a.set_sample_rate(SR)
+    b.set_sample_rate(SR)
+    x = (rng.random((V, a.inputs(), T), dtype=np.float32) * 2 - 1).astype(np.float32)
+    cuts = [0, 64 * 2 + 5, 64 * 9 + 5, T]
+    vm = run(a, x, LAYOUT_VOICE_MINOR, MODE_PROCESS, cuts)
+    pl = run(b, x, LAYOUT_PLANAR, MODE_PROCESS, cuts)
+    assert_bit_equal(vm, pl, f"{kind}: voice-minor (staged) == planar")
+    for v in (0, 63, 64, V - 1):
+        n = net()
+        n.set_sample_rate(SR)
+        want = np.concatenate([n.render_blocks(x[v][:, s:e]) for s, e in zip(cuts[:-1], cuts[1:])], axis=1)
+        assert_bit_equal(vm[v], want, f"{kind} instance {v}")

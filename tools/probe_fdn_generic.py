@@ -42,7 +42,7 @@ for n, w, nin, nout, V in [(16, (0.2, 0.4, 0.2), 1, 1, 2048), (16, (0.2, 0.4, 0.
           f"{V * T / ms / 1e3:10.1f} M instance-frames/s", flush=True)
     xv = x.permute(1, 2, 0).contiguous()                          # voice-minor [channel][frame][instance]
     ms_v, _ = timed(fast, xv, T, layout=F.LAYOUT_VOICE_MINOR)
-    print(f"    the same bank with voice-minor I/O (a lane = frame kernel gathers it): {ms_v:8.3f} ms", flush=True)
+    print(f"    the same bank with voice-minor I/O (through the planar staging copy: transpose in, render, transpose out): {ms_v:8.3f} ms", flush=True)
     if V <= 2048:
         Ts = 4800
         slow = F.Bank.from_graph(net(n, w, nin, nout), V, sample_rate=SR, fdn_kernel=False)
