@@ -221,6 +221,14 @@ fn golden(out_dir: &Path) {
             let mut g4 = reverb4_stereo(20.0, 2.0);
             g4.set_sample_rate(SR);
             write_npy(&out_dir.join(format!("reverb4_stereo_{tag}.npy")), 2, t_n, &flatten(&render(&mut g4, &x, t_n, process)));
+            // the prelude's own fdn example (src/prelude.rs:1334, "Mono Reverb") on the left channel of the same input: the graph
+            // fdsp_fdn_create renders through the lane-per-frame kernel (round 6)
+            let mut gf = split::<U16>()
+                >> fdn::<U16, _>(stacki::<U16, _, _>(|i| delay(lerp(0.01f32, 0.03f32, rnd1(i as u64) as f32)) >> fir((0.2, 0.4, 0.2))))
+                >> join::<U16>();
+            gf.set_sample_rate(SR);
+            let xm = vec![x[0].clone()];
+            write_npy(&out_dir.join(format!("fdn16_mono_reverb_{tag}.npy")), 1, t_n, &flatten(&render(&mut gf, &xm, t_n, process)));
         }
     }
 

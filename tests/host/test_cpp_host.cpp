@@ -197,6 +197,36 @@ static void gpu_checks() {
         }
         o_free(n);
     }
+    // the prelude's own fdn example (prelude.rs:1334): split >> fdn::<U16>(stacki(delay >> fir)) >> join through Bank::fdn (fdsp_fdn_create, the
+    // lane-per-frame kernel) against the oracle's generic Feedback graph, block by block
+    {
+        std::vector<double> delays;
+        std::vector<onode*> lines;
+        const float w[3] = {0.2f, 0.4f, 0.2f};
+        for (int i = 0; i < 16; i++) {
+            const float t = 0.01f + 0.00125f * (float)i;   // 480 .. 1380 samples at 48 kHz
+            delays.push_back((double)t);
+            lines.push_back(o_pipe(o_delay((double)t), o_fir(3, w)));
+        }
+        Bank b = Bank::fdn(2, delays, {0.2f, 0.4f, 0.2f});
+        b.set_sample_rate(SR);
+        onode* n = o_pipe(o_pipe(o_split(1, 16), o_feedback(o_multi(1, 16, lines.data(), 0), nullptr, 1)), o_join(1, 16));
+        o_set_sample_rate(n, SR);
+        EXPECT(b.inputs() == 1 && b.outputs() == 1);
+        uint32_t s = 777;
+        for (int blk = 0; blk < 60; blk++) {   // 3840 frames: several trips around every line
+            std::vector<float> x(2 * 64, 0.0f), got(2 * 64), want(64);
+            for (int i = 0; i < 64; i++) {
+                s = s * 1664525u + 1013904223u;
+                x[i] = x[64 + i] = blk < 30 ? (float)(s >> 8) * (1.0f / 8388608.0f) - 1.0f : 0.0f;
+            }
+            b.process(64, x.data(), got.data());
+            o_process(n, 64, x.data(), want.data());
+            if (!bit_equal(got.data(), want.data(), 64, "fdn<16> instance 0")) break;
+            if (!bit_equal(got.data() + 64, want.data(), 64, "fdn<16> instance 1")) break;
+        }
+        o_free(n);
+    }
     // a filter with an input: noise through the C ABI, the same samples through the oracle
     {
         Bank b("fixed_svf", 1);

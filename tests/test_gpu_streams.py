@@ -194,3 +194,46 @@ def test_run_time_compiled_fast_small_bank_captures_its_first_launch(gpu, how):
     exact = gpu.Bank.from_graph(mk(), V, sample_rate=SR)
     exact.set_seed(p["seed"])
     assert not torch.equal(ints(exact.process(64 * NB)), ints(want)), "the FAST bank must not have rendered exactly"
+
+
+@pytest.mark.parametrize("layout_name", ["voice_minor_staged", "planar"])
+def test_fdn_bank_block_launches_captured_into_a_hip_graph(gpu, layout_name):
+    """The lane-per-frame FDN banks (here the generic network, fdsp_fdn_create) under stream capture: block launches recorded once and
+    replayed equal one uncaptured render -- in the planar layout, and with voice-minor buffers through the bank's planar staging copy
+    (64 instances or more; sized by a launch before the capture, like the partial-mix buffer)."""
+    import torch
+    import fundsp_amd as F
+
+    V, NB = 80, 5
+    delays = [0.004 + 0.0007 * i for i in range(8)]
+    mk = lambda: gpu.Bank.fdn(V, 8, delays, 3, [0.2, 0.45, 0.2], 2, 2)
+    planar = layout_name == "planar"
+    b, r = mk(), mk()
+    b.set_sample_rate(SR)
+    r.set_sample_rate(SR)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand((V, 2, 64 * NB * 2) if planar else (2, 64 * NB * 2, V), device="cuda", generator=g) * 2 - 1
+    kw = dict(layout=F.LAYOUT_PLANAR, frame_stride=64) if planar else dict(layout=F.LAYOUT_VOICE_MINOR)
+    want = r.process(64 * NB * 2, x, **(dict(layout=F.LAYOUT_PLANAR, frame_stride=64 * NB * 2) if planar else kw))
+    ins = [torch.empty((V, 2, 64) if planar else (2, 64, V), device="cuda") for _ in range(NB)]
+    outs = [torch.empty_like(t) for t in ins]
+    s = torch.cuda.Stream()
+    chunks = []
+    with torch.cuda.stream(s):
+        ins[0].zero_()
+        b.process(64, ins[0], out=outs[0], **kw)        # loads the kernels and sizes the staging buffer before the capture ...
+        b.reset()                                        # ... and leaves no trace: silence through zeroed rings, then reset
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            for k in range(NB):
+                b.process(64, ins[k], out=outs[k], **kw)
+        for rep in range(2):
+            for k in range(NB):
+                sl = slice((rep * NB + k) * 64, (rep * NB + k + 1) * 64)
+                ins[k].copy_(x[:, :, sl] if planar else x[:, sl, :])
+            gr.replay()
+            chunks.append(torch.cat(outs, dim=2 if planar else 1).clone())
+        torch.cuda.synchronize()
+    got = torch.cat(chunks, dim=2 if planar else 1)
+    assert torch.equal(ints(got), ints(want))
