@@ -1040,7 +1040,7 @@ int fdsp_reverb4_stereo_create_on(int device, size_t instances, double room_size
 
 int fdsp_fdn_create_on(int device, size_t instances, int lines, const double* delays, int taps, const float* weights, int inputs, int outputs, fdsp_bank** out) {
     if (out) *out = nullptr;
-    if (lines != 4 && lines != 8 && lines != 16 && lines != 32) return fail(FDSP_EINVAL, "fdsp_fdn_create: lines takes 4, 8, 16 or 32 (FrameHadamard needs a power of two; the kernel holds at most 32 lines in registers)");
+    if (lines != 2 && lines != 4 && lines != 8 && lines != 16 && lines != 32) return fail(FDSP_EINVAL, "fdsp_fdn_create: lines takes 2, 4, 8, 16 or 32 (FrameHadamard needs a power of two; the kernel holds at most 32 lines in registers)");
     if (taps < 1 || taps > 3) return fail(FDSP_EINVAL, "fdsp_fdn_create: taps takes 1..3 (Fir<U1> .. Fir<U3>)");
     if ((inputs != 1 && inputs != 2) || (outputs != 1 && outputs != 2)) return fail(FDSP_EINVAL, "fdsp_fdn_create: inputs / outputs take 1 (split / join) or 2 (multisplit::<U2, _> / multijoin::<U2, _>)");
     if (!delays || !weights) return fail(FDSP_EINVAL, "fdsp_fdn_create: delays or weights NULL");

@@ -741,6 +741,7 @@ void fdn_launch_render(const FdnConst& c, const FdnState& s, size_t instances, c
     if (c.generic) {
         tl_opts.last_kernel = LK_FDN_FRAMES;
         switch (c.lines) {
+        case 2: return fdn_launch_generic<2>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream);
         case 4: return fdn_launch_generic<4>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream);
         case 8: return fdn_launch_generic<8>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream);
         case 16: return fdn_launch_generic<16>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream);

@@ -34,7 +34,7 @@ namespace fd {
 struct FdnConst {            // uniform over the bank (all instances share room / time / damping)
     int sections;            // 1: reverb_stereo (one 32-line FDN); 2: reverb4_stereo (two 16-line FDNs in series, lines 0-15 | 16-31)
     // the generic network `split / multisplit >> fdn::<N>(stacki(|i| delay(t_i) >> fir(w))) >> join / multijoin` (prelude.rs:1323-1345 and its
-    // doc example :1334): generic != 0, `lines` = N (4, 8, 16, 32), `taps` = the FIR's order (1..3), line k takes input channel k % nin
+    // doc example :1334): generic != 0, `lines` = N (2, 4, 8, 16, 32), `taps` = the FIR's order (1..3), line k takes input channel k % nin
     // (Split<N> :527-568, MultiSplit<M, N/M> :571-613), output channel j averages lines j, j + nout, .. (Join<N> :617-660, MultiJoin<M, N/M>
     // :668-730).  The reverbs: generic = 0, lines = 32 (all of them, both sections), taps = 3, nin = nout = 2.
     int generic, lines, taps, nin, nout;

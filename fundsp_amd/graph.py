@@ -558,7 +558,7 @@ def fdn_plan(g):
 
         split(N) | multisplit(2, N/2)  >>  fdn(stacki(N, lambda i: delay(t_i) >> fir(w..)))  >>  join(N) | multijoin(2, N/2)
 
-    with N in 4, 8, 16, 32, one to three FIR weights shared by all lines, and every parameter a scalar (the same network in every
+    with N in 2, 4, 8, 16, 32, one to three FIR weights shared by all lines, and every parameter a scalar (the same network in every
     instance) -- else None.  Such a graph renders through the lane-per-frame FDN kernel (one wave per instance, the lines in registers,
     coalesced ring rows) instead of lane-per-voice; Bank.from_graph takes that route when every delay exceeds two blocks."""
     name, kids = _parse_type(g.type)
@@ -599,7 +599,7 @@ def fdn_plan(g):
         taps = int(line[1][1][1][0][0])
     except (IndexError, ValueError):
         return None
-    if n not in (4, 8, 16, 32) or n_in != n or n_out != n or not 1 <= taps <= 3:
+    if n not in (2, 4, 8, 16, 32) or n_in != n or n_out != n or not 1 <= taps <= 3:
         return None
     vals = {}
     for path, field, value, _u in g.params:

@@ -198,7 +198,7 @@ int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, d
 int fdsp_reverb4_stereo_create(size_t instances, double room_size, double time, fdsp_bank** out);
 /* The generic Hadamard feedback delay network as the prelude documents it (src/prelude.rs:1323-1345, "Mono Reverb" :1334):
  *     split::<N>() >> fdn::<N, _>(stacki::<N, _, _>(|i| delay(delays[i]) >> fir(weights))) >> join::<N>()
- * `instances` independent networks of `lines` = N delay lines (4, 8, 16 or 32), Delay::new(delays[i]) seconds each
+ * `instances` independent networks of `lines` = N delay lines (2, 4, 8, 16 or 32), Delay::new(delays[i]) seconds each
  * (src/delay.rs:82-113), every line followed by the same Fir of `taps` = 1..3 weights (src/fir.rs:14-70), Feedback with FrameHadamard
  * around them (src/feedback.rs:35-57,108-146).  `inputs` = 1 puts split::<N>() in front (src/audionode.rs:527-568), 2
  * multisplit::<U2, N/2>() (:571-613: line k takes channel k % 2); `outputs` = 1 puts join::<N>() behind (:617-660), 2

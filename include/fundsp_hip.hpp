@@ -526,7 +526,7 @@ class Bank {
     }
     // split / multisplit >> fdn::<N, _>(stacki(|i| delay(delays[i]) >> fir(weights))) >> join / multijoin (prelude.rs:1323-1345, the
     // documented "Mono Reverb" :1334 with inputs = outputs = 1): the generic Hadamard network through the same lane-per-frame kernel family;
-    // delays.size() = N in 4, 8, 16, 32, one to three FIR weights, every delay longer than 128 samples at the bank's sample rate
+    // delays.size() = N in 2, 4, 8, 16, 32, one to three FIR weights, every delay longer than 128 samples at the bank's sample rate
     static Bank fdn(size_t instances, const std::vector<double>& delays, const std::vector<float>& weights, int inputs = 1, int outputs = 1) {
         Bank b;
         check(fdsp_fdn_create(instances, (int)delays.size(), delays.data(), (int)weights.size(), weights.data(), inputs, outputs, &b.h_));

@@ -168,7 +168,7 @@ impl<NI: Size<f32>, NO: Size<f32>> HipBank<NI, NO> {
 
     /// `instances` x the Hadamard feedback delay network of the prelude's own example (src/prelude.rs:1323-1345):
     /// `split::<N>() >> fdn::<N, _>(stacki::<N, _, _>(|i| delay(delays[i]) >> fir(weights))) >> join::<N>()` with `inputs = outputs = 1`,
-    /// `multisplit::<U2, _>` / `multijoin::<U2, _>` around it with 2.  `delays.len()` = N in 4, 8, 16, 32; one to three FIR weights; every
+    /// `multisplit::<U2, _>` / `multijoin::<U2, _>` around it with 2.  `delays.len()` = N in 2, 4, 8, 16, 32; one to three FIR weights; every
     /// delay longer than 128 samples at the bank's sample rate.  Same kernel family as the reverbs: bit-identical to the `Feedback` graph
     /// `from_graph` would build for the type, two orders of magnitude faster.
     pub fn fdn(instances: usize, delays: &[f64], weights: &[f32], inputs: usize, outputs: usize, device: i32) -> Result<Self, String> {

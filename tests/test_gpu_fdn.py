@@ -60,6 +60,7 @@ CASES = [  # lines, FIR weights, inputs, outputs
     (32, (-0.21, -0.45, -0.2), 2, 2),
     (8, (0.55, 0.4), 2, 1),
     (4, (0.93,), 1, 2),
+    (2, (0.45, 0.45), 1, 1),
 ]
 
 
@@ -186,3 +187,25 @@ def test_voice_minor_launches_of_larger_banks_take_the_staging_copy(gpu, kind):
         n.set_sample_rate(SR)
         want = np.concatenate([n.render_blocks(x[v][:, s:e]) for s, e in zip(cuts[:-1], cuts[1:])], axis=1)
         assert_bit_equal(vm[v], want, f"{kind} instance {v}")
+
+
+def test_generic_fdn_at_bench_size(gpu):
+    """The bench line's shape (bench.py "fdn16": 4 096 instances of the prelude's 16-line example x 48 000 frames, planar, built with
+    Bank.from_graph): spot instances against the oracle over the whole second, and the same second in two launches equals the one launch."""
+    import torch
+
+    V, T, n, w = 4096, 48000, 16, (0.2, 0.4, 0.2)
+    delays = delays_of(n)
+    b = gpu.Bank.from_graph(device_graph(n, delays, w, 1, 1), V, sample_rate=SR)
+    assert b.kind == "fdn"
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.rand((V, 1, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
+    one = b.process(T, x, layout=LAYOUT_PLANAR, frame_stride=T)
+    b.reset()
+    cut = 64 * 301 + 17
+    a1 = b.process(cut, x[:, :, :cut].contiguous(), layout=LAYOUT_PLANAR, frame_stride=cut)
+    a2 = b.process(T - cut, x[:, :, cut:].contiguous(), layout=LAYOUT_PLANAR, frame_stride=T - cut)
+    assert torch.equal(torch.cat([a1, a2], dim=2).view(torch.int32), one.view(torch.int32)), "two launches == one"
+    for v in (0, 1, 2047, 2048, V - 1):
+        net = oracle_net(n, delays, w, 1, 1)
+        assert_bit_equal(one[v].cpu().numpy(), net.render_blocks(x[v].cpu().numpy()), f"instance {v} of {V}, {T} frames")

@@ -184,7 +184,8 @@ def test_fdn_plan_recognises_the_documented_network_and_nothing_else():
     p = G.fdn_plan(g)
     assert p["lines"] == 8 and p["taps"] == 2 and p["inputs"] == 2 and p["outputs"] == 2
     assert G.fdn_plan(net(16, G.split(16), G.join(16), per_voice=True)) is None            # a per-voice delay: the generic kernels
-    assert G.fdn_plan(net(2, G.split(2), G.join(2))) is None                                # fewer than four lines
+    assert G.fdn_plan(net(2, G.split(2), G.join(2)))["lines"] == 2                          # the smallest Hadamard network
+    assert G.fdn_plan(G.split(64) >> G.fdn(G.stacki(64, lambda i: G.delay(0.01) >> G.fir(0.5))) >> G.join(64)) is None   # more lines than the kernel holds
     assert G.fdn_plan(G.split(4) >> G.feedback(G.stacki(4, lambda i: G.delay(0.01) >> G.fir(0.5))) >> G.join(4)) is None   # no Hadamard
     assert G.fdn_plan(G.split(4) >> G.fdn(G.stacki(4, lambda i: G.delay(0.01) >> G.lowpole_hz(1000.0))) >> G.join(4)) is None  # a recursive line filter
     assert G.fdn_plan(G.split(4) >> G.fdn(G.stacki(4, lambda i: G.delay(0.01) >> G.fir(0.1 * (i + 1)))) >> G.join(4)) is None  # per-line weights

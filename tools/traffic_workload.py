@@ -13,7 +13,7 @@ import torch
 import fundsp_amd as F
 from fundsp_amd import workloads as W
 
-WHICH = os.environ.get("TRAFFIC_WORKLOAD", "c3")   # c3 (default: the headline kernel) | c2 | c4v | c5 | c5r4: the other HBM-side kernels
+WHICH = os.environ.get("TRAFFIC_WORKLOAD", "c3")   # c3 (default: the headline kernel) | c2 | c4v | c5 | c5r4 | fdn16: the other HBM-side kernels
 T = 48000
 if WHICH == "c3":
     V = 65536
@@ -36,6 +36,19 @@ elif WHICH == "c4v":       # config 4, the gate a Var slot: 8 B per voice-sample
         for gate in (1.0, 0.0):
             bank.set_param(W.C4V_SLOTS["gate"], gate)
             bank.process(T // 2, None, out)
+elif WHICH == "fdn16":     # the prelude's fdn example through the generic lane-per-frame kernel: 136 B per instance-frame (16 rings r/w + 1 in + 1 out)
+    import numpy as np
+    from fundsp_amd import graph as G
+
+    V = 4096
+    r = W.rnd1(np.arange(16, dtype=np.uint64))
+    d = [float(np.float32(np.float32(0.01) * (np.float32(1) - np.float32(x)) + np.float32(0.03) * np.float32(x))) for x in r]
+    bank = F.Bank.from_graph(G.split(16) >> G.fdn(G.stacki(16, lambda i: G.delay(d[i]) >> G.fir(0.2, 0.4, 0.2))) >> G.join(16), V, sample_rate=48000.0)
+    assert bank.kind == "fdn"
+    inp = torch.rand((V, 1, T), dtype=torch.float32, device="cuda") * 2 - 1
+    outp = torch.empty((V, 1, T), dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        bank.process(T, inp, outp, layout=F.LAYOUT_PLANAR, frame_stride=T)
 else:                      # c5: reverb_stereo(10, 2, 0.5); c5r4: reverb4_stereo(20, 2): 272 B per instance-frame (rings + I/O)
     V = 2048
     bank = F.Bank.reverb_stereo(V, 10.0, 2.0, 0.5) if WHICH == "c5" else F.Bank.reverb4_stereo(V, 20.0, 2.0)
