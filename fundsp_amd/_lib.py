@@ -44,6 +44,8 @@ SYMBOLS = {
     "fdsp_reverb_stereo_create": (_i, [_sz, _d, _d, _d, C.POINTER(_P)]),
     "fdsp_reverb4_stereo_create": (_i, [_sz, _d, _d, C.POINTER(_P)]),
     "fdsp_reverb4_stereo_create_on": (_i, [_i, _sz, _d, _d, C.POINTER(_P)]),
+    "fdsp_reverb3_stereo_create": (_i, [_sz, _d, _d, _f, C.POINTER(_P)]),
+    "fdsp_reverb3_stereo_create_on": (_i, [_i, _sz, _d, _d, _f, C.POINTER(_P)]),
     "fdsp_fdn_create": (_i, [_sz, _i, C.POINTER(_d), _i, C.POINTER(C.c_float), _i, _i, C.POINTER(_P)]),
     "fdsp_fdn_create_on": (_i, [_i, _sz, _i, C.POINTER(_d), _i, C.POINTER(C.c_float), _i, _i, C.POINTER(_P)]),
     "fdsp_device_count": (_i, []),

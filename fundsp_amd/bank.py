@@ -56,6 +56,14 @@ class Bank:
         two orders of magnitude faster than one lane per voice; `fdn_kernel=False` keeps the run-time compiled form."""
         from . import graph as G
 
+        rv3 = getattr(graph, "reverb3_plan", None) if fdn_kernel else None
+        if rv3 is not None and graph.type.startswith("Reverb3<"):   # reverb3_stereo(time, diffusion, lowpole_hz(cutoff)) itself: its lane-per-frame kernel
+            if min(_lib.DEFAULT_SR, float(sample_rate or _lib.DEFAULT_SR)) >= 14200.0:
+                b = cls.reverb3_stereo(voices, **rv3)
+                if sample_rate is not None:
+                    b.set_sample_rate(sample_rate)
+                b.reset()
+                return b
         plan = G.fdn_plan(graph) if fdn_kernel else None
         if plan is not None:
             rates = {_lib.DEFAULT_SR, float(sample_rate or _lib.DEFAULT_SR)}   # the bank is constructed at DEFAULT_SR and then moved
@@ -107,6 +115,14 @@ class Bank:
         h = C.c_void_p()
         check(lib().fdsp_reverb4_stereo_create(int(instances), float(room_size), float(time), C.byref(h)))
         return cls("reverb4_stereo", instances, _handle=h)
+
+    @classmethod
+    def reverb3_stereo(cls, instances, time, diffusion, cutoff, device=-1):
+        """Bank of `instances` x reverb3_stereo(time, diffusion, lowpole_hz(cutoff)) (prelude.rs:1858-1871, reverb.rs:152-279: the allpass-loop
+        reverb) through its lane-per-frame kernel (fdsp_reverb3_stereo_create)."""
+        h = C.c_void_p()
+        check(lib().fdsp_reverb3_stereo_create_on(int(device), int(instances), float(time), float(diffusion), float(cutoff), C.byref(h)))
+        return cls("reverb3_stereo", instances, _handle=h)
 
     @classmethod
     def fdn(cls, instances, lines, delays, taps, weights, inputs=1, outputs=1, device=-1):

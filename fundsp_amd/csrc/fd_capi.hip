@@ -14,6 +14,7 @@
 #include "../../include/fundsp_hip.h"
 #include "fd_engine.hpp"
 #include "fd_fdn.hpp"
+#include "fd_reverb3.hpp"
 #include "fd_opts.hpp"
 
 namespace {
@@ -386,8 +387,12 @@ int build_default_table_set(int set) {
 }  // namespace
 
 struct FdnBank {  // reverb_stereo / reverb4_stereo banks (fd_fdn.hip): rings + per-line state instead of the slot SoA
-    int kind = 0;  // 0 = reverb_stereo(room, time, damping), 1 = reverb4_stereo(room, time), 2 = the generic network (fdsp_fdn_create: desc)
+    int kind = 0;  // 0 = reverb_stereo(room, time, damping), 1 = reverb4_stereo(room, time), 2 = the generic network (fdsp_fdn_create: desc),
+                   // 3 = reverb3_stereo(time, diffusion = `damping`, lowpole_hz(cutoff)): the allpass loop of fd_reverb3.hip (c3 / st3; `c` only carries nin / nout)
     double room = 0.0, time = 0.0, damping = 0.0;
+    float cutoff = 0.0f;
+    fd::Rv3Const c3;
+    fd::Rv3State st3{};
     fd::FdnDesc desc;
     fd::FdnConst c;
     fd::FdnState st;
@@ -979,6 +984,58 @@ static void fdn_free(FdnBank* f) {
     if (f->st.v2) hipFree(f->st.v2);
     if (f->st.fb) hipFree(f->st.fb);
     f->st = fd::FdnState{};
+    if (f->st3.rings) hipFree(f->st3.rings);
+    if (f->st3.wpos) hipFree(f->st3.wpos);
+    f->st3.rings = nullptr;   // (pre, wpre, fval outlive a re-configuration: rv3_free_persistent)
+    f->st3.wpos = nullptr;
+}
+static void rv3_free_persistent(FdnBank* f) {
+    if (f->st3.pre) hipFree(f->st3.pre);
+    if (f->st3.wpre) hipFree(f->st3.wpre);
+    if (f->st3.fval) hipFree(f->st3.fval);
+    f->st3.pre = nullptr; f->st3.wpre = nullptr; f->st3.fval = nullptr;
+}
+// reverb3_stereo banks: (re)allocate the loop's lines for a sample rate.  Transactional like fdn_configure.  What the reference's
+// Reverb::set_sample_rate leaves alone survives the move (the `pre` diffusers entirely; every allpass's z, the feedback sample and the
+// filters' values: fd_reverb3.hpp rv3_launch_migrate); the first configuration zeroes everything.
+static int rv3_configure(fdsp_bank* b, double sr) {
+    FdnBank* f = b->fdn;
+    fd::Rv3Const c;
+    if (!fd::rv3_make_const(f->time, f->damping, f->cutoff, sr, &c))
+        return fail(FDSP_EINVAL, "reverb3_stereo: every delay must exceed 128 samples at the bank's sample rate (two blocks: the lane-per-frame kernel's rule; >= 14.2 kHz)");
+    const size_t n = b->V;
+    const bool first = f->st3.pre == nullptr;
+    fd::Rv3State st = f->st3;
+    st.rings = nullptr;
+    st.wpos = nullptr;
+    hipError_t e = hipMalloc((void**)&st.rings, n * c.ring_stride * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&st.wpos, n * sizeof(int));
+    if (e == hipSuccess && first) e = hipMalloc((void**)&st.pre, n * 4 * (fd::RV3_PRE_CAP + 64) * sizeof(float));
+    if (e == hipSuccess && first) e = hipMalloc((void**)&st.wpre, n * sizeof(int));
+    if (e == hipSuccess && first) e = hipMalloc((void**)&st.fval, n * 16 * sizeof(float));
+    if (e != hipSuccess) {
+        if (st.rings) hipFree(st.rings);
+        if (st.wpos) hipFree(st.wpos);
+        if (first) { if (st.pre) hipFree(st.pre); if (st.wpre) hipFree(st.wpre); if (st.fval) hipFree(st.fval); }
+        return fail(e == hipErrorOutOfMemory ? FDSP_ENOMEM : FDSP_EDEVICE, std::string("reverb3_stereo buffers: ") + hipGetErrorString(e));
+    }
+    if (first) fd::rv3_launch_init(c, st, n, b->stream);
+    else {
+        // the new lines start empty; pre / filter values stay where they are; z and the feedback sample move over
+        fd::Rv3State fresh = st;
+        hipMemsetAsync(st.rings, 0, n * c.ring_stride * sizeof(float), b->stream);
+        hipMemsetAsync(st.wpos, 0, n * sizeof(int), b->stream);
+        fd::rv3_launch_migrate(f->c3, f->st3, c, fresh, n, b->stream);
+        hipStreamSynchronize(b->stream);
+        hipFree(f->st3.rings);
+        hipFree(f->st3.wpos);
+    }
+    f->c3 = c;
+    f->st3 = st;
+    f->c.nin = f->c.nout = 2;
+    b->sr = sr;
+    HIPCHK(hipGetLastError());
+    return FDSP_OK;
 }
 static void fdn_free_stage(FdnBank* f) {
     if (f && f->stage) hipFree(f->stage);
@@ -991,6 +1048,7 @@ static void fdn_free_stage(FdnBank* f) {
 // any failure the bank keeps its old constants, rings and rate.
 static int fdn_configure(fdsp_bank* b, double sr) {
     FdnBank* f = b->fdn;
+    if (f->kind == 3) return rv3_configure(b, sr);
     fd::FdnConst c;
     if (f->kind == 2) fd::fdn_make_const_generic(f->desc, sr, &c);
     else if (f->kind == 1) fd::fdn_make_const_reverb4(f->room, f->time, sr, &c);
@@ -1059,6 +1117,17 @@ int fdsp_fdn_create_on(int device, size_t instances, int lines, const double* de
 int fdsp_fdn_create(size_t instances, int lines, const double* delays, int taps, const float* weights, int inputs, int outputs, fdsp_bank** out) {
     return fdsp_fdn_create_on(-1, instances, lines, delays, taps, weights, inputs, outputs, out);
 }
+int fdsp_reverb3_stereo_create_on(int device, size_t instances, double time, double diffusion, float lowpole_cutoff, fdsp_bank** out) {
+    if (out) *out = nullptr;
+    if (!(time > 0.0) || !(diffusion >= 0.0 && diffusion <= 1.0) || !(lowpole_cutoff > 0.0f))
+        return fail(FDSP_EINVAL, "fdsp_reverb3_stereo_create: time > 0, diffusion in 0..1, lowpole cutoff > 0 Hz");
+    fd::FdnDesc d;   // (unused by this kind; carries the cutoff through the common constructor)
+    d.w[0] = lowpole_cutoff;
+    return fdn_bank_create_on(3, device, instances, 1.0, time, diffusion, out, &d);
+}
+int fdsp_reverb3_stereo_create(size_t instances, double time, double diffusion, float lowpole_cutoff, fdsp_bank** out) {
+    return fdsp_reverb3_stereo_create_on(-1, instances, time, diffusion, lowpole_cutoff, out);
+}
 
 static int fdn_bank_create_on(int kind, int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out, const fd::FdnDesc* desc) {
     if (!out) return fail(FDSP_EINVAL, "out is NULL");
@@ -1078,6 +1147,7 @@ static int fdn_bank_create_on(int kind, int device, size_t instances, double roo
     b->fdn->time = time;
     b->fdn->damping = damping;
     if (desc) b->fdn->desc = *desc;
+    if (kind == 3 && desc) b->fdn->cutoff = desc->w[0];
     b->fdn->st = fd::FdnState{};
     b->ops = nullptr;
     b->V = instances;
@@ -1113,6 +1183,7 @@ void fdsp_bank_destroy(fdsp_bank* b) {
     if (b->stream) sync_bank_stream(b);
     if (b->fdn) {
         fdn_free(b->fdn);
+        rv3_free_persistent(b->fdn);
         fdn_free_stage(b->fdn);
         delete b->fdn;
         b->fdn = nullptr;
@@ -1166,6 +1237,15 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
             }
         }
         const size_t n = src->V;
+        if (src->fdn->kind == 3) {
+            const fd::Rv3State &a3 = src->fdn->st3, &d3 = b->fdn->st3;
+            e = hipMemcpyAsync(d3.rings, a3.rings, n * src->fdn->c3.ring_stride * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(d3.pre, a3.pre, n * 4 * (fd::RV3_PRE_CAP + 64) * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(d3.wpos, a3.wpos, n * sizeof(int), hipMemcpyDeviceToDevice, b->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(d3.wpre, a3.wpre, n * sizeof(int), hipMemcpyDeviceToDevice, b->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(d3.fval, a3.fval, n * 16 * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
+            if (e != hipSuccess) return bail(e, "reverb3 state");
+        } else {
         const fd::FdnState &a = src->fdn->st, &d = b->fdn->st;
         e = hipMemcpyAsync(d.rings, a.rings, n * src->fdn->c.ring_stride * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d.wpos, a.wpos, n * sizeof(int), hipMemcpyDeviceToDevice, b->stream);
@@ -1173,6 +1253,7 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
         if (e == hipSuccess) e = hipMemcpyAsync(d.v2, a.v2, n * 32 * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d.fb, a.fb, n * 32 * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
         if (e != hipSuccess) return bail(e, "reverb state");
+        }
     } else {
         b->sr = src->sr;
         e = hipMemcpyAsync(b->slots, src->slots, (size_t)(src->nslots > 0 ? src->nslots : 1) * src->stride * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
@@ -1241,7 +1322,8 @@ int fdsp_bank_reset(fdsp_bank* b) {
     DeviceGuard guard(b->device);
     if (b->fdn) {
         HIPCHK(await_last_render(b));
-        fd::fdn_launch_reset(b->fdn->c, b->fdn->st, b->V, b->stream);
+        if (b->fdn->kind == 3) fd::rv3_launch_reset(b->fdn->c3, b->fdn->st3, b->V, b->stream);
+        else fd::fdn_launch_reset(b->fdn->c, b->fdn->st, b->V, b->stream);
         HIPCHK(hipGetLastError());
         HIPCHK(sync_bank_stream(b));
         return FDSP_OK;
@@ -1425,7 +1507,11 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
         const int tick = mode == FDSP_MODE_TICK ? 1 : 0, nin = f->c.nin, nout = f->c.nout;
         // voice-minor buffers of banks with at least a tile of instances go through the planar staging copy (the lane = frame kernels read
         // 256-byte runs of it instead of gathering a line per frame); the staging buffer grows outside captures only, like the partial mixes
-        bool staged = layout == FDSP_LAYOUT_VOICE_MINOR && b->V >= 64 && (f->c.generic || fd::tl_opts.fdn_kernel == 0 || f->c.sections == 2);
+        bool staged = layout == FDSP_LAYOUT_VOICE_MINOR && b->V >= 64 && (f->kind == 3 || f->c.generic || fd::tl_opts.fdn_kernel == 0 || f->c.sections == 2);
+        auto render = [&](const float* pi, float* po, size_t fs, int lay) {
+            if (f->kind == 3) fd::rv3_launch_render(f->c3, f->st3, b->V, pi, po, frames, fs, lay, s);   // (Reverb has no process override: one arithmetic)
+            else fd::fdn_launch_render(f->c, f->st, b->V, pi, po, frames, fs, lay, tick, s);
+        };
         const size_t need = b->V * (size_t)(nin + nout) * frames;
         if (staged && need > f->stage_n) {
             if (capturing) staged = false;
@@ -1439,10 +1525,10 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
             float* pin = f->stage;
             float* pout = f->stage + b->V * (size_t)nin * frames;
             fd::fdn_launch_transpose(d_in, pin, b->V, frames, nin, true, s);
-            fd::fdn_launch_render(f->c, f->st, b->V, pin, pout, frames, frames, FDSP_LAYOUT_PLANAR, tick, s);
+            render(pin, pout, frames, FDSP_LAYOUT_PLANAR);
             fd::fdn_launch_transpose(pout, d_out, b->V, frames, nout, false, s);
         } else {
-            fd::fdn_launch_render(f->c, f->st, b->V, d_in, d_out, frames, frame_stride, layout, tick, s);
+            render(d_in, d_out, frame_stride, layout);
         }
     } else if (b->math == FDSP_MATH_FAST && b->ops->render_fast)
         b->ops->render_fast(b->slots, b->stride, b->V, d_in, d_out, frames, frame_stride, layout, mode, b->aux, b->ring, b->ring_cap, s);

@@ -508,7 +508,14 @@ def reverb3_stereo(time, diffusion, make_filter):
     for b in range(8):                      # visit order of Reverb3: pre 0..3, then per block ap0 x4, ap1 x4, f0, f1, delay
         for k, flt in ((4 + b * 11 + 8, fs[2 * b]), (4 + b * 11 + 9, fs[2 * b + 1])):
             ps += [((k,) + p, fld, v, u) for p, fld, v, u in flt.params]
-    return Graph(f"Reverb3<{fs[0].type}>", 2, 2, ps, 76 + 16 * fs[0].rings, fs[0].source)
+    g = Graph(f"Reverb3<{fs[0].type}>", 2, 2, ps, 76 + 16 * fs[0].rings, fs[0].source)
+    # The stock shape -- reverb3_stereo(time, diffusion, lowpole_hz(cutoff)) with one cutoff for all sixteen filters and every argument a
+    # scalar -- has a dedicated lane-per-frame kernel (fdsp_reverb3_stereo_create); Bank.from_graph takes it when the graph IS this node
+    cut = {float(np.asarray(v)) for x in fs for _p, fld, v, _u in x.params if fld == "cutoff" and np.asarray(v).ndim == 0}
+    if (fs[0].type == "OnePole<OP_LOWPOLE,1>" and len(cut) == 1 and all(len(x.params) == 1 for x in fs)
+            and np.asarray(time).ndim == 0 and np.asarray(diffusion).ndim == 0):
+        g.reverb3_plan = dict(time=float(time), diffusion=float(diffusion), cutoff=float(np.float32(cut.pop())))
+    return g
 
 
 def reverb4_stereo_delays(delays, time):  # prelude.rs:1917-1941: two 16-line Hadamard FDNs in series

@@ -207,6 +207,17 @@ int fdsp_reverb4_stereo_create(size_t instances, double room_size, double time, 
  * rows as 256-byte runs: 8 * lines + 4 * (inputs + outputs) bytes per instance-frame), which needs every delay to exceed two blocks
  * (128 samples) at the bank's sample rate -- FDSP_EINVAL otherwise; such a graph still renders lane-per-voice through
  * fdsp_graph_compile.  Flushes f32 denormals like every graph with a Feedback node.  Handle semantics of the reverb banks. */
+/* reverb3_stereo(time, diffusion, lowpole_hz(cutoff)) (src/prelude.rs:1858-1871): the allpass-loop reverb Reverb<F> of src/reverb.rs:152-279
+ * with the documented loop filter, a one-pole lowpass (src/filter.rs:19-66).  `instances` independent reverbs, 2 inputs / 2 outputs each, all
+ * with the same parameters.  One wave per instance, one lane per FRAME of a 64-sample block: all 76 delay lines of the structure (4 input
+ * diffusers, 8 x (4 + 4) Schroeder allpasses, 8 block delays) are longer than two blocks, so their reads are known at the head of a block and
+ * every allpass is feed-forward inside it; the sixteen loop filters -- the only recurrences in time -- run on eight lanes between the two
+ * allpass layers.  624 B per instance-frame (76 ring reads + 76 ring writes + 2 in + 2 out).  The graph the run-time compiler builds for the
+ * same node renders the same samples one lane per voice, two to three orders of magnitude slower.  Like the reference: no process
+ * override (FDSP_MODE_PROCESS == FDSP_MODE_TICK), IEEE denormals kept (no Feedback node), reset() and set_sample_rate() leave the input
+ * diffusers alone (src/reverb.rs:211-238), a change of rate empties the lines but keeps every allpass's pending sample, the feedback sample
+ * and the filters' values.  Needs >= 14.2 kHz (every delay longer than 128 samples).  Handle semantics and layouts of the reverb banks. */
+int fdsp_reverb3_stereo_create(size_t instances, double time, double diffusion, float lowpole_cutoff_hz, fdsp_bank** out);
 int fdsp_fdn_create(size_t instances, int lines, const double* delays, int taps, const float* weights, int inputs, int outputs, fdsp_bank** out);
 /* Several GPUs from one process.  A bank lives on ONE device, fixed at creation: the `_on` constructors take the HIP
  * device index (-1 = the calling thread's current device, which is what the constructors above use).  Every entry point
@@ -218,6 +229,7 @@ int fdsp_device_count(void);
 int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring_frames, fdsp_bank** out);
 int fdsp_reverb_stereo_create_on(int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out);
 int fdsp_reverb4_stereo_create_on(int device, size_t instances, double room_size, double time, fdsp_bank** out);
+int fdsp_reverb3_stereo_create_on(int device, size_t instances, double time, double diffusion, float lowpole_cutoff_hz, fdsp_bank** out);
 int fdsp_fdn_create_on(int device, size_t instances, int lines, const double* delays, int taps, const float* weights, int inputs, int outputs, fdsp_bank** out);
 int fdsp_bank_device(const fdsp_bank* bank);
 void fdsp_bank_destroy(fdsp_bank* bank);
