@@ -233,6 +233,18 @@ def make_workload(F, W, torch, config, V, T, sr, first, layout, math, voice_out=
         inp = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
         n_out, bps, slot_bytes = 2, 272, 512       # 32 ring reads + 32 ring writes + 2 in + 2 out, x 4 B
         kernel = "fd::k_fdn_render_frames (lane = frame, one wave per instance)" + ("" if config == 5 else ", two 16-line networks in series")
+    elif config == "rv3":
+        # reverb3_stereo(2.0, 0.5, lowpole_hz(8000.0)) -- the reference's own example (prelude.rs:1850-1856) -- built from the GRAPH: Bank.from_graph
+        # sees the stock node and takes its lane-per-frame kernel (fdsp_reverb3_stereo_create); planar I/O, stereo noise in
+        from fundsp_amd import graph as G
+
+        layout = F.LAYOUT_PLANAR
+        bank = F.Bank.from_graph(G.reverb3_stereo(2.0, 0.5, lambda: G.lowpole_hz(8000.0)), V, sample_rate=sr)
+        assert bank.kind == "reverb3_stereo", "Bank.from_graph did not take the lane-per-frame kernel for reverb3_stereo"
+        g = torch.Generator(device="cuda").manual_seed(777 + first)
+        inp = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
+        n_out, bps, slot_bytes = 2, 624, 1024      # 76 ring reads + 76 ring writes + 2 in + 2 out, x 4 B
+        kernel = "fd::k_rv3_render (lane = frame, one wave per instance; the sixteen loop filters on eight lanes between the allpass layers)"
     elif config == "fdn16":
         # the Hadamard network the prelude documents (prelude.rs:1334 "Mono Reverb"): split >> fdn::<U16>(stacki(delay(lerp(0.01, 0.03, rnd1(i)))
         # >> fir((0.2, 0.4, 0.2)))) >> join, built from the GRAPH: Bank.from_graph recognises the shape (graph.fdn_plan) and takes the
@@ -516,7 +528,8 @@ def secondary(F, W, torch, sr, mode):
                                      (4, 32768, "config4_math_fast", "Msamples/s", "fast"),
                                      (5, 2048, "config5_reverb_stereo_2048", "M instance-frames/s", "exact"),
                                      ("5r4", 2048, "reverb4_stereo_2048", "M instance-frames/s", "exact"),
-                                     ("fdn16", 4096, "fdn16_mono_reverb_from_graph_4096", "M instance-frames/s", "exact")):
+                                     ("fdn16", 4096, "fdn16_mono_reverb_from_graph_4096", "M instance-frames/s", "exact"),
+                                     ("rv3", 2048, "reverb3_stereo_from_graph_2048", "M instance-frames/s", "exact")):
         T = 48000
         wl = make_workload(F, W, torch, cfg, V, T, sr, 0, F.LAYOUT_VOICE_MINOR, math)
         ms, kms = quick(F, torch, wl, T, mode, steps=6 if cfg == "4v" else 4, warmup=3 if cfg == "4v" else 1)
@@ -526,7 +539,11 @@ def secondary(F, W, torch, sr, mode):
         shape = {"4v": " -- the reference's gate shape `var(gate) >> adsr_live` (examples/live_adsr.rs:72): no graph input, the step = two launches "
                        "(gate high 24000 frames, low 24000) with the Var slot set on the device in between; 8 B per voice-sample (stereo out)",
                  4: " -- the gate as an audio-rate HBM input stream [frames][voices] (hosts that modulate the gate per sample): 4 B in + 8 B out per voice-sample"}.get(cfg, "")
-        what = (f"the generic Hadamard network of the prelude's own example (prelude.rs:1334: split >> fdn::<U16>(stacki(delay >> fir)) >> join), {V} instances x {T} frames, built "
+        what = (f"the reference's allpass-loop reverb, reverb3_stereo(2.0, 0.5, lowpole_hz(8000)) (prelude.rs:1850-1871, reverb.rs:152-279), {V} instances x {T} frames, built with "
+                "Bank.from_graph: the stock node is rendered by its lane-per-frame kernel (fdsp_reverb3_stereo_create) -- the run-time compiled lane-per-voice Reverb3 node renders the "
+                "same samples ~160 x slower (profiles/r06_reverb3_probe.txt); 624 B per instance-frame (76 ring reads + 76 ring writes + 2 in + 2 out)"
+                if cfg == "rv3" else
+                f"the generic Hadamard network of the prelude's own example (prelude.rs:1334: split >> fdn::<U16>(stacki(delay >> fir)) >> join), {V} instances x {T} frames, built "
                 "with Bank.from_graph: the graph's shape is recognised and rendered by the lane-per-frame FDN kernel (fdsp_fdn_create) -- the run-time compiled lane-per-voice "
                 "form of the same graph renders the same samples ~130 x slower (profiles/r06_fdn_generic_probe.txt); 136 B per instance-frame (16 ring reads + 16 ring writes + 1 in + 1 out)"
                 if cfg == "fdn16" else

@@ -1072,11 +1072,20 @@ static int fdn_configure(fdsp_bank* b, double sr) {
         fdn_free(&tmp);
         return fail(e == hipErrorOutOfMemory ? FDSP_ENOMEM : FDSP_EDEVICE, std::string("reverb_stereo buffers: ") + hipGetErrorString(e));
     }
-    fdn_free(f);  // the old buffers (the caller has synchronised the bank's stream)
+    // The new lines start empty (Delay::set_sample_rate resizes and resets, delay.rs:105-113) -- but a change of rate resets nothing else: the
+    // FIRs keep their two samples of history (Fir::set_sample_rate, fir.rs:52-54) and Feedback its value (feedback.rs:125-127), so a tail that
+    // is sounding when the rate changes goes on from those, exactly like the reference's
+    fd::fdn_launch_reset(c, st, n, b->stream);
+    if (f->st.v1) {
+        hipMemcpyAsync(st.v1, f->st.v1, n * 32 * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
+        hipMemcpyAsync(st.v2, f->st.v2, n * 32 * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
+        hipMemcpyAsync(st.fb, f->st.fb, n * 32 * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
+        hipStreamSynchronize(b->stream);
+    }
+    fdn_free(f);  // the old buffers
     f->c = c;
     f->st = st;
     b->sr = sr;
-    fd::fdn_launch_reset(f->c, f->st, n, b->stream);
     HIPCHK(hipGetLastError());
     return FDSP_OK;
 }

@@ -524,6 +524,13 @@ class Bank {
         b.kind_ = "reverb4_stereo";
         return b;
     }
+    // reverb3_stereo(time, diffusion, lowpole_hz(cutoff)) (prelude.rs:1858-1871, reverb.rs:152-279): the allpass-loop reverb through its lane-per-frame kernel
+    static Bank reverb3_stereo(size_t instances, double time, double diffusion, float lowpole_cutoff_hz) {
+        Bank b;
+        check(fdsp_reverb3_stereo_create(instances, time, diffusion, lowpole_cutoff_hz, &b.h_));
+        b.kind_ = "reverb3_stereo";
+        return b;
+    }
     // split / multisplit >> fdn::<N, _>(stacki(|i| delay(delays[i]) >> fir(weights))) >> join / multijoin (prelude.rs:1323-1345, the
     // documented "Mono Reverb" :1334 with inputs = outputs = 1): the generic Hadamard network through the same lane-per-frame kernel family;
     // delays.size() = N in 2, 4, 8, 16, 32, one to three FIR weights, every delay longer than 128 samples at the bank's sample rate

@@ -52,6 +52,7 @@ pub mod ffi {
         pub fn fdsp_bank_create_on(device: c_int, kind: *const c_char, voices: usize, ring_frames: usize, out: *mut *mut FdspBank) -> c_int;
         pub fn fdsp_reverb_stereo_create_on(device: c_int, instances: usize, room_size: f64, time: f64, damping: f64, out: *mut *mut FdspBank) -> c_int;
         pub fn fdsp_reverb4_stereo_create_on(device: c_int, instances: usize, room_size: f64, time: f64, out: *mut *mut FdspBank) -> c_int;
+        pub fn fdsp_reverb3_stereo_create_on(device: c_int, instances: usize, time: f64, diffusion: f64, lowpole_cutoff_hz: f32, out: *mut *mut FdspBank) -> c_int;
         pub fn fdsp_fdn_create_on(device: c_int, instances: usize, lines: c_int, delays: *const f64, taps: c_int, weights: *const f32, inputs: c_int, outputs: c_int, out: *mut *mut FdspBank) -> c_int;
         pub fn fdsp_bank_destroy(bank: *mut FdspBank);
         pub fn fdsp_bank_clone(bank: *const FdspBank, out: *mut *mut FdspBank) -> c_int; // Clone: slots, rings, sample rate, options, events
@@ -164,6 +165,14 @@ impl<NI: Size<f32>, NO: Size<f32>> HipBank<NI, NO> {
         let mut bank: *mut FdspBank = core::ptr::null_mut();
         check(unsafe { fdsp_reverb4_stereo_create_on(device as c_int, instances, room_size, time, &mut bank) })?;
         Self::adopt(bank, "reverb4_stereo", instances)
+    }
+
+    /// `instances` x `reverb3_stereo(time, diffusion, lowpole_hz(cutoff))` (src/prelude.rs:1858-1871; `Reverb<F>`, src/reverb.rs:152-279) through its
+    /// lane-per-frame kernel: bit-identical to the `Reverb3` node `from_graph` builds for the type, two orders of magnitude faster.
+    pub fn reverb3_stereo(instances: usize, time: f64, diffusion: f64, lowpole_cutoff_hz: f32, device: i32) -> Result<Self, String> {
+        let mut bank: *mut FdspBank = core::ptr::null_mut();
+        check(unsafe { fdsp_reverb3_stereo_create_on(device as c_int, instances, time, diffusion, lowpole_cutoff_hz, &mut bank) })?;
+        Self::adopt(bank, "reverb3_stereo", instances)
     }
 
     /// `instances` x the Hadamard feedback delay network of the prelude's own example (src/prelude.rs:1323-1345):

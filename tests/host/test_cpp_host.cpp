@@ -227,6 +227,31 @@ static void gpu_checks() {
         }
         o_free(n);
     }
+    // reverb3_stereo(2.0, 0.5, lowpole_hz(8000)) (the reference's own example, prelude.rs:1850-1856) through Bank::reverb3_stereo against the
+    // oracle's Reverb::tick restatement, block by block, a burst and its tail
+    {
+        Bank b = Bank::reverb3_stereo(2, 2.0, 0.5, 8000.0f);
+        b.set_sample_rate(SR);
+        onode* fl[16];
+        for (int i = 0; i < 16; i++) fl[i] = o_onepole(0, 1, 8000.0f);
+        onode* n = o_reverb3(2.0, 0.5, fl);
+        o_set_sample_rate(n, SR);
+        EXPECT(b.inputs() == 2 && b.outputs() == 2);
+        uint32_t s = 4242;
+        for (int blk = 0; blk < 200; blk++) {   // 12 800 frames: once around the loop
+            std::vector<float> x(2 * 2 * 64, 0.0f), got(2 * 2 * 64), want(2 * 64);
+            if (blk < 40)
+                for (int i = 0; i < 128; i++) {
+                    s = s * 1664525u + 1013904223u;
+                    x[i] = x[128 + i] = (float)(s >> 8) * (1.0f / 8388608.0f) - 1.0f;
+                }
+            b.process(64, x.data(), got.data());
+            o_process(n, 64, x.data(), want.data());
+            if (!bit_equal(got.data(), want.data(), 128, "reverb3_stereo instance 0")) break;
+            if (!bit_equal(got.data() + 128, want.data(), 128, "reverb3_stereo instance 1")) break;
+        }
+        o_free(n);
+    }
     // a filter with an input: noise through the C ABI, the same samples through the oracle
     {
         Bank b("fixed_svf", 1);

@@ -108,9 +108,11 @@ def test_generic_fdn_clone_and_other_sample_rate(gpu):
     assert_bit_equal(c2, a2, "the clone continues like the original")
     net = oracle_net(n, delays, w, 1, 1)
     assert_bit_equal(np.concatenate([a1, a2], axis=2)[3], net.render_blocks(x[3]), "chunked == the oracle's one pass")
-    # another rate: Delay::set_sample_rate resizes and resets (delay.rs:105-113)
+    # another rate: Delay::set_sample_rate resizes and empties the lines (delay.rs:105-113); the FIR history and the feedback value stay
+    # (the oracle graph goes the same way: one second at 48 kHz, then the move)
     b.set_sample_rate(96000.0)
     net = oracle_net(n, delays, w, 1, 1)
+    net.render_blocks(x[1])
     net.set_sample_rate(96000.0)
     got = run(b, x, LAYOUT_VOICE_MINOR, MODE_PROCESS, [0, T])
     assert_bit_equal(got[1], net.render_blocks(x[1]), "96 kHz")
@@ -209,3 +211,35 @@ def test_generic_fdn_at_bench_size(gpu):
     for v in (0, 1, 2047, 2048, V - 1):
         net = oracle_net(n, delays, w, 1, 1)
         assert_bit_equal(one[v].cpu().numpy(), net.render_blocks(x[v].cpu().numpy()), f"instance {v} of {V}, {T} frames")
+
+
+@pytest.mark.parametrize("kind", ["fdn16", "reverb_stereo", "reverb4_stereo"])
+def test_a_sample_rate_change_in_mid_tail_keeps_what_the_reference_keeps(gpu, kind):
+    """A change of rate empties the delay lines (Delay::set_sample_rate, delay.rs:105-113) and nothing else: the FIRs keep their history
+    (fir.rs:52-54), Feedback keeps its value (feedback.rs:125-127).  A bank moved from 48 kHz to 44.1 kHz while its tail sounds continues
+    like the oracle graph moved the same way (round 6; before, the move cleared those too -- right only for a silent bank)."""
+    V, T1, T2 = 3, 64 * 120 + 7, 64 * 130
+    rng = np.random.default_rng(77)
+    if kind == "fdn16":
+        delays, w = delays_of(16), (0.2, 0.4, 0.2)
+        b = gpu.Bank.fdn(V, 16, delays, 3, w)
+        net = lambda: oracle_net(16, delays, w, 1, 1)
+    elif kind == "reverb_stereo":
+        b = gpu.Bank.reverb_stereo(V, 10.0, 2.0, 0.5)
+        net = lambda: O.reverb_stereo(10.0, 2.0, 0.5)
+    else:
+        b = gpu.Bank.reverb4_stereo(V, 20.0, 2.0)
+        net = lambda: O.reverb4_stereo(20.0, 2.0)
+    b.set_sample_rate(SR)
+    x = (rng.random((V, b.inputs(), T1 + T2), dtype=np.float32) * 2 - 1).astype(np.float32)
+    x[:, :, T1:] = 0.0
+    run(b, x[:, :, :T1], LAYOUT_PLANAR, MODE_PROCESS, [0, T1])
+    b.set_sample_rate(44100.0)
+    got = run(b, x[:, :, T1:], LAYOUT_PLANAR, MODE_PROCESS, [0, 64 * 2 + 9, T2])
+    for v in range(V):
+        n = net()
+        n.set_sample_rate(SR)
+        n.render_blocks(x[v][:, :T1])
+        n.set_sample_rate(44100.0)
+        assert_bit_equal(got[v], n.render_blocks(x[v][:, T1:]), f"{kind} instance {v} after the move")
+    assert np.abs(got[:, :, :4]).max() > 1e-4       # the FIR history and the feedback value sound at once; the lines themselves start empty

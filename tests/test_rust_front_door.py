@@ -190,3 +190,17 @@ def test_fdn_plan_recognises_the_documented_network_and_nothing_else():
     assert G.fdn_plan(G.split(4) >> G.fdn(G.stacki(4, lambda i: G.delay(0.01) >> G.lowpole_hz(1000.0))) >> G.join(4)) is None  # a recursive line filter
     assert G.fdn_plan(G.split(4) >> G.fdn(G.stacki(4, lambda i: G.delay(0.01) >> G.fir(0.1 * (i + 1)))) >> G.join(4)) is None  # per-line weights
     assert G.fdn_plan(G.reverb4_stereo(20.0, 2.0)) is None and G.fdn_plan(G.sine_hz(440.0)) is None
+
+
+def test_reverb3_plan_marks_the_stock_node_only():
+    """graph.reverb3_stereo(time, diffusion, lowpole_hz(cutoff)) with scalar arguments carries the plan Bank.from_graph hands to
+    fdsp_reverb3_stereo_create; per-voice arguments, other loop filters, or the node inside a larger graph do not."""
+    import numpy as np
+    from fundsp_amd import graph as G
+
+    g = G.reverb3_stereo(2.0, 0.5, lambda: G.lowpole_hz(8000.0))
+    assert g.type == "Reverb3<OnePole<OP_LOWPOLE,1>>" and g.reverb3_plan == dict(time=2.0, diffusion=0.5, cutoff=8000.0)
+    assert getattr(G.reverb3_stereo(2.0, 0.5, lambda: G.lowpole_hz(np.array([900.0, 1000.0], np.float32))), "reverb3_plan", None) is None
+    assert getattr(G.reverb3_stereo(2.0, 0.5, lambda: G.highpole_hz(80.0)), "reverb3_plan", None) is None
+    assert getattr((G.noise() | G.noise()) >> g, "reverb3_plan", None) is None          # combinators build new Graph objects: no plan
+    assert getattr(g * 0.5, "reverb3_plan", None) is None

@@ -13,7 +13,7 @@ import torch
 import fundsp_amd as F
 from fundsp_amd import workloads as W
 
-WHICH = os.environ.get("TRAFFIC_WORKLOAD", "c3")   # c3 (default: the headline kernel) | c2 | c4v | c5 | c5r4 | fdn16: the other HBM-side kernels
+WHICH = os.environ.get("TRAFFIC_WORKLOAD", "c3")   # c3 (default: the headline kernel) | c2 | c4v | c5 | c5r4 | fdn16 | rv3: the other HBM-side kernels
 T = 48000
 if WHICH == "c3":
     V = 65536
@@ -47,6 +47,16 @@ elif WHICH == "fdn16":     # the prelude's fdn example through the generic lane-
     assert bank.kind == "fdn"
     inp = torch.rand((V, 1, T), dtype=torch.float32, device="cuda") * 2 - 1
     outp = torch.empty((V, 1, T), dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        bank.process(T, inp, outp, layout=F.LAYOUT_PLANAR, frame_stride=T)
+elif WHICH == "rv3":       # reverb3_stereo(2, 0.5, lowpole_hz(8000)): 624 B per instance-frame (76 rings r/w + 2 in + 2 out)
+    from fundsp_amd import graph as G
+
+    V = 2048
+    bank = F.Bank.from_graph(G.reverb3_stereo(2.0, 0.5, lambda: G.lowpole_hz(8000.0)), V, sample_rate=48000.0)
+    assert bank.kind == "reverb3_stereo"
+    inp = torch.rand((V, 2, T), dtype=torch.float32, device="cuda") * 2 - 1
+    outp = torch.empty((V, 2, T), dtype=torch.float32, device="cuda")
     for _ in range(3):
         bank.process(T, inp, outp, layout=F.LAYOUT_PLANAR, frame_stride=T)
 else:                      # c5: reverb_stereo(10, 2, 0.5); c5r4: reverb4_stereo(20, 2): 272 B per instance-frame (rings + I/O)
