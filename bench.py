@@ -760,8 +760,8 @@ def parse_args(argv=None):
     ap.add_argument("--gate", choices=["var", "stream"], default="var",
                     help="--config 4: var = the reference's own gate shape `var(gate) >> adsr_live` (examples/live_adsr.rs:72): no graph input, one step = the "
                          "launches of one note with the Var slot set on the device in between (default); stream = the gate as an audio-rate HBM input [frames][voices]")
-    ap.add_argument("--reverb", choices=["stereo", "4"], default="stereo",
-                    help="--config 5: stereo = reverb_stereo(10, 2, 0.5), BASELINE config 5 (default); 4 = reverb4_stereo(20, 2), two 16-line networks in series")
+    ap.add_argument("--reverb", choices=["stereo", "4", "3"], default="stereo",
+                    help="--config 5: stereo = reverb_stereo(10, 2, 0.5), BASELINE config 5 (default); 4 = reverb4_stereo(20, 2), two 16-line networks in series; 3 = reverb3_stereo(2, 0.5, lowpole_hz(8000)), the allpass-loop reverb (624 B per instance-frame)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall-time budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs 2 / 4 / 5, tolerance mode)")
     return ap.parse_args(argv)
@@ -994,7 +994,7 @@ def run_rank(args, torch, F, peers, device):
         else:
             first, V = rank * base_voices, base_voices
         fused = fused_mix(args, F, layout)
-        cfg = "4v" if args.config == 4 and args.gate == "var" else "5r4" if args.config == 5 and args.reverb == "4" else args.config
+        cfg = "4v" if args.config == 4 and args.gate == "var" else "5r4" if args.config == 5 and args.reverb == "4" else "rv3" if args.config == 5 and args.reverb == "3" else args.config
         wl = make_workload(F, W, torch, cfg, V, T, sr, first, layout, args.math, voice_out=not fused)
         bank = wl["bank"]
         mixes = []
@@ -1158,7 +1158,7 @@ def run_rank(args, torch, F, peers, device):
             "metric": {3: "Msamples/s (whole node) for 65536-voice SVF+FM graph",
                        2: "Msamples/s (whole node) for the 1024-voice biquad_bank on white noise (BASELINE config 2, informational)",
                        4: "Msamples/s (whole node) for saw>>moog*adsr>>pan voices (BASELINE config 4, informational)",
-                       5: f"M instance-frames/s (whole node) for {'reverb4_stereo' if args.reverb == '4' else 'reverb_stereo'} FDN instances (BASELINE config 5{' shape, the four-channel-network reverb' if args.reverb == '4' else ''}, informational)"}[args.config],
+                       5: f"M instance-frames/s (whole node) for {'reverb4_stereo' if args.reverb == '4' else 'reverb3_stereo' if args.reverb == '3' else 'reverb_stereo'} instances (BASELINE config 5{' shape, the four-channel-network reverb' if args.reverb == '4' else ' shape, the allpass-loop reverb' if args.reverb == '3' else ''}, informational)"}[args.config],
             "value": round(value, 3),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -1178,6 +1178,7 @@ def run_rank(args, torch, F, peers, device):
                                  "set between the launches of one note (high 0.5 s, low 0.5 s), " if args.gate == "var" else
                                  "BASELINE config 4 voice: ((dc(f)>>saw()|dc(fc)|dc(q))>>moog())*adsr_live(.01,.1,.6,.2)>>pan(p), gate in as an audio-rate stream, "),
                              5: ("reverb4_stereo(20.0, 2.0): two 16-line FDNs in series (prelude.rs:1873-1941), stereo noise in, planar I/O, " if args.reverb == "4" else
+                                 "reverb3_stereo(2.0, 0.5, lowpole_hz(8000.0)): the allpass-loop reverb (prelude.rs:1850-1871, reverb.rs:152-279), stereo noise in, planar I/O, " if args.reverb == "3" else
                                  "BASELINE config 5: reverb_stereo(10.0, 2.0, 0.5) 32-line FDN, stereo noise in, planar I/O, ")}[args.config] +
                             f"{total_voices} {unit_name} in total = {V} per GPU x {T} frames/step @ {sr:g} Hz, "
                             f"{'planar ([' + unit_name[:-1] + '][channel][frame] f32)' if args.config == 5 or args.layout == 'planar' else ('mix-out ([2][frame] f32, fused stereo mix-down: mode B)' if fused_mix(args, F, layout) else 'voice-out ([frame][voice] f32)')}, "

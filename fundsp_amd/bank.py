@@ -10,6 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from ._lib import FdspError  # noqa: E402
 from ._lib import FADE_POWER, FADE_SMOOTH, LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MIX_PAN, MIX_SUM, MODE_PROCESS, MODE_TICK, check, lib
 
 SVF_MODES = dict(lowpass=0, highpass=1, bandpass=2, notch=3, peak=4, allpass=5, bell=6, lowshelf=7, highshelf=8)
@@ -56,6 +57,17 @@ class Bank:
         two orders of magnitude faster than one lane per voice; `fdn_kernel=False` keeps the run-time compiled form."""
         from . import graph as G
 
+        stock = getattr(graph, "stock_reverb", None) if fdn_kernel else None
+        if stock is not None and graph.type.startswith("Pipe<") and "Feedback<" in graph.type:
+            # reverb_stereo(..) / reverb4_stereo(..) themselves (graph.py marks the object its constructor returns): their lane-per-frame kernels
+            try:
+                b = cls.reverb_stereo(voices, *stock[1]) if stock[0] == "reverb_stereo" else cls.reverb4_stereo(voices, *stock[1])
+                if sample_rate is not None:
+                    b.set_sample_rate(sample_rate)
+                b.reset()
+                return b
+            except FdspError:
+                pass   # (a room too small for the kernel's two-block rule at this rate: the run-time compiled graph renders it)
         rv3 = getattr(graph, "reverb3_plan", None) if fdn_kernel else None
         if rv3 is not None and graph.type.startswith("Reverb3<"):   # reverb3_stereo(time, diffusion, lowpole_hz(cutoff)) itself: its lane-per-frame kernel
             if min(_lib.DEFAULT_SR, float(sample_rate or _lib.DEFAULT_SR)) >= 14200.0:

@@ -532,7 +532,31 @@ def reverb4_stereo_delays(delays, time):  # prelude.rs:1917-1941: two 16-line Ha
 def reverb4_stereo(room_size, time):  # prelude.rs:1873-1914
     f = np.float32
     scale = max(f(room_size), f(15.0)) / f(10.0)
-    return reverb4_stereo_delays([f(d) * scale for d in REVERB4_DELAYS], time)
+    g = reverb4_stereo_delays([f(d) * scale for d in REVERB4_DELAYS], time)
+    if np.asarray(room_size).ndim == 0 and np.asarray(time).ndim == 0:   # the stock reverb itself: Bank.from_graph takes its dedicated kernel
+        g.stock_reverb = ("reverb4_stereo", (float(room_size), float(time)))
+    return g
+
+
+REVERB_DELAYS = [0.073904, 0.052918, 0.066238, 0.066387, 0.037783, 0.080073, 0.050961, 0.075900, 0.043646, 0.072095, 0.056194, 0.045961,
+                 0.058934, 0.068016, 0.047529, 0.058156, 0.072972, 0.036084, 0.062715, 0.076377, 0.044339, 0.076725, 0.077884, 0.046126,
+                 0.067741, 0.049800, 0.051709, 0.082923, 0.070121, 0.079315, 0.055039, 0.081859]   # prelude.rs:1739-1744
+
+
+def reverb_stereo(room_size, time, damping):
+    """reverb_stereo(room_size, time, damping) (prelude.rs:1732-1762): multisplit::<U2, U16>() >> fdn::<U32>(stacki(|i| delay(DELAYS[i] * room / 10)
+    >> fir3(1 - damping) * a)) >> sumf::<U32>(pan) * dc((1/16, 1/16)) -- BASELINE config 5 as a graph (scalar arguments)."""
+    f = np.float32
+    a = f(_db_amp(-60.0) ** (0.03 * room_size / 10.0 / time))                       # :1746
+    gain = f(1.0) - f(damping)
+    alpha = (gain + f(1.0)) / f(2.0)
+    beta = (f(1.0) - alpha) / f(2.0)
+    w = (beta * a, alpha * a, beta * a)                                              # fir3(gain).weights() * a  :1747, :863-867
+    line = stacki(32, lambda i: delay(float(f(REVERB_DELAYS[i] * room_size / 10.0))) >> fir(*w))   # delay(t as f32) :1749
+    pans = sumf(32, lambda x: pan(f(-1.0) * (f(1.0) - _smooth9(x)) + f(1.0) * _smooth9(x)))
+    g = multisplit(2, 16) >> fdn(line) >> pans * dc(1.0 / 16.0, 1.0 / 16.0)
+    g.stock_reverb = ("reverb_stereo", (float(room_size), float(time), float(damping)))
+    return g
 
 
 def _parse_type(t):

@@ -278,7 +278,8 @@ def test_jit_reverb4_stereo(gpu):
     assert g.rings == 32 and (g.nin, g.nout) == (2, 2)
     x = noise_input(V, 2, T, seed=21)
     x[:, :, 2000:] = 0.0                                           # a burst, then the tail
-    b = gpu.Bank.from_graph(g, V, ring_frames=8192, sample_rate=SR)
+    b = gpu.Bank.from_graph(g, V, ring_frames=8192, sample_rate=SR, fdn_kernel=False)   # (the run-time compiled graph, not the dedicated kernel)
+    assert b.kind.startswith("jit_")
     got = run_bank(b, x, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
     for v in (0, V - 1):
         n = O.reverb4_stereo(20.0, 2.0)

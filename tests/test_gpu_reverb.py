@@ -133,7 +133,8 @@ def test_reverb4_dedicated_kernel_equals_the_run_time_compiled_graph(gpu):
     a = gpu.Bank.reverb4_stereo(V, 20.0, 2.0)
     a.set_sample_rate(SR)
     ya = a.process(T, x, layout=LAYOUT_PLANAR, frame_stride=T)
-    b = gpu.Bank.from_graph(GR.reverb4_stereo(20.0, 2.0), V, sample_rate=SR)
+    b = gpu.Bank.from_graph(GR.reverb4_stereo(20.0, 2.0), V, sample_rate=SR, fdn_kernel=False)
+    assert b.kind.startswith("jit_") and gpu.Bank.from_graph(GR.reverb4_stereo(20.0, 2.0), 2, sample_rate=SR).kind == "reverb4_stereo"
     yb = b.process(T, x, layout=LAYOUT_PLANAR, frame_stride=T)
     torch.cuda.synchronize()
     assert float(ya.abs().max()) > 0.05
@@ -165,3 +166,28 @@ def test_reverb4_stereo_sample_rate_change_and_reset(gpu):
     with pytest.raises(gpu.FdspError):
         tiny.set_sample_rate(2000.0)          # the shortest line would be 95 samples: not longer than two blocks
     tiny.set_sample_rate(SR)                  # the bank keeps working at a rate that fits
+
+
+def test_from_graph_takes_the_dedicated_kernels_for_the_stock_reverbs(gpu):
+    """graph.reverb_stereo(..) / graph.reverb4_stereo(..) ARE the stock reverbs: Bank.from_graph builds their lane-per-frame banks (as it does for the
+    generic fdn network and reverb3_stereo); fdn_kernel=False compiles the same graph at run time.  reverb_stereo(10, 2, 0.5) -- BASELINE
+    config 5 spelled as a graph -- both ways, bit for bit; inside a larger graph the marker is gone and the run-time compiler renders it."""
+    import torch
+    from fundsp_amd import graph as GR
+
+    V, T = 5, 64 * 140 + 3
+    fast = gpu.Bank.from_graph(GR.reverb_stereo(10.0, 2.0, 0.5), V, sample_rate=SR)
+    slow = gpu.Bank.from_graph(GR.reverb_stereo(10.0, 2.0, 0.5), V, ring_frames=4096, sample_rate=SR, fdn_kernel=False)
+    assert fast.kind == "reverb_stereo" and slow.kind.startswith("jit_")
+    rng = np.random.default_rng(3)
+    x = (rng.random((V, 2, T), dtype=np.float32) * 2 - 1).astype(np.float32)
+    x[:, :, T // 2:] = 0.0
+    a, b = render(fast, x, LAYOUT_VOICE_MINOR), render(slow, x, LAYOUT_VOICE_MINOR)
+    assert fast.get_option("last_kernel") == 6 and slow.get_option("last_kernel") != 6
+    assert_bit_equal(a, b, "reverb_stereo: dedicated kernel vs run-time compiled graph")
+    n = O.reverb_stereo(10.0, 2.0, 0.5)
+    n.set_sample_rate(SR)
+    assert_bit_equal(a[4], n.render_blocks(x[4]), "... and the oracle")
+    wrapped = (GR.pass_() | GR.pass_()) >> GR.reverb_stereo(10.0, 2.0, 0.5)
+    assert getattr(wrapped, "stock_reverb", None) is None
+    del torch

@@ -204,3 +204,13 @@ def test_reverb3_plan_marks_the_stock_node_only():
     assert getattr(G.reverb3_stereo(2.0, 0.5, lambda: G.highpole_hz(80.0)), "reverb3_plan", None) is None
     assert getattr((G.noise() | G.noise()) >> g, "reverb3_plan", None) is None          # combinators build new Graph objects: no plan
     assert getattr(g * 0.5, "reverb3_plan", None) is None
+
+
+def test_stock_reverb_graphs_are_marked():
+    from fundsp_amd import graph as G
+
+    assert G.reverb_stereo(10.0, 2.0, 0.5).stock_reverb == ("reverb_stereo", (10.0, 2.0, 0.5))
+    assert G.reverb4_stereo(20.0, 2.0).stock_reverb == ("reverb4_stereo", (20.0, 2.0))
+    g = G.reverb_stereo(10.0, 2.0, 0.5)
+    assert g.type.startswith("Pipe<Pipe<MultiSplit<2,16>,Feedback<MultiStack<32,Pipe<Delay,Fir<3>>>,FbHadamard>>") and (g.nin, g.nout, g.rings) == (2, 2, 32)
+    assert getattr(G.reverb4_stereo_delays([0.03] * 32, 2.0), "stock_reverb", None) is None   # custom delays: the run-time compiler
