@@ -46,6 +46,8 @@ SYMBOLS = {
     "fdsp_reverb4_stereo_create_on": (_i, [_i, _sz, _d, _d, C.POINTER(_P)]),
     "fdsp_reverb3_stereo_create": (_i, [_sz, _d, _d, _f, C.POINTER(_P)]),
     "fdsp_reverb3_stereo_create_on": (_i, [_i, _sz, _d, _d, _f, C.POINTER(_P)]),
+    "fdsp_reverb3_stereo_svf_create": (_i, [_sz, _d, _d, _i, _f, _f, _f, C.POINTER(_P)]),
+    "fdsp_reverb3_stereo_svf_create_on": (_i, [_i, _sz, _d, _d, _i, _f, _f, _f, C.POINTER(_P)]),
     "fdsp_fdn_create": (_i, [_sz, _i, C.POINTER(_d), _i, C.POINTER(C.c_float), _i, _i, C.POINTER(_P)]),
     "fdsp_fdn_create_on": (_i, [_i, _sz, _i, C.POINTER(_d), _i, C.POINTER(C.c_float), _i, _i, C.POINTER(_P)]),
     "fdsp_device_count": (_i, []),

@@ -129,11 +129,17 @@ class Bank:
         return cls("reverb4_stereo", instances, _handle=h)
 
     @classmethod
-    def reverb3_stereo(cls, instances, time, diffusion, cutoff, device=-1):
-        """Bank of `instances` x reverb3_stereo(time, diffusion, lowpole_hz(cutoff)) (prelude.rs:1858-1871, reverb.rs:152-279: the allpass-loop
-        reverb) through its lane-per-frame kernel (fdsp_reverb3_stereo_create)."""
+    def reverb3_stereo(cls, instances, time, diffusion, cutoff, device=-1, svf=None, q=1.0, gain=1.0):
+        """Bank of `instances` x reverb3_stereo(time, diffusion, filter) (prelude.rs:1858-1871, reverb.rs:152-279: the allpass-loop reverb) through its
+        lane-per-frame kernel.  The loop filter: lowpole_hz(cutoff) (the documented one; fdsp_reverb3_stereo_create), or with `svf` = "lowpass" ..
+        "highshelf" the FixedSvf of that mode at (cutoff, q, gain) -- e.g. svf="highshelf" for the highshelf_hz(5000, 1, db_amp(-1)) of the
+        reference's examples (fdsp_reverb3_stereo_svf_create)."""
         h = C.c_void_p()
-        check(lib().fdsp_reverb3_stereo_create_on(int(device), int(instances), float(time), float(diffusion), float(cutoff), C.byref(h)))
+        if svf is None:
+            check(lib().fdsp_reverb3_stereo_create_on(int(device), int(instances), float(time), float(diffusion), float(cutoff), C.byref(h)))
+        else:
+            check(lib().fdsp_reverb3_stereo_svf_create_on(int(device), int(instances), float(time), float(diffusion), int(SVF_MODES[svf] if isinstance(svf, str) else svf),
+                                                          float(cutoff), float(q), float(gain), C.byref(h)))
         return cls("reverb3_stereo", instances, _handle=h)
 
     @classmethod

@@ -390,7 +390,8 @@ struct FdnBank {  // reverb_stereo / reverb4_stereo banks (fd_fdn.hip): rings + 
     int kind = 0;  // 0 = reverb_stereo(room, time, damping), 1 = reverb4_stereo(room, time), 2 = the generic network (fdsp_fdn_create: desc),
                    // 3 = reverb3_stereo(time, diffusion = `damping`, lowpole_hz(cutoff)): the allpass loop of fd_reverb3.hip (c3 / st3; `c` only carries nin / nout)
     double room = 0.0, time = 0.0, damping = 0.0;
-    float cutoff = 0.0f;
+    float cutoff = 0.0f;    // (kind 3: kept for the error texts; the loop filter is `flt`)
+    fd::Rv3Filter flt;
     fd::Rv3Const c3;
     fd::Rv3State st3{};
     fd::FdnDesc desc;
@@ -1001,7 +1002,7 @@ static void rv3_free_persistent(FdnBank* f) {
 static int rv3_configure(fdsp_bank* b, double sr) {
     FdnBank* f = b->fdn;
     fd::Rv3Const c;
-    if (!fd::rv3_make_const(f->time, f->damping, f->cutoff, sr, &c))
+    if (!fd::rv3_make_const(f->time, f->damping, f->flt, sr, &c))
         return fail(FDSP_EINVAL, "reverb3_stereo: every delay must exceed 128 samples at the bank's sample rate (two blocks: the lane-per-frame kernel's rule; >= 14.2 kHz)");
     const size_t n = b->V;
     const bool first = f->st3.pre == nullptr;
@@ -1012,7 +1013,7 @@ static int rv3_configure(fdsp_bank* b, double sr) {
     if (e == hipSuccess) e = hipMalloc((void**)&st.wpos, n * sizeof(int));
     if (e == hipSuccess && first) e = hipMalloc((void**)&st.pre, n * 4 * (fd::RV3_PRE_CAP + 64) * sizeof(float));
     if (e == hipSuccess && first) e = hipMalloc((void**)&st.wpre, n * sizeof(int));
-    if (e == hipSuccess && first) e = hipMalloc((void**)&st.fval, n * 16 * sizeof(float));
+    if (e == hipSuccess && first) e = hipMalloc((void**)&st.fval, n * 32 * sizeof(float));
     if (e != hipSuccess) {
         if (st.rings) hipFree(st.rings);
         if (st.wpos) hipFree(st.wpos);
@@ -1126,16 +1127,36 @@ int fdsp_fdn_create_on(int device, size_t instances, int lines, const double* de
 int fdsp_fdn_create(size_t instances, int lines, const double* delays, int taps, const float* weights, int inputs, int outputs, fdsp_bank** out) {
     return fdsp_fdn_create_on(-1, instances, lines, delays, taps, weights, inputs, outputs, out);
 }
-int fdsp_reverb3_stereo_create_on(int device, size_t instances, double time, double diffusion, float lowpole_cutoff, fdsp_bank** out) {
+static int rv3_create(int device, size_t instances, double time, double diffusion, const fd::Rv3Filter& flt, fdsp_bank** out) {
     if (out) *out = nullptr;
-    if (!(time > 0.0) || !(diffusion >= 0.0 && diffusion <= 1.0) || !(lowpole_cutoff > 0.0f))
-        return fail(FDSP_EINVAL, "fdsp_reverb3_stereo_create: time > 0, diffusion in 0..1, lowpole cutoff > 0 Hz");
-    fd::FdnDesc d;   // (unused by this kind; carries the cutoff through the common constructor)
-    d.w[0] = lowpole_cutoff;
+    if (!(time > 0.0) || !(diffusion >= 0.0 && diffusion <= 1.0) || !(flt.cutoff > 0.0f))
+        return fail(FDSP_EINVAL, "fdsp_reverb3_stereo_create: time > 0, diffusion in 0..1, the loop filter's cutoff > 0 Hz");
+    fd::FdnDesc d;   // (unused by this kind; carries the loop filter through the common constructor)
+    d.lines = flt.kind;
+    d.taps = flt.mode;
+    d.w[0] = flt.cutoff; d.w[1] = flt.q; d.w[2] = flt.gain;
     return fdn_bank_create_on(3, device, instances, 1.0, time, diffusion, out, &d);
+}
+int fdsp_reverb3_stereo_create_on(int device, size_t instances, double time, double diffusion, float lowpole_cutoff, fdsp_bank** out) {
+    fd::Rv3Filter f;
+    f.kind = 0;
+    f.cutoff = lowpole_cutoff;
+    return rv3_create(device, instances, time, diffusion, f, out);
 }
 int fdsp_reverb3_stereo_create(size_t instances, double time, double diffusion, float lowpole_cutoff, fdsp_bank** out) {
     return fdsp_reverb3_stereo_create_on(-1, instances, time, diffusion, lowpole_cutoff, out);
+}
+int fdsp_reverb3_stereo_svf_create_on(int device, size_t instances, double time, double diffusion, int svf_mode, float cutoff, float q, float gain, fdsp_bank** out) {
+    if (out) *out = nullptr;
+    if (svf_mode < 0 || svf_mode > 8 || !(q > 0.0f) || !(gain > 0.0f)) return fail(FDSP_EINVAL, "fdsp_reverb3_stereo_svf_create: svf_mode 0..8 (FDSP_SVF_*), q > 0, gain > 0 (an amplitude, used by bell / lowshelf / highshelf)");
+    fd::Rv3Filter f;
+    f.kind = 1;
+    f.mode = svf_mode;
+    f.cutoff = cutoff; f.q = q; f.gain = gain;
+    return rv3_create(device, instances, time, diffusion, f, out);
+}
+int fdsp_reverb3_stereo_svf_create(size_t instances, double time, double diffusion, int svf_mode, float cutoff, float q, float gain, fdsp_bank** out) {
+    return fdsp_reverb3_stereo_svf_create_on(-1, instances, time, diffusion, svf_mode, cutoff, q, gain, out);
 }
 
 static int fdn_bank_create_on(int kind, int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out, const fd::FdnDesc* desc) {
@@ -1156,7 +1177,12 @@ static int fdn_bank_create_on(int kind, int device, size_t instances, double roo
     b->fdn->time = time;
     b->fdn->damping = damping;
     if (desc) b->fdn->desc = *desc;
-    if (kind == 3 && desc) b->fdn->cutoff = desc->w[0];
+    if (kind == 3 && desc) {
+        b->fdn->cutoff = desc->w[0];
+        b->fdn->flt.kind = desc->lines;
+        b->fdn->flt.mode = desc->taps;
+        b->fdn->flt.cutoff = desc->w[0]; b->fdn->flt.q = desc->w[1]; b->fdn->flt.gain = desc->w[2];
+    }
     b->fdn->st = fd::FdnState{};
     b->ops = nullptr;
     b->V = instances;
@@ -1252,7 +1278,7 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
             if (e == hipSuccess) e = hipMemcpyAsync(d3.pre, a3.pre, n * 4 * (fd::RV3_PRE_CAP + 64) * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(d3.wpos, a3.wpos, n * sizeof(int), hipMemcpyDeviceToDevice, b->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(d3.wpre, a3.wpre, n * sizeof(int), hipMemcpyDeviceToDevice, b->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(d3.fval, a3.fval, n * 16 * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(d3.fval, a3.fval, n * 32 * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
             if (e != hipSuccess) return bail(e, "reverb3 state");
         } else {
         const fd::FdnState &a = src->fdn->st, &d = b->fdn->st;

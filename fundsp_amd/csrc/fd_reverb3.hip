@@ -6,6 +6,7 @@
 #include "fd_reverb3.hpp"
 #include "fd_opts.hpp"
 #include "fd_math.hpp"
+#include "fd_nodes.hpp"   // svf_coefs, SvfCore (host + device)
 
 namespace fd {
 
@@ -16,7 +17,7 @@ static const int RV3_RDELAYS[32] = {419, 433, 457, 479, 491, 509, 541, 557, 577,
 static const int RV3_BDELAYS[8] = {1087, 1091, 1093, 1097, 1103, 1109, 1117, 1123};                                   // :171
 static const int RV3_PDELAYS[4] = {245, 367, 263, 349};                                                                // :198
 
-bool rv3_make_const(double time, double diffusion, float cutoff, double sample_rate, Rv3Const* c) {
+bool rv3_make_const(double time, double diffusion, const Rv3Filter& filter, double sample_rate, Rv3Const* c) {
     *c = Rv3Const{};
     // Delay::new(t) at DEFAULT_SR, then set_sample_rate: time_in_samples = round(t * sample_rate) (delay.rs:105-112)
     auto samples = [&](int at_default) { return (int)std::round(((double)at_default / 44100.0) * sample_rate); };
@@ -43,8 +44,14 @@ bool rv3_make_const(double time, double diffusion, float cutoff, double sample_r
     // pow(db_amp(-60.0), 0.035 / time) as f32 (:196); db_amp(x) = exp((x / 20) * LN_10) (math.rs:76-78, 294)
     c->a = (float)std::pow(std::exp((-60.0 / 20.0) * 2.302585092994046), 0.035 / time);
     const float sr = (float)sample_rate;
-    c->c = expf_musl(-F32_TAU * cutoff / sr);   // Lowpole::set_cutoff, F = f32 (filter.rs:35-38)
-    c->omc = 1.0f - c->c;
+    c->fkind = filter.kind;
+    if (filter.kind == 0) {
+        c->c = expf_musl(-F32_TAU * filter.cutoff / sr);   // Lowpole::set_cutoff, F = f32 (filter.rs:35-38)
+        c->omc = 1.0f - c->c;
+    } else {
+        const SvfCoefs k = svf_coefs(filter.mode, sr, filter.cutoff, filter.q, filter.gain);   // FixedSvf::set_sample_rate -> update (svf.rs:989-992, 236-239)
+        c->sa1 = k.a1; c->sa2 = k.a2; c->sa3 = k.a3; c->sm0 = k.m0; c->sm1 = k.m1; c->sm2 = k.m2;
+    }
     return true;
 }
 
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(256) void k_rv3_zero(Rv3Const c, Rv3State s, size_t
     // Reverb::reset (reverb.rs:211-224): the loop blocks' lines, allpass z, filters and the feedback sample -- not `pre`
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
     for (size_t i = gid; i < instances * c.ring_stride; i += step) s.rings[i] = 0.0f;
-    for (size_t i = gid; i < instances * 16; i += step) s.fval[i] = 0.0f;
+    for (size_t i = gid; i < instances * 32; i += step) s.fval[i] = 0.0f;
     for (size_t i = gid; i < instances; i += step) s.wpos[i] = 0;
     if (with_pre) {
         for (size_t i = gid; i < instances * 4 * (RV3_PRE_CAP + 64); i += step) s.pre[i] = 0.0f;
@@ -97,6 +104,7 @@ constexpr int RS = 68;  // floats per row of the filter hand-over tiles (16-byte
         ZREG = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(RSRC, lane4, ((BASE) + (NEXT)) * 4, 0));           \
     }
 
+template <int FK>
 __global__ __launch_bounds__(256) void k_rv3_render(Rv3Const c, Rv3State s, size_t V, const float* __restrict__ in, float* __restrict__ out,
                                                     size_t T, size_t fstride, int layout) {
     __shared__ float tile_all[4][8 * RS];
@@ -111,9 +119,11 @@ __global__ __launch_bounds__(256) void k_rv3_render(Rv3Const c, Rv3State s, size
     const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc(s.pre + inst * 4 * PCP, 0, (int)(4 * PCP * sizeof(float)), 0x00020000);
     const int lane4 = lane * 4;
     int wp = __builtin_amdgcn_readfirstlane(s.wpos[inst]), wq = __builtin_amdgcn_readfirstlane(s.wpre[inst]);
-    float fv = lane < 16 ? s.fval[inst * 16 + lane] : 0.0f;   // lanes 0-7: filter0 of block `lane`; lanes 8-15: filter1 of block `lane - 8`
-    const float f1v = __shfl(fv, (lane & 7) + 8);               // ... both layers run on lanes 0-7
-    float val0 = fv, val1 = f1v;
+    // filter state of the serial lanes 0-7 (lane = loop block): layer 0 = filter0, layer 1 = filter1; a FixedSvf has two words per filter
+    float val0 = lane < 8 ? s.fval[inst * 32 + lane] : 0.0f, val1 = lane < 8 ? s.fval[inst * 32 + 8 + lane] : 0.0f;
+    float vb0 = (FK == 1 && lane < 8) ? s.fval[inst * 32 + 16 + lane] : 0.0f, vb1 = (FK == 1 && lane < 8) ? s.fval[inst * 32 + 24 + lane] : 0.0f;
+    SvfCore svf;
+    svf.a1 = c.sa1; svf.a2 = c.sa2; svf.a3 = c.sa3; svf.m0 = c.sm0; svf.m1 = c.sm1; svf.m2 = c.sm2; svf.ic1eq = 0.0f; svf.ic2eq = 0.0f;
     // The 76 lines' reads of a block (lane = frame) sit in 76 registers; each is consumed in place and the NEXT block's read of the same line is
     // issued into the same register right behind it (its slots lie before this block's write window: every distance exceeds 128), so a load has a
     // whole block of arithmetic to land
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256) void k_rv3_render(Rv3Const c, Rv3State s, size
                 RV3_AP(z0[b][1], rings, (b * 9 + 1) * CP, wide, pos, (wn - c.dap0[b][1]) & CMASK)
                 RV3_AP(z0[b][2], rings, (b * 9 + 2) * CP, wide, pos, (wn - c.dap0[b][2]) & CMASK)
                 RV3_AP(z0[b][3], rings, (b * 9 + 3) * CP, wide, pos, (wn - c.dap0[b][3]) & CMASK)
-                tile[b * RS + lane] = omc * x;   // Lowpole::tick: (1 - coeff) * x ...
+                tile[b * RS + lane] = FK == 0 ? omc * x : x;   // Lowpole::tick: (1 - coeff) * x ...  | FixedSvf: the sample itself
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -178,7 +188,23 @@ __global__ __launch_bounds__(256) void k_rv3_render(Rv3Const c, Rv3State s, size
                 float r[64];
 #pragma unroll
                 for (int n = 0; n < 64; n++) r[n] = tile[lane * RS + n];
-                if (size == 64) {
+                if (FK == 1) {   // FixedSvf::tick, the reference's operations in the reference's order (svf.rs:995-1006)
+                    svf.ic1eq = val0;
+                    svf.ic2eq = vb0;
+                    if (size == 64) {
+#pragma unroll
+                        for (int n = 0; n < 64; n++) r[n] = svf.tick(r[n]);
+                    } else {
+#pragma unroll
+                        for (int n = 0; n < 64; n++) {
+                            const float i1 = svf.ic1eq, i2 = svf.ic2eq;
+                            r[n] = svf.tick(r[n]);
+                            if (n >= size) { svf.ic1eq = i1; svf.ic2eq = i2; }
+                        }
+                    }
+                    val0 = svf.ic1eq;
+                    vb0 = svf.ic2eq;
+                } else if (size == 64) {
 #pragma unroll
                     for (int n = 0; n < 64; n++) {
                         val0 = r[n] + fc * val0;
@@ -213,7 +239,7 @@ __global__ __launch_bounds__(256) void k_rv3_render(Rv3Const c, Rv3State s, size
                 RV3_AP(z1[b][1], rings, (b * 9 + 5) * CP, wide, pos, (wn - c.dap1[b][1]) & CMASK)
                 RV3_AP(z1[b][2], rings, (b * 9 + 6) * CP, wide, pos, (wn - c.dap1[b][2]) & CMASK)
                 RV3_AP(z1[b][3], rings, (b * 9 + 7) * CP, wide, pos, (wn - c.dap1[b][3]) & CMASK)
-                tile[b * RS + lane] = omc * x;
+                tile[b * RS + lane] = FK == 0 ? omc * x : x;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -222,7 +248,23 @@ __global__ __launch_bounds__(256) void k_rv3_render(Rv3Const c, Rv3State s, size
                 float r[64];
 #pragma unroll
                 for (int n = 0; n < 64; n++) r[n] = tile[lane * RS + n];
-                if (size == 64) {
+                if (FK == 1) {   // FixedSvf::tick, the reference's operations in the reference's order (svf.rs:995-1006)
+                    svf.ic1eq = val1;
+                    svf.ic2eq = vb1;
+                    if (size == 64) {
+#pragma unroll
+                        for (int n = 0; n < 64; n++) r[n] = svf.tick(r[n]);
+                    } else {
+#pragma unroll
+                        for (int n = 0; n < 64; n++) {
+                            const float i1 = svf.ic1eq, i2 = svf.ic2eq;
+                            r[n] = svf.tick(r[n]);
+                            if (n >= size) { svf.ic1eq = i1; svf.ic2eq = i2; }
+                        }
+                    }
+                    val1 = svf.ic1eq;
+                    vb1 = svf.ic2eq;
+                } else if (size == 64) {
 #pragma unroll
                     for (int n = 0; n < 64; n++) {
                         val1 = r[n] + fc * val1;
@@ -278,8 +320,12 @@ __global__ __launch_bounds__(256) void k_rv3_render(Rv3Const c, Rv3State s, size
         s.wpre[inst] = wq;
     }
     if (lane < 8) {
-        s.fval[inst * 16 + lane] = val0;
-        s.fval[inst * 16 + 8 + lane] = val1;
+        s.fval[inst * 32 + lane] = val0;
+        s.fval[inst * 32 + 8 + lane] = val1;
+        if (FK == 1) {
+            s.fval[inst * 32 + 16 + lane] = vb0;
+            s.fval[inst * 32 + 24 + lane] = vb1;
+        }
     }
 }
 
@@ -297,7 +343,8 @@ void rv3_launch_render(const Rv3Const& c, const Rv3State& s, size_t instances, c
                        int layout, hipStream_t stream) {
     if (instances == 0 || T == 0) return;
     tl_opts.last_kernel = LK_FDN_FRAMES;
-    hipLaunchKernelGGL(k_rv3_render, dim3((unsigned)((instances + 3) / 4)), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout);
+    if (c.fkind == 1) hipLaunchKernelGGL(k_rv3_render<1>, dim3((unsigned)((instances + 3) / 4)), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout);
+    else hipLaunchKernelGGL(k_rv3_render<0>, dim3((unsigned)((instances + 3) / 4)), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout);
 }
 
 }  // namespace fd

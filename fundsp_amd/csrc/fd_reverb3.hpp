@@ -9,8 +9,8 @@
 // What makes a block of 64 frames parallel over its frames: every delay in the structure -- the 64 + 4 allpass lines (245 .. 1033
 // samples at 44.1 kHz) and the eight block delays (1087 .. 1123) -- is longer than two blocks, so all 76 ring reads of a block are known at
 // its head, each allpass is feed-forward inside the block, and the eight blocks do not see each other's output of the same block.  The one
-// thing that IS serial in time is the loop filter (a one-pole lowpass, filter.rs:19-66: value = (1 - c) * x + c * value): 16 of them per
-// instance, two per loop block.  So a wave renders one instance with lane = frame for everything but those, and hands each of the two
+// thing that IS serial in time is the loop filter (the documented one-pole lowpass, filter.rs:19-66: value = (1 - c) * x + c * value; or a
+// FixedSvf such as the highshelf_hz the reference's examples put there, svf.rs:995-1006): 16 of them per instance, two per loop block.  So a wave renders one instance with lane = frame for everything but those, and hands each of the two
 // filter layers over through a small LDS tile to lanes 0-7 (lane = loop block), which run the 64-step recurrence in registers.
 //
 // Rings: as in fd_fdn.hpp -- one write position per instance, ring k read at slot (w - dist_k), a 64-float mirror behind every ring so that
@@ -37,8 +37,16 @@ struct Rv3Const {                  // uniform over the bank
     int cap;                       // slots per main ring (power of two > the longest distance + 64); rings are cap + 64 floats apart
     float eta;                     // lerp(0.5, 0.9, diffusion) as f32   reverb.rs:173
     float a;                       // pow(db_amp(-60.0), 0.035 / time) as f32   :196
+    int fkind;                     // the loop filter: 0 = lowpole_hz(cutoff) (filter.rs:19-66), 1 = a FixedSvf (lowpass_hz .. highshelf_hz, svf.rs:861-1031)
     float c, omc;                  // Lowpole: coeff = exp(-TAU * cutoff / sr) (filter.rs:35-38), and 1 - coeff as tick computes it (:65)
+    float sa1, sa2, sa3, sm0, sm1, sm2;   // FixedSvf: SvfCoefs of (mode, sr, cutoff, q, gain) (svf.rs:28-221)
     size_t ring_stride;            // floats per instance = 72 * (cap + 64)
+};
+
+struct Rv3Filter {                 // host side: which loop filter, with what parameters
+    int kind = 0;                  // 0 lowpole_hz(cutoff) | 1 FixedSvf
+    int mode = 0;                  // SVF_LOWPASS .. SVF_HIGHSHELF
+    float cutoff = 0.0f, q = 1.0f, gain = 1.0f;
 };
 
 struct Rv3State {
@@ -46,11 +54,11 @@ struct Rv3State {
     float* pre;                    // [instances][4][RV3_PRE_CAP + 64]
     int* wpos;                     // [instances] write position of the main rings
     int* wpre;                     // [instances] ... of the pre rings (never reset)
-    float* fval;                   // [instances][16] Lowpole::value: filter0 of blocks 0-7, filter1 of blocks 0-7
+    float* fval;                   // [instances][32]: [0..15] Lowpole::value / FixedSvf::ic1eq of filter0 of blocks 0-7, filter1 of blocks 0-7; [16..31] ic2eq
 };
 
 // host: constants at `sample_rate`; false when a delay is not longer than two blocks there (the kernel's rule)
-bool rv3_make_const(double time, double diffusion, float cutoff, double sample_rate, Rv3Const* c);
+bool rv3_make_const(double time, double diffusion, const Rv3Filter& filter, double sample_rate, Rv3Const* c);
 void rv3_launch_init(const Rv3Const& c, const Rv3State& s, size_t instances, hipStream_t stream);   // construction: everything zero
 void rv3_launch_reset(const Rv3Const& c, const Rv3State& s, size_t instances, hipStream_t stream);  // Reverb::reset: all but `pre`
 // Reverb::set_sample_rate to a NEW rate: the lines of `to` are zero (Delay resizes and resets, delay.rs:105-113) but what the reference

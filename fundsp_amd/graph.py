@@ -509,12 +509,18 @@ def reverb3_stereo(time, diffusion, make_filter):
         for k, flt in ((4 + b * 11 + 8, fs[2 * b]), (4 + b * 11 + 9, fs[2 * b + 1])):
             ps += [((k,) + p, fld, v, u) for p, fld, v, u in flt.params]
     g = Graph(f"Reverb3<{fs[0].type}>", 2, 2, ps, 76 + 16 * fs[0].rings, fs[0].source)
-    # The stock shape -- reverb3_stereo(time, diffusion, lowpole_hz(cutoff)) with one cutoff for all sixteen filters and every argument a
-    # scalar -- has a dedicated lane-per-frame kernel (fdsp_reverb3_stereo_create); Bank.from_graph takes it when the graph IS this node
-    cut = {float(np.asarray(v)) for x in fs for _p, fld, v, _u in x.params if fld == "cutoff" and np.asarray(v).ndim == 0}
-    if (fs[0].type == "OnePole<OP_LOWPOLE,1>" and len(cut) == 1 and all(len(x.params) == 1 for x in fs)
-            and np.asarray(time).ndim == 0 and np.asarray(diffusion).ndim == 0):
-        g.reverb3_plan = dict(time=float(time), diffusion=float(diffusion), cutoff=float(np.float32(cut.pop())))
+    # The stock shapes -- reverb3_stereo(time, diffusion, lowpole_hz(cutoff)) or (time, diffusion, <a FixedSvf: lowpass_hz .. highshelf_hz>) with the same scalar
+    # parameters in all sixteen filters -- have a dedicated lane-per-frame kernel (fdsp_reverb3_stereo[_svf]_create); Bank.from_graph takes it when the graph IS this node
+    def uniform(field):   # the one scalar value all sixteen filters hold in `field`, else None
+        vals = {float(np.float32(np.asarray(v))) for x in fs for _p, fld, v, _u in x.params if fld == field and np.asarray(v).ndim == 0}
+        n = sum(1 for x in fs for _p, fld, _v, _u in x.params if fld == field)
+        return vals.pop() if len(vals) == 1 and n == 16 else None
+
+    if np.asarray(time).ndim == 0 and np.asarray(diffusion).ndim == 0:
+        if fs[0].type == "OnePole<OP_LOWPOLE,1>" and all(len(x.params) == 1 for x in fs) and uniform("cutoff") is not None:
+            g.reverb3_plan = dict(time=float(time), diffusion=float(diffusion), cutoff=uniform("cutoff"))
+        elif fs[0].type == "FixedSvf" and all(len(x.params) == 4 for x in fs) and None not in [uniform(k) for k in ("mode", "cutoff", "q", "gain")]:
+            g.reverb3_plan = dict(time=float(time), diffusion=float(diffusion), cutoff=uniform("cutoff"), svf=int(uniform("mode")), q=uniform("q"), gain=uniform("gain"))
     return g
 
 

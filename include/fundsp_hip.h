@@ -218,6 +218,10 @@ int fdsp_reverb4_stereo_create(size_t instances, double room_size, double time, 
  * diffusers alone (src/reverb.rs:211-238), a change of rate empties the lines but keeps every allpass's pending sample, the feedback sample
  * and the filters' values.  Needs >= 14.2 kHz (every delay longer than 128 samples).  Handle semantics and layouts of the reverb banks. */
 int fdsp_reverb3_stereo_create(size_t instances, double time, double diffusion, float lowpole_cutoff_hz, fdsp_bank** out);
+/* The same reverb with a FixedSvf as the loop filter -- reverb3_stereo(time, diffusion, highshelf_hz(5000.0, 1.0, db_amp(-1.0))) is what the
+ * reference's examples put there (examples/keys.rs:134): svf_mode = FDSP_SVF_LOWPASS .. FDSP_SVF_HIGHSHELF (the modes of fdsp_svf_coefs),
+ * `gain` an amplitude (bell / shelves).  Same kernel; the sixteen filters' recurrences (src/svf.rs:995-1006) run on the eight serial lanes. */
+int fdsp_reverb3_stereo_svf_create(size_t instances, double time, double diffusion, int svf_mode, float cutoff_hz, float q, float gain, fdsp_bank** out);
 int fdsp_fdn_create(size_t instances, int lines, const double* delays, int taps, const float* weights, int inputs, int outputs, fdsp_bank** out);
 /* Several GPUs from one process.  A bank lives on ONE device, fixed at creation: the `_on` constructors take the HIP
  * device index (-1 = the calling thread's current device, which is what the constructors above use).  Every entry point
@@ -230,6 +234,7 @@ int fdsp_bank_create_on(int device, const char* kind, size_t voices, size_t ring
 int fdsp_reverb_stereo_create_on(int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out);
 int fdsp_reverb4_stereo_create_on(int device, size_t instances, double room_size, double time, fdsp_bank** out);
 int fdsp_reverb3_stereo_create_on(int device, size_t instances, double time, double diffusion, float lowpole_cutoff_hz, fdsp_bank** out);
+int fdsp_reverb3_stereo_svf_create_on(int device, size_t instances, double time, double diffusion, int svf_mode, float cutoff_hz, float q, float gain, fdsp_bank** out);
 int fdsp_fdn_create_on(int device, size_t instances, int lines, const double* delays, int taps, const float* weights, int inputs, int outputs, fdsp_bank** out);
 int fdsp_bank_device(const fdsp_bank* bank);
 void fdsp_bank_destroy(fdsp_bank* bank);

@@ -531,6 +531,13 @@ class Bank {
         b.kind_ = "reverb3_stereo";
         return b;
     }
+    // ... with a FixedSvf as the loop filter, e.g. svf_mode = FDSP_SVF_HIGHSHELF for highshelf_hz(5000.0, 1.0, db_amp(-1.0)) (examples/keys.rs:134)
+    static Bank reverb3_stereo_svf(size_t instances, double time, double diffusion, int svf_mode, float cutoff_hz, float q, float gain = 1.0f) {
+        Bank b;
+        check(fdsp_reverb3_stereo_svf_create(instances, time, diffusion, svf_mode, cutoff_hz, q, gain, &b.h_));
+        b.kind_ = "reverb3_stereo";
+        return b;
+    }
     // split / multisplit >> fdn::<N, _>(stacki(|i| delay(delays[i]) >> fir(weights))) >> join / multijoin (prelude.rs:1323-1345, the
     // documented "Mono Reverb" :1334 with inputs = outputs = 1): the generic Hadamard network through the same lane-per-frame kernel family;
     // delays.size() = N in 2, 4, 8, 16, 32, one to three FIR weights, every delay longer than 128 samples at the bank's sample rate

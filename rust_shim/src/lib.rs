@@ -53,6 +53,7 @@ pub mod ffi {
         pub fn fdsp_reverb_stereo_create_on(device: c_int, instances: usize, room_size: f64, time: f64, damping: f64, out: *mut *mut FdspBank) -> c_int;
         pub fn fdsp_reverb4_stereo_create_on(device: c_int, instances: usize, room_size: f64, time: f64, out: *mut *mut FdspBank) -> c_int;
         pub fn fdsp_reverb3_stereo_create_on(device: c_int, instances: usize, time: f64, diffusion: f64, lowpole_cutoff_hz: f32, out: *mut *mut FdspBank) -> c_int;
+        pub fn fdsp_reverb3_stereo_svf_create_on(device: c_int, instances: usize, time: f64, diffusion: f64, svf_mode: c_int, cutoff_hz: f32, q: f32, gain: f32, out: *mut *mut FdspBank) -> c_int;
         pub fn fdsp_fdn_create_on(device: c_int, instances: usize, lines: c_int, delays: *const f64, taps: c_int, weights: *const f32, inputs: c_int, outputs: c_int, out: *mut *mut FdspBank) -> c_int;
         pub fn fdsp_bank_destroy(bank: *mut FdspBank);
         pub fn fdsp_bank_clone(bank: *const FdspBank, out: *mut *mut FdspBank) -> c_int; // Clone: slots, rings, sample rate, options, events
@@ -172,6 +173,14 @@ impl<NI: Size<f32>, NO: Size<f32>> HipBank<NI, NO> {
     pub fn reverb3_stereo(instances: usize, time: f64, diffusion: f64, lowpole_cutoff_hz: f32, device: i32) -> Result<Self, String> {
         let mut bank: *mut FdspBank = core::ptr::null_mut();
         check(unsafe { fdsp_reverb3_stereo_create_on(device as c_int, instances, time, diffusion, lowpole_cutoff_hz, &mut bank) })?;
+        Self::adopt(bank, "reverb3_stereo", instances)
+    }
+
+    /// ... with a `FixedSvf` as the loop filter: `svf_mode` 0..8 = lowpass, highpass, bandpass, notch, peak, allpass, bell, lowshelf, highshelf
+    /// (`reverb3_stereo(time, diffusion, highshelf_hz(5000.0, 1.0, db_amp(-1.0)))` of examples/keys.rs:134 is mode 8).
+    pub fn reverb3_stereo_svf(instances: usize, time: f64, diffusion: f64, svf_mode: i32, cutoff_hz: f32, q: f32, gain: f32, device: i32) -> Result<Self, String> {
+        let mut bank: *mut FdspBank = core::ptr::null_mut();
+        check(unsafe { fdsp_reverb3_stereo_svf_create_on(device as c_int, instances, time, diffusion, svf_mode as c_int, cutoff_hz, q, gain, &mut bank) })?;
         Self::adopt(bank, "reverb3_stereo", instances)
     }
 

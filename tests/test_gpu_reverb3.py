@@ -118,9 +118,59 @@ def test_from_graph_takes_the_reverb3_kernel_and_equals_the_run_time_compiled_no
     assert getattr(g, "reverb3_plan", None) is None
     g = GR.reverb3_stereo(2.5, 0.5, lambda: GR.dcblock_hz(30.0))
     assert getattr(g, "reverb3_plan", None) is None
+    g = GR.reverb3_stereo(2.5, 0.5, lambda: GR.highshelf_hz(5000.0, 1.0, 0.9))          # a FixedSvf with scalar parameters: the kernel's other filter
+    assert g.reverb3_plan["svf"] == 8
 
 
 def test_reverb3_bad_arguments(gpu):
     for args in ((0.0, 0.5, 1000.0), (2.0, 1.5, 1000.0), (2.0, 0.5, 0.0)):
         with pytest.raises(gpu.FdspError, match="reverb3"):
             gpu.Bank.reverb3_stereo(2, *args)
+
+
+SVF_FILTERS = [  # loop filters of the FixedSvf family: (graph / oracle constructor name, args)
+    ("highshelf_hz", (5000.0, 1.0, 0.8912509)),     # examples/keys.rs:134: highshelf_hz(5000.0, 1.0, db_amp(-1.0))
+    ("lowpass_hz", (3000.0, 0.7)),
+    ("bell_hz", (1200.0, 2.0, 0.7)),
+    ("notch_hz", (2000.0, 1.5)),
+]
+
+
+@pytest.mark.parametrize("name,args", SVF_FILTERS)
+def test_reverb3_with_a_fixed_svf_as_the_loop_filter(gpu, name, args):
+    """reverb3_stereo(time, diffusion, <FixedSvf>) -- the highshelf_hz of the reference's examples and three other modes -- through the same kernel
+    (fdsp_reverb3_stereo_svf_create: the sixteen SVF recurrences on the eight serial lanes): built with Bank.from_graph, bit-exact against the oracle
+    over ragged launches, a reset, and a change of rate in mid-tail (the coefficients follow the rate, the filters' states stay)."""
+    V, T = 4, 64 * 250 + 9
+    x = signal(V, T, 71)
+    mk_o = lambda: O.reverb3_stereo(1.8, 0.7, lambda: getattr(O, name)(*args))
+    b = gpu.Bank.from_graph(GR.reverb3_stereo(1.8, 0.7, lambda: getattr(GR, name)(*args)), V, sample_rate=SR)
+    assert b.kind == "reverb3_stereo"
+    cuts = [0, 64 * 5 + 3, 64 * 120 + 3, T]
+    got = run(b, x, LAYOUT_PLANAR, MODE_PROCESS, cuts)
+    assert b.get_option("last_kernel") == 6
+    for v in range(V):
+        n = mk_o()
+        n.set_sample_rate(SR)
+        want = np.concatenate([n.render_blocks(x[v][:, a:e]) for a, e in zip(cuts[:-1], cuts[1:])], axis=1)
+        assert_bit_equal(got[v], want, f"reverb3_stereo with {name}{args}, instance {v}")
+    assert np.abs(got[0][:, 12000:]).max() > 1e-4
+    # on with the tail at another rate, then a reset
+    b.set_sample_rate(44100.0)
+    z = np.zeros((V, 2, 64 * 40), dtype=np.float32)
+    tail = run(b, z, LAYOUT_VOICE_MINOR, MODE_TICK, [0, 64 * 40])
+    n = mk_o()
+    n.set_sample_rate(SR)
+    n.render_blocks(x[0])
+    n.set_sample_rate(44100.0)
+    assert_bit_equal(tail[0], n.render_ticks(z[0]), "the tail after the move to 44.1 kHz")
+    b.reset()
+    n.reset()
+    assert_bit_equal(run(b, x[:, :, :640], LAYOUT_PLANAR, MODE_PROCESS, [0, 640])[0], n.render_blocks(x[0][:, :640]), "after reset()")
+
+
+def test_reverb3_svf_bad_arguments(gpu):
+    with pytest.raises(gpu.FdspError, match="svf_mode"):
+        gpu.Bank.reverb3_stereo(2, 2.0, 0.5, 1000.0, svf=11)
+    with pytest.raises(gpu.FdspError, match="svf_mode"):
+        gpu.Bank.reverb3_stereo(2, 2.0, 0.5, 1000.0, svf="lowpass", q=0.0)

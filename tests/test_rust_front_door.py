@@ -202,6 +202,9 @@ def test_reverb3_plan_marks_the_stock_node_only():
     assert g.type == "Reverb3<OnePole<OP_LOWPOLE,1>>" and g.reverb3_plan == dict(time=2.0, diffusion=0.5, cutoff=8000.0)
     assert getattr(G.reverb3_stereo(2.0, 0.5, lambda: G.lowpole_hz(np.array([900.0, 1000.0], np.float32))), "reverb3_plan", None) is None
     assert getattr(G.reverb3_stereo(2.0, 0.5, lambda: G.highpole_hz(80.0)), "reverb3_plan", None) is None
+    p = G.reverb3_stereo(2.0, 0.5, lambda: G.highshelf_hz(5000.0, 1.0, 0.5)).reverb3_plan      # examples/keys.rs:134's loop filter family
+    assert p == dict(time=2.0, diffusion=0.5, cutoff=5000.0, svf=8, q=1.0, gain=0.5)
+    assert getattr(G.reverb3_stereo(2.0, 0.5, lambda: G.lowpass_hz(np.array([900.0, 1000.0], np.float32), 1.0)), "reverb3_plan", None) is None
     assert getattr((G.noise() | G.noise()) >> g, "reverb3_plan", None) is None          # combinators build new Graph objects: no plan
     assert getattr(g * 0.5, "reverb3_plan", None) is None
 

@@ -48,3 +48,15 @@ for V in (256, 2048, 8192):
         print(f"    run-time compiled lane-per-voice, T={Ts}: {ms2:8.3f} ms = {624 * V * Ts / ms2 / 1e6:8.1f} GB/s; per frame {ms2 / Ts / (ms / T):.0f} x the lane-per-frame kernel; identical samples: {same}", flush=True)
         slow.close()
     fast.close()
+
+# the loop filter of the reference's examples (examples/keys.rs:134): highshelf_hz(5000, 1, db_amp(-1)) -- sixteen SVF recurrences on the serial lanes
+V, T = 2048, 48000
+x = torch.rand((V, 2, T), device="cuda") * 2 - 1
+b = F.Bank.from_graph(G.reverb3_stereo(2.0, 0.5, lambda: G.highshelf_hz(5000.0, 1.0, 10.0 ** (-1.0 / 20.0))), V, sample_rate=SR)
+assert b.kind == "reverb3_stereo"
+ms, _ = timed(b, x, T)
+print(f"reverb3_stereo(2, 0.5, highshelf_hz(5000, 1, db_amp(-1))) V={V} T={T}: lane-per-frame {ms:8.3f} ms = {624 * V * T / ms / 1e6 / 8000:.3f} of 8 TB/s", flush=True)
+b.close()
+b = F.Bank.from_graph(G.reverb3_stereo(2.0, 0.5, lambda: G.highshelf_hz(5000.0, 1.0, 10.0 ** (-1.0 / 20.0))), 256, sample_rate=SR)
+ms, _ = timed(b, x[:256].contiguous(), T)
+print(f"    256 instances (one wave per instance, one per SIMD): {ms:8.3f} ms", flush=True)
