@@ -229,6 +229,14 @@ fn golden(out_dir: &Path) {
             gf.set_sample_rate(SR);
             let xm = vec![x[0].clone()];
             write_npy(&out_dir.join(format!("fdn16_mono_reverb_{tag}.npy")), 1, t_n, &flatten(&render(&mut gf, &xm, t_n, process)));
+            // reverb3_stereo, the allpass-loop reverb (src/reverb.rs:152-279), with the documented loop filter and with the one the examples use
+            // (examples/keys.rs:134): the graphs fdsp_reverb3_stereo_create / _svf_create render through their lane-per-frame kernel (round 6)
+            let mut g3 = reverb3_stereo(2.0, 0.5, lowpole_hz(8000.0));
+            g3.set_sample_rate(SR);
+            write_npy(&out_dir.join(format!("reverb3_stereo_lowpole_{tag}.npy")), 2, t_n, &flatten(&render(&mut g3, &x, t_n, process)));
+            let mut g3h = reverb3_stereo(2.0, 0.5, highshelf_hz(5000.0, 1.0, db_amp(-1.0)));
+            g3h.set_sample_rate(SR);
+            write_npy(&out_dir.join(format!("reverb3_stereo_highshelf_{tag}.npy")), 2, t_n, &flatten(&render(&mut g3h, &x, t_n, process)));
         }
     }
 
