@@ -390,8 +390,7 @@ struct FdnBank {  // reverb_stereo / reverb4_stereo banks (fd_fdn.hip): rings + 
     int kind = 0;  // 0 = reverb_stereo(room, time, damping), 1 = reverb4_stereo(room, time), 2 = the generic network (fdsp_fdn_create: desc),
                    // 3 = reverb3_stereo(time, diffusion = `damping`, lowpole_hz(cutoff)): the allpass loop of fd_reverb3.hip (c3 / st3; `c` only carries nin / nout)
     double room = 0.0, time = 0.0, damping = 0.0;
-    float cutoff = 0.0f;    // (kind 3: kept for the error texts; the loop filter is `flt`)
-    fd::Rv3Filter flt;
+    fd::Rv3Filter flt;      // kind 3: the loop filter
     fd::Rv3Const c3;
     fd::Rv3State st3{};
     fd::FdnDesc desc;
@@ -1095,7 +1094,8 @@ int fdsp_reverb_stereo_create(size_t instances, double room_size, double time, d
     return fdsp_reverb_stereo_create_on(-1, instances, room_size, time, damping, out);
 }
 
-static int fdn_bank_create_on(int kind, int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out, const fd::FdnDesc* desc = nullptr);
+static int fdn_bank_create_on(int kind, int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out, const fd::FdnDesc* desc = nullptr,
+                              const fd::Rv3Filter* flt = nullptr);
 int fdsp_reverb_stereo_create_on(int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out) {
     return fdn_bank_create_on(0, device, instances, room_size, time, damping, out);
 }
@@ -1131,11 +1131,7 @@ static int rv3_create(int device, size_t instances, double time, double diffusio
     if (out) *out = nullptr;
     if (!(time > 0.0) || !(diffusion >= 0.0 && diffusion <= 1.0) || !(flt.cutoff > 0.0f))
         return fail(FDSP_EINVAL, "fdsp_reverb3_stereo_create: time > 0, diffusion in 0..1, the loop filter's cutoff > 0 Hz");
-    fd::FdnDesc d;   // (unused by this kind; carries the loop filter through the common constructor)
-    d.lines = flt.kind;
-    d.taps = flt.mode;
-    d.w[0] = flt.cutoff; d.w[1] = flt.q; d.w[2] = flt.gain;
-    return fdn_bank_create_on(3, device, instances, 1.0, time, diffusion, out, &d);
+    return fdn_bank_create_on(3, device, instances, 1.0, time, diffusion, out, nullptr, &flt);
 }
 int fdsp_reverb3_stereo_create_on(int device, size_t instances, double time, double diffusion, float lowpole_cutoff, fdsp_bank** out) {
     fd::Rv3Filter f;
@@ -1159,7 +1155,8 @@ int fdsp_reverb3_stereo_svf_create(size_t instances, double time, double diffusi
     return fdsp_reverb3_stereo_svf_create_on(-1, instances, time, diffusion, svf_mode, cutoff, q, gain, out);
 }
 
-static int fdn_bank_create_on(int kind, int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out, const fd::FdnDesc* desc) {
+static int fdn_bank_create_on(int kind, int device, size_t instances, double room_size, double time, double damping, fdsp_bank** out, const fd::FdnDesc* desc,
+                              const fd::Rv3Filter* flt) {
     if (!out) return fail(FDSP_EINVAL, "out is NULL");
     *out = nullptr;
     if (instances == 0 || !(room_size > 0.0) || !(time > 0.0)) return fail(FDSP_EINVAL, "bad reverb_stereo / reverb4_stereo arguments");
@@ -1177,12 +1174,7 @@ static int fdn_bank_create_on(int kind, int device, size_t instances, double roo
     b->fdn->time = time;
     b->fdn->damping = damping;
     if (desc) b->fdn->desc = *desc;
-    if (kind == 3 && desc) {
-        b->fdn->cutoff = desc->w[0];
-        b->fdn->flt.kind = desc->lines;
-        b->fdn->flt.mode = desc->taps;
-        b->fdn->flt.cutoff = desc->w[0]; b->fdn->flt.q = desc->w[1]; b->fdn->flt.gain = desc->w[2];
-    }
+    if (flt) b->fdn->flt = *flt;
     b->fdn->st = fd::FdnState{};
     b->ops = nullptr;
     b->V = instances;
@@ -1252,7 +1244,7 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
     fdsp_bank* b = nullptr;
     int rc;
     if (src->fdn)
-        rc = fdn_bank_create_on(src->fdn->kind, src->device, src->V, src->fdn->room, src->fdn->time, src->fdn->damping, &b, &src->fdn->desc);
+        rc = fdn_bank_create_on(src->fdn->kind, src->device, src->V, src->fdn->room, src->fdn->time, src->fdn->damping, &b, &src->fdn->desc, &src->fdn->flt);
     else
         rc = fdsp_bank_create_on(src->device, src->ops->name.c_str(), src->V, src->ring_frames, &b);
     if (rc != FDSP_OK) return rc;

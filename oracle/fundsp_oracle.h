@@ -246,6 +246,9 @@ double o_biquad_bank8_render(const o_bank_job *job, float *out);
 /* Config 5: `instances` x reverb_stereo(room, time, damping) on the SAME stereo input x [2][frames]; out (or NULL) = [instance][2][frames] */
 double o_reverb_bank_render(int threads, int fast, double sample_rate, size_t instances, size_t frames, double room, double time, double damping,
                             const float *x, float *out);
+/* round 6: tree-walk CPU legs of reverb3_stereo (which = 0: p = time, diffusion, lowpole cutoff) and of the prelude's fdn example (which = 1: p = 16
+ * delays + 3 FIR weights); x [inputs][frames] shared by the instances, out [instances][outputs][frames] or NULL; returns seconds */
+double o_graph_bank_render(int threads, int which, const double *p, double sample_rate, size_t instances, size_t frames, const float *x, float *out);
 const char *o_fast_simd_flavour(void);
 
 #ifdef __cplusplus

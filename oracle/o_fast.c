@@ -355,6 +355,65 @@ double o_reverb_bank_render(int threads, int fast, double sample_rate, size_t in
     return s;
 }
 
+/* ---- CPU legs of round 6's lane-per-frame kinds (bench.py secondary entries): the generic tree walk of the graph, one graph object per instance, the
+ * instances split over pinned threads.  which = 0: reverb3_stereo(p[0], p[1], lowpole_hz(p[2])) (reverb.rs:152-279), 2 in / 2 out;
+ * which = 1: the prelude's fdn example (prelude.rs:1334) split >> fdn::<U16>(stacki(|i| delay(p[i]) >> fir((p[16], p[17], p[18])))) >> join, 1 in / 1 out.
+ * x = [inputs][frames] shared by all instances; out = [instances][outputs][frames] or NULL. */
+typedef struct {
+    int which, t, nin, nout;
+    double sr;
+    const double *p;
+    size_t i0, i1, frames;
+    const float *x;
+    float *out;
+} ggslice;
+static ggslice g_gg;
+static void gg_fill(void *q, size_t i0, size_t i1, int t) {
+    ggslice *s = (ggslice *)q;
+    *s = g_gg;
+    s->i0 = i0; s->i1 = i1; s->t = t;
+}
+static onode *gg_make(int which, const double *p) {
+    if (which == 0) {
+        onode *fl[16];
+        for (int i = 0; i < 16; i++) fl[i] = o_onepole(0, 1, (float)p[2]);
+        return o_reverb3(p[0], p[1], fl);
+    }
+    onode *lines[16];
+    const float w[3] = {(float)p[16], (float)p[17], (float)p[18]};
+    for (int i = 0; i < 16; i++) lines[i] = o_pipe(o_delay(p[i]), o_fir(3, w));
+    return o_pipe(o_pipe(o_split(1, 16), o_feedback(o_multi(O_MULTI_STACK, 16, lines, 0), NULL, 1)), o_join(1, 16));
+}
+static void *run_gg_slice(void *arg) {
+    ggslice *s = (ggslice *)arg;
+    o_bank_pin_self(s->t);
+    const size_t T = s->frames;
+    float in[2 * 64], blk[2 * 64];
+    for (size_t k = s->i0; k < s->i1; k++) {
+        onode *g = gg_make(s->which, s->p);
+        o_set_sample_rate(g, s->sr);
+        for (size_t i = 0; i < T; i += 64) {
+            const int n = (int)(T - i < 64 ? T - i : 64);
+            for (int c = 0; c < s->nin; c++) memcpy(in + 64 * c, s->x + (size_t)c * T + i, (size_t)n * sizeof(float));
+            o_process(g, n, in, blk);
+            if (s->out)
+                for (int c = 0; c < s->nout; c++) memcpy(&s->out[(k * (size_t)s->nout + (size_t)c) * T + i], blk + 64 * c, (size_t)n * sizeof(float));
+        }
+        o_free(g);
+    }
+    return NULL;
+}
+double o_graph_bank_render(int threads, int which, const double *p, double sample_rate, size_t instances, size_t frames, const float *x, float *out) {
+    int nt = threads > 0 ? threads : 1;
+    ggslice *sl = (ggslice *)calloc((size_t)nt, sizeof(ggslice));
+    memset(&g_gg, 0, sizeof g_gg);
+    g_gg.which = which; g_gg.p = p; g_gg.sr = sample_rate; g_gg.frames = frames; g_gg.x = x; g_gg.out = out;
+    g_gg.nin = which == 0 ? 2 : 1; g_gg.nout = which == 0 ? 2 : 1;
+    const double s = run_threads(nt, instances, run_gg_slice, sl, sizeof(ggslice), gg_fill);
+    free(sl);
+    return s;
+}
+
 /* ---- BASELINE config 2 the way the reference runs it: BiquadBank<f32x8> (biquad_bank.rs:14-130) -- EIGHT voices per SIMD instruction ----
  * `(noise() | .. | noise()) >> biquad_bank()`: 8 Noise generators (Noise::process noise.rs:204-218: 8 frames per item, time-vectorised
  * integer hash) feed one bank whose tick (biquad_bank.rs:73-84) is the DF1 expression on f32x8 -- lane k of bank j is voice 8 j + k of

@@ -174,3 +174,23 @@ def test_reverb3_svf_bad_arguments(gpu):
         gpu.Bank.reverb3_stereo(2, 2.0, 0.5, 1000.0, svf=11)
     with pytest.raises(gpu.FdspError, match="svf_mode"):
         gpu.Bank.reverb3_stereo(2, 2.0, 0.5, 1000.0, svf="lowpass", q=0.0)
+
+
+def test_reverb3_at_bench_size(gpu):
+    """The bench line's shape (bench.py "rv3": 2 048 instances x 48 000 frames, planar, built with Bank.from_graph): spot instances against the oracle over
+    the whole second; the same second in two ragged launches equals the one launch."""
+    import torch
+
+    V, T = 2048, 48000
+    b = gpu.Bank.from_graph(GR.reverb3_stereo(2.0, 0.5, lambda: GR.lowpole_hz(8000.0)), V, sample_rate=SR)
+    c = b.clone()
+    assert b.kind == "reverb3_stereo"
+    g = torch.Generator(device="cuda").manual_seed(123)
+    x = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
+    one = b.process(T, x, layout=LAYOUT_PLANAR, frame_stride=T)
+    cut = 64 * 411 + 29
+    a1 = c.process(cut, x[:, :, :cut].contiguous(), layout=LAYOUT_PLANAR, frame_stride=cut)
+    a2 = c.process(T - cut, x[:, :, cut:].contiguous(), layout=LAYOUT_PLANAR, frame_stride=T - cut)
+    assert torch.equal(torch.cat([a1, a2], dim=2).view(torch.int32), one.view(torch.int32)), "two launches == one"
+    for v in (0, 3, 1023, 1024, V - 1):
+        assert_bit_equal(one[v].cpu().numpy(), oracle_rv3(2.0, 0.5, 8000.0).render_blocks(x[v].cpu().numpy()), f"instance {v} of {V}, {T} frames")

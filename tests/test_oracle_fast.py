@@ -138,3 +138,24 @@ def test_config2_biquad_bank_f32x8_equals_the_scalar_voices(V, frames):
         want, _ = O.bank_render(*args, layout, 1)
         got, _ = O.bank_render(*args, layout, 3, fast=True)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"V={V} frames={frames} layout={layout}"
+
+
+def test_graph_bank_driver_equals_the_node_render():
+    """o_graph_bank_render (the threaded CPU leg of bench.py's reverb3_stereo / fdn16 entries) renders what the same graph renders through the Node
+    interface: every instance, three threads, a ragged length."""
+    import oracle as O
+
+    rng = np.random.default_rng(9)
+    T = 64 * 30 + 7
+    x2 = (rng.random((2, T), dtype=np.float32) * 2 - 1).astype(np.float32)
+    out, secs = O.graph_bank_render("reverb3", (2.0, 0.5, 8000.0), 5, x2, threads=3)
+    n = O.reverb3_stereo(2.0, 0.5, lambda: O.lowpole_hz(8000.0))
+    n.set_sample_rate(48000.0)
+    want = n.render_blocks(x2)
+    assert secs > 0 and all(np.array_equal(out[i].view(np.uint32), want.view(np.uint32)) for i in range(5))
+    d = [float(np.float32(0.01 + 0.00125 * i)) for i in range(16)]
+    out, _ = O.graph_bank_render("fdn16", d + [0.2, 0.4, 0.2], 4, x2[:1], threads=2)
+    n = O.split(16) >> O.fdn(O.stacki(16, lambda i: O.delay(np.float32(d[i])) >> O.fir(0.2, 0.4, 0.2))) >> O.join(16)
+    n.set_sample_rate(48000.0)
+    want = n.render_blocks(x2[:1])
+    assert all(np.array_equal(out[i].view(np.uint32), want.view(np.uint32)) for i in range(4))
