@@ -875,7 +875,7 @@ def main(argv=None):
     print(json.dumps(res), flush=True)
 
 
-HEADLINE_KERNEL_SOURCES = ("fd_math.hpp", "fd_nodes.hpp", "fd_device.hpp", "fd_engine.hpp", "fd_opts.hpp", "fd_kinds_fm.hpp", "fd_kinds_fm.hip", "Makefile")
+HEADLINE_KERNEL_SOURCES = ("fd_math.hpp", "fd_nodes.hpp", "fd_device.hpp", "fd_engine.hpp", "fd_opts.hpp", "fd_kinds_fm.hpp", "fd_kinds_fm.hip")
 
 
 def headline_kernel_source_hash():
@@ -887,6 +887,17 @@ def headline_kernel_source_hash():
     for name in HEADLINE_KERNEL_SOURCES:
         h.update(name.encode() + b"\0")
         h.update(open(os.path.join(ROOT, "fundsp_amd", "csrc", name), "rb").read())
+    # ... and from the COMMAND that compiles it (compiler, flags, per-TU scheduling strategy), as `make -n` spells it -- not the Makefile's bytes:
+    # adding an unrelated translation unit to the library does not make the headline kernel another kernel (round 6)
+    csrc = os.path.join(ROOT, "fundsp_amd", "csrc")
+    try:
+        cmd = subprocess.run(["make", "-C", csrc, "-n", "-B", "fd_kinds_fm.o"], capture_output=True, text=True, timeout=60).stdout
+        cmd = "\n".join(line.strip() for line in cmd.splitlines() if "fd_kinds_fm" in line and not line.startswith("make"))
+    except Exception:
+        cmd = ""
+    if not cmd:   # no make on this box: the Makefile's bytes (a stricter stamp)
+        cmd = open(os.path.join(csrc, "Makefile")).read()
+    h.update(b"build\0" + cmd.encode())
     return h.hexdigest()
 
 
