@@ -154,7 +154,7 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
     own node functions without the tree; bit-equal to it, tests/test_oracle_fast.py) -- with the generic tree walk beside it
     (`tree_walk_value`).  Config 2: the reference's own SIMD form, BiquadBank<f32x8> -- EIGHT voices per vector instruction (o_fast.c
     o_biquad_bank8_render; bit-equal to the scalar voices) -- with one scalar Biquad per voice beside it (`scalar_voice_value`).
-    "rv3" / "fdn16" (round 6: reverb3_stereo and the prelude's fdn example): the generic tree walk only (o_fast.c o_graph_bank_render), `kind` says so."""
+    "rv3" / "fdn16" (round 6: reverb3_stereo and the prelude's fdn example): their monomorphised block forms and the tree walk (o_fast.c o_graph_bank_render)."""
     import numpy as np
 
     from fundsp_amd import workloads as W
@@ -181,8 +181,8 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
             what = ("config-4 voices, gate = " + ("an audio-rate input stream" if config == 4 else "var(gate) >> adsr_live, the variable set between the two halves of the note"))
             legs = (("value", True), ("tree_walk_value", False))
         elif config in ("rv3", "fdn16"):
-            # round 6's lane-per-frame kinds: the generic tree walk of the graph, one graph object per instance (oracle/o_fast.c o_graph_bank_render);
-            # no monomorphised form of these was written, the one leg says so in `kind`
+            # round 6's lane-per-frame kinds (oracle/o_fast.c o_graph_bank_render): the monomorphised block forms (fundsp_oracle.c o_reverb3_block /
+            # o_fdn16_block: the tree walk's ticks written out on plain state, bit-equal to it -- tests/test_oracle_fast.py) and the generic tree walk
             rng = np.random.default_rng(5)
             nch = 2 if config == "rv3" else 1
             x = (rng.random((nch, frames), dtype=np.float32) * 2 - 1).astype(np.float32)
@@ -194,8 +194,8 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
                 which, what = "fdn16", "instances of the prelude's fdn example (16 lines) on one mono noise input"
 
             def timed(n, fast):
-                return O.graph_bank_render(which, params, n, x, sample_rate, threads=cores, store=False, lib=L)[1]
-            unit, legs = "M instance-frames/s", (("value", False),)
+                return O.graph_bank_render(which, params, n, x, sample_rate, threads=cores, store=False, lib=L, fast=fast)[1]
+            unit, legs = "M instance-frames/s", (("value", True), ("tree_walk_value", False))
         else:
             rng = np.random.default_rng(5)
             x = (rng.random((2, frames), dtype=np.float32) * 2 - 1).astype(np.float32)
@@ -204,7 +204,7 @@ def cpu_baseline_config(config, sample_rate, frames, target_seconds=3.0):
                 return O.reverb_bank_render(n, x, sample_rate, 10.0, 2.0, 0.5, threads=cores, fast=fast, store=False, lib=L)[1]
             unit, what, legs = "M instance-frames/s", "reverb_stereo(10, 2, 0.5) instances on one stereo noise input", (("value", True), ("tree_walk_value", False))
         out = {"unit": unit, "cores": cores, "threads_pinned": True,
-               "kind": "port (tree walk)" if config in ("rv3", "fdn16") else "port (monomorphised)", "flags": f"gcc {NATIVE_FLAGS}"}
+               "kind": "port (monomorphised)", "flags": f"gcc {NATIVE_FLAGS}"}
         notes = []
         for key, fast in legs:
             n = cores

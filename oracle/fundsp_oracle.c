@@ -2961,3 +2961,109 @@ void o_reverb_stereo_block(onode *n, int size, const float *in, float *out) {
 #endif
 }
 int o_is_reverb_stereo(const onode *n) { return n && n->type == O_REVERB_STEREO; }
+
+/* reverb3_stereo(time, diffusion, lowpole_hz(cutoff)) (reverb.rs:241-272), one BLOCK per call, MONOMORPHISED: the O_REVERB3 tick above with its 76
+ * AllNest / Delay / Lowpole ticks written out on the nodes' own state (static dispatch, everything inlined) -- what rustc makes of Reverb<Lowpole>.
+ * Bit-equal to the tree walk (tests/test_oracle_fast.py).  Only for loop filters that are fixed-cutoff lowpoles; in / out = [2][64]. */
+static inline float rv3_allnest(onode *a, float x) { /* AllNest<U1, Delay>::tick delay.rs:344-352 + Delay::tick :116-124 */
+    onode *d = a->x;
+    const float v = x - a->s.eta * a->s.zz;
+    const float y = a->s.eta * v + a->s.zz;
+    d->s.dbuf[d->s.di] = v;
+    d->s.di += 1;
+    if (d->s.di >= d->s.dlen) d->s.di = 0;
+    a->s.zz = d->s.dbuf[d->s.di];
+    return y;
+}
+static inline float rv3_delay(onode *d, float x) {
+    d->s.dbuf[d->s.di] = x;
+    d->s.di += 1;
+    if (d->s.di >= d->s.dlen) d->s.di = 0;
+    return d->s.dbuf[d->s.di];
+}
+static inline float rv3_lowpole(onode *f, float x) { /* filter.rs:64-66 */
+    const float c = f->s.op_coeff;
+    f->s.op_y1 = (1.0f - c) * x + c * f->s.op_y1;
+    return f->s.op_y1;
+}
+int o_reverb3_block_ok(const onode *n) {
+    if (!n || n->type != O_REVERB3) return 0;
+    for (int b = 0; b < 8; b++)
+        for (int j = 8; j < 10; j++) {
+            const onode *f = n->kids[b * 11 + j];
+            if (f->type != O_ONEPOLE || f->s.op_kind != O_OP_LOWPOLE || f->nin != 1) return 0;
+        }
+    return 1;
+}
+void o_reverb3_block(onode *n, int size, const float *in, float *out) {
+    const float a = n->rv3_a;
+    float v0 = n->rv3_feedback;
+    for (int t = 0; t < size; t++) {
+        float input0 = rv3_allnest(n->pre[0], in[t] * 0.5f);
+        input0 = rv3_allnest(n->pre[1], input0);
+        float input1 = rv3_allnest(n->pre[2], in[MAXB + t] * 0.5f);
+        input1 = rv3_allnest(n->pre[3], input1);
+        float o0 = 0.0f, o1 = 0.0f;
+        for (int b = 0; b < 8; b++) {
+            onode **k = n->kids + b * 11;
+            v0 = rv3_delay(k[10], v0);
+            v0 = rv3_allnest(k[0], a * v0 + input0);
+            v0 = rv3_allnest(k[1], v0);
+            v0 = rv3_allnest(k[2], v0);
+            v0 = rv3_allnest(k[3], v0);
+            v0 = rv3_lowpole(k[8], v0);
+            o0 = v0;
+            v0 = rv3_allnest(k[4], a * v0 + input1);
+            v0 = rv3_allnest(k[5], v0);
+            v0 = rv3_allnest(k[6], v0);
+            v0 = rv3_allnest(k[7], v0);
+            v0 = rv3_lowpole(k[9], v0);
+            o1 = v0;
+        }
+        out[t] = o0;
+        out[MAXB + t] = o1;
+    }
+    n->rv3_feedback = v0;
+}
+
+/* The prelude's fdn example (prelude.rs:1334): split::<U16>() >> fdn::<U16, _>(stacki(|i| delay(t_i) >> fir((w0, w1, w2)))) >> join::<U16>(), one BLOCK
+ * per call, MONOMORPHISED on plain arrays: Split, Feedback::tick (feedback.rs:130-134) with FrameHadamard (:35-57), Delay, Fir<U3> (fir.rs:57-70),
+ * Join::process (audionode.rs:649-659: every term scaled by 1/16, then added) -- under the MXCSR switch of Feedback::new.  `st` = the caller's state:
+ * [16] ring pointers / lengths / positions, v[16][3], value[16].  in / out = [64]. */
+void o_fdn16_block(float **ring, const size_t *len, size_t *pos, float (*v)[3], float *value, const float *w, int size, const float *in, float *out) {
+#if defined(__x86_64__) || defined(__i386__)
+    const unsigned int csr = _mm_getcsr();
+    _mm_setcsr(0x9fc0);
+#endif
+    const float scale = (float)(1.0 / sqrt(16.0)), z = 1.0f / 16.0f;
+    for (int t = 0; t < size; t++) {
+        float o[16], h[16];
+        for (int i = 0; i < 16; i++) {
+            const float x = in[t] + value[i];
+            ring[i][pos[i]] = x;
+            pos[i] += 1;
+            if (pos[i] >= len[i]) pos[i] = 0;
+            v[i][0] = v[i][1]; v[i][1] = v[i][2]; v[i][2] = ring[i][pos[i]];
+            float acc = 0.0f;
+            acc += w[0] * v[i][0];
+            acc += w[1] * v[i][1];
+            acc += w[2] * v[i][2];
+            o[i] = acc;
+            h[i] = acc;
+        }
+        for (int hh = 1; hh < 16; hh *= 2)
+            for (int i = 0; i < 16; i += hh * 2)
+                for (int j = i; j < i + hh; j++) {
+                    const float x = h[j], y = h[j + hh];
+                    h[j] = x + y;
+                    h[j + hh] = x - y;
+                }
+        for (int i = 0; i < 16; i++) value[i] = h[i] * scale;
+        float y = o[0] * z;
+        for (int i = 1; i < 16; i++) y += o[i] * z;
+        out[t] = y;
+    }
+#if defined(__x86_64__) || defined(__i386__)
+    _mm_setcsr(csr);
+#endif
+}

@@ -223,6 +223,10 @@ typedef struct {
 int o_c4_open(onode *g, o_c4_voice *v);                                       /* 0, or -1 if the tree has another shape */
 void o_c4_block(o_c4_voice *v, int size, const float *gate, float *out);     /* gate [64] or NULL (Var shape); out [2][64] */
 void o_reverb_stereo_block(onode *n, int size, const float *in, float *out); /* in, out [2][64] */
+/* round 6: the monomorphised block forms of reverb3_stereo(.., lowpole_hz(..)) and of the prelude's fdn example (CPU legs; bit-equal to the tree walk) */
+int o_reverb3_block_ok(const onode *n);
+void o_reverb3_block(onode *n, int size, const float *in, float *out); /* in, out [2][64] */
+void o_fdn16_block(float **ring, const size_t *len, size_t *pos, float (*v)[3], float *value, const float *w, int size, const float *in, float *out);
 int o_is_reverb_stereo(const onode *n);
 /* Threaded drivers of the cpu_baseline legs of configs 4 / 5 (o_fast.c): voices [v0, v1) of a thread's slice rendered one after the other,
  * many per thread, `frames` frames each in 64-sample blocks; returns seconds.  Config 4: p0..p3 = f, fc, q, pan; adsr = a, d, s, r;
@@ -246,9 +250,9 @@ double o_biquad_bank8_render(const o_bank_job *job, float *out);
 /* Config 5: `instances` x reverb_stereo(room, time, damping) on the SAME stereo input x [2][frames]; out (or NULL) = [instance][2][frames] */
 double o_reverb_bank_render(int threads, int fast, double sample_rate, size_t instances, size_t frames, double room, double time, double damping,
                             const float *x, float *out);
-/* round 6: tree-walk CPU legs of reverb3_stereo (which = 0: p = time, diffusion, lowpole cutoff) and of the prelude's fdn example (which = 1: p = 16
+/* round 6: CPU legs (fast = 1: the monomorphised block forms, 0: the generic tree walk) of reverb3_stereo (which = 0: p = time, diffusion, lowpole cutoff) and of the prelude's fdn example (which = 1: p = 16
  * delays + 3 FIR weights); x [inputs][frames] shared by the instances, out [instances][outputs][frames] or NULL; returns seconds */
-double o_graph_bank_render(int threads, int which, const double *p, double sample_rate, size_t instances, size_t frames, const float *x, float *out);
+double o_graph_bank_render(int threads, int which, int fast, const double *p, double sample_rate, size_t instances, size_t frames, const float *x, float *out);
 const char *o_fast_simd_flavour(void);
 
 #ifdef __cplusplus

@@ -355,12 +355,12 @@ double o_reverb_bank_render(int threads, int fast, double sample_rate, size_t in
     return s;
 }
 
-/* ---- CPU legs of round 6's lane-per-frame kinds (bench.py secondary entries): the generic tree walk of the graph, one graph object per instance, the
- * instances split over pinned threads.  which = 0: reverb3_stereo(p[0], p[1], lowpole_hz(p[2])) (reverb.rs:152-279), 2 in / 2 out;
+/* ---- CPU legs of round 6's lane-per-frame kinds (bench.py secondary entries): fast = 1 the monomorphised block forms (fundsp_oracle.c o_reverb3_block /
+ * o_fdn16_block), fast = 0 the generic tree walk of the graph; one graph object per instance, the instances split over pinned threads.  which = 0: reverb3_stereo(p[0], p[1], lowpole_hz(p[2])) (reverb.rs:152-279), 2 in / 2 out;
  * which = 1: the prelude's fdn example (prelude.rs:1334) split >> fdn::<U16>(stacki(|i| delay(p[i]) >> fir((p[16], p[17], p[18])))) >> join, 1 in / 1 out.
  * x = [inputs][frames] shared by all instances; out = [instances][outputs][frames] or NULL. */
 typedef struct {
-    int which, t, nin, nout;
+    int which, fast, t, nin, nout;
     double sr;
     const double *p;
     size_t i0, i1, frames;
@@ -390,12 +390,33 @@ static void *run_gg_slice(void *arg) {
     const size_t T = s->frames;
     float in[2 * 64], blk[2 * 64];
     for (size_t k = s->i0; k < s->i1; k++) {
+        if (s->fast && s->which == 1) {   /* the fdn example on plain arrays (o_fdn16_block) */
+            float *ring[16], v[16][3], value[16];
+            size_t len[16], pos[16];
+            const float w[3] = {(float)s->p[16], (float)s->p[17], (float)s->p[18]};
+            for (int i = 0; i < 16; i++) {
+                len[i] = (size_t)round(s->p[i] * s->sr) + 1;   /* Delay::set_sample_rate delay.rs:105-112 */
+                ring[i] = (float *)calloc(len[i], sizeof(float));
+                pos[i] = 0;
+                v[i][0] = v[i][1] = v[i][2] = 0.0f;
+                value[i] = 0.0f;
+            }
+            for (size_t i = 0; i < T; i += 64) {
+                const int n = (int)(T - i < 64 ? T - i : 64);
+                o_fdn16_block(ring, len, pos, v, value, w, n, s->x + i, blk);
+                if (s->out) memcpy(&s->out[k * T + i], blk, (size_t)n * sizeof(float));
+            }
+            for (int i = 0; i < 16; i++) free(ring[i]);
+            continue;
+        }
         onode *g = gg_make(s->which, s->p);
         o_set_sample_rate(g, s->sr);
+        const int block3 = s->fast && s->which == 0 && o_reverb3_block_ok(g);
         for (size_t i = 0; i < T; i += 64) {
             const int n = (int)(T - i < 64 ? T - i : 64);
             for (int c = 0; c < s->nin; c++) memcpy(in + 64 * c, s->x + (size_t)c * T + i, (size_t)n * sizeof(float));
-            o_process(g, n, in, blk);
+            if (block3) o_reverb3_block(g, n, in, blk);
+            else o_process(g, n, in, blk);
             if (s->out)
                 for (int c = 0; c < s->nout; c++) memcpy(&s->out[(k * (size_t)s->nout + (size_t)c) * T + i], blk + 64 * c, (size_t)n * sizeof(float));
         }
@@ -403,11 +424,11 @@ static void *run_gg_slice(void *arg) {
     }
     return NULL;
 }
-double o_graph_bank_render(int threads, int which, const double *p, double sample_rate, size_t instances, size_t frames, const float *x, float *out) {
+double o_graph_bank_render(int threads, int which, int fast, const double *p, double sample_rate, size_t instances, size_t frames, const float *x, float *out) {
     int nt = threads > 0 ? threads : 1;
     ggslice *sl = (ggslice *)calloc((size_t)nt, sizeof(ggslice));
     memset(&g_gg, 0, sizeof g_gg);
-    g_gg.which = which; g_gg.p = p; g_gg.sr = sample_rate; g_gg.frames = frames; g_gg.x = x; g_gg.out = out;
+    g_gg.which = which; g_gg.fast = fast; g_gg.p = p; g_gg.sr = sample_rate; g_gg.frames = frames; g_gg.x = x; g_gg.out = out;
     g_gg.nin = which == 0 ? 2 : 1; g_gg.nout = which == 0 ? 2 : 1;
     const double s = run_threads(nt, instances, run_gg_slice, sl, sizeof(ggslice), gg_fill);
     free(sl);

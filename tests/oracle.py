@@ -792,8 +792,8 @@ def reverb_bank_render(instances, x, sample_rate=48000.0, room=10.0, time=2.0, d
     return out, secs
 
 
-def graph_bank_render(which, params, instances, x, sample_rate=48000.0, threads=1, store=True, lib=None):
-    """Tree-walk CPU leg of round 6's lane-per-frame kinds (o_fast.c o_graph_bank_render): which = "reverb3" (params = time, diffusion, lowpole cutoff;
+def graph_bank_render(which, params, instances, x, sample_rate=48000.0, threads=1, store=True, lib=None, fast=False):
+    """CPU leg (fast: the monomorphised block form, else the tree walk) of round 6's lane-per-frame kinds (o_fast.c o_graph_bank_render): which = "reverb3" (params = time, diffusion, lowpole cutoff;
     x [2][frames]) or "fdn16" (params = 16 delays + 3 FIR weights; x [1][frames]) -> (out [instances][outputs][frames] or None, seconds)"""
     k = {"reverb3": 0, "fdn16": 1}[which]
     nch = 2 if k == 0 else 1
@@ -804,8 +804,8 @@ def graph_bank_render(which, params, instances, x, sample_rate=48000.0, threads=
     out = np.zeros((instances, nch, frames), dtype=np.float32) if store else None
     L = lib or globals()["lib"]()
     L.o_graph_bank_render.restype = C.c_double
-    L.o_graph_bank_render.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_double, C.c_size_t, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-    secs = L.o_graph_bank_render(threads, k, p, sample_rate, instances, frames, _fptr(x), _fptr(out))
+    L.o_graph_bank_render.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_double, C.c_size_t, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    secs = L.o_graph_bank_render(threads, k, int(fast), p, sample_rate, instances, frames, _fptr(x), _fptr(out))
     return out, secs
 
 

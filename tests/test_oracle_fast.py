@@ -149,12 +149,16 @@ def test_graph_bank_driver_equals_the_node_render():
     T = 64 * 30 + 7
     x2 = (rng.random((2, T), dtype=np.float32) * 2 - 1).astype(np.float32)
     out, secs = O.graph_bank_render("reverb3", (2.0, 0.5, 8000.0), 5, x2, threads=3)
+    fast, _ = O.graph_bank_render("reverb3", (2.0, 0.5, 8000.0), 5, x2, threads=2, fast=True)      # the monomorphised block form
+    assert np.array_equal(fast.view(np.uint32), out.view(np.uint32))
     n = O.reverb3_stereo(2.0, 0.5, lambda: O.lowpole_hz(8000.0))
     n.set_sample_rate(48000.0)
     want = n.render_blocks(x2)
     assert secs > 0 and all(np.array_equal(out[i].view(np.uint32), want.view(np.uint32)) for i in range(5))
     d = [float(np.float32(0.01 + 0.00125 * i)) for i in range(16)]
     out, _ = O.graph_bank_render("fdn16", d + [0.2, 0.4, 0.2], 4, x2[:1], threads=2)
+    fast, _ = O.graph_bank_render("fdn16", d + [0.2, 0.4, 0.2], 4, x2[:1], threads=3, fast=True)
+    assert np.array_equal(fast.view(np.uint32), out.view(np.uint32))
     n = O.split(16) >> O.fdn(O.stacki(16, lambda i: O.delay(np.float32(d[i])) >> O.fir(0.2, 0.4, 0.2))) >> O.join(16)
     n.set_sample_rate(48000.0)
     want = n.render_blocks(x2[:1])
