@@ -1074,19 +1074,33 @@ def run_rank(args, torch, F, peers, device):
             step()
         fence()
         kernel_ms = []
+        # Plain voice-out steps (the headline): the K launches are enqueued back to back on ONE stream, each between a pair of HIP events
+        # recorded on that stream, and nothing waits inside the timed region -- the durations are read after the closing fence.  (Rounds 1-5
+        # read the library's own event pair after every step, which made the host wait for each launch: 20-30 us of idle GPU per step on a
+        # quiet host, 0.9 ms per step on a box whose host was busy -- profiles/r06_bench_default_f.json.)  Steps with a mix-down keep the
+        # per-step read: their kernel figure is the render launch alone, which only the library's pair brackets.
+        pairs = None
+        if plan is None and not args.mix:
+            pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         t0 = time.perf_counter()
         for i in range(steps):
+            if pairs is not None:
+                pairs[i][0].record()
             step()
+            if pairs is not None:
+                pairs[i][1].record()
             if meter is not None and i == steps // 2:
-                meter.sample_clock()   # while this step's kernel runs (the launch is asynchronous, the read below waits for it)
-            # HIP events recorded by the C ABI on the launch stream around the render kernel (reading here synchronises
+                meter.sample_clock()   # (a library call, no device wait)
+            # mix-down steps: HIP events recorded by the C ABI on the launch stream around the render kernel (reading here synchronises
             # on that launch, which the next step's launch on the same stream is ordered behind anyway)
-            if plan is None:
+            if plan is None and pairs is None:
                 kernel_ms.append(bank.last_kernel_ms())
         if args.mix:
             peers.comm.wait(peers.slot)   # the last all-reduce belongs to the timed region
         fence()
         elapsed = peers.max(time.perf_counter() - t0, torch)
+        if pairs is not None:
+            kernel_ms = [a.elapsed_time(b) for a, b in pairs]
         if plan is not None:   # the kernels' own HIP-event times: three more steps of the same work, waiting for every launch
             plan_kernel_ms[0] = True
             for _ in range(3):
@@ -1098,7 +1112,11 @@ def run_rank(args, torch, F, peers, device):
         wl["power"] = meter.stop(window_steps + warmup + steps) if meter is not None else None
         return elapsed, kernel_ms, wl, V
 
-    elapsed, kernel_ms, wl, V = timed_run(args.scaling, args.steps, args.warmup)
+    # everything of the timed run goes to ONE non-default stream: Bank.process launches on torch's current stream when that is not the
+    # default one (the default stream's handle is 0 = "the bank's own stream"), and the event pairs around the launches must sit on it too
+    run_stream = torch.cuda.Stream()
+    with torch.cuda.stream(run_stream):
+        elapsed, kernel_ms, wl, V = timed_run(args.scaling, args.steps, args.warmup)
     total_voices = base_voices if args.scaling == "strong" else base_voices * world
     scaling_alt = None
     if distributed and args.config == 3:   # the other scaling law, outside the timed region, a few steps
