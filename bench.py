@@ -706,6 +706,136 @@ def secondary(F, W, torch, sr, mode):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's own benches (benches/benchmark.rs, criterion) as banks
+# ---------------------------------------------------------------------------------------------------------------------
+CRITERION_VOICES = {"sine": 65536, "pass": 65536, "wavetable": 65536, "envelope": 65536, "oversample": 65536, "equalizer": 65536,
+                    "reverb": 4096, "limiter": 65536, "phaser": 65536}
+
+
+def _oracle_on_native_build():
+    """tests/oracle.py's graph notation on the -O3 -march=native build of the oracle made on this host (oracle/Makefile `native`)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"])
+    native = os.path.join(ROOT, "oracle", "_native", "libfundsp_oracle_native.so")
+    if getattr(O, "_native_path", None) != native:
+        O._lib = None
+        O.build = lambda: native
+        O._native_path = native
+    return O
+
+
+def criterion_benches(F, torch, names=None, cpu_seconds=1.0, steps=3):
+    """The reference's OWN benchmark harness (benches/benchmark.rs: criterion, each bench = Wave::render of 1 s of ONE graph at 44.1 kHz on one
+    thread; no figures are published) with the graphs as BANKS of instances: ms per rendered second of V instances, the
+    instance-seconds of audio per wall second that is (`x_real_time`), next to the oracle's C restatement of the same graph on this host --
+    ONE instance on one thread (= what criterion times: `cpu_ms_per_instance_second`) and one instance per core on all cores.  Nine of the
+    thirteen benches are graphs of nodes on the path (tests/criterion_graphs.py, each instance bit-equal to the oracle:
+    tests/test_gpu_criterion.py); `reverb` also as the chain of two banks (fundsp_amd.Chain: generator kernel + lane-per-frame network kernel)."""
+    import threading
+
+    import numpy as np
+
+    from fundsp_amd import graph as GR
+
+    O = _oracle_on_native_build()
+    import criterion_graphs as CG
+
+    cores = host_cpu_budget()["effective_cpus"]
+    T, sr = CG.FRAMES, CG.SAMPLE_RATE
+    res = {"what": "benches/benchmark.rs (criterion: 1 s of one graph at 44.1 kHz per iteration) as banks of V instances with per-instance seeds; "
+                   "x_real_time = instance-seconds of audio per wall second; cpu = the oracle's tree walk (gcc " + NATIVE_FLAGS + "), one instance per thread",
+           "sample_rate": sr, "frames": T, "cpu_cores": cores, "not_on_the_path": CG.NOT_ON_THE_PATH, "benches": {}}
+
+    def gpu_time(run):
+        for _ in range(1):
+            run()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            run()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return min(ts)
+
+    def cpu_leg(name):
+        def make():
+            n = CG.table(O, O)[name][0]
+            n.set_sample_rate(sr)
+            return n
+        n = make()
+        n.render_blocks(None, length=T, block=64)     # (tables, page faults)
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < cpu_seconds or k < 2:
+            n.render_blocks(None, length=T, block=64)
+            k += 1
+        one = (time.perf_counter() - t0) / k * 1e3
+        nodes, counts = [make() for _ in range(cores)], [0] * cores
+        stop = time.perf_counter() + cpu_seconds
+
+        def work(j):
+            while time.perf_counter() < stop or counts[j] < 1:
+                nodes[j].render_blocks(None, length=T, block=64)   # (ctypes releases the GIL inside the C call)
+                counts[j] += 1
+        th = [threading.Thread(target=work, args=(j,)) for j in range(cores)]
+        t0 = time.perf_counter()
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return one, sum(counts) / (time.perf_counter() - t0)
+
+    for name in (names or list(CG.table(O, O))):
+        V = CRITERION_VOICES[name]
+        e = {"benchmark_rs_line": CG.table(O, O)[name][2], "instances": V}
+        try:
+            g, ring, _ = CG.table(GR, O)[name]
+            for kind in GR.uses_wavetables(g):
+                F.wavetable_build(kind)
+            t0 = time.perf_counter()
+            seeds = np.arange(V, dtype=np.uint64) * 7919 + 13
+            if name == "reverb":   # as one lane-per-voice graph (fewer instances: it is two orders slower) and as the chain
+                Vg = 256
+                b = F.Bank.from_graph(g, Vg, ring_frames=ring, sample_rate=sr)
+                b.set_seed(seeds[:Vg])
+                out = torch.empty((g.nout, T, Vg), dtype=torch.float32, device="cuda")
+                ms1 = gpu_time(lambda: b.process(T, None, out, layout=F.LAYOUT_VOICE_MINOR))
+                e["as_one_graph"] = {"instances": Vg, "ms_per_rendered_second": round(ms1, 3), "x_real_time": round(Vg / (ms1 * 1e-3), 1), "last_kernel": b.get_option("last_kernel")}
+                del b, out
+                ch = F.Chain(F.Bank.from_graph(GR.noise() | GR.noise(), V, sample_rate=sr), F.Bank.from_graph(GR.reverb_stereo(10.0, 1.0, 0.5), V, sample_rate=sr))
+                ch.set_seed(seeds)
+                e["compile_and_create_s"] = round(time.perf_counter() - t0, 2)
+                out = torch.empty((V, 2, ch.frame_stride(T)), dtype=torch.float32, device="cuda")
+                ms = gpu_time(lambda: ch.process(T, None, out))
+                e["form"] = "fundsp_amd.Chain(noise | noise bank, reverb_stereo bank: fd::k_fdn_render_frames, lane = frame)"
+                del ch, out
+            else:
+                b = F.Bank.from_graph(g, V, ring_frames=ring, sample_rate=sr)
+                b.set_seed(seeds)
+                e["compile_and_create_s"] = round(time.perf_counter() - t0, 2)
+                out = torch.empty((g.nout, T, V), dtype=torch.float32, device="cuda")
+                ms = gpu_time(lambda: b.process(T, None, out, layout=F.LAYOUT_VOICE_MINOR))
+                e["last_kernel"] = b.get_option("last_kernel")
+                del b, out
+            e["ms_per_rendered_second"] = round(ms, 3)
+            e["x_real_time"] = round(V / (ms * 1e-3), 1)
+            e["value"] = round(V * T / ms / 1e3, 1)
+            e["unit"] = "Msamples/s"
+        except Exception as ex:
+            e["error"] = repr(ex)[:300]
+        try:
+            one, rate = cpu_leg(name)
+            e["cpu_ms_per_instance_second"] = round(one, 3)
+            e["cpu_x_real_time_all_cores"] = round(rate, 1)
+            if "x_real_time" in e:
+                e["gpu_over_cpu_all_cores"] = round(e["x_real_time"] / rate, 1)
+        except Exception as ex:
+            e["cpu_error"] = repr(ex)[:300]
+        res["benches"][name] = e
+    return res
+
+
 class quiet_stdout:
     """RCCL prints a version banner to the C-level stdout when a communicator is created; the contract of this script is ONE
     JSON line on stdout.  Inside this context fd 1 points at stderr; C stdio is flushed before fd 1 is restored."""
@@ -787,6 +917,7 @@ def parse_args(argv=None):
     ap.add_argument("--reverb", choices=["stereo", "4", "3"], default="stereo",
                     help="--config 5: stereo = reverb_stereo(10, 2, 0.5), BASELINE config 5 (default); 4 = reverb4_stereo(20, 2), two 16-line networks in series; 3 = reverb3_stereo(2, 0.5, lowpole_hz(8000)), the allpass-loop reverb (624 B per instance-frame)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall-time budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--criterion", action="store_true", help="only the reference's own criterion benches (benches/benchmark.rs) as banks: one JSON line {\"criterion\": ..}")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs 2 / 4 / 5, tolerance mode)")
     return ap.parse_args(argv)
 
@@ -820,6 +951,12 @@ def main(argv=None):
 
     if args.pipe_split != 1:
         assert _lib.lib().fdsp_set_option(b"pipe_split", args.pipe_split) == 0
+    if args.criterion:   # the reference's own harness as banks, nothing else (one GPU)
+        torch.cuda.set_device(0)
+        with quiet_stdout():
+            res = criterion_benches(F, torch, cpu_seconds=max(0.5, min(2.0, args.cpu_seconds / 8.0)))
+        print(json.dumps({"criterion": res}), flush=True)
+        return
     if plan == "threads":   # one process, N GPUs, N host threads: `python bench.py --gpus N` as typed
         import threading
 

@@ -415,6 +415,85 @@ class Bank:
         return ms.value
 
 
+PIPE_ID = 6   # Pipe::ID (audionode.rs:1375-1492; fd_nodes.hpp)
+
+
+def atto(state, data):
+    """AttoHash::hash (math.rs:649-658) on numpy u64 (scalars or arrays)."""
+    s = np.asarray(state, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        r = (s << np.uint64(5)) | (s >> np.uint64(59))
+        return (r ^ np.uint64(data)) * np.uint64(0x517CC1B727220A95)
+
+
+class Chain:
+    """Two banks in series, composed on the host: `source >> effect` where each half has the kernel family that suits it -- e.g. the
+    reference's own `reverb` bench, `(noise() | noise()) >> reverb_stereo(10, 1, 0.5)` (benches/benchmark.rs:79-85): compiled as ONE
+    lane-per-voice graph the 32 delay lines are read one lane per instance (uncoalesced rings); as a chain the generator runs in its fused
+    kernel and the network in its lane-per-frame kernel (fdsp_reverb_stereo_create), two launches on one stream with a planar buffer
+    [instance][channel][frame] in HBM between them, two orders of magnitude faster.
+
+    What it is in the reference's terms: two AudioNodes whose buffers the HOST pipes -- every half keeps the construction hash of a
+    stand-alone node.  `set_seed` gives the halves what AudioNode::set_seed of `Pipe<source, effect>` would give them
+    (Pipe::ping, audionode.rs:1459: the source sees atto(seed, Pipe::ID)); the effect's own ping is skipped, which is exact for the stock
+    reverbs and networks (no node of theirs keeps hashed state)."""
+
+    def __init__(self, source, effect):
+        if source.voices != effect.voices or source.outputs() != effect.inputs():
+            raise ValueError(f"chain mismatch: {source.voices} x {source.outputs()} outputs into {effect.voices} x {effect.inputs()} inputs")
+        self.source, self.effect, self.voices = source, effect, source.voices
+        self._mid = self._stream = None
+
+    def inputs(self):
+        return self.source.inputs()
+
+    def outputs(self):
+        return self.effect.outputs()
+
+    def set_sample_rate(self, sample_rate):
+        self.source.set_sample_rate(sample_rate)
+        self.effect.set_sample_rate(sample_rate)
+
+    def reset(self):
+        self.source.reset()
+        self.effect.reset()
+
+    def set_seed(self, seeds):
+        self.source.set_seed(atto(np.ascontiguousarray(seeds, dtype=np.uint64), PIPE_ID))
+
+    @staticmethod
+    def frame_stride(frames):
+        """row stride of every buffer of a chain launch: `frames` rounded up to whole blocks"""
+        return (int(frames) + 63) // 64 * 64
+
+    def process(self, frames, inp=None, out=None, mode=MODE_PROCESS, stream=None):
+        """Render `frames` samples per instance: planar buffers [instance][channel][frame_stride(frames)] throughout (a launch has ONE layout
+        for its input and output, and the buffer between the halves is the source's output and the effect's input).  Both launches go to
+        ONE stream, nothing waits in between on the host: `stream` if given, else a stream of the chain's own that is ordered behind torch's
+        current stream before the launches and in front of it after them (the C ABI reads a NULL stream -- torch's default stream -- as "the
+        bank's own stream", and two banks' own streams do not order each other)."""
+        import torch
+
+        frames = int(frames)
+        fs = self.frame_stride(frames)
+        if self._mid is None or self._mid.shape[2] != fs:
+            self._mid = torch.empty((self.voices, self.source.outputs(), fs), dtype=torch.float32, device="cuda")
+        if out is None:
+            out = torch.empty((self.voices, self.effect.outputs(), fs), dtype=torch.float32, device="cuda")
+        own = None
+        if stream is None:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            own, cur = self._stream, torch.cuda.current_stream()
+            own.wait_stream(cur)
+            stream = own.cuda_stream
+        self.source.process(frames, inp, self._mid, layout=LAYOUT_PLANAR, frame_stride=fs, mode=mode, stream=stream)
+        self.effect.process(frames, self._mid, out, layout=LAYOUT_PLANAR, frame_stride=fs, mode=mode, stream=stream)
+        if own is not None:
+            cur.wait_stream(own)
+        return out
+
+
 def svf_coefs(mode, sample_rate, cutoff, q, gain=1.0):
     out = np.zeros(6, dtype=np.float32)
     check(lib().fdsp_svf_coefs(SVF_MODES[mode], sample_rate, cutoff, q, gain, _fptr(out)))

@@ -148,15 +148,210 @@ FD_D void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- wide sums of generators: branch-major blocks -------------------------------------------------------------
+// Reduce<N, X, OP> / MultiBus<N, X> over N input-free branches of one type (sumi / busi of oscillators -- additive synthesis; the reference's
+// own `sine` bench is sumi::<U100>(sine_hz(100 (i + 1))), benches/benchmark.rs:4-10).  Frame-major, the way render_body walks every other
+// graph, such a node keeps the state of all N branches in registers: 100 sines are 700 words per lane, the compiler parks them in scratch
+// memory and the loop pays for it per frame (measured: 1.29 s per rendered second, whatever the bank size).  The reference's process()
+// walks it the other way round (audionode.rs:2406-2462, 2123-2134): one 64-frame block of branch 0, then of branch 1 folded into it, ...
+// The branches take no input, so they do not see each other: branch-major and frame-major give every branch the same samples and every
+// output frame the same left fold.  Here: per 64-frame block and branch, load the branch's slots, render the block into registers (packed
+// path, 32 frame pairs, rollback to the scalar path if a guard trips), fold into the accumulator, store the branch's state.  The
+// accumulator lives in registers for whole process blocks and in LDS (one column per lane, [channel][frame][lane]: conflict-free, any frame
+// index) for the ragged last block, the tick executor and the rollback.
+struct VCountWords {
+    int n = 0;
+    FD_D void f(float&, FieldKind, const char*) { n++; }
+    FD_D void fi(float&, FieldKind, const char*, int) { n++; }
+    FD_D void u32(uint32_t&, FieldKind, const char*) { n++; }
+    FD_D void u64(uint64_t&, FieldKind, const char*) { n += 2; }
+    FD_D void enter(int) {}
+    FD_D void leave() {}
+};
+template <class G> struct WideSum { static constexpr bool value = false; };
+template <int N_, class X, class OP_> struct WideSum<Reduce<N_, X, OP_>> {
+    static constexpr bool value = N_ >= 8 && X::IN == 0 && X::OUT >= 1 && X::OUT <= 2;
+    static constexpr int N = N_;
+    static constexpr bool BUS = false;
+    using Branch = X;
+    using OP = OP_;
+};
+template <int N_, class X> struct WideSum<MultiBus<N_, X>> {
+    static constexpr bool value = N_ >= 8 && X::IN == 0 && X::OUT >= 1 && X::OUT <= 2;
+    static constexpr int N = N_;
+    static constexpr bool BUS = true;   // tick folds from a zero frame: (0 + x0) + x1 .. (audionode.rs:2117-2121)
+    using Branch = X;
+    using OP = OpAdd;
+};
+
+template <class G, int MODE, int LAYOUT, int WPB>
+FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T, size_t fstride,
+                           const void* aux, float* ring, uint32_t ring_cap) {
+    using WS = WideSum<G>;
+    using X = typename WS::Branch;
+    using OP = typename WS::OP;
+    constexpr int N = WS::N, NO = X::OUT;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int vpw = (LAYOUT == LAYOUT_VOICE_MINOR && fstride > 0 && fstride < 64) ? (int)fstride : 64;   // partially filled waves of small banks, as render_body
+    const size_t v0 = ((size_t)blockIdx.x * WPB + wib) * vpw;
+    const size_t v = v0 + lane;
+    const bool active = v < V && lane < vpw;
+    if (v0 >= stride) return;
+    // voice-minor: a lane past the end of the bank / of a partially filled wave has nothing to do (every LDS column is private to its lane, no
+    // wave-level hand-over in that layout).  Planar: padding lanes (V <= v < stride) own private zeroed slot / ring columns and take part.
+    if (LAYOUT == LAYOUT_VOICE_MINOR && !active) return;
+    const size_t vc = v;
+    int K;  // slot words of one branch (a constant after inlining)
+    {
+        X probe;
+        VCountWords c;
+        probe.visit(c);
+        K = c.n;
+    }
+    __shared__ float acc_all[WPB * NO * 64 * 64];
+    float* accl = acc_all + (size_t)wib * NO * 64 * 64 + lane;   // this lane's column: accl[(c * 64 + frame) * 64]
+    auto branch_in = [&](X& x, int i) {
+        Ctx ctx{static_cast<const Aux*>(aux), ring + vc, ring_cap, stride, i * X::RINGS};
+        x.bind(ctx);
+        VLoad ld{slots + vc, stride, i * K};
+        x.visit(ld);
+    };
+    auto branch_out = [&](X& x, int i) {
+        if (active) {
+            VStore<false> st{slots + v, stride, i * K};
+            x.visit(st);
+        }
+    };
+    for (size_t t0 = 0; t0 < T; t0 += 64) {
+        const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+        const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
+        if (MODE == MODE_PROCESS && size == 64) {
+            v2f acc[NO][32];
+#pragma unroll 1
+            for (int i = 0; i < N; i++) {
+                X x;
+                branch_in(x, i);
+                x.begin_block(64);
+                const X snap = x;
+                v2f tmp[NO][32];
+#pragma unroll
+                for (int k = 0; k < 32; k++) {
+                    v2f po[NO];
+                    x.template step2<PH_SIMD>(nullptr, po);
+#pragma unroll
+                    for (int c = 0; c < NO; c++) tmp[c][k] = po[c];
+                }
+                if (__builtin_expect(x.tripped(), 0)) {  // a packed-path shortcut left its exact domain: this branch's block again, scalar
+                    x = snap;
+#pragma unroll 1
+                    for (int f = 0; f < 64; f++) {
+                        float fo[NO];
+                        x.template step<PH_SIMD>(nullptr, fo);
+#pragma unroll
+                        for (int c = 0; c < NO; c++) accl[(c * 64 + f) * 64] = fo[c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < NO; c++)
+#pragma unroll
+                        for (int k = 0; k < 32; k++) tmp[c][k] = v2f{accl[(c * 64 + 2 * k) * 64], accl[(c * 64 + 2 * k + 1) * 64]};
+                }
+                x.end_simd();
+#pragma unroll
+                for (int c = 0; c < NO; c++)
+#pragma unroll
+                    for (int k = 0; k < 32; k++) acc[c][k] = i == 0 ? tmp[c][k] : OP::f(acc[c][k], tmp[c][k]);
+                branch_out(x, i);
+            }
+            if (LAYOUT == LAYOUT_VOICE_MINOR) {
+                if (active) {
+                    float* outw = out + v0;
+#pragma unroll
+                    for (int c = 0; c < NO; c++)
+#pragma unroll
+                        for (int k = 0; k < 32; k++) {
+                            outw[((size_t)c * T + t0 + 2 * k) * V + lane] = acc[c][k].x;
+                            outw[((size_t)c * T + t0 + 2 * k + 1) * V + lane] = acc[c][k].y;
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NO; c++)
+#pragma unroll
+                    for (int k = 0; k < 32; k++) {
+                        accl[(c * 64 + 2 * k) * 64] = acc[c][k].x;
+                        accl[(c * 64 + 2 * k + 1) * 64] = acc[c][k].y;
+                    }
+            }
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < N; i++) {
+                X x;
+                branch_in(x, i);
+                x.begin_block(size);
+#pragma unroll 1
+                for (int f = 0; f < size; f++) {
+                    float fo[NO];
+                    if (f < full) {
+                        x.template step<PH_SIMD>(nullptr, fo);
+                    } else {
+                        if (MODE == MODE_PROCESS && f == full) x.end_simd();
+                        x.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(nullptr, fo);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NO; c++) {
+                        float* a = &accl[(c * 64 + f) * 64];
+                        *a = i == 0 ? ((WS::BUS && MODE == MODE_TICK) ? 0.0f + fo[c] : fo[c]) : OP::f(*a, fo[c]);
+                    }
+                }
+                if (MODE == MODE_PROCESS && full == size) x.end_simd();
+                branch_out(x, i);
+            }
+            if (LAYOUT == LAYOUT_VOICE_MINOR && active) {
+                float* outw = out + v0;
+                for (int f = 0; f < size; f++)
+#pragma unroll
+                    for (int c = 0; c < NO; c++) outw[((size_t)c * T + t0 + f) * V + lane] = accl[(c * 64 + f) * 64];
+            }
+        }
+        if (LAYOUT == LAYOUT_PLANAR) {  // LDS [channel][frame][lane = voice] -> global [voice][channel][frame]: a lane writes 4 consecutive frames of one voice
+            wave_sync();
+            const float* accw = acc_all + (size_t)wib * NO * 64 * 64;
+            const int sub = lane >> 4, fr = (lane & 15) << 2;
+            const bool vec = ((fstride & 3) == 0) && ((((uintptr_t)out) & 15) == 0) && (t0 + 64 <= fstride);
+#pragma unroll
+            for (int c = 0; c < NO; c++)
+                for (int r = 0; r < 16; r++) {
+                    const int vr = r * 4 + sub;
+                    const size_t gv = v0 + vr;
+                    if (gv < V) {
+                        float4 q = make_float4(accw[(c * 64 + fr) * 64 + vr], accw[(c * 64 + fr + 1) * 64 + vr], accw[(c * 64 + fr + 2) * 64 + vr],
+                                               accw[(c * 64 + fr + 3) * 64 + vr]);
+                        float* dst = out + (gv * NO + c) * fstride + t0 + fr;
+                        if (vec && fr + 4 <= ((size + 3) & ~3)) {
+                            *reinterpret_cast<float4*>(dst) = q;
+                        } else {
+                            if (fr + 0 < size) dst[0] = q.x;
+                            if (fr + 1 < size) dst[1] = q.y;
+                            if (fr + 2 < size) dst[2] = q.z;
+                            if (fr + 3 < size) dst[3] = q.w;
+                        }
+                    }
+                }
+            wave_sync();
+        }
+    }
+}
+
 // ---- the hot kernel ----------------------------------------------------------------------------------------
 // WPB = waves per workgroup.  Four-wave workgroups are used whenever LDS allows: the dispatcher places the four
 // waves of one workgroup on the four SIMDs of a CU, so a 65 536-voice bank (256 workgroups) lands exactly one wave
 // per SIMD.  Single-wave workgroups do NOT spread evenly (measured with tools/census.hip: 1024 x 64-thread
 // workgroups leave ~10 % of the SIMDs idle and double up as many), which stretches a VALU-bound launch.
 template <class G, int MODE, int LAYOUT, int WPB>
-FD_D void render_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
-                      float* __restrict__ out, size_t T, size_t fstride, const void* aux, float* ring,
-                      uint32_t ring_cap) {
+FD_D void render_body_frames(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
+                             float* __restrict__ out, size_t T, size_t fstride, const void* aux, float* ring,
+                             uint32_t ring_cap) {
     constexpr int NI = G::IN, NO = G::OUT;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave in block (wave-uniform -> SGPR)
@@ -383,6 +578,16 @@ FD_D void render_body(float* __restrict__ slots, size_t stride, size_t V, const 
 
     VStore<false> st{slots + v, stride, 0};
     g.visit(st);
+}
+
+template <class G, int MODE, int LAYOUT, int WPB>
+FD_D void render_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
+                      float* __restrict__ out, size_t T, size_t fstride, const void* aux, float* ring,
+                      uint32_t ring_cap) {
+    if constexpr (WideSum<G>::value)  // a wide sum of generators at the root: branch-major blocks (above)
+        render_body_wide<G, MODE, LAYOUT, WPB>(slots, stride, V, out, T, fstride, aux, ring, ring_cap);
+    else
+        render_body_frames<G, MODE, LAYOUT, WPB>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
 }
 
 template <class G, int MODE, int LAYOUT, int WPB>

@@ -1748,6 +1748,18 @@ onode *o_envelope(float interval, int outputs, o_env_fn fn, void *ctx) { /* Enve
     leaf_reset(n);
     return n;
 }
+/* The two closures of the reference's own criterion benches (benches/benchmark.rs) as C functions, so that a CPU timing of those graphs
+   does not pay a Python callback per envelope sample (tests/criterion_graphs.py passes their addresses to o_envelope). */
+void o_envfn_criterion_envelope(float t, float *out, void *ctx) { /* benchmark.rs:57  |t| (-t).exp() * sin_hz(1.0, t);  sin_hz math.rs:462-464 */
+    (void)ctx;
+    out[0] = o_expf(-t) * o_sinf(t * 1.0f * F32_TAU);
+}
+void o_envfn_criterion_phaser(float t, float *out, void *ctx) { /* benchmark.rs:94  |t| sin_hz(0.1, t) * 0.5 + 0.5, inside phaser's
+                                                                     lfo(move |t| lerp(2.0, 20.0, clamp01(phase_f(t)))) prelude.rs:2747 */
+    (void)ctx;
+    float p = o_sinf(t * 0.1f * F32_TAU) * 0.5f + 0.5f;
+    out[0] = lerpf(2.0f, 20.0f, clamp01f(p));
+}
 static void envin_next_segment(onode *n, const float *input) { /* EnvelopeIn::next_segment envelope.rs:244-278 */
     if (n->s.et0 == 0.0f && n->s.et1 == 0.0f) {
         n->s.envin_fn(n->s.et0, input, n->s.env_v0, n->s.env_ctx);

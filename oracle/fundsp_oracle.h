@@ -77,6 +77,8 @@ onode *o_pinkpass(void);
 /* Envelope<f32, E, R> (envelope.rs:17): `fn` plays the Rust closure E(t) -> R, writing `outputs` (<= 8) values */
 typedef void (*o_env_fn)(float t, float *out, void *ctx);
 onode *o_envelope(float interval, int outputs, o_env_fn fn, void *ctx);
+void o_envfn_criterion_envelope(float t, float *out, void *ctx);   /* the closures of benches/benchmark.rs:57,94 (criterion) */
+void o_envfn_criterion_phaser(float t, float *out, void *ctx);
 /* EnvelopeIn<f32, E, I, R> (envelope.rs:185) with a stateless closure E(t, &inputs) -> R */
 typedef void (*o_envin_fn)(float t, const float *in, float *out, void *ctx);
 onode *o_envelope_in(float interval, int inputs, int outputs, o_envin_fn fn, void *ctx);

@@ -523,6 +523,15 @@ def envelope(fn, outputs=1, interval=0.002):                                  # 
 
 
 lfo = envelope
+
+
+def envelope_c(symbol, outputs=1, interval=0.002):
+    """envelope(..) whose closure is one of the oracle's own C functions (`symbol`, signature o_env_fn): no Python callback per envelope
+    sample -- for CPU timings of graphs with closures (tests/criterion_graphs.py)."""
+    L = lib()
+    return Node(L.o_envelope(np.float32(interval), outputs, C.cast(getattr(L, symbol), C.c_void_p), None))
+
+
 ENVIN_FN = C.CFUNCTYPE(None, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
 
 
@@ -633,7 +642,10 @@ def phaser(feedback_amount, phase_f):                                           
         p = f32(phase_f(t))
         p = f32(min(max(p, f32(0.0)), f32(1.0)))
         return f32(2.0) * (f32(1.0) - p) + f32(20.0) * p
-    return pass_() & feedback((pass_() | lfo(wrapped)) >> pipei(10, lambda _i: add(0.0, 0.1) >> ~allpole())
+    return phaser_lfo(feedback_amount, lfo(wrapped))
+def phaser_lfo(feedback_amount, wrapped_lfo):
+    """phaser(..) around an lfo node that already computes lerp(2.0, 20.0, clamp01(phase_f(t))) (e.g. envelope_c of a C closure)"""
+    return pass_() & feedback((pass_() | wrapped_lfo) >> pipei(10, lambda _i: add(0.0, 0.1) >> ~allpole())
                               >> (mul(feedback_amount) | sink()))
 
 

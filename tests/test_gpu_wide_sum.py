@@ -1,0 +1,64 @@
+"""Wide sums of generators -- Reduce<N, X, OP> / MultiBus<N, X> over N >= 8 input-free branches of one type (sumi / busi of oscillators) --
+are rendered branch-major, one 64-frame block of one branch at a time, like the reference's process() (audionode.rs:2406-2462, 2123-2134;
+fd_device.hpp render_body_wide).  Every instance bit-equal to the oracle's frame-by-frame tree walk: both executors, both layouts, ragged
+launches, partially filled waves, branches with delay rings, two-channel branches, a branch that trips the packed sine's guard, chunked
+launches, and the frame-major form of the same sum (N below the threshold) as the neighbour."""
+import numpy as np
+import pytest
+
+import oracle as O
+from fundsp_amd import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS, MODE_TICK
+from fundsp_amd import graph as GR
+from test_gpu_parity import assert_bit_equal, oracle_render, run_bank
+
+pytestmark = pytest.mark.gpu
+SR = 48000.0
+
+GRAPHS = {
+    # name: (builder, ring_frames)
+    "sumi12_sines": (lambda m: m.sumi(12, lambda i: m.sine_hz(55.0 * (i + 1))), 0),
+    "busi9_sines": (lambda m: m.busi(9, lambda i: m.sine_hz(110.0 * (i + 1)) * 0.1), 0),                 # MultiBus: tick folds from a zero frame
+    "sumi8_noise_delays": (lambda m: m.sumi(8, lambda i: m.noise() >> m.delay(0.0005 * (i + 1))), 256),   # branches with rings
+    "sumi8_panned": (lambda m: m.sumi(8, lambda i: m.sine_hz(100.0 * (i + 1)) >> m.pan(-0.7 + 0.2 * i)), 0),   # two channels per branch
+    "sumi10_one_trips": (lambda m: m.sumi(10, lambda i: m.sine_hz(3.0e6 if i == 4 else 200.0 * (i + 1))), 0),  # branch 4 leaves the packed sine's domain every block
+    "sumi7_sines_frame_major": (lambda m: m.sumi(7, lambda i: m.sine_hz(55.0 * (i + 1))), 0),          # below the threshold: the frame-major walk
+}
+
+
+@pytest.mark.parametrize("name", list(GRAPHS))
+def test_wide_sum_matches_the_oracle(gpu, name):
+    build, ring = GRAPHS[name]
+    g = build(GR)
+    V, T = 130, 64 * 6 + 13
+    seeds = np.arange(V, dtype=np.uint64) * 7919 + 13
+    for mode in (MODE_PROCESS, MODE_TICK):
+        for layout in (LAYOUT_VOICE_MINOR, LAYOUT_PLANAR):
+            b = gpu.Bank.from_graph(g, V, ring_frames=ring, sample_rate=SR)
+            b.set_seed(seeds)
+            got = run_bank(b, None, T, layout, mode)
+            for v in (0, 15, 16, 64, 129):
+                n = build(O)
+                n.set_sample_rate(SR)
+                n.set_seed(int(seeds[v]))
+                assert_bit_equal(got[v], oracle_render(n, None, T, mode), f"{name} instance {v} mode {mode} layout {layout}")
+
+
+def test_wide_sum_chunked_launches_and_reset(gpu):
+    """ragged launches one after the other (each walks its own 64-frame blocks + remainder, like consecutive process() calls), then reset"""
+    build, _ = GRAPHS["sumi12_sines"]
+    V, chunks = 70, (64, 200, 1, 311)
+    b = gpu.Bank.from_graph(build(GR), V, sample_rate=SR)
+    seeds = np.arange(V, dtype=np.uint64) + 99
+
+    def oracle(v):
+        n = build(O)
+        n.set_sample_rate(SR)
+        n.set_seed(int(seeds[v]))
+        return np.concatenate([n.render_blocks(None, length=k, block=64) for k in chunks], axis=1)
+
+    for _round in range(2):
+        b.reset()
+        b.set_seed(seeds)
+        got = np.concatenate([run_bank(b, None, k, LAYOUT_VOICE_MINOR, MODE_PROCESS) for k in chunks], axis=2)
+        for v in (3, 69):
+            assert_bit_equal(got[v], oracle(v), f"chunked launches, instance {v}")
