@@ -703,6 +703,12 @@ def secondary(F, W, torch, sr, mode):
         del wl, mixbuf
     except Exception as e:
         out.append({"name": "config3_mix_pan_fused", "error": repr(e)})
+    # the reference's own harness (benches/benchmark.rs) as banks -- `python bench.py --criterion` is the same block alone, with longer CPU legs
+    try:
+        torch.cuda.empty_cache()
+        out.append({"name": "reference_criterion_benches", **criterion_benches(F, torch, cpu_seconds=0.5, steps=2)})
+    except Exception as e:
+        out.append({"name": "reference_criterion_benches", "error": repr(e)})
     return out
 
 
@@ -797,18 +803,20 @@ def criterion_benches(F, torch, names=None, cpu_seconds=1.0, steps=3):
             seeds = np.arange(V, dtype=np.uint64) * 7919 + 13
             if name == "reverb":   # as one lane-per-voice graph (fewer instances: it is two orders slower) and as the chain
                 Vg = 256
-                b = F.Bank.from_graph(g, Vg, ring_frames=ring, sample_rate=sr)
+                b = F.Bank.from_graph(g, Vg, ring_frames=ring, sample_rate=sr, fdn_kernel=False)
                 b.set_seed(seeds[:Vg])
                 out = torch.empty((g.nout, T, Vg), dtype=torch.float32, device="cuda")
                 ms1 = gpu_time(lambda: b.process(T, None, out, layout=F.LAYOUT_VOICE_MINOR))
                 e["as_one_graph"] = {"instances": Vg, "ms_per_rendered_second": round(ms1, 3), "x_real_time": round(Vg / (ms1 * 1e-3), 1), "last_kernel": b.get_option("last_kernel")}
                 del b, out
-                ch = F.Chain(F.Bank.from_graph(GR.noise() | GR.noise(), V, sample_rate=sr), F.Bank.from_graph(GR.reverb_stereo(10.0, 1.0, 0.5), V, sample_rate=sr))
+                t0 = time.perf_counter()
+                ch = F.Bank.from_graph(g, V, sample_rate=sr)   # `generator >> stock reverb`: from_graph builds the chain by itself
+                assert isinstance(ch, F.Chain) and ch.effect.kind == "reverb_stereo"
                 ch.set_seed(seeds)
                 e["compile_and_create_s"] = round(time.perf_counter() - t0, 2)
                 out = torch.empty((V, 2, ch.frame_stride(T)), dtype=torch.float32, device="cuda")
-                ms = gpu_time(lambda: ch.process(T, None, out))
-                e["form"] = "fundsp_amd.Chain(noise | noise bank, reverb_stereo bank: fd::k_fdn_render_frames, lane = frame)"
+                ms = gpu_time(lambda: ch.process(T, None, out, layout=F.LAYOUT_PLANAR))
+                e["form"] = "Bank.from_graph -> fundsp_amd.Chain(noise | noise bank, reverb_stereo bank: fd::k_fdn_render_frames, lane = frame)"
                 del ch, out
             else:
                 b = F.Bank.from_graph(g, V, ring_frames=ring, sample_rate=sr)

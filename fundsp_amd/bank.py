@@ -85,6 +85,17 @@ class Bank:
                     b.set_sample_rate(sample_rate)
                 b.reset()
                 return b
+        parts = getattr(graph, "pipe_parts", None) if fdn_kernel else None
+        if (parts is not None and parts[0].nin == 0 and parts[0].rings == 0 and not ring_frames and
+                (getattr(parts[1], "stock_reverb", None) is not None or getattr(parts[1], "reverb3_plan", None) is not None or G.fdn_plan(parts[1]) is not None)):
+            # `generator >> stock reverb / network` (the reference's own `reverb` bench: (noise() | noise()) >> reverb_stereo(..)): compiled as
+            # ONE lane-per-voice graph the delay lines are read one lane per instance; as a chain the generator keeps its fused kernel and
+            # the network its lane-per-frame kernel -- the same samples (the generator is seeded as the Pipe would seed it), 400-700 x faster
+            eff = cls.from_graph(parts[1], voices, sample_rate=sample_rate)
+            if isinstance(eff, Bank) and eff.kind in LANE_PER_FRAME_KINDS:
+                src = cls.from_graph(parts[0], voices, sample_rate=sample_rate)
+                return Chain(src, eff, construction_hash=probe_hash(graph))
+            eff.close()
         name = graph.kind_name()
         rc = lib().fdsp_graph_compile_src(name.encode(), graph.type.encode(), graph.source.encode() if graph.source else None)
         if rc < 0:
@@ -416,6 +427,48 @@ class Bank:
 
 
 PIPE_ID = 6   # Pipe::ID (audionode.rs:1375-1492; fd_nodes.hpp)
+LANE_PER_FRAME_KINDS = ("reverb_stereo", "reverb4_stereo", "reverb3_stereo", "fdn")
+
+# A one-slot node whose constructor stores what `G::ping(true, AttoHash::new(G::ID))` returns -- the hash a combinator's constructor hands
+# down to its nodes (audionode.rs:871-876, 1389-1394) -- so that the host can read it: the probe walks the TYPE only, no node state.
+_PROBE_SRC = """
+template <class G> struct HashProbe {
+    static constexpr int IN = 0, OUT = 1, RINGS = 0;
+    static constexpr uint64_t ID = 0;
+    uint64_t h;
+    template <class V> FD_HD void visit(V& v) { v.u64(h, STATE, "probe"); }
+    FD_HD void bind(Ctx&) {}
+    FD_HD void init() { G g; h = g.ping(true, G::ID); }
+    FD_HD void update(double) {}
+    FD_HD void reset() {}
+    FD_HD uint64_t ping(bool, uint64_t x) { return x; }
+    FD_HD void begin_block(int) {}
+    FD_HD bool tripped() const { return false; }
+    FD_HD void end_simd() {}
+    template <int PH> FD_HD void step(const float*, float* out) { out[0] = 0.0f; }
+    FD_STEP2_VIA_STEP
+};
+"""
+_probe_cache = {}
+
+
+def probe_hash(graph):
+    """`G::ping(true, AttoHash::new(G::ID))` of the graph's type, evaluated on the device by a one-slot probe kind (compiled once per type)."""
+    import hashlib
+
+    key = graph.type + "\0" + graph.source
+    if key not in _probe_cache:
+        name = "jit_probe_" + hashlib.sha1(key.encode()).hexdigest()[:16]
+        src = (graph.source + "\n" if graph.source else "") + _PROBE_SRC
+        rc = lib().fdsp_graph_compile_src(name.encode(), f"HashProbe<{graph.type}>".encode(), src.encode())
+        if rc < 0:
+            check(rc)
+        b = Bank(name, 1)
+        w = b.get_state()[:2, 0].view(np.uint32)
+        b.close()
+        _probe_cache[key] = (int(w[1]) << 32) | int(w[0])
+    return _probe_cache[key]
+
 
 
 def atto(state, data):
@@ -430,19 +483,26 @@ class Chain:
     """Two banks in series, composed on the host: `source >> effect` where each half has the kernel family that suits it -- e.g. the
     reference's own `reverb` bench, `(noise() | noise()) >> reverb_stereo(10, 1, 0.5)` (benches/benchmark.rs:79-85): compiled as ONE
     lane-per-voice graph the 32 delay lines are read one lane per instance (uncoalesced rings); as a chain the generator runs in its fused
-    kernel and the network in its lane-per-frame kernel (fdsp_reverb_stereo_create), two launches on one stream with a planar buffer
-    [instance][channel][frame] in HBM between them, two orders of magnitude faster.
+    kernel and the network in its lane-per-frame kernel (fdsp_reverb_stereo_create), two launches on one stream with a buffer in HBM
+    between them, two to three orders of magnitude faster.  `Bank.from_graph` builds it by itself for `generator >> stock reverb / network`.
 
-    What it is in the reference's terms: two AudioNodes whose buffers the HOST pipes -- every half keeps the construction hash of a
-    stand-alone node.  `set_seed` gives the halves what AudioNode::set_seed of `Pipe<source, effect>` would give them
-    (Pipe::ping, audionode.rs:1459: the source sees atto(seed, Pipe::ID)); the effect's own ping is skipped, which is exact for the stock
-    reverbs and networks (no node of theirs keeps hashed state)."""
+    Hashes.  `construction_hash` = what Pipe::new's probe ping returns for the WHOLE graph (`probe_hash`): the source then starts from the
+    hash the Pipe's constructor would hand it -- Pipe::ping (audionode.rs:1459) gives its left side atto(hash, Pipe::ID) -- and the chain
+    renders what the one graph renders.  Without it (a chain the host puts together from two banks) every half keeps the construction hash
+    of a stand-alone node, as two AudioNodes piped by hand would.  `set_seed(seeds)` = AudioNode::set_seed of the Pipe.  The effect's own
+    ping is skipped: exact for the stock reverbs and networks (no node of theirs keeps hashed state)."""
 
-    def __init__(self, source, effect):
+    def __init__(self, source, effect, construction_hash=None):
         if source.voices != effect.voices or source.outputs() != effect.inputs():
             raise ValueError(f"chain mismatch: {source.voices} x {source.outputs()} outputs into {effect.voices} x {effect.inputs()} inputs")
         self.source, self.effect, self.voices = source, effect, source.voices
+        self.kind = f"chain({source.kind} >> {effect.kind})"
+        self.sample_rate = effect.sample_rate
         self._mid = self._stream = None
+        self._ctor = construction_hash
+        if construction_hash is not None:
+            self.set_seed(None)
+            self.source.reset()
 
     def inputs(self):
         return self.source.inputs()
@@ -453,33 +513,59 @@ class Chain:
     def set_sample_rate(self, sample_rate):
         self.source.set_sample_rate(sample_rate)
         self.effect.set_sample_rate(sample_rate)
+        self.sample_rate = float(sample_rate)
 
     def reset(self):
         self.source.reset()
         self.effect.reset()
 
-    def set_seed(self, seeds):
+    def set_seed(self, seeds=None):
+        """AudioNode::set_seed per instance; None re-applies the construction-time hash (as Bank.set_seed)."""
+        if seeds is None:
+            if self._ctor is None:
+                self.source.set_seed(None)
+            else:
+                self.source.set_seed(np.full(self.voices, atto(np.uint64(self._ctor), PIPE_ID), dtype=np.uint64))
+            return
         self.source.set_seed(atto(np.ascontiguousarray(seeds, dtype=np.uint64), PIPE_ID))
+
+    def get_option(self, name):
+        return self.effect.get_option(name)
+
+    def synchronize(self):
+        self.source.synchronize()
+        self.effect.synchronize()
+
+    def close(self):
+        self.source.close()
+        self.effect.close()
 
     @staticmethod
     def frame_stride(frames):
-        """row stride of every buffer of a chain launch: `frames` rounded up to whole blocks"""
+        """default row stride of a planar chain launch: `frames` rounded up to whole blocks"""
         return (int(frames) + 63) // 64 * 64
 
-    def process(self, frames, inp=None, out=None, mode=MODE_PROCESS, stream=None):
-        """Render `frames` samples per instance: planar buffers [instance][channel][frame_stride(frames)] throughout (a launch has ONE layout
-        for its input and output, and the buffer between the halves is the source's output and the effect's input).  Both launches go to
-        ONE stream, nothing waits in between on the host: `stream` if given, else a stream of the chain's own that is ordered behind torch's
-        current stream before the launches and in front of it after them (the C ABI reads a NULL stream -- torch's default stream -- as "the
-        bank's own stream", and two banks' own streams do not order each other)."""
+    def process(self, frames, inp=None, out=None, layout=LAYOUT_VOICE_MINOR, frame_stride=None, mode=MODE_PROCESS, stream=None):
+        """As Bank.process: voice-minor out [outputs, frames, V] / planar out [V, outputs, frame_stride] (planar default stride: frames
+        rounded up to whole blocks).  A launch has ONE layout and stride for its input and output, and the buffer between the halves is the
+        source's output and the effect's input, so every buffer of the call has them.  Both launches go to ONE stream, nothing waits in
+        between on the host: `stream` if given, else a stream of the chain's own that is ordered behind torch's current stream before the
+        launches and in front of it after them (the C ABI reads a NULL stream -- torch's default stream -- as "the bank's own stream", and
+        two banks' own streams do not order each other)."""
         import torch
 
         frames = int(frames)
-        fs = self.frame_stride(frames)
-        if self._mid is None or self._mid.shape[2] != fs:
-            self._mid = torch.empty((self.voices, self.source.outputs(), fs), dtype=torch.float32, device="cuda")
+        V = self.voices
+        if layout == LAYOUT_PLANAR:
+            fs = int(frame_stride) if frame_stride else self.frame_stride(frames)
+            mshape, oshape = (V, self.source.outputs(), fs), (V, self.effect.outputs(), fs)
+        else:
+            fs = 0
+            mshape, oshape = (self.source.outputs(), frames, V), (self.effect.outputs(), frames, V)
+        if self._mid is None or tuple(self._mid.shape) != mshape:
+            self._mid = torch.empty(mshape, dtype=torch.float32, device="cuda")
         if out is None:
-            out = torch.empty((self.voices, self.effect.outputs(), fs), dtype=torch.float32, device="cuda")
+            out = torch.empty(oshape, dtype=torch.float32, device="cuda")
         own = None
         if stream is None:
             if self._stream is None:
@@ -487,8 +573,8 @@ class Chain:
             own, cur = self._stream, torch.cuda.current_stream()
             own.wait_stream(cur)
             stream = own.cuda_stream
-        self.source.process(frames, inp, self._mid, layout=LAYOUT_PLANAR, frame_stride=fs, mode=mode, stream=stream)
-        self.effect.process(frames, self._mid, out, layout=LAYOUT_PLANAR, frame_stride=fs, mode=mode, stream=stream)
+        self.source.process(frames, inp, self._mid, layout=layout, frame_stride=fs or None, mode=mode, stream=stream)
+        self.effect.process(frames, self._mid, out, layout=layout, frame_stride=fs or None, mode=mode, stream=stream)
         if own is not None:
             cur.wait_stream(own)
         return out

@@ -371,9 +371,23 @@ int jit_compile_src(const std::string& src, const std::string& type_expr, std::v
     // a graph with a Feedback node renders with f32 denormals flushed, like the reference after Feedback::new's
     // prevent_denormals() (feedback.rs:96, denormal.rs:18)
     const bool ftz = type_expr.find("Feedback") != std::string::npos;
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
-                          "-fgpu-flush-denormals-to-zero", "-DFD_FTZ=1"};  // FD_FTZ: fd_math.hpp's flush-only selects
-    hiprtcResult r = hiprtcCompileProgram(prog, ftz ? 8 : 6, opts);
+    // A wide sum of plain oscillators at the root (fd_device.hpp render_body_wide: 32 independent frame pairs per branch and block): the default
+    // machine scheduler emits the packed sine polynomials pair by pair with an s_nop behind every dependent packed instruction (328 per
+    // branch-block of the reference's 100-sine bench); the max-ILP strategy interleaves the pairs (4 s_nop, 160 -> 200 VGPRs).  Only for
+    // branches made of the plain feed-forward nodes it was tried on -- other strategies have crashed this compiler on other kinds.
+    bool wide_ilp = type_expr.rfind("Reduce<", 0) == 0 || type_expr.rfind("MultiBus<", 0) == 0;
+    for (const char* heavy : {"Oversampler", "Resample", "Feedback", "Limiter", "Reverb3", "Envelope", "Moog", "Pluck"})
+        if (type_expr.find(heavy) != std::string::npos) wide_ilp = false;
+    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"};
+    if (ftz) {
+        opts.push_back("-fgpu-flush-denormals-to-zero");
+        opts.push_back("-DFD_FTZ=1");  // FD_FTZ: fd_math.hpp's flush-only selects
+    }
+    if (wide_ilp) {
+        opts.push_back("-mllvm");
+        opts.push_back("-amdgpu-sched-strategy=max-ilp");
+    }
+    hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);
     if (ls > 1) {

@@ -3160,32 +3160,47 @@ struct Limiter {
     FD_HD void begin_block(int) {}
     FD_HD bool tripped() const { return false; }
     FD_HD void end_simd() {}
-    FD_HD void tree_set(uint32_t idx, float value) {  // ReduceBuffer::set :104-112
-        uint32_t i = leaf + idx;
-        tree[(size_t)i * vs] = value;
-        float cur = value;
+    // ReduceBuffer::set :104-112, returns the new total (= buffer[1]).  The walk to the root reads the SIBLING of every node on the path and
+    // writes its parent; the siblings are off the path, so no load of this update sees a store of this update: CH levels' loads are issued
+    // together, then their maxima and stores (one memory round trip per CH levels instead of one per level -- the 4 410-frame window of the
+    // reference's own limiter bench is a 13-level tree; the loop as the reference writes it, load / max / store per level, ran 172 ms per rendered
+    // second of 65 536 instances on the latency of its loads alone).  Windows up to 256 frames: 8 levels at a time; longer ones: 16.
+    template <int CH> FD_HD float tree_walk(uint32_t i, float cur) {
         while (i > 1u) {
-            cur = __builtin_fmaxf(cur, tree[(size_t)(i ^ 1u) * vs]);
-            i >>= 1;
-            tree[(size_t)i * vs] = cur;
+            float s[CH];
+            _Pragma("unroll") for (int k = 0; k < CH; k++) {
+                const uint32_t j = i >> k;
+                s[k] = j > 1u ? tree[(size_t)(j ^ 1u) * vs] : 0.0f;
+            }
+            _Pragma("unroll") for (int k = 0; k < CH; k++) {
+                const uint32_t j = i >> k;
+                if (j > 1u) {
+                    cur = __builtin_fmaxf(cur, s[k]);
+                    tree[(size_t)(j >> 1) * vs] = cur;
+                }
+            }
+            i >>= CH;
         }
+        return cur;
+    }
+    FD_HD float tree_set(uint32_t idx, float value) {
+        const uint32_t i = leaf + idx;
+        tree[(size_t)i * vs] = value;
+        return leaf > 256u ? tree_walk<16>(i, value) : tree_walk<8>(i, value);
     }
     template <int PH> FD_HD void step(const float* in, float* out) {  // tick :202-226
         float amplitude = 0.0f;
         for (int c = 0; c < N; c++) amplitude = __builtin_fmaxf(amplitude, __builtin_fabsf(in[c]));
-        tree_set(index, amplitude);
-        const float total = tree[vs];  // [1]
+        float o[N];  // the delay line's oldest sample, read ahead of the tree walk (its round trip overlaps the walk's; unused while the line fills)
+        for (int c = 0; c < N; c++) o[c] = buf[c][(size_t)index * vs];
+        const float total = tree_set(index, amplitude);  // reducer.total() = buffer[1], the root the walk just wrote
         if (fill < length) {
             for (int c = 0; c < N; c++) buf[c][(size_t)index * vs] = in[c];
             fill++;
             if (fill == length) follower.v1 = follower.v2 = follower.v3 = total;  // set_value :196-200
             for (int c = 0; c < N; c++) out[c] = 0.0f;
         } else {
-            float o[N];
-            for (int c = 0; c < N; c++) {
-                o[c] = buf[c][(size_t)index * vs];
-                buf[c][(size_t)index * vs] = in[c];
-            }
+            for (int c = 0; c < N; c++) buf[c][(size_t)index * vs] = in[c];
             float x = __builtin_fmaxf(1.0f, total * 1.10f), y;
             follower.template step<PH_TICK>(&x, &y);
             const float limit = follower.v3;

@@ -39,7 +39,9 @@ class Graph:
     def __rshift__(self, other):
         if self.nout != other.nin:
             raise TypeError(f"Pipe arity mismatch: {self.nout} outputs >> {other.nin} inputs")
-        return self._pair(other, "Pipe", self.nin, other.nout)
+        g = self._pair(other, "Pipe", self.nin, other.nout)
+        g.pipe_parts = (self, other)   # Bank.from_graph renders `generator >> stock reverb / network` as a chain of two banks (bank.Chain)
+        return g
 
     def __or__(self, other):
         return self._pair(other, "Stack", self.nin + other.nin, self.nout + other.nout)

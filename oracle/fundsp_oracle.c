@@ -783,6 +783,29 @@ static uint64_t o_ping(onode *n, int probe, uint64_t hash) {
     case O_OVERSAMPLE: /* oversample.rs:218-220 */
     case O_ALLNEST: /* delay.rs:337-339 */
         return o_ping(n->x, probe, o_atto(hash, n->id));
+    case O_REVERB_STEREO: {
+        /* This node stands for the tree reverb_stereo builds (prelude.rs:1755-1763):
+         *   multisplit::<U2, U16>() >> fdn::<U32>(stacki::<U32>(|i| delay(..) >> fir(..))) >> sumf::<U32>(|x| pan(..)) * dc((1/16, 1/16))
+         * = Pipe<Pipe<MultiSplit, Feedback<MultiStack<U32, Pipe<Delay, Fir>>>>, Binop<Mul, Reduce<U32, Pan>, Constant>>, and its ping is the walk
+         * of that tree (Pipe / Binop: y.ping(x.ping(hash.hash(ID))); Feedback :152-154; MultiStack / Reduce: own ID, then the nodes in order;
+         * leaves: hash.hash(ID)).  None of those nodes keeps hashed state, so only the hash handed on matters -- to whatever hashed node follows
+         * the reverb in a Pipe, and, through the probe ping of a constructor, to every hashed node of the graph (found by the construction-hash
+         * test of the reverb bench, tests/test_gpu_criterion.py: the leaf default below had stood in for the walk). */
+        uint64_t h = o_atto(hash, 6);  /* Pipe<Pipe<..>, Binop> */
+        h = o_atto(h, 6);              /* Pipe<MultiSplit, Feedback> */
+        h = o_atto(h, 38);             /* MultiSplit */
+        h = o_atto(h, 11);             /* Feedback */
+        h = o_atto(h, 30);             /* MultiStack<U32, _> */
+        for (int i = 0; i < 32; i++) {
+            h = o_atto(h, 6);          /* Pipe<Delay, Fir> */
+            h = o_atto(h, 13);         /* Delay */
+            h = o_atto(h, 52);         /* Fir */
+        }
+        h = o_atto(h, 3);              /* Binop<FrameMul, Reduce, Constant> */
+        h = o_atto(h, 31);             /* Reduce<U32, Pan, FrameAdd> */
+        for (int i = 0; i < 32; i++) h = o_atto(h, 49); /* Pan */
+        return o_atto(h, 2);           /* Constant */
+    }
     default:
         if (!probe) leaf_set_hash(n, hash);
         return o_atto(hash, n->id);

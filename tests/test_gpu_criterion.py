@@ -59,31 +59,59 @@ def test_criterion_graph_tick_executor_and_planar_layout(gpu, name):
 
 
 def test_reverb_bench_as_a_chain_of_two_banks(gpu):
-    """(noise() | noise()) >> reverb_stereo(10, 1, 0.5) as gpu.Chain(generator bank, lane-per-frame network bank): bit-equal to the oracle's
-    rendering of the ONE graph with the same seed, and to the run-time compiled one-graph bank."""
+    """(noise() | noise()) >> reverb_stereo(10, 1, 0.5): Bank.from_graph renders `generator >> stock reverb` as gpu.Chain(generator bank,
+    lane-per-frame network bank).  Bit-equal to the oracle's rendering of the ONE graph and to the run-time compiled one-graph bank: as
+    constructed (the hash Pipe::new's probe ping hands down, read from the device by a probe kind), after set_seed, in both executors and
+    both layouts, across chunked launches, and for a chain the host puts together from two banks."""
     import torch
 
     V, T = 130, 64 * 40 + 17
-    src = gpu.Bank.from_graph(GR.noise() | GR.noise(), V, sample_rate=CG.SAMPLE_RATE)
-    rev = gpu.Bank.from_graph(GR.reverb_stereo(10.0, 1.0, 0.5), V, sample_rate=CG.SAMPLE_RATE)
-    assert rev.kind == "reverb_stereo"
-    ch = gpu.Chain(src, rev)
-    assert (ch.inputs(), ch.outputs()) == (0, 2)
-    seeds = np.arange(V, dtype=np.uint64) * 7 + 3
+    g = CG.table(GR, O)["reverb"][0]
+    ch = gpu.Bank.from_graph(g, V, sample_rate=CG.SAMPLE_RATE)
+    assert isinstance(ch, gpu.Chain) and ch.effect.kind == "reverb_stereo" and (ch.inputs(), ch.outputs()) == (0, 2)
     one, _g = _bank(gpu, "reverb", V)
+    assert one.kind.startswith("jit_")
+
+    def planar(bank, mode):
+        out = bank.process(T, layout=LAYOUT_PLANAR, mode=mode)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()[:, :, :T]
+
+    # as constructed: every instance is the reference's freshly constructed graph
+    got = planar(ch, MODE_PROCESS)
+    n = CG.table(O, O)["reverb"][0]
+    n.set_sample_rate(CG.SAMPLE_RATE)
+    want = oracle_render(n, None, T, MODE_PROCESS)
+    for v in (0, 64, 129):
+        assert_bit_equal(got[v], want, f"as constructed, instance {v}")
+    assert_bit_equal(got, run_bank(one, None, T, LAYOUT_PLANAR, MODE_PROCESS), "as constructed: chain == one graph")
+    seeds = np.arange(V, dtype=np.uint64) * 7 + 3
     for mode in (MODE_PROCESS, MODE_TICK):
         ch.reset(); one.reset()
         ch.set_seed(seeds); one.set_seed(seeds)
-        out = ch.process(T, mode=mode)
-        torch.cuda.synchronize()
-        got = out.cpu().numpy()[:, :, :T]
+        got = planar(ch, mode)
         assert_bit_equal(got, run_bank(one, None, T, LAYOUT_PLANAR, mode), f"chain == one graph, mode {mode}")
         for v in (0, 64, 129):
             assert_bit_equal(got[v], oracle_render(_oracle("reverb", seeds[v]), None, T, mode), f"chain instance {v} mode {mode}")
+    # voice-minor buffers (the network bank's staging copy), and set_seed(None) = the construction hash again
+    ch.reset(); ch.set_seed(seeds)
+    vm = ch.process(T)
+    torch.cuda.synchronize()
+    ch.reset(); ch.set_seed(seeds)
+    assert_bit_equal(vm.cpu().numpy().transpose(2, 0, 1), planar(ch, MODE_PROCESS), "voice-minor == planar")
+    ch.reset(); ch.set_seed(None)
+    assert_bit_equal(planar(ch, MODE_PROCESS)[77], want, "set_seed(None) re-applies the construction hash")
     # chunked launches continue the tail
     ch.reset(); ch.set_seed(seeds)
-    a = ch.process(1000).cpu().numpy()[:, :, :1000]
-    b2 = ch.process(T - 1000).cpu().numpy()[:, :, :T - 1000]
-    ch.reset(); ch.set_seed(seeds)
-    whole = ch.process(T).cpu().numpy()[:, :, :T]
-    assert_bit_equal(np.concatenate([a, b2], axis=2), whole, "chunked == whole")
+    a = ch.process(1000, layout=LAYOUT_PLANAR).cpu().numpy()[:, :, :1000]
+    b2 = ch.process(T - 1000, layout=LAYOUT_PLANAR).cpu().numpy()[:, :, :T - 1000]
+    n = _oracle("reverb", seeds[5])
+    w2 = np.concatenate([n.render_blocks(None, length=1000, block=64), n.render_blocks(None, length=T - 1000, block=64)], axis=1)
+    assert_bit_equal(np.concatenate([a, b2], axis=2)[5], w2, "chunked launches, instance 5")
+    # a chain put together by the host: two stand-alone nodes piped by hand
+    src = gpu.Bank.from_graph(GR.noise() | GR.noise(), V, sample_rate=CG.SAMPLE_RATE)
+    rev = gpu.Bank.from_graph(GR.reverb_stereo(10.0, 1.0, 0.5), V, sample_rate=CG.SAMPLE_RATE)
+    by_hand = gpu.Chain(src, rev)
+    ns, nr = O.noise() | O.noise(), O.reverb_stereo(10.0, 1.0, 0.5)
+    ns.set_sample_rate(CG.SAMPLE_RATE); nr.set_sample_rate(CG.SAMPLE_RATE)
+    assert_bit_equal(planar(by_hand, MODE_PROCESS)[3], nr.render_blocks(ns.render_blocks(None, length=T, block=64), block=64), "two stand-alone nodes")

@@ -57,3 +57,35 @@ def test_tick_and_process_agree_like_check_wave(name):
     ya, yb = a.render_blocks(None, length=T, block=64), b.render_ticks(None, length=T)
     scale = 100.0 if name == "sine" else 1.0    # the sum of 100 unit sines
     assert np.abs(ya - yb).max() <= 1e-4 * scale
+
+
+def _generic_reverb_stereo(m, room_size, time, damping):
+    """reverb_stereo spelled out of its parts (prelude.rs:1744-1763), as fundsp_amd.graph.reverb_stereo does, in notation `m`"""
+    a = f32(GR._db_amp(-60.0) ** (0.03 * room_size / 10.0 / time))
+    gain = f32(1.0) - f32(damping)
+    alpha = (gain + f32(1.0)) / f32(2.0)
+    beta = (f32(1.0) - alpha) / f32(2.0)
+    w = (beta * a, alpha * a, beta * a)
+    line = m.stacki(32, lambda i: m.delay(float(f32(GR.REVERB_DELAYS[i] * room_size / 10.0))) >> m.fir(*w))
+    pans = m.sumf(32, lambda x: m.pan(f32(-1.0) * (f32(1.0) - GR._smooth9(x)) + f32(1.0) * GR._smooth9(x)))
+    return m.multisplit(2, 16) >> m.fdn(line) >> pans * m.dc(1.0 / 16.0, 1.0 / 16.0)
+
+
+def test_the_reverb_node_hands_on_the_hash_of_the_tree_it_stands_for():
+    """The oracle's reverb_stereo is ONE native node standing for a tree of 100 nodes; AudioNode::ping walks that tree.  The hash it hands on
+    reaches, through the probe ping of a constructor, every hashed node of the graph -- here the two noise generators in front of it, as
+    constructed (the reverb bench's own situation) -- and the hashed node behind it after set_seed."""
+    for tail in (False, True):
+        def build(rev):
+            g = (O.noise() | O.noise()) >> rev
+            return (g >> (O.pass_() | O.pass_() * O.noise())) if tail else g
+        a, b = build(O.reverb_stereo(10.0, 1.0, 0.5)), build(_generic_reverb_stereo(O, 10.0, 1.0, 0.5))
+        for n in (a, b):
+            n.set_sample_rate(CG.SAMPLE_RATE)
+        ya, yb = a.render_blocks(None, length=4000, block=64), b.render_blocks(None, length=4000, block=64)
+        assert np.abs(ya).max() > 0 and (ya.view(np.uint32) == yb.view(np.uint32)).all(), f"as constructed, tail={tail}"
+        for n in (a, b):
+            n.reset()
+            n.set_seed(12345)
+        ya, yb = a.render_blocks(None, length=4000, block=64), b.render_blocks(None, length=4000, block=64)
+        assert (ya.view(np.uint32) == yb.view(np.uint32)).all(), f"after set_seed, tail={tail}"
