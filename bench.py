@@ -826,6 +826,18 @@ def criterion_benches(F, torch, names=None, cpu_seconds=1.0, steps=3):
                 ms = gpu_time(lambda: b.process(T, None, out, layout=F.LAYOUT_VOICE_MINOR))
                 e["last_kernel"] = b.get_option("last_kernel")
                 del b, out
+                if name == "sine":   # ... and on a bank that does not fill the chip: the chain of waves per voice group (last_kernel 8) against one wave per group (1)
+                    Vs = 1024
+                    bs = F.Bank.from_graph(g, Vs, sample_rate=sr)
+                    bs.set_seed(seeds[:Vs])
+                    outs = torch.empty((g.nout, T, Vs), dtype=torch.float32, device="cuda")
+                    small = {"instances": Vs}
+                    for key, split in (("chain_of_waves", 1), ("one_wave_per_voice_group", 0)):
+                        bs.set_option("pipe_split", split)
+                        m1 = gpu_time(lambda: bs.process(T, None, outs, layout=F.LAYOUT_VOICE_MINOR))
+                        small[key] = {"ms_per_rendered_second": round(m1, 3), "x_real_time": round(Vs / (m1 * 1e-3), 1), "last_kernel": bs.get_option("last_kernel")}
+                    e["small_bank"] = small
+                    del bs, outs
             e["ms_per_rendered_second"] = round(ms, 3)
             e["x_real_time"] = round(V / (ms * 1e-3), 1)
             e["value"] = round(V * T / ms / 1e3, 1)

@@ -343,6 +343,182 @@ FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, f
     }
 }
 
+// ... and the same sum on a bank too small to fill the chip with one wave per voice group (render_body_wide takes as long for 4 096 instances as
+// for 65 536).  The left fold fixes the ORDER of the additions, not who evaluates the branches: a voice group becomes a workgroup of W waves, wave w
+// owns the branches [w N / W, (w + 1) N / W) and the blocks travel down the chain -- in round r wave w works on block r - w: it takes the block's
+// accumulator tile from LDS as wave w - 1 left it, folds its own branches into it in order, and leaves it for wave w + 1 (the last wave writes the
+// output).  W blocks are in flight, block k lives in tile k mod W for its whole trip, so one workgroup barrier per round hands every tile on; the fill
+// and drain of the chain cost W - 1 rounds per launch.  Same branch arithmetic, same fold, same slots traffic as render_body_wide -- bit-identical to
+// it (tests/test_gpu_wide_sum.py renders every case through both).  W = 8 mono / 4 stereo branches: W tiles of 16 / 32 KB = 128 KB of LDS, one
+// workgroup per CU, two waves per SIMD.
+template <class G> struct WideChain {
+    static constexpr bool on = WideSum<G>::value;
+    static constexpr int W = !on ? 1 : (G::OUT == 1 ? 8 : 4);
+};
+
+template <class G, int MODE, int LAYOUT>
+FD_D void render_body_wide_chain(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T, size_t fstride,
+                                 const void* aux, float* ring, uint32_t ring_cap) {
+    if constexpr (WideSum<G>::value) {
+        using WS = WideSum<G>;
+        using X = typename WS::Branch;
+        using OP = typename WS::OP;
+        constexpr int N = WS::N, NO = X::OUT, W = WideChain<G>::W;
+        const int lane = threadIdx.x & 63;
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // place in the chain
+        const size_t v0 = (size_t)blockIdx.x * 64;
+        const size_t v = v0 + lane;  // < stride: the slot / ring arrays are padded to whole voice groups (padding lanes own private zeroed columns)
+        const bool active = v < V;
+        int K;
+        {
+            X probe;
+            VCountWords c;
+            probe.visit(c);
+            K = c.n;
+        }
+        const int b0 = w * N / W, b1 = (w + 1) * N / W;
+        __shared__ float tiles[W * NO * 64 * 64];  // [tile][channel][frame][lane]
+        auto branch_in = [&](X& x, int i) {
+            Ctx ctx{static_cast<const Aux*>(aux), ring + v, ring_cap, stride, i * X::RINGS};
+            x.bind(ctx);
+            VLoad ld{slots + v, stride, i * K};
+            x.visit(ld);
+        };
+        auto branch_out = [&](X& x, int i) {
+            if (active) {
+                VStore<false> st{slots + v, stride, i * K};
+                x.visit(st);
+            }
+        };
+        const size_t nblocks = (T + 63) / 64;
+        for (size_t r = 0; r < nblocks + W - 1; r++) {
+            __syncthreads();  // every tile moves one wave down the chain
+            if (r < (size_t)w || r - w >= nblocks) continue;
+            const size_t k = r - w, t0 = k * 64;
+            const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
+            const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
+            float* tile0 = tiles + (k % W) * (NO * 64 * 64);
+            float* accl = tile0 + lane;  // this lane's column: accl[(c * 64 + frame) * 64]
+            if (MODE == MODE_PROCESS && size == 64) {
+                v2f acc[NO][32];
+                if (w > 0) {
+#pragma unroll
+                    for (int c = 0; c < NO; c++)
+#pragma unroll
+                        for (int q = 0; q < 32; q++) acc[c][q] = v2f{accl[(c * 64 + 2 * q) * 64], accl[(c * 64 + 2 * q + 1) * 64]};
+                }
+#pragma unroll 1
+                for (int i = b0; i < b1; i++) {
+                    X x;
+                    branch_in(x, i);
+                    x.begin_block(64);
+                    const X snap = x;
+                    v2f tmp[NO][32];
+#pragma unroll
+                    for (int q = 0; q < 32; q++) {
+                        v2f po[NO];
+                        x.template step2<PH_SIMD>(nullptr, po);
+#pragma unroll
+                        for (int c = 0; c < NO; c++) tmp[c][q] = po[c];
+                    }
+                    if (__builtin_expect(x.tripped(), 0)) {  // this branch's block again, scalar (the accumulator is in registers: the tile is free)
+                        x = snap;
+#pragma unroll 1
+                        for (int f = 0; f < 64; f++) {
+                            float fo[NO];
+                            x.template step<PH_SIMD>(nullptr, fo);
+#pragma unroll
+                            for (int c = 0; c < NO; c++) accl[(c * 64 + f) * 64] = fo[c];
+                        }
+#pragma unroll
+                        for (int c = 0; c < NO; c++)
+#pragma unroll
+                            for (int q = 0; q < 32; q++) tmp[c][q] = v2f{accl[(c * 64 + 2 * q) * 64], accl[(c * 64 + 2 * q + 1) * 64]};
+                    }
+                    x.end_simd();
+#pragma unroll
+                    for (int c = 0; c < NO; c++)
+#pragma unroll
+                        for (int q = 0; q < 32; q++) acc[c][q] = i == 0 ? tmp[c][q] : OP::f(acc[c][q], tmp[c][q]);
+                    branch_out(x, i);
+                }
+                if (w == W - 1 && LAYOUT == LAYOUT_VOICE_MINOR) {
+                    if (active) {
+#pragma unroll
+                        for (int c = 0; c < NO; c++)
+#pragma unroll
+                            for (int q = 0; q < 32; q++) {
+                                out[((size_t)c * T + t0 + 2 * q) * V + v] = acc[c][q].x;
+                                out[((size_t)c * T + t0 + 2 * q + 1) * V + v] = acc[c][q].y;
+                            }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NO; c++)
+#pragma unroll
+                        for (int q = 0; q < 32; q++) {
+                            accl[(c * 64 + 2 * q) * 64] = acc[c][q].x;
+                            accl[(c * 64 + 2 * q + 1) * 64] = acc[c][q].y;
+                        }
+                }
+            } else {  // the ragged last block, the tick executor: the fold in place, in the tile
+#pragma unroll 1
+                for (int i = b0; i < b1; i++) {
+                    X x;
+                    branch_in(x, i);
+                    x.begin_block(size);
+#pragma unroll 1
+                    for (int f = 0; f < size; f++) {
+                        float fo[NO];
+                        if (f < full) {
+                            x.template step<PH_SIMD>(nullptr, fo);
+                        } else {
+                            if (MODE == MODE_PROCESS && f == full) x.end_simd();
+                            x.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(nullptr, fo);
+                        }
+#pragma unroll
+                        for (int c = 0; c < NO; c++) {
+                            float* a = &accl[(c * 64 + f) * 64];
+                            *a = i == 0 ? ((WS::BUS && MODE == MODE_TICK) ? 0.0f + fo[c] : fo[c]) : OP::f(*a, fo[c]);
+                        }
+                    }
+                    if (MODE == MODE_PROCESS && full == size) x.end_simd();
+                    branch_out(x, i);
+                }
+                if (w == W - 1 && LAYOUT == LAYOUT_VOICE_MINOR && active) {
+                    for (int f = 0; f < size; f++)
+#pragma unroll
+                        for (int c = 0; c < NO; c++) out[((size_t)c * T + t0 + f) * V + v] = accl[(c * 64 + f) * 64];
+                }
+            }
+            if (w == W - 1 && LAYOUT == LAYOUT_PLANAR) {  // tile [channel][frame][voice] -> global [voice][channel][frame]
+                wave_sync();
+                const int sub = lane >> 4, fr = (lane & 15) << 2;
+                const bool vec = ((fstride & 3) == 0) && ((((uintptr_t)out) & 15) == 0) && (t0 + 64 <= fstride);
+#pragma unroll
+                for (int c = 0; c < NO; c++)
+                    for (int rr = 0; rr < 16; rr++) {
+                        const int vr = rr * 4 + sub;
+                        const size_t gv = v0 + vr;
+                        if (gv < V) {
+                            float4 q4 = make_float4(tile0[(c * 64 + fr) * 64 + vr], tile0[(c * 64 + fr + 1) * 64 + vr], tile0[(c * 64 + fr + 2) * 64 + vr],
+                                                    tile0[(c * 64 + fr + 3) * 64 + vr]);
+                            float* dst = out + (gv * NO + c) * fstride + t0 + fr;
+                            if (vec && fr + 4 <= ((size + 3) & ~3)) {
+                                *reinterpret_cast<float4*>(dst) = q4;
+                            } else {
+                                if (fr + 0 < size) dst[0] = q4.x;
+                                if (fr + 1 < size) dst[1] = q4.y;
+                                if (fr + 2 < size) dst[2] = q4.z;
+                                if (fr + 3 < size) dst[3] = q4.w;
+                            }
+                        }
+                    }
+            }
+        }
+    }
+}
+
 // ---- the hot kernel ----------------------------------------------------------------------------------------
 // WPB = waves per workgroup.  Four-wave workgroups are used whenever LDS allows: the dispatcher places the four
 // waves of one workgroup on the four SIMDs of a CU, so a 65 536-voice bank (256 workgroups) lands exactly one wave
@@ -2424,6 +2600,7 @@ FD_D void describe_body(char* out, int cap, int* meta) {
     meta[9] = JitPipeSmall<G>::on ? 1 : 0;                                 // heavy: jit_pipe_g1 / _g2 exist for small banks
     meta[10] = PipeMinT<G>::v;                                             // launch length from which the pipeline kernel is taken
     meta[11] = TsPlan<G>::ok ? 1 : 0;                                      // a three-stage generator chain: small banks take the time-split kernels (jit_ts3_g1 / _g2)
+    meta[12] = WideChain<G>::on ? WideChain<G>::W : 0;                     // a wide sum of generators: waves of the chain kernel (jit_wide_*) small banks take, 0 = none
 }
 // the three-way time-split kernels for run-time compiled graphs (small banks of three-stage generator chains; a module of their own with the
 // mix-down kernels, compiled on first use): empty when the graph does not qualify

@@ -56,6 +56,7 @@ struct JitFuncs {
     hipFunction_t pipe[2] = {nullptr, nullptr};                              // [mode], pipeline kernel
     hipFunction_t pipe_small[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [groups per workgroup - 1][mode], heavy graphs only
     hipFunction_t pipe_planar[2] = {nullptr, nullptr};                       // [mode], planar-layout pipeline kernel
+    hipFunction_t wide[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [mode][layout], wide sums of generators on small banks (a chain of waves per voice group)
 };
 struct JitModule {
     static constexpr int MAXD = 64;
@@ -66,6 +67,7 @@ struct JitModule {
     int pipe_stages = 0, pipe_threads = 0, pipe_planar_threads = 0, pipe_min_t = 256;
     bool pipe_small = false;                                                 // heavy graph: workgroups of 1 / 2 voice groups for small banks
     bool ts_ok = false;                                                      // three-stage generator chain: small banks take the time-split kernels
+    int wide_waves = 0;                                                      // a wide sum of generators: waves per voice group of the chain kernel (0 = none)
     int wpb[2] = {4, 4};                                                     // per layout
     // the tolerance-mode twin of this graph (FastOf<G>), compiled on first use
     std::string type_expr, prelude;
@@ -105,6 +107,8 @@ struct JitModule {
             for (int l = 0; l < 2 && ok; l++) {
                 std::string fn = "jit_render_" + std::to_string(m) + std::to_string(l);
                 ok = hipModuleGetFunction(&f.render[m][l], f.mod, fn.c_str()) == hipSuccess;
+                fn = "jit_wide_" + std::to_string(m) + std::to_string(l);
+                ok = ok && hipModuleGetFunction(&f.wide[m][l], f.mod, fn.c_str()) == hipSuccess;
             }
         for (int m = 0; m < 2 && ok; m++) {
             std::string fn = "jit_events_" + std::to_string(m);
@@ -217,9 +221,19 @@ void jit_render(JitModule* jm, float* slots, size_t stride, size_t V, const floa
             }
         }
     }
+    // A wide sum of generators at the root (fd_device.hpp WideSum): its kernels are the branch-major ones, whatever the layout -- on a bank that
+    // leaves SIMDs idle at one wave per voice group the chain of waves (render_body_wide_chain), else render_body_wide through the single-wave
+    // entry point below; the stage pipelines walk such a graph frame-major with every branch in registers.
+    const bool wide = jm->wide_waves > 0;
+    if (wide && tl_opts.pipe_split && T > 64 && (V + 63) / 64 <= (size_t)simd_count() / 2) {
+        void* wargs[] = {&slots, &stride, &V, &outp, &T, &fstride, &aux, &ring, &ring_cap};
+        hipModuleLaunchKernel(f->wide[mode][layout], (unsigned)((V + 63) / 64), 1, 1, 64u * (unsigned)jm->wide_waves, 1, 1, 0, s, wargs, nullptr);
+        tl_opts.last_kernel = LK_WIDE_CHAIN;
+        return;
+    }
     // loader wave / stage split; short launches (real-time blocks) are faster through the single-wave kernel, as for
     // the ahead-of-time kinds (launch_render)
-    if (layout == LAYOUT_VOICE_MINOR && tl_opts.pipe_split && jm->pipe_stages >= 1 && (T >= (size_t)jm->pipe_min_t || tl_opts.pipe_split > 1)) {
+    if (!wide && layout == LAYOUT_VOICE_MINOR && tl_opts.pipe_split && jm->pipe_stages >= 1 && (T >= (size_t)jm->pipe_min_t || tl_opts.pipe_split > 1)) {
         void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &aux, &ring, &ring_cap};
         const size_t groups = (V + 63) / 64, cus = (size_t)simd_count() / 4;
         if (jm->pipe_small && groups <= 2 * cus) {  // heavy graph, small bank: as launch_render_pipe
@@ -234,7 +248,7 @@ void jit_render(JitModule* jm, float* slots, size_t stride, size_t V, const floa
         tl_opts.last_kernel = LK_PIPELINE;
         return;
     }
-    if (layout == LAYOUT_PLANAR && tl_opts.pipe_split && jm->pipe_planar_threads > 0 && (T >= FD_PLANAR_PIPE_MIN_T || tl_opts.pipe_split > 1) && fstride % 4 == 0 &&
+    if (!wide && layout == LAYOUT_PLANAR && tl_opts.pipe_split && jm->pipe_planar_threads > 0 && (T >= FD_PLANAR_PIPE_MIN_T || tl_opts.pipe_split > 1) && fstride % 4 == 0 &&
         ((uintptr_t)in & 15) == 0 && ((uintptr_t)outp & 15) == 0) {  // loader / stages / storer (see launch_render)
         void* pargs[] = {&slots, &stride, &V, &in, &outp, &T, &fstride, &aux, &ring, &ring_cap};
         hipModuleLaunchKernel(f->pipe_planar[mode], (unsigned)(((V + 63) / 64 + 3) / 4), 1, 1, (unsigned)jm->pipe_planar_threads, 1, 1,
@@ -272,6 +286,13 @@ std::string jit_source(const std::string& type_expr, const std::string& prelude)
                  "size_t T, size_t fstride, const void* aux, float* ring, uint32_t cap) {\n"
                  "  fd::render_body<JitG, " + m + ", " + l + ", JIT_WPB" + l +
                  ">(slots, stride, V, in, out, T, fstride, aux, ring, cap); }\n";
+        }
+    for (int mode = 0; mode < 2; mode++)   // wide sums of generators on small banks: a chain of waves per voice group (empty bodies for every other graph)
+        for (int layout = 0; layout < 2; layout++) {
+            std::string m = std::to_string(mode), l = std::to_string(layout);
+            s += "extern \"C\" __global__ __launch_bounds__(64 * fd::WideChain<JitG>::W) void jit_wide_" + m + l +
+                 "(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T, size_t fstride, const void* aux, "
+                 "float* ring, uint32_t cap) {\n  fd::render_body_wide_chain<JitG, " + m + ", " + l + ">(slots, stride, V, out, T, fstride, aux, ring, cap); }\n";
         }
     s += "constexpr int JIT_PIPE_THREADS = fd::JitPipeThreads<JitG>::v;\n";
     for (int mode = 0; mode < 2; mode++) {
@@ -451,6 +472,7 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
     jm->pipe_small = meta[9] != 0;
     jm->pipe_min_t = meta[10] > 0 ? meta[10] : 256;
     jm->ts_ok = meta[11] != 0;
+    jm->wide_waves = meta[12];
     out->slots.clear();
     std::istringstream lines(std::string(txt.data(), (size_t)meta[3]));
     std::string line;
@@ -484,6 +506,7 @@ int jit_make_kind(const std::string& name, const std::string& type_expr, const s
                 fm->pipe_threads = jm->pipe_threads;
                 fm->pipe_planar_threads = jm->pipe_planar_threads;
                 fm->pipe_small = jm->pipe_small;
+                fm->wide_waves = jm->wide_waves;
                 fm->wpb[0] = jm->wpb[0];
                 fm->wpb[1] = jm->wpb[1];
                 jm->fast = fm;

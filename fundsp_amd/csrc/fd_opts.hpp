@@ -16,6 +16,6 @@ struct LaunchOpts {
     int last_kernel = 0;
 };
 enum LastKernel { LK_NONE = 0, LK_SINGLE_WAVE = 1, LK_PIPELINE = 2, LK_PIPELINE_PLANAR = 3, LK_TIME_SPLIT = 4, LK_EVENTS = 5,
-                  LK_FDN_FRAMES = 6, LK_FDN_LINES = 7 };
+                  LK_FDN_FRAMES = 6, LK_FDN_LINES = 7, LK_WIDE_CHAIN = 8 };
 extern thread_local LaunchOpts tl_opts;  // fd_capi.hip
 }  // namespace fd

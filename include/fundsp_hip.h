@@ -126,7 +126,8 @@ int fdsp_bank_get_option(const fdsp_bank* bank, const char* name);
  * "timing" (default 1): every render records a HIP event pair around the kernel (fdsp_bank_last_kernel_ms); 0 drops
  * the pair -- a real-time host rendering one 64-frame block per call saves two event records per launch.
  * fdsp_bank_get_option(bank, "last_kernel") (read-only): the kernel family the most recent render launch took --
- * 1 single-wave, 2 pipeline, 3 planar pipeline, 4 time-split, 5 voice scheduler, 6 / 7 reverb lane-per-frame / -line. */
+ * 1 single-wave, 2 pipeline, 3 planar pipeline, 4 time-split, 5 voice scheduler, 6 / 7 reverb lane-per-frame / -line,
+ * 8 the chain of waves that renders a wide sum of generators (sumi / busi of >= 8 oscillators) on a small bank. */
 /* fdsp_bank_get_option(bank, "has_fused_mix") (read-only): 1 if fdsp_bank_process_mix has kernels for the bank's kind. */
 /* "host_zero_copy_max" (default 262144): fdsp_bank_process_host calls moving at most this many floats per direction
  * let the kernel read/write pinned host memory directly instead of staging through HBM (lower per-block latency). */

@@ -31,16 +31,21 @@ def test_wide_sum_matches_the_oracle(gpu, name):
     g = build(GR)
     V, T = 130, 64 * 6 + 13
     seeds = np.arange(V, dtype=np.uint64) * 7919 + 13
+    wide = "frame_major" not in name
     for mode in (MODE_PROCESS, MODE_TICK):
         for layout in (LAYOUT_VOICE_MINOR, LAYOUT_PLANAR):
-            b = gpu.Bank.from_graph(g, V, ring_frames=ring, sample_rate=SR)
-            b.set_seed(seeds)
-            got = run_bank(b, None, T, layout, mode)
-            for v in (0, 15, 16, 64, 129):
-                n = build(O)
-                n.set_sample_rate(SR)
-                n.set_seed(int(seeds[v]))
-                assert_bit_equal(got[v], oracle_render(n, None, T, mode), f"{name} instance {v} mode {mode} layout {layout}")
+            # a small bank takes the chain of waves (last_kernel 8); with "pipe_split" 0 the one-wave-per-voice-group kernel renders it (1)
+            for split, kernel in ((1, 8 if wide else None), (0, 1)):   # (the frame-major neighbour takes whatever the stage pipelines offer)
+                b = gpu.Bank.from_graph(g, V, ring_frames=ring, sample_rate=SR)
+                b.set_option("pipe_split", split)
+                b.set_seed(seeds)
+                got = run_bank(b, None, T, layout, mode)
+                assert kernel is None or b.get_option("last_kernel") == kernel, (name, mode, layout, split, b.get_option("last_kernel"))
+                for v in (0, 15, 16, 64, 129):
+                    n = build(O)
+                    n.set_sample_rate(SR)
+                    n.set_seed(int(seeds[v]))
+                    assert_bit_equal(got[v], oracle_render(n, None, T, mode), f"{name} instance {v} mode {mode} layout {layout} pipe_split {split}")
 
 
 def test_wide_sum_chunked_launches_and_reset(gpu):
@@ -62,3 +67,42 @@ def test_wide_sum_chunked_launches_and_reset(gpu):
         got = np.concatenate([run_bank(b, None, k, LAYOUT_VOICE_MINOR, MODE_PROCESS) for k in chunks], axis=2)
         for v in (3, 69):
             assert_bit_equal(got[v], oracle(v), f"chunked launches, instance {v}")
+
+
+def test_wide_sum_on_a_bank_that_fills_the_chip_takes_one_wave_per_voice_group(gpu):
+    """more voice groups than half the SIMDs: the chain of waves has nothing to win, render_body_wide renders (last_kernel 1); ragged bank size"""
+    build, _ = GRAPHS["sumi12_sines"]
+    V, T = 64 * 520 + 5, 64 * 2 + 3
+    b = gpu.Bank.from_graph(build(GR), V, sample_rate=SR)
+    seeds = np.arange(V, dtype=np.uint64) * 3 + 1
+    b.set_seed(seeds)
+    got = run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    assert b.get_option("last_kernel") == 1
+    for v in (0, 64 * 519 + 63, V - 1):
+        n = build(O)
+        n.set_sample_rate(SR)
+        n.set_seed(int(seeds[v]))
+        assert_bit_equal(got[v], oracle_render(n, None, T, MODE_PROCESS), f"instance {v}")
+
+
+def test_wide_sum_one_block_launches_and_fast_math(gpu):
+    """a launch of ONE block has no chain to fill (the one-wave kernel takes it); the tolerance-mode twin of a wide sum renders through the same
+    two kernels and stays within its stated tolerance of the exact bank"""
+    build, _ = GRAPHS["sumi12_sines"]
+    V = 70
+    seeds = np.arange(V, dtype=np.uint64) + 7
+    b = gpu.Bank.from_graph(build(GR), V, sample_rate=SR)
+    b.set_seed(seeds)
+    n = build(O)
+    n.set_sample_rate(SR)
+    n.set_seed(int(seeds[9]))
+    for k in range(3):
+        got = run_bank(b, None, 64, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+        assert b.get_option("last_kernel") == 1
+        assert_bit_equal(got[9], n.render_blocks(None, length=64, block=64), f"block {k}")
+    exact = gpu.Bank.from_graph(build(GR), V, sample_rate=SR)
+    fast = gpu.Bank.from_graph(build(GR), V, sample_rate=SR)
+    fast.set_option("math", gpu.MATH_FAST)
+    exact.set_seed(seeds); fast.set_seed(seeds)
+    a, f = run_bank(exact, None, 441, LAYOUT_VOICE_MINOR, MODE_PROCESS), run_bank(fast, None, 441, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    assert fast.get_option("last_kernel") == 8 and np.abs(a - f).max() <= 12 * 1e-4   # 12 unit sines, each within the mode's 1e-4 over 441 samples
