@@ -826,7 +826,7 @@ def criterion_benches(F, torch, names=None, cpu_seconds=1.0, steps=3):
                 ms = gpu_time(lambda: b.process(T, None, out, layout=F.LAYOUT_VOICE_MINOR))
                 e["last_kernel"] = b.get_option("last_kernel")
                 del b, out
-                if name == "sine":   # ... and on a bank that does not fill the chip: the chain of waves per voice group (last_kernel 8) against one wave per group (1)
+                if name == "sine":   # ... and on a small bank; both through the chain of waves per voice group (last_kernel 8) and through one wave per group (1)
                     Vs = 1024
                     bs = F.Bank.from_graph(g, Vs, sample_rate=sr)
                     bs.set_seed(seeds[:Vs])

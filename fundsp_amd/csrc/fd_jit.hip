@@ -221,11 +221,14 @@ void jit_render(JitModule* jm, float* slots, size_t stride, size_t V, const floa
             }
         }
     }
-    // A wide sum of generators at the root (fd_device.hpp WideSum): its kernels are the branch-major ones, whatever the layout -- on a bank that
-    // leaves SIMDs idle at one wave per voice group the chain of waves (render_body_wide_chain), else render_body_wide through the single-wave
-    // entry point below; the stage pipelines walk such a graph frame-major with every branch in registers.
+    // A wide sum of generators at the root (fd_device.hpp WideSum): its kernels are the branch-major ones, whatever the layout -- the chain of
+    // waves (render_body_wide_chain) for every launch of more than one block: it fills the chip from 256 voice groups on where one wave per
+    // voice group needs 1 024, and at 1 024 groups it still wins by its two waves per SIMD (the reference's 100-sine bench, ms per rendered
+    // second at 64 / 1 024 / 16 384 / 32 768 / 49 152 / 65 536 instances: 41 / 41 / 43 / 85 / 128 / 171 against 169 / 233 / 181 / 180 / 313 / 181,
+    // profiles/r06_wide_chain_probe.txt); one-block launches and "pipe_split" 0: render_body_wide through the single-wave entry point below.
+    // The stage pipelines walk such a graph frame-major with every branch in registers: never.
     const bool wide = jm->wide_waves > 0;
-    if (wide && tl_opts.pipe_split && T > 64 && (V + 63) / 64 <= (size_t)simd_count() / 2) {
+    if (wide && tl_opts.pipe_split && T > 64) {
         void* wargs[] = {&slots, &stride, &V, &outp, &T, &fstride, &aux, &ring, &ring_cap};
         hipModuleLaunchKernel(f->wide[mode][layout], (unsigned)((V + 63) / 64), 1, 1, 64u * (unsigned)jm->wide_waves, 1, 1, 0, s, wargs, nullptr);
         tl_opts.last_kernel = LK_WIDE_CHAIN;

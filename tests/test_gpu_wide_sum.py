@@ -69,20 +69,22 @@ def test_wide_sum_chunked_launches_and_reset(gpu):
             assert_bit_equal(got[v], oracle(v), f"chunked launches, instance {v}")
 
 
-def test_wide_sum_on_a_bank_that_fills_the_chip_takes_one_wave_per_voice_group(gpu):
-    """more voice groups than half the SIMDs: the chain of waves has nothing to win, render_body_wide renders (last_kernel 1); ragged bank size"""
+def test_wide_sum_on_a_bank_larger_than_the_chip(gpu):
+    """more voice groups than CUs (the chain's workgroups run in batches), ragged bank size: the chain of waves and the one-wave kernel"""
     build, _ = GRAPHS["sumi12_sines"]
     V, T = 64 * 520 + 5, 64 * 2 + 3
-    b = gpu.Bank.from_graph(build(GR), V, sample_rate=SR)
     seeds = np.arange(V, dtype=np.uint64) * 3 + 1
-    b.set_seed(seeds)
-    got = run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
-    assert b.get_option("last_kernel") == 1
-    for v in (0, 64 * 519 + 63, V - 1):
-        n = build(O)
-        n.set_sample_rate(SR)
-        n.set_seed(int(seeds[v]))
-        assert_bit_equal(got[v], oracle_render(n, None, T, MODE_PROCESS), f"instance {v}")
+    for split, kernel in ((1, 8), (0, 1)):
+        b = gpu.Bank.from_graph(build(GR), V, sample_rate=SR)
+        b.set_option("pipe_split", split)
+        b.set_seed(seeds)
+        got = run_bank(b, None, T, LAYOUT_VOICE_MINOR, MODE_PROCESS)
+        assert b.get_option("last_kernel") == kernel
+        for v in (0, 64 * 519 + 63, V - 1):
+            n = build(O)
+            n.set_sample_rate(SR)
+            n.set_seed(int(seeds[v]))
+            assert_bit_equal(got[v], oracle_render(n, None, T, MODE_PROCESS), f"instance {v} pipe_split {split}")
 
 
 def test_wide_sum_one_block_launches_and_fast_math(gpu):

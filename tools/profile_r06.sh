@@ -17,6 +17,7 @@ kt c5 python bench.py --config 5 --steps 10 --warmup 3 --cpu-seconds 0 --no-seco
 kt c4 python bench.py --config 4 --steps 10 --warmup 3 --cpu-seconds 0 --no-secondary
 kt fdn python tools/probe_fdn_generic.py
 kt rv3 python tools/probe_reverb3.py
+kt criterion python bench.py --criterion --cpu-seconds 4
 bash tools/pmc_hbm_pass.sh r06 > $OUT/pmc_hbm.log 2>&1
 WORKLOADS="rv3 fdn16 c5 c4v" bash tools/pmc_hbm_others.sh r06 > $OUT/pmc_others.log 2>&1
 rm -rf $OUT/kt_*/ $OUT/pmc_*/ 2>/dev/null
