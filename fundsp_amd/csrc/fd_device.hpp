@@ -170,27 +170,34 @@ struct VCountWords {
 };
 template <class G> struct WideSum { static constexpr bool value = false; };
 template <int N_, class X, class OP_> struct WideSum<Reduce<N_, X, OP_>> {
-    static constexpr bool value = N_ >= 8 && X::IN == 0 && X::OUT >= 1 && X::OUT <= 2;
+    static constexpr bool value = N_ >= 8 && X::IN <= 4 && X::OUT >= 1 && X::OUT <= 2;
     static constexpr int N = N_;
     static constexpr bool BUS = false;
     using Branch = X;
     using OP = OP_;
 };
 template <int N_, class X> struct WideSum<MultiBus<N_, X>> {
-    static constexpr bool value = N_ >= 8 && X::IN == 0 && X::OUT >= 1 && X::OUT <= 2;
+    static constexpr bool value = N_ >= 8 && X::IN <= 4 && X::OUT >= 1 && X::OUT <= 2;
     static constexpr int N = N_;
     static constexpr bool BUS = true;   // tick folds from a zero frame: (0 + x0) + x1 .. (audionode.rs:2117-2121)
     using Branch = X;
     using OP = OpAdd;
 };
 
+// input sample of graph channel `ch` at frame t for voice v (the branches of a MultiBus share the graph's inputs, those of a Reduce have their own:
+// branch i reads channels i X::IN ..).  Every branch re-reads the block's input rows; after the first branch they come from L2.
+template <int LAYOUT>
+FD_D float wide_in(const float* __restrict__ in, size_t ch, size_t t, size_t T, size_t V, size_t v, size_t gin, size_t fstride) {
+    return LAYOUT == LAYOUT_VOICE_MINOR ? in[(ch * T + t) * V + v] : in[(v * gin + ch) * fstride + t];
+}
+
 template <class G, int MODE, int LAYOUT, int WPB>
-FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T, size_t fstride,
-                           const void* aux, float* ring, uint32_t ring_cap) {
+FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ out, size_t T,
+                           size_t fstride, const void* aux, float* ring, uint32_t ring_cap) {
     using WS = WideSum<G>;
     using X = typename WS::Branch;
     using OP = typename WS::OP;
-    constexpr int N = WS::N, NO = X::OUT;
+    constexpr int N = WS::N, NO = X::OUT, NI = X::IN;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int vpw = (LAYOUT == LAYOUT_VOICE_MINOR && fstride > 0 && fstride < 64) ? (int)fstride : 64;   // partially filled waves of small banks, as render_body
@@ -202,6 +209,7 @@ FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, f
     // wave-level hand-over in that layout).  Planar: padding lanes (V <= v < stride) own private zeroed slot / ring columns and take part.
     if (LAYOUT == LAYOUT_VOICE_MINOR && !active) return;
     const size_t vc = v;
+    const size_t vin = v < V ? v : v0;  // planar: a padding lane reads a real voice's input rows (its samples are never stored)
     int K;  // slot words of one branch (a constant after inlining)
     {
         X probe;
@@ -237,8 +245,13 @@ FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, f
                 v2f tmp[NO][32];
 #pragma unroll
                 for (int k = 0; k < 32; k++) {
-                    v2f po[NO];
-                    x.template step2<PH_SIMD>(nullptr, po);
+                    v2f po[NO], pi[NI > 0 ? NI : 1];
+#pragma unroll
+                    for (int c = 0; c < NI; c++) {
+                        const size_t ch = WS::BUS ? c : i * NI + c;
+                        pi[c] = v2f{wide_in<LAYOUT>(in, ch, t0 + 2 * k, T, V, vin, G::IN, fstride), wide_in<LAYOUT>(in, ch, t0 + 2 * k + 1, T, V, vin, G::IN, fstride)};
+                    }
+                    x.template step2<PH_SIMD>(pi, po);
 #pragma unroll
                     for (int c = 0; c < NO; c++) tmp[c][k] = po[c];
                 }
@@ -246,8 +259,10 @@ FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, f
                     x = snap;
 #pragma unroll 1
                     for (int f = 0; f < 64; f++) {
-                        float fo[NO];
-                        x.template step<PH_SIMD>(nullptr, fo);
+                        float fo[NO], fi[NI > 0 ? NI : 1];
+#pragma unroll
+                        for (int c = 0; c < NI; c++) fi[c] = wide_in<LAYOUT>(in, WS::BUS ? c : i * NI + c, t0 + f, T, V, vin, G::IN, fstride);
+                        x.template step<PH_SIMD>(fi, fo);
 #pragma unroll
                         for (int c = 0; c < NO; c++) accl[(c * 64 + f) * 64] = fo[c];
                     }
@@ -291,12 +306,14 @@ FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, f
                 x.begin_block(size);
 #pragma unroll 1
                 for (int f = 0; f < size; f++) {
-                    float fo[NO];
+                    float fo[NO], fi[NI > 0 ? NI : 1];
+#pragma unroll
+                    for (int c = 0; c < NI; c++) fi[c] = wide_in<LAYOUT>(in, WS::BUS ? c : i * NI + c, t0 + f, T, V, vin, G::IN, fstride);
                     if (f < full) {
-                        x.template step<PH_SIMD>(nullptr, fo);
+                        x.template step<PH_SIMD>(fi, fo);
                     } else {
                         if (MODE == MODE_PROCESS && f == full) x.end_simd();
-                        x.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(nullptr, fo);
+                        x.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(fi, fo);
                     }
 #pragma unroll
                     for (int c = 0; c < NO; c++) {
@@ -349,21 +366,21 @@ FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, f
 // accumulator tile from LDS as wave w - 1 left it, folds its own branches into it in order, and leaves it for wave w + 1 (the last wave writes the
 // output).  W blocks are in flight, block k lives in tile k mod W for its whole trip, so one workgroup barrier per round hands every tile on; the fill
 // and drain of the chain cost W - 1 rounds per launch.  Same branch arithmetic, same fold, same slots traffic as render_body_wide -- bit-identical to
-// it (tests/test_gpu_wide_sum.py renders every case through both).  W = 8 mono / 4 stereo branches: W tiles of 16 / 32 KB = 128 KB of LDS, one
-// workgroup per CU, two waves per SIMD.
+// it (tests/test_gpu_wide_sum.py renders every case through both).  W = 8 for mono generators (8 tiles of 16 KB = 128 KB of LDS, one workgroup per
+// CU, two waves per SIMD), 4 for stereo branches and for branches with inputs.
 template <class G> struct WideChain {
     static constexpr bool on = WideSum<G>::value;
-    static constexpr int W = !on ? 1 : (G::OUT == 1 ? 8 : 4);
+    static constexpr int W = !on ? 1 : (G::OUT == 1 && G::IN == 0 ? 8 : 4);  // (branches with inputs keep 64 more samples in flight per block: 4 waves leave each the whole register file)
 };
 
 template <class G, int MODE, int LAYOUT>
-FD_D void render_body_wide_chain(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T, size_t fstride,
-                                 const void* aux, float* ring, uint32_t ring_cap) {
+FD_D void render_body_wide_chain(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ out,
+                                 size_t T, size_t fstride, const void* aux, float* ring, uint32_t ring_cap) {
     if constexpr (WideSum<G>::value) {
         using WS = WideSum<G>;
         using X = typename WS::Branch;
         using OP = typename WS::OP;
-        constexpr int N = WS::N, NO = X::OUT, W = WideChain<G>::W;
+        constexpr int N = WS::N, NO = X::OUT, NI = X::IN, W = WideChain<G>::W;
         const int lane = threadIdx.x & 63;
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // place in the chain
         const size_t v0 = (size_t)blockIdx.x * 64;
@@ -416,8 +433,14 @@ FD_D void render_body_wide_chain(float* __restrict__ slots, size_t stride, size_
                     v2f tmp[NO][32];
 #pragma unroll
                     for (int q = 0; q < 32; q++) {
-                        v2f po[NO];
-                        x.template step2<PH_SIMD>(nullptr, po);
+                        v2f po[NO], pi[NI > 0 ? NI : 1];
+#pragma unroll
+                        for (int c = 0; c < NI; c++) {
+                            const size_t ch = WS::BUS ? c : i * NI + c;
+                            pi[c] = active ? v2f{wide_in<LAYOUT>(in, ch, t0 + 2 * q, T, V, v, G::IN, fstride), wide_in<LAYOUT>(in, ch, t0 + 2 * q + 1, T, V, v, G::IN, fstride)}
+                                           : v2f{0.0f, 0.0f};
+                        }
+                        x.template step2<PH_SIMD>(pi, po);
 #pragma unroll
                         for (int c = 0; c < NO; c++) tmp[c][q] = po[c];
                     }
@@ -425,8 +448,10 @@ FD_D void render_body_wide_chain(float* __restrict__ slots, size_t stride, size_
                         x = snap;
 #pragma unroll 1
                         for (int f = 0; f < 64; f++) {
-                            float fo[NO];
-                            x.template step<PH_SIMD>(nullptr, fo);
+                            float fo[NO], fi[NI > 0 ? NI : 1];
+#pragma unroll
+                            for (int c = 0; c < NI; c++) fi[c] = active ? wide_in<LAYOUT>(in, WS::BUS ? c : i * NI + c, t0 + f, T, V, v, G::IN, fstride) : 0.0f;
+                            x.template step<PH_SIMD>(fi, fo);
 #pragma unroll
                             for (int c = 0; c < NO; c++) accl[(c * 64 + f) * 64] = fo[c];
                         }
@@ -469,12 +494,14 @@ FD_D void render_body_wide_chain(float* __restrict__ slots, size_t stride, size_
                     x.begin_block(size);
 #pragma unroll 1
                     for (int f = 0; f < size; f++) {
-                        float fo[NO];
+                        float fo[NO], fi[NI > 0 ? NI : 1];
+#pragma unroll
+                        for (int c = 0; c < NI; c++) fi[c] = active ? wide_in<LAYOUT>(in, WS::BUS ? c : i * NI + c, t0 + f, T, V, v, G::IN, fstride) : 0.0f;
                         if (f < full) {
-                            x.template step<PH_SIMD>(nullptr, fo);
+                            x.template step<PH_SIMD>(fi, fo);
                         } else {
                             if (MODE == MODE_PROCESS && f == full) x.end_simd();
-                            x.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(nullptr, fo);
+                            x.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(fi, fo);
                         }
 #pragma unroll
                         for (int c = 0; c < NO; c++) {
@@ -761,7 +788,7 @@ FD_D void render_body(float* __restrict__ slots, size_t stride, size_t V, const 
                       float* __restrict__ out, size_t T, size_t fstride, const void* aux, float* ring,
                       uint32_t ring_cap) {
     if constexpr (WideSum<G>::value)  // a wide sum of generators at the root: branch-major blocks (above)
-        render_body_wide<G, MODE, LAYOUT, WPB>(slots, stride, V, out, T, fstride, aux, ring, ring_cap);
+        render_body_wide<G, MODE, LAYOUT, WPB>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
     else
         render_body_frames<G, MODE, LAYOUT, WPB>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
 }

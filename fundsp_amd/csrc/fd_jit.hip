@@ -229,7 +229,7 @@ void jit_render(JitModule* jm, float* slots, size_t stride, size_t V, const floa
     // The stage pipelines walk such a graph frame-major with every branch in registers: never.
     const bool wide = jm->wide_waves > 0;
     if (wide && tl_opts.pipe_split && T > 64) {
-        void* wargs[] = {&slots, &stride, &V, &outp, &T, &fstride, &aux, &ring, &ring_cap};
+        void* wargs[] = {&slots, &stride, &V, &in, &outp, &T, &fstride, &aux, &ring, &ring_cap};
         hipModuleLaunchKernel(f->wide[mode][layout], (unsigned)((V + 63) / 64), 1, 1, 64u * (unsigned)jm->wide_waves, 1, 1, 0, s, wargs, nullptr);
         tl_opts.last_kernel = LK_WIDE_CHAIN;
         return;
@@ -294,8 +294,8 @@ std::string jit_source(const std::string& type_expr, const std::string& prelude)
         for (int layout = 0; layout < 2; layout++) {
             std::string m = std::to_string(mode), l = std::to_string(layout);
             s += "extern \"C\" __global__ __launch_bounds__(64 * fd::WideChain<JitG>::W) void jit_wide_" + m + l +
-                 "(float* __restrict__ slots, size_t stride, size_t V, float* __restrict__ out, size_t T, size_t fstride, const void* aux, "
-                 "float* ring, uint32_t cap) {\n  fd::render_body_wide_chain<JitG, " + m + ", " + l + ">(slots, stride, V, out, T, fstride, aux, ring, cap); }\n";
+                 "(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ out, size_t T, size_t fstride, "
+                 "const void* aux, float* ring, uint32_t cap) {\n  fd::render_body_wide_chain<JitG, " + m + ", " + l + ">(slots, stride, V, in, out, T, fstride, aux, ring, cap); }\n";
         }
     s += "constexpr int JIT_PIPE_THREADS = fd::JitPipeThreads<JitG>::v;\n";
     for (int mode = 0; mode < 2; mode++) {

@@ -9,7 +9,7 @@ import pytest
 import oracle as O
 from fundsp_amd import LAYOUT_PLANAR, LAYOUT_VOICE_MINOR, MODE_PROCESS, MODE_TICK
 from fundsp_amd import graph as GR
-from test_gpu_parity import assert_bit_equal, oracle_render, run_bank
+from test_gpu_parity import assert_bit_equal, noise_input, oracle_render, run_bank
 
 pytestmark = pytest.mark.gpu
 SR = 48000.0
@@ -22,6 +22,10 @@ GRAPHS = {
     "sumi8_panned": (lambda m: m.sumi(8, lambda i: m.sine_hz(100.0 * (i + 1)) >> m.pan(-0.7 + 0.2 * i)), 0),   # two channels per branch
     "sumi10_one_trips": (lambda m: m.sumi(10, lambda i: m.sine_hz(3.0e6 if i == 4 else 200.0 * (i + 1))), 0),  # branch 4 leaves the packed sine's domain every block
     "sumi7_sines_frame_major": (lambda m: m.sumi(7, lambda i: m.sine_hz(55.0 * (i + 1))), 0),          # below the threshold: the frame-major walk
+    # branches WITH inputs: a MultiBus hands every branch the graph's inputs, a Reduce gives every branch its own
+    "busi20_harmonics_of_an_input": (lambda m: m.busi(20, lambda i: m.mul(float(i + 1)) >> m.sine()), 0),   # README.md:1152: input = frequency
+    "sumi8_lowpasses_own_inputs": (lambda m: m.sumi(8, lambda i: m.lowpass_hz(150.0 * (i + 1), 1.0 + 0.25 * i)), 0),
+    "busi10_resonators_panned": (lambda m: m.busi(10, lambda i: m.resonator_hz(300.0 * (i + 1), 25.0) >> m.pan(-0.9 + 0.2 * i)), 0),   # 1 in, 2 out
 }
 
 
@@ -31,6 +35,11 @@ def test_wide_sum_matches_the_oracle(gpu, name):
     g = build(GR)
     V, T = 130, 64 * 6 + 13
     seeds = np.arange(V, dtype=np.uint64) * 7919 + 13
+    x = None
+    if g.nin:
+        x = noise_input(V, g.nin, T, seed=5)
+        if "harmonics" in name:
+            x = (np.abs(x) * np.float32(300.0) + np.float32(40.0)).astype(np.float32)   # a frequency input
     wide = "frame_major" not in name
     for mode in (MODE_PROCESS, MODE_TICK):
         for layout in (LAYOUT_VOICE_MINOR, LAYOUT_PLANAR):
@@ -39,13 +48,13 @@ def test_wide_sum_matches_the_oracle(gpu, name):
                 b = gpu.Bank.from_graph(g, V, ring_frames=ring, sample_rate=SR)
                 b.set_option("pipe_split", split)
                 b.set_seed(seeds)
-                got = run_bank(b, None, T, layout, mode)
+                got = run_bank(b, x, T, layout, mode)
                 assert kernel is None or b.get_option("last_kernel") == kernel, (name, mode, layout, split, b.get_option("last_kernel"))
                 for v in (0, 15, 16, 64, 129):
                     n = build(O)
                     n.set_sample_rate(SR)
                     n.set_seed(int(seeds[v]))
-                    assert_bit_equal(got[v], oracle_render(n, None, T, mode), f"{name} instance {v} mode {mode} layout {layout} pipe_split {split}")
+                    assert_bit_equal(got[v], oracle_render(n, None if x is None else x[v], T, mode), f"{name} instance {v} mode {mode} layout {layout} pipe_split {split}")
 
 
 def test_wide_sum_chunked_launches_and_reset(gpu):
