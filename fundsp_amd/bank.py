@@ -532,6 +532,19 @@ class Chain:
     def get_option(self, name):
         return self.effect.get_option(name)
 
+    def set_option(self, name, value):
+        self.source.set_option(name, value)
+        self.effect.set_option(name, value)
+
+    def clone(self):
+        """AudioNode: Clone -- both halves continue exactly where they stand"""
+        c = Chain(self.source.clone(), self.effect.clone())
+        c._ctor, c.sample_rate = self._ctor, self.sample_rate
+        return c
+
+    def last_kernel_ms(self):
+        return self.source.last_kernel_ms() + self.effect.last_kernel_ms()
+
     def synchronize(self):
         self.source.synchronize()
         self.effect.synchronize()

@@ -39,6 +39,9 @@ def main():
     np.savez_compressed(os.path.join(HERE, "graphs_v1.npz"), **gv)
     print("wrote", os.path.join(HERE, "graphs_v1.npz"))
     harness_inputs(p2, p3, gv)
+    cv = criterion_vectors()
+    np.savez_compressed(os.path.join(HERE, "criterion_v1.npz"), **cv)
+    print("wrote", os.path.join(HERE, "criterion_v1.npz"))
 
 
 def kat_args():
@@ -125,6 +128,30 @@ def graph_vectors():
             n.set_seed(12345)
             xin = x[:ni] if ni else None
             out[f"{name}__{mode}"] = n.render_blocks(xin, length=GRAPH_FRAMES) if mode == "process" else n.render_ticks(xin, length=GRAPH_FRAMES)
+    return out
+
+
+CRITERION_WINDOWS = {"limiter": (4352, 5440)}   # (the limiter looks 4 410 frames ahead: silence before); every other bench: the first 1 088 frames
+
+
+def criterion_vectors():
+    """The reference's own bench graphs (benches/benchmark.rs; tests/criterion_graphs.py) at 44.1 kHz: a window of the second each bench renders,
+    AS CONSTRUCTED (no set_seed: the hashes the constructors' pings hand down -- the reverb bench pins the walk of the tree the oracle's
+    reverb_stereo node stands for) and after set_seed(7), process executor; the first 300 frames in the tick executor."""
+    import criterion_graphs as CG
+
+    out = {}
+    for name in CG.table(O, O):
+        a, b = CRITERION_WINDOWS.get(name, (0, 1088))
+        for tag, seed in (("ctor", None), ("seed7", 7)):
+            n = CG.table(O, O)[name][0]
+            n.set_sample_rate(CG.SAMPLE_RATE)
+            if seed is not None:
+                n.set_seed(seed)
+            out[f"{name}__{tag}__process"] = n.render_blocks(None, length=b, block=64)[:, a:b]
+        n = CG.table(O, O)[name][0]
+        n.set_sample_rate(CG.SAMPLE_RATE)
+        out[f"{name}__ctor__tick"] = n.render_ticks(None, length=300)
     return out
 
 

@@ -108,6 +108,11 @@ def test_reverb_bench_as_a_chain_of_two_banks(gpu):
     n = _oracle("reverb", seeds[5])
     w2 = np.concatenate([n.render_blocks(None, length=1000, block=64), n.render_blocks(None, length=T - 1000, block=64)], axis=1)
     assert_bit_equal(np.concatenate([a, b2], axis=2)[5], w2, "chunked launches, instance 5")
+    # Clone in mid-tail: the clone and the original continue alike
+    ch.reset(); ch.set_seed(seeds)
+    planar(ch, MODE_PROCESS)
+    twin = ch.clone()
+    assert_bit_equal(planar(twin, MODE_PROCESS), planar(ch, MODE_PROCESS), "clone continues like the original")
     # a chain put together by the host: two stand-alone nodes piped by hand
     src = gpu.Bank.from_graph(GR.noise() | GR.noise(), V, sample_rate=CG.SAMPLE_RATE)
     rev = gpu.Bank.from_graph(GR.reverb_stereo(10.0, 1.0, 0.5), V, sample_rate=CG.SAMPLE_RATE)
