@@ -3205,17 +3205,17 @@ struct Limiter {
     // order); per update one leaf store + on average one load and one store instead of 13 + 14 for the reference bench's 4 410-frame window:
     // 119 -> ~45 ms per rendered second of 65 536 instances (the kernel was bound by the scattered 256-byte rows of that traffic, not by latency:
     // more waves per SIMD made it slower).
-    FD_HD float tree_set_inc(uint32_t i, float value) {
+    template <int LV> FD_HD float tree_set_inc(uint32_t i, float value) {  // LV: levels unrolled (>= the tree's height below the root)
         const uint32_t ip = prev ? prev : i;  // the first update after a clear leaves nothing behind (all-zero tree, all-zero caches)
         const uint32_t x = i ^ ip;
         const int h = x ? 31 - __builtin_clz(x) : -1;
-        float ld[MAXL];
-        _Pragma("unroll") for (int l = 0; l < MAXL; l++) ld[l] = (l < h) ? tree[(size_t)((i >> l) ^ 1u) * vs] : 0.0f;
-        _Pragma("unroll") for (int l = 1; l < MAXL; l++)
+        float ld[LV];
+        _Pragma("unroll") for (int l = 0; l < LV; l++) ld[l] = (l < h) ? tree[(size_t)((i >> l) ^ 1u) * vs] : 0.0f;
+        _Pragma("unroll") for (int l = 1; l < LV; l++)
             if (l <= h) tree[(size_t)(ip >> l) * vs] = pv[l];
         tree[(size_t)i * vs] = value;
         float cur = value;
-        _Pragma("unroll") for (int l = 0; l < MAXL; l++) {
+        _Pragma("unroll") for (int l = 0; l < LV; l++) {
             if ((i >> l) > 1u) {  // level l is below the root
                 const float s = l < h ? ld[l] : (l == h ? pv[l] : sv[l]);
                 pv[l] = cur;
@@ -3228,7 +3228,8 @@ struct Limiter {
     }
     FD_HD float tree_set(uint32_t idx, float value) {
         const uint32_t i = leaf + idx;
-        if (leaf > 256u && leaf <= (1u << MAXL)) return tree_set_inc(i, value);
+        if (leaf > 256u && leaf <= (1u << MAXL))  // (branches on the tree's height: uniform unless voices differ in attack time)
+            return leaf <= (1u << 10) ? tree_set_inc<10>(i, value) : leaf <= (1u << 13) ? tree_set_inc<13>(i, value) : leaf <= (1u << 16) ? tree_set_inc<16>(i, value) : tree_set_inc<MAXL>(i, value);
         tree[(size_t)i * vs] = value;
         return leaf > 256u ? tree_walk<16>(i, value) : tree_walk<8>(i, value);
     }
