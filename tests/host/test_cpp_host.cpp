@@ -252,6 +252,36 @@ static void gpu_checks() {
         }
         o_free(n);
     }
+    // the reference's own `reverb` bench, (noise() | noise()) >> reverb_stereo(10.0, 1.0, 0.5) at 44.1 kHz (benches/benchmark.rs:79-85), as a Chain of two
+    // banks -- the generator's fused kernel, the network's lane-per-frame kernel -- against the oracle's ONE graph: as constructed (the hash Pipe::new's
+    // probe ping hands down, read from the device by probe_hash) and after set_seed, block by block until the tail sounds
+    {
+        const size_t V = 2;
+        const double R = 44100.0;
+        const An whole = (noise() | noise()) >> reverb_stereo(10.0, 1.0, 0.5);
+        Bank rev = Bank::reverb_stereo(V, 10.0, 1.0, 0.5);
+        rev.set_sample_rate(R);
+        Chain ch(Bank::from_graph(noise() | noise(), V, 0, R), std::move(rev), &whole);
+        EXPECT(ch.inputs() == 0 && ch.outputs() == 2 && ch.voices() == V);
+        onode* n = o_pipe(o_stack(o_noise(), o_noise()), o_reverb_stereo(10.0, 1.0, 0.5));
+        o_set_sample_rate(n, R);
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1) {
+                ch.reset();
+                ch.set_seed(77);
+                o_reset(n);
+                o_set_seed(n, 77);
+            }
+            for (int blk = 0; blk < 60; blk++) {   // 3 840 frames: past the longest line's first return
+                std::vector<float> got(V * 2 * 64), want(2 * 64);
+                ch.process(64, nullptr, got.data());
+                o_process(n, 64, nullptr, want.data());
+                if (!bit_equal(got.data(), want.data(), 128, pass ? "chain after set_seed, instance 0" : "chain as constructed, instance 0")) break;
+                if (!bit_equal(got.data() + 128, want.data(), 128, pass ? "chain after set_seed, instance 1" : "chain as constructed, instance 1")) break;
+            }
+        }
+        o_free(n);
+    }
     // a filter with an input: noise through the C ABI, the same samples through the oracle
     {
         Bank b("fixed_svf", 1);
