@@ -3108,7 +3108,7 @@ struct Limiter {
     AFollow follower;
     uint32_t length, leaf, index, fill;
     float last_sr;
-    // long windows (leaf_offset > 256): the walk is INCREMENTAL -- the values of the last update's path and of its siblings stay in registers
+    // windows of four frames and more: the walk is INCREMENTAL -- the values of the last update's path and of its siblings stay in registers
     // (slots between launches), see tree_set_inc
     static constexpr int MAXL = 20;
     float pv[MAXL], sv[MAXL];
@@ -3195,7 +3195,7 @@ struct Limiter {
         }
         return cur;
     }
-    // ... and for long windows not even that.  Consecutive updates touch neighbouring leaves: the new path shares every node above level h (the
+    // ... and not even that (windows of four frames and more).  Consecutive updates touch neighbouring leaves: the new path shares every node above level h (the
     // highest bit in which the two leaf indices differ) with the previous one, so above h the siblings are the previous update's siblings, AT h the
     // sibling is the previous path's node, and only below h -- h is the number of trailing zeros of an incremented index: one level on average -- are
     // the siblings nodes this lap has not reached yet, final since the last lap, to be loaded.  The nodes the path LEAVES (the previous path's levels
@@ -3228,9 +3228,10 @@ struct Limiter {
     }
     FD_HD float tree_set(uint32_t idx, float value) {
         const uint32_t i = leaf + idx;
-        if (leaf > 256u && leaf <= (1u << MAXL))  // (branches on the tree's height: uniform unless voices differ in attack time)
-            return leaf <= (1u << 10) ? tree_set_inc<10>(i, value) : leaf <= (1u << 13) ? tree_set_inc<13>(i, value) : leaf <= (1u << 16) ? tree_set_inc<16>(i, value) : tree_set_inc<MAXL>(i, value);
-        tree[(size_t)i * vs] = value;
+        if (leaf >= 4u && leaf <= (1u << MAXL))  // (branches on the tree's height: uniform unless voices differ in attack time)
+            return leaf <= (1u << 7) ? tree_set_inc<7>(i, value) : leaf <= (1u << 10) ? tree_set_inc<10>(i, value) : leaf <= (1u << 13) ? tree_set_inc<13>(i, value)
+                   : leaf <= (1u << 16) ? tree_set_inc<16>(i, value) : tree_set_inc<MAXL>(i, value);
+        tree[(size_t)i * vs] = value;  // windows of one to three frames, and of more than 2^20: the walk level by level
         return leaf > 256u ? tree_walk<16>(i, value) : tree_walk<8>(i, value);
     }
     template <int PH> FD_HD void step(const float* in, float* out) {  // tick :202-226

@@ -326,10 +326,10 @@ def test_lfo2_envelope_in(gpu, mode):
 
 
 def test_limiter_long_windows_walk_the_tree_incrementally(gpu):
-    """Limiter windows longer than 256 frames update their reduce tree incrementally (path and sibling values in registers / slots, the nodes the path
-    leaves written when it leaves them: fd_nodes.hpp tree_set_inc).  Per-voice attack times -- windows of 290 .. 2 400 frames, so the lanes of a wave
-    sit at different tree indices with different tree heights, some below the 256-frame threshold in the same wave --, several laps of every window
-    over three launches, a clone taken in mid-stream, a reset: every voice bit-equal to the oracle's ReduceBuffer walk."""
+    """Limiter windows update their reduce tree incrementally (path and sibling values in registers / slots, the nodes the path leaves written when it
+    leaves them: fd_nodes.hpp tree_set_inc).  Per-voice attack times -- windows of 192 .. 2 400 frames, so the lanes of a wave sit at different tree
+    indices in trees of different heights (two specialisations of the walk in one wave) --, several laps of every window over three launches, a clone
+    taken in mid-stream, a reset: every voice bit-equal to the oracle's ReduceBuffer walk."""
     from fundsp_amd import graph as GR
 
     V = 70
@@ -356,7 +356,7 @@ def test_limiter_long_windows_walk_the_tree_incrementally(gpu):
     rest_t.append(run_bank(twin, x[:, :, at:], chunks[2], LAYOUT_PLANAR, MODE_PROCESS))
     got = np.concatenate([first] + rest_b, axis=2)
     assert_bit_equal(np.concatenate([first] + rest_t, axis=2), got, "the clone continues like the original (other executor / layout)")
-    for v in (0, 5, 6, 33, 69):   # (voices 0..5 have windows below the threshold: the per-level walk, in the same wave)
+    for v in (0, 5, 6, 33, 69):
         n = O.pass_() * 2.5 >> O.limiter(float(attack[v]), 0.05)
         n.set_sample_rate(SR)
         want = np.concatenate([n.render_blocks(x[v][:, a:a + k], block=64) for a, k in ((0, chunks[0]), (3000, chunks[1]), (at, chunks[2]))], axis=1)
