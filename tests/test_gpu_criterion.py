@@ -113,6 +113,12 @@ def test_reverb_bench_as_a_chain_of_two_banks(gpu):
     planar(ch, MODE_PROCESS)
     twin = ch.clone()
     assert_bit_equal(planar(twin, MODE_PROCESS), planar(ch, MODE_PROCESS), "clone continues like the original")
+    # a handful of instances (below the network bank's staging threshold): voice-minor buffers gathered directly
+    few = gpu.Bank.from_graph(g, 3, sample_rate=CG.SAMPLE_RATE)
+    assert isinstance(few, gpu.Chain)
+    out3 = few.process(T)
+    torch.cuda.synchronize()
+    assert_bit_equal(out3.cpu().numpy()[:, :, 2], want, "three instances, voice-minor, as constructed")
     # a chain put together by the host: two stand-alone nodes piped by hand
     src = gpu.Bank.from_graph(GR.noise() | GR.noise(), V, sample_rate=CG.SAMPLE_RATE)
     rev = gpu.Bank.from_graph(GR.reverb_stereo(10.0, 1.0, 0.5), V, sample_rate=CG.SAMPLE_RATE)
