@@ -148,17 +148,21 @@ FD_D void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// ---- wide sums of generators: branch-major blocks -------------------------------------------------------------
-// Reduce<N, X, OP> / MultiBus<N, X> over N input-free branches of one type (sumi / busi of oscillators -- additive synthesis; the reference's
-// own `sine` bench is sumi::<U100>(sine_hz(100 (i + 1))), benches/benchmark.rs:4-10).  Frame-major, the way render_body walks every other
-// graph, such a node keeps the state of all N branches in registers: 100 sines are 700 words per lane, the compiler parks them in scratch
-// memory and the loop pays for it per frame (measured: 1.29 s per rendered second, whatever the bank size).  The reference's process()
-// walks it the other way round (audionode.rs:2406-2462, 2123-2134): one 64-frame block of branch 0, then of branch 1 folded into it, ...
-// The branches take no input, so they do not see each other: branch-major and frame-major give every branch the same samples and every
-// output frame the same left fold.  Here: per 64-frame block and branch, load the branch's slots, render the block into registers (packed
-// path, 32 frame pairs, rollback to the scalar path if a guard trips), fold into the accumulator, store the branch's state.  The
-// accumulator lives in registers for whole process blocks and in LDS (one column per lane, [channel][frame][lane]: conflict-free, any frame
-// index) for the ragged last block, the tick executor and the rollback.
+// ---- wide sums: branch-major blocks ---------------------------------------------------------------------------
+// Reduce<N, X, OP> / MultiBus<N, X> over N >= 8 branches of one type (sumi / busi of oscillators -- additive synthesis; the reference's own `sine`
+// bench is sumi::<U100>(sine_hz(100 (i + 1))), benches/benchmark.rs:4-10 --, of filters on a shared or on their own inputs).  Frame-major, the way
+// render_body_frames walks every other graph, such a node keeps the state of all N branches in registers: 100 sines are 700 words per lane, the compiler
+// parks them in scratch memory and the loop pays for it per frame (measured: 1.29 s per rendered second, whatever the bank size).  The reference's
+// process() walks it the other way round (audionode.rs:2406-2462, 2123-2134): one 64-frame block of branch 0, then of branch 1 folded into it, ...
+// The branches do not see each other, so branch-major and frame-major give every branch the same samples and every output frame the same left fold.
+// Here: per 64-frame block and branch, load the branch's slots, render the block into registers (packed path, 32 frame pairs, rollback to the scalar
+// path if a guard trips), fold into the accumulator, store the branch's state.  The accumulator lives in registers for whole process blocks and in LDS
+// (one column per lane, [channel][frame][lane]: conflict-free, any frame index) for the ragged last block, the tick executor and the rollback.
+//
+// The sum need not be the whole graph: it may sit at the HEAD of a chain of Pipe / Unop nodes -- sumi(..) * 0.01 >> lowpass_hz(..) >> pan(..), an
+// additive voice with its gain, filter and panner (WideSplit below).  The rest of the graph, its TAIL, is the same type with MultiPass in the sum's place:
+// it walks the accumulated block frame-major, its state in registers for the whole launch (in the wave that finishes the fold), and produces the output.
+// The sum's slots (and delay rings) come first in the graph's visit order, the tail's follow.
 struct VCountWords {
     int n = 0;
     FD_D void f(float&, FieldKind, const char*) { n++; }
@@ -183,6 +187,28 @@ template <int N_, class X> struct WideSum<MultiBus<N_, X>> {
     using Branch = X;
     using OP = OpAdd;
 };
+// G = a wide sum (Head) followed by a Tail: Head at the left end of a spine of Pipe / Unop nodes
+template <class G> struct WideSplit {
+    static constexpr bool ok = WideSum<G>::value;
+    using Head = G;
+    using Tail = MultiPass<(G::OUT > 0 ? G::OUT : 1)>;
+};
+template <class X, class Y> struct WideSplit<Pipe<X, Y>> {
+    static constexpr bool ok = WideSplit<X>::ok && Y::OUT >= 1 && Y::OUT <= 2;
+    using Head = typename WideSplit<X>::Head;
+    using Tail = Pipe<typename WideSplit<X>::Tail, Y>;
+};
+template <class X, class U> struct WideSplit<Unop<X, U>> {
+    static constexpr bool ok = WideSplit<X>::ok;
+    using Head = typename WideSplit<X>::Head;
+    using Tail = Unop<typename WideSplit<X>::Tail, U>;
+};
+template <class G> struct WideGeom {  // channels a block tile holds: the sum's, or the tail's if it has more (mono sum >> pan)
+    using H = typename WideSplit<G>::Head;
+    static constexpr bool ok = WideSplit<G>::ok;
+    static constexpr bool BARE = SameType<G, H>::v;
+    static constexpr int NO = H::OUT, TO = G::OUT, C = NO > TO ? NO : TO;
+};
 
 // input sample of graph channel `ch` at frame t for voice v (the branches of a MultiBus share the graph's inputs, those of a Reduce have their own:
 // branch i reads channels i X::IN ..).  Every branch re-reads the block's input rows; after the first branch they come from L2.
@@ -191,16 +217,234 @@ FD_D float wide_in(const float* __restrict__ in, size_t ch, size_t t, size_t T, 
     return LAYOUT == LAYOUT_VOICE_MINOR ? in[(ch * T + t) * V + v] : in[(v * gin + ch) * fstride + t];
 }
 
+// One 64-frame block of the branches [b0, b1) of the sum folded into the block's accumulator -- registers `acc` for a whole process block (FAST), else
+// the LDS column `accl` ([(channel * 64 + frame) * 64]) in place.  `first`: branch 0 starts the fold.  `iv`: the voice whose input rows this lane reads,
+// `live`: whether it may (lanes past the end of the bank read nothing).
+template <class G, int MODE, int LAYOUT, bool FAST, class ACC>
+FD_D void wide_fold(int b0, int b1, int K, float* __restrict__ slots, size_t stride, size_t V, size_t v, bool active, size_t iv, bool live,
+                    const float* __restrict__ in, size_t T, size_t fstride, size_t t0, int size, const void* aux, float* ring, uint32_t ring_cap,
+                    ACC& acc, float* accl) {
+    using H = typename WideSplit<G>::Head;
+    using WS = WideSum<H>;
+    using X = typename WS::Branch;
+    using OP = typename WS::OP;
+    constexpr int NO = X::OUT, NI = X::IN;
+    const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
+#pragma unroll 1
+    for (int i = b0; i < b1; i++) {
+        X x;
+        {
+            Ctx ctx{static_cast<const Aux*>(aux), ring + v, ring_cap, stride, i * X::RINGS};
+            x.bind(ctx);
+            VLoad ld{slots + v, stride, i * K};
+            x.visit(ld);
+        }
+        x.begin_block(size);
+        if constexpr (FAST) {
+            const X snap = x;
+            v2f tmp[NO][32];
+#pragma unroll
+            for (int q = 0; q < 32; q++) {
+                v2f po[NO], pi[NI > 0 ? NI : 1];
+#pragma unroll
+                for (int c = 0; c < NI; c++) {
+                    const size_t ch = WS::BUS ? c : i * NI + c;
+                    pi[c] = live ? v2f{wide_in<LAYOUT>(in, ch, t0 + 2 * q, T, V, iv, H::IN, fstride), wide_in<LAYOUT>(in, ch, t0 + 2 * q + 1, T, V, iv, H::IN, fstride)}
+                                 : v2f{0.0f, 0.0f};
+                }
+                x.template step2<PH_SIMD>(pi, po);
+#pragma unroll
+                for (int c = 0; c < NO; c++) tmp[c][q] = po[c];
+            }
+            if (__builtin_expect(x.tripped(), 0)) {  // a packed-path shortcut left its exact domain: this branch's block again, scalar (the column is free: the accumulator is in registers)
+                x = snap;
+#pragma unroll 1
+                for (int f = 0; f < 64; f++) {
+                    float fo[NO], fi[NI > 0 ? NI : 1];
+#pragma unroll
+                    for (int c = 0; c < NI; c++) fi[c] = live ? wide_in<LAYOUT>(in, WS::BUS ? c : i * NI + c, t0 + f, T, V, iv, H::IN, fstride) : 0.0f;
+                    x.template step<PH_SIMD>(fi, fo);
+#pragma unroll
+                    for (int c = 0; c < NO; c++) accl[(c * 64 + f) * 64] = fo[c];
+                }
+#pragma unroll
+                for (int c = 0; c < NO; c++)
+#pragma unroll
+                    for (int q = 0; q < 32; q++) tmp[c][q] = v2f{accl[(c * 64 + 2 * q) * 64], accl[(c * 64 + 2 * q + 1) * 64]};
+            }
+            x.end_simd();
+#pragma unroll
+            for (int c = 0; c < NO; c++)
+#pragma unroll
+                for (int q = 0; q < 32; q++) acc[c][q] = i == 0 ? tmp[c][q] : OP::f(acc[c][q], tmp[c][q]);
+        } else {
+#pragma unroll 1
+            for (int f = 0; f < size; f++) {
+                float fo[NO], fi[NI > 0 ? NI : 1];
+#pragma unroll
+                for (int c = 0; c < NI; c++) fi[c] = live ? wide_in<LAYOUT>(in, WS::BUS ? c : i * NI + c, t0 + f, T, V, iv, H::IN, fstride) : 0.0f;
+                if (f < full) {
+                    x.template step<PH_SIMD>(fi, fo);
+                } else {
+                    if (MODE == MODE_PROCESS && f == full) x.end_simd();
+                    x.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(fi, fo);
+                }
+#pragma unroll
+                for (int c = 0; c < NO; c++) {
+                    float* a = &accl[(c * 64 + f) * 64];
+                    *a = i == 0 ? ((WS::BUS && MODE == MODE_TICK) ? 0.0f + fo[c] : fo[c]) : OP::f(*a, fo[c]);
+                }
+            }
+            if (MODE == MODE_PROCESS && full == size) x.end_simd();
+        }
+        if (active) {
+            VStore<false> st{slots + v, stride, i * K};
+            x.visit(st);
+        }
+    }
+}
+
+// The finished fold of one block -> the graph's output: through the tail (if the sum is not the whole graph), then to HBM.  Voice-minor: straight from
+// registers / the lane's column; planar: through the tile `tile0` ([channel][frame][voice]), transposed.  `acc` (FAST) or the column `accl` hold the sum.
+template <class G, int MODE, int LAYOUT, bool FAST, class ACC, class TAIL>
+FD_D void wide_finish(TAIL& tail, ACC& acc, float* accl, float* tile0, float* __restrict__ out, size_t T, size_t V, size_t v0, size_t v, bool active,
+                      int lane, size_t fstride, size_t t0, int size) {
+    using GEO = WideGeom<G>;
+    constexpr int NO = GEO::NO, TO = GEO::TO;
+    const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
+    if constexpr (FAST) {
+        v2f res[TO][32];
+        if constexpr (GEO::BARE) {
+#pragma unroll
+            for (int c = 0; c < TO; c++)
+#pragma unroll
+                for (int q = 0; q < 32; q++) res[c][q] = acc[c][q];
+        } else {
+            tail.begin_block(64);
+            const TAIL snap = tail;
+#pragma unroll
+            for (int q = 0; q < 32; q++) {
+                v2f pi[NO], po[TO];
+#pragma unroll
+                for (int c = 0; c < NO; c++) pi[c] = acc[c][q];
+                tail.template step2<PH_SIMD>(pi, po);
+#pragma unroll
+                for (int c = 0; c < TO; c++) res[c][q] = po[c];
+            }
+            if (__builtin_expect(tail.tripped(), 0)) {  // the tail's packed path left its exact domain: its block again, scalar, through the column
+                tail = snap;
+#pragma unroll
+                for (int c = 0; c < NO; c++)
+#pragma unroll
+                    for (int q = 0; q < 32; q++) {
+                        accl[(c * 64 + 2 * q) * 64] = acc[c][q].x;
+                        accl[(c * 64 + 2 * q + 1) * 64] = acc[c][q].y;
+                    }
+#pragma unroll 1
+                for (int f = 0; f < 64; f++) {
+                    float fi[NO], fo[TO];
+#pragma unroll
+                    for (int c = 0; c < NO; c++) fi[c] = accl[(c * 64 + f) * 64];
+                    tail.template step<PH_SIMD>(fi, fo);
+#pragma unroll
+                    for (int c = 0; c < TO; c++) accl[(c * 64 + f) * 64] = fo[c];   // (frame f's inputs are consumed: TO >= NO columns exist)
+                }
+#pragma unroll
+                for (int c = 0; c < TO; c++)
+#pragma unroll
+                    for (int q = 0; q < 32; q++) res[c][q] = v2f{accl[(c * 64 + 2 * q) * 64], accl[(c * 64 + 2 * q + 1) * 64]};
+            }
+            tail.end_simd();
+        }
+        if (LAYOUT == LAYOUT_VOICE_MINOR) {
+            if (active) {
+#pragma unroll
+                for (int c = 0; c < TO; c++)
+#pragma unroll
+                    for (int q = 0; q < 32; q++) {
+                        out[((size_t)c * T + t0 + 2 * q) * V + v] = res[c][q].x;
+                        out[((size_t)c * T + t0 + 2 * q + 1) * V + v] = res[c][q].y;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < TO; c++)
+#pragma unroll
+                for (int q = 0; q < 32; q++) {
+                    accl[(c * 64 + 2 * q) * 64] = res[c][q].x;
+                    accl[(c * 64 + 2 * q + 1) * 64] = res[c][q].y;
+                }
+        }
+    } else {
+        if constexpr (!GEO::BARE) {
+            tail.begin_block(size);
+#pragma unroll 1
+            for (int f = 0; f < size; f++) {
+                float fi[NO], fo[TO];
+#pragma unroll
+                for (int c = 0; c < NO; c++) fi[c] = accl[(c * 64 + f) * 64];
+                if (f < full) {
+                    tail.template step<PH_SIMD>(fi, fo);
+                } else {
+                    if (MODE == MODE_PROCESS && f == full) tail.end_simd();
+                    tail.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(fi, fo);
+                }
+#pragma unroll
+                for (int c = 0; c < TO; c++) accl[(c * 64 + f) * 64] = fo[c];
+            }
+            if (MODE == MODE_PROCESS && full == size) tail.end_simd();
+        }
+        if (LAYOUT == LAYOUT_VOICE_MINOR && active) {
+            for (int f = 0; f < size; f++)
+#pragma unroll
+                for (int c = 0; c < TO; c++) out[((size_t)c * T + t0 + f) * V + v] = accl[(c * 64 + f) * 64];
+        }
+    }
+    if (LAYOUT == LAYOUT_PLANAR) {  // tile [channel][frame][lane = voice] -> global [voice][channel][frame]: a lane writes 4 consecutive frames of one voice
+        wave_sync();
+        const int sub = lane >> 4, fr = (lane & 15) << 2;
+        const bool vec = ((fstride & 3) == 0) && ((((uintptr_t)out) & 15) == 0) && (t0 + 64 <= fstride);
+#pragma unroll
+        for (int c = 0; c < TO; c++)
+            for (int rr = 0; rr < 16; rr++) {
+                const int vr = rr * 4 + sub;
+                const size_t gv = v0 + vr;
+                if (gv < V) {
+                    float4 q4 = make_float4(tile0[(c * 64 + fr) * 64 + vr], tile0[(c * 64 + fr + 1) * 64 + vr], tile0[(c * 64 + fr + 2) * 64 + vr],
+                                            tile0[(c * 64 + fr + 3) * 64 + vr]);
+                    float* dst = out + (gv * TO + c) * fstride + t0 + fr;
+                    if (vec && fr + 4 <= ((size + 3) & ~3)) {
+                        *reinterpret_cast<float4*>(dst) = q4;
+                    } else {
+                        if (fr + 0 < size) dst[0] = q4.x;
+                        if (fr + 1 < size) dst[1] = q4.y;
+                        if (fr + 2 < size) dst[2] = q4.z;
+                        if (fr + 3 < size) dst[3] = q4.w;
+                    }
+                }
+            }
+        wave_sync();
+    }
+}
+
+template <class G> FD_D int wide_branch_words() {  // slot words of one branch (a constant after inlining)
+    typename WideSum<typename WideSplit<G>::Head>::Branch probe;
+    VCountWords c;
+    probe.visit(c);
+    return c.n;
+}
+
+// one wave per voice group: one-block launches and "pipe_split" 0 (the chain below renders everything else)
 template <class G, int MODE, int LAYOUT, int WPB>
 FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ out, size_t T,
                            size_t fstride, const void* aux, float* ring, uint32_t ring_cap) {
-    using WS = WideSum<G>;
-    using X = typename WS::Branch;
-    using OP = typename WS::OP;
-    constexpr int N = WS::N, NO = X::OUT, NI = X::IN;
+    using GEO = WideGeom<G>;
+    using H = typename WideSplit<G>::Head;
+    using TAIL = typename WideSplit<G>::Tail;
+    constexpr int N = WideSum<H>::N, NO = GEO::NO, C = GEO::C;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int vpw = (LAYOUT == LAYOUT_VOICE_MINOR && fstride > 0 && fstride < 64) ? (int)fstride : 64;   // partially filled waves of small banks, as render_body
+    const int vpw = (LAYOUT == LAYOUT_VOICE_MINOR && fstride > 0 && fstride < 64) ? (int)fstride : 64;   // partially filled waves of small banks, as render_body_frames
     const size_t v0 = ((size_t)blockIdx.x * WPB + wib) * vpw;
     const size_t v = v0 + lane;
     const bool active = v < V && lane < vpw;
@@ -208,213 +452,83 @@ FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, c
     // voice-minor: a lane past the end of the bank / of a partially filled wave has nothing to do (every LDS column is private to its lane, no
     // wave-level hand-over in that layout).  Planar: padding lanes (V <= v < stride) own private zeroed slot / ring columns and take part.
     if (LAYOUT == LAYOUT_VOICE_MINOR && !active) return;
-    const size_t vc = v;
     const size_t vin = v < V ? v : v0;  // planar: a padding lane reads a real voice's input rows (its samples are never stored)
-    int K;  // slot words of one branch (a constant after inlining)
-    {
-        X probe;
-        VCountWords c;
-        probe.visit(c);
-        K = c.n;
+    const int K = wide_branch_words<G>();
+    __shared__ float acc_all[WPB * C * 64 * 64];
+    float* tile0 = acc_all + (size_t)wib * C * 64 * 64;
+    float* accl = tile0 + lane;
+    TAIL tail;
+    if constexpr (!GEO::BARE) {
+        Ctx ctx{static_cast<const Aux*>(aux), ring + v, ring_cap, stride, N * WideSum<H>::Branch::RINGS};
+        tail.bind(ctx);
+        VLoad ld{slots + v, stride, N * K};
+        tail.visit(ld);
     }
-    __shared__ float acc_all[WPB * NO * 64 * 64];
-    float* accl = acc_all + (size_t)wib * NO * 64 * 64 + lane;   // this lane's column: accl[(c * 64 + frame) * 64]
-    auto branch_in = [&](X& x, int i) {
-        Ctx ctx{static_cast<const Aux*>(aux), ring + vc, ring_cap, stride, i * X::RINGS};
-        x.bind(ctx);
-        VLoad ld{slots + vc, stride, i * K};
-        x.visit(ld);
-    };
-    auto branch_out = [&](X& x, int i) {
-        if (active) {
-            VStore<false> st{slots + v, stride, i * K};
-            x.visit(st);
-        }
-    };
     for (size_t t0 = 0; t0 < T; t0 += 64) {
         const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
-        const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
         if (MODE == MODE_PROCESS && size == 64) {
             v2f acc[NO][32];
-#pragma unroll 1
-            for (int i = 0; i < N; i++) {
-                X x;
-                branch_in(x, i);
-                x.begin_block(64);
-                const X snap = x;
-                v2f tmp[NO][32];
-#pragma unroll
-                for (int k = 0; k < 32; k++) {
-                    v2f po[NO], pi[NI > 0 ? NI : 1];
-#pragma unroll
-                    for (int c = 0; c < NI; c++) {
-                        const size_t ch = WS::BUS ? c : i * NI + c;
-                        pi[c] = v2f{wide_in<LAYOUT>(in, ch, t0 + 2 * k, T, V, vin, G::IN, fstride), wide_in<LAYOUT>(in, ch, t0 + 2 * k + 1, T, V, vin, G::IN, fstride)};
-                    }
-                    x.template step2<PH_SIMD>(pi, po);
-#pragma unroll
-                    for (int c = 0; c < NO; c++) tmp[c][k] = po[c];
-                }
-                if (__builtin_expect(x.tripped(), 0)) {  // a packed-path shortcut left its exact domain: this branch's block again, scalar
-                    x = snap;
-#pragma unroll 1
-                    for (int f = 0; f < 64; f++) {
-                        float fo[NO], fi[NI > 0 ? NI : 1];
-#pragma unroll
-                        for (int c = 0; c < NI; c++) fi[c] = wide_in<LAYOUT>(in, WS::BUS ? c : i * NI + c, t0 + f, T, V, vin, G::IN, fstride);
-                        x.template step<PH_SIMD>(fi, fo);
-#pragma unroll
-                        for (int c = 0; c < NO; c++) accl[(c * 64 + f) * 64] = fo[c];
-                    }
-#pragma unroll
-                    for (int c = 0; c < NO; c++)
-#pragma unroll
-                        for (int k = 0; k < 32; k++) tmp[c][k] = v2f{accl[(c * 64 + 2 * k) * 64], accl[(c * 64 + 2 * k + 1) * 64]};
-                }
-                x.end_simd();
-#pragma unroll
-                for (int c = 0; c < NO; c++)
-#pragma unroll
-                    for (int k = 0; k < 32; k++) acc[c][k] = i == 0 ? tmp[c][k] : OP::f(acc[c][k], tmp[c][k]);
-                branch_out(x, i);
-            }
-            if (LAYOUT == LAYOUT_VOICE_MINOR) {
-                if (active) {
-                    float* outw = out + v0;
-#pragma unroll
-                    for (int c = 0; c < NO; c++)
-#pragma unroll
-                        for (int k = 0; k < 32; k++) {
-                            outw[((size_t)c * T + t0 + 2 * k) * V + lane] = acc[c][k].x;
-                            outw[((size_t)c * T + t0 + 2 * k + 1) * V + lane] = acc[c][k].y;
-                        }
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < NO; c++)
-#pragma unroll
-                    for (int k = 0; k < 32; k++) {
-                        accl[(c * 64 + 2 * k) * 64] = acc[c][k].x;
-                        accl[(c * 64 + 2 * k + 1) * 64] = acc[c][k].y;
-                    }
-            }
+            wide_fold<G, MODE, LAYOUT, true>(0, N, K, slots, stride, V, v, active, vin, true, in, T, fstride, t0, size, aux, ring, ring_cap, acc, accl);
+            wide_finish<G, MODE, LAYOUT, true>(tail, acc, accl, tile0, out, T, V, v0, v, active, lane, fstride, t0, size);
         } else {
-#pragma unroll 1
-            for (int i = 0; i < N; i++) {
-                X x;
-                branch_in(x, i);
-                x.begin_block(size);
-#pragma unroll 1
-                for (int f = 0; f < size; f++) {
-                    float fo[NO], fi[NI > 0 ? NI : 1];
-#pragma unroll
-                    for (int c = 0; c < NI; c++) fi[c] = wide_in<LAYOUT>(in, WS::BUS ? c : i * NI + c, t0 + f, T, V, vin, G::IN, fstride);
-                    if (f < full) {
-                        x.template step<PH_SIMD>(fi, fo);
-                    } else {
-                        if (MODE == MODE_PROCESS && f == full) x.end_simd();
-                        x.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(fi, fo);
-                    }
-#pragma unroll
-                    for (int c = 0; c < NO; c++) {
-                        float* a = &accl[(c * 64 + f) * 64];
-                        *a = i == 0 ? ((WS::BUS && MODE == MODE_TICK) ? 0.0f + fo[c] : fo[c]) : OP::f(*a, fo[c]);
-                    }
-                }
-                if (MODE == MODE_PROCESS && full == size) x.end_simd();
-                branch_out(x, i);
-            }
-            if (LAYOUT == LAYOUT_VOICE_MINOR && active) {
-                float* outw = out + v0;
-                for (int f = 0; f < size; f++)
-#pragma unroll
-                    for (int c = 0; c < NO; c++) outw[((size_t)c * T + t0 + f) * V + lane] = accl[(c * 64 + f) * 64];
-            }
+            int none = 0;
+            wide_fold<G, MODE, LAYOUT, false>(0, N, K, slots, stride, V, v, active, vin, true, in, T, fstride, t0, size, aux, ring, ring_cap, none, accl);
+            wide_finish<G, MODE, LAYOUT, false>(tail, none, accl, tile0, out, T, V, v0, v, active, lane, fstride, t0, size);
         }
-        if (LAYOUT == LAYOUT_PLANAR) {  // LDS [channel][frame][lane = voice] -> global [voice][channel][frame]: a lane writes 4 consecutive frames of one voice
-            wave_sync();
-            const float* accw = acc_all + (size_t)wib * NO * 64 * 64;
-            const int sub = lane >> 4, fr = (lane & 15) << 2;
-            const bool vec = ((fstride & 3) == 0) && ((((uintptr_t)out) & 15) == 0) && (t0 + 64 <= fstride);
-#pragma unroll
-            for (int c = 0; c < NO; c++)
-                for (int r = 0; r < 16; r++) {
-                    const int vr = r * 4 + sub;
-                    const size_t gv = v0 + vr;
-                    if (gv < V) {
-                        float4 q = make_float4(accw[(c * 64 + fr) * 64 + vr], accw[(c * 64 + fr + 1) * 64 + vr], accw[(c * 64 + fr + 2) * 64 + vr],
-                                               accw[(c * 64 + fr + 3) * 64 + vr]);
-                        float* dst = out + (gv * NO + c) * fstride + t0 + fr;
-                        if (vec && fr + 4 <= ((size + 3) & ~3)) {
-                            *reinterpret_cast<float4*>(dst) = q;
-                        } else {
-                            if (fr + 0 < size) dst[0] = q.x;
-                            if (fr + 1 < size) dst[1] = q.y;
-                            if (fr + 2 < size) dst[2] = q.z;
-                            if (fr + 3 < size) dst[3] = q.w;
-                        }
-                    }
-                }
-            wave_sync();
+    }
+    if constexpr (!GEO::BARE) {
+        if (active) {
+            VStore<false> st{slots + v, stride, N * K};
+            tail.visit(st);
         }
     }
 }
 
-// ... and the same sum on a bank too small to fill the chip with one wave per voice group (render_body_wide takes as long for 4 096 instances as
-// for 65 536).  The left fold fixes the ORDER of the additions, not who evaluates the branches: a voice group becomes a workgroup of W waves, wave w
-// owns the branches [w N / W, (w + 1) N / W) and the blocks travel down the chain -- in round r wave w works on block r - w: it takes the block's
-// accumulator tile from LDS as wave w - 1 left it, folds its own branches into it in order, and leaves it for wave w + 1 (the last wave writes the
-// output).  W blocks are in flight, block k lives in tile k mod W for its whole trip, so one workgroup barrier per round hands every tile on; the fill
-// and drain of the chain cost W - 1 rounds per launch.  Same branch arithmetic, same fold, same slots traffic as render_body_wide -- bit-identical to
-// it (tests/test_gpu_wide_sum.py renders every case through both).  W = 8 for mono generators (8 tiles of 16 KB = 128 KB of LDS, one workgroup per
-// CU, two waves per SIMD), 4 for stereo branches and for branches with inputs.
+// ... and the same sum with a voice group spread over W waves.  One wave per voice group takes as long for 64 instances as for 65 536; but the left fold
+// fixes the ORDER of the additions, not who evaluates the branches: a voice group becomes a workgroup of W waves, wave w owns the branches
+// [w N / W, (w + 1) N / W) and the blocks travel down the chain -- in round r wave w works on block r - w: it takes the block's accumulator tile from LDS
+// as wave w - 1 left it, folds its own branches into it in order, and leaves it for wave w + 1; the last wave runs the tail and writes the output.  W
+// blocks are in flight, block k lives in tile k mod W for its whole trip, so one workgroup barrier per round hands every tile on; the fill and drain of
+// the chain cost W - 1 rounds per launch.  Same branch arithmetic, same fold, same slots traffic as render_body_wide -- bit-identical to it
+// (tests/test_gpu_wide_sum.py renders every case through both).  W = 8 for mono generators without a wider tail (8 tiles of 16 KB = 128 KB of LDS, one
+// workgroup per CU, two waves per SIMD), 4 for stereo tiles and for branches with inputs.
 template <class G> struct WideChain {
-    static constexpr bool on = WideSum<G>::value;
-    static constexpr int W = !on ? 1 : (G::OUT == 1 && G::IN == 0 ? 8 : 4);  // (branches with inputs keep 64 more samples in flight per block: 4 waves leave each the whole register file)
+    static constexpr bool on = WideSplit<G>::ok;
+    static constexpr int W = !on ? 1 : (WideGeom<G>::C == 1 && G::IN == 0 ? 8 : 4);  // (branches with inputs keep 64 more samples in flight per block: 4 waves leave each the whole register file)
 };
 
 template <class G, int MODE, int LAYOUT>
 FD_D void render_body_wide_chain(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in, float* __restrict__ out,
                                  size_t T, size_t fstride, const void* aux, float* ring, uint32_t ring_cap) {
-    if constexpr (WideSum<G>::value) {
-        using WS = WideSum<G>;
-        using X = typename WS::Branch;
-        using OP = typename WS::OP;
-        constexpr int N = WS::N, NO = X::OUT, NI = X::IN, W = WideChain<G>::W;
+    if constexpr (WideSplit<G>::ok) {
+        using GEO = WideGeom<G>;
+        using H = typename WideSplit<G>::Head;
+        using TAIL = typename WideSplit<G>::Tail;
+        constexpr int N = WideSum<H>::N, NO = GEO::NO, C = GEO::C, W = WideChain<G>::W;
         const int lane = threadIdx.x & 63;
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // place in the chain
         const size_t v0 = (size_t)blockIdx.x * 64;
         const size_t v = v0 + lane;  // < stride: the slot / ring arrays are padded to whole voice groups (padding lanes own private zeroed columns)
         const bool active = v < V;
-        int K;
-        {
-            X probe;
-            VCountWords c;
-            probe.visit(c);
-            K = c.n;
-        }
+        const int K = wide_branch_words<G>();
         const int b0 = w * N / W, b1 = (w + 1) * N / W;
-        __shared__ float tiles[W * NO * 64 * 64];  // [tile][channel][frame][lane]
-        auto branch_in = [&](X& x, int i) {
-            Ctx ctx{static_cast<const Aux*>(aux), ring + v, ring_cap, stride, i * X::RINGS};
-            x.bind(ctx);
-            VLoad ld{slots + v, stride, i * K};
-            x.visit(ld);
-        };
-        auto branch_out = [&](X& x, int i) {
-            if (active) {
-                VStore<false> st{slots + v, stride, i * K};
-                x.visit(st);
+        __shared__ float tiles[W * C * 64 * 64];  // [tile][channel][frame][lane]
+        TAIL tail;
+        if constexpr (!GEO::BARE) {
+            if (w == W - 1) {
+                Ctx ctx{static_cast<const Aux*>(aux), ring + v, ring_cap, stride, N * WideSum<H>::Branch::RINGS};
+                tail.bind(ctx);
+                VLoad ld{slots + v, stride, N * K};
+                tail.visit(ld);
             }
-        };
+        }
         const size_t nblocks = (T + 63) / 64;
         for (size_t r = 0; r < nblocks + W - 1; r++) {
             __syncthreads();  // every tile moves one wave down the chain
             if (r < (size_t)w || r - w >= nblocks) continue;
             const size_t k = r - w, t0 = k * 64;
             const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
-            const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
-            float* tile0 = tiles + (k % W) * (NO * 64 * 64);
+            float* tile0 = tiles + (k % W) * (C * 64 * 64);
             float* accl = tile0 + lane;  // this lane's column: accl[(c * 64 + frame) * 64]
             if (MODE == MODE_PROCESS && size == 64) {
                 v2f acc[NO][32];
@@ -424,59 +538,9 @@ FD_D void render_body_wide_chain(float* __restrict__ slots, size_t stride, size_
 #pragma unroll
                         for (int q = 0; q < 32; q++) acc[c][q] = v2f{accl[(c * 64 + 2 * q) * 64], accl[(c * 64 + 2 * q + 1) * 64]};
                 }
-#pragma unroll 1
-                for (int i = b0; i < b1; i++) {
-                    X x;
-                    branch_in(x, i);
-                    x.begin_block(64);
-                    const X snap = x;
-                    v2f tmp[NO][32];
-#pragma unroll
-                    for (int q = 0; q < 32; q++) {
-                        v2f po[NO], pi[NI > 0 ? NI : 1];
-#pragma unroll
-                        for (int c = 0; c < NI; c++) {
-                            const size_t ch = WS::BUS ? c : i * NI + c;
-                            pi[c] = active ? v2f{wide_in<LAYOUT>(in, ch, t0 + 2 * q, T, V, v, G::IN, fstride), wide_in<LAYOUT>(in, ch, t0 + 2 * q + 1, T, V, v, G::IN, fstride)}
-                                           : v2f{0.0f, 0.0f};
-                        }
-                        x.template step2<PH_SIMD>(pi, po);
-#pragma unroll
-                        for (int c = 0; c < NO; c++) tmp[c][q] = po[c];
-                    }
-                    if (__builtin_expect(x.tripped(), 0)) {  // this branch's block again, scalar (the accumulator is in registers: the tile is free)
-                        x = snap;
-#pragma unroll 1
-                        for (int f = 0; f < 64; f++) {
-                            float fo[NO], fi[NI > 0 ? NI : 1];
-#pragma unroll
-                            for (int c = 0; c < NI; c++) fi[c] = active ? wide_in<LAYOUT>(in, WS::BUS ? c : i * NI + c, t0 + f, T, V, v, G::IN, fstride) : 0.0f;
-                            x.template step<PH_SIMD>(fi, fo);
-#pragma unroll
-                            for (int c = 0; c < NO; c++) accl[(c * 64 + f) * 64] = fo[c];
-                        }
-#pragma unroll
-                        for (int c = 0; c < NO; c++)
-#pragma unroll
-                            for (int q = 0; q < 32; q++) tmp[c][q] = v2f{accl[(c * 64 + 2 * q) * 64], accl[(c * 64 + 2 * q + 1) * 64]};
-                    }
-                    x.end_simd();
-#pragma unroll
-                    for (int c = 0; c < NO; c++)
-#pragma unroll
-                        for (int q = 0; q < 32; q++) acc[c][q] = i == 0 ? tmp[c][q] : OP::f(acc[c][q], tmp[c][q]);
-                    branch_out(x, i);
-                }
-                if (w == W - 1 && LAYOUT == LAYOUT_VOICE_MINOR) {
-                    if (active) {
-#pragma unroll
-                        for (int c = 0; c < NO; c++)
-#pragma unroll
-                            for (int q = 0; q < 32; q++) {
-                                out[((size_t)c * T + t0 + 2 * q) * V + v] = acc[c][q].x;
-                                out[((size_t)c * T + t0 + 2 * q + 1) * V + v] = acc[c][q].y;
-                            }
-                    }
+                wide_fold<G, MODE, LAYOUT, true>(b0, b1, K, slots, stride, V, v, active, v, active, in, T, fstride, t0, size, aux, ring, ring_cap, acc, accl);
+                if (w == W - 1) {
+                    wide_finish<G, MODE, LAYOUT, true>(tail, acc, accl, tile0, out, T, V, v0, v, active, lane, fstride, t0, size);
                 } else {
 #pragma unroll
                     for (int c = 0; c < NO; c++)
@@ -487,60 +551,15 @@ FD_D void render_body_wide_chain(float* __restrict__ slots, size_t stride, size_
                         }
                 }
             } else {  // the ragged last block, the tick executor: the fold in place, in the tile
-#pragma unroll 1
-                for (int i = b0; i < b1; i++) {
-                    X x;
-                    branch_in(x, i);
-                    x.begin_block(size);
-#pragma unroll 1
-                    for (int f = 0; f < size; f++) {
-                        float fo[NO], fi[NI > 0 ? NI : 1];
-#pragma unroll
-                        for (int c = 0; c < NI; c++) fi[c] = active ? wide_in<LAYOUT>(in, WS::BUS ? c : i * NI + c, t0 + f, T, V, v, G::IN, fstride) : 0.0f;
-                        if (f < full) {
-                            x.template step<PH_SIMD>(fi, fo);
-                        } else {
-                            if (MODE == MODE_PROCESS && f == full) x.end_simd();
-                            x.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(fi, fo);
-                        }
-#pragma unroll
-                        for (int c = 0; c < NO; c++) {
-                            float* a = &accl[(c * 64 + f) * 64];
-                            *a = i == 0 ? ((WS::BUS && MODE == MODE_TICK) ? 0.0f + fo[c] : fo[c]) : OP::f(*a, fo[c]);
-                        }
-                    }
-                    if (MODE == MODE_PROCESS && full == size) x.end_simd();
-                    branch_out(x, i);
-                }
-                if (w == W - 1 && LAYOUT == LAYOUT_VOICE_MINOR && active) {
-                    for (int f = 0; f < size; f++)
-#pragma unroll
-                        for (int c = 0; c < NO; c++) out[((size_t)c * T + t0 + f) * V + v] = accl[(c * 64 + f) * 64];
-                }
+                int none = 0;
+                wide_fold<G, MODE, LAYOUT, false>(b0, b1, K, slots, stride, V, v, active, v, active, in, T, fstride, t0, size, aux, ring, ring_cap, none, accl);
+                if (w == W - 1) wide_finish<G, MODE, LAYOUT, false>(tail, none, accl, tile0, out, T, V, v0, v, active, lane, fstride, t0, size);
             }
-            if (w == W - 1 && LAYOUT == LAYOUT_PLANAR) {  // tile [channel][frame][voice] -> global [voice][channel][frame]
-                wave_sync();
-                const int sub = lane >> 4, fr = (lane & 15) << 2;
-                const bool vec = ((fstride & 3) == 0) && ((((uintptr_t)out) & 15) == 0) && (t0 + 64 <= fstride);
-#pragma unroll
-                for (int c = 0; c < NO; c++)
-                    for (int rr = 0; rr < 16; rr++) {
-                        const int vr = rr * 4 + sub;
-                        const size_t gv = v0 + vr;
-                        if (gv < V) {
-                            float4 q4 = make_float4(tile0[(c * 64 + fr) * 64 + vr], tile0[(c * 64 + fr + 1) * 64 + vr], tile0[(c * 64 + fr + 2) * 64 + vr],
-                                                    tile0[(c * 64 + fr + 3) * 64 + vr]);
-                            float* dst = out + (gv * NO + c) * fstride + t0 + fr;
-                            if (vec && fr + 4 <= ((size + 3) & ~3)) {
-                                *reinterpret_cast<float4*>(dst) = q4;
-                            } else {
-                                if (fr + 0 < size) dst[0] = q4.x;
-                                if (fr + 1 < size) dst[1] = q4.y;
-                                if (fr + 2 < size) dst[2] = q4.z;
-                                if (fr + 3 < size) dst[3] = q4.w;
-                            }
-                        }
-                    }
+        }
+        if constexpr (!GEO::BARE) {
+            if (w == W - 1 && active) {
+                VStore<false> st{slots + v, stride, N * K};
+                tail.visit(st);
             }
         }
     }
@@ -787,7 +806,7 @@ template <class G, int MODE, int LAYOUT, int WPB>
 FD_D void render_body(float* __restrict__ slots, size_t stride, size_t V, const float* __restrict__ in,
                       float* __restrict__ out, size_t T, size_t fstride, const void* aux, float* ring,
                       uint32_t ring_cap) {
-    if constexpr (WideSum<G>::value)  // a wide sum of generators at the root: branch-major blocks (above)
+    if constexpr (WideSplit<G>::ok)  // a wide sum at the head of the graph: branch-major blocks (above)
         render_body_wide<G, MODE, LAYOUT, WPB>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);
     else
         render_body_frames<G, MODE, LAYOUT, WPB>(slots, stride, V, in, out, T, fstride, aux, ring, ring_cap);

@@ -395,13 +395,28 @@ int jit_compile_src(const std::string& src, const std::string& type_expr, std::v
     // a graph with a Feedback node renders with f32 denormals flushed, like the reference after Feedback::new's
     // prevent_denormals() (feedback.rs:96, denormal.rs:18)
     const bool ftz = type_expr.find("Feedback") != std::string::npos;
-    // A wide sum of plain oscillators at the root (fd_device.hpp render_body_wide: 32 independent frame pairs per branch and block): the default
-    // machine scheduler emits the packed sine polynomials pair by pair with an s_nop behind every dependent packed instruction (328 per
-    // branch-block of the reference's 100-sine bench); the max-ILP strategy interleaves the pairs (4 s_nop, 160 -> 200 VGPRs).  Only for
-    // branches made of the plain feed-forward nodes it was tried on -- other strategies have crashed this compiler on other kinds.
-    bool wide_ilp = type_expr.rfind("Reduce<", 0) == 0 || type_expr.rfind("MultiBus<", 0) == 0;
-    for (const char* heavy : {"Oversampler", "Resample", "Feedback", "Limiter", "Reverb3", "Envelope", "Moog", "Pluck"})
-        if (type_expr.find(heavy) != std::string::npos) wide_ilp = false;
+    // A wide sum of plain oscillators / filters at the head of the graph (fd_device.hpp render_body_wide: 32 independent frame pairs per branch and
+    // block): the default machine scheduler emits the packed sine polynomials pair by pair with an s_nop behind every dependent packed instruction
+    // (328 per branch-block of the reference's 100-sine bench); the max-ILP strategy interleaves the pairs (4 s_nop, 160 -> 200 VGPRs).  Only for
+    // graphs made ENTIRELY of the plain nodes it was tried on -- other strategies have crashed this compiler on other kinds.
+    bool wide_ilp = type_expr.find("Reduce<") != std::string::npos || type_expr.find("MultiBus<") != std::string::npos;
+    if (wide_ilp) {
+        static const char* plain[] = {"Reduce", "MultiBus", "Pipe", "Unop", "Binop", "Stack", "Constant", "Sine", "Pass", "MultiPass", "Panner", "FixedSvf",
+                                      "Noise", "Resonator", "OpAdd", "OpSub", "OpMul", "UNeg", "UAddScalar", "UNegAddScalar", "UMulScalar"};
+        for (size_t i = 0; i < type_expr.size() && wide_ilp;) {
+            if (isalpha((unsigned char)type_expr[i]) || type_expr[i] == '_') {
+                size_t j = i;
+                while (j < type_expr.size() && (isalnum((unsigned char)type_expr[j]) || type_expr[j] == '_')) j++;
+                const std::string tok = type_expr.substr(i, j - i);
+                bool known = false;
+                for (const char* p : plain) known = known || tok == p;
+                wide_ilp = known;
+                i = j;
+            } else {
+                i++;
+            }
+        }
+    }
     std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"};
     if (ftz) {
         opts.push_back("-fgpu-flush-denormals-to-zero");

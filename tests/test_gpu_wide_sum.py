@@ -26,6 +26,12 @@ GRAPHS = {
     "busi20_harmonics_of_an_input": (lambda m: m.busi(20, lambda i: m.mul(float(i + 1)) >> m.sine()), 0),   # README.md:1152: input = frequency
     "sumi8_lowpasses_own_inputs": (lambda m: m.sumi(8, lambda i: m.lowpass_hz(150.0 * (i + 1), 1.0 + 0.25 * i)), 0),
     "busi10_resonators_panned": (lambda m: m.busi(10, lambda i: m.resonator_hz(300.0 * (i + 1), 25.0) >> m.pan(-0.9 + 0.2 * i)), 0),   # 1 in, 2 out
+    # the sum at the HEAD of a chain of Pipe / Unop nodes: the rest of the graph is the tail the finishing wave walks frame-major
+    "additive_voice_gain_filter_pan": (lambda m: m.sumi(12, lambda i: m.sine_hz(82.4 * (i + 1))) * 0.05 >> m.lowpass_hz(900.0, 1.5) >> m.pan(0.3), 0),   # mono sum, stereo out
+    "harmonics_of_an_input_gain": (lambda m: m.busi(20, lambda i: m.mul(float(i + 1)) >> m.sine()) * 0.05, 0),
+    "sum_shaped_with_a_seeded_tail": (lambda m: m.sumi(9, lambda i: m.sine_hz(110.0 * (i + 1))) >> m.shape("tanh", 0.5) >> (m.pass_() + m.noise() * 0.01), 0),
+    "rings_in_the_sum_and_in_the_tail": (lambda m: m.sumi(8, lambda i: m.noise() >> m.delay(0.0005 * (i + 1))) >> m.delay(0.001) >> m.lowpole_hz(2000.0), 256),
+    "tail_whose_packed_sine_trips": (lambda m: m.sumi(8, lambda i: m.sine_hz(50.0 * (i + 1))) * 2.0e6 + 3.0e6 >> m.sine(), 0),   # the tail's Sine leaves its packed domain every block
 }
 
 

@@ -67,6 +67,14 @@ def test_wide_sums_with_inputs_and_stereo_branches_compile_without_spills(tmp_pa
         assert meta["jit_wide_00"]["lds"] in (4 * 64 * 64 * 4, 4 * 2 * 64 * 64 * 4), (t, meta["jit_wide_00"])   # four-wave chains
 
 
+def test_wide_sum_with_a_tail_compiles_without_spills(tmp_path):
+    """sumi(..) * gain >> lowpass_hz(..) >> pan(..): the sum at the head of a Pipe / Unop spine, the rest of the graph walked as its tail (mono sum, stereo tile)"""
+    meta = compile_kernels(tmp_path, "Pipe<Pipe<Unop<Reduce<12, Pipe<Constant<1>, Sine>, OpAdd>, UMulScalar>, FixedSvf>, Panner>", ILP)
+    for name, k in meta.items():
+        assert k["spill"] == 0, (name, k)
+    assert meta["jit_wide_00"]["lds"] == 4 * 2 * 64 * 64 * 4
+
+
 def test_limiter_graph_compiles_without_scratch(tmp_path):
     """noise() >> limiter(..): the incremental reduce tree keeps 2 x 20 path / sibling values in registers"""
     meta = compile_kernels(tmp_path, "Pipe<Noise, Limiter<1>>")
