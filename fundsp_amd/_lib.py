@@ -13,6 +13,7 @@ OK, EINVAL, ENOMEM, EDEVICE, ENOTSUP = 0, -1, -2, -3, -4
 LAYOUT_VOICE_MINOR, LAYOUT_PLANAR = 0, 1
 MODE_PROCESS, MODE_TICK = 0, 1
 MATH_EXACT, MATH_FAST = 0, 1
+BUS_NONE, BUS_WET, BUS_DRY_WET = 0, 1, 2  # fdsp_bank_set_bus: the node alone | wet * node | dry * multipass() & wet * node
 MIX_SUM, MIX_PAN = 1, 2  # fdsp_bank_process_mix: sum the output channels over the voices | pan a mono graph per voice, then sum
 FADE_POWER, FADE_SMOOTH = 0, 1  # sequencer.rs Fade::Power / Fade::Smooth
 MAX_BUFFER_SIZE = 64
@@ -50,6 +51,8 @@ SYMBOLS = {
     "fdsp_reverb3_stereo_svf_create_on": (_i, [_i, _sz, _d, _d, _i, _f, _f, _f, C.POINTER(_P)]),
     "fdsp_fdn_create": (_i, [_sz, _i, C.POINTER(_d), _i, C.POINTER(C.c_float), _i, _i, C.POINTER(_P)]),
     "fdsp_fdn_create_on": (_i, [_i, _sz, _i, C.POINTER(_d), _i, C.POINTER(C.c_float), _i, _i, C.POINTER(_P)]),
+    "fdsp_bank_set_bus": (_i, [_P, _i, _f, _f]),
+    "fdsp_bank_get_bus": (_i, [_P, C.POINTER(_i), C.POINTER(_f), C.POINTER(_f)]),
     "fdsp_device_count": (_i, []),
     "fdsp_bank_create_on": (_i, [_i, _cs, _sz, _sz, C.POINTER(_P)]),
     "fdsp_reverb_stereo_create_on": (_i, [_i, _sz, _d, _d, _d, C.POINTER(_P)]),

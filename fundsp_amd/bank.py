@@ -85,9 +85,19 @@ class Bank:
                     b.set_sample_rate(sample_rate)
                 b.reset()
                 return b
+        bus = G.bus_plan(graph) if fdn_kernel else None
+        if bus is not None and G.lane_per_frame_shape(bus[0]):
+            # `multipass() & 0.2 * reverb_stereo(..)` (README.md:436) and its relatives: the reverb's own bank with the gain and the dry bus folded into
+            # its kernel's epilogue (fdsp_bank_set_bus) -- the Unop, MultiPass and Bus nodes cost two multiplications and an addition per output sample
+            eff = cls.from_graph(bus[0], voices, sample_rate=sample_rate)
+            if isinstance(eff, Bank) and eff.kind in LANE_PER_FRAME_KINDS:
+                eff.set_bus(*bus[1:])
+                return eff
+            eff.close()   # (a room too small for the kernel's two-block rule: the whole graph renders lane-per-voice)
         parts = getattr(graph, "pipe_parts", None) if fdn_kernel else None
+        pbus = G.bus_plan(parts[1]) if parts is not None else None
         if (parts is not None and parts[0].nin == 0 and parts[0].rings == 0 and not ring_frames and
-                (getattr(parts[1], "stock_reverb", None) is not None or getattr(parts[1], "reverb3_plan", None) is not None or G.fdn_plan(parts[1]) is not None)):
+                (G.lane_per_frame_shape(parts[1]) or (pbus is not None and G.lane_per_frame_shape(pbus[0])))):
             # `generator >> stock reverb / network` (the reference's own `reverb` bench: (noise() | noise()) >> reverb_stereo(..)): compiled as
             # ONE lane-per-voice graph the delay lines are read one lane per instance; as a chain the generator keeps its fused kernel and
             # the network its lane-per-frame kernel -- the same samples (the generator is seeded as the Pipe would seed it), 400-700 x faster
@@ -192,6 +202,16 @@ class Bank:
 
     def outputs(self):
         return lib().fdsp_bank_outputs(self._h)
+
+    def set_bus(self, mode, wet=1.0, dry=1.0):
+        """A gain and a dry bus around a reverb / network bank, folded into its render kernel (fdsp_bank_set_bus): BUS_WET = `wet * node`,
+        BUS_DRY_WET = `dry * multipass() & wet * node` (README.md:436: `multipass() & 0.2 * reverb_stereo(20.0, 2.0, 1.0)`), BUS_NONE = the node alone."""
+        check(lib().fdsp_bank_set_bus(self._h, int(mode), float(wet), float(dry)))
+
+    def get_bus(self):
+        m, w, d = C.c_int(), C.c_float(), C.c_float()
+        check(lib().fdsp_bank_get_bus(self._h, C.byref(m), C.byref(w), C.byref(d)))
+        return m.value, w.value, d.value
 
     def set_sample_rate(self, sample_rate):
         check(lib().fdsp_bank_set_sample_rate(self._h, float(sample_rate)))

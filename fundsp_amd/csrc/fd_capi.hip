@@ -396,6 +396,7 @@ struct FdnBank {  // reverb_stereo / reverb4_stereo banks (fd_fdn.hip): rings + 
     fd::FdnDesc desc;
     fd::FdnConst c;
     fd::FdnState st;
+    fd::FdnBus bus;           // fdsp_bank_set_bus: wet * node [& dry * multipass()] folded into the render kernels' epilogue
     float* stage = nullptr;   // planar staging of voice-minor launches: [V][inputs][frames] | [V][outputs][frames] (fd_fdn.hip "voice-minor I/O")
     size_t stage_n = 0;
 };
@@ -1311,6 +1312,7 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
         if (e == hipSuccess) e = hipMemcpyAsync(b->panw, src->panw, 2 * src->stride * sizeof(float), hipMemcpyDeviceToDevice, b->stream);
         if (e != hipSuccess) return bail(e, "pan weights");
     }
+    if (src->fdn) b->fdn->bus = src->fdn->bus;
     b->math = src->math;
     b->opt_pipe_split = src->opt_pipe_split;
     b->opt_time_split = src->opt_time_split;
@@ -1319,6 +1321,28 @@ int fdsp_bank_clone(const fdsp_bank* src, fdsp_bank** out) {
     e = sync_bank_stream(b);
     if (e != hipSuccess) return bail(e, "copy");
     *out = b;
+    return FDSP_OK;
+}
+
+// `wet * node` / `dry * multipass() & wet * node` around a reverb / network bank (fd_fdn.hpp FdnBus): a host-side setting, read at every launch
+int fdsp_bank_set_bus(fdsp_bank* b, int mode, float wet, float dry) {
+    if (!b) return fail(FDSP_EINVAL, "fdsp_bank_set_bus: bank NULL");
+    if (!b->fdn) return fail(FDSP_ENOTSUP, "fdsp_bank_set_bus: reverb / network banks only (a run-time compiled graph carries its bus in the graph: fdsp_graph_compile)");
+    if (mode < FDSP_BUS_NONE || mode > FDSP_BUS_DRY_WET) return fail(FDSP_EINVAL, "fdsp_bank_set_bus: mode takes FDSP_BUS_NONE, FDSP_BUS_WET or FDSP_BUS_DRY_WET");
+    if (mode == FDSP_BUS_DRY_WET && b->fdn->c.nin != b->fdn->c.nout)
+        return fail(FDSP_EINVAL, "fdsp_bank_set_bus: a Bus needs as many outputs as inputs (Bus<X, Y>: Y::Inputs = X::Inputs, Y::Outputs = X::Outputs; multipass::<N>() is N -> N)");
+    b->fdn->bus.mode = mode;
+    b->fdn->bus.wet = wet;
+    b->fdn->bus.dry = dry;
+    return FDSP_OK;
+}
+
+int fdsp_bank_get_bus(const fdsp_bank* b, int* mode, float* wet, float* dry) {
+    if (!b) return fail(FDSP_EINVAL, "fdsp_bank_get_bus: bank NULL");
+    if (!b->fdn) return fail(FDSP_ENOTSUP, "fdsp_bank_get_bus: reverb / network banks only");
+    if (mode) *mode = b->fdn->bus.mode;
+    if (wet) *wet = b->fdn->bus.wet;
+    if (dry) *dry = b->fdn->bus.dry;
     return FDSP_OK;
 }
 
@@ -1536,8 +1560,8 @@ int fdsp_bank_process(fdsp_bank* b, size_t frames, const float* d_in, float* d_o
         // 256-byte runs of it instead of gathering a line per frame); the staging buffer grows outside captures only, like the partial mixes
         bool staged = layout == FDSP_LAYOUT_VOICE_MINOR && b->V >= 64 && (f->kind == 3 || f->c.generic || fd::tl_opts.fdn_kernel == 0 || f->c.sections == 2);
         auto render = [&](const float* pi, float* po, size_t fs, int lay) {
-            if (f->kind == 3) fd::rv3_launch_render(f->c3, f->st3, b->V, pi, po, frames, fs, lay, s);   // (Reverb has no process override: one arithmetic)
-            else fd::fdn_launch_render(f->c, f->st, b->V, pi, po, frames, fs, lay, tick, s);
+            if (f->kind == 3) fd::rv3_launch_render(f->c3, f->st3, b->V, pi, po, frames, fs, lay, s, f->bus);   // (Reverb has no process override: one arithmetic)
+            else fd::fdn_launch_render(f->c, f->st, b->V, pi, po, frames, fs, lay, tick, s, f->bus);
         };
         const size_t need = b->V * (size_t)(nin + nout) * frames;
         if (staged && need > f->stage_n) {

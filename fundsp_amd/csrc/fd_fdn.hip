@@ -179,7 +179,7 @@ __device__ __forceinline__ void fdn_wave_sync() {
 // full lanes whenever the bank has fewer than two 2-instance waves per SIMD (BASELINE config 5: 2048 per GPU).
 template <int IPW>
 __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size_t V, const float* __restrict__ in,
-                                                    float* __restrict__ out, size_t T, size_t fstride, int layout) {
+                                                    float* __restrict__ out, size_t T, size_t fstride, int layout, FdnBus bus) {
     constexpr int R = 32 * IPW;                // ring rows (delay lines) per wave
     __shared__ float tile_all[4][R * TS];      // ring samples in / new ring samples out, one row per (instance, line)
     __shared__ float tileo_all[4][R * TS];     // line outputs of the block, for the ordered pan sum
@@ -322,6 +322,10 @@ __global__ __launch_bounds__(256) void k_fdn_render(FdnConst c, FdnState s, size
             }
             l *= (float)(1.0 / 16.0);  // * dc((1/16, 1/16))
             rr *= (float)(1.0 / 16.0);
+            if (bus.mode) {  // wet * reverb [& dry * multipass()] (fd_fdn.hpp FdnBus): the block's input frames are still in their tile
+                l = fdn_bus(bus, l, tin[(jj * 2 + 0) * 64 + lane]);
+                rr = fdn_bus(bus, rr, tin[(jj * 2 + 1) * 64 + lane]);
+            }
             if (ri < V && lane < size) {
                 if (layout == 0) {
                     out[((size_t)0 * T + t0 + lane) * V + ri] = l;
@@ -368,7 +372,7 @@ constexpr int HS = 68;  // floats per history row: [0..1] carry-in, [2..65] this
 // outputs of the same frame.
 template <int CAP_LOG2, int NSEC>
 __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState s, size_t V, const float* __restrict__ in,
-                                                           float* __restrict__ out, size_t T, size_t fstride, int layout, int tick_mode) {
+                                                           float* __restrict__ out, size_t T, size_t fstride, int layout, int tick_mode, FdnBus bus) {
     constexpr int C = 1 << CAP_LOG2, CMASK = C - 1, CP = C + 64;
     constexpr int NL = 32 / NSEC;  // lines per network
     __shared__ float hist_all[4][32 * HS];  // per line: delay outputs d[n-2], d[n-1] | d[0..63]
@@ -495,6 +499,10 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
         }
         l *= c.out_scale;  // * dc((1/16, 1/16)) | * dc((1/4, 1/4))
         rr *= c.out_scale;
+        if (bus.mode) {  // wet * reverb [& dry * multipass()] (fd_fdn.hpp FdnBus)
+            l = fdn_bus(bus, l, xi0);
+            rr = fdn_bus(bus, rr, xi1);
+        }
         if (lane < size) {
             if (layout == 0) {
                 out[((size_t)0 * T + t0 + lane) * V + inst] = l;
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(256) void k_fdn_render_frames(FdnConst c, FdnState 
 // the chip for 2 048 instances); this kernel is what Bank.from_graph / fdsp_fdn_create give them instead.
 template <int NL, int K>
 __global__ __launch_bounds__(256) void k_fdn_frames_generic(FdnConst c, FdnState s, size_t V, const float* __restrict__ in,
-                                                            float* __restrict__ out, size_t T, size_t fstride, int layout, int tick_mode) {
+                                                            float* __restrict__ out, size_t T, size_t fstride, int layout, int tick_mode, FdnBus bus) {
     static_assert(K >= 1 && K <= 3 && NL >= 2 && NL <= 32 && (NL & (NL - 1)) == 0, "generic FDN: 2..32 lines (a power of two), FIR order 1..3");
     constexpr int H0 = K - 1;               // carried delay outputs per line: Fir::v[1 .. K-1]
     __shared__ float hist_all[4][NL * HS];  // per line: the H0 carried delay outputs | d[0..63]
@@ -576,6 +584,7 @@ __global__ __launch_bounds__(256) void k_fdn_frames_generic(FdnConst c, FdnState
         const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
         float d[NL];
         const float xi0 = xin[0], xi1 = nin == 2 ? xin[1] : xin[0];
+        const float xin_now[2] = {xin[0], xin[1]};   // (this block's input frames, by channel: the bus reads them at the end of the block)
 #pragma unroll
         for (int k = 0; k < NL; k++) d[k] = dn[k];
         if (t0 + 64 < T) fetch(t0 + 64, (wp + 64) & CMASK);
@@ -655,6 +664,10 @@ __global__ __launch_bounds__(256) void k_fdn_frames_generic(FdnConst c, FdnState
                 for (int i = 1; i < NL / 2; i++) { y0 += o[2 * i] * z; y1 += o[2 * i + 1] * z; }
             }
         }
+        if (bus.mode) {  // wet * network [& dry * multipass()] (fd_fdn.hpp FdnBus; mode 2: nin == nout)
+            y0 = fdn_bus(bus, y0, xin_now[0]);
+            y1 = fdn_bus(bus, y1, xin_now[1]);
+        }
         if (lane < size) {
             if (layout == 0) {
                 out[((size_t)0 * T + t0 + lane) * V + inst] = y0;
@@ -687,11 +700,11 @@ __global__ __launch_bounds__(256) void k_fdn_frames_generic(FdnConst c, FdnState
 
 template <int NL>
 static void fdn_launch_generic(const FdnConst& c, const FdnState& s, size_t instances, const float* in, float* out, size_t T, size_t fstride, int layout,
-                               int tick_mode, hipStream_t stream) {
+                               int tick_mode, hipStream_t stream, const FdnBus& bus) {
     const dim3 grid((unsigned)((instances + 3) / 4)), block(256);
-    if (c.taps == 3) hipLaunchKernelGGL((k_fdn_frames_generic<NL, 3>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode);
-    else if (c.taps == 2) hipLaunchKernelGGL((k_fdn_frames_generic<NL, 2>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode);
-    else hipLaunchKernelGGL((k_fdn_frames_generic<NL, 1>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode);
+    if (c.taps == 3) hipLaunchKernelGGL((k_fdn_frames_generic<NL, 3>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode, bus);
+    else if (c.taps == 2) hipLaunchKernelGGL((k_fdn_frames_generic<NL, 2>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode, bus);
+    else hipLaunchKernelGGL((k_fdn_frames_generic<NL, 1>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode, bus);
 }
 
 // ---- voice-minor I/O for the lane = frame kernels -----------------------------------------------------------------------------------
@@ -736,16 +749,16 @@ void fdn_launch_reset(const FdnConst& c, const FdnState& s, size_t instances, hi
 }
 
 void fdn_launch_render(const FdnConst& c, const FdnState& s, size_t instances, const float* in, float* out, size_t T,
-                       size_t fstride, int layout, int tick_mode, hipStream_t stream) {
+                       size_t fstride, int layout, int tick_mode, hipStream_t stream, const FdnBus& bus) {
     if (instances == 0 || T == 0) return;
     if (c.generic) {
         tl_opts.last_kernel = LK_FDN_FRAMES;
         switch (c.lines) {
-        case 2: return fdn_launch_generic<2>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream);
-        case 4: return fdn_launch_generic<4>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream);
-        case 8: return fdn_launch_generic<8>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream);
-        case 16: return fdn_launch_generic<16>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream);
-        default: return fdn_launch_generic<32>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream);
+        case 2: return fdn_launch_generic<2>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream, bus);
+        case 4: return fdn_launch_generic<4>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream, bus);
+        case 8: return fdn_launch_generic<8>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream, bus);
+        case 16: return fdn_launch_generic<16>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream, bus);
+        default: return fdn_launch_generic<32>(c, s, instances, in, out, T, fstride, layout, tick_mode, stream, bus);
         }
     }
     const bool frames = tl_opts.fdn_kernel == 0 || c.sections == 2;  // (two networks in series: the lane = frame formulation only)
@@ -755,23 +768,23 @@ void fdn_launch_render(const FdnConst& c, const FdnState& s, size_t instances, c
         switch (c.cap) {  // the ring capacity is a template parameter of the lane = frame kernel
 #define FD_FDN_CASE(L)                                                                                                                                     \
     case 1 << L:                                                                                                                                           \
-        if (c.sections == 2) hipLaunchKernelGGL((k_fdn_render_frames<L, 2>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode); \
-        else hipLaunchKernelGGL((k_fdn_render_frames<L, 1>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode);                 \
+        if (c.sections == 2) hipLaunchKernelGGL((k_fdn_render_frames<L, 2>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode, bus); \
+        else hipLaunchKernelGGL((k_fdn_render_frames<L, 1>), grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, tick_mode, bus);                 \
         break;
             FD_FDN_CASE(8) FD_FDN_CASE(9) FD_FDN_CASE(10) FD_FDN_CASE(11) FD_FDN_CASE(12) FD_FDN_CASE(13) FD_FDN_CASE(14)
             FD_FDN_CASE(15) FD_FDN_CASE(16) FD_FDN_CASE(17) FD_FDN_CASE(18)
 #undef FD_FDN_CASE
         default:  // longer than 2^18 slots (5.4 s at 48 kHz): the lane = line kernel takes any capacity (reverb_stereo; fdn_configure
                   // refuses such a reverb4_stereo)
-            hipLaunchKernelGGL(k_fdn_render<1>, grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout);
+            hipLaunchKernelGGL(k_fdn_render<1>, grid, block, 0, stream, c, s, instances, in, out, T, fstride, layout, bus);
         }
     } else if ((instances + 1) / 2 < 2 * (size_t)simd_count()) {
         // lane = line kernel: one instance per wave while that is what it takes to have two waves per SIMD
         const unsigned grid = (unsigned)((instances + 3) / 4);
-        hipLaunchKernelGGL(k_fdn_render<1>, dim3(grid), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout);
+        hipLaunchKernelGGL(k_fdn_render<1>, dim3(grid), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout, bus);
     } else {
         const unsigned grid = (unsigned)((instances + 7) / 8);
-        hipLaunchKernelGGL(k_fdn_render<2>, dim3(grid), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout);
+        hipLaunchKernelGGL(k_fdn_render<2>, dim3(grid), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout, bus);
     }
 }
 

@@ -63,6 +63,26 @@ struct FdnState {
     float* fb;               // [instances][32]   Feedback::value
 };
 
+// A gain and a dry bus around the network -- the way the reference's documentation puts its reverbs to use: `multipass() & 0.2 * reverb_stereo(20.0,
+// 2.0, 1.0)` (README.md:436), `0.2 * reverb_stereo(10.0, 1.0, 0.5) & multipass()` (wave.rs:514), `wet * reverb_stereo(10.0, time) & (1.0 - wet) *
+// multipass()` (CHANGES.md:203).  `wet * node` is Unop<X, FrameMulScalar> (combinator.rs:477-488; every output sample times the scalar,
+// audionode.rs:1190-1228), `x & y` is Bus (audionode.rs:1842-1877: both sides see the node's input, the outputs are added -- tick :1862-1866 and
+// process :1868-1877 the same one addition per sample), MultiPass hands its input on (:373-403).  Folded into the kernels' epilogue (the block's
+// input frames are still in registers there): out = wet * y (mode 1), out = dry * in + wet * y (mode 2), one rounding per operation like the
+// reference's three nodes; a factor of 1.0 is the node the host left out (x * 1.0 == x).  Mode 2 needs as many outputs as inputs.
+struct FdnBus {
+    int mode = 0;            // 0: the network alone | 1: wet * network | 2: dry * multipass() & wet * network
+    float wet = 1.0f, dry = 1.0f;
+};
+// (the bus of one output sample; `x` = the input sample of the same channel and frame)
+__device__ __forceinline__ float fdn_bus(const FdnBus& b, float y, float x) {
+    if (b.mode == 0) return y;
+    const float w = b.wet * y;
+    if (b.mode == 1) return w;
+    const float d = b.dry * x;
+    return d + w;
+}
+
 // host: constants of reverb_stereo(room_size, time, damping) at `sample_rate` (prelude.rs:1739-1759)
 void fdn_make_const(double room_size, double time, double damping, double sample_rate, FdnConst* c);
 void fdn_launch_reset(const FdnConst& c, const FdnState& s, size_t instances, hipStream_t stream);
@@ -74,7 +94,7 @@ void fdn_make_const_reverb4(double room_size, double time, double sample_rate, F
 // host: constants of the generic network at `sample_rate`
 void fdn_make_const_generic(const FdnDesc& d, double sample_rate, FdnConst* c);
 void fdn_launch_render(const FdnConst& c, const FdnState& s, size_t instances, const float* in, float* out, size_t T,
-                       size_t fstride, int layout, int tick_mode, hipStream_t stream);
+                       size_t fstride, int layout, int tick_mode, hipStream_t stream, const FdnBus& bus = FdnBus());
 
 // [channels][T][V] (voice-minor) <-> [V][channels][T] (planar, frame stride T): the staging copies of voice-minor launches (fd_fdn.hip)
 void fdn_launch_transpose(const float* src, float* dst, size_t V, size_t T, int channels, bool to_planar, hipStream_t stream);

@@ -106,7 +106,7 @@ constexpr int RS = 68;  // floats per row of the filter hand-over tiles (16-byte
 
 template <int FK>
 __global__ __launch_bounds__(256) void k_rv3_render(Rv3Const c, Rv3State s, size_t V, const float* __restrict__ in, float* __restrict__ out,
-                                                    size_t T, size_t fstride, int layout) {
+                                                    size_t T, size_t fstride, int layout, FdnBus bus) {
     __shared__ float tile_all[4][8 * RS];
     const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* tile = tile_all[wib];
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_rv3_render(Rv3Const c, Rv3State s, size
             float f0[8];
 #pragma unroll
             for (int b = 0; b < 8; b++) f0[b] = tile[b * RS + lane];
-            const float out0 = f0[7];
+            float out0 = f0[7];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -297,6 +297,10 @@ __global__ __launch_bounds__(256) void k_rv3_render(Rv3Const c, Rv3State s, size
                     if (pos < 64) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f1), rings, (c.cap + pos) * 4, base * 4, 0);
                 }
             }
+            if (bus.mode) {  // wet * reverb3_stereo(..) [& dry * multipass()] (fd_fdn.hpp FdnBus)
+                out0 = fdn_bus(bus, out0, in0);
+                out1 = fdn_bus(bus, out1, in1);
+            }
             if (lane < size) {
                 if (layout == 0) {
                     out[((size_t)0 * T + t0 + lane) * V + inst] = out0;
@@ -340,11 +344,11 @@ void rv3_launch_migrate(const Rv3Const& from, const Rv3State& sfrom, const Rv3Co
     hipLaunchKernelGGL(k_rv3_migrate, dim3((unsigned)instances), dim3(64), 0, stream, from, sfrom, to, sto, instances);
 }
 void rv3_launch_render(const Rv3Const& c, const Rv3State& s, size_t instances, const float* in, float* out, size_t T, size_t fstride,
-                       int layout, hipStream_t stream) {
+                       int layout, hipStream_t stream, const FdnBus& bus) {
     if (instances == 0 || T == 0) return;
     tl_opts.last_kernel = LK_FDN_FRAMES;
-    if (c.fkind == 1) hipLaunchKernelGGL(k_rv3_render<1>, dim3((unsigned)((instances + 3) / 4)), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout);
-    else hipLaunchKernelGGL(k_rv3_render<0>, dim3((unsigned)((instances + 3) / 4)), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout);
+    if (c.fkind == 1) hipLaunchKernelGGL(k_rv3_render<1>, dim3((unsigned)((instances + 3) / 4)), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout, bus);
+    else hipLaunchKernelGGL(k_rv3_render<0>, dim3((unsigned)((instances + 3) / 4)), dim3(256), 0, stream, c, s, instances, in, out, T, fstride, layout, bus);
 }
 
 }  // namespace fd

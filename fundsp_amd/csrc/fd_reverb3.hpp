@@ -26,6 +26,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "fd_fdn.hpp"   // FdnBus: the gain and dry bus the lane-per-frame kernels fold into their epilogue
+
 namespace fd {
 
 constexpr int RV3_PRE_CAP = 512;   // slots per `pre` ring (their delays are 245 .. 367 samples at every rate)
@@ -65,6 +67,6 @@ void rv3_launch_reset(const Rv3Const& c, const Rv3State& s, size_t instances, hi
 // does not reset survives -- every allpass's z (the sample it reads next), the feedback sample, the filters' values, all of `pre`
 void rv3_launch_migrate(const Rv3Const& from, const Rv3State& sfrom, const Rv3Const& to, const Rv3State& sto, size_t instances, hipStream_t stream);
 void rv3_launch_render(const Rv3Const& c, const Rv3State& s, size_t instances, const float* in, float* out, size_t T, size_t fstride,
-                       int layout, hipStream_t stream);
+                       int layout, hipStream_t stream, const FdnBus& bus = FdnBus());
 
 }  // namespace fd

@@ -49,7 +49,9 @@ class Graph:
     def __and__(self, other):  # Bus, combinator.rs `&`
         if self.nin != other.nin or self.nout != other.nout:
             raise TypeError("Bus arity mismatch")
-        return self._pair(other, "Bus", self.nin, self.nout)
+        g = self._pair(other, "Bus", self.nin, self.nout)
+        g.bus_parts = (self, other)    # bus_plan: `multipass() & wet * reverb` around a lane-per-frame bank (fdsp_bank_set_bus)
+        return g
 
     def __xor__(self, other):  # Branch, combinator.rs `^`
         if self.nin != other.nin:
@@ -71,7 +73,9 @@ class Graph:
         ps = [((0,) + p, f, v, uu) for p, f, v, uu in self.params]
         if scalar is not None:
             ps.append(((), "scalar", scalar, False))
-        return Graph(f"Unop<{self.type},{u}>", self.nin, self.nout, ps, self.rings, self.source)
+        g = Graph(f"Unop<{self.type},{u}>", self.nin, self.nout, ps, self.rings, self.source)
+        g.unop_parts = (self, u, scalar)
+        return g
 
     def __mul__(self, o): return self._binop(o, "OpMul") if isinstance(o, Graph) else self._unop("UMulScalar", o)
     def __rmul__(self, o): return self._unop("UMulScalar", o)
@@ -656,6 +660,40 @@ def fdn_plan(g):
     if len(vals) != n * (1 + taps):
         return None           # something else carries parameters (builders on the nodes): not this shape
     return dict(lines=n, delays=delays, taps=taps, weights=[float(x) for x in ws[0]], inputs=nin, outputs=nout)
+
+
+def lane_per_frame_shape(g):
+    """whether `g` is one of the nodes / networks with a lane-per-frame kernel (what Bank.from_graph builds as an FDN / reverb bank)"""
+    return getattr(g, "stock_reverb", None) is not None or getattr(g, "reverb3_plan", None) is not None or fdn_plan(g) is not None
+
+
+def bus_plan(g):
+    """(inner graph, mode, wet, dry) -- the arguments of fdsp_bank_set_bus -- when `g` is a gain and / or a dry bus around `inner`, the shapes the
+    reference's documentation gives its reverbs (README.md:436, wave.rs:514, CHANGES.md:203, net.rs:681):
+
+        wet * inner                        (FDSP_BUS_WET)        Unop<X, FrameMulScalar>, combinator.rs:477-488
+        multipass() & wet * inner          (FDSP_BUS_DRY_WET)    Bus, audionode.rs:1842-1877; either order of the `&`,
+        dry * multipass() & wet * inner                          with or without the factors (`pass()` for a mono network)
+
+    with scalar factors (the same bus in every instance); else None.  Bank.from_graph folds such a bus into the inner bank's render kernel when
+    `inner` has a lane-per-frame kernel (lane_per_frame_shape)."""
+    def scaled(x):
+        up = getattr(x, "unop_parts", None)
+        if up is not None and up[1] == "UMulScalar" and np.asarray(up[2]).ndim == 0:
+            return up[0], float(np.float32(up[2]))
+        return x, None
+
+    bp = getattr(g, "bus_parts", None)
+    if bp is None:
+        inner, wet = scaled(g)
+        return None if wet is None else (inner, 1, wet, 1.0)
+    for dry_side, wet_side in (bp, bp[::-1]):
+        d, dry = scaled(dry_side)
+        if not (d.type == "Pass" or d.type.startswith("MultiPass<")) or d.params:
+            continue
+        inner, wet = scaled(wet_side)
+        return inner, 2, 1.0 if wet is None else wet, 1.0 if dry is None else dry
+    return None
 
 
 def uses_wavetables(g):

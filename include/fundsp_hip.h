@@ -224,6 +224,28 @@ int fdsp_reverb3_stereo_create(size_t instances, double time, double diffusion, 
  * `gain` an amplitude (bell / shelves).  Same kernel; the sixteen filters' recurrences (src/svf.rs:995-1006) run on the eight serial lanes. */
 int fdsp_reverb3_stereo_svf_create(size_t instances, double time, double diffusion, int svf_mode, float cutoff_hz, float q, float gain, fdsp_bank** out);
 int fdsp_fdn_create(size_t instances, int lines, const double* delays, int taps, const float* weights, int inputs, int outputs, fdsp_bank** out);
+/* A gain and a dry bus around a reverb / network bank -- the shape the reference's documentation gives its reverbs:
+ *     multipass() & 0.2 * reverb_stereo(20.0, 2.0, 1.0)                       README.md:436 ("to add 20% reverb to a stereo signal")
+ *     0.2 * reverb_stereo(10.0, 1.0, 0.5) & multipass()                       src/wave.rs:514
+ *     wet * reverb_stereo(10.0, time) & (1.0 - wet) * multipass()             CHANGES.md:203
+ * `wet * node` is Unop<X, FrameMulScalar> (src/combinator.rs:477-488, src/audionode.rs:1190-1228: every output sample times the scalar),
+ * `x & y` is Bus<X, Y> (src/audionode.rs:1842-1877: both sides take the node's input and the outputs are added, one addition per sample in
+ * tick :1862-1866 and in process :1868-1877), multipass() hands its input on (:373-403).  The render kernels fold these nodes into their
+ * epilogue (the block's input frames are still in registers there; no second pass over the output, no buffer for the wet signal):
+ *     FDSP_BUS_NONE     out = node(in)                          (the bank as created)
+ *     FDSP_BUS_WET      out = wet * node(in)                    `wet * node`; `dry` ignored
+ *     FDSP_BUS_DRY_WET  out = dry * in + wet * node(in)         `dry * multipass() & wet * node` in either order of the `&` (f32 addition commutes);
+ *                                                               needs inputs == outputs (Bus: both sides have the same arities)
+ * one f32 rounding per multiplication and per addition, as the reference's three nodes; pass 1.0 for a factor the graph does not have (x * 1.0 is x
+ * bit for bit, so `multipass() & 0.2 * node` is (FDSP_BUS_DRY_WET, 0.2, 1.0) and `multipass() & node` (src/net.rs:681) is (.., 1.0, 1.0)).  A host-side
+ * setting: takes effect at the next launch, survives reset / set_sample_rate, travels with fdsp_bank_clone.  Banks of the reverb / network
+ * constructors above only (FDSP_ENOTSUP otherwise: a compiled graph carries its bus in its type).  The nodes' pings are no concern of the bank: none
+ * of these nodes keeps hashed state (a generator in FRONT of the bus is seeded by the host from the whole graph's construction hash). */
+#define FDSP_BUS_NONE 0
+#define FDSP_BUS_WET 1
+#define FDSP_BUS_DRY_WET 2
+int fdsp_bank_set_bus(fdsp_bank* bank, int mode, float wet, float dry);
+int fdsp_bank_get_bus(const fdsp_bank* bank, int* mode, float* wet, float* dry);
 /* Several GPUs from one process.  A bank lives on ONE device, fixed at creation: the `_on` constructors take the HIP
  * device index (-1 = the calling thread's current device, which is what the constructors above use).  Every entry point
  * that takes a bank makes the bank's device current for its own duration and restores the caller's, so a host thread

@@ -583,6 +583,10 @@ class Bank {
         b.ring_frames_ = ring_frames_;
         return b;
     }
+    // A gain and a dry bus around a reverb / network bank, folded into its render kernel (fdsp_bank_set_bus): FDSP_BUS_WET = `wet * node`,
+    // FDSP_BUS_DRY_WET = `dry * multipass() & wet * node` -- README.md:436 `multipass() & 0.2 * reverb_stereo(20.0, 2.0, 1.0)` is
+    // set_bus(FDSP_BUS_DRY_WET, 0.2f) --, FDSP_BUS_NONE = the node alone.  Unop<X, FrameMulScalar> + Bus + MultiPass: audionode.rs:1190-1228, 1842-1877, 373-403
+    void set_bus(int mode, float wet = 1.0f, float dry = 1.0f) { check(fdsp_bank_set_bus(h_, mode, wet, dry)); }
     // launch options of this bank ("pipe_split", "time_split", "fdn_kernel", "timing", "math"; -1 = process-wide default)
     void set_option(const std::string& name, int value) { check(fdsp_bank_set_option(h_, name.c_str(), value)); }
     int get_option(const std::string& name) const {

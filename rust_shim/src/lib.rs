@@ -67,6 +67,7 @@ pub mod ffi {
         pub fn fdsp_bank_set_param(bank: *mut FdspBank, name: *const c_char, values: *const f32, first: usize, count: usize) -> c_int;
         pub fn fdsp_bank_set_param_all(bank: *mut FdspBank, name: *const c_char, value: f32) -> c_int;
         pub fn fdsp_bank_set_option(bank: *mut FdspBank, name: *const c_char, value: c_int) -> c_int;
+        pub fn fdsp_bank_set_bus(bank: *mut FdspBank, mode: c_int, wet: f32, dry: f32) -> c_int;
         pub fn fdsp_bank_slot_count(bank: *const FdspBank) -> c_int;
         pub fn fdsp_bank_get_state(bank: *mut FdspBank, slots: *mut f32) -> c_int; // Clone
         pub fn fdsp_bank_set_state(bank: *mut FdspBank, slots: *const f32) -> c_int;
@@ -259,6 +260,13 @@ impl<NI: Size<f32>, NO: Size<f32>> HipBank<NI, NO> {
     /// `AudioNode::set_seed` per voice (`ping(false, AttoHash::new(seed))`).
     pub fn set_seeds(&mut self, seeds: &[u64]) -> Result<(), String> {
         check(unsafe { fdsp_bank_set_seed(self.bank, seeds.as_ptr(), 0, seeds.len()) })
+    }
+
+    /// `dry * multipass() & wet * node` around a reverb / network bank (src/audionode.rs:1842-1877 `Bus`, :1190-1228 `FrameMulScalar`), folded
+    /// into the bank's render kernel: README.md:436's `multipass() & 0.2 * reverb_stereo(20.0, 2.0, 1.0)` is `set_bus(Some(1.0), 0.2)`;
+    /// `None` for the dry side leaves `wet * node` alone.  Factors of 1.0 are the nodes a graph leaves out (x * 1.0 == x).
+    pub fn set_bus(&mut self, dry: Option<f32>, wet: f32) -> Result<(), String> {
+        check(unsafe { fdsp_bank_set_bus(self.bank, if dry.is_some() { 2 } else { 1 }, wet, dry.unwrap_or(1.0)) })
     }
 
     /// Tolerance mode (FDSP_MATH_FAST): FMA polynomials for feed-forward transcendentals, recurrences exact.

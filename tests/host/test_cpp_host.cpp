@@ -282,6 +282,29 @@ static void gpu_checks() {
         }
         o_free(n);
     }
+    // README.md:436, "to add 20% reverb to a stereo signal": multipass() & 0.2 * reverb_stereo(20.0, 2.0, 1.0) -- the reverb's bank with the gain and the
+    // dry bus folded into its kernel (Bank::set_bus) against the oracle's graph of Bus, MultiPass, Unop and the reverb, block by block
+    {
+        Bank b = Bank::reverb_stereo(2, 20.0, 2.0, 1.0);
+        b.set_sample_rate(SR);
+        b.set_bus(FDSP_BUS_DRY_WET, 0.2f);
+        onode* n = o_bus(o_multipass(2), o_unop(O_MUL_SCALAR, o_reverb_stereo(20.0, 2.0, 1.0), 0.2f));
+        o_set_sample_rate(n, SR);
+        uint32_t s = 99;
+        for (int blk = 0; blk < 120; blk++) {   // 7 680 frames: past the longest line's first return (20 m room)
+            std::vector<float> x(2 * 2 * 64, 0.0f), got(2 * 2 * 64), want(2 * 64);
+            if (blk < 30)
+                for (int i = 0; i < 128; i++) {
+                    s = s * 1664525u + 1013904223u;
+                    x[i] = x[128 + i] = (float)(s >> 8) * (1.0f / 8388608.0f) - 1.0f;
+                }
+            b.process(64, x.data(), got.data());
+            o_process(n, 64, x.data(), want.data());
+            if (!bit_equal(got.data(), want.data(), 128, "multipass() & 0.2 * reverb_stereo, instance 0")) break;
+            if (!bit_equal(got.data() + 128, want.data(), 128, "multipass() & 0.2 * reverb_stereo, instance 1")) break;
+        }
+        o_free(n);
+    }
     // a filter with an input: noise through the C ABI, the same samples through the oracle
     {
         Bank b("fixed_svf", 1);
