@@ -125,3 +125,67 @@ def test_random_graph_matches_oracle(gpu, seed):
             n.set_sample_rate(SR)
             n.set_seed(int(seeds[v]))
             assert_bit_equal(got[v], oracle_render(n, None if x is None else x[v], T, mode), f"seed {seed} voice {v} mode {mode}: {tree}")
+
+
+def wide_tree(rng):
+    """A wide sum (sumi / busi over 8..14 branches of one random shape, parameters varying with the branch index) at the head of a random spine of
+    Pipe / Unop nodes -- the shapes fd_device.hpp WideSplit takes branch-major, with the rest of the graph as the tail."""
+    n = int(rng.integers(8, 15))
+    bus = bool(rng.integers(2))
+    nin = int(rng.integers(0, 2)) if bus else int(rng.integers(0, 2))
+    nout = int(rng.integers(1, 3))
+    branch = gen(rng, nin, nout, depth=int(rng.integers(0, 3)))
+    spine = ("wide", "busi" if bus else "sumi", n, branch)
+    width = nout
+    for _ in range(int(rng.integers(0, 4))):
+        if rng.integers(3) == 0:
+            spine = ("unop", ["mul", "add", "neg", "rsub"][rng.integers(4)], float(np.float32(rng.uniform(-1.5, 1.5))), spine)
+        else:
+            k = int(rng.integers(1, 3))
+            spine = ("pipe", spine, gen(rng, width, k, depth=int(rng.integers(0, 3))))
+            width = k
+    gin = nin if bus else n * nin
+    return spine, gin, width
+
+
+def scale_tree(t, i):
+    """branch i of a wide sum: the same shape, every frequency-like leaf parameter moved with the branch index (sumi(|i| sine_hz(f * (i + 1))))"""
+    if not isinstance(t, tuple):
+        return t
+    if t[0] in ("sine_hz", "poly_saw_hz", "lowpass_hz", "lowpole_hz", "highpole_hz", "bell_hz", "moog_hz"):
+        return (t[0], float(np.float32(t[1] * (1.0 + 0.13 * i))),) + t[2:]
+    return tuple(scale_tree(x, i) for x in t)
+
+
+def build_wide(t, m):
+    if t[0] == "wide":
+        return getattr(m, t[1])(t[2], lambda i: build_wide(scale_tree(t[3], i), m))
+    if t[0] == "pipe":
+        return build_wide(t[1], m) >> build(t[2], m)
+    if t[0] == "unop":
+        x = build_wide(t[3], m)
+        return x * t[2] if t[1] == "mul" else x + t[2] if t[1] == "add" else -x if t[1] == "neg" else t[2] - x
+    return build(t, m)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_WIDE", "10"))))   # more for a bug hunt
+def test_random_wide_sum_with_a_tail_matches_oracle(gpu, seed):
+    """both wide kernels (the chain of waves, and with "pipe_split" 0 one wave per voice group), both executors, both layouts, ragged launch"""
+    rng = np.random.default_rng(int(os.environ.get("FUNDSP_FUZZ_SEED0", "1000")) + 50000 + seed)
+    tree, nin, nout = wide_tree(rng)
+    g = build_wide(tree, GR)
+    assert (g.nin, g.nout) == (nin, nout), tree
+    V, T = 67, 64 * 3 + 19
+    seeds = np.arange(V, dtype=np.uint64) * 977 + seed
+    x = noise_input(V, nin, T, seed=seed) if nin else None
+    for mode, layout, split in ((MODE_PROCESS, LAYOUT_VOICE_MINOR, 1), (MODE_TICK, LAYOUT_PLANAR, 1), (MODE_PROCESS, LAYOUT_PLANAR, 0), (MODE_TICK, LAYOUT_VOICE_MINOR, 0)):
+        b = gpu.Bank.from_graph(g, V, ring_frames=256 if g.rings else 0, sample_rate=SR)
+        b.set_option("pipe_split", split)
+        b.set_seed(seeds)
+        got = run_bank(b, x, T, layout, mode)
+        assert b.get_option("last_kernel") == (8 if split else 1), (b.get_option("last_kernel"), tree)
+        for v in (0, 63, V - 1):
+            n = build_wide(tree, O)
+            n.set_sample_rate(SR)
+            n.set_seed(int(seeds[v]))
+            assert_bit_equal(got[v], oracle_render(n, None if x is None else x[v], T, mode), f"seed {seed} voice {v} mode {mode} split {split}: {tree}")

@@ -122,6 +122,17 @@ def test_set_bus_by_hand_clone_reset_and_errors(gpu):
     want = (x + np.float32(0.2) * plain).astype(np.float32)     # one rounding per operation: dry * in (in * 1.0 = in) + wet * y
     assert_bit_equal(got[0], want[0], "the bus is x + 0.2 * (the bank without it)")
     assert_bit_equal(got[3], want[3], "the bus is x + 0.2 * (the bank without it)")
+    # the other formulation of reverb_stereo (one lane per delay line, "fdn_kernel" 1) reads the block's inputs back from its LDS tile
+    for V2, T2 in ((V, T), (4100, 64 * 6 + 3)):                 # one instance per wave | two (banks of 4 096 instances and more)
+        x2 = inputs(V2, 2, T2, seed=11)
+        lines, frames_ = gpu.Bank.reverb_stereo(V2, 10.0, 1.0, 0.5), gpu.Bank.reverb_stereo(V2, 10.0, 1.0, 0.5)
+        for bank, k in ((lines, 1), (frames_, 0)):
+            bank.set_sample_rate(SR)
+            bank.set_option("fdn_kernel", k)
+            bank.set_bus(BUS_DRY_WET, 0.2, 0.9)
+        got_lines = run_bank(lines, x2, T2, LAYOUT_PLANAR, MODE_PROCESS)
+        assert lines.get_option("last_kernel") == 7
+        assert_bit_equal(got_lines, run_bank(frames_, x2, T2, LAYOUT_PLANAR, MODE_PROCESS), f"lane = line kernel with the bus == lane = frame kernel ({V2} instances)")
     b.set_sample_rate(44100.0)                                  # the setting survives a re-configuration of the rings
     assert b.get_bus()[0] == BUS_DRY_WET
     b.set_bus(BUS_NONE)
