@@ -208,6 +208,7 @@ template <class G> struct WideGeom {  // channels a block tile holds: the sum's,
     static constexpr bool ok = WideSplit<G>::ok;
     static constexpr bool BARE = SameType<G, H>::v;
     static constexpr int NO = H::OUT, TO = G::OUT, C = NO > TO ? NO : TO;
+    static constexpr int X = C - NO;   // channels the tail adds to the sum's: they live in a tile of their own next to the travelling ones (the chain)
 };
 
 // input sample of graph channel `ch` at frame t for voice v (the branches of a MultiBus share the graph's inputs, those of a Reduce have their own:
@@ -305,20 +306,35 @@ FD_D void wide_fold(int b0, int b1, int K, float* __restrict__ slots, size_t str
 }
 
 // The finished fold of one block -> the graph's output: through the tail (if the sum is not the whole graph), then to HBM.  Voice-minor: straight from
-// registers / the lane's column; planar: through the tile `tile0` ([channel][frame][voice]), transposed.  `acc` (FAST) or the column `accl` hold the sum.
+// registers / the lane's column; planar: through the tile `tile0` ([channel][frame][voice]; channels past the sum's in `tilex`), transposed.  `acc` (FAST) or the lane's column of `tile0` hold the sum.
 template <class G, int MODE, int LAYOUT, bool FAST, class ACC, class TAIL>
-FD_D void wide_finish(TAIL& tail, ACC& acc, float* accl, float* tile0, float* __restrict__ out, size_t T, size_t V, size_t v0, size_t v, bool active,
+FD_D void wide_finish(TAIL& tail, ACC& acc, float* tile0, float* tilex, float* __restrict__ out, size_t T, size_t V, size_t v0, size_t v, bool active,
                       int lane, size_t fstride, size_t t0, int size) {
     using GEO = WideGeom<G>;
     constexpr int NO = GEO::NO, TO = GEO::TO;
+    // channel c of the block: the sum's NO channels in the tile that travelled with the block, the channels a wider tail adds (mono sum >> pan) in `tilex`
+    auto chp = [&](int c) { return c < NO ? tile0 + c * 4096 : tilex + (c - NO) * 4096; };
+    auto colp = [&](int c) { return chp(c) + lane; };   // ... this lane's column of it: colp(c)[frame * 64]
     const int full = MODE == MODE_PROCESS ? (size & ~7) : 0;
     if constexpr (FAST) {
-        v2f res[TO][32];
+        // a finished frame pair of channel c leaves at once -- to HBM (voice-minor) or into the lane's column (planar: the tile is free, the sum is in
+        // registers) --, so the block's output never sits in registers next to the accumulator (a chain of eight waves has 256 VGPRs per wave)
+        auto emit = [&](int c, int q, v2f p) {
+            if (LAYOUT == LAYOUT_VOICE_MINOR) {
+                if (active) {
+                    out[((size_t)c * T + t0 + 2 * q) * V + v] = p.x;
+                    out[((size_t)c * T + t0 + 2 * q + 1) * V + v] = p.y;
+                }
+            } else {
+                colp(c)[(2 * q) * 64] = p.x;
+                colp(c)[(2 * q + 1) * 64] = p.y;
+            }
+        };
         if constexpr (GEO::BARE) {
 #pragma unroll
             for (int c = 0; c < TO; c++)
 #pragma unroll
-                for (int q = 0; q < 32; q++) res[c][q] = acc[c][q];
+                for (int q = 0; q < 32; q++) emit(c, q, acc[c][q]);
         } else {
             tail.begin_block(64);
             const TAIL snap = tail;
@@ -329,51 +345,34 @@ FD_D void wide_finish(TAIL& tail, ACC& acc, float* accl, float* tile0, float* __
                 for (int c = 0; c < NO; c++) pi[c] = acc[c][q];
                 tail.template step2<PH_SIMD>(pi, po);
 #pragma unroll
-                for (int c = 0; c < TO; c++) res[c][q] = po[c];
+                for (int c = 0; c < TO; c++) emit(c, q, po[c]);
             }
-            if (__builtin_expect(tail.tripped(), 0)) {  // the tail's packed path left its exact domain: its block again, scalar, through the column
+            if (__builtin_expect(tail.tripped(), 0)) {  // the tail's packed path left its exact domain: its block again, scalar, through the columns -- and out again, over what the packed pass wrote
                 tail = snap;
 #pragma unroll
                 for (int c = 0; c < NO; c++)
 #pragma unroll
                     for (int q = 0; q < 32; q++) {
-                        accl[(c * 64 + 2 * q) * 64] = acc[c][q].x;
-                        accl[(c * 64 + 2 * q + 1) * 64] = acc[c][q].y;
+                        colp(c)[(2 * q) * 64] = acc[c][q].x;
+                        colp(c)[(2 * q + 1) * 64] = acc[c][q].y;
                     }
 #pragma unroll 1
                 for (int f = 0; f < 64; f++) {
                     float fi[NO], fo[TO];
 #pragma unroll
-                    for (int c = 0; c < NO; c++) fi[c] = accl[(c * 64 + f) * 64];
+                    for (int c = 0; c < NO; c++) fi[c] = colp(c)[(f) * 64];
                     tail.template step<PH_SIMD>(fi, fo);
 #pragma unroll
-                    for (int c = 0; c < TO; c++) accl[(c * 64 + f) * 64] = fo[c];   // (frame f's inputs are consumed: TO >= NO columns exist)
+                    for (int c = 0; c < TO; c++) colp(c)[(f) * 64] = fo[c];   // (frame f's inputs are consumed)
                 }
+                if (LAYOUT == LAYOUT_VOICE_MINOR && active) {
+#pragma unroll 1
+                    for (int f = 0; f < 64; f++)
 #pragma unroll
-                for (int c = 0; c < TO; c++)
-#pragma unroll
-                    for (int q = 0; q < 32; q++) res[c][q] = v2f{accl[(c * 64 + 2 * q) * 64], accl[(c * 64 + 2 * q + 1) * 64]};
+                        for (int c = 0; c < TO; c++) out[((size_t)c * T + t0 + f) * V + v] = colp(c)[(f) * 64];
+                }
             }
             tail.end_simd();
-        }
-        if (LAYOUT == LAYOUT_VOICE_MINOR) {
-            if (active) {
-#pragma unroll
-                for (int c = 0; c < TO; c++)
-#pragma unroll
-                    for (int q = 0; q < 32; q++) {
-                        out[((size_t)c * T + t0 + 2 * q) * V + v] = res[c][q].x;
-                        out[((size_t)c * T + t0 + 2 * q + 1) * V + v] = res[c][q].y;
-                    }
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < TO; c++)
-#pragma unroll
-                for (int q = 0; q < 32; q++) {
-                    accl[(c * 64 + 2 * q) * 64] = res[c][q].x;
-                    accl[(c * 64 + 2 * q + 1) * 64] = res[c][q].y;
-                }
         }
     } else {
         if constexpr (!GEO::BARE) {
@@ -382,7 +381,7 @@ FD_D void wide_finish(TAIL& tail, ACC& acc, float* accl, float* tile0, float* __
             for (int f = 0; f < size; f++) {
                 float fi[NO], fo[TO];
 #pragma unroll
-                for (int c = 0; c < NO; c++) fi[c] = accl[(c * 64 + f) * 64];
+                for (int c = 0; c < NO; c++) fi[c] = colp(c)[(f) * 64];
                 if (f < full) {
                     tail.template step<PH_SIMD>(fi, fo);
                 } else {
@@ -390,14 +389,14 @@ FD_D void wide_finish(TAIL& tail, ACC& acc, float* accl, float* tile0, float* __
                     tail.template step<(MODE == MODE_PROCESS ? PH_REM : PH_TICK)>(fi, fo);
                 }
 #pragma unroll
-                for (int c = 0; c < TO; c++) accl[(c * 64 + f) * 64] = fo[c];
+                for (int c = 0; c < TO; c++) colp(c)[(f) * 64] = fo[c];
             }
             if (MODE == MODE_PROCESS && full == size) tail.end_simd();
         }
         if (LAYOUT == LAYOUT_VOICE_MINOR && active) {
             for (int f = 0; f < size; f++)
 #pragma unroll
-                for (int c = 0; c < TO; c++) out[((size_t)c * T + t0 + f) * V + v] = accl[(c * 64 + f) * 64];
+                for (int c = 0; c < TO; c++) out[((size_t)c * T + t0 + f) * V + v] = colp(c)[(f) * 64];
         }
     }
     if (LAYOUT == LAYOUT_PLANAR) {  // tile [channel][frame][lane = voice] -> global [voice][channel][frame]: a lane writes 4 consecutive frames of one voice
@@ -410,8 +409,8 @@ FD_D void wide_finish(TAIL& tail, ACC& acc, float* accl, float* tile0, float* __
                 const int vr = rr * 4 + sub;
                 const size_t gv = v0 + vr;
                 if (gv < V) {
-                    float4 q4 = make_float4(tile0[(c * 64 + fr) * 64 + vr], tile0[(c * 64 + fr + 1) * 64 + vr], tile0[(c * 64 + fr + 2) * 64 + vr],
-                                            tile0[(c * 64 + fr + 3) * 64 + vr]);
+                    float4 q4 = make_float4(chp(c)[(fr) * 64 + vr], chp(c)[(fr + 1) * 64 + vr], chp(c)[(fr + 2) * 64 + vr],
+                                            chp(c)[(fr + 3) * 64 + vr]);
                     float* dst = out + (gv * TO + c) * fstride + t0 + fr;
                     if (vec && fr + 4 <= ((size + 3) & ~3)) {
                         *reinterpret_cast<float4*>(dst) = q4;
@@ -469,11 +468,11 @@ FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, c
         if (MODE == MODE_PROCESS && size == 64) {
             v2f acc[NO][32];
             wide_fold<G, MODE, LAYOUT, true>(0, N, K, slots, stride, V, v, active, vin, true, in, T, fstride, t0, size, aux, ring, ring_cap, acc, accl);
-            wide_finish<G, MODE, LAYOUT, true>(tail, acc, accl, tile0, out, T, V, v0, v, active, lane, fstride, t0, size);
+            wide_finish<G, MODE, LAYOUT, true>(tail, acc, tile0, tile0 + NO * 4096, out, T, V, v0, v, active, lane, fstride, t0, size);
         } else {
             int none = 0;
             wide_fold<G, MODE, LAYOUT, false>(0, N, K, slots, stride, V, v, active, vin, true, in, T, fstride, t0, size, aux, ring, ring_cap, none, accl);
-            wide_finish<G, MODE, LAYOUT, false>(tail, none, accl, tile0, out, T, V, v0, v, active, lane, fstride, t0, size);
+            wide_finish<G, MODE, LAYOUT, false>(tail, none, tile0, tile0 + NO * 4096, out, T, V, v0, v, active, lane, fstride, t0, size);
         }
     }
     if constexpr (!GEO::BARE) {
@@ -494,7 +493,7 @@ FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, c
 // workgroup per CU, two waves per SIMD), 4 for stereo tiles and for branches with inputs.
 template <class G> struct WideChain {
     static constexpr bool on = WideSplit<G>::ok;
-    static constexpr int W = !on ? 1 : (WideGeom<G>::C == 1 && G::IN == 0 ? 8 : 4);  // (branches with inputs keep 64 more samples in flight per block: 4 waves leave each the whole register file)
+    static constexpr int W = !on ? 1 : (WideGeom<G>::NO == 1 && G::IN == 0 ? 8 : 4);  // (branches with inputs keep 64 more samples in flight per block: 4 waves leave each the whole register file)
 };
 
 template <class G, int MODE, int LAYOUT>
@@ -511,8 +510,21 @@ FD_D void render_body_wide_chain(float* __restrict__ slots, size_t stride, size_
         const size_t v = v0 + lane;  // < stride: the slot / ring arrays are padded to whole voice groups (padding lanes own private zeroed columns)
         const bool active = v < V;
         const int K = wide_branch_words<G>();
-        const int b0 = w * N / W, b1 = (w + 1) * N / W;
-        __shared__ float tiles[W * C * 64 * 64];  // [tile][channel][frame][lane]
+        // The last wave also walks the tail: it gets fewer branches, by the tail's weight in branch units -- estimated from the state words of the
+        // two (a gain, an SVF and a panner behind sines: 16 words against 7, measured as two branches' worth).  Any partition into consecutive runs
+        // gives the same fold.
+        int E = 0;
+        if constexpr (!GEO::BARE) {
+            TAIL probe;
+            VCountWords c;
+            probe.visit(c);
+            E = (c.n + K / 2) / (K > 0 ? K : 1);
+            E = E < 1 ? 1 : (E > N / W ? N / W : E);
+        }
+        const int b0r = w * (N + E) / W, b1r = (w + 1) * (N + E) / W;
+        const int b0 = b0r < N ? b0r : N, b1 = b1r < N ? b1r : N;
+        __shared__ float tiles[(W * NO + GEO::X) * 64 * 64];  // [tile][channel of the sum][frame][lane], then the channels only the tail has (the last wave's)
+        float* tilex = tiles + W * NO * 64 * 64;
         TAIL tail;
         if constexpr (!GEO::BARE) {
             if (w == W - 1) {
@@ -528,7 +540,7 @@ FD_D void render_body_wide_chain(float* __restrict__ slots, size_t stride, size_
             if (r < (size_t)w || r - w >= nblocks) continue;
             const size_t k = r - w, t0 = k * 64;
             const int size = (int)((T - t0) < 64 ? (T - t0) : 64);
-            float* tile0 = tiles + (k % W) * (C * 64 * 64);
+            float* tile0 = tiles + (k % W) * (NO * 64 * 64);
             float* accl = tile0 + lane;  // this lane's column: accl[(c * 64 + frame) * 64]
             if (MODE == MODE_PROCESS && size == 64) {
                 v2f acc[NO][32];
@@ -540,7 +552,7 @@ FD_D void render_body_wide_chain(float* __restrict__ slots, size_t stride, size_
                 }
                 wide_fold<G, MODE, LAYOUT, true>(b0, b1, K, slots, stride, V, v, active, v, active, in, T, fstride, t0, size, aux, ring, ring_cap, acc, accl);
                 if (w == W - 1) {
-                    wide_finish<G, MODE, LAYOUT, true>(tail, acc, accl, tile0, out, T, V, v0, v, active, lane, fstride, t0, size);
+                    wide_finish<G, MODE, LAYOUT, true>(tail, acc, tile0, tilex, out, T, V, v0, v, active, lane, fstride, t0, size);
                 } else {
 #pragma unroll
                     for (int c = 0; c < NO; c++)
@@ -553,7 +565,7 @@ FD_D void render_body_wide_chain(float* __restrict__ slots, size_t stride, size_
             } else {  // the ragged last block, the tick executor: the fold in place, in the tile
                 int none = 0;
                 wide_fold<G, MODE, LAYOUT, false>(b0, b1, K, slots, stride, V, v, active, v, active, in, T, fstride, t0, size, aux, ring, ring_cap, none, accl);
-                if (w == W - 1) wide_finish<G, MODE, LAYOUT, false>(tail, none, accl, tile0, out, T, V, v0, v, active, lane, fstride, t0, size);
+                if (w == W - 1) wide_finish<G, MODE, LAYOUT, false>(tail, none, tile0, tilex, out, T, V, v0, v, active, lane, fstride, t0, size);
             }
         }
         if constexpr (!GEO::BARE) {
