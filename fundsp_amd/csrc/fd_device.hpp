@@ -489,8 +489,8 @@ FD_D void render_body_wide(float* __restrict__ slots, size_t stride, size_t V, c
 // as wave w - 1 left it, folds its own branches into it in order, and leaves it for wave w + 1; the last wave runs the tail and writes the output.  W
 // blocks are in flight, block k lives in tile k mod W for its whole trip, so one workgroup barrier per round hands every tile on; the fill and drain of
 // the chain cost W - 1 rounds per launch.  Same branch arithmetic, same fold, same slots traffic as render_body_wide -- bit-identical to it
-// (tests/test_gpu_wide_sum.py renders every case through both).  W = 8 for mono generators without a wider tail (8 tiles of 16 KB = 128 KB of LDS, one
-// workgroup per CU, two waves per SIMD), 4 for stereo tiles and for branches with inputs.
+// (tests/test_gpu_wide_sum.py renders every case through both).  W = 8 for mono sums of generators (8 tiles of 16 KB = 128 KB of LDS, one workgroup per
+// CU, two waves per SIMD; a stereo tail adds ONE 16 KB tile for its second channel, the finishing wave's), 4 for stereo sums and for branches with inputs.
 template <class G> struct WideChain {
     static constexpr bool on = WideSplit<G>::ok;
     static constexpr int W = !on ? 1 : (WideGeom<G>::NO == 1 && G::IN == 0 ? 8 : 4);  // (branches with inputs keep 64 more samples in flight per block: 4 waves leave each the whole register file)

@@ -172,3 +172,32 @@ def test_reverb4_stereo_full_size(gpu):
     a = b2.process(64 * 100, x[:, :, :6400].contiguous(), layout=LAYOUT_PLANAR, frame_stride=6400)
     b = b2.process(T - 6400, x[:, :, 6400:].contiguous(), layout=LAYOUT_PLANAR, frame_stride=T - 6400)
     assert torch.equal(out[:, :, :6400], a) and torch.equal(out[:, :, 6400:], b)
+
+
+def test_config5_with_the_documented_bus_full_size(gpu):
+    """README.md:436's `multipass() & 0.2 * reverb_stereo(20.0, 2.0, 1.0)` at config 5's sizes (2048 instances x 48 000 frames), built from the graph
+    (graph.bus_plan -> fdsp_bank_set_bus): spot instances against the oracle's WHOLE graph (Bus, MultiPass, Unop and the reverb), and -- the
+    size-independent property -- every sample of every instance equal to `in + 0.2 * (the bare reverb's output)`, one rounding per operation,
+    evaluated by separate elementwise kernels over the whole buffers."""
+    import torch
+
+    from fundsp_amd import BUS_DRY_WET
+    from fundsp_amd import graph as GR
+
+    V, T = 2048, 48000
+    bank = gpu.Bank.from_graph(GR.multipass(2) & 0.2 * GR.reverb_stereo(20.0, 2.0, 1.0), V, sample_rate=SR)
+    assert bank.kind == "reverb_stereo" and bank.get_bus()[0] == BUS_DRY_WET
+    g = torch.Generator(device="cuda").manual_seed(299)
+    x = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
+    out = bank.process(T, x, layout=LAYOUT_PLANAR, frame_stride=T)
+    torch.cuda.synchronize()
+    for v in (0, 1027, V - 1):
+        n = O.multipass(2) & 0.2 * O.reverb_stereo(20.0, 2.0, 1.0)
+        n.set_sample_rate(SR)
+        assert_bit_equal(out[v].cpu().numpy(), n.render_blocks(x[v].cpu().numpy()), f"multipass() & 0.2 * reverb_stereo full size, instance {v}")
+    bare = gpu.Bank.reverb_stereo(V, 20.0, 2.0, 1.0)
+    bare.set_sample_rate(SR)
+    y = bare.process(T, x, layout=LAYOUT_PLANAR, frame_stride=T)
+    torch.cuda.synchronize()
+    wet = y * torch.tensor(0.2, dtype=torch.float32, device="cuda")     # (one kernel per operation: no contraction)
+    assert torch.equal(out, x + wet)
