@@ -250,6 +250,19 @@ def make_workload(F, W, torch, config, V, T, sr, first, layout, math, voice_out=
         inp = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
         n_out, bps, slot_bytes = 2, 272, 512       # 32 ring reads + 32 ring writes + 2 in + 2 out, x 4 B
         kernel = "fd::k_fdn_render_frames (lane = frame, one wave per instance)" + ("" if config == 5 else ", two 16-line networks in series")
+    elif config == "5bus":
+        # the reverb as the reference's documentation uses it: `multipass() & 0.2 * reverb_stereo(20.0, 2.0, 1.0)` ("to add 20% reverb to a stereo signal",
+        # README.md:436), built from the GRAPH: Bank.from_graph recognises the bus (graph.bus_plan), builds the reverb's lane-per-frame bank and folds the
+        # Unop, MultiPass and Bus nodes into its kernel's epilogue (fdsp_bank_set_bus); planar I/O, stereo noise in
+        from fundsp_amd import graph as G
+
+        layout = F.LAYOUT_PLANAR
+        bank = F.Bank.from_graph(G.multipass(2) & 0.2 * G.reverb_stereo(20.0, 2.0, 1.0), V, sample_rate=sr)
+        assert bank.kind == "reverb_stereo" and bank.get_bus()[0] == F.BUS_DRY_WET, "Bank.from_graph did not fold the bus into the reverb's lane-per-frame bank"
+        g = torch.Generator(device="cuda").manual_seed(555 + first)
+        inp = torch.rand((V, 2, T), dtype=torch.float32, device="cuda", generator=g) * 2 - 1
+        n_out, bps, slot_bytes = 2, 272, 512       # the bare reverb's bytes: the bus reads and writes nothing of its own
+        kernel = "fd::k_fdn_render_frames (lane = frame, one wave per instance), dry / wet bus in the epilogue"
     elif config == "rv3":
         # reverb3_stereo(2.0, 0.5, lowpole_hz(8000.0)) -- the reference's own example (prelude.rs:1850-1856) -- built from the GRAPH: Bank.from_graph
         # sees the stock node and takes its lane-per-frame kernel (fdsp_reverb3_stereo_create); planar I/O, stereo noise in
@@ -552,6 +565,7 @@ def secondary(F, W, torch, sr, mode):
                                      (4, 32768, "config4_math_fast", "Msamples/s", "fast"),
                                      (5, 2048, "config5_reverb_stereo_2048", "M instance-frames/s", "exact"),
                                      ("5r4", 2048, "reverb4_stereo_2048", "M instance-frames/s", "exact"),
+                                     ("5bus", 2048, "reverb_stereo_with_its_documented_bus_2048", "M instance-frames/s", "exact"),
                                      ("fdn16", 4096, "fdn16_mono_reverb_from_graph_4096", "M instance-frames/s", "exact"),
                                      ("rv3", 2048, "reverb3_stereo_from_graph_2048", "M instance-frames/s", "exact")):
         T = 48000
@@ -567,6 +581,11 @@ def secondary(F, W, torch, sr, mode):
                 "Bank.from_graph: the stock node is rendered by its lane-per-frame kernel (fdsp_reverb3_stereo_create) -- the run-time compiled lane-per-voice Reverb3 node renders the "
                 "same samples ~160 x slower (profiles/r06_reverb3_probe.txt); 624 B per instance-frame (76 ring reads + 76 ring writes + 2 in + 2 out)"
                 if cfg == "rv3" else
+                f"the reverb as the reference's documentation uses it, `multipass() & 0.2 * reverb_stereo(20.0, 2.0, 1.0)` (README.md:436 'to add 20% reverb to a stereo signal'; "
+                f"Bus audionode.rs:1842-1877, Unop<X, FrameMulScalar> combinator.rs:477-488), {V} instances x {T} frames, built with Bank.from_graph: the bus is recognised and folded "
+                "into the epilogue of the reverb's lane-per-frame kernel (fdsp_bank_set_bus: out = in + 0.2 * y on the input frames the block still holds in registers) -- the same 272 B "
+                "per instance-frame as the bare reverb; the whole graph compiled as one lane-per-voice kernel renders the same samples ~220 x slower (profiles/r06_reverb_bus_probe.txt)"
+                if cfg == "5bus" else
                 f"the generic Hadamard network of the prelude's own example (prelude.rs:1334: split >> fdn::<U16>(stacki(delay >> fir)) >> join), {V} instances x {T} frames, built "
                 "with Bank.from_graph: the graph's shape is recognised and rendered by the lane-per-frame FDN kernel (fdsp_fdn_create) -- the run-time compiled lane-per-voice "
                 "form of the same graph renders the same samples ~130 x slower (profiles/r06_fdn_generic_probe.txt); 136 B per instance-frame (16 ring reads + 16 ring writes + 1 in + 1 out)"
@@ -600,7 +619,7 @@ def secondary(F, W, torch, sr, mode):
                 del mixbufs
             except Exception as e:
                 out[-1]["mode_b_fused_mix"] = {"error": repr(e)}
-        if math == "exact" and cfg != "5r4":
+        if math == "exact" and cfg not in ("5r4", "5bus"):
             try:
                 out[-1]["cpu_baseline"] = cpu_baseline_config(cfg, sr, T)
             except Exception as e:
