@@ -49,12 +49,15 @@ class Bank:
         self.sample_rate = _lib.DEFAULT_SR
 
     @classmethod
-    def from_graph(cls, graph, voices, ring_frames=0, sample_rate=None, fdn_kernel=True):
+    def from_graph(cls, graph, voices, ring_frames=0, sample_rate=None, fdn_kernel=True, flush_denormals=False):
         """Compile `graph` (fundsp_amd.graph notation) into a fused kernel set at run time and build a bank of `voices`
         instances of it with the graph's parameters applied (scalars to every voice, arrays per voice).
         A graph that IS a Hadamard feedback delay network (graph.fdn_plan: split >> fdn(stacki(delay >> fir)) >> join, uniform parameters,
         every delay longer than two blocks) becomes a bank of the lane-per-frame FDN kernel instead (fdsp_fdn_create) -- the same samples,
-        two orders of magnitude faster than one lane per voice; `fdn_kernel=False` keeps the run-time compiled form."""
+        two orders of magnitude faster than one lane per voice; `fdn_kernel=False` keeps the run-time compiled form.
+        `flush_denormals`: compile the graph with f32 denormals flushed although it has no Feedback node of its own -- the front half of a chain
+        whose other half has one (Feedback::new's prevent_denormals() sets FTZ + DAZ for the constructing thread, feedback.rs:96, denormal.rs:18: the
+        reference renders the WHOLE graph flushed, and so does the oracle)."""
         from . import graph as G
 
         stock = getattr(graph, "stock_reverb", None) if fdn_kernel else None
@@ -96,18 +99,28 @@ class Bank:
             eff.close()   # (a room too small for the kernel's two-block rule: the whole graph renders lane-per-voice)
         parts = getattr(graph, "pipe_parts", None) if fdn_kernel else None
         pbus = G.bus_plan(parts[1]) if parts is not None else None
-        if (parts is not None and parts[0].nin == 0 and parts[0].rings == 0 and not ring_frames and
-                (G.lane_per_frame_shape(parts[1]) or (pbus is not None and G.lane_per_frame_shape(pbus[0])))):
-            # `generator >> stock reverb / network` (the reference's own `reverb` bench: (noise() | noise()) >> reverb_stereo(..)): compiled as
-            # ONE lane-per-voice graph the delay lines are read one lane per instance; as a chain the generator keeps its fused kernel and
-            # the network its lane-per-frame kernel -- the same samples (the generator is seeded as the Pipe would seed it), 400-700 x faster
+        if parts is not None and (G.lane_per_frame_shape(parts[1]) or (pbus is not None and G.lane_per_frame_shape(pbus[0]))):
+            # `front >> stock reverb / network [with its bus]` -- the reference's own `reverb` bench, (noise() | noise()) >> reverb_stereo(..); an
+            # instrument or an effect chain in front of `multipass() & 0.2 * reverb_stereo(..)` (examples/beep.rs:105) --: compiled as ONE
+            # lane-per-voice graph the delay lines are read one lane per instance; as a chain the front keeps its fused kernel (inputs, delay
+            # rings and all) and the network its lane-per-frame kernel -- the same samples (the front is seeded as the Pipe would seed it, and
+            # flushes denormals when the network has a Feedback node, as the one graph would), 200-700 x faster
             eff = cls.from_graph(parts[1], voices, sample_rate=sample_rate)
             if isinstance(eff, Bank) and eff.kind in LANE_PER_FRAME_KINDS:
-                src = cls.from_graph(parts[0], voices, sample_rate=sample_rate)
+                src = cls.from_graph(parts[0], voices, ring_frames=ring_frames, sample_rate=sample_rate, flush_denormals=flush_denormals or "Feedback<" in parts[1].type)
                 return Chain(src, eff, construction_hash=probe_hash(graph))
             eff.close()
-        name = graph.kind_name()
-        rc = lib().fdsp_graph_compile_src(name.encode(), graph.type.encode(), graph.source.encode() if graph.source else None)
+        name, ctype, csrc = graph.kind_name(), graph.type, graph.source
+        if flush_denormals and "Feedback" not in ctype:
+            # the run-time compiler flushes a kind whose type expression names a Feedback node (fd_jit.hip): hand it the same type under an alias
+            # that does -- the type itself, every kernel specialisation keyed on it and the slot names are unchanged
+            import hashlib
+
+            alias = "FeedbackThreadFlushed_" + hashlib.sha1((ctype + "\0" + csrc).encode()).hexdigest()[:16]
+            csrc = (csrc + "\n" if csrc else "") + f"using {alias} = {ctype};"
+            ctype = alias
+            name = "jit_" + hashlib.sha1((ctype + "\0" + csrc).encode()).hexdigest()[:16]
+        rc = lib().fdsp_graph_compile_src(name.encode(), ctype.encode(), csrc.encode() if csrc else None)
         if rc < 0:
             check(rc)
         for kind in G.uses_wavetables(graph):

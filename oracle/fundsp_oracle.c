@@ -1375,6 +1375,9 @@ onode *o_reverb_stereo(double room_size, double time, double damping) {
     onode *n = o_new(O_REVERB_STEREO, 2, 2, 6);
     n->s.rv_room = room_size; n->s.rv_time = time; n->s.rv_damping = damping;
     n->s.rv_sr = 0.0;
+    n->ftz = 1; /* the node stands for a tree with a Feedback node in it: constructing it runs prevent_denormals() (feedback.rs:96), after which the
+                 * reference renders the WHOLE graph on that thread under FTZ + DAZ -- the nodes in front of the reverb and a dry bus around it
+                 * included, not only the reverb's own arithmetic (see o_feedback; combinators inherit the flag in ctor_ping) */
     leaf_set_sample_rate(n, DEFAULT_SR);
     return n;
 }

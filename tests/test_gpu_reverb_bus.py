@@ -181,3 +181,45 @@ def test_generator_into_a_bussed_reverb_is_a_chain_of_two_banks(gpu):
         n.set_sample_rate(SR)
         n.set_seed(int(seeds[v]))
         assert_bit_equal(got[v], oracle_render(n, None, T, MODE_TICK), f"set_seed, tick executor, instance {v}")
+
+
+def test_effect_chain_with_inputs_and_rings_in_front_of_a_bussed_reverb(gpu):
+    """An effect chain WITH inputs and delay rings in front of the reverb -- (lowpass_hz | (pass() & delay)) >> (multipass() & 0.3 * reverb_stereo(..)) --
+    is a chain of two banks too: the front in its fused kernel, compiled with flushed denormals because the one graph has a Feedback node (the
+    reference renders ALL of it under FTZ + DAZ once Feedback::new has run, feedback.rs:96); an instance in the denormal range is where a front
+    that kept its denormals would differ.  reverb3_stereo has no Feedback node: its front keeps IEEE denormals."""
+    V, T = 70, 64 * 25 + 11
+
+    def with_feedback(m):
+        return (m.lowpass_hz(800.0, 1.0) | (m.pass_() & m.delay(0.002))) >> (m.multipass(2) & 0.3 * m.reverb_stereo(10.0, 1.0, 0.5))
+
+    def without(m):
+        return (m.lowpole_hz(900.0) | m.lowpole_hz(700.0)) >> (m.multipass(2) & 0.3 * m.reverb3_stereo(2.0, 0.6, lambda: m.lowpole_hz(6000.0)))
+
+    for build_, effect in ((with_feedback, "reverb_stereo"), (without, "reverb3_stereo")):
+        x = inputs(V, 2, T, seed=21)
+        x[1] = (x[1] * np.float32(1e-8)).astype(np.float32)     # 1e-38 .. 1e-45: denormal products inside the front's filters
+        x[3, :, 300:] = 0.0                                     # a filter tail that decays through the denormal range
+        for mode, layout in ((MODE_PROCESS, LAYOUT_PLANAR), (MODE_TICK, LAYOUT_VOICE_MINOR)):
+            ch = gpu.Bank.from_graph(build_(GR), V, sample_rate=SR)
+            assert isinstance(ch, gpu.Chain) and ch.effect.kind == effect and (ch.inputs(), ch.outputs()) == (2, 2)
+            assert ch.effect.get_bus()[0] == BUS_DRY_WET
+            got = run(ch, x, layout, mode, [0, 64 * 7 + 5, T])
+            for v in (0, 1, 2, 3, 69):
+                n = build_(O)
+                n.set_sample_rate(SR)
+                want = [n.render_blocks(x[v][:, a:e]) if mode == MODE_PROCESS else n.render_ticks(x[v][:, a:e]) for a, e in ((0, 64 * 7 + 5), (64 * 7 + 5, T))]
+                assert_bit_equal(got[v], np.concatenate(want, axis=1), f"{effect} behind an effect chain, mode {mode} layout {layout} instance {v}")
+
+
+def test_flushed_front_differs_from_an_unflushed_one_only_in_the_denormal_range(gpu):
+    """the alias that makes the run-time compiler flush a kind (Bank.from_graph(.., flush_denormals=True)) changes nothing but that"""
+    V, T = 8, 64 * 6
+    g = lambda: GR.lowpole_hz(900.0) >> GR.lowpole_hz(500.0)
+    a, b = gpu.Bank.from_graph(g(), V, sample_rate=SR), gpu.Bank.from_graph(g(), V, sample_rate=SR, flush_denormals=True)
+    assert a.kind != b.kind
+    x = inputs(V, 1, T, seed=5)
+    x[1] = (x[1] * np.float32(1e-8)).astype(np.float32)
+    ya, yb = run_bank(a, x, T, LAYOUT_PLANAR, MODE_PROCESS), run_bank(b, x, T, LAYOUT_PLANAR, MODE_PROCESS)
+    assert_bit_equal(ya[0], yb[0], "normal range: identical")
+    assert np.abs(ya[1]).max() > 0 and np.abs(yb[1]).max() == 0   # the denormal instance: kept | flushed

@@ -89,3 +89,22 @@ def test_the_reverb_node_hands_on_the_hash_of_the_tree_it_stands_for():
             n.set_seed(12345)
         ya, yb = a.render_blocks(None, length=4000, block=64), b.render_blocks(None, length=4000, block=64)
         assert (ya.view(np.uint32) == yb.view(np.uint32)).all(), f"after set_seed, tail={tail}"
+
+
+def test_the_reverb_node_flushes_the_whole_graph_like_the_tree_it_stands_for():
+    """Constructing reverb_stereo constructs a Feedback node, and Feedback::new switches the thread to FTZ + DAZ for good (feedback.rs:96,
+    denormal.rs:18): the reference then renders the WHOLE graph flushed -- a filter in front of the reverb, a dry bus around it --, not just the
+    reverb's own arithmetic.  The native node must mark its graph the way the generic tree's Feedback node does: an input in the denormal range
+    through `(lowpass_hz | pass) >> (multipass() & 0.3 * reverb)` is where a node that only flushed inside its own tick gave the dry path's
+    denormals away (found by the chain-of-two-banks test of exactly this graph, tests/test_gpu_reverb_bus.py)."""
+    rng = np.random.default_rng(3)
+    x = ((rng.random((2, 700), dtype=np.float32) * 2 - 1) * f32(1e-38)).astype(np.float32)
+    x[:, 400:] *= f32(1e8)          # ... and back into the normal range
+    for executor in ("render_blocks", "render_ticks"):
+        outs = []
+        for rev in (O.reverb_stereo(10.0, 1.0, 0.5), _generic_reverb_stereo(O, 10.0, 1.0, 0.5)):
+            g = (O.lowpass_hz(800.0, 1.0) | O.pass_()) >> (O.multipass(2) & 0.3 * rev)
+            g.set_sample_rate(CG.SAMPLE_RATE)
+            outs.append(getattr(g, executor)(x))
+        assert (outs[0].view(np.uint32) == outs[1].view(np.uint32)).all(), executor
+        assert not outs[0][:, :400].any() and np.abs(outs[0][:, 400:]).max() > 1e-31, executor
