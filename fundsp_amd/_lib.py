@@ -53,6 +53,7 @@ SYMBOLS = {
     "fdsp_fdn_create_on": (_i, [_i, _sz, _i, C.POINTER(_d), _i, C.POINTER(C.c_float), _i, _i, C.POINTER(_P)]),
     "fdsp_bank_set_bus": (_i, [_P, _i, _f, _f]),
     "fdsp_bank_get_bus": (_i, [_P, C.POINTER(_i), C.POINTER(_f), C.POINTER(_f)]),
+    "fdsp_jit_compiler": (C.c_char_p, []),
     "fdsp_device_count": (_i, []),
     "fdsp_bank_create_on": (_i, [_i, _cs, _sz, _sz, C.POINTER(_P)]),
     "fdsp_reverb_stereo_create_on": (_i, [_i, _sz, _d, _d, _d, C.POINTER(_P)]),

@@ -24,6 +24,7 @@ thread_local std::string g_err;
 namespace fd {
 std::string jit_source_mix(const std::string& type_expr, const std::string& prelude);  // fd_jit.hip: the second module of a run-time compiled graph
 int jit_compile_src(const std::string& src, const std::string& type_expr, std::vector<char>* code, std::string* log);
+const char* jit_compiler_origin();
 }  // namespace fd
 namespace fd {
 // process-wide DEFAULTS (fdsp_set_option); a bank's own value (fdsp_bank_set_option) overrides them for that bank.  Atomics:
@@ -796,6 +797,8 @@ int fdsp_bank_get_option(const fdsp_bank* b, const char* name) {
     if (name && std::strcmp(name, "last_kernel") == 0) return b->last_kernel;
     return fail(FDSP_EINVAL, "unknown bank option");
 }
+
+const char* fdsp_jit_compiler(void) { return fd::jit_compiler_origin(); }
 
 int fdsp_graph_compile(const char* name, const char* type_expr) { return fdsp_graph_compile_src(name, type_expr, nullptr); }
 

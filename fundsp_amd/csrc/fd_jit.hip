@@ -6,7 +6,13 @@
 // library was built from (fd_math.hpp, fd_nodes.hpp, fd_device.hpp, read from fundsp_amd/csrc next to the .so) with the
 // same flags (-O3, -ffp-contract=off), so a JIT kind is sample-identical to the same graph compiled ahead of time.
 // No tracing, no IR: the "compiler" is the C++ template instantiation itself.
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE 1
+#endif
 #include <dlfcn.h>
+#include <link.h>
+#include <limits.h>
+#include <stdlib.h>
 #include <hip/hiprtc.h>
 
 #include <cstring>
@@ -42,6 +48,89 @@ bool read_file(const std::string& path, std::string* out) {
     ss << f.rdbuf();
     *out = ss.str();
     return true;
+}
+
+// ---- which compiler compiles the graphs ------------------------------------------------------------------------------------------
+// "hiprtc compiles the very headers the library was built from, with the same flags" is only half of the promise: it must also be the COMPILER the
+// library was built with.  Plain linkage does not guarantee that.  A host process may already hold another ROCm's libhiprtc / libamd_comgr under the
+// same sonames -- a PyTorch wheel bundles its own (ROCm 7.0's, next to this image's 7.2) and loads them first --, the dynamic loader then satisfies
+// this library's `libhiprtc.so.7` with THAT copy, and run-time compiled kinds come out of a different LLVM than the ahead-of-time ones.  Found the
+// hard way: the bundled 7.0 compiler MISCOMPILES the planar single-wave kernel of `(mls() ^ impulse()) + c` (it allocates the Impulse's value and the
+// already-dead `bits` of the Mls to one register and drops the copy that separates them: the first frame of the impulse comes out as bits + c);
+// this ROCm's compiler, given the same source and flags, does not (tests/test_gpu_jit_compiler.py; the generated code of both is in
+// profiles/r06_jit_compiler_miscompile.txt).
+// So: when the process's hiprtc (or an already-loaded comgr) is not the file in the ROCm directory this library was built against, that ROCm's
+// libhiprtc is loaded into a link-map namespace of its own (dlmopen: its dlopen("libamd_comgr.so.3") then resolves inside that namespace, to its own
+// neighbour) and the compile calls go there.  FDSP_HIPRTC=linked keeps the process's copy, FDSP_HIPRTC=<path to a libhiprtc> names another one.
+#ifndef FD_ROCM_LIB
+#define FD_ROCM_LIB "/opt/rocm/lib"
+#endif
+struct Rtc {
+    decltype(&hiprtcCreateProgram) create = &hiprtcCreateProgram;
+    decltype(&hiprtcCompileProgram) compile = &hiprtcCompileProgram;
+    decltype(&hiprtcGetCodeSize) code_size = &hiprtcGetCodeSize;
+    decltype(&hiprtcGetCode) get_code = &hiprtcGetCode;
+    decltype(&hiprtcGetProgramLogSize) log_size = &hiprtcGetProgramLogSize;
+    decltype(&hiprtcGetProgramLog) get_log = &hiprtcGetProgramLog;
+    decltype(&hiprtcGetErrorString) error_string = &hiprtcGetErrorString;
+    decltype(&hiprtcDestroyProgram) destroy = &hiprtcDestroyProgram;
+    std::string origin;   // what fdsp_jit_compiler() reports
+};
+
+std::string real_path(const std::string& p) {
+    char buf[PATH_MAX];
+    return realpath(p.c_str(), buf) ? std::string(buf) : p;
+}
+
+std::string loaded_path_of(void* symbol) {
+    Dl_info info;
+    return (dladdr(symbol, &info) && info.dli_fname) ? real_path(info.dli_fname) : std::string();
+}
+
+const Rtc& rtc() {
+    static const Rtc instance = [] {
+        Rtc r;
+        const std::string linked = loaded_path_of((void*)&hiprtcCreateProgram);
+        r.origin = "linked: " + linked;
+        const char* env = getenv("FDSP_HIPRTC");
+        if (env && !strcmp(env, "linked")) return r;
+        const std::string want = real_path(env && *env ? std::string(env) : std::string(FD_ROCM_LIB) + "/libhiprtc.so.7");
+        bool foreign = linked != want;
+        if (!foreign) {  // the right hiprtc; but it looks its comgr up by soname, and a comgr of another ROCm may already answer to it
+            if (void* c = dlopen("libamd_comgr.so.3", RTLD_NOLOAD | RTLD_LAZY)) {
+                struct link_map* lm = nullptr;
+                if (dlinfo(c, RTLD_DI_LINKMAP, &lm) == 0 && lm && lm->l_name && *lm->l_name) {
+                    const std::string have = real_path(lm->l_name), dir = want.substr(0, want.find_last_of('/'));
+                    foreign = have.compare(0, dir.size(), dir) != 0;
+                }
+                dlclose(c);
+            }
+        }
+        if (!foreign) return r;
+        void* h = dlmopen(LM_ID_NEWLM, want.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            r.origin += std::string(" (another ROCm's; isolating ") + want + " failed: " + dlerror() + ")";
+            return r;
+        }
+        Rtc iso;
+        bool ok = true;
+        auto sym = [&](const char* name) { void* f = dlsym(h, name); ok = ok && f; return f; };
+        iso.create = (decltype(iso.create))sym("hiprtcCreateProgram");
+        iso.compile = (decltype(iso.compile))sym("hiprtcCompileProgram");
+        iso.code_size = (decltype(iso.code_size))sym("hiprtcGetCodeSize");
+        iso.get_code = (decltype(iso.get_code))sym("hiprtcGetCode");
+        iso.log_size = (decltype(iso.log_size))sym("hiprtcGetProgramLogSize");
+        iso.get_log = (decltype(iso.get_log))sym("hiprtcGetProgramLog");
+        iso.error_string = (decltype(iso.error_string))sym("hiprtcGetErrorString");
+        iso.destroy = (decltype(iso.destroy))sym("hiprtcDestroyProgram");
+        if (!ok) {
+            r.origin += " (another ROCm's; " + want + " lacks a hiprtc entry point)";
+            return r;
+        }
+        iso.origin = "isolated: " + want + " (the process's own is " + linked + ")";
+        return iso;
+    }();
+    return instance;
 }
 
 struct JitMix;
@@ -376,6 +465,8 @@ int jit_compile_code(const std::string& type_expr, const std::string& prelude, s
     return jit_compile_src(jit_source(type_expr, prelude), type_expr, code, log);
 }
 
+const char* jit_compiler_origin() { return rtc().origin.c_str(); }
+
 int jit_compile_src(const std::string& src, const std::string& type_expr, std::vector<char>* code, std::string* log) {
     const std::string dir = lib_dir() + "/csrc/";
     const char* names[3] = {"fd_math.hpp", "fd_nodes.hpp", "fd_device.hpp"};
@@ -387,7 +478,7 @@ int jit_compile_src(const std::string& src, const std::string& type_expr, std::v
         }
     const char* hsrc[3] = {hdr[0].c_str(), hdr[1].c_str(), hdr[2].c_str()};
     hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "fdsp_jit_graph.hip", 3, hsrc, names) != HIPRTC_SUCCESS) {
+    if (rtc().create(&prog, src.c_str(), "fdsp_jit_graph.hip", 3, hsrc, names) != HIPRTC_SUCCESS) {
         *log = "hiprtcCreateProgram failed";
         return -1;
     }
@@ -426,23 +517,34 @@ int jit_compile_src(const std::string& src, const std::string& type_expr, std::v
         opts.push_back("-mllvm");
         opts.push_back("-amdgpu-sched-strategy=max-ilp");
     }
-    hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+    hiprtcResult r = rtc().compile(prog, (int)opts.size(), opts.data());
+    if (const char* dump = getenv("FDSP_JIT_DUMP")) {  // debugging aid: the generated source and code object of every compiled module, numbered
+        static int dump_n = 0;
+        const std::string base = std::string(dump) + "/jit_" + std::to_string(dump_n++);
+        if (FILE* f = fopen((base + ".hip").c_str(), "w")) { fputs(("// " + type_expr + "\n" + src).c_str(), f); fclose(f); }
+        size_t n = 0;
+        if (r == HIPRTC_SUCCESS && rtc().code_size(prog, &n) == HIPRTC_SUCCESS) {
+            std::vector<char> co(n);
+            rtc().get_code(prog, co.data());
+            if (FILE* f = fopen((base + ".co").c_str(), "wb")) { fwrite(co.data(), 1, n, f); fclose(f); }
+        }
+    }
     size_t ls = 0;
-    hiprtcGetProgramLogSize(prog, &ls);
+    rtc().log_size(prog, &ls);
     if (ls > 1) {
         log->resize(ls);
-        hiprtcGetProgramLog(prog, &(*log)[0]);
+        rtc().get_log(prog, &(*log)[0]);
     }
     if (r != HIPRTC_SUCCESS) {
-        *log = "hiprtc: " + std::string(hiprtcGetErrorString(r)) + " while compiling graph type `" + type_expr + "`:\n" + *log;
-        hiprtcDestroyProgram(&prog);
+        *log = "hiprtc: " + std::string(rtc().error_string(r)) + " while compiling graph type `" + type_expr + "`:\n" + *log;
+        rtc().destroy(&prog);
         return -1;
     }
     size_t cs = 0;
-    hiprtcGetCodeSize(prog, &cs);
+    rtc().code_size(prog, &cs);
     code->resize(cs);
-    hiprtcGetCode(prog, code->data());
-    hiprtcDestroyProgram(&prog);
+    rtc().get_code(prog, code->data());
+    rtc().destroy(&prog);
     return 0;
 }
 

@@ -148,6 +148,15 @@ int fdsp_graph_compile(const char* name, const char* type_expr);
  * refers to -- typically the functor that stands in for the Rust closure of envelope(|t| ...) / lfo(|t| ...), see
  * Envelope<FN> in fundsp_amd/csrc/fd_nodes.hpp for the functor contract (OUT, visit, init, eval). */
 int fdsp_graph_compile_src(const char* name, const char* type_expr, const char* source);
+/* Which compiler compiles these graphs.  The promise of a run-time compiled kind -- the same samples as the same graph compiled ahead of time -- needs
+ * the headers, the flags AND the compiler of the library's own build.  A host process may already hold another ROCm's libhiprtc / libamd_comgr under
+ * the same sonames (a PyTorch wheel bundles ROCm 7.0's next to this image's 7.2 and loads them first); the dynamic loader then hands this library THAT
+ * copy.  The library detects it and loads the libhiprtc of the ROCm it was built against into a link-map namespace of its own (dlmopen), where it finds
+ * its own comgr.  Returns a description: "linked: <path>" (the process's hiprtc is the right one) or "isolated: <path> (the process's own is <path>)".
+ * Environment: FDSP_HIPRTC=linked keeps the process's copy whatever it is, FDSP_HIPRTC=<path of a libhiprtc.so> names another one;
+ * FDSP_JIT_DUMP=<directory> writes the generated source and code object of every compiled module there.  Why it matters: the bundled 7.0 compiler
+ * miscompiles one kernel variant of `(mls() ^ impulse()) + c` (DESIGN.md section 0, round 6 "third part, 4"; tests/test_gpu_jit_compiler.py). */
+const char* fdsp_jit_compiler(void);
 int fdsp_graph_check(const char* type_expr);
 /* The Rust side of the compiler: hand over `core::any::type_name::<X>()` of the graph `An<X>` as it is, e.g.
  *   fundsp::combinator::An<fundsp::audionode::Pipe<fundsp::audionode::Pipe<fundsp::audionode::Constant<typenum::uint::

@@ -490,10 +490,20 @@ class Bank {
         check(ring_frames ? fdsp_bank_create_ring(kind.c_str(), voices, ring_frames, &h_) : fdsp_bank_create(kind.c_str(), voices, &h_));
     }
     // compile the graph (one fused kernel set, cached by type + source), create the bank, apply the graph's parameters
-    static Bank from_graph(const An& g, size_t voices, size_t ring_frames = 0, double sample_rate = DEFAULT_SR) {
+    // `flush_denormals`: for the FRONT half of a Chain whose other half has a Feedback node (reverb_stereo, reverb4_stereo, an fdn network) --
+    // Feedback::new switches the constructing thread to FTZ + DAZ (feedback.rs:96, denormal.rs:18), so the reference renders the whole graph
+    // flushed; a front compiled on its own has no Feedback in its type, and is handed to the run-time compiler (which flushes kinds whose type
+    // expression names one) under an alias that does.  Same type, same kernels, same slot names.
+    static Bank from_graph(const An& g, size_t voices, size_t ring_frames = 0, double sample_rate = DEFAULT_SR, bool flush_denormals = false) {
         if (g.rings > 0 && ring_frames == 0) throw Error(FDSP_EINVAL, "this graph has delay lines: pass ring_frames");
-        const std::string name = "cpp_" + std::to_string(std::hash<std::string>{}(g.type + '\0' + g.source));
-        if (fdsp_kind_by_name(name.c_str()) < 0) check(fdsp_graph_compile_src(name.c_str(), g.type.c_str(), g.source.c_str()));
+        std::string ctype = g.type, csrc = g.source;
+        if (flush_denormals && ctype.find("Feedback") == std::string::npos) {
+            const std::string alias = "FeedbackThreadFlushed_" + std::to_string(std::hash<std::string>{}(ctype + '\0' + csrc));
+            csrc += (csrc.empty() ? "" : "\n") + ("using " + alias + " = " + ctype + ";");
+            ctype = alias;
+        }
+        const std::string name = "cpp_" + std::to_string(std::hash<std::string>{}(ctype + '\0' + csrc));
+        if (fdsp_kind_by_name(name.c_str()) < 0) check(fdsp_graph_compile_src(name.c_str(), ctype.c_str(), csrc.c_str()));
         // the shared wavetables of the reference (saw_table() etc., wavetable.rs:493-623) are built on first use
         static const std::pair<const char*, int> tables[] = {{"WaveSynth<0", 0}, {"PulseWave", 0}, {"WaveSynth<1", 1}, {"WaveSynth<2", 2},
                                                              {"WaveSynth<4", 4}, {"WaveSynth<5", 5}, {"WaveSynth<6", 6}};

@@ -261,7 +261,7 @@ static void gpu_checks() {
         const An whole = (noise() | noise()) >> reverb_stereo(10.0, 1.0, 0.5);
         Bank rev = Bank::reverb_stereo(V, 10.0, 1.0, 0.5);
         rev.set_sample_rate(R);
-        Chain ch(Bank::from_graph(noise() | noise(), V, 0, R), std::move(rev), &whole);
+        Chain ch(Bank::from_graph(noise() | noise(), V, 0, R, /* flush_denormals: the one graph has a Feedback node */ true), std::move(rev), &whole);
         EXPECT(ch.inputs() == 0 && ch.outputs() == 2 && ch.voices() == V);
         onode* n = o_pipe(o_stack(o_noise(), o_noise()), o_reverb_stereo(10.0, 1.0, 0.5));
         o_set_sample_rate(n, R);

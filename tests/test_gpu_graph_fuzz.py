@@ -116,15 +116,24 @@ def test_random_graph_matches_oracle(gpu, seed):
     V, T = 5, 64 * 4 + 19
     seeds = np.arange(V, dtype=np.uint64) * 977 + seed
     x = noise_input(V, nin, T, seed=seed) if nin else None
-    for mode, layout in ((MODE_PROCESS, LAYOUT_VOICE_MINOR), (MODE_TICK, LAYOUT_PLANAR), (MODE_PROCESS, LAYOUT_PLANAR)):
+    for mode, layout in ((MODE_PROCESS, LAYOUT_VOICE_MINOR), (MODE_TICK, LAYOUT_PLANAR), (MODE_PROCESS, LAYOUT_PLANAR), (MODE_PROCESS, "planar, tight rows"), (MODE_TICK, "planar, tight rows")):
         b = gpu.Bank.from_graph(g, V, ring_frames=256 if g.rings else 0, sample_rate=SR)
         b.set_seed(seeds)
-        got = run_bank(b, x, T, layout, mode)
+        if isinstance(layout, str):   # rows exactly T = 275 floats apart: no 16-byte runs, so the single-wave planar kernel renders them (aligned rows: the planar pipeline)
+            import torch
+
+            xi = None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
+            out = b.process(T, xi, layout=LAYOUT_PLANAR, frame_stride=T, mode=mode)
+            torch.cuda.synchronize()
+            assert b.get_option("last_kernel") == 1
+            got = out.cpu().numpy()
+        else:
+            got = run_bank(b, x, T, layout, mode)
         for v in (0, V - 1):
             n = build(tree, O)
             n.set_sample_rate(SR)
             n.set_seed(int(seeds[v]))
-            assert_bit_equal(got[v], oracle_render(n, None if x is None else x[v], T, mode), f"seed {seed} voice {v} mode {mode}: {tree}")
+            assert_bit_equal(got[v], oracle_render(n, None if x is None else x[v], T, mode), f"seed {seed} voice {v} mode {mode} layout {layout}: {tree}")
 
 
 def wide_tree(rng):
@@ -189,3 +198,81 @@ def test_random_wide_sum_with_a_tail_matches_oracle(gpu, seed):
             n.set_sample_rate(SR)
             n.set_seed(int(seeds[v]))
             assert_bit_equal(got[v], oracle_render(n, None if x is None else x[v], T, mode), f"seed {seed} voice {v} mode {mode} split {split}: {tree}")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_CHAINS", "8"))))   # more for a bug hunt
+def test_random_front_into_a_lane_per_frame_node_with_a_bus(gpu, seed):
+    """A random front graph (generators, filters on inputs, delay lines, feedback loops, hashed nodes) piped into a reverb / network with one of
+    the documented buses around it: Bank.from_graph builds a chain of two banks -- the front's fused kernel, seeded from the construction hash of
+    the WHOLE graph and flushing denormals when the network half has a Feedback node, and the network's lane-per-frame kernel with the bus in
+    its epilogue.  Against the oracle's ONE graph, as constructed and after set_seed, inputs in the normal and in the denormal range."""
+    import test_gpu_reverb_bus as RB
+
+    rng = np.random.default_rng(int(os.environ.get("FUNDSP_FUZZ_SEED0", "1000")) + 90000 + seed)
+    node = list(RB.NODES)[rng.integers(len(RB.NODES))]
+    bus = (list(RB.BUSES) + ["bare"])[rng.integers(len(RB.BUSES) + 1)]
+    mid = 1 if node == "fdn8_mono" else 2
+    nin = int(rng.integers(0, 3))
+    tree = gen(rng, nin, mid, depth=int(rng.integers(1, 4)))
+
+    def whole(m):
+        back = RB.NODES[node][0](m) if bus == "bare" else RB.build(m, node, bus)
+        return build(tree, m) >> back
+
+    front_rings = build(tree, GR).rings
+    V, T = 6, 64 * 40 + 7
+    x = None
+    if nin:
+        x = noise_input(V, nin, T, seed=seed)
+        x[1] = (x[1] * np.float32(1e-38)).astype(np.float32)     # an instance in the denormal range
+        x[2, :, T // 2:] = 0.0                                    # tails that decay
+    seeds = np.arange(V, dtype=np.uint64) * 131 + seed
+    for mode, layout, seeded in ((MODE_PROCESS, LAYOUT_PLANAR, False), (MODE_TICK, LAYOUT_VOICE_MINOR, True)):
+        ch = gpu.Bank.from_graph(whole(GR), V, ring_frames=256 if front_rings else 0, sample_rate=SR)
+        assert isinstance(ch, gpu.Chain) and ch.effect.kind == RB.NODES[node][1], (node, bus, tree)
+        if seeded:
+            ch.set_seed(seeds)
+        got = RB.run(ch, x if x is not None else np.zeros((V, 0, T), dtype=np.float32), layout, mode, [0, 64 * 9 + 5, T]) if nin else None
+        if not nin:
+            import torch
+
+            parts = [ch.process(n, layout=layout, frame_stride=n if layout == LAYOUT_PLANAR else None, mode=mode) for n in (64 * 9 + 5, T - 64 * 9 - 5)]
+            torch.cuda.synchronize()
+            got = np.concatenate([p.cpu().numpy() if layout == LAYOUT_PLANAR else p.cpu().numpy().transpose(2, 0, 1) for p in parts], axis=2)
+        for v in (0, 1, 2, V - 1):
+            n = whole(O)
+            n.set_sample_rate(SR)
+            if seeded:
+                n.set_seed(int(seeds[v]))
+            cuts = ((0, 64 * 9 + 5), (64 * 9 + 5, T))
+            if mode == MODE_PROCESS:
+                want = [n.render_blocks(None if x is None else x[v][:, a:e], length=e - a) for a, e in cuts]
+            else:
+                want = [n.render_ticks(None if x is None else x[v][:, a:e], length=e - a) for a, e in cuts]
+            assert_bit_equal(got[v], np.concatenate(want, axis=1), f"seed {seed} {node} {bus} instance {v} mode {mode} seeded {seeded}: {tree}")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_TINY", "10"))))   # more for a bug hunt
+def test_random_graph_on_inputs_in_the_denormal_range(gpu, seed):
+    """The general fuzzer's graphs with inputs, fed tiny signals: 1e-38 (denormal on arrival), 1e-30 and 1e-20 (products and filter tails go
+    denormal inside).  Graphs with a Feedback node render flushed (the run-time compiler's module flag on the device, MXCSR FTZ + DAZ in the
+    oracle: denormal.rs:18), all others keep IEEE denormals -- the two must agree on which is which, node by node."""
+    rng = np.random.default_rng(int(os.environ.get("FUNDSP_FUZZ_SEED0", "1000")) + 70000 + seed)
+    nin, nout = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    tree = gen(rng, nin, nout, depth=int(rng.integers(2, 5)))
+    g = build(tree, GR)
+    V, T = 5, 64 * 4 + 19
+    seeds = np.arange(V, dtype=np.uint64) * 977 + seed
+    x = noise_input(V, nin, T, seed=seed)
+    for v, s in ((1, 1e-38), (2, 1e-30), (3, 1e-20)):
+        x[v] = (x[v] * np.float32(s)).astype(np.float32)
+    x[4, :, T // 3:] = 0.0
+    for mode, layout in ((MODE_PROCESS, LAYOUT_VOICE_MINOR), (MODE_TICK, LAYOUT_PLANAR)):
+        b = gpu.Bank.from_graph(g, V, ring_frames=256 if g.rings else 0, sample_rate=SR)
+        b.set_seed(seeds)
+        got = run_bank(b, x, T, layout, mode)
+        for v in range(V):
+            n = build(tree, O)
+            n.set_sample_rate(SR)
+            n.set_seed(int(seeds[v]))
+            assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"seed {seed} voice {v} mode {mode} ({'flushed' if 'Feedback' in g.type else 'IEEE denormals'}): {tree}")
