@@ -276,3 +276,53 @@ def test_random_graph_on_inputs_in_the_denormal_range(gpu, seed):
             n.set_sample_rate(SR)
             n.set_seed(int(seeds[v]))
             assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"seed {seed} voice {v} mode {mode} ({'flushed' if 'Feedback' in g.type else 'IEEE denormals'}): {tree}")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_ROUTES", "10"))))   # more for a bug hunt
+def test_random_graph_renders_the_same_through_every_kernel_route(gpu, seed):
+    """One graph, one executor, every route the dispatcher has: "pipe_split" 0 (the single-wave kernels), 1 (the default choice by launch length) and
+    2 (the stage / planar pipelines forced) x voice-minor, planar with 16-byte rows, planar with tight odd rows -- launched whole and in ragged
+    chunks.  All must give the same bits; the first is held against the oracle.  (A route only ever taken at sizes no parity test uses is where the
+    miscompiled single-wave planar kernel had hidden.)"""
+    import torch
+
+    rng = np.random.default_rng(int(os.environ.get("FUNDSP_FUZZ_SEED0", "1000")) + 30000 + seed)
+    nin, nout = int(rng.integers(0, 3)), int(rng.integers(1, 3))
+    tree = gen(rng, nin, nout, depth=int(rng.integers(2, 5)))
+    g = build(tree, GR)
+    V, T = 67, 64 * 5 + 11
+    seeds = np.arange(V, dtype=np.uint64) * 977 + seed
+    x = noise_input(V, nin, T, seed=seed) if nin else None
+    for mode in (MODE_PROCESS, MODE_TICK):
+        ref = {}
+        for split in (0, 1, 2):
+            for layout in ("voice-minor", "planar", "planar, tight rows"):
+                for cuts in ((0, T), (0, 64 * 2 + 5, 64 * 2 + 5 + 9, T)):
+                    b = gpu.Bank.from_graph(g, V, ring_frames=256 if g.rings else 0, sample_rate=SR)
+                    b.set_option("pipe_split", split)
+                    b.set_seed(seeds)
+                    parts = []
+                    for a, e in zip(cuts[:-1], cuts[1:]):
+                        n = e - a
+                        if layout == "voice-minor":
+                            xi = None if x is None else torch.from_numpy(np.ascontiguousarray(x[:, :, a:e].transpose(1, 2, 0))).cuda()
+                            parts.append(b.process(n, xi, mode=mode).cpu().numpy().transpose(2, 0, 1))
+                        else:
+                            fs = n if layout.endswith("tight rows") else (n + 63) // 64 * 64
+                            xi = None
+                            if x is not None:
+                                buf = np.zeros((V, nin, fs), dtype=np.float32)
+                                buf[:, :, :n] = x[:, :, a:e]
+                                xi = torch.from_numpy(buf).cuda()
+                            parts.append(b.process(n, xi, layout=LAYOUT_PLANAR, frame_stride=fs, mode=mode).cpu().numpy()[:, :, :n])
+                    got = np.concatenate(parts, axis=2)
+                    if cuts not in ref:   # (a launch walks its own blocks and remainder, like a process() call of that size: every chunking has its own samples)
+                        ref[cuts] = got
+                        for v in (0, 63, V - 1):
+                            n_ = build(tree, O)
+                            n_.set_sample_rate(SR)
+                            n_.set_seed(int(seeds[v]))
+                            want = np.concatenate([oracle_render(n_, None if x is None else x[v][:, a:e], e - a, mode) for a, e in zip(cuts[:-1], cuts[1:])], axis=1)
+                            assert_bit_equal(got[v], want, f"seed {seed} voice {v} mode {mode} cuts {cuts}: {tree}")
+                    else:
+                        assert_bit_equal(got, ref[cuts], f"seed {seed} mode {mode} pipe_split {split} {layout} cuts {cuts} != the first route: {tree}")
