@@ -48,3 +48,47 @@ def test_samples_do_not_depend_on_bank_size(gpu, kind):
         for V in sizes[1:]:
             with np.errstate(all="ignore"):
                 assert_bit_equal(render(gpu, kind, V, T, x, layout, mode), want, f"{kind} V={V} layout={layout} mode={mode}")
+
+
+@pytest.mark.parametrize("kind", GRAPH_KINDS + ["saw_moog_var_adsr_pan", "sine", "fixed_svf", "biquad", "moog_hz", "noise"])
+def test_every_dispatcher_route_of_an_ahead_of_time_kind_gives_the_same_samples(gpu, kind):
+    """The routes a launch can take -- "pipe_split" 0 (single-wave kernels), 1 (the default choice), 2 (pipelines forced) x voice-minor, planar rows
+    with 16-byte runs, planar rows of an odd tight length (the single-wave planar kernel whatever the option says) -- for the ahead-of-time kinds:
+    all bit-identical per executor.  (The run-time compiled kinds have the same check in tests/test_gpu_graph_fuzz.py, where a tight planar row
+    first exposed a miscompiled kernel variant.)"""
+    import torch
+
+    if kind not in gpu.kinds():
+        pytest.skip(f"no ahead-of-time kind {kind}")
+    if "saw_moog" in kind:
+        gpu.wavetable_build("saw")
+    V, T = 130, 64 * 4 + 13
+    ni = gpu.Bank(kind, 1).inputs()
+    x = noise_input(V, max(ni, 1), T, seed=7) if ni else None
+    if x is not None and kind == "saw_moog_adsr_pan":
+        x[:, 0, :] = 0.0
+        x[:, 0, 3:200] = 1.0
+    for mode in (MODE_PROCESS, MODE_TICK):
+        ref = None
+        for split in (1, 0, 2):
+            for layout in ("voice-minor", "planar", "planar, tight rows"):
+                b = gpu.Bank(kind, V)
+                b.set_sample_rate(SR)
+                b.set_option("pipe_split", split)
+                b.set_seed(np.arange(V, dtype=np.uint64) * 3 + 11)
+                if layout == "voice-minor":
+                    xi = None if x is None else torch.from_numpy(np.ascontiguousarray(x.transpose(1, 2, 0))).cuda()
+                    got = b.process(T, xi, mode=mode).cpu().numpy().transpose(2, 0, 1)
+                else:
+                    fs = T if layout.endswith("tight rows") else (T + 63) // 64 * 64
+                    xi = None
+                    if x is not None:
+                        buf = np.zeros((V, ni, fs), dtype=np.float32)
+                        buf[:, :, :T] = x
+                        xi = torch.from_numpy(buf).cuda()
+                    got = b.process(T, xi, layout=LAYOUT_PLANAR, frame_stride=fs, mode=mode).cpu().numpy()[:, :, :T]
+                if ref is None:
+                    ref = got
+                else:
+                    with np.errstate(all="ignore"):
+                        assert_bit_equal(got, ref, f"{kind} mode {mode} pipe_split {split} {layout} != pipe_split 1 voice-minor")
