@@ -326,3 +326,42 @@ def test_random_graph_renders_the_same_through_every_kernel_route(gpu, seed):
                             assert_bit_equal(got[v], want, f"seed {seed} voice {v} mode {mode} cuts {cuts}: {tree}")
                     else:
                         assert_bit_equal(got, ref[cuts], f"seed {seed} mode {mode} pipe_split {split} {layout} cuts {cuts} != the first route: {tree}")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_MIX", "8"))))   # more for a bug hunt
+def test_random_graph_fused_mix_equals_the_mix_of_its_voice_out_render(gpu, seed):
+    """fdsp_bank_process_mix of a random run-time compiled graph -- the mix kernels are a module of their own, compiled on first use -- against
+    fdsp_sum_voices / fdsp_mix_stereo of the voice-out render of a clone: the same fixed summation order, so bit for bit; whole and chunked, both
+    executors.  (Kinds without a fused mix-down say so: "has_fused_mix" 0.)"""
+    import torch
+    from fundsp_amd import MIX_PAN, MIX_SUM
+
+    rng = np.random.default_rng(int(os.environ.get("FUNDSP_FUZZ_SEED0", "1000")) + 110000 + seed)
+    nin, nout = int(rng.integers(0, 3)), int(rng.integers(1, 3))
+    tree = gen(rng, nin, nout, depth=int(rng.integers(2, 5)))
+    g = build(tree, GR)
+    V, T = (67, 300, 1030)[seed % 3], 64 * 3 + 7
+    seeds = np.arange(V, dtype=np.uint64) * 977 + seed
+    x = noise_input(V, nin, T, seed=seed) if nin else None
+    xi = None if x is None else torch.from_numpy(np.ascontiguousarray(x.transpose(1, 2, 0))).cuda()
+    pan = np.linspace(-1, 1, V).astype(np.float32)
+    for mode in (MODE_PROCESS, MODE_TICK):
+        b = gpu.Bank.from_graph(g, V, ring_frames=256 if g.rings else 0, sample_rate=SR)
+        if b.get_option("has_fused_mix") != 1:
+            return
+        b.set_seed(seeds)
+        ref = b.clone()
+        out = ref.process(T, xi, mode=mode)
+        how = MIX_PAN if nout == 1 and seed % 2 else MIX_SUM
+        if how == MIX_PAN:
+            b.set_pan(pan)
+            want = gpu.mix_stereo(out[0], torch.from_numpy(pan).cuda()).cpu().numpy()
+        else:
+            want = gpu.sum_voices(out).cpu().numpy()
+        chunked = b.clone()
+        if how == MIX_PAN:
+            chunked.set_pan(pan)
+        assert_bit_equal(b.process_mix(T, xi, mix=how, mode=mode).cpu().numpy(), want, f"seed {seed} mode {mode} mix {how} V {V}: {tree}")
+        if mode == MODE_TICK:   # (a tick-executor launch has no block structure: chunks continue the whole)
+            parts = [chunked.process_mix(e - a, None if xi is None else xi[:, a:e].contiguous(), mix=how, mode=mode).cpu().numpy() for a, e in ((0, 64 + 3), (64 + 3, T))]
+            assert_bit_equal(np.concatenate(parts, axis=1), want, f"seed {seed} chunked mix, tick executor: {tree}")
