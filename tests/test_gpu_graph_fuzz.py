@@ -365,3 +365,44 @@ def test_random_graph_fused_mix_equals_the_mix_of_its_voice_out_render(gpu, seed
         if mode == MODE_TICK:   # (a tick-executor launch has no block structure: chunks continue the whole)
             parts = [chunked.process_mix(e - a, None if xi is None else xi[:, a:e].contiguous(), mix=how, mode=mode).cpu().numpy() for a, e in ((0, 64 + 3), (64 + 3, T))]
             assert_bit_equal(np.concatenate(parts, axis=1), want, f"seed {seed} chunked mix, tick executor: {tree}")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_EVENTS", "6"))))   # more for a bug hunt
+def test_random_generator_under_the_voice_scheduler(gpu, seed):
+    """A random run-time compiled generator graph as the unit of every Sequencer event (sequencer.rs: per-voice start / end / fades, off-grid times):
+    fdsp_bank_process_events (the kind's jit_events kernels) against the oracle's Sequencer restatement, every voice's faded contribution bit for bit,
+    both executors; the fused Sequencer output (process_events_mix) against the sum of those contributions."""
+    import torch
+    from test_gpu_sequencer import random_events
+
+    rng = np.random.default_rng(int(os.environ.get("FUNDSP_FUZZ_SEED0", "1000")) + 130000 + seed)
+    nout = int(rng.integers(1, 3))
+    tree = gen(rng, 0, nout, depth=int(rng.integers(1, 4)))
+    g = build(tree, GR)
+    V, T = 40, 64 * 7 + 21
+    seeds = np.arange(V, dtype=np.uint64) * 977 + seed
+    start, end, fin, fout, fade = random_events(V, T, np.random.default_rng(seed))
+    for mode in (MODE_PROCESS, MODE_TICK):
+        b = gpu.Bank.from_graph(g, V, ring_frames=256 if g.rings else 0, sample_rate=SR)
+        b.set_seed(seeds)
+        b.set_events(start, end, fin, fout, fade)
+        got = b.process_events(T, mode=mode)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy().transpose(2, 0, 1)
+        seq = O.Sequencer(0, nout, SR)
+        for v in range(V):
+            n = build(tree, O)
+            n.set_sample_rate(SR)
+            n.set_seed(int(seeds[v]))
+            seq.push(start[v], end[v], int(fade[v]), fin[v], fout[v], n)
+        _mix, per = seq.render(T, process=(mode == MODE_PROCESS))
+        for v in range(V):
+            assert_bit_equal(got[v], per[v], f"seed {seed} event voice {v} mode {mode}: {tree}")
+        assert abs(b.events_time() - seq.time()) == 0.0
+        if b.get_option("has_fused_mix") == 1:
+            b2 = gpu.Bank.from_graph(g, V, ring_frames=256 if g.rings else 0, sample_rate=SR)
+            b2.set_seed(seeds)
+            b2.set_events(start, end, fin, fout, fade)
+            fused = b2.process_events_mix(T, mode=mode).cpu().numpy()
+            summed = gpu.sum_voices(torch.from_numpy(np.ascontiguousarray(got.transpose(1, 2, 0))).cuda()).cpu().numpy()
+            assert_bit_equal(fused, summed, f"seed {seed} mode {mode}: Sequencer output fused vs sum of the events: {tree}")
