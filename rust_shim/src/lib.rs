@@ -68,6 +68,7 @@ pub mod ffi {
         pub fn fdsp_bank_set_param_all(bank: *mut FdspBank, name: *const c_char, value: f32) -> c_int;
         pub fn fdsp_bank_set_option(bank: *mut FdspBank, name: *const c_char, value: c_int) -> c_int;
         pub fn fdsp_bank_set_bus(bank: *mut FdspBank, mode: c_int, wet: f32, dry: f32) -> c_int;
+        pub fn fdsp_jit_compiler() -> *const c_char;
         pub fn fdsp_bank_slot_count(bank: *const FdspBank) -> c_int;
         pub fn fdsp_bank_get_state(bank: *mut FdspBank, slots: *mut f32) -> c_int; // Clone
         pub fn fdsp_bank_set_state(bank: *mut FdspBank, slots: *const f32) -> c_int;
@@ -267,6 +268,11 @@ impl<NI: Size<f32>, NO: Size<f32>> HipBank<NI, NO> {
     /// `None` for the dry side leaves `wet * node` alone.  Factors of 1.0 are the nodes a graph leaves out (x * 1.0 == x).
     pub fn set_bus(&mut self, dry: Option<f32>, wet: f32) -> Result<(), String> {
         check(unsafe { fdsp_bank_set_bus(self.bank, if dry.is_some() { 2 } else { 1 }, wet, dry.unwrap_or(1.0)) })
+    }
+
+    /// Which hiprtc compiles run-time compiled graphs in this process (`"linked: <path>"` for a Rust host; see include/fundsp_hip.h).
+    pub fn jit_compiler() -> String {
+        unsafe { std::ffi::CStr::from_ptr(fdsp_jit_compiler()) }.to_string_lossy().into_owned()
     }
 
     /// Tolerance mode (FDSP_MATH_FAST): FMA polynomials for feed-forward transcendentals, recurrences exact.

@@ -48,6 +48,12 @@ static bool bit_equal(const float* a, const float* b, size_t n, const char* what
 }
 
 static void host_checks() {
+    // a C++ host holds no other ROCm: the run-time compiler is the hiprtc the library links, the one of the ROCm it was built with
+    // (a Python process answers "isolated: ..": include/fundsp_hip.h fdsp_jit_compiler, tests/test_gpu_jit_compiler.py)
+    {
+        const std::string who = fdsp_jit_compiler();
+        EXPECT(who.rfind("linked: ", 0) == 0 && who.find("libhiprtc") != std::string::npos);
+    }
     // README.md:98-103 of the reference: sine_hz(f) * f * m + f >> sine() >> lowpass_hz(fc, q)
     const float f = 110.0f, m = 2.0f;
     An fm = sine_hz(f) * f * m + f >> sine() >> lowpass_hz(1000.0f, 1.0f);
