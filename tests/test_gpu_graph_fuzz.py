@@ -406,3 +406,57 @@ def test_random_generator_under_the_voice_scheduler(gpu, seed):
             fused = b2.process_events_mix(T, mode=mode).cpu().numpy()
             summed = gpu.sum_voices(torch.from_numpy(np.ascontiguousarray(got.transpose(1, 2, 0))).cuda()).cpu().numpy()
             assert_bit_equal(fused, summed, f"seed {seed} mode {mode}: Sequencer output fused vs sum of the events: {tree}")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_LIFE", "8"))))   # more for a bug hunt
+def test_random_graph_through_a_life_of_lifecycle_calls(gpu, seed):
+    """render, set_sample_rate, render, reset, render, set_seed, render -- the AudioNode lifecycle in mid-stream (what each node keeps and what it
+    recomputes or clears on set_sample_rate / reset / set_hash differs from node to node: delay lines resize and empty, filters recompute
+    coefficients and keep state, oscillators re-derive their phase from the hash) -- with the oracle's graph taken through the same calls; a clone
+    taken in mid-stream continues like the original."""
+    rng = np.random.default_rng(int(os.environ.get("FUNDSP_FUZZ_SEED0", "1000")) + 150000 + seed)
+    nin, nout = int(rng.integers(0, 3)), int(rng.integers(1, 3))
+    tree = gen(rng, nin, nout, depth=int(rng.integers(2, 5)))
+    g = build(tree, GR)
+    V = 5
+    seeds = np.arange(V, dtype=np.uint64) * 977 + seed
+    seeds2 = seeds * np.uint64(31) + np.uint64(7)
+    steps = [("render", 150), ("rate", 44100.0), ("render", 64 * 2 + 9), ("reset", None), ("render", 100), ("seed", None), ("render", 64 + 30), ("rate", 96000.0), ("render", 70)]
+    total = sum(n for k, n in steps if k == "render")
+    x = noise_input(V, nin, total, seed=seed) if nin else None
+    for mode, layout in ((MODE_PROCESS, LAYOUT_VOICE_MINOR), (MODE_TICK, LAYOUT_PLANAR)):
+        b = gpu.Bank.from_graph(g, V, ring_frames=1024 if g.rings else 0, sample_rate=SR)
+        b.set_seed(seeds)
+        nodes = []
+        for v in (0, V - 1):
+            n = build(tree, O)
+            n.set_sample_rate(SR)
+            n.set_seed(int(seeds[v]))
+            nodes.append((v, n))
+        t, twin = 0, None
+        for k, (what, arg) in enumerate(steps):
+            if what == "render":
+                xs = None if x is None else x[:, :, t:t + arg]
+                got = run_bank(b, xs, arg, layout, mode)
+                if twin is not None:
+                    assert_bit_equal(run_bank(twin, xs, arg, layout, mode), got, f"seed {seed} step {k}: the clone continues like the original: {tree}")
+                    twin = None
+                for v, n in nodes:
+                    assert_bit_equal(got[v], oracle_render(n, None if xs is None else xs[v], arg, mode), f"seed {seed} step {k} ({what}) voice {v} mode {mode}: {tree}")
+                t += arg
+                if k == 0:
+                    twin = b.clone()
+            elif what == "rate":
+                b.set_sample_rate(arg)
+                if twin is not None:
+                    twin.set_sample_rate(arg)
+                for _v, n in nodes:
+                    n.set_sample_rate(arg)
+            elif what == "reset":
+                b.reset()
+                for _v, n in nodes:
+                    n.reset()
+            else:
+                b.set_seed(seeds2)
+                for v, n in nodes:
+                    n.set_seed(int(seeds2[v]))
