@@ -2715,20 +2715,35 @@ struct Oversampler {
             push_out(o);
             decimate(out);
         } else {              // process :178-212, walked sample by sample
+            // Two passes over `size / 2` outer samples each; per pass the inner node processes an inner block of `size` samples (:191-195) -- for an
+            // ODD size that is one sample MORE than the 2 (size / 2) the pass interpolated: the last slot of the zero-initialised inner input
+            // buffer (BufferArray::new(), :179), whose output nobody reads.  It advances the inner node all the same (an oscillator's phase, a
+            // filter's state), so it is rendered here too: after the last pair of each pass, and -- size 1, where a pass is nothing else -- on
+            // the untouched outer sample.
             const int half = blk_size >> 1;
             const int i = blk_i++;
-            if (i >= 2 * half) {  // odd tail: never processed by the reference
+            const bool tail_sample = i >= 2 * half;   // the odd last outer sample: never written by the reference
+            int n = 0, k = 0;                          // inner samples to render now, and the index of the first in the pass's inner block
+            if (tail_sample) {
 #pragma unroll
                 for (int c = 0; c < OUT; c++) out[c] = 0.0f;
-                return;
+                n = half == 0 ? 2 : 0;                 // size 1: two passes of one zero-input inner sample each
+            } else {
+                k = (i >= half ? i - half : i) * 2;
+                interpolate(in, even, odd);
+                n = 2 + (((blk_size & 1) && (i == half - 1 || i == 2 * half - 1)) ? 1 : 0);
             }
-            const int k = (i >= half ? i - half : i) * 2;
-            interpolate(in, even, odd);
-            inner_process_step(k, even, o);
-            push_out(o);
-            inner_process_step(k + 1, odd, o);
-            push_out(o);
-            decimate(out);
+            // ONE call site of the inner node in a loop that is not unrolled (an Oversampler around an Oversampler multiplies what is inlined here)
+#pragma unroll 1
+            for (int r = 0; r < n; r++) {
+                const bool real = !tail_sample && r < 2;
+                float sel[IN > 0 ? IN : 1];
+#pragma unroll
+                for (int c = 0; c < IN; c++) sel[c] = real ? (r == 0 ? even[c] : odd[c]) : 0.0f;
+                inner_process_step(tail_sample ? 0 : k + r, sel, o);
+                if (real) push_out(o);
+            }
+            if (!tail_sample) decimate(out);
         }
     }
     FD_STEP2_VIA_STEP

@@ -2548,7 +2548,9 @@ void o_process(onode *n, int size, const float *in, float *out) {
                           * over Inputs::USIZE channels (:200), so a generator (0 inputs) is never written at all and a
                           * node with more inputs than outputs indexes out of range; the loop below runs over the
                           * OUTPUT channels, which is identical whenever inputs == outputs. */
-        float ii[O_MAX_CH * MAXB], io[O_MAX_CH * MAXB];
+        float ii[O_MAX_CH * MAXB] = {0}, io[O_MAX_CH * MAXB]; /* BufferArray::new() :179 is zero-initialised -- and it matters: for an odd `size` the
+                                                                * inner block's last sample (index 2 * (size / 2)) is never interpolated, the inner
+                                                                * node reads the zero and advances by it */
         const int offs[2] = {0, size / 2};
         for (int pass = 0; pass < 2; pass++) {
             int offset = offs[pass];

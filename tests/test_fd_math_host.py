@@ -113,3 +113,22 @@ def test_envelope_block_preparation_matches_the_oracle(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bad 0" in r.stdout
+
+
+def test_oversampler_walk_over_odd_block_sizes_matches_the_oracle(tmp_path):
+    """Oversampler::process over launch blocks of odd sizes (19, 1, 7, 63, ..): per pass the inner node processes `size` samples, one more than the
+    pass interpolated (oversample.rs:191-195) -- the engine's per-sample walk and the oracle's block restatement, state carried across blocks."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    import oracle as O
+
+    O.build()
+    exe = tmp_path / "check_oversample_odd"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-ffp-contract=off", "-std=c++17", "-Wno-unused-result",
+           "-I", os.path.join(ROOT, "fundsp_amd", "csrc"), "-I", os.path.join(ROOT, "oracle"), "-o", str(exe),
+           os.path.join(ROOT, "tests", "host", "check_oversample_odd.hip"), "-L" + os.path.join(ROOT, "oracle"), "-lfundsp_oracle",
+           "-Wl,-rpath," + os.path.join(ROOT, "oracle")]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all equal" in r.stdout, r.stdout + r.stderr

@@ -460,3 +460,91 @@ def test_random_graph_through_a_life_of_lifecycle_calls(gpu, seed):
                 b.set_seed(seeds2)
                 for v, n in nodes:
                     n.set_seed(int(seeds2[v]))
+
+
+# ---- the wider leaf pool ---------------------------------------------------------------------------------------------------------------------------
+# The fuzzers above draw from a pool of some thirty leaves.  This one adds the rest of the fixed-parameter opcodes both notations spell alike: the
+# wavetable oscillators (shared tables on the device), the PolyBLEP family, coloured noises, every SVF mode, the biquad family, one-pole and
+# resonant filters, followers, shapers, the look-ahead limiter (a reduce tree in ring memory), 2x oversampling around a sub-graph.
+def wide_leaves(rng):
+    r = lambda lo, hi: float(np.float32(rng.uniform(lo, hi)))
+    return [
+        ("saw_hz", r(40, 3000)), ("organ_hz", r(40, 2000)), ("hammond_hz", r(40, 2000)), ("soft_saw_hz", r(40, 3000)), ("ramp_hz", r(1, 2000)),
+        ("poly_square_hz", r(50, 2000)), ("poly_pulse_hz", r(50, 2000), r(0.1, 0.9)), ("pink",), ("brown",), ("white",),
+        ("highpass_hz", r(50, 8000), r(0.5, 3)), ("bandpass_hz", r(100, 6000), r(0.5, 4)), ("notch_hz", r(100, 6000), r(0.5, 4)),
+        ("peak_hz", r(100, 6000), r(0.5, 4)), ("allpass_hz", r(100, 6000), r(0.5, 4)), ("lowshelf_hz", r(100, 3000), r(0.5, 2), r(0.3, 3)),
+        ("highshelf_hz", r(1000, 9000), r(0.5, 2), r(0.3, 3)), ("butterpass_hz", r(100, 9000)), ("resonator_hz", r(100, 6000), r(10, 800)),
+        ("dcblock_hz", r(5, 100)), ("allpole_delay", r(0.1, 1.9)), ("pinkpass",), ("lowrez_hz", r(100, 6000), r(0.0, 0.9)),
+        ("bandrez_hz", r(100, 6000), r(0.0, 0.9)), ("morph_hz", r(100, 6000), r(0.5, 3), r(-1, 1)), ("afollow", r(0.001, 0.02), r(0.01, 0.1)),
+        ("clip",), ("clip_to", r(-0.8, -0.1), r(0.1, 0.8)), ("shape_k", ["softsign", "atan", "clip", "crush", "soft_crush"][rng.integers(5)], r(0.5, 8)),
+        ("limiter", r(0.0005, 0.002), r(0.005, 0.05)),
+    ]
+
+
+_WIDE_ARITY = {}
+
+
+def build2(t, m):
+    k = t[0]
+    if k == "oversample": return m.oversample(build2(t[1], m))
+    if k == "shape_k": return m.shape(t[1], t[2])
+    if k in ("pipe", "stack", "bus", "branch", "thru", "binop", "unop"):
+        sub = [build2(x, m) if isinstance(x, tuple) else x for x in t[1:]]
+        if k == "pipe": return sub[0] >> sub[1]
+        if k == "stack": return sub[0] | sub[1]
+        if k == "bus": return sub[0] & sub[1]
+        if k == "branch": return sub[0] ^ sub[1]
+        if k == "thru": return ~sub[0]
+        if k == "binop":
+            a, b = sub[1], sub[2]
+            return a + b if t[1] == "+" else a - b if t[1] == "-" else a * b
+        x = sub[2]
+        return x * t[2] if t[1] == "mul" else x + t[2] if t[1] == "add" else -x if t[1] == "neg" else t[2] - x
+    return build(t, m)
+
+
+def gen2(rng, nin, nout, depth):
+    """gen() with the wider pool at the leaves and `oversample` among the combinators"""
+    if depth > 0 and nin == nout and nin >= 1 and rng.integers(8) == 0:
+        return ("oversample", gen2(rng, nin, nout, depth - 1))
+    if depth > 0 and rng.integers(3) > 0:
+        t = gen(rng, nin, nout, 1)   # one combinator (or a leaf) of the base grammar ...
+        if t[0] in ("pipe", "stack", "bus", "branch", "thru", "binop", "unop"):   # ... whose children are drawn again, from this grammar
+            def redraw(x):
+                if not isinstance(x, tuple):
+                    return x
+                gx = build(x, GR)
+                return gen2(rng, gx.nin, gx.nout, depth - 1)
+            return tuple(redraw(x) if isinstance(x, tuple) else x for x in t)
+        return t
+    cands = []
+    for lf in wide_leaves(rng):
+        if lf[0] not in _WIDE_ARITY:
+            gl = build2(lf, GR)
+            _WIDE_ARITY[lf[0]] = (gl.nin, gl.nout)
+        if _WIDE_ARITY[lf[0]] == (nin, nout):
+            cands.append(lf)
+    if cands and rng.integers(4) > 0:
+        return cands[rng.integers(len(cands))]
+    return gen(rng, nin, nout, 0)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_WIDER", "12"))))   # more for a bug hunt
+def test_random_graph_of_the_wider_leaf_pool_matches_oracle(gpu, seed):
+    rng = np.random.default_rng(int(os.environ.get("FUNDSP_FUZZ_SEED0", "1000")) + 170000 + seed)
+    nin, nout = int(rng.integers(0, 3)), int(rng.integers(1, 3))
+    tree = gen2(rng, nin, nout, depth=int(rng.integers(3, 7)))
+    g = build2(tree, GR)
+    assert (g.nin, g.nout) == (nin, nout), tree
+    V, T = 5, 64 * 4 + 19
+    seeds = np.arange(V, dtype=np.uint64) * 977 + seed
+    x = noise_input(V, nin, T, seed=seed) if nin else None
+    for mode, layout in ((MODE_PROCESS, LAYOUT_VOICE_MINOR), (MODE_TICK, LAYOUT_PLANAR), (MODE_PROCESS, LAYOUT_PLANAR)):
+        b = gpu.Bank.from_graph(g, V, ring_frames=512 if g.rings else 0, sample_rate=SR)
+        b.set_seed(seeds)
+        got = run_bank(b, x, T, layout, mode)
+        for v in (0, V - 1):
+            n = build2(tree, O)
+            n.set_sample_rate(SR)
+            n.set_seed(int(seeds[v]))
+            assert_bit_equal(got[v], oracle_render(n, None if x is None else x[v], T, mode), f"seed {seed} voice {v} mode {mode} layout {layout}: {tree}")

@@ -371,3 +371,36 @@ def test_limiter_long_windows_walk_the_tree_incrementally(gpu):
     n.reset()
     want = np.concatenate([n.render_blocks(x[40][:, a:a + k], block=64) for a, k in spans], axis=1)
     assert_bit_equal(again[40], want, "after reset")
+
+
+def test_oversampled_stateful_inner_node_over_odd_launch_lengths(gpu):
+    """Oversampler::process hands its inner node a block of `size` samples per pass (oversample.rs:191-195): with an odd `size` that is one zero-input
+    sample more than the pass interpolated, and a STATEFUL inner node (a filter, an oscillator) advances by it.  Launches whose last block is odd
+    (275 = 4 x 64 + 19), launches of 1, 19 and 7 frames, then a whole block: every one continues the oracle's state.  (Found by the wider-pool
+    fuzzer; tests/host/check_oversample_odd.hip is the same check on the CPU.)"""
+    import oracle as O
+    from fundsp_amd import graph as GR
+    from test_gpu_parity import run_bank as run_bank_
+
+    V = 5
+    seeds = np.arange(V, dtype=np.uint64) * 13 + 5
+    graphs = {
+        "noise >> oversample(lowpass_hz)": lambda m: m.noise() >> m.oversample(m.lowpass_hz(3000.0, 1.0)),
+        "oversample(sine_hz * 0.5 >> highpole_hz)": lambda m: m.oversample(m.sine_hz(440.0) * 0.5 >> m.highpole_hz(200.0)),
+    }
+    for name, mk in graphs.items():
+        for layout in (LAYOUT_VOICE_MINOR, LAYOUT_PLANAR):
+            b = gpu.Bank.from_graph(mk(GR), V, sample_rate=SR)
+            b.set_seed(seeds)
+            nodes = []
+            for v in (0, V - 1):
+                n = mk(O)
+                n.set_sample_rate(SR)
+                n.set_seed(int(seeds[v]))
+                nodes.append((v, n))
+            for frames in (275, 1, 19, 7, 64, 1, 63, 128):
+                got = run_bank_(b, None, frames, layout, MODE_PROCESS)
+                for v, n in nodes:
+                    want = n.render_blocks(None, length=frames, block=64)
+                    even = frames - (frames % 64 % 2)   # the odd last outer sample of a block is never written by the reference
+                    assert_bit_equal(got[v][:, :even], want[:, :even], f"{name} layout {layout} launch of {frames} frames, instance {v}")
