@@ -2723,27 +2723,30 @@ struct Oversampler {
             const int half = blk_size >> 1;
             const int i = blk_i++;
             const bool tail_sample = i >= 2 * half;   // the odd last outer sample: never written by the reference
-            int n = 0, k = 0;                          // inner samples to render now, and the index of the first in the pass's inner block
+            int extra = 0;                             // zero-input inner samples to render after this outer sample
             if (tail_sample) {
 #pragma unroll
                 for (int c = 0; c < OUT; c++) out[c] = 0.0f;
-                n = half == 0 ? 2 : 0;                 // size 1: two passes of one zero-input inner sample each
+                extra = half == 0 ? 2 : 0;             // size 1: two passes of one zero-input inner sample each
             } else {
-                k = (i >= half ? i - half : i) * 2;
+                const int k = (i >= half ? i - half : i) * 2;
                 interpolate(in, even, odd);
-                n = 2 + (((blk_size & 1) && (i == half - 1 || i == 2 * half - 1)) ? 1 : 0);
+                inner_process_step(k, even, o);
+                push_out(o);
+                inner_process_step(k + 1, odd, o);
+                push_out(o);
+                decimate(out);
+                extra = ((blk_size & 1) && (i == half - 1 || i == 2 * half - 1)) ? 1 : 0;
             }
-            // ONE call site of the inner node in a loop that is not unrolled (an Oversampler around an Oversampler multiplies what is inlined here)
+            // the rare part in a loop that is not unrolled: one more call site of the inner node, not two (an Oversampler around an Oversampler
+            // multiplies what is inlined here), and nothing of it in the way of the two steps above
 #pragma unroll 1
-            for (int r = 0; r < n; r++) {
-                const bool real = !tail_sample && r < 2;
-                float sel[IN > 0 ? IN : 1];
+            for (int r = 0; r < extra; r++) {
+                float z[IN > 0 ? IN : 1], drop[OUT];
 #pragma unroll
-                for (int c = 0; c < IN; c++) sel[c] = real ? (r == 0 ? even[c] : odd[c]) : 0.0f;
-                inner_process_step(tail_sample ? 0 : k + r, sel, o);
-                if (real) push_out(o);
+                for (int c = 0; c < IN; c++) z[c] = 0.0f;
+                inner_process_step(tail_sample ? 0 : 2 * half, z, drop);
             }
-            if (!tail_sample) decimate(out);
         }
     }
     FD_STEP2_VIA_STEP
