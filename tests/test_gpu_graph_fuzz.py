@@ -200,7 +200,7 @@ def test_random_wide_sum_with_a_tail_matches_oracle(gpu, seed):
             assert_bit_equal(got[v], oracle_render(n, None if x is None else x[v], T, mode), f"seed {seed} voice {v} mode {mode} split {split}: {tree}")
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_CHAINS", "8"))))   # more for a bug hunt
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_CHAINS", "6"))))   # more for a bug hunt
 def test_random_front_into_a_lane_per_frame_node_with_a_bus(gpu, seed):
     """A random front graph (generators, filters on inputs, delay lines, feedback loops, hashed nodes) piped into a reverb / network with one of
     the documented buses around it: Bank.from_graph builds a chain of two banks -- the front's fused kernel, seeded from the construction hash of
@@ -252,7 +252,7 @@ def test_random_front_into_a_lane_per_frame_node_with_a_bus(gpu, seed):
             assert_bit_equal(got[v], np.concatenate(want, axis=1), f"seed {seed} {node} {bus} instance {v} mode {mode} seeded {seeded}: {tree}")
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_TINY", "10"))))   # more for a bug hunt
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_TINY", "8"))))   # more for a bug hunt
 def test_random_graph_on_inputs_in_the_denormal_range(gpu, seed):
     """The general fuzzer's graphs with inputs, fed tiny signals: 1e-38 (denormal on arrival), 1e-30 and 1e-20 (products and filter tails go
     denormal inside).  Graphs with a Feedback node render flushed (the run-time compiler's module flag on the device, MXCSR FTZ + DAZ in the
@@ -278,7 +278,7 @@ def test_random_graph_on_inputs_in_the_denormal_range(gpu, seed):
             assert_bit_equal(got[v], oracle_render(n, x[v], T, mode), f"seed {seed} voice {v} mode {mode} ({'flushed' if 'Feedback' in g.type else 'IEEE denormals'}): {tree}")
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_ROUTES", "10"))))   # more for a bug hunt
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_ROUTES", "6"))))   # more for a bug hunt
 def test_random_graph_renders_the_same_through_every_kernel_route(gpu, seed):
     """One graph, one executor, every route the dispatcher has: "pipe_split" 0 (the single-wave kernels), 1 (the default choice by launch length) and
     2 (the stage / planar pipelines forced) x voice-minor, planar with 16-byte rows, planar with tight odd rows -- launched whole and in ragged
@@ -328,7 +328,7 @@ def test_random_graph_renders_the_same_through_every_kernel_route(gpu, seed):
                         assert_bit_equal(got, ref[cuts], f"seed {seed} mode {mode} pipe_split {split} {layout} cuts {cuts} != the first route: {tree}")
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_MIX", "8"))))   # more for a bug hunt
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_MIX", "6"))))   # more for a bug hunt
 def test_random_graph_fused_mix_equals_the_mix_of_its_voice_out_render(gpu, seed):
     """fdsp_bank_process_mix of a random run-time compiled graph -- the mix kernels are a module of their own, compiled on first use -- against
     fdsp_sum_voices / fdsp_mix_stereo of the voice-out render of a clone: the same fixed summation order, so bit for bit; whole and chunked, both
@@ -408,7 +408,7 @@ def test_random_generator_under_the_voice_scheduler(gpu, seed):
             assert_bit_equal(fused, summed, f"seed {seed} mode {mode}: Sequencer output fused vs sum of the events: {tree}")
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_LIFE", "8"))))   # more for a bug hunt
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_LIFE", "6"))))   # more for a bug hunt
 def test_random_graph_through_a_life_of_lifecycle_calls(gpu, seed):
     """render, set_sample_rate, render, reset, render, set_seed, render -- the AudioNode lifecycle in mid-stream (what each node keeps and what it
     recomputes or clears on set_sample_rate / reset / set_hash differs from node to node: delay lines resize and empty, filters recompute
@@ -529,7 +529,7 @@ def gen2(rng, nin, nout, depth):
     return gen(rng, nin, nout, 0)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_WIDER", "12"))))   # more for a bug hunt
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUNDSP_FUZZ_WIDER", "8"))))   # more for a bug hunt
 def test_random_graph_of_the_wider_leaf_pool_matches_oracle(gpu, seed):
     rng = np.random.default_rng(int(os.environ.get("FUNDSP_FUZZ_SEED0", "1000")) + 170000 + seed)
     nin, nout = int(rng.integers(0, 3)), int(rng.integers(1, 3))
